@@ -1,0 +1,14 @@
+"""CPU oracle for the TopDown captioner hot path.
+
+TEST INFRASTRUCTURE ONLY.  Nothing under ``unpaired_image_captioning_amd/`` may
+import this package: only ``tests/``, ``__graft_entry__.smoke()`` and the
+``cpu_baseline`` leg of ``bench.py`` use it, and only as the checker / the
+reported CPU baseline, never as the thing shipped.
+
+Parity status: PINNED.  ``tests/golden/make_golden.py`` imports the reference's
+own modules (``/root/reference/pivot_based_eccv2018/models/AttModel.py`` and
+``misc/criterion.py``) in the build container and stores their outputs in
+``tests/golden/*.npz``; ``tests/test_oracle_golden.py`` checks this restatement
+against every one of them.
+"""
+from . import topdown  # noqa: F401
