@@ -1,0 +1,193 @@
+#!/usr/bin/env python3
+"""Benchmark of the hot path: train captions/sec of the TopDown attention-LSTM captioner
+(BASELINE.json configs[1]: 36x2048 region features, hidden 512, 128 images x 5 captions = 640
+caption rows per GPU, bf16 operands), synthetic data generated on the device.
+
+One "step" = Trainer.train's work with inputs already resident in HBM: operand casts, feature
+projection, 17-step teacher-forced unroll, logit GEMM + log-softmax + LanguageModelCriterion,
+full BPTT, [RCCL all-reduce of the flat gradient arena], Adam, weight-copy refresh.
+
+    python bench.py --gpus 1 --steps 20 --warmup 5
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` (attention-step
+kernel, HBM-bound) and, at N=1, `cpu_baseline` (the CPU oracle timed on this host's cores).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import torch
+import torch.distributed as dist
+
+HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+
+CFG = dict(V=9487, E=512, H=512, A=512, D=2048, L=16, R=36, n_img=128, S=5)
+
+
+def make_opt(dtype, seed):
+    c = CFG
+    return argparse.Namespace(vocab_size=c["V"], input_encoding_size=c["E"], rnn_size=c["H"], num_layers=1,
+                              drop_prob_lm=0.5, seq_length=c["L"], fc_feat_size=c["D"], att_feat_size=c["D"],
+                              att_hid_size=c["A"], use_bn=0, logit_layers=1, caption_model="topdown",
+                              compute_dtype=dtype, seed=seed, i2t_learning_rate=5e-4, i2t_train_flag=1)
+
+
+def attention_roofline(dtype_id, iters=50):
+    """Time the attention-step forward kernel alone, with HIP events on the launch stream, at the
+    bench shapes; algorithmic bytes per launch = N * (R*A + R*H + 2H + R) * sizeof."""
+    from unpaired_image_captioning_amd import _lib as L
+    lib = L.load()
+    c = CFG
+    N, R, A, H = c["n_img"] * c["S"], c["R"], c["A"], c["H"]
+    td = L.TORCH_DTYPE[dtype_id]
+    g = torch.Generator(device="cuda").manual_seed(1)
+    att_h = torch.randn(N, A, device="cuda", generator=g)
+    p_att = torch.randn(N, R, A, device="cuda", generator=g).to(td)
+    att = torch.randn(N, R, H, device="cuda", generator=g).abs().to(td)
+    w = torch.randn(A, device="cuda", generator=g) * 0.05
+    b = torch.zeros(1, device="cuda")
+    alpha = torch.empty(N, R, device="cuda")
+    ctx = torch.empty(N, H, device="cuda", dtype=td)
+
+    def launch():
+        L.check(lib.uic_attention_fwd(dtype_id, N, R, A, H, L.ptr(att_h), L.ptr(p_att), L.ptr(att), L.ptr(w), L.ptr(b),
+                                      None, L.ptr(alpha), L.ptr(ctx), L.stream()))
+    for _ in range(5):
+        launch()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        launch()
+    e1.record()
+    torch.cuda.synchronize()
+    dur_s = e0.elapsed_time(e1) / 1e3 / iters
+    es = p_att.element_size()
+    bytes_per_launch = N * (R * A + R * H + 2 * H + R) * es
+    achieved = bytes_per_launch / dur_s / 1e9
+    return {"bound": "hbm", "kernel": "attn_fwd_kernel", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
+            "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+            "bytes_per_launch": bytes_per_launch, "us_per_launch": round(dur_s * 1e6, 2)}
+
+
+def cpu_baseline():
+    """The CPU oracle (results-identical restatement of the reference trainer step) on this host."""
+    from oracle import topdown as O
+    c = CFG
+    n_img = 32
+    torch.manual_seed(0)
+    W = O.init_weights(c["V"] + 1, c["E"], c["H"], c["A"], c["D"], c["D"], seed=7)
+    b = O.synthetic_batch(n_img, c["S"], c["R"], c["D"], c["V"], c["L"], seed=1234)
+    N = n_img * c["S"]
+    T = c["L"] + 1
+    g = torch.Generator().manual_seed(1)
+
+    def masks():
+        def m(*shape):
+            return (torch.rand(*shape, generator=g) >= 0.5).float() * 2.0
+        return dict(fc=m(N, c["H"]), att=m(N, c["R"], c["H"]), embed=m(T, N, c["E"]), out=m(T, N, c["H"]))
+    P = {k: v.clone() for k, v in W.items()}
+    m1 = {k: torch.zeros_like(v) for k, v in P.items()}
+    v1 = {k: torch.zeros_like(v) for k, v in P.items()}
+    times = []
+    for step in range(1, 4):
+        t0 = time.perf_counter()
+        loss, grads, _ = O.xe_loss_and_grads(P, b["fc_feats"], b["att_feats"], b["labels"], b["masks"], b["att_masks"], masks())
+        O.adam_step(P, grads, m1, v1, step, 5e-4)
+        times.append(time.perf_counter() - t0)
+    best = sum(times[1:]) / len(times[1:])
+    return {"value": round(N / best, 1), "unit": "captions/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": "%d images x %d captions = %d rows, fp32, 1 warm-up + 2 timed steps of fwd+loss+bwd+Adam "
+                      "(oracle/topdown.py, torch CPU ops)" % (n_img, c["S"], N)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--dtype", default="bf16")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the captioner hot path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", rank=rank, world_size=world)
+
+    from unpaired_image_captioning_amd import _lib as L
+    from unpaired_image_captioning_amd.synthetic import synthetic_batch
+    from unpaired_image_captioning_amd.trainer import Trainer
+
+    c = CFG
+    torch.manual_seed(1234)                                    # identical initial weights on every rank
+    tr = Trainer(make_opt(args.dtype, 1234 + rank))
+    tr.build_optimizer()
+    batch = synthetic_batch(c["n_img"], c["S"], c["R"], c["D"], c["V"], c["L"], seed=1234 + rank)
+    N = c["n_img"] * c["S"]
+    T = c["L"] + 1
+    t_run = tr.i2t_model._steps_to_run(batch["labels"])
+    den_local = float(batch["masks"][:, 1:T + 1].sum().item())
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        tr.train_device_batch(batch, t_run, den_local)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = tr.train_device_batch(batch, t_run, den_local)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = t.item()
+    loss_val = float(loss.item())
+
+    if rank == 0:
+        dtype_id = L.dtype_id(args.dtype)
+        out = {
+            "metric": "train captions/sec, TopDown-attn LSTM on 36x2048 feats, batch 128, 1/2/4/8 GPU",
+            "value": round(world * N * args.steps / elapsed, 1),
+            "unit": "captions/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 3),
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": args.dtype,
+            "data": "synthetic",
+            "config": {"workload": "BASELINE configs[1]: TopDown attention LSTM, 128 images x 5 captions = 640 caption "
+                                   "rows per GPU, R=36, D=2048, H=E=A=512, V+1=9488, 17 decode steps, dropout 0.5, "
+                                   "XE loss + BPTT + Adam", "rows_per_gpu": N, "parallelism": "dp%d" % world},
+            "final_loss": round(loss_val, 4),
+            "roofline": attention_roofline(dtype_id),
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,179 @@
+/* libuic_hip.so -- C ABI of the MI355X (gfx950) TopDown captioner hot path.
+ *
+ * The reference (gujiuxiang/unpaired_image_captioning, tree pivot_based_eccv2018/, "P/" below)
+ * has no native boundary: its hot path is Python nn.Module code calling stock PyTorch ops.
+ * Each entry point therefore names the reference Python call site it replaces.  All pointers
+ * are device pointers unless stated; the caller owns every buffer (the library never allocates,
+ * frees or retains memory); every call only enqueues work on `stream` (hipStream_t passed as
+ * void*), never synchronises, and returns 0 on success, a negative value for an argument error
+ * and a positive hipError_t otherwise.  uic_last_error_string() describes the last failure on
+ * the calling thread.  dtype: 0 = f32 operands (exact-f32 MFMA, parity path), 1 = bf16 operands
+ * (bf16 MFMA, f32 accumulation / state / loss).
+ */
+#ifndef UIC_HIP_H
+#define UIC_HIP_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define UIC_DTYPE_F32 0
+#define UIC_DTYPE_BF16 1
+
+const char* uic_last_error_string(void);
+int uic_version(void);
+
+/* ---- shapes of one TopDown step (P/models/AttModel.py:56-92,422-428,530-536) ---- */
+typedef struct uic_topdown_dims {
+  int32_t N;        /* caption rows = batch_size * seq_per_img (P/misc/dataloader/dataloader.py:231) */
+  int32_t R;        /* regions per image (att_feats.size(1)) */
+  int32_t D;        /* att_feat_size */
+  int32_t Dfc;      /* fc_feat_size */
+  int32_t H;        /* rnn_size */
+  int32_t E;        /* input_encoding_size */
+  int32_t A;        /* att_hid_size */
+  int32_t V1;       /* vocab_size + 1 */
+  int32_t T;        /* decode steps the workspace is sized for (labels.size(1) - 1) */
+  int32_t dtype;    /* UIC_DTYPE_* */
+  float drop_p;     /* drop_prob_lm; applied only when `training` is non-zero */
+} uic_topdown_dims;
+
+/* Master parameters (f32), one pointer per tensor of TopDownModel.state_dict() with use_bn = 0,
+ * same order and shapes as the reference.  The same struct carries
+ * the gradient pointers on the way back. */
+typedef struct uic_topdown_weights {
+  float* embed_w;         /* embed.0.weight            [V1, E]        */
+  float* fc_w;            /* fc_embed.0.weight         [H, Dfc]       */
+  float* fc_b;            /* fc_embed.0.bias           [H]            */
+  float* att_w;           /* att_embed.0.weight        [H, D]         */
+  float* att_b;           /* att_embed.0.bias          [H]            */
+  float* logit_w;         /* logit.weight              [V1, H]        */
+  float* logit_b;         /* logit.bias                [V1]           */
+  float* ctx2att_w;       /* ctx2att.weight            [A, H]         */
+  float* ctx2att_b;       /* ctx2att.bias              [A]            */
+  float* att_lstm_w_ih;   /* core.att_lstm.weight_ih   [4H, E + 2H]   columns: [h_lang | fc | xt] */
+  float* att_lstm_w_hh;   /* core.att_lstm.weight_hh   [4H, H]        */
+  float* att_lstm_b_ih;   /* core.att_lstm.bias_ih     [4H]           */
+  float* att_lstm_b_hh;   /* core.att_lstm.bias_hh     [4H]           */
+  float* lang_lstm_w_ih;  /* core.lang_lstm.weight_ih  [4H, 2H]       columns: [att_res | h_att]  */
+  float* lang_lstm_w_hh;  /* core.lang_lstm.weight_hh  [4H, H]        */
+  float* lang_lstm_b_ih;  /* core.lang_lstm.bias_ih    [4H]           */
+  float* lang_lstm_b_hh;  /* core.lang_lstm.bias_hh    [4H]           */
+  float* h2att_w;         /* core.attention.h2att.weight     [A, H]   */
+  float* h2att_b;         /* core.attention.h2att.bias       [A]      */
+  float* alpha_w;         /* core.attention.alpha_net.weight [1, A]   */
+  float* alpha_b;         /* core.attention.alpha_net.bias   [1]      */
+} uic_topdown_weights;
+
+/* The batch dict of DataLoader.get_batch as consumed at P/trainer.py:147-149 (device copies). */
+typedef struct uic_topdown_batch {
+  const float* fc_feats;    /* [N, Dfc] */
+  const float* att_feats;   /* [N, R, D] */
+  const float* att_masks;   /* [N, R] or NULL */
+  const int64_t* labels;    /* [N, ld_labels]; column 0 is BOS = 0 */
+  int32_t ld_labels;
+  const float* masks;       /* [N, ld_masks] or NULL (forward only) */
+  int32_t ld_masks;
+} uic_topdown_batch;
+
+/* Sizes (bytes) of the two caller-allocated arenas. */
+size_t uic_topdown_workspace_bytes(const uic_topdown_dims* d);
+size_t uic_topdown_derived_bytes(const uic_topdown_dims* d);
+
+/* Rebuild the operand-dtype / transposed weight copies in `derived` from the f32 masters.
+ * Must run after every change of the masters (optimizer step, load_state_dict). */
+int uic_topdown_refresh_weights(const uic_topdown_dims* d, const uic_topdown_weights* w, void* derived, void* stream);
+
+/* AttModel._forward (P/models/AttModel.py:119-156) with ss_prob = 0: feature projection, the
+ * teacher-forced unroll over `t_run` <= d->T steps (t_run < T reproduces the early break at :151)
+ * and the logit GEMM.  If `logprobs_out` != NULL it receives log-probs as [N, T, V1] f32 (rows of
+ * steps >= t_run are left untouched: pass a zero-filled tensor).  Activations stay in `workspace`
+ * for uic_topdown_xe_loss / uic_topdown_backward. */
+int uic_topdown_forward(const uic_topdown_dims* d, const uic_topdown_weights* w, const void* derived,
+                        const uic_topdown_batch* batch, int32_t t_run, int32_t training, uint32_t seed,
+                        void* workspace, float* logprobs_out, void* stream);
+
+/* LanguageModelCriterion (P/misc/criterion.py:143-150) fused with log_softmax on the logits left by
+ * uic_topdown_forward: loss_out[0] = -sum(logp[target] * mask) / sum(mask) over labels[:,1:], masks[:,1:],
+ * and d loss / d logits is left in the workspace for uic_topdown_backward(dlogprobs = NULL).
+ * `inv_den` (device, optional) overrides 1/sum(mask) -- data-parallel ranks pass the global value. */
+int uic_topdown_xe_loss(const uic_topdown_dims* d, const uic_topdown_batch* batch, int32_t t_run, void* workspace,
+                        const float* inv_den, float* loss_out, float* den_out, void* stream);
+
+/* Backward of uic_topdown_forward (what autograd does for P/trainer.py:173).  If `dlogprobs` != NULL it
+ * is the dense upstream gradient w.r.t. the [N, T, V1] log-probs and `logprobs` must be the forward output;
+ * otherwise the gradient prepared by uic_topdown_xe_loss is used.  Every tensor of `grads` is overwritten. */
+int uic_topdown_backward(const uic_topdown_dims* d, const uic_topdown_weights* w, const void* derived,
+                         const uic_topdown_batch* batch, int32_t t_run, int32_t training, uint32_t seed,
+                         void* workspace, const float* dlogprobs, const float* logprobs,
+                         const uic_topdown_weights* grads, void* stream);
+
+/* AttModel._sample with beam_size = 1 (P/models/AttModel.py:198-253): greedy (sample_max = 1) or
+ * multinomial decode of `L` <= d->T tokens.  seq [N, L] int64 and seq_logp [N, L] f32 are fully written.
+ * `forced` (optional, [N, L] int64) replaces the multinomial draws (parity tests). */
+int uic_topdown_sample(const uic_topdown_dims* d, const uic_topdown_weights* w, const void* derived,
+                       const uic_topdown_batch* batch, int32_t L, int32_t sample_max, float temperature,
+                       int32_t decoding_constraint, uint32_t seed, const int64_t* forced, void* workspace,
+                       int64_t* seq, float* seq_logp, void* stream);
+
+/* Address of a named activation inside the workspace (tests / debugging); NULL if unknown.
+ * Names: fc_embed att_embed p_att xt gx h_att h_lang c_att c_lang att_h alpha ctx logits dlogits ... */
+void* uic_topdown_workspace_ptr(const uic_topdown_dims* d, void* workspace, const char* name);
+
+/* ---- single operators (also used by the parity tests) ---- */
+
+/* nn.Linear as C[M,N] = A[M,K] B[N,K]^T (+bias)(+ReLU); flags: 1 ReLU, 2 accumulate into C, 4 C is f32. */
+int uic_linear(int32_t dtype, int32_t M, int32_t N, int32_t K, const void* A, int32_t lda, const void* B, int32_t ldb,
+               void* C, int32_t ldc, const float* bias, int32_t flags, void* stream);
+
+/* nn.LSTMCell (P/models/AttModel.py:426-427,434,441) on the concatenation of up to three inputs:
+ * gates = sum_i x_i W_i^T + h W_hh^T + b_ih + b_hh.  x_i [M,K_i] (operand dtype), W_i = weight_ih column block
+ * (ldw = row stride of weight_ih).  Outputs: c_out f32 [M,H], h_out operand dtype [M,H], gates_out (optional). */
+int uic_lstm_cell_fwd(int32_t dtype, int32_t M, int32_t H, int32_t nx, const void* const* x, const int32_t* Kx,
+                      const void* const* Wx, const int32_t* ldw, const void* h, const void* W_hh,
+                      const float* b_ih, const float* b_hh, const float* c_prev, float* c_out, void* h_out,
+                      void* gates_out, void* stream);
+/* Pointwise backward of the cell: dh [M,H] f32, dc [M,H] f32 (in: from the future, out: for the past),
+ * gates (activated), c_prev, c  ->  dgates [M,4H] operand dtype. */
+int uic_lstm_cell_bwd(int32_t dtype, int32_t M, int32_t H, const float* dh, float* dc, const void* gates,
+                      const float* c_prev, const float* c, void* dgates, void* stream);
+
+/* Attention.forward after h2att (P/models/AttModel.py:544-556). */
+int uic_attention_fwd(int32_t dtype, int32_t N, int32_t R, int32_t A, int32_t H, const float* att_h, const void* p_att,
+                      const void* att, const float* w_alpha, const float* b_alpha, const float* mask, float* alpha,
+                      void* ctx, void* stream);
+int uic_attention_bwd_step(int32_t dtype, int32_t N, int32_t R, int32_t A, int32_t H, const float* att_h,
+                           const void* p_att, const void* att, const float* w_alpha, const float* alpha,
+                           const float* dctx, float* de, void* d_att_h, void* stream);
+int uic_attention_bwd_accum(int32_t dtype, int32_t N, int32_t R, int32_t A, int32_t H, int32_t T,
+                            const float* att_h_all, const float* alpha_all, const float* de_all, const float* dctx_all,
+                            const void* p_att, const float* w_alpha, float* d_att, void* d_p_att, float* d_walpha_part,
+                            void* stream);
+
+/* torch.optim.Adam step (P/misc/optimizer.py:70,93) on one flat f32 arena; `step` is 1-based. */
+int uic_adam_step(float* p, const float* g, float* m, float* v, size_t n, float lr, float beta1, float beta2,
+                  float eps, int32_t step, float grad_scale, void* stream);
+
+/* LanguageModelCriterion on materialised log-probs [N, T, V1] (API-compatible path): loss_out[0] and,
+ * if dlogp != NULL, the dense gradient scaled by grad_out (host scalar). */
+int uic_lm_criterion(int32_t N, int32_t T, int32_t V1, const float* logp, const int64_t* target, int32_t ld_target,
+                     const float* mask, int32_t ld_mask, float* loss_out, float* scratch, float* dlogp, float grad_out,
+                     void* stream);
+
+/* utilities */
+int uic_cast_from_f32(int32_t dtype, const float* src, void* dst, size_t n, void* stream);
+int uic_cast_to_f32(int32_t dtype, const void* src, float* dst, size_t n, void* stream);
+int uic_transpose(int32_t dtype, const void* src, int32_t rows, int32_t cols, int32_t ld_src, void* dst, int32_t ld_dst, void* stream);
+/* the multiplicative dropout mask (0 or 1/(1-p)) the kernels use at `site` for elements base..base+n-1 */
+int uic_dropout_mask(float* out, size_t n, float p, uint32_t seed, uint32_t site, size_t base, void* stream);
+#define UIC_SITE_FC 1u
+#define UIC_SITE_ATT 2u
+#define UIC_SITE_EMBED 3u
+#define UIC_SITE_OUT0 16u   /* + decode step */
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* UIC_HIP_H */

@@ -1,0 +1,310 @@
+"""GPU parity of the single operators of libuic_hip.so against the CPU oracle / plain torch fp32
+(called through the C ABI).  Tolerances: f32 path 1e-4 relative to the tensor's scale (MFMA f32 is
+an exact-f32 fma chain, only the summation order differs); bf16 path 2e-2 (operands rounded to bf16)."""
+import ctypes as C
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import topdown as O  # noqa: E402
+
+
+def _lib():
+    from unpaired_image_captioning_amd import _lib
+    return _lib
+
+
+TOL = {0: 1e-4, 1: 2e-2}
+TD = {0: torch.float32, 1: torch.bfloat16}
+
+
+def dev(t, dt=None):
+    t = t.cuda()
+    return t.to(TD[dt]) if dt is not None else t
+
+
+def rel_err(got, ref):
+    got = got.detach().float().cpu().double()
+    ref = ref.detach().float().cpu().double()
+    assert got.shape == ref.shape, (got.shape, ref.shape)
+    return ((got - ref).abs().max() / ref.abs().max().clamp_min(1e-6)).item()
+
+
+def rounded(t, dt):
+    return t.to(TD[dt]).float()
+
+
+@pytest.mark.parametrize("dt", [0, 1])
+@pytest.mark.parametrize("shape", [(70, 51, 72), (640, 512, 512), (129, 200, 40), (1, 8, 8), (2304, 96, 2048)])
+@pytest.mark.parametrize("flags", [0, 1, 4, 6])
+def test_linear(dt, shape, flags):
+    L = _lib()
+    lib = L.load()
+    M, N, K = shape
+    g = torch.Generator().manual_seed(M * 131 + N * 7 + K + flags)
+    A = torch.randn(M, K, generator=g)
+    B = torch.randn(N, K, generator=g) / K ** 0.5
+    bias = torch.randn(N, generator=g)
+    C0 = torch.randn(M, N, generator=g)
+    out_f32 = bool(flags & 4) or dt == 0
+    Ad, Bd = dev(A, dt), dev(B, dt)
+    Cd = dev(C0) if out_f32 else dev(C0, dt)
+    L.check(lib.uic_linear(dt, M, N, K, L.ptr(Ad), K, L.ptr(Bd), K, L.ptr(Cd), N, L.ptr(dev(bias)), flags, L.stream()))
+    torch.cuda.synchronize()
+    ref = rounded(A, dt) @ rounded(B, dt).t() + bias
+    if flags & 1:
+        ref = torch.relu(ref)
+    if flags & 2:
+        ref = ref + (C0 if out_f32 else rounded(C0, dt))
+    assert rel_err(Cd, ref) < TOL[dt]
+
+
+@pytest.mark.parametrize("dt", [0, 1])
+def test_linear_strided_operands(dt):
+    """Column blocks of wider matrices: lda/ldb/ldc larger than the logical widths (weight_ih column blocks)."""
+    L = _lib()
+    lib = L.load()
+    M, N, K, ld = 37, 64, 24, 88
+    g = torch.Generator().manual_seed(5)
+    Abig = torch.randn(M, ld, generator=g)
+    Bbig = torch.randn(N, ld, generator=g)
+    Cbig = torch.zeros(M, 100)
+    Ad, Bd, Cd = dev(Abig, dt), dev(Bbig, dt), dev(Cbig)
+    es = Ad.element_size()
+    L.check(lib.uic_linear(dt, M, N, K, Ad.data_ptr() + 16 * es, ld, Bd.data_ptr() + 40 * es, ld,
+                           Cd.data_ptr() + 4 * 4, 100, None, 4, L.stream()))
+    torch.cuda.synchronize()
+    ref = rounded(Abig, dt)[:, 16:16 + K] @ rounded(Bbig, dt)[:, 40:40 + K].t()
+    assert rel_err(Cd[:, 4:4 + N], ref) < TOL[dt]
+    assert Cd[:, :4].abs().max().item() == 0 and Cd[:, 4 + N:].abs().max().item() == 0
+
+
+def test_linear_rejects_bad_arguments():
+    L = _lib()
+    lib = L.load()
+    x = torch.zeros(64, 64, device="cuda")
+    rc = lib.uic_linear(0, 8, 8, 6, L.ptr(x), 6, L.ptr(x), 6, L.ptr(x), 8, None, 0, L.stream())   # K % 4 != 0
+    assert rc < 0 and b"multiples" in lib.uic_last_error_string()
+    rc = lib.uic_linear(7, 8, 8, 8, L.ptr(x), 8, L.ptr(x), 8, L.ptr(x), 8, None, 0, L.stream())
+    assert rc < 0
+
+
+@pytest.mark.parametrize("dt", [0, 1])
+@pytest.mark.parametrize("MH", [(70, 40), (640, 512), (6, 32), (33, 96)])
+def test_lstm_cell_fwd_bwd(dt, MH):
+    L = _lib()
+    lib = L.load()
+    M, H = MH
+    K1, K2 = 24, H
+    g = torch.Generator().manual_seed(M + H)
+    x1, x2, h = torch.randn(M, K1, generator=g), torch.randn(M, K2, generator=g), torch.randn(M, H, generator=g)
+    c = torch.randn(M, H, generator=g)
+    w_ih = torch.randn(4 * H, K1 + K2, generator=g) / (K1 + K2) ** 0.5
+    w_hh = torch.randn(4 * H, H, generator=g) / H ** 0.5
+    b_ih, b_hh = torch.randn(4 * H, generator=g), torch.randn(4 * H, generator=g)
+    x1d, x2d, hd, wihd, whhd = dev(x1, dt), dev(x2, dt), dev(h, dt), dev(w_ih, dt), dev(w_hh, dt)
+    es = x1d.element_size()
+    c_out = torch.empty(M, H, device="cuda")
+    h_out = torch.empty(M, H, device="cuda", dtype=TD[dt])
+    gates = torch.empty(M, 4 * H, device="cuda", dtype=TD[dt])
+    xs = (C.c_void_p * 2)(x1d.data_ptr(), x2d.data_ptr())
+    ks = (C.c_int32 * 2)(K1, K2)
+    ws = (C.c_void_p * 2)(wihd.data_ptr(), wihd.data_ptr() + K1 * es)
+    lds = (C.c_int32 * 2)(K1 + K2, K1 + K2)
+    L.check(lib.uic_lstm_cell_fwd(dt, M, H, 2, xs, ks, ws, lds, L.ptr(hd), L.ptr(whhd), L.ptr(dev(b_ih)), L.ptr(dev(b_hh)),
+                                  L.ptr(dev(c)), L.ptr(c_out), L.ptr(h_out), L.ptr(gates), L.stream()))
+    torch.cuda.synchronize()
+    xr = torch.cat([rounded(x1, dt), rounded(x2, dt)], 1)
+    hr, cr = O.lstm_cell(xr, rounded(h, dt), c, rounded(w_ih, dt), rounded(w_hh, dt), b_ih, b_hh)
+    assert rel_err(h_out, hr) < TOL[dt]
+    assert rel_err(c_out, cr) < TOL[dt]
+    # pointwise backward vs autograd on the same activated gates
+    dh, dc_in = torch.randn(M, H, generator=g), torch.randn(M, H, generator=g)
+    gact = gates.float().cpu()
+    pre = torch.zeros(M, 4 * H, requires_grad=True)
+    i, f, gg, o = gact.chunk(4, 1)
+    # express activated gates as functions of a dummy pre-activation so autograd yields d(pre)
+    pre_vals = torch.cat([torch.logit(i.clamp(1e-6, 1 - 1e-6)), torch.logit(f.clamp(1e-6, 1 - 1e-6)),
+                          torch.atanh(gg.clamp(-1 + 1e-6, 1 - 1e-6)), torch.logit(o.clamp(1e-6, 1 - 1e-6))], 1)
+    pre = pre_vals.clone().requires_grad_(True)
+    c_prev = c.clone().requires_grad_(True)
+    pi, pf, pg, po = pre.chunk(4, 1)
+    c2 = torch.sigmoid(pf) * c_prev + torch.sigmoid(pi) * torch.tanh(pg)
+    h2 = torch.sigmoid(po) * torch.tanh(c2)
+    (h2 * dh).sum().backward(retain_graph=True, inputs=[pre, c_prev])
+    gpre, gc = pre.grad.clone(), c_prev.grad.clone()
+    pre.grad = None
+    c_prev.grad = None
+    (c2 * dc_in).sum().backward(inputs=[pre, c_prev])
+    gpre += pre.grad
+    gc += c_prev.grad
+    dcd = dev(dc_in).clone()
+    dgates = torch.empty(M, 4 * H, device="cuda", dtype=TD[dt])
+    c2d = c2.detach().cuda()
+    L.check(lib.uic_lstm_cell_bwd(dt, M, H, L.ptr(dev(dh)), L.ptr(dcd), L.ptr(gates), L.ptr(dev(c)), L.ptr(c2d), L.ptr(dgates), L.stream()))
+    torch.cuda.synchronize()
+    assert rel_err(dgates, gpre) < max(TOL[dt], 2e-3)
+    assert rel_err(dcd, gc) < max(TOL[dt], 2e-3)
+
+
+def _attn_inputs(N, R, A, H, seed, masked):
+    g = torch.Generator().manual_seed(seed)
+    att_h = torch.randn(N, A, generator=g)
+    p_att = torch.randn(N, R, A, generator=g)
+    att = torch.randn(N, R, H, generator=g).abs()
+    w = torch.randn(A, generator=g) / A ** 0.5
+    b = torch.randn(1, generator=g)
+    mask = None
+    if masked:
+        cnt = torch.randint(1, R + 1, (N,), generator=g)
+        cnt[0] = R
+        mask = (torch.arange(R)[None, :] < cnt[:, None]).float()
+    return att_h, p_att, att, w, b, mask
+
+
+def _attn_ref(att_h, p_att, att, w, b, mask):
+    dot = torch.tanh(p_att + att_h.unsqueeze(1)) @ w + b
+    weight = torch.softmax(dot, 1)
+    if mask is not None:
+        weight = weight * mask
+        weight = weight / weight.sum(1, keepdim=True)
+    return torch.bmm(weight.unsqueeze(1), att).squeeze(1), weight
+
+
+@pytest.mark.parametrize("dt", [0, 1])
+@pytest.mark.parametrize("dims", [(6, 5, 32, 32), (7, 7, 48, 40), (40, 36, 512, 512), (3, 196, 64, 128)])
+@pytest.mark.parametrize("masked", [False, True])
+def test_attention_fwd_bwd(dt, dims, masked):
+    L = _lib()
+    lib = L.load()
+    N, R, A, H = dims
+    att_h, p_att, att, w, b, mask = _attn_inputs(N, R, A, H, N * R + A, masked)
+    pr, ar = rounded(p_att, dt), rounded(att, dt)
+    att_h_r = att_h.clone().requires_grad_(True)
+    pr_g, ar_g, w_g = pr.clone().requires_grad_(True), ar.clone().requires_grad_(True), w.clone().requires_grad_(True)
+    ctx_ref, alpha_ref = _attn_ref(att_h_r, pr_g, ar_g, w_g, b, mask)
+    pd, ad = dev(p_att, dt), dev(att, dt)
+    alpha = torch.empty(N, R, device="cuda")
+    ctx = torch.empty(N, H, device="cuda", dtype=TD[dt])
+    L.check(lib.uic_attention_fwd(dt, N, R, A, H, L.ptr(dev(att_h)), L.ptr(pd), L.ptr(ad), L.ptr(dev(w)), L.ptr(dev(b)),
+                                  L.ptr(dev(mask)) if masked else None, L.ptr(alpha), L.ptr(ctx), L.stream()))
+    torch.cuda.synchronize()
+    tol = 1e-4 if dt == 0 else 2e-2
+    assert rel_err(alpha, alpha_ref) < tol
+    assert rel_err(ctx, ctx_ref) < tol
+    # backward of one step
+    g = torch.Generator().manual_seed(3)
+    dctx = torch.randn(N, H, generator=g)
+    (ctx_ref * dctx).sum().backward()
+    de = torch.empty(N, R, device="cuda")
+    d_att_h = torch.empty(N, A, device="cuda", dtype=TD[dt])
+    alpha_in = alpha_ref.detach().cuda().contiguous()
+    L.check(lib.uic_attention_bwd_step(dt, N, R, A, H, L.ptr(dev(att_h)), L.ptr(pd), L.ptr(ad), L.ptr(dev(w)), L.ptr(alpha_in),
+                                       L.ptr(dev(dctx)), L.ptr(de), L.ptr(d_att_h), L.stream()))
+    torch.cuda.synchronize()
+    assert rel_err(d_att_h, att_h_r.grad) < max(tol, 1e-3)
+    # deferred accumulation with T = 1 reproduces d att, d p_att, d w_alpha of that single step
+    d_att = torch.empty(N, R, H, device="cuda")
+    d_p_att = torch.empty(N, R, A, device="cuda", dtype=TD[dt])
+    part = torch.empty(N, A + 1, device="cuda")
+    L.check(lib.uic_attention_bwd_accum(dt, N, R, A, H, 1, L.ptr(dev(att_h)), L.ptr(alpha_in), L.ptr(de), L.ptr(dev(dctx)),
+                                        L.ptr(pd), L.ptr(dev(w)), L.ptr(d_att), L.ptr(d_p_att), L.ptr(part), L.stream()))
+    torch.cuda.synchronize()
+    assert rel_err(d_att, ar_g.grad) < max(tol, 1e-3)
+    assert rel_err(d_p_att, pr_g.grad) < max(tol, 1e-3)
+    assert rel_err(part[:, :A].sum(0), w_g.grad) < max(tol, 1e-3)
+    assert part[:, A].abs().max().item() < 1e-3       # d b_alpha = sum(de) = 0 (softmax shift invariance)
+
+
+@pytest.mark.parametrize("dt", [0, 1])
+def test_attention_bwd_accum_multi_step(dt):
+    L = _lib()
+    lib = L.load()
+    N, R, A, H, T = 5, 9, 64, 48, 4
+    g = torch.Generator().manual_seed(77)
+    p_att = torch.randn(N, R, A, generator=g)
+    w = torch.randn(A, generator=g) / A ** 0.5
+    att_h = torch.randn(T, N, A, generator=g)
+    alpha = torch.softmax(torch.randn(T, N, R, generator=g), 2)
+    de = torch.randn(T, N, R, generator=g) * 0.1
+    dctx = torch.randn(T, N, H, generator=g)
+    pr = rounded(p_att, dt)
+    d_att_ref = torch.einsum("tnr,tnh->nrh", alpha, dctx)
+    th = torch.tanh(pr.unsqueeze(0) + att_h.unsqueeze(2))                       # [T,N,R,A]
+    d_p_ref = (de.unsqueeze(3) * (1 - th * th)).sum(0) * w
+    d_w_ref = (de.unsqueeze(3) * th).sum((0, 1, 2))
+    d_att = torch.empty(N, R, H, device="cuda")
+    d_p = torch.empty(N, R, A, device="cuda", dtype=TD[dt])
+    part = torch.empty(N, A + 1, device="cuda")
+    L.check(lib.uic_attention_bwd_accum(dt, N, R, A, H, T, L.ptr(dev(att_h)), L.ptr(dev(alpha)), L.ptr(dev(de)), L.ptr(dev(dctx)),
+                                        L.ptr(dev(p_att, dt)), L.ptr(dev(w)), L.ptr(d_att), L.ptr(d_p), L.ptr(part), L.stream()))
+    torch.cuda.synchronize()
+    tol = 1e-4 if dt == 0 else 2e-2
+    assert rel_err(d_att, d_att_ref) < tol
+    assert rel_err(d_p, d_p_ref) < tol
+    assert rel_err(part[:, :A].sum(0), d_w_ref) < tol
+    assert rel_err(part[:, A].sum().view(1), de.sum().view(1)) < 1e-3
+
+
+@pytest.mark.parametrize("dt", [0, 1])
+@pytest.mark.parametrize("shape", [(42, 78, 80), (130, 64, 64), (7, 5, 8)])
+def test_transpose_and_casts(dt, shape):
+    L = _lib()
+    lib = L.load()
+    rows, cols, lds = shape
+    ldd = (rows + 7) // 8 * 8
+    g = torch.Generator().manual_seed(rows)
+    src = torch.randn(rows, lds, generator=g)
+    sd = torch.empty(rows, lds, device="cuda", dtype=TD[dt])
+    L.check(lib.uic_cast_from_f32(dt, L.ptr(dev(src)), L.ptr(sd), rows * lds, L.stream()))
+    dst = torch.full((cols, ldd), 7.0, device="cuda", dtype=TD[dt])
+    L.check(lib.uic_transpose(dt, L.ptr(sd), rows, cols, lds, L.ptr(dst), ldd, L.stream()))
+    back = torch.empty(cols, ldd, device="cuda")
+    L.check(lib.uic_cast_to_f32(dt, L.ptr(dst), L.ptr(back), cols * ldd, L.stream()))
+    torch.cuda.synchronize()
+    ref = rounded(src, dt)[:, :cols].t()
+    assert torch.equal(back[:, :rows].cpu(), ref)            # bit-exact data movement
+    assert back[:, rows:].abs().max().item() == 0 if ldd > rows else True
+
+
+def test_adam_step_matches_oracle():
+    L = _lib()
+    lib = L.load()
+    g = torch.Generator().manual_seed(9)
+    n = 100003
+    p0, grads = torch.randn(n, generator=g), [torch.randn(n, generator=g) for _ in range(3)]
+    P = {"w": p0.clone()}
+    m, v = {"w": torch.zeros(n)}, {"w": torch.zeros(n)}
+    pd, md, vd = dev(p0).clone(), torch.zeros(n, device="cuda"), torch.zeros(n, device="cuda")
+    for step, gr in enumerate(grads, 1):
+        O.adam_step(P, {"w": gr}, m, v, step, 5e-4)
+        L.check(lib.uic_adam_step(L.ptr(pd), L.ptr(dev(gr)), L.ptr(md), L.ptr(vd), n, 5e-4, 0.9, 0.999, 1e-8, step, 1.0, L.stream()))
+    torch.cuda.synchronize()
+    assert (pd.cpu() - P["w"]).abs().max().item() < 1e-6
+
+
+def test_lm_criterion_matches_oracle():
+    from unpaired_image_captioning_amd.misc.criterion import LanguageModelCriterion
+    g = torch.Generator().manual_seed(4)
+    N, T, V1 = 6, 7, 51
+    logp = torch.log_softmax(torch.randn(N, T, V1, generator=g), 2)
+    target = torch.randint(0, V1, (N, T + 2), generator=g)
+    mask = (torch.rand(N, T + 2, generator=g) > 0.3).float()
+    lr = logp.clone().requires_grad_(True)
+    ref = O.lm_criterion(lr, target, mask)
+    ref.backward()
+    ld = logp.cuda().requires_grad_(True)
+    out = LanguageModelCriterion()(ld, target.cuda(), mask.cuda())
+    out.backward()
+    assert abs(out.item() - ref.item()) < 1e-5
+    assert rel_err(ld.grad, lr.grad) < 1e-5
+
+
+def test_library_exports_every_declared_symbol():
+    L = _lib()
+    lib = L.load()
+    for name in L.EXPORTS:
+        assert hasattr(lib, name), name
+    assert lib.uic_version() >= 100

@@ -1,0 +1,140 @@
+"""ctypes binding of libuic_hip.so (include/uic_hip.h).
+
+The product path has no CPU or eager-PyTorch fallback: if the HIP library is missing,
+or a call fails, this module raises.
+"""
+import ctypes as C
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libuic_hip.so")
+
+F32, BF16 = 0, 1
+DTYPE_IDS = {"f32": F32, "fp32": F32, "float32": F32, "bf16": BF16, "bfloat16": BF16}
+TORCH_DTYPE = {F32: torch.float32, BF16: torch.bfloat16}
+
+SITE_FC, SITE_ATT, SITE_EMBED, SITE_OUT0 = 1, 2, 3, 16
+
+
+class Dims(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ("N", "R", "D", "Dfc", "H", "E", "A", "V1", "T", "dtype")] + [("drop_p", C.c_float)]
+
+
+WEIGHT_FIELDS = [
+    # (struct field, reference state_dict key)
+    ("embed_w", "embed.0.weight"),
+    ("fc_w", "fc_embed.0.weight"),
+    ("fc_b", "fc_embed.0.bias"),
+    ("att_w", "att_embed.0.weight"),
+    ("att_b", "att_embed.0.bias"),
+    ("logit_w", "logit.weight"),
+    ("logit_b", "logit.bias"),
+    ("ctx2att_w", "ctx2att.weight"),
+    ("ctx2att_b", "ctx2att.bias"),
+    ("att_lstm_w_ih", "core.att_lstm.weight_ih"),
+    ("att_lstm_w_hh", "core.att_lstm.weight_hh"),
+    ("att_lstm_b_ih", "core.att_lstm.bias_ih"),
+    ("att_lstm_b_hh", "core.att_lstm.bias_hh"),
+    ("lang_lstm_w_ih", "core.lang_lstm.weight_ih"),
+    ("lang_lstm_w_hh", "core.lang_lstm.weight_hh"),
+    ("lang_lstm_b_ih", "core.lang_lstm.bias_ih"),
+    ("lang_lstm_b_hh", "core.lang_lstm.bias_hh"),
+    ("h2att_w", "core.attention.h2att.weight"),
+    ("h2att_b", "core.attention.h2att.bias"),
+    ("alpha_w", "core.attention.alpha_net.weight"),
+    ("alpha_b", "core.attention.alpha_net.bias"),
+]
+
+
+class Weights(C.Structure):
+    _fields_ = [(f, C.c_void_p) for f, _ in WEIGHT_FIELDS]
+
+
+class Batch(C.Structure):
+    _fields_ = [("fc_feats", C.c_void_p), ("att_feats", C.c_void_p), ("att_masks", C.c_void_p),
+                ("labels", C.c_void_p), ("ld_labels", C.c_int32),
+                ("masks", C.c_void_p), ("ld_masks", C.c_int32)]
+
+
+_SIGS = {
+    "uic_last_error_string": (C.c_char_p, []),
+    "uic_version": (C.c_int, []),
+    "uic_topdown_workspace_bytes": (C.c_size_t, [C.POINTER(Dims)]),
+    "uic_topdown_derived_bytes": (C.c_size_t, [C.POINTER(Dims)]),
+    "uic_topdown_refresh_weights": (C.c_int, [C.POINTER(Dims), C.POINTER(Weights), C.c_void_p, C.c_void_p]),
+    "uic_topdown_forward": (C.c_int, [C.POINTER(Dims), C.POINTER(Weights), C.c_void_p, C.POINTER(Batch), C.c_int32,
+                                      C.c_int32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "uic_topdown_xe_loss": (C.c_int, [C.POINTER(Dims), C.POINTER(Batch), C.c_int32, C.c_void_p, C.c_void_p,
+                                      C.c_void_p, C.c_void_p, C.c_void_p]),
+    "uic_topdown_backward": (C.c_int, [C.POINTER(Dims), C.POINTER(Weights), C.c_void_p, C.POINTER(Batch), C.c_int32,
+                                       C.c_int32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(Weights),
+                                       C.c_void_p]),
+    "uic_topdown_sample": (C.c_int, [C.POINTER(Dims), C.POINTER(Weights), C.c_void_p, C.POINTER(Batch), C.c_int32,
+                                     C.c_int32, C.c_float, C.c_int32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p,
+                                     C.c_void_p, C.c_void_p]),
+    "uic_topdown_workspace_ptr": (C.c_void_p, [C.POINTER(Dims), C.c_void_p, C.c_char_p]),
+    "uic_linear": (C.c_int, [C.c_int32] * 4 + [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32,
+                             C.c_void_p, C.c_int32, C.c_void_p]),
+    "uic_lstm_cell_fwd": (C.c_int, [C.c_int32] * 4 + [C.POINTER(C.c_void_p), C.POINTER(C.c_int32), C.POINTER(C.c_void_p),
+                                    C.POINTER(C.c_int32)] + [C.c_void_p] * 9),
+    "uic_lstm_cell_bwd": (C.c_int, [C.c_int32] * 3 + [C.c_void_p] * 7),
+    "uic_attention_fwd": (C.c_int, [C.c_int32] * 5 + [C.c_void_p] * 9),
+    "uic_attention_bwd_step": (C.c_int, [C.c_int32] * 5 + [C.c_void_p] * 9),
+    "uic_attention_bwd_accum": (C.c_int, [C.c_int32] * 6 + [C.c_void_p] * 10),
+    "uic_adam_step": (C.c_int, [C.c_void_p] * 4 + [C.c_size_t] + [C.c_float] * 4 + [C.c_int32, C.c_float, C.c_void_p]),
+    "uic_lm_criterion": (C.c_int, [C.c_int32] * 3 + [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32,
+                                   C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_void_p]),
+    "uic_cast_from_f32": (C.c_int, [C.c_int32, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "uic_cast_to_f32": (C.c_int, [C.c_int32, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "uic_transpose": (C.c_int, [C.c_int32, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p]),
+    "uic_dropout_mask": (C.c_int, [C.c_void_p, C.c_size_t, C.c_float, C.c_uint32, C.c_uint32, C.c_size_t, C.c_void_p]),
+}
+EXPORTS = tuple(_SIGS)
+
+_lib = None
+
+
+def load():
+    """Load libuic_hip.so; raise (never fall back) if it is not built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                "libuic_hip.so is not built (%s). Run `python -m unpaired_image_captioning_amd.build`; "
+                "there is no CPU fallback for the captioner hot path." % LIB_PATH)
+        lib = C.CDLL(LIB_PATH)
+        for name, (res, args) in _SIGS.items():
+            fn = getattr(lib, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = lib
+    return _lib
+
+
+def check(rc, what=""):
+    if rc != 0:
+        msg = load().uic_last_error_string()
+        raise RuntimeError("libuic_hip %s failed (rc=%d): %s" % (what, rc, msg.decode() if msg else "?"))
+
+
+def ptr(t):
+    """Device pointer of a contiguous CUDA(HIP) tensor, or NULL for None."""
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise RuntimeError("libuic_hip needs device tensors; got a %s tensor" % t.device)
+    if not t.is_contiguous():
+        raise RuntimeError("libuic_hip needs contiguous tensors")
+    return t.data_ptr()
+
+
+def stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def dtype_id(name):
+    if isinstance(name, int):
+        return name
+    return DTYPE_IDS[str(name).lower()]

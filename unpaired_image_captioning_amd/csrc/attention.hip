@@ -1,0 +1,349 @@
+// Additive attention over the R region features of one caption row, gfx950.
+//
+// Replaces Attention.forward (P/models/AttModel.py:538-558): the reference runs
+// linear / expand+add / tanh / linear / softmax / mul+div / bmm as seven kernels that
+// round-trip [N,R,A] intermediates through HBM.  Here one workgroup per caption row
+// streams p_att[n] and att[n] exactly once with 16-byte coalesced loads, keeps
+// att_h / w_alpha / scores in LDS, reduces each region's score across a 64-lane
+// wavefront, normalises the R scores in LDS and accumulates the weighted sum per wave.
+//
+// Backward is split so the BPTT loop stays read-only on the big tensors:
+//   * bwd_step  (inside the loop): d alpha, softmax backward, d att_h   -- reads att, p_att once
+//   * bwd_accum (after the loop):  d att'[n,r,:]  = sum_t alpha_t[r] dctx_t
+//                                  d p_att[n,r,a] = sum_t de_t[r] w_a (1 - tanh^2(p_att + att_h_t))
+//     one pass, no read-modify-write of [N,R,*] accumulators per decode step.
+#include "uic_common.h"
+
+namespace {
+
+constexpr int NTHREADS = 256;
+constexpr int NWAVES = 4;
+
+template <typename T>
+__global__ __launch_bounds__(NTHREADS) void attn_fwd_kernel(const UicAttnParams p) {
+  constexpr int VEC = uic_vec<T>::N;
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  const int A = p.A, H = p.H, R = p.R;
+  float* s_atth = sm;
+  float* s_w = s_atth + A;
+  float* s_e = s_w + A;
+  float* s_red = s_e + ((R + 3) & ~3);
+  const int n = blockIdx.x;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+
+  for (int a = tid; a < A; a += NTHREADS) {
+    s_atth[a] = p.att_h[(size_t)n * A + a];
+    s_w[a] = p.w_alpha[a];
+  }
+  __syncthreads();
+
+  // ---- scores e_r = w . tanh(p_att[r] + att_h) + b   (AttModel.py:543-549)
+  const T* pa = (const T*)p.p_att + (size_t)n * R * A;
+  const int ncA = A / VEC;
+  const float b_alpha = p.b_alpha ? p.b_alpha[0] : 0.f;
+  for (int r0 = wave; r0 < R; r0 += 3 * NWAVES) {
+    float part[3] = {0.f, 0.f, 0.f};
+    for (int c = lane; c < ncA; c += 64) {
+      uint4 v[3];
+#pragma unroll
+      for (int u = 0; u < 3; ++u) {
+        const int r = r0 + u * NWAVES;
+        v[u] = r < R ? *(const uint4*)(pa + (size_t)r * A + c * VEC) : make_uint4(0, 0, 0, 0);
+      }
+#pragma unroll
+      for (int u = 0; u < 3; ++u) {
+        float f[VEC];
+        uic_unpack<T>(v[u], f);
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) part[u] += s_w[c * VEC + j] * uic_tanh<T>(f[j] + s_atth[c * VEC + j]);
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < 3; ++u) {
+      const int r = r0 + u * NWAVES;
+      const float s = uic_wave_sum(part[u]);
+      if (lane == 0 && r < R) s_e[r] = s + b_alpha;
+    }
+  }
+  __syncthreads();
+
+  // ---- softmax over R, then mask-renormalise (AttModel.py:551-554)
+  float mx = -INFINITY;
+  for (int r = 0; r < R; ++r) mx = fmaxf(mx, s_e[r]);
+  float sum = 0.f;
+  for (int r = 0; r < R; ++r) sum += expf(s_e[r] - mx);
+  const float inv = 1.f / sum;
+  float usum = 1.f;
+  const float* mk = p.mask ? p.mask + (size_t)n * p.ldmask : nullptr;
+  if (mk) {
+    usum = 0.f;
+    for (int r = 0; r < R; ++r) usum += expf(s_e[r] - mx) * inv * mk[r];
+  }
+  __syncthreads();
+  for (int r = tid; r < R; r += NTHREADS) {
+    float w = expf(s_e[r] - mx) * inv;
+    if (mk) w = w * mk[r] / usum;
+    s_e[r] = w;
+    p.alpha[(size_t)n * R + r] = w;
+  }
+  __syncthreads();
+
+  // ---- ctx = sum_r alpha_r att[r]   (AttModel.py:555-556)
+  const T* pt = (const T*)p.att + (size_t)n * R * H;
+  const int ncH = H / VEC;
+  for (int c = lane; c < ncH; c += 64) {
+    float acc[VEC];
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) acc[j] = 0.f;
+#pragma unroll 3
+    for (int r = wave; r < R; r += NWAVES) {
+      const uint4 v = *(const uint4*)(pt + (size_t)r * H + c * VEC);
+      float f[VEC];
+      uic_unpack<T>(v, f);
+      const float al = s_e[r];
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) acc[j] += al * f[j];
+    }
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) s_red[wave * H + c * VEC + j] = acc[j];
+  }
+  __syncthreads();
+  T* ctx = (T*)p.ctx + (size_t)n * p.ldctx;
+  for (int h = tid; h < H; h += NTHREADS)
+    ctx[h] = uic_from_f<T>(s_red[h] + s_red[H + h] + s_red[2 * H + h] + s_red[3 * H + h]);
+}
+
+template <typename T>
+__global__ __launch_bounds__(NTHREADS) void attn_bwd_step_kernel(const UicAttnParams p) {
+  constexpr int VEC = uic_vec<T>::N;
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  const int A = p.A, H = p.H, R = p.R;
+  const int Rp = (R + 3) & ~3;
+  float* s_atth = sm;
+  float* s_w = s_atth + A;
+  float* s_dctx = s_w + A;
+  float* s_al = s_dctx + H;
+  float* s_da = s_al + Rp;
+  float* s_red = s_da + Rp;
+  const int n = blockIdx.x;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+
+  for (int a = tid; a < A; a += NTHREADS) {
+    s_atth[a] = p.att_h[(size_t)n * A + a];
+    s_w[a] = p.w_alpha[a];
+  }
+  for (int h = tid; h < H; h += NTHREADS) s_dctx[h] = p.dctx[(size_t)n * p.lddctx + h];
+  for (int r = tid; r < R; r += NTHREADS) s_al[r] = p.alpha[(size_t)n * R + r];
+  __syncthreads();
+
+  // d alpha_r = dctx . att[r]
+  const T* pt = (const T*)p.att + (size_t)n * R * H;
+  const int ncH = H / VEC;
+  for (int r0 = wave; r0 < R; r0 += 3 * NWAVES) {
+    float part[3] = {0.f, 0.f, 0.f};
+    for (int c = lane; c < ncH; c += 64) {
+      uint4 v[3];
+#pragma unroll
+      for (int u = 0; u < 3; ++u) {
+        const int r = r0 + u * NWAVES;
+        v[u] = r < R ? *(const uint4*)(pt + (size_t)r * H + c * VEC) : make_uint4(0, 0, 0, 0);
+      }
+#pragma unroll
+      for (int u = 0; u < 3; ++u) {
+        float f[VEC];
+        uic_unpack<T>(v[u], f);
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) part[u] += s_dctx[c * VEC + j] * f[j];
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < 3; ++u) {
+      const int r = r0 + u * NWAVES;
+      const float s = uic_wave_sum(part[u]);
+      if (lane == 0 && r < R) s_da[r] = s;
+    }
+  }
+  __syncthreads();
+  // backward of softmax (+ mask renormalisation): de_r = alpha_r (dalpha_r - sum_j alpha_j dalpha_j)
+  float wbar = 0.f;
+  for (int r = 0; r < R; ++r) wbar += s_al[r] * s_da[r];
+  __syncthreads();
+  for (int r = tid; r < R; r += NTHREADS) {
+    const float de = s_al[r] * (s_da[r] - wbar);
+    s_da[r] = de;
+    p.de[(size_t)n * R + r] = de;
+  }
+  __syncthreads();
+  // d att_h[a] = w_a sum_r de_r (1 - tanh^2(p_att[r,a] + att_h[a]))
+  const T* pa = (const T*)p.p_att + (size_t)n * R * A;
+  const int ncA = A / VEC;
+  for (int c = lane; c < ncA; c += 64) {
+    float acc[VEC];
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) acc[j] = 0.f;
+#pragma unroll 3
+    for (int r = wave; r < R; r += NWAVES) {
+      const uint4 v = *(const uint4*)(pa + (size_t)r * A + c * VEC);
+      float f[VEC];
+      uic_unpack<T>(v, f);
+      const float de = s_da[r];
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) {
+        const float th = uic_tanh<T>(f[j] + s_atth[c * VEC + j]);
+        acc[j] += de * (1.f - th * th);
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) s_red[wave * A + c * VEC + j] = acc[j] * s_w[c * VEC + j];
+  }
+  __syncthreads();
+  T* out = (T*)p.d_att_h + (size_t)n * A;
+  for (int a = tid; a < A; a += NTHREADS)
+    out[a] = uic_from_f<T>(s_red[a] + s_red[A + a] + s_red[2 * A + a] + s_red[3 * A + a]);
+}
+
+template <typename T>
+__global__ __launch_bounds__(NTHREADS) void attn_bwd_accum_kernel(const UicAttnAccumParams p) {
+  constexpr int VEC = uic_vec<T>::N;
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  const int A = p.A, H = p.H, R = p.R, TS = p.T, N = p.N;
+  const int Rp = (R + 3) & ~3;
+  float* s_atth = sm;                 // [TS][A]
+  float* s_dctx = s_atth + TS * A;    // [TS][H]
+  float* s_al = s_dctx + TS * H;      // [TS][Rp]
+  float* s_de = s_al + TS * Rp;       // [TS][Rp]
+  float* s_w = s_de + TS * Rp;        // [A]
+  float* s_red = s_w + A;             // [NWAVES][A]
+  const int n = blockIdx.x;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+
+  for (int i = tid; i < TS * A; i += NTHREADS) {
+    const int t = i / A, a = i - t * A;
+    s_atth[i] = p.att_h_all[((size_t)t * N + n) * A + a];
+  }
+  for (int i = tid; i < TS * H; i += NTHREADS) {
+    const int t = i / H, h = i - t * H;
+    s_dctx[i] = p.dctx_all[(size_t)t * p.dctx_step_stride + (size_t)n * p.lddctx + h];
+  }
+  for (int i = tid; i < TS * R; i += NTHREADS) {
+    const int t = i / R, r = i - t * R;
+    s_al[t * Rp + r] = p.alpha_all[((size_t)t * N + n) * R + r];
+    s_de[t * Rp + r] = p.de_all[((size_t)t * N + n) * R + r];
+  }
+  for (int a = tid; a < A; a += NTHREADS) s_w[a] = p.w_alpha[a];
+  __syncthreads();
+
+  // d att'[n,r,:] = sum_t alpha_t[r] dctx_t   (backward of the bmm, AttModel.py:555-556)
+  float* dat = p.d_att + (size_t)n * R * H;
+  const int nc4 = H / 4;
+  for (int r = wave; r < R; r += NWAVES) {
+    for (int c = lane; c < nc4; c += 64) {
+      float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+      for (int t = 0; t < TS; ++t) {
+        const float al = s_al[t * Rp + r];
+        const float4 d = *(const float4*)(s_dctx + t * H + c * 4);
+        acc.x += al * d.x; acc.y += al * d.y; acc.z += al * d.z; acc.w += al * d.w;
+      }
+      *(float4*)(dat + (size_t)r * H + c * 4) = acc;
+    }
+  }
+
+  // d p_att[n,r,a] = w_a sum_t de_t[r] (1 - tanh^2(.)) ;  d w_alpha[a] += sum_{t,r} de_t[r] tanh(.)
+  const T* pa = (const T*)p.p_att + (size_t)n * R * A;
+  T* dpa = (T*)p.d_p_att + (size_t)n * R * A;
+  const int ncA = A / VEC;
+  for (int c = lane; c < ncA; c += 64) {
+    float dwacc[VEC];
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) dwacc[j] = 0.f;
+    for (int r = wave; r < R; r += NWAVES) {
+      const uint4 v = *(const uint4*)(pa + (size_t)r * A + c * VEC);
+      float f[VEC], acc[VEC];
+      uic_unpack<T>(v, f);
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) acc[j] = 0.f;
+      for (int t = 0; t < TS; ++t) {
+        const float de = s_de[t * Rp + r];
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) {
+          const float th = uic_tanh<T>(f[j] + s_atth[t * A + c * VEC + j]);
+          acc[j] += de * (1.f - th * th);
+          dwacc[j] += de * th;
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) acc[j] *= s_w[c * VEC + j];
+      *(uint4*)(dpa + (size_t)r * A + c * VEC) = uic_pack<T>(acc);
+    }
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) s_red[wave * A + c * VEC + j] = dwacc[j];
+  }
+  __syncthreads();
+  float* part = p.d_walpha_part + (size_t)n * (A + 1);
+  for (int a = tid; a < A; a += NTHREADS) part[a] = s_red[a] + s_red[A + a] + s_red[2 * A + a] + s_red[3 * A + a];
+  if (tid == 0) {
+    float s = 0.f;
+    for (int t = 0; t < TS; ++t)
+      for (int r = 0; r < R; ++r) s += s_de[t * Rp + r];
+    part[A] = s;
+  }
+}
+
+int check_common(int dtype, int N, int R, int A, int H) {
+  const int vec = dtype == UIC_BF16 ? 8 : 4;
+  UIC_REQUIRE(dtype == UIC_F32 || dtype == UIC_BF16, "attention: bad dtype %d", dtype);
+  UIC_REQUIRE(N >= 0 && R > 0 && A > 0 && H > 0, "attention: bad sizes N=%d R=%d A=%d H=%d", N, R, A, H);
+  UIC_REQUIRE(A % vec == 0 && H % vec == 0, "attention: A=%d and H=%d must be multiples of %d", A, H, vec);
+  return UIC_OK;
+}
+
+}  // namespace
+
+int uic_attention_fwd_launch(const UicAttnParams& p, hipStream_t s) {
+  UIC_TRY(check_common(p.dtype, p.N, p.R, p.A, p.H));
+  UIC_REQUIRE(p.att_h && p.p_att && p.att && p.w_alpha && p.alpha && p.ctx, "attention_fwd: null pointer");
+  if (p.N == 0) return UIC_OK;
+  const size_t lds = sizeof(float) * (2 * (size_t)p.A + ((p.R + 3) & ~3) + NWAVES * (size_t)p.H);
+  UIC_REQUIRE(lds <= 160 * 1024, "attention_fwd: needs %zu B of LDS", lds);
+  if (p.dtype == UIC_BF16)
+    hipLaunchKernelGGL(attn_fwd_kernel<bf16_t>, dim3(p.N), dim3(NTHREADS), lds, s, p);
+  else
+    hipLaunchKernelGGL(attn_fwd_kernel<float>, dim3(p.N), dim3(NTHREADS), lds, s, p);
+  UIC_LAUNCH_CHECK("attn_fwd_kernel");
+  return UIC_OK;
+}
+
+int uic_attention_bwd_step_launch(const UicAttnParams& p, hipStream_t s) {
+  UIC_TRY(check_common(p.dtype, p.N, p.R, p.A, p.H));
+  UIC_REQUIRE(p.att_h && p.p_att && p.att && p.w_alpha && p.alpha && p.dctx && p.de && p.d_att_h,
+              "attention_bwd_step: null pointer");
+  if (p.N == 0) return UIC_OK;
+  const size_t lds = sizeof(float) * (2 * (size_t)p.A + p.H + 2 * ((p.R + 3) & ~3) + NWAVES * (size_t)p.A);
+  UIC_REQUIRE(lds <= 160 * 1024, "attention_bwd_step: needs %zu B of LDS", lds);
+  if (p.dtype == UIC_BF16)
+    hipLaunchKernelGGL(attn_bwd_step_kernel<bf16_t>, dim3(p.N), dim3(NTHREADS), lds, s, p);
+  else
+    hipLaunchKernelGGL(attn_bwd_step_kernel<float>, dim3(p.N), dim3(NTHREADS), lds, s, p);
+  UIC_LAUNCH_CHECK("attn_bwd_step_kernel");
+  return UIC_OK;
+}
+
+int uic_attention_bwd_accum_launch(const UicAttnAccumParams& p, hipStream_t s) {
+  UIC_TRY(check_common(p.dtype, p.N, p.R, p.A, p.H));
+  UIC_REQUIRE(p.T > 0, "attention_bwd_accum: T=%d", p.T);
+  UIC_REQUIRE(p.att_h_all && p.alpha_all && p.de_all && p.dctx_all && p.p_att && p.w_alpha && p.d_att && p.d_p_att &&
+                  p.d_walpha_part, "attention_bwd_accum: null pointer");
+  if (p.N == 0) return UIC_OK;
+  const int Rp = (p.R + 3) & ~3;
+  const size_t lds = sizeof(float) * ((size_t)p.T * (p.A + p.H + 2 * Rp) + p.A + NWAVES * (size_t)p.A);
+  UIC_REQUIRE(lds <= 160 * 1024, "attention_bwd_accum: needs %zu B of LDS (T=%d)", lds, p.T);
+  if (p.dtype == UIC_BF16) {
+    if (lds > 64 * 1024) UIC_TRY(uic_check_hip(hipFuncSetAttribute((const void*)attn_bwd_accum_kernel<bf16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds), "hipFuncSetAttribute"));
+    hipLaunchKernelGGL(attn_bwd_accum_kernel<bf16_t>, dim3(p.N), dim3(NTHREADS), lds, s, p);
+  } else {
+    if (lds > 64 * 1024) UIC_TRY(uic_check_hip(hipFuncSetAttribute((const void*)attn_bwd_accum_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds), "hipFuncSetAttribute"));
+    hipLaunchKernelGGL(attn_bwd_accum_kernel<float>, dim3(p.N), dim3(NTHREADS), lds, s, p);
+  }
+  UIC_LAUNCH_CHECK("attn_bwd_accum_kernel");
+  return UIC_OK;
+}

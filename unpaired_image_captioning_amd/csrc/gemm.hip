@@ -1,0 +1,279 @@
+// MFMA GEMM for gfx950:  C[M,N] = sum_seg A_s[M,K_s] * B_s[N,K_s]^T  (+ epilogue)
+//
+// Replaces the nn.Linear / nn.LSTMCell GEMM call sites of the reference hot path
+// (P/models/AttModel.py:76-92 fc_embed/att_embed/logit/ctx2att, :426-427,434,441 the two
+// LSTMCells, :543 h2att).  Both operands are K-contiguous ("NT"), which is how nn.Linear
+// stores its weight; transposed weight/activation copies make every backward GEMM NT too.
+//
+//  * bf16 operands -> v_mfma_f32_32x32x16_bf16, f32 operands -> v_mfma_f32_32x32x2_f32
+//    (exact-f32 MFMA, the parity path); accumulation is always f32.
+//  * A block stages a [BM x 128 B] A tile and a [BN x 128 B] B tile per K step through LDS
+//    (row stride 144 B => the 16-lane groups of ds_read_b128 hit 16 distinct 16-B slots).
+//    Each lane half owns 64 contiguous bytes of the 128-B K slice, so fragments are plain
+//    16-B LDS reads; the K order inside a tile is permuted identically for A and B.
+//  * K segments: the concatenations torch.cat([prev_h, fc, xt]) / cat([att, h_att]) of
+//    TopDownCore.forward (AttModel.py:432,438) are never materialised.
+//  * LSTM mode: a wave owns the 4 gates (i,f,g,o) of 32 hidden units for 32 rows in four
+//    32x32 accumulators with identical lane layout, so the cell update
+//    c' = s(f) c + s(i) tanh(g), h' = s(o) tanh(c') runs in the epilogue on registers.
+#include "uic_common.h"
+
+namespace {
+
+constexpr int LDS_STRIDE = 144;   // 128-B K slice + 16-B pad
+
+template <typename T, int TM, int TN, int WM, int WN, bool LSTM>
+__global__ __launch_bounds__(64 * WM * WN) void uic_gemm_kernel(const UicGemmParams p) {
+  constexpr int NT = 64 * WM * WN;
+  constexpr int BM = 32 * TM * WM;
+  constexpr int BN = 32 * TN * WN;
+  constexpr int VEC = 16 / (int)sizeof(T);
+  constexpr int BK = 128 / (int)sizeof(T);
+  constexpr int A_CH = BM * 8 / NT;
+  constexpr int B_CH = BN * 8 / NT;
+  static_assert(BM * 8 % NT == 0 && BN * 8 % NT == 0, "tile/threads mismatch");
+  static_assert(!LSTM || TN == 4, "LSTM mode keeps the 4 gates in the 4 N tiles of a wave");
+
+  __shared__ __attribute__((aligned(16))) char smem[(BM + BN) * LDS_STRIDE];
+  char* sA = smem;
+  char* sB = smem + BM * LDS_STRIDE;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int wm = wave / WN;
+  const int wn = wave % WN;
+  const int half = lane >> 5;
+  const int r32 = lane & 31;
+  const int m0 = blockIdx.x * BM;
+  const int n0 = blockIdx.y * (LSTM ? 32 * WN : BN);   // LSTM: first hidden unit of the block
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int k = 0; k < 16; ++k) acc[i][j][k] = 0.f;
+
+  int ntiles = 0;
+  for (int s = 0; s < p.nseg; ++s) ntiles += (p.seg[s].K + BK - 1) / BK;
+
+  uint4 ra[A_CH], rb[B_CH];
+  int seg = 0, k0 = 0;
+
+  auto load_tile = [&]() {
+    const UicGemmSeg sg = p.seg[seg];
+    const char* Ab = (const char*)sg.A;
+    const char* Bb = (const char*)sg.B;
+#pragma unroll
+    for (int i = 0; i < A_CH; ++i) {
+      const int c = tid + i * NT;
+      const int row = c >> 3;
+      const int k = k0 + (c & 7) * VEC;
+      const int gm = m0 + row;
+      uint4 v = make_uint4(0, 0, 0, 0);
+      if (gm < p.M && k < sg.K) v = *(const uint4*)(Ab + ((size_t)gm * sg.lda + k) * sizeof(T));
+      ra[i] = v;
+    }
+#pragma unroll
+    for (int i = 0; i < B_CH; ++i) {
+      const int c = tid + i * NT;
+      const int row = c >> 3;
+      const int k = k0 + (c & 7) * VEC;
+      int grow;
+      bool ok;
+      if (LSTM) {
+        const int u = n0 + (row >> 7) * 32 + (row & 31);
+        grow = ((row >> 5) & 3) * p.H + u;
+        ok = u < p.H;
+      } else {
+        grow = n0 + row;
+        ok = grow < p.N;
+      }
+      uint4 v = make_uint4(0, 0, 0, 0);
+      if (ok && k < sg.K) v = *(const uint4*)(Bb + ((size_t)grow * sg.ldb + k) * sizeof(T));
+      rb[i] = v;
+    }
+  };
+  auto store_tile = [&]() {
+#pragma unroll
+    for (int i = 0; i < A_CH; ++i) {
+      const int c = tid + i * NT;
+      *(uint4*)(sA + (c >> 3) * LDS_STRIDE + (c & 7) * 16) = ra[i];
+    }
+#pragma unroll
+    for (int i = 0; i < B_CH; ++i) {
+      const int c = tid + i * NT;
+      *(uint4*)(sB + (c >> 3) * LDS_STRIDE + (c & 7) * 16) = rb[i];
+    }
+  };
+
+  if (ntiles > 0) load_tile();
+  for (int it = 0; it < ntiles; ++it) {
+    store_tile();
+    __syncthreads();
+    if (it + 1 < ntiles) {
+      k0 += BK;
+      if (k0 >= p.seg[seg].K) { ++seg; k0 = 0; }
+      load_tile();
+    }
+    const char* pa = sA + (wm * 32 * TM + r32) * LDS_STRIDE + half * 64;
+    const char* pb = sB + (wn * 32 * TN + r32) * LDS_STRIDE + half * 64;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      uint4 fa[TM], fb[TN];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) fa[i] = *(const uint4*)(pa + i * 32 * LDS_STRIDE + ks * 16);
+#pragma unroll
+      for (int j = 0; j < TN; ++j) fb[j] = *(const uint4*)(pb + j * 32 * LDS_STRIDE + ks * 16);
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+          if constexpr (sizeof(T) == 2) {
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
+                __builtin_bit_cast(bf16x8, fa[i]), __builtin_bit_cast(bf16x8, fb[j]), acc[i][j], 0, 0, 0);
+          } else {
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(fa[i].x), __uint_as_float(fb[j].x), acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(fa[i].y), __uint_as_float(fb[j].y), acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(fa[i].z), __uint_as_float(fb[j].z), acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(fa[i].w), __uint_as_float(fb[j].w), acc[i][j], 0, 0, 0);
+          }
+        }
+    }
+    __syncthreads();
+  }
+
+  // ------------------------------------------------------------------ epilogue
+  // C/D layout of the 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
+  const float inv_keep = p.drop_p > 0.f ? 1.f / (1.f - p.drop_p) : 1.f;
+  if constexpr (!LSTM) {
+    const bool out_f32 = (p.flags & UIC_GEMM_OUT_F32) || sizeof(T) == 4;
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        const int col = n0 + (wn * TN + j) * 32 + r32;
+        if (col >= p.N) continue;
+        float b = 0.f;
+        if (p.bias) b += p.bias[col];
+        if (p.bias2) b += p.bias2[col];
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg) {
+          const int row = m0 + (wm * TM + i) * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * half;
+          if (row >= p.M) continue;
+          float v = acc[i][j][reg] + b;
+          if (p.flags & UIC_GEMM_RELU) v = fmaxf(v, 0.f);
+          if (p.row_len) {
+            const int n = row / p.R;
+            if (row - n * p.R >= p.row_len[n]) v = 0.f;
+          }
+          if (p.drop_p > 0.f) v *= uic_drop_scale(p.seed, p.site, (unsigned)row * (unsigned)p.N + (unsigned)col, p.drop_p, inv_keep);
+          const size_t o = (size_t)row * p.ldc + col;
+          if (out_f32) {
+            float* C = (float*)p.C;
+            if (p.flags & UIC_GEMM_ACCUM) v += C[o];
+            C[o] = v;
+          } else {
+            T* C = (T*)p.C;
+            if (p.flags & UIC_GEMM_ACCUM) v += uic_to_f(C[o]);
+            C[o] = uic_from_f<T>(v);
+          }
+        }
+      }
+  } else {
+    const int H = p.H;
+    const int u = n0 + wn * 32 + r32;
+    if (u < H) {
+      float bg[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        if (p.bias) bg[g] += p.bias[g * H + u];
+        if (p.bias2) bg[g] += p.bias2[g * H + u];
+      }
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg) {
+          const int row = m0 + (wm * TM + i) * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * half;
+          if (row >= p.M) continue;
+          float g4[4];
+#pragma unroll
+          for (int g = 0; g < 4; ++g) {
+            float v = acc[i][g][reg] + bg[g];
+            if (p.pre1) v += p.pre1[(size_t)row * p.ldpre1 + g * H + u];
+            if (p.pre2) v += p.pre2[(size_t)row * p.ldpre2 + g * H + u];
+            g4[g] = v;
+          }
+          const float gi = uic_sigmoid(g4[0]);
+          const float gf = uic_sigmoid(g4[1]);
+          const float gg = tanhf(g4[2]);
+          const float go = uic_sigmoid(g4[3]);
+          const float cp = p.c_prev ? p.c_prev[(size_t)row * H + u] : 0.f;
+          const float c = gf * cp + gi * gg;
+          const float h = go * tanhf(c);
+          p.c_out[(size_t)row * H + u] = c;
+          ((T*)p.h_out)[(size_t)row * p.ldh + u] = uic_from_f<T>(h);
+          if (p.h_drop) {
+            float hd = h;
+            if (p.drop_p > 0.f) hd *= uic_drop_scale(p.seed, p.site, (unsigned)row * (unsigned)H + (unsigned)u, p.drop_p, inv_keep);
+            ((T*)p.h_drop)[(size_t)row * p.ldhd + u] = uic_from_f<T>(hd);
+          }
+          if (p.gates_out) {
+            T* G = (T*)p.gates_out + (size_t)row * 4 * H + u;
+            G[0] = uic_from_f<T>(gi);
+            G[H] = uic_from_f<T>(gf);
+            G[2 * H] = uic_from_f<T>(gg);
+            G[3 * H] = uic_from_f<T>(go);
+          }
+        }
+    }
+  }
+}
+
+template <typename T, int TM, int TN, int WM, int WN, bool LSTM>
+int launch_cfg(const UicGemmParams& p, hipStream_t s) {
+  constexpr int BM = 32 * TM * WM, BN = 32 * TN * WN;
+  dim3 grid((p.M + BM - 1) / BM, LSTM ? (p.H + 32 * WN - 1) / (32 * WN) : (p.N + BN - 1) / BN);
+  hipLaunchKernelGGL((uic_gemm_kernel<T, TM, TN, WM, WN, LSTM>), grid, dim3(64 * WM * WN), 0, s, p);
+  UIC_LAUNCH_CHECK("uic_gemm_kernel");
+  return UIC_OK;
+}
+
+template <typename T>
+int launch_typed(const UicGemmParams& p, hipStream_t s) {
+  if (p.lstm) {
+    // 64 rows x 32 units per 2-wave block while that fills the chip, else 128 rows per 4-wave block
+    const long blocks64 = (long)((p.M + 63) / 64) * ((p.H + 31) / 32);
+    if (blocks64 <= 1024) return launch_cfg<T, 1, 4, 2, 1, true>(p, s);
+    return launch_cfg<T, 1, 4, 4, 1, true>(p, s);
+  }
+  const long blocks128 = (long)((p.M + 127) / 128) * ((p.N + 127) / 128);
+  if (blocks128 >= 256) return launch_cfg<T, 2, 2, 2, 2, false>(p, s);
+  return launch_cfg<T, 1, 1, 2, 2, false>(p, s);
+}
+
+}  // namespace
+
+int uic_gemm_launch(const UicGemmParams& p, hipStream_t s) {
+  UIC_REQUIRE(p.dtype == UIC_F32 || p.dtype == UIC_BF16, "gemm: bad dtype %d", p.dtype);
+  UIC_REQUIRE(p.M >= 0 && p.N >= 0, "gemm: negative size");
+  UIC_REQUIRE(p.nseg >= 1 && p.nseg <= UIC_GEMM_MAX_SEG, "gemm: nseg %d out of range", p.nseg);
+  const int vec = p.dtype == UIC_BF16 ? 8 : 4;
+  for (int i = 0; i < p.nseg; ++i) {
+    const UicGemmSeg& g = p.seg[i];
+    UIC_REQUIRE(g.A && g.B, "gemm: null operand in segment %d", i);
+    UIC_REQUIRE(g.K > 0 && g.K % vec == 0 && g.lda % vec == 0 && g.ldb % vec == 0,
+                "gemm: segment %d K=%d lda=%d ldb=%d must be multiples of %d elements", i, g.K, g.lda, g.ldb, vec);
+    UIC_REQUIRE(((uintptr_t)g.A & 15) == 0 && ((uintptr_t)g.B & 15) == 0, "gemm: segment %d operands must be 16-byte aligned", i);
+  }
+  if (p.lstm) {
+    UIC_REQUIRE(p.H > 0 && p.N == 4 * p.H, "gemm(lstm): N=%d must equal 4*H (H=%d)", p.N, p.H);
+    UIC_REQUIRE(p.c_out && p.h_out, "gemm(lstm): c_out and h_out are required");
+  } else {
+    UIC_REQUIRE(p.C != nullptr, "gemm: null C");
+  }
+  if (p.M == 0 || p.N == 0) return UIC_OK;
+  return p.dtype == UIC_BF16 ? launch_typed<bf16_t>(p, s) : launch_typed<float>(p, s);
+}

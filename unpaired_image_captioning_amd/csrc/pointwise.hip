@@ -1,0 +1,563 @@
+// HBM-bound helper kernels of the TopDown training / decoding path (gfx950).
+// Every kernel cites the reference lines whose arithmetic it carries.
+#include "uic_common.h"
+
+namespace {
+
+constexpr int NT = 256;
+
+inline int grid_for(size_t n, int per_block) {
+  size_t g = (n + per_block - 1) / per_block;
+  if (g > 65536) g = 65536;   // grid-stride beyond that
+  if (g == 0) g = 1;
+  return (int)g;
+}
+
+// ------------------------------------------------------------------ casts / fills
+template <typename T>
+__global__ void cast_from_f32_kernel(const float* __restrict__ src, T* __restrict__ dst, size_t n) {
+  const size_t stride = (size_t)gridDim.x * blockDim.x * 4;
+  for (size_t i = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * 4; i < n; i += stride) {
+    if (i + 3 < n) {
+      const float4 v = *(const float4*)(src + i);
+      if constexpr (sizeof(T) == 2) {
+        *(uint2*)(dst + i) = make_uint2(uic_pack_bf16x2(v.x, v.y), uic_pack_bf16x2(v.z, v.w));
+      } else {
+        *(float4*)(dst + i) = v;
+      }
+    } else {
+      for (size_t j = i; j < n; ++j) dst[j] = uic_from_f<T>(src[j]);
+    }
+  }
+}
+template <typename T>
+__global__ void cast_to_f32_kernel(const T* __restrict__ src, float* __restrict__ dst, size_t n) {
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) dst[i] = uic_to_f(src[i]);
+}
+
+// ------------------------------------------------------------------ transpose
+template <typename T>
+__global__ __launch_bounds__(NT) void transpose_kernel(const T* __restrict__ src, int rows, int cols, int lds,
+                                                       T* __restrict__ dst, int ldd) {
+  __shared__ T tile[64][66];
+  const int r0 = blockIdx.x * 64, c0 = blockIdx.y * 64;
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const int r = r0 + ty + 4 * i, c = c0 + tx;
+    T v = uic_from_f<T>(0.f);
+    if (r < rows && c < cols) v = src[(size_t)r * lds + c];
+    tile[ty + 4 * i][tx] = v;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const int c = c0 + ty + 4 * i, r = r0 + tx;
+    if (c < cols && r < ldd) dst[(size_t)c * ldd + r] = tile[tx][ty + 4 * i];
+  }
+}
+
+// ------------------------------------------------------------------ column sums (bias gradients)
+template <typename T>
+__global__ __launch_bounds__(NT) void colsum_stage1(const T* __restrict__ src, int rows, int cols, int lds,
+                                                    int rows_per_block, float* __restrict__ part) {
+  const int c = blockIdx.x * NT + threadIdx.x;
+  if (c >= cols) return;
+  const int rb = blockIdx.y;
+  const int r_lo = rb * rows_per_block;
+  const int r_hi = min(rows, r_lo + rows_per_block);
+  float s = 0.f;
+  for (int r = r_lo; r < r_hi; ++r) s += uic_to_f(src[(size_t)r * lds + c]);
+  part[(size_t)rb * cols + c] = s;
+}
+__global__ __launch_bounds__(NT) void colsum_stage2(const float* __restrict__ part, int nrb, int cols, float* __restrict__ out) {
+  const int c = blockIdx.x * NT + threadIdx.x;
+  if (c >= cols) return;
+  float s = 0.f;
+  for (int rb = 0; rb < nrb; ++rb) s += part[(size_t)rb * cols + c];
+  out[c] = s;
+}
+
+template <typename T>
+__global__ void sum_steps_kernel(const T* __restrict__ src, int TS, size_t step, T* __restrict__ dst) {
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < step; i += stride) {
+    float s = 0.f;
+    for (int t = 0; t < TS; ++t) s += uic_to_f(src[(size_t)t * step + i]);
+    dst[i] = uic_from_f<T>(s);
+  }
+}
+
+// ------------------------------------------------------------------ word embedding
+// self.embed = Embedding + ReLU + Dropout (P/models/AttModel.py:73-75,160), all T steps at once:
+// out[(t*N+n), :] = dropout(relu(table[tokens[n, t]]))
+template <typename T>
+__global__ void embed_fwd_kernel(const float* __restrict__ table, int V1, int E, const int64_t* __restrict__ tokens,
+                                 int ldtok, int N, int TS, float drop_p, unsigned seed, unsigned site, T* __restrict__ out) {
+  const int e4 = E / 4;
+  const size_t total = (size_t)TS * N * e4;
+  const float inv_keep = drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f;
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+    const size_t row = i / e4;
+    const int c = (int)(i - row * e4) * 4;
+    const int t = (int)(row / N), n = (int)(row - (size_t)t * N);
+    long tok = tokens[(size_t)n * ldtok + t];
+    if (tok < 0 || tok >= V1) tok = 0;
+    const float4 v = *(const float4*)(table + (size_t)tok * E + c);
+    float f[4] = {fmaxf(v.x, 0.f), fmaxf(v.y, 0.f), fmaxf(v.z, 0.f), fmaxf(v.w, 0.f)};
+    if (drop_p > 0.f) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) f[j] *= uic_drop_scale(seed, site, (unsigned)(row * E + c + j), drop_p, inv_keep);
+    }
+    T* o = out + row * E + c;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) o[j] = uic_from_f<T>(f[j]);
+  }
+}
+// d table[tok] += dxt * (xt > 0 ? 1/(1-p) : 0): xt > 0 iff the ReLU was open and the unit was kept
+template <typename T>
+__global__ void embed_bwd_kernel(const float* __restrict__ dxt, const T* __restrict__ xt, const int64_t* __restrict__ tokens,
+                                 int ldtok, int N, int TS, int V1, int E, float inv_keep, float* __restrict__ dtable) {
+  const size_t total = (size_t)TS * N * E;
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+    const size_t row = i / E;
+    const int e = (int)(i - row * E);
+    if (uic_to_f(xt[i]) > 0.f) {
+      const int t = (int)(row / N), n = (int)(row - (size_t)t * N);
+      long tok = tokens[(size_t)n * ldtok + t];
+      if (tok < 0 || tok >= V1) tok = 0;
+      atomicAdd(dtable + (size_t)tok * E + e, dxt[i] * inv_keep);
+    }
+  }
+}
+
+template <typename T>
+__global__ void relu_mask_bwd_kernel(const float* __restrict__ g, const T* __restrict__ act, float scale,
+                                     T* __restrict__ dst, size_t n) {
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)
+    dst[i] = uic_from_f<T>(uic_to_f(act[i]) > 0.f ? g[i] * scale : 0.f);
+}
+
+// ------------------------------------------------------------------ LSTM cell backward (pointwise part)
+// Backward of nn.LSTMCell's gate math (P/models/AttModel.py:434,441): gates are stored activated.
+template <typename T>
+__global__ void lstm_bwd_kernel(const UicLstmBwdParams p) {
+  const int H = p.H;
+  const size_t total = (size_t)p.M * H;
+  const float inv_keep = p.drop_p > 0.f ? 1.f / (1.f - p.drop_p) : 1.f;
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += stride) {
+    const int m = (int)(idx / H), u = (int)(idx - (size_t)m * H);
+    float dh = 0.f;
+    if (p.dh0) {
+      float v = p.dh0[(size_t)m * p.lddh0 + u];
+      if (p.drop_p > 0.f) v *= uic_drop_scale(p.seed, p.site, (unsigned)idx, p.drop_p, inv_keep);
+      dh += v;
+    }
+    if (p.dh1) dh += p.dh1[(size_t)m * p.lddh1 + u];
+    if (p.dh2) dh += p.dh2[(size_t)m * p.lddh2 + u];
+    const T* G = (const T*)p.gates + (size_t)m * 4 * H + u;
+    const float gi = uic_to_f(G[0]), gf = uic_to_f(G[H]), gg = uic_to_f(G[2 * H]), go = uic_to_f(G[3 * H]);
+    const float c = p.c[idx];
+    const float cp = p.c_prev ? p.c_prev[idx] : 0.f;
+    const float tc = tanhf(c);
+    const float dc = p.dc[idx] + dh * go * (1.f - tc * tc);
+    const float d_o = dh * tc;
+    T* D = (T*)p.dgates + (size_t)m * 4 * H + u;
+    D[0] = uic_from_f<T>(dc * gg * gi * (1.f - gi));
+    D[H] = uic_from_f<T>(dc * cp * gf * (1.f - gf));
+    D[2 * H] = uic_from_f<T>(dc * gi * (1.f - gg * gg));
+    D[3 * H] = uic_from_f<T>(d_o * go * (1.f - go));
+    p.dc[idx] = dc * gf;
+  }
+}
+
+// ------------------------------------------------------------------ log-softmax + LanguageModelCriterion
+__device__ __forceinline__ float block_reduce_max(float v, float* s_buf) {
+  v = uic_wave_max(v);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  __syncthreads();
+  if (lane == 0) s_buf[wave] = v;
+  __syncthreads();
+  float r = s_buf[0];
+  for (int i = 1; i < NT / 64; ++i) r = fmaxf(r, s_buf[i]);
+  return r;
+}
+__device__ __forceinline__ float block_reduce_sum(float v, float* s_buf) {
+  v = uic_wave_sum(v);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  __syncthreads();
+  if (lane == 0) s_buf[wave] = v;
+  __syncthreads();
+  float r = 0.f;
+  for (int i = 0; i < NT / 64; ++i) r += s_buf[i];
+  return r;
+}
+
+// One block per (t, n) row of logits: log_softmax (AttModel.py:163) fused with the masked NLL
+// and its gradient (criterion.py:143-150): d logits = (softmax - onehot) * mask / sum(mask).
+template <typename T>
+__global__ __launch_bounds__(NT) void xe_kernel(const UicXeParams p, const float* __restrict__ logits, T* __restrict__ dlogits) {
+  __shared__ float s_buf[NT / 64];
+  const int m = blockIdx.x;
+  const int t = m / p.N, n = m - t * p.N;
+  const float* row = logits + (size_t)m * p.ldv;
+  float mx = -INFINITY;
+  for (int v = threadIdx.x; v < p.V1; v += NT) mx = fmaxf(mx, row[v]);
+  mx = block_reduce_max(mx, s_buf);
+  float sum = 0.f;
+  for (int v = threadIdx.x; v < p.V1; v += NT) sum += expf(row[v] - mx);
+  sum = block_reduce_sum(sum, s_buf);
+  const float lse = mx + logf(sum);
+  long y = 0;
+  float mk = 0.f;
+  if (p.target) {
+    y = p.target[(size_t)n * p.ldtarget + p.target_col0 + t];
+    mk = p.mask[(size_t)n * p.ldmask + p.mask_col0 + t];
+    if (y < 0 || y >= p.V1) y = 0;
+    if (threadIdx.x == 0) p.row_loss[m] = -(row[y] - lse) * mk;
+  }
+  if (p.logprobs) {
+    float* lp = p.logprobs + (size_t)n * p.lp_row_stride + (size_t)t * p.lp_step_stride;
+    for (int v = threadIdx.x; v < p.V1; v += NT) lp[v] = row[v] - lse;
+  }
+  if (p.write_grad) {
+    const float sc = mk * p.inv_den[0];
+    T* d = dlogits + (size_t)m * p.ldv;
+    for (int v = threadIdx.x; v < p.ldv; v += NT) {
+      float g = 0.f;
+      if (v < p.V1) g = (expf(row[v] - lse) - (v == y ? 1.f : 0.f)) * sc;
+      d[v] = uic_from_f<T>(g);
+    }
+  }
+}
+
+// API-compat backward: upstream grad g wrt log-probs [n][t][v]; d logits = g - softmax * sum_v g
+template <typename T>
+__global__ __launch_bounds__(NT) void logsoftmax_bwd_kernel(T* __restrict__ dlogits, int V1, int ldv, int N, const float* __restrict__ g,
+                                                            size_t g_step, size_t g_row, const float* __restrict__ logprobs) {
+  __shared__ float s_buf[NT / 64];
+  const int m = blockIdx.x;
+  const int t = m / N, n = m - t * N;
+  const float* gr = g + (size_t)n * g_row + (size_t)t * g_step;
+  const float* lp = logprobs + (size_t)n * g_row + (size_t)t * g_step;
+  float sum = 0.f;
+  for (int v = threadIdx.x; v < V1; v += NT) sum += gr[v];
+  sum = block_reduce_sum(sum, s_buf);
+  T* d = dlogits + (size_t)m * ldv;
+  for (int v = threadIdx.x; v < ldv; v += NT) {
+    float x = 0.f;
+    if (v < V1) x = gr[v] - expf(lp[v]) * sum;
+    d[v] = uic_from_f<T>(x);
+  }
+}
+
+__global__ __launch_bounds__(NT) void masked_sum_kernel(const float* __restrict__ mask, int ldmask, int col0, int N, int TS,
+                                                        float* out_sum, float* out_inv) {
+  __shared__ float s_buf[NT / 64];
+  float s = 0.f;
+  for (int i = threadIdx.x; i < N * TS; i += NT) {
+    const int n = i / TS, t = i - n * TS;
+    s += mask[(size_t)n * ldmask + col0 + t];
+  }
+  s = block_reduce_sum(s, s_buf);
+  if (threadIdx.x == 0) {
+    if (out_sum) out_sum[0] = s;
+    if (out_inv) out_inv[0] = 1.f / s;
+  }
+}
+
+__global__ __launch_bounds__(NT) void reduce_sum_kernel(const float* __restrict__ x, size_t n, const float* scale, float* out) {
+  __shared__ float s_buf[NT / 64];
+  float s = 0.f;
+  for (size_t i = threadIdx.x; i < n; i += NT) s += x[i];
+  s = block_reduce_sum(s, s_buf);
+  if (threadIdx.x == 0) out[0] = scale ? s * scale[0] : s;
+}
+
+// ------------------------------------------------------------------ Adam (torch.optim.Adam, P/misc/optimizer.py:70)
+__global__ void adam_kernel(const UicAdamParams a) {
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  const float step_size = a.lr / a.bc1;
+  const float inv_sqrt_bc2 = 1.f / sqrtf(a.bc2);
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < a.n; i += stride) {
+    const float g = a.g[i] * a.grad_scale;
+    const float m = a.beta1 * a.m[i] + (1.f - a.beta1) * g;
+    const float v = a.beta2 * a.v[i] + (1.f - a.beta2) * g * g;
+    a.m[i] = m;
+    a.v[i] = v;
+    const float denom = sqrtf(v) * inv_sqrt_bc2 + a.eps;
+    a.p[i] -= step_size * (m / denom);
+  }
+}
+
+// ------------------------------------------------------------------ one decode step of AttModel._sample
+// (P/models/AttModel.py:216-251): log_softmax, optional decoding constraint, greedy max (lowest index on
+// ties) or multinomial draw, finished-row bookkeeping.  The reference's host-side early break
+// (`unfinished.sum() == 0`) becomes a device counter per step, so no host sync is needed.
+__global__ __launch_bounds__(NT) void sample_step_kernel(const UicSampleParams p) {
+  __shared__ float s_buf[NT / 64];
+  __shared__ float s_val[NT];
+  __shared__ int s_idx[NT];
+  const int n = blockIdx.x;
+  const int t = p.t;
+  const float* row = (const float*)p.logits + (size_t)n * p.ldv;
+  const bool dead = t > 0 && p.n_unfinished[t - 1] == 0;   // every row had finished: the reference broke out
+  long banned = -1;
+  if (p.decoding_constraint && t > 0) banned = p.seq[(size_t)n * p.L + t - 1];
+
+  float mx = -INFINITY;
+  for (int v = threadIdx.x; v < p.V1; v += NT) mx = fmaxf(mx, row[v]);
+  mx = block_reduce_max(mx, s_buf);
+  float sum = 0.f;
+  for (int v = threadIdx.x; v < p.V1; v += NT) sum += expf(row[v] - mx);
+  sum = block_reduce_sum(sum, s_buf);
+  const float lse = mx + logf(sum);
+  if (p.logprobs_out)
+    for (int v = threadIdx.x; v < p.V1; v += NT) p.logprobs_out[(size_t)n * p.V1 + v] = row[v] - lse;
+
+  int choice = 0;
+  if (p.sample_max) {
+    float bv = -INFINITY;
+    int bi = 0x7fffffff;
+    for (int v = threadIdx.x; v < p.V1; v += NT) {
+      const float x = (v == banned) ? -INFINITY : row[v];
+      if (x > bv || (x == bv && v < bi)) { bv = x; bi = v; }
+    }
+    s_val[threadIdx.x] = bv;
+    s_idx[threadIdx.x] = bi;
+    __syncthreads();
+    for (int o = NT / 2; o > 0; o >>= 1) {
+      if (threadIdx.x < o) {
+        const float ov = s_val[threadIdx.x + o];
+        const int oi = s_idx[threadIdx.x + o];
+        if (ov > s_val[threadIdx.x] || (ov == s_val[threadIdx.x] && oi < s_idx[threadIdx.x])) {
+          s_val[threadIdx.x] = ov;
+          s_idx[threadIdx.x] = oi;
+        }
+      }
+      __syncthreads();
+    }
+    choice = s_idx[0];
+  } else if (p.forced) {
+    choice = (int)p.forced[(size_t)n * p.L + t];
+  } else {
+    // inverse-CDF draw from softmax(logprobs / temperature) with the banned token removed
+    const float invT = 1.f / p.temperature;
+    float part = 0.f;
+    const int per = (p.V1 + NT - 1) / NT;
+    const int v_lo = threadIdx.x * per, v_hi = min(p.V1, v_lo + per);
+    for (int v = v_lo; v < v_hi; ++v) part += (v == banned) ? 0.f : expf((row[v] - lse) * invT);
+    s_val[threadIdx.x] = part;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      float tot = 0.f;
+      for (int i = 0; i < NT; ++i) tot += s_val[i];
+      unsigned x = (unsigned)n * 0x9E3779B1u ^ (p.seed + (unsigned)t * 0x85EBCA77u);
+      x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16;
+      const float target = (float)(x >> 8) * (1.0f / 16777216.0f) * tot;
+      float cum = 0.f;
+      int seg = NT - 1;
+      for (int i = 0; i < NT; ++i) {
+        if (cum + s_val[i] > target) { seg = i; break; }
+        cum += s_val[i];
+      }
+      int pick = -1;
+      const int lo = seg * per, hi = min(p.V1, lo + per);
+      for (int v = lo; v < hi; ++v) {
+        const float pr = (v == banned) ? 0.f : expf((row[v] - lse) * invT);
+        if (pr > 0.f) pick = v;
+        cum += pr;
+        if (cum > target && pr > 0.f) break;
+      }
+      s_idx[0] = pick < 0 ? 0 : pick;
+    }
+    __syncthreads();
+    choice = s_idx[0];
+  }
+  if (threadIdx.x == 0) {
+    if (dead) {
+      p.seq[(size_t)n * p.L + t] = 0;
+      p.seq_logp[(size_t)n * p.L + t] = 0.f;
+      p.it[n] = 0;
+    } else {
+      const float lp = row[choice] - lse;
+      int unf = choice > 0;
+      if (t > 0) unf = unf && p.unfinished[n];
+      p.unfinished[n] = unf;
+      const long tok = unf ? choice : 0;
+      p.it[n] = tok;
+      p.seq[(size_t)n * p.L + t] = tok;
+      p.seq_logp[(size_t)n * p.L + t] = lp;
+      if (unf) atomicAdd(&p.n_unfinished[t], 1);
+    }
+  }
+}
+
+__global__ void dropout_mask_kernel(float* out, size_t n, float pdrop, unsigned seed, unsigned site, size_t base) {
+  const float inv_keep = pdrop > 0.f ? 1.f / (1.f - pdrop) : 1.f;
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)
+    out[i] = pdrop > 0.f ? uic_drop_scale(seed, site, (unsigned)(base + i), pdrop, inv_keep) : 1.f;
+}
+
+}  // namespace
+
+#define DISPATCH_T(dtype, CALL_BF16, CALL_F32) \
+  do {                                         \
+    if ((dtype) == UIC_BF16) { CALL_BF16; } else { CALL_F32; } \
+  } while (0)
+
+int uic_cast_f32_launch(int dtype, const float* src, void* dst, size_t n, hipStream_t s) {
+  if (n == 0) return UIC_OK;
+  const int g = grid_for(n, NT * 4);
+  DISPATCH_T(dtype, hipLaunchKernelGGL(cast_from_f32_kernel<bf16_t>, dim3(g), dim3(NT), 0, s, src, (bf16_t*)dst, n),
+             hipLaunchKernelGGL(cast_from_f32_kernel<float>, dim3(g), dim3(NT), 0, s, src, (float*)dst, n));
+  UIC_LAUNCH_CHECK("cast_from_f32");
+  return UIC_OK;
+}
+int uic_to_f32_launch(int dtype, const void* src, float* dst, size_t n, hipStream_t s) {
+  if (n == 0) return UIC_OK;
+  const int g = grid_for(n, NT);
+  DISPATCH_T(dtype, hipLaunchKernelGGL(cast_to_f32_kernel<bf16_t>, dim3(g), dim3(NT), 0, s, (const bf16_t*)src, dst, n),
+             hipLaunchKernelGGL(cast_to_f32_kernel<float>, dim3(g), dim3(NT), 0, s, (const float*)src, dst, n));
+  UIC_LAUNCH_CHECK("cast_to_f32");
+  return UIC_OK;
+}
+int uic_fill_launch(void* dst, int value_byte, size_t bytes, hipStream_t s) {
+  if (bytes == 0) return UIC_OK;
+  return uic_check_hip(hipMemsetAsync(dst, value_byte, bytes, s), "hipMemsetAsync");
+}
+int uic_transpose_launch(int dtype, const void* src, int rows, int cols, int lds, void* dst, int ldd, hipStream_t s) {
+  UIC_REQUIRE(ldd >= rows && lds >= cols, "transpose: ldd=%d < rows=%d or lds=%d < cols=%d", ldd, rows, lds, cols);
+  if (rows == 0 || cols == 0) return UIC_OK;
+  dim3 grid((ldd + 63) / 64, (cols + 63) / 64);
+  DISPATCH_T(dtype,
+             hipLaunchKernelGGL(transpose_kernel<bf16_t>, grid, dim3(NT), 0, s, (const bf16_t*)src, rows, cols, lds, (bf16_t*)dst, ldd),
+             hipLaunchKernelGGL(transpose_kernel<float>, grid, dim3(NT), 0, s, (const float*)src, rows, cols, lds, (float*)dst, ldd));
+  UIC_LAUNCH_CHECK("transpose");
+  return UIC_OK;
+}
+int uic_colsum_launch(int src_dtype, const void* src, int rows, int cols, int lds, float* out, float* scratch,
+                      size_t scratch_floats, hipStream_t s) {
+  if (cols == 0) return UIC_OK;
+  int nrb = (rows + 255) / 256;
+  if (nrb > 128) nrb = 128;
+  if (nrb < 1) nrb = 1;
+  while (nrb > 1 && (size_t)nrb * cols > scratch_floats) nrb /= 2;
+  UIC_REQUIRE((size_t)nrb * cols <= scratch_floats, "colsum: scratch too small (%zu floats for %d cols)", scratch_floats, cols);
+  const int rpb = (rows + nrb - 1) / nrb;
+  dim3 grid((cols + NT - 1) / NT, nrb);
+  DISPATCH_T(src_dtype,
+             hipLaunchKernelGGL(colsum_stage1<bf16_t>, grid, dim3(NT), 0, s, (const bf16_t*)src, rows, cols, lds, rpb, scratch),
+             hipLaunchKernelGGL(colsum_stage1<float>, grid, dim3(NT), 0, s, (const float*)src, rows, cols, lds, rpb, scratch));
+  UIC_LAUNCH_CHECK("colsum_stage1");
+  hipLaunchKernelGGL(colsum_stage2, dim3((cols + NT - 1) / NT), dim3(NT), 0, s, scratch, nrb, cols, out);
+  UIC_LAUNCH_CHECK("colsum_stage2");
+  return UIC_OK;
+}
+int uic_sum_steps_launch(int dtype, const void* src, int T, size_t step_elems, void* dst, hipStream_t s) {
+  if (step_elems == 0) return UIC_OK;
+  const int g = grid_for(step_elems, NT);
+  DISPATCH_T(dtype, hipLaunchKernelGGL(sum_steps_kernel<bf16_t>, dim3(g), dim3(NT), 0, s, (const bf16_t*)src, T, step_elems, (bf16_t*)dst),
+             hipLaunchKernelGGL(sum_steps_kernel<float>, dim3(g), dim3(NT), 0, s, (const float*)src, T, step_elems, (float*)dst));
+  UIC_LAUNCH_CHECK("sum_steps");
+  return UIC_OK;
+}
+int uic_embed_fwd_launch(int dtype, const float* table, int V1, int E, const int64_t* tokens, int ldtok, int N, int T,
+                         float drop_p, unsigned seed, unsigned site, void* out, hipStream_t s) {
+  UIC_REQUIRE(E % 4 == 0, "embed: E=%d must be a multiple of 4", E);
+  if (N == 0 || T == 0) return UIC_OK;
+  const int g = grid_for((size_t)T * N * (E / 4), NT);
+  DISPATCH_T(dtype,
+             hipLaunchKernelGGL(embed_fwd_kernel<bf16_t>, dim3(g), dim3(NT), 0, s, table, V1, E, tokens, ldtok, N, T, drop_p, seed, site, (bf16_t*)out),
+             hipLaunchKernelGGL(embed_fwd_kernel<float>, dim3(g), dim3(NT), 0, s, table, V1, E, tokens, ldtok, N, T, drop_p, seed, site, (float*)out));
+  UIC_LAUNCH_CHECK("embed_fwd");
+  return UIC_OK;
+}
+int uic_embed_bwd_launch(int dtype, const float* dxt, const void* xt, const int64_t* tokens, int ldtok, int N, int T,
+                         int V1, int E, float drop_p, float* dtable, hipStream_t s) {
+  if (N == 0 || T == 0) return UIC_OK;
+  const float inv_keep = drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f;
+  const int g = grid_for((size_t)T * N * E, NT);
+  DISPATCH_T(dtype,
+             hipLaunchKernelGGL(embed_bwd_kernel<bf16_t>, dim3(g), dim3(NT), 0, s, dxt, (const bf16_t*)xt, tokens, ldtok, N, T, V1, E, inv_keep, dtable),
+             hipLaunchKernelGGL(embed_bwd_kernel<float>, dim3(g), dim3(NT), 0, s, dxt, (const float*)xt, tokens, ldtok, N, T, V1, E, inv_keep, dtable));
+  UIC_LAUNCH_CHECK("embed_bwd");
+  return UIC_OK;
+}
+int uic_relu_mask_bwd_launch(int dtype, const float* grad, const void* act, float scale, void* dst, size_t n, hipStream_t s) {
+  if (n == 0) return UIC_OK;
+  const int g = grid_for(n, NT);
+  DISPATCH_T(dtype, hipLaunchKernelGGL(relu_mask_bwd_kernel<bf16_t>, dim3(g), dim3(NT), 0, s, grad, (const bf16_t*)act, scale, (bf16_t*)dst, n),
+             hipLaunchKernelGGL(relu_mask_bwd_kernel<float>, dim3(g), dim3(NT), 0, s, grad, (const float*)act, scale, (float*)dst, n));
+  UIC_LAUNCH_CHECK("relu_mask_bwd");
+  return UIC_OK;
+}
+int uic_lstm_bwd_launch(const UicLstmBwdParams& p, hipStream_t s) {
+  UIC_REQUIRE(p.dc && p.gates && p.c && p.dgates, "lstm_bwd: null pointer");
+  if (p.M == 0) return UIC_OK;
+  const int g = grid_for((size_t)p.M * p.H, NT);
+  DISPATCH_T(p.dtype, hipLaunchKernelGGL(lstm_bwd_kernel<bf16_t>, dim3(g), dim3(NT), 0, s, p),
+             hipLaunchKernelGGL(lstm_bwd_kernel<float>, dim3(g), dim3(NT), 0, s, p));
+  UIC_LAUNCH_CHECK("lstm_bwd");
+  return UIC_OK;
+}
+int uic_xe_launch(const UicXeParams& p, hipStream_t s) {
+  UIC_REQUIRE(p.logits && p.N > 0, "xe: null logits or N=0");
+  UIC_REQUIRE(!p.write_grad || (p.target && p.mask && p.inv_den), "xe: gradient needs target, mask and inv_den");
+  UIC_REQUIRE(!p.write_grad || p.dlogits, "xe: null dlogits");
+  UIC_REQUIRE(!p.target || p.row_loss, "xe: null row_loss");
+  if (p.M == 0) return UIC_OK;
+  DISPATCH_T(p.dtype, hipLaunchKernelGGL(xe_kernel<bf16_t>, dim3(p.M), dim3(NT), 0, s, p, p.logits, (bf16_t*)p.dlogits),
+             hipLaunchKernelGGL(xe_kernel<float>, dim3(p.M), dim3(NT), 0, s, p, p.logits, (float*)p.dlogits));
+  UIC_LAUNCH_CHECK("xe_kernel");
+  return UIC_OK;
+}
+int uic_logsoftmax_bwd_launch(int dtype, void* dlogits, int M, int V1, int ldv, int N, const float* g,
+                              size_t g_step_stride, size_t g_row_stride, const float* logprobs, hipStream_t s) {
+  UIC_REQUIRE(dlogits && g && logprobs && N > 0, "logsoftmax_bwd: null pointer");
+  if (M == 0) return UIC_OK;
+  DISPATCH_T(dtype,
+             hipLaunchKernelGGL(logsoftmax_bwd_kernel<bf16_t>, dim3(M), dim3(NT), 0, s, (bf16_t*)dlogits, V1, ldv, N, g, g_step_stride, g_row_stride, logprobs),
+             hipLaunchKernelGGL(logsoftmax_bwd_kernel<float>, dim3(M), dim3(NT), 0, s, (float*)dlogits, V1, ldv, N, g, g_step_stride, g_row_stride, logprobs));
+  UIC_LAUNCH_CHECK("logsoftmax_bwd");
+  return UIC_OK;
+}
+int uic_masked_sum_launch(const float* x, const float* mask, int ldmask, int col0, int N, int T, float* out_sum,
+                          float* out_inv, hipStream_t s) {
+  (void)x;
+  hipLaunchKernelGGL(masked_sum_kernel, dim3(1), dim3(NT), 0, s, mask, ldmask, col0, N, T, out_sum, out_inv);
+  UIC_LAUNCH_CHECK("masked_sum");
+  return UIC_OK;
+}
+int uic_reduce_sum_launch(const float* x, size_t n, float unused, const float* scale, float* out, hipStream_t s) {
+  (void)unused;
+  hipLaunchKernelGGL(reduce_sum_kernel, dim3(1), dim3(NT), 0, s, x, n, scale, out);
+  UIC_LAUNCH_CHECK("reduce_sum");
+  return UIC_OK;
+}
+int uic_adam_launch(const UicAdamParams& a, hipStream_t s) {
+  if (a.n == 0) return UIC_OK;
+  hipLaunchKernelGGL(adam_kernel, dim3(grid_for(a.n, NT)), dim3(NT), 0, s, a);
+  UIC_LAUNCH_CHECK("adam");
+  return UIC_OK;
+}
+int uic_sample_step_launch(const UicSampleParams& p, hipStream_t s) {
+  UIC_REQUIRE(p.logits && p.seq && p.seq_logp && p.it && p.unfinished && p.n_unfinished, "sample_step: null pointer");
+  UIC_REQUIRE(p.t >= 0 && p.t < p.L, "sample_step: t=%d outside [0,%d)", p.t, p.L);
+  if (p.N == 0) return UIC_OK;
+  hipLaunchKernelGGL(sample_step_kernel, dim3(p.N), dim3(NT), 0, s, p);
+  UIC_LAUNCH_CHECK("sample_step");
+  return UIC_OK;
+}
+int uic_dropout_mask_launch(float* out, size_t n, float p, unsigned seed, unsigned site, size_t base, hipStream_t s) {
+  if (n == 0) return UIC_OK;
+  hipLaunchKernelGGL(dropout_mask_kernel, dim3(grid_for(n, NT)), dim3(NT), 0, s, out, n, p, seed, site, base);
+  UIC_LAUNCH_CHECK("dropout_mask");
+  return UIC_OK;
+}

@@ -1,0 +1,706 @@
+// Host-side sequencing of the TopDown captioner step on one MI355X: every launch of
+// AttModel._forward / _sample, LanguageModelCriterion and their backward, enqueued on the
+// caller's HIP stream with no host synchronisation (hipGraph-capturable).
+//
+// Restructuring relative to the reference's per-step Python loop (P/models/AttModel.py:119-165):
+//   * teacher forcing makes xt_t and fc' known up front, so their share of the att_lstm gate
+//     GEMM is batched over all T steps (Gx, Gfc); only K = 2H stays in the recurrence;
+//   * the logit GEMM, log_softmax and the criterion run once over all T*N rows, never
+//     materialising [N,T,V1] log-probs unless the caller asks for them;
+//   * in backward only dX GEMMs and the attention step stay in the BPTT loop; every weight
+//     gradient is one GEMM over the T*N stacked rows afterwards, and the attention's [N,R,*]
+//     gradients are produced by one deferred pass (attention.hip).
+#include "uic_common.h"
+#include "../../include/uic_hip.h"
+#include <string.h>
+
+namespace {
+
+struct Bump {
+  char* base;
+  size_t off;
+  void* take(size_t bytes) {
+    off = (off + 255) & ~(size_t)255;
+    void* p = base ? base + off : nullptr;
+    off += bytes;
+    return p;
+  }
+};
+
+struct Layout {
+  // forward activations
+  void* fcT; void* attT; int* row_len;
+  void* fcp; void* attp; void* patt;
+  void* xt_all; float* gx; float* gfc;
+  void* h_att; void* h_lang; float* c_att; float* c_lang;   // [(T+1), N, H]
+  void* gates1; void* gates2;
+  float* atth_all; float* alpha_all; void* ctx_all; void* hdrop_all;
+  float* logits; void* dlogits; float* row_loss; float* scalars;
+  // backward
+  float* dhdrop; float* dx2_all; float* dx1; float* dc_att; float* dc_lang;
+  void* dg1_all; void* dg2_all; float* de_all; void* datth_all;
+  void* dgfc; float* dfcp; void* dfcpre; float* dxt;
+  float* d_att; void* d_patt; float* dwalpha_part; void* d_pre;
+  void* tA; void* tB; float* colscratch; size_t colscratch_floats; float* small;
+  // sampling
+  void* s_h_att[2]; void* s_h_lang[2]; float* s_c_att[2]; float* s_c_lang[2];
+  void* s_xt; float* s_atth; float* s_alpha; void* s_ctx; float* s_logits;
+  int64_t* s_it; int* s_unf; int* s_nunf;
+  size_t total;
+};
+
+inline size_t rup8(size_t x) { return (x + 7) & ~(size_t)7; }
+
+Layout make_layout(const uic_topdown_dims& d, void* ws) {
+  Layout L;
+  memset(&L, 0, sizeof(L));
+  Bump b{(char*)ws, 0};
+  const size_t S = uic_dtype_size(d.dtype);
+  const size_t N = d.N, R = d.R, D = d.D, Dfc = d.Dfc, H = d.H, E = d.E, A = d.A, V1 = d.V1, T = d.T;
+  const size_t M = T * N, Mp = rup8(M), Np = rup8(N), NR = N * R, NRp = rup8(NR), V1p = rup8(V1);
+  L.fcT = b.take(N * Dfc * S);
+  L.attT = b.take(NR * D * S);
+  L.row_len = (int*)b.take(N * sizeof(int));
+  L.fcp = b.take(N * H * S);
+  L.attp = b.take(NR * H * S);
+  L.patt = b.take(NR * A * S);
+  L.xt_all = b.take(M * E * S);
+  L.gx = (float*)b.take(M * 4 * H * 4);
+  L.gfc = (float*)b.take(N * 4 * H * 4);
+  L.h_att = b.take((T + 1) * N * H * S);
+  L.h_lang = b.take((T + 1) * N * H * S);
+  L.c_att = (float*)b.take((T + 1) * N * H * 4);
+  L.c_lang = (float*)b.take((T + 1) * N * H * 4);
+  L.gates1 = b.take(M * 4 * H * S);
+  L.gates2 = b.take(M * 4 * H * S);
+  L.atth_all = (float*)b.take(M * A * 4);
+  L.alpha_all = (float*)b.take(M * R * 4);
+  L.ctx_all = b.take(M * H * S);
+  L.hdrop_all = b.take(M * H * S);
+  L.logits = (float*)b.take(M * V1p * 4);
+  L.dlogits = b.take(M * V1p * S);
+  L.row_loss = (float*)b.take(M * 4);
+  L.scalars = (float*)b.take(64);
+  L.dhdrop = (float*)b.take(M * H * 4);
+  L.dx2_all = (float*)b.take(M * 3 * H * 4);
+  L.dx1 = (float*)b.take(N * 2 * H * 4);
+  L.dc_att = (float*)b.take(N * H * 4);
+  L.dc_lang = (float*)b.take(N * H * 4);
+  L.dg1_all = b.take(M * 4 * H * S);
+  L.dg2_all = b.take(M * 4 * H * S);
+  L.de_all = (float*)b.take(M * R * 4);
+  L.datth_all = b.take(M * A * S);
+  L.dgfc = b.take(N * 4 * H * S);
+  L.dfcp = (float*)b.take(N * H * 4);
+  L.dfcpre = b.take(N * H * S);
+  L.dxt = (float*)b.take(M * E * 4);
+  L.d_att = (float*)b.take(NR * H * 4);
+  L.d_patt = b.take(NR * A * S);
+  L.dwalpha_part = (float*)b.take(N * (A + 1) * 4);
+  L.d_pre = b.take(NR * H * S);
+  size_t ta = V1 * Mp;
+  if (4 * H * Mp > ta) ta = 4 * H * Mp;
+  if (A * Mp > ta) ta = A * Mp;
+  if (A * NRp > ta) ta = A * NRp;
+  if (H * NRp > ta) ta = H * NRp;
+  if (4 * H * Np > ta) ta = 4 * H * Np;
+  size_t tb = (H > E ? H : E) * Mp;
+  if ((H > D ? H : D) * NRp > tb) tb = (H > D ? H : D) * NRp;
+  if ((H > Dfc ? H : Dfc) * Np > tb) tb = (H > Dfc ? H : Dfc) * Np;
+  L.tA = b.take(ta * S);
+  L.tB = b.take(tb * S);
+  size_t maxcols = V1p;
+  if (4 * H > maxcols) maxcols = 4 * H;
+  if (A + 1 > maxcols) maxcols = A + 1;
+  L.colscratch_floats = 128 * maxcols;
+  L.colscratch = (float*)b.take(L.colscratch_floats * 4);
+  L.small = (float*)b.take((A + 8) * 4);
+  for (int i = 0; i < 2; ++i) {
+    L.s_h_att[i] = b.take(N * H * S);
+    L.s_h_lang[i] = b.take(N * H * S);
+    L.s_c_att[i] = (float*)b.take(N * H * 4);
+    L.s_c_lang[i] = (float*)b.take(N * H * 4);
+  }
+  L.s_xt = b.take(N * E * S);
+  L.s_atth = (float*)b.take(N * A * 4);
+  L.s_alpha = (float*)b.take(N * R * 4);
+  L.s_ctx = b.take(N * H * S);
+  L.s_logits = (float*)b.take(N * V1p * 4);
+  L.s_it = (int64_t*)b.take(N * 8);
+  L.s_unf = (int*)b.take(N * 4);
+  L.s_nunf = (int*)b.take((T + 2) * 4);
+  L.total = (b.off + 255) & ~(size_t)255;
+  return L;
+}
+
+// operand-dtype and transposed weight copies
+struct Derived {
+  const void* fc_w; const void* att_w; const void* ctx2att_w; const void* logit_w;
+  const void* att_w_ih; const void* att_w_hh; const void* lang_w_ih; const void* lang_w_hh; const void* h2att_w;
+  void* logit_wT;    // [H, V1p]
+  void* w2T;         // [3H, 4H] = [lang_w_ih^T ; lang_w_hh^T]
+  void* w1recT;      // [2H, 4H] = [att_w_ih[:, 0:H]^T ; att_w_hh^T]
+  void* wxT;         // [E, 4H]  = att_w_ih[:, 2H:]^T
+  void* wfcpT;       // [H, 4H]  = att_w_ih[:, H:2H]^T
+  void* h2attT;      // [H, A]
+  void* ctx2attT;    // [H, A]
+  size_t total;
+};
+
+Derived make_derived(const uic_topdown_dims& d, const uic_topdown_weights* w, void* base) {
+  Derived v;
+  memset(&v, 0, sizeof(v));
+  Bump b{(char*)base, 0};
+  const size_t S = uic_dtype_size(d.dtype);
+  const size_t D = d.D, Dfc = d.Dfc, H = d.H, E = d.E, A = d.A, V1 = d.V1, V1p = rup8(V1);
+  const bool bf = d.dtype == UIC_BF16;
+  auto copy = [&](const float* master, size_t n) -> const void* {
+    if (!bf) return master;
+    return b.take(n * S);
+  };
+  v.fc_w = copy(w ? w->fc_w : nullptr, H * Dfc);
+  v.att_w = copy(w ? w->att_w : nullptr, H * D);
+  v.ctx2att_w = copy(w ? w->ctx2att_w : nullptr, A * H);
+  v.logit_w = copy(w ? w->logit_w : nullptr, V1 * H);
+  v.att_w_ih = copy(w ? w->att_lstm_w_ih : nullptr, 4 * H * (E + 2 * H));
+  v.att_w_hh = copy(w ? w->att_lstm_w_hh : nullptr, 4 * H * H);
+  v.lang_w_ih = copy(w ? w->lang_lstm_w_ih : nullptr, 4 * H * 2 * H);
+  v.lang_w_hh = copy(w ? w->lang_lstm_w_hh : nullptr, 4 * H * H);
+  v.h2att_w = copy(w ? w->h2att_w : nullptr, A * H);
+  v.logit_wT = b.take(H * V1p * S);
+  v.w2T = b.take(3 * H * 4 * H * S);
+  v.w1recT = b.take(2 * H * 4 * H * S);
+  v.wxT = b.take(E * 4 * H * S);
+  v.wfcpT = b.take(H * 4 * H * S);
+  v.h2attT = b.take(H * A * S);
+  v.ctx2attT = b.take(H * A * S);
+  v.total = (b.off + 255) & ~(size_t)255;
+  return v;
+}
+
+int check_dims(const uic_topdown_dims* d) {
+  UIC_REQUIRE(d != nullptr, "null dims");
+  UIC_REQUIRE(d->dtype == UIC_F32 || d->dtype == UIC_BF16, "bad dtype %d", d->dtype);
+  UIC_REQUIRE(d->N > 0 && d->R > 0 && d->T > 0 && d->V1 > 1, "bad sizes N=%d R=%d T=%d V1=%d", d->N, d->R, d->T, d->V1);
+  UIC_REQUIRE(d->D % 8 == 0 && d->Dfc % 8 == 0 && d->H % 8 == 0 && d->E % 8 == 0 && d->A % 8 == 0,
+              "D=%d Dfc=%d H=%d E=%d A=%d must all be multiples of 8", d->D, d->Dfc, d->H, d->E, d->A);
+  UIC_REQUIRE(d->drop_p >= 0.f && d->drop_p < 1.f, "drop_p=%f outside [0,1)", (double)d->drop_p);
+  return UIC_OK;
+}
+
+inline const char* off(const void* p, size_t elems, int dtype) { return (const char*)p + elems * uic_dtype_size(dtype); }
+inline char* offw(void* p, size_t elems, int dtype) { return (char*)p + elems * uic_dtype_size(dtype); }
+
+UicGemmParams gemm_base(int dtype, int M, int N) {
+  UicGemmParams g;
+  memset(&g, 0, sizeof(g));
+  g.dtype = dtype; g.M = M; g.N = N;
+  return g;
+}
+inline void add_seg(UicGemmParams& g, const void* A, int lda, const void* B, int ldb, int K) {
+  UicGemmSeg& s = g.seg[g.nseg++];
+  s.A = A; s.B = B; s.K = K; s.lda = lda; s.ldb = ldb;
+}
+
+__global__ void rowlen_kernel(const float* mask, int N, int R, int* out) {
+  const int n = blockIdx.x * blockDim.x + threadIdx.x;
+  if (n >= N) return;
+  int c = 0;
+  for (int r = 0; r < R; ++r) c += mask[(size_t)n * R + r] != 0.f;
+  out[n] = c;
+}
+
+// _prepare_feature (P/models/AttModel.py:107-117) + operand casts
+int prepare_features(const uic_topdown_dims& d, const uic_topdown_weights* w, const Derived& dv, const uic_topdown_batch* b,
+                     const Layout& L, float drop_p, unsigned seed, const void** fc_in_out, const void** att_in_out, hipStream_t s) {
+  const int dt = d.dtype;
+  const int N = d.N, R = d.R, H = d.H, A = d.A;
+  const void* fc_in = b->fc_feats;
+  const void* att_in = b->att_feats;
+  if (dt == UIC_BF16) {
+    UIC_TRY(uic_cast_f32_launch(dt, b->fc_feats, L.fcT, (size_t)N * d.Dfc, s));
+    UIC_TRY(uic_cast_f32_launch(dt, b->att_feats, L.attT, (size_t)N * R * d.D, s));
+    fc_in = L.fcT;
+    att_in = L.attT;
+  }
+  *fc_in_out = fc_in;
+  *att_in_out = att_in;
+  if (b->att_masks) {
+    hipLaunchKernelGGL(rowlen_kernel, dim3((N + 255) / 256), dim3(256), 0, s, b->att_masks, N, R, L.row_len);
+    UIC_LAUNCH_CHECK("rowlen_kernel");
+  }
+  {
+    UicGemmParams g = gemm_base(dt, N, H);
+    add_seg(g, fc_in, d.Dfc, dv.fc_w, d.Dfc, d.Dfc);
+    g.C = L.fcp; g.ldc = H; g.bias = w->fc_b; g.flags = UIC_GEMM_RELU;
+    g.drop_p = drop_p; g.seed = seed; g.site = UIC_SITE_FC;
+    UIC_TRY(uic_gemm_launch(g, s));
+  }
+  {
+    UicGemmParams g = gemm_base(dt, N * R, H);
+    add_seg(g, att_in, d.D, dv.att_w, d.D, d.D);
+    g.C = L.attp; g.ldc = H; g.bias = w->att_b; g.flags = UIC_GEMM_RELU;
+    if (b->att_masks) { g.row_len = L.row_len; g.R = R; }
+    g.drop_p = drop_p; g.seed = seed; g.site = UIC_SITE_ATT;
+    UIC_TRY(uic_gemm_launch(g, s));
+  }
+  {
+    UicGemmParams g = gemm_base(dt, N * R, A);
+    add_seg(g, L.attp, H, dv.ctx2att_w, H, H);
+    g.C = L.patt; g.ldc = A; g.bias = w->ctx2att_b;
+    UIC_TRY(uic_gemm_launch(g, s));
+  }
+  return UIC_OK;
+}
+
+int attention_step(const uic_topdown_dims& d, const uic_topdown_weights* w, const Derived& dv, const uic_topdown_batch* b,
+                   const Layout& L, const void* h_att, float* att_h, float* alpha, void* ctx, hipStream_t s) {
+  UicGemmParams g = gemm_base(d.dtype, d.N, d.A);
+  add_seg(g, h_att, d.H, dv.h2att_w, d.H, d.H);
+  g.C = att_h; g.ldc = d.A; g.bias = w->h2att_b; g.flags = UIC_GEMM_OUT_F32;
+  UIC_TRY(uic_gemm_launch(g, s));
+  UicAttnParams a;
+  memset(&a, 0, sizeof(a));
+  a.dtype = d.dtype; a.N = d.N; a.R = d.R; a.A = d.A; a.H = d.H;
+  a.att_h = att_h; a.p_att = L.patt; a.att = L.attp; a.w_alpha = w->alpha_w; a.b_alpha = w->alpha_b;
+  a.mask = b->att_masks; a.ldmask = d.R; a.alpha = alpha; a.ctx = ctx; a.ldctx = d.H;
+  return uic_attention_fwd_launch(a, s);
+}
+
+}  // namespace
+
+extern "C" {
+
+size_t uic_topdown_workspace_bytes(const uic_topdown_dims* d) {
+  if (check_dims(d)) return 0;
+  return make_layout(*d, nullptr).total;
+}
+size_t uic_topdown_derived_bytes(const uic_topdown_dims* d) {
+  if (check_dims(d)) return 0;
+  return make_derived(*d, nullptr, nullptr).total;
+}
+
+void* uic_topdown_workspace_ptr(const uic_topdown_dims* d, void* workspace, const char* name) {
+  if (check_dims(d) || !workspace || !name) return nullptr;
+  const Layout L = make_layout(*d, workspace);
+  struct { const char* n; void* p; } tab[] = {
+      {"fc_embed", L.fcp}, {"att_embed", L.attp}, {"p_att", L.patt}, {"xt", L.xt_all}, {"gx", L.gx}, {"gfc", L.gfc},
+      {"h_att", L.h_att}, {"h_lang", L.h_lang}, {"c_att", L.c_att}, {"c_lang", L.c_lang}, {"gates1", L.gates1},
+      {"gates2", L.gates2}, {"att_h", L.atth_all}, {"alpha", L.alpha_all}, {"ctx", L.ctx_all}, {"hdrop", L.hdrop_all},
+      {"logits", L.logits}, {"dlogits", L.dlogits}, {"row_loss", L.row_loss}, {"scalars", L.scalars},
+      {"dhdrop", L.dhdrop}, {"dx2", L.dx2_all}, {"dg1", L.dg1_all}, {"dg2", L.dg2_all}, {"de", L.de_all},
+      {"datth", L.datth_all}, {"d_att", L.d_att}, {"d_p_att", L.d_patt}, {"dxt", L.dxt}};
+  for (auto& e : tab)
+    if (!strcmp(e.n, name)) return e.p;
+  return nullptr;
+}
+
+int uic_topdown_refresh_weights(const uic_topdown_dims* d, const uic_topdown_weights* w, void* derived, void* stream) {
+  UIC_TRY(check_dims(d));
+  UIC_REQUIRE(w && derived, "refresh_weights: null pointer");
+  hipStream_t s = (hipStream_t)stream;
+  const Derived v = make_derived(*d, w, derived);
+  const int dt = d->dtype;
+  const int D = d->D, Dfc = d->Dfc, H = d->H, E = d->E, A = d->A, V1 = d->V1;
+  const int V1p = (int)rup8(V1);
+  if (dt == UIC_BF16) {
+    UIC_TRY(uic_cast_f32_launch(dt, w->fc_w, (void*)v.fc_w, (size_t)H * Dfc, s));
+    UIC_TRY(uic_cast_f32_launch(dt, w->att_w, (void*)v.att_w, (size_t)H * D, s));
+    UIC_TRY(uic_cast_f32_launch(dt, w->ctx2att_w, (void*)v.ctx2att_w, (size_t)A * H, s));
+    UIC_TRY(uic_cast_f32_launch(dt, w->logit_w, (void*)v.logit_w, (size_t)V1 * H, s));
+    UIC_TRY(uic_cast_f32_launch(dt, w->att_lstm_w_ih, (void*)v.att_w_ih, (size_t)4 * H * (E + 2 * H), s));
+    UIC_TRY(uic_cast_f32_launch(dt, w->att_lstm_w_hh, (void*)v.att_w_hh, (size_t)4 * H * H, s));
+    UIC_TRY(uic_cast_f32_launch(dt, w->lang_lstm_w_ih, (void*)v.lang_w_ih, (size_t)4 * H * 2 * H, s));
+    UIC_TRY(uic_cast_f32_launch(dt, w->lang_lstm_w_hh, (void*)v.lang_w_hh, (size_t)4 * H * H, s));
+    UIC_TRY(uic_cast_f32_launch(dt, w->h2att_w, (void*)v.h2att_w, (size_t)A * H, s));
+  }
+  const int H4 = 4 * H, ldih = E + 2 * H;
+  UIC_TRY(uic_transpose_launch(dt, v.logit_w, V1, H, H, v.logit_wT, V1p, s));
+  // w2T rows [0,2H) <- lang_w_ih^T, rows [2H,3H) <- lang_w_hh^T
+  UIC_TRY(uic_transpose_launch(dt, v.lang_w_ih, H4, 2 * H, 2 * H, v.w2T, H4, s));
+  UIC_TRY(uic_transpose_launch(dt, v.lang_w_hh, H4, H, H, offw(v.w2T, (size_t)2 * H * H4, dt), H4, s));
+  UIC_TRY(uic_transpose_launch(dt, v.att_w_ih, H4, H, ldih, v.w1recT, H4, s));
+  UIC_TRY(uic_transpose_launch(dt, v.att_w_hh, H4, H, H, offw(v.w1recT, (size_t)H * H4, dt), H4, s));
+  UIC_TRY(uic_transpose_launch(dt, off(v.att_w_ih, 2 * H, dt), H4, E, ldih, v.wxT, H4, s));
+  UIC_TRY(uic_transpose_launch(dt, off(v.att_w_ih, H, dt), H4, H, ldih, v.wfcpT, H4, s));
+  UIC_TRY(uic_transpose_launch(dt, v.h2att_w, A, H, H, v.h2attT, A, s));
+  UIC_TRY(uic_transpose_launch(dt, v.ctx2att_w, A, H, H, v.ctx2attT, A, s));
+  return UIC_OK;
+}
+
+int uic_topdown_forward(const uic_topdown_dims* d, const uic_topdown_weights* w, const void* derived,
+                        const uic_topdown_batch* b, int32_t t_run, int32_t training, uint32_t seed,
+                        void* workspace, float* logprobs_out, void* stream) {
+  UIC_TRY(check_dims(d));
+  UIC_REQUIRE(w && derived && b && workspace, "forward: null pointer");
+  UIC_REQUIRE(b->fc_feats && b->att_feats && b->labels, "forward: batch needs fc_feats, att_feats and labels");
+  UIC_REQUIRE(t_run >= 1 && t_run <= d->T, "forward: t_run=%d outside [1,%d]", t_run, d->T);
+  UIC_REQUIRE(b->ld_labels >= t_run, "forward: labels have %d columns, need %d", b->ld_labels, t_run);
+  hipStream_t s = (hipStream_t)stream;
+  const Layout L = make_layout(*d, workspace);
+  const Derived dv = make_derived(*d, w, (void*)derived);
+  const int dt = d->dtype;
+  const int N = d->N, H = d->H, E = d->E, V1 = d->V1;
+  const int V1p = (int)rup8(V1), H4 = 4 * H, ldih = E + 2 * H;
+  const size_t S = uic_dtype_size(dt);
+  const float drop_p = training ? d->drop_p : 0.f;
+  const int Meff = t_run * N;
+
+  const void *fc_in, *att_in;
+  UIC_TRY(prepare_features(*d, w, dv, b, L, drop_p, seed, &fc_in, &att_in, s));
+  // xt_t = dropout(relu(embed[labels[:, t]])) for all steps (AttModel.py:145,160)
+  UIC_TRY(uic_embed_fwd_launch(dt, w->embed_w, V1, E, b->labels, b->ld_labels, N, t_run, drop_p, seed, UIC_SITE_EMBED, L.xt_all, s));
+  {  // Gx = xt W_ih[:, 2H:]^T + b_ih + b_hh, all steps
+    UicGemmParams g = gemm_base(dt, Meff, H4);
+    add_seg(g, L.xt_all, E, off(dv.att_w_ih, 2 * H, dt), ldih, E);
+    g.C = L.gx; g.ldc = H4; g.bias = w->att_lstm_b_ih; g.bias2 = w->att_lstm_b_hh; g.flags = UIC_GEMM_OUT_F32;
+    UIC_TRY(uic_gemm_launch(g, s));
+  }
+  {  // Gfc = fc' W_ih[:, H:2H]^T
+    UicGemmParams g = gemm_base(dt, N, H4);
+    add_seg(g, L.fcp, H, off(dv.att_w_ih, H, dt), ldih, H);
+    g.C = L.gfc; g.ldc = H4; g.flags = UIC_GEMM_OUT_F32;
+    UIC_TRY(uic_gemm_launch(g, s));
+  }
+  const size_t NH = (size_t)N * H;
+  UIC_TRY(uic_fill_launch(L.h_att, 0, NH * S, s));     // init_hidden (AttModel.py:94-97)
+  UIC_TRY(uic_fill_launch(L.h_lang, 0, NH * S, s));
+  UIC_TRY(uic_fill_launch(L.c_att, 0, NH * 4, s));
+  UIC_TRY(uic_fill_launch(L.c_lang, 0, NH * 4, s));
+
+  for (int t = 0; t < t_run; ++t) {
+    const void* h_att_prev = off(L.h_att, t * NH, dt);
+    void* h_att_new = offw(L.h_att, (t + 1) * NH, dt);
+    const void* h_lang_prev = off(L.h_lang, t * NH, dt);
+    void* h_lang_new = offw(L.h_lang, (t + 1) * NH, dt);
+    {  // att_lstm on cat([h_lang_prev, fc', xt]) (AttModel.py:431-434)
+      UicGemmParams g = gemm_base(dt, N, H4);
+      g.lstm = 1; g.H = H;
+      add_seg(g, h_lang_prev, H, dv.att_w_ih, ldih, H);
+      add_seg(g, h_att_prev, H, dv.att_w_hh, H, H);
+      g.pre1 = L.gx + (size_t)t * N * H4; g.ldpre1 = H4;
+      g.pre2 = L.gfc; g.ldpre2 = H4;
+      g.c_prev = L.c_att + t * NH; g.c_out = L.c_att + (t + 1) * NH;
+      g.h_out = h_att_new; g.ldh = H;
+      g.gates_out = offw(L.gates1, (size_t)t * N * H4, dt);
+      UIC_TRY(uic_gemm_launch(g, s));
+    }
+    UIC_TRY(attention_step(*d, w, dv, b, L, h_att_new, L.atth_all + (size_t)t * N * d->A, L.alpha_all + (size_t)t * N * d->R,
+                           offw(L.ctx_all, t * NH, dt), s));
+    {  // lang_lstm on cat([att_res, h_att]) (AttModel.py:438-441) + output dropout (:443)
+      UicGemmParams g = gemm_base(dt, N, H4);
+      g.lstm = 1; g.H = H;
+      add_seg(g, off(L.ctx_all, t * NH, dt), H, dv.lang_w_ih, 2 * H, H);
+      add_seg(g, h_att_new, H, off(dv.lang_w_ih, H, dt), 2 * H, H);
+      add_seg(g, h_lang_prev, H, dv.lang_w_hh, H, H);
+      g.bias = w->lang_lstm_b_ih; g.bias2 = w->lang_lstm_b_hh;
+      g.c_prev = L.c_lang + t * NH; g.c_out = L.c_lang + (t + 1) * NH;
+      g.h_out = h_lang_new; g.ldh = H;
+      g.h_drop = offw(L.hdrop_all, t * NH, dt); g.ldhd = H;
+      g.drop_p = drop_p; g.seed = seed; g.site = UIC_SITE_OUT0 + (unsigned)t;
+      g.gates_out = offw(L.gates2, (size_t)t * N * H4, dt);
+      UIC_TRY(uic_gemm_launch(g, s));
+    }
+  }
+  {  // logits for all steps (AttModel.py:163)
+    UicGemmParams g = gemm_base(dt, Meff, V1);
+    add_seg(g, L.hdrop_all, H, dv.logit_w, H, H);
+    g.C = L.logits; g.ldc = V1p; g.bias = w->logit_b; g.flags = UIC_GEMM_OUT_F32;
+    UIC_TRY(uic_gemm_launch(g, s));
+  }
+  if (logprobs_out) {
+    UicXeParams x;
+    memset(&x, 0, sizeof(x));
+    x.dtype = dt; x.M = Meff; x.V1 = V1; x.ldv = V1p; x.logits = L.logits; x.N = N;
+    x.logprobs = logprobs_out; x.lp_step_stride = V1; x.lp_row_stride = (size_t)d->T * V1;
+    UIC_TRY(uic_xe_launch(x, s));
+  }
+  return UIC_OK;
+}
+
+int uic_topdown_xe_loss(const uic_topdown_dims* d, const uic_topdown_batch* b, int32_t t_run, void* workspace,
+                        const float* inv_den, float* loss_out, float* den_out, void* stream) {
+  UIC_TRY(check_dims(d));
+  UIC_REQUIRE(b && workspace && b->labels && b->masks && loss_out, "xe_loss: null pointer");
+  UIC_REQUIRE(t_run >= 1 && t_run <= d->T, "xe_loss: t_run=%d outside [1,%d]", t_run, d->T);
+  UIC_REQUIRE(b->ld_labels >= d->T + 1 && b->ld_masks >= d->T + 1, "xe_loss: labels/masks need %d columns", d->T + 1);
+  hipStream_t s = (hipStream_t)stream;
+  const Layout L = make_layout(*d, workspace);
+  const int N = d->N, V1 = d->V1, V1p = (int)rup8(V1);
+  // denominator: sum of masks[:, 1:T+1] over ALL T columns (criterion.py:146-149), also after an early break
+  UIC_TRY(uic_masked_sum_launch(nullptr, b->masks, b->ld_masks, 1, N, d->T, L.scalars, L.scalars + 1, s));
+  const float* inv = inv_den ? inv_den : L.scalars + 1;
+  UicXeParams x;
+  memset(&x, 0, sizeof(x));
+  x.dtype = d->dtype; x.M = t_run * N; x.V1 = V1; x.ldv = V1p; x.logits = L.logits; x.dlogits = L.dlogits; x.N = N;
+  x.target = b->labels; x.ldtarget = b->ld_labels; x.target_col0 = 1;
+  x.mask = b->masks; x.ldmask = b->ld_masks; x.mask_col0 = 1;
+  x.inv_den = inv; x.row_loss = L.row_loss; x.write_grad = 1;
+  UIC_TRY(uic_xe_launch(x, s));
+  UIC_TRY(uic_reduce_sum_launch(L.row_loss, (size_t)t_run * N, 0.f, inv, loss_out, s));
+  if (den_out) UIC_TRY(uic_check_hip(hipMemcpyAsync(den_out, L.scalars, 4, hipMemcpyDeviceToDevice, s), "hipMemcpyAsync"));
+  return UIC_OK;
+}
+
+int uic_topdown_backward(const uic_topdown_dims* d, const uic_topdown_weights* w, const void* derived,
+                         const uic_topdown_batch* b, int32_t t_run, int32_t training, uint32_t seed,
+                         void* workspace, const float* dlogprobs, const float* logprobs,
+                         const uic_topdown_weights* G, void* stream) {
+  UIC_TRY(check_dims(d));
+  UIC_REQUIRE(w && derived && b && workspace && G, "backward: null pointer");
+  UIC_REQUIRE(t_run >= 1 && t_run <= d->T, "backward: t_run=%d outside [1,%d]", t_run, d->T);
+  UIC_REQUIRE(!dlogprobs || logprobs, "backward: dlogprobs needs the forward log-probs");
+  hipStream_t s = (hipStream_t)stream;
+  const Layout L = make_layout(*d, workspace);
+  const Derived dv = make_derived(*d, w, (void*)derived);
+  const int dt = d->dtype;
+  const int N = d->N, R = d->R, D = d->D, Dfc = d->Dfc, H = d->H, E = d->E, A = d->A, V1 = d->V1;
+  const int V1p = (int)rup8(V1), H4 = 4 * H, ldih = E + 2 * H;
+  const size_t S = uic_dtype_size(dt);
+  const float drop_p = training ? d->drop_p : 0.f;
+  const float inv_keep = drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f;
+  const int Meff = t_run * N, Mp = (int)rup8(Meff), Np = (int)rup8(N), NR = N * R, NRp = (int)rup8(NR);
+  const size_t NH = (size_t)N * H;
+  const void* fc_in = dt == UIC_BF16 ? L.fcT : (const void*)b->fc_feats;
+  const void* att_in = dt == UIC_BF16 ? L.attT : (const void*)b->att_feats;
+
+  if (dlogprobs)
+    UIC_TRY(uic_logsoftmax_bwd_launch(dt, L.dlogits, Meff, V1, V1p, N, dlogprobs, (size_t)V1, (size_t)d->T * V1, logprobs, s));
+
+  auto wgrad = [&](const void* left, int lrows, const void* right, int rrows, int K, float* C, int ldc) -> int {
+    // C[lrows, rrows] = left[lrows, K] right[rrows, K]^T   (both already transposed, K = padded row count)
+    UicGemmParams g = gemm_base(dt, lrows, rrows);
+    add_seg(g, left, K, right, K, K);
+    g.C = C; g.ldc = ldc; g.flags = UIC_GEMM_OUT_F32;
+    return uic_gemm_launch(g, s);
+  };
+
+  // ---- logit layer
+  {
+    UicGemmParams g = gemm_base(dt, Meff, H);
+    add_seg(g, L.dlogits, V1p, dv.logit_wT, V1p, V1p);
+    g.C = L.dhdrop; g.ldc = H; g.flags = UIC_GEMM_OUT_F32;
+    UIC_TRY(uic_gemm_launch(g, s));
+  }
+  UIC_TRY(uic_transpose_launch(dt, L.dlogits, Meff, V1, V1p, L.tA, Mp, s));
+  UIC_TRY(uic_transpose_launch(dt, L.hdrop_all, Meff, H, H, L.tB, Mp, s));
+  UIC_TRY(wgrad(L.tA, V1, L.tB, H, Mp, G->logit_w, H));
+  UIC_TRY(uic_colsum_launch(dt, L.dlogits, Meff, V1, V1p, G->logit_b, L.colscratch, L.colscratch_floats, s));
+
+  // ---- BPTT over the executed steps
+  UIC_TRY(uic_fill_launch(L.dc_att, 0, NH * 4, s));
+  UIC_TRY(uic_fill_launch(L.dc_lang, 0, NH * 4, s));
+  for (int t = t_run - 1; t >= 0; --t) {
+    const bool last = t == t_run - 1;
+    float* dx2 = L.dx2_all + (size_t)t * N * 3 * H;
+    const float* dx2_next = L.dx2_all + (size_t)(t + 1) * N * 3 * H;
+    {
+      UicLstmBwdParams p;
+      memset(&p, 0, sizeof(p));
+      p.dtype = dt; p.M = N; p.H = H;
+      p.dh0 = L.dhdrop + t * NH; p.lddh0 = H;
+      p.drop_p = drop_p; p.seed = seed; p.site = UIC_SITE_OUT0 + (unsigned)t;
+      if (!last) { p.dh1 = dx2_next + 2 * H; p.lddh1 = 3 * H; p.dh2 = L.dx1; p.lddh2 = 2 * H; }
+      p.dc = L.dc_lang; p.gates = off(L.gates2, (size_t)t * N * H4, dt);
+      p.c_prev = L.c_lang + t * NH; p.c = L.c_lang + (t + 1) * NH;
+      p.dgates = offw(L.dg2_all, (size_t)t * N * H4, dt);
+      UIC_TRY(uic_lstm_bwd_launch(p, s));
+    }
+    {  // d[att_res | h_att | h_lang_prev] = dG2 [W_ih | W_hh]
+      UicGemmParams g = gemm_base(dt, N, 3 * H);
+      add_seg(g, off(L.dg2_all, (size_t)t * N * H4, dt), H4, dv.w2T, H4, H4);
+      g.C = dx2; g.ldc = 3 * H; g.flags = UIC_GEMM_OUT_F32;
+      UIC_TRY(uic_gemm_launch(g, s));
+    }
+    {
+      UicAttnParams a;
+      memset(&a, 0, sizeof(a));
+      a.dtype = dt; a.N = N; a.R = R; a.A = A; a.H = H;
+      a.att_h = L.atth_all + (size_t)t * N * A; a.p_att = L.patt; a.att = L.attp; a.w_alpha = w->alpha_w;
+      a.alpha = L.alpha_all + (size_t)t * N * R;
+      a.dctx = dx2; a.lddctx = 3 * H;
+      a.de = L.de_all + (size_t)t * N * R;
+      a.d_att_h = offw(L.datth_all, (size_t)t * N * A, dt);
+      UIC_TRY(uic_attention_bwd_step_launch(a, s));
+    }
+    {  // dh_att += d_att_h W_h2att
+      UicGemmParams g = gemm_base(dt, N, H);
+      add_seg(g, off(L.datth_all, (size_t)t * N * A, dt), A, dv.h2attT, A, A);
+      g.C = dx2 + H; g.ldc = 3 * H; g.flags = UIC_GEMM_OUT_F32 | UIC_GEMM_ACCUM;
+      UIC_TRY(uic_gemm_launch(g, s));
+    }
+    {
+      UicLstmBwdParams p;
+      memset(&p, 0, sizeof(p));
+      p.dtype = dt; p.M = N; p.H = H;
+      p.dh0 = dx2 + H; p.lddh0 = 3 * H;
+      if (!last) { p.dh1 = L.dx1 + H; p.lddh1 = 2 * H; }
+      p.dc = L.dc_att; p.gates = off(L.gates1, (size_t)t * N * H4, dt);
+      p.c_prev = L.c_att + t * NH; p.c = L.c_att + (t + 1) * NH;
+      p.dgates = offw(L.dg1_all, (size_t)t * N * H4, dt);
+      UIC_TRY(uic_lstm_bwd_launch(p, s));
+    }
+    if (t > 0) {  // d[h_lang_prev | h_att_prev] = dG1 [W_ih[:, :H] | W_hh]
+      UicGemmParams g = gemm_base(dt, N, 2 * H);
+      add_seg(g, off(L.dg1_all, (size_t)t * N * H4, dt), H4, dv.w1recT, H4, H4);
+      g.C = L.dx1; g.ldc = 2 * H; g.flags = UIC_GEMM_OUT_F32;
+      UIC_TRY(uic_gemm_launch(g, s));
+    }
+  }
+
+  // ---- weight gradients, one GEMM per weight block over all executed steps
+  // lang_lstm
+  UIC_TRY(uic_transpose_launch(dt, L.dg2_all, Meff, H4, H4, L.tA, Mp, s));
+  UIC_TRY(uic_transpose_launch(dt, L.ctx_all, Meff, H, H, L.tB, Mp, s));
+  UIC_TRY(wgrad(L.tA, H4, L.tB, H, Mp, G->lang_lstm_w_ih, 2 * H));
+  UIC_TRY(uic_transpose_launch(dt, off(L.h_att, NH, dt), Meff, H, H, L.tB, Mp, s));
+  UIC_TRY(wgrad(L.tA, H4, L.tB, H, Mp, G->lang_lstm_w_ih + H, 2 * H));
+  UIC_TRY(uic_transpose_launch(dt, L.h_lang, Meff, H, H, L.tB, Mp, s));
+  UIC_TRY(wgrad(L.tA, H4, L.tB, H, Mp, G->lang_lstm_w_hh, H));
+  UIC_TRY(uic_colsum_launch(dt, L.dg2_all, Meff, H4, H4, G->lang_lstm_b_ih, L.colscratch, L.colscratch_floats, s));
+  UIC_TRY(uic_check_hip(hipMemcpyAsync(G->lang_lstm_b_hh, G->lang_lstm_b_ih, (size_t)H4 * 4, hipMemcpyDeviceToDevice, s), "memcpy b_hh"));
+  // att_lstm
+  UIC_TRY(uic_transpose_launch(dt, L.dg1_all, Meff, H4, H4, L.tA, Mp, s));
+  UIC_TRY(wgrad(L.tA, H4, L.tB, H, Mp, G->att_lstm_w_ih, ldih));                 // tB still holds h_lang_prev^T
+  UIC_TRY(uic_transpose_launch(dt, L.xt_all, Meff, E, E, L.tB, Mp, s));
+  UIC_TRY(wgrad(L.tA, H4, L.tB, E, Mp, G->att_lstm_w_ih + 2 * H, ldih));
+  UIC_TRY(uic_transpose_launch(dt, L.h_att, Meff, H, H, L.tB, Mp, s));
+  UIC_TRY(wgrad(L.tA, H4, L.tB, H, Mp, G->att_lstm_w_hh, H));
+  UIC_TRY(uic_colsum_launch(dt, L.dg1_all, Meff, H4, H4, G->att_lstm_b_ih, L.colscratch, L.colscratch_floats, s));
+  UIC_TRY(uic_check_hip(hipMemcpyAsync(G->att_lstm_b_hh, G->att_lstm_b_ih, (size_t)H4 * 4, hipMemcpyDeviceToDevice, s), "memcpy b_hh"));
+  {  // d xt -> embedding table
+    UicGemmParams g = gemm_base(dt, Meff, E);
+    add_seg(g, L.dg1_all, H4, dv.wxT, H4, H4);
+    g.C = L.dxt; g.ldc = E; g.flags = UIC_GEMM_OUT_F32;
+    UIC_TRY(uic_gemm_launch(g, s));
+    UIC_TRY(uic_fill_launch(G->embed_w, 0, (size_t)V1 * E * 4, s));
+    UIC_TRY(uic_embed_bwd_launch(dt, L.dxt, L.xt_all, b->labels, b->ld_labels, N, t_run, V1, E, drop_p, G->embed_w, s));
+  }
+  // fc' path: dGfc = sum_t dG1_t
+  UIC_TRY(uic_sum_steps_launch(dt, L.dg1_all, t_run, (size_t)N * H4, L.dgfc, s));
+  UIC_TRY(uic_transpose_launch(dt, L.dgfc, N, H4, H4, L.tA, Np, s));
+  UIC_TRY(uic_transpose_launch(dt, L.fcp, N, H, H, L.tB, Np, s));
+  UIC_TRY(wgrad(L.tA, H4, L.tB, H, Np, G->att_lstm_w_ih + H, ldih));
+  {
+    UicGemmParams g = gemm_base(dt, N, H);
+    add_seg(g, L.dgfc, H4, dv.wfcpT, H4, H4);
+    g.C = L.dfcp; g.ldc = H; g.flags = UIC_GEMM_OUT_F32;
+    UIC_TRY(uic_gemm_launch(g, s));
+  }
+  UIC_TRY(uic_relu_mask_bwd_launch(dt, L.dfcp, L.fcp, inv_keep, L.dfcpre, NH, s));
+  UIC_TRY(uic_transpose_launch(dt, L.dfcpre, N, H, H, L.tA, Np, s));
+  UIC_TRY(uic_transpose_launch(dt, fc_in, N, Dfc, Dfc, L.tB, Np, s));
+  UIC_TRY(wgrad(L.tA, H, L.tB, Dfc, Np, G->fc_w, Dfc));
+  UIC_TRY(uic_colsum_launch(dt, L.dfcpre, N, H, H, G->fc_b, L.colscratch, L.colscratch_floats, s));
+  // h2att
+  UIC_TRY(uic_transpose_launch(dt, L.datth_all, Meff, A, A, L.tA, Mp, s));
+  UIC_TRY(uic_transpose_launch(dt, off(L.h_att, NH, dt), Meff, H, H, L.tB, Mp, s));
+  UIC_TRY(wgrad(L.tA, A, L.tB, H, Mp, G->h2att_w, H));
+  UIC_TRY(uic_colsum_launch(dt, L.datth_all, Meff, A, A, G->h2att_b, L.colscratch, L.colscratch_floats, s));
+  // attention: deferred accumulation over steps
+  {
+    UicAttnAccumParams a;
+    memset(&a, 0, sizeof(a));
+    a.dtype = dt; a.N = N; a.R = R; a.A = A; a.H = H; a.T = t_run;
+    a.att_h_all = L.atth_all; a.alpha_all = L.alpha_all; a.de_all = L.de_all;
+    a.dctx_all = L.dx2_all; a.lddctx = 3 * H; a.dctx_step_stride = (size_t)N * 3 * H;
+    a.p_att = L.patt; a.w_alpha = w->alpha_w;
+    a.d_att = L.d_att; a.d_p_att = L.d_patt; a.d_walpha_part = L.dwalpha_part;
+    UIC_TRY(uic_attention_bwd_accum_launch(a, s));
+    UIC_TRY(uic_colsum_launch(UIC_F32, L.dwalpha_part, N, A + 1, A + 1, L.small, L.colscratch, L.colscratch_floats, s));
+    UIC_TRY(uic_check_hip(hipMemcpyAsync(G->alpha_w, L.small, (size_t)A * 4, hipMemcpyDeviceToDevice, s), "memcpy alpha_w"));
+    UIC_TRY(uic_check_hip(hipMemcpyAsync(G->alpha_b, L.small + A, 4, hipMemcpyDeviceToDevice, s), "memcpy alpha_b"));
+  }
+  // ctx2att
+  UIC_TRY(uic_transpose_launch(dt, L.d_patt, NR, A, A, L.tA, NRp, s));
+  UIC_TRY(uic_transpose_launch(dt, L.attp, NR, H, H, L.tB, NRp, s));
+  UIC_TRY(wgrad(L.tA, A, L.tB, H, NRp, G->ctx2att_w, H));
+  UIC_TRY(uic_colsum_launch(dt, L.d_patt, NR, A, A, G->ctx2att_b, L.colscratch, L.colscratch_floats, s));
+  {
+    UicGemmParams g = gemm_base(dt, NR, H);
+    add_seg(g, L.d_patt, A, dv.ctx2attT, A, A);
+    g.C = L.d_att; g.ldc = H; g.flags = UIC_GEMM_OUT_F32 | UIC_GEMM_ACCUM;
+    UIC_TRY(uic_gemm_launch(g, s));
+  }
+  // att_embed (padded regions have att' = 0 -> zero gradient, as pack_wrapper never touched them)
+  UIC_TRY(uic_relu_mask_bwd_launch(dt, L.d_att, L.attp, inv_keep, L.d_pre, (size_t)NR * H, s));
+  UIC_TRY(uic_transpose_launch(dt, L.d_pre, NR, H, H, L.tA, NRp, s));
+  UIC_TRY(uic_transpose_launch(dt, att_in, NR, D, D, L.tB, NRp, s));
+  UIC_TRY(wgrad(L.tA, H, L.tB, D, NRp, G->att_w, D));
+  UIC_TRY(uic_colsum_launch(dt, L.d_pre, NR, H, H, G->att_b, L.colscratch, L.colscratch_floats, s));
+  (void)S;
+  return UIC_OK;
+}
+
+int uic_topdown_sample(const uic_topdown_dims* d, const uic_topdown_weights* w, const void* derived,
+                       const uic_topdown_batch* b, int32_t Lsteps, int32_t sample_max, float temperature,
+                       int32_t decoding_constraint, uint32_t seed, const int64_t* forced, void* workspace,
+                       int64_t* seq, float* seq_logp, void* stream) {
+  UIC_TRY(check_dims(d));
+  UIC_REQUIRE(w && derived && b && workspace && seq && seq_logp, "sample: null pointer");
+  UIC_REQUIRE(b->fc_feats && b->att_feats, "sample: batch needs fc_feats and att_feats");
+  UIC_REQUIRE(Lsteps >= 1 && Lsteps <= d->T, "sample: L=%d outside [1,%d]", Lsteps, d->T);
+  UIC_REQUIRE(temperature > 0.f, "sample: temperature must be positive");
+  hipStream_t s = (hipStream_t)stream;
+  const Layout L = make_layout(*d, workspace);
+  const Derived dv = make_derived(*d, w, (void*)derived);
+  const int dt = d->dtype;
+  const int N = d->N, H = d->H, E = d->E, V1 = d->V1;
+  const int V1p = (int)rup8(V1), H4 = 4 * H, ldih = E + 2 * H;
+  const size_t S = uic_dtype_size(dt);
+  const size_t NH = (size_t)N * H;
+  const void *fc_in, *att_in;
+  UIC_TRY(prepare_features(*d, w, dv, b, L, 0.f, 0, &fc_in, &att_in, s));
+  UIC_TRY(uic_fill_launch(L.s_h_att[0], 0, NH * S, s));
+  UIC_TRY(uic_fill_launch(L.s_h_lang[0], 0, NH * S, s));
+  UIC_TRY(uic_fill_launch(L.s_c_att[0], 0, NH * 4, s));
+  UIC_TRY(uic_fill_launch(L.s_c_lang[0], 0, NH * 4, s));
+  UIC_TRY(uic_fill_launch(L.s_it, 0, (size_t)N * 8, s));       // <bos> = 0 (AttModel.py:214-215)
+  UIC_TRY(uic_fill_launch(L.s_unf, 0, (size_t)N * 4, s));
+  UIC_TRY(uic_fill_launch(L.s_nunf, 0, (size_t)(d->T + 2) * 4, s));
+  for (int t = 0; t < Lsteps; ++t) {
+    const int cur = t & 1, nxt = cur ^ 1;
+    UIC_TRY(uic_embed_fwd_launch(dt, w->embed_w, V1, E, L.s_it, 1, N, 1, 0.f, 0, 0, L.s_xt, s));
+    {
+      UicGemmParams g = gemm_base(dt, N, H4);
+      g.lstm = 1; g.H = H;
+      add_seg(g, L.s_h_lang[cur], H, dv.att_w_ih, ldih, H);
+      add_seg(g, L.fcp, H, off(dv.att_w_ih, H, dt), ldih, H);
+      add_seg(g, L.s_xt, E, off(dv.att_w_ih, 2 * H, dt), ldih, E);
+      add_seg(g, L.s_h_att[cur], H, dv.att_w_hh, H, H);
+      g.bias = w->att_lstm_b_ih; g.bias2 = w->att_lstm_b_hh;
+      g.c_prev = L.s_c_att[cur]; g.c_out = L.s_c_att[nxt];
+      g.h_out = L.s_h_att[nxt]; g.ldh = H;
+      UIC_TRY(uic_gemm_launch(g, s));
+    }
+    UIC_TRY(attention_step(*d, w, dv, b, L, L.s_h_att[nxt], L.s_atth, L.s_alpha, L.s_ctx, s));
+    {
+      UicGemmParams g = gemm_base(dt, N, H4);
+      g.lstm = 1; g.H = H;
+      add_seg(g, L.s_ctx, H, dv.lang_w_ih, 2 * H, H);
+      add_seg(g, L.s_h_att[nxt], H, off(dv.lang_w_ih, H, dt), 2 * H, H);
+      add_seg(g, L.s_h_lang[cur], H, dv.lang_w_hh, H, H);
+      g.bias = w->lang_lstm_b_ih; g.bias2 = w->lang_lstm_b_hh;
+      g.c_prev = L.s_c_lang[cur]; g.c_out = L.s_c_lang[nxt];
+      g.h_out = L.s_h_lang[nxt]; g.ldh = H;
+      UIC_TRY(uic_gemm_launch(g, s));
+    }
+    {
+      UicGemmParams g = gemm_base(dt, N, V1);
+      add_seg(g, L.s_h_lang[nxt], H, dv.logit_w, H, H);
+      g.C = L.s_logits; g.ldc = V1p; g.bias = w->logit_b; g.flags = UIC_GEMM_OUT_F32;
+      UIC_TRY(uic_gemm_launch(g, s));
+    }
+    UicSampleParams p;
+    memset(&p, 0, sizeof(p));
+    p.dtype = dt; p.N = N; p.V1 = V1; p.ldv = V1p; p.t = t; p.L = Lsteps;
+    p.logits = L.s_logits; p.sample_max = sample_max; p.temperature = temperature; p.seed = seed;
+    p.decoding_constraint = decoding_constraint;
+    p.seq = seq; p.seq_logp = seq_logp; p.it = L.s_it; p.unfinished = L.s_unf; p.n_unfinished = L.s_nunf;
+    p.forced = forced;
+    UIC_TRY(uic_sample_step_launch(p, s));
+  }
+  return UIC_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,259 @@
+// Internal declarations shared by the HIP translation units of libuic_hip.so.
+// gfx950 (MI355X / CDNA4) only: 64-wide wavefronts, MFMA 32x32 tiles, 160 KB LDS.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stddef.h>
+
+#define UIC_F32 0
+#define UIC_BF16 1
+
+#define UIC_OK 0
+#define UIC_EARG (-1)
+
+typedef __bf16 bf16_t;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+
+void uic_set_error(const char* fmt, ...);
+int uic_check_hip(hipError_t e, const char* what);
+
+#define UIC_REQUIRE(cond, ...)                 \
+  do {                                         \
+    if (!(cond)) {                             \
+      uic_set_error(__VA_ARGS__);              \
+      return UIC_EARG;                         \
+    }                                          \
+  } while (0)
+
+#define UIC_LAUNCH_CHECK(what)                                   \
+  do {                                                           \
+    int _e = uic_check_hip(hipGetLastError(), what);             \
+    if (_e) return _e;                                           \
+  } while (0)
+
+#define UIC_TRY(expr)          \
+  do {                         \
+    int _e = (expr);           \
+    if (_e) return _e;         \
+  } while (0)
+
+static inline size_t uic_dtype_size(int dtype) { return dtype == UIC_BF16 ? 2 : 4; }
+static inline int uic_round_up(int x, int m) { return (x + m - 1) / m * m; }
+
+// ---------------------------------------------------------------- device helpers
+#ifdef __HIPCC__
+template <typename T> struct uic_vec;   // 16-byte vector of T
+template <> struct uic_vec<float> { static constexpr int N = 4; };
+template <> struct uic_vec<bf16_t> { static constexpr int N = 8; };
+
+__device__ __forceinline__ float uic_to_f(float x) { return x; }
+__device__ __forceinline__ float uic_to_f(bf16_t x) { return (float)x; }
+template <typename T> __device__ __forceinline__ T uic_from_f(float x);
+template <> __device__ __forceinline__ float uic_from_f<float>(float x) { return x; }
+template <> __device__ __forceinline__ bf16_t uic_from_f<bf16_t>(float x) { return (bf16_t)x; }
+
+// unpack a 16-byte chunk into floats (4 for f32, 8 for bf16)
+template <typename T> __device__ __forceinline__ void uic_unpack(const uint4& v, float* f);
+template <> __device__ __forceinline__ void uic_unpack<float>(const uint4& v, float* f) {
+  f[0] = __uint_as_float(v.x); f[1] = __uint_as_float(v.y);
+  f[2] = __uint_as_float(v.z); f[3] = __uint_as_float(v.w);
+}
+template <> __device__ __forceinline__ void uic_unpack<bf16_t>(const uint4& v, float* f) {
+  f[0] = __uint_as_float(v.x << 16); f[1] = __uint_as_float(v.x & 0xffff0000u);
+  f[2] = __uint_as_float(v.y << 16); f[3] = __uint_as_float(v.y & 0xffff0000u);
+  f[4] = __uint_as_float(v.z << 16); f[5] = __uint_as_float(v.z & 0xffff0000u);
+  f[6] = __uint_as_float(v.w << 16); f[7] = __uint_as_float(v.w & 0xffff0000u);
+}
+__device__ __forceinline__ unsigned uic_pack_bf16x2(float lo, float hi) {
+  bf16_t a = (bf16_t)lo, b = (bf16_t)hi;
+  unsigned short ua = __builtin_bit_cast(unsigned short, a), ub = __builtin_bit_cast(unsigned short, b);
+  return (unsigned)ua | ((unsigned)ub << 16);
+}
+template <typename T> __device__ __forceinline__ uint4 uic_pack(const float* f);
+template <> __device__ __forceinline__ uint4 uic_pack<float>(const float* f) {
+  return make_uint4(__float_as_uint(f[0]), __float_as_uint(f[1]), __float_as_uint(f[2]), __float_as_uint(f[3]));
+}
+template <> __device__ __forceinline__ uint4 uic_pack<bf16_t>(const float* f) {
+  return make_uint4(uic_pack_bf16x2(f[0], f[1]), uic_pack_bf16x2(f[2], f[3]),
+                    uic_pack_bf16x2(f[4], f[5]), uic_pack_bf16x2(f[6], f[7]));
+}
+
+// Counter-based dropout: the keep decision of element `idx` at dropout site `site` is a pure
+// function of (seed, site, idx), so forward, backward and the exported test masks agree.
+__device__ __forceinline__ float uic_drop_scale(unsigned seed, unsigned site, unsigned idx, float p, float inv_keep) {
+  unsigned x = idx * 0x9E3779B1u ^ (seed + site * 0x85EBCA77u);
+  x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16;
+  float u = (float)(x >> 8) * (1.0f / 16777216.0f);
+  return u < p ? 0.f : inv_keep;
+}
+
+__device__ __forceinline__ float uic_sigmoid(float x) { return 1.f / (1.f + expf(-x)); }
+
+// tanh: exact libm form on the f32 path (parity), exp-based fast form on the bf16 path
+template <typename T> __device__ __forceinline__ float uic_tanh(float x);
+template <> __device__ __forceinline__ float uic_tanh<float>(float x) { return tanhf(x); }
+template <> __device__ __forceinline__ float uic_tanh<bf16_t>(float x) {
+  float e = __expf(2.f * x);
+  return 1.f - __fdividef(2.f, e + 1.f);
+}
+
+__device__ __forceinline__ float uic_wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float uic_wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+#endif  // __HIPCC__
+
+// ---------------------------------------------------------------- GEMM (gemm.hip)
+#define UIC_GEMM_RELU 1      // v = max(v, 0)
+#define UIC_GEMM_ACCUM 2     // C += v
+#define UIC_GEMM_OUT_F32 4   // C is float regardless of the operand dtype
+#define UIC_GEMM_MAX_SEG 4
+
+// One K-segment: C += A[M,K] * B[Nrows,K]^T.  Segments are summed, which expresses
+// torch.cat([...],1) followed by a Linear without materialising the concatenation.
+struct UicGemmSeg {
+  const void* A; const void* B;
+  int K, lda, ldb;
+};
+
+struct UicGemmParams {
+  int dtype;                // operand dtype (UIC_F32 / UIC_BF16)
+  int M, N;
+  int nseg;
+  UicGemmSeg seg[UIC_GEMM_MAX_SEG];
+  void* C; int ldc;
+  const float* bias;        // [N] or null
+  const float* bias2;       // [N] or null
+  int flags;
+  // pack_wrapper semantics (AttModel.py:44-53): row m = n*R + r is live iff r < row_len[n]
+  const int* row_len; int R;
+  // dropout applied after ReLU
+  float drop_p; unsigned seed; unsigned site;
+  // ---- fused LSTM cell epilogue (N must be 4*H) ----
+  int lstm; int H;
+  const float* pre1; int ldpre1;   // [M,4H] added to the gate pre-activations (may be null)
+  const float* pre2; int ldpre2;
+  const float* c_prev;             // [M,H] or null (= 0)
+  float* c_out;                    // [M,H]
+  void* h_out; int ldh;            // [M,H] operand dtype
+  void* h_drop; int ldhd;          // dropout(h) copy, or null
+  void* gates_out;                 // [M,4H] activated gates (i,f,g,o), operand dtype, or null
+};
+
+int uic_gemm_launch(const UicGemmParams& p, hipStream_t stream);
+
+// ---------------------------------------------------------------- attention (attention.hip)
+struct UicAttnParams {
+  int dtype, N, R, A, H;
+  const float* att_h;      // [N,A]  h2att(h) incl. bias
+  const void* p_att;       // [N,R,A]
+  const void* att;         // [N,R,H]
+  const float* w_alpha;    // [A]
+  const float* b_alpha;    // [1]
+  const float* mask; int ldmask;   // [N,R] or null
+  float* alpha;            // [N,R] out (fwd) / in (bwd)
+  void* ctx; int ldctx;    // [N,H] operand dtype (fwd out)
+  // backward step
+  const float* dctx; int lddctx;   // [N,H]
+  float* de;               // [N,R]
+  void* d_att_h;           // [N,A] operand dtype
+};
+int uic_attention_fwd_launch(const UicAttnParams& p, hipStream_t s);
+int uic_attention_bwd_step_launch(const UicAttnParams& p, hipStream_t s);
+
+struct UicAttnAccumParams {
+  int dtype, N, R, A, H, T;          // T = number of executed decode steps
+  const float* att_h_all;  // [T,N,A]
+  const float* alpha_all;  // [T,N,R]
+  const float* de_all;     // [T,N,R]
+  const float* dctx_all; int lddctx; size_t dctx_step_stride;  // [T][N,lddctx]
+  const void* p_att;       // [N,R,A]
+  const float* w_alpha;
+  float* d_att;            // [N,R,H] fp32 out (overwritten)
+  void* d_p_att;           // [N,R,A] operand dtype out
+  float* d_walpha_part;    // [N,A+1] per-row partial of (d w_alpha, d b_alpha)
+};
+int uic_attention_bwd_accum_launch(const UicAttnAccumParams& p, hipStream_t s);
+
+// ---------------------------------------------------------------- pointwise (pointwise.hip)
+int uic_cast_f32_launch(int dtype, const float* src, void* dst, size_t n, hipStream_t s);
+int uic_to_f32_launch(int dtype, const void* src, float* dst, size_t n, hipStream_t s);
+int uic_fill_launch(void* dst, int value_byte, size_t bytes, hipStream_t s);
+// dst[cols, ldd] = src[rows, lds]^T, zero-filling dst columns rows..ldd-1
+int uic_transpose_launch(int dtype, const void* src, int rows, int cols, int lds, void* dst, int ldd, hipStream_t s);
+// out[c] = sum_r src[r, c]  (deterministic two-stage; src operand dtype or f32)
+int uic_colsum_launch(int src_dtype, const void* src, int rows, int cols, int lds, float* out, float* scratch,
+                      size_t scratch_floats, hipStream_t s);
+// dst[n, c] = sum_t src[t, n, c]
+int uic_sum_steps_launch(int dtype, const void* src, int T, size_t step_elems, void* dst, hipStream_t s);
+int uic_embed_fwd_launch(int dtype, const float* table, int V1, int E, const int64_t* tokens, int ldtok, int N, int T,
+                         float drop_p, unsigned seed, unsigned site, void* out, hipStream_t s);
+int uic_embed_bwd_launch(int dtype, const float* dxt, const void* xt, const int64_t* tokens, int ldtok, int N, int T,
+                         int V1, int E, float drop_p, float* dtable, hipStream_t s);
+// dst = (act > 0 ? scale : 0) * grad ; grad f32, act/dst operand dtype
+int uic_relu_mask_bwd_launch(int dtype, const float* grad, const void* act, float scale, void* dst, size_t n, hipStream_t s);
+
+struct UicLstmBwdParams {
+  int dtype, M, H;
+  const float* dh0; int lddh0;   // up to three dh sources (null = absent)
+  const float* dh1; int lddh1;
+  const float* dh2; int lddh2;
+  float drop_p; unsigned seed; unsigned site; size_t drop_base;  // dropout applied to dh0 only (out-dropout)
+  float* dc;                     // [M,H] in: dc from step t+1 ; out: dc for step t-1  (in place)
+  const void* gates;             // [M,4H] activated (i,f,g,o)
+  const float* c_prev;           // [M,H] or null
+  const float* c;                // [M,H]
+  void* dgates;                  // [M,4H] operand dtype out
+};
+int uic_lstm_bwd_launch(const UicLstmBwdParams& p, hipStream_t s);
+
+struct UicXeParams {
+  int dtype, M, V1, ldv;         // logits f32 [M, ldv] in; dlogits [M, ldv] operand dtype out
+  const float* logits;
+  void* dlogits;
+  const int64_t* target; int ldtarget; int target_col0;   // target[n, target_col0 + t]
+  const float* mask; int ldmask; int mask_col0;
+  int N;                         // row m = t*N + n
+  const float* inv_den;          // device scalar: 1 / sum(mask)
+  float* row_loss;               // [M]
+  float* logprobs; size_t lp_step_stride, lp_row_stride;  // optional full log-probs out [n][t][v]
+  int write_grad;
+};
+int uic_xe_launch(const UicXeParams& p, hipStream_t s);
+// general log-softmax backward given dense upstream grad g [N,T,V1] (API-compat path):
+// dlogits = g - softmax * sum(g)
+int uic_logsoftmax_bwd_launch(int dtype, void* dlogits, int M, int V1, int ldv, int N, const float* g,
+                              size_t g_step_stride, size_t g_row_stride, const float* logprobs, hipStream_t s);
+int uic_masked_sum_launch(const float* x, const float* mask, int ldmask, int col0, int N, int T, float* out_sum,
+                          float* out_inv, hipStream_t s);
+int uic_reduce_sum_launch(const float* x, size_t n, float scale_by_dev_ptr_or_one, const float* scale, float* out, hipStream_t s);
+
+struct UicAdamParams {
+  float* p; const float* g; float* m; float* v; size_t n;
+  float lr, beta1, beta2, eps, bc1, bc2, grad_scale;
+};
+int uic_adam_launch(const UicAdamParams& a, hipStream_t s);
+
+struct UicSampleParams {
+  int dtype, N, V1, ldv, t, L;
+  const void* logits;            // [N, ldv]
+  int sample_max; float temperature; unsigned seed;
+  int decoding_constraint;
+  int64_t* seq;                  // [N, L]
+  float* seq_logp;               // [N, L]
+  int64_t* it;                   // [N] next input token
+  int* unfinished;               // [N]
+  int* n_unfinished;             // [L+1] live-row counters per step
+  const int64_t* forced;         // optional [N, L] tokens replacing the multinomial draw
+  float* logprobs_out;           // optional [N, V1]
+};
+int uic_sample_step_launch(const UicSampleParams& p, hipStream_t s);
+int uic_dropout_mask_launch(float* out, size_t n, float p, unsigned seed, unsigned site, size_t base, hipStream_t s);

@@ -1,0 +1,175 @@
+"""TopDownModel behind the reference's constructor / call / state_dict contract
+(P/models/AttModel.py:55-253, 421-446, 529-558, 686-690), computed by libuic_hip.so.
+
+The nn.Module tree below exists only to own parameters under the reference's names
+(`embed.0.weight`, `core.att_lstm.weight_ih`, ...), so `state_dict()` / `load_state_dict()`
+round-trip the reference's `model_i2t-best.pth` unchanged; none of these sub-modules'
+`forward` is ever called.  There is no eager fallback: without the HIP library, or on a
+CPU tensor, every call raises.
+"""
+import torch
+import torch.nn as nn
+
+from .CaptionModel import CaptionModel
+from .. import _lib
+from ..topdown_engine import TopDownEngine
+
+
+class Attention(nn.Module):
+    def __init__(self, opt):
+        super(Attention, self).__init__()
+        self.rnn_size = opt.rnn_size
+        self.att_hid_size = opt.att_hid_size
+        self.h2att = nn.Linear(self.rnn_size, self.att_hid_size)
+        self.alpha_net = nn.Linear(self.att_hid_size, 1)
+
+
+class TopDownCore(nn.Module):
+    def __init__(self, opt, use_maxout=False):
+        super(TopDownCore, self).__init__()
+        self.drop_prob_lm = opt.drop_prob_lm
+        self.att_lstm = nn.LSTMCell(opt.input_encoding_size + opt.rnn_size * 2, opt.rnn_size)
+        self.lang_lstm = nn.LSTMCell(opt.rnn_size * 2, opt.rnn_size)
+        self.attention = Attention(opt)
+
+
+class _TopDownForward(torch.autograd.Function):
+    """log-probs = AttModel._forward(...); backward = the library's BPTT."""
+
+    @staticmethod
+    def forward(ctx, model, fc, att, seq, att_masks, t_run, *params):
+        eng = model.engine
+        names = model.param_names
+        pd = dict(zip(names, params))
+        seed = model.next_seed()
+        training = model.training
+        logp, ws, (d, w, b) = eng.forward(pd, fc, att, att_masks, seq, t_run, training, seed, want_logprobs=True)
+        ctx.model = model
+        ctx.ws = ws
+        ctx.call = (d, t_run, training, seed)
+        ctx.inputs = (fc, att, att_masks, seq)
+        ctx.params = params
+        ctx.save_for_backward(logp)
+        return logp
+
+    @staticmethod
+    def backward(ctx, g):
+        model = ctx.model
+        eng = model.engine
+        (logp,) = ctx.saved_tensors
+        d, t_run, training, seed = ctx.call
+        fc, att, att_masks, seq = ctx.inputs
+        pd = dict(zip(model.param_names, ctx.params))
+        w = eng.refresh(pd, d)
+        b = eng.batch_struct(fc, att, att_masks, seq)
+        grads = {k: torch.empty_like(v) for k, v in pd.items()}
+        eng.backward(ctx.ws, d, w, b, t_run, training, seed, grads, dlogprobs=g.contiguous(), logprobs=logp)
+        eng.release(ctx.ws)
+        ctx.ws = None
+        return (None, None, None, None, None, None) + tuple(grads[k] for k in model.param_names)
+
+
+class AttModel(CaptionModel):
+    def __init__(self, opt):
+        super(AttModel, self).__init__()
+        self.vocab_size = opt.vocab_size
+        self.input_encoding_size = opt.input_encoding_size
+        self.rnn_size = opt.rnn_size
+        self.num_layers = opt.num_layers
+        self.drop_prob_lm = opt.drop_prob_lm
+        self.seq_length = opt.seq_length
+        self.fc_feat_size = opt.fc_feat_size
+        self.att_feat_size = opt.att_feat_size
+        self.att_hid_size = opt.att_hid_size
+        self.use_bn = getattr(opt, 'use_bn', 0)
+        self.ss_prob = 0.0  # Schedule sampling probability
+        if self.use_bn:
+            raise NotImplementedError("use_bn=%d: BatchNorm in att_embed is not on the MI355X hot path yet "
+                                      "(BASELINE config 2 is measured with use_bn=0)" % self.use_bn)
+        if getattr(opt, 'logit_layers', 1) != 1:
+            raise NotImplementedError("logit_layers > 1 is not on the MI355X hot path")
+        self.logit_layers = 1
+
+        self.embed = nn.Sequential(nn.Embedding(self.vocab_size + 1, self.input_encoding_size),
+                                   nn.ReLU(),
+                                   nn.Dropout(self.drop_prob_lm))
+        self.fc_embed = nn.Sequential(nn.Linear(self.fc_feat_size, self.rnn_size),
+                                      nn.ReLU(),
+                                      nn.Dropout(self.drop_prob_lm))
+        self.att_embed = nn.Sequential(nn.Linear(self.att_feat_size, self.rnn_size),
+                                       nn.ReLU(),
+                                       nn.Dropout(self.drop_prob_lm))
+        self.logit = nn.Linear(self.rnn_size, self.vocab_size + 1)
+        self.ctx2att = nn.Linear(self.rnn_size, self.att_hid_size)
+
+        # MI355X engine state (not part of the checkpoint)
+        self.compute_dtype = getattr(opt, 'compute_dtype', 'bf16')
+        self._engine = None
+        self._seed_counter = int(getattr(opt, 'seed', 0) or 0) & 0x7FFFFFFF
+
+    # ------------------------------------------------------------------ engine plumbing
+    @property
+    def engine(self):
+        if self._engine is None:
+            self._engine = TopDownEngine(dict(V1=self.vocab_size + 1, E=self.input_encoding_size, H=self.rnn_size,
+                                              A=self.att_hid_size, D=self.att_feat_size, Dfc=self.fc_feat_size),
+                                         dtype=self.compute_dtype, drop_p=self.drop_prob_lm)
+        return self._engine
+
+    @property
+    def param_names(self):
+        return [k for _, k in _lib.WEIGHT_FIELDS]
+
+    def param_dict(self):
+        sd = dict(self.named_parameters())
+        return {k: sd[k] for k in self.param_names}
+
+    def next_seed(self):
+        self._seed_counter = (self._seed_counter * 1103515245 + 12345) & 0x7FFFFFFF
+        return self._seed_counter
+
+    def init_hidden(self, bsz):
+        weight = next(self.parameters())
+        return (weight.new_zeros(self.num_layers, bsz, self.rnn_size),
+                weight.new_zeros(self.num_layers, bsz, self.rnn_size))
+
+    @staticmethod
+    def _steps_to_run(seq):
+        """Early break of AttModel._forward (:148-151): stop at the first all-zero column i >= 1."""
+        T = seq.size(1) - 1
+        zero_cols = (seq[:, 1:T].sum(0) == 0).nonzero()
+        return int(zero_cols[0].item()) + 1 if zero_cols.numel() else T
+
+    # ------------------------------------------------------------------ reference call surface
+    def _forward(self, fc_feats, attri_feats, att_feats, seq, att_masks=None):
+        if self.training and self.ss_prob > 0.0:
+            raise NotImplementedError("scheduled sampling (ss_prob > 0) is not on the MI355X hot path yet")
+        t_run = self._steps_to_run(seq)
+        fc = fc_feats.contiguous().float()
+        att = att_feats.contiguous().float()
+        am = att_masks.contiguous().float() if att_masks is not None else None
+        params = [self.param_dict()[k] for k in self.param_names]
+        return _TopDownForward.apply(self, fc, att, seq.contiguous(), am, t_run, *params)
+
+    def _sample(self, fc_feats, attri_feats, att_feats, att_masks=None, opt={}):
+        sample_max = opt.get('sample_max', 1)
+        beam_size = opt.get('beam_size', 1)
+        temperature = opt.get('temperature', 1.0)
+        decoding_constraint = opt.get('decoding_constraint', 0)
+        if beam_size > 1:
+            raise NotImplementedError("beam search (beam_size > 1) is a 'next' row of the hot-path scope")
+        fc = fc_feats.contiguous().float()
+        att = att_feats.contiguous().float()
+        am = att_masks.contiguous().float() if att_masks is not None else None
+        with torch.no_grad():
+            pd = {k: v.detach() for k, v in self.param_dict().items()}
+            return self.engine.sample(pd, fc, att, am, self.seq_length, sample_max=sample_max,
+                                      temperature=temperature, decoding_constraint=decoding_constraint,
+                                      seed=self.next_seed(), forced=opt.get('forced_tokens'))
+
+
+class TopDownModel(AttModel):
+    def __init__(self, opt):
+        super(TopDownModel, self).__init__(opt)
+        self.num_layers = 2
+        self.core = TopDownCore(opt)

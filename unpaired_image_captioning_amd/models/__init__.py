@@ -1,0 +1,10 @@
+"""`models.setup(opt)` with the reference's dispatch (P/models/__init__.py:22-58), restricted to
+the architectures on the hot path."""
+from .AttModel import TopDownModel  # noqa: F401
+from .CaptionModel import CaptionModel  # noqa: F401
+
+
+def setup(opt):
+    if opt.caption_model == 'topdown':
+        return TopDownModel(opt)
+    raise Exception("Caption model not supported by the MI355X hot path: {}".format(opt.caption_model))

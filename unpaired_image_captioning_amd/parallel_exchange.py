@@ -1,0 +1,50 @@
+"""Data-parallel exchange of the captioner step: one process per GPU, one RCCL all-reduce
+of the flat gradient arena per step over xGMI (backend "nccl" is RCCL on ROCm; "gloo" in the
+CPU tests).  Replaces torch.nn.DataParallel's per-step parameter broadcast, output gather to
+GPU0 and reduce-add (P/trainer.py:74, SURVEY.md section 2a "Collectives").
+
+Loss normalisation: the reference divides by the mask sum of the WHOLE batch
+(P/misc/criterion.py:149).  Each rank therefore scales its rows by 1 / sum_over_ranks(mask sum)
+-- a 1-float all-reduce issued before the forward -- and gradients are summed, not averaged.
+"""
+import torch
+import torch.distributed as dist
+
+
+class GradientExchange(object):
+    def __init__(self, group=None):
+        self.group = group
+
+    @property
+    def world_size(self):
+        return dist.get_world_size(self.group) if dist.is_available() and dist.is_initialized() else 1
+
+    @property
+    def rank(self):
+        return dist.get_rank(self.group) if dist.is_available() and dist.is_initialized() else 0
+
+    def global_inv_den(self, den_local, device):
+        """1 / (global mask sum) as a device scalar, or None on a single rank (the kernel computes it)."""
+        if self.world_size == 1:
+            return None
+        t = torch.tensor([float(den_local)], dtype=torch.float32, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
+        return t.reciprocal_()
+
+    def allreduce_sum(self, flat):
+        """Sum the flat gradient arena over ranks, in place (one collective per step)."""
+        if self.world_size > 1:
+            dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group)
+        return flat
+
+    def allreduce_sum_scalar(self, x):
+        if self.world_size > 1:
+            x = x.clone()
+            dist.all_reduce(x, op=dist.ReduceOp.SUM, group=self.group)
+        return x
+
+    def shard_images(self, n_images):
+        """Images [lo, hi) of this rank: shard by image so the seq_per_img replicas stay together."""
+        w, r = self.world_size, self.rank
+        per = (n_images + w - 1) // w
+        return min(r * per, n_images), min((r + 1) * per, n_images)

@@ -1,0 +1,140 @@
+"""Device-side driver of the TopDown captioner: owns the caller-allocated arenas
+(workspace, derived weights) the C ABI asks for and turns torch tensors into the
+pointer structs of include/uic_hip.h.  torch is plumbing only (device memory,
+streams); all arithmetic happens in libuic_hip.so.
+"""
+import ctypes as C
+
+import torch
+
+from . import _lib
+from ._lib import Batch, Dims, Weights, WEIGHT_FIELDS, check, ptr, stream
+
+
+class Workspace(object):
+    """One forward's activations; held until its backward has run."""
+
+    def __init__(self, dims, buf):
+        self.dims = dims
+        self.buf = buf
+
+
+class TopDownEngine(object):
+    def __init__(self, sizes, dtype="bf16", drop_p=0.5):
+        """sizes: dict with V1, E, H, A, D, Dfc."""
+        self.lib = _lib.load()
+        self.sizes = dict(sizes)
+        self.dtype = _lib.dtype_id(dtype)
+        self.drop_p = float(drop_p)
+        self._derived = None
+        self._derived_key = None
+        self._pool = {}
+        self.seed = 0x5EED
+
+    # ------------------------------------------------------------------ arenas
+    def dims(self, N, R, T):
+        s = self.sizes
+        return Dims(N=N, R=R, D=s["D"], Dfc=s["Dfc"], H=s["H"], E=s["E"], A=s["A"], V1=s["V1"], T=T,
+                    dtype=self.dtype, drop_p=self.drop_p)
+
+    @staticmethod
+    def _key(d):
+        return (d.N, d.R, d.T, d.dtype)
+
+    def checkout(self, d, device):
+        free = self._pool.setdefault(self._key(d), [])
+        if free:
+            return free.pop()
+        nbytes = self.lib.uic_topdown_workspace_bytes(C.byref(d))
+        if nbytes == 0:
+            check(-1, "uic_topdown_workspace_bytes")
+        return Workspace(d, torch.empty(nbytes, dtype=torch.uint8, device=device))
+
+    def release(self, ws):
+        self._pool.setdefault(self._key(ws.dims), []).append(ws)
+
+    def weights_struct(self, tensors):
+        """tensors: dict reference-state_dict-key -> contiguous f32 device tensor."""
+        w = Weights()
+        for field, key in WEIGHT_FIELDS:
+            t = tensors[key]
+            if t.dtype != torch.float32:
+                raise RuntimeError("parameter %s must be float32, got %s" % (key, t.dtype))
+            setattr(w, field, ptr(t))
+        return w
+
+    def refresh(self, params, d):
+        """Rebuild operand-dtype / transposed weight copies from the f32 masters."""
+        dev = next(iter(params.values())).device
+        nbytes = self.lib.uic_topdown_derived_bytes(C.byref(d))
+        if self._derived is None or self._derived.numel() < nbytes or self._derived.device != dev:
+            self._derived = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        w = self.weights_struct(params)
+        check(self.lib.uic_topdown_refresh_weights(C.byref(d), C.byref(w), ptr(self._derived), stream()), "refresh_weights")
+        return w
+
+    @staticmethod
+    def batch_struct(fc, att, att_masks, labels=None, masks=None):
+        b = Batch()
+        b.fc_feats = ptr(fc)
+        b.att_feats = ptr(att)
+        b.att_masks = ptr(att_masks)
+        b.labels = ptr(labels)
+        b.ld_labels = labels.shape[1] if labels is not None else 0
+        b.masks = ptr(masks)
+        b.ld_masks = masks.shape[1] if masks is not None else 0
+        return b
+
+    # ------------------------------------------------------------------ calls
+    def forward(self, params, fc, att, att_masks, labels, t_run, training, seed, want_logprobs=True, masks=None):
+        N, R = att.shape[0], att.shape[1]
+        T = labels.shape[1] - 1
+        d = self.dims(N, R, T)
+        w = self.refresh(params, d)
+        ws = self.checkout(d, fc.device)
+        b = self.batch_struct(fc, att, att_masks, labels, masks)
+        logp = torch.zeros(N, T, d.V1, dtype=torch.float32, device=fc.device) if want_logprobs else None
+        check(self.lib.uic_topdown_forward(C.byref(d), C.byref(w), ptr(self._derived), C.byref(b), t_run,
+                                           int(training), seed & 0xFFFFFFFF, ptr(ws.buf), ptr(logp), stream()), "forward")
+        return logp, ws, (d, w, b)
+
+    def xe_loss(self, ws, d, b, t_run, inv_den=None):
+        out = torch.empty(2, dtype=torch.float32, device=ws.buf.device)
+        check(self.lib.uic_topdown_xe_loss(C.byref(d), C.byref(b), t_run, ptr(ws.buf), ptr(inv_den),
+                                           out.data_ptr(), out.data_ptr() + 4, stream()), "xe_loss")
+        return out            # [loss, sum(mask)]
+
+    def backward(self, ws, d, w, b, t_run, training, seed, grads, dlogprobs=None, logprobs=None):
+        g = self.weights_struct(grads)
+        check(self.lib.uic_topdown_backward(C.byref(d), C.byref(w), ptr(self._derived), C.byref(b), t_run, int(training),
+                                            seed & 0xFFFFFFFF, ptr(ws.buf), ptr(dlogprobs), ptr(logprobs), C.byref(g),
+                                            stream()), "backward")
+
+    def sample(self, params, fc, att, att_masks, L, sample_max=1, temperature=1.0, decoding_constraint=0, seed=0,
+               forced=None):
+        N, R = att.shape[0], att.shape[1]
+        d = self.dims(N, R, L + 1)
+        w = self.refresh(params, d)
+        ws = self.checkout(d, fc.device)
+        b = self.batch_struct(fc, att, att_masks)
+        seq = torch.zeros(N, L, dtype=torch.int64, device=fc.device)
+        lp = torch.zeros(N, L, dtype=torch.float32, device=fc.device)
+        try:
+            check(self.lib.uic_topdown_sample(C.byref(d), C.byref(w), ptr(self._derived), C.byref(b), L, int(sample_max),
+                                              float(temperature), int(decoding_constraint), seed & 0xFFFFFFFF, ptr(forced),
+                                              ptr(ws.buf), ptr(seq), ptr(lp), stream()), "sample")
+        finally:
+            self.release(ws)
+        return seq, lp
+
+    def workspace_tensor(self, ws, name, shape, dtype):
+        """View of a named activation inside a workspace (tests)."""
+        p = self.lib.uic_topdown_workspace_ptr(C.byref(ws.dims), ptr(ws.buf), name.encode())
+        if not p:
+            raise KeyError(name)
+        offset = p - ws.buf.data_ptr()
+        n = 1
+        for s in shape:
+            n *= s
+        esz = torch.empty(0, dtype=dtype).element_size()
+        return ws.buf[offset:offset + n * esz].view(dtype).view(*shape)

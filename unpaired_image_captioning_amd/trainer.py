@@ -1,0 +1,163 @@
+"""One training step of the captioner, as the reference's Trainer.train does it
+(P/trainer.py:141-193): host batch -> device, forward, LanguageModelCriterion, backward,
+Adam (P/misc/optimizer.py:89-93; the captioner's gradient clipping is a no-op there because
+`i2t_params` is a consumed generator, :78-79,92, and is therefore not applied here either).
+
+MI355X-first differences (results-identical): log_softmax + criterion are fused over all T*N
+rows (no [N,T,V1] log-prob tensor), parameters / gradients / Adam moments live in flat f32
+arenas so the optimizer is one kernel and data parallelism is ONE RCCL all-reduce per step
+(instead of DataParallel's per-step broadcast + gather + reduce, P/trainer.py:74).
+"""
+import os
+
+import numpy as np
+import torch
+
+from . import _lib, models
+from ._lib import check, ptr, stream
+from .parallel_exchange import GradientExchange
+
+
+def _steps_from_host_labels(labels_np):
+    """Early break of AttModel._forward (:151) decided on the host copy of the labels: no device sync."""
+    T = labels_np.shape[1] - 1
+    colsum = labels_np[:, 1:T].sum(0)
+    z = np.nonzero(colsum == 0)[0]
+    return int(z[0]) + 1 if z.size else T
+
+
+def xe_step(model, batch, t_run=None, inv_den=None, grads=None, return_seed=False):
+    """forward + fused criterion + backward on device tensors.  Returns (loss[device scalar], grads dict)."""
+    eng = model.engine
+    labels = batch["labels"]
+    if t_run is None:
+        t_run = model._steps_to_run(labels)
+    pd = {k: v.detach() for k, v in model.param_dict().items()}
+    seed = model.next_seed()
+    training = model.training
+    _, ws, (d, w, b) = eng.forward(pd, batch["fc_feats"], batch["att_feats"], batch.get("att_masks"), labels, t_run,
+                                   training, seed, want_logprobs=False, masks=batch["masks"])
+    out = eng.xe_loss(ws, d, b, t_run, inv_den)
+    if grads is None:
+        grads = {k: torch.empty_like(v) for k, v in pd.items()}
+    eng.backward(ws, d, w, b, t_run, training, seed, grads)
+    eng.release(ws)
+    if return_seed:
+        return out[0], grads, seed
+    return out[0], grads
+
+
+class FlatArena(object):
+    """All parameters of a module re-homed into one flat f32 tensor (plus same-layout grad / Adam arenas)."""
+
+    def __init__(self, module, names):
+        params = dict(module.named_parameters())
+        self.names = list(names)
+        self.offsets = {}
+        off = 0
+        for k in self.names:
+            self.offsets[k] = off
+            off += (params[k].numel() + 63) // 64 * 64          # 256-byte aligned blocks
+        dev = params[self.names[0]].device
+        self.numel = off
+        self.flat = torch.zeros(off, dtype=torch.float32, device=dev)
+        self.grad = torch.zeros(off, dtype=torch.float32, device=dev)
+        self.exp_avg = torch.zeros(off, dtype=torch.float32, device=dev)
+        self.exp_avg_sq = torch.zeros(off, dtype=torch.float32, device=dev)
+        self.grad_views = {}
+        for k in self.names:
+            p = params[k]
+            o, n = self.offsets[k], p.numel()
+            view = self.flat[o:o + n].view(p.shape)
+            view.copy_(p.data)
+            p.data = view
+            self.grad_views[k] = self.grad[o:o + n].view(p.shape)
+
+
+class Trainer(object):
+    """Captioner (i2t) half of the reference Trainer: build, one train step, save."""
+
+    def __init__(self, opt, exchange=None):
+        self.opt = opt
+        self.i2t_train_flag = getattr(opt, 'i2t_train_flag', 1)
+        self.i2t_model = models.setup(opt)
+        self.dp_i2t_model = self.i2t_model
+        self.i2t_model.train(bool(self.i2t_train_flag))
+        self.i2t_train_loss = 0.0
+        self.sc_flag = False
+        self.exchange = exchange if exchange is not None else GradientExchange()
+        self.lr = getattr(opt, 'i2t_learning_rate', 4e-4)
+        self.i2t_current_lr = self.lr
+        self.betas = (getattr(opt, 'i2t_optim_alpha', 0.9), getattr(opt, 'i2t_optim_beta', 0.999))
+        self.eps = getattr(opt, 'i2t_optim_epsilon', 1e-8)
+        if getattr(opt, 'i2t_optim', 'adam') != 'adam':
+            raise NotImplementedError("only Adam is on the MI355X hot path (i2t_optim=%s)" % opt.i2t_optim)
+        if getattr(opt, 'i2t_weight_decay', 0):
+            raise NotImplementedError("i2t_weight_decay != 0 is not on the MI355X hot path")
+        self._step = 0
+        self.arena = None
+        self.last_loss = None
+
+    def build_optimizer(self):
+        self.i2t_model.cuda()
+        self.arena = FlatArena(self.i2t_model, self.i2t_model.param_names)
+        self._step = 0
+
+    def update_LearningRate(self, epoch):
+        """Optim.update_LearningRate('i2t', epoch), P/misc/optimizer.py:114-122."""
+        o = self.opt
+        start = getattr(o, 'i2t_learning_rate_decay_start', -1)
+        if epoch > start and start >= 0:
+            frac = (epoch - start) // getattr(o, 'i2t_learning_rate_decay_every', 3)
+            self.i2t_current_lr = self.lr * getattr(o, 'i2t_learning_rate_decay_rate', 0.8) ** frac
+        else:
+            self.i2t_current_lr = self.lr
+
+    def to_device(self, data):
+        """numpy batch dict of DataLoader.get_batch -> device tensors (P/trainer.py:147-149)."""
+        out = {}
+        for k in ("fc_feats", "att_feats", "labels", "masks", "att_masks"):
+            v = data.get(k)
+            if v is None:
+                continue
+            t = torch.from_numpy(np.ascontiguousarray(v)) if isinstance(v, np.ndarray) else v
+            if k == "labels":
+                t = t.long()
+            else:
+                t = t.float()
+            out[k] = t.cuda(non_blocking=True)
+        return out
+
+    def train_device_batch(self, batch, t_run, den_local):
+        """The timed hot path: everything from device-resident inputs to updated weights."""
+        if self.arena is None:
+            self.build_optimizer()
+        inv_den = self.exchange.global_inv_den(den_local, batch["fc_feats"].device)
+        loss, _ = xe_step(self.i2t_model, batch, t_run=t_run, inv_den=inv_den, grads=self.arena.grad_views)
+        self.exchange.allreduce_sum(self.arena.grad)
+        self._step += 1
+        a = self.arena
+        check(_lib.load().uic_adam_step(ptr(a.flat), ptr(a.grad), ptr(a.exp_avg), ptr(a.exp_avg_sq), a.numel,
+                                        self.i2t_current_lr, self.betas[0], self.betas[1], self.eps, self._step, 1.0,
+                                        stream()), "adam_step")
+        self.last_loss = loss
+        return loss
+
+    def train(self, data, loader=None, iteration=None, epoch=None, nmt_epoch=None):
+        """Trainer.train for the XE captioner step (P/trainer.py:141-173,193)."""
+        labels_np = np.asarray(data["labels"])
+        t_run = _steps_from_host_labels(labels_np)
+        T = labels_np.shape[1] - 1
+        den_local = float(np.asarray(data["masks"])[:, 1:T + 1].sum())
+        batch = self.to_device(data)
+        loss = self.train_device_batch(batch, t_run, den_local)
+        loss = self.exchange.allreduce_sum_scalar(loss)
+        self.i2t_train_loss = loss.item()          # the reference's per-step host sync (trainer.py:172)
+        return self.i2t_train_loss
+
+    def save_models(self, tag=''):
+        """P/trainer.py:98-104: model_i2t[-best].pth = state_dict of the un-wrapped module."""
+        path = self.opt.checkpoint_path
+        os.makedirs(path, exist_ok=True)
+        torch.save({k: v.detach().cpu().clone() for k, v in self.i2t_model.state_dict().items()},
+                   os.path.join(path, 'model_i2t' + tag + '.pth'))
