@@ -20,9 +20,20 @@ TOL = {0: 1e-4, 1: 2e-2}
 TD = {0: torch.float32, 1: torch.bfloat16}
 
 
+_KEEP = []
+
+
 def dev(t, dt=None):
+    """Device copy that stays alive until the test module is torn down (raw pointers are passed to C)."""
+    if t is None:
+        return None
     t = t.cuda()
-    return t.to(TD[dt]) if dt is not None else t
+    t = t.to(TD[dt]) if dt is not None else t
+    _KEEP.append(t)
+    if len(_KEEP) > 256:
+        torch.cuda.synchronize()
+        del _KEEP[:128]
+    return t
 
 
 def rel_err(got, ref):
