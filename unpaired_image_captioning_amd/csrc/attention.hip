@@ -18,6 +18,7 @@ namespace {
 
 constexpr int NTHREADS = 256;
 constexpr int NWAVES = 4;
+constexpr int UB = 9;   // regions a wave keeps in flight per batch (R = 36 -> one batch per wave)
 
 template <typename T>
 __global__ __launch_bounds__(NTHREADS) void attn_fwd_kernel(const UicAttnParams p) {
@@ -41,17 +42,19 @@ __global__ __launch_bounds__(NTHREADS) void attn_fwd_kernel(const UicAttnParams 
   const T* pa = (const T*)p.p_att + (size_t)n * R * A;
   const int ncA = A / VEC;
   const float b_alpha = p.b_alpha ? p.b_alpha[0] : 0.f;
-  for (int r0 = wave; r0 < R; r0 += 3 * NWAVES) {
-    float part[3] = {0.f, 0.f, 0.f};
-    for (int c = lane; c < ncA; c += 64) {
-      uint4 v[3];
+  for (int r0 = wave; r0 < R; r0 += UB * NWAVES) {
+    float part[UB];
 #pragma unroll
-      for (int u = 0; u < 3; ++u) {
+    for (int u = 0; u < UB; ++u) part[u] = 0.f;
+    for (int c = lane; c < ncA; c += 64) {
+      uint4 v[UB];
+#pragma unroll
+      for (int u = 0; u < UB; ++u) {
         const int r = r0 + u * NWAVES;
         v[u] = r < R ? *(const uint4*)(pa + (size_t)r * A + c * VEC) : make_uint4(0, 0, 0, 0);
       }
 #pragma unroll
-      for (int u = 0; u < 3; ++u) {
+      for (int u = 0; u < UB; ++u) {
         float f[VEC];
         uic_unpack<T>(v[u], f);
 #pragma unroll
@@ -59,7 +62,7 @@ __global__ __launch_bounds__(NTHREADS) void attn_fwd_kernel(const UicAttnParams 
       }
     }
 #pragma unroll
-    for (int u = 0; u < 3; ++u) {
+    for (int u = 0; u < UB; ++u) {
       const int r = r0 + u * NWAVES;
       const float s = uic_wave_sum(part[u]);
       if (lane == 0 && r < R) s_e[r] = s + b_alpha;
@@ -95,14 +98,22 @@ __global__ __launch_bounds__(NTHREADS) void attn_fwd_kernel(const UicAttnParams 
     float acc[VEC];
 #pragma unroll
     for (int j = 0; j < VEC; ++j) acc[j] = 0.f;
-#pragma unroll 3
-    for (int r = wave; r < R; r += NWAVES) {
-      const uint4 v = *(const uint4*)(pt + (size_t)r * H + c * VEC);
-      float f[VEC];
-      uic_unpack<T>(v, f);
-      const float al = s_e[r];
+    for (int r0 = wave; r0 < R; r0 += UB * NWAVES) {
+      uint4 v[UB];
 #pragma unroll
-      for (int j = 0; j < VEC; ++j) acc[j] += al * f[j];
+      for (int u = 0; u < UB; ++u) {
+        const int r = r0 + u * NWAVES;
+        v[u] = r < R ? *(const uint4*)(pt + (size_t)r * H + c * VEC) : make_uint4(0, 0, 0, 0);
+      }
+#pragma unroll
+      for (int u = 0; u < UB; ++u) {
+        const int r = r0 + u * NWAVES;
+        float f[VEC];
+        uic_unpack<T>(v[u], f);
+        const float al = r < R ? s_e[r] : 0.f;
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) acc[j] += al * f[j];
+      }
     }
 #pragma unroll
     for (int j = 0; j < VEC; ++j) s_red[wave * H + c * VEC + j] = acc[j];
@@ -139,17 +150,19 @@ __global__ __launch_bounds__(NTHREADS) void attn_bwd_step_kernel(const UicAttnPa
   // d alpha_r = dctx . att[r]
   const T* pt = (const T*)p.att + (size_t)n * R * H;
   const int ncH = H / VEC;
-  for (int r0 = wave; r0 < R; r0 += 3 * NWAVES) {
-    float part[3] = {0.f, 0.f, 0.f};
-    for (int c = lane; c < ncH; c += 64) {
-      uint4 v[3];
+  for (int r0 = wave; r0 < R; r0 += UB * NWAVES) {
+    float part[UB];
 #pragma unroll
-      for (int u = 0; u < 3; ++u) {
+    for (int u = 0; u < UB; ++u) part[u] = 0.f;
+    for (int c = lane; c < ncH; c += 64) {
+      uint4 v[UB];
+#pragma unroll
+      for (int u = 0; u < UB; ++u) {
         const int r = r0 + u * NWAVES;
         v[u] = r < R ? *(const uint4*)(pt + (size_t)r * H + c * VEC) : make_uint4(0, 0, 0, 0);
       }
 #pragma unroll
-      for (int u = 0; u < 3; ++u) {
+      for (int u = 0; u < UB; ++u) {
         float f[VEC];
         uic_unpack<T>(v[u], f);
 #pragma unroll
@@ -157,7 +170,7 @@ __global__ __launch_bounds__(NTHREADS) void attn_bwd_step_kernel(const UicAttnPa
       }
     }
 #pragma unroll
-    for (int u = 0; u < 3; ++u) {
+    for (int u = 0; u < UB; ++u) {
       const int r = r0 + u * NWAVES;
       const float s = uic_wave_sum(part[u]);
       if (lane == 0 && r < R) s_da[r] = s;
@@ -181,16 +194,24 @@ __global__ __launch_bounds__(NTHREADS) void attn_bwd_step_kernel(const UicAttnPa
     float acc[VEC];
 #pragma unroll
     for (int j = 0; j < VEC; ++j) acc[j] = 0.f;
-#pragma unroll 3
-    for (int r = wave; r < R; r += NWAVES) {
-      const uint4 v = *(const uint4*)(pa + (size_t)r * A + c * VEC);
-      float f[VEC];
-      uic_unpack<T>(v, f);
-      const float de = s_da[r];
+    for (int r0 = wave; r0 < R; r0 += UB * NWAVES) {
+      uint4 v[UB];
 #pragma unroll
-      for (int j = 0; j < VEC; ++j) {
-        const float th = uic_tanh<T>(f[j] + s_atth[c * VEC + j]);
-        acc[j] += de * (1.f - th * th);
+      for (int u = 0; u < UB; ++u) {
+        const int r = r0 + u * NWAVES;
+        v[u] = r < R ? *(const uint4*)(pa + (size_t)r * A + c * VEC) : make_uint4(0, 0, 0, 0);
+      }
+#pragma unroll
+      for (int u = 0; u < UB; ++u) {
+        const int r = r0 + u * NWAVES;
+        float f[VEC];
+        uic_unpack<T>(v[u], f);
+        const float de = r < R ? s_da[r] : 0.f;
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) {
+          const float th = uic_tanh<T>(f[j] + s_atth[c * VEC + j]);
+          acc[j] += de * (1.f - th * th);
+        }
       }
     }
 #pragma unroll
@@ -202,8 +223,175 @@ __global__ __launch_bounds__(NTHREADS) void attn_bwd_step_kernel(const UicAttnPa
     out[a] = uic_from_f<T>(s_red[a] + s_red[A + a] + s_red[2 * A + a] + s_red[3 * A + a]);
 }
 
+
+// ---------------------------------------------------------------------------------------------------
+// Fast path (R <= UB * NWAVES regions, A and H at most 64 16-byte chunks: the BASELINE shapes in bf16).
+// Every lane issues ALL of its p_att and att loads (2 x UB x 16 B) before the first use, so a
+// workgroup exposes one memory latency instead of one per phase, and the only LDS traffic is the
+// R scores and the 4-wave reduction of the context vector.
 template <typename T>
-__global__ __launch_bounds__(NTHREADS) void attn_bwd_accum_kernel(const UicAttnAccumParams p) {
+__device__ __forceinline__ void load_chunk_f32(const float* src, int c, bool ok, float* out) {
+  constexpr int VEC = uic_vec<T>::N;
+#pragma unroll
+  for (int q = 0; q < VEC / 4; ++q) {
+    float4 v = ok ? *(const float4*)(src + c * VEC + q * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+    out[q * 4 + 0] = v.x; out[q * 4 + 1] = v.y; out[q * 4 + 2] = v.z; out[q * 4 + 3] = v.w;
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(NTHREADS) void attn_fwd_fast_kernel(const UicAttnParams p) {
+  constexpr int VEC = uic_vec<T>::N;
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  const int A = p.A, H = p.H, R = p.R;
+  float* s_e = sm;
+  float* s_red = s_e + ((R + 3) & ~3);
+  const int n = blockIdx.x;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const bool la = lane < A / VEC, lh = lane < H / VEC;
+  const T* pa = (const T*)p.p_att + (size_t)n * R * A + lane * VEC;
+  const T* pt = (const T*)p.att + (size_t)n * R * H + lane * VEC;
+  uint4 vp[UB], va[UB];
+#pragma unroll
+  for (int u = 0; u < UB; ++u) {
+    const int r = wave + u * NWAVES;
+    vp[u] = (r < R && la) ? *(const uint4*)(pa + (size_t)r * A) : make_uint4(0, 0, 0, 0);
+  }
+#pragma unroll
+  for (int u = 0; u < UB; ++u) {
+    const int r = wave + u * NWAVES;
+    va[u] = (r < R && lh) ? *(const uint4*)(pt + (size_t)r * H) : make_uint4(0, 0, 0, 0);
+  }
+  float ah[VEC], w[VEC];
+  load_chunk_f32<T>(p.att_h + (size_t)n * A, lane, la, ah);
+  load_chunk_f32<T>(p.w_alpha, lane, la, w);
+  const float b_alpha = p.b_alpha ? p.b_alpha[0] : 0.f;
+#pragma unroll
+  for (int u = 0; u < UB; ++u) {
+    const int r = wave + u * NWAVES;
+    float f[VEC];
+    uic_unpack<T>(vp[u], f);
+    float part = 0.f;
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) part += w[j] * uic_tanh<T>(f[j] + ah[j]);
+    part = uic_wave_sum(part);
+    if (lane == 0 && r < R) s_e[r] = part + b_alpha;
+  }
+  __syncthreads();
+  // every wave normalises the R <= 64 scores with one lane per region (softmax, then mask-renormalise)
+  const float* mk = p.mask ? p.mask + (size_t)n * p.ldmask : nullptr;
+  const float e = lane < R ? s_e[lane] : -INFINITY;
+  const float mx = uic_wave_max(e);
+  const float ex = lane < R ? expf(e - mx) : 0.f;
+  float wgt = ex * (1.f / uic_wave_sum(ex));
+  if (mk) {
+    wgt *= lane < R ? mk[lane] : 0.f;
+    wgt = wgt / uic_wave_sum(wgt);
+  }
+  if (wave == 0 && lane < R) p.alpha[(size_t)n * R + lane] = wgt;
+  float acc[VEC];
+#pragma unroll
+  for (int j = 0; j < VEC; ++j) acc[j] = 0.f;
+#pragma unroll
+  for (int u = 0; u < UB; ++u) {
+    const int r = wave + u * NWAVES;
+    float al = __shfl(wgt, r < R ? r : 0, 64);
+    if (r >= R) al = 0.f;
+    float f[VEC];
+    uic_unpack<T>(va[u], f);
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) acc[j] += al * f[j];
+  }
+  if (lh) {
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) s_red[wave * H + lane * VEC + j] = acc[j];
+  }
+  __syncthreads();
+  T* ctx = (T*)p.ctx + (size_t)n * p.ldctx;
+  for (int h = tid; h < H; h += NTHREADS)
+    ctx[h] = uic_from_f<T>(s_red[h] + s_red[H + h] + s_red[2 * H + h] + s_red[3 * H + h]);
+}
+
+template <typename T>
+__global__ __launch_bounds__(NTHREADS) void attn_bwd_step_fast_kernel(const UicAttnParams p) {
+  constexpr int VEC = uic_vec<T>::N;
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  const int A = p.A, H = p.H, R = p.R;
+  const int Rp = (R + 3) & ~3;
+  float* s_al = sm;
+  float* s_da = s_al + Rp;
+  float* s_red = s_da + Rp;
+  const int n = blockIdx.x;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const bool la = lane < A / VEC, lh = lane < H / VEC;
+  const T* pa = (const T*)p.p_att + (size_t)n * R * A + lane * VEC;
+  const T* pt = (const T*)p.att + (size_t)n * R * H + lane * VEC;
+  uint4 vp[UB], va[UB];
+#pragma unroll
+  for (int u = 0; u < UB; ++u) {
+    const int r = wave + u * NWAVES;
+    va[u] = (r < R && lh) ? *(const uint4*)(pt + (size_t)r * H) : make_uint4(0, 0, 0, 0);
+  }
+#pragma unroll
+  for (int u = 0; u < UB; ++u) {
+    const int r = wave + u * NWAVES;
+    vp[u] = (r < R && la) ? *(const uint4*)(pa + (size_t)r * A) : make_uint4(0, 0, 0, 0);
+  }
+  float ah[VEC], w[VEC], dc[VEC];
+  load_chunk_f32<T>(p.att_h + (size_t)n * A, lane, la, ah);
+  load_chunk_f32<T>(p.w_alpha, lane, la, w);
+  load_chunk_f32<T>(p.dctx + (size_t)n * p.lddctx, lane, lh, dc);
+  for (int r = tid; r < R; r += NTHREADS) s_al[r] = p.alpha[(size_t)n * R + r];
+#pragma unroll
+  for (int u = 0; u < UB; ++u) {
+    const int r = wave + u * NWAVES;
+    float f[VEC];
+    uic_unpack<T>(va[u], f);
+    float part = 0.f;
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) part += dc[j] * f[j];
+    part = uic_wave_sum(part);
+    if (lane == 0 && r < R) s_da[r] = part;
+  }
+  __syncthreads();
+  float wbar = 0.f;
+  for (int r = 0; r < R; ++r) wbar += s_al[r] * s_da[r];
+  float acc[VEC];
+#pragma unroll
+  for (int j = 0; j < VEC; ++j) acc[j] = 0.f;
+#pragma unroll
+  for (int u = 0; u < UB; ++u) {
+    const int r = wave + u * NWAVES;
+    float de = 0.f;
+    if (r < R) {
+      de = s_al[r] * (s_da[r] - wbar);
+      if (lane == 0) p.de[(size_t)n * R + r] = de;
+    }
+    float f[VEC];
+    uic_unpack<T>(vp[u], f);
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) {
+      const float th = uic_tanh<T>(f[j] + ah[j]);
+      acc[j] += de * (1.f - th * th);
+    }
+  }
+  if (la) {
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) s_red[wave * A + lane * VEC + j] = acc[j] * w[j];
+  }
+  __syncthreads();
+  T* out = (T*)p.d_att_h + (size_t)n * A;
+  for (int a = tid; a < A; a += NTHREADS)
+    out[a] = uic_from_f<T>(s_red[a] + s_red[A + a] + s_red[2 * A + a] + s_red[3 * A + a]);
+}
+
+inline bool fast_ok(const UicAttnParams& p) {
+  const int vec = p.dtype == UIC_BF16 ? 8 : 4;
+  return p.R <= UB * NWAVES && p.A / vec <= 64 && p.H / vec <= 64 && (p.lddctx % 4 == 0);
+}
+
+template <typename T>
+__global__ __launch_bounds__(1024) void attn_bwd_accum_kernel(const UicAttnAccumParams p) {
   constexpr int VEC = uic_vec<T>::N;
   extern __shared__ __attribute__((aligned(16))) float sm[];
   const int A = p.A, H = p.H, R = p.R, TS = p.T, N = p.N;
@@ -213,30 +401,31 @@ __global__ __launch_bounds__(NTHREADS) void attn_bwd_accum_kernel(const UicAttnA
   float* s_al = s_dctx + TS * H;      // [TS][Rp]
   float* s_de = s_al + TS * Rp;       // [TS][Rp]
   float* s_w = s_de + TS * Rp;        // [A]
-  float* s_red = s_w + A;             // [NWAVES][A]
+  float* s_red = s_w + A;             // [nw][A]
+  const int nthreads = blockDim.x, nw = blockDim.x >> 6;
   const int n = blockIdx.x;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
 
-  for (int i = tid; i < TS * A; i += NTHREADS) {
+  for (int i = tid; i < TS * A; i += nthreads) {
     const int t = i / A, a = i - t * A;
     s_atth[i] = p.att_h_all[((size_t)t * N + n) * A + a];
   }
-  for (int i = tid; i < TS * H; i += NTHREADS) {
+  for (int i = tid; i < TS * H; i += nthreads) {
     const int t = i / H, h = i - t * H;
     s_dctx[i] = p.dctx_all[(size_t)t * p.dctx_step_stride + (size_t)n * p.lddctx + h];
   }
-  for (int i = tid; i < TS * R; i += NTHREADS) {
+  for (int i = tid; i < TS * R; i += nthreads) {
     const int t = i / R, r = i - t * R;
     s_al[t * Rp + r] = p.alpha_all[((size_t)t * N + n) * R + r];
     s_de[t * Rp + r] = p.de_all[((size_t)t * N + n) * R + r];
   }
-  for (int a = tid; a < A; a += NTHREADS) s_w[a] = p.w_alpha[a];
+  for (int a = tid; a < A; a += nthreads) s_w[a] = p.w_alpha[a];
   __syncthreads();
 
   // d att'[n,r,:] = sum_t alpha_t[r] dctx_t   (backward of the bmm, AttModel.py:555-556)
   float* dat = p.d_att + (size_t)n * R * H;
   const int nc4 = H / 4;
-  for (int r = wave; r < R; r += NWAVES) {
+  for (int r = wave; r < R; r += nw) {
     for (int c = lane; c < nc4; c += 64) {
       float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
       for (int t = 0; t < TS; ++t) {
@@ -256,7 +445,7 @@ __global__ __launch_bounds__(NTHREADS) void attn_bwd_accum_kernel(const UicAttnA
     float dwacc[VEC];
 #pragma unroll
     for (int j = 0; j < VEC; ++j) dwacc[j] = 0.f;
-    for (int r = wave; r < R; r += NWAVES) {
+    for (int r = wave; r < R; r += nw) {
       const uint4 v = *(const uint4*)(pa + (size_t)r * A + c * VEC);
       float f[VEC], acc[VEC];
       uic_unpack<T>(v, f);
@@ -280,7 +469,11 @@ __global__ __launch_bounds__(NTHREADS) void attn_bwd_accum_kernel(const UicAttnA
   }
   __syncthreads();
   float* part = p.d_walpha_part + (size_t)n * (A + 1);
-  for (int a = tid; a < A; a += NTHREADS) part[a] = s_red[a] + s_red[A + a] + s_red[2 * A + a] + s_red[3 * A + a];
+  for (int a = tid; a < A; a += nthreads) {
+    float sacc = 0.f;
+    for (int wv = 0; wv < nw; ++wv) sacc += s_red[wv * A + a];
+    part[a] = sacc;
+  }
   if (tid == 0) {
     float s = 0.f;
     for (int t = 0; t < TS; ++t)
@@ -305,7 +498,12 @@ int uic_attention_fwd_launch(const UicAttnParams& p, hipStream_t s) {
   if (p.N == 0) return UIC_OK;
   const size_t lds = sizeof(float) * (2 * (size_t)p.A + ((p.R + 3) & ~3) + NWAVES * (size_t)p.H);
   UIC_REQUIRE(lds <= 160 * 1024, "attention_fwd: needs %zu B of LDS", lds);
-  if (p.dtype == UIC_BF16)
+  if (fast_ok(p)) {
+    if (p.dtype == UIC_BF16)
+      hipLaunchKernelGGL(attn_fwd_fast_kernel<bf16_t>, dim3(p.N), dim3(NTHREADS), lds, s, p);
+    else
+      hipLaunchKernelGGL(attn_fwd_fast_kernel<float>, dim3(p.N), dim3(NTHREADS), lds, s, p);
+  } else if (p.dtype == UIC_BF16)
     hipLaunchKernelGGL(attn_fwd_kernel<bf16_t>, dim3(p.N), dim3(NTHREADS), lds, s, p);
   else
     hipLaunchKernelGGL(attn_fwd_kernel<float>, dim3(p.N), dim3(NTHREADS), lds, s, p);
@@ -320,7 +518,12 @@ int uic_attention_bwd_step_launch(const UicAttnParams& p, hipStream_t s) {
   if (p.N == 0) return UIC_OK;
   const size_t lds = sizeof(float) * (2 * (size_t)p.A + p.H + 2 * ((p.R + 3) & ~3) + NWAVES * (size_t)p.A);
   UIC_REQUIRE(lds <= 160 * 1024, "attention_bwd_step: needs %zu B of LDS", lds);
-  if (p.dtype == UIC_BF16)
+  if (fast_ok(p)) {
+    if (p.dtype == UIC_BF16)
+      hipLaunchKernelGGL(attn_bwd_step_fast_kernel<bf16_t>, dim3(p.N), dim3(NTHREADS), lds, s, p);
+    else
+      hipLaunchKernelGGL(attn_bwd_step_fast_kernel<float>, dim3(p.N), dim3(NTHREADS), lds, s, p);
+  } else if (p.dtype == UIC_BF16)
     hipLaunchKernelGGL(attn_bwd_step_kernel<bf16_t>, dim3(p.N), dim3(NTHREADS), lds, s, p);
   else
     hipLaunchKernelGGL(attn_bwd_step_kernel<float>, dim3(p.N), dim3(NTHREADS), lds, s, p);
@@ -335,14 +538,19 @@ int uic_attention_bwd_accum_launch(const UicAttnAccumParams& p, hipStream_t s) {
                   p.d_walpha_part, "attention_bwd_accum: null pointer");
   if (p.N == 0) return UIC_OK;
   const int Rp = (p.R + 3) & ~3;
-  const size_t lds = sizeof(float) * ((size_t)p.T * (p.A + p.H + 2 * Rp) + p.A + NWAVES * (size_t)p.A);
+  int nthreads = 1024;   // 16 waves share one row's staged [T, A + H + 2R] block; fewer if LDS is short
+  size_t lds = 0;
+  for (;; nthreads >>= 1) {
+    lds = sizeof(float) * ((size_t)p.T * (p.A + p.H + 2 * Rp) + p.A + (nthreads / 64) * (size_t)p.A);
+    if (lds <= 160 * 1024 || nthreads == 64) break;
+  }
   UIC_REQUIRE(lds <= 160 * 1024, "attention_bwd_accum: needs %zu B of LDS (T=%d)", lds, p.T);
   if (p.dtype == UIC_BF16) {
     if (lds > 64 * 1024) UIC_TRY(uic_check_hip(hipFuncSetAttribute((const void*)attn_bwd_accum_kernel<bf16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds), "hipFuncSetAttribute"));
-    hipLaunchKernelGGL(attn_bwd_accum_kernel<bf16_t>, dim3(p.N), dim3(NTHREADS), lds, s, p);
+    hipLaunchKernelGGL(attn_bwd_accum_kernel<bf16_t>, dim3(p.N), dim3(nthreads), lds, s, p);
   } else {
     if (lds > 64 * 1024) UIC_TRY(uic_check_hip(hipFuncSetAttribute((const void*)attn_bwd_accum_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds), "hipFuncSetAttribute"));
-    hipLaunchKernelGGL(attn_bwd_accum_kernel<float>, dim3(p.N), dim3(NTHREADS), lds, s, p);
+    hipLaunchKernelGGL(attn_bwd_accum_kernel<float>, dim3(p.N), dim3(nthreads), lds, s, p);
   }
   UIC_LAUNCH_CHECK("attn_bwd_accum_kernel");
   return UIC_OK;

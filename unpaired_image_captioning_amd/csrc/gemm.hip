@@ -17,36 +17,56 @@
 //    32x32 accumulators with identical lane layout, so the cell update
 //    c' = s(f) c + s(i) tanh(g), h' = s(o) tanh(c') runs in the epilogue on registers.
 #include "uic_common.h"
+#include <type_traits>
 
 namespace {
 
 constexpr int LDS_STRIDE = 144;   // 128-B K slice + 16-B pad
 
-template <typename T, int TM, int TN, int WM, int WN, bool LSTM>
-__global__ __launch_bounds__(64 * WM * WN) void uic_gemm_kernel(const UicGemmParams p) {
-  constexpr int NT = 64 * WM * WN;
+// KS > 1: KS groups of WM x WN waves each take one 128-byte K slice of a (KS * 128)-byte K step for the
+// SAME output tile and are summed through LDS at the end.  The skinny per-decode-step GEMMs (M = 640)
+// are latency chains of K/BK dependent load->LDS->MFMA rounds; KS = 4 makes the chain 4x shorter and
+// puts 4x the bytes in flight per round.
+template <typename T, int TM, int TN, int WM, int WN, int KS, bool LSTM>
+__global__ __launch_bounds__(64 * WM * WN * KS) void uic_gemm_kernel(const UicGemmParams p) {
+  constexpr int NT = 64 * WM * WN * KS;
   constexpr int BM = 32 * TM * WM;
   constexpr int BN = 32 * TN * WN;
   constexpr int VEC = 16 / (int)sizeof(T);
-  constexpr int BK = 128 / (int)sizeof(T);
-  constexpr int A_CH = BM * 8 / NT;
-  constexpr int B_CH = BN * 8 / NT;
-  static_assert(BM * 8 % NT == 0 && BN * 8 % NT == 0, "tile/threads mismatch");
+  constexpr int BK = KS * 128 / (int)sizeof(T);   // K elements per round
+  constexpr int CPR = 8 * KS;                      // 16-byte chunks per tile row per round
+  constexpr int A_CH = BM * CPR / NT;
+  constexpr int B_CH = BN * CPR / NT;
+  static_assert(BM * CPR % NT == 0 && BN * CPR % NT == 0, "tile/threads mismatch");
   static_assert(!LSTM || TN == 4, "LSTM mode keeps the 4 gates in the 4 N tiles of a wave");
 
-  __shared__ __attribute__((aligned(16))) char smem[(BM + BN) * LDS_STRIDE];
+  extern __shared__ __attribute__((aligned(16))) char smem[];
   char* sA = smem;
-  char* sB = smem + BM * LDS_STRIDE;
+  char* sB = smem + KS * BM * LDS_STRIDE;
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = tid >> 6;
-  const int wm = wave / WN;
-  const int wn = wave % WN;
+  const int ks_id = wave / (WM * WN);
+  const int wmn = wave % (WM * WN);
+  const int wm = wmn / WN;
+  const int wn = wmn % WN;
   const int half = lane >> 5;
   const int r32 = lane & 31;
-  const int m0 = blockIdx.x * BM;
-  const int n0 = blockIdx.y * (LSTM ? 32 * WN : BN);   // LSTM: first hidden unit of the block
+  // XCD-aware tile order: workgroups are dealt round-robin over the 8 XCDs (each with a private 4 MB L2), so
+  // give every XCD a contiguous run of tiles, M fastest: the tiles of one XCD share a few B (weight) tiles and
+  // walk A once, which keeps the re-reads of both operands inside that XCD's L2.  (bijective for any grid)
+  int bm, bn;
+  {
+    const int gx = gridDim.x, nblk = gx * gridDim.y;
+    const int lin = blockIdx.x + gx * blockIdx.y;
+    const int q = nblk >> 3, r = nblk & 7, xcd = lin & 7, idx = lin >> 3;
+    const int lp = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    bm = lp % gx;
+    bn = lp / gx;
+  }
+  const int m0 = bm * BM;
+  const int n0 = bn * (LSTM ? 32 * WN : BN);   // LSTM: first hidden unit of the block
 
   f32x16 acc[TM][TN];
 #pragma unroll
@@ -69,8 +89,8 @@ __global__ __launch_bounds__(64 * WM * WN) void uic_gemm_kernel(const UicGemmPar
 #pragma unroll
     for (int i = 0; i < A_CH; ++i) {
       const int c = tid + i * NT;
-      const int row = c >> 3;
-      const int k = k0 + (c & 7) * VEC;
+      const int row = c / CPR;
+      const int k = k0 + (c % CPR) * VEC;
       const int gm = m0 + row;
       uint4 v = make_uint4(0, 0, 0, 0);
       if (gm < p.M && k < sg.K) v = *(const uint4*)(Ab + ((size_t)gm * sg.lda + k) * sizeof(T));
@@ -79,8 +99,8 @@ __global__ __launch_bounds__(64 * WM * WN) void uic_gemm_kernel(const UicGemmPar
 #pragma unroll
     for (int i = 0; i < B_CH; ++i) {
       const int c = tid + i * NT;
-      const int row = c >> 3;
-      const int k = k0 + (c & 7) * VEC;
+      const int row = c / CPR;
+      const int k = k0 + (c % CPR) * VEC;
       int grow;
       bool ok;
       if (LSTM) {
@@ -100,12 +120,14 @@ __global__ __launch_bounds__(64 * WM * WN) void uic_gemm_kernel(const UicGemmPar
 #pragma unroll
     for (int i = 0; i < A_CH; ++i) {
       const int c = tid + i * NT;
-      *(uint4*)(sA + (c >> 3) * LDS_STRIDE + (c & 7) * 16) = ra[i];
+      const int kc = c % CPR;
+      *(uint4*)(sA + ((kc >> 3) * BM + c / CPR) * LDS_STRIDE + (kc & 7) * 16) = ra[i];
     }
 #pragma unroll
     for (int i = 0; i < B_CH; ++i) {
       const int c = tid + i * NT;
-      *(uint4*)(sB + (c >> 3) * LDS_STRIDE + (c & 7) * 16) = rb[i];
+      const int kc = c % CPR;
+      *(uint4*)(sB + ((kc >> 3) * BN + c / CPR) * LDS_STRIDE + (kc & 7) * 16) = rb[i];
     }
   };
 
@@ -118,8 +140,8 @@ __global__ __launch_bounds__(64 * WM * WN) void uic_gemm_kernel(const UicGemmPar
       if (k0 >= p.seg[seg].K) { ++seg; k0 = 0; }
       load_tile();
     }
-    const char* pa = sA + (wm * 32 * TM + r32) * LDS_STRIDE + half * 64;
-    const char* pb = sB + (wn * 32 * TN + r32) * LDS_STRIDE + half * 64;
+    const char* pa = sA + (ks_id * BM + wm * 32 * TM + r32) * LDS_STRIDE + half * 64;
+    const char* pb = sB + (ks_id * BN + wn * 32 * TN + r32) * LDS_STRIDE + half * 64;
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
       uint4 fa[TM], fb[TN];
@@ -145,113 +167,168 @@ __global__ __launch_bounds__(64 * WM * WN) void uic_gemm_kernel(const UicGemmPar
     __syncthreads();
   }
 
+  // ---- reduce-scatter over the KS wave groups: group q ends up with the complete sums of accumulator
+  // registers [q*RPG, (q+1)*RPG) of every tile (= 8-row bands of the output), so ALL waves share the epilogue.
+  constexpr int RPG = 16 / KS;
+  if constexpr (KS > 1) {
+    float* red = (float*)smem;    // [dst group][src slot][wmn][tile][RPG][64]; staging buffers are free now
+    constexpr int TILE = TM * TN;
+#pragma unroll
+    for (int q = 0; q < KS; ++q) {
+      if (q != ks_id) {
+        const int slot = ks_id < q ? ks_id : ks_id - 1;
+        float* dst = red + (size_t)(((q * (KS - 1) + slot) * WM * WN + wmn) * TILE) * RPG * 64 + lane;
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int rr = 0; rr < RPG; ++rr) dst[((i * TN + j) * RPG + rr) * 64] = acc[i][j][q * RPG + rr];
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < KS; ++q) {
+      if (q == ks_id) {
+#pragma unroll
+        for (int slot = 0; slot < KS - 1; ++slot) {
+          const float* src = red + (size_t)(((q * (KS - 1) + slot) * WM * WN + wmn) * TILE) * RPG * 64 + lane;
+#pragma unroll
+          for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+              for (int rr = 0; rr < RPG; ++rr) acc[i][j][q * RPG + rr] += src[((i * TN + j) * RPG + rr) * 64];
+        }
+      }
+    }
+  }
+
   // ------------------------------------------------------------------ epilogue
   // C/D layout of the 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
   const float inv_keep = p.drop_p > 0.f ? 1.f / (1.f - p.drop_p) : 1.f;
-  if constexpr (!LSTM) {
-    const bool out_f32 = (p.flags & UIC_GEMM_OUT_F32) || sizeof(T) == 4;
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-      for (int j = 0; j < TN; ++j) {
-        const int col = n0 + (wn * TN + j) * 32 + r32;
-        if (col >= p.N) continue;
-        float b = 0.f;
-        if (p.bias) b += p.bias[col];
-        if (p.bias2) b += p.bias2[col];
-#pragma unroll
-        for (int reg = 0; reg < 16; ++reg) {
-          const int row = m0 + (wm * TM + i) * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * half;
-          if (row >= p.M) continue;
-          float v = acc[i][j][reg] + b;
-          if (p.flags & UIC_GEMM_RELU) v = fmaxf(v, 0.f);
-          if (p.row_len) {
-            const int n = row / p.R;
-            if (row - n * p.R >= p.row_len[n]) v = 0.f;
-          }
-          if (p.drop_p > 0.f) v *= uic_drop_scale(p.seed, p.site, (unsigned)row * (unsigned)p.N + (unsigned)col, p.drop_p, inv_keep);
-          const size_t o = (size_t)row * p.ldc + col;
-          if (out_f32) {
-            float* C = (float*)p.C;
-            if (p.flags & UIC_GEMM_ACCUM) v += C[o];
-            C[o] = v;
-          } else {
-            T* C = (T*)p.C;
-            if (p.flags & UIC_GEMM_ACCUM) v += uic_to_f(C[o]);
-            C[o] = uic_from_f<T>(v);
-          }
-        }
-      }
-  } else {
-    const int H = p.H;
-    const int u = n0 + wn * 32 + r32;
-    if (u < H) {
-      float bg[4] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        if (p.bias) bg[g] += p.bias[g * H + u];
-        if (p.bias2) bg[g] += p.bias2[g * H + u];
-      }
+  auto epilogue = [&](auto r0c) {
+    constexpr int R0 = decltype(r0c)::value;
+    if constexpr (!LSTM) {
+      const bool out_f32 = (p.flags & UIC_GEMM_OUT_F32) || sizeof(T) == 4;
 #pragma unroll
       for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int reg = 0; reg < 16; ++reg) {
-          const int row = m0 + (wm * TM + i) * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * half;
-          if (row >= p.M) continue;
-          float g4[4];
+        for (int j = 0; j < TN; ++j) {
+          const int col = n0 + (wn * TN + j) * 32 + r32;
+          if (col >= p.N) continue;
+          float b = 0.f;
+          if (p.bias) b += p.bias[col];
+          if (p.bias2) b += p.bias2[col];
 #pragma unroll
-          for (int g = 0; g < 4; ++g) {
-            float v = acc[i][g][reg] + bg[g];
-            if (p.pre1) v += p.pre1[(size_t)row * p.ldpre1 + g * H + u];
-            if (p.pre2) v += p.pre2[(size_t)row * p.ldpre2 + g * H + u];
-            g4[g] = v;
-          }
-          const float gi = uic_sigmoid(g4[0]);
-          const float gf = uic_sigmoid(g4[1]);
-          const float gg = tanhf(g4[2]);
-          const float go = uic_sigmoid(g4[3]);
-          const float cp = p.c_prev ? p.c_prev[(size_t)row * H + u] : 0.f;
-          const float c = gf * cp + gi * gg;
-          const float h = go * tanhf(c);
-          p.c_out[(size_t)row * H + u] = c;
-          ((T*)p.h_out)[(size_t)row * p.ldh + u] = uic_from_f<T>(h);
-          if (p.h_drop) {
-            float hd = h;
-            if (p.drop_p > 0.f) hd *= uic_drop_scale(p.seed, p.site, (unsigned)row * (unsigned)H + (unsigned)u, p.drop_p, inv_keep);
-            ((T*)p.h_drop)[(size_t)row * p.ldhd + u] = uic_from_f<T>(hd);
-          }
-          if (p.gates_out) {
-            T* G = (T*)p.gates_out + (size_t)row * 4 * H + u;
-            G[0] = uic_from_f<T>(gi);
-            G[H] = uic_from_f<T>(gf);
-            G[2 * H] = uic_from_f<T>(gg);
-            G[3 * H] = uic_from_f<T>(go);
+          for (int reg = R0; reg < R0 + RPG; ++reg) {
+            const int row = m0 + (wm * TM + i) * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * half;
+            if (row >= p.M) continue;
+            float v = acc[i][j][reg] + b;
+            if (p.flags & UIC_GEMM_RELU) v = fmaxf(v, 0.f);
+            if (p.row_len) {
+              const int n = row / p.R;
+              if (row - n * p.R >= p.row_len[n]) v = 0.f;
+            }
+            if (p.drop_p > 0.f) v *= uic_drop_scale(p.seed, p.site, (unsigned)row * (unsigned)p.N + (unsigned)col, p.drop_p, inv_keep);
+            const size_t o = (size_t)row * p.ldc + col;
+            if (out_f32) {
+              float* C = (float*)p.C;
+              if (p.flags & UIC_GEMM_ACCUM) v += C[o];
+              C[o] = v;
+            } else {
+              T* C = (T*)p.C;
+              if (p.flags & UIC_GEMM_ACCUM) v += uic_to_f(C[o]);
+              C[o] = uic_from_f<T>(v);
+            }
           }
         }
+    } else {
+      const int H = p.H;
+      const int u = n0 + wn * 32 + r32;
+      if (u < H) {
+        float bg[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          if (p.bias) bg[g] += p.bias[g * H + u];
+          if (p.bias2) bg[g] += p.bias2[g * H + u];
+        }
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int reg = R0; reg < R0 + RPG; ++reg) {
+            const int row = m0 + (wm * TM + i) * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * half;
+            if (row >= p.M) continue;
+            float g4[4];
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+              float v = acc[i][g][reg] + bg[g];
+              if (p.pre1) v += p.pre1[(size_t)row * p.ldpre1 + g * H + u];
+              if (p.pre2) v += p.pre2[(size_t)row * p.ldpre2 + g * H + u];
+              g4[g] = v;
+            }
+            const float gi = uic_sigmoid_t<T>(g4[0]);
+            const float gf = uic_sigmoid_t<T>(g4[1]);
+            const float gg = uic_tanh<T>(g4[2]);
+            const float go = uic_sigmoid_t<T>(g4[3]);
+            const float cp = p.c_prev ? p.c_prev[(size_t)row * H + u] : 0.f;
+            const float c = gf * cp + gi * gg;
+            const float h = go * uic_tanh<T>(c);
+            p.c_out[(size_t)row * H + u] = c;
+            ((T*)p.h_out)[(size_t)row * p.ldh + u] = uic_from_f<T>(h);
+            if (p.h_drop) {
+              float hd = h;
+              if (p.drop_p > 0.f) hd *= uic_drop_scale(p.seed, p.site, (unsigned)row * (unsigned)H + (unsigned)u, p.drop_p, inv_keep);
+              ((T*)p.h_drop)[(size_t)row * p.ldhd + u] = uic_from_f<T>(hd);
+            }
+            if (p.gates_out) {
+              T* G = (T*)p.gates_out + (size_t)row * 4 * H + u;
+              G[0] = uic_from_f<T>(gi);
+              G[H] = uic_from_f<T>(gf);
+              G[2 * H] = uic_from_f<T>(gg);
+              G[3 * H] = uic_from_f<T>(go);
+            }
+          }
+      }
     }
+  };
+  if constexpr (KS == 1) {
+    epilogue(std::integral_constant<int, 0>{});
+  } else {
+    static_assert(KS == 4, "epilogue dispatch is written for KS = 4");
+    if (ks_id == 0) epilogue(std::integral_constant<int, 0>{});
+    else if (ks_id == 1) epilogue(std::integral_constant<int, RPG>{});
+    else if (ks_id == 2) epilogue(std::integral_constant<int, 2 * RPG>{});
+    else epilogue(std::integral_constant<int, 3 * RPG>{});
   }
 }
 
-template <typename T, int TM, int TN, int WM, int WN, bool LSTM>
+template <typename T, int TM, int TN, int WM, int WN, int KS, bool LSTM>
 int launch_cfg(const UicGemmParams& p, hipStream_t s) {
   constexpr int BM = 32 * TM * WM, BN = 32 * TN * WN;
+  constexpr int stage_bytes = KS * (BM + BN) * LDS_STRIDE;
+  constexpr int red_bytes = KS * (KS - 1) * WM * WN * TM * TN * (16 / KS) * 64 * 4;
+  constexpr int lds = stage_bytes > red_bytes ? stage_bytes : red_bytes;
+  static bool configured = false;
+  if (!configured) {
+    if (lds > 64 * 1024)
+      UIC_TRY(uic_check_hip(hipFuncSetAttribute((const void*)uic_gemm_kernel<T, TM, TN, WM, WN, KS, LSTM>,
+                                                hipFuncAttributeMaxDynamicSharedMemorySize, lds), "hipFuncSetAttribute(gemm)"));
+    configured = true;
+  }
   dim3 grid((p.M + BM - 1) / BM, LSTM ? (p.H + 32 * WN - 1) / (32 * WN) : (p.N + BN - 1) / BN);
-  hipLaunchKernelGGL((uic_gemm_kernel<T, TM, TN, WM, WN, LSTM>), grid, dim3(64 * WM * WN), 0, s, p);
+  hipLaunchKernelGGL((uic_gemm_kernel<T, TM, TN, WM, WN, KS, LSTM>), grid, dim3(64 * WM * WN * KS), lds, s, p);
   UIC_LAUNCH_CHECK("uic_gemm_kernel");
   return UIC_OK;
 }
 
 template <typename T>
 int launch_typed(const UicGemmParams& p, hipStream_t s) {
-  if (p.lstm) {
-    // 64 rows x 32 units per 2-wave block while that fills the chip, else 128 rows per 4-wave block
-    const long blocks64 = (long)((p.M + 63) / 64) * ((p.H + 31) / 32);
-    if (blocks64 <= 1024) return launch_cfg<T, 1, 4, 2, 1, true>(p, s);
-    return launch_cfg<T, 1, 4, 4, 1, true>(p, s);
-  }
+  // skinny problems (the per-decode-step GEMMs, M = rows of one step): 64-row tiles with a 4-way in-block K split
+  if (p.lstm) return launch_cfg<T, 1, 4, 2, 1, 4, true>(p, s);
   const long blocks128 = (long)((p.M + 127) / 128) * ((p.N + 127) / 128);
-  if (blocks128 >= 256) return launch_cfg<T, 2, 2, 2, 2, false>(p, s);
-  return launch_cfg<T, 1, 1, 2, 2, false>(p, s);
+  if (blocks128 >= 200) return launch_cfg<T, 2, 2, 2, 2, 1, false>(p, s);
+  return launch_cfg<T, 1, 1, 2, 2, 4, false>(p, s);
 }
 
 }  // namespace

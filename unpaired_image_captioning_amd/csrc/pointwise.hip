@@ -59,17 +59,24 @@ __global__ __launch_bounds__(NT) void transpose_kernel(const T* __restrict__ src
 }
 
 // ------------------------------------------------------------------ column sums (bias gradients)
+// stage 1: a block sums `rows_per_block` rows of a 64-column strip; its 4 waves take rows r, r+4, ...
 template <typename T>
 __global__ __launch_bounds__(NT) void colsum_stage1(const T* __restrict__ src, int rows, int cols, int lds,
                                                     int rows_per_block, float* __restrict__ part) {
-  const int c = blockIdx.x * NT + threadIdx.x;
-  if (c >= cols) return;
+  __shared__ float s_part[4][64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + lane;
   const int rb = blockIdx.y;
   const int r_lo = rb * rows_per_block;
   const int r_hi = min(rows, r_lo + rows_per_block);
   float s = 0.f;
-  for (int r = r_lo; r < r_hi; ++r) s += uic_to_f(src[(size_t)r * lds + c]);
-  part[(size_t)rb * cols + c] = s;
+  if (c < cols) {
+#pragma unroll 4
+    for (int r = r_lo + wave; r < r_hi; r += 4) s += uic_to_f(src[(size_t)r * lds + c]);
+  }
+  s_part[wave][lane] = s;
+  __syncthreads();
+  if (wave == 0 && c < cols) part[(size_t)rb * cols + c] = s_part[0][lane] + s_part[1][lane] + s_part[2][lane] + s_part[3][lane];
 }
 __global__ __launch_bounds__(NT) void colsum_stage2(const float* __restrict__ part, int nrb, int cols, float* __restrict__ out) {
   const int c = blockIdx.x * NT + threadIdx.x;
@@ -232,6 +239,60 @@ __global__ __launch_bounds__(NT) void xe_kernel(const UicXeParams p, const float
       float g = 0.f;
       if (v < p.V1) g = (expf(row[v] - lse) - (v == y ? 1.f : 0.f)) * sc;
       d[v] = uic_from_f<T>(g);
+    }
+  }
+}
+
+// Same, with the logits row staged once in LDS (rows up to 64 KB): one HBM read of the 413 MB logits
+// tensor instead of three.
+template <typename T>
+__global__ __launch_bounds__(NT) void xe_lds_kernel(const UicXeParams p, const float* __restrict__ logits, T* __restrict__ dlogits) {
+  extern __shared__ __attribute__((aligned(16))) float s_row[];
+  __shared__ float s_buf[NT / 64];
+  const int m = blockIdx.x;
+  const int t = m / p.N, n = m - t * p.N;
+  const float* row = logits + (size_t)m * p.ldv;
+  float mx = -INFINITY;
+  for (int v = threadIdx.x * 4; v < p.ldv; v += NT * 4) {
+    const float4 x = *(const float4*)(row + v);
+    *(float4*)(s_row + v) = x;
+    if (v < p.V1) mx = fmaxf(mx, x.x);
+    if (v + 1 < p.V1) mx = fmaxf(mx, x.y);
+    if (v + 2 < p.V1) mx = fmaxf(mx, x.z);
+    if (v + 3 < p.V1) mx = fmaxf(mx, x.w);
+  }
+  mx = block_reduce_max(mx, s_buf);
+  float sum = 0.f;
+  for (int v = threadIdx.x; v < p.V1; v += NT) sum += __expf(s_row[v] - mx);
+  sum = block_reduce_sum(sum, s_buf);
+  const float lse = mx + logf(sum);
+  long y = 0;
+  float mk = 0.f;
+  if (p.target) {
+    y = p.target[(size_t)n * p.ldtarget + p.target_col0 + t];
+    mk = p.mask[(size_t)n * p.ldmask + p.mask_col0 + t];
+    if (y < 0 || y >= p.V1) y = 0;
+    if (threadIdx.x == 0) p.row_loss[m] = -(s_row[y] - lse) * mk;
+  }
+  if (p.logprobs) {
+    float* lp = p.logprobs + (size_t)n * p.lp_row_stride + (size_t)t * p.lp_step_stride;
+    for (int v = threadIdx.x; v < p.V1; v += NT) lp[v] = s_row[v] - lse;
+  }
+  if (p.write_grad) {
+    const float sc = mk * p.inv_den[0];
+    T* d = dlogits + (size_t)m * p.ldv;
+    for (int v = threadIdx.x * 4; v < p.ldv; v += NT * 4) {
+      float g[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int vv = v + j;
+        g[j] = vv < p.V1 ? (__expf(s_row[vv] - lse) - (vv == y ? 1.f : 0.f)) * sc : 0.f;
+      }
+      if constexpr (sizeof(T) == 2) {
+        *(uint2*)(d + v) = make_uint2(uic_pack_bf16x2(g[0], g[1]), uic_pack_bf16x2(g[2], g[3]));
+      } else {
+        *(float4*)(d + v) = make_float4(g[0], g[1], g[2], g[3]);
+      }
     }
   }
 }
@@ -445,13 +506,13 @@ int uic_transpose_launch(int dtype, const void* src, int rows, int cols, int lds
 int uic_colsum_launch(int src_dtype, const void* src, int rows, int cols, int lds, float* out, float* scratch,
                       size_t scratch_floats, hipStream_t s) {
   if (cols == 0) return UIC_OK;
-  int nrb = (rows + 255) / 256;
+  int nrb = (rows + 63) / 64;
   if (nrb > 128) nrb = 128;
   if (nrb < 1) nrb = 1;
   while (nrb > 1 && (size_t)nrb * cols > scratch_floats) nrb /= 2;
   UIC_REQUIRE((size_t)nrb * cols <= scratch_floats, "colsum: scratch too small (%zu floats for %d cols)", scratch_floats, cols);
   const int rpb = (rows + nrb - 1) / nrb;
-  dim3 grid((cols + NT - 1) / NT, nrb);
+  dim3 grid((cols + 63) / 64, nrb);
   DISPATCH_T(src_dtype,
              hipLaunchKernelGGL(colsum_stage1<bf16_t>, grid, dim3(NT), 0, s, (const bf16_t*)src, rows, cols, lds, rpb, scratch),
              hipLaunchKernelGGL(colsum_stage1<float>, grid, dim3(NT), 0, s, (const float*)src, rows, cols, lds, rpb, scratch));
@@ -513,6 +574,13 @@ int uic_xe_launch(const UicXeParams& p, hipStream_t s) {
   UIC_REQUIRE(!p.write_grad || p.dlogits, "xe: null dlogits");
   UIC_REQUIRE(!p.target || p.row_loss, "xe: null row_loss");
   if (p.M == 0) return UIC_OK;
+  const size_t row_bytes = (size_t)p.ldv * 4;
+  if (p.dtype == UIC_BF16 && p.ldv % 4 == 0 && row_bytes <= 64 * 1024 && ((uintptr_t)p.logits & 15) == 0) {
+    // bf16 path: LDS-staged row + hardware exp (the f32 parity path keeps libm exp)
+    hipLaunchKernelGGL(xe_lds_kernel<bf16_t>, dim3(p.M), dim3(NT), row_bytes, s, p, p.logits, (bf16_t*)p.dlogits);
+    UIC_LAUNCH_CHECK("xe_lds_kernel");
+    return UIC_OK;
+  }
   DISPATCH_T(p.dtype, hipLaunchKernelGGL(xe_kernel<bf16_t>, dim3(p.M), dim3(NT), 0, s, p, p.logits, (bf16_t*)p.dlogits),
              hipLaunchKernelGGL(xe_kernel<float>, dim3(p.M), dim3(NT), 0, s, p, p.logits, (float*)p.dlogits));
   UIC_LAUNCH_CHECK("xe_kernel");

@@ -99,6 +99,11 @@ template <> __device__ __forceinline__ float uic_tanh<bf16_t>(float x) {
   return 1.f - __fdividef(2.f, e + 1.f);
 }
 
+// sigmoid: libm exp on the f32 path, hardware exp + fast reciprocal on the bf16 path
+template <typename T> __device__ __forceinline__ float uic_sigmoid_t(float x);
+template <> __device__ __forceinline__ float uic_sigmoid_t<float>(float x) { return 1.f / (1.f + expf(-x)); }
+template <> __device__ __forceinline__ float uic_sigmoid_t<bf16_t>(float x) { return __fdividef(1.f, 1.f + __expf(-x)); }
+
 __device__ __forceinline__ float uic_wave_sum(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
