@@ -1,0 +1,131 @@
+"""CPU-side checks (no GPU): the C ABI library loads and exports every symbol include/uic_hip.h declares,
+the host-side mirror keeps the reference's contracts, and the product path fails loudly without a device."""
+import argparse
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import ROOT, load_golden
+
+
+def _opt(**kw):
+    base = dict(vocab_size=50, input_encoding_size=32, rnn_size=32, num_layers=1, drop_prob_lm=0.5, seq_length=6,
+                fc_feat_size=64, att_feat_size=64, att_hid_size=32, use_bn=0, caption_model="topdown", compute_dtype="f32")
+    base.update(kw)
+    return argparse.Namespace(**base)
+
+
+def test_library_exports_every_symbol_declared_in_header():
+    from unpaired_image_captioning_amd import _lib
+    from unpaired_image_captioning_amd.build import build
+    build(verbose=False)
+    header = open(os.path.join(ROOT, "include", "uic_hip.h")).read()
+    declared = set(re.findall(r"\b(uic_[a-z0-9_]+)\s*\(", header))
+    declared -= {"uic_topdown_dims", "uic_topdown_weights", "uic_topdown_batch"}
+    assert len(declared) >= 20
+    lib = C.CDLL(_lib.LIB_PATH)
+    for name in sorted(declared):
+        assert hasattr(lib, name), "header declares %s but libuic_hip.so does not export it" % name
+    assert set(_lib.EXPORTS) == declared, set(_lib.EXPORTS) ^ declared
+    assert _lib.load().uic_version() >= 100
+
+
+def test_workspace_size_queries_and_argument_errors():
+    from unpaired_image_captioning_amd import _lib
+    lib = _lib.load()
+    d = _lib.Dims(N=640, R=36, D=2048, Dfc=2048, H=512, E=512, A=512, V1=9488, T=17, dtype=1, drop_p=0.5)
+    ws_bf16 = lib.uic_topdown_workspace_bytes(C.byref(d))
+    d.dtype = 0
+    ws_f32 = lib.uic_topdown_workspace_bytes(C.byref(d))
+    assert 1 << 30 < ws_bf16 < ws_f32 < 4 << 30 and ws_bf16 % 256 == 0
+    assert lib.uic_topdown_derived_bytes(C.byref(d)) > 0
+    d.H = 510                                         # not a multiple of 8 -> rejected, with a message
+    assert lib.uic_topdown_workspace_bytes(C.byref(d)) == 0
+    assert b"multiples of 8" in lib.uic_last_error_string()
+    d.H = 512
+    d.dtype = 9
+    assert lib.uic_topdown_workspace_bytes(C.byref(d)) == 0
+    # null pointers are argument errors (negative), never a crash
+    assert lib.uic_adam_step(None, None, None, None, 10, 1e-3, 0.9, 0.999, 1e-8, 1, 1.0, None) < 0
+
+
+def test_weight_struct_matches_reference_state_dict_order():
+    from unpaired_image_captioning_amd import _lib, models
+    cfg, W, I, Out, G, X = load_golden("topdown_tiny")
+    model = models.setup(_opt())
+    assert [k for _, k in _lib.WEIGHT_FIELDS] == list(W.keys()) == list(model.state_dict().keys())
+    model.load_state_dict(W)
+    for k, v in model.state_dict().items():
+        assert torch.equal(v, W[k])
+    assert [f for f, _ in _lib.Weights._fields_] == [f for f, _ in _lib.WEIGHT_FIELDS]
+
+
+def test_same_seed_gives_reference_initialisation():
+    """The parameter-owning module tree is built in the reference's order, so torch.manual_seed(s) reproduces
+    the reference model's initial weights (golden `w::` entries were drawn with seed 11)."""
+    from unpaired_image_captioning_amd import models
+    cfg, W, I, Out, G, X = load_golden("topdown_tiny")
+    torch.manual_seed(11)
+    model = models.setup(_opt(drop_prob_lm=0.0))
+    for k, v in model.state_dict().items():
+        assert torch.equal(v, W[k]), k
+
+
+def test_no_cpu_fallback():
+    from unpaired_image_captioning_amd import models
+    cfg, W, I, Out, G, X = load_golden("topdown_tiny")
+    model = models.setup(_opt(drop_prob_lm=0.0))
+    model.load_state_dict(W)
+    with pytest.raises(RuntimeError, match="device tensors"):
+        model(I["fc_feats"], None, I["att_feats"], I["labels"], I["att_masks"])
+    with pytest.raises(RuntimeError, match="device tensors"):
+        model(I["fc_feats"], None, I["att_feats"], I["att_masks"], opt={"sample_max": 1}, mode="sample")
+
+
+def test_unsupported_options_raise():
+    from unpaired_image_captioning_amd import models
+    with pytest.raises(NotImplementedError):
+        models.setup(_opt(use_bn=1))
+    with pytest.raises(Exception, match="not supported"):
+        models.setup(_opt(caption_model="transformer"))
+    m = models.setup(_opt())
+    with pytest.raises(NotImplementedError):
+        m(None, None, None, None, opt={"beam_size": 3}, mode="sample")
+
+
+def test_early_break_step_count_matches_reference_rule():
+    from unpaired_image_captioning_amd.models.AttModel import AttModel
+    from unpaired_image_captioning_amd.trainer import _steps_from_host_labels
+    for name in ("topdown_tiny", "topdown_tiny_earlybreak", "topdown_odd"):
+        cfg, W, I, Out, G, X = load_golden(name)
+        labels = I["labels"]
+        ref_zero = (Out["logprobs"].abs().sum((0, 2)) == 0).nonzero().view(-1)
+        expect = int(ref_zero[0]) if ref_zero.numel() else labels.shape[1] - 1
+        assert AttModel._steps_to_run(labels) == expect
+        assert _steps_from_host_labels(labels.numpy()) == expect
+
+
+def test_lr_schedule_matches_reference_formula():
+    from unpaired_image_captioning_amd.trainer import Trainer
+    tr = Trainer(_opt(i2t_learning_rate=4e-4, i2t_learning_rate_decay_start=0, i2t_learning_rate_decay_every=3,
+                      i2t_learning_rate_decay_rate=0.8))
+    for epoch in range(0, 12):
+        tr.update_LearningRate(epoch)
+        frac = (epoch - 0) // 3 if epoch > 0 else 0        # P/misc/optimizer.py:116-120
+        assert tr.i2t_current_lr == pytest.approx(4e-4 * 0.8 ** frac)
+
+
+def test_synthetic_batch_layout_cpu():
+    from unpaired_image_captioning_amd.synthetic import synthetic_batch
+    b = synthetic_batch(4, 5, 36, 64, 100, 16, seed=1, device="cpu", ragged_regions=True)
+    assert b["att_feats"].shape == (20, 36, 64) and b["labels"].shape == (20, 18) and b["masks"].shape == (20, 18)
+    assert (b["labels"][:, 0] == 0).all() and (b["labels"][:, -1] == 0).all()
+    nz = (b["labels"] != 0).sum(1) + 2
+    assert torch.equal(b["masks"].sum(1).long(), nz)                    # P/misc/dataloader/dataloader.py:283-286
+    assert torch.equal(b["att_feats"][0], b["att_feats"][4]) and not torch.equal(b["att_feats"][0], b["att_feats"][5])
+    cnt = b["att_masks"].sum(1)
+    assert (cnt[:-1] >= cnt[1:]).all()                                   # sorted by region count, as the loader does
