@@ -2,7 +2,8 @@
 import csv, glob, sys, collections
 d = sys.argv[1]
 steps = float(sys.argv[2]) if len(sys.argv) > 2 else 1.0
-f = glob.glob(d + '/*/*kernel_stats.csv')[0]
+import os
+f = max(glob.glob(d + '/*/*kernel_stats.csv'), key=os.path.getmtime)
 rows = list(csv.DictReader(open(f)))
 tot = sum(float(r['TotalDurationNs']) for r in rows)
 print("total kernel time %.3f ms  (%.3f ms/step over %g steps)" % (tot / 1e6, tot / 1e6 / steps, steps))

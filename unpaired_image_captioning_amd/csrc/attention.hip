@@ -249,19 +249,15 @@ __global__ __launch_bounds__(NTHREADS) void attn_fwd_fast_kernel(const UicAttnPa
   const int n = blockIdx.x;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const bool la = lane < A / VEC, lh = lane < H / VEC;
-  const T* pa = (const T*)p.p_att + (size_t)n * R * A + lane * VEC;
-  const T* pt = (const T*)p.att + (size_t)n * R * H + lane * VEC;
+  // indices are clamped instead of predicated (no exec-mask branches around the 18 loads); out-of-range
+  // regions / lanes read valid memory and are neutralised by zero weights below
+  const T* pa = (const T*)p.p_att + (size_t)n * R * A + (la ? lane : 0) * VEC;
+  const T* pt = (const T*)p.att + (size_t)n * R * H + (lh ? lane : 0) * VEC;
   uint4 vp[UB], va[UB];
 #pragma unroll
-  for (int u = 0; u < UB; ++u) {
-    const int r = wave + u * NWAVES;
-    vp[u] = (r < R && la) ? *(const uint4*)(pa + (size_t)r * A) : make_uint4(0, 0, 0, 0);
-  }
+  for (int u = 0; u < UB; ++u) vp[u] = *(const uint4*)(pa + (size_t)min(wave + u * NWAVES, R - 1) * A);
 #pragma unroll
-  for (int u = 0; u < UB; ++u) {
-    const int r = wave + u * NWAVES;
-    va[u] = (r < R && lh) ? *(const uint4*)(pt + (size_t)r * H) : make_uint4(0, 0, 0, 0);
-  }
+  for (int u = 0; u < UB; ++u) va[u] = *(const uint4*)(pt + (size_t)min(wave + u * NWAVES, R - 1) * H);
   float ah[VEC], w[VEC];
   load_chunk_f32<T>(p.att_h + (size_t)n * A, lane, la, ah);
   load_chunk_f32<T>(p.w_alpha, lane, la, w);
@@ -324,19 +320,13 @@ __global__ __launch_bounds__(NTHREADS) void attn_bwd_step_fast_kernel(const UicA
   const int n = blockIdx.x;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const bool la = lane < A / VEC, lh = lane < H / VEC;
-  const T* pa = (const T*)p.p_att + (size_t)n * R * A + lane * VEC;
-  const T* pt = (const T*)p.att + (size_t)n * R * H + lane * VEC;
+  const T* pa = (const T*)p.p_att + (size_t)n * R * A + (la ? lane : 0) * VEC;
+  const T* pt = (const T*)p.att + (size_t)n * R * H + (lh ? lane : 0) * VEC;
   uint4 vp[UB], va[UB];
 #pragma unroll
-  for (int u = 0; u < UB; ++u) {
-    const int r = wave + u * NWAVES;
-    va[u] = (r < R && lh) ? *(const uint4*)(pt + (size_t)r * H) : make_uint4(0, 0, 0, 0);
-  }
+  for (int u = 0; u < UB; ++u) va[u] = *(const uint4*)(pt + (size_t)min(wave + u * NWAVES, R - 1) * H);
 #pragma unroll
-  for (int u = 0; u < UB; ++u) {
-    const int r = wave + u * NWAVES;
-    vp[u] = (r < R && la) ? *(const uint4*)(pa + (size_t)r * A) : make_uint4(0, 0, 0, 0);
-  }
+  for (int u = 0; u < UB; ++u) vp[u] = *(const uint4*)(pa + (size_t)min(wave + u * NWAVES, R - 1) * A);
   float ah[VEC], w[VEC], dc[VEC];
   load_chunk_f32<T>(p.att_h + (size_t)n * A, lane, la, ah);
   load_chunk_f32<T>(p.w_alpha, lane, la, w);

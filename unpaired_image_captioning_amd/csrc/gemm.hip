@@ -22,6 +22,7 @@
 namespace {
 
 constexpr int LDS_STRIDE = 144;   // 128-B K slice + 16-B pad
+typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
 
 // KS > 1: KS groups of WM x WN waves each take one 128-byte K slice of a (KS * 128)-byte K step for the
 // SAME output tile and are summed through LDS at the end.  The skinny per-decode-step GEMMs (M = 640)
@@ -303,6 +304,225 @@ __global__ __launch_bounds__(64 * WM * WN * KS) void uic_gemm_kernel(const UicGe
   }
 }
 
+// ---------------------------------------------------------------------------------------------------
+// Large-GEMM path: 128x128 tile, 4 waves (2x2, 64x64 each), K rounds of 128 bytes staged global -> LDS
+// directly (global_load_lds_dwordx4, no VGPR round trip) into two LDS buffers, one barrier per round.
+// LDS rows are the bare 128-byte K slices (an LDS-DMA wave instruction writes 1 KiB = 8 rows linearly),
+// so the bank-conflict fix is an XOR swizzle applied to the per-lane SOURCE address and again on the
+// fragment read: 16-byte chunk c of tile row r lives at chunk c ^ ((r >> 1) & 7), which makes the 16-lane
+// groups of ds_read_b128 hit 16 distinct 16-byte slots of the 256-byte bank row.
+// Requires one K segment with K a multiple of the round (64 bf16 / 32 f32 elements).
+template <typename T>
+__global__ __launch_bounds__(256) void uic_gemm_glds_kernel(const UicGemmParams p) {
+  constexpr int BM = 128, BN = 128;
+  constexpr int BK = 128 / (int)sizeof(T);
+  extern __shared__ __attribute__((aligned(16))) char smem[];   // [2][A 16 KB | B 16 KB]
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  const int half = lane >> 5, r32 = lane & 31;
+
+  // XCD-aware + grouped tile order: each XCD takes a contiguous run of tiles; inside it tiles advance over
+  // GM = 8 row-tiles before moving to the next column tile, so one XCD's L2 holds an 8-tile A band while
+  // B tiles stream through once per band.
+  int bm, bn;
+  {
+    const int gx = gridDim.x, gy = gridDim.y, nblk = gx * gy;
+    const int lin = blockIdx.x + gx * blockIdx.y;
+    const int q = nblk >> 3, r = nblk & 7, xcd = lin & 7, idx = lin >> 3;
+    const int lp = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    constexpr int GM = 8;
+    const int width = GM * gy;
+    const int first = (lp / width) * GM;
+    const int gsz = min(gx - first, GM);
+    const int rem = lp % width;
+    bm = first + rem % gsz;
+    bn = rem / gsz;
+  }
+  const int m0 = bm * BM, n0 = bn * BN;
+
+  const UicGemmSeg sg = p.seg[0];
+  // per-lane source pointers of this wave's 4 A and 4 B LDS-DMA instructions per round
+  const int slot = lane & 7;
+  const char* srcA[4];
+  const char* srcB[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int row = (wave * 4 + i) * 8 + (lane >> 3);
+    const int chunk = slot ^ ((row >> 1) & 7);
+    const int gm = min(m0 + row, p.M - 1);
+    const int gn = min(n0 + row, p.N - 1);
+    srcA[i] = (const char*)sg.A + (size_t)gm * sg.lda * sizeof(T) + chunk * 16;
+    srcB[i] = (const char*)sg.B + (size_t)gn * sg.ldb * sizeof(T) + chunk * 16;
+  }
+  auto stage = [&](int kt, int buf) {
+    char* dA = smem + buf * 32768 + wave * 4096;
+    char* dB = dA + 16384;
+    const size_t koff = (size_t)kt * 128;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(srcA[i] + koff),
+                                       (__attribute__((address_space(3))) void*)(dA + i * 1024), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(srcB[i] + koff),
+                                       (__attribute__((address_space(3))) void*)(dB + i * 1024), 16, 0, 0);
+    }
+  };
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int k = 0; k < 16; ++k) acc[i][j][k] = 0.f;
+
+  // K rounds of this workgroup: all of them, or slice blockIdx.z of a split-K launch
+  int kt0 = 0, nt = sg.K / BK;
+  if (p.splitk > 1) {
+    const int tps = (nt + p.splitk - 1) / p.splitk;
+    kt0 = blockIdx.z * tps;
+    nt = max(0, min(nt - kt0, tps));
+  }
+  // LDS byte addresses of this lane's fragment chunks (buffer 0, first 32-row sub-tile), one per K step
+  const int sw = (r32 >> 1) & 7;
+  const unsigned lds0 = (unsigned)(size_t)((__attribute__((address_space(3))) char*)smem);
+  unsigned adA[4], adB[4];
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) {
+    const unsigned pc = (unsigned)(((half * 4 + ks) ^ sw) * 16);
+    adA[ks] = lds0 + (unsigned)((wm * 64 + r32) * 128) + pc;
+    adB[ks] = lds0 + 16384u + (unsigned)((wn * 64 + r32) * 128) + pc;
+  }
+  // The fragment reads are inline asm on purpose: hipcc cannot tell the LDS-DMA writes of the NEXT round's
+  // buffer from these reads and would drain vmcnt(0) before the first ds_read of every round, serialising
+  // load and MFMA.  Ordering is by hand: vmcnt(0) + barrier at the top of a round covers the RAW on this
+  // round's buffer and the WAR on the other one; counted lgkmcnt waits name their destination registers.
+#define UIC_DSR(dst, addr, off) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(off))
+#define UIC_MFMA4(A0, A1, B0, B1)                                                                         \
+  do {                                                                                                   \
+    if constexpr (sizeof(T) == 2) {                                                                      \
+      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, A0), __builtin_bit_cast(bf16x8, B0), acc[0][0], 0, 0, 0); \
+      acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, A0), __builtin_bit_cast(bf16x8, B1), acc[0][1], 0, 0, 0); \
+      acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, A1), __builtin_bit_cast(bf16x8, B0), acc[1][0], 0, 0, 0); \
+      acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, A1), __builtin_bit_cast(bf16x8, B1), acc[1][1], 0, 0, 0); \
+    } else {                                                                                             \
+      const u32x4 aa[2] = {A0, A1}, bb[2] = {B0, B1};                                                    \
+      _Pragma("unroll") for (int i = 0; i < 2; ++i) _Pragma("unroll") for (int j = 0; j < 2; ++j) {      \
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(aa[i].x), __uint_as_float(bb[j].x), acc[i][j], 0, 0, 0); \
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(aa[i].y), __uint_as_float(bb[j].y), acc[i][j], 0, 0, 0); \
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(aa[i].z), __uint_as_float(bb[j].z), acc[i][j], 0, 0, 0); \
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(aa[i].w), __uint_as_float(bb[j].w), acc[i][j], 0, 0, 0); \
+      }                                                                                                  \
+    }                                                                                                    \
+  } while (0)
+#define UIC_ISSUE(A0, A1, B0, B1, KS, BO) \
+  UIC_DSR(A0, adA[KS], BO); UIC_DSR(A1, adA[KS], BO + 4096); UIC_DSR(B0, adB[KS], BO); UIC_DSR(B1, adB[KS], BO + 4096)
+#define UIC_WAIT(N, A0, A1, B0, B1)                                                           \
+  asm volatile("s_waitcnt lgkmcnt(" #N ")" : "+v"(A0), "+v"(A1), "+v"(B0), "+v"(B1));         \
+  __builtin_amdgcn_sched_barrier(0)
+  auto compute = [&](auto bufc) {
+    constexpr int BO = decltype(bufc)::value * 32768;
+    u32x4 a00, a01, b00, b01, a10, a11, b10, b11;     // two register sets: K step ks uses set ks & 1
+    UIC_ISSUE(a00, a01, b00, b01, 0, BO);
+    UIC_ISSUE(a10, a11, b10, b11, 1, BO);
+    UIC_WAIT(4, a00, a01, b00, b01);
+    UIC_MFMA4(a00, a01, b00, b01);
+    UIC_ISSUE(a00, a01, b00, b01, 2, BO);
+    UIC_WAIT(4, a10, a11, b10, b11);
+    UIC_MFMA4(a10, a11, b10, b11);
+    UIC_ISSUE(a10, a11, b10, b11, 3, BO);
+    UIC_WAIT(4, a00, a01, b00, b01);
+    UIC_MFMA4(a00, a01, b00, b01);
+    UIC_WAIT(0, a10, a11, b10, b11);
+    UIC_MFMA4(a10, a11, b10, b11);
+  };
+#undef UIC_WAIT
+#undef UIC_ISSUE
+#undef UIC_MFMA4
+#undef UIC_DSR
+  if (nt > 0) stage(kt0, 0);
+  for (int t = 0; t < nt; t += 2) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (t + 1 < nt) stage(kt0 + t + 1, 1);
+    compute(std::integral_constant<int, 0>{});
+    if (t + 1 < nt) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      if (t + 2 < nt) stage(kt0 + t + 2, 0);
+      compute(std::integral_constant<int, 1>{});
+    }
+  }
+
+  if (p.slab) {   // raw partial tile -> slab[z]
+    float* slab = p.slab + (size_t)blockIdx.z * p.M * p.N;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int col = n0 + (wn * 2 + j) * 32 + r32;
+        if (col >= p.N) continue;
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg) {
+          const int row = m0 + (wm * 2 + i) * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * half;
+          if (row < p.M) slab[(size_t)row * p.N + col] = acc[i][j][reg];
+        }
+      }
+    return;
+  }
+
+  const float inv_keep = p.drop_p > 0.f ? 1.f / (1.f - p.drop_p) : 1.f;
+  const bool out_f32 = (p.flags & UIC_GEMM_OUT_F32) || sizeof(T) == 4;
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int col = n0 + (wn * 2 + j) * 32 + r32;
+      if (col >= p.N) continue;
+      float b = 0.f;
+      if (p.bias) b += p.bias[col];
+      if (p.bias2) b += p.bias2[col];
+#pragma unroll
+      for (int reg = 0; reg < 16; ++reg) {
+        const int row = m0 + (wm * 2 + i) * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * half;
+        if (row >= p.M) continue;
+        float v = acc[i][j][reg] + b;
+        if (p.flags & UIC_GEMM_RELU) v = fmaxf(v, 0.f);
+        if (p.row_len) {
+          const int n = row / p.R;
+          if (row - n * p.R >= p.row_len[n]) v = 0.f;
+        }
+        if (p.drop_p > 0.f) v *= uic_drop_scale(p.seed, p.site, (unsigned)row * (unsigned)p.N + (unsigned)col, p.drop_p, inv_keep);
+        const size_t o = (size_t)row * p.ldc + col;
+        if (out_f32) {
+          float* C = (float*)p.C;
+          if (p.flags & UIC_GEMM_ACCUM) v += C[o];
+          C[o] = v;
+        } else {
+          T* C = (T*)p.C;
+          if (p.flags & UIC_GEMM_ACCUM) v += uic_to_f(C[o]);
+          C[o] = uic_from_f<T>(v);
+        }
+      }
+    }
+}
+
+template <typename T>
+int launch_glds(const UicGemmParams& p, hipStream_t s) {
+  static bool configured = false;
+  if (!configured) {
+    UIC_TRY(uic_check_hip(hipFuncSetAttribute((const void*)uic_gemm_glds_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536),
+                          "hipFuncSetAttribute(gemm glds)"));
+    configured = true;
+  }
+  dim3 grid((p.M + 127) / 128, (p.N + 127) / 128, p.splitk > 1 ? p.splitk : 1);
+  hipLaunchKernelGGL((uic_gemm_glds_kernel<T>), grid, dim3(256), 65536, s, p);
+  UIC_LAUNCH_CHECK("uic_gemm_glds_kernel");
+  return UIC_OK;
+}
+
 template <typename T, int TM, int TN, int WM, int WN, int KS, bool LSTM>
 int launch_cfg(const UicGemmParams& p, hipStream_t s) {
   constexpr int BM = 32 * TM * WM, BN = 32 * TN * WN;
@@ -327,11 +547,43 @@ int launch_typed(const UicGemmParams& p, hipStream_t s) {
   // skinny problems (the per-decode-step GEMMs, M = rows of one step): 64-row tiles with a 4-way in-block K split
   if (p.lstm) return launch_cfg<T, 1, 4, 2, 1, 4, true>(p, s);
   const long blocks128 = (long)((p.M + 127) / 128) * ((p.N + 127) / 128);
+  const bool glds_ok = p.nseg == 1 && p.seg[0].K % (128 / (int)sizeof(T)) == 0;
+  if (p.slab) {
+    UIC_REQUIRE(glds_ok && !p.lstm, "gemm: slab output needs one K segment that is a multiple of 128 bytes");
+    return launch_glds<T>(p, s);
+  }
+  if (blocks128 >= 200 && glds_ok) return launch_glds<T>(p, s);
   if (blocks128 >= 200) return launch_cfg<T, 2, 2, 2, 2, 1, false>(p, s);
   return launch_cfg<T, 1, 1, 2, 2, 4, false>(p, s);
 }
 
 }  // namespace
+
+namespace {
+__global__ void splitk_reduce_kernel(const float* __restrict__ slab, int splitk, int M, int N, int col0, int ncols,
+                                     float* __restrict__ C, int ldc) {
+  const size_t total = (size_t)M * ncols;
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+    const int row = (int)(i / ncols), c = (int)(i - (size_t)row * ncols);
+    const float* src = slab + (size_t)row * N + col0 + c;
+    float v = 0.f;
+    for (int z = 0; z < splitk; ++z) v += src[(size_t)z * M * N];
+    C[(size_t)row * ldc + c] = v;
+  }
+}
+}  // namespace
+
+int uic_splitk_reduce_launch(const float* slab, int splitk, int M, int N, int col0, int ncols, float* C, int ldc, hipStream_t s) {
+  if (M == 0 || ncols == 0) return UIC_OK;
+  size_t g = ((size_t)M * ncols + 255) / 256;
+  if (g > 4096) g = 4096;
+  hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)g), dim3(256), 0, s, slab, splitk, M, N, col0, ncols, C, ldc);
+  UIC_LAUNCH_CHECK("splitk_reduce");
+  return UIC_OK;
+}
+
+bool uic_gemm_glds_eligible(int dtype, int K) { return K > 0 && K % (dtype == UIC_BF16 ? 64 : 32) == 0; }
 
 int uic_gemm_launch(const UicGemmParams& p, hipStream_t s) {
   UIC_REQUIRE(p.dtype == UIC_F32 || p.dtype == UIC_BF16, "gemm: bad dtype %d", p.dtype);
@@ -349,7 +601,7 @@ int uic_gemm_launch(const UicGemmParams& p, hipStream_t s) {
     UIC_REQUIRE(p.H > 0 && p.N == 4 * p.H, "gemm(lstm): N=%d must equal 4*H (H=%d)", p.N, p.H);
     UIC_REQUIRE(p.c_out && p.h_out, "gemm(lstm): c_out and h_out are required");
   } else {
-    UIC_REQUIRE(p.C != nullptr, "gemm: null C");
+    UIC_REQUIRE(p.C != nullptr || p.slab != nullptr, "gemm: null C");
   }
   if (p.M == 0 || p.N == 0) return UIC_OK;
   return p.dtype == UIC_BF16 ? launch_typed<bf16_t>(p, s) : launch_typed<float>(p, s);

@@ -42,6 +42,7 @@ struct Layout {
   void* dgfc; float* dfcp; void* dfcpre; float* dxt;
   float* d_att; void* d_patt; float* dwalpha_part; void* d_pre;
   void* tA; void* tB; float* colscratch; size_t colscratch_floats; float* small;
+  float* slab; size_t slab_bytes;
   // sampling
   void* s_h_att[2]; void* s_h_lang[2]; float* s_c_att[2]; float* s_c_lang[2];
   void* s_xt; float* s_atth; float* s_alpha; void* s_ctx; float* s_logits;
@@ -50,6 +51,9 @@ struct Layout {
 };
 
 inline size_t rup8(size_t x) { return (x + 7) & ~(size_t)7; }
+// padded vocabulary width (leading dimension of logits / dlogits): a multiple of 64 for real vocabularies so the
+// K = V1 backward GEMM runs on the 128-byte-round LDS-DMA path, a multiple of 8 for toy sizes
+inline size_t vpad(size_t v1) { return v1 >= 1024 ? (v1 + 63) & ~(size_t)63 : rup8(v1); }
 
 Layout make_layout(const uic_topdown_dims& d, void* ws) {
   Layout L;
@@ -57,7 +61,7 @@ Layout make_layout(const uic_topdown_dims& d, void* ws) {
   Bump b{(char*)ws, 0};
   const size_t S = uic_dtype_size(d.dtype);
   const size_t N = d.N, R = d.R, D = d.D, Dfc = d.Dfc, H = d.H, E = d.E, A = d.A, V1 = d.V1, T = d.T;
-  const size_t M = T * N, Mp = rup8(M), Np = rup8(N), NR = N * R, NRp = rup8(NR), V1p = rup8(V1);
+  const size_t M = T * N, Mp = rup8(M), Np = rup8(N), NR = N * R, NRp = rup8(NR), V1p = vpad(V1);
   L.fcT = b.take(N * Dfc * S);
   L.attT = b.take(NR * D * S);
   L.row_len = (int*)b.take(N * sizeof(int));
@@ -104,7 +108,7 @@ Layout make_layout(const uic_topdown_dims& d, void* ws) {
   if (A * NRp > ta) ta = A * NRp;
   if (H * NRp > ta) ta = H * NRp;
   if (4 * H * Np > ta) ta = 4 * H * Np;
-  size_t tb = (H > E ? H : E) * Mp;
+  size_t tb = (2 * H + E) * Mp;      // up to three stacked right operands of the merged LSTM weight-gradient GEMMs
   if ((H > D ? H : D) * NRp > tb) tb = (H > D ? H : D) * NRp;
   if ((H > Dfc ? H : Dfc) * Np > tb) tb = (H > Dfc ? H : Dfc) * Np;
   L.tA = b.take(ta * S);
@@ -115,6 +119,13 @@ Layout make_layout(const uic_topdown_dims& d, void* ws) {
   L.colscratch_floats = 128 * maxcols;
   L.colscratch = (float*)b.take(L.colscratch_floats * 4);
   L.small = (float*)b.take((A + 8) * 4);
+  {  // split-K partial slabs: room for 4 slices of the largest merged weight gradient [4H, 2H + E]
+    size_t sl = 4 * (4 * H) * (2 * H + E) * 4;
+    const size_t cap = (size_t)256 << 20;
+    if (sl > cap) sl = cap;
+    L.slab_bytes = sl;
+    L.slab = (float*)b.take(sl);
+  }
   for (int i = 0; i < 2; ++i) {
     L.s_h_att[i] = b.take(N * H * S);
     L.s_h_lang[i] = b.take(N * H * S);
@@ -152,7 +163,7 @@ Derived make_derived(const uic_topdown_dims& d, const uic_topdown_weights* w, vo
   memset(&v, 0, sizeof(v));
   Bump b{(char*)base, 0};
   const size_t S = uic_dtype_size(d.dtype);
-  const size_t D = d.D, Dfc = d.Dfc, H = d.H, E = d.E, A = d.A, V1 = d.V1, V1p = rup8(V1);
+  const size_t D = d.D, Dfc = d.Dfc, H = d.H, E = d.E, A = d.A, V1 = d.V1, V1p = vpad(V1);
   const bool bf = d.dtype == UIC_BF16;
   auto copy = [&](const float* master, size_t n) -> const void* {
     if (!bf) return master;
@@ -200,6 +211,38 @@ UicGemmParams gemm_base(int dtype, int M, int N) {
 inline void add_seg(UicGemmParams& g, const void* A, int lda, const void* B, int ldb, int K) {
   UicGemmSeg& s = g.seg[g.nseg++];
   s.A = A; s.B = B; s.K = K; s.lda = lda; s.ldb = ldb;
+}
+
+// Weight gradient(s) C_i = left[lrows, K] * right[cols_i, K]^T for one or several destinations that share `left`
+// (right operands stacked row-wise in `right`).  Long-K, few-tile problems run split-K over workgroups on the
+// LDS-DMA GEMM with deterministic slab reduction; anything else falls back to one direct GEMM per destination.
+struct WDest { float* C; int ldc; int col0; int ncols; };
+int wgrad_multi(const Layout& L, int dt, const void* left, int lrows, const void* right, int rrows, int K,
+                const WDest* dst, int nd, hipStream_t s) {
+  const long blocks = (long)((lrows + 127) / 128) * ((rrows + 127) / 128);
+  if (uic_gemm_glds_eligible(dt, K) && lrows >= 128 && rrows >= 128) {
+    const int nt = K / (dt == UIC_BF16 ? 64 : 32);
+    int sk = (int)((384 + blocks - 1) / blocks);
+    if (sk > 8) sk = 8;
+    if (sk > nt / 4) sk = nt / 4 > 0 ? nt / 4 : 1;
+    while (sk > 1 && (size_t)sk * lrows * rrows * 4 > L.slab_bytes) --sk;
+    if ((size_t)sk * lrows * rrows * 4 <= L.slab_bytes && (sk > 1 || nd > 1)) {
+      UicGemmParams g = gemm_base(dt, lrows, rrows);
+      add_seg(g, left, K, right, K, K);
+      g.splitk = sk; g.slab = L.slab;
+      UIC_TRY(uic_gemm_launch(g, s));
+      for (int i = 0; i < nd; ++i)
+        UIC_TRY(uic_splitk_reduce_launch(L.slab, sk, lrows, rrows, dst[i].col0, dst[i].ncols, dst[i].C, dst[i].ldc, s));
+      return UIC_OK;
+    }
+  }
+  for (int i = 0; i < nd; ++i) {
+    UicGemmParams g = gemm_base(dt, lrows, dst[i].ncols);
+    add_seg(g, left, K, (const char*)right + (size_t)dst[i].col0 * K * uic_dtype_size(dt), K, K);
+    g.C = dst[i].C; g.ldc = dst[i].ldc; g.flags = UIC_GEMM_OUT_F32;
+    UIC_TRY(uic_gemm_launch(g, s));
+  }
+  return UIC_OK;
 }
 
 __global__ void rowlen_kernel(const float* mask, int N, int R, int* out) {
@@ -302,7 +345,7 @@ int uic_topdown_refresh_weights(const uic_topdown_dims* d, const uic_topdown_wei
   const Derived v = make_derived(*d, w, derived);
   const int dt = d->dtype;
   const int D = d->D, Dfc = d->Dfc, H = d->H, E = d->E, A = d->A, V1 = d->V1;
-  const int V1p = (int)rup8(V1);
+  const int V1p = (int)vpad(V1);
   if (dt == UIC_BF16) {
     UIC_TRY(uic_cast_f32_launch(dt, w->fc_w, (void*)v.fc_w, (size_t)H * Dfc, s));
     UIC_TRY(uic_cast_f32_launch(dt, w->att_w, (void*)v.att_w, (size_t)H * D, s));
@@ -341,7 +384,7 @@ int uic_topdown_forward(const uic_topdown_dims* d, const uic_topdown_weights* w,
   const Derived dv = make_derived(*d, w, (void*)derived);
   const int dt = d->dtype;
   const int N = d->N, H = d->H, E = d->E, V1 = d->V1;
-  const int V1p = (int)rup8(V1), H4 = 4 * H, ldih = E + 2 * H;
+  const int V1p = (int)vpad(V1), H4 = 4 * H, ldih = E + 2 * H;
   const size_t S = uic_dtype_size(dt);
   const float drop_p = training ? d->drop_p : 0.f;
   const int Meff = t_run * N;
@@ -426,7 +469,7 @@ int uic_topdown_xe_loss(const uic_topdown_dims* d, const uic_topdown_batch* b, i
   UIC_REQUIRE(b->ld_labels >= d->T + 1 && b->ld_masks >= d->T + 1, "xe_loss: labels/masks need %d columns", d->T + 1);
   hipStream_t s = (hipStream_t)stream;
   const Layout L = make_layout(*d, workspace);
-  const int N = d->N, V1 = d->V1, V1p = (int)rup8(V1);
+  const int N = d->N, V1 = d->V1, V1p = (int)vpad(V1);
   // denominator: sum of masks[:, 1:T+1] over ALL T columns (criterion.py:146-149), also after an early break
   UIC_TRY(uic_masked_sum_launch(nullptr, b->masks, b->ld_masks, 1, N, d->T, L.scalars, L.scalars + 1, s));
   const float* inv = inv_den ? inv_den : L.scalars + 1;
@@ -455,7 +498,7 @@ int uic_topdown_backward(const uic_topdown_dims* d, const uic_topdown_weights* w
   const Derived dv = make_derived(*d, w, (void*)derived);
   const int dt = d->dtype;
   const int N = d->N, R = d->R, D = d->D, Dfc = d->Dfc, H = d->H, E = d->E, A = d->A, V1 = d->V1;
-  const int V1p = (int)rup8(V1), H4 = 4 * H, ldih = E + 2 * H;
+  const int V1p = (int)vpad(V1), H4 = 4 * H, ldih = E + 2 * H;
   const size_t S = uic_dtype_size(dt);
   const float drop_p = training ? d->drop_p : 0.f;
   const float inv_keep = drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f;
@@ -469,10 +512,8 @@ int uic_topdown_backward(const uic_topdown_dims* d, const uic_topdown_weights* w
 
   auto wgrad = [&](const void* left, int lrows, const void* right, int rrows, int K, float* C, int ldc) -> int {
     // C[lrows, rrows] = left[lrows, K] right[rrows, K]^T   (both already transposed, K = padded row count)
-    UicGemmParams g = gemm_base(dt, lrows, rrows);
-    add_seg(g, left, K, right, K, K);
-    g.C = C; g.ldc = ldc; g.flags = UIC_GEMM_OUT_F32;
-    return uic_gemm_launch(g, s);
+    const WDest d1{C, ldc, 0, rrows};
+    return wgrad_multi(L, dt, left, lrows, right, rrows, K, &d1, 1, s);
   };
 
   // ---- logit layer
@@ -548,24 +589,27 @@ int uic_topdown_backward(const uic_topdown_dims* d, const uic_topdown_weights* w
     }
   }
 
-  // ---- weight gradients, one GEMM per weight block over all executed steps
-  // lang_lstm
+  // ---- weight gradients over all executed steps: per LSTM ONE GEMM dG^T [4H, T*N] x [stacked inputs]^T
+  // lang_lstm: inputs [att_res | h_att | h_lang_prev]
   UIC_TRY(uic_transpose_launch(dt, L.dg2_all, Meff, H4, H4, L.tA, Mp, s));
   UIC_TRY(uic_transpose_launch(dt, L.ctx_all, Meff, H, H, L.tB, Mp, s));
-  UIC_TRY(wgrad(L.tA, H4, L.tB, H, Mp, G->lang_lstm_w_ih, 2 * H));
-  UIC_TRY(uic_transpose_launch(dt, off(L.h_att, NH, dt), Meff, H, H, L.tB, Mp, s));
-  UIC_TRY(wgrad(L.tA, H4, L.tB, H, Mp, G->lang_lstm_w_ih + H, 2 * H));
-  UIC_TRY(uic_transpose_launch(dt, L.h_lang, Meff, H, H, L.tB, Mp, s));
-  UIC_TRY(wgrad(L.tA, H4, L.tB, H, Mp, G->lang_lstm_w_hh, H));
+  UIC_TRY(uic_transpose_launch(dt, off(L.h_att, NH, dt), Meff, H, H, offw(L.tB, (size_t)H * Mp, dt), Mp, s));
+  UIC_TRY(uic_transpose_launch(dt, L.h_lang, Meff, H, H, offw(L.tB, (size_t)2 * H * Mp, dt), Mp, s));
+  {
+    const WDest dd[2] = {{G->lang_lstm_w_ih, 2 * H, 0, 2 * H}, {G->lang_lstm_w_hh, H, 2 * H, H}};
+    UIC_TRY(wgrad_multi(L, dt, L.tA, H4, L.tB, 3 * H, Mp, dd, 2, s));
+  }
   UIC_TRY(uic_colsum_launch(dt, L.dg2_all, Meff, H4, H4, G->lang_lstm_b_ih, L.colscratch, L.colscratch_floats, s));
   UIC_TRY(uic_check_hip(hipMemcpyAsync(G->lang_lstm_b_hh, G->lang_lstm_b_ih, (size_t)H4 * 4, hipMemcpyDeviceToDevice, s), "memcpy b_hh"));
-  // att_lstm
+  // att_lstm: inputs [h_lang_prev | xt | h_att_prev]  (the fc' columns are handled below from dGfc)
   UIC_TRY(uic_transpose_launch(dt, L.dg1_all, Meff, H4, H4, L.tA, Mp, s));
-  UIC_TRY(wgrad(L.tA, H4, L.tB, H, Mp, G->att_lstm_w_ih, ldih));                 // tB still holds h_lang_prev^T
-  UIC_TRY(uic_transpose_launch(dt, L.xt_all, Meff, E, E, L.tB, Mp, s));
-  UIC_TRY(wgrad(L.tA, H4, L.tB, E, Mp, G->att_lstm_w_ih + 2 * H, ldih));
-  UIC_TRY(uic_transpose_launch(dt, L.h_att, Meff, H, H, L.tB, Mp, s));
-  UIC_TRY(wgrad(L.tA, H4, L.tB, H, Mp, G->att_lstm_w_hh, H));
+  UIC_TRY(uic_transpose_launch(dt, L.h_lang, Meff, H, H, L.tB, Mp, s));
+  UIC_TRY(uic_transpose_launch(dt, L.xt_all, Meff, E, E, offw(L.tB, (size_t)H * Mp, dt), Mp, s));
+  UIC_TRY(uic_transpose_launch(dt, L.h_att, Meff, H, H, offw(L.tB, (size_t)(H + E) * Mp, dt), Mp, s));
+  {
+    const WDest dd[3] = {{G->att_lstm_w_ih, ldih, 0, H}, {G->att_lstm_w_ih + 2 * H, ldih, H, E}, {G->att_lstm_w_hh, H, H + E, H}};
+    UIC_TRY(wgrad_multi(L, dt, L.tA, H4, L.tB, 2 * H + E, Mp, dd, 3, s));
+  }
   UIC_TRY(uic_colsum_launch(dt, L.dg1_all, Meff, H4, H4, G->att_lstm_b_ih, L.colscratch, L.colscratch_floats, s));
   UIC_TRY(uic_check_hip(hipMemcpyAsync(G->att_lstm_b_hh, G->att_lstm_b_ih, (size_t)H4 * 4, hipMemcpyDeviceToDevice, s), "memcpy b_hh"));
   {  // d xt -> embedding table
@@ -646,7 +690,7 @@ int uic_topdown_sample(const uic_topdown_dims* d, const uic_topdown_weights* w, 
   const Derived dv = make_derived(*d, w, (void*)derived);
   const int dt = d->dtype;
   const int N = d->N, H = d->H, E = d->E, V1 = d->V1;
-  const int V1p = (int)rup8(V1), H4 = 4 * H, ldih = E + 2 * H;
+  const int V1p = (int)vpad(V1), H4 = 4 * H, ldih = E + 2 * H;
   const size_t S = uic_dtype_size(dt);
   const size_t NH = (size_t)N * H;
   const void *fc_in, *att_in;

@@ -95,14 +95,18 @@ __device__ __forceinline__ float uic_sigmoid(float x) { return 1.f / (1.f + expf
 template <typename T> __device__ __forceinline__ float uic_tanh(float x);
 template <> __device__ __forceinline__ float uic_tanh<float>(float x) { return tanhf(x); }
 template <> __device__ __forceinline__ float uic_tanh<bf16_t>(float x) {
-  float e = __expf(2.f * x);
-  return 1.f - __fdividef(2.f, e + 1.f);
+  // 1 - 2 / (1 + e^{2x}) with v_exp_f32 / v_rcp_f32 (1 ulp-class hardware ops; saturates correctly at +-inf).
+  // NB: __fdividef expands to the full IEEE division sequence on gfx950 (10 instructions), hence the builtins.
+  const float e = __builtin_amdgcn_exp2f(x * 2.8853900817779268f);
+  return 1.f - 2.f * __builtin_amdgcn_rcpf(e + 1.f);
 }
 
 // sigmoid: libm exp on the f32 path, hardware exp + fast reciprocal on the bf16 path
 template <typename T> __device__ __forceinline__ float uic_sigmoid_t(float x);
 template <> __device__ __forceinline__ float uic_sigmoid_t<float>(float x) { return 1.f / (1.f + expf(-x)); }
-template <> __device__ __forceinline__ float uic_sigmoid_t<bf16_t>(float x) { return __fdividef(1.f, 1.f + __expf(-x)); }
+template <> __device__ __forceinline__ float uic_sigmoid_t<bf16_t>(float x) {
+  return __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(x * -1.4426950408889634f));
+}
 
 __device__ __forceinline__ float uic_wave_sum(float v) {
 #pragma unroll
@@ -151,7 +155,14 @@ struct UicGemmParams {
   void* h_out; int ldh;            // [M,H] operand dtype
   void* h_drop; int ldhd;          // dropout(h) copy, or null
   void* gates_out;                 // [M,4H] activated gates (i,f,g,o), operand dtype, or null
+  // ---- split-K over workgroups (large-GEMM path only): slice z of `splitk` writes its raw partial tile to
+  // slab[z][M][N] (f32, dense); uic_splitk_reduce_launch sums the slabs in a fixed order (deterministic)
+  int splitk; float* slab;
 };
+// C[row, c - col0] = sum_z slab[z][row, c] for c in [col0, col0 + ncols)
+int uic_splitk_reduce_launch(const float* slab, int splitk, int M, int N, int col0, int ncols, float* C, int ldc, hipStream_t s);
+// true if the large-GEMM (LDS-DMA) path accepts this single-segment problem
+bool uic_gemm_glds_eligible(int dtype, int K);
 
 int uic_gemm_launch(const UicGemmParams& p, hipStream_t stream);
 
