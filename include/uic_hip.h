@@ -110,6 +110,15 @@ int uic_topdown_backward(const uic_topdown_dims* d, const uic_topdown_weights* w
                          void* workspace, const float* dlogprobs, const float* logprobs,
                          const uic_topdown_weights* grads, void* stream);
 
+/* One fused XE training step = uic_topdown_forward + uic_topdown_xe_loss + uic_topdown_backward (what
+ * P/trainer.py:164-165,173 do), scheduled on TWO HIP streams: the recurrence runs on `stream`, the logit layer
+ * of finished decode steps (logit GEMM, log-softmax + criterion, dH, dW_logit) on a library-owned side stream,
+ * joined back into `stream` before return.  Results are identical to the three separate calls. */
+int uic_topdown_xe_train_step(const uic_topdown_dims* d, const uic_topdown_weights* w, const void* derived,
+                              const uic_topdown_batch* batch, int32_t t_run, int32_t training, uint32_t seed,
+                              void* workspace, const float* inv_den, float* loss_out, float* den_out,
+                              const uic_topdown_weights* grads, void* stream);
+
 /* AttModel._sample with beam_size = 1 (P/models/AttModel.py:198-253): greedy (sample_max = 1) or
  * multinomial decode of `L` <= d->T tokens.  seq [N, L] int64 and seq_logp [N, L] f32 are fully written.
  * `forced` (optional, [N, L] int64) replaces the multinomial draws (parity tests). */

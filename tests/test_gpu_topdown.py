@@ -173,6 +173,27 @@ def test_multinomial_sampling_scored_by_oracle():
     assert torch.equal(seq_o2, seq2.cpu()) and absmax(lp2, lp_o2) < 1e-3
 
 
+def test_two_stream_train_step_equals_separate_calls():
+    """uic_topdown_xe_train_step (recurrence + side-stream logit layer) == forward, xe_loss, backward in sequence."""
+    from unpaired_image_captioning_amd.trainer import xe_step
+    cfg, W, I, Out, G, X = load_golden("topdown_odd")
+    for dtype in ("f32", "bf16"):
+        model = build_model(cfg, W, dtype, drop=0.5)
+        model.train()
+        batch = {k: I[k].cuda() for k in ("fc_feats", "att_feats", "labels", "masks", "att_masks")}
+        model._seed_counter = 77
+        l1, g1 = xe_step(model, batch, fused=True)
+        model._seed_counter = 77
+        l2, g2 = xe_step(model, batch, fused=False)
+        torch.cuda.synchronize()
+        assert l1.item() == l2.item()
+        for k in g1:
+            if k == "embed.0.weight":        # scatter-add by float atomics: summation order may differ
+                assert (g1[k] - g2[k]).abs().max().item() <= 1e-6 * max(1.0, g2[k].abs().max().item())
+            else:
+                assert torch.equal(g1[k], g2[k]), k
+
+
 def test_fused_xe_path_equals_api_path():
     """Trainer's fused log-softmax + criterion + backward == materialised log-probs + LanguageModelCriterion."""
     from unpaired_image_captioning_amd.trainer import xe_step

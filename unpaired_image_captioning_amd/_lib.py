@@ -71,6 +71,9 @@ _SIGS = {
     "uic_topdown_backward": (C.c_int, [C.POINTER(Dims), C.POINTER(Weights), C.c_void_p, C.POINTER(Batch), C.c_int32,
                                        C.c_int32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(Weights),
                                        C.c_void_p]),
+    "uic_topdown_xe_train_step": (C.c_int, [C.POINTER(Dims), C.POINTER(Weights), C.c_void_p, C.POINTER(Batch), C.c_int32,
+                                            C.c_int32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                            C.POINTER(Weights), C.c_void_p]),
     "uic_topdown_sample": (C.c_int, [C.POINTER(Dims), C.POINTER(Weights), C.c_void_p, C.POINTER(Batch), C.c_int32,
                                      C.c_int32, C.c_float, C.c_int32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p,
                                      C.c_void_p, C.c_void_p]),

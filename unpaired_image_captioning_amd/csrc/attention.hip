@@ -244,8 +244,8 @@ __global__ __launch_bounds__(NTHREADS) void attn_fwd_fast_kernel(const UicAttnPa
   constexpr int VEC = uic_vec<T>::N;
   extern __shared__ __attribute__((aligned(16))) float sm[];
   const int A = p.A, H = p.H, R = p.R;
-  float* s_e = sm;
-  float* s_red = s_e + ((R + 3) & ~3);
+  float* s_e = sm;                    // [R][4] row-of-16 partial scores
+  float* s_red = s_e + 4 * R;
   const int n = blockIdx.x;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const bool la = lane < A / VEC, lh = lane < H / VEC;
@@ -270,13 +270,17 @@ __global__ __launch_bounds__(NTHREADS) void attn_fwd_fast_kernel(const UicAttnPa
     float part = 0.f;
 #pragma unroll
     for (int j = 0; j < VEC; ++j) part += w[j] * uic_tanh<T>(f[j] + ah[j]);
-    part = uic_wave_sum(part);
-    if (lane == 0 && r < R) s_e[r] = part + b_alpha;
+    part = uic_row16_sum(part);                       // 4 row sums per region, added when the scores are read
+    if ((lane & 15) == 0 && r < R) s_e[r * 4 + (lane >> 4)] = part;
   }
   __syncthreads();
   // every wave normalises the R <= 64 scores with one lane per region (softmax, then mask-renormalise)
   const float* mk = p.mask ? p.mask + (size_t)n * p.ldmask : nullptr;
-  const float e = lane < R ? s_e[lane] : -INFINITY;
+  float e = -INFINITY;
+  if (lane < R) {
+    const float4 q = *(const float4*)(s_e + lane * 4);
+    e = (q.x + q.y) + (q.z + q.w) + b_alpha;
+  }
   const float mx = uic_wave_max(e);
   const float ex = lane < R ? expf(e - mx) : 0.f;
   float wgt = ex * (1.f / uic_wave_sum(ex));
@@ -315,8 +319,8 @@ __global__ __launch_bounds__(NTHREADS) void attn_bwd_step_fast_kernel(const UicA
   const int A = p.A, H = p.H, R = p.R;
   const int Rp = (R + 3) & ~3;
   float* s_al = sm;
-  float* s_da = s_al + Rp;
-  float* s_red = s_da + Rp;
+  float* s_da4 = s_al + Rp;           // [R][4] row-of-16 partial d alpha
+  float* s_red = s_da4 + 4 * Rp;
   const int n = blockIdx.x;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const bool la = lane < A / VEC, lh = lane < H / VEC;
@@ -340,23 +344,28 @@ __global__ __launch_bounds__(NTHREADS) void attn_bwd_step_fast_kernel(const UicA
     float part = 0.f;
 #pragma unroll
     for (int j = 0; j < VEC; ++j) part += dc[j] * f[j];
-    part = uic_wave_sum(part);
-    if (lane == 0 && r < R) s_da[r] = part;
+    part = uic_row16_sum(part);
+    if ((lane & 15) == 0 && r < R) s_da4[r * 4 + (lane >> 4)] = part;
   }
   __syncthreads();
-  float wbar = 0.f;
-  for (int r = 0; r < R; ++r) wbar += s_al[r] * s_da[r];
+  // one lane per region: d alpha_r, then wbar = sum_r alpha_r d alpha_r by a wave reduction (every wave redundantly)
+  float da_l = 0.f, al_l = 0.f;
+  if (lane < R) {
+    const float4 q = *(const float4*)(s_da4 + lane * 4);
+    da_l = (q.x + q.y) + (q.z + q.w);
+    al_l = s_al[lane];
+  }
+  const float wbar = uic_wave_sum(al_l * da_l);
+  const float de_l = al_l * (da_l - wbar);
+  if (wave == 0 && lane < R) p.de[(size_t)n * R + lane] = de_l;
   float acc[VEC];
 #pragma unroll
   for (int j = 0; j < VEC; ++j) acc[j] = 0.f;
 #pragma unroll
   for (int u = 0; u < UB; ++u) {
     const int r = wave + u * NWAVES;
-    float de = 0.f;
-    if (r < R) {
-      de = s_al[r] * (s_da[r] - wbar);
-      if (lane == 0) p.de[(size_t)n * R + r] = de;
-    }
+    float de = __shfl(de_l, r < R ? r : 0, 64);
+    if (r >= R) de = 0.f;
     float f[VEC];
     uic_unpack<T>(vp[u], f);
 #pragma unroll
@@ -486,7 +495,7 @@ int uic_attention_fwd_launch(const UicAttnParams& p, hipStream_t s) {
   UIC_TRY(check_common(p.dtype, p.N, p.R, p.A, p.H));
   UIC_REQUIRE(p.att_h && p.p_att && p.att && p.w_alpha && p.alpha && p.ctx, "attention_fwd: null pointer");
   if (p.N == 0) return UIC_OK;
-  const size_t lds = sizeof(float) * (2 * (size_t)p.A + ((p.R + 3) & ~3) + NWAVES * (size_t)p.H);
+  const size_t lds = sizeof(float) * (2 * (size_t)p.A + 4 * (size_t)p.R + 4 + NWAVES * (size_t)p.H);
   UIC_REQUIRE(lds <= 160 * 1024, "attention_fwd: needs %zu B of LDS", lds);
   if (fast_ok(p)) {
     if (p.dtype == UIC_BF16)
@@ -506,7 +515,7 @@ int uic_attention_bwd_step_launch(const UicAttnParams& p, hipStream_t s) {
   UIC_REQUIRE(p.att_h && p.p_att && p.att && p.w_alpha && p.alpha && p.dctx && p.de && p.d_att_h,
               "attention_bwd_step: null pointer");
   if (p.N == 0) return UIC_OK;
-  const size_t lds = sizeof(float) * (2 * (size_t)p.A + p.H + 2 * ((p.R + 3) & ~3) + NWAVES * (size_t)p.A);
+  const size_t lds = sizeof(float) * (2 * (size_t)p.A + p.H + 5 * ((p.R + 3) & ~3) + NWAVES * (size_t)p.A);
   UIC_REQUIRE(lds <= 160 * 1024, "attention_bwd_step: needs %zu B of LDS", lds);
   if (fast_ok(p)) {
     if (p.dtype == UIC_BF16)

@@ -13,6 +13,7 @@
 #include "uic_common.h"
 #include "../../include/uic_hip.h"
 #include <string.h>
+#include <stdlib.h>
 
 namespace {
 
@@ -43,6 +44,7 @@ struct Layout {
   float* d_att; void* d_patt; float* dwalpha_part; void* d_pre;
   void* tA; void* tB; float* colscratch; size_t colscratch_floats; float* small;
   float* slab; size_t slab_bytes;
+  void* tLA; void* tLB; float* colscratchL;   // scratch of the logit-layer weight gradients (side stream)
   // sampling
   void* s_h_att[2]; void* s_h_lang[2]; float* s_c_att[2]; float* s_c_lang[2];
   void* s_xt; float* s_atth; float* s_alpha; void* s_ctx; float* s_logits;
@@ -102,8 +104,7 @@ Layout make_layout(const uic_topdown_dims& d, void* ws) {
   L.d_patt = b.take(NR * A * S);
   L.dwalpha_part = (float*)b.take(N * (A + 1) * 4);
   L.d_pre = b.take(NR * H * S);
-  size_t ta = V1 * Mp;
-  if (4 * H * Mp > ta) ta = 4 * H * Mp;
+  size_t ta = 4 * H * Mp;
   if (A * Mp > ta) ta = A * Mp;
   if (A * NRp > ta) ta = A * NRp;
   if (H * NRp > ta) ta = H * NRp;
@@ -119,6 +120,9 @@ Layout make_layout(const uic_topdown_dims& d, void* ws) {
   L.colscratch_floats = 128 * maxcols;
   L.colscratch = (float*)b.take(L.colscratch_floats * 4);
   L.small = (float*)b.take((A + 8) * 4);
+  L.tLA = b.take(V1 * Mp * S);
+  L.tLB = b.take(H * Mp * S);
+  L.colscratchL = (float*)b.take(L.colscratch_floats * 4);
   {  // split-K partial slabs: room for 4 slices of the largest merged weight gradient [4H, 2H + E]
     size_t sl = 4 * (4 * H) * (2 * H + E) * 4;
     const size_t cap = (size_t)256 << 20;
@@ -371,47 +375,110 @@ int uic_topdown_refresh_weights(const uic_topdown_dims* d, const uic_topdown_wei
   return UIC_OK;
 }
 
-int uic_topdown_forward(const uic_topdown_dims* d, const uic_topdown_weights* w, const void* derived,
-                        const uic_topdown_batch* b, int32_t t_run, int32_t training, uint32_t seed,
-                        void* workspace, float* logprobs_out, void* stream) {
-  UIC_TRY(check_dims(d));
-  UIC_REQUIRE(w && derived && b && workspace, "forward: null pointer");
-  UIC_REQUIRE(b->fc_feats && b->att_feats && b->labels, "forward: batch needs fc_feats, att_feats and labels");
-  UIC_REQUIRE(t_run >= 1 && t_run <= d->T, "forward: t_run=%d outside [1,%d]", t_run, d->T);
-  UIC_REQUIRE(b->ld_labels >= t_run, "forward: labels have %d columns, need %d", b->ld_labels, t_run);
-  hipStream_t s = (hipStream_t)stream;
-  const Layout L = make_layout(*d, workspace);
-  const Derived dv = make_derived(*d, w, (void*)derived);
-  const int dt = d->dtype;
-  const int N = d->N, H = d->H, E = d->E, V1 = d->V1;
-  const int V1p = (int)vpad(V1), H4 = 4 * H, ldih = E + 2 * H;
-  const size_t S = uic_dtype_size(dt);
-  const float drop_p = training ? d->drop_p : 0.f;
-  const int Meff = t_run * N;
+}  // extern "C" (re-opened below)
 
-  const void *fc_in, *att_in;
-  UIC_TRY(prepare_features(*d, w, dv, b, L, drop_p, seed, &fc_in, &att_in, s));
-  // xt_t = dropout(relu(embed[labels[:, t]])) for all steps (AttModel.py:145,160)
-  UIC_TRY(uic_embed_fwd_launch(dt, w->embed_w, V1, E, b->labels, b->ld_labels, N, t_run, drop_p, seed, UIC_SITE_EMBED, L.xt_all, s));
-  {  // Gx = xt W_ih[:, 2H:]^T + b_ih + b_hh, all steps
-    UicGemmParams g = gemm_base(dt, Meff, H4);
-    add_seg(g, L.xt_all, E, off(dv.att_w_ih, 2 * H, dt), ldih, E);
-    g.C = L.gx; g.ldc = H4; g.bias = w->att_lstm_b_ih; g.bias2 = w->att_lstm_b_hh; g.flags = UIC_GEMM_OUT_F32;
-    UIC_TRY(uic_gemm_launch(g, s));
-  }
-  {  // Gfc = fc' W_ih[:, H:2H]^T
-    UicGemmParams g = gemm_base(dt, N, H4);
-    add_seg(g, L.fcp, H, off(dv.att_w_ih, H, dt), ldih, H);
-    g.C = L.gfc; g.ldc = H4; g.flags = UIC_GEMM_OUT_F32;
-    UIC_TRY(uic_gemm_launch(g, s));
-  }
-  const size_t NH = (size_t)N * H;
-  UIC_TRY(uic_fill_launch(L.h_att, 0, NH * S, s));     // init_hidden (AttModel.py:94-97)
-  UIC_TRY(uic_fill_launch(L.h_lang, 0, NH * S, s));
-  UIC_TRY(uic_fill_launch(L.c_att, 0, NH * 4, s));
-  UIC_TRY(uic_fill_launch(L.c_lang, 0, NH * 4, s));
+namespace {
 
-  for (int t = 0; t < t_run; ++t) {
+// Side stream + events for the fused training step: the logit layer of finished decode steps (logit GEMM,
+// log-softmax/criterion, dH GEMM, later dW_logit) runs beside the latency-bound recurrence on a second HIP stream.
+constexpr int MAX_CHUNKS = 64;
+struct SideStream {
+  hipStream_t stream = nullptr;
+  hipEvent_t ev_den = nullptr, ev_done = nullptr;
+  hipEvent_t ev_main[MAX_CHUNKS];   // main  -> side: decode steps of chunk c are finished
+  hipEvent_t ev_side[MAX_CHUNKS];   // side  -> main: d hdrop of chunk c is ready
+  bool ready = false;
+};
+SideStream g_side[16];
+
+int get_side(SideStream** out) {
+  int dev = 0;
+  UIC_TRY(uic_check_hip(hipGetDevice(&dev), "hipGetDevice"));
+  UIC_REQUIRE(dev >= 0 && dev < 16, "device index %d out of range", dev);
+  SideStream& ss = g_side[dev];
+  if (!ss.ready) {
+    // The side stream is confined to a subset of the CUs (UIC_SIDE_CUS=n, experiment only; default: no mask):
+    // its large GEMMs would otherwise fill every CU and the latency-bound recurrence kernels of the main
+    // stream would queue behind them, which costs more than the overlap gains.
+    int ncu = 0;   // measured on MI355X: masking the side stream to 64..160 CUs is 1.6-2x SLOWER than no mask
+    if (const char* e = getenv("UIC_SIDE_CUS")) ncu = atoi(e);
+    if (ncu > 0 && ncu < 256) {
+      uint32_t mask[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+      for (int i = 0; i < ncu; ++i) mask[i >> 5] |= 1u << (i & 31);
+      UIC_TRY(uic_check_hip(hipExtStreamCreateWithCUMask(&ss.stream, 8, mask), "hipExtStreamCreateWithCUMask"));
+    } else {
+      UIC_TRY(uic_check_hip(hipStreamCreateWithFlags(&ss.stream, hipStreamNonBlocking), "hipStreamCreateWithFlags"));
+    }
+    UIC_TRY(uic_check_hip(hipEventCreateWithFlags(&ss.ev_den, hipEventDisableTiming), "hipEventCreate"));
+    UIC_TRY(uic_check_hip(hipEventCreateWithFlags(&ss.ev_done, hipEventDisableTiming), "hipEventCreate"));
+    for (int i = 0; i < MAX_CHUNKS; ++i) {
+      UIC_TRY(uic_check_hip(hipEventCreateWithFlags(&ss.ev_main[i], hipEventDisableTiming), "hipEventCreate"));
+      UIC_TRY(uic_check_hip(hipEventCreateWithFlags(&ss.ev_side[i], hipEventDisableTiming), "hipEventCreate"));
+    }
+    ss.ready = true;
+  }
+  *out = &ss;
+  return UIC_OK;
+}
+
+// One teacher-forced step of the captioner on one GPU, split into the pieces the public entry points
+// (and the two-stream fused training step) sequence.
+struct Step {
+  uic_topdown_dims d;
+  const uic_topdown_weights* w;
+  const uic_topdown_batch* b;
+  const uic_topdown_weights* G;
+  Layout L;
+  Derived dv;
+  int dt, N, R, D, Dfc, H, E, A, V1, V1p, H4, ldih, t_run, Meff, Mp, Np, NR, NRp;
+  size_t S, NH;
+  float drop_p, inv_keep;
+  unsigned seed;
+  const void* fc_in;
+  const void* att_in;
+
+  void init(const uic_topdown_dims* d_, const uic_topdown_weights* w_, const void* derived, const uic_topdown_batch* b_,
+            int t_run_, int training, unsigned seed_, void* workspace, const uic_topdown_weights* G_) {
+    d = *d_; w = w_; b = b_; G = G_;
+    L = make_layout(d, workspace);
+    dv = make_derived(d, w, (void*)derived);
+    dt = d.dtype; N = d.N; R = d.R; D = d.D; Dfc = d.Dfc; H = d.H; E = d.E; A = d.A; V1 = d.V1;
+    V1p = (int)vpad(V1); H4 = 4 * H; ldih = E + 2 * H; t_run = t_run_;
+    Meff = t_run * N; Mp = (int)rup8(Meff); Np = (int)rup8(N); NR = N * R; NRp = (int)rup8(NR);
+    S = uic_dtype_size(dt); NH = (size_t)N * H;
+    drop_p = training ? d.drop_p : 0.f;
+    inv_keep = drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f;
+    seed = seed_;
+    fc_in = dt == UIC_BF16 ? L.fcT : (const void*)b->fc_feats;
+    att_in = dt == UIC_BF16 ? L.attT : (const void*)b->att_feats;
+  }
+
+  // ---------------------------------------------------------------- forward
+  int fwd_prologue(hipStream_t s) {
+    const void *f, *a;
+    UIC_TRY(prepare_features(d, w, dv, b, L, drop_p, seed, &f, &a, s));
+    // xt_t = dropout(relu(embed[labels[:, t]])) for all steps (AttModel.py:145,160)
+    UIC_TRY(uic_embed_fwd_launch(dt, w->embed_w, V1, E, b->labels, b->ld_labels, N, t_run, drop_p, seed, UIC_SITE_EMBED, L.xt_all, s));
+    {  // Gx = xt W_ih[:, 2H:]^T + b_ih + b_hh, all steps
+      UicGemmParams g = gemm_base(dt, Meff, H4);
+      add_seg(g, L.xt_all, E, off(dv.att_w_ih, 2 * H, dt), ldih, E);
+      g.C = L.gx; g.ldc = H4; g.bias = w->att_lstm_b_ih; g.bias2 = w->att_lstm_b_hh; g.flags = UIC_GEMM_OUT_F32;
+      UIC_TRY(uic_gemm_launch(g, s));
+    }
+    {  // Gfc = fc' W_ih[:, H:2H]^T
+      UicGemmParams g = gemm_base(dt, N, H4);
+      add_seg(g, L.fcp, H, off(dv.att_w_ih, H, dt), ldih, H);
+      g.C = L.gfc; g.ldc = H4; g.flags = UIC_GEMM_OUT_F32;
+      UIC_TRY(uic_gemm_launch(g, s));
+    }
+    UIC_TRY(uic_fill_launch(L.h_att, 0, NH * S, s));     // init_hidden (AttModel.py:94-97)
+    UIC_TRY(uic_fill_launch(L.h_lang, 0, NH * S, s));
+    UIC_TRY(uic_fill_launch(L.c_att, 0, NH * 4, s));
+    UIC_TRY(uic_fill_launch(L.c_lang, 0, NH * 4, s));
+    return UIC_OK;
+  }
+
+  int fwd_step(int t, hipStream_t s) {
     const void* h_att_prev = off(L.h_att, t * NH, dt);
     void* h_att_new = offw(L.h_att, (t + 1) * NH, dt);
     const void* h_lang_prev = off(L.h_lang, t * NH, dt);
@@ -428,7 +495,7 @@ int uic_topdown_forward(const uic_topdown_dims* d, const uic_topdown_weights* w,
       g.gates_out = offw(L.gates1, (size_t)t * N * H4, dt);
       UIC_TRY(uic_gemm_launch(g, s));
     }
-    UIC_TRY(attention_step(*d, w, dv, b, L, h_att_new, L.atth_all + (size_t)t * N * d->A, L.alpha_all + (size_t)t * N * d->R,
+    UIC_TRY(attention_step(d, w, dv, b, L, h_att_new, L.atth_all + (size_t)t * N * A, L.alpha_all + (size_t)t * N * R,
                            offw(L.ctx_all, t * NH, dt), s));
     {  // lang_lstm on cat([att_res, h_att]) (AttModel.py:438-441) + output dropout (:443)
       UicGemmParams g = gemm_base(dt, N, H4);
@@ -444,94 +511,60 @@ int uic_topdown_forward(const uic_topdown_dims* d, const uic_topdown_weights* w,
       g.gates_out = offw(L.gates2, (size_t)t * N * H4, dt);
       UIC_TRY(uic_gemm_launch(g, s));
     }
+    return UIC_OK;
   }
-  {  // logits for all steps (AttModel.py:163)
-    UicGemmParams g = gemm_base(dt, Meff, V1);
-    add_seg(g, L.hdrop_all, H, dv.logit_w, H, H);
-    g.C = L.logits; g.ldc = V1p; g.bias = w->logit_b; g.flags = UIC_GEMM_OUT_F32;
-    UIC_TRY(uic_gemm_launch(g, s));
+
+  // logits of decode steps [t0, t1) (AttModel.py:163)
+  int logits_rows(int t0, int t1, hipStream_t s) {
+    UicGemmParams g = gemm_base(dt, (t1 - t0) * N, V1);
+    add_seg(g, off(L.hdrop_all, t0 * NH, dt), H, dv.logit_w, H, H);
+    g.C = L.logits + (size_t)t0 * N * V1p; g.ldc = V1p; g.bias = w->logit_b; g.flags = UIC_GEMM_OUT_F32;
+    return uic_gemm_launch(g, s);
   }
-  if (logprobs_out) {
+  // log-softmax + LanguageModelCriterion rows of steps [t0, t1): row losses and d logits
+  int xe_rows(int t0, int t1, const float* inv, float* logprobs_out, int with_loss, hipStream_t s) {
     UicXeParams x;
     memset(&x, 0, sizeof(x));
-    x.dtype = dt; x.M = Meff; x.V1 = V1; x.ldv = V1p; x.logits = L.logits; x.N = N;
-    x.logprobs = logprobs_out; x.lp_step_stride = V1; x.lp_row_stride = (size_t)d->T * V1;
-    UIC_TRY(uic_xe_launch(x, s));
+    const size_t r0 = (size_t)t0 * N;
+    x.dtype = dt; x.M = (t1 - t0) * N; x.V1 = V1; x.ldv = V1p; x.N = N;
+    x.logits = L.logits + r0 * V1p;
+    if (with_loss) {
+      x.dlogits = offw(L.dlogits, r0 * V1p, dt);
+      x.target = b->labels; x.ldtarget = b->ld_labels; x.target_col0 = 1 + t0;
+      x.mask = b->masks; x.ldmask = b->ld_masks; x.mask_col0 = 1 + t0;
+      x.inv_den = inv; x.row_loss = L.row_loss + r0; x.write_grad = 1;
+    }
+    if (logprobs_out) {
+      x.logprobs = logprobs_out + (size_t)t0 * V1; x.lp_step_stride = V1; x.lp_row_stride = (size_t)d.T * V1;
+    }
+    return uic_xe_launch(x, s);
   }
-  return UIC_OK;
-}
-
-int uic_topdown_xe_loss(const uic_topdown_dims* d, const uic_topdown_batch* b, int32_t t_run, void* workspace,
-                        const float* inv_den, float* loss_out, float* den_out, void* stream) {
-  UIC_TRY(check_dims(d));
-  UIC_REQUIRE(b && workspace && b->labels && b->masks && loss_out, "xe_loss: null pointer");
-  UIC_REQUIRE(t_run >= 1 && t_run <= d->T, "xe_loss: t_run=%d outside [1,%d]", t_run, d->T);
-  UIC_REQUIRE(b->ld_labels >= d->T + 1 && b->ld_masks >= d->T + 1, "xe_loss: labels/masks need %d columns", d->T + 1);
-  hipStream_t s = (hipStream_t)stream;
-  const Layout L = make_layout(*d, workspace);
-  const int N = d->N, V1 = d->V1, V1p = (int)vpad(V1);
-  // denominator: sum of masks[:, 1:T+1] over ALL T columns (criterion.py:146-149), also after an early break
-  UIC_TRY(uic_masked_sum_launch(nullptr, b->masks, b->ld_masks, 1, N, d->T, L.scalars, L.scalars + 1, s));
-  const float* inv = inv_den ? inv_den : L.scalars + 1;
-  UicXeParams x;
-  memset(&x, 0, sizeof(x));
-  x.dtype = d->dtype; x.M = t_run * N; x.V1 = V1; x.ldv = V1p; x.logits = L.logits; x.dlogits = L.dlogits; x.N = N;
-  x.target = b->labels; x.ldtarget = b->ld_labels; x.target_col0 = 1;
-  x.mask = b->masks; x.ldmask = b->ld_masks; x.mask_col0 = 1;
-  x.inv_den = inv; x.row_loss = L.row_loss; x.write_grad = 1;
-  UIC_TRY(uic_xe_launch(x, s));
-  UIC_TRY(uic_reduce_sum_launch(L.row_loss, (size_t)t_run * N, 0.f, inv, loss_out, s));
-  if (den_out) UIC_TRY(uic_check_hip(hipMemcpyAsync(den_out, L.scalars, 4, hipMemcpyDeviceToDevice, s), "hipMemcpyAsync"));
-  return UIC_OK;
-}
-
-int uic_topdown_backward(const uic_topdown_dims* d, const uic_topdown_weights* w, const void* derived,
-                         const uic_topdown_batch* b, int32_t t_run, int32_t training, uint32_t seed,
-                         void* workspace, const float* dlogprobs, const float* logprobs,
-                         const uic_topdown_weights* G, void* stream) {
-  UIC_TRY(check_dims(d));
-  UIC_REQUIRE(w && derived && b && workspace && G, "backward: null pointer");
-  UIC_REQUIRE(t_run >= 1 && t_run <= d->T, "backward: t_run=%d outside [1,%d]", t_run, d->T);
-  UIC_REQUIRE(!dlogprobs || logprobs, "backward: dlogprobs needs the forward log-probs");
-  hipStream_t s = (hipStream_t)stream;
-  const Layout L = make_layout(*d, workspace);
-  const Derived dv = make_derived(*d, w, (void*)derived);
-  const int dt = d->dtype;
-  const int N = d->N, R = d->R, D = d->D, Dfc = d->Dfc, H = d->H, E = d->E, A = d->A, V1 = d->V1;
-  const int V1p = (int)vpad(V1), H4 = 4 * H, ldih = E + 2 * H;
-  const size_t S = uic_dtype_size(dt);
-  const float drop_p = training ? d->drop_p : 0.f;
-  const float inv_keep = drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f;
-  const int Meff = t_run * N, Mp = (int)rup8(Meff), Np = (int)rup8(N), NR = N * R, NRp = (int)rup8(NR);
-  const size_t NH = (size_t)N * H;
-  const void* fc_in = dt == UIC_BF16 ? L.fcT : (const void*)b->fc_feats;
-  const void* att_in = dt == UIC_BF16 ? L.attT : (const void*)b->att_feats;
-
-  if (dlogprobs)
-    UIC_TRY(uic_logsoftmax_bwd_launch(dt, L.dlogits, Meff, V1, V1p, N, dlogprobs, (size_t)V1, (size_t)d->T * V1, logprobs, s));
-
-  auto wgrad = [&](const void* left, int lrows, const void* right, int rrows, int K, float* C, int ldc) -> int {
-    // C[lrows, rrows] = left[lrows, K] right[rrows, K]^T   (both already transposed, K = padded row count)
-    const WDest d1{C, ldc, 0, rrows};
-    return wgrad_multi(L, dt, left, lrows, right, rrows, K, &d1, 1, s);
-  };
-
-  // ---- logit layer
-  {
-    UicGemmParams g = gemm_base(dt, Meff, H);
-    add_seg(g, L.dlogits, V1p, dv.logit_wT, V1p, V1p);
-    g.C = L.dhdrop; g.ldc = H; g.flags = UIC_GEMM_OUT_F32;
+  // d hdrop rows of steps [t0, t1) = d logits W_logit
+  int dh_rows(int t0, int t1, hipStream_t s) {
+    const size_t r0 = (size_t)t0 * N;
+    UicGemmParams g = gemm_base(dt, (t1 - t0) * N, H);
+    add_seg(g, off(L.dlogits, r0 * V1p, dt), V1p, dv.logit_wT, V1p, V1p);
+    g.C = L.dhdrop + r0 * H; g.ldc = H; g.flags = UIC_GEMM_OUT_F32;
+    return uic_gemm_launch(g, s);
+  }
+  // d W_logit, d b_logit over all executed steps (own scratch buffers: may run beside the BPTT loop)
+  int logit_weight_grads(hipStream_t s) {
+    UIC_TRY(uic_transpose_launch(dt, L.dlogits, Meff, V1, V1p, L.tLA, Mp, s));
+    UIC_TRY(uic_transpose_launch(dt, L.hdrop_all, Meff, H, H, L.tLB, Mp, s));
+    UicGemmParams g = gemm_base(dt, V1, H);
+    add_seg(g, L.tLA, Mp, L.tLB, Mp, Mp);
+    g.C = G->logit_w; g.ldc = H; g.flags = UIC_GEMM_OUT_F32;
     UIC_TRY(uic_gemm_launch(g, s));
+    return uic_colsum_launch(dt, L.dlogits, Meff, V1, V1p, G->logit_b, L.colscratchL, L.colscratch_floats, s);
   }
-  UIC_TRY(uic_transpose_launch(dt, L.dlogits, Meff, V1, V1p, L.tA, Mp, s));
-  UIC_TRY(uic_transpose_launch(dt, L.hdrop_all, Meff, H, H, L.tB, Mp, s));
-  UIC_TRY(wgrad(L.tA, V1, L.tB, H, Mp, G->logit_w, H));
-  UIC_TRY(uic_colsum_launch(dt, L.dlogits, Meff, V1, V1p, G->logit_b, L.colscratch, L.colscratch_floats, s));
 
-  // ---- BPTT over the executed steps
-  UIC_TRY(uic_fill_launch(L.dc_att, 0, NH * 4, s));
-  UIC_TRY(uic_fill_launch(L.dc_lang, 0, NH * 4, s));
-  for (int t = t_run - 1; t >= 0; --t) {
+  // ---------------------------------------------------------------- backward
+  int bwd_begin(hipStream_t s) {
+    UIC_TRY(uic_fill_launch(L.dc_att, 0, NH * 4, s));
+    return uic_fill_launch(L.dc_lang, 0, NH * 4, s);
+  }
+
+  int bwd_step(int t, hipStream_t s) {
     const bool last = t == t_run - 1;
     float* dx2 = L.dx2_all + (size_t)t * N * 3 * H;
     const float* dx2_next = L.dx2_all + (size_t)(t + 1) * N * 3 * H;
@@ -587,92 +620,214 @@ int uic_topdown_backward(const uic_topdown_dims* d, const uic_topdown_weights* w
       g.C = L.dx1; g.ldc = 2 * H; g.flags = UIC_GEMM_OUT_F32;
       UIC_TRY(uic_gemm_launch(g, s));
     }
+    return UIC_OK;
   }
 
-  // ---- weight gradients over all executed steps: per LSTM ONE GEMM dG^T [4H, T*N] x [stacked inputs]^T
-  // lang_lstm: inputs [att_res | h_att | h_lang_prev]
-  UIC_TRY(uic_transpose_launch(dt, L.dg2_all, Meff, H4, H4, L.tA, Mp, s));
-  UIC_TRY(uic_transpose_launch(dt, L.ctx_all, Meff, H, H, L.tB, Mp, s));
-  UIC_TRY(uic_transpose_launch(dt, off(L.h_att, NH, dt), Meff, H, H, offw(L.tB, (size_t)H * Mp, dt), Mp, s));
-  UIC_TRY(uic_transpose_launch(dt, L.h_lang, Meff, H, H, offw(L.tB, (size_t)2 * H * Mp, dt), Mp, s));
-  {
-    const WDest dd[2] = {{G->lang_lstm_w_ih, 2 * H, 0, 2 * H}, {G->lang_lstm_w_hh, H, 2 * H, H}};
-    UIC_TRY(wgrad_multi(L, dt, L.tA, H4, L.tB, 3 * H, Mp, dd, 2, s));
+  // weight gradients of everything except the logit layer, over all executed steps
+  int bwd_epilogue(hipStream_t s) {
+    auto wgrad = [&](const void* left, int lrows, const void* right, int rrows, int K, float* C, int ldc) -> int {
+      const WDest d1{C, ldc, 0, rrows};
+      return wgrad_multi(L, dt, left, lrows, right, rrows, K, &d1, 1, s);
+    };
+    // per LSTM ONE GEMM dG^T [4H, T*N] x [stacked inputs]^T; lang_lstm inputs [att_res | h_att | h_lang_prev]
+    UIC_TRY(uic_transpose_launch(dt, L.dg2_all, Meff, H4, H4, L.tA, Mp, s));
+    UIC_TRY(uic_transpose_launch(dt, L.ctx_all, Meff, H, H, L.tB, Mp, s));
+    UIC_TRY(uic_transpose_launch(dt, off(L.h_att, NH, dt), Meff, H, H, offw(L.tB, (size_t)H * Mp, dt), Mp, s));
+    UIC_TRY(uic_transpose_launch(dt, L.h_lang, Meff, H, H, offw(L.tB, (size_t)2 * H * Mp, dt), Mp, s));
+    {
+      const WDest dd[2] = {{G->lang_lstm_w_ih, 2 * H, 0, 2 * H}, {G->lang_lstm_w_hh, H, 2 * H, H}};
+      UIC_TRY(wgrad_multi(L, dt, L.tA, H4, L.tB, 3 * H, Mp, dd, 2, s));
+    }
+    UIC_TRY(uic_colsum_launch(dt, L.dg2_all, Meff, H4, H4, G->lang_lstm_b_ih, L.colscratch, L.colscratch_floats, s));
+    UIC_TRY(uic_check_hip(hipMemcpyAsync(G->lang_lstm_b_hh, G->lang_lstm_b_ih, (size_t)H4 * 4, hipMemcpyDeviceToDevice, s), "memcpy b_hh"));
+    // att_lstm inputs [h_lang_prev | xt | h_att_prev]  (the fc' columns are handled below from dGfc)
+    UIC_TRY(uic_transpose_launch(dt, L.dg1_all, Meff, H4, H4, L.tA, Mp, s));
+    UIC_TRY(uic_transpose_launch(dt, L.h_lang, Meff, H, H, L.tB, Mp, s));
+    UIC_TRY(uic_transpose_launch(dt, L.xt_all, Meff, E, E, offw(L.tB, (size_t)H * Mp, dt), Mp, s));
+    UIC_TRY(uic_transpose_launch(dt, L.h_att, Meff, H, H, offw(L.tB, (size_t)(H + E) * Mp, dt), Mp, s));
+    {
+      const WDest dd[3] = {{G->att_lstm_w_ih, ldih, 0, H}, {G->att_lstm_w_ih + 2 * H, ldih, H, E}, {G->att_lstm_w_hh, H, H + E, H}};
+      UIC_TRY(wgrad_multi(L, dt, L.tA, H4, L.tB, 2 * H + E, Mp, dd, 3, s));
+    }
+    UIC_TRY(uic_colsum_launch(dt, L.dg1_all, Meff, H4, H4, G->att_lstm_b_ih, L.colscratch, L.colscratch_floats, s));
+    UIC_TRY(uic_check_hip(hipMemcpyAsync(G->att_lstm_b_hh, G->att_lstm_b_ih, (size_t)H4 * 4, hipMemcpyDeviceToDevice, s), "memcpy b_hh"));
+    {  // d xt -> embedding table
+      UicGemmParams g = gemm_base(dt, Meff, E);
+      add_seg(g, L.dg1_all, H4, dv.wxT, H4, H4);
+      g.C = L.dxt; g.ldc = E; g.flags = UIC_GEMM_OUT_F32;
+      UIC_TRY(uic_gemm_launch(g, s));
+      UIC_TRY(uic_fill_launch(G->embed_w, 0, (size_t)V1 * E * 4, s));
+      UIC_TRY(uic_embed_bwd_launch(dt, L.dxt, L.xt_all, b->labels, b->ld_labels, N, t_run, V1, E, drop_p, G->embed_w, s));
+    }
+    // fc' path: dGfc = sum_t dG1_t
+    UIC_TRY(uic_sum_steps_launch(dt, L.dg1_all, t_run, (size_t)N * H4, L.dgfc, s));
+    UIC_TRY(uic_transpose_launch(dt, L.dgfc, N, H4, H4, L.tA, Np, s));
+    UIC_TRY(uic_transpose_launch(dt, L.fcp, N, H, H, L.tB, Np, s));
+    UIC_TRY(wgrad(L.tA, H4, L.tB, H, Np, G->att_lstm_w_ih + H, ldih));
+    {
+      UicGemmParams g = gemm_base(dt, N, H);
+      add_seg(g, L.dgfc, H4, dv.wfcpT, H4, H4);
+      g.C = L.dfcp; g.ldc = H; g.flags = UIC_GEMM_OUT_F32;
+      UIC_TRY(uic_gemm_launch(g, s));
+    }
+    UIC_TRY(uic_relu_mask_bwd_launch(dt, L.dfcp, L.fcp, inv_keep, L.dfcpre, NH, s));
+    UIC_TRY(uic_transpose_launch(dt, L.dfcpre, N, H, H, L.tA, Np, s));
+    UIC_TRY(uic_transpose_launch(dt, fc_in, N, Dfc, Dfc, L.tB, Np, s));
+    UIC_TRY(wgrad(L.tA, H, L.tB, Dfc, Np, G->fc_w, Dfc));
+    UIC_TRY(uic_colsum_launch(dt, L.dfcpre, N, H, H, G->fc_b, L.colscratch, L.colscratch_floats, s));
+    // h2att
+    UIC_TRY(uic_transpose_launch(dt, L.datth_all, Meff, A, A, L.tA, Mp, s));
+    UIC_TRY(uic_transpose_launch(dt, off(L.h_att, NH, dt), Meff, H, H, L.tB, Mp, s));
+    UIC_TRY(wgrad(L.tA, A, L.tB, H, Mp, G->h2att_w, H));
+    UIC_TRY(uic_colsum_launch(dt, L.datth_all, Meff, A, A, G->h2att_b, L.colscratch, L.colscratch_floats, s));
+    {  // attention: deferred accumulation over steps
+      UicAttnAccumParams a;
+      memset(&a, 0, sizeof(a));
+      a.dtype = dt; a.N = N; a.R = R; a.A = A; a.H = H; a.T = t_run;
+      a.att_h_all = L.atth_all; a.alpha_all = L.alpha_all; a.de_all = L.de_all;
+      a.dctx_all = L.dx2_all; a.lddctx = 3 * H; a.dctx_step_stride = (size_t)N * 3 * H;
+      a.p_att = L.patt; a.w_alpha = w->alpha_w;
+      a.d_att = L.d_att; a.d_p_att = L.d_patt; a.d_walpha_part = L.dwalpha_part;
+      UIC_TRY(uic_attention_bwd_accum_launch(a, s));
+      UIC_TRY(uic_colsum_launch(UIC_F32, L.dwalpha_part, N, A + 1, A + 1, L.small, L.colscratch, L.colscratch_floats, s));
+      UIC_TRY(uic_check_hip(hipMemcpyAsync(G->alpha_w, L.small, (size_t)A * 4, hipMemcpyDeviceToDevice, s), "memcpy alpha_w"));
+      UIC_TRY(uic_check_hip(hipMemcpyAsync(G->alpha_b, L.small + A, 4, hipMemcpyDeviceToDevice, s), "memcpy alpha_b"));
+    }
+    // ctx2att
+    UIC_TRY(uic_transpose_launch(dt, L.d_patt, NR, A, A, L.tA, NRp, s));
+    UIC_TRY(uic_transpose_launch(dt, L.attp, NR, H, H, L.tB, NRp, s));
+    UIC_TRY(wgrad(L.tA, A, L.tB, H, NRp, G->ctx2att_w, H));
+    UIC_TRY(uic_colsum_launch(dt, L.d_patt, NR, A, A, G->ctx2att_b, L.colscratch, L.colscratch_floats, s));
+    {
+      UicGemmParams g = gemm_base(dt, NR, H);
+      add_seg(g, L.d_patt, A, dv.ctx2attT, A, A);
+      g.C = L.d_att; g.ldc = H; g.flags = UIC_GEMM_OUT_F32 | UIC_GEMM_ACCUM;
+      UIC_TRY(uic_gemm_launch(g, s));
+    }
+    // att_embed (padded regions have att' = 0 -> zero gradient, as pack_wrapper never touched them)
+    UIC_TRY(uic_relu_mask_bwd_launch(dt, L.d_att, L.attp, inv_keep, L.d_pre, (size_t)NR * H, s));
+    UIC_TRY(uic_transpose_launch(dt, L.d_pre, NR, H, H, L.tA, NRp, s));
+    UIC_TRY(uic_transpose_launch(dt, att_in, NR, D, D, L.tB, NRp, s));
+    UIC_TRY(wgrad(L.tA, H, L.tB, D, NRp, G->att_w, D));
+    return uic_colsum_launch(dt, L.d_pre, NR, H, H, G->att_b, L.colscratch, L.colscratch_floats, s);
   }
-  UIC_TRY(uic_colsum_launch(dt, L.dg2_all, Meff, H4, H4, G->lang_lstm_b_ih, L.colscratch, L.colscratch_floats, s));
-  UIC_TRY(uic_check_hip(hipMemcpyAsync(G->lang_lstm_b_hh, G->lang_lstm_b_ih, (size_t)H4 * 4, hipMemcpyDeviceToDevice, s), "memcpy b_hh"));
-  // att_lstm: inputs [h_lang_prev | xt | h_att_prev]  (the fc' columns are handled below from dGfc)
-  UIC_TRY(uic_transpose_launch(dt, L.dg1_all, Meff, H4, H4, L.tA, Mp, s));
-  UIC_TRY(uic_transpose_launch(dt, L.h_lang, Meff, H, H, L.tB, Mp, s));
-  UIC_TRY(uic_transpose_launch(dt, L.xt_all, Meff, E, E, offw(L.tB, (size_t)H * Mp, dt), Mp, s));
-  UIC_TRY(uic_transpose_launch(dt, L.h_att, Meff, H, H, offw(L.tB, (size_t)(H + E) * Mp, dt), Mp, s));
-  {
-    const WDest dd[3] = {{G->att_lstm_w_ih, ldih, 0, H}, {G->att_lstm_w_ih + 2 * H, ldih, H, E}, {G->att_lstm_w_hh, H, H + E, H}};
-    UIC_TRY(wgrad_multi(L, dt, L.tA, H4, L.tB, 2 * H + E, Mp, dd, 3, s));
+};
+
+}  // namespace
+
+extern "C" {
+
+int uic_topdown_forward(const uic_topdown_dims* d, const uic_topdown_weights* w, const void* derived,
+                        const uic_topdown_batch* b, int32_t t_run, int32_t training, uint32_t seed,
+                        void* workspace, float* logprobs_out, void* stream) {
+  UIC_TRY(check_dims(d));
+  UIC_REQUIRE(w && derived && b && workspace, "forward: null pointer");
+  UIC_REQUIRE(b->fc_feats && b->att_feats && b->labels, "forward: batch needs fc_feats, att_feats and labels");
+  UIC_REQUIRE(t_run >= 1 && t_run <= d->T, "forward: t_run=%d outside [1,%d]", t_run, d->T);
+  UIC_REQUIRE(b->ld_labels >= t_run, "forward: labels have %d columns, need %d", b->ld_labels, t_run);
+  hipStream_t s = (hipStream_t)stream;
+  Step st;
+  st.init(d, w, derived, b, t_run, training, seed, workspace, nullptr);
+  UIC_TRY(st.fwd_prologue(s));
+  for (int t = 0; t < t_run; ++t) UIC_TRY(st.fwd_step(t, s));
+  UIC_TRY(st.logits_rows(0, t_run, s));
+  if (logprobs_out) UIC_TRY(st.xe_rows(0, t_run, nullptr, logprobs_out, 0, s));
+  return UIC_OK;
+}
+
+int uic_topdown_xe_loss(const uic_topdown_dims* d, const uic_topdown_batch* b, int32_t t_run, void* workspace,
+                        const float* inv_den, float* loss_out, float* den_out, void* stream) {
+  UIC_TRY(check_dims(d));
+  UIC_REQUIRE(b && workspace && b->labels && b->masks && loss_out, "xe_loss: null pointer");
+  UIC_REQUIRE(t_run >= 1 && t_run <= d->T, "xe_loss: t_run=%d outside [1,%d]", t_run, d->T);
+  UIC_REQUIRE(b->ld_labels >= d->T + 1 && b->ld_masks >= d->T + 1, "xe_loss: labels/masks need %d columns", d->T + 1);
+  hipStream_t s = (hipStream_t)stream;
+  uic_topdown_weights none;
+  memset(&none, 0, sizeof(none));
+  Step st;
+  st.init(d, &none, nullptr, b, t_run, 0, 0, workspace, nullptr);
+  // denominator: sum of masks[:, 1:T+1] over ALL T columns (criterion.py:146-149), also after an early break
+  UIC_TRY(uic_masked_sum_launch(nullptr, b->masks, b->ld_masks, 1, d->N, d->T, st.L.scalars, st.L.scalars + 1, s));
+  const float* inv = inv_den ? inv_den : st.L.scalars + 1;
+  UIC_TRY(st.xe_rows(0, t_run, inv, nullptr, 1, s));
+  UIC_TRY(uic_reduce_sum_launch(st.L.row_loss, (size_t)t_run * d->N, 0.f, inv, loss_out, s));
+  if (den_out) UIC_TRY(uic_check_hip(hipMemcpyAsync(den_out, st.L.scalars, 4, hipMemcpyDeviceToDevice, s), "hipMemcpyAsync"));
+  return UIC_OK;
+}
+
+int uic_topdown_backward(const uic_topdown_dims* d, const uic_topdown_weights* w, const void* derived,
+                         const uic_topdown_batch* b, int32_t t_run, int32_t training, uint32_t seed,
+                         void* workspace, const float* dlogprobs, const float* logprobs,
+                         const uic_topdown_weights* G, void* stream) {
+  UIC_TRY(check_dims(d));
+  UIC_REQUIRE(w && derived && b && workspace && G, "backward: null pointer");
+  UIC_REQUIRE(t_run >= 1 && t_run <= d->T, "backward: t_run=%d outside [1,%d]", t_run, d->T);
+  UIC_REQUIRE(!dlogprobs || logprobs, "backward: dlogprobs needs the forward log-probs");
+  hipStream_t s = (hipStream_t)stream;
+  Step st;
+  st.init(d, w, derived, b, t_run, training, seed, workspace, G);
+  if (dlogprobs)
+    UIC_TRY(uic_logsoftmax_bwd_launch(st.dt, st.L.dlogits, st.Meff, st.V1, st.V1p, st.N, dlogprobs, (size_t)st.V1,
+                                      (size_t)d->T * st.V1, logprobs, s));
+  UIC_TRY(st.dh_rows(0, t_run, s));
+  UIC_TRY(st.logit_weight_grads(s));
+  UIC_TRY(st.bwd_begin(s));
+  for (int t = t_run - 1; t >= 0; --t) UIC_TRY(st.bwd_step(t, s));
+  return st.bwd_epilogue(s);
+}
+
+int uic_topdown_xe_train_step(const uic_topdown_dims* d, const uic_topdown_weights* w, const void* derived,
+                              const uic_topdown_batch* b, int32_t t_run, int32_t training, uint32_t seed,
+                              void* workspace, const float* inv_den, float* loss_out, float* den_out,
+                              const uic_topdown_weights* G, void* stream) {
+  UIC_TRY(check_dims(d));
+  UIC_REQUIRE(w && derived && b && workspace && G && loss_out, "xe_train_step: null pointer");
+  UIC_REQUIRE(b->fc_feats && b->att_feats && b->labels && b->masks, "xe_train_step: batch needs features, labels and masks");
+  UIC_REQUIRE(t_run >= 1 && t_run <= d->T, "xe_train_step: t_run=%d outside [1,%d]", t_run, d->T);
+  UIC_REQUIRE(b->ld_labels >= d->T + 1 && b->ld_masks >= d->T + 1, "xe_train_step: labels/masks need %d columns", d->T + 1);
+  hipStream_t s = (hipStream_t)stream;
+  SideStream* ss = nullptr;
+  UIC_TRY(get_side(&ss));
+  hipStream_t s2 = ss->stream;
+  Step st;
+  st.init(d, w, derived, b, t_run, training, seed, workspace, G);
+  const int CH = 4;                                   // decode steps per hand-off to the side stream
+  const int nchunk = (t_run + CH - 1) / CH;
+  UIC_REQUIRE(nchunk <= MAX_CHUNKS, "xe_train_step: too many decode steps (%d)", t_run);
+#define UIC_HIP(expr) UIC_TRY(uic_check_hip((expr), #expr))
+
+  // main: loss denominator, features, recurrence; hands each finished chunk of steps to the side stream
+  UIC_TRY(uic_masked_sum_launch(nullptr, b->masks, b->ld_masks, 1, d->N, d->T, st.L.scalars, st.L.scalars + 1, s));
+  const float* inv = inv_den ? inv_den : st.L.scalars + 1;
+  UIC_HIP(hipEventRecord(ss->ev_den, s));
+  UIC_HIP(hipStreamWaitEvent(s2, ss->ev_den, 0));
+  UIC_TRY(st.fwd_prologue(s));
+  for (int c = 0; c < nchunk; ++c) {
+    const int t0 = c * CH, t1 = t0 + CH < t_run ? t0 + CH : t_run;
+    for (int t = t0; t < t1; ++t) UIC_TRY(st.fwd_step(t, s));
+    UIC_HIP(hipEventRecord(ss->ev_main[c], s));
+    // side: logit layer of the chunk, forward and backward-to-h (beside the next chunk's recurrence)
+    UIC_HIP(hipStreamWaitEvent(s2, ss->ev_main[c], 0));
+    UIC_TRY(st.logits_rows(t0, t1, s2));
+    UIC_TRY(st.xe_rows(t0, t1, inv, nullptr, 1, s2));
+    UIC_TRY(st.dh_rows(t0, t1, s2));
+    UIC_HIP(hipEventRecord(ss->ev_side[c], s2));
   }
-  UIC_TRY(uic_colsum_launch(dt, L.dg1_all, Meff, H4, H4, G->att_lstm_b_ih, L.colscratch, L.colscratch_floats, s));
-  UIC_TRY(uic_check_hip(hipMemcpyAsync(G->att_lstm_b_hh, G->att_lstm_b_ih, (size_t)H4 * 4, hipMemcpyDeviceToDevice, s), "memcpy b_hh"));
-  {  // d xt -> embedding table
-    UicGemmParams g = gemm_base(dt, Meff, E);
-    add_seg(g, L.dg1_all, H4, dv.wxT, H4, H4);
-    g.C = L.dxt; g.ldc = E; g.flags = UIC_GEMM_OUT_F32;
-    UIC_TRY(uic_gemm_launch(g, s));
-    UIC_TRY(uic_fill_launch(G->embed_w, 0, (size_t)V1 * E * 4, s));
-    UIC_TRY(uic_embed_bwd_launch(dt, L.dxt, L.xt_all, b->labels, b->ld_labels, N, t_run, V1, E, drop_p, G->embed_w, s));
+  // side: logit-layer weight gradients + loss reduction, beside the BPTT loop
+  UIC_TRY(st.logit_weight_grads(s2));
+  UIC_TRY(uic_reduce_sum_launch(st.L.row_loss, (size_t)t_run * d->N, 0.f, inv, loss_out, s2));
+  if (den_out) UIC_HIP(hipMemcpyAsync(den_out, st.L.scalars, 4, hipMemcpyDeviceToDevice, s2));
+  UIC_HIP(hipEventRecord(ss->ev_done, s2));
+  // main: BPTT, each step waits for the d hdrop rows of its chunk
+  UIC_TRY(st.bwd_begin(s));
+  for (int c = nchunk - 1; c >= 0; --c) {
+    const int t0 = c * CH, t1 = t0 + CH < t_run ? t0 + CH : t_run;
+    UIC_HIP(hipStreamWaitEvent(s, ss->ev_side[c], 0));
+    for (int t = t1 - 1; t >= t0; --t) UIC_TRY(st.bwd_step(t, s));
   }
-  // fc' path: dGfc = sum_t dG1_t
-  UIC_TRY(uic_sum_steps_launch(dt, L.dg1_all, t_run, (size_t)N * H4, L.dgfc, s));
-  UIC_TRY(uic_transpose_launch(dt, L.dgfc, N, H4, H4, L.tA, Np, s));
-  UIC_TRY(uic_transpose_launch(dt, L.fcp, N, H, H, L.tB, Np, s));
-  UIC_TRY(wgrad(L.tA, H4, L.tB, H, Np, G->att_lstm_w_ih + H, ldih));
-  {
-    UicGemmParams g = gemm_base(dt, N, H);
-    add_seg(g, L.dgfc, H4, dv.wfcpT, H4, H4);
-    g.C = L.dfcp; g.ldc = H; g.flags = UIC_GEMM_OUT_F32;
-    UIC_TRY(uic_gemm_launch(g, s));
-  }
-  UIC_TRY(uic_relu_mask_bwd_launch(dt, L.dfcp, L.fcp, inv_keep, L.dfcpre, NH, s));
-  UIC_TRY(uic_transpose_launch(dt, L.dfcpre, N, H, H, L.tA, Np, s));
-  UIC_TRY(uic_transpose_launch(dt, fc_in, N, Dfc, Dfc, L.tB, Np, s));
-  UIC_TRY(wgrad(L.tA, H, L.tB, Dfc, Np, G->fc_w, Dfc));
-  UIC_TRY(uic_colsum_launch(dt, L.dfcpre, N, H, H, G->fc_b, L.colscratch, L.colscratch_floats, s));
-  // h2att
-  UIC_TRY(uic_transpose_launch(dt, L.datth_all, Meff, A, A, L.tA, Mp, s));
-  UIC_TRY(uic_transpose_launch(dt, off(L.h_att, NH, dt), Meff, H, H, L.tB, Mp, s));
-  UIC_TRY(wgrad(L.tA, A, L.tB, H, Mp, G->h2att_w, H));
-  UIC_TRY(uic_colsum_launch(dt, L.datth_all, Meff, A, A, G->h2att_b, L.colscratch, L.colscratch_floats, s));
-  // attention: deferred accumulation over steps
-  {
-    UicAttnAccumParams a;
-    memset(&a, 0, sizeof(a));
-    a.dtype = dt; a.N = N; a.R = R; a.A = A; a.H = H; a.T = t_run;
-    a.att_h_all = L.atth_all; a.alpha_all = L.alpha_all; a.de_all = L.de_all;
-    a.dctx_all = L.dx2_all; a.lddctx = 3 * H; a.dctx_step_stride = (size_t)N * 3 * H;
-    a.p_att = L.patt; a.w_alpha = w->alpha_w;
-    a.d_att = L.d_att; a.d_p_att = L.d_patt; a.d_walpha_part = L.dwalpha_part;
-    UIC_TRY(uic_attention_bwd_accum_launch(a, s));
-    UIC_TRY(uic_colsum_launch(UIC_F32, L.dwalpha_part, N, A + 1, A + 1, L.small, L.colscratch, L.colscratch_floats, s));
-    UIC_TRY(uic_check_hip(hipMemcpyAsync(G->alpha_w, L.small, (size_t)A * 4, hipMemcpyDeviceToDevice, s), "memcpy alpha_w"));
-    UIC_TRY(uic_check_hip(hipMemcpyAsync(G->alpha_b, L.small + A, 4, hipMemcpyDeviceToDevice, s), "memcpy alpha_b"));
-  }
-  // ctx2att
-  UIC_TRY(uic_transpose_launch(dt, L.d_patt, NR, A, A, L.tA, NRp, s));
-  UIC_TRY(uic_transpose_launch(dt, L.attp, NR, H, H, L.tB, NRp, s));
-  UIC_TRY(wgrad(L.tA, A, L.tB, H, NRp, G->ctx2att_w, H));
-  UIC_TRY(uic_colsum_launch(dt, L.d_patt, NR, A, A, G->ctx2att_b, L.colscratch, L.colscratch_floats, s));
-  {
-    UicGemmParams g = gemm_base(dt, NR, H);
-    add_seg(g, L.d_patt, A, dv.ctx2attT, A, A);
-    g.C = L.d_att; g.ldc = H; g.flags = UIC_GEMM_OUT_F32 | UIC_GEMM_ACCUM;
-    UIC_TRY(uic_gemm_launch(g, s));
-  }
-  // att_embed (padded regions have att' = 0 -> zero gradient, as pack_wrapper never touched them)
-  UIC_TRY(uic_relu_mask_bwd_launch(dt, L.d_att, L.attp, inv_keep, L.d_pre, (size_t)NR * H, s));
-  UIC_TRY(uic_transpose_launch(dt, L.d_pre, NR, H, H, L.tA, NRp, s));
-  UIC_TRY(uic_transpose_launch(dt, att_in, NR, D, D, L.tB, NRp, s));
-  UIC_TRY(wgrad(L.tA, H, L.tB, D, NRp, G->att_w, D));
-  UIC_TRY(uic_colsum_launch(dt, L.d_pre, NR, H, H, G->att_b, L.colscratch, L.colscratch_floats, s));
-  (void)S;
+  UIC_TRY(st.bwd_epilogue(s));
+  UIC_HIP(hipStreamWaitEvent(s, ss->ev_done, 0));     // join
+#undef UIC_HIP
   return UIC_OK;
 }
 

@@ -113,6 +113,19 @@ __device__ __forceinline__ float uic_wave_sum(float v) {
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
   return v;
 }
+// Sum over each row of 16 lanes with DPP modifiers only (no LDS-pipe shuffles): xor 1, xor 2 (quad_perm),
+// row_half_mirror, row_mirror.  Every lane of a row ends up with the row's sum.
+__device__ __forceinline__ float uic_row16_sum(float v) {
+#define UIC_DPP_ADD(ctrl) \
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), ctrl, 0xf, 0xf, true))
+  UIC_DPP_ADD(0xB1);    // quad_perm [1,0,3,2]
+  UIC_DPP_ADD(0x4E);    // quad_perm [2,3,0,1]
+  UIC_DPP_ADD(0x141);   // row_half_mirror
+  UIC_DPP_ADD(0x140);   // row_mirror
+#undef UIC_DPP_ADD
+  return v;
+}
+
 __device__ __forceinline__ float uic_wave_max(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));

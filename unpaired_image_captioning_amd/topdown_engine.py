@@ -110,6 +110,25 @@ class TopDownEngine(object):
                                             seed & 0xFFFFFFFF, ptr(ws.buf), ptr(dlogprobs), ptr(logprobs), C.byref(g),
                                             stream()), "backward")
 
+    def xe_train_step(self, params, fc, att, att_masks, labels, masks, t_run, training, seed, grads, inv_den=None):
+        """Fused forward + criterion + backward on two HIP streams; returns a device tensor [loss, sum(mask)]."""
+        N, R = att.shape[0], att.shape[1]
+        T = labels.shape[1] - 1
+        d = self.dims(N, R, T)
+        w = self.refresh(params, d)
+        ws = self.checkout(d, fc.device)
+        b = self.batch_struct(fc, att, att_masks, labels, masks)
+        g = self.weights_struct(grads)
+        out = torch.empty(2, dtype=torch.float32, device=fc.device)
+        try:
+            check(self.lib.uic_topdown_xe_train_step(C.byref(d), C.byref(w), ptr(self._derived), C.byref(b), t_run,
+                                                     int(training), seed & 0xFFFFFFFF, ptr(ws.buf), ptr(inv_den),
+                                                     out.data_ptr(), out.data_ptr() + 4, C.byref(g), stream()),
+                  "xe_train_step")
+        finally:
+            self.release(ws)
+        return out
+
     def sample(self, params, fc, att, att_masks, L, sample_max=1, temperature=1.0, decoding_constraint=0, seed=0,
                forced=None):
         N, R = att.shape[0], att.shape[1]

@@ -26,8 +26,9 @@ def _steps_from_host_labels(labels_np):
     return int(z[0]) + 1 if z.size else T
 
 
-def xe_step(model, batch, t_run=None, inv_den=None, grads=None, return_seed=False):
-    """forward + fused criterion + backward on device tensors.  Returns (loss[device scalar], grads dict)."""
+def xe_step(model, batch, t_run=None, inv_den=None, grads=None, return_seed=False, fused=True):
+    """forward + fused criterion + backward on device tensors.  Returns (loss[device scalar], grads dict).
+    fused=True: one library call scheduled on two HIP streams; False: the three separate calls."""
     eng = model.engine
     labels = batch["labels"]
     if t_run is None:
@@ -35,6 +36,14 @@ def xe_step(model, batch, t_run=None, inv_den=None, grads=None, return_seed=Fals
     pd = {k: v.detach() for k, v in model.param_dict().items()}
     seed = model.next_seed()
     training = model.training
+    if fused:
+        if grads is None:
+            grads = {k: torch.empty_like(v) for k, v in pd.items()}
+        out = eng.xe_train_step(pd, batch["fc_feats"], batch["att_feats"], batch.get("att_masks"), labels, batch["masks"],
+                                t_run, training, seed, grads, inv_den)
+        if return_seed:
+            return out[0], grads, seed
+        return out[0], grads
     _, ws, (d, w, b) = eng.forward(pd, batch["fc_feats"], batch["att_feats"], batch.get("att_masks"), labels, t_run,
                                    training, seed, want_logprobs=False, masks=batch["masks"])
     out = eng.xe_loss(ws, d, b, t_run, inv_den)
