@@ -76,6 +76,9 @@ typedef struct uic_topdown_batch {
   int32_t ld_labels;
   const float* masks;       /* [N, ld_masks] or NULL (forward only) */
   int32_t ld_masks;
+  const float* grad_scale;  /* optional [N, ld_grad_scale]: d loss / d logprob[n, t, labels[n, t+1]] given directly (column t),
+                               replacing mask / sum(mask) -- the self-critical step (P/trainer.py:167-171) */
+  int32_t ld_grad_scale;
 } uic_topdown_batch;
 
 /* Sizes (bytes) of the two caller-allocated arenas. */
@@ -121,11 +124,12 @@ int uic_topdown_xe_train_step(const uic_topdown_dims* d, const uic_topdown_weigh
 
 /* AttModel._sample with beam_size = 1 (P/models/AttModel.py:198-253): greedy (sample_max = 1) or
  * multinomial decode of `L` <= d->T tokens.  seq [N, L] int64 and seq_logp [N, L] f32 are fully written.
- * `forced` (optional, [N, L] int64) replaces the multinomial draws (parity tests). */
+ * `forced` (optional, [N, L] int64) replaces the multinomial draws (parity tests).  training != 0 applies the
+ * dropout masks of (seed) exactly as uic_topdown_forward would (the sampling pass of the self-critical step). */
 int uic_topdown_sample(const uic_topdown_dims* d, const uic_topdown_weights* w, const void* derived,
                        const uic_topdown_batch* batch, int32_t L, int32_t sample_max, float temperature,
-                       int32_t decoding_constraint, uint32_t seed, const int64_t* forced, void* workspace,
-                       int64_t* seq, float* seq_logp, void* stream);
+                       int32_t decoding_constraint, uint32_t seed, const int64_t* forced, int32_t training,
+                       void* workspace, int64_t* seq, float* seq_logp, void* stream);
 
 /* Address of a named activation inside the workspace (tests / debugging); NULL if unknown.
  * Names: fc_embed att_embed p_att xt gx h_att h_lang c_att c_lang att_h alpha ctx logits dlogits ... */
@@ -170,6 +174,11 @@ int uic_adam_step(float* p, const float* g, float* m, float* v, size_t n, float 
 int uic_lm_criterion(int32_t N, int32_t T, int32_t V1, const float* logp, const int64_t* target, int32_t ld_target,
                      const float* mask, int32_t ld_mask, float* loss_out, float* scratch, float* dlogp, float grad_out,
                      void* stream);
+
+/* RewardCriterion (P/misc/criterion.py:117-124): loss_out[0] = -sum(logp * reward * m) / sum(m), m = (seq > 0) shifted
+ * right by one with a leading 1; if dlogp != NULL it receives d loss / d logp [N, L]. */
+int uic_reward_criterion(int32_t N, int32_t L, const float* logp, const int64_t* seq, const float* reward, float* loss_out,
+                         float* dlogp, void* stream);
 
 /* utilities */
 int uic_cast_from_f32(int32_t dtype, const float* src, void* dst, size_t n, void* stream);

@@ -196,22 +196,25 @@ def reward_criterion(logp: Tensor, seq: Tensor, reward: Tensor) -> Tensor:
 def sample(W: Weights, fc_feats: Tensor, att_feats: Tensor, att_masks: Optional[Tensor],
            seq_length: int, sample_max: int = 1, temperature: float = 1.0,
            decoding_constraint: int = 0, use_bn: int = 0, generator=None,
-           forced_tokens: Optional[Tensor] = None):
+           forced_tokens: Optional[Tensor] = None, drop=None):
     """AttModel._sample (beam_size = 1), P/models/AttModel.py:198-253.
 
     ``forced_tokens`` [N, L] replaces the multinomial draw so a device sampler's
-    own draws can be scored by this oracle (sample_max = 0 only).
+    own draws can be scored by this oracle (sample_max = 0 only).  ``drop`` (training-mode sampling pass of
+    the self-critical step, P/trainer.py:167) uses the same mask layout as forward_logprobs.
     """
     N = fc_feats.shape[0]
     H = W["logit.weight"].shape[1]
-    fc, att, p_att, masks = prepare_feature(W, fc_feats, att_feats, att_masks, None, use_bn, False)
+    fc, att, p_att, masks = prepare_feature(W, fc_feats, att_feats, att_masks, drop, use_bn, False)
     state = (torch.zeros(2, N, H), torch.zeros(2, N, H))
     seq = torch.zeros(N, seq_length, dtype=torch.long)
-    seq_logp = torch.zeros(N, seq_length)
+    lps = []
     it = torch.zeros(N, dtype=torch.long)
     unfinished = None
     for t in range(seq_length + 1):
-        logp, state, _ = logprobs_step(W, it, fc, att, p_att, masks, state)
+        em = None if drop is None or t >= seq_length else drop["embed"][t]
+        om = None if drop is None or t >= seq_length else drop["out"][t]
+        logp, state, _ = logprobs_step(W, it, fc, att, p_att, masks, state, em, om)
         if decoding_constraint and t > 0:                              # :220-223
             tmp = torch.zeros_like(logp)
             tmp.scatter_(1, seq[:, t - 1].unsqueeze(1), float("-inf"))
@@ -230,9 +233,12 @@ def sample(W: Weights, fc_feats: Tensor, att_feats: Tensor, att_masks: Optional[
         unfinished = (it > 0) if t == 0 else unfinished & (it > 0)     # :242-246
         it = it * unfinished.long()
         seq[:, t] = it
-        seq_logp[:, t] = lp
+        lps.append(lp)
         if int(unfinished.sum()) == 0:
             break
+    seq_logp = torch.stack(lps, 1)
+    if seq_logp.shape[1] < seq_length:
+        seq_logp = torch.cat([seq_logp, torch.zeros(N, seq_length - seq_logp.shape[1])], 1)
     return seq, seq_logp
 
 

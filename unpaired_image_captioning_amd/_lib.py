@@ -55,7 +55,8 @@ class Weights(C.Structure):
 class Batch(C.Structure):
     _fields_ = [("fc_feats", C.c_void_p), ("att_feats", C.c_void_p), ("att_masks", C.c_void_p),
                 ("labels", C.c_void_p), ("ld_labels", C.c_int32),
-                ("masks", C.c_void_p), ("ld_masks", C.c_int32)]
+                ("masks", C.c_void_p), ("ld_masks", C.c_int32),
+                ("grad_scale", C.c_void_p), ("ld_grad_scale", C.c_int32)]
 
 
 _SIGS = {
@@ -75,8 +76,8 @@ _SIGS = {
                                             C.c_int32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                             C.POINTER(Weights), C.c_void_p]),
     "uic_topdown_sample": (C.c_int, [C.POINTER(Dims), C.POINTER(Weights), C.c_void_p, C.POINTER(Batch), C.c_int32,
-                                     C.c_int32, C.c_float, C.c_int32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p,
-                                     C.c_void_p, C.c_void_p]),
+                                     C.c_int32, C.c_float, C.c_int32, C.c_uint32, C.c_void_p, C.c_int32, C.c_void_p,
+                                     C.c_void_p, C.c_void_p, C.c_void_p]),
     "uic_topdown_workspace_ptr": (C.c_void_p, [C.POINTER(Dims), C.c_void_p, C.c_char_p]),
     "uic_linear": (C.c_int, [C.c_int32] * 4 + [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32,
                              C.c_void_p, C.c_int32, C.c_void_p]),
@@ -89,6 +90,7 @@ _SIGS = {
     "uic_adam_step": (C.c_int, [C.c_void_p] * 4 + [C.c_size_t] + [C.c_float] * 4 + [C.c_int32, C.c_float, C.c_void_p]),
     "uic_lm_criterion": (C.c_int, [C.c_int32] * 3 + [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32,
                                    C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_void_p]),
+    "uic_reward_criterion": (C.c_int, [C.c_int32, C.c_int32] + [C.c_void_p] * 6),
     "uic_cast_from_f32": (C.c_int, [C.c_int32, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     "uic_cast_to_f32": (C.c_int, [C.c_int32, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     "uic_transpose": (C.c_int, [C.c_int32, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p]),

@@ -54,6 +54,31 @@ __global__ void lm_crit_bwd_kernel(int N, int T, int V1, const int64_t* target, 
   if (y < 0 || y >= V1) y = 0;
   dlogp[((size_t)n * T + t) * V1 + y] = -mask[(size_t)n * ldm + t] / loss_den[1] * grad_out;
 }
+// RewardCriterion (P/misc/criterion.py:117-124), one block
+__global__ void reward_crit_kernel(int N, int L, const float* logp, const int64_t* seq, const float* reward, float* loss_out, float* dlogp) {
+  __shared__ float s_a[256], s_b[256];
+  float a = 0.f, b = 0.f;
+  for (int i = threadIdx.x; i < N * L; i += 256) {
+    const int n = i / L, t = i - n * L;
+    const float m = (t == 0 || seq[(size_t)n * L + t - 1] > 0) ? 1.f : 0.f;
+    a += -logp[i] * reward[i] * m;
+    b += m;
+  }
+  s_a[threadIdx.x] = a; s_b[threadIdx.x] = b;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if (threadIdx.x < o) { s_a[threadIdx.x] += s_a[threadIdx.x + o]; s_b[threadIdx.x] += s_b[threadIdx.x + o]; }
+    __syncthreads();
+  }
+  const float den = s_b[0];
+  if (threadIdx.x == 0) loss_out[0] = s_a[0] / den;
+  if (dlogp)
+    for (int i = threadIdx.x; i < N * L; i += 256) {
+      const int n = i / L, t = i - n * L;
+      const float m = (t == 0 || seq[(size_t)n * L + t - 1] > 0) ? 1.f : 0.f;
+      dlogp[i] = -reward[i] * m / den;
+    }
+}
 }  // namespace
 
 extern "C" {
@@ -163,6 +188,15 @@ int uic_lm_criterion(int32_t N, int32_t T, int32_t V1, const float* logp, const 
     hipLaunchKernelGGL(lm_crit_bwd_kernel, dim3((n + 255) / 256), dim3(256), 0, s, N, T, V1, target, ld_target, mask, ld_mask, fin, grad_out, dlogp);
     UIC_LAUNCH_CHECK("lm_crit_bwd");
   }
+  return UIC_OK;
+}
+
+int uic_reward_criterion(int32_t N, int32_t L, const float* logp, const int64_t* seq, const float* reward, float* loss_out,
+                         float* dlogp, void* stream) {
+  UIC_REQUIRE(logp && seq && reward && loss_out, "reward_criterion: null pointer");
+  UIC_REQUIRE(N > 0 && L > 0, "reward_criterion: empty input");
+  hipLaunchKernelGGL(reward_crit_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, N, L, logp, seq, reward, loss_out, dlogp);
+  UIC_LAUNCH_CHECK("reward_crit_kernel");
   return UIC_OK;
 }
 

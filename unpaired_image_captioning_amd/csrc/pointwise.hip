@@ -101,7 +101,7 @@ __global__ void sum_steps_kernel(const T* __restrict__ src, int TS, size_t step,
 // out[(t*N+n), :] = dropout(relu(table[tokens[n, t]]))
 template <typename T>
 __global__ void embed_fwd_kernel(const float* __restrict__ table, int V1, int E, const int64_t* __restrict__ tokens,
-                                 int ldtok, int N, int TS, float drop_p, unsigned seed, unsigned site, T* __restrict__ out) {
+                                 int ldtok, int N, int TS, float drop_p, unsigned seed, unsigned site, size_t idx_base, T* __restrict__ out) {
   const int e4 = E / 4;
   const size_t total = (size_t)TS * N * e4;
   const float inv_keep = drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f;
@@ -116,7 +116,7 @@ __global__ void embed_fwd_kernel(const float* __restrict__ table, int V1, int E,
     float f[4] = {fmaxf(v.x, 0.f), fmaxf(v.y, 0.f), fmaxf(v.z, 0.f), fmaxf(v.w, 0.f)};
     if (drop_p > 0.f) {
 #pragma unroll
-      for (int j = 0; j < 4; ++j) f[j] *= uic_drop_scale(seed, site, (unsigned)(row * E + c + j), drop_p, inv_keep);
+      for (int j = 0; j < 4; ++j) f[j] *= uic_drop_scale(seed, site, (unsigned)(idx_base + row * E + c + j), drop_p, inv_keep);
     }
     T* o = out + row * E + c;
 #pragma unroll
@@ -224,7 +224,7 @@ __global__ __launch_bounds__(NT) void xe_kernel(const UicXeParams p, const float
   float mk = 0.f;
   if (p.target) {
     y = p.target[(size_t)n * p.ldtarget + p.target_col0 + t];
-    mk = p.mask[(size_t)n * p.ldmask + p.mask_col0 + t];
+    mk = p.mask ? p.mask[(size_t)n * p.ldmask + p.mask_col0 + t] : 0.f;
     if (y < 0 || y >= p.V1) y = 0;
     if (threadIdx.x == 0) p.row_loss[m] = -(row[y] - lse) * mk;
   }
@@ -233,7 +233,7 @@ __global__ __launch_bounds__(NT) void xe_kernel(const UicXeParams p, const float
     for (int v = threadIdx.x; v < p.V1; v += NT) lp[v] = row[v] - lse;
   }
   if (p.write_grad) {
-    const float sc = mk * p.inv_den[0];
+    const float sc = p.grad_scale ? p.grad_scale[(size_t)n * p.ldscale + p.scale_col0 + t] : mk * p.inv_den[0];
     T* d = dlogits + (size_t)m * p.ldv;
     for (int v = threadIdx.x; v < p.ldv; v += NT) {
       float g = 0.f;
@@ -270,7 +270,7 @@ __global__ __launch_bounds__(NT) void xe_lds_kernel(const UicXeParams p, const f
   float mk = 0.f;
   if (p.target) {
     y = p.target[(size_t)n * p.ldtarget + p.target_col0 + t];
-    mk = p.mask[(size_t)n * p.ldmask + p.mask_col0 + t];
+    mk = p.mask ? p.mask[(size_t)n * p.ldmask + p.mask_col0 + t] : 0.f;
     if (y < 0 || y >= p.V1) y = 0;
     if (threadIdx.x == 0) p.row_loss[m] = -(s_row[y] - lse) * mk;
   }
@@ -279,7 +279,7 @@ __global__ __launch_bounds__(NT) void xe_lds_kernel(const UicXeParams p, const f
     for (int v = threadIdx.x; v < p.V1; v += NT) lp[v] = s_row[v] - lse;
   }
   if (p.write_grad) {
-    const float sc = mk * p.inv_den[0];
+    const float sc = p.grad_scale ? p.grad_scale[(size_t)n * p.ldscale + p.scale_col0 + t] : mk * p.inv_den[0];
     T* d = dlogits + (size_t)m * p.ldv;
     for (int v = threadIdx.x * 4; v < p.ldv; v += NT * 4) {
       float g[4];
@@ -530,13 +530,13 @@ int uic_sum_steps_launch(int dtype, const void* src, int T, size_t step_elems, v
   return UIC_OK;
 }
 int uic_embed_fwd_launch(int dtype, const float* table, int V1, int E, const int64_t* tokens, int ldtok, int N, int T,
-                         float drop_p, unsigned seed, unsigned site, void* out, hipStream_t s) {
+                         float drop_p, unsigned seed, unsigned site, size_t idx_base, void* out, hipStream_t s) {
   UIC_REQUIRE(E % 4 == 0, "embed: E=%d must be a multiple of 4", E);
   if (N == 0 || T == 0) return UIC_OK;
   const int g = grid_for((size_t)T * N * (E / 4), NT);
   DISPATCH_T(dtype,
-             hipLaunchKernelGGL(embed_fwd_kernel<bf16_t>, dim3(g), dim3(NT), 0, s, table, V1, E, tokens, ldtok, N, T, drop_p, seed, site, (bf16_t*)out),
-             hipLaunchKernelGGL(embed_fwd_kernel<float>, dim3(g), dim3(NT), 0, s, table, V1, E, tokens, ldtok, N, T, drop_p, seed, site, (float*)out));
+             hipLaunchKernelGGL(embed_fwd_kernel<bf16_t>, dim3(g), dim3(NT), 0, s, table, V1, E, tokens, ldtok, N, T, drop_p, seed, site, idx_base, (bf16_t*)out),
+             hipLaunchKernelGGL(embed_fwd_kernel<float>, dim3(g), dim3(NT), 0, s, table, V1, E, tokens, ldtok, N, T, drop_p, seed, site, idx_base, (float*)out));
   UIC_LAUNCH_CHECK("embed_fwd");
   return UIC_OK;
 }
@@ -570,7 +570,7 @@ int uic_lstm_bwd_launch(const UicLstmBwdParams& p, hipStream_t s) {
 }
 int uic_xe_launch(const UicXeParams& p, hipStream_t s) {
   UIC_REQUIRE(p.logits && p.N > 0, "xe: null logits or N=0");
-  UIC_REQUIRE(!p.write_grad || (p.target && p.mask && p.inv_den), "xe: gradient needs target, mask and inv_den");
+  UIC_REQUIRE(!p.write_grad || (p.target && ((p.mask && p.inv_den) || p.grad_scale)), "xe: gradient needs target and mask+inv_den or grad_scale");
   UIC_REQUIRE(!p.write_grad || p.dlogits, "xe: null dlogits");
   UIC_REQUIRE(!p.target || p.row_loss, "xe: null row_loss");
   if (p.M == 0) return UIC_OK;

@@ -47,7 +47,7 @@ struct Layout {
   void* tLA; void* tLB; float* colscratchL;   // scratch of the logit-layer weight gradients (side stream)
   // sampling
   void* s_h_att[2]; void* s_h_lang[2]; float* s_c_att[2]; float* s_c_lang[2];
-  void* s_xt; float* s_atth; float* s_alpha; void* s_ctx; float* s_logits;
+  void* s_xt; float* s_atth; float* s_alpha; void* s_ctx; void* s_hdrop; float* s_logits;
   int64_t* s_it; int* s_unf; int* s_nunf;
   size_t total;
 };
@@ -140,6 +140,7 @@ Layout make_layout(const uic_topdown_dims& d, void* ws) {
   L.s_atth = (float*)b.take(N * A * 4);
   L.s_alpha = (float*)b.take(N * R * 4);
   L.s_ctx = b.take(N * H * S);
+  L.s_hdrop = b.take(N * H * S);
   L.s_logits = (float*)b.take(N * V1p * 4);
   L.s_it = (int64_t*)b.take(N * 8);
   L.s_unf = (int*)b.take(N * 4);
@@ -458,7 +459,7 @@ struct Step {
     const void *f, *a;
     UIC_TRY(prepare_features(d, w, dv, b, L, drop_p, seed, &f, &a, s));
     // xt_t = dropout(relu(embed[labels[:, t]])) for all steps (AttModel.py:145,160)
-    UIC_TRY(uic_embed_fwd_launch(dt, w->embed_w, V1, E, b->labels, b->ld_labels, N, t_run, drop_p, seed, UIC_SITE_EMBED, L.xt_all, s));
+    UIC_TRY(uic_embed_fwd_launch(dt, w->embed_w, V1, E, b->labels, b->ld_labels, N, t_run, drop_p, seed, UIC_SITE_EMBED, 0, L.xt_all, s));
     {  // Gx = xt W_ih[:, 2H:]^T + b_ih + b_hh, all steps
       UicGemmParams g = gemm_base(dt, Meff, H4);
       add_seg(g, L.xt_all, E, off(dv.att_w_ih, 2 * H, dt), ldih, E);
@@ -533,6 +534,7 @@ struct Step {
       x.target = b->labels; x.ldtarget = b->ld_labels; x.target_col0 = 1 + t0;
       x.mask = b->masks; x.ldmask = b->ld_masks; x.mask_col0 = 1 + t0;
       x.inv_den = inv; x.row_loss = L.row_loss + r0; x.write_grad = 1;
+      x.grad_scale = b->grad_scale; x.ldscale = b->ld_grad_scale; x.scale_col0 = t0;
     }
     if (logprobs_out) {
       x.logprobs = logprobs_out + (size_t)t0 * V1; x.lp_step_stride = V1; x.lp_row_stride = (size_t)d.T * V1;
@@ -782,9 +784,10 @@ int uic_topdown_xe_train_step(const uic_topdown_dims* d, const uic_topdown_weigh
                               const uic_topdown_weights* G, void* stream) {
   UIC_TRY(check_dims(d));
   UIC_REQUIRE(w && derived && b && workspace && G && loss_out, "xe_train_step: null pointer");
-  UIC_REQUIRE(b->fc_feats && b->att_feats && b->labels && b->masks, "xe_train_step: batch needs features, labels and masks");
+  UIC_REQUIRE(b->fc_feats && b->att_feats && b->labels && (b->masks || b->grad_scale), "xe_train_step: batch needs features, labels and masks (or grad_scale)");
   UIC_REQUIRE(t_run >= 1 && t_run <= d->T, "xe_train_step: t_run=%d outside [1,%d]", t_run, d->T);
-  UIC_REQUIRE(b->ld_labels >= d->T + 1 && b->ld_masks >= d->T + 1, "xe_train_step: labels/masks need %d columns", d->T + 1);
+  UIC_REQUIRE(b->ld_labels >= d->T + 1 && (!b->masks || b->ld_masks >= d->T + 1), "xe_train_step: labels/masks need %d columns", d->T + 1);
+  UIC_REQUIRE(!b->grad_scale || b->ld_grad_scale >= t_run, "xe_train_step: grad_scale needs %d columns", t_run);
   hipStream_t s = (hipStream_t)stream;
   SideStream* ss = nullptr;
   UIC_TRY(get_side(&ss));
@@ -797,7 +800,7 @@ int uic_topdown_xe_train_step(const uic_topdown_dims* d, const uic_topdown_weigh
 #define UIC_HIP(expr) UIC_TRY(uic_check_hip((expr), #expr))
 
   // main: loss denominator, features, recurrence; hands each finished chunk of steps to the side stream
-  UIC_TRY(uic_masked_sum_launch(nullptr, b->masks, b->ld_masks, 1, d->N, d->T, st.L.scalars, st.L.scalars + 1, s));
+  if (b->masks) UIC_TRY(uic_masked_sum_launch(nullptr, b->masks, b->ld_masks, 1, d->N, d->T, st.L.scalars, st.L.scalars + 1, s));
   const float* inv = inv_den ? inv_den : st.L.scalars + 1;
   UIC_HIP(hipEventRecord(ss->ev_den, s));
   UIC_HIP(hipStreamWaitEvent(s2, ss->ev_den, 0));
@@ -833,8 +836,8 @@ int uic_topdown_xe_train_step(const uic_topdown_dims* d, const uic_topdown_weigh
 
 int uic_topdown_sample(const uic_topdown_dims* d, const uic_topdown_weights* w, const void* derived,
                        const uic_topdown_batch* b, int32_t Lsteps, int32_t sample_max, float temperature,
-                       int32_t decoding_constraint, uint32_t seed, const int64_t* forced, void* workspace,
-                       int64_t* seq, float* seq_logp, void* stream) {
+                       int32_t decoding_constraint, uint32_t seed, const int64_t* forced, int32_t training,
+                       void* workspace, int64_t* seq, float* seq_logp, void* stream) {
   UIC_TRY(check_dims(d));
   UIC_REQUIRE(w && derived && b && workspace && seq && seq_logp, "sample: null pointer");
   UIC_REQUIRE(b->fc_feats && b->att_feats, "sample: batch needs fc_feats and att_feats");
@@ -849,7 +852,8 @@ int uic_topdown_sample(const uic_topdown_dims* d, const uic_topdown_weights* w, 
   const size_t S = uic_dtype_size(dt);
   const size_t NH = (size_t)N * H;
   const void *fc_in, *att_in;
-  UIC_TRY(prepare_features(*d, w, dv, b, L, 0.f, 0, &fc_in, &att_in, s));
+  const float drop_p = training ? d->drop_p : 0.f;
+  UIC_TRY(prepare_features(*d, w, dv, b, L, drop_p, seed, &fc_in, &att_in, s));
   UIC_TRY(uic_fill_launch(L.s_h_att[0], 0, NH * S, s));
   UIC_TRY(uic_fill_launch(L.s_h_lang[0], 0, NH * S, s));
   UIC_TRY(uic_fill_launch(L.s_c_att[0], 0, NH * 4, s));
@@ -859,7 +863,7 @@ int uic_topdown_sample(const uic_topdown_dims* d, const uic_topdown_weights* w, 
   UIC_TRY(uic_fill_launch(L.s_nunf, 0, (size_t)(d->T + 2) * 4, s));
   for (int t = 0; t < Lsteps; ++t) {
     const int cur = t & 1, nxt = cur ^ 1;
-    UIC_TRY(uic_embed_fwd_launch(dt, w->embed_w, V1, E, L.s_it, 1, N, 1, 0.f, 0, 0, L.s_xt, s));
+    UIC_TRY(uic_embed_fwd_launch(dt, w->embed_w, V1, E, L.s_it, 1, N, 1, drop_p, seed, UIC_SITE_EMBED, (size_t)t * N * E, L.s_xt, s));
     {
       UicGemmParams g = gemm_base(dt, N, H4);
       g.lstm = 1; g.H = H;
@@ -882,11 +886,13 @@ int uic_topdown_sample(const uic_topdown_dims* d, const uic_topdown_weights* w, 
       g.bias = w->lang_lstm_b_ih; g.bias2 = w->lang_lstm_b_hh;
       g.c_prev = L.s_c_lang[cur]; g.c_out = L.s_c_lang[nxt];
       g.h_out = L.s_h_lang[nxt]; g.ldh = H;
+      g.h_drop = L.s_hdrop; g.ldhd = H;        // dropout(h_lang) feeds the logit layer (AttModel.py:443)
+      g.drop_p = drop_p; g.seed = seed; g.site = UIC_SITE_OUT0 + (unsigned)t;
       UIC_TRY(uic_gemm_launch(g, s));
     }
     {
       UicGemmParams g = gemm_base(dt, N, V1);
-      add_seg(g, L.s_h_lang[nxt], H, dv.logit_w, H, H);
+      add_seg(g, L.s_hdrop, H, dv.logit_w, H, H);
       g.C = L.s_logits; g.ldc = V1p; g.bias = w->logit_b; g.flags = UIC_GEMM_OUT_F32;
       UIC_TRY(uic_gemm_launch(g, s));
     }

@@ -224,7 +224,7 @@ int uic_colsum_launch(int src_dtype, const void* src, int rows, int cols, int ld
 // dst[n, c] = sum_t src[t, n, c]
 int uic_sum_steps_launch(int dtype, const void* src, int T, size_t step_elems, void* dst, hipStream_t s);
 int uic_embed_fwd_launch(int dtype, const float* table, int V1, int E, const int64_t* tokens, int ldtok, int N, int T,
-                         float drop_p, unsigned seed, unsigned site, void* out, hipStream_t s);
+                         float drop_p, unsigned seed, unsigned site, size_t idx_base, void* out, hipStream_t s);
 int uic_embed_bwd_launch(int dtype, const float* dxt, const void* xt, const int64_t* tokens, int ldtok, int N, int T,
                          int V1, int E, float drop_p, float* dtable, hipStream_t s);
 // dst = (act > 0 ? scale : 0) * grad ; grad f32, act/dst operand dtype
@@ -252,6 +252,7 @@ struct UicXeParams {
   const float* mask; int ldmask; int mask_col0;
   int N;                         // row m = t*N + n
   const float* inv_den;          // device scalar: 1 / sum(mask)
+  const float* grad_scale; int ldscale; int scale_col0;   // optional: gradient weight of row (n,t) instead of mask/den (SCST)
   float* row_loss;               // [M]
   float* logprobs; size_t lp_step_stride, lp_row_stride;  // optional full log-probs out [n][t][v]
   int write_grad;

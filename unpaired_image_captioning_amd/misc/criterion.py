@@ -48,3 +48,34 @@ class LanguageModelCriterion(nn.Module):
         if 'stackcap' in self.caption_model:
             raise NotImplementedError("stackcap is outside the MI355X hot path")
         return _LMCriterionFn.apply(input, target, mask)
+
+
+class _RewardCriterionFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, logp, seq, reward):
+        lib = _lib.load()
+        N, L = logp.shape
+        logp = logp.contiguous().float()
+        seq = seq.contiguous()
+        reward = reward.contiguous().float()
+        loss = torch.empty((), dtype=torch.float32, device=logp.device)
+        dlogp = torch.empty_like(logp)
+        check(lib.uic_reward_criterion(N, L, ptr(logp), ptr(seq), ptr(reward), loss.data_ptr(), ptr(dlogp), stream()),
+              "reward_criterion")
+        ctx.save_for_backward(dlogp)
+        return loss
+
+    @staticmethod
+    def backward(ctx, g):
+        (dlogp,) = ctx.saved_tensors
+        return dlogp * g, None, None
+
+
+class RewardCriterion(nn.Module):
+    """forward(input [N,L] sampled log-probs, seq [N,L], reward [N,L]) -> scalar (criterion.py:104-124)."""
+
+    def __init__(self):
+        super(RewardCriterion, self).__init__()
+
+    def forward(self, input, seq, reward):
+        return _RewardCriterionFn.apply(input, seq, reward)

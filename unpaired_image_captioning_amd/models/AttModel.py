@@ -69,6 +69,42 @@ class _TopDownForward(torch.autograd.Function):
         return (None, None, None, None, None, None) + tuple(grads[k] for k in model.param_names)
 
 
+class _TopDownSample(torch.autograd.Function):
+    """Multinomial sampling pass of the self-critical step (P/trainer.py:167): returns (seq, seqLogprobs) with
+    seqLogprobs differentiable.  Backward replays the sampled sequence teacher-forced with the SAME dropout seed
+    (the masks are a pure function of seed/site/index) and feeds d loss / d logprob of the sampled tokens
+    straight into the fused training step."""
+
+    @staticmethod
+    def forward(ctx, model, fc, att, att_masks, sample_kw, *params):
+        eng = model.engine
+        pd = dict(zip(model.param_names, params))
+        seed = model.next_seed()
+        seq, lp = eng.sample(pd, fc, att, att_masks, model.seq_length, seed=seed, training=model.training, **sample_kw)
+        ctx.model = model
+        ctx.call = (seed, model.training)
+        ctx.inputs = (fc, att, att_masks, seq)
+        ctx.params = params
+        ctx.mark_non_differentiable(seq)
+        return seq, lp
+
+    @staticmethod
+    def backward(ctx, g_seq, g_lp):
+        model = ctx.model
+        eng = model.engine
+        seed, training = ctx.call
+        fc, att, att_masks, seq = ctx.inputs
+        pd = dict(zip(model.param_names, ctx.params))
+        N, L = seq.shape
+        labels = torch.zeros(N, L + 2, dtype=torch.int64, device=seq.device)
+        labels[:, 1:L + 1] = seq
+        grads = {k: torch.empty_like(v) for k, v in pd.items()}
+        # d loss / d logits = -g * (softmax - onehot)  ->  gradient weight of position (n, t) is -g[n, t]
+        eng.xe_train_step(pd, fc, att, att_masks, labels[:, :L + 1].contiguous(), None, L, training, seed, grads,
+                          grad_scale=(-g_lp).contiguous())
+        return (None, None, None, None, None) + tuple(grads[k] for k in model.param_names)
+
+
 class AttModel(CaptionModel):
     def __init__(self, opt):
         super(AttModel, self).__init__()
@@ -161,11 +197,14 @@ class AttModel(CaptionModel):
         fc = fc_feats.contiguous().float()
         att = att_feats.contiguous().float()
         am = att_masks.contiguous().float() if att_masks is not None else None
+        kw = dict(sample_max=sample_max, temperature=temperature, decoding_constraint=decoding_constraint,
+                  forced=opt.get('forced_tokens'))
+        if torch.is_grad_enabled() and not sample_max:
+            params = [self.param_dict()[k] for k in self.param_names]
+            return _TopDownSample.apply(self, fc, att, am, kw, *params)
         with torch.no_grad():
             pd = {k: v.detach() for k, v in self.param_dict().items()}
-            return self.engine.sample(pd, fc, att, am, self.seq_length, sample_max=sample_max,
-                                      temperature=temperature, decoding_constraint=decoding_constraint,
-                                      seed=self.next_seed(), forced=opt.get('forced_tokens'))
+            return self.engine.sample(pd, fc, att, am, self.seq_length, seed=self.next_seed(), training=self.training, **kw)
 
 
 class TopDownModel(AttModel):

@@ -74,7 +74,7 @@ class TopDownEngine(object):
         return w
 
     @staticmethod
-    def batch_struct(fc, att, att_masks, labels=None, masks=None):
+    def batch_struct(fc, att, att_masks, labels=None, masks=None, grad_scale=None):
         b = Batch()
         b.fc_feats = ptr(fc)
         b.att_feats = ptr(att)
@@ -83,6 +83,8 @@ class TopDownEngine(object):
         b.ld_labels = labels.shape[1] if labels is not None else 0
         b.masks = ptr(masks)
         b.ld_masks = masks.shape[1] if masks is not None else 0
+        b.grad_scale = ptr(grad_scale)
+        b.ld_grad_scale = grad_scale.shape[1] if grad_scale is not None else 0
         return b
 
     # ------------------------------------------------------------------ calls
@@ -110,14 +112,15 @@ class TopDownEngine(object):
                                             seed & 0xFFFFFFFF, ptr(ws.buf), ptr(dlogprobs), ptr(logprobs), C.byref(g),
                                             stream()), "backward")
 
-    def xe_train_step(self, params, fc, att, att_masks, labels, masks, t_run, training, seed, grads, inv_den=None):
+    def xe_train_step(self, params, fc, att, att_masks, labels, masks, t_run, training, seed, grads, inv_den=None,
+                      grad_scale=None):
         """Fused forward + criterion + backward on two HIP streams; returns a device tensor [loss, sum(mask)]."""
         N, R = att.shape[0], att.shape[1]
         T = labels.shape[1] - 1
         d = self.dims(N, R, T)
         w = self.refresh(params, d)
         ws = self.checkout(d, fc.device)
-        b = self.batch_struct(fc, att, att_masks, labels, masks)
+        b = self.batch_struct(fc, att, att_masks, labels, masks, grad_scale)
         g = self.weights_struct(grads)
         out = torch.empty(2, dtype=torch.float32, device=fc.device)
         try:
@@ -130,7 +133,7 @@ class TopDownEngine(object):
         return out
 
     def sample(self, params, fc, att, att_masks, L, sample_max=1, temperature=1.0, decoding_constraint=0, seed=0,
-               forced=None):
+               forced=None, training=False):
         N, R = att.shape[0], att.shape[1]
         d = self.dims(N, R, L + 1)
         w = self.refresh(params, d)
@@ -141,7 +144,7 @@ class TopDownEngine(object):
         try:
             check(self.lib.uic_topdown_sample(C.byref(d), C.byref(w), ptr(self._derived), C.byref(b), L, int(sample_max),
                                               float(temperature), int(decoding_constraint), seed & 0xFFFFFFFF, ptr(forced),
-                                              ptr(ws.buf), ptr(seq), ptr(lp), stream()), "sample")
+                                              int(training), ptr(ws.buf), ptr(seq), ptr(lp), stream()), "sample")
         finally:
             self.release(ws)
         return seq, lp

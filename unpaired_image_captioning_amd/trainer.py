@@ -164,6 +164,41 @@ class Trainer(object):
         self.i2t_train_loss = loss.item()          # the reference's per-step host sync (trainer.py:172)
         return self.i2t_train_loss
 
+    def train_self_critical(self, data, reward_fn):
+        """The self-critical branch of Trainer.train (P/trainer.py:166-171).  `reward_fn(data, sampled, greedy)`
+        -> float array [N, L] stands for get_self_critical_reward's CPU scorer (P/misc/rewards.py:37-82: CIDEr-D /
+        BLEU of the sampled caption minus that of the greedy one, repeated over L), which is outside the hot path."""
+        from .misc.criterion import RewardCriterion
+        if self.arena is None:
+            self.build_optimizer()
+        batch = self.to_device(data)
+        model = self.i2t_model
+        fc, att, am = batch["fc_feats"], batch["att_feats"], batch.get("att_masks")
+        model.train()
+        gen_result, sample_logprobs = model(fc, None, att, am, opt={'sample_max': 0}, mode='sample')
+        model.eval()
+        with torch.no_grad():                                           # rewards.py:42-47: greedy baseline, eval mode
+            greedy_res, _ = model(fc, None, att, am, opt={'sample_max': 1}, mode='sample')
+        model.train()
+        reward = np.asarray(reward_fn(data, gen_result.cpu().numpy(), greedy_res.cpu().numpy()), dtype=np.float32)
+        loss = RewardCriterion()(sample_logprobs, gen_result, torch.from_numpy(reward).cuda())
+        for p in model.parameters():
+            p.grad = None
+        loss.backward()
+        params = dict(model.named_parameters())
+        for k, view in self.arena.grad_views.items():
+            view.copy_(params[k].grad)
+        self.exchange.allreduce_sum(self.arena.grad)
+        self._step += 1
+        a = self.arena
+        scale = 1.0 / self.exchange.world_size                           # per-rank means -> global mean
+        check(_lib.load().uic_adam_step(ptr(a.flat), ptr(a.grad), ptr(a.exp_avg), ptr(a.exp_avg_sq), a.numel,
+                                        self.i2t_current_lr, self.betas[0], self.betas[1], self.eps, self._step, scale,
+                                        stream()), "adam_step")
+        self.i2t_avg_reward = float(np.mean(reward[:, 0]))
+        self.i2t_train_loss = loss.item()
+        return self.i2t_train_loss
+
     def save_models(self, tag=''):
         """P/trainer.py:98-104: model_i2t[-best].pth = state_dict of the un-wrapped module."""
         path = self.opt.checkpoint_path
