@@ -135,6 +135,48 @@ int uic_topdown_sample(const uic_topdown_dims* d, const uic_topdown_weights* w, 
  * Names: fc_embed att_embed p_att xt gx h_att h_lang c_att c_lang att_h alpha ctx logits dlogits ... */
 void* uic_topdown_workspace_ptr(const uic_topdown_dims* d, void* workspace, const char* name);
 
+/* ---- FC captioner: the `fc` caption model = FCModel_NMT + maxout LSTMCore (P/models/FCModel_NMT.py:21-217,
+ * P/models/__init__.py:24-26; BASELINE config 1) ---- */
+typedef struct uic_fc_dims {
+  int32_t N;        /* caption rows */
+  int32_t Dfc;      /* fc_feat_size */
+  int32_t H;        /* rnn_size */
+  int32_t E;        /* input_encoding_size */
+  int32_t V1;       /* vocab_size + 1 */
+  int32_t S;        /* core steps the workspace is sized for = labels.size(1) (image step + L+1 token steps) */
+  int32_t dtype;
+  float drop_p;
+} uic_fc_dims;
+
+typedef struct uic_fc_weights {      /* FCModel_NMT.state_dict() order */
+  float* img_embed_w;   /* img_embed.weight  [E, Dfc] */
+  float* img_embed_b;   /* img_embed.bias    [E]      */
+  float* i2h_w;         /* core.i2h.weight   [5H, E]  chunks (in, forget, out, a, b) */
+  float* i2h_b;         /* core.i2h.bias     [5H]     */
+  float* h2h_w;         /* core.h2h.weight   [5H, H]  */
+  float* h2h_b;         /* core.h2h.bias     [5H]     */
+  float* embed_w;       /* embed.weight      [V1, E]  */
+  float* logit_w;       /* logit.weight      [V1, H]  */
+  float* logit_b;       /* logit.bias        [V1]     */
+} uic_fc_weights;
+
+size_t uic_fc_workspace_bytes(const uic_fc_dims* d);
+/* FCModel_NMT._forward (:89-124): `s_run` <= S core steps (s_run < S = the early break at :115); log-probs of
+ * steps 1.. are written to logprobs_out [N, S-1, V1] if given.  batch: fc_feats, labels (att fields ignored). */
+int uic_fc_forward(const uic_fc_dims* d, const uic_fc_weights* w, const uic_topdown_batch* batch, int32_t s_run,
+                   int32_t training, uint32_t seed, void* workspace, float* logprobs_out, void* stream);
+/* LanguageModelCriterion fused with log_softmax on the logits left by uic_fc_forward. */
+int uic_fc_xe_loss(const uic_fc_dims* d, const uic_topdown_batch* batch, int32_t s_run, void* workspace,
+                   const float* inv_den, float* loss_out, void* stream);
+/* Backward of uic_fc_forward (dense upstream gradient, or the one prepared by uic_fc_xe_loss if dlogprobs == NULL). */
+int uic_fc_backward(const uic_fc_dims* d, const uic_fc_weights* w, const uic_topdown_batch* batch, int32_t s_run,
+                    int32_t training, uint32_t seed, void* workspace, const float* dlogprobs, const float* logprobs,
+                    const uic_fc_weights* grads, void* stream);
+/* FCModel_NMT._sample (:164-217, beam_size = 1): seq / seq_logp are [N, L+1] (last column stays 0). */
+int uic_fc_sample(const uic_fc_dims* d, const uic_fc_weights* w, const uic_topdown_batch* batch, int32_t L,
+                  int32_t sample_max, float temperature, uint32_t seed, const int64_t* forced, void* workspace,
+                  int64_t* seq, float* seq_logp, void* stream);
+
 /* ---- single operators (also used by the parity tests) ---- */
 
 /* nn.Linear as C[M,N] = A[M,K] B[N,K]^T (+bias)(+ReLU); flags: 1 ReLU, 2 accumulate into C, 4 C is f32. */

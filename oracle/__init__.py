@@ -12,3 +12,4 @@ own modules (``/root/reference/pivot_based_eccv2018/models/AttModel.py`` and
 against every one of them.
 """
 from . import topdown  # noqa: F401
+from . import fc  # noqa: F401

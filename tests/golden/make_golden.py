@@ -54,6 +54,8 @@ def _load_reference():
     load("models.CaptionModel", os.path.join(P, "models", "CaptionModel.py"))
     att = load("models.AttModel", os.path.join(P, "models", "AttModel.py"))
     crit = load("refcriterion", os.path.join(P, "misc", "criterion.py"))
+    global FC_MOD
+    FC_MOD = load("models.FCModel_NMT", os.path.join(P, "models", "FCModel_NMT.py"))
     return att, crit
 
 
@@ -186,8 +188,69 @@ def run_case(att_mod, crit_mod, name, V, E, H, A, D, L, n_img, S, R, seed, ragge
     print("wrote %s (%.1f KB) loss=%.6f" % (path, os.path.getsize(path) / 1024, loss.item()))
 
 
+FC_MOD = None
+
+
+def run_fc_case(crit_mod, name, V, E, H, D, L, n_img, S, seed, short_all=False, wseed=None):
+    """FCModel_NMT (the `fc` caption model, P/models/__init__.py:24-26): forward, loss, grads, greedy decode."""
+    torch.manual_seed(seed)
+    opt = _argparse.Namespace(vocab_size=V, input_encoding_size=E, rnn_type="LSTM", rnn_size=H, num_layers=1,
+                              drop_prob_lm=0.0, seq_length=L, fc_feat_size=D, caption_model="fc")
+    model = FC_MOD.FCModel_NMT(opt)
+    if wseed is not None:        # big case: weights are a pure function of the seed (oracle.fc.init_weights), not stored
+        from oracle.fc import init_weights as fc_init
+        model.load_state_dict(fc_init(V + 1, E, H, D, seed=wseed))
+    crit = crit_mod.LanguageModelCriterion(opt)
+    b = synth(n_img, S, 3, D, V, L, seed, False)
+    if short_all:
+        b["labels"][:, L // 2 + 1:] = 0
+        nz = (b["labels"] != 0).sum(1) + 2
+        b["masks"] = (torch.arange(L + 2)[None, :] < nz[:, None]).float()
+    fc, labels, masks = b["fc_feats"], b["labels"], b["masks"]
+    out = {"cfg": np.array([V, E, H, 0, D, L, n_img, S, 0, 0, 0], dtype=np.int64)}
+    if wseed is None:
+        for k, v in model.state_dict().items():
+            out["w::" + k] = v.detach().clone().numpy()
+        out["in::fc_feats"] = fc.numpy()
+        out["in::labels"] = labels.numpy()
+        out["in::masks"] = masks.numpy()
+    else:
+        out["seeds"] = np.array([wseed, seed], dtype=np.int64)
+    model.train()
+    logp = model._forward(fc, None, labels)                      # the reference's own 4-argument signature (:89)
+    loss = crit(logp, labels[:, 1:], masks[:, 1:])
+    loss.backward()
+    out["out::loss"] = np.array(loss.item(), dtype=np.float64)
+    if wseed is None:
+        out["out::logprobs"] = logp.detach().numpy()
+        for k, p in model.named_parameters():
+            out["grad::" + k] = p.grad.detach().clone().numpy()
+    else:
+        out["out::logprobs_sub"] = logp.detach()[:, :, ::37].numpy()
+        for k, p in model.named_parameters():
+            if p.dim() == 1:
+                out["grad::" + k] = p.grad.detach().clone().numpy()
+            else:
+                out["gradnorm::" + k] = np.array(p.grad.double().norm().item())
+    model.eval()
+    idx = torch.arange(n_img) * S
+    with torch.no_grad():
+        seq, seq_logp = model._sample(fc[idx], None, None, {"sample_max": 1, "beam_size": 1})
+    out["out::greedy_seq"] = seq.numpy()
+    out["out::greedy_logp"] = seq_logp.numpy()
+    path = os.path.join(HERE, name + ".npz")
+    np.savez_compressed(path, **out)
+    print("wrote %s (%.1f KB) loss=%.6f" % (path, os.path.getsize(path) / 1024, loss.item()))
+
+
 def main():
     att_mod, crit_mod = _load_reference()
+    run_fc_case(crit_mod, "fc_tiny", V=50, E=32, H=32, D=64, L=6, n_img=3, S=2, seed=21)
+    run_fc_case(crit_mod, "fc_tiny_earlybreak", V=50, E=32, H=32, D=64, L=6, n_img=3, S=2, seed=22, short_all=True)
+    run_fc_case(crit_mod, "fc_odd", V=77, E=24, H=40, D=72, L=5, n_img=2, S=3, seed=23)
+    # BASELINE config 1 shapes: batch 16 images x 5 captions, seq_len 16, 2048-d fc feats, hidden 512 (weights from a seed,
+    # outputs sub-sampled, to keep the fixture small)
+    run_fc_case(crit_mod, "fc_cfg1", V=9487, E=512, H=512, D=2048, L=16, n_img=16, S=5, seed=24, wseed=2025)
     tiny = dict(V=50, E=32, H=32, A=32, D=64, L=6, n_img=3, S=2, R=5)
     run_case(att_mod, crit_mod, "topdown_tiny", seed=11, adam_steps=3, **tiny)
     run_case(att_mod, crit_mod, "topdown_tiny_ragged", seed=12, ragged=True, **tiny)

@@ -52,6 +52,22 @@ class Weights(C.Structure):
     _fields_ = [(f, C.c_void_p) for f, _ in WEIGHT_FIELDS]
 
 
+class FcDims(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ("N", "Dfc", "H", "E", "V1", "S", "dtype")] + [("drop_p", C.c_float)]
+
+
+FC_WEIGHT_FIELDS = [
+    ("img_embed_w", "img_embed.weight"), ("img_embed_b", "img_embed.bias"),
+    ("i2h_w", "core.i2h.weight"), ("i2h_b", "core.i2h.bias"),
+    ("h2h_w", "core.h2h.weight"), ("h2h_b", "core.h2h.bias"),
+    ("embed_w", "embed.weight"), ("logit_w", "logit.weight"), ("logit_b", "logit.bias"),
+]
+
+
+class FcWeights(C.Structure):
+    _fields_ = [(f, C.c_void_p) for f, _ in FC_WEIGHT_FIELDS]
+
+
 class Batch(C.Structure):
     _fields_ = [("fc_feats", C.c_void_p), ("att_feats", C.c_void_p), ("att_masks", C.c_void_p),
                 ("labels", C.c_void_p), ("ld_labels", C.c_int32),
@@ -78,6 +94,14 @@ _SIGS = {
     "uic_topdown_sample": (C.c_int, [C.POINTER(Dims), C.POINTER(Weights), C.c_void_p, C.POINTER(Batch), C.c_int32,
                                      C.c_int32, C.c_float, C.c_int32, C.c_uint32, C.c_void_p, C.c_int32, C.c_void_p,
                                      C.c_void_p, C.c_void_p, C.c_void_p]),
+    "uic_fc_workspace_bytes": (C.c_size_t, [C.POINTER(FcDims)]),
+    "uic_fc_forward": (C.c_int, [C.POINTER(FcDims), C.POINTER(FcWeights), C.POINTER(Batch), C.c_int32, C.c_int32, C.c_uint32,
+                                 C.c_void_p, C.c_void_p, C.c_void_p]),
+    "uic_fc_xe_loss": (C.c_int, [C.POINTER(FcDims), C.POINTER(Batch), C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "uic_fc_backward": (C.c_int, [C.POINTER(FcDims), C.POINTER(FcWeights), C.POINTER(Batch), C.c_int32, C.c_int32, C.c_uint32,
+                                  C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(FcWeights), C.c_void_p]),
+    "uic_fc_sample": (C.c_int, [C.POINTER(FcDims), C.POINTER(FcWeights), C.POINTER(Batch), C.c_int32, C.c_int32, C.c_float,
+                                C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "uic_topdown_workspace_ptr": (C.c_void_p, [C.POINTER(Dims), C.c_void_p, C.c_char_p]),
     "uic_linear": (C.c_int, [C.c_int32] * 4 + [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32,
                              C.c_void_p, C.c_int32, C.c_void_p]),

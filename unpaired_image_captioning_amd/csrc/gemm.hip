@@ -39,7 +39,7 @@ __global__ __launch_bounds__(64 * WM * WN * KS) void uic_gemm_kernel(const UicGe
   constexpr int A_CH = BM * CPR / NT;
   constexpr int B_CH = BN * CPR / NT;
   static_assert(BM * CPR % NT == 0 && BN * CPR % NT == 0, "tile/threads mismatch");
-  static_assert(!LSTM || TN == 4, "LSTM mode keeps the 4 gates in the 4 N tiles of a wave");
+  static_assert(!LSTM || TN == 4 || TN == 5, "LSTM mode keeps the 4 (nn.LSTMCell) or 5 (maxout LSTMCore) gate chunks in the N tiles of a wave");
 
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* sA = smem;
@@ -105,8 +105,8 @@ __global__ __launch_bounds__(64 * WM * WN * KS) void uic_gemm_kernel(const UicGe
       int grow;
       bool ok;
       if (LSTM) {
-        const int u = n0 + (row >> 7) * 32 + (row & 31);
-        grow = ((row >> 5) & 3) * p.H + u;
+        const int u = n0 + (row / (TN * 32)) * 32 + (row & 31);
+        grow = ((row % (TN * 32)) >> 5) * p.H + u;
         ok = u < p.H;
       } else {
         grow = n0 + row;
@@ -248,9 +248,10 @@ __global__ __launch_bounds__(64 * WM * WN * KS) void uic_gemm_kernel(const UicGe
       const int H = p.H;
       const int u = n0 + wn * 32 + r32;
       if (u < H) {
-        float bg[4] = {0.f, 0.f, 0.f, 0.f};
+        float bg[TN];
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
+        for (int g = 0; g < TN; ++g) {
+          bg[g] = 0.f;
           if (p.bias) bg[g] += p.bias[g * H + u];
           if (p.bias2) bg[g] += p.bias2[g * H + u];
         }
@@ -260,34 +261,58 @@ __global__ __launch_bounds__(64 * WM * WN * KS) void uic_gemm_kernel(const UicGe
           for (int reg = R0; reg < R0 + RPG; ++reg) {
             const int row = m0 + (wm * TM + i) * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * half;
             if (row >= p.M) continue;
-            float g4[4];
+            float g4[TN];
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
+            for (int g = 0; g < TN; ++g) {
               float v = acc[i][g][reg] + bg[g];
               if (p.pre1) v += p.pre1[(size_t)row * p.ldpre1 + g * H + u];
               if (p.pre2) v += p.pre2[(size_t)row * p.ldpre2 + g * H + u];
               g4[g] = v;
             }
-            const float gi = uic_sigmoid_t<T>(g4[0]);
-            const float gf = uic_sigmoid_t<T>(g4[1]);
-            const float gg = uic_tanh<T>(g4[2]);
-            const float go = uic_sigmoid_t<T>(g4[3]);
             const float cp = p.c_prev ? p.c_prev[(size_t)row * H + u] : 0.f;
-            const float c = gf * cp + gi * gg;
-            const float h = go * uic_tanh<T>(c);
-            p.c_out[(size_t)row * H + u] = c;
-            ((T*)p.h_out)[(size_t)row * p.ldh + u] = uic_from_f<T>(h);
-            if (p.h_drop) {
-              float hd = h;
-              if (p.drop_p > 0.f) hd *= uic_drop_scale(p.seed, p.site, (unsigned)row * (unsigned)H + (unsigned)u, p.drop_p, inv_keep);
-              ((T*)p.h_drop)[(size_t)row * p.ldhd + u] = uic_from_f<T>(hd);
-            }
-            if (p.gates_out) {
-              T* G = (T*)p.gates_out + (size_t)row * 4 * H + u;
-              G[0] = uic_from_f<T>(gi);
-              G[H] = uic_from_f<T>(gf);
-              G[2 * H] = uic_from_f<T>(gg);
-              G[3 * H] = uic_from_f<T>(go);
+            if constexpr (TN == 4) {
+              // nn.LSTMCell: chunks (i, f, g, o)
+              const float gi = uic_sigmoid_t<T>(g4[0]);
+              const float gf = uic_sigmoid_t<T>(g4[1]);
+              const float gg = uic_tanh<T>(g4[2]);
+              const float go = uic_sigmoid_t<T>(g4[3]);
+              const float c = gf * cp + gi * gg;
+              const float h = go * uic_tanh<T>(c);
+              p.c_out[(size_t)row * H + u] = c;
+              ((T*)p.h_out)[(size_t)row * p.ldh + u] = uic_from_f<T>(h);
+              if (p.h_drop) {
+                float hd = h;
+                if (p.drop_p > 0.f) hd *= uic_drop_scale(p.seed, p.site, (unsigned)row * (unsigned)H + (unsigned)u, p.drop_p, inv_keep);
+                ((T*)p.h_drop)[(size_t)row * p.ldhd + u] = uic_from_f<T>(hd);
+              }
+              if (p.gates_out) {
+                T* G = (T*)p.gates_out + (size_t)row * 4 * H + u;
+                G[0] = uic_from_f<T>(gi);
+                G[H] = uic_from_f<T>(gf);
+                G[2 * H] = uic_from_f<T>(gg);
+                G[3 * H] = uic_from_f<T>(go);
+              }
+            } else {
+              // maxout LSTMCore (P/models/FCModel_NMT.py:32-50): chunks (in, forget, out, a, b); g = max(a, b);
+              // the DROPPED next_h is both the output and the recurrent state (:47-50)
+              const float gi = uic_sigmoid_t<T>(g4[0]);
+              const float gf = uic_sigmoid_t<T>(g4[1]);
+              const float go = uic_sigmoid_t<T>(g4[2]);
+              const bool first = g4[3] >= g4[4];
+              const float gg = first ? g4[3] : g4[4];
+              const float c = gf * cp + gi * gg;
+              float h = go * uic_tanh<T>(c);
+              if (p.drop_p > 0.f) h *= uic_drop_scale(p.seed, p.site, (unsigned)row * (unsigned)H + (unsigned)u, p.drop_p, inv_keep);
+              p.c_out[(size_t)row * H + u] = c;
+              ((T*)p.h_out)[(size_t)row * p.ldh + u] = uic_from_f<T>(h);
+              if (p.gates_out) {
+                T* G = (T*)p.gates_out + (size_t)row * 5 * H + u;
+                G[0] = uic_from_f<T>(gi);
+                G[H] = uic_from_f<T>(gf);
+                G[2 * H] = uic_from_f<T>(go);
+                G[3 * H] = uic_from_f<T>(gg);
+                G[4 * H] = uic_from_f<T>(first ? 1.f : 0.f);
+              }
             }
           }
       }
@@ -545,6 +570,7 @@ int launch_cfg(const UicGemmParams& p, hipStream_t s) {
 template <typename T>
 int launch_typed(const UicGemmParams& p, hipStream_t s) {
   // skinny problems (the per-decode-step GEMMs, M = rows of one step): 64-row tiles with a 4-way in-block K split
+  if (p.lstm == 2) return launch_cfg<T, 1, 5, 2, 1, 4, true>(p, s);
   if (p.lstm) return launch_cfg<T, 1, 4, 2, 1, 4, true>(p, s);
   const long blocks128 = (long)((p.M + 127) / 128) * ((p.N + 127) / 128);
   const bool glds_ok = p.nseg == 1 && p.seg[0].K % (128 / (int)sizeof(T)) == 0;
@@ -598,7 +624,7 @@ int uic_gemm_launch(const UicGemmParams& p, hipStream_t s) {
     UIC_REQUIRE(((uintptr_t)g.A & 15) == 0 && ((uintptr_t)g.B & 15) == 0, "gemm: segment %d operands must be 16-byte aligned", i);
   }
   if (p.lstm) {
-    UIC_REQUIRE(p.H > 0 && p.N == 4 * p.H, "gemm(lstm): N=%d must equal 4*H (H=%d)", p.N, p.H);
+    UIC_REQUIRE(p.H > 0 && p.N == (p.lstm == 2 ? 5 : 4) * p.H, "gemm(lstm): N=%d must equal %d*H (H=%d)", p.N, p.lstm == 2 ? 5 : 4, p.H);
     UIC_REQUIRE(p.c_out && p.h_out, "gemm(lstm): c_out and h_out are required");
   } else {
     UIC_REQUIRE(p.C != nullptr || p.slab != nullptr, "gemm: null C");

@@ -101,7 +101,7 @@ __global__ void sum_steps_kernel(const T* __restrict__ src, int TS, size_t step,
 // out[(t*N+n), :] = dropout(relu(table[tokens[n, t]]))
 template <typename T>
 __global__ void embed_fwd_kernel(const float* __restrict__ table, int V1, int E, const int64_t* __restrict__ tokens,
-                                 int ldtok, int N, int TS, float drop_p, unsigned seed, unsigned site, size_t idx_base, T* __restrict__ out) {
+                                 int ldtok, int N, int TS, float drop_p, unsigned seed, unsigned site, size_t idx_base, int relu, T* __restrict__ out) {
   const int e4 = E / 4;
   const size_t total = (size_t)TS * N * e4;
   const float inv_keep = drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f;
@@ -113,7 +113,11 @@ __global__ void embed_fwd_kernel(const float* __restrict__ table, int V1, int E,
     long tok = tokens[(size_t)n * ldtok + t];
     if (tok < 0 || tok >= V1) tok = 0;
     const float4 v = *(const float4*)(table + (size_t)tok * E + c);
-    float f[4] = {fmaxf(v.x, 0.f), fmaxf(v.y, 0.f), fmaxf(v.z, 0.f), fmaxf(v.w, 0.f)};
+    float f[4] = {v.x, v.y, v.z, v.w};
+    if (relu) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) f[j] = fmaxf(f[j], 0.f);
+    }
     if (drop_p > 0.f) {
 #pragma unroll
       for (int j = 0; j < 4; ++j) f[j] *= uic_drop_scale(seed, site, (unsigned)(idx_base + row * E + c + j), drop_p, inv_keep);
@@ -132,7 +136,7 @@ __global__ void embed_bwd_kernel(const float* __restrict__ dxt, const T* __restr
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
     const size_t row = i / E;
     const int e = (int)(i - row * E);
-    if (uic_to_f(xt[i]) > 0.f) {
+    if (!xt || uic_to_f(xt[i]) > 0.f) {
       const int t = (int)(row / N), n = (int)(row - (size_t)t * N);
       long tok = tokens[(size_t)n * ldtok + t];
       if (tok < 0 || tok >= V1) tok = 0;
@@ -180,6 +184,51 @@ __global__ void lstm_bwd_kernel(const UicLstmBwdParams p) {
     D[2 * H] = uic_from_f<T>(dc * gi * (1.f - gg * gg));
     D[3 * H] = uic_from_f<T>(d_o * go * (1.f - go));
     p.dc[idx] = dc * gf;
+  }
+}
+
+// Backward of the maxout LSTMCore gate math (P/models/FCModel_NMT.py:32-50).  gates = (in, forget, out, g, first)
+// as stored by the forward GEMM epilogue; the dropout mask applies to the SUM of the incoming dh because the dropped
+// next_h is both the output and the recurrent state.
+template <typename T>
+__global__ void maxout_lstm_bwd_kernel(const UicLstmBwdParams p) {
+  const int H = p.H;
+  const size_t total = (size_t)p.M * H;
+  const float inv_keep = p.drop_p > 0.f ? 1.f / (1.f - p.drop_p) : 1.f;
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += stride) {
+    const int m = (int)(idx / H), u = (int)(idx - (size_t)m * H);
+    float dh = 0.f;
+    if (p.dh0) dh += p.dh0[(size_t)m * p.lddh0 + u];
+    if (p.dh1) dh += p.dh1[(size_t)m * p.lddh1 + u];
+    if (p.drop_p > 0.f) dh *= uic_drop_scale(p.seed, p.site, (unsigned)idx, p.drop_p, inv_keep);
+    const T* G = (const T*)p.gates + (size_t)m * 5 * H + u;
+    const float gi = uic_to_f(G[0]), gf = uic_to_f(G[H]), go = uic_to_f(G[2 * H]), gg = uic_to_f(G[3 * H]);
+    const bool first = uic_to_f(G[4 * H]) > 0.5f;
+    const float c = p.c[idx];
+    const float cp = p.c_prev ? p.c_prev[idx] : 0.f;
+    const float tc = tanhf(c);
+    const float dc = p.dc[idx] + dh * go * (1.f - tc * tc);
+    const float dg = dc * gi;
+    T* D = (T*)p.dgates + (size_t)m * 5 * H + u;
+    D[0] = uic_from_f<T>(dc * gg * gi * (1.f - gi));
+    D[H] = uic_from_f<T>(dc * cp * gf * (1.f - gf));
+    D[2 * H] = uic_from_f<T>(dh * tc * go * (1.f - go));
+    D[3 * H] = uic_from_f<T>(first ? dg : 0.f);
+    D[4 * H] = uic_from_f<T>(first ? 0.f : dg);
+    p.dc[idx] = dc * gf;
+  }
+}
+
+// FCModel_NMT._sample breaks BEFORE writing the step at which every row has finished (:203-206): zero that
+// column and everything after it.
+__global__ void sample_fixup_kernel(int N, int L, int ld, const int* n_unfinished, int64_t* seq, float* seq_logp) {
+  int first = L;
+  for (int t = 0; t < L; ++t)
+    if (n_unfinished[t] == 0) { first = t; break; }
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < N * ld; i += gridDim.x * blockDim.x) {
+    const int t = i % ld;
+    if (t >= first) { seq[i] = 0; seq_logp[i] = 0.f; }
   }
 }
 
@@ -367,9 +416,10 @@ __global__ __launch_bounds__(NT) void sample_step_kernel(const UicSampleParams p
   const int n = blockIdx.x;
   const int t = p.t;
   const float* row = (const float*)p.logits + (size_t)n * p.ldv;
-  const bool dead = t > 0 && p.n_unfinished[t - 1] == 0;   // every row had finished: the reference broke out
+  const bool dead = !p.fc_mode && t > 0 && p.n_unfinished[t - 1] == 0;   // every row had finished: the reference broke out
   long banned = -1;
-  if (p.decoding_constraint && t > 0) banned = p.seq[(size_t)n * p.L + t - 1];
+  const int ldo = p.ld_out > 0 ? p.ld_out : p.L;
+  if (p.decoding_constraint && t > 0) banned = p.seq[(size_t)n * ldo + t - 1];
 
   float mx = -INFINITY;
   for (int v = threadIdx.x; v < p.V1; v += NT) mx = fmaxf(mx, row[v]);
@@ -442,8 +492,8 @@ __global__ __launch_bounds__(NT) void sample_step_kernel(const UicSampleParams p
   }
   if (threadIdx.x == 0) {
     if (dead) {
-      p.seq[(size_t)n * p.L + t] = 0;
-      p.seq_logp[(size_t)n * p.L + t] = 0.f;
+      p.seq[(size_t)n * ldo + t] = 0;
+      p.seq_logp[(size_t)n * ldo + t] = 0.f;
       p.it[n] = 0;
     } else {
       const float lp = row[choice] - lse;
@@ -451,9 +501,9 @@ __global__ __launch_bounds__(NT) void sample_step_kernel(const UicSampleParams p
       if (t > 0) unf = unf && p.unfinished[n];
       p.unfinished[n] = unf;
       const long tok = unf ? choice : 0;
-      p.it[n] = tok;
-      p.seq[(size_t)n * p.L + t] = tok;
-      p.seq_logp[(size_t)n * p.L + t] = lp;
+      p.it[n] = p.fc_mode ? (long)choice : tok;      // FCModel_NMT feeds the RAW sampled token to the next step (:199)
+      p.seq[(size_t)n * ldo + t] = tok;
+      p.seq_logp[(size_t)n * ldo + t] = lp;
       if (unf) atomicAdd(&p.n_unfinished[t], 1);
     }
   }
@@ -530,13 +580,13 @@ int uic_sum_steps_launch(int dtype, const void* src, int T, size_t step_elems, v
   return UIC_OK;
 }
 int uic_embed_fwd_launch(int dtype, const float* table, int V1, int E, const int64_t* tokens, int ldtok, int N, int T,
-                         float drop_p, unsigned seed, unsigned site, size_t idx_base, void* out, hipStream_t s) {
+                         float drop_p, unsigned seed, unsigned site, size_t idx_base, int relu, void* out, hipStream_t s) {
   UIC_REQUIRE(E % 4 == 0, "embed: E=%d must be a multiple of 4", E);
   if (N == 0 || T == 0) return UIC_OK;
   const int g = grid_for((size_t)T * N * (E / 4), NT);
   DISPATCH_T(dtype,
-             hipLaunchKernelGGL(embed_fwd_kernel<bf16_t>, dim3(g), dim3(NT), 0, s, table, V1, E, tokens, ldtok, N, T, drop_p, seed, site, idx_base, (bf16_t*)out),
-             hipLaunchKernelGGL(embed_fwd_kernel<float>, dim3(g), dim3(NT), 0, s, table, V1, E, tokens, ldtok, N, T, drop_p, seed, site, idx_base, (float*)out));
+             hipLaunchKernelGGL(embed_fwd_kernel<bf16_t>, dim3(g), dim3(NT), 0, s, table, V1, E, tokens, ldtok, N, T, drop_p, seed, site, idx_base, relu, (bf16_t*)out),
+             hipLaunchKernelGGL(embed_fwd_kernel<float>, dim3(g), dim3(NT), 0, s, table, V1, E, tokens, ldtok, N, T, drop_p, seed, site, idx_base, relu, (float*)out));
   UIC_LAUNCH_CHECK("embed_fwd");
   return UIC_OK;
 }
@@ -621,6 +671,20 @@ int uic_sample_step_launch(const UicSampleParams& p, hipStream_t s) {
   if (p.N == 0) return UIC_OK;
   hipLaunchKernelGGL(sample_step_kernel, dim3(p.N), dim3(NT), 0, s, p);
   UIC_LAUNCH_CHECK("sample_step");
+  return UIC_OK;
+}
+int uic_maxout_lstm_bwd_launch(const UicLstmBwdParams& p, hipStream_t s) {
+  UIC_REQUIRE(p.dc && p.gates && p.c && p.dgates, "maxout_lstm_bwd: null pointer");
+  if (p.M == 0) return UIC_OK;
+  const int g = grid_for((size_t)p.M * p.H, NT);
+  DISPATCH_T(p.dtype, hipLaunchKernelGGL(maxout_lstm_bwd_kernel<bf16_t>, dim3(g), dim3(NT), 0, s, p),
+             hipLaunchKernelGGL(maxout_lstm_bwd_kernel<float>, dim3(g), dim3(NT), 0, s, p));
+  UIC_LAUNCH_CHECK("maxout_lstm_bwd");
+  return UIC_OK;
+}
+int uic_sample_fixup_launch(int N, int L, int ld, const int* n_unfinished, int64_t* seq, float* seq_logp, hipStream_t s) {
+  hipLaunchKernelGGL(sample_fixup_kernel, dim3(8), dim3(NT), 0, s, N, L, ld, n_unfinished, seq, seq_logp);
+  UIC_LAUNCH_CHECK("sample_fixup");
   return UIC_OK;
 }
 int uic_dropout_mask_launch(float* out, size_t n, float p, unsigned seed, unsigned site, size_t base, hipStream_t s) {

@@ -11,22 +11,12 @@
 //     gradient is one GEMM over the T*N stacked rows afterwards, and the attention's [N,R,*]
 //     gradients are produced by one deferred pass (attention.hip).
 #include "uic_common.h"
+#include "uic_host.h"
 #include "../../include/uic_hip.h"
 #include <string.h>
 #include <stdlib.h>
 
 namespace {
-
-struct Bump {
-  char* base;
-  size_t off;
-  void* take(size_t bytes) {
-    off = (off + 255) & ~(size_t)255;
-    void* p = base ? base + off : nullptr;
-    off += bytes;
-    return p;
-  }
-};
 
 struct Layout {
   // forward activations
@@ -51,11 +41,6 @@ struct Layout {
   int64_t* s_it; int* s_unf; int* s_nunf;
   size_t total;
 };
-
-inline size_t rup8(size_t x) { return (x + 7) & ~(size_t)7; }
-// padded vocabulary width (leading dimension of logits / dlogits): a multiple of 64 for real vocabularies so the
-// K = V1 backward GEMM runs on the 128-byte-round LDS-DMA path, a multiple of 8 for toy sizes
-inline size_t vpad(size_t v1) { return v1 >= 1024 ? (v1 + 63) & ~(size_t)63 : rup8(v1); }
 
 Layout make_layout(const uic_topdown_dims& d, void* ws) {
   Layout L;
@@ -201,52 +186,6 @@ int check_dims(const uic_topdown_dims* d) {
   UIC_REQUIRE(d->D % 8 == 0 && d->Dfc % 8 == 0 && d->H % 8 == 0 && d->E % 8 == 0 && d->A % 8 == 0,
               "D=%d Dfc=%d H=%d E=%d A=%d must all be multiples of 8", d->D, d->Dfc, d->H, d->E, d->A);
   UIC_REQUIRE(d->drop_p >= 0.f && d->drop_p < 1.f, "drop_p=%f outside [0,1)", (double)d->drop_p);
-  return UIC_OK;
-}
-
-inline const char* off(const void* p, size_t elems, int dtype) { return (const char*)p + elems * uic_dtype_size(dtype); }
-inline char* offw(void* p, size_t elems, int dtype) { return (char*)p + elems * uic_dtype_size(dtype); }
-
-UicGemmParams gemm_base(int dtype, int M, int N) {
-  UicGemmParams g;
-  memset(&g, 0, sizeof(g));
-  g.dtype = dtype; g.M = M; g.N = N;
-  return g;
-}
-inline void add_seg(UicGemmParams& g, const void* A, int lda, const void* B, int ldb, int K) {
-  UicGemmSeg& s = g.seg[g.nseg++];
-  s.A = A; s.B = B; s.K = K; s.lda = lda; s.ldb = ldb;
-}
-
-// Weight gradient(s) C_i = left[lrows, K] * right[cols_i, K]^T for one or several destinations that share `left`
-// (right operands stacked row-wise in `right`).  Long-K, few-tile problems run split-K over workgroups on the
-// LDS-DMA GEMM with deterministic slab reduction; anything else falls back to one direct GEMM per destination.
-struct WDest { float* C; int ldc; int col0; int ncols; };
-int wgrad_multi(const Layout& L, int dt, const void* left, int lrows, const void* right, int rrows, int K,
-                const WDest* dst, int nd, hipStream_t s) {
-  const long blocks = (long)((lrows + 127) / 128) * ((rrows + 127) / 128);
-  if (uic_gemm_glds_eligible(dt, K) && lrows >= 128 && rrows >= 128) {
-    const int nt = K / (dt == UIC_BF16 ? 64 : 32);
-    int sk = (int)((384 + blocks - 1) / blocks);
-    if (sk > 8) sk = 8;
-    if (sk > nt / 4) sk = nt / 4 > 0 ? nt / 4 : 1;
-    while (sk > 1 && (size_t)sk * lrows * rrows * 4 > L.slab_bytes) --sk;
-    if ((size_t)sk * lrows * rrows * 4 <= L.slab_bytes && (sk > 1 || nd > 1)) {
-      UicGemmParams g = gemm_base(dt, lrows, rrows);
-      add_seg(g, left, K, right, K, K);
-      g.splitk = sk; g.slab = L.slab;
-      UIC_TRY(uic_gemm_launch(g, s));
-      for (int i = 0; i < nd; ++i)
-        UIC_TRY(uic_splitk_reduce_launch(L.slab, sk, lrows, rrows, dst[i].col0, dst[i].ncols, dst[i].C, dst[i].ldc, s));
-      return UIC_OK;
-    }
-  }
-  for (int i = 0; i < nd; ++i) {
-    UicGemmParams g = gemm_base(dt, lrows, dst[i].ncols);
-    add_seg(g, left, K, (const char*)right + (size_t)dst[i].col0 * K * uic_dtype_size(dt), K, K);
-    g.C = dst[i].C; g.ldc = dst[i].ldc; g.flags = UIC_GEMM_OUT_F32;
-    UIC_TRY(uic_gemm_launch(g, s));
-  }
   return UIC_OK;
 }
 
@@ -459,7 +398,7 @@ struct Step {
     const void *f, *a;
     UIC_TRY(prepare_features(d, w, dv, b, L, drop_p, seed, &f, &a, s));
     // xt_t = dropout(relu(embed[labels[:, t]])) for all steps (AttModel.py:145,160)
-    UIC_TRY(uic_embed_fwd_launch(dt, w->embed_w, V1, E, b->labels, b->ld_labels, N, t_run, drop_p, seed, UIC_SITE_EMBED, 0, L.xt_all, s));
+    UIC_TRY(uic_embed_fwd_launch(dt, w->embed_w, V1, E, b->labels, b->ld_labels, N, t_run, drop_p, seed, UIC_SITE_EMBED, 0, 1, L.xt_all, s));
     {  // Gx = xt W_ih[:, 2H:]^T + b_ih + b_hh, all steps
       UicGemmParams g = gemm_base(dt, Meff, H4);
       add_seg(g, L.xt_all, E, off(dv.att_w_ih, 2 * H, dt), ldih, E);
@@ -629,7 +568,7 @@ struct Step {
   int bwd_epilogue(hipStream_t s) {
     auto wgrad = [&](const void* left, int lrows, const void* right, int rrows, int K, float* C, int ldc) -> int {
       const WDest d1{C, ldc, 0, rrows};
-      return wgrad_multi(L, dt, left, lrows, right, rrows, K, &d1, 1, s);
+      return wgrad_multi(L.slab, L.slab_bytes, dt, left, lrows, right, rrows, K, &d1, 1, s);
     };
     // per LSTM ONE GEMM dG^T [4H, T*N] x [stacked inputs]^T; lang_lstm inputs [att_res | h_att | h_lang_prev]
     UIC_TRY(uic_transpose_launch(dt, L.dg2_all, Meff, H4, H4, L.tA, Mp, s));
@@ -638,7 +577,7 @@ struct Step {
     UIC_TRY(uic_transpose_launch(dt, L.h_lang, Meff, H, H, offw(L.tB, (size_t)2 * H * Mp, dt), Mp, s));
     {
       const WDest dd[2] = {{G->lang_lstm_w_ih, 2 * H, 0, 2 * H}, {G->lang_lstm_w_hh, H, 2 * H, H}};
-      UIC_TRY(wgrad_multi(L, dt, L.tA, H4, L.tB, 3 * H, Mp, dd, 2, s));
+      UIC_TRY(wgrad_multi(L.slab, L.slab_bytes, dt, L.tA, H4, L.tB, 3 * H, Mp, dd, 2, s));
     }
     UIC_TRY(uic_colsum_launch(dt, L.dg2_all, Meff, H4, H4, G->lang_lstm_b_ih, L.colscratch, L.colscratch_floats, s));
     UIC_TRY(uic_check_hip(hipMemcpyAsync(G->lang_lstm_b_hh, G->lang_lstm_b_ih, (size_t)H4 * 4, hipMemcpyDeviceToDevice, s), "memcpy b_hh"));
@@ -649,7 +588,7 @@ struct Step {
     UIC_TRY(uic_transpose_launch(dt, L.h_att, Meff, H, H, offw(L.tB, (size_t)(H + E) * Mp, dt), Mp, s));
     {
       const WDest dd[3] = {{G->att_lstm_w_ih, ldih, 0, H}, {G->att_lstm_w_ih + 2 * H, ldih, H, E}, {G->att_lstm_w_hh, H, H + E, H}};
-      UIC_TRY(wgrad_multi(L, dt, L.tA, H4, L.tB, 2 * H + E, Mp, dd, 3, s));
+      UIC_TRY(wgrad_multi(L.slab, L.slab_bytes, dt, L.tA, H4, L.tB, 2 * H + E, Mp, dd, 3, s));
     }
     UIC_TRY(uic_colsum_launch(dt, L.dg1_all, Meff, H4, H4, G->att_lstm_b_ih, L.colscratch, L.colscratch_floats, s));
     UIC_TRY(uic_check_hip(hipMemcpyAsync(G->att_lstm_b_hh, G->att_lstm_b_ih, (size_t)H4 * 4, hipMemcpyDeviceToDevice, s), "memcpy b_hh"));
@@ -863,7 +802,7 @@ int uic_topdown_sample(const uic_topdown_dims* d, const uic_topdown_weights* w, 
   UIC_TRY(uic_fill_launch(L.s_nunf, 0, (size_t)(d->T + 2) * 4, s));
   for (int t = 0; t < Lsteps; ++t) {
     const int cur = t & 1, nxt = cur ^ 1;
-    UIC_TRY(uic_embed_fwd_launch(dt, w->embed_w, V1, E, L.s_it, 1, N, 1, drop_p, seed, UIC_SITE_EMBED, (size_t)t * N * E, L.s_xt, s));
+    UIC_TRY(uic_embed_fwd_launch(dt, w->embed_w, V1, E, L.s_it, 1, N, 1, drop_p, seed, UIC_SITE_EMBED, (size_t)t * N * E, 1, L.s_xt, s));
     {
       UicGemmParams g = gemm_base(dt, N, H4);
       g.lstm = 1; g.H = H;

@@ -224,7 +224,7 @@ int uic_colsum_launch(int src_dtype, const void* src, int rows, int cols, int ld
 // dst[n, c] = sum_t src[t, n, c]
 int uic_sum_steps_launch(int dtype, const void* src, int T, size_t step_elems, void* dst, hipStream_t s);
 int uic_embed_fwd_launch(int dtype, const float* table, int V1, int E, const int64_t* tokens, int ldtok, int N, int T,
-                         float drop_p, unsigned seed, unsigned site, size_t idx_base, void* out, hipStream_t s);
+                         float drop_p, unsigned seed, unsigned site, size_t idx_base, int relu, void* out, hipStream_t s);
 int uic_embed_bwd_launch(int dtype, const float* dxt, const void* xt, const int64_t* tokens, int ldtok, int N, int T,
                          int V1, int E, float drop_p, float* dtable, hipStream_t s);
 // dst = (act > 0 ? scale : 0) * grad ; grad f32, act/dst operand dtype
@@ -243,6 +243,8 @@ struct UicLstmBwdParams {
   void* dgates;                  // [M,4H] operand dtype out
 };
 int uic_lstm_bwd_launch(const UicLstmBwdParams& p, hipStream_t s);
+int uic_maxout_lstm_bwd_launch(const UicLstmBwdParams& p, hipStream_t s);   // gates/dgates are [M,5H]; dh = (dh0 + dh1) * dropout
+int uic_sample_fixup_launch(int N, int L, int ld, const int* n_unfinished, int64_t* seq, float* seq_logp, hipStream_t s);
 
 struct UicXeParams {
   int dtype, M, V1, ldv;         // logits f32 [M, ldv] in; dlogits [M, ldv] operand dtype out
@@ -284,6 +286,8 @@ struct UicSampleParams {
   int* n_unfinished;             // [L+1] live-row counters per step
   const int64_t* forced;         // optional [N, L] tokens replacing the multinomial draw
   float* logprobs_out;           // optional [N, V1]
+  int fc_mode;                   // FCModel_NMT._sample semantics (raw token fed forward, break before write)
+  int ld_out;                    // row stride of seq / seq_logp (0 = L)
 };
 int uic_sample_step_launch(const UicSampleParams& p, hipStream_t s);
 int uic_dropout_mask_launch(float* out, size_t n, float p, unsigned seed, unsigned site, size_t base, hipStream_t s);

@@ -1,0 +1,72 @@
+// Host-side helpers shared by the model-level sequencers (topdown.hip, fcmodel.hip).
+#pragma once
+#include "uic_common.h"
+#include <string.h>
+
+namespace {
+
+// bump allocator over a caller-provided arena (base == nullptr: size query)
+struct Bump {
+  char* base;
+  size_t off;
+  void* take(size_t bytes) {
+    off = (off + 255) & ~(size_t)255;
+    void* p = base ? base + off : nullptr;
+    off += bytes;
+    return p;
+  }
+};
+
+inline size_t rup8(size_t x) { return (x + 7) & ~(size_t)7; }
+// padded vocabulary width (leading dimension of logits / dlogits): a multiple of 64 for real vocabularies so the
+// K = V1 backward GEMM runs on the 128-byte-round LDS-DMA path, a multiple of 8 for toy sizes
+inline size_t vpad(size_t v1) { return v1 >= 1024 ? (v1 + 63) & ~(size_t)63 : rup8(v1); }
+
+inline const char* off(const void* p, size_t elems, int dtype) { return (const char*)p + elems * uic_dtype_size(dtype); }
+inline char* offw(void* p, size_t elems, int dtype) { return (char*)p + elems * uic_dtype_size(dtype); }
+
+inline UicGemmParams gemm_base(int dtype, int M, int N) {
+  UicGemmParams g;
+  memset(&g, 0, sizeof(g));
+  g.dtype = dtype; g.M = M; g.N = N;
+  return g;
+}
+inline void add_seg(UicGemmParams& g, const void* A, int lda, const void* B, int ldb, int K) {
+  UicGemmSeg& s = g.seg[g.nseg++];
+  s.A = A; s.B = B; s.K = K; s.lda = lda; s.ldb = ldb;
+}
+
+// Weight gradient(s) C_i = left[lrows, K] * right[cols_i, K]^T for one or several destinations that share `left`
+// (right operands stacked row-wise in `right`).  Long-K, few-tile problems run split-K over workgroups on the
+// LDS-DMA GEMM with deterministic slab reduction; anything else falls back to one direct GEMM per destination.
+struct WDest { float* C; int ldc; int col0; int ncols; };
+inline int wgrad_multi(float* slab, size_t slab_bytes, int dt, const void* left, int lrows, const void* right, int rrows, int K,
+                const WDest* dst, int nd, hipStream_t s) {
+  const long blocks = (long)((lrows + 127) / 128) * ((rrows + 127) / 128);
+  if (uic_gemm_glds_eligible(dt, K) && lrows >= 128 && rrows >= 128) {
+    const int nt = K / (dt == UIC_BF16 ? 64 : 32);
+    int sk = (int)((384 + blocks - 1) / blocks);
+    if (sk > 8) sk = 8;
+    if (sk > nt / 4) sk = nt / 4 > 0 ? nt / 4 : 1;
+    while (sk > 1 && (size_t)sk * lrows * rrows * 4 > slab_bytes) --sk;
+    if ((size_t)sk * lrows * rrows * 4 <= slab_bytes && (sk > 1 || nd > 1)) {
+      UicGemmParams g = gemm_base(dt, lrows, rrows);
+      add_seg(g, left, K, right, K, K);
+      g.splitk = sk; g.slab = slab;
+      UIC_TRY(uic_gemm_launch(g, s));
+      for (int i = 0; i < nd; ++i)
+        UIC_TRY(uic_splitk_reduce_launch(slab, sk, lrows, rrows, dst[i].col0, dst[i].ncols, dst[i].C, dst[i].ldc, s));
+      return UIC_OK;
+    }
+  }
+  for (int i = 0; i < nd; ++i) {
+    UicGemmParams g = gemm_base(dt, lrows, dst[i].ncols);
+    add_seg(g, left, K, (const char*)right + (size_t)dst[i].col0 * K * uic_dtype_size(dt), K, K);
+    g.C = dst[i].C; g.ldc = dst[i].ldc; g.flags = UIC_GEMM_OUT_F32;
+    UIC_TRY(uic_gemm_launch(g, s));
+  }
+  return UIC_OK;
+}
+
+
+}  // namespace

@@ -2,9 +2,12 @@
 the architectures on the hot path."""
 from .AttModel import TopDownModel  # noqa: F401
 from .CaptionModel import CaptionModel  # noqa: F401
+from .FCModel_NMT import FCModel_NMT  # noqa: F401
 
 
 def setup(opt):
+    if opt.caption_model == 'fc':
+        return FCModel_NMT(opt)          # P/models/__init__.py:24-26
     if opt.caption_model == 'topdown':
         return TopDownModel(opt)
     raise Exception("Caption model not supported by the MI355X hot path: {}".format(opt.caption_model))
