@@ -13,3 +13,4 @@ against every one of them.
 """
 from . import topdown  # noqa: F401
 from . import fc  # noqa: F401
+from . import nmt  # noqa: F401

@@ -1,0 +1,159 @@
+#!/usr/bin/env python3
+"""Golden vectors for the pivot NMT path from the REFERENCE's own modules:
+``models/NMT_Models.py`` (Embeddings, Encoder, Decoder, NMTModel.forward) with the vendored OpenNMT fork's
+``StackedRNN.py`` / ``GlobalAttention.py`` / ``Util.py`` / ``Gate.py`` and ``misc/criterion.py::NMTCriterion``.
+
+Build-container only.  Harness-side shims (reference files untouched): a synthetic ``onmt``
+package assembled from the py3-clean files of the fork, ``onmt.modules.activations`` and ``evaluation`` stubbed,
+``.cuda()`` neutralised (NMT_Models.py:231 calls it unconditionally), ``nltk`` stubbed.
+
+    python tests/golden/make_golden_nmt.py
+"""
+import argparse
+import importlib.util
+import os
+import sys
+import types
+
+os.environ["PYTHONDONTWRITEBYTECODE"] = "1"
+sys.dont_write_bytecode = True
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+P = "/root/reference/pivot_based_eccv2018"
+O = os.path.join(P, "misc", "OpenNMT-py-dalegebit", "onmt")
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def load(modname, path):
+    spec = importlib.util.spec_from_file_location(modname, path)
+    mod = importlib.util.module_from_spec(spec)
+    sys.modules[modname] = mod
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def load_reference():
+    for name in ("nltk", "nltk.translate", "nltk.translate.bleu_score", "evaluation"):
+        m = types.ModuleType(name)
+        m.__path__ = []
+        sys.modules[name] = m
+    sys.modules["nltk.translate.bleu_score"].SmoothingFunction = object
+    torch.Tensor.cuda = lambda self, *a, **k: self
+    nn.Module.cuda = lambda self, *a, **k: self
+    onmt = types.ModuleType("onmt")
+    onmt.__path__ = []
+    sys.modules["onmt"] = onmt
+    onmt.Constants = load("onmt.Constants", os.path.join(O, "Constants.py"))
+    mods = types.ModuleType("onmt.modules")
+    mods.__path__ = []
+    sys.modules["onmt.modules"] = mods
+    onmt.modules = mods
+    act = types.ModuleType("onmt.modules.activations")
+    for n in ("Softmax", "Sparsemax", "ConstrainedSoftmax", "ConstrainedSparsemax"):
+        setattr(act, n, type(n, (nn.Module,), {}))
+    sys.modules["onmt.modules.activations"] = act
+    util = load("onmt.modules.Util", os.path.join(O, "modules", "Util.py"))
+    mods.aeq, mods.BottleLinear, mods.Bottle = util.aeq, util.BottleLinear, util.Bottle
+    srnn = load("onmt.modules.StackedRNN", os.path.join(O, "modules", "StackedRNN.py"))
+    mods.StackedLSTM, mods.StackedGRU = srnn.StackedLSTM, srnn.StackedGRU
+    ga = load("onmt.modules.GlobalAttention", os.path.join(O, "modules", "GlobalAttention.py"))
+    mods.GlobalAttention = ga.GlobalAttention
+    load("onmt.modules.Gate", os.path.join(O, "modules", "Gate.py"))
+    sys.path.insert(0, P)
+    pkg = types.ModuleType("models")
+    pkg.__path__ = [os.path.join(P, "models")]
+    sys.modules["models"] = pkg
+    nmt = load("models.NMT_Models", os.path.join(P, "models", "NMT_Models.py"))
+    crit = load("refcriterion", os.path.join(P, "misc", "criterion.py"))
+    return nmt, crit
+
+
+class FakeDict(object):
+    def __init__(self, n):
+        self.n = n
+
+    def size(self):
+        return self.n
+
+    def align(self, other):
+        return [0] * self.n
+
+
+def make_opt(layers, rnn_size, wvec, dropout=0.0):
+    return argparse.Namespace(position_encoding=False, word_vec_size=wvec, dropout=dropout, layers=layers, brnn=True,
+                              rnn_size=rnn_size, encoder_layer="rnn", decoder_layer="rnn", rnn_type="LSTM", fertility=2.0,
+                              predict_fertility=False, supervised_fertility=None, guided_fertility=None, coverage_attn=False,
+                              exhaustion_loss=False, input_feed=1, context_gate=None, attention_type="dotprod",
+                              attn_transform="softmax", c_attn=0.0, copy_attn=False, gpus=[], batch_size=4,
+                              lambda_coverage=1, lambda_fertility=0.4, lambda_exhaust=0.5)
+
+
+def synth_batch(B, S, T, Vs, Vt, seed):
+    """Length-sorted padded src/tgt like onmt_dataset_h5.Batch (P/misc/dataloader/onmt_dataset_h5.py:45-107):
+    src [S,B,1] (PAD = 0), lengths [1,B] descending, tgt [T,B] = BOS .. EOS PAD.."""
+    g = torch.Generator().manual_seed(seed)
+    lens = torch.sort(torch.randint(max(2, S // 2), S + 1, (B,), generator=g), descending=True)[0]
+    lens[0] = S
+    src = torch.zeros(S, B, 1, dtype=torch.long)
+    for b in range(B):
+        src[:lens[b], b, 0] = torch.randint(4, Vs, (int(lens[b]),), generator=g)
+    tl = torch.randint(max(3, T // 2), T + 1, (B,), generator=g)
+    tl[0] = T
+    tgt = torch.zeros(T, B, dtype=torch.long)
+    for b in range(B):
+        n = int(tl[b])
+        tgt[0, b] = 2
+        tgt[1:n - 1, b] = torch.randint(4, Vt, (n - 2,), generator=g)
+        tgt[n - 1, b] = 3
+    return src, lens.view(1, -1), tgt
+
+
+def run_case(nmt, crit_mod, name, layers, H, B, S, T, Vs, Vt, seed):
+    torch.manual_seed(seed)
+    opt = make_opt(layers, H, H)
+    sd, td = FakeDict(Vs), FakeDict(Vt)
+    enc = nmt.Encoder(opt, sd)
+    dec = nmt.Decoder(opt, td)
+    model = nmt.NMTModel(opt, enc, dec, sd, td)
+    generator = nn.Sequential(nn.Linear(H, Vt), nn.LogSoftmax(dim=1))       # P/trainer.py:85
+    model.generator = generator
+    loss_fn = crit_mod.NMTCriterion(Vt, opt)
+    src, lengths, tgt = synth_batch(B, S, T, Vs, Vt, seed)
+    model.train()
+    outputs, attns, dec_state, ub = model(src, tgt, lengths)
+    scores = generator(outputs.view(-1, outputs.size(2)))
+    loss = loss_fn(scores, tgt[1:].view(-1))
+    loss.backward()
+    enc_hidden, context, _ = enc(src, lengths)
+    out = {"cfg": np.array([layers, H, B, S, T, Vs, Vt], dtype=np.int64)}
+    for k, v in model.state_dict().items():
+        out["w::" + k] = v.detach().clone().numpy()
+    out["in::src"] = src.numpy()
+    out["in::lengths"] = lengths.numpy()
+    out["in::tgt"] = tgt.numpy()
+    out["out::context"] = context.detach().numpy()
+    out["out::enc_h"] = model._fix_enc_hidden(enc_hidden[0]).detach().numpy()
+    out["out::enc_c"] = model._fix_enc_hidden(enc_hidden[1]).detach().numpy()
+    out["out::outputs"] = outputs.detach().numpy()
+    out["out::attn"] = attns["std"].detach().numpy()
+    out["out::scores"] = scores.detach().numpy()
+    out["out::loss"] = np.array(loss.item(), dtype=np.float64)
+    pred = scores.max(1)[1]
+    nonpad = tgt[1:].view(-1).ne(0)
+    out["out::num_correct"] = np.array(int((pred.eq(tgt[1:].view(-1)) & nonpad).sum()))
+    out["out::num_words"] = np.array(int(nonpad.sum()))
+    for k, p in model.named_parameters():
+        out["grad::" + k] = p.grad.detach().clone().numpy()
+    path = os.path.join(HERE, name + ".npz")
+    np.savez_compressed(path, **out)
+    print("wrote %s (%.1f KB) loss=%.5f keys=%d" % (path, os.path.getsize(path) / 1024, loss.item(), len(model.state_dict())))
+
+
+if __name__ == "__main__":
+    nmt, crit_mod = load_reference()
+    run_case(nmt, crit_mod, "nmt_tiny", layers=2, H=32, B=4, S=9, T=10, Vs=40, Vt=45, seed=31)
+    run_case(nmt, crit_mod, "nmt_tiny_1layer", layers=1, H=32, B=3, S=6, T=7, Vs=30, Vt=37, seed=32)
+    run_case(nmt, crit_mod, "nmt_odd", layers=2, H=48, B=5, S=11, T=8, Vs=53, Vt=61, seed=33)
