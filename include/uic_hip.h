@@ -177,6 +177,56 @@ int uic_fc_sample(const uic_fc_dims* d, const uic_fc_weights* w, const uic_topdo
                   int32_t sample_max, float temperature, uint32_t seed, const int64_t* forced, void* workspace,
                   int64_t* seq, float* seq_logp, void* stream);
 
+/* ---- pivot NMT step: NMTModel.forward + generator + NMTCriterion and their backward (P/models/NMT_Models.py:27-295,
+ * 414-420; O = misc/OpenNMT-py-dalegebit/onmt: O/modules/StackedRNN.py:20-34, O/modules/GlobalAttention.py:112-167;
+ * P/misc/criterion.py:126-136,161-205).  Supported configuration = the reference's defaults: LSTM, brnn, input_feed,
+ * dotprod attention with softmax, no context gate / coverage / copy attention. ---- */
+#define UIC_NMT_MAX_LAYERS 4
+typedef struct uic_nmt_dims {
+  int32_t B;        /* batch (sentences) */
+  int32_t S;        /* padded source length */
+  int32_t T;        /* padded target length incl. BOS/EOS; the decoder runs T-1 steps on tgt[:-1] */
+  int32_t H;        /* rnn_size (encoder direction size = H/2) */
+  int32_t W;        /* word_vec_size */
+  int32_t layers;
+  int32_t Vs, Vt;   /* source / target dictionary sizes */
+  int32_t dtype;
+  float drop_p;     /* opt.dropout */
+} uic_nmt_dims;
+
+typedef struct uic_nmt_weights {     /* keys of NMTModel.state_dict() + generator (P/trainer.py:85-89) */
+  float* enc_lut;                                   /* encoder.embeddings.word_lut.weight   [Vs, W]   */
+  float* enc_lin_w;                                 /* encoder.embeddings.linear.weight     [W, W]    */
+  float* enc_lin_b;                                 /* encoder.embeddings.linear.bias       [W]       */
+  float* enc_w_ih[UIC_NMT_MAX_LAYERS][2];           /* encoder.rnn.weight_ih_l{k}[_reverse] [4H/2, in]*/
+  float* enc_w_hh[UIC_NMT_MAX_LAYERS][2];           /* encoder.rnn.weight_hh_l{k}[_reverse] [4H/2, H/2] */
+  float* enc_b_ih[UIC_NMT_MAX_LAYERS][2];
+  float* enc_b_hh[UIC_NMT_MAX_LAYERS][2];
+  float* dec_lut;                                   /* decoder.embeddings.word_lut.weight   [Vt, W]   */
+  float* dec_w_ih[UIC_NMT_MAX_LAYERS];              /* decoder.rnn.layers.{k}.weight_ih     [4H, W+H | H] */
+  float* dec_w_hh[UIC_NMT_MAX_LAYERS];              /* decoder.rnn.layers.{k}.weight_hh     [4H, H]   */
+  float* dec_b_ih[UIC_NMT_MAX_LAYERS];
+  float* dec_b_hh[UIC_NMT_MAX_LAYERS];
+  float* attn_in_w;                                 /* decoder.attn.linear_in.weight        [H, H]    */
+  float* attn_out_w;                                /* decoder.attn.linear_out.weight       [H, 2H]   */
+  float* gen_w;                                     /* generator.0.weight                   [Vt, H]   */
+  float* gen_b;                                     /* generator.0.bias                     [Vt]      */
+} uic_nmt_weights;
+
+size_t uic_nmt_workspace_bytes(const uic_nmt_dims* d);
+/* Forward + loss: src [S,B] int64 (PAD = 0), lengths sorted descending (host AND device copies: the reference moves
+ * them to the host for pack_padded_sequence too), tgt [T,B] int64.  Outputs (all optional except loss): loss_out[0] =
+ * sum of NLL over non-PAD targets; stats_out = {num_correct, num_words} (int32, device); outputs_out [T-1,B,H] and
+ * attn_out [T-1,B,S] f32 as returned by NMTModel.forward; context_out [S,B,H] f32. */
+int uic_nmt_forward_loss(const uic_nmt_dims* d, const uic_nmt_weights* w, const int64_t* src, const int32_t* lengths_host,
+                         const int32_t* lengths_dev, const int64_t* tgt, int32_t training, uint32_t seed, void* workspace,
+                         float* loss_out, int32_t* stats_out, float* outputs_out, float* attn_out, float* context_out,
+                         void* stream);
+/* Backward of the sum-NLL loss left in the workspace by uic_nmt_forward_loss; every tensor of `grads` is overwritten. */
+int uic_nmt_backward(const uic_nmt_dims* d, const uic_nmt_weights* w, const int64_t* src, const int32_t* lengths_host,
+                     const int64_t* tgt, int32_t training, uint32_t seed, void* workspace, const uic_nmt_weights* grads,
+                     void* stream);
+
 /* ---- single operators (also used by the parity tests) ---- */
 
 /* nn.Linear as C[M,N] = A[M,K] B[N,K]^T (+bias)(+ReLU); flags: 1 ReLU, 2 accumulate into C, 4 C is f32. */
@@ -232,6 +282,9 @@ int uic_dropout_mask(float* out, size_t n, float p, uint32_t seed, uint32_t site
 #define UIC_SITE_ATT 2u
 #define UIC_SITE_EMBED 3u
 #define UIC_SITE_OUT0 16u   /* + decode step */
+#define UIC_SITE_NMT_ENC0 1000u  /* + l: nn.LSTM dropout after encoder layer l, element (s*B + b)*H + j           */
+#define UIC_SITE_NMT_DEC0 2000u  /* + l*256 + t: StackedLSTM dropout after decoder layer l at step t, element b*H+j */
+#define UIC_SITE_NMT_OUT0 4000u  /* + t: Decoder.dropout on the attentional output of step t, element b*H + j      */
 
 #ifdef __cplusplus
 }

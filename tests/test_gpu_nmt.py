@@ -1,0 +1,235 @@
+"""GPU parity of the pivot NMT step (Embeddings + packed bi-LSTM Encoder, input-feed
+StackedLSTM Decoder with dot GlobalAttention, generator + NMTCriterion) against golden vectors from the reference's own
+modules (tests/golden/nmt_*.npz) and against the CPU oracle on seeded inputs, through the C ABI
+(uic_nmt_forward_loss / uic_nmt_backward) behind the reference-shaped python surface."""
+import argparse
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import GOLDEN
+from oracle import nmt as ON
+from test_gpu_topdown import absmax, grads_close
+
+pytestmark = pytest.mark.gpu
+
+OUT_TOL = {"f32": 1e-3, "bf16": 2e-2}       # decoder outputs are tanh-bounded; attention weights are probabilities
+GRAD_TOL = {"f32": 2e-3, "bf16": 1e-1}      # f32: max-entry error; bf16: L2 error (see grads_close)
+
+
+def load(name):
+    z = np.load(os.path.join(GOLDEN, name + ".npz"))
+    W = {k[3:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("w::")}
+    I = {k[4:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("in::")}
+    Out = {k[5:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("out::")}
+    G = {k[6:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("grad::")}
+    layers, H, B, S, T, Vs, Vt = [int(x) for x in z["cfg"]]
+    cfg = dict(layers=layers, H=H, W=W["encoder.embeddings.word_lut.weight"].shape[1], B=B, S=S, T=T, Vs=Vs, Vt=Vt)
+    return cfg, W, I, Out, G
+
+
+def make_opt(cfg, dtype, dropout=0.0, seed=0):
+    return argparse.Namespace(layers=cfg["layers"], rnn_size=cfg["H"], word_vec_size=cfg["W"], brnn=True, rnn_type="LSTM",
+                              dropout=dropout, input_feed=1, position_encoding=False, coverage_attn=False, copy_attn=False,
+                              context_gate=None, attention_type="dot", attn_transform="softmax", fertility=None,
+                              predict_fertility=False, guided_fertility=None, supervised_fertility=None,
+                              lambda_coverage=0, lambda_fertility=0, lambda_exhaust=0, batch_size=cfg["B"], gpus=[0],
+                              compute_dtype=dtype, seed=seed)
+
+
+def build(cfg, W, dtype, dropout=0.0, seed=0):
+    """The construction sequence of P/trainer.py:80-94."""
+    import torch.nn as nn
+    from unpaired_image_captioning_amd.models import NMT_Models
+    from unpaired_image_captioning_amd.misc import criterion
+    opt = make_opt(cfg, dtype, dropout, seed)
+    enc = NMT_Models.Encoder(opt, cfg["Vs"])
+    dec = NMT_Models.Decoder(opt, cfg["Vt"])
+    model = NMT_Models.NMTModel(opt, enc, dec, None, None, False)
+    gen = nn.Sequential(nn.Linear(opt.rnn_size, cfg["Vt"]), nn.LogSoftmax(dim=-1))
+    model.generator = gen
+    if W is not None:
+        assert list(model.state_dict().keys()) == list(W.keys())
+        model.load_state_dict(W)
+    model.cuda()
+    crit = criterion.NMT_loss(opt, gen, criterion.NMTCriterion(cfg["Vt"], opt))
+    return model, crit
+
+
+def run(model, crit, I):
+    Batch = argparse.Namespace
+    batch = Batch(src=I["src"].cuda(), tgt=I["tgt"].cuda(), lengths=I["lengths"])
+    outputs, attns, dec_state, ub = model(batch.src, batch.tgt, batch.lengths, None)
+    loss = crit(None, batch, outputs, attns)
+    return outputs, attns["std"], loss
+
+
+def test_nmt_state_dict_matches_reference_contract():
+    cfg, W, I, Out, G = load("nmt_tiny")
+    model, _ = build(cfg, None, "f32")
+    sd = model.state_dict()
+    assert list(sd.keys()) == list(W.keys())
+    for k in W:
+        assert tuple(sd[k].shape) == tuple(W[k].shape), k
+
+
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+@pytest.mark.parametrize("name", ["nmt_tiny", "nmt_tiny_1layer", "nmt_odd"])
+def test_nmt_forward_loss_backward_vs_reference_golden(name, dtype):
+    cfg, W, I, Out, G = load(name)
+    model, crit = build(cfg, W, dtype)
+    model.train()
+    outputs, attn, loss = run(model, crit, I)
+    assert absmax(outputs, Out["outputs"]) < OUT_TOL[dtype]
+    assert absmax(attn, Out["attn"]) < OUT_TOL[dtype]
+    n_words = int(Out["num_words"])
+    assert abs(loss.item() - float(Out["loss"])) < OUT_TOL[dtype] * n_words
+    assert crit.report_stats.n_words == n_words
+    if dtype == "f32":
+        assert crit.report_stats.n_correct == int(Out["num_correct"])
+    assert abs(crit.report_stats.ppl() - float(np.exp(min(float(Out["loss"]) / n_words, 100)))) < 5e-2 * crit.report_stats.ppl()
+    loss.backward()
+    grads = {k: p.grad for k, p in model.named_parameters()}
+    assert all(g is not None for g in grads.values())
+    grads_close(grads, G, GRAD_TOL[dtype])
+    # nn.Embedding(padding_idx=PAD): no gradient reaches the PAD rows
+    assert grads["encoder.embeddings.word_lut.weight"][0].abs().max().item() == 0
+    assert grads["decoder.embeddings.word_lut.weight"][0].abs().max().item() == 0
+
+
+def test_nmt_context_and_workspace_api_f32():
+    """Raw C-ABI call: context (memory bank) output, padded source positions exactly zero (pad_packed_sequence)."""
+    import ctypes as C
+    from unpaired_image_captioning_amd import _lib as L
+    cfg, W, I, Out, G = load("nmt_odd")
+    lib = L.load()
+    d = L.NmtDims(B=cfg["B"], S=cfg["S"], T=cfg["T"], H=cfg["H"], W=cfg["W"], layers=cfg["layers"], Vs=cfg["Vs"], Vt=cfg["Vt"],
+                  dtype=L.F32, drop_p=0.0)
+    nbytes = lib.uic_nmt_workspace_bytes(C.byref(d))
+    assert nbytes > 0
+    ws = torch.empty(nbytes, dtype=torch.uint8, device="cuda")
+    Wd = {k: v.cuda().contiguous() for k, v in W.items()}
+    w = L.nmt_weights(Wd, cfg["layers"])
+    src = I["src"][:, :, 0].contiguous().cuda()
+    tgt = I["tgt"].contiguous().cuda()
+    lens_h = [int(x) for x in I["lengths"].reshape(-1).tolist()]
+    lens = (C.c_int32 * cfg["B"])(*lens_h)
+    lens_d = torch.tensor(lens_h, dtype=torch.int32, device="cuda")
+    loss = torch.zeros(1, device="cuda")
+    stats = torch.zeros(2, dtype=torch.int32, device="cuda")
+    context = torch.empty(cfg["S"], cfg["B"], cfg["H"], device="cuda")
+    L.check(lib.uic_nmt_forward_loss(C.byref(d), C.byref(w), L.ptr(src), lens, L.ptr(lens_d), L.ptr(tgt), 1, 0, L.ptr(ws),
+                                     L.ptr(loss), L.ptr(stats), None, None, L.ptr(context), L.stream()), "nmt_forward_loss")
+    assert absmax(context, Out["context"]) < 1e-4
+    for b, n in enumerate(lens_h):
+        assert context[n:, b].abs().max().item() == 0 if n < cfg["S"] else True
+    assert abs(loss.item() - float(Out["loss"])) < 1e-2
+    assert stats.tolist() == [int(Out["num_correct"]), int(Out["num_words"])]
+    # unsorted lengths are rejected like pack_padded_sequence does
+    bad = (C.c_int32 * cfg["B"])(*sorted(lens_h))
+    if sorted(lens_h) != lens_h:
+        rc = lib.uic_nmt_forward_loss(C.byref(d), C.byref(w), L.ptr(src), bad, L.ptr(lens_d), L.ptr(tgt), 1, 0, L.ptr(ws),
+                                      L.ptr(loss), None, None, None, None, L.stream())
+        assert rc != 0 and b"sorted" in lib.uic_last_error_string()
+
+
+def synthetic(cfg, seed):
+    g = torch.Generator().manual_seed(seed)
+    B, S, T = cfg["B"], cfg["S"], cfg["T"]
+    lengths = torch.sort(torch.randint(max(1, S // 3), S + 1, (B,), generator=g), descending=True)[0]
+    lengths[0] = S
+    src = torch.randint(4, cfg["Vs"], (S, B), generator=g)
+    for b in range(B):
+        src[lengths[b]:, b] = 0
+    tl = torch.randint(max(3, T // 2), T + 1, (B,), generator=g)
+    tl[0] = T
+    tgt = torch.randint(4, cfg["Vt"], (T, B), generator=g)
+    tgt[0] = 2                                     # BOS
+    for b in range(B):
+        tgt[tl[b] - 1, b] = 3                      # EOS
+        tgt[tl[b]:, b] = 0
+    return dict(src=src.unsqueeze(2), tgt=tgt, lengths=lengths.view(1, -1))
+
+
+def random_weights(cfg, seed, scale=0.1):
+    model, _ = build(cfg, None, "f32")
+    g = torch.Generator().manual_seed(seed)
+    return {k: (torch.rand(v.shape, generator=g) * 2 - 1) * scale for k, v in model.state_dict().items()}
+
+
+MID = dict(layers=2, H=256, W=192, B=24, S=21, T=17, Vs=900, Vt=1100)
+
+
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+def test_nmt_mid_size_vs_oracle(dtype):
+    cfg = MID
+    W = random_weights(cfg, 11)
+    I = synthetic(cfg, 5)
+    ref_loss, ref_g, aux = ON.loss_and_grads(W, I["src"], I["tgt"], I["lengths"])
+    model, crit = build(cfg, W, dtype)
+    model.train()
+    outputs, attn, loss = run(model, crit, I)
+    assert absmax(outputs, aux["outputs"]) < OUT_TOL[dtype]
+    assert absmax(attn, aux["attn"]) < OUT_TOL[dtype]
+    assert abs(loss.item() - ref_loss.item()) < OUT_TOL[dtype] * aux["num_words"]
+    loss.backward()
+    grads_close({k: p.grad for k, p in model.named_parameters()}, ref_g, GRAD_TOL[dtype])
+
+
+def export_masks(cfg, seed, p):
+    """The multiplicative masks the kernels use, in the oracle's `drop` layout."""
+    from unpaired_image_captioning_amd import _lib as L
+    lib = L.load()
+    B, S, Td, H, NL = cfg["B"], cfg["S"], cfg["T"] - 1, cfg["H"], cfg["layers"]
+
+    def mask(site, n):
+        out = torch.empty(n, device="cuda")
+        L.check(lib.uic_dropout_mask(L.ptr(out), n, p, seed, site, 0, L.stream()))
+        return out.cpu()
+
+    enc = [mask(L.SITE_NMT_ENC0 + l, S * B * H).view(S, B, H) for l in range(NL - 1)]
+    dec = [torch.stack([mask(L.SITE_NMT_DEC0 + l * 256 + t, B * H).view(B, H) for t in range(Td)]) for l in range(NL - 1)]
+    out = torch.stack([mask(L.SITE_NMT_OUT0 + t, B * H).view(B, H) for t in range(Td)])
+    return dict(enc=enc, dec=dec, out=out)
+
+
+@pytest.mark.parametrize("name", ["nmt_tiny", "nmt_odd"])
+def test_nmt_dropout_matches_oracle_with_exported_masks(name):
+    cfg, W, I, Out, G = load(name)
+    p = 0.3
+    model, crit = build(cfg, W, "f32", dropout=p, seed=77)
+    model.train()
+    outputs, attn, loss = run(model, crit, I)
+    drop = export_masks(cfg, model._last_seed, p)
+    ref_loss, ref_g, aux = ON.loss_and_grads(W, I["src"], I["tgt"], I["lengths"], drop)
+    assert absmax(outputs, aux["outputs"]) < 1e-3
+    assert abs(loss.item() - ref_loss.item()) < 1e-3 * aux["num_words"]
+    assert abs(loss.item() - float(Out["loss"])) > 1e-3          # dropout did change the result
+    loss.backward()
+    grads_close({k: q.grad for k, q in model.named_parameters()}, ref_g, 2e-3)
+    # eval mode: no dropout, equals the golden
+    model.eval()
+    outputs, attn, loss = run(model, crit, I)
+    assert absmax(outputs, Out["outputs"]) < 1e-3
+
+
+def test_nmt_training_reduces_loss_bf16():
+    cfg = dict(layers=2, H=128, W=128, B=16, S=12, T=11, Vs=200, Vt=220)
+    I = synthetic(cfg, 3)
+    torch.manual_seed(0)
+    model, crit = build(cfg, None, "bf16", dropout=0.1, seed=5)
+    for p in model.parameters():
+        p.data.uniform_(-0.1, 0.1)
+    opt = torch.optim.Adam(model.parameters(), lr=5e-3)
+    model.train()
+    first = None
+    for step in range(60):
+        opt.zero_grad()
+        outputs, attn, loss = run(model, crit, I)
+        loss.backward()
+        opt.step()
+        first = loss.item() if first is None else first
+    assert loss.item() < 0.7 * first, (first, loss.item())
+    assert crit.report_stats.accuracy() >= 0.0

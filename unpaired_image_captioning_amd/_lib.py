@@ -68,6 +68,56 @@ class FcWeights(C.Structure):
     _fields_ = [(f, C.c_void_p) for f, _ in FC_WEIGHT_FIELDS]
 
 
+NMT_MAX_LAYERS = 4
+SITE_NMT_ENC0, SITE_NMT_DEC0, SITE_NMT_OUT0 = 1000, 2000, 4000   # + layer ; + layer*256 + step ; + step
+
+
+class NmtDims(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ("B", "S", "T", "H", "W", "layers", "Vs", "Vt", "dtype")] + [("drop_p", C.c_float)]
+
+
+class NmtWeights(C.Structure):
+    _fields_ = [("enc_lut", C.c_void_p), ("enc_lin_w", C.c_void_p), ("enc_lin_b", C.c_void_p)] + \
+               [(f, (C.c_void_p * 2) * NMT_MAX_LAYERS) for f in ("enc_w_ih", "enc_w_hh", "enc_b_ih", "enc_b_hh")] + \
+               [("dec_lut", C.c_void_p)] + \
+               [(f, C.c_void_p * NMT_MAX_LAYERS) for f in ("dec_w_ih", "dec_w_hh", "dec_b_ih", "dec_b_hh")] + \
+               [("attn_in_w", C.c_void_p), ("attn_out_w", C.c_void_p), ("gen_w", C.c_void_p), ("gen_b", C.c_void_p)]
+
+
+def nmt_weight_keys(layers):
+    """(struct field, layer, direction, reference state_dict key) in NMTModel.state_dict() order, generator last."""
+    out = [("enc_lut", None, None, "encoder.embeddings.word_lut.weight"),
+           ("enc_lin_w", None, None, "encoder.embeddings.linear.weight"),
+           ("enc_lin_b", None, None, "encoder.embeddings.linear.bias")]
+    for l in range(layers):
+        for d, suf in ((0, ""), (1, "_reverse")):
+            for f, k in (("enc_w_ih", "weight_ih"), ("enc_w_hh", "weight_hh"), ("enc_b_ih", "bias_ih"), ("enc_b_hh", "bias_hh")):
+                out.append((f, l, d, "encoder.rnn.%s_l%d%s" % (k, l, suf)))
+    out.append(("dec_lut", None, None, "decoder.embeddings.word_lut.weight"))
+    for l in range(layers):
+        for f, k in (("dec_w_ih", "weight_ih"), ("dec_w_hh", "weight_hh"), ("dec_b_ih", "bias_ih"), ("dec_b_hh", "bias_hh")):
+            out.append((f, l, None, "decoder.rnn.layers.%d.%s" % (l, k)))
+    out += [("attn_in_w", None, None, "decoder.attn.linear_in.weight"),
+            ("attn_out_w", None, None, "decoder.attn.linear_out.weight"),
+            ("gen_w", None, None, "generator.0.weight"), ("gen_b", None, None, "generator.0.bias")]
+    return out
+
+
+def nmt_weights(tensors, layers):
+    """Fill a uic_nmt_weights from {reference key: contiguous f32 device tensor}."""
+    w = NmtWeights()
+    for f, l, d, k in nmt_weight_keys(layers):
+        t = tensors[k]
+        assert t.dtype == torch.float32 and t.is_contiguous(), k
+        if l is None:
+            setattr(w, f, t.data_ptr())
+        elif d is None:
+            getattr(w, f)[l] = t.data_ptr()
+        else:
+            getattr(w, f)[l][d] = t.data_ptr()
+    return w
+
+
 class Batch(C.Structure):
     _fields_ = [("fc_feats", C.c_void_p), ("att_feats", C.c_void_p), ("att_masks", C.c_void_p),
                 ("labels", C.c_void_p), ("ld_labels", C.c_int32),
@@ -102,6 +152,12 @@ _SIGS = {
                                   C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(FcWeights), C.c_void_p]),
     "uic_fc_sample": (C.c_int, [C.POINTER(FcDims), C.POINTER(FcWeights), C.POINTER(Batch), C.c_int32, C.c_int32, C.c_float,
                                 C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "uic_nmt_workspace_bytes": (C.c_size_t, [C.POINTER(NmtDims)]),
+    "uic_nmt_forward_loss": (C.c_int, [C.POINTER(NmtDims), C.POINTER(NmtWeights), C.c_void_p, C.POINTER(C.c_int32), C.c_void_p,
+                                       C.c_void_p, C.c_int32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                       C.c_void_p, C.c_void_p, C.c_void_p]),
+    "uic_nmt_backward": (C.c_int, [C.POINTER(NmtDims), C.POINTER(NmtWeights), C.c_void_p, C.POINTER(C.c_int32), C.c_void_p,
+                                   C.c_int32, C.c_uint32, C.c_void_p, C.POINTER(NmtWeights), C.c_void_p]),
     "uic_topdown_workspace_ptr": (C.c_void_p, [C.POINTER(Dims), C.c_void_p, C.c_char_p]),
     "uic_linear": (C.c_int, [C.c_int32] * 4 + [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32,
                              C.c_void_p, C.c_int32, C.c_void_p]),

@@ -284,7 +284,7 @@ int uic_fc_backward(const uic_fc_dims* d, const uic_fc_weights* w, const uic_top
     UIC_TRY(uic_gemm_launch(g, s));
   }
   UIC_TRY(uic_fill_launch(G->embed_w, 0, (size_t)V1 * E * 4, s));
-  UIC_TRY(uic_embed_bwd_launch(dt, L.dx_all + (size_t)N * E, nullptr, b->labels, b->ld_labels, N, s_run - 1, V1, E, 0.f, G->embed_w, s));
+  UIC_TRY(uic_embed_bwd_launch(dt, L.dx_all + (size_t)N * E, nullptr, b->labels, b->ld_labels, N, s_run - 1, V1, E, 0.f, -1, G->embed_w, s));
   // img_embed from d x_0
   UIC_TRY(uic_cast_f32_launch(dt, L.dx_all, L.dx0, (size_t)N * E, s));
   UIC_TRY(uic_transpose_launch(dt, L.dx0, N, E, E, L.tA, Np, s));

@@ -227,6 +227,7 @@ __global__ __launch_bounds__(64 * WM * WN * KS) void uic_gemm_kernel(const UicGe
             if (row >= p.M) continue;
             float v = acc[i][j][reg] + b;
             if (p.flags & UIC_GEMM_RELU) v = fmaxf(v, 0.f);
+            if (p.flags & UIC_GEMM_TANH) v = uic_tanh<T>(v);
             if (p.row_len) {
               const int n = row / p.R;
               if (row - n * p.R >= p.row_len[n]) v = 0.f;
@@ -515,6 +516,7 @@ __global__ __launch_bounds__(256) void uic_gemm_glds_kernel(const UicGemmParams 
         if (row >= p.M) continue;
         float v = acc[i][j][reg] + b;
         if (p.flags & UIC_GEMM_RELU) v = fmaxf(v, 0.f);
+        if (p.flags & UIC_GEMM_TANH) v = uic_tanh<T>(v);
         if (p.row_len) {
           const int n = row / p.R;
           if (row - n * p.R >= p.row_len[n]) v = 0.f;

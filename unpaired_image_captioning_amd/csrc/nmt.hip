@@ -1,0 +1,804 @@
+// Pivot NMT step (zh -> en teacher) on one MI355X: SURVEY.md section 8a rows 12-15.
+//
+// Replaces NMTModel.forward (P/models/NMT_Models.py:414-420) = Embeddings + packed bi-LSTM Encoder (:27-135),
+// _fix_enc_hidden / init_decoder_state (:284-295), input-feed Decoder over StackedLSTM + dot GlobalAttention
+// (:183-271, O/modules/StackedRNN.py:20-34, O/modules/GlobalAttention.py:112-167), the generator +
+// NMTCriterion with the NMT_loss.score counters (P/misc/criterion.py:126-136,175-184), and their backward.
+//
+// Layout: time-major like the reference ([S,B,*], [T,B,*]).  pack_padded_sequence semantics without packing: the
+// batch is length-sorted (descending), so the rows alive at source step s are the prefix [0, nb(s)) and every
+// recurrent GEMM simply runs on that many rows; state buffers carry one zero slot before and after the S steps, so
+// "previous state" of both directions is a plain view and padded positions stay exactly zero (unpack's padding).
+// Input projections (W_ih x) are batched over all steps; only W_hh (and the input-feed part) stays in the loops.
+// Like the reference, attention is NOT masked over padded source positions (GlobalAttention.mask is never set in
+// training): their context vectors are zero, their scores are 0, and they take part in the softmax.
+#include "uic_common.h"
+#include "uic_host.h"
+#include "../../include/uic_hip.h"
+#include <string.h>
+
+#define SITE_NMT_ENC(l) (1000u + (unsigned)(l))
+#define SITE_NMT_DEC(l, t) (2000u + (unsigned)(l) * 256u + (unsigned)(t))
+#define SITE_NMT_OUT(t) (4000u + (unsigned)(t))
+
+namespace {
+
+constexpr int NT = 256;
+
+// tgt [T,B] -> target_bt [B,T-1] (= tgt[1:]), mask_bt [B,T-1] (target != PAD), tgt_in [(T-1)*B] (= tgt[:-1], flat)
+__global__ void nmt_prep_kernel(const int64_t* tgt, int T, int B, int64_t* target_bt, float* mask_bt, int64_t* tgt_in) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (T - 1) * B) return;
+  const int t = i / B, b = i - t * B;
+  const long y = tgt[(size_t)(t + 1) * B + b];
+  target_bt[(size_t)b * (T - 1) + t] = y;
+  mask_bt[(size_t)b * (T - 1) + t] = y != 0 ? 1.f : 0.f;
+  tgt_in[i] = tgt[i];
+}
+
+template <typename T>
+__global__ void dropout_apply_kernel(const void* src_, void* dst_, size_t n, float p, unsigned seed, unsigned site) {
+  const T* src = (const T*)src_;
+  T* dst = (T*)dst_;
+  const float inv_keep = 1.f / (1.f - p);
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)
+    dst[i] = uic_from_f<T>(uic_to_f(src[i]) * uic_drop_scale(seed, site, (unsigned)i, p, inv_keep));
+}
+// g[i] *= mask (f32 gradient through a dropout site)
+__global__ void dropout_grad_kernel(float* g, size_t n, float p, unsigned seed, unsigned site) {
+  const float inv_keep = 1.f / (1.f - p);
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)
+    g[i] *= uic_drop_scale(seed, site, (unsigned)i, p, inv_keep);
+}
+
+// _fix_enc_hidden (NMT_Models.py:284-287): decoder initial state of layer l, row b = [fwd final | bwd final]; the
+// forward direction ends at the row's last valid step (slot len), the backward one at step 0 (slot 1).
+template <typename T>
+__global__ void enc_final_kernel(const void* xl_, const float* c_f, const float* c_b, const int* lens, int B, int H, int Hd,
+                                 void* h0_, float* c0) {
+  const T* xl = (const T*)xl_;
+  T* h0 = (T*)h0_;
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= B * H) return;
+  const int b = i / H, j = i - b * H;
+  const int d = j >= Hd;
+  const int slot = d ? 1 : lens[b];
+  h0[i] = xl[((size_t)slot * B + b) * H + j];
+  c0[i] = (d ? c_b : c_f)[((size_t)slot * B + b) * Hd + (j - d * Hd)];
+}
+
+// ---- dot GlobalAttention (O/modules/GlobalAttention.py:112-116,152,160-162), one workgroup per batch row
+template <typename T>
+__global__ __launch_bounds__(NT) void gattn_fwd_kernel(const void* ctx_, const float* target, int S, int B, int H, float* attn,
+                                                       void* cvec_) {
+  const T* ctx = (const T*)ctx_;
+  T* cvec = (T*)cvec_;
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  float* s_t = sm;            // [H]
+  float* s_a = s_t + H;       // [S]
+  float* s_red = s_a + S;     // [4][H]
+  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  for (int j = tid; j < H; j += NT) s_t[j] = target[(size_t)b * H + j];
+  __syncthreads();
+  for (int s = wave; s < S; s += 4) {
+    const T* v = ctx + ((size_t)s * B + b) * H;
+    float p = 0.f;
+    for (int j = lane; j < H; j += 64) p += uic_to_f(v[j]) * s_t[j];
+    p = uic_wave_sum(p);
+    if (lane == 0) s_a[s] = p;
+  }
+  __syncthreads();
+  float mx = -INFINITY;
+  for (int s = 0; s < S; ++s) mx = fmaxf(mx, s_a[s]);
+  float sum = 0.f;
+  for (int s = 0; s < S; ++s) sum += expf(s_a[s] - mx);
+  const float inv = 1.f / sum;
+  __syncthreads();
+  for (int s = tid; s < S; s += NT) {
+    const float a = expf(s_a[s] - mx) * inv;
+    s_a[s] = a;
+    attn[(size_t)b * S + s] = a;
+  }
+  __syncthreads();
+  for (int j = lane; j < H; j += 64) {
+    float acc = 0.f;
+    for (int s = wave; s < S; s += 4) acc += s_a[s] * uic_to_f(ctx[((size_t)s * B + b) * H + j]);
+    s_red[wave * H + j] = acc;
+  }
+  __syncthreads();
+  for (int j = tid; j < H; j += NT)
+    cvec[(size_t)b * H + j] = uic_from_f<T>(s_red[j] + s_red[H + j] + s_red[2 * H + j] + s_red[3 * H + j]);
+}
+
+// backward of one decode step: d_a = d_c . ctx[s]; d_score = a (d_a - sum a d_a); d_target = sum_s d_score ctx[s]
+template <typename T>
+__global__ __launch_bounds__(NT) void gattn_bwd_step_kernel(const void* ctx_, const float* attn, const float* dcq, int lddcq,
+                                                            int S, int B, int H, float* dscore, void* dtarget_) {
+  const T* ctx = (const T*)ctx_;
+  T* dtarget = (T*)dtarget_;
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  float* s_dc = sm;           // [H]
+  float* s_a = s_dc + H;      // [S]
+  float* s_da = s_a + S;      // [S]
+  float* s_red = s_da + S;    // [4][H]
+  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  for (int j = tid; j < H; j += NT) s_dc[j] = dcq[(size_t)b * lddcq + j];
+  for (int s = tid; s < S; s += NT) s_a[s] = attn[(size_t)b * S + s];
+  __syncthreads();
+  for (int s = wave; s < S; s += 4) {
+    const T* v = ctx + ((size_t)s * B + b) * H;
+    float p = 0.f;
+    for (int j = lane; j < H; j += 64) p += uic_to_f(v[j]) * s_dc[j];
+    p = uic_wave_sum(p);
+    if (lane == 0) s_da[s] = p;
+  }
+  __syncthreads();
+  float wbar = 0.f;
+  for (int s = 0; s < S; ++s) wbar += s_a[s] * s_da[s];
+  __syncthreads();
+  for (int s = tid; s < S; s += NT) {
+    const float ds = s_a[s] * (s_da[s] - wbar);
+    s_da[s] = ds;
+    dscore[(size_t)b * S + s] = ds;
+  }
+  __syncthreads();
+  for (int j = lane; j < H; j += 64) {
+    float acc = 0.f;
+    for (int s = wave; s < S; s += 4) acc += s_da[s] * uic_to_f(ctx[((size_t)s * B + b) * H + j]);
+    s_red[wave * H + j] = acc;
+  }
+  __syncthreads();
+  for (int j = tid; j < H; j += NT)
+    dtarget[(size_t)b * H + j] = uic_from_f<T>(s_red[j] + s_red[H + j] + s_red[2 * H + j] + s_red[3 * H + j]);
+}
+
+// deferred over decode steps: d ctx[s,b,:] = sum_t (a_t[b,s] d_c_t[b,:] + d_score_t[b,s] target_t[b,:])
+__global__ void gattn_bwd_accum_kernel(const float* attn_all, const float* dscore_all, const float* dcq_all, int lddcq,
+                                       const float* target_all, int Td, int S, int B, int H, float* dctx) {
+  const size_t total = (size_t)S * B * H;
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+    const int j = (int)(i % H);
+    const size_t sb = i / H;
+    const int b = (int)(sb % B), s = (int)(sb / B);
+    float acc = 0.f;
+    for (int t = 0; t < Td; ++t) {
+      const size_t tb = (size_t)t * B + b;
+      acc += attn_all[tb * S + s] * dcq_all[tb * lddcq + j] + dscore_all[tb * S + s] * target_all[tb * H + j];
+    }
+    dctx[i] = acc;
+  }
+}
+
+// d_pre = (d_out + d_feed) * dropout_mask * (1 - out_pre^2): backward of out = dropout(tanh(.))
+template <typename T>
+__global__ void tanh_drop_bwd_kernel(const float* d_out, const float* d_feed, const void* out_pre_, int n, float p, unsigned seed,
+                                     unsigned site, void* d_pre_) {
+  const T* out_pre = (const T*)out_pre_;
+  T* d_pre = (T*)d_pre_;
+  const float inv_keep = p > 0.f ? 1.f / (1.f - p) : 1.f;
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  float g = d_out[i] + (d_feed ? d_feed[i] : 0.f);
+  if (p > 0.f) g *= uic_drop_scale(seed, site, (unsigned)i, p, inv_keep);
+  const float o = uic_to_f(out_pre[i]);
+  d_pre[i] = uic_from_f<T>(g * (1.f - o * o));
+}
+
+// NMT_loss.score (criterion.py:175-179): correct = argmax(scores) == target over non-PAD targets
+__global__ __launch_bounds__(NT) void nmt_score_kernel(const float* logits, int V, int ldv, const int64_t* target_bt, int B,
+                                                       int Td, int* stats) {
+  __shared__ float s_val[NT];
+  __shared__ int s_idx[NT];
+  const int m = blockIdx.x;                  // row = t*B + b
+  const int t = m / B, b = m - t * B;
+  const long y = target_bt[(size_t)b * Td + t];
+  const float* row = logits + (size_t)m * ldv;
+  float bv = -INFINITY;
+  int bi = 0x7fffffff;
+  for (int v = threadIdx.x; v < V; v += NT) {
+    const float x = row[v];
+    if (x > bv || (x == bv && v < bi)) { bv = x; bi = v; }
+  }
+  s_val[threadIdx.x] = bv; s_idx[threadIdx.x] = bi;
+  __syncthreads();
+  for (int o = NT / 2; o > 0; o >>= 1) {
+    if (threadIdx.x < o) {
+      const float ov = s_val[threadIdx.x + o];
+      const int oi = s_idx[threadIdx.x + o];
+      if (ov > s_val[threadIdx.x] || (ov == s_val[threadIdx.x] && oi < s_idx[threadIdx.x])) { s_val[threadIdx.x] = ov; s_idx[threadIdx.x] = oi; }
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0 && y != 0) {
+    atomicAdd(&stats[1], 1);
+    if (s_idx[0] == (int)y) atomicAdd(&stats[0], 1);
+  }
+}
+
+__global__ void fill_f32_kernel(float* p, float v, int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) p[i] = v;
+}
+
+inline int gridn(size_t n) { size_t g = (n + NT - 1) / NT; return (int)(g > 65536 ? 65536 : (g ? g : 1)); }
+
+#define NMT_T(KERNEL, GRID, LDS, ...)                                                            \
+  do {                                                                                           \
+    if (dt == UIC_BF16) hipLaunchKernelGGL(KERNEL<bf16_t>, dim3(GRID), dim3(NT), LDS, s, __VA_ARGS__); \
+    else hipLaunchKernelGGL(KERNEL<float>, dim3(GRID), dim3(NT), LDS, s, __VA_ARGS__);           \
+    UIC_LAUNCH_CHECK(#KERNEL);                                                                   \
+  } while (0)
+
+constexpr int ML = UIC_NMT_MAX_LAYERS;
+
+struct NmtLayout {
+  // operand-dtype weight views (masters in f32 mode, copies in bf16 mode) and transposes for the dX GEMMs
+  const void* enc_lin_w; const void* enc_w_ih[ML][2]; const void* enc_w_hh[ML][2];
+  const void* dec_w_ih[ML]; const void* dec_w_hh[ML]; const void* attn_in_w; const void* attn_out_w; const void* gen_w;
+  void* c_enc_lin_w; void* c_enc_w_ih[ML][2]; void* c_enc_w_hh[ML][2]; void* c_dec_w_ih[ML]; void* c_dec_w_hh[ML];
+  void* c_attn_in_w; void* c_attn_out_w; void* c_gen_w;
+  void* enc_lin_wT;            // [W, W]
+  void* enc_w_ihT[ML][2];      // [in, 4Hd]
+  void* enc_w_hhT[ML][2];      // [Hd, 4Hd]
+  void* dec_wT[ML];            // [in_l + H, 4H] = [W_ih^T ; W_hh^T]
+  void* attn_in_wT;            // [H, H]
+  void* attn_out_wT;           // [2H, H]
+  void* gen_wT;                // [H, Vtp]
+  // encoder: xl[l] = input of layer l with one zero slot before and after the S steps: [(S+2), B, in_l]
+  void* xe; void* xl[ML + 1]; void* xd[ML];
+  float* gx_e[ML][2]; float* c_e[ML][2]; void* gates_e[ML][2]; void* dg_e[ML][2];
+  // decoder
+  int64_t* target_bt; float* mask_bt; int64_t* tgt_in;
+  void* emb_d; float* gx_d0;
+  void* hd[ML]; float* cd[ML]; void* hdrop[ML]; void* gates_d[ML]; void* dg_d[ML]; float* dhrec_d[ML]; float* dcd[ML];
+  float* targetq; float* attn_all; void* cvec_all; void* out_pre; void* out_all;
+  float* logits; void* dlogits; float* row_loss; float* scalars; int* stats;
+  // backward
+  float* d_out_all; float* dfeed; void* d_pre_all; float* d_cq_all; float* dscore_all; void* dtarget_all; float* dq;
+  float* dx_lstm; float* d_lay; float* dhrec_e; float* dc_e; float* dx_e; void* dpre_e; float* dxe; float* demb_d;
+  void* tA; void* tB; float* colscratch; size_t colscratch_floats; float* slab; size_t slab_bytes;
+  size_t total;
+};
+
+NmtLayout nmt_layout(const uic_nmt_dims& d, const uic_nmt_weights* w, void* ws) {
+  NmtLayout L;
+  memset(&L, 0, sizeof(L));
+  Bump b{(char*)ws, 0};
+  const size_t Sz = uic_dtype_size(d.dtype);
+  const size_t B = d.B, S = d.S, Td = d.T - 1, H = d.H, W = d.W, Hd = H / 2, NL = d.layers, Vt = d.Vt, Vtp = vpad(Vt);
+  const bool bf = d.dtype == UIC_BF16;
+  auto wcopy = [&](const float* master, size_t n, void** copy) -> const void* {
+    *copy = b.take(n * Sz);
+    return (bf || !w) ? *copy : (const void*)master;
+  };
+  L.enc_lin_w = wcopy(w ? w->enc_lin_w : nullptr, W * W, &L.c_enc_lin_w);
+  for (size_t l = 0; l < NL; ++l) {
+    const size_t in = l == 0 ? W : H, din = l == 0 ? W + H : H;
+    for (int dd = 0; dd < 2; ++dd) {
+      L.enc_w_ih[l][dd] = wcopy(w ? w->enc_w_ih[l][dd] : nullptr, 4 * Hd * in, &L.c_enc_w_ih[l][dd]);
+      L.enc_w_hh[l][dd] = wcopy(w ? w->enc_w_hh[l][dd] : nullptr, 4 * Hd * Hd, &L.c_enc_w_hh[l][dd]);
+      L.enc_w_ihT[l][dd] = b.take(in * 4 * Hd * Sz);
+      L.enc_w_hhT[l][dd] = b.take(Hd * 4 * Hd * Sz);
+    }
+    L.dec_w_ih[l] = wcopy(w ? w->dec_w_ih[l] : nullptr, 4 * H * din, &L.c_dec_w_ih[l]);
+    L.dec_w_hh[l] = wcopy(w ? w->dec_w_hh[l] : nullptr, 4 * H * H, &L.c_dec_w_hh[l]);
+    L.dec_wT[l] = b.take((din + H) * 4 * H * Sz);
+  }
+  L.attn_in_w = wcopy(w ? w->attn_in_w : nullptr, H * H, &L.c_attn_in_w);
+  L.attn_out_w = wcopy(w ? w->attn_out_w : nullptr, H * 2 * H, &L.c_attn_out_w);
+  L.gen_w = wcopy(w ? w->gen_w : nullptr, Vt * H, &L.c_gen_w);
+  L.enc_lin_wT = b.take(W * W * Sz);
+  L.attn_in_wT = b.take(H * H * Sz);
+  L.attn_out_wT = b.take(2 * H * H * Sz);
+  L.gen_wT = b.take(H * Vtp * Sz);
+  L.xe = b.take(S * B * W * Sz);
+  for (size_t l = 0; l <= NL; ++l) L.xl[l] = b.take((S + 2) * B * (l == 0 ? W : H) * Sz);
+  for (size_t l = 1; l < NL; ++l) L.xd[l] = b.take((S + 2) * B * H * Sz);
+  for (size_t l = 0; l < NL; ++l)
+    for (int dd = 0; dd < 2; ++dd) {
+      L.gx_e[l][dd] = (float*)b.take(S * B * 4 * Hd * 4);
+      L.c_e[l][dd] = (float*)b.take((S + 2) * B * Hd * 4);
+      L.gates_e[l][dd] = b.take(S * B * 4 * Hd * Sz);
+      L.dg_e[l][dd] = b.take(S * B * 4 * Hd * Sz);
+    }
+  L.target_bt = (int64_t*)b.take(B * Td * 8);
+  L.mask_bt = (float*)b.take(B * Td * 4);
+  L.tgt_in = (int64_t*)b.take(Td * B * 8);
+  L.emb_d = b.take(Td * B * W * Sz);
+  L.gx_d0 = (float*)b.take(Td * B * 4 * H * 4);
+  for (size_t l = 0; l < NL; ++l) {
+    L.hd[l] = b.take((Td + 1) * B * H * Sz);
+    L.cd[l] = (float*)b.take((Td + 1) * B * H * 4);
+    L.hdrop[l] = b.take(Td * B * H * Sz);
+    L.gates_d[l] = b.take(Td * B * 4 * H * Sz);
+    L.dg_d[l] = b.take(Td * B * 4 * H * Sz);
+    L.dhrec_d[l] = (float*)b.take(B * H * 4);
+    L.dcd[l] = (float*)b.take(B * H * 4);
+  }
+  L.targetq = (float*)b.take(Td * B * H * 4);
+  L.attn_all = (float*)b.take(Td * B * S * 4);
+  L.cvec_all = b.take(Td * B * H * Sz);
+  L.out_pre = b.take(Td * B * H * Sz);
+  L.out_all = b.take((Td + 1) * B * H * Sz);
+  L.logits = (float*)b.take(Td * B * Vtp * 4);
+  L.dlogits = b.take(Td * B * Vtp * Sz);
+  L.row_loss = (float*)b.take(Td * B * 4);
+  L.scalars = (float*)b.take(64);
+  L.stats = (int*)b.take(64);
+  L.d_out_all = (float*)b.take(Td * B * H * 4);
+  L.dfeed = (float*)b.take(B * H * 4);
+  L.d_pre_all = b.take(Td * B * H * Sz);
+  L.d_cq_all = (float*)b.take(Td * B * 2 * H * 4);
+  L.dscore_all = (float*)b.take(Td * B * S * 4);
+  L.dtarget_all = b.take(Td * B * H * Sz);
+  L.dq = (float*)b.take(B * H * 4);
+  L.dx_lstm = (float*)b.take(B * 2 * H * 4);
+  L.d_lay = (float*)b.take(S * B * H * 4);
+  L.dhrec_e = (float*)b.take(B * Hd * 4);
+  L.dc_e = (float*)b.take(B * Hd * 4);
+  L.dx_e = (float*)b.take(S * B * (W > H ? W : H) * 4);
+  L.dpre_e = b.take(S * B * W * Sz);
+  L.dxe = (float*)b.take(S * B * W * 4);
+  L.demb_d = (float*)b.take(Td * B * W * 4);
+  const size_t rows = rup8((S > Td ? S : Td) * B);
+  L.tA = b.take((Vt > 4 * H ? Vt : 4 * H) * rows * Sz);
+  L.tB = b.take((W + 2 * H) * rows * Sz);
+  const size_t maxcols = Vtp > 4 * H ? Vtp : 4 * H;
+  L.colscratch_floats = 128 * maxcols;
+  L.colscratch = (float*)b.take(L.colscratch_floats * 4);
+  L.slab_bytes = 4 * (4 * H) * (W + 2 * H) * 4;
+  L.slab = (float*)b.take(L.slab_bytes);
+  L.total = (b.off + 255) & ~(size_t)255;
+  return L;
+}
+
+int nmt_check(const uic_nmt_dims* d) {
+  UIC_REQUIRE(d != nullptr, "null dims");
+  UIC_REQUIRE(d->dtype == UIC_F32 || d->dtype == UIC_BF16, "bad dtype %d", d->dtype);
+  UIC_REQUIRE(d->B > 0 && d->S > 0 && d->S <= 4096 && d->T >= 2 && d->Vs > 1 && d->Vt > 1, "bad sizes B=%d S=%d T=%d", d->B, d->S, d->T);
+  UIC_REQUIRE(d->layers >= 1 && d->layers <= ML, "layers=%d outside [1,%d]", d->layers, ML);
+  UIC_REQUIRE(d->H % 16 == 0 && d->W % 8 == 0, "rnn_size=%d must be a multiple of 16, word_vec_size=%d of 8", d->H, d->W);
+  UIC_REQUIRE(d->T - 1 < 256, "target length %d too long for the dropout site encoding", d->T);
+  UIC_REQUIRE(d->drop_p >= 0.f && d->drop_p < 1.f, "dropout=%f outside [0,1)", (double)d->drop_p);
+  return UIC_OK;
+}
+
+struct Nmt {
+  uic_nmt_dims d;
+  const uic_nmt_weights* w;
+  const uic_nmt_weights* G;
+  NmtLayout L;
+  int dt, B, S, Td, H, W, Hd, NL, Vs, Vt, Vtp;
+  size_t Sz, BH, BHd;
+  float drop_p;
+  unsigned seed;
+  const int64_t* src;
+  const int64_t* tgt;
+  int nb[4096];
+
+  int init(const uic_nmt_dims* d_, const uic_nmt_weights* w_, const int64_t* src_, const int32_t* lengths_host,
+           const int64_t* tgt_, int training, unsigned seed_, void* ws, const uic_nmt_weights* G_) {
+    d = *d_; w = w_; G = G_; src = src_; tgt = tgt_;
+    L = nmt_layout(d, w, ws);
+    dt = d.dtype; B = d.B; S = d.S; Td = d.T - 1; H = d.H; W = d.W; Hd = H / 2; NL = d.layers; Vs = d.Vs; Vt = d.Vt;
+    Vtp = (int)vpad(Vt);
+    Sz = uic_dtype_size(dt); BH = (size_t)B * H; BHd = (size_t)B * Hd;
+    drop_p = training ? d.drop_p : 0.f;
+    seed = seed_;
+    for (int b = 0; b < B; ++b) {
+      UIC_REQUIRE(lengths_host[b] >= 1 && lengths_host[b] <= S, "lengths[%d]=%d outside [1,%d]", b, lengths_host[b], S);
+      UIC_REQUIRE(b == 0 || lengths_host[b] <= lengths_host[b - 1], "lengths must be sorted in decreasing order (pack_padded_sequence)");
+    }
+    for (int st = 0; st < S; ++st) {
+      int n = 0;
+      while (n < B && lengths_host[n] > st) ++n;
+      nb[st] = n;
+    }
+    return UIC_OK;
+  }
+
+  int refresh(hipStream_t s) {
+    if (dt == UIC_BF16) {
+      UIC_TRY(uic_cast_f32_launch(dt, w->enc_lin_w, L.c_enc_lin_w, (size_t)W * W, s));
+      for (int l = 0; l < NL; ++l) {
+        const int in = l == 0 ? W : H, din = l == 0 ? W + H : H;
+        for (int dd = 0; dd < 2; ++dd) {
+          UIC_TRY(uic_cast_f32_launch(dt, w->enc_w_ih[l][dd], L.c_enc_w_ih[l][dd], (size_t)4 * Hd * in, s));
+          UIC_TRY(uic_cast_f32_launch(dt, w->enc_w_hh[l][dd], L.c_enc_w_hh[l][dd], (size_t)4 * Hd * Hd, s));
+        }
+        UIC_TRY(uic_cast_f32_launch(dt, w->dec_w_ih[l], L.c_dec_w_ih[l], (size_t)4 * H * din, s));
+        UIC_TRY(uic_cast_f32_launch(dt, w->dec_w_hh[l], L.c_dec_w_hh[l], (size_t)4 * H * H, s));
+      }
+      UIC_TRY(uic_cast_f32_launch(dt, w->attn_in_w, L.c_attn_in_w, (size_t)H * H, s));
+      UIC_TRY(uic_cast_f32_launch(dt, w->attn_out_w, L.c_attn_out_w, (size_t)H * 2 * H, s));
+      UIC_TRY(uic_cast_f32_launch(dt, w->gen_w, L.c_gen_w, (size_t)Vt * H, s));
+    }
+    UIC_TRY(uic_transpose_launch(dt, L.enc_lin_w, W, W, W, L.enc_lin_wT, W, s));
+    for (int l = 0; l < NL; ++l) {
+      const int in = l == 0 ? W : H, din = l == 0 ? W + H : H;
+      for (int dd = 0; dd < 2; ++dd) {
+        UIC_TRY(uic_transpose_launch(dt, L.enc_w_ih[l][dd], 4 * Hd, in, in, L.enc_w_ihT[l][dd], 4 * Hd, s));
+        UIC_TRY(uic_transpose_launch(dt, L.enc_w_hh[l][dd], 4 * Hd, Hd, Hd, L.enc_w_hhT[l][dd], 4 * Hd, s));
+      }
+      UIC_TRY(uic_transpose_launch(dt, L.dec_w_ih[l], 4 * H, din, din, L.dec_wT[l], 4 * H, s));
+      UIC_TRY(uic_transpose_launch(dt, L.dec_w_hh[l], 4 * H, H, H, offw(L.dec_wT[l], (size_t)din * 4 * H, dt), 4 * H, s));
+    }
+    UIC_TRY(uic_transpose_launch(dt, L.attn_in_w, H, H, H, L.attn_in_wT, H, s));
+    UIC_TRY(uic_transpose_launch(dt, L.attn_out_w, H, 2 * H, 2 * H, L.attn_out_wT, H, s));
+    return uic_transpose_launch(dt, L.gen_w, Vt, H, H, L.gen_wT, Vtp, s);
+  }
+
+  // input of encoder layer l as seen by its W_ih GEMM (slots 1..S): the dropped copy between layers in training
+  const void* enc_in(int l) const {
+    const int in = l == 0 ? W : H;
+    return off(l > 0 && drop_p > 0.f ? L.xd[l] : L.xl[l], (size_t)B * in, dt);
+  }
+
+  int encoder_fwd(const int32_t* lengths_dev, hipStream_t s) {
+    // relu(linear(word_lut[src]))  (NMT_Models.py:63-67)
+    UIC_TRY(uic_embed_fwd_launch(dt, w->enc_lut, Vs, W, src, 1, S * B, 1, 0.f, 0, 0, 0, 0, L.xe, s));
+    {
+      UicGemmParams g = gemm_base(dt, S * B, W);
+      add_seg(g, L.xe, W, L.enc_lin_w, W, W);
+      g.C = offw(L.xl[0], (size_t)B * W, dt); g.ldc = W; g.bias = w->enc_lin_b; g.flags = UIC_GEMM_RELU;
+      UIC_TRY(uic_gemm_launch(g, s));
+    }
+    for (int l = 0; l < NL; ++l) {
+      const int in = l == 0 ? W : H;
+      UIC_TRY(uic_fill_launch(L.xl[l + 1], 0, (size_t)(S + 2) * BH * Sz, s));
+      for (int dd = 0; dd < 2; ++dd) {
+        UIC_TRY(uic_fill_launch(L.c_e[l][dd], 0, (size_t)(S + 2) * BHd * 4, s));
+        {  // W_ih x + b_ih + b_hh for every (s, b)
+          UicGemmParams g = gemm_base(dt, S * B, 4 * Hd);
+          add_seg(g, enc_in(l), in, L.enc_w_ih[l][dd], in, in);
+          g.C = L.gx_e[l][dd]; g.ldc = 4 * Hd; g.bias = w->enc_b_ih[l][dd]; g.bias2 = w->enc_b_hh[l][dd]; g.flags = UIC_GEMM_OUT_F32;
+          UIC_TRY(uic_gemm_launch(g, s));
+        }
+        for (int k = 0; k < S; ++k) {
+          const int st = dd == 0 ? k : S - 1 - k;          // time step; its slot is st + 1
+          const int prev = dd == 0 ? st : st + 2;          // slot of the previous state in this direction
+          if (nb[st] == 0) continue;                       // S longer than the longest sentence
+          UicGemmParams g = gemm_base(dt, nb[st], 4 * Hd);
+          g.lstm = 1; g.H = Hd;
+          add_seg(g, off(L.xl[l + 1], (size_t)prev * BH + dd * Hd, dt), H, L.enc_w_hh[l][dd], Hd, Hd);
+          g.pre1 = L.gx_e[l][dd] + (size_t)st * B * 4 * Hd; g.ldpre1 = 4 * Hd;
+          g.c_prev = L.c_e[l][dd] + (size_t)prev * BHd; g.c_out = L.c_e[l][dd] + (size_t)(st + 1) * BHd;
+          g.h_out = offw(L.xl[l + 1], (size_t)(st + 1) * BH + dd * Hd, dt); g.ldh = H;
+          g.gates_out = offw(L.gates_e[l][dd], (size_t)st * B * 4 * Hd, dt);
+          UIC_TRY(uic_gemm_launch(g, s));
+        }
+      }
+      if (l + 1 < NL && drop_p > 0.f) {  // nn.LSTM's inter-layer dropout (element index over the [S*B, H] slots 1..S)
+        UIC_TRY(uic_fill_launch(L.xd[l + 1], 0, (size_t)(S + 2) * BH * Sz, s));
+        NMT_T(dropout_apply_kernel, gridn((size_t)S * BH), 0, (const void*)off(L.xl[l + 1], BH, dt), (void*)offw(L.xd[l + 1], BH, dt),
+              (size_t)S * BH, drop_p, seed, SITE_NMT_ENC(l));
+      }
+    }
+    // decoder initial state (_fix_enc_hidden + init_decoder_state, :284-295): slot 0 of the decoder state buffers
+    for (int l = 0; l < NL; ++l)
+      NMT_T(enc_final_kernel, gridn(BH), 0, (const void*)L.xl[l + 1], (const float*)L.c_e[l][0], (const float*)L.c_e[l][1],
+            lengths_dev, B, H, Hd, (void*)L.hd[l], L.cd[l]);
+    return UIC_OK;
+  }
+
+  int decoder_fwd(hipStream_t s) {
+    const int H4 = 4 * H;
+    hipLaunchKernelGGL(nmt_prep_kernel, dim3(gridn((size_t)Td * B)), dim3(NT), 0, s, tgt, Td + 1, B, L.target_bt, L.mask_bt, L.tgt_in);
+    UIC_LAUNCH_CHECK("nmt_prep_kernel");
+    UIC_TRY(uic_embed_fwd_launch(dt, w->dec_lut, Vt, W, L.tgt_in, 1, Td * B, 1, 0.f, 0, 0, 0, 0, L.emb_d, s));
+    {  // layer-0 input projection of the embedding part for all steps (the input-feed part stays in the loop)
+      UicGemmParams g = gemm_base(dt, Td * B, H4);
+      add_seg(g, L.emb_d, W, L.dec_w_ih[0], W + H, W);
+      g.C = L.gx_d0; g.ldc = H4; g.bias = w->dec_b_ih[0]; g.bias2 = w->dec_b_hh[0]; g.flags = UIC_GEMM_OUT_F32;
+      UIC_TRY(uic_gemm_launch(g, s));
+    }
+    UIC_TRY(uic_fill_launch(L.out_all, 0, BH * Sz, s));        // init_input_feed: zeros (:454-458)
+    const size_t lds_att = sizeof(float) * ((size_t)H + S + 4 * (size_t)H);
+    for (int t = 0; t < Td; ++t) {
+      const void* x = nullptr;
+      for (int l = 0; l < NL; ++l) {                           // StackedLSTM.forward (StackedRNN.py:20-34)
+        UicGemmParams g = gemm_base(dt, B, H4);
+        g.lstm = 1; g.H = H;
+        if (l == 0) {
+          add_seg(g, off(L.out_all, (size_t)t * BH, dt), H, off(L.dec_w_ih[0], W, dt), W + H, H);   // input feed (:248-249)
+          g.pre1 = L.gx_d0 + (size_t)t * B * H4; g.ldpre1 = H4;
+        } else {
+          add_seg(g, x, H, L.dec_w_ih[l], H, H);
+          g.bias = w->dec_b_ih[l]; g.bias2 = w->dec_b_hh[l];
+        }
+        add_seg(g, off(L.hd[l], (size_t)t * BH, dt), H, L.dec_w_hh[l], H, H);
+        g.c_prev = L.cd[l] + (size_t)t * BH; g.c_out = L.cd[l] + (size_t)(t + 1) * BH;
+        g.h_out = offw(L.hd[l], (size_t)(t + 1) * BH, dt); g.ldh = H;
+        g.gates_out = offw(L.gates_d[l], (size_t)t * B * H4, dt);
+        if (l + 1 < NL) {                                      // dropout between layers only
+          g.h_drop = offw(L.hdrop[l], (size_t)t * BH, dt); g.ldhd = H;
+          g.drop_p = drop_p; g.seed = seed; g.site = SITE_NMT_DEC(l, t);
+          x = g.h_drop;
+        }
+        UIC_TRY(uic_gemm_launch(g, s));
+      }
+      const void* q = off(L.hd[NL - 1], (size_t)(t + 1) * BH, dt);       // rnn_output = top layer's h
+      float* target = L.targetq + (size_t)t * BH;
+      {  // targetT = linear_in(rnn_output) (GlobalAttention.py:114)
+        UicGemmParams g = gemm_base(dt, B, H);
+        add_seg(g, q, H, L.attn_in_w, H, H);
+        g.C = target; g.ldc = H; g.flags = UIC_GEMM_OUT_F32;
+        UIC_TRY(uic_gemm_launch(g, s));
+      }
+      NMT_T(gattn_fwd_kernel, B, lds_att, (const void*)off(L.xl[NL], BH, dt), (const float*)target, S, B, H,
+            L.attn_all + (size_t)t * B * S, (void*)offw(L.cvec_all, (size_t)t * BH, dt));
+      {  // tanh(linear_out([c ; rnn_output])) (:165-167)
+        UicGemmParams g = gemm_base(dt, B, H);
+        add_seg(g, off(L.cvec_all, (size_t)t * BH, dt), H, L.attn_out_w, 2 * H, H);
+        add_seg(g, q, H, off(L.attn_out_w, H, dt), 2 * H, H);
+        g.C = offw(L.out_pre, (size_t)t * BH, dt); g.ldc = H; g.flags = UIC_GEMM_TANH;
+        UIC_TRY(uic_gemm_launch(g, s));
+      }
+      // output = dropout(attn_output) = next step's input feed (NMT_Models.py:258-259)
+      if (drop_p > 0.f)
+        NMT_T(dropout_apply_kernel, gridn(BH), 0, (const void*)off(L.out_pre, (size_t)t * BH, dt),
+              (void*)offw(L.out_all, (size_t)(t + 1) * BH, dt), BH, drop_p, seed, SITE_NMT_OUT(t));
+      else
+        UIC_TRY(uic_check_hip(hipMemcpyAsync(offw(L.out_all, (size_t)(t + 1) * BH, dt), off(L.out_pre, (size_t)t * BH, dt), BH * Sz,
+                                             hipMemcpyDeviceToDevice, s), "memcpy out"));
+    }
+    return UIC_OK;
+  }
+
+  // generator + NMTCriterion + NMT_loss.score (criterion.py:126-136,175-184)
+  int loss_fwd(float* loss_out, int32_t* stats_out, hipStream_t s) {
+    {
+      UicGemmParams g = gemm_base(dt, Td * B, Vt);
+      add_seg(g, off(L.out_all, BH, dt), H, L.gen_w, H, H);
+      g.C = L.logits; g.ldc = Vtp; g.bias = w->gen_b; g.flags = UIC_GEMM_OUT_F32;
+      UIC_TRY(uic_gemm_launch(g, s));
+    }
+    hipLaunchKernelGGL(fill_f32_kernel, dim3(1), dim3(64), 0, s, L.scalars, 1.0f, 1);      // size_average=False: no denominator
+    UIC_LAUNCH_CHECK("fill_f32_kernel");
+    UicXeParams x;
+    memset(&x, 0, sizeof(x));
+    x.dtype = dt; x.M = Td * B; x.V1 = Vt; x.ldv = Vtp; x.logits = L.logits; x.dlogits = L.dlogits; x.N = B;
+    x.target = L.target_bt; x.ldtarget = Td; x.target_col0 = 0;
+    x.mask = L.mask_bt; x.ldmask = Td; x.mask_col0 = 0;             // weight[PAD] = 0
+    x.inv_den = L.scalars; x.row_loss = L.row_loss; x.write_grad = 1;
+    UIC_TRY(uic_xe_launch(x, s));
+    UIC_TRY(uic_reduce_sum_launch(L.row_loss, (size_t)Td * B, 0.f, nullptr, loss_out, s));
+    if (stats_out) {
+      UIC_TRY(uic_fill_launch(L.stats, 0, 8, s));
+      hipLaunchKernelGGL(nmt_score_kernel, dim3(Td * B), dim3(NT), 0, s, L.logits, Vt, Vtp, L.target_bt, B, Td, L.stats);
+      UIC_LAUNCH_CHECK("nmt_score_kernel");
+      UIC_TRY(uic_check_hip(hipMemcpyAsync(stats_out, L.stats, 8, hipMemcpyDeviceToDevice, s), "memcpy stats"));
+    }
+    return UIC_OK;
+  }
+
+  int wgrad1(const void* left, int lrows, const void* right, int rrows, int K, float* C, int ldc, hipStream_t s) {
+    const WDest d1{C, ldc, 0, rrows};
+    return wgrad_multi(L.slab, L.slab_bytes, dt, left, lrows, right, rrows, K, &d1, 1, s);
+  }
+
+  int backward(hipStream_t s) {
+    const int H4 = 4 * H, Md = Td * B, Mdp = (int)rup8(Md), Ms = S * B, Msp = (int)rup8(Ms);
+    // ---- generator
+    {
+      UicGemmParams g = gemm_base(dt, Md, H);
+      add_seg(g, L.dlogits, Vtp, L.gen_wT, Vtp, Vtp);
+      g.C = L.d_out_all; g.ldc = H; g.flags = UIC_GEMM_OUT_F32;
+      UIC_TRY(uic_gemm_launch(g, s));
+    }
+    UIC_TRY(uic_transpose_launch(dt, L.dlogits, Md, Vt, Vtp, L.tA, Mdp, s));
+    UIC_TRY(uic_transpose_launch(dt, off(L.out_all, BH, dt), Md, H, H, L.tB, Mdp, s));
+    UIC_TRY(wgrad1(L.tA, Vt, L.tB, H, Mdp, G->gen_w, H, s));
+    UIC_TRY(uic_colsum_launch(dt, L.dlogits, Md, Vt, Vtp, G->gen_b, L.colscratch, L.colscratch_floats, s));
+    // ---- decoder BPTT
+    for (int l = 0; l < NL; ++l) {
+      UIC_TRY(uic_fill_launch(L.dhrec_d[l], 0, BH * 4, s));
+      UIC_TRY(uic_fill_launch(L.dcd[l], 0, BH * 4, s));
+    }
+    const size_t lds_att = sizeof(float) * ((size_t)H + 2 * (size_t)S + 4 * (size_t)H);
+    for (int t = Td - 1; t >= 0; --t) {
+      const bool last = t == Td - 1;
+      void* d_pre = offw(L.d_pre_all, (size_t)t * BH, dt);
+      float* d_cq = L.d_cq_all + (size_t)t * B * 2 * H;
+      NMT_T(tanh_drop_bwd_kernel, gridn(BH), 0, (const float*)(L.d_out_all + (size_t)t * BH), (const float*)(last ? nullptr : L.dfeed),
+            (const void*)off(L.out_pre, (size_t)t * BH, dt), (int)BH, drop_p, seed, SITE_NMT_OUT(t), d_pre);
+      {  // d[c ; q] = d_pre W_out
+        UicGemmParams g = gemm_base(dt, B, 2 * H);
+        add_seg(g, d_pre, H, L.attn_out_wT, H, H);
+        g.C = d_cq; g.ldc = 2 * H; g.flags = UIC_GEMM_OUT_F32;
+        UIC_TRY(uic_gemm_launch(g, s));
+      }
+      NMT_T(gattn_bwd_step_kernel, B, lds_att, (const void*)off(L.xl[NL], BH, dt), (const float*)(L.attn_all + (size_t)t * B * S),
+            (const float*)d_cq, 2 * H, S, B, H, L.dscore_all + (size_t)t * B * S, (void*)offw(L.dtarget_all, (size_t)t * BH, dt));
+      {  // d q = d_cq[:, H:] + d_target W_in
+        UicGemmParams g = gemm_base(dt, B, H);
+        add_seg(g, off(L.dtarget_all, (size_t)t * BH, dt), H, L.attn_in_wT, H, H);
+        g.C = d_cq + H; g.ldc = 2 * H; g.flags = UIC_GEMM_OUT_F32 | UIC_GEMM_ACCUM;
+        UIC_TRY(uic_gemm_launch(g, s));
+      }
+      for (int l = NL - 1; l >= 0; --l) {
+        UicLstmBwdParams p;
+        memset(&p, 0, sizeof(p));
+        p.dtype = dt; p.M = B; p.H = H;
+        if (l == NL - 1) { p.dh0 = d_cq + H; p.lddh0 = 2 * H; }
+        else {                                               // gradient w.r.t. the dropped h of layer l (input of layer l+1)
+          p.dh0 = L.dx_lstm; p.lddh0 = 2 * H;
+          p.drop_p = drop_p; p.seed = seed; p.site = SITE_NMT_DEC(l, t);
+        }
+        if (!last) { p.dh1 = L.dhrec_d[l]; p.lddh1 = H; }
+        p.dc = L.dcd[l]; p.gates = off(L.gates_d[l], (size_t)t * B * H4, dt);
+        p.c_prev = L.cd[l] + (size_t)t * BH; p.c = L.cd[l] + (size_t)(t + 1) * BH;
+        p.dgates = offw(L.dg_d[l], (size_t)t * B * H4, dt);
+        UIC_TRY(uic_lstm_bwd_launch(p, s));
+        const int din = l == 0 ? W + H : H;
+        if (l > 0) {   // d[x_l | h_l_prev] = dG [W_ih | W_hh]
+          UicGemmParams g = gemm_base(dt, B, 2 * H);
+          add_seg(g, p.dgates, H4, L.dec_wT[l], H4, H4);
+          g.C = L.dx_lstm; g.ldc = 2 * H; g.flags = UIC_GEMM_OUT_F32;
+          UIC_TRY(uic_gemm_launch(g, s));
+          UIC_TRY(uic_check_hip(hipMemcpy2DAsync(L.dhrec_d[l], (size_t)H * 4, L.dx_lstm + H, (size_t)2 * H * 4, (size_t)H * 4, B,
+                                                 hipMemcpyDeviceToDevice, s), "memcpy2d dhrec"));
+        } else {       // layer 0: d[feed | h_0_prev] = dG [W_ih[:, W:] | W_hh]  (the embedding part is batched below)
+          UicGemmParams g = gemm_base(dt, B, H);
+          add_seg(g, p.dgates, H4, off(L.dec_wT[0], (size_t)W * H4, dt), H4, H4);
+          g.C = L.dfeed; g.ldc = H; g.flags = UIC_GEMM_OUT_F32;
+          UIC_TRY(uic_gemm_launch(g, s));
+          UicGemmParams g2 = gemm_base(dt, B, H);
+          add_seg(g2, p.dgates, H4, off(L.dec_wT[0], (size_t)din * H4, dt), H4, H4);
+          g2.C = L.dhrec_d[0]; g2.ldc = H; g2.flags = UIC_GEMM_OUT_F32;
+          UIC_TRY(uic_gemm_launch(g2, s));
+        }
+      }
+    }
+    // ---- decoder weights over all steps
+    for (int l = 0; l < NL; ++l) {
+      UIC_TRY(uic_transpose_launch(dt, L.dg_d[l], Md, H4, H4, L.tA, Mdp, s));
+      if (l == 0) {   // inputs [emb | feed_prev | h_prev]
+        UIC_TRY(uic_transpose_launch(dt, L.emb_d, Md, W, W, L.tB, Mdp, s));
+        UIC_TRY(uic_transpose_launch(dt, L.out_all, Md, H, H, offw(L.tB, (size_t)W * Mdp, dt), Mdp, s));
+        UIC_TRY(uic_transpose_launch(dt, L.hd[0], Md, H, H, offw(L.tB, (size_t)(W + H) * Mdp, dt), Mdp, s));
+        const WDest dd[2] = {{G->dec_w_ih[0], W + H, 0, W + H}, {G->dec_w_hh[0], H, W + H, H}};
+        UIC_TRY(wgrad_multi(L.slab, L.slab_bytes, dt, L.tA, H4, L.tB, W + 2 * H, Mdp, dd, 2, s));
+      } else {        // inputs [dropped h of layer l-1 | h_prev]
+        UIC_TRY(uic_transpose_launch(dt, L.hdrop[l - 1], Md, H, H, L.tB, Mdp, s));
+        UIC_TRY(uic_transpose_launch(dt, L.hd[l], Md, H, H, offw(L.tB, (size_t)H * Mdp, dt), Mdp, s));
+        const WDest dd[2] = {{G->dec_w_ih[l], H, 0, H}, {G->dec_w_hh[l], H, H, H}};
+        UIC_TRY(wgrad_multi(L.slab, L.slab_bytes, dt, L.tA, H4, L.tB, 2 * H, Mdp, dd, 2, s));
+      }
+      UIC_TRY(uic_colsum_launch(dt, L.dg_d[l], Md, H4, H4, G->dec_b_ih[l], L.colscratch, L.colscratch_floats, s));
+      UIC_TRY(uic_check_hip(hipMemcpyAsync(G->dec_b_hh[l], G->dec_b_ih[l], (size_t)H4 * 4, hipMemcpyDeviceToDevice, s), "memcpy b_hh"));
+    }
+    {  // decoder embeddings (padding_idx = PAD keeps that row's gradient at zero)
+      UicGemmParams g = gemm_base(dt, Md, W);
+      add_seg(g, L.dg_d[0], H4, L.dec_wT[0], H4, H4);
+      g.C = L.demb_d; g.ldc = W; g.flags = UIC_GEMM_OUT_F32;
+      UIC_TRY(uic_gemm_launch(g, s));
+      UIC_TRY(uic_fill_launch(G->dec_lut, 0, (size_t)Vt * W * 4, s));
+      UIC_TRY(uic_embed_bwd_launch(dt, L.demb_d, nullptr, L.tgt_in, 1, Md, 1, Vt, W, 0.f, 0, G->dec_lut, s));
+    }
+    // attention weights: linear_in from (d_target, q), linear_out from (d_pre, [c | q])
+    UIC_TRY(uic_transpose_launch(dt, L.dtarget_all, Md, H, H, L.tA, Mdp, s));
+    UIC_TRY(uic_transpose_launch(dt, off(L.hd[NL - 1], BH, dt), Md, H, H, L.tB, Mdp, s));
+    UIC_TRY(wgrad1(L.tA, H, L.tB, H, Mdp, G->attn_in_w, H, s));
+    UIC_TRY(uic_transpose_launch(dt, L.d_pre_all, Md, H, H, L.tA, Mdp, s));
+    UIC_TRY(uic_transpose_launch(dt, L.cvec_all, Md, H, H, L.tB, Mdp, s));
+    UIC_TRY(uic_transpose_launch(dt, off(L.hd[NL - 1], BH, dt), Md, H, H, offw(L.tB, (size_t)H * Mdp, dt), Mdp, s));
+    UIC_TRY(wgrad1(L.tA, H, L.tB, 2 * H, Mdp, G->attn_out_w, 2 * H, s));
+    // ---- encoder: d context = deferred attention gradient; d h0/c0 of the decoder enter at each row's final steps
+    float* d_top = L.d_lay;
+    hipLaunchKernelGGL(gattn_bwd_accum_kernel, dim3(gridn((size_t)S * BH)), dim3(NT), 0, s, L.attn_all, L.dscore_all, L.d_cq_all,
+                       2 * H, L.targetq, Td, S, B, H, d_top);
+    UIC_LAUNCH_CHECK("gattn_bwd_accum_kernel");
+    for (int l = NL - 1; l >= 0; --l) {
+      const int in = l == 0 ? W : H;
+      for (int dd = 0; dd < 2; ++dd) {
+        UIC_TRY(uic_fill_launch(L.dg_e[l][dd], 0, (size_t)Ms * 4 * Hd * Sz, s));
+        // carried dh / dc start from the decoder-initial-state gradient halves (rows join the BPTT when they become active)
+        UIC_TRY(uic_check_hip(hipMemcpy2DAsync(L.dhrec_e, (size_t)Hd * 4, L.dhrec_d[l] + dd * Hd, (size_t)H * 4, (size_t)Hd * 4, B,
+                                               hipMemcpyDeviceToDevice, s), "memcpy2d dh0"));
+        UIC_TRY(uic_check_hip(hipMemcpy2DAsync(L.dc_e, (size_t)Hd * 4, L.dcd[l] + dd * Hd, (size_t)H * 4, (size_t)Hd * 4, B,
+                                               hipMemcpyDeviceToDevice, s), "memcpy2d dc0"));
+        for (int k = S - 1; k >= 0; --k) {
+          const int st = dd == 0 ? k : S - 1 - k;
+          const int prev = dd == 0 ? st : st + 2;
+          if (nb[st] == 0) continue;
+          UicLstmBwdParams p;
+          memset(&p, 0, sizeof(p));
+          p.dtype = dt; p.M = nb[st]; p.H = Hd;
+          p.dh0 = d_top + (size_t)st * BH + dd * Hd; p.lddh0 = H;
+          p.dh1 = L.dhrec_e; p.lddh1 = Hd;
+          p.dc = L.dc_e; p.gates = off(L.gates_e[l][dd], (size_t)st * B * 4 * Hd, dt);
+          p.c_prev = L.c_e[l][dd] + (size_t)prev * BHd; p.c = L.c_e[l][dd] + (size_t)(st + 1) * BHd;
+          p.dgates = offw(L.dg_e[l][dd], (size_t)st * B * 4 * Hd, dt);
+          UIC_TRY(uic_lstm_bwd_launch(p, s));
+          UicGemmParams g = gemm_base(dt, nb[st], Hd);
+          add_seg(g, p.dgates, 4 * Hd, L.enc_w_hhT[l][dd], 4 * Hd, 4 * Hd);
+          g.C = L.dhrec_e; g.ldc = Hd; g.flags = UIC_GEMM_OUT_F32;
+          UIC_TRY(uic_gemm_launch(g, s));
+        }
+        // weights of this direction: dG^T [4Hd, S*B] x [x_l | h_prev]^T  (padded rows of dG are zero)
+        UIC_TRY(uic_transpose_launch(dt, L.dg_e[l][dd], Ms, 4 * Hd, 4 * Hd, L.tA, Msp, s));
+        UIC_TRY(uic_transpose_launch(dt, enc_in(l), Ms, in, in, L.tB, Msp, s));
+        UIC_TRY(uic_transpose_launch(dt, off(L.xl[l + 1], (size_t)(dd == 0 ? 0 : 2) * BH + dd * Hd, dt), Ms, Hd, H,
+                                     offw(L.tB, (size_t)in * Msp, dt), Msp, s));
+        const WDest dw[2] = {{G->enc_w_ih[l][dd], in, 0, in}, {G->enc_w_hh[l][dd], Hd, in, Hd}};
+        UIC_TRY(wgrad_multi(L.slab, L.slab_bytes, dt, L.tA, 4 * Hd, L.tB, in + Hd, Msp, dw, 2, s));
+        UIC_TRY(uic_colsum_launch(dt, L.dg_e[l][dd], Ms, 4 * Hd, 4 * Hd, G->enc_b_ih[l][dd], L.colscratch, L.colscratch_floats, s));
+        UIC_TRY(uic_check_hip(hipMemcpyAsync(G->enc_b_hh[l][dd], G->enc_b_ih[l][dd], (size_t)4 * Hd * 4, hipMemcpyDeviceToDevice, s), "memcpy b_hh"));
+      }
+      {  // d input of layer l = sum over directions dG W_ih
+        UicGemmParams g = gemm_base(dt, Ms, in);
+        add_seg(g, L.dg_e[l][0], 4 * Hd, L.enc_w_ihT[l][0], 4 * Hd, 4 * Hd);
+        add_seg(g, L.dg_e[l][1], 4 * Hd, L.enc_w_ihT[l][1], 4 * Hd, 4 * Hd);
+        g.C = L.dx_e; g.ldc = in; g.flags = UIC_GEMM_OUT_F32;
+        UIC_TRY(uic_gemm_launch(g, s));
+      }
+      if (l > 0) {
+        if (drop_p > 0.f) {
+          hipLaunchKernelGGL(dropout_grad_kernel, dim3(gridn((size_t)Ms * H)), dim3(NT), 0, s, L.dx_e, (size_t)Ms * H, drop_p, seed, SITE_NMT_ENC(l - 1));
+          UIC_LAUNCH_CHECK("dropout_grad_kernel");
+        }
+        UIC_TRY(uic_check_hip(hipMemcpyAsync(L.d_lay, L.dx_e, (size_t)Ms * H * 4, hipMemcpyDeviceToDevice, s), "memcpy d_lay"));
+        d_top = L.d_lay;
+      }
+    }
+    // encoder embeddings: x0 = relu(linear(emb))
+    UIC_TRY(uic_relu_mask_bwd_launch(dt, L.dx_e, off(L.xl[0], (size_t)B * W, dt), 1.f, L.dpre_e, (size_t)Ms * W, s));
+    UIC_TRY(uic_transpose_launch(dt, L.dpre_e, Ms, W, W, L.tA, Msp, s));
+    UIC_TRY(uic_transpose_launch(dt, L.xe, Ms, W, W, L.tB, Msp, s));
+    UIC_TRY(wgrad1(L.tA, W, L.tB, W, Msp, G->enc_lin_w, W, s));
+    UIC_TRY(uic_colsum_launch(dt, L.dpre_e, Ms, W, W, G->enc_lin_b, L.colscratch, L.colscratch_floats, s));
+    {
+      UicGemmParams g = gemm_base(dt, Ms, W);
+      add_seg(g, L.dpre_e, W, L.enc_lin_wT, W, W);
+      g.C = L.dxe; g.ldc = W; g.flags = UIC_GEMM_OUT_F32;
+      UIC_TRY(uic_gemm_launch(g, s));
+    }
+    UIC_TRY(uic_fill_launch(G->enc_lut, 0, (size_t)Vs * W * 4, s));
+    return uic_embed_bwd_launch(dt, L.dxe, nullptr, src, 1, Ms, 1, Vs, W, 0.f, 0, G->enc_lut, s);
+  }
+};
+
+}  // namespace
+
+extern "C" {
+
+size_t uic_nmt_workspace_bytes(const uic_nmt_dims* d) {
+  if (nmt_check(d)) return 0;
+  return nmt_layout(*d, nullptr, nullptr).total;
+}
+
+int uic_nmt_forward_loss(const uic_nmt_dims* d, const uic_nmt_weights* w, const int64_t* src, const int32_t* lengths_host,
+                         const int32_t* lengths_dev, const int64_t* tgt, int32_t training, uint32_t seed, void* workspace,
+                         float* loss_out, int32_t* stats_out, float* outputs_out, float* attn_out, float* context_out,
+                         void* stream) {
+  UIC_TRY(nmt_check(d));
+  UIC_REQUIRE(w && src && lengths_host && lengths_dev && tgt && workspace && loss_out, "nmt_forward_loss: null pointer");
+  hipStream_t s = (hipStream_t)stream;
+  static thread_local Nmt st;
+  UIC_TRY(st.init(d, w, src, lengths_host, tgt, training, seed, workspace, nullptr));
+  UIC_TRY(st.refresh(s));
+  UIC_TRY(st.encoder_fwd(lengths_dev, s));
+  UIC_TRY(st.decoder_fwd(s));
+  UIC_TRY(st.loss_fwd(loss_out, stats_out, s));
+  const int dt = st.dt;
+  if (outputs_out) UIC_TRY(uic_to_f32_launch(dt, off(st.L.out_all, st.BH, dt), outputs_out, (size_t)st.Td * st.BH, s));
+  if (attn_out) UIC_TRY(uic_check_hip(hipMemcpyAsync(attn_out, st.L.attn_all, (size_t)st.Td * st.B * st.S * 4, hipMemcpyDeviceToDevice, s), "memcpy attn"));
+  if (context_out) UIC_TRY(uic_to_f32_launch(dt, off(st.L.xl[st.NL], st.BH, dt), context_out, (size_t)st.S * st.BH, s));
+  return UIC_OK;
+}
+
+int uic_nmt_backward(const uic_nmt_dims* d, const uic_nmt_weights* w, const int64_t* src, const int32_t* lengths_host,
+                     const int64_t* tgt, int32_t training, uint32_t seed, void* workspace, const uic_nmt_weights* grads,
+                     void* stream) {
+  UIC_TRY(nmt_check(d));
+  UIC_REQUIRE(w && src && lengths_host && tgt && workspace && grads, "nmt_backward: null pointer");
+  static thread_local Nmt st;
+  UIC_TRY(st.init(d, w, src, lengths_host, tgt, training, seed, workspace, grads));
+  return st.backward((hipStream_t)stream);
+}
+
+}  // extern "C"

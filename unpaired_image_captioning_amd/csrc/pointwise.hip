@@ -130,7 +130,7 @@ __global__ void embed_fwd_kernel(const float* __restrict__ table, int V1, int E,
 // d table[tok] += dxt * (xt > 0 ? 1/(1-p) : 0): xt > 0 iff the ReLU was open and the unit was kept
 template <typename T>
 __global__ void embed_bwd_kernel(const float* __restrict__ dxt, const T* __restrict__ xt, const int64_t* __restrict__ tokens,
-                                 int ldtok, int N, int TS, int V1, int E, float inv_keep, float* __restrict__ dtable) {
+                                 int ldtok, int N, int TS, int V1, int E, float inv_keep, long skip_token, float* __restrict__ dtable) {
   const size_t total = (size_t)TS * N * E;
   const size_t stride = (size_t)gridDim.x * blockDim.x;
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
@@ -140,7 +140,7 @@ __global__ void embed_bwd_kernel(const float* __restrict__ dxt, const T* __restr
       const int t = (int)(row / N), n = (int)(row - (size_t)t * N);
       long tok = tokens[(size_t)n * ldtok + t];
       if (tok < 0 || tok >= V1) tok = 0;
-      atomicAdd(dtable + (size_t)tok * E + e, dxt[i] * inv_keep);
+      if (tok != skip_token) atomicAdd(dtable + (size_t)tok * E + e, dxt[i] * inv_keep);
     }
   }
 }
@@ -591,13 +591,13 @@ int uic_embed_fwd_launch(int dtype, const float* table, int V1, int E, const int
   return UIC_OK;
 }
 int uic_embed_bwd_launch(int dtype, const float* dxt, const void* xt, const int64_t* tokens, int ldtok, int N, int T,
-                         int V1, int E, float drop_p, float* dtable, hipStream_t s) {
+                         int V1, int E, float drop_p, long skip_token, float* dtable, hipStream_t s) {
   if (N == 0 || T == 0) return UIC_OK;
   const float inv_keep = drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f;
   const int g = grid_for((size_t)T * N * E, NT);
   DISPATCH_T(dtype,
-             hipLaunchKernelGGL(embed_bwd_kernel<bf16_t>, dim3(g), dim3(NT), 0, s, dxt, (const bf16_t*)xt, tokens, ldtok, N, T, V1, E, inv_keep, dtable),
-             hipLaunchKernelGGL(embed_bwd_kernel<float>, dim3(g), dim3(NT), 0, s, dxt, (const float*)xt, tokens, ldtok, N, T, V1, E, inv_keep, dtable));
+             hipLaunchKernelGGL(embed_bwd_kernel<bf16_t>, dim3(g), dim3(NT), 0, s, dxt, (const bf16_t*)xt, tokens, ldtok, N, T, V1, E, inv_keep, skip_token, dtable),
+             hipLaunchKernelGGL(embed_bwd_kernel<float>, dim3(g), dim3(NT), 0, s, dxt, (const float*)xt, tokens, ldtok, N, T, V1, E, inv_keep, skip_token, dtable));
   UIC_LAUNCH_CHECK("embed_bwd");
   return UIC_OK;
 }

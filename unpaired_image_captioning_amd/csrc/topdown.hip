@@ -598,7 +598,7 @@ struct Step {
       g.C = L.dxt; g.ldc = E; g.flags = UIC_GEMM_OUT_F32;
       UIC_TRY(uic_gemm_launch(g, s));
       UIC_TRY(uic_fill_launch(G->embed_w, 0, (size_t)V1 * E * 4, s));
-      UIC_TRY(uic_embed_bwd_launch(dt, L.dxt, L.xt_all, b->labels, b->ld_labels, N, t_run, V1, E, drop_p, G->embed_w, s));
+      UIC_TRY(uic_embed_bwd_launch(dt, L.dxt, L.xt_all, b->labels, b->ld_labels, N, t_run, V1, E, drop_p, -1, G->embed_w, s));
     }
     // fc' path: dGfc = sum_t dG1_t
     UIC_TRY(uic_sum_steps_launch(dt, L.dg1_all, t_run, (size_t)N * H4, L.dgfc, s));

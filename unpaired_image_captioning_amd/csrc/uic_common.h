@@ -137,6 +137,7 @@ __device__ __forceinline__ float uic_wave_max(float v) {
 #define UIC_GEMM_RELU 1      // v = max(v, 0)
 #define UIC_GEMM_ACCUM 2     // C += v
 #define UIC_GEMM_OUT_F32 4   // C is float regardless of the operand dtype
+#define UIC_GEMM_TANH 8      // v = tanh(v)
 #define UIC_GEMM_MAX_SEG 4
 
 // One K-segment: C += A[M,K] * B[Nrows,K]^T.  Segments are summed, which expresses
@@ -226,7 +227,7 @@ int uic_sum_steps_launch(int dtype, const void* src, int T, size_t step_elems, v
 int uic_embed_fwd_launch(int dtype, const float* table, int V1, int E, const int64_t* tokens, int ldtok, int N, int T,
                          float drop_p, unsigned seed, unsigned site, size_t idx_base, int relu, void* out, hipStream_t s);
 int uic_embed_bwd_launch(int dtype, const float* dxt, const void* xt, const int64_t* tokens, int ldtok, int N, int T,
-                         int V1, int E, float drop_p, float* dtable, hipStream_t s);
+                         int V1, int E, float drop_p, long skip_token, float* dtable, hipStream_t s);   // skip_token < 0: none (nn.Embedding padding_idx otherwise)
 // dst = (act > 0 ? scale : 0) * grad ; grad f32, act/dst operand dtype
 int uic_relu_mask_bwd_launch(int dtype, const float* grad, const void* act, float scale, void* dst, size_t n, hipStream_t s);
 

@@ -1,6 +1,8 @@
 """Criteria of the captioner with the reference's call signatures (P/misc/criterion.py:104-159),
 computed by libuic_hip.so on device tensors."""
 import ctypes as C
+import math
+import time
 
 import torch
 import torch.nn as nn
@@ -79,3 +81,77 @@ class RewardCriterion(nn.Module):
 
     def forward(self, input, seq, reward):
         return _RewardCriterionFn.apply(input, seq, reward)
+
+
+# ---------------------------------------------------------------- pivot NMT (P/misc/criterion.py:47-101,126-205)
+class Statistics(object):
+    """Accumulator for loss statistics (P/misc/criterion.py:47-101): accuracy, perplexity, elapsed time."""
+
+    def __init__(self, loss=0, n_words=0, n_correct=0):
+        self.loss = loss
+        self.n_words = n_words
+        self.n_correct = n_correct
+        self.n_src_words = 0
+        self.start_time = time.time()
+
+    def update(self, stat):
+        self.loss += stat.loss
+        self.n_words += stat.n_words
+        self.n_correct += stat.n_correct
+
+    def accuracy(self):
+        return 100 * (float(self.n_correct) / self.n_words)
+
+    def ppl(self):
+        return math.exp(min(self.loss / self.n_words, 100))
+
+    def elapsed_time(self):
+        return time.time() - self.start_time
+
+
+class _NMTCriterion(nn.Module):
+    """Marker for nn.NLLLoss(weight[PAD]=0, size_average=False) (P/misc/criterion.py:126-136).  The weighted NLL is
+    computed inside uic_nmt_forward_loss next to the generator GEMM; this object only carries the vocabulary size."""
+
+    def __init__(self, vocabSize):
+        super(_NMTCriterion, self).__init__()
+        self.vocabSize = vocabSize
+        self.register_buffer('weight', torch.ones(vocabSize))
+        self.weight[0] = 0
+
+    def forward(self, scores, target):
+        raise RuntimeError("the NMT NLL is fused into uic_nmt_forward_loss; call NMT_loss(loader, batch, outputs, attns)")
+
+
+def NMTCriterion(vocabSize, opt):
+    return _NMTCriterion(vocabSize)
+
+
+class NMT_loss(nn.Module):
+    """P/misc/criterion.py:161-205.  `outputs` must come from models.NMT_Models.NMTModel.forward, which already ran the
+    generator, the loss and the `score` counters on the device (outputs.uic_loss / outputs.uic_stats)."""
+
+    def __init__(self, opt, generator, crit, eval=False):
+        super(NMT_loss, self).__init__()
+        for name in ('lambda_coverage', 'lambda_fertility', 'lambda_exhaust'):
+            if getattr(opt, name, 0):
+                raise NotImplementedError("opt.%s is outside the MI355X NMT hot path" % name)
+        self.generator = generator
+        self.crit = crit
+        self.batch_size = getattr(opt, 'batch_size', None)
+        self.total_stats = Statistics()
+        self.report_stats = Statistics()
+
+    def forward(self, loader, batch, outputs, attns):
+        if not hasattr(outputs, 'uic_loss'):
+            raise RuntimeError("NMT_loss needs the `outputs` tensor returned by the HIP NMTModel.forward (no eager fallback)")
+        nmt_stats_reset = bool(loader is not None and loader.nmt_batchIdx > len(loader.nmt_trainData))
+        loss_t = outputs.uic_loss
+        num_correct, num_words = [int(x) for x in outputs.uic_stats.tolist()]      # one small D2H, like loss_t.data[0]
+        stats = Statistics(float(loss_t.detach()), num_words, num_correct)
+        self.total_stats.update(stats)
+        self.report_stats.update(stats)
+        if nmt_stats_reset:
+            self.total_stats = Statistics()
+            self.report_stats = Statistics()
+        return loss_t

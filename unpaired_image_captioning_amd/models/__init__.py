@@ -3,6 +3,7 @@ the architectures on the hot path."""
 from .AttModel import TopDownModel  # noqa: F401
 from .CaptionModel import CaptionModel  # noqa: F401
 from .FCModel_NMT import FCModel_NMT  # noqa: F401
+from . import NMT_Models  # noqa: F401
 
 
 def setup(opt):
