@@ -261,6 +261,14 @@ int uic_attention_bwd_accum(int32_t dtype, int32_t N, int32_t R, int32_t A, int3
 int uic_adam_step(float* p, const float* g, float* m, float* v, size_t n, float lr, float beta1, float beta2,
                   float eps, int32_t step, float grad_scale, void* stream);
 
+/* torch.nn.utils.clip_grad_norm + Adam as Optim.step applies them to the NMT model (P/misc/optimizer.py:93-100,
+ * --nmt_max_grad_norm 5): uic_grad_sqnorm leaves sum(g^2) of the flat gradient arena in out[0] (deterministic
+ * two-stage sum; scratch >= 1024 floats); uic_adam_step_clip scales the gradient by grad_scale and, if
+ * max_norm / (|grad_scale| * sqrt(sqnorm[0]) + 1e-6) < 1, by that coefficient too, read on the device. */
+int uic_grad_sqnorm(const float* g, size_t n, float* scratch, float* out, void* stream);
+int uic_adam_step_clip(float* p, const float* g, float* m, float* v, size_t n, float lr, float beta1, float beta2,
+                       float eps, int32_t step, float grad_scale, float max_norm, const float* sqnorm, void* stream);
+
 /* LanguageModelCriterion on materialised log-probs [N, T, V1] (API-compatible path): loss_out[0] and,
  * if dlogp != NULL, the dense gradient scaled by grad_out (host scalar). */
 int uic_lm_criterion(int32_t N, int32_t T, int32_t V1, const float* logp, const int64_t* target, int32_t ld_target,

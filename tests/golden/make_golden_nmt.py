@@ -152,8 +152,82 @@ def run_case(nmt, crit_mod, name, layers, H, B, S, T, Vs, Vt, seed):
     print("wrote %s (%.1f KB) loss=%.5f keys=%d" % (path, os.path.getsize(path) / 1024, loss.item(), len(model.state_dict())))
 
 
+def optim_opt(**kw):
+    o = argparse.Namespace(
+        i2t_train_flag=0, i2t_eval_flag=0, i2t_optim="adam", i2t_learning_rate=4e-4, i2t_learning_rate_decay_start=0,
+        i2t_learning_rate_decay_every=3, i2t_learning_rate_decay_rate=0.8, i2t_optim_alpha=0.9, i2t_optim_beta=0.999,
+        i2t_optim_epsilon=1e-8, i2t_momentum=0, i2t_max_grad_norm=0, i2t_grad_clip=0.1, i2t_decay_method="", i2t_weight_decay=0,
+        nmt_train_flag=1, nmt_eval_flag=0, nmt_optim="adam", nmt_learning_rate=1e-3, nmt_learning_rate_decay_start=8,
+        nmt_learning_rate_decay_every=3, nmt_learning_rate_decay_rate=0.5, nmt_optim_alpha=0.9, nmt_optim_beta=0.999,
+        nmt_optim_epsilon=1e-8, nmt_momentum=0, nmt_max_grad_norm=5, nmt_grad_clip=0.1, nmt_decay_method="", nmt_weight_decay=0,
+        nmt_warmup_steps=4000, rnn_size=32, start_from=None, scheduled_sampling_start=0, scheduled_sampling_increase_every=5,
+        scheduled_sampling_increase_prob=0.05, scheduled_sampling_max_prob=0.25)
+    for k, v in kw.items():
+        setattr(o, k, v)
+    return o
+
+
+def run_optim_case(nmt, crit_mod, name, steps, seed, **optkw):
+    """Trainer.train's NMT half (P/trainer.py:175-193) driven by the reference's own Optim (P/misc/optimizer.py:59-131):
+    zero_grad, forward, NMTCriterion, backward, step (noam LR, clip_grad_norm 5, Adam) on ONE fixed batch."""
+    import torch.nn.utils as U
+    U.clip_grad_norm = U.clip_grad_norm_                     # removed spelling, imported by misc/optimizer.py:5
+    optim_mod = load("refoptimizer", os.path.join(P, "misc", "optimizer.py"))
+    layers, H, B, S, T, Vs, Vt = 2, 32, 4, 9, 10, 40, 45
+    torch.manual_seed(seed)
+    mopt = make_opt(layers, H, H)
+    sd, td = FakeDict(Vs), FakeDict(Vt)
+    model = nmt.NMTModel(mopt, nmt.Encoder(mopt, sd), nmt.Decoder(mopt, td), sd, td)
+    generator = nn.Sequential(nn.Linear(H, Vt), nn.LogSoftmax(dim=1))
+    model.generator = generator
+    loss_fn = crit_mod.NMTCriterion(Vt, mopt)
+    src, lengths, tgt = synth_batch(B, S, T, Vs, Vt, seed)
+    oo = optim_opt(**optkw)
+    optim = optim_mod.Optim(oo)
+    optim.set_parameters(None, model)
+    out = {"cfg": np.array([layers, H, B, S, T, Vs, Vt], dtype=np.int64),
+           "optcfg": np.array([oo.nmt_learning_rate, oo.nmt_max_grad_norm, oo.nmt_warmup_steps, 1.0 if oo.nmt_decay_method == "noam" else 0.0,
+                               oo.nmt_optim_alpha, oo.nmt_optim_beta, oo.nmt_optim_epsilon], dtype=np.float64)}
+    for k, v in model.state_dict().items():
+        out["w::" + k] = v.detach().clone().numpy()
+    out["in::src"], out["in::lengths"], out["in::tgt"] = src.numpy(), lengths.numpy(), tgt.numpy()
+    losses, norms, lrs = [], [], []
+    model.train()
+    for it in range(steps):
+        optim.zero_grad()
+        outputs, attns, _, _ = model(src, tgt, lengths)
+        loss = loss_fn(generator(outputs.view(-1, outputs.size(2))), tgt[1:].view(-1))
+        loss.backward()
+        norms.append(float(torch.sqrt(sum((p.grad.double() ** 2).sum() for p in model.parameters()))))
+        optim.step()
+        losses.append(loss.item())
+        lrs.append(optim.nmt_optimizer.param_groups[0]["lr"])
+    out["out::losses"] = np.array(losses, dtype=np.float64)
+    out["out::grad_norms"] = np.array(norms, dtype=np.float64)
+    out["out::lrs"] = np.array(lrs, dtype=np.float64)
+    for k, v in model.state_dict().items():
+        out["final::" + k] = v.detach().clone().numpy()
+    # the epoch schedules (P/misc/optimizer.py:108-131)
+    sched_nmt, sched_i2t, sched_ss = [], [], []
+    holder = argparse.Namespace(ss_prob=0.0)
+    o2 = optim_mod.Optim(optim_opt(i2t_train_flag=1))
+    o2.set_parameters(nn.Linear(2, 2), model)
+    for epoch in range(14):
+        o2.update_LearningRate("nmt", epoch)
+        o2.update_LearningRate("i2t", epoch)
+        o2.update_ScheduledSampling_prob(o2.opt, epoch, holder)
+        sched_nmt.append(o2.nmt_current_lr); sched_i2t.append(o2.i2t_current_lr); sched_ss.append(holder.ss_prob)
+    out["out::sched_nmt"] = np.array(sched_nmt); out["out::sched_i2t"] = np.array(sched_i2t); out["out::sched_ss"] = np.array(sched_ss)
+    path = os.path.join(HERE, name + ".npz")
+    np.savez_compressed(path, **out)
+    print("wrote %s (%.1f KB) losses=%s norms=%s lrs=%s" % (path, os.path.getsize(path) / 1024, losses, norms, lrs))
+
+
 if __name__ == "__main__":
     nmt, crit_mod = load_reference()
+    run_optim_case(nmt, crit_mod, "nmt_optim_clip", steps=4, seed=41, nmt_learning_rate=1e-2)
+    run_optim_case(nmt, crit_mod, "nmt_optim_noam", steps=4, seed=42, nmt_learning_rate=0.2, nmt_decay_method="noam", nmt_warmup_steps=3,
+                   nmt_max_grad_norm=0)
     run_case(nmt, crit_mod, "nmt_tiny", layers=2, H=32, B=4, S=9, T=10, Vs=40, Vt=45, seed=31)
     run_case(nmt, crit_mod, "nmt_tiny_1layer", layers=1, H=32, B=3, S=6, T=7, Vs=30, Vt=37, seed=32)
     run_case(nmt, crit_mod, "nmt_odd", layers=2, H=48, B=5, S=11, T=8, Vs=53, Vt=61, seed=33)

@@ -233,3 +233,68 @@ def test_nmt_training_reduces_loss_bf16():
         first = loss.item() if first is None else first
     assert loss.item() < 0.7 * first, (first, loss.item())
     assert crit.report_stats.accuracy() >= 0.0
+
+
+# ---------------------------------------------------------------- Optim on the NMT model
+def load_optim_case(name):
+    z = np.load(os.path.join(GOLDEN, name + ".npz"))
+    cfg, W, I, Out, G = load(name)
+    final = {k[7:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("final::")}
+    lr, max_norm, warmup, noam, alpha, beta, eps = [float(x) for x in z["optcfg"]]
+    return cfg, W, I, Out, final, dict(lr=lr, max_norm=max_norm, warmup=int(warmup), noam=bool(noam), alpha=alpha, beta=beta, eps=eps)
+
+
+@pytest.mark.parametrize("name", ["nmt_optim_clip", "nmt_optim_noam"])
+def test_nmt_optim_trajectory_vs_reference_golden(name):
+    """4 steps of zero_grad / forward / NMT_loss / backward / Optim.step on one batch, against the same loop run with the
+    reference's own Optim (clip_grad_norm 5 resp. noam schedule) -- losses, gradient norms, learning rates and the
+    final weights."""
+    from unpaired_image_captioning_amd.misc.optimizer import Optim
+    cfg, W, I, Out, final, oc = load_optim_case(name)
+    model, crit = build(cfg, W, "f32")
+    o = model.opt
+    o.nmt_train_flag, o.i2t_train_flag = 1, 0
+    o.nmt_optim, o.nmt_learning_rate, o.nmt_max_grad_norm = "adam", oc["lr"], oc["max_norm"]
+    o.nmt_decay_method, o.nmt_warmup_steps = ("noam" if oc["noam"] else ""), oc["warmup"]
+    o.nmt_optim_alpha, o.nmt_optim_beta, o.nmt_optim_epsilon = oc["alpha"], oc["beta"], oc["eps"]
+    optim = Optim(o)
+    optim.set_parameters(None, model)
+    model.train()
+    losses, norms, lrs = [], [], []
+    for it in range(len(Out["losses"])):
+        optim.zero_grad()
+        outputs, attn, loss = run(model, crit, I)
+        loss.backward()
+        norms.append(optim.nmt_arena.grad_norm())
+        optim.step()
+        losses.append(loss.item())
+        lrs.append(optim.nmt_current_lr)
+    np.testing.assert_allclose(lrs, Out["lrs"].numpy(), rtol=1e-6)
+    np.testing.assert_allclose(losses, Out["losses"].numpy(), rtol=2e-4)
+    np.testing.assert_allclose(norms, Out["grad_norms"].numpy(), rtol=5e-3)
+    sd = model.state_dict()
+    for k, ref in final.items():
+        moved = (ref - W[k]).norm().item()
+        err = (sd[k].cpu() - ref).norm().item()
+        assert err <= 2e-2 * moved + 1e-6, (k, err, moved)
+
+
+def test_trainer_nmt_half_runs_and_saves(tmp_path):
+    """Trainer.build_nmt + train_nmt (P/trainer.py:80-94,175-193) and model_nmt.pth with the reference's keys."""
+    from unpaired_image_captioning_amd.trainer import Trainer
+    cfg = dict(layers=2, H=64, W=64, B=8, S=10, T=9, Vs=120, Vt=130)
+    o = make_opt(cfg, "bf16", dropout=0.1, seed=3)
+    o.nmt_train_flag, o.i2t_train_flag, o.checkpoint_path = 1, 0, str(tmp_path)
+    o.nmt_learning_rate, o.nmt_max_grad_norm, o.param_init = 5e-3, 5, 0.1
+    tr = Trainer(o)
+    tr.build_nmt(cfg["Vs"], cfg["Vt"])
+    I = synthetic(cfg, 9)
+    batch = argparse.Namespace(src=I["src"].cuda(), tgt=I["tgt"].cuda(), lengths=I["lengths"])
+    first = tr.train_nmt(batch)
+    for _ in range(30):
+        last = tr.train_nmt(batch)
+    assert last < 0.8 * first, (first, last)
+    assert tr.nmt_train_ppl > 1.0 and 0.0 <= tr.nmt_train_acc <= 100.0
+    tr.save_models()
+    sd = torch.load(os.path.join(str(tmp_path), "model_nmt.pth"))
+    assert list(sd.keys()) == tr.nmt_model.param_names

@@ -165,6 +165,24 @@ int uic_adam_step(float* p, const float* g, float* m, float* v, size_t n, float 
   a.bc1 = (float)(1.0 - pow((double)beta1, (double)step));
   a.bc2 = (float)(1.0 - pow((double)beta2, (double)step));
   a.grad_scale = grad_scale;
+  a.max_norm = 0.f; a.sqnorm = nullptr;
+  return uic_adam_launch(a, (hipStream_t)stream);
+}
+
+int uic_grad_sqnorm(const float* g, size_t n, float* scratch, float* out, void* stream) {
+  return uic_sqnorm_launch(g, n, scratch, out, (hipStream_t)stream);
+}
+
+int uic_adam_step_clip(float* p, const float* g, float* m, float* v, size_t n, float lr, float beta1, float beta2,
+                       float eps, int32_t step, float grad_scale, float max_norm, const float* sqnorm, void* stream) {
+  UIC_REQUIRE(p && g && m && v && sqnorm, "adam_step_clip: null pointer");
+  UIC_REQUIRE(step >= 1 && max_norm > 0.f, "adam_step_clip: step=%d must be >= 1 and max_norm=%f > 0", step, (double)max_norm);
+  UicAdamParams a;
+  a.p = p; a.g = g; a.m = m; a.v = v; a.n = n; a.lr = lr; a.beta1 = beta1; a.beta2 = beta2; a.eps = eps;
+  a.bc1 = (float)(1.0 - pow((double)beta1, (double)step));
+  a.bc2 = (float)(1.0 - pow((double)beta2, (double)step));
+  a.grad_scale = grad_scale;
+  a.max_norm = max_norm; a.sqnorm = sqnorm;
   return uic_adam_launch(a, (hipStream_t)stream);
 }
 

@@ -390,12 +390,25 @@ __global__ __launch_bounds__(NT) void reduce_sum_kernel(const float* __restrict_
 }
 
 // ------------------------------------------------------------------ Adam (torch.optim.Adam, P/misc/optimizer.py:70)
+__global__ __launch_bounds__(NT) void sqnorm_part_kernel(const float* __restrict__ g, size_t n, float* __restrict__ part) {
+  __shared__ float s_buf[NT / 64];
+  const size_t stride = (size_t)gridDim.x * NT;
+  float s = 0.f;
+  for (size_t i = (size_t)blockIdx.x * NT + threadIdx.x; i < n; i += stride) s += g[i] * g[i];
+  s = block_reduce_sum(s, s_buf);
+  if (threadIdx.x == 0) part[blockIdx.x] = s;
+}
 __global__ void adam_kernel(const UicAdamParams a) {
   const size_t stride = (size_t)gridDim.x * blockDim.x;
   const float step_size = a.lr / a.bc1;
   const float inv_sqrt_bc2 = 1.f / sqrtf(a.bc2);
+  float gs = a.grad_scale;
+  if (a.sqnorm) {
+    const float coef = a.max_norm / (fabsf(a.grad_scale) * sqrtf(a.sqnorm[0]) + 1e-6f);
+    if (coef < 1.f) gs *= coef;
+  }
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < a.n; i += stride) {
-    const float g = a.g[i] * a.grad_scale;
+    const float g = a.g[i] * gs;
     const float m = a.beta1 * a.m[i] + (1.f - a.beta1) * g;
     const float v = a.beta2 * a.v[i] + (1.f - a.beta2) * g * g;
     a.m[i] = m;
@@ -657,6 +670,15 @@ int uic_reduce_sum_launch(const float* x, size_t n, float unused, const float* s
   (void)unused;
   hipLaunchKernelGGL(reduce_sum_kernel, dim3(1), dim3(NT), 0, s, x, n, scale, out);
   UIC_LAUNCH_CHECK("reduce_sum");
+  return UIC_OK;
+}
+int uic_sqnorm_launch(const float* g, size_t n, float* scratch, float* out, hipStream_t s) {
+  UIC_REQUIRE(g && scratch && out, "sqnorm: null pointer");
+  const int blocks = (int)(n / (NT * 8) > 1024 ? 1024 : (n / (NT * 8) ? n / (NT * 8) : 1));
+  hipLaunchKernelGGL(sqnorm_part_kernel, dim3(blocks), dim3(NT), 0, s, g, n, scratch);
+  UIC_LAUNCH_CHECK("sqnorm_part");
+  hipLaunchKernelGGL(reduce_sum_kernel, dim3(1), dim3(NT), 0, s, scratch, (size_t)blocks, (const float*)nullptr, out);
+  UIC_LAUNCH_CHECK("sqnorm_final");
   return UIC_OK;
 }
 int uic_adam_launch(const UicAdamParams& a, hipStream_t s) {

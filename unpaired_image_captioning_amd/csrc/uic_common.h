@@ -272,7 +272,12 @@ int uic_reduce_sum_launch(const float* x, size_t n, float scale_by_dev_ptr_or_on
 struct UicAdamParams {
   float* p; const float* g; float* m; float* v; size_t n;
   float lr, beta1, beta2, eps, bc1, bc2, grad_scale;
+  // clip_grad_norm (P/misc/optimizer.py:99): if sqnorm != null, gradients are additionally scaled by
+  // min(1, max_norm / (grad_scale * sqrt(sqnorm[0]) + 1e-6)), read on the device (no host sync)
+  float max_norm; const float* sqnorm;
 };
+// out[0] = sum_i g[i]^2, deterministic two-stage reduction; scratch >= 1024 floats
+int uic_sqnorm_launch(const float* g, size_t n, float* scratch, float* out, hipStream_t s);
 int uic_adam_launch(const UicAdamParams& a, hipStream_t s);
 
 struct UicSampleParams {

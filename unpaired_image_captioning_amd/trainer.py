@@ -15,6 +15,7 @@ import torch
 
 from . import _lib, models
 from ._lib import check, ptr, stream
+from .misc.optimizer import FlatArena, Optim  # noqa: F401
 from .parallel_exchange import GradientExchange
 
 
@@ -56,42 +57,18 @@ def xe_step(model, batch, t_run=None, inv_den=None, grads=None, return_seed=Fals
     return out[0], grads
 
 
-class FlatArena(object):
-    """All parameters of a module re-homed into one flat f32 tensor (plus same-layout grad / Adam arenas)."""
-
-    def __init__(self, module, names):
-        params = dict(module.named_parameters())
-        self.names = list(names)
-        self.offsets = {}
-        off = 0
-        for k in self.names:
-            self.offsets[k] = off
-            off += (params[k].numel() + 63) // 64 * 64          # 256-byte aligned blocks
-        dev = params[self.names[0]].device
-        self.numel = off
-        self.flat = torch.zeros(off, dtype=torch.float32, device=dev)
-        self.grad = torch.zeros(off, dtype=torch.float32, device=dev)
-        self.exp_avg = torch.zeros(off, dtype=torch.float32, device=dev)
-        self.exp_avg_sq = torch.zeros(off, dtype=torch.float32, device=dev)
-        self.grad_views = {}
-        for k in self.names:
-            p = params[k]
-            o, n = self.offsets[k], p.numel()
-            view = self.flat[o:o + n].view(p.shape)
-            view.copy_(p.data)
-            p.data = view
-            self.grad_views[k] = self.grad[o:o + n].view(p.shape)
-
-
 class Trainer(object):
-    """Captioner (i2t) half of the reference Trainer: build, one train step, save."""
+    """The reference Trainer's two halves: captioner (i2t: build, XE / self-critical step, save) and, after
+    `build_nmt`, the pivot NMT teacher (P/trainer.py:56-58: each half is built only when its flag asks for it)."""
 
     def __init__(self, opt, exchange=None):
         self.opt = opt
         self.i2t_train_flag = getattr(opt, 'i2t_train_flag', 1)
-        self.i2t_model = models.setup(opt)
+        self.i2t_model = models.setup(opt) if getattr(opt, 'caption_model', None) else None
         self.dp_i2t_model = self.i2t_model
-        self.i2t_model.train(bool(self.i2t_train_flag))
+        if self.i2t_model is not None:
+            self.i2t_model.train(bool(self.i2t_train_flag))
+        self.nmt_model = None
         self.i2t_train_loss = 0.0
         self.sc_flag = False
         self.exchange = exchange if exchange is not None else GradientExchange()
@@ -199,9 +176,56 @@ class Trainer(object):
         self.i2t_train_loss = loss.item()
         return self.i2t_train_loss
 
+    # ------------------------------------------------------------------ pivot NMT half (P/trainer.py:80-94,175-193)
+    def build_nmt(self, src_dict, tgt_dict):
+        """Trainer.build_nmt: encoder/decoder/NMTModel, the generator attached as `model.generator`, NMT_loss, and the
+        optimizer over the model's flat arena.  `src_dict` / `tgt_dict`: onmt.Dict-like (`.size()`) or plain sizes."""
+        import torch.nn as nn
+        from .models import NMT_Models
+        from .misc import criterion
+        opt = self.opt
+        tgt_size = int(tgt_dict.size()) if hasattr(tgt_dict, 'size') else int(tgt_dict)
+        self.nmt_encoder = NMT_Models.Encoder(opt, src_dict)
+        self.nmt_decoder = NMT_Models.Decoder(opt, tgt_dict)
+        self.nmt_model = NMT_Models.NMTModel(opt, self.nmt_encoder, self.nmt_decoder, src_dict, tgt_dict, False)
+        self.nmt_generator = nn.Sequential(nn.Linear(opt.rnn_size, tgt_size), nn.LogSoftmax(dim=-1))
+        param_init = getattr(opt, 'param_init', 0.1)
+        if param_init:
+            for p in list(self.nmt_model.parameters()) + list(self.nmt_generator.parameters()):
+                p.data.uniform_(-param_init, param_init)
+        self.nmt_model.generator = self.nmt_generator
+        self.dp_nmt_model = self.nmt_model
+        self.nmt_model.cuda()
+        self.nmt_model.train(bool(getattr(opt, 'nmt_train_flag', 1)))
+        self.nmt_loss = criterion.NMTCriterion(tgt_size, opt)
+        self.nmt_crit = criterion.NMT_loss(opt, self.nmt_generator, self.nmt_loss)
+        self.optim = Optim(opt, self.exchange)
+        self.optim.set_parameters(None, self.nmt_model)
+        self.nmt_train_ppl = self.nmt_train_acc = 0.0
+        return self.nmt_model
+
+    def train_nmt(self, nmt_batch, loader=None, nmt_epoch=None, update_lr=False):
+        """The NMT branch of Trainer.train (P/trainer.py:175-193): zero_grad, forward, NMT_loss, backward,
+        Optim.step (noam LR, clip_grad_norm, Adam).  Returns the summed NLL of the batch (host float)."""
+        if update_lr:
+            self.optim.update_LearningRate('nmt', nmt_epoch)
+        self.optim.zero_grad()
+        outputs, attn, dec_state, upper_bounds = self.dp_nmt_model(nmt_batch.src, nmt_batch.tgt, nmt_batch.lengths, None)
+        nmt_loss = self.nmt_crit(loader, nmt_batch, outputs, attn)
+        self.nmt_crit.report_stats.n_src_words += int(nmt_batch.lengths.sum())
+        self.nmt_train_ppl = self.nmt_crit.report_stats.ppl()
+        self.nmt_train_acc = self.nmt_crit.report_stats.accuracy()
+        nmt_loss.backward()
+        self.optim.step()
+        return float(nmt_loss.detach())
+
     def save_models(self, tag=''):
         """P/trainer.py:98-104: model_i2t[-best].pth = state_dict of the un-wrapped module."""
         path = self.opt.checkpoint_path
         os.makedirs(path, exist_ok=True)
-        torch.save({k: v.detach().cpu().clone() for k, v in self.i2t_model.state_dict().items()},
-                   os.path.join(path, 'model_i2t' + tag + '.pth'))
+        if self.i2t_model is not None:
+            torch.save({k: v.detach().cpu().clone() for k, v in self.i2t_model.state_dict().items()},
+                       os.path.join(path, 'model_i2t' + tag + '.pth'))
+        if getattr(self, 'nmt_model', None) is not None and getattr(self.opt, 'nmt_train_flag', 0):
+            torch.save({k: v.detach().cpu().clone() for k, v in self.nmt_model.state_dict().items()},
+                       os.path.join(path, 'model_nmt' + tag + '.pth'))
