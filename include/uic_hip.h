@@ -38,11 +38,16 @@ typedef struct uic_topdown_dims {
   int32_t T;        /* decode steps the workspace is sized for (labels.size(1) - 1) */
   int32_t dtype;    /* UIC_DTYPE_* */
   float drop_p;     /* drop_prob_lm; applied only when `training` is non-zero */
+  int32_t use_bn;   /* opt.use_bn (P/opts.py:52): 0 none, 1 BatchNorm1d(D) in front of att_embed's Linear, 2 also
+                     * BatchNorm1d(H) after its Dropout (P/models/AttModel.py:78-84) */
 } uic_topdown_dims;
 
-/* Master parameters (f32), one pointer per tensor of TopDownModel.state_dict() with use_bn = 0,
- * same order and shapes as the reference.  The same struct carries
- * the gradient pointers on the way back. */
+/* Master parameters (f32), one pointer per tensor of TopDownModel.state_dict(), same shapes as the reference
+ * (with use_bn >= 1 the Linear of att_embed sits at att_embed.1).  The same struct
+ * carries the gradient pointers on the way back (running statistics have no gradient: those pointers are ignored).
+ * `training` arguments below: bit 0 = train mode (dropout on, BatchNorm batch statistics); bit 1 = do NOT update the
+ * BatchNorm running statistics (the teacher-forced replay of a sampled caption in self-critical training re-runs
+ * the forward of an iteration whose sampling pass already updated them). */
 typedef struct uic_topdown_weights {
   float* embed_w;         /* embed.0.weight            [V1, E]        */
   float* fc_w;            /* fc_embed.0.weight         [H, Dfc]       */
@@ -65,6 +70,16 @@ typedef struct uic_topdown_weights {
   float* h2att_b;         /* core.attention.h2att.bias       [A]      */
   float* alpha_w;         /* core.attention.alpha_net.weight [1, A]   */
   float* alpha_b;         /* core.attention.alpha_net.bias   [1]      */
+  /* use_bn >= 1 (NULL otherwise): att_embed.0 = BatchNorm1d(D), updated in place by a training-mode forward */
+  float* att_bn0_w;       /* att_embed.0.weight        [D]            */
+  float* att_bn0_b;       /* att_embed.0.bias          [D]            */
+  float* att_bn0_rm;      /* att_embed.0.running_mean  [D]            */
+  float* att_bn0_rv;      /* att_embed.0.running_var   [D]            */
+  /* use_bn == 2 (NULL otherwise): att_embed.4 = BatchNorm1d(H) */
+  float* att_bn4_w;       /* att_embed.4.weight        [H]            */
+  float* att_bn4_b;       /* att_embed.4.bias          [H]            */
+  float* att_bn4_rm;      /* att_embed.4.running_mean  [H]            */
+  float* att_bn4_rv;      /* att_embed.4.running_var   [H]            */
 } uic_topdown_weights;
 
 /* The batch dict of DataLoader.get_batch as consumed at P/trainer.py:147-149 (device copies). */

@@ -19,7 +19,7 @@ SITE_FC, SITE_ATT, SITE_EMBED, SITE_OUT0 = 1, 2, 3, 16
 
 
 class Dims(C.Structure):
-    _fields_ = [(n, C.c_int32) for n in ("N", "R", "D", "Dfc", "H", "E", "A", "V1", "T", "dtype")] + [("drop_p", C.c_float)]
+    _fields_ = [(n, C.c_int32) for n in ("N", "R", "D", "Dfc", "H", "E", "A", "V1", "T", "dtype")] + [("drop_p", C.c_float), ("use_bn", C.c_int32)]
 
 
 WEIGHT_FIELDS = [
@@ -48,8 +48,32 @@ WEIGHT_FIELDS = [
 ]
 
 
+# BatchNorm1d tensors of att_embed with opt.use_bn >= 1 (att_embed.0) / == 2 (att_embed.4); (field, key, is_parameter)
+BN_FIELDS = [
+    ("att_bn0_w", "att_embed.0.weight", True), ("att_bn0_b", "att_embed.0.bias", True),
+    ("att_bn0_rm", "att_embed.0.running_mean", False), ("att_bn0_rv", "att_embed.0.running_var", False),
+    ("att_bn4_w", "att_embed.4.weight", True), ("att_bn4_b", "att_embed.4.bias", True),
+    ("att_bn4_rm", "att_embed.4.running_mean", False), ("att_bn4_rv", "att_embed.4.running_var", False),
+]
+
+
+def weight_fields(use_bn=0):
+    """[(struct field, reference state_dict key, is_parameter)] for opt.use_bn, parameters in named_parameters()
+    order.  With use_bn >= 1 the Linear of att_embed moves to index 1 (P/models/AttModel.py:78-84)."""
+    out = []
+    for f, k in WEIGHT_FIELDS:
+        if f == "att_w" and use_bn:
+            out += [b for b in BN_FIELDS[:4]]
+        if f in ("att_w", "att_b") and use_bn:
+            k = k.replace("att_embed.0.", "att_embed.1.")
+        out.append((f, k, True))
+        if f == "att_b" and use_bn == 2:
+            out += [b for b in BN_FIELDS[4:]]
+    return out
+
+
 class Weights(C.Structure):
-    _fields_ = [(f, C.c_void_p) for f, _ in WEIGHT_FIELDS]
+    _fields_ = [(f, C.c_void_p) for f, _ in WEIGHT_FIELDS] + [(f, C.c_void_p) for f, _, _ in BN_FIELDS]
 
 
 class FcDims(C.Structure):

@@ -22,6 +22,7 @@ struct Layout {
   // forward activations
   void* fcT; void* attT; int* row_len;
   void* fcp; void* attp; void* patt;
+  void* ybn; float* bn_stat0; float* bn_stat4; float* bn_part; float* bn_red;   // use_bn: pre-BN4 activations, {mean, rstd}, scratch
   void* xt_all; float* gx; float* gfc;
   void* h_att; void* h_lang; float* c_att; float* c_lang;   // [(T+1), N, H]
   void* gates1; void* gates2;
@@ -55,6 +56,14 @@ Layout make_layout(const uic_topdown_dims& d, void* ws) {
   L.fcp = b.take(N * H * S);
   L.attp = b.take(NR * H * S);
   L.patt = b.take(NR * A * S);
+  if (d.use_bn) {
+    L.bn_stat0 = (float*)b.take(2 * D * 4);
+    L.bn_stat4 = (float*)b.take(2 * H * 4);
+    const size_t p0 = uic_bn_scratch_floats((int)NR, (int)D), p4 = uic_bn_scratch_floats((int)NR, (int)H);
+    L.bn_part = (float*)b.take((p0 > p4 ? p0 : p4) * 4);
+    L.bn_red = (float*)b.take(3 * (D > H ? D : H) * 4);
+    if (d.use_bn == 2) L.ybn = b.take(NR * H * S);
+  }
   L.xt_all = b.take(M * E * S);
   L.gx = (float*)b.take(M * 4 * H * 4);
   L.gfc = (float*)b.take(N * 4 * H * 4);
@@ -145,6 +154,7 @@ struct Derived {
   void* wfcpT;       // [H, 4H]  = att_w_ih[:, H:2H]^T
   void* h2attT;      // [H, A]
   void* ctx2attT;    // [H, A]
+  float* att_beff;   // use_bn: b' = att_b + att_w bn0_beta  [H]  (att_w then points at W' = att_w diag(bn0_gamma))
   size_t total;
 };
 
@@ -160,7 +170,12 @@ Derived make_derived(const uic_topdown_dims& d, const uic_topdown_weights* w, vo
     return b.take(n * S);
   };
   v.fc_w = copy(w ? w->fc_w : nullptr, H * Dfc);
-  v.att_w = copy(w ? w->att_w : nullptr, H * D);
+  if (d.use_bn) {
+    v.att_w = b.take(H * D * S);
+    v.att_beff = (float*)b.take(H * 4);
+  } else {
+    v.att_w = copy(w ? w->att_w : nullptr, H * D);
+  }
   v.ctx2att_w = copy(w ? w->ctx2att_w : nullptr, A * H);
   v.logit_w = copy(w ? w->logit_w : nullptr, V1 * H);
   v.att_w_ih = copy(w ? w->att_lstm_w_ih : nullptr, 4 * H * (E + 2 * H));
@@ -186,8 +201,11 @@ int check_dims(const uic_topdown_dims* d) {
   UIC_REQUIRE(d->D % 8 == 0 && d->Dfc % 8 == 0 && d->H % 8 == 0 && d->E % 8 == 0 && d->A % 8 == 0,
               "D=%d Dfc=%d H=%d E=%d A=%d must all be multiples of 8", d->D, d->Dfc, d->H, d->E, d->A);
   UIC_REQUIRE(d->drop_p >= 0.f && d->drop_p < 1.f, "drop_p=%f outside [0,1)", (double)d->drop_p);
+  UIC_REQUIRE(d->use_bn >= 0 && d->use_bn <= 2, "use_bn=%d outside {0,1,2}", d->use_bn);
   return UIC_OK;
 }
+
+constexpr float BN_MOMENTUM = 0.1f, BN_EPS = 1e-5f;   // nn.BatchNorm1d defaults (AttModel.py:79,83)
 
 __global__ void rowlen_kernel(const float* mask, int N, int R, int* out) {
   const int n = blockIdx.x * blockDim.x + threadIdx.x;
@@ -199,23 +217,37 @@ __global__ void rowlen_kernel(const float* mask, int N, int R, int* out) {
 
 // _prepare_feature (P/models/AttModel.py:107-117) + operand casts
 int prepare_features(const uic_topdown_dims& d, const uic_topdown_weights* w, const Derived& dv, const uic_topdown_batch* b,
-                     const Layout& L, float drop_p, unsigned seed, const void** fc_in_out, const void** att_in_out, hipStream_t s) {
+                     const Layout& L, int training, float drop_p, unsigned seed, const void** fc_in_out, const void** att_in_out,
+                     hipStream_t s) {
   const int dt = d.dtype;
   const int N = d.N, R = d.R, H = d.H, A = d.A;
+  const bool bn_train = (training & 1) != 0, bn_update = bn_train && !(training & 2);
+  const int* row_len = b->att_masks ? L.row_len : nullptr;
   const void* fc_in = b->fc_feats;
   const void* att_in = b->att_feats;
-  if (dt == UIC_BF16) {
-    UIC_TRY(uic_cast_f32_launch(dt, b->fc_feats, L.fcT, (size_t)N * d.Dfc, s));
-    UIC_TRY(uic_cast_f32_launch(dt, b->att_feats, L.attT, (size_t)N * R * d.D, s));
-    fc_in = L.fcT;
-    att_in = L.attT;
-  }
-  *fc_in_out = fc_in;
-  *att_in_out = att_in;
   if (b->att_masks) {
     hipLaunchKernelGGL(rowlen_kernel, dim3((N + 255) / 256), dim3(256), 0, s, b->att_masks, N, R, L.row_len);
     UIC_LAUNCH_CHECK("rowlen_kernel");
   }
+  if (dt == UIC_BF16) {
+    UIC_TRY(uic_cast_f32_launch(dt, b->fc_feats, L.fcT, (size_t)N * d.Dfc, s));
+    fc_in = L.fcT;
+  }
+  if (d.use_bn) {
+    // BatchNorm1d(D) over the packed live regions; xhat goes to the GEMM, the affine part lives in W' / b'
+    if (bn_train)
+      UIC_TRY(uic_bn_stats_launch(UIC_F32, b->att_feats, N * R, R, d.D, row_len, L.bn_part, BN_MOMENTUM, BN_EPS, L.bn_stat0,
+                                  bn_update ? w->att_bn0_rm : nullptr, bn_update ? w->att_bn0_rv : nullptr, s));
+    else
+      UIC_TRY(uic_bn_stats_running_launch(w->att_bn0_rm, w->att_bn0_rv, d.D, BN_EPS, L.bn_stat0, s));
+    UIC_TRY(uic_bn_apply_launch(UIC_F32, dt, b->att_feats, N * R, R, d.D, row_len, L.bn_stat0, nullptr, nullptr, 0, L.attT, s));
+    att_in = L.attT;
+  } else if (dt == UIC_BF16) {
+    UIC_TRY(uic_cast_f32_launch(dt, b->att_feats, L.attT, (size_t)N * R * d.D, s));
+    att_in = L.attT;
+  }
+  *fc_in_out = fc_in;
+  *att_in_out = att_in;
   {
     UicGemmParams g = gemm_base(dt, N, H);
     add_seg(g, fc_in, d.Dfc, dv.fc_w, d.Dfc, d.Dfc);
@@ -226,10 +258,18 @@ int prepare_features(const uic_topdown_dims& d, const uic_topdown_weights* w, co
   {
     UicGemmParams g = gemm_base(dt, N * R, H);
     add_seg(g, att_in, d.D, dv.att_w, d.D, d.D);
-    g.C = L.attp; g.ldc = H; g.bias = w->att_b; g.flags = UIC_GEMM_RELU;
+    g.C = d.use_bn == 2 ? L.ybn : L.attp; g.ldc = H; g.bias = d.use_bn ? dv.att_beff : w->att_b; g.flags = UIC_GEMM_RELU;
     if (b->att_masks) { g.row_len = L.row_len; g.R = R; }
     g.drop_p = drop_p; g.seed = seed; g.site = UIC_SITE_ATT;
     UIC_TRY(uic_gemm_launch(g, s));
+  }
+  if (d.use_bn == 2) {   // BatchNorm1d(H) after the Dropout; padded regions stay zero (pad_unsort_packed_sequence)
+    if (bn_train)
+      UIC_TRY(uic_bn_stats_launch(dt, L.ybn, N * R, R, H, row_len, L.bn_part, BN_MOMENTUM, BN_EPS, L.bn_stat4,
+                                  bn_update ? w->att_bn4_rm : nullptr, bn_update ? w->att_bn4_rv : nullptr, s));
+    else
+      UIC_TRY(uic_bn_stats_running_launch(w->att_bn4_rm, w->att_bn4_rv, H, BN_EPS, L.bn_stat4, s));
+    UIC_TRY(uic_bn_apply_launch(dt, dt, L.ybn, N * R, R, H, row_len, L.bn_stat4, w->att_bn4_w, w->att_bn4_b, 1, L.attp, s));
   }
   {
     UicGemmParams g = gemm_base(dt, N * R, A);
@@ -292,7 +332,7 @@ int uic_topdown_refresh_weights(const uic_topdown_dims* d, const uic_topdown_wei
   const int V1p = (int)vpad(V1);
   if (dt == UIC_BF16) {
     UIC_TRY(uic_cast_f32_launch(dt, w->fc_w, (void*)v.fc_w, (size_t)H * Dfc, s));
-    UIC_TRY(uic_cast_f32_launch(dt, w->att_w, (void*)v.att_w, (size_t)H * D, s));
+    if (!d->use_bn) UIC_TRY(uic_cast_f32_launch(dt, w->att_w, (void*)v.att_w, (size_t)H * D, s));
     UIC_TRY(uic_cast_f32_launch(dt, w->ctx2att_w, (void*)v.ctx2att_w, (size_t)A * H, s));
     UIC_TRY(uic_cast_f32_launch(dt, w->logit_w, (void*)v.logit_w, (size_t)V1 * H, s));
     UIC_TRY(uic_cast_f32_launch(dt, w->att_lstm_w_ih, (void*)v.att_w_ih, (size_t)4 * H * (E + 2 * H), s));
@@ -300,6 +340,11 @@ int uic_topdown_refresh_weights(const uic_topdown_dims* d, const uic_topdown_wei
     UIC_TRY(uic_cast_f32_launch(dt, w->lang_lstm_w_ih, (void*)v.lang_w_ih, (size_t)4 * H * 2 * H, s));
     UIC_TRY(uic_cast_f32_launch(dt, w->lang_lstm_w_hh, (void*)v.lang_w_hh, (size_t)4 * H * H, s));
     UIC_TRY(uic_cast_f32_launch(dt, w->h2att_w, (void*)v.h2att_w, (size_t)A * H, s));
+  }
+  if (d->use_bn) {
+    UIC_REQUIRE(w->att_bn0_w && w->att_bn0_b && w->att_bn0_rm && w->att_bn0_rv, "use_bn=%d needs the att_embed.0 BatchNorm tensors", d->use_bn);
+    UIC_REQUIRE(d->use_bn < 2 || (w->att_bn4_w && w->att_bn4_b && w->att_bn4_rm && w->att_bn4_rv), "use_bn=2 needs the att_embed.4 BatchNorm tensors");
+    UIC_TRY(uic_bn_fold_weight_launch(dt, w->att_w, w->att_bn0_w, w->att_bn0_b, w->att_b, H, D, (void*)v.att_w, v.att_beff, s));
   }
   const int H4 = 4 * H, ldih = E + 2 * H;
   UIC_TRY(uic_transpose_launch(dt, v.logit_w, V1, H, H, v.logit_wT, V1p, s));
@@ -374,11 +419,12 @@ struct Step {
   size_t S, NH;
   float drop_p, inv_keep;
   unsigned seed;
+  int training;          // bit 0: train mode; bit 1: keep the BatchNorm running statistics untouched
   const void* fc_in;
   const void* att_in;
 
   void init(const uic_topdown_dims* d_, const uic_topdown_weights* w_, const void* derived, const uic_topdown_batch* b_,
-            int t_run_, int training, unsigned seed_, void* workspace, const uic_topdown_weights* G_) {
+            int t_run_, int training_, unsigned seed_, void* workspace, const uic_topdown_weights* G_) {
     d = *d_; w = w_; b = b_; G = G_;
     L = make_layout(d, workspace);
     dv = make_derived(d, w, (void*)derived);
@@ -386,17 +432,18 @@ struct Step {
     V1p = (int)vpad(V1); H4 = 4 * H; ldih = E + 2 * H; t_run = t_run_;
     Meff = t_run * N; Mp = (int)rup8(Meff); Np = (int)rup8(N); NR = N * R; NRp = (int)rup8(NR);
     S = uic_dtype_size(dt); NH = (size_t)N * H;
-    drop_p = training ? d.drop_p : 0.f;
+    training = training_;
+    drop_p = (training & 1) ? d.drop_p : 0.f;
     inv_keep = drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f;
     seed = seed_;
     fc_in = dt == UIC_BF16 ? L.fcT : (const void*)b->fc_feats;
-    att_in = dt == UIC_BF16 ? L.attT : (const void*)b->att_feats;
+    att_in = (dt == UIC_BF16 || d.use_bn) ? L.attT : (const void*)b->att_feats;
   }
 
   // ---------------------------------------------------------------- forward
   int fwd_prologue(hipStream_t s) {
     const void *f, *a;
-    UIC_TRY(prepare_features(d, w, dv, b, L, drop_p, seed, &f, &a, s));
+    UIC_TRY(prepare_features(d, w, dv, b, L, training, drop_p, seed, &f, &a, s));
     // xt_t = dropout(relu(embed[labels[:, t]])) for all steps (AttModel.py:145,160)
     UIC_TRY(uic_embed_fwd_launch(dt, w->embed_w, V1, E, b->labels, b->ld_labels, N, t_run, drop_p, seed, UIC_SITE_EMBED, 0, 1, L.xt_all, s));
     {  // Gx = xt W_ih[:, 2H:]^T + b_ih + b_hh, all steps
@@ -646,11 +693,23 @@ struct Step {
       UIC_TRY(uic_gemm_launch(g, s));
     }
     // att_embed (padded regions have att' = 0 -> zero gradient, as pack_wrapper never touched them)
-    UIC_TRY(uic_relu_mask_bwd_launch(dt, L.d_att, L.attp, inv_keep, L.d_pre, (size_t)NR * H, s));
+    const void* act = L.attp;
+    if (d.use_bn == 2) {   // through BatchNorm1d(H): d_att <- d y (in place), grads of its affine parameters
+      UIC_REQUIRE(G->att_bn4_w && G->att_bn4_b, "backward: use_bn=2 needs gradient tensors for att_embed.4");
+      UIC_TRY(uic_bn_bwd_launch(dt, L.d_att, L.ybn, NR, R, H, b->att_masks ? L.row_len : nullptr, L.bn_stat4, w->att_bn4_w,
+                                training & 1, L.bn_part, L.bn_red, G->att_bn4_w, G->att_bn4_b, s));
+      act = L.ybn;
+    }
+    UIC_TRY(uic_relu_mask_bwd_launch(dt, L.d_att, act, inv_keep, L.d_pre, (size_t)NR * H, s));
     UIC_TRY(uic_transpose_launch(dt, L.d_pre, NR, H, H, L.tA, NRp, s));
     UIC_TRY(uic_transpose_launch(dt, att_in, NR, D, D, L.tB, NRp, s));
     UIC_TRY(wgrad(L.tA, H, L.tB, D, NRp, G->att_w, D));
-    return uic_colsum_launch(dt, L.d_pre, NR, H, H, G->att_b, L.colscratch, L.colscratch_floats, s);
+    UIC_TRY(uic_colsum_launch(dt, L.d_pre, NR, H, H, G->att_b, L.colscratch, L.colscratch_floats, s));
+    if (d.use_bn) {        // G->att_w holds dW' = d_pre^T xhat: unfold the BatchNorm1d(D) affine part (batchnorm.hip)
+      UIC_REQUIRE(G->att_bn0_w && G->att_bn0_b, "backward: use_bn needs gradient tensors for att_embed.0");
+      UIC_TRY(uic_bn_fold_grad_launch(w->att_w, w->att_bn0_w, w->att_bn0_b, G->att_w, G->att_b, H, D, G->att_bn0_w, G->att_bn0_b, s));
+    }
+    return UIC_OK;
   }
 };
 
@@ -791,8 +850,8 @@ int uic_topdown_sample(const uic_topdown_dims* d, const uic_topdown_weights* w, 
   const size_t S = uic_dtype_size(dt);
   const size_t NH = (size_t)N * H;
   const void *fc_in, *att_in;
-  const float drop_p = training ? d->drop_p : 0.f;
-  UIC_TRY(prepare_features(*d, w, dv, b, L, drop_p, seed, &fc_in, &att_in, s));
+  const float drop_p = (training & 1) ? d->drop_p : 0.f;
+  UIC_TRY(prepare_features(*d, w, dv, b, L, training, drop_p, seed, &fc_in, &att_in, s));
   UIC_TRY(uic_fill_launch(L.s_h_att[0], 0, NH * S, s));
   UIC_TRY(uic_fill_launch(L.s_h_lang[0], 0, NH * S, s));
   UIC_TRY(uic_fill_launch(L.s_c_att[0], 0, NH * 4, s));

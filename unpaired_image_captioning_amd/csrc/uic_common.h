@@ -231,6 +231,23 @@ int uic_embed_bwd_launch(int dtype, const float* dxt, const void* xt, const int6
 // dst = (act > 0 ? scale : 0) * grad ; grad f32, act/dst operand dtype
 int uic_relu_mask_bwd_launch(int dtype, const float* grad, const void* act, float scale, void* dst, size_t n, hipStream_t s);
 
+// ---------------------------------------------------------------- BatchNorm1d of att_embed (batchnorm.hip)
+size_t uic_bn_scratch_floats(int NR, int C);
+// batch statistics over the live rows (row (n, r) live iff r < row_len[n]; all rows if row_len is null):
+// stat[0:C] = mean, stat[C:2C] = 1/sqrt(var + eps); running stats updated in place when non-null
+int uic_bn_stats_launch(int in_dtype, const void* x, int NR, int R, int C, const int* row_len, float* part, float momentum,
+                        float eps, float* stat, float* run_mean, float* run_var, hipStream_t s);
+int uic_bn_stats_running_launch(const float* run_mean, const float* run_var, int C, float eps, float* stat, hipStream_t s);
+int uic_bn_apply_launch(int in_dtype, int out_dtype, const void* x, int NR, int R, int C, const int* row_len, const float* stat,
+                        const float* gamma, const float* beta, int zero_padded, void* out, hipStream_t s);
+// d (f32, in place) <- gradient w.r.t. the BatchNorm input y; dgamma / dbeta out; red: 3C floats of scratch
+int uic_bn_bwd_launch(int dtype, float* d, const void* y, int NR, int R, int C, const int* row_len, const float* stat,
+                      const float* gamma, int training, float* part, float* red, float* dgamma, float* dbeta, hipStream_t s);
+int uic_bn_fold_weight_launch(int dtype, const float* W, const float* gamma, const float* beta, const float* b, int H, int D,
+                              void* Weff, float* beff, hipStream_t s);
+int uic_bn_fold_grad_launch(const float* W, const float* gamma, const float* beta, float* dW, const float* db, int H, int D,
+                            float* dgamma, float* dbeta, hipStream_t s);
+
 struct UicLstmBwdParams {
   int dtype, M, H;
   const float* dh0; int lddh0;   // up to three dh sources (null = absent)

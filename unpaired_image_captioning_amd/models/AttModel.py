@@ -100,7 +100,8 @@ class _TopDownSample(torch.autograd.Function):
         labels[:, 1:L + 1] = seq
         grads = {k: torch.empty_like(v) for k, v in pd.items()}
         # d loss / d logits = -g * (softmax - onehot)  ->  gradient weight of position (n, t) is -g[n, t]
-        eng.xe_train_step(pd, fc, att, att_masks, labels[:, :L + 1].contiguous(), None, L, training, seed, grads,
+        # bit 1: the sampling pass of this iteration already updated the BatchNorm running statistics
+        eng.xe_train_step(pd, fc, att, att_masks, labels[:, :L + 1].contiguous(), None, L, int(training) | 2, seed, grads,
                           grad_scale=(-g_lp).contiguous())
         return (None, None, None, None, None) + tuple(grads[k] for k in model.param_names)
 
@@ -119,9 +120,8 @@ class AttModel(CaptionModel):
         self.att_hid_size = opt.att_hid_size
         self.use_bn = getattr(opt, 'use_bn', 0)
         self.ss_prob = 0.0  # Schedule sampling probability
-        if self.use_bn:
-            raise NotImplementedError("use_bn=%d: BatchNorm in att_embed is not on the MI355X hot path yet "
-                                      "(BASELINE config 2 is measured with use_bn=0)" % self.use_bn)
+        if self.use_bn not in (0, 1, 2):
+            raise ValueError("use_bn=%r must be 0, 1 or 2" % (self.use_bn,))
         if getattr(opt, 'logit_layers', 1) != 1:
             raise NotImplementedError("logit_layers > 1 is not on the MI355X hot path")
         self.logit_layers = 1
@@ -132,9 +132,12 @@ class AttModel(CaptionModel):
         self.fc_embed = nn.Sequential(nn.Linear(self.fc_feat_size, self.rnn_size),
                                       nn.ReLU(),
                                       nn.Dropout(self.drop_prob_lm))
-        self.att_embed = nn.Sequential(nn.Linear(self.att_feat_size, self.rnn_size),
-                                       nn.ReLU(),
-                                       nn.Dropout(self.drop_prob_lm))
+        self.att_embed = nn.Sequential(*(
+            ((nn.BatchNorm1d(self.att_feat_size),) if self.use_bn else ()) +
+            (nn.Linear(self.att_feat_size, self.rnn_size),
+             nn.ReLU(),
+             nn.Dropout(self.drop_prob_lm)) +
+            ((nn.BatchNorm1d(self.rnn_size),) if self.use_bn == 2 else ())))
         self.logit = nn.Linear(self.rnn_size, self.vocab_size + 1)
         self.ctx2att = nn.Linear(self.rnn_size, self.att_hid_size)
 
@@ -149,12 +152,21 @@ class AttModel(CaptionModel):
         if self._engine is None:
             self._engine = TopDownEngine(dict(V1=self.vocab_size + 1, E=self.input_encoding_size, H=self.rnn_size,
                                               A=self.att_hid_size, D=self.att_feat_size, Dfc=self.fc_feat_size),
-                                         dtype=self.compute_dtype, drop_p=self.drop_prob_lm)
+                                         dtype=self.compute_dtype, drop_p=self.drop_prob_lm, use_bn=self.use_bn)
+        if self.use_bn:      # buffers may have been re-homed by .cuda()/.to(): always hand the live tensors over
+            self._engine.buffers = {k: v for k, v in self.named_buffers() if k.endswith(("running_mean", "running_var"))}
         return self._engine
 
     @property
     def param_names(self):
-        return [k for _, k in _lib.WEIGHT_FIELDS]
+        return [k for _, k, is_param in _lib.weight_fields(self.use_bn) if is_param]
+
+    def _bn_count_batch(self):
+        """num_batches_tracked += 1, as a train-mode nn.BatchNorm1d forward does."""
+        if self.use_bn and self.training:
+            for m in self.att_embed:
+                if isinstance(m, nn.BatchNorm1d):
+                    m.num_batches_tracked += 1
 
     def param_dict(self):
         sd = dict(self.named_parameters())
@@ -181,6 +193,7 @@ class AttModel(CaptionModel):
         if self.training and self.ss_prob > 0.0:
             raise NotImplementedError("scheduled sampling (ss_prob > 0) is not on the MI355X hot path yet")
         t_run = self._steps_to_run(seq)
+        self._bn_count_batch()
         fc = fc_feats.contiguous().float()
         att = att_feats.contiguous().float()
         am = att_masks.contiguous().float() if att_masks is not None else None
@@ -194,6 +207,7 @@ class AttModel(CaptionModel):
         decoding_constraint = opt.get('decoding_constraint', 0)
         if beam_size > 1:
             raise NotImplementedError("beam search (beam_size > 1) is a 'next' row of the hot-path scope")
+        self._bn_count_batch()
         fc = fc_feats.contiguous().float()
         att = att_feats.contiguous().float()
         am = att_masks.contiguous().float() if att_masks is not None else None

@@ -8,7 +8,7 @@ import ctypes as C
 import torch
 
 from . import _lib
-from ._lib import Batch, Dims, Weights, WEIGHT_FIELDS, check, ptr, stream
+from ._lib import Batch, Dims, Weights, check, ptr, stream, weight_fields
 
 
 class Workspace(object):
@@ -20,8 +20,11 @@ class Workspace(object):
 
 
 class TopDownEngine(object):
-    def __init__(self, sizes, dtype="bf16", drop_p=0.5):
-        """sizes: dict with V1, E, H, A, D, Dfc."""
+    def __init__(self, sizes, dtype="bf16", drop_p=0.5, use_bn=0):
+        """sizes: dict with V1, E, H, A, D, Dfc.  use_bn: opt.use_bn; the BatchNorm running statistics (buffers, not
+        parameters) are looked up in `self.buffers`, which the owning model keeps pointed at its live tensors."""
+        self.use_bn = int(use_bn)
+        self.buffers = {}
         self.lib = _lib.load()
         self.sizes = dict(sizes)
         self.dtype = _lib.dtype_id(dtype)
@@ -35,7 +38,7 @@ class TopDownEngine(object):
     def dims(self, N, R, T):
         s = self.sizes
         return Dims(N=N, R=R, D=s["D"], Dfc=s["Dfc"], H=s["H"], E=s["E"], A=s["A"], V1=s["V1"], T=T,
-                    dtype=self.dtype, drop_p=self.drop_p)
+                    dtype=self.dtype, drop_p=self.drop_p, use_bn=self.use_bn)
 
     @staticmethod
     def _key(d):
@@ -56,8 +59,12 @@ class TopDownEngine(object):
     def weights_struct(self, tensors):
         """tensors: dict reference-state_dict-key -> contiguous f32 device tensor."""
         w = Weights()
-        for field, key in WEIGHT_FIELDS:
-            t = tensors[key]
+        for field, key, is_param in weight_fields(self.use_bn):
+            t = tensors.get(key) if is_param else tensors.get(key, self.buffers.get(key))
+            if t is None:
+                if is_param:
+                    raise KeyError(key)
+                continue                      # gradient structs carry no running statistics
             if t.dtype != torch.float32:
                 raise RuntimeError("parameter %s must be float32, got %s" % (key, t.dtype))
             setattr(w, field, ptr(t))
