@@ -147,11 +147,17 @@ def logprobs_step(W: Weights, it: Tensor, fc, att, p_att, att_masks, state,
 
 def forward_logprobs(W: Weights, fc_feats: Tensor, att_feats: Tensor, seq: Tensor,
                      att_masks: Optional[Tensor] = None, drop=None, use_bn: int = 0,
-                     training: bool = False, return_aux: bool = False):
-    """AttModel._forward with ss_prob = 0, P/models/AttModel.py:119-156.
+                     training: bool = False, return_aux: bool = False, ss=None):
+    """AttModel._forward, P/models/AttModel.py:119-156.
 
     seq is labels [N, L+2]; returns log-probs [N, L+1, V1], zero-filled after the
     early break at the first all-zero label column i >= 1 (:148-151).
+
+    Scheduled sampling (:130-143, training mode and step i >= 1 only): ``ss = {'prob': p}`` draws exactly as the
+    reference does (``uniform_`` over the batch, then ``torch.multinomial`` of exp(previous log-probs) for EVERY row
+    whenever at least one row is selected), from torch's global CPU generator, so seeding it reproduces the
+    reference call for call.  ``ss = {'prob': p, 'mask': bool [T, N], 'tokens': int64 [N, T]}`` replays somebody
+    else's decisions and draws (the device's) instead.  The chosen inputs are returned in aux['inputs'].
     """
     N = fc_feats.shape[0]
     T = seq.shape[1] - 1
@@ -161,19 +167,34 @@ def forward_logprobs(W: Weights, fc_feats: Tensor, att_feats: Tensor, seq: Tenso
     state = (torch.zeros(2, N, H), torch.zeros(2, N, H))               # init_hidden :94-97
     outputs = []
     auxes = []
+    inputs = []
     for i in range(T):
+        it = seq[:, i].clone()
+        if training and i >= 1 and ss is not None and ss["prob"] > 0.0:  # :130-143
+            if "mask" in ss:
+                sample_mask = ss["mask"][i].bool()
+            else:
+                sample_mask = torch.empty(N).uniform_(0, 1) < ss["prob"]
+            if int(sample_mask.sum()) != 0:
+                sample_ind = sample_mask.nonzero().view(-1)
+                if "tokens" in ss:
+                    drawn = ss["tokens"][:, i]
+                else:
+                    drawn = torch.multinomial(torch.exp(outputs[-1].detach()), 1).view(-1)
+                it.index_copy_(0, sample_ind, drawn.index_select(0, sample_ind))
         if i >= 1 and int(seq[:, i].sum()) == 0:                       # :151
             break
         em = None if drop is None else drop["embed"][i]
         om = None if drop is None else drop["out"][i]
-        logp, state, aux = logprobs_step(W, seq[:, i], fc, att, p_att, masks, state, em, om)
+        logp, state, aux = logprobs_step(W, it, fc, att, p_att, masks, state, em, om)
         outputs.append(logp)
         auxes.append(aux)
+        inputs.append(it)
     out = torch.stack(outputs, 1)
     if out.shape[1] < T:
         out = torch.cat([out, torch.zeros(N, T - out.shape[1], V1)], 1)
     if return_aux:
-        return out, dict(fc=fc, att=att, p_att=p_att, steps=auxes)
+        return out, dict(fc=fc, att=att, p_att=p_att, steps=auxes, inputs=torch.stack(inputs, 1))
     return out
 
 
@@ -263,12 +284,12 @@ TRAINABLE_SKIP = ("running_mean", "running_var", "num_batches_tracked")
 
 
 def xe_loss_and_grads(W: Weights, fc_feats, att_feats, labels, masks, att_masks=None,
-                      drop=None, use_bn: int = 0, training: bool = True):
+                      drop=None, use_bn: int = 0, training: bool = True, ss=None):
     """One Trainer.train XE step up to backward(), P/trainer.py:164-165,172-173."""
     Wg = {k: (v.detach().clone().requires_grad_(True)
               if v.is_floating_point() and not k.endswith(TRAINABLE_SKIP) else v)
           for k, v in W.items()}
-    logp = forward_logprobs(Wg, fc_feats, att_feats, labels, att_masks, drop, use_bn, training)
+    logp = forward_logprobs(Wg, fc_feats, att_feats, labels, att_masks, drop, use_bn, training, ss=ss)
     loss = lm_criterion(logp, labels[:, 1:], masks[:, 1:])
     loss.backward()
     grads = {k: (v.grad if v.grad is not None else torch.zeros_like(v))

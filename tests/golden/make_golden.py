@@ -73,7 +73,7 @@ def synth(n_img, S, R, D, V, L, seed, ragged):
 
 def run_case(att_mod, crit_mod, name, V, E, H, A, D, L, n_img, S, R, seed, ragged=False,
              use_masks=True, use_bn=0, short_all=False, adam_steps=0, store_grads=True,
-             bn_train=False):
+             bn_train=False, ss_prob=0.0, ss_seed=0):
     torch.manual_seed(seed)
     opt = make_opt(V, E, H, A, D, L, use_bn=use_bn)
     model = att_mod.TopDownModel(opt)
@@ -137,6 +137,13 @@ def run_case(att_mod, crit_mod, name, V, E, H, A, D, L, n_img, S, R, seed, ragge
 
     # full teacher-forced forward through the reference's public call convention
     model.zero_grad()
+    if ss_prob > 0:
+        # scheduled sampling (AttModel.py:130-143): train mode, torch's CPU generator seeded right before the call, so
+        # the oracle can reproduce the reference's uniform_/multinomial draws call for call
+        model.train()
+        model.ss_prob = ss_prob
+        out["ss"] = np.array([ss_prob, ss_seed], dtype=np.float64)
+        torch.manual_seed(ss_seed)
     logp = model(fc, attri, att, labels, att_masks)                     # mode='forward'
     loss = crit(logp, labels[:, 1:], masks[:, 1:])
     loss.backward()
@@ -258,6 +265,7 @@ def main():
     run_case(att_mod, crit_mod, "topdown_tiny_earlybreak", seed=14, short_all=True, **tiny)
     run_case(att_mod, crit_mod, "topdown_tiny_bn1_eval", seed=15, use_bn=1, ragged=True, **tiny)
     run_case(att_mod, crit_mod, "topdown_tiny_bn2_train", seed=16, use_bn=2, ragged=True, bn_train=True, **tiny)
+    run_case(att_mod, crit_mod, "topdown_tiny_ss", seed=18, ragged=True, ss_prob=0.5, ss_seed=97, **tiny)
     # non-power-of-two / odd sizes (E != H != A, V1 not a tile multiple)
     run_case(att_mod, crit_mod, "topdown_odd", seed=17, V=77, E=24, H=40, A=48, D=72, L=5,
              n_img=2, S=3, R=7, ragged=True)

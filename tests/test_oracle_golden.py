@@ -125,3 +125,26 @@ def test_real_size_rows():
     seq, lp = O.sample(Wt, b["fc_feats"][idx], b["att_feats"][idx], b["att_masks"][idx], L)
     assert torch.equal(seq, Out["greedy_seq"])
     _close(lp, Out["greedy_logp"], 2e-5)
+
+
+def test_scheduled_sampling_matches_reference_draw_for_draw():
+    """ss_prob = 0.5 (AttModel.py:130-143): with torch's CPU generator seeded as the golden harness seeded it, the oracle's
+    uniform_/multinomial calls replay the reference's, so log-probs, loss and gradients must agree; and at least one
+    input token really was replaced by a sampled one."""
+    cfg, W, I, Out, G, X = load_golden("topdown_tiny_ss")
+    ss_prob, ss_seed = float(X["ss"][0]), int(X["ss"][1])
+    torch.manual_seed(ss_seed)
+    loss, grads, logp = O.xe_loss_and_grads(W, I["fc_feats"], I["att_feats"], I["labels"], I["masks"], I["att_masks"],
+                                            None, 0, True, ss={"prob": ss_prob})
+    _close(logp, Out["logprobs"], 1e-5)
+    assert abs(loss.item() - float(Out["loss"])) < 1e-5
+    for k in G:
+        _close(grads[k], G[k], 1e-5)
+    torch.manual_seed(ss_seed)
+    _, aux = O.forward_logprobs(W, I["fc_feats"], I["att_feats"], I["labels"], I["att_masks"], None, 0, True, True,
+                                ss={"prob": ss_prob})
+    used = aux["inputs"]
+    assert (used != I["labels"][:, :used.shape[1]]).any()
+    # teacher forcing (no ss) gives a different loss on this fixture
+    loss_tf, _, _ = O.xe_loss_and_grads(W, I["fc_feats"], I["att_feats"], I["labels"], I["masks"], I["att_masks"])
+    assert abs(loss_tf.item() - float(Out["loss"])) > 1e-4
