@@ -94,6 +94,10 @@ typedef struct uic_topdown_batch {
   const float* grad_scale;  /* optional [N, ld_grad_scale]: d loss / d logprob[n, t, labels[n, t+1]] given directly (column t),
                                replacing mask / sum(mask) -- the self-critical step (P/trainer.py:167-171) */
   int32_t ld_grad_scale;
+  float ss_prob;            /* scheduled-sampling probability (model.ss_prob, P/models/AttModel.py:130-143; applied in train
+                               mode at steps >= 1): with this probability a row's input token is replaced by a draw from
+                               exp(previous step's log-probs).  The inputs actually used stay in the workspace
+                               ("tok_used", [N, T] int64) for the backward pass and for the tests. 0 = teacher forcing. */
 } uic_topdown_batch;
 
 /* Sizes (bytes) of the two caller-allocated arenas. */
@@ -305,6 +309,8 @@ int uic_dropout_mask(float* out, size_t n, float p, uint32_t seed, uint32_t site
 #define UIC_SITE_ATT 2u
 #define UIC_SITE_EMBED 3u
 #define UIC_SITE_OUT0 16u   /* + decode step */
+#define UIC_SITE_SS_MASK0 512u  /* + decode step: row n is re-sampled iff u(seed, site, n) < ss_prob                  */
+#define UIC_SITE_SS_DRAW0 768u  /* + decode step: u(seed, site, n) drives the inverse-CDF draw of row n              */
 #define UIC_SITE_NMT_ENC0 1000u  /* + l: nn.LSTM dropout after encoder layer l, element (s*B + b)*H + j           */
 #define UIC_SITE_NMT_DEC0 2000u  /* + l*256 + t: StackedLSTM dropout after decoder layer l at step t, element b*H+j */
 #define UIC_SITE_NMT_OUT0 4000u  /* + t: Decoder.dropout on the attentional output of step t, element b*H + j      */

@@ -489,3 +489,112 @@ def test_use_bn_training_step_with_dropout_vs_oracle(use_bn, dtype):
     for k, v in before.items():
         assert torch.equal(model.state_dict()[k], v), k
     assert abs(out2[0].item() - loss.item()) < 1e-6
+
+
+# ---------------------------------------------------------------- scheduled sampling (AttModel.py:130-143)
+def _ss_run(model, batch, ss_prob, seed_counter):
+    """One fused training step with scheduled sampling; returns loss, grads, the inputs actually used [N, t_run], the
+    per-step selection mask [t_run, N] (from the kernels' own uniforms) and the dropout seed."""
+    from unpaired_image_captioning_amd import _lib as L
+    lib = L.load()
+    eng = model.engine
+    model._seed_counter = seed_counter
+    seed = model.next_seed()
+    pd = {k: v.detach() for k, v in model.param_dict().items()}
+    grads = {k: torch.empty_like(v) for k, v in pd.items()}
+    labels = batch["labels"]
+    N, T = labels.shape[0], labels.shape[1] - 1
+    t_run = model._steps_to_run(labels)
+    out, ws = eng.xe_train_step(pd, batch["fc_feats"], batch["att_feats"], batch.get("att_masks"), labels, batch["masks"],
+                                t_run, True, seed, grads, ss_prob=ss_prob, keep_workspace=True)
+    torch.cuda.synchronize()
+    used = eng.workspace_tensor(ws, "tok_used", (N, T), torch.int64)[:, :t_run].cpu().clone()
+    eng.release(ws)
+    sel = torch.zeros(t_run, N, dtype=torch.bool)
+    for t in range(1, t_run):
+        m = torch.empty(N, device="cuda")
+        L.check(lib.uic_dropout_mask(L.ptr(m), N, ss_prob, seed, L.SITE_SS_MASK0 + t, 0, L.stream()))
+        sel[t] = (m == 0).cpu()
+    return out[0], grads, used, sel, seed
+
+
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+def test_scheduled_sampling_step_vs_oracle(dtype):
+    cfg, W, I, Out, G, X = load_golden("topdown_tiny_ss")
+    ss_prob = float(X["ss"][0])
+    model = build_model(cfg, W, dtype)
+    model.train()
+    batch = {k: I[k].cuda() for k in ("fc_feats", "att_feats", "labels", "masks", "att_masks")}
+    loss, grads, used, sel, _ = _ss_run(model, batch, ss_prob, 1234)
+    labels = I["labels"]
+    t_run = used.shape[1]
+    assert torch.equal(used[:, 0], labels[:, 0])
+    keep = ~sel.t()
+    assert torch.equal(used[keep], labels[:, :t_run][keep])             # unselected rows are teacher-forced
+    assert sel[1:].any() and (used != labels[:, :t_run]).any()          # and some inputs really were re-sampled
+    assert int(used.max()) <= cfg["V"] and int(used.min()) >= 0
+    loss_o, grads_o, _ = O.xe_loss_and_grads(W, I["fc_feats"], I["att_feats"], labels, I["masks"], I["att_masks"], None, 0, True,
+                                             ss={"prob": ss_prob, "mask": sel, "tokens": used})
+    assert abs(loss.item() - loss_o.item()) < LOGP_TOL[dtype]
+    grads_close(grads, grads_o, GRAD_TOL[dtype])
+    assert abs(loss.item() - float(Out["loss"])) > 1e-5                 # different draws than the CPU golden's
+
+
+def test_scheduled_sampling_api_path_equals_fused_path_and_eval_ignores_it():
+    from unpaired_image_captioning_amd.misc.criterion import LanguageModelCriterion
+    cfg, W, I, Out, G, X = load_golden("topdown_tiny_ss")
+    model = build_model(cfg, W, "f32")
+    model.train()
+    model.ss_prob = 0.5
+    batch = {k: I[k].cuda() for k in ("fc_feats", "att_feats", "labels", "masks", "att_masks")}
+    loss_f, grads_f, used, sel, _ = _ss_run(model, batch, 0.5, 99)
+    model._seed_counter = 99
+    logp = model(batch["fc_feats"], None, batch["att_feats"], batch["labels"], batch["att_masks"])
+    loss = LanguageModelCriterion(make_opt(cfg, "f32"))(logp, batch["labels"][:, 1:], batch["masks"][:, 1:])
+    loss.backward()
+    assert abs(loss.item() - loss_f.item()) < 1e-5
+    for k, p in model.named_parameters():
+        assert (p.grad - grads_f[k]).abs().max().item() <= 1e-5 * max(1.0, grads_f[k].abs().max().item()), k
+    model.eval()                                                        # `self.training and ...` (:130)
+    with torch.no_grad():
+        lp_eval = model(batch["fc_feats"], None, batch["att_feats"], batch["labels"], batch["att_masks"])
+    model.ss_prob = 0.0
+    with torch.no_grad():
+        lp_tf = model(batch["fc_feats"], None, batch["att_feats"], batch["labels"], batch["att_masks"])
+    assert torch.equal(lp_eval, lp_tf)
+    assert absmax(lp_tf, Out["logprobs"]) > 1e-4                        # golden logprobs are the ss ones
+
+
+def test_scheduled_sampling_draw_statistics():
+    """Selection rate ~ ss_prob and the drawn tokens follow exp(previous log-probs): E[p(drawn)] = sum p^2."""
+    cfg = dict(V=40, E=32, H=32, A=32, D=64, L=8, n_img=100, S=3, R=4)
+    from unpaired_image_captioning_amd import models
+    torch.manual_seed(5)
+    model = models.setup(make_opt(cfg, "f32", seed=3))
+    with torch.no_grad():
+        model.logit.weight.mul_(60.0)                                   # peaky, row-dependent distributions
+    W = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    model.cuda().train()
+    b = O.synthetic_batch(cfg["n_img"], cfg["S"], cfg["R"], cfg["D"], cfg["V"], cfg["L"], seed=2)
+    batch = {k: v.cuda() for k, v in b.items()}
+    ss_prob = 0.4
+    loss, grads, used, sel, _ = _ss_run(model, batch, ss_prob, 7)
+    t_run = used.shape[1]
+    rate = sel[1:].float().mean().item()
+    n_dec = sel[1:].numel()
+    assert abs(rate - ss_prob) < 4 * (ss_prob * (1 - ss_prob) / n_dec) ** 0.5 + 1e-3, rate
+    # replay on the oracle to get every step's previous distribution
+    logp, aux = O.forward_logprobs(W, b["fc_feats"], b["att_feats"], b["labels"], b["att_masks"], None, 0, True, True,
+                                   ss={"prob": ss_prob, "mask": sel, "tokens": used})
+    got, want, var = 0.0, 0.0, 0.0
+    for t in range(1, t_run):
+        p = logp[:, t - 1].exp()[sel[t]]
+        drawn = used[:, t][sel[t]]
+        got += p.gather(1, drawn[:, None]).sum().item()
+        want += (p * p).sum().item()
+        var += ((p ** 3).sum(1) - (p * p).sum(1) ** 2).sum().item()
+    n = int(sel[1:].sum())
+    assert n > 500
+    assert abs(got - want) < 5 * var ** 0.5 + 1e-6, (got / n, want / n)
+    uniform_expect = 1.0 / (cfg["V"] + 1)
+    assert got / n > 2 * uniform_expect                                 # clearly not uniform draws

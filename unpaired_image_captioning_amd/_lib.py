@@ -16,6 +16,7 @@ DTYPE_IDS = {"f32": F32, "fp32": F32, "float32": F32, "bf16": BF16, "bfloat16": 
 TORCH_DTYPE = {F32: torch.float32, BF16: torch.bfloat16}
 
 SITE_FC, SITE_ATT, SITE_EMBED, SITE_OUT0 = 1, 2, 3, 16
+SITE_SS_MASK0, SITE_SS_DRAW0 = 512, 768          # + decode step
 
 
 class Dims(C.Structure):
@@ -146,7 +147,7 @@ class Batch(C.Structure):
     _fields_ = [("fc_feats", C.c_void_p), ("att_feats", C.c_void_p), ("att_masks", C.c_void_p),
                 ("labels", C.c_void_p), ("ld_labels", C.c_int32),
                 ("masks", C.c_void_p), ("ld_masks", C.c_int32),
-                ("grad_scale", C.c_void_p), ("ld_grad_scale", C.c_int32)]
+                ("grad_scale", C.c_void_p), ("ld_grad_scale", C.c_int32), ("ss_prob", C.c_float)]
 
 
 _SIGS = {

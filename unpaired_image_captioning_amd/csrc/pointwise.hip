@@ -1,6 +1,7 @@
 // HBM-bound helper kernels of the TopDown training / decoding path (gfx950).
 // Every kernel cites the reference lines whose arithmetic it carries.
 #include "uic_common.h"
+#include "../../include/uic_hip.h"
 
 namespace {
 
@@ -418,6 +419,58 @@ __global__ void adam_kernel(const UicAdamParams a) {
   }
 }
 
+// ------------------------------------------------------------------ scheduled sampling (AttModel.py:130-143)
+// One block per caption row: rows whose uniform falls under ss_prob take an inverse-CDF draw from
+// softmax(previous step's logits) (= exp(outputs[:, i-1]), torch.multinomial's distribution); the others keep seq[:, i].
+__global__ __launch_bounds__(NT) void ss_sample_kernel(const float* __restrict__ logits, int V1, int ldv,
+                                                       const int64_t* __restrict__ labels, int ld_labels, int t, float ss_prob,
+                                                       unsigned seed, int64_t* __restrict__ used, int ld_used) {
+  __shared__ float s_buf[NT / 64];
+  __shared__ float s_val[NT];
+  const int n = blockIdx.x;
+  if (!(uic_uniform(seed, UIC_SITE_SS_MASK0 + (unsigned)t, (unsigned)n) < ss_prob)) {
+    if (threadIdx.x == 0) used[(size_t)n * ld_used + t] = labels[(size_t)n * ld_labels + t];
+    return;
+  }
+  const float* row = logits + (size_t)n * ldv;
+  float mx = -INFINITY;
+  for (int v = threadIdx.x; v < V1; v += NT) mx = fmaxf(mx, row[v]);
+  mx = block_reduce_max(mx, s_buf);
+  const int per = (V1 + NT - 1) / NT;
+  const int v_lo = threadIdx.x * per, v_hi = min(V1, v_lo + per);
+  float part = 0.f;
+  for (int v = v_lo; v < v_hi; ++v) part += expf(row[v] - mx);
+  s_val[threadIdx.x] = part;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float tot = 0.f;
+    for (int i = 0; i < NT; ++i) tot += s_val[i];
+    const float target = uic_uniform(seed, UIC_SITE_SS_DRAW0 + (unsigned)t, (unsigned)n) * tot;
+    float cum = 0.f;
+    int seg = NT - 1;
+    for (int i = 0; i < NT; ++i) {
+      if (cum + s_val[i] > target) { seg = i; break; }
+      cum += s_val[i];
+    }
+    int pick = -1;
+    const int lo = seg * per, hi = min(V1, lo + per);
+    for (int v = lo; v < hi; ++v) {
+      const float pr = expf(row[v] - mx);
+      if (pr > 0.f) pick = v;
+      cum += pr;
+      if (cum > target && pr > 0.f) break;
+    }
+    if (pick < 0) pick = 0;
+    used[(size_t)n * ld_used + t] = pick;
+  }
+}
+__global__ void copy_tokens_kernel(const int64_t* __restrict__ src, int ld_src, int N, int T, int64_t* __restrict__ dst, int ld_dst) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= N * T) return;
+  const int n = i / T, t = i - n * T;
+  dst[(size_t)n * ld_dst + t] = src[(size_t)n * ld_src + t];
+}
+
 // ------------------------------------------------------------------ one decode step of AttModel._sample
 // (P/models/AttModel.py:216-251): log_softmax, optional decoding constraint, greedy max (lowest index on
 // ties) or multinomial draw, finished-row bookkeeping.  The reference's host-side early break
@@ -670,6 +723,20 @@ int uic_reduce_sum_launch(const float* x, size_t n, float unused, const float* s
   (void)unused;
   hipLaunchKernelGGL(reduce_sum_kernel, dim3(1), dim3(NT), 0, s, x, n, scale, out);
   UIC_LAUNCH_CHECK("reduce_sum");
+  return UIC_OK;
+}
+int uic_ss_sample_launch(const float* logits_prev, int N, int V1, int ldv, const int64_t* labels, int ld_labels, int t,
+                         float ss_prob, unsigned seed, int64_t* used, int ld_used, hipStream_t s) {
+  UIC_REQUIRE(logits_prev && labels && used && t >= 1 && t < 256, "ss_sample: bad arguments (t=%d)", t);
+  if (N == 0) return UIC_OK;
+  hipLaunchKernelGGL(ss_sample_kernel, dim3(N), dim3(NT), 0, s, logits_prev, V1, ldv, labels, ld_labels, t, ss_prob, seed, used, ld_used);
+  UIC_LAUNCH_CHECK("ss_sample");
+  return UIC_OK;
+}
+int uic_copy_tokens_launch(const int64_t* src, int ld_src, int N, int T, int64_t* dst, int ld_dst, hipStream_t s) {
+  if (N * T == 0) return UIC_OK;
+  hipLaunchKernelGGL(copy_tokens_kernel, dim3((N * T + NT - 1) / NT), dim3(NT), 0, s, src, ld_src, N, T, dst, ld_dst);
+  UIC_LAUNCH_CHECK("copy_tokens");
   return UIC_OK;
 }
 int uic_sqnorm_launch(const float* g, size_t n, float* scratch, float* out, hipStream_t s) {

@@ -24,6 +24,7 @@ struct Layout {
   void* fcp; void* attp; void* patt;
   void* ybn; float* bn_stat0; float* bn_stat4; float* bn_part; float* bn_red;   // use_bn: pre-BN4 activations, {mean, rstd}, scratch
   void* xt_all; float* gx; float* gfc;
+  int64_t* tok_used;   // [N, T] inputs actually fed to the embedding (differs from labels under scheduled sampling)
   void* h_att; void* h_lang; float* c_att; float* c_lang;   // [(T+1), N, H]
   void* gates1; void* gates2;
   float* atth_all; float* alpha_all; void* ctx_all; void* hdrop_all;
@@ -64,6 +65,7 @@ Layout make_layout(const uic_topdown_dims& d, void* ws) {
     L.bn_red = (float*)b.take(3 * (D > H ? D : H) * 4);
     if (d.use_bn == 2) L.ybn = b.take(NR * H * S);
   }
+  L.tok_used = (int64_t*)b.take(N * T * 8);
   L.xt_all = b.take(M * E * S);
   L.gx = (float*)b.take(M * 4 * H * 4);
   L.gfc = (float*)b.take(N * 4 * H * 4);
@@ -311,7 +313,7 @@ void* uic_topdown_workspace_ptr(const uic_topdown_dims* d, void* workspace, cons
   if (check_dims(d) || !workspace || !name) return nullptr;
   const Layout L = make_layout(*d, workspace);
   struct { const char* n; void* p; } tab[] = {
-      {"fc_embed", L.fcp}, {"att_embed", L.attp}, {"p_att", L.patt}, {"xt", L.xt_all}, {"gx", L.gx}, {"gfc", L.gfc},
+      {"tok_used", L.tok_used}, {"fc_embed", L.fcp}, {"att_embed", L.attp}, {"p_att", L.patt}, {"xt", L.xt_all}, {"gx", L.gx}, {"gfc", L.gfc},
       {"h_att", L.h_att}, {"h_lang", L.h_lang}, {"c_att", L.c_att}, {"c_lang", L.c_lang}, {"gates1", L.gates1},
       {"gates2", L.gates2}, {"att_h", L.atth_all}, {"alpha", L.alpha_all}, {"ctx", L.ctx_all}, {"hdrop", L.hdrop_all},
       {"logits", L.logits}, {"dlogits", L.dlogits}, {"row_loss", L.row_loss}, {"scalars", L.scalars},
@@ -440,6 +442,9 @@ struct Step {
     att_in = (dt == UIC_BF16 || d.use_bn) ? L.attT : (const void*)b->att_feats;
   }
 
+  // scheduled sampling (AttModel.py:130-143) is active in train mode only
+  bool ss_on() const { return (training & 1) && b->ss_prob > 0.f; }
+
   // ---------------------------------------------------------------- forward
   int fwd_prologue(hipStream_t s) {
     const void *f, *a;
@@ -458,6 +463,7 @@ struct Step {
       g.C = L.gfc; g.ldc = H4; g.flags = UIC_GEMM_OUT_F32;
       UIC_TRY(uic_gemm_launch(g, s));
     }
+    if (ss_on()) UIC_TRY(uic_copy_tokens_launch(b->labels, b->ld_labels, N, t_run, L.tok_used, d.T, s));
     UIC_TRY(uic_fill_launch(L.h_att, 0, NH * S, s));     // init_hidden (AttModel.py:94-97)
     UIC_TRY(uic_fill_launch(L.h_lang, 0, NH * S, s));
     UIC_TRY(uic_fill_launch(L.c_att, 0, NH * 4, s));
@@ -466,6 +472,18 @@ struct Step {
   }
 
   int fwd_step(int t, hipStream_t s) {
+    if (ss_on() && t >= 1) {
+      // choose this step's input tokens from the previous step's distribution, then redo the step's embedding row block
+      // and its slice of Gx (the prologue's teacher-forced values for the rows that keep their label are recomputed too)
+      UIC_TRY(uic_ss_sample_launch(L.logits + (size_t)(t - 1) * N * V1p, N, V1, V1p, b->labels, b->ld_labels, t, b->ss_prob, seed,
+                                   L.tok_used, d.T, s));
+      UIC_TRY(uic_embed_fwd_launch(dt, w->embed_w, V1, E, L.tok_used + t, d.T, N, 1, drop_p, seed, UIC_SITE_EMBED,
+                                   (size_t)t * N * E, 1, offw(L.xt_all, (size_t)t * N * E, dt), s));
+      UicGemmParams g = gemm_base(dt, N, H4);
+      add_seg(g, off(L.xt_all, (size_t)t * N * E, dt), E, off(dv.att_w_ih, 2 * H, dt), ldih, E);
+      g.C = L.gx + (size_t)t * N * H4; g.ldc = H4; g.bias = w->att_lstm_b_ih; g.bias2 = w->att_lstm_b_hh; g.flags = UIC_GEMM_OUT_F32;
+      UIC_TRY(uic_gemm_launch(g, s));
+    }
     const void* h_att_prev = off(L.h_att, t * NH, dt);
     void* h_att_new = offw(L.h_att, (t + 1) * NH, dt);
     const void* h_lang_prev = off(L.h_lang, t * NH, dt);
@@ -498,11 +516,16 @@ struct Step {
       g.gates_out = offw(L.gates2, (size_t)t * N * H4, dt);
       UIC_TRY(uic_gemm_launch(g, s));
     }
+    if (ss_on()) UIC_TRY(logits_rows_now(t, t + 1, s));   // the next step samples from this step's distribution
     return UIC_OK;
   }
 
-  // logits of decode steps [t0, t1) (AttModel.py:163)
+  // logits of decode steps [t0, t1) (AttModel.py:163); under scheduled sampling every step already produced its own
   int logits_rows(int t0, int t1, hipStream_t s) {
+    if (ss_on()) return UIC_OK;
+    return logits_rows_now(t0, t1, s);
+  }
+  int logits_rows_now(int t0, int t1, hipStream_t s) {
     UicGemmParams g = gemm_base(dt, (t1 - t0) * N, V1);
     add_seg(g, off(L.hdrop_all, t0 * NH, dt), H, dv.logit_w, H, H);
     g.C = L.logits + (size_t)t0 * N * V1p; g.ldc = V1p; g.bias = w->logit_b; g.flags = UIC_GEMM_OUT_F32;
@@ -645,7 +668,8 @@ struct Step {
       g.C = L.dxt; g.ldc = E; g.flags = UIC_GEMM_OUT_F32;
       UIC_TRY(uic_gemm_launch(g, s));
       UIC_TRY(uic_fill_launch(G->embed_w, 0, (size_t)V1 * E * 4, s));
-      UIC_TRY(uic_embed_bwd_launch(dt, L.dxt, L.xt_all, b->labels, b->ld_labels, N, t_run, V1, E, drop_p, -1, G->embed_w, s));
+      UIC_TRY(uic_embed_bwd_launch(dt, L.dxt, L.xt_all, ss_on() ? L.tok_used : b->labels, ss_on() ? d.T : b->ld_labels, N, t_run,
+                                   V1, E, drop_p, -1, G->embed_w, s));
     }
     // fc' path: dGfc = sum_t dG1_t
     UIC_TRY(uic_sum_steps_launch(dt, L.dg1_all, t_run, (size_t)N * H4, L.dgfc, s));

@@ -89,6 +89,12 @@ __device__ __forceinline__ float uic_drop_scale(unsigned seed, unsigned site, un
   return u < p ? 0.f : inv_keep;
 }
 
+__device__ __forceinline__ float uic_uniform(unsigned seed, unsigned site, unsigned idx) {
+  unsigned x = idx * 0x9E3779B1u ^ (seed + site * 0x85EBCA77u);
+  x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16;
+  return (float)(x >> 8) * (1.0f / 16777216.0f);
+}
+
 __device__ __forceinline__ float uic_sigmoid(float x) { return 1.f / (1.f + expf(-x)); }
 
 // tanh: exact libm form on the f32 path (parity), exp-based fast form on the bf16 path
@@ -230,6 +236,11 @@ int uic_embed_bwd_launch(int dtype, const float* dxt, const void* xt, const int6
                          int V1, int E, float drop_p, long skip_token, float* dtable, hipStream_t s);   // skip_token < 0: none (nn.Embedding padding_idx otherwise)
 // dst = (act > 0 ? scale : 0) * grad ; grad f32, act/dst operand dtype
 int uic_relu_mask_bwd_launch(int dtype, const float* grad, const void* act, float scale, void* dst, size_t n, hipStream_t s);
+
+// scheduled sampling (AttModel.py:130-143): used[n, t] = u_mask(n) < ss_prob ? draw from softmax(logits_prev[n]) : labels[n, t]
+int uic_ss_sample_launch(const float* logits_prev, int N, int V1, int ldv, const int64_t* labels, int ld_labels, int t,
+                         float ss_prob, unsigned seed, int64_t* used, int ld_used, hipStream_t s);
+int uic_copy_tokens_launch(const int64_t* src, int ld_src, int N, int T, int64_t* dst, int ld_dst, hipStream_t s);
 
 // ---------------------------------------------------------------- BatchNorm1d of att_embed (batchnorm.hip)
 size_t uic_bn_scratch_floats(int NR, int C);

@@ -43,10 +43,11 @@ class _TopDownForward(torch.autograd.Function):
         pd = dict(zip(names, params))
         seed = model.next_seed()
         training = model.training
-        logp, ws, (d, w, b) = eng.forward(pd, fc, att, att_masks, seq, t_run, training, seed, want_logprobs=True)
+        ss_prob = float(model.ss_prob) if training else 0.0          # AttModel.py:130
+        logp, ws, (d, w, b) = eng.forward(pd, fc, att, att_masks, seq, t_run, training, seed, want_logprobs=True, ss_prob=ss_prob)
         ctx.model = model
         ctx.ws = ws
-        ctx.call = (d, t_run, training, seed)
+        ctx.call = (d, t_run, training, seed, ss_prob)
         ctx.inputs = (fc, att, att_masks, seq)
         ctx.params = params
         ctx.save_for_backward(logp)
@@ -57,11 +58,11 @@ class _TopDownForward(torch.autograd.Function):
         model = ctx.model
         eng = model.engine
         (logp,) = ctx.saved_tensors
-        d, t_run, training, seed = ctx.call
+        d, t_run, training, seed, ss_prob = ctx.call
         fc, att, att_masks, seq = ctx.inputs
         pd = dict(zip(model.param_names, ctx.params))
         w = eng.refresh(pd, d)
-        b = eng.batch_struct(fc, att, att_masks, seq)
+        b = eng.batch_struct(fc, att, att_masks, seq, ss_prob=ss_prob)
         grads = {k: torch.empty_like(v) for k, v in pd.items()}
         eng.backward(ctx.ws, d, w, b, t_run, training, seed, grads, dlogprobs=g.contiguous(), logprobs=logp)
         eng.release(ctx.ws)
@@ -190,8 +191,6 @@ class AttModel(CaptionModel):
 
     # ------------------------------------------------------------------ reference call surface
     def _forward(self, fc_feats, attri_feats, att_feats, seq, att_masks=None):
-        if self.training and self.ss_prob > 0.0:
-            raise NotImplementedError("scheduled sampling (ss_prob > 0) is not on the MI355X hot path yet")
         t_run = self._steps_to_run(seq)
         self._bn_count_batch()
         fc = fc_feats.contiguous().float()

@@ -81,7 +81,7 @@ class TopDownEngine(object):
         return w
 
     @staticmethod
-    def batch_struct(fc, att, att_masks, labels=None, masks=None, grad_scale=None):
+    def batch_struct(fc, att, att_masks, labels=None, masks=None, grad_scale=None, ss_prob=0.0):
         b = Batch()
         b.fc_feats = ptr(fc)
         b.att_feats = ptr(att)
@@ -92,16 +92,17 @@ class TopDownEngine(object):
         b.ld_masks = masks.shape[1] if masks is not None else 0
         b.grad_scale = ptr(grad_scale)
         b.ld_grad_scale = grad_scale.shape[1] if grad_scale is not None else 0
+        b.ss_prob = float(ss_prob)
         return b
 
     # ------------------------------------------------------------------ calls
-    def forward(self, params, fc, att, att_masks, labels, t_run, training, seed, want_logprobs=True, masks=None):
+    def forward(self, params, fc, att, att_masks, labels, t_run, training, seed, want_logprobs=True, masks=None, ss_prob=0.0):
         N, R = att.shape[0], att.shape[1]
         T = labels.shape[1] - 1
         d = self.dims(N, R, T)
         w = self.refresh(params, d)
         ws = self.checkout(d, fc.device)
-        b = self.batch_struct(fc, att, att_masks, labels, masks)
+        b = self.batch_struct(fc, att, att_masks, labels, masks, ss_prob=ss_prob)
         logp = torch.zeros(N, T, d.V1, dtype=torch.float32, device=fc.device) if want_logprobs else None
         check(self.lib.uic_topdown_forward(C.byref(d), C.byref(w), ptr(self._derived), C.byref(b), t_run,
                                            int(training), seed & 0xFFFFFFFF, ptr(ws.buf), ptr(logp), stream()), "forward")
@@ -120,14 +121,14 @@ class TopDownEngine(object):
                                             stream()), "backward")
 
     def xe_train_step(self, params, fc, att, att_masks, labels, masks, t_run, training, seed, grads, inv_den=None,
-                      grad_scale=None):
+                      grad_scale=None, ss_prob=0.0, keep_workspace=False):
         """Fused forward + criterion + backward on two HIP streams; returns a device tensor [loss, sum(mask)]."""
         N, R = att.shape[0], att.shape[1]
         T = labels.shape[1] - 1
         d = self.dims(N, R, T)
         w = self.refresh(params, d)
         ws = self.checkout(d, fc.device)
-        b = self.batch_struct(fc, att, att_masks, labels, masks, grad_scale)
+        b = self.batch_struct(fc, att, att_masks, labels, masks, grad_scale, ss_prob)
         g = self.weights_struct(grads)
         out = torch.empty(2, dtype=torch.float32, device=fc.device)
         try:
@@ -136,7 +137,10 @@ class TopDownEngine(object):
                                                      out.data_ptr(), out.data_ptr() + 4, C.byref(g), stream()),
                   "xe_train_step")
         finally:
-            self.release(ws)
+            if not keep_workspace:
+                self.release(ws)
+        if keep_workspace:
+            return out, ws
         return out
 
     def sample(self, params, fc, att, att_masks, L, sample_max=1, temperature=1.0, decoding_constraint=0, seed=0,

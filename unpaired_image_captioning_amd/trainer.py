@@ -37,16 +37,19 @@ def xe_step(model, batch, t_run=None, inv_den=None, grads=None, return_seed=Fals
     pd = {k: v.detach() for k, v in model.param_dict().items()}
     seed = model.next_seed()
     training = model.training
+    ss_prob = float(getattr(model, 'ss_prob', 0.0)) if training else 0.0      # scheduled sampling, AttModel.py:130
+    if hasattr(model, '_bn_count_batch'):
+        model._bn_count_batch()
     if fused:
         if grads is None:
             grads = {k: torch.empty_like(v) for k, v in pd.items()}
         out = eng.xe_train_step(pd, batch["fc_feats"], batch["att_feats"], batch.get("att_masks"), labels, batch["masks"],
-                                t_run, training, seed, grads, inv_den)
+                                t_run, training, seed, grads, inv_den, ss_prob=ss_prob)
         if return_seed:
             return out[0], grads, seed
         return out[0], grads
     _, ws, (d, w, b) = eng.forward(pd, batch["fc_feats"], batch["att_feats"], batch.get("att_masks"), labels, t_run,
-                                   training, seed, want_logprobs=False, masks=batch["masks"])
+                                   training, seed, want_logprobs=False, masks=batch["masks"], ss_prob=ss_prob)
     out = eng.xe_loss(ws, d, b, t_run, inv_den)
     if grads is None:
         grads = {k: torch.empty_like(v) for k, v in pd.items()}
