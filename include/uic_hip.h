@@ -140,6 +140,12 @@ int uic_topdown_xe_train_step(const uic_topdown_dims* d, const uic_topdown_weigh
                               const uic_topdown_batch* batch, int32_t t_run, int32_t training, uint32_t seed,
                               void* workspace, const float* inv_den, float* loss_out, float* den_out,
                               const uic_topdown_weights* grads, void* stream);
+/* Data-parallel overlap: makes `stream` wait until the most recent uic_topdown_xe_train_step on the current device has
+ * FINAL gradients for every tensor except the late group {att_embed.*, ctx2att.*, core.attention.h2att.*,
+ * core.attention.alpha_net.*}, which that call is still computing on its own stream.  A caller that keeps the late
+ * group at the tail of its flat gradient arena can start the RCCL all-reduce of the head (> 85 % of the bytes) on
+ * `stream` right away; the tail follows on the step's stream.  Enqueue-only (hipStreamWaitEvent), no host sync. */
+int uic_topdown_grad_ready_wait(void* stream);
 
 /* AttModel._sample with beam_size = 1 (P/models/AttModel.py:198-253): greedy (sample_max = 1) or
  * multinomial decode of `L` <= d->T tokens.  seq [N, L] int64 and seq_logp [N, L] f32 are fully written.

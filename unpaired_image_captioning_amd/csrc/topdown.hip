@@ -372,6 +372,8 @@ constexpr int MAX_CHUNKS = 64;
 struct SideStream {
   hipStream_t stream = nullptr;
   hipEvent_t ev_den = nullptr, ev_done = nullptr;
+  hipEvent_t ev_early = nullptr;    // main: every gradient except the late group (see uic_topdown_grad_ready_wait) is final
+  bool early_recorded = false;
   hipEvent_t ev_main[MAX_CHUNKS];   // main  -> side: decode steps of chunk c are finished
   hipEvent_t ev_side[MAX_CHUNKS];   // side  -> main: d hdrop of chunk c is ready
   bool ready = false;
@@ -398,6 +400,7 @@ int get_side(SideStream** out) {
     }
     UIC_TRY(uic_check_hip(hipEventCreateWithFlags(&ss.ev_den, hipEventDisableTiming), "hipEventCreate"));
     UIC_TRY(uic_check_hip(hipEventCreateWithFlags(&ss.ev_done, hipEventDisableTiming), "hipEventCreate"));
+    UIC_TRY(uic_check_hip(hipEventCreateWithFlags(&ss.ev_early, hipEventDisableTiming), "hipEventCreate"));
     for (int i = 0; i < MAX_CHUNKS; ++i) {
       UIC_TRY(uic_check_hip(hipEventCreateWithFlags(&ss.ev_main[i], hipEventDisableTiming), "hipEventCreate"));
       UIC_TRY(uic_check_hip(hipEventCreateWithFlags(&ss.ev_side[i], hipEventDisableTiming), "hipEventCreate"));
@@ -634,8 +637,18 @@ struct Step {
     return UIC_OK;
   }
 
-  // weight gradients of everything except the logit layer, over all executed steps
+  // weight gradients of everything except the logit layer, over all executed steps; split in two so that a
+  // data-parallel caller can start exchanging the early group (LSTMs, embedding, fc_embed; with the logit layer
+  // > 85 % of the bytes) while the late group (h2att, alpha_net, ctx2att, att_embed) is still being computed
   int bwd_epilogue(hipStream_t s) {
+    UIC_TRY(bwd_epilogue_early(s));
+    return bwd_epilogue_late(s);
+  }
+  int wgrad1(const void* left, int lrows, const void* right, int rrows, int K, float* C, int ldc, hipStream_t s) {
+    const WDest d1{C, ldc, 0, rrows};
+    return wgrad_multi(L.slab, L.slab_bytes, dt, left, lrows, right, rrows, K, &d1, 1, s);
+  }
+  int bwd_epilogue_early(hipStream_t s) {
     auto wgrad = [&](const void* left, int lrows, const void* right, int rrows, int K, float* C, int ldc) -> int {
       const WDest d1{C, ldc, 0, rrows};
       return wgrad_multi(L.slab, L.slab_bytes, dt, left, lrows, right, rrows, K, &d1, 1, s);
@@ -687,6 +700,12 @@ struct Step {
     UIC_TRY(uic_transpose_launch(dt, fc_in, N, Dfc, Dfc, L.tB, Np, s));
     UIC_TRY(wgrad(L.tA, H, L.tB, Dfc, Np, G->fc_w, Dfc));
     UIC_TRY(uic_colsum_launch(dt, L.dfcpre, N, H, H, G->fc_b, L.colscratch, L.colscratch_floats, s));
+    return UIC_OK;
+  }
+  int bwd_epilogue_late(hipStream_t s) {
+    auto wgrad = [&](const void* left, int lrows, const void* right, int rrows, int K, float* C, int ldc) -> int {
+      return wgrad1(left, lrows, right, rrows, K, C, ldc, s);
+    };
     // h2att
     UIC_TRY(uic_transpose_launch(dt, L.datth_all, Meff, A, A, L.tA, Mp, s));
     UIC_TRY(uic_transpose_launch(dt, off(L.h_att, NH, dt), Meff, H, H, L.tB, Mp, s));
@@ -850,10 +869,20 @@ int uic_topdown_xe_train_step(const uic_topdown_dims* d, const uic_topdown_weigh
     UIC_HIP(hipStreamWaitEvent(s, ss->ev_side[c], 0));
     for (int t = t1 - 1; t >= t0; --t) UIC_TRY(st.bwd_step(t, s));
   }
-  UIC_TRY(st.bwd_epilogue(s));
-  UIC_HIP(hipStreamWaitEvent(s, ss->ev_done, 0));     // join
+  UIC_TRY(st.bwd_epilogue_early(s));
+  UIC_HIP(hipStreamWaitEvent(s, ss->ev_done, 0));     // join: logit-layer gradients and the loss are final
+  UIC_HIP(hipEventRecord(ss->ev_early, s));
+  ss->early_recorded = true;
+  UIC_TRY(st.bwd_epilogue_late(s));
 #undef UIC_HIP
   return UIC_OK;
+}
+
+int uic_topdown_grad_ready_wait(void* stream) {
+  SideStream* ss = nullptr;
+  UIC_TRY(get_side(&ss));
+  UIC_REQUIRE(ss->early_recorded, "grad_ready_wait: no uic_topdown_xe_train_step has run on this device yet");
+  return uic_check_hip(hipStreamWaitEvent((hipStream_t)stream, ss->ev_early, 0), "hipStreamWaitEvent");
 }
 
 int uic_topdown_sample(const uic_topdown_dims* d, const uic_topdown_weights* w, const void* derived,

@@ -37,6 +37,25 @@ class GradientExchange(object):
             dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group)
         return flat
 
+    def allreduce_sum_overlapped(self, flat, split, wait_early):
+        """Sum `flat` over ranks in two collectives: the head flat[:split] starts on a communication stream as soon as
+        `wait_early(raw_stream)` lets it (uic_topdown_grad_ready_wait: the step's early gradient group is final) and so
+        runs beside the rest of the backward pass; the tail follows on the current stream.  The current stream then
+        waits for the communication stream, so whatever is enqueued next (Adam) sees the summed gradients."""
+        if self.world_size == 1:
+            return flat
+        if not flat.is_cuda or split <= 0 or split >= flat.numel():
+            return self.allreduce_sum(flat)
+        if getattr(self, "_comm_stream", None) is None or self._comm_stream.device != flat.device:
+            self._comm_stream = torch.cuda.Stream(device=flat.device)
+        comm = self._comm_stream
+        wait_early(comm.cuda_stream)
+        with torch.cuda.stream(comm):
+            dist.all_reduce(flat[:split], op=dist.ReduceOp.SUM, group=self.group)
+        dist.all_reduce(flat[split:], op=dist.ReduceOp.SUM, group=self.group)
+        torch.cuda.current_stream(flat.device).wait_stream(comm)
+        return flat
+
     def allreduce_sum_scalar(self, x):
         if self.world_size > 1:
             x = x.clone()

@@ -87,9 +87,16 @@ class Trainer(object):
         self.arena = None
         self.last_loss = None
 
+    # gradients still being computed when uic_topdown_grad_ready_wait fires (include/uic_hip.h): kept at the arena's tail
+    LATE_GRADS = ("att_embed.", "ctx2att.", "core.attention.")
+
     def build_optimizer(self):
         self.i2t_model.cuda()
-        self.arena = FlatArena(self.i2t_model, self.i2t_model.param_names)
+        names = self.i2t_model.param_names
+        early = [k for k in names if not k.startswith(self.LATE_GRADS)]
+        late = [k for k in names if k.startswith(self.LATE_GRADS)]
+        self.arena = FlatArena(self.i2t_model, early + late)
+        self.arena_split = self.arena.offsets[late[0]] if late and early else 0
         self._step = 0
 
     def update_LearningRate(self, epoch):
@@ -123,7 +130,11 @@ class Trainer(object):
             self.build_optimizer()
         inv_den = self.exchange.global_inv_den(den_local, batch["fc_feats"].device)
         loss, _ = xe_step(self.i2t_model, batch, t_run=t_run, inv_den=inv_den, grads=self.arena.grad_views)
-        self.exchange.allreduce_sum(self.arena.grad)
+        if self.exchange.world_size > 1:
+            lib = _lib.load()
+            self.exchange.allreduce_sum_overlapped(
+                self.arena.grad, getattr(self, 'arena_split', 0) if hasattr(self.i2t_model, 'use_bn') else 0,
+                lambda raw: check(lib.uic_topdown_grad_ready_wait(raw), "grad_ready_wait"))
         self._step += 1
         a = self.arena
         check(_lib.load().uic_adam_step(ptr(a.flat), ptr(a.grad), ptr(a.exp_avg), ptr(a.exp_avg_sq), a.numel,
