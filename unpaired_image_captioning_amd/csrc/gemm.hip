@@ -18,6 +18,7 @@
 //    c' = s(f) c + s(i) tanh(g), h' = s(o) tanh(c') runs in the epilogue on registers.
 #include "uic_common.h"
 #include <type_traits>
+#include <stdlib.h>
 
 namespace {
 
@@ -28,7 +29,9 @@ typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
 // SAME output tile and are summed through LDS at the end.  The skinny per-decode-step GEMMs (M = 640)
 // are latency chains of K/BK dependent load->LDS->MFMA rounds; KS = 4 makes the chain 4x shorter and
 // puts 4x the bytes in flight per round.
-template <typename T, int TM, int TN, int WM, int WN, int KS, bool LSTM>
+// PF: K rounds kept in flight in registers (global -> VGPR) ahead of the round being multiplied.  With PF rounds
+// outstanding the chain is one load latency plus the LDS/MFMA rounds instead of one load latency PER round.
+template <typename T, int TM, int TN, int WM, int WN, int KS, bool LSTM, int PF>
 __global__ __launch_bounds__(64 * WM * WN * KS) void uic_gemm_kernel(const UicGemmParams p) {
   constexpr int NT = 64 * WM * WN * KS;
   constexpr int BM = 32 * TM * WM;
@@ -80,10 +83,10 @@ __global__ __launch_bounds__(64 * WM * WN * KS) void uic_gemm_kernel(const UicGe
   int ntiles = 0;
   for (int s = 0; s < p.nseg; ++s) ntiles += (p.seg[s].K + BK - 1) / BK;
 
-  uint4 ra[A_CH], rb[B_CH];
-  int seg = 0, k0 = 0;
+  uint4 rra[PF][A_CH], rrb[PF][B_CH];
+  int seg = 0, k0 = 0;        // K position of the NEXT round to load
 
-  auto load_tile = [&]() {
+  auto load_tile = [&](uint4* ra, uint4* rb) {
     const UicGemmSeg sg = p.seg[seg];
     const char* Ab = (const char*)sg.A;
     const char* Bb = (const char*)sg.B;
@@ -116,8 +119,10 @@ __global__ __launch_bounds__(64 * WM * WN * KS) void uic_gemm_kernel(const UicGe
       if (ok && k < sg.K) v = *(const uint4*)(Bb + ((size_t)grow * sg.ldb + k) * sizeof(T));
       rb[i] = v;
     }
+    k0 += BK;
+    if (k0 >= sg.K) { ++seg; k0 = 0; }
   };
-  auto store_tile = [&]() {
+  auto store_tile = [&](const uint4* ra, const uint4* rb) {
 #pragma unroll
     for (int i = 0; i < A_CH; ++i) {
       const int c = tid + i * NT;
@@ -132,15 +137,17 @@ __global__ __launch_bounds__(64 * WM * WN * KS) void uic_gemm_kernel(const UicGe
     }
   };
 
-  if (ntiles > 0) load_tile();
-  for (int it = 0; it < ntiles; ++it) {
-    store_tile();
+#pragma unroll
+  for (int j = 0; j < PF; ++j)
+    if (j < ntiles) load_tile(rra[j], rrb[j]);
+  for (int it0 = 0; it0 < ntiles; it0 += PF) {
+#pragma unroll
+  for (int j = 0; j < PF; ++j) {
+    const int it = it0 + j;
+    if (it >= ntiles) break;
+    store_tile(rra[j], rrb[j]);
     __syncthreads();
-    if (it + 1 < ntiles) {
-      k0 += BK;
-      if (k0 >= p.seg[seg].K) { ++seg; k0 = 0; }
-      load_tile();
-    }
+    if (it + PF < ntiles) load_tile(rra[j], rrb[j]);
     const char* pa = sA + (ks_id * BM + wm * 32 * TM + r32) * LDS_STRIDE + half * 64;
     const char* pb = sB + (ks_id * BN + wn * 32 * TN + r32) * LDS_STRIDE + half * 64;
 #pragma unroll
@@ -166,6 +173,7 @@ __global__ __launch_bounds__(64 * WM * WN * KS) void uic_gemm_kernel(const UicGe
         }
     }
     __syncthreads();
+  }
   }
 
   // ---- reduce-scatter over the KS wave groups: group q ends up with the complete sums of accumulator
@@ -550,7 +558,7 @@ int launch_glds(const UicGemmParams& p, hipStream_t s) {
   return UIC_OK;
 }
 
-template <typename T, int TM, int TN, int WM, int WN, int KS, bool LSTM>
+template <typename T, int TM, int TN, int WM, int WN, int KS, bool LSTM, int PF = 1>
 int launch_cfg(const UicGemmParams& p, hipStream_t s) {
   constexpr int BM = 32 * TM * WM, BN = 32 * TN * WN;
   constexpr int stage_bytes = KS * (BM + BN) * LDS_STRIDE;
@@ -559,12 +567,12 @@ int launch_cfg(const UicGemmParams& p, hipStream_t s) {
   static bool configured = false;
   if (!configured) {
     if (lds > 64 * 1024)
-      UIC_TRY(uic_check_hip(hipFuncSetAttribute((const void*)uic_gemm_kernel<T, TM, TN, WM, WN, KS, LSTM>,
+      UIC_TRY(uic_check_hip(hipFuncSetAttribute((const void*)uic_gemm_kernel<T, TM, TN, WM, WN, KS, LSTM, PF>,
                                                 hipFuncAttributeMaxDynamicSharedMemorySize, lds), "hipFuncSetAttribute(gemm)"));
     configured = true;
   }
   dim3 grid((p.M + BM - 1) / BM, LSTM ? (p.H + 32 * WN - 1) / (32 * WN) : (p.N + BN - 1) / BN);
-  hipLaunchKernelGGL((uic_gemm_kernel<T, TM, TN, WM, WN, KS, LSTM>), grid, dim3(64 * WM * WN * KS), lds, s, p);
+  hipLaunchKernelGGL((uic_gemm_kernel<T, TM, TN, WM, WN, KS, LSTM, PF>), grid, dim3(64 * WM * WN * KS), lds, s, p);
   UIC_LAUNCH_CHECK("uic_gemm_kernel");
   return UIC_OK;
 }
@@ -572,6 +580,8 @@ int launch_cfg(const UicGemmParams& p, hipStream_t s) {
 template <typename T>
 int launch_typed(const UicGemmParams& p, hipStream_t s) {
   // skinny problems (the per-decode-step GEMMs, M = rows of one step): 64-row tiles with a 4-way in-block K split
+  // PF (register prefetch depth) stays 1: measured on MI355X, PF = 2 / 4 do not shorten these launches (their time is
+  // launch + epilogue overhead plus ~0.9 us per K round, not exposed load latency) and PF = 4 slows the dX GEMMs.
   if (p.lstm == 2) return launch_cfg<T, 1, 5, 2, 1, 4, true>(p, s);
   if (p.lstm) return launch_cfg<T, 1, 4, 2, 1, 4, true>(p, s);
   const long blocks128 = (long)((p.M + 127) / 128) * ((p.N + 127) / 128);
@@ -589,7 +599,7 @@ int launch_typed(const UicGemmParams& p, hipStream_t s) {
 
 namespace {
 __global__ void splitk_reduce_kernel(const float* __restrict__ slab, int splitk, int M, int N, int col0, int ncols,
-                                     float* __restrict__ C, int ldc) {
+                                     float* __restrict__ C, int ldc, int accumulate) {
   const size_t total = (size_t)M * ncols;
   const size_t stride = (size_t)gridDim.x * blockDim.x;
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
@@ -597,16 +607,18 @@ __global__ void splitk_reduce_kernel(const float* __restrict__ slab, int splitk,
     const float* src = slab + (size_t)row * N + col0 + c;
     float v = 0.f;
     for (int z = 0; z < splitk; ++z) v += src[(size_t)z * M * N];
+    if (accumulate) v += C[(size_t)row * ldc + c];
     C[(size_t)row * ldc + c] = v;
   }
 }
 }  // namespace
 
-int uic_splitk_reduce_launch(const float* slab, int splitk, int M, int N, int col0, int ncols, float* C, int ldc, hipStream_t s) {
+int uic_splitk_reduce_launch(const float* slab, int splitk, int M, int N, int col0, int ncols, float* C, int ldc, hipStream_t s,
+                             int accumulate) {
   if (M == 0 || ncols == 0) return UIC_OK;
   size_t g = ((size_t)M * ncols + 255) / 256;
   if (g > 4096) g = 4096;
-  hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)g), dim3(256), 0, s, slab, splitk, M, N, col0, ncols, C, ldc);
+  hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)g), dim3(256), 0, s, slab, splitk, M, N, col0, ncols, C, ldc, accumulate);
   UIC_LAUNCH_CHECK("splitk_reduce");
   return UIC_OK;
 }

@@ -79,12 +79,19 @@ __global__ __launch_bounds__(NT) void colsum_stage1(const T* __restrict__ src, i
   __syncthreads();
   if (wave == 0 && c < cols) part[(size_t)rb * cols + c] = s_part[0][lane] + s_part[1][lane] + s_part[2][lane] + s_part[3][lane];
 }
+// stage 2: 64 columns per block; the 4 waves split the row-block partials (fixed order -> deterministic)
 __global__ __launch_bounds__(NT) void colsum_stage2(const float* __restrict__ part, int nrb, int cols, float* __restrict__ out) {
-  const int c = blockIdx.x * NT + threadIdx.x;
-  if (c >= cols) return;
+  __shared__ float s_part[4][64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + lane;
   float s = 0.f;
-  for (int rb = 0; rb < nrb; ++rb) s += part[(size_t)rb * cols + c];
-  out[c] = s;
+  if (c < cols) {
+#pragma unroll 4
+    for (int rb = wave; rb < nrb; rb += 4) s += part[(size_t)rb * cols + c];
+  }
+  s_part[wave][lane] = s;
+  __syncthreads();
+  if (wave == 0 && c < cols) out[c] = (s_part[0][lane] + s_part[1][lane]) + (s_part[2][lane] + s_part[3][lane]);
 }
 
 template <typename T>
@@ -623,7 +630,7 @@ int uic_colsum_launch(int src_dtype, const void* src, int rows, int cols, int ld
                       size_t scratch_floats, hipStream_t s) {
   if (cols == 0) return UIC_OK;
   int nrb = (rows + 63) / 64;
-  if (nrb > 128) nrb = 128;
+  if (nrb > 32) nrb = 32;
   if (nrb < 1) nrb = 1;
   while (nrb > 1 && (size_t)nrb * cols > scratch_floats) nrb /= 2;
   UIC_REQUIRE((size_t)nrb * cols <= scratch_floats, "colsum: scratch too small (%zu floats for %d cols)", scratch_floats, cols);
@@ -633,7 +640,7 @@ int uic_colsum_launch(int src_dtype, const void* src, int rows, int cols, int ld
              hipLaunchKernelGGL(colsum_stage1<bf16_t>, grid, dim3(NT), 0, s, (const bf16_t*)src, rows, cols, lds, rpb, scratch),
              hipLaunchKernelGGL(colsum_stage1<float>, grid, dim3(NT), 0, s, (const float*)src, rows, cols, lds, rpb, scratch));
   UIC_LAUNCH_CHECK("colsum_stage1");
-  hipLaunchKernelGGL(colsum_stage2, dim3((cols + NT - 1) / NT), dim3(NT), 0, s, scratch, nrb, cols, out);
+  hipLaunchKernelGGL(colsum_stage2, dim3((cols + 63) / 64), dim3(NT), 0, s, scratch, nrb, cols, out);
   UIC_LAUNCH_CHECK("colsum_stage2");
   return UIC_OK;
 }

@@ -18,6 +18,8 @@
 
 namespace {
 
+constexpr int WG_CHUNK = 4;   // decode steps per hand-off between the two streams of the fused training step
+
 struct Layout {
   // forward activations
   void* fcT; void* attT; int* row_len;
@@ -37,6 +39,7 @@ struct Layout {
   void* tA; void* tB; float* colscratch; size_t colscratch_floats; float* small;
   float* slab; size_t slab_bytes;
   void* tLA; void* tLB; float* colscratchL;   // scratch of the logit-layer weight gradients (side stream)
+  void* tSA; void* tSB; float* slab2;         // scratch of the per-chunk recurrent weight gradients (side stream)
   // sampling
   void* s_h_att[2]; void* s_h_lang[2]; float* s_c_att[2]; float* s_c_lang[2];
   void* s_xt; float* s_atth; float* s_alpha; void* s_ctx; void* s_hdrop; float* s_logits;
@@ -119,12 +122,18 @@ Layout make_layout(const uic_topdown_dims& d, void* ws) {
   L.tLA = b.take(V1 * Mp * S);
   L.tLB = b.take(H * Mp * S);
   L.colscratchL = (float*)b.take(L.colscratch_floats * 4);
+  {
+    const size_t Kc = rup8((size_t)WG_CHUNK * N);
+    L.tSA = b.take(4 * H * Kc * S);
+    L.tSB = b.take((2 * H + E) * Kc * S);
+  }
   {  // split-K partial slabs: room for 4 slices of the largest merged weight gradient [4H, 2H + E]
     size_t sl = 4 * (4 * H) * (2 * H + E) * 4;
     const size_t cap = (size_t)256 << 20;
     if (sl > cap) sl = cap;
     L.slab_bytes = sl;
     L.slab = (float*)b.take(sl);
+    L.slab2 = (float*)b.take(sl);
   }
   for (int i = 0; i < 2; ++i) {
     L.s_h_att[i] = b.take(N * H * S);
@@ -648,28 +657,62 @@ struct Step {
     const WDest d1{C, ldc, 0, rrows};
     return wgrad_multi(L.slab, L.slab_bytes, dt, left, lrows, right, rrows, K, &d1, 1, s);
   }
-  int bwd_epilogue_early(hipStream_t s) {
+  // recurrent weight gradients (both LSTMs' weights and h2att) restricted to decode steps [t0, t1): one chunk of the
+  // stacked-row GEMMs, accumulated into G unless `first`.  Used by the fused step on the side stream, chunk by chunk
+  // behind the BPTT loop, so that only the last chunk's share is left when the loop ends.
+  int wgrad_chunk(int t0, int t1, bool first, hipStream_t s) {
+    const int rows = (t1 - t0) * N, Kp = (int)rup8(rows);
+    const size_t r0 = (size_t)t0 * N;
+    // lang_lstm: dG2^T x [att_res | h_att | h_lang_prev]
+    UIC_TRY(uic_transpose_launch(dt, off(L.dg2_all, r0 * H4, dt), rows, H4, H4, L.tSA, Kp, s));
+    UIC_TRY(uic_transpose_launch(dt, off(L.ctx_all, r0 * H, dt), rows, H, H, L.tSB, Kp, s));
+    UIC_TRY(uic_transpose_launch(dt, off(L.h_att, NH + r0 * H, dt), rows, H, H, offw(L.tSB, (size_t)H * Kp, dt), Kp, s));
+    UIC_TRY(uic_transpose_launch(dt, off(L.h_lang, r0 * H, dt), rows, H, H, offw(L.tSB, (size_t)2 * H * Kp, dt), Kp, s));
+    {
+      const WDest dd[2] = {{G->lang_lstm_w_ih, 2 * H, 0, 2 * H}, {G->lang_lstm_w_hh, H, 2 * H, H}};
+      UIC_TRY(wgrad_multi(L.slab2, L.slab_bytes, dt, L.tSA, H4, L.tSB, 3 * H, Kp, dd, 2, s, !first));
+    }
+    // h2att: d_att_h^T x h_att   (tSB rows [H, 2H) still hold h_att^T)
+    UIC_TRY(uic_transpose_launch(dt, off(L.datth_all, r0 * A, dt), rows, A, A, L.tSA, Kp, s));
+    {
+      const WDest d1{G->h2att_w, H, 0, H};
+      UIC_TRY(wgrad_multi(L.slab2, L.slab_bytes, dt, L.tSA, A, off(L.tSB, (size_t)H * Kp, dt), H, Kp, &d1, 1, s, !first));
+    }
+    // att_lstm: dG1^T x [h_lang_prev | xt | h_att_prev]
+    UIC_TRY(uic_transpose_launch(dt, off(L.dg1_all, r0 * H4, dt), rows, H4, H4, L.tSA, Kp, s));
+    UIC_TRY(uic_transpose_launch(dt, off(L.h_lang, r0 * H, dt), rows, H, H, L.tSB, Kp, s));
+    UIC_TRY(uic_transpose_launch(dt, off(L.xt_all, r0 * E, dt), rows, E, E, offw(L.tSB, (size_t)H * Kp, dt), Kp, s));
+    UIC_TRY(uic_transpose_launch(dt, off(L.h_att, r0 * H, dt), rows, H, H, offw(L.tSB, (size_t)(H + E) * Kp, dt), Kp, s));
+    {
+      const WDest dd[3] = {{G->att_lstm_w_ih, ldih, 0, H}, {G->att_lstm_w_ih + 2 * H, ldih, H, E}, {G->att_lstm_w_hh, H, H + E, H}};
+      UIC_TRY(wgrad_multi(L.slab2, L.slab_bytes, dt, L.tSA, H4, L.tSB, 2 * H + E, Kp, dd, 3, s, !first));
+    }
+    return UIC_OK;
+  }
+
+  // chunked == true: wgrad_chunk already produced the LSTM / h2att weight gradients
+  int bwd_epilogue_early(hipStream_t s, bool chunked = false) {
     auto wgrad = [&](const void* left, int lrows, const void* right, int rrows, int K, float* C, int ldc) -> int {
       const WDest d1{C, ldc, 0, rrows};
       return wgrad_multi(L.slab, L.slab_bytes, dt, left, lrows, right, rrows, K, &d1, 1, s);
     };
     // per LSTM ONE GEMM dG^T [4H, T*N] x [stacked inputs]^T; lang_lstm inputs [att_res | h_att | h_lang_prev]
-    UIC_TRY(uic_transpose_launch(dt, L.dg2_all, Meff, H4, H4, L.tA, Mp, s));
-    UIC_TRY(uic_transpose_launch(dt, L.ctx_all, Meff, H, H, L.tB, Mp, s));
-    UIC_TRY(uic_transpose_launch(dt, off(L.h_att, NH, dt), Meff, H, H, offw(L.tB, (size_t)H * Mp, dt), Mp, s));
-    UIC_TRY(uic_transpose_launch(dt, L.h_lang, Meff, H, H, offw(L.tB, (size_t)2 * H * Mp, dt), Mp, s));
-    {
+    if (!chunked) {
+      UIC_TRY(uic_transpose_launch(dt, L.dg2_all, Meff, H4, H4, L.tA, Mp, s));
+      UIC_TRY(uic_transpose_launch(dt, L.ctx_all, Meff, H, H, L.tB, Mp, s));
+      UIC_TRY(uic_transpose_launch(dt, off(L.h_att, NH, dt), Meff, H, H, offw(L.tB, (size_t)H * Mp, dt), Mp, s));
+      UIC_TRY(uic_transpose_launch(dt, L.h_lang, Meff, H, H, offw(L.tB, (size_t)2 * H * Mp, dt), Mp, s));
       const WDest dd[2] = {{G->lang_lstm_w_ih, 2 * H, 0, 2 * H}, {G->lang_lstm_w_hh, H, 2 * H, H}};
       UIC_TRY(wgrad_multi(L.slab, L.slab_bytes, dt, L.tA, H4, L.tB, 3 * H, Mp, dd, 2, s));
     }
     UIC_TRY(uic_colsum_launch(dt, L.dg2_all, Meff, H4, H4, G->lang_lstm_b_ih, L.colscratch, L.colscratch_floats, s));
     UIC_TRY(uic_check_hip(hipMemcpyAsync(G->lang_lstm_b_hh, G->lang_lstm_b_ih, (size_t)H4 * 4, hipMemcpyDeviceToDevice, s), "memcpy b_hh"));
     // att_lstm inputs [h_lang_prev | xt | h_att_prev]  (the fc' columns are handled below from dGfc)
-    UIC_TRY(uic_transpose_launch(dt, L.dg1_all, Meff, H4, H4, L.tA, Mp, s));
-    UIC_TRY(uic_transpose_launch(dt, L.h_lang, Meff, H, H, L.tB, Mp, s));
-    UIC_TRY(uic_transpose_launch(dt, L.xt_all, Meff, E, E, offw(L.tB, (size_t)H * Mp, dt), Mp, s));
-    UIC_TRY(uic_transpose_launch(dt, L.h_att, Meff, H, H, offw(L.tB, (size_t)(H + E) * Mp, dt), Mp, s));
-    {
+    if (!chunked) {
+      UIC_TRY(uic_transpose_launch(dt, L.dg1_all, Meff, H4, H4, L.tA, Mp, s));
+      UIC_TRY(uic_transpose_launch(dt, L.h_lang, Meff, H, H, L.tB, Mp, s));
+      UIC_TRY(uic_transpose_launch(dt, L.xt_all, Meff, E, E, offw(L.tB, (size_t)H * Mp, dt), Mp, s));
+      UIC_TRY(uic_transpose_launch(dt, L.h_att, Meff, H, H, offw(L.tB, (size_t)(H + E) * Mp, dt), Mp, s));
       const WDest dd[3] = {{G->att_lstm_w_ih, ldih, 0, H}, {G->att_lstm_w_ih + 2 * H, ldih, H, E}, {G->att_lstm_w_hh, H, H + E, H}};
       UIC_TRY(wgrad_multi(L.slab, L.slab_bytes, dt, L.tA, H4, L.tB, 2 * H + E, Mp, dd, 3, s));
     }
@@ -702,14 +745,16 @@ struct Step {
     UIC_TRY(uic_colsum_launch(dt, L.dfcpre, N, H, H, G->fc_b, L.colscratch, L.colscratch_floats, s));
     return UIC_OK;
   }
-  int bwd_epilogue_late(hipStream_t s) {
+  int bwd_epilogue_late(hipStream_t s, bool chunked = false) {
     auto wgrad = [&](const void* left, int lrows, const void* right, int rrows, int K, float* C, int ldc) -> int {
       return wgrad1(left, lrows, right, rrows, K, C, ldc, s);
     };
     // h2att
-    UIC_TRY(uic_transpose_launch(dt, L.datth_all, Meff, A, A, L.tA, Mp, s));
-    UIC_TRY(uic_transpose_launch(dt, off(L.h_att, NH, dt), Meff, H, H, L.tB, Mp, s));
-    UIC_TRY(wgrad(L.tA, A, L.tB, H, Mp, G->h2att_w, H));
+    if (!chunked) {
+      UIC_TRY(uic_transpose_launch(dt, L.datth_all, Meff, A, A, L.tA, Mp, s));
+      UIC_TRY(uic_transpose_launch(dt, off(L.h_att, NH, dt), Meff, H, H, L.tB, Mp, s));
+      UIC_TRY(wgrad(L.tA, A, L.tB, H, Mp, G->h2att_w, H));
+    }
     UIC_TRY(uic_colsum_launch(dt, L.datth_all, Meff, A, A, G->h2att_b, L.colscratch, L.colscratch_floats, s));
     {  // attention: deferred accumulation over steps
       UicAttnAccumParams a;
@@ -835,7 +880,7 @@ int uic_topdown_xe_train_step(const uic_topdown_dims* d, const uic_topdown_weigh
   hipStream_t s2 = ss->stream;
   Step st;
   st.init(d, w, derived, b, t_run, training, seed, workspace, G);
-  const int CH = 4;                                   // decode steps per hand-off to the side stream
+  const int CH = WG_CHUNK;                            // decode steps per hand-off to the side stream
   const int nchunk = (t_run + CH - 1) / CH;
   UIC_REQUIRE(nchunk <= MAX_CHUNKS, "xe_train_step: too many decode steps (%d)", t_run);
 #define UIC_HIP(expr) UIC_TRY(uic_check_hip((expr), #expr))
@@ -861,19 +906,23 @@ int uic_topdown_xe_train_step(const uic_topdown_dims* d, const uic_topdown_weigh
   UIC_TRY(st.logit_weight_grads(s2));
   UIC_TRY(uic_reduce_sum_launch(st.L.row_loss, (size_t)t_run * d->N, 0.f, inv, loss_out, s2));
   if (den_out) UIC_HIP(hipMemcpyAsync(den_out, st.L.scalars, 4, hipMemcpyDeviceToDevice, s2));
-  UIC_HIP(hipEventRecord(ss->ev_done, s2));
-  // main: BPTT, each step waits for the d hdrop rows of its chunk
+  // main: BPTT, each step waits for the d hdrop rows of its chunk; side: the recurrent weight gradients of every
+  // finished chunk (transposes + accumulating GEMMs), so only the last chunk's share outlives the loop
   UIC_TRY(st.bwd_begin(s));
   for (int c = nchunk - 1; c >= 0; --c) {
     const int t0 = c * CH, t1 = t0 + CH < t_run ? t0 + CH : t_run;
     UIC_HIP(hipStreamWaitEvent(s, ss->ev_side[c], 0));
     for (int t = t1 - 1; t >= t0; --t) UIC_TRY(st.bwd_step(t, s));
+    UIC_HIP(hipEventRecord(ss->ev_main[c], s));       // (the forward's use of ev_main[c] was consumed long ago)
+    UIC_HIP(hipStreamWaitEvent(s2, ss->ev_main[c], 0));
+    UIC_TRY(st.wgrad_chunk(t0, t1, c == nchunk - 1, s2));
   }
-  UIC_TRY(st.bwd_epilogue_early(s));
-  UIC_HIP(hipStreamWaitEvent(s, ss->ev_done, 0));     // join: logit-layer gradients and the loss are final
+  UIC_HIP(hipEventRecord(ss->ev_done, s2));
+  UIC_TRY(st.bwd_epilogue_early(s, true));
+  UIC_HIP(hipStreamWaitEvent(s, ss->ev_done, 0));     // join: logit-layer + recurrent weight gradients, loss
   UIC_HIP(hipEventRecord(ss->ev_early, s));
   ss->early_recorded = true;
-  UIC_TRY(st.bwd_epilogue_late(s));
+  UIC_TRY(st.bwd_epilogue_late(s, true));
 #undef UIC_HIP
   return UIC_OK;
 }

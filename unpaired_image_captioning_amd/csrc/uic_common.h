@@ -180,7 +180,8 @@ struct UicGemmParams {
   int splitk; float* slab;
 };
 // C[row, c - col0] = sum_z slab[z][row, c] for c in [col0, col0 + ncols)
-int uic_splitk_reduce_launch(const float* slab, int splitk, int M, int N, int col0, int ncols, float* C, int ldc, hipStream_t s);
+int uic_splitk_reduce_launch(const float* slab, int splitk, int M, int N, int col0, int ncols, float* C, int ldc, hipStream_t s,
+                             int accumulate = 0);   // accumulate: C += sum_z slab[z]
 // true if the large-GEMM (LDS-DMA) path accepts this single-segment problem
 bool uic_gemm_glds_eligible(int dtype, int K);
 

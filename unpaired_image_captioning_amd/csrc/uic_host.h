@@ -41,7 +41,7 @@ inline void add_seg(UicGemmParams& g, const void* A, int lda, const void* B, int
 // LDS-DMA GEMM with deterministic slab reduction; anything else falls back to one direct GEMM per destination.
 struct WDest { float* C; int ldc; int col0; int ncols; };
 inline int wgrad_multi(float* slab, size_t slab_bytes, int dt, const void* left, int lrows, const void* right, int rrows, int K,
-                const WDest* dst, int nd, hipStream_t s) {
+                const WDest* dst, int nd, hipStream_t s, bool accumulate = false) {
   const long blocks = (long)((lrows + 127) / 128) * ((rrows + 127) / 128);
   if (uic_gemm_glds_eligible(dt, K) && lrows >= 128 && rrows >= 128) {
     const int nt = K / (dt == UIC_BF16 ? 64 : 32);
@@ -49,20 +49,20 @@ inline int wgrad_multi(float* slab, size_t slab_bytes, int dt, const void* left,
     if (sk > 8) sk = 8;
     if (sk > nt / 4) sk = nt / 4 > 0 ? nt / 4 : 1;
     while (sk > 1 && (size_t)sk * lrows * rrows * 4 > slab_bytes) --sk;
-    if ((size_t)sk * lrows * rrows * 4 <= slab_bytes && (sk > 1 || nd > 1)) {
+    if ((size_t)sk * lrows * rrows * 4 <= slab_bytes && (sk > 1 || nd > 1 || accumulate)) {
       UicGemmParams g = gemm_base(dt, lrows, rrows);
       add_seg(g, left, K, right, K, K);
       g.splitk = sk; g.slab = slab;
       UIC_TRY(uic_gemm_launch(g, s));
       for (int i = 0; i < nd; ++i)
-        UIC_TRY(uic_splitk_reduce_launch(slab, sk, lrows, rrows, dst[i].col0, dst[i].ncols, dst[i].C, dst[i].ldc, s));
+        UIC_TRY(uic_splitk_reduce_launch(slab, sk, lrows, rrows, dst[i].col0, dst[i].ncols, dst[i].C, dst[i].ldc, s, accumulate ? 1 : 0));
       return UIC_OK;
     }
   }
   for (int i = 0; i < nd; ++i) {
     UicGemmParams g = gemm_base(dt, lrows, dst[i].ncols);
     add_seg(g, left, K, (const char*)right + (size_t)dst[i].col0 * K * uic_dtype_size(dt), K, K);
-    g.C = dst[i].C; g.ldc = dst[i].ldc; g.flags = UIC_GEMM_OUT_F32;
+    g.C = dst[i].C; g.ldc = dst[i].ldc; g.flags = UIC_GEMM_OUT_F32 | (accumulate ? UIC_GEMM_ACCUM : 0);
     UIC_TRY(uic_gemm_launch(g, s));
   }
   return UIC_OK;
