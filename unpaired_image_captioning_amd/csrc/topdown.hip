@@ -40,6 +40,7 @@ struct Layout {
   float* slab; size_t slab_bytes;
   void* tLA; void* tLB; float* colscratchL;   // scratch of the logit-layer weight gradients (side stream)
   void* tSA; void* tSB; float* slab2;         // scratch of the per-chunk recurrent weight gradients (side stream)
+  void* attinT; void* attpT;                  // [D, NR^8], [H, NR^8]: transposed att_embed input / output, made once per step
   // sampling
   void* s_h_att[2]; void* s_h_lang[2]; float* s_c_att[2]; float* s_c_lang[2];
   void* s_xt; float* s_atth; float* s_alpha; void* s_ctx; void* s_hdrop; float* s_logits;
@@ -108,7 +109,7 @@ Layout make_layout(const uic_topdown_dims& d, void* ws) {
   if (A * NRp > ta) ta = A * NRp;
   if (H * NRp > ta) ta = H * NRp;
   if (4 * H * Np > ta) ta = 4 * H * Np;
-  size_t tb = (2 * H + E) * Mp;      // up to three stacked right operands of the merged LSTM weight-gradient GEMMs
+  size_t tb = (2 * H + (E > H ? E : H)) * Mp;   // three stacked right operands of the merged LSTM weight-gradient GEMMs
   if ((H > D ? H : D) * NRp > tb) tb = (H > D ? H : D) * NRp;
   if ((H > Dfc ? H : Dfc) * Np > tb) tb = (H > Dfc ? H : Dfc) * Np;
   L.tA = b.take(ta * S);
@@ -124,8 +125,13 @@ Layout make_layout(const uic_topdown_dims& d, void* ws) {
   L.colscratchL = (float*)b.take(L.colscratch_floats * 4);
   {
     const size_t Kc = rup8((size_t)WG_CHUNK * N);
+    size_t rb = 2 * H + E;                      // att_lstm inputs [h_lang | xt | h_att]; lang_lstm inputs are 3H wide
+    if (3 * H > rb) rb = 3 * H;
+    if (Dfc > rb) rb = Dfc;
     L.tSA = b.take(4 * H * Kc * S);
-    L.tSB = b.take((2 * H + E) * Kc * S);
+    L.tSB = b.take(rb * Kc * S);
+    L.attinT = b.take(D * NRp * S);
+    L.attpT = b.take(H * NRp * S);
   }
   {  // split-K partial slabs: room for 4 slices of the largest merged weight gradient [4H, 2H + E]
     size_t sl = 4 * (4 * H) * (2 * H + E) * 4;
@@ -322,7 +328,7 @@ void* uic_topdown_workspace_ptr(const uic_topdown_dims* d, void* workspace, cons
   if (check_dims(d) || !workspace || !name) return nullptr;
   const Layout L = make_layout(*d, workspace);
   struct { const char* n; void* p; } tab[] = {
-      {"tok_used", L.tok_used}, {"fc_embed", L.fcp}, {"att_embed", L.attp}, {"p_att", L.patt}, {"xt", L.xt_all}, {"gx", L.gx}, {"gfc", L.gfc},
+      {"tok_used", L.tok_used}, {"attinT", L.attinT}, {"attpT", L.attpT}, {"d_pre", L.d_pre}, {"fc_embed", L.fcp}, {"att_embed", L.attp}, {"p_att", L.patt}, {"xt", L.xt_all}, {"gx", L.gx}, {"gfc", L.gfc},
       {"h_att", L.h_att}, {"h_lang", L.h_lang}, {"c_att", L.c_att}, {"c_lang", L.c_lang}, {"gates1", L.gates1},
       {"gates2", L.gates2}, {"att_h", L.atth_all}, {"alpha", L.alpha_all}, {"ctx", L.ctx_all}, {"hdrop", L.hdrop_all},
       {"logits", L.logits}, {"dlogits", L.dlogits}, {"row_loss", L.row_loss}, {"scalars", L.scalars},
@@ -657,6 +663,12 @@ struct Step {
     const WDest d1{C, ldc, 0, rrows};
     return wgrad_multi(L.slab, L.slab_bytes, dt, left, lrows, right, rrows, K, &d1, 1, s);
   }
+  // transposes that depend on the feature projection only: done once, early, beside the recurrence (fused step)
+  int hoist_transposes(hipStream_t s) {
+    UIC_TRY(uic_transpose_launch(dt, L.attp, NR, H, H, L.attpT, NRp, s));
+    return uic_transpose_launch(dt, att_in, NR, D, D, L.attinT, NRp, s);
+  }
+
   // recurrent weight gradients (both LSTMs' weights and h2att) restricted to decode steps [t0, t1): one chunk of the
   // stacked-row GEMMs, accumulated into G unless `first`.  Used by the fused step on the side stream, chunk by chunk
   // behind the BPTT loop, so that only the last chunk's share is left when the loop ends.
@@ -691,32 +703,39 @@ struct Step {
   }
 
   // chunked == true: wgrad_chunk already produced the LSTM / h2att weight gradients
-  int bwd_epilogue_early(hipStream_t s, bool chunked = false) {
+  // side == true: runs on the fused step's side stream with that stream's own scratch buffers
+  int bwd_epilogue_early(hipStream_t s, bool chunked = false, bool side = false) {
+    void* const tA = side ? L.tSA : L.tA;
+    void* const tB = side ? L.tSB : L.tB;
+    float* const colscratch = side ? L.colscratchL : L.colscratch;
+    float* const slab = side ? L.slab2 : L.slab;
     auto wgrad = [&](const void* left, int lrows, const void* right, int rrows, int K, float* C, int ldc) -> int {
       const WDest d1{C, ldc, 0, rrows};
-      return wgrad_multi(L.slab, L.slab_bytes, dt, left, lrows, right, rrows, K, &d1, 1, s);
+      return wgrad_multi(slab, L.slab_bytes, dt, left, lrows, right, rrows, K, &d1, 1, s);
     };
+    if (chunked)   // h2att.bias belongs to the early group then (its weight came from wgrad_chunk)
+      UIC_TRY(uic_colsum_launch(dt, L.datth_all, Meff, A, A, G->h2att_b, colscratch, L.colscratch_floats, s));
     // per LSTM ONE GEMM dG^T [4H, T*N] x [stacked inputs]^T; lang_lstm inputs [att_res | h_att | h_lang_prev]
     if (!chunked) {
-      UIC_TRY(uic_transpose_launch(dt, L.dg2_all, Meff, H4, H4, L.tA, Mp, s));
-      UIC_TRY(uic_transpose_launch(dt, L.ctx_all, Meff, H, H, L.tB, Mp, s));
-      UIC_TRY(uic_transpose_launch(dt, off(L.h_att, NH, dt), Meff, H, H, offw(L.tB, (size_t)H * Mp, dt), Mp, s));
-      UIC_TRY(uic_transpose_launch(dt, L.h_lang, Meff, H, H, offw(L.tB, (size_t)2 * H * Mp, dt), Mp, s));
+      UIC_TRY(uic_transpose_launch(dt, L.dg2_all, Meff, H4, H4, tA, Mp, s));
+      UIC_TRY(uic_transpose_launch(dt, L.ctx_all, Meff, H, H, tB, Mp, s));
+      UIC_TRY(uic_transpose_launch(dt, off(L.h_att, NH, dt), Meff, H, H, offw(tB, (size_t)H * Mp, dt), Mp, s));
+      UIC_TRY(uic_transpose_launch(dt, L.h_lang, Meff, H, H, offw(tB, (size_t)2 * H * Mp, dt), Mp, s));
       const WDest dd[2] = {{G->lang_lstm_w_ih, 2 * H, 0, 2 * H}, {G->lang_lstm_w_hh, H, 2 * H, H}};
-      UIC_TRY(wgrad_multi(L.slab, L.slab_bytes, dt, L.tA, H4, L.tB, 3 * H, Mp, dd, 2, s));
+      UIC_TRY(wgrad_multi(slab, L.slab_bytes, dt, tA, H4, tB, 3 * H, Mp, dd, 2, s));
     }
-    UIC_TRY(uic_colsum_launch(dt, L.dg2_all, Meff, H4, H4, G->lang_lstm_b_ih, L.colscratch, L.colscratch_floats, s));
+    UIC_TRY(uic_colsum_launch(dt, L.dg2_all, Meff, H4, H4, G->lang_lstm_b_ih, colscratch, L.colscratch_floats, s));
     UIC_TRY(uic_check_hip(hipMemcpyAsync(G->lang_lstm_b_hh, G->lang_lstm_b_ih, (size_t)H4 * 4, hipMemcpyDeviceToDevice, s), "memcpy b_hh"));
     // att_lstm inputs [h_lang_prev | xt | h_att_prev]  (the fc' columns are handled below from dGfc)
     if (!chunked) {
-      UIC_TRY(uic_transpose_launch(dt, L.dg1_all, Meff, H4, H4, L.tA, Mp, s));
-      UIC_TRY(uic_transpose_launch(dt, L.h_lang, Meff, H, H, L.tB, Mp, s));
-      UIC_TRY(uic_transpose_launch(dt, L.xt_all, Meff, E, E, offw(L.tB, (size_t)H * Mp, dt), Mp, s));
-      UIC_TRY(uic_transpose_launch(dt, L.h_att, Meff, H, H, offw(L.tB, (size_t)(H + E) * Mp, dt), Mp, s));
+      UIC_TRY(uic_transpose_launch(dt, L.dg1_all, Meff, H4, H4, tA, Mp, s));
+      UIC_TRY(uic_transpose_launch(dt, L.h_lang, Meff, H, H, tB, Mp, s));
+      UIC_TRY(uic_transpose_launch(dt, L.xt_all, Meff, E, E, offw(tB, (size_t)H * Mp, dt), Mp, s));
+      UIC_TRY(uic_transpose_launch(dt, L.h_att, Meff, H, H, offw(tB, (size_t)(H + E) * Mp, dt), Mp, s));
       const WDest dd[3] = {{G->att_lstm_w_ih, ldih, 0, H}, {G->att_lstm_w_ih + 2 * H, ldih, H, E}, {G->att_lstm_w_hh, H, H + E, H}};
-      UIC_TRY(wgrad_multi(L.slab, L.slab_bytes, dt, L.tA, H4, L.tB, 2 * H + E, Mp, dd, 3, s));
+      UIC_TRY(wgrad_multi(slab, L.slab_bytes, dt, tA, H4, tB, 2 * H + E, Mp, dd, 3, s));
     }
-    UIC_TRY(uic_colsum_launch(dt, L.dg1_all, Meff, H4, H4, G->att_lstm_b_ih, L.colscratch, L.colscratch_floats, s));
+    UIC_TRY(uic_colsum_launch(dt, L.dg1_all, Meff, H4, H4, G->att_lstm_b_ih, colscratch, L.colscratch_floats, s));
     UIC_TRY(uic_check_hip(hipMemcpyAsync(G->att_lstm_b_hh, G->att_lstm_b_ih, (size_t)H4 * 4, hipMemcpyDeviceToDevice, s), "memcpy b_hh"));
     {  // d xt -> embedding table
       UicGemmParams g = gemm_base(dt, Meff, E);
@@ -729,9 +748,9 @@ struct Step {
     }
     // fc' path: dGfc = sum_t dG1_t
     UIC_TRY(uic_sum_steps_launch(dt, L.dg1_all, t_run, (size_t)N * H4, L.dgfc, s));
-    UIC_TRY(uic_transpose_launch(dt, L.dgfc, N, H4, H4, L.tA, Np, s));
-    UIC_TRY(uic_transpose_launch(dt, L.fcp, N, H, H, L.tB, Np, s));
-    UIC_TRY(wgrad(L.tA, H4, L.tB, H, Np, G->att_lstm_w_ih + H, ldih));
+    UIC_TRY(uic_transpose_launch(dt, L.dgfc, N, H4, H4, tA, Np, s));
+    UIC_TRY(uic_transpose_launch(dt, L.fcp, N, H, H, tB, Np, s));
+    UIC_TRY(wgrad(tA, H4, tB, H, Np, G->att_lstm_w_ih + H, ldih));
     {
       UicGemmParams g = gemm_base(dt, N, H);
       add_seg(g, L.dgfc, H4, dv.wfcpT, H4, H4);
@@ -739,10 +758,10 @@ struct Step {
       UIC_TRY(uic_gemm_launch(g, s));
     }
     UIC_TRY(uic_relu_mask_bwd_launch(dt, L.dfcp, L.fcp, inv_keep, L.dfcpre, NH, s));
-    UIC_TRY(uic_transpose_launch(dt, L.dfcpre, N, H, H, L.tA, Np, s));
-    UIC_TRY(uic_transpose_launch(dt, fc_in, N, Dfc, Dfc, L.tB, Np, s));
-    UIC_TRY(wgrad(L.tA, H, L.tB, Dfc, Np, G->fc_w, Dfc));
-    UIC_TRY(uic_colsum_launch(dt, L.dfcpre, N, H, H, G->fc_b, L.colscratch, L.colscratch_floats, s));
+    UIC_TRY(uic_transpose_launch(dt, L.dfcpre, N, H, H, tA, Np, s));
+    UIC_TRY(uic_transpose_launch(dt, fc_in, N, Dfc, Dfc, tB, Np, s));
+    UIC_TRY(wgrad(tA, H, tB, Dfc, Np, G->fc_w, Dfc));
+    UIC_TRY(uic_colsum_launch(dt, L.dfcpre, N, H, H, G->fc_b, colscratch, L.colscratch_floats, s));
     return UIC_OK;
   }
   int bwd_epilogue_late(hipStream_t s, bool chunked = false) {
@@ -754,8 +773,8 @@ struct Step {
       UIC_TRY(uic_transpose_launch(dt, L.datth_all, Meff, A, A, L.tA, Mp, s));
       UIC_TRY(uic_transpose_launch(dt, off(L.h_att, NH, dt), Meff, H, H, L.tB, Mp, s));
       UIC_TRY(wgrad(L.tA, A, L.tB, H, Mp, G->h2att_w, H));
+      UIC_TRY(uic_colsum_launch(dt, L.datth_all, Meff, A, A, G->h2att_b, L.colscratch, L.colscratch_floats, s));
     }
-    UIC_TRY(uic_colsum_launch(dt, L.datth_all, Meff, A, A, G->h2att_b, L.colscratch, L.colscratch_floats, s));
     {  // attention: deferred accumulation over steps
       UicAttnAccumParams a;
       memset(&a, 0, sizeof(a));
@@ -771,8 +790,8 @@ struct Step {
     }
     // ctx2att
     UIC_TRY(uic_transpose_launch(dt, L.d_patt, NR, A, A, L.tA, NRp, s));
-    UIC_TRY(uic_transpose_launch(dt, L.attp, NR, H, H, L.tB, NRp, s));
-    UIC_TRY(wgrad(L.tA, A, L.tB, H, NRp, G->ctx2att_w, H));
+    if (!chunked) UIC_TRY(uic_transpose_launch(dt, L.attp, NR, H, H, L.attpT, NRp, s));   // fused step: hoisted
+    UIC_TRY(wgrad(L.tA, A, L.attpT, H, NRp, G->ctx2att_w, H));
     UIC_TRY(uic_colsum_launch(dt, L.d_patt, NR, A, A, G->ctx2att_b, L.colscratch, L.colscratch_floats, s));
     {
       UicGemmParams g = gemm_base(dt, NR, H);
@@ -790,8 +809,8 @@ struct Step {
     }
     UIC_TRY(uic_relu_mask_bwd_launch(dt, L.d_att, act, inv_keep, L.d_pre, (size_t)NR * H, s));
     UIC_TRY(uic_transpose_launch(dt, L.d_pre, NR, H, H, L.tA, NRp, s));
-    UIC_TRY(uic_transpose_launch(dt, att_in, NR, D, D, L.tB, NRp, s));
-    UIC_TRY(wgrad(L.tA, H, L.tB, D, NRp, G->att_w, D));
+    if (!chunked) UIC_TRY(uic_transpose_launch(dt, att_in, NR, D, D, L.attinT, NRp, s));    // fused step: hoisted
+    UIC_TRY(wgrad(L.tA, H, L.attinT, D, NRp, G->att_w, D));
     UIC_TRY(uic_colsum_launch(dt, L.d_pre, NR, H, H, G->att_b, L.colscratch, L.colscratch_floats, s));
     if (d.use_bn) {        // G->att_w holds dW' = d_pre^T xhat: unfold the BatchNorm1d(D) affine part (batchnorm.hip)
       UIC_REQUIRE(G->att_bn0_w && G->att_bn0_b, "backward: use_bn needs gradient tensors for att_embed.0");
@@ -891,6 +910,9 @@ int uic_topdown_xe_train_step(const uic_topdown_dims* d, const uic_topdown_weigh
   UIC_HIP(hipEventRecord(ss->ev_den, s));
   UIC_HIP(hipStreamWaitEvent(s2, ss->ev_den, 0));
   UIC_TRY(st.fwd_prologue(s));
+  UIC_HIP(hipEventRecord(ss->ev_den, s));             // (re-used: the features are projected)
+  UIC_HIP(hipStreamWaitEvent(s2, ss->ev_den, 0));
+  UIC_TRY(st.hoist_transposes(s2));
   for (int c = 0; c < nchunk; ++c) {
     const int t0 = c * CH, t1 = t0 + CH < t_run ? t0 + CH : t_run;
     for (int t = t0; t < t1; ++t) UIC_TRY(st.fwd_step(t, s));
@@ -917,12 +939,13 @@ int uic_topdown_xe_train_step(const uic_topdown_dims* d, const uic_topdown_weigh
     UIC_HIP(hipStreamWaitEvent(s2, ss->ev_main[c], 0));
     UIC_TRY(st.wgrad_chunk(t0, t1, c == nchunk - 1, s2));
   }
-  UIC_HIP(hipEventRecord(ss->ev_done, s2));
-  UIC_TRY(st.bwd_epilogue_early(s, true));
-  UIC_HIP(hipStreamWaitEvent(s, ss->ev_done, 0));     // join: logit-layer + recurrent weight gradients, loss
-  UIC_HIP(hipEventRecord(ss->ev_early, s));
+  // side: the rest of the early gradient group (LSTM / h2att biases, embedding, fc_embed); main: the late group
+  // (attention accumulation, ctx2att, att_embed).  ev_early: the early group, the logit layer and the loss are final.
+  UIC_TRY(st.bwd_epilogue_early(s2, true, true));
+  UIC_HIP(hipEventRecord(ss->ev_early, s2));
   ss->early_recorded = true;
   UIC_TRY(st.bwd_epilogue_late(s, true));
+  UIC_HIP(hipStreamWaitEvent(s, ss->ev_early, 0));    // join
 #undef UIC_HIP
   return UIC_OK;
 }
