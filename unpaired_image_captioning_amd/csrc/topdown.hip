@@ -569,12 +569,13 @@ struct Step {
     return uic_xe_launch(x, s);
   }
   // d hdrop rows of steps [t0, t1) = d logits W_logit
-  int dh_rows(int t0, int t1, hipStream_t s) {
+  // (long K = V1, few output tiles: split-K over workgroups on the LDS-DMA GEMM when the shape allows; `side` picks
+  // the side stream's slab)
+  int dh_rows(int t0, int t1, hipStream_t s, bool side = false) {
     const size_t r0 = (size_t)t0 * N;
-    UicGemmParams g = gemm_base(dt, (t1 - t0) * N, H);
-    add_seg(g, off(L.dlogits, r0 * V1p, dt), V1p, dv.logit_wT, V1p, V1p);
-    g.C = L.dhdrop + r0 * H; g.ldc = H; g.flags = UIC_GEMM_OUT_F32;
-    return uic_gemm_launch(g, s);
+    const WDest d1{L.dhdrop + r0 * H, H, 0, H};
+    return wgrad_multi(side ? L.slab2 : L.slab, L.slab_bytes, dt, off(L.dlogits, r0 * V1p, dt), (t1 - t0) * N, dv.logit_wT, H, V1p,
+                       &d1, 1, s);
   }
   // d W_logit, d b_logit over all executed steps (own scratch buffers: may run beside the BPTT loop)
   int logit_weight_grads(hipStream_t s) {
@@ -921,7 +922,7 @@ int uic_topdown_xe_train_step(const uic_topdown_dims* d, const uic_topdown_weigh
     UIC_HIP(hipStreamWaitEvent(s2, ss->ev_main[c], 0));
     UIC_TRY(st.logits_rows(t0, t1, s2));
     UIC_TRY(st.xe_rows(t0, t1, inv, nullptr, 1, s2));
-    UIC_TRY(st.dh_rows(t0, t1, s2));
+    UIC_TRY(st.dh_rows(t0, t1, s2, true));
     UIC_HIP(hipEventRecord(ss->ev_side[c], s2));
   }
   // side: logit-layer weight gradients + loss reduction, beside the BPTT loop
