@@ -311,6 +311,63 @@ int attention_step(const uic_topdown_dims& d, const uic_topdown_weights* w, cons
   return uic_attention_fwd_launch(a, s);
 }
 
+// Side stream + events for the fused training step: the logit layer of finished decode steps (logit GEMM,
+// log-softmax/criterion, dH GEMM, later dW_logit) runs beside the latency-bound recurrence on a second HIP stream.
+constexpr int MAX_CHUNKS = 64;
+struct SideStream {
+  hipStream_t stream = nullptr;
+  hipEvent_t ev_den = nullptr, ev_done = nullptr;
+  hipEvent_t ev_early = nullptr;    // main: every gradient except the late group (see uic_topdown_grad_ready_wait) is final
+  bool early_recorded = false;
+  hipEvent_t ev_r0 = nullptr, ev_refresh = nullptr;   // uic_topdown_refresh_weights: main -> side, side -> consumers
+  bool refresh_pending = false;
+  hipEvent_t ev_main[MAX_CHUNKS];   // main  -> side: decode steps of chunk c are finished
+  hipEvent_t ev_side[MAX_CHUNKS];   // side  -> main: d hdrop of chunk c is ready
+  bool ready = false;
+};
+SideStream g_side[16];
+
+int get_side(SideStream** out) {
+  int dev = 0;
+  UIC_TRY(uic_check_hip(hipGetDevice(&dev), "hipGetDevice"));
+  UIC_REQUIRE(dev >= 0 && dev < 16, "device index %d out of range", dev);
+  SideStream& ss = g_side[dev];
+  if (!ss.ready) {
+    // The side stream is confined to a subset of the CUs (UIC_SIDE_CUS=n, experiment only; default: no mask):
+    // its large GEMMs would otherwise fill every CU and the latency-bound recurrence kernels of the main
+    // stream would queue behind them, which costs more than the overlap gains.
+    int ncu = 0;   // measured on MI355X: masking the side stream to 64..160 CUs is 1.6-2x SLOWER than no mask
+    if (const char* e = getenv("UIC_SIDE_CUS")) ncu = atoi(e);
+    if (ncu > 0 && ncu < 256) {
+      uint32_t mask[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+      for (int i = 0; i < ncu; ++i) mask[i >> 5] |= 1u << (i & 31);
+      UIC_TRY(uic_check_hip(hipExtStreamCreateWithCUMask(&ss.stream, 8, mask), "hipExtStreamCreateWithCUMask"));
+    } else {
+      UIC_TRY(uic_check_hip(hipStreamCreateWithFlags(&ss.stream, hipStreamNonBlocking), "hipStreamCreateWithFlags"));
+    }
+    UIC_TRY(uic_check_hip(hipEventCreateWithFlags(&ss.ev_den, hipEventDisableTiming), "hipEventCreate"));
+    UIC_TRY(uic_check_hip(hipEventCreateWithFlags(&ss.ev_done, hipEventDisableTiming), "hipEventCreate"));
+    UIC_TRY(uic_check_hip(hipEventCreateWithFlags(&ss.ev_early, hipEventDisableTiming), "hipEventCreate"));
+    UIC_TRY(uic_check_hip(hipEventCreateWithFlags(&ss.ev_r0, hipEventDisableTiming), "hipEventCreate"));
+    UIC_TRY(uic_check_hip(hipEventCreateWithFlags(&ss.ev_refresh, hipEventDisableTiming), "hipEventCreate"));
+    for (int i = 0; i < MAX_CHUNKS; ++i) {
+      UIC_TRY(uic_check_hip(hipEventCreateWithFlags(&ss.ev_main[i], hipEventDisableTiming), "hipEventCreate"));
+      UIC_TRY(uic_check_hip(hipEventCreateWithFlags(&ss.ev_side[i], hipEventDisableTiming), "hipEventCreate"));
+    }
+    ss.ready = true;
+  }
+  *out = &ss;
+  return UIC_OK;
+}
+
+// every consumer of the derived weights first lets its stream wait for the side-stream part of the last refresh
+int wait_refresh(hipStream_t s) {
+  SideStream* ss = nullptr;
+  UIC_TRY(get_side(&ss));
+  if (ss->refresh_pending) UIC_TRY(uic_check_hip(hipStreamWaitEvent(s, ss->ev_refresh, 0), "hipStreamWaitEvent(refresh)"));
+  return UIC_OK;
+}
+
 }  // namespace
 
 extern "C" {
@@ -347,16 +404,24 @@ int uic_topdown_refresh_weights(const uic_topdown_dims* d, const uic_topdown_wei
   const int dt = d->dtype;
   const int D = d->D, Dfc = d->Dfc, H = d->H, E = d->E, A = d->A, V1 = d->V1;
   const int V1p = (int)vpad(V1);
+  // The copies the feature projection and the batched input GEMMs need come first, on the caller's stream; everything
+  // the recurrence, the logit layer and the backward pass need is produced on the side stream meanwhile (consumers
+  // wait for ev_refresh, see wait_refresh), so a training step does not start with ~0.1 ms of serial weight shuffling.
+  SideStream* ss = nullptr;
+  UIC_TRY(get_side(&ss));
+  hipStream_t s2 = ss->stream;
+  UIC_TRY(uic_check_hip(hipEventRecord(ss->ev_r0, s), "hipEventRecord"));          // the master weights are final
+  UIC_TRY(uic_check_hip(hipStreamWaitEvent(s2, ss->ev_r0, 0), "hipStreamWaitEvent"));
   if (dt == UIC_BF16) {
     UIC_TRY(uic_cast_f32_launch(dt, w->fc_w, (void*)v.fc_w, (size_t)H * Dfc, s));
     if (!d->use_bn) UIC_TRY(uic_cast_f32_launch(dt, w->att_w, (void*)v.att_w, (size_t)H * D, s));
     UIC_TRY(uic_cast_f32_launch(dt, w->ctx2att_w, (void*)v.ctx2att_w, (size_t)A * H, s));
-    UIC_TRY(uic_cast_f32_launch(dt, w->logit_w, (void*)v.logit_w, (size_t)V1 * H, s));
     UIC_TRY(uic_cast_f32_launch(dt, w->att_lstm_w_ih, (void*)v.att_w_ih, (size_t)4 * H * (E + 2 * H), s));
-    UIC_TRY(uic_cast_f32_launch(dt, w->att_lstm_w_hh, (void*)v.att_w_hh, (size_t)4 * H * H, s));
-    UIC_TRY(uic_cast_f32_launch(dt, w->lang_lstm_w_ih, (void*)v.lang_w_ih, (size_t)4 * H * 2 * H, s));
-    UIC_TRY(uic_cast_f32_launch(dt, w->lang_lstm_w_hh, (void*)v.lang_w_hh, (size_t)4 * H * H, s));
-    UIC_TRY(uic_cast_f32_launch(dt, w->h2att_w, (void*)v.h2att_w, (size_t)A * H, s));
+    UIC_TRY(uic_cast_f32_launch(dt, w->logit_w, (void*)v.logit_w, (size_t)V1 * H, s2));
+    UIC_TRY(uic_cast_f32_launch(dt, w->att_lstm_w_hh, (void*)v.att_w_hh, (size_t)4 * H * H, s2));
+    UIC_TRY(uic_cast_f32_launch(dt, w->lang_lstm_w_ih, (void*)v.lang_w_ih, (size_t)4 * H * 2 * H, s2));
+    UIC_TRY(uic_cast_f32_launch(dt, w->lang_lstm_w_hh, (void*)v.lang_w_hh, (size_t)4 * H * H, s2));
+    UIC_TRY(uic_cast_f32_launch(dt, w->h2att_w, (void*)v.h2att_w, (size_t)A * H, s2));
   }
   if (d->use_bn) {
     UIC_REQUIRE(w->att_bn0_w && w->att_bn0_b && w->att_bn0_rm && w->att_bn0_rv, "use_bn=%d needs the att_embed.0 BatchNorm tensors", d->use_bn);
@@ -364,67 +429,27 @@ int uic_topdown_refresh_weights(const uic_topdown_dims* d, const uic_topdown_wei
     UIC_TRY(uic_bn_fold_weight_launch(dt, w->att_w, w->att_bn0_w, w->att_bn0_b, w->att_b, H, D, (void*)v.att_w, v.att_beff, s));
   }
   const int H4 = 4 * H, ldih = E + 2 * H;
-  UIC_TRY(uic_transpose_launch(dt, v.logit_w, V1, H, H, v.logit_wT, V1p, s));
+  // the transposes of att_w_ih read the copy made on `s` above
+  UIC_TRY(uic_check_hip(hipEventRecord(ss->ev_r0, s), "hipEventRecord"));
+  UIC_TRY(uic_check_hip(hipStreamWaitEvent(s2, ss->ev_r0, 0), "hipStreamWaitEvent"));
+  UIC_TRY(uic_transpose_launch(dt, v.logit_w, V1, H, H, v.logit_wT, V1p, s2));
   // w2T rows [0,2H) <- lang_w_ih^T, rows [2H,3H) <- lang_w_hh^T
-  UIC_TRY(uic_transpose_launch(dt, v.lang_w_ih, H4, 2 * H, 2 * H, v.w2T, H4, s));
-  UIC_TRY(uic_transpose_launch(dt, v.lang_w_hh, H4, H, H, offw(v.w2T, (size_t)2 * H * H4, dt), H4, s));
-  UIC_TRY(uic_transpose_launch(dt, v.att_w_ih, H4, H, ldih, v.w1recT, H4, s));
-  UIC_TRY(uic_transpose_launch(dt, v.att_w_hh, H4, H, H, offw(v.w1recT, (size_t)H * H4, dt), H4, s));
-  UIC_TRY(uic_transpose_launch(dt, off(v.att_w_ih, 2 * H, dt), H4, E, ldih, v.wxT, H4, s));
-  UIC_TRY(uic_transpose_launch(dt, off(v.att_w_ih, H, dt), H4, H, ldih, v.wfcpT, H4, s));
-  UIC_TRY(uic_transpose_launch(dt, v.h2att_w, A, H, H, v.h2attT, A, s));
-  UIC_TRY(uic_transpose_launch(dt, v.ctx2att_w, A, H, H, v.ctx2attT, A, s));
+  UIC_TRY(uic_transpose_launch(dt, v.lang_w_ih, H4, 2 * H, 2 * H, v.w2T, H4, s2));
+  UIC_TRY(uic_transpose_launch(dt, v.lang_w_hh, H4, H, H, offw(v.w2T, (size_t)2 * H * H4, dt), H4, s2));
+  UIC_TRY(uic_transpose_launch(dt, v.att_w_ih, H4, H, ldih, v.w1recT, H4, s2));
+  UIC_TRY(uic_transpose_launch(dt, v.att_w_hh, H4, H, H, offw(v.w1recT, (size_t)H * H4, dt), H4, s2));
+  UIC_TRY(uic_transpose_launch(dt, off(v.att_w_ih, 2 * H, dt), H4, E, ldih, v.wxT, H4, s2));
+  UIC_TRY(uic_transpose_launch(dt, off(v.att_w_ih, H, dt), H4, H, ldih, v.wfcpT, H4, s2));
+  UIC_TRY(uic_transpose_launch(dt, v.h2att_w, A, H, H, v.h2attT, A, s2));
+  UIC_TRY(uic_transpose_launch(dt, v.ctx2att_w, A, H, H, v.ctx2attT, A, s2));
+  UIC_TRY(uic_check_hip(hipEventRecord(ss->ev_refresh, s2), "hipEventRecord"));
+  ss->refresh_pending = true;
   return UIC_OK;
 }
 
 }  // extern "C" (re-opened below)
 
 namespace {
-
-// Side stream + events for the fused training step: the logit layer of finished decode steps (logit GEMM,
-// log-softmax/criterion, dH GEMM, later dW_logit) runs beside the latency-bound recurrence on a second HIP stream.
-constexpr int MAX_CHUNKS = 64;
-struct SideStream {
-  hipStream_t stream = nullptr;
-  hipEvent_t ev_den = nullptr, ev_done = nullptr;
-  hipEvent_t ev_early = nullptr;    // main: every gradient except the late group (see uic_topdown_grad_ready_wait) is final
-  bool early_recorded = false;
-  hipEvent_t ev_main[MAX_CHUNKS];   // main  -> side: decode steps of chunk c are finished
-  hipEvent_t ev_side[MAX_CHUNKS];   // side  -> main: d hdrop of chunk c is ready
-  bool ready = false;
-};
-SideStream g_side[16];
-
-int get_side(SideStream** out) {
-  int dev = 0;
-  UIC_TRY(uic_check_hip(hipGetDevice(&dev), "hipGetDevice"));
-  UIC_REQUIRE(dev >= 0 && dev < 16, "device index %d out of range", dev);
-  SideStream& ss = g_side[dev];
-  if (!ss.ready) {
-    // The side stream is confined to a subset of the CUs (UIC_SIDE_CUS=n, experiment only; default: no mask):
-    // its large GEMMs would otherwise fill every CU and the latency-bound recurrence kernels of the main
-    // stream would queue behind them, which costs more than the overlap gains.
-    int ncu = 0;   // measured on MI355X: masking the side stream to 64..160 CUs is 1.6-2x SLOWER than no mask
-    if (const char* e = getenv("UIC_SIDE_CUS")) ncu = atoi(e);
-    if (ncu > 0 && ncu < 256) {
-      uint32_t mask[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-      for (int i = 0; i < ncu; ++i) mask[i >> 5] |= 1u << (i & 31);
-      UIC_TRY(uic_check_hip(hipExtStreamCreateWithCUMask(&ss.stream, 8, mask), "hipExtStreamCreateWithCUMask"));
-    } else {
-      UIC_TRY(uic_check_hip(hipStreamCreateWithFlags(&ss.stream, hipStreamNonBlocking), "hipStreamCreateWithFlags"));
-    }
-    UIC_TRY(uic_check_hip(hipEventCreateWithFlags(&ss.ev_den, hipEventDisableTiming), "hipEventCreate"));
-    UIC_TRY(uic_check_hip(hipEventCreateWithFlags(&ss.ev_done, hipEventDisableTiming), "hipEventCreate"));
-    UIC_TRY(uic_check_hip(hipEventCreateWithFlags(&ss.ev_early, hipEventDisableTiming), "hipEventCreate"));
-    for (int i = 0; i < MAX_CHUNKS; ++i) {
-      UIC_TRY(uic_check_hip(hipEventCreateWithFlags(&ss.ev_main[i], hipEventDisableTiming), "hipEventCreate"));
-      UIC_TRY(uic_check_hip(hipEventCreateWithFlags(&ss.ev_side[i], hipEventDisableTiming), "hipEventCreate"));
-    }
-    ss.ready = true;
-  }
-  *out = &ss;
-  return UIC_OK;
-}
 
 // One teacher-forced step of the captioner on one GPU, split into the pieces the public entry points
 // (and the two-stream fused training step) sequence.
@@ -837,6 +862,7 @@ int uic_topdown_forward(const uic_topdown_dims* d, const uic_topdown_weights* w,
   Step st;
   st.init(d, w, derived, b, t_run, training, seed, workspace, nullptr);
   UIC_TRY(st.fwd_prologue(s));
+  UIC_TRY(wait_refresh(s));
   for (int t = 0; t < t_run; ++t) UIC_TRY(st.fwd_step(t, s));
   UIC_TRY(st.logits_rows(0, t_run, s));
   if (logprobs_out) UIC_TRY(st.xe_rows(0, t_run, nullptr, logprobs_out, 0, s));
@@ -874,6 +900,7 @@ int uic_topdown_backward(const uic_topdown_dims* d, const uic_topdown_weights* w
   hipStream_t s = (hipStream_t)stream;
   Step st;
   st.init(d, w, derived, b, t_run, training, seed, workspace, G);
+  UIC_TRY(wait_refresh(s));
   if (dlogprobs)
     UIC_TRY(uic_logsoftmax_bwd_launch(st.dt, st.L.dlogits, st.Meff, st.V1, st.V1p, st.N, dlogprobs, (size_t)st.V1,
                                       (size_t)d->T * st.V1, logprobs, s));
@@ -914,6 +941,7 @@ int uic_topdown_xe_train_step(const uic_topdown_dims* d, const uic_topdown_weigh
   UIC_HIP(hipEventRecord(ss->ev_den, s));             // (re-used: the features are projected)
   UIC_HIP(hipStreamWaitEvent(s2, ss->ev_den, 0));
   UIC_TRY(st.hoist_transposes(s2));
+  UIC_TRY(wait_refresh(s));                           // the recurrence needs the side-stream half of the weight refresh
   for (int c = 0; c < nchunk; ++c) {
     const int t0 = c * CH, t1 = t0 + CH < t_run ? t0 + CH : t_run;
     for (int t = t0; t < t1; ++t) UIC_TRY(st.fwd_step(t, s));
@@ -978,6 +1006,7 @@ int uic_topdown_sample(const uic_topdown_dims* d, const uic_topdown_weights* w, 
   const void *fc_in, *att_in;
   const float drop_p = (training & 1) ? d->drop_p : 0.f;
   UIC_TRY(prepare_features(*d, w, dv, b, L, training, drop_p, seed, &fc_in, &att_in, s));
+  UIC_TRY(wait_refresh(s));
   UIC_TRY(uic_fill_launch(L.s_h_att[0], 0, NH * S, s));
   UIC_TRY(uic_fill_launch(L.s_h_lang[0], 0, NH * S, s));
   UIC_TRY(uic_fill_launch(L.s_c_att[0], 0, NH * 4, s));
