@@ -11,6 +11,7 @@ import sys
 
 d = sys.argv[1]
 back = int(sys.argv[2]) if len(sys.argv) > 2 else 3
+win = (float(sys.argv[3]), float(sys.argv[4])) if len(sys.argv) > 4 else None   # [ms, ms): print every kernel inside
 f = glob.glob(d + "/**/*kernel_trace.csv", recursive=True)[0]
 ev = []
 for r in csv.DictReader(open(f)):
@@ -53,3 +54,10 @@ for q in streams:
     for n, s, e, b, c in runs:
         if b > 15000 or c > 1:
             print("   @%7.3f ms  span %7.3f ms  busy %7.3f ms  x%-3d %s" % ((s - t0) / 1e6, (e - s) / 1e6, b / 1e6, c, n))
+
+if win:
+    print("\nall kernels starting in [%.3f, %.3f) ms:" % win)
+    for e in step:
+        st = (e[0] - t0) / 1e6
+        if win[0] <= st < win[1]:
+            print("   q%s @%7.3f ms  %7.1f us  %s" % (e[4], st, (e[1] - e[0]) / 1e3, short(e[2])))

@@ -389,95 +389,104 @@ inline bool fast_ok(const UicAttnParams& p) {
   return p.R <= UB * NWAVES && p.A / vec <= 64 && p.H / vec <= 64 && (p.lddctx % 4 == 0);
 }
 
-template <typename T>
-__global__ __launch_bounds__(1024) void attn_bwd_accum_kernel(const UicAttnAccumParams p) {
+// PART 1: d att' only (stages alpha, dctx);  PART 2: d p_att and d w_alpha only (stages att_h, de).  Two launches of
+// 256-thread workgroups with < 50 KB of LDS each instead of one 1024-thread / > 100 KB workgroup per row: the small
+// workgroups interleave with whatever else is resident (the fused step's other stream) instead of waiting for whole CUs.
+template <typename T, int PART>
+__global__ __launch_bounds__(256) void attn_bwd_accum_kernel(const UicAttnAccumParams p) {
   constexpr int VEC = uic_vec<T>::N;
   extern __shared__ __attribute__((aligned(16))) float sm[];
   const int A = p.A, H = p.H, R = p.R, TS = p.T, N = p.N;
   const int Rp = (R + 3) & ~3;
-  float* s_atth = sm;                 // [TS][A]
-  float* s_dctx = s_atth + TS * A;    // [TS][H]
-  float* s_al = s_dctx + TS * H;      // [TS][Rp]
-  float* s_de = s_al + TS * Rp;       // [TS][Rp]
-  float* s_w = s_de + TS * Rp;        // [A]
-  float* s_red = s_w + A;             // [nw][A]
   const int nthreads = blockDim.x, nw = blockDim.x >> 6;
   const int n = blockIdx.x;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
 
-  for (int i = tid; i < TS * A; i += nthreads) {
-    const int t = i / A, a = i - t * A;
-    s_atth[i] = p.att_h_all[((size_t)t * N + n) * A + a];
-  }
-  for (int i = tid; i < TS * H; i += nthreads) {
-    const int t = i / H, h = i - t * H;
-    s_dctx[i] = p.dctx_all[(size_t)t * p.dctx_step_stride + (size_t)n * p.lddctx + h];
-  }
-  for (int i = tid; i < TS * R; i += nthreads) {
-    const int t = i / R, r = i - t * R;
-    s_al[t * Rp + r] = p.alpha_all[((size_t)t * N + n) * R + r];
-    s_de[t * Rp + r] = p.de_all[((size_t)t * N + n) * R + r];
-  }
-  for (int a = tid; a < A; a += nthreads) s_w[a] = p.w_alpha[a];
-  __syncthreads();
-
-  // d att'[n,r,:] = sum_t alpha_t[r] dctx_t   (backward of the bmm, AttModel.py:555-556)
-  float* dat = p.d_att + (size_t)n * R * H;
-  const int nc4 = H / 4;
-  for (int r = wave; r < R; r += nw) {
-    for (int c = lane; c < nc4; c += 64) {
-      float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-      for (int t = 0; t < TS; ++t) {
-        const float al = s_al[t * Rp + r];
-        const float4 d = *(const float4*)(s_dctx + t * H + c * 4);
-        acc.x += al * d.x; acc.y += al * d.y; acc.z += al * d.z; acc.w += al * d.w;
-      }
-      *(float4*)(dat + (size_t)r * H + c * 4) = acc;
+  if constexpr (PART == 1) {
+    float* s_dctx = sm;                 // [TS][H]
+    float* s_al = s_dctx + TS * H;      // [TS][Rp]
+    for (int i = tid; i < TS * H; i += nthreads) {
+      const int t = i / H, h = i - t * H;
+      s_dctx[i] = p.dctx_all[(size_t)t * p.dctx_step_stride + (size_t)n * p.lddctx + h];
     }
-  }
-
-  // d p_att[n,r,a] = w_a sum_t de_t[r] (1 - tanh^2(.)) ;  d w_alpha[a] += sum_{t,r} de_t[r] tanh(.)
-  const T* pa = (const T*)p.p_att + (size_t)n * R * A;
-  T* dpa = (T*)p.d_p_att + (size_t)n * R * A;
-  const int ncA = A / VEC;
-  for (int c = lane; c < ncA; c += 64) {
-    float dwacc[VEC];
-#pragma unroll
-    for (int j = 0; j < VEC; ++j) dwacc[j] = 0.f;
+    for (int i = tid; i < TS * R; i += nthreads) {
+      const int t = i / R, r = i - t * R;
+      s_al[t * Rp + r] = p.alpha_all[((size_t)t * N + n) * R + r];
+    }
+    __syncthreads();
+    // d att'[n,r,:] = sum_t alpha_t[r] dctx_t   (backward of the bmm, AttModel.py:555-556)
+    float* dat = p.d_att + (size_t)n * R * H;
+    const int nc4 = H / 4;
     for (int r = wave; r < R; r += nw) {
-      const uint4 v = *(const uint4*)(pa + (size_t)r * A + c * VEC);
-      float f[VEC], acc[VEC];
-      uic_unpack<T>(v, f);
-#pragma unroll
-      for (int j = 0; j < VEC; ++j) acc[j] = 0.f;
-      for (int t = 0; t < TS; ++t) {
-        const float de = s_de[t * Rp + r];
-#pragma unroll
-        for (int j = 0; j < VEC; ++j) {
-          const float th = uic_tanh<T>(f[j] + s_atth[t * A + c * VEC + j]);
-          acc[j] += de * (1.f - th * th);
-          dwacc[j] += de * th;
+      for (int c = lane; c < nc4; c += 64) {
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int t = 0; t < TS; ++t) {
+          const float al = s_al[t * Rp + r];
+          const float4 d = *(const float4*)(s_dctx + t * H + c * 4);
+          acc.x += al * d.x; acc.y += al * d.y; acc.z += al * d.z; acc.w += al * d.w;
         }
+        *(float4*)(dat + (size_t)r * H + c * 4) = acc;
+      }
+    }
+  } else {
+    float* s_atth = sm;                 // [TS][A]
+    float* s_de = s_atth + TS * A;      // [TS][Rp]
+    float* s_w = s_de + TS * Rp;        // [A]
+    float* s_red = s_w + A;             // [nw][A]
+    for (int i = tid; i < TS * A; i += nthreads) {
+      const int t = i / A, a = i - t * A;
+      s_atth[i] = p.att_h_all[((size_t)t * N + n) * A + a];
+    }
+    for (int i = tid; i < TS * R; i += nthreads) {
+      const int t = i / R, r = i - t * R;
+      s_de[t * Rp + r] = p.de_all[((size_t)t * N + n) * R + r];
+    }
+    for (int a = tid; a < A; a += nthreads) s_w[a] = p.w_alpha[a];
+    for (int i = tid; i < nw * A; i += nthreads) s_red[i] = 0.f;
+    __syncthreads();
+    // d p_att[n,r,a] = w_a sum_t de_t[r] (1 - tanh^2(.)) ;  d w_alpha[a] += sum_{t,r} de_t[r] tanh(.)
+    const T* pa = (const T*)p.p_att + (size_t)n * R * A;
+    T* dpa = (T*)p.d_p_att + (size_t)n * R * A;
+    const int ncA = A / VEC;
+    for (int c = lane; c < ncA; c += 64) {
+      float dwacc[VEC];
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) dwacc[j] = 0.f;
+      for (int r = wave; r < R; r += nw) {
+        const uint4 v = *(const uint4*)(pa + (size_t)r * A + c * VEC);
+        float f[VEC], acc[VEC];
+        uic_unpack<T>(v, f);
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) acc[j] = 0.f;
+        for (int t = 0; t < TS; ++t) {
+          const float de = s_de[t * Rp + r];
+#pragma unroll
+          for (int j = 0; j < VEC; ++j) {
+            const float th = uic_tanh<T>(f[j] + s_atth[t * A + c * VEC + j]);
+            acc[j] += de * (1.f - th * th);
+            dwacc[j] += de * th;
+          }
+        }
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) acc[j] *= s_w[c * VEC + j];
+        *(uint4*)(dpa + (size_t)r * A + c * VEC) = uic_pack<T>(acc);
       }
 #pragma unroll
-      for (int j = 0; j < VEC; ++j) acc[j] *= s_w[c * VEC + j];
-      *(uint4*)(dpa + (size_t)r * A + c * VEC) = uic_pack<T>(acc);
+      for (int j = 0; j < VEC; ++j) s_red[wave * A + c * VEC + j] = dwacc[j];
     }
-#pragma unroll
-    for (int j = 0; j < VEC; ++j) s_red[wave * A + c * VEC + j] = dwacc[j];
-  }
-  __syncthreads();
-  float* part = p.d_walpha_part + (size_t)n * (A + 1);
-  for (int a = tid; a < A; a += nthreads) {
-    float sacc = 0.f;
-    for (int wv = 0; wv < nw; ++wv) sacc += s_red[wv * A + a];
-    part[a] = sacc;
-  }
-  if (tid == 0) {
-    float s = 0.f;
-    for (int t = 0; t < TS; ++t)
-      for (int r = 0; r < R; ++r) s += s_de[t * Rp + r];
-    part[A] = s;
+    __syncthreads();
+    float* part = p.d_walpha_part + (size_t)n * (A + 1);
+    for (int a = tid; a < A; a += nthreads) {
+      float sacc = 0.f;
+      for (int wv = 0; wv < nw; ++wv) sacc += s_red[wv * A + a];
+      part[a] = sacc;
+    }
+    if (tid == 0) {
+      float s = 0.f;
+      for (int t = 0; t < TS; ++t)
+        for (int r = 0; r < R; ++r) s += s_de[t * Rp + r];
+      part[A] = s;
+    }
   }
 }
 
@@ -537,20 +546,19 @@ int uic_attention_bwd_accum_launch(const UicAttnAccumParams& p, hipStream_t s) {
                   p.d_walpha_part, "attention_bwd_accum: null pointer");
   if (p.N == 0) return UIC_OK;
   const int Rp = (p.R + 3) & ~3;
-  int nthreads = 1024;   // 16 waves share one row's staged [T, A + H + 2R] block; fewer if LDS is short
-  size_t lds = 0;
-  for (;; nthreads >>= 1) {
-    lds = sizeof(float) * ((size_t)p.T * (p.A + p.H + 2 * Rp) + p.A + (nthreads / 64) * (size_t)p.A);
-    if (lds <= 160 * 1024 || nthreads == 64) break;
-  }
-  UIC_REQUIRE(lds <= 160 * 1024, "attention_bwd_accum: needs %zu B of LDS (T=%d)", lds, p.T);
-  if (p.dtype == UIC_BF16) {
-    if (lds > 64 * 1024) UIC_TRY(uic_check_hip(hipFuncSetAttribute((const void*)attn_bwd_accum_kernel<bf16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds), "hipFuncSetAttribute"));
-    hipLaunchKernelGGL(attn_bwd_accum_kernel<bf16_t>, dim3(p.N), dim3(nthreads), lds, s, p);
-  } else {
-    if (lds > 64 * 1024) UIC_TRY(uic_check_hip(hipFuncSetAttribute((const void*)attn_bwd_accum_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds), "hipFuncSetAttribute"));
-    hipLaunchKernelGGL(attn_bwd_accum_kernel<float>, dim3(p.N), dim3(nthreads), lds, s, p);
-  }
+  const int nthreads = 256;
+  const size_t lds1 = sizeof(float) * ((size_t)p.T * (p.H + Rp));
+  const size_t lds2 = sizeof(float) * ((size_t)p.T * (p.A + Rp) + p.A + (nthreads / 64) * (size_t)p.A);
+  UIC_REQUIRE(lds1 <= 160 * 1024 && lds2 <= 160 * 1024, "attention_bwd_accum: needs %zu B of LDS (T=%d)", lds1 > lds2 ? lds1 : lds2, p.T);
+#define ACCUM_LAUNCH(TT)                                                                                                          \
+  do {                                                                                                                            \
+    if (lds1 > 64 * 1024) UIC_TRY(uic_check_hip(hipFuncSetAttribute((const void*)attn_bwd_accum_kernel<TT, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1), "hipFuncSetAttribute")); \
+    if (lds2 > 64 * 1024) UIC_TRY(uic_check_hip(hipFuncSetAttribute((const void*)attn_bwd_accum_kernel<TT, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2), "hipFuncSetAttribute")); \
+    hipLaunchKernelGGL((attn_bwd_accum_kernel<TT, 2>), dim3(p.N), dim3(nthreads), lds2, s, p);                                      \
+    hipLaunchKernelGGL((attn_bwd_accum_kernel<TT, 1>), dim3(p.N), dim3(nthreads), lds1, s, p);                                      \
+  } while (0)
+  if (p.dtype == UIC_BF16) ACCUM_LAUNCH(bf16_t); else ACCUM_LAUNCH(float);
+#undef ACCUM_LAUNCH
   UIC_LAUNCH_CHECK("attn_bwd_accum_kernel");
   return UIC_OK;
 }

@@ -343,7 +343,13 @@ int get_side(SideStream** out) {
       for (int i = 0; i < ncu; ++i) mask[i >> 5] |= 1u << (i & 31);
       UIC_TRY(uic_check_hip(hipExtStreamCreateWithCUMask(&ss.stream, 8, mask), "hipExtStreamCreateWithCUMask"));
     } else {
-      UIC_TRY(uic_check_hip(hipStreamCreateWithFlags(&ss.stream, hipStreamNonBlocking), "hipStreamCreateWithFlags"));
+      // lowest priority: when CUs free up, the dispatcher serves the latency-critical recurrence of the caller's stream
+      // before the bulk work queued here (UIC_SIDE_PRIO=0 keeps the default priority, for A/B measurements)
+      int least = 0, greatest = 0;
+      UIC_TRY(uic_check_hip(hipDeviceGetStreamPriorityRange(&least, &greatest), "hipDeviceGetStreamPriorityRange"));
+      const char* pe = getenv("UIC_SIDE_PRIO");
+      const int prio = (pe && atoi(pe) == 0) ? 0 : least;
+      UIC_TRY(uic_check_hip(hipStreamCreateWithPriority(&ss.stream, hipStreamNonBlocking, prio), "hipStreamCreateWithPriority"));
     }
     UIC_TRY(uic_check_hip(hipEventCreateWithFlags(&ss.ev_den, hipEventDisableTiming), "hipEventCreate"));
     UIC_TRY(uic_check_hip(hipEventCreateWithFlags(&ss.ev_done, hipEventDisableTiming), "hipEventCreate"));
@@ -790,18 +796,20 @@ struct Step {
     UIC_TRY(uic_colsum_launch(dt, L.dfcpre, N, H, H, G->fc_b, colscratch, L.colscratch_floats, s));
     return UIC_OK;
   }
-  int bwd_epilogue_late(hipStream_t s, bool chunked = false) {
+  // part: 0 = everything, 1 = only the deferred attention accumulation, 2 = everything else.  (Measured: running the
+  // accumulation -- whole-CU workgroups -- before releasing the side stream's tail is 3 % SLOWER than letting both run.)
+  int bwd_epilogue_late(hipStream_t s, bool chunked = false, int part = 0) {
     auto wgrad = [&](const void* left, int lrows, const void* right, int rrows, int K, float* C, int ldc) -> int {
       return wgrad1(left, lrows, right, rrows, K, C, ldc, s);
     };
     // h2att
-    if (!chunked) {
+    if (!chunked && part != 1) {
       UIC_TRY(uic_transpose_launch(dt, L.datth_all, Meff, A, A, L.tA, Mp, s));
       UIC_TRY(uic_transpose_launch(dt, off(L.h_att, NH, dt), Meff, H, H, L.tB, Mp, s));
       UIC_TRY(wgrad(L.tA, A, L.tB, H, Mp, G->h2att_w, H));
       UIC_TRY(uic_colsum_launch(dt, L.datth_all, Meff, A, A, G->h2att_b, L.colscratch, L.colscratch_floats, s));
     }
-    {  // attention: deferred accumulation over steps
+    if (part != 2) {  // attention: deferred accumulation over steps
       UicAttnAccumParams a;
       memset(&a, 0, sizeof(a));
       a.dtype = dt; a.N = N; a.R = R; a.A = A; a.H = H; a.T = t_run;
@@ -814,6 +822,7 @@ struct Step {
       UIC_TRY(uic_check_hip(hipMemcpyAsync(G->alpha_w, L.small, (size_t)A * 4, hipMemcpyDeviceToDevice, s), "memcpy alpha_w"));
       UIC_TRY(uic_check_hip(hipMemcpyAsync(G->alpha_b, L.small + A, 4, hipMemcpyDeviceToDevice, s), "memcpy alpha_b"));
     }
+    if (part == 1) return UIC_OK;
     // ctx2att
     UIC_TRY(uic_transpose_launch(dt, L.d_patt, NR, A, A, L.tA, NRp, s));
     if (!chunked) UIC_TRY(uic_transpose_launch(dt, L.attp, NR, H, H, L.attpT, NRp, s));   // fused step: hoisted
