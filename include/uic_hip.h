@@ -258,6 +258,13 @@ int uic_nmt_backward(const uic_nmt_dims* d, const uic_nmt_weights* w, const int6
 int uic_linear(int32_t dtype, int32_t M, int32_t N, int32_t K, const void* A, int32_t lda, const void* B, int32_t ldb,
                void* C, int32_t ldc, const float* bias, int32_t flags, void* stream);
 
+/* Weight gradient of nn.Linear without transposed copies: dW[M,N] (f32) = dY[K,M]^T X[K,N] (+= if accumulate), dY / X bf16
+ * row-major with the reduction index (caption rows / decode steps) as the ROW index, exactly as the backward pass holds
+ * them.  gfx950 transposing LDS reads (csrc/gemm_tn.hip).  Needs M >= 128, M % 8 == 0, N % 128 == 0, K % 64 == 0;
+ * workspace: at least 4*M*N bytes (more lets it split K over workgroups, up to 8 slices). */
+int uic_linear_wgrad(int32_t dtype, int32_t M, int32_t N, int32_t K, const void* dY, int32_t ldy, const void* X, int32_t ldx,
+                     float* dW, int32_t ldw, void* workspace, size_t workspace_bytes, int32_t accumulate, void* stream);
+
 /* nn.LSTMCell (P/models/AttModel.py:426-427,434,441) on the concatenation of up to three inputs:
  * gates = sum_i x_i W_i^T + h W_hh^T + b_ih + b_hh.  x_i [M,K_i] (operand dtype), W_i = weight_ih column block
  * (ldw = row stride of weight_ih).  Outputs: c_out f32 [M,H], h_out operand dtype [M,H], gates_out (optional). */

@@ -319,3 +319,35 @@ def test_library_exports_every_declared_symbol():
     for name in L.EXPORTS:
         assert hasattr(lib, name), name
     assert lib.uic_version() >= 100
+
+
+@pytest.mark.parametrize("M,N,K,ldy,ldx", [(128, 128, 64, 128, 128), (256, 384, 640, 256, 384), (2048, 512, 2560, 2048, 512),
+                                            (1192, 256, 1280, 1216, 320), (512, 2048, 4608, 512, 2048)])
+@pytest.mark.parametrize("accumulate", [0, 1])
+def test_linear_wgrad_tn_matches_matmul(M, N, K, ldy, ldx, accumulate):
+    """dW = dY^T X straight from row-major [K, M] / [K, N] bf16 operands (transposing LDS reads, no transposed copies):
+    exact products, f32 accumulation -> compare with a float64 matmul of the same bf16 values; ragged M (1192), leading
+    dimensions larger than the width, one K round (64) up to 72, split-K chosen from the workspace size."""
+    from unpaired_image_captioning_amd import _lib as L
+    lib = L.load()
+    g = torch.Generator().manual_seed(M + N + K)
+    dY = torch.randn(K, ldy, generator=g).bfloat16()
+    X = torch.randn(K, ldx, generator=g).bfloat16()
+    ref = dY[:, :M].double().t() @ X[:, :N].double()
+    dW0 = torch.randn(M, N, generator=g)
+    dW = dW0.clone().cuda()
+    ws = torch.empty(8 * M * N * 4, dtype=torch.uint8, device="cuda")
+    dYd, Xd = dY.cuda(), X.cuda()
+    L.check(lib.uic_linear_wgrad(L.BF16, M, N, K, L.ptr(dYd), ldy, L.ptr(Xd), ldx, L.ptr(dW), N, L.ptr(ws), ws.numel(), accumulate,
+                                 L.stream()), "linear_wgrad")
+    want = ref + (dW0.double() if accumulate else 0)
+    err = (dW.cpu().double() - want).abs().max().item()
+    assert err <= 2e-5 * max(1.0, want.abs().max().item()) * (K ** 0.5), err
+    # a workspace with room for a single slice only (no split-K) gives the same result up to summation order
+    dW2 = dW0.clone().cuda()
+    ws1 = torch.empty(M * N * 4, dtype=torch.uint8, device="cuda")
+    L.check(lib.uic_linear_wgrad(L.BF16, M, N, K, L.ptr(dYd), ldy, L.ptr(Xd), ldx, L.ptr(dW2), N, L.ptr(ws1), ws1.numel(), accumulate,
+                                 L.stream()), "linear_wgrad")
+    assert (dW2 - dW).abs().max().item() <= 1e-4 * max(1.0, want.abs().max().item())
+    # ineligible shapes are argument errors, not silent fallbacks
+    assert lib.uic_linear_wgrad(L.BF16, M, N, K - 8, L.ptr(dYd), ldy, L.ptr(Xd), ldx, L.ptr(dW), N, L.ptr(ws), ws.numel(), 0, L.stream()) != 0

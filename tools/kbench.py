@@ -35,6 +35,27 @@ def bench_linear(M, N, K, dt=1, flags=4, label=""):
         label, M, N, K, us, fl / us / 1e6, us_ref, fl / us_ref / 1e6), flush=True)
 
 
+def bench_wgrad_tn(M, N, K, label=""):
+    """dW = dY^T X: transposing-read kernel vs (two transposes + NT GEMM) vs torch."""
+    dY = torch.randn(K, M, device="cuda").bfloat16()
+    X = torch.randn(K, N, device="cuda").bfloat16()
+    dW = torch.empty(M, N, device="cuda")
+    ws = torch.empty(8 * M * N * 4, dtype=torch.uint8, device="cuda")
+    us = timeit(lambda: L.check(lib.uic_linear_wgrad(1, M, N, K, L.ptr(dY), M, L.ptr(X), N, L.ptr(dW), N, L.ptr(ws), ws.numel(), 0, L.stream())))
+    dYt = torch.empty(M, K, device="cuda", dtype=torch.bfloat16)
+    Xt = torch.empty(N, K, device="cuda", dtype=torch.bfloat16)
+
+    def old():
+        L.check(lib.uic_transpose(1, L.ptr(dY), K, M, M, L.ptr(dYt), K, L.stream()))
+        L.check(lib.uic_transpose(1, L.ptr(X), K, N, N, L.ptr(Xt), K, L.stream()))
+        L.check(lib.uic_linear(1, M, N, K, L.ptr(dYt), K, L.ptr(Xt), K, L.ptr(dW), N, None, 4, L.stream()))
+    us_old = timeit(old)
+    us_ref = timeit(lambda: torch.matmul(dY.t(), X))
+    fl = 2.0 * M * N * K
+    print("wgrad %-18s M=%5d N=%5d K=%6d  tn %8.1f us %6.1f TF/s | transposes+NT %8.1f us | torch %8.1f us %6.1f TF/s" % (
+        label, M, N, K, us, fl / us / 1e6, us_old, us_ref, fl / us_ref / 1e6), flush=True)
+
+
 def bench_lstm(M, H, Ks, dt=1):
     td = L.TORCH_DTYPE[dt]
     xs = [torch.randn(M, k, device="cuda").to(td) for k in Ks]
@@ -102,6 +123,13 @@ if __name__ == "__main__":
     if which in ("all", "lstm"):
         bench_lstm(640, 512, [512])            # att_lstm recurrent part: K = 512 + 512
         bench_lstm(640, 512, [512, 512])       # lang_lstm: K = 1024 + 512
+    if which in ("all", "tn"):
+        bench_wgrad_tn(2048, 1536, 2560, "lstm chunk")
+        bench_wgrad_tn(2048, 1536, 640, "lstm last chunk")
+        bench_wgrad_tn(512, 512, 2560, "h2att chunk")
+        bench_wgrad_tn(9488, 512, 10880, "logit")
+        bench_wgrad_tn(512, 512, 23040, "ctx2att")
+        bench_wgrad_tn(512, 2048, 23040, "att_embed")
     if which in ("all", "gemm"):
         bench_linear(640, 512, 512, label="h2att fwd")
         bench_linear(640, 1536, 2048, label="dX2")

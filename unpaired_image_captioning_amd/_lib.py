@@ -187,6 +187,8 @@ _SIGS = {
     "uic_topdown_workspace_ptr": (C.c_void_p, [C.POINTER(Dims), C.c_void_p, C.c_char_p]),
     "uic_linear": (C.c_int, [C.c_int32] * 4 + [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32,
                              C.c_void_p, C.c_int32, C.c_void_p]),
+    "uic_linear_wgrad": (C.c_int, [C.c_int32] * 4 + [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32,
+                                   C.c_void_p, C.c_size_t, C.c_int32, C.c_void_p]),
     "uic_lstm_cell_fwd": (C.c_int, [C.c_int32] * 4 + [C.POINTER(C.c_void_p), C.POINTER(C.c_int32), C.POINTER(C.c_void_p),
                                     C.POINTER(C.c_int32)] + [C.c_void_p] * 9),
     "uic_lstm_cell_bwd": (C.c_int, [C.c_int32] * 3 + [C.c_void_p] * 7),

@@ -1,5 +1,6 @@
 // extern "C" surface of libuic_hip.so for the single operators + error reporting.
 #include "uic_common.h"
+#include "uic_host.h"
 #include "../../include/uic_hip.h"
 #include <stdarg.h>
 #include <stdio.h>
@@ -94,6 +95,19 @@ int uic_linear(int32_t dtype, int32_t M, int32_t N, int32_t K, const void* A, in
   g.seg[0].A = A; g.seg[0].B = B; g.seg[0].K = K; g.seg[0].lda = lda; g.seg[0].ldb = ldb;
   g.C = C; g.ldc = ldc; g.bias = bias; g.flags = flags;
   return uic_gemm_launch(g, (hipStream_t)stream);
+}
+
+int uic_linear_wgrad(int32_t dtype, int32_t M, int32_t N, int32_t K, const void* dY, int32_t ldy, const void* X, int32_t ldx,
+                     float* dW, int32_t ldw, void* workspace, size_t workspace_bytes, int32_t accumulate, void* stream) {
+  UIC_REQUIRE(dY && X && dW && workspace, "linear_wgrad: null pointer");
+  UIC_REQUIRE(dtype == UIC_BF16, "linear_wgrad: the transposing-read kernel is bf16 only (dtype=%d)", dtype);
+  const WDest d1{dW, ldw, 0, N};
+  const UicGemmTnSeg seg{X, ldx, N};
+  bool done = false;
+  UIC_TRY(wgrad_tn((float*)workspace, workspace_bytes, dtype, dY, ldy, M, &seg, 1, K, &d1, 1, (hipStream_t)stream, accumulate != 0, &done));
+  UIC_REQUIRE(done, "linear_wgrad: shape M=%d N=%d K=%d not eligible (needs M >= 128, M %% 8 == 0, N %% 128 == 0, K %% 64 == 0, "
+                    "16-byte aligned rows) or workspace of %zu bytes too small", M, N, K, workspace_bytes);
+  return UIC_OK;
 }
 
 int uic_lstm_cell_fwd(int32_t dtype, int32_t M, int32_t H, int32_t nx, const void* const* x, const int32_t* Kx,

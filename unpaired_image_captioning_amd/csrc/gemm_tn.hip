@@ -1,0 +1,204 @@
+// "TN" MFMA GEMM for gfx950 (bf16):  C[i, j] = sum_k A[k, i] * B[k, j]   -- both operands stored with the REDUCTION
+// index as their row index.  This is the shape of every weight gradient of the hot path,
+//     dW = dG^T X      (dG [rows, out], X [rows, in], rows = decode steps x captions or captions x regions),
+// i.e. the backward of the nn.Linear / nn.LSTMCell call sites of P/models/AttModel.py:76-92,426-441,543.  With
+// K-contiguous ("NT") kernels only, both operands had to be transposed through HBM first (64 transpose launches and
+// 0.85 ms per training step); here the tiles are staged exactly as they lie in memory and the transposition happens in
+// the LDS read: gfx950's ds_read_b64_tr_b16 hands every lane the 4 k-consecutive elements of ITS column, so two of them
+// build the 8-element bf16 MFMA operand.
+//
+//  * 128 x 128 output tile per workgroup of 4 waves (2 x 2, 64 x 64 each = 2 x 2 MFMA 32x32x16 tiles), 64 k-rows per
+//    round, double-buffered LDS (2 x 32 KB), operands staged with 16-byte global_load_lds DMA (no VGPR round trip).
+//  * LDS image of a staged tile: [64 k][128 columns] rows of 256 B; 16-byte chunk ch of row r sits at
+//    256 r + 16 (ch ^ (((r & 3) << 2) | ((r >> 2) & 3))) -- the XOR keeps the transposed reads bank-conflict free.  The
+//    DMA writes LDS lane-linearly, so the XOR is applied on the SOURCE side: lane (row, slot) fetches chunk slot ^ f(row).
+//  * B may be up to 4 column segments living in different matrices ([ctx | h_att | h_lang] of the LSTM weight
+//    gradients): torch.cat is never materialised on this side either.
+//  * Output: raw f32 partial tiles into slab[z][M][N] (split-K over blockIdx.z); uic_splitk_reduce_launch sums the
+//    slices in a fixed order and scatters column ranges to their destinations (deterministic).
+#include "uic_common.h"
+#include <type_traits>
+
+namespace {
+
+typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
+typedef __attribute__((ext_vector_type(4))) unsigned u32x4v;
+
+__global__ __launch_bounds__(256) void uic_gemm_tn_kernel(const UicGemmTnParams p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];   // [2][A 16 KB | B 16 KB]
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  const int half = lane >> 5, r32 = lane & 31;
+
+  const int m0 = blockIdx.x * 128, n0 = blockIdx.y * 128;
+  // column segment of this tile (uniform): segments are multiples of 128 columns wide
+  int sidx = 0, c0 = n0;
+  while (sidx + 1 < p.nseg && c0 >= p.seg[sidx].ncols) { c0 -= p.seg[sidx].ncols; ++sidx; }
+  const char* Bbase = (const char*)p.seg[sidx].B;
+  const int ldb = p.seg[sidx].ldb, ncolsB = p.seg[sidx].ncols;
+
+  // per-lane source pointers of this wave's 4 A and 4 B LDS-DMA instructions per round (4 k-rows of 256 B each)
+  const char* srcA[4];
+  const char* srcB[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int r = (wave * 4 + i) * 4 + (lane >> 4);
+    const int f = ((r & 3) << 2) | ((r >> 2) & 3);
+    const int ch = (lane & 15) ^ f;
+    const int colA = min(m0 + ch * 8, p.M - 8);
+    const int colB = min(c0 + ch * 8, ncolsB - 8);
+    srcA[i] = (const char*)p.A + ((size_t)r * p.lda + colA) * 2;
+    srcB[i] = Bbase + ((size_t)r * ldb + colB) * 2;
+  }
+  const size_t strideA = (size_t)64 * p.lda * 2, strideB = (size_t)64 * ldb * 2;
+  auto stage = [&](int kt, int buf) {
+    char* dA = smem + buf * 32768 + wave * 4096;
+    char* dB = dA + 16384;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(srcA[i] + (size_t)kt * strideA),
+                                       (__attribute__((address_space(3))) void*)(dA + i * 1024), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(srcB[i] + (size_t)kt * strideB),
+                                       (__attribute__((address_space(3))) void*)(dB + i * 1024), 16, 0, 0);
+    }
+  };
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int k = 0; k < 16; ++k) acc[i][j][k] = 0.f;
+
+  int kt0 = 0, nt = p.K / 64;
+  if (p.splitk > 1) {
+    const int tps = (nt + p.splitk - 1) / p.splitk;
+    kt0 = blockIdx.z * tps;
+    nt = max(0, min(nt - kt0, tps));
+  }
+
+  // Transposed fragment reads.  16-lane group g of the wave: k half = g >> 1 (MFMA lanes 0-31 carry k 0..7, lanes 32-63
+  // k 8..15 of a 16-k step), column block = g & 1 (columns 0-15 / 16-31 of the 32-wide operand tile).  Inside the group
+  // lane 4q + pp supplies the address of block row q, columns 4pp..4pp+3 and RECEIVES column (lane & 15), rows 0..3.
+  // Read h (0 / 1) covers k rows 4h .. 4h+3 of the lane's 8.  The swizzle term depends on (q, k half, h) only, so the
+  // K step is an immediate offset (4096 B per 16 k-rows) and so is the stage buffer (32768 B).
+  const int g = lane >> 4, khalf = g >> 1, colblk = g & 1, q = (lane & 15) >> 2, pp = lane & 3;
+  const unsigned lds0 = (unsigned)(size_t)((__attribute__((address_space(3))) char*)smem);
+  unsigned adA[2][2], adB[2][2];
+#pragma unroll
+  for (int ti = 0; ti < 2; ++ti)
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int r = khalf * 8 + h * 4 + q;
+      const int f = (q << 2) | (khalf * 2 + h);
+      const int ca = ((wm * 64 + ti * 32 + colblk * 16) >> 3) + (pp >> 1);
+      const int cb = ((wn * 64 + ti * 32 + colblk * 16) >> 3) + (pp >> 1);
+      adA[ti][h] = lds0 + (unsigned)(256 * r + 16 * (ca ^ f) + 8 * (pp & 1));
+      adB[ti][h] = lds0 + 16384u + (unsigned)(256 * r + 16 * (cb ^ f) + 8 * (pp & 1));
+    }
+
+#define TN_RD(dst, addr, off) asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(off))
+#define TN_ISSUE_A(S, KS, BO)                                                             \
+  TN_RD(S##a0l, adA[0][0], BO + KS * 4096); TN_RD(S##a0h, adA[0][1], BO + KS * 4096);     \
+  TN_RD(S##a1l, adA[1][0], BO + KS * 4096); TN_RD(S##a1h, adA[1][1], BO + KS * 4096)
+#define TN_ISSUE_B(S, KS, BO)                                                             \
+  TN_RD(S##b0l, adB[0][0], BO + KS * 4096); TN_RD(S##b0h, adB[0][1], BO + KS * 4096);     \
+  TN_RD(S##b1l, adB[1][0], BO + KS * 4096); TN_RD(S##b1h, adB[1][1], BO + KS * 4096)
+#define TN_WAIT(N, S)                                                                                              \
+  asm volatile("s_waitcnt lgkmcnt(" #N ")"                                                                         \
+               : "+v"(S##a0l), "+v"(S##a0h), "+v"(S##a1l), "+v"(S##a1h), "+v"(S##b0l), "+v"(S##b0h), "+v"(S##b1l), "+v"(S##b1h)); \
+  __builtin_amdgcn_sched_barrier(0)
+#define TN_OP(lo, hi) __builtin_bit_cast(bf16x8, (u32x4v){lo.x, lo.y, hi.x, hi.y})
+#define TN_MFMA4(S)                                                                                                          \
+  do {                                                                                                                       \
+    acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(TN_OP(S##a0l, S##a0h), TN_OP(S##b0l, S##b0h), acc[0][0], 0, 0, 0);   \
+    acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(TN_OP(S##a0l, S##a0h), TN_OP(S##b1l, S##b1h), acc[0][1], 0, 0, 0);   \
+    acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(TN_OP(S##a1l, S##a1h), TN_OP(S##b0l, S##b0h), acc[1][0], 0, 0, 0);   \
+    acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(TN_OP(S##a1l, S##a1h), TN_OP(S##b1l, S##b1h), acc[1][1], 0, 0, 0);   \
+  } while (0)
+  // two register sets (x: even K steps, y: odd); at most 12 LDS reads outstanding (lgkmcnt is a 4-bit counter)
+  auto compute = [&](auto bufc) {
+    constexpr int BO = decltype(bufc)::value * 32768;
+    u32x2 xa0l, xa0h, xa1l, xa1h, xb0l, xb0h, xb1l, xb1h, ya0l, ya0h, ya1l, ya1h, yb0l, yb0h, yb1l, yb1h;
+    TN_ISSUE_A(x, 0, BO); TN_ISSUE_B(x, 0, BO);
+    TN_ISSUE_A(y, 1, BO);
+    TN_WAIT(4, x);
+    TN_MFMA4(x);
+    TN_ISSUE_B(y, 1, BO);
+    TN_ISSUE_A(x, 2, BO);
+    TN_WAIT(4, y);
+    TN_MFMA4(y);
+    TN_ISSUE_B(x, 2, BO);
+    TN_ISSUE_A(y, 3, BO);
+    TN_WAIT(4, x);
+    TN_MFMA4(x);
+    TN_ISSUE_B(y, 3, BO);
+    TN_WAIT(0, y);
+    TN_MFMA4(y);
+  };
+#undef TN_MFMA4
+#undef TN_OP
+#undef TN_WAIT
+#undef TN_ISSUE_B
+#undef TN_ISSUE_A
+#undef TN_RD
+  if (nt > 0) stage(kt0, 0);
+  for (int t = 0; t < nt; t += 2) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (t + 1 < nt) stage(kt0 + t + 1, 1);
+    compute(std::integral_constant<int, 0>{});
+    if (t + 1 < nt) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      if (t + 2 < nt) stage(kt0 + t + 2, 0);
+      compute(std::integral_constant<int, 1>{});
+    }
+  }
+
+  // C/D layout of the 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
+  float* slab = p.slab + (size_t)blockIdx.z * p.M * p.N;
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int col = n0 + (wn * 2 + j) * 32 + r32;
+      if (col >= p.N) continue;
+#pragma unroll
+      for (int reg = 0; reg < 16; ++reg) {
+        const int row = m0 + (wm * 2 + i) * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * half;
+        if (row < p.M) slab[(size_t)row * p.N + col] = acc[i][j][reg];
+      }
+    }
+}
+
+}  // namespace
+
+bool uic_gemm_tn_eligible(const UicGemmTnParams& p) {
+  if (p.M < 128 || p.N < 128 || p.K < 64 || p.K % 64 != 0 || p.M % 8 != 0 || p.lda % 8 != 0) return false;
+  if (p.nseg < 1 || p.nseg > UIC_GEMM_TN_MAX_SEG || ((uintptr_t)p.A & 15)) return false;
+  int n = 0;
+  for (int i = 0; i < p.nseg; ++i) {
+    if (p.seg[i].ncols % 128 != 0 || p.seg[i].ldb % 8 != 0 || ((uintptr_t)p.seg[i].B & 15) || !p.seg[i].B) return false;
+    n += p.seg[i].ncols;
+  }
+  return n == p.N;
+}
+
+int uic_gemm_tn_launch(const UicGemmTnParams& p, hipStream_t s) {
+  UIC_REQUIRE(uic_gemm_tn_eligible(p), "gemm_tn: shape M=%d N=%d K=%d not eligible (K %% 64, segment widths %% 128, 16-byte alignment)", p.M, p.N, p.K);
+  UIC_REQUIRE(p.slab && p.splitk >= 1, "gemm_tn: needs a slab and splitk >= 1");
+  static bool configured = false;
+  if (!configured) {
+    UIC_TRY(uic_check_hip(hipFuncSetAttribute((const void*)uic_gemm_tn_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 65536),
+                          "hipFuncSetAttribute(gemm tn)"));
+    configured = true;
+  }
+  dim3 grid((p.M + 127) / 128, (p.N + 127) / 128, p.splitk);
+  hipLaunchKernelGGL(uic_gemm_tn_kernel, grid, dim3(256), 65536, s, p);
+  UIC_LAUNCH_CHECK("uic_gemm_tn_kernel");
+  return UIC_OK;
+}

@@ -40,7 +40,6 @@ struct Layout {
   float* slab; size_t slab_bytes;
   void* tLA; void* tLB; float* colscratchL;   // scratch of the logit-layer weight gradients (side stream)
   void* tSA; void* tSB; float* slab2;         // scratch of the per-chunk recurrent weight gradients (side stream)
-  void* attinT; void* attpT;                  // [D, NR^8], [H, NR^8]: transposed att_embed input / output, made once per step
   // sampling
   void* s_h_att[2]; void* s_h_lang[2]; float* s_c_att[2]; float* s_c_lang[2];
   void* s_xt; float* s_atth; float* s_alpha; void* s_ctx; void* s_hdrop; float* s_logits;
@@ -130,8 +129,6 @@ Layout make_layout(const uic_topdown_dims& d, void* ws) {
     if (Dfc > rb) rb = Dfc;
     L.tSA = b.take(4 * H * Kc * S);
     L.tSB = b.take(rb * Kc * S);
-    L.attinT = b.take(D * NRp * S);
-    L.attpT = b.take(H * NRp * S);
   }
   {  // split-K partial slabs: room for 4 slices of the largest merged weight gradient [4H, 2H + E]
     size_t sl = 4 * (4 * H) * (2 * H + E) * 4;
@@ -391,7 +388,7 @@ void* uic_topdown_workspace_ptr(const uic_topdown_dims* d, void* workspace, cons
   if (check_dims(d) || !workspace || !name) return nullptr;
   const Layout L = make_layout(*d, workspace);
   struct { const char* n; void* p; } tab[] = {
-      {"tok_used", L.tok_used}, {"attinT", L.attinT}, {"attpT", L.attpT}, {"d_pre", L.d_pre}, {"fc_embed", L.fcp}, {"att_embed", L.attp}, {"p_att", L.patt}, {"xt", L.xt_all}, {"gx", L.gx}, {"gfc", L.gfc},
+      {"tok_used", L.tok_used}, {"d_pre", L.d_pre}, {"fc_embed", L.fcp}, {"att_embed", L.attp}, {"p_att", L.patt}, {"xt", L.xt_all}, {"gx", L.gx}, {"gfc", L.gfc},
       {"h_att", L.h_att}, {"h_lang", L.h_lang}, {"c_att", L.c_att}, {"c_lang", L.c_lang}, {"gates1", L.gates1},
       {"gates2", L.gates2}, {"att_h", L.atth_all}, {"alpha", L.alpha_all}, {"ctx", L.ctx_all}, {"hdrop", L.hdrop_all},
       {"logits", L.logits}, {"dlogits", L.dlogits}, {"row_loss", L.row_loss}, {"scalars", L.scalars},
@@ -609,13 +606,12 @@ struct Step {
                        &d1, 1, s);
   }
   // d W_logit, d b_logit over all executed steps (own scratch buffers: may run beside the BPTT loop)
-  int logit_weight_grads(hipStream_t s) {
-    UIC_TRY(uic_transpose_launch(dt, L.dlogits, Meff, V1, V1p, L.tLA, Mp, s));
-    UIC_TRY(uic_transpose_launch(dt, L.hdrop_all, Meff, H, H, L.tLB, Mp, s));
-    UicGemmParams g = gemm_base(dt, V1, H);
-    add_seg(g, L.tLA, Mp, L.tLB, Mp, Mp);
-    g.C = G->logit_w; g.ldc = H; g.flags = UIC_GEMM_OUT_F32;
-    UIC_TRY(uic_gemm_launch(g, s));
+  int logit_weight_grads(hipStream_t s, bool side = false) {
+    {
+      const UicGemmTnSeg seg{L.hdrop_all, H, H};
+      const WDest d1{G->logit_w, H, 0, H};
+      UIC_TRY(wgrad_group(side ? L.slab2 : L.slab, L.dlogits, V1p, V1, &seg, 1, Meff, &d1, 1, s, false, L.tLA, L.tLB));
+    }
     return uic_colsum_launch(dt, L.dlogits, Meff, V1, V1p, G->logit_b, L.colscratchL, L.colscratch_floats, s);
   }
 
@@ -695,41 +691,48 @@ struct Step {
     const WDest d1{C, ldc, 0, rrows};
     return wgrad_multi(L.slab, L.slab_bytes, dt, left, lrows, right, rrows, K, &d1, 1, s);
   }
-  // transposes that depend on the feature projection only: done once, early, beside the recurrence (fused step)
-  int hoist_transposes(hipStream_t s) {
-    UIC_TRY(uic_transpose_launch(dt, L.attp, NR, H, H, L.attpT, NRp, s));
-    return uic_transpose_launch(dt, att_in, NR, D, D, L.attinT, NRp, s);
+  // One group of weight gradients sharing the left operand:  C_i = A[rows, lrows]^T * [B_0 | B_1 | ...][rows, cols].
+  // bf16 on eligible shapes: gemm_tn.hip reads both operands as they lie (transposing LDS reads).  Otherwise (f32 parity
+  // path, odd sizes): transposed copies into tA / tB and the NT kernels (wgrad_multi).
+  int wgrad_group(float* slab, const void* A, int lda, int lrows, const UicGemmTnSeg* segs, int nseg, int rows, const WDest* dst,
+                  int nd, hipStream_t s, bool accumulate, void* tA, void* tB) {
+    bool done = false;
+    UIC_TRY(wgrad_tn(slab, L.slab_bytes, dt, A, lda, lrows, segs, nseg, rows, dst, nd, s, accumulate, &done));
+    if (done) return UIC_OK;
+    const int Kp = (int)rup8(rows);
+    UIC_TRY(uic_transpose_launch(dt, A, rows, lrows, lda, tA, Kp, s));
+    int col = 0;
+    for (int i = 0; i < nseg; ++i) {
+      UIC_TRY(uic_transpose_launch(dt, segs[i].B, rows, segs[i].ncols, segs[i].ldb, offw(tB, (size_t)col * Kp, dt), Kp, s));
+      col += segs[i].ncols;
+    }
+    return wgrad_multi(slab, L.slab_bytes, dt, tA, lrows, tB, col, Kp, dst, nd, s, accumulate);
   }
 
   // recurrent weight gradients (both LSTMs' weights and h2att) restricted to decode steps [t0, t1): one chunk of the
   // stacked-row GEMMs, accumulated into G unless `first`.  Used by the fused step on the side stream, chunk by chunk
   // behind the BPTT loop, so that only the last chunk's share is left when the loop ends.
   int wgrad_chunk(int t0, int t1, bool first, hipStream_t s) {
-    const int rows = (t1 - t0) * N, Kp = (int)rup8(rows);
+    const int rows = (t1 - t0) * N;
     const size_t r0 = (size_t)t0 * N;
-    // lang_lstm: dG2^T x [att_res | h_att | h_lang_prev]
-    UIC_TRY(uic_transpose_launch(dt, off(L.dg2_all, r0 * H4, dt), rows, H4, H4, L.tSA, Kp, s));
-    UIC_TRY(uic_transpose_launch(dt, off(L.ctx_all, r0 * H, dt), rows, H, H, L.tSB, Kp, s));
-    UIC_TRY(uic_transpose_launch(dt, off(L.h_att, NH + r0 * H, dt), rows, H, H, offw(L.tSB, (size_t)H * Kp, dt), Kp, s));
-    UIC_TRY(uic_transpose_launch(dt, off(L.h_lang, r0 * H, dt), rows, H, H, offw(L.tSB, (size_t)2 * H * Kp, dt), Kp, s));
-    {
+    const void* ctx = off(L.ctx_all, r0 * H, dt);
+    const void* h_att_new = off(L.h_att, NH + r0 * H, dt);
+    const void* h_att_prev = off(L.h_att, r0 * H, dt);
+    const void* h_lang_prev = off(L.h_lang, r0 * H, dt);
+    {  // lang_lstm: dG2^T x [att_res | h_att | h_lang_prev]
+      const UicGemmTnSeg segs[3] = {{ctx, H, H}, {h_att_new, H, H}, {h_lang_prev, H, H}};
       const WDest dd[2] = {{G->lang_lstm_w_ih, 2 * H, 0, 2 * H}, {G->lang_lstm_w_hh, H, 2 * H, H}};
-      UIC_TRY(wgrad_multi(L.slab2, L.slab_bytes, dt, L.tSA, H4, L.tSB, 3 * H, Kp, dd, 2, s, !first));
+      UIC_TRY(wgrad_group(L.slab2, off(L.dg2_all, r0 * H4, dt), H4, H4, segs, 3, rows, dd, 2, s, !first, L.tSA, L.tSB));
     }
-    // h2att: d_att_h^T x h_att   (tSB rows [H, 2H) still hold h_att^T)
-    UIC_TRY(uic_transpose_launch(dt, off(L.datth_all, r0 * A, dt), rows, A, A, L.tSA, Kp, s));
-    {
+    {  // h2att: d_att_h^T x h_att
+      const UicGemmTnSeg seg{h_att_new, H, H};
       const WDest d1{G->h2att_w, H, 0, H};
-      UIC_TRY(wgrad_multi(L.slab2, L.slab_bytes, dt, L.tSA, A, off(L.tSB, (size_t)H * Kp, dt), H, Kp, &d1, 1, s, !first));
+      UIC_TRY(wgrad_group(L.slab2, off(L.datth_all, r0 * A, dt), A, A, &seg, 1, rows, &d1, 1, s, !first, L.tSA, L.tSB));
     }
-    // att_lstm: dG1^T x [h_lang_prev | xt | h_att_prev]
-    UIC_TRY(uic_transpose_launch(dt, off(L.dg1_all, r0 * H4, dt), rows, H4, H4, L.tSA, Kp, s));
-    UIC_TRY(uic_transpose_launch(dt, off(L.h_lang, r0 * H, dt), rows, H, H, L.tSB, Kp, s));
-    UIC_TRY(uic_transpose_launch(dt, off(L.xt_all, r0 * E, dt), rows, E, E, offw(L.tSB, (size_t)H * Kp, dt), Kp, s));
-    UIC_TRY(uic_transpose_launch(dt, off(L.h_att, r0 * H, dt), rows, H, H, offw(L.tSB, (size_t)(H + E) * Kp, dt), Kp, s));
-    {
+    {  // att_lstm: dG1^T x [h_lang_prev | xt | h_att_prev]
+      const UicGemmTnSeg segs[3] = {{h_lang_prev, H, H}, {off(L.xt_all, r0 * E, dt), E, E}, {h_att_prev, H, H}};
       const WDest dd[3] = {{G->att_lstm_w_ih, ldih, 0, H}, {G->att_lstm_w_ih + 2 * H, ldih, H, E}, {G->att_lstm_w_hh, H, H + E, H}};
-      UIC_TRY(wgrad_multi(L.slab2, L.slab_bytes, dt, L.tSA, H4, L.tSB, 2 * H + E, Kp, dd, 3, s, !first));
+      UIC_TRY(wgrad_group(L.slab2, off(L.dg1_all, r0 * H4, dt), H4, H4, segs, 3, rows, dd, 3, s, !first, L.tSA, L.tSB));
     }
     return UIC_OK;
   }
@@ -749,23 +752,17 @@ struct Step {
       UIC_TRY(uic_colsum_launch(dt, L.datth_all, Meff, A, A, G->h2att_b, colscratch, L.colscratch_floats, s));
     // per LSTM ONE GEMM dG^T [4H, T*N] x [stacked inputs]^T; lang_lstm inputs [att_res | h_att | h_lang_prev]
     if (!chunked) {
-      UIC_TRY(uic_transpose_launch(dt, L.dg2_all, Meff, H4, H4, tA, Mp, s));
-      UIC_TRY(uic_transpose_launch(dt, L.ctx_all, Meff, H, H, tB, Mp, s));
-      UIC_TRY(uic_transpose_launch(dt, off(L.h_att, NH, dt), Meff, H, H, offw(tB, (size_t)H * Mp, dt), Mp, s));
-      UIC_TRY(uic_transpose_launch(dt, L.h_lang, Meff, H, H, offw(tB, (size_t)2 * H * Mp, dt), Mp, s));
+      const UicGemmTnSeg segs[3] = {{L.ctx_all, H, H}, {off(L.h_att, NH, dt), H, H}, {L.h_lang, H, H}};
       const WDest dd[2] = {{G->lang_lstm_w_ih, 2 * H, 0, 2 * H}, {G->lang_lstm_w_hh, H, 2 * H, H}};
-      UIC_TRY(wgrad_multi(slab, L.slab_bytes, dt, tA, H4, tB, 3 * H, Mp, dd, 2, s));
+      UIC_TRY(wgrad_group(slab, L.dg2_all, H4, H4, segs, 3, Meff, dd, 2, s, false, tA, tB));
     }
     UIC_TRY(uic_colsum_launch(dt, L.dg2_all, Meff, H4, H4, G->lang_lstm_b_ih, colscratch, L.colscratch_floats, s));
     UIC_TRY(uic_check_hip(hipMemcpyAsync(G->lang_lstm_b_hh, G->lang_lstm_b_ih, (size_t)H4 * 4, hipMemcpyDeviceToDevice, s), "memcpy b_hh"));
     // att_lstm inputs [h_lang_prev | xt | h_att_prev]  (the fc' columns are handled below from dGfc)
     if (!chunked) {
-      UIC_TRY(uic_transpose_launch(dt, L.dg1_all, Meff, H4, H4, tA, Mp, s));
-      UIC_TRY(uic_transpose_launch(dt, L.h_lang, Meff, H, H, tB, Mp, s));
-      UIC_TRY(uic_transpose_launch(dt, L.xt_all, Meff, E, E, offw(tB, (size_t)H * Mp, dt), Mp, s));
-      UIC_TRY(uic_transpose_launch(dt, L.h_att, Meff, H, H, offw(tB, (size_t)(H + E) * Mp, dt), Mp, s));
+      const UicGemmTnSeg segs[3] = {{L.h_lang, H, H}, {L.xt_all, E, E}, {L.h_att, H, H}};
       const WDest dd[3] = {{G->att_lstm_w_ih, ldih, 0, H}, {G->att_lstm_w_ih + 2 * H, ldih, H, E}, {G->att_lstm_w_hh, H, H + E, H}};
-      UIC_TRY(wgrad_multi(slab, L.slab_bytes, dt, tA, H4, tB, 2 * H + E, Mp, dd, 3, s));
+      UIC_TRY(wgrad_group(slab, L.dg1_all, H4, H4, segs, 3, Meff, dd, 3, s, false, tA, tB));
     }
     UIC_TRY(uic_colsum_launch(dt, L.dg1_all, Meff, H4, H4, G->att_lstm_b_ih, colscratch, L.colscratch_floats, s));
     UIC_TRY(uic_check_hip(hipMemcpyAsync(G->att_lstm_b_hh, G->att_lstm_b_ih, (size_t)H4 * 4, hipMemcpyDeviceToDevice, s), "memcpy b_hh"));
@@ -780,9 +777,11 @@ struct Step {
     }
     // fc' path: dGfc = sum_t dG1_t
     UIC_TRY(uic_sum_steps_launch(dt, L.dg1_all, t_run, (size_t)N * H4, L.dgfc, s));
-    UIC_TRY(uic_transpose_launch(dt, L.dgfc, N, H4, H4, tA, Np, s));
-    UIC_TRY(uic_transpose_launch(dt, L.fcp, N, H, H, tB, Np, s));
-    UIC_TRY(wgrad(tA, H4, tB, H, Np, G->att_lstm_w_ih + H, ldih));
+    {
+      const UicGemmTnSeg seg{L.fcp, H, H};
+      const WDest d1{G->att_lstm_w_ih + H, ldih, 0, H};
+      UIC_TRY(wgrad_group(slab, L.dgfc, H4, H4, &seg, 1, N, &d1, 1, s, false, tA, tB));
+    }
     {
       UicGemmParams g = gemm_base(dt, N, H);
       add_seg(g, L.dgfc, H4, dv.wfcpT, H4, H4);
@@ -790,9 +789,11 @@ struct Step {
       UIC_TRY(uic_gemm_launch(g, s));
     }
     UIC_TRY(uic_relu_mask_bwd_launch(dt, L.dfcp, L.fcp, inv_keep, L.dfcpre, NH, s));
-    UIC_TRY(uic_transpose_launch(dt, L.dfcpre, N, H, H, tA, Np, s));
-    UIC_TRY(uic_transpose_launch(dt, fc_in, N, Dfc, Dfc, tB, Np, s));
-    UIC_TRY(wgrad(tA, H, tB, Dfc, Np, G->fc_w, Dfc));
+    {
+      const UicGemmTnSeg seg{fc_in, Dfc, Dfc};
+      const WDest d1{G->fc_w, Dfc, 0, Dfc};
+      UIC_TRY(wgrad_group(slab, L.dfcpre, H, H, &seg, 1, N, &d1, 1, s, false, tA, tB));
+    }
     UIC_TRY(uic_colsum_launch(dt, L.dfcpre, N, H, H, G->fc_b, colscratch, L.colscratch_floats, s));
     return UIC_OK;
   }
@@ -804,9 +805,9 @@ struct Step {
     };
     // h2att
     if (!chunked && part != 1) {
-      UIC_TRY(uic_transpose_launch(dt, L.datth_all, Meff, A, A, L.tA, Mp, s));
-      UIC_TRY(uic_transpose_launch(dt, off(L.h_att, NH, dt), Meff, H, H, L.tB, Mp, s));
-      UIC_TRY(wgrad(L.tA, A, L.tB, H, Mp, G->h2att_w, H));
+      const UicGemmTnSeg seg{off(L.h_att, NH, dt), H, H};
+      const WDest d1{G->h2att_w, H, 0, H};
+      UIC_TRY(wgrad_group(L.slab, L.datth_all, A, A, &seg, 1, Meff, &d1, 1, s, false, L.tA, L.tB));
       UIC_TRY(uic_colsum_launch(dt, L.datth_all, Meff, A, A, G->h2att_b, L.colscratch, L.colscratch_floats, s));
     }
     if (part != 2) {  // attention: deferred accumulation over steps
@@ -824,9 +825,11 @@ struct Step {
     }
     if (part == 1) return UIC_OK;
     // ctx2att
-    UIC_TRY(uic_transpose_launch(dt, L.d_patt, NR, A, A, L.tA, NRp, s));
-    if (!chunked) UIC_TRY(uic_transpose_launch(dt, L.attp, NR, H, H, L.attpT, NRp, s));   // fused step: hoisted
-    UIC_TRY(wgrad(L.tA, A, L.attpT, H, NRp, G->ctx2att_w, H));
+    {
+      const UicGemmTnSeg seg{L.attp, H, H};
+      const WDest d1{G->ctx2att_w, H, 0, H};
+      UIC_TRY(wgrad_group(L.slab, L.d_patt, A, A, &seg, 1, NR, &d1, 1, s, false, L.tA, L.tB));
+    }
     UIC_TRY(uic_colsum_launch(dt, L.d_patt, NR, A, A, G->ctx2att_b, L.colscratch, L.colscratch_floats, s));
     {
       UicGemmParams g = gemm_base(dt, NR, H);
@@ -843,9 +846,11 @@ struct Step {
       act = L.ybn;
     }
     UIC_TRY(uic_relu_mask_bwd_launch(dt, L.d_att, act, inv_keep, L.d_pre, (size_t)NR * H, s));
-    UIC_TRY(uic_transpose_launch(dt, L.d_pre, NR, H, H, L.tA, NRp, s));
-    if (!chunked) UIC_TRY(uic_transpose_launch(dt, att_in, NR, D, D, L.attinT, NRp, s));    // fused step: hoisted
-    UIC_TRY(wgrad(L.tA, H, L.attinT, D, NRp, G->att_w, D));
+    {
+      const UicGemmTnSeg seg{att_in, D, D};
+      const WDest d1{G->att_w, D, 0, D};
+      UIC_TRY(wgrad_group(L.slab, L.d_pre, H, H, &seg, 1, NR, &d1, 1, s, false, L.tA, L.tB));
+    }
     UIC_TRY(uic_colsum_launch(dt, L.d_pre, NR, H, H, G->att_b, L.colscratch, L.colscratch_floats, s));
     if (d.use_bn) {        // G->att_w holds dW' = d_pre^T xhat: unfold the BatchNorm1d(D) affine part (batchnorm.hip)
       UIC_REQUIRE(G->att_bn0_w && G->att_bn0_b, "backward: use_bn needs gradient tensors for att_embed.0");
@@ -947,9 +952,6 @@ int uic_topdown_xe_train_step(const uic_topdown_dims* d, const uic_topdown_weigh
   UIC_HIP(hipEventRecord(ss->ev_den, s));
   UIC_HIP(hipStreamWaitEvent(s2, ss->ev_den, 0));
   UIC_TRY(st.fwd_prologue(s));
-  UIC_HIP(hipEventRecord(ss->ev_den, s));             // (re-used: the features are projected)
-  UIC_HIP(hipStreamWaitEvent(s2, ss->ev_den, 0));
-  UIC_TRY(st.hoist_transposes(s2));
   UIC_TRY(wait_refresh(s));                           // the recurrence needs the side-stream half of the weight refresh
   for (int c = 0; c < nchunk; ++c) {
     const int t0 = c * CH, t1 = t0 + CH < t_run ? t0 + CH : t_run;
@@ -963,7 +965,7 @@ int uic_topdown_xe_train_step(const uic_topdown_dims* d, const uic_topdown_weigh
     UIC_HIP(hipEventRecord(ss->ev_side[c], s2));
   }
   // side: logit-layer weight gradients + loss reduction, beside the BPTT loop
-  UIC_TRY(st.logit_weight_grads(s2));
+  UIC_TRY(st.logit_weight_grads(s2, true));
   UIC_TRY(uic_reduce_sum_launch(st.L.row_loss, (size_t)t_run * d->N, 0.f, inv, loss_out, s2));
   if (den_out) UIC_HIP(hipMemcpyAsync(den_out, st.L.scalars, 4, hipMemcpyDeviceToDevice, s2));
   // main: BPTT, each step waits for the d hdrop rows of its chunk; side: the recurrent weight gradients of every

@@ -187,6 +187,19 @@ bool uic_gemm_glds_eligible(int dtype, int K);
 
 int uic_gemm_launch(const UicGemmParams& p, hipStream_t stream);
 
+// ---------------------------------------------------------------- TN GEMM (gemm_tn.hip): C[i,j] = sum_k A[k,i] B[k,j]
+#define UIC_GEMM_TN_MAX_SEG 4
+struct UicGemmTnSeg { const void* B; int ldb; int ncols; };   // [K, ncols] bf16 row-major; ncols % 128 == 0
+struct UicGemmTnParams {
+  const void* A; int lda;       // [K, M] bf16 row-major
+  int M, N, K;                  // N = sum of the segments' ncols; K % 64 == 0
+  int nseg;
+  UicGemmTnSeg seg[UIC_GEMM_TN_MAX_SEG];
+  int splitk; float* slab;      // raw f32 partial tiles: slab[z][M][N]
+};
+bool uic_gemm_tn_eligible(const UicGemmTnParams& p);
+int uic_gemm_tn_launch(const UicGemmTnParams& p, hipStream_t s);
+
 // ---------------------------------------------------------------- attention (attention.hip)
 struct UicAttnParams {
   int dtype, N, R, A, H;

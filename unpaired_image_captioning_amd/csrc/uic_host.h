@@ -68,5 +68,33 @@ inline int wgrad_multi(float* slab, size_t slab_bytes, int dt, const void* left,
   return UIC_OK;
 }
 
+// The same weight gradients WITHOUT transposed copies (bf16, gfx950 transposing LDS reads, gemm_tn.hip):
+// C_i = A[K, lrows]^T * [B_0 | B_1 | ...][K, cols].  Returns UIC_OK with *done = false when the shape is not eligible (the
+// caller then transposes and uses wgrad_multi).
+inline int wgrad_tn(float* slab, size_t slab_bytes, int dt, const void* A, int lda, int lrows, const UicGemmTnSeg* segs, int nseg,
+                    int K, const WDest* dst, int nd, hipStream_t s, bool accumulate, bool* done) {
+  *done = false;
+  if (dt != UIC_BF16 || nseg > UIC_GEMM_TN_MAX_SEG) return UIC_OK;
+  UicGemmTnParams p;
+  memset(&p, 0, sizeof(p));
+  p.A = A; p.lda = lda; p.M = lrows; p.K = K; p.nseg = nseg;
+  int rrows = 0;
+  for (int i = 0; i < nseg; ++i) { p.seg[i] = segs[i]; rrows += segs[i].ncols; }
+  p.N = rrows;
+  if (!uic_gemm_tn_eligible(p)) return UIC_OK;
+  const long blocks = (long)((lrows + 127) / 128) * ((rrows + 127) / 128);
+  const int nt = K / 64;
+  int sk = (int)((384 + blocks - 1) / blocks);
+  if (sk > 8) sk = 8;
+  if (sk > nt / 4) sk = nt / 4 > 0 ? nt / 4 : 1;
+  while (sk > 1 && (size_t)sk * lrows * rrows * 4 > slab_bytes) --sk;
+  if ((size_t)sk * lrows * rrows * 4 > slab_bytes) return UIC_OK;
+  p.splitk = sk; p.slab = slab;
+  UIC_TRY(uic_gemm_tn_launch(p, s));
+  for (int i = 0; i < nd; ++i)
+    UIC_TRY(uic_splitk_reduce_launch(slab, sk, lrows, rrows, dst[i].col0, dst[i].ncols, dst[i].C, dst[i].ldc, s, accumulate ? 1 : 0));
+  *done = true;
+  return UIC_OK;
+}
 
 }  // namespace
