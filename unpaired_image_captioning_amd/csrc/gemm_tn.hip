@@ -160,6 +160,28 @@ __global__ __launch_bounds__(256) void uic_gemm_tn_kernel(const UicGemmTnParams 
   }
 
   // C/D layout of the 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
+  if (p.splitk == 1 && p.ndst > 0) {   // straight to the destination(s)
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int col = n0 + (wn * 2 + j) * 32 + r32;
+        if (col >= p.N) continue;
+        float* C = nullptr;
+        int ldc = 0, cc = 0;
+        for (int d = 0; d < p.ndst; ++d)
+          if (col >= p.dst[d].col0 && col < p.dst[d].col0 + p.dst[d].ncols) { C = p.dst[d].C; ldc = p.dst[d].ldc; cc = col - p.dst[d].col0; }
+        if (!C) continue;
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg) {
+          const int row = m0 + (wm * 2 + i) * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * half;
+          if (row >= p.M) continue;
+          float* o = C + (size_t)row * ldc + cc;
+          *o = p.accumulate ? *o + acc[i][j][reg] : acc[i][j][reg];
+        }
+      }
+    return;
+  }
   float* slab = p.slab + (size_t)blockIdx.z * p.M * p.N;
 #pragma unroll
   for (int i = 0; i < 2; ++i)
@@ -175,7 +197,38 @@ __global__ __launch_bounds__(256) void uic_gemm_tn_kernel(const UicGemmTnParams 
     }
 }
 
+__global__ void splitk_reduce_multi_kernel(const float* __restrict__ slab, int splitk, int M, int N, UicSlabDest d0, UicSlabDest d1,
+                                           UicSlabDest d2, UicSlabDest d3, int nd, int accumulate) {
+  const UicSlabDest ds[4] = {d0, d1, d2, d3};
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (int k = 0; k < nd; ++k) {
+    const UicSlabDest d = ds[k];
+    const size_t total = (size_t)M * d.ncols;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+      const int row = (int)(i / d.ncols), c = (int)(i - (size_t)row * d.ncols);
+      const float* src = slab + (size_t)row * N + d.col0 + c;
+      float v = 0.f;
+      for (int z = 0; z < splitk; ++z) v += src[(size_t)z * M * N];
+      float* o = d.C + (size_t)row * d.ldc + c;
+      *o = accumulate ? *o + v : v;
+    }
+  }
+}
+
 }  // namespace
+
+int uic_splitk_reduce_multi_launch(const float* slab, int splitk, int M, int N, const UicSlabDest* dst, int nd, int accumulate, hipStream_t s) {
+  UIC_REQUIRE(nd >= 1 && nd <= 4, "splitk_reduce_multi: %d destinations", nd);
+  UicSlabDest d[4] = {dst[0], dst[nd > 1 ? 1 : 0], dst[nd > 2 ? 2 : 0], dst[nd > 3 ? 3 : 0]};
+  size_t cols = 0;
+  for (int i = 0; i < nd; ++i) cols += dst[i].ncols;
+  size_t g = ((size_t)M * cols / nd + 255) / 256;
+  if (g > 2048) g = 2048;
+  if (g < 1) g = 1;
+  hipLaunchKernelGGL(splitk_reduce_multi_kernel, dim3((unsigned)g), dim3(256), 0, s, slab, splitk, M, N, d[0], d[1], d[2], d[3], nd, accumulate);
+  UIC_LAUNCH_CHECK("splitk_reduce_multi");
+  return UIC_OK;
+}
 
 bool uic_gemm_tn_eligible(const UicGemmTnParams& p) {
   if (p.M < 128 || p.N < 128 || p.K < 64 || p.K % 64 != 0 || p.M % 8 != 0 || p.lda % 8 != 0) return false;
@@ -190,7 +243,7 @@ bool uic_gemm_tn_eligible(const UicGemmTnParams& p) {
 
 int uic_gemm_tn_launch(const UicGemmTnParams& p, hipStream_t s) {
   UIC_REQUIRE(uic_gemm_tn_eligible(p), "gemm_tn: shape M=%d N=%d K=%d not eligible (K %% 64, segment widths %% 128, 16-byte alignment)", p.M, p.N, p.K);
-  UIC_REQUIRE(p.slab && p.splitk >= 1, "gemm_tn: needs a slab and splitk >= 1");
+  UIC_REQUIRE(p.splitk >= 1 && (p.slab || (p.splitk == 1 && p.ndst > 0)), "gemm_tn: needs a slab (or direct destinations with splitk == 1)");
   static bool configured = false;
   if (!configured) {
     UIC_TRY(uic_check_hip(hipFuncSetAttribute((const void*)uic_gemm_tn_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 65536),

@@ -195,8 +195,15 @@ struct UicGemmTnParams {
   int M, N, K;                  // N = sum of the segments' ncols; K % 64 == 0
   int nseg;
   UicGemmTnSeg seg[UIC_GEMM_TN_MAX_SEG];
-  int splitk; float* slab;      // raw f32 partial tiles: slab[z][M][N]
+  int splitk; float* slab;      // splitk > 1 (or ndst == 0): raw f32 partial tiles into slab[z][M][N]
+  // splitk == 1 and ndst > 0: the epilogue writes (or, with `accumulate`, adds to) the destinations directly:
+  // columns [col0, col0 + ncols) of the product go to C[row * ldc + (col - col0)]
+  int ndst; int accumulate;
+  struct { float* C; int ldc, col0, ncols; } dst[UIC_GEMM_TN_MAX_SEG];
 };
+// C_i[row, c - col0_i] (+)= sum_z slab[z][row, c] for every destination i, one launch
+struct UicSlabDest { float* C; int ldc, col0, ncols; };
+int uic_splitk_reduce_multi_launch(const float* slab, int splitk, int M, int N, const UicSlabDest* dst, int nd, int accumulate, hipStream_t s);
 bool uic_gemm_tn_eligible(const UicGemmTnParams& p);
 int uic_gemm_tn_launch(const UicGemmTnParams& p, hipStream_t s);
 

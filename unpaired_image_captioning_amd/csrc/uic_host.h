@@ -84,15 +84,26 @@ inline int wgrad_tn(float* slab, size_t slab_bytes, int dt, const void* A, int l
   if (!uic_gemm_tn_eligible(p)) return UIC_OK;
   const long blocks = (long)((lrows + 127) / 128) * ((rrows + 127) / 128);
   const int nt = K / 64;
-  int sk = (int)((384 + blocks - 1) / blocks);
+  int sk = blocks >= 160 ? 1 : (int)((384 + blocks - 1) / blocks);   // >= 160 tiles fill the 256 CUs well enough: no slab pass
   if (sk > 8) sk = 8;
   if (sk > nt / 4) sk = nt / 4 > 0 ? nt / 4 : 1;
   while (sk > 1 && (size_t)sk * lrows * rrows * 4 > slab_bytes) --sk;
-  if ((size_t)sk * lrows * rrows * 4 > slab_bytes) return UIC_OK;
+  if (sk > 1 && (size_t)sk * lrows * rrows * 4 > slab_bytes) return UIC_OK;
   p.splitk = sk; p.slab = slab;
-  UIC_TRY(uic_gemm_tn_launch(p, s));
-  for (int i = 0; i < nd; ++i)
-    UIC_TRY(uic_splitk_reduce_launch(slab, sk, lrows, rrows, dst[i].col0, dst[i].ncols, dst[i].C, dst[i].ldc, s, accumulate ? 1 : 0));
+  if (sk == 1 && nd <= UIC_GEMM_TN_MAX_SEG) {
+    p.ndst = nd; p.accumulate = accumulate ? 1 : 0;
+    for (int i = 0; i < nd; ++i) { p.dst[i].C = dst[i].C; p.dst[i].ldc = dst[i].ldc; p.dst[i].col0 = dst[i].col0; p.dst[i].ncols = dst[i].ncols; }
+    UIC_TRY(uic_gemm_tn_launch(p, s));
+  } else {
+    if ((size_t)sk * lrows * rrows * 4 > slab_bytes) return UIC_OK;
+    UIC_TRY(uic_gemm_tn_launch(p, s));
+    UicSlabDest sd[4];
+    for (int i0 = 0; i0 < nd; i0 += 4) {
+      const int n = nd - i0 < 4 ? nd - i0 : 4;
+      for (int i = 0; i < n; ++i) sd[i] = UicSlabDest{dst[i0 + i].C, dst[i0 + i].ldc, dst[i0 + i].col0, dst[i0 + i].ncols};
+      UIC_TRY(uic_splitk_reduce_multi_launch(slab, sk, lrows, rrows, sd, n, accumulate ? 1 : 0, s));
+    }
+  }
   *done = true;
   return UIC_OK;
 }
