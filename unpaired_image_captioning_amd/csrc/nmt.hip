@@ -589,9 +589,11 @@ struct Nmt {
       g.C = L.d_out_all; g.ldc = H; g.flags = UIC_GEMM_OUT_F32;
       UIC_TRY(uic_gemm_launch(g, s));
     }
-    UIC_TRY(uic_transpose_launch(dt, L.dlogits, Md, Vt, Vtp, L.tA, Mdp, s));
-    UIC_TRY(uic_transpose_launch(dt, off(L.out_all, BH, dt), Md, H, H, L.tB, Mdp, s));
-    UIC_TRY(wgrad1(L.tA, Vt, L.tB, H, Mdp, G->gen_w, H, s));
+    {
+      const UicGemmTnSeg seg{off(L.out_all, BH, dt), H, H};
+      const WDest d1{G->gen_w, H, 0, H};
+      UIC_TRY(wgrad_group(L.slab, L.slab_bytes, dt, L.dlogits, Vtp, Vt, &seg, 1, Md, &d1, 1, s, false, L.tA, L.tB));
+    }
     UIC_TRY(uic_colsum_launch(dt, L.dlogits, Md, Vt, Vtp, G->gen_b, L.colscratch, L.colscratch_floats, s));
     // ---- decoder BPTT
     for (int l = 0; l < NL; ++l) {
@@ -655,18 +657,14 @@ struct Nmt {
     }
     // ---- decoder weights over all steps
     for (int l = 0; l < NL; ++l) {
-      UIC_TRY(uic_transpose_launch(dt, L.dg_d[l], Md, H4, H4, L.tA, Mdp, s));
       if (l == 0) {   // inputs [emb | feed_prev | h_prev]
-        UIC_TRY(uic_transpose_launch(dt, L.emb_d, Md, W, W, L.tB, Mdp, s));
-        UIC_TRY(uic_transpose_launch(dt, L.out_all, Md, H, H, offw(L.tB, (size_t)W * Mdp, dt), Mdp, s));
-        UIC_TRY(uic_transpose_launch(dt, L.hd[0], Md, H, H, offw(L.tB, (size_t)(W + H) * Mdp, dt), Mdp, s));
+        const UicGemmTnSeg segs[3] = {{L.emb_d, W, W}, {L.out_all, H, H}, {L.hd[0], H, H}};
         const WDest dd[2] = {{G->dec_w_ih[0], W + H, 0, W + H}, {G->dec_w_hh[0], H, W + H, H}};
-        UIC_TRY(wgrad_multi(L.slab, L.slab_bytes, dt, L.tA, H4, L.tB, W + 2 * H, Mdp, dd, 2, s));
+        UIC_TRY(wgrad_group(L.slab, L.slab_bytes, dt, L.dg_d[0], H4, H4, segs, 3, Md, dd, 2, s, false, L.tA, L.tB));
       } else {        // inputs [dropped h of layer l-1 | h_prev]
-        UIC_TRY(uic_transpose_launch(dt, L.hdrop[l - 1], Md, H, H, L.tB, Mdp, s));
-        UIC_TRY(uic_transpose_launch(dt, L.hd[l], Md, H, H, offw(L.tB, (size_t)H * Mdp, dt), Mdp, s));
+        const UicGemmTnSeg segs[2] = {{L.hdrop[l - 1], H, H}, {L.hd[l], H, H}};
         const WDest dd[2] = {{G->dec_w_ih[l], H, 0, H}, {G->dec_w_hh[l], H, H, H}};
-        UIC_TRY(wgrad_multi(L.slab, L.slab_bytes, dt, L.tA, H4, L.tB, 2 * H, Mdp, dd, 2, s));
+        UIC_TRY(wgrad_group(L.slab, L.slab_bytes, dt, L.dg_d[l], H4, H4, segs, 2, Md, dd, 2, s, false, L.tA, L.tB));
       }
       UIC_TRY(uic_colsum_launch(dt, L.dg_d[l], Md, H4, H4, G->dec_b_ih[l], L.colscratch, L.colscratch_floats, s));
       UIC_TRY(uic_check_hip(hipMemcpyAsync(G->dec_b_hh[l], G->dec_b_ih[l], (size_t)H4 * 4, hipMemcpyDeviceToDevice, s), "memcpy b_hh"));
@@ -680,13 +678,14 @@ struct Nmt {
       UIC_TRY(uic_embed_bwd_launch(dt, L.demb_d, nullptr, L.tgt_in, 1, Md, 1, Vt, W, 0.f, 0, G->dec_lut, s));
     }
     // attention weights: linear_in from (d_target, q), linear_out from (d_pre, [c | q])
-    UIC_TRY(uic_transpose_launch(dt, L.dtarget_all, Md, H, H, L.tA, Mdp, s));
-    UIC_TRY(uic_transpose_launch(dt, off(L.hd[NL - 1], BH, dt), Md, H, H, L.tB, Mdp, s));
-    UIC_TRY(wgrad1(L.tA, H, L.tB, H, Mdp, G->attn_in_w, H, s));
-    UIC_TRY(uic_transpose_launch(dt, L.d_pre_all, Md, H, H, L.tA, Mdp, s));
-    UIC_TRY(uic_transpose_launch(dt, L.cvec_all, Md, H, H, L.tB, Mdp, s));
-    UIC_TRY(uic_transpose_launch(dt, off(L.hd[NL - 1], BH, dt), Md, H, H, offw(L.tB, (size_t)H * Mdp, dt), Mdp, s));
-    UIC_TRY(wgrad1(L.tA, H, L.tB, 2 * H, Mdp, G->attn_out_w, 2 * H, s));
+    {
+      const UicGemmTnSeg seg{off(L.hd[NL - 1], BH, dt), H, H};
+      const WDest d1{G->attn_in_w, H, 0, H};
+      UIC_TRY(wgrad_group(L.slab, L.slab_bytes, dt, L.dtarget_all, H, H, &seg, 1, Md, &d1, 1, s, false, L.tA, L.tB));
+      const UicGemmTnSeg segs[2] = {{L.cvec_all, H, H}, {off(L.hd[NL - 1], BH, dt), H, H}};
+      const WDest d2{G->attn_out_w, 2 * H, 0, 2 * H};
+      UIC_TRY(wgrad_group(L.slab, L.slab_bytes, dt, L.d_pre_all, H, H, segs, 2, Md, &d2, 1, s, false, L.tA, L.tB));
+    }
     // ---- encoder: d context = deferred attention gradient; d h0/c0 of the decoder enter at each row's final steps
     float* d_top = L.d_lay;
     hipLaunchKernelGGL(gattn_bwd_accum_kernel, dim3(gridn((size_t)S * BH)), dim3(NT), 0, s, L.attn_all, L.dscore_all, L.d_cq_all,
@@ -720,12 +719,11 @@ struct Nmt {
           UIC_TRY(uic_gemm_launch(g, s));
         }
         // weights of this direction: dG^T [4Hd, S*B] x [x_l | h_prev]^T  (padded rows of dG are zero)
-        UIC_TRY(uic_transpose_launch(dt, L.dg_e[l][dd], Ms, 4 * Hd, 4 * Hd, L.tA, Msp, s));
-        UIC_TRY(uic_transpose_launch(dt, enc_in(l), Ms, in, in, L.tB, Msp, s));
-        UIC_TRY(uic_transpose_launch(dt, off(L.xl[l + 1], (size_t)(dd == 0 ? 0 : 2) * BH + dd * Hd, dt), Ms, Hd, H,
-                                     offw(L.tB, (size_t)in * Msp, dt), Msp, s));
-        const WDest dw[2] = {{G->enc_w_ih[l][dd], in, 0, in}, {G->enc_w_hh[l][dd], Hd, in, Hd}};
-        UIC_TRY(wgrad_multi(L.slab, L.slab_bytes, dt, L.tA, 4 * Hd, L.tB, in + Hd, Msp, dw, 2, s));
+        {
+          const UicGemmTnSeg segs[2] = {{enc_in(l), in, in}, {off(L.xl[l + 1], (size_t)(dd == 0 ? 0 : 2) * BH + dd * Hd, dt), H, Hd}};
+          const WDest dw[2] = {{G->enc_w_ih[l][dd], in, 0, in}, {G->enc_w_hh[l][dd], Hd, in, Hd}};
+          UIC_TRY(wgrad_group(L.slab, L.slab_bytes, dt, L.dg_e[l][dd], 4 * Hd, 4 * Hd, segs, 2, Ms, dw, 2, s, false, L.tA, L.tB));
+        }
         UIC_TRY(uic_colsum_launch(dt, L.dg_e[l][dd], Ms, 4 * Hd, 4 * Hd, G->enc_b_ih[l][dd], L.colscratch, L.colscratch_floats, s));
         UIC_TRY(uic_check_hip(hipMemcpyAsync(G->enc_b_hh[l][dd], G->enc_b_ih[l][dd], (size_t)4 * Hd * 4, hipMemcpyDeviceToDevice, s), "memcpy b_hh"));
       }
@@ -747,9 +745,11 @@ struct Nmt {
     }
     // encoder embeddings: x0 = relu(linear(emb))
     UIC_TRY(uic_relu_mask_bwd_launch(dt, L.dx_e, off(L.xl[0], (size_t)B * W, dt), 1.f, L.dpre_e, (size_t)Ms * W, s));
-    UIC_TRY(uic_transpose_launch(dt, L.dpre_e, Ms, W, W, L.tA, Msp, s));
-    UIC_TRY(uic_transpose_launch(dt, L.xe, Ms, W, W, L.tB, Msp, s));
-    UIC_TRY(wgrad1(L.tA, W, L.tB, W, Msp, G->enc_lin_w, W, s));
+    {
+      const UicGemmTnSeg seg{L.xe, W, W};
+      const WDest d1{G->enc_lin_w, W, 0, W};
+      UIC_TRY(wgrad_group(L.slab, L.slab_bytes, dt, L.dpre_e, W, W, &seg, 1, Ms, &d1, 1, s, false, L.tA, L.tB));
+    }
     UIC_TRY(uic_colsum_launch(dt, L.dpre_e, Ms, W, W, G->enc_lin_b, L.colscratch, L.colscratch_floats, s));
     {
       UicGemmParams g = gemm_base(dt, Ms, W);

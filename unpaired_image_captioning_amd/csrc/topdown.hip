@@ -691,22 +691,9 @@ struct Step {
     const WDest d1{C, ldc, 0, rrows};
     return wgrad_multi(L.slab, L.slab_bytes, dt, left, lrows, right, rrows, K, &d1, 1, s);
   }
-  // One group of weight gradients sharing the left operand:  C_i = A[rows, lrows]^T * [B_0 | B_1 | ...][rows, cols].
-  // bf16 on eligible shapes: gemm_tn.hip reads both operands as they lie (transposing LDS reads).  Otherwise (f32 parity
-  // path, odd sizes): transposed copies into tA / tB and the NT kernels (wgrad_multi).
   int wgrad_group(float* slab, const void* A, int lda, int lrows, const UicGemmTnSeg* segs, int nseg, int rows, const WDest* dst,
                   int nd, hipStream_t s, bool accumulate, void* tA, void* tB) {
-    bool done = false;
-    UIC_TRY(wgrad_tn(slab, L.slab_bytes, dt, A, lda, lrows, segs, nseg, rows, dst, nd, s, accumulate, &done));
-    if (done) return UIC_OK;
-    const int Kp = (int)rup8(rows);
-    UIC_TRY(uic_transpose_launch(dt, A, rows, lrows, lda, tA, Kp, s));
-    int col = 0;
-    for (int i = 0; i < nseg; ++i) {
-      UIC_TRY(uic_transpose_launch(dt, segs[i].B, rows, segs[i].ncols, segs[i].ldb, offw(tB, (size_t)col * Kp, dt), Kp, s));
-      col += segs[i].ncols;
-    }
-    return wgrad_multi(slab, L.slab_bytes, dt, tA, lrows, tB, col, Kp, dst, nd, s, accumulate);
+    return ::wgrad_group(slab, L.slab_bytes, dt, A, lda, lrows, segs, nseg, rows, dst, nd, s, accumulate, tA, tB);
   }
 
   // recurrent weight gradients (both LSTMs' weights and h2att) restricted to decode steps [t0, t1): one chunk of the

@@ -108,4 +108,22 @@ inline int wgrad_tn(float* slab, size_t slab_bytes, int dt, const void* A, int l
   return UIC_OK;
 }
 
+// One group of weight gradients sharing the left operand:  C_i = A[rows, lrows]^T * [B_0 | B_1 | ...][rows, cols].
+// bf16 on eligible shapes: gemm_tn.hip reads both operands as they lie (transposing LDS reads).  Otherwise (f32 parity path,
+// odd sizes): transposed copies into tA [lrows, rows^8] / tB [cols, rows^8] and the NT kernels (wgrad_multi).
+inline int wgrad_group(float* slab, size_t slab_bytes, int dt, const void* A, int lda, int lrows, const UicGemmTnSeg* segs, int nseg,
+                       int rows, const WDest* dst, int nd, hipStream_t s, bool accumulate, void* tA, void* tB) {
+  bool done = false;
+  UIC_TRY(wgrad_tn(slab, slab_bytes, dt, A, lda, lrows, segs, nseg, rows, dst, nd, s, accumulate, &done));
+  if (done) return UIC_OK;
+  const int Kp = (int)rup8(rows);
+  UIC_TRY(uic_transpose_launch(dt, A, rows, lrows, lda, tA, Kp, s));
+  int col = 0;
+  for (int i = 0; i < nseg; ++i) {
+    UIC_TRY(uic_transpose_launch(dt, segs[i].B, rows, segs[i].ncols, segs[i].ldb, offw(tB, (size_t)col * Kp, dt), Kp, s));
+    col += segs[i].ncols;
+  }
+  return wgrad_multi(slab, slab_bytes, dt, tA, lrows, tB, col, Kp, dst, nd, s, accumulate);
+}
+
 }  // namespace

@@ -145,6 +145,8 @@ class Optim(object):
             self._check_method('nmt', self.nmt_method, self.nmt_weight_decay)
             self.nmt_arena = FlatArena(nmt_model, getattr(nmt_model, 'param_names', None))
             self.nmt_arena.bind_grads()
+            if hasattr(nmt_model, 'grad_sink'):
+                nmt_model.grad_sink = self.nmt_arena.grad_views      # backward writes the arena in place
 
     def _exchange(self, arena):
         if self.exchange is not None and self.exchange.world_size > 1:
