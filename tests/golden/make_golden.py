@@ -42,6 +42,7 @@ def _load_reference():
     import builtins
     import functools
     builtins.reduce = functools.reduce
+    torch.Tensor.cuda = lambda self, *a, **k: self          # CaptionModel.py:131,172 call .cuda() unconditionally
 
     def load(modname, path):
         spec = importlib.util.spec_from_file_location(modname, path)
@@ -165,6 +166,21 @@ def run_case(att_mod, crit_mod, name, V, E, H, A, D, L, n_img, S, R, seed, ragge
                               opt={"sample_max": 1, "beam_size": 1}, mode="sample")
     out["out::greedy_seq"] = seq.numpy()
     out["out::greedy_logp"] = seq_logp.numpy()
+
+    # beam search (AttModel._sample_beam + CaptionModel.beam_search) through the public call convention; the EOS bias
+    # variant raises logit.bias[0] so that beams really finish early (random weights hardly ever emit token 0)
+    import builtins
+    import functools
+    builtins.reduce = functools.reduce                                  # CaptionModel.py:176 is py2
+    for tag, bs, dc, mp, eos_bias in (("b3", 3, 0, 0, 0.0), ("b2c", 2, 1, 0, 0.0), ("b3eos", 3, 0, 0, 3.0), ("b4ppl", 4, 1, 1, 2.5)):
+        with torch.no_grad():
+            model.logit.bias[0] += eos_bias
+            bseq, blp = model(fc[idx], attri[idx], att[idx], att_masks[idx] if att_masks is not None else None,
+                              opt={"sample_max": 1, "beam_size": bs, "decoding_constraint": dc, "max_ppl": mp}, mode="sample")
+            model.logit.bias[0] -= eos_bias
+        out["beam::%s_cfg" % tag] = np.array([bs, dc, mp, eos_bias], dtype=np.float64)
+        out["beam::%s_seq" % tag] = bseq.numpy().copy()
+        out["beam::%s_logp" % tag] = blp.numpy().copy()
 
     # RewardCriterion on a hand-made reward
     g = torch.Generator().manual_seed(seed + 1)

@@ -148,3 +148,32 @@ def test_scheduled_sampling_matches_reference_draw_for_draw():
     # teacher forcing (no ss) gives a different loss on this fixture
     loss_tf, _, _ = O.xe_loss_and_grads(W, I["fc_feats"], I["att_feats"], I["labels"], I["masks"], I["att_masks"])
     assert abs(loss_tf.item() - float(Out["loss"])) > 1e-4
+
+
+BEAM_TAGS = ("b3", "b2c", "b3eos", "b4ppl")
+
+
+@pytest.mark.parametrize("name", TINY)
+def test_beam_search_matches_reference(name):
+    """AttModel._sample_beam + CaptionModel.beam_search (beam 2-4, decoding_constraint, max_ppl, early-finishing beams via a
+    raised EOS bias): token ids identical, per-step log-probs within 1e-5."""
+    cfg, W, I, Out, G, X = load_golden(name)
+    idx = torch.arange(cfg["n_img"]) * cfg["S"]
+    am = I.get("att_masks")
+    W = dict(W)
+    for k, v in X.items():          # the reference decoded after its train-mode forward updated BN stats
+        if k.startswith("bnstat::"):
+            W[k.split("::", 1)[1]] = torch.as_tensor(v)
+    n_early = 0
+    for tag in BEAM_TAGS:
+        bs, dc, mp, eos_bias = [float(x) for x in X["beam::%s_cfg" % tag]]
+        Wb = dict(W)
+        Wb["logit.bias"] = W["logit.bias"].clone()
+        Wb["logit.bias"][0] += eos_bias
+        seq, lp = O.sample_beam(Wb, I["fc_feats"][idx], I["att_feats"][idx], None if am is None else am[idx], cfg["L"],
+                                int(bs), int(dc), int(mp), use_bn=cfg["use_bn"])
+        ref_seq = torch.as_tensor(X["beam::%s_seq" % tag])
+        assert torch.equal(seq, ref_seq), (tag, seq, ref_seq)
+        _close(lp, torch.as_tensor(X["beam::%s_logp" % tag]), 1e-5)
+        n_early += int((ref_seq == 0).any())
+    assert n_early > 0          # the fixtures do contain beams that finished before the last step
