@@ -155,6 +155,14 @@ int uic_topdown_sample(const uic_topdown_dims* d, const uic_topdown_weights* w, 
                        const uic_topdown_batch* batch, int32_t L, int32_t sample_max, float temperature,
                        int32_t decoding_constraint, uint32_t seed, const int64_t* forced, int32_t training,
                        void* workspace, int64_t* seq, float* seq_logp, void* stream);
+/* AttModel._sample_beam + CaptionModel.beam_search with group_size = 1 (P/models/AttModel.py:167-196,
+ * P/models/CaptionModel.py:33-177), all images at once.  The batch holds every image REPLICATED beam_size times (row =
+ * image * beam_size + beam; N = images * beam_size), eval mode.  Outputs: the best finished beam per image, seq
+ * [images, L] int64 and its per-step log-probs [images, L] (as recorded by the reference: after the -1000 on the last
+ * vocabulary index and, with decoding_constraint, -inf on the previous word).  max_ppl ranks finished beams by p / length. */
+int uic_topdown_sample_beam(const uic_topdown_dims* d, const uic_topdown_weights* w, const void* derived,
+                            const uic_topdown_batch* b, int32_t L, int32_t beam_size, int32_t decoding_constraint,
+                            int32_t max_ppl, void* workspace, int64_t* seq, float* seq_logp, void* stream);
 
 /* Address of a named activation inside the workspace (tests / debugging); NULL if unknown.
  * Names: fc_embed att_embed p_att xt gx h_att h_lang c_att c_lang att_h alpha ctx logits dlogits ... */

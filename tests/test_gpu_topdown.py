@@ -601,3 +601,64 @@ def test_scheduled_sampling_draw_statistics():
     assert abs(got - want) < 5 * var ** 0.5 + 1e-6, (got / n, want / n)
     uniform_expect = 1.0 / (cfg["V"] + 1)
     assert got / n > 2 * uniform_expect                                 # clearly not uniform draws
+
+
+# ---------------------------------------------------------------- beam search
+BEAM_TAGS = ("b3", "b2c", "b3eos", "b4ppl")
+
+
+@pytest.mark.parametrize("name", FIXTURES + BN_FIXTURES)
+def test_beam_search_token_ids_bit_exact_vs_reference_golden(name):
+    """AttModel._sample_beam + CaptionModel.beam_search (beam 2-4, decoding_constraint, max_ppl, early-finishing beams via a
+    raised EOS bias): f32 token ids identical to the reference's, per-step log-probs within 1e-3."""
+    cfg, W, I, Out, G, X = load_golden(name)
+    W = dict(W)
+    for k, v in X.items():          # the reference decoded after its train-mode forward updated BN stats
+        if k.startswith("bnstat::"):
+            W[k.split("::", 1)[1]] = torch.as_tensor(v)
+    model = build_model(cfg, W, "f32").eval()
+    idx = torch.arange(cfg["n_img"]) * cfg["S"]
+    fc, att = I["fc_feats"][idx].cuda(), I["att_feats"][idx].cuda()
+    am = I["att_masks"][idx].cuda() if "att_masks" in I else None
+    for tag in BEAM_TAGS:
+        bs, dc, mp, eos_bias = [float(x) for x in X["beam::%s_cfg" % tag]]
+        with torch.no_grad():
+            model.logit.bias[0] += eos_bias
+        seq, lp = model(fc, None, att, am, opt={"sample_max": 1, "beam_size": int(bs), "decoding_constraint": int(dc), "max_ppl": int(mp)},
+                        mode="sample")
+        with torch.no_grad():
+            model.logit.bias[0] -= eos_bias
+        ref_seq = torch.as_tensor(X["beam::%s_seq" % tag])
+        assert torch.equal(seq.cpu(), ref_seq), (tag, seq.cpu(), ref_seq)
+        assert absmax(lp, torch.as_tensor(X["beam::%s_logp" % tag])) < 1e-3, tag
+        assert len(model.done_beams) == cfg["n_img"] and torch.equal(model.done_beams[0][0]["seq"], seq[0])
+
+
+def test_beam_search_bf16_and_real_vocab_vs_oracle():
+    """bf16 + a 9488-word vocabulary on a few images: the device's beams scored by the oracle (same tokens re-run through
+    the oracle's beam search must agree unless two candidates tie within bf16 noise, so compare log-probs of the
+    device's own sequences teacher-forced through the oracle)."""
+    cfg = dict(V=9487, E=64, H=64, A=64, D=128, L=8, n_img=5, S=1, R=6)
+    from unpaired_image_captioning_amd import models
+    torch.manual_seed(9)
+    model = models.setup(make_opt(cfg, "bf16", seed=1))
+    with torch.no_grad():
+        model.logit.weight.mul_(20.0)
+        model.logit.bias[0] += 2.0
+    W = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    model.cuda().eval()
+    b = O.synthetic_batch(cfg["n_img"], 1, cfg["R"], cfg["D"], cfg["V"], cfg["L"], seed=4, ragged_regions=True)
+    seq, lp = model(b["fc_feats"].cuda(), None, b["att_feats"].cuda(), b["att_masks"].cuda(), opt={"beam_size": 3}, mode="sample")
+    seq, lp = seq.cpu(), lp.cpu()
+    assert seq.shape == (cfg["n_img"], cfg["L"]) and int(seq.max()) <= cfg["V"]
+    # teacher-force the device's sequences through the oracle and compare the recorded per-step log-probs
+    labels = torch.cat([torch.zeros(cfg["n_img"], 1, dtype=torch.long), seq, torch.zeros(cfg["n_img"], 1, dtype=torch.long)], 1)
+    logp = O.forward_logprobs(W, b["fc_feats"], b["att_feats"], labels, b["att_masks"])
+    for k in range(cfg["n_img"]):
+        for t in range(cfg["L"]):
+            tok = int(seq[k, t])
+            ref = logp[k, t, tok].item() - (1000.0 if tok == cfg["V"] else 0.0)
+            assert abs(lp[k, t].item() - ref) < 5e-2, (k, t, lp[k, t].item(), ref)
+            if tok == 0:
+                assert int(seq[k, t:].abs().sum()) == 0 and float(lp[k, t + 1:].abs().sum()) == 0
+                break

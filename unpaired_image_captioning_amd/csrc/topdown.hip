@@ -44,6 +44,9 @@ struct Layout {
   void* s_h_att[2]; void* s_h_lang[2]; float* s_c_att[2]; float* s_c_lang[2];
   void* s_xt; float* s_atth; float* s_alpha; void* s_ctx; void* s_hdrop; float* s_logits;
   int64_t* s_it; int* s_unf; int* s_nunf;
+  // beam search bookkeeping (rows = (image, beam); sizes depend on N and T only)
+  float* bm_cand_val; int* bm_cand_idx; int64_t* bm_seq[2]; float* bm_lp[2]; float* bm_sum; int* bm_parent;
+  int* bm_done_count; float* bm_done_p; int64_t* bm_done_seq; float* bm_done_lp;
   size_t total;
 };
 
@@ -153,6 +156,18 @@ Layout make_layout(const uic_topdown_dims& d, void* ws) {
   L.s_it = (int64_t*)b.take(N * 8);
   L.s_unf = (int*)b.take(N * 4);
   L.s_nunf = (int*)b.take((T + 2) * 4);
+  L.bm_cand_val = (float*)b.take(N * UIC_BEAM_MAX * 4);
+  L.bm_cand_idx = (int*)b.take(N * UIC_BEAM_MAX * 4);
+  for (int i = 0; i < 2; ++i) {
+    L.bm_seq[i] = (int64_t*)b.take(N * T * 8);
+    L.bm_lp[i] = (float*)b.take(N * T * 4);
+  }
+  L.bm_sum = (float*)b.take(N * 4);
+  L.bm_parent = (int*)b.take(N * 4);
+  L.bm_done_count = (int*)b.take(N * 4);
+  L.bm_done_p = (float*)b.take(N * T * 4);
+  L.bm_done_seq = (int64_t*)b.take(N * T * T * 8);
+  L.bm_done_lp = (float*)b.take(N * T * T * 4);
   L.total = (b.off + 255) & ~(size_t)255;
   return L;
 }
@@ -847,6 +862,46 @@ struct Step {
   }
 };
 
+// One decode step of AttModel.get_logprobs_state (:158-165) on the sampling buffers: embedding of L.s_it, both LSTM cells,
+// attention, logits into L.s_logits; recurrent state read from slot `cur`, written to slot `nxt`.
+int decode_step(const uic_topdown_dims& d, const uic_topdown_weights* w, const Derived& dv, const uic_topdown_batch* b, const Layout& L,
+                int cur, int nxt, int t, float drop_p, unsigned seed, hipStream_t s) {
+  const int dt = d.dtype;
+  const int N = d.N, H = d.H, E = d.E, V1 = d.V1;
+  const int V1p = (int)vpad(V1), H4 = 4 * H, ldih = E + 2 * H;
+  UIC_TRY(uic_embed_fwd_launch(dt, w->embed_w, V1, E, L.s_it, 1, N, 1, drop_p, seed, UIC_SITE_EMBED, (size_t)t * N * E, 1, L.s_xt, s));
+  {
+    UicGemmParams g = gemm_base(dt, N, H4);
+    g.lstm = 1; g.H = H;
+    add_seg(g, L.s_h_lang[cur], H, dv.att_w_ih, ldih, H);
+    add_seg(g, L.fcp, H, off(dv.att_w_ih, H, dt), ldih, H);
+    add_seg(g, L.s_xt, E, off(dv.att_w_ih, 2 * H, dt), ldih, E);
+    add_seg(g, L.s_h_att[cur], H, dv.att_w_hh, H, H);
+    g.bias = w->att_lstm_b_ih; g.bias2 = w->att_lstm_b_hh;
+    g.c_prev = L.s_c_att[cur]; g.c_out = L.s_c_att[nxt];
+    g.h_out = L.s_h_att[nxt]; g.ldh = H;
+    UIC_TRY(uic_gemm_launch(g, s));
+  }
+  UIC_TRY(attention_step(d, w, dv, b, L, L.s_h_att[nxt], L.s_atth, L.s_alpha, L.s_ctx, s));
+  {
+    UicGemmParams g = gemm_base(dt, N, H4);
+    g.lstm = 1; g.H = H;
+    add_seg(g, L.s_ctx, H, dv.lang_w_ih, 2 * H, H);
+    add_seg(g, L.s_h_att[nxt], H, off(dv.lang_w_ih, H, dt), 2 * H, H);
+    add_seg(g, L.s_h_lang[cur], H, dv.lang_w_hh, H, H);
+    g.bias = w->lang_lstm_b_ih; g.bias2 = w->lang_lstm_b_hh;
+    g.c_prev = L.s_c_lang[cur]; g.c_out = L.s_c_lang[nxt];
+    g.h_out = L.s_h_lang[nxt]; g.ldh = H;
+    g.h_drop = L.s_hdrop; g.ldhd = H;        // dropout(h_lang) feeds the logit layer (AttModel.py:443)
+    g.drop_p = drop_p; g.seed = seed; g.site = UIC_SITE_OUT0 + (unsigned)t;
+    UIC_TRY(uic_gemm_launch(g, s));
+  }
+  UicGemmParams g = gemm_base(dt, N, V1);
+  add_seg(g, L.s_hdrop, H, dv.logit_w, H, H);
+  g.C = L.s_logits; g.ldc = V1p; g.bias = w->logit_b; g.flags = UIC_GEMM_OUT_F32;
+  return uic_gemm_launch(g, s);
+}
+
 }  // namespace
 
 extern "C" {
@@ -1014,39 +1069,7 @@ int uic_topdown_sample(const uic_topdown_dims* d, const uic_topdown_weights* w, 
   UIC_TRY(uic_fill_launch(L.s_nunf, 0, (size_t)(d->T + 2) * 4, s));
   for (int t = 0; t < Lsteps; ++t) {
     const int cur = t & 1, nxt = cur ^ 1;
-    UIC_TRY(uic_embed_fwd_launch(dt, w->embed_w, V1, E, L.s_it, 1, N, 1, drop_p, seed, UIC_SITE_EMBED, (size_t)t * N * E, 1, L.s_xt, s));
-    {
-      UicGemmParams g = gemm_base(dt, N, H4);
-      g.lstm = 1; g.H = H;
-      add_seg(g, L.s_h_lang[cur], H, dv.att_w_ih, ldih, H);
-      add_seg(g, L.fcp, H, off(dv.att_w_ih, H, dt), ldih, H);
-      add_seg(g, L.s_xt, E, off(dv.att_w_ih, 2 * H, dt), ldih, E);
-      add_seg(g, L.s_h_att[cur], H, dv.att_w_hh, H, H);
-      g.bias = w->att_lstm_b_ih; g.bias2 = w->att_lstm_b_hh;
-      g.c_prev = L.s_c_att[cur]; g.c_out = L.s_c_att[nxt];
-      g.h_out = L.s_h_att[nxt]; g.ldh = H;
-      UIC_TRY(uic_gemm_launch(g, s));
-    }
-    UIC_TRY(attention_step(*d, w, dv, b, L, L.s_h_att[nxt], L.s_atth, L.s_alpha, L.s_ctx, s));
-    {
-      UicGemmParams g = gemm_base(dt, N, H4);
-      g.lstm = 1; g.H = H;
-      add_seg(g, L.s_ctx, H, dv.lang_w_ih, 2 * H, H);
-      add_seg(g, L.s_h_att[nxt], H, off(dv.lang_w_ih, H, dt), 2 * H, H);
-      add_seg(g, L.s_h_lang[cur], H, dv.lang_w_hh, H, H);
-      g.bias = w->lang_lstm_b_ih; g.bias2 = w->lang_lstm_b_hh;
-      g.c_prev = L.s_c_lang[cur]; g.c_out = L.s_c_lang[nxt];
-      g.h_out = L.s_h_lang[nxt]; g.ldh = H;
-      g.h_drop = L.s_hdrop; g.ldhd = H;        // dropout(h_lang) feeds the logit layer (AttModel.py:443)
-      g.drop_p = drop_p; g.seed = seed; g.site = UIC_SITE_OUT0 + (unsigned)t;
-      UIC_TRY(uic_gemm_launch(g, s));
-    }
-    {
-      UicGemmParams g = gemm_base(dt, N, V1);
-      add_seg(g, L.s_hdrop, H, dv.logit_w, H, H);
-      g.C = L.s_logits; g.ldc = V1p; g.bias = w->logit_b; g.flags = UIC_GEMM_OUT_F32;
-      UIC_TRY(uic_gemm_launch(g, s));
-    }
+    UIC_TRY(decode_step(*d, w, dv, b, L, cur, nxt, t, drop_p, seed, s));
     UicSampleParams p;
     memset(&p, 0, sizeof(p));
     p.dtype = dt; p.N = N; p.V1 = V1; p.ldv = V1p; p.t = t; p.L = Lsteps;
@@ -1057,6 +1080,56 @@ int uic_topdown_sample(const uic_topdown_dims* d, const uic_topdown_weights* w, 
     UIC_TRY(uic_sample_step_launch(p, s));
   }
   return UIC_OK;
+}
+
+
+int uic_topdown_sample_beam(const uic_topdown_dims* d, const uic_topdown_weights* w, const void* derived,
+                            const uic_topdown_batch* b, int32_t Lsteps, int32_t beam_size, int32_t decoding_constraint,
+                            int32_t max_ppl, void* workspace, int64_t* seq, float* seq_logp, void* stream) {
+  UIC_TRY(check_dims(d));
+  UIC_REQUIRE(w && derived && b && workspace && seq && seq_logp, "sample_beam: null pointer");
+  UIC_REQUIRE(b->fc_feats && b->att_feats, "sample_beam: batch needs fc_feats and att_feats");
+  UIC_REQUIRE(Lsteps >= 1 && Lsteps <= d->T, "sample_beam: L=%d outside [1,%d]", Lsteps, d->T);
+  UIC_REQUIRE(beam_size >= 1 && beam_size <= UIC_BEAM_MAX && beam_size <= d->V1, "sample_beam: beam_size=%d outside [1, %d]", beam_size, UIC_BEAM_MAX);
+  UIC_REQUIRE(d->N % beam_size == 0, "sample_beam: N=%d rows must be images x beam_size=%d (every image replicated beam_size times)", d->N, beam_size);
+  hipStream_t s = (hipStream_t)stream;
+  const Layout L = make_layout(*d, workspace);
+  const Derived dv = make_derived(*d, w, (void*)derived);
+  const int dt = d->dtype;
+  const int N = d->N, H = d->H, V1 = d->V1, T = d->T;
+  const size_t S = uic_dtype_size(dt), NH = (size_t)N * H;
+  const void *fc_in, *att_in;
+  UIC_TRY(prepare_features(*d, w, dv, b, L, 0, 0.f, 0, &fc_in, &att_in, s));      // eval mode, like eval_utils.eval_split
+  UIC_TRY(wait_refresh(s));
+  UIC_TRY(uic_fill_launch(L.s_h_att[0], 0, NH * S, s));
+  UIC_TRY(uic_fill_launch(L.s_h_lang[0], 0, NH * S, s));
+  UIC_TRY(uic_fill_launch(L.s_c_att[0], 0, NH * 4, s));
+  UIC_TRY(uic_fill_launch(L.s_c_lang[0], 0, NH * 4, s));
+  UIC_TRY(uic_fill_launch(L.s_it, 0, (size_t)N * 8, s));       // <bos> for every beam row (AttModel.py:187)
+  for (int i = 0; i < 2; ++i) {
+    UIC_TRY(uic_fill_launch(L.bm_seq[i], 0, (size_t)N * T * 8, s));
+    UIC_TRY(uic_fill_launch(L.bm_lp[i], 0, (size_t)N * T * 4, s));
+  }
+  UIC_TRY(uic_fill_launch(L.bm_sum, 0, (size_t)N * 4, s));
+  UIC_TRY(uic_fill_launch(L.bm_done_count, 0, (size_t)N * 4, s));
+  UicBeamParams p;
+  memset(&p, 0, sizeof(p));
+  p.n_img = N / beam_size; p.B = beam_size; p.L = Lsteps; p.V1 = V1; p.ldv = (int)vpad(V1);
+  p.decoding_constraint = decoding_constraint; p.max_ppl = max_ppl;
+  p.logits = L.s_logits; p.cand_val = L.bm_cand_val; p.cand_idx = L.bm_cand_idx;
+  p.beam_seq_hist[0] = L.bm_seq[0]; p.beam_seq_hist[1] = L.bm_seq[1]; p.beam_lp_hist[0] = L.bm_lp[0]; p.beam_lp_hist[1] = L.bm_lp[1];
+  p.beam_sum = L.bm_sum; p.parent = L.bm_parent; p.it = L.s_it;
+  p.done_count = L.bm_done_count; p.done_p = L.bm_done_p; p.done_seq = L.bm_done_seq; p.done_lp = L.bm_done_lp;
+  UIC_TRY(decode_step(*d, w, dv, b, L, 0, 1, 0, 0.f, 0, s));   // logprobs after <bos> (AttModel.py:184-190)
+  for (int t = 0; t < Lsteps; ++t) {
+    p.t = t;
+    UIC_TRY(uic_beam_step_launch(p, s));
+    if (t + 1 == Lsteps) break;                                // (the reference's last get_logprobs_state is never used)
+    UIC_TRY(uic_beam_gather_launch(dt, L.bm_parent, N, beam_size, H, L.s_h_att[1], L.s_h_att[0], L.s_h_lang[1], L.s_h_lang[0],
+                                   L.s_c_att[1], L.s_c_att[0], L.s_c_lang[1], L.s_c_lang[0], s));
+    UIC_TRY(decode_step(*d, w, dv, b, L, 0, 1, t + 1, 0.f, 0, s));
+  }
+  return uic_beam_final_launch(p, seq, seq_logp, s);
 }
 
 }  // extern "C"

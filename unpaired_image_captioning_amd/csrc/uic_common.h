@@ -345,4 +345,22 @@ struct UicSampleParams {
   int ld_out;                    // row stride of seq / seq_logp (0 = L)
 };
 int uic_sample_step_launch(const UicSampleParams& p, hipStream_t s);
+// ---- beam search bookkeeping (beam.hip): rows = (image, beam)
+#define UIC_BEAM_MAX 16
+struct UicBeamParams {
+  int n_img, B, L, V1, ldv, t;
+  int decoding_constraint, max_ppl;
+  const float* logits;                 // [n_img * B, ldv] of the current step
+  float* cand_val; int* cand_idx;      // [n_img * B, B]
+  int64_t* beam_seq_hist[2]; float* beam_lp_hist[2];   // [n_img, L, B] x 2 generations (read t & 1, write the other)
+  const int64_t* beam_seq;             // set by the launcher: the generation holding steps < t
+  float* beam_sum;                     // [n_img, B]
+  int* parent;                         // [n_img * B] surviving parent beam of each new beam
+  int64_t* it;                         // [n_img * B] next input tokens
+  int* done_count; float* done_p; int64_t* done_seq; float* done_lp;   // [n_img], [n_img, L*B], [n_img, L*B, L] x 2
+};
+int uic_beam_step_launch(const UicBeamParams& p, hipStream_t s);
+int uic_beam_gather_launch(int dtype, const int* parent, int rows, int B, int H, const void* h1s, void* h1d, const void* h2s, void* h2d,
+                           const float* c1s, float* c1d, const float* c2s, float* c2d, hipStream_t s);
+int uic_beam_final_launch(const UicBeamParams& p, int64_t* seq_out, float* lp_out, hipStream_t s);
 int uic_dropout_mask_launch(float* out, size_t n, float p, unsigned seed, unsigned site, size_t base, hipStream_t s);

@@ -199,13 +199,33 @@ class AttModel(CaptionModel):
         params = [self.param_dict()[k] for k in self.param_names]
         return _TopDownForward.apply(self, fc, att, seq.contiguous(), am, t_run, *params)
 
+    def _sample_beam(self, fc_feats, att_feats, att_masks=None, opt={}):
+        """AttModel._sample_beam (P/models/AttModel.py:167-196) over CaptionModel.beam_search (P/models/CaptionModel.py:
+        33-177): all images in one device pass.  `self.done_beams[k]` holds the winning beam of image k ('seq', 'logps');
+        the reference's full per-image list of finished beams is not materialised on the host."""
+        beam_size = opt.get('beam_size', 10)
+        if opt.get('group_size', 1) != 1:
+            raise NotImplementedError("diverse beam search (group_size > 1) is not on the MI355X hot path")
+        if self.training:
+            raise NotImplementedError("beam search runs in eval mode (eval_utils.eval_split calls model.eval() first)")
+        assert beam_size <= self.vocab_size + 1
+        fc = fc_feats.contiguous().float()
+        att = att_feats.contiguous().float()
+        am = att_masks.contiguous().float() if att_masks is not None else None
+        with torch.no_grad():
+            pd = {k: v.detach() for k, v in self.param_dict().items()}
+            seq, lp = self.engine.sample_beam(pd, fc, att, am, self.seq_length, beam_size, opt.get('decoding_constraint', 0),
+                                              opt.get('max_ppl', 0))
+        self.done_beams = [[{'seq': seq[k], 'logps': lp[k]}] for k in range(seq.shape[0])]
+        return seq, lp
+
     def _sample(self, fc_feats, attri_feats, att_feats, att_masks=None, opt={}):
         sample_max = opt.get('sample_max', 1)
         beam_size = opt.get('beam_size', 1)
         temperature = opt.get('temperature', 1.0)
         decoding_constraint = opt.get('decoding_constraint', 0)
         if beam_size > 1:
-            raise NotImplementedError("beam search (beam_size > 1) is a 'next' row of the hot-path scope")
+            return self._sample_beam(fc_feats, att_feats, att_masks, opt)
         self._bn_count_batch()
         fc = fc_feats.contiguous().float()
         att = att_feats.contiguous().float()

@@ -160,6 +160,25 @@ class TopDownEngine(object):
             self.release(ws)
         return seq, lp
 
+    def sample_beam(self, params, fc, att, att_masks, L, beam_size, decoding_constraint=0, max_ppl=0):
+        """Beam search for all images at once: every image is replicated beam_size times (rows = (image, beam))."""
+        n_img = att.shape[0]
+        rep = lambda t: None if t is None else t.repeat_interleave(beam_size, 0).contiguous()   # noqa: E731
+        fcb, attb, amb = rep(fc), rep(att), rep(att_masks)
+        d = self.dims(n_img * beam_size, att.shape[1], L + 1)
+        w = self.refresh(params, d)
+        ws = self.checkout(d, fc.device)
+        b = self.batch_struct(fcb, attb, amb)
+        seq = torch.zeros(n_img, L, dtype=torch.int64, device=fc.device)
+        lp = torch.zeros(n_img, L, dtype=torch.float32, device=fc.device)
+        try:
+            check(self.lib.uic_topdown_sample_beam(C.byref(d), C.byref(w), ptr(self._derived), C.byref(b), L, int(beam_size),
+                                                   int(decoding_constraint), int(max_ppl), ptr(ws.buf), ptr(seq), ptr(lp), stream()),
+                  "sample_beam")
+        finally:
+            self.release(ws)
+        return seq, lp
+
     def workspace_tensor(self, ws, name, shape, dtype):
         """View of a named activation inside a workspace (tests)."""
         p = self.lib.uic_topdown_workspace_ptr(C.byref(ws.dims), ptr(ws.buf), name.encode())
