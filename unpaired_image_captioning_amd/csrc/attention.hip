@@ -13,12 +13,14 @@
 //                                  d p_att[n,r,a] = sum_t de_t[r] w_a (1 - tanh^2(p_att + att_h_t))
 //     one pass, no read-modify-write of [N,R,*] accumulators per decode step.
 #include "uic_common.h"
+#include <stdlib.h>
 
 namespace {
 
 constexpr int NTHREADS = 256;
 constexpr int NWAVES = 4;
 constexpr int UB = 9;   // regions a wave keeps in flight per batch (R = 36 -> one batch per wave)
+constexpr int UIC_ATT_FAST_R = UB * NWAVES;   // regions the fast kernels cover
 
 template <typename T>
 __global__ __launch_bounds__(NTHREADS) void attn_fwd_kernel(const UicAttnParams p) {
@@ -239,8 +241,11 @@ __device__ __forceinline__ void load_chunk_f32(const float* src, int c, bool ok,
   }
 }
 
-template <typename T>
-__global__ __launch_bounds__(NTHREADS) void attn_fwd_fast_kernel(const UicAttnParams p) {
+// NW waves per caption row, each keeping UBX = ceil(36 / NW) regions in flight (NW = 8: more waves to hide the HBM latency of
+// the one-shot load burst and half the per-wave tanh / reduction work; measured against NW = 4 on MI355X)
+template <typename T, int NW>
+__global__ __launch_bounds__(NW * 64) void attn_fwd_fast_kernel(const UicAttnParams p) {
+  constexpr int NWAVES = NW, NTHREADS = NW * 64, UB = (UIC_ATT_FAST_R + NW - 1) / NW;
   constexpr int VEC = uic_vec<T>::N;
   extern __shared__ __attribute__((aligned(16))) float sm[];
   const int A = p.A, H = p.H, R = p.R;
@@ -309,7 +314,12 @@ __global__ __launch_bounds__(NTHREADS) void attn_fwd_fast_kernel(const UicAttnPa
   __syncthreads();
   T* ctx = (T*)p.ctx + (size_t)n * p.ldctx;
   for (int h = tid; h < H; h += NTHREADS)
-    ctx[h] = uic_from_f<T>(s_red[h] + s_red[H + h] + s_red[2 * H + h] + s_red[3 * H + h]);
+  {
+    float acc = 0.f;
+#pragma unroll
+    for (int wv = 0; wv < NWAVES; ++wv) acc += s_red[wv * H + h];
+    ctx[h] = uic_from_f<T>(acc);
+  }
 }
 
 template <typename T>
@@ -507,10 +517,17 @@ int uic_attention_fwd_launch(const UicAttnParams& p, hipStream_t s) {
   const size_t lds = sizeof(float) * (2 * (size_t)p.A + 4 * (size_t)p.R + 4 + NWAVES * (size_t)p.H);
   UIC_REQUIRE(lds <= 160 * 1024, "attention_fwd: needs %zu B of LDS", lds);
   if (fast_ok(p)) {
-    if (p.dtype == UIC_BF16)
-      hipLaunchKernelGGL(attn_fwd_fast_kernel<bf16_t>, dim3(p.N), dim3(NTHREADS), lds, s, p);
+    static const int nw_env = getenv("UIC_ATT_NW") ? atoi(getenv("UIC_ATT_NW")) : 8;
+    if (nw_env == 8) {
+      const size_t lds8 = sizeof(float) * (4 * (size_t)p.R + 4 + 8 * (size_t)p.H);
+      if (p.dtype == UIC_BF16)
+        hipLaunchKernelGGL((attn_fwd_fast_kernel<bf16_t, 8>), dim3(p.N), dim3(512), lds8, s, p);
+      else
+        hipLaunchKernelGGL((attn_fwd_fast_kernel<float, 8>), dim3(p.N), dim3(512), lds8, s, p);
+    } else if (p.dtype == UIC_BF16)
+      hipLaunchKernelGGL((attn_fwd_fast_kernel<bf16_t, 4>), dim3(p.N), dim3(NTHREADS), lds, s, p);
     else
-      hipLaunchKernelGGL(attn_fwd_fast_kernel<float>, dim3(p.N), dim3(NTHREADS), lds, s, p);
+      hipLaunchKernelGGL((attn_fwd_fast_kernel<float, 4>), dim3(p.N), dim3(NTHREADS), lds, s, p);
   } else if (p.dtype == UIC_BF16)
     hipLaunchKernelGGL(attn_fwd_kernel<bf16_t>, dim3(p.N), dim3(NTHREADS), lds, s, p);
   else
