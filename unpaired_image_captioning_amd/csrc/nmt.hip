@@ -258,7 +258,7 @@ struct NmtLayout {
   float* logits; void* dlogits; float* row_loss; float* scalars; int* stats;
   // backward
   float* d_out_all; float* dfeed; void* d_pre_all; float* d_cq_all; float* dscore_all; void* dtarget_all; float* dq;
-  float* dx_lstm; float* d_lay; float* dhrec_e; float* dc_e; float* dx_e; void* dpre_e; float* dxe; float* demb_d;
+  float* dx_lstm; float* d_lay; float* dhrec_e; float* dc_e; float* dhrec_e1; float* dc_e1; float* dx_e; void* dpre_e; float* dxe; float* demb_d;
   void* tA; void* tB; float* colscratch; size_t colscratch_floats; float* slab; size_t slab_bytes;
   size_t total;
 };
@@ -339,6 +339,8 @@ NmtLayout nmt_layout(const uic_nmt_dims& d, const uic_nmt_weights* w, void* ws) 
   L.d_lay = (float*)b.take(S * B * H * 4);
   L.dhrec_e = (float*)b.take(B * Hd * 4);
   L.dc_e = (float*)b.take(B * Hd * 4);
+  L.dhrec_e1 = (float*)b.take(B * Hd * 4);
+  L.dc_e1 = (float*)b.take(B * Hd * 4);
   L.dx_e = (float*)b.take(S * B * (W > H ? W : H) * 4);
   L.dpre_e = b.take(S * B * W * Sz);
   L.dxe = (float*)b.take(S * B * W * 4);
@@ -363,6 +365,29 @@ int nmt_check(const uic_nmt_dims* d) {
   UIC_REQUIRE(d->H % 16 == 0 && d->W % 8 == 0, "rnn_size=%d must be a multiple of 16, word_vec_size=%d of 8", d->H, d->W);
   UIC_REQUIRE(d->T - 1 < 256, "target length %d too long for the dropout site encoding", d->T);
   UIC_REQUIRE(d->drop_p >= 0.f && d->drop_p < 1.f, "dropout=%f outside [0,1)", (double)d->drop_p);
+  return UIC_OK;
+}
+
+// Second HIP stream for the backward-direction half of every encoder layer (the two directions of a bidirectional
+// layer are independent chains of S latency-bound launches each).
+struct NmtSide {
+  hipStream_t stream = nullptr;
+  hipEvent_t ev_go = nullptr, ev_done = nullptr;
+  bool ready = false;
+};
+NmtSide g_nmt_side[16];
+int nmt_side(NmtSide** out) {
+  int dev = 0;
+  UIC_TRY(uic_check_hip(hipGetDevice(&dev), "hipGetDevice"));
+  UIC_REQUIRE(dev >= 0 && dev < 16, "device index %d out of range", dev);
+  NmtSide& ss = g_nmt_side[dev];
+  if (!ss.ready) {
+    UIC_TRY(uic_check_hip(hipStreamCreateWithFlags(&ss.stream, hipStreamNonBlocking), "hipStreamCreateWithFlags"));
+    UIC_TRY(uic_check_hip(hipEventCreateWithFlags(&ss.ev_go, hipEventDisableTiming), "hipEventCreate"));
+    UIC_TRY(uic_check_hip(hipEventCreateWithFlags(&ss.ev_done, hipEventDisableTiming), "hipEventCreate"));
+    ss.ready = true;
+  }
+  *out = &ss;
   return UIC_OK;
 }
 
@@ -449,13 +474,19 @@ struct Nmt {
     for (int l = 0; l < NL; ++l) {
       const int in = l == 0 ? W : H;
       UIC_TRY(uic_fill_launch(L.xl[l + 1], 0, (size_t)(S + 2) * BH * Sz, s));
-      for (int dd = 0; dd < 2; ++dd) {
-        UIC_TRY(uic_fill_launch(L.c_e[l][dd], 0, (size_t)(S + 2) * BHd * 4, s));
+      // the layer's input and the zeroed output buffer are ready: the backward direction runs on the side stream
+      NmtSide* ss = nullptr;
+      UIC_TRY(nmt_side(&ss));
+      UIC_TRY(uic_check_hip(hipEventRecord(ss->ev_go, s), "hipEventRecord"));
+      UIC_TRY(uic_check_hip(hipStreamWaitEvent(ss->stream, ss->ev_go, 0), "hipStreamWaitEvent"));
+      for (int dd = 1; dd >= 0; --dd) {
+        hipStream_t sd = dd == 1 ? ss->stream : s;
+        UIC_TRY(uic_fill_launch(L.c_e[l][dd], 0, (size_t)(S + 2) * BHd * 4, sd));
         {  // W_ih x + b_ih + b_hh for every (s, b)
           UicGemmParams g = gemm_base(dt, S * B, 4 * Hd);
           add_seg(g, enc_in(l), in, L.enc_w_ih[l][dd], in, in);
           g.C = L.gx_e[l][dd]; g.ldc = 4 * Hd; g.bias = w->enc_b_ih[l][dd]; g.bias2 = w->enc_b_hh[l][dd]; g.flags = UIC_GEMM_OUT_F32;
-          UIC_TRY(uic_gemm_launch(g, s));
+          UIC_TRY(uic_gemm_launch(g, sd));
         }
         for (int k = 0; k < S; ++k) {
           const int st = dd == 0 ? k : S - 1 - k;          // time step; its slot is st + 1
@@ -468,9 +499,11 @@ struct Nmt {
           g.c_prev = L.c_e[l][dd] + (size_t)prev * BHd; g.c_out = L.c_e[l][dd] + (size_t)(st + 1) * BHd;
           g.h_out = offw(L.xl[l + 1], (size_t)(st + 1) * BH + dd * Hd, dt); g.ldh = H;
           g.gates_out = offw(L.gates_e[l][dd], (size_t)st * B * 4 * Hd, dt);
-          UIC_TRY(uic_gemm_launch(g, s));
+          UIC_TRY(uic_gemm_launch(g, sd));
         }
+        if (dd == 1) UIC_TRY(uic_check_hip(hipEventRecord(ss->ev_done, sd), "hipEventRecord"));
       }
+      UIC_TRY(uic_check_hip(hipStreamWaitEvent(s, ss->ev_done, 0), "hipStreamWaitEvent"));
       if (l + 1 < NL && drop_p > 0.f) {  // nn.LSTM's inter-layer dropout (element index over the [S*B, H] slots 1..S)
         UIC_TRY(uic_fill_launch(L.xd[l + 1], 0, (size_t)(S + 2) * BH * Sz, s));
         NMT_T(dropout_apply_kernel, gridn((size_t)S * BH), 0, (const void*)off(L.xl[l + 1], BH, dt), (void*)offw(L.xd[l + 1], BH, dt),
@@ -693,13 +726,20 @@ struct Nmt {
     UIC_LAUNCH_CHECK("gattn_bwd_accum_kernel");
     for (int l = NL - 1; l >= 0; --l) {
       const int in = l == 0 ? W : H;
-      for (int dd = 0; dd < 2; ++dd) {
-        UIC_TRY(uic_fill_launch(L.dg_e[l][dd], 0, (size_t)Ms * 4 * Hd * Sz, s));
+      NmtSide* ss = nullptr;
+      UIC_TRY(nmt_side(&ss));
+      UIC_TRY(uic_check_hip(hipEventRecord(ss->ev_go, s), "hipEventRecord"));          // d_top of this layer is final
+      UIC_TRY(uic_check_hip(hipStreamWaitEvent(ss->stream, ss->ev_go, 0), "hipStreamWaitEvent"));
+      for (int dd = 1; dd >= 0; --dd) {                                                  // backward direction on the side stream
+        hipStream_t sd = dd == 1 ? ss->stream : s;
+        float* dhrec = dd == 1 ? L.dhrec_e1 : L.dhrec_e;
+        float* dcc = dd == 1 ? L.dc_e1 : L.dc_e;
+        UIC_TRY(uic_fill_launch(L.dg_e[l][dd], 0, (size_t)Ms * 4 * Hd * Sz, sd));
         // carried dh / dc start from the decoder-initial-state gradient halves (rows join the BPTT when they become active)
-        UIC_TRY(uic_check_hip(hipMemcpy2DAsync(L.dhrec_e, (size_t)Hd * 4, L.dhrec_d[l] + dd * Hd, (size_t)H * 4, (size_t)Hd * 4, B,
-                                               hipMemcpyDeviceToDevice, s), "memcpy2d dh0"));
-        UIC_TRY(uic_check_hip(hipMemcpy2DAsync(L.dc_e, (size_t)Hd * 4, L.dcd[l] + dd * Hd, (size_t)H * 4, (size_t)Hd * 4, B,
-                                               hipMemcpyDeviceToDevice, s), "memcpy2d dc0"));
+        UIC_TRY(uic_check_hip(hipMemcpy2DAsync(dhrec, (size_t)Hd * 4, L.dhrec_d[l] + dd * Hd, (size_t)H * 4, (size_t)Hd * 4, B,
+                                               hipMemcpyDeviceToDevice, sd), "memcpy2d dh0"));
+        UIC_TRY(uic_check_hip(hipMemcpy2DAsync(dcc, (size_t)Hd * 4, L.dcd[l] + dd * Hd, (size_t)H * 4, (size_t)Hd * 4, B,
+                                               hipMemcpyDeviceToDevice, sd), "memcpy2d dc0"));
         for (int k = S - 1; k >= 0; --k) {
           const int st = dd == 0 ? k : S - 1 - k;
           const int prev = dd == 0 ? st : st + 2;
@@ -708,16 +748,20 @@ struct Nmt {
           memset(&p, 0, sizeof(p));
           p.dtype = dt; p.M = nb[st]; p.H = Hd;
           p.dh0 = d_top + (size_t)st * BH + dd * Hd; p.lddh0 = H;
-          p.dh1 = L.dhrec_e; p.lddh1 = Hd;
-          p.dc = L.dc_e; p.gates = off(L.gates_e[l][dd], (size_t)st * B * 4 * Hd, dt);
+          p.dh1 = dhrec; p.lddh1 = Hd;
+          p.dc = dcc; p.gates = off(L.gates_e[l][dd], (size_t)st * B * 4 * Hd, dt);
           p.c_prev = L.c_e[l][dd] + (size_t)prev * BHd; p.c = L.c_e[l][dd] + (size_t)(st + 1) * BHd;
           p.dgates = offw(L.dg_e[l][dd], (size_t)st * B * 4 * Hd, dt);
-          UIC_TRY(uic_lstm_bwd_launch(p, s));
+          UIC_TRY(uic_lstm_bwd_launch(p, sd));
           UicGemmParams g = gemm_base(dt, nb[st], Hd);
           add_seg(g, p.dgates, 4 * Hd, L.enc_w_hhT[l][dd], 4 * Hd, 4 * Hd);
-          g.C = L.dhrec_e; g.ldc = Hd; g.flags = UIC_GEMM_OUT_F32;
-          UIC_TRY(uic_gemm_launch(g, s));
+          g.C = dhrec; g.ldc = Hd; g.flags = UIC_GEMM_OUT_F32;
+          UIC_TRY(uic_gemm_launch(g, sd));
         }
+        if (dd == 1) UIC_TRY(uic_check_hip(hipEventRecord(ss->ev_done, sd), "hipEventRecord"));
+      }
+      UIC_TRY(uic_check_hip(hipStreamWaitEvent(s, ss->ev_done, 0), "hipStreamWaitEvent"));
+      for (int dd = 0; dd < 2; ++dd) {
         // weights of this direction: dG^T [4Hd, S*B] x [x_l | h_prev]^T  (padded rows of dG are zero)
         {
           const UicGemmTnSeg segs[2] = {{enc_in(l), in, in}, {off(L.xl[l + 1], (size_t)(dd == 0 ? 0 : 2) * BH + dd * Hd, dt), H, Hd}};
