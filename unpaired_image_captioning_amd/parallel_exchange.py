@@ -24,10 +24,25 @@ class GradientExchange(object):
         return dist.get_rank(self.group) if dist.is_available() and dist.is_initialized() else 0
 
     def global_inv_den(self, den_local, device):
-        """1 / (global mask sum) as a device scalar, or None on a single rank (the kernel computes it)."""
+        """1 / (global mask sum) as a device scalar, or None on a single rank (the kernel computes it).
+
+        No host synchronisation: the local sum travels through a ring of pinned host floats and a non-blocking copy
+        (a plain `torch.tensor(x, device=...)` is a synchronous pageable copy that would make the host wait for the
+        previous step every iteration and forfeit its ~9 steps of run-ahead)."""
         if self.world_size == 1:
             return None
-        t = torch.tensor([float(den_local)], dtype=torch.float32, device=device)
+        if torch.is_tensor(den_local) and den_local.is_cuda:
+            t = den_local.detach().float().reshape(1).clone()
+        elif torch.device(device).type != "cuda":
+            t = torch.tensor([float(den_local)], dtype=torch.float32, device=device)
+        else:
+            if getattr(self, "_pin", None) is None:
+                self._pin = torch.zeros(64, dtype=torch.float32).pin_memory()
+                self._pin_i = 0
+            i = self._pin_i
+            self._pin_i = (i + 1) % 64
+            self._pin[i] = float(den_local)
+            t = self._pin[i:i + 1].to(device, non_blocking=True)
         dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
         return t.reciprocal_()
 
