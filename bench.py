@@ -31,11 +31,11 @@ HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 CFG = dict(V=9487, E=512, H=512, A=512, D=2048, L=16, R=36, n_img=128, S=5)
 
 
-def make_opt(dtype, seed):
+def make_opt(dtype, seed, use_bn=0):
     c = CFG
     return argparse.Namespace(vocab_size=c["V"], input_encoding_size=c["E"], rnn_size=c["H"], num_layers=1,
                               drop_prob_lm=0.5, seq_length=c["L"], fc_feat_size=c["D"], att_feat_size=c["D"],
-                              att_hid_size=c["A"], use_bn=0, logit_layers=1, caption_model="topdown",
+                              att_hid_size=c["A"], use_bn=use_bn, logit_layers=1, caption_model="topdown",
                               compute_dtype=dtype, seed=seed, i2t_learning_rate=5e-4, i2t_train_flag=1)
 
 
@@ -135,6 +135,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--dtype", default="bf16")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--use-bn", type=int, default=0, help="opt.use_bn of the captioner (secondary measurement; the metric is quoted at 0)")
     ap.add_argument("--cpu-threads", type=int, default=0, help="threads for the CPU oracle leg (0: min(host cores, 16), the fastest setting measured on the GPU box's 256-thread host: 8->293, 16->379, 32->211, 64->110, 128->24 captions/s)")
     args = ap.parse_args()
 
@@ -154,7 +155,7 @@ def main():
 
     c = CFG
     torch.manual_seed(1234)                                    # identical initial weights on every rank
-    tr = Trainer(make_opt(args.dtype, 1234 + rank))
+    tr = Trainer(make_opt(args.dtype, 1234 + rank, args.use_bn))
     tr.build_optimizer()
     batch = synthetic_batch(c["n_img"], c["S"], c["R"], c["D"], c["V"], c["L"], seed=1234 + rank)
     N = c["n_img"] * c["S"]
@@ -199,7 +200,7 @@ def main():
             "data": "synthetic",
             "config": {"workload": "BASELINE configs[1]: TopDown attention LSTM, 128 images x 5 captions = 640 caption "
                                    "rows per GPU, R=36, D=2048, H=E=A=512, V+1=9488, 17 decode steps, dropout 0.5, "
-                                   "XE loss + BPTT + Adam", "rows_per_gpu": N, "parallelism": "dp%d" % world},
+                                   "XE loss + BPTT + Adam", "rows_per_gpu": N, "parallelism": "dp%d" % world, "use_bn": args.use_bn},
             "final_loss": round(loss_val, 4),
             "roofline": attention_roofline(dtype_id, args.dtype),
         }

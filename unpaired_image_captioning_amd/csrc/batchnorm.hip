@@ -69,21 +69,29 @@ __global__ __launch_bounds__(NT) void bn_stats_part_kernel(const TI* __restrict_
   }
 }
 
-// stat[c] = batch mean, stat[C + c] = 1/sqrt(biased var + eps); running stats as nn.BatchNorm1d (momentum, unbiased var)
-__global__ void bn_stats_final_kernel(const float* __restrict__ part, int nchunks, int C, float momentum, float eps,
-                                      float* __restrict__ stat, float* run_mean, float* run_var) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
+// stat[c] = batch mean, stat[C + c] = 1/sqrt(biased var + eps); running stats as nn.BatchNorm1d (momentum, unbiased var).
+// 64 columns per workgroup; its 4 waves each Chan-merge a quarter of the chunks, then the 4 partials are merged in a fixed
+// order (deterministic).
+__device__ __forceinline__ void chan_merge(float& n, float& mean, float& M2, float nb, float mb, float m2b) {
+  if (nb == 0.f) return;
+  const float nt = n + nb, dlt = mb - mean;
+  mean += dlt * (nb / nt);
+  M2 += m2b + dlt * dlt * (n * nb / nt);
+  n = nt;
+}
+__global__ __launch_bounds__(NT) void bn_stats_final_kernel(const float* __restrict__ part, int nchunks, int C, float momentum, float eps,
+                                                            float* __restrict__ stat, float* run_mean, float* run_var) {
+  __shared__ float s_n[4][64], s_m[4][64], s_q[4][64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + lane;
   float n = 0.f, mean = 0.f, M2 = 0.f;
-  for (int b = 0; b < nchunks; ++b) {
-    const float nb = part[(size_t)b * 3 * C + c];
-    if (nb == 0.f) continue;
-    const float mb = part[((size_t)b * 3 + 1) * C + c], m2b = part[((size_t)b * 3 + 2) * C + c];
-    const float nt = n + nb, dlt = mb - mean;
-    mean += dlt * (nb / nt);
-    M2 += m2b + dlt * dlt * (n * nb / nt);
-    n = nt;
-  }
+  if (c < C)
+    for (int b = wave; b < nchunks; b += 4)
+      chan_merge(n, mean, M2, part[(size_t)b * 3 * C + c], part[((size_t)b * 3 + 1) * C + c], part[((size_t)b * 3 + 2) * C + c]);
+  s_n[wave][lane] = n; s_m[wave][lane] = mean; s_q[wave][lane] = M2;
+  __syncthreads();
+  if (wave != 0 || c >= C) return;
+  for (int wv = 1; wv < 4; ++wv) chan_merge(n, mean, M2, s_n[wv][lane], s_m[wv][lane], s_q[wv][lane]);
   const float var = n > 0.f ? M2 / n : 0.f;
   stat[c] = mean;
   stat[C + c] = rsqrtf(var + eps);
@@ -156,17 +164,25 @@ __global__ __launch_bounds__(NT) void bn_bwd_part_kernel(const float* __restrict
     p[2 * C + j] = s2[j];
   }
 }
-// red[c] = n, red[C + c] = dbeta, red[2C + c] = dgamma
-__global__ void bn_bwd_final_kernel(const float* __restrict__ part, int nchunks, int C, float* __restrict__ red,
-                                    float* dgamma, float* dbeta) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
+// red[c] = n, red[C + c] = dbeta, red[2C + c] = dgamma   (64 columns per workgroup, 4 waves split the chunks)
+__global__ __launch_bounds__(NT) void bn_bwd_final_kernel(const float* __restrict__ part, int nchunks, int C, float* __restrict__ red,
+                                                          float* dgamma, float* dbeta) {
+  __shared__ float s_n[4][64], s_1[4][64], s_2[4][64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + lane;
   float n = 0.f, s1 = 0.f, s2 = 0.f;
-  for (int b = 0; b < nchunks; ++b) {
-    n += part[(size_t)b * 3 * C + c];
-    s1 += part[((size_t)b * 3 + 1) * C + c];
-    s2 += part[((size_t)b * 3 + 2) * C + c];
-  }
+  if (c < C)
+    for (int b = wave; b < nchunks; b += 4) {
+      n += part[(size_t)b * 3 * C + c];
+      s1 += part[((size_t)b * 3 + 1) * C + c];
+      s2 += part[((size_t)b * 3 + 2) * C + c];
+    }
+  s_n[wave][lane] = n; s_1[wave][lane] = s1; s_2[wave][lane] = s2;
+  __syncthreads();
+  if (wave != 0 || c >= C) return;
+  n = (s_n[0][lane] + s_n[1][lane]) + (s_n[2][lane] + s_n[3][lane]);
+  s1 = (s_1[0][lane] + s_1[1][lane]) + (s_1[2][lane] + s_1[3][lane]);
+  s2 = (s_2[0][lane] + s_2[1][lane]) + (s_2[2][lane] + s_2[3][lane]);
   red[c] = n; red[C + c] = s1; red[2 * C + c] = s2;
   if (dbeta) dbeta[c] = s1;
   if (dgamma) dgamma[c] = s2;
@@ -225,23 +241,32 @@ __global__ __launch_bounds__(NT) void bn_fold_weight_kernel(const float* __restr
   }
 }
 
-// in: dW = dW' [H, D], db [H]; out: dgamma, dbeta [D] and dW <- dW' diag(gamma) + db beta^T   -- one thread per column
-__global__ void bn_fold_grad_kernel(const float* __restrict__ W, const float* __restrict__ gamma, const float* __restrict__ beta,
-                                    float* __restrict__ dW, const float* __restrict__ db, int H, int D,
-                                    float* __restrict__ dgamma, float* __restrict__ dbeta) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= D) return;
+// in: dW = dW' [H, D], db [H]; out: dgamma, dbeta [D] and dW <- dW' diag(gamma) + db beta^T.  64 columns per workgroup, the 4
+// waves split the H rows (fixed-order combination -> deterministic).
+__global__ __launch_bounds__(NT) void bn_fold_grad_kernel(const float* __restrict__ W, const float* __restrict__ gamma,
+                                                          const float* __restrict__ beta, float* __restrict__ dW,
+                                                          const float* __restrict__ db, int H, int D, float* __restrict__ dgamma,
+                                                          float* __restrict__ dbeta) {
+  __shared__ float s_g[4][64], s_b[4][64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + lane;
   float ag = 0.f, ab = 0.f;
-  const float g = gamma[c], bt = beta[c];
-  for (int h = 0; h < H; ++h) {
-    const float w = W[(size_t)h * D + c];
-    const float dw = dW[(size_t)h * D + c];
-    ag += w * dw;
-    ab += w * db[h];
-    dW[(size_t)h * D + c] = dw * g + db[h] * bt;
+  const float g = c < D ? gamma[c] : 0.f, bt = c < D ? beta[c] : 0.f;
+  if (c < D)
+    for (int h = wave; h < H; h += 4) {
+      const float w = W[(size_t)h * D + c];
+      const float dw = dW[(size_t)h * D + c];
+      const float dbh = db[h];
+      ag += w * dw;
+      ab += w * dbh;
+      dW[(size_t)h * D + c] = dw * g + dbh * bt;
+    }
+  s_g[wave][lane] = ag; s_b[wave][lane] = ab;
+  __syncthreads();
+  if (wave == 0 && c < D) {
+    dgamma[c] = (s_g[0][lane] + s_g[1][lane]) + (s_g[2][lane] + s_g[3][lane]);
+    dbeta[c] = (s_b[0][lane] + s_b[1][lane]) + (s_b[2][lane] + s_b[3][lane]);
   }
-  dgamma[c] = ag;
-  dbeta[c] = ab;
 }
 
 inline int chunks_for(int NR, int* rows_per_chunk) {
@@ -271,7 +296,7 @@ int uic_bn_stats_launch(int in_dtype, const void* x, int NR, int R, int C, const
   else
     hipLaunchKernelGGL(bn_stats_part_kernel<float>, grid, dim3(NT), 0, s, (const float*)x, NR, R, C, row_len, rpc, part);
   UIC_LAUNCH_CHECK("bn_stats_part");
-  hipLaunchKernelGGL(bn_stats_final_kernel, dim3((C + NT - 1) / NT), dim3(NT), 0, s, part, nch, C, momentum, eps, stat, run_mean, run_var);
+  hipLaunchKernelGGL(bn_stats_final_kernel, dim3((C + 63) / 64), dim3(NT), 0, s, part, nch, C, momentum, eps, stat, run_mean, run_var);
   UIC_LAUNCH_CHECK("bn_stats_final");
   return UIC_OK;
 }
@@ -306,7 +331,7 @@ int uic_bn_bwd_launch(int dtype, float* d, const void* y, int NR, int R, int C, 
   else
     hipLaunchKernelGGL(bn_bwd_part_kernel<float>, grid, dim3(NT), 0, s, (const float*)d, (const float*)y, NR, R, C, row_len, stat, rpc, part);
   UIC_LAUNCH_CHECK("bn_bwd_part");
-  hipLaunchKernelGGL(bn_bwd_final_kernel, dim3((C + NT - 1) / NT), dim3(NT), 0, s, part, nch, C, red, dgamma, dbeta);
+  hipLaunchKernelGGL(bn_bwd_final_kernel, dim3((C + 63) / 64), dim3(NT), 0, s, part, nch, C, red, dgamma, dbeta);
   UIC_LAUNCH_CHECK("bn_bwd_final");
   const int g = gridn((size_t)NR * (C / 4));
   if (dtype == UIC_BF16)
@@ -331,7 +356,7 @@ int uic_bn_fold_weight_launch(int dtype, const float* W, const float* gamma, con
 int uic_bn_fold_grad_launch(const float* W, const float* gamma, const float* beta, float* dW, const float* db, int H, int D,
                             float* dgamma, float* dbeta, hipStream_t s) {
   UIC_REQUIRE(W && gamma && beta && dW && db && dgamma && dbeta, "bn_fold_grad: null pointer");
-  hipLaunchKernelGGL(bn_fold_grad_kernel, dim3((D + NT - 1) / NT), dim3(NT), 0, s, W, gamma, beta, dW, db, H, D, dgamma, dbeta);
+  hipLaunchKernelGGL(bn_fold_grad_kernel, dim3((D + 63) / 64), dim3(NT), 0, s, W, gamma, beta, dW, db, H, D, dgamma, dbeta);
   UIC_LAUNCH_CHECK("bn_fold_grad");
   return UIC_OK;
 }
