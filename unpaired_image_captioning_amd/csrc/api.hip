@@ -41,7 +41,7 @@ __global__ void lm_crit_final_kernel(const float* row_loss, const float* row_mas
   s_a[threadIdx.x] = a; s_b[threadIdx.x] = b;
   __syncthreads();
   for (int o = 128; o > 0; o >>= 1) {
-    if (threadIdx.x < o) { s_a[threadIdx.x] += s_a[threadIdx.x + o]; s_b[threadIdx.x] += s_b[threadIdx.x + o]; }
+    if ((int)threadIdx.x < o) { s_a[threadIdx.x] += s_a[threadIdx.x + o]; s_b[threadIdx.x] += s_b[threadIdx.x + o]; }
     __syncthreads();
   }
   if (threadIdx.x == 0) { out[0] = s_a[0] / s_b[0]; out[1] = s_b[0]; }
@@ -68,7 +68,7 @@ __global__ void reward_crit_kernel(int N, int L, const float* logp, const int64_
   s_a[threadIdx.x] = a; s_b[threadIdx.x] = b;
   __syncthreads();
   for (int o = 128; o > 0; o >>= 1) {
-    if (threadIdx.x < o) { s_a[threadIdx.x] += s_a[threadIdx.x + o]; s_b[threadIdx.x] += s_b[threadIdx.x + o]; }
+    if ((int)threadIdx.x < o) { s_a[threadIdx.x] += s_a[threadIdx.x + o]; s_b[threadIdx.x] += s_b[threadIdx.x + o]; }
     __syncthreads();
   }
   const float den = s_b[0];

@@ -70,7 +70,7 @@ __global__ __launch_bounds__(NT) void beam_topk_kernel(const UicBeamParams p) {
     s_val[threadIdx.x] = bv; s_idx[threadIdx.x] = bi;
     __syncthreads();
     for (int o = NT / 2; o > 0; o >>= 1) {
-      if (threadIdx.x < o) {
+      if ((int)threadIdx.x < o) {
         const float ov = s_val[threadIdx.x + o];
         const int oi = s_idx[threadIdx.x + o];
         if (ov > s_val[threadIdx.x] || (ov == s_val[threadIdx.x] && oi < s_idx[threadIdx.x])) { s_val[threadIdx.x] = ov; s_idx[threadIdx.x] = oi; }

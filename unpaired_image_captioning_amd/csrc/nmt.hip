@@ -198,14 +198,14 @@ __global__ __launch_bounds__(NT) void nmt_score_kernel(const float* logits, int 
   const float* row = logits + (size_t)m * ldv;
   float bv = -INFINITY;
   int bi = 0x7fffffff;
-  for (int v = threadIdx.x; v < V; v += NT) {
+  for (int v = (int)threadIdx.x; v < V; v += NT) {
     const float x = row[v];
     if (x > bv || (x == bv && v < bi)) { bv = x; bi = v; }
   }
   s_val[threadIdx.x] = bv; s_idx[threadIdx.x] = bi;
   __syncthreads();
   for (int o = NT / 2; o > 0; o >>= 1) {
-    if (threadIdx.x < o) {
+    if ((int)threadIdx.x < o) {
       const float ov = s_val[threadIdx.x + o];
       const int oi = s_idx[threadIdx.x + o];
       if (ov > s_val[threadIdx.x] || (ov == s_val[threadIdx.x] && oi < s_idx[threadIdx.x])) { s_val[threadIdx.x] = ov; s_idx[threadIdx.x] = oi; }
@@ -608,13 +608,9 @@ struct Nmt {
     return UIC_OK;
   }
 
-  int wgrad1(const void* left, int lrows, const void* right, int rrows, int K, float* C, int ldc, hipStream_t s) {
-    const WDest d1{C, ldc, 0, rrows};
-    return wgrad_multi(L.slab, L.slab_bytes, dt, left, lrows, right, rrows, K, &d1, 1, s);
-  }
 
   int backward(hipStream_t s) {
-    const int H4 = 4 * H, Md = Td * B, Mdp = (int)rup8(Md), Ms = S * B, Msp = (int)rup8(Ms);
+    const int H4 = 4 * H, Md = Td * B, Ms = S * B;
     // ---- generator
     {
       UicGemmParams g = gemm_base(dt, Md, H);

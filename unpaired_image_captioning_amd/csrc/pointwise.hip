@@ -516,7 +516,7 @@ __global__ __launch_bounds__(NT) void sample_step_kernel(const UicSampleParams p
     s_idx[threadIdx.x] = bi;
     __syncthreads();
     for (int o = NT / 2; o > 0; o >>= 1) {
-      if (threadIdx.x < o) {
+      if ((int)threadIdx.x < o) {
         const float ov = s_val[threadIdx.x + o];
         const int oi = s_idx[threadIdx.x + o];
         if (ov > s_val[threadIdx.x] || (ov == s_val[threadIdx.x] && oi < s_idx[threadIdx.x])) {

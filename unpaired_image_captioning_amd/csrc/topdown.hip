@@ -345,24 +345,11 @@ int get_side(SideStream** out) {
   UIC_REQUIRE(dev >= 0 && dev < 16, "device index %d out of range", dev);
   SideStream& ss = g_side[dev];
   if (!ss.ready) {
-    // The side stream is confined to a subset of the CUs (UIC_SIDE_CUS=n, experiment only; default: no mask):
-    // its large GEMMs would otherwise fill every CU and the latency-bound recurrence kernels of the main
-    // stream would queue behind them, which costs more than the overlap gains.
-    int ncu = 0;   // measured on MI355X: masking the side stream to 64..160 CUs is 1.6-2x SLOWER than no mask
-    if (const char* e = getenv("UIC_SIDE_CUS")) ncu = atoi(e);
-    if (ncu > 0 && ncu < 256) {
-      uint32_t mask[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-      for (int i = 0; i < ncu; ++i) mask[i >> 5] |= 1u << (i & 31);
-      UIC_TRY(uic_check_hip(hipExtStreamCreateWithCUMask(&ss.stream, 8, mask), "hipExtStreamCreateWithCUMask"));
-    } else {
-      // lowest priority: when CUs free up, the dispatcher serves the latency-critical recurrence of the caller's stream
-      // before the bulk work queued here (UIC_SIDE_PRIO=0 keeps the default priority, for A/B measurements)
-      int least = 0, greatest = 0;
-      UIC_TRY(uic_check_hip(hipDeviceGetStreamPriorityRange(&least, &greatest), "hipDeviceGetStreamPriorityRange"));
-      const char* pe = getenv("UIC_SIDE_PRIO");
-      const int prio = (pe && atoi(pe) == 0) ? 0 : least;
-      UIC_TRY(uic_check_hip(hipStreamCreateWithPriority(&ss.stream, hipStreamNonBlocking, prio), "hipStreamCreateWithPriority"));
-    }
+    // A plain second stream at the lowest priority.  Measured alternatives: confining it to a subset of the CUs
+    // (hipExtStreamCreateWithCUMask, 64..224 CUs) makes the whole step 2x SLOWER; the priority itself is neutral.
+    int least = 0, greatest = 0;
+    UIC_TRY(uic_check_hip(hipDeviceGetStreamPriorityRange(&least, &greatest), "hipDeviceGetStreamPriorityRange"));
+    UIC_TRY(uic_check_hip(hipStreamCreateWithPriority(&ss.stream, hipStreamNonBlocking, least), "hipStreamCreateWithPriority"));
     UIC_TRY(uic_check_hip(hipEventCreateWithFlags(&ss.ev_den, hipEventDisableTiming), "hipEventCreate"));
     UIC_TRY(uic_check_hip(hipEventCreateWithFlags(&ss.ev_done, hipEventDisableTiming), "hipEventCreate"));
     UIC_TRY(uic_check_hip(hipEventCreateWithFlags(&ss.ev_early, hipEventDisableTiming), "hipEventCreate"));
@@ -702,10 +689,6 @@ struct Step {
     UIC_TRY(bwd_epilogue_early(s));
     return bwd_epilogue_late(s);
   }
-  int wgrad1(const void* left, int lrows, const void* right, int rrows, int K, float* C, int ldc, hipStream_t s) {
-    const WDest d1{C, ldc, 0, rrows};
-    return wgrad_multi(L.slab, L.slab_bytes, dt, left, lrows, right, rrows, K, &d1, 1, s);
-  }
   int wgrad_group(float* slab, const void* A, int lda, int lrows, const UicGemmTnSeg* segs, int nseg, int rows, const WDest* dst,
                   int nd, hipStream_t s, bool accumulate, void* tA, void* tB) {
     return ::wgrad_group(slab, L.slab_bytes, dt, A, lda, lrows, segs, nseg, rows, dst, nd, s, accumulate, tA, tB);
@@ -746,10 +729,6 @@ struct Step {
     void* const tB = side ? L.tSB : L.tB;
     float* const colscratch = side ? L.colscratchL : L.colscratch;
     float* const slab = side ? L.slab2 : L.slab;
-    auto wgrad = [&](const void* left, int lrows, const void* right, int rrows, int K, float* C, int ldc) -> int {
-      const WDest d1{C, ldc, 0, rrows};
-      return wgrad_multi(slab, L.slab_bytes, dt, left, lrows, right, rrows, K, &d1, 1, s);
-    };
     if (chunked)   // h2att.bias belongs to the early group then (its weight came from wgrad_chunk)
       UIC_TRY(uic_colsum_launch(dt, L.datth_all, Meff, A, A, G->h2att_b, colscratch, L.colscratch_floats, s));
     // per LSTM ONE GEMM dG^T [4H, T*N] x [stacked inputs]^T; lang_lstm inputs [att_res | h_att | h_lang_prev]
@@ -802,9 +781,6 @@ struct Step {
   // part: 0 = everything, 1 = only the deferred attention accumulation, 2 = everything else.  (Measured: running the
   // accumulation -- whole-CU workgroups -- before releasing the side stream's tail is 3 % SLOWER than letting both run.)
   int bwd_epilogue_late(hipStream_t s, bool chunked = false, int part = 0) {
-    auto wgrad = [&](const void* left, int lrows, const void* right, int rrows, int K, float* C, int ldc) -> int {
-      return wgrad1(left, lrows, right, rrows, K, C, ldc, s);
-    };
     // h2att
     if (!chunked && part != 1) {
       const UicGemmTnSeg seg{off(L.h_att, NH, dt), H, H};
@@ -1052,8 +1028,8 @@ int uic_topdown_sample(const uic_topdown_dims* d, const uic_topdown_weights* w, 
   const Layout L = make_layout(*d, workspace);
   const Derived dv = make_derived(*d, w, (void*)derived);
   const int dt = d->dtype;
-  const int N = d->N, H = d->H, E = d->E, V1 = d->V1;
-  const int V1p = (int)vpad(V1), H4 = 4 * H, ldih = E + 2 * H;
+  const int N = d->N, H = d->H, V1 = d->V1;
+  const int V1p = (int)vpad(V1);
   const size_t S = uic_dtype_size(dt);
   const size_t NH = (size_t)N * H;
   const void *fc_in, *att_in;
