@@ -662,3 +662,38 @@ def test_beam_search_bf16_and_real_vocab_vs_oracle():
             if tok == 0:
                 assert int(seq[k, t:].abs().sum()) == 0 and float(lp[k, t + 1:].abs().sum()) == 0
                 break
+
+
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+def test_shapes_off_the_fast_paths_vs_oracle(dtype):
+    """R = 50 regions (beyond the 36-region fast attention kernels), A != H != E, 70 caption rows (not a tile multiple), a
+    1001-word vocabulary: the generic kernels and the transposing fall-backs of the weight gradients against the oracle."""
+    from unpaired_image_captioning_amd import models
+    from unpaired_image_captioning_amd.trainer import xe_step
+    cfg = dict(V=1000, E=96, H=160, A=128, D=200, L=9, n_img=14, S=5, R=50)
+    torch.manual_seed(2)
+    model = models.setup(make_opt(cfg, dtype, seed=4))
+    W = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    model.cuda().train()
+    b = O.synthetic_batch(cfg["n_img"], cfg["S"], cfg["R"], cfg["D"], cfg["V"], cfg["L"], seed=6, ragged_regions=True)
+    batch = {k: v.cuda() for k, v in b.items()}
+    loss, grads = xe_step(model, batch)
+    loss_o, grads_o, logp_o = O.xe_loss_and_grads(W, b["fc_feats"], b["att_feats"], b["labels"], b["masks"], b["att_masks"])
+    assert abs(loss.item() - loss_o.item()) < LOGP_TOL[dtype]
+    grads_close(grads, grads_o, GRAD_TOL[dtype])
+    model.eval()
+    idx = torch.arange(cfg["n_img"]) * cfg["S"]
+    seq, lp = model(batch["fc_feats"][idx], None, batch["att_feats"][idx], batch["att_masks"][idx], opt={"sample_max": 1}, mode="sample")
+    seq_o, lp_o = O.sample(W, b["fc_feats"][idx], b["att_feats"][idx], b["att_masks"][idx], cfg["L"])
+    if dtype == "f32":
+        assert torch.equal(seq.cpu(), seq_o)
+        assert absmax(lp, lp_o) < 1e-3
+        bseq, blp = model(batch["fc_feats"][idx], None, batch["att_feats"][idx], batch["att_masks"][idx], opt={"beam_size": 4}, mode="sample")
+        bseq_o, blp_o = O.sample_beam(W, b["fc_feats"][idx], b["att_feats"][idx], b["att_masks"][idx], cfg["L"], 4)
+        # untrained weights give nearly flat distributions: two candidates can tie to within f32 rounding and swap between
+        # the device and the CPU, so images may differ in the chosen beam -- but only between beams of (numerically) equal
+        # score; wherever the tokens agree the recorded log-probs must agree too
+        same = (bseq.cpu() == bseq_o).all(1)
+        assert same.float().mean().item() >= 0.7
+        assert absmax(blp[same.cuda()], blp_o[same]) < 1e-3
+        assert (blp.cpu().sum(1) - blp_o.sum(1)).abs().max().item() < 2e-3

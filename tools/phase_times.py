@@ -1,0 +1,80 @@
+#!/usr/bin/env python3
+"""Isolated phase timings of the captioner step at the bench shapes (HIP events): forward API call (prologue + recurrence +
+all logits, one stream), XE, backward API call (one stream), fused two-stream step, Adam."""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+import bench
+from unpaired_image_captioning_amd.synthetic import synthetic_batch
+from unpaired_image_captioning_amd.trainer import Trainer, xe_step
+
+c = bench.CFG
+torch.manual_seed(1234)
+tr = Trainer(bench.make_opt("bf16", 1234)); tr.build_optimizer()
+batch = synthetic_batch(c["n_img"], c["S"], c["R"], c["D"], c["V"], c["L"], seed=1234)
+model = tr.i2t_model
+eng = model.engine
+t_run = model._steps_to_run(batch["labels"])
+pd = {k: v.detach() for k, v in model.param_dict().items()}
+grads = tr.arena.grad_views
+
+
+def timeit(fn, iters=10, warm=3):
+    for _ in range(warm):
+        fn()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize(); e0.record()
+    for _ in range(iters):
+        fn()
+    e1.record(); torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / iters
+
+
+state = {}
+def fwd():
+    _, ws, (d, w, b) = eng.forward(pd, batch["fc_feats"], batch["att_feats"], batch["att_masks"], batch["labels"], t_run, True, 5,
+                                   want_logprobs=False, masks=batch["masks"])
+    state["x"] = (ws, d, w, b)
+def fwd_rel():
+    fwd(); eng.release(state["x"][0])
+def loss():
+    ws, d, w, b = state["x"]; eng.xe_loss(ws, d, b, t_run)
+def bwd():
+    ws, d, w, b = state["x"]; eng.backward(ws, d, w, b, t_run, True, 5, grads)
+print("forward API (refresh + prologue + 17 steps + logits): %.3f ms" % timeit(fwd_rel))
+fwd()
+print("xe_loss: %.3f ms" % timeit(loss))
+print("backward API (single stream): %.3f ms" % timeit(bwd))
+eng.release(state["x"][0])
+print("fused two-stream step (xe_step): %.3f ms" % timeit(lambda: xe_step(model, batch, t_run=t_run, grads=grads)))
+print("separate calls (xe_step fused=False): %.3f ms" % timeit(lambda: xe_step(model, batch, t_run=t_run, grads=grads, fused=False)))
+den = float(batch["masks"][:, 1:c["L"] + 2].sum().item())
+print("whole trainer step: %.3f ms" % timeit(lambda: tr.train_device_batch(batch, t_run, den)))
+
+# ---- self-critical branch (P/trainer.py:166-171): multinomial sampling pass (train mode), greedy baseline (eval mode),
+# teacher-forced replay + backward with the reward weights
+fc, att, am = batch["fc_feats"], batch["att_feats"], batch["att_masks"]
+def sample_pass():
+    model.train()
+    with torch.no_grad():
+        return model(fc, None, att, am, opt={'sample_max': 0}, mode='sample')
+def greedy_pass():
+    model.eval()
+    with torch.no_grad():
+        r = model(fc, None, att, am, opt={'sample_max': 1}, mode='sample')
+    model.train()
+    return r
+def beam_pass():
+    model.eval()
+    with torch.no_grad():
+        r = model(fc[::5], None, att[::5], am[::5], opt={'beam_size': 3}, mode='sample')
+    model.train()
+    return r
+print("multinomial sampling pass, 640 rows x 16 steps: %.3f ms" % timeit(sample_pass))
+print("greedy pass, 640 rows x 16 steps: %.3f ms" % timeit(greedy_pass))
+print("beam-3 search, 128 images x 16 steps: %.3f ms" % timeit(beam_pass))
+import numpy as np
+data = {k: v.cpu().numpy() for k, v in batch.items()}
+def scst():
+    tr.train_self_critical(data, lambda d, s, g: np.ones(s.shape, dtype=np.float32))
+print("Trainer.train_self_critical incl. H2D of the batch and the reward round trip: %.3f ms" % timeit(scst, iters=5, warm=2))
