@@ -122,3 +122,27 @@ def init_weights(V1: int, E: int, H: int, Dfc: int, seed: int = 0) -> Weights:
         "embed.weight": (torch.rand(V1, E, generator=g) * 2 - 1) * 0.1,
         "logit.weight": (torch.rand(V1, H, generator=g) * 2 - 1) * 0.1, "logit.bias": torch.zeros(V1),
     }
+
+
+def sample_beam(W: Weights, fc_feats: Tensor, seq_length: int, beam_size: int, decoding_constraint: int = 0, max_ppl: int = 0):
+    """FCModel_NMT._sample_beam (P/models/FCModel_NMT.py:136-162) over CaptionModel.beam_search
+    (``oracle.topdown.beam_search_core``): two warm-up core steps (image embedding, then <bos>), then the search with
+    get_logprobs_state = embed -> core -> log_softmax(logit) (:126-134).  Returns [N, L] tensors."""
+    from .topdown import beam_search_core
+    N = fc_feats.shape[0]
+    H = W["core.h2h.weight"].shape[1]
+    B, L = beam_size, seq_length
+    seq = torch.zeros(N, L, dtype=torch.long)
+    seq_logp = torch.zeros(N, L)
+
+    def step_fn(it, state):
+        h, c = lstm_core(W, W["embed.weight"][it], state[0][0], state[1][0])
+        return F.log_softmax(F.linear(h, W["logit.weight"], W["logit.bias"]), dim=1), (h.unsqueeze(0), c.unsqueeze(0))
+    for k in range(N):
+        xt = F.linear(fc_feats[k:k + 1], W["img_embed.weight"], W["img_embed.bias"]).expand(B, -1)
+        h, c = lstm_core(W, xt, torch.zeros(B, H), torch.zeros(B, H))
+        logprobs, state = step_fn(torch.zeros(B, dtype=torch.long), (h.unsqueeze(0), c.unsqueeze(0)))
+        done = beam_search_core(step_fn, logprobs, state, L, B, decoding_constraint, max_ppl)
+        seq[k] = done[0]["seq"]
+        seq_logp[k] = done[0]["logps"]
+    return seq, seq_logp

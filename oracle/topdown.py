@@ -263,18 +263,62 @@ def sample(W: Weights, fc_feats: Tensor, att_feats: Tensor, att_masks: Optional[
     return seq, seq_logp
 
 
-def sample_beam(W: Weights, fc_feats: Tensor, att_feats: Tensor, att_masks: Optional[Tensor], seq_length: int,
-                beam_size: int, decoding_constraint: int = 0, max_ppl: int = 0, use_bn: int = 0, return_beams: bool = False):
-    """AttModel._sample_beam + CaptionModel.beam_search with group_size = 1 (P/models/AttModel.py:167-196,
-    P/models/CaptionModel.py:33-177), image by image like the reference.
+def beam_search_core(step_fn, logprobs: Tensor, state, seq_length: int, beam_size: int, decoding_constraint: int = 0,
+                     max_ppl: int = 0):
+    """CaptionModel.beam_search with group_size = 1 (P/models/CaptionModel.py:33-177) for ONE image.
+    ``step_fn(it [B], state) -> (logprobs [B, V1], state)`` is the model's get_logprobs_state; ``state`` a tuple of
+    [layers, B, H] tensors.  Returns the done beams, best first.
 
     Kept exactly: step 0 expands beam 0 only (:64-66); candidates are enumerated word-rank-major, beam-minor and sorted
     by joint log-prob with a stable sort (:67-74); the last vocabulary index gets -1000 (:133) and, with
     decoding_constraint, the previous word -inf (:130-131) BEFORE ranking, and the modified value is what is recorded as
     the step's log-prob (:98); a beam that emitted 0 -- or any beam at the last step -- is copied to the done list and
     its running sum set to -1000 but it keeps being expanded (:147-161); done beams are ranked by p (p / length with
-    max_ppl) with a stable sort and the best one is the result (:174-176, AttModel.py:193-194).
-    """
+    max_ppl) with a stable sort (:174-176)."""
+    B, L = beam_size, seq_length
+    beam_seq = torch.zeros(L, B, dtype=torch.long)
+    beam_lp = torch.zeros(L, B)
+    beam_sum = torch.zeros(B)
+    done = []
+    for t in range(L):
+        lpf = logprobs.clone()
+        if decoding_constraint and t > 0:
+            lpf.scatter_(1, beam_seq[t - 1].unsqueeze(1), float("-inf"))
+        lpf[:, -1] = lpf[:, -1] - 1000
+        ys, ix = torch.sort(lpf, 1, True)
+        cands = []
+        rows = 1 if t == 0 else B
+        for c in range(min(B, ys.shape[1])):
+            for q in range(rows):
+                cands.append(dict(c=int(ix[q, c]), q=q, p=float(beam_sum[q]) + float(ys[q, c]), r=float(lpf[q, ix[q, c]])))
+        cands = sorted(cands, key=lambda x: -x["p"])
+        new_state = tuple(x.clone() for x in state)
+        prev_seq, prev_lp = beam_seq[:t].clone(), beam_lp[:t].clone()
+        for vix in range(B):
+            v = cands[vix]
+            if t >= 1:
+                beam_seq[:t, vix] = prev_seq[:, v["q"]]
+                beam_lp[:t, vix] = prev_lp[:, v["q"]]
+            for k in range(len(state)):
+                new_state[k][:, vix] = state[k][:, v["q"]]
+            beam_seq[t, vix] = v["c"]
+            beam_lp[t, vix] = v["r"]
+            beam_sum[vix] = v["p"]
+        state = new_state
+        for vix in range(B):
+            if int(beam_seq[t, vix]) == 0 or t == L - 1:
+                p = float(beam_sum[vix])
+                done.append(dict(seq=beam_seq[:, vix].clone(), logps=beam_lp[:, vix].clone(),
+                                 p=p / (t + 1) if max_ppl else p))
+                beam_sum[vix] = -1000
+        logprobs, state = step_fn(beam_seq[t].clone(), state)
+    return sorted(done, key=lambda x: -x["p"])[:B]
+
+
+def sample_beam(W: Weights, fc_feats: Tensor, att_feats: Tensor, att_masks: Optional[Tensor], seq_length: int,
+                beam_size: int, decoding_constraint: int = 0, max_ppl: int = 0, use_bn: int = 0, return_beams: bool = False):
+    """AttModel._sample_beam (P/models/AttModel.py:167-196) over beam_search_core, image by image like the reference;
+    the best finished beam per image is the result (:193-194)."""
     assert beam_size <= W["logit.weight"].shape[0]
     N = fc_feats.shape[0]
     H = W["logit.weight"].shape[1]
@@ -288,45 +332,13 @@ def sample_beam(W: Weights, fc_feats: Tensor, att_feats: Tensor, att_masks: Opti
         tatt = att[k:k + 1].expand(B, -1, -1).contiguous()
         tpatt = p_att[k:k + 1].expand(B, -1, -1).contiguous()
         tmask = masks[k:k + 1].expand(B, -1).contiguous() if masks is not None else None
+
+        def step_fn(it, state):
+            lp, st, _ = logprobs_step(W, it, tfc, tatt, tpatt, tmask, state)
+            return lp, st
         state = (torch.zeros(2, B, H), torch.zeros(2, B, H))
-        logprobs, state, _ = logprobs_step(W, torch.zeros(B, dtype=torch.long), tfc, tatt, tpatt, tmask, state)
-        beam_seq = torch.zeros(L, B, dtype=torch.long)
-        beam_lp = torch.zeros(L, B)
-        beam_sum = torch.zeros(B)
-        done = []
-        for t in range(L):
-            lpf = logprobs.clone()
-            if decoding_constraint and t > 0:
-                lpf.scatter_(1, beam_seq[t - 1].unsqueeze(1), float("-inf"))
-            lpf[:, -1] = lpf[:, -1] - 1000
-            ys, ix = torch.sort(lpf, 1, True)
-            cands = []
-            rows = 1 if t == 0 else B
-            for c in range(min(B, ys.shape[1])):
-                for q in range(rows):
-                    cands.append(dict(c=int(ix[q, c]), q=q, p=float(beam_sum[q]) + float(ys[q, c]), r=float(lpf[q, ix[q, c]])))
-            cands = sorted(cands, key=lambda x: -x["p"])
-            new_state = (state[0].clone(), state[1].clone())
-            prev_seq, prev_lp = beam_seq[:t].clone(), beam_lp[:t].clone()
-            for vix in range(B):
-                v = cands[vix]
-                if t >= 1:
-                    beam_seq[:t, vix] = prev_seq[:, v["q"]]
-                    beam_lp[:t, vix] = prev_lp[:, v["q"]]
-                new_state[0][:, vix] = state[0][:, v["q"]]
-                new_state[1][:, vix] = state[1][:, v["q"]]
-                beam_seq[t, vix] = v["c"]
-                beam_lp[t, vix] = v["r"]
-                beam_sum[vix] = v["p"]
-            state = new_state
-            for vix in range(B):
-                if int(beam_seq[t, vix]) == 0 or t == L - 1:
-                    p = float(beam_sum[vix])
-                    done.append(dict(seq=beam_seq[:, vix].clone(), logps=beam_lp[:, vix].clone(),
-                                     p=p / (t + 1) if max_ppl else p))
-                    beam_sum[vix] = -1000
-            logprobs, state, _ = logprobs_step(W, beam_seq[t].clone(), tfc, tatt, tpatt, tmask, state)
-        done = sorted(done, key=lambda x: -x["p"])[:B]
+        logprobs, state = step_fn(torch.zeros(B, dtype=torch.long), state)
+        done = beam_search_core(step_fn, logprobs, state, L, B, decoding_constraint, max_ppl)
         seq[k] = done[0]["seq"]
         seq_logp[k] = done[0]["logps"]
         all_done.append(done)

@@ -261,6 +261,23 @@ def run_fc_case(crit_mod, name, V, E, H, D, L, n_img, S, seed, short_all=False, 
         seq, seq_logp = model._sample(fc[idx], None, None, {"sample_max": 1, "beam_size": 1})
     out["out::greedy_seq"] = seq.numpy()
     out["out::greedy_logp"] = seq_logp.numpy()
+    # beam search (FCModel_NMT._sample_beam + CaptionModel.beam_search); the EOS-bias variants make beams finish early
+    if H <= 64:
+        for tag, bs, dc, mp, eos_bias in (("b3", 3, 0, 0, 0.0), ("b2c", 2, 1, 0, 0.0), ("b3eos", 3, 0, 0, 3.0), ("b4ppl", 4, 1, 1, 2.5)):
+            with torch.no_grad():
+                model.logit.bias[0] += eos_bias
+                opts = {"sample_max": 1, "beam_size": bs, "decoding_constraint": dc, "max_ppl": mp}
+                # public path: FCModel_NMT._sample hands `opt` to _sample_beam as its att_masks argument (:168), so the
+                # search really runs with the defaults beam_size 10, no constraint, no max_ppl
+                bseq, blp = model._sample(fc[idx], None, None, opts)
+                # direct call with the options honoured
+                dseq, dlp = model._sample_beam(fc[idx], None, None, opts)
+                model.logit.bias[0] -= eos_bias
+            out["beam::%s_cfg" % tag] = np.array([bs, dc, mp, eos_bias], dtype=np.float64)
+            out["beam::%s_seq" % tag] = bseq.numpy().copy()
+            out["beam::%s_logp" % tag] = blp.numpy().copy()
+            out["beamd::%s_seq" % tag] = dseq.numpy().copy()
+            out["beamd::%s_logp" % tag] = dlp.numpy().copy()
     path = os.path.join(HERE, name + ".npz")
     np.savez_compressed(path, **out)
     print("wrote %s (%.1f KB) loss=%.6f" % (path, os.path.getsize(path) / 1024, loss.item()))

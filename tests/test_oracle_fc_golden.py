@@ -55,3 +55,26 @@ def test_fc_config1_shapes():
     seq, lp = OF.sample(Wt, b["fc_feats"][idx], L)
     assert torch.equal(seq, Out["greedy_seq"])
     _close(lp, Out["greedy_logp"], 2e-5)
+
+
+@pytest.mark.parametrize("name", ["fc_tiny", "fc_tiny_earlybreak", "fc_odd"])
+def test_fc_beam_search_matches_reference(name):
+    """FCModel_NMT._sample_beam + CaptionModel.beam_search: token ids identical, log-probs within 1e-5.  Two paths:
+    the direct `_sample_beam(..., opt)` call honours the options; the public `_sample(..., opt)` call passes `opt` in the
+    att_masks slot (P/models/FCModel_NMT.py:168), so the reference searches with beam_size 10 and no constraint whatever
+    the caller asked for -- both behaviours are pinned."""
+    cfg, W, I, Out, G, X = load_golden(name)
+    idx = torch.arange(cfg["n_img"]) * cfg["S"]
+    n_early = 0
+    for tag in ("b3", "b2c", "b3eos", "b4ppl"):
+        bs, dc, mp, eos_bias = [float(x) for x in X["beam::%s_cfg" % tag]]
+        Wb = dict(W)
+        Wb["logit.bias"] = W["logit.bias"].clone()
+        Wb["logit.bias"][0] += eos_bias
+        for prefix, args in (("beamd", (int(bs), int(dc), int(mp))), ("beam", (10, 0, 0))):
+            seq, lp = OF.sample_beam(Wb, I["fc_feats"][idx], cfg["L"], *args)
+            ref = torch.as_tensor(X["%s::%s_seq" % (prefix, tag)])
+            assert torch.equal(seq, ref), (prefix, tag, seq, ref)
+            assert (lp - torch.as_tensor(X["%s::%s_logp" % (prefix, tag)])).abs().max().item() < 1e-5
+            n_early += int((ref == 0).any())
+    assert n_early > 0
