@@ -209,6 +209,10 @@ int uic_fc_backward(const uic_fc_dims* d, const uic_fc_weights* w, const uic_top
 int uic_fc_sample(const uic_fc_dims* d, const uic_fc_weights* w, const uic_topdown_batch* batch, int32_t L,
                   int32_t sample_max, float temperature, uint32_t seed, const int64_t* forced, void* workspace,
                   int64_t* seq, float* seq_logp, void* stream);
+/* FCModel_NMT._sample_beam (P/models/FCModel_NMT.py:136-162) over CaptionModel.beam_search, all images at once; the batch
+ * holds every image replicated beam_size times (N = images * beam_size).  seq / seq_logp: [images, L]. */
+int uic_fc_sample_beam(const uic_fc_dims* d, const uic_fc_weights* w, const uic_topdown_batch* b, int32_t L, int32_t beam_size,
+                       int32_t decoding_constraint, int32_t max_ppl, void* workspace, int64_t* seq, float* seq_logp, void* stream);
 
 /* ---- pivot NMT step: NMTModel.forward + generator + NMTCriterion and their backward (P/models/NMT_Models.py:27-295,
  * 414-420; O = misc/OpenNMT-py-dalegebit/onmt: O/modules/StackedRNN.py:20-34, O/modules/GlobalAttention.py:112-167;

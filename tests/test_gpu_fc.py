@@ -128,3 +128,26 @@ def test_fc_config1_shapes_vs_reference_golden(dtype):
         seq, lp = model(fc[idx], None, None, opt={"sample_max": 1}, mode="sample")
         assert torch.equal(seq.cpu(), Out["greedy_seq"])
         assert absmax(lp, Out["greedy_logp"]) < 1e-3
+
+
+@pytest.mark.parametrize("name", ["fc_tiny", "fc_tiny_earlybreak", "fc_odd"])
+def test_fc_beam_search_bit_exact_vs_reference_golden(name):
+    """FCModel_NMT._sample_beam + CaptionModel.beam_search on the device, f32: the direct call honours the options; the
+    public `_sample` call reproduces the reference's lost-options behaviour (beam 10, no constraint)."""
+    cfg, W, I, Out, G, X = load_golden(name)
+    model = build(cfg, W, "f32").eval()
+    idx = torch.arange(cfg["n_img"]) * cfg["S"]
+    fc = I["fc_feats"][idx].cuda()
+    for tag in ("b3", "b2c", "b3eos", "b4ppl"):
+        bs, dc, mp, eos_bias = [float(x) for x in X["beam::%s_cfg" % tag]]
+        opts = {"sample_max": 1, "beam_size": int(bs), "decoding_constraint": int(dc), "max_ppl": int(mp)}
+        with torch.no_grad():
+            model.logit.bias[0] += eos_bias
+        seq_d, lp_d = model._sample_beam(fc, None, None, opts)
+        seq_p, lp_p = model(fc, None, None, opt=opts, mode="sample")
+        with torch.no_grad():
+            model.logit.bias[0] -= eos_bias
+        assert torch.equal(seq_d.cpu(), torch.as_tensor(X["beamd::%s_seq" % tag])), tag
+        assert absmax(lp_d, torch.as_tensor(X["beamd::%s_logp" % tag])) < 1e-3
+        assert torch.equal(seq_p.cpu(), torch.as_tensor(X["beam::%s_seq" % tag])), tag
+        assert absmax(lp_p, torch.as_tensor(X["beam::%s_logp" % tag])) < 1e-3

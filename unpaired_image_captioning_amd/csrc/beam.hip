@@ -154,7 +154,8 @@ __global__ void beam_gather_kernel(const int* __restrict__ parent, int B, int H,
     const int j = (int)(i - row * H);
     const size_t src = (row / B) * B + parent[row];
     const size_t o = src * H + j;
-    h1d[i] = h1s[o]; h2d[i] = h2s[o]; c1d[i] = c1s[o]; c2d[i] = c2s[o];
+    h1d[i] = h1s[o]; c1d[i] = c1s[o];
+    if (h2s) { h2d[i] = h2s[o]; c2d[i] = c2s[o]; }   // second LSTM layer (none in the FC model)
   }
 }
 

@@ -32,6 +32,9 @@ struct FcLayout {
   void* tA; void* tB; float* colscratch; size_t colscratch_floats; float* slab; size_t slab_bytes;
   // sampling
   void* s_h[2]; float* s_c[2]; void* s_xt; float* s_logits; int64_t* s_it; int* s_unf; int* s_nunf;
+  // beam search bookkeeping (rows = (image, beam))
+  float* bm_cand_val; int* bm_cand_idx; int64_t* bm_seq[2]; float* bm_lp[2]; float* bm_sum; int* bm_parent;
+  int* bm_done_count; float* bm_done_p; int64_t* bm_done_seq; float* bm_done_lp;
   size_t total;
 };
 
@@ -91,6 +94,18 @@ FcLayout fc_layout(const uic_fc_dims& d, const uic_fc_weights* w, void* ws) {
   L.s_it = (int64_t*)b.take(N * 8);
   L.s_unf = (int*)b.take(N * 4);
   L.s_nunf = (int*)b.take((S + 2) * 4);
+  L.bm_cand_val = (float*)b.take(N * UIC_BEAM_MAX * 4);
+  L.bm_cand_idx = (int*)b.take(N * UIC_BEAM_MAX * 4);
+  for (int i = 0; i < 2; ++i) {
+    L.bm_seq[i] = (int64_t*)b.take(N * S * 8);
+    L.bm_lp[i] = (float*)b.take(N * S * 4);
+  }
+  L.bm_sum = (float*)b.take(N * 4);
+  L.bm_parent = (int*)b.take(N * 4);
+  L.bm_done_count = (int*)b.take(N * 4);
+  L.bm_done_p = (float*)b.take(N * S * 4);
+  L.bm_done_seq = (int64_t*)b.take(N * S * S * 8);
+  L.bm_done_lp = (float*)b.take(N * S * S * 4);
   L.total = (b.off + 255) & ~(size_t)255;
   return L;
 }
@@ -240,11 +255,10 @@ int uic_fc_backward(const uic_fc_dims* d, const uic_fc_weights* w, const uic_top
     g.C = L.dh_all; g.ldc = H; g.flags = UIC_GEMM_OUT_F32;
     UIC_TRY(uic_gemm_launch(g, s));
   }
-  UIC_TRY(uic_transpose_launch(dt, L.dlogits, Ml, V1, V1p, L.tA, Mlp, s));
-  UIC_TRY(uic_transpose_launch(dt, off(L.h_buf, 2 * NH, dt), Ml, H, H, L.tB, Mlp, s));
   {
+    const UicGemmTnSeg seg{off(L.h_buf, 2 * NH, dt), H, H};
     const WDest d1{G->logit_w, H, 0, H};
-    UIC_TRY(wgrad_multi(L.slab, L.slab_bytes, dt, L.tA, V1, L.tB, H, Mlp, &d1, 1, s));
+    UIC_TRY(wgrad_group(L.slab, L.slab_bytes, dt, L.dlogits, V1p, V1, &seg, 1, Ml, &d1, 1, s, false, L.tA, L.tB));
   }
   UIC_TRY(uic_colsum_launch(dt, L.dlogits, Ml, V1, V1p, G->logit_b, L.colscratch, L.colscratch_floats, s));
   // BPTT
@@ -268,12 +282,10 @@ int uic_fc_backward(const uic_fc_dims* d, const uic_fc_weights* w, const uic_top
     }
   }
   // core weights: dS^T [5H, S*N] x [h_prev | x]^T in one GEMM
-  UIC_TRY(uic_transpose_launch(dt, L.ds_all, Ms, H5, H5, L.tA, Msp, s));
-  UIC_TRY(uic_transpose_launch(dt, L.h_buf, Ms, H, H, L.tB, Msp, s));
-  UIC_TRY(uic_transpose_launch(dt, L.x_all, Ms, E, E, offw(L.tB, (size_t)H * Msp, dt), Msp, s));
   {
+    const UicGemmTnSeg segs[2] = {{L.h_buf, H, H}, {L.x_all, E, E}};
     const WDest dd[2] = {{G->h2h_w, H, 0, H}, {G->i2h_w, E, H, E}};
-    UIC_TRY(wgrad_multi(L.slab, L.slab_bytes, dt, L.tA, H5, L.tB, H + E, Msp, dd, 2, s));
+    UIC_TRY(wgrad_group(L.slab, L.slab_bytes, dt, L.ds_all, H5, H5, segs, 2, Ms, dd, 2, s, false, L.tA, L.tB));
   }
   UIC_TRY(uic_colsum_launch(dt, L.ds_all, Ms, H5, H5, G->i2h_b, L.colscratch, L.colscratch_floats, s));
   UIC_TRY(uic_check_hip(hipMemcpyAsync(G->h2h_b, G->i2h_b, (size_t)H5 * 4, hipMemcpyDeviceToDevice, s), "memcpy h2h_b"));
@@ -287,11 +299,10 @@ int uic_fc_backward(const uic_fc_dims* d, const uic_fc_weights* w, const uic_top
   UIC_TRY(uic_embed_bwd_launch(dt, L.dx_all + (size_t)N * E, nullptr, b->labels, b->ld_labels, N, s_run - 1, V1, E, 0.f, -1, G->embed_w, s));
   // img_embed from d x_0
   UIC_TRY(uic_cast_f32_launch(dt, L.dx_all, L.dx0, (size_t)N * E, s));
-  UIC_TRY(uic_transpose_launch(dt, L.dx0, N, E, E, L.tA, Np, s));
-  UIC_TRY(uic_transpose_launch(dt, fc_in, N, Dfc, Dfc, L.tB, Np, s));
   {
+    const UicGemmTnSeg seg{fc_in, Dfc, Dfc};
     const WDest d1{G->img_embed_w, Dfc, 0, Dfc};
-    UIC_TRY(wgrad_multi(L.slab, L.slab_bytes, dt, L.tA, E, L.tB, Dfc, Np, &d1, 1, s));
+    UIC_TRY(wgrad_group(L.slab, L.slab_bytes, dt, L.dx0, E, E, &seg, 1, N, &d1, 1, s, false, L.tA, L.tB));
   }
   return uic_colsum_launch(UIC_F32, L.dx_all, N, E, E, G->img_embed_b, L.colscratch, L.colscratch_floats, s);
 }
@@ -347,6 +358,71 @@ int uic_fc_sample(const uic_fc_dims* d, const uic_fc_weights* w, const uic_topdo
     }
   }
   return uic_sample_fixup_launch(N, Lsteps, ld, L.s_nunf, seq, seq_logp, s);
+}
+
+
+int uic_fc_sample_beam(const uic_fc_dims* d, const uic_fc_weights* w, const uic_topdown_batch* b, int32_t Lsteps, int32_t beam_size,
+                       int32_t decoding_constraint, int32_t max_ppl, void* workspace, int64_t* seq, float* seq_logp, void* stream) {
+  UIC_TRY(fc_check(d));
+  UIC_REQUIRE(w && b && workspace && seq && seq_logp && b->fc_feats, "fc_sample_beam: null pointer");
+  UIC_REQUIRE(Lsteps >= 1 && Lsteps <= d->S, "fc_sample_beam: L=%d outside [1,%d]", Lsteps, d->S);
+  UIC_REQUIRE(beam_size >= 1 && beam_size <= UIC_BEAM_MAX && beam_size <= d->V1, "fc_sample_beam: beam_size=%d outside [1, %d]", beam_size, UIC_BEAM_MAX);
+  UIC_REQUIRE(d->N % beam_size == 0, "fc_sample_beam: N=%d rows must be images x beam_size=%d", d->N, beam_size);
+  hipStream_t s = (hipStream_t)stream;
+  const FcLayout L = fc_layout(*d, w, workspace);
+  const int dt = d->dtype, N = d->N, H = d->H, E = d->E, V1 = d->V1, V1p = (int)vpad(V1), S = d->S;
+  const size_t Sz = uic_dtype_size(dt), NH = (size_t)N * H;
+  UIC_TRY(fc_refresh(*d, w, L, s));
+  const void* fc_in = b->fc_feats;
+  if (dt == UIC_BF16) {
+    UIC_TRY(uic_cast_f32_launch(dt, b->fc_feats, L.fcT, (size_t)N * d->Dfc, s));
+    fc_in = L.fcT;
+  }
+  UIC_TRY(uic_fill_launch(L.s_h[0], 0, NH * Sz, s));
+  UIC_TRY(uic_fill_launch(L.s_c[0], 0, NH * 4, s));
+  UIC_TRY(uic_fill_launch(L.s_it, 0, (size_t)N * 8, s));            // <bos> (:151-153)
+  for (int i = 0; i < 2; ++i) {
+    UIC_TRY(uic_fill_launch(L.bm_seq[i], 0, (size_t)N * S * 8, s));
+    UIC_TRY(uic_fill_launch(L.bm_lp[i], 0, (size_t)N * S * 4, s));
+  }
+  UIC_TRY(uic_fill_launch(L.bm_sum, 0, (size_t)N * 4, s));
+  UIC_TRY(uic_fill_launch(L.bm_done_count, 0, (size_t)N * 4, s));
+  auto logits = [&](const void* h) -> int {
+    UicGemmParams g = gemm_base(dt, N, V1);
+    add_seg(g, h, H, L.logit_w, H, H);
+    g.C = L.s_logits; g.ldc = V1p; g.bias = w->logit_b; g.flags = UIC_GEMM_OUT_F32;
+    return uic_gemm_launch(g, s);
+  };
+  {  // warm-up step 0: the image embedding (:149-150), state slot 0 -> 1
+    UicGemmParams g = gemm_base(dt, N, E);
+    add_seg(g, fc_in, d->Dfc, L.img_w, d->Dfc, d->Dfc);
+    g.C = L.s_xt; g.ldc = E; g.bias = w->img_embed_b;
+    UIC_TRY(uic_gemm_launch(g, s));
+    UIC_TRY(fc_core(*d, L, L.s_xt, w, nullptr, L.s_h[0], L.s_c[0], L.s_c[1], L.s_h[1], nullptr, 0.f, 0, 0, s));
+  }
+  // warm-up step 1: <bos> (:151-156), slot 1 -> 0; its log-probs open the search
+  UIC_TRY(uic_embed_fwd_launch(dt, w->embed_w, V1, E, L.s_it, 1, N, 1, 0.f, 0, 0, 0, 0, L.s_xt, s));
+  UIC_TRY(fc_core(*d, L, L.s_xt, w, nullptr, L.s_h[1], L.s_c[1], L.s_c[0], L.s_h[0], nullptr, 0.f, 0, 1, s));
+  UIC_TRY(logits(L.s_h[0]));
+  UicBeamParams p;
+  memset(&p, 0, sizeof(p));
+  p.n_img = N / beam_size; p.B = beam_size; p.L = Lsteps; p.V1 = V1; p.ldv = V1p;
+  p.decoding_constraint = decoding_constraint; p.max_ppl = max_ppl;
+  p.logits = L.s_logits; p.cand_val = L.bm_cand_val; p.cand_idx = L.bm_cand_idx;
+  p.beam_seq_hist[0] = L.bm_seq[0]; p.beam_seq_hist[1] = L.bm_seq[1]; p.beam_lp_hist[0] = L.bm_lp[0]; p.beam_lp_hist[1] = L.bm_lp[1];
+  p.beam_sum = L.bm_sum; p.parent = L.bm_parent; p.it = L.s_it;
+  p.done_count = L.bm_done_count; p.done_p = L.bm_done_p; p.done_seq = L.bm_done_seq; p.done_lp = L.bm_done_lp;
+  for (int t = 0; t < Lsteps; ++t) {
+    p.t = t;
+    UIC_TRY(uic_beam_step_launch(p, s));
+    if (t + 1 == Lsteps) break;
+    UIC_TRY(uic_beam_gather_launch(dt, L.bm_parent, N, beam_size, H, L.s_h[0], L.s_h[1], nullptr, nullptr, L.s_c[0], L.s_c[1], nullptr, nullptr, s));
+    // get_logprobs_state (:126-134): embed -> core -> log_softmax(logit), slot 1 -> 0
+    UIC_TRY(uic_embed_fwd_launch(dt, w->embed_w, V1, E, L.s_it, 1, N, 1, 0.f, 0, 0, 0, 0, L.s_xt, s));
+    UIC_TRY(fc_core(*d, L, L.s_xt, w, nullptr, L.s_h[1], L.s_c[1], L.s_c[0], L.s_h[0], nullptr, 0.f, 0, t + 2, s));
+    UIC_TRY(logits(L.s_h[0]));
+  }
+  return uic_beam_final_launch(p, seq, seq_logp, s);
 }
 
 }  // extern "C"

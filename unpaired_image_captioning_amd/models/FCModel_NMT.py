@@ -164,17 +164,51 @@ class FCModel_NMT(CaptionModel):
         # reference signature (fc, att, seq[, att_masks]) or trainer call (fc, attri, att, seq, att_masks)
         seq = next(r for r in rest if torch.is_tensor(r) and r.dtype == torch.int64)
         if self.training and self.ss_prob > 0.0:
-            raise NotImplementedError("scheduled sampling (ss_prob > 0) is not on the MI355X hot path yet")
+            # P/models/FCModel_NMT.py:108 samples from exp(outputs[-1]) -- the [S, V+1] log-prob slab of the LAST BATCH ROW, not
+            # the previous step's [N, V+1] -- and then indexes those S draws with batch-row indices (:109-110): an index error
+            # as soon as a selected row index reaches S.  There is no behaviour to reproduce.
+            raise NotImplementedError("FCModel_NMT scheduled sampling is broken in the reference (outputs[-1] indexes the "
+                                      "batch, P/models/FCModel_NMT.py:108); not provided")
         s_run = self._steps_to_run(seq)
         params = [self.param_dict()[k] for k in self.param_names]
         return _FcForward.apply(self, fc_feats.contiguous().float(), seq.contiguous(), s_run, *params)
+
+    def _sample_beam(self, fc_feats, att_feats, att_masks=None, opt={}):
+        """FCModel_NMT._sample_beam (P/models/FCModel_NMT.py:136-162) over CaptionModel.beam_search, all images in one
+        device pass; returns [N, L] tensors.  `self.done_beams[k]` holds the winning beam of image k."""
+        beam_size = opt.get('beam_size', 10)
+        if opt.get('group_size', 1) != 1:
+            raise NotImplementedError("diverse beam search (group_size > 1) is not on the MI355X hot path")
+        if self.training:
+            raise NotImplementedError("beam search runs in eval mode")
+        assert beam_size <= self.vocab_size + 1
+        eng = self.engine
+        fc = fc_feats.contiguous().float()
+        n_img, L = fc.shape[0], self.seq_length
+        fcb = fc.repeat_interleave(beam_size, 0).contiguous()
+        d = eng.dims(n_img * beam_size, L + 2)
+        ws = eng.workspace(d, fc.device)
+        seq = torch.zeros(n_img, L, dtype=torch.int64, device=fc.device)
+        lp = torch.zeros(n_img, L, dtype=torch.float32, device=fc.device)
+        with torch.no_grad():
+            w = eng.weights({k: v.detach() for k, v in self.param_dict().items()})
+            b = eng.batch(fcb)
+            check(eng.lib.uic_fc_sample_beam(C.byref(d), C.byref(w), C.byref(b), L, int(beam_size), int(opt.get('decoding_constraint', 0)),
+                                             int(opt.get('max_ppl', 0)), ptr(ws), ptr(seq), ptr(lp), stream()), "fc_sample_beam")
+        eng.release(d, ws)
+        self.done_beams = [[{'seq': seq[k], 'logps': lp[k]}] for k in range(n_img)]
+        return seq, lp
 
     def _sample(self, fc_feats, *rest, **kw):
         opt = kw.get('opt', None)
         if opt is None:
             opt = next((r for r in rest if isinstance(r, dict)), {})
         if opt.get('beam_size', 1) > 1:
-            raise NotImplementedError("beam search (beam_size > 1) is a 'next' row of the hot-path scope")
+            # P/models/FCModel_NMT.py:168 calls `self._sample_beam(fc_feats, att_feats, opt)`: `opt` lands in the att_masks
+            # slot, so the reference searches with the DEFAULT options (beam_size 10, no constraint, no max_ppl) whatever the
+            # caller asked for.  Kept, so that eval scripts decode the same captions.
+            att_feats = rest[0] if rest else None
+            return self._sample_beam(fc_feats, att_feats, opt)
         eng = self.engine
         fc = fc_feats.contiguous().float()
         N, L = fc.shape[0], self.seq_length
