@@ -245,7 +245,7 @@ int uic_fc_backward(const uic_fc_dims* d, const uic_fc_weights* w, const uic_top
   const int dt = d->dtype, N = d->N, H = d->H, E = d->E, V1 = d->V1, V1p = (int)vpad(V1), H5 = 5 * H, Dfc = d->Dfc;
   const size_t NH = (size_t)N * H;
   const float drop_p = training ? d->drop_p : 0.f;
-  const int Ml = (s_run - 1) * N, Ms = s_run * N, Mlp = (int)rup8(Ml), Msp = (int)rup8(Ms), Np = (int)rup8(N);
+  const int Ml = (s_run - 1) * N, Ms = s_run * N;
   const void* fc_in = dt == UIC_BF16 ? L.fcT : (const void*)b->fc_feats;
   if (dlogprobs)
     UIC_TRY(uic_logsoftmax_bwd_launch(dt, L.dlogits, Ml, V1, V1p, N, dlogprobs, (size_t)V1, (size_t)(d->S - 1) * V1, logprobs, s));
