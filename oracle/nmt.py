@@ -132,3 +132,86 @@ def loss_and_grads(W: Weights, src, tgt, lengths, drop=None):
     grads = {k: (v.grad if v.grad is not None else torch.zeros_like(v)) for k, v in Wg.items()}
     return loss.detach(), grads, dict(outputs=outputs.detach(), attn=attn.detach(), context=context.detach(),
                                       h=h.detach(), c=c.detach(), scores=scores.detach(), num_correct=nc, num_words=nw)
+
+
+def translate_batch(W: Weights, src: Tensor, beam_size: int = 15, max_steps: int = 100):
+    """NMTModel.translateBatch (P/models/NMT_Models.py:322-395) with the fork's Beam (O/Beam.py:21-117), n_best = 1.
+
+    Kept exactly: the encoder runs WITHOUT lengths (:327: PAD positions go through both LSTM directions and the final
+    states are those of the last / first array position), source padding is masked in the attention only (:345,352);
+    every beam starts as [BOS, PAD, ...] and the first step expands slot 0 only (Beam.py:37-38,66-69); a step takes
+    the top `beam_size` of the flattened beam x word scores (:73); a sentence is done when its TOP hypothesis ends in
+    EOS (:85-87) but its beam KEEPS ADVANCING until every sentence of the batch is done (translateBatch calls advance
+    for all beams in every iteration, :372-376), and the hypothesis is read out after the last iteration by walking the
+    back-pointers from the best final score (:384-392, Beam.py:93-117) -- so its length is the number of iterations.
+
+    src [S, B, 1] int64.  Returns (hyp [B, n_iter] int64, scores [B], attn [B, n_iter, S] with PAD columns zeroed and
+    packed to the left like the reference's index_select over the valid positions)."""
+    BOS, EOS = 2, 3
+    S, B = src.shape[0], src.shape[1]
+    K = beam_size
+    context, h0, c0 = encoder(W, src, torch.full((1, B), S, dtype=torch.long))     # lengths=None: every position is "valid"
+    L = h0.shape[0]
+    H = context.shape[2]
+    # beam-major replication like `.repeat(1, beamSize, 1)`: row k * B + b
+    ctx_b = context.repeat(1, K, 1).transpose(0, 1)                                  # [K*B, S, H]
+    h = [h0[l].repeat(K, 1) for l in range(L)]
+    c = [c0[l].repeat(K, 1) for l in range(L)]
+    feed = torch.zeros(K * B, H)
+    pad_mask = src[:, :, 0].eq(PAD).t().repeat(K, 1)                                 # [K*B, S]
+    scores = [torch.zeros(K) for _ in range(B)]
+    next_ys = [[torch.full((K,), PAD, dtype=torch.long)] for _ in range(B)]
+    for b in range(B):
+        next_ys[b][0][0] = BOS
+    prev_ks = [[] for _ in range(B)]
+    attns = [[] for _ in range(B)]
+    done = [False] * B
+    for _ in range(max_steps):
+        inp = torch.stack([next_ys[b][-1] for b in range(B)]).t().contiguous().view(-1)     # [K*B], row k*B+b
+        x = torch.cat([W["decoder.embeddings.word_lut.weight"][inp], feed], 1)
+        for l in range(L):
+            h[l], c[l] = lstm_cell(x, h[l], c[l], W["decoder.rnn.layers.%d.weight_ih" % l], W["decoder.rnn.layers.%d.weight_hh" % l],
+                                   W["decoder.rnn.layers.%d.bias_ih" % l], W["decoder.rnn.layers.%d.bias_hh" % l])
+            x = h[l]
+        target = F.linear(x, W["decoder.attn.linear_in.weight"])
+        sc = torch.bmm(ctx_b, target.unsqueeze(2)).squeeze(2).masked_fill(pad_mask, float("-inf"))
+        attn = F.softmax(sc, dim=1)
+        cvec = torch.bmm(attn.unsqueeze(1), ctx_b).squeeze(1)
+        feed = torch.tanh(F.linear(torch.cat([cvec, x], 1), W["decoder.attn.linear_out.weight"]))
+        out = F.log_softmax(F.linear(feed, W["generator.0.weight"], W["generator.0.bias"]), dim=1)
+        word = out.view(K, B, -1).transpose(0, 1)                                    # [B, K, V]
+        att = attn.view(K, B, -1).transpose(0, 1)                                    # [B, K, S]
+        active = 0
+        for b in range(B):
+            V = word.shape[2]
+            lk = word[b] + scores[b].unsqueeze(1) if prev_ks[b] else word[b][0]
+            best, ids = lk.reshape(-1).topk(K, 0, True, True)
+            scores[b] = best
+            pk = torch.div(ids, V, rounding_mode="floor")
+            prev_ks[b].append(pk)
+            next_ys[b].append(ids - pk * V)
+            attns[b].append(att[b].index_select(0, pk))
+            if int(next_ys[b][-1][0]) == EOS:
+                done[b] = True
+            if not done[b]:
+                active += 1
+            # beamUpdate_: re-thread this sentence's rows of every state tensor to the surviving parents
+            rows = torch.arange(K) * B + b
+            for t_ in h + c + [feed]:
+                t_[rows] = t_[rows].index_select(0, pk)
+        if not active:
+            break
+    n_iter = len(prev_ks[0])
+    hyp = torch.zeros(B, n_iter, dtype=torch.long)
+    out_scores = torch.zeros(B)
+    out_attn = torch.zeros(B, n_iter, S)
+    for b in range(B):
+        sc_sorted, ks = torch.sort(scores[b], 0, True)
+        k = int(ks[0])
+        out_scores[b] = sc_sorted[0]
+        valid = src[:, b, 0].ne(PAD).nonzero().view(-1)
+        for j in range(n_iter - 1, -1, -1):
+            hyp[b, j] = next_ys[b][j + 1][k]
+            out_attn[b, j, :valid.numel()] = attns[b][j][k].index_select(0, valid)
+            k = int(prev_ks[b][j][k])
+    return hyp, out_scores, out_attn

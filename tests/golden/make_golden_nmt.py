@@ -223,6 +223,78 @@ def run_optim_case(nmt, crit_mod, name, steps, seed, **optkw):
     print("wrote %s (%.1f KB) losses=%s norms=%s lrs=%s" % (path, os.path.getsize(path) / 1024, losses, norms, lrs))
 
 
+def old_torch_semantics():
+    """The 2018 translator relies on torch 0.3/0.4 behaviour that later versions changed.  Emulated in the harness (the
+    reference files stay untouched): torch.cuda.*Tensor constructors on a CPU-only box, integer `/` as floor division
+    (O/Beam.py:77 `prevK = bestScoresId / numWords`), and masked_fill_ with a same-numel mask of a different shape
+    (O/modules/GlobalAttention.py:139 fills a [batch*beam, S] tensor with a [beam, batch, S] mask)."""
+    torch.cuda.FloatTensor = torch.FloatTensor
+    torch.cuda.LongTensor = torch.LongTensor
+    _td = torch.Tensor.__truediv__
+
+    def _old_div(a, b):
+        if not a.is_floating_point() and (isinstance(b, int) or (torch.is_tensor(b) and not b.is_floating_point())):
+            return torch.div(a, b, rounding_mode="floor")
+        return _td(a, b)
+    torch.Tensor.__truediv__ = _old_div
+    _mf = torch.Tensor.masked_fill_
+
+    def _old_masked_fill_(self, mask, value):
+        if mask.shape != self.shape and mask.numel() == self.numel():
+            mask = mask.reshape(self.shape)
+        return _mf(self, mask.bool(), value)
+    torch.Tensor.masked_fill_ = _old_masked_fill_
+
+
+def run_translate_case(nmt, name, layers, H, B, S, Vs, Vt, seed, eos_bias, min_len=2):
+    """NMTModel.translateBatch (P/models/NMT_Models.py:322-395) with the fork's Beam (O/Beam.py): beam 15, at most 100
+    steps, source padding masked in the attention, encoder run WITHOUT lengths (PAD positions go through the LSTM)."""
+    import onmt
+    onmt.Beam = load("onmt.Beam", os.path.join(O, "Beam.py")).Beam
+    torch.manual_seed(seed)
+    opt = make_opt(layers, H, H)
+    sd, td = FakeDict(Vs), FakeDict(Vt)
+    model = nmt.NMTModel(opt, nmt.Encoder(opt, sd), nmt.Decoder(opt, td), sd, td)
+    model.generator = nn.Sequential(nn.Linear(H, Vt), nn.LogSoftmax(dim=1))
+    with torch.no_grad():
+        # stronger weights than the default init, so that the output distribution really depends on the decoder state (with
+        # the default it is almost the same at every step: EOS either wins at step 0 or never), then an EOS (= 3) bias tuned
+        # per case so that the sentences finish at different steps
+        for k, v in model.named_parameters():
+            if "rnn" in k or "attn" in k:
+                v.mul_(4.0)
+            elif "word_lut" in k:
+                v.mul_(3.0)
+        model.generator[0].weight.mul_(10.0)
+        model.generator[0].bias[3] += eos_bias
+    src, lengths, _ = synth_batch(B, S, 4, Vs, Vt, seed)
+    if min_len < S:                                       # more padding than synth_batch makes
+        for b in range(1, B):
+            n = max(min_len, int(lengths[0, b]) - b)
+            src[n:, b, 0] = 0
+    batch = argparse.Namespace(src=src, batchSize=B)
+    model.eval()
+    with torch.no_grad():
+        allHyp, allScores, allAttn, gold = model.translateBatch(batch)
+    n_iter = len(allHyp[0][0])
+    out = {"cfg": np.array([layers, H, B, S, n_iter, Vs, Vt], dtype=np.int64)}
+    for k, v in model.state_dict().items():
+        out["w::" + k] = v.detach().clone().numpy()
+    out["in::src"] = src.numpy()
+    out["out::hyp"] = np.array([[int(t) for t in allHyp[b][0]] for b in range(B)], dtype=np.int64)
+    out["out::scores"] = np.array([float(allScores[b][0]) for b in range(B)], dtype=np.float64)
+    attn = np.zeros((B, n_iter, S), dtype=np.float32)
+    for b in range(B):
+        a = allAttn[b][0].numpy()
+        attn[b, :, :a.shape[1]] = a                       # (columns of PAD positions were dropped by the reference)
+    out["out::attn"] = attn
+    path = os.path.join(HERE, name + ".npz")
+    np.savez_compressed(path, **out)
+    print("wrote %s (%.1f KB) n_iter=%d first EOS at %s scores=%s" % (
+        path, os.path.getsize(path) / 1024, n_iter, [([int(t) for t in allHyp[b][0]] + [3]).index(3) for b in range(B)],
+        [round(float(allScores[b][0]), 3) for b in range(B)]))
+
+
 if __name__ == "__main__":
     nmt, crit_mod = load_reference()
     run_optim_case(nmt, crit_mod, "nmt_optim_clip", steps=4, seed=41, nmt_learning_rate=1e-2)
@@ -231,3 +303,8 @@ if __name__ == "__main__":
     run_case(nmt, crit_mod, "nmt_tiny", layers=2, H=32, B=4, S=9, T=10, Vs=40, Vt=45, seed=31)
     run_case(nmt, crit_mod, "nmt_tiny_1layer", layers=1, H=32, B=3, S=6, T=7, Vs=30, Vt=37, seed=32)
     run_case(nmt, crit_mod, "nmt_odd", layers=2, H=48, B=5, S=11, T=8, Vs=53, Vt=61, seed=33)
+    old_torch_semantics()                                  # (after the training-path cases: they need none of it)
+    run_translate_case(nmt, "nmt_translate_tiny", layers=2, H=32, B=3, S=7, Vs=30, Vt=35, seed=51, eos_bias=4.0)      # 7 steps
+    run_translate_case(nmt, "nmt_translate_odd", layers=2, H=48, B=5, S=9, Vs=41, Vt=52, seed=52, eos_bias=8.0)       # 6 steps
+    run_translate_case(nmt, "nmt_translate_1layer", layers=1, H=32, B=2, S=5, Vs=30, Vt=33, seed=53, eos_bias=2.0)    # 4 steps
+    run_translate_case(nmt, "nmt_translate_long", layers=2, H=32, B=3, S=7, Vs=30, Vt=35, seed=51, eos_bias=3.0)      # all 100 steps

@@ -40,3 +40,14 @@ def test_nmt_forward_loss_grads(name):
         close(grads[k], G[k], 2e-5)
     # padding_idx: the PAD rows of both embedding tables receive no gradient (nn.Embedding(padding_idx=PAD))
     assert G["encoder.embeddings.word_lut.weight"][0].abs().max() == 0
+
+
+@pytest.mark.parametrize("name", ["nmt_translate_tiny", "nmt_translate_odd", "nmt_translate_1layer", "nmt_translate_long"])
+def test_nmt_translate_batch_matches_reference(name):
+    """NMTModel.translateBatch + onmt Beam (beam 15): hypotheses token for token, final scores, attention of the winning
+    hypothesis; incl. a case that runs all 100 steps and cases whose sentences finish at different steps."""
+    W, I, Out, G = load(name)
+    hyp, scores, attn = ON.translate_batch(W, I["src"])
+    assert torch.equal(hyp, Out["hyp"]), (hyp, Out["hyp"])
+    assert (scores.double() - Out["scores"]).abs().max().item() < 1e-3 * max(1.0, Out["scores"].abs().max().item())
+    close(attn, Out["attn"], 1e-4)
