@@ -264,6 +264,17 @@ int uic_nmt_backward(const uic_nmt_dims* d, const uic_nmt_weights* w, const int6
                      const int64_t* tgt, int32_t training, uint32_t seed, void* workspace, const uic_nmt_weights* grads,
                      void* stream);
 
+/* NMTModel.translateBatch (P/models/NMT_Models.py:322-395) with the fork's Beam (O/Beam.py): beam search translation of a
+ * batch, n_best = 1.  src [S, B] int64 (PAD = 0; the encoder runs without lengths, as the reference's does here).  Outputs:
+ * hyp_out [B, max_steps] int64 (first *n_iter_out columns valid: the number of decoder steps taken, identical for all
+ * sentences -- a sentence's beam keeps advancing until every sentence is done, :372-378), score_out [B] (best final beam
+ * score), attn_out [B, max_steps, S] or NULL (attention of the winning hypothesis, PAD source columns dropped and the rest
+ * packed to the left), n_iter_out (HOST int).  Unlike the other entry points this one synchronises with the host once per
+ * decoder step (the reference's `if not active: break`).  The reference hard-codes beam_size 15 and max_steps 100. */
+size_t uic_nmt_translate_workspace_bytes(const uic_nmt_dims* d, int32_t beam_size, int32_t max_steps);
+int uic_nmt_translate(const uic_nmt_dims* d, const uic_nmt_weights* w, const int64_t* src, int32_t beam_size, int32_t max_steps,
+                      void* workspace, int64_t* hyp_out, float* score_out, float* attn_out, int32_t* n_iter_out, void* stream);
+
 /* ---- single operators (also used by the parity tests) ---- */
 
 /* nn.Linear as C[M,N] = A[M,K] B[N,K]^T (+bias)(+ReLU); flags: 1 ReLU, 2 accumulate into C, 4 C is f32. */

@@ -298,3 +298,43 @@ def test_trainer_nmt_half_runs_and_saves(tmp_path):
     tr.save_models()
     sd = torch.load(os.path.join(str(tmp_path), "model_nmt.pth"))
     assert list(sd.keys()) == tr.nmt_model.param_names
+
+
+@pytest.mark.parametrize("name", ["nmt_translate_tiny", "nmt_translate_odd", "nmt_translate_1layer", "nmt_translate_long"])
+def test_nmt_translate_batch_vs_reference_golden(name):
+    """NMTModel.translateBatch + onmt Beam (beam 15, up to 100 steps) on the device, f32: hypotheses token for token, the
+    number of decoder steps, final scores, attention of the winning hypotheses."""
+    cfg, W, I, Out, G = load(name)
+    cfg["T"] = 2
+    model, _ = build(cfg, W, "f32")
+    model.eval()
+    batch = argparse.Namespace(src=I["src"].cuda(), batchSize=cfg["B"])
+    allHyp, allScores, allAttn, gold = model.translateBatch(batch)
+    ref = Out["hyp"]
+    assert len(allHyp) == cfg["B"] and len(allHyp[0][0]) == ref.shape[1]
+    assert torch.equal(torch.tensor([h[0] for h in allHyp]), ref), (allHyp, ref)
+    got_scores = torch.stack([s_[0] for s_ in allScores]).cpu().double()
+    assert (got_scores - Out["scores"]).abs().max().item() < 2e-3 * max(1.0, Out["scores"].abs().max().item())
+    for b in range(cfg["B"]):
+        a = allAttn[b][0].cpu()
+        assert (a - Out["attn"][b, :, :a.shape[1]]).abs().max().item() < 1e-3
+        assert Out["attn"][b, :, a.shape[1]:].abs().max().item() == 0 if a.shape[1] < cfg["S"] else True
+    assert float(gold.abs().sum()) == 0
+
+
+def test_nmt_translate_bf16_mid_size_vs_oracle():
+    """bf16, 16 sentences, 500-word vocabulary: the device's hypotheses re-scored by the oracle (bf16 can swap near-tied
+    candidates, so compare the final beam scores instead of demanding identical tokens)."""
+    cfg = dict(layers=2, H=128, W=128, B=16, S=12, T=2, Vs=400, Vt=500)
+    W = random_weights(cfg, 21, scale=0.3)
+    W["generator.0.bias"][3] += 3.0
+    I = synthetic(dict(cfg, T=6), 8)
+    model, _ = build(cfg, W, "bf16")
+    model.eval()
+    batch = argparse.Namespace(src=I["src"].cuda(), batchSize=cfg["B"])
+    allHyp, allScores, allAttn, gold = model.translateBatch(batch)
+    hyp_o, scores_o, attn_o = ON.translate_batch(W, I["src"])
+    n_same = sum(int(allHyp[b][0] == [int(t) for t in hyp_o[b]]) for b in range(cfg["B"])) if len(allHyp[0][0]) == hyp_o.shape[1] else 0
+    got = torch.stack([s_[0] for s_ in allScores]).cpu()
+    assert (got - scores_o).abs().max().item() < 0.15 * max(1.0, scores_o.abs().max().item()), (got, scores_o)
+    assert n_same >= cfg["B"] // 2, n_same

@@ -188,6 +188,9 @@ _SIGS = {
                                    C.c_int32, C.c_uint32, C.c_void_p, C.POINTER(NmtWeights), C.c_void_p]),
     "uic_fc_sample_beam": (C.c_int, [C.POINTER(FcDims), C.POINTER(FcWeights), C.POINTER(Batch), C.c_int32, C.c_int32, C.c_int32,
                                      C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "uic_nmt_translate_workspace_bytes": (C.c_size_t, [C.POINTER(NmtDims), C.c_int32, C.c_int32]),
+    "uic_nmt_translate": (C.c_int, [C.POINTER(NmtDims), C.POINTER(NmtWeights), C.c_void_p, C.c_int32, C.c_int32, C.c_void_p,
+                                    C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_int32), C.c_void_p]),
     "uic_topdown_workspace_ptr": (C.c_void_p, [C.POINTER(Dims), C.c_void_p, C.c_char_p]),
     "uic_linear": (C.c_int, [C.c_int32] * 4 + [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32,
                              C.c_void_p, C.c_int32, C.c_void_p]),

@@ -54,7 +54,7 @@ __global__ __launch_bounds__(NT) void beam_topk_kernel(const UicBeamParams p) {
   sum = bsum(sum, s_buf);
   const float lse = mx + logf(sum);
   long banned = -1;
-  if (p.decoding_constraint && p.t > 0) banned = p.beam_seq[((size_t)(row / p.B) * p.L + (p.t - 1)) * p.B + (row % p.B)];
+  if (p.decoding_constraint && p.t > 0 && !p.plain) banned = p.beam_seq[((size_t)(row / p.B) * p.L + (p.t - 1)) * p.B + (row % p.B)];
   for (int k = 0; k < p.B; ++k) {
     float bv = -INFINITY;
     int bi = 0x7fffffff;
@@ -64,7 +64,7 @@ __global__ __launch_bounds__(NT) void beam_topk_kernel(const UicBeamParams p) {
       if (taken) continue;
       float lp = x[v] - lse;
       if (v == banned) lp = -INFINITY;
-      if (v == p.V1 - 1) lp -= 1000.f;
+      if (v == p.V1 - 1 && !p.plain) lp -= 1000.f;
       if (lp > bv || (lp == bv && v < bi)) { bv = lp; bi = v; }
     }
     s_val[threadIdx.x] = bv; s_idx[threadIdx.x] = bi;
@@ -154,7 +154,8 @@ __global__ void beam_gather_kernel(const int* __restrict__ parent, int B, int H,
     const int j = (int)(i - row * H);
     const size_t src = (row / B) * B + parent[row];
     const size_t o = src * H + j;
-    h1d[i] = h1s[o]; c1d[i] = c1s[o];
+    h1d[i] = h1s[o];
+    if (c1s) c1d[i] = c1s[o];
     if (h2s) { h2d[i] = h2s[o]; c2d[i] = c2s[o]; }   // second LSTM layer (none in the FC model)
   }
 }
@@ -185,6 +186,13 @@ int uic_beam_step_launch(const UicBeamParams& p, hipStream_t s) {
   UIC_LAUNCH_CHECK("beam_topk");
   hipLaunchKernelGGL(beam_merge_kernel, dim3((p.n_img + 63) / 64), dim3(64), 0, s, q);
   UIC_LAUNCH_CHECK("beam_merge");
+  return UIC_OK;
+}
+
+int uic_beam_topk_launch(const UicBeamParams& p, hipStream_t s) {
+  UIC_REQUIRE(p.B >= 1 && p.B <= UIC_BEAM_MAX && p.B <= p.V1 && p.n_img > 0, "beam topk: bad sizes (beam_size=%d)", p.B);
+  hipLaunchKernelGGL(beam_topk_kernel, dim3(p.n_img * p.B), dim3(NT), 0, s, p);
+  UIC_LAUNCH_CHECK("beam_topk");
   return UIC_OK;
 }
 

@@ -72,7 +72,7 @@ __global__ void enc_final_kernel(const void* xl_, const float* c_f, const float*
 // ---- dot GlobalAttention (O/modules/GlobalAttention.py:112-116,152,160-162), one workgroup per batch row
 template <typename T>
 __global__ __launch_bounds__(NT) void gattn_fwd_kernel(const void* ctx_, const float* target, int S, int B, int H, float* attn,
-                                                       void* cvec_) {
+                                                       void* cvec_, const int64_t* mask_src = nullptr) {
   const T* ctx = (const T*)ctx_;
   T* cvec = (T*)cvec_;
   extern __shared__ __attribute__((aligned(16))) float sm[];
@@ -87,6 +87,8 @@ __global__ __launch_bounds__(NT) void gattn_fwd_kernel(const void* ctx_, const f
     float p = 0.f;
     for (int j = lane; j < H; j += 64) p += uic_to_f(v[j]) * s_t[j];
     p = uic_wave_sum(p);
+    // translator only: source padding is masked (GlobalAttention.applyMask, NMT_Models.py:345,352)
+    if (mask_src && mask_src[(size_t)s * B + b] == 0) p = -INFINITY;
     if (lane == 0) s_a[s] = p;
   }
   __syncthreads();
@@ -224,6 +226,84 @@ __global__ void fill_f32_kernel(float* p, float v, int n) {
 }
 
 inline int gridn(size_t n) { size_t g = (n + NT - 1) / NT; return (int)(g > 65536 ? 65536 : (g ? g : 1)); }
+
+// ---- translator bookkeeping (NMTModel.translateBatch + O/Beam.py); rows are sentence-major: row = b * K + k
+// dst[s, b * K + k] = src[s, b]
+__global__ void nmt_replicate_src_kernel(const int64_t* __restrict__ src, int S, int B, int K, int64_t* __restrict__ dst) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= S * B * K) return;
+  const int s = i / (B * K), r = i - s * B * K;
+  dst[i] = src[(size_t)s * B + r / K];
+}
+// Beam.__init__: every beam starts as [BOS, PAD, PAD, ...] with zero scores (O/Beam.py:28-38)
+__global__ void nmt_beam_init_kernel(int B, int K, int64_t* tok, float* scores, int* done, int* flags) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < B * K) { tok[i] = (i % K) == 0 ? 2 : 0; scores[i] = 0.f; }
+  if (i < B) done[i] = 0;
+  if (i < 2) flags[i] = 0;
+}
+// Beam.advance for every sentence (O/Beam.py:52-89): top K of the flattened beam x word scores -- the candidates are the
+// per-row top K (cand_val / cand_idx from beam_topk), enumerated beam-major so that ties resolve to the lower flat index --
+// back-pointers, next tokens; a sentence is done once its TOP hypothesis ends in EOS; flags[0] = all sentences done.
+__global__ void nmt_beam_advance_kernel(int B, int K, int step, const float* __restrict__ cand_val, const int* __restrict__ cand_idx,
+                                        float* __restrict__ scores, int* __restrict__ prev_ks, int64_t* __restrict__ next_ys, int64_t* __restrict__ tok,
+                                        int* __restrict__ done, int* __restrict__ flags) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  const int rows = step == 0 ? 1 : K;
+  bool used[UIC_BEAM_MAX * UIC_BEAM_MAX];
+  for (int i = 0; i < rows * K; ++i) used[i] = false;
+  float ns[UIC_BEAM_MAX];
+  for (int j = 0; j < K; ++j) {
+    int best = -1;
+    float bp = 0.f;
+    long bflat = 0;
+    for (int k = 0; k < rows; ++k)
+      for (int c = 0; c < K; ++c) {
+        const int id = k * K + c;
+        if (used[id]) continue;
+        const size_t cr = ((size_t)b * K + k) * K + c;
+        const float pj = (step == 0 ? 0.f : scores[(size_t)b * K + k]) + cand_val[cr];
+        const long flat = (long)k * 0x40000000L + cand_idx[cr];
+        if (best < 0 || pj > bp || (pj == bp && flat < bflat)) { best = id; bp = pj; bflat = flat; }
+      }
+    used[best] = true;
+    const int k = best / K, c = best - k * K;
+    const int word = cand_idx[((size_t)b * K + k) * K + c];
+    ns[j] = bp;
+    prev_ks[((size_t)step * B + b) * K + j] = k;
+    next_ys[((size_t)step * B + b) * K + j] = word;
+    tok[(size_t)b * K + j] = word;
+  }
+  for (int j = 0; j < K; ++j) scores[(size_t)b * K + j] = ns[j];
+  if (next_ys[((size_t)step * B + b) * K] == 3) done[b] = 1;
+  if (!done[b]) atomicAdd(&flags[1], 1);       // flags[1]: active sentences of this step (zeroed by the host loop's memset)
+}
+// read-out (translateBatch :384-392, Beam.getHyp :93-117): best final score (first maximum), walk the back-pointers; the
+// attention of hypothesis position j is the one of the PARENT beam at step j, PAD source columns dropped (packed left)
+__global__ void nmt_beam_readout_kernel(int B, int K, int S, int n_iter, int ld_out, const float* __restrict__ scores, const int* __restrict__ prev_ks,
+                                        const int64_t* __restrict__ next_ys, const float* __restrict__ attn_hist, const int64_t* __restrict__ src,
+                                        int64_t* __restrict__ hyp, float* __restrict__ score_out, float* __restrict__ attn_out) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  int k = 0;
+  for (int j = 1; j < K; ++j)
+    if (scores[(size_t)b * K + j] > scores[(size_t)b * K + k]) k = j;
+  score_out[b] = scores[(size_t)b * K + k];
+  for (int j = n_iter - 1; j >= 0; --j) {
+    hyp[(size_t)b * ld_out + j] = next_ys[((size_t)j * B + b) * K + k];
+    const int parent = prev_ks[((size_t)j * B + b) * K + k];
+    if (attn_out) {
+      const float* a = attn_hist + ((size_t)j * B * K + (size_t)b * K + parent) * S;
+      float* o = attn_out + ((size_t)b * ld_out + j) * S;
+      int n = 0;
+      for (int s2 = 0; s2 < S; ++s2)
+        if (src[(size_t)s2 * B + b] != 0) o[n++] = a[s2];
+      for (; n < S; ++n) o[n] = 0.f;
+    }
+    k = parent;
+  }
+}
 
 #define NMT_T(KERNEL, GRID, LDS, ...)                                                            \
   do {                                                                                           \
@@ -839,6 +919,176 @@ int uic_nmt_backward(const uic_nmt_dims* d, const uic_nmt_weights* w, const int6
   static thread_local Nmt st;
   UIC_TRY(st.init(d, w, src, lengths_host, tgt, training, seed, workspace, grads));
   return st.backward((hipStream_t)stream);
+}
+
+
+// ---------------------------------------------------------------- translator (NMTModel.translateBatch, beam search)
+}  // extern "C"
+
+namespace {
+
+struct TrLayout {
+  int64_t* src_rep; int32_t* lens_dev;
+  void* h[ML][2]; float* c[ML][2]; void* feed[2]; void* emb;
+  float* targetq; float* attn; void* cvec; float* logits;
+  float* cand_val; int* cand_idx; float* scores; int64_t* tok; int* prev_ks; int64_t* next_ys; float* attn_hist;
+  int* done; int* flags;
+  void* enc_ws; size_t enc_bytes;
+  size_t total;
+};
+
+TrLayout tr_layout(const uic_nmt_dims& d, int K, int max_steps, void* ws) {
+  TrLayout T;
+  memset(&T, 0, sizeof(T));
+  Bump b{(char*)ws, 0};
+  const size_t Sz = uic_dtype_size(d.dtype);
+  const size_t B = d.B, R = B * K, S = d.S, H = d.H, W = d.W, NL = d.layers, Vtp = vpad(d.Vt);
+  T.src_rep = (int64_t*)b.take(S * R * 8);
+  T.lens_dev = (int32_t*)b.take(R * 4);
+  for (size_t l = 0; l < NL; ++l)
+    for (int i = 0; i < 2; ++i) {
+      T.h[l][i] = b.take(R * H * Sz);
+      T.c[l][i] = (float*)b.take(R * H * 4);
+    }
+  for (int i = 0; i < 2; ++i) T.feed[i] = b.take(R * H * Sz);
+  T.emb = b.take(R * W * Sz);
+  T.targetq = (float*)b.take(R * H * 4);
+  T.attn = (float*)b.take(R * S * 4);
+  T.cvec = b.take(R * H * Sz);
+  T.logits = (float*)b.take(R * Vtp * 4);
+  T.cand_val = (float*)b.take(R * UIC_BEAM_MAX * 4);
+  T.cand_idx = (int*)b.take(R * UIC_BEAM_MAX * 4);
+  T.scores = (float*)b.take(R * 4);
+  T.tok = (int64_t*)b.take(R * 8);
+  T.prev_ks = (int*)b.take((size_t)max_steps * R * 4);
+  T.next_ys = (int64_t*)b.take((size_t)max_steps * R * 8);
+  T.attn_hist = (float*)b.take((size_t)max_steps * R * S * 4);
+  T.done = (int*)b.take(B * 4);
+  T.flags = (int*)b.take(64);
+  // the encoder (and the weight copies) run through the training path's workspace on the replicated batch
+  uic_nmt_dims d2 = d;
+  d2.B = (int)R; d2.T = 2;
+  T.enc_bytes = nmt_layout(d2, nullptr, nullptr).total;
+  T.enc_ws = b.take(T.enc_bytes);
+  T.total = (b.off + 255) & ~(size_t)255;
+  return T;
+}
+
+}  // namespace
+
+extern "C" {
+
+size_t uic_nmt_translate_workspace_bytes(const uic_nmt_dims* d, int32_t beam_size, int32_t max_steps) {
+  if (nmt_check(d) || beam_size < 1 || beam_size > UIC_BEAM_MAX || max_steps < 1) return 0;
+  return tr_layout(*d, beam_size, max_steps, nullptr).total;
+}
+
+int uic_nmt_translate(const uic_nmt_dims* d, const uic_nmt_weights* w, const int64_t* src, int32_t beam_size, int32_t max_steps,
+                      void* workspace, int64_t* hyp_out, float* score_out, float* attn_out, int32_t* n_iter_out, void* stream) {
+  UIC_TRY(nmt_check(d));
+  UIC_REQUIRE(w && src && workspace && hyp_out && score_out && n_iter_out, "nmt_translate: null pointer");
+  UIC_REQUIRE(beam_size >= 1 && beam_size <= UIC_BEAM_MAX && beam_size <= d->Vt, "nmt_translate: beam_size=%d outside [1, %d]", beam_size, UIC_BEAM_MAX);
+  UIC_REQUIRE(max_steps >= 1, "nmt_translate: max_steps=%d", max_steps);
+  hipStream_t s = (hipStream_t)stream;
+  const int K = beam_size, B = d->B, R = B * K, S = d->S, H = d->H, W = d->W, NL = d->layers, Vt = d->Vt, dt = d->dtype;
+  const int Vtp = (int)vpad(Vt), H4 = 4 * H;
+  const size_t Sz = uic_dtype_size(dt), RH = (size_t)R * H;
+  const TrLayout T = tr_layout(*d, K, max_steps, workspace);
+  // (1) encoder on the replicated batch, WITHOUT lengths: every position of every row is processed (translateBatch :327)
+  hipLaunchKernelGGL(nmt_replicate_src_kernel, dim3(gridn((size_t)S * R)), dim3(NT), 0, s, src, S, B, K, T.src_rep);
+  UIC_LAUNCH_CHECK("nmt_replicate_src_kernel");
+  uic_nmt_dims d2 = *d;
+  d2.B = R; d2.T = 2; d2.drop_p = 0.f;
+  static thread_local Nmt st;
+  {
+    static thread_local int32_t lens_host[4096 * UIC_BEAM_MAX];
+    UIC_REQUIRE(R <= 4096 * UIC_BEAM_MAX, "nmt_translate: too many rows (%d)", R);
+    for (int i = 0; i < R; ++i) lens_host[i] = S;
+    UIC_TRY(st.init(&d2, w, T.src_rep, lens_host, nullptr, 0, 0, T.enc_ws, nullptr));
+    UIC_TRY(uic_check_hip(hipMemcpyAsync(T.lens_dev, lens_host, (size_t)R * 4, hipMemcpyHostToDevice, s), "memcpy lengths"));
+  }
+  UIC_TRY(st.refresh(s));
+  UIC_TRY(st.encoder_fwd(T.lens_dev, s));
+  const NmtLayout& L = st.L;
+  // (2) decoder state = encoder final states (slot 0 of the training path's state buffers), zero input feed
+  for (int l = 0; l < NL; ++l) {
+    UIC_TRY(uic_check_hip(hipMemcpyAsync(T.h[l][0], L.hd[l], RH * Sz, hipMemcpyDeviceToDevice, s), "memcpy h0"));
+    UIC_TRY(uic_check_hip(hipMemcpyAsync(T.c[l][0], L.cd[l], RH * 4, hipMemcpyDeviceToDevice, s), "memcpy c0"));
+  }
+  UIC_TRY(uic_fill_launch(T.feed[0], 0, RH * Sz, s));
+  hipLaunchKernelGGL(nmt_beam_init_kernel, dim3(gridn((size_t)R)), dim3(NT), 0, s, B, K, T.tok, T.scores, T.done, T.flags);
+  UIC_LAUNCH_CHECK("nmt_beam_init_kernel");
+  const void* ctx = off(L.xl[NL], (size_t)R * H, dt);            // memory bank [S, R, H] (slot 1 onwards)
+  const size_t lds_att = sizeof(float) * ((size_t)H + S + 4 * (size_t)H);
+  UicBeamParams bp;
+  memset(&bp, 0, sizeof(bp));
+  bp.n_img = B; bp.B = K; bp.L = max_steps; bp.V1 = Vt; bp.ldv = Vtp; bp.plain = 1;
+  bp.logits = T.logits; bp.cand_val = T.cand_val; bp.cand_idx = T.cand_idx;
+  int n_iter = 0;
+  // (3) the main loop (:349-378): state slot 0 -> 1, then re-threaded back into slot 0 by the back-pointers
+  for (int step = 0; step < max_steps; ++step) {
+    UIC_TRY(uic_embed_fwd_launch(dt, w->dec_lut, Vt, W, T.tok, 1, R, 1, 0.f, 0, 0, 0, 0, T.emb, s));
+    const void* x = nullptr;
+    for (int l = 0; l < NL; ++l) {
+      UicGemmParams g = gemm_base(dt, R, H4);
+      g.lstm = 1; g.H = H;
+      if (l == 0) {
+        add_seg(g, T.emb, W, L.dec_w_ih[0], W + H, W);
+        add_seg(g, T.feed[0], H, off(L.dec_w_ih[0], W, dt), W + H, H);
+      } else {
+        add_seg(g, x, H, L.dec_w_ih[l], H, H);
+      }
+      add_seg(g, T.h[l][0], H, L.dec_w_hh[l], H, H);
+      g.bias = w->dec_b_ih[l]; g.bias2 = w->dec_b_hh[l];
+      g.c_prev = T.c[l][0]; g.c_out = T.c[l][1]; g.h_out = T.h[l][1]; g.ldh = H;
+      UIC_TRY(uic_gemm_launch(g, s));
+      x = T.h[l][1];
+    }
+    {
+      UicGemmParams g = gemm_base(dt, R, H);
+      add_seg(g, x, H, L.attn_in_w, H, H);
+      g.C = T.targetq; g.ldc = H; g.flags = UIC_GEMM_OUT_F32;
+      UIC_TRY(uic_gemm_launch(g, s));
+    }
+    float* attn_t = T.attn_hist + (size_t)step * R * S;
+    NMT_T(gattn_fwd_kernel, R, lds_att, ctx, (const float*)T.targetq, S, R, H, attn_t, (void*)T.cvec, (const int64_t*)T.src_rep);
+    {
+      UicGemmParams g = gemm_base(dt, R, H);
+      add_seg(g, T.cvec, H, L.attn_out_w, 2 * H, H);
+      add_seg(g, x, H, off(L.attn_out_w, H, dt), 2 * H, H);
+      g.C = T.feed[1]; g.ldc = H; g.flags = UIC_GEMM_TANH;
+      UIC_TRY(uic_gemm_launch(g, s));
+    }
+    {
+      UicGemmParams g = gemm_base(dt, R, Vt);
+      add_seg(g, T.feed[1], H, L.gen_w, H, H);
+      g.C = T.logits; g.ldc = Vtp; g.bias = w->gen_b; g.flags = UIC_GEMM_OUT_F32;
+      UIC_TRY(uic_gemm_launch(g, s));
+    }
+    bp.t = step;
+    UIC_TRY(uic_beam_topk_launch(bp, s));
+    UIC_TRY(uic_fill_launch(T.flags + 1, 0, 4, s));
+    hipLaunchKernelGGL(nmt_beam_advance_kernel, dim3((B + 63) / 64), dim3(64), 0, s, B, K, step, T.cand_val, T.cand_idx, T.scores,
+                       T.prev_ks, T.next_ys, T.tok, T.done, T.flags);
+    UIC_LAUNCH_CHECK("nmt_beam_advance_kernel");
+    // decStates.beamUpdate_ (:376): re-thread every state tensor of every sentence to the surviving parents
+    const int* parents = T.prev_ks + (size_t)step * R;
+    for (int l = 0; l < NL; ++l)
+      UIC_TRY(uic_beam_gather_launch(dt, parents, R, K, H, T.h[l][1], T.h[l][0], nullptr, nullptr, T.c[l][1], T.c[l][0], nullptr, nullptr, s));
+    UIC_TRY(uic_beam_gather_launch(dt, parents, R, K, H, T.feed[1], T.feed[0], nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, s));
+    n_iter = step + 1;
+    // `if not active: break` (:377-378) -- the one host synchronisation per step of this (evaluation-only) entry point
+    int active = 0;
+    UIC_TRY(uic_check_hip(hipMemcpyAsync(&active, T.flags + 1, 4, hipMemcpyDeviceToHost, s), "memcpy active"));
+    UIC_TRY(uic_check_hip(hipStreamSynchronize(s), "hipStreamSynchronize"));
+    if (active == 0) break;
+  }
+  *n_iter_out = n_iter;
+  // (4) read-out
+  hipLaunchKernelGGL(nmt_beam_readout_kernel, dim3((B + 63) / 64), dim3(64), 0, s, B, K, S, n_iter, max_steps, T.scores, T.prev_ks, T.next_ys,
+                     T.attn_hist, src, hyp_out, score_out, attn_out);
+  UIC_LAUNCH_CHECK("nmt_beam_readout_kernel");
+  return UIC_OK;
 }
 
 }  // extern "C"

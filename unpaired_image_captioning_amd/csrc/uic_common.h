@@ -350,6 +350,7 @@ int uic_sample_step_launch(const UicSampleParams& p, hipStream_t s);
 struct UicBeamParams {
   int n_img, B, L, V1, ldv, t;
   int decoding_constraint, max_ppl;
+  int plain;                           // 1: plain log-softmax top-B (NMT translator): no -1000 on the last index, no constraint
   const float* logits;                 // [n_img * B, ldv] of the current step
   float* cand_val; int* cand_idx;      // [n_img * B, B]
   int64_t* beam_seq_hist[2]; float* beam_lp_hist[2];   // [n_img, L, B] x 2 generations (read t & 1, write the other)
@@ -360,6 +361,7 @@ struct UicBeamParams {
   int* done_count; float* done_p; int64_t* done_seq; float* done_lp;   // [n_img], [n_img, L*B], [n_img, L*B, L] x 2
 };
 int uic_beam_step_launch(const UicBeamParams& p, hipStream_t s);
+int uic_beam_topk_launch(const UicBeamParams& p, hipStream_t s);     // only the per-row log-softmax + top-B into cand_val / cand_idx
 int uic_beam_gather_launch(int dtype, const int* parent, int rows, int B, int H, const void* h1s, void* h1d, const void* h2s, void* h2d,
                            const float* c1s, float* c1d, const float* c2s, float* c2d, hipStream_t s);
 int uic_beam_final_launch(const UicBeamParams& p, int64_t* seq_out, float* lp_out, hipStream_t s);

@@ -255,6 +255,39 @@ class NMTModel(nn.Module):
         return {k: sd[k] for k in self.param_names}
 
     # ---- reference surface
+    def translateBatch(self, batch, beam_size=15, max_steps=100):
+        """NMTModel.translateBatch (P/models/NMT_Models.py:322-395): beam-search translation of `batch.src` [S, B, 1] with
+        the reference's hard-coded beam 15 / 100 steps.  Returns (allHyp, allScores, allAttn, goldScores) shaped like the
+        reference's: per sentence a 1-best list of token-id lists (as long as the number of decoder steps taken -- cut
+        them at EOS like buildTargetTokens does), its score, and its attention [steps, valid source positions]."""
+        if self.training:
+            raise NotImplementedError("translateBatch runs in eval mode")
+        src = batch.src
+        if src.dim() == 3:
+            src = src[:, :, 0]
+        src = src.contiguous()
+        S, B = src.shape
+        eng = self.engine
+        d = eng.dims(B, S, 2)
+        nbytes = eng.lib.uic_nmt_translate_workspace_bytes(C.byref(d), beam_size, max_steps)
+        if nbytes == 0:
+            check(-1, "uic_nmt_translate_workspace_bytes")
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=src.device)
+        hyp = torch.zeros(B, max_steps, dtype=torch.int64, device=src.device)
+        scores = torch.zeros(B, dtype=torch.float32, device=src.device)
+        attn = torch.zeros(B, max_steps, S, dtype=torch.float32, device=src.device)
+        n_iter = C.c_int32(0)
+        with torch.no_grad():
+            w = eng.weights({k: v.detach() for k, v in self._param_dict().items()})
+            check(eng.lib.uic_nmt_translate(C.byref(d), C.byref(w), ptr(src), beam_size, max_steps, ptr(ws), ptr(hyp), ptr(scores),
+                                            ptr(attn), C.byref(n_iter), stream()), "nmt_translate")
+        n = n_iter.value
+        hyp_h, valid = hyp[:, :n].cpu(), (src != PAD).sum(0).cpu()
+        allHyp = [[[int(t) for t in hyp_h[b]]] for b in range(B)]
+        allScores = [scores[b:b + 1] for b in range(B)]
+        allAttn = [[attn[b, :n, :int(valid[b])]] for b in range(B)]
+        return allHyp, allScores, allAttn, scores.new_zeros(B)
+
     def forward(self, src, tgt, lengths, dec_state=None):
         """src [S,B,1] int64, tgt [T,B] int64, lengths [1,B] (sorted descending).  Returns (outputs [T-1,B,H],
         attns {'std': [T-1,B,S]}, dec_state=None, upper_bounds=None) like P/models/NMT_Models.py:414-420."""
