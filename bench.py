@@ -144,10 +144,13 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the captioner hot path has no CPU fallback")
-    torch.cuda.set_device(local_rank)
+    # UIC_BENCH_SHARE_GPU=1 (functional test of the N > 1 path on a 1-GPU box): every rank uses device 0 and the
+    # collectives go through gloo, since RCCL needs one GPU per rank.  Never set for a measurement.
+    share = os.environ.get("UIC_BENCH_SHARE_GPU") == "1"
+    torch.cuda.set_device(0 if share else local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", rank=rank, world_size=world)
+        dist.init_process_group(backend="gloo" if share else "nccl", rank=rank, world_size=world)
 
     from unpaired_image_captioning_amd import _lib as L
     from unpaired_image_captioning_amd.synthetic import synthetic_batch
@@ -197,7 +200,7 @@ def main():
             "scaling": "weak",
             "vs_baseline": None,
             "dtype": args.dtype,
-            "data": "synthetic",
+            "data": "synthetic" if not share else "synthetic (UIC_BENCH_SHARE_GPU functional test: ranks share one GPU, gloo; NOT a measurement)",
             "config": {"workload": "BASELINE configs[1]: TopDown attention LSTM, 128 images x 5 captions = 640 caption "
                                    "rows per GPU, R=36, D=2048, H=E=A=512, V+1=9488, 17 decode steps, dropout 0.5, "
                                    "XE loss + BPTT + Adam", "rows_per_gpu": N, "parallelism": "dp%d" % world, "use_bn": args.use_bn},
