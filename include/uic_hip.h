@@ -141,11 +141,14 @@ int uic_topdown_xe_train_step(const uic_topdown_dims* d, const uic_topdown_weigh
                               void* workspace, const float* inv_den, float* loss_out, float* den_out,
                               const uic_topdown_weights* grads, void* stream);
 /* Data-parallel overlap: makes `stream` wait until the most recent uic_topdown_xe_train_step on the current device has
- * FINAL gradients for every tensor except the late group {att_embed.*, ctx2att.*, core.attention.h2att.*,
- * core.attention.alpha_net.*}, which that call is still computing on its own stream.  A caller that keeps the late
- * group at the tail of its flat gradient arena can start the RCCL all-reduce of the head (> 85 % of the bytes) on
- * `stream` right away; the tail follows on the step's stream.  Enqueue-only (hipStreamWaitEvent), no host sync. */
-int uic_topdown_grad_ready_wait(void* stream);
+ * FINAL gradients for a group of tensors, while that call is still computing the rest on its own streams:
+ *   group 0: logit.weight / logit.bias (and the loss)  -- final when the BPTT loop STARTS (~48 % of the bytes);
+ *   group 1: everything except the late group {att_embed.*, ctx2att.*, core.attention.h2att.*,
+ *            core.attention.alpha_net.*}               -- final when the recurrent weight gradients are done.
+ * A caller that lays its flat gradient arena out as [logit | rest of the early group | late group] can start the RCCL
+ * all-reduce of the first two pieces on a communication stream as each becomes final; the tail follows on the step's
+ * stream.  Enqueue-only (hipStreamWaitEvent), no host sync. */
+int uic_topdown_grad_ready_wait(void* stream, int32_t group);
 
 /* AttModel._sample with beam_size = 1 (P/models/AttModel.py:198-253): greedy (sample_max = 1) or
  * multinomial decode of `L` <= d->T tokens.  seq [N, L] int64 and seq_logp [N, L] f32 are fully written.

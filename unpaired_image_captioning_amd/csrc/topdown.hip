@@ -329,6 +329,7 @@ constexpr int MAX_CHUNKS = 64;
 struct SideStream {
   hipStream_t stream = nullptr;
   hipEvent_t ev_den = nullptr, ev_done = nullptr;
+  hipEvent_t ev_logit = nullptr;    // side: the logit layer's gradients and the loss are final (start of the BPTT loop)
   hipEvent_t ev_early = nullptr;    // main: every gradient except the late group (see uic_topdown_grad_ready_wait) is final
   bool early_recorded = false;
   hipEvent_t ev_r0 = nullptr, ev_refresh = nullptr;   // uic_topdown_refresh_weights: main -> side, side -> consumers
@@ -353,6 +354,7 @@ int get_side(SideStream** out) {
     UIC_TRY(uic_check_hip(hipEventCreateWithFlags(&ss.ev_den, hipEventDisableTiming), "hipEventCreate"));
     UIC_TRY(uic_check_hip(hipEventCreateWithFlags(&ss.ev_done, hipEventDisableTiming), "hipEventCreate"));
     UIC_TRY(uic_check_hip(hipEventCreateWithFlags(&ss.ev_early, hipEventDisableTiming), "hipEventCreate"));
+    UIC_TRY(uic_check_hip(hipEventCreateWithFlags(&ss.ev_logit, hipEventDisableTiming), "hipEventCreate"));
     UIC_TRY(uic_check_hip(hipEventCreateWithFlags(&ss.ev_r0, hipEventDisableTiming), "hipEventCreate"));
     UIC_TRY(uic_check_hip(hipEventCreateWithFlags(&ss.ev_refresh, hipEventDisableTiming), "hipEventCreate"));
     for (int i = 0; i < MAX_CHUNKS; ++i) {
@@ -986,6 +988,7 @@ int uic_topdown_xe_train_step(const uic_topdown_dims* d, const uic_topdown_weigh
   UIC_TRY(st.logit_weight_grads(s2, true));
   UIC_TRY(uic_reduce_sum_launch(st.L.row_loss, (size_t)t_run * d->N, 0.f, inv, loss_out, s2));
   if (den_out) UIC_HIP(hipMemcpyAsync(den_out, st.L.scalars, 4, hipMemcpyDeviceToDevice, s2));
+  UIC_HIP(hipEventRecord(ss->ev_logit, s2));          // gradient group 0 (logit layer) final: its exchange can start now
   // main: BPTT, each step waits for the d hdrop rows of its chunk; side: the recurrent weight gradients of every
   // finished chunk (transposes + accumulating GEMMs), so only the last chunk's share outlives the loop
   UIC_TRY(st.bwd_begin(s));
@@ -1008,11 +1011,12 @@ int uic_topdown_xe_train_step(const uic_topdown_dims* d, const uic_topdown_weigh
   return UIC_OK;
 }
 
-int uic_topdown_grad_ready_wait(void* stream) {
+int uic_topdown_grad_ready_wait(void* stream, int32_t group) {
   SideStream* ss = nullptr;
   UIC_TRY(get_side(&ss));
+  UIC_REQUIRE(group == 0 || group == 1, "grad_ready_wait: group=%d must be 0 (logit layer) or 1 (early group)", group);
   UIC_REQUIRE(ss->early_recorded, "grad_ready_wait: no uic_topdown_xe_train_step has run on this device yet");
-  return uic_check_hip(hipStreamWaitEvent((hipStream_t)stream, ss->ev_early, 0), "hipStreamWaitEvent");
+  return uic_check_hip(hipStreamWaitEvent((hipStream_t)stream, group == 0 ? ss->ev_logit : ss->ev_early, 0), "hipStreamWaitEvent");
 }
 
 int uic_topdown_sample(const uic_topdown_dims* d, const uic_topdown_weights* w, const void* derived,

@@ -52,22 +52,31 @@ class GradientExchange(object):
             dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group)
         return flat
 
-    def allreduce_sum_overlapped(self, flat, split, wait_early):
-        """Sum `flat` over ranks in two collectives: the head flat[:split] starts on a communication stream as soon as
-        `wait_early(raw_stream)` lets it (uic_topdown_grad_ready_wait: the step's early gradient group is final) and so
-        runs beside the rest of the backward pass; the tail follows on the current stream.  The current stream then
-        waits for the communication stream, so whatever is enqueued next (Adam) sees the summed gradients."""
+    def allreduce_sum_overlapped(self, flat, splits, wait_group):
+        """Sum `flat` over ranks in len(splits) + 1 collectives.  Piece g = flat[splits[g-1]:splits[g]] starts on a
+        communication stream as soon as `wait_group(raw_stream, g)` lets it (uic_topdown_grad_ready_wait: gradient
+        group g of the step is final) and so runs beside the rest of the backward pass; the tail flat[splits[-1]:]
+        follows on the current stream.  The current stream then waits for the communication stream, so whatever is
+        enqueued next (Adam) sees the summed gradients."""
         if self.world_size == 1:
             return flat
-        if not flat.is_cuda or split <= 0 or split >= flat.numel():
+        if isinstance(splits, int):
+            splits = [splits]
+        splits = [int(x) for x in splits]
+        ok = flat.is_cuda and splits and all(0 < a < flat.numel() for a in splits) and \
+            all(a < b for a, b in zip(splits, splits[1:]))
+        if not ok:
             return self.allreduce_sum(flat)
         if getattr(self, "_comm_stream", None) is None or self._comm_stream.device != flat.device:
             self._comm_stream = torch.cuda.Stream(device=flat.device)
         comm = self._comm_stream
-        wait_early(comm.cuda_stream)
-        with torch.cuda.stream(comm):
-            dist.all_reduce(flat[:split], op=dist.ReduceOp.SUM, group=self.group)
-        dist.all_reduce(flat[split:], op=dist.ReduceOp.SUM, group=self.group)
+        lo = 0
+        for g, hi in enumerate(splits):
+            wait_group(comm.cuda_stream, g)
+            with torch.cuda.stream(comm):
+                dist.all_reduce(flat[lo:hi], op=dist.ReduceOp.SUM, group=self.group)
+            lo = hi
+        dist.all_reduce(flat[lo:], op=dist.ReduceOp.SUM, group=self.group)
         torch.cuda.current_stream(flat.device).wait_stream(comm)
         return flat
 

@@ -87,16 +87,19 @@ class Trainer(object):
         self.arena = None
         self.last_loss = None
 
-    # gradients still being computed when uic_topdown_grad_ready_wait fires (include/uic_hip.h): kept at the arena's tail
+    # flat-arena order [FIRST_GRADS | rest | LATE_GRADS] = gradient groups 0 / 1 / tail of uic_topdown_grad_ready_wait
+    # (include/uic_hip.h): each piece's all-reduce starts while the step is still computing the following ones
+    FIRST_GRADS = ("logit.",)
     LATE_GRADS = ("att_embed.", "ctx2att.", "core.attention.")
 
     def build_optimizer(self):
         self.i2t_model.cuda()
         names = self.i2t_model.param_names
-        early = [k for k in names if not k.startswith(self.LATE_GRADS)]
+        first = [k for k in names if k.startswith(self.FIRST_GRADS)]
         late = [k for k in names if k.startswith(self.LATE_GRADS)]
-        self.arena = FlatArena(self.i2t_model, early + late)
-        self.arena_split = self.arena.offsets[late[0]] if late and early else 0
+        early = [k for k in names if k not in first and k not in late]
+        self.arena = FlatArena(self.i2t_model, first + early + late)
+        self.arena_splits = [self.arena.offsets[g[0]] for g in (early, late) if g] if first and early and late else []
         self._step = 0
 
     def update_LearningRate(self, epoch):
@@ -133,8 +136,8 @@ class Trainer(object):
         if self.exchange.world_size > 1:
             lib = _lib.load()
             self.exchange.allreduce_sum_overlapped(
-                self.arena.grad, getattr(self, 'arena_split', 0) if hasattr(self.i2t_model, 'use_bn') else 0,
-                lambda raw: check(lib.uic_topdown_grad_ready_wait(raw), "grad_ready_wait"))
+                self.arena.grad, getattr(self, 'arena_splits', []) if hasattr(self.i2t_model, 'use_bn') else [],
+                lambda raw, g: check(lib.uic_topdown_grad_ready_wait(raw, g), "grad_ready_wait"))
         self._step += 1
         a = self.arena
         check(_lib.load().uic_adam_step(ptr(a.flat), ptr(a.grad), ptr(a.exp_avg), ptr(a.exp_avg_sq), a.numel,
