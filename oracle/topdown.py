@@ -315,15 +315,79 @@ def beam_search_core(step_fn, logprobs: Tensor, state, seq_length: int, beam_siz
     return sorted(done, key=lambda x: -x["p"])[:B]
 
 
+def diverse_beam_search_core(step_fn, logprobs: Tensor, state, seq_length: int, beam_size: int, group_size: int,
+                             diversity_lambda: float = 0.5, decoding_constraint: int = 0, max_ppl: int = 0):
+    """CaptionModel.beam_search with group_size > 1 (P/models/CaptionModel.py:36-45,100-177) for ONE image: group g runs
+    ``bdash = beam_size // group_size`` beams one step behind group g-1 (:125-127); before ranking, every word chosen
+    at the same local step by a beam of an EARLIER group costs diversity_lambda per choosing beam (:36-45; the rows of
+    the earlier groups' tables as re-threaded up to this moment), the recorded per-step log-prob is the un-penalised one
+    (:72,98) while the running sum uses the penalised one (:71).  ``logprobs`` / ``state`` are the first step's for
+    bdash rows (every group starts from the same replicated image).  Returns the concatenation of each group's done
+    beams, best first within a group (:174-176) -- so entry 0 is the best beam of group 0, which never sees a penalty."""
+    G, B, L = group_size, beam_size // group_size, seq_length
+    seqs = [torch.zeros(L, B, dtype=torch.long) for _ in range(G)]
+    lps = [torch.zeros(L, B) for _ in range(G)]
+    sums = [torch.zeros(B) for _ in range(G)]
+    done = [[] for _ in range(G)]
+    states = [tuple(x.clone() for x in state) for _ in range(G)]
+    lp_tab = [logprobs.clone() for _ in range(G)]
+    for t in range(L + G - 1):
+        for g in range(G):
+            if not (g <= t <= L + g - 1):
+                continue
+            lt = t - g
+            lpf = lp_tab[g].clone()
+            if decoding_constraint and lt > 0:
+                lpf.scatter_(1, seqs[g][lt - 1].unsqueeze(1), float("-inf"))
+            lpf[:, -1] = lpf[:, -1] - 1000
+            unaug = lpf.clone()
+            for pg in range(g):
+                for w in seqs[pg][lt].tolist():
+                    lpf[:, w] = lpf[:, w] - diversity_lambda
+            ys, ix = torch.sort(lpf, 1, True)
+            cands = []
+            rows = 1 if lt == 0 else B
+            for c in range(min(B, ys.shape[1])):
+                for q in range(rows):
+                    cands.append(dict(c=int(ix[q, c]), q=q, p=float(sums[g][q]) + float(ys[q, c]), r=float(unaug[q, ix[q, c]])))
+            cands = sorted(cands, key=lambda x: -x["p"])
+            new_state = tuple(x.clone() for x in states[g])
+            prev_seq, prev_lp = seqs[g][:lt].clone(), lps[g][:lt].clone()
+            for vix in range(B):
+                v = cands[vix]
+                if lt >= 1:
+                    seqs[g][:lt, vix] = prev_seq[:, v["q"]]
+                    lps[g][:lt, vix] = prev_lp[:, v["q"]]
+                for k in range(len(new_state)):
+                    new_state[k][:, vix] = states[g][k][:, v["q"]]
+                seqs[g][lt, vix] = v["c"]
+                lps[g][lt, vix] = v["r"]
+                sums[g][vix] = v["p"]
+            states[g] = new_state
+            for vix in range(B):
+                if int(seqs[g][lt, vix]) == 0 or lt == L - 1:
+                    p = float(sums[g][vix])
+                    done[g].append(dict(seq=seqs[g][:, vix].clone(), logps=lps[g][:, vix].clone(),
+                                        p=p / (lt + 1) if max_ppl else p, group=g))
+                    sums[g][vix] = -1000
+            lp_tab[g], states[g] = step_fn(seqs[g][lt].clone(), states[g])
+    out = []
+    for g in range(G):
+        out += sorted(done[g], key=lambda x: -x["p"])[:B]
+    return out
+
+
 def sample_beam(W: Weights, fc_feats: Tensor, att_feats: Tensor, att_masks: Optional[Tensor], seq_length: int,
-                beam_size: int, decoding_constraint: int = 0, max_ppl: int = 0, use_bn: int = 0, return_beams: bool = False):
+                beam_size: int, decoding_constraint: int = 0, max_ppl: int = 0, use_bn: int = 0, return_beams: bool = False,
+                group_size: int = 1, diversity_lambda: float = 0.5):
     """AttModel._sample_beam (P/models/AttModel.py:167-196) over beam_search_core, image by image like the reference;
-    the best finished beam per image is the result (:193-194)."""
+    the best finished beam per image is the result (:193-194).  group_size > 1: diverse_beam_search_core with
+    beam_size // group_size beams per group (the replicated rows are chunked per group, CaptionModel.py:113-120)."""
     assert beam_size <= W["logit.weight"].shape[0]
     N = fc_feats.shape[0]
     H = W["logit.weight"].shape[1]
     fc, att, p_att, masks = prepare_feature(W, fc_feats, att_feats, att_masks, None, use_bn, False)
-    B, L = beam_size, seq_length
+    B, L = beam_size // group_size, seq_length
     seq = torch.zeros(N, L, dtype=torch.long)
     seq_logp = torch.zeros(N, L)
     all_done = []
@@ -338,7 +402,11 @@ def sample_beam(W: Weights, fc_feats: Tensor, att_feats: Tensor, att_masks: Opti
             return lp, st
         state = (torch.zeros(2, B, H), torch.zeros(2, B, H))
         logprobs, state = step_fn(torch.zeros(B, dtype=torch.long), state)
-        done = beam_search_core(step_fn, logprobs, state, L, B, decoding_constraint, max_ppl)
+        if group_size > 1:
+            done = diverse_beam_search_core(step_fn, logprobs, state, L, beam_size, group_size, diversity_lambda,
+                                            decoding_constraint, max_ppl)
+        else:
+            done = beam_search_core(step_fn, logprobs, state, L, B, decoding_constraint, max_ppl)
         seq[k] = done[0]["seq"]
         seq_logp[k] = done[0]["logps"]
         all_done.append(done)

@@ -182,6 +182,19 @@ def run_case(att_mod, crit_mod, name, V, E, H, A, D, L, n_img, S, R, seed, ragge
         out["beam::%s_seq" % tag] = bseq.numpy().copy()
         out["beam::%s_logp" % tag] = blp.numpy().copy()
 
+    # diverse beam search (group_size > 1, CaptionModel.py:36-45,100-176): _sample_beam returns done_beams[k][0], the best
+    # beam of group 0 -- the group that never sees a diversity penalty
+    for tag, bs, gs, dc, mp, eos_bias, lam in (("g2b4", 4, 2, 0, 0, 0.0, 0.5), ("g3b6eos", 6, 3, 1, 1, 2.5, 0.7)):
+        with torch.no_grad():
+            model.logit.bias[0] += eos_bias
+            bseq, blp = model(fc[idx], attri[idx], att[idx], att_masks[idx] if att_masks is not None else None,
+                              opt={"sample_max": 1, "beam_size": bs, "group_size": gs, "diversity_lambda": lam,
+                                   "decoding_constraint": dc, "max_ppl": mp}, mode="sample")
+            model.logit.bias[0] -= eos_bias
+        out["beamg::%s_cfg" % tag] = np.array([bs, gs, dc, mp, eos_bias, lam], dtype=np.float64)
+        out["beamg::%s_seq" % tag] = bseq.numpy().copy()
+        out["beamg::%s_logp" % tag] = blp.numpy().copy()
+
     # RewardCriterion on a hand-made reward
     g = torch.Generator().manual_seed(seed + 1)
     reward = torch.randn(seq.shape, generator=g)

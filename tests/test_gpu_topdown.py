@@ -634,6 +634,33 @@ def test_beam_search_token_ids_bit_exact_vs_reference_golden(name):
         assert len(model.done_beams) == cfg["n_img"] and torch.equal(model.done_beams[0][0]["seq"], seq[0])
 
 
+@pytest.mark.parametrize("name", FIXTURES[:2] + BN_FIXTURES[:1])
+def test_diverse_beam_groups_return_value_vs_reference_golden(name):
+    """group_size > 1: _sample_beam returns the best beam of group 0 (AttModel.py:193-194), the group without a diversity
+    penalty -- token ids identical to the reference's diverse search (tests/test_oracle_golden.py proves the equivalence
+    with the full staggered algorithm)."""
+    cfg, W, I, Out, G, X = load_golden(name)
+    W = dict(W)
+    for k, v in X.items():
+        if k.startswith("bnstat::"):
+            W[k.split("::", 1)[1]] = torch.as_tensor(v)
+    model = build_model(cfg, W, "f32").eval()
+    idx = torch.arange(cfg["n_img"]) * cfg["S"]
+    fc, att = I["fc_feats"][idx].cuda(), I["att_feats"][idx].cuda()
+    am = I["att_masks"][idx].cuda() if "att_masks" in I else None
+    for tag in ("g2b4", "g3b6eos"):
+        bs, gs, dc, mp, eos_bias, lam = [float(x) for x in X["beamg::%s_cfg" % tag]]
+        with torch.no_grad():
+            model.logit.bias[0] += eos_bias
+        seq, lp = model(fc, None, att, am, opt={"sample_max": 1, "beam_size": int(bs), "group_size": int(gs),
+                                                "diversity_lambda": lam, "decoding_constraint": int(dc),
+                                                "max_ppl": int(mp)}, mode="sample")
+        with torch.no_grad():
+            model.logit.bias[0] -= eos_bias
+        assert torch.equal(seq.cpu(), torch.as_tensor(X["beamg::%s_seq" % tag])), tag
+        assert absmax(lp, torch.as_tensor(X["beamg::%s_logp" % tag])) < 1e-3, tag
+
+
 def test_beam_search_bf16_and_real_vocab_vs_oracle():
     """bf16 + a 9488-word vocabulary on a few images: the device's beams scored by the oracle (same tokens re-run through
     the oracle's beam search must agree unless two candidates tie within bf16 noise, so compare log-probs of the

@@ -94,9 +94,6 @@ def test_unsupported_options_raise():
         models.setup(_opt(logit_layers=2))
     with pytest.raises(Exception, match="not supported"):
         models.setup(_opt(caption_model="transformer"))
-    m = models.setup(_opt()).eval()
-    with pytest.raises(NotImplementedError):
-        m(None, None, None, None, opt={"beam_size": 3, "group_size": 3}, mode="sample")
 
 
 def test_early_break_step_count_matches_reference_rule():

@@ -177,3 +177,34 @@ def test_beam_search_matches_reference(name):
         _close(lp, torch.as_tensor(X["beam::%s_logp" % tag]), 1e-5)
         n_early += int((ref_seq == 0).any())
     assert n_early > 0          # the fixtures do contain beams that finished before the last step
+
+
+@pytest.mark.parametrize("name", TINY)
+def test_diverse_beam_search_matches_reference(name):
+    """group_size > 1 (CaptionModel.py:36-45,100-177): the staggered groups with diversity penalties, restated in full;
+    what _sample_beam returns is the best beam of group 0 -- identical to a plain search with beam_size // group_size
+    beams, which is how the device path serves it."""
+    cfg, W, I, Out, G, X = load_golden(name)
+    idx = torch.arange(cfg["n_img"]) * cfg["S"]
+    am = I.get("att_masks")
+    W = dict(W)
+    for k, v in X.items():
+        if k.startswith("bnstat::"):
+            W[k.split("::", 1)[1]] = torch.as_tensor(v)
+    for tag in ("g2b4", "g3b6eos"):
+        bs, gs, dc, mp, eos_bias, lam = [float(x) for x in X["beamg::%s_cfg" % tag]]
+        Wb = dict(W)
+        Wb["logit.bias"] = W["logit.bias"].clone()
+        Wb["logit.bias"][0] += eos_bias
+        args = (Wb, I["fc_feats"][idx], I["att_feats"][idx], None if am is None else am[idx], cfg["L"])
+        seq, lp, beams = O.sample_beam(*args, int(bs), int(dc), int(mp), use_bn=cfg["use_bn"], group_size=int(gs),
+                                       diversity_lambda=lam, return_beams=True)
+        ref_seq = torch.as_tensor(X["beamg::%s_seq" % tag])
+        assert torch.equal(seq, ref_seq), (tag, seq, ref_seq)
+        _close(lp, torch.as_tensor(X["beamg::%s_logp" % tag]), 1e-5)
+        seq1, lp1 = O.sample_beam(*args, int(bs) // int(gs), int(dc), int(mp), use_bn=cfg["use_bn"])
+        assert torch.equal(seq1, seq) and torch.equal(lp1, lp)
+        # the later groups did feel the penalty: their beams differ from group 0's somewhere in the fixture
+        assert all(len(b) == int(bs) for b in beams)
+        if eos_bias == 0:
+            assert any(not torch.equal(b[0]["seq"], b[int(bs) // int(gs)]["seq"]) for b in beams)

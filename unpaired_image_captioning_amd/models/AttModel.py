@@ -204,8 +204,11 @@ class AttModel(CaptionModel):
         33-177): all images in one device pass.  `self.done_beams[k]` holds the winning beam of image k ('seq', 'logps');
         the reference's full per-image list of finished beams is not materialised on the host."""
         beam_size = opt.get('beam_size', 10)
-        if opt.get('group_size', 1) != 1:
-            raise NotImplementedError("diverse beam search (group_size > 1) is not on the MI355X hot path")
+        group_size = opt.get('group_size', 1)
+        if group_size > 1:
+            # diverse groups (CaptionModel.py:100-177): the caller only ever receives done_beams[k][0] (AttModel.py:193-194),
+            # the best beam of group 0, which never sees a diversity penalty -- a plain search over its bdash beams
+            beam_size = beam_size // group_size
         if self.training:
             raise NotImplementedError("beam search runs in eval mode (eval_utils.eval_split calls model.eval() first)")
         assert beam_size <= self.vocab_size + 1

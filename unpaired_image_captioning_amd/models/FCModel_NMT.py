@@ -177,8 +177,11 @@ class FCModel_NMT(CaptionModel):
         """FCModel_NMT._sample_beam (P/models/FCModel_NMT.py:136-162) over CaptionModel.beam_search, all images in one
         device pass; returns [N, L] tensors.  `self.done_beams[k]` holds the winning beam of image k."""
         beam_size = opt.get('beam_size', 10)
-        if opt.get('group_size', 1) != 1:
-            raise NotImplementedError("diverse beam search (group_size > 1) is not on the MI355X hot path")
+        group_size = opt.get('group_size', 1)
+        if group_size > 1:
+            # diverse groups (CaptionModel.py:100-177): the caller only ever receives done_beams[k][0] (FCModel_NMT.py:159-160),
+            # the best beam of group 0, which never sees a diversity penalty -- a plain search over its bdash beams
+            beam_size = beam_size // group_size
         if self.training:
             raise NotImplementedError("beam search runs in eval mode")
         assert beam_size <= self.vocab_size + 1
