@@ -40,6 +40,12 @@ typedef struct uic_topdown_dims {
   float drop_p;     /* drop_prob_lm; applied only when `training` is non-zero */
   int32_t use_bn;   /* opt.use_bn (P/opts.py:52): 0 none, 1 BatchNorm1d(D) in front of att_embed's Linear, 2 also
                      * BatchNorm1d(H) after its Dropout (P/models/AttModel.py:78-84) */
+  int32_t seq_per_img; /* 0 or 1: the batch carries one feature row per CAPTION row, replicated by the loader as the
+                     * reference does on the host (P/misc/dataloader/dataloader.py:270-277).  S > 1 (must divide N): the
+                     * batch carries fc_feats / att_feats / att_masks once per IMAGE ([N/S, ...]); caption row n uses image
+                     * n / S.  Results are those of the S-fold replicated batch (same dropout masks per caption row); the
+                     * att_embed Linear and its weight gradient then run on N/S * R rows instead of N * R (use_bn = 0;
+                     * with BatchNorm the input is replicated on the device first). */
 } uic_topdown_dims;
 
 /* Master parameters (f32), one pointer per tensor of TopDownModel.state_dict(), same shapes as the reference
@@ -84,9 +90,9 @@ typedef struct uic_topdown_weights {
 
 /* The batch dict of DataLoader.get_batch as consumed at P/trainer.py:147-149 (device copies). */
 typedef struct uic_topdown_batch {
-  const float* fc_feats;    /* [N, Dfc] */
-  const float* att_feats;   /* [N, R, D] */
-  const float* att_masks;   /* [N, R] or NULL */
+  const float* fc_feats;    /* [N, Dfc]   ([N / seq_per_img, Dfc]  when dims.seq_per_img > 1) */
+  const float* att_feats;   /* [N, R, D]  ([N / seq_per_img, R, D]) */
+  const float* att_masks;   /* [N, R] or NULL  ([N / seq_per_img, R]) */
   const int64_t* labels;    /* [N, ld_labels]; column 0 is BOS = 0 */
   int32_t ld_labels;
   const float* masks;       /* [N, ld_masks] or NULL (forward only) */

@@ -337,12 +337,17 @@ def test_real_size_rows_vs_reference_golden(dtype):
         assert absmax(lp, Out["greedy_logp"]) < 1e-3
 
 
-def test_adam_trajectory_vs_reference_golden():
-    """Three Trainer.train steps (forward, criterion, backward, Adam) reproduce the reference's losses."""
+@pytest.mark.parametrize("per_image", [False, True])
+def test_adam_trajectory_vs_reference_golden(per_image):
+    """Three Trainer.train steps (forward, criterion, backward, Adam) reproduce the reference's losses -- also when the
+    Trainer ships every image's features once (opt.seq_per_img) and the replication happens on the device."""
     from unpaired_image_captioning_amd.trainer import Trainer
     cfg, W, I, Out, G, X = load_golden("topdown_tiny")
     opt = make_opt(cfg, "f32")
     opt.i2t_learning_rate = 5e-4
+    if per_image:
+        opt.seq_per_img = cfg["S"]
+        assert cfg["S"] > 1
     tr = Trainer(opt)
     tr.i2t_model.load_state_dict(W)
     tr.i2t_model.cuda()
@@ -356,6 +361,14 @@ def test_adam_trajectory_vs_reference_golden():
     sd = tr.i2t_model.state_dict()
     assert absmax(sd["logit.bias"], Out["adam_final_logit_bias"]) < 1e-4
     assert absmax(sd["core.attention.h2att.weight"], Out["adam_final_h2att_weight"]) < 1e-4
+    if per_image:
+        assert tr.to_device(data)["att_feats"].shape[0] * cfg["S"] == data["labels"].shape[0]
+        bad = dict(data)
+        bad["att_feats"] = data["att_feats"].copy()
+        bad["att_feats"][1] += 1.0
+        tr2 = Trainer(opt)
+        with pytest.raises(ValueError, match="not 2-fold replicated|not %d-fold replicated" % cfg["S"]):
+            tr2.to_device(bad)
 
 
 def test_full_size_properties_bf16():
@@ -724,3 +737,79 @@ def test_shapes_off_the_fast_paths_vs_oracle(dtype):
         assert same.float().mean().item() >= 0.7
         assert absmax(blp[same.cuda()], blp_o[same]) < 1e-3
         assert (blp.cpu().sum(1) - blp_o.sum(1)).abs().max().item() < 2e-3
+
+
+# ---------------------------------------------------------------- features once per image (dims.seq_per_img > 1)
+def _per_image(batch, S):
+    out = dict(batch)
+    for k in ("fc_feats", "att_feats", "att_masks"):
+        if out.get(k) is not None:
+            full = out[k]
+            assert torch.equal(full.view(-1, S, *full.shape[1:])[:, 0], full[::S])
+            for j in range(1, S):
+                assert torch.equal(full[j::S], full[::S]), "fixture rows are not replicated"
+            out[k] = full[::S].contiguous()
+    return out
+
+
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+@pytest.mark.parametrize("use_bn", [0, 1, 2])
+@pytest.mark.parametrize("fused", [True, False])
+def test_features_per_image_equal_replicated_batch(dtype, use_bn, fused):
+    """The loader's S-fold replication done on the device (dims.seq_per_img = S): a training step with dropout 0.5 on
+    per-image features (ragged region counts) must give the loss and gradients of the replicated batch -- the same
+    dropout masks per caption row; the att_embed Linear runs per image (use_bn = 0) and its weight gradient over the
+    S-summed row gradients."""
+    from unpaired_image_captioning_amd import models
+    from unpaired_image_captioning_amd.trainer import xe_step
+    cfg = dict(V=300, E=64, H=96, A=64, D=160, L=7, n_img=12, S=3, R=9, use_bn=use_bn)
+    torch.manual_seed(5)
+    b = O.synthetic_batch(cfg["n_img"], cfg["S"], cfg["R"], cfg["D"], cfg["V"], cfg["L"], seed=9, ragged_regions=True)
+    full = {k: v.cuda() for k, v in b.items()}
+    img = _per_image(full, cfg["S"])
+    assert img["att_feats"].shape[0] * cfg["S"] == full["att_feats"].shape[0] == full["labels"].shape[0]
+    res = []
+    for batch in (full, img):
+        torch.manual_seed(3)
+        model = models.setup(make_opt(cfg, dtype, drop=0.5, seed=21)).cuda().train()
+        loss, grads = xe_step(model, batch, fused=fused)
+        res.append((loss.item(), {k: v.float().cpu() for k, v in grads.items()},
+                    {k: v.float().cpu().clone() for k, v in model.state_dict().items() if "running" in k}))
+    (l0, g0, s0), (l1, g1, s1) = res
+    assert abs(l0 - l1) < (1e-5 if dtype == "f32" else 2e-3), (l0, l1)
+    grads_close(g1, g0, 2e-4 if dtype == "f32" else 3e-2)
+    for k in s0:
+        assert absmax(s1[k], s0[k]) < 1e-6, k
+
+
+def test_features_per_image_sampling_and_forward_logprobs():
+    """mode='forward' log-probs and the multinomial sampling pass with per-image features (labels / rows per caption)."""
+    from unpaired_image_captioning_amd import models
+    cfg = dict(V=300, E=64, H=96, A=64, D=160, L=7, n_img=6, S=4, R=9, use_bn=0)
+    b = O.synthetic_batch(cfg["n_img"], cfg["S"], cfg["R"], cfg["D"], cfg["V"], cfg["L"], seed=2, ragged_regions=True)
+    full = {k: v.cuda() for k, v in b.items()}
+    img = _per_image(full, cfg["S"])
+    torch.manual_seed(1)
+    model = models.setup(make_opt(cfg, "f32", drop=0.5, seed=7)).cuda().train()
+    outs = []
+    for batch in (full, img):
+        model._seed_counter = 77
+        lp = model(batch["fc_feats"], None, batch["att_feats"], batch["labels"], batch["att_masks"])
+        outs.append(lp.detach().cpu())
+    assert outs[0].shape == outs[1].shape and absmax(outs[1], outs[0]) < 1e-5
+    eng = model.engine
+    pd = {k: v.detach() for k, v in model.param_dict().items()}
+    s0, lp0 = eng.sample(pd, full["fc_feats"], full["att_feats"], full["att_masks"], cfg["L"], sample_max=0, seed=5, training=True)
+    s1, lp1 = eng.sample(pd, img["fc_feats"], img["att_feats"], img["att_masks"], cfg["L"], sample_max=0, seed=5, training=True,
+                         seq_per_img=cfg["S"])
+    assert torch.equal(s0, s1) and absmax(lp1, lp0) < 1e-5
+
+
+def test_features_per_image_argument_errors():
+    from unpaired_image_captioning_amd import models
+    cfg = dict(V=50, E=32, H=32, A=32, D=64, L=6, n_img=3, S=2, R=5, use_bn=0)
+    b = O.synthetic_batch(cfg["n_img"], cfg["S"], cfg["R"], cfg["D"], cfg["V"], cfg["L"], seed=2)
+    full = {k: v.cuda() for k, v in b.items()}
+    model = models.setup(make_opt(cfg, "f32")).cuda()
+    with pytest.raises(ValueError, match="whole number"):
+        model(full["fc_feats"][:4], None, full["att_feats"][:4], full["labels"], None)

@@ -20,7 +20,7 @@ SITE_SS_MASK0, SITE_SS_DRAW0 = 512, 768          # + decode step
 
 
 class Dims(C.Structure):
-    _fields_ = [(n, C.c_int32) for n in ("N", "R", "D", "Dfc", "H", "E", "A", "V1", "T", "dtype")] + [("drop_p", C.c_float), ("use_bn", C.c_int32)]
+    _fields_ = [(n, C.c_int32) for n in ("N", "R", "D", "Dfc", "H", "E", "A", "V1", "T", "dtype")] + [("drop_p", C.c_float), ("use_bn", C.c_int32), ("seq_per_img", C.c_int32)]
 
 
 WEIGHT_FIELDS = [

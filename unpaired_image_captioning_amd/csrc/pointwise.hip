@@ -161,6 +161,64 @@ __global__ void relu_mask_bwd_kernel(const float* __restrict__ g, const T* __res
     dst[i] = uic_from_f<T>(uic_to_f(act[i]) > 0.f ? g[i] * scale : 0.f);
 }
 
+// ------------------------------------------------------------------ seq_per_img > 1: per-image features -> caption rows
+// (the loader's S-fold replication, P/misc/dataloader/dataloader.py:270-277, done on the device instead of the host)
+template <typename T>
+__global__ void expand_rows_kernel(const float* __restrict__ src, T* __restrict__ dst, int S, size_t row, size_t total) {
+  const size_t stride = (size_t)gridDim.x * blockDim.x * 4;
+  for (size_t i = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * 4; i < total; i += stride) {   // i indexes src; row % 4 == 0
+    const size_t img = i / row, e = i - img * row;
+    const float4 v = *(const float4*)(src + i);
+    for (int j = 0; j < S; ++j) {
+      T* o = dst + (img * S + j) * row + e;
+      if constexpr (sizeof(T) == 2) *(uint2*)o = make_uint2(uic_pack_bf16x2(v.x, v.y), uic_pack_bf16x2(v.z, v.w));
+      else *(float4*)o = v;
+    }
+  }
+}
+template <typename T>
+__global__ void expand_rows_scalar_kernel(const float* __restrict__ src, T* __restrict__ dst, int S, size_t row, size_t total) {
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+    const size_t img = i / row, e = i - img * row;
+    for (int j = 0; j < S; ++j) dst[(img * S + j) * row + e] = uic_from_f<T>(src[i]);
+  }
+}
+template <typename T>
+__global__ void expand_drop_kernel(const float* __restrict__ y, T* __restrict__ out, int S, size_t row, size_t total,
+                                   float drop_p, unsigned seed, unsigned site) {
+  const float inv_keep = drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f;
+  const size_t stride = (size_t)gridDim.x * blockDim.x * 4;
+  for (size_t i = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * 4; i < total; i += stride) {
+    const size_t img = i / row, e = i - img * row;
+    const float4 v = *(const float4*)(y + i);
+    const float f[4] = {v.x, v.y, v.z, v.w};
+    for (int j = 0; j < S; ++j) {
+      const size_t o = (img * S + j) * row + e;
+      float g[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+        g[q] = drop_p > 0.f ? f[q] * uic_drop_scale(seed, site, (unsigned)(o + q), drop_p, inv_keep) : f[q];
+      if constexpr (sizeof(T) == 2) *(uint2*)(out + o) = make_uint2(uic_pack_bf16x2(g[0], g[1]), uic_pack_bf16x2(g[2], g[3]));
+      else *(float4*)(out + o) = make_float4(g[0], g[1], g[2], g[3]);
+    }
+  }
+}
+template <typename T>
+__global__ void relu_mask_bwd_fold_kernel(const float* __restrict__ g, const T* __restrict__ act, float scale,
+                                          T* __restrict__ dst, int S, size_t row, size_t total) {
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+    const size_t img = i / row, e = i - img * row;
+    float acc = 0.f;
+    for (int j = 0; j < S; ++j) {
+      const size_t o = (img * S + j) * row + e;
+      acc += uic_to_f(act[o]) > 0.f ? g[o] * scale : 0.f;
+    }
+    dst[i] = uic_from_f<T>(acc);
+  }
+}
+
 // ------------------------------------------------------------------ LSTM cell backward (pointwise part)
 // Backward of nn.LSTMCell's gate math (P/models/AttModel.py:434,441): gates are stored activated.
 template <typename T>
@@ -680,6 +738,45 @@ int uic_relu_mask_bwd_launch(int dtype, const float* grad, const void* act, floa
   DISPATCH_T(dtype, hipLaunchKernelGGL(relu_mask_bwd_kernel<bf16_t>, dim3(g), dim3(NT), 0, s, grad, (const bf16_t*)act, scale, (bf16_t*)dst, n),
              hipLaunchKernelGGL(relu_mask_bwd_kernel<float>, dim3(g), dim3(NT), 0, s, grad, (const float*)act, scale, (float*)dst, n));
   UIC_LAUNCH_CHECK("relu_mask_bwd");
+  return UIC_OK;
+}
+int uic_expand_rows_launch(int dtype_out, const float* src, void* dst, int n_img, int S, size_t row, hipStream_t s) {
+  UIC_REQUIRE(src && dst && S >= 1, "expand_rows: bad arguments");
+  const size_t total = (size_t)n_img * row;
+  if (total == 0) return UIC_OK;
+  if (row % 4 != 0) {     // short odd rows (att_masks [n_img, R])
+    const int g1 = grid_for(total, NT);
+    DISPATCH_T(dtype_out, hipLaunchKernelGGL(expand_rows_scalar_kernel<bf16_t>, dim3(g1), dim3(NT), 0, s, src, (bf16_t*)dst, S, row, total),
+               hipLaunchKernelGGL(expand_rows_scalar_kernel<float>, dim3(g1), dim3(NT), 0, s, src, (float*)dst, S, row, total));
+    UIC_LAUNCH_CHECK("expand_rows_scalar");
+    return UIC_OK;
+  }
+  const int g = grid_for(total / 4, NT);
+  DISPATCH_T(dtype_out, hipLaunchKernelGGL(expand_rows_kernel<bf16_t>, dim3(g), dim3(NT), 0, s, src, (bf16_t*)dst, S, row, total),
+             hipLaunchKernelGGL(expand_rows_kernel<float>, dim3(g), dim3(NT), 0, s, src, (float*)dst, S, row, total));
+  UIC_LAUNCH_CHECK("expand_rows");
+  return UIC_OK;
+}
+int uic_expand_drop_launch(int dtype, const float* y, void* out, int n_img, int S, size_t row, float drop_p, unsigned seed,
+                           unsigned site, hipStream_t s) {
+  UIC_REQUIRE(y && out && S >= 1 && row % 4 == 0, "expand_drop: bad arguments");
+  const size_t total = (size_t)n_img * row;
+  if (total == 0) return UIC_OK;
+  const int g = grid_for(total / 4, NT);
+  DISPATCH_T(dtype, hipLaunchKernelGGL(expand_drop_kernel<bf16_t>, dim3(g), dim3(NT), 0, s, y, (bf16_t*)out, S, row, total, drop_p, seed, site),
+             hipLaunchKernelGGL(expand_drop_kernel<float>, dim3(g), dim3(NT), 0, s, y, (float*)out, S, row, total, drop_p, seed, site));
+  UIC_LAUNCH_CHECK("expand_drop");
+  return UIC_OK;
+}
+int uic_relu_mask_bwd_fold_launch(int dtype, const float* grad, const void* act, float scale, void* dst, int n_img, int S,
+                                  size_t row, hipStream_t s) {
+  UIC_REQUIRE(grad && act && dst && S >= 1, "relu_mask_bwd_fold: bad arguments");
+  const size_t total = (size_t)n_img * row;
+  if (total == 0) return UIC_OK;
+  const int g = grid_for(total, NT);
+  DISPATCH_T(dtype, hipLaunchKernelGGL(relu_mask_bwd_fold_kernel<bf16_t>, dim3(g), dim3(NT), 0, s, grad, (const bf16_t*)act, scale, (bf16_t*)dst, S, row, total),
+             hipLaunchKernelGGL(relu_mask_bwd_fold_kernel<float>, dim3(g), dim3(NT), 0, s, grad, (const float*)act, scale, (float*)dst, S, row, total));
+  UIC_LAUNCH_CHECK("relu_mask_bwd_fold");
   return UIC_OK;
 }
 int uic_lstm_bwd_launch(const UicLstmBwdParams& p, hipStream_t s) {

@@ -23,6 +23,7 @@ constexpr int WG_CHUNK = 4;   // decode steps per hand-off between the two strea
 struct Layout {
   // forward activations
   void* fcT; void* attT; int* row_len;
+  float* ypre; float* amask_rep; float* att_rep;   // seq_per_img > 1: per-image relu(att_embed) (f32), att_masks / att_feats per caption row
   void* fcp; void* attp; void* patt;
   void* ybn; float* bn_stat0; float* bn_stat4; float* bn_part; float* bn_red;   // use_bn: pre-BN4 activations, {mean, rstd}, scratch
   void* xt_all; float* gx; float* gfc;
@@ -60,6 +61,11 @@ Layout make_layout(const uic_topdown_dims& d, void* ws) {
   L.fcT = b.take(N * Dfc * S);
   L.attT = b.take(NR * D * S);
   L.row_len = (int*)b.take(N * sizeof(int));
+  if (d.seq_per_img > 1) {
+    L.amask_rep = (float*)b.take(NR * 4);
+    if (d.use_bn) L.att_rep = (float*)b.take(NR * D * 4);          // BatchNorm path: replicate the input, then as S = 1
+    else L.ypre = (float*)b.take(N / d.seq_per_img * R * H * 4);
+  }
   L.fcp = b.take(N * H * S);
   L.attp = b.take(NR * H * S);
   L.patt = b.take(NR * A * S);
@@ -231,6 +237,8 @@ int check_dims(const uic_topdown_dims* d) {
               "D=%d Dfc=%d H=%d E=%d A=%d must all be multiples of 8", d->D, d->Dfc, d->H, d->E, d->A);
   UIC_REQUIRE(d->drop_p >= 0.f && d->drop_p < 1.f, "drop_p=%f outside [0,1)", (double)d->drop_p);
   UIC_REQUIRE(d->use_bn >= 0 && d->use_bn <= 2, "use_bn=%d outside {0,1,2}", d->use_bn);
+  UIC_REQUIRE(d->seq_per_img >= 0 && (d->seq_per_img <= 1 || d->N % d->seq_per_img == 0),
+              "seq_per_img=%d must divide N=%d", d->seq_per_img, d->N);
   return UIC_OK;
 }
 
@@ -251,28 +259,46 @@ int prepare_features(const uic_topdown_dims& d, const uic_topdown_weights* w, co
   const int dt = d.dtype;
   const int N = d.N, R = d.R, H = d.H, A = d.A;
   const bool bn_train = (training & 1) != 0, bn_update = bn_train && !(training & 2);
+  // seq_per_img = S > 1: fc_feats / att_feats / att_masks hold one row per IMAGE; caption row n belongs to image n / S
+  const int S = d.seq_per_img > 1 ? d.seq_per_img : 1, Ni = N / S;
+  const bool fold = S > 1 && !d.use_bn;     // att_embed's Linear runs once per image; dropout is applied per caption row
+  const float* att_src = b->att_feats;
+  const float* amask = b->att_masks;        // per caption row
+  if (S > 1 && b->att_masks) {
+    UIC_TRY(uic_expand_rows_launch(UIC_F32, b->att_masks, L.amask_rep, Ni, S, (size_t)R, s));
+    amask = L.amask_rep;
+  }
+  if (S > 1 && d.use_bn) {                  // batch statistics are defined over the replicated rows: replicate, then as S = 1
+    UIC_TRY(uic_expand_rows_launch(UIC_F32, b->att_feats, L.att_rep, Ni, S, (size_t)R * d.D, s));
+    att_src = L.att_rep;
+  }
   const int* row_len = b->att_masks ? L.row_len : nullptr;
   const void* fc_in = b->fc_feats;
-  const void* att_in = b->att_feats;
+  const void* att_in = att_src;
   if (b->att_masks) {
-    hipLaunchKernelGGL(rowlen_kernel, dim3((N + 255) / 256), dim3(256), 0, s, b->att_masks, N, R, L.row_len);
+    const int rows = fold ? Ni : N;
+    hipLaunchKernelGGL(rowlen_kernel, dim3((rows + 255) / 256), dim3(256), 0, s, fold ? b->att_masks : amask, rows, R, L.row_len);
     UIC_LAUNCH_CHECK("rowlen_kernel");
   }
-  if (dt == UIC_BF16) {
+  if (S > 1) {
+    UIC_TRY(uic_expand_rows_launch(dt, b->fc_feats, L.fcT, Ni, S, (size_t)d.Dfc, s));
+    fc_in = L.fcT;
+  } else if (dt == UIC_BF16) {
     UIC_TRY(uic_cast_f32_launch(dt, b->fc_feats, L.fcT, (size_t)N * d.Dfc, s));
     fc_in = L.fcT;
   }
+  const int Na = fold ? Ni : N;             // rows of att_src
   if (d.use_bn) {
     // BatchNorm1d(D) over the packed live regions; xhat goes to the GEMM, the affine part lives in W' / b'
     if (bn_train)
-      UIC_TRY(uic_bn_stats_launch(UIC_F32, b->att_feats, N * R, R, d.D, row_len, L.bn_part, BN_MOMENTUM, BN_EPS, L.bn_stat0,
+      UIC_TRY(uic_bn_stats_launch(UIC_F32, att_src, N * R, R, d.D, row_len, L.bn_part, BN_MOMENTUM, BN_EPS, L.bn_stat0,
                                   bn_update ? w->att_bn0_rm : nullptr, bn_update ? w->att_bn0_rv : nullptr, s));
     else
       UIC_TRY(uic_bn_stats_running_launch(w->att_bn0_rm, w->att_bn0_rv, d.D, BN_EPS, L.bn_stat0, s));
-    UIC_TRY(uic_bn_apply_launch(UIC_F32, dt, b->att_feats, N * R, R, d.D, row_len, L.bn_stat0, nullptr, nullptr, 0, L.attT, s));
+    UIC_TRY(uic_bn_apply_launch(UIC_F32, dt, att_src, N * R, R, d.D, row_len, L.bn_stat0, nullptr, nullptr, 0, L.attT, s));
     att_in = L.attT;
   } else if (dt == UIC_BF16) {
-    UIC_TRY(uic_cast_f32_launch(dt, b->att_feats, L.attT, (size_t)N * R * d.D, s));
+    UIC_TRY(uic_cast_f32_launch(dt, att_src, L.attT, (size_t)Na * R * d.D, s));
     att_in = L.attT;
   }
   *fc_in_out = fc_in;
@@ -284,7 +310,16 @@ int prepare_features(const uic_topdown_dims& d, const uic_topdown_weights* w, co
     g.drop_p = drop_p; g.seed = seed; g.site = UIC_SITE_FC;
     UIC_TRY(uic_gemm_launch(g, s));
   }
-  {
+  if (fold) {
+    // relu(W att + b) once per image (f32), then S caption rows with their own dropout masks -- element for element
+    // what the S-fold replicated GEMM epilogue writes
+    UicGemmParams g = gemm_base(dt, Ni * R, H);
+    add_seg(g, att_in, d.D, dv.att_w, d.D, d.D);
+    g.C = L.ypre; g.ldc = H; g.bias = w->att_b; g.flags = UIC_GEMM_RELU | UIC_GEMM_OUT_F32;
+    if (b->att_masks) { g.row_len = L.row_len; g.R = R; }
+    UIC_TRY(uic_gemm_launch(g, s));
+    UIC_TRY(uic_expand_drop_launch(dt, L.ypre, L.attp, Ni, S, (size_t)R * H, drop_p, seed, UIC_SITE_ATT, s));
+  } else {
     UicGemmParams g = gemm_base(dt, N * R, H);
     add_seg(g, att_in, d.D, dv.att_w, d.D, d.D);
     g.C = d.use_bn == 2 ? L.ybn : L.attp; g.ldc = H; g.bias = d.use_bn ? dv.att_beff : w->att_b; g.flags = UIC_GEMM_RELU;
@@ -319,7 +354,7 @@ int attention_step(const uic_topdown_dims& d, const uic_topdown_weights* w, cons
   memset(&a, 0, sizeof(a));
   a.dtype = d.dtype; a.N = d.N; a.R = d.R; a.A = d.A; a.H = d.H;
   a.att_h = att_h; a.p_att = L.patt; a.att = L.attp; a.w_alpha = w->alpha_w; a.b_alpha = w->alpha_b;
-  a.mask = b->att_masks; a.ldmask = d.R; a.alpha = alpha; a.ctx = ctx; a.ldctx = d.H;
+  a.mask = b->att_masks ? (d.seq_per_img > 1 ? L.amask_rep : b->att_masks) : nullptr; a.ldmask = d.R; a.alpha = alpha; a.ctx = ctx; a.ldctx = d.H;
   return uic_attention_fwd_launch(a, s);
 }
 
@@ -488,8 +523,8 @@ struct Step {
     drop_p = (training & 1) ? d.drop_p : 0.f;
     inv_keep = drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f;
     seed = seed_;
-    fc_in = dt == UIC_BF16 ? L.fcT : (const void*)b->fc_feats;
-    att_in = (dt == UIC_BF16 || d.use_bn) ? L.attT : (const void*)b->att_feats;
+    fc_in = (dt == UIC_BF16 || d.seq_per_img > 1) ? L.fcT : (const void*)b->fc_feats;
+    att_in = (dt == UIC_BF16 || d.use_bn) ? L.attT : (const void*)b->att_feats;   // per image when seq_per_img > 1 without BN
   }
 
   // scheduled sampling (AttModel.py:130-143) is active in train mode only
@@ -825,13 +860,20 @@ struct Step {
                                 training & 1, L.bn_part, L.bn_red, G->att_bn4_w, G->att_bn4_b, s));
       act = L.ybn;
     }
-    UIC_TRY(uic_relu_mask_bwd_launch(dt, L.d_att, act, inv_keep, L.d_pre, (size_t)NR * H, s));
+    // seq_per_img > 1 without BN: the S caption rows of an image share the Linear's input, so their gradients are summed
+    // first and the weight-gradient GEMM runs over the per-image rows
+    const bool fold = d.seq_per_img > 1 && !d.use_bn;
+    const int NRa = fold ? NR / d.seq_per_img : NR;
+    if (fold)
+      UIC_TRY(uic_relu_mask_bwd_fold_launch(dt, L.d_att, act, inv_keep, L.d_pre, N / d.seq_per_img, d.seq_per_img, (size_t)R * H, s));
+    else
+      UIC_TRY(uic_relu_mask_bwd_launch(dt, L.d_att, act, inv_keep, L.d_pre, (size_t)NR * H, s));
     {
       const UicGemmTnSeg seg{att_in, D, D};
       const WDest d1{G->att_w, D, 0, D};
-      UIC_TRY(wgrad_group(L.slab, L.d_pre, H, H, &seg, 1, NR, &d1, 1, s, false, L.tA, L.tB));
+      UIC_TRY(wgrad_group(L.slab, L.d_pre, H, H, &seg, 1, NRa, &d1, 1, s, false, L.tA, L.tB));
     }
-    UIC_TRY(uic_colsum_launch(dt, L.d_pre, NR, H, H, G->att_b, L.colscratch, L.colscratch_floats, s));
+    UIC_TRY(uic_colsum_launch(dt, L.d_pre, NRa, H, H, G->att_b, L.colscratch, L.colscratch_floats, s));
     if (d.use_bn) {        // G->att_w holds dW' = d_pre^T xhat: unfold the BatchNorm1d(D) affine part (batchnorm.hip)
       UIC_REQUIRE(G->att_bn0_w && G->att_bn0_b, "backward: use_bn needs gradient tensors for att_embed.0");
       UIC_TRY(uic_bn_fold_grad_launch(w->att_w, w->att_bn0_w, w->att_bn0_b, G->att_w, G->att_b, H, D, G->att_bn0_w, G->att_bn0_b, s));

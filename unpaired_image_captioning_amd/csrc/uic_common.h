@@ -257,6 +257,15 @@ int uic_embed_bwd_launch(int dtype, const float* dxt, const void* xt, const int6
                          int V1, int E, float drop_p, long skip_token, float* dtable, hipStream_t s);   // skip_token < 0: none (nn.Embedding padding_idx otherwise)
 // dst = (act > 0 ? scale : 0) * grad ; grad f32, act/dst operand dtype
 int uic_relu_mask_bwd_launch(int dtype, const float* grad, const void* act, float scale, void* dst, size_t n, hipStream_t s);
+// seq_per_img > 1 (features given per image, caption rows = image * S + j):
+//   expand_rows: dst[(i*S + j) * row + e] = cast(src[i * row + e])                       (dst dtype: dtype_out)
+//   expand_drop: out[(i*S + j), e] = cast(y[i, e] * dropout keep-scale of element ((i*S + j) * row + e) at `site`)
+//   relu_mask_bwd_fold: dst[i, e] = cast(sum_j (act[(i*S+j), e] > 0 ? grad[(i*S+j), e] * scale : 0))
+int uic_expand_rows_launch(int dtype_out, const float* src, void* dst, int n_img, int S, size_t row, hipStream_t s);
+int uic_expand_drop_launch(int dtype, const float* y, void* out, int n_img, int S, size_t row, float drop_p, unsigned seed,
+                           unsigned site, hipStream_t s);
+int uic_relu_mask_bwd_fold_launch(int dtype, const float* grad, const void* act, float scale, void* dst, int n_img, int S,
+                                  size_t row, hipStream_t s);
 
 // scheduled sampling (AttModel.py:130-143): used[n, t] = u_mask(n) < ss_prob ? draw from softmax(logits_prev[n]) : labels[n, t]
 int uic_ss_sample_launch(const float* logits_prev, int N, int V1, int ldv, const int64_t* labels, int ld_labels, int t,

@@ -35,14 +35,24 @@ class TopDownEngine(object):
         self.seed = 0x5EED
 
     # ------------------------------------------------------------------ arenas
-    def dims(self, N, R, T):
+    def dims(self, N, R, T, seq_per_img=1):
         s = self.sizes
         return Dims(N=N, R=R, D=s["D"], Dfc=s["Dfc"], H=s["H"], E=s["E"], A=s["A"], V1=s["V1"], T=T,
-                    dtype=self.dtype, drop_p=self.drop_p, use_bn=self.use_bn)
+                    dtype=self.dtype, drop_p=self.drop_p, use_bn=self.use_bn, seq_per_img=seq_per_img)
 
     @staticmethod
     def _key(d):
-        return (d.N, d.R, d.T, d.dtype)
+        return (d.N, d.R, d.T, d.dtype, d.seq_per_img)
+
+    @staticmethod
+    def _rows(att, labels):
+        """(caption rows N, seq_per_img S): features may come once per image ([N / S, ...]) with labels per caption row --
+        the loader's S-fold replication (P/misc/dataloader/dataloader.py:270-277) then happens on the device."""
+        N = labels.shape[0]
+        n_feat = att.shape[0]
+        if N % n_feat != 0:
+            raise ValueError("labels have %d rows, features %d: not a whole number of captions per image" % (N, n_feat))
+        return N, N // n_feat
 
     def checkout(self, d, device):
         free = self._pool.setdefault(self._key(d), [])
@@ -97,9 +107,9 @@ class TopDownEngine(object):
 
     # ------------------------------------------------------------------ calls
     def forward(self, params, fc, att, att_masks, labels, t_run, training, seed, want_logprobs=True, masks=None, ss_prob=0.0):
-        N, R = att.shape[0], att.shape[1]
+        (N, S), R = self._rows(att, labels), att.shape[1]
         T = labels.shape[1] - 1
-        d = self.dims(N, R, T)
+        d = self.dims(N, R, T, S)
         w = self.refresh(params, d)
         ws = self.checkout(d, fc.device)
         b = self.batch_struct(fc, att, att_masks, labels, masks, ss_prob=ss_prob)
@@ -123,9 +133,9 @@ class TopDownEngine(object):
     def xe_train_step(self, params, fc, att, att_masks, labels, masks, t_run, training, seed, grads, inv_den=None,
                       grad_scale=None, ss_prob=0.0, keep_workspace=False):
         """Fused forward + criterion + backward on two HIP streams; returns a device tensor [loss, sum(mask)]."""
-        N, R = att.shape[0], att.shape[1]
+        (N, S), R = self._rows(att, labels), att.shape[1]
         T = labels.shape[1] - 1
-        d = self.dims(N, R, T)
+        d = self.dims(N, R, T, S)
         w = self.refresh(params, d)
         ws = self.checkout(d, fc.device)
         b = self.batch_struct(fc, att, att_masks, labels, masks, grad_scale, ss_prob)
@@ -144,9 +154,10 @@ class TopDownEngine(object):
         return out
 
     def sample(self, params, fc, att, att_masks, L, sample_max=1, temperature=1.0, decoding_constraint=0, seed=0,
-               forced=None, training=False):
-        N, R = att.shape[0], att.shape[1]
-        d = self.dims(N, R, L + 1)
+               forced=None, training=False, seq_per_img=1):
+        """seq_per_img = S > 1: features come once per image and S captions are decoded per image (rows image * S + j)."""
+        N, R = att.shape[0] * seq_per_img, att.shape[1]
+        d = self.dims(N, R, L + 1, seq_per_img)
         w = self.refresh(params, d)
         ws = self.checkout(d, fc.device)
         b = self.batch_struct(fc, att, att_masks)
@@ -161,14 +172,13 @@ class TopDownEngine(object):
         return seq, lp
 
     def sample_beam(self, params, fc, att, att_masks, L, beam_size, decoding_constraint=0, max_ppl=0):
-        """Beam search for all images at once: every image is replicated beam_size times (rows = (image, beam))."""
+        """Beam search for all images at once: rows = (image, beam); the beam_size-fold replication of every image's
+        features (AttModel.py:180-184) happens on the device (dims.seq_per_img = beam_size)."""
         n_img = att.shape[0]
-        rep = lambda t: None if t is None else t.repeat_interleave(beam_size, 0).contiguous()   # noqa: E731
-        fcb, attb, amb = rep(fc), rep(att), rep(att_masks)
-        d = self.dims(n_img * beam_size, att.shape[1], L + 1)
+        d = self.dims(n_img * beam_size, att.shape[1], L + 1, beam_size)
         w = self.refresh(params, d)
         ws = self.checkout(d, fc.device)
-        b = self.batch_struct(fcb, attb, amb)
+        b = self.batch_struct(fc, att, att_masks)
         seq = torch.zeros(n_img, L, dtype=torch.int64, device=fc.device)
         lp = torch.zeros(n_img, L, dtype=torch.float32, device=fc.device)
         try:

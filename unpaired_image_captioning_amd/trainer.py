@@ -112,19 +112,35 @@ class Trainer(object):
         else:
             self.i2t_current_lr = self.lr
 
-    def to_device(self, data):
-        """numpy batch dict of DataLoader.get_batch -> device tensors (P/trainer.py:147-149)."""
+    def to_device(self, data, per_image=True):
+        """numpy batch dict of DataLoader.get_batch -> device tensors (P/trainer.py:147-149).
+
+        The loader replicates every image's features seq_per_img times on the host (P/misc/dataloader/dataloader.py:
+        270-277).  With opt.seq_per_img > 1 only every seq_per_img-th feature row crosses PCIe (37.7 MB instead of
+        188.7 MB at config 2) and the replication happens on the device (uic_topdown_dims.seq_per_img); the first batch
+        is checked to really be replicated.  opt.ship_replicated_features = 1 keeps the reference's behaviour."""
+        S = int(getattr(self.opt, 'seq_per_img', 1) or 1)
+        if not per_image or getattr(self.opt, 'ship_replicated_features', 0) or not hasattr(self.i2t_model, 'use_bn'):
+            S = 1
         out = {}
         for k in ("fc_feats", "att_feats", "labels", "masks", "att_masks"):
             v = data.get(k)
             if v is None:
                 continue
+            if S > 1 and k in ("fc_feats", "att_feats", "att_masks") and isinstance(v, np.ndarray) and len(v) == len(data["labels"]):
+                if not getattr(self, '_replication_checked', False):
+                    for j in range(1, S):
+                        if not (np.asarray(v[j::S]) == np.asarray(v[::S])).all():
+                            raise ValueError("opt.seq_per_img=%d but the rows of %s are not %d-fold replicated; set "
+                                             "opt.ship_replicated_features=1 for per-caption features" % (S, k, S))
+                v = v[::S]
             t = torch.from_numpy(np.ascontiguousarray(v)) if isinstance(v, np.ndarray) else v
             if k == "labels":
                 t = t.long()
             else:
                 t = t.float()
             out[k] = t.cuda(non_blocking=True)
+        self._replication_checked = True
         return out
 
     def train_device_batch(self, batch, t_run, den_local):
@@ -165,7 +181,7 @@ class Trainer(object):
         from .misc.criterion import RewardCriterion
         if self.arena is None:
             self.build_optimizer()
-        batch = self.to_device(data)
+        batch = self.to_device(data, per_image=False)     # the sampling calls take one feature row per caption row
         model = self.i2t_model
         fc, att, am = batch["fc_feats"], batch["att_feats"], batch.get("att_masks")
         model.train()
