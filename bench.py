@@ -36,7 +36,7 @@ def make_opt(dtype, seed, use_bn=0):
     return argparse.Namespace(vocab_size=c["V"], input_encoding_size=c["E"], rnn_size=c["H"], num_layers=1,
                               drop_prob_lm=0.5, seq_length=c["L"], fc_feat_size=c["D"], att_feat_size=c["D"],
                               att_hid_size=c["A"], use_bn=use_bn, logit_layers=1, caption_model="topdown",
-                              compute_dtype=dtype, seed=seed, i2t_learning_rate=5e-4, i2t_train_flag=1)
+                              compute_dtype=dtype, seed=seed, i2t_learning_rate=5e-4, i2t_train_flag=1, seq_per_img=c["S"])
 
 
 def _pmc_traffic(dtype):

@@ -813,3 +813,32 @@ def test_features_per_image_argument_errors():
     model = models.setup(make_opt(cfg, "f32")).cuda()
     with pytest.raises(ValueError, match="whole number"):
         model(full["fc_feats"][:4], None, full["att_feats"][:4], full["labels"], None)
+
+
+def test_self_critical_step_per_image_features_equal_replicated():
+    """Trainer.train_self_critical with every image shipped once (opt.seq_per_img: sampling pass with S captions per image,
+    greedy baseline decoded once per image, replay with device-side replication) == the replicated batch."""
+    from unpaired_image_captioning_amd.trainer import Trainer
+    cfg, W, I, Out, G, X = load_golden("topdown_tiny_ragged")
+    data = {k: I[k].numpy() for k in ("fc_feats", "att_feats", "labels", "masks", "att_masks")}
+
+    def reward_fn(data, sampled, greedy):
+        r = np.where(sampled[:, :1] % 2 == 0, 1.0, -1.0) - np.where(greedy[:, :1] % 2 == 0, 0.5, -0.5)
+        return np.repeat(r, sampled.shape[1], 1)
+
+    res = []
+    for ship_replicated in (1, 0):
+        opt = make_opt(cfg, "f32", drop=0.5, seed=3)
+        opt.i2t_learning_rate = 1e-3
+        opt.seq_per_img = cfg["S"]
+        opt.ship_replicated_features = ship_replicated
+        tr = Trainer(opt)
+        tr.i2t_model.load_state_dict(W)
+        tr.build_optimizer()
+        assert tr.to_device(data)["att_feats"].shape[0] == (len(data["labels"]) if ship_replicated else len(data["labels"]) // cfg["S"])
+        losses = [tr.train_self_critical(data, reward_fn) for _ in range(3)]
+        res.append((losses, {k: v.detach().cpu().clone() for k, v in tr.i2t_model.state_dict().items()}))
+    (l0, w0), (l1, w1) = res
+    np.testing.assert_allclose(l1, l0, rtol=0, atol=1e-5)
+    for k in w0:
+        assert absmax(w1[k], w0[k]) < 2e-5, k

@@ -78,3 +78,9 @@ data = {k: v.cpu().numpy() for k, v in batch.items()}
 def scst():
     tr.train_self_critical(data, lambda d, s, g: np.ones(s.shape, dtype=np.float32))
 print("Trainer.train_self_critical incl. H2D of the batch and the reward round trip: %.3f ms" % timeit(scst, iters=5, warm=2))
+
+def xe_host():
+    tr.train(data)
+print("Trainer.train (XE) from host numpy incl. H2D (features once per image) and the loss.item() sync: %.3f ms" % timeit(xe_host, iters=10, warm=3))
+tr.opt.ship_replicated_features = 1
+print("Trainer.train (XE) from host numpy, features replicated on the host as the reference ships them: %.3f ms" % timeit(xe_host, iters=5, warm=2))

@@ -1,0 +1,57 @@
+#!/usr/bin/env python3
+"""Where the self-critical step's wall time goes (host-synchronised sections; config-2 shapes)."""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import torch
+import bench
+from unpaired_image_captioning_amd.synthetic import synthetic_batch
+from unpaired_image_captioning_amd.trainer import Trainer
+from unpaired_image_captioning_amd.misc.criterion import RewardCriterion
+
+c = bench.CFG
+torch.manual_seed(1234)
+tr = Trainer(bench.make_opt("bf16", 1234)); tr.build_optimizer()
+batch = synthetic_batch(c["n_img"], c["S"], c["R"], c["D"], c["V"], c["L"], seed=1234)
+data = {k: v.cpu().numpy() for k, v in batch.items()}
+model = tr.i2t_model
+
+
+def sec(name, fn, acc):
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    r = fn()
+    torch.cuda.synchronize(); acc[name] = acc.get(name, 0.0) + (time.perf_counter() - t0) * 1e3
+    return r
+
+
+acc = {}
+for it in range(8):
+    if it == 3:
+        acc = {}
+    b = sec("to_device", lambda: tr.to_device(data), acc)
+    fc, att, am = b["fc_feats"], b["att_feats"], b.get("att_masks")
+    S = len(data["labels"]) // att.shape[0]
+    model.train()
+    gen, lp = sec("sample", lambda: model(fc, None, att, am, opt={'sample_max': 0, 'seq_per_img': S}, mode='sample'), acc)
+    model.eval()
+    def greedy():
+        with torch.no_grad():
+            g, _ = model(fc, None, att, am, opt={'sample_max': 1}, mode='sample')
+            return g.repeat_interleave(S, 0)
+    gr = sec("greedy", greedy, acc)
+    model.train()
+    rw = sec("reward roundtrip", lambda: torch.from_numpy(np.ones(gen.cpu().numpy().shape, dtype=np.float32) + 0 * gr.cpu().numpy()).cuda(), acc)
+    loss = sec("criterion", lambda: RewardCriterion()(lp, gen, rw), acc)
+    def bw():
+        for p in model.parameters():
+            p.grad = None
+        loss.backward()
+    sec("backward (replay + BPTT)", bw, acc)
+    def upd():
+        params = dict(model.named_parameters())
+        for k, view in tr.arena.grad_views.items():
+            view.copy_(params[k].grad)
+    sec("grad copy to arena", upd, acc)
+for k, v in acc.items():
+    print("%-28s %.3f ms" % (k, v / 5))
+print("sum %.3f ms; S=%d" % (sum(acc.values()) / 5, S))

@@ -134,14 +134,44 @@ class Trainer(object):
                             raise ValueError("opt.seq_per_img=%d but the rows of %s are not %d-fold replicated; set "
                                              "opt.ship_replicated_features=1 for per-caption features" % (S, k, S))
                 v = v[::S]
-            t = torch.from_numpy(np.ascontiguousarray(v)) if isinstance(v, np.ndarray) else v
-            if k == "labels":
-                t = t.long()
-            else:
-                t = t.float()
-            out[k] = t.cuda(non_blocking=True)
+            if isinstance(v, np.ndarray):
+                v = torch.from_numpy(v if v.flags.writeable else v.copy())
+            out[k] = self._ship(k, v, torch.int64 if k == "labels" else torch.float32)
         self._replication_checked = True
         return out
+
+    def _ship(self, key, t, dtype):
+        """Host tensor (any strides / dtype) -> device: ONE threaded gather-and-convert pass into a pinned staging buffer
+        (two per key, guarded by events) and an asynchronous copy, instead of ascontiguousarray + a pageable hipMemcpy
+        that stages a second time."""
+        if t.is_cuda:
+            return t.to(dtype)
+        ring = self.__dict__.setdefault('_pin', {}).setdefault(key, [])
+        slot = self.__dict__.setdefault('_pin_slot', {})
+        i = slot.get(key, 0)
+        slot[key] = (i + 1) % 2
+        while len(ring) <= i:
+            ring.append(None)
+        if ring[i] is None or ring[i][0].shape != t.shape or ring[i][0].dtype != dtype:
+            ring[i] = [torch.empty(t.shape, dtype=dtype, pin_memory=True), None]
+        pin, ev = ring[i]
+        if ev is not None:
+            ev.synchronize()                       # the copy that last read this buffer has finished
+        # at most 8 copy threads: a machine-wide OpenMP team (256 threads on the MI355X hosts) keeps spinning after the
+        # copy and slows the following kernel enqueues 4x (measured: the replay + BPTT enqueue 4.2 -> 16.7 ms)
+        nthr = torch.get_num_threads()
+        if nthr > 8:
+            torch.set_num_threads(8)
+        try:
+            pin.copy_(t)
+        finally:
+            if nthr > 8:
+                torch.set_num_threads(nthr)
+        dev = pin.cuda(non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        ring[i][1] = ev
+        return dev
 
     def train_device_batch(self, batch, t_run, den_local):
         """The timed hot path: everything from device-resident inputs to updated weights."""
@@ -181,14 +211,18 @@ class Trainer(object):
         from .misc.criterion import RewardCriterion
         if self.arena is None:
             self.build_optimizer()
-        batch = self.to_device(data, per_image=False)     # the sampling calls take one feature row per caption row
+        batch = self.to_device(data)
         model = self.i2t_model
         fc, att, am = batch["fc_feats"], batch["att_feats"], batch.get("att_masks")
+        n_rows = len(data["labels"]) if data.get("labels") is not None else att.shape[0]
+        S = n_rows // att.shape[0]                        # > 1 when to_device shipped every image once
         model.train()
-        gen_result, sample_logprobs = model(fc, None, att, am, opt={'sample_max': 0}, mode='sample')
+        gen_result, sample_logprobs = model(fc, None, att, am, opt={'sample_max': 0, 'seq_per_img': S}, mode='sample')
         model.eval()
         with torch.no_grad():                                           # rewards.py:42-47: greedy baseline, eval mode
             greedy_res, _ = model(fc, None, att, am, opt={'sample_max': 1}, mode='sample')
+            if S > 1:                                     # eval mode is deterministic: the S replicas decode identically
+                greedy_res = greedy_res.repeat_interleave(S, 0)
         model.train()
         reward = np.asarray(reward_fn(data, gen_result.cpu().numpy(), greedy_res.cpu().numpy()), dtype=np.float32)
         loss = RewardCriterion()(sample_logprobs, gen_result, torch.from_numpy(reward).cuda())
