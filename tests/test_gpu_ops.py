@@ -230,7 +230,11 @@ def test_attention_fwd_bwd(dt, dims, masked):
 
 
 @pytest.mark.parametrize("dt", [0, 1])
-def test_attention_bwd_accum_multi_step(dt):
+@pytest.mark.parametrize("large", [0, 1, 2])
+def test_attention_bwd_accum_multi_step(dt, large):
+    """large = 1 / 2: pre-activations beyond the range in which the bf16 kernel may factor e^{2(p + h)} into
+    e^{2p} e^{2h} (|2x| > 40), incl. operands of opposite sign whose SUM is small -- the kernel must fall back to the
+    direct form for those rows (1: a few p_att entries, 2: a whole caption row's att_h)."""
     L = _lib()
     lib = L.load()
     N, R, A, H, T = 5, 9, 64, 48, 4
@@ -238,6 +242,12 @@ def test_attention_bwd_accum_multi_step(dt):
     p_att = torch.randn(N, R, A, generator=g)
     w = torch.randn(A, generator=g) / A ** 0.5
     att_h = torch.randn(T, N, A, generator=g)
+    if large == 1:
+        p_att[1, 2, 5] = 32.0; att_h[:, 1, 5] = -31.5          # sum 0.5: tanh far from saturation
+        p_att[3, 0, 9] = -64.0; p_att[4, 8, 63] = 100.0
+    elif large == 2:
+        att_h[2, 2] = 48.0 * torch.sign(torch.randn(A, generator=g))
+        p_att[2] -= att_h[2, 2] * 0.99
     alpha = torch.softmax(torch.randn(T, N, R, generator=g), 2)
     de = torch.randn(T, N, R, generator=g) * 0.1
     dctx = torch.randn(T, N, H, generator=g)

@@ -442,9 +442,22 @@ __global__ __launch_bounds__(256) void attn_bwd_accum_kernel(const UicAttnAccumP
     float* s_de = s_atth + TS * A;      // [TS][Rp]
     float* s_w = s_de + TS * Rp;        // [A]
     float* s_red = s_w + A;             // [nw][A]
+    // bf16 path: e^{2(p + h)} = e^{2p} e^{2h}, so the T x R x A tanh evaluations need ONE transcendental each (the
+    // reciprocal) instead of two: e^{2h} is staged once per (t, a) and e^{2p} computed once per (r, a).  Exact products
+    // need |2p|, |2h| <= EXP_LIM (no overflow / 0 * inf); anything larger -- never seen with trained or initial
+    // weights -- takes the direct form below.
+    constexpr bool FACTORED = sizeof(T) == 2;
+    constexpr float EXP_LIM = 40.f, LOG2E2 = 2.8853900817779268f;
+    int bad_h = 0;
     for (int i = tid; i < TS * A; i += nthreads) {
       const int t = i / A, a = i - t * A;
-      s_atth[i] = p.att_h_all[((size_t)t * N + n) * A + a];
+      const float v = p.att_h_all[((size_t)t * N + n) * A + a];
+      if constexpr (FACTORED) {
+        bad_h |= !(fabsf(v) * 2.f <= EXP_LIM);
+        s_atth[i] = __builtin_amdgcn_exp2f(v * LOG2E2);
+      } else {
+        s_atth[i] = v;
+      }
     }
     for (int i = tid; i < TS * R; i += nthreads) {
       const int t = i / R, r = i - t * R;
@@ -452,7 +465,7 @@ __global__ __launch_bounds__(256) void attn_bwd_accum_kernel(const UicAttnAccumP
     }
     for (int a = tid; a < A; a += nthreads) s_w[a] = p.w_alpha[a];
     for (int i = tid; i < nw * A; i += nthreads) s_red[i] = 0.f;
-    __syncthreads();
+    const bool wg_direct = __syncthreads_or(bad_h) != 0;
     // d p_att[n,r,a] = w_a sum_t de_t[r] (1 - tanh^2(.)) ;  d w_alpha[a] += sum_{t,r} de_t[r] tanh(.)
     const T* pa = (const T*)p.p_att + (size_t)n * R * A;
     T* dpa = (T*)p.d_p_att + (size_t)n * R * A;
@@ -467,13 +480,36 @@ __global__ __launch_bounds__(256) void attn_bwd_accum_kernel(const UicAttnAccumP
         uic_unpack<T>(v, f);
 #pragma unroll
         for (int j = 0; j < VEC; ++j) acc[j] = 0.f;
-        for (int t = 0; t < TS; ++t) {
-          const float de = s_de[t * Rp + r];
+        bool direct = !FACTORED;
+        if constexpr (FACTORED) {
+          direct = wg_direct;
 #pragma unroll
-          for (int j = 0; j < VEC; ++j) {
-            const float th = uic_tanh<T>(f[j] + s_atth[t * A + c * VEC + j]);
-            acc[j] += de * (1.f - th * th);
-            dwacc[j] += de * th;
+          for (int j = 0; j < VEC; ++j) direct |= !(fabsf(f[j]) * 2.f <= EXP_LIM);
+        }
+        if (!direct) {
+          float ep[VEC];
+#pragma unroll
+          for (int j = 0; j < VEC; ++j) ep[j] = __builtin_amdgcn_exp2f(f[j] * LOG2E2);
+          for (int t = 0; t < TS; ++t) {
+            const float de = s_de[t * Rp + r];
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) {
+              // rc = 1 / (1 + e^{2x});  tanh x = 1 - 2 rc;  1 - tanh^2 x = 4 rc (1 - rc)
+              const float rc = __builtin_amdgcn_rcpf(fmaf(ep[j], s_atth[t * A + c * VEC + j], 1.f));
+              acc[j] = fmaf(de * 4.f, rc - rc * rc, acc[j]);
+              dwacc[j] = fmaf(de, fmaf(-2.f, rc, 1.f), dwacc[j]);
+            }
+          }
+        } else {
+          for (int t = 0; t < TS; ++t) {
+            const float de = s_de[t * Rp + r];
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) {
+              const float h = FACTORED ? p.att_h_all[((size_t)t * N + n) * A + c * VEC + j] : s_atth[t * A + c * VEC + j];
+              const float th = uic_tanh<T>(f[j] + h);
+              acc[j] += de * (1.f - th * th);
+              dwacc[j] += de * th;
+            }
           }
         }
 #pragma unroll
