@@ -360,6 +360,34 @@ int uic_dropout_mask(float* out, size_t n, float p, uint32_t seed, uint32_t site
 #define UIC_SITE_NMT_DEC0 2000u  /* + l*256 + t: StackedLSTM dropout after decoder layer l at step t, element b*H+j */
 #define UIC_SITE_NMT_OUT0 4000u  /* + t: Decoder.dropout on the attentional output of step t, element b*H + j      */
 
+/* ---- CIDEr-D reward of the self-critical step ----
+ * get_self_critical_reward (P/misc/rewards.py:37-81) over the CIDEr-D scorer
+ * (P/misc/cider/pyciderevalcap/ciderD/ciderD_scorer.py:116-209, ciderD.py:26-50) on integer token rows, so that the sampled
+ * and greedy captions stay on the device.  A caption's words are its tokens up to and including the first 0
+ * (array_to_str, rewards.py:29-35).
+ *
+ * Document frequencies live in an open-addressing hash table keyed by the n-gram's tokens:
+ *   uic_ciderd_table_slots(n)  capacity (power of two) for n n-grams;
+ *   uic_ciderd_table_build     HOST arrays in, HOST arrays out (the caller uploads slot_keys [slots, 4] int32 and
+ *                              slot_vals [slots] f64): keys [n, 4] int32 (unused positions -1), values [n] =
+ *                              log(max(1, df)) as the scorer's counts2vec uses it (:128). */
+int64_t uic_ciderd_table_slots(int64_t n_entries);
+int uic_ciderd_table_build(const int32_t* keys, const double* values, int64_t n, int32_t* slot_keys, double* slot_vals,
+                           int64_t slots);
+/* CiderD.compute_score for n_hyp hypotheses hyp [n_hyp, L] (int64): hypothesis h is scored against the references of
+ * image (h % batch_size) / seq_per_img (rewards.py:59); references of image i are rows ref_start[i] .. ref_start[i+1] - 1
+ * of ref_tok [*, Lr] (int64, the zero-padded label rows of data['gts']).  ref_len as the scorer holds it (the value stored
+ * in the cached-tokens pickle, or log(n_hyp) in 'corpus' mode); penalty[d + pen_half] = e^(-d^2 / (2 sigma^2)) for
+ * d = -pen_half .. pen_half (pen_half >= max(L, Lr)), made on the host.  slots = 0: no table, every df is 0.
+ * scores [n_hyp] f64 = 10 * mean over n-gram orders and references, as :181-197.  L, Lr <= 64. */
+int uic_ciderd_scores(const int64_t* hyp, int32_t n_hyp, int32_t L, int32_t batch_size, int32_t seq_per_img,
+                      const int64_t* ref_tok, int32_t Lr, const int32_t* ref_start, int32_t n_img,
+                      const int32_t* slot_keys, const double* slot_vals, int64_t slots, double ref_len,
+                      const double* penalty, int32_t pen_half, double* scores, void* stream);
+/* reward [N, L] f32 = weight * (scores[n] - scores[N + n]) repeated over the L positions (rewards.py:74-79): rows 0..N-1 of
+ * `scores` are the sampled captions, rows N..2N-1 the greedy baseline. */
+int uic_ciderd_reward(const double* scores, int32_t N, int32_t L, float weight, float* reward, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

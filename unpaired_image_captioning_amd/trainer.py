@@ -204,11 +204,14 @@ class Trainer(object):
         self.i2t_train_loss = loss.item()          # the reference's per-step host sync (trainer.py:172)
         return self.i2t_train_loss
 
-    def train_self_critical(self, data, reward_fn):
-        """The self-critical branch of Trainer.train (P/trainer.py:166-171).  `reward_fn(data, sampled, greedy)`
-        -> float array [N, L] stands for get_self_critical_reward's CPU scorer (P/misc/rewards.py:37-82: CIDEr-D /
-        BLEU of the sampled caption minus that of the greedy one, repeated over L), which is outside the hot path."""
+    def train_self_critical(self, data, reward_fn=None):
+        """The self-critical branch of Trainer.train (P/trainer.py:166-171).  reward_fn None: the reference's reward,
+        CIDEr-D(sampled) - CIDEr-D(greedy) against data['gts'] with the cached document frequencies of
+        opt.cached_tokens (P/misc/rewards.py:37-81), scored on the device -- the captions never visit the host and the
+        step synchronises once, for loss.item().  A callable `reward_fn(data, sampled, greedy)` -> float array [N, L]
+        replaces the scorer (host round trip)."""
         from .misc.criterion import RewardCriterion
+        from .misc import rewards
         if self.arena is None:
             self.build_optimizer()
         batch = self.to_device(data)
@@ -221,11 +224,19 @@ class Trainer(object):
         model.eval()
         with torch.no_grad():                                           # rewards.py:42-47: greedy baseline, eval mode
             greedy_res, _ = model(fc, None, att, am, opt={'sample_max': 1}, mode='sample')
+        model.train()
+        if reward_fn is None:
+            if getattr(self.opt, 'bleu_reward_weight', 0) > 0:
+                raise NotImplementedError("bleu_reward_weight > 0 is not on the MI355X path (the reference's default is 0)")
+            scorer = rewards.init_scorer(getattr(self.opt, 'cached_tokens', 'corpus'))
+            reward_t = rewards.self_critical_reward_device(scorer, gen_result, greedy_res, data['gts'],
+                                                           float(getattr(self.opt, 'cider_reward_weight', 1)))
+        else:
             if S > 1:                                     # eval mode is deterministic: the S replicas decode identically
                 greedy_res = greedy_res.repeat_interleave(S, 0)
-        model.train()
-        reward = np.asarray(reward_fn(data, gen_result.cpu().numpy(), greedy_res.cpu().numpy()), dtype=np.float32)
-        loss = RewardCriterion()(sample_logprobs, gen_result, torch.from_numpy(reward).cuda())
+            reward = np.asarray(reward_fn(data, gen_result.cpu().numpy(), greedy_res.cpu().numpy()), dtype=np.float32)
+            reward_t = torch.from_numpy(reward).cuda()
+        loss = RewardCriterion()(sample_logprobs, gen_result, reward_t)
         for p in model.parameters():
             p.grad = None
         loss.backward()
@@ -239,8 +250,9 @@ class Trainer(object):
         check(_lib.load().uic_adam_step(ptr(a.flat), ptr(a.grad), ptr(a.exp_avg), ptr(a.exp_avg_sq), a.numel,
                                         self.i2t_current_lr, self.betas[0], self.betas[1], self.eps, self._step, scale,
                                         stream()), "adam_step")
-        self.i2t_avg_reward = float(np.mean(reward[:, 0]))
+        avg = reward_t[:, 0].mean()
         self.i2t_train_loss = loss.item()
+        self.i2t_avg_reward = float(avg.item())
         return self.i2t_train_loss
 
     # ------------------------------------------------------------------ pivot NMT half (P/trainer.py:80-94,175-193)
