@@ -1,0 +1,24 @@
+#!/bin/bash
+# One measurement pass on the GPU box (profiles/README.md): bench line, kernel stats, PMC traffic of the attention kernel, MFMA-busy.
+# Run as: gpurun -- bash tools/measure_pass.sh   (outputs under gpurun_out/v6; copy what is to be judged into profiles/)
+set -x
+R=$GRAFT_REPO_ROOT
+O=$R/gpurun_out/v6
+mkdir -p $O
+cd /tmp && export TMPDIR=/tmp
+timeout 400 python3 $R/bench.py > $O/bench.json 2> $O/bench.err
+tail -c 600 $O/bench.json
+timeout 500 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/p6 -- python3 $R/bench.py --steps 10 --warmup 3 --no-cpu-baseline > /tmp/p6.log 2>&1
+python3 $R/tools/prof_summary.py /tmp/p6 26 45 > $O/bench_summary.txt 2>&1
+grep '"metric"' /tmp/p6.log | tail -1 > $O/bench_under_rocprof.json   # the same process's own HIP-event figures
+cp $(find /tmp/p6 -name "*kernel_stats.csv" | head -1) $O/bench_kernel_stats.csv
+timeout 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d /tmp/pm/fetch -- python3 $R/tools/attn_kernel_only.py > /tmp/pmf.log 2>&1
+timeout 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d /tmp/pm/write -- python3 $R/tools/attn_kernel_only.py > /tmp/pmw.log 2>&1
+python3 $R/tools/pmc_traffic.py /tmp/pm attn_fwd_fast_kernel $O/attn_fwd_pmc_bf16.json
+cp $(find /tmp/pm/fetch -name "*counter_collection.csv" | head -1) $O/attn_fwd_pmc_fetch.csv
+cp $(find /tmp/pm/write -name "*counter_collection.csv" | head -1) $O/attn_fwd_pmc_write.csv
+timeout 400 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d /tmp/mf -- python3 $R/bench.py --steps 4 --warmup 2 --no-cpu-baseline > /tmp/mf.log 2>&1
+python3 $R/tools/pmc_mfma.py /tmp/mf 12 > $O/mfma_busy.txt 2>&1
+head -12 $O/mfma_busy.txt
+tail -5 $O/bench_summary.txt
+cat $O/attn_fwd_pmc_bf16.json
