@@ -199,7 +199,7 @@ def main():
         batch = per_image
     elapsed, loss = timed(batch)
     elapsed_img = None
-    if args.features == "per-caption" and not share:
+    if args.features == "per-caption" and world == 1:
         elapsed_img, _ = timed(per_image)
     loss_val = float(loss.item())
 

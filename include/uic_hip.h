@@ -9,6 +9,9 @@
  * and a positive hipError_t otherwise.  uic_last_error_string() describes the last failure on
  * the calling thread.  dtype: 0 = f32 operands (exact-f32 MFMA, parity path), 1 = bf16 operands
  * (bf16 MFMA, f32 accumulation / state / loss).
+ * Threading: the only state the library keeps is one lazily created set of side streams / events per device (mutex
+ * guarded creation) used by the fused steps; like any stream-ordered resource it is driven by one host thread per
+ * device at a time -- different devices (one process or thread per GPU) are independent.
  */
 #ifndef UIC_HIP_H
 #define UIC_HIP_H

@@ -13,6 +13,7 @@
 // Like the reference, attention is NOT masked over padded source positions (GlobalAttention.mask is never set in
 // training): their context vectors are zero, their scores are 0, and they take part in the softmax.
 #include "uic_common.h"
+#include <mutex>
 #include "uic_host.h"
 #include "../../include/uic_hip.h"
 #include <string.h>
@@ -456,11 +457,13 @@ struct NmtSide {
   bool ready = false;
 };
 NmtSide g_nmt_side[16];
+std::mutex g_nmt_side_mutex;
 int nmt_side(NmtSide** out) {
   int dev = 0;
   UIC_TRY(uic_check_hip(hipGetDevice(&dev), "hipGetDevice"));
   UIC_REQUIRE(dev >= 0 && dev < 16, "device index %d out of range", dev);
   NmtSide& ss = g_nmt_side[dev];
+  std::lock_guard<std::mutex> lock(g_nmt_side_mutex);
   if (!ss.ready) {
     UIC_TRY(uic_check_hip(hipStreamCreateWithFlags(&ss.stream, hipStreamNonBlocking), "hipStreamCreateWithFlags"));
     UIC_TRY(uic_check_hip(hipEventCreateWithFlags(&ss.ev_go, hipEventDisableTiming), "hipEventCreate"));

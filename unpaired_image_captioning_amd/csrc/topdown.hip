@@ -11,6 +11,7 @@
 //     gradient is one GEMM over the T*N stacked rows afterwards, and the attention's [N,R,*]
 //     gradients are produced by one deferred pass (attention.hip).
 #include "uic_common.h"
+#include <mutex>
 #include "uic_host.h"
 #include "../../include/uic_hip.h"
 #include <string.h>
@@ -374,12 +375,15 @@ struct SideStream {
   bool ready = false;
 };
 SideStream g_side[16];
+std::mutex g_side_mutex;   // guards the one-time creation of a device's streams / events (calls themselves are per device:
+                           // one host thread drives a device at a time, as with any stream-ordered library state)
 
 int get_side(SideStream** out) {
   int dev = 0;
   UIC_TRY(uic_check_hip(hipGetDevice(&dev), "hipGetDevice"));
   UIC_REQUIRE(dev >= 0 && dev < 16, "device index %d out of range", dev);
   SideStream& ss = g_side[dev];
+  std::lock_guard<std::mutex> lock(g_side_mutex);
   if (!ss.ready) {
     // A plain second stream at the lowest priority.  Measured alternatives: confining it to a subset of the CUs
     // (hipExtStreamCreateWithCUMask, 64..224 CUs) makes the whole step 2x SLOWER; the priority itself is neutral.
