@@ -139,19 +139,50 @@ class NMT_loss(nn.Module):
         self.generator = generator
         self.crit = crit
         self.batch_size = getattr(opt, 'batch_size', None)
-        self.total_stats = Statistics()
-        self.report_stats = Statistics()
+        self._total_stats = Statistics()
+        self._report_stats = Statistics()
+        self._pending = []
+
+    # The counters of a batch live on the device until somebody looks at the statistics: reading them inside forward()
+    # (the reference's loss.data[0], criterion.py:199-203) would stall the host between the forward and the backward
+    # enqueue of every step and leave the GPU idle meanwhile.
+    def _flush(self):
+        for loss_t, stats_t, reset in self._pending:
+            num_correct, num_words = [int(x) for x in stats_t.tolist()]            # one small D2H
+            stats = Statistics(float(loss_t), num_words, num_correct)
+            self._total_stats.update(stats)
+            self._report_stats.update(stats)
+            if reset:
+                self._total_stats = Statistics()
+                self._report_stats = Statistics()
+        self._pending = []
+
+    @property
+    def total_stats(self):
+        self._flush()
+        return self._total_stats
+
+    @total_stats.setter
+    def total_stats(self, v):
+        self._flush()
+        self._total_stats = v
+
+    @property
+    def report_stats(self):
+        self._flush()
+        return self._report_stats
+
+    @report_stats.setter
+    def report_stats(self, v):
+        self._flush()
+        self._report_stats = v
 
     def forward(self, loader, batch, outputs, attns):
         if not hasattr(outputs, 'uic_loss'):
             raise RuntimeError("NMT_loss needs the `outputs` tensor returned by the HIP NMTModel.forward (no eager fallback)")
         nmt_stats_reset = bool(loader is not None and loader.nmt_batchIdx > len(loader.nmt_trainData))
         loss_t = outputs.uic_loss
-        num_correct, num_words = [int(x) for x in outputs.uic_stats.tolist()]      # one small D2H, like loss_t.data[0]
-        stats = Statistics(float(loss_t.detach()), num_words, num_correct)
-        self.total_stats.update(stats)
-        self.report_stats.update(stats)
-        if nmt_stats_reset:
-            self.total_stats = Statistics()
-            self.report_stats = Statistics()
+        self._pending.append((loss_t.detach(), outputs.uic_stats, nmt_stats_reset))
+        if len(self._pending) > 64:          # nobody is reading: keep the backlog bounded
+            self._flush()
         return loss_t
