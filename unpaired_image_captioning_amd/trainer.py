@@ -291,11 +291,12 @@ class Trainer(object):
         self.optim.zero_grad()
         outputs, attn, dec_state, upper_bounds = self.dp_nmt_model(nmt_batch.src, nmt_batch.tgt, nmt_batch.lengths, None)
         nmt_loss = self.nmt_crit(loader, nmt_batch, outputs, attn)
+        nmt_loss.backward()
+        self.optim.step()
+        # the statistics are read AFTER the whole step is enqueued (one host sync per step, at its end)
         self.nmt_crit.report_stats.n_src_words += int(nmt_batch.lengths.sum())
         self.nmt_train_ppl = self.nmt_crit.report_stats.ppl()
         self.nmt_train_acc = self.nmt_crit.report_stats.accuracy()
-        nmt_loss.backward()
-        self.optim.step()
         return float(nmt_loss.detach())
 
     def save_models(self, tag=''):
