@@ -43,7 +43,6 @@ __global__ __launch_bounds__(NT) void beam_topk_kernel(const UicBeamParams p) {
   __shared__ float s_buf[NT / 64];
   __shared__ float s_val[NT];
   __shared__ int s_idx[NT];
-  __shared__ int s_taken[UIC_BEAM_MAX];
   const int row = blockIdx.x;
   const float* x = p.logits + (size_t)row * p.ldv;
   float mx = -INFINITY;
@@ -55,34 +54,66 @@ __global__ __launch_bounds__(NT) void beam_topk_kernel(const UicBeamParams p) {
   const float lse = mx + logf(sum);
   long banned = -1;
   if (p.decoding_constraint && p.t > 0 && !p.plain) banned = p.beam_seq[((size_t)(row / p.B) * p.L + (p.t - 1)) * p.B + (row % p.B)];
+  const int V1 = p.V1;
+  auto value = [&](int v) {
+    float lp = x[v] - lse;
+    if (v == banned) lp = -INFINITY;
+    if (v == V1 - 1 && !p.plain) lp -= 1000.f;
+    return lp;
+  };
+  // order of the result: value descending, lower index first on ties (what the reference's sort + enumeration uses)
+  auto better = [](float av, int ai, float bv_, int bi_) { return av > bv_ || (av == bv_ && ai < bi_); };
+  // Selection without B passes over the row: every thread keeps the best of ITS elements (v = tid, tid + NT, ...); each
+  // round the block picks the best of the 256 thread-bests, and only the wave of the thread that owned it rescans that
+  // thread's elements for its next-best (everything that sorts strictly after the one just taken).
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  float bv = -INFINITY;
+  int bi = 0x7fffffff;
+  for (int v = tid; v < V1; v += NT) {
+    const float lp = value(v);
+    if (better(lp, v, bv, bi)) { bv = lp; bi = v; }
+  }
+  float* s_wv = s_val;            // [NT / 64] per-wave winners
+  int* s_wi = s_idx;
   for (int k = 0; k < p.B; ++k) {
-    float bv = -INFINITY;
-    int bi = 0x7fffffff;
-    for (int v = threadIdx.x; v < p.V1; v += NT) {
-      bool taken = false;
-      for (int j = 0; j < k; ++j) taken |= (s_taken[j] == v);
-      if (taken) continue;
-      float lp = x[v] - lse;
-      if (v == banned) lp = -INFINITY;
-      if (v == p.V1 - 1 && !p.plain) lp -= 1000.f;
-      if (lp > bv || (lp == bv && v < bi)) { bv = lp; bi = v; }
+    float wv = bv;
+    int wi = bi;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      const float ov = __shfl_xor(wv, o, 64);
+      const int oi = __shfl_xor(wi, o, 64);
+      if (better(ov, oi, wv, wi)) { wv = ov; wi = oi; }
     }
-    s_val[threadIdx.x] = bv; s_idx[threadIdx.x] = bi;
+    __syncthreads();                                  // the previous round's readers are done with s_wv / s_wi
+    if (lane == 0) { s_wv[wave] = wv; s_wi[wave] = wi; }
     __syncthreads();
-    for (int o = NT / 2; o > 0; o >>= 1) {
-      if ((int)threadIdx.x < o) {
-        const float ov = s_val[threadIdx.x + o];
-        const int oi = s_idx[threadIdx.x + o];
-        if (ov > s_val[threadIdx.x] || (ov == s_val[threadIdx.x] && oi < s_idx[threadIdx.x])) { s_val[threadIdx.x] = ov; s_idx[threadIdx.x] = oi; }
+    float gv = s_wv[0];
+    int gi = s_wi[0];
+#pragma unroll
+    for (int w2 = 1; w2 < NT / 64; ++w2)
+      if (better(s_wv[w2], s_wi[w2], gv, gi)) { gv = s_wv[w2]; gi = s_wi[w2]; }
+    if (tid == 0) {
+      p.cand_val[(size_t)row * p.B + k] = gv;
+      p.cand_idx[(size_t)row * p.B + k] = gi;
+    }
+    if (gi == 0x7fffffff) continue;                   // nothing left (only possible when B exceeds the row length)
+    const int owner = gi % NT;
+    if (wave == (owner >> 6)) {
+      float nv = -INFINITY;
+      int ni = 0x7fffffff;
+      for (int v = owner + lane * NT; v < V1; v += 64 * NT) {
+        const float lp = value(v);
+        const bool after = lp < gv || (lp == gv && v > gi);          // sorts strictly after the element just taken
+        if (after && better(lp, v, nv, ni)) { nv = lp; ni = v; }
       }
-      __syncthreads();
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) {
+        const float ov = __shfl_xor(nv, o, 64);
+        const int oi = __shfl_xor(ni, o, 64);
+        if (better(ov, oi, nv, ni)) { nv = ov; ni = oi; }
+      }
+      if (tid == owner) { bv = nv; bi = ni; }
     }
-    if (threadIdx.x == 0) {
-      s_taken[k] = s_idx[0];
-      p.cand_val[(size_t)row * p.B + k] = s_val[0];
-      p.cand_idx[(size_t)row * p.B + k] = s_idx[0];
-    }
-    __syncthreads();
   }
 }
 

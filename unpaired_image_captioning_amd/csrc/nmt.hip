@@ -246,39 +246,62 @@ __global__ void nmt_beam_init_kernel(int B, int K, int64_t* tok, float* scores, 
 // Beam.advance for every sentence (O/Beam.py:52-89): top K of the flattened beam x word scores -- the candidates are the
 // per-row top K (cand_val / cand_idx from beam_topk), enumerated beam-major so that ties resolve to the lower flat index --
 // back-pointers, next tokens; a sentence is done once its TOP hypothesis ends in EOS; flags[0] = all sentences done.
-__global__ void nmt_beam_advance_kernel(int B, int K, int step, const float* __restrict__ cand_val, const int* __restrict__ cand_idx,
+__global__ __launch_bounds__(64) void nmt_beam_advance_kernel(int B, int K, int step, const float* __restrict__ cand_val, const int* __restrict__ cand_idx,
                                         float* __restrict__ scores, int* __restrict__ prev_ks, int64_t* __restrict__ next_ys, int64_t* __restrict__ tok,
                                         int* __restrict__ done, int* __restrict__ flags) {
-  const int b = blockIdx.x * blockDim.x + threadIdx.x;
-  if (b >= B) return;
-  const int rows = step == 0 ? 1 : K;
-  bool used[UIC_BEAM_MAX * UIC_BEAM_MAX];
-  for (int i = 0; i < rows * K; ++i) used[i] = false;
-  float ns[UIC_BEAM_MAX];
-  for (int j = 0; j < K; ++j) {
-    int best = -1;
-    float bp = 0.f;
-    long bflat = 0;
-    for (int k = 0; k < rows; ++k)
-      for (int c = 0; c < K; ++c) {
-        const int id = k * K + c;
-        if (used[id]) continue;
-        const size_t cr = ((size_t)b * K + k) * K + c;
-        const float pj = (step == 0 ? 0.f : scores[(size_t)b * K + k]) + cand_val[cr];
-        const long flat = (long)k * 0x40000000L + cand_idx[cr];
-        if (best < 0 || pj > bp || (pj == bp && flat < bflat)) { best = id; bp = pj; bflat = flat; }
-      }
-    used[best] = true;
-    const int k = best / K, c = best - k * K;
-    const int word = cand_idx[((size_t)b * K + k) * K + c];
-    ns[j] = bp;
-    prev_ks[((size_t)step * B + b) * K + j] = k;
-    next_ys[((size_t)step * B + b) * K + j] = word;
-    tok[(size_t)b * K + j] = word;
+  // one wavefront per sentence: the rows x K candidates sit 4 to a lane, K rounds of a wave-wide arg-max
+  constexpr int PER = (UIC_BEAM_MAX * UIC_BEAM_MAX + 63) / 64;
+  const int b = blockIdx.x, lane = threadIdx.x;
+  const int rows = step == 0 ? 1 : K, n = rows * K;
+  float pj[PER];
+  long flat[PER];
+  bool used[PER];
+#pragma unroll
+  for (int q = 0; q < PER; ++q) {
+    const int id = lane + q * 64;
+    used[q] = id >= n;
+    pj[q] = 0.f;
+    flat[q] = 0;
+    if (id < n) {
+      const int k = id / K;
+      const size_t cr = (size_t)b * K * K + id;          // = ((b * K + k) * K + c)
+      pj[q] = (step == 0 ? 0.f : scores[(size_t)b * K + k]) + cand_val[cr];
+      flat[q] = (long)k * 0x40000000L + cand_idx[cr];
+    }
   }
-  for (int j = 0; j < K; ++j) scores[(size_t)b * K + j] = ns[j];
-  if (next_ys[((size_t)step * B + b) * K] == 3) done[b] = 1;
-  if (!done[b]) atomicAdd(&flags[1], 1);       // flags[1]: active sentences of this step (zeroed by the host loop's memset)
+  __syncthreads();                                        // every lane has read the old scores before lane 0 overwrites them
+  int first_word = -1;
+  for (int j = 0; j < K; ++j) {
+    float bp = 0.f;
+    long bflat = 0x7fffffffffffffffL;
+    int bid = -1;
+#pragma unroll
+    for (int q = 0; q < PER; ++q)
+      if (!used[q] && (bid < 0 || pj[q] > bp || (pj[q] == bp && flat[q] < bflat))) { bp = pj[q]; bflat = flat[q]; bid = lane + q * 64; }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      const float op = __shfl_xor(bp, o, 64);
+      const long of = __shfl_xor(bflat, o, 64);
+      const int oi = __shfl_xor(bid, o, 64);
+      if (oi >= 0 && (bid < 0 || op > bp || (op == bp && of < bflat))) { bp = op; bflat = of; bid = oi; }
+    }
+#pragma unroll
+    for (int q = 0; q < PER; ++q)
+      if (bid == lane + q * 64) used[q] = true;
+    const int k = bid / K;
+    const int word = (int)(bflat - (long)k * 0x40000000L);
+    if (j == 0) first_word = word;
+    if (lane == 0) {
+      prev_ks[((size_t)step * B + b) * K + j] = k;
+      next_ys[((size_t)step * B + b) * K + j] = word;
+      tok[(size_t)b * K + j] = word;
+      scores[(size_t)b * K + j] = bp;
+    }
+  }
+  if (lane == 0) {
+    if (first_word == 3) done[b] = 1;
+    if (!done[b]) atomicAdd(&flags[1], 1);       // flags[1]: active sentences of this step (zeroed by the host loop's memset)
+  }
 }
 // read-out (translateBatch :384-392, Beam.getHyp :93-117): best final score (first maximum), walk the back-pointers; the
 // attention of hypothesis position j is the one of the PARENT beam at step j, PAD source columns dropped (packed left)
@@ -1071,7 +1094,7 @@ int uic_nmt_translate(const uic_nmt_dims* d, const uic_nmt_weights* w, const int
     bp.t = step;
     UIC_TRY(uic_beam_topk_launch(bp, s));
     UIC_TRY(uic_fill_launch(T.flags + 1, 0, 4, s));
-    hipLaunchKernelGGL(nmt_beam_advance_kernel, dim3((B + 63) / 64), dim3(64), 0, s, B, K, step, T.cand_val, T.cand_idx, T.scores,
+    hipLaunchKernelGGL(nmt_beam_advance_kernel, dim3(B), dim3(64), 0, s, B, K, step, T.cand_val, T.cand_idx, T.scores,
                        T.prev_ks, T.next_ys, T.tok, T.done, T.flags);
     UIC_LAUNCH_CHECK("nmt_beam_advance_kernel");
     // decStates.beamUpdate_ (:376): re-thread every state tensor of every sentence to the surviving parents
