@@ -540,13 +540,25 @@ __global__ void copy_tokens_kernel(const int64_t* __restrict__ src, int ld_src, 
 // (P/models/AttModel.py:216-251): log_softmax, optional decoding constraint, greedy max (lowest index on
 // ties) or multinomial draw, finished-row bookkeeping.  The reference's host-side early break
 // (`unfinished.sum() == 0`) becomes a device counter per step, so no host sync is needed.
+// STAGED: the logits row is copied into LDS once (16-byte loads) and every pass below reads it from there; rows too long
+// for 64 KB of LDS are read from memory by each pass.  Same arithmetic in the same order either way.
+template <bool STAGED>
 __global__ __launch_bounds__(NT) void sample_step_kernel(const UicSampleParams p) {
   __shared__ float s_buf[NT / 64];
   __shared__ float s_val[NT];
   __shared__ int s_idx[NT];
+  extern __shared__ __attribute__((aligned(16))) float s_row[];
   const int n = blockIdx.x;
   const int t = p.t;
-  const float* row = (const float*)p.logits + (size_t)n * p.ldv;
+  const float* grow = (const float*)p.logits + (size_t)n * p.ldv;
+  const float* row = grow;
+  if constexpr (STAGED) {
+    const int n4 = p.V1 >> 2;
+    for (int i = threadIdx.x; i < n4; i += NT) *(float4*)(s_row + 4 * i) = *(const float4*)(grow + 4 * i);
+    for (int v = (n4 << 2) + threadIdx.x; v < p.V1; v += NT) s_row[v] = grow[v];
+    __syncthreads();
+    row = s_row;
+  }
   const bool dead = !p.fc_mode && t > 0 && p.n_unfinished[t - 1] == 0;   // every row had finished: the reference broke out
   long banned = -1;
   const int ldo = p.ld_out > 0 ? p.ld_out : p.L;
@@ -862,7 +874,10 @@ int uic_sample_step_launch(const UicSampleParams& p, hipStream_t s) {
   UIC_REQUIRE(p.logits && p.seq && p.seq_logp && p.it && p.unfinished && p.n_unfinished, "sample_step: null pointer");
   UIC_REQUIRE(p.t >= 0 && p.t < p.L, "sample_step: t=%d outside [0,%d)", p.t, p.L);
   if (p.N == 0) return UIC_OK;
-  hipLaunchKernelGGL(sample_step_kernel, dim3(p.N), dim3(NT), 0, s, p);
+  const size_t row_bytes = ((size_t)p.V1 * 4 + 15) & ~(size_t)15;
+  const bool staged = row_bytes <= 60 * 1024 && p.ldv % 4 == 0 && ((uintptr_t)p.logits & 15) == 0;
+  if (staged) hipLaunchKernelGGL(sample_step_kernel<true>, dim3(p.N), dim3(NT), row_bytes, s, p);
+  else hipLaunchKernelGGL(sample_step_kernel<false>, dim3(p.N), dim3(NT), 0, s, p);
   UIC_LAUNCH_CHECK("sample_step");
   return UIC_OK;
 }
