@@ -178,6 +178,27 @@ def test_nmt_mid_size_vs_oracle(dtype):
     grads_close({k: p.grad for k, p in model.named_parameters()}, ref_g, GRAD_TOL[dtype])
 
 
+def test_nmt_large_vocabulary_criterion_bf16_vs_oracle():
+    """A 20 003-word target vocabulary (80 KB logits rows: past the LDS-staged criterion kernel, onto the two-pass
+    running-max kernel that also feeds NMT_loss.score's counters): loss, accuracy counters and gradients against the
+    oracle; a generator bias makes some arg-maxes hit their targets."""
+    cfg = dict(layers=1, H=64, W=64, B=6, S=7, T=6, Vs=50, Vt=20003)
+    W = random_weights(cfg, 31)
+    I = synthetic(cfg, 9)
+    tgt = I["tgt"]
+    W["generator.0.bias"][int(tgt[1, 0])] += 4.0                      # the first target of sentence 0 becomes the arg-max ...
+    W["generator.0.bias"][20002] += 2.0                               # ... and the last vocabulary index a frequent runner-up
+    ref_loss, ref_g, aux = ON.loss_and_grads(W, I["src"], I["tgt"], I["lengths"])
+    model, crit = build(cfg, W, "bf16")
+    model.train()
+    outputs, attn, loss = run(model, crit, I)
+    assert abs(loss.item() - ref_loss.item()) < OUT_TOL["bf16"] * aux["num_words"]
+    st = crit.report_stats
+    assert st.n_words == aux["num_words"] and abs(st.n_correct - aux["num_correct"]) <= 1 and aux["num_correct"] >= 1
+    loss.backward()
+    grads_close({k: p.grad for k, p in model.named_parameters()}, ref_g, GRAD_TOL["bf16"])
+
+
 def export_masks(cfg, seed, p):
     """The multiplicative masks the kernels use, in the oracle's `drop` layout."""
     from unpaired_image_captioning_amd import _lib as L

@@ -190,37 +190,7 @@ __global__ void tanh_drop_bwd_kernel(const float* d_out, const float* d_feed, co
   d_pre[i] = uic_from_f<T>(g * (1.f - o * o));
 }
 
-// NMT_loss.score (criterion.py:175-179): correct = argmax(scores) == target over non-PAD targets
-__global__ __launch_bounds__(NT) void nmt_score_kernel(const float* logits, int V, int ldv, const int64_t* target_bt, int B,
-                                                       int Td, int* stats) {
-  __shared__ float s_val[NT];
-  __shared__ int s_idx[NT];
-  const int m = blockIdx.x;                  // row = t*B + b
-  const int t = m / B, b = m - t * B;
-  const long y = target_bt[(size_t)b * Td + t];
-  const float* row = logits + (size_t)m * ldv;
-  float bv = -INFINITY;
-  int bi = 0x7fffffff;
-  for (int v = (int)threadIdx.x; v < V; v += NT) {
-    const float x = row[v];
-    if (x > bv || (x == bv && v < bi)) { bv = x; bi = v; }
-  }
-  s_val[threadIdx.x] = bv; s_idx[threadIdx.x] = bi;
-  __syncthreads();
-  for (int o = NT / 2; o > 0; o >>= 1) {
-    if ((int)threadIdx.x < o) {
-      const float ov = s_val[threadIdx.x + o];
-      const int oi = s_idx[threadIdx.x + o];
-      if (ov > s_val[threadIdx.x] || (ov == s_val[threadIdx.x] && oi < s_idx[threadIdx.x])) { s_val[threadIdx.x] = ov; s_idx[threadIdx.x] = oi; }
-    }
-    __syncthreads();
-  }
-  if (threadIdx.x == 0 && y != 0) {
-    atomicAdd(&stats[1], 1);
-    if (s_idx[0] == (int)y) atomicAdd(&stats[0], 1);
-  }
-}
-
+// (NMT_loss.score's counters, criterion.py:175-179, are computed by the criterion kernel: UicXeParams.score_stats)
 __global__ void fill_f32_kernel(float* p, float v, int n) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) p[i] = v;
@@ -703,12 +673,13 @@ struct Nmt {
     x.target = L.target_bt; x.ldtarget = Td; x.target_col0 = 0;
     x.mask = L.mask_bt; x.ldmask = Td; x.mask_col0 = 0;             // weight[PAD] = 0
     x.inv_den = L.scalars; x.row_loss = L.row_loss; x.write_grad = 1;
+    if (stats_out) {       // NMT_loss.score's counters ride on the criterion kernel's pass over the logits
+      UIC_TRY(uic_fill_launch(L.stats, 0, 8, s));
+      x.score_stats = L.stats;
+    }
     UIC_TRY(uic_xe_launch(x, s));
     UIC_TRY(uic_reduce_sum_launch(L.row_loss, (size_t)Td * B, 0.f, nullptr, loss_out, s));
     if (stats_out) {
-      UIC_TRY(uic_fill_launch(L.stats, 0, 8, s));
-      hipLaunchKernelGGL(nmt_score_kernel, dim3(Td * B), dim3(NT), 0, s, L.logits, Vt, Vtp, L.target_bt, B, Td, L.stats);
-      UIC_LAUNCH_CHECK("nmt_score_kernel");
       UIC_TRY(uic_check_hip(hipMemcpyAsync(stats_out, L.stats, 8, hipMemcpyDeviceToDevice, s), "memcpy stats"));
     }
     return UIC_OK;

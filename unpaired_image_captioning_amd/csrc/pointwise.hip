@@ -320,6 +320,29 @@ __device__ __forceinline__ float block_reduce_sum(float v, float* s_buf) {
   return r;
 }
 
+// arg-max of a row (lowest index on ties) for the accuracy counters of NMT_loss.score; `src` may be LDS or global
+__device__ __forceinline__ int block_argmax(const float* src, int V1, int* s_bi, float* s_bv) {
+  float bv = -INFINITY;
+  int bi = 0x7fffffff;
+  for (int v = threadIdx.x; v < V1; v += NT) {
+    const float x = src[v];
+    if (x > bv || (x == bv && v < bi)) { bv = x; bi = v; }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const float ov = __shfl_xor(bv, o, 64);
+    const int oi = __shfl_xor(bi, o, 64);
+    if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+  }
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) { s_bv[threadIdx.x >> 6] = bv; s_bi[threadIdx.x >> 6] = bi; }
+  __syncthreads();
+  bv = s_bv[0]; bi = s_bi[0];
+  for (int w2 = 1; w2 < NT / 64; ++w2)
+    if (s_bv[w2] > bv || (s_bv[w2] == bv && s_bi[w2] < bi)) { bv = s_bv[w2]; bi = s_bi[w2]; }
+  return bi;
+}
+
 // One block per (t, n) row of logits: log_softmax (AttModel.py:163) fused with the masked NLL
 // and its gradient (criterion.py:143-150): d logits = (softmax - onehot) * mask / sum(mask).
 template <typename T>
@@ -340,6 +363,15 @@ __global__ __launch_bounds__(NT) void xe_kernel(const UicXeParams p, const float
   if (p.target) {
     y = p.target[(size_t)n * p.ldtarget + p.target_col0 + t];
     mk = p.mask ? p.mask[(size_t)n * p.ldmask + p.mask_col0 + t] : 0.f;
+    if (p.score_stats) {
+      __shared__ float s_bv[NT / 64];
+      __shared__ int s_bi[NT / 64];
+      const int am = block_argmax(row, p.V1, s_bi, s_bv);
+      if (threadIdx.x == 0 && y != 0) {
+        atomicAdd(&p.score_stats[1], 1);
+        if (am == (int)y) atomicAdd(&p.score_stats[0], 1);
+      }
+    }
     if (y < 0 || y >= p.V1) y = 0;
     if (threadIdx.x == 0) p.row_loss[m] = -(row[y] - lse) * mk;
   }
@@ -354,6 +386,84 @@ __global__ __launch_bounds__(NT) void xe_kernel(const UicXeParams p, const float
       float g = 0.f;
       if (v < p.V1) g = (expf(row[v] - lse) - (v == y ? 1.f : 0.f)) * sc;
       d[v] = uic_from_f<T>(g);
+    }
+  }
+}
+
+// Rows too long for LDS (the 50 004-word NMT generator: 200 KB per row): TWO passes over the row instead of three --
+// pass 1 keeps a running (max, sum of exp) per thread (rescaled when the max moves) together with the arg-max, pass 2
+// writes the gradient -- with 16-byte loads.  The arg-max feeds the accuracy counters of NMT_loss.score
+// (criterion.py:175-184), which otherwise cost a third pass of their own.
+template <typename T>
+__global__ __launch_bounds__(NT) void xe_big_kernel(const UicXeParams p, const float* __restrict__ logits, T* __restrict__ dlogits) {
+  __shared__ float s_m[NT / 64], s_s[NT / 64], s_bv[NT / 64];
+  __shared__ int s_bi[NT / 64];
+  const int m = blockIdx.x;
+  const int t = m / p.N, n = m - t * p.N;
+  const float* row = logits + (size_t)m * p.ldv;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  float mx = -INFINITY, sum = 0.f, bv = -INFINITY;
+  int bi = 0x7fffffff;
+  auto take = [&](float x, int v) {
+    if (x > bv || (x == bv && v < bi)) { bv = x; bi = v; }
+    if (x > mx) { sum = sum * __expf(mx - x) + 1.f; mx = x; }
+    else if (mx != -INFINITY) sum += __expf(x - mx);          // (x = mx = -inf contributes nothing)
+  };
+  for (int v = threadIdx.x * 4; v < p.V1; v += NT * 4) {
+    const float4 x = *(const float4*)(row + v);            // ldv is a multiple of 4 and >= V1: in bounds
+    take(x.x, v);
+    if (v + 1 < p.V1) take(x.y, v + 1);
+    if (v + 2 < p.V1) take(x.z, v + 2);
+    if (v + 3 < p.V1) take(x.w, v + 3);
+  }
+  auto merge = [&](float om, float os, float ov, int oi) {
+    if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+    const float nm = fmaxf(mx, om);
+    if (nm != -INFINITY) sum = sum * __expf(mx - nm) + os * __expf(om - nm);
+    mx = nm;
+  };
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1)
+    merge(__shfl_xor(mx, o, 64), __shfl_xor(sum, o, 64), __shfl_xor(bv, o, 64), __shfl_xor(bi, o, 64));
+  if (lane == 0) { s_m[wave] = mx; s_s[wave] = sum; s_bv[wave] = bv; s_bi[wave] = bi; }
+  __syncthreads();
+  mx = s_m[0]; sum = s_s[0]; bv = s_bv[0]; bi = s_bi[0];
+#pragma unroll
+  for (int w2 = 1; w2 < NT / 64; ++w2) merge(s_m[w2], s_s[w2], s_bv[w2], s_bi[w2]);
+  const float lse = mx + logf(sum);
+  long y = 0;
+  float mk = 0.f;
+  if (p.target) {
+    y = p.target[(size_t)n * p.ldtarget + p.target_col0 + t];
+    mk = p.mask ? p.mask[(size_t)n * p.ldmask + p.mask_col0 + t] : 0.f;
+    if (threadIdx.x == 0 && p.score_stats && y != 0) {
+      atomicAdd(&p.score_stats[1], 1);
+      if (bi == (int)y) atomicAdd(&p.score_stats[0], 1);
+    }
+    if (y < 0 || y >= p.V1) y = 0;
+    if (threadIdx.x == 0) p.row_loss[m] = -(row[y] - lse) * mk;
+  }
+  if (p.logprobs) {
+    float* lp = p.logprobs + (size_t)n * p.lp_row_stride + (size_t)t * p.lp_step_stride;
+    for (int v = threadIdx.x; v < p.V1; v += NT) lp[v] = row[v] - lse;
+  }
+  if (p.write_grad) {
+    const float sc = p.grad_scale ? p.grad_scale[(size_t)n * p.ldscale + p.scale_col0 + t] : mk * p.inv_den[0];
+    T* d = dlogits + (size_t)m * p.ldv;
+    for (int v = threadIdx.x * 4; v < p.ldv; v += NT * 4) {
+      const float4 x = *(const float4*)(row + v);
+      const float xs[4] = {x.x, x.y, x.z, x.w};
+      float g[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int vv = v + j;
+        g[j] = vv < p.V1 ? (__expf(xs[j] - lse) - (vv == y ? 1.f : 0.f)) * sc : 0.f;
+      }
+      if constexpr (sizeof(T) == 2) {
+        *(uint2*)(d + v) = make_uint2(uic_pack_bf16x2(g[0], g[1]), uic_pack_bf16x2(g[2], g[3]));
+      } else {
+        *(float4*)(d + v) = make_float4(g[0], g[1], g[2], g[3]);
+      }
     }
   }
 }
@@ -386,6 +496,15 @@ __global__ __launch_bounds__(NT) void xe_lds_kernel(const UicXeParams p, const f
   if (p.target) {
     y = p.target[(size_t)n * p.ldtarget + p.target_col0 + t];
     mk = p.mask ? p.mask[(size_t)n * p.ldmask + p.mask_col0 + t] : 0.f;
+    if (p.score_stats) {
+      __shared__ float s_bv[NT / 64];
+      __shared__ int s_bi[NT / 64];
+      const int am = block_argmax(s_row, p.V1, s_bi, s_bv);
+      if (threadIdx.x == 0 && y != 0) {
+        atomicAdd(&p.score_stats[1], 1);
+        if (am == (int)y) atomicAdd(&p.score_stats[0], 1);
+      }
+    }
     if (y < 0 || y >= p.V1) y = 0;
     if (threadIdx.x == 0) p.row_loss[m] = -(s_row[y] - lse) * mk;
   }
@@ -811,6 +930,11 @@ int uic_xe_launch(const UicXeParams& p, hipStream_t s) {
     // bf16 path: LDS-staged row + hardware exp (the f32 parity path keeps libm exp)
     hipLaunchKernelGGL(xe_lds_kernel<bf16_t>, dim3(p.M), dim3(NT), row_bytes, s, p, p.logits, (bf16_t*)p.dlogits);
     UIC_LAUNCH_CHECK("xe_lds_kernel");
+    return UIC_OK;
+  }
+  if (p.dtype == UIC_BF16 && p.ldv % 4 == 0 && ((uintptr_t)p.logits & 15) == 0 && (!p.dlogits || ((uintptr_t)p.dlogits & 7) == 0)) {
+    hipLaunchKernelGGL(xe_big_kernel<bf16_t>, dim3(p.M), dim3(NT), 0, s, p, p.logits, (bf16_t*)p.dlogits);
+    UIC_LAUNCH_CHECK("xe_big_kernel");
     return UIC_OK;
   }
   DISPATCH_T(p.dtype, hipLaunchKernelGGL(xe_kernel<bf16_t>, dim3(p.M), dim3(NT), 0, s, p, p.logits, (bf16_t*)p.dlogits),

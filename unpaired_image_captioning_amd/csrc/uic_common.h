@@ -317,6 +317,7 @@ struct UicXeParams {
   float* row_loss;               // [M]
   float* logprobs; size_t lp_step_stride, lp_row_stride;  // optional full log-probs out [n][t][v]
   int write_grad;
+  int* score_stats;              // optional: [0] += rows whose arg-max (lowest index on ties) is the target, [1] += rows with target != 0
 };
 int uic_xe_launch(const UicXeParams& p, hipStream_t s);
 // general log-softmax backward given dense upstream grad g [N,T,V1] (API-compat path):
