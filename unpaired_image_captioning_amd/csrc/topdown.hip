@@ -137,7 +137,8 @@ Layout make_layout(const uic_topdown_dims& d, void* ws) {
     size_t rb = 2 * H + E;                      // att_lstm inputs [h_lang | xt | h_att]; lang_lstm inputs are 3H wide
     if (3 * H > rb) rb = 3 * H;
     if (Dfc > rb) rb = Dfc;
-    L.tSA = b.take(4 * H * Kc * S);
+    const size_t la = 4 * H > A ? 4 * H : A;    // left operands: dG [rows, 4H] of the LSTMs, d att_h [rows, A] of h2att
+    L.tSA = b.take(la * Kc * S);
     L.tSB = b.take(rb * Kc * S);
   }
   {  // split-K partial slabs: room for 4 slices of the largest merged weight gradient [4H, 2H + E]
