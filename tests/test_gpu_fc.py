@@ -151,3 +151,42 @@ def test_fc_beam_search_bit_exact_vs_reference_golden(name):
         assert absmax(lp_d, torch.as_tensor(X["beamd::%s_logp" % tag])) < 1e-3
         assert torch.equal(seq_p.cpu(), torch.as_tensor(X["beam::%s_seq" % tag])), tag
         assert absmax(lp_p, torch.as_tensor(X["beam::%s_logp" % tag])) < 1e-3
+
+
+def _fc_sweep(n, seed):
+    import numpy as np
+    g = np.random.default_rng(seed)
+    return [dict(V=int(g.integers(5, 500)), E=int(g.integers(1, 24)) * 8, H=int(g.integers(1, 24)) * 8, D=int(g.integers(1, 40)) * 8,
+                 L=int(g.integers(1, 21)), n_img=int(g.integers(1, 12)), S=int(g.integers(1, 6)), drop=bool(g.integers(0, 2)), idx=i)
+            for i in range(n)]
+
+
+@pytest.mark.parametrize("cfg", _fc_sweep(24, 5), ids=lambda c: "fc%d" % c["idx"])
+def test_fc_random_shape_sweep_vs_oracle(cfg):
+    """24 seeded random FC-model configurations (f32): log-probs and every gradient against the oracle, with the kernels'
+    own dropout masks when dropout is on."""
+    from unpaired_image_captioning_amd import _lib as L
+    from unpaired_image_captioning_amd.misc.criterion import LanguageModelCriterion
+    W = OF.init_weights(cfg["V"] + 1, cfg["E"], cfg["H"], cfg["D"], seed=cfg["idx"])
+    b = O.synthetic_batch(cfg["n_img"], cfg["S"], 2, cfg["D"], cfg["V"], cfg["L"], seed=50 + cfg["idx"])
+    p = 0.5 if cfg["drop"] else 0.0
+    model = build(cfg, W, "f32", drop=p)
+    model.train()
+    fc, labels, masks = b["fc_feats"].cuda(), b["labels"].cuda(), b["masks"].cuda()
+    logp = model(fc, None, None, labels, None)
+    seed = model._seed_counter
+    loss = LanguageModelCriterion()(logp, labels[:, 1:], masks[:, 1:])
+    loss.backward()
+    drop = None
+    if p:
+        lib = L.load()
+        N, H, S = fc.shape[0], cfg["H"], labels.shape[1]
+
+        def mask(t):
+            out = torch.empty(N * H, device="cuda")
+            L.check(lib.uic_dropout_mask(L.ptr(out), N * H, p, seed, L.SITE_OUT0 + t, 0, L.stream()))
+            return out.cpu().view(N, H)
+        drop = {"out": torch.stack([mask(t) for t in range(S)])}
+    loss_o, grads_o, logp_o = OF.xe_loss_and_grads(W, b["fc_feats"], b["labels"], b["masks"], drop)
+    assert absmax(logp, logp_o) < LOGP_TOL["f32"]
+    grads_close({k: q.grad for k, q in model.named_parameters()}, grads_o, 5e-3)

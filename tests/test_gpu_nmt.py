@@ -178,6 +178,34 @@ def test_nmt_mid_size_vs_oracle(dtype):
     grads_close({k: p.grad for k, p in model.named_parameters()}, ref_g, GRAD_TOL[dtype])
 
 
+def _nmt_sweep(n, seed):
+    g = np.random.default_rng(seed)
+    out = []
+    for i in range(n):
+        H = int(g.integers(1, 12)) * 16                       # rnn_size (even halves per direction, multiples of 8)
+        out.append(dict(layers=int(g.integers(1, 4)), H=H, W=int(g.integers(1, 12)) * 8, B=int(g.integers(1, 20)),
+                        S=int(g.integers(1, 16)), T=int(g.integers(3, 14)), Vs=int(g.integers(8, 300)), Vt=int(g.integers(8, 300)), idx=i))
+    return out
+
+
+@pytest.mark.parametrize("cfg", _nmt_sweep(24, 77), ids=lambda c: "nmt%d" % c["idx"])
+def test_nmt_random_shape_sweep_vs_oracle(cfg):
+    """24 seeded random NMT configurations (1-3 layers, odd batch sizes and lengths incl. one-word sources, hidden sizes
+    that are multiples of 16 only): f32 forward, loss, counters and every gradient against the oracle."""
+    W = random_weights(cfg, 100 + cfg["idx"])
+    I = synthetic(cfg, 200 + cfg["idx"])
+    ref_loss, ref_g, aux = ON.loss_and_grads(W, I["src"], I["tgt"], I["lengths"])
+    model, crit = build(cfg, W, "f32")
+    model.train()
+    outputs, attn, loss = run(model, crit, I)
+    assert absmax(outputs, aux["outputs"]) < OUT_TOL["f32"]
+    assert absmax(attn, aux["attn"]) < OUT_TOL["f32"]
+    assert abs(loss.item() - ref_loss.item()) < OUT_TOL["f32"] * max(1, aux["num_words"])
+    assert crit.report_stats.n_words == aux["num_words"] and crit.report_stats.n_correct == aux["num_correct"]
+    loss.backward()
+    grads_close({k: p.grad for k, p in model.named_parameters()}, ref_g, 5e-3)
+
+
 def test_nmt_large_vocabulary_criterion_bf16_vs_oracle():
     """A 20 003-word target vocabulary (80 KB logits rows: past the LDS-staged criterion kernel, onto the two-pass
     running-max kernel that also feeds NMT_loss.score's counters): loss, accuracy counters and gradients against the
