@@ -828,6 +828,35 @@ def test_random_shape_sweep_vs_oracle(cfg):
     grads_close(grads, {k: grads_o[k] for k in grads}, 5e-3)
 
 
+def _sweep_configs_bf16(n, seed):
+    g = np.random.default_rng(seed)
+    pick = lambda xs: int(xs[int(g.integers(0, len(xs)))])       # noqa: E731
+    return [dict(V=int(g.integers(100, 3000)), E=pick([64, 72, 128, 256]), H=pick([64, 128, 136, 256]), A=pick([40, 64, 128, 256, 520]),
+                 D=pick([120, 128, 256, 512]), L=int(g.integers(4, 17)), n_img=int(g.integers(4, 41)), S=int(g.integers(1, 6)),
+                 R=int(g.integers(4, 37)), use_bn=int(g.integers(0, 3)), per_image=bool(g.integers(0, 2)), idx=i) for i in range(n)]
+
+
+@pytest.mark.parametrize("cfg", _sweep_configs_bf16(24, 31), ids=lambda c: "bf%d" % c["idx"])
+def test_random_shape_sweep_bf16_vs_oracle(cfg):
+    """24 seeded random mid-size configurations in bf16 -- sizes on and off the eligibility boundaries of the LDS-DMA and
+    transposing-read GEMMs (multiples of 128 / 64 and not), att_hid_size above 4 * rnn_size, up to 200 caption rows --
+    the fused training step (dropout off) against the f32 oracle at the bf16 tolerances."""
+    from unpaired_image_captioning_amd import models
+    from unpaired_image_captioning_amd.trainer import xe_step
+    torch.manual_seed(300 + cfg["idx"])
+    model = models.setup(make_opt(cfg, "bf16", seed=cfg["idx"]))
+    W = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    model.cuda().train()
+    b = O.synthetic_batch(cfg["n_img"], cfg["S"], cfg["R"], cfg["D"], cfg["V"], cfg["L"], seed=cfg["idx"], ragged_regions=True)
+    full = {k: v.cuda() for k, v in b.items()}
+    batch = _per_image(full, cfg["S"]) if cfg["per_image"] and cfg["S"] > 1 else full
+    loss, grads = xe_step(model, batch)
+    loss_o, grads_o, _ = O.xe_loss_and_grads(W, b["fc_feats"], b["att_feats"], b["labels"], b["masks"], b["att_masks"], None,
+                                             use_bn=cfg["use_bn"], training=True)
+    assert abs(loss.item() - loss_o.item()) < LOGP_TOL["bf16"], (cfg, loss.item(), loss_o.item())
+    grads_close(grads, {k: grads_o[k] for k in grads}, 0.15 if cfg["use_bn"] else GRAD_TOL["bf16"])
+
+
 # ---------------------------------------------------------------- features once per image (dims.seq_per_img > 1)
 def _per_image(batch, S):
     out = dict(batch)
