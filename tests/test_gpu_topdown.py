@@ -857,6 +857,60 @@ def test_random_shape_sweep_bf16_vs_oracle(cfg):
     grads_close(grads, {k: grads_o[k] for k in grads}, 0.15 if cfg["use_bn"] else GRAD_TOL["bf16"])
 
 
+@pytest.mark.parametrize("cfg", _sweep_configs(16, 555), ids=lambda c: "dec%d" % c["idx"])
+def test_decode_paths_random_sweep_vs_oracle(cfg):
+    """16 seeded random configurations through the decoders (f32, eval mode): multinomial sampling (the device's draws
+    replayed by the oracle: same finished-row bookkeeping, same log-probs), greedy (every chosen token is the oracle's
+    arg-max up to f32 noise) and beam search (final beam scored by the oracle)."""
+    from unpaired_image_captioning_amd import models
+    torch.manual_seed(500 + cfg["idx"])
+    cfg = dict(cfg, V=max(cfg["V"], 8))
+    model = models.setup(make_opt(cfg, "f32", seed=cfg["idx"]))
+    gw = torch.Generator().manual_seed(cfg["idx"])
+    for k, v in model.state_dict().items():
+        if "running_var" in k:
+            v.copy_(0.5 + torch.rand(v.shape, generator=gw))
+        elif "running_mean" in k:
+            v.copy_(0.1 * torch.randn(v.shape, generator=gw))
+    with torch.no_grad():
+        model.logit.bias[0] += 1.5                           # some captions end early
+    W = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    model.cuda().eval()
+    b = O.synthetic_batch(cfg["n_img"], 1, cfg["R"], cfg["D"], cfg["V"], cfg["L"], seed=cfg["idx"], ragged_regions=cfg["R"] > 1)
+    fc, att, am = b["fc_feats"].cuda(), b["att_feats"].cuda(), b["att_masks"].cuda()
+    ub = cfg["use_bn"]
+    dc = cfg["idx"] % 2
+    seq, lp = model(fc, None, att, am, opt={"sample_max": 0, "temperature": 1.0, "decoding_constraint": dc}, mode="sample")
+    seq_o, lp_o = O.sample(W, b["fc_feats"], b["att_feats"], b["att_masks"], cfg["L"], sample_max=0, forced_tokens=seq.cpu(),
+                           decoding_constraint=dc, use_bn=ub)
+    # positions after a row's first 0 hold the log-prob of whatever was drawn there (AttModel.py:232-251 keeps sampling
+    # for finished rows and stores token 0); the replay only knows the stored 0, so compare up to the first 0 -- the
+    # positions RewardCriterion's mask keeps (criterion.py:113-116)
+    live = torch.cat([torch.ones_like(seq[:, :1]), (seq[:, :-1] > 0).long().cumprod(1)], 1).bool().cpu()
+    assert torch.equal(seq_o, seq.cpu()) and absmax(lp.cpu()[live], lp_o[live]) < 1e-3
+    gseq, glp = model(fc, None, att, am, opt={"sample_max": 1, "decoding_constraint": dc}, mode="sample")
+    gseq_o, glp_o = O.sample(W, b["fc_feats"], b["att_feats"], b["att_masks"], cfg["L"], sample_max=1, decoding_constraint=dc, use_bn=ub)
+    same = (gseq.cpu() == gseq_o).all(1)
+    assert same.float().mean().item() >= 0.6                  # untrained weights: near-ties may resolve differently
+    assert absmax(glp[same.cuda()], glp_o[same]) < 1e-3
+    # rows that differ: the device's tokens, replayed by the oracle, must score within f32 noise of the oracle's own choice
+    if (~same).any():
+        r_seq, r_lp = O.sample(W, b["fc_feats"], b["att_feats"], b["att_masks"], cfg["L"], sample_max=0, forced_tokens=gseq.cpu(),
+                               decoding_constraint=dc, use_bn=ub)
+        first = (gseq.cpu() != gseq_o).float().argmax(1)
+        for n in (~same).nonzero().view(-1).tolist():
+            t = int(first[n])
+            assert abs(float(r_lp[n, t]) - float(glp_o[n, t])) < 1e-4, (n, t)
+    K = 2 + cfg["idx"] % 3
+    if K <= cfg["V"]:
+        bseq, blp = model(fc, None, att, am, opt={"beam_size": K, "decoding_constraint": dc}, mode="sample")
+        bseq_o, blp_o = O.sample_beam(W, b["fc_feats"], b["att_feats"], b["att_masks"], cfg["L"], K, dc, 0, use_bn=ub)
+        sameb = (bseq.cpu() == bseq_o).all(1)
+        assert sameb.float().mean().item() >= 0.6
+        assert absmax(blp[sameb.cuda()], blp_o[sameb]) < 1e-3
+        assert (blp.cpu().sum(1) - blp_o.sum(1)).abs().max().item() < 5e-3      # beams that differ tie in score
+
+
 # ---------------------------------------------------------------- features once per image (dims.seq_per_img > 1)
 def _per_image(batch, S):
     out = dict(batch)
