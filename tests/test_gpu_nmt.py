@@ -387,3 +387,23 @@ def test_nmt_translate_bf16_mid_size_vs_oracle():
     got = torch.stack([s_[0] for s_ in allScores]).cpu()
     assert (got - scores_o).abs().max().item() < 0.15 * max(1.0, scores_o.abs().max().item()), (got, scores_o)
     assert n_same >= cfg["B"] // 2, n_same
+
+
+@pytest.mark.parametrize("cfg", _nmt_sweep(10, 4242), ids=lambda c: "tr%d" % c["idx"])
+def test_nmt_translate_random_sweep_vs_oracle(cfg):
+    """10 seeded random configurations through translateBatch (beam 15, f32): the oracle's hypotheses token for token for
+    most sentences (random weights produce near-tied candidates that may swap) and its final scores for all of them."""
+    cfg = dict(cfg, Vt=max(cfg["Vt"], 20), T=2)
+    W = random_weights(cfg, 300 + cfg["idx"], scale=0.3)
+    W["generator.0.bias"][3] += 2.5                                   # EOS likely enough for sentences to end at varied steps
+    I = synthetic(dict(cfg, T=6), 400 + cfg["idx"])
+    model, _ = build(cfg, W, "f32")
+    model.eval()
+    batch = argparse.Namespace(src=I["src"].cuda(), batchSize=cfg["B"])
+    allHyp, allScores, allAttn, gold = model.translateBatch(batch, max_steps=12)
+    hyp_o, scores_o, attn_o = ON.translate_batch(W, I["src"], max_steps=12)
+    got = torch.stack([s_[0] for s_ in allScores]).cpu()
+    assert (got - scores_o).abs().max().item() < 2e-3 * max(1.0, scores_o.abs().max().item()), (got, scores_o)
+    if len(allHyp[0][0]) == hyp_o.shape[1]:
+        n_same = sum(int(allHyp[b][0] == [int(t) for t in hyp_o[b]]) for b in range(cfg["B"]))
+        assert n_same >= (cfg["B"] + 1) // 2, (n_same, cfg["B"])
