@@ -1014,3 +1014,40 @@ def test_self_critical_step_per_image_features_equal_replicated():
     np.testing.assert_allclose(l1, l0, rtol=0, atol=1e-5)
     for k in w0:
         assert absmax(w1[k], w0[k]) < 2e-5, k
+
+
+def test_trainer_prefetch_next_batch_equals_plain_training():
+    """Trainer.train(data, next_data=...) ships batch k+1 on a copy stream while batch k computes: same losses and final
+    weights as shipping every batch when it is needed; a batch that was not the prefetched one is shipped normally."""
+    from unpaired_image_captioning_amd.trainer import Trainer
+    cfg, W, I, Out, G, X = load_golden("topdown_tiny_ragged")
+    base = {k: I[k].numpy() for k in ("fc_feats", "att_feats", "labels", "masks", "att_masks")}
+    g = np.random.default_rng(0)
+    batches = []
+    for i in range(4):
+        d = {k: v.copy() for k, v in base.items()}
+        perm = g.permutation(len(d["labels"]) // cfg["S"])
+        for k in d:
+            d[k] = d[k].reshape(len(perm), cfg["S"], *d[k].shape[1:])[perm].reshape(d[k].shape)
+        d["fc_feats"] = d["fc_feats"] * (1.0 + 0.1 * i)
+        batches.append(d)
+    res = []
+    for mode in ("plain", "prefetch"):
+        opt = make_opt(cfg, "f32", seed=3)
+        opt.i2t_learning_rate = 1e-3
+        opt.seq_per_img = cfg["S"]
+        tr = Trainer(opt)
+        tr.i2t_model.load_state_dict(W)
+        tr.build_optimizer()
+        losses = []
+        for i, d in enumerate(batches):
+            if mode == "plain":
+                losses.append(tr.train(d))
+            else:
+                nxt = batches[i + 1] if i + 1 < len(batches) and i != 1 else None     # step 2's batch is NOT prefetched
+                losses.append(tr.train(d, next_data=nxt))
+        res.append((losses, {k: v.detach().cpu().clone() for k, v in tr.i2t_model.state_dict().items()}))
+    (l0, w0), (l1, w1) = res
+    assert l0 == l1, (l0, l1)
+    for k in w0:
+        assert torch.equal(w0[k], w1[k]), k

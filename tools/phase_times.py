@@ -110,5 +110,11 @@ print("CIDEr-D scores of 1280 captions x 5 references (kernel + reference upload
 def xe_host():
     tr.train(data)
 print("Trainer.train (XE) from host numpy incl. H2D (features once per image) and the loss.item() sync: %.3f ms" % timeit(xe_host, iters=10, warm=3))
+data2 = dict(data)
+state2 = {"cur": data, "nxt": data2}
+def xe_host_prefetch():
+    tr.train(state2["cur"], next_data=state2["nxt"])
+    state2["cur"], state2["nxt"] = state2["nxt"], state2["cur"]
+print("Trainer.train (XE) from host numpy with the NEXT batch shipped during the step (next_data=): %.3f ms" % timeit(xe_host_prefetch, iters=10, warm=3))
 tr.opt.ship_replicated_features = 1
 print("Trainer.train (XE) from host numpy, features replicated on the host as the reference ships them: %.3f ms" % timeit(xe_host, iters=5, warm=2))

@@ -192,15 +192,41 @@ class Trainer(object):
         self.last_loss = loss
         return loss
 
-    def train(self, data, loader=None, iteration=None, epoch=None, nmt_epoch=None):
-        """Trainer.train for the XE captioner step (P/trainer.py:141-173,193)."""
+    def prefetch(self, data, per_image=True):
+        """Ship a batch to the device on a copy stream NOW (pinned staging + asynchronous H2D), to be consumed by the next
+        train(data) / train_self_critical(data) call with this very dict.  Called by train(..., next_data=...) right after a
+        step is enqueued, so the host gather and the PCIe transfer of batch k+1 run while the GPU computes batch k."""
+        if getattr(self, '_copy_stream', None) is None:
+            self._copy_stream = torch.cuda.Stream()
+        with torch.cuda.stream(self._copy_stream):
+            batch = self.to_device(data, per_image)
+            ev = torch.cuda.Event()
+            ev.record()
+        self._prefetched = (id(data), per_image, batch, ev)
+
+    def _device_batch(self, data, per_image=True):
+        pf = getattr(self, '_prefetched', None)
+        self._prefetched = None
+        if pf is not None and pf[0] == id(data) and pf[1] == per_image:
+            cur = torch.cuda.current_stream()
+            cur.wait_event(pf[3])
+            for t in pf[2].values():
+                t.record_stream(cur)               # allocated on the copy stream, consumed on this one
+            return pf[2]
+        return self.to_device(data, per_image)
+
+    def train(self, data, loader=None, iteration=None, epoch=None, nmt_epoch=None, next_data=None):
+        """Trainer.train for the XE captioner step (P/trainer.py:141-173,193).  next_data (optional extension): the
+        following batch, shipped to the device while this step computes (see prefetch)."""
         labels_np = np.asarray(data["labels"])
         t_run = _steps_from_host_labels(labels_np)
         T = labels_np.shape[1] - 1
         den_local = float(np.asarray(data["masks"])[:, 1:T + 1].sum())
-        batch = self.to_device(data)
+        batch = self._device_batch(data)
         loss = self.train_device_batch(batch, t_run, den_local)
         loss = self.exchange.allreduce_sum_scalar(loss)
+        if next_data is not None:
+            self.prefetch(next_data)
         self.i2t_train_loss = loss.item()          # the reference's per-step host sync (trainer.py:172)
         return self.i2t_train_loss
 
@@ -214,7 +240,7 @@ class Trainer(object):
         from .misc import rewards
         if self.arena is None:
             self.build_optimizer()
-        batch = self.to_device(data)
+        batch = self._device_batch(data)
         model = self.i2t_model
         fc, att, am = batch["fc_feats"], batch["att_feats"], batch.get("att_masks")
         n_rows = len(data["labels"]) if data.get("labels") is not None else att.shape[0]
