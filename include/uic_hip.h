@@ -49,7 +49,11 @@ typedef struct uic_topdown_dims {
                      * n / S.  Results are those of the S-fold replicated batch (same dropout masks per caption row); the
                      * att_embed Linear and its weight gradient then run on N/S * R rows instead of N * R (use_bn = 0;
                      * with BatchNorm the input is replicated on the device first). */
+  int32_t logit_layers; /* opt.logit_layers (P/models/AttModel.py:86-91): 0 or 1 = logit is one Linear(H, V1); n > 1 (at most
+                     * UIC_MAX_LOGIT_LAYERS) = n - 1 blocks Linear(H, H) + ReLU + Dropout(0.5) in front of it (the 0.5 is
+                     * hard-coded in the reference and active in train mode whatever drop_p is). */
 } uic_topdown_dims;
+#define UIC_MAX_LOGIT_LAYERS 4
 
 /* Master parameters (f32), one pointer per tensor of TopDownModel.state_dict(), same shapes as the reference
  * (with use_bn >= 1 the Linear of att_embed sits at att_embed.1).  The same struct
@@ -89,6 +93,10 @@ typedef struct uic_topdown_weights {
   float* att_bn4_b;       /* att_embed.4.bias          [H]            */
   float* att_bn4_rm;      /* att_embed.4.running_mean  [H]            */
   float* att_bn4_rv;      /* att_embed.4.running_var   [H]            */
+  /* logit_layers = n > 1 (NULL otherwise): hidden block l = 0 .. n-2 is logit.{3l} = Linear(H, H); logit_w / logit_b above
+   * are then logit.{3(n-1)}, the final Linear(H, V1) */
+  float* logit_h_w[UIC_MAX_LOGIT_LAYERS - 1];   /* logit.{3l}.weight [H, H] */
+  float* logit_h_b[UIC_MAX_LOGIT_LAYERS - 1];   /* logit.{3l}.bias   [H]    */
 } uic_topdown_weights;
 
 /* The batch dict of DataLoader.get_batch as consumed at P/trainer.py:147-149 (device copies). */
@@ -357,6 +365,7 @@ int uic_dropout_mask(float* out, size_t n, float p, uint32_t seed, uint32_t site
 #define UIC_SITE_ATT 2u
 #define UIC_SITE_EMBED 3u
 #define UIC_SITE_OUT0 16u   /* + decode step */
+#define UIC_SITE_LOGIT_H0 8u   /* + l: Dropout(0.5) of hidden logit block l (logit_layers > 1), element (t*N + n)*H + j */
 #define UIC_SITE_SS_MASK0 512u  /* + decode step: row n is re-sampled iff u(seed, site, n) < ss_prob                  */
 #define UIC_SITE_SS_DRAW0 768u  /* + decode step: u(seed, site, n) drives the inverse-CDF draw of row n              */
 #define UIC_SITE_NMT_ENC0 1000u  /* + l: nn.LSTM dropout after encoder layer l, element (s*B + b)*H + j           */

@@ -136,12 +136,39 @@ def embed(W: Weights, it: Tensor, mask: Optional[Tensor] = None) -> Tensor:
     return xt if mask is None else xt * mask
 
 
+def _logit_indices(W):
+    return sorted(int(k.split(".")[1]) for k in W if k.startswith("logit.") and k.endswith(".weight") and k.count(".") == 2)
+
+
+def logit_final_key(W, what: str = "weight") -> str:
+    """state_dict key of the vocabulary layer: 'logit.weight', or 'logit.{3(n-1)}.weight' when logit_layers = n > 1."""
+    return "logit." + what if "logit.weight" in W else "logit.%d.%s" % (_logit_indices(W)[-1], what)
+
+
+def logit_final_weight(W) -> Tensor:
+    """The vocabulary layer's weight [V1, H]: `logit.weight`, or the last Linear of the Sequential when logit_layers > 1."""
+    return W["logit.weight"] if "logit.weight" in W else W["logit.%d.weight" % _logit_indices(W)[-1]]
+
+
+def logit_layer(W: Weights, x: Tensor, masks=None) -> Tensor:
+    """self.logit (P/models/AttModel.py:86-91): one Linear, or logit_layers - 1 blocks [Linear(H, H), ReLU, Dropout(0.5)]
+    followed by the vocabulary Linear.  ``masks``: per hidden block, the multiplicative dropout mask [N, H] (train mode)."""
+    if "logit.weight" in W:
+        return F.linear(x, W["logit.weight"], W["logit.bias"])
+    idx = _logit_indices(W)
+    for j, i in enumerate(idx[:-1]):
+        x = torch.relu(F.linear(x, W["logit.%d.weight" % i], W["logit.%d.bias" % i]))
+        if masks is not None:
+            x = x * masks[j]
+    return F.linear(x, W["logit.%d.weight" % idx[-1]], W["logit.%d.bias" % idx[-1]])
+
+
 def logprobs_step(W: Weights, it: Tensor, fc, att, p_att, att_masks, state,
-                  embed_mask=None, out_mask=None):
+                  embed_mask=None, out_mask=None, logit_masks=None):
     """AttModel.get_logprobs_state, P/models/AttModel.py:158-165."""
     xt = embed(W, it, embed_mask)
     out, state, aux = core_step(W, xt, fc, att, p_att, state, att_masks, out_mask)
-    logp = F.log_softmax(F.linear(out, W["logit.weight"], W["logit.bias"]), dim=1)
+    logp = F.log_softmax(logit_layer(W, out, logit_masks), dim=1)
     return logp, state, aux
 
 
@@ -161,8 +188,8 @@ def forward_logprobs(W: Weights, fc_feats: Tensor, att_feats: Tensor, seq: Tenso
     """
     N = fc_feats.shape[0]
     T = seq.shape[1] - 1
-    H = W["logit.weight"].shape[1]
-    V1 = W["logit.weight"].shape[0]
+    H = logit_final_weight(W).shape[1]
+    V1 = logit_final_weight(W).shape[0]
     fc, att, p_att, masks = prepare_feature(W, fc_feats, att_feats, att_masks, drop, use_bn, training)
     state = (torch.zeros(2, N, H), torch.zeros(2, N, H))               # init_hidden :94-97
     outputs = []
@@ -186,7 +213,8 @@ def forward_logprobs(W: Weights, fc_feats: Tensor, att_feats: Tensor, seq: Tenso
             break
         em = None if drop is None else drop["embed"][i]
         om = None if drop is None else drop["out"][i]
-        logp, state, aux = logprobs_step(W, it, fc, att, p_att, masks, state, em, om)
+        lm = None if drop is None or "logit" not in drop else [m[i] for m in drop["logit"]]
+        logp, state, aux = logprobs_step(W, it, fc, att, p_att, masks, state, em, om, lm)
         outputs.append(logp)
         auxes.append(aux)
         inputs.append(it)
@@ -225,7 +253,7 @@ def sample(W: Weights, fc_feats: Tensor, att_feats: Tensor, att_masks: Optional[
     the self-critical step, P/trainer.py:167) uses the same mask layout as forward_logprobs.
     """
     N = fc_feats.shape[0]
-    H = W["logit.weight"].shape[1]
+    H = logit_final_weight(W).shape[1]
     fc, att, p_att, masks = prepare_feature(W, fc_feats, att_feats, att_masks, drop, use_bn, False)
     state = (torch.zeros(2, N, H), torch.zeros(2, N, H))
     seq = torch.zeros(N, seq_length, dtype=torch.long)
@@ -235,7 +263,8 @@ def sample(W: Weights, fc_feats: Tensor, att_feats: Tensor, att_masks: Optional[
     for t in range(seq_length + 1):
         em = None if drop is None or t >= seq_length else drop["embed"][t]
         om = None if drop is None or t >= seq_length else drop["out"][t]
-        logp, state, _ = logprobs_step(W, it, fc, att, p_att, masks, state, em, om)
+        lm = None if drop is None or t >= seq_length or "logit" not in drop else [m[t] for m in drop["logit"]]
+        logp, state, _ = logprobs_step(W, it, fc, att, p_att, masks, state, em, om, lm)
         if decoding_constraint and t > 0:                              # :220-223
             tmp = torch.zeros_like(logp)
             tmp.scatter_(1, seq[:, t - 1].unsqueeze(1), float("-inf"))
@@ -383,9 +412,9 @@ def sample_beam(W: Weights, fc_feats: Tensor, att_feats: Tensor, att_masks: Opti
     """AttModel._sample_beam (P/models/AttModel.py:167-196) over beam_search_core, image by image like the reference;
     the best finished beam per image is the result (:193-194).  group_size > 1: diverse_beam_search_core with
     beam_size // group_size beams per group (the replicated rows are chunked per group, CaptionModel.py:113-120)."""
-    assert beam_size <= W["logit.weight"].shape[0]
+    assert beam_size <= logit_final_weight(W).shape[0]
     N = fc_feats.shape[0]
-    H = W["logit.weight"].shape[1]
+    H = logit_final_weight(W).shape[1]
     fc, att, p_att, masks = prepare_feature(W, fc_feats, att_feats, att_masks, None, use_bn, False)
     B, L = beam_size // group_size, seq_length
     seq = torch.zeros(N, L, dtype=torch.long)

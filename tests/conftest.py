@@ -31,6 +31,7 @@ def load_golden(name):
         kind, key = k.split("::", 1)
         t = torch.from_numpy(z[k])
         {"w": W, "in": I, "out": O, "grad": G}.get(kind, X)[key if kind in ("w", "in", "out", "grad") else k] = t
+    cfg["logit_layers"] = int(X.pop("logit_layers", 1))
     return cfg, W, I, O, G, X
 
 

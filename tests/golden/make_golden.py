@@ -60,10 +60,10 @@ def _load_reference():
     return att, crit
 
 
-def make_opt(V, E, H, A, D, L, use_bn=0, drop=0.0):
+def make_opt(V, E, H, A, D, L, use_bn=0, drop=0.0, logit_layers=1):
     return _argparse.Namespace(vocab_size=V, input_encoding_size=E, rnn_size=H, num_layers=1,
                                drop_prob_lm=drop, seq_length=L, fc_feat_size=D, att_feat_size=D,
-                               att_hid_size=A, use_bn=use_bn, logit_layers=1, caption_model="topdown")
+                               att_hid_size=A, use_bn=use_bn, logit_layers=logit_layers, caption_model="topdown")
 
 
 def synth(n_img, S, R, D, V, L, seed, ragged):
@@ -74,10 +74,15 @@ def synth(n_img, S, R, D, V, L, seed, ragged):
 
 def run_case(att_mod, crit_mod, name, V, E, H, A, D, L, n_img, S, R, seed, ragged=False,
              use_masks=True, use_bn=0, short_all=False, adam_steps=0, store_grads=True,
-             bn_train=False, ss_prob=0.0, ss_seed=0):
+             bn_train=False, ss_prob=0.0, ss_seed=0, logit_layers=1):
+    import builtins
+    import functools
+    builtins.reduce = functools.reduce                                  # AttModel.py:91 and CaptionModel.py:176 are py2
+    att_mod.reduce = functools.reduce
     torch.manual_seed(seed)
-    opt = make_opt(V, E, H, A, D, L, use_bn=use_bn)
+    opt = make_opt(V, E, H, A, D, L, use_bn=use_bn, logit_layers=logit_layers)
     model = att_mod.TopDownModel(opt)
+    final_logit = model.logit if logit_layers == 1 else model.logit[-1]
     if use_bn:
         # non-trivial BN affine parameters / running stats
         g = torch.Generator().manual_seed(seed + 7)
@@ -107,6 +112,8 @@ def run_case(att_mod, crit_mod, name, V, E, H, A, D, L, n_img, S, R, seed, ragge
     if att_masks is not None:
         out["in::att_masks"] = att_masks.numpy()
     out["cfg"] = np.array([V, E, H, A, D, L, n_img, S, R, use_bn, int(bn_train)], dtype=np.int64)
+    if logit_layers != 1:
+        out["logit_layers"] = np.array(logit_layers, dtype=np.int64)
 
     model.train(bool(bn_train))      # drop_prob_lm = 0 -> dropout is the identity either way
     attri = torch.zeros(fc.shape[0], 1)
@@ -174,10 +181,10 @@ def run_case(att_mod, crit_mod, name, V, E, H, A, D, L, n_img, S, R, seed, ragge
     builtins.reduce = functools.reduce                                  # CaptionModel.py:176 is py2
     for tag, bs, dc, mp, eos_bias in (("b3", 3, 0, 0, 0.0), ("b2c", 2, 1, 0, 0.0), ("b3eos", 3, 0, 0, 3.0), ("b4ppl", 4, 1, 1, 2.5)):
         with torch.no_grad():
-            model.logit.bias[0] += eos_bias
+            final_logit.bias[0] += eos_bias
             bseq, blp = model(fc[idx], attri[idx], att[idx], att_masks[idx] if att_masks is not None else None,
                               opt={"sample_max": 1, "beam_size": bs, "decoding_constraint": dc, "max_ppl": mp}, mode="sample")
-            model.logit.bias[0] -= eos_bias
+            final_logit.bias[0] -= eos_bias
         out["beam::%s_cfg" % tag] = np.array([bs, dc, mp, eos_bias], dtype=np.float64)
         out["beam::%s_seq" % tag] = bseq.numpy().copy()
         out["beam::%s_logp" % tag] = blp.numpy().copy()
@@ -186,11 +193,11 @@ def run_case(att_mod, crit_mod, name, V, E, H, A, D, L, n_img, S, R, seed, ragge
     # beam of group 0 -- the group that never sees a diversity penalty
     for tag, bs, gs, dc, mp, eos_bias, lam in (("g2b4", 4, 2, 0, 0, 0.0, 0.5), ("g3b6eos", 6, 3, 1, 1, 2.5, 0.7)):
         with torch.no_grad():
-            model.logit.bias[0] += eos_bias
+            final_logit.bias[0] += eos_bias
             bseq, blp = model(fc[idx], attri[idx], att[idx], att_masks[idx] if att_masks is not None else None,
                               opt={"sample_max": 1, "beam_size": bs, "group_size": gs, "diversity_lambda": lam,
                                    "decoding_constraint": dc, "max_ppl": mp}, mode="sample")
-            model.logit.bias[0] -= eos_bias
+            final_logit.bias[0] -= eos_bias
         out["beamg::%s_cfg" % tag] = np.array([bs, gs, dc, mp, eos_bias, lam], dtype=np.float64)
         out["beamg::%s_seq" % tag] = bseq.numpy().copy()
         out["beamg::%s_logp" % tag] = blp.numpy().copy()
@@ -312,6 +319,9 @@ def main():
     run_case(att_mod, crit_mod, "topdown_tiny_bn1_eval", seed=15, use_bn=1, ragged=True, **tiny)
     run_case(att_mod, crit_mod, "topdown_tiny_bn2_train", seed=16, use_bn=2, ragged=True, bn_train=True, **tiny)
     run_case(att_mod, crit_mod, "topdown_tiny_ss", seed=18, ragged=True, ss_prob=0.5, ss_seed=97, **tiny)
+    # logit_layers > 1 (AttModel.py:86-91): eval mode, so the hard-coded Dropout(0.5) of the hidden blocks is the identity
+    run_case(att_mod, crit_mod, "topdown_tiny_logit2", seed=19, ragged=True, logit_layers=2, **tiny)
+    run_case(att_mod, crit_mod, "topdown_tiny_logit3_bn1", seed=20, ragged=True, logit_layers=3, use_bn=1, **tiny)
     # non-power-of-two / odd sizes (E != H != A, V1 not a tile multiple)
     run_case(att_mod, crit_mod, "topdown_odd", seed=17, V=77, E=24, H=40, A=48, D=72, L=5,
              n_img=2, S=3, R=7, ragged=True)

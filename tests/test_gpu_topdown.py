@@ -13,7 +13,7 @@ from oracle import topdown as O
 
 pytestmark = pytest.mark.gpu
 
-FIXTURES = ["topdown_tiny", "topdown_tiny_ragged", "topdown_tiny_nomask", "topdown_tiny_earlybreak", "topdown_odd"]
+FIXTURES = ["topdown_tiny", "topdown_tiny_ragged", "topdown_tiny_nomask", "topdown_tiny_earlybreak", "topdown_odd", "topdown_tiny_logit2"]
 LOGP_TOL = {"f32": 1e-3, "bf16": 1e-2}
 GRAD_TOL = {"f32": 2e-3, "bf16": 1e-1}      # f32: max-entry error; bf16: L2 error (see grads_close)
 
@@ -21,7 +21,7 @@ GRAD_TOL = {"f32": 2e-3, "bf16": 1e-1}      # f32: max-entry error; bf16: L2 err
 def make_opt(cfg, dtype, drop=0.0, seed=0):
     return argparse.Namespace(vocab_size=cfg["V"], input_encoding_size=cfg["E"], rnn_size=cfg["H"], num_layers=1,
                               drop_prob_lm=drop, seq_length=cfg["L"], fc_feat_size=cfg["D"], att_feat_size=cfg["D"],
-                              att_hid_size=cfg["A"], use_bn=cfg.get("use_bn", 0), logit_layers=1, caption_model="topdown",
+                              att_hid_size=cfg["A"], use_bn=cfg.get("use_bn", 0), logit_layers=cfg.get("logit_layers", 1), caption_model="topdown",
                               compute_dtype=dtype, seed=seed)
 
 
@@ -31,6 +31,11 @@ def build_model(cfg, W, dtype, drop=0.0):
     missing = model.load_state_dict(W, strict=True)
     assert not missing.missing_keys and not missing.unexpected_keys
     return model.cuda()
+
+
+def final_logit(model):
+    """The vocabulary Linear: model.logit, or the last module of the Sequential when logit_layers > 1."""
+    return model.logit if isinstance(model.logit, torch.nn.Linear) else model.logit[-1]
 
 
 def rel(got, ref):
@@ -77,7 +82,8 @@ def test_forward_loss_backward_vs_reference_golden(name, dtype):
     from unpaired_image_captioning_amd.misc.criterion import LanguageModelCriterion
     cfg, W, I, Out, G, X = load_golden(name)
     model = build_model(cfg, W, dtype)
-    model.train()                                   # drop_prob_lm = 0: train mode is deterministic
+    model.train(cfg["logit_layers"] == 1)          # drop_prob_lm = 0: train mode is deterministic -- except for the hard-coded
+                                                    # Dropout(0.5) of hidden logit blocks, whose fixtures were made in eval mode
     fc, att, labels, masks = (I[k].cuda() for k in ("fc_feats", "att_feats", "labels", "masks"))
     am = I["att_masks"].cuda() if "att_masks" in I else None
     attri = torch.zeros(fc.shape[0], 1, device="cuda")
@@ -198,12 +204,14 @@ def test_two_stream_train_step_equals_separate_calls():
 
 
 @pytest.mark.parametrize("dtype", ["f32", "bf16"])
-def test_self_critical_step_vs_oracle(dtype):
+@pytest.mark.parametrize("name", ["topdown_tiny_ragged", "topdown_tiny_logit2"])
+def test_self_critical_step_vs_oracle(dtype, name):
     """SCST (P/trainer.py:167-171): multinomial sampling pass in train mode (dropout on), RewardCriterion,
-    backward through the sampled log-probs.  The oracle replays the device's own tokens and dropout masks."""
+    backward through the sampled log-probs.  The oracle replays the device's own tokens and dropout masks (with
+    logit_layers = 2 also the hidden logit block's: the sampling pass and the teacher-forced replay must agree on them)."""
     from unpaired_image_captioning_amd import _lib as L
     from unpaired_image_captioning_amd.misc.criterion import RewardCriterion
-    cfg, W, I, Out, G, X = load_golden("topdown_tiny_ragged")
+    cfg, W, I, Out, G, X = load_golden(name)
     model = build_model(cfg, W, dtype, drop=0.5)
     model.train()
     fc, att, am = I["fc_feats"].cuda(), I["att_feats"].cuda(), I["att_masks"].cuda()
@@ -225,6 +233,8 @@ def test_self_critical_step_vs_oracle(dtype):
     drop = dict(fc=mask(N * H, L.SITE_FC).view(N, H), att=mask(N * R * H, L.SITE_ATT).view(N, R, H),
                 embed=mask(Ls * N * E, L.SITE_EMBED).view(Ls, N, E),
                 out=torch.stack([mask(N * H, L.SITE_OUT0 + t).view(N, H) for t in range(Ls)]))
+    if cfg["logit_layers"] > 1:
+        drop["logit"] = [mask(Ls * N * H, L.SITE_LOGIT_H0 + l).view(Ls, N, H) for l in range(cfg["logit_layers"] - 1)]
     Wg = {k: v.clone().requires_grad_(True) for k, v in W.items()}
     seq_o, lp_o = O.sample(Wg, I["fc_feats"], I["att_feats"], I["att_masks"], Ls, sample_max=0, forced_tokens=seq.cpu(), drop=drop)
     assert torch.equal(seq_o, seq.cpu())
@@ -402,7 +412,7 @@ def test_full_size_properties_bf16():
 
 
 # ---------------------------------------------------------------- opt.use_bn (reference default 1, P/opts.py:52)
-BN_FIXTURES = ["topdown_tiny_bn1_eval", "topdown_tiny_bn2_train"]
+BN_FIXTURES = ["topdown_tiny_bn1_eval", "topdown_tiny_bn2_train", "topdown_tiny_logit3_bn1"]
 
 
 @pytest.mark.parametrize("dtype", ["f32", "bf16"])
@@ -636,11 +646,11 @@ def test_beam_search_token_ids_bit_exact_vs_reference_golden(name):
     for tag in BEAM_TAGS:
         bs, dc, mp, eos_bias = [float(x) for x in X["beam::%s_cfg" % tag]]
         with torch.no_grad():
-            model.logit.bias[0] += eos_bias
+            final_logit(model).bias[0] += eos_bias
         seq, lp = model(fc, None, att, am, opt={"sample_max": 1, "beam_size": int(bs), "decoding_constraint": int(dc), "max_ppl": int(mp)},
                         mode="sample")
         with torch.no_grad():
-            model.logit.bias[0] -= eos_bias
+            final_logit(model).bias[0] -= eos_bias
         ref_seq = torch.as_tensor(X["beam::%s_seq" % tag])
         assert torch.equal(seq.cpu(), ref_seq), (tag, seq.cpu(), ref_seq)
         assert absmax(lp, torch.as_tensor(X["beam::%s_logp" % tag])) < 1e-3, tag
@@ -664,12 +674,12 @@ def test_diverse_beam_groups_return_value_vs_reference_golden(name):
     for tag in ("g2b4", "g3b6eos"):
         bs, gs, dc, mp, eos_bias, lam = [float(x) for x in X["beamg::%s_cfg" % tag]]
         with torch.no_grad():
-            model.logit.bias[0] += eos_bias
+            final_logit(model).bias[0] += eos_bias
         seq, lp = model(fc, None, att, am, opt={"sample_max": 1, "beam_size": int(bs), "group_size": int(gs),
                                                 "diversity_lambda": lam, "decoding_constraint": int(dc),
                                                 "max_ppl": int(mp)}, mode="sample")
         with torch.no_grad():
-            model.logit.bias[0] -= eos_bias
+            final_logit(model).bias[0] -= eos_bias
         assert torch.equal(seq.cpu(), torch.as_tensor(X["beamg::%s_seq" % tag])), tag
         assert absmax(lp, torch.as_tensor(X["beamg::%s_logp" % tag])) < 1e-3, tag
 
@@ -684,7 +694,7 @@ def test_beam_search_bf16_and_real_vocab_vs_oracle():
     model = models.setup(make_opt(cfg, "bf16", seed=1))
     with torch.no_grad():
         model.logit.weight.mul_(20.0)
-        model.logit.bias[0] += 2.0
+        final_logit(model).bias[0] += 2.0
     W = {k: v.detach().clone() for k, v in model.state_dict().items()}
     model.cuda().eval()
     b = O.synthetic_batch(cfg["n_img"], 1, cfg["R"], cfg["D"], cfg["V"], cfg["L"], seed=4, ragged_regions=True)
@@ -783,13 +793,16 @@ def _sweep_configs(n, seed):
         out.append(dict(V=int(g.integers(5, 400)), E=m8(1, 20), H=m8(1, 20), A=m8(1, 20), D=m8(1, 30), L=int(g.integers(1, 21)),
                         n_img=int(g.integers(1, 15)), S=int(g.integers(1, 6)), R=int(g.integers(1, 70)),
                         use_bn=int(g.integers(0, 3)), per_image=bool(g.integers(0, 2)), drop=bool(g.integers(0, 2)), idx=i))
+    for c in out:                                                    # (drawn afterwards so that the shapes above stay as they were)
+        c["logit_layers"] = int(g.integers(1, 4))
     return out
 
 
 @pytest.mark.parametrize("cfg", _sweep_configs(48, 2024), ids=lambda c: "cfg%d" % c["idx"])
 def test_random_shape_sweep_vs_oracle(cfg):
     """48 seeded random configurations (sizes that are multiples of 8 but of nothing else, 1..14 images x 1..5 captions,
-    1..69 regions with ragged masks, 1..20 words, use_bn 0/1/2, features per caption row or per image, dropout on/off):
+    1..69 regions with ragged masks, 1..20 words, use_bn 0/1/2, logit_layers 1..3, features per caption row or per image,
+    dropout on/off):
     the fused f32 training step against the oracle (fed with the kernels' own dropout masks)."""
     from unpaired_image_captioning_amd import _lib as L
     from unpaired_image_captioning_amd import models
@@ -812,16 +825,21 @@ def test_random_shape_sweep_vs_oracle(cfg):
     N, R, H, E = b["labels"].shape[0], cfg["R"], cfg["H"], cfg["E"]
     T = b["labels"].shape[1] - 1
     drop = None
-    if p:
+    nlh = cfg["logit_layers"] - 1
+    if p or nlh:
         lib = L.load()
 
-        def mask(n, site):
+        def mask(n, site, pp=p):
+            if not pp:
+                return torch.ones(n)
             out = torch.empty(n, device="cuda")
-            L.check(lib.uic_dropout_mask(L.ptr(out), n, p, seed, site, 0, L.stream()))
+            L.check(lib.uic_dropout_mask(L.ptr(out), n, pp, seed, site, 0, L.stream()))
             return out.cpu()
         drop = dict(fc=mask(N * H, L.SITE_FC).view(N, H), att=mask(N * R * H, L.SITE_ATT).view(N, R, H),
                     embed=mask(T * N * E, L.SITE_EMBED).view(T, N, E),
                     out=torch.stack([mask(N * H, L.SITE_OUT0 + t).view(N, H) for t in range(T)]))
+        if nlh:     # the hidden logit blocks' Dropout(0.5) is hard-coded: active in train mode whatever drop_prob_lm is
+            drop["logit"] = [mask(T * N * H, L.SITE_LOGIT_H0 + l, 0.5).view(T, N, H) for l in range(nlh)]
     loss_o, grads_o, _ = O.xe_loss_and_grads(W, b["fc_feats"], b["att_feats"], b["labels"], b["masks"], b["att_masks"], drop,
                                              use_bn=cfg["use_bn"], training=True)
     assert abs(loss.item() - loss_o.item()) < 2e-4 * max(1.0, abs(loss_o.item())), (cfg, loss.item(), loss_o.item())
@@ -873,7 +891,7 @@ def test_decode_paths_random_sweep_vs_oracle(cfg):
         elif "running_mean" in k:
             v.copy_(0.1 * torch.randn(v.shape, generator=gw))
     with torch.no_grad():
-        model.logit.bias[0] += 1.5                           # some captions end early
+        final_logit(model).bias[0] += 1.5                           # some captions end early
     W = {k: v.detach().clone() for k, v in model.state_dict().items()}
     model.cuda().eval()
     b = O.synthetic_batch(cfg["n_img"], 1, cfg["R"], cfg["D"], cfg["V"], cfg["L"], seed=cfg["idx"], ragged_regions=cfg["R"] > 1)

@@ -61,7 +61,14 @@ def test_weight_struct_matches_reference_state_dict_order():
     model.load_state_dict(W)
     for k, v in model.state_dict().items():
         assert torch.equal(v, W[k])
-    assert [f for f, _ in _lib.Weights._fields_] == [f for f, _ in _lib.WEIGHT_FIELDS] + [f for f, _, _ in _lib.BN_FIELDS]
+    assert [f for f, _ in _lib.Weights._fields_] == [f for f, _ in _lib.WEIGHT_FIELDS] + [f for f, _, _ in _lib.BN_FIELDS] + \
+        ["logit_h_w", "logit_h_b"]
+    # logit_layers > 1: `logit` becomes a Sequential, hidden blocks at logit.{3l}, the vocabulary layer last (AttModel.py:90-91)
+    m3 = models.setup(_opt(logit_layers=3))
+    assert [k for _, k, _ in _lib.weight_fields(0, 3)] == list(m3.state_dict().keys())
+    assert [k for k in m3.state_dict() if k.startswith("logit.")] == ["logit.0.weight", "logit.0.bias", "logit.3.weight", "logit.3.bias",
+                                                                     "logit.6.weight", "logit.6.bias"]
+    assert tuple(m3.state_dict()["logit.6.weight"].shape) == (51, 32) and tuple(m3.state_dict()["logit.3.weight"].shape) == (32, 32)
 
 
 def test_same_seed_gives_reference_initialisation():
@@ -91,7 +98,7 @@ def test_unsupported_options_raise():
     with pytest.raises(ValueError):
         models.setup(_opt(use_bn=3))
     with pytest.raises(NotImplementedError):
-        models.setup(_opt(logit_layers=2))
+        models.setup(_opt(logit_layers=5))
     with pytest.raises(Exception, match="not supported"):
         models.setup(_opt(caption_model="transformer"))
 

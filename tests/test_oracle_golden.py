@@ -8,7 +8,7 @@ from conftest import load_golden
 from oracle import topdown as O
 
 TINY = ["topdown_tiny", "topdown_tiny_ragged", "topdown_tiny_nomask", "topdown_tiny_earlybreak",
-        "topdown_tiny_bn1_eval", "topdown_tiny_bn2_train", "topdown_odd"]
+        "topdown_tiny_bn1_eval", "topdown_tiny_bn2_train", "topdown_odd", "topdown_tiny_logit2", "topdown_tiny_logit3_bn1"]
 TOL = 2e-6
 
 
@@ -168,8 +168,9 @@ def test_beam_search_matches_reference(name):
     for tag in BEAM_TAGS:
         bs, dc, mp, eos_bias = [float(x) for x in X["beam::%s_cfg" % tag]]
         Wb = dict(W)
-        Wb["logit.bias"] = W["logit.bias"].clone()
-        Wb["logit.bias"][0] += eos_bias
+        bk = O.logit_final_key(W, "bias")
+        Wb[bk] = W[bk].clone()
+        Wb[bk][0] += eos_bias
         seq, lp = O.sample_beam(Wb, I["fc_feats"][idx], I["att_feats"][idx], None if am is None else am[idx], cfg["L"],
                                 int(bs), int(dc), int(mp), use_bn=cfg["use_bn"])
         ref_seq = torch.as_tensor(X["beam::%s_seq" % tag])
@@ -194,8 +195,9 @@ def test_diverse_beam_search_matches_reference(name):
     for tag in ("g2b4", "g3b6eos"):
         bs, gs, dc, mp, eos_bias, lam = [float(x) for x in X["beamg::%s_cfg" % tag]]
         Wb = dict(W)
-        Wb["logit.bias"] = W["logit.bias"].clone()
-        Wb["logit.bias"][0] += eos_bias
+        bk = O.logit_final_key(W, "bias")
+        Wb[bk] = W[bk].clone()
+        Wb[bk][0] += eos_bias
         args = (Wb, I["fc_feats"][idx], I["att_feats"][idx], None if am is None else am[idx], cfg["L"])
         seq, lp, beams = O.sample_beam(*args, int(bs), int(dc), int(mp), use_bn=cfg["use_bn"], group_size=int(gs),
                                        diversity_lambda=lam, return_beams=True)

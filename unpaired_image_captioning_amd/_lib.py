@@ -20,7 +20,11 @@ SITE_SS_MASK0, SITE_SS_DRAW0 = 512, 768          # + decode step
 
 
 class Dims(C.Structure):
-    _fields_ = [(n, C.c_int32) for n in ("N", "R", "D", "Dfc", "H", "E", "A", "V1", "T", "dtype")] + [("drop_p", C.c_float), ("use_bn", C.c_int32), ("seq_per_img", C.c_int32)]
+    _fields_ = [(n, C.c_int32) for n in ("N", "R", "D", "Dfc", "H", "E", "A", "V1", "T", "dtype")] + [("drop_p", C.c_float), ("use_bn", C.c_int32), ("seq_per_img", C.c_int32), ("logit_layers", C.c_int32)]
+
+
+MAX_LOGIT_LAYERS = 4
+SITE_LOGIT_H0 = 8       # + hidden logit block
 
 
 WEIGHT_FIELDS = [
@@ -58,15 +62,24 @@ BN_FIELDS = [
 ]
 
 
-def weight_fields(use_bn=0):
-    """[(struct field, reference state_dict key, is_parameter)] for opt.use_bn, parameters in named_parameters()
-    order.  With use_bn >= 1 the Linear of att_embed moves to index 1 (P/models/AttModel.py:78-84)."""
+def weight_fields(use_bn=0, logit_layers=1):
+    """[(struct field, reference state_dict key, is_parameter)] for opt.use_bn / opt.logit_layers, parameters in
+    named_parameters() order.  With use_bn >= 1 the Linear of att_embed moves to index 1 (P/models/AttModel.py:78-84); with
+    logit_layers = n > 1 `logit` is a Sequential of n - 1 blocks [Linear(H, H), ReLU, Dropout] and the vocabulary layer, so
+    hidden block l is `logit.{3l}` and the final Linear `logit.{3(n-1)}` (:90-91).  Struct fields "logit_h_w:l" / "logit_h_b:l"
+    index the pointer arrays of uic_topdown_weights."""
     out = []
     for f, k in WEIGHT_FIELDS:
         if f == "att_w" and use_bn:
             out += [b for b in BN_FIELDS[:4]]
         if f in ("att_w", "att_b") and use_bn:
             k = k.replace("att_embed.0.", "att_embed.1.")
+        if f == "logit_w" and logit_layers > 1:
+            for l in range(logit_layers - 1):
+                out.append(("logit_h_w:%d" % l, "logit.%d.weight" % (3 * l), True))
+                out.append(("logit_h_b:%d" % l, "logit.%d.bias" % (3 * l), True))
+        if f in ("logit_w", "logit_b") and logit_layers > 1:
+            k = k.replace("logit.", "logit.%d." % (3 * (logit_layers - 1)))
         out.append((f, k, True))
         if f == "att_b" and use_bn == 2:
             out += [b for b in BN_FIELDS[4:]]
@@ -74,7 +87,8 @@ def weight_fields(use_bn=0):
 
 
 class Weights(C.Structure):
-    _fields_ = [(f, C.c_void_p) for f, _ in WEIGHT_FIELDS] + [(f, C.c_void_p) for f, _, _ in BN_FIELDS]
+    _fields_ = [(f, C.c_void_p) for f, _ in WEIGHT_FIELDS] + [(f, C.c_void_p) for f, _, _ in BN_FIELDS] + \
+        [("logit_h_w", C.c_void_p * (MAX_LOGIT_LAYERS - 1)), ("logit_h_b", C.c_void_p * (MAX_LOGIT_LAYERS - 1))]
 
 
 class FcDims(C.Structure):

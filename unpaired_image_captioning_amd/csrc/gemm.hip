@@ -240,7 +240,7 @@ __global__ __launch_bounds__(64 * WM * WN * KS) void uic_gemm_kernel(const UicGe
               const int n = row / p.R;
               if (row - n * p.R >= p.row_len[n]) v = 0.f;
             }
-            if (p.drop_p > 0.f) v *= uic_drop_scale(p.seed, p.site, (unsigned)row * (unsigned)p.N + (unsigned)col, p.drop_p, inv_keep);
+            if (p.drop_p > 0.f) v *= uic_drop_scale(p.seed, p.site, (unsigned)(row + p.drop_row0) * (unsigned)p.N + (unsigned)col, p.drop_p, inv_keep);
             const size_t o = (size_t)row * p.ldc + col;
             if (out_f32) {
               float* C = (float*)p.C;
@@ -529,7 +529,7 @@ __global__ __launch_bounds__(256) void uic_gemm_glds_kernel(const UicGemmParams 
           const int n = row / p.R;
           if (row - n * p.R >= p.row_len[n]) v = 0.f;
         }
-        if (p.drop_p > 0.f) v *= uic_drop_scale(p.seed, p.site, (unsigned)row * (unsigned)p.N + (unsigned)col, p.drop_p, inv_keep);
+        if (p.drop_p > 0.f) v *= uic_drop_scale(p.seed, p.site, (unsigned)(row + p.drop_row0) * (unsigned)p.N + (unsigned)col, p.drop_p, inv_keep);
         const size_t o = (size_t)row * p.ldc + col;
         if (out_f32) {
           float* C = (float*)p.C;

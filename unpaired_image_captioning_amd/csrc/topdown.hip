@@ -33,6 +33,10 @@ struct Layout {
   void* gates1; void* gates2;
   float* atth_all; float* alpha_all; void* ctx_all; void* hdrop_all;
   float* logits; void* dlogits; float* row_loss; float* scalars;
+  void* lh[UIC_MAX_LOGIT_LAYERS - 1];       // logit_layers > 1: dropout(relu(hidden logit block l)) [T*N, H]
+  void* dlh_pre[UIC_MAX_LOGIT_LAYERS - 1];  // its pre-activation gradient [T*N, H] (operand dtype), kept for the weight gradient
+  float* dlh;                               // gradient flowing between the logit blocks [T*N, H] f32
+  void* s_lh[UIC_MAX_LOGIT_LAYERS - 1];     // the same activations of one decode step [N, H]
   // backward
   float* dhdrop; float* dx2_all; float* dx1; float* dc_att; float* dc_lang;
   void* dg1_all; void* dg2_all; float* de_all; void* datth_all;
@@ -95,6 +99,12 @@ Layout make_layout(const uic_topdown_dims& d, void* ws) {
   L.logits = (float*)b.take(M * V1p * 4);
   L.dlogits = b.take(M * V1p * S);
   L.row_loss = (float*)b.take(M * 4);
+  for (int l = 0; l + 1 < d.logit_layers; ++l) {
+    L.lh[l] = b.take(M * H * S);
+    L.dlh_pre[l] = b.take(M * H * S);
+    L.s_lh[l] = b.take(N * H * S);
+  }
+  if (d.logit_layers > 1) L.dlh = (float*)b.take(M * H * 4);
   L.scalars = (float*)b.take(64);
   L.dhdrop = (float*)b.take(M * H * 4);
   L.dx2_all = (float*)b.take(M * 3 * H * 4);
@@ -129,7 +139,7 @@ Layout make_layout(const uic_topdown_dims& d, void* ws) {
   L.colscratch_floats = 128 * maxcols;
   L.colscratch = (float*)b.take(L.colscratch_floats * 4);
   L.small = (float*)b.take((A + 8) * 4);
-  L.tLA = b.take(V1 * Mp * S);
+  L.tLA = b.take((d.logit_layers > 1 && H > V1 ? H : V1) * Mp * S);   // dlogits^T [V1, M]; hidden logit blocks: d pre^T [H, M]
   L.tLB = b.take(H * Mp * S);
   L.colscratchL = (float*)b.take(L.colscratch_floats * 4);
   {
@@ -192,6 +202,8 @@ struct Derived {
   void* h2attT;      // [H, A]
   void* ctx2attT;    // [H, A]
   float* att_beff;   // use_bn: b' = att_b + att_w bn0_beta  [H]  (att_w then points at W' = att_w diag(bn0_gamma))
+  const void* logit_h_w[UIC_MAX_LOGIT_LAYERS - 1];   // hidden logit blocks [H, H]
+  void* logit_h_wT[UIC_MAX_LOGIT_LAYERS - 1];        // their transposes for the dX GEMMs
   size_t total;
 };
 
@@ -227,6 +239,10 @@ Derived make_derived(const uic_topdown_dims& d, const uic_topdown_weights* w, vo
   v.wfcpT = b.take(H * 4 * H * S);
   v.h2attT = b.take(H * A * S);
   v.ctx2attT = b.take(H * A * S);
+  for (int l = 0; l + 1 < d.logit_layers; ++l) {
+    v.logit_h_w[l] = copy(w ? w->logit_h_w[l] : nullptr, H * H);
+    v.logit_h_wT[l] = b.take(H * H * S);
+  }
   v.total = (b.off + 255) & ~(size_t)255;
   return v;
 }
@@ -239,6 +255,8 @@ int check_dims(const uic_topdown_dims* d) {
               "D=%d Dfc=%d H=%d E=%d A=%d must all be multiples of 8", d->D, d->Dfc, d->H, d->E, d->A);
   UIC_REQUIRE(d->drop_p >= 0.f && d->drop_p < 1.f, "drop_p=%f outside [0,1)", (double)d->drop_p);
   UIC_REQUIRE(d->use_bn >= 0 && d->use_bn <= 2, "use_bn=%d outside {0,1,2}", d->use_bn);
+  UIC_REQUIRE(d->logit_layers >= 0 && d->logit_layers <= UIC_MAX_LOGIT_LAYERS, "logit_layers=%d outside [0,%d]", d->logit_layers,
+              UIC_MAX_LOGIT_LAYERS);
   UIC_REQUIRE(d->seq_per_img >= 0 && (d->seq_per_img <= 1 || d->N % d->seq_per_img == 0),
               "seq_per_img=%d must divide N=%d", d->seq_per_img, d->N);
   return UIC_OK;
@@ -489,6 +507,11 @@ int uic_topdown_refresh_weights(const uic_topdown_dims* d, const uic_topdown_wei
   UIC_TRY(uic_transpose_launch(dt, off(v.att_w_ih, H, dt), H4, H, ldih, v.wfcpT, H4, s2));
   UIC_TRY(uic_transpose_launch(dt, v.h2att_w, A, H, H, v.h2attT, A, s2));
   UIC_TRY(uic_transpose_launch(dt, v.ctx2att_w, A, H, H, v.ctx2attT, A, s2));
+  for (int l = 0; l + 1 < d->logit_layers; ++l) {
+    UIC_REQUIRE(w->logit_h_w[l] && w->logit_h_b[l], "logit_layers=%d needs the hidden logit block %d", d->logit_layers, l);
+    if (dt == UIC_BF16) UIC_TRY(uic_cast_f32_launch(dt, w->logit_h_w[l], (void*)v.logit_h_w[l], (size_t)H * H, s2));
+    UIC_TRY(uic_transpose_launch(dt, v.logit_h_w[l], H, H, H, v.logit_h_wT[l], H, s2));
+  }
   UIC_TRY(uic_check_hip(hipEventRecord(ss->ev_refresh, s2), "hipEventRecord"));
   ss->refresh_pending = true;
   return UIC_OK;
@@ -615,9 +638,20 @@ struct Step {
     if (ss_on()) return UIC_OK;
     return logits_rows_now(t0, t1, s);
   }
+  // logit_layers = n > 1 (AttModel.py:90-91): n - 1 blocks Linear(H, H) + ReLU + Dropout(0.5) in front of the vocabulary layer
+  int nlh() const { return d.logit_layers > 1 ? d.logit_layers - 1 : 0; }
+  const void* logit_in_all() const { return nlh() ? L.lh[nlh() - 1] : L.hdrop_all; }
   int logits_rows_now(int t0, int t1, hipStream_t s) {
-    UicGemmParams g = gemm_base(dt, (t1 - t0) * N, V1);
-    add_seg(g, off(L.hdrop_all, t0 * NH, dt), H, dv.logit_w, H, H);
+    const int rows = (t1 - t0) * N;
+    for (int l = 0; l < nlh(); ++l) {
+      UicGemmParams g = gemm_base(dt, rows, H);
+      add_seg(g, off(l ? L.lh[l - 1] : L.hdrop_all, t0 * NH, dt), H, dv.logit_h_w[l], H, H);
+      g.C = offw(L.lh[l], t0 * NH, dt); g.ldc = H; g.bias = w->logit_h_b[l]; g.flags = UIC_GEMM_RELU;
+      if (training & 1) { g.drop_p = 0.5f; g.seed = seed; g.site = UIC_SITE_LOGIT_H0 + (unsigned)l; g.drop_row0 = t0 * N; }
+      UIC_TRY(uic_gemm_launch(g, s));
+    }
+    UicGemmParams g = gemm_base(dt, rows, V1);
+    add_seg(g, off(logit_in_all(), t0 * NH, dt), H, dv.logit_w, H, H);
     g.C = L.logits + (size_t)t0 * N * V1p; g.ldc = V1p; g.bias = w->logit_b; g.flags = UIC_GEMM_OUT_F32;
     return uic_gemm_launch(g, s);
   }
@@ -645,16 +679,33 @@ struct Step {
   // the side stream's slab)
   int dh_rows(int t0, int t1, hipStream_t s, bool side = false) {
     const size_t r0 = (size_t)t0 * N;
-    const WDest d1{L.dhdrop + r0 * H, H, 0, H};
-    return wgrad_multi(side ? L.slab2 : L.slab, L.slab_bytes, dt, off(L.dlogits, r0 * V1p, dt), (t1 - t0) * N, dv.logit_wT, H, V1p,
-                       &d1, 1, s);
+    const int rows = (t1 - t0) * N;
+    const WDest d1{(nlh() ? L.dlh : L.dhdrop) + r0 * H, H, 0, H};
+    UIC_TRY(wgrad_multi(side ? L.slab2 : L.slab, L.slab_bytes, dt, off(L.dlogits, r0 * V1p, dt), rows, dv.logit_wT, H, V1p, &d1, 1, s));
+    // back through the hidden blocks: Dropout(0.5) + ReLU mask, then d x = d pre W
+    for (int l = nlh() - 1; l >= 0; --l) {
+      UIC_TRY(uic_relu_mask_bwd_launch(dt, L.dlh + r0 * H, off(L.lh[l], r0 * H, dt), (training & 1) ? 2.f : 1.f,
+                                       offw(L.dlh_pre[l], r0 * H, dt), (size_t)rows * H, s));
+      UicGemmParams g = gemm_base(dt, rows, H);
+      add_seg(g, off(L.dlh_pre[l], r0 * H, dt), H, dv.logit_h_wT[l], H, H);
+      g.C = (l ? L.dlh : L.dhdrop) + r0 * H; g.ldc = H; g.flags = UIC_GEMM_OUT_F32;
+      UIC_TRY(uic_gemm_launch(g, s));
+    }
+    return UIC_OK;
   }
   // d W_logit, d b_logit over all executed steps (own scratch buffers: may run beside the BPTT loop)
   int logit_weight_grads(hipStream_t s, bool side = false) {
     {
-      const UicGemmTnSeg seg{L.hdrop_all, H, H};
+      const UicGemmTnSeg seg{logit_in_all(), H, H};
       const WDest d1{G->logit_w, H, 0, H};
       UIC_TRY(wgrad_group(side ? L.slab2 : L.slab, L.dlogits, V1p, V1, &seg, 1, Meff, &d1, 1, s, false, L.tLA, L.tLB));
+    }
+    for (int l = 0; l < nlh(); ++l) {
+      UIC_REQUIRE(G->logit_h_w[l] && G->logit_h_b[l], "backward: logit_layers=%d needs gradient tensors for hidden block %d", d.logit_layers, l);
+      const UicGemmTnSeg seg{l ? L.lh[l - 1] : L.hdrop_all, H, H};
+      const WDest d1{G->logit_h_w[l], H, 0, H};
+      UIC_TRY(wgrad_group(side ? L.slab2 : L.slab, L.dlh_pre[l], H, H, &seg, 1, Meff, &d1, 1, s, false, L.tLA, L.tLB));
+      UIC_TRY(uic_colsum_launch(dt, L.dlh_pre[l], Meff, H, H, G->logit_h_b[l], L.colscratchL, L.colscratch_floats, s));
     }
     return uic_colsum_launch(dt, L.dlogits, Meff, V1, V1p, G->logit_b, L.colscratchL, L.colscratch_floats, s);
   }
@@ -890,7 +941,7 @@ struct Step {
 // One decode step of AttModel.get_logprobs_state (:158-165) on the sampling buffers: embedding of L.s_it, both LSTM cells,
 // attention, logits into L.s_logits; recurrent state read from slot `cur`, written to slot `nxt`.
 int decode_step(const uic_topdown_dims& d, const uic_topdown_weights* w, const Derived& dv, const uic_topdown_batch* b, const Layout& L,
-                int cur, int nxt, int t, float drop_p, unsigned seed, hipStream_t s) {
+                int cur, int nxt, int t, float drop_p, unsigned seed, hipStream_t s, bool train_mode = false) {
   const int dt = d.dtype;
   const int N = d.N, H = d.H, E = d.E, V1 = d.V1;
   const int V1p = (int)vpad(V1), H4 = 4 * H, ldih = E + 2 * H;
@@ -921,8 +972,17 @@ int decode_step(const uic_topdown_dims& d, const uic_topdown_weights* w, const D
     g.drop_p = drop_p; g.seed = seed; g.site = UIC_SITE_OUT0 + (unsigned)t;
     UIC_TRY(uic_gemm_launch(g, s));
   }
+  const void* x = L.s_hdrop;
+  for (int l = 0; l + 1 < d.logit_layers; ++l) {      // hidden logit blocks (AttModel.py:90-91), same masks as a training pass of step t
+    UicGemmParams g = gemm_base(dt, N, H);
+    add_seg(g, x, H, dv.logit_h_w[l], H, H);
+    g.C = L.s_lh[l]; g.ldc = H; g.bias = w->logit_h_b[l]; g.flags = UIC_GEMM_RELU;
+    if (train_mode) { g.drop_p = 0.5f; g.seed = seed; g.site = UIC_SITE_LOGIT_H0 + (unsigned)l; g.drop_row0 = t * N; }
+    UIC_TRY(uic_gemm_launch(g, s));
+    x = L.s_lh[l];
+  }
   UicGemmParams g = gemm_base(dt, N, V1);
-  add_seg(g, L.s_hdrop, H, dv.logit_w, H, H);
+  add_seg(g, x, H, dv.logit_w, H, H);
   g.C = L.s_logits; g.ldc = V1p; g.bias = w->logit_b; g.flags = UIC_GEMM_OUT_F32;
   return uic_gemm_launch(g, s);
 }
@@ -1096,7 +1156,7 @@ int uic_topdown_sample(const uic_topdown_dims* d, const uic_topdown_weights* w, 
   UIC_TRY(uic_fill_launch(L.s_nunf, 0, (size_t)(d->T + 2) * 4, s));
   for (int t = 0; t < Lsteps; ++t) {
     const int cur = t & 1, nxt = cur ^ 1;
-    UIC_TRY(decode_step(*d, w, dv, b, L, cur, nxt, t, drop_p, seed, s));
+    UIC_TRY(decode_step(*d, w, dv, b, L, cur, nxt, t, drop_p, seed, s, (training & 1) != 0));
     UicSampleParams p;
     memset(&p, 0, sizeof(p));
     p.dtype = dt; p.N = N; p.V1 = V1; p.ldv = V1p; p.t = t; p.L = Lsteps;

@@ -123,9 +123,9 @@ class AttModel(CaptionModel):
         self.ss_prob = 0.0  # Schedule sampling probability
         if self.use_bn not in (0, 1, 2):
             raise ValueError("use_bn=%r must be 0, 1 or 2" % (self.use_bn,))
-        if getattr(opt, 'logit_layers', 1) != 1:
-            raise NotImplementedError("logit_layers > 1 is not on the MI355X hot path")
-        self.logit_layers = 1
+        self.logit_layers = getattr(opt, 'logit_layers', 1)
+        if not 1 <= self.logit_layers <= _lib.MAX_LOGIT_LAYERS:
+            raise NotImplementedError("logit_layers=%r: the MI355X path supports 1..%d" % (self.logit_layers, _lib.MAX_LOGIT_LAYERS))
 
         self.embed = nn.Sequential(nn.Embedding(self.vocab_size + 1, self.input_encoding_size),
                                    nn.ReLU(),
@@ -139,7 +139,13 @@ class AttModel(CaptionModel):
              nn.ReLU(),
              nn.Dropout(self.drop_prob_lm)) +
             ((nn.BatchNorm1d(self.rnn_size),) if self.use_bn == 2 else ())))
-        self.logit = nn.Linear(self.rnn_size, self.vocab_size + 1)
+        if self.logit_layers == 1:
+            self.logit = nn.Linear(self.rnn_size, self.vocab_size + 1)
+        else:       # P/models/AttModel.py:90-91: blocks [Linear(H, H), ReLU, Dropout(0.5)] in front of the vocabulary layer
+            blocks = []
+            for _ in range(self.logit_layers - 1):
+                blocks += [nn.Linear(self.rnn_size, self.rnn_size), nn.ReLU(), nn.Dropout(0.5)]
+            self.logit = nn.Sequential(*(blocks + [nn.Linear(self.rnn_size, self.vocab_size + 1)]))
         self.ctx2att = nn.Linear(self.rnn_size, self.att_hid_size)
 
         # MI355X engine state (not part of the checkpoint)
@@ -153,14 +159,15 @@ class AttModel(CaptionModel):
         if self._engine is None:
             self._engine = TopDownEngine(dict(V1=self.vocab_size + 1, E=self.input_encoding_size, H=self.rnn_size,
                                               A=self.att_hid_size, D=self.att_feat_size, Dfc=self.fc_feat_size),
-                                         dtype=self.compute_dtype, drop_p=self.drop_prob_lm, use_bn=self.use_bn)
+                                         dtype=self.compute_dtype, drop_p=self.drop_prob_lm, use_bn=self.use_bn,
+                                         logit_layers=self.logit_layers)
         if self.use_bn:      # buffers may have been re-homed by .cuda()/.to(): always hand the live tensors over
             self._engine.buffers = {k: v for k, v in self.named_buffers() if k.endswith(("running_mean", "running_var"))}
         return self._engine
 
     @property
     def param_names(self):
-        return [k for _, k, is_param in _lib.weight_fields(self.use_bn) if is_param]
+        return [k for _, k, is_param in _lib.weight_fields(self.use_bn, self.logit_layers) if is_param]
 
     def _bn_count_batch(self):
         """num_batches_tracked += 1, as a train-mode nn.BatchNorm1d forward does."""

@@ -20,10 +20,11 @@ class Workspace(object):
 
 
 class TopDownEngine(object):
-    def __init__(self, sizes, dtype="bf16", drop_p=0.5, use_bn=0):
+    def __init__(self, sizes, dtype="bf16", drop_p=0.5, use_bn=0, logit_layers=1):
         """sizes: dict with V1, E, H, A, D, Dfc.  use_bn: opt.use_bn; the BatchNorm running statistics (buffers, not
         parameters) are looked up in `self.buffers`, which the owning model keeps pointed at its live tensors."""
         self.use_bn = int(use_bn)
+        self.logit_layers = int(logit_layers)
         self.buffers = {}
         self.lib = _lib.load()
         self.sizes = dict(sizes)
@@ -38,7 +39,8 @@ class TopDownEngine(object):
     def dims(self, N, R, T, seq_per_img=1):
         s = self.sizes
         return Dims(N=N, R=R, D=s["D"], Dfc=s["Dfc"], H=s["H"], E=s["E"], A=s["A"], V1=s["V1"], T=T,
-                    dtype=self.dtype, drop_p=self.drop_p, use_bn=self.use_bn, seq_per_img=seq_per_img)
+                    dtype=self.dtype, drop_p=self.drop_p, use_bn=self.use_bn, seq_per_img=seq_per_img,
+                    logit_layers=self.logit_layers)
 
     @staticmethod
     def _key(d):
@@ -69,7 +71,7 @@ class TopDownEngine(object):
     def weights_struct(self, tensors):
         """tensors: dict reference-state_dict-key -> contiguous f32 device tensor."""
         w = Weights()
-        for field, key, is_param in weight_fields(self.use_bn):
+        for field, key, is_param in weight_fields(self.use_bn, self.logit_layers):
             t = tensors.get(key) if is_param else tensors.get(key, self.buffers.get(key))
             if t is None:
                 if is_param:
@@ -77,7 +79,11 @@ class TopDownEngine(object):
                 continue                      # gradient structs carry no running statistics
             if t.dtype != torch.float32:
                 raise RuntimeError("parameter %s must be float32, got %s" % (key, t.dtype))
-            setattr(w, field, ptr(t))
+            if ":" in field:                  # element of a pointer array (hidden logit blocks)
+                name, idx = field.split(":")
+                getattr(w, name)[int(idx)] = ptr(t)
+            else:
+                setattr(w, field, ptr(t))
         return w
 
     def refresh(self, params, d):
