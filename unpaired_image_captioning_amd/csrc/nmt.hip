@@ -70,6 +70,40 @@ __global__ void enc_final_kernel(const void* xl_, const float* c_f, const float*
   c0[i] = (d ? c_b : c_f)[((size_t)slot * B + b) * Hd + (j - d * Hd)];
 }
 
+// sum_j row[j] * vec[j] over one wavefront, 16-byte loads (H is a multiple of the vector width)
+template <typename T>
+__device__ __forceinline__ float row_dot(const T* __restrict__ row, const float* __restrict__ vec, int H, int lane) {
+  constexpr int VEC = uic_vec<T>::N;
+  float p = 0.f;
+  for (int c = lane; c < H / VEC; c += 64) {
+    float f[VEC];
+    uic_unpack<T>(*(const uint4*)(row + c * VEC), f);
+#pragma unroll
+    for (int k = 0; k < VEC; ++k) p += f[k] * vec[c * VEC + k];
+  }
+  return uic_wave_sum(p);
+}
+// s_red[wave][:] = sum over this wave's source positions s of coef[s] * ctx[s, b, :]
+template <typename T>
+__device__ __forceinline__ void weighted_rows(const T* __restrict__ ctx, const float* __restrict__ coef, int S, int B, int H, int b,
+                                              int lane, int wave, float* __restrict__ s_red) {
+  constexpr int VEC = uic_vec<T>::N;
+  for (int c = lane; c < H / VEC; c += 64) {
+    float acc[VEC];
+#pragma unroll
+    for (int k = 0; k < VEC; ++k) acc[k] = 0.f;
+    for (int s = wave; s < S; s += 4) {
+      float f[VEC];
+      uic_unpack<T>(*(const uint4*)(ctx + ((size_t)s * B + b) * H + c * VEC), f);
+      const float a = coef[s];
+#pragma unroll
+      for (int k = 0; k < VEC; ++k) acc[k] += a * f[k];
+    }
+#pragma unroll
+    for (int k = 0; k < VEC; ++k) s_red[wave * H + c * VEC + k] = acc[k];
+  }
+}
+
 // ---- dot GlobalAttention (O/modules/GlobalAttention.py:112-116,152,160-162), one workgroup per batch row
 template <typename T>
 __global__ __launch_bounds__(NT) void gattn_fwd_kernel(const void* ctx_, const float* target, int S, int B, int H, float* attn,
@@ -84,10 +118,7 @@ __global__ __launch_bounds__(NT) void gattn_fwd_kernel(const void* ctx_, const f
   for (int j = tid; j < H; j += NT) s_t[j] = target[(size_t)b * H + j];
   __syncthreads();
   for (int s = wave; s < S; s += 4) {
-    const T* v = ctx + ((size_t)s * B + b) * H;
-    float p = 0.f;
-    for (int j = lane; j < H; j += 64) p += uic_to_f(v[j]) * s_t[j];
-    p = uic_wave_sum(p);
+    float p = row_dot<T>(ctx + ((size_t)s * B + b) * H, s_t, H, lane);
     // translator only: source padding is masked (GlobalAttention.applyMask, NMT_Models.py:345,352)
     if (mask_src && mask_src[(size_t)s * B + b] == 0) p = -INFINITY;
     if (lane == 0) s_a[s] = p;
@@ -105,11 +136,7 @@ __global__ __launch_bounds__(NT) void gattn_fwd_kernel(const void* ctx_, const f
     attn[(size_t)b * S + s] = a;
   }
   __syncthreads();
-  for (int j = lane; j < H; j += 64) {
-    float acc = 0.f;
-    for (int s = wave; s < S; s += 4) acc += s_a[s] * uic_to_f(ctx[((size_t)s * B + b) * H + j]);
-    s_red[wave * H + j] = acc;
-  }
+  weighted_rows<T>(ctx, s_a, S, B, H, b, lane, wave, s_red);
   __syncthreads();
   for (int j = tid; j < H; j += NT)
     cvec[(size_t)b * H + j] = uic_from_f<T>(s_red[j] + s_red[H + j] + s_red[2 * H + j] + s_red[3 * H + j]);
@@ -131,10 +158,7 @@ __global__ __launch_bounds__(NT) void gattn_bwd_step_kernel(const void* ctx_, co
   for (int s = tid; s < S; s += NT) s_a[s] = attn[(size_t)b * S + s];
   __syncthreads();
   for (int s = wave; s < S; s += 4) {
-    const T* v = ctx + ((size_t)s * B + b) * H;
-    float p = 0.f;
-    for (int j = lane; j < H; j += 64) p += uic_to_f(v[j]) * s_dc[j];
-    p = uic_wave_sum(p);
+    const float p = row_dot<T>(ctx + ((size_t)s * B + b) * H, s_dc, H, lane);
     if (lane == 0) s_da[s] = p;
   }
   __syncthreads();
@@ -147,11 +171,7 @@ __global__ __launch_bounds__(NT) void gattn_bwd_step_kernel(const void* ctx_, co
     dscore[(size_t)b * S + s] = ds;
   }
   __syncthreads();
-  for (int j = lane; j < H; j += 64) {
-    float acc = 0.f;
-    for (int s = wave; s < S; s += 4) acc += s_da[s] * uic_to_f(ctx[((size_t)s * B + b) * H + j]);
-    s_red[wave * H + j] = acc;
-  }
+  weighted_rows<T>(ctx, s_da, S, B, H, b, lane, wave, s_red);
   __syncthreads();
   for (int j = tid; j < H; j += NT)
     dtarget[(size_t)b * H + j] = uic_from_f<T>(s_red[j] + s_red[H + j] + s_red[2 * H + j] + s_red[3 * H + j]);
