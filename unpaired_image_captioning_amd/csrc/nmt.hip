@@ -352,7 +352,8 @@ struct NmtLayout {
   float* logits; void* dlogits; float* row_loss; float* scalars; int* stats;
   // backward
   float* d_out_all; float* dfeed; void* d_pre_all; float* d_cq_all; float* dscore_all; void* dtarget_all; float* dq;
-  float* dx_lstm; float* d_lay; float* dhrec_e; float* dc_e; float* dhrec_e1; float* dc_e1; float* dx_e; void* dpre_e; float* dxe; float* demb_d;
+  // dx_lstm[l]: d[x_l | h_l(t-1)] of decoder layer l > 0, one buffer per layer so that nothing has to be copied
+  float* dx_lstm[ML]; float* d_lay; float* dhrec_e; float* dc_e; float* dhrec_e1; float* dc_e1; float* dx_e; void* dpre_e; float* dxe; float* demb_d;
   void* tA; void* tB; float* colscratch; size_t colscratch_floats; float* slab; size_t slab_bytes;
   size_t total;
 };
@@ -429,7 +430,7 @@ NmtLayout nmt_layout(const uic_nmt_dims& d, const uic_nmt_weights* w, void* ws) 
   L.dscore_all = (float*)b.take(Td * B * S * 4);
   L.dtarget_all = b.take(Td * B * H * Sz);
   L.dq = (float*)b.take(B * H * 4);
-  L.dx_lstm = (float*)b.take(B * 2 * H * 4);
+  for (int l = 0; l < ML; ++l) L.dx_lstm[l] = (float*)b.take(B * 2 * H * 4);
   L.d_lay = (float*)b.take(S * B * H * 4);
   L.dhrec_e = (float*)b.take(B * Hd * 4);
   L.dc_e = (float*)b.take(B * Hd * 4);
@@ -753,10 +754,13 @@ struct Nmt {
         p.dtype = dt; p.M = B; p.H = H;
         if (l == NL - 1) { p.dh0 = d_cq + H; p.lddh0 = 2 * H; }
         else {                                               // gradient w.r.t. the dropped h of layer l (input of layer l+1)
-          p.dh0 = L.dx_lstm; p.lddh0 = 2 * H;
+          p.dh0 = L.dx_lstm[l + 1]; p.lddh0 = 2 * H;
           p.drop_p = drop_p; p.seed = seed; p.site = SITE_NMT_DEC(l, t);
         }
-        if (!last) { p.dh1 = L.dhrec_d[l]; p.lddh1 = H; }
+        if (!last) {       // d h_l(t) from step t + 1: layer 0 has its own buffer, layers > 0 read the second half of their dX
+          if (l == 0) { p.dh1 = L.dhrec_d[0]; p.lddh1 = H; }
+          else { p.dh1 = L.dx_lstm[l] + H; p.lddh1 = 2 * H; }
+        }
         p.dc = L.dcd[l]; p.gates = off(L.gates_d[l], (size_t)t * B * H4, dt);
         p.c_prev = L.cd[l] + (size_t)t * BH; p.c = L.cd[l] + (size_t)(t + 1) * BH;
         p.dgates = offw(L.dg_d[l], (size_t)t * B * H4, dt);
@@ -765,10 +769,8 @@ struct Nmt {
         if (l > 0) {   // d[x_l | h_l_prev] = dG [W_ih | W_hh]
           UicGemmParams g = gemm_base(dt, B, 2 * H);
           add_seg(g, p.dgates, H4, L.dec_wT[l], H4, H4);
-          g.C = L.dx_lstm; g.ldc = 2 * H; g.flags = UIC_GEMM_OUT_F32;
+          g.C = L.dx_lstm[l]; g.ldc = 2 * H; g.flags = UIC_GEMM_OUT_F32;
           UIC_TRY(uic_gemm_launch(g, s));
-          UIC_TRY(uic_check_hip(hipMemcpy2DAsync(L.dhrec_d[l], (size_t)H * 4, L.dx_lstm + H, (size_t)2 * H * 4, (size_t)H * 4, B,
-                                                 hipMemcpyDeviceToDevice, s), "memcpy2d dhrec"));
         } else {       // layer 0: d[feed | h_0_prev] = dG [W_ih[:, W:] | W_hh]  (the embedding part is batched below)
           UicGemmParams g = gemm_base(dt, B, H);
           add_seg(g, p.dgates, H4, off(L.dec_wT[0], (size_t)W * H4, dt), H4, H4);
@@ -829,7 +831,10 @@ struct Nmt {
         float* dcc = dd == 1 ? L.dc_e1 : L.dc_e;
         UIC_TRY(uic_fill_launch(L.dg_e[l][dd], 0, (size_t)Ms * 4 * Hd * Sz, sd));
         // carried dh / dc start from the decoder-initial-state gradient halves (rows join the BPTT when they become active)
-        UIC_TRY(uic_check_hip(hipMemcpy2DAsync(dhrec, (size_t)Hd * 4, L.dhrec_d[l] + dd * Hd, (size_t)H * 4, (size_t)Hd * 4, B,
+        // (d h_l(-1) of decoder layers > 0 sits in the second half of that layer's last dX)
+        const float* dh_init = l == 0 ? L.dhrec_d[0] : L.dx_lstm[l] + H;
+        const size_t dh_pitch = (size_t)(l == 0 ? H : 2 * H) * 4;
+        UIC_TRY(uic_check_hip(hipMemcpy2DAsync(dhrec, (size_t)Hd * 4, dh_init + dd * Hd, dh_pitch, (size_t)Hd * 4, B,
                                                hipMemcpyDeviceToDevice, sd), "memcpy2d dh0"));
         UIC_TRY(uic_check_hip(hipMemcpy2DAsync(dcc, (size_t)Hd * 4, L.dcd[l] + dd * Hd, (size_t)H * 4, (size_t)Hd * 4, B,
                                                hipMemcpyDeviceToDevice, sd), "memcpy2d dc0"));
