@@ -240,6 +240,7 @@ __global__ __launch_bounds__(64 * WM * WN * KS) void uic_gemm_kernel(const UicGe
               const int n = row / p.R;
               if (row - n * p.R >= p.row_len[n]) v = 0.f;
             }
+            if (p.C_pre) ((T*)p.C_pre)[(size_t)row * p.ldc_pre + col] = uic_from_f<T>(v);
             if (p.drop_p > 0.f) v *= uic_drop_scale(p.seed, p.site, (unsigned)(row + p.drop_row0) * (unsigned)p.N + (unsigned)col, p.drop_p, inv_keep);
             const size_t o = (size_t)row * p.ldc + col;
             if (out_f32) {
@@ -590,7 +591,7 @@ int launch_typed(const UicGemmParams& p, hipStream_t s) {
     UIC_REQUIRE(glds_ok && !p.lstm, "gemm: slab output needs one K segment that is a multiple of 128 bytes");
     return launch_glds<T>(p, s);
   }
-  if (blocks128 >= 200 && glds_ok) return launch_glds<T>(p, s);
+  if (blocks128 >= 200 && glds_ok && !p.C_pre) return launch_glds<T>(p, s);
   if (blocks128 >= 200) return launch_cfg<T, 2, 2, 2, 2, 1, false>(p, s);
   return launch_cfg<T, 1, 1, 2, 2, 4, false>(p, s);
 }

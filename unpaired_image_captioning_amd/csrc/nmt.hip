@@ -664,16 +664,13 @@ struct Nmt {
         UicGemmParams g = gemm_base(dt, B, H);
         add_seg(g, off(L.cvec_all, (size_t)t * BH, dt), H, L.attn_out_w, 2 * H, H);
         add_seg(g, q, H, off(L.attn_out_w, H, dt), 2 * H, H);
-        g.C = offw(L.out_pre, (size_t)t * BH, dt); g.ldc = H; g.flags = UIC_GEMM_TANH;
+        // output = dropout(attn_output) = next step's input feed (NMT_Models.py:258-259): the epilogue writes both the
+        // tanh output (kept for the backward pass) and its dropped copy
+        g.C_pre = offw(L.out_pre, (size_t)t * BH, dt); g.ldc_pre = H;
+        g.C = offw(L.out_all, (size_t)(t + 1) * BH, dt); g.ldc = H; g.flags = UIC_GEMM_TANH;
+        g.drop_p = drop_p; g.seed = seed; g.site = SITE_NMT_OUT(t);
         UIC_TRY(uic_gemm_launch(g, s));
       }
-      // output = dropout(attn_output) = next step's input feed (NMT_Models.py:258-259)
-      if (drop_p > 0.f)
-        NMT_T(dropout_apply_kernel, gridn(BH), 0, (const void*)off(L.out_pre, (size_t)t * BH, dt),
-              (void*)offw(L.out_all, (size_t)(t + 1) * BH, dt), BH, drop_p, seed, SITE_NMT_OUT(t));
-      else
-        UIC_TRY(uic_check_hip(hipMemcpyAsync(offw(L.out_all, (size_t)(t + 1) * BH, dt), off(L.out_pre, (size_t)t * BH, dt), BH * Sz,
-                                             hipMemcpyDeviceToDevice, s), "memcpy out"));
     }
     return UIC_OK;
   }

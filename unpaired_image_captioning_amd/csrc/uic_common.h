@@ -167,6 +167,7 @@ struct UicGemmParams {
   // dropout applied after ReLU
   float drop_p; unsigned seed; unsigned site;
   int drop_row0;            // the dropout element index of C[row, col] is (row + drop_row0) * N + col
+  void* C_pre; int ldc_pre; // optional (skinny path, operand dtype): the value BEFORE dropout goes here, C gets the dropped one
   // ---- fused LSTM cell epilogue (N must be 4*H) ----
   int lstm; int H;
   const float* pre1; int ldpre1;   // [M,4H] added to the gate pre-activations (may be null)
