@@ -32,7 +32,8 @@ int uic_version(void);
 typedef struct uic_topdown_dims {
   int32_t N;        /* caption rows = batch_size * seq_per_img (P/misc/dataloader/dataloader.py:231) */
   int32_t R;        /* regions per image (att_feats.size(1)) */
-  int32_t D;        /* att_feat_size */
+  int32_t D;        /* att_feat_size; a multiple of 8 -- for 2048 + 5 box features pad feature rows and the columns of
+                     * att_embed's Linear / BatchNorm with zeros (exact; the Python engine does it) */
   int32_t Dfc;      /* fc_feat_size */
   int32_t H;        /* rnn_size */
   int32_t E;        /* input_encoding_size */

@@ -32,6 +32,7 @@ def load_golden(name):
         t = torch.from_numpy(z[k])
         {"w": W, "in": I, "out": O, "grad": G}.get(kind, X)[key if kind in ("w", "in", "out", "grad") else k] = t
     cfg["logit_layers"] = int(X.pop("logit_layers", 1))
+    cfg["Dfc"] = int(X.pop("fc_feat_size", cfg["D"]))
     return cfg, W, I, O, G, X
 
 

@@ -60,9 +60,9 @@ def _load_reference():
     return att, crit
 
 
-def make_opt(V, E, H, A, D, L, use_bn=0, drop=0.0, logit_layers=1):
+def make_opt(V, E, H, A, D, L, use_bn=0, drop=0.0, logit_layers=1, Dfc=None):
     return _argparse.Namespace(vocab_size=V, input_encoding_size=E, rnn_size=H, num_layers=1,
-                               drop_prob_lm=drop, seq_length=L, fc_feat_size=D, att_feat_size=D,
+                               drop_prob_lm=drop, seq_length=L, fc_feat_size=Dfc or D, att_feat_size=D,
                                att_hid_size=A, use_bn=use_bn, logit_layers=logit_layers, caption_model="topdown")
 
 
@@ -74,13 +74,13 @@ def synth(n_img, S, R, D, V, L, seed, ragged):
 
 def run_case(att_mod, crit_mod, name, V, E, H, A, D, L, n_img, S, R, seed, ragged=False,
              use_masks=True, use_bn=0, short_all=False, adam_steps=0, store_grads=True,
-             bn_train=False, ss_prob=0.0, ss_seed=0, logit_layers=1):
+             bn_train=False, ss_prob=0.0, ss_seed=0, logit_layers=1, Dfc=None):
     import builtins
     import functools
     builtins.reduce = functools.reduce                                  # AttModel.py:91 and CaptionModel.py:176 are py2
     att_mod.reduce = functools.reduce
     torch.manual_seed(seed)
-    opt = make_opt(V, E, H, A, D, L, use_bn=use_bn, logit_layers=logit_layers)
+    opt = make_opt(V, E, H, A, D, L, use_bn=use_bn, logit_layers=logit_layers, Dfc=Dfc)
     model = att_mod.TopDownModel(opt)
     final_logit = model.logit if logit_layers == 1 else model.logit[-1]
     if use_bn:
@@ -101,6 +101,8 @@ def run_case(att_mod, crit_mod, name, V, E, H, A, D, L, n_img, S, R, seed, ragge
         nz = (b["labels"] != 0).sum(1) + 2
         b["masks"] = (torch.arange(L + 2)[None, :] < nz[:, None]).float()
     fc, att, labels, masks = b["fc_feats"], b["att_feats"], b["labels"], b["masks"]
+    if Dfc:
+        fc = fc[:, :Dfc].contiguous()               # fc_feat_size != att_feat_size (box features widen only the region features)
     att_masks = b["att_masks"] if use_masks else None
     out = {}
     for k, v in model.state_dict().items():
@@ -114,6 +116,8 @@ def run_case(att_mod, crit_mod, name, V, E, H, A, D, L, n_img, S, R, seed, ragge
     out["cfg"] = np.array([V, E, H, A, D, L, n_img, S, R, use_bn, int(bn_train)], dtype=np.int64)
     if logit_layers != 1:
         out["logit_layers"] = np.array(logit_layers, dtype=np.int64)
+    if Dfc:
+        out["fc_feat_size"] = np.array(Dfc, dtype=np.int64)
 
     model.train(bool(bn_train))      # drop_prob_lm = 0 -> dropout is the identity either way
     attri = torch.zeros(fc.shape[0], 1)
@@ -322,6 +326,11 @@ def main():
     # logit_layers > 1 (AttModel.py:86-91): eval mode, so the hard-coded Dropout(0.5) of the hidden blocks is the identity
     run_case(att_mod, crit_mod, "topdown_tiny_logit2", seed=19, ragged=True, logit_layers=2, **tiny)
     run_case(att_mod, crit_mod, "topdown_tiny_logit3_bn1", seed=20, ragged=True, logit_layers=3, use_bn=1, **tiny)
+    # use_box = 1 (the reference's default, P/opts.py:80): 5 box features widen the region features, att_feat_size is no
+    # multiple of 8 any more; with the default use_bn = 1 (train-mode statistics) and without BatchNorm
+    box = dict(tiny, D=69)
+    run_case(att_mod, crit_mod, "topdown_tiny_box_bn1", seed=31, ragged=True, use_bn=1, bn_train=True, Dfc=64, **box)
+    run_case(att_mod, crit_mod, "topdown_tiny_box", seed=32, ragged=True, Dfc=64, **box)
     # non-power-of-two / odd sizes (E != H != A, V1 not a tile multiple)
     run_case(att_mod, crit_mod, "topdown_odd", seed=17, V=77, E=24, H=40, A=48, D=72, L=5,
              n_img=2, S=3, R=7, ragged=True)

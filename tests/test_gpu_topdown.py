@@ -13,14 +13,14 @@ from oracle import topdown as O
 
 pytestmark = pytest.mark.gpu
 
-FIXTURES = ["topdown_tiny", "topdown_tiny_ragged", "topdown_tiny_nomask", "topdown_tiny_earlybreak", "topdown_odd", "topdown_tiny_logit2"]
+FIXTURES = ["topdown_tiny", "topdown_tiny_ragged", "topdown_tiny_nomask", "topdown_tiny_earlybreak", "topdown_odd", "topdown_tiny_logit2", "topdown_tiny_box"]
 LOGP_TOL = {"f32": 1e-3, "bf16": 1e-2}
 GRAD_TOL = {"f32": 2e-3, "bf16": 1e-1}      # f32: max-entry error; bf16: L2 error (see grads_close)
 
 
 def make_opt(cfg, dtype, drop=0.0, seed=0):
     return argparse.Namespace(vocab_size=cfg["V"], input_encoding_size=cfg["E"], rnn_size=cfg["H"], num_layers=1,
-                              drop_prob_lm=drop, seq_length=cfg["L"], fc_feat_size=cfg["D"], att_feat_size=cfg["D"],
+                              drop_prob_lm=drop, seq_length=cfg["L"], fc_feat_size=cfg.get("Dfc", cfg["D"]), att_feat_size=cfg["D"],
                               att_hid_size=cfg["A"], use_bn=cfg.get("use_bn", 0), logit_layers=cfg.get("logit_layers", 1), caption_model="topdown",
                               compute_dtype=dtype, seed=seed)
 
@@ -412,7 +412,7 @@ def test_full_size_properties_bf16():
 
 
 # ---------------------------------------------------------------- opt.use_bn (reference default 1, P/opts.py:52)
-BN_FIXTURES = ["topdown_tiny_bn1_eval", "topdown_tiny_bn2_train", "topdown_tiny_logit3_bn1"]
+BN_FIXTURES = ["topdown_tiny_bn1_eval", "topdown_tiny_bn2_train", "topdown_tiny_logit3_bn1", "topdown_tiny_box_bn1"]
 
 
 @pytest.mark.parametrize("dtype", ["f32", "bf16"])
@@ -444,7 +444,7 @@ def test_use_bn_forward_backward_and_running_stats_vs_reference_golden(name, dty
             assert (got - ref).abs().max().item() <= tol * max(1.0, ref.abs().max().item()), key
             assert not torch.equal(ref, W[key].double())          # the fixture really moved them
             n_stats += 1
-    assert n_stats == (6 if cfg["bn_train"] else 0)
+    assert n_stats == (3 * cfg["use_bn"] if cfg["bn_train"] else 0)       # running_mean, running_var, num_batches_tracked per BatchNorm
     if dtype == "f32":
         model.eval()
         idx = torch.arange(cfg["n_img"]) * cfg["S"]
@@ -795,6 +795,10 @@ def _sweep_configs(n, seed):
                         use_bn=int(g.integers(0, 3)), per_image=bool(g.integers(0, 2)), drop=bool(g.integers(0, 2)), idx=i))
     for c in out:                                                    # (drawn afterwards so that the shapes above stay as they were)
         c["logit_layers"] = int(g.integers(1, 4))
+    for c in out:                # att_feat_size off the multiples of 8 (box features): fc_feat_size keeps the old value
+        c["Dfc"] = c["D"]
+        if g.integers(0, 3) == 0:
+            c["D"] += int(g.integers(1, 8))
     return out
 
 
@@ -819,6 +823,7 @@ def test_random_shape_sweep_vs_oracle(cfg):
     W = {k: v.detach().clone() for k, v in model.state_dict().items()}
     model.cuda().train()
     b = O.synthetic_batch(cfg["n_img"], cfg["S"], cfg["R"], cfg["D"], cfg["V"], cfg["L"], seed=cfg["idx"], ragged_regions=cfg["R"] > 1)
+    b["fc_feats"] = b["fc_feats"][:, :cfg["Dfc"]].contiguous()
     full = {k: v.cuda() for k, v in b.items()}
     batch = _per_image(full, cfg["S"]) if cfg["per_image"] and cfg["S"] > 1 else full
     loss, grads, seed = xe_step(model, batch, return_seed=True)
@@ -895,6 +900,7 @@ def test_decode_paths_random_sweep_vs_oracle(cfg):
     W = {k: v.detach().clone() for k, v in model.state_dict().items()}
     model.cuda().eval()
     b = O.synthetic_batch(cfg["n_img"], 1, cfg["R"], cfg["D"], cfg["V"], cfg["L"], seed=cfg["idx"], ragged_regions=cfg["R"] > 1)
+    b["fc_feats"] = b["fc_feats"][:, :cfg["Dfc"]].contiguous()
     fc, att, am = b["fc_feats"].cuda(), b["att_feats"].cuda(), b["att_masks"].cuda()
     ub = cfg["use_bn"]
     dc = cfg["idx"] % 2

@@ -8,7 +8,8 @@ from conftest import load_golden
 from oracle import topdown as O
 
 TINY = ["topdown_tiny", "topdown_tiny_ragged", "topdown_tiny_nomask", "topdown_tiny_earlybreak",
-        "topdown_tiny_bn1_eval", "topdown_tiny_bn2_train", "topdown_odd", "topdown_tiny_logit2", "topdown_tiny_logit3_bn1"]
+        "topdown_tiny_bn1_eval", "topdown_tiny_bn2_train", "topdown_odd", "topdown_tiny_logit2", "topdown_tiny_logit3_bn1",
+        "topdown_tiny_box", "topdown_tiny_box_bn1"]
 TOL = 2e-6
 
 

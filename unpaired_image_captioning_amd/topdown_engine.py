@@ -28,6 +28,11 @@ class TopDownEngine(object):
         self.buffers = {}
         self.lib = _lib.load()
         self.sizes = dict(sizes)
+        # att_feat_size that is not a multiple of 8 (2048 + 5 box features with the reference's default use_box = 1): the
+        # library works on zero-padded feature rows / weight columns, which is exact (see _pad_for_library)
+        self.D = int(self.sizes["D"])
+        self.Dp = (self.D + 7) // 8 * 8
+        self.sizes["D"] = self.Dp
         self.dtype = _lib.dtype_id(dtype)
         self.drop_p = float(drop_p)
         self._derived = None
@@ -68,17 +73,57 @@ class TopDownEngine(object):
     def release(self, ws):
         self._pool.setdefault(self._key(ws.dims), []).append(ws)
 
-    def weights_struct(self, tensors):
-        """tensors: dict reference-state_dict-key -> contiguous f32 device tensor."""
+    # ---- att_feat_size % 8 != 0: zero feature columns meet zero weight columns, a BatchNorm over an all-zero column gives
+    # xhat = 0 (mean 0, var 0), so padded results and gradients equal the unpadded ones; the padded columns of every
+    # output (gradients, running statistics) are dropped on the way back
+    _PAD_FILL = {"weight": 1.0, "bias": 0.0, "running_mean": 0.0, "running_var": 1.0}
+
+    def _pad_for_library(self, key, t, as_output):
+        """Padded stand-in of tensor `key` when it has an att_feat_size axis, else None."""
+        if self.Dp == self.D:
+            return None
+        lin = "att_embed.1.weight" if self.use_bn else "att_embed.0.weight"
+        if key == lin:
+            tmp = t.new_zeros(t.shape[0], self.Dp)
+        elif self.use_bn and key.startswith("att_embed.0."):
+            tmp = t.new_full((self.Dp,), 0.0 if as_output else self._PAD_FILL[key.rsplit(".", 1)[1]])
+        else:
+            return None
+        if not as_output:
+            tmp[..., :self.D].copy_(t)
+        return tmp
+
+    def _pad_att(self, att):
+        if att is None or self.Dp == self.D:
+            return att
+        if att.shape[-1] != self.D:
+            raise ValueError("att_feats have %d columns, the model was built for att_feat_size=%d" % (att.shape[-1], self.D))
+        return torch.nn.functional.pad(att, (0, self.Dp - self.D)).contiguous()
+
+    def _write_back(self, w):
+        """Copy what the library wrote into padded stand-ins (gradients, BatchNorm running statistics) to the real tensors."""
+        for tmp, orig in getattr(w, "_writeback", ()):
+            orig.copy_(tmp[..., :self.D])
+
+    def weights_struct(self, tensors, outputs=False):
+        """tensors: dict reference-state_dict-key -> contiguous f32 device tensor.  outputs: the struct will be WRITTEN by
+        the library (a gradient struct): padded stand-ins start as zeros and are copied back by _write_back."""
         w = Weights()
+        w._keep, w._writeback = [], []
         for field, key, is_param in weight_fields(self.use_bn, self.logit_layers):
-            t = tensors.get(key) if is_param else tensors.get(key, self.buffers.get(key))
+            t = tensors.get(key) if (is_param or outputs) else tensors.get(key, self.buffers.get(key))
             if t is None:
                 if is_param:
                     raise KeyError(key)
                 continue                      # gradient structs carry no running statistics
             if t.dtype != torch.float32:
                 raise RuntimeError("parameter %s must be float32, got %s" % (key, t.dtype))
+            tmp = self._pad_for_library(key, t, outputs)
+            if tmp is not None:
+                w._keep.append(tmp)
+                if outputs or not is_param:   # gradients; running statistics (updated in place by a train-mode forward)
+                    w._writeback.append((tmp, t))
+                t = tmp
             if ":" in field:                  # element of a pointer array (hidden logit blocks)
                 name, idx = field.split(":")
                 getattr(w, name)[int(idx)] = ptr(t)
@@ -96,9 +141,10 @@ class TopDownEngine(object):
         check(self.lib.uic_topdown_refresh_weights(C.byref(d), C.byref(w), ptr(self._derived), stream()), "refresh_weights")
         return w
 
-    @staticmethod
-    def batch_struct(fc, att, att_masks, labels=None, masks=None, grad_scale=None, ss_prob=0.0):
+    def batch_struct(self, fc, att, att_masks, labels=None, masks=None, grad_scale=None, ss_prob=0.0):
         b = Batch()
+        att = self._pad_att(att)
+        b._keep = att                          # (a padded copy must outlive the call)
         b.fc_feats = ptr(fc)
         b.att_feats = ptr(att)
         b.att_masks = ptr(att_masks)
@@ -122,6 +168,7 @@ class TopDownEngine(object):
         logp = torch.zeros(N, T, d.V1, dtype=torch.float32, device=fc.device) if want_logprobs else None
         check(self.lib.uic_topdown_forward(C.byref(d), C.byref(w), ptr(self._derived), C.byref(b), t_run,
                                            int(training), seed & 0xFFFFFFFF, ptr(ws.buf), ptr(logp), stream()), "forward")
+        self._write_back(w)
         return logp, ws, (d, w, b)
 
     def xe_loss(self, ws, d, b, t_run, inv_den=None):
@@ -131,10 +178,11 @@ class TopDownEngine(object):
         return out            # [loss, sum(mask)]
 
     def backward(self, ws, d, w, b, t_run, training, seed, grads, dlogprobs=None, logprobs=None):
-        g = self.weights_struct(grads)
+        g = self.weights_struct(grads, outputs=True)
         check(self.lib.uic_topdown_backward(C.byref(d), C.byref(w), ptr(self._derived), C.byref(b), t_run, int(training),
                                             seed & 0xFFFFFFFF, ptr(ws.buf), ptr(dlogprobs), ptr(logprobs), C.byref(g),
                                             stream()), "backward")
+        self._write_back(g)
 
     def xe_train_step(self, params, fc, att, att_masks, labels, masks, t_run, training, seed, grads, inv_den=None,
                       grad_scale=None, ss_prob=0.0, keep_workspace=False):
@@ -145,13 +193,15 @@ class TopDownEngine(object):
         w = self.refresh(params, d)
         ws = self.checkout(d, fc.device)
         b = self.batch_struct(fc, att, att_masks, labels, masks, grad_scale, ss_prob)
-        g = self.weights_struct(grads)
+        g = self.weights_struct(grads, outputs=True)
         out = torch.empty(2, dtype=torch.float32, device=fc.device)
         try:
             check(self.lib.uic_topdown_xe_train_step(C.byref(d), C.byref(w), ptr(self._derived), C.byref(b), t_run,
                                                      int(training), seed & 0xFFFFFFFF, ptr(ws.buf), ptr(inv_den),
                                                      out.data_ptr(), out.data_ptr() + 4, C.byref(g), stream()),
                   "xe_train_step")
+            self._write_back(w)
+            self._write_back(g)
         finally:
             if not keep_workspace:
                 self.release(ws)
@@ -173,6 +223,7 @@ class TopDownEngine(object):
             check(self.lib.uic_topdown_sample(C.byref(d), C.byref(w), ptr(self._derived), C.byref(b), L, int(sample_max),
                                               float(temperature), int(decoding_constraint), seed & 0xFFFFFFFF, ptr(forced),
                                               int(training), ptr(ws.buf), ptr(seq), ptr(lp), stream()), "sample")
+            self._write_back(w)
         finally:
             self.release(ws)
         return seq, lp
