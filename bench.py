@@ -31,10 +31,10 @@ HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 CFG = dict(V=9487, E=512, H=512, A=512, D=2048, L=16, R=36, n_img=128, S=5)
 
 
-def make_opt(dtype, seed, use_bn=0):
+def make_opt(dtype, seed, use_bn=0, att_feat_size=None):
     c = CFG
     return argparse.Namespace(vocab_size=c["V"], input_encoding_size=c["E"], rnn_size=c["H"], num_layers=1,
-                              drop_prob_lm=0.5, seq_length=c["L"], fc_feat_size=c["D"], att_feat_size=c["D"],
+                              drop_prob_lm=0.5, seq_length=c["L"], fc_feat_size=c["D"], att_feat_size=att_feat_size or c["D"],
                               att_hid_size=c["A"], use_bn=use_bn, logit_layers=1, caption_model="topdown",
                               compute_dtype=dtype, seed=seed, i2t_learning_rate=5e-4, i2t_train_flag=1, seq_per_img=c["S"])
 
@@ -138,6 +138,9 @@ def main():
     ap.add_argument("--features", default="per-caption", choices=["per-caption", "per-image"],
                     help="per-caption: the reference's batch dict (features replicated seq_per_img times, the headline); "
                          "per-image: features once per image, replication on the device")
+    ap.add_argument("--att-feat-size", type=int, default=0,
+                    help="region feature width (secondary measurement): 2053 = 2048 + 5 box features, the reference's default "
+                         "use_box=1; the metric is quoted at 2048")
     ap.add_argument("--use-bn", type=int, default=0, help="opt.use_bn of the captioner (secondary measurement; the metric is quoted at 0)")
     ap.add_argument("--cpu-threads", type=int, default=0, help="threads for the CPU oracle leg (0: min(host cores, 16), the fastest setting measured on the GPU box's 256-thread host: 8->293, 16->379, 32->211, 64->110, 128->24 captions/s)")
     args = ap.parse_args()
@@ -161,9 +164,11 @@ def main():
 
     c = CFG
     torch.manual_seed(1234)                                    # identical initial weights on every rank
-    tr = Trainer(make_opt(args.dtype, 1234 + rank, args.use_bn))
+    Datt = args.att_feat_size or c["D"]
+    tr = Trainer(make_opt(args.dtype, 1234 + rank, args.use_bn, Datt))
     tr.build_optimizer()
-    batch = synthetic_batch(c["n_img"], c["S"], c["R"], c["D"], c["V"], c["L"], seed=1234 + rank)
+    batch = synthetic_batch(c["n_img"], c["S"], c["R"], Datt, c["V"], c["L"], seed=1234 + rank)
+    batch["fc_feats"] = batch["fc_feats"][:, :c["D"]].contiguous()
     N = c["n_img"] * c["S"]
     T = c["L"] + 1
     t_run = tr.i2t_model._steps_to_run(batch["labels"])
@@ -220,7 +225,7 @@ def main():
             "data": "synthetic" if not share else "synthetic (UIC_BENCH_SHARE_GPU functional test: ranks share one GPU, gloo; NOT a measurement)",
             "config": {"workload": "BASELINE configs[1]: TopDown attention LSTM, 128 images x 5 captions = 640 caption "
                                    "rows per GPU, R=36, D=2048, H=E=A=512, V+1=9488, 17 decode steps, dropout 0.5, "
-                                   "XE loss + BPTT + Adam", "rows_per_gpu": N, "parallelism": "dp%d" % world, "use_bn": args.use_bn,
+                                   "XE loss + BPTT + Adam", "rows_per_gpu": N, "parallelism": "dp%d" % world, "use_bn": args.use_bn, "att_feat_size": Datt,
                        "features": args.features},
             "final_loss": round(loss_val, 4),
             "roofline": attention_roofline(dtype_id, args.dtype),

@@ -31,7 +31,8 @@ class TopDownEngine(object):
         # att_feat_size that is not a multiple of 8 (2048 + 5 box features with the reference's default use_box = 1): the
         # library works on zero-padded feature rows / weight columns, which is exact (see _pad_for_library)
         self.D = int(self.sizes["D"])
-        self.Dp = (self.D + 7) // 8 * 8
+        # (padded to a multiple of 128, not just 8, so that the LDS-DMA and transposing-read GEMMs stay eligible)
+        self.Dp = self.D if self.D % 8 == 0 else (self.D + 127) // 128 * 128
         self.sizes["D"] = self.Dp
         self.dtype = _lib.dtype_id(dtype)
         self.drop_p = float(drop_p)
