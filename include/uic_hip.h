@@ -48,8 +48,8 @@ typedef struct uic_topdown_dims {
                      * reference does on the host (P/misc/dataloader/dataloader.py:270-277).  S > 1 (must divide N): the
                      * batch carries fc_feats / att_feats / att_masks once per IMAGE ([N/S, ...]); caption row n uses image
                      * n / S.  Results are those of the S-fold replicated batch (same dropout masks per caption row); the
-                     * att_embed Linear and its weight gradient then run on N/S * R rows instead of N * R (use_bn = 0;
-                     * with BatchNorm the input is replicated on the device first). */
+                     * att_embed [BatchNorm +] Linear and its weight gradient then run on N/S * R rows instead of N * R
+                     * (batch statistics: every image row counts S times). */
   int32_t logit_layers; /* opt.logit_layers (P/models/AttModel.py:86-91): 0 or 1 = logit is one Linear(H, V1); n > 1 (at most
                      * UIC_MAX_LOGIT_LAYERS) = n - 1 blocks Linear(H, H) + ReLU + Dropout(0.5) in front of it (the 0.5 is
                      * hard-coded in the reference and active in train mode whatever drop_p is). */

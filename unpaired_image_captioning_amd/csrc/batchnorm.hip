@@ -79,8 +79,10 @@ __device__ __forceinline__ void chan_merge(float& n, float& mean, float& M2, flo
   M2 += m2b + dlt * dlt * (n * nb / nt);
   n = nt;
 }
+// `rep`: every row stands for `rep` identical rows (features given once per image, seq_per_img caption rows each): mean and
+// biased variance are unchanged, the unbiased variance of the running statistics becomes rep*M2 / (rep*n - 1).
 __global__ __launch_bounds__(NT) void bn_stats_final_kernel(const float* __restrict__ part, int nchunks, int C, float momentum, float eps,
-                                                            float* __restrict__ stat, float* run_mean, float* run_var) {
+                                                            float* __restrict__ stat, float* run_mean, float* run_var, float rep) {
   __shared__ float s_n[4][64], s_m[4][64], s_q[4][64];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int c = blockIdx.x * 64 + lane;
@@ -96,7 +98,7 @@ __global__ __launch_bounds__(NT) void bn_stats_final_kernel(const float* __restr
   stat[c] = mean;
   stat[C + c] = rsqrtf(var + eps);
   if (run_mean) run_mean[c] = (1.f - momentum) * run_mean[c] + momentum * mean;
-  if (run_var) run_var[c] = (1.f - momentum) * run_var[c] + momentum * (n > 1.f ? M2 / (n - 1.f) : var);
+  if (run_var) run_var[c] = (1.f - momentum) * run_var[c] + momentum * (n * rep > 1.f ? M2 * rep / (n * rep - 1.f) : var);
 }
 
 __global__ void bn_stats_running_kernel(const float* __restrict__ rm, const float* __restrict__ rv, int C, float eps,
@@ -286,8 +288,8 @@ size_t uic_bn_scratch_floats(int NR, int C) {
 }
 
 int uic_bn_stats_launch(int in_dtype, const void* x, int NR, int R, int C, const int* row_len, float* part, float momentum,
-                        float eps, float* stat, float* run_mean, float* run_var, hipStream_t s) {
-  UIC_REQUIRE(x && part && stat && C % 4 == 0, "bn_stats: bad arguments (C=%d)", C);
+                        float eps, float* stat, float* run_mean, float* run_var, hipStream_t s, float rep) {
+  UIC_REQUIRE(x && part && stat && C % 4 == 0 && rep >= 1.f, "bn_stats: bad arguments (C=%d)", C);
   int rpc;
   const int nch = chunks_for(NR, &rpc);
   const dim3 grid((C / 4 + NT - 1) / NT, nch);
@@ -296,7 +298,7 @@ int uic_bn_stats_launch(int in_dtype, const void* x, int NR, int R, int C, const
   else
     hipLaunchKernelGGL(bn_stats_part_kernel<float>, grid, dim3(NT), 0, s, (const float*)x, NR, R, C, row_len, rpc, part);
   UIC_LAUNCH_CHECK("bn_stats_part");
-  hipLaunchKernelGGL(bn_stats_final_kernel, dim3((C + 63) / 64), dim3(NT), 0, s, part, nch, C, momentum, eps, stat, run_mean, run_var);
+  hipLaunchKernelGGL(bn_stats_final_kernel, dim3((C + 63) / 64), dim3(NT), 0, s, part, nch, C, momentum, eps, stat, run_mean, run_var, rep);
   UIC_LAUNCH_CHECK("bn_stats_final");
   return UIC_OK;
 }

@@ -24,7 +24,7 @@ constexpr int WG_CHUNK = 4;   // decode steps per hand-off between the two strea
 struct Layout {
   // forward activations
   void* fcT; void* attT; int* row_len;
-  float* ypre; float* amask_rep; float* att_rep;   // seq_per_img > 1: per-image relu(att_embed) (f32), att_masks / att_feats per caption row
+  float* ypre; float* amask_rep; int* row_len_rep;   // seq_per_img > 1: per-image relu(att_embed) (f32), att_masks / region counts per caption row
   void* fcp; void* attp; void* patt;
   void* ybn; float* bn_stat0; float* bn_stat4; float* bn_part; float* bn_red;   // use_bn: pre-BN4 activations, {mean, rstd}, scratch
   void* xt_all; float* gx; float* gfc;
@@ -68,8 +68,8 @@ Layout make_layout(const uic_topdown_dims& d, void* ws) {
   L.row_len = (int*)b.take(N * sizeof(int));
   if (d.seq_per_img > 1) {
     L.amask_rep = (float*)b.take(NR * 4);
-    if (d.use_bn) L.att_rep = (float*)b.take(NR * D * 4);          // BatchNorm path: replicate the input, then as S = 1
-    else L.ypre = (float*)b.take(N / d.seq_per_img * R * H * 4);
+    L.row_len_rep = (int*)b.take(N * sizeof(int));
+    L.ypre = (float*)b.take(N / d.seq_per_img * R * H * 4);
   }
   L.fcp = b.take(N * H * S);
   L.attp = b.take(NR * H * S);
@@ -281,25 +281,25 @@ int prepare_features(const uic_topdown_dims& d, const uic_topdown_weights* w, co
   const bool bn_train = (training & 1) != 0, bn_update = bn_train && !(training & 2);
   // seq_per_img = S > 1: fc_feats / att_feats / att_masks hold one row per IMAGE; caption row n belongs to image n / S
   const int S = d.seq_per_img > 1 ? d.seq_per_img : 1, Ni = N / S;
-  const bool fold = S > 1 && !d.use_bn;     // att_embed's Linear runs once per image; dropout is applied per caption row
+  const bool fold = S > 1;                  // att_embed's [BatchNorm +] Linear runs once per image; dropout is applied per caption row
   const float* att_src = b->att_feats;
   const float* amask = b->att_masks;        // per caption row
-  if (S > 1 && b->att_masks) {
-    UIC_TRY(uic_expand_rows_launch(UIC_F32, b->att_masks, L.amask_rep, Ni, S, (size_t)R, s));
-    amask = L.amask_rep;
+  const int Na = fold ? Ni : N;             // rows of att_src
+  const int* row_len = b->att_masks ? L.row_len : nullptr;          // per row of att_src
+  const int* row_len_cap = row_len;                                 // per caption row
+  if (b->att_masks) {
+    hipLaunchKernelGGL(rowlen_kernel, dim3((Na + 255) / 256), dim3(256), 0, s, b->att_masks, Na, R, L.row_len);
+    UIC_LAUNCH_CHECK("rowlen_kernel");
+    if (fold) {
+      UIC_TRY(uic_expand_rows_launch(UIC_F32, b->att_masks, L.amask_rep, Ni, S, (size_t)R, s));
+      amask = L.amask_rep;
+      hipLaunchKernelGGL(rowlen_kernel, dim3((N + 255) / 256), dim3(256), 0, s, amask, N, R, L.row_len_rep);
+      UIC_LAUNCH_CHECK("rowlen_kernel");
+      row_len_cap = L.row_len_rep;
+    }
   }
-  if (S > 1 && d.use_bn) {                  // batch statistics are defined over the replicated rows: replicate, then as S = 1
-    UIC_TRY(uic_expand_rows_launch(UIC_F32, b->att_feats, L.att_rep, Ni, S, (size_t)R * d.D, s));
-    att_src = L.att_rep;
-  }
-  const int* row_len = b->att_masks ? L.row_len : nullptr;
   const void* fc_in = b->fc_feats;
   const void* att_in = att_src;
-  if (b->att_masks) {
-    const int rows = fold ? Ni : N;
-    hipLaunchKernelGGL(rowlen_kernel, dim3((rows + 255) / 256), dim3(256), 0, s, fold ? b->att_masks : amask, rows, R, L.row_len);
-    UIC_LAUNCH_CHECK("rowlen_kernel");
-  }
   if (S > 1) {
     UIC_TRY(uic_expand_rows_launch(dt, b->fc_feats, L.fcT, Ni, S, (size_t)d.Dfc, s));
     fc_in = L.fcT;
@@ -307,15 +307,15 @@ int prepare_features(const uic_topdown_dims& d, const uic_topdown_weights* w, co
     UIC_TRY(uic_cast_f32_launch(dt, b->fc_feats, L.fcT, (size_t)N * d.Dfc, s));
     fc_in = L.fcT;
   }
-  const int Na = fold ? Ni : N;             // rows of att_src
   if (d.use_bn) {
-    // BatchNorm1d(D) over the packed live regions; xhat goes to the GEMM, the affine part lives in W' / b'
+    // BatchNorm1d(D) over the packed live regions; xhat goes to the GEMM, the affine part lives in W' / b'.  Features given
+    // once per image stand for S identical caption rows each: same mean / biased variance, `rep` fixes the unbiased one.
     if (bn_train)
-      UIC_TRY(uic_bn_stats_launch(UIC_F32, att_src, N * R, R, d.D, row_len, L.bn_part, BN_MOMENTUM, BN_EPS, L.bn_stat0,
-                                  bn_update ? w->att_bn0_rm : nullptr, bn_update ? w->att_bn0_rv : nullptr, s));
+      UIC_TRY(uic_bn_stats_launch(UIC_F32, att_src, Na * R, R, d.D, row_len, L.bn_part, BN_MOMENTUM, BN_EPS, L.bn_stat0,
+                                  bn_update ? w->att_bn0_rm : nullptr, bn_update ? w->att_bn0_rv : nullptr, s, (float)S));
     else
       UIC_TRY(uic_bn_stats_running_launch(w->att_bn0_rm, w->att_bn0_rv, d.D, BN_EPS, L.bn_stat0, s));
-    UIC_TRY(uic_bn_apply_launch(UIC_F32, dt, att_src, N * R, R, d.D, row_len, L.bn_stat0, nullptr, nullptr, 0, L.attT, s));
+    UIC_TRY(uic_bn_apply_launch(UIC_F32, dt, att_src, Na * R, R, d.D, row_len, L.bn_stat0, nullptr, nullptr, 0, L.attT, s));
     att_in = L.attT;
   } else if (dt == UIC_BF16) {
     UIC_TRY(uic_cast_f32_launch(dt, att_src, L.attT, (size_t)Na * R * d.D, s));
@@ -330,30 +330,31 @@ int prepare_features(const uic_topdown_dims& d, const uic_topdown_weights* w, co
     g.drop_p = drop_p; g.seed = seed; g.site = UIC_SITE_FC;
     UIC_TRY(uic_gemm_launch(g, s));
   }
+  void* const att_out = d.use_bn == 2 ? L.ybn : L.attp;
   if (fold) {
     // relu(W att + b) once per image (f32), then S caption rows with their own dropout masks -- element for element
     // what the S-fold replicated GEMM epilogue writes
     UicGemmParams g = gemm_base(dt, Ni * R, H);
     add_seg(g, att_in, d.D, dv.att_w, d.D, d.D);
-    g.C = L.ypre; g.ldc = H; g.bias = w->att_b; g.flags = UIC_GEMM_RELU | UIC_GEMM_OUT_F32;
+    g.C = L.ypre; g.ldc = H; g.bias = d.use_bn ? dv.att_beff : w->att_b; g.flags = UIC_GEMM_RELU | UIC_GEMM_OUT_F32;
     if (b->att_masks) { g.row_len = L.row_len; g.R = R; }
     UIC_TRY(uic_gemm_launch(g, s));
-    UIC_TRY(uic_expand_drop_launch(dt, L.ypre, L.attp, Ni, S, (size_t)R * H, drop_p, seed, UIC_SITE_ATT, s));
+    UIC_TRY(uic_expand_drop_launch(dt, L.ypre, att_out, Ni, S, (size_t)R * H, drop_p, seed, UIC_SITE_ATT, s));
   } else {
     UicGemmParams g = gemm_base(dt, N * R, H);
     add_seg(g, att_in, d.D, dv.att_w, d.D, d.D);
-    g.C = d.use_bn == 2 ? L.ybn : L.attp; g.ldc = H; g.bias = d.use_bn ? dv.att_beff : w->att_b; g.flags = UIC_GEMM_RELU;
+    g.C = att_out; g.ldc = H; g.bias = d.use_bn ? dv.att_beff : w->att_b; g.flags = UIC_GEMM_RELU;
     if (b->att_masks) { g.row_len = L.row_len; g.R = R; }
     g.drop_p = drop_p; g.seed = seed; g.site = UIC_SITE_ATT;
     UIC_TRY(uic_gemm_launch(g, s));
   }
   if (d.use_bn == 2) {   // BatchNorm1d(H) after the Dropout; padded regions stay zero (pad_unsort_packed_sequence)
     if (bn_train)
-      UIC_TRY(uic_bn_stats_launch(dt, L.ybn, N * R, R, H, row_len, L.bn_part, BN_MOMENTUM, BN_EPS, L.bn_stat4,
+      UIC_TRY(uic_bn_stats_launch(dt, L.ybn, N * R, R, H, row_len_cap, L.bn_part, BN_MOMENTUM, BN_EPS, L.bn_stat4,
                                   bn_update ? w->att_bn4_rm : nullptr, bn_update ? w->att_bn4_rv : nullptr, s));
     else
       UIC_TRY(uic_bn_stats_running_launch(w->att_bn4_rm, w->att_bn4_rv, H, BN_EPS, L.bn_stat4, s));
-    UIC_TRY(uic_bn_apply_launch(dt, dt, L.ybn, N * R, R, H, row_len, L.bn_stat4, w->att_bn4_w, w->att_bn4_b, 1, L.attp, s));
+    UIC_TRY(uic_bn_apply_launch(dt, dt, L.ybn, N * R, R, H, row_len_cap, L.bn_stat4, w->att_bn4_w, w->att_bn4_b, 1, L.attp, s));
   }
   {
     UicGemmParams g = gemm_base(dt, N * R, A);
@@ -552,7 +553,7 @@ struct Step {
     inv_keep = drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f;
     seed = seed_;
     fc_in = (dt == UIC_BF16 || d.seq_per_img > 1) ? L.fcT : (const void*)b->fc_feats;
-    att_in = (dt == UIC_BF16 || d.use_bn) ? L.attT : (const void*)b->att_feats;   // per image when seq_per_img > 1 without BN
+    att_in = (dt == UIC_BF16 || d.use_bn) ? L.attT : (const void*)b->att_feats;   // per image when seq_per_img > 1
   }
 
   // scheduled sampling (AttModel.py:130-143) is active in train mode only
@@ -912,13 +913,13 @@ struct Step {
     const void* act = L.attp;
     if (d.use_bn == 2) {   // through BatchNorm1d(H): d_att <- d y (in place), grads of its affine parameters
       UIC_REQUIRE(G->att_bn4_w && G->att_bn4_b, "backward: use_bn=2 needs gradient tensors for att_embed.4");
-      UIC_TRY(uic_bn_bwd_launch(dt, L.d_att, L.ybn, NR, R, H, b->att_masks ? L.row_len : nullptr, L.bn_stat4, w->att_bn4_w,
+      UIC_TRY(uic_bn_bwd_launch(dt, L.d_att, L.ybn, NR, R, H, b->att_masks ? (d.seq_per_img > 1 ? L.row_len_rep : L.row_len) : nullptr, L.bn_stat4, w->att_bn4_w,
                                 training & 1, L.bn_part, L.bn_red, G->att_bn4_w, G->att_bn4_b, s));
       act = L.ybn;
     }
     // seq_per_img > 1 without BN: the S caption rows of an image share the Linear's input, so their gradients are summed
     // first and the weight-gradient GEMM runs over the per-image rows
-    const bool fold = d.seq_per_img > 1 && !d.use_bn;
+    const bool fold = d.seq_per_img > 1;
     const int NRa = fold ? NR / d.seq_per_img : NR;
     if (fold)
       UIC_TRY(uic_relu_mask_bwd_fold_launch(dt, L.d_att, act, inv_keep, L.d_pre, N / d.seq_per_img, d.seq_per_img, (size_t)R * H, s));

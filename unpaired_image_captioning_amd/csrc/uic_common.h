@@ -279,7 +279,7 @@ size_t uic_bn_scratch_floats(int NR, int C);
 // batch statistics over the live rows (row (n, r) live iff r < row_len[n]; all rows if row_len is null):
 // stat[0:C] = mean, stat[C:2C] = 1/sqrt(var + eps); running stats updated in place when non-null
 int uic_bn_stats_launch(int in_dtype, const void* x, int NR, int R, int C, const int* row_len, float* part, float momentum,
-                        float eps, float* stat, float* run_mean, float* run_var, hipStream_t s);
+                        float eps, float* stat, float* run_mean, float* run_var, hipStream_t s, float rep = 1.f);
 int uic_bn_stats_running_launch(const float* run_mean, const float* run_var, int C, float eps, float* stat, hipStream_t s);
 int uic_bn_apply_launch(int in_dtype, int out_dtype, const void* x, int NR, int R, int C, const int* row_len, const float* stat,
                         const float* gamma, const float* beta, int zero_padded, void* out, hipStream_t s);
