@@ -197,14 +197,14 @@ __global__ void gattn_bwd_accum_kernel(const float* attn_all, const float* dscor
 
 // d_pre = (d_out + d_feed) * dropout_mask * (1 - out_pre^2): backward of out = dropout(tanh(.))
 template <typename T>
-__global__ void tanh_drop_bwd_kernel(const float* d_out, const float* d_feed, const void* out_pre_, int n, float p, unsigned seed,
-                                     unsigned site, void* d_pre_) {
+__global__ void tanh_drop_bwd_kernel(const float* d_out, const float* d_feed, int ld_feed, int H, const void* out_pre_, int n, float p,
+                                     unsigned seed, unsigned site, void* d_pre_) {
   const T* out_pre = (const T*)out_pre_;
   T* d_pre = (T*)d_pre_;
   const float inv_keep = p > 0.f ? 1.f / (1.f - p) : 1.f;
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
-  float g = d_out[i] + (d_feed ? d_feed[i] : 0.f);
+  float g = d_out[i] + (d_feed ? d_feed[(size_t)(i / H) * ld_feed + (i % H)] : 0.f);
   if (p > 0.f) g *= uic_drop_scale(seed, site, (unsigned)i, p, inv_keep);
   const float o = uic_to_f(out_pre[i]);
   d_pre[i] = uic_from_f<T>(g * (1.f - o * o));
@@ -424,7 +424,7 @@ NmtLayout nmt_layout(const uic_nmt_dims& d, const uic_nmt_weights* w, void* ws) 
   L.scalars = (float*)b.take(64);
   L.stats = (int*)b.take(64);
   L.d_out_all = (float*)b.take(Td * B * H * 4);
-  L.dfeed = (float*)b.take(B * H * 4);
+  L.dfeed = (float*)b.take(B * 2 * H * 4);
   L.d_pre_all = b.take(Td * B * H * Sz);
   L.d_cq_all = (float*)b.take(Td * B * 2 * H * 4);
   L.dscore_all = (float*)b.take(Td * B * S * 4);
@@ -730,7 +730,7 @@ struct Nmt {
       void* d_pre = offw(L.d_pre_all, (size_t)t * BH, dt);
       float* d_cq = L.d_cq_all + (size_t)t * B * 2 * H;
       NMT_T(tanh_drop_bwd_kernel, gridn(BH), 0, (const float*)(L.d_out_all + (size_t)t * BH), (const float*)(last ? nullptr : L.dfeed),
-            (const void*)off(L.out_pre, (size_t)t * BH, dt), (int)BH, drop_p, seed, SITE_NMT_OUT(t), d_pre);
+            2 * H, H, (const void*)off(L.out_pre, (size_t)t * BH, dt), (int)BH, drop_p, seed, SITE_NMT_OUT(t), d_pre);
       {  // d[c ; q] = d_pre W_out
         UicGemmParams g = gemm_base(dt, B, 2 * H);
         add_seg(g, d_pre, H, L.attn_out_wT, H, H);
@@ -755,28 +755,24 @@ struct Nmt {
           p.drop_p = drop_p; p.seed = seed; p.site = SITE_NMT_DEC(l, t);
         }
         if (!last) {       // d h_l(t) from step t + 1: layer 0 has its own buffer, layers > 0 read the second half of their dX
-          if (l == 0) { p.dh1 = L.dhrec_d[0]; p.lddh1 = H; }
+          if (l == 0) { p.dh1 = L.dfeed + H; p.lddh1 = 2 * H; }
           else { p.dh1 = L.dx_lstm[l] + H; p.lddh1 = 2 * H; }
         }
         p.dc = L.dcd[l]; p.gates = off(L.gates_d[l], (size_t)t * B * H4, dt);
         p.c_prev = L.cd[l] + (size_t)t * BH; p.c = L.cd[l] + (size_t)(t + 1) * BH;
         p.dgates = offw(L.dg_d[l], (size_t)t * B * H4, dt);
         UIC_TRY(uic_lstm_bwd_launch(p, s));
-        const int din = l == 0 ? W + H : H;
         if (l > 0) {   // d[x_l | h_l_prev] = dG [W_ih | W_hh]
           UicGemmParams g = gemm_base(dt, B, 2 * H);
           add_seg(g, p.dgates, H4, L.dec_wT[l], H4, H4);
           g.C = L.dx_lstm[l]; g.ldc = 2 * H; g.flags = UIC_GEMM_OUT_F32;
           UIC_TRY(uic_gemm_launch(g, s));
-        } else {       // layer 0: d[feed | h_0_prev] = dG [W_ih[:, W:] | W_hh]  (the embedding part is batched below)
-          UicGemmParams g = gemm_base(dt, B, H);
+        } else {       // layer 0: d[feed | h_0_prev] = dG [W_ih[:, W:] | W_hh] in ONE GEMM (rows W .. W + 2H of dec_wT[0] are
+                       // contiguous; the embedding part is batched below): L.dfeed is [B, 2H] = [d feed | d h_0(t-1)]
+          UicGemmParams g = gemm_base(dt, B, 2 * H);
           add_seg(g, p.dgates, H4, off(L.dec_wT[0], (size_t)W * H4, dt), H4, H4);
-          g.C = L.dfeed; g.ldc = H; g.flags = UIC_GEMM_OUT_F32;
+          g.C = L.dfeed; g.ldc = 2 * H; g.flags = UIC_GEMM_OUT_F32;
           UIC_TRY(uic_gemm_launch(g, s));
-          UicGemmParams g2 = gemm_base(dt, B, H);
-          add_seg(g2, p.dgates, H4, off(L.dec_wT[0], (size_t)din * H4, dt), H4, H4);
-          g2.C = L.dhrec_d[0]; g2.ldc = H; g2.flags = UIC_GEMM_OUT_F32;
-          UIC_TRY(uic_gemm_launch(g2, s));
         }
       }
     }
@@ -829,8 +825,8 @@ struct Nmt {
         UIC_TRY(uic_fill_launch(L.dg_e[l][dd], 0, (size_t)Ms * 4 * Hd * Sz, sd));
         // carried dh / dc start from the decoder-initial-state gradient halves (rows join the BPTT when they become active)
         // (d h_l(-1) of decoder layers > 0 sits in the second half of that layer's last dX)
-        const float* dh_init = l == 0 ? L.dhrec_d[0] : L.dx_lstm[l] + H;
-        const size_t dh_pitch = (size_t)(l == 0 ? H : 2 * H) * 4;
+        const float* dh_init = (l == 0 ? L.dfeed : L.dx_lstm[l]) + H;
+        const size_t dh_pitch = (size_t)2 * H * 4;
         UIC_TRY(uic_check_hip(hipMemcpy2DAsync(dhrec, (size_t)Hd * 4, dh_init + dd * Hd, dh_pitch, (size_t)Hd * 4, B,
                                                hipMemcpyDeviceToDevice, sd), "memcpy2d dh0"));
         UIC_TRY(uic_check_hip(hipMemcpy2DAsync(dcc, (size_t)Hd * 4, L.dcd[l] + dd * Hd, (size_t)H * 4, (size_t)Hd * 4, B,
