@@ -106,8 +106,11 @@ __device__ __forceinline__ void weighted_rows(const T* __restrict__ ctx, const f
 
 // ---- dot GlobalAttention (O/modules/GlobalAttention.py:112-116,152,160-162), one workgroup per batch row
 template <typename T>
+// Training path: `ctxw` = context x W_in (f32, made once per batch) and `qvec` = the decoder's rnn_output, so that
+// score[s] = ctxw[s, b, :] . q -- the same number as context[s, b, :] . linear_in(q) without a linear_in GEMM per step.
 __global__ __launch_bounds__(NT) void gattn_fwd_kernel(const void* ctx_, const float* target, int S, int B, int H, float* attn,
-                                                       void* cvec_, const int64_t* mask_src = nullptr) {
+                                                       void* cvec_, const int64_t* mask_src = nullptr, const float* ctxw = nullptr,
+                                                       const void* qvec_ = nullptr) {
   const T* ctx = (const T*)ctx_;
   T* cvec = (T*)cvec_;
   extern __shared__ __attribute__((aligned(16))) float sm[];
@@ -115,10 +118,11 @@ __global__ __launch_bounds__(NT) void gattn_fwd_kernel(const void* ctx_, const f
   float* s_a = s_t + H;       // [S]
   float* s_red = s_a + S;     // [4][H]
   const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  for (int j = tid; j < H; j += NT) s_t[j] = target[(size_t)b * H + j];
+  for (int j = tid; j < H; j += NT) s_t[j] = ctxw ? uic_to_f(((const T*)qvec_)[(size_t)b * H + j]) : target[(size_t)b * H + j];
   __syncthreads();
   for (int s = wave; s < S; s += 4) {
-    float p = row_dot<T>(ctx + ((size_t)s * B + b) * H, s_t, H, lane);
+    float p = ctxw ? row_dot<float>(ctxw + ((size_t)s * B + b) * H, s_t, H, lane)
+                   : row_dot<T>(ctx + ((size_t)s * B + b) * H, s_t, H, lane);
     // translator only: source padding is masked (GlobalAttention.applyMask, NMT_Models.py:345,352)
     if (mask_src && mask_src[(size_t)s * B + b] == 0) p = -INFINITY;
     if (lane == 0) s_a[s] = p;
@@ -142,12 +146,12 @@ __global__ __launch_bounds__(NT) void gattn_fwd_kernel(const void* ctx_, const f
     cvec[(size_t)b * H + j] = uic_from_f<T>(s_red[j] + s_red[H + j] + s_red[2 * H + j] + s_red[3 * H + j]);
 }
 
-// backward of one decode step: d_a = d_c . ctx[s]; d_score = a (d_a - sum a d_a); d_target = sum_s d_score ctx[s]
+// backward of one decode step: d_a = d_c . ctx[s]; d_score = a (d_a - sum a d_a); with the hoisted linear_in the
+// query's gradient is direct: d q += sum_s d_score[s] ctxw[s, b, :] (added to `dq`, which already holds the linear_out share)
 template <typename T>
 __global__ __launch_bounds__(NT) void gattn_bwd_step_kernel(const void* ctx_, const float* attn, const float* dcq, int lddcq,
-                                                            int S, int B, int H, float* dscore, void* dtarget_) {
+                                                            int S, int B, int H, float* dscore, const float* ctxw, float* dq, int lddq) {
   const T* ctx = (const T*)ctx_;
-  T* dtarget = (T*)dtarget_;
   extern __shared__ __attribute__((aligned(16))) float sm[];
   float* s_dc = sm;           // [H]
   float* s_a = s_dc + H;      // [S]
@@ -171,27 +175,32 @@ __global__ __launch_bounds__(NT) void gattn_bwd_step_kernel(const void* ctx_, co
     dscore[(size_t)b * S + s] = ds;
   }
   __syncthreads();
-  weighted_rows<T>(ctx, s_da, S, B, H, b, lane, wave, s_red);
+  weighted_rows<float>(ctxw, s_da, S, B, H, b, lane, wave, s_red);
   __syncthreads();
   for (int j = tid; j < H; j += NT)
-    dtarget[(size_t)b * H + j] = uic_from_f<T>(s_red[j] + s_red[H + j] + s_red[2 * H + j] + s_red[3 * H + j]);
+    dq[(size_t)b * lddq + j] += s_red[j] + s_red[H + j] + s_red[2 * H + j] + s_red[3 * H + j];
 }
 
-// deferred over decode steps: d ctx[s,b,:] = sum_t (a_t[b,s] d_c_t[b,:] + d_score_t[b,s] target_t[b,:])
+// deferred over decode steps: d ctx[s,b,:] = sum_t a_t[b,s] d_c_t[b,:]  and  d ctxw[s,b,:] = sum_t d_score_t[b,s] q_t[b,:]
+template <typename T>
 __global__ void gattn_bwd_accum_kernel(const float* attn_all, const float* dscore_all, const float* dcq_all, int lddcq,
-                                       const float* target_all, int Td, int S, int B, int H, float* dctx) {
+                                       const void* q_all_, int Td, int S, int B, int H, float* dctx, void* dctxw_) {
+  const T* q_all = (const T*)q_all_;
+  T* dctxw = (T*)dctxw_;
   const size_t total = (size_t)S * B * H;
   const size_t stride = (size_t)gridDim.x * blockDim.x;
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
     const int j = (int)(i % H);
     const size_t sb = i / H;
     const int b = (int)(sb % B), s = (int)(sb / B);
-    float acc = 0.f;
+    float acc = 0.f, accw = 0.f;
     for (int t = 0; t < Td; ++t) {
       const size_t tb = (size_t)t * B + b;
-      acc += attn_all[tb * S + s] * dcq_all[tb * lddcq + j] + dscore_all[tb * S + s] * target_all[tb * H + j];
+      acc += attn_all[tb * S + s] * dcq_all[tb * lddcq + j];
+      accw += dscore_all[tb * S + s] * uic_to_f(q_all[tb * H + j]);
     }
     dctx[i] = acc;
+    dctxw[i] = uic_from_f<T>(accw);
   }
 }
 
@@ -348,10 +357,10 @@ struct NmtLayout {
   int64_t* target_bt; float* mask_bt; int64_t* tgt_in;
   void* emb_d; float* gx_d0;
   void* hd[ML]; float* cd[ML]; void* hdrop[ML]; void* gates_d[ML]; void* dg_d[ML]; float* dhrec_d[ML]; float* dcd[ML];
-  float* targetq; float* attn_all; void* cvec_all; void* out_pre; void* out_all;
+  float* ctxw; void* dctxw; float* attn_all; void* cvec_all; void* out_pre; void* out_all;   // ctxw = context x W_in [S*B, H] f32
   float* logits; void* dlogits; float* row_loss; float* scalars; int* stats;
   // backward
-  float* d_out_all; float* dfeed; void* d_pre_all; float* d_cq_all; float* dscore_all; void* dtarget_all; float* dq;
+  float* d_out_all; float* dfeed; void* d_pre_all; float* d_cq_all; float* dscore_all; float* dq;
   // dx_lstm[l]: d[x_l | h_l(t-1)] of decoder layer l > 0, one buffer per layer so that nothing has to be copied
   float* dx_lstm[ML]; float* d_lay; float* dhrec_e; float* dc_e; float* dhrec_e1; float* dc_e1; float* dx_e; void* dpre_e; float* dxe; float* demb_d;
   void* tA; void* tB; float* colscratch; size_t colscratch_floats; float* slab; size_t slab_bytes;
@@ -413,7 +422,8 @@ NmtLayout nmt_layout(const uic_nmt_dims& d, const uic_nmt_weights* w, void* ws) 
     L.dhrec_d[l] = (float*)b.take(B * H * 4);
     L.dcd[l] = (float*)b.take(B * H * 4);
   }
-  L.targetq = (float*)b.take(Td * B * H * 4);
+  L.ctxw = (float*)b.take(S * B * H * 4);
+  L.dctxw = b.take(S * B * H * Sz);
   L.attn_all = (float*)b.take(Td * B * S * 4);
   L.cvec_all = b.take(Td * B * H * Sz);
   L.out_pre = b.take(Td * B * H * Sz);
@@ -428,7 +438,6 @@ NmtLayout nmt_layout(const uic_nmt_dims& d, const uic_nmt_weights* w, void* ws) 
   L.d_pre_all = b.take(Td * B * H * Sz);
   L.d_cq_all = (float*)b.take(Td * B * 2 * H * 4);
   L.dscore_all = (float*)b.take(Td * B * S * 4);
-  L.dtarget_all = b.take(Td * B * H * Sz);
   L.dq = (float*)b.take(B * H * 4);
   for (int l = 0; l < ML; ++l) L.dx_lstm[l] = (float*)b.take(B * 2 * H * 4);
   L.d_lay = (float*)b.take(S * B * H * 4);
@@ -626,6 +635,12 @@ struct Nmt {
       UIC_TRY(uic_gemm_launch(g, s));
     }
     UIC_TRY(uic_fill_launch(L.out_all, 0, BH * Sz, s));        // init_input_feed: zeros (:454-458)
+    {  // ctxw[s, b, :] = context[s, b, :] W_in, all source positions at once (see gattn_fwd_kernel)
+      UicGemmParams g = gemm_base(dt, S * B, H);
+      add_seg(g, off(L.xl[NL], BH, dt), H, L.attn_in_wT, H, H);
+      g.C = L.ctxw; g.ldc = H; g.flags = UIC_GEMM_OUT_F32;
+      UIC_TRY(uic_gemm_launch(g, s));
+    }
     const size_t lds_att = sizeof(float) * ((size_t)H + S + 4 * (size_t)H);
     for (int t = 0; t < Td; ++t) {
       const void* x = nullptr;
@@ -651,15 +666,11 @@ struct Nmt {
         UIC_TRY(uic_gemm_launch(g, s));
       }
       const void* q = off(L.hd[NL - 1], (size_t)(t + 1) * BH, dt);       // rnn_output = top layer's h
-      float* target = L.targetq + (size_t)t * BH;
-      {  // targetT = linear_in(rnn_output) (GlobalAttention.py:114)
-        UicGemmParams g = gemm_base(dt, B, H);
-        add_seg(g, q, H, L.attn_in_w, H, H);
-        g.C = target; g.ldc = H; g.flags = UIC_GEMM_OUT_F32;
-        UIC_TRY(uic_gemm_launch(g, s));
-      }
-      NMT_T(gattn_fwd_kernel, B, lds_att, (const void*)off(L.xl[NL], BH, dt), (const float*)target, S, B, H,
-            L.attn_all + (size_t)t * B * S, (void*)offw(L.cvec_all, (size_t)t * BH, dt));
+      // scores = context . linear_in(rnn_output) (GlobalAttention.py:114-116) = (context W_in) . rnn_output: L.ctxw was
+      // made once before the loop, so no linear_in GEMM sits in the per-step chain
+      NMT_T(gattn_fwd_kernel, B, lds_att, (const void*)off(L.xl[NL], BH, dt), (const float*)nullptr, S, B, H,
+            L.attn_all + (size_t)t * B * S, (void*)offw(L.cvec_all, (size_t)t * BH, dt), (const int64_t*)nullptr,
+            (const float*)L.ctxw, q);
       {  // tanh(linear_out([c ; rnn_output])) (:165-167)
         UicGemmParams g = gemm_base(dt, B, H);
         add_seg(g, off(L.cvec_all, (size_t)t * BH, dt), H, L.attn_out_w, 2 * H, H);
@@ -737,14 +748,9 @@ struct Nmt {
         g.C = d_cq; g.ldc = 2 * H; g.flags = UIC_GEMM_OUT_F32;
         UIC_TRY(uic_gemm_launch(g, s));
       }
+      // d q = d_cq[:, H:] (linear_out's share) + sum_s d_score[s] ctxw[s]: added by the attention kernel itself
       NMT_T(gattn_bwd_step_kernel, B, lds_att, (const void*)off(L.xl[NL], BH, dt), (const float*)(L.attn_all + (size_t)t * B * S),
-            (const float*)d_cq, 2 * H, S, B, H, L.dscore_all + (size_t)t * B * S, (void*)offw(L.dtarget_all, (size_t)t * BH, dt));
-      {  // d q = d_cq[:, H:] + d_target W_in
-        UicGemmParams g = gemm_base(dt, B, H);
-        add_seg(g, off(L.dtarget_all, (size_t)t * BH, dt), H, L.attn_in_wT, H, H);
-        g.C = d_cq + H; g.ldc = 2 * H; g.flags = UIC_GEMM_OUT_F32 | UIC_GEMM_ACCUM;
-        UIC_TRY(uic_gemm_launch(g, s));
-      }
+            (const float*)d_cq, 2 * H, S, B, H, L.dscore_all + (size_t)t * B * S, (const float*)L.ctxw, d_cq + H, 2 * H);
       for (int l = NL - 1; l >= 0; --l) {
         UicLstmBwdParams p;
         memset(&p, 0, sizeof(p));
@@ -798,20 +804,27 @@ struct Nmt {
       UIC_TRY(uic_fill_launch(G->dec_lut, 0, (size_t)Vt * W * 4, s));
       UIC_TRY(uic_embed_bwd_launch(dt, L.demb_d, nullptr, L.tgt_in, 1, Md, 1, Vt, W, 0.f, 0, G->dec_lut, s));
     }
-    // attention weights: linear_in from (d_target, q), linear_out from (d_pre, [c | q])
+    // ---- deferred attention gradients: d context (direct share) and d ctxw, then linear_in through ctxw = context W_in:
+    // dW_in = context^T d ctxw,  d context += d ctxw W_in^T
+    float* d_top = L.d_lay;
+    NMT_T(gattn_bwd_accum_kernel, gridn((size_t)S * BH), 0, (const float*)L.attn_all, (const float*)L.dscore_all, (const float*)L.d_cq_all,
+          2 * H, (const void*)off(L.hd[NL - 1], BH, dt), Td, S, B, H, d_top, (void*)L.dctxw);
     {
-      const UicGemmTnSeg seg{off(L.hd[NL - 1], BH, dt), H, H};
+      const UicGemmTnSeg seg{L.dctxw, H, H};
       const WDest d1{G->attn_in_w, H, 0, H};
-      UIC_TRY(wgrad_group(L.slab, L.slab_bytes, dt, L.dtarget_all, H, H, &seg, 1, Md, &d1, 1, s, false, L.tA, L.tB));
+      UIC_TRY(wgrad_group(L.slab, L.slab_bytes, dt, off(L.xl[NL], BH, dt), H, H, &seg, 1, Ms, &d1, 1, s, false, L.tA, L.tB));
+      UicGemmParams g = gemm_base(dt, Ms, H);
+      add_seg(g, L.dctxw, H, L.attn_in_w, H, H);
+      g.C = d_top; g.ldc = H; g.flags = UIC_GEMM_OUT_F32 | UIC_GEMM_ACCUM;
+      UIC_TRY(uic_gemm_launch(g, s));
+    }
+    // linear_out from (d_pre, [c | q])
+    {
       const UicGemmTnSeg segs[2] = {{L.cvec_all, H, H}, {off(L.hd[NL - 1], BH, dt), H, H}};
       const WDest d2{G->attn_out_w, 2 * H, 0, 2 * H};
       UIC_TRY(wgrad_group(L.slab, L.slab_bytes, dt, L.d_pre_all, H, H, segs, 2, Md, &d2, 1, s, false, L.tA, L.tB));
     }
     // ---- encoder: d context = deferred attention gradient; d h0/c0 of the decoder enter at each row's final steps
-    float* d_top = L.d_lay;
-    hipLaunchKernelGGL(gattn_bwd_accum_kernel, dim3(gridn((size_t)S * BH)), dim3(NT), 0, s, L.attn_all, L.dscore_all, L.d_cq_all,
-                       2 * H, L.targetq, Td, S, B, H, d_top);
-    UIC_LAUNCH_CHECK("gattn_bwd_accum_kernel");
     for (int l = NL - 1; l >= 0; --l) {
       const int in = l == 0 ? W : H;
       NmtSide* ss = nullptr;
