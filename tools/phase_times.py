@@ -103,6 +103,11 @@ rewards.CiderD_scorer = None
 def scst_dev():
     tr.train_self_critical(data)
 print("Trainer.train_self_critical with the device CIDEr-D reward (%d n-grams in the table), incl. H2D: %.3f ms" % (len(df), timeit(scst_dev, iters=5, warm=2)))
+st3 = {"cur": data, "nxt": dict(data)}
+def scst_dev_prefetch():
+    tr.train_self_critical(st3["cur"], next_data=st3["nxt"])
+    st3["cur"], st3["nxt"] = st3["nxt"], st3["cur"]
+print("  ... with the next batch shipped during the step (next_data=): %.3f ms" % timeit(scst_dev_prefetch, iters=5, warm=2))
 hyp = torch.randint(0, c["V"], (2 * 640, L_), device="cuda")
 sc = rewards.CiderD_scorer
 print("CIDEr-D scores of 1280 captions x 5 references (kernel + reference upload): %.3f ms" % timeit(lambda: sc.scores(hyp, data["gts"], 640, c["S"])))

@@ -230,7 +230,7 @@ class Trainer(object):
         self.i2t_train_loss = loss.item()          # the reference's per-step host sync (trainer.py:172)
         return self.i2t_train_loss
 
-    def train_self_critical(self, data, reward_fn=None):
+    def train_self_critical(self, data, reward_fn=None, next_data=None):
         """The self-critical branch of Trainer.train (P/trainer.py:166-171).  reward_fn None: the reference's reward,
         CIDEr-D(sampled) - CIDEr-D(greedy) against data['gts'] with the cached document frequencies of
         opt.cached_tokens (P/misc/rewards.py:37-81), scored on the device -- the captions never visit the host and the
@@ -277,6 +277,8 @@ class Trainer(object):
                                         self.i2t_current_lr, self.betas[0], self.betas[1], self.eps, self._step, scale,
                                         stream()), "adam_step")
         avg = reward_t[:, 0].mean()
+        if next_data is not None:
+            self.prefetch(next_data)              # the next batch crosses PCIe while this step computes (see train)
         self.i2t_train_loss = loss.item()
         self.i2t_avg_reward = float(avg.item())
         return self.i2t_train_loss
