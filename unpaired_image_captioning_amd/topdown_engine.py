@@ -132,8 +132,29 @@ class TopDownEngine(object):
                 setattr(w, field, ptr(t))
         return w
 
+    def hold_weights(self):
+        """Context manager: the caller promises that the parameters do not change inside (e.g. the sampling pass, the greedy
+        baseline and the replay of one self-critical step), so the operand-dtype / transposed weight copies are rebuilt by
+        the first call only instead of by every call."""
+        eng = self
+
+        class _Hold(object):
+            def __enter__(self):
+                eng._hold = {"fresh": False}
+                return eng
+
+            def __exit__(self, *a):
+                eng._hold = None
+                return False
+        return _Hold()
+
     def refresh(self, params, d):
         """Rebuild operand-dtype / transposed weight copies from the f32 masters."""
+        hold = getattr(self, "_hold", None)
+        if hold is not None and hold["fresh"] and self._derived is not None:
+            return self.weights_struct(params)          # same masters as the call that refreshed: pointers only
+        if hold is not None:
+            hold["fresh"] = True
         dev = next(iter(params.values())).device
         nbytes = self.lib.uic_topdown_derived_bytes(C.byref(d))
         if self._derived is None or self._derived.numel() < nbytes or self._derived.device != dev:

@@ -245,27 +245,31 @@ class Trainer(object):
         fc, att, am = batch["fc_feats"], batch["att_feats"], batch.get("att_masks")
         n_rows = len(data["labels"]) if data.get("labels") is not None else att.shape[0]
         S = n_rows // att.shape[0]                        # > 1 when to_device shipped every image once
-        model.train()
-        gen_result, sample_logprobs = model(fc, None, att, am, opt={'sample_max': 0, 'seq_per_img': S}, mode='sample')
-        model.eval()
-        with torch.no_grad():                                           # rewards.py:42-47: greedy baseline, eval mode
-            greedy_res, _ = model(fc, None, att, am, opt={'sample_max': 1}, mode='sample')
-        model.train()
-        if reward_fn is None:
-            if getattr(self.opt, 'bleu_reward_weight', 0) > 0:
-                raise NotImplementedError("bleu_reward_weight > 0 is not on the MI355X path (the reference's default is 0)")
-            scorer = rewards.init_scorer(getattr(self.opt, 'cached_tokens', 'corpus'))
-            reward_t = rewards.self_critical_reward_device(scorer, gen_result, greedy_res, data['gts'],
-                                                           float(getattr(self.opt, 'cider_reward_weight', 1)))
-        else:
-            if S > 1:                                     # eval mode is deterministic: the S replicas decode identically
-                greedy_res = greedy_res.repeat_interleave(S, 0)
-            reward = np.asarray(reward_fn(data, gen_result.cpu().numpy(), greedy_res.cpu().numpy()), dtype=np.float32)
-            reward_t = torch.from_numpy(reward).cuda()
-        loss = RewardCriterion()(sample_logprobs, gen_result, reward_t)
-        for p in model.parameters():
-            p.grad = None
-        loss.backward()
+        import contextlib
+        eng = getattr(model, 'engine', None)
+        # the weights stay put until Adam below: ONE weight refresh serves the sampling pass, the greedy baseline and the replay
+        with (eng.hold_weights() if hasattr(eng, 'hold_weights') else contextlib.nullcontext()):
+            model.train()
+            gen_result, sample_logprobs = model(fc, None, att, am, opt={'sample_max': 0, 'seq_per_img': S}, mode='sample')
+            model.eval()
+            with torch.no_grad():                                           # rewards.py:42-47: greedy baseline, eval mode
+                greedy_res, _ = model(fc, None, att, am, opt={'sample_max': 1}, mode='sample')
+            model.train()
+            if reward_fn is None:
+                if getattr(self.opt, 'bleu_reward_weight', 0) > 0:
+                    raise NotImplementedError("bleu_reward_weight > 0 is not on the MI355X path (the reference's default is 0)")
+                scorer = rewards.init_scorer(getattr(self.opt, 'cached_tokens', 'corpus'))
+                reward_t = rewards.self_critical_reward_device(scorer, gen_result, greedy_res, data['gts'],
+                                                               float(getattr(self.opt, 'cider_reward_weight', 1)))
+            else:
+                if S > 1:                                     # eval mode is deterministic: the S replicas decode identically
+                    greedy_res = greedy_res.repeat_interleave(S, 0)
+                reward = np.asarray(reward_fn(data, gen_result.cpu().numpy(), greedy_res.cpu().numpy()), dtype=np.float32)
+                reward_t = torch.from_numpy(reward).cuda()
+            loss = RewardCriterion()(sample_logprobs, gen_result, reward_t)
+            for p in model.parameters():
+                p.grad = None
+            loss.backward()
         params = dict(model.named_parameters())
         for k, view in self.arena.grad_views.items():
             view.copy_(params[k].grad)
