@@ -93,7 +93,7 @@ FcLayout fc_layout(const uic_fc_dims& d, const uic_fc_weights* w, void* ws) {
   L.s_logits = (float*)b.take(N * V1p * 4);
   L.s_it = (int64_t*)b.take(N * 8);
   L.s_unf = (int*)b.take(N * 4);
-  L.s_nunf = (int*)b.take((S + 2) * 4);
+  L.s_nunf = (int*)b.take((S + 2) * UIC_NUNF_STRIPES * 4);
   L.bm_cand_val = (float*)b.take(N * UIC_BEAM_MAX * 4);
   L.bm_cand_idx = (int*)b.take(N * UIC_BEAM_MAX * 4);
   for (int i = 0; i < 2; ++i) {
@@ -328,7 +328,7 @@ int uic_fc_sample(const uic_fc_dims* d, const uic_fc_weights* w, const uic_topdo
   UIC_TRY(uic_fill_launch(L.s_c[0], 0, NH * 4, s));
   UIC_TRY(uic_fill_launch(L.s_it, 0, (size_t)N * 8, s));            // <bos> at step 1 (:183-184)
   UIC_TRY(uic_fill_launch(L.s_unf, 0, (size_t)N * 4, s));
-  UIC_TRY(uic_fill_launch(L.s_nunf, 0, (size_t)(d->S + 2) * 4, s));
+  UIC_TRY(uic_fill_launch(L.s_nunf, 0, (size_t)(d->S + 2) * UIC_NUNF_STRIPES * 4, s));
   const int ld = Lsteps + 1;                                         // seq / seqLogprobs are [N, L+1] (:176-177)
   UIC_TRY(uic_fill_launch(seq, 0, (size_t)N * ld * 8, s));
   UIC_TRY(uic_fill_launch(seq_logp, 0, (size_t)N * ld * 4, s));

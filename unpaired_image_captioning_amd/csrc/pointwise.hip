@@ -290,8 +290,11 @@ __global__ void maxout_lstm_bwd_kernel(const UicLstmBwdParams p) {
 // column and everything after it.
 __global__ void sample_fixup_kernel(int N, int L, int ld, const int* n_unfinished, int64_t* seq, float* seq_logp) {
   int first = L;
-  for (int t = 0; t < L; ++t)
-    if (n_unfinished[t] == 0) { first = t; break; }
+  for (int t = 0; t < L; ++t) {
+    int live = 0;
+    for (int k = 0; k < UIC_NUNF_STRIPES; ++k) live += n_unfinished[t * UIC_NUNF_STRIPES + k];
+    if (live == 0) { first = t; break; }
+  }
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < N * ld; i += gridDim.x * blockDim.x) {
     const int t = i % ld;
     if (t >= first) { seq[i] = 0; seq_logp[i] = 0.f; }
@@ -661,8 +664,10 @@ __global__ void copy_tokens_kernel(const int64_t* __restrict__ src, int ld_src, 
 // (`unfinished.sum() == 0`) becomes a device counter per step, so no host sync is needed.
 // STAGED: the logits row is copied into LDS once (16-byte loads) and every pass below reads it from there; rows too long
 // for 64 KB of LDS are read from memory by each pass.  Same arithmetic in the same order either way.
-template <bool STAGED>
+// FAST (bf16 models): hardware exp; the f32 parity path keeps libm's
+template <bool STAGED, bool FAST>
 __global__ __launch_bounds__(NT) void sample_step_kernel(const UicSampleParams p) {
+  auto ex = [](float x) { return FAST ? __expf(x) : expf(x); };
   __shared__ float s_buf[NT / 64];
   __shared__ float s_val[NT];
   __shared__ int s_idx[NT];
@@ -678,7 +683,11 @@ __global__ __launch_bounds__(NT) void sample_step_kernel(const UicSampleParams p
     __syncthreads();
     row = s_row;
   }
-  const bool dead = !p.fc_mode && t > 0 && p.n_unfinished[t - 1] == 0;   // every row had finished: the reference broke out
+  bool dead = false;                                                       // every row had finished: the reference broke out
+  if (!p.fc_mode && t > 0) {
+    int live = threadIdx.x < UIC_NUNF_STRIPES ? p.n_unfinished[(t - 1) * UIC_NUNF_STRIPES + threadIdx.x] : 0;
+    dead = __syncthreads_or(live) == 0;
+  }
   long banned = -1;
   const int ldo = p.ld_out > 0 ? p.ld_out : p.L;
   if (p.decoding_constraint && t > 0) banned = p.seq[(size_t)n * ldo + t - 1];
@@ -687,7 +696,7 @@ __global__ __launch_bounds__(NT) void sample_step_kernel(const UicSampleParams p
   for (int v = threadIdx.x; v < p.V1; v += NT) mx = fmaxf(mx, row[v]);
   mx = block_reduce_max(mx, s_buf);
   float sum = 0.f;
-  for (int v = threadIdx.x; v < p.V1; v += NT) sum += expf(row[v] - mx);
+  for (int v = threadIdx.x; v < p.V1; v += NT) sum += ex(row[v] - mx);
   sum = block_reduce_sum(sum, s_buf);
   const float lse = mx + logf(sum);
   if (p.logprobs_out)
@@ -701,21 +710,21 @@ __global__ __launch_bounds__(NT) void sample_step_kernel(const UicSampleParams p
       const float x = (v == banned) ? -INFINITY : row[v];
       if (x > bv || (x == bv && v < bi)) { bv = x; bi = v; }
     }
-    s_val[threadIdx.x] = bv;
-    s_idx[threadIdx.x] = bi;
-    __syncthreads();
-    for (int o = NT / 2; o > 0; o >>= 1) {
-      if ((int)threadIdx.x < o) {
-        const float ov = s_val[threadIdx.x + o];
-        const int oi = s_idx[threadIdx.x + o];
-        if (ov > s_val[threadIdx.x] || (ov == s_val[threadIdx.x] && oi < s_idx[threadIdx.x])) {
-          s_val[threadIdx.x] = ov;
-          s_idx[threadIdx.x] = oi;
-        }
-      }
-      __syncthreads();
+    // wave-level arg-max by shuffles, then one LDS exchange between the four waves (value descending, lowest index on ties)
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      const float ov = __shfl_xor(bv, o, 64);
+      const int oi = __shfl_xor(bi, o, 64);
+      if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
     }
-    choice = s_idx[0];
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) { s_val[threadIdx.x >> 6] = bv; s_idx[threadIdx.x >> 6] = bi; }
+    __syncthreads();
+    bv = s_val[0]; bi = s_idx[0];
+#pragma unroll
+    for (int w2 = 1; w2 < NT / 64; ++w2)
+      if (s_val[w2] > bv || (s_val[w2] == bv && s_idx[w2] < bi)) { bv = s_val[w2]; bi = s_idx[w2]; }
+    choice = bi;
   } else if (p.forced) {
     choice = (int)p.forced[(size_t)n * p.L + t];
   } else {
@@ -724,7 +733,7 @@ __global__ __launch_bounds__(NT) void sample_step_kernel(const UicSampleParams p
     float part = 0.f;
     const int per = (p.V1 + NT - 1) / NT;
     const int v_lo = threadIdx.x * per, v_hi = min(p.V1, v_lo + per);
-    for (int v = v_lo; v < v_hi; ++v) part += (v == banned) ? 0.f : expf((row[v] - lse) * invT);
+    for (int v = v_lo; v < v_hi; ++v) part += (v == banned) ? 0.f : ex((row[v] - lse) * invT);
     s_val[threadIdx.x] = part;
     __syncthreads();
     if (threadIdx.x == 0) {
@@ -742,7 +751,7 @@ __global__ __launch_bounds__(NT) void sample_step_kernel(const UicSampleParams p
       int pick = -1;
       const int lo = seg * per, hi = min(p.V1, lo + per);
       for (int v = lo; v < hi; ++v) {
-        const float pr = (v == banned) ? 0.f : expf((row[v] - lse) * invT);
+        const float pr = (v == banned) ? 0.f : ex((row[v] - lse) * invT);
         if (pr > 0.f) pick = v;
         cum += pr;
         if (cum > target && pr > 0.f) break;
@@ -766,7 +775,7 @@ __global__ __launch_bounds__(NT) void sample_step_kernel(const UicSampleParams p
       p.it[n] = p.fc_mode ? (long)choice : tok;      // FCModel_NMT feeds the RAW sampled token to the next step (:199)
       p.seq[(size_t)n * ldo + t] = tok;
       p.seq_logp[(size_t)n * ldo + t] = lp;
-      if (unf) atomicAdd(&p.n_unfinished[t], 1);
+      if (unf) atomicAdd(&p.n_unfinished[t * UIC_NUNF_STRIPES + (n % UIC_NUNF_STRIPES)], 1);
     }
   }
 }
@@ -1000,8 +1009,11 @@ int uic_sample_step_launch(const UicSampleParams& p, hipStream_t s) {
   if (p.N == 0) return UIC_OK;
   const size_t row_bytes = ((size_t)p.V1 * 4 + 15) & ~(size_t)15;
   const bool staged = row_bytes <= 60 * 1024 && p.ldv % 4 == 0 && ((uintptr_t)p.logits & 15) == 0;
-  if (staged) hipLaunchKernelGGL(sample_step_kernel<true>, dim3(p.N), dim3(NT), row_bytes, s, p);
-  else hipLaunchKernelGGL(sample_step_kernel<false>, dim3(p.N), dim3(NT), 0, s, p);
+  const bool fast = p.dtype == UIC_BF16;
+  if (staged && fast) hipLaunchKernelGGL((sample_step_kernel<true, true>), dim3(p.N), dim3(NT), row_bytes, s, p);
+  else if (staged) hipLaunchKernelGGL((sample_step_kernel<true, false>), dim3(p.N), dim3(NT), row_bytes, s, p);
+  else if (fast) hipLaunchKernelGGL((sample_step_kernel<false, true>), dim3(p.N), dim3(NT), 0, s, p);
+  else hipLaunchKernelGGL((sample_step_kernel<false, false>), dim3(p.N), dim3(NT), 0, s, p);
   UIC_LAUNCH_CHECK("sample_step");
   return UIC_OK;
 }

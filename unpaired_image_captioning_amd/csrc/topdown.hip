@@ -173,7 +173,7 @@ Layout make_layout(const uic_topdown_dims& d, void* ws) {
   L.s_logits = (float*)b.take(N * V1p * 4);
   L.s_it = (int64_t*)b.take(N * 8);
   L.s_unf = (int*)b.take(N * 4);
-  L.s_nunf = (int*)b.take((T + 2) * 4);
+  L.s_nunf = (int*)b.take((T + 2) * UIC_NUNF_STRIPES * 4);
   L.bm_cand_val = (float*)b.take(N * UIC_BEAM_MAX * 4);
   L.bm_cand_idx = (int*)b.take(N * UIC_BEAM_MAX * 4);
   for (int i = 0; i < 2; ++i) {
@@ -1154,7 +1154,7 @@ int uic_topdown_sample(const uic_topdown_dims* d, const uic_topdown_weights* w, 
   UIC_TRY(uic_fill_launch(L.s_c_lang[0], 0, NH * 4, s));
   UIC_TRY(uic_fill_launch(L.s_it, 0, (size_t)N * 8, s));       // <bos> = 0 (AttModel.py:214-215)
   UIC_TRY(uic_fill_launch(L.s_unf, 0, (size_t)N * 4, s));
-  UIC_TRY(uic_fill_launch(L.s_nunf, 0, (size_t)(d->T + 2) * 4, s));
+  UIC_TRY(uic_fill_launch(L.s_nunf, 0, (size_t)(d->T + 2) * UIC_NUNF_STRIPES * 4, s));
   for (int t = 0; t < Lsteps; ++t) {
     const int cur = t & 1, nxt = cur ^ 1;
     UIC_TRY(decode_step(*d, w, dv, b, L, cur, nxt, t, drop_p, seed, s, (training & 1) != 0));
