@@ -1075,3 +1075,23 @@ def test_trainer_prefetch_next_batch_equals_plain_training():
     assert l0 == l1, (l0, l1)
     for k in w0:
         assert torch.equal(w0[k], w1[k]), k
+
+
+def test_hold_weights_refreshes_again_after_the_block():
+    """engine.hold_weights() (one weight refresh for the passes of a self-critical step) must not outlive its block: a
+    parameter changed afterwards is seen by the next call; inside the block the first call refreshes."""
+    cfg, W, I, Out, G, X = load_golden("topdown_tiny")
+    model = build_model(cfg, W, "f32").eval()
+    fc, att, labels, am = (I[k].cuda() for k in ("fc_feats", "att_feats", "labels", "att_masks"))
+    with torch.no_grad():
+        base = model(fc, None, att, labels, am).clone()
+        with model.engine.hold_weights():
+            a = model(fc, None, att, labels, am)
+            b = model(fc, None, att, labels, am)          # no refresh here
+        assert torch.equal(a, base) and torch.equal(b, base)
+        final_logit(model).bias[3] += 1.0
+        c = model(fc, None, att, labels, am)
+        assert (c - base).abs().max().item() > 1e-2       # the change is picked up: the hold is over
+        with model.engine.hold_weights():
+            d = model(fc, None, att, labels, am)          # first call inside a new block refreshes too
+        assert torch.equal(c, d)
