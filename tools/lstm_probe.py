@@ -1,7 +1,7 @@
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.argv = [sys.argv[0], "none"]
-import tools.kbench as kb
+import kbench as kb
 for M in (640, 320, 128, 64):
     for Ks in ([64], [256], [512], [512, 512], [512, 512, 512]):
         kb.bench_lstm(M, 512, Ks)
