@@ -2,8 +2,9 @@
  * device memory.  Compiled and run by tests/test_gpu_c_abi.py on the GPU box:
  *     gcc -std=c11 tests/c_abi_client.c -Iinclude -I/opt/rocm/include -D__HIP_PLATFORM_AMD__ -Lunpaired_image_captioning_amd -luic_hip \
  *         -L/opt/rocm/lib -lamdhip64 -lm -o c_abi_client
- * Exercises: the workspace-size queries, an argument error with its message, uic_linear (f32), uic_attention_fwd (f32)
- * and uic_adam_step against loops written here, on the caller's own stream.  Prints "C ABI OK" and exits 0. */
+ * Exercises: the workspace-size queries, an argument error with its message, uic_linear (f32), uic_attention_fwd (f32),
+ * uic_adam_step and the fused captioner training step (uic_topdown_refresh_weights + uic_topdown_xe_train_step) against
+ * loops / closed forms written here, on the caller's own stream.  Prints "C ABI OK" and exits 0. */
 #include <math.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -126,6 +127,70 @@ int main(void) {
     double worst = 0;
     for (int i = 0; i < n; ++i) { double e = fabs(out[i] - rp[i]); if (e > worst) worst = e; }
     if (worst > 1e-5) { fprintf(stderr, "uic_adam_step off by %g\n", worst); return 1; }
+  }
+  /* the fused training step of the captioner from C: with all-zero weights every step predicts the uniform distribution,
+   * so loss = ln(V1) and d loss / d logit.bias[v] = sum_rows mask * (1/V1 - [label == v]) / sum(mask) */
+  {
+    uic_topdown_dims dd;
+    memset(&dd, 0, sizeof(dd));
+    dd.N = 6; dd.R = 5; dd.D = 64; dd.Dfc = 64; dd.H = 32; dd.E = 32; dd.A = 32; dd.V1 = 51; dd.T = 7;
+    dd.dtype = UIC_DTYPE_F32; dd.drop_p = 0.f;
+    const int N = dd.N, R = dd.R, D = dd.D, H = dd.H, E = dd.E, A = dd.A, V1 = dd.V1, T = dd.T, ld = T + 1;
+    const size_t sizes[21] = {(size_t)V1 * E, (size_t)H * D, H, (size_t)H * D, H, (size_t)V1 * H, V1, (size_t)A * H, A,
+                              (size_t)4 * H * (E + 2 * H), (size_t)4 * H * H, 4 * H, 4 * H, (size_t)4 * H * 2 * H, (size_t)4 * H * H, 4 * H, 4 * H,
+                              (size_t)A * H, A, A, 1};
+    uic_topdown_weights W, G;
+    memset(&W, 0, sizeof(W));
+    memset(&G, 0, sizeof(G));
+    float** wp = (float**)&W;      /* the first 21 members are the float* tensors in state_dict order */
+    float** gp = (float**)&G;
+    for (int i = 0; i < 21; ++i) {
+      wp[i] = to_dev(NULL, sizeof(float) * sizes[i]);
+      gp[i] = to_dev(NULL, sizeof(float) * sizes[i]);
+      if (!wp[i] || !gp[i]) return 2;
+      CHECK_HIP(hipMemsetAsync(wp[i], 0, sizeof(float) * sizes[i], stream));
+    }
+    float *fc = malloc(sizeof(float) * N * D), *att = malloc(sizeof(float) * N * R * D), *masks = calloc((size_t)N * ld, sizeof(float));
+    long long* labels = calloc((size_t)N * ld, sizeof(long long));
+    for (int i = 0; i < N * D; ++i) fc[i] = frand(&seed);
+    for (int i = 0; i < N * R * D; ++i) att[i] = frand(&seed);
+    double den = 0;
+    for (int n = 0; n < N; ++n) {
+      const int len = 2 + n % 4;                       /* caption length; the mask covers len + 2 positions (dataloader.py:283-286) */
+      for (int t = 1; t <= len; ++t) labels[n * ld + t] = 1 + (n * 7 + t * 3) % (V1 - 1);
+      for (int t = 0; t < len + 2 && t < ld; ++t) masks[n * ld + t] = 1.f;
+      for (int t = 1; t <= T; ++t) den += masks[n * ld + t];
+    }
+    uic_topdown_batch b;
+    memset(&b, 0, sizeof(b));
+    b.fc_feats = to_dev(fc, sizeof(float) * N * D);
+    b.att_feats = to_dev(att, sizeof(float) * N * R * D);
+    b.labels = to_dev(labels, sizeof(long long) * N * ld); b.ld_labels = ld;
+    b.masks = to_dev(masks, sizeof(float) * N * ld); b.ld_masks = ld;
+    void* wsp = to_dev(NULL, uic_topdown_workspace_bytes(&dd));
+    void* drv = to_dev(NULL, uic_topdown_derived_bytes(&dd));
+    float* out = to_dev(NULL, 2 * sizeof(float));
+    if (!b.fc_feats || !b.att_feats || !b.labels || !b.masks || !wsp || !drv || !out) return 2;
+    CHECK_UIC(uic_topdown_refresh_weights(&dd, &W, drv, stream));
+    CHECK_UIC(uic_topdown_xe_train_step(&dd, &W, drv, &b, T, 1, 123u, wsp, NULL, out, out + 1, &G, stream));
+    CHECK_HIP(hipStreamSynchronize(stream));
+    float h_out[2], *gb = malloc(sizeof(float) * V1);
+    CHECK_HIP(hipMemcpy(h_out, out, sizeof(h_out), hipMemcpyDeviceToHost));
+    CHECK_HIP(hipMemcpy(gb, G.logit_b, sizeof(float) * V1, hipMemcpyDeviceToHost));
+    if (fabs(h_out[0] - log((double)V1)) > 1e-5 || fabs(h_out[1] - den) > 1e-6) {
+      fprintf(stderr, "xe_train_step: loss %g (want %g), sum(mask) %g (want %g)\n", h_out[0], log((double)V1), h_out[1], den);
+      return 1;
+    }
+    double worst = 0;
+    for (int v = 0; v < V1; ++v) {
+      double want = 0;
+      for (int n = 0; n < N; ++n)
+        for (int t = 0; t < T; ++t) want += masks[n * ld + t + 1] * (1.0 / V1 - (labels[n * ld + t + 1] == v ? 1.0 : 0.0));
+      want /= den;
+      const double e = fabs(want - gb[v]);
+      if (e > worst) worst = e;
+    }
+    if (worst > 1e-6) { fprintf(stderr, "xe_train_step: d logit.bias off by %g\n", worst); return 1; }
   }
   printf("C ABI OK\n");
   return 0;
