@@ -93,6 +93,18 @@ def test_no_cpu_fallback():
         model(I["fc_feats"], None, I["att_feats"], I["att_masks"], opt={"sample_max": 1}, mode="sample")
 
 
+def test_missing_library_fails_loudly(monkeypatch, tmp_path):
+    """No libuic_hip.so -> RuntimeError naming the build command; never a silent CPU / eager path."""
+    from unpaired_image_captioning_amd import _lib
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_lib, "LIB_PATH", str(tmp_path / "libuic_hip.so"))
+    with pytest.raises(RuntimeError, match="not built.*no CPU fallback"):
+        _lib.load()
+    with pytest.raises(RuntimeError, match="not built"):
+        from unpaired_image_captioning_amd.topdown_engine import TopDownEngine
+        TopDownEngine(dict(V1=51, E=32, H=32, A=32, D=64, Dfc=64))
+
+
 def test_unsupported_options_raise():
     from unpaired_image_captioning_amd import models
     with pytest.raises(ValueError):
