@@ -105,6 +105,32 @@ def test_missing_library_fails_loudly(monkeypatch, tmp_path):
         TopDownEngine(dict(V1=51, E=32, H=32, A=32, D=64, Dfc=64))
 
 
+def test_product_code_never_imports_the_oracle():
+    """oracle/ is test infrastructure: nothing under unpaired_image_captioning_amd/ may import or execute it, and the only
+    top-level users are bench.py's cpu_baseline leg and __graft_entry__.smoke()."""
+    import ast
+    pkg = os.path.join(ROOT, "unpaired_image_captioning_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if not f.endswith(".py"):
+                continue
+            tree = ast.parse(open(os.path.join(dirpath, f)).read())
+            for node in ast.walk(tree):
+                names = []
+                if isinstance(node, ast.Import):
+                    names = [a.name for a in node.names]
+                elif isinstance(node, ast.ImportFrom):
+                    names = [node.module or ""]
+                assert not any(n == "oracle" or n.startswith("oracle.") for n in names), (f, names)
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    tree = ast.parse(src)
+    users = [fn.name for fn in ast.walk(tree) if isinstance(fn, ast.FunctionDef)
+             and any(isinstance(n, (ast.Import, ast.ImportFrom)) and "oracle" in ast.dump(n) for n in ast.walk(fn))]
+    assert users == ["cpu_baseline"], users
+    top = [n for n in tree.body if isinstance(n, (ast.Import, ast.ImportFrom)) and "oracle" in ast.dump(n)]
+    assert not top
+
+
 def test_unsupported_options_raise():
     from unpaired_image_captioning_amd import models
     with pytest.raises(ValueError):
