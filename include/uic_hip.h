@@ -160,7 +160,7 @@ int uic_topdown_xe_train_step(const uic_topdown_dims* d, const uic_topdown_weigh
                               const uic_topdown_weights* grads, void* stream);
 /* Data-parallel overlap: makes `stream` wait until the most recent uic_topdown_xe_train_step on the current device has
  * FINAL gradients for a group of tensors, while that call is still computing the rest on its own streams:
- *   group 0: logit.weight / logit.bias (and the loss)  -- final when the BPTT loop STARTS (~48 % of the bytes);
+ *   group 0: logit.weight / logit.bias (and the loss)  -- final when the BPTT loop STARTS (~25 % of the bytes);
  *   group 1: everything except the late group {att_embed.*, ctx2att.*, core.attention.h2att.*,
  *            core.attention.alpha_net.*}               -- final when the recurrent weight gradients are done.
  * A caller that lays its flat gradient arena out as [logit | rest of the early group | late group] can start the RCCL
