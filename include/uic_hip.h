@@ -160,12 +160,13 @@ int uic_topdown_xe_train_step(const uic_topdown_dims* d, const uic_topdown_weigh
                               const uic_topdown_weights* grads, void* stream);
 /* Data-parallel overlap: makes `stream` wait until the most recent uic_topdown_xe_train_step on the current device has
  * FINAL gradients for a group of tensors, while that call is still computing the rest on its own streams:
- *   group 0: logit.weight / logit.bias (and the loss)  -- final when the BPTT loop STARTS (~25 % of the bytes);
- *   group 1: everything except the late group {att_embed.*, ctx2att.*, core.attention.h2att.*,
- *            core.attention.alpha_net.*}               -- final when the recurrent weight gradients are done.
- * A caller that lays its flat gradient arena out as [logit | rest of the early group | late group] can start the RCCL
- * all-reduce of the first two pieces on a communication stream as each becomes final; the tail follows on the step's
- * stream.  Enqueue-only (hipStreamWaitEvent), no host sync. */
+ *   group 0: logit.* (and the loss)                       -- final when the BPTT loop STARTS (~25 % of the bytes);
+ *   group 1: core.att_lstm.weight_{ih,hh}, core.lang_lstm.weight_{ih,hh} -- final right after the BPTT loop (~37 %);
+ *   group 2: everything except the late group {att_embed.*, ctx2att.*, core.attention.h2att.*,
+ *            core.attention.alpha_net.*}                   -- final when the embedding / fc_embed / bias gradients are done.
+ * A caller that lays its flat gradient arena out as [logit | LSTM weight matrices | rest of the early group | late group] can
+ * start the RCCL all-reduce of the first three pieces on a communication stream as each becomes final; the tail follows on
+ * the step's stream.  Enqueue-only (hipStreamWaitEvent), no host sync. */
 int uic_topdown_grad_ready_wait(void* stream, int32_t group);
 
 /* AttModel._sample with beam_size = 1 (P/models/AttModel.py:198-253): greedy (sample_max = 1) or

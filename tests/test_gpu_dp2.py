@@ -56,7 +56,7 @@ def _worker(rank, world, port, out_dir):
     rows = slice(lo * cfg["S"], hi * cfg["S"])
     data = {k: I[k][rows].numpy() for k in ("fc_feats", "att_feats", "labels", "masks", "att_masks")}
     tr, losses = _train(cfg, W, data, STEPS)
-    assert tr.exchange.world_size == world and len(tr.arena_splits) == 2 and 0 < tr.arena_splits[0] < tr.arena_splits[1] < tr.arena.numel
+    assert tr.exchange.world_size == world and len(tr.arena_splits) == 3 and 0 < tr.arena_splits[0] < tr.arena_splits[1] < tr.arena_splits[2] < tr.arena.numel
     if rank == 0:
         torch.save({"sd": {k: v.cpu() for k, v in tr.i2t_model.state_dict().items()}, "losses": losses},
                    os.path.join(out_dir, "dp2.pt"))

@@ -87,19 +87,22 @@ class Trainer(object):
         self.arena = None
         self.last_loss = None
 
-    # flat-arena order [FIRST_GRADS | rest | LATE_GRADS] = gradient groups 0 / 1 / tail of uic_topdown_grad_ready_wait
+    # flat-arena order [FIRST_GRADS | LSTM_W_GRADS | rest | LATE_GRADS] = gradient groups 0 / 1 / 2 / tail of uic_topdown_grad_ready_wait
     # (include/uic_hip.h): each piece's all-reduce starts while the step is still computing the following ones
     FIRST_GRADS = ("logit.",)
+    LSTM_W_GRADS = ("core.att_lstm.weight_", "core.lang_lstm.weight_")
     LATE_GRADS = ("att_embed.", "ctx2att.", "core.attention.")
 
     def build_optimizer(self):
         self.i2t_model.cuda()
         names = self.i2t_model.param_names
         first = [k for k in names if k.startswith(self.FIRST_GRADS)]
+        lstm_w = [k for k in names if k.startswith(self.LSTM_W_GRADS)]
         late = [k for k in names if k.startswith(self.LATE_GRADS)]
-        early = [k for k in names if k not in first and k not in late]
-        self.arena = FlatArena(self.i2t_model, first + early + late)
-        self.arena_splits = [self.arena.offsets[g[0]] for g in (early, late) if g] if first and early and late else []
+        early = [k for k in names if k not in first and k not in lstm_w and k not in late]
+        self.arena = FlatArena(self.i2t_model, first + lstm_w + early + late)
+        groups = (lstm_w, early, late)
+        self.arena_splits = [self.arena.offsets[g[0]] for g in groups] if first and all(groups) else []
         self._step = 0
 
     def update_LearningRate(self, epoch):
