@@ -161,10 +161,11 @@ int uic_topdown_xe_train_step(const uic_topdown_dims* d, const uic_topdown_weigh
 /* Data-parallel overlap: makes `stream` wait until the most recent uic_topdown_xe_train_step on the current device has
  * FINAL gradients for a group of tensors, while that call is still computing the rest on its own streams:
  *   group 0: logit.* (and the loss)                       -- final when the BPTT loop STARTS (~25 % of the bytes);
- *   group 1: core.att_lstm.weight_{ih,hh}, core.lang_lstm.weight_{ih,hh} -- final right after the BPTT loop (~37 %);
+ *   group 1: core.lang_lstm.weight_{ih,hh}, core.att_lstm.weight_hh       -- final right after the BPTT loop (~21 %; the fc'
+ *            columns of core.att_lstm.weight_ih still come from the sum over steps, so that matrix belongs to group 2);
  *   group 2: everything except the late group {att_embed.*, ctx2att.*, core.attention.h2att.*,
  *            core.attention.alpha_net.*}                   -- final when the embedding / fc_embed / bias gradients are done.
- * A caller that lays its flat gradient arena out as [logit | LSTM weight matrices | rest of the early group | late group] can
+ * A caller that lays its flat gradient arena out as [logit | group 1 | rest of the early group | late group] can
  * start the RCCL all-reduce of the first three pieces on a communication stream as each becomes final; the tail follows on
  * the step's stream.  Enqueue-only (hipStreamWaitEvent), no host sync. */
 int uic_topdown_grad_ready_wait(void* stream, int32_t group);

@@ -386,7 +386,7 @@ struct SideStream {
   hipStream_t stream = nullptr;
   hipEvent_t ev_den = nullptr, ev_done = nullptr;
   hipEvent_t ev_logit = nullptr;    // side: the logit layer's gradients and the loss are final (start of the BPTT loop)
-  hipEvent_t ev_lstm = nullptr;     // side: the LSTM weight matrices' gradients are final (right after the BPTT loop)
+  hipEvent_t ev_lstm = nullptr;     // side: lang_lstm.weight_{ih,hh} and att_lstm.weight_hh are final (right after the BPTT loop)
   hipEvent_t ev_early = nullptr;    // main: every gradient except the late group (see uic_topdown_grad_ready_wait) is final
   bool early_recorded = false;
   hipEvent_t ev_r0 = nullptr, ev_refresh = nullptr;   // uic_topdown_refresh_weights: main -> side, side -> consumers
@@ -782,7 +782,6 @@ struct Step {
   // data-parallel caller can start exchanging the early group (LSTMs, embedding, fc_embed; with the logit layer
   // > 85 % of the bytes) while the late group (h2att, alpha_net, ctx2att, att_embed) is still being computed
   int bwd_epilogue(hipStream_t s) {
-    UIC_TRY(bwd_epilogue_fc_cols(s));      // (also produces dGfc, which the early group's fc_embed gradients need)
     UIC_TRY(bwd_epilogue_early(s));
     return bwd_epilogue_late(s);
   }
@@ -821,14 +820,6 @@ struct Step {
 
   // chunked == true: wgrad_chunk already produced the LSTM / h2att weight gradients
   // side == true: runs on the fused step's side stream with that stream's own scratch buffers
-  // fc' columns of att_lstm.weight_ih: dGfc = sum_t dG1_t, dW[:, H:2H] = dGfc^T fc'.  Runs FIRST after the BPTT loop, so that all
-  // four LSTM weight matrices are final (and their exchange can start) before the rest of the early group is computed.
-  int bwd_epilogue_fc_cols(hipStream_t s, bool side = false) {
-    UIC_TRY(uic_sum_steps_launch(dt, L.dg1_all, t_run, (size_t)N * H4, L.dgfc, s));
-    const UicGemmTnSeg seg{L.fcp, H, H};
-    const WDest d1{G->att_lstm_w_ih + H, ldih, 0, H};
-    return wgrad_group(side ? L.slab2 : L.slab, L.dgfc, H4, H4, &seg, 1, N, &d1, 1, s, false, side ? L.tSA : L.tA, side ? L.tSB : L.tB);
-  }
   int bwd_epilogue_early(hipStream_t s, bool chunked = false, bool side = false) {
     void* const tA = side ? L.tSA : L.tA;
     void* const tB = side ? L.tSB : L.tB;
@@ -860,6 +851,13 @@ struct Step {
       UIC_TRY(uic_fill_launch(G->embed_w, 0, (size_t)V1 * E * 4, s));
       UIC_TRY(uic_embed_bwd_launch(dt, L.dxt, L.xt_all, ss_on() ? L.tok_used : b->labels, ss_on() ? d.T : b->ld_labels, N, t_run,
                                    V1, E, drop_p, -1, G->embed_w, s));
+    }
+    // fc' path: dGfc = sum_t dG1_t
+    UIC_TRY(uic_sum_steps_launch(dt, L.dg1_all, t_run, (size_t)N * H4, L.dgfc, s));
+    {
+      const UicGemmTnSeg seg{L.fcp, H, H};
+      const WDest d1{G->att_lstm_w_ih + H, ldih, 0, H};
+      UIC_TRY(wgrad_group(slab, L.dgfc, H4, H4, &seg, 1, N, &d1, 1, s, false, tA, tB));
     }
     {
       UicGemmParams g = gemm_base(dt, N, H);
@@ -1114,8 +1112,7 @@ int uic_topdown_xe_train_step(const uic_topdown_dims* d, const uic_topdown_weigh
   }
   // side: the rest of the early gradient group (LSTM / h2att biases, embedding, fc_embed); main: the late group
   // (attention accumulation, ctx2att, att_embed).  ev_early: the early group, the logit layer and the loss are final.
-  UIC_TRY(st.bwd_epilogue_fc_cols(s2, true));
-  UIC_HIP(hipEventRecord(ss->ev_lstm, s2));           // gradient group 1 (the four LSTM weight matrices) final
+  UIC_HIP(hipEventRecord(ss->ev_lstm, s2));           // gradient group 1 (lang_lstm.weight_*, att_lstm.weight_hh) final
   UIC_TRY(st.bwd_epilogue_early(s2, true, true));
   UIC_HIP(hipEventRecord(ss->ev_early, s2));
   ss->early_recorded = true;

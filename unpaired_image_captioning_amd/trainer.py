@@ -90,7 +90,7 @@ class Trainer(object):
     # flat-arena order [FIRST_GRADS | LSTM_W_GRADS | rest | LATE_GRADS] = gradient groups 0 / 1 / 2 / tail of uic_topdown_grad_ready_wait
     # (include/uic_hip.h): each piece's all-reduce starts while the step is still computing the following ones
     FIRST_GRADS = ("logit.",)
-    LSTM_W_GRADS = ("core.att_lstm.weight_", "core.lang_lstm.weight_")
+    LSTM_W_GRADS = ("core.lang_lstm.weight_", "core.att_lstm.weight_hh")      # final right after the BPTT loop
     LATE_GRADS = ("att_embed.", "ctx2att.", "core.attention.")
 
     def build_optimizer(self):
