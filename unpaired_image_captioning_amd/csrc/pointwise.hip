@@ -557,10 +557,19 @@ __global__ __launch_bounds__(NT) void logsoftmax_bwd_kernel(T* __restrict__ dlog
 __global__ __launch_bounds__(NT) void masked_sum_kernel(const float* __restrict__ mask, int ldmask, int col0, int N, int TS,
                                                         float* out_sum, float* out_inv) {
   __shared__ float s_buf[NT / 64];
+  // eight independent loads in flight per thread: a single 256-thread block chasing one load at a time took 21 us here
   float s = 0.f;
-  for (int i = threadIdx.x; i < N * TS; i += NT) {
-    const int n = i / TS, t = i - n * TS;
-    s += mask[(size_t)n * ldmask + col0 + t];
+  const int total = N * TS;
+  for (int i0 = threadIdx.x; i0 < total; i0 += NT * 8) {
+    float v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int i = i0 + u * NT;
+      const int n = i / TS, t = i - n * TS;
+      v[u] = i < total ? mask[(size_t)n * ldmask + col0 + t] : 0.f;
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) s += v[u];
   }
   s = block_reduce_sum(s, s_buf);
   if (threadIdx.x == 0) {
@@ -572,9 +581,24 @@ __global__ __launch_bounds__(NT) void masked_sum_kernel(const float* __restrict_
 __global__ __launch_bounds__(NT) void reduce_sum_kernel(const float* __restrict__ x, size_t n, const float* scale, float* out) {
   __shared__ float s_buf[NT / 64];
   float s = 0.f;
-  for (size_t i = threadIdx.x; i < n; i += NT) s += x[i];
+  for (size_t i0 = threadIdx.x; i0 < n; i0 += (size_t)NT * 8) {
+    float v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = i0 + (size_t)u * NT < n ? x[i0 + (size_t)u * NT] : 0.f;
+#pragma unroll
+    for (int u = 0; u < 8; ++u) s += v[u];
+  }
   s = block_reduce_sum(s, s_buf);
   if (threadIdx.x == 0) out[0] = scale ? s * scale[0] : s;
+}
+
+struct UicZero4 { uint4* p[4]; size_t n[4]; };     // n in 16-byte units
+__global__ void zero4_kernel(const UicZero4 z) {
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  const uint4 zero = make_uint4(0, 0, 0, 0);
+#pragma unroll
+  for (int k = 0; k < 4; ++k)
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < z.n[k]; i += stride) z.p[k][i] = zero;
 }
 
 // ------------------------------------------------------------------ Adam (torch.optim.Adam, P/misc/optimizer.py:70)
@@ -966,6 +990,22 @@ int uic_masked_sum_launch(const float* x, const float* mask, int ldmask, int col
   (void)x;
   hipLaunchKernelGGL(masked_sum_kernel, dim3(1), dim3(NT), 0, s, mask, ldmask, col0, N, T, out_sum, out_inv);
   UIC_LAUNCH_CHECK("masked_sum");
+  return UIC_OK;
+}
+int uic_zero4_launch(void* p0, size_t b0, void* p1, size_t b1, void* p2, size_t b2, void* p3, size_t b3, hipStream_t s) {
+  void* ps[4] = {p0, p1, p2, p3};
+  const size_t bs[4] = {b0, b1, b2, b3};
+  UicZero4 z;
+  size_t most = 0;
+  for (int k = 0; k < 4; ++k) {
+    UIC_REQUIRE(bs[k] == 0 || (ps[k] && ((uintptr_t)ps[k] & 15) == 0 && bs[k] % 16 == 0), "zero4: buffer %d must be 16-byte aligned / sized", k);
+    z.p[k] = (uint4*)ps[k];
+    z.n[k] = bs[k] / 16;
+    if (z.n[k] > most) most = z.n[k];
+  }
+  if (most == 0) return UIC_OK;
+  hipLaunchKernelGGL(zero4_kernel, dim3(grid_for(most, NT)), dim3(NT), 0, s, z);
+  UIC_LAUNCH_CHECK("zero4");
   return UIC_OK;
 }
 int uic_reduce_sum_launch(const float* x, size_t n, float unused, const float* scale, float* out, hipStream_t s) {

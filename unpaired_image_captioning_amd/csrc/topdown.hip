@@ -580,11 +580,8 @@ struct Step {
       UIC_TRY(uic_gemm_launch(g, s));
     }
     if (ss_on()) UIC_TRY(uic_copy_tokens_launch(b->labels, b->ld_labels, N, t_run, L.tok_used, d.T, s));
-    UIC_TRY(uic_fill_launch(L.h_att, 0, NH * S, s));     // init_hidden (AttModel.py:94-97)
-    UIC_TRY(uic_fill_launch(L.h_lang, 0, NH * S, s));
-    UIC_TRY(uic_fill_launch(L.c_att, 0, NH * 4, s));
-    UIC_TRY(uic_fill_launch(L.c_lang, 0, NH * 4, s));
-    return UIC_OK;
+    // init_hidden (AttModel.py:94-97): slot 0 of the four state buffers, one launch
+    return uic_zero4_launch(L.h_att, NH * S, L.h_lang, NH * S, L.c_att, NH * 4, L.c_lang, NH * 4, s);
   }
 
   int fwd_step(int t, hipStream_t s) {
@@ -715,8 +712,7 @@ struct Step {
 
   // ---------------------------------------------------------------- backward
   int bwd_begin(hipStream_t s) {
-    UIC_TRY(uic_fill_launch(L.dc_att, 0, NH * 4, s));
-    return uic_fill_launch(L.dc_lang, 0, NH * 4, s);
+    return uic_zero4_launch(L.dc_att, NH * 4, L.dc_lang, NH * 4, nullptr, 0, nullptr, 0, s);
   }
 
   int bwd_step(int t, hipStream_t s) {

@@ -246,6 +246,8 @@ int uic_attention_bwd_accum_launch(const UicAttnAccumParams& p, hipStream_t s);
 int uic_cast_f32_launch(int dtype, const float* src, void* dst, size_t n, hipStream_t s);
 int uic_to_f32_launch(int dtype, const void* src, float* dst, size_t n, hipStream_t s);
 int uic_fill_launch(void* dst, int value_byte, size_t bytes, hipStream_t s);
+// zero up to four buffers (16-byte aligned, sizes multiples of 16) in ONE launch instead of one memset node each
+int uic_zero4_launch(void* p0, size_t b0, void* p1, size_t b1, void* p2, size_t b2, void* p3, size_t b3, hipStream_t s);
 // dst[cols, ldd] = src[rows, lds]^T, zero-filling dst columns rows..ldd-1
 int uic_transpose_launch(int dtype, const void* src, int rows, int cols, int lds, void* dst, int ldd, hipStream_t s);
 // out[c] = sum_r src[r, c]  (deterministic two-stage; src operand dtype or f32)
