@@ -403,6 +403,24 @@ int uic_ciderd_scores(const int64_t* hyp, int32_t n_hyp, int32_t L, int32_t batc
  * `scores` are the sampled captions, rows N..2N-1 the greedy baseline. */
 int uic_ciderd_reward(const double* scores, int32_t N, int32_t L, float weight, float* reward, void* stream);
 
+/* ---- input pipeline: batch assembly on the device --------------------------------------------------------------------
+ * Replaces the per-image numpy work of DataLoader.__getitem__ (P/misc/dataloader/dataloader.py:302-331) and the padding /
+ * masking of DataLoader.get_batch (:277-283).  The host packs the RAW per-image files back to back, once per image (no
+ * seq_per_img replication -- that is uic_topdown_dims.seq_per_img):
+ *   feat_pack    [n_regions, D] f32: the `feat` arrays of the att .npz files, images in loader order;
+ *   box_pack     [n_regions, 4] f32 (x1, y1, x2, y2) of the box .npy files, or NULL for use_box = 0;
+ *   region_start [n_img + 1] i32: image i owns regions region_start[i] .. region_start[i+1] - 1;
+ *   img_hw       [n_img, 3] f32 (height, width, width * height) from the info json (needed with box_pack);
+ *   img_slot     [n_img] i32: output position of image i (get_batch's stable sort by region count, descending, :264-265).
+ * Output att_feats [n_img, Rmax, ld_out] f32 (ld_out >= D + 5 with boxes; columns past the data are zero-filled so a row
+ * padded for the captioner's GEMMs needs no second pass) and att_masks [n_img, Rmax] f32.  Per region: x / ||x||_2 when
+ * norm_att_feat (:310-311), box features (x1/w, y1/h, x2/w, y2/h, area/(wh)) [/ their L2 norm when norm_box_feat] appended
+ * (:318-325), regions sorted by the last column, descending, stable (:327).  Every f32 operation is done in numpy's order
+ * (pairwise summation included): the batch is bit-identical to the reference's.  D <= 16384, Rmax <= 2048. */
+int uic_att_batch_assemble(const float* feat_pack, const float* box_pack, const int32_t* region_start, const float* img_hw,
+                           const int32_t* img_slot, int32_t n_img, int32_t D, int32_t norm_att_feat, int32_t norm_box_feat,
+                           int32_t Rmax, int32_t ld_out, float* att_feats, float* att_masks, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

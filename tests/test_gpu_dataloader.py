@@ -1,0 +1,177 @@
+"""The device input pipeline (csrc/loader.hip through uic_att_batch_assemble, and the DataLoader above it) against
+(1) what the reference's own DataLoader returned for the same files (tests/golden/dataloader_*.npz) and (2) the numpy
+oracle on random data sets.  Bit-exact: the kernel restates numpy's float32 arithmetic, pairwise summation included."""
+import os
+import random
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import GOLDEN
+from dataset_files import loader_opt, write_dataset
+from test_oracle_dataloader import CASES, load_case
+
+pytestmark = pytest.mark.gpu
+
+
+def hdf5_or_npz():
+    from unpaired_image_captioning_amd.misc.dataloader import label_store
+    try:
+        import h5py  # noqa: F401
+        return "h5"
+    except ImportError:
+        pass
+    try:
+        label_store.Hdf5Library()
+        return "h5"
+    except ImportError:
+        return "npz"
+
+
+def make_loader(tmp_path, cfg, z):
+    from unpaired_image_captioning_amd.misc.dataloader.dataloader import DataLoader
+    n = cfg["n_images"]
+    label_path = write_dataset(str(tmp_path), [z["in::att_%d" % i] for i in range(n)],
+                               [z["in::box_%d" % i] for i in range(n)], [z["in::fc_%d" % i] for i in range(n)],
+                               z["in::hw"], z["in::ids"], z["in::labels"], z["in::label_start_ix"], z["in::label_end_ix"],
+                               cfg["V"], label_format=hdf5_or_npz())
+    opt = loader_opt(str(tmp_path), label_path, cfg["batch_size"], cfg["S"], cfg["Dfc"], cfg["D"] + 5 * cfg["use_box"],
+                     cfg["use_box"], cfg["norm_att"], cfg["norm_box"])
+    return DataLoader(opt)
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_batches_equal_the_reference_loaders(name, tmp_path):
+    from unpaired_image_captioning_amd.misc.dataloader.dataloader import reference_layout
+    cfg, z = load_case(name)
+    loader = make_loader(tmp_path, cfg, z)
+    assert loader.get_seq_length() == cfg["L"] and loader.get_vocab_size() == cfg["V"]
+    random.seed(cfg["seed"])
+    for b in range(cfg["n_batches"]):
+        dev = loader.get_batch("train")
+        assert dev["att_feats"].is_cuda and dev["att_feats"].shape[0] == cfg["batch_size"]          # once per image
+        data = reference_layout(dev)
+        for k in ("fc_feats", "att_feats", "att_masks", "labels", "masks"):
+            want = z["out::b%d_%s" % (b, k)]
+            got = np.asarray(data[k])
+            assert got.shape == want.shape, (b, k, got.shape, want.shape)
+            assert np.array_equal(got, want), (b, k, np.abs(got.astype(np.float64) - want).max())
+        assert [d["ix"] for d in data["infos"]] == list(z["out::b%d_ix" % b])
+        assert [d["id"] for d in data["infos"]] == list(z["out::b%d_id" % b])
+        for j, g in enumerate(data["gts"]):
+            assert np.array_equal(g, z["out::b%d_gts_%d" % (b, j)])
+        bd = data["bounds"]
+        assert [bd["it_pos_now"], bd["it_max"], int(bd["wrapped"])] == list(z["out::b%d_bounds" % b])
+
+
+def assemble(lib, att, box, hw, norm_att, norm_box, ld=None):
+    """Straight through the C ABI: list of per-image arrays -> (att_feats [n, Rmax, Dout], att_masks)."""
+    from unpaired_image_captioning_amd._lib import check, ptr, stream
+    n = len(att)
+    counts = [a.shape[0] for a in att]
+    order = sorted(range(n), key=lambda i: counts[i], reverse=True)
+    slot = np.empty(n, dtype=np.int32)
+    slot[order] = np.arange(n, dtype=np.int32)
+    start = np.zeros(n + 1, dtype=np.int32)
+    start[1:] = np.cumsum(counts)
+    D, Rmax = att[0].shape[1], max(counts)
+    Dout = D + (5 if box is not None else 0)
+    ld = ld or Dout
+    dev = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
+    feat_d, start_d, slot_d = dev(np.concatenate(att, 0)), dev(start), dev(slot)
+    box_d = dev(np.concatenate(box, 0)) if box is not None else None
+    hw_d = dev(np.array([(h, w, w * h) for h, w in hw], dtype=np.float32)) if box is not None else None
+    out = torch.full((n, Rmax, ld), float("nan"), device="cuda")
+    masks = torch.full((n, Rmax), float("nan"), device="cuda")
+    check(lib.uic_att_batch_assemble(ptr(feat_d), ptr(box_d), ptr(start_d), ptr(hw_d), ptr(slot_d), n, D, norm_att, norm_box,
+                                     Rmax, ld, ptr(out), ptr(masks), stream()), "att_batch_assemble")
+    return out.cpu().numpy(), masks.cpu().numpy(), order
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_random_data_sets_against_the_oracle(seed):
+    from oracle import dataloader as O
+    from unpaired_image_captioning_amd import _lib
+    lib = _lib.load()
+    rng = np.random.default_rng(100 + seed)
+    D = int(rng.choice([1, 3, 7, 8, 9, 20, 127, 128, 129, 136, 260, 1000, 1027, 2048, 4096]))
+    n = int(rng.integers(1, 7))
+    use_box, norm_att, norm_box = int(rng.integers(0, 2)), int(rng.integers(0, 2)), int(rng.integers(0, 2))
+    att, box, hw = [], [], []
+    for i in range(n):
+        R = int(rng.integers(1, 40))
+        a = rng.standard_normal((R, D)).astype(np.float32)
+        if rng.integers(0, 2):
+            a = np.abs(a)
+        att.append(a)
+        h, w = int(rng.integers(100, 1200)), int(rng.integers(100, 1200))
+        b = rng.uniform(0, 1, (R, 4)).astype(np.float32) * np.float32(min(h, w))
+        b[:, 2:] += b[:, :2] + np.float32(1.0)
+        if R > 2:
+            b[R - 1] = b[0]                                   # a tie: the sort is stable
+        box.append(b)
+        hw.append((h, w))
+    Dout = D + 5 * use_box
+    ld = Dout if seed % 2 == 0 else (Dout + 127) // 128 * 128
+    got, masks, order = assemble(lib, att, box if use_box else None, hw, norm_att, norm_box, ld)
+    Rmax = max(a.shape[0] for a in att)
+    for pos, i in enumerate(order):
+        want = O.region_features(att[i], box[i] if use_box else None, hw[i][0], hw[i][1], norm_att, norm_box)
+        R = want.shape[0]
+        assert np.array_equal(got[pos, :R, :Dout], want), (seed, D, i)
+        assert (got[pos, R:] == 0).all() and (got[pos, :, Dout:] == 0).all()
+        assert (masks[pos, :R] == 1).all() and (masks[pos, R:] == 0).all()
+    assert got.shape == (n, Rmax, ld)
+
+
+def test_val_split_keeps_its_order_and_reset_iterator(tmp_path):
+    from unpaired_image_captioning_amd.misc.dataloader.dataloader import DataLoader
+    cfg, z = load_case("dataloader_tiny")
+    n = cfg["n_images"]
+    splits = ["train", "val", "val", "test", "restval", "val", "train"][:n]
+    label_path = write_dataset(str(tmp_path), [z["in::att_%d" % i] for i in range(n)], [z["in::box_%d" % i] for i in range(n)],
+                               [z["in::fc_%d" % i] for i in range(n)], z["in::hw"], z["in::ids"], z["in::labels"],
+                               z["in::label_start_ix"], z["in::label_end_ix"], cfg["V"], splits=splits, label_format="npz")
+    opt = loader_opt(str(tmp_path), label_path, 2, 2, cfg["Dfc"], cfg["D"] + 5, 1, 1, 1)
+    loader = DataLoader(opt)
+    assert loader.split_ix == {"train": [0, 4, 6], "val": [1, 2, 5], "test": [3]}
+    seen = []
+    for _ in range(3):
+        d = loader.get_batch("val")
+        seen += [i["ix"] for i in d["infos"]]
+    assert sorted(seen[:2]) == [1, 2] and loader.split_ix["val"] == [1, 2, 5]      # no shuffle outside 'train'
+    loader.reset_iterator("val")
+    assert loader.iterators["val"] == 0
+    d = loader.get_batch("test", batch_size=1, seq_per_img=3)
+    assert d["labels"].shape == (3, cfg["L"] + 2) and d["att_feats"].shape[0] == 1 and d["bounds"]["wrapped"]
+
+
+def test_loader_batch_trains_the_captioner_without_a_padding_copy(tmp_path):
+    """att_feat_size = 2053 (boxes): the loader hands rows already at the 2176-column stride the library wants; the step on
+    that view equals the step on a plain contiguous copy of the same batch."""
+    import argparse
+    from unpaired_image_captioning_amd import models
+    from unpaired_image_captioning_amd.trainer import xe_step
+    cfg, z = load_case("dataloader_real")
+    loader = make_loader(tmp_path, cfg, z)
+    random.seed(1)
+    d = loader.get_batch("train")
+    att = d["att_feats"]
+    assert att.shape[-1] == 2053 and att.stride(1) == 2176 and getattr(att, "_uic_zero_padded_ld") == 2176
+    opt = argparse.Namespace(vocab_size=cfg["V"], input_encoding_size=64, rnn_size=64, num_layers=1, drop_prob_lm=0.0,
+                             seq_length=cfg["L"], fc_feat_size=2048, att_feat_size=2053, att_hid_size=64, use_bn=0,
+                             logit_layers=1, caption_model="topdown")
+    torch.manual_seed(0)
+    model = models.setup(opt).cuda()
+    model.train()
+    batch = {"fc_feats": d["fc_feats"], "att_feats": att, "att_masks": d["att_masks"],
+             "labels": torch.from_numpy(d["labels"]).cuda(), "masks": torch.from_numpy(d["masks"]).cuda()}
+    padded = model.engine._pad_att(att)
+    assert padded.data_ptr() == att.data_ptr() and padded.shape[-1] == 2176                     # no copy
+    loss_a, grads_a = xe_step(model, batch)
+    batch_b = dict(batch, att_feats=att.contiguous())
+    loss_b, grads_b = xe_step(model, batch_b)
+    assert torch.equal(loss_a, loss_b)
+    for k in grads_a:                  # (atomically accumulated gradients: equal up to summation order)
+        torch.testing.assert_close(grads_a[k], grads_b[k], rtol=1e-4, atol=1e-7, msg=k)

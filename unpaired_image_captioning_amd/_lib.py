@@ -214,6 +214,7 @@ _SIGS = {
                                     C.c_int32, C.c_void_p, C.c_void_p, C.c_int64, C.c_double, C.c_void_p, C.c_int32, C.c_void_p,
                                     C.c_void_p]),
     "uic_ciderd_reward": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_float, C.c_void_p, C.c_void_p]),
+    "uic_att_batch_assemble": (C.c_int, [C.c_void_p] * 5 + [C.c_int32] * 6 + [C.c_void_p] * 3),
     "uic_linear_wgrad": (C.c_int, [C.c_int32] * 4 + [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32,
                                    C.c_void_p, C.c_size_t, C.c_int32, C.c_void_p]),
     "uic_lstm_cell_fwd": (C.c_int, [C.c_int32] * 4 + [C.POINTER(C.c_void_p), C.POINTER(C.c_int32), C.POINTER(C.c_void_p),

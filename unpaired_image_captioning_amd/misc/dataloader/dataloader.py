@@ -1,0 +1,294 @@
+"""DataLoader of the reference (P/misc/dataloader/dataloader.py, P = pivot_based_eccv2018) for the MI355X path: same
+constructor (`DataLoader(opt, train=True)`), same on-disk formats, same iteration state (`iterators`, `split_ix`, shuffle
+at wrap-around, caption sampling from the global `random` stream), same batch dict -- but the per-image numpy work of
+`__getitem__` (:302-331: L2 norm, box features, sort by box area) and the padding of `get_batch` (:270-283) run ON THE
+DEVICE in one kernel (csrc/loader.hip, `uic_att_batch_assemble`, bit-identical to numpy), and the features are shipped
+ONCE PER IMAGE: `att_feats [n_img, Rmax, att_feat_size]`, `fc_feats [n_img, fc_feat_size]`, `att_masks [n_img, Rmax]` are
+device tensors with one row per image, `labels` / `masks` [n_img * seq_per_img, L + 2] numpy arrays as in the reference.
+The captioner replicates on the device (uic_topdown_dims.seq_per_img); `reference_layout(data)` gives the reference's
+replicated numpy arrays where a caller wants them.
+
+What the host does: read the files (a small thread pool, read-ahead of the next batch), copy them back to back into a
+pinned staging buffer, one asynchronous H2D copy per array.  Nothing here falls back to a CPU computation: without the
+HIP library the constructor raises.
+
+On-disk formats:
+  opt.input_json         {'ix_to_word': {'1': ..}, 'images': [{'id', 'file_path', 'split', 'height', 'width'}]}
+  opt.input_att_dir      <id>.npz with `feat` [R_i, D] f32 (scripts/make_bu_data.py:55)
+  opt.input_fc_dir       <id>.npz with `feat` [Dfc] f32                                  (:331)
+  opt.input_box_dir      <id>.npy [R_i, 4] f32 (x1, y1, x2, y2)
+  opt.input_label_h5     HDF5 with `labels` uint32 [M, L], `label_start_ix` / `label_end_ix` (1-indexed), read through
+                         h5py when it is installed, else through the HDF5 C library (ctypes); an .npz with the same array
+                         names is accepted as well.
+Not served here: use_box_cls_prob (`attri_feats`, unused by the TopDown / FC captioners: the entry is None) and the NMT
+corpus (`data['nmt']`: see onmt_dataset_h5 in this package).
+"""
+import ctypes as C
+import json
+import os
+import random
+from concurrent.futures import ThreadPoolExecutor
+
+import numpy as np
+import torch
+
+from ... import _lib
+from ..._lib import check, ptr, stream
+from .label_store import open_label_store
+
+
+def padded_width(D):
+    """Row stride the captioner's library wants for att_feat_size D (TopDownEngine: a multiple of 8 as is, else the next
+    multiple of 128): the assembly kernel zero-fills up to it, so no second padding pass is needed."""
+    return D if D % 8 == 0 else (D + 127) // 128 * 128
+
+
+class DataLoader(object):
+
+    def reset_iterator(self, split):                                   # :26-30
+        self._ahead.clear()
+        self.iterators[split] = 0
+
+    def get_vocab_size(self):
+        return self.vocab_size
+
+    def get_vocab(self):
+        return self.ix_to_word
+
+    def get_seq_length(self):
+        return self.seq_length
+
+    def __init__(self, opt, train=True, device="cuda", read_threads=8):
+        self.lib = _lib.load()                                         # raises when the HIP library is missing
+        self.device = torch.device(device)
+        self.opt = opt
+        self.batch_size = self.opt.batch_size
+        self.nmt_train_flag = getattr(opt, 'nmt_train_flag', 0)
+        self.nmt_eval_flag = getattr(opt, 'nmt_eval_flag', 0)
+        self.fc_feat_size = opt.fc_feat_size
+        self.att_feat_size = opt.att_feat_size
+        self.seq_per_img = opt.seq_per_img
+        self.type = train
+        self.use_att = getattr(opt, 'use_att', True)
+        self.use_box = getattr(opt, 'use_box', 0)
+        self.use_box_cls_prob = 0                                      # see the module docstring
+        self.norm_att_feat = getattr(opt, 'norm_att_feat', 0)
+        self.norm_box_feat = getattr(opt, 'norm_box_feat', 0)
+
+        with open(self.opt.input_json) as f:
+            self.info = json.load(f)
+        self.ix_to_word = self.info['ix_to_word']
+        self.vocab_size = len(self.ix_to_word)
+
+        store = open_label_store(self.opt.input_label_h5)
+        self.labels = np.ascontiguousarray(store['labels'])            # [M, L] (uint32 on disk)
+        self.seq_length = self.labels.shape[1]
+        self.label_start_ix = np.asarray(store['label_start_ix']).astype(np.int64)       # 1-indexed
+        self.label_end_ix = np.asarray(store['label_end_ix']).astype(np.int64)
+        self.num_images = self.label_start_ix.shape[0]
+
+        self.input_fc_dir = self.opt.input_fc_dir
+        self.input_att_dir = self.opt.input_att_dir
+        self.input_box_dir = getattr(self.opt, 'input_box_dir', None)
+
+        self.split_ix = {'train': [], 'val': [], 'test': []}           # :100-110
+        for ix, img in enumerate(self.info['images']):
+            if img['split'] in self.split_ix:
+                self.split_ix[img['split']].append(ix)
+            elif getattr(opt, 'train_only', 0) == 0:                   # restval
+                self.split_ix['train'].append(ix)
+        self.iterators = {'train': 0, 'val': 0, 'test': 0}
+
+        self._pool = ThreadPoolExecutor(max_workers=read_threads)
+        self._ahead = {}                                               # image index -> Future of its raw arrays
+        self._pin = {}
+        self._pin_turn = 0
+
+    # ------------------------------------------------------------------ iteration state (BlobFetcher, :373-387)
+    def _next_index(self, split):
+        max_index = len(self.split_ix[split])
+        wrapped = False
+        ri = self.iterators[split]
+        ix = self.split_ix[split][ri]
+        ri_next = ri + 1
+        if ri_next >= max_index:
+            ri_next = 0
+            if split == 'train':
+                random.shuffle(self.split_ix[split])
+            wrapped = True
+        self.iterators[split] = ri_next
+        return ix, wrapped
+
+    def get_captions(self, ix, seq_per_img):                           # :181-198
+        ix1 = int(self.label_start_ix[ix]) - 1
+        ix2 = int(self.label_end_ix[ix]) - 1
+        ncap = ix2 - ix1 + 1
+        assert ncap > 0, 'an image does not have any label. this can be handled but right now isn\'t'
+        if ncap < seq_per_img:
+            seq = np.zeros([seq_per_img, self.seq_length], dtype='int')
+            for q in range(seq_per_img):
+                ixl = random.randint(ix1, ix2)
+                seq[q, :] = self.labels[ixl, :self.seq_length]
+        else:
+            ixl = random.randint(ix1, ix2 - seq_per_img + 1)
+            seq = self.labels[ixl: ixl + seq_per_img, :self.seq_length]
+        return seq
+
+    # ------------------------------------------------------------------ files
+    def _read_raw(self, ix):
+        """The raw arrays of image ix, untouched: (fc [Dfc], att [R, D], box [R, 4] | None)."""
+        iid = str(self.info['images'][ix]['id'])
+        fc = np.load(os.path.join(self.input_fc_dir, iid + '.npz'))['feat']
+        if not self.use_att:
+            return fc, np.zeros((1, 1), dtype=np.float32), None
+        att = np.load(os.path.join(self.input_att_dir, iid + '.npz'))['feat']
+        box = np.load(os.path.join(self.input_box_dir, iid + '.npy')) if self.use_box else None
+        for name, a in (("att", att), ("box", box), ("fc", fc)):
+            if a is not None and a.dtype != np.float32:
+                raise TypeError("%s features of image %s are %s: the assembly kernel restates the reference's float32 "
+                                "arithmetic (scripts/make_bu_data.py writes float32)" % (name, iid, a.dtype))
+        if att.ndim != 2 or (box is not None and box.shape != (att.shape[0], 4)):
+            raise ValueError("image %s: att features %s, boxes %s" % (iid, att.shape, None if box is None else box.shape))
+        return fc, att, box
+
+    def _fetch(self, ix):
+        fut = self._ahead.pop(ix, None)
+        return fut if fut is not None else self._pool.submit(self._read_raw, ix)
+
+    def _read_ahead(self, split, count):
+        """Start reading the files of the images the next get_batch(split) will ask for (known unless the epoch wraps)."""
+        if len(self._ahead) > 4 * count:
+            self._ahead.clear()
+        ri = self.iterators[split]
+        for ix in self.split_ix[split][ri: ri + count]:
+            if ix not in self._ahead:
+                self._ahead[ix] = self._pool.submit(self._read_raw, ix)
+
+    def _staging(self, key, shape, dtype):
+        """Pinned host buffer (two per key, alternating: the copy out of the previous batch's may still be in flight)."""
+        n = int(np.prod(shape))
+        slot = self._pin.setdefault((key, self._pin_turn), [None, None])
+        if slot[0] is None or slot[0].numel() < n or slot[0].dtype != dtype:
+            slot[0] = torch.empty(max(n, 1), dtype=dtype, pin_memory=self.device.type == "cuda")
+        elif slot[1] is not None:
+            slot[1].synchronize()
+        return slot[0][:n].view(shape), slot
+
+    def _to_device(self, key, host_view, slot):
+        dev = host_view.to(self.device, non_blocking=True)
+        if self.device.type == "cuda":
+            slot[1] = torch.cuda.Event()
+            slot[1].record()
+        return dev
+
+    # ------------------------------------------------------------------ the batch
+    def get_batch(self, split, batch_size=None, seq_per_img=None):
+        """:209-299.  Features once per image, on the device (module docstring); everything else as the reference."""
+        batch_size = batch_size or self.batch_size
+        S = seq_per_img or self.seq_per_img
+        L = self.seq_length
+        label_batch = np.zeros([batch_size * S, L + 2], dtype='int')
+        mask_batch = np.zeros([batch_size * S, L + 2], dtype='float32')
+        wrapped = False
+        futures, infos, gts = [], [], []
+        for i in range(batch_size):
+            ix, w = self._next_index(split)                            # may reshuffle: BEFORE the caption draw, as :236,247
+            futures.append(self._fetch(ix))
+            label_batch[i * S:(i + 1) * S, 1:L + 1] = self.get_captions(ix, S)
+            wrapped = wrapped or w
+            gts.append(self.labels[self.label_start_ix[ix] - 1: self.label_end_ix[ix]])
+            img = self.info['images'][ix]
+            infos.append({'ix': ix, 'id': img['id'], 'file_path': img['file_path']})
+        if wrapped:
+            self._ahead.clear()
+        self._read_ahead(split, batch_size)
+        raw = [f.result() for f in futures]
+
+        counts = [r[1].shape[0] for r in raw]
+        order = sorted(range(batch_size), key=lambda i: counts[i], reverse=True)          # :264-265, stable
+        slot_of = np.empty(batch_size, dtype=np.int32)
+        slot_of[order] = np.arange(batch_size, dtype=np.int32)
+        label_batch = np.vstack([label_batch[i * S:(i + 1) * S] for i in order])
+        gts = [gts[i] for i in order]
+        infos = [infos[i] for i in order]
+
+        data = {}
+        data['fc_feats'], data['att_feats'], data['att_masks'] = self._assemble(raw, counts, order, slot_of, infos)
+        data['attri_feats'] = None
+        data['labels'] = label_batch
+        nonzeros = (label_batch != 0).sum(1) + 2                       # :287-290
+        mask_batch[np.arange(L + 2)[None, :] < nonzeros[:, None]] = 1
+        data['masks'] = mask_batch
+        data['gts'] = gts
+        data['nmt'] = None
+        data['bounds'] = {'it_pos_now': self.iterators[split], 'it_max': len(self.split_ix[split]), 'wrapped': wrapped,
+                          'wrapper_nmt': False}
+        data['infos'] = infos
+        data['seq_per_img'] = S
+        return data
+
+    def _assemble(self, raw, counts, order, slot_of, infos):
+        n_img = len(raw)
+        self._pin_turn ^= 1
+        fc_h, fc_slot = self._staging("fc", (n_img, raw[0][0].shape[-1]), torch.float32)
+        fc_np = fc_h.numpy()
+        for pos, i in enumerate(order):
+            fc_np[pos] = raw[i][0]
+        fc_d = self._to_device("fc", fc_h, fc_slot)
+        if not self.use_att:
+            z = torch.zeros(n_img, 1, 1, device=self.device)
+            return fc_d, z, torch.ones(n_img, 1, device=self.device)
+
+        D = raw[0][1].shape[1]
+        start = np.zeros(n_img + 1, dtype=np.int32)
+        start[1:] = np.cumsum(counts)
+        total, Rmax = int(start[-1]), max(counts)
+        feat_h, feat_slot = self._staging("feat", (total, D), torch.float32)
+        feat_np = feat_h.numpy()
+
+        def put(i):
+            feat_np[start[i]:start[i + 1]] = raw[i][1]
+        list(self._pool.map(put, range(n_img)))                        # the copy into pinned memory, in parallel
+        feat_d = self._to_device("feat", feat_h, feat_slot)
+
+        meta_h, meta_slot = self._staging("meta", (n_img + 1 + n_img,), torch.int32)
+        meta_np = meta_h.numpy()
+        meta_np[:n_img + 1] = start
+        meta_np[n_img + 1:] = slot_of
+        meta_d = self._to_device("meta", meta_h, meta_slot)
+        start_d, slot_d = meta_d[:n_img + 1], meta_d[n_img + 1:]
+
+        box_d = hw_d = None
+        if self.use_box:
+            box_h, box_slot = self._staging("box", (total * 4 + n_img * 3,), torch.float32)
+            box_np = box_h.numpy()
+            for i in range(n_img):
+                box_np[start[i] * 4:start[i + 1] * 4] = raw[i][2].reshape(-1)
+                img = self.info['images'][infos[slot_of[i]]['ix']]
+                h, w = img['height'], img['width']
+                box_np[total * 4 + 3 * i: total * 4 + 3 * i + 3] = (np.float32(h), np.float32(w), np.float32(w * h))
+            bd = self._to_device("box", box_h, box_slot)
+            box_d, hw_d = bd[:total * 4], bd[total * 4:]
+
+        Dout = D + (5 if self.use_box else 0)
+        ld = padded_width(Dout)
+        att = torch.empty(n_img, Rmax, ld, dtype=torch.float32, device=self.device)
+        masks = torch.empty(n_img, Rmax, dtype=torch.float32, device=self.device)
+        check(self.lib.uic_att_batch_assemble(ptr(feat_d), ptr(box_d), ptr(start_d), ptr(hw_d), ptr(slot_d), n_img, D,
+                                              int(bool(self.norm_att_feat)), int(bool(self.norm_box_feat)), Rmax, ld,
+                                              ptr(att), ptr(masks), stream()), "att_batch_assemble")
+        view = att[:, :, :Dout] if ld != Dout else att
+        view._uic_zero_padded_ld = ld                                  # TopDownEngine._pad_att: already padded, no copy
+        return fc_d, view, masks
+
+    def __len__(self):
+        return len(self.info['images'])
+
+
+def reference_layout(data):
+    """The batch dict with the reference's host arrays: features replicated seq_per_img times (:267-277), float32 numpy."""
+    S = int(data['seq_per_img'])
+    out = dict(data)
+    for k in ('fc_feats', 'att_feats', 'att_masks'):
+        out[k] = np.repeat(data[k].detach().cpu().numpy(), S, axis=0)
+    return out

@@ -99,6 +99,10 @@ class TopDownEngine(object):
             return att
         if att.shape[-1] != self.D:
             raise ValueError("att_feats have %d columns, the model was built for att_feat_size=%d" % (att.shape[-1], self.D))
+        if (getattr(att, "_uic_zero_padded_ld", 0) == self.Dp and att.dim() == 3 and
+                att.stride() == (att.shape[1] * self.Dp, self.Dp, 1)):
+            # the loader's assembly kernel wrote the rows at the padded stride already, padding zero-filled
+            return att.as_strided((att.shape[0], att.shape[1], self.Dp), att.stride())
         return torch.nn.functional.pad(att, (0, self.Dp - self.D)).contiguous()
 
     def _write_back(self, w):
