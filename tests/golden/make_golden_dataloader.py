@@ -148,7 +148,7 @@ def run_case(ref, name, seed, n_images, D, Dfc, rmin, rmax, V, L, caps, use_box,
 def main():
     ref = load_reference()
     #            name                 seed  n   D    Dfc  rmin rmax V   L  caps    box na nb  bs S  nb
-    run_case(ref, "dataloader_tiny",     11, 7,  16,  12,  3,   7,   40, 6, (1, 6), 1, 1, 1,  3, 2, 4)    # wraps + reshuffles
+    run_case(ref, "dataloader_tiny",     11, 7,  16,  16,  3,   7,   40, 6, (1, 6), 1, 1, 1,  3, 2, 4)    # wraps + reshuffles
     run_case(ref, "dataloader_nobox",    12, 5,  24,  24,  2,   6,   40, 6, (2, 4), 0, 1, 0,  2, 3, 2)
     run_case(ref, "dataloader_nonorm",   13, 5,  10,  8,   1,   5,   40, 6, (5, 7), 1, 0, 0,  5, 5, 1)    # D % 4 != 0, R = 1
     run_case(ref, "dataloader_boxnorm0", 14, 4,  136, 8,   4,   9,   40, 6, (5, 5), 1, 1, 0,  4, 1, 1)    # 8 < D, two pairwise leaves

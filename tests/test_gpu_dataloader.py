@@ -125,6 +125,25 @@ def test_random_data_sets_against_the_oracle(seed):
     assert got.shape == (n, Rmax, ld)
 
 
+@pytest.mark.parametrize("D", [128, 256, 512, 1024, 2048, 4096, 8192, 384, 2560])
+@pytest.mark.parametrize("use_box", [0, 1])
+def test_feature_widths_of_the_butterfly_path_and_its_neighbours(D, use_box):
+    """D = 128 * 2^k (k <= 5) takes the kernel's shuffle-only summation; 8192, 384, 2560 the general one."""
+    from oracle import dataloader as O
+    from unpaired_image_captioning_amd import _lib
+    lib = _lib.load()
+    rng = np.random.default_rng(D + use_box)
+    att = [np.abs(rng.standard_normal((R, D))).astype(np.float32) for R in (5, 9, 2)]
+    box = [np.hstack([b, b + 1 + rng.uniform(0, 50, b.shape)]).astype(np.float32)
+           for b in (rng.uniform(0, 100, (a.shape[0], 2)) for a in att)]
+    hw = [(300, 400), (480, 640), (1000, 333)]
+    Dout = D + 5 * use_box
+    got, masks, order = assemble(lib, att, box if use_box else None, hw, 1, 1, (Dout + 127) // 128 * 128)
+    for pos, i in enumerate(order):
+        want = O.region_features(att[i], box[i] if use_box else None, hw[i][0], hw[i][1], 1, 1)
+        assert np.array_equal(got[pos, :want.shape[0], :Dout], want), (D, i)
+
+
 def test_val_split_keeps_its_order_and_reset_iterator(tmp_path):
     from unpaired_image_captioning_amd.misc.dataloader.dataloader import DataLoader
     cfg, z = load_case("dataloader_tiny")
@@ -175,3 +194,35 @@ def test_loader_batch_trains_the_captioner_without_a_padding_copy(tmp_path):
     assert torch.equal(loss_a, loss_b)
     for k in grads_a:                  # (atomically accumulated gradients: equal up to summation order)
         torch.testing.assert_close(grads_a[k], grads_b[k], rtol=1e-4, atol=1e-7, msg=k)
+
+
+def test_trainer_steps_from_loader_batches_equal_steps_from_reference_shaped_batches(tmp_path):
+    """Trainer.train on the loader's per-image device batches (with next_data prefetch) follows the same loss trajectory as
+    Trainer.train on the reference-shaped host batches (features replicated seq_per_img times in numpy)."""
+    import argparse
+    from unpaired_image_captioning_amd.misc.dataloader.dataloader import reference_layout
+    from unpaired_image_captioning_amd.trainer import Trainer
+    cfg, z = load_case("dataloader_tiny")
+
+    def run(per_image):
+        loader = make_loader(tmp_path / ("a" if per_image else "b"), cfg, z)
+        opt = argparse.Namespace(vocab_size=cfg["V"], input_encoding_size=32, rnn_size=32, num_layers=1, drop_prob_lm=0.0,
+                                 seq_length=cfg["L"], fc_feat_size=cfg["Dfc"], att_feat_size=cfg["D"] + 5, att_hid_size=32,
+                                 use_bn=0, logit_layers=1, caption_model="topdown", compute_dtype="f32", seed=0,
+                                 seq_per_img=cfg["S"], i2t_learning_rate=1e-3)
+        torch.manual_seed(3)
+        tr = Trainer(opt)
+        tr.i2t_model.cuda()
+        tr.build_optimizer()
+        random.seed(cfg["seed"])
+        batches = [loader.get_batch("train") for _ in range(4)]
+        if not per_image:
+            batches = [reference_layout(b) for b in batches]
+        losses = []
+        for i, data in enumerate(batches):
+            tr.train(data, next_data=batches[i + 1] if i + 1 < len(batches) else None)
+            losses.append(float(tr.i2t_train_loss))
+        return losses
+    a, b = run(True), run(False)
+    assert all(np.isfinite(a)) and a[-1] < a[0] + 1.0
+    np.testing.assert_allclose(a, b, rtol=0, atol=2e-5)

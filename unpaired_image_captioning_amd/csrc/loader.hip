@@ -24,8 +24,9 @@ constexpr int LD_MAX_R = 2048;          // regions of one image (bottom-up featu
 constexpr int LD_PW_BLOCK = 128;        // numpy's PW_BLOCKSIZE
 
 // The leaves of numpy's pairwise_sum recursion over n elements, in order, each with its depth in the recursion tree.
-__device__ int pw_leaves(int n, int* leaf_start, int* leaf_len, int* leaf_depth) {
-  int st_s[24], st_n[24], st_d[24];
+// (one thread; `stack` = 3 * 24 ints of LDS: private arrays indexed at run time would live in scratch memory)
+__device__ int pw_leaves(int n, int* leaf_start, int* leaf_len, int* leaf_depth, int* stack) {
+  int* st_s = stack; int* st_n = stack + 24; int* st_d = stack + 48;
   int sp = 0, nl = 0;
   st_s[0] = 0; st_n[0] = n; st_d[0] = 0; sp = 1;
   while (sp > 0) {
@@ -65,8 +66,9 @@ __global__ __launch_bounds__(LD_THREADS) void att_batch_assemble_kernel(
   float* xs = smem;                                  // [D] the raw feature row
   __shared__ int leaf_start[LD_MAX_LEAVES], leaf_len[LD_MAX_LEAVES], leaf_depth[LD_MAX_LEAVES];
   __shared__ float leaf_sum[LD_MAX_LEAVES];
-  __shared__ int n_leaves_s, rank_s;
-  __shared__ float norm_s, mybox[5];
+  __shared__ int n_leaves_s, rank_s, dfs_stack[72];
+  __shared__ float norm_s, mybox[5], merge_v[24];
+  __shared__ int merge_d[24];
 
   const int img = blockIdx.x / Rmax, q = blockIdx.x % Rmax;
   const int r0 = region_start[img], Ri = region_start[img + 1] - r0;
@@ -87,7 +89,10 @@ __global__ __launch_bounds__(LD_THREADS) void att_batch_assemble_kernel(
   } else {
     for (int c = tid; c < D; c += LD_THREADS) xs[c] = src[c];
   }
-  if (tid == 0) { rank_s = 0; n_leaves_s = norm_att ? pw_leaves(D, leaf_start, leaf_len, leaf_depth) : 0; }
+  if (tid == 0) {
+    rank_s = 0;
+    n_leaves_s = norm_att ? pw_leaves(D, leaf_start, leaf_len, leaf_depth, dfs_stack) : 0;
+  }
   __syncthreads();
 
   // ---- where this region goes: regions sorted by the LAST column, descending, stable (:327) ----
@@ -130,13 +135,13 @@ __global__ __launch_bounds__(LD_THREADS) void att_batch_assemble_kernel(
     }
     __syncthreads();
     if (tid == 0) {                                  // pw(left) + pw(right), bottom-up: merge equal depths
-      float vs[24]; int vd[24]; int sp = 0;
+      int sp = 0;
       for (int lf = 0; lf < nl; ++lf) {
         float v = leaf_sum[lf]; int d = leaf_depth[lf];
-        while (sp > 0 && vd[sp - 1] == d) { v = vs[sp - 1] + v; --sp; --d; }
-        vs[sp] = v; vd[sp] = d; ++sp;
+        while (sp > 0 && merge_d[sp - 1] == d) { v = merge_v[sp - 1] + v; --sp; --d; }
+        merge_v[sp] = v; merge_d[sp] = d; ++sp;
       }
-      norm_s = sqrtf(0.f + vs[0]);
+      norm_s = sqrtf(0.f + merge_v[0]);
     }
   }
   __syncthreads();
@@ -157,6 +162,104 @@ __global__ __launch_bounds__(LD_THREADS) void att_batch_assemble_kernel(
   if (tid == 0) att_masks[(size_t)slot * Rmax + rank] = 1.f;
 }
 
+
+// D = 128 * 2^k, k <= 5 (2048: the bottom-up features): every halving of numpy's recursion lands on a multiple of 8, so
+// the tree is a perfect binary tree over 2^k leaves of 128 elements and the whole sum is xor-butterflies.  ONE WAVE per
+// region row, the row held in registers (K float4 per lane, all loads in flight at once), LDS used only to hand each lane
+// the 16 elements of its accumulator (leaf rows skewed by 8 floats: the 8 leaves of a pass hit 64 distinct banks); no
+// serial section, every row of a 128 x 36 batch resident at once (18 workgroups of 8.5 KB per CU).
+template <int K>
+__global__ __launch_bounds__(64) void att_batch_assemble_wave_kernel(
+    const float* __restrict__ feat_pack, const float* __restrict__ box_pack, const int32_t* __restrict__ region_start,
+    const float* __restrict__ img_hw, const int32_t* __restrict__ img_slot, int D, int norm_att, int norm_box, int Rmax,
+    int ld_out, float* __restrict__ att_feats, float* __restrict__ att_masks) {
+  extern __shared__ float xs[];                      // [D + 8 * D / 128]
+  const int img = blockIdx.x / Rmax, q = blockIdx.x % Rmax;
+  const int r0 = region_start[img], Ri = region_start[img + 1] - r0;
+  const int slot = img_slot[img];
+  const int lane = threadIdx.x;
+  const int Dout = box_pack ? D + 5 : D;
+
+  if (q >= Ri) {
+    float* dst = att_feats + ((size_t)slot * Rmax + q) * ld_out;
+    for (int c = lane * 4; c < ld_out; c += 256) *(float4*)(dst + c) = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (lane == 0) att_masks[(size_t)slot * Rmax + q] = 0.f;
+    return;
+  }
+
+  const float* src = feat_pack + (size_t)(r0 + q) * D;
+  float4 v[K];
+#pragma unroll
+  for (int k = 0; k < K; ++k) {
+    const int c = (lane + 64 * k) * 4;
+    if (c < D) v[k] = *(const float4*)(src + c);
+  }
+
+  int rank = q;
+  float mine[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
+  if (box_pack) {
+    const float h = img_hw[img * 3], w = img_hw[img * 3 + 1], wh = img_hw[img * 3 + 2];
+    box_features(box_pack + (size_t)(r0 + q) * 4, h, w, wh, norm_box, mine);
+    int cnt = 0;
+    for (int j = lane; j < Ri; j += 64) {
+      float other[5];
+      box_features(box_pack + (size_t)(r0 + j) * 4, h, w, wh, norm_box, other);
+      cnt += (other[4] > mine[4]) || (other[4] == mine[4] && j < q);
+    }
+    for (int o = 32; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o);
+    rank = cnt;
+  }
+
+  float nrm = 1.f;
+  if (norm_att) {
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+      const int c = (lane + 64 * k) * 4;
+      if (c < D) *(float4*)(xs + c + (c >> 7) * 8) = v[k];
+    }
+    __syncthreads();
+    const int nl = D / LD_PW_BLOCK;                  // 1, 2, 4, .. 32 leaves; a pass sums 8 of them: lane = (leaf % 8, accumulator)
+    const int j = lane & 7;
+    constexpr int NP = K >= 4 ? K / 4 : 1;
+    float tot[NP];
+#pragma unroll
+    for (int p = 0; p < NP; ++p) {
+      const int lf = p * 8 + (lane >> 3);
+      float r = 0.f;
+      if (lf < nl) {
+        const float* a = xs + lf * (LD_PW_BLOCK + 8) + j;
+        r = a[0] * a[0];
+#pragma unroll
+        for (int i = 8; i < LD_PW_BLOCK; i += 8) r = r + a[i] * a[i];
+      }
+      r = r + __shfl_xor(r, 1);                      // ((r0+r1)+(r2+r3))+((r4+r5)+(r6+r7))
+      r = r + __shfl_xor(r, 2);
+      r = r + __shfl_xor(r, 4);
+      if (nl >= 2) r = r + __shfl_xor(r, 8);         // leaf pairs, pairs of pairs, ..: the recursion, bottom-up
+      if (nl >= 4) r = r + __shfl_xor(r, 16);
+      if (nl >= 8) r = r + __shfl_xor(r, 32);
+      tot[p] = r;
+    }
+    float total = tot[0];
+    if (NP == 2) total = tot[0] + tot[1];
+    if (NP == 4) total = (tot[0] + tot[1]) + (tot[2] + tot[NP - 1]);
+    nrm = sqrtf(0.f + __shfl(total, 0));             // (with fewer than 8 leaves only the low lanes hold the sum)
+  }
+
+  float* dst = att_feats + ((size_t)slot * Rmax + rank) * ld_out;
+#pragma unroll
+  for (int k = 0; k < K; ++k) {
+    const int c = (lane + 64 * k) * 4;
+    if (c < D) {
+      float4 x = v[k];
+      if (norm_att) { x.x = x.x / nrm; x.y = x.y / nrm; x.z = x.z / nrm; x.w = x.w / nrm; }
+      *(float4*)(dst + c) = x;
+    }
+  }
+  for (int c = D + lane; c < ld_out; c += 64) dst[c] = (box_pack && c < Dout) ? mine[c - D] : 0.f;
+  if (lane == 0) att_masks[(size_t)slot * Rmax + rank] = 1.f;
+}
+
 }  // namespace
 
 extern "C" {
@@ -173,12 +276,25 @@ int uic_att_batch_assemble(const float* feat_pack, const float* box_pack, const 
   const bool vec4 = D % 4 == 0 && ld_out % 4 == 0 && ((uintptr_t)feat_pack % 16) == 0 && ((uintptr_t)att_feats % 16) == 0;
   const size_t lds = sizeof(float) * (size_t)((D + 3) / 4 * 4);
   hipStream_t s = (hipStream_t)stream;
-  if (vec4)
-    hipLaunchKernelGGL(att_batch_assemble_kernel<true>, dim3(n_img * Rmax), dim3(LD_THREADS), lds, s, feat_pack, box_pack,
-                       region_start, img_hw, img_slot, D, norm_att_feat, norm_box_feat, Rmax, ld_out, att_feats, att_masks);
-  else
-    hipLaunchKernelGGL(att_batch_assemble_kernel<false>, dim3(n_img * Rmax), dim3(LD_THREADS), lds, s, feat_pack, box_pack,
-                       region_start, img_hw, img_slot, D, norm_att_feat, norm_box_feat, Rmax, ld_out, att_feats, att_masks);
+  const int leaves = D / LD_PW_BLOCK;
+  const bool regular = vec4 && D % LD_PW_BLOCK == 0 && (leaves & (leaves - 1)) == 0 && leaves <= 32;
+#define UIC_ASSEMBLE(V)                                                                                                \
+  hipLaunchKernelGGL((att_batch_assemble_kernel<V>), dim3(n_img * Rmax), dim3(LD_THREADS), lds, s, feat_pack, box_pack,   \
+                     region_start, img_hw, img_slot, D, norm_att_feat, norm_box_feat, Rmax, ld_out, att_feats, att_masks)
+#define UIC_ASSEMBLE_WAVE(K)                                                                                           \
+  hipLaunchKernelGGL((att_batch_assemble_wave_kernel<K>), dim3(n_img * Rmax), dim3(64), sizeof(float) * (D + D / 16), s, \
+                     feat_pack, box_pack, region_start, img_hw, img_slot, D, norm_att_feat, norm_box_feat, Rmax, ld_out,  \
+                     att_feats, att_masks)
+  if (regular) {
+    if (D <= 256) UIC_ASSEMBLE_WAVE(1);
+    else if (D == 512) UIC_ASSEMBLE_WAVE(2);
+    else if (D == 1024) UIC_ASSEMBLE_WAVE(4);
+    else if (D == 2048) UIC_ASSEMBLE_WAVE(8);
+    else UIC_ASSEMBLE_WAVE(16);
+  } else if (vec4) UIC_ASSEMBLE(true);
+  else UIC_ASSEMBLE(false);
+#undef UIC_ASSEMBLE
+#undef UIC_ASSEMBLE_WAVE
   UIC_LAUNCH_CHECK("att_batch_assemble");
   return UIC_OK;
 }

@@ -20,8 +20,10 @@ On-disk formats:
   opt.input_label_h5     HDF5 with `labels` uint32 [M, L], `label_start_ix` / `label_end_ix` (1-indexed), read through
                          h5py when it is installed, else through the HDF5 C library (ctypes); an .npz with the same array
                          names is accepted as well.
-Not served here: use_box_cls_prob (`attri_feats`, unused by the TopDown / FC captioners: the entry is None) and the NMT
-corpus (`data['nmt']`: see onmt_dataset_h5 in this package).
+  opt.input_nmt_h5       (nmt_train_flag / nmt_eval_flag) the NMT corpus, batched by onmt_dataset_h5 in this package;
+                         `data['nmt']` and `bounds['wrapper_nmt']` as :200-207,292-296.
+Not served here: use_box_cls_prob (`attri_feats`, unused by the TopDown / FC captioners: the entry is None), the .pt corpus
+(input_nmt_choice = 0) and the onmt.Dict vocabularies (only printed by the reference's loader).
 """
 import ctypes as C
 import json
@@ -34,7 +36,9 @@ import torch
 
 from ... import _lib
 from ..._lib import check, ptr, stream
-from .label_store import open_label_store
+from .label_store import NMT_NAMES, open_label_store
+from .onmt_dataset_h5 import onmt_dataset_h5
+from .npfile import load_array
 
 
 def padded_width(D):
@@ -98,6 +102,14 @@ class DataLoader(object):
             elif getattr(opt, 'train_only', 0) == 0:                   # restval
                 self.split_ix['train'].append(ix)
         self.iterators = {'train': 0, 'val': 0, 'test': 0}
+        self.nmt_batchIdx = 0
+        self.nmt_trainData = self.nmt_validData = None
+        if self.nmt_train_flag or self.nmt_eval_flag and self.type:      # :78 (the reference's own precedence)
+            corpus = open_label_store(self.opt.input_nmt_h5, NMT_NAMES)
+            on_device = self.device.type == "cuda"
+            self.nmt_trainData = onmt_dataset_h5(corpus, 'train', opt.batch_size, on_device)
+            self.nmt_validData = onmt_dataset_h5(corpus, 'valid', opt.batch_size, on_device, volatile=True)
+            self.batchOrder = torch.randperm(len(self.nmt_trainData))   # :138 (drawn, never used, by the reference too)
 
         self._pool = ThreadPoolExecutor(max_workers=read_threads)
         self._ahead = {}                                               # image index -> Future of its raw arrays
@@ -134,15 +146,25 @@ class DataLoader(object):
             seq = self.labels[ixl: ixl + seq_per_img, :self.seq_length]
         return seq
 
+    def get_nmt_batch(self, split):                                    # :200-207
+        wrapped_nmt = False
+        self.nmt_batch = self.nmt_trainData[self.nmt_batchIdx]
+        if self.nmt_batchIdx + 1 < self.nmt_trainData.numBatches:
+            self.nmt_batchIdx = self.nmt_batchIdx + 1
+        else:
+            wrapped_nmt = True
+            self.nmt_batchIdx = 0
+        return self.nmt_batch, wrapped_nmt
+
     # ------------------------------------------------------------------ files
     def _read_raw(self, ix):
         """The raw arrays of image ix, untouched: (fc [Dfc], att [R, D], box [R, 4] | None)."""
         iid = str(self.info['images'][ix]['id'])
-        fc = np.load(os.path.join(self.input_fc_dir, iid + '.npz'))['feat']
+        fc = load_array(os.path.join(self.input_fc_dir, iid + '.npz'))
         if not self.use_att:
             return fc, np.zeros((1, 1), dtype=np.float32), None
-        att = np.load(os.path.join(self.input_att_dir, iid + '.npz'))['feat']
-        box = np.load(os.path.join(self.input_box_dir, iid + '.npy')) if self.use_box else None
+        att = load_array(os.path.join(self.input_att_dir, iid + '.npz'))
+        box = load_array(os.path.join(self.input_box_dir, iid + '.npy')) if self.use_box else None
         for name, a in (("att", att), ("box", box), ("fc", fc)):
             if a is not None and a.dtype != np.float32:
                 raise TypeError("%s features of image %s are %s: the assembly kernel restates the reference's float32 "
@@ -220,9 +242,9 @@ class DataLoader(object):
         mask_batch[np.arange(L + 2)[None, :] < nonzeros[:, None]] = 1
         data['masks'] = mask_batch
         data['gts'] = gts
-        data['nmt'] = None
+        data['nmt'], wrapped_nmt = self.get_nmt_batch('train') if self.nmt_train_flag and self.type else (None, False)
         data['bounds'] = {'it_pos_now': self.iterators[split], 'it_max': len(self.split_ix[split]), 'wrapped': wrapped,
-                          'wrapper_nmt': False}
+                          'wrapper_nmt': wrapped_nmt}
         data['infos'] = infos
         data['seq_per_img'] = S
         return data
