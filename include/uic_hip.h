@@ -420,6 +420,16 @@ int uic_ciderd_reward(const double* scores, int32_t N, int32_t L, float weight, 
 int uic_att_batch_assemble(const float* feat_pack, const float* box_pack, const int32_t* region_start, const float* img_hw,
                            const int32_t* img_slot, int32_t n_img, int32_t D, int32_t norm_att_feat, int32_t norm_box_feat,
                            int32_t Rmax, int32_t ld_out, float* att_feats, float* att_masks, void* stream);
+/* Host side of the input pipeline (no device work): the per-image feature files read by a thread team straight into
+ * the caller's (pinned) staging buffer -- replaces np.load in the reference's DataLoader worker processes
+ * (P/misc/dataloader/dataloader.py:309,319,331,351-356).  Files: .npy, or .npz whose FIRST member is `<member>.npy`, stored
+ * or deflated (np.savez / np.savez_compressed, scripts/make_bu_data.py:55-57); float32, C order, 1 or 2 dimensions.
+ * uic_loader_scan: info [n, 6] i64 per file = (ndim, d0, d1, offset of the data inside the member, zip method or -1,
+ * offset of the member in the file).  uic_loader_read: the d0 * d1 floats of file i are written at dst[i]; `info` as
+ * returned by the scan.  `member` may be NULL for plain .npy files.  A file that cannot be read, or is not float32, fails the
+ * whole call (UIC_EARG, uic_last_error_string() names the file).  Thread-safe; n_threads <= 64. */
+int uic_loader_scan(const char* const* paths, int32_t n, const char* member, int64_t* info, int32_t n_threads);
+int uic_loader_read(const char* const* paths, int32_t n, const int64_t* info, void* const* dst, int32_t n_threads);
 
 #ifdef __cplusplus
 }

@@ -55,10 +55,10 @@ def test_iteration_and_caption_sampling_follow_the_reference(name, tmp_path, mon
                      cfg["use_box"], cfg["norm_att"], cfg["norm_box"])
     seen = {}
 
-    def no_device(self, raw, counts, order, slot_of, infos):
-        seen["counts"], seen["order"] = counts, order
+    def no_device(self, st):
+        seen.update(st)
         return None, None, None
-    monkeypatch.setattr(M.DataLoader, "_assemble", no_device)
+    monkeypatch.setattr(M.DataLoader, "_ship", no_device)
     loader = M.DataLoader(opt, device="cpu")
     random.seed(cfg["seed"])
     for b in range(cfg["n_batches"]):
@@ -72,6 +72,17 @@ def test_iteration_and_caption_sampling_follow_the_reference(name, tmp_path, mon
         assert [bd["it_pos_now"], bd["it_max"], int(bd["wrapped"])] == list(z["out::b%d_bounds" % b])
         want_regions = z["out::b%d_att_masks" % b][::cfg["S"]].sum(1).astype(int)
         assert [seen["counts"][i] for i in seen["order"]] == list(want_regions)
+        # what the library's reader staged for the kernel: raw files back to back in fetch order, fc rows in batch order
+        fetch = [data["infos"][seen["slot_of"][i]]["ix"] for i in range(cfg["batch_size"])]
+        assert np.array_equal(seen["feat"][0].numpy(), np.concatenate([z["in::att_%d" % ix] for ix in fetch], 0))
+        assert np.array_equal(seen["fc"][0].numpy(), np.stack([z["in::fc_%d" % d["ix"]] for d in data["infos"]]))
+        assert np.array_equal(seen["meta"][0].numpy()[:cfg["batch_size"] + 1], seen["start"])
+        if cfg["use_box"]:
+            total = int(seen["start"][-1])
+            assert np.array_equal(seen["box"][0].numpy()[:total * 4].reshape(-1, 4),
+                                  np.concatenate([z["in::box_%d" % ix] for ix in fetch], 0))
+            hw = seen["box"][0].numpy()[total * 4:].reshape(-1, 3)
+            assert np.array_equal(hw[:, :2], z["in::hw"][fetch].astype(np.float32))
 
 
 def test_loader_rejects_feature_files_that_are_not_float32(tmp_path):
@@ -83,7 +94,7 @@ def test_loader_rejects_feature_files_that_are_not_float32(tmp_path):
                                z["in::labels"], z["in::label_start_ix"], z["in::label_end_ix"], cfg["V"], label_format="npz")
     opt = loader_opt(str(tmp_path), label_path, 2, 2, cfg["Dfc"], cfg["D"], 0, 1, 0)
     loader = M.DataLoader(opt, device="cpu")
-    with pytest.raises(TypeError, match="float32"):
+    with pytest.raises(RuntimeError, match="float32"):
         loader.get_batch("train")
 
 
@@ -131,7 +142,7 @@ def test_loader_serves_nmt_batches_beside_the_caption_batch(tmp_path, monkeypatc
     np.savez(corpus_path, **{k[4:]: g[k] for k in g.files if k.startswith("in::")})
     opt = loader_opt(str(tmp_path), label_path, 6, 2, cfg["Dfc"], cfg["D"], 0, 1, 0)
     opt.nmt_train_flag, opt.input_nmt_h5 = 1, corpus_path
-    monkeypatch.setattr(M.DataLoader, "_assemble", lambda self, *a: (None, None, None))
+    monkeypatch.setattr(M.DataLoader, "_ship", lambda self, st: (None, None, None))
     loader = M.DataLoader(opt, device="cpu")
     n_batches = int(g["out::train_numBatches"][0])
     for b in range(n_batches + 1):
@@ -139,3 +150,68 @@ def test_loader_serves_nmt_batches_beside_the_caption_batch(tmp_path, monkeypatc
         want = g["out::train_%d_tgt" % (b % n_batches)]
         assert np.array_equal(data["nmt"].tgt.numpy(), want)
         assert data["bounds"]["wrapper_nmt"] == (b % n_batches == n_batches - 1)
+
+
+def test_library_reader_takes_npy_stored_npz_and_deflated_npz(tmp_path):
+    """uic_loader_scan / uic_loader_read on the three ways the reference's scripts write feature files
+    (scripts/make_bu_data.py:55-57: np.savez_compressed for att, np.save for fc and boxes; np.savez elsewhere)."""
+    import ctypes as C
+    from unpaired_image_captioning_amd import _lib
+    lib = _lib.load()
+    rng = np.random.default_rng(3)
+    arrays = [rng.standard_normal((37, 2048)).astype(np.float32), rng.standard_normal((5, 16)).astype(np.float32),
+              np.abs(rng.standard_normal((1, 8))).astype(np.float32).round(1)]
+    for kind in ("stored", "deflated"):
+        paths = []
+        for i, a in enumerate(arrays):
+            p = str(tmp_path / ("%s_%d.npz" % (kind, i)))
+            (np.savez if kind == "stored" else np.savez_compressed)(p, feat=a)
+            paths.append(p.encode())
+        arr = (C.c_char_p * len(paths))(*paths)
+        info = np.zeros((len(paths), 6), dtype=np.int64)
+        _lib.check(lib.uic_loader_scan(arr, len(paths), b"feat", info.ctypes.data, 4), "scan")
+        assert [tuple(r[:3]) for r in info] == [(2,) + a.shape for a in arrays]
+        assert set(info[:, 4]) == ({0} if kind == "stored" else {8})
+        out = [np.full(a.shape, np.nan, dtype=np.float32) for a in arrays]
+        dst = (C.c_void_p * len(out))(*[o.ctypes.data for o in out])
+        _lib.check(lib.uic_loader_read(arr, len(paths), info.ctypes.data, dst, 4), "read")
+        assert all(np.array_equal(o, a) for o, a in zip(out, arrays))
+    vec = rng.standard_normal(2048).astype(np.float32)
+    p = str(tmp_path / "v.npy")
+    np.save(p, vec)
+    arr = (C.c_char_p * 1)(p.encode())
+    info = np.zeros((1, 6), dtype=np.int64)
+    _lib.check(lib.uic_loader_scan(arr, 1, None, info.ctypes.data, 1), "scan")
+    assert tuple(info[0, :5]) == (1, 2048, 1, 128, -1)
+    out = np.empty(2048, dtype=np.float32)
+    _lib.check(lib.uic_loader_read(arr, 1, info.ctypes.data, (C.c_void_p * 1)(out.ctypes.data), 1), "read")
+    assert np.array_equal(out, vec)
+    np.savez(str(tmp_path / "two.npz"), other=vec, feat=vec)
+    arr = (C.c_char_p * 1)(str(tmp_path / "two.npz").encode())
+    with pytest.raises(RuntimeError, match="first zip member is not feat.npy"):
+        _lib.check(lib.uic_loader_scan(arr, 1, b"feat", info.ctypes.data, 1), "scan")
+    arr = (C.c_char_p * 1)(str(tmp_path / "absent.npz").encode())
+    with pytest.raises(RuntimeError, match="cannot read"):
+        _lib.check(lib.uic_loader_scan(arr, 1, b"feat", info.ctypes.data, 1), "scan")
+
+
+def test_fc_vectors_as_npy_files(tmp_path, monkeypatch):
+    """make_bu_data.py writes the fc vectors as <id>.npy; the loader takes either extension."""
+    import os
+    from unpaired_image_captioning_amd.misc.dataloader import dataloader as M
+    cfg, z = load_case("dataloader_nobox")
+    n = cfg["n_images"]
+    label_path = write_dataset(str(tmp_path), [z["in::att_%d" % i] for i in range(n)], None, [z["in::fc_%d" % i] for i in range(n)],
+                               z["in::hw"], z["in::ids"], z["in::labels"], z["in::label_start_ix"], z["in::label_end_ix"],
+                               cfg["V"], label_format="npz")
+    for i, iid in enumerate(z["in::ids"]):
+        os.remove(str(tmp_path / "fc" / ("%d.npz" % iid)))
+        np.save(str(tmp_path / "fc" / ("%d.npy" % iid)), z["in::fc_%d" % i])
+        np.savez_compressed(str(tmp_path / "att" / ("%d.npz" % iid)), feat=z["in::att_%d" % i])      # as make_bu_data.py:55
+    seen = {}
+    monkeypatch.setattr(M.DataLoader, "_ship", lambda self, st: (seen.update(st), (None, None, None))[1])
+    loader = M.DataLoader(loader_opt(str(tmp_path), label_path, 3, 2, cfg["Dfc"], cfg["D"], 0, 1, 0), device="cpu", read_ahead=False)
+    data = loader.get_batch("val" if False else "train")
+    assert np.array_equal(seen["fc"][0].numpy(), np.stack([z["in::fc_%d" % d["ix"]] for d in data["infos"]]))
+    fetch = [data["infos"][seen["slot_of"][i]]["ix"] for i in range(3)]
+    assert np.array_equal(seen["feat"][0].numpy(), np.concatenate([z["in::att_%d" % ix] for ix in fetch], 0))

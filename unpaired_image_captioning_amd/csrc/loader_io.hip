@@ -1,0 +1,223 @@
+// Host side of the input pipeline: the per-image feature files (.npy, and .npz as np.savez / np.savez_compressed write
+// them -- scripts/make_bu_data.py:55-57) read by a thread team STRAIGHT INTO the caller's pinned staging buffer, at the
+// offsets the batch-assembly kernel (loader.hip) wants them.  The reference reads them with np.load in 4 DataLoader worker
+// processes (P/misc/dataloader/dataloader.py:309,319,331,351-356) and re-copies them three times on the way to the device
+// (worker -> pickle -> np.stack / replication -> torch.from_numpy().cuda()).
+//
+// Two calls: uic_loader_scan parses the headers (shapes are needed to lay the batch out), uic_loader_read moves the data.
+// No device code in this file.
+#include "uic_common.h"
+
+#include <fcntl.h>
+#include <sys/stat.h>
+#include <unistd.h>
+#include <zlib.h>
+
+#include <atomic>
+#include <cstring>
+#include <string>
+#include <thread>
+#include <vector>
+
+namespace {
+
+constexpr int IO_MAX_THREADS = 64;
+constexpr int IO_INFO = 6;            // per file: ndim, d0, d1, data offset in the (uncompressed) member, zip method, member offset in the file
+
+struct FileBytes {
+  std::vector<unsigned char> buf;
+  bool read_all(const char* path, size_t limit) {
+    const int fd = open(path, O_RDONLY);
+    if (fd < 0) return false;
+    struct stat st;
+    if (fstat(fd, &st) != 0) { close(fd); return false; }
+    size_t want = (size_t)st.st_size;
+    if (limit && want > limit) want = limit;
+    buf.resize(want);
+    size_t got = 0;
+    while (got < want) {
+      const ssize_t r = pread(fd, buf.data() + got, want - got, (off_t)got);
+      if (r <= 0) break;
+      got += (size_t)r;
+    }
+    close(fd);
+    buf.resize(got);
+    return got == want;
+  }
+};
+
+uint32_t le16(const unsigned char* p) { return p[0] | (p[1] << 8); }
+uint32_t le32(const unsigned char* p) { return p[0] | (p[1] << 8) | (p[2] << 16) | ((uint32_t)p[3] << 24); }
+
+// Locate member `member`.npy at the head of a zip (np.savez writes one member per array, ours has one): method and the
+// offset of its data.  A plain .npy: method -1, offset 0.
+bool locate(const std::vector<unsigned char>& b, const char* member, int* method, size_t* off, std::string* why) {
+  if (b.size() >= 30 && b[0] == 'P' && b[1] == 'K' && b[2] == 3 && b[3] == 4) {
+    const uint32_t nlen = le16(&b[26]), xlen = le16(&b[28]);
+    *method = (int)le16(&b[8]);
+    const std::string want = std::string(member ? member : "") + ".npy";
+    if (b.size() < 30 + nlen || std::string((const char*)&b[30], nlen) != want) { *why = "first zip member is not " + want; return false; }
+    if (*method != 0 && *method != 8) { *why = "zip method is neither stored nor deflate"; return false; }
+    *off = 30 + nlen + xlen;
+    return true;
+  }
+  *method = -1;
+  *off = 0;
+  return true;
+}
+
+// The .npy header at p[0..n): shape and the offset of the data (numpy/lib/format.py).  float32, C order only.
+bool parse_npy(const unsigned char* p, size_t n, int64_t* ndim, int64_t* d0, int64_t* d1, size_t* data_off, std::string* why) {
+  if (n < 12 || memcmp(p, "\x93NUMPY", 6) != 0) { *why = "not an .npy image"; return false; }
+  size_t hlen, start;
+  if (p[6] == 1) { hlen = le16(p + 8); start = 10; }
+  else if (p[6] == 2 || p[6] == 3) { hlen = le32(p + 8); start = 12; }
+  else { *why = "unknown .npy version"; return false; }
+  if (start + hlen > n) { *why = ".npy header longer than the bytes scanned"; return false; }
+  const std::string h((const char*)p + start, hlen);
+  const size_t dpos = h.find("'descr'");
+  if (dpos == std::string::npos || h.find("'<f4'", dpos) == std::string::npos || h.find("'<f4'", dpos) > dpos + 12) {
+    *why = "dtype is not float32 ('<f4'): the assembly kernel restates the reference's float32 arithmetic";
+    return false;
+  }
+  if (h.find("'fortran_order': False") == std::string::npos) { *why = "fortran_order is not False"; return false; }
+  size_t s = h.find("'shape'");
+  if (s == std::string::npos || (s = h.find('(', s)) == std::string::npos) { *why = "no shape in the .npy header"; return false; }
+  int64_t dims[2] = {1, 1};
+  int nd = 0;
+  for (++s; s < h.size() && h[s] != ')';) {
+    if (h[s] >= '0' && h[s] <= '9') {
+      int64_t v = 0;
+      while (s < h.size() && h[s] >= '0' && h[s] <= '9') v = v * 10 + (h[s++] - '0');
+      if (nd >= 2) { *why = "more than 2 dimensions"; return false; }
+      dims[nd++] = v;
+    } else {
+      ++s;
+    }
+  }
+  *ndim = nd; *d0 = dims[0]; *d1 = dims[1];
+  *data_off = start + hlen;
+  return true;
+}
+
+// inflate raw deflate data src[0..n) : skip `skip` bytes of output, then write `want` bytes to dst (dst may be NULL when
+// want == 0 and only `head` -- the first head_cap bytes -- is wanted).
+bool inflate_member(const unsigned char* src, size_t n, size_t skip, unsigned char* dst, size_t want, unsigned char* head,
+                    size_t head_cap, size_t* head_got) {
+  z_stream z;
+  memset(&z, 0, sizeof(z));
+  if (inflateInit2(&z, -15) != Z_OK) return false;
+  z.next_in = const_cast<unsigned char*>(src);
+  z.avail_in = (uInt)n;
+  bool ok = true;
+  if (head) {
+    z.next_out = head; z.avail_out = (uInt)head_cap;
+    const int r = inflate(&z, Z_SYNC_FLUSH);
+    ok = r == Z_OK || r == Z_STREAM_END || r == Z_BUF_ERROR;
+    *head_got = head_cap - z.avail_out;
+  } else {
+    std::vector<unsigned char> scratch(skip ? skip : 1);
+    z.next_out = scratch.data(); z.avail_out = (uInt)skip;
+    while (ok && z.avail_out > 0) {
+      const int r = inflate(&z, Z_NO_FLUSH);
+      if (r == Z_STREAM_END) break;
+      ok = r == Z_OK;
+    }
+    ok = ok && z.avail_out == 0;
+    z.next_out = dst; z.avail_out = (uInt)want;
+    while (ok && z.avail_out > 0) {
+      const int r = inflate(&z, Z_NO_FLUSH);
+      if (r == Z_STREAM_END) break;
+      ok = r == Z_OK;
+    }
+    ok = ok && z.avail_out == 0;
+  }
+  inflateEnd(&z);
+  return ok;
+}
+
+template <typename F>
+int run_team(int n, int n_threads, F&& work, std::string* first_error) {
+  std::atomic<int> next(0), failed(0);
+  std::string errors[IO_MAX_THREADS];
+  const int nt = n_threads < 1 ? 1 : (n_threads > IO_MAX_THREADS ? IO_MAX_THREADS : n_threads);
+  auto body = [&](int t) {
+    for (;;) {
+      const int i = next.fetch_add(1);
+      if (i >= n || failed.load()) return;
+      std::string why;
+      if (!work(i, &why)) { errors[t] = why; failed.store(1); return; }
+    }
+  };
+  std::vector<std::thread> team;
+  for (int t = 1; t < nt && t < n; ++t) team.emplace_back(body, t);
+  body(0);
+  for (auto& th : team) th.join();
+  if (failed.load())
+    for (int t = 0; t < nt; ++t)
+      if (!errors[t].empty()) { *first_error = errors[t]; return 1; }
+  return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+int uic_loader_scan(const char* const* paths, int32_t n, const char* member, int64_t* info, int32_t n_threads) {
+  UIC_REQUIRE(paths && info && n >= 1, "loader_scan: bad arguments (n=%d)", n);
+  std::string err;
+  const int rc = run_team(n, n_threads, [&](int i, std::string* why) {
+    FileBytes f;
+    if (!f.read_all(paths[i], 4096)) { *why = std::string("cannot read ") + paths[i]; return false; }
+    int method; size_t off; std::string w;
+    if (!locate(f.buf, member, &method, &off, &w)) { *why = std::string(paths[i]) + ": " + w; return false; }
+    unsigned char head[1024];
+    const unsigned char* p = f.buf.data() + off;
+    size_t avail = f.buf.size() > off ? f.buf.size() - off : 0;
+    if (method == 8) {
+      size_t got = 0;
+      if (!inflate_member(p, avail, 0, nullptr, 0, head, sizeof(head), &got)) { *why = std::string(paths[i]) + ": inflate failed"; return false; }
+      p = head; avail = got;
+    }
+    int64_t* o = info + (size_t)i * IO_INFO;
+    size_t data_off;
+    if (!parse_npy(p, avail, &o[0], &o[1], &o[2], &data_off, &w)) { *why = std::string(paths[i]) + ": " + w; return false; }
+    o[3] = (int64_t)data_off; o[4] = method; o[5] = (int64_t)off;
+    return true;
+  }, &err);
+  UIC_REQUIRE(rc == 0, "loader_scan: %s", err.c_str());
+  return UIC_OK;
+}
+
+int uic_loader_read(const char* const* paths, int32_t n, const int64_t* info, void* const* dst, int32_t n_threads) {
+  UIC_REQUIRE(paths && info && dst && n >= 1, "loader_read: bad arguments (n=%d)", n);
+  std::string err;
+  const int rc = run_team(n, n_threads, [&](int i, std::string* why) {
+    const int64_t* o = info + (size_t)i * IO_INFO;
+    const size_t want = (size_t)(o[1] * o[2]) * sizeof(float), data_off = (size_t)o[3], off = (size_t)o[5];
+    if (o[4] == 8) {                                   // deflate: the whole file, inflate past the header into place
+      FileBytes f;
+      if (!f.read_all(paths[i], 0) || f.buf.size() <= off) { *why = std::string("cannot read ") + paths[i]; return false; }
+      if (!inflate_member(f.buf.data() + off, f.buf.size() - off, data_off, (unsigned char*)dst[i], want, nullptr, 0, nullptr)) {
+        *why = std::string(paths[i]) + ": inflate failed or the member is shorter than its header says";
+        return false;
+      }
+      return true;
+    }
+    const int fd = open(paths[i], O_RDONLY);           // stored member / plain .npy: pread straight into the staging buffer
+    if (fd < 0) { *why = std::string("cannot open ") + paths[i]; return false; }
+    size_t got = 0;
+    while (got < want) {
+      const ssize_t r = pread(fd, (char*)dst[i] + got, want - got, (off_t)(off + data_off + got));
+      if (r <= 0) break;
+      got += (size_t)r;
+    }
+    close(fd);
+    if (got != want) { *why = std::string(paths[i]) + ": file is shorter than its header says"; return false; }
+    return true;
+  }, &err);
+  UIC_REQUIRE(rc == 0, "loader_read: %s", err.c_str());
+  return UIC_OK;
+}
+
+}  // extern "C"

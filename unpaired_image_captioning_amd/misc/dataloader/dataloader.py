@@ -8,8 +8,9 @@ device tensors with one row per image, `labels` / `masks` [n_img * seq_per_img, 
 The captioner replicates on the device (uic_topdown_dims.seq_per_img); `reference_layout(data)` gives the reference's
 replicated numpy arrays where a caller wants them.
 
-What the host does: read the files (a small thread pool, read-ahead of the next batch), copy them back to back into a
-pinned staging buffer, one asynchronous H2D copy per array.  Nothing here falls back to a CPU computation: without the
+What the host does: the library's thread team (csrc/loader_io.hip: uic_loader_scan / uic_loader_read) reads the files --
+.npy, .npz stored or deflated -- STRAIGHT INTO a pinned staging buffer at the offsets the kernel wants, the next batch's
+on a read-ahead thread while this one trains; then one asynchronous H2D copy per array.  Nothing here falls back to a CPU computation: without the
 HIP library the constructor raises.
 
 On-disk formats:
@@ -38,7 +39,6 @@ from ... import _lib
 from ..._lib import check, ptr, stream
 from .label_store import NMT_NAMES, open_label_store
 from .onmt_dataset_h5 import onmt_dataset_h5
-from .npfile import load_array
 
 
 def padded_width(D):
@@ -50,7 +50,6 @@ def padded_width(D):
 class DataLoader(object):
 
     def reset_iterator(self, split):                                   # :26-30
-        self._ahead.clear()
         self.iterators[split] = 0
 
     def get_vocab_size(self):
@@ -62,7 +61,7 @@ class DataLoader(object):
     def get_seq_length(self):
         return self.seq_length
 
-    def __init__(self, opt, train=True, device="cuda", read_threads=8):
+    def __init__(self, opt, train=True, device="cuda", read_threads=None, read_ahead=True):
         self.lib = _lib.load()                                         # raises when the HIP library is missing
         self.device = torch.device(device)
         self.opt = opt
@@ -111,8 +110,14 @@ class DataLoader(object):
             self.nmt_validData = onmt_dataset_h5(corpus, 'valid', opt.batch_size, on_device, volatile=True)
             self.batchOrder = torch.randperm(len(self.nmt_trainData))   # :138 (drawn, never used, by the reference too)
 
-        self._pool = ThreadPoolExecutor(max_workers=read_threads)
-        self._ahead = {}                                               # image index -> Future of its raw arrays
+        # make_bu_data.py:56 writes the fc vectors as <id>.npy, the reference's loader reads <id>.npz['feat'] (:331, the
+        # .npy line is commented out at :330): take whichever the data set has
+        first = str(self.info['images'][0]['id'])
+        self._fc_ext = '.npz' if os.path.exists(os.path.join(self.input_fc_dir, first + '.npz')) else '.npy'
+        self.read_threads = int(read_threads or min(32, os.cpu_count() or 8))
+        self.read_ahead = read_ahead
+        self._pool = ThreadPoolExecutor(max_workers=1)                 # the read-ahead thread (the team is inside the library)
+        self._ahead_job = None
         self._pin = {}
         self._pin_turn = 0
 
@@ -156,52 +161,112 @@ class DataLoader(object):
             self.nmt_batchIdx = 0
         return self.nmt_batch, wrapped_nmt
 
-    # ------------------------------------------------------------------ files
-    def _read_raw(self, ix):
-        """The raw arrays of image ix, untouched: (fc [Dfc], att [R, D], box [R, 4] | None)."""
-        iid = str(self.info['images'][ix]['id'])
-        fc = load_array(os.path.join(self.input_fc_dir, iid + '.npz'))
-        if not self.use_att:
-            return fc, np.zeros((1, 1), dtype=np.float32), None
-        att = load_array(os.path.join(self.input_att_dir, iid + '.npz'))
-        box = load_array(os.path.join(self.input_box_dir, iid + '.npy')) if self.use_box else None
-        for name, a in (("att", att), ("box", box), ("fc", fc)):
-            if a is not None and a.dtype != np.float32:
-                raise TypeError("%s features of image %s are %s: the assembly kernel restates the reference's float32 "
-                                "arithmetic (scripts/make_bu_data.py writes float32)" % (name, iid, a.dtype))
-        if att.ndim != 2 or (box is not None and box.shape != (att.shape[0], 4)):
-            raise ValueError("image %s: att features %s, boxes %s" % (iid, att.shape, None if box is None else box.shape))
+    # ------------------------------------------------------------------ files -> pinned staging (host only)
+    def _paths(self, indices):
+        ids = [str(self.info['images'][ix]['id']) for ix in indices]
+        fc = [os.path.join(self.input_fc_dir, i + self._fc_ext).encode() for i in ids]
+        att = [os.path.join(self.input_att_dir, i + '.npz').encode() for i in ids] if self.use_att else []
+        box = [os.path.join(self.input_box_dir, i + '.npy').encode() for i in ids] if self.use_att and self.use_box else []
         return fc, att, box
 
-    def _fetch(self, ix):
-        fut = self._ahead.pop(ix, None)
-        return fut if fut is not None else self._pool.submit(self._read_raw, ix)
+    def _scan(self, paths, member):
+        arr = (C.c_char_p * len(paths))(*paths)
+        info = np.empty((len(paths), 6), dtype=np.int64)
+        check(self.lib.uic_loader_scan(arr, len(paths), member, info.ctypes.data, self.read_threads), "loader_scan")
+        return arr, info
 
-    def _read_ahead(self, split, count):
-        """Start reading the files of the images the next get_batch(split) will ask for (known unless the epoch wraps)."""
-        if len(self._ahead) > 4 * count:
-            self._ahead.clear()
-        ri = self.iterators[split]
-        for ix in self.split_ix[split][ri: ri + count]:
-            if ix not in self._ahead:
-                self._ahead[ix] = self._pool.submit(self._read_raw, ix)
+    def _stage(self, indices, turn):
+        """Files of the images `indices` (fetch order) -> pinned staging buffers, laid out as uic_att_batch_assemble wants
+        them; returns what _ship needs.  Host work only (library calls release the GIL): runs on the read-ahead thread."""
+        n_img = len(indices)
+        fc_p, att_p, box_p = self._paths(indices)
+        fc_arr, fc_info = self._scan(fc_p, b"feat" if self._fc_ext == '.npz' else None)
+        Dfc = int(fc_info[0, 1] * fc_info[0, 2])
+        if not (fc_info[:, 1] * fc_info[:, 2] == Dfc).all():
+            raise ValueError("fc feature files of different sizes in one batch")
+        st = {"n_img": n_img, "turn": turn}
+        if self.use_att:
+            att_arr, att_info = self._scan(att_p, b"feat")
+            if not (att_info[:, 0] == 2).all() or not (att_info[:, 2] == att_info[0, 2]).all():
+                raise ValueError("att feature files must hold [regions, %d] arrays" % att_info[0, 2])
+            counts = [int(c) for c in att_info[:, 1]]
+            D = int(att_info[0, 2])
+        else:
+            counts, D = [1] * n_img, 0
+        order = sorted(range(n_img), key=lambda i: counts[i], reverse=True)               # :264-265, stable
+        slot_of = np.empty(n_img, dtype=np.int32)
+        slot_of[order] = np.arange(n_img, dtype=np.int32)
+        start = np.zeros(n_img + 1, dtype=np.int32)
+        start[1:] = np.cumsum(counts)
+        total = int(start[-1])
+        st.update(counts=counts, order=order, slot_of=slot_of, start=start, D=D, Dfc=Dfc)
 
-    def _staging(self, key, shape, dtype):
+        st["fc"] = fc_h, _ = self._staging("fc", (n_img, Dfc), torch.float32, turn)
+        paths, infos = list(fc_p), [fc_info]
+        dsts = [fc_h.data_ptr() + int(slot_of[i]) * Dfc * 4 for i in range(n_img)]       # fc rows land in batch order
+        if self.use_att:
+            st["feat"] = feat_h, _ = self._staging("feat", (total, D), torch.float32, turn)
+            paths += att_p
+            infos.append(att_info)
+            dsts += [feat_h.data_ptr() + int(start[i]) * D * 4 for i in range(n_img)]
+            st["meta"] = meta_h, _ = self._staging("meta", (2 * n_img + 1,), torch.int32, turn)
+            meta_h.numpy()[:n_img + 1] = start
+            meta_h.numpy()[n_img + 1:] = slot_of
+            if self.use_box:
+                box_arr, box_info = self._scan(box_p, None)
+                if not (box_info[:, 1] == att_info[:, 1]).all() or not (box_info[:, 2] == 4).all():
+                    raise ValueError("box files must hold [regions, 4] arrays with the regions of the att features")
+                st["box"] = box_h, _ = self._staging("box", (total * 4 + n_img * 3,), torch.float32, turn)
+                paths += box_p
+                infos.append(box_info)
+                dsts += [box_h.data_ptr() + int(start[i]) * 16 for i in range(n_img)]
+                hw = box_h.numpy()[total * 4:].reshape(n_img, 3)
+                for i, ix in enumerate(indices):
+                    img = self.info['images'][ix]
+                    h, w = img['height'], img['width']
+                    hw[i] = (np.float32(h), np.float32(w), np.float32(w * h))
+        arr = (C.c_char_p * len(paths))(*paths)
+        info = np.ascontiguousarray(np.concatenate(infos, 0))
+        dst = (C.c_void_p * len(dsts))(*dsts)
+        check(self.lib.uic_loader_read(arr, len(paths), info.ctypes.data, dst, self.read_threads), "loader_read")
+        return st
+
+    def _staging(self, key, shape, dtype, turn):
         """Pinned host buffer (two per key, alternating: the copy out of the previous batch's may still be in flight)."""
         n = int(np.prod(shape))
-        slot = self._pin.setdefault((key, self._pin_turn), [None, None])
+        slot = self._pin.setdefault((key, turn), [None, None])
         if slot[0] is None or slot[0].numel() < n or slot[0].dtype != dtype:
             slot[0] = torch.empty(max(n, 1), dtype=dtype, pin_memory=self.device.type == "cuda")
         elif slot[1] is not None:
             slot[1].synchronize()
         return slot[0][:n].view(shape), slot
 
-    def _to_device(self, key, host_view, slot):
+    def _to_device(self, host_and_slot):
+        host_view, slot = host_and_slot
         dev = host_view.to(self.device, non_blocking=True)
         if self.device.type == "cuda":
             slot[1] = torch.cuda.Event()
             slot[1].record()
         return dev
+
+    def _staged(self, indices):
+        """The staged files of this batch: from the read-ahead thread when it guessed the indices, else read now."""
+        ahead, self._ahead_job = self._ahead_job, None
+        if ahead is not None:
+            want, fut = ahead
+            st = fut.result()
+            if want == list(indices):
+                return st
+        self._pin_turn ^= 1
+        return self._stage(list(indices), self._pin_turn)
+
+    def _read_ahead(self, split, count):
+        """Start staging the files the next get_batch(split) will ask for (known unless the epoch wraps before)."""
+        ri = self.iterators[split]
+        nxt = list(self.split_ix[split][ri: ri + count])
+        if len(nxt) == count:
+            self._pin_turn ^= 1
+            self._ahead_job = (nxt, self._pool.submit(self._stage, nxt, self._pin_turn))
 
     # ------------------------------------------------------------------ the batch
     def get_batch(self, split, batch_size=None, seq_per_img=None):
@@ -212,30 +277,25 @@ class DataLoader(object):
         label_batch = np.zeros([batch_size * S, L + 2], dtype='int')
         mask_batch = np.zeros([batch_size * S, L + 2], dtype='float32')
         wrapped = False
-        futures, infos, gts = [], [], []
+        indices, infos, gts = [], [], []
         for i in range(batch_size):
             ix, w = self._next_index(split)                            # may reshuffle: BEFORE the caption draw, as :236,247
-            futures.append(self._fetch(ix))
+            indices.append(ix)
             label_batch[i * S:(i + 1) * S, 1:L + 1] = self.get_captions(ix, S)
             wrapped = wrapped or w
             gts.append(self.labels[self.label_start_ix[ix] - 1: self.label_end_ix[ix]])
             img = self.info['images'][ix]
             infos.append({'ix': ix, 'id': img['id'], 'file_path': img['file_path']})
-        if wrapped:
-            self._ahead.clear()
-        self._read_ahead(split, batch_size)
-        raw = [f.result() for f in futures]
-
-        counts = [r[1].shape[0] for r in raw]
-        order = sorted(range(batch_size), key=lambda i: counts[i], reverse=True)          # :264-265, stable
-        slot_of = np.empty(batch_size, dtype=np.int32)
-        slot_of[order] = np.arange(batch_size, dtype=np.int32)
+        st = self._staged(indices)
+        order = st["order"]
         label_batch = np.vstack([label_batch[i * S:(i + 1) * S] for i in order])
         gts = [gts[i] for i in order]
         infos = [infos[i] for i in order]
 
         data = {}
-        data['fc_feats'], data['att_feats'], data['att_masks'] = self._assemble(raw, counts, order, slot_of, infos)
+        data['fc_feats'], data['att_feats'], data['att_masks'] = self._ship(st)
+        if self.read_ahead and not wrapped:
+            self._read_ahead(split, batch_size)
         data['attri_feats'] = None
         data['labels'] = label_batch
         nonzeros = (label_batch != 0).sum(1) + 2                       # :287-290
@@ -249,49 +309,21 @@ class DataLoader(object):
         data['seq_per_img'] = S
         return data
 
-    def _assemble(self, raw, counts, order, slot_of, infos):
-        n_img = len(raw)
-        self._pin_turn ^= 1
-        fc_h, fc_slot = self._staging("fc", (n_img, raw[0][0].shape[-1]), torch.float32)
-        fc_np = fc_h.numpy()
-        for pos, i in enumerate(order):
-            fc_np[pos] = raw[i][0]
-        fc_d = self._to_device("fc", fc_h, fc_slot)
+    def _ship(self, st):
+        """Staged batch -> device: one asynchronous copy per array, then the assembly kernel."""
+        n_img = st["n_img"]
+        fc_d = self._to_device(st["fc"])
         if not self.use_att:
-            z = torch.zeros(n_img, 1, 1, device=self.device)
-            return fc_d, z, torch.ones(n_img, 1, device=self.device)
-
-        D = raw[0][1].shape[1]
-        start = np.zeros(n_img + 1, dtype=np.int32)
-        start[1:] = np.cumsum(counts)
-        total, Rmax = int(start[-1]), max(counts)
-        feat_h, feat_slot = self._staging("feat", (total, D), torch.float32)
-        feat_np = feat_h.numpy()
-
-        def put(i):
-            feat_np[start[i]:start[i + 1]] = raw[i][1]
-        list(self._pool.map(put, range(n_img)))                        # the copy into pinned memory, in parallel
-        feat_d = self._to_device("feat", feat_h, feat_slot)
-
-        meta_h, meta_slot = self._staging("meta", (n_img + 1 + n_img,), torch.int32)
-        meta_np = meta_h.numpy()
-        meta_np[:n_img + 1] = start
-        meta_np[n_img + 1:] = slot_of
-        meta_d = self._to_device("meta", meta_h, meta_slot)
+            return fc_d, torch.zeros(n_img, 1, 1, device=self.device), torch.ones(n_img, 1, device=self.device)
+        D, total = st["D"], int(st["start"][-1])
+        Rmax = max(st["counts"])
+        feat_d = self._to_device(st["feat"])
+        meta_d = self._to_device(st["meta"])
         start_d, slot_d = meta_d[:n_img + 1], meta_d[n_img + 1:]
-
         box_d = hw_d = None
         if self.use_box:
-            box_h, box_slot = self._staging("box", (total * 4 + n_img * 3,), torch.float32)
-            box_np = box_h.numpy()
-            for i in range(n_img):
-                box_np[start[i] * 4:start[i + 1] * 4] = raw[i][2].reshape(-1)
-                img = self.info['images'][infos[slot_of[i]]['ix']]
-                h, w = img['height'], img['width']
-                box_np[total * 4 + 3 * i: total * 4 + 3 * i + 3] = (np.float32(h), np.float32(w), np.float32(w * h))
-            bd = self._to_device("box", box_h, box_slot)
+            bd = self._to_device(st["box"])
             box_d, hw_d = bd[:total * 4], bd[total * 4:]
-
         Dout = D + (5 if self.use_box else 0)
         ld = padded_width(Dout)
         att = torch.empty(n_img, Rmax, ld, dtype=torch.float32, device=self.device)
