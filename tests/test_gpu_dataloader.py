@@ -205,7 +205,7 @@ def test_trainer_steps_from_loader_batches_equal_steps_from_reference_shaped_bat
     cfg, z = load_case("dataloader_tiny")
 
     def run(per_image):
-        loader = make_loader(tmp_path / ("a" if per_image else "b"), cfg, z)
+        loader = make_loader(tmp_path / str(per_image), cfg, z)
         opt = argparse.Namespace(vocab_size=cfg["V"], input_encoding_size=32, rnn_size=32, num_layers=1, drop_prob_lm=0.0,
                                  seq_length=cfg["L"], fc_feat_size=cfg["Dfc"], att_feat_size=cfg["D"] + 5, att_hid_size=32,
                                  use_bn=0, logit_layers=1, caption_model="topdown", compute_dtype="f32", seed=0,
@@ -219,10 +219,21 @@ def test_trainer_steps_from_loader_batches_equal_steps_from_reference_shaped_bat
         if not per_image:
             batches = [reference_layout(b) for b in batches]
         losses = []
+        if per_image == "fetch":           # the next batch is fetched by the Trainer after the step is enqueued (copy stream)
+            it = iter(batches[1:] + [None])
+            cur = batches[0]
+            while cur is not None:
+                tr.train(cur, next_data=lambda: next(it))
+                losses.append(float(tr.i2t_train_loss))
+                cur = tr.next_data
+            return losses
         for i, data in enumerate(batches):
             tr.train(data, next_data=batches[i + 1] if i + 1 < len(batches) else None)
             losses.append(float(tr.i2t_train_loss))
         return losses
     a, b = run(True), run(False)
+    c = run("fetch")
+    assert len(c) == 4
+    np.testing.assert_allclose(c, a, rtol=0, atol=2e-5)
     assert all(np.isfinite(a)) and a[-1] < a[0] + 1.0
     np.testing.assert_allclose(a, b, rtol=0, atol=2e-5)

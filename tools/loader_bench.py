@@ -101,6 +101,38 @@ def main():
         torch.cuda.synchronize()
         dt_loader = (time.perf_counter() - t0) / a.batches
 
+        # ---- 3. training from files: loader -> Trainer.train, the reference's defaults (use_box: 2053 features, use_bn 1) ----
+        import argparse as _ap
+        from unpaired_image_captioning_amd.trainer import Trainer
+        topt = _ap.Namespace(vocab_size=9487, input_encoding_size=512, rnn_size=512, num_layers=1, drop_prob_lm=0.5,
+                             seq_length=16, fc_feat_size=D, att_feat_size=Dout, att_hid_size=512, use_bn=1, logit_layers=1,
+                             caption_model="topdown", compute_dtype="bf16", seed=1, i2t_learning_rate=5e-4, i2t_train_flag=1,
+                             seq_per_img=5)
+        tr = Trainer(topt)
+        tr.i2t_model.cuda()
+        tr.build_optimizer()
+        fetch = lambda: loader.get_batch("train")
+        cur = fetch()
+        for _ in range(4):
+            tr.train(cur, next_data=fetch)              # the next batch is fetched after this step is enqueued
+            cur = tr.next_data
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(a.batches):
+            tr.train(cur, next_data=fetch)
+            cur = tr.next_data
+        torch.cuda.synchronize()
+        dt_train = (time.perf_counter() - t0) / a.batches
+        syn = {k: (v.clone() if torch.is_tensor(v) else v) for k, v in cur.items()}
+        for _ in range(3):
+            tr.train(syn, next_data=syn)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(a.batches):
+            tr.train(syn, next_data=syn)
+        torch.cuda.synchronize()
+        dt_resident = (time.perf_counter() - t0) / a.batches
+
         # the reference's per-image work (numpy) + merge, files read the same way, one process (its DataLoader workers: 4)
         def oracle_batch(first):
             fcs, atts, rows, gts, infos = [], [], [], [], []
@@ -141,6 +173,9 @@ def main():
         "loader_end_to_end": {"ms_per_batch": round(dt_loader * 1e3, 2), "images_per_s": round(n / dt_loader, 1),
                               "reader_threads": loader.read_threads, "att_files": "deflated" if a.compressed else "stored",
                               "note": "files in the page cache, library reader team straight into pinned staging, read-ahead of the next batch, un-replicated H2D"},
+        "train_from_files": {"ms_per_step": round(dt_train * 1e3, 2), "captions_per_s": round(n * 5 / dt_train, 0),
+                             "ms_per_step_same_batch_resident": round(dt_resident * 1e3, 2),
+                             "note": "Trainer.train(loader.get_batch(..)) loop, TopDown 512/512/9488, bf16, use_bn 1, 640 caption rows per step"},
         "cpu_oracle": {"ms_per_batch": round(dt_oracle * 1e3, 2), "images_per_s": round(n / dt_oracle, 1),
                        "of_which_file_reads_ms": round(dt_files * 1e3, 2), "cores": 1,
                        "note": "numpy restatement of the reference's __getitem__ + get_batch merge (S = 5 replication included)"},

@@ -202,6 +202,14 @@ class Trainer(object):
         if getattr(self, '_copy_stream', None) is None:
             self._copy_stream = torch.cuda.Stream()
         with torch.cuda.stream(self._copy_stream):
+            if callable(data):
+                # e.g. `lambda: loader.get_batch('train')`: the loader's host work, its H2D copies and its assembly kernel
+                # all happen here -- after this step was enqueued, on the copy stream; the batch is left in self.next_data
+                data = data()
+            self.next_data = data
+            if data is None:                          # the caller's source is exhausted
+                self._prefetched = None
+                return
             batch = self.to_device(data, per_image)
             ev = torch.cuda.Event()
             ev.record()
@@ -220,7 +228,8 @@ class Trainer(object):
 
     def train(self, data, loader=None, iteration=None, epoch=None, nmt_epoch=None, next_data=None):
         """Trainer.train for the XE captioner step (P/trainer.py:141-173,193).  next_data (optional extension): the
-        following batch, shipped to the device while this step computes (see prefetch)."""
+        following batch -- or a callable returning it, e.g. `lambda: loader.get_batch('train')` -- fetched / shipped to the
+        device while this step computes (see prefetch); afterwards it is `self.next_data`."""
         labels_np = np.asarray(data["labels"])
         t_run = _steps_from_host_labels(labels_np)
         T = labels_np.shape[1] - 1
