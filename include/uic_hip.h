@@ -399,6 +399,13 @@ int uic_ciderd_scores(const int64_t* hyp, int32_t n_hyp, int32_t L, int32_t batc
                       const int64_t* ref_tok, int32_t Lr, const int32_t* ref_start, int32_t n_img,
                       const int32_t* slot_keys, const double* slot_vals, int64_t slots, double ref_len,
                       const double* penalty, int32_t pen_half, double* scores, void* stream);
+/* Per-sentence BLEU-4 of the same hypotheses against the same references (the `bleu_reward_weight` term of
+ * get_self_critical_reward, rewards.py:70-75: Bleu(4).compute_score -> bleu_scores[3]); BleuScorer.compute_score with
+ * option='closest' (coco_caption/pycxevalcap/bleu/bleu_scorer.py:199-240): clipped n-gram matches, the reference length
+ * closest to the hypothesis (ties: the shorter), (correct + 1e-15) / (guess + 1e-9) products, ^(1/4), brevity penalty
+ * exp(1 - 1/ratio).  scores [n_hyp] f64 (pow / exp of the device math library: within 1e-14 relative of the host's). */
+int uic_bleu_scores(const int64_t* hyp, int32_t n_hyp, int32_t L, int32_t batch_size, int32_t seq_per_img,
+                    const int64_t* ref_tok, int32_t Lr, const int32_t* ref_start, int32_t n_img, double* scores, void* stream);
 /* reward [N, L] f32 = weight * (scores[n] - scores[N + n]) repeated over the L positions (rewards.py:74-79): rows 0..N-1 of
  * `scores` are the sampled captions, rows N..2N-1 the greedy baseline. */
 int uic_ciderd_reward(const double* scores, int32_t N, int32_t L, float weight, float* reward, void* stream);

@@ -213,6 +213,8 @@ _SIGS = {
     "uic_ciderd_scores": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p,
                                     C.c_int32, C.c_void_p, C.c_void_p, C.c_int64, C.c_double, C.c_void_p, C.c_int32, C.c_void_p,
                                     C.c_void_p]),
+    "uic_bleu_scores": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p,
+                                  C.c_int32, C.c_void_p, C.c_void_p]),
     "uic_ciderd_reward": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_float, C.c_void_p, C.c_void_p]),
     "uic_loader_scan": (C.c_int, [C.c_void_p, C.c_int32, C.c_char_p, C.c_void_p, C.c_int32]),
     "uic_loader_read": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32]),

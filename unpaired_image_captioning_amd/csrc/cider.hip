@@ -157,6 +157,79 @@ __global__ __launch_bounds__(64) void ciderd_kernel(const CiderParams p) {
   }
 }
 
+// ---- per-sentence BLEU-4 (the bleu_reward_weight half of the reward): BleuScorer.compute_score(option='closest'),
+// P/AI_Challenger/Evaluation/caption_eval/coco_caption/pycxevalcap/bleu/bleu_scorer.py:23-88,199-240.  One wave per
+// hypothesis; all counting in integers, the final products / pow / exp in f64 in the scorer's order.
+struct BleuParams {
+  const int64_t* hyp; int L, batch_size, seq_per_img;
+  const int64_t* ref_tok; int Lr; const int32_t* ref_start;
+  double* scores;
+};
+
+__global__ __launch_bounds__(64) void bleu_kernel(const BleuParams p) {
+  __shared__ int tok_h[MAXW], tok_r[MAXW];
+  __shared__ int cnt_h[NG * MAXW], ref_max[NG * MAXW];
+  __shared__ unsigned char first_h[NG * MAXW];
+  __shared__ int correct[NG];
+  const int h = blockIdx.x, lane = threadIdx.x;
+  const int img = (h % p.batch_size) / p.seq_per_img;
+  const int Wh = load_words(p.hyp + (size_t)h * p.L, p.L, tok_h, lane);
+  for (int g = lane; g < NG * MAXW; g += 64) {       // precook(test): count of every n-gram, flagged at its first position
+    const int k = g / MAXW, i = g - k * MAXW;
+    int c = 0;
+    unsigned char f = 0;
+    if (i + k < Wh) {
+      f = 1;
+      for (int j = 0; j + k < Wh; ++j) {
+        bool m = true;
+        for (int q = 0; q <= k; ++q) m = m && tok_h[i + q] == tok_h[j + q];
+        c += m;
+        if (m && j < i) f = 0;
+      }
+    }
+    cnt_h[g] = c; first_h[g] = f; ref_max[g] = 0;
+  }
+  int best_diff = 1 << 30, reflen = 0;               // min((abs(l - testlen), l) for l in reflens)[1]  (:76)
+  const int r0 = p.ref_start[img], r1 = p.ref_start[img + 1];
+  for (int r = r0; r < r1; ++r) {
+    __syncthreads();
+    const int Wr = load_words(p.ref_tok + (size_t)r * p.Lr, p.Lr, tok_r, lane);
+    const int diff = Wr > Wh ? Wr - Wh : Wh - Wr;
+    if (diff < best_diff || (diff == best_diff && Wr < reflen)) { best_diff = diff; reflen = Wr; }
+    for (int g = lane; g < NG * MAXW; g += 64) {     // cook_refs: the most often any one reference holds the n-gram
+      if (!first_h[g]) continue;
+      const int k = g / MAXW, i = g - k * MAXW;
+      int c = 0;
+      for (int j = 0; j + k < Wr; ++j) {
+        bool m = true;
+        for (int q = 0; q <= k; ++q) m = m && tok_h[i + q] == tok_r[j + q];
+        c += m;
+      }
+      if (c > ref_max[g]) ref_max[g] = c;
+    }
+  }
+  __syncthreads();
+  if (lane < NG) {                                   // cook_test: clipped matches per order
+    int c = 0;
+    for (int i = 0; i + lane < Wh; ++i)
+      if (first_h[lane * MAXW + i]) c += min(ref_max[lane * MAXW + i], cnt_h[lane * MAXW + i]);
+    correct[lane] = c;
+  }
+  __syncthreads();
+  if (lane == 0) {
+    const double small = 1e-9, tiny = 1e-15;
+    double bleu = 1.0;
+    for (int k = 0; k < NG; ++k) {
+      const int guess = Wh - k > 0 ? Wh - k : 0;
+      bleu *= ((double)correct[k] + tiny) / ((double)guess + small);
+    }
+    double b4 = pow(bleu, 1.0 / NG);
+    const double ratio = ((double)Wh + tiny) / ((double)reflen + small);
+    if (ratio < 1.0) b4 *= exp(1.0 - 1.0 / ratio);
+    p.scores[h] = b4;
+  }
+}
+
 __global__ void reward_kernel(const double* scores, int N, int L, float weight, float* reward) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= N * L) return;
@@ -215,6 +288,18 @@ int uic_ciderd_scores(const int64_t* hyp, int32_t n_hyp, int32_t L, int32_t batc
   p.penalty = penalty; p.pen_half = pen_half; p.scores = scores;
   hipLaunchKernelGGL(ciderd_kernel, dim3(n_hyp), dim3(64), 0, (hipStream_t)stream, p);
   UIC_LAUNCH_CHECK("ciderd_kernel");
+  return UIC_OK;
+}
+
+int uic_bleu_scores(const int64_t* hyp, int32_t n_hyp, int32_t L, int32_t batch_size, int32_t seq_per_img,
+                    const int64_t* ref_tok, int32_t Lr, const int32_t* ref_start, int32_t n_img, double* scores, void* stream) {
+  UIC_REQUIRE(hyp && ref_tok && ref_start && scores, "bleu_scores: null pointer");
+  UIC_REQUIRE(L >= 1 && L <= MAXW && Lr >= 1 && Lr <= MAXW, "bleu_scores: caption rows of %d / %d tokens (max %d)", L, Lr, MAXW);
+  UIC_REQUIRE(n_hyp >= 1 && batch_size >= 1 && seq_per_img >= 1 && batch_size % seq_per_img == 0 && batch_size / seq_per_img == n_img,
+              "bleu_scores: batch_size=%d seq_per_img=%d n_img=%d do not agree", batch_size, seq_per_img, n_img);
+  BleuParams p{hyp, L, batch_size, seq_per_img, ref_tok, Lr, ref_start, scores};
+  hipLaunchKernelGGL(bleu_kernel, dim3(n_hyp), dim3(64), 0, (hipStream_t)stream, p);
+  UIC_LAUNCH_CHECK("bleu_scores");
   return UIC_OK;
 }
 

@@ -6,7 +6,8 @@ Same surface as the reference module: `init_scorer(cached_tokens)`, `array_to_st
 fc_feats, attri_feats, att_feats, att_masks, data, gen_result, opt)` -> float array [N, L].  The Trainer uses
 `self_critical_reward_device`, which returns the device tensor without synchronising.
 
-bleu_reward_weight (default 0, P/opts.py:154) is not on the device path: a non-zero value raises NotImplementedError.
+bleu_reward_weight > 0 (default 0, P/opts.py:154) adds the per-sentence BLEU-4 of the reference's Bleu(4) scorer
+(rewards.py:70-75), also scored on the device (`uic_bleu_scores`).
 """
 import ctypes as C
 import os
@@ -85,17 +86,13 @@ class DeviceCiderD(object):
                 df[g] = df.get(g, 0.0) + 1.0
         return self._table(df) + (float(np.log(float(n_hyp))),)
 
-    def scores(self, hyp, gts, batch_size, seq_per_img):
+    def scores(self, hyp, gts, batch_size, seq_per_img, refs=None):
         """hyp: device int64 [n_hyp, L]; gts: list (one per image) of integer arrays [n_caps, Lr] (data['gts']).
         Returns device f64 [n_hyp] -- enqueue only."""
         hyp = hyp.contiguous()
         n_hyp, L = hyp.shape
         n_img = len(gts)
-        ref = np.concatenate([np.asarray(g).reshape(len(g), -1) for g in gts], 0).astype(np.int64)
-        start = np.cumsum([0] + [len(g) for g in gts]).astype(np.int32)
-        Lr = ref.shape[1]
-        ref_d = torch.from_numpy(np.ascontiguousarray(ref)).to(self.device, non_blocking=True)
-        start_d = torch.from_numpy(start).to(self.device, non_blocking=True)
+        ref_d, start_d, Lr = refs if refs is not None else upload_references(gts, self.device)
         if self.corpus:
             sk, sv, slots, ref_len = self._corpus_table(gts, n_hyp, batch_size, seq_per_img)
         else:
@@ -107,6 +104,28 @@ class DeviceCiderD(object):
                                          ptr(sk), ptr(sv), slots, C.c_double(ref_len), ptr(pen), half, ptr(out), stream()),
               "ciderd_scores")
         return out
+
+
+def upload_references(gts, device):
+    """data['gts'] (one integer array [n_caps, Lr] per image) -> (tokens [sum n_caps, Lr] i64, first row per image [n_img + 1]
+    i32, Lr) on the device -- shared by the CIDEr-D and the BLEU kernel."""
+    ref = np.concatenate([np.asarray(g).reshape(len(g), -1) for g in gts], 0).astype(np.int64)
+    start = np.cumsum([0] + [len(g) for g in gts]).astype(np.int32)
+    ref_d = torch.from_numpy(np.ascontiguousarray(ref)).to(device, non_blocking=True)
+    start_d = torch.from_numpy(start).to(device, non_blocking=True)
+    return ref_d, start_d, ref.shape[1]
+
+
+def bleu4_scores_device(hyp, gts, batch_size, seq_per_img, refs=None):
+    """Bleu(4).compute_score(gts, res)[1][3] (rewards.py:71-72) for hyp [n_hyp, L] i64 on the device -> f64 [n_hyp], enqueue only."""
+    lib = _lib.load()
+    hyp = hyp.contiguous()
+    n_hyp, L = hyp.shape
+    ref_d, start_d, Lr = refs if refs is not None else upload_references(gts, hyp.device)
+    out = torch.empty(n_hyp, dtype=torch.float64, device=hyp.device)
+    check(lib.uic_bleu_scores(ptr(hyp), n_hyp, L, batch_size, seq_per_img, ptr(ref_d), Lr, ptr(start_d), len(gts), ptr(out),
+                              stream()), "bleu_scores")
+    return out
 
 
 def init_scorer(cached_tokens, device="cuda"):
@@ -136,25 +155,33 @@ def array_to_str(arr):
     return out.strip()
 
 
-def self_critical_reward_device(scorer, gen_result, greedy_res, gts, cider_reward_weight=1.0):
-    """reward [N, L] f32 on the device, no host synchronisation: CIDEr-D(sampled) - CIDEr-D(greedy) per caption row,
-    repeated over the L positions (P/misc/rewards.py:49-79).  greedy_res may hold one row per image (the eval-mode
-    decode of identical replicas is identical): it is expanded to the N caption rows."""
+def self_critical_reward_device(scorer, gen_result, greedy_res, gts, cider_reward_weight=1.0, bleu_reward_weight=0.0):
+    """reward [N, L] f32 on the device, no host synchronisation: score(sampled) - score(greedy) per caption row, repeated
+    over the L positions, score = cider_reward_weight * CIDEr-D + bleu_reward_weight * BLEU-4 (P/misc/rewards.py:49-79).
+    greedy_res may hold one row per image (the eval-mode decode of identical replicas is identical): it is expanded to
+    the N caption rows."""
     N, L = gen_result.shape
     seq_per_img = N // len(gts)
     if greedy_res.shape[0] != N:
         greedy_res = greedy_res.repeat_interleave(N // greedy_res.shape[0], 0)
     hyp = torch.cat([gen_result, greedy_res], 0)
-    s = scorer.scores(hyp, gts, N, seq_per_img)
+    refs = upload_references(gts, gen_result.device)
+    lib = _lib.load()
     reward = torch.empty(N, L, dtype=torch.float32, device=gen_result.device)
-    check(scorer.lib.uic_ciderd_reward(ptr(s), N, L, float(cider_reward_weight), ptr(reward), stream()), "ciderd_reward")
+    if bleu_reward_weight > 0:
+        s = float(bleu_reward_weight) * bleu4_scores_device(hyp, gts, N, seq_per_img, refs)
+        if cider_reward_weight > 0:                   # :76, in that order, f64
+            s = float(cider_reward_weight) * scorer.scores(hyp, gts, N, seq_per_img, refs) + s
+        weight = 1.0
+    else:
+        s = scorer.scores(hyp, gts, N, seq_per_img, refs)
+        weight = float(cider_reward_weight)
+    check(lib.uic_ciderd_reward(ptr(s), N, L, weight, ptr(reward), stream()), "ciderd_reward")
     return reward
 
 
 def get_self_critical_reward(model, fc_feats, attri_feats, att_feats, att_masks, data, gen_result, opt):
     """P/misc/rewards.py:37-81: greedy baseline in eval mode, then the reward as a float array [N, L]."""
-    if getattr(opt, 'bleu_reward_weight', 0) > 0:
-        raise NotImplementedError("bleu_reward_weight > 0 is not on the MI355X path (the reference's default is 0)")
     if CiderD_scorer is None:
         raise RuntimeError("call init_scorer(opt.cached_tokens) first (P/trainer.py:158)")
     model.eval()
@@ -162,7 +189,8 @@ def get_self_critical_reward(model, fc_feats, attri_feats, att_feats, att_masks,
         greedy_res, _ = model(fc_feats, attri_feats, att_feats, att_masks=att_masks, mode='sample')
     model.train()
     w = float(getattr(opt, 'cider_reward_weight', 1))
-    if w <= 0:
+    bw = float(getattr(opt, 'bleu_reward_weight', 0))
+    if w <= 0 and bw <= 0:
         return np.zeros(tuple(gen_result.shape), dtype=np.float64)
-    r = self_critical_reward_device(CiderD_scorer, gen_result.detach(), greedy_res, data['gts'], w)
+    r = self_critical_reward_device(CiderD_scorer, gen_result.detach(), greedy_res, data['gts'], w, bw)
     return r.double().cpu().numpy()

@@ -268,11 +268,10 @@ class Trainer(object):
                 greedy_res, _ = model(fc, None, att, am, opt={'sample_max': 1}, mode='sample')
             model.train()
             if reward_fn is None:
-                if getattr(self.opt, 'bleu_reward_weight', 0) > 0:
-                    raise NotImplementedError("bleu_reward_weight > 0 is not on the MI355X path (the reference's default is 0)")
                 scorer = rewards.init_scorer(getattr(self.opt, 'cached_tokens', 'corpus'))
                 reward_t = rewards.self_critical_reward_device(scorer, gen_result, greedy_res, data['gts'],
-                                                               float(getattr(self.opt, 'cider_reward_weight', 1)))
+                                                               float(getattr(self.opt, 'cider_reward_weight', 1)),
+                                                               float(getattr(self.opt, 'bleu_reward_weight', 0)))
             else:
                 if S > 1:                                     # eval mode is deterministic: the S replicas decode identically
                     greedy_res = greedy_res.repeat_interleave(S, 0)
