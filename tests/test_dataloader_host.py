@@ -215,3 +215,37 @@ def test_fc_vectors_as_npy_files(tmp_path, monkeypatch):
     assert np.array_equal(seen["fc"][0].numpy(), np.stack([z["in::fc_%d" % d["ix"]] for d in data["infos"]]))
     fetch = [data["infos"][seen["slot_of"][i]]["ix"] for i in range(3)]
     assert np.array_equal(seen["feat"][0].numpy(), np.concatenate([z["in::att_%d" % ix] for ix in fetch], 0))
+
+
+def test_ranks_partition_the_global_batch(tmp_path, monkeypatch):
+    """world_size 2: both ranks walk the same global sequence (same seed) and keep disjoint halves; together they hold
+    exactly the batches one loader with twice the batch size produces (rows up to the per-rank sort by region count)."""
+    from unpaired_image_captioning_amd.misc.dataloader import dataloader as M
+    cfg, z = load_case("dataloader_tiny")
+    n = cfg["n_images"]
+    label_path = write_dataset(str(tmp_path), [z["in::att_%d" % i] for i in range(n)], [z["in::box_%d" % i] for i in range(n)],
+                               [z["in::fc_%d" % i] for i in range(n)], z["in::hw"], z["in::ids"], z["in::labels"],
+                               z["in::label_start_ix"], z["in::label_end_ix"], cfg["V"], label_format="npz")
+    monkeypatch.setattr(M.DataLoader, "_ship", lambda self, st: (None, None, None))
+    S = cfg["S"]
+
+    def run(batch_size, rank, world):
+        opt = loader_opt(str(tmp_path), label_path, batch_size, S, cfg["Dfc"], cfg["D"] + 5, 1, 1, 1)
+        loader = M.DataLoader(opt, device="cpu", rank=rank, world_size=world)
+        random.seed(5)
+        out = []
+        for _ in range(5):                                  # 5 x 4 images over 7: wraps and reshuffles twice
+            d = loader.get_batch("train")
+            out.append({info["ix"]: d["labels"][j * S:(j + 1) * S] for j, info in enumerate(d["infos"])})
+        return out, loader
+    whole, _ = run(4, 0, 1)
+    r0, l0 = run(2, 0, 2)
+    r1, l1 = run(2, 1, 2)
+    assert l0.iterators == l1.iterators and l0.split_ix == l1.split_ix
+    for b in range(5):
+        assert len(r0[b]) + len(r1[b]) == len(whole[b]) or len(set(r0[b]) | set(r1[b])) == len(whole[b])
+        merged = dict(r0[b])
+        merged.update(r1[b])
+        assert sorted(merged) == sorted(whole[b])
+        for ix in whole[b]:
+            assert np.array_equal(merged[ix], whole[b][ix])

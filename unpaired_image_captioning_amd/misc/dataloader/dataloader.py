@@ -61,8 +61,12 @@ class DataLoader(object):
     def get_seq_length(self):
         return self.seq_length
 
-    def __init__(self, opt, train=True, device="cuda", read_threads=None, read_ahead=True):
+    def __init__(self, opt, train=True, device="cuda", read_threads=None, read_ahead=True, rank=0, world_size=1):
         self.lib = _lib.load()                                         # raises when the HIP library is missing
+        # one process per GPU: every rank walks the SAME global sequence (same `random` seed: same shuffles, same
+        # caption draws) over world_size * batch_size images per step and keeps images [rank * B, (rank + 1) * B) of it
+        self.rank, self.world_size = int(rank), int(world_size)
+        assert 0 <= self.rank < self.world_size
         self.device = torch.device(device)
         self.opt = opt
         self.batch_size = self.opt.batch_size
@@ -263,7 +267,8 @@ class DataLoader(object):
     def _read_ahead(self, split, count):
         """Start staging the files the next get_batch(split) will ask for (known unless the epoch wraps before)."""
         ri = self.iterators[split]
-        nxt = list(self.split_ix[split][ri: ri + count])
+        glob = self.split_ix[split][ri: ri + count * self.world_size]
+        nxt = list(glob[self.rank * count: (self.rank + 1) * count]) if len(glob) == count * self.world_size else []
         if len(nxt) == count:
             self._pin_turn ^= 1
             self._ahead_job = (nxt, self._pool.submit(self._stage, nxt, self._pin_turn))
@@ -278,11 +283,15 @@ class DataLoader(object):
         mask_batch = np.zeros([batch_size * S, L + 2], dtype='float32')
         wrapped = False
         indices, infos, gts = [], [], []
-        for i in range(batch_size):
+        for g in range(batch_size * self.world_size):
             ix, w = self._next_index(split)                            # may reshuffle: BEFORE the caption draw, as :236,247
-            indices.append(ix)
-            label_batch[i * S:(i + 1) * S, 1:L + 1] = self.get_captions(ix, S)
+            seq = self.get_captions(ix, S)
             wrapped = wrapped or w
+            i = g - self.rank * batch_size
+            if i < 0 or i >= batch_size:
+                continue                                               # another rank's image (its draws were consumed above)
+            indices.append(ix)
+            label_batch[i * S:(i + 1) * S, 1:L + 1] = seq
             gts.append(self.labels[self.label_start_ix[ix] - 1: self.label_end_ix[ix]])
             img = self.info['images'][ix]
             infos.append({'ix': ix, 'id': img['id'], 'file_path': img['file_path']})
