@@ -237,3 +237,49 @@ def test_trainer_steps_from_loader_batches_equal_steps_from_reference_shaped_bat
     np.testing.assert_allclose(c, a, rtol=0, atol=2e-5)
     assert all(np.isfinite(a)) and a[-1] < a[0] + 1.0
     np.testing.assert_allclose(a, b, rtol=0, atol=2e-5)
+
+
+def test_eval_split_over_the_val_images(tmp_path):
+    """eval_split (P/eval_utils.py:194-313) on a split of 5 images with batch 2: every image captioned exactly once (the
+    wrap-around surplus is popped), greedy captions equal the model's own decode of the reference-shaped batch, the loss is
+    the criterion's mean over the batches, beam search runs, and the model comes back in training mode."""
+    import argparse
+    from unpaired_image_captioning_amd import eval_utils, models
+    from unpaired_image_captioning_amd.misc import utils
+    from unpaired_image_captioning_amd.misc.dataloader.dataloader import DataLoader
+    cfg, z = load_case("dataloader_tiny")
+    n = cfg["n_images"]
+    splits = ["val", "val", "train", "val", "val", "train", "val"][:n]
+    label_path = write_dataset(str(tmp_path), [z["in::att_%d" % i] for i in range(n)], [z["in::box_%d" % i] for i in range(n)],
+                               [z["in::fc_%d" % i] for i in range(n)], z["in::hw"], z["in::ids"], z["in::labels"],
+                               z["in::label_start_ix"], z["in::label_end_ix"], cfg["V"], splits=splits, label_format="npz")
+    lopt = loader_opt(str(tmp_path), label_path, 2, 2, cfg["Dfc"], cfg["D"] + 5, 1, 1, 1)
+    loader = DataLoader(lopt)
+    opt = argparse.Namespace(vocab_size=cfg["V"], input_encoding_size=32, rnn_size=32, num_layers=1, drop_prob_lm=0.5,
+                             seq_length=cfg["L"], fc_feat_size=cfg["Dfc"], att_feat_size=cfg["D"] + 5, att_hid_size=32,
+                             use_bn=0, logit_layers=1, caption_model="topdown", compute_dtype="f32", seed=0, nmt_eval_flag=0)
+    torch.manual_seed(1)
+    model = models.setup(opt).cuda()
+    model.train()
+    random.seed(2)
+    loss, preds, lang, _, _ = eval_utils.eval_split(opt, loader, model, None, {"split": "val", "verbose": False, "sample_max": 1})
+    assert model.training and lang is None and np.isfinite(loss) and loss > 0
+    val_ids = [int(z["in::ids"][i]) for i in range(n) if splits[i] == "val"]
+    assert sorted(p["image_id"] for p in preds) == sorted(val_ids)
+    # the same captions from a direct greedy decode of each image
+    model.eval()
+    loader.reset_iterator("val")
+    by_id = {}
+    for _ in range(3):
+        d = loader.get_batch("val")
+        with torch.no_grad():
+            seq, _lp = model(d["fc_feats"], None, d["att_feats"], d["att_masks"], opt={"sample_max": 1}, mode="sample")
+        for info, s in zip(d["infos"], utils.decode_sequence(loader.get_vocab(), seq)):
+            by_id[info["id"]] = s
+    assert all(by_id[p["image_id"]] == p["caption"] for p in preds)
+    assert all(w.startswith("w") for p in preds for w in p["caption"].split())
+    _, preds_b, _, _, _ = eval_utils.eval_split(opt, loader, model, None, {"split": "val", "verbose": False, "verbose_beam": 0,
+                                                                          "beam_size": 2, "num_images": 3})
+    assert len(preds_b) == 3
+    with pytest.raises(NotImplementedError):
+        eval_utils.eval_split(opt, loader, model, None, {"split": "val", "language_eval": 1})

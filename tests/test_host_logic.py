@@ -221,3 +221,13 @@ def test_use_bn_state_dict_matches_reference(name, use_bn):
     fields = _lib.weight_fields(use_bn)
     assert [k for _, k, p in fields if p] == model.param_names
     assert all(k in sd for _, k, _ in fields)
+
+
+def test_decode_sequence_and_if_use_att():
+    """P/misc/utils.py:42-66."""
+    import torch
+    from unpaired_image_captioning_amd.misc import utils
+    vocab = {"1": "a", "2": "b", "3": "c"}
+    seq = torch.tensor([[1, 2, 0, 3], [3, 3, 3, 3], [0, 1, 1, 1]])
+    assert utils.decode_sequence(vocab, seq) == ["a b", "c c c c", ""]
+    assert utils.if_use_att("topdown") and not utils.if_use_att("fc")
