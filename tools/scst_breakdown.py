@@ -32,7 +32,7 @@ for it in range(8):
     fc, att, am = b["fc_feats"], b["att_feats"], b.get("att_masks")
     S = len(data["labels"]) // att.shape[0]
     model.train()
-    gen, lp = sec("sample", lambda: model(fc, None, att, am, opt={'sample_max': 0, 'seq_per_img': S}, mode='sample'), acc)
+    gen, lp = sec("sample", lambda: model(fc, None, att, am, opt={'sample_max': 0, 'captions_per_image': S}, mode='sample'), acc)
     model.eval()
     def greedy():
         with torch.no_grad():

@@ -240,9 +240,9 @@ class AttModel(CaptionModel):
         fc = fc_feats.contiguous().float()
         att = att_feats.contiguous().float()
         am = att_masks.contiguous().float() if att_masks is not None else None
-        # opt['seq_per_img'] = S > 1 (extension): features come once per image, S captions are decoded per image
+        # opt['captions_per_image'] = S > 1 (extension; not 'seq_per_img': callers pass all of vars(opt) as eval_kwargs, P/train.py): features come once per image, S captions are decoded per image
         kw = dict(sample_max=sample_max, temperature=temperature, decoding_constraint=decoding_constraint,
-                  forced=opt.get('forced_tokens'), seq_per_img=int(opt.get('seq_per_img', 1) or 1))
+                  forced=opt.get('forced_tokens'), seq_per_img=int(opt.get('captions_per_image', 1) or 1))
         if torch.is_grad_enabled() and not sample_max:
             params = [self.param_dict()[k] for k in self.param_names]
             return _TopDownSample.apply(self, fc, att, am, kw, *params)

@@ -262,7 +262,7 @@ class Trainer(object):
         # the weights stay put until Adam below: ONE weight refresh serves the sampling pass, the greedy baseline and the replay
         with (eng.hold_weights() if hasattr(eng, 'hold_weights') else contextlib.nullcontext()):
             model.train()
-            gen_result, sample_logprobs = model(fc, None, att, am, opt={'sample_max': 0, 'seq_per_img': S}, mode='sample')
+            gen_result, sample_logprobs = model(fc, None, att, am, opt={'sample_max': 0, 'captions_per_image': S}, mode='sample')
             model.eval()
             with torch.no_grad():                                           # rewards.py:42-47: greedy baseline, eval mode
                 greedy_res, _ = model(fc, None, att, am, opt={'sample_max': 1}, mode='sample')
