@@ -331,6 +331,16 @@ def test_training_loop_from_files_checkpoints_and_resumes(tmp_path):
     opt2.att_feat_size = cfg["D"]
     trainer2, infos2, _ = train_loop.main(opt2, max_iterations=saved["iter"] + 2, log=lines.append)
     assert infos2["iter"] == saved["iter"] + 2
+    # self-critical phase straight from the loader's batches (device CIDEr-D + BLEU reward against data['gts'])
+    from unpaired_image_captioning_amd.misc import rewards
+    rewards.CiderD_scorer = None
+    opt3 = argparse_copy(opt2)
+    opt3.att_feat_size, opt3.start_from, opt3.self_critical_after = cfg["D"], None, 0
+    opt3.cached_tokens, opt3.cider_reward_weight, opt3.bleu_reward_weight = "corpus", 1.0, 0.5
+    opt3.checkpoint_path = str(tmp_path / "ckpt_sc")
+    trainer3, infos3, hist3 = train_loop.main(opt3, max_iterations=3, log=lines.append)
+    rewards.CiderD_scorer = None
+    assert trainer3.sc_flag and np.isfinite(trainer3.i2t_avg_reward) and len(hist3["loss_history"]) == 3
 
 
 def argparse_copy(ns):
