@@ -192,7 +192,9 @@ __global__ __launch_bounds__(64) void att_batch_assemble_wave_kernel(
 #pragma unroll
   for (int k = 0; k < K; ++k) {
     const int c = (lane + 64 * k) * 4;
-    if (c < D) v[k] = *(const float4*)(src + c);
+    if (c < D)                                         // read once, written once: keep both out of the caches' way
+      v[k] = make_float4(__builtin_nontemporal_load(src + c), __builtin_nontemporal_load(src + c + 1),
+                         __builtin_nontemporal_load(src + c + 2), __builtin_nontemporal_load(src + c + 3));
   }
 
   int rank = q;
@@ -253,7 +255,8 @@ __global__ __launch_bounds__(64) void att_batch_assemble_wave_kernel(
     if (c < D) {
       float4 x = v[k];
       if (norm_att) { x.x = x.x / nrm; x.y = x.y / nrm; x.z = x.z / nrm; x.w = x.w / nrm; }
-      *(float4*)(dst + c) = x;
+      __builtin_nontemporal_store(x.x, dst + c); __builtin_nontemporal_store(x.y, dst + c + 1);
+      __builtin_nontemporal_store(x.z, dst + c + 2); __builtin_nontemporal_store(x.w, dst + c + 3);
     }
   }
   for (int c = D + lane; c < ld_out; c += 64) dst[c] = (box_pack && c < Dout) ? mine[c - D] : 0.f;
