@@ -296,11 +296,11 @@ __global__ __launch_bounds__(64 * WM * WN * KS) void uic_gemm_kernel(const UicGe
                 ((T*)p.h_drop)[(size_t)row * p.ldhd + u] = uic_from_f<T>(hd);
               }
               if (p.gates_out) {
-                T* G = (T*)p.gates_out + (size_t)row * 4 * H + u;
-                G[0] = uic_from_f<T>(gi);
-                G[H] = uic_from_f<T>(gf);
-                G[2 * H] = uic_from_f<T>(gg);
-                G[3 * H] = uic_from_f<T>(go);
+                T* G = (T*)p.gates_out + (size_t)row * 4 * H + u;      // read again only in the backward pass
+                __builtin_nontemporal_store(uic_from_f<T>(gi), G);
+                __builtin_nontemporal_store(uic_from_f<T>(gf), G + H);
+                __builtin_nontemporal_store(uic_from_f<T>(gg), G + 2 * H);
+                __builtin_nontemporal_store(uic_from_f<T>(go), G + 3 * H);
               }
             } else {
               // maxout LSTMCore (P/models/FCModel_NMT.py:32-50): chunks (in, forget, out, a, b); g = max(a, b);
