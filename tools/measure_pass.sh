@@ -1,9 +1,9 @@
 #!/bin/bash
 # One measurement pass on the GPU box (profiles/README.md): bench line, kernel stats, PMC traffic of the attention kernel, MFMA-busy.
-# Run as: gpurun -- bash tools/measure_pass.sh   (outputs under gpurun_out/v8; copy what is to be judged into profiles/)
+# Run as: gpurun -- bash tools/measure_pass.sh   (outputs under gpurun_out/v9; copy what is to be judged into profiles/)
 set -x
 R=$GRAFT_REPO_ROOT
-O=$R/gpurun_out/v8
+O=$R/gpurun_out/v9
 mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
 timeout 400 python3 $R/bench.py > $O/bench.json 2> $O/bench.err

@@ -552,10 +552,14 @@ int uic_attention_fwd_launch(const UicAttnParams& p, hipStream_t s) {
   const size_t lds = sizeof(float) * (2 * (size_t)p.A + 4 * (size_t)p.R + 4 + NWAVES * (size_t)p.H);
   UIC_REQUIRE(lds <= 160 * 1024, "attention_fwd: needs %zu B of LDS", lds);
   if (fast_ok(p)) {
-    // 8 waves per caption row (measured against 4: 11.9 vs 12.1 us cache-resident, 13.1 vs 13.5 us HBM-cold at N = 640)
+    // waves per caption row, measured at N = 640 (bf16; 3 alternating passes each): 4 -> 12.1 us cache-resident / 13.5 us
+    // HBM-cold, 8 -> 11.8-12.5 / 12.9-13.1, 9 -> 12.3 / 13.1, 6 -> 12.4 / 13.4, 12 -> 11.7 / 12.8-12.9 (3 regions per wave).
+    // 12 costs the two-stream training step 0.4 % (a 768-thread workgroup leaves the side stream fewer free slots) and is
+    // taken for the steadier, faster kernel.
     const size_t lds8 = sizeof(float) * (4 * (size_t)p.R + 4 + 8 * (size_t)p.H);
+    const size_t lds12 = sizeof(float) * (4 * (size_t)p.R + 4 + 12 * (size_t)p.H);
     if (p.dtype == UIC_BF16)
-      hipLaunchKernelGGL((attn_fwd_fast_kernel<bf16_t, 8>), dim3(p.N), dim3(512), lds8, s, p);
+      hipLaunchKernelGGL((attn_fwd_fast_kernel<bf16_t, 12>), dim3(p.N), dim3(768), lds12, s, p);
     else
       hipLaunchKernelGGL((attn_fwd_fast_kernel<float, 8>), dim3(p.N), dim3(512), lds8, s, p);
   } else if (p.dtype == UIC_BF16)
