@@ -184,13 +184,14 @@ class DataLoader(object):
         them; returns what _ship needs.  Host work only (library calls release the GIL): runs on the read-ahead thread."""
         n_img = len(indices)
         fc_p, att_p, box_p = self._paths(indices)
-        fc_arr, fc_info = self._scan(fc_p, b"feat" if self._fc_ext == '.npz' else None)
+        # ONE scan for every file of the batch (a thread team is started per library call; `member` only matters for zips)
+        _, info_all = self._scan(fc_p + att_p + box_p, b"feat")
+        fc_info, att_info, box_info = (info_all[:n_img], info_all[n_img:n_img + len(att_p)], info_all[n_img + len(att_p):])
         Dfc = int(fc_info[0, 1] * fc_info[0, 2])
         if not (fc_info[:, 1] * fc_info[:, 2] == Dfc).all():
             raise ValueError("fc feature files of different sizes in one batch")
         st = {"n_img": n_img, "turn": turn}
         if self.use_att:
-            att_arr, att_info = self._scan(att_p, b"feat")
             if not (att_info[:, 0] == 2).all() or not (att_info[:, 2] == att_info[0, 2]).all():
                 raise ValueError("att feature files must hold [regions, %d] arrays" % att_info[0, 2])
             counts = [int(c) for c in att_info[:, 1]]
@@ -217,7 +218,6 @@ class DataLoader(object):
             meta_h.numpy()[:n_img + 1] = start
             meta_h.numpy()[n_img + 1:] = slot_of
             if self.use_box:
-                box_arr, box_info = self._scan(box_p, None)
                 if not (box_info[:, 1] == att_info[:, 1]).all() or not (box_info[:, 2] == 4).all():
                     raise ValueError("box files must hold [regions, 4] arrays with the regions of the att features")
                 st["box"] = box_h, _ = self._staging("box", (total * 4 + n_img * 3,), torch.float32, turn)
@@ -303,7 +303,7 @@ class DataLoader(object):
 
         data = {}
         data['fc_feats'], data['att_feats'], data['att_masks'] = self._ship(st)
-        if self.read_ahead and not wrapped:
+        if self.read_ahead:                 # (after a wrap the split is already reshuffled: the peek below sees the new order)
             self._read_ahead(split, batch_size)
         data['attri_feats'] = None
         data['labels'] = label_batch
