@@ -620,11 +620,13 @@ __global__ void adam_kernel(const UicAdamParams a) {
     if (coef < 1.f) gs *= coef;
   }
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < a.n; i += stride) {
-    const float g = a.g[i] * gs;
-    const float m = a.beta1 * a.m[i] + (1.f - a.beta1) * g;
-    const float v = a.beta2 * a.v[i] + (1.f - a.beta2) * g * g;
-    a.m[i] = m;
-    a.v[i] = v;
+    // gradient and moments are touched once per step, by this kernel only: streamed past the caches (the parameters are
+    // re-read right after by the operand-copy refresh and stay cacheable)
+    const float g = __builtin_nontemporal_load(a.g + i) * gs;
+    const float m = a.beta1 * __builtin_nontemporal_load(a.m + i) + (1.f - a.beta1) * g;
+    const float v = a.beta2 * __builtin_nontemporal_load(a.v + i) + (1.f - a.beta2) * g * g;
+    __builtin_nontemporal_store(m, a.m + i);
+    __builtin_nontemporal_store(v, a.v + i);
     const float denom = sqrtf(v) * inv_sqrt_bc2 + a.eps;
     a.p[i] -= step_size * (m / denom);
   }
