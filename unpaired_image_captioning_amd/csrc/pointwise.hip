@@ -20,7 +20,9 @@ __global__ void cast_from_f32_kernel(const float* __restrict__ src, T* __restric
   const size_t stride = (size_t)gridDim.x * blockDim.x * 4;
   for (size_t i = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * 4; i < n; i += stride) {
     if (i + 3 < n) {
-      const float4 v = *(const float4*)(src + i);
+      // the f32 source (master parameters, the loader's features) is not read again this step: streamed
+      const float4 v = make_float4(__builtin_nontemporal_load(src + i), __builtin_nontemporal_load(src + i + 1),
+                                   __builtin_nontemporal_load(src + i + 2), __builtin_nontemporal_load(src + i + 3));
       if constexpr (sizeof(T) == 2) {
         *(uint2*)(dst + i) = make_uint2(uic_pack_bf16x2(v.x, v.y), uic_pack_bf16x2(v.z, v.w));
       } else {
