@@ -237,112 +237,3 @@ def test_trainer_steps_from_loader_batches_equal_steps_from_reference_shaped_bat
     np.testing.assert_allclose(c, a, rtol=0, atol=2e-5)
     assert all(np.isfinite(a)) and a[-1] < a[0] + 1.0
     np.testing.assert_allclose(a, b, rtol=0, atol=2e-5)
-
-
-def test_eval_split_over_the_val_images(tmp_path):
-    """eval_split (P/eval_utils.py:194-313) on a split of 5 images with batch 2: every image captioned exactly once (the
-    wrap-around surplus is popped), greedy captions equal the model's own decode of the reference-shaped batch, the loss is
-    the criterion's mean over the batches, beam search runs, and the model comes back in training mode."""
-    import argparse
-    from unpaired_image_captioning_amd import eval_utils, models
-    from unpaired_image_captioning_amd.misc import utils
-    from unpaired_image_captioning_amd.misc.dataloader.dataloader import DataLoader
-    cfg, z = load_case("dataloader_tiny")
-    n = cfg["n_images"]
-    splits = ["val", "val", "train", "val", "val", "train", "val"][:n]
-    label_path = write_dataset(str(tmp_path), [z["in::att_%d" % i] for i in range(n)], [z["in::box_%d" % i] for i in range(n)],
-                               [z["in::fc_%d" % i] for i in range(n)], z["in::hw"], z["in::ids"], z["in::labels"],
-                               z["in::label_start_ix"], z["in::label_end_ix"], cfg["V"], splits=splits, label_format="npz")
-    lopt = loader_opt(str(tmp_path), label_path, 2, 2, cfg["Dfc"], cfg["D"] + 5, 1, 1, 1)
-    loader = DataLoader(lopt)
-    opt = argparse.Namespace(vocab_size=cfg["V"], input_encoding_size=32, rnn_size=32, num_layers=1, drop_prob_lm=0.5,
-                             seq_length=cfg["L"], fc_feat_size=cfg["Dfc"], att_feat_size=cfg["D"] + 5, att_hid_size=32,
-                             use_bn=0, logit_layers=1, caption_model="topdown", compute_dtype="f32", seed=0, nmt_eval_flag=0)
-    torch.manual_seed(1)
-    model = models.setup(opt).cuda()
-    model.train()
-    random.seed(2)
-    loss, preds, lang, _, _ = eval_utils.eval_split(opt, loader, model, None, {"split": "val", "verbose": False, "sample_max": 1})
-    assert model.training and lang is None and np.isfinite(loss) and loss > 0
-    val_ids = [int(z["in::ids"][i]) for i in range(n) if splits[i] == "val"]
-    assert sorted(p["image_id"] for p in preds) == sorted(val_ids)
-    # the same captions from a direct greedy decode of each image
-    model.eval()
-    loader.reset_iterator("val")
-    by_id = {}
-    for _ in range(3):
-        d = loader.get_batch("val")
-        with torch.no_grad():
-            seq, _lp = model(d["fc_feats"], None, d["att_feats"], d["att_masks"], opt={"sample_max": 1}, mode="sample")
-        for info, s in zip(d["infos"], utils.decode_sequence(loader.get_vocab(), seq)):
-            by_id[info["id"]] = s
-    assert all(by_id[p["image_id"]] == p["caption"] for p in preds)
-    assert all(w.startswith("w") for p in preds for w in p["caption"].split())
-    _, preds_b, _, _, _ = eval_utils.eval_split(opt, loader, model, None, {"split": "val", "verbose": False, "verbose_beam": 0,
-                                                                          "beam_size": 2, "num_images": 3})
-    assert len(preds_b) == 3
-    with pytest.raises(NotImplementedError):
-        eval_utils.eval_split(opt, loader, model, None, {"split": "val", "language_eval": 1})
-
-
-def test_training_loop_from_files_checkpoints_and_resumes(tmp_path):
-    """train_loop.main (P/train.py): a few epochs over a 7-image data set -- the loss falls, the checkpoint files of the
-    reference appear with its keys, the state_dict loads into a fresh model, and a second run resumes from infos-best.pkl."""
-    import pickle
-    from unpaired_image_captioning_amd import models, train_loop
-    cfg, z = load_case("dataloader_tiny")
-    n = cfg["n_images"]
-    splits = ["train", "train", "val", "train", "train", "val", "train"][:n]
-    label_path = write_dataset(str(tmp_path / "data"), [z["in::att_%d" % i] for i in range(n)], [z["in::box_%d" % i] for i in range(n)],
-                               [z["in::fc_%d" % i] for i in range(n)], z["in::hw"], z["in::ids"], z["in::labels"],
-                               z["in::label_start_ix"], z["in::label_end_ix"], cfg["V"], splits=splits, label_format=hdf5_or_npz())
-    opt = loader_opt(str(tmp_path / "data"), label_path, 2, 2, cfg["Dfc"], cfg["D"], 1, 1, 1)     # use_box adds the 5 columns
-    for k, v in dict(caption_model="topdown", input_encoding_size=32, rnn_size=32, num_layers=1, rnn_type="lstm", drop_prob_lm=0.0,
-                     att_hid_size=32, use_bn=0, logit_layers=1, compute_dtype="f32", seed=7, i2t_learning_rate=5e-3,
-                     i2t_learning_rate_decay_start=0, i2t_learning_rate_decay_every=2, i2t_learning_rate_decay_rate=0.5,
-                     scheduled_sampling_start=-1, self_critical_after=-1, save_checkpoint_every=6, losses_log_every=1,
-                     checkpoint_path=str(tmp_path / "ckpt"), start_from=None, id="t", language_eval=0, nmt_eval_flag=0,
-                     i2t_train_flag=1, max_epochs=-1, sample_max=1, beam_size=1).items():
-        setattr(opt, k, v)
-    random.seed(3)
-    lines = []
-    trainer, infos, hist = train_loop.main(opt, max_iterations=12, log=lines.append)
-    assert opt.att_feat_size == cfg["D"] + 5 and opt.vocab_size == cfg["V"] and opt.seq_length == cfg["L"]
-    losses = [hist["loss_history"][i] for i in sorted(hist["loss_history"])]
-    assert len(losses) == 12 and losses[-1] < losses[0]
-    assert infos["iter"] == 12 and infos["epoch"] >= 3 and sorted(hist["val_result_history"]) == [6, 12]
-    assert trainer.i2t_current_lr < 5e-3                               # the epoch schedule was applied
-    files = sorted(os.listdir(str(tmp_path / "ckpt")))
-    assert "model_i2t-best.pth" in files and "infos-best.pkl" in files and "histories-best.pkl" in files
-    with open(str(tmp_path / "ckpt" / "infos-best.pkl"), "rb") as f:
-        saved = pickle.load(f)
-    assert {"iter", "epoch", "iterators", "split_ix", "best_val_score", "opt", "vocab"} <= set(saved)
-    fresh = models.setup(opt)
-    sd = torch.load(str(tmp_path / "ckpt" / "model_i2t-best.pth"))
-    assert list(sd) == list(fresh.state_dict())
-    fresh.load_state_dict(sd)
-    preds = hist["val_result_history"][12]["predictions"]
-    assert sorted(p["image_id"] for p in preds) == sorted(int(z["in::ids"][i]) for i in range(n) if splits[i] == "val")
-    # resume
-    opt.start_from = str(tmp_path / "ckpt")
-    opt.use_box = 0                                                    # (att_feat_size already carries the 5 columns)
-    opt2 = argparse_copy(opt)
-    opt2.use_box = 1
-    opt2.att_feat_size = cfg["D"]
-    trainer2, infos2, _ = train_loop.main(opt2, max_iterations=saved["iter"] + 2, log=lines.append)
-    assert infos2["iter"] == saved["iter"] + 2
-    # self-critical phase straight from the loader's batches (device CIDEr-D + BLEU reward against data['gts'])
-    from unpaired_image_captioning_amd.misc import rewards
-    rewards.CiderD_scorer = None
-    opt3 = argparse_copy(opt2)
-    opt3.att_feat_size, opt3.start_from, opt3.self_critical_after = cfg["D"], None, 0
-    opt3.cached_tokens, opt3.cider_reward_weight, opt3.bleu_reward_weight = "corpus", 1.0, 0.5
-    opt3.checkpoint_path = str(tmp_path / "ckpt_sc")
-    trainer3, infos3, hist3 = train_loop.main(opt3, max_iterations=3, log=lines.append)
-    rewards.CiderD_scorer = None
-    assert trainer3.sc_flag and np.isfinite(trainer3.i2t_avg_reward) and len(hist3["loss_history"]) == 3
-
-
-def argparse_copy(ns):
-    import argparse
-    return argparse.Namespace(**vars(ns))
