@@ -167,6 +167,8 @@ class Batch(C.Structure):
 _SIGS = {
     "uic_last_error_string": (C.c_char_p, []),
     "uic_version": (C.c_int, []),
+    "uic_set_persistent_rnn": (C.c_int, [C.c_int32]),
+    "uic_set_persistent_status": (C.c_int, [C.c_void_p]),
     "uic_topdown_workspace_bytes": (C.c_size_t, [C.POINTER(Dims)]),
     "uic_topdown_derived_bytes": (C.c_size_t, [C.POINTER(Dims)]),
     "uic_topdown_refresh_weights": (C.c_int, [C.POINTER(Dims), C.POINTER(Weights), C.c_void_p, C.c_void_p]),
@@ -259,6 +261,27 @@ def load():
             fn.argtypes = args
         _lib = lib
     return _lib
+
+
+_status = {}
+
+
+def persistent_status(device=None):
+    """The sticky status words of the persistent recurrence kernel on `device` (registered on first use) as a list
+    [timeout code, XCD-local launches, SAFE launches]; synchronises.  A non-zero timeout code raises."""
+    lib = load()
+    dev = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+    idx = dev.index if dev.index is not None else torch.cuda.current_device()
+    first = idx not in _status
+    if first:
+        with torch.cuda.device(idx):
+            _status[idx] = torch.zeros(4, dtype=torch.int32, device="cuda:%d" % idx)
+            check(lib.uic_set_persistent_status(_status[idx].data_ptr()), "set_persistent_status")
+    vals = [int(v) for v in _status[idx].cpu().tolist()]
+    if vals[0] != 0:
+        _status[idx].zero_()
+        raise RuntimeError("persistent recurrence kernel timed out (code 0x%x): results of the last calls are invalid" % vals[0])
+    return vals[:3]
 
 
 def check(rc, what=""):

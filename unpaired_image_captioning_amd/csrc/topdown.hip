@@ -46,6 +46,7 @@ struct Layout {
   float* slab; size_t slab_bytes;
   void* tLA; void* tLB; float* colscratchL;   // scratch of the logit-layer weight gradients (side stream)
   void* tSA; void* tSB; float* slab2;         // scratch of the per-chunk recurrent weight gradients (side stream)
+  unsigned* rnn_sync; unsigned long long* rnn_dbg;   // persistent recurrence (rnn_persist.hip): sync block, optional time stamps
   // sampling
   void* s_h_att[2]; void* s_h_lang[2]; float* s_c_att[2]; float* s_c_lang[2];
   void* s_xt; float* s_atth; float* s_alpha; void* s_ctx; void* s_hdrop; float* s_logits;
@@ -159,6 +160,8 @@ Layout make_layout(const uic_topdown_dims& d, void* ws) {
     L.slab = (float*)b.take(sl);
     L.slab2 = (float*)b.take(sl);
   }
+  L.rnn_sync = (unsigned*)b.take(uic_rnn_persist_sync_bytes());
+  L.rnn_dbg = (unsigned long long*)b.take((size_t)256 * T * 16 * 8);
   for (int i = 0; i < 2; ++i) {
     L.s_h_att[i] = b.take(N * H * S);
     L.s_h_lang[i] = b.take(N * H * S);
@@ -458,7 +461,7 @@ void* uic_topdown_workspace_ptr(const uic_topdown_dims* d, void* workspace, cons
       {"gates2", L.gates2}, {"att_h", L.atth_all}, {"alpha", L.alpha_all}, {"ctx", L.ctx_all}, {"hdrop", L.hdrop_all},
       {"logits", L.logits}, {"dlogits", L.dlogits}, {"row_loss", L.row_loss}, {"scalars", L.scalars},
       {"dhdrop", L.dhdrop}, {"dx2", L.dx2_all}, {"dg1", L.dg1_all}, {"dg2", L.dg2_all}, {"de", L.de_all},
-      {"datth", L.datth_all}, {"d_att", L.d_att}, {"d_p_att", L.d_patt}, {"dxt", L.dxt}};
+      {"datth", L.datth_all}, {"d_att", L.d_att}, {"d_p_att", L.d_patt}, {"dxt", L.dxt}, {"rnn_dbg", L.rnn_dbg}};
   for (auto& e : tab)
     if (!strcmp(e.n, name)) return e.p;
   return nullptr;
@@ -631,6 +634,37 @@ struct Step {
     }
     if (ss_on()) UIC_TRY(logits_rows_now(t, t + 1, s));   // the next step samples from this step's distribution
     return UIC_OK;
+  }
+
+  // decode steps [t0, t1) of the recurrence: one persistent launch (rnn_persist.hip) when the shapes allow, else the
+  // per-step chain.  Scheduled sampling needs the logits of step t - 1 on the host-sequenced path.
+  bool persist_ok() const { return !ss_on() && uic_rnn_persist_eligible(dt, N, H, A, R); }
+  int fwd_steps(int t0, int t1, hipStream_t s) {
+    if (!persist_ok()) {
+      for (int t = t0; t < t1; ++t) UIC_TRY(fwd_step(t, s));
+      return UIC_OK;
+    }
+    UicRnnFwdParams p;
+    memset(&p, 0, sizeof(p));
+    p.dtype = dt; p.N = N; p.R = R; p.t0 = t0; p.t1 = t1;
+    p.gx = L.gx; p.gfc = L.gfc;
+    p.att_w_ih = dv.att_w_ih; p.ld_att_ih = ldih; p.att_w_hh = dv.att_w_hh;
+    p.lang_w_ih = dv.lang_w_ih; p.lang_w_hh = dv.lang_w_hh;
+    p.lang_b_ih = w->lang_lstm_b_ih; p.lang_b_hh = w->lang_lstm_b_hh;
+    p.h2att_w = dv.h2att_w; p.h2att_b = w->h2att_b;
+    p.w_alpha = w->alpha_w; p.b_alpha = w->alpha_b;
+    p.p_att = L.patt; p.att = L.attp;
+    p.mask = b->att_masks ? (d.seq_per_img > 1 ? L.amask_rep : b->att_masks) : nullptr; p.ldmask = R;
+    p.h_att = L.h_att; p.h_lang = L.h_lang; p.c_att = L.c_att; p.c_lang = L.c_lang;
+    p.gates1 = L.gates1; p.gates2 = L.gates2;
+    p.att_h_all = L.atth_all; p.alpha_all = L.alpha_all; p.ctx_all = L.ctx_all; p.hdrop_all = L.hdrop_all;
+    p.drop_p = drop_p; p.seed = seed;
+    p.sync = L.rnn_sync;
+    static const bool dbg_on = getenv("UIC_PERSIST_DBG") != nullptr;
+    p.dbg = dbg_on ? L.rnn_dbg : nullptr; p.dbg_T = d.T;
+    static const int exp_flags = getenv("UIC_PERSIST_EXP") ? atoi(getenv("UIC_PERSIST_EXP")) : 0;
+    p.exp = exp_flags;
+    return uic_rnn_fwd_persist_launch(p, s);
   }
 
   // logits of decode steps [t0, t1) (AttModel.py:163); under scheduled sampling every step already produced its own
@@ -1003,7 +1037,7 @@ int uic_topdown_forward(const uic_topdown_dims* d, const uic_topdown_weights* w,
   st.init(d, w, derived, b, t_run, training, seed, workspace, nullptr);
   UIC_TRY(st.fwd_prologue(s));
   UIC_TRY(wait_refresh(s));
-  for (int t = 0; t < t_run; ++t) UIC_TRY(st.fwd_step(t, s));
+  UIC_TRY(st.fwd_steps(0, t_run, s));
   UIC_TRY(st.logits_rows(0, t_run, s));
   if (logprobs_out) UIC_TRY(st.xe_rows(0, t_run, nullptr, logprobs_out, 0, s));
   return UIC_OK;
@@ -1081,7 +1115,7 @@ int uic_topdown_xe_train_step(const uic_topdown_dims* d, const uic_topdown_weigh
   UIC_TRY(wait_refresh(s));                           // the recurrence needs the side-stream half of the weight refresh
   for (int c = 0; c < nchunk; ++c) {
     const int t0 = c * CH, t1 = t0 + CH < t_run ? t0 + CH : t_run;
-    for (int t = t0; t < t1; ++t) UIC_TRY(st.fwd_step(t, s));
+    UIC_TRY(st.fwd_steps(t0, t1, s));
     UIC_HIP(hipEventRecord(ss->ev_main[c], s));
     // side: logit layer of the chunk, forward and backward-to-h (beside the next chunk's recurrence)
     UIC_HIP(hipStreamWaitEvent(s2, ss->ev_main[c], 0));

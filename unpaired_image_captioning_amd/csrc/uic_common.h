@@ -242,6 +242,36 @@ struct UicAttnAccumParams {
 };
 int uic_attention_bwd_accum_launch(const UicAttnAccumParams& p, hipStream_t s);
 
+// ---------------------------------------------------------------- persistent recurrence (rnn_persist.hip)
+// Decode steps [t0, t1) of the TopDown recurrence (P/models/AttModel.py:129-154, :430-446, :538-558) in ONE launch.
+// All state / activation buffers are the time-major workspace slabs of topdown.hip (step stride N*H etc.).
+struct UicRnnFwdParams {
+  int dtype, N, R, t0, t1;
+  int row0, Nrows, force_safe;       // filled by the launcher (slabs of <= 640 caption rows)
+  const float* gx;                   // [T, N, 4H] xt W_x^T + b_ih + b_hh of att_lstm
+  const float* gfc;                  // [N, 4H] fc' W_fc^T, or null
+  const void* att_w_ih; int ld_att_ih;   // [4H, ld]: columns [0, H) multiply h_lang_prev
+  const void* att_w_hh;              // [4H, H]
+  const void* lang_w_ih;             // [4H, 2H]: [att_res | h_att]
+  const void* lang_w_hh;             // [4H, H]
+  const float* lang_b_ih; const float* lang_b_hh;
+  const void* h2att_w; const float* h2att_b;     // [A, H]
+  const float* w_alpha; const float* b_alpha;
+  const void* p_att; const void* att;            // [N, R, A], [N, R, H]
+  const float* mask; int ldmask;                 // [N, R] or null
+  void* h_att; void* h_lang; float* c_att; float* c_lang;     // [(T+1), N, H]: slot t is the state before step t
+  void* gates1; void* gates2;                    // [T, N, 4H] activated gates for the backward pass, or null
+  float* att_h_all; float* alpha_all; void* ctx_all; void* hdrop_all;   // [T, N, .]
+  float drop_p; unsigned seed;
+  unsigned* sync;                    // uic_rnn_persist_sync_bytes() bytes, zeroed by the launcher
+  unsigned long long* dbg; int dbg_T; int exp; // optional [256][dbg_T][16] phase time stamps; exp: timing experiments (wrong results) (100 MHz), indexed by absolute step
+  unsigned* status;                  // filled by the launcher: sticky status words (uic_set_persistent_status) or null
+};
+int uic_rnn_persist_mode();          // 0 off, 1 on, 2 on + SAFE protocol (UIC_PERSIST / uic_set_persistent_rnn)
+size_t uic_rnn_persist_sync_bytes();
+bool uic_rnn_persist_eligible(int dtype, int N, int H, int A, int R);
+int uic_rnn_fwd_persist_launch(const UicRnnFwdParams& p, hipStream_t s);
+
 // ---------------------------------------------------------------- pointwise (pointwise.hip)
 int uic_cast_f32_launch(int dtype, const float* src, void* dst, size_t n, hipStream_t s);
 int uic_to_f32_launch(int dtype, const void* src, float* dst, size_t n, hipStream_t s);
