@@ -97,11 +97,12 @@ for mode in (1, 2):
             seg = d[:, :, k + 1] - d[:, :, k]
             print("   phase %-6s mean %6.2f us   median %6.2f   max over WGs (mean over t) %6.2f" %
                   (names[k], seg.mean().item(), seg.median().item(), seg.max(dim=0)[0].mean().item()))
-        for nm, k0 in (("lstm1", 0), ("lstm2", 6)):
-            base = 8 if nm == "lstm1" else 12
-            seq = [d[:, :, k0]] + [d[:, :, base + j] for j in range(3)] + [d[:, :, k0 + 1]]
-            lab = ["start->gemm done", "->pass0 partials in LDS", "->pass1 partials in LDS", "->phase end"]
-            print("   %s wave0: %s" % (nm, ", ".join("%s %.2f" % (lab[j], (seq[j + 1] - seq[j]).mean().item()) for j in range(4))))
+        if os.environ.get("UIC_PERSIST_WS", "1") != "0" and args.dtype == "bf16":
+            def seg(a, b):
+                return (d[:, :, b] - d[:, :, a]).mean().item()
+            print("   lstm1 (wave 0): loads+MFMA of own tile %.2f, cell %.2f, fifth tile %.2f" % (seg(0, 8), seg(8, 9), seg(9, 1)))
+            print("   lstm2 (wave 0): to pass0 barrier %.2f, then per pass %s, tail %.2f" %
+                  (seg(6, 11), [round(seg(11 + i, 12 + i), 2) for i in range(4)], seg(15, 7)))
         step = d[:, 1:, 0] - d[:, :-1, 0]
         print("   step   mean %6.2f us  (first WG0 steps: %s)" % (step.mean().item(), [round(x, 2) for x in step[0, :5].tolist()]))
         tot = (d[:, t_run - 1, 7] - d[:, 0, 0])

@@ -29,7 +29,7 @@ def build(force: bool = False, verbose: bool = True) -> str:
     for s in srcs:
         o = s[:-4] + ".o"
         objs.append(o)
-        cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-c", s, "-o", o]
+        cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17"] + os.environ.get("UIC_EXTRA_HIPCC_FLAGS", "").split() + ["-c", s, "-o", o]
         if verbose:
             print(" ".join(cmd), flush=True)
         procs.append((cmd, subprocess.Popen(cmd)))

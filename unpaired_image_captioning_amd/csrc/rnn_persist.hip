@@ -37,7 +37,7 @@ constexpr int MT_MAX = 5;           // 16-row tiles per group
 constexpr int HH = 16 * PW;         // rnn_size == att_hid_size == 512 (P/opts.py:45-46 defaults)
 constexpr int HALF_T = 3;           // row tiles reduced per LDS pass (8 waves x 3 tiles x 4 gates x 1 KB = 96 KB)
 constexpr unsigned SPIN_MAX = 1u << 17;
-constexpr int ATT_UB = 5;           // regions per wave in the attention phase: R <= 8 * 5
+constexpr int ATT_R = 40;           // regions the attention phase covers (8 waves x 5 or 4 waves x 10 per row)
 constexpr int LDS_BYTES = NWAVE * HALF_T * 4 * 1024;
 
 typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
@@ -294,53 +294,62 @@ __device__ __forceinline__ void h2att_phase(Ctx& c, const T* h_att_new, const T*
   __syncthreads();
 }
 
-// Attention.forward after h2att (P/models/AttModel.py:544-556) for caption row n, all 8 waves (attention.hip's
-// attn_fwd_fast_kernel with the row's att_h read past the L1)
-template <typename T, bool SAFE>
-__device__ __forceinline__ void attn_row(const Ctx& c, const UicRnnFwdParams& p, int n, const float* att_h, float* alpha, T* ctx) {
-  constexpr int VEC = 16 / (int)sizeof(T);
-  constexpr int CH = HH / VEC / 64;               // 16-byte chunks of a 512-wide row per lane (bf16: 1, f32: 2)
+// Attention.forward after h2att (P/models/AttModel.py:544-556), all 8 waves per caption row (attention.hip's
+// attn_fwd_fast_kernel with the row's att_h read past the L1).  A workgroup has up to three rows per step; their loads are
+// software-pipelined through three register slots of 5 x 16 B per lane (p_att of a row, att' of a row), so that two
+// slots' worth of loads are always in flight while the third is being consumed.
+template <typename T> struct AttnCfg {
+  static constexpr int VEC = 16 / (int)sizeof(T);
+  static constexpr int CH = HH / VEC / 64;        // 16-byte chunks of a 512-wide row per lane (bf16: 1, f32: 2)
+};
+template <typename T, int NW> struct AttnSlot { uint4 v[ATT_R / NW][AttnCfg<T>::CH]; };
+template <typename T> struct AttnHead { u32x4 ah[AttnCfg<T>::CH][AttnCfg<T>::VEC / 4]; };
+
+template <typename T, int NW>
+__device__ __forceinline__ void attn_load_slot(const Ctx& c, int R, const T* base, AttnSlot<T, NW>& q) {
+  constexpr int VEC = AttnCfg<T>::VEC, CH = AttnCfg<T>::CH;
+#pragma unroll
+  for (int u = 0; u < ATT_R / NW; ++u) {
+    const int r = min(c.wave + u * NW, R - 1);
+#pragma unroll
+    for (int k = 0; k < CH; ++k) q.v[u][k] = *(const uint4*)(base + (unsigned)(r * HH + (c.lane + 64 * k) * VEC));
+  }
+}
+template <typename T>
+__device__ __forceinline__ void attn_load_head(const Ctx& c, const float* att_h_row, AttnHead<T>& q) {
+  constexpr int VEC = AttnCfg<T>::VEC, CH = AttnCfg<T>::CH;
+  const __amdgpu_buffer_rsrc_t rh = rsrc_of(att_h_row);
+#pragma unroll
+  for (int k = 0; k < CH; ++k)
+#pragma unroll
+    for (int v = 0; v < VEC / 4; ++v) q.ah[k][v] = bload<true>(rh, (unsigned)(((c.lane + 64 * k) * VEC + v * 4) * 4), 0);
+}
+// scores + softmax (+ mask renormalisation) of row n; returns this lane's weight (lane r < R holds alpha_r)
+template <typename T, int NW>
+__device__ __forceinline__ float attn_scores(const Ctx& c, const UicRnnFwdParams& p, int n, const AttnSlot<T, NW>& vp, const AttnHead<T>& hd,
+                                             float* alpha) {
+  constexpr int VEC = AttnCfg<T>::VEC, CH = AttnCfg<T>::CH;
   const int R = p.R;
   float* s_e = (float*)c.smem + 64;               // [R][4] row-of-16 partial scores (word 0 of smem is the barrier flag)
-  float* s_red = s_e + 4 * ((R + 3) & ~3);        // [NWAVE][HH]
-  const T* pa = (const T*)p.p_att + (size_t)n * R * HH;
-  const T* pt = (const T*)p.att + (size_t)n * R * HH;
-  uint4 vp[ATT_UB][CH], va[ATT_UB][CH];
-#pragma unroll
-  for (int u = 0; u < ATT_UB; ++u) {
-    const int r = min(c.wave + u * NWAVE, R - 1);
-#pragma unroll
-    for (int k = 0; k < CH; ++k) vp[u][k] = *(const uint4*)(pa + (unsigned)(r * HH + (c.lane + 64 * k) * VEC));
-  }
-#pragma unroll
-  for (int u = 0; u < ATT_UB; ++u) {
-    const int r = min(c.wave + u * NWAVE, R - 1);
-#pragma unroll
-    for (int k = 0; k < CH; ++k) va[u][k] = *(const uint4*)(pt + (unsigned)(r * HH + (c.lane + 64 * k) * VEC));
-  }
   float ah[CH][VEC], w[CH][VEC];
-  {
-    const __amdgpu_buffer_rsrc_t rh = rsrc_of(att_h + (size_t)n * HH);
 #pragma unroll
-    for (int k = 0; k < CH; ++k)
+  for (int k = 0; k < CH; ++k)
 #pragma unroll
-      for (int q = 0; q < VEC / 4; ++q) {
-        const u32x4 v = bload<true>(rh, (unsigned)(((c.lane + 64 * k) * VEC + q * 4) * 4), 0);
-        ah[k][q * 4 + 0] = __uint_as_float(v.x); ah[k][q * 4 + 1] = __uint_as_float(v.y);
-        ah[k][q * 4 + 2] = __uint_as_float(v.z); ah[k][q * 4 + 3] = __uint_as_float(v.w);
-        const float4 ww = *(const float4*)(p.w_alpha + (c.lane + 64 * k) * VEC + q * 4);
-        w[k][q * 4 + 0] = ww.x; w[k][q * 4 + 1] = ww.y; w[k][q * 4 + 2] = ww.z; w[k][q * 4 + 3] = ww.w;
-      }
-  }
+    for (int v = 0; v < VEC / 4; ++v) {
+      ah[k][v * 4 + 0] = __uint_as_float(hd.ah[k][v].x); ah[k][v * 4 + 1] = __uint_as_float(hd.ah[k][v].y);
+      ah[k][v * 4 + 2] = __uint_as_float(hd.ah[k][v].z); ah[k][v * 4 + 3] = __uint_as_float(hd.ah[k][v].w);
+      const float4 ww = *(const float4*)(p.w_alpha + (c.lane + 64 * k) * VEC + v * 4);
+      w[k][v * 4 + 0] = ww.x; w[k][v * 4 + 1] = ww.y; w[k][v * 4 + 2] = ww.z; w[k][v * 4 + 3] = ww.w;
+    }
   const float b_alpha = p.b_alpha ? p.b_alpha[0] : 0.f;
 #pragma unroll
-  for (int u = 0; u < ATT_UB; ++u) {
-    const int r = c.wave + u * NWAVE;
+  for (int u = 0; u < ATT_R / NW; ++u) {
+    const int r = c.wave + u * NW;
     float part = 0.f;
 #pragma unroll
     for (int k = 0; k < CH; ++k) {
       float f[VEC];
-      uic_unpack<T>(vp[u][k], f);
+      uic_unpack<T>(vp.v[u][k], f);
 #pragma unroll
       for (int j = 0; j < VEC; ++j) part += w[k][j] * uic_tanh<T>(f[j] + ah[k][j]);
     }
@@ -351,8 +360,8 @@ __device__ __forceinline__ void attn_row(const Ctx& c, const UicRnnFwdParams& p,
   const float* mk = p.mask ? p.mask + (size_t)n * p.ldmask : nullptr;
   float e = -INFINITY;
   if (c.lane < R) {
-    const float4 q = *(const float4*)(s_e + c.lane * 4);
-    e = (q.x + q.y) + (q.z + q.w) + b_alpha;
+    const float4 qq = *(const float4*)(s_e + c.lane * 4);
+    e = (qq.x + qq.y) + (qq.z + qq.w) + b_alpha;
   }
   const float mx = uic_wave_max(e);
   const float ex = c.lane < R ? expf(e - mx) : 0.f;
@@ -362,20 +371,27 @@ __device__ __forceinline__ void attn_row(const Ctx& c, const UicRnnFwdParams& p,
     wgt = wgt / uic_wave_sum(wgt);
   }
   if (c.wave == 0 && c.lane < R) alpha[(unsigned)(n * R + c.lane)] = wgt;
+  return wgt;
+}
+template <typename T, bool SAFE, int NW>
+__device__ __forceinline__ void attn_context(const Ctx& c, const UicRnnFwdParams& p, int n, const AttnSlot<T, NW>& va, float wgt, T* ctx) {
+  constexpr int VEC = AttnCfg<T>::VEC, CH = AttnCfg<T>::CH;
+  const int R = p.R;
+  float* s_red = (float*)c.smem + 64 + 4 * ((R + 3) & ~3);        // [NW][HH]
   float acc[CH][VEC];
 #pragma unroll
   for (int k = 0; k < CH; ++k)
 #pragma unroll
     for (int j = 0; j < VEC; ++j) acc[k][j] = 0.f;
 #pragma unroll
-  for (int u = 0; u < ATT_UB; ++u) {
-    const int r = c.wave + u * NWAVE;
+  for (int u = 0; u < ATT_R / NW; ++u) {
+    const int r = c.wave + u * NW;
     float al = __shfl(wgt, r < R ? r : 0, 64);
     if (r >= R) al = 0.f;
 #pragma unroll
     for (int k = 0; k < CH; ++k) {
       float f[VEC];
-      uic_unpack<T>(va[u][k], f);
+      uic_unpack<T>(va.v[u][k], f);
 #pragma unroll
       for (int j = 0; j < VEC; ++j) acc[k][j] += al * f[j];
     }
@@ -385,14 +401,79 @@ __device__ __forceinline__ void attn_row(const Ctx& c, const UicRnnFwdParams& p,
 #pragma unroll
     for (int j = 0; j < VEC; ++j) s_red[c.wave * HH + (c.lane + 64 * k) * VEC + j] = acc[k][j];
   __syncthreads();
-  {
-    const int h = c.tid;             // NTH == HH
+#pragma unroll
+  for (int h = c.tid; h < HH; h += NW * 64) {
     float sacc = 0.f;
 #pragma unroll
-    for (int wv = 0; wv < NWAVE; ++wv) sacc += s_red[wv * HH + h];
+    for (int wv = 0; wv < NW; ++wv) sacc += s_red[wv * HH + h];
     st_x<SAFE>(ctx + (unsigned)(n * HH + h), sacc);
   }
   __syncthreads();
+}
+// the attention phase of one workgroup: rows rank, rank + 32, rank + 64 of the group (<= 3).  SLOTS = 3: p_att and att' of
+// a row plus p_att of the next one in flight; SLOTS = 2 (the weight-stationary kernel, whose registers hold weights):
+// one slot in flight while the other is consumed.
+template <typename T, bool SAFE, int NW, int SLOTS>
+__device__ __forceinline__ void attn_phase(const Ctx& c, const UicRnnFwdParams& p, const float* att_h, float* alpha, T* ctx) {
+  const int R = p.R;
+  const int r0 = c.rank, r1 = c.rank + PW, r2 = c.rank + 2 * PW;
+  if (r0 >= c.nrow) return;
+  const bool has1 = r1 < c.nrow, has2 = r2 < c.nrow;
+  const int n0 = c.rbegin + r0, n1 = c.rbegin + r1, n2 = c.rbegin + r2;
+  const T* P = (const T*)p.p_att;
+  const T* V = (const T*)p.att;
+  AttnHead<T> h0, h1;
+  if constexpr (SLOTS == 3) {
+    AttnSlot<T, NW> s0, s1, s2;
+    attn_load_head<T>(c, att_h + (size_t)n0 * HH, h0);
+    attn_load_slot<T, NW>(c, R, P + (size_t)n0 * R * HH, s0);
+    attn_load_slot<T, NW>(c, R, V + (size_t)n0 * R * HH, s1);
+    if (has1) {
+      attn_load_head<T>(c, att_h + (size_t)n1 * HH, h1);
+      attn_load_slot<T, NW>(c, R, P + (size_t)n1 * R * HH, s2);
+    }
+    float wgt = attn_scores<T, NW>(c, p, n0, s0, h0, alpha);
+    if (has1) attn_load_slot<T, NW>(c, R, V + (size_t)n1 * R * HH, s0);
+    attn_context<T, SAFE, NW>(c, p, n0, s1, wgt, ctx);
+    if (has2) {
+      attn_load_head<T>(c, att_h + (size_t)n2 * HH, h0);
+      attn_load_slot<T, NW>(c, R, P + (size_t)n2 * R * HH, s1);
+    }
+    if (has1) {
+      wgt = attn_scores<T, NW>(c, p, n1, s2, h1, alpha);
+      if (has2) attn_load_slot<T, NW>(c, R, V + (size_t)n2 * R * HH, s2);
+      attn_context<T, SAFE, NW>(c, p, n1, s0, wgt, ctx);
+    }
+    if (has2) {
+      wgt = attn_scores<T, NW>(c, p, n2, s1, h0, alpha);
+      attn_context<T, SAFE, NW>(c, p, n2, s2, wgt, ctx);
+    }
+  } else {
+    AttnSlot<T, NW> s0, s1;
+    attn_load_head<T>(c, att_h + (size_t)n0 * HH, h0);
+    attn_load_slot<T, NW>(c, R, P + (size_t)n0 * R * HH, s0);
+    attn_load_slot<T, NW>(c, R, V + (size_t)n0 * R * HH, s1);
+    float wgt = attn_scores<T, NW>(c, p, n0, s0, h0, alpha);
+    if (has1) {
+      attn_load_head<T>(c, att_h + (size_t)n1 * HH, h1);
+      attn_load_slot<T, NW>(c, R, P + (size_t)n1 * R * HH, s0);
+    }
+    attn_context<T, SAFE, NW>(c, p, n0, s1, wgt, ctx);
+    if (has1) {
+      attn_load_slot<T, NW>(c, R, V + (size_t)n1 * R * HH, s1);
+      wgt = attn_scores<T, NW>(c, p, n1, s0, h1, alpha);
+      if (has2) {
+        attn_load_head<T>(c, att_h + (size_t)n2 * HH, h0);
+        attn_load_slot<T, NW>(c, R, P + (size_t)n2 * R * HH, s0);
+      }
+      attn_context<T, SAFE, NW>(c, p, n1, s1, wgt, ctx);
+    }
+    if (has2) {
+      attn_load_slot<T, NW>(c, R, V + (size_t)n2 * R * HH, s1);
+      wgt = attn_scores<T, NW>(c, p, n2, s0, h0, alpha);
+      attn_context<T, SAFE, NW>(c, p, n2, s1, wgt, ctx);
+    }
+  }
 }
 
 template <typename T, bool SAFE>
@@ -433,8 +514,7 @@ __device__ __forceinline__ void run_steps(const UicRnnFwdParams& p, Ctx& c) {
     if (!group_barrier(c)) return;
     if (dbg && c.tid == 0) dbg[4] = __builtin_amdgcn_s_memrealtime();
     T* ctx = (T*)p.ctx_all + (size_t)t * NH;
-    for (int rr = c.rank; rr < c.nrow; rr += PW)
-      attn_row<T, SAFE>(c, p, c.rbegin + rr, att_h, p.alpha_all + (size_t)t * N * p.R, ctx);
+    attn_phase<T, SAFE, NWAVE, 3>(c, p, att_h, p.alpha_all + (size_t)t * N * p.R, ctx);
     if (dbg && c.tid == 0) dbg[5] = __builtin_amdgcn_s_memrealtime();
     if (!group_barrier(c)) return;
     if (dbg && c.tid == 0) dbg[6] = __builtin_amdgcn_s_memrealtime();
@@ -456,11 +536,10 @@ __device__ __forceinline__ void run_steps(const UicRnnFwdParams& p, Ctx& c) {
   }
 }
 
-template <typename T>
-__global__ __launch_bounds__(NTH) void rnn_fwd_persist_kernel(const UicRnnFwdParams p) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
+// Registration + grouping shared by both kernels.  Returns 0 (leave), 1 (XCD-local protocol) or 2 (SAFE protocol).
+__device__ __forceinline__ int setup_ctx(const UicRnnFwdParams& p, char* scratch, Ctx& c) {
   unsigned* sy = p.sync;
-  int* info = (int*)smem;
+  int* info = (int*)scratch;
   const int tid = threadIdx.x;
   if (tid == 0) {
     // Registration: every workgroup reports the XCD it actually runs on (hardware register, not blockIdx) and takes a rank
@@ -491,30 +570,421 @@ __global__ __launch_bounds__(NTH) void rnn_fwd_persist_kernel(const UicRnnFwdPar
     info[3] = ok;
   }
   __syncthreads();
-  Ctx c;
   c.tid = tid; c.lane = tid & 63; c.wave = __builtin_amdgcn_readfirstlane(tid >> 6); c.l15 = c.lane & 15; c.lq = c.lane >> 4;
   c.group = __builtin_amdgcn_readfirstlane(info[0]);
   c.rank = __builtin_amdgcn_readfirstlane(info[1]);
   const int safe = __builtin_amdgcn_readfirstlane(info[2]);
   const int ok = __builtin_amdgcn_readfirstlane(info[3]);
   __syncthreads();
-  if (!ok) return;
+  if (!ok) return 0;
   const int G = gridDim.x / PW;
   const int Rg = (p.Nrows + G - 1) / G;
   c.u0 = c.rank * 16;
   c.rbegin = p.row0 + c.group * Rg;
   c.nrow = min(Rg, p.row0 + p.Nrows - c.rbegin);
-  if (c.nrow <= 0) return;
+  if (c.nrow <= 0) return 0;
   c.MT = (c.nrow + 15) >> 4;
   c.bar = sy + SY_BAR + 32 * c.group;
   c.err = sy + SY_ERR;
   c.status = p.status;
   c.bar_target = 0;
-  c.smem = smem;
+  c.smem = scratch;
   c.dbg = nullptr; c.exp = p.exp;
   if (tid == 0 && blockIdx.x == 0 && p.status) __hip_atomic_fetch_add(p.status + (safe ? 2 : 1), 1u, RLX_AGENT);   // launches per protocol
-  if (safe) run_steps<T, true>(p, c);
+  return safe ? 2 : 1;
+}
+
+template <typename T>
+__global__ __launch_bounds__(NTH) void rnn_fwd_persist_kernel(const UicRnnFwdParams p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  Ctx c;
+  const int mode = setup_ctx(p, smem, c);
+  if (mode == 0) return;
+  if (mode == 2) run_steps<T, true>(p, c);
   else run_steps<T, false>(p, c);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Weight-stationary bf16 variant.  A workgroup's slice of the recurrent weights is 336 KB in bf16 (64 gate columns of
+// att_lstm x K 1024, 64 of lang_lstm x K 1536, 16 columns of h2att x K 512): streamed from the Infinity Cache every step
+// it is 10.7 MB per XCD and step, as much as the activations.  Here the two LSTM slices are loaded ONCE per launch by a
+// workgroup of FOUR waves with the whole 512-entry register file of their SIMD each:
+//   * att_lstm's slice (128 KB) lives in LDS as MFMA B fragments [k-step][gate][lane][16 B]; wave w owns the 16-row tile w
+//     of the group and walks all 32 k-steps itself, so the four gate accumulators of a (row, unit) end up in one lane and
+//     the cell update needs no cross-wave reduction (the fifth tile of an 80-row group is split over the waves by K and
+//     summed through LDS);
+//   * lang_lstm's slice (192 KB) lives in REGISTERS, K split over the 4 waves (wave w holds k-steps w, w+4, ...: 48
+//     fragments = 192 registers, MFMA operands only); the partial tiles are summed through two 16 KB LDS buffers, one
+//     row tile per pass and one workgroup barrier per pass;
+//   * h2att's slice (16 KB) is re-read every step beside the activations (4 MB per step chip-wide).
+// The c state of both cells stays in the registers of the lanes that update it.
+#ifndef WS_P1_CHUNK
+#define WS_P1_CHUNK 8
+#endif
+#ifndef WS_P2_ALL
+#define WS_P2_ALL 0
+#endif
+#ifndef WS_ATT_SLOTS
+#define WS_ATT_SLOTS 2
+#endif
+#ifndef WS_P4_DEPTH
+#define WS_P4_DEPTH 2
+#endif
+constexpr int WS_NW = 4;
+constexpr int WS_NTH = WS_NW * 64;
+constexpr int WS_W1_BYTES = 32 * 4 * 1024;
+constexpr int WS_SCR_BYTES = 32 * 1024;
+constexpr int WS_LDS_BYTES = WS_W1_BYTES + WS_SCR_BYTES;
+
+__device__ __forceinline__ f32x4 mma_bf16(const u32x4& a, const u32x4& b, f32x4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
+
+// nn.LSTMCell's pointwise part for the 4 rows x 1 unit a lane holds in the D layout of four gate accumulators
+template <bool SAFE>
+__device__ __forceinline__ void ws_cell(const Ctx& c, int tile, const f32x4 (&s)[4], const float (&pv)[4][4], float (&cst)[4],
+                                        float* c_out, bf16_t* h_out, bf16_t* h_drop, bf16_t* gates_out, float drop_p,
+                                        unsigned seed, unsigned site) {
+  const unsigned u = (unsigned)(c.u0 + c.l15);
+  const float inv_keep = drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int rr = 16 * tile + 4 * c.lq + r;
+    const float gi = uic_sigmoid_t<bf16_t>(s[0][r] + pv[r][0]);
+    const float gf = uic_sigmoid_t<bf16_t>(s[1][r] + pv[r][1]);
+    const float gg = uic_tanh<bf16_t>(s[2][r] + pv[r][2]);
+    const float go = uic_sigmoid_t<bf16_t>(s[3][r] + pv[r][3]);
+    const float cn = gf * cst[r] + gi * gg;
+    const float h = go * uic_tanh<bf16_t>(cn);
+    cst[r] = cn;
+    if (rr < c.nrow) {
+      const unsigned nn = (unsigned)((c.rbegin + rr) * HH);
+      const unsigned o = nn + u;
+      c_out[o] = cn;
+      st_x<SAFE>(h_out + o, h);
+      if (h_drop) {
+        float hd = h;
+        if (drop_p > 0.f) hd *= uic_drop_scale(seed, site, o, drop_p, inv_keep);
+        h_drop[o] = (bf16_t)hd;
+      }
+      if (gates_out) {
+        const unsigned og = 4u * nn + u;
+        __builtin_nontemporal_store((bf16_t)gi, gates_out + og);
+        __builtin_nontemporal_store((bf16_t)gf, gates_out + og + HH);
+        __builtin_nontemporal_store((bf16_t)gg, gates_out + og + 2 * HH);
+        __builtin_nontemporal_store((bf16_t)go, gates_out + og + 3 * HH);
+      }
+    }
+  }
+}
+
+template <bool SAFE>
+__device__ __forceinline__ void ws_run(const UicRnnFwdParams& p, Ctx& c, char* lds) {
+  typedef bf16_t T;
+  const int N = p.N;
+  const size_t NH = (size_t)N * HH;
+  const size_t rb = (size_t)c.rbegin * HH;
+  const u32x4* w1 = (const u32x4*)lds;             // [k-step 32][gate 4][lane 64]
+  f32x4* scr = (f32x4*)c.smem;                     // 32 KB: two 16 KB halves
+  // ---- one-time weight load
+  u32x4 w2[12][4];                                 // k-step (wave + 4 j) of [att_res | h_att | h_lang_prev], gate g
+  {
+    const unsigned bl = (unsigned)(c.lq * 8);
+    const __amdgpu_buffer_rsrc_t r_ih = rsrc_of(p.lang_w_ih), r_hh = rsrc_of(p.lang_w_hh);
+#pragma unroll
+    for (int j = 0; j < 12; ++j) {
+      const int sg = j >> 2;                        // 0: att_res, 1: h_att, 2: h_lang_prev   (16 k-steps each)
+      const unsigned kk = (unsigned)(((j & 3) * 4 + c.wave) * 32);
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const unsigned row = (unsigned)(g * HH + c.u0 + c.l15);
+        w2[j][g] = sg < 2 ? bload<false>(r_ih, (row * (2u * HH) + (unsigned)(sg * HH) + kk + bl) * 2u, 0)
+                          : bload<false>(r_hh, (row * (unsigned)HH + kk + bl) * 2u, 0);
+      }
+    }
+    const __amdgpu_buffer_rsrc_t r_a_ih = rsrc_of(p.att_w_ih), r_a_hh = rsrc_of(p.att_w_hh);
+#pragma unroll
+    for (int jj = 0; jj < 8; ++jj) {
+      const int s = c.wave + 4 * jj;                // k-step of [h_lang_prev | h_att_prev]
+      const unsigned kk = (unsigned)((s & 15) * 32);
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const unsigned row = (unsigned)(g * HH + c.u0 + c.l15);
+        const u32x4 v = jj < 4 ? bload<false>(r_a_ih, (row * (unsigned)p.ld_att_ih + kk + bl) * 2u, 0)
+                               : bload<false>(r_a_hh, (row * (unsigned)HH + kk + bl) * 2u, 0);
+        ((u32x4*)lds)[(s * 4 + g) * 64 + c.lane] = v;
+      }
+    }
+  }
+  // lang_lstm's bias for the unit of this lane (tile owners: wave w owns row tile w, wave 0 also tile 4)
+  float pb[4][4];
+  {
+    const unsigned u = (unsigned)(c.u0 + c.l15);
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const float b = (p.lang_b_ih ? p.lang_b_ih[g * HH + u] : 0.f) + (p.lang_b_hh ? p.lang_b_hh[g * HH + u] : 0.f);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) pb[r][g] = b;
+    }
+  }
+  __syncthreads();                                  // the W1 image is complete
+  unsigned long long* dbg = p.dbg ? p.dbg + ((size_t)blockIdx.x * p.dbg_T + p.t0) * 16 : nullptr;
+  for (int t = p.t0; t < p.t1; ++t) {
+    asm volatile("" : "+v"(c.lane), "+v"(c.l15), "+v"(c.lq), "+v"(c.tid));
+    asm volatile("" : "+s"(c.wave), "+s"(c.u0), "+s"(c.rbegin), "+s"(c.nrow), "+s"(c.MT));
+    T* h_att_prev = (T*)p.h_att + (size_t)t * NH;
+    T* h_att_new = h_att_prev + NH;
+    T* h_lang_prev = (T*)p.h_lang + (size_t)t * NH;
+    T* h_lang_new = h_lang_prev + NH;
+    float* att_h = p.att_h_all + (size_t)t * NH;
+    T* ctx = (T*)p.ctx_all + (size_t)t * NH;
+    c.dbg = dbg;
+    if (dbg && c.tid == 0) dbg[0] = __builtin_amdgcn_s_memrealtime();
+    // ---- att_lstm (:431-434): wave w = row tile w (all 32 k-steps, B fragments from LDS); tile 4: k-steps w, w+4, ...
+    {
+      const __amdgpu_buffer_rsrc_t ra0 = rsrc_of(h_lang_prev + rb), ra1 = rsrc_of(h_att_prev + rb);
+      const float* gx = p.gx + (size_t)t * N * 4 * HH;
+      const unsigned u = (unsigned)(c.u0 + c.l15);
+      const float* c_prev = p.c_att + (size_t)t * NH;
+      auto load_pre = [&](int tile, float (&pv)[4][4], float (&cp)[4]) {
+        // the recurrence-independent share of the gate pre-activations (xt and fc' terms, both biases) and the cell state
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int rr = 16 * tile + 4 * c.lq + r;
+          const unsigned n4 = 4u * (unsigned)((c.rbegin + (rr < c.nrow ? rr : c.nrow - 1)) * HH);
+          cp[r] = c_prev[(n4 >> 2) + u];
+#pragma unroll
+          for (int g = 0; g < 4; ++g) pv[r][g] = gx[n4 + (unsigned)(g * HH) + u] + (p.gfc ? p.gfc[n4 + (unsigned)(g * HH) + u] : 0.f);
+        }
+      };
+      const bool split5 = c.MT > WS_NW;             // an 80-row group: a fifth tile, shared by the waves (then every wave has a tile of its own too)
+      if (c.wave < c.MT) {
+        const int i = c.wave;
+        int ar = 16 * i + c.l15;
+        ar = ar < c.nrow ? ar : c.nrow - 1;
+        const unsigned aoff = (unsigned)((ar * HH + c.lq * 8) * 2);
+        int ar5 = 16 * WS_NW + c.l15;
+        ar5 = ar5 < c.nrow ? ar5 : c.nrow - 1;
+        const unsigned aoff5 = (unsigned)((ar5 * HH + c.lq * 8) * 2);
+        // WS_P1_CHUNK k-steps per chunk, two chunks of the tile's activations in flight (32: the whole tile at once); the L2
+        // latency is paid once per chunk pair and the MFMAs run as the fragments arrive (loads return in order)
+        constexpr int CK = WS_P1_CHUNK, NCK = 32 / CK, NB = NCK > 1 ? 2 : 1;
+        u32x4 fa[NB][CK];
+#pragma unroll
+        for (int q = 0; q < CK; ++q) fa[0][q] = bload<true>(q < 16 ? ra0 : ra1, aoff, (unsigned)((q & 15) * 64));
+        float pv[4][4], cp[4];
+        if (NCK == 1) load_pre(i, pv, cp);
+        f32x4 acc[4];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) acc[g] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int cc = 0; cc < NCK; ++cc) {
+          if (cc + 1 < NCK) {
+#pragma unroll
+            for (int q = 0; q < CK; ++q) {
+              const int s = (cc + 1) * CK + q;
+              fa[(cc + 1) & 1][q] = bload<true>(s < 16 ? ra0 : ra1, aoff, (unsigned)((s & 15) * 64));
+            }
+            if (cc == 0) load_pre(i, pv, cp);
+          } else if (split5 && NCK > 1) {
+            // the buffer that has just been consumed takes this wave's share of tile 4: k-steps wave, wave + 4, ...
+#pragma unroll
+            for (int k = 0; k < 8; ++k) fa[(cc + 1) & 1][k] = bload<true>(k < 4 ? ra0 : ra1, aoff5, (unsigned)(((c.wave + 4 * k) & 15) * 64));
+          }
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int q = 0; q < CK; ++q) {
+            const int s = cc * CK + q;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) acc[g] = mma_bf16(fa[cc & 1][q], w1[(s * 4 + g) * 64 + c.lane], acc[g]);
+            if (NCK == 1 && q == 15 && split5) {
+              __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+              for (int k = 0; k < 8; ++k) fa[0][k] = bload<true>(k < 4 ? ra0 : ra1, aoff5, (unsigned)(((c.wave + 4 * k) & 15) * 64));
+              __builtin_amdgcn_sched_barrier(0);
+            }
+          }
+          __builtin_amdgcn_sched_barrier(0);
+        }
+        u32x4 (&f5)[CK] = fa[NCK > 1 ? (NCK & 1) : 0];
+        if (dbg && c.tid == 0) dbg[8] = __builtin_amdgcn_s_memrealtime();
+        ws_cell<SAFE>(c, i, acc, pv, cp, p.c_att + (size_t)(t + 1) * NH, h_att_new, (T*)nullptr,
+                      p.gates1 ? (T*)p.gates1 + (size_t)t * N * 4 * HH : nullptr, 0.f, 0u, 0u);
+        if (dbg && c.tid == 0) dbg[9] = __builtin_amdgcn_s_memrealtime();
+        if (split5) {
+          if (c.wave == 0) load_pre(WS_NW, pv, cp);
+#pragma unroll
+          for (int g = 0; g < 4; ++g) acc[g] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int q = 0; q < 8; ++q) {
+            const int s = c.wave + 4 * q;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) acc[g] = mma_bf16(f5[q], w1[(s * 4 + g) * 64 + c.lane], acc[g]);
+          }
+#pragma unroll
+          for (int g = 0; g < 4; ++g) scr[(c.wave * 4 + g) * 64 + c.lane] = acc[g];
+          __syncthreads();                          // (split5 => MT == 5 => all four waves are here)
+          if (c.wave == 0) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+              acc[g] = scr[g * 64 + c.lane];
+#pragma unroll
+              for (int w = 1; w < WS_NW; ++w) acc[g] += scr[(w * 4 + g) * 64 + c.lane];
+            }
+            ws_cell<SAFE>(c, WS_NW, acc, pv, cp, p.c_att + (size_t)(t + 1) * NH, h_att_new, (T*)nullptr,
+                          p.gates1 ? (T*)p.gates1 + (size_t)t * N * 4 * HH : nullptr, 0.f, 0u, 0u);
+          }
+        }
+      }
+    }
+    if (dbg && c.tid == 0) dbg[1] = __builtin_amdgcn_s_memrealtime();
+    if (!group_barrier(c)) return;
+    if (dbg && c.tid == 0) dbg[2] = __builtin_amdgcn_s_memrealtime();
+    asm volatile("" : "+v"(c.lane), "+v"(c.l15), "+v"(c.lq), "+v"(c.tid));   // keep this phase's lane-derived values out of the others' live ranges
+    // ---- h2att (:543): the waves split K, wave w (and wave 0 for tile 4) reduces its row tile
+    {
+      const __amdgpu_buffer_rsrc_t ra = rsrc_of(h_att_new + rb), r_h2 = rsrc_of(p.h2att_w);
+      constexpr int P2D = WS_P2_ALL ? MT_MAX : 2;   // row tiles of activations in flight
+      u32x4 wh[4], fa[P2D][4];
+      auto load_tile = [&](int buf, int i) {
+        int ar = 16 * i + c.l15;
+        ar = ar < c.nrow ? ar : c.nrow - 1;
+        const unsigned aoff = (unsigned)((ar * HH + c.lq * 8) * 2);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) fa[buf][j] = bload<true>(ra, aoff, (unsigned)((c.wave + 4 * j) * 64));
+      };
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        wh[j] = bload<false>(r_h2, (unsigned)(((c.u0 + c.l15) * HH + c.lq * 8) * 2), (unsigned)((c.wave + 4 * j) * 64));
+#pragma unroll
+      for (int i = 0; i < P2D - 1; ++i)
+        if (i < c.MT) load_tile(i, i);
+#pragma unroll
+      for (int i = 0; i < MT_MAX; ++i)
+        if (i < c.MT) {
+          if (i + P2D - 1 < MT_MAX && i + P2D - 1 < c.MT) load_tile((i + P2D - 1) % P2D, i + P2D - 1);
+          __builtin_amdgcn_sched_barrier(0);
+          f32x4 a = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int j = 0; j < 4; ++j) a = mma_bf16(fa[i % P2D][j], wh[j], a);
+          scr[(c.wave * MT_MAX + i) * 64 + c.lane] = a;
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      __syncthreads();
+      const int a = c.u0 + c.l15;
+      const float bias = p.h2att_b ? p.h2att_b[a] : 0.f;
+#pragma unroll
+      for (int k = 0; k < 2; ++k) {
+        const int i = c.wave + WS_NW * k;
+        if (i < c.MT && (k == 0 || c.wave == 0)) {
+          f32x4 sum = scr[(0 * MT_MAX + i) * 64 + c.lane];
+#pragma unroll
+          for (int w = 1; w < WS_NW; ++w) sum += scr[(w * MT_MAX + i) * 64 + c.lane];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int rr = 16 * i + 4 * c.lq + r;
+            if (rr < c.nrow) st_x<SAFE>(att_h + (unsigned)((c.rbegin + rr) * HH + a), sum[r] + bias);
+          }
+        }
+      }
+    }
+    if (dbg && c.tid == 0) dbg[3] = __builtin_amdgcn_s_memrealtime();
+    if (!group_barrier(c)) return;
+    if (dbg && c.tid == 0) dbg[4] = __builtin_amdgcn_s_memrealtime();
+    asm volatile("" : "+v"(c.lane), "+v"(c.l15), "+v"(c.lq), "+v"(c.tid));   // keep this phase's lane-derived values out of the others' live ranges
+    // ---- attention (:544-556)
+    attn_phase<T, SAFE, WS_NW, WS_ATT_SLOTS>(c, p, att_h, p.alpha_all + (size_t)t * N * p.R, ctx);
+    if (dbg && c.tid == 0) dbg[5] = __builtin_amdgcn_s_memrealtime();
+    if (!group_barrier(c)) return;
+    if (dbg && c.tid == 0) dbg[6] = __builtin_amdgcn_s_memrealtime();
+    asm volatile("" : "+v"(c.lane), "+v"(c.l15), "+v"(c.lq), "+v"(c.tid));   // keep this phase's lane-derived values out of the others' live ranges
+    // ---- lang_lstm (:438-441) + output dropout (:443): K split over the waves (stationary fragments in registers), one row
+    // tile per pass; pass i writes its partial tiles to LDS half i & 1, ONE barrier, then the tile's owner sums and finishes
+    // it while the other waves already multiply tile i + 1 (whose partials go to the other half)
+    {
+      const __amdgpu_buffer_rsrc_t rs0 = rsrc_of(ctx + rb), rs1 = rsrc_of(h_att_new + rb), rs2 = rsrc_of(h_lang_prev + rb);
+      float cl[2][4];                              // c_lang of the tiles this wave finishes (tile wave, and tile 4 on wave 0)
+      {
+        const float* c_prev = p.c_lang + (size_t)t * NH;
+        const unsigned u = (unsigned)(c.u0 + c.l15);
+#pragma unroll
+        for (int k = 0; k < 2; ++k)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int rr = 16 * (c.wave + WS_NW * k) + 4 * c.lq + r;
+            cl[k][r] = c_prev[(unsigned)((c.rbegin + (rr < c.nrow ? rr : c.nrow - 1)) * HH) + u];
+          }
+      }
+      // One register set of 12 activation fragments: fragment j of the NEXT row tile is requested right after the MFMAs that
+      // consumed fragment j of this one, so a whole pass (MFMAs, barrier, the owner's cell update) covers its latency.
+      u32x4 fa[12];
+      auto aoff_of = [&](int i) {
+        int ar = 16 * i + c.l15;
+        ar = ar < c.nrow ? ar : c.nrow - 1;
+        return (unsigned)((ar * HH + c.lq * 8) * 2);
+      };
+      auto load_frag = [&](int j, unsigned aoff) {
+        fa[j] = bload<true>((j >> 2) == 0 ? rs0 : (j >> 2) == 1 ? rs1 : rs2, aoff, (unsigned)(((j & 3) * 4 + c.wave) * 64));
+      };
+      {
+        const unsigned a0 = aoff_of(0);
+#pragma unroll
+        for (int j = 0; j < 12; ++j) load_frag(j, a0);
+      }
+#pragma unroll
+      for (int i = 0; i < MT_MAX; ++i) {
+        if (i < c.MT) {
+          const bool more = i + 1 < MT_MAX && i + 1 < c.MT;
+          const unsigned an = aoff_of(more ? i + 1 : i);
+          // The stationary B fragments are named as ACCUMULATOR-file operands ("a"), which is what keeps them there for the
+          // whole launch: left to itself hipcc parks them in AGPRs but copies each one back (4 x v_accvgpr_read) in front of
+          // every MFMA.  Inline-asm MFMAs get no hazard padding from the compiler: gate g's chain is re-entered only after
+          // the three other gates' MFMAs (the matrix pipe is in order), and the nops below cover MFMA result -> LDS store.
+          f32x4 acc[4];
+#pragma unroll
+          for (int j = 0; j < 12; ++j) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+              if (j == 0) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, 0" : "=&v"(acc[g]) : "v"(fa[0]), "a"(w2[0][g]));
+              else asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(acc[g]) : "v"(fa[j]), "a"(w2[j][g]));
+            }
+            if (more) load_frag(j, an);
+          }
+          asm volatile("s_nop 7\n\ts_nop 7" : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3]));
+          f32x4* half = scr + (i & 1) * (WS_NW * 4 * 64);
+#pragma unroll
+          for (int g = 0; g < 4; ++g) half[(c.wave * 4 + g) * 64 + c.lane] = acc[g];
+          __syncthreads();
+          if (dbg && c.tid == 0) dbg[11 + i] = __builtin_amdgcn_s_memrealtime();
+          if (c.wave == (i & 3)) {
+            // the owner adds the other waves' partial tiles to its own (fixed order: deterministic)
+#pragma unroll
+            for (int k = 1; k < WS_NW; ++k) {
+              const int w = (c.wave + k) & (WS_NW - 1);
+#pragma unroll
+              for (int g = 0; g < 4; ++g) acc[g] += half[(w * 4 + g) * 64 + c.lane];
+            }
+            ws_cell<SAFE>(c, i, acc, pb, cl[i >> 2], p.c_lang + (size_t)(t + 1) * NH, h_lang_new,
+                          p.hdrop_all ? (T*)p.hdrop_all + (size_t)t * NH : nullptr,
+                          p.gates2 ? (T*)p.gates2 + (size_t)t * N * 4 * HH : nullptr, p.drop_p, p.seed, UIC_SITE_OUT0 + (unsigned)t);
+          }
+        }
+      }
+      __syncthreads();                              // the scratch halves are free again (barrier flag, next step)
+    }
+    if (dbg && c.tid == 0) dbg[7] = __builtin_amdgcn_s_memrealtime();
+    if (!group_barrier(c)) return;
+    if (dbg) dbg += 16;
+  }
+}
+
+__global__ __launch_bounds__(WS_NTH) void rnn_fwd_persist_ws_kernel(const UicRnnFwdParams p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  Ctx c;
+  const int mode = setup_ctx(p, smem + WS_W1_BYTES, c);
+  if (mode == 0) return;
+  if (mode == 2) ws_run<true>(p, c, smem);
+  else ws_run<false>(p, c, smem);
 }
 
 unsigned* g_status[16] = {};   // caller-allocated sticky status words per device (uic_set_persistent_status)
@@ -551,7 +1021,7 @@ size_t uic_rnn_persist_sync_bytes() { return (size_t)MAX_SLABS * SY_WORDS * 4; }
 bool uic_rnn_persist_eligible(int dtype, int N, int H, int A, int R) {
   if (!uic_rnn_persist_mode()) return false;
   if (dtype != UIC_BF16 && dtype != UIC_F32) return false;
-  if (H != HH || A != HH || R < 1 || R > ATT_UB * NWAVE || N < 1 || N > MAX_SLABS * 8 * 16 * MT_MAX) return false;
+  if (H != HH || A != HH || R < 1 || R > ATT_R || N < 1 || N > MAX_SLABS * 8 * 16 * MT_MAX) return false;
   static int cus = -1;
   if (cus < 0) {
     int dev = 0;
@@ -568,6 +1038,7 @@ int uic_rnn_fwd_persist_launch(const UicRnnFwdParams& p0, hipStream_t s) {
   if (!configured) {
     UIC_TRY(uic_check_hip(hipFuncSetAttribute((const void*)rnn_fwd_persist_kernel<bf16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES), "hipFuncSetAttribute(rnn persist)"));
     UIC_TRY(uic_check_hip(hipFuncSetAttribute((const void*)rnn_fwd_persist_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES), "hipFuncSetAttribute(rnn persist)"));
+    UIC_TRY(uic_check_hip(hipFuncSetAttribute((const void*)rnn_fwd_persist_ws_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, WS_LDS_BYTES), "hipFuncSetAttribute(rnn persist ws)"));
     configured = true;
   }
   const int G = 8, cap = G * 16 * MT_MAX;     // caption rows one launch covers
@@ -583,7 +1054,9 @@ int uic_rnn_fwd_persist_launch(const UicRnnFwdParams& p0, hipStream_t s) {
     }
     p.sync = p0.sync + (size_t)(r0 / cap) * SY_WORDS;
     UIC_TRY(uic_check_hip(hipMemsetAsync(p.sync, 0, (size_t)SY_WORDS * 4, s), "hipMemsetAsync(rnn sync)"));
-    if (p.dtype == UIC_BF16) hipLaunchKernelGGL(rnn_fwd_persist_kernel<bf16_t>, dim3(G * PW), dim3(NTH), LDS_BYTES, s, p);
+    static const bool ws_on = !(getenv("UIC_PERSIST_WS") && atoi(getenv("UIC_PERSIST_WS")) == 0);
+    if (p.dtype == UIC_BF16 && ws_on) hipLaunchKernelGGL(rnn_fwd_persist_ws_kernel, dim3(G * PW), dim3(WS_NTH), WS_LDS_BYTES, s, p);
+    else if (p.dtype == UIC_BF16) hipLaunchKernelGGL(rnn_fwd_persist_kernel<bf16_t>, dim3(G * PW), dim3(NTH), LDS_BYTES, s, p);
     else hipLaunchKernelGGL(rnn_fwd_persist_kernel<float>, dim3(G * PW), dim3(NTH), LDS_BYTES, s, p);
     UIC_LAUNCH_CHECK("rnn_fwd_persist_kernel");
   }
