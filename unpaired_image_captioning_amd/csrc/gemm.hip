@@ -220,6 +220,16 @@ __global__ __launch_bounds__(64 * WM * WN * KS) void uic_gemm_kernel(const UicGe
     constexpr int R0 = decltype(r0c)::value;
     if constexpr (!LSTM) {
       const bool out_f32 = (p.flags & UIC_GEMM_OUT_F32) || sizeof(T) == 4;
+      int arow[TM][RPG];                 // addend row of every output row this lane holds (row % add_mod, once per row)
+      if (p.addend) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int q = 0; q < RPG; ++q) {
+            const int reg = R0 + q;
+            arow[i][q] = (m0 + (wm * TM + i) * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * half) % p.add_mod;
+          }
+      }
 #pragma unroll
       for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -234,6 +244,7 @@ __global__ __launch_bounds__(64 * WM * WN * KS) void uic_gemm_kernel(const UicGe
             const int row = m0 + (wm * TM + i) * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * half;
             if (row >= p.M) continue;
             float v = acc[i][j][reg] + b;
+            if (p.addend) v += p.addend[(size_t)arow[i][reg - R0] * p.ld_add + col];
             if (p.flags & UIC_GEMM_RELU) v = fmaxf(v, 0.f);
             if (p.flags & UIC_GEMM_TANH) v = uic_tanh<T>(v);
             if (p.row_len) {
@@ -510,6 +521,13 @@ __global__ __launch_bounds__(256) void uic_gemm_glds_kernel(const UicGemmParams 
 
   const float inv_keep = p.drop_p > 0.f ? 1.f / (1.f - p.drop_p) : 1.f;
   const bool out_f32 = (p.flags & UIC_GEMM_OUT_F32) || sizeof(T) == 4;
+  int arow[2][16];                       // addend row of every output row this lane holds (row % add_mod, once per row)
+  if (p.addend) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int reg = 0; reg < 16; ++reg) arow[i][reg] = (m0 + (wm * 2 + i) * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * half) % p.add_mod;
+  }
 #pragma unroll
   for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -524,6 +542,7 @@ __global__ __launch_bounds__(256) void uic_gemm_glds_kernel(const UicGemmParams 
         const int row = m0 + (wm * 2 + i) * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * half;
         if (row >= p.M) continue;
         float v = acc[i][j][reg] + b;
+        if (p.addend) v += p.addend[(size_t)arow[i][reg] * p.ld_add + col];
         if (p.flags & UIC_GEMM_RELU) v = fmaxf(v, 0.f);
         if (p.flags & UIC_GEMM_TANH) v = uic_tanh<T>(v);
         if (p.row_len) {

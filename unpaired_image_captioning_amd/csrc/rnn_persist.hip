@@ -115,7 +115,7 @@ __device__ __forceinline__ bool group_barrier(Ctx& c) {
     *flag = ok;
   }
   __syncthreads();
-  const int ok = *flag;
+  const int ok = __builtin_amdgcn_readfirstlane(*flag);
   __syncthreads();      // the flag word lives in the reduction buffer
   return ok != 0;
 }
@@ -305,14 +305,21 @@ template <typename T> struct AttnCfg {
 template <typename T, int NW> struct AttnSlot { uint4 v[ATT_R / NW][AttnCfg<T>::CH]; };
 template <typename T> struct AttnHead { u32x4 ah[AttnCfg<T>::CH][AttnCfg<T>::VEC / 4]; };
 
-template <typename T, int NW>
+// STREAM: the load is non-temporal (does not stay in the XCD's L2).  A workgroup re-reads the SAME rows of p_att and att'
+// every decode step: 5.9 MB per XCD and step against a 4 MB L2, so with one policy for both the L2 thrashes; streaming att'
+// lets the 2.95 MB of p_att rows stay resident.
+template <typename T, int NW, bool STREAM>
 __device__ __forceinline__ void attn_load_slot(const Ctx& c, int R, const T* base, AttnSlot<T, NW>& q) {
   constexpr int VEC = AttnCfg<T>::VEC, CH = AttnCfg<T>::CH;
 #pragma unroll
   for (int u = 0; u < ATT_R / NW; ++u) {
     const int r = min(c.wave + u * NW, R - 1);
 #pragma unroll
-    for (int k = 0; k < CH; ++k) q.v[u][k] = *(const uint4*)(base + (unsigned)(r * HH + (c.lane + 64 * k) * VEC));
+    for (int k = 0; k < CH; ++k) {
+      const u32x4* src = (const u32x4*)(base + (unsigned)(r * HH + (c.lane + 64 * k) * VEC));
+      const u32x4 v = (STREAM && !(c.exp & 512)) ? __builtin_nontemporal_load(src) : *src;
+      q.v[u][k] = make_uint4(v.x, v.y, v.z, v.w);
+    }
   }
 }
 template <typename T>
@@ -426,22 +433,22 @@ __device__ __forceinline__ void attn_phase(const Ctx& c, const UicRnnFwdParams& 
   if constexpr (SLOTS == 3) {
     AttnSlot<T, NW> s0, s1, s2;
     attn_load_head<T>(c, att_h + (size_t)n0 * HH, h0);
-    attn_load_slot<T, NW>(c, R, P + (size_t)n0 * R * HH, s0);
-    attn_load_slot<T, NW>(c, R, V + (size_t)n0 * R * HH, s1);
+    attn_load_slot<T, NW, false>(c, R, P + (size_t)n0 * R * HH, s0);
+    attn_load_slot<T, NW, true>(c, R, V + (size_t)n0 * R * HH, s1);
     if (has1) {
       attn_load_head<T>(c, att_h + (size_t)n1 * HH, h1);
-      attn_load_slot<T, NW>(c, R, P + (size_t)n1 * R * HH, s2);
+      attn_load_slot<T, NW, false>(c, R, P + (size_t)n1 * R * HH, s2);
     }
     float wgt = attn_scores<T, NW>(c, p, n0, s0, h0, alpha);
-    if (has1) attn_load_slot<T, NW>(c, R, V + (size_t)n1 * R * HH, s0);
+    if (has1) attn_load_slot<T, NW, true>(c, R, V + (size_t)n1 * R * HH, s0);
     attn_context<T, SAFE, NW>(c, p, n0, s1, wgt, ctx);
     if (has2) {
       attn_load_head<T>(c, att_h + (size_t)n2 * HH, h0);
-      attn_load_slot<T, NW>(c, R, P + (size_t)n2 * R * HH, s1);
+      attn_load_slot<T, NW, false>(c, R, P + (size_t)n2 * R * HH, s1);
     }
     if (has1) {
       wgt = attn_scores<T, NW>(c, p, n1, s2, h1, alpha);
-      if (has2) attn_load_slot<T, NW>(c, R, V + (size_t)n2 * R * HH, s2);
+      if (has2) attn_load_slot<T, NW, true>(c, R, V + (size_t)n2 * R * HH, s2);
       attn_context<T, SAFE, NW>(c, p, n1, s0, wgt, ctx);
     }
     if (has2) {
@@ -451,25 +458,25 @@ __device__ __forceinline__ void attn_phase(const Ctx& c, const UicRnnFwdParams& 
   } else {
     AttnSlot<T, NW> s0, s1;
     attn_load_head<T>(c, att_h + (size_t)n0 * HH, h0);
-    attn_load_slot<T, NW>(c, R, P + (size_t)n0 * R * HH, s0);
-    attn_load_slot<T, NW>(c, R, V + (size_t)n0 * R * HH, s1);
+    attn_load_slot<T, NW, false>(c, R, P + (size_t)n0 * R * HH, s0);
+    attn_load_slot<T, NW, true>(c, R, V + (size_t)n0 * R * HH, s1);
     float wgt = attn_scores<T, NW>(c, p, n0, s0, h0, alpha);
     if (has1) {
       attn_load_head<T>(c, att_h + (size_t)n1 * HH, h1);
-      attn_load_slot<T, NW>(c, R, P + (size_t)n1 * R * HH, s0);
+      attn_load_slot<T, NW, false>(c, R, P + (size_t)n1 * R * HH, s0);
     }
     attn_context<T, SAFE, NW>(c, p, n0, s1, wgt, ctx);
     if (has1) {
-      attn_load_slot<T, NW>(c, R, V + (size_t)n1 * R * HH, s1);
+      attn_load_slot<T, NW, true>(c, R, V + (size_t)n1 * R * HH, s1);
       wgt = attn_scores<T, NW>(c, p, n1, s0, h1, alpha);
       if (has2) {
         attn_load_head<T>(c, att_h + (size_t)n2 * HH, h0);
-        attn_load_slot<T, NW>(c, R, P + (size_t)n2 * R * HH, s0);
+        attn_load_slot<T, NW, false>(c, R, P + (size_t)n2 * R * HH, s0);
       }
       attn_context<T, SAFE, NW>(c, p, n1, s1, wgt, ctx);
     }
     if (has2) {
-      attn_load_slot<T, NW>(c, R, V + (size_t)n2 * R * HH, s1);
+      attn_load_slot<T, NW, true>(c, R, V + (size_t)n2 * R * HH, s1);
       wgt = attn_scores<T, NW>(c, p, n2, s0, h0, alpha);
       attn_context<T, SAFE, NW>(c, p, n2, s1, wgt, ctx);
     }
@@ -660,14 +667,14 @@ __device__ __forceinline__ void ws_cell(const Ctx& c, int tile, const f32x4 (&s)
     if (rr < c.nrow) {
       const unsigned nn = (unsigned)((c.rbegin + rr) * HH);
       const unsigned o = nn + u;
-      c_out[o] = cn;
+      if (!(c.exp & 8)) c_out[o] = cn;
       st_x<SAFE>(h_out + o, h);
-      if (h_drop) {
+      if (h_drop && !(c.exp & 8)) {
         float hd = h;
         if (drop_p > 0.f) hd *= uic_drop_scale(seed, site, o, drop_p, inv_keep);
         h_drop[o] = (bf16_t)hd;
       }
-      if (gates_out) {
+      if (gates_out && !(c.exp & 4)) {
         const unsigned og = 4u * nn + u;
         __builtin_nontemporal_store((bf16_t)gi, gates_out + og);
         __builtin_nontemporal_store((bf16_t)gf, gates_out + og + HH);
@@ -687,19 +694,30 @@ __device__ __forceinline__ void ws_run(const UicRnnFwdParams& p, Ctx& c, char* l
   const u32x4* w1 = (const u32x4*)lds;             // [k-step 32][gate 4][lane 64]
   f32x4* scr = (f32x4*)c.smem;                     // 32 KB: two 16 KB halves
   // ---- one-time weight load
-  u32x4 w2[12][4];                                 // k-step (wave + 4 j) of [att_res | h_att | h_lang_prev], gate g
+  // De-phasing: all 32 workgroups of a group read the SAME activation rows in every GEMM phase.  Walking them in the same
+  // order at the same time puts every request of the XCD on the same few L2 channels, so each workgroup starts its walk
+  // over K (and over the row tiles) at an offset of its own, `rank`; the stationary fragments are laid out to match.
+  const int j0 = __builtin_amdgcn_readfirstlane(c.rank % 12);
+  const int tr = __builtin_amdgcn_readfirstlane(c.rank % c.MT);   // the row tiles are walked starting at tile tr
+  u32x4 w2[12][4];                                 // slot j: k-step wave + 4 m, m = (j + j0) % 12, of [att_res | h_att | h_lang_prev]
   {
     const unsigned bl = (unsigned)(c.lq * 8);
-    const __amdgpu_buffer_rsrc_t r_ih = rsrc_of(p.lang_w_ih), r_hh = rsrc_of(p.lang_w_hh);
+    // (one descriptor for weight_ih and weight_hh of lang_lstm: which of them slot j reads is a select of a 32-bit offset)
+    const char* wlo = (const char*)p.lang_w_ih < (const char*)p.lang_w_hh ? (const char*)p.lang_w_ih : (const char*)p.lang_w_hh;
+    const __amdgpu_buffer_rsrc_t r_w = __builtin_amdgcn_make_buffer_rsrc((void*)wlo, 0, -1, 0x00020000);
+    const unsigned o_ih = (unsigned)((const char*)p.lang_w_ih - wlo), o_hh = (unsigned)((const char*)p.lang_w_hh - wlo);
 #pragma unroll
     for (int j = 0; j < 12; ++j) {
-      const int sg = j >> 2;                        // 0: att_res, 1: h_att, 2: h_lang_prev   (16 k-steps each)
-      const unsigned kk = (unsigned)(((j & 3) * 4 + c.wave) * 32);
+      int m = j + j0;
+      m = m >= 12 ? m - 12 : m;
+      const int sg = m >> 2;                        // 0: att_res, 1: h_att, 2: h_lang_prev   (16 k-steps each)
+      const unsigned kk = (unsigned)(((m & 3) * 4 + c.wave) * 32);
+      const unsigned ld = sg < 2 ? 2u * HH : (unsigned)HH;
+      const unsigned so = (sg < 2 ? o_ih + (unsigned)(sg * HH) * 2u : o_hh) + kk * 2u;
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
         const unsigned row = (unsigned)(g * HH + c.u0 + c.l15);
-        w2[j][g] = sg < 2 ? bload<false>(r_ih, (row * (2u * HH) + (unsigned)(sg * HH) + kk + bl) * 2u, 0)
-                          : bload<false>(r_hh, (row * (unsigned)HH + kk + bl) * 2u, 0);
+        w2[j][g] = bload<false>(r_w, (row * ld + bl) * 2u, so);
       }
     }
     const __amdgpu_buffer_rsrc_t r_a_ih = rsrc_of(p.att_w_ih), r_a_hh = rsrc_of(p.att_w_hh);
@@ -727,6 +745,32 @@ __device__ __forceinline__ void ws_run(const UicRnnFwdParams& p, Ctx& c, char* l
       for (int r = 0; r < 4; ++r) pb[r][g] = b;
     }
   }
+  // The recurrence-independent share of att_lstm's gate pre-activations (xt and fc' terms and both biases, one f32 tensor
+  // made by the batched input GEMM) and the cell state of step `ts`, for the 4 rows x 1 unit this lane finishes in row tile
+  // `tile`.  They come from HBM / the Infinity Cache.
+  auto load_pre = [&](int ts, int tile, float (&pv)[4][4], float (&cp)[4]) {
+    const float* gx = p.gx + (size_t)ts * N * 4 * HH;
+    const float* c_prev = p.c_att + (size_t)ts * NH;
+    const unsigned u = (unsigned)(c.u0 + c.l15);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int rr = 16 * tile + 4 * c.lq + r;
+      const unsigned n1 = (unsigned)((c.rbegin + (rr < c.nrow ? rr : c.nrow - 1)) * HH);
+      cp[r] = c_prev[n1 + u];
+#pragma unroll
+      for (int g = 0; g < 4; ++g) pv[r][g] = gx[4u * n1 + (unsigned)(g * HH) + u] + (p.gfc ? p.gfc[4u * n1 + (unsigned)(g * HH) + u] : 0.f);
+    }
+  };
+  // fifth tile: its cell update is shared by the four waves, wave w takes row 4 lq + w of every 4-row group
+  auto load_pre5 = [&](int ts, float (&pv)[4], float& cp) {
+    const float* gx = p.gx + (size_t)ts * N * 4 * HH;
+    const unsigned u = (unsigned)(c.u0 + c.l15);
+    const int rr = 16 * WS_NW + 4 * c.lq + c.wave;
+    const unsigned n1 = (unsigned)((c.rbegin + (rr < c.nrow ? rr : c.nrow - 1)) * HH);
+    cp = p.c_att[(size_t)ts * NH + n1 + u];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) pv[g] = gx[4u * n1 + (unsigned)(g * HH) + u] + (p.gfc ? p.gfc[4u * n1 + (unsigned)(g * HH) + u] : 0.f);
+  };
   __syncthreads();                                  // the W1 image is complete
   unsigned long long* dbg = p.dbg ? p.dbg + ((size_t)blockIdx.x * p.dbg_T + p.t0) * 16 : nullptr;
   for (int t = p.t0; t < p.t1; ++t) {
@@ -739,24 +783,20 @@ __device__ __forceinline__ void ws_run(const UicRnnFwdParams& p, Ctx& c, char* l
     float* att_h = p.att_h_all + (size_t)t * NH;
     T* ctx = (T*)p.ctx_all + (size_t)t * NH;
     c.dbg = dbg;
+    // every exchanged slab is addressed through ONE buffer descriptor (base = lowest of their addresses, from the host) plus
+    // a 32-bit byte offset: which slab a k-step comes from is then a scalar select of an offset, not of a pointer
+    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)p.xbase, 0, -1, 0x00020000);
+    const unsigned o_hlp = (unsigned)((const char*)(h_lang_prev + rb) - (const char*)p.xbase);
+    const unsigned o_hap = (unsigned)((const char*)(h_att_prev + rb) - (const char*)p.xbase);
+    const unsigned o_han = (unsigned)((const char*)(h_att_new + rb) - (const char*)p.xbase);
+    const unsigned o_ctx = (unsigned)((const char*)(ctx + rb) - (const char*)p.xbase);
     if (dbg && c.tid == 0) dbg[0] = __builtin_amdgcn_s_memrealtime();
     // ---- att_lstm (:431-434): wave w = row tile w (all 32 k-steps, B fragments from LDS); tile 4: k-steps w, w+4, ...
     {
-      const __amdgpu_buffer_rsrc_t ra0 = rsrc_of(h_lang_prev + rb), ra1 = rsrc_of(h_att_prev + rb);
-      const float* gx = p.gx + (size_t)t * N * 4 * HH;
-      const unsigned u = (unsigned)(c.u0 + c.l15);
-      const float* c_prev = p.c_att + (size_t)t * NH;
-      auto load_pre = [&](int tile, float (&pv)[4][4], float (&cp)[4]) {
-        // the recurrence-independent share of the gate pre-activations (xt and fc' terms, both biases) and the cell state
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int rr = 16 * tile + 4 * c.lq + r;
-          const unsigned n4 = 4u * (unsigned)((c.rbegin + (rr < c.nrow ? rr : c.nrow - 1)) * HH);
-          cp[r] = c_prev[(n4 >> 2) + u];
-#pragma unroll
-          for (int g = 0; g < 4; ++g) pv[r][g] = gx[n4 + (unsigned)(g * HH) + u] + (p.gfc ? p.gfc[n4 + (unsigned)(g * HH) + u] : 0.f);
-        }
-      };
+      // k-step s of [h_lang_prev | h_att_prev]: its slab and its byte offset inside a row
+      auto a_soff = [&](int s) { return ((s >> 4) ? o_hap : o_hlp) + (unsigned)((s & 15) * 64); };
+      const int s0 = c.rank;                        // this workgroup walks the 32 k-steps starting at s0
+      float pv5[4], cp5 = 0.f;
       const bool split5 = c.MT > WS_NW;             // an 80-row group: a fifth tile, shared by the waves (then every wave has a tile of its own too)
       if (c.wave < c.MT) {
         const int i = c.wave;
@@ -771,36 +811,53 @@ __device__ __forceinline__ void ws_run(const UicRnnFwdParams& p, Ctx& c, char* l
         constexpr int CK = WS_P1_CHUNK, NCK = 32 / CK, NB = NCK > 1 ? 2 : 1;
         u32x4 fa[NB][CK];
 #pragma unroll
-        for (int q = 0; q < CK; ++q) fa[0][q] = bload<true>(q < 16 ? ra0 : ra1, aoff, (unsigned)((q & 15) * 64));
-        float pv[4][4], cp[4];
-        if (NCK == 1) load_pre(i, pv, cp);
+        for (int q = 0; q < CK; ++q) {
+          const int sr = (q + s0) & 31;
+          fa[0][q] = bload<true>(rx, aoff, a_soff(sr));
+        }
+        float pvn[4][4], cpn[4];
+        if (NCK == 1) load_pre(t, i, pvn, cpn);
         f32x4 acc[4];
 #pragma unroll
         for (int g = 0; g < 4; ++g) acc[g] = f32x4{0.f, 0.f, 0.f, 0.f};
+        // B fragments of k-step q + 1 are read from LDS while the MFMAs of k-step q run (left alone hipcc emits
+        // read - wait - MFMA per fragment: an LDS round trip per MFMA, 7 us for the 128 of a tile)
+        u32x4 fb[2][4];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) fb[0][g] = w1[((s0 & 31) * 4 + g) * 64 + c.lane];
 #pragma unroll
         for (int cc = 0; cc < NCK; ++cc) {
           if (cc + 1 < NCK) {
 #pragma unroll
             for (int q = 0; q < CK; ++q) {
-              const int s = (cc + 1) * CK + q;
-              fa[(cc + 1) & 1][q] = bload<true>(s < 16 ? ra0 : ra1, aoff, (unsigned)((s & 15) * 64));
+              const int sr = ((cc + 1) * CK + q + s0) & 31;
+              if (!(c.exp & 256)) fa[(cc + 1) & 1][q] = bload<true>(rx, aoff, a_soff(sr));
             }
-            if (cc == 0) load_pre(i, pv, cp);
+            if (cc == 0) load_pre(t, i, pvn, cpn);
           } else if (split5 && NCK > 1) {
             // the buffer that has just been consumed takes this wave's share of tile 4: k-steps wave, wave + 4, ...
 #pragma unroll
-            for (int k = 0; k < 8; ++k) fa[(cc + 1) & 1][k] = bload<true>(k < 4 ? ra0 : ra1, aoff5, (unsigned)(((c.wave + 4 * k) & 15) * 64));
+            for (int k = 0; k < 8; ++k) {
+              const int sr = c.wave + 4 * ((k + s0) & 7);
+              fa[(cc + 1) & 1][k] = bload<true>(rx, aoff5, a_soff(sr));
+            }
           }
           __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
           for (int q = 0; q < CK; ++q) {
-            const int s = cc * CK + q;
+            const int qq = cc * CK + q;
+            const int sn = (qq + 1 + s0) & 31;      // (the last prefetch wraps to k-step s0 and is unused)
 #pragma unroll
-            for (int g = 0; g < 4; ++g) acc[g] = mma_bf16(fa[cc & 1][q], w1[(s * 4 + g) * 64 + c.lane], acc[g]);
+            for (int g = 0; g < 4; ++g) fb[(qq + 1) & 1][g] = (c.exp & 128) ? fb[qq & 1][g] : w1[(sn * 4 + g) * 64 + c.lane];
+#pragma unroll
+            for (int g = 0; g < 4; ++g) acc[g] = mma_bf16(fa[cc & 1][q], fb[qq & 1][g], acc[g]);
             if (NCK == 1 && q == 15 && split5) {
               __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-              for (int k = 0; k < 8; ++k) fa[0][k] = bload<true>(k < 4 ? ra0 : ra1, aoff5, (unsigned)(((c.wave + 4 * k) & 15) * 64));
+              for (int k = 0; k < 8; ++k) {
+                const int sr = c.wave + 4 * ((k + s0) & 7);
+                fa[0][k] = bload<true>(rx, aoff5, a_soff(sr));
+              }
               __builtin_amdgcn_sched_barrier(0);
             }
           }
@@ -808,31 +865,56 @@ __device__ __forceinline__ void ws_run(const UicRnnFwdParams& p, Ctx& c, char* l
         }
         u32x4 (&f5)[CK] = fa[NCK > 1 ? (NCK & 1) : 0];
         if (dbg && c.tid == 0) dbg[8] = __builtin_amdgcn_s_memrealtime();
-        ws_cell<SAFE>(c, i, acc, pv, cp, p.c_att + (size_t)(t + 1) * NH, h_att_new, (T*)nullptr,
+        ws_cell<SAFE>(c, i, acc, pvn, cpn, p.c_att + (size_t)(t + 1) * NH, h_att_new, (T*)nullptr,
                       p.gates1 ? (T*)p.gates1 + (size_t)t * N * 4 * HH : nullptr, 0.f, 0u, 0u);
         if (dbg && c.tid == 0) dbg[9] = __builtin_amdgcn_s_memrealtime();
         if (split5) {
-          if (c.wave == 0) load_pre(WS_NW, pv, cp);
 #pragma unroll
           for (int g = 0; g < 4; ++g) acc[g] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-          for (int q = 0; q < 8; ++q) {
-            const int s = c.wave + 4 * q;
+          for (int g = 0; g < 4; ++g) fb[0][g] = w1[((c.wave + 4 * (s0 & 7)) * 4 + g) * 64 + c.lane];
 #pragma unroll
-            for (int g = 0; g < 4; ++g) acc[g] = mma_bf16(f5[q], w1[(s * 4 + g) * 64 + c.lane], acc[g]);
+          for (int q = 0; q < 8; ++q) {
+            const int sn = c.wave + 4 * ((q + 1 + s0) & 7);
+#pragma unroll
+            for (int g = 0; g < 4; ++g) fb[(q + 1) & 1][g] = w1[(sn * 4 + g) * 64 + c.lane];
+#pragma unroll
+            for (int g = 0; g < 4; ++g) acc[g] = mma_bf16(f5[q], fb[q & 1][g], acc[g]);
           }
 #pragma unroll
           for (int g = 0; g < 4; ++g) scr[(c.wave * 4 + g) * 64 + c.lane] = acc[g];
+          load_pre5(t, pv5, cp5);
           __syncthreads();                          // (split5 => MT == 5 => all four waves are here)
-          if (c.wave == 0) {
+          {
+            float sg4[4];
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
-              acc[g] = scr[g * 64 + c.lane];
+              float v = 0.f;
 #pragma unroll
-              for (int w = 1; w < WS_NW; ++w) acc[g] += scr[(w * 4 + g) * 64 + c.lane];
+              for (int w = 0; w < WS_NW; ++w) v += ((const float*)(scr + (w * 4 + g) * 64 + c.lane))[c.wave];
+              sg4[g] = v;
             }
-            ws_cell<SAFE>(c, WS_NW, acc, pv, cp, p.c_att + (size_t)(t + 1) * NH, h_att_new, (T*)nullptr,
-                          p.gates1 ? (T*)p.gates1 + (size_t)t * N * 4 * HH : nullptr, 0.f, 0u, 0u);
+            const int rr = 16 * WS_NW + 4 * c.lq + c.wave;
+            const unsigned u = (unsigned)(c.u0 + c.l15);
+            const float gi = uic_sigmoid_t<bf16_t>(sg4[0] + pv5[0]);
+            const float gf = uic_sigmoid_t<bf16_t>(sg4[1] + pv5[1]);
+            const float gg = uic_tanh<bf16_t>(sg4[2] + pv5[2]);
+            const float go = uic_sigmoid_t<bf16_t>(sg4[3] + pv5[3]);
+            const float cn = gf * cp5 + gi * gg;
+            const float h = go * uic_tanh<bf16_t>(cn);
+            if (rr < c.nrow) {
+              const unsigned nn = (unsigned)((c.rbegin + rr) * HH);
+              const unsigned o = nn + u;
+              p.c_att[(size_t)(t + 1) * NH + o] = cn;
+              st_x<SAFE>(h_att_new + o, h);
+              if (p.gates1) {
+                T* G = (T*)p.gates1 + (size_t)t * N * 4 * HH + 4u * nn + u;
+                __builtin_nontemporal_store((bf16_t)gi, G);
+                __builtin_nontemporal_store((bf16_t)gf, G + HH);
+                __builtin_nontemporal_store((bf16_t)gg, G + 2 * HH);
+                __builtin_nontemporal_store((bf16_t)go, G + 3 * HH);
+              }
+            }
           }
         }
       }
@@ -843,19 +925,20 @@ __device__ __forceinline__ void ws_run(const UicRnnFwdParams& p, Ctx& c, char* l
     asm volatile("" : "+v"(c.lane), "+v"(c.l15), "+v"(c.lq), "+v"(c.tid));   // keep this phase's lane-derived values out of the others' live ranges
     // ---- h2att (:543): the waves split K, wave w (and wave 0 for tile 4) reduces its row tile
     {
-      const __amdgpu_buffer_rsrc_t ra = rsrc_of(h_att_new + rb), r_h2 = rsrc_of(p.h2att_w);
+      const __amdgpu_buffer_rsrc_t r_h2 = rsrc_of(p.h2att_w);
       constexpr int P2D = WS_P2_ALL ? MT_MAX : 2;   // row tiles of activations in flight
       u32x4 wh[4], fa[P2D][4];
+      auto tile_of = [&](int i) { const int x = i + tr; return x >= c.MT ? x - c.MT : x; };
       auto load_tile = [&](int buf, int i) {
-        int ar = 16 * i + c.l15;
+        int ar = 16 * tile_of(i) + c.l15;
         ar = ar < c.nrow ? ar : c.nrow - 1;
         const unsigned aoff = (unsigned)((ar * HH + c.lq * 8) * 2);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) fa[buf][j] = bload<true>(ra, aoff, (unsigned)((c.wave + 4 * j) * 64));
+        for (int j = 0; j < 4; ++j) fa[buf][j] = bload<true>(rx, aoff, o_han + (unsigned)((c.wave + 4 * ((j + c.rank) & 3)) * 64));
       };
 #pragma unroll
       for (int j = 0; j < 4; ++j)
-        wh[j] = bload<false>(r_h2, (unsigned)(((c.u0 + c.l15) * HH + c.lq * 8) * 2), (unsigned)((c.wave + 4 * j) * 64));
+        wh[j] = bload<false>(r_h2, (unsigned)(((c.u0 + c.l15) * HH + c.lq * 8) * 2), (unsigned)((c.wave + 4 * ((j + c.rank) & 3)) * 64));
 #pragma unroll
       for (int i = 0; i < P2D - 1; ++i)
         if (i < c.MT) load_tile(i, i);
@@ -867,7 +950,7 @@ __device__ __forceinline__ void ws_run(const UicRnnFwdParams& p, Ctx& c, char* l
           f32x4 a = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
           for (int j = 0; j < 4; ++j) a = mma_bf16(fa[i % P2D][j], wh[j], a);
-          scr[(c.wave * MT_MAX + i) * 64 + c.lane] = a;
+          scr[(c.wave * MT_MAX + tile_of(i)) * 64 + c.lane] = a;
           __builtin_amdgcn_sched_barrier(0);
         }
       __syncthreads();
@@ -897,23 +980,38 @@ __device__ __forceinline__ void ws_run(const UicRnnFwdParams& p, Ctx& c, char* l
     if (dbg && c.tid == 0) dbg[5] = __builtin_amdgcn_s_memrealtime();
     if (!group_barrier(c)) return;
     if (dbg && c.tid == 0) dbg[6] = __builtin_amdgcn_s_memrealtime();
+    if (dbg && (c.exp & 64) && c.wave == 0) {
+      // latency probe: one sc1 load of fresh exchanged data (ctx of another workgroup's row), then one of a second line,
+      // then a plain load of a third line
+      const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+      u32x4 v = bload<true>(rx, (unsigned)(c.lane * 16), o_ctx + 0u);
+      asm volatile("s_waitcnt vmcnt(0)" : "+v"(v));
+      const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+      u32x4 v2 = bload<true>(rx, (unsigned)(c.lane * 16), o_ctx + 1024u * 7);
+      asm volatile("s_waitcnt vmcnt(0)" : "+v"(v2));
+      const unsigned long long t2 = __builtin_amdgcn_s_memtime();
+      u32x4 v3 = bload<false>(rx, (unsigned)(c.lane * 16), o_ctx + 1024u * 13);
+      asm volatile("s_waitcnt vmcnt(0)" : "+v"(v3));
+      const unsigned long long t3 = __builtin_amdgcn_s_memtime();
+      if (c.tid == 0) { dbg[8] = t1 - t0; dbg[9] = t2 - t1; dbg[10] = t3 - t2 + ((v.x ^ v2.x ^ v3.x) == 0x12345 ? 1 : 0); }
+    }
     asm volatile("" : "+v"(c.lane), "+v"(c.l15), "+v"(c.lq), "+v"(c.tid));   // keep this phase's lane-derived values out of the others' live ranges
     // ---- lang_lstm (:438-441) + output dropout (:443): K split over the waves (stationary fragments in registers), one row
     // tile per pass; pass i writes its partial tiles to LDS half i & 1, ONE barrier, then the tile's owner sums and finishes
     // it while the other waves already multiply tile i + 1 (whose partials go to the other half)
     {
-      const __amdgpu_buffer_rsrc_t rs0 = rsrc_of(ctx + rb), rs1 = rsrc_of(h_att_new + rb), rs2 = rsrc_of(h_lang_prev + rb);
-      float cl[2][4];                              // c_lang of the tiles this wave finishes (tile wave, and tile 4 on wave 0)
+      auto tile_of = [&](int i) { const int x = i + tr; return x >= c.MT ? x - c.MT : x; };
+      // The cell update of a tile is shared by the four waves: wave w takes accumulator component w, i.e. row 4 lq + w of
+      // every 4-row group, so a pass costs a quarter of the transcendental work on its critical path.
+      float cl[MT_MAX];                            // c_lang of (tile i, row 4 lq + wave, unit u0 + l15)
       {
         const float* c_prev = p.c_lang + (size_t)t * NH;
         const unsigned u = (unsigned)(c.u0 + c.l15);
 #pragma unroll
-        for (int k = 0; k < 2; ++k)
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const int rr = 16 * (c.wave + WS_NW * k) + 4 * c.lq + r;
-            cl[k][r] = c_prev[(unsigned)((c.rbegin + (rr < c.nrow ? rr : c.nrow - 1)) * HH) + u];
-          }
+        for (int i = 0; i < MT_MAX; ++i) {
+          const int rr = 16 * i + 4 * c.lq + c.wave;
+          cl[i] = c_prev[(unsigned)((c.rbegin + (rr < c.nrow ? rr : c.nrow - 1)) * HH) + u];
+        }
       }
       // One register set of 12 activation fragments: fragment j of the NEXT row tile is requested right after the MFMAs that
       // consumed fragment j of this one, so a whole pass (MFMAs, barrier, the owner's cell update) covers its latency.
@@ -924,10 +1022,15 @@ __device__ __forceinline__ void ws_run(const UicRnnFwdParams& p, Ctx& c, char* l
         return (unsigned)((ar * HH + c.lq * 8) * 2);
       };
       auto load_frag = [&](int j, unsigned aoff) {
-        fa[j] = bload<true>((j >> 2) == 0 ? rs0 : (j >> 2) == 1 ? rs1 : rs2, aoff, (unsigned)(((j & 3) * 4 + c.wave) * 64));
+        int m = j + j0;
+        m = m >= 12 ? m - 12 : m;
+        // (two independent selects: a three-way select chain becomes a table in private memory, and with it everything
+        // this lambda captures)
+        const unsigned so = o_ctx + (m >= 4 ? o_han - o_ctx : 0u) + (m >= 8 ? o_hlp - o_han : 0u);
+        fa[j] = bload<true>(rx, aoff, so + (unsigned)(((m & 3) * 4 + c.wave) * 64));
       };
       {
-        const unsigned a0 = aoff_of(0);
+        const unsigned a0 = aoff_of(tile_of(0));
 #pragma unroll
         for (int j = 0; j < 12; ++j) load_frag(j, a0);
       }
@@ -935,11 +1038,14 @@ __device__ __forceinline__ void ws_run(const UicRnnFwdParams& p, Ctx& c, char* l
       for (int i = 0; i < MT_MAX; ++i) {
         if (i < c.MT) {
           const bool more = i + 1 < MT_MAX && i + 1 < c.MT;
-          const unsigned an = aoff_of(more ? i + 1 : i);
+          const int tile = tile_of(i);
+          const unsigned an = aoff_of(tile_of(more ? i + 1 : i));
           // The stationary B fragments are named as ACCUMULATOR-file operands ("a"), which is what keeps them there for the
           // whole launch: left to itself hipcc parks them in AGPRs but copies each one back (4 x v_accvgpr_read) in front of
           // every MFMA.  Inline-asm MFMAs get no hazard padding from the compiler: gate g's chain is re-entered only after
           // the three other gates' MFMAs (the matrix pipe is in order), and the nops below cover MFMA result -> LDS store.
+          const bool prof = dbg && c.tid == 0 && i == 1 && (c.exp & 32);
+          if (prof) { dbg[8] = __builtin_amdgcn_s_memtime(); dbg[13] = __builtin_amdgcn_s_memrealtime(); }
           f32x4 acc[4];
 #pragma unroll
           for (int j = 0; j < 12; ++j) {
@@ -948,26 +1054,58 @@ __device__ __forceinline__ void ws_run(const UicRnnFwdParams& p, Ctx& c, char* l
               if (j == 0) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, 0" : "=&v"(acc[g]) : "v"(fa[0]), "a"(w2[0][g]));
               else asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(acc[g]) : "v"(fa[j]), "a"(w2[j][g]));
             }
-            if (more) load_frag(j, an);
+            if (more && !(c.exp & 16)) load_frag(j, an);
           }
           asm volatile("s_nop 7\n\ts_nop 7" : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3]));
+          if (prof) dbg[9] = __builtin_amdgcn_s_memtime();
           f32x4* half = scr + (i & 1) * (WS_NW * 4 * 64);
 #pragma unroll
           for (int g = 0; g < 4; ++g) half[(c.wave * 4 + g) * 64 + c.lane] = acc[g];
+          if (prof) dbg[10] = __builtin_amdgcn_s_memtime();
           __syncthreads();
-          if (dbg && c.tid == 0) dbg[11 + i] = __builtin_amdgcn_s_memrealtime();
-          if (c.wave == (i & 3)) {
-            // the owner adds the other waves' partial tiles to its own (fixed order: deterministic)
+          if (prof) dbg[11] = __builtin_amdgcn_s_memtime();
+          if (dbg && c.tid == 0 && !(c.exp & 32)) dbg[11 + i] = __builtin_amdgcn_s_memrealtime();
+          {
+            // every wave sums component `wave` of the four partial tiles (fixed order: deterministic) and finishes that row
+            float sg4[4];
 #pragma unroll
-            for (int k = 1; k < WS_NW; ++k) {
-              const int w = (c.wave + k) & (WS_NW - 1);
+            for (int g = 0; g < 4; ++g) {
+              float v = 0.f;
 #pragma unroll
-              for (int g = 0; g < 4; ++g) acc[g] += half[(w * 4 + g) * 64 + c.lane];
+              for (int w = 0; w < WS_NW; ++w) v += ((const float*)(half + (w * 4 + g) * 64 + c.lane))[c.wave];
+              sg4[g] = v;
             }
-            ws_cell<SAFE>(c, i, acc, pb, cl[i >> 2], p.c_lang + (size_t)(t + 1) * NH, h_lang_new,
-                          p.hdrop_all ? (T*)p.hdrop_all + (size_t)t * NH : nullptr,
-                          p.gates2 ? (T*)p.gates2 + (size_t)t * N * 4 * HH : nullptr, p.drop_p, p.seed, UIC_SITE_OUT0 + (unsigned)t);
+            float cst = cl[0];
+#pragma unroll
+            for (int k = 1; k < MT_MAX; ++k) cst = tile == k ? cl[k] : cst;
+            const int rr = 16 * tile + 4 * c.lq + c.wave;
+            const unsigned u = (unsigned)(c.u0 + c.l15);
+            const float gi = uic_sigmoid_t<bf16_t>(sg4[0] + pb[0][0]);
+            const float gf = uic_sigmoid_t<bf16_t>(sg4[1] + pb[0][1]);
+            const float gg = uic_tanh<bf16_t>(sg4[2] + pb[0][2]);
+            const float go = uic_sigmoid_t<bf16_t>(sg4[3] + pb[0][3]);
+            const float cn = gf * cst + gi * gg;
+            const float h = go * uic_tanh<bf16_t>(cn);
+            if (rr < c.nrow) {
+              const unsigned nn = (unsigned)((c.rbegin + rr) * HH);
+              const unsigned o = nn + u;
+              if (!(c.exp & 8)) p.c_lang[(size_t)(t + 1) * NH + o] = cn;
+              st_x<SAFE>(h_lang_new + o, h);
+              if (p.hdrop_all && !(c.exp & 8)) {
+                float hd = h;
+                if (p.drop_p > 0.f) hd *= uic_drop_scale(p.seed, UIC_SITE_OUT0 + (unsigned)t, o, p.drop_p, 1.f / (1.f - p.drop_p));
+                ((T*)p.hdrop_all)[(size_t)t * NH + o] = (bf16_t)hd;
+              }
+              if (p.gates2 && !(c.exp & 4)) {
+                T* G = (T*)p.gates2 + (size_t)t * N * 4 * HH + 4u * nn + u;
+                __builtin_nontemporal_store((bf16_t)gi, G);
+                __builtin_nontemporal_store((bf16_t)gf, G + HH);
+                __builtin_nontemporal_store((bf16_t)gg, G + 2 * HH);
+                __builtin_nontemporal_store((bf16_t)go, G + 3 * HH);
+              }
+            }
           }
+          if (prof) { dbg[12] = __builtin_amdgcn_s_memtime(); dbg[14] = __builtin_amdgcn_s_memrealtime(); }
         }
       }
       __syncthreads();                              // the scratch halves are free again (barrier flag, next step)
@@ -988,12 +1126,12 @@ __global__ __launch_bounds__(WS_NTH) void rnn_fwd_persist_ws_kernel(const UicRnn
 }
 
 unsigned* g_status[16] = {};   // caller-allocated sticky status words per device (uic_set_persistent_status)
-int g_persist_mode = -1;     // -1: read UIC_PERSIST (default on), 0: off, 1: on, 2: on + force the SAFE protocol
+int g_persist_mode = -1;     // -1: read UIC_PERSIST (default 1); see uic_set_persistent_rnn in include/uic_hip.h
 
 }  // namespace
 
 extern "C" int uic_set_persistent_rnn(int32_t mode) {
-  UIC_REQUIRE(mode >= 0 && mode <= 2, "set_persistent_rnn: mode=%d must be 0 (off), 1 (on) or 2 (on, SAFE protocol)", mode);
+  UIC_REQUIRE(mode >= 0 && mode <= 3, "set_persistent_rnn: mode=%d must be 0 (off), 1 (forward calls), 2 (forward calls, SAFE protocol) or 3 (also the fused training step)", mode);
   g_persist_mode = mode;
   return UIC_OK;
 }
@@ -1010,7 +1148,7 @@ int uic_rnn_persist_mode() {
   if (g_persist_mode < 0) {
     const char* e = getenv("UIC_PERSIST");
     g_persist_mode = e ? atoi(e) : 1;
-    if (g_persist_mode < 0 || g_persist_mode > 2) g_persist_mode = 1;
+    if (g_persist_mode < 0 || g_persist_mode > 3) g_persist_mode = 1;
   }
   return g_persist_mode;
 }
@@ -1047,6 +1185,15 @@ int uic_rnn_fwd_persist_launch(const UicRnnFwdParams& p0, hipStream_t s) {
     p.row0 = r0;
     p.Nrows = p0.N - r0 < cap ? p0.N - r0 : cap;
     p.force_safe = uic_rnn_persist_mode() == 2;
+    {
+      const char* lo = (const char*)p.h_att;
+      if ((const char*)p.h_lang < lo) lo = (const char*)p.h_lang;
+      if ((const char*)p.ctx_all < lo) lo = (const char*)p.ctx_all;
+      const char* ends[3] = {(const char*)p.h_att, (const char*)p.h_lang, (const char*)p.ctx_all};
+      for (int k = 0; k < 3; ++k)
+        UIC_REQUIRE((size_t)(ends[k] - lo) + (size_t)(p.t1 + 1) * p.N * HH * 4 < ((size_t)1 << 32), "rnn_fwd_persist: the state slabs must lie within 4 GB of each other");
+      p.xbase = lo;
+    }
     {
       int dev = 0;
       UIC_TRY(uic_check_hip(hipGetDevice(&dev), "hipGetDevice"));

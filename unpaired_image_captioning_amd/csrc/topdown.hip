@@ -570,16 +570,17 @@ struct Step {
     UIC_TRY(prepare_features(d, w, dv, b, L, training, drop_p, seed, &f, &a, s));
     // xt_t = dropout(relu(embed[labels[:, t]])) for all steps (AttModel.py:145,160)
     UIC_TRY(uic_embed_fwd_launch(dt, w->embed_w, V1, E, b->labels, b->ld_labels, N, t_run, drop_p, seed, UIC_SITE_EMBED, 0, 1, L.xt_all, s));
-    {  // Gx = xt W_ih[:, 2H:]^T + b_ih + b_hh, all steps
-      UicGemmParams g = gemm_base(dt, Meff, H4);
-      add_seg(g, L.xt_all, E, off(dv.att_w_ih, 2 * H, dt), ldih, E);
-      g.C = L.gx; g.ldc = H4; g.bias = w->att_lstm_b_ih; g.bias2 = w->att_lstm_b_hh; g.flags = UIC_GEMM_OUT_F32;
-      UIC_TRY(uic_gemm_launch(g, s));
-    }
     {  // Gfc = fc' W_ih[:, H:2H]^T
       UicGemmParams g = gemm_base(dt, N, H4);
       add_seg(g, L.fcp, H, off(dv.att_w_ih, H, dt), ldih, H);
       g.C = L.gfc; g.ldc = H4; g.flags = UIC_GEMM_OUT_F32;
+      UIC_TRY(uic_gemm_launch(g, s));
+    }
+    {  // Gx = xt W_ih[:, 2H:]^T + b_ih + b_hh + Gfc (every step's rows get their caption row's fc' term), all steps
+      UicGemmParams g = gemm_base(dt, Meff, H4);
+      add_seg(g, L.xt_all, E, off(dv.att_w_ih, 2 * H, dt), ldih, E);
+      g.C = L.gx; g.ldc = H4; g.bias = w->att_lstm_b_ih; g.bias2 = w->att_lstm_b_hh; g.flags = UIC_GEMM_OUT_F32;
+      g.addend = L.gfc; g.add_mod = N; g.ld_add = H4;
       UIC_TRY(uic_gemm_launch(g, s));
     }
     if (ss_on()) UIC_TRY(uic_copy_tokens_launch(b->labels, b->ld_labels, N, t_run, L.tok_used, d.T, s));
@@ -598,6 +599,7 @@ struct Step {
       UicGemmParams g = gemm_base(dt, N, H4);
       add_seg(g, off(L.xt_all, (size_t)t * N * E, dt), E, off(dv.att_w_ih, 2 * H, dt), ldih, E);
       g.C = L.gx + (size_t)t * N * H4; g.ldc = H4; g.bias = w->att_lstm_b_ih; g.bias2 = w->att_lstm_b_hh; g.flags = UIC_GEMM_OUT_F32;
+      g.addend = L.gfc; g.add_mod = N; g.ld_add = H4;
       UIC_TRY(uic_gemm_launch(g, s));
     }
     const void* h_att_prev = off(L.h_att, t * NH, dt);
@@ -609,8 +611,7 @@ struct Step {
       g.lstm = 1; g.H = H;
       add_seg(g, h_lang_prev, H, dv.att_w_ih, ldih, H);
       add_seg(g, h_att_prev, H, dv.att_w_hh, H, H);
-      g.pre1 = L.gx + (size_t)t * N * H4; g.ldpre1 = H4;
-      g.pre2 = L.gfc; g.ldpre2 = H4;
+      g.pre1 = L.gx + (size_t)t * N * H4; g.ldpre1 = H4;     // (Gfc is already folded into Gx)
       g.c_prev = L.c_att + t * NH; g.c_out = L.c_att + (t + 1) * NH;
       g.h_out = h_att_new; g.ldh = H;
       g.gates_out = offw(L.gates1, (size_t)t * N * H4, dt);
@@ -638,16 +639,22 @@ struct Step {
 
   // decode steps [t0, t1) of the recurrence: one persistent launch (rnn_persist.hip) when the shapes allow, else the
   // per-step chain.  Scheduled sampling needs the logits of step t - 1 on the host-sequenced path.
-  bool persist_ok() const { return !ss_on() && uic_rnn_persist_eligible(dt, N, H, A, R); }
-  int fwd_steps(int t0, int t1, hipStream_t s) {
-    if (!persist_ok()) {
+  // `fused`: called from the two-stream training step.  There the per-step launches win: the persistent kernel holds
+  // every CU (160 KB of LDS, the whole register file), so the logit layer on the side stream can no longer run beside the
+  // recurrence, and what the recurrence saves (1.02 -> 0.83 ms) is less than the overlap that is lost (measured 4.25 vs
+  // 4.49 ms per step).  Mode 3 forces it there for experiments.
+  bool persist_ok(bool fused) const {
+    return !ss_on() && uic_rnn_persist_eligible(dt, N, H, A, R) && (!fused || uic_rnn_persist_mode() == 3);
+  }
+  int fwd_steps(int t0, int t1, hipStream_t s, bool fused = false) {
+    if (!persist_ok(fused)) {
       for (int t = t0; t < t1; ++t) UIC_TRY(fwd_step(t, s));
       return UIC_OK;
     }
     UicRnnFwdParams p;
     memset(&p, 0, sizeof(p));
     p.dtype = dt; p.N = N; p.R = R; p.t0 = t0; p.t1 = t1;
-    p.gx = L.gx; p.gfc = L.gfc;
+    p.gx = L.gx; p.gfc = nullptr;     // (Gfc is already folded into Gx)
     p.att_w_ih = dv.att_w_ih; p.ld_att_ih = ldih; p.att_w_hh = dv.att_w_hh;
     p.lang_w_ih = dv.lang_w_ih; p.lang_w_hh = dv.lang_w_hh;
     p.lang_b_ih = w->lang_lstm_b_ih; p.lang_b_hh = w->lang_lstm_b_hh;
@@ -1115,7 +1122,7 @@ int uic_topdown_xe_train_step(const uic_topdown_dims* d, const uic_topdown_weigh
   UIC_TRY(wait_refresh(s));                           // the recurrence needs the side-stream half of the weight refresh
   for (int c = 0; c < nchunk; ++c) {
     const int t0 = c * CH, t1 = t0 + CH < t_run ? t0 + CH : t_run;
-    UIC_TRY(st.fwd_steps(t0, t1, s));
+    UIC_TRY(st.fwd_steps(t0, t1, s, true));
     UIC_HIP(hipEventRecord(ss->ev_main[c], s));
     // side: logit layer of the chunk, forward and backward-to-h (beside the next chunk's recurrence)
     UIC_HIP(hipStreamWaitEvent(s2, ss->ev_main[c], 0));

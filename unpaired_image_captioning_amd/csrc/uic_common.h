@@ -161,6 +161,7 @@ struct UicGemmParams {
   void* C; int ldc;
   const float* bias;        // [N] or null
   const float* bias2;       // [N] or null
+  const float* addend; int add_mod, ld_add;   // optional f32 [add_mod, ld_add]: C[row, col] += addend[row % add_mod, col] (before ReLU etc.)
   int flags;
   // pack_wrapper semantics (AttModel.py:44-53): row m = n*R + r is live iff r < row_len[n]
   const int* row_len; int R;
@@ -263,11 +264,12 @@ struct UicRnnFwdParams {
   void* gates1; void* gates2;                    // [T, N, 4H] activated gates for the backward pass, or null
   float* att_h_all; float* alpha_all; void* ctx_all; void* hdrop_all;   // [T, N, .]
   float drop_p; unsigned seed;
+  const void* xbase;                 // filled by the launcher: lowest address of h_att / h_lang / ctx_all (one buffer descriptor)
   unsigned* sync;                    // uic_rnn_persist_sync_bytes() bytes, zeroed by the launcher
   unsigned long long* dbg; int dbg_T; int exp; // optional [256][dbg_T][16] phase time stamps; exp: timing experiments (wrong results) (100 MHz), indexed by absolute step
   unsigned* status;                  // filled by the launcher: sticky status words (uic_set_persistent_status) or null
 };
-int uic_rnn_persist_mode();          // 0 off, 1 on, 2 on + SAFE protocol (UIC_PERSIST / uic_set_persistent_rnn)
+int uic_rnn_persist_mode();          // 0 off, 1 forward calls, 2 forward calls + SAFE protocol, 3 also the fused training step
 size_t uic_rnn_persist_sync_bytes();
 bool uic_rnn_persist_eligible(int dtype, int N, int H, int A, int R);
 int uic_rnn_fwd_persist_launch(const UicRnnFwdParams& p, hipStream_t s);
