@@ -39,3 +39,4 @@ def load_golden(name):
 @pytest.fixture(scope="session")
 def golden_loader():
     return load_golden
+

@@ -1,0 +1,141 @@
+"""Full-size parity of BASELINE.json configs[1] (128 images x 5 captions = 640 caption rows, R = 36, D = 2048, H = E = A = 512,
+vocabulary 9487 + 1, 17 decode steps) against the CPU oracle -- not properties, the oracle's own numbers: log-probs, loss,
+the norm of every gradient tensor and three gradient tensors entry by entry -- and of the persistent recurrence kernel
+(csrc/rnn_persist.hip) against the per-step launch chain it replaces, under both of its exchange protocols.
+Tolerances (north_star): log-probs 1e-3 (f32) / 1e-2 (bf16)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import topdown as O
+from test_gpu_topdown import build_model
+
+pytestmark = pytest.mark.gpu
+
+V, E, H, A, D, L, R = 9487, 512, 512, 512, 2048, 16, 36
+CFG = dict(V=V, E=E, H=H, A=A, D=D, L=L)
+LOGP_TOL = {"f32": 1e-3, "bf16": 1e-2}
+# Gradients: L2 error of every tensor relative to max(|oracle tensor|_2, floor), floor = 1e-3 x the largest tensor norm of the
+# model (h2att / alpha_net gradients are cancellations of size 1e-10 at random initialisation and are compared at the model's
+# scale, not their own).  Measured on MI355X at these shapes: f32 1.2e-6, bf16 6.0e-3; the bounds are ~3x that.
+GRAD_TOL = {"f32": 4e-6, "bf16": 2e-2}
+FULL_TENSORS = ["core.att_lstm.weight_hh", "core.attention.h2att.weight", "ctx2att.weight"]
+
+
+def _lib():
+    from unpaired_image_captioning_amd import _lib as L_
+    return L_
+
+
+@pytest.fixture(scope="module")
+def case():
+    """Weights, the 640-row batch, and the oracle's forward + loss + backward on it (CPU, ~10 s)."""
+    torch.manual_seed(0)
+    W = O.init_weights(V + 1, E, H, A, D, D, seed=7)
+    b = O.synthetic_batch(128, 5, R, D, V, L, seed=1234, ragged_regions=True)
+    nt = torch.get_num_threads()
+    torch.set_num_threads(min(16, nt))
+    loss, grads, logp = O.xe_loss_and_grads(W, b["fc_feats"], b["att_feats"], b["labels"], b["masks"], b["att_masks"])
+    torch.set_num_threads(nt)
+    return W, b, float(loss), grads, logp
+
+
+@pytest.mark.parametrize("mode", [0, 1, 2, 3])
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+def test_configs1_full_size_vs_oracle(case, dtype, mode):
+    """mode: uic_set_persistent_rnn -- 0 per-step launches, 1 persistent recurrence in the forward call, 2 the same with the
+    SAFE protocol, 3 persistent recurrence inside the fused training step as well."""
+    from unpaired_image_captioning_amd.trainer import xe_step
+    Lb = _lib()
+    W, b, ref_loss, ref_grads, ref_logp = case
+    batch = {k: v.cuda() for k, v in b.items()}
+    model = build_model(CFG, W, dtype)
+    model.train()                                    # drop_prob_lm = 0: deterministic
+    Lb.check(Lb.load().uic_set_persistent_rnn(mode))
+    try:
+        logp = model(batch["fc_feats"], None, batch["att_feats"], batch["labels"], batch["att_masks"])
+        t_run = model._steps_to_run(batch["labels"])
+        # log-probs: every row and step on a strided subset of the vocabulary, and the target entries
+        cols = torch.arange(0, V + 1, 37)
+        got = logp[:, :t_run][:, :, cols.cuda()].float().cpu()
+        assert (got - ref_logp[:, :t_run][:, :, cols]).abs().max().item() < LOGP_TOL[dtype]
+        tgt = batch["labels"][:, 1:t_run + 1]
+        got_t = logp[:, :t_run].gather(2, tgt.unsqueeze(2)).float().cpu()
+        assert (got_t - ref_logp[:, :t_run].gather(2, b["labels"][:, 1:t_run + 1].unsqueeze(2))).abs().max().item() < LOGP_TOL[dtype]
+        loss, grads = xe_step(model, batch)
+        assert abs(loss.item() - ref_loss) < LOGP_TOL[dtype]
+        st = Lb.persistent_status()
+    finally:
+        Lb.check(Lb.load().uic_set_persistent_rnn(1))
+    assert st[0] == 0
+    floor = 1e-3 * max(float(v.norm()) for v in ref_grads.values())
+    worst = max(((grads[k].float().cpu().double() - r.double()).norm() / max(r.double().norm().item(), floor)).item() for k, r in ref_grads.items())
+    print("full size %s mode %d: loss %.6f (oracle %.6f), worst per-tensor L2 gradient error %.3e" % (dtype, mode, loss.item(), ref_loss, worst))
+    for k, r in ref_grads.items():
+        g = grads[k].float().cpu().double()
+        r = r.double()
+        # per-tensor gradient norm
+        assert abs(g.norm().item() - r.norm().item()) <= GRAD_TOL[dtype] * max(r.norm().item(), floor), (k, g.norm().item(), r.norm().item())
+    # every tensor entry by entry (L2), three of them also by their worst entry on the f32 path
+    for k, r in ref_grads.items():
+        g = grads[k].float().cpu().double()
+        r = r.double()
+        assert ((g - r).norm() / max(r.norm().item(), floor)).item() < GRAD_TOL[dtype], k
+    efloor = 1e-3 * max(float(v.abs().max()) for v in ref_grads.values())
+    for k in FULL_TENSORS:
+        g = grads[k].float().cpu().double()
+        r = ref_grads[k].double()
+        err = ((g - r).abs().max() / max(r.abs().max().item(), efloor)).item()
+        print("   %s: worst entry error %.3e" % (k, err))
+        assert err < (2e-5 if dtype == "f32" else 5e-2), k
+
+
+NAMES = lambda T, N, td: [("h_att", (T + 1, N, H), td), ("h_lang", (T + 1, N, H), td), ("c_att", (T + 1, N, H), torch.float32),
+                          ("c_lang", (T + 1, N, H), torch.float32), ("att_h", (T, N, H), torch.float32), ("alpha", (T, N, R), torch.float32),
+                          ("ctx", (T, N, H), td), ("hdrop", (T, N, H), td), ("gates1", (T, N, 4 * H), td), ("gates2", (T, N, 4 * H), td)]
+
+
+@pytest.mark.parametrize("n_img,S", [(1, 4), (17, 5), (128, 5), (140, 5), (129, 1)])
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+def test_persistent_recurrence_equals_the_launch_chain(dtype, n_img, S):
+    """Every activation the recurrence leaves for the backward pass, every decode step, persistent kernel vs per-step
+    launches: 4 rows (most row groups empty), 85 rows (11 per group: ragged 16-row tiles), 640 (the benchmark), 700 (two
+    launches of <= 640 rows), 129 -- with ragged region counts (att_masks), training-mode dropout, and both exchange
+    protocols; results must not depend on the protocol and must repeat bit for bit."""
+    Lb = _lib()
+    lib = Lb.load()
+    W = O.init_weights(V + 1, E, H, A, D, D, seed=11)
+    b = O.synthetic_batch(n_img, S, R, D, V, L, seed=77, ragged_regions=True)
+    batch = {k: v.cuda() for k, v in b.items()}
+    model = build_model(CFG, W, dtype, drop=0.5)
+    model.train()
+    eng = model.engine
+    N, T = n_img * S, L + 1
+    t_run = model._steps_to_run(batch["labels"])
+    pd = {k: v.detach() for k, v in model.param_dict().items()}
+    td = torch.float32 if dtype == "f32" else torch.bfloat16
+
+    def run(mode):
+        Lb.check(lib.uic_set_persistent_rnn(mode))
+        logp, ws, _ = eng.forward(pd, batch["fc_feats"], batch["att_feats"], batch["att_masks"], batch["labels"], t_run, True, 99)
+        out = {n: eng.workspace_tensor(ws, n, shp, dt)[: (t_run + 1 if shp[0] == T + 1 else t_run)].float().clone() for n, shp, dt in NAMES(T, N, td)}
+        out["logp"] = logp[:, :t_run].clone()
+        torch.cuda.synchronize()
+        eng.release(ws)
+        return out
+    try:
+        before = Lb.persistent_status()
+        ref = run(0)
+        got1, got1b, got2 = run(1), run(1), run(2)
+        after = Lb.persistent_status()
+    finally:
+        Lb.check(lib.uic_set_persistent_rnn(1))
+    assert after[0] == 0
+    n_launch = (N + 639) // 640
+    assert after[1] - before[1] == 2 * n_launch and after[2] - before[2] == n_launch      # XCD-local twice, SAFE once
+    tol = 2e-5 if dtype == "f32" else 1.6e-2          # bf16: one rounding step of a value <= 2 (h, gates) is 2^-7
+    for k in ref:
+        assert torch.equal(got1[k], got1b[k]), k                         # bit-repeatable
+        assert torch.equal(got1[k], got2[k]), k                          # independent of the protocol / placement
+        assert (got1[k] - ref[k]).abs().max().item() < tol, (k, (got1[k] - ref[k]).abs().max().item())
+    assert (got1["logp"] - ref["logp"]).abs().max().item() < (2e-4 if dtype == "f32" else 1e-2)

@@ -15,7 +15,10 @@ pytestmark = pytest.mark.gpu
 
 FIXTURES = ["topdown_tiny", "topdown_tiny_ragged", "topdown_tiny_nomask", "topdown_tiny_earlybreak", "topdown_odd", "topdown_tiny_logit2", "topdown_tiny_box"]
 LOGP_TOL = {"f32": 1e-3, "bf16": 1e-2}
-GRAD_TOL = {"f32": 2e-3, "bf16": 1e-1}      # f32: max-entry error; bf16: L2 error (see grads_close)
+GRAD_TOL = {"f32": 2e-3, "bf16": 1e-1}      # f32: max-entry error; bf16: L2 error (see grads_close).  The bf16 bound is for the TINY
+# fixtures (32 hidden units, a handful of rows), where one ReLU within bf16 rounding of zero moves a whole tensor by several
+# per cent (worst measured over all fixtures: 0.10); at BASELINE's shapes the measured error is 6e-3 and
+# tests/test_gpu_fullsize.py bounds it by 2e-2
 
 
 def make_opt(cfg, dtype, drop=0.0, seed=0):

@@ -584,6 +584,7 @@ __device__ __forceinline__ int setup_ctx(const UicRnnFwdParams& p, char* scratch
   const int ok = __builtin_amdgcn_readfirstlane(info[3]);
   __syncthreads();
   if (!ok) return 0;
+  if (tid == 0 && blockIdx.x == 0 && p.status) __hip_atomic_fetch_add(p.status + (safe ? 2 : 1), 1u, RLX_AGENT);   // launches per protocol
   const int G = gridDim.x / PW;
   const int Rg = (p.Nrows + G - 1) / G;
   c.u0 = c.rank * 16;
@@ -597,7 +598,6 @@ __device__ __forceinline__ int setup_ctx(const UicRnnFwdParams& p, char* scratch
   c.bar_target = 0;
   c.smem = scratch;
   c.dbg = nullptr; c.exp = p.exp;
-  if (tid == 0 && blockIdx.x == 0 && p.status) __hip_atomic_fetch_add(p.status + (safe ? 2 : 1), 1u, RLX_AGENT);   // launches per protocol
   return safe ? 2 : 1;
 }
 
