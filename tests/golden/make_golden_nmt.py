@@ -152,6 +152,61 @@ def run_case(nmt, crit_mod, name, layers, H, B, S, T, Vs, Vt, seed):
     print("wrote %s (%.1f KB) loss=%.5f keys=%d" % (path, os.path.getsize(path) / 1024, loss.item(), len(model.state_dict())))
 
 
+def recipe_weights(state_dict, seed, scale):
+    """Weights as a pure function of (state_dict order and shapes, seed, scale): U(-scale, scale) from ONE torch CPU generator,
+    tensor after tensor.  The GPU-side test rebuilds them with the same three lines (tests/test_gpu_nmt.py::recipe_weights),
+    so a fixture at the real widths (50 004-word vocabularies: 300 MB of weights) only has to store results."""
+    g = torch.Generator().manual_seed(seed)
+    return {k: (torch.rand(v.shape, generator=g) * 2 - 1) * scale for k, v in state_dict.items()}
+
+
+def run_real_width_case(nmt, crit_mod, name, layers, H, B, S, T, Vs, Vt, seed, scale=0.08):
+    """BASELINE configs[2] at its real widths (2 layers, 512, vocabularies of 50 004) on a few sentences: outputs, attention,
+    loss, counters, the norm of every gradient tensor, decoder.attn.linear_in.weight's gradient in full and the generator /
+    embedding gradient rows of the words that occur."""
+    torch.manual_seed(seed)
+    opt = make_opt(layers, H, H)
+    sd, td = FakeDict(Vs), FakeDict(Vt)
+    model = nmt.NMTModel(opt, nmt.Encoder(opt, sd), nmt.Decoder(opt, td), sd, td)
+    generator = nn.Sequential(nn.Linear(H, Vt), nn.LogSoftmax(dim=1))
+    model.generator = generator
+    model.load_state_dict(recipe_weights(model.state_dict(), seed, scale))
+    loss_fn = crit_mod.NMTCriterion(Vt, opt)
+    src, lengths, tgt = synth_batch(B, S, T, Vs, Vt, seed)
+    model.train()
+    outputs, attns, _, _ = model(src, tgt, lengths)
+    scores = generator(outputs.view(-1, outputs.size(2)))
+    loss = loss_fn(scores, tgt[1:].view(-1))
+    loss.backward()
+    out = {"cfg": np.array([layers, H, B, S, T, Vs, Vt], dtype=np.int64), "recipe": np.array([seed, scale], dtype=np.float64),
+           "keys": np.array(list(model.state_dict().keys())),
+           "in::src": src.numpy(), "in::lengths": lengths.numpy(), "in::tgt": tgt.numpy(),
+           "out::outputs": outputs.detach().numpy(), "out::attn": attns["std"].detach().numpy(),
+           "out::loss": np.array(loss.item(), dtype=np.float64)}
+    pred = scores.max(1)[1]
+    nonpad = tgt[1:].view(-1).ne(0)
+    out["out::num_correct"] = np.array(int((pred.eq(tgt[1:].view(-1)) & nonpad).sum()))
+    out["out::num_words"] = np.array(int(nonpad.sum()))
+    tgt_rows = torch.unique(tgt[1:].reshape(-1))
+    src_rows = torch.unique(src.reshape(-1))
+    dec_rows = torch.unique(tgt[:-1].reshape(-1))
+    out["rows::generator"], out["rows::enc_lut"], out["rows::dec_lut"] = tgt_rows.numpy(), src_rows.numpy(), dec_rows.numpy()
+    for k, p_ in model.named_parameters():
+        gr = p_.grad.detach()
+        out["gnorm::" + k] = np.array(float(gr.double().norm()), dtype=np.float64)
+        if k == "decoder.attn.linear_in.weight":
+            out["grad::" + k] = gr.numpy()
+        elif k == "generator.0.weight":
+            out["gradrows::" + k] = gr[tgt_rows].numpy()
+        elif k == "encoder.embeddings.word_lut.weight":
+            out["gradrows::" + k] = gr[src_rows].numpy()
+        elif k == "decoder.embeddings.word_lut.weight":
+            out["gradrows::" + k] = gr[dec_rows].numpy()
+    path = os.path.join(HERE, name + ".npz")
+    np.savez_compressed(path, **out)
+    print("wrote %s (%.1f KB) loss=%.5f words=%d" % (path, os.path.getsize(path) / 1024, loss.item(), int(nonpad.sum())))
+
+
 def optim_opt(**kw):
     o = argparse.Namespace(
         i2t_train_flag=0, i2t_eval_flag=0, i2t_optim="adam", i2t_learning_rate=4e-4, i2t_learning_rate_decay_start=0,
@@ -303,6 +358,7 @@ if __name__ == "__main__":
     run_case(nmt, crit_mod, "nmt_tiny", layers=2, H=32, B=4, S=9, T=10, Vs=40, Vt=45, seed=31)
     run_case(nmt, crit_mod, "nmt_tiny_1layer", layers=1, H=32, B=3, S=6, T=7, Vs=30, Vt=37, seed=32)
     run_case(nmt, crit_mod, "nmt_odd", layers=2, H=48, B=5, S=11, T=8, Vs=53, Vt=61, seed=33)
+    run_real_width_case(nmt, crit_mod, "nmt_real_b4", layers=2, H=512, B=4, S=12, T=11, Vs=50004, Vt=50004, seed=34)
     old_torch_semantics()                                  # (after the training-path cases: they need none of it)
     run_translate_case(nmt, "nmt_translate_tiny", layers=2, H=32, B=3, S=7, Vs=30, Vt=35, seed=51, eos_bias=4.0)      # 7 steps
     run_translate_case(nmt, "nmt_translate_odd", layers=2, H=48, B=5, S=9, Vs=41, Vt=52, seed=52, eos_bias=8.0)       # 6 steps

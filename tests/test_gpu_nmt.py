@@ -407,3 +407,86 @@ def test_nmt_translate_random_sweep_vs_oracle(cfg):
     if len(allHyp[0][0]) == hyp_o.shape[1]:
         n_same = sum(int(allHyp[b][0] == [int(t) for t in hyp_o[b]]) for b in range(cfg["B"]))
         assert n_same >= (cfg["B"] + 1) // 2, (n_same, cfg["B"])
+
+
+# ---------------------------------------------------------------- BASELINE configs[2] at its real size
+def recipe_weights(cfg, seed, scale):
+    """tests/golden/make_golden_nmt.py::recipe_weights on this side: U(-scale, scale) from one torch CPU generator, tensor
+    after tensor in state_dict order."""
+    model, _ = build(cfg, None, "f32")
+    g = torch.Generator().manual_seed(seed)
+    return {k: (torch.rand(v.shape, generator=g) * 2 - 1) * scale for k, v in model.state_dict().items()}
+
+
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+def test_nmt_real_width_vs_reference_golden(dtype):
+    """2 layers, rnn_size 512, vocabularies of 50 004 words (the widths of BASELINE configs[2]) on four sentences: the
+    reference's own NMTModel / NMTCriterion produced outputs, attention, loss, accuracy counters, the norm of every gradient,
+    decoder.attn.linear_in.weight's gradient and the generator / embedding gradient rows of the words that occur
+    (tests/golden/nmt_real_b4.npz; the 300 MB of weights are rebuilt from the recipe stored with it)."""
+    z = np.load(os.path.join(GOLDEN, "nmt_real_b4.npz"))
+    layers, H, B, S, T, Vs, Vt = [int(x) for x in z["cfg"]]
+    cfg = dict(layers=layers, H=H, W=H, B=B, S=S, T=T, Vs=Vs, Vt=Vt)
+    seed, scale = int(z["recipe"][0]), float(z["recipe"][1])
+    W = recipe_weights(cfg, seed, scale)
+    assert list(W.keys()) == [str(k) for k in z["keys"]]
+    I = dict(src=torch.from_numpy(z["in::src"]), tgt=torch.from_numpy(z["in::tgt"]), lengths=torch.from_numpy(z["in::lengths"]))
+    model, crit = build(cfg, W, dtype)
+    model.train()
+    outputs, attn, loss = run(model, crit, I)
+    assert absmax(outputs, torch.from_numpy(z["out::outputs"])) < OUT_TOL[dtype]
+    assert absmax(attn, torch.from_numpy(z["out::attn"])) < OUT_TOL[dtype]
+    nw = int(z["out::num_words"])
+    assert abs(loss.item() - float(z["out::loss"])) < OUT_TOL[dtype] * nw
+    st = crit.report_stats
+    assert st.n_words == nw and abs(st.n_correct - int(z["out::num_correct"])) <= (0 if dtype == "f32" else 1)
+    loss.backward()
+    g = {k: p.grad.detach().float().cpu().double() for k, p in model.named_parameters()}
+    big = max(float(z["gnorm::" + k]) for k in g)
+    tol = 2e-4 if dtype == "f32" else 4e-2
+    for k, v in g.items():
+        ref = float(z["gnorm::" + k])
+        assert abs(v.norm().item() - ref) <= tol * max(ref, 1e-3 * big), (k, v.norm().item(), ref)
+
+    def close(got, ref, what):
+        ref = torch.from_numpy(ref).double()
+        assert ((got - ref).norm() / max(ref.norm().item(), 1e-3 * big)).item() < tol, what
+    close(g["decoder.attn.linear_in.weight"], z["grad::decoder.attn.linear_in.weight"], "linear_in")
+    close(g["generator.0.weight"][torch.from_numpy(z["rows::generator"])], z["gradrows::generator.0.weight"], "generator rows")
+    close(g["encoder.embeddings.word_lut.weight"][torch.from_numpy(z["rows::enc_lut"])], z["gradrows::encoder.embeddings.word_lut.weight"], "enc rows")
+    close(g["decoder.embeddings.word_lut.weight"][torch.from_numpy(z["rows::dec_lut"])], z["gradrows::decoder.embeddings.word_lut.weight"], "dec rows")
+
+
+CONFIGS2 = dict(layers=2, H=512, W=512, B=64, S=30, T=31, Vs=50004, Vt=50004)
+
+
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+def test_nmt_configs2_full_size_vs_oracle(dtype):
+    """BASELINE configs[2] at full size (batch 64, 2 layers, 512, vocabularies 50 004, lengths up to 30): decoder outputs,
+    attention, loss, accuracy counters and every gradient against oracle/nmt.py on the same inputs (the oracle's 1 920 x 50 004
+    generator GEMM and its backward take a few seconds on the host)."""
+    cfg = CONFIGS2
+    W = recipe_weights(cfg, 5, 0.08)
+    I = synthetic(cfg, 6)
+    nt = torch.get_num_threads()
+    torch.set_num_threads(min(16, nt))
+    ref_loss, ref_g, aux = ON.loss_and_grads(W, I["src"], I["tgt"], I["lengths"])
+    torch.set_num_threads(nt)
+    model, crit = build(cfg, W, dtype)
+    model.train()
+    outputs, attn, loss = run(model, crit, I)
+    assert absmax(outputs, aux["outputs"]) < OUT_TOL[dtype]
+    assert absmax(attn, aux["attn"]) < OUT_TOL[dtype]
+    assert abs(loss.item() - ref_loss.item()) < OUT_TOL[dtype] * aux["num_words"]
+    st = crit.report_stats
+    assert st.n_words == aux["num_words"] and abs(st.n_correct - aux["num_correct"]) <= (0 if dtype == "f32" else 2)
+    loss.backward()
+    big = max(float(v.norm()) for v in ref_g.values())
+    tol = 2e-5 if dtype == "f32" else 6e-2            # measured on MI355X: 2.3e-6 / 3.7e-2
+    worst = 0.0
+    for k, p in model.named_parameters():
+        g, r = p.grad.detach().float().cpu().double(), ref_g[k].double()
+        err = ((g - r).norm() / max(r.norm().item(), 1e-3 * big)).item()
+        worst = max(worst, err)
+        assert err < tol, (k, err)
+    print("configs[2] full size %s: loss %.4f (oracle %.4f), worst per-tensor L2 gradient error %.3e" % (dtype, loss.item(), ref_loss.item(), worst))
