@@ -200,6 +200,29 @@ int uic_topdown_sample_beam(const uic_topdown_dims* d, const uic_topdown_weights
                             const uic_topdown_batch* b, int32_t L, int32_t beam_size, int32_t decoding_constraint,
                             int32_t max_ppl, void* workspace, int64_t* seq, float* seq_logp, void* stream);
 
+/* The rest of uic_topdown_sample_beam's done list, read from the workspace right after it: CaptionModel.beam_search's
+ * done_beams_table (P/models/CaptionModel.py:147-161,174-176) in insertion order -- done_count [images] int32 entries per
+ * image, done_p [images, L * beam_size] (p, or p / length with max_ppl), done_seq [images, L * beam_size, L] int64,
+ * done_lp likewise f32.  The reference's done_beams[k] is these entries sorted by -p (stable), first beam_size kept. */
+int uic_topdown_beam_done_lists(const uic_topdown_dims* d, void* workspace, int32_t L, int32_t beam_size, int32_t* done_count,
+                                float* done_p, int64_t* done_seq, float* done_lp, void* stream);
+
+/* AttModel._prepare_feature (P/models/AttModel.py:107-117: fc_embed, pack_wrapper(att_embed), ctx2att) as its own call,
+ * for callers that drive the decoder step by step (CaptionModel.beam_search :172, eval_ensemble.py): fc_out [N, H],
+ * att_out [N, R, H], p_att_out [N, R, A], all f32 (the workspace keeps them in the operand dtype). */
+int uic_topdown_prepare_feature(const uic_topdown_dims* d, const uic_topdown_weights* w, const void* derived,
+                                const uic_topdown_batch* batch, int32_t training, uint32_t seed, void* workspace,
+                                float* fc_out, float* att_out, float* p_att_out, void* stream);
+/* AttModel.get_logprobs_state (P/models/AttModel.py:158-165): ONE decode step from caller-held prepared features and
+ * state.  it [N] int64; fc [N, H], att [N, R, H], p_att [N, R, A] f32 as returned by uic_topdown_prepare_feature;
+ * att_masks [N, R] or NULL; state in / out as the reference stacks it: h [2, N, H] = (h_att, h_lang), c likewise, f32.
+ * logprobs [N, V1] = log_softmax(logit(dropout(h_lang))).  `t` picks the dropout masks of decode step t when training != 0.
+ * dims->seq_per_img must be 0 or 1 (the prepared features are per row). */
+int uic_topdown_logprobs_state(const uic_topdown_dims* d, const uic_topdown_weights* w, const void* derived, const int64_t* it,
+                               const float* fc, const float* att, const float* p_att, const float* att_masks,
+                               const float* h_in, const float* c_in, int32_t t, int32_t training, uint32_t seed, void* workspace,
+                               float* logprobs, float* h_out, float* c_out, void* stream);
+
 /* Address of a named activation inside the workspace (tests / debugging); NULL if unknown.
  * Names: fc_embed att_embed p_att xt gx h_att h_lang c_att c_lang att_h alpha ctx logits dlogits ... */
 void* uic_topdown_workspace_ptr(const uic_topdown_dims* d, void* workspace, const char* name);

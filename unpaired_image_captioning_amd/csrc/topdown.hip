@@ -1212,6 +1212,82 @@ int uic_topdown_sample(const uic_topdown_dims* d, const uic_topdown_weights* w, 
 }
 
 
+int uic_topdown_prepare_feature(const uic_topdown_dims* d, const uic_topdown_weights* w, const void* derived,
+                                const uic_topdown_batch* b, int32_t training, uint32_t seed, void* workspace,
+                                float* fc_out, float* att_out, float* p_att_out, void* stream) {
+  UIC_TRY(check_dims(d));
+  UIC_REQUIRE(w && derived && b && workspace && fc_out && att_out && p_att_out, "prepare_feature: null pointer");
+  UIC_REQUIRE(b->fc_feats && b->att_feats, "prepare_feature: batch needs fc_feats and att_feats");
+  hipStream_t s = (hipStream_t)stream;
+  const Layout L = make_layout(*d, workspace);
+  const Derived dv = make_derived(*d, w, (void*)derived);
+  const void *fc_in, *att_in;
+  const float drop_p = (training & 1) ? d->drop_p : 0.f;
+  UIC_TRY(prepare_features(*d, w, dv, b, L, training, drop_p, seed, &fc_in, &att_in, s));
+  const size_t N = d->N, R = d->R, H = d->H, A = d->A;
+  UIC_TRY(uic_to_f32_launch(d->dtype, L.fcp, fc_out, N * H, s));
+  UIC_TRY(uic_to_f32_launch(d->dtype, L.attp, att_out, N * R * H, s));
+  return uic_to_f32_launch(d->dtype, L.patt, p_att_out, N * R * A, s);
+}
+
+int uic_topdown_logprobs_state(const uic_topdown_dims* d, const uic_topdown_weights* w, const void* derived, const int64_t* it,
+                               const float* fc, const float* att, const float* p_att, const float* att_masks,
+                               const float* h_in, const float* c_in, int32_t t, int32_t training, uint32_t seed, void* workspace,
+                               float* logprobs, float* h_out, float* c_out, void* stream) {
+  UIC_TRY(check_dims(d));
+  UIC_REQUIRE(w && derived && it && fc && att && p_att && h_in && c_in && workspace && logprobs && h_out && c_out, "logprobs_state: null pointer");
+  UIC_REQUIRE(d->seq_per_img <= 1, "logprobs_state: the prepared features are per caption row (seq_per_img must be 0 or 1)");
+  UIC_REQUIRE(t >= 0, "logprobs_state: t=%d", t);
+  hipStream_t s = (hipStream_t)stream;
+  const Layout L = make_layout(*d, workspace);
+  const Derived dv = make_derived(*d, w, (void*)derived);
+  const int dt = d->dtype;
+  const size_t N = d->N, R = d->R, H = d->H, A = d->A, V1 = d->V1;
+  const size_t S = uic_dtype_size(dt);
+  UIC_TRY(wait_refresh(s));
+  // the caller's prepared features and state become the step's operands (operand dtype) ...
+  UIC_TRY(uic_cast_f32_launch(dt, fc, L.fcp, N * H, s));
+  UIC_TRY(uic_cast_f32_launch(dt, att, L.attp, N * R * H, s));
+  UIC_TRY(uic_cast_f32_launch(dt, p_att, L.patt, N * R * A, s));
+  UIC_TRY(uic_cast_f32_launch(dt, h_in, L.s_h_att[0], N * H, s));
+  UIC_TRY(uic_cast_f32_launch(dt, h_in + N * H, L.s_h_lang[0], N * H, s));
+  UIC_TRY(uic_check_hip(hipMemcpyAsync(L.s_c_att[0], c_in, N * H * 4, hipMemcpyDeviceToDevice, s), "memcpy c"));
+  UIC_TRY(uic_check_hip(hipMemcpyAsync(L.s_c_lang[0], c_in + N * H, N * H * 4, hipMemcpyDeviceToDevice, s), "memcpy c"));
+  UIC_TRY(uic_check_hip(hipMemcpyAsync(L.s_it, it, N * 8, hipMemcpyDeviceToDevice, s), "memcpy it"));
+  uic_topdown_batch b;
+  memset(&b, 0, sizeof(b));
+  b.att_masks = att_masks;
+  const float drop_p = (training & 1) ? d->drop_p : 0.f;
+  // ... one get_logprobs_state (P/models/AttModel.py:158-165) ...
+  UIC_TRY(decode_step(*d, w, dv, &b, L, 0, 1, t, drop_p, seed, s, (training & 1) != 0));
+  // ... and its results go back out: log_softmax of the logits, the new (h, c) stacks [att_lstm, lang_lstm]
+  UicXeParams x;
+  memset(&x, 0, sizeof(x));
+  x.dtype = dt; x.M = (int)N; x.V1 = (int)V1; x.ldv = (int)vpad(V1); x.N = (int)N;
+  x.logits = L.s_logits; x.logprobs = logprobs; x.lp_step_stride = V1; x.lp_row_stride = V1;
+  UIC_TRY(uic_xe_launch(x, s));
+  UIC_TRY(uic_to_f32_launch(dt, L.s_h_att[1], h_out, N * H, s));
+  UIC_TRY(uic_to_f32_launch(dt, L.s_h_lang[1], h_out + N * H, N * H, s));
+  UIC_TRY(uic_check_hip(hipMemcpyAsync(c_out, L.s_c_att[1], N * H * 4, hipMemcpyDeviceToDevice, s), "memcpy c"));
+  UIC_TRY(uic_check_hip(hipMemcpyAsync(c_out + N * H, L.s_c_lang[1], N * H * 4, hipMemcpyDeviceToDevice, s), "memcpy c"));
+  (void)S;
+  return UIC_OK;
+}
+
+int uic_topdown_beam_done_lists(const uic_topdown_dims* d, void* workspace, int32_t Lsteps, int32_t beam_size, int32_t* done_count,
+                                float* done_p, int64_t* done_seq, float* done_lp, void* stream) {
+  UIC_TRY(check_dims(d));
+  UIC_REQUIRE(workspace && done_count && done_p && done_seq && done_lp, "beam_done_lists: null pointer");
+  UIC_REQUIRE(beam_size >= 1 && d->N % beam_size == 0 && Lsteps >= 1 && Lsteps <= d->T, "beam_done_lists: bad sizes");
+  hipStream_t s = (hipStream_t)stream;
+  const Layout L = make_layout(*d, workspace);
+  const size_t n_img = (size_t)d->N / beam_size, LB = (size_t)Lsteps * beam_size;
+  UIC_TRY(uic_check_hip(hipMemcpyAsync(done_count, L.bm_done_count, n_img * 4, hipMemcpyDeviceToDevice, s), "memcpy done_count"));
+  UIC_TRY(uic_check_hip(hipMemcpyAsync(done_p, L.bm_done_p, n_img * LB * 4, hipMemcpyDeviceToDevice, s), "memcpy done_p"));
+  UIC_TRY(uic_check_hip(hipMemcpyAsync(done_seq, L.bm_done_seq, n_img * LB * Lsteps * 8, hipMemcpyDeviceToDevice, s), "memcpy done_seq"));
+  return uic_check_hip(hipMemcpyAsync(done_lp, L.bm_done_lp, n_img * LB * Lsteps * 4, hipMemcpyDeviceToDevice, s), "memcpy done_lp");
+}
+
 int uic_topdown_sample_beam(const uic_topdown_dims* d, const uic_topdown_weights* w, const void* derived,
                             const uic_topdown_batch* b, int32_t Lsteps, int32_t beam_size, int32_t decoding_constraint,
                             int32_t max_ppl, void* workspace, int64_t* seq, float* seq_logp, void* stream) {

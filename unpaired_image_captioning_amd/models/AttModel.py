@@ -206,10 +206,44 @@ class AttModel(CaptionModel):
         params = [self.param_dict()[k] for k in self.param_names]
         return _TopDownForward.apply(self, fc, att, seq.contiguous(), am, t_run, *params)
 
+    def clip_att(self, att_feats, att_masks):
+        """P/models/AttModel.py:99-105: clip the region axis to the longest row of att_masks."""
+        if att_masks is not None:
+            max_len = int(att_masks.long().sum(1).max())
+            att_feats = att_feats[:, :max_len].contiguous()
+            att_masks = att_masks[:, :max_len].contiguous()
+        return att_feats, att_masks
+
+    def _prepare_feature(self, fc_feats, att_feats, att_masks):
+        """P/models/AttModel.py:107-117 -> (fc', att', p_att, att_masks), f32 device tensors (no autograd: this is the
+        decode-time call of beam search / ensembles; training goes through _forward)."""
+        att_feats, att_masks = self.clip_att(att_feats, att_masks)
+        fc = fc_feats.contiguous().float()
+        att = att_feats.contiguous().float()
+        am = att_masks.contiguous().float() if att_masks is not None else None
+        with torch.no_grad():
+            pd = {k: v.detach() for k, v in self.param_dict().items()}
+            self._bn_count_batch()
+            fc_p, att_p, p_att = self.engine.prepare_feature(pd, fc, att, am, training=self.training,
+                                                             seed=self.next_seed() if self.training else 0)
+        return fc_p, att_p, p_att, am
+
+    def get_logprobs_state(self, it, fc_feats, att_feats, p_att_feats, att_masks, state, t=0):
+        """P/models/AttModel.py:158-165: one decode step from prepared features -> (log-probs [N, V+1], new state);
+        state = (h [2, N, H], c [2, N, H]) stacked (att_lstm, lang_lstm) as TopDownCore returns it (:445)."""
+        with torch.no_grad():
+            pd = {k: v.detach() for k, v in self.param_dict().items()}
+            am = att_masks.contiguous().float() if att_masks is not None else None
+            logp, h, c = self.engine.logprobs_state(pd, it.contiguous().long(), fc_feats.contiguous().float(), att_feats.contiguous().float(),
+                                                    p_att_feats.contiguous().float(), am, state[0].contiguous().float(),
+                                                    state[1].contiguous().float(), t=t, training=self.training,
+                                                    seed=self._seed_counter if self.training else 0)
+        return logp, (h, c)
+
     def _sample_beam(self, fc_feats, att_feats, att_masks=None, opt={}):
         """AttModel._sample_beam (P/models/AttModel.py:167-196) over CaptionModel.beam_search (P/models/CaptionModel.py:
-        33-177): all images in one device pass.  `self.done_beams[k]` holds the winning beam of image k ('seq', 'logps');
-        the reference's full per-image list of finished beams is not materialised on the host."""
+        33-177): all images in one device pass.  `self.done_beams[k]` is the reference's list for image k: its finished
+        beams sorted by -p (stable), the first beam_size of them, each {'seq', 'logps', 'unaug_p', 'p'} (:147-161,174-176)."""
         beam_size = opt.get('beam_size', 10)
         group_size = opt.get('group_size', 1)
         if group_size > 1:
@@ -224,9 +258,14 @@ class AttModel(CaptionModel):
         am = att_masks.contiguous().float() if att_masks is not None else None
         with torch.no_grad():
             pd = {k: v.detach() for k, v in self.param_dict().items()}
-            seq, lp = self.engine.sample_beam(pd, fc, att, am, self.seq_length, beam_size, opt.get('decoding_constraint', 0),
-                                              opt.get('max_ppl', 0))
-        self.done_beams = [[{'seq': seq[k], 'logps': lp[k]}] for k in range(seq.shape[0])]
+            seq, lp, (cnt, dp, dseq, dlp) = self.engine.sample_beam(pd, fc, att, am, self.seq_length, beam_size,
+                                                                   opt.get('decoding_constraint', 0), opt.get('max_ppl', 0), done_lists=True)
+        cnt_h, dp_h = cnt.cpu().tolist(), dp.cpu()
+        self.done_beams = []
+        for k in range(seq.shape[0]):
+            order = sorted(range(cnt_h[k]), key=lambda i: -float(dp_h[k, i]))[:beam_size]     # sorted() is stable, like the reference's
+            self.done_beams.append([{'seq': dseq[k, i], 'logps': dlp[k, i], 'unaug_p': float(dlp[k, i].sum()), 'p': float(dp_h[k, i])}
+                                    for i in order])
         return seq, lp
 
     def _sample(self, fc_feats, attri_feats, att_feats, att_masks=None, opt={}):

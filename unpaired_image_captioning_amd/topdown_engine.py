@@ -254,9 +254,10 @@ class TopDownEngine(object):
             self.release(ws)
         return seq, lp
 
-    def sample_beam(self, params, fc, att, att_masks, L, beam_size, decoding_constraint=0, max_ppl=0):
+    def sample_beam(self, params, fc, att, att_masks, L, beam_size, decoding_constraint=0, max_ppl=0, done_lists=False):
         """Beam search for all images at once: rows = (image, beam); the beam_size-fold replication of every image's
-        features (AttModel.py:180-184) happens on the device (dims.seq_per_img = beam_size)."""
+        features (AttModel.py:180-184) happens on the device (dims.seq_per_img = beam_size).  done_lists: also return the
+        whole done list of every image (count [n_img], p [n_img, L*B], seq [n_img, L*B, L], logps likewise)."""
         n_img = att.shape[0]
         d = self.dims(n_img * beam_size, att.shape[1], L + 1, beam_size)
         w = self.refresh(params, d)
@@ -264,13 +265,62 @@ class TopDownEngine(object):
         b = self.batch_struct(fc, att, att_masks)
         seq = torch.zeros(n_img, L, dtype=torch.int64, device=fc.device)
         lp = torch.zeros(n_img, L, dtype=torch.float32, device=fc.device)
+        lists = None
         try:
             check(self.lib.uic_topdown_sample_beam(C.byref(d), C.byref(w), ptr(self._derived), C.byref(b), L, int(beam_size),
                                                    int(decoding_constraint), int(max_ppl), ptr(ws.buf), ptr(seq), ptr(lp), stream()),
                   "sample_beam")
+            if done_lists:
+                LB = L * beam_size
+                cnt = torch.zeros(n_img, dtype=torch.int32, device=fc.device)
+                dp = torch.zeros(n_img, LB, dtype=torch.float32, device=fc.device)
+                dseq = torch.zeros(n_img, LB, L, dtype=torch.int64, device=fc.device)
+                dlp = torch.zeros(n_img, LB, L, dtype=torch.float32, device=fc.device)
+                check(self.lib.uic_topdown_beam_done_lists(C.byref(d), ptr(ws.buf), L, int(beam_size), ptr(cnt), ptr(dp), ptr(dseq),
+                                                           ptr(dlp), stream()), "beam_done_lists")
+                lists = (cnt, dp, dseq, dlp)
         finally:
             self.release(ws)
+        if done_lists:
+            return seq, lp, lists
         return seq, lp
+
+    def prepare_feature(self, params, fc, att, att_masks, training=False, seed=0):
+        """AttModel._prepare_feature: (fc', att', p_att) as f32 tensors."""
+        N, R = att.shape[0], att.shape[1]
+        d = self.dims(N, R, 2)
+        w = self.refresh(params, d)
+        ws = self.checkout(d, fc.device)
+        b = self.batch_struct(fc, att, att_masks)
+        s = self.sizes
+        fc_o = torch.empty(N, s["H"], dtype=torch.float32, device=fc.device)
+        att_o = torch.empty(N, R, s["H"], dtype=torch.float32, device=fc.device)
+        patt_o = torch.empty(N, R, s["A"], dtype=torch.float32, device=fc.device)
+        try:
+            check(self.lib.uic_topdown_prepare_feature(C.byref(d), C.byref(w), ptr(self._derived), C.byref(b), int(training),
+                                                       seed & 0xFFFFFFFF, ptr(ws.buf), ptr(fc_o), ptr(att_o), ptr(patt_o), stream()),
+                  "prepare_feature")
+            self._write_back(w)
+        finally:
+            self.release(ws)
+        return fc_o, att_o, patt_o
+
+    def logprobs_state(self, params, it, fc, att, p_att, att_masks, h, c, t=0, training=False, seed=0):
+        """AttModel.get_logprobs_state: one decode step; returns (logprobs [N, V1], h' [2, N, H], c' [2, N, H])."""
+        N, R = att.shape[0], att.shape[1]
+        d = self.dims(N, R, 2)
+        w = self.refresh(params, d)
+        ws = self.checkout(d, fc.device)
+        s = self.sizes
+        logp = torch.empty(N, s["V1"], dtype=torch.float32, device=fc.device)
+        h2, c2 = torch.empty_like(h), torch.empty_like(c)
+        try:
+            check(self.lib.uic_topdown_logprobs_state(C.byref(d), C.byref(w), ptr(self._derived), ptr(it), ptr(fc), ptr(att), ptr(p_att),
+                                                      ptr(att_masks), ptr(h), ptr(c), int(t), int(training), seed & 0xFFFFFFFF,
+                                                      ptr(ws.buf), ptr(logp), ptr(h2), ptr(c2), stream()), "logprobs_state")
+        finally:
+            self.release(ws)
+        return logp, h2, c2
 
     def workspace_tensor(self, ws, name, shape, dtype):
         """View of a named activation inside a workspace (tests)."""
