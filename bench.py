@@ -50,12 +50,11 @@ def _pmc_traffic(dtype):
 
 
 def attention_roofline(dtype_id, dtype_name, iters=64, pool=8):
-    """Time the attention-step forward kernel alone, with HIP events on the launch stream, at the
-    bench shapes; algorithmic bytes per launch = N * (R*A + R*H + 2H + R) * sizeof.
-    `achieved` is the kernel as the training step runs it: ONE p_att/att pair (47 MB bf16) re-read by every decode
-    step, so it stays in the 256 MiB Infinity Cache between launches -- this is the duration rocprofv3 reports for
-    the kernel inside the step (profiles/).  `us_per_launch_hbm_cold` / `frac_hbm_cold` rotate through `pool` pairs
-    (377 MB bf16 > the Infinity Cache) so that every launch streams from HBM proper."""
+    """Time the attention-step forward kernel alone, one HIP event pair per launch on the launch stream, at the bench
+    shapes; algorithmic bytes per launch = N * (R*A + R*H + 2H + R) * sizeof.
+    `achieved` / `frac` are HBM-COLD: the launches rotate through `pool` p_att/att pairs (377 MB in bf16, more than the
+    256 MiB Infinity Cache), so every byte comes from HBM.  `us_per_launch_cache_resident` / `frac_cache_resident` re-read
+    ONE pair (47 MB, Infinity-Cache resident) the way the 17 decode steps of a training step do -- not an HBM figure."""
     from unpaired_image_captioning_amd import _lib as L
     lib = L.load()
     c = CFG
@@ -75,24 +74,69 @@ def attention_roofline(dtype_id, dtype_name, iters=64, pool=8):
                                       None, L.ptr(alpha), L.ptr(ctx), L.stream()))
 
     def timed(rotate):
+        """Mean duration of ONE launch: an event pair around every launch (not a back-to-back average, whose launches overlap
+        each other's ramps), on the stream the kernel is launched on."""
         for i in range(8):
             launch(i % pool if rotate else 0)
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
+        ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(iters)]
         for i in range(iters):
+            ev[i][0].record()
             launch(i % pool if rotate else 0)
-        e1.record()
+            ev[i][1].record()
         torch.cuda.synchronize()
-        return e0.elapsed_time(e1) / 1e3 / iters
-    cold_s, dur_s = timed(True), timed(False)
+        d = sorted(a.elapsed_time(b) for a, b in ev)
+        return sum(d[iters // 8: iters - iters // 8]) / (iters - 2 * (iters // 8)) / 1e3      # trimmed mean, seconds
+    cold_s, res_s = timed(True), timed(False)
     es = p_atts[0].element_size()
     bytes_per_launch = N * (R * A + R * H + 2 * H + R) * es
-    achieved = bytes_per_launch / dur_s / 1e9
+    achieved = bytes_per_launch / cold_s / 1e9
+    traffic = _pmc_traffic(dtype_name)
     return {"bound": "hbm", "kernel": "attn_fwd_fast_kernel", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
-            "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": _pmc_traffic(dtype_name),
-            "bytes_per_launch": bytes_per_launch, "us_per_launch": round(dur_s * 1e6, 2),
-            "us_per_launch_hbm_cold": round(cold_s * 1e6, 2),
-            "frac_hbm_cold": round(bytes_per_launch / cold_s / 1e9 / HBM_PEAK_GBS, 4)}
+            "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
+            "note": "HBM-cold: the launches rotate through %d p_att/att pairs (%d MB > the 256 MiB Infinity Cache), one HIP event pair per launch" % (pool, pool * 2 * N * R * H * es // 2 ** 20),
+            "traffic": traffic,
+            "traffic_source": "profiles/attn_fwd_pmc_%s.json (committed rocprofv3 PMC passes of this kernel, NOT measured in this run)" % dtype_name if traffic else None,
+            "bytes_per_launch": bytes_per_launch, "us_per_launch": round(cold_s * 1e6, 2),
+            "us_per_launch_cache_resident": round(res_s * 1e6, 2),
+            "frac_cache_resident": round(bytes_per_launch / res_s / 1e9 / HBM_PEAK_GBS, 4)}
+
+
+MFMA_PEAK_TFLOPS = {"bf16": 2500.0, "f32": 157.3}     # dense peaks (MI355X_MICROARCH.md)
+
+
+def gemm_roofline(dtype_id, dtype_name, iters=32):
+    """The dominant MFMA-bound GEMM family of the step, the large NT kernel (uic_gemm_glds_kernel), on its largest
+    call: the logit layer of one 4-step chunk, [2560 x 512] x [9488 x 512]^T (P/models/AttModel.py:163) -- achieved
+    TFLOP/s from one HIP event pair per launch against the dense MFMA peak of the operand dtype."""
+    from unpaired_image_captioning_amd import _lib as L
+    lib = L.load()
+    c = CFG
+    M, Nn, K = 4 * c["n_img"] * c["S"], c["V"] + 1, c["H"]
+    td = L.TORCH_DTYPE[dtype_id]
+    g = torch.Generator(device="cuda").manual_seed(2)
+    Aop = torch.randn(M, K, device="cuda", generator=g).to(td)
+    Bop = torch.randn(Nn, K, device="cuda", generator=g).to(td)
+    ldc = (Nn + 63) // 64 * 64
+    Cout = torch.empty(M, ldc, device="cuda", dtype=torch.float32)
+    bias = torch.zeros(Nn, device="cuda")
+
+    def launch():
+        L.check(lib.uic_linear(dtype_id, M, Nn, K, L.ptr(Aop), K, L.ptr(Bop), K, L.ptr(Cout), ldc, L.ptr(bias), 4, L.stream()))
+    for _ in range(4):
+        launch()
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(iters)]
+    for a, b in ev:
+        a.record()
+        launch()
+        b.record()
+    torch.cuda.synchronize()
+    d = sorted(a.elapsed_time(b) for a, b in ev)
+    dur = sum(d[iters // 8: iters - iters // 8]) / (iters - 2 * (iters // 8)) / 1e3
+    flops = 2.0 * M * Nn * K
+    tf = flops / dur / 1e12
+    return {"bound": "mfma", "kernel": "uic_gemm_glds_kernel (logit layer of a 4-step chunk: %d x %d x %d)" % (M, Nn, K),
+            "achieved": round(tf, 1), "peak": MFMA_PEAK_TFLOPS[dtype_name], "unit": "TFLOP/s", "frac": round(tf / MFMA_PEAK_TFLOPS[dtype_name], 4),
+            "flops_per_launch": flops, "us_per_launch": round(dur * 1e6, 2), "traffic": None}
 
 
 def cpu_baseline(threads=None):
@@ -101,7 +145,7 @@ def cpu_baseline(threads=None):
     c = CFG
     if threads:
         torch.set_num_threads(threads)
-    n_img = 64
+    n_img = c["n_img"]                                        # the full 128 images x 5 captions = 640 rows
     torch.manual_seed(0)
     W = O.init_weights(c["V"] + 1, c["E"], c["H"], c["A"], c["D"], c["D"], seed=7)
     b = O.synthetic_batch(n_img, c["S"], c["R"], c["D"], c["V"], c["L"], seed=1234)
@@ -117,14 +161,14 @@ def cpu_baseline(threads=None):
     m1 = {k: torch.zeros_like(v) for k, v in P.items()}
     v1 = {k: torch.zeros_like(v) for k, v in P.items()}
     times = []
-    for step in range(1, 12):
+    for step in range(1, 14):
         t0 = time.perf_counter()
         loss, grads, _ = O.xe_loss_and_grads(P, b["fc_feats"], b["att_feats"], b["labels"], b["masks"], b["att_masks"], masks())
         O.adam_step(P, grads, m1, v1, step, 5e-4)
         times.append(time.perf_counter() - t0)
-    best = sum(times[1:]) / len(times[1:])
+    best = sum(times[3:]) / len(times[3:])
     return {"value": round(N / best, 1), "unit": "captions/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": "%d images x %d captions = %d rows, fp32, 1 warm-up + 10 timed steps of fwd+loss+bwd+Adam "
+            "sample": "%d images x %d captions = %d rows, fp32, 3 warm-up + 10 timed steps of fwd+loss+bwd+Adam "
                       "(oracle/topdown.py, torch CPU ops)" % (n_img, c["S"], N)}
 
 
@@ -135,6 +179,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--dtype", default="bf16")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-f32", action="store_true", help="skip the secondary f32 (parity path) measurement")
     ap.add_argument("--features", default="per-caption", choices=["per-caption", "per-image"],
                     help="per-caption: the reference's batch dict (features replicated seq_per_img times, the headline); "
                          "per-image: features once per image, replication on the device")
@@ -145,9 +190,31 @@ def main():
     ap.add_argument("--cpu-threads", type=int, default=0, help="threads for the CPU oracle leg (0: min(host cores, 16), the fastest setting measured on the GPU box's 256-thread host: 8->293, 16->379, 32->211, 64->110, 128->24 captions/s)")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` without a launcher: start the N ranks here.  Fresh child processes, started BEFORE this
+        # process makes any GPU call (counting devices does not initialise the GPU on this image); it only waits for them.
+        import subprocess
+        n_dev = torch.cuda.device_count()
+        if n_dev < args.gpus and os.environ.get("UIC_BENCH_SHARE_GPU") != "1":
+            raise SystemExit("bench.py --gpus %d: this node has %d GPU(s)" % (args.gpus, n_dev))
+        import socket
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        procs = []
+        for r in range(args.gpus):
+            env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), MASTER_ADDR="127.0.0.1",
+                       MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+            procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+        rc = 0
+        for pr in procs:
+            rc = max(rc, pr.wait())
+        raise SystemExit(rc)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d ranks were launched; refusing to report a number for a different job" % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the captioner hot path has no CPU fallback")
     # UIC_BENCH_SHARE_GPU=1 (functional test of the N > 1 path on a 1-GPU box): every rank uses device 0 and the
@@ -207,6 +274,25 @@ def main():
     if args.features == "per-caption" and world == 1:
         elapsed_img, _ = timed(per_image)
     loss_val = float(loss.item())
+    L.persistent_status()                                      # raises if a persistent-kernel spin timed out
+    f32_line = None
+    if world == 1 and args.dtype != "f32" and not args.no_f32:
+        # the reference's own precision (exact-f32 MFMA parity path): same step, same batch, a few iterations
+        del tr
+        torch.manual_seed(1234)
+        tr32 = Trainer(make_opt("f32", 1234, args.use_bn, Datt))
+        tr32.build_optimizer()
+        for _ in range(2):
+            tr32.train_device_batch(batch, t_run, den_local)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(5):
+            l32 = tr32.train_device_batch(batch, t_run, den_local)
+        torch.cuda.synchronize()
+        e32 = time.perf_counter() - t0
+        f32_line = {"value": round(N * 5 / e32, 1), "unit": "captions/s", "ms_per_step": round(e32 / 5 * 1e3, 3), "steps": 5,
+                    "warmup": 2, "final_loss": round(float(l32.item()), 4), "note": "same step with f32 operands (exact-f32 MFMA), the reference's precision"}
+        del tr32
 
     if rank == 0:
         dtype_id = L.dtype_id(args.dtype)
@@ -228,8 +314,12 @@ def main():
                                    "XE loss + BPTT + Adam", "rows_per_gpu": N, "parallelism": "dp%d" % world, "use_bn": args.use_bn, "att_feat_size": Datt,
                        "features": args.features},
             "final_loss": round(loss_val, 4),
+            "rccl_ranks": dist.get_world_size() if (world > 1 and dist.get_backend() == "nccl") else (1 if world == 1 else 0),
             "roofline": attention_roofline(dtype_id, args.dtype),
+            "roofline_mfma": gemm_roofline(dtype_id, args.dtype),
         }
+        if f32_line is not None:
+            out["f32"] = f32_line
         if elapsed_img is not None:
             out["per_image_features"] = {"value": round(world * N * args.steps / elapsed_img, 1), "unit": "captions/s",
                                          "ms_per_step": round(elapsed_img / args.steps * 1e3, 3),

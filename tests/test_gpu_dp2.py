@@ -43,13 +43,14 @@ def _train(cfg, W, data, steps):
     return tr, losses
 
 
-def _worker(rank, world, port, out_dir):
+def _worker(rank, world, port, out_dir, backend="gloo"):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
-    torch.cuda.set_device(0)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    torch.cuda.set_device(rank if backend == "nccl" else 0)     # RCCL: one GPU per rank; gloo: both ranks share cuda:0
+    dist.init_process_group(backend, rank=rank, world_size=world)
     from unpaired_image_captioning_amd.parallel_exchange import GradientExchange
     cfg, W, I, Out, G, X = load_golden("topdown_tiny_ragged")
     lo, hi = GradientExchange().shard_images(cfg["n_img"])
@@ -64,9 +65,7 @@ def _worker(rank, world, port, out_dir):
     dist.destroy_process_group()
 
 
-def test_two_ranks_on_one_gpu_match_single_process(tmp_path):
-    world = 2
-    mp.spawn(_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+def _check_against_single_process(tmp_path):
     res = torch.load(os.path.join(str(tmp_path), "dp2.pt"))
     cfg, W, I, Out, G, X = load_golden("topdown_tiny_ragged")
     data = {k: I[k].numpy() for k in ("fc_feats", "att_feats", "labels", "masks", "att_masks")}
@@ -83,3 +82,18 @@ def test_two_ranks_on_one_gpu_match_single_process(tmp_path):
         # noise there, so its update is compared against the learning-rate scale instead of its own movement
         floor = 3 * 5e-3 * 1e-2 if k == "core.attention.alpha_net.bias" else 1e-7
         assert (v - ref).abs().max().item() <= 2e-2 * moved + floor, (k, (v - ref).abs().max().item(), moved)
+
+
+def test_two_ranks_on_one_gpu_match_single_process(tmp_path):
+    world = 2
+    mp.spawn(_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    _check_against_single_process(tmp_path)
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="RCCL needs one GPU per rank: this box has %d" % torch.cuda.device_count())
+def test_two_ranks_over_rccl_match_single_process(tmp_path):
+    """The same step with the collectives on RCCL (backend "nccl"), one GPU per rank over xGMI: runs wherever two GPUs are
+    visible (the 1-GPU boxes skip it)."""
+    world = 2
+    mp.spawn(_worker, args=(world, _free_port(), str(tmp_path), "nccl"), nprocs=world, join=True)
+    _check_against_single_process(tmp_path)

@@ -231,3 +231,24 @@ def test_decode_sequence_and_if_use_att():
     seq = torch.tensor([[1, 2, 0, 3], [3, 3, 3, 3], [0, 1, 1, 1]])
     assert utils.decode_sequence(vocab, seq) == ["a b", "c c c c", ""]
     assert utils.if_use_att("topdown") and not utils.if_use_att("fc")
+
+
+def test_data_parallel_ranks_start_from_different_dropout_seeds():
+    """Dropout / sampling noise is a hash of (seed, site, LOCAL row index): rank r of a data-parallel job must not reuse
+    rank 0's stream, or every shard draws the same masks (Trainer._mix_rank_into_seed)."""
+    import argparse
+    from unpaired_image_captioning_amd.trainer import Trainer
+
+    class FakeExchange(object):
+        def __init__(self, rank):
+            self.rank, self.world_size = rank, 4
+
+    class M(object):
+        _seed_counter = 1234
+
+    seeds = []
+    for r in range(4):
+        m = M()
+        Trainer._mix_rank_into_seed(m, FakeExchange(r))
+        seeds.append(m._seed_counter)
+    assert seeds[0] == 1234 and len(set(seeds)) == 4 and all(0 <= s_ <= 0x7FFFFFFF for s_ in seeds)

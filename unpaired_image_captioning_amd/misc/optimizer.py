@@ -146,7 +146,8 @@ class Optim(object):
             self.nmt_arena = FlatArena(nmt_model, getattr(nmt_model, 'param_names', None))
             self.nmt_arena.bind_grads()
             if hasattr(nmt_model, 'grad_sink'):
-                nmt_model.grad_sink = self.nmt_arena.grad_views      # backward writes the arena in place
+                nmt_model.grad_sink = self.nmt_arena.grad_views      # backward may write the arena in place (see _NmtStep.backward)
+                self._nmt_model = nmt_model
 
     def _exchange(self, arena):
         if self.exchange is not None and self.exchange.world_size > 1:
@@ -173,6 +174,8 @@ class Optim(object):
             self.i2t_arena.zero_grad()
         if self.nmt_train_flag and self.nmt_arena is not None:
             self.nmt_arena.zero_grad()
+            if getattr(self, '_nmt_model', None) is not None:
+                self._nmt_model._sink_written = False
 
     def update_ScheduledSampling_prob(self, opt, epoch, dp_i2t_model):
         if epoch > opt.scheduled_sampling_start and opt.scheduled_sampling_start >= 0:

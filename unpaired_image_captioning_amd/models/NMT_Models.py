@@ -192,10 +192,17 @@ class _NmtStep(torch.autograd.Function):
         src, tgt = ctx.inputs
         pd = dict(zip(model.param_names, ctx.params))
         sink = model.grad_sink
-        direct = sink is not None and all(pd[k].grad is sink[k] for k in model.param_names)
+        direct = (sink is not None and model.unit_loss_gradient and all(pd[k].grad is sink[k] for k in model.param_names))
         # direct: every p.grad IS its view of the optimizer's flat gradient arena (Optim.zero_grad just zeroed it) and the
-        # loss is backpropagated with weight 1 (loss.backward()), so the kernels write the arena in place -- no temporaries,
-        # no scale, no accumulate pass over the 86 M parameters
+        # caller has DECLARED (model.unit_loss_gradient, set by Trainer.train_nmt) that the loss is backpropagated with
+        # weight 1 (a plain loss.backward()), so the kernels write the arena in place -- no temporaries, no scale, no
+        # accumulate pass over the 86 M parameters.  Any other caller (scaled losses, loss.backward(gradient=...)) takes
+        # the general path below, which honours g_loss and lets autograd accumulate.
+        if direct:
+            if model._sink_written:
+                raise RuntimeError("NMT backward ran twice into the optimizer's gradient arena without Optim.zero_grad() in between: "
+                                   "the in-place path overwrites, it does not accumulate (clear model.unit_loss_gradient to accumulate)")
+            model._sink_written = True
         grads = sink if direct else {k: torch.empty_like(v) for k, v in pd.items()}
         w, gw = eng.weights(pd), eng.weights(grads)
         check(eng.lib.uic_nmt_backward(C.byref(ctx.d), C.byref(w), ptr(src), lens, ptr(tgt), int(training), seed, ptr(ctx.ws),
@@ -231,6 +238,8 @@ class NMTModel(nn.Module):
         self._last_seed = None
         self.generator = None
         self.grad_sink = None      # set by misc.optimizer.Optim: {key: view of the flat gradient arena}
+        self.unit_loss_gradient = False   # set by Trainer.train_nmt: the loss is backpropagated as is (weight 1)
+        self._sink_written = False        # cleared by Optim.zero_grad
 
     # ---- engine plumbing
     @property

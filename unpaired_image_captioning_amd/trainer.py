@@ -75,6 +75,8 @@ class Trainer(object):
         self.i2t_train_loss = 0.0
         self.sc_flag = False
         self.exchange = exchange if exchange is not None else GradientExchange()
+        if self.i2t_model is not None:
+            self._mix_rank_into_seed(self.i2t_model, self.exchange)
         self.lr = getattr(opt, 'i2t_learning_rate', 4e-4)
         self.i2t_current_lr = self.lr
         self.betas = (getattr(opt, 'i2t_optim_alpha', 0.9), getattr(opt, 'i2t_optim_beta', 0.999))
@@ -86,6 +88,14 @@ class Trainer(object):
         self._step = 0
         self.arena = None
         self.last_loss = None
+
+    @staticmethod
+    def _mix_rank_into_seed(model, exchange):
+        """Dropout masks, multinomial draws and scheduled-sampling decisions are hashes of (seed, site, LOCAL row index): under
+        data parallelism every rank must start from a different seed, or all shards share their noise."""
+        rank = exchange.rank if exchange is not None else 0
+        if rank and hasattr(model, '_seed_counter'):
+            model._seed_counter = (model._seed_counter + 0x9E3779B1 * rank) & 0x7FFFFFFF
 
     # flat-arena order [FIRST_GRADS | LSTM_W_GRADS | rest | LATE_GRADS] = gradient groups 0 / 1 / 2 / tail of uic_topdown_grad_ready_wait
     # (include/uic_hip.h): each piece's all-reduce starts while the step is still computing the following ones
@@ -310,6 +320,7 @@ class Trainer(object):
         self.nmt_encoder = NMT_Models.Encoder(opt, src_dict)
         self.nmt_decoder = NMT_Models.Decoder(opt, tgt_dict)
         self.nmt_model = NMT_Models.NMTModel(opt, self.nmt_encoder, self.nmt_decoder, src_dict, tgt_dict, False)
+        self._mix_rank_into_seed(self.nmt_model, self.exchange)
         self.nmt_generator = nn.Sequential(nn.Linear(opt.rnn_size, tgt_size), nn.LogSoftmax(dim=-1))
         param_init = getattr(opt, 'param_init', 0.1)
         if param_init:
@@ -332,6 +343,7 @@ class Trainer(object):
         if update_lr:
             self.optim.update_LearningRate('nmt', nmt_epoch)
         self.optim.zero_grad()
+        self.nmt_model.unit_loss_gradient = True      # loss.backward() below: the kernels may write the gradient arena in place
         outputs, attn, dec_state, upper_bounds = self.dp_nmt_model(nmt_batch.src, nmt_batch.tgt, nmt_batch.lengths, None)
         nmt_loss = self.nmt_crit(loader, nmt_batch, outputs, attn)
         nmt_loss.backward()
