@@ -1120,9 +1120,13 @@ int uic_topdown_xe_train_step(const uic_topdown_dims* d, const uic_topdown_weigh
   UIC_HIP(hipStreamWaitEvent(s2, ss->ev_den, 0));
   UIC_TRY(st.fwd_prologue(s));
   UIC_TRY(wait_refresh(s));                           // the recurrence needs the side-stream half of the weight refresh
+  // mode 3 (experiments): the whole recurrence as ONE persistent launch; the logit layer follows chunk by chunk on the side
+  // stream while the main stream already starts the backward prologue
+  const bool one_launch = st.persist_ok(true);
+  if (one_launch) UIC_TRY(st.fwd_steps(0, t_run, s, true));
   for (int c = 0; c < nchunk; ++c) {
     const int t0 = c * CH, t1 = t0 + CH < t_run ? t0 + CH : t_run;
-    UIC_TRY(st.fwd_steps(t0, t1, s, true));
+    if (!one_launch) UIC_TRY(st.fwd_steps(t0, t1, s, true));
     UIC_HIP(hipEventRecord(ss->ev_main[c], s));
     // side: logit layer of the chunk, forward and backward-to-h (beside the next chunk's recurrence)
     UIC_HIP(hipStreamWaitEvent(s2, ss->ev_main[c], 0));
