@@ -149,10 +149,10 @@ __device__ __forceinline__ void gemm_ksplit(const Ctx& c, f32x4 (&acc)[MT_MAX][N
     const __amdgpu_buffer_rsrc_t rb = rsrc_of(Bseg[sg]);
 #pragma unroll
     for (int g = 0; g < NCT; ++g)
-      fb[buf][g] = (c.exp & 1) ? u32x4{0, 0, 0, 0} : bload<false>(rb, (brow[g] * (unsigned)ldb[sg] + (unsigned)(c.lq * VEC)) * (unsigned)sizeof(T), kk);
+      fb[buf][g] = bload<false>(rb, (brow[g] * (unsigned)ldb[sg] + (unsigned)(c.lq * VEC)) * (unsigned)sizeof(T), kk);
 #pragma unroll
     for (int i = 0; i < MT_MAX; ++i)
-      if (i < c.MT) fa[buf][i] = (c.exp & 2) ? u32x4{0, 0, 0, 0} : bload<true>(ra, aoff[i], kk);
+      if (i < c.MT) fa[buf][i] = bload<true>(ra, aoff[i], kk);
   };
   // two k-steps of operands in flight per wave (8 waves x 2 x 9 KB per CU: enough to cover the L2 latency at the
   // ~70 GB/s a CU takes in); the scheduling barriers keep hipcc from hoisting every k-step's loads to the top
@@ -317,7 +317,7 @@ __device__ __forceinline__ void attn_load_slot(const Ctx& c, int R, const T* bas
 #pragma unroll
     for (int k = 0; k < CH; ++k) {
       const u32x4* src = (const u32x4*)(base + (unsigned)(r * HH + (c.lane + 64 * k) * VEC));
-      const u32x4 v = (STREAM && !(c.exp & 512)) ? __builtin_nontemporal_load(src) : *src;
+      const u32x4 v = *src;
       q.v[u][k] = make_uint4(v.x, v.y, v.z, v.w);
     }
   }
@@ -625,6 +625,9 @@ __global__ __launch_bounds__(NTH) void rnn_fwd_persist_kernel(const UicRnnFwdPar
 //     row tile per pass and one workgroup barrier per pass;
 //   * h2att's slice (16 KB) is re-read every step beside the activations (4 MB per step chip-wide).
 // The c state of both cells stays in the registers of the lanes that update it.
+#ifndef WS_EARLY_PRE
+#define WS_EARLY_PRE 0
+#endif
 #ifndef WS_P1_CHUNK
 #define WS_P1_CHUNK 8
 #endif
@@ -771,6 +774,10 @@ __device__ __forceinline__ void ws_run(const UicRnnFwdParams& p, Ctx& c, char* l
 #pragma unroll
     for (int g = 0; g < 4; ++g) pv[g] = gx[4u * n1 + (unsigned)(g * HH) + u] + (p.gfc ? p.gfc[4u * n1 + (unsigned)(g * HH) + u] : 0.f);
   };
+#if WS_EARLY_PRE
+  float pvn[4][4], cpn[4];                          // of the NEXT att_lstm phase, own tile (tile = wave): requested one phase early
+  load_pre(p.t0, c.wave, pvn, cpn);
+#endif
   __syncthreads();                                  // the W1 image is complete
   unsigned long long* dbg = p.dbg ? p.dbg + ((size_t)blockIdx.x * p.dbg_T + p.t0) * 16 : nullptr;
   for (int t = p.t0; t < p.t1; ++t) {
@@ -815,8 +822,10 @@ __device__ __forceinline__ void ws_run(const UicRnnFwdParams& p, Ctx& c, char* l
           const int sr = (q + s0) & 31;
           fa[0][q] = bload<true>(rx, aoff, a_soff(sr));
         }
+#if !WS_EARLY_PRE
         float pvn[4][4], cpn[4];
         if (NCK == 1) load_pre(t, i, pvn, cpn);
+#endif
         f32x4 acc[4];
 #pragma unroll
         for (int g = 0; g < 4; ++g) acc[g] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -831,9 +840,11 @@ __device__ __forceinline__ void ws_run(const UicRnnFwdParams& p, Ctx& c, char* l
 #pragma unroll
             for (int q = 0; q < CK; ++q) {
               const int sr = ((cc + 1) * CK + q + s0) & 31;
-              if (!(c.exp & 256)) fa[(cc + 1) & 1][q] = bload<true>(rx, aoff, a_soff(sr));
+              fa[(cc + 1) & 1][q] = bload<true>(rx, aoff, a_soff(sr));
             }
+#if !WS_EARLY_PRE
             if (cc == 0) load_pre(t, i, pvn, cpn);
+#endif
           } else if (split5 && NCK > 1) {
             // the buffer that has just been consumed takes this wave's share of tile 4: k-steps wave, wave + 4, ...
 #pragma unroll
@@ -848,7 +859,7 @@ __device__ __forceinline__ void ws_run(const UicRnnFwdParams& p, Ctx& c, char* l
             const int qq = cc * CK + q;
             const int sn = (qq + 1 + s0) & 31;      // (the last prefetch wraps to k-step s0 and is unused)
 #pragma unroll
-            for (int g = 0; g < 4; ++g) fb[(qq + 1) & 1][g] = (c.exp & 128) ? fb[qq & 1][g] : w1[(sn * 4 + g) * 64 + c.lane];
+            for (int g = 0; g < 4; ++g) fb[(qq + 1) & 1][g] = w1[(sn * 4 + g) * 64 + c.lane];
 #pragma unroll
             for (int g = 0; g < 4; ++g) acc[g] = mma_bf16(fa[cc & 1][q], fb[qq & 1][g], acc[g]);
             if (NCK == 1 && q == 15 && split5) {
@@ -1044,6 +1055,9 @@ __device__ __forceinline__ void ws_run(const UicRnnFwdParams& p, Ctx& c, char* l
           // whole launch: left to itself hipcc parks them in AGPRs but copies each one back (4 x v_accvgpr_read) in front of
           // every MFMA.  Inline-asm MFMAs get no hazard padding from the compiler: gate g's chain is re-entered only after
           // the three other gates' MFMAs (the matrix pipe is in order), and the nops below cover MFMA result -> LDS store.
+#if WS_EARLY_PRE
+          if (!more && t + 1 < p.t1) load_pre(t + 1, c.wave, pvn, cpn);   // last pass: no later request of this phase waits behind these
+#endif
           const bool prof = dbg && c.tid == 0 && i == 1 && (c.exp & 32);
           if (prof) { dbg[8] = __builtin_amdgcn_s_memtime(); dbg[13] = __builtin_amdgcn_s_memrealtime(); }
           f32x4 acc[4];
@@ -1054,7 +1068,7 @@ __device__ __forceinline__ void ws_run(const UicRnnFwdParams& p, Ctx& c, char* l
               if (j == 0) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, 0" : "=&v"(acc[g]) : "v"(fa[0]), "a"(w2[0][g]));
               else asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(acc[g]) : "v"(fa[j]), "a"(w2[j][g]));
             }
-            if (more && !(c.exp & 16)) load_frag(j, an);
+            if (more) load_frag(j, an);
           }
           asm volatile("s_nop 7\n\ts_nop 7" : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3]));
           if (prof) dbg[9] = __builtin_amdgcn_s_memtime();
