@@ -31,10 +31,10 @@ int uic_version(void);
 /* Persistent recurrence (csrc/rnn_persist.hip): with rnn_size = att_hid_size = 512 and at most 40 regions the decode loop of
  * AttModel._forward (P/models/AttModel.py:129-154: att_lstm, h2att, attention, lang_lstm per step) can run as ONE launch
  * for a range of decode steps instead of four dependent launches per step (bf16: the recurrent weights stay in LDS and
- * registers for the whole launch).  mode 0: never; 1 (default, or the UIC_PERSIST environment variable): in
- * uic_topdown_forward, where nothing else competes for the CUs; 2: the same with its placement-independent SAFE exchange
- * protocol forced (tests); 3: also inside uic_topdown_xe_train_step (slower there: the kernel holds every CU, so the
- * side-stream work no longer overlaps).  Two processes sharing one GPU must not both enable it.
+ * registers for the whole launch).  mode 0: never; 1: in uic_topdown_forward only; 2: the same with its
+ * placement-independent SAFE exchange protocol forced (tests); 3 (default, or the UIC_PERSIST environment variable): also
+ * inside uic_topdown_xe_train_step, whose logit layer then follows the recurrence chunk by chunk, last chunk first, beside
+ * the BPTT loop; -1: back to the default.  Two processes sharing one GPU must not both enable it.
  * uic_set_persistent_status registers (per device; NULL unregisters) 4 caller-allocated, caller-zeroed uint32 on the
  * device that the kernel updates: [0] != 0 after a bounded spin timed out (the results of that call are invalid), [1] /
  * [2] launches that ran with the XCD-local / the SAFE protocol. */

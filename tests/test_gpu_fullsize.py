@@ -66,7 +66,7 @@ def test_configs1_full_size_vs_oracle(case, dtype, mode):
         assert abs(loss.item() - ref_loss) < LOGP_TOL[dtype]
         st = Lb.persistent_status()
     finally:
-        Lb.check(Lb.load().uic_set_persistent_rnn(1))
+        Lb.check(Lb.load().uic_set_persistent_rnn(-1))
     assert st[0] == 0
     floor = 1e-3 * max(float(v.norm()) for v in ref_grads.values())
     worst = max(((grads[k].float().cpu().double() - r.double()).norm() / max(r.double().norm().item(), floor)).item() for k, r in ref_grads.items())
@@ -129,7 +129,7 @@ def test_persistent_recurrence_equals_the_launch_chain(dtype, n_img, S):
         got1, got1b, got2 = run(1), run(1), run(2)
         after = Lb.persistent_status()
     finally:
-        Lb.check(lib.uic_set_persistent_rnn(1))
+        Lb.check(lib.uic_set_persistent_rnn(-1))
     assert after[0] == 0
     n_launch = (N + 639) // 640
     assert after[1] - before[1] == 2 * n_launch and after[2] - before[2] == n_launch      # XCD-local twice, SAFE once

@@ -214,7 +214,7 @@ int uic_lm_criterion(int32_t N, int32_t T, int32_t V1, const float* logp, const 
   UIC_LAUNCH_CHECK("lm_crit_rows");
   hipLaunchKernelGGL(lm_crit_final_kernel, dim3(1), dim3(256), 0, s, row_loss, row_mask, n, fin);
   UIC_LAUNCH_CHECK("lm_crit_final");
-  UIC_TRY(uic_check_hip(hipMemcpyAsync(loss_out, fin, 4, hipMemcpyDeviceToDevice, s), "memcpy loss"));
+  UIC_TRY(uic_copy_launch(loss_out, fin, 4, s));
   if (dlogp) {
     UIC_TRY(uic_fill_launch(dlogp, 0, (size_t)n * V1 * 4, s));
     hipLaunchKernelGGL(lm_crit_bwd_kernel, dim3((n + 255) / 256), dim3(256), 0, s, N, T, V1, target, ld_target, mask, ld_mask, fin, grad_out, dlogp);

@@ -288,7 +288,7 @@ int uic_fc_backward(const uic_fc_dims* d, const uic_fc_weights* w, const uic_top
     UIC_TRY(wgrad_group(L.slab, L.slab_bytes, dt, L.ds_all, H5, H5, segs, 2, Ms, dd, 2, s, false, L.tA, L.tB));
   }
   UIC_TRY(uic_colsum_launch(dt, L.ds_all, Ms, H5, H5, G->i2h_b, L.colscratch, L.colscratch_floats, s));
-  UIC_TRY(uic_check_hip(hipMemcpyAsync(G->h2h_b, G->i2h_b, (size_t)H5 * 4, hipMemcpyDeviceToDevice, s), "memcpy h2h_b"));
+  UIC_TRY(uic_copy_launch(G->h2h_b, G->i2h_b, (size_t)H5 * 4, s));
   {  // d x for all steps
     UicGemmParams g = gemm_base(dt, Ms, E);
     add_seg(g, L.ds_all, H5, L.i2hT, H5, H5);

@@ -197,21 +197,23 @@ __global__ __launch_bounds__(256) void uic_gemm_tn_kernel(const UicGemmTnParams 
     }
 }
 
+// blockIdx.y picks the destination (a uniform select: indexing an array of the by-value structs would put it in scratch)
 __global__ void splitk_reduce_multi_kernel(const float* __restrict__ slab, int splitk, int M, int N, UicSlabDest d0, UicSlabDest d1,
-                                           UicSlabDest d2, UicSlabDest d3, int nd, int accumulate) {
-  const UicSlabDest ds[4] = {d0, d1, d2, d3};
+                                           UicSlabDest d2, UicSlabDest d3, int accumulate) {
+  const int k = blockIdx.y;
+  float* const C = k == 0 ? d0.C : k == 1 ? d1.C : k == 2 ? d2.C : d3.C;
+  const int ldc = k == 0 ? d0.ldc : k == 1 ? d1.ldc : k == 2 ? d2.ldc : d3.ldc;
+  const int col0 = k == 0 ? d0.col0 : k == 1 ? d1.col0 : k == 2 ? d2.col0 : d3.col0;
+  const int ncols = k == 0 ? d0.ncols : k == 1 ? d1.ncols : k == 2 ? d2.ncols : d3.ncols;
   const size_t stride = (size_t)gridDim.x * blockDim.x;
-  for (int k = 0; k < nd; ++k) {
-    const UicSlabDest d = ds[k];
-    const size_t total = (size_t)M * d.ncols;
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
-      const int row = (int)(i / d.ncols), c = (int)(i - (size_t)row * d.ncols);
-      const float* src = slab + (size_t)row * N + d.col0 + c;
-      float v = 0.f;
-      for (int z = 0; z < splitk; ++z) v += src[(size_t)z * M * N];
-      float* o = d.C + (size_t)row * d.ldc + c;
-      *o = accumulate ? *o + v : v;
-    }
+  const size_t total = (size_t)M * ncols;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+    const int row = (int)(i / ncols), c = (int)(i - (size_t)row * ncols);
+    const float* src = slab + (size_t)row * N + col0 + c;
+    float v = 0.f;
+    for (int z = 0; z < splitk; ++z) v += src[(size_t)z * M * N];
+    float* o = C + (size_t)row * ldc + c;
+    *o = accumulate ? *o + v : v;
   }
 }
 
@@ -225,7 +227,7 @@ int uic_splitk_reduce_multi_launch(const float* slab, int splitk, int M, int N, 
   size_t g = ((size_t)M * cols / nd + 255) / 256;
   if (g > 2048) g = 2048;
   if (g < 1) g = 1;
-  hipLaunchKernelGGL(splitk_reduce_multi_kernel, dim3((unsigned)g), dim3(256), 0, s, slab, splitk, M, N, d[0], d[1], d[2], d[3], nd, accumulate);
+  hipLaunchKernelGGL(splitk_reduce_multi_kernel, dim3((unsigned)g, (unsigned)nd), dim3(256), 0, s, slab, splitk, M, N, d[0], d[1], d[2], d[3], accumulate);
   UIC_LAUNCH_CHECK("splitk_reduce_multi");
   return UIC_OK;
 }

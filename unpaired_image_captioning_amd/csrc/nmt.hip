@@ -709,7 +709,7 @@ struct Nmt {
     UIC_TRY(uic_xe_launch(x, s));
     UIC_TRY(uic_reduce_sum_launch(L.row_loss, (size_t)Td * B, 0.f, nullptr, loss_out, s));
     if (stats_out) {
-      UIC_TRY(uic_check_hip(hipMemcpyAsync(stats_out, L.stats, 8, hipMemcpyDeviceToDevice, s), "memcpy stats"));
+      UIC_TRY(uic_copy_launch(stats_out, L.stats, 8, s));
     }
     return UIC_OK;
   }
@@ -794,7 +794,7 @@ struct Nmt {
         UIC_TRY(wgrad_group(L.slab, L.slab_bytes, dt, L.dg_d[l], H4, H4, segs, 2, Md, dd, 2, s, false, L.tA, L.tB));
       }
       UIC_TRY(uic_colsum_launch(dt, L.dg_d[l], Md, H4, H4, G->dec_b_ih[l], L.colscratch, L.colscratch_floats, s));
-      UIC_TRY(uic_check_hip(hipMemcpyAsync(G->dec_b_hh[l], G->dec_b_ih[l], (size_t)H4 * 4, hipMemcpyDeviceToDevice, s), "memcpy b_hh"));
+      UIC_TRY(uic_copy_launch(G->dec_b_hh[l], G->dec_b_ih[l], (size_t)H4 * 4, s));
     }
     {  // decoder embeddings (padding_idx = PAD keeps that row's gradient at zero)
       UicGemmParams g = gemm_base(dt, Md, W);
@@ -873,7 +873,7 @@ struct Nmt {
           UIC_TRY(wgrad_group(L.slab, L.slab_bytes, dt, L.dg_e[l][dd], 4 * Hd, 4 * Hd, segs, 2, Ms, dw, 2, s, false, L.tA, L.tB));
         }
         UIC_TRY(uic_colsum_launch(dt, L.dg_e[l][dd], Ms, 4 * Hd, 4 * Hd, G->enc_b_ih[l][dd], L.colscratch, L.colscratch_floats, s));
-        UIC_TRY(uic_check_hip(hipMemcpyAsync(G->enc_b_hh[l][dd], G->enc_b_ih[l][dd], (size_t)4 * Hd * 4, hipMemcpyDeviceToDevice, s), "memcpy b_hh"));
+        UIC_TRY(uic_copy_launch(G->enc_b_hh[l][dd], G->enc_b_ih[l][dd], (size_t)4 * Hd * 4, s));
       }
       {  // d input of layer l = sum over directions dG W_ih
         UicGemmParams g = gemm_base(dt, Ms, in);
@@ -887,7 +887,7 @@ struct Nmt {
           hipLaunchKernelGGL(dropout_grad_kernel, dim3(gridn((size_t)Ms * H)), dim3(NT), 0, s, L.dx_e, (size_t)Ms * H, drop_p, seed, SITE_NMT_ENC(l - 1));
           UIC_LAUNCH_CHECK("dropout_grad_kernel");
         }
-        UIC_TRY(uic_check_hip(hipMemcpyAsync(L.d_lay, L.dx_e, (size_t)Ms * H * 4, hipMemcpyDeviceToDevice, s), "memcpy d_lay"));
+        UIC_TRY(uic_copy_launch(L.d_lay, L.dx_e, (size_t)Ms * H * 4, s));
         d_top = L.d_lay;
       }
     }
@@ -934,7 +934,7 @@ int uic_nmt_forward_loss(const uic_nmt_dims* d, const uic_nmt_weights* w, const 
   UIC_TRY(st.loss_fwd(loss_out, stats_out, s));
   const int dt = st.dt;
   if (outputs_out) UIC_TRY(uic_to_f32_launch(dt, off(st.L.out_all, st.BH, dt), outputs_out, (size_t)st.Td * st.BH, s));
-  if (attn_out) UIC_TRY(uic_check_hip(hipMemcpyAsync(attn_out, st.L.attn_all, (size_t)st.Td * st.B * st.S * 4, hipMemcpyDeviceToDevice, s), "memcpy attn"));
+  if (attn_out) UIC_TRY(uic_copy_launch(attn_out, st.L.attn_all, (size_t)st.Td * st.B * st.S * 4, s));
   if (context_out) UIC_TRY(uic_to_f32_launch(dt, off(st.L.xl[st.NL], st.BH, dt), context_out, (size_t)st.S * st.BH, s));
   return UIC_OK;
 }
@@ -1040,8 +1040,8 @@ int uic_nmt_translate(const uic_nmt_dims* d, const uic_nmt_weights* w, const int
   const NmtLayout& L = st.L;
   // (2) decoder state = encoder final states (slot 0 of the training path's state buffers), zero input feed
   for (int l = 0; l < NL; ++l) {
-    UIC_TRY(uic_check_hip(hipMemcpyAsync(T.h[l][0], L.hd[l], RH * Sz, hipMemcpyDeviceToDevice, s), "memcpy h0"));
-    UIC_TRY(uic_check_hip(hipMemcpyAsync(T.c[l][0], L.cd[l], RH * 4, hipMemcpyDeviceToDevice, s), "memcpy c0"));
+    UIC_TRY(uic_copy_launch(T.h[l][0], L.hd[l], RH * Sz, s));
+    UIC_TRY(uic_copy_launch(T.c[l][0], L.cd[l], RH * 4, s));
   }
   UIC_TRY(uic_fill_launch(T.feed[0], 0, RH * Sz, s));
   hipLaunchKernelGGL(nmt_beam_init_kernel, dim3(gridn((size_t)R)), dim3(NT), 0, s, B, K, T.tok, T.scores, T.done, T.flags);

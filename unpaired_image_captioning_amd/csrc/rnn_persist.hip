@@ -1140,12 +1140,12 @@ __global__ __launch_bounds__(WS_NTH) void rnn_fwd_persist_ws_kernel(const UicRnn
 }
 
 unsigned* g_status[16] = {};   // caller-allocated sticky status words per device (uic_set_persistent_status)
-int g_persist_mode = -1;     // -1: read UIC_PERSIST (default 1); see uic_set_persistent_rnn in include/uic_hip.h
+int g_persist_mode = -1;     // -1: read UIC_PERSIST (default 3); see uic_set_persistent_rnn in include/uic_hip.h
 
 }  // namespace
 
 extern "C" int uic_set_persistent_rnn(int32_t mode) {
-  UIC_REQUIRE(mode >= 0 && mode <= 3, "set_persistent_rnn: mode=%d must be 0 (off), 1 (forward calls), 2 (forward calls, SAFE protocol) or 3 (also the fused training step)", mode);
+  UIC_REQUIRE(mode >= -1 && mode <= 3, "set_persistent_rnn: mode=%d must be -1 (default), 0 (off), 1 (forward calls), 2 (forward calls, SAFE protocol) or 3 (also the fused training step)", mode);
   g_persist_mode = mode;
   return UIC_OK;
 }
@@ -1161,8 +1161,8 @@ extern "C" int uic_set_persistent_status(void* status) {
 int uic_rnn_persist_mode() {
   if (g_persist_mode < 0) {
     const char* e = getenv("UIC_PERSIST");
-    g_persist_mode = e ? atoi(e) : 1;
-    if (g_persist_mode < 0 || g_persist_mode > 3) g_persist_mode = 1;
+    g_persist_mode = e ? atoi(e) : 3;
+    if (g_persist_mode < 0 || g_persist_mode > 3) g_persist_mode = 3;
   }
   return g_persist_mode;
 }

@@ -871,7 +871,7 @@ struct Step {
       UIC_TRY(wgrad_group(slab, L.dg2_all, H4, H4, segs, 3, Meff, dd, 2, s, false, tA, tB));
     }
     UIC_TRY(uic_colsum_launch(dt, L.dg2_all, Meff, H4, H4, G->lang_lstm_b_ih, colscratch, L.colscratch_floats, s));
-    UIC_TRY(uic_check_hip(hipMemcpyAsync(G->lang_lstm_b_hh, G->lang_lstm_b_ih, (size_t)H4 * 4, hipMemcpyDeviceToDevice, s), "memcpy b_hh"));
+    UIC_TRY(uic_copy_launch(G->lang_lstm_b_hh, G->lang_lstm_b_ih, (size_t)H4 * 4, s));
     // att_lstm inputs [h_lang_prev | xt | h_att_prev]  (the fc' columns are handled below from dGfc)
     if (!chunked) {
       const UicGemmTnSeg segs[3] = {{L.h_lang, H, H}, {L.xt_all, E, E}, {L.h_att, H, H}};
@@ -879,7 +879,7 @@ struct Step {
       UIC_TRY(wgrad_group(slab, L.dg1_all, H4, H4, segs, 3, Meff, dd, 3, s, false, tA, tB));
     }
     UIC_TRY(uic_colsum_launch(dt, L.dg1_all, Meff, H4, H4, G->att_lstm_b_ih, colscratch, L.colscratch_floats, s));
-    UIC_TRY(uic_check_hip(hipMemcpyAsync(G->att_lstm_b_hh, G->att_lstm_b_ih, (size_t)H4 * 4, hipMemcpyDeviceToDevice, s), "memcpy b_hh"));
+    UIC_TRY(uic_copy_launch(G->att_lstm_b_hh, G->att_lstm_b_ih, (size_t)H4 * 4, s));
     {  // d xt -> embedding table
       UicGemmParams g = gemm_base(dt, Meff, E);
       add_seg(g, L.dg1_all, H4, dv.wxT, H4, H4);
@@ -931,8 +931,8 @@ struct Step {
       a.d_att = L.d_att; a.d_p_att = L.d_patt; a.d_walpha_part = L.dwalpha_part;
       UIC_TRY(uic_attention_bwd_accum_launch(a, s));
       UIC_TRY(uic_colsum_launch(UIC_F32, L.dwalpha_part, N, A + 1, A + 1, L.small, L.colscratch, L.colscratch_floats, s));
-      UIC_TRY(uic_check_hip(hipMemcpyAsync(G->alpha_w, L.small, (size_t)A * 4, hipMemcpyDeviceToDevice, s), "memcpy alpha_w"));
-      UIC_TRY(uic_check_hip(hipMemcpyAsync(G->alpha_b, L.small + A, 4, hipMemcpyDeviceToDevice, s), "memcpy alpha_b"));
+      UIC_TRY(uic_copy_launch(G->alpha_w, L.small, (size_t)A * 4, s));
+      UIC_TRY(uic_copy_launch(G->alpha_b, L.small + A, 4, s));
     }
     if (part == 1) return UIC_OK;
     // ctx2att
@@ -1066,7 +1066,7 @@ int uic_topdown_xe_loss(const uic_topdown_dims* d, const uic_topdown_batch* b, i
   const float* inv = inv_den ? inv_den : st.L.scalars + 1;
   UIC_TRY(st.xe_rows(0, t_run, inv, nullptr, 1, s));
   UIC_TRY(uic_reduce_sum_launch(st.L.row_loss, (size_t)t_run * d->N, 0.f, inv, loss_out, s));
-  if (den_out) UIC_TRY(uic_check_hip(hipMemcpyAsync(den_out, st.L.scalars, 4, hipMemcpyDeviceToDevice, s), "hipMemcpyAsync"));
+  if (den_out) UIC_TRY(uic_copy_launch(den_out, st.L.scalars, 4, s));
   return UIC_OK;
 }
 
@@ -1120,16 +1120,19 @@ int uic_topdown_xe_train_step(const uic_topdown_dims* d, const uic_topdown_weigh
   UIC_HIP(hipStreamWaitEvent(s2, ss->ev_den, 0));
   UIC_TRY(st.fwd_prologue(s));
   UIC_TRY(wait_refresh(s));                           // the recurrence needs the side-stream half of the weight refresh
-  // mode 3 (experiments): the whole recurrence as ONE persistent launch; the logit layer follows chunk by chunk on the side
-  // stream while the main stream already starts the backward prologue
+  // persistent mode 3: the whole recurrence as ONE launch (it holds every CU, nothing overlaps it); the logit layer follows
+  // chunk by chunk on the side stream beside the BPTT loop
   const bool one_launch = st.persist_ok(true);
   if (one_launch) UIC_TRY(st.fwd_steps(0, t_run, s, true));
-  for (int c = 0; c < nchunk; ++c) {
+  for (int i = 0; i < nchunk; ++i) {
+    // after a single launch every step is there at once: the logit layer then takes the chunks LAST FIRST, the order the
+    // BPTT loop consumes them in, so that loop starts after one chunk instead of after all of them
+    const int c = one_launch ? nchunk - 1 - i : i;
     const int t0 = c * CH, t1 = t0 + CH < t_run ? t0 + CH : t_run;
     if (!one_launch) UIC_TRY(st.fwd_steps(t0, t1, s, true));
-    UIC_HIP(hipEventRecord(ss->ev_main[c], s));
+    if (!one_launch || i == 0) UIC_HIP(hipEventRecord(ss->ev_main[c], s));
     // side: logit layer of the chunk, forward and backward-to-h (beside the next chunk's recurrence)
-    UIC_HIP(hipStreamWaitEvent(s2, ss->ev_main[c], 0));
+    if (!one_launch || i == 0) UIC_HIP(hipStreamWaitEvent(s2, ss->ev_main[c], 0));
     UIC_TRY(st.logits_rows(t0, t1, s2));
     UIC_TRY(st.xe_rows(t0, t1, inv, nullptr, 1, s2));
     UIC_TRY(st.dh_rows(t0, t1, s2, true));
@@ -1138,7 +1141,7 @@ int uic_topdown_xe_train_step(const uic_topdown_dims* d, const uic_topdown_weigh
   // side: logit-layer weight gradients + loss reduction, beside the BPTT loop
   UIC_TRY(st.logit_weight_grads(s2, true));
   UIC_TRY(uic_reduce_sum_launch(st.L.row_loss, (size_t)t_run * d->N, 0.f, inv, loss_out, s2));
-  if (den_out) UIC_HIP(hipMemcpyAsync(den_out, st.L.scalars, 4, hipMemcpyDeviceToDevice, s2));
+  if (den_out) UIC_TRY(uic_copy_launch(den_out, st.L.scalars, 4, s2));
   UIC_HIP(hipEventRecord(ss->ev_logit, s2));          // gradient group 0 (logit layer) final: its exchange can start now
   // main: BPTT, each step waits for the d hdrop rows of its chunk; side: the recurrent weight gradients of every
   // finished chunk (transposes + accumulating GEMMs), so only the last chunk's share outlives the loop
@@ -1255,9 +1258,9 @@ int uic_topdown_logprobs_state(const uic_topdown_dims* d, const uic_topdown_weig
   UIC_TRY(uic_cast_f32_launch(dt, p_att, L.patt, N * R * A, s));
   UIC_TRY(uic_cast_f32_launch(dt, h_in, L.s_h_att[0], N * H, s));
   UIC_TRY(uic_cast_f32_launch(dt, h_in + N * H, L.s_h_lang[0], N * H, s));
-  UIC_TRY(uic_check_hip(hipMemcpyAsync(L.s_c_att[0], c_in, N * H * 4, hipMemcpyDeviceToDevice, s), "memcpy c"));
-  UIC_TRY(uic_check_hip(hipMemcpyAsync(L.s_c_lang[0], c_in + N * H, N * H * 4, hipMemcpyDeviceToDevice, s), "memcpy c"));
-  UIC_TRY(uic_check_hip(hipMemcpyAsync(L.s_it, it, N * 8, hipMemcpyDeviceToDevice, s), "memcpy it"));
+  UIC_TRY(uic_copy_launch(L.s_c_att[0], c_in, N * H * 4, s));
+  UIC_TRY(uic_copy_launch(L.s_c_lang[0], c_in + N * H, N * H * 4, s));
+  UIC_TRY(uic_copy_launch(L.s_it, it, N * 8, s));
   uic_topdown_batch b;
   memset(&b, 0, sizeof(b));
   b.att_masks = att_masks;
@@ -1272,8 +1275,8 @@ int uic_topdown_logprobs_state(const uic_topdown_dims* d, const uic_topdown_weig
   UIC_TRY(uic_xe_launch(x, s));
   UIC_TRY(uic_to_f32_launch(dt, L.s_h_att[1], h_out, N * H, s));
   UIC_TRY(uic_to_f32_launch(dt, L.s_h_lang[1], h_out + N * H, N * H, s));
-  UIC_TRY(uic_check_hip(hipMemcpyAsync(c_out, L.s_c_att[1], N * H * 4, hipMemcpyDeviceToDevice, s), "memcpy c"));
-  UIC_TRY(uic_check_hip(hipMemcpyAsync(c_out + N * H, L.s_c_lang[1], N * H * 4, hipMemcpyDeviceToDevice, s), "memcpy c"));
+  UIC_TRY(uic_copy_launch(c_out, L.s_c_att[1], N * H * 4, s));
+  UIC_TRY(uic_copy_launch(c_out + N * H, L.s_c_lang[1], N * H * 4, s));
   (void)S;
   return UIC_OK;
 }
@@ -1286,10 +1289,10 @@ int uic_topdown_beam_done_lists(const uic_topdown_dims* d, void* workspace, int3
   hipStream_t s = (hipStream_t)stream;
   const Layout L = make_layout(*d, workspace);
   const size_t n_img = (size_t)d->N / beam_size, LB = (size_t)Lsteps * beam_size;
-  UIC_TRY(uic_check_hip(hipMemcpyAsync(done_count, L.bm_done_count, n_img * 4, hipMemcpyDeviceToDevice, s), "memcpy done_count"));
-  UIC_TRY(uic_check_hip(hipMemcpyAsync(done_p, L.bm_done_p, n_img * LB * 4, hipMemcpyDeviceToDevice, s), "memcpy done_p"));
-  UIC_TRY(uic_check_hip(hipMemcpyAsync(done_seq, L.bm_done_seq, n_img * LB * Lsteps * 8, hipMemcpyDeviceToDevice, s), "memcpy done_seq"));
-  return uic_check_hip(hipMemcpyAsync(done_lp, L.bm_done_lp, n_img * LB * Lsteps * 4, hipMemcpyDeviceToDevice, s), "memcpy done_lp");
+  UIC_TRY(uic_copy_launch(done_count, L.bm_done_count, n_img * 4, s));
+  UIC_TRY(uic_copy_launch(done_p, L.bm_done_p, n_img * LB * 4, s));
+  UIC_TRY(uic_copy_launch(done_seq, L.bm_done_seq, n_img * LB * Lsteps * 8, s));
+  return uic_copy_launch(done_lp, L.bm_done_lp, n_img * LB * Lsteps * 4, s);
 }
 
 int uic_topdown_sample_beam(const uic_topdown_dims* d, const uic_topdown_weights* w, const void* derived,
