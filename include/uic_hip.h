@@ -182,6 +182,14 @@ int uic_topdown_xe_train_step(const uic_topdown_dims* d, const uic_topdown_weigh
  * start the RCCL all-reduce of the first three pieces on a communication stream as each becomes final; the tail follows on
  * the step's stream.  Enqueue-only (hipStreamWaitEvent), no host sync. */
 int uic_topdown_grad_ready_wait(void* stream, int32_t group);
+/* Timing marks of the last uic_topdown_xe_train_step on this device (diagnostics; off by default, the step records no timing
+ * events then).  enable != 0 switches the marks on for the following steps.  ms_out (optional, UIC_STEP_MARKS floats): waits
+ * for the last marked step and writes, in ms since its first launch: [1] feature projection + batched input GEMMs done,
+ * [2] recurrence done, [3] side stream: logit layer + loss + d hdrop done, [4] BPTT loop starts, [5] BPTT loop done,
+ * [6] side stream: recurrent weight gradients done, [7] main tail (attention accumulation, ctx2att, att_embed) done,
+ * [8] side tail (biases, embedding, fc_embed) done, [9] joined. */
+#define UIC_STEP_MARKS 10
+int uic_topdown_step_marks(int32_t enable, float* ms_out);
 
 /* AttModel._sample with beam_size = 1 (P/models/AttModel.py:198-253): greedy (sample_max = 1) or
  * multinomial decode of `L` <= d->T tokens.  seq [N, L] int64 and seq_logp [N, L] f32 are fully written.

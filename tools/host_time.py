@@ -49,3 +49,20 @@ for phase in ("warm", "run"):
     wall = time.perf_counter() - t0
 print("steps %d: wall %.3f ms/step, host time inside uic_topdown_xe_train_step %.3f ms/call (%d calls)" %
       (args.steps, wall / args.steps * 1e3, acc["t"] / max(acc["n"], 1) * 1e3, acc["n"]))
+
+# where the step's time goes on the GPU: timing marks recorded by the fused step itself (no profiler attached)
+import ctypes as C
+lib.uic_topdown_xe_train_step = real
+L.check(lib.uic_topdown_step_marks(1, None))
+tot = [0.0] * 10
+for _ in range(args.steps):
+    loss, grads = trainer.xe_step(model, batch)
+    loss.item()
+    ms = (C.c_float * 10)()
+    L.check(lib.uic_topdown_step_marks(1, ms))
+    tot = [a + b for a, b in zip(tot, ms)]
+L.check(lib.uic_topdown_step_marks(0, None))
+names = ["start", "prologue done", "recurrence done", "side: logit layer done", "BPTT starts", "BPTT done", "side: recurrent wgrads done",
+         "main tail done", "side tail done", "joined"]
+for n, v in zip(names, tot):
+    print("   %-30s %8.3f ms" % (n, v / args.steps))

@@ -168,6 +168,7 @@ _SIGS = {
     "uic_last_error_string": (C.c_char_p, []),
     "uic_version": (C.c_int, []),
     "uic_set_persistent_rnn": (C.c_int, [C.c_int32]),
+    "uic_topdown_step_marks": (C.c_int, [C.c_int32, C.POINTER(C.c_float)]),
     "uic_set_persistent_status": (C.c_int, [C.c_void_p]),
     "uic_topdown_workspace_bytes": (C.c_size_t, [C.POINTER(Dims)]),
     "uic_topdown_derived_bytes": (C.c_size_t, [C.POINTER(Dims)]),
@@ -259,7 +260,7 @@ def load():
             raise RuntimeError(
                 "libuic_hip.so is not built (%s). Run `python -m unpaired_image_captioning_amd.build`; "
                 "there is no CPU fallback for the captioner hot path." % LIB_PATH)
-        lib = C.CDLL(LIB_PATH)
+        lib = C.CDLL(os.environ.get("UIC_LIB", LIB_PATH))      # UIC_LIB: a variant build to A/B (tools/build_variant.sh)
         for name, (res, args) in _SIGS.items():
             fn = getattr(lib, name)
             fn.restype = res

@@ -19,7 +19,10 @@
 
 namespace {
 
-constexpr int WG_CHUNK = 4;   // decode steps per hand-off between the two streams of the fused training step
+#ifndef UIC_WG_CHUNK
+#define UIC_WG_CHUNK 4
+#endif
+constexpr int WG_CHUNK = UIC_WG_CHUNK;   // decode steps per hand-off between the two streams of the fused training step
 
 struct Layout {
   // forward activations
@@ -397,6 +400,9 @@ struct SideStream {
   hipEvent_t ev_main[MAX_CHUNKS];   // main  -> side: decode steps of chunk c are finished
   hipEvent_t ev_side[MAX_CHUNKS];   // side  -> main: d hdrop of chunk c is ready
   bool ready = false;
+  // uic_topdown_step_marks: timing events of the last fused step (only recorded while marks_on)
+  bool marks_on = false, marks_valid = false;
+  hipEvent_t mark[UIC_STEP_MARKS];
 };
 SideStream g_side[16];
 std::mutex g_side_mutex;   // guards the one-time creation of a device's streams / events (calls themselves are per device:
@@ -421,6 +427,7 @@ int get_side(SideStream** out) {
     UIC_TRY(uic_check_hip(hipEventCreateWithFlags(&ss.ev_lstm, hipEventDisableTiming), "hipEventCreate"));
     UIC_TRY(uic_check_hip(hipEventCreateWithFlags(&ss.ev_r0, hipEventDisableTiming), "hipEventCreate"));
     UIC_TRY(uic_check_hip(hipEventCreateWithFlags(&ss.ev_refresh, hipEventDisableTiming), "hipEventCreate"));
+    for (int i = 0; i < UIC_STEP_MARKS; ++i) UIC_TRY(uic_check_hip(hipEventCreate(&ss.mark[i]), "hipEventCreate"));
     for (int i = 0; i < MAX_CHUNKS; ++i) {
       UIC_TRY(uic_check_hip(hipEventCreateWithFlags(&ss.ev_main[i], hipEventDisableTiming), "hipEventCreate"));
       UIC_TRY(uic_check_hip(hipEventCreateWithFlags(&ss.ev_side[i], hipEventDisableTiming), "hipEventCreate"));
@@ -1112,7 +1119,9 @@ int uic_topdown_xe_train_step(const uic_topdown_dims* d, const uic_topdown_weigh
   const int nchunk = (t_run + CH - 1) / CH;
   UIC_REQUIRE(nchunk <= MAX_CHUNKS, "xe_train_step: too many decode steps (%d)", t_run);
 #define UIC_HIP(expr) UIC_TRY(uic_check_hip((expr), #expr))
+#define UIC_MARK(i, strm) do { if (ss->marks_on) UIC_HIP(hipEventRecord(ss->mark[i], strm)); } while (0)
 
+  UIC_MARK(0, s);
   // main: loss denominator, features, recurrence; hands each finished chunk of steps to the side stream
   if (b->masks) UIC_TRY(uic_masked_sum_launch(nullptr, b->masks, b->ld_masks, 1, d->N, d->T, st.L.scalars, st.L.scalars + 1, s));
   const float* inv = inv_den ? inv_den : st.L.scalars + 1;
@@ -1120,10 +1129,11 @@ int uic_topdown_xe_train_step(const uic_topdown_dims* d, const uic_topdown_weigh
   UIC_HIP(hipStreamWaitEvent(s2, ss->ev_den, 0));
   UIC_TRY(st.fwd_prologue(s));
   UIC_TRY(wait_refresh(s));                           // the recurrence needs the side-stream half of the weight refresh
+  UIC_MARK(1, s);
   // persistent mode 3: the whole recurrence as ONE launch (it holds every CU, nothing overlaps it); the logit layer follows
   // chunk by chunk on the side stream beside the BPTT loop
   const bool one_launch = st.persist_ok(true);
-  if (one_launch) UIC_TRY(st.fwd_steps(0, t_run, s, true));
+  if (one_launch) { UIC_TRY(st.fwd_steps(0, t_run, s, true)); UIC_MARK(2, s); }
   for (int i = 0; i < nchunk; ++i) {
     // after a single launch every step is there at once: the logit layer then takes the chunks LAST FIRST, the order the
     // BPTT loop consumes them in, so that loop starts after one chunk instead of after all of them
@@ -1138,6 +1148,8 @@ int uic_topdown_xe_train_step(const uic_topdown_dims* d, const uic_topdown_weigh
     UIC_TRY(st.dh_rows(t0, t1, s2, true));
     UIC_HIP(hipEventRecord(ss->ev_side[c], s2));
   }
+  if (!one_launch) UIC_MARK(2, s);
+  UIC_MARK(3, s2);                                    // side: the logit layer (forward, loss, d hdrop) is through
   // side: logit-layer weight gradients + loss reduction, beside the BPTT loop
   UIC_TRY(st.logit_weight_grads(s2, true));
   UIC_TRY(uic_reduce_sum_launch(st.L.row_loss, (size_t)t_run * d->N, 0.f, inv, loss_out, s2));
@@ -1149,6 +1161,7 @@ int uic_topdown_xe_train_step(const uic_topdown_dims* d, const uic_topdown_weigh
   for (int c = nchunk - 1; c >= 0; --c) {
     const int t0 = c * CH, t1 = t0 + CH < t_run ? t0 + CH : t_run;
     UIC_HIP(hipStreamWaitEvent(s, ss->ev_side[c], 0));
+    if (c == nchunk - 1) UIC_MARK(4, s);              // main: BPTT starts
     for (int t = t1 - 1; t >= t0; --t) UIC_TRY(st.bwd_step(t, s));
     UIC_HIP(hipEventRecord(ss->ev_main[c], s));       // (the forward's use of ev_main[c] was consumed long ago)
     UIC_HIP(hipStreamWaitEvent(s2, ss->ev_main[c], 0));
@@ -1156,13 +1169,35 @@ int uic_topdown_xe_train_step(const uic_topdown_dims* d, const uic_topdown_weigh
   }
   // side: the rest of the early gradient group (LSTM / h2att biases, embedding, fc_embed); main: the late group
   // (attention accumulation, ctx2att, att_embed).  ev_early: the early group, the logit layer and the loss are final.
+  UIC_MARK(5, s);                                     // main: BPTT done
   UIC_HIP(hipEventRecord(ss->ev_lstm, s2));           // gradient group 1 (lang_lstm.weight_*, att_lstm.weight_hh) final
+  UIC_MARK(6, s2);                                    // side: recurrent weight gradients done
+  UIC_TRY(st.bwd_epilogue_late(s, true));             // (enqueued first: it is the longer of the two tails)
+  UIC_MARK(7, s);
   UIC_TRY(st.bwd_epilogue_early(s2, true, true));
   UIC_HIP(hipEventRecord(ss->ev_early, s2));
   ss->early_recorded = true;
-  UIC_TRY(st.bwd_epilogue_late(s, true));
+  UIC_MARK(8, s2);
   UIC_HIP(hipStreamWaitEvent(s, ss->ev_early, 0));    // join
+  UIC_MARK(9, s);
+  ss->marks_valid = ss->marks_on;
+#undef UIC_MARK
 #undef UIC_HIP
+  return UIC_OK;
+}
+
+int uic_topdown_step_marks(int32_t enable, float* ms_out) {
+  SideStream* ss = nullptr;
+  UIC_TRY(get_side(&ss));
+  if (ms_out) {
+    UIC_REQUIRE(ss->marks_valid, "step_marks: no fused step has run with the marks enabled");
+    UIC_TRY(uic_check_hip(hipEventSynchronize(ss->mark[UIC_STEP_MARKS - 1]), "hipEventSynchronize"));
+    UIC_TRY(uic_check_hip(hipEventSynchronize(ss->mark[8]), "hipEventSynchronize"));
+    ms_out[0] = 0.f;
+    for (int i = 1; i < UIC_STEP_MARKS; ++i) UIC_TRY(uic_check_hip(hipEventElapsedTime(&ms_out[i], ss->mark[0], ss->mark[i]), "hipEventElapsedTime"));
+  }
+  ss->marks_on = enable != 0;
+  if (!ss->marks_on) ss->marks_valid = false;
   return UIC_OK;
 }
 
