@@ -10,8 +10,9 @@ full BPTT, [RCCL all-reduce of the flat gradient arena], Adam, weight-copy refre
     python bench.py --gpus 1 --steps 20 --warmup 5
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` (attention-step
-kernel, HBM-bound) and, at N=1, `cpu_baseline` (the CPU oracle timed on this host's cores).
+Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` (the persistent
+recurrence kernel; `roofline_attention_step` = the stand-alone attention kernel, HBM-bound; `roofline_mfma` = the large
+GEMM) and, at N=1, `cpu_baseline` (the CPU oracle timed on this host's cores).
 """
 import argparse
 import json
@@ -102,6 +103,56 @@ def attention_roofline(dtype_id, dtype_name, iters=64, pool=8):
 
 
 MFMA_PEAK_TFLOPS = {"bf16": 2500.0, "f32": 157.3}     # dense peaks (MI355X_MICROARCH.md)
+
+
+def recurrence_roofline(tr, batch, t_run, den_local, dtype_name, extra_steps=6):
+    """The dominant single launch of the step since round 2: the persistent recurrence kernel (csrc/rnn_persist.hip), ONE
+    launch = all t_run decode steps of all caption rows (att_lstm, h2att, attention, lang_lstm; AttModel.py:129-154).
+    Duration: HIP timing events the fused step itself records on the stream the kernel is launched on
+    (uic_topdown_step_marks: mark[2] - mark[1]), over `extra_steps` UNTIMED extra training steps run after the timed region.
+    Algorithmic bytes per launch = SURVEY.md 8(d)'s attention-step figure (R*A + R*H + 2H + R) * sizeof per (row, step)
+    x the N * t_run units of the launch.  Returns None when the step did not use the persistent kernel."""
+    import ctypes as C
+    from unpaired_image_captioning_amd import _lib as L
+    lib = L.load()
+    c = CFG
+    before = L.persistent_status()
+    L.check(lib.uic_topdown_step_marks(1, None))
+    durs = []
+    try:
+        for _ in range(extra_steps):
+            tr.train_device_batch(batch, t_run, den_local)
+            ms = (C.c_float * 10)()
+            L.check(lib.uic_topdown_step_marks(1, ms))
+            durs.append((ms[2] - ms[1]) * 1e-3)
+    finally:
+        L.check(lib.uic_topdown_step_marks(0, None))
+    after = L.persistent_status()
+    if (after[1] + after[2]) - (before[1] + before[2]) < extra_steps:
+        return None
+    durs = sorted(durs)[1:-1] if len(durs) > 4 else durs
+    dur = sum(durs) / len(durs)
+    N, R, A, H = batch["labels"].shape[0], c["R"], c["A"], c["H"]
+    es = 2 if dtype_name == "bf16" else 4
+    units = N * t_run
+    bytes_per_unit = (R * A + R * H + 2 * H + R) * es
+    flops_per_unit = 2.0 * (2 * H * 4 * H + H * A + 3 * H * 4 * H) + 2.0 * (R * A + R * H)   # att_lstm (recurrent inputs), h2att, lang_lstm, scores + context
+    achieved = units * bytes_per_unit / dur / 1e9
+    traffic = None
+    try:
+        with open(os.path.join(ROOT, "profiles", "rnn_persist_pmc_%s.json" % dtype_name)) as f:
+            traffic = json.load(f)["traffic_bytes_per_launch"]
+    except (OSError, KeyError, ValueError):
+        pass
+    return {"bound": "hbm", "kernel": "rnn_fwd_persist_%skernel (one launch = %d decode steps x %d caption rows: att_lstm, h2att, attention, lang_lstm)" % ("ws_" if dtype_name == "bf16" else "", t_run, N),
+            "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
+            "traffic": traffic,
+            "traffic_source": "profiles/rnn_persist_pmc_%s.json (committed rocprofv3 PMC passes of this kernel, NOT measured in this run)" % dtype_name if traffic else None,
+            "units_per_launch": units, "bytes_per_unit": bytes_per_unit, "bytes_per_launch": units * bytes_per_unit,
+            "us_per_launch": round(dur * 1e6, 1), "us_per_decode_step": round(dur * 1e6 / t_run, 2),
+            "mfma_tflops": round(units * flops_per_unit / dur / 1e12, 1), "mfma_frac": round(units * flops_per_unit / dur / 1e12 / MFMA_PEAK_TFLOPS[dtype_name], 4),
+            "note": "a chain of t_run dependent steps x 4 chip-wide exchanges: bound by exchange latency and the XCD-L2 operand broadcast (DESIGN.md 4), "
+                    "neither by HBM nor by MFMA; the per-(row, step) attention bytes re-read p_att / att' from the 256 MiB Infinity Cache after the first step"}
 
 
 def gemm_roofline(dtype_id, dtype_name, iters=32):
@@ -275,6 +326,7 @@ def main():
         elapsed_img, _ = timed(per_image)
     loss_val = float(loss.item())
     L.persistent_status()                                      # raises if a persistent-kernel spin timed out
+    rec_roof = recurrence_roofline(tr, batch, t_run, den_local, args.dtype)   # untimed extra steps, every rank (collectives stay matched)
     f32_line = None
     if world == 1 and args.dtype != "f32" and not args.no_f32:
         # the reference's own precision (exact-f32 MFMA parity path): same step, same batch, a few iterations
@@ -315,9 +367,16 @@ def main():
                        "features": args.features},
             "final_loss": round(loss_val, 4),
             "rccl_ranks": dist.get_world_size() if (world > 1 and dist.get_backend() == "nccl") else (1 if world == 1 else 0),
-            "roofline": attention_roofline(dtype_id, args.dtype),
             "roofline_mfma": gemm_roofline(dtype_id, args.dtype),
         }
+        # `roofline`: the dominant single launch of the timed region -- the persistent recurrence kernel when the step uses it;
+        # the stand-alone attention-step kernel (decode paths, per-step launch chain) is reported beside it
+        att_roof = attention_roofline(dtype_id, args.dtype)
+        if rec_roof is not None:
+            out["roofline"] = rec_roof
+            out["roofline_attention_step"] = att_roof
+        else:
+            out["roofline"] = att_roof
         if f32_line is not None:
             out["f32"] = f32_line
         if elapsed_img is not None:

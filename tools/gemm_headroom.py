@@ -1,0 +1,47 @@
+#!/usr/bin/env python3
+"""How far the hot path's GEMM shapes are from what the vendor library reaches on the same GPU: torch.matmul (hipBLASLt /
+rocBLAS) vs libuic_hip's kernels, bf16 operands, one HIP event pair per launch, trimmed mean.  Diagnostic only."""
+import os
+import sys
+import ctypes as C
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch
+from unpaired_image_captioning_amd import _lib as L
+
+lib = L.load()
+
+
+def timeit(fn, iters=24):
+    for _ in range(4):
+        fn()
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(iters)]
+    for a, b in ev:
+        a.record(); fn(); b.record()
+    torch.cuda.synchronize()
+    d = sorted(a.elapsed_time(b) for a, b in ev)
+    return sum(d[iters // 8: iters - iters // 8]) / (iters - 2 * (iters // 8)) * 1e3   # us
+
+
+g = torch.Generator(device="cuda").manual_seed(3)
+print("%-44s %10s %10s %10s %10s" % ("NT shape  C[M,N] = A[M,K] B[N,K]^T", "lib us", "lib TF/s", "uic us", "uic TF/s"))
+for name, M, N, K in [("logit fwd chunk", 2560, 9488, 512), ("att_embed fwd", 23040, 512, 2048), ("ctx2att fwd", 23040, 512, 512),
+                      ("Gx batched input GEMM", 10880, 2048, 1024), ("d xt", 10880, 512, 2048), ("logit dX chunk", 2560, 512, 9536),
+                      ("BPTT d x2 (one step)", 640, 1536, 2048), ("BPTT d x1 (one step)", 640, 1024, 2048), ("BPTT h2att (one step)", 640, 512, 512)]:
+    A = torch.randn(M, K, device="cuda", generator=g).bfloat16()
+    B = torch.randn(N, K, device="cuda", generator=g).bfloat16()
+    ldc = (N + 63) // 64 * 64
+    Cu = torch.empty(M, ldc, device="cuda", dtype=torch.float32)
+    bias = torch.zeros(N, device="cuda")
+    t_lib = timeit(lambda: torch.matmul(A, B.t()))
+    t_uic = timeit(lambda: L.check(lib.uic_linear(1, M, N, K, L.ptr(A), K, L.ptr(B), K, L.ptr(Cu), ldc, L.ptr(bias), 4, L.stream())))
+    fl = 2.0 * M * N * K
+    print("%-44s %10.1f %10.1f %10.1f %10.1f" % ("%s %dx%dx%d" % (name, M, N, K), t_lib, fl / t_lib / 1e6, t_uic, fl / t_uic / 1e6))
+print("%-44s %10s %10s" % ("TN shape  C[M,N] = A[K,M]^T B[K,N]", "lib us", "lib TF/s"))
+for name, M, N, K in [("logit dW", 9488, 512, 10880), ("LSTM dW chunk", 2048, 1536, 2560), ("LSTM dW all steps", 2048, 1536, 10880),
+                      ("att_embed dW (folded)", 512, 2048, 4608), ("ctx2att dW", 512, 512, 23040)]:
+    A = torch.randn(K, M, device="cuda", generator=g).bfloat16()
+    B = torch.randn(K, N, device="cuda", generator=g).bfloat16()
+    t_lib = timeit(lambda: torch.matmul(A.t(), B))
+    fl = 2.0 * M * N * K
+    print("%-44s %10.1f %10.1f" % ("%s %dx%dx%d" % (name, M, N, K), t_lib, fl / t_lib / 1e6))

@@ -1,14 +1,14 @@
 #!/bin/bash
 # One measurement pass on the GPU box (profiles/README.md): bench line, kernel stats, PMC traffic of the attention kernel, MFMA-busy.
-# Run as: gpurun -- bash tools/measure_pass.sh   (outputs under gpurun_out/v9; copy what is to be judged into profiles/)
+# Run as: gpurun -- bash tools/measure_pass.sh   (outputs under gpurun_out/pass; copy what is to be judged into profiles/)
 set -x
 R=$GRAFT_REPO_ROOT
-O=$R/gpurun_out/v9
+O=$R/gpurun_out/pass
 mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
 timeout 400 python3 $R/bench.py > $O/bench.json 2> $O/bench.err
 tail -c 600 $O/bench.json
-timeout 500 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/p6 -- python3 $R/bench.py --steps 10 --warmup 3 --no-cpu-baseline > /tmp/p6.log 2>&1
+timeout 500 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/p6 -- python3 $R/bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-f32 > /tmp/p6.log 2>&1
 python3 $R/tools/prof_summary.py /tmp/p6 26 45 > $O/bench_summary.txt 2>&1
 grep '"metric"' /tmp/p6.log | tail -1 > $O/bench_under_rocprof.json   # the same process's own HIP-event figures
 cp $(find /tmp/p6 -name "*kernel_stats.csv" | head -1) $O/bench_kernel_stats.csv
@@ -17,8 +17,20 @@ timeout 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d /tm
 python3 $R/tools/pmc_traffic.py /tmp/pm attn_fwd_fast_kernel $O/attn_fwd_pmc_bf16.json
 cp $(find /tmp/pm/fetch -name "*counter_collection.csv" | head -1) $O/attn_fwd_pmc_fetch.csv
 cp $(find /tmp/pm/write -name "*counter_collection.csv" | head -1) $O/attn_fwd_pmc_write.csv
-timeout 400 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d /tmp/mf -- python3 $R/bench.py --steps 4 --warmup 2 --no-cpu-baseline > /tmp/mf.log 2>&1
+timeout 400 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d /tmp/mf -- python3 $R/bench.py --steps 4 --warmup 2 --no-cpu-baseline --no-f32 > /tmp/mf.log 2>&1
 python3 $R/tools/pmc_mfma.py /tmp/mf 12 > $O/mfma_busy.txt 2>&1
 head -12 $O/mfma_busy.txt
 tail -5 $O/bench_summary.txt
 cat $O/attn_fwd_pmc_bf16.json
+# where the fused step's time goes without a profiler attached (timing marks recorded by the step itself) and the host time of its C call
+timeout 200 python3 $R/tools/host_time.py > $O/step_marks.txt 2>&1
+tail -11 $O/step_marks.txt
+# persistent recurrence kernel: phase stamps, parity against the per-step launch chain, forward time in modes 0 / 1 / 2
+timeout 200 python3 $R/tools/rnn_persist_probe.py --dbg > $O/rnn_persist_probe.txt 2>&1
+grep -E "phase|step  |forward" $O/rnn_persist_probe.txt
+timeout 200 python3 $R/tools/gemm_headroom.py > $O/gemm_headroom.txt 2>&1
+# HBM traffic of the persistent recurrence kernel (separate PMC passes, same corrections as for the attention kernel)
+timeout 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d /tmp/pr/fetch -- python3 $R/tools/rnn_kernel_only.py > /tmp/prf.log 2>&1
+timeout 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d /tmp/pr/write -- python3 $R/tools/rnn_kernel_only.py > /tmp/prw.log 2>&1
+tail -2 /tmp/prf.log
+python3 $R/tools/pmc_traffic.py /tmp/pr rnn_fwd_persist $O/rnn_persist_pmc_bf16.json
