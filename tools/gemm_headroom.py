@@ -37,11 +37,17 @@ for name, M, N, K in [("logit fwd chunk", 2560, 9488, 512), ("att_embed fwd", 23
     t_uic = timeit(lambda: L.check(lib.uic_linear(1, M, N, K, L.ptr(A), K, L.ptr(B), K, L.ptr(Cu), ldc, L.ptr(bias), 4, L.stream())))
     fl = 2.0 * M * N * K
     print("%-44s %10.1f %10.1f %10.1f %10.1f" % ("%s %dx%dx%d" % (name, M, N, K), t_lib, fl / t_lib / 1e6, t_uic, fl / t_uic / 1e6))
-print("%-44s %10s %10s" % ("TN shape  C[M,N] = A[K,M]^T B[K,N]", "lib us", "lib TF/s"))
+print("%-44s %10s %10s %10s %10s" % ("TN shape  C[M,N] = A[K,M]^T B[K,N]", "lib us", "lib TF/s", "uic us", "uic TF/s"))
+wsb = 64 << 20
+wsp = torch.empty(wsb, dtype=torch.uint8, device="cuda")
 for name, M, N, K in [("logit dW", 9488, 512, 10880), ("LSTM dW chunk", 2048, 1536, 2560), ("LSTM dW all steps", 2048, 1536, 10880),
                       ("att_embed dW (folded)", 512, 2048, 4608), ("ctx2att dW", 512, 512, 23040)]:
     A = torch.randn(K, M, device="cuda", generator=g).bfloat16()
     B = torch.randn(K, N, device="cuda", generator=g).bfloat16()
     t_lib = timeit(lambda: torch.matmul(A.t(), B))
+    dW = torch.empty(M, N, device="cuda", dtype=torch.float32)
+    t_uic = timeit(lambda: L.check(lib.uic_linear_wgrad(1, M, N, K, L.ptr(A), M, L.ptr(B), N, L.ptr(dW), N, L.ptr(wsp), wsb, 0, L.stream())))
+    ref = torch.matmul(A.t().float(), B.float())
+    err = float((dW - ref).abs().max() / ref.abs().max())
     fl = 2.0 * M * N * K
-    print("%-44s %10.1f %10.1f" % ("%s %dx%dx%d" % (name, M, N, K), t_lib, fl / t_lib / 1e6))
+    print("%-44s %10.1f %10.1f %10.1f %10.1f   max rel err %.1e" % ("%s %dx%dx%d" % (name, M, N, K), t_lib, fl / t_lib / 1e6, t_uic, fl / t_uic / 1e6, err))

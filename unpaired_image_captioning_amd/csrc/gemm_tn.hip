@@ -18,14 +18,21 @@
 //    slices in a fixed order and scatters column ranges to their destinations (deterministic).
 #include "uic_common.h"
 #include <type_traits>
+#include <stdlib.h>
+
+thread_local int g_uic_tn_ring_off = 0;
 
 namespace {
 
 typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
 typedef __attribute__((ext_vector_type(4))) unsigned u32x4v;
 
+// NS = LDS stages (32 KB each).  2: one K round in flight behind the one being multiplied, two workgroups per CU.  4: three
+// rounds in flight with counted vmcnt waits, one workgroup per CU -- for grids of at most one workgroup per CU (the 4-step
+// weight-gradient chunks: 192 tiles), where nothing else hides the global -> LDS latency of a round.
+template <int NS>
 __global__ __launch_bounds__(256) void uic_gemm_tn_kernel(const UicGemmTnParams p) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];   // [2][A 16 KB | B 16 KB]
+  extern __shared__ __attribute__((aligned(16))) char smem[];   // [NS][A 16 KB | B 16 KB]
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -87,7 +94,9 @@ __global__ __launch_bounds__(256) void uic_gemm_tn_kernel(const UicGemmTnParams 
   // K step is an immediate offset (4096 B per 16 k-rows) and so is the stage buffer (32768 B).
   const int g = lane >> 4, khalf = g >> 1, colblk = g & 1, q = (lane & 15) >> 2, pp = lane & 3;
   const unsigned lds0 = (unsigned)(size_t)((__attribute__((address_space(3))) char*)smem);
-  unsigned adA[2][2], adB[2][2];
+  // (the DS offset field is 16 bits: buffers 2 and 3 of the 4-stage ring get their own base registers, 64 KB up)
+  constexpr int NHI = NS / 2;
+  unsigned adAx[NHI][2][2], adBx[NHI][2][2];
 #pragma unroll
   for (int ti = 0; ti < 2; ++ti)
 #pragma unroll
@@ -96,17 +105,20 @@ __global__ __launch_bounds__(256) void uic_gemm_tn_kernel(const UicGemmTnParams 
       const int f = (q << 2) | (khalf * 2 + h);
       const int ca = ((wm * 64 + ti * 32 + colblk * 16) >> 3) + (pp >> 1);
       const int cb = ((wn * 64 + ti * 32 + colblk * 16) >> 3) + (pp >> 1);
-      adA[ti][h] = lds0 + (unsigned)(256 * r + 16 * (ca ^ f) + 8 * (pp & 1));
-      adB[ti][h] = lds0 + 16384u + (unsigned)(256 * r + 16 * (cb ^ f) + 8 * (pp & 1));
+#pragma unroll
+      for (int hi = 0; hi < NHI; ++hi) {
+        adAx[hi][ti][h] = lds0 + (unsigned)(hi * 65536) + (unsigned)(256 * r + 16 * (ca ^ f) + 8 * (pp & 1));
+        adBx[hi][ti][h] = lds0 + (unsigned)(hi * 65536) + 16384u + (unsigned)(256 * r + 16 * (cb ^ f) + 8 * (pp & 1));
+      }
     }
 
 #define TN_RD(dst, addr, off) asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(off))
 #define TN_ISSUE_A(S, KS, BO)                                                             \
-  TN_RD(S##a0l, adA[0][0], BO + KS * 4096); TN_RD(S##a0h, adA[0][1], BO + KS * 4096);     \
-  TN_RD(S##a1l, adA[1][0], BO + KS * 4096); TN_RD(S##a1h, adA[1][1], BO + KS * 4096)
+  TN_RD(S##a0l, adAx[HI][0][0], BO + KS * 4096); TN_RD(S##a0h, adAx[HI][0][1], BO + KS * 4096);     \
+  TN_RD(S##a1l, adAx[HI][1][0], BO + KS * 4096); TN_RD(S##a1h, adAx[HI][1][1], BO + KS * 4096)
 #define TN_ISSUE_B(S, KS, BO)                                                             \
-  TN_RD(S##b0l, adB[0][0], BO + KS * 4096); TN_RD(S##b0h, adB[0][1], BO + KS * 4096);     \
-  TN_RD(S##b1l, adB[1][0], BO + KS * 4096); TN_RD(S##b1h, adB[1][1], BO + KS * 4096)
+  TN_RD(S##b0l, adBx[HI][0][0], BO + KS * 4096); TN_RD(S##b0h, adBx[HI][0][1], BO + KS * 4096);     \
+  TN_RD(S##b1l, adBx[HI][1][0], BO + KS * 4096); TN_RD(S##b1h, adBx[HI][1][1], BO + KS * 4096)
 #define TN_WAIT(N, S)                                                                                              \
   asm volatile("s_waitcnt lgkmcnt(" #N ")"                                                                         \
                : "+v"(S##a0l), "+v"(S##a0h), "+v"(S##a1l), "+v"(S##a1h), "+v"(S##b0l), "+v"(S##b0h), "+v"(S##b1l), "+v"(S##b1h)); \
@@ -121,7 +133,7 @@ __global__ __launch_bounds__(256) void uic_gemm_tn_kernel(const UicGemmTnParams 
   } while (0)
   // two register sets (x: even K steps, y: odd); at most 12 LDS reads outstanding (lgkmcnt is a 4-bit counter)
   auto compute = [&](auto bufc) {
-    constexpr int BO = decltype(bufc)::value * 32768;
+    constexpr int BO = (decltype(bufc)::value & 1) * 32768, HI = decltype(bufc)::value >> 1;
     u32x2 xa0l, xa0h, xa1l, xa1h, xb0l, xb0h, xb1l, xb1h, ya0l, ya0h, ya1l, ya1h, yb0l, yb0h, yb1l, yb1h;
     TN_ISSUE_A(x, 0, BO); TN_ISSUE_B(x, 0, BO);
     TN_ISSUE_A(y, 1, BO);
@@ -145,17 +157,43 @@ __global__ __launch_bounds__(256) void uic_gemm_tn_kernel(const UicGemmTnParams 
 #undef TN_ISSUE_B
 #undef TN_ISSUE_A
 #undef TN_RD
-  if (nt > 0) stage(kt0, 0);
-  for (int t = 0; t < nt; t += 2) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    if (t + 1 < nt) stage(kt0 + t + 1, 1);
-    compute(std::integral_constant<int, 0>{});
-    if (t + 1 < nt) {
+  if constexpr (NS == 2) {
+    if (nt > 0) stage(kt0, 0);
+    for (int t = 0; t < nt; t += 2) {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();
-      if (t + 2 < nt) stage(kt0 + t + 2, 0);
-      compute(std::integral_constant<int, 1>{});
+      if (t + 1 < nt) stage(kt0 + t + 1, 1);
+      compute(std::integral_constant<int, 0>{});
+      if (t + 1 < nt) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (t + 2 < nt) stage(kt0 + t + 2, 0);
+        compute(std::integral_constant<int, 1>{});
+      }
+    }
+  } else {
+    static_assert(NS == 4, "ring written for 4 stages");
+    // Ring of 4 buffers, 3 rounds in flight.  A round's 8 LDS-DMA loads per lane are retired by a COUNTED vmcnt (16 = the two
+    // younger rounds may still be in flight), then the barrier makes every wave's share visible; the round issued now goes
+    // into the buffer read LAST round (all waves are past that read once they are past this barrier).
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+      if (i < nt) stage(kt0 + i, i);
+    auto round = [&](int r, auto jc) {
+      constexpr int J = decltype(jc)::value;
+      const int younger = nt - 1 - r;        // rounds issued after r that are still allowed to be in flight: min(2, younger)
+      if (younger >= 2) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+      else if (younger == 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      if (r + 3 < nt) stage(kt0 + r + 3, (J + 3) & 3);
+      compute(std::integral_constant<int, J>{});
+    };
+    for (int t = 0; t < nt; t += 4) {
+      round(t, std::integral_constant<int, 0>{});
+      if (t + 1 < nt) round(t + 1, std::integral_constant<int, 1>{});
+      if (t + 2 < nt) round(t + 2, std::integral_constant<int, 2>{});
+      if (t + 3 < nt) round(t + 3, std::integral_constant<int, 3>{});
     }
   }
 
@@ -248,12 +286,19 @@ int uic_gemm_tn_launch(const UicGemmTnParams& p, hipStream_t s) {
   UIC_REQUIRE(p.splitk >= 1 && (p.slab || (p.splitk == 1 && p.ndst > 0)), "gemm_tn: needs a slab (or direct destinations with splitk == 1)");
   static bool configured = false;
   if (!configured) {
-    UIC_TRY(uic_check_hip(hipFuncSetAttribute((const void*)uic_gemm_tn_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 65536),
+    UIC_TRY(uic_check_hip(hipFuncSetAttribute((const void*)uic_gemm_tn_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536),
                           "hipFuncSetAttribute(gemm tn)"));
+    UIC_TRY(uic_check_hip(hipFuncSetAttribute((const void*)uic_gemm_tn_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072),
+                          "hipFuncSetAttribute(gemm tn, 4 stages)"));
     configured = true;
   }
   dim3 grid((p.M + 127) / 128, (p.N + 127) / 128, p.splitk);
-  hipLaunchKernelGGL(uic_gemm_tn_kernel, grid, dim3(256), 65536, s, p);
+  const int ring_max = g_uic_tn_ring_off ? 0 : 256;     // workgroups: at most one per CU
+  const long wgs = (long)grid.x * grid.y * grid.z;
+  if (wgs <= ring_max && p.K / 64 / (p.splitk > 1 ? p.splitk : 1) >= 8)
+    hipLaunchKernelGGL(uic_gemm_tn_kernel<4>, grid, dim3(256), 131072, s, p);
+  else
+    hipLaunchKernelGGL(uic_gemm_tn_kernel<2>, grid, dim3(256), 65536, s, p);
   UIC_LAUNCH_CHECK("uic_gemm_tn_kernel");
   return UIC_OK;
 }

@@ -1151,6 +1151,9 @@ int uic_topdown_xe_train_step(const uic_topdown_dims* d, const uic_topdown_weigh
   if (!one_launch) UIC_MARK(2, s);
   UIC_MARK(3, s2);                                    // side: the logit layer (forward, loss, d hdrop) is through
   // side: logit-layer weight gradients + loss reduction, beside the BPTT loop
+  // (weight-gradient GEMMs that run beside the BPTT loop keep the 2-stage kernel: the 4-stage ring's 128 KB of LDS would
+  // keep the loop's 74-KB workgroups off its CUs -- measured 3.89 -> 3.99 ms)
+  g_uic_tn_ring_off = 1;
   UIC_TRY(st.logit_weight_grads(s2, true));
   UIC_TRY(uic_reduce_sum_launch(st.L.row_loss, (size_t)t_run * d->N, 0.f, inv, loss_out, s2));
   if (den_out) UIC_TRY(uic_copy_launch(den_out, st.L.scalars, 4, s2));
@@ -1169,6 +1172,7 @@ int uic_topdown_xe_train_step(const uic_topdown_dims* d, const uic_topdown_weigh
   }
   // side: the rest of the early gradient group (LSTM / h2att biases, embedding, fc_embed); main: the late group
   // (attention accumulation, ctx2att, att_embed).  ev_early: the early group, the logit layer and the loss are final.
+  g_uic_tn_ring_off = 0;
   UIC_MARK(5, s);                                     // main: BPTT done
   UIC_HIP(hipEventRecord(ss->ev_lstm, s2));           // gradient group 1 (lang_lstm.weight_*, att_lstm.weight_hh) final
   UIC_MARK(6, s2);                                    // side: recurrent weight gradients done

@@ -139,6 +139,10 @@ __device__ __forceinline__ float uic_wave_max(float v) {
 }
 #endif  // __HIPCC__
 
+// gemm_tn.hip: set (by the calling host thread, around its launches) to keep uic_gemm_tn_launch on the 2-stage kernel even
+// for grids of at most one workgroup per CU -- for launches that must share CUs with another stream's LDS-heavy workgroups
+extern thread_local int g_uic_tn_ring_off;
+
 // ---------------------------------------------------------------- GEMM (gemm.hip)
 #define UIC_GEMM_RELU 1      // v = max(v, 0)
 #define UIC_GEMM_ACCUM 2     // C += v
