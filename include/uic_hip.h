@@ -342,6 +342,18 @@ size_t uic_nmt_translate_workspace_bytes(const uic_nmt_dims* d, int32_t beam_siz
 int uic_nmt_translate(const uic_nmt_dims* d, const uic_nmt_weights* w, const int64_t* src, int32_t beam_size, int32_t max_steps,
                       void* workspace, int64_t* hyp_out, float* score_out, float* attn_out, int32_t* n_iter_out, void* stream);
 
+/* ---- data-parallel gradient exchange on RCCL (replaces DataParallel's reduce-add, P/trainer.py:74,88-89), for callers
+ * that do not use torch.distributed.  librccl is dlopen()ed on first use.  uic_comm_unique_id: rank 0 obtains the 128-byte
+ * rendezvous id and hands it to every rank out of band (file, socket, MPI, a torch store); uic_comm_init: collective over all
+ * `world` ranks, each on ITS current device (one process per GPU); uic_comm_allreduce: in-place sum of `count` elements
+ * (UIC_F32 or UIC_BF16) on `stream`, enqueue only -- e.g. the flat gradient arena after uic_topdown_grad_ready_wait.
+ * Errors: 1000 + ncclResult_t. ---- */
+#define UIC_COMM_ID_BYTES 128
+int uic_comm_unique_id(void* id_out);
+int uic_comm_init(int32_t rank, int32_t world, const void* id, void** comm_out);
+int uic_comm_allreduce(void* comm, void* buf, size_t count, int32_t dtype, void* stream);
+int uic_comm_destroy(void* comm);
+
 /* ---- single operators (also used by the parity tests) ---- */
 
 /* nn.Linear as C[M,N] = A[M,K] B[N,K]^T (+bias)(+ReLU); flags: 1 ReLU, 2 accumulate into C, 4 C is f32. */

@@ -97,3 +97,26 @@ def test_two_ranks_over_rccl_match_single_process(tmp_path):
     world = 2
     mp.spawn(_worker, args=(world, _free_port(), str(tmp_path), "nccl"), nprocs=world, join=True)
     _check_against_single_process(tmp_path)
+
+
+def test_uic_comm_single_rank_rccl():
+    """uic_comm_* (include/uic_hip.h): RCCL through libuic_hip's own C-ABI entry points, no torch.distributed.  With one GPU per
+    box only a world of 1 can be formed: unique id, communicator, in-place all-reduce (identity for one rank) of an f32 and a
+    bf16 buffer on the current stream, destroy; and the exchange object the Trainer takes."""
+    import torch
+    from unpaired_image_captioning_amd.parallel_exchange import UicCommExchange
+    uid = UicCommExchange.new_unique_id()
+    assert len(uid) == 128 and any(uid)
+    ex = UicCommExchange(0, 1, uid)
+    try:
+        g = torch.Generator(device="cuda").manual_seed(5)
+        a = torch.randn(1 << 20, device="cuda", generator=g)
+        b = torch.randn(4099, device="cuda", generator=g).bfloat16()
+        a0, b0 = a.clone(), b.clone()
+        ex._sum(a)
+        ex._sum(b)
+        torch.cuda.synchronize()
+        assert torch.equal(a, a0) and torch.equal(b, b0)
+        assert ex.world_size == 1 and ex.rank == 0 and ex.allreduce_sum(a) is a
+    finally:
+        ex.close()

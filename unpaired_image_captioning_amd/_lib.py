@@ -168,6 +168,10 @@ _SIGS = {
     "uic_last_error_string": (C.c_char_p, []),
     "uic_version": (C.c_int, []),
     "uic_set_persistent_rnn": (C.c_int, [C.c_int32]),
+    "uic_comm_unique_id": (C.c_int, [C.c_void_p]),
+    "uic_comm_init": (C.c_int, [C.c_int32, C.c_int32, C.c_void_p, C.POINTER(C.c_void_p)]),
+    "uic_comm_allreduce": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int32, C.c_void_p]),
+    "uic_comm_destroy": (C.c_int, [C.c_void_p]),
     "uic_topdown_step_marks": (C.c_int, [C.c_int32, C.POINTER(C.c_float)]),
     "uic_set_persistent_status": (C.c_int, [C.c_void_p]),
     "uic_topdown_workspace_bytes": (C.c_size_t, [C.POINTER(Dims)]),

@@ -10,7 +10,7 @@ import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
-SOURCES = ["api.hip", "gemm.hip", "gemm_tn.hip", "attention.hip", "rnn_persist.hip", "pointwise.hip", "batchnorm.hip", "beam.hip", "topdown.hip", "fcmodel.hip", "nmt.hip", "cider.hip", "loader.hip", "loader_io.hip"]
+SOURCES = ["api.hip", "gemm.hip", "gemm_tn.hip", "attention.hip", "rnn_persist.hip", "pointwise.hip", "batchnorm.hip", "beam.hip", "topdown.hip", "fcmodel.hip", "nmt.hip", "cider.hip", "loader.hip", "loader_io.hip", "comm.hip"]
 LIB = os.path.join(HERE, "libuic_hip.so")
 
 
@@ -36,7 +36,7 @@ def build(force: bool = False, verbose: bool = True) -> str:
     for cmd, p in procs:
         if p.wait() != 0:
             raise RuntimeError("hipcc failed: " + " ".join(cmd))
-    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs + ["-lz", "-lpthread"]
+    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs + ["-lz", "-lpthread", "-ldl"]
     if verbose:
         print(" ".join(cmd), flush=True)
     subprocess.check_call(cmd)

@@ -1,6 +1,7 @@
 // Host-side sequencing of the TopDown captioner step on one MI355X: every launch of
 // AttModel._forward / _sample, LanguageModelCriterion and their backward, enqueued on the
-// caller's HIP stream with no host synchronisation (hipGraph-capturable).
+// caller's HIP stream with no host synchronisation.  (The fused training step also forks onto a library-owned side stream
+// and joins it before returning; capturing it into a hipGraph is untested.)
 //
 // Restructuring relative to the reference's per-step Python loop (P/models/AttModel.py:119-165):
 //   * teacher forcing makes xt_t and fc' known up front, so their share of the att_lstm gate

@@ -23,6 +23,10 @@ class GradientExchange(object):
     def rank(self):
         return dist.get_rank(self.group) if dist.is_available() and dist.is_initialized() else 0
 
+    def _sum(self, t):
+        """In-place sum of `t` over the ranks, on the current stream."""
+        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
+
     def global_inv_den(self, den_local, device):
         """1 / (global mask sum) as a device scalar, or None on a single rank (the kernel computes it).
 
@@ -43,13 +47,13 @@ class GradientExchange(object):
             self._pin_i = (i + 1) % 64
             self._pin[i] = float(den_local)
             t = self._pin[i:i + 1].to(device, non_blocking=True)
-        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
+        self._sum(t)
         return t.reciprocal_()
 
     def allreduce_sum(self, flat):
         """Sum the flat gradient arena over ranks, in place (one collective per step)."""
         if self.world_size > 1:
-            dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group)
+            self._sum(flat)
         return flat
 
     def allreduce_sum_overlapped(self, flat, splits, wait_group):
@@ -74,16 +78,16 @@ class GradientExchange(object):
         for g, hi in enumerate(splits):
             wait_group(comm.cuda_stream, g)
             with torch.cuda.stream(comm):
-                dist.all_reduce(flat[lo:hi], op=dist.ReduceOp.SUM, group=self.group)
+                self._sum(flat[lo:hi])
             lo = hi
-        dist.all_reduce(flat[lo:], op=dist.ReduceOp.SUM, group=self.group)
+        self._sum(flat[lo:])
         torch.cuda.current_stream(flat.device).wait_stream(comm)
         return flat
 
     def allreduce_sum_scalar(self, x):
         if self.world_size > 1:
             x = x.clone()
-            dist.all_reduce(x, op=dist.ReduceOp.SUM, group=self.group)
+            self._sum(x)
         return x
 
     def shard_images(self, n_images):
@@ -91,3 +95,57 @@ class GradientExchange(object):
         w, r = self.world_size, self.rank
         per = (n_images + w - 1) // w
         return min(r * per, n_images), min((r + 1) * per, n_images)
+
+
+class UicCommExchange(GradientExchange):
+    """The same exchange on libuic_hip's own RCCL communicator (uic_comm_*, include/uic_hip.h) instead of torch.distributed:
+    one process per GPU, `unique_id` = the 128 bytes rank 0 got from `UicCommExchange.new_unique_id()` and handed to every rank
+    out of band.  `from_torch_distributed()` does that hand-over through an already initialised process group of any backend
+    (e.g. gloo) and is what a launcher would normally call."""
+
+    def __init__(self, rank, world_size, unique_id):
+        import ctypes as C
+        from . import _lib
+        GradientExchange.__init__(self, None)
+        self._rank, self._world = int(rank), int(world_size)
+        self._lib = _lib.load()
+        assert len(unique_id) == 128
+        buf = (C.c_char * 128).from_buffer_copy(bytes(unique_id))
+        comm = C.c_void_p()
+        _lib.check(self._lib.uic_comm_init(self._rank, self._world, C.cast(buf, C.c_void_p), C.byref(comm)), "uic_comm_init")
+        self._comm = comm
+
+    @staticmethod
+    def new_unique_id():
+        import ctypes as C
+        from . import _lib
+        buf = (C.c_char * 128)()
+        _lib.check(_lib.load().uic_comm_unique_id(C.cast(buf, C.c_void_p)), "uic_comm_unique_id")
+        return bytes(buf.raw)
+
+    @classmethod
+    def from_torch_distributed(cls, group=None):
+        rank, world = dist.get_rank(group), dist.get_world_size(group)
+        box = [cls.new_unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(box, src=0, group=group)
+        return cls(rank, world, box[0])
+
+    @property
+    def world_size(self):
+        return self._world
+
+    @property
+    def rank(self):
+        return self._rank
+
+    def _sum(self, t):
+        from . import _lib
+        assert t.is_cuda and t.is_contiguous() and t.dtype in (torch.float32, torch.bfloat16)
+        _lib.check(self._lib.uic_comm_allreduce(self._comm, t.data_ptr(), t.numel(), 0 if t.dtype == torch.float32 else 1,
+                                                torch.cuda.current_stream(t.device).cuda_stream), "uic_comm_allreduce")
+
+    def close(self):
+        from . import _lib
+        if self._comm is not None:
+            _lib.check(self._lib.uic_comm_destroy(self._comm), "uic_comm_destroy")
+            self._comm = None
