@@ -431,6 +431,41 @@ int uic_dropout_mask(float* out, size_t n, float p, uint32_t seed, uint32_t site
 #define UIC_SITE_NMT_DEC0 2000u  /* + l*256 + t: StackedLSTM dropout after decoder layer l at step t, element b*H+j */
 #define UIC_SITE_NMT_OUT0 4000u  /* + t: Decoder.dropout on the attentional output of step t, element b*H + j      */
 
+#define UIC_SITE_DISC 6000u      /* Dropout on the sentence discriminator's highway output, element n*Ft + a             */
+
+/* ---- CNN sentence discriminator (BASELINE configs[3]; north_star "the sentence-discriminator forward/backward").
+ * THE REFERENCE TREE HOLDS NO DISCRIMINATOR CODE: this is the package's own statement of the usual text-CNN critic and its
+ * parity is UNPINNED (csrc/discriminator.hip states the architecture; oracle/discriminator.py restates it on the CPU).
+ *   x = relu(Emb[tok]) [N, L, E];  y_w = relu(conv1d_w(x) + b_w), right zero padding;  p = concat_w max_t y_w  [N, nw*F];
+ *   g, h = sigmoid / relu of hw_w p + hw_b (hw_w = [W_gate; W_transform], [2 Ft, Ft]);  z = g h + (1 - g) p;
+ *   logit = out_w . dropout(z) + out_b;  D = sigmoid(logit).
+ * conv_w[i] is [F, widths[i], E] row-major (= nn.Conv1d weight [F, E, w] with the last two axes swapped).  Rows are the
+ * captioner's int64 token rows [N, ld_tokens], first L columns.  Gradient struct = weight struct, f32, overwritten. ---- */
+#define UIC_DISC_MAX_WIDTHS 4
+#define UIC_DISC_MAX_WIDTH 4
+typedef struct {
+  int32_t dtype, N, L, V1, E, F, nw;
+  int32_t widths[UIC_DISC_MAX_WIDTHS];
+  float drop_p;
+} uic_disc_dims;
+typedef struct {
+  float* embed_w;                        /* [V1, E] */
+  float* conv_w[UIC_DISC_MAX_WIDTHS];    /* [F, w, E] */
+  float* conv_b[UIC_DISC_MAX_WIDTHS];    /* [F] */
+  float* hw_w; float* hw_b;              /* [2 Ft, Ft], [2 Ft] */
+  float* out_w; float* out_b;            /* [Ft], [1] */
+} uic_disc_weights;
+size_t uic_disc_workspace_bytes(const uic_disc_dims* d);
+/* forward: logits_out / prob_out (optional, [N] f32).  training != 0: dropout with `seed`, and the workspace keeps what
+ * uic_disc_backward needs. */
+int uic_disc_forward(const uic_disc_dims* d, const uic_disc_weights* w, const int64_t* tokens, int32_t ld_tokens, int32_t training,
+                     uint32_t seed, void* workspace, float* logits_out, float* prob_out, void* stream);
+/* BCEWithLogitsLoss (mean): loss_out[0]; dlogits_out (optional) = (sigmoid(logit) - label) / N */
+int uic_disc_bce(const float* logits, const float* labels, int32_t N, float* loss_out, float* dlogits_out, void* stream);
+/* backward of the forward that last ran on `workspace` (same tokens, training, seed): every gradient of G from dlogits [N] */
+int uic_disc_backward(const uic_disc_dims* d, const uic_disc_weights* w, const int64_t* tokens, int32_t ld_tokens, int32_t training,
+                      uint32_t seed, void* workspace, const float* dlogits, const uic_disc_weights* G, void* stream);
+
 /* ---- CIDEr-D reward of the self-critical step ----
  * get_self_critical_reward (P/misc/rewards.py:37-81) over the CIDEr-D scorer
  * (P/misc/cider/pyciderevalcap/ciderD/ciderD_scorer.py:116-209, ciderD.py:26-50) on integer token rows, so that the sampled

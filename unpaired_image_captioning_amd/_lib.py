@@ -107,6 +107,19 @@ class FcWeights(C.Structure):
     _fields_ = [(f, C.c_void_p) for f, _ in FC_WEIGHT_FIELDS]
 
 
+DISC_MAX_WIDTHS = 4
+SITE_DISC = 6000
+
+
+class DiscDims(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ("dtype", "N", "L", "V1", "E", "F", "nw")] + [("widths", C.c_int32 * DISC_MAX_WIDTHS), ("drop_p", C.c_float)]
+
+
+class DiscWeights(C.Structure):
+    _fields_ = [("embed_w", C.c_void_p), ("conv_w", C.c_void_p * DISC_MAX_WIDTHS), ("conv_b", C.c_void_p * DISC_MAX_WIDTHS),
+                ("hw_w", C.c_void_p), ("hw_b", C.c_void_p), ("out_w", C.c_void_p), ("out_b", C.c_void_p)]
+
+
 NMT_MAX_LAYERS = 4
 SITE_NMT_ENC0, SITE_NMT_DEC0, SITE_NMT_OUT0 = 1000, 2000, 4000   # + layer ; + layer*256 + step ; + step
 
@@ -169,6 +182,12 @@ _SIGS = {
     "uic_version": (C.c_int, []),
     "uic_set_persistent_rnn": (C.c_int, [C.c_int32]),
     "uic_comm_unique_id": (C.c_int, [C.c_void_p]),
+    "uic_disc_workspace_bytes": (C.c_size_t, [C.POINTER(DiscDims)]),
+    "uic_disc_forward": (C.c_int, [C.POINTER(DiscDims), C.POINTER(DiscWeights), C.c_void_p, C.c_int32, C.c_int32, C.c_uint32, C.c_void_p,
+                                   C.c_void_p, C.c_void_p, C.c_void_p]),
+    "uic_disc_bce": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "uic_disc_backward": (C.c_int, [C.POINTER(DiscDims), C.POINTER(DiscWeights), C.c_void_p, C.c_int32, C.c_int32, C.c_uint32, C.c_void_p,
+                                    C.c_void_p, C.POINTER(DiscWeights), C.c_void_p]),
     "uic_comm_init": (C.c_int, [C.c_int32, C.c_int32, C.c_void_p, C.POINTER(C.c_void_p)]),
     "uic_comm_allreduce": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int32, C.c_void_p]),
     "uic_comm_destroy": (C.c_int, [C.c_void_p]),

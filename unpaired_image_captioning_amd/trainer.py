@@ -287,6 +287,12 @@ class Trainer(object):
                     greedy_res = greedy_res.repeat_interleave(S, 0)
                 reward = np.asarray(reward_fn(data, gen_result.cpu().numpy(), greedy_res.cpu().numpy()), dtype=np.float32)
                 reward_t = torch.from_numpy(reward).cuda()
+            dw = float(getattr(self.opt, 'disc_reward_weight', 0) or 0)
+            if dw > 0 and getattr(self, 'discriminator', None) is not None:
+                # adversarial reward of BASELINE configs[3]: + w (D(sampled) - D(greedy)), the same self-critical form, per row
+                g_rows = greedy_res.repeat_interleave(S, 0) if greedy_res.shape[0] != gen_result.shape[0] else greedy_res
+                adv = self.discriminator_scores(gen_result) - self.discriminator_scores(g_rows)
+                reward_t = reward_t + dw * adv[:, None]
             loss = RewardCriterion()(sample_logprobs, gen_result, reward_t)
             for p in model.parameters():
                 p.grad = None
@@ -307,6 +313,49 @@ class Trainer(object):
         self.i2t_train_loss = loss.item()
         self.i2t_avg_reward = float(avg.item())
         return self.i2t_train_loss
+
+    # ------------------------------------------------------------------ sentence discriminator (BASELINE configs[3]; parity unpinned)
+    def build_discriminator(self):
+        """The CNN sentence discriminator of the unpaired / adversarial configuration (models/Discriminator.py) with its own flat
+        Adam arena; data parallel like the captioner (gradient arena summed over the ranks)."""
+        from .models import SentenceDiscriminator
+        from .misc.optimizer import FlatArena
+        self.discriminator = SentenceDiscriminator(self.opt).cuda()
+        rank = self.exchange.rank if self.exchange is not None else 0
+        self.discriminator.seed = (self.discriminator.seed + 0x9E3779B1 * rank) & 0x7FFFFFFF    # per-rank dropout noise
+        self.disc_arena = FlatArena(self.discriminator)
+        self.disc_lr = float(getattr(self.opt, 'disc_learning_rate', 1e-4) or 1e-4)
+        self._disc_step = 0
+        return self.discriminator
+
+    def _pad_rows(self, seq):
+        """Caption rows [N, L'] (int64, 0 = end) as the discriminator's [N, seq_length] rows."""
+        L = self.discriminator.L
+        seq = seq.cuda() if not seq.is_cuda else seq
+        if seq.shape[1] < L:
+            seq = torch.cat([seq, seq.new_zeros(seq.shape[0], L - seq.shape[1])], 1)
+        return seq[:, :L].contiguous().long()
+
+    def discriminator_scores(self, seq):
+        self.discriminator.eval()
+        return self.discriminator.scores(self._pad_rows(seq))
+
+    def train_discriminator(self, real_seq, fake_seq):
+        """One BCE step: real caption rows (label 1) against generated rows (label 0).  Returns the loss (one host sync)."""
+        if getattr(self, 'discriminator', None) is None:
+            self.build_discriminator()
+        D, a = self.discriminator, self.disc_arena
+        D.train()
+        tok = torch.cat([self._pad_rows(real_seq), self._pad_rows(fake_seq)])
+        lab = torch.cat([torch.ones(real_seq.shape[0]), torch.zeros(fake_seq.shape[0])]).cuda()
+        a.zero_grad()
+        loss = D.bce(D(tok), lab)
+        loss.backward()
+        self.exchange.allreduce_sum(a.grad)
+        self._disc_step += 1
+        a.adam(self.disc_lr, self.betas, self.eps, self._disc_step, grad_scale=1.0 / self.exchange.world_size)
+        self.disc_train_loss = loss.item()
+        return self.disc_train_loss
 
     # ------------------------------------------------------------------ pivot NMT half (P/trainer.py:80-94,175-193)
     def build_nmt(self, src_dict, tgt_dict):
