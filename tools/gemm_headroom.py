@@ -36,7 +36,10 @@ for name, M, N, K in [("logit fwd chunk", 2560, 9488, 512), ("att_embed fwd", 23
     t_lib = timeit(lambda: torch.matmul(A, B.t()))
     t_uic = timeit(lambda: L.check(lib.uic_linear(1, M, N, K, L.ptr(A), K, L.ptr(B), K, L.ptr(Cu), ldc, L.ptr(bias), 4, L.stream())))
     fl = 2.0 * M * N * K
-    print("%-44s %10.1f %10.1f %10.1f %10.1f" % ("%s %dx%dx%d" % (name, M, N, K), t_lib, fl / t_lib / 1e6, t_uic, fl / t_uic / 1e6))
+    rows = torch.arange(0, M, max(1, M // 512), device="cuda")
+    ref = A[rows].float() @ B.float().t()
+    err = float((Cu[rows][:, :N] - ref).abs().max() / ref.abs().max())
+    print("%-44s %10.1f %10.1f %10.1f %10.1f   max rel err %.1e" % ("%s %dx%dx%d" % (name, M, N, K), t_lib, fl / t_lib / 1e6, t_uic, fl / t_uic / 1e6, err))
 print("%-44s %10s %10s %10s %10s" % ("TN shape  C[M,N] = A[K,M]^T B[K,N]", "lib us", "lib TF/s", "uic us", "uic TF/s"))
 wsb = 64 << 20
 wsp = torch.empty(wsb, dtype=torch.uint8, device="cuda")
