@@ -260,13 +260,27 @@ class AttModel(CaptionModel):
             pd = {k: v.detach() for k, v in self.param_dict().items()}
             seq, lp, (cnt, dp, dseq, dlp) = self.engine.sample_beam(pd, fc, att, am, self.seq_length, beam_size,
                                                                    opt.get('decoding_constraint', 0), opt.get('max_ppl', 0), done_lists=True)
-        cnt_h, dp_h = cnt.cpu().tolist(), dp.cpu()
-        self.done_beams = []
-        for k in range(seq.shape[0]):
-            order = sorted(range(cnt_h[k]), key=lambda i: -float(dp_h[k, i]))[:beam_size]     # sorted() is stable, like the reference's
-            self.done_beams.append([{'seq': dseq[k, i], 'logps': dlp[k, i], 'unaug_p': float(dlp[k, i].sum()), 'p': float(dp_h[k, i])}
-                                    for i in order])
+        # the per-image lists are built on first access to `self.done_beams` (one D2H copy per array then): a caller that only wants
+        # the best captions -- eval_split without `verbose_beam`, the pivot decode -- pays nothing for them
+        self._done_raw = (cnt, dp, dseq, dlp, beam_size)
+        self._done_beams = None
         return seq, lp
+
+    @property
+    def done_beams(self):
+        if getattr(self, '_done_beams', None) is None and getattr(self, '_done_raw', None) is not None:
+            cnt, dp, dseq, dlp, beam_size = self._done_raw
+            cnt_h, dp_h, unaug = cnt.cpu().tolist(), dp.cpu(), dlp.sum(-1).cpu()
+            out = []
+            for k in range(len(cnt_h)):
+                order = sorted(range(cnt_h[k]), key=lambda i: -float(dp_h[k, i]))[:beam_size]     # sorted() is stable, like the reference's
+                out.append([{'seq': dseq[k, i], 'logps': dlp[k, i], 'unaug_p': float(unaug[k, i]), 'p': float(dp_h[k, i])} for i in order])
+            self._done_beams = out
+        return getattr(self, '_done_beams', None)
+
+    @done_beams.setter
+    def done_beams(self, value):
+        self._done_beams, self._done_raw = value, None
 
     def _sample(self, fc_feats, attri_feats, att_feats, att_masks=None, opt={}):
         sample_max = opt.get('sample_max', 1)
