@@ -402,7 +402,7 @@ inline bool fast_ok(const UicAttnParams& p) {
 // 256-thread workgroups with < 50 KB of LDS each instead of one 1024-thread / > 100 KB workgroup per row: the small
 // workgroups interleave with whatever else is resident (the fused step's other stream) instead of waiting for whole CUs.
 template <typename T, int PART>
-__global__ __launch_bounds__(256) void attn_bwd_accum_kernel(const UicAttnAccumParams p) {
+__global__ __launch_bounds__(512) void attn_bwd_accum_kernel(const UicAttnAccumParams p) {
   constexpr int VEC = uic_vec<T>::N;
   extern __shared__ __attribute__((aligned(16))) float sm[];
   const int A = p.A, H = p.H, R = p.R, TS = p.T, N = p.N;
@@ -490,6 +490,7 @@ __global__ __launch_bounds__(256) void attn_bwd_accum_kernel(const UicAttnAccumP
           float ep[VEC];
 #pragma unroll
           for (int j = 0; j < VEC; ++j) ep[j] = __builtin_amdgcn_exp2f(f[j] * LOG2E2);
+#pragma unroll 8
           for (int t = 0; t < TS; ++t) {
             const float de = s_de[t * Rp + r];
 #pragma unroll
@@ -597,16 +598,18 @@ int uic_attention_bwd_accum_launch(const UicAttnAccumParams& p, hipStream_t s) {
                   p.d_walpha_part, "attention_bwd_accum: null pointer");
   if (p.N == 0) return UIC_OK;
   const int Rp = (p.R + 3) & ~3;
-  const int nthreads = 256;
+  // measured at the benchmark shapes: PART 1 (f32 FMAs over LDS-staged rows) 42 -> 32 us with 8 waves per workgroup, PART 2
+  // (one reciprocal per element) 110 us with 4 waves, 118 with 8
+  const int nthreads1 = 512, nthreads2 = 256;
   const size_t lds1 = sizeof(float) * ((size_t)p.T * (p.H + Rp));
-  const size_t lds2 = sizeof(float) * ((size_t)p.T * (p.A + Rp) + p.A + (nthreads / 64) * (size_t)p.A);
+  const size_t lds2 = sizeof(float) * ((size_t)p.T * (p.A + Rp) + p.A + (nthreads2 / 64) * (size_t)p.A);
   UIC_REQUIRE(lds1 <= 160 * 1024 && lds2 <= 160 * 1024, "attention_bwd_accum: needs %zu B of LDS (T=%d)", lds1 > lds2 ? lds1 : lds2, p.T);
 #define ACCUM_LAUNCH(TT)                                                                                                          \
   do {                                                                                                                            \
     if (lds1 > 64 * 1024) UIC_TRY(uic_check_hip(hipFuncSetAttribute((const void*)attn_bwd_accum_kernel<TT, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1), "hipFuncSetAttribute")); \
     if (lds2 > 64 * 1024) UIC_TRY(uic_check_hip(hipFuncSetAttribute((const void*)attn_bwd_accum_kernel<TT, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2), "hipFuncSetAttribute")); \
-    hipLaunchKernelGGL((attn_bwd_accum_kernel<TT, 2>), dim3(p.N), dim3(nthreads), lds2, s, p);                                      \
-    hipLaunchKernelGGL((attn_bwd_accum_kernel<TT, 1>), dim3(p.N), dim3(nthreads), lds1, s, p);                                      \
+    hipLaunchKernelGGL((attn_bwd_accum_kernel<TT, 2>), dim3(p.N), dim3(nthreads2), lds2, s, p);                                     \
+    hipLaunchKernelGGL((attn_bwd_accum_kernel<TT, 1>), dim3(p.N), dim3(nthreads1), lds1, s, p);                                     \
   } while (0)
   if (p.dtype == UIC_BF16) ACCUM_LAUNCH(bf16_t); else ACCUM_LAUNCH(float);
 #undef ACCUM_LAUNCH
