@@ -1098,3 +1098,25 @@ def test_hold_weights_refreshes_again_after_the_block():
         with model.engine.hold_weights():
             d = model(fc, None, att, labels, am)          # first call inside a new block refreshes too
         assert torch.equal(c, d)
+
+
+def test_multinomial_draws_follow_the_softmax():
+    """The inverse-CDF draw of sample_step_kernel (segment scan across the workgroup + owner search): 8192 rows of ONE image
+    draw their first token independently (the uniform number is a hash of the row index), so the histogram must match the
+    model's own step-0 probabilities; every category within 5 sigma, and the total variation distance small."""
+    cfg, W, I, Out, G, X = load_golden("topdown_tiny")
+    model = build_model(cfg, W, "f32")
+    model.eval()
+    N = 8192
+    fc = I["fc_feats"][:1].repeat(N, 1).cuda()
+    att = I["att_feats"][:1].repeat(N, 1, 1).cuda()
+    am = I["att_masks"][:1].repeat(N, 1).cuda()
+    with torch.no_grad():
+        seq, _ = model(fc, None, att, am, opt={"sample_max": 0, "temperature": 1.0}, mode="sample")
+        labels = torch.zeros(1, cfg["L"] + 2, dtype=torch.long).cuda()
+        logp = model(fc[:1], None, att[:1], labels, am[:1])
+    p = logp[0, 0].exp().double().cpu()
+    counts = torch.bincount(seq[:, 0].cpu(), minlength=p.numel()).double()
+    sigma = (N * p * (1 - p)).sqrt().clamp_min(1.0)
+    assert ((counts - N * p).abs() / sigma).max().item() < 5.0
+    assert 0.5 * (counts / N - p).abs().sum().item() < 0.05

@@ -756,37 +756,64 @@ __global__ __launch_bounds__(NT) void sample_step_kernel(const UicSampleParams p
   } else if (p.forced) {
     choice = (int)p.forced[(size_t)n * p.L + t];
   } else {
-    // inverse-CDF draw from softmax(logprobs / temperature) with the banned token removed
+    // inverse-CDF draw from softmax(logprobs / temperature) with the banned token removed.  Thread i owns the contiguous
+    // vocabulary segment [i * per, (i + 1) * per); an inclusive scan of the segment masses (wave shuffles + one LDS exchange
+    // between the waves) finds the segment the uniform number falls into, and only that segment's owner walks its <= per
+    // entries.  (The first version summed and searched the NT segment masses on thread 0: two serial loops of NT LDS reads,
+    // ~14 us of the kernel's 32.)
     const float invT = 1.f / p.temperature;
     float part = 0.f;
     const int per = (p.V1 + NT - 1) / NT;
     const int v_lo = threadIdx.x * per, v_hi = min(p.V1, v_lo + per);
     for (int v = v_lo; v < v_hi; ++v) part += (v == banned) ? 0.f : ex((row[v] - lse) * invT);
-    s_val[threadIdx.x] = part;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    float incl = part;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const float up = __shfl_up(incl, o, 64);
+      if (lane >= o) incl += up;
+    }
+    __syncthreads();                                   // s_buf was last read by block_reduce_sum
+    if (lane == 63) s_buf[wv] = incl;
     __syncthreads();
-    if (threadIdx.x == 0) {
-      float tot = 0.f;
-      for (int i = 0; i < NT; ++i) tot += s_val[i];
-      unsigned x = (unsigned)n * 0x9E3779B1u ^ (p.seed + (unsigned)t * 0x85EBCA77u);
-      x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16;
-      const float target = (float)(x >> 8) * (1.0f / 16777216.0f) * tot;
-      float cum = 0.f;
-      int seg = NT - 1;
-      for (int i = 0; i < NT; ++i) {
-        if (cum + s_val[i] > target) { seg = i; break; }
-        cum += s_val[i];
-      }
+    float woff = 0.f, tot = 0.f;
+#pragma unroll
+    for (int w2 = 0; w2 < NT / 64; ++w2) {
+      if (w2 < wv) woff += s_buf[w2];
+      tot += s_buf[w2];
+    }
+    incl += woff;
+    s_val[threadIdx.x] = incl;
+    if (threadIdx.x == 0) s_idx[0] = -1;
+    __syncthreads();
+    unsigned x = (unsigned)n * 0x9E3779B1u ^ (p.seed + (unsigned)t * 0x85EBCA77u);
+    x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16;
+    const float target = (float)(x >> 8) * (1.0f / 16777216.0f) * tot;
+    const float below = threadIdx.x > 0 ? s_val[threadIdx.x - 1] : 0.f;
+    // the owner: the first segment whose inclusive mass exceeds the target (the last one if rounding leaves none)
+    const bool owner = (incl > target && !(below > target)) || (threadIdx.x == NT - 1 && !(incl > target));
+    if (owner) {
+      float cum = below;
       int pick = -1;
-      const int lo = seg * per, hi = min(p.V1, lo + per);
-      for (int v = lo; v < hi; ++v) {
+      for (int v = v_lo; v < v_hi; ++v) {
         const float pr = (v == banned) ? 0.f : ex((row[v] - lse) * invT);
         if (pr > 0.f) pick = v;
         cum += pr;
         if (cum > target && pr > 0.f) break;
       }
-      s_idx[0] = pick < 0 ? 0 : pick;
+      s_idx[0] = pick;
     }
     __syncthreads();
+    if (s_idx[0] < 0) {
+      // rounding left the target at or beyond the total mass and the last segment is empty: the last token that has mass (rare)
+      if (threadIdx.x == 0) {
+        int pick = 0;
+        for (int v = p.V1 - 1; v >= 0; --v)
+          if (v != banned && ex((row[v] - lse) * invT) > 0.f) { pick = v; break; }
+        s_idx[0] = pick;
+      }
+      __syncthreads();
+    }
     choice = s_idx[0];
   }
   if (threadIdx.x == 0) {
