@@ -271,12 +271,33 @@ class Trainer(object):
         eng = getattr(model, 'engine', None)
         # the weights stay put until Adam below: ONE weight refresh serves the sampling pass, the greedy baseline and the replay
         with (eng.hold_weights() if hasattr(eng, 'hold_weights') else contextlib.nullcontext()):
-            model.train()
-            gen_result, sample_logprobs = model(fc, None, att, am, opt={'sample_max': 0, 'captions_per_image': S}, mode='sample')
-            model.eval()
-            with torch.no_grad():                                           # rewards.py:42-47: greedy baseline, eval mode
-                greedy_res, _ = model(fc, None, att, am, opt={'sample_max': 1}, mode='sample')
-            model.train()
+            # The sampling pass (train mode) and the greedy baseline (eval mode, rewards.py:42-47) are independent latency chains
+            # of ~7 small launches per decode step: the baseline runs on a second stream beside the sampling pass.  Not with
+            # BatchNorm in att_embed: there the train-mode pass updates the running statistics the eval-mode pass reads (the
+            # reference runs them in this order), so the two stay serial.
+            cur = torch.cuda.current_stream()
+            overlap = hasattr(eng, 'hold_weights') and int(getattr(model, 'use_bn', 0) or 0) == 0 and not getattr(self, 'serial_baseline', False)
+            if overlap:
+                if getattr(self, '_baseline_stream', None) is None:
+                    self._baseline_stream = torch.cuda.Stream()
+                # the derived weight copies are rebuilt once, here, on the current stream (hold_weights: later calls reuse them);
+                # the baseline stream then orders itself behind that and behind the batch's H2D copies
+                eng.refresh({k: v.detach() for k, v in model.param_dict().items()}, eng.dims(att.shape[0], att.shape[1], model.seq_length + 1))
+                self._baseline_stream.wait_stream(cur)
+                model.eval()
+                with torch.cuda.stream(self._baseline_stream), torch.no_grad():
+                    greedy_res, _ = model(fc, None, att, am, opt={'sample_max': 1}, mode='sample')
+                model.train()
+                gen_result, sample_logprobs = model(fc, None, att, am, opt={'sample_max': 0, 'captions_per_image': S}, mode='sample')
+                cur.wait_stream(self._baseline_stream)
+                greedy_res.record_stream(cur)
+            else:
+                model.train()
+                gen_result, sample_logprobs = model(fc, None, att, am, opt={'sample_max': 0, 'captions_per_image': S}, mode='sample')
+                model.eval()
+                with torch.no_grad():                                       # rewards.py:42-47: greedy baseline, eval mode
+                    greedy_res, _ = model(fc, None, att, am, opt={'sample_max': 1}, mode='sample')
+                model.train()
             if reward_fn is None:
                 scorer = rewards.init_scorer(getattr(self.opt, 'cached_tokens', 'corpus'))
                 reward_t = rewards.self_critical_reward_device(scorer, gen_result, greedy_res, data['gts'],
