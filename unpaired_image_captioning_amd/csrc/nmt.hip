@@ -724,12 +724,20 @@ struct Nmt {
       g.C = L.d_out_all; g.ldc = H; g.flags = UIC_GEMM_OUT_F32;
       UIC_TRY(uic_gemm_launch(g, s));
     }
+    // the generator's weight / bias gradients (the largest GEMM of the backward pass, [Vt, H] over all target rows) need nothing
+    // from the BPTT loop and the loop -- ~6 dependent launches of 64 rows per step -- leaves the chip idle: they run on the side
+    // stream beside it and are joined before the main stream next touches the shared scratch buffers
+    NmtSide* ssg = nullptr;
+    UIC_TRY(nmt_side(&ssg));
+    UIC_TRY(uic_check_hip(hipEventRecord(ssg->ev_go, s), "hipEventRecord"));
+    UIC_TRY(uic_check_hip(hipStreamWaitEvent(ssg->stream, ssg->ev_go, 0), "hipStreamWaitEvent"));
     {
       const UicGemmTnSeg seg{off(L.out_all, BH, dt), H, H};
       const WDest d1{G->gen_w, H, 0, H};
-      UIC_TRY(wgrad_group(L.slab, L.slab_bytes, dt, L.dlogits, Vtp, Vt, &seg, 1, Md, &d1, 1, s, false, L.tA, L.tB));
+      UIC_TRY(wgrad_group(L.slab, L.slab_bytes, dt, L.dlogits, Vtp, Vt, &seg, 1, Md, &d1, 1, ssg->stream, false, L.tA, L.tB));
     }
-    UIC_TRY(uic_colsum_launch(dt, L.dlogits, Md, Vt, Vtp, G->gen_b, L.colscratch, L.colscratch_floats, s));
+    UIC_TRY(uic_colsum_launch(dt, L.dlogits, Md, Vt, Vtp, G->gen_b, L.colscratch, L.colscratch_floats, ssg->stream));
+    UIC_TRY(uic_check_hip(hipEventRecord(ssg->ev_done, ssg->stream), "hipEventRecord"));
     // ---- decoder BPTT
     for (int l = 0; l < NL; ++l) {
       UIC_TRY(uic_fill_launch(L.dhrec_d[l], 0, BH * 4, s));
@@ -782,6 +790,7 @@ struct Nmt {
         }
       }
     }
+    UIC_TRY(uic_check_hip(hipStreamWaitEvent(s, ssg->ev_done, 0), "hipStreamWaitEvent"));   // generator gradients done: scratch is free
     // ---- decoder weights over all steps
     for (int l = 0; l < NL; ++l) {
       if (l == 0) {   // inputs [emb | feed_prev | h_prev]
