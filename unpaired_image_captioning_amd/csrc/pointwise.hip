@@ -1,6 +1,7 @@
 // HBM-bound helper kernels of the TopDown training / decoding path (gfx950).
 // Every kernel cites the reference lines whose arithmetic it carries.
 #include "uic_common.h"
+#include <stdlib.h>
 #include "../../include/uic_hip.h"
 
 namespace {
@@ -536,6 +537,62 @@ __global__ __launch_bounds__(NT) void xe_lds_kernel(const UicXeParams p, const f
   }
 }
 
+// Training-path variant (loss + d logits, no log-prob output): the row lives in REGISTERS (up to XE_RCH float4 per thread), one
+// HBM read, one exp per element (the e^{x - max} of the normaliser pass is reused for the gradient), no LDS staging -- 8 instead
+// of 4 workgroups per CU keep more loads in flight on the HBM-bound pass over the logits.
+constexpr int XE_RCH = 10;     // rows up to 10 * NT * 4 = 10 240 columns
+template <typename T>
+__global__ __launch_bounds__(NT) void xe_reg_kernel(const UicXeParams p, const float* __restrict__ logits, T* __restrict__ dlogits) {
+  __shared__ float s_buf[NT / 64];
+  __shared__ float s_y;
+  const int m = blockIdx.x;
+  const int t = m / p.N, n = m - t * p.N;
+  const float* row = logits + (size_t)m * p.ldv;
+  long y = p.target[(size_t)n * p.ldtarget + p.target_col0 + t];
+  const float mk = p.mask ? p.mask[(size_t)n * p.ldmask + p.mask_col0 + t] : 0.f;
+  if (y < 0 || y >= p.V1) y = 0;
+  float4 x[XE_RCH];
+  float mx = -INFINITY;
+#pragma unroll
+  for (int i = 0; i < XE_RCH; ++i) {
+    const int v = (threadIdx.x + i * NT) * 4;
+    x[i] = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+    if (v < p.ldv) {
+      const float4 r = *(const float4*)(row + v);
+      x[i].x = v < p.V1 ? r.x : -INFINITY; x[i].y = v + 1 < p.V1 ? r.y : -INFINITY;
+      x[i].z = v + 2 < p.V1 ? r.z : -INFINITY; x[i].w = v + 3 < p.V1 ? r.w : -INFINITY;
+      if ((long)v <= y && y < (long)v + 4) s_y = y == v ? r.x : y == v + 1 ? r.y : y == v + 2 ? r.z : r.w;
+    }
+    mx = fmaxf(mx, fmaxf(fmaxf(x[i].x, x[i].y), fmaxf(x[i].z, x[i].w)));
+  }
+  mx = block_reduce_max(mx, s_buf);
+  float sum = 0.f;
+#pragma unroll
+  for (int i = 0; i < XE_RCH; ++i) {        // padded / out-of-row entries hold -inf -> e = 0
+    x[i].x = __expf(x[i].x - mx); x[i].y = __expf(x[i].y - mx); x[i].z = __expf(x[i].z - mx); x[i].w = __expf(x[i].w - mx);
+    sum += (x[i].x + x[i].y) + (x[i].z + x[i].w);
+  }
+  sum = block_reduce_sum(sum, s_buf);       // (its barriers also publish s_y)
+  const float lse = mx + logf(sum);
+  if (threadIdx.x == 0) p.row_loss[m] = -(s_y - lse) * mk;
+  const float sc = p.grad_scale ? p.grad_scale[(size_t)n * p.ldscale + p.scale_col0 + t] : mk * p.inv_den[0];
+  const float k = sc / sum;
+  T* d = dlogits + (size_t)m * p.ldv;
+#pragma unroll
+  for (int i = 0; i < XE_RCH; ++i) {
+    const int v = (threadIdx.x + i * NT) * 4;
+    if (v >= p.ldv) continue;
+    float g[4] = {x[i].x * k, x[i].y * k, x[i].z * k, x[i].w * k};
+    const long j = y - (long)v;           // (a dynamic index into g[] would put it in scratch)
+    g[0] -= j == 0 ? sc : 0.f; g[1] -= j == 1 ? sc : 0.f; g[2] -= j == 2 ? sc : 0.f; g[3] -= j == 3 ? sc : 0.f;
+    if constexpr (sizeof(T) == 2) {
+      *(uint2*)(d + v) = make_uint2(uic_pack_bf16x2(g[0], g[1]), uic_pack_bf16x2(g[2], g[3]));
+    } else {
+      *(float4*)(d + v) = make_float4(g[0], g[1], g[2], g[3]);
+    }
+  }
+}
+
 // API-compat backward: upstream grad g wrt log-probs [n][t][v]; d logits = g - softmax * sum_v g
 template <typename T>
 __global__ __launch_bounds__(NT) void logsoftmax_bwd_kernel(T* __restrict__ dlogits, int V1, int ldv, int N, const float* __restrict__ g,
@@ -1007,6 +1064,13 @@ int uic_xe_launch(const UicXeParams& p, hipStream_t s) {
   UIC_REQUIRE(!p.target || p.row_loss, "xe: null row_loss");
   if (p.M == 0) return UIC_OK;
   const size_t row_bytes = (size_t)p.ldv * 4;
+  static const bool xe_reg_on = !(getenv("UIC_XE_REG") && !atoi(getenv("UIC_XE_REG")));
+  if (xe_reg_on && p.dtype == UIC_BF16 && p.ldv % 4 == 0 && p.ldv <= XE_RCH * NT * 4 && ((uintptr_t)p.logits & 15) == 0 && p.write_grad && p.target &&
+      !p.logprobs && !p.score_stats && ((uintptr_t)p.dlogits & 7) == 0) {
+    hipLaunchKernelGGL(xe_reg_kernel<bf16_t>, dim3(p.M), dim3(NT), 0, s, p, p.logits, (bf16_t*)p.dlogits);
+    UIC_LAUNCH_CHECK("xe_reg_kernel");
+    return UIC_OK;
+  }
   if (p.dtype == UIC_BF16 && p.ldv % 4 == 0 && row_bytes <= 64 * 1024 && ((uintptr_t)p.logits & 15) == 0) {
     // bf16 path: LDS-staged row + hardware exp (the f32 parity path keeps libm exp)
     hipLaunchKernelGGL(xe_lds_kernel<bf16_t>, dim3(p.M), dim3(NT), row_bytes, s, p, p.logits, (bf16_t*)p.dlogits);
