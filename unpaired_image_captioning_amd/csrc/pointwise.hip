@@ -164,6 +164,152 @@ __global__ void relu_mask_bwd_kernel(const float* __restrict__ g, const T* __res
     dst[i] = uic_from_f<T>(uic_to_f(act[i]) > 0.f ? g[i] * scale : 0.f);
 }
 
+// The same gradient with the T*N positions first bucketed by token (histogram -> exclusive scan -> fill): equal tokens become
+// neighbours, so embed_gather_kernel can sum them in registers before it touches the table.
+// Wave-aggregated counting: a token shared by many lanes of a wave (the padding token at late decode steps, frequent words)
+// costs ONE atomic per wave instead of one per lane -- plain per-lane atomics on cnt[0] serialise ~3000 deep.  Two aggregation
+// rounds (the tokens of the first two still-active lanes) catch the hot tokens; the remaining lanes use plain atomics.
+// Returns the lane's slot (old counter value + rank inside its group); `want` = false skips the (slow) returning form.
+__device__ __forceinline__ int wave_token_add(int* base, int tok, bool active, bool want) {
+  const int lane = threadIdx.x & 63;
+  int slot = 0;
+#pragma unroll
+  for (int round = 0; round < 2; ++round) {
+    const unsigned long long todo = __ballot(active);
+    if (todo == 0) break;
+    const int leader = __ffsll((long long)todo) - 1;
+    const int t0 = __shfl(tok, leader, 64);
+    const unsigned long long m = __ballot(active && tok == t0);
+    int old = 0;
+    if (lane == leader) old = atomicAdd(base + t0, __popcll(m));
+    if (want) old = __shfl(old, leader, 64);
+    if (active && tok == t0) {
+      slot = old + __popcll(m & ((1ull << lane) - 1ull));
+      active = false;
+    }
+  }
+  if (active) slot = atomicAdd(base + tok, 1);
+  return slot;
+}
+__global__ void embed_hist_kernel(const int64_t* __restrict__ tokens, int ldtok, int N, int TS, int V1, int* __restrict__ cnt) {
+  const int total = TS * N;
+  const int span = (total + 63) & ~63;                       // whole waves enter the aggregation together
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < span; i += gridDim.x * blockDim.x) {
+    const bool ok = i < total;
+    long tok = 0;
+    if (ok) {
+      const int t = i / N, n = i - t * N;
+      tok = tokens[(size_t)n * ldtok + t];
+      if (tok < 0 || tok >= V1) tok = 0;
+    }
+    wave_token_add(cnt, (int)tok, ok, false);
+  }
+}
+// single workgroup: off[v] = exclusive prefix of cnt, cur[v] = off[v] (the fill cursor), off[V1] = total
+__global__ __launch_bounds__(1024) void embed_scan_kernel(const int* __restrict__ cnt, int V1, int* __restrict__ off, int* __restrict__ cur) {
+  __shared__ int s_part[1024];
+  const int per = (V1 + 1023) / 1024;
+  const int lo = threadIdx.x * per, hi = min(V1, lo + per);
+  int sum = 0;
+  for (int v = lo; v < hi; ++v) sum += cnt[v];
+  s_part[threadIdx.x] = sum;
+  __syncthreads();
+  for (int o = 1; o < 1024; o <<= 1) {          // Hillis-Steele inclusive scan of the per-thread sums
+    const int add = threadIdx.x >= o ? s_part[threadIdx.x - o] : 0;
+    __syncthreads();
+    s_part[threadIdx.x] += add;
+    __syncthreads();
+  }
+  int run = s_part[threadIdx.x] - sum;
+  for (int v = lo; v < hi; ++v) { off[v] = run; cur[v] = run; run += cnt[v]; }
+  if (threadIdx.x == 1023) off[V1] = s_part[1023];
+}
+__global__ void embed_fill_kernel(const int64_t* __restrict__ tokens, int ldtok, int N, int TS, int V1, int* __restrict__ cur, int* __restrict__ perm) {
+  const int total = TS * N;
+  const int span = (total + 63) & ~63;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < span; i += gridDim.x * blockDim.x) {
+    const bool ok = i < total;
+    long tok = 0;
+    if (ok) {
+      const int t = i / N, n = i - t * N;
+      tok = tokens[(size_t)n * ldtok + t];
+      if (tok < 0 || tok >= V1) tok = 0;
+    }
+    const int slot = wave_token_add(cur, (int)tok, ok, true);
+    if (ok) perm[slot] = i;
+  }
+}
+// One workgroup per CH consecutive entries of the token-bucketed position list: it loads its CH rows up front, sums runs of
+// equal tokens in registers and flushes every run with one atomicAdd per column -- a hot token (the padding token 0 owns
+// thousands of positions) costs positions / CH contended atomics per column instead of one per position, rare tokens one.
+constexpr int EMB_CH = 16;
+template <typename T>
+__global__ __launch_bounds__(128) void embed_gather_kernel(const float* __restrict__ dxt, const T* __restrict__ xt, const int64_t* __restrict__ tokens,
+                                                           int ldtok, int N, int V1, const int* __restrict__ off, const int* __restrict__ perm, int total,
+                                                           int E, float inv_keep, long skip_token, float* __restrict__ dtable) {
+  const int start = blockIdx.x * EMB_CH;
+  const int cnt = min(EMB_CH, total - start);
+  __shared__ int s_pos[EMB_CH];
+  __shared__ int s_tok[EMB_CH];
+  if (threadIdx.x < cnt) {
+    const int pos = perm[start + threadIdx.x];
+    const int t = pos / N, n = pos - t * N;
+    long tok = tokens[(size_t)n * ldtok + t];
+    if (tok < 0 || tok >= V1) tok = 0;
+    s_pos[threadIdx.x] = pos;
+    s_tok[threadIdx.x] = (int)tok;
+  }
+  __syncthreads();
+  for (int c = threadIdx.x; c < E / 4; c += blockDim.x) {
+    float4 g[EMB_CH];
+#pragma unroll
+    for (int j = 0; j < EMB_CH; ++j) {
+      g[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (j < cnt) {
+        const size_t o = (size_t)s_pos[j] * E + c * 4;
+        g[j] = *(const float4*)(dxt + o);
+        if (xt) {
+          float a4[4];
+          if constexpr (sizeof(T) == 2) {
+            const uint2 q = *(const uint2*)(xt + o);            // 4 bf16 in one 8-byte load
+            a4[0] = __uint_as_float(q.x << 16); a4[1] = __uint_as_float(q.x & 0xffff0000u);
+            a4[2] = __uint_as_float(q.y << 16); a4[3] = __uint_as_float(q.y & 0xffff0000u);
+          } else {
+            const float4 q = *(const float4*)(xt + o);
+            a4[0] = q.x; a4[1] = q.y; a4[2] = q.z; a4[3] = q.w;
+          }
+          if (!(a4[0] > 0.f)) g[j].x = 0.f;
+          if (!(a4[1] > 0.f)) g[j].y = 0.f;
+          if (!(a4[2] > 0.f)) g[j].z = 0.f;
+          if (!(a4[3] > 0.f)) g[j].w = 0.f;
+        }
+      }
+    }
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int j = 0; j < EMB_CH; ++j) {
+      if (j < cnt) {
+        acc.x += g[j].x; acc.y += g[j].y; acc.z += g[j].z; acc.w += g[j].w;
+        const bool last = j + 1 == cnt || s_tok[j + 1] != s_tok[j];       // uniform over the workgroup
+        if (last) {
+          if (s_tok[j] != skip_token) {
+            float* o = dtable + (size_t)s_tok[j] * E + c * 4;
+            // a bucket that lies wholly inside this workgroup's entries (most tokens occur once or twice) is stored, not added:
+            // the table was zeroed and nobody else touches the row; only hot / straddling buckets pay for atomics
+            const bool whole = off[s_tok[j]] >= start && off[s_tok[j] + 1] <= start + cnt;
+            if (whole) {
+              *(float4*)o = make_float4(acc.x * inv_keep, acc.y * inv_keep, acc.z * inv_keep, acc.w * inv_keep);
+            } else {
+              atomicAdd(o, acc.x * inv_keep); atomicAdd(o + 1, acc.y * inv_keep); atomicAdd(o + 2, acc.z * inv_keep); atomicAdd(o + 3, acc.w * inv_keep);
+            }
+          }
+          acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+      }
+    }
+  }
+}
+
 // ------------------------------------------------------------------ seq_per_img > 1: per-image features -> caption rows
 // (the loader's S-fold replication, P/misc/dataloader/dataloader.py:270-277, done on the device instead of the host)
 template <typename T>
@@ -999,6 +1145,35 @@ int uic_embed_bwd_launch(int dtype, const float* dxt, const void* xt, const int6
              hipLaunchKernelGGL(embed_bwd_kernel<bf16_t>, dim3(g), dim3(NT), 0, s, dxt, (const bf16_t*)xt, tokens, ldtok, N, T, V1, E, inv_keep, skip_token, dtable),
              hipLaunchKernelGGL(embed_bwd_kernel<float>, dim3(g), dim3(NT), 0, s, dxt, (const float*)xt, tokens, ldtok, N, T, V1, E, inv_keep, skip_token, dtable));
   UIC_LAUNCH_CHECK("embed_bwd");
+  return UIC_OK;
+}
+size_t uic_embed_bwd_sorted_scratch_ints(int N, int T, int V1) { return (size_t)3 * (V1 + 1) + (size_t)N * T + 64; }
+// dtable [V1, E] is overwritten.  scratch: uic_embed_bwd_sorted_scratch_ints ints.
+int uic_embed_bwd_sorted_launch(int dtype, const float* dxt, const void* xt, const int64_t* tokens, int ldtok, int N, int T,
+                                int V1, int E, float drop_p, long skip_token, float* dtable, int* scratch, hipStream_t s) {
+  UIC_REQUIRE(E % 4 == 0 && scratch, "embed_bwd_sorted: E=%d must be a multiple of 4", E);
+  if (V1 == 0) return UIC_OK;
+  int* cnt = scratch;
+  int* off = cnt + (V1 + 1);
+  int* cur = off + (V1 + 1);
+  int* perm = cur + (V1 + 1);
+  const float inv_keep = drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f;
+  const int total = N * T;
+  UIC_TRY(uic_fill_launch(dtable, 0, (size_t)V1 * E * 4, s));
+  if (total == 0) return UIC_OK;
+  UIC_TRY(uic_fill_launch(cnt, 0, (size_t)(V1 + 1) * 4, s));
+  const int g = grid_for((size_t)total, NT);
+  hipLaunchKernelGGL(embed_hist_kernel, dim3(g), dim3(NT), 0, s, tokens, ldtok, N, T, V1, cnt);
+  UIC_LAUNCH_CHECK("embed_hist");
+  hipLaunchKernelGGL(embed_scan_kernel, dim3(1), dim3(1024), 0, s, (const int*)cnt, V1, off, cur);
+  UIC_LAUNCH_CHECK("embed_scan");
+  hipLaunchKernelGGL(embed_fill_kernel, dim3(g), dim3(NT), 0, s, tokens, ldtok, N, T, V1, cur, perm);
+  UIC_LAUNCH_CHECK("embed_fill");
+  const int gw = (total + EMB_CH - 1) / EMB_CH;
+  DISPATCH_T(dtype,
+             hipLaunchKernelGGL(embed_gather_kernel<bf16_t>, dim3(gw), dim3(128), 0, s, dxt, (const bf16_t*)xt, tokens, ldtok, N, V1, (const int*)off, (const int*)perm, total, E, inv_keep, skip_token, dtable),
+             hipLaunchKernelGGL(embed_gather_kernel<float>, dim3(gw), dim3(128), 0, s, dxt, (const float*)xt, tokens, ldtok, N, V1, (const int*)off, (const int*)perm, total, E, inv_keep, skip_token, dtable));
+  UIC_LAUNCH_CHECK("embed_gather");
   return UIC_OK;
 }
 int uic_relu_mask_bwd_launch(int dtype, const float* grad, const void* act, float scale, void* dst, size_t n, hipStream_t s) {

@@ -50,6 +50,7 @@ struct Layout {
   float* slab; size_t slab_bytes;
   void* tLA; void* tLB; float* colscratchL;   // scratch of the logit-layer weight gradients (side stream)
   void* tSA; void* tSB; float* slab2;         // scratch of the per-chunk recurrent weight gradients (side stream)
+  int* embed_scratch;                         // uic_embed_bwd_sorted_launch
   unsigned* rnn_sync; unsigned long long* rnn_dbg;   // persistent recurrence (rnn_persist.hip): sync block, optional time stamps
   // sampling
   void* s_h_att[2]; void* s_h_lang[2]; float* s_c_att[2]; float* s_c_lang[2];
@@ -164,6 +165,7 @@ Layout make_layout(const uic_topdown_dims& d, void* ws) {
     L.slab = (float*)b.take(sl);
     L.slab2 = (float*)b.take(sl);
   }
+  L.embed_scratch = (int*)b.take(uic_embed_bwd_sorted_scratch_ints(N, T, V1) * 4);
   L.rnn_sync = (unsigned*)b.take(uic_rnn_persist_sync_bytes());
   L.rnn_dbg = (unsigned long long*)b.take((size_t)256 * T * 16 * 8);
   for (int i = 0; i < 2; ++i) {
@@ -893,9 +895,8 @@ struct Step {
       add_seg(g, L.dg1_all, H4, dv.wxT, H4, H4);
       g.C = L.dxt; g.ldc = E; g.flags = UIC_GEMM_OUT_F32;
       UIC_TRY(uic_gemm_launch(g, s));
-      UIC_TRY(uic_fill_launch(G->embed_w, 0, (size_t)V1 * E * 4, s));
-      UIC_TRY(uic_embed_bwd_launch(dt, L.dxt, L.xt_all, ss_on() ? L.tok_used : b->labels, ss_on() ? d.T : b->ld_labels, N, t_run,
-                                   V1, E, drop_p, -1, G->embed_w, s));
+      UIC_TRY(uic_embed_bwd_sorted_launch(dt, L.dxt, L.xt_all, ss_on() ? L.tok_used : b->labels, ss_on() ? d.T : b->ld_labels, N, t_run,
+                                          V1, E, drop_p, -1, G->embed_w, L.embed_scratch, s));
     }
     // fc' path: dGfc = sum_t dG1_t
     UIC_TRY(uic_sum_steps_launch(dt, L.dg1_all, t_run, (size_t)N * H4, L.dgfc, s));

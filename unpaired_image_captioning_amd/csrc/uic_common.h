@@ -296,6 +296,11 @@ int uic_embed_fwd_launch(int dtype, const float* table, int V1, int E, const int
                          float drop_p, unsigned seed, unsigned site, size_t idx_base, int relu, void* out, hipStream_t s);
 int uic_embed_bwd_launch(int dtype, const float* dxt, const void* xt, const int64_t* tokens, int ldtok, int N, int T,
                          int V1, int E, float drop_p, long skip_token, float* dtable, hipStream_t s);   // skip_token < 0: none (nn.Embedding padding_idx otherwise)
+// the same with the positions bucketed by token first, so that runs of equal tokens are summed in registers and a hot token
+// (padding) costs 1/16 of the contended atomics: dtable is overwritten; scratch = uic_embed_bwd_sorted_scratch_ints(N, T, V1) ints
+size_t uic_embed_bwd_sorted_scratch_ints(int N, int T, int V1);
+int uic_embed_bwd_sorted_launch(int dtype, const float* dxt, const void* xt, const int64_t* tokens, int ldtok, int N, int T,
+                                int V1, int E, float drop_p, long skip_token, float* dtable, int* scratch, hipStream_t s);
 // dst = (act > 0 ? scale : 0) * grad ; grad f32, act/dst operand dtype
 int uic_relu_mask_bwd_launch(int dtype, const float* grad, const void* act, float scale, void* dst, size_t n, hipStream_t s);
 // seq_per_img > 1 (features given per image, caption rows = image * S + j):
