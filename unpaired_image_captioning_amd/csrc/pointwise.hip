@@ -1089,6 +1089,21 @@ int uic_fill_launch(void* dst, int value_byte, size_t bytes, hipStream_t s) {
   if (bytes == 0) return UIC_OK;
   return uic_check_hip(hipMemsetAsync(dst, value_byte, bytes, s), "hipMemsetAsync");
 }
+namespace {
+template <typename T>
+__global__ void fill_value_kernel(T* __restrict__ dst, size_t n, float value) {
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) dst[i] = uic_from_f<T>(value);
+}
+}  // namespace
+int uic_fill_value_launch(int dtype, void* dst, size_t n, float value, hipStream_t s) {
+  if (n == 0) return UIC_OK;
+  const int g = grid_for(n, NT);
+  DISPATCH_T(dtype, hipLaunchKernelGGL(fill_value_kernel<bf16_t>, dim3(g), dim3(NT), 0, s, (bf16_t*)dst, n, value),
+             hipLaunchKernelGGL(fill_value_kernel<float>, dim3(g), dim3(NT), 0, s, (float*)dst, n, value));
+  UIC_LAUNCH_CHECK("fill_value");
+  return UIC_OK;
+}
 int uic_transpose_launch(int dtype, const void* src, int rows, int cols, int lds, void* dst, int ldd, hipStream_t s) {
   UIC_REQUIRE(ldd >= rows && lds >= cols, "transpose: ldd=%d < rows=%d or lds=%d < cols=%d", ldd, rows, lds, cols);
   if (rows == 0 || cols == 0) return UIC_OK;

@@ -51,6 +51,7 @@ struct Layout {
   void* tLA; void* tLB; float* colscratchL;   // scratch of the logit-layer weight gradients (side stream)
   void* tSA; void* tSB; float* slab2;         // scratch of the per-chunk recurrent weight gradients (side stream)
   int* embed_scratch;                         // uic_embed_bwd_sorted_launch
+  void* ones_blk;                             // [WG_CHUNK * N, 128] operand dtype, all ones: the "input" whose weight gradient is the bias gradient
   unsigned* rnn_sync; unsigned long long* rnn_dbg;   // persistent recurrence (rnn_persist.hip): sync block, optional time stamps
   // sampling
   void* s_h_att[2]; void* s_h_lang[2]; float* s_c_att[2]; float* s_c_lang[2];
@@ -150,8 +151,8 @@ Layout make_layout(const uic_topdown_dims& d, void* ws) {
   L.colscratchL = (float*)b.take(L.colscratch_floats * 4);
   {
     const size_t Kc = rup8((size_t)WG_CHUNK * N);
-    size_t rb = 2 * H + E;                      // att_lstm inputs [h_lang | xt | h_att]; lang_lstm inputs are 3H wide
-    if (3 * H > rb) rb = 3 * H;
+    size_t rb = 2 * H + E + 128;                // att_lstm inputs [h_lang | xt | h_att]; lang_lstm inputs are 3H wide; + the ones block
+    if (3 * H + 128 > rb) rb = 3 * H + 128;
     if (Dfc > rb) rb = Dfc;
     const size_t la = 4 * H > A ? 4 * H : A;    // left operands: dG [rows, 4H] of the LSTMs, d att_h [rows, A] of h2att
     L.tSA = b.take(la * Kc * S);
@@ -166,6 +167,7 @@ Layout make_layout(const uic_topdown_dims& d, void* ws) {
     L.slab2 = (float*)b.take(sl);
   }
   L.embed_scratch = (int*)b.take(uic_embed_bwd_sorted_scratch_ints(N, T, V1) * 4);
+  L.ones_blk = b.take(rup8((size_t)WG_CHUNK * N) * 128 * S);
   L.rnn_sync = (unsigned*)b.take(uic_rnn_persist_sync_bytes());
   L.rnn_dbg = (unsigned long long*)b.take((size_t)256 * T * 16 * 8);
   for (int i = 0; i < 2; ++i) {
@@ -847,22 +849,44 @@ struct Step {
     const void* h_att_new = off(L.h_att, NH + r0 * H, dt);
     const void* h_att_prev = off(L.h_att, r0 * H, dt);
     const void* h_lang_prev = off(L.h_lang, r0 * H, dt);
-    {  // lang_lstm: dG2^T x [att_res | h_att | h_lang_prev]
+    if (bias_in_chunks()) {
+      // the bias gradients (column sums of dG) ride in the same GEMMs: a fourth "input" segment of ones whose first column's
+      // weight gradient IS the column sum -- one more column tile per row tile instead of two column-sum passes in the tail
+      if (first) UIC_TRY(uic_fill_value_launch(dt, L.ones_blk, rup8((size_t)WG_CHUNK * N) * 128, 1.f, s));
+      const UicGemmTnSeg segs[4] = {{ctx, H, H}, {h_att_new, H, H}, {h_lang_prev, H, H}, {L.ones_blk, 128, 128}};
+      const WDest dd[3] = {{G->lang_lstm_w_ih, 2 * H, 0, 2 * H}, {G->lang_lstm_w_hh, H, 2 * H, H}, {G->lang_lstm_b_ih, 1, 3 * H, 1}};
+      UIC_TRY(wgrad_group(L.slab2, off(L.dg2_all, r0 * H4, dt), H4, H4, segs, 4, rows, dd, 3, s, !first, L.tSA, L.tSB));
+    } else {  // lang_lstm: dG2^T x [att_res | h_att | h_lang_prev]
       const UicGemmTnSeg segs[3] = {{ctx, H, H}, {h_att_new, H, H}, {h_lang_prev, H, H}};
       const WDest dd[2] = {{G->lang_lstm_w_ih, 2 * H, 0, 2 * H}, {G->lang_lstm_w_hh, H, 2 * H, H}};
       UIC_TRY(wgrad_group(L.slab2, off(L.dg2_all, r0 * H4, dt), H4, H4, segs, 3, rows, dd, 2, s, !first, L.tSA, L.tSB));
     }
-    {  // h2att: d_att_h^T x h_att
+    if (bias_in_chunks() && A % 128 == 0) {  // h2att: d_att_h^T x [h_att | ones]
+      const UicGemmTnSeg segs[2] = {{h_att_new, H, H}, {L.ones_blk, 128, 128}};
+      const WDest dd[2] = {{G->h2att_w, H, 0, H}, {G->h2att_b, 1, H, 1}};
+      UIC_TRY(wgrad_group(L.slab2, off(L.datth_all, r0 * A, dt), A, A, segs, 2, rows, dd, 2, s, !first, L.tSA, L.tSB));
+    } else {  // h2att: d_att_h^T x h_att
       const UicGemmTnSeg seg{h_att_new, H, H};
       const WDest d1{G->h2att_w, H, 0, H};
       UIC_TRY(wgrad_group(L.slab2, off(L.datth_all, r0 * A, dt), A, A, &seg, 1, rows, &d1, 1, s, !first, L.tSA, L.tSB));
     }
-    {  // att_lstm: dG1^T x [h_lang_prev | xt | h_att_prev]
+    if (bias_in_chunks()) {
+      const UicGemmTnSeg segs[4] = {{h_lang_prev, H, H}, {off(L.xt_all, r0 * E, dt), E, E}, {h_att_prev, H, H}, {L.ones_blk, 128, 128}};
+      const WDest dd[4] = {{G->att_lstm_w_ih, ldih, 0, H}, {G->att_lstm_w_ih + 2 * H, ldih, H, E}, {G->att_lstm_w_hh, H, H + E, H},
+                           {G->att_lstm_b_ih, 1, 2 * H + E, 1}};
+      UIC_TRY(wgrad_group(L.slab2, off(L.dg1_all, r0 * H4, dt), H4, H4, segs, 4, rows, dd, 4, s, !first, L.tSA, L.tSB));
+    } else {  // att_lstm: dG1^T x [h_lang_prev | xt | h_att_prev]
       const UicGemmTnSeg segs[3] = {{h_lang_prev, H, H}, {off(L.xt_all, r0 * E, dt), E, E}, {h_att_prev, H, H}};
       const WDest dd[3] = {{G->att_lstm_w_ih, ldih, 0, H}, {G->att_lstm_w_ih + 2 * H, ldih, H, E}, {G->att_lstm_w_hh, H, H + E, H}};
       UIC_TRY(wgrad_group(L.slab2, off(L.dg1_all, r0 * H4, dt), H4, H4, segs, 3, rows, dd, 3, s, !first, L.tSA, L.tSB));
     }
     return UIC_OK;
+  }
+  // true when EVERY chunk's LSTM weight-gradient GEMM takes the direct transposing-read (TN) path with room for one more
+  // 128-column segment: bf16, whole 64-row K rounds per decode step, 128-multiples everywhere
+  bool bias_in_chunks() const {
+    static const bool on = !(getenv("UIC_BIAS_IN_CHUNKS") && !atoi(getenv("UIC_BIAS_IN_CHUNKS")));
+    return on && dt == UIC_BF16 && N % 64 == 0 && H % 128 == 0 && E % 128 == 0 && (3 * H + 128) / 128 * (H4 / 128) >= 160 && (2 * H + E + 128) / 128 * (H4 / 128) >= 160;
   }
 
   // chunked == true: wgrad_chunk already produced the LSTM / h2att weight gradients
@@ -872,7 +896,7 @@ struct Step {
     void* const tB = side ? L.tSB : L.tB;
     float* const colscratch = side ? L.colscratchL : L.colscratch;
     float* const slab = side ? L.slab2 : L.slab;
-    if (chunked)   // h2att.bias belongs to the early group then (its weight came from wgrad_chunk)
+    if (chunked && !(bias_in_chunks() && A % 128 == 0))   // h2att.bias belongs to the early group then (its weight came from wgrad_chunk)
       UIC_TRY(uic_colsum_launch(dt, L.datth_all, Meff, A, A, G->h2att_b, colscratch, L.colscratch_floats, s));
     // per LSTM ONE GEMM dG^T [4H, T*N] x [stacked inputs]^T; lang_lstm inputs [att_res | h_att | h_lang_prev]
     if (!chunked) {
@@ -880,7 +904,8 @@ struct Step {
       const WDest dd[2] = {{G->lang_lstm_w_ih, 2 * H, 0, 2 * H}, {G->lang_lstm_w_hh, H, 2 * H, H}};
       UIC_TRY(wgrad_group(slab, L.dg2_all, H4, H4, segs, 3, Meff, dd, 2, s, false, tA, tB));
     }
-    UIC_TRY(uic_colsum_launch(dt, L.dg2_all, Meff, H4, H4, G->lang_lstm_b_ih, colscratch, L.colscratch_floats, s));
+    if (!(chunked && bias_in_chunks()))
+      UIC_TRY(uic_colsum_launch(dt, L.dg2_all, Meff, H4, H4, G->lang_lstm_b_ih, colscratch, L.colscratch_floats, s));
     UIC_TRY(uic_copy_launch(G->lang_lstm_b_hh, G->lang_lstm_b_ih, (size_t)H4 * 4, s));
     // att_lstm inputs [h_lang_prev | xt | h_att_prev]  (the fc' columns are handled below from dGfc)
     if (!chunked) {
@@ -888,7 +913,8 @@ struct Step {
       const WDest dd[3] = {{G->att_lstm_w_ih, ldih, 0, H}, {G->att_lstm_w_ih + 2 * H, ldih, H, E}, {G->att_lstm_w_hh, H, H + E, H}};
       UIC_TRY(wgrad_group(slab, L.dg1_all, H4, H4, segs, 3, Meff, dd, 3, s, false, tA, tB));
     }
-    UIC_TRY(uic_colsum_launch(dt, L.dg1_all, Meff, H4, H4, G->att_lstm_b_ih, colscratch, L.colscratch_floats, s));
+    if (!(chunked && bias_in_chunks()))
+      UIC_TRY(uic_colsum_launch(dt, L.dg1_all, Meff, H4, H4, G->att_lstm_b_ih, colscratch, L.colscratch_floats, s));
     UIC_TRY(uic_copy_launch(G->att_lstm_b_hh, G->att_lstm_b_ih, (size_t)H4 * 4, s));
     {  // d xt -> embedding table
       UicGemmParams g = gemm_base(dt, Meff, E);

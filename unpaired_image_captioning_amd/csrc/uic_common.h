@@ -282,7 +282,8 @@ int uic_rnn_fwd_persist_launch(const UicRnnFwdParams& p, hipStream_t s);
 int uic_cast_f32_launch(int dtype, const float* src, void* dst, size_t n, hipStream_t s);
 int uic_to_f32_launch(int dtype, const void* src, float* dst, size_t n, hipStream_t s);
 int uic_fill_launch(void* dst, int value_byte, size_t bytes, hipStream_t s);
-int uic_copy_launch(void* dst, const void* src, size_t bytes, hipStream_t s);   // device -> device, 4-byte granules
+int uic_copy_launch(void* dst, const void* src, size_t bytes, hipStream_t s);
+int uic_fill_value_launch(int dtype, void* dst, size_t n, float value, hipStream_t s);   // n elements of the operand dtype = value   // device -> device, 4-byte granules
 // zero up to four buffers (16-byte aligned, sizes multiples of 16) in ONE launch instead of one memset node each
 int uic_zero4_launch(void* p0, size_t b0, void* p1, size_t b1, void* p2, size_t b2, void* p3, size_t b3, hipStream_t s);
 // dst[cols, ldd] = src[rows, lds]^T, zero-filling dst columns rows..ldd-1
