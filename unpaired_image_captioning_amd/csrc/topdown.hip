@@ -51,7 +51,7 @@ struct Layout {
   void* tLA; void* tLB; float* colscratchL;   // scratch of the logit-layer weight gradients (side stream)
   void* tSA; void* tSB; float* slab2;         // scratch of the per-chunk recurrent weight gradients (side stream)
   int* embed_scratch;                         // uic_embed_bwd_sorted_launch
-  void* ones_blk;                             // [WG_CHUNK * N, 128] operand dtype, all ones: the "input" whose weight gradient is the bias gradient
+  void* ones_blk; size_t ones_rows;           // [max(WG_CHUNK * N, N * R), 128] operand dtype, all ones: the "input" whose weight gradient is the bias gradient
   unsigned* rnn_sync; unsigned long long* rnn_dbg;   // persistent recurrence (rnn_persist.hip): sync block, optional time stamps
   // sampling
   void* s_h_att[2]; void* s_h_lang[2]; float* s_c_att[2]; float* s_c_lang[2];
@@ -138,6 +138,7 @@ Layout make_layout(const uic_topdown_dims& d, void* ws) {
   size_t tb = (2 * H + (E > H ? E : H)) * Mp;   // three stacked right operands of the merged LSTM weight-gradient GEMMs
   if ((H > D ? H : D) * NRp > tb) tb = (H > D ? H : D) * NRp;
   if ((H > Dfc ? H : Dfc) * Np > tb) tb = (H > Dfc ? H : Dfc) * Np;
+  tb += 128 * (NRp > Mp ? NRp : Mp);            // + the ones segment of the bias gradients
   L.tA = b.take(ta * S);
   L.tB = b.take(tb * S);
   size_t maxcols = V1p;
@@ -167,7 +168,8 @@ Layout make_layout(const uic_topdown_dims& d, void* ws) {
     L.slab2 = (float*)b.take(sl);
   }
   L.embed_scratch = (int*)b.take(uic_embed_bwd_sorted_scratch_ints(N, T, V1) * 4);
-  L.ones_blk = b.take(rup8((size_t)WG_CHUNK * N) * 128 * S);
+  L.ones_rows = rup8((size_t)WG_CHUNK * N) > (size_t)N * R ? rup8((size_t)WG_CHUNK * N) : (size_t)N * R;
+  L.ones_blk = b.take(L.ones_rows * 128 * S);
   L.rnn_sync = (unsigned*)b.take(uic_rnn_persist_sync_bytes());
   L.rnn_dbg = (unsigned long long*)b.take((size_t)256 * T * 16 * 8);
   for (int i = 0; i < 2; ++i) {
@@ -765,6 +767,7 @@ struct Step {
 
   // ---------------------------------------------------------------- backward
   int bwd_begin(hipStream_t s) {
+    if (bias_in_chunks()) UIC_TRY(uic_fill_value_launch(dt, L.ones_blk, L.ones_rows * 128, 1.f, s));
     return uic_zero4_launch(L.dc_att, NH * 4, L.dc_lang, NH * 4, nullptr, 0, nullptr, 0, s);
   }
 
@@ -852,7 +855,6 @@ struct Step {
     if (bias_in_chunks()) {
       // the bias gradients (column sums of dG) ride in the same GEMMs: a fourth "input" segment of ones whose first column's
       // weight gradient IS the column sum -- one more column tile per row tile instead of two column-sum passes in the tail
-      if (first) UIC_TRY(uic_fill_value_launch(dt, L.ones_blk, rup8((size_t)WG_CHUNK * N) * 128, 1.f, s));
       const UicGemmTnSeg segs[4] = {{ctx, H, H}, {h_att_new, H, H}, {h_lang_prev, H, H}, {L.ones_blk, 128, 128}};
       const WDest dd[3] = {{G->lang_lstm_w_ih, 2 * H, 0, 2 * H}, {G->lang_lstm_w_hh, H, 2 * H, H}, {G->lang_lstm_b_ih, 1, 3 * H, 1}};
       UIC_TRY(wgrad_group(L.slab2, off(L.dg2_all, r0 * H4, dt), H4, H4, segs, 4, rows, dd, 3, s, !first, L.tSA, L.tSB));
@@ -970,13 +972,18 @@ struct Step {
       UIC_TRY(uic_copy_launch(G->alpha_b, L.small + A, 4, s));
     }
     if (part == 1) return UIC_OK;
-    // ctx2att
-    {
+    // ctx2att (bias gradient as the ones segment's first column where the TN path takes it, else a column-sum pass)
+    const bool ones_ok = bias_in_chunks() && A % 128 == 0 && NR % 64 == 0;
+    if (ones_ok) {
+      const UicGemmTnSeg segs[2] = {{L.attp, H, H}, {L.ones_blk, 128, 128}};
+      const WDest dd[2] = {{G->ctx2att_w, H, 0, H}, {G->ctx2att_b, 1, H, 1}};
+      UIC_TRY(wgrad_group(L.slab, L.d_patt, A, A, segs, 2, NR, dd, 2, s, false, L.tA, L.tB));
+    } else {
       const UicGemmTnSeg seg{L.attp, H, H};
       const WDest d1{G->ctx2att_w, H, 0, H};
       UIC_TRY(wgrad_group(L.slab, L.d_patt, A, A, &seg, 1, NR, &d1, 1, s, false, L.tA, L.tB));
+      UIC_TRY(uic_colsum_launch(dt, L.d_patt, NR, A, A, G->ctx2att_b, L.colscratch, L.colscratch_floats, s));
     }
-    UIC_TRY(uic_colsum_launch(dt, L.d_patt, NR, A, A, G->ctx2att_b, L.colscratch, L.colscratch_floats, s));
     {
       UicGemmParams g = gemm_base(dt, NR, H);
       add_seg(g, L.d_patt, A, dv.ctx2attT, A, A);
@@ -999,12 +1006,16 @@ struct Step {
       UIC_TRY(uic_relu_mask_bwd_fold_launch(dt, L.d_att, act, inv_keep, L.d_pre, N / d.seq_per_img, d.seq_per_img, (size_t)R * H, s));
     else
       UIC_TRY(uic_relu_mask_bwd_launch(dt, L.d_att, act, inv_keep, L.d_pre, (size_t)NR * H, s));
-    {
+    if (ones_ok && D % 128 == 0 && NRa % 64 == 0) {
+      const UicGemmTnSeg segs[2] = {{att_in, D, D}, {L.ones_blk, 128, 128}};
+      const WDest dd[2] = {{G->att_w, D, 0, D}, {G->att_b, 1, D, 1}};
+      UIC_TRY(wgrad_group(L.slab, L.d_pre, H, H, segs, 2, NRa, dd, 2, s, false, L.tA, L.tB));
+    } else {
       const UicGemmTnSeg seg{att_in, D, D};
       const WDest d1{G->att_w, D, 0, D};
       UIC_TRY(wgrad_group(L.slab, L.d_pre, H, H, &seg, 1, NRa, &d1, 1, s, false, L.tA, L.tB));
+      UIC_TRY(uic_colsum_launch(dt, L.d_pre, NRa, H, H, G->att_b, L.colscratch, L.colscratch_floats, s));
     }
-    UIC_TRY(uic_colsum_launch(dt, L.d_pre, NRa, H, H, G->att_b, L.colscratch, L.colscratch_floats, s));
     if (d.use_bn) {        // G->att_w holds dW' = d_pre^T xhat: unfold the BatchNorm1d(D) affine part (batchnorm.hip)
       UIC_REQUIRE(G->att_bn0_w && G->att_bn0_b, "backward: use_bn needs gradient tensors for att_embed.0");
       UIC_TRY(uic_bn_fold_grad_launch(w->att_w, w->att_bn0_w, w->att_bn0_b, G->att_w, G->att_b, H, D, G->att_bn0_w, G->att_bn0_b, s));
