@@ -1163,16 +1163,15 @@ int uic_embed_bwd_launch(int dtype, const float* dxt, const void* xt, const int6
   return UIC_OK;
 }
 size_t uic_embed_bwd_sorted_scratch_ints(int N, int T, int V1) { return (size_t)3 * (V1 + 1) + (size_t)N * T + 64; }
-// dtable [V1, E] is overwritten.  scratch: uic_embed_bwd_sorted_scratch_ints ints.
-int uic_embed_bwd_sorted_launch(int dtype, const float* dxt, const void* xt, const int64_t* tokens, int ldtok, int N, int T,
-                                int V1, int E, float drop_p, long skip_token, float* dtable, int* scratch, hipStream_t s) {
+// Two halves, so that a caller can do the token bucketing (which needs only the tokens) long before the gradients exist:
+//   prepare: zero dtable, histogram -> scan -> fill of the position list into `scratch`;   gather: the sums.
+int uic_embed_bwd_sorted_prepare(const int64_t* tokens, int ldtok, int N, int T, int V1, int E, float* dtable, int* scratch, hipStream_t s) {
   UIC_REQUIRE(E % 4 == 0 && scratch, "embed_bwd_sorted: E=%d must be a multiple of 4", E);
   if (V1 == 0) return UIC_OK;
   int* cnt = scratch;
   int* off = cnt + (V1 + 1);
   int* cur = off + (V1 + 1);
   int* perm = cur + (V1 + 1);
-  const float inv_keep = drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f;
   const int total = N * T;
   UIC_TRY(uic_fill_launch(dtable, 0, (size_t)V1 * E * 4, s));
   if (total == 0) return UIC_OK;
@@ -1184,11 +1183,51 @@ int uic_embed_bwd_sorted_launch(int dtype, const float* dxt, const void* xt, con
   UIC_LAUNCH_CHECK("embed_scan");
   hipLaunchKernelGGL(embed_fill_kernel, dim3(g), dim3(NT), 0, s, tokens, ldtok, N, T, V1, cur, perm);
   UIC_LAUNCH_CHECK("embed_fill");
+  return UIC_OK;
+}
+int uic_embed_bwd_sorted_gather(int dtype, const float* dxt, const void* xt, const int64_t* tokens, int ldtok, int N, int T,
+                                int V1, int E, float drop_p, long skip_token, float* dtable, const int* scratch, hipStream_t s) {
+  const int total = N * T;
+  if (V1 == 0 || total == 0) return UIC_OK;
+  const int* off = scratch + (V1 + 1);
+  const int* perm = scratch + 3 * (V1 + 1);
+  const float inv_keep = drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f;
   const int gw = (total + EMB_CH - 1) / EMB_CH;
   DISPATCH_T(dtype,
-             hipLaunchKernelGGL(embed_gather_kernel<bf16_t>, dim3(gw), dim3(128), 0, s, dxt, (const bf16_t*)xt, tokens, ldtok, N, V1, (const int*)off, (const int*)perm, total, E, inv_keep, skip_token, dtable),
-             hipLaunchKernelGGL(embed_gather_kernel<float>, dim3(gw), dim3(128), 0, s, dxt, (const float*)xt, tokens, ldtok, N, V1, (const int*)off, (const int*)perm, total, E, inv_keep, skip_token, dtable));
+             hipLaunchKernelGGL(embed_gather_kernel<bf16_t>, dim3(gw), dim3(128), 0, s, dxt, (const bf16_t*)xt, tokens, ldtok, N, V1, off, perm, total, E, inv_keep, skip_token, dtable),
+             hipLaunchKernelGGL(embed_gather_kernel<float>, dim3(gw), dim3(128), 0, s, dxt, (const float*)xt, tokens, ldtok, N, V1, off, perm, total, E, inv_keep, skip_token, dtable));
   UIC_LAUNCH_CHECK("embed_gather");
+  return UIC_OK;
+}
+// dtable [V1, E] is overwritten.  scratch: uic_embed_bwd_sorted_scratch_ints ints.
+int uic_embed_bwd_sorted_launch(int dtype, const float* dxt, const void* xt, const int64_t* tokens, int ldtok, int N, int T,
+                                int V1, int E, float drop_p, long skip_token, float* dtable, int* scratch, hipStream_t s) {
+  UIC_TRY(uic_embed_bwd_sorted_prepare(tokens, ldtok, N, T, V1, E, dtable, scratch, s));
+  return uic_embed_bwd_sorted_gather(dtype, dxt, xt, tokens, ldtok, N, T, V1, E, drop_p, skip_token, dtable, scratch, s);
+}
+// out[c] = sum_n part[n, c] for the ncols <= 1024 columns of a small [rows, ncols] f32 matrix, split over two destinations
+// (columns [0, n0) -> out0, the rest -> out1): d w_alpha / d b_alpha from the attention accumulation's per-row partials in ONE
+// launch instead of a two-stage column sum and two copies.
+namespace {
+__global__ __launch_bounds__(256) void colsum_small_kernel(const float* __restrict__ part, int rows, int ncols, int n0, float* __restrict__ out0,
+                                                           float* __restrict__ out1) {
+  __shared__ float s_acc[4][64];
+  const int c = blockIdx.x * 64 + (threadIdx.x & 63), g = threadIdx.x >> 6;
+  float acc = 0.f;
+  if (c < ncols)
+    for (int r = g; r < rows; r += 4) acc += part[(size_t)r * ncols + c];
+  s_acc[g][threadIdx.x & 63] = acc;
+  __syncthreads();
+  if (g == 0 && c < ncols) {
+    const float v = (s_acc[0][threadIdx.x] + s_acc[1][threadIdx.x]) + (s_acc[2][threadIdx.x] + s_acc[3][threadIdx.x]);
+    if (c < n0) out0[c] = v; else out1[c - n0] = v;
+  }
+}
+}  // namespace
+int uic_colsum_small_launch(const float* part, int rows, int ncols, int n0, float* out0, float* out1, hipStream_t s) {
+  if (ncols == 0) return UIC_OK;
+  hipLaunchKernelGGL(colsum_small_kernel, dim3((ncols + 63) / 64), dim3(256), 0, s, part, rows, ncols, n0, out0, out1);
+  UIC_LAUNCH_CHECK("colsum_small");
   return UIC_OK;
 }
 int uic_relu_mask_bwd_launch(int dtype, const float* grad, const void* act, float scale, void* dst, size_t n, hipStream_t s) {

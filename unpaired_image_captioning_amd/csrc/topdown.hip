@@ -923,6 +923,7 @@ struct Step {
       add_seg(g, L.dg1_all, H4, dv.wxT, H4, H4);
       g.C = L.dxt; g.ldc = E; g.flags = UIC_GEMM_OUT_F32;
       UIC_TRY(uic_gemm_launch(g, s));
+      // (bucketing the tokens at the start of the step, on the then idle side stream, was measured: no gain)
       UIC_TRY(uic_embed_bwd_sorted_launch(dt, L.dxt, L.xt_all, ss_on() ? L.tok_used : b->labels, ss_on() ? d.T : b->ld_labels, N, t_run,
                                           V1, E, drop_p, -1, G->embed_w, L.embed_scratch, s));
     }
@@ -967,9 +968,7 @@ struct Step {
       a.p_att = L.patt; a.w_alpha = w->alpha_w;
       a.d_att = L.d_att; a.d_p_att = L.d_patt; a.d_walpha_part = L.dwalpha_part;
       UIC_TRY(uic_attention_bwd_accum_launch(a, s));
-      UIC_TRY(uic_colsum_launch(UIC_F32, L.dwalpha_part, N, A + 1, A + 1, L.small, L.colscratch, L.colscratch_floats, s));
-      UIC_TRY(uic_copy_launch(G->alpha_w, L.small, (size_t)A * 4, s));
-      UIC_TRY(uic_copy_launch(G->alpha_b, L.small + A, 4, s));
+      UIC_TRY(uic_colsum_small_launch(L.dwalpha_part, N, A + 1, A, G->alpha_w, G->alpha_b, s));
     }
     if (part == 1) return UIC_OK;
     // ctx2att (bias gradient as the ones segment's first column where the TN path takes it, else a column-sum pass)

@@ -302,6 +302,12 @@ int uic_embed_bwd_launch(int dtype, const float* dxt, const void* xt, const int6
 size_t uic_embed_bwd_sorted_scratch_ints(int N, int T, int V1);
 int uic_embed_bwd_sorted_launch(int dtype, const float* dxt, const void* xt, const int64_t* tokens, int ldtok, int N, int T,
                                 int V1, int E, float drop_p, long skip_token, float* dtable, int* scratch, hipStream_t s);
+// the two halves of it: `prepare` needs only the tokens (zeroes dtable, buckets the positions), `gather` the gradients
+int uic_embed_bwd_sorted_prepare(const int64_t* tokens, int ldtok, int N, int T, int V1, int E, float* dtable, int* scratch, hipStream_t s);
+int uic_embed_bwd_sorted_gather(int dtype, const float* dxt, const void* xt, const int64_t* tokens, int ldtok, int N, int T,
+                                int V1, int E, float drop_p, long skip_token, float* dtable, const int* scratch, hipStream_t s);
+// column sums of a small f32 [rows, ncols] matrix into two destinations (columns [0, n0) -> out0, the rest -> out1), one launch
+int uic_colsum_small_launch(const float* part, int rows, int ncols, int n0, float* out0, float* out1, hipStream_t s);
 // dst = (act > 0 ? scale : 0) * grad ; grad f32, act/dst operand dtype
 int uic_relu_mask_bwd_launch(int dtype, const float* grad, const void* act, float scale, void* dst, size_t n, hipStream_t s);
 // seq_per_img > 1 (features given per image, caption rows = image * S + j):
