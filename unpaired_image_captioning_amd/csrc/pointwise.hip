@@ -1209,24 +1209,29 @@ int uic_embed_bwd_sorted_launch(int dtype, const float* dxt, const void* xt, con
 // (columns [0, n0) -> out0, the rest -> out1): d w_alpha / d b_alpha from the attention accumulation's per-row partials in ONE
 // launch instead of a two-stage column sum and two copies.
 namespace {
-__global__ __launch_bounds__(256) void colsum_small_kernel(const float* __restrict__ part, int rows, int ncols, int n0, float* __restrict__ out0,
-                                                           float* __restrict__ out1) {
-  __shared__ float s_acc[4][64];
-  const int c = blockIdx.x * 64 + (threadIdx.x & 63), g = threadIdx.x >> 6;
+__global__ __launch_bounds__(1024) void colsum_small_kernel(const float* __restrict__ part, int rows, int ncols, int n0, float* __restrict__ out0,
+                                                            float* __restrict__ out1) {
+  __shared__ float s_acc[16][64];
+  const int lc = threadIdx.x & 63, g = threadIdx.x >> 6;          // 64 columns x 16 row groups per workgroup
+  const int c = blockIdx.x * 64 + lc;
   float acc = 0.f;
-  if (c < ncols)
-    for (int r = g; r < rows; r += 4) acc += part[(size_t)r * ncols + c];
-  s_acc[g][threadIdx.x & 63] = acc;
+  if (c < ncols) {
+#pragma unroll 8
+    for (int r = g; r < rows; r += 16) acc += part[(size_t)r * ncols + c];
+  }
+  s_acc[g][lc] = acc;
   __syncthreads();
   if (g == 0 && c < ncols) {
-    const float v = (s_acc[0][threadIdx.x] + s_acc[1][threadIdx.x]) + (s_acc[2][threadIdx.x] + s_acc[3][threadIdx.x]);
+    float v = 0.f;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) v += s_acc[k][lc];
     if (c < n0) out0[c] = v; else out1[c - n0] = v;
   }
 }
 }  // namespace
 int uic_colsum_small_launch(const float* part, int rows, int ncols, int n0, float* out0, float* out1, hipStream_t s) {
   if (ncols == 0) return UIC_OK;
-  hipLaunchKernelGGL(colsum_small_kernel, dim3((ncols + 63) / 64), dim3(256), 0, s, part, rows, ncols, n0, out0, out1);
+  hipLaunchKernelGGL(colsum_small_kernel, dim3((ncols + 63) / 64), dim3(1024), 0, s, part, rows, ncols, n0, out0, out1);
   UIC_LAUNCH_CHECK("colsum_small");
   return UIC_OK;
 }
