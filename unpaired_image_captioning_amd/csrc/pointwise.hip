@@ -106,6 +106,27 @@ __global__ void sum_steps_kernel(const T* __restrict__ src, int TS, size_t step,
     dst[i] = uic_from_f<T>(s);
   }
 }
+// 16-byte chunks (step_elems a multiple of the vector width, 16-byte aligned pointers): one load instruction per step
+template <typename T>
+__global__ void sum_steps_vec_kernel(const T* __restrict__ src, int TS, size_t step, T* __restrict__ dst) {
+  constexpr int VEC = uic_vec<T>::N;
+  const size_t nch = step / VEC;
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (size_t c = (size_t)blockIdx.x * blockDim.x + threadIdx.x; c < nch; c += stride) {
+    float acc[VEC];
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) acc[j] = 0.f;
+#pragma unroll 4
+    for (int t = 0; t < TS; ++t) {
+      const uint4 v = *(const uint4*)(src + (size_t)t * step + c * VEC);
+      float f[VEC];
+      uic_unpack<T>(v, f);
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) acc[j] += f[j];
+    }
+    *(uint4*)(dst + c * VEC) = uic_pack<T>(acc);
+  }
+}
 
 // ------------------------------------------------------------------ word embedding
 // self.embed = Embedding + ReLU + Dropout (P/models/AttModel.py:73-75,160), all T steps at once:
@@ -207,22 +228,29 @@ __global__ void embed_hist_kernel(const int64_t* __restrict__ tokens, int ldtok,
 }
 // single workgroup: off[v] = exclusive prefix of cnt, cur[v] = off[v] (the fill cursor), off[V1] = total
 __global__ __launch_bounds__(1024) void embed_scan_kernel(const int* __restrict__ cnt, int V1, int* __restrict__ off, int* __restrict__ cur) {
-  __shared__ int s_part[1024];
+  __shared__ int s_wave[16];
   const int per = (V1 + 1023) / 1024;
   const int lo = threadIdx.x * per, hi = min(V1, lo + per);
   int sum = 0;
   for (int v = lo; v < hi; ++v) sum += cnt[v];
-  s_part[threadIdx.x] = sum;
-  __syncthreads();
-  for (int o = 1; o < 1024; o <<= 1) {          // Hillis-Steele inclusive scan of the per-thread sums
-    const int add = threadIdx.x >= o ? s_part[threadIdx.x - o] : 0;
-    __syncthreads();
-    s_part[threadIdx.x] += add;
-    __syncthreads();
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  int incl = sum;                                  // inclusive scan of the per-thread sums: shuffles inside the wave, LDS across
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const int up = __shfl_up(incl, o, 64);
+    if (lane >= o) incl += up;
   }
-  int run = s_part[threadIdx.x] - sum;
+  if (lane == 63) s_wave[wv] = incl;
+  __syncthreads();
+  int woff = 0, tot = 0;
+#pragma unroll
+  for (int k = 0; k < 16; ++k) {
+    if (k < wv) woff += s_wave[k];
+    tot += s_wave[k];
+  }
+  int run = incl + woff - sum;
   for (int v = lo; v < hi; ++v) { off[v] = run; cur[v] = run; run += cnt[v]; }
-  if (threadIdx.x == 1023) off[V1] = s_part[1023];
+  if (threadIdx.x == 0) off[V1] = tot;
 }
 __global__ void embed_fill_kernel(const int64_t* __restrict__ tokens, int ldtok, int N, int TS, int V1, int* __restrict__ cur, int* __restrict__ perm) {
   const int total = TS * N;
@@ -1134,6 +1162,14 @@ int uic_colsum_launch(int src_dtype, const void* src, int rows, int cols, int ld
 }
 int uic_sum_steps_launch(int dtype, const void* src, int T, size_t step_elems, void* dst, hipStream_t s) {
   if (step_elems == 0) return UIC_OK;
+  const size_t vec = dtype == UIC_BF16 ? 8 : 4;
+  if (step_elems % vec == 0 && (((uintptr_t)src | (uintptr_t)dst) & 15) == 0) {
+    const int gv = grid_for(step_elems / vec, NT);
+    DISPATCH_T(dtype, hipLaunchKernelGGL(sum_steps_vec_kernel<bf16_t>, dim3(gv), dim3(NT), 0, s, (const bf16_t*)src, T, step_elems, (bf16_t*)dst),
+               hipLaunchKernelGGL(sum_steps_vec_kernel<float>, dim3(gv), dim3(NT), 0, s, (const float*)src, T, step_elems, (float*)dst));
+    UIC_LAUNCH_CHECK("sum_steps_vec");
+    return UIC_OK;
+  }
   const int g = grid_for(step_elems, NT);
   DISPATCH_T(dtype, hipLaunchKernelGGL(sum_steps_kernel<bf16_t>, dim3(g), dim3(NT), 0, s, (const bf16_t*)src, T, step_elems, (bf16_t*)dst),
              hipLaunchKernelGGL(sum_steps_kernel<float>, dim3(g), dim3(NT), 0, s, (const float*)src, T, step_elems, (float*)dst));
