@@ -1,6 +1,7 @@
 // HBM-bound helper kernels of the TopDown training / decoding path (gfx950).
 // Every kernel cites the reference lines whose arithmetic it carries.
 #include "uic_common.h"
+#include <string.h>
 #include <stdlib.h>
 #include "../../include/uic_hip.h"
 
@@ -1086,6 +1087,49 @@ int uic_cast_f32_launch(int dtype, const float* src, void* dst, size_t n, hipStr
   DISPATCH_T(dtype, hipLaunchKernelGGL(cast_from_f32_kernel<bf16_t>, dim3(g), dim3(NT), 0, s, src, (bf16_t*)dst, n),
              hipLaunchKernelGGL(cast_from_f32_kernel<float>, dim3(g), dim3(NT), 0, s, src, (float*)dst, n));
   UIC_LAUNCH_CHECK("cast_from_f32");
+  return UIC_OK;
+}
+// up to UIC_CAST_MULTI tensors in ONE launch (blockIdx.y picks the tensor): the weight refresh of a training step is a handful
+// of small casts whose launches, not their bytes, are what the step waits for
+namespace {
+struct CastMulti { const float* src[UIC_CAST_MULTI]; void* dst[UIC_CAST_MULTI]; size_t n[UIC_CAST_MULTI]; };
+template <typename T>
+__global__ void cast_multi_kernel(const CastMulti c) {
+  const int k = blockIdx.y;
+  const float* src = k == 0 ? c.src[0] : k == 1 ? c.src[1] : k == 2 ? c.src[2] : k == 3 ? c.src[3] : k == 4 ? c.src[4] : c.src[5];
+  T* dst = (T*)(k == 0 ? c.dst[0] : k == 1 ? c.dst[1] : k == 2 ? c.dst[2] : k == 3 ? c.dst[3] : k == 4 ? c.dst[4] : c.dst[5]);
+  const size_t n = k == 0 ? c.n[0] : k == 1 ? c.n[1] : k == 2 ? c.n[2] : k == 3 ? c.n[3] : k == 4 ? c.n[4] : c.n[5];
+  const size_t stride = (size_t)gridDim.x * blockDim.x * 4;
+  for (size_t i = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * 4; i < n; i += stride) {
+    if (i + 3 < n) {
+      const float4 v = make_float4(__builtin_nontemporal_load(src + i), __builtin_nontemporal_load(src + i + 1),
+                                   __builtin_nontemporal_load(src + i + 2), __builtin_nontemporal_load(src + i + 3));
+      if constexpr (sizeof(T) == 2) *(uint2*)(dst + i) = make_uint2(uic_pack_bf16x2(v.x, v.y), uic_pack_bf16x2(v.z, v.w));
+      else *(float4*)(dst + i) = v;
+    } else {
+      for (size_t j = i; j < n; ++j) dst[j] = uic_from_f<T>(src[j]);
+    }
+  }
+}
+}  // namespace
+int uic_cast_f32_multi_launch(int dtype, int count, const float* const* src, void* const* dst, const size_t* n, hipStream_t s) {
+  UIC_REQUIRE(count >= 0 && count <= UIC_CAST_MULTI, "cast_multi: %d tensors (max %d)", count, UIC_CAST_MULTI);
+  CastMulti c;
+  memset(&c, 0, sizeof(c));
+  size_t most = 0;
+  int m = 0;
+  for (int i = 0; i < count; ++i) {
+    if (n[i] == 0) continue;
+    UIC_REQUIRE(src[i] && dst[i] && (((uintptr_t)src[i] | (uintptr_t)dst[i]) & 15) == 0, "cast_multi: tensor %d must be 16-byte aligned", i);
+    c.src[m] = src[i]; c.dst[m] = dst[i]; c.n[m] = n[i];
+    if (n[i] > most) most = n[i];
+    ++m;
+  }
+  if (m == 0) return UIC_OK;
+  const int g = grid_for(most, NT * 4);
+  DISPATCH_T(dtype, hipLaunchKernelGGL(cast_multi_kernel<bf16_t>, dim3(g, m), dim3(NT), 0, s, c),
+             hipLaunchKernelGGL(cast_multi_kernel<float>, dim3(g, m), dim3(NT), 0, s, c));
+  UIC_LAUNCH_CHECK("cast_multi");
   return UIC_OK;
 }
 int uic_to_f32_launch(int dtype, const void* src, float* dst, size_t n, hipStream_t s) {

@@ -497,16 +497,19 @@ int uic_topdown_refresh_weights(const uic_topdown_dims* d, const uic_topdown_wei
   hipStream_t s2 = ss->stream;
   UIC_TRY(uic_check_hip(hipEventRecord(ss->ev_r0, s), "hipEventRecord"));          // the master weights are final
   UIC_TRY(uic_check_hip(hipStreamWaitEvent(s2, ss->ev_r0, 0), "hipStreamWaitEvent"));
-  if (dt == UIC_BF16) {
-    UIC_TRY(uic_cast_f32_launch(dt, w->fc_w, (void*)v.fc_w, (size_t)H * Dfc, s));
-    if (!d->use_bn) UIC_TRY(uic_cast_f32_launch(dt, w->att_w, (void*)v.att_w, (size_t)H * D, s));
-    UIC_TRY(uic_cast_f32_launch(dt, w->ctx2att_w, (void*)v.ctx2att_w, (size_t)A * H, s));
-    UIC_TRY(uic_cast_f32_launch(dt, w->att_lstm_w_ih, (void*)v.att_w_ih, (size_t)4 * H * (E + 2 * H), s));
-    UIC_TRY(uic_cast_f32_launch(dt, w->logit_w, (void*)v.logit_w, (size_t)V1 * H, s2));
-    UIC_TRY(uic_cast_f32_launch(dt, w->att_lstm_w_hh, (void*)v.att_w_hh, (size_t)4 * H * H, s2));
-    UIC_TRY(uic_cast_f32_launch(dt, w->lang_lstm_w_ih, (void*)v.lang_w_ih, (size_t)4 * H * 2 * H, s2));
-    UIC_TRY(uic_cast_f32_launch(dt, w->lang_lstm_w_hh, (void*)v.lang_w_hh, (size_t)4 * H * H, s2));
-    UIC_TRY(uic_cast_f32_launch(dt, w->h2att_w, (void*)v.h2att_w, (size_t)A * H, s2));
+  if (dt == UIC_BF16) {   // one launch per stream (the step waits for launches here, not for bytes)
+    {
+      const float* src[4] = {w->fc_w, d->use_bn ? nullptr : w->att_w, w->ctx2att_w, w->att_lstm_w_ih};
+      void* dst[4] = {(void*)v.fc_w, (void*)v.att_w, (void*)v.ctx2att_w, (void*)v.att_w_ih};
+      const size_t n[4] = {(size_t)H * Dfc, d->use_bn ? 0 : (size_t)H * D, (size_t)A * H, (size_t)4 * H * (E + 2 * H)};
+      UIC_TRY(uic_cast_f32_multi_launch(dt, 4, src, dst, n, s));
+    }
+    {
+      const float* src[5] = {w->logit_w, w->att_lstm_w_hh, w->lang_lstm_w_ih, w->lang_lstm_w_hh, w->h2att_w};
+      void* dst[5] = {(void*)v.logit_w, (void*)v.att_w_hh, (void*)v.lang_w_ih, (void*)v.lang_w_hh, (void*)v.h2att_w};
+      const size_t n[5] = {(size_t)V1 * H, (size_t)4 * H * H, (size_t)4 * H * 2 * H, (size_t)4 * H * H, (size_t)A * H};
+      UIC_TRY(uic_cast_f32_multi_launch(dt, 5, src, dst, n, s2));
+    }
   }
   if (d->use_bn) {
     UIC_REQUIRE(w->att_bn0_w && w->att_bn0_b && w->att_bn0_rm && w->att_bn0_rv, "use_bn=%d needs the att_embed.0 BatchNorm tensors", d->use_bn);

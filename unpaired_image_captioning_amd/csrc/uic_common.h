@@ -281,6 +281,8 @@ int uic_rnn_fwd_persist_launch(const UicRnnFwdParams& p, hipStream_t s);
 // ---------------------------------------------------------------- pointwise (pointwise.hip)
 int uic_cast_f32_launch(int dtype, const float* src, void* dst, size_t n, hipStream_t s);
 int uic_to_f32_launch(int dtype, const void* src, float* dst, size_t n, hipStream_t s);
+#define UIC_CAST_MULTI 6
+int uic_cast_f32_multi_launch(int dtype, int count, const float* const* src, void* const* dst, const size_t* n, hipStream_t s);   // several casts, one launch
 int uic_fill_launch(void* dst, int value_byte, size_t bytes, hipStream_t s);
 int uic_copy_launch(void* dst, const void* src, size_t bytes, hipStream_t s);
 int uic_fill_value_launch(int dtype, void* dst, size_t n, float value, hipStream_t s);   // n elements of the operand dtype = value   // device -> device, 4-byte granules
