@@ -580,6 +580,7 @@ struct Step {
 
   // scheduled sampling (AttModel.py:130-143) is active in train mode only
   bool ss_on() const { return (training & 1) && b->ss_prob > 0.f; }
+  bool embed_prepared = false;   // the fused step bucketed the tokens (uic_embed_bwd_sorted_prepare) while the side stream was idle
 
   // ---------------------------------------------------------------- forward
   int fwd_prologue(hipStream_t s) {
@@ -926,8 +927,9 @@ struct Step {
       add_seg(g, L.dg1_all, H4, dv.wxT, H4, H4);
       g.C = L.dxt; g.ldc = E; g.flags = UIC_GEMM_OUT_F32;
       UIC_TRY(uic_gemm_launch(g, s));
-      // (bucketing the tokens at the start of the step, on the then idle side stream, was measured: no gain)
-      UIC_TRY(uic_embed_bwd_sorted_launch(dt, L.dxt, L.xt_all, ss_on() ? L.tok_used : b->labels, ss_on() ? d.T : b->ld_labels, N, t_run,
+      if (!embed_prepared)
+        UIC_TRY(uic_embed_bwd_sorted_prepare(ss_on() ? L.tok_used : b->labels, ss_on() ? d.T : b->ld_labels, N, t_run, V1, E, G->embed_w, L.embed_scratch, s));
+      UIC_TRY(uic_embed_bwd_sorted_gather(dt, L.dxt, L.xt_all, ss_on() ? L.tok_used : b->labels, ss_on() ? d.T : b->ld_labels, N, t_run,
                                           V1, E, drop_p, -1, G->embed_w, L.embed_scratch, s));
     }
     // fc' path: dGfc = sum_t dG1_t
@@ -1202,6 +1204,10 @@ int uic_topdown_xe_train_step(const uic_topdown_dims* d, const uic_topdown_weigh
   // main: BPTT, each step waits for the d hdrop rows of its chunk; side: the recurrent weight gradients of every
   // finished chunk (transposes + accumulating GEMMs), so only the last chunk's share outlives the loop
   UIC_TRY(st.bwd_begin(s));
+  if (!st.ss_on()) {   // the embedding gradient's token bucketing needs only the labels: in the side stream's slack inside the BPTT window
+    UIC_TRY(uic_embed_bwd_sorted_prepare(b->labels, b->ld_labels, d->N, t_run, d->V1, d->E, G->embed_w, st.L.embed_scratch, s2));
+    st.embed_prepared = true;
+  }
   for (int c = nchunk - 1; c >= 0; --c) {
     const int t0 = c * CH, t1 = t0 + CH < t_run ? t0 + CH : t_run;
     UIC_HIP(hipStreamWaitEvent(s, ss->ev_side[c], 0));
