@@ -466,6 +466,21 @@ int uic_disc_bce(const float* logits, const float* labels, int32_t N, float* los
 int uic_disc_backward(const uic_disc_dims* d, const uic_disc_weights* w, const int64_t* tokens, int32_t ld_tokens, int32_t training,
                       uint32_t seed, void* workspace, const float* dlogits, const uic_disc_weights* G, void* stream);
 
+/* ---- Scene-graph GCN encoder (BASELINE configs[4]: "GCN over 36 objects + relations -> attention-LSTM decoder").  NO REFERENCE
+ * CODE EXISTS: like the discriminator this is the package's own statement of the usual graph convolution, parity UNPINNED
+ * (csrc/gcn.hip, oracle/gcn.py).  X_0 = x [N, R, D];  X_{l+1} = relu(A_hat (X_l W_l^T) + b_l), W_l [H, D_l] (nn.Linear
+ * layout), l < layers <= UIC_GCN_MAX_LAYERS;  adj = A_hat [N, R, R] f32, the caller's normalised relation graph (data, no
+ * gradient; R <= 64).  out [N, R, H] f32 = the att_feats the captioner takes (att_feat_size = H). ---- */
+#define UIC_GCN_MAX_LAYERS 3
+typedef struct { int32_t dtype, N, R, D, H, layers; } uic_gcn_dims;
+typedef struct { float* w[UIC_GCN_MAX_LAYERS]; float* b[UIC_GCN_MAX_LAYERS]; } uic_gcn_weights;
+size_t uic_gcn_workspace_bytes(const uic_gcn_dims* d);
+int uic_gcn_forward(const uic_gcn_dims* d, const uic_gcn_weights* w, const float* x, const float* adj, void* workspace, float* out,
+                    void* stream);
+/* backward of the forward that last ran on `workspace`: G (f32, overwritten) from dout [N, R, H]; dx (optional) [N, R, D] */
+int uic_gcn_backward(const uic_gcn_dims* d, const uic_gcn_weights* w, const float* adj, void* workspace, const float* dout,
+                     const uic_gcn_weights* G, float* dx, void* stream);
+
 /* ---- CIDEr-D reward of the self-critical step ----
  * get_self_critical_reward (P/misc/rewards.py:37-81) over the CIDEr-D scorer
  * (P/misc/cider/pyciderevalcap/ciderD/ciderD_scorer.py:116-209, ciderD.py:26-50) on integer token rows, so that the sampled

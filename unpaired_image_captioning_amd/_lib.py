@@ -120,6 +120,17 @@ class DiscWeights(C.Structure):
                 ("hw_w", C.c_void_p), ("hw_b", C.c_void_p), ("out_w", C.c_void_p), ("out_b", C.c_void_p)]
 
 
+GCN_MAX_LAYERS = 3
+
+
+class GcnDims(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ("dtype", "N", "R", "D", "H", "layers")]
+
+
+class GcnWeights(C.Structure):
+    _fields_ = [("w", C.c_void_p * GCN_MAX_LAYERS), ("b", C.c_void_p * GCN_MAX_LAYERS)]
+
+
 NMT_MAX_LAYERS = 4
 SITE_NMT_ENC0, SITE_NMT_DEC0, SITE_NMT_OUT0 = 1000, 2000, 4000   # + layer ; + layer*256 + step ; + step
 
@@ -182,6 +193,10 @@ _SIGS = {
     "uic_version": (C.c_int, []),
     "uic_set_persistent_rnn": (C.c_int, [C.c_int32]),
     "uic_comm_unique_id": (C.c_int, [C.c_void_p]),
+    "uic_gcn_workspace_bytes": (C.c_size_t, [C.POINTER(GcnDims)]),
+    "uic_gcn_forward": (C.c_int, [C.POINTER(GcnDims), C.POINTER(GcnWeights), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "uic_gcn_backward": (C.c_int, [C.POINTER(GcnDims), C.POINTER(GcnWeights), C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(GcnWeights),
+                                   C.c_void_p, C.c_void_p]),
     "uic_disc_workspace_bytes": (C.c_size_t, [C.POINTER(DiscDims)]),
     "uic_disc_forward": (C.c_int, [C.POINTER(DiscDims), C.POINTER(DiscWeights), C.c_void_p, C.c_int32, C.c_int32, C.c_uint32, C.c_void_p,
                                    C.c_void_p, C.c_void_p, C.c_void_p]),

@@ -5,6 +5,7 @@ from .CaptionModel import CaptionModel  # noqa: F401
 from .FCModel_NMT import FCModel_NMT  # noqa: F401
 from . import NMT_Models  # noqa: F401
 from .Discriminator import SentenceDiscriminator  # noqa: F401
+from .GCN import SceneGraphEncoder  # noqa: F401
 
 
 def setup(opt):
