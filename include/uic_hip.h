@@ -129,6 +129,11 @@ typedef struct uic_topdown_batch {
                                mode at steps >= 1): with this probability a row's input token is replaced by a draw from
                                exp(previous step's log-probs).  The inputs actually used stay in the workspace
                                ("tok_used", [N, T] int64) for the backward pass and for the tests. 0 = teacher forcing. */
+  /* Optional outputs of uic_topdown_backward / uic_topdown_xe_train_step (NULL = not computed, the default of every
+     reference call site: the reference's features are data).  Gradients of the loss w.r.t. the input features, for an
+     encoder in front of the captioner (BASELINE configs[4]'s scene-graph GCN, uic_gcn_backward's `dout`): */
+  float* d_att_feats;       /* [N, R, D]  ([N / seq_per_img, R, D]); padded regions get zeros.  Needs dims.use_bn == 0 */
+  float* d_fc_feats;        /* [N, Dfc]   ([N / seq_per_img, Dfc]) */
 } uic_topdown_batch;
 
 /* Sizes (bytes) of the two caller-allocated arenas. */

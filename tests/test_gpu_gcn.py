@@ -80,3 +80,54 @@ def test_gcn_nodes_feed_the_captioner():
     with torch.no_grad():
         logp = cap(nodes.mean(1), None, nodes.detach(), labels.cuda(), None)
     assert logp.shape[0] == N and torch.isfinite(logp).all()
+
+
+def test_encoder_trains_jointly_with_the_captioner_vs_chained_oracles():
+    """configs[4] end to end (f32): loss = LanguageModelCriterion(TopDown(fc = mean node, att = GCN(x, A_hat))) through
+    torch.autograd on the device -- the captioner hands d att_feats / d fc_feats back (uic_topdown_batch.d_att_feats /
+    d_fc_feats) and the encoder's backward takes them as `dout` -- against autograd through oracle/gcn.py + oracle/topdown.py."""
+    from oracle import topdown as OT
+    from unpaired_image_captioning_amd import models
+    from unpaired_image_captioning_amd.models import SceneGraphEncoder
+    from unpaired_image_captioning_amd.misc.criterion import LanguageModelCriterion
+    N, R, D, H, V, L = 10, 12, 48, 64, 40, 6
+    eopt = argparse.Namespace(att_feat_size=D, gcn_hidden_size=H, gcn_layers=2, compute_dtype="f32")
+    copt = argparse.Namespace(vocab_size=V, input_encoding_size=32, rnn_size=64, num_layers=1, drop_prob_lm=0.0, seq_length=L,
+                              fc_feat_size=H, att_feat_size=H, att_hid_size=32, use_bn=0, caption_model="topdown", compute_dtype="f32")
+    torch.manual_seed(3)
+    enc = SceneGraphEncoder(eopt)
+    cap = models.setup(copt)
+    We = {k: v.detach().clone() for k, v in enc.state_dict().items()}
+    Wc = {k: v.detach().clone() for k, v in cap.state_dict().items()}
+    enc.cuda()
+    cap.cuda().train()
+    g = torch.Generator().manual_seed(8)
+    x = torch.randn(N, R, D, generator=g).abs()
+    adj = O.normalised_adjacency(N, R, seed=4)
+    b = OT.synthetic_batch(N, 1, R, D, V, L, seed=11)
+    labels, masks = b["labels"], b["masks"]
+
+    # oracle chain
+    Weg = {k: v.clone().requires_grad_(True) for k, v in We.items()}
+    Wcg = {k: (v.clone().requires_grad_(True) if v.is_floating_point() else v) for k, v in Wc.items()}
+    nodes_o = O.forward(Weg, x, adj, 2)
+    logp_o = OT.forward_logprobs(Wcg, nodes_o.mean(1), nodes_o, labels, None, None, 0, True)
+    loss_o = OT.lm_criterion(logp_o, labels[:, 1:], masks[:, 1:])
+    loss_o.backward()
+
+    nodes = enc(x.cuda(), adj.cuda())
+    logp = cap(nodes.mean(1), None, nodes, labels.cuda(), None)
+    loss = LanguageModelCriterion()(logp, labels[:, 1:].cuda(), masks[:, 1:].cuda())
+    loss.backward()
+    assert abs(loss.item() - loss_o.item()) < 1e-4
+    floor = 1e-3 * max(float(v.grad.norm()) for v in Weg.values())
+    for k, p in enc.named_parameters():
+        r = Weg[k].grad.double()
+        err = ((p.grad.cpu().double() - r).norm() / max(r.norm().item(), floor)).item()
+        assert err < 2e-4, (k, err)
+    for k, p in cap.named_parameters():      # and the decoder's own gradients are the usual ones
+        r = Wcg[k].grad
+        if r is None:
+            continue
+        scale = max(r.double().norm().item(), 1e-3 * max(float(v.grad.norm()) for v in Wcg.values() if getattr(v, "grad", None) is not None))
+        assert ((p.grad.cpu().double() - r.double()).norm() / scale).item() < 2e-4, k

@@ -1120,3 +1120,61 @@ def test_multinomial_draws_follow_the_softmax():
     sigma = (N * p * (1 - p)).sqrt().clamp_min(1.0)
     assert ((counts - N * p).abs() / sigma).max().item() < 5.0
     assert 0.5 * (counts / N - p).abs().sum().item() < 0.05
+
+
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+@pytest.mark.parametrize("per_image", [False, True])
+@pytest.mark.parametrize("fused", [True, False])
+def test_input_feature_gradients_vs_oracle(dtype, per_image, fused):
+    """Optional outputs Batch.d_fc_feats / d_att_feats (an encoder in front of the captioner, BASELINE configs[4]): the loss
+    gradient w.r.t. the input features against autograd through the oracle; with per-image features the S caption rows of
+    an image are summed; padded regions get exact zeros; the weight gradients are untouched by asking for them."""
+    from unpaired_image_captioning_amd import models
+    from unpaired_image_captioning_amd.trainer import xe_step
+    cfg = dict(V=300, E=64, H=96, A=64, D=157, Dfc=136, L=7, n_img=12, S=3, R=9)        # D is padded to 160 columns inside
+    torch.manual_seed(5)
+    model = models.setup(make_opt(cfg, dtype, seed=4))
+    W = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    model.cuda().train()
+    b = O.synthetic_batch(cfg["n_img"], cfg["S"], cfg["R"], cfg["D"], cfg["V"], cfg["L"], seed=9, ragged_regions=True)
+    b["fc_feats"] = b["fc_feats"][:, :1].repeat(1, cfg["Dfc"]) * torch.linspace(0.5, 1.5, cfg["Dfc"])   # Dfc != D
+    fc_o = b["fc_feats"].clone().requires_grad_(True)
+    att_o = b["att_feats"].clone().requires_grad_(True)
+    loss_o, grads_o, _ = O.xe_loss_and_grads(W, fc_o, att_o, b["labels"], b["masks"], b["att_masks"])
+    dfc_o, datt_o = fc_o.grad, att_o.grad
+    batch = {k: v.cuda() for k, v in b.items()}
+    if per_image:
+        batch = _per_image(batch, cfg["S"])
+        dfc_o = dfc_o.view(cfg["n_img"], cfg["S"], -1).sum(1)
+        datt_o = datt_o.view(cfg["n_img"], cfg["S"], cfg["R"], -1).sum(1)
+    d_fc, d_att = model.engine.input_grad_buffers(batch["fc_feats"], batch["att_feats"])
+    d_fc.fill_(float("nan"))
+    d_att.fill_(float("nan"))
+    loss, grads = xe_step(model, batch, fused=fused, d_fc=d_fc, d_att=d_att)
+    assert abs(loss.item() - loss_o.item()) < LOGP_TOL[dtype]
+    grads_close(grads, grads_o, GRAD_TOL[dtype])
+    d_att = d_att[..., :cfg["D"]]
+    # bf16: d att_feats sits behind the whole bf16 backward (attention, both ReLU masks, bf16 d_pre x bf16 W_att) -- 5e-2 measured
+    tol = 2e-4 if dtype == "f32" else 8e-2
+    for name, got, ref in (("d_fc", d_fc, dfc_o), ("d_att", d_att, datt_o)):
+        got = got.cpu().double()
+        assert torch.isfinite(got).all(), name
+        err = ((got - ref.double()).norm() / ref.double().norm()).item()
+        assert err < tol, (name, err)
+    dead = batch["att_masks"].cpu() == 0
+    assert dead.any() and (d_att.cpu()[dead] == 0).all()
+
+
+def test_input_feature_gradient_refused_through_batchnorm():
+    from unpaired_image_captioning_amd import models
+    from unpaired_image_captioning_amd.trainer import xe_step
+    cfg = dict(V=50, E=32, H=32, A=32, D=64, L=5, n_img=4, S=1, R=6, use_bn=1)
+    model = models.setup(make_opt(cfg, "f32", seed=1)).cuda().train()
+    b = O.synthetic_batch(cfg["n_img"], cfg["S"], cfg["R"], cfg["D"], cfg["V"], cfg["L"], seed=2)
+    batch = {k: v.cuda() for k, v in b.items()}
+    d_fc, d_att = model.engine.input_grad_buffers(batch["fc_feats"], batch["att_feats"])
+    with pytest.raises(RuntimeError, match="d_att_feats"):
+        xe_step(model, batch, d_fc=d_fc, d_att=d_att)
+    torch.cuda.synchronize()
+    loss, _ = xe_step(model, batch, d_fc=d_fc)          # the fc branch has no BatchNorm
+    assert torch.isfinite(loss) and torch.isfinite(d_fc).all()

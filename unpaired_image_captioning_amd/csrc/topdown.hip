@@ -51,6 +51,7 @@ struct Layout {
   void* tLA; void* tLB; float* colscratchL;   // scratch of the logit-layer weight gradients (side stream)
   void* tSA; void* tSB; float* slab2;         // scratch of the per-chunk recurrent weight gradients (side stream)
   int* embed_scratch;                         // uic_embed_bwd_sorted_launch
+  void* fcwT; void* attwT;                     // fc_embed / att_embed weights transposed ([Dfc, H], [D, H]): only for the optional input-feature gradients
   void* ones_blk; size_t ones_rows;           // [max(WG_CHUNK * N, N * R), 128] operand dtype, all ones: the "input" whose weight gradient is the bias gradient
   unsigned* rnn_sync; unsigned long long* rnn_dbg;   // persistent recurrence (rnn_persist.hip): sync block, optional time stamps
   // sampling
@@ -168,6 +169,8 @@ Layout make_layout(const uic_topdown_dims& d, void* ws) {
     L.slab2 = (float*)b.take(sl);
   }
   L.embed_scratch = (int*)b.take(uic_embed_bwd_sorted_scratch_ints(N, T, V1) * 4);
+  L.fcwT = b.take(Dfc * H * S);
+  L.attwT = b.take(D * H * S);
   L.ones_rows = rup8((size_t)WG_CHUNK * N) > (size_t)N * R ? rup8((size_t)WG_CHUNK * N) : (size_t)N * R;
   L.ones_blk = b.take(L.ones_rows * 128 * S);
   L.rnn_sync = (unsigned*)b.take(uic_rnn_persist_sync_bytes());
@@ -952,6 +955,16 @@ struct Step {
       UIC_TRY(wgrad_group(slab, L.dfcpre, H, H, &seg, 1, N, &d1, 1, s, false, tA, tB));
     }
     UIC_TRY(uic_colsum_launch(dt, L.dfcpre, N, H, H, G->fc_b, colscratch, L.colscratch_floats, s));
+    if (b->d_fc_feats) {   // optional: d fc_feats = d fc_pre W_fc, the S caption rows of an image summed (row i S + k of d fc_pre: lda = S H)
+      const int S = d.seq_per_img > 1 ? d.seq_per_img : 1;
+      UIC_TRY(uic_transpose_launch(dt, dv.fc_w, H, Dfc, Dfc, L.fcwT, H, s));
+      for (int k = 0; k < S; ++k) {
+        UicGemmParams g = gemm_base(dt, N / S, Dfc);
+        add_seg(g, off(L.dfcpre, (size_t)k * H, dt), S * H, L.fcwT, H, H);
+        g.C = b->d_fc_feats; g.ldc = Dfc; g.flags = UIC_GEMM_OUT_F32 | (k ? UIC_GEMM_ACCUM : 0);
+        UIC_TRY(uic_gemm_launch(g, s));
+      }
+    }
     return UIC_OK;
   }
   // part: 0 = everything, 1 = only the deferred attention accumulation, 2 = everything else.  (Measured: running the
@@ -1019,6 +1032,13 @@ struct Step {
       const WDest d1{G->att_w, D, 0, D};
       UIC_TRY(wgrad_group(L.slab, L.d_pre, H, H, &seg, 1, NRa, &d1, 1, s, false, L.tA, L.tB));
       UIC_TRY(uic_colsum_launch(dt, L.d_pre, NRa, H, H, G->att_b, L.colscratch, L.colscratch_floats, s));
+    }
+    if (b->d_att_feats) {  // optional: d att_feats = d_pre W_att  (one row per image region; d_pre is already folded over seq_per_img)
+      UIC_TRY(uic_transpose_launch(dt, dv.att_w, H, D, D, L.attwT, H, s));
+      UicGemmParams g = gemm_base(dt, NRa, D);
+      add_seg(g, L.d_pre, H, L.attwT, H, H);
+      g.C = b->d_att_feats; g.ldc = D; g.flags = UIC_GEMM_OUT_F32;
+      UIC_TRY(uic_gemm_launch(g, s));
     }
     if (d.use_bn) {        // G->att_w holds dW' = d_pre^T xhat: unfold the BatchNorm1d(D) affine part (batchnorm.hip)
       UIC_REQUIRE(G->att_bn0_w && G->att_bn0_b, "backward: use_bn needs gradient tensors for att_embed.0");
@@ -1128,6 +1148,7 @@ int uic_topdown_backward(const uic_topdown_dims* d, const uic_topdown_weights* w
   UIC_REQUIRE(w && derived && b && workspace && G, "backward: null pointer");
   UIC_REQUIRE(t_run >= 1 && t_run <= d->T, "backward: t_run=%d outside [1,%d]", t_run, d->T);
   UIC_REQUIRE(!dlogprobs || logprobs, "backward: dlogprobs needs the forward log-probs");
+  UIC_REQUIRE(!b->d_att_feats || !d->use_bn, "backward: d_att_feats is not available through att_embed's BatchNorm (use_bn=%d)", d->use_bn);
   hipStream_t s = (hipStream_t)stream;
   Step st;
   st.init(d, w, derived, b, t_run, training, seed, workspace, G);
@@ -1152,6 +1173,7 @@ int uic_topdown_xe_train_step(const uic_topdown_dims* d, const uic_topdown_weigh
   UIC_REQUIRE(t_run >= 1 && t_run <= d->T, "xe_train_step: t_run=%d outside [1,%d]", t_run, d->T);
   UIC_REQUIRE(b->ld_labels >= d->T + 1 && (!b->masks || b->ld_masks >= d->T + 1), "xe_train_step: labels/masks need %d columns", d->T + 1);
   UIC_REQUIRE(!b->grad_scale || b->ld_grad_scale >= t_run, "xe_train_step: grad_scale needs %d columns", t_run);
+  UIC_REQUIRE(!b->d_att_feats || !d->use_bn, "xe_train_step: d_att_feats is not available through att_embed's BatchNorm (use_bn=%d)", d->use_bn);
   hipStream_t s = (hipStream_t)stream;
   SideStream* ss = nullptr;
   UIC_TRY(get_side(&ss));

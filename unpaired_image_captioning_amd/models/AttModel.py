@@ -62,12 +62,17 @@ class _TopDownForward(torch.autograd.Function):
         fc, att, att_masks, seq = ctx.inputs
         pd = dict(zip(model.param_names, ctx.params))
         w = eng.refresh(pd, d)
-        b = eng.batch_struct(fc, att, att_masks, seq, ss_prob=ss_prob)
+        # features that came out of an encoder (the scene-graph GCN of configs[4]) ask for their gradient; the reference's
+        # own features are data and pay nothing
+        d_fc, d_att = eng.input_grad_buffers(fc, att, ctx.needs_input_grad[1], ctx.needs_input_grad[2])
+        b = eng.batch_struct(fc, att, att_masks, seq, ss_prob=ss_prob, d_fc=d_fc, d_att=d_att)
         grads = {k: torch.empty_like(v) for k, v in pd.items()}
         eng.backward(ctx.ws, d, w, b, t_run, training, seed, grads, dlogprobs=g.contiguous(), logprobs=logp)
         eng.release(ctx.ws)
         ctx.ws = None
-        return (None, None, None, None, None, None) + tuple(grads[k] for k in model.param_names)
+        if d_att is not None:
+            d_att = d_att[..., :att.shape[-1]]
+        return (None, d_fc, d_att, None, None, None) + tuple(grads[k] for k in model.param_names)
 
 
 class _TopDownSample(torch.autograd.Function):

@@ -167,10 +167,18 @@ class TopDownEngine(object):
         check(self.lib.uic_topdown_refresh_weights(C.byref(d), C.byref(w), ptr(self._derived), stream()), "refresh_weights")
         return w
 
-    def batch_struct(self, fc, att, att_masks, labels=None, masks=None, grad_scale=None, ss_prob=0.0):
+    def input_grad_buffers(self, fc, att, want_fc=True, want_att=True):
+        """Output tensors for Batch.d_fc_feats / d_att_feats (att at the padded row width; slice [..., :D] afterwards)."""
+        d_fc = torch.empty(fc.shape, dtype=torch.float32, device=fc.device) if want_fc else None
+        d_att = torch.empty(att.shape[:-1] + (self.Dp,), dtype=torch.float32, device=att.device) if want_att else None
+        return d_fc, d_att
+
+    def batch_struct(self, fc, att, att_masks, labels=None, masks=None, grad_scale=None, ss_prob=0.0, d_fc=None, d_att=None):
         b = Batch()
         att = self._pad_att(att)
         b._keep = att                          # (a padded copy must outlive the call)
+        b.d_fc_feats = ptr(d_fc)
+        b.d_att_feats = ptr(d_att)
         b.fc_feats = ptr(fc)
         b.att_feats = ptr(att)
         b.att_masks = ptr(att_masks)
@@ -211,14 +219,14 @@ class TopDownEngine(object):
         self._write_back(g)
 
     def xe_train_step(self, params, fc, att, att_masks, labels, masks, t_run, training, seed, grads, inv_den=None,
-                      grad_scale=None, ss_prob=0.0, keep_workspace=False):
+                      grad_scale=None, ss_prob=0.0, keep_workspace=False, d_fc=None, d_att=None):
         """Fused forward + criterion + backward on two HIP streams; returns a device tensor [loss, sum(mask)]."""
         (N, S), R = self._rows(att, labels), att.shape[1]
         T = labels.shape[1] - 1
         d = self.dims(N, R, T, S)
         w = self.refresh(params, d)
         ws = self.checkout(d, fc.device)
-        b = self.batch_struct(fc, att, att_masks, labels, masks, grad_scale, ss_prob)
+        b = self.batch_struct(fc, att, att_masks, labels, masks, grad_scale, ss_prob, d_fc=d_fc, d_att=d_att)
         g = self.weights_struct(grads, outputs=True)
         out = torch.empty(2, dtype=torch.float32, device=fc.device)
         try:

@@ -27,9 +27,11 @@ def _steps_from_host_labels(labels_np):
     return int(z[0]) + 1 if z.size else T
 
 
-def xe_step(model, batch, t_run=None, inv_den=None, grads=None, return_seed=False, fused=True):
+def xe_step(model, batch, t_run=None, inv_den=None, grads=None, return_seed=False, fused=True, d_fc=None, d_att=None):
     """forward + fused criterion + backward on device tensors.  Returns (loss[device scalar], grads dict).
-    fused=True: one library call scheduled on two HIP streams; False: the three separate calls."""
+    fused=True: one library call scheduled on two HIP streams; False: the three separate calls.
+    d_fc / d_att (eng.input_grad_buffers): optional outputs for the gradients w.r.t. the input features (an encoder in
+    front of the captioner; the reference's features are data)."""
     eng = model.engine
     labels = batch["labels"]
     if t_run is None:
@@ -44,7 +46,7 @@ def xe_step(model, batch, t_run=None, inv_den=None, grads=None, return_seed=Fals
         if grads is None:
             grads = {k: torch.empty_like(v) for k, v in pd.items()}
         out = eng.xe_train_step(pd, batch["fc_feats"], batch["att_feats"], batch.get("att_masks"), labels, batch["masks"],
-                                t_run, training, seed, grads, inv_den, ss_prob=ss_prob)
+                                t_run, training, seed, grads, inv_den, ss_prob=ss_prob, d_fc=d_fc, d_att=d_att)
         if return_seed:
             return out[0], grads, seed
         return out[0], grads
@@ -53,6 +55,9 @@ def xe_step(model, batch, t_run=None, inv_den=None, grads=None, return_seed=Fals
     out = eng.xe_loss(ws, d, b, t_run, inv_den)
     if grads is None:
         grads = {k: torch.empty_like(v) for k, v in pd.items()}
+    if d_fc is not None or d_att is not None:
+        b = eng.batch_struct(batch["fc_feats"], batch["att_feats"], batch.get("att_masks"), labels, batch["masks"], ss_prob=ss_prob,
+                             d_fc=d_fc, d_att=d_att)
     eng.backward(ws, d, w, b, t_run, training, seed, grads)
     eng.release(ws)
     if return_seed:
