@@ -63,6 +63,37 @@ __global__ __launch_bounds__(NT) void transpose_kernel(const T* __restrict__ src
   }
 }
 
+// several transposes in one launch (blockIdx.z picks the job; every field by a uniform select -- indexing the by-value
+// table would put it in private memory): the weight refresh's transposes are launch-bound, not byte-bound
+struct TransposeMulti { UicTransposeJob j[UIC_TRANSPOSE_MULTI]; };
+#define UIC_TSEL(f) (k == 0 ? c.j[0].f : k == 1 ? c.j[1].f : k == 2 ? c.j[2].f : k == 3 ? c.j[3].f : k == 4 ? c.j[4].f : k == 5 ? c.j[5].f : \
+                     k == 6 ? c.j[6].f : k == 7 ? c.j[7].f : k == 8 ? c.j[8].f : k == 9 ? c.j[9].f : k == 10 ? c.j[10].f : c.j[11].f)
+template <typename T>
+__global__ __launch_bounds__(NT) void transpose_multi_kernel(const TransposeMulti c) {
+  __shared__ T tile[64][66];
+  const int k = blockIdx.z;
+  const T* __restrict__ src = (const T*)UIC_TSEL(src);
+  T* __restrict__ dst = (T*)UIC_TSEL(dst);
+  const int rows = UIC_TSEL(rows), cols = UIC_TSEL(cols), lds = UIC_TSEL(lds), ldd = UIC_TSEL(ldd);
+  const int r0 = blockIdx.x * 64, c0 = blockIdx.y * 64;
+  if (r0 >= ldd || c0 >= cols) return;
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const int r = r0 + ty + 4 * i, cc = c0 + tx;
+    T v = uic_from_f<T>(0.f);
+    if (r < rows && cc < cols) v = src[(size_t)r * lds + cc];
+    tile[ty + 4 * i][tx] = v;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const int cc = c0 + ty + 4 * i, r = r0 + tx;
+    if (cc < cols && r < ldd) dst[(size_t)cc * ldd + r] = tile[tx][ty + 4 * i];
+  }
+}
+#undef UIC_TSEL
+
 // ------------------------------------------------------------------ column sums (bias gradients)
 // stage 1: a block sums `rows_per_block` rows of a 64-column strip; its 4 waves take rows r, r+4, ...
 template <typename T>
@@ -1184,6 +1215,23 @@ int uic_transpose_launch(int dtype, const void* src, int rows, int cols, int lds
              hipLaunchKernelGGL(transpose_kernel<bf16_t>, grid, dim3(NT), 0, s, (const bf16_t*)src, rows, cols, lds, (bf16_t*)dst, ldd),
              hipLaunchKernelGGL(transpose_kernel<float>, grid, dim3(NT), 0, s, (const float*)src, rows, cols, lds, (float*)dst, ldd));
   UIC_LAUNCH_CHECK("transpose");
+  return UIC_OK;
+}
+int uic_transpose_multi_launch(int dtype, int count, const UicTransposeJob* jobs, hipStream_t s) {
+  UIC_REQUIRE(count >= 0 && count <= UIC_TRANSPOSE_MULTI, "transpose_multi: %d jobs (max %d)", count, UIC_TRANSPOSE_MULTI);
+  TransposeMulti c;
+  memset(&c, 0, sizeof(c));
+  int m = 0, gx = 0, gy = 0;
+  for (int i = 0; i < count; ++i) {
+    if (jobs[i].rows == 0 || jobs[i].cols == 0) continue;
+    c.j[m++] = jobs[i];
+    gx = gx > (jobs[i].ldd + 63) / 64 ? gx : (jobs[i].ldd + 63) / 64;
+    gy = gy > (jobs[i].cols + 63) / 64 ? gy : (jobs[i].cols + 63) / 64;
+  }
+  if (m == 0) return UIC_OK;
+  DISPATCH_T(dtype, hipLaunchKernelGGL(transpose_multi_kernel<bf16_t>, dim3(gx, gy, m), dim3(NT), 0, s, c),
+             hipLaunchKernelGGL(transpose_multi_kernel<float>, dim3(gx, gy, m), dim3(NT), 0, s, c));
+  UIC_LAUNCH_CHECK("transpose_multi");
   return UIC_OK;
 }
 int uic_colsum_launch(int src_dtype, const void* src, int rows, int cols, int lds, float* out, float* scratch,

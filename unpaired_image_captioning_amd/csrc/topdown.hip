@@ -288,10 +288,12 @@ __global__ void rowlen_kernel(const float* mask, int N, int R, int* out) {
   out[n] = c;
 }
 
-// _prepare_feature (P/models/AttModel.py:107-117) + operand casts
+// _prepare_feature (P/models/AttModel.py:107-117) + operand casts.  part: 0 = everything; 1 = only the fc_embed branch
+// (fc' = dropout(relu(fc_embed(fc)))), 2 = only the att_embed / ctx2att branch -- the two are independent, the fused
+// training step runs them on its two streams.
 int prepare_features(const uic_topdown_dims& d, const uic_topdown_weights* w, const Derived& dv, const uic_topdown_batch* b,
                      const Layout& L, int training, float drop_p, unsigned seed, const void** fc_in_out, const void** att_in_out,
-                     hipStream_t s) {
+                     hipStream_t s, int part = 0) {
   const int dt = d.dtype;
   const int N = d.N, R = d.R, H = d.H, A = d.A;
   const bool bn_train = (training & 1) != 0, bn_update = bn_train && !(training & 2);
@@ -303,7 +305,10 @@ int prepare_features(const uic_topdown_dims& d, const uic_topdown_weights* w, co
   const int Na = fold ? Ni : N;             // rows of att_src
   const int* row_len = b->att_masks ? L.row_len : nullptr;          // per row of att_src
   const int* row_len_cap = row_len;                                 // per caption row
-  if (b->att_masks) {
+  const bool do_fc = part != 2, do_att = part != 1;
+  if (b->att_masks && !do_att) {       // (pointers only)
+    if (fold) { amask = L.amask_rep; row_len_cap = L.row_len_rep; }
+  } else if (b->att_masks) {
     hipLaunchKernelGGL(rowlen_kernel, dim3((Na + 255) / 256), dim3(256), 0, s, b->att_masks, Na, R, L.row_len);
     UIC_LAUNCH_CHECK("rowlen_kernel");
     if (fold) {
@@ -317,13 +322,14 @@ int prepare_features(const uic_topdown_dims& d, const uic_topdown_weights* w, co
   const void* fc_in = b->fc_feats;
   const void* att_in = att_src;
   if (S > 1) {
-    UIC_TRY(uic_expand_rows_launch(dt, b->fc_feats, L.fcT, Ni, S, (size_t)d.Dfc, s));
+    if (do_fc) UIC_TRY(uic_expand_rows_launch(dt, b->fc_feats, L.fcT, Ni, S, (size_t)d.Dfc, s));
     fc_in = L.fcT;
   } else if (dt == UIC_BF16) {
-    UIC_TRY(uic_cast_f32_launch(dt, b->fc_feats, L.fcT, (size_t)N * d.Dfc, s));
+    if (do_fc) UIC_TRY(uic_cast_f32_launch(dt, b->fc_feats, L.fcT, (size_t)N * d.Dfc, s));
     fc_in = L.fcT;
   }
-  if (d.use_bn) {
+  if (d.use_bn || dt == UIC_BF16) att_in = L.attT;
+  if (do_att && d.use_bn) {
     // BatchNorm1d(D) over the packed live regions; xhat goes to the GEMM, the affine part lives in W' / b'.  Features given
     // once per image stand for S identical caption rows each: same mean / biased variance, `rep` fixes the unbiased one.
     if (bn_train)
@@ -332,20 +338,19 @@ int prepare_features(const uic_topdown_dims& d, const uic_topdown_weights* w, co
     else
       UIC_TRY(uic_bn_stats_running_launch(w->att_bn0_rm, w->att_bn0_rv, d.D, BN_EPS, L.bn_stat0, s));
     UIC_TRY(uic_bn_apply_launch(UIC_F32, dt, att_src, Na * R, R, d.D, row_len, L.bn_stat0, nullptr, nullptr, 0, L.attT, s));
-    att_in = L.attT;
-  } else if (dt == UIC_BF16) {
+  } else if (do_att && dt == UIC_BF16) {
     UIC_TRY(uic_cast_f32_launch(dt, att_src, L.attT, (size_t)Na * R * d.D, s));
-    att_in = L.attT;
   }
   *fc_in_out = fc_in;
   *att_in_out = att_in;
-  {
+  if (do_fc) {
     UicGemmParams g = gemm_base(dt, N, H);
     add_seg(g, fc_in, d.Dfc, dv.fc_w, d.Dfc, d.Dfc);
     g.C = L.fcp; g.ldc = H; g.bias = w->fc_b; g.flags = UIC_GEMM_RELU;
     g.drop_p = drop_p; g.seed = seed; g.site = UIC_SITE_FC;
     UIC_TRY(uic_gemm_launch(g, s));
   }
+  if (!do_att) return UIC_OK;
   void* const att_out = d.use_bn == 2 ? L.ybn : L.attp;
   if (fold) {
     // relu(W att + b) once per image (f32), then S caption rows with their own dropout masks -- element for element
@@ -401,12 +406,19 @@ constexpr int MAX_CHUNKS = 64;
 struct SideStream {
   hipStream_t stream = nullptr;
   hipEvent_t ev_den = nullptr, ev_done = nullptr;
+  hipEvent_t ev_pro = nullptr;      // side: its branch of the forward prologue (fc_embed, embedding, batched input GEMM) is through
   hipEvent_t ev_logit = nullptr;    // side: the logit layer's gradients and the loss are final (start of the BPTT loop)
   hipEvent_t ev_lstm = nullptr;     // side: lang_lstm.weight_{ih,hh} and att_lstm.weight_hh are final (right after the BPTT loop)
   hipEvent_t ev_early = nullptr;    // main: every gradient except the late group (see uic_topdown_grad_ready_wait) is final
   bool early_recorded = false;
   hipEvent_t ev_r0 = nullptr, ev_refresh = nullptr;   // uic_topdown_refresh_weights: main -> side, side -> consumers
   bool refresh_pending = false;
+  // The refresh in two halves: the operand-dtype copies (all the forward pass needs; ev_cast) are enqueued by the call
+  // itself, the transposes (backward pass only) by the first consumer -- the fused step puts its side-stream prologue branch
+  // in front of them, everything else gets them through wait_refresh.
+  hipEvent_t ev_cast = nullptr;
+  bool cast_recorded = false, transposes_pending = false;
+  uic_topdown_dims tp_d; uic_topdown_weights tp_w; void* tp_derived = nullptr;
   hipEvent_t ev_main[MAX_CHUNKS];   // main  -> side: decode steps of chunk c are finished
   hipEvent_t ev_side[MAX_CHUNKS];   // side  -> main: d hdrop of chunk c is ready
   bool ready = false;
@@ -432,11 +444,13 @@ int get_side(SideStream** out) {
     UIC_TRY(uic_check_hip(hipStreamCreateWithPriority(&ss.stream, hipStreamNonBlocking, least), "hipStreamCreateWithPriority"));
     UIC_TRY(uic_check_hip(hipEventCreateWithFlags(&ss.ev_den, hipEventDisableTiming), "hipEventCreate"));
     UIC_TRY(uic_check_hip(hipEventCreateWithFlags(&ss.ev_done, hipEventDisableTiming), "hipEventCreate"));
+    UIC_TRY(uic_check_hip(hipEventCreateWithFlags(&ss.ev_pro, hipEventDisableTiming), "hipEventCreate"));
     UIC_TRY(uic_check_hip(hipEventCreateWithFlags(&ss.ev_early, hipEventDisableTiming), "hipEventCreate"));
     UIC_TRY(uic_check_hip(hipEventCreateWithFlags(&ss.ev_logit, hipEventDisableTiming), "hipEventCreate"));
     UIC_TRY(uic_check_hip(hipEventCreateWithFlags(&ss.ev_lstm, hipEventDisableTiming), "hipEventCreate"));
     UIC_TRY(uic_check_hip(hipEventCreateWithFlags(&ss.ev_r0, hipEventDisableTiming), "hipEventCreate"));
     UIC_TRY(uic_check_hip(hipEventCreateWithFlags(&ss.ev_refresh, hipEventDisableTiming), "hipEventCreate"));
+    UIC_TRY(uic_check_hip(hipEventCreateWithFlags(&ss.ev_cast, hipEventDisableTiming), "hipEventCreate"));
     for (int i = 0; i < UIC_STEP_MARKS; ++i) UIC_TRY(uic_check_hip(hipEventCreate(&ss.mark[i]), "hipEventCreate"));
     for (int i = 0; i < MAX_CHUNKS; ++i) {
       UIC_TRY(uic_check_hip(hipEventCreateWithFlags(&ss.ev_main[i], hipEventDisableTiming), "hipEventCreate"));
@@ -448,10 +462,41 @@ int get_side(SideStream** out) {
   return UIC_OK;
 }
 
+// the deferred half of uic_topdown_refresh_weights: the transposed copies the backward pass reads, on the side stream
+int flush_transposes(SideStream* ss) {
+  if (!ss->transposes_pending) return UIC_OK;
+  ss->transposes_pending = false;
+  const uic_topdown_dims* d = &ss->tp_d;
+  const Derived v = make_derived(*d, &ss->tp_w, ss->tp_derived);
+  hipStream_t s2 = ss->stream;
+  const int dt = d->dtype, H = d->H, E = d->E, A = d->A, V1 = d->V1;
+  const int V1p = (int)vpad(V1), H4 = 4 * H, ldih = E + 2 * H;
+  // one launch for all of them (the launches, not the 10 MB, are what the side stream would spend its time on)
+  UicTransposeJob jobs[UIC_TRANSPOSE_MULTI];
+  int nj = 0;
+  auto job = [&](const void* src, int rows, int cols, int lds, void* dst, int ldd) { jobs[nj++] = UicTransposeJob{src, dst, rows, cols, lds, ldd}; };
+  job(v.logit_w, V1, H, H, v.logit_wT, V1p);
+  // w2T rows [0,2H) <- lang_w_ih^T, rows [2H,3H) <- lang_w_hh^T
+  job(v.lang_w_ih, H4, 2 * H, 2 * H, v.w2T, H4);
+  job(v.lang_w_hh, H4, H, H, offw(v.w2T, (size_t)2 * H * H4, dt), H4);
+  job(v.att_w_ih, H4, H, ldih, v.w1recT, H4);
+  job(v.att_w_hh, H4, H, H, offw(v.w1recT, (size_t)H * H4, dt), H4);
+  job(off(v.att_w_ih, 2 * H, dt), H4, E, ldih, v.wxT, H4);
+  job(off(v.att_w_ih, H, dt), H4, H, ldih, v.wfcpT, H4);
+  job(v.h2att_w, A, H, H, v.h2attT, A);
+  job(v.ctx2att_w, A, H, H, v.ctx2attT, A);
+  for (int l = 0; l + 1 < d->logit_layers; ++l) job(v.logit_h_w[l], H, H, H, v.logit_h_wT[l], H);
+  UIC_TRY(uic_transpose_multi_launch(dt, nj, jobs, s2));
+  UIC_TRY(uic_check_hip(hipEventRecord(ss->ev_refresh, s2), "hipEventRecord"));
+  ss->refresh_pending = true;
+  return UIC_OK;
+}
+
 // every consumer of the derived weights first lets its stream wait for the side-stream part of the last refresh
 int wait_refresh(hipStream_t s) {
   SideStream* ss = nullptr;
   UIC_TRY(get_side(&ss));
+  UIC_TRY(flush_transposes(ss));
   if (ss->refresh_pending) UIC_TRY(uic_check_hip(hipStreamWaitEvent(s, ss->ev_refresh, 0), "hipStreamWaitEvent(refresh)"));
   return UIC_OK;
 }
@@ -498,6 +543,7 @@ int uic_topdown_refresh_weights(const uic_topdown_dims* d, const uic_topdown_wei
   SideStream* ss = nullptr;
   UIC_TRY(get_side(&ss));
   hipStream_t s2 = ss->stream;
+  if (ss->transposes_pending && ss->tp_derived != derived) UIC_TRY(flush_transposes(ss));   // another model's deferred half
   UIC_TRY(uic_check_hip(hipEventRecord(ss->ev_r0, s), "hipEventRecord"));          // the master weights are final
   UIC_TRY(uic_check_hip(hipStreamWaitEvent(s2, ss->ev_r0, 0), "hipStreamWaitEvent"));
   if (dt == UIC_BF16) {   // one launch per stream (the step waits for launches here, not for bytes)
@@ -519,27 +565,18 @@ int uic_topdown_refresh_weights(const uic_topdown_dims* d, const uic_topdown_wei
     UIC_REQUIRE(d->use_bn < 2 || (w->att_bn4_w && w->att_bn4_b && w->att_bn4_rm && w->att_bn4_rv), "use_bn=2 needs the att_embed.4 BatchNorm tensors");
     UIC_TRY(uic_bn_fold_weight_launch(dt, w->att_w, w->att_bn0_w, w->att_bn0_b, w->att_b, H, D, (void*)v.att_w, v.att_beff, s));
   }
-  const int H4 = 4 * H, ldih = E + 2 * H;
-  // the transposes of att_w_ih read the copy made on `s` above
+  // the side stream's later work (the transposes of att_w_ih among it) reads the copies made on `s` above
   UIC_TRY(uic_check_hip(hipEventRecord(ss->ev_r0, s), "hipEventRecord"));
   UIC_TRY(uic_check_hip(hipStreamWaitEvent(s2, ss->ev_r0, 0), "hipStreamWaitEvent"));
-  UIC_TRY(uic_transpose_launch(dt, v.logit_w, V1, H, H, v.logit_wT, V1p, s2));
-  // w2T rows [0,2H) <- lang_w_ih^T, rows [2H,3H) <- lang_w_hh^T
-  UIC_TRY(uic_transpose_launch(dt, v.lang_w_ih, H4, 2 * H, 2 * H, v.w2T, H4, s2));
-  UIC_TRY(uic_transpose_launch(dt, v.lang_w_hh, H4, H, H, offw(v.w2T, (size_t)2 * H * H4, dt), H4, s2));
-  UIC_TRY(uic_transpose_launch(dt, v.att_w_ih, H4, H, ldih, v.w1recT, H4, s2));
-  UIC_TRY(uic_transpose_launch(dt, v.att_w_hh, H4, H, H, offw(v.w1recT, (size_t)H * H4, dt), H4, s2));
-  UIC_TRY(uic_transpose_launch(dt, off(v.att_w_ih, 2 * H, dt), H4, E, ldih, v.wxT, H4, s2));
-  UIC_TRY(uic_transpose_launch(dt, off(v.att_w_ih, H, dt), H4, H, ldih, v.wfcpT, H4, s2));
-  UIC_TRY(uic_transpose_launch(dt, v.h2att_w, A, H, H, v.h2attT, A, s2));
-  UIC_TRY(uic_transpose_launch(dt, v.ctx2att_w, A, H, H, v.ctx2attT, A, s2));
   for (int l = 0; l + 1 < d->logit_layers; ++l) {
     UIC_REQUIRE(w->logit_h_w[l] && w->logit_h_b[l], "logit_layers=%d needs the hidden logit block %d", d->logit_layers, l);
     if (dt == UIC_BF16) UIC_TRY(uic_cast_f32_launch(dt, w->logit_h_w[l], (void*)v.logit_h_w[l], (size_t)H * H, s2));
-    UIC_TRY(uic_transpose_launch(dt, v.logit_h_w[l], H, H, H, v.logit_h_wT[l], H, s2));
   }
-  UIC_TRY(uic_check_hip(hipEventRecord(ss->ev_refresh, s2), "hipEventRecord"));
-  ss->refresh_pending = true;
+  UIC_TRY(uic_check_hip(hipEventRecord(ss->ev_cast, s2), "hipEventRecord"));
+  ss->cast_recorded = true;
+  // the transposes (backward pass only) follow when the first consumer asks for them: flush_transposes
+  ss->tp_d = *d; ss->tp_w = *w; ss->tp_derived = derived;
+  ss->transposes_pending = true;
   return UIC_OK;
 }
 
@@ -586,9 +623,12 @@ struct Step {
   bool embed_prepared = false;   // the fused step bucketed the tokens (uic_embed_bwd_sorted_prepare) while the side stream was idle
 
   // ---------------------------------------------------------------- forward
-  int fwd_prologue(hipStream_t s) {
+  // part: 0 = everything on one stream; 1 = the branch that ends in the batched input GEMM (fc_embed, embedding, Gfc, Gx,
+  // initial state), 2 = the att_embed / ctx2att branch -- independent of each other (the fused step forks them)
+  int fwd_prologue(hipStream_t s, int part = 0) {
     const void *f, *a;
-    UIC_TRY(prepare_features(d, w, dv, b, L, training, drop_p, seed, &f, &a, s));
+    UIC_TRY(prepare_features(d, w, dv, b, L, training, drop_p, seed, &f, &a, s, part));
+    if (part == 2) return UIC_OK;
     // xt_t = dropout(relu(embed[labels[:, t]])) for all steps (AttModel.py:145,160)
     UIC_TRY(uic_embed_fwd_launch(dt, w->embed_w, V1, E, b->labels, b->ld_labels, N, t_run, drop_p, seed, UIC_SITE_EMBED, 0, 1, L.xt_all, s));
     {  // Gfc = fc' W_ih[:, H:2H]^T
@@ -1192,8 +1232,20 @@ int uic_topdown_xe_train_step(const uic_topdown_dims* d, const uic_topdown_weigh
   const float* inv = inv_den ? inv_den : st.L.scalars + 1;
   UIC_HIP(hipEventRecord(ss->ev_den, s));
   UIC_HIP(hipStreamWaitEvent(s2, ss->ev_den, 0));
-  UIC_TRY(st.fwd_prologue(s));
-  UIC_TRY(wait_refresh(s));                           // the recurrence needs the side-stream half of the weight refresh
+  // the prologue's two independent branches side by side: att_embed + ctx2att here, fc_embed + embedding + the batched
+  // input GEMM on the side stream (idle until the recurrence is through; its part of the weight refresh comes first there)
+  static const bool fork_prologue = getenv("UIC_FORK_PROLOGUE") ? atoi(getenv("UIC_FORK_PROLOGUE")) != 0 : true;
+  if (fork_prologue) {
+    UIC_TRY(st.fwd_prologue(s2, 1));
+    UIC_HIP(hipEventRecord(ss->ev_pro, s2));
+    UIC_TRY(flush_transposes(ss));                    // (behind the branch: only the backward pass reads them)
+    UIC_TRY(st.fwd_prologue(s, 2));
+    UIC_HIP(hipStreamWaitEvent(s, ss->ev_pro, 0));
+    if (ss->cast_recorded) UIC_HIP(hipStreamWaitEvent(s, ss->ev_cast, 0));   // the recurrence reads copies made on the side stream
+  } else {
+    UIC_TRY(st.fwd_prologue(s));
+    UIC_TRY(wait_refresh(s));                         // the recurrence needs the side-stream half of the weight refresh
+  }
   UIC_MARK(1, s);
   // persistent mode 3: the whole recurrence as ONE launch (it holds every CU, nothing overlaps it); the logit layer follows
   // chunk by chunk on the side stream beside the BPTT loop
@@ -1225,6 +1277,7 @@ int uic_topdown_xe_train_step(const uic_topdown_dims* d, const uic_topdown_weigh
   UIC_HIP(hipEventRecord(ss->ev_logit, s2));          // gradient group 0 (logit layer) final: its exchange can start now
   // main: BPTT, each step waits for the d hdrop rows of its chunk; side: the recurrent weight gradients of every
   // finished chunk (transposes + accumulating GEMMs), so only the last chunk's share outlives the loop
+  UIC_TRY(wait_refresh(s));                           // the BPTT loop reads the transposed weight copies
   UIC_TRY(st.bwd_begin(s));
   if (!st.ss_on()) {   // the embedding gradient's token bucketing needs only the labels: in the side stream's slack inside the BPTT window
     UIC_TRY(uic_embed_bwd_sorted_prepare(b->labels, b->ld_labels, d->N, t_run, d->V1, d->E, G->embed_w, st.L.embed_scratch, s2));

@@ -290,6 +290,10 @@ int uic_fill_value_launch(int dtype, void* dst, size_t n, float value, hipStream
 int uic_zero4_launch(void* p0, size_t b0, void* p1, size_t b1, void* p2, size_t b2, void* p3, size_t b3, hipStream_t s);
 // dst[cols, ldd] = src[rows, lds]^T, zero-filling dst columns rows..ldd-1
 int uic_transpose_launch(int dtype, const void* src, int rows, int cols, int lds, void* dst, int ldd, hipStream_t s);
+// up to UIC_TRANSPOSE_MULTI transposes (same argument meaning, one entry each) in ONE launch
+#define UIC_TRANSPOSE_MULTI 12
+struct UicTransposeJob { const void* src; void* dst; int rows, cols, lds, ldd; };
+int uic_transpose_multi_launch(int dtype, int count, const UicTransposeJob* jobs, hipStream_t s);
 // out[c] = sum_r src[r, c]  (deterministic two-stage; src operand dtype or f32)
 int uic_colsum_launch(int src_dtype, const void* src, int rows, int cols, int lds, float* out, float* scratch,
                       size_t scratch_floats, hipStream_t s);
