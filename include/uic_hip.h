@@ -74,7 +74,8 @@ typedef struct uic_topdown_dims {
  * carries the gradient pointers on the way back (running statistics have no gradient: those pointers are ignored).
  * `training` arguments below: bit 0 = train mode (dropout on, BatchNorm batch statistics); bit 1 = do NOT update the
  * BatchNorm running statistics (the teacher-forced replay of a sampled caption in self-critical training re-runs
- * the forward of an iteration whose sampling pass already updated them). */
+ * the forward of an iteration whose sampling pass already updated them); bit 2 (uic_topdown_xe_train_step only) = the
+ * workspace already holds this forward pass, left there by uic_topdown_sample_train: start at the criterion. */
 typedef struct uic_topdown_weights {
   float* embed_w;         /* embed.0.weight            [V1, E]        */
   float* fc_w;            /* fc_embed.0.weight         [H, Dfc]       */
@@ -204,6 +205,17 @@ int uic_topdown_sample(const uic_topdown_dims* d, const uic_topdown_weights* w, 
                        const uic_topdown_batch* batch, int32_t L, int32_t sample_max, float temperature,
                        int32_t decoding_constraint, uint32_t seed, const int64_t* forced, int32_t training,
                        void* workspace, int64_t* seq, float* seq_logp, void* stream);
+
+/* The same pass in the TRAINING layout (the sampling pass of the self-critical step, P/trainer.py:167): the per-step
+ * chain of uic_topdown_forward with every step's input tokens drawn from the previous step's distribution, so that all
+ * activations the backward pass reads (and the logits) stay in the workspace.  A following
+ * uic_topdown_xe_train_step(..., training | 4, same seed, same dims, same workspace, labels = [0, seq, 0], grad_scale)
+ * then starts at the criterion instead of replaying the sampled captions teacher-forced.  Same arguments and results
+ * as uic_topdown_sample. */
+int uic_topdown_sample_train(const uic_topdown_dims* d, const uic_topdown_weights* w, const void* derived,
+                             const uic_topdown_batch* b, int32_t Lsteps, int32_t sample_max, float temperature,
+                             int32_t decoding_constraint, uint32_t seed, const int64_t* forced, int32_t training,
+                             void* workspace, int64_t* seq, float* seq_logp, void* stream);
 /* AttModel._sample_beam + CaptionModel.beam_search with group_size = 1 (P/models/AttModel.py:167-196,
  * P/models/CaptionModel.py:33-177), all images at once.  The batch holds every image REPLICATED beam_size times (row =
  * image * beam_size + beam; N = images * beam_size), eval mode.  Outputs: the best finished beam per image, seq

@@ -1178,3 +1178,42 @@ def test_input_feature_gradient_refused_through_batchnorm():
     torch.cuda.synchronize()
     loss, _ = xe_step(model, batch, d_fc=d_fc)          # the fc branch has no BatchNorm
     assert torch.isfinite(loss) and torch.isfinite(d_fc).all()
+
+
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+@pytest.mark.parametrize("use_bn,S", [(0, 1), (0, 3), (2, 1)])
+def test_self_critical_backward_from_kept_forward_equals_replay(dtype, use_bn, S):
+    """The train-mode sampling pass keeps its forward in the training layout (uic_topdown_sample_train) and the backward
+    starts at the criterion (training bit 2); with model.scst_keep_forward = False the sampled captions are replayed
+    teacher-forced (the round-1 path).  Same seed -> the same draws, log-probs and gradients (dropout 0.5, ragged regions,
+    per-image features, BatchNorm running statistics updated exactly once)."""
+    from unpaired_image_captioning_amd import models
+    from unpaired_image_captioning_amd.misc.criterion import RewardCriterion
+    cfg = dict(V=300, E=64, H=96, A=64, D=160, L=7, n_img=12, S=S, R=9, use_bn=use_bn)
+    b = O.synthetic_batch(cfg["n_img"], 1, cfg["R"], cfg["D"], cfg["V"], cfg["L"], seed=9, ragged_regions=True)
+    fc, att, am = b["fc_feats"].cuda(), b["att_feats"].cuda(), b["att_masks"].cuda()
+    g = torch.Generator().manual_seed(5)
+    reward = torch.randn(cfg["n_img"] * S, cfg["L"], generator=g).cuda()
+    res = []
+    for keep in (True, False):
+        torch.manual_seed(3)
+        model = models.setup(make_opt(cfg, dtype, drop=0.5, seed=21)).cuda().train()
+        model.scst_keep_forward = keep
+        seq, lp = model(fc, None, att, am, opt={"sample_max": 0, "captions_per_image": S}, mode="sample")
+        loss = RewardCriterion()(lp, seq, reward)
+        loss.backward()
+        res.append((seq.cpu(), lp.detach().cpu(), loss.item(), {k: p.grad.float().cpu() for k, p in model.named_parameters()},
+                    {k: v.float().cpu().clone() for k, v in model.state_dict().items() if "running" in k}))
+        pool = model.engine._pool
+        assert sum(len(v) for v in pool.values()) >= 1          # the kept workspace went back to the pool
+    (seq0, lp0, l0, g0, s0), (seq1, lp1, l1, g1, s1) = res
+    if dtype == "f32":
+        assert torch.equal(seq0, seq1)
+    same = (seq0 == seq1).all(1)
+    assert same.float().mean().item() > 0.9                      # bf16: a near-tie in a draw may fall either way
+    assert absmax(lp0[same], lp1[same]) < (2e-5 if dtype == "f32" else 2e-2)
+    if bool(same.all()):
+        assert abs(l0 - l1) < (1e-5 if dtype == "f32" else 2e-3)
+        grads_close(g0, g1, 2e-4 if dtype == "f32" else 3e-2)
+    for k in s0:
+        assert absmax(s0[k], s1[k]) < 1e-6, k

@@ -1,0 +1,84 @@
+#!/usr/bin/env python3
+"""Where the self-critical step's time goes: host time to enqueue each phase and, separately, each phase with a device
+sync after it (640 caption rows, per-image features, device CIDEr-D reward).  Diagnostic only."""
+import os, sys, time, pickle, tempfile
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import torch
+import bench
+from unpaired_image_captioning_amd.synthetic import synthetic_batch
+from unpaired_image_captioning_amd.trainer import Trainer
+from unpaired_image_captioning_amd.misc import rewards
+from unpaired_image_captioning_amd.misc.criterion import RewardCriterion
+
+c = bench.CFG
+torch.manual_seed(1234)
+tr = Trainer(bench.make_opt("bf16", 1234)); tr.build_optimizer()
+batch = synthetic_batch(c["n_img"], c["S"], c["R"], c["D"], c["V"], c["L"], seed=1234)
+model = tr.i2t_model
+eng = model.engine
+data = {k: v.cpu().numpy() for k, v in batch.items()}
+L_ = c["L"]
+data["gts"] = [data["labels"][i * c["S"]:(i + 1) * c["S"], 1:L_ + 1].astype(np.int64) for i in range(c["n_img"])]
+df = {}
+for img in data["gts"]:
+    grams = set()
+    for r in img:
+        w = rewards.DeviceCiderD._words(r)
+        for k in range(1, 5):
+            for i in range(len(w) - k + 1):
+                grams.add(tuple(str(t) for t in w[i:i + k]))
+    for ng in grams:
+        df[ng] = df.get(ng, 0.0) + 1.0
+pk = os.path.join(tempfile.gettempdir(), "uic_scst_phases-idxs.p")
+with open(pk, "wb") as f:
+    pickle.dump({"document_frequency": df, "ref_len": float(c["n_img"])}, f)
+tr.opt.cached_tokens = pk
+rewards.CiderD_scorer = None
+
+
+def run(sync):
+    t = {}
+    def mark(name, t0):
+        if sync:
+            torch.cuda.synchronize()
+        t[name] = t.get(name, 0.0) + (time.perf_counter() - t0) * 1e3
+    t0 = time.perf_counter(); b = tr.to_device(data, True); mark("to_device", t0)
+    fc, att, am = b["fc_feats"], b["att_feats"], b.get("att_masks")
+    S = len(data["labels"]) // att.shape[0]
+    with eng.hold_weights():
+        t0 = time.perf_counter()
+        eng.refresh({k: v.detach() for k, v in model.param_dict().items()}, eng.dims(att.shape[0], att.shape[1], model.seq_length + 1))
+        mark("refresh", t0)
+        t0 = time.perf_counter(); model.eval()
+        with torch.no_grad():
+            greedy, _ = model(fc, None, att, am, opt={'sample_max': 1}, mode='sample')
+        model.train(); mark("greedy", t0)
+        t0 = time.perf_counter(); gen, lp = model(fc, None, att, am, opt={'sample_max': 0, 'captions_per_image': S}, mode='sample'); mark("sample", t0)
+        t0 = time.perf_counter()
+        scorer = rewards.init_scorer(pk)
+        reward_t = rewards.self_critical_reward_device(scorer, gen, greedy, data['gts'], 1.0, 0.0); mark("reward", t0)
+        t0 = time.perf_counter(); loss = RewardCriterion()(lp, gen, reward_t)
+        for p in model.parameters():
+            p.grad = None
+        loss.backward(); mark("backward", t0)
+    t0 = time.perf_counter()
+    params = dict(model.named_parameters())
+    for k, view in tr.arena.grad_views.items():
+        view.copy_(params[k].grad)
+    mark("grad copies", t0)
+    t0 = time.perf_counter(); loss.item(); mark("final sync", t0)
+    return t
+
+
+for sync in (False, True):
+    for _ in range(3):
+        run(sync)
+    acc = {}
+    for _ in range(5):
+        for k, v in run(sync).items():
+            acc[k] = acc.get(k, 0.0) + v / 5
+    print("per phase, %s:" % ("device-synchronised after each phase" if sync else "host enqueue time only (one sync at the end)"))
+    for k, v in acc.items():
+        print("   %-12s %7.3f ms" % (k, v))
+    print("   %-12s %7.3f ms" % ("total", sum(acc.values())))

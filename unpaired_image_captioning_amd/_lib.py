@@ -233,6 +233,9 @@ _SIGS = {
     "uic_topdown_sample": (C.c_int, [C.POINTER(Dims), C.POINTER(Weights), C.c_void_p, C.POINTER(Batch), C.c_int32,
                                      C.c_int32, C.c_float, C.c_int32, C.c_uint32, C.c_void_p, C.c_int32, C.c_void_p,
                                      C.c_void_p, C.c_void_p, C.c_void_p]),
+    "uic_topdown_sample_train": (C.c_int, [C.POINTER(Dims), C.POINTER(Weights), C.c_void_p, C.POINTER(Batch), C.c_int32,
+                                     C.c_int32, C.c_float, C.c_int32, C.c_uint32, C.c_void_p, C.c_int32, C.c_void_p,
+                                     C.c_void_p, C.c_void_p, C.c_void_p]),
     "uic_fc_workspace_bytes": (C.c_size_t, [C.POINTER(FcDims)]),
     "uic_fc_forward": (C.c_int, [C.POINTER(FcDims), C.POINTER(FcWeights), C.POINTER(Batch), C.c_int32, C.c_int32, C.c_uint32,
                                  C.c_void_p, C.c_void_p, C.c_void_p]),

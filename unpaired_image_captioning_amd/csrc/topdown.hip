@@ -631,12 +631,7 @@ struct Step {
     if (part == 2) return UIC_OK;
     // xt_t = dropout(relu(embed[labels[:, t]])) for all steps (AttModel.py:145,160)
     UIC_TRY(uic_embed_fwd_launch(dt, w->embed_w, V1, E, b->labels, b->ld_labels, N, t_run, drop_p, seed, UIC_SITE_EMBED, 0, 1, L.xt_all, s));
-    {  // Gfc = fc' W_ih[:, H:2H]^T
-      UicGemmParams g = gemm_base(dt, N, H4);
-      add_seg(g, L.fcp, H, off(dv.att_w_ih, H, dt), ldih, H);
-      g.C = L.gfc; g.ldc = H4; g.flags = UIC_GEMM_OUT_F32;
-      UIC_TRY(uic_gemm_launch(g, s));
-    }
+    UIC_TRY(fwd_gfc(s));
     {  // Gx = xt W_ih[:, 2H:]^T + b_ih + b_hh + Gfc (every step's rows get their caption row's fc' term), all steps
       UicGemmParams g = gemm_base(dt, Meff, H4);
       add_seg(g, L.xt_all, E, off(dv.att_w_ih, 2 * H, dt), ldih, E);
@@ -649,19 +644,33 @@ struct Step {
     return uic_zero4_launch(L.h_att, NH * S, L.h_lang, NH * S, L.c_att, NH * 4, L.c_lang, NH * 4, s);
   }
 
-  int fwd_step(int t, hipStream_t s) {
+  // step t's embedding row block and its slice of Gx from the tokens tok[n * ld] (the prologue made them from the labels)
+  int fwd_step_inputs(int t, const int64_t* tok, int ld, hipStream_t s) {
+    UIC_TRY(uic_embed_fwd_launch(dt, w->embed_w, V1, E, tok, ld, N, 1, drop_p, seed, UIC_SITE_EMBED,
+                                 (size_t)t * N * E, 1, offw(L.xt_all, (size_t)t * N * E, dt), s));
+    UicGemmParams g = gemm_base(dt, N, H4);
+    add_seg(g, off(L.xt_all, (size_t)t * N * E, dt), E, off(dv.att_w_ih, 2 * H, dt), ldih, E);
+    g.C = L.gx + (size_t)t * N * H4; g.ldc = H4; g.bias = w->att_lstm_b_ih; g.bias2 = w->att_lstm_b_hh; g.flags = UIC_GEMM_OUT_F32;
+    g.addend = L.gfc; g.add_mod = N; g.ld_add = H4;
+    return uic_gemm_launch(g, s);
+  }
+  // Gfc = fc' W_ih[:, H:2H]^T, the caption row's share of every step's att_lstm pre-activations
+  int fwd_gfc(hipStream_t s) {
+    UicGemmParams g = gemm_base(dt, N, H4);
+    add_seg(g, L.fcp, H, off(dv.att_w_ih, H, dt), ldih, H);
+    g.C = L.gfc; g.ldc = H4; g.flags = UIC_GEMM_OUT_F32;
+    return uic_gemm_launch(g, s);
+  }
+
+  // inline_inputs: xt_t and fc' enter att_lstm's GEMM as K segments of their own (with both biases) instead of through the
+  // prologue's Gx -- the sampling pass, whose step-t embedding exists only once step t - 1 has drawn its tokens
+  int fwd_step(int t, hipStream_t s, bool inline_inputs = false) {
     if (ss_on() && t >= 1) {
       // choose this step's input tokens from the previous step's distribution, then redo the step's embedding row block
       // and its slice of Gx (the prologue's teacher-forced values for the rows that keep their label are recomputed too)
       UIC_TRY(uic_ss_sample_launch(L.logits + (size_t)(t - 1) * N * V1p, N, V1, V1p, b->labels, b->ld_labels, t, b->ss_prob, seed,
                                    L.tok_used, d.T, s));
-      UIC_TRY(uic_embed_fwd_launch(dt, w->embed_w, V1, E, L.tok_used + t, d.T, N, 1, drop_p, seed, UIC_SITE_EMBED,
-                                   (size_t)t * N * E, 1, offw(L.xt_all, (size_t)t * N * E, dt), s));
-      UicGemmParams g = gemm_base(dt, N, H4);
-      add_seg(g, off(L.xt_all, (size_t)t * N * E, dt), E, off(dv.att_w_ih, 2 * H, dt), ldih, E);
-      g.C = L.gx + (size_t)t * N * H4; g.ldc = H4; g.bias = w->att_lstm_b_ih; g.bias2 = w->att_lstm_b_hh; g.flags = UIC_GEMM_OUT_F32;
-      g.addend = L.gfc; g.add_mod = N; g.ld_add = H4;
-      UIC_TRY(uic_gemm_launch(g, s));
+      UIC_TRY(fwd_step_inputs(t, L.tok_used + t, d.T, s));
     }
     const void* h_att_prev = off(L.h_att, t * NH, dt);
     void* h_att_new = offw(L.h_att, (t + 1) * NH, dt);
@@ -671,8 +680,14 @@ struct Step {
       UicGemmParams g = gemm_base(dt, N, H4);
       g.lstm = 1; g.H = H;
       add_seg(g, h_lang_prev, H, dv.att_w_ih, ldih, H);
+      if (inline_inputs) {
+        add_seg(g, L.fcp, H, off(dv.att_w_ih, H, dt), ldih, H);
+        add_seg(g, off(L.xt_all, (size_t)t * N * E, dt), E, off(dv.att_w_ih, 2 * H, dt), ldih, E);
+        g.bias = w->att_lstm_b_ih; g.bias2 = w->att_lstm_b_hh;
+      } else {
+        g.pre1 = L.gx + (size_t)t * N * H4; g.ldpre1 = H4;   // (Gfc is already folded into Gx)
+      }
       add_seg(g, h_att_prev, H, dv.att_w_hh, H, H);
-      g.pre1 = L.gx + (size_t)t * N * H4; g.ldpre1 = H4;     // (Gfc is already folded into Gx)
       g.c_prev = L.c_att + t * NH; g.c_out = L.c_att + (t + 1) * NH;
       g.h_out = h_att_new; g.ldh = H;
       g.gates_out = offw(L.gates1, (size_t)t * N * H4, dt);
@@ -1235,7 +1250,12 @@ int uic_topdown_xe_train_step(const uic_topdown_dims* d, const uic_topdown_weigh
   // the prologue's two independent branches side by side: att_embed + ctx2att here, fc_embed + embedding + the batched
   // input GEMM on the side stream (idle until the recurrence is through; its part of the weight refresh comes first there)
   static const bool fork_prologue = getenv("UIC_FORK_PROLOGUE") ? atoi(getenv("UIC_FORK_PROLOGUE")) != 0 : true;
-  if (fork_prologue) {
+  // training bit 2: the workspace already holds this forward pass (uic_topdown_sample_train drew b->labels with these
+  // weights, this seed and these dims): the step starts at the criterion
+  const bool resume = (training & 4) != 0;
+  UIC_REQUIRE(!resume || !st.ss_on(), "xe_train_step: a resumed step cannot use scheduled sampling");
+  if (resume) {
+  } else if (fork_prologue) {
     UIC_TRY(st.fwd_prologue(s2, 1));
     UIC_HIP(hipEventRecord(ss->ev_pro, s2));
     UIC_TRY(flush_transposes(ss));                    // (behind the branch: only the backward pass reads them)
@@ -1249,8 +1269,8 @@ int uic_topdown_xe_train_step(const uic_topdown_dims* d, const uic_topdown_weigh
   UIC_MARK(1, s);
   // persistent mode 3: the whole recurrence as ONE launch (it holds every CU, nothing overlaps it); the logit layer follows
   // chunk by chunk on the side stream beside the BPTT loop
-  const bool one_launch = st.persist_ok(true);
-  if (one_launch) { UIC_TRY(st.fwd_steps(0, t_run, s, true)); UIC_MARK(2, s); }
+  const bool one_launch = resume || st.persist_ok(true);
+  if (one_launch) { if (!resume) UIC_TRY(st.fwd_steps(0, t_run, s, true)); UIC_MARK(2, s); }
   for (int i = 0; i < nchunk; ++i) {
     // after a single launch every step is there at once: the logit layer then takes the chunks LAST FIRST, the order the
     // BPTT loop consumes them in, so that loop starts after one chunk instead of after all of them
@@ -1260,7 +1280,7 @@ int uic_topdown_xe_train_step(const uic_topdown_dims* d, const uic_topdown_weigh
     if (!one_launch || i == 0) UIC_HIP(hipEventRecord(ss->ev_main[c], s));
     // side: logit layer of the chunk, forward and backward-to-h (beside the next chunk's recurrence)
     if (!one_launch || i == 0) UIC_HIP(hipStreamWaitEvent(s2, ss->ev_main[c], 0));
-    UIC_TRY(st.logits_rows(t0, t1, s2));
+    if (!resume) UIC_TRY(st.logits_rows(t0, t1, s2));
     UIC_TRY(st.xe_rows(t0, t1, inv, nullptr, 1, s2));
     UIC_TRY(st.dh_rows(t0, t1, s2, true));
     UIC_HIP(hipEventRecord(ss->ev_side[c], s2));
@@ -1379,6 +1399,49 @@ int uic_topdown_sample(const uic_topdown_dims* d, const uic_topdown_weights* w, 
   return UIC_OK;
 }
 
+
+// The multinomial / greedy pass in the TRAINING layout: the per-step chain of uic_topdown_forward with each step's input
+// tokens drawn from the previous step's distribution, so that every activation the backward pass reads (gates, states,
+// attention weights, contexts, dropped outputs, logits) is left in the workspace -- uic_topdown_xe_train_step with
+// training bit 2 (value 4) then starts at the criterion instead of replaying the sampled captions teacher-forced.
+int uic_topdown_sample_train(const uic_topdown_dims* d, const uic_topdown_weights* w, const void* derived,
+                             const uic_topdown_batch* b, int32_t Lsteps, int32_t sample_max, float temperature,
+                             int32_t decoding_constraint, uint32_t seed, const int64_t* forced, int32_t training,
+                             void* workspace, int64_t* seq, float* seq_logp, void* stream) {
+  UIC_TRY(check_dims(d));
+  UIC_REQUIRE(w && derived && b && workspace && seq && seq_logp, "sample_train: null pointer");
+  UIC_REQUIRE(b->fc_feats && b->att_feats, "sample_train: batch needs fc_feats and att_feats");
+  UIC_REQUIRE(Lsteps >= 1 && Lsteps <= d->T, "sample_train: L=%d outside [1,%d]", Lsteps, d->T);
+  UIC_REQUIRE(temperature > 0.f, "sample_train: temperature must be positive");
+  UIC_REQUIRE(!(b->ss_prob > 0.f), "sample_train: the pass draws every token itself (ss_prob must be 0)");
+  hipStream_t s = (hipStream_t)stream;
+  Step st;
+  st.init(d, w, derived, b, Lsteps, training, seed, workspace, nullptr);
+  const Layout& L = st.L;
+  const int N = d->N;
+  const void *f, *a;
+  UIC_TRY(prepare_features(st.d, w, st.dv, b, L, training, st.drop_p, seed, &f, &a, s));
+  UIC_TRY(uic_zero4_launch(L.h_att, st.NH * st.S, L.h_lang, st.NH * st.S, L.c_att, st.NH * 4, L.c_lang, st.NH * 4, s));
+  UIC_TRY(wait_refresh(s));
+  UIC_TRY(uic_fill_launch(L.s_it, 0, (size_t)N * 8, s));       // <bos> = 0 (AttModel.py:214-215)
+  UIC_TRY(uic_fill_launch(L.s_unf, 0, (size_t)N * 4, s));
+  UIC_TRY(uic_fill_launch(L.s_nunf, 0, (size_t)(d->T + 2) * UIC_NUNF_STRIPES * 4, s));
+  for (int t = 0; t < Lsteps; ++t) {
+    UIC_TRY(uic_embed_fwd_launch(st.dt, w->embed_w, st.V1, st.E, L.s_it, 1, N, 1, st.drop_p, seed, UIC_SITE_EMBED,
+                                 (size_t)t * N * st.E, 1, offw(L.xt_all, (size_t)t * N * st.E, st.dt), s));
+    UIC_TRY(st.fwd_step(t, s, true));
+    UIC_TRY(st.logits_rows_now(t, t + 1, s));
+    UicSampleParams p;
+    memset(&p, 0, sizeof(p));
+    p.dtype = st.dt; p.N = N; p.V1 = st.V1; p.ldv = st.V1p; p.t = t; p.L = Lsteps;
+    p.logits = L.logits + (size_t)t * N * st.V1p; p.sample_max = sample_max; p.temperature = temperature; p.seed = seed;
+    p.decoding_constraint = decoding_constraint;
+    p.seq = seq; p.seq_logp = seq_logp; p.it = L.s_it; p.unfinished = L.s_unf; p.n_unfinished = L.s_nunf;
+    p.forced = forced;
+    UIC_TRY(uic_sample_step_launch(p, s));
+  }
+  return UIC_OK;
+}
 
 int uic_topdown_prepare_feature(const uic_topdown_dims* d, const uic_topdown_weights* w, const void* derived,
                                 const uic_topdown_batch* b, int32_t training, uint32_t seed, void* workspace,

@@ -75,6 +75,26 @@ class _TopDownForward(torch.autograd.Function):
         return (None, d_fc, d_att, None, None, None) + tuple(grads[k] for k in model.param_names)
 
 
+class _HeldWorkspace(object):
+    """A checked-out engine workspace that goes back to the pool when backward has used it -- or when the graph that
+    holds it is dropped without a backward pass."""
+
+    def __init__(self, eng, ws):
+        self.eng, self.ws = eng, ws
+
+    def take(self):
+        ws, self.ws = self.ws, None
+        return ws
+
+    def __del__(self):
+        if self.ws is not None:
+            try:
+                self.eng.release(self.ws)
+            except Exception:
+                pass
+            self.ws = None
+
+
 class _TopDownSample(torch.autograd.Function):
     """Multinomial sampling pass of the self-critical step (P/trainer.py:167): returns (seq, seqLogprobs) with
     seqLogprobs differentiable.  Backward replays the sampled sequence teacher-forced with the SAME dropout seed
@@ -86,7 +106,14 @@ class _TopDownSample(torch.autograd.Function):
         eng = model.engine
         pd = dict(zip(model.param_names, params))
         seed = model.next_seed()
-        seq, lp = eng.sample(pd, fc, att, att_masks, model.seq_length, seed=seed, training=model.training, **sample_kw)
+        # in train mode the pass keeps its forward (training layout): backward starts at the criterion instead of replaying
+        keep = bool(model.training) and getattr(model, 'scst_keep_forward', True)
+        if keep:
+            seq, lp, ws = eng.sample(pd, fc, att, att_masks, model.seq_length, seed=seed, training=True, keep_forward=True, **sample_kw)
+            ctx.ws = _HeldWorkspace(eng, ws)
+        else:
+            seq, lp = eng.sample(pd, fc, att, att_masks, model.seq_length, seed=seed, training=model.training, **sample_kw)
+            ctx.ws = None
         ctx.model = model
         ctx.call = (seed, model.training)
         ctx.inputs = (fc, att, att_masks, seq)
@@ -104,15 +131,29 @@ class _TopDownSample(torch.autograd.Function):
         N, L = seq.shape
         labels = torch.zeros(N, L + 2, dtype=torch.int64, device=seq.device)
         labels[:, 1:L + 1] = seq
-        grads = {k: torch.empty_like(v) for k, v in pd.items()}
+        # direct: every p.grad IS its view of the optimizer's flat gradient arena (Trainer.train_self_critical set both up):
+        # the kernels write there and autograd gets nothing to copy or accumulate; otherwise fresh tensors go back to autograd
+        sink = getattr(model, '_grad_sink', None)
+        direct = sink is not None and all(p.grad is sink[k] for k, p in zip(model.param_names, ctx.params))
+        grads = sink if direct else {k: torch.empty_like(v) for k, v in pd.items()}
         # d loss / d logits = -g * (softmax - onehot)  ->  gradient weight of position (n, t) is -g[n, t]
         # bit 1: the sampling pass of this iteration already updated the BatchNorm running statistics
-        eng.xe_train_step(pd, fc, att, att_masks, labels[:, :L + 1].contiguous(), None, L, int(training) | 2, seed, grads,
-                          grad_scale=(-g_lp).contiguous())
+        held = ctx.ws.take() if ctx.ws is not None else None
+        if held is not None:
+            # the sampling pass left its whole forward in `held` (dims T = L + 1: the labels keep their L + 2 columns)
+            eng.xe_train_step(pd, fc, att, att_masks, labels, None, L, int(training) | 2, seed, grads,
+                              grad_scale=(-g_lp).contiguous(), resume_ws=held)
+        else:
+            eng.xe_train_step(pd, fc, att, att_masks, labels[:, :L + 1].contiguous(), None, L, int(training) | 2, seed, grads,
+                              grad_scale=(-g_lp).contiguous())
+        if direct:
+            return (None, None, None, None, None) + (None,) * len(model.param_names)
         return (None, None, None, None, None) + tuple(grads[k] for k in model.param_names)
 
 
 class AttModel(CaptionModel):
+    supports_grad_sink = True      # _TopDownSample.backward can write straight into Trainer's flat gradient arena
+
     def __init__(self, opt):
         super(AttModel, self).__init__()
         self.vocab_size = opt.vocab_size

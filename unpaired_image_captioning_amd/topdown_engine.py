@@ -219,13 +219,19 @@ class TopDownEngine(object):
         self._write_back(g)
 
     def xe_train_step(self, params, fc, att, att_masks, labels, masks, t_run, training, seed, grads, inv_den=None,
-                      grad_scale=None, ss_prob=0.0, keep_workspace=False, d_fc=None, d_att=None):
-        """Fused forward + criterion + backward on two HIP streams; returns a device tensor [loss, sum(mask)]."""
+                      grad_scale=None, ss_prob=0.0, keep_workspace=False, d_fc=None, d_att=None, resume_ws=None):
+        """Fused forward + criterion + backward on two HIP streams; returns a device tensor [loss, sum(mask)].
+        resume_ws: the workspace sample(..., keep_forward=True) left behind for these labels (same weights, seed, L): the
+        step starts at the criterion (training bit 2) and the workspace is released afterwards."""
         (N, S), R = self._rows(att, labels), att.shape[1]
         T = labels.shape[1] - 1
         d = self.dims(N, R, T, S)
         w = self.refresh(params, d)
-        ws = self.checkout(d, fc.device)
+        if resume_ws is not None:
+            ws = resume_ws
+            training = int(training) | 4
+        else:
+            ws = self.checkout(d, fc.device)
         b = self.batch_struct(fc, att, att_masks, labels, masks, grad_scale, ss_prob, d_fc=d_fc, d_att=d_att)
         g = self.weights_struct(grads, outputs=True)
         out = torch.empty(2, dtype=torch.float32, device=fc.device)
@@ -244,8 +250,10 @@ class TopDownEngine(object):
         return out
 
     def sample(self, params, fc, att, att_masks, L, sample_max=1, temperature=1.0, decoding_constraint=0, seed=0,
-               forced=None, training=False, seq_per_img=1):
-        """seq_per_img = S > 1: features come once per image and S captions are decoded per image (rows image * S + j)."""
+               forced=None, training=False, seq_per_img=1, keep_forward=False):
+        """seq_per_img = S > 1: features come once per image and S captions are decoded per image (rows image * S + j).
+        keep_forward: run the pass in the training layout (uic_topdown_sample_train) and return (seq, lp, ws) with the
+        workspace still checked out -- it holds the whole forward pass for xe_train_step(..., resume_ws=ws)."""
         N, R = att.shape[0] * seq_per_img, att.shape[1]
         d = self.dims(N, R, L + 1, seq_per_img)
         w = self.refresh(params, d)
@@ -253,13 +261,19 @@ class TopDownEngine(object):
         b = self.batch_struct(fc, att, att_masks)
         seq = torch.zeros(N, L, dtype=torch.int64, device=fc.device)
         lp = torch.zeros(N, L, dtype=torch.float32, device=fc.device)
+        fn = self.lib.uic_topdown_sample_train if keep_forward else self.lib.uic_topdown_sample
+        ok = False
         try:
-            check(self.lib.uic_topdown_sample(C.byref(d), C.byref(w), ptr(self._derived), C.byref(b), L, int(sample_max),
-                                              float(temperature), int(decoding_constraint), seed & 0xFFFFFFFF, ptr(forced),
-                                              int(training), ptr(ws.buf), ptr(seq), ptr(lp), stream()), "sample")
+            check(fn(C.byref(d), C.byref(w), ptr(self._derived), C.byref(b), L, int(sample_max),
+                     float(temperature), int(decoding_constraint), seed & 0xFFFFFFFF, ptr(forced),
+                     int(training), ptr(ws.buf), ptr(seq), ptr(lp), stream()), "sample")
             self._write_back(w)
+            ok = True
         finally:
-            self.release(ws)
+            if not (keep_forward and ok):
+                self.release(ws)
+        if keep_forward:
+            return seq, lp, ws
         return seq, lp
 
     def sample_beam(self, params, fc, att, att_masks, L, beam_size, decoding_constraint=0, max_ppl=0, done_lists=False):

@@ -320,12 +320,21 @@ class Trainer(object):
                 adv = self.discriminator_scores(gen_result) - self.discriminator_scores(g_rows)
                 reward_t = reward_t + dw * adv[:, None]
             loss = RewardCriterion()(sample_logprobs, gen_result, reward_t)
-            for p in model.parameters():
-                p.grad = None
-            loss.backward()
-        params = dict(model.named_parameters())
-        for k, view in self.arena.grad_views.items():
-            view.copy_(params[k].grad)
+            # every p.grad is its view of the flat gradient arena: the backward kernels write there directly (models/AttModel.py
+            # _TopDownSample.backward); a model without that path hands tensors back to autograd, copied below
+            params = dict(model.named_parameters())
+            views = self.arena.grad_views
+            sink_ok = getattr(model, 'supports_grad_sink', False)
+            for k, p in params.items():
+                p.grad = views[k] if (sink_ok and k in views) else None
+            model._grad_sink = views if sink_ok else None
+            try:
+                loss.backward()
+            finally:
+                model._grad_sink = None
+        for k, view in views.items():
+            if params[k].grad is not view:
+                view.copy_(params[k].grad)
         self.exchange.allreduce_sum(self.arena.grad)
         self._step += 1
         a = self.arena
