@@ -13,6 +13,8 @@
 // beam_final_kernel ranks the done list (stable, by p) and writes the best beam's tokens and log-probs (:174-176,
 // AttModel.py:193-194).
 #include "uic_common.h"
+#include <stdlib.h>
+#include <stdint.h>
 
 namespace {
 
@@ -39,7 +41,9 @@ __device__ __forceinline__ float bsum(float v, float* s_buf) {
   return r;
 }
 
-__global__ __launch_bounds__(NT) void beam_topk_kernel(const UicBeamParams p) {
+// three passes over the row (maximum, sum, candidates), one word per lane and load: the shorter rows of the captioner's
+// vocabulary (9 488 words stay in the L2 between the passes); rows of >= 16 384 words take the one-pass kernel below
+__global__ __launch_bounds__(NT) void beam_topk3_kernel(const UicBeamParams p) {
   __shared__ float s_buf[NT / 64];
   __shared__ float s_val[NT];
   __shared__ int s_idx[NT];
@@ -102,6 +106,100 @@ __global__ __launch_bounds__(NT) void beam_topk_kernel(const UicBeamParams p) {
       float nv = -INFINITY;
       int ni = 0x7fffffff;
       for (int v = owner + lane * NT; v < V1; v += 64 * NT) {
+        const float lp = value(v);
+        const bool after = lp < gv || (lp == gv && v > gi);          // sorts strictly after the element just taken
+        if (after && better(lp, v, nv, ni)) { nv = lp; ni = v; }
+      }
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) {
+        const float ov = __shfl_xor(nv, o, 64);
+        const int oi = __shfl_xor(ni, o, 64);
+        if (better(ov, oi, nv, ni)) { nv = ov; ni = oi; }
+      }
+      if (tid == owner) { bv = nv; bi = ni; }
+    }
+  }
+}
+
+__global__ __launch_bounds__(NT) void beam_topk_kernel(const UicBeamParams p) {
+  __shared__ float s_buf[NT / 64];
+  __shared__ float s_val[NT];
+  __shared__ int s_idx[NT];
+  const int row = blockIdx.x;
+  const float* x = p.logits + (size_t)row * p.ldv;
+  long banned = -1;
+  if (p.decoding_constraint && p.t > 0 && !p.plain) banned = p.beam_seq[((size_t)(row / p.B) * p.L + (p.t - 1)) * p.B + (row % p.B)];
+  const int V1 = p.V1;
+  // the reference's modifications act on single indices and log-softmax shifts the whole row by one number, so the order of
+  // the candidates can be read off the raw logits: `raw` is everything of value() except the common - lse
+  auto raw = [&](int v, float xv) {
+    if (v == banned) xv = -INFINITY;
+    if (v == V1 - 1 && !p.plain) xv -= 1000.f;
+    return xv;
+  };
+  // order of the result: value descending, lower index first on ties (what the reference's sort + enumeration uses)
+  auto better = [](float av, int ai, float bv_, int bi_) { return av > bv_ || (av == bv_ && ai < bi_); };
+  // ONE pass over the row (a 50 004-word row is 200 KB and there are ~1 000 of them per step: three passes were three trips to
+  // HBM / the Infinity Cache): every thread keeps a running maximum with the sum of exponentials rescaled to it, and the best
+  // of ITS elements -- element groups g = tid, tid + NT, ... of four consecutive words, one 16-byte load each.
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  float bv = -INFINITY;
+  int bi = 0x7fffffff;
+  float mx = -INFINITY, sum = 0.f;
+  const bool vec_ok = p.ldv % 4 == 0 && ((size_t)p.logits & 15) == 0;
+  for (int v0 = tid * 4; v0 < V1; v0 += NT * 4) {
+    float q[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+    if (vec_ok && v0 + 3 < V1) {
+      const float4 f = *(const float4*)(x + v0);
+      q[0] = f.x; q[1] = f.y; q[2] = f.z; q[3] = f.w;
+    } else {
+      for (int c = 0; v0 + c < V1; ++c) q[c] = x[v0 + c];
+    }
+    const float m4 = fmaxf(fmaxf(q[0], q[1]), fmaxf(q[2], q[3]));
+    if (m4 > mx) { sum *= expf(mx - m4); mx = m4; }          // (exp(-inf) = 0 on the first group)
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      sum += expf(q[c] - mx);                                // slots past the row hold -inf: + 0
+      const float rv = raw(v0 + c, q[c]);
+      if (v0 + c < V1 && better(rv, v0 + c, bv, bi)) { bv = rv; bi = v0 + c; }
+    }
+  }
+  const float gmx = bmax(mx, s_buf);
+  sum = bsum(sum * expf(mx - gmx), s_buf);
+  const float lse = gmx + logf(sum);
+  bv -= lse;
+  auto value = [&](int v) { return raw(v, x[v]) - lse; };
+  float* s_wv = s_val;            // [NT / 64] per-wave winners
+  int* s_wi = s_idx;
+  for (int k = 0; k < p.B; ++k) {
+    float wv = bv;
+    int wi = bi;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      const float ov = __shfl_xor(wv, o, 64);
+      const int oi = __shfl_xor(wi, o, 64);
+      if (better(ov, oi, wv, wi)) { wv = ov; wi = oi; }
+    }
+    __syncthreads();                                  // the previous round's readers are done with s_wv / s_wi
+    if (lane == 0) { s_wv[wave] = wv; s_wi[wave] = wi; }
+    __syncthreads();
+    float gv = s_wv[0];
+    int gi = s_wi[0];
+#pragma unroll
+    for (int w2 = 1; w2 < NT / 64; ++w2)
+      if (better(s_wv[w2], s_wi[w2], gv, gi)) { gv = s_wv[w2]; gi = s_wi[w2]; }
+    if (tid == 0) {
+      p.cand_val[(size_t)row * p.B + k] = gv;
+      p.cand_idx[(size_t)row * p.B + k] = gi;
+    }
+    if (gi == 0x7fffffff) continue;                   // nothing left (only possible when B exceeds the row length)
+    const int owner = (gi >> 2) % NT;                 // the thread whose element groups hold word gi
+    if (wave == (owner >> 6)) {
+      float nv = -INFINITY;
+      int ni = 0x7fffffff;
+      for (int g = owner + (lane >> 2) * NT; g * 4 < V1; g += 16 * NT) {   // 4 lanes per group, 16 groups per round
+        const int v = g * 4 + (lane & 3);
+        if (v >= V1) continue;
         const float lp = value(v);
         const bool after = lp < gv || (lp == gv && v > gi);          // sorts strictly after the element just taken
         if (after && better(lp, v, nv, ni)) { nv = lp; ni = v; }
@@ -208,13 +306,19 @@ __global__ void beam_final_kernel(const UicBeamParams p, int64_t* __restrict__ s
 
 }  // namespace
 
+static int launch_topk(const UicBeamParams& p, hipStream_t s) {
+  if (p.V1 >= 16384) hipLaunchKernelGGL(beam_topk_kernel, dim3(p.n_img * p.B), dim3(NT), 0, s, p);
+  else hipLaunchKernelGGL(beam_topk3_kernel, dim3(p.n_img * p.B), dim3(NT), 0, s, p);
+  UIC_LAUNCH_CHECK("beam_topk");
+  return UIC_OK;
+}
+
 int uic_beam_step_launch(const UicBeamParams& p, hipStream_t s) {
   UIC_REQUIRE(p.B >= 1 && p.B <= UIC_BEAM_MAX && p.B <= p.V1, "beam search: beam_size=%d outside [1, min(%d, V1)]", p.B, UIC_BEAM_MAX);
   UIC_REQUIRE(p.n_img > 0 && p.L > 0 && p.t >= 0 && p.t < p.L, "beam search: bad sizes");
   UicBeamParams q = p;
   q.beam_seq = p.beam_seq_hist[p.t & 1];     // generation holding steps < t
-  hipLaunchKernelGGL(beam_topk_kernel, dim3(p.n_img * p.B), dim3(NT), 0, s, q);
-  UIC_LAUNCH_CHECK("beam_topk");
+  UIC_TRY(launch_topk(q, s));
   hipLaunchKernelGGL(beam_merge_kernel, dim3((p.n_img + 63) / 64), dim3(64), 0, s, q);
   UIC_LAUNCH_CHECK("beam_merge");
   return UIC_OK;
@@ -222,9 +326,7 @@ int uic_beam_step_launch(const UicBeamParams& p, hipStream_t s) {
 
 int uic_beam_topk_launch(const UicBeamParams& p, hipStream_t s) {
   UIC_REQUIRE(p.B >= 1 && p.B <= UIC_BEAM_MAX && p.B <= p.V1 && p.n_img > 0, "beam topk: bad sizes (beam_size=%d)", p.B);
-  hipLaunchKernelGGL(beam_topk_kernel, dim3(p.n_img * p.B), dim3(NT), 0, s, p);
-  UIC_LAUNCH_CHECK("beam_topk");
-  return UIC_OK;
+  return launch_topk(p, s);
 }
 
 int uic_beam_gather_launch(int dtype, const int* parent, int rows, int B, int H, const void* h1s, void* h1d, const void* h2s, void* h2d,

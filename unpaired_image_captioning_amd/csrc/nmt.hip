@@ -240,7 +240,17 @@ __global__ void nmt_beam_init_kernel(int B, int K, int64_t* tok, float* scores, 
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < B * K) { tok[i] = (i % K) == 0 ? 2 : 0; scores[i] = 0.f; }
   if (i < B) done[i] = 0;
-  if (i < 2) flags[i] = 0;
+  if (i < 4) flags[i] = 0;
+}
+// `if not active: break` (translateBatch :377-378) decided ON THE DEVICE, so the host loop need not wait for every step:
+// before step `step` advances, flags[1] still holds the number of active sentences after step - 1.  None left: the search is
+// frozen (flags[2]) -- the remaining, speculatively enqueued steps leave every beam tensor alone -- else flags[3] = the number
+// of steps that really ran (the reference's loop count) and the counter is cleared for this step.
+__global__ void nmt_beam_begin_kernel(int step, int* flags) {
+  if (flags[2]) return;
+  if (step > 0 && flags[1] == 0) { flags[2] = 1; return; }
+  flags[3] = step + 1;
+  flags[1] = 0;
 }
 // Beam.advance for every sentence (O/Beam.py:52-89): top K of the flattened beam x word scores -- the candidates are the
 // per-row top K (cand_val / cand_idx from beam_topk), enumerated beam-major so that ties resolve to the lower flat index --
@@ -251,6 +261,7 @@ __global__ __launch_bounds__(64) void nmt_beam_advance_kernel(int B, int K, int 
   // one wavefront per sentence: the rows x K candidates sit 4 to a lane, K rounds of a wave-wide arg-max
   constexpr int PER = (UIC_BEAM_MAX * UIC_BEAM_MAX + 63) / 64;
   const int b = blockIdx.x, lane = threadIdx.x;
+  if (flags[2]) return;                                   // frozen: every sentence was done before this step (nmt_beam_begin_kernel)
   const int rows = step == 0 ? 1 : K, n = rows * K;
   float pj[PER];
   long flat[PER];
@@ -1055,6 +1066,7 @@ int uic_nmt_translate(const uic_nmt_dims* d, const uic_nmt_weights* w, const int
   UIC_TRY(uic_fill_launch(T.feed[0], 0, RH * Sz, s));
   hipLaunchKernelGGL(nmt_beam_init_kernel, dim3(gridn((size_t)R)), dim3(NT), 0, s, B, K, T.tok, T.scores, T.done, T.flags);
   UIC_LAUNCH_CHECK("nmt_beam_init_kernel");
+  UIC_TRY(uic_fill_launch(T.prev_ks, 0, (size_t)max_steps * R * 4, s));   // (speculative steps of a frozen search gather parent 0)
   const void* ctx = off(L.xl[NL], (size_t)R * H, dt);            // memory bank [S, R, H] (slot 1 onwards)
   const size_t lds_att = sizeof(float) * ((size_t)H + S + 4 * (size_t)H);
   UicBeamParams bp;
@@ -1104,7 +1116,8 @@ int uic_nmt_translate(const uic_nmt_dims* d, const uic_nmt_weights* w, const int
     }
     bp.t = step;
     UIC_TRY(uic_beam_topk_launch(bp, s));
-    UIC_TRY(uic_fill_launch(T.flags + 1, 0, 4, s));
+    hipLaunchKernelGGL(nmt_beam_begin_kernel, dim3(1), dim3(1), 0, s, step, T.flags);
+    UIC_LAUNCH_CHECK("nmt_beam_begin_kernel");
     hipLaunchKernelGGL(nmt_beam_advance_kernel, dim3(B), dim3(64), 0, s, B, K, step, T.cand_val, T.cand_idx, T.scores,
                        T.prev_ks, T.next_ys, T.tok, T.done, T.flags);
     UIC_LAUNCH_CHECK("nmt_beam_advance_kernel");
@@ -1113,12 +1126,23 @@ int uic_nmt_translate(const uic_nmt_dims* d, const uic_nmt_weights* w, const int
     for (int l = 0; l < NL; ++l)
       UIC_TRY(uic_beam_gather_launch(dt, parents, R, K, H, T.h[l][1], T.h[l][0], nullptr, nullptr, T.c[l][1], T.c[l][0], nullptr, nullptr, s));
     UIC_TRY(uic_beam_gather_launch(dt, parents, R, K, H, T.feed[1], T.feed[0], nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, s));
-    n_iter = step + 1;
-    // `if not active: break` (:377-378) -- the one host synchronisation per step of this (evaluation-only) entry point
-    int active = 0;
-    UIC_TRY(uic_check_hip(hipMemcpyAsync(&active, T.flags + 1, 4, hipMemcpyDeviceToHost, s), "memcpy active"));
+    // `if not active: break` (:377-378): the device freezes the search by itself (nmt_beam_begin_kernel); the host looks at the
+    // flags every SYNC_EVERY steps only -- at most SYNC_EVERY - 1 speculative steps run on a finished search, and the GPU no
+    // longer idles through a host round trip + 13 launches after every step
+    constexpr int SYNC_EVERY = 4;
+    if ((step + 1) % SYNC_EVERY == 0 && step + 1 < max_steps) {
+      int fl[4] = {0, 0, 0, 0};
+      UIC_TRY(uic_check_hip(hipMemcpyAsync(fl, T.flags, 16, hipMemcpyDeviceToHost, s), "memcpy flags"));
+      UIC_TRY(uic_check_hip(hipStreamSynchronize(s), "hipStreamSynchronize"));
+      if (fl[2] || fl[1] == 0) break;                    // frozen already, or this very step finished the last sentence
+    }
+  }
+  {
+    // steps that really ran: flags[3] (a search that never froze ran them all)
+    int fl[4] = {0, 0, 0, 0};
+    UIC_TRY(uic_check_hip(hipMemcpyAsync(fl, T.flags, 16, hipMemcpyDeviceToHost, s), "memcpy flags"));
     UIC_TRY(uic_check_hip(hipStreamSynchronize(s), "hipStreamSynchronize"));
-    if (active == 0) break;
+    n_iter = fl[3];
   }
   *n_iter_out = n_iter;
   // (4) read-out
