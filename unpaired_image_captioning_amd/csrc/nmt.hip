@@ -543,33 +543,55 @@ struct Nmt {
   }
 
   int refresh(hipStream_t s) {
+    // operand-dtype copies and transposes of the weights, a handful of multi-tensor launches instead of one per tensor
+    // (the step is a chain of small launches: 34 of them were this)
     if (dt == UIC_BF16) {
-      UIC_TRY(uic_cast_f32_launch(dt, w->enc_lin_w, L.c_enc_lin_w, (size_t)W * W, s));
+      const float* src[UIC_CAST_MULTI]; void* dst[UIC_CAST_MULTI]; size_t n[UIC_CAST_MULTI];
+      int k = 0;
+      auto flush = [&]() -> int { if (k) UIC_TRY(uic_cast_f32_multi_launch(dt, k, src, dst, n, s)); k = 0; return UIC_OK; };
+      auto add = [&](const float* a, const void* b, size_t cnt) -> int {
+        src[k] = a; dst[k] = (void*)b; n[k] = cnt;
+        if (++k == UIC_CAST_MULTI) return flush();
+        return UIC_OK;
+      };
+      UIC_TRY(add(w->enc_lin_w, L.c_enc_lin_w, (size_t)W * W));
       for (int l = 0; l < NL; ++l) {
         const int in = l == 0 ? W : H, din = l == 0 ? W + H : H;
         for (int dd = 0; dd < 2; ++dd) {
-          UIC_TRY(uic_cast_f32_launch(dt, w->enc_w_ih[l][dd], L.c_enc_w_ih[l][dd], (size_t)4 * Hd * in, s));
-          UIC_TRY(uic_cast_f32_launch(dt, w->enc_w_hh[l][dd], L.c_enc_w_hh[l][dd], (size_t)4 * Hd * Hd, s));
+          UIC_TRY(add(w->enc_w_ih[l][dd], L.c_enc_w_ih[l][dd], (size_t)4 * Hd * in));
+          UIC_TRY(add(w->enc_w_hh[l][dd], L.c_enc_w_hh[l][dd], (size_t)4 * Hd * Hd));
         }
-        UIC_TRY(uic_cast_f32_launch(dt, w->dec_w_ih[l], L.c_dec_w_ih[l], (size_t)4 * H * din, s));
-        UIC_TRY(uic_cast_f32_launch(dt, w->dec_w_hh[l], L.c_dec_w_hh[l], (size_t)4 * H * H, s));
+        UIC_TRY(add(w->dec_w_ih[l], L.c_dec_w_ih[l], (size_t)4 * H * din));
+        UIC_TRY(add(w->dec_w_hh[l], L.c_dec_w_hh[l], (size_t)4 * H * H));
       }
-      UIC_TRY(uic_cast_f32_launch(dt, w->attn_in_w, L.c_attn_in_w, (size_t)H * H, s));
-      UIC_TRY(uic_cast_f32_launch(dt, w->attn_out_w, L.c_attn_out_w, (size_t)H * 2 * H, s));
-      UIC_TRY(uic_cast_f32_launch(dt, w->gen_w, L.c_gen_w, (size_t)Vt * H, s));
+      UIC_TRY(add(w->attn_in_w, L.c_attn_in_w, (size_t)H * H));
+      UIC_TRY(add(w->attn_out_w, L.c_attn_out_w, (size_t)H * 2 * H));
+      UIC_TRY(flush());
+      UIC_TRY(uic_cast_f32_launch(dt, w->gen_w, L.c_gen_w, (size_t)Vt * H, s));   // (25.6 M elements: a launch of its own)
     }
-    UIC_TRY(uic_transpose_launch(dt, L.enc_lin_w, W, W, W, L.enc_lin_wT, W, s));
-    for (int l = 0; l < NL; ++l) {
-      const int in = l == 0 ? W : H, din = l == 0 ? W + H : H;
-      for (int dd = 0; dd < 2; ++dd) {
-        UIC_TRY(uic_transpose_launch(dt, L.enc_w_ih[l][dd], 4 * Hd, in, in, L.enc_w_ihT[l][dd], 4 * Hd, s));
-        UIC_TRY(uic_transpose_launch(dt, L.enc_w_hh[l][dd], 4 * Hd, Hd, Hd, L.enc_w_hhT[l][dd], 4 * Hd, s));
+    {
+      UicTransposeJob jobs[UIC_TRANSPOSE_MULTI];
+      int k = 0;
+      auto flush = [&]() -> int { if (k) UIC_TRY(uic_transpose_multi_launch(dt, k, jobs, s)); k = 0; return UIC_OK; };
+      auto add = [&](const void* src, int rows, int cols, int lds, void* dst, int ldd) -> int {
+        jobs[k] = UicTransposeJob{src, dst, rows, cols, lds, ldd};
+        if (++k == UIC_TRANSPOSE_MULTI) return flush();
+        return UIC_OK;
+      };
+      UIC_TRY(add(L.enc_lin_w, W, W, W, L.enc_lin_wT, W));
+      for (int l = 0; l < NL; ++l) {
+        const int in = l == 0 ? W : H, din = l == 0 ? W + H : H;
+        for (int dd = 0; dd < 2; ++dd) {
+          UIC_TRY(add(L.enc_w_ih[l][dd], 4 * Hd, in, in, L.enc_w_ihT[l][dd], 4 * Hd));
+          UIC_TRY(add(L.enc_w_hh[l][dd], 4 * Hd, Hd, Hd, L.enc_w_hhT[l][dd], 4 * Hd));
+        }
+        UIC_TRY(add(L.dec_w_ih[l], 4 * H, din, din, L.dec_wT[l], 4 * H));
+        UIC_TRY(add(L.dec_w_hh[l], 4 * H, H, H, offw(L.dec_wT[l], (size_t)din * 4 * H, dt), 4 * H));
       }
-      UIC_TRY(uic_transpose_launch(dt, L.dec_w_ih[l], 4 * H, din, din, L.dec_wT[l], 4 * H, s));
-      UIC_TRY(uic_transpose_launch(dt, L.dec_w_hh[l], 4 * H, H, H, offw(L.dec_wT[l], (size_t)din * 4 * H, dt), 4 * H, s));
+      UIC_TRY(add(L.attn_in_w, H, H, H, L.attn_in_wT, H));
+      UIC_TRY(add(L.attn_out_w, H, 2 * H, 2 * H, L.attn_out_wT, H));
+      UIC_TRY(flush());
     }
-    UIC_TRY(uic_transpose_launch(dt, L.attn_in_w, H, H, H, L.attn_in_wT, H, s));
-    UIC_TRY(uic_transpose_launch(dt, L.attn_out_w, H, 2 * H, 2 * H, L.attn_out_wT, H, s));
     return uic_transpose_launch(dt, L.gen_w, Vt, H, H, L.gen_wT, Vtp, s);
   }
 
