@@ -342,11 +342,17 @@ __global__ __launch_bounds__(64 * WM * WN * KS) void uic_gemm_kernel(const UicGe
   if constexpr (KS == 1) {
     epilogue(std::integral_constant<int, 0>{});
   } else {
-    static_assert(KS == 4, "epilogue dispatch is written for KS = 4");
+    static_assert(KS == 4 || KS == 8, "epilogue dispatch is written for KS = 4 or 8");
     if (ks_id == 0) epilogue(std::integral_constant<int, 0>{});
     else if (ks_id == 1) epilogue(std::integral_constant<int, RPG>{});
     else if (ks_id == 2) epilogue(std::integral_constant<int, 2 * RPG>{});
-    else epilogue(std::integral_constant<int, 3 * RPG>{});
+    else if (ks_id == 3) epilogue(std::integral_constant<int, 3 * RPG>{});
+    else if constexpr (KS == 8) {
+      if (ks_id == 4) epilogue(std::integral_constant<int, 4 * RPG>{});
+      else if (ks_id == 5) epilogue(std::integral_constant<int, 5 * RPG>{});
+      else if (ks_id == 6) epilogue(std::integral_constant<int, 6 * RPG>{});
+      else epilogue(std::integral_constant<int, 7 * RPG>{});
+    }
   }
 }
 
@@ -611,7 +617,15 @@ int launch_typed(const UicGemmParams& p, hipStream_t s) {
     return launch_glds<T>(p, s);
   }
   if (blocks128 >= 200 && glds_ok && !p.C_pre) return launch_glds<T>(p, s);
-  if (blocks128 >= 200) return launch_cfg<T, 2, 2, 2, 2, 1, false>(p, s);
+  if (blocks128 >= 200) return launch_cfg<T, 1 + 1, 2, 2, 2, 1, false>(p, s);
+  // one row tile (M <= 64: the pivot NMT's per-step GEMMs at batch 64) with a long reduction: 8-way in-block K split on a
+  // 64 x 32 tile -- the chain of dependent K rounds is what such a launch takes, and twice as many workgroups share the columns
+  static const int ks8 = getenv("UIC_GEMM_KS8") ? atoi(getenv("UIC_GEMM_KS8")) : 1;
+  if (ks8 && p.M <= 64 && !p.C_pre) {
+    int ktot = 0;
+    for (int i = 0; i < p.nseg; ++i) ktot += p.seg[i].K;
+    if (ktot * (int)sizeof(T) >= 2048) return launch_cfg<T, 1, 1, 2, 1, 8, false>(p, s);
+  }
   return launch_cfg<T, 1, 1, 2, 2, 4, false>(p, s);
 }
 
