@@ -34,3 +34,11 @@ timeout 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d /tm
 timeout 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d /tmp/pr/write -- python3 $R/tools/rnn_kernel_only.py > /tmp/prw.log 2>&1
 tail -2 /tmp/prf.log
 python3 $R/tools/pmc_traffic.py /tmp/pr rnn_fwd_persist $O/rnn_persist_pmc_bf16.json
+# secondary paths on the same box: API / decode / self-critical phases, pivot NMT training step, joint pivot decode
+timeout 300 python3 $R/tools/phase_times.py > $O/phase_times.txt 2>/dev/null
+timeout 200 python3 $R/tools/scst_phases.py 2>/dev/null | tail -21 > $O/scst_phases.txt
+timeout 200 python3 $R/tools/nmt_bench.py --steps 20 2>/dev/null | tail -1 > $O/nmt_bench.txt
+timeout 200 python3 $R/tools/pivot_decode_bench.py --iters 20 2>/dev/null | tail -1 > $O/pivot_decode.txt
+timeout 300 bash $R/tools/nmt_profile.sh > $O/nmt_profile.txt 2>&1
+timeout 300 bash $R/tools/pivot_profile.sh > $O/pivot_profile.txt 2>&1
+cat $O/nmt_bench.txt $O/pivot_decode.txt
