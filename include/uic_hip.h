@@ -142,11 +142,13 @@ size_t uic_topdown_workspace_bytes(const uic_topdown_dims* d);
 size_t uic_topdown_derived_bytes(const uic_topdown_dims* d);
 
 /* Rebuild the operand-dtype / transposed weight copies in `derived` from the f32 masters.
- * Must run after every change of the masters (optimizer step, load_state_dict).  The call enqueues the operand-dtype copies
- * (partly on the library's second stream); the transposed copies, which only backward passes read, are enqueued by the first
- * uic_topdown_* call that follows on this device (the fused training step puts its side-stream prologue in front of them):
- * `w`'s tensors and `derived` must stay alive and unchanged until then, as they must for that call anyway. */
+ * Must run after every change of the masters (optimizer step, load_state_dict). */
 int uic_topdown_refresh_weights(const uic_topdown_dims* d, const uic_topdown_weights* w, void* derived, void* stream);
+/* The same, for a caller whose NEXT call on this device is a uic_topdown_* consumer of `derived` (the training loop: refresh,
+ * then uic_topdown_xe_train_step): only the operand-dtype copies are enqueued here; the transposed copies, which backward
+ * passes alone read, are enqueued by that next call -- the fused step puts its side-stream prologue in front of them.  `w`'s
+ * tensors and `derived` must stay alive and unchanged until then (as they must for that call anyway). */
+int uic_topdown_refresh_weights_deferred(const uic_topdown_dims* d, const uic_topdown_weights* w, void* derived, void* stream);
 
 /* AttModel._forward (P/models/AttModel.py:119-156) with ss_prob = 0: feature projection, the
  * teacher-forced unroll over `t_run` <= d->T steps (t_run < T reproduces the early break at :151)

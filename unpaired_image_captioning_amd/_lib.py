@@ -212,6 +212,7 @@ _SIGS = {
     "uic_topdown_workspace_bytes": (C.c_size_t, [C.POINTER(Dims)]),
     "uic_topdown_derived_bytes": (C.c_size_t, [C.POINTER(Dims)]),
     "uic_topdown_refresh_weights": (C.c_int, [C.POINTER(Dims), C.POINTER(Weights), C.c_void_p, C.c_void_p]),
+    "uic_topdown_refresh_weights_deferred": (C.c_int, [C.POINTER(Dims), C.POINTER(Weights), C.c_void_p, C.c_void_p]),
     "uic_topdown_forward": (C.c_int, [C.POINTER(Dims), C.POINTER(Weights), C.c_void_p, C.POINTER(Batch), C.c_int32,
                                       C.c_int32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]),
     "uic_topdown_xe_loss": (C.c_int, [C.POINTER(Dims), C.POINTER(Batch), C.c_int32, C.c_void_p, C.c_void_p,

@@ -530,6 +530,13 @@ void* uic_topdown_workspace_ptr(const uic_topdown_dims* d, void* workspace, cons
 }
 
 int uic_topdown_refresh_weights(const uic_topdown_dims* d, const uic_topdown_weights* w, void* derived, void* stream) {
+  UIC_TRY(uic_topdown_refresh_weights_deferred(d, w, derived, stream));
+  SideStream* ss = nullptr;
+  UIC_TRY(get_side(&ss));
+  return flush_transposes(ss);
+}
+
+int uic_topdown_refresh_weights_deferred(const uic_topdown_dims* d, const uic_topdown_weights* w, void* derived, void* stream) {
   UIC_TRY(check_dims(d));
   UIC_REQUIRE(w && derived, "refresh_weights: null pointer");
   hipStream_t s = (hipStream_t)stream;

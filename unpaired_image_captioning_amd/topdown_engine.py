@@ -152,8 +152,9 @@ class TopDownEngine(object):
                 return False
         return _Hold()
 
-    def refresh(self, params, d):
-        """Rebuild operand-dtype / transposed weight copies from the f32 masters."""
+    def refresh(self, params, d, defer=False):
+        """Rebuild operand-dtype / transposed weight copies from the f32 masters.  defer: the caller's very next library call
+        consumes them (xe_train_step), so the transposes may be left to that call (uic_topdown_refresh_weights_deferred)."""
         hold = getattr(self, "_hold", None)
         if hold is not None and hold["fresh"] and self._derived is not None:
             return self.weights_struct(params)          # same masters as the call that refreshed: pointers only
@@ -164,7 +165,8 @@ class TopDownEngine(object):
         if self._derived is None or self._derived.numel() < nbytes or self._derived.device != dev:
             self._derived = torch.empty(nbytes, dtype=torch.uint8, device=dev)
         w = self.weights_struct(params)
-        check(self.lib.uic_topdown_refresh_weights(C.byref(d), C.byref(w), ptr(self._derived), stream()), "refresh_weights")
+        fn = self.lib.uic_topdown_refresh_weights_deferred if defer else self.lib.uic_topdown_refresh_weights
+        check(fn(C.byref(d), C.byref(w), ptr(self._derived), stream()), "refresh_weights")
         return w
 
     def input_grad_buffers(self, fc, att, want_fc=True, want_att=True):
@@ -226,7 +228,7 @@ class TopDownEngine(object):
         (N, S), R = self._rows(att, labels), att.shape[1]
         T = labels.shape[1] - 1
         d = self.dims(N, R, T, S)
-        w = self.refresh(params, d)
+        w = self.refresh(params, d, defer=True)
         if resume_ws is not None:
             ws = resume_ws
             training = int(training) | 4
