@@ -137,6 +137,33 @@ __global__ __launch_bounds__(64 * WM * WN * KS) void uic_gemm_kernel(const UicGe
     }
   };
 
+  // LSTM epilogue operands of the (row, unit) pairs this lane will finish -- the gate pre-activations made elsewhere, the
+  // previous cell state, the biases: requested NOW, so that their latency passes under the K rounds instead of after them
+  // (these launches are a few microseconds of dependent latencies each; the NMT step is 256 of them)
+  constexpr int RPG0 = 16 / KS;
+  float pf_pre[LSTM ? TM : 1][LSTM ? RPG0 : 1][LSTM ? TN : 1], pf_c[LSTM ? TM : 1][LSTM ? RPG0 : 1], pf_b[LSTM ? TN : 1];
+  if constexpr (LSTM) {
+    const int u = n0 + wn * 32 + r32;
+#pragma unroll
+    for (int g = 0; g < TN; ++g) {
+      pf_b[g] = 0.f;
+      if (u < p.H) {
+        if (p.bias) pf_b[g] += p.bias[g * p.H + u];
+        if (p.bias2) pf_b[g] += p.bias2[g * p.H + u];
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int q = 0; q < RPG0; ++q) {
+        const int reg = ks_id * RPG0 + q;
+        const int row = m0 + (wm * TM + i) * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * half;
+        const bool ok = row < p.M && u < p.H;
+        pf_c[i][q] = (ok && p.c_prev) ? p.c_prev[(size_t)row * p.H + u] : 0.f;
+#pragma unroll
+        for (int g = 0; g < TN; ++g) pf_pre[i][q][g] = (ok && p.pre1) ? p.pre1[(size_t)row * p.ldpre1 + g * p.H + u] : 0.f;
+      }
+  }
 #pragma unroll
   for (int j = 0; j < PF; ++j)
     if (j < ntiles) load_tile(rra[j], rrb[j]);
@@ -269,13 +296,6 @@ __global__ __launch_bounds__(64 * WM * WN * KS) void uic_gemm_kernel(const UicGe
       const int H = p.H;
       const int u = n0 + wn * 32 + r32;
       if (u < H) {
-        float bg[TN];
-#pragma unroll
-        for (int g = 0; g < TN; ++g) {
-          bg[g] = 0.f;
-          if (p.bias) bg[g] += p.bias[g * H + u];
-          if (p.bias2) bg[g] += p.bias2[g * H + u];
-        }
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -285,12 +305,12 @@ __global__ __launch_bounds__(64 * WM * WN * KS) void uic_gemm_kernel(const UicGe
             float g4[TN];
 #pragma unroll
             for (int g = 0; g < TN; ++g) {
-              float v = acc[i][g][reg] + bg[g];
-              if (p.pre1) v += p.pre1[(size_t)row * p.ldpre1 + g * H + u];
+              float v = acc[i][g][reg] + pf_b[g];
+              if (p.pre1) v += pf_pre[i][reg - R0][g];             // (requested before the K rounds)
               if (p.pre2) v += p.pre2[(size_t)row * p.ldpre2 + g * H + u];
               g4[g] = v;
             }
-            const float cp = p.c_prev ? p.c_prev[(size_t)row * H + u] : 0.f;
+            const float cp = pf_c[i][reg - R0];
             if constexpr (TN == 4) {
               // nn.LSTMCell: chunks (i, f, g, o)
               const float gi = uic_sigmoid_t<T>(g4[0]);
