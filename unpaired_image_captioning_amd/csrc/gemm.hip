@@ -164,6 +164,26 @@ __global__ __launch_bounds__(64 * WM * WN * KS) void uic_gemm_kernel(const UicGe
         for (int g = 0; g < TN; ++g) pf_pre[i][q][g] = (ok && p.pre1) ? p.pre1[(size_t)row * p.ldpre1 + g * p.H + u] : 0.f;
       }
   }
+  // likewise the values an accumulating skinny GEMM adds to (f32 C += A B^T: the per-step `h2att` term of the BPTT loop)
+  constexpr bool PFA = !LSTM && KS > 1;
+  float pf_acc[PFA ? TM : 1][PFA ? TN : 1][PFA ? RPG0 : 1];
+  const bool pf_accum = PFA && (p.flags & UIC_GEMM_ACCUM) && ((p.flags & UIC_GEMM_OUT_F32) || sizeof(T) == 4);
+  if constexpr (PFA) {
+    if (pf_accum) {
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+          const int col = n0 + (wn * TN + j) * 32 + r32;
+#pragma unroll
+          for (int q = 0; q < RPG0; ++q) {
+            const int reg = ks_id * RPG0 + q;
+            const int row = m0 + (wm * TM + i) * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * half;
+            pf_acc[i][j][q] = (row < p.M && col < p.N) ? ((const float*)p.C)[(size_t)row * p.ldc + col] : 0.f;
+          }
+        }
+    }
+  }
 #pragma unroll
   for (int j = 0; j < PF; ++j)
     if (j < ntiles) load_tile(rra[j], rrb[j]);
@@ -283,7 +303,11 @@ __global__ __launch_bounds__(64 * WM * WN * KS) void uic_gemm_kernel(const UicGe
             const size_t o = (size_t)row * p.ldc + col;
             if (out_f32) {
               float* C = (float*)p.C;
-              if (p.flags & UIC_GEMM_ACCUM) v += C[o];
+              if constexpr (PFA) {
+                if (p.flags & UIC_GEMM_ACCUM) v += pf_accum ? pf_acc[i][j][reg - R0] : C[o];   // (requested before the K rounds)
+              } else {
+                if (p.flags & UIC_GEMM_ACCUM) v += C[o];
+              }
               C[o] = v;
             } else {
               T* C = (T*)p.C;
