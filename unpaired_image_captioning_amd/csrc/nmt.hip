@@ -181,6 +181,150 @@ __global__ __launch_bounds__(NT) void gattn_bwd_step_kernel(const void* ctx_, co
     dq[(size_t)b * lddq + j] += s_red[j] + s_red[H + j] + s_red[2 * H + j] + s_red[3 * H + j];
 }
 
+// The same two kernels for bf16 rows of H = 512 and S <= 4 * MAXR source positions, with EVERY global load of the launch issued
+// at its top: a wave keeps its <= MAXR context rows (16 B per lane) and, where scores or gradients go through ctxw, those f32
+// rows (2 x 16 B per lane) in registers.  The generic kernels above pay a memory latency per phase (query, score rows,
+// weighted rows); at batch 64 the launch IS those latencies.  Same arithmetic in the same order: bit-identical results.
+template <int MAXR>
+__global__ __launch_bounds__(NT) void gattn_fwd_fast_kernel(const bf16_t* __restrict__ ctx, const float* __restrict__ target, int S, int B,
+                                                            float* __restrict__ attn, bf16_t* __restrict__ cvec,
+                                                            const int64_t* __restrict__ mask_src, const float* __restrict__ ctxw,
+                                                            const bf16_t* __restrict__ qvec) {
+  constexpr int H = 512;
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  float* s_t = sm;            // [H]
+  float* s_a = s_t + H;       // [S]
+  float* s_red = s_a + S;     // [4][H]
+  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  uint4 cr[MAXR];
+  float4 wr[MAXR][2];
+  long mk[MAXR];
+#pragma unroll
+  for (int u = 0; u < MAXR; ++u) {
+    const int sp = wave + 4 * u;
+    const size_t r = ((size_t)(sp < S ? sp : S - 1) * B + b) * H;
+    cr[u] = *(const uint4*)(ctx + r + lane * 8);
+    if (ctxw) { wr[u][0] = *(const float4*)(ctxw + r + lane * 4); wr[u][1] = *(const float4*)(ctxw + r + (lane + 64) * 4); }
+    mk[u] = mask_src ? mask_src[(size_t)(sp < S ? sp : S - 1) * B + b] : 1;
+  }
+  for (int j = tid; j < H; j += NT) s_t[j] = ctxw ? uic_to_f(qvec[(size_t)b * H + j]) : target[(size_t)b * H + j];
+  __syncthreads();
+#pragma unroll
+  for (int u = 0; u < MAXR; ++u) {
+    const int sp = wave + 4 * u;
+    if (sp >= S) break;
+    float p = 0.f;
+    if (ctxw) {                                           // row_dot<float>: chunks lane, lane + 64 of four floats
+      const float* v0 = s_t + lane * 4; const float* v1 = s_t + (lane + 64) * 4;
+      p += wr[u][0].x * v0[0]; p += wr[u][0].y * v0[1]; p += wr[u][0].z * v0[2]; p += wr[u][0].w * v0[3];
+      p += wr[u][1].x * v1[0]; p += wr[u][1].y * v1[1]; p += wr[u][1].z * v1[2]; p += wr[u][1].w * v1[3];
+    } else {                                              // row_dot<bf16>: chunk lane of eight
+      float f[8];
+      uic_unpack<bf16_t>(cr[u], f);
+#pragma unroll
+      for (int k = 0; k < 8; ++k) p += f[k] * s_t[lane * 8 + k];
+    }
+    p = uic_wave_sum(p);
+    if (mk[u] == 0) p = -INFINITY;
+    if (lane == 0) s_a[sp] = p;
+  }
+  __syncthreads();
+  float mx = -INFINITY;
+  for (int sp = 0; sp < S; ++sp) mx = fmaxf(mx, s_a[sp]);
+  float sum = 0.f;
+  for (int sp = 0; sp < S; ++sp) sum += expf(s_a[sp] - mx);
+  const float inv = 1.f / sum;
+  __syncthreads();
+  for (int sp = tid; sp < S; sp += NT) {
+    const float a = expf(s_a[sp] - mx) * inv;
+    s_a[sp] = a;
+    attn[(size_t)b * S + sp] = a;
+  }
+  __syncthreads();
+  float acc[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) acc[k] = 0.f;
+#pragma unroll
+  for (int u = 0; u < MAXR; ++u) {
+    const int sp = wave + 4 * u;
+    if (sp >= S) break;
+    float f[8];
+    uic_unpack<bf16_t>(cr[u], f);
+    const float a = s_a[sp];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) acc[k] += a * f[k];
+  }
+#pragma unroll
+  for (int k = 0; k < 8; ++k) s_red[wave * H + lane * 8 + k] = acc[k];
+  __syncthreads();
+  for (int j = tid; j < H; j += NT) cvec[(size_t)b * H + j] = (bf16_t)(s_red[j] + s_red[H + j] + s_red[2 * H + j] + s_red[3 * H + j]);
+}
+
+template <int MAXR>
+__global__ __launch_bounds__(NT) void gattn_bwd_step_fast_kernel(const bf16_t* __restrict__ ctx, const float* __restrict__ attn,
+                                                                 const float* __restrict__ dcq, int lddcq, int S, int B,
+                                                                 float* __restrict__ dscore, const float* __restrict__ ctxw,
+                                                                 float* __restrict__ dq, int lddq) {
+  constexpr int H = 512;
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  float* s_dc = sm;           // [H]
+  float* s_a = s_dc + H;      // [S]
+  float* s_da = s_a + S;      // [S]
+  float* s_red = s_da + S;    // [4][H]
+  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  uint4 cr[MAXR];
+  float4 wr[MAXR][2];
+#pragma unroll
+  for (int u = 0; u < MAXR; ++u) {
+    const int sp = wave + 4 * u;
+    const size_t r = ((size_t)(sp < S ? sp : S - 1) * B + b) * H;
+    cr[u] = *(const uint4*)(ctx + r + lane * 8);
+    wr[u][0] = *(const float4*)(ctxw + r + lane * 4);
+    wr[u][1] = *(const float4*)(ctxw + r + (lane + 64) * 4);
+  }
+  const float dq0 = dq[(size_t)b * lddq + tid], dq1 = dq[(size_t)b * lddq + tid + NT];      // (H = 2 NT)
+  for (int j = tid; j < H; j += NT) s_dc[j] = dcq[(size_t)b * lddcq + j];
+  for (int sp = tid; sp < S; sp += NT) s_a[sp] = attn[(size_t)b * S + sp];
+  __syncthreads();
+#pragma unroll
+  for (int u = 0; u < MAXR; ++u) {
+    const int sp = wave + 4 * u;
+    if (sp >= S) break;
+    float f[8];
+    uic_unpack<bf16_t>(cr[u], f);
+    float p = 0.f;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) p += f[k] * s_dc[lane * 8 + k];
+    p = uic_wave_sum(p);
+    if (lane == 0) s_da[sp] = p;
+  }
+  __syncthreads();
+  float wbar = 0.f;
+  for (int sp = 0; sp < S; ++sp) wbar += s_a[sp] * s_da[sp];
+  __syncthreads();
+  for (int sp = tid; sp < S; sp += NT) {
+    const float ds = s_a[sp] * (s_da[sp] - wbar);
+    s_da[sp] = ds;
+    dscore[(size_t)b * S + sp] = ds;
+  }
+  __syncthreads();
+  // weighted_rows<float>(ctxw, s_da): chunks lane, lane + 64 of four floats
+  float a0[4] = {0.f, 0.f, 0.f, 0.f}, a1[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int u = 0; u < MAXR; ++u) {
+    const int sp = wave + 4 * u;
+    if (sp >= S) break;
+    const float a = s_da[sp];
+    a0[0] += a * wr[u][0].x; a0[1] += a * wr[u][0].y; a0[2] += a * wr[u][0].z; a0[3] += a * wr[u][0].w;
+    a1[0] += a * wr[u][1].x; a1[1] += a * wr[u][1].y; a1[2] += a * wr[u][1].z; a1[3] += a * wr[u][1].w;
+  }
+#pragma unroll
+  for (int k = 0; k < 4; ++k) { s_red[wave * H + lane * 4 + k] = a0[k]; s_red[wave * H + (lane + 64) * 4 + k] = a1[k]; }
+  __syncthreads();
+  dq[(size_t)b * lddq + tid] = dq0 + (s_red[tid] + s_red[H + tid] + s_red[2 * H + tid] + s_red[3 * H + tid]);
+  dq[(size_t)b * lddq + tid + NT] = dq1 + (s_red[tid + NT] + s_red[H + tid + NT] + s_red[2 * H + tid + NT] + s_red[3 * H + tid + NT]);
+}
+
 // deferred over decode steps: d ctx[s,b,:] = sum_t a_t[b,s] d_c_t[b,:]  and  d ctxw[s,b,:] = sum_t d_score_t[b,s] q_t[b,:]
 template <typename T>
 __global__ void gattn_bwd_accum_kernel(const float* attn_all, const float* dscore_all, const float* dcq_all, int lddcq,
@@ -339,6 +483,21 @@ __global__ void nmt_beam_readout_kernel(int B, int K, int S, int n_iter, int ld_
   }
 }
 
+// the attention launches: register-resident fast kernels for bf16, H = 512, S <= 64 (NT = 256 threads = 4 waves), else generic
+#define NMT_GATTN_FWD(GRID, LDS, CTX, TARGET, S_, B_, H_, ATTN, CVEC, MASK, CTXW, Q)                                              \
+  do {                                                                                                                           \
+    if (dt == UIC_BF16 && (H_) == 512 && (S_) <= 32)                                                                             \
+      hipLaunchKernelGGL(gattn_fwd_fast_kernel<8>, dim3(GRID), dim3(NT), LDS, s, (const bf16_t*)(CTX), TARGET, S_, B_, ATTN,     \
+                         (bf16_t*)(CVEC), MASK, CTXW, (const bf16_t*)(Q));                                                       \
+    else if (dt == UIC_BF16 && (H_) == 512 && (S_) <= 64)                                                                        \
+      hipLaunchKernelGGL(gattn_fwd_fast_kernel<16>, dim3(GRID), dim3(NT), LDS, s, (const bf16_t*)(CTX), TARGET, S_, B_, ATTN,    \
+                         (bf16_t*)(CVEC), MASK, CTXW, (const bf16_t*)(Q));                                                       \
+    else if (dt == UIC_BF16)                                                                                                     \
+      hipLaunchKernelGGL(gattn_fwd_kernel<bf16_t>, dim3(GRID), dim3(NT), LDS, s, CTX, TARGET, S_, B_, H_, ATTN, CVEC, MASK, CTXW, Q); \
+    else                                                                                                                         \
+      hipLaunchKernelGGL(gattn_fwd_kernel<float>, dim3(GRID), dim3(NT), LDS, s, CTX, TARGET, S_, B_, H_, ATTN, CVEC, MASK, CTXW, Q);  \
+    UIC_LAUNCH_CHECK("gattn_fwd_kernel");                                                                                        \
+  } while (0)
 #define NMT_T(KERNEL, GRID, LDS, ...)                                                            \
   do {                                                                                           \
     if (dt == UIC_BF16) hipLaunchKernelGGL(KERNEL<bf16_t>, dim3(GRID), dim3(NT), LDS, s, __VA_ARGS__); \
@@ -701,9 +860,9 @@ struct Nmt {
       const void* q = off(L.hd[NL - 1], (size_t)(t + 1) * BH, dt);       // rnn_output = top layer's h
       // scores = context . linear_in(rnn_output) (GlobalAttention.py:114-116) = (context W_in) . rnn_output: L.ctxw was
       // made once before the loop, so no linear_in GEMM sits in the per-step chain
-      NMT_T(gattn_fwd_kernel, B, lds_att, (const void*)off(L.xl[NL], BH, dt), (const float*)nullptr, S, B, H,
-            L.attn_all + (size_t)t * B * S, (void*)offw(L.cvec_all, (size_t)t * BH, dt), (const int64_t*)nullptr,
-            (const float*)L.ctxw, q);
+      NMT_GATTN_FWD(B, lds_att, (const void*)off(L.xl[NL], BH, dt), (const float*)nullptr, S, B, H,
+                    L.attn_all + (size_t)t * B * S, (void*)offw(L.cvec_all, (size_t)t * BH, dt), (const int64_t*)nullptr,
+                    (const float*)L.ctxw, q);
       {  // tanh(linear_out([c ; rnn_output])) (:165-167)
         UicGemmParams g = gemm_base(dt, B, H);
         add_seg(g, off(L.cvec_all, (size_t)t * BH, dt), H, L.attn_out_w, 2 * H, H);
@@ -790,6 +949,18 @@ struct Nmt {
         UIC_TRY(uic_gemm_launch(g, s));
       }
       // d q = d_cq[:, H:] (linear_out's share) + sum_s d_score[s] ctxw[s]: added by the attention kernel itself
+      if (dt == UIC_BF16 && H == 512 && S <= 64) {
+        const bf16_t* cx = (const bf16_t*)off(L.xl[NL], BH, dt);
+        const float* at = L.attn_all + (size_t)t * B * S;
+        float* dsc = L.dscore_all + (size_t)t * B * S;
+        if (S <= 32)
+          hipLaunchKernelGGL(gattn_bwd_step_fast_kernel<8>, dim3(B), dim3(NT), lds_att, s, cx, at, (const float*)d_cq, 2 * H, S, B, dsc,
+                             (const float*)L.ctxw, d_cq + H, 2 * H);
+        else
+          hipLaunchKernelGGL(gattn_bwd_step_fast_kernel<16>, dim3(B), dim3(NT), lds_att, s, cx, at, (const float*)d_cq, 2 * H, S, B, dsc,
+                             (const float*)L.ctxw, d_cq + H, 2 * H);
+        UIC_LAUNCH_CHECK("gattn_bwd_step_fast_kernel");
+      } else
       NMT_T(gattn_bwd_step_kernel, B, lds_att, (const void*)off(L.xl[NL], BH, dt), (const float*)(L.attn_all + (size_t)t * B * S),
             (const float*)d_cq, 2 * H, S, B, H, L.dscore_all + (size_t)t * B * S, (const float*)L.ctxw, d_cq + H, 2 * H);
       for (int l = NL - 1; l >= 0; --l) {
@@ -1122,7 +1293,8 @@ int uic_nmt_translate(const uic_nmt_dims* d, const uic_nmt_weights* w, const int
       UIC_TRY(uic_gemm_launch(g, s));
     }
     float* attn_t = T.attn_hist + (size_t)step * R * S;
-    NMT_T(gattn_fwd_kernel, R, lds_att, ctx, (const float*)T.targetq, S, R, H, attn_t, (void*)T.cvec, (const int64_t*)T.src_rep);
+    NMT_GATTN_FWD(R, lds_att, ctx, (const float*)T.targetq, S, R, H, attn_t, (void*)T.cvec, (const int64_t*)T.src_rep,
+                  (const float*)nullptr, (const void*)nullptr);
     {
       UicGemmParams g = gemm_base(dt, R, H);
       add_seg(g, T.cvec, H, L.attn_out_w, 2 * H, H);
