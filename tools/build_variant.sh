@@ -12,6 +12,6 @@ objs=""
 for o in $C/*.o; do
   if [ "$(basename $o)" = "${src%.hip}.o" ]; then objs="$objs variants/${src%.hip}_$name.o"; else objs="$objs $o"; fi
 done
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o variants/libuic_$name.so $objs -lz -lpthread
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o variants/libuic_$name.so $objs -lz -lpthread -ldl
 rm -f variants/${src%.hip}_$name.o
 echo variants/libuic_$name.so
