@@ -358,8 +358,10 @@ int uic_nmt_backward(const uic_nmt_dims* d, const uic_nmt_weights* w, const int6
  * hyp_out [B, max_steps] int64 (first *n_iter_out columns valid: the number of decoder steps taken, identical for all
  * sentences -- a sentence's beam keeps advancing until every sentence is done, :372-378), score_out [B] (best final beam
  * score), attn_out [B, max_steps, S] or NULL (attention of the winning hypothesis, PAD source columns dropped and the rest
- * packed to the left), n_iter_out (HOST int).  Unlike the other entry points this one synchronises with the host once per
- * decoder step (the reference's `if not active: break`).  The reference hard-codes beam_size 15 and max_steps 100. */
+ * packed to the left), n_iter_out (HOST int).  The reference's `if not active: break` is decided on the device (the search
+ * freezes itself once no sentence is active and counts the steps that ran); unlike the other entry points this one
+ * synchronises with the host -- every fourth decoder step, to stop enqueueing, and once at the end for n_iter_out.  The
+ * reference hard-codes beam_size 15 and max_steps 100. */
 size_t uic_nmt_translate_workspace_bytes(const uic_nmt_dims* d, int32_t beam_size, int32_t max_steps);
 int uic_nmt_translate(const uic_nmt_dims* d, const uic_nmt_weights* w, const int64_t* src, int32_t beam_size, int32_t max_steps,
                       void* workspace, int64_t* hyp_out, float* score_out, float* attn_out, int32_t* n_iter_out, void* stream);
