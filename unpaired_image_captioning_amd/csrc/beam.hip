@@ -143,31 +143,49 @@ __global__ __launch_bounds__(NT) void beam_topk_kernel(const UicBeamParams p) {
   // HBM / the Infinity Cache): every thread keeps a running maximum with the sum of exponentials rescaled to it, and the best
   // of ITS elements -- element groups g = tid, tid + NT, ... of four consecutive words, one 16-byte load each.
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  float bv = -INFINITY;
-  int bi = 0x7fffffff;
+  float bv = -INFINITY, bv2 = -INFINITY;
+  int bi = 0x7fffffff, bi2 = 0x7fffffff;
   float mx = -INFINITY, sum = 0.f;
+  // exp(d), d <= 0, as one v_exp_f32 (2^(d log2 e)): expf's range handling is most of this pass's arithmetic
+  auto fexp = [](float d) { return __builtin_amdgcn_exp2f(d * 1.44269504088896340736f); };
   const bool vec_ok = p.ldv % 4 == 0 && ((size_t)p.logits & 15) == 0;
-  for (int v0 = tid * 4; v0 < V1; v0 += NT * 4) {
-    float q[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
-    if (vec_ok && v0 + 3 < V1) {
-      const float4 f = *(const float4*)(x + v0);
-      q[0] = f.x; q[1] = f.y; q[2] = f.z; q[3] = f.w;
-    } else {
-      for (int c = 0; v0 + c < V1; ++c) q[c] = x[v0 + c];
-    }
-    const float m4 = fmaxf(fmaxf(q[0], q[1]), fmaxf(q[2], q[3]));
-    if (m4 > mx) { sum *= expf(mx - m4); mx = m4; }          // (exp(-inf) = 0 on the first group)
+  // four groups per trip: their loads are in flight together (one 16-byte load per trip left the kernel waiting on latency)
+  for (int vb = tid * 4; vb < V1; vb += NT * 4 * 4) {
+    float qq[4][4];
 #pragma unroll
-    for (int c = 0; c < 4; ++c) {
-      sum += expf(q[c] - mx);                                // slots past the row hold -inf: + 0
-      const float rv = raw(v0 + c, q[c]);
-      if (v0 + c < V1 && better(rv, v0 + c, bv, bi)) { bv = rv; bi = v0 + c; }
+    for (int g = 0; g < 4; ++g) {
+      const int v0 = vb + g * NT * 4;
+      qq[g][0] = qq[g][1] = qq[g][2] = qq[g][3] = -INFINITY;
+      if (vec_ok && v0 + 3 < V1) {
+        const float4 f = *(const float4*)(x + v0);
+        qq[g][0] = f.x; qq[g][1] = f.y; qq[g][2] = f.z; qq[g][3] = f.w;
+      } else {
+        for (int c = 0; c < 4 && v0 + c < V1; ++c) qq[g][c] = x[v0 + c];
+      }
+    }
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const int v0 = vb + g * NT * 4;
+      const float* q = qq[g];
+      const float m4 = fmaxf(fmaxf(q[0], q[1]), fmaxf(q[2], q[3]));
+      if (m4 > mx) { sum *= fexp(mx - m4); mx = m4; }        // (exp(-inf) = 0 on the first group)
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        sum += m4 == -INFINITY ? 0.f : fexp(q[c] - mx);      // slots past the row hold -inf: + 0
+        const float rv = raw(v0 + c, q[c]);
+        if (v0 + c < V1) {                                    // the thread's best and second best (raw values)
+          if (better(rv, v0 + c, bv, bi)) { bv2 = bv; bi2 = bi; bv = rv; bi = v0 + c; }
+          else if (better(rv, v0 + c, bv2, bi2)) { bv2 = rv; bi2 = v0 + c; }
+        }
+      }
     }
   }
   const float gmx = bmax(mx, s_buf);
   sum = bsum(sum * expf(mx - gmx), s_buf);
   const float lse = gmx + logf(sum);
   bv -= lse;
+  bv2 -= lse;
+  bool has2 = true;                                   // bv2 / bi2 is this thread's next element in the order (until it is used)
   auto value = [&](int v) { return raw(v, x[v]) - lse; };
   float* s_wv = s_val;            // [NT / 64] per-wave winners
   int* s_wi = s_idx;
@@ -194,7 +212,11 @@ __global__ __launch_bounds__(NT) void beam_topk_kernel(const UicBeamParams p) {
     }
     if (gi == 0x7fffffff) continue;                   // nothing left (only possible when B exceeds the row length)
     const int owner = (gi >> 2) % NT;                 // the thread whose element groups hold word gi
-    if (wave == (owner >> 6)) {
+    // its second best, kept from the pass, is its next element in the order: only a thread that wins a third time goes back to
+    // its 195 words in memory (the rescan, a trip to L2 per selection round, was half of this kernel)
+    if (wave == (owner >> 6) && __shfl(has2 ? 1 : 0, owner & 63, 64)) {
+      if (tid == owner) { bv = bv2; bi = bi2; has2 = false; }
+    } else if (wave == (owner >> 6)) {
       float nv = -INFINITY;
       int ni = 0x7fffffff;
       for (int g = owner + (lane >> 2) * NT; g * 4 < V1; g += 16 * NT) {   // 4 lanes per group, 16 groups per round
