@@ -1161,6 +1161,31 @@ __global__ __launch_bounds__(NT) void sample_step_kernel(const UicSampleParams p
       if (unf) atomicAdd(&p.n_unfinished[t * UIC_NUNF_STRIPES + (n % UIC_NUNF_STRIPES)], 1);
     }
   }
+  if (p.xt_out) {   // the next step's input embedding of this row (embed_fwd_kernel's arithmetic)
+    __syncthreads();                                   // (s_idx[0] was read by everybody above)
+    if (threadIdx.x == 0) s_idx[0] = (int)p.it[n];
+    __syncthreads();
+    long tok = s_idx[0];
+    if (tok < 0 || tok >= p.embed_V1) tok = 0;
+    const int E = p.embed_E;
+    const float inv_keep = p.embed_drop_p > 0.f ? 1.f / (1.f - p.embed_drop_p) : 1.f;
+    for (int c = threadIdx.x * 4; c < E; c += NT * 4) {
+      const float4 v = *(const float4*)(p.embed_table + (size_t)tok * E + c);
+      float f[4] = {fmaxf(v.x, 0.f), fmaxf(v.y, 0.f), fmaxf(v.z, 0.f), fmaxf(v.w, 0.f)};
+      if (p.embed_drop_p > 0.f) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          f[j] *= uic_drop_scale(p.seed, p.embed_site, (unsigned)(p.embed_idx_base + (size_t)n * E + c + j), p.embed_drop_p, inv_keep);
+      }
+      if (p.dtype == UIC_BF16) {
+        bf16_t* o = (bf16_t*)p.xt_out + (size_t)n * E + c;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) o[j] = (bf16_t)f[j];
+      } else {
+        *(float4*)((float*)p.xt_out + (size_t)n * E + c) = make_float4(f[0], f[1], f[2], f[3]);
+      }
+    }
+  }
 }
 
 __global__ void dropout_mask_kernel(float* out, size_t n, float pdrop, unsigned seed, unsigned site, size_t base) {

@@ -1113,11 +1113,12 @@ struct Step {
 // One decode step of AttModel.get_logprobs_state (:158-165) on the sampling buffers: embedding of L.s_it, both LSTM cells,
 // attention, logits into L.s_logits; recurrent state read from slot `cur`, written to slot `nxt`.
 int decode_step(const uic_topdown_dims& d, const uic_topdown_weights* w, const Derived& dv, const uic_topdown_batch* b, const Layout& L,
-                int cur, int nxt, int t, float drop_p, unsigned seed, hipStream_t s, bool train_mode = false) {
+                int cur, int nxt, int t, float drop_p, unsigned seed, hipStream_t s, bool train_mode = false, bool xt_ready = false) {
   const int dt = d.dtype;
   const int N = d.N, H = d.H, E = d.E, V1 = d.V1;
   const int V1p = (int)vpad(V1), H4 = 4 * H, ldih = E + 2 * H;
-  UIC_TRY(uic_embed_fwd_launch(dt, w->embed_w, V1, E, L.s_it, 1, N, 1, drop_p, seed, UIC_SITE_EMBED, (size_t)t * N * E, 1, L.s_xt, s));
+  // (xt_ready: the sampling kernel of the previous step already wrote this step's embedding rows into L.s_xt)
+  if (!xt_ready) UIC_TRY(uic_embed_fwd_launch(dt, w->embed_w, V1, E, L.s_it, 1, N, 1, drop_p, seed, UIC_SITE_EMBED, (size_t)t * N * E, 1, L.s_xt, s));
   {
     UicGemmParams g = gemm_base(dt, N, H4);
     g.lstm = 1; g.H = H;
@@ -1393,7 +1394,7 @@ int uic_topdown_sample(const uic_topdown_dims* d, const uic_topdown_weights* w, 
   UIC_TRY(uic_fill_launch(L.s_nunf, 0, (size_t)(d->T + 2) * UIC_NUNF_STRIPES * 4, s));
   for (int t = 0; t < Lsteps; ++t) {
     const int cur = t & 1, nxt = cur ^ 1;
-    UIC_TRY(decode_step(*d, w, dv, b, L, cur, nxt, t, drop_p, seed, s, (training & 1) != 0));
+    UIC_TRY(decode_step(*d, w, dv, b, L, cur, nxt, t, drop_p, seed, s, (training & 1) != 0, t > 0));
     UicSampleParams p;
     memset(&p, 0, sizeof(p));
     p.dtype = dt; p.N = N; p.V1 = V1; p.ldv = V1p; p.t = t; p.L = Lsteps;
@@ -1401,6 +1402,10 @@ int uic_topdown_sample(const uic_topdown_dims* d, const uic_topdown_weights* w, 
     p.decoding_constraint = decoding_constraint;
     p.seq = seq; p.seq_logp = seq_logp; p.it = L.s_it; p.unfinished = L.s_unf; p.n_unfinished = L.s_nunf;
     p.forced = forced;
+    if (t + 1 < Lsteps) {      // the next step's embedding rows ride in the sampling kernel (one launch less per step)
+      p.embed_table = w->embed_w; p.embed_V1 = V1; p.embed_E = d->E; p.embed_drop_p = drop_p; p.embed_site = UIC_SITE_EMBED;
+      p.embed_idx_base = (size_t)(t + 1) * N * d->E; p.xt_out = L.s_xt;
+    }
     UIC_TRY(uic_sample_step_launch(p, s));
   }
   return UIC_OK;
@@ -1434,8 +1439,9 @@ int uic_topdown_sample_train(const uic_topdown_dims* d, const uic_topdown_weight
   UIC_TRY(uic_fill_launch(L.s_unf, 0, (size_t)N * 4, s));
   UIC_TRY(uic_fill_launch(L.s_nunf, 0, (size_t)(d->T + 2) * UIC_NUNF_STRIPES * 4, s));
   for (int t = 0; t < Lsteps; ++t) {
-    UIC_TRY(uic_embed_fwd_launch(st.dt, w->embed_w, st.V1, st.E, L.s_it, 1, N, 1, st.drop_p, seed, UIC_SITE_EMBED,
-                                 (size_t)t * N * st.E, 1, offw(L.xt_all, (size_t)t * N * st.E, st.dt), s));
+    if (t == 0)   // (later steps: written by the previous step's sampling kernel)
+      UIC_TRY(uic_embed_fwd_launch(st.dt, w->embed_w, st.V1, st.E, L.s_it, 1, N, 1, st.drop_p, seed, UIC_SITE_EMBED,
+                                   (size_t)t * N * st.E, 1, offw(L.xt_all, (size_t)t * N * st.E, st.dt), s));
     UIC_TRY(st.fwd_step(t, s, true));
     UIC_TRY(st.logits_rows_now(t, t + 1, s));
     UicSampleParams p;
@@ -1445,6 +1451,10 @@ int uic_topdown_sample_train(const uic_topdown_dims* d, const uic_topdown_weight
     p.decoding_constraint = decoding_constraint;
     p.seq = seq; p.seq_logp = seq_logp; p.it = L.s_it; p.unfinished = L.s_unf; p.n_unfinished = L.s_nunf;
     p.forced = forced;
+    if (t + 1 < Lsteps) {
+      p.embed_table = w->embed_w; p.embed_V1 = st.V1; p.embed_E = st.E; p.embed_drop_p = st.drop_p; p.embed_site = UIC_SITE_EMBED;
+      p.embed_idx_base = (size_t)(t + 1) * N * st.E; p.xt_out = offw(L.xt_all, (size_t)(t + 1) * N * st.E, st.dt);
+    }
     UIC_TRY(uic_sample_step_launch(p, s));
   }
   return UIC_OK;

@@ -414,6 +414,10 @@ struct UicSampleParams {
   float* logprobs_out;           // optional [N, V1]
   int fc_mode;                   // FCModel_NMT._sample semantics (raw token fed forward, break before write)
   int ld_out;                    // row stride of seq / seq_logp (0 = L)
+  // optional: the NEXT step's embedding row of every caption row, written by the workgroup that just chose its token
+  // (xt_out[n, :] = dropout(relu(embed_table[it[n]])), element index embed_idx_base + n * E + e at site embed_site, seed `seed`):
+  // one launch less per decode step
+  const float* embed_table; int embed_V1, embed_E; float embed_drop_p; unsigned embed_site; size_t embed_idx_base; void* xt_out;
 };
 int uic_sample_step_launch(const UicSampleParams& p, hipStream_t s);
 // ---- beam search bookkeeping (beam.hip): rows = (image, beam)
