@@ -571,13 +571,12 @@ __global__ __launch_bounds__(256, 2) void uic_gemm_glds_kernel(const UicGemmPara
 
   const float inv_keep = p.drop_p > 0.f ? 1.f / (1.f - p.drop_p) : 1.f;
   const bool out_f32 = (p.flags & UIC_GEMM_OUT_F32) || sizeof(T) == 4;
-  // Fast epilogue for the common outputs (bias, optionally ReLU and dropout; no addend / region mask / tanh / accumulate):
-  // every uniform condition is decided ONCE, offsets are 32-bit, and whole tiles skip the bounds tests.  Measured: the general
+  // Fast epilogue (everything but tanh): ReLU / dropout / output type / whole-tile are decided ONCE (16 specialised bodies), the
+  // rarer options (addend, region mask) cost a uniform test per row, offsets are 32-bit, whole tiles skip the bounds tests.  Measured: the general
   // epilogue below, which tests its eight options per element, was ~14 us per wave of tiles -- 43 of the 62 us of a logit chunk.
-  if (!p.addend && !p.row_len && !(p.flags & (UIC_GEMM_TANH | UIC_GEMM_ACCUM)) && (size_t)p.M * (size_t)p.ldc < ((size_t)1 << 31) &&
-      (size_t)(p.M + p.drop_row0) * (size_t)p.N < ((size_t)1 << 32)) {
+  if (!(p.flags & UIC_GEMM_TANH) && (size_t)p.M * (size_t)p.ldc < ((size_t)1 << 31)) {
     const bool full = m0 + BM <= p.M && n0 + BN <= p.N;
-    const bool relu = (p.flags & UIC_GEMM_RELU) != 0, drop = p.drop_p > 0.f;
+    const bool relu = (p.flags & UIC_GEMM_RELU) != 0, drop = p.drop_p > 0.f, accum = (p.flags & UIC_GEMM_ACCUM) != 0;
     float bj[2];
     unsigned cj[2];
     bool cok[2];
@@ -597,14 +596,27 @@ __global__ __launch_bounds__(256, 2) void uic_gemm_glds_kernel(const UicGemmPara
           if (!FULL && row >= p.M) continue;
           const unsigned ro = (unsigned)row * (unsigned)p.ldc;
           const unsigned dro = (unsigned)(row + p.drop_row0) * (unsigned)p.N;
+          // per-row work of the rarer options (uniform tests): the addend's row, the region mask of pack_wrapper
+          const float* ad = p.addend ? p.addend + (size_t)(row % p.add_mod) * p.ld_add : nullptr;
+          bool live = true;
+          if (p.row_len) { const int n = row / p.R; live = row - n * p.R < p.row_len[n]; }
 #pragma unroll
           for (int j = 0; j < 2; ++j) {
             if (!FULL && !cok[j]) continue;
             float v = acc[i][j][reg] + bj[j];
+            if (ad) v += ad[cj[j]];
             if (RELU) v = fmaxf(v, 0.f);
+            if (!live) v = 0.f;
             if (DROP) v *= uic_drop_scale(p.seed, p.site, dro + cj[j], p.drop_p, inv_keep);
-            if (F32) ((float*)p.C)[ro + cj[j]] = v;
-            else ((T*)p.C)[ro + cj[j]] = uic_from_f<T>(v);
+            if (F32) {
+              float* o = (float*)p.C + (ro + cj[j]);
+              if (accum) v += *o;
+              *o = v;
+            } else {
+              T* o = (T*)p.C + (ro + cj[j]);
+              if (accum) v += uic_to_f(*o);
+              *o = uic_from_f<T>(v);
+            }
           }
         }
     };
