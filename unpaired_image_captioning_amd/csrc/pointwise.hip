@@ -450,7 +450,7 @@ __global__ void lstm_bwd_kernel(const UicLstmBwdParams p) {
     const float gi = uic_to_f(G[0]), gf = uic_to_f(G[H]), gg = uic_to_f(G[2 * H]), go = uic_to_f(G[3 * H]);
     const float c = p.c[idx];
     const float cp = p.c_prev ? p.c_prev[idx] : 0.f;
-    const float tc = tanhf(c);
+    const float tc = uic_tanh<T>(c);                 // (the forward's own tanh: hardware exp on the bf16 path, libm on f32)
     const float dc = p.dc[idx] + dh * go * (1.f - tc * tc);
     const float d_o = dh * tc;
     T* D = (T*)p.dgates + (size_t)m * 4 * H + u;
@@ -509,7 +509,7 @@ __global__ __launch_bounds__(NT) void lstm_bwd_vec4_kernel(const UicLstmBwdParam
     if (p.dh1) dh += dh1[k];
     if (p.dh2) dh += dh2[k];
     const float gi = g[0][k], gf = g[1][k], gg = g[2][k], go = g[3][k];
-    const float tc = tanhf(cc[k]);
+    const float tc = uic_tanh<T>(cc[k]);
     const float dc = dcv[k] + dh * go * (1.f - tc * tc);
     const float d_o = dh * tc;
     o[0][k] = dc * gg * gi * (1.f - gi);
