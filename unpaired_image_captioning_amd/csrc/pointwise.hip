@@ -468,10 +468,9 @@ __global__ void lstm_bwd_kernel(const UicLstmBwdParams p) {
 template <typename T>
 __global__ __launch_bounds__(NT) void lstm_bwd_vec4_kernel(const UicLstmBwdParams p) {
   const int H = p.H, H4 = H >> 2;
-  const size_t total = (size_t)p.M * H4;
-  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= total) return;
-  const int m = (int)(i / H4), u = (int)(i - (size_t)m * H4) * 4;
+  const int m = blockIdx.y, u4 = blockIdx.x * blockDim.x + threadIdx.x;      // (row from the grid: no division per lane)
+  if (u4 >= H4) return;
+  const int u = u4 * 4;
   const size_t idx = (size_t)m * H + u;
   const float inv_keep = p.drop_p > 0.f ? 1.f / (1.f - p.drop_p) : 1.f;
   // every load first
@@ -1509,12 +1508,13 @@ int uic_lstm_bwd_launch(const UicLstmBwdParams& p, hipStream_t s) {
   const bool vec = vec_on && (size_t)p.M * p.H >= 65536 && p.H % 4 == 0 && al16(p.dc) && al16(p.c) && (!p.c_prev || al16(p.c_prev)) &&
                    ((uintptr_t)p.gates & 7) == 0 && ((uintptr_t)p.dgates & 7) == 0 && (p.dtype == UIC_BF16 || (al16(p.gates) && al16(p.dgates))) &&
                    (!p.dh0 || (al16(p.dh0) && p.lddh0 % 4 == 0)) && (!p.dh1 || (al16(p.dh1) && p.lddh1 % 4 == 0)) &&
-                   (!p.dh2 || (al16(p.dh2) && p.lddh2 % 4 == 0)) && (size_t)p.M * p.H < ((size_t)1 << 32);
+                   (!p.dh2 || (al16(p.dh2) && p.lddh2 % 4 == 0)) && (size_t)p.M * p.H < ((size_t)1 << 32) && p.M <= 65535;
   if (vec) {
-    const size_t n4 = (size_t)p.M * (p.H / 4);
-    const unsigned g4 = (unsigned)((n4 + NT - 1) / NT);
-    DISPATCH_T(p.dtype, hipLaunchKernelGGL(lstm_bwd_vec4_kernel<bf16_t>, dim3(g4), dim3(NT), 0, s, p),
-               hipLaunchKernelGGL(lstm_bwd_vec4_kernel<float>, dim3(g4), dim3(NT), 0, s, p));
+    const int h4 = p.H / 4;
+    const int bt = h4 >= NT ? NT : ((h4 + 63) / 64) * 64;
+    const dim3 g4((unsigned)((h4 + bt - 1) / bt), (unsigned)p.M);
+    DISPATCH_T(p.dtype, hipLaunchKernelGGL(lstm_bwd_vec4_kernel<bf16_t>, g4, dim3(bt), 0, s, p),
+               hipLaunchKernelGGL(lstm_bwd_vec4_kernel<float>, g4, dim3(bt), 0, s, p));
     UIC_LAUNCH_CHECK("lstm_bwd_vec4");
     return UIC_OK;
   }
