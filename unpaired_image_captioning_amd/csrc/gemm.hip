@@ -762,11 +762,36 @@ __global__ void splitk_reduce_kernel(const float* __restrict__ slab, int splitk,
     C[(size_t)row * ldc + c] = v;
   }
 }
+// four columns per lane, the row from the grid (see splitk_reduce_multi_vec_kernel in gemm_tn.hip)
+__global__ void splitk_reduce_vec_kernel(const float* __restrict__ slab, int splitk, int M, int N, int col0, int ncols,
+                                         float* __restrict__ C, int ldc, int accumulate) {
+  const int c = (blockIdx.x * blockDim.x + threadIdx.x) * 4;
+  if (c >= ncols) return;
+  const size_t MN = (size_t)M * N;
+  for (int row = blockIdx.y; row < M; row += gridDim.y) {
+    const float* src = slab + (size_t)row * N + col0 + c;
+    float4 v = *(const float4*)src;
+    for (int z = 1; z < splitk; ++z) {
+      const float4 w = *(const float4*)(src + (size_t)z * MN);
+      v.x += w.x; v.y += w.y; v.z += w.z; v.w += w.w;
+    }
+    float4* o = (float4*)(C + (size_t)row * ldc + c);
+    if (accumulate) { const float4 w = *o; v.x = w.x + v.x; v.y = w.y + v.y; v.z = w.z + v.z; v.w = w.w + v.w; }
+    *o = v;
+  }
+}
 }  // namespace
 
 int uic_splitk_reduce_launch(const float* slab, int splitk, int M, int N, int col0, int ncols, float* C, int ldc, hipStream_t s,
                              int accumulate) {
   if (M == 0 || ncols == 0) return UIC_OK;
+  if (N % 4 == 0 && ncols % 4 == 0 && col0 % 4 == 0 && ldc % 4 == 0 && ((uintptr_t)slab & 15) == 0 && ((uintptr_t)C & 15) == 0 && ((size_t)M * N) % 4 == 0) {
+    const int bt = ncols / 4 >= 256 ? 256 : ((ncols / 4 + 63) / 64) * 64;
+    hipLaunchKernelGGL(splitk_reduce_vec_kernel, dim3((unsigned)((ncols / 4 + bt - 1) / bt), (unsigned)(M > 65535 ? 65535 : M)), dim3(bt), 0, s,
+                       slab, splitk, M, N, col0, ncols, C, ldc, accumulate);
+    UIC_LAUNCH_CHECK("splitk_reduce_vec");
+    return UIC_OK;
+  }
   size_t g = ((size_t)M * ncols + 255) / 256;
   if (g > 4096) g = 4096;
   hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)g), dim3(256), 0, s, slab, splitk, M, N, col0, ncols, C, ldc, accumulate);

@@ -255,6 +255,43 @@ __global__ void splitk_reduce_multi_kernel(const float* __restrict__ slab, int s
   }
 }
 
+// the same, four columns per lane and the row from the grid (no division, 16-byte accesses): every extent and leading dimension
+// a multiple of 4 and 16-byte aligned pointers
+__global__ void splitk_reduce_multi_vec_kernel(const float* __restrict__ slab, int splitk, int M, int N, UicSlabDest d0, UicSlabDest d1,
+                                               UicSlabDest d2, UicSlabDest d3, int accumulate) {
+  const int k = blockIdx.y;
+  float* const C = k == 0 ? d0.C : k == 1 ? d1.C : k == 2 ? d2.C : d3.C;
+  const int ldc = k == 0 ? d0.ldc : k == 1 ? d1.ldc : k == 2 ? d2.ldc : d3.ldc;
+  const int col0 = k == 0 ? d0.col0 : k == 1 ? d1.col0 : k == 2 ? d2.col0 : d3.col0;
+  const int ncols = k == 0 ? d0.ncols : k == 1 ? d1.ncols : k == 2 ? d2.ncols : d3.ncols;
+  const size_t MN = (size_t)M * N;
+  if (ncols % 4 || col0 % 4 || ldc % 4 || ((size_t)C & 15)) {      // a destination that cannot take 16-byte accesses (a bias column): one column per lane
+    const int c1 = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c1 >= ncols) return;
+    for (int row = blockIdx.z; row < M; row += gridDim.z) {
+      const float* src = slab + (size_t)row * N + col0 + c1;
+      float v = 0.f;
+      for (int z = 0; z < splitk; ++z) v += src[(size_t)z * MN];
+      float* o = C + (size_t)row * ldc + c1;
+      *o = accumulate ? *o + v : v;
+    }
+    return;
+  }
+  const int c = (blockIdx.x * blockDim.x + threadIdx.x) * 4;
+  if (c >= ncols) return;
+  for (int row = blockIdx.z; row < M; row += gridDim.z) {
+    const float* src = slab + (size_t)row * N + col0 + c;
+    float4 v = *(const float4*)src;
+    for (int z = 1; z < splitk; ++z) {
+      const float4 w = *(const float4*)(src + (size_t)z * MN);
+      v.x += w.x; v.y += w.y; v.z += w.z; v.w += w.w;
+    }
+    float4* o = (float4*)(C + (size_t)row * ldc + c);
+    if (accumulate) { const float4 w = *o; v.x = w.x + v.x; v.y = w.y + v.y; v.z = w.z + v.z; v.w = w.w + v.w; }
+    *o = v;
+  }
+}
+
 }  // namespace
 
 int uic_splitk_reduce_multi_launch(const float* slab, int splitk, int M, int N, const UicSlabDest* dst, int nd, int accumulate, hipStream_t s) {
@@ -262,6 +299,21 @@ int uic_splitk_reduce_multi_launch(const float* slab, int splitk, int M, int N, 
   UicSlabDest d[4] = {dst[0], dst[nd > 1 ? 1 : 0], dst[nd > 2 ? 2 : 0], dst[nd > 3 ? 3 : 0]};
   size_t cols = 0;
   for (int i = 0; i < nd; ++i) cols += dst[i].ncols;
+  const bool vec = N % 4 == 0 && ((uintptr_t)slab & 15) == 0 && ((size_t)M * N) % 4 == 0;
+  int maxt = 0;      // lanes a destination needs along its columns: ncols / 4, or ncols where it takes the one-column path
+  for (int i = 0; i < nd; ++i) {
+    const bool v4 = dst[i].ncols % 4 == 0 && dst[i].col0 % 4 == 0 && dst[i].ldc % 4 == 0 && ((uintptr_t)dst[i].C & 15) == 0;
+    const int t = v4 ? dst[i].ncols / 4 : dst[i].ncols;
+    maxt = t > maxt ? t : maxt;
+  }
+  if (vec && M > 0 && maxt > 0) {
+    const int bt = maxt >= 256 ? 256 : ((maxt + 63) / 64) * 64;
+    const unsigned gz = (unsigned)(M > 65535 ? 65535 : M);
+    hipLaunchKernelGGL(splitk_reduce_multi_vec_kernel, dim3((unsigned)((maxt + bt - 1) / bt), (unsigned)nd, gz), dim3(bt), 0, s, slab, splitk, M, N,
+                       d[0], d[1], d[2], d[3], accumulate);
+    UIC_LAUNCH_CHECK("splitk_reduce_multi_vec");
+    return UIC_OK;
+  }
   size_t g = ((size_t)M * cols / nd + 255) / 256;
   if (g > 2048) g = 2048;
   if (g < 1) g = 1;
