@@ -65,18 +65,23 @@ __global__ __launch_bounds__(NT) void transpose_kernel(const T* __restrict__ src
 
 // several transposes in one launch (blockIdx.z picks the job; every field by a uniform select -- indexing the by-value
 // table would put it in private memory): the weight refresh's transposes are launch-bound, not byte-bound
-struct TransposeMulti { UicTransposeJob j[UIC_TRANSPOSE_MULTI]; };
+struct TransposeMulti { UicTransposeJob j[UIC_TRANSPOSE_MULTI]; int start[UIC_TRANSPOSE_MULTI + 1]; };   // start[k]: first 64 x 64 tile of job k
+#define UIC_TSEL2(f) (k == 0 ? c.f[0] : k == 1 ? c.f[1] : k == 2 ? c.f[2] : k == 3 ? c.f[3] : k == 4 ? c.f[4] : k == 5 ? c.f[5] : \
+                      k == 6 ? c.f[6] : k == 7 ? c.f[7] : k == 8 ? c.f[8] : k == 9 ? c.f[9] : k == 10 ? c.f[10] : c.f[11])
 #define UIC_TSEL(f) (k == 0 ? c.j[0].f : k == 1 ? c.j[1].f : k == 2 ? c.j[2].f : k == 3 ? c.j[3].f : k == 4 ? c.j[4].f : k == 5 ? c.j[5].f : \
                      k == 6 ? c.j[6].f : k == 7 ? c.j[7].f : k == 8 ? c.j[8].f : k == 9 ? c.j[9].f : k == 10 ? c.j[10].f : c.j[11].f)
 template <typename T>
 __global__ __launch_bounds__(NT) void transpose_multi_kernel(const TransposeMulti c) {
   __shared__ T tile[64][66];
-  const int k = blockIdx.z;
+  // the job of this tile: the grid is the concatenation of the jobs' tile lists (one block per 64 x 64 tile, none idle)
+  int k = 0;
+#pragma unroll
+  for (int q = 1; q < UIC_TRANSPOSE_MULTI; ++q) k += (int)blockIdx.x >= c.start[q] ? 1 : 0;
   const T* __restrict__ src = (const T*)UIC_TSEL(src);
   T* __restrict__ dst = (T*)UIC_TSEL(dst);
   const int rows = UIC_TSEL(rows), cols = UIC_TSEL(cols), lds = UIC_TSEL(lds), ldd = UIC_TSEL(ldd);
-  const int r0 = blockIdx.x * 64, c0 = blockIdx.y * 64;
-  if (r0 >= ldd || c0 >= cols) return;
+  const int t = blockIdx.x - UIC_TSEL2(start), tx_n = (ldd + 63) / 64;
+  const int r0 = (t % tx_n) * 64, c0 = (t / tx_n) * 64;
   const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
 #pragma unroll
   for (int i = 0; i < 16; ++i) {
@@ -93,6 +98,7 @@ __global__ __launch_bounds__(NT) void transpose_multi_kernel(const TransposeMult
   }
 }
 #undef UIC_TSEL
+#undef UIC_TSEL2
 
 // ------------------------------------------------------------------ column sums (bias gradients)
 // stage 1: a block sums `rows_per_block` rows of a 64-column strip; its 4 waves take rows r, r+4, ...
@@ -1310,16 +1316,17 @@ int uic_transpose_multi_launch(int dtype, int count, const UicTransposeJob* jobs
   UIC_REQUIRE(count >= 0 && count <= UIC_TRANSPOSE_MULTI, "transpose_multi: %d jobs (max %d)", count, UIC_TRANSPOSE_MULTI);
   TransposeMulti c;
   memset(&c, 0, sizeof(c));
-  int m = 0, gx = 0, gy = 0;
+  int m = 0, tiles = 0;
   for (int i = 0; i < count; ++i) {
     if (jobs[i].rows == 0 || jobs[i].cols == 0) continue;
+    c.start[m] = tiles;
     c.j[m++] = jobs[i];
-    gx = gx > (jobs[i].ldd + 63) / 64 ? gx : (jobs[i].ldd + 63) / 64;
-    gy = gy > (jobs[i].cols + 63) / 64 ? gy : (jobs[i].cols + 63) / 64;
+    tiles += ((jobs[i].ldd + 63) / 64) * ((jobs[i].cols + 63) / 64);
   }
   if (m == 0) return UIC_OK;
-  DISPATCH_T(dtype, hipLaunchKernelGGL(transpose_multi_kernel<bf16_t>, dim3(gx, gy, m), dim3(NT), 0, s, c),
-             hipLaunchKernelGGL(transpose_multi_kernel<float>, dim3(gx, gy, m), dim3(NT), 0, s, c));
+  for (int i = m; i <= UIC_TRANSPOSE_MULTI; ++i) c.start[i] = 0x7fffffff;     // (never reached by a block index)
+  DISPATCH_T(dtype, hipLaunchKernelGGL(transpose_multi_kernel<bf16_t>, dim3(tiles), dim3(NT), 0, s, c),
+             hipLaunchKernelGGL(transpose_multi_kernel<float>, dim3(tiles), dim3(NT), 0, s, c));
   UIC_LAUNCH_CHECK("transpose_multi");
   return UIC_OK;
 }
