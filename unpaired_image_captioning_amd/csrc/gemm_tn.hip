@@ -210,12 +210,28 @@ __global__ __launch_bounds__(256) void uic_gemm_tn_kernel(const UicGemmTnParams 
         for (int d = 0; d < p.ndst; ++d)
           if (col >= p.dst[d].col0 && col < p.dst[d].col0 + p.dst[d].ncols) { C = p.dst[d].C; ldc = p.dst[d].ldc; cc = col - p.dst[d].col0; }
         if (!C) continue;
+        // (the accumulate test hoisted, 32-bit offsets where the destination allows, whole row tiles unchecked)
+        const bool rows_ok = m0 + 128 <= p.M, small = (size_t)p.M * (size_t)ldc < ((size_t)1 << 31);
+        if (small && rows_ok && !p.accumulate) {
 #pragma unroll
-        for (int reg = 0; reg < 16; ++reg) {
-          const int row = m0 + (wm * 2 + i) * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * half;
-          if (row >= p.M) continue;
-          float* o = C + (size_t)row * ldc + cc;
-          *o = p.accumulate ? *o + acc[i][j][reg] : acc[i][j][reg];
+          for (int reg = 0; reg < 16; ++reg)
+            C[(unsigned)(m0 + (wm * 2 + i) * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * half) * (unsigned)ldc + (unsigned)cc] = acc[i][j][reg];
+        } else if (small && rows_ok) {
+          float old[16];
+#pragma unroll
+          for (int reg = 0; reg < 16; ++reg)
+            old[reg] = C[(unsigned)(m0 + (wm * 2 + i) * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * half) * (unsigned)ldc + (unsigned)cc];
+#pragma unroll
+          for (int reg = 0; reg < 16; ++reg)
+            C[(unsigned)(m0 + (wm * 2 + i) * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * half) * (unsigned)ldc + (unsigned)cc] = old[reg] + acc[i][j][reg];
+        } else {
+#pragma unroll
+          for (int reg = 0; reg < 16; ++reg) {
+            const int row = m0 + (wm * 2 + i) * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * half;
+            if (row >= p.M) continue;
+            float* o = C + (size_t)row * ldc + cc;
+            *o = p.accumulate ? *o + acc[i][j][reg] : acc[i][j][reg];
+          }
         }
       }
     return;
