@@ -237,6 +237,17 @@ __global__ __launch_bounds__(256) void uic_gemm_tn_kernel(const UicGemmTnParams 
     return;
   }
   float* slab = p.slab + (size_t)blockIdx.z * p.M * p.N;
+  if (m0 + 128 <= p.M && n0 + 128 <= p.N && (size_t)p.M * (size_t)p.N < ((size_t)1 << 31)) {   // whole tile: no tests, 32-bit offsets
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int reg = 0; reg < 16; ++reg) {
+        const unsigned ro = (unsigned)(m0 + (wm * 2 + i) * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * half) * (unsigned)p.N + (unsigned)(n0 + wn * 64 + r32);
+        slab[ro] = acc[i][0][reg];
+        slab[ro + 32] = acc[i][1][reg];
+      }
+    return;
+  }
 #pragma unroll
   for (int i = 0; i < 2; ++i)
 #pragma unroll
