@@ -371,8 +371,9 @@ __device__ __forceinline__ float attn_scores(const Ctx& c, const UicRnnFwdParams
     e = (qq.x + qq.y) + (qq.z + qq.w) + b_alpha;
   }
   const float mx = uic_wave_max(e);
-  const float ex = c.lane < R ? expf(e - mx) : 0.f;
-  float wgt = ex * (1.f / uic_wave_sum(ex));
+  // (bf16 path: one v_exp_f32 / v_rcp_f32 instead of libm's exp and an IEEE division -- this kernel is made of instruction issue)
+  const float ex = c.lane < R ? (sizeof(T) == 2 ? __builtin_amdgcn_exp2f((e - mx) * 1.4426950408889634f) : expf(e - mx)) : 0.f;
+  float wgt = ex * (sizeof(T) == 2 ? __builtin_amdgcn_rcpf(uic_wave_sum(ex)) : 1.f / uic_wave_sum(ex));
   if (mk) {
     wgt *= c.lane < R ? mk[c.lane] : 0.f;
     wgt = wgt / uic_wave_sum(wgt);
