@@ -475,8 +475,11 @@ __global__ __launch_bounds__(512) void attn_bwd_accum_kernel(const UicAttnAccumP
       float dwacc[VEC];
 #pragma unroll
       for (int j = 0; j < VEC; ++j) dwacc[j] = 0.f;
+      // (the next row's chunk is requested before this row's arithmetic: one exposed memory latency instead of one per row)
+      uint4 vnext = *(const uint4*)(pa + (size_t)(wave < R ? wave : 0) * A + c * VEC);
       for (int r = wave; r < R; r += nw) {
-        const uint4 v = *(const uint4*)(pa + (size_t)r * A + c * VEC);
+        const uint4 v = vnext;
+        if (r + nw < R) vnext = *(const uint4*)(pa + (size_t)(r + nw) * A + c * VEC);
         float f[VEC], acc[VEC];
         uic_unpack<T>(v, f);
 #pragma unroll
