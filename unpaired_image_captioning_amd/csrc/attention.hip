@@ -415,13 +415,13 @@ __global__ __launch_bounds__(512) void attn_bwd_accum_kernel(const UicAttnAccumP
   if constexpr (PART == 1) {
     float* s_dctx = sm;                 // [TS][H]
     float* s_al = s_dctx + TS * H;      // [TS][Rp]
-    for (int i = tid; i < TS * H; i += nthreads) {
-      const int t = i / H, h = i - t * H;
-      s_dctx[i] = p.dctx_all[(size_t)t * p.dctx_step_stride + (size_t)n * p.lddctx + h];
+    for (int h = tid; h < H; h += nthreads) {
+#pragma unroll 8
+      for (int t = 0; t < TS; ++t) s_dctx[t * H + h] = p.dctx_all[(size_t)t * p.dctx_step_stride + (size_t)n * p.lddctx + h];
     }
-    for (int i = tid; i < TS * R; i += nthreads) {
-      const int t = i / R, r = i - t * R;
-      s_al[t * Rp + r] = p.alpha_all[((size_t)t * N + n) * R + r];
+    for (int r = tid; r < R; r += nthreads) {
+#pragma unroll 8
+      for (int t = 0; t < TS; ++t) s_al[t * Rp + r] = p.alpha_all[((size_t)t * N + n) * R + r];
     }
     __syncthreads();
     // d att'[n,r,:] = sum_t alpha_t[r] dctx_t   (backward of the bmm, AttModel.py:555-556)
@@ -450,19 +450,23 @@ __global__ __launch_bounds__(512) void attn_bwd_accum_kernel(const UicAttnAccumP
     constexpr bool FACTORED = sizeof(T) == 2;
     constexpr float EXP_LIM = 40.f, LOG2E2 = 2.8853900817779268f;
     int bad_h = 0;
-    for (int i = tid; i < TS * A; i += nthreads) {
-      const int t = i / A, a = i - t * A;
-      const float v = p.att_h_all[((size_t)t * N + n) * A + a];
-      if constexpr (FACTORED) {
-        bad_h |= !(fabsf(v) * 2.f <= EXP_LIM);
-        s_atth[i] = __builtin_amdgcn_exp2f(v * LOG2E2);
-      } else {
-        s_atth[i] = v;
+    // staging, step by step (no division per element) and eight steps' loads in flight at a time: the flat loop ran TS * A /
+    // nthreads dependent trips of one load each
+    for (int a = tid; a < A; a += nthreads) {
+#pragma unroll 8
+      for (int t = 0; t < TS; ++t) {
+        const float v = p.att_h_all[((size_t)t * N + n) * A + a];
+        if constexpr (FACTORED) {
+          bad_h |= !(fabsf(v) * 2.f <= EXP_LIM);
+          s_atth[t * A + a] = __builtin_amdgcn_exp2f(v * LOG2E2);
+        } else {
+          s_atth[t * A + a] = v;
+        }
       }
     }
-    for (int i = tid; i < TS * R; i += nthreads) {
-      const int t = i / R, r = i - t * R;
-      s_de[t * Rp + r] = p.de_all[((size_t)t * N + n) * R + r];
+    for (int r = tid; r < R; r += nthreads) {
+#pragma unroll 8
+      for (int t = 0; t < TS; ++t) s_de[t * Rp + r] = p.de_all[((size_t)t * N + n) * R + r];
     }
     for (int a = tid; a < A; a += nthreads) s_w[a] = p.w_alpha[a];
     for (int i = tid; i < nw * A; i += nthreads) s_red[i] = 0.f;
