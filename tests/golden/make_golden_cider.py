@@ -121,7 +121,9 @@ def make_case(name, scorer_mod, ciderd_mod, rewards, seed, V, L, n_img, S, mode,
         sc.cider_scorer.document_frequency = df
         keys = np.full((len(df), 4), -1, dtype=np.int32)
         cnt = np.zeros(len(df), dtype=np.float64)
-        for j, (k, v) in enumerate(df.items()):
+        # (rows in a fixed order -- by n-gram -- so that the fixture regenerates bit for bit: the dict's own order follows
+        # python's per-process string hashing)
+        for j, (k, v) in enumerate(sorted(df.items(), key=lambda kv: tuple(int(x) for x in kv[0]))):
             keys[j, :len(k)] = [int(x) for x in k]
             cnt[j] = v
         out["df_keys"], out["df_count"], out["ref_len"] = keys, cnt, np.array(ref_len)

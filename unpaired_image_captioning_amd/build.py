@@ -10,7 +10,7 @@ import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
-SOURCES = ["api.hip", "gemm.hip", "gemm_tn.hip", "attention.hip", "rnn_persist.hip", "pointwise.hip", "batchnorm.hip", "beam.hip", "topdown.hip", "fcmodel.hip", "nmt.hip", "cider.hip", "loader.hip", "loader_io.hip", "comm.hip", "discriminator.hip", "gcn.hip"]
+SOURCES = ["api.hip", "gemm.hip", "gemm_tn.hip", "attention.hip", "rnn_persist.hip", "rnn_bwd_persist.hip", "pointwise.hip", "batchnorm.hip", "beam.hip", "topdown.hip", "fcmodel.hip", "nmt.hip", "cider.hip", "loader.hip", "loader_io.hip", "comm.hip", "discriminator.hip", "gcn.hip"]
 LIB = os.path.join(HERE, "libuic_hip.so")
 
 
@@ -20,7 +20,7 @@ def _newest(paths):
 
 def build(force: bool = False, verbose: bool = True) -> str:
     srcs = [os.path.join(CSRC, s) for s in SOURCES]
-    deps = srcs + [os.path.join(CSRC, "uic_common.h"), os.path.join(CSRC, "uic_host.h"), os.path.join(HERE, "..", "include", "uic_hip.h")]
+    deps = srcs + [os.path.join(CSRC, "uic_common.h"), os.path.join(CSRC, "uic_host.h"), os.path.join(CSRC, "rnn_persist_common.h"), os.path.join(HERE, "..", "include", "uic_hip.h")]
     if not force and os.path.exists(LIB) and os.path.getmtime(LIB) >= _newest(deps):
         return LIB
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")

@@ -54,6 +54,7 @@ struct Layout {
   void* fcwT; void* attwT;                     // fc_embed / att_embed weights transposed ([Dfc, H], [D, H]): only for the optional input-feature gradients
   void* ones_blk; size_t ones_rows;           // [max(WG_CHUNK * N, N * R), 128] operand dtype, all ones: the "input" whose weight gradient is the bias gradient
   unsigned* rnn_sync; unsigned long long* rnn_dbg;   // persistent recurrence (rnn_persist.hip): sync block, optional time stamps
+  unsigned* rnn_bwd_sync; size_t rnn_bwd_sync_bytes; unsigned long long* rnn_bwd_dbg;   // persistent BPTT (rnn_bwd_persist.hip): one sync block per launch of a step
   // sampling
   void* s_h_att[2]; void* s_h_lang[2]; float* s_c_att[2]; float* s_c_lang[2];
   void* s_xt; float* s_atth; float* s_alpha; void* s_ctx; void* s_hdrop; float* s_logits;
@@ -175,6 +176,9 @@ Layout make_layout(const uic_topdown_dims& d, void* ws) {
   L.ones_blk = b.take(L.ones_rows * 128 * S);
   L.rnn_sync = (unsigned*)b.take(uic_rnn_persist_sync_bytes());
   L.rnn_dbg = (unsigned long long*)b.take((size_t)256 * T * 16 * 8);
+  L.rnn_bwd_sync_bytes = T * uic_rnn_persist_sync_bytes();
+  L.rnn_bwd_sync = (unsigned*)b.take(L.rnn_bwd_sync_bytes);
+  L.rnn_bwd_dbg = (unsigned long long*)b.take((size_t)256 * T * 16 * 8);
   for (int i = 0; i < 2; ++i) {
     L.s_h_att[i] = b.take(N * H * S);
     L.s_h_lang[i] = b.take(N * H * S);
@@ -523,7 +527,8 @@ void* uic_topdown_workspace_ptr(const uic_topdown_dims* d, void* workspace, cons
       {"gates2", L.gates2}, {"att_h", L.atth_all}, {"alpha", L.alpha_all}, {"ctx", L.ctx_all}, {"hdrop", L.hdrop_all},
       {"logits", L.logits}, {"dlogits", L.dlogits}, {"row_loss", L.row_loss}, {"scalars", L.scalars},
       {"dhdrop", L.dhdrop}, {"dx2", L.dx2_all}, {"dg1", L.dg1_all}, {"dg2", L.dg2_all}, {"de", L.de_all},
-      {"datth", L.datth_all}, {"d_att", L.d_att}, {"d_p_att", L.d_patt}, {"dxt", L.dxt}, {"rnn_dbg", L.rnn_dbg}};
+      {"datth", L.datth_all}, {"d_att", L.d_att}, {"d_p_att", L.d_patt}, {"dxt", L.dxt}, {"rnn_dbg", L.rnn_dbg}, {"rnn_bwd_dbg", L.rnn_bwd_dbg},
+      {"dx1", L.dx1}, {"dc_att", L.dc_att}, {"dc_lang", L.dc_lang}};
   for (auto& e : tab)
     if (!strcmp(e.n, name)) return e.p;
   return nullptr;
@@ -727,7 +732,7 @@ struct Step {
   // recurrence, and what the recurrence saves (1.02 -> 0.83 ms) is less than the overlap that is lost (measured 4.25 vs
   // 4.49 ms per step).  Mode 3 forces it there for experiments.
   bool persist_ok(bool fused) const {
-    return !ss_on() && uic_rnn_persist_eligible(dt, N, H, A, R) && (!fused || uic_rnn_persist_mode() == 3);
+    return !ss_on() && uic_rnn_persist_eligible(dt, N, H, A, R) && (!fused || uic_rnn_persist_mode() >= 3);
   }
   int fwd_steps(int t0, int t1, hipStream_t s, bool fused = false) {
     if (!persist_ok(fused)) {
@@ -837,7 +842,37 @@ struct Step {
   // ---------------------------------------------------------------- backward
   int bwd_begin(hipStream_t s) {
     if (bias_in_chunks()) UIC_TRY(uic_fill_value_launch(dt, L.ones_blk, L.ones_rows * 128, 1.f, s));
-    return uic_zero4_launch(L.dc_att, NH * 4, L.dc_lang, NH * 4, nullptr, 0, nullptr, 0, s);
+    bwd_launches = 0;
+    return uic_zero4_launch(L.dc_att, NH * 4, L.dc_lang, NH * 4, bwd_persist_ok() ? L.rnn_bwd_sync : nullptr, bwd_persist_ok() ? L.rnn_bwd_sync_bytes : 0,
+                            nullptr, 0, s);
+  }
+
+  // BPTT of decode steps [t_lo, t_hi), latest first: ONE persistent launch (rnn_bwd_persist.hip) when the shapes allow, else
+  // the chain of six launches per step.  Either may continue where the other stopped (same carry buffers).
+  bool bwd_persist_ok() const { return uic_rnn_persist_mode() >= 4 && uic_rnn_bwd_persist_eligible(dt, N, H, A, R); }
+  int bwd_launches = 0;
+  int bwd_steps(int t_lo, int t_hi, hipStream_t s) {
+    if (!bwd_persist_ok()) {
+      for (int t = t_hi - 1; t >= t_lo; --t) UIC_TRY(bwd_step(t, s));
+      return UIC_OK;
+    }
+    UicRnnBwdParams p;
+    memset(&p, 0, sizeof(p));
+    p.N = N; p.R = R; p.t_lo = t_lo; p.t_hi = t_hi; p.first = t_hi == t_run;
+    p.w2T = dv.w2T; p.w1recT = dv.w1recT; p.h2attT = dv.h2attT; p.w_alpha = w->alpha_w;
+    p.p_att = L.patt; p.att = L.attp;
+    p.gates1 = L.gates1; p.gates2 = L.gates2; p.c_att = L.c_att; p.c_lang = L.c_lang;
+    p.att_h_all = L.atth_all; p.alpha_all = L.alpha_all; p.dhdrop = L.dhdrop;
+    p.drop_p = drop_p; p.seed = seed;
+    p.dg1_all = L.dg1_all; p.dg2_all = L.dg2_all; p.dx2_all = L.dx2_all; p.dx1 = L.dx1;
+    p.dc_att = L.dc_att; p.dc_lang = L.dc_lang; p.de_all = L.de_all; p.datth_all = L.datth_all;
+    UIC_REQUIRE(bwd_launches < d.T, "backward: more BPTT launches than decode steps");
+    p.sync = L.rnn_bwd_sync + (size_t)bwd_launches * (uic_rnn_persist_sync_bytes() / 4);
+    p.sync_zeroed = 1;                 // (bwd_begin zeroed every launch's block of this step)
+    ++bwd_launches;
+    static const bool dbg_on = getenv("UIC_PERSIST_DBG") != nullptr;
+    p.dbg = dbg_on ? L.rnn_bwd_dbg : nullptr; p.dbg_T = d.T;
+    return uic_rnn_bwd_persist_launch(p, s);
   }
 
   int bwd_step(int t, hipStream_t s) {
@@ -1222,7 +1257,7 @@ int uic_topdown_backward(const uic_topdown_dims* d, const uic_topdown_weights* w
   UIC_TRY(st.dh_rows(0, t_run, s));
   UIC_TRY(st.logit_weight_grads(s));
   UIC_TRY(st.bwd_begin(s));
-  for (int t = t_run - 1; t >= 0; --t) UIC_TRY(st.bwd_step(t, s));
+  UIC_TRY(st.bwd_steps(0, t_run, s));
   return st.bwd_epilogue(s);
 }
 
@@ -1315,7 +1350,7 @@ int uic_topdown_xe_train_step(const uic_topdown_dims* d, const uic_topdown_weigh
     const int t0 = c * CH, t1 = t0 + CH < t_run ? t0 + CH : t_run;
     UIC_HIP(hipStreamWaitEvent(s, ss->ev_side[c], 0));
     if (c == nchunk - 1) UIC_MARK(4, s);              // main: BPTT starts
-    for (int t = t1 - 1; t >= t0; --t) UIC_TRY(st.bwd_step(t, s));
+    UIC_TRY(st.bwd_steps(t0, t1, s));
     UIC_HIP(hipEventRecord(ss->ev_main[c], s));       // (the forward's use of ev_main[c] was consumed long ago)
     UIC_HIP(hipStreamWaitEvent(s2, ss->ev_main[c], 0));
     UIC_TRY(st.wgrad_chunk(t0, t1, c == nchunk - 1, s2));

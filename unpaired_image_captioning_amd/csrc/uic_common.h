@@ -278,6 +278,41 @@ size_t uic_rnn_persist_sync_bytes();
 bool uic_rnn_persist_eligible(int dtype, int N, int H, int A, int R);
 int uic_rnn_fwd_persist_launch(const UicRnnFwdParams& p, hipStream_t s);
 
+// BPTT of decode steps [t_lo, t_hi) of the same recurrence (latest step first) in ONE launch (rnn_bwd_persist.hip; bf16):
+// per step lang_lstm cell backward, d[att_res | h_att | h_lang_prev] = dG2 W2, attention backward (scores, softmax,
+// d att_h), d h_att += d att_h W_h2att, att_lstm cell backward, d[h_lang_prev | h_att_prev] = dG1 W1rec -- the six dependent
+// launches per step of Step::bwd_step (topdown.hip).  Reads what the forward pass saved, writes what the weight-gradient
+// GEMMs and the deferred attention accumulation read afterwards (dg1_all, dg2_all, datth_all, de_all, the d ctx columns of
+// dx2_all); the gradients carried from step to step enter and leave through the buffers the launch chain uses
+// (dc_att, dc_lang, dx1, the h_lang columns of dx2_all[t_hi] / dx2_all[t_lo]), so chunks of steps may be run by either.
+struct UicRnnBwdParams {
+  int N, R, t_lo, t_hi;
+  int first;                         // 1: step t_hi - 1 is the last executed decode step (nothing carried in)
+  int row0, Nrows, force_safe;       // filled by the launcher (slabs of <= 640 caption rows)
+  const void* w2T;                   // [3H, 4H]: rows = inputs [att_res | h_att | h_lang_prev] of lang_lstm, K = its gate columns
+  const void* w1recT;                // [2H, 4H]: rows = inputs [h_lang_prev | h_att_prev] of att_lstm
+  const void* h2attT;                // [H, A]
+  const float* w_alpha;
+  const void* p_att; const void* att;            // [N, R, A], [N, R, H]
+  const void* gates1; const void* gates2;        // [T, N, 4H] activated gates saved by the forward pass
+  const float* c_att; const float* c_lang;       // [(T+1), N, H]
+  const float* att_h_all; const float* alpha_all;   // [T, N, A], [T, N, R]
+  const float* dhdrop;               // [T, N, H] gradient w.r.t. dropout(h_lang) from the logit layer
+  float drop_p; unsigned seed;
+  void* dg1_all; void* dg2_all;      // [T, N, 4H] out
+  float* dx2_all;                    // [T, N, 3H]: columns [0, H) of every step out (d att_res), columns [2H, 3H) carry
+  float* dx1;                        // [N, 2H] carry
+  float* dc_att; float* dc_lang;     // [N, H] carry
+  float* de_all; void* datth_all;    // [T, N, R], [T, N, A] out
+  unsigned* sync;                    // uic_rnn_persist_sync_bytes() bytes; zeroed by the launcher unless sync_zeroed
+  int sync_zeroed;                   // the caller zeroed this launch's sync block itself (one memset for all chunks of a step)
+  unsigned long long* dbg; int dbg_T; int exp;   // optional [256][dbg_T][16] phase time stamps (100 MHz), indexed by absolute step
+  unsigned* status;                  // filled by the launcher
+};
+bool uic_rnn_bwd_persist_eligible(int dtype, int N, int H, int A, int R);
+int uic_rnn_bwd_persist_launch(const UicRnnBwdParams& p, hipStream_t s);
+unsigned* uic_rnn_persist_status_word();   // the calling thread's device: sticky status words or null (rnn_persist.hip)
+
 // ---------------------------------------------------------------- pointwise (pointwise.hip)
 int uic_cast_f32_launch(int dtype, const float* src, void* dst, size_t n, hipStream_t s);
 int uic_to_f32_launch(int dtype, const void* src, float* dst, size_t n, hipStream_t s);

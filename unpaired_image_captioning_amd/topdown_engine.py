@@ -17,6 +17,7 @@ class Workspace(object):
     def __init__(self, dims, buf):
         self.dims = dims
         self.buf = buf
+        self.released = (None, None)     # (event, stream) of the last release: see TopDownEngine.checkout
 
 
 class TopDownEngine(object):
@@ -64,14 +65,27 @@ class TopDownEngine(object):
 
     def checkout(self, d, device):
         free = self._pool.setdefault(self._key(d), [])
-        if free:
-            return free.pop()
+        # release() happens at ENQUEUE time: the kernels that use a pooled buffer may still be running on the stream that
+        # released it (the self-critical step's greedy baseline runs on a second stream beside the sampling pass, and with
+        # one caption per image both passes ask for the same dims).  A buffer is handed out again only to the stream that
+        # released it (stream order protects it) or once that stream has passed the release point; otherwise the pool grows.
+        cur = torch.cuda.current_stream().cuda_stream
+        for i, ws in enumerate(free):
+            ev, sid = ws.released
+            if ev is None or sid == cur or ev.query():
+                free.pop(i)
+                ws.released = (None, None)
+                return ws
         nbytes = self.lib.uic_topdown_workspace_bytes(C.byref(d))
         if nbytes == 0:
             check(-1, "uic_topdown_workspace_bytes")
         return Workspace(d, torch.empty(nbytes, dtype=torch.uint8, device=device))
 
     def release(self, ws):
+        cur = torch.cuda.current_stream()
+        ev = torch.cuda.Event()
+        ev.record(cur)
+        ws.released = (ev, cur.cuda_stream)
         self._pool.setdefault(self._key(ws.dims), []).append(ws)
 
     # ---- att_feat_size % 8 != 0: zero feature columns meet zero weight columns, a BatchNorm over an all-zero column gives
