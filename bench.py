@@ -80,6 +80,11 @@ def attention_roofline(dtype_id, dtype_name, iters=64, pool=8):
         for i in range(8):
             launch(i % pool if rotate else 0)
         ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(iters)]
+        # The host needs ~15 us to enqueue one (event, launch, event) triple through ctypes -- longer than the kernel runs -- so an
+        # empty queue would let the GPU wait for the host INSIDE the event pair.  A ~2 ms spin kernel in front lets the host run
+        # ahead; every pair then measures the device only: marker, kernel dispatch, kernel, marker (tools/micro/attn_variants.hip
+        # reads the same 13.1 us from a C++ host).
+        torch.cuda._sleep(int(5e6))
         for i in range(iters):
             ev[i][0].record()
             launch(i % pool if rotate else 0)
@@ -144,8 +149,12 @@ def recurrence_roofline(tr, batch, t_run, den_local, dtype_name, extra_steps=6):
             traffic = json.load(f)["traffic_bytes_per_launch"]
     except (OSError, KeyError, ValueError):
         pass
-    return {"bound": "hbm", "kernel": "rnn_fwd_persist_%skernel (one launch = %d decode steps x %d caption rows: att_lstm, h2att, attention, lang_lstm)" % ("ws_" if dtype_name == "bf16" else "", t_run, N),
+    # "bound": neither roofline binds this launch -- it is a chain of t_run x 4 group exchanges.  achieved / peak /
+    # frac stay the HBM figures of the task's contract (attention bytes per unit over the launch duration); the MFMA figures are
+    # beside them.
+    return {"bound": "latency", "kernel": "rnn_fwd_persist_%skernel (one launch = %d decode steps x %d caption rows: att_lstm, h2att, attention, lang_lstm)" % ("ws_" if dtype_name == "bf16" else "", t_run, N),
             "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
+            "hbm_frac": round(achieved / HBM_PEAK_GBS, 4),
             "traffic": traffic,
             "traffic_source": "profiles/rnn_persist_pmc_%s.json (committed rocprofv3 PMC passes of this kernel, NOT measured in this run)" % dtype_name if traffic else None,
             "units_per_launch": units, "bytes_per_unit": bytes_per_unit, "bytes_per_launch": units * bytes_per_unit,
@@ -218,7 +227,19 @@ def cpu_baseline(threads=None):
         O.adam_step(P, grads, m1, v1, step, 5e-4)
         times.append(time.perf_counter() - t0)
     best = sum(times[3:]) / len(times[3:])
+    cpu_model = "?"
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("model name"):
+                    cpu_model = line.split(":", 1)[1].strip()
+                    break
+    except OSError:
+        pass
     return {"value": round(N / best, 1), "unit": "captions/s", "cores": torch.get_num_threads(), "kind": "port",
+            "cpu_model": cpu_model, "host_logical_cpus": os.cpu_count(),
+            "cores_note": "threads used = the fastest setting measured on the GPU box's 256-thread host (8 -> 293, 16 -> 379, 32 -> 211, "
+                          "64 -> 110, 128 -> 24 captions/s: torch's CPU kernels stop scaling at this problem size)",
             "sample": "%d images x %d captions = %d rows, fp32, 3 warm-up + 10 timed steps of fwd+loss+bwd+Adam "
                       "(oracle/topdown.py, torch CPU ops)" % (n_img, c["S"], N)}
 
@@ -238,6 +259,8 @@ def main():
                     help="region feature width (secondary measurement): 2053 = 2048 + 5 box features, the reference's default "
                          "use_box=1; the metric is quoted at 2048")
     ap.add_argument("--use-bn", type=int, default=0, help="opt.use_bn of the captioner (secondary measurement; the metric is quoted at 0)")
+    ap.add_argument("--rows-per-gpu-probe", type=int, default=80,
+                    help="also time the step at this many caption rows (the per-rank size of a strong-scaling run; 0 = skip); secondary key only")
     ap.add_argument("--cpu-threads", type=int, default=0, help="threads for the CPU oracle leg (0: min(host cores, 16), the fastest setting measured on the GPU box's 256-thread host: 8->293, 16->379, 32->211, 64->110, 128->24 captions/s)")
     args = ap.parse_args()
 
@@ -280,15 +303,15 @@ def main():
     from unpaired_image_captioning_amd.synthetic import synthetic_batch
     from unpaired_image_captioning_amd.trainer import Trainer
 
-    if share:
-        # two processes on ONE GPU must not both run the persistent recurrence kernel (each wants every CU for itself and waits,
-        # bounded, for the other: include/uic_hip.h): the functional N > 1 test on a 1-GPU box uses the per-step launch chain
-        L.check(L.load().uic_set_persistent_rnn(0))
     c = CFG
     torch.manual_seed(1234)                                    # identical initial weights on every rank
     Datt = args.att_feat_size or c["D"]
     tr = Trainer(make_opt(args.dtype, 1234 + rank, args.use_bn, Datt))
     tr.build_optimizer()
+    if share:
+        # two processes on ONE GPU must not both run the persistent recurrence kernel (each wants every CU for itself and waits,
+        # bounded, for the other: include/uic_hip.h): the functional N > 1 test on a 1-GPU box uses the per-step launch chain
+        tr.i2t_model.engine.recurrence = L.REC_FWD_CHAIN
     batch = synthetic_batch(c["n_img"], c["S"], c["R"], Datt, c["V"], c["L"], seed=1234 + rank)
     batch["fc_feats"] = batch["fc_feats"][:, :c["D"]].contiguous()
     N = c["n_img"] * c["S"]
@@ -330,6 +353,27 @@ def main():
         elapsed_img, _ = timed(per_image)
     loss_val = float(loss.item())
     L.persistent_status()                                      # raises if a persistent-kernel spin timed out
+    strong = None
+    if world == 1 and args.rows_per_gpu_probe:
+        # What one rank of a STRONG-scaling run (640 rows over 8 GPUs) would do per step: the same step on rows_per_gpu_probe
+        # caption rows -- a latency chain at that size -- next to the host time of enqueueing it (a secondary key, never `value`).
+        n_img_s = max(1, args.rows_per_gpu_probe // c["S"])
+        small = {k: v[:n_img_s * c["S"]].contiguous() for k, v in batch.items()}
+        den_s = float(small["masks"][:, 1:T + 1].sum().item())
+        for _ in range(5):
+            tr.train_device_batch(small, t_run, den_s)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        host = 0.0
+        for _ in range(20):
+            h0 = time.perf_counter()
+            tr.train_device_batch(small, t_run, den_s)
+            host += time.perf_counter() - h0
+        torch.cuda.synchronize()
+        el_s = time.perf_counter() - t0
+        strong = {"rows_per_gpu": n_img_s * c["S"], "ms_per_step": round(el_s / 20 * 1e3, 3), "host_enqueue_ms_per_step": round(host / 20 * 1e3, 3),
+                  "captions_per_s_per_gpu": round(n_img_s * c["S"] * 20 / el_s, 1),
+                  "note": "1-GPU step at the per-rank size of a strong-scaling run (640 rows / 8 GPUs); no collective in it"}
     rec_roof = recurrence_roofline(tr, batch, t_run, den_local, args.dtype)   # untimed extra steps, every rank (collectives stay matched)
     f32_line = None
     if world == 1 and args.dtype != "f32" and not args.no_f32:
@@ -383,6 +427,8 @@ def main():
             out["roofline"] = att_roof
         if f32_line is not None:
             out["f32"] = f32_line
+        if strong is not None:
+            out["strong_scaling_probe"] = strong
         if elapsed_img is not None:
             out["per_image_features"] = {"value": round(world * N * args.steps / elapsed_img, 1), "unit": "captions/s",
                                          "ms_per_step": round(elapsed_img / args.steps * 1e3, 3),

@@ -28,18 +28,28 @@ extern "C" {
 const char* uic_last_error_string(void);
 int uic_version(void);
 
-/* Persistent recurrence (csrc/rnn_persist.hip): with rnn_size = att_hid_size = 512 and at most 40 regions the decode loop of
- * AttModel._forward (P/models/AttModel.py:129-154: att_lstm, h2att, attention, lang_lstm per step) can run as ONE launch
- * for a range of decode steps instead of four dependent launches per step (bf16: the recurrent weights stay in LDS and
- * registers for the whole launch).  mode 0: never; 1: in uic_topdown_forward only; 2: the same with its
- * placement-independent SAFE exchange protocol forced (tests); 3 (default, or the UIC_PERSIST environment variable): also
- * inside uic_topdown_xe_train_step, whose logit layer then follows the recurrence chunk by chunk, last chunk first, beside
- * the BPTT loop; -1: back to the default.  Two processes sharing one GPU must not both enable it.
- * uic_set_persistent_status registers (per device; NULL unregisters) 4 caller-allocated, caller-zeroed uint32 on the
- * device that the kernel updates: [0] != 0 after a bounded spin timed out (the results of that call are invalid), [1] /
- * [2] launches that ran with the XCD-local / the SAFE protocol. */
-int uic_set_persistent_rnn(int32_t mode);
-int uic_set_persistent_status(void* status);
+/* Persistent recurrence (csrc/rnn_persist.hip, csrc/rnn_bwd_persist.hip): with rnn_size = att_hid_size = 512 and at most 40
+ * regions the decode loop of AttModel._forward (P/models/AttModel.py:129-154: att_lstm, h2att, attention, lang_lstm per
+ * step) runs as ONE launch for a range of decode steps instead of four dependent launches per step (bf16: the recurrent
+ * weights stay in LDS and registers for the whole launch; it holds every CU while it runs), in uic_topdown_forward and in
+ * uic_topdown_xe_train_step, whose logit layer then follows the recurrence chunk by chunk, last chunk first, beside the BPTT
+ * loop.  How a call launches the loop is part of its dims (uic_topdown_dims.recurrence, no library-wide state):
+ *   UIC_REC_FWD_CHAIN    the forward recurrence as per-step launches (two processes sharing one GPU must both set it: the
+ *                        persistent kernel's workgroups have to be resident together)
+ *   UIC_REC_BWD_PERSIST  the BPTT loop as one persistent launch per chunk of decode steps (bf16) instead of six launches per
+ *                        step.  Off by default: alone it runs a step in 57 us instead of 82, but beside the side stream's
+ *                        GEMMs of uic_topdown_xe_train_step both slow down (step 3.9 vs 3.6 ms)
+ *   UIC_REC_SAFE         the persistent kernels use their placement-independent exchange protocol (device-scope stores, groups
+ *                        by arrival order) instead of XCD-local groups -- same results bit for bit; tests
+ *   UIC_REC_STAMPS       the persistent kernels write per-phase time stamps into the workspace ("rnn_dbg" / "rnn_bwd_dbg" of
+ *                        uic_topdown_workspace_ptr: [256 workgroups][T][16] uint64, 100 MHz); tools/
+ * uic_topdown_dims.rnn_status: NULL, or 4 caller-allocated, caller-zeroed uint32 on the device that the persistent kernels
+ * update: [0] != 0 after a bounded spin timed out (the results of that call are invalid), [1] / [2] launches that ran with
+ * the XCD-local / the SAFE protocol. */
+#define UIC_REC_FWD_CHAIN 1
+#define UIC_REC_BWD_PERSIST 2
+#define UIC_REC_SAFE 4
+#define UIC_REC_STAMPS 8
 
 /* ---- shapes of one TopDown step (P/models/AttModel.py:56-92,422-428,530-536) ---- */
 typedef struct uic_topdown_dims {
@@ -66,6 +76,8 @@ typedef struct uic_topdown_dims {
   int32_t logit_layers; /* opt.logit_layers (P/models/AttModel.py:86-91): 0 or 1 = logit is one Linear(H, V1); n > 1 (at most
                      * UIC_MAX_LOGIT_LAYERS) = n - 1 blocks Linear(H, H) + ReLU + Dropout(0.5) in front of it (the 0.5 is
                      * hard-coded in the reference and active in train mode whatever drop_p is). */
+  int32_t recurrence;  /* UIC_REC_* flags (above); 0 = default */
+  uint32_t* rnn_status; /* status words of the persistent kernels (above) or NULL */
 } uic_topdown_dims;
 #define UIC_MAX_LOGIT_LAYERS 4
 
@@ -383,6 +395,12 @@ int uic_comm_destroy(void* comm);
 /* nn.Linear as C[M,N] = A[M,K] B[N,K]^T (+bias)(+ReLU); flags: 1 ReLU, 2 accumulate into C, 4 C is f32. */
 int uic_linear(int32_t dtype, int32_t M, int32_t N, int32_t K, const void* A, int32_t lda, const void* B, int32_t ldb,
                void* C, int32_t ldc, const float* bias, int32_t flags, void* stream);
+
+/* The same product split over K: slice z of `splitk` (each a whole number of 128-byte K rounds) leaves its raw partial tile in
+ * slab[z][M][N] (f32, dense); the caller sums the slices -- what the BPTT loop's d x GEMMs do, whose consumers (cell backward,
+ * attention backward) add the slices while they read them.  One K segment, K % 64 == 0 (bf16) / % 32 (f32). */
+int uic_linear_partials(int32_t dtype, int32_t M, int32_t N, int32_t K, const void* A, int32_t lda, const void* B, int32_t ldb,
+                        float* slab, int32_t splitk, void* stream);
 
 /* Weight gradient of nn.Linear without transposed copies: dW[M,N] (f32) = dY[K,M]^T X[K,N] (+= if accumulate), dY / X bf16
  * row-major with the reduction index (caption rows / decode steps) as the ROW index, exactly as the backward pass holds

@@ -123,6 +123,36 @@ def test_training_separates_real_from_shuffled_captions():
     assert s[:N].mean().item() > 0.8 and s[N:].mean().item() < 0.2
 
 
+def test_two_forward_passes_before_one_backward_keep_their_own_activations():
+    """D(real) and D(fake) evaluated separately and summed into one loss, and a no-grad scores() call in between: every
+    forward pass saves its activations in a workspace of its own, so the gradients equal those of the two passes run and
+    differentiated one after the other."""
+    V, L, N = 120, 10, 32
+    g = torch.Generator().manual_seed(3)
+    real = torch.randint(1, V + 1, (N, L), generator=g).cuda()
+    fake = torch.randint(1, V + 1, (N, L), generator=g).cuda()
+    opt = argparse.Namespace(vocab_size=V, seq_length=L, input_encoding_size=64, disc_num_filters=32, disc_filter_sizes=(1, 2, 3),
+                             disc_dropout=0.0, compute_dtype="f32", seed=4)
+    from unpaired_image_captioning_amd.models import SentenceDiscriminator
+    torch.manual_seed(0)
+    m = SentenceDiscriminator(opt).cuda()
+    m.train()
+    ones, zeros = torch.ones(N, device="cuda"), torch.zeros(N, device="cuda")
+
+    def grads_of(loss):
+        m.zero_grad()
+        loss.backward()
+        return [p.grad.detach().clone() for p in m.parameters()]
+    ga = grads_of(m.bce(m(real, seed=1), ones))
+    gb = grads_of(m.bce(m(fake, seed=1), zeros))
+    a = m(real, seed=1)
+    b = m(fake, seed=1)                       # same batch size: would overwrite a's saved activations in a shared buffer
+    m.scores(fake)
+    both = grads_of(m.bce(a, ones) + m.bce(b, zeros))
+    for x, y, z in zip(ga, gb, both):
+        assert (z - (x + y)).abs().max().item() <= 1e-6 * max(1.0, float((x + y).abs().max())), float((z - (x + y)).abs().max())
+
+
 def test_trainer_adversarial_round_runs():
     """BASELINE configs[3] in miniature: the generator samples captions, the discriminator takes one BCE step on ground-truth
     vs sampled rows, and the self-critical step adds w (D(sampled) - D(greedy)) to its reward (reward_fn = 0, so the policy

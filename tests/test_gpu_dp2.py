@@ -33,9 +33,9 @@ def _opt(cfg, use_bn=0):
                               compute_dtype="f32", seed=5, i2t_learning_rate=5e-3, i2t_train_flag=1)
 
 
-def _train(cfg, W, data, steps):
+def _train(cfg, W, data, steps, exchange=None):
     from unpaired_image_captioning_amd.trainer import Trainer
-    tr = Trainer(_opt(cfg))
+    tr = Trainer(_opt(cfg), exchange=exchange)
     tr.i2t_model.load_state_dict(W)
     tr.build_optimizer()
     losses = [tr.train(data) for _ in range(steps)]
@@ -43,24 +43,29 @@ def _train(cfg, W, data, steps):
     return tr, losses
 
 
-def _worker(rank, world, port, out_dir, backend="gloo"):
+def _worker(rank, world, port, out_dir, backend="gloo", uic_comm=False):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-    torch.cuda.set_device(rank if backend == "nccl" else 0)     # RCCL: one GPU per rank; gloo: both ranks share cuda:0
+    torch.cuda.set_device(rank if (backend == "nccl" or uic_comm) else 0)     # RCCL: one GPU per rank; gloo: both ranks share cuda:0
     dist.init_process_group(backend, rank=rank, world_size=world)
-    from unpaired_image_captioning_amd.parallel_exchange import GradientExchange
+    from unpaired_image_captioning_amd.parallel_exchange import GradientExchange, UicCommExchange
+    # uic_comm: the collectives go through libuic_hip's own RCCL communicator (uic_comm_*), torch.distributed (gloo) only
+    # hands the unique id from rank 0 to the others
+    exchange = UicCommExchange.from_torch_distributed() if uic_comm else None
     cfg, W, I, Out, G, X = load_golden("topdown_tiny_ragged")
     lo, hi = GradientExchange().shard_images(cfg["n_img"])
     rows = slice(lo * cfg["S"], hi * cfg["S"])
     data = {k: I[k][rows].numpy() for k in ("fc_feats", "att_feats", "labels", "masks", "att_masks")}
-    tr, losses = _train(cfg, W, data, STEPS)
+    tr, losses = _train(cfg, W, data, STEPS, exchange)
     assert tr.exchange.world_size == world and len(tr.arena_splits) == 3 and 0 < tr.arena_splits[0] < tr.arena_splits[1] < tr.arena_splits[2] < tr.arena.numel
     if rank == 0:
         torch.save({"sd": {k: v.cpu() for k, v in tr.i2t_model.state_dict().items()}, "losses": losses},
                    os.path.join(out_dir, "dp2.pt"))
+    if exchange is not None:
+        exchange.close()
     dist.barrier()
     dist.destroy_process_group()
 
@@ -99,6 +104,21 @@ def test_two_ranks_over_rccl_match_single_process(tmp_path):
     _check_against_single_process(tmp_path)
 
 
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="RCCL needs one GPU per rank: this box has %d" % torch.cuda.device_count())
+def test_two_ranks_over_uic_comm_match_single_process(tmp_path):
+    """The same step with the collectives on libuic_hip's OWN RCCL communicator (uic_comm_init / uic_comm_allreduce with the
+    by-value ncclUniqueId hand-over, UicCommExchange.from_torch_distributed): exercises the C-ABI communicator across ranks."""
+    world = 2
+    mp.spawn(_worker, args=(world, _free_port(), str(tmp_path), "gloo", True), nprocs=world, join=True)
+    _check_against_single_process(tmp_path)
+
+
+def test_uic_comm_rejects_a_bad_unique_id():
+    from unpaired_image_captioning_amd.parallel_exchange import UicCommExchange
+    with pytest.raises(ValueError, match="128 bytes"):
+        UicCommExchange(0, 1, b"short")
+
+
 def test_uic_comm_single_rank_rccl():
     """uic_comm_* (include/uic_hip.h): RCCL through libuic_hip's own C-ABI entry points, no torch.distributed.  With one GPU per
     box only a world of 1 can be formed: unique id, communicator, in-place all-reduce (identity for one rank) of an f32 and a
@@ -107,8 +127,7 @@ def test_uic_comm_single_rank_rccl():
     from unpaired_image_captioning_amd.parallel_exchange import UicCommExchange
     uid = UicCommExchange.new_unique_id()
     assert len(uid) == 128 and any(uid)
-    ex = UicCommExchange(0, 1, uid)
-    try:
+    with UicCommExchange(0, 1, uid) as ex:
         g = torch.Generator(device="cuda").manual_seed(5)
         a = torch.randn(1 << 20, device="cuda", generator=g)
         b = torch.randn(4099, device="cuda", generator=g).bfloat16()
@@ -118,5 +137,4 @@ def test_uic_comm_single_rank_rccl():
         torch.cuda.synchronize()
         assert torch.equal(a, a0) and torch.equal(b, b0)
         assert ex.world_size == 1 and ex.rank == 0 and ex.allreduce_sum(a) is a
-    finally:
-        ex.close()
+    assert ex._comm is None                                     # closed by the context manager

@@ -1,7 +1,8 @@
 """Full-size parity of BASELINE.json configs[1] (128 images x 5 captions = 640 caption rows, R = 36, D = 2048, H = E = A = 512,
 vocabulary 9487 + 1, 17 decode steps) against the CPU oracle -- not properties, the oracle's own numbers: log-probs, loss,
-the norm of every gradient tensor and three gradient tensors entry by entry -- and of the persistent recurrence kernel
-(csrc/rnn_persist.hip) against the per-step launch chain it replaces, under both of its exchange protocols.
+the norm of every gradient tensor and three gradient tensors entry by entry -- and of the persistent recurrence kernels
+(csrc/rnn_persist.hip: the decode loop, csrc/rnn_bwd_persist.hip: its BPTT) against the per-step launch chains they replace,
+under both of their exchange protocols.
 Tolerances (north_star): log-probs 1e-3 (f32) / 1e-2 (bf16)."""
 import numpy as np
 import pytest
@@ -40,18 +41,24 @@ def case():
     return W, b, float(loss), grads, logp
 
 
-@pytest.mark.parametrize("mode", [0, 1, 2, 3])
+# uic_topdown_dims.recurrence: per-step launches everywhere / the default (persistent forward recurrence) / the same with
+# the SAFE exchange protocol / persistent BPTT as well / that with the SAFE protocol
+REC_MODES = {"chain": 1, "default": 0, "safe": 4, "bptt": 2, "bptt_safe": 6}
+
+
+@pytest.mark.parametrize("mode", list(REC_MODES))
 @pytest.mark.parametrize("dtype", ["f32", "bf16"])
 def test_configs1_full_size_vs_oracle(case, dtype, mode):
-    """mode: uic_set_persistent_rnn -- 0 per-step launches, 1 persistent recurrence in the forward call, 2 the same with the
-    SAFE protocol, 3 persistent recurrence inside the fused training step as well."""
+    """Forward call, fused training step (loss, every gradient) at BASELINE configs[1] size against the oracle, in every
+    way the library can launch the recurrence (REC_MODES; the f32 path has no persistent BPTT kernel and runs the chain)."""
     from unpaired_image_captioning_amd.trainer import xe_step
     Lb = _lib()
     W, b, ref_loss, ref_grads, ref_logp = case
     batch = {k: v.cuda() for k, v in b.items()}
     model = build_model(CFG, W, dtype)
     model.train()                                    # drop_prob_lm = 0: deterministic
-    Lb.check(Lb.load().uic_set_persistent_rnn(mode))
+    model.engine.recurrence = REC_MODES[mode]
+    before = Lb.persistent_status()
     try:
         logp = model(batch["fc_feats"], None, batch["att_feats"], batch["labels"], batch["att_masks"])
         t_run = model._steps_to_run(batch["labels"])
@@ -66,11 +73,16 @@ def test_configs1_full_size_vs_oracle(case, dtype, mode):
         assert abs(loss.item() - ref_loss) < LOGP_TOL[dtype]
         st = Lb.persistent_status()
     finally:
-        Lb.check(Lb.load().uic_set_persistent_rnn(-1))
+        model.engine.recurrence = 0
     assert st[0] == 0
+    launches = (st[1] - before[1], st[2] - before[2])            # (XCD-local, SAFE) persistent launches of this test
+    chunks = (t_run + 3) // 4                                      # BPTT: one launch per hand-off chunk of the fused step
+    want = {"chain": (0, 0), "default": (2, 0), "safe": (0, 2), "bptt": (2 + (chunks if dtype == "bf16" else 0), 0),
+            "bptt_safe": (0, 2 + (chunks if dtype == "bf16" else 0))}[mode]
+    assert launches == want, (mode, launches, want)
     floor = 1e-3 * max(float(v.norm()) for v in ref_grads.values())
     worst = max(((grads[k].float().cpu().double() - r.double()).norm() / max(r.double().norm().item(), floor)).item() for k, r in ref_grads.items())
-    print("full size %s mode %d: loss %.6f (oracle %.6f), worst per-tensor L2 gradient error %.3e" % (dtype, mode, loss.item(), ref_loss, worst))
+    print("full size %s mode %s: loss %.6f (oracle %.6f), worst per-tensor L2 gradient error %.3e" % (dtype, mode, loss.item(), ref_loss, worst))
     for k, r in ref_grads.items():
         g = grads[k].float().cpu().double()
         r = r.double()
@@ -115,8 +127,8 @@ def test_persistent_recurrence_equals_the_launch_chain(dtype, n_img, S):
     pd = {k: v.detach() for k, v in model.param_dict().items()}
     td = torch.float32 if dtype == "f32" else torch.bfloat16
 
-    def run(mode):
-        Lb.check(lib.uic_set_persistent_rnn(mode))
+    def run(rec):
+        eng.recurrence = rec
         logp, ws, _ = eng.forward(pd, batch["fc_feats"], batch["att_feats"], batch["att_masks"], batch["labels"], t_run, True, 99)
         out = {n: eng.workspace_tensor(ws, n, shp, dt)[: (t_run + 1 if shp[0] == T + 1 else t_run)].float().clone() for n, shp, dt in NAMES(T, N, td)}
         out["logp"] = logp[:, :t_run].clone()
@@ -125,11 +137,11 @@ def test_persistent_recurrence_equals_the_launch_chain(dtype, n_img, S):
         return out
     try:
         before = Lb.persistent_status()
-        ref = run(0)
-        got1, got1b, got2 = run(1), run(1), run(2)
+        ref = run(Lb.REC_FWD_CHAIN)
+        got1, got1b, got2 = run(0), run(0), run(Lb.REC_SAFE)
         after = Lb.persistent_status()
     finally:
-        Lb.check(lib.uic_set_persistent_rnn(-1))
+        eng.recurrence = 0
     assert after[0] == 0
     n_launch = (N + 639) // 640
     assert after[1] - before[1] == 2 * n_launch and after[2] - before[2] == n_launch      # XCD-local twice, SAFE once
@@ -139,6 +151,66 @@ def test_persistent_recurrence_equals_the_launch_chain(dtype, n_img, S):
         assert torch.equal(got1[k], got2[k]), k                          # independent of the protocol / placement
         assert (got1[k] - ref[k]).abs().max().item() < tol, (k, (got1[k] - ref[k]).abs().max().item())
     assert (got1["logp"] - ref["logp"]).abs().max().item() < (2e-4 if dtype == "f32" else 1e-2)
+
+
+BNAMES = lambda T, N: [("dg1", (T, N, 4 * H), torch.bfloat16), ("dg2", (T, N, 4 * H), torch.bfloat16), ("datth", (T, N, H), torch.bfloat16),
+                       ("de", (T, N, R), torch.float32), ("dx2", (T, N, 3 * H), torch.float32)]
+
+
+@pytest.mark.parametrize("n_img,S", [(1, 4), (17, 5), (128, 5), (140, 5), (129, 1)])
+def test_persistent_bptt_equals_the_launch_chain(n_img, S):
+    """Everything the BPTT loop leaves behind -- both cells' gate gradients, d att_h, the attention score gradients and d att_res
+    of every decode step, and every gradient tensor of the model -- persistent kernel (csrc/rnn_bwd_persist.hip, one launch for
+    all steps) vs six launches per step, on the same forward pass: 4 rows (most row groups empty), 85 rows (11 per group:
+    ragged 16-row tiles), 640 (the benchmark), 700 (two launches of <= 640 rows), 129; ragged region counts, training-mode
+    dropout; both exchange protocols must agree bit for bit and repeat bit for bit."""
+    Lb = _lib()
+    W = O.init_weights(V + 1, E, H, A, D, D, seed=11)
+    b = O.synthetic_batch(n_img, S, R, D, V, L, seed=77, ragged_regions=True)
+    batch = {k: v.cuda() for k, v in b.items()}
+    model = build_model(CFG, W, "bf16", drop=0.5)
+    model.train()
+    eng = model.engine
+    N, T = n_img * S, L + 1
+    t_run = model._steps_to_run(batch["labels"])
+    pd = {k: v.detach() for k, v in model.param_dict().items()}
+
+    def run(rec):
+        eng.recurrence = 0
+        _, ws, (d, w, bs) = eng.forward(pd, batch["fc_feats"], batch["att_feats"], batch["att_masks"], batch["labels"], t_run, True, 99,
+                                        want_logprobs=False, masks=batch["masks"])
+        eng.xe_loss(ws, d, bs, t_run)
+        eng.recurrence = rec
+        d = eng.dims(N, R, T)
+        grads = {k: torch.zeros_like(v) for k, v in pd.items()}
+        eng.backward(ws, d, w, bs, t_run, True, 99, grads)
+        torch.cuda.synchronize()
+        out = {n: eng.workspace_tensor(ws, n, shp, dt)[:t_run].float().clone() for n, shp, dt in BNAMES(T, N)}
+        out["dx2"] = out["dx2"][:, :, :H].contiguous()            # the d att_res columns are what outlives the loop
+        out.update({"grad:" + k: g.float().clone() for k, g in grads.items()})
+        eng.release(ws)
+        return out
+    try:
+        before = Lb.persistent_status()
+        ref = run(0)
+        got1, got1b, got2 = run(Lb.REC_BWD_PERSIST), run(Lb.REC_BWD_PERSIST), run(Lb.REC_BWD_PERSIST | Lb.REC_SAFE)
+        after = Lb.persistent_status()
+    finally:
+        eng.recurrence = 0
+    assert after[0] == 0
+    n_launch = (N + 639) // 640
+    # (each run's forward pass is one XCD-local launch per 640 rows as well)
+    assert after[1] - before[1] == 4 * n_launch + 2 * n_launch and after[2] - before[2] == n_launch
+    floor = 1e-3 * max(float(v.norm()) for k, v in ref.items() if k.startswith("grad:"))
+    for k in ref:
+        if k != "grad:embed.0.weight":                   # (the embedding gradient's atomics are order-dependent in both modes)
+            assert torch.equal(got1[k], got1b[k]), k                     # bit-repeatable
+            assert torch.equal(got1[k], got2[k]), k                      # independent of the protocol / placement
+        den = max(float(ref[k].norm()), floor if k.startswith("grad:") else 1e-30)
+        err = float((got1[k] - ref[k]).norm()) / den
+        # measured at 640 rows: per-step buffers 3e-4 .. 9e-4 (bf16 rounding of the gate gradients after a different f32
+        # summation order), gradient tensors <= 6e-4
+        assert err < 5e-3, (k, err)
 
 
 @pytest.mark.parametrize("dtype", ["f32", "bf16"])

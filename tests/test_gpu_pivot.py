@@ -17,8 +17,11 @@ pytestmark = pytest.mark.gpu
 
 V, E, H, A, D, L, R = 9487, 512, 512, 512, 2048, 16, 36
 CAP = dict(V=V, E=E, H=H, A=A, D=D, L=L)
-NMT = dict(layers=2, H=512, W=512, B=8, S=L, T=2, Vs=50004, Vt=50004)
-STEPS = 9                                           # translator iterations (the oracle's 120 x 50 004 GEMM per step runs on the host)
+STEPS = 9                                           # translator iterations (the oracle's (15 B) x 50 004 GEMM per step runs on the host)
+
+
+def nmt_cfg(B):
+    return dict(layers=2, H=512, W=512, B=B, S=L, T=2, Vs=50004, Vt=50004)
 
 
 def to_source(seq):
@@ -29,23 +32,26 @@ def to_source(seq):
     return src
 
 
-@pytest.fixture(scope="module")
-def weights():
+@pytest.fixture(scope="module", params=[8, 64], ids=["B8", "B64"])       # 64 = BASELINE configs[2]'s batch
+def weights(request):
+    NMT = nmt_cfg(request.param)
     Wc = O.init_weights(V + 1, E, H, A, D, D, seed=3)
     Wc["logit.weight"] *= 30.0                      # a peaked word distribution ...
     Wc["logit.bias"][0] += 0.8                      # ... in which EOS (= 0) wins at once for the weakest images and never for the rest
     Wn = recipe_weights(NMT, 9, 0.25)
     Wn["generator.0.bias"][3] += 2.0               # sentences that end at different steps
     b = O.synthetic_batch(NMT["B"], 1, R, D, V, L, seed=21, ragged_regions=True)
-    sc = 1 + 2.0 * torch.arange(NMT["B"]).float()   # images of very different feature magnitude: the captions differ
+    sc = 1 + 2.0 * (torch.arange(NMT["B"]) % 8).float()   # images of very different feature magnitude: the captions differ
     b["att_feats"] = b["att_feats"] * sc[:, None, None]
     b["fc_feats"] = b["fc_feats"] * sc[:, None]
-    return Wc, Wn, b
+    return Wc, Wn, b, NMT
 
 
 @pytest.mark.parametrize("dtype", ["f32", "bf16"])
 def test_pivot_decode_captioner_beam_then_translate(weights, dtype):
-    Wc, Wn, b = weights
+    Wc, Wn, b, NMT = weights
+    nt = torch.get_num_threads()
+    torch.set_num_threads(min(16, nt))
     cap = build_model(CAP, Wc, dtype).eval()
     nmt, _ = build_nmt(NMT, Wn, dtype)
     nmt.eval()
@@ -64,6 +70,12 @@ def test_pivot_decode_captioner_beam_then_translate(weights, dtype):
     else:
         same = (seq.cpu() == seq_o).all(1).float().mean().item()
         assert same >= 0.5, same
+        # and the numbers of the device's OWN captions: the oracle, walked along the device's tokens, must give every recorded
+        # step log-prob (the beam's -1000 bookkeeping entries aside) within the bf16 tolerance
+        _, lp_f = O.sample(Wc, b["fc_feats"], b["att_feats"], b["att_masks"], L, sample_max=0, forced_tokens=seq.cpu())
+        live = (seq_lp.cpu() > -100) & (torch.cat([torch.ones(seq.shape[0], 1, dtype=torch.bool), seq.cpu()[:, :-1] > 0], 1))
+        # (logit.weight x 30 above: the logits span ~60 here, a bf16 rounding step of the hidden state moves one by 1.2e-2 measured)
+        assert (seq_lp.cpu() - lp_f)[live].abs().max().item() < 2e-2
     # stage 2 against the oracle's translator ON THE DEVICE'S pivot captions (so a bf16 tie-swap in stage 1 is not counted twice)
     hyp_o, scores_o, attn_o = ON.translate_batch(Wn, src.cpu(), max_steps=STEPS)
     got = torch.stack([s_[0] for s_ in allScores]).cpu()
@@ -79,4 +91,5 @@ def test_pivot_decode_captioner_beam_then_translate(weights, dtype):
         # (beam 15 over 50 004 near-tied words at random weights: bf16 swaps candidates, so token identity is only asked of
         # some sentences -- 3 of 8 measured -- while every final beam score must agree)
         n_same = sum(int(allHyp[k][0] == [int(t) for t in hyp_o[k]]) for k in range(NMT["B"]))
-        assert n_same >= 2, n_same
+        assert n_same >= max(2, NMT["B"] // 8), n_same
+    torch.set_num_threads(nt)

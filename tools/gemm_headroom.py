@@ -40,6 +40,19 @@ for name, M, N, K in [("logit fwd chunk", 2560, 9488, 512), ("att_embed fwd", 23
     ref = A[rows].float() @ B.float().t()
     err = float((Cu[rows][:, :N] - ref).abs().max() / ref.abs().max())
     print("%-44s %10.1f %10.1f %10.1f %10.1f   max rel err %.1e" % ("%s %dx%dx%d" % (name, M, N, K), t_lib, fl / t_lib / 1e6, t_uic, fl / t_uic / 1e6, err))
+print("%-44s %10s %10s" % ("NT split-K partials (uic_linear_partials)", "uic us", "uic TF/s"))
+for name, M, N, K, sk in [("BPTT d x2, 4 slices", 640, 1536, 2048, 4), ("BPTT d x2, 2 slices", 640, 1536, 2048, 2), ("BPTT d x2, 8 slices", 640, 1536, 2048, 8),
+                          ("BPTT d x1, 4 slices", 640, 1024, 2048, 4), ("BPTT d x1, 8 slices", 640, 1024, 2048, 8),
+                          ("logit dX chunk, 3 slices", 2560, 512, 9536, 3), ("logit dX chunk, 5 slices", 2560, 512, 9536, 5)]:
+    A = torch.randn(M, K, device="cuda", generator=g).bfloat16()
+    B = torch.randn(N, K, device="cuda", generator=g).bfloat16()
+    slab = torch.empty(sk, M, N, device="cuda", dtype=torch.float32)
+    t_uic = timeit(lambda: L.check(lib.uic_linear_partials(1, M, N, K, L.ptr(A), K, L.ptr(B), K, L.ptr(slab), sk, L.stream())))
+    rows = torch.arange(0, M, max(1, M // 256), device="cuda")
+    ref = A[rows].float() @ B.float().t()
+    err = float((slab.sum(0)[rows] - ref).abs().max() / ref.abs().max())
+    fl = 2.0 * M * N * K
+    print("%-44s %10.1f %10.1f   max rel err %.1e" % ("%s %dx%dx%d" % (name, M, N, K), t_uic, fl / t_uic / 1e6, err))
 print("%-44s %10s %10s %10s %10s" % ("TN shape  C[M,N] = A[K,M]^T B[K,N]", "lib us", "lib TF/s", "uic us", "uic TF/s"))
 wsb = 64 << 20
 wsp = torch.empty(wsb, dtype=torch.uint8, device="cuda")

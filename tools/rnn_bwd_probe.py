@@ -21,8 +21,6 @@ ap.add_argument("--iters", type=int, default=20)
 ap.add_argument("--ragged", action="store_true")
 ap.add_argument("--no-step", action="store_true")
 args = ap.parse_args()
-if args.dbg:
-    os.environ["UIC_PERSIST_DBG"] = "1"
 
 import torch
 from bench import CFG, make_opt
@@ -54,9 +52,15 @@ def fwd():
     return ws, d, w, b
 
 
+# mode 3: BPTT as six launches per step (the default), 4: the persistent BPTT kernel
+def set_mode(mode):
+    eng.recurrence = (L.REC_BWD_PERSIST if mode >= 4 else 0) | (L.REC_STAMPS if args.dbg else 0)
+
+
 def run(mode):
-    L.check(lib.uic_set_persistent_rnn(mode))
+    set_mode(mode)
     ws, d, w, b = fwd()
+    d = eng.dims(N, R, T, d.seq_per_img)
     grads = {k: torch.zeros_like(v) for k, v in params.items()}
     eng.backward(ws, d, w, b, t_run, True, 77, grads)
     torch.cuda.synchronize()
@@ -70,8 +74,9 @@ def run(mode):
 
 
 def time_backward(mode):
-    L.check(lib.uic_set_persistent_rnn(mode))
+    set_mode(mode)
     ws, d, w, b = fwd()
+    d = eng.dims(N, R, T, d.seq_per_img)
     grads = {k: torch.zeros_like(v) for k, v in params.items()}
     for _ in range(3):
         eng.backward(ws, d, w, b, t_run, True, 77, grads)
@@ -86,7 +91,7 @@ def time_backward(mode):
 
 
 def time_step(mode, steps=30):
-    L.check(lib.uic_set_persistent_rnn(mode))
+    set_mode(mode)
     for _ in range(5):
         loss, _ = trainer.xe_step(model, batch)
         loss.item()
@@ -148,5 +153,5 @@ if not args.no_step:
         res.setdefault("step_ms_mode%d" % mode, []).append(ms)
         print("fused step mode %d: %.3f ms   " % (mode, ms) + "  ".join("%s %.3f" % (n.split(":")[-1].strip(), v) for n, v in zip(names[1:], marks[1:])))
 print("status:", L.persistent_status())
-L.check(lib.uic_set_persistent_rnn(-1))
+eng.recurrence = 0
 print(json.dumps(res))

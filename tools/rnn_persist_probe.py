@@ -21,8 +21,6 @@ ap.add_argument("--dbg", action="store_true")
 ap.add_argument("--iters", type=int, default=20)
 ap.add_argument("--ragged", action="store_true")
 args = ap.parse_args()
-if args.dbg:
-    os.environ["UIC_PERSIST_DBG"] = "1"
 
 import torch
 from bench import CFG, make_opt
@@ -47,8 +45,12 @@ NAMES = [("h_att", (T + 1, N, H), td), ("h_lang", (T + 1, N, H), td), ("c_att", 
          ("ctx", (T, N, H), td), ("hdrop", (T, N, H), td), ("gates1", (T, N, 4 * H), td), ("gates2", (T, N, 4 * H), td)]
 
 
+# mode: 0 per-step launches, 1 persistent kernel, 2 persistent kernel with the SAFE exchange protocol
+REC = {0: L.REC_FWD_CHAIN, 1: 0, 2: L.REC_SAFE}
+
+
 def run(mode, want_lp=True):
-    L.check(lib.uic_set_persistent_rnn(mode))
+    eng.recurrence = REC[mode] | (L.REC_STAMPS if args.dbg else 0)
     logp, ws, _ = eng.forward(params, batch["fc_feats"], batch["att_feats"], batch["att_masks"] if args.ragged else None,
                               batch["labels"], t_run, args.train, 77, want_logprobs=want_lp)
     out = {n: eng.workspace_tensor(ws, n, shp, dt)[: (t_run + 1 if shp[0] == T + 1 else t_run)].float().clone() for n, shp, dt in NAMES}
@@ -63,7 +65,7 @@ def run(mode, want_lp=True):
 
 
 def timeit(mode):
-    L.check(lib.uic_set_persistent_rnn(mode))
+    eng.recurrence = REC[mode]
     for _ in range(3):
         _, ws, _ = eng.forward(params, batch["fc_feats"], batch["att_feats"], None, batch["labels"], t_run, args.train, 77, want_logprobs=False)
         eng.release(ws)
@@ -97,17 +99,7 @@ for mode in (1, 2):
             seg = d[:, :, k + 1] - d[:, :, k]
             print("   phase %-6s mean %6.2f us   median %6.2f   max over WGs (mean over t) %6.2f" %
                   (names[k], seg.mean().item(), seg.median().item(), seg.max(dim=0)[0].mean().item()))
-        if int(os.environ.get("UIC_PERSIST_EXP", "0")) & 64:
-            r = dbg[:, :t_run].double()
-            print("   load latency after bar3 (cycles, median / p90 over WGs and steps): first sc1 %.0f / %.0f, second sc1 %.0f / %.0f, plain %.0f / %.0f" %
-                  tuple(x for k in (8, 9, 10) for x in (r[:, :, k].median().item(), r[:, :, k].flatten().kthvalue(int(0.9 * r[:, :, k].numel()))[0].item())))
-        elif int(os.environ.get("UIC_PERSIST_EXP", "0")) & 32:
-            r = dbg[:, :t_run].double()
-            cyc = lambda a, b: (r[:, :, b] - r[:, :, a]).median().item()
-            tot_c, tot_t = cyc(8, 12), (r[:, :, 14] - r[:, :, 13]).median().item() * 10e-3
-            print("   P4 pass 1 (wave 0, shader cycles): MFMA loop %.0f, LDS writes %.0f, barrier wait %.0f, cell update %.0f; total %.0f cycles in %.2f us -> %.2f GHz" %
-                  (cyc(8, 9), cyc(9, 10), cyc(10, 11), cyc(11, 12), tot_c, tot_t, tot_c / tot_t / 1e3))
-        elif os.environ.get("UIC_PERSIST_WS", "1") != "0" and args.dtype == "bf16":
+        if args.dtype == "bf16":
             def seg(a, b):
                 return (d[:, :, b] - d[:, :, a]).mean().item()
             print("   lstm1 (wave 0): loads+MFMA of own tile %.2f, cell %.2f, fifth tile %.2f" % (seg(0, 8), seg(8, 9), seg(9, 1)))

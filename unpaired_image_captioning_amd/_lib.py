@@ -20,7 +20,12 @@ SITE_SS_MASK0, SITE_SS_DRAW0 = 512, 768          # + decode step
 
 
 class Dims(C.Structure):
-    _fields_ = [(n, C.c_int32) for n in ("N", "R", "D", "Dfc", "H", "E", "A", "V1", "T", "dtype")] + [("drop_p", C.c_float), ("use_bn", C.c_int32), ("seq_per_img", C.c_int32), ("logit_layers", C.c_int32)]
+    _fields_ = [(n, C.c_int32) for n in ("N", "R", "D", "Dfc", "H", "E", "A", "V1", "T", "dtype")] + [("drop_p", C.c_float), ("use_bn", C.c_int32), ("seq_per_img", C.c_int32), ("logit_layers", C.c_int32),
+                                                                                                  ("recurrence", C.c_int32), ("rnn_status", C.c_void_p)]
+
+
+# uic_topdown_dims.recurrence (include/uic_hip.h)
+REC_FWD_CHAIN, REC_BWD_PERSIST, REC_SAFE, REC_STAMPS = 1, 2, 4, 8
 
 
 MAX_LOGIT_LAYERS = 4
@@ -192,7 +197,6 @@ class Batch(C.Structure):
 _SIGS = {
     "uic_last_error_string": (C.c_char_p, []),
     "uic_version": (C.c_int, []),
-    "uic_set_persistent_rnn": (C.c_int, [C.c_int32]),
     "uic_comm_unique_id": (C.c_int, [C.c_void_p]),
     "uic_gcn_workspace_bytes": (C.c_size_t, [C.POINTER(GcnDims)]),
     "uic_gcn_forward": (C.c_int, [C.POINTER(GcnDims), C.POINTER(GcnWeights), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
@@ -208,7 +212,6 @@ _SIGS = {
     "uic_comm_allreduce": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int32, C.c_void_p]),
     "uic_comm_destroy": (C.c_int, [C.c_void_p]),
     "uic_topdown_step_marks": (C.c_int, [C.c_int32, C.POINTER(C.c_float)]),
-    "uic_set_persistent_status": (C.c_int, [C.c_void_p]),
     "uic_topdown_workspace_bytes": (C.c_size_t, [C.POINTER(Dims)]),
     "uic_topdown_derived_bytes": (C.c_size_t, [C.POINTER(Dims)]),
     "uic_topdown_refresh_weights": (C.c_int, [C.POINTER(Dims), C.POINTER(Weights), C.c_void_p, C.c_void_p]),
@@ -259,6 +262,7 @@ _SIGS = {
     "uic_topdown_workspace_ptr": (C.c_void_p, [C.POINTER(Dims), C.c_void_p, C.c_char_p]),
     "uic_linear": (C.c_int, [C.c_int32] * 4 + [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32,
                              C.c_void_p, C.c_int32, C.c_void_p]),
+    "uic_linear_partials": (C.c_int, [C.c_int32] * 4 + [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p]),
     "uic_ciderd_table_slots": (C.c_int64, [C.c_int64]),
     "uic_ciderd_table_build": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int64]),
     "uic_ciderd_scores": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p,
@@ -315,17 +319,23 @@ def load():
 _status = {}
 
 
-def persistent_status(device=None):
-    """The sticky status words of the persistent recurrence kernel on `device` (registered on first use) as a list
-    [timeout code, XCD-local launches, SAFE launches]; synchronises.  A non-zero timeout code raises."""
-    lib = load()
+def status_words(device=None):
+    """The 4 status words of the persistent recurrence kernels on `device` (a device tensor, allocated on first use): what
+    TopDownEngine.dims() hands the library as uic_topdown_dims.rnn_status."""
     dev = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
     idx = dev.index if dev.index is not None else torch.cuda.current_device()
-    first = idx not in _status
-    if first:
+    if idx not in _status:
         with torch.cuda.device(idx):
             _status[idx] = torch.zeros(4, dtype=torch.int32, device="cuda:%d" % idx)
-            check(lib.uic_set_persistent_status(_status[idx].data_ptr()), "set_persistent_status")
+    return _status[idx]
+
+
+def persistent_status(device=None):
+    """[timeout code, XCD-local launches, SAFE launches] of the persistent recurrence kernels on `device`; synchronises.
+    A non-zero timeout code raises (and is cleared)."""
+    dev = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+    idx = dev.index if dev.index is not None else torch.cuda.current_device()
+    status_words(dev)
     vals = [int(v) for v in _status[idx].cpu().tolist()]
     if vals[0] != 0:
         _status[idx].zero_()

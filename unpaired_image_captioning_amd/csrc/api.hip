@@ -97,6 +97,18 @@ int uic_linear(int32_t dtype, int32_t M, int32_t N, int32_t K, const void* A, in
   return uic_gemm_launch(g, (hipStream_t)stream);
 }
 
+int uic_linear_partials(int32_t dtype, int32_t M, int32_t N, int32_t K, const void* A, int32_t lda, const void* B, int32_t ldb,
+                        float* slab, int32_t splitk, void* stream) {
+  UIC_REQUIRE(slab && splitk >= 1 && splitk <= 16, "linear_partials: slab / splitk=%d", splitk);
+  UIC_REQUIRE(uic_gemm_glds_eligible(dtype, K), "linear_partials: K=%d must be a multiple of one 128-byte round", K);
+  UicGemmParams g;
+  memset(&g, 0, sizeof(g));
+  g.dtype = dtype; g.M = M; g.N = N; g.nseg = 1;
+  g.seg[0].A = A; g.seg[0].B = B; g.seg[0].K = K; g.seg[0].lda = lda; g.seg[0].ldb = ldb;
+  g.slab = slab; g.splitk = splitk;
+  return uic_gemm_launch(g, (hipStream_t)stream);
+}
+
 int uic_linear_wgrad(int32_t dtype, int32_t M, int32_t N, int32_t K, const void* dY, int32_t ldy, const void* X, int32_t ldx,
                      float* dW, int32_t ldw, void* workspace, size_t workspace_bytes, int32_t accumulate, void* stream) {
   UIC_REQUIRE(dY && X && dW && workspace, "linear_wgrad: null pointer");

@@ -737,8 +737,7 @@ int launch_typed(const UicGemmParams& p, hipStream_t s) {
   if (blocks128 >= 200) return launch_cfg<T, 1 + 1, 2, 2, 2, 1, false>(p, s);
   // one row tile (M <= 64: the pivot NMT's per-step GEMMs at batch 64) with a long reduction: 8-way in-block K split on a
   // 64 x 32 tile -- the chain of dependent K rounds is what such a launch takes, and twice as many workgroups share the columns
-  static const int ks8 = getenv("UIC_GEMM_KS8") ? atoi(getenv("UIC_GEMM_KS8")) : 1;
-  if (ks8 && p.M <= 64) {
+  if (p.M <= 64) {
     int ktot = 0;
     for (int i = 0; i < p.nseg; ++i) ktot += p.seg[i].K;
     if (ktot * (int)sizeof(T) >= 2048) return launch_cfg<T, 1, 1, 2, 1, 8, false>(p, s);   // (K = 512 launches: no gain measured)

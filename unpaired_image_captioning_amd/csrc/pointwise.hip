@@ -1510,9 +1510,8 @@ int uic_lstm_bwd_launch(const UicLstmBwdParams& p, hipStream_t s) {
   UIC_REQUIRE(p.dc && p.gates && p.c && p.dgates, "lstm_bwd: null pointer");
   if (p.M == 0) return UIC_OK;
   auto al16 = [](const void* q) { return ((uintptr_t)q & 15) == 0; };
-  static const bool vec_on = getenv("UIC_LSTM_BWD_VEC") ? atoi(getenv("UIC_LSTM_BWD_VEC")) != 0 : true;
   // (small problems -- the pivot NMT's 64 rows -- keep one unit per lane: four times the workgroups, measured faster there)
-  const bool vec = vec_on && (size_t)p.M * p.H >= 65536 && p.H % 4 == 0 && al16(p.dc) && al16(p.c) && (!p.c_prev || al16(p.c_prev)) &&
+  const bool vec = (size_t)p.M * p.H >= 65536 && p.H % 4 == 0 && al16(p.dc) && al16(p.c) && (!p.c_prev || al16(p.c_prev)) &&
                    ((uintptr_t)p.gates & 7) == 0 && ((uintptr_t)p.dgates & 7) == 0 && (p.dtype == UIC_BF16 || (al16(p.gates) && al16(p.dgates))) &&
                    (!p.dh0 || (al16(p.dh0) && p.lddh0 % 4 == 0)) && (!p.dh1 || (al16(p.dh1) && p.lddh1 % 4 == 0)) &&
                    (!p.dh2 || (al16(p.dh2) && p.lddh2 % 4 == 0)) && (size_t)p.M * p.H < ((size_t)1 << 32) && p.M <= 65535;
@@ -1538,8 +1537,7 @@ int uic_xe_launch(const UicXeParams& p, hipStream_t s) {
   UIC_REQUIRE(!p.target || p.row_loss, "xe: null row_loss");
   if (p.M == 0) return UIC_OK;
   const size_t row_bytes = (size_t)p.ldv * 4;
-  static const bool xe_reg_on = !(getenv("UIC_XE_REG") && !atoi(getenv("UIC_XE_REG")));
-  if (xe_reg_on && p.dtype == UIC_BF16 && p.ldv % 4 == 0 && p.ldv <= XE_RCH * NT * 4 && ((uintptr_t)p.logits & 15) == 0 && p.write_grad && p.target &&
+  if (p.dtype == UIC_BF16 && p.ldv % 4 == 0 && p.ldv <= XE_RCH * NT * 4 && ((uintptr_t)p.logits & 15) == 0 && p.write_grad && p.target &&
       !p.logprobs && !p.score_stats && ((uintptr_t)p.dlogits & 7) == 0) {
     hipLaunchKernelGGL(xe_reg_kernel<bf16_t>, dim3(p.M), dim3(NT), 0, s, p, p.logits, (bf16_t*)p.dlogits);
     UIC_LAUNCH_CHECK("xe_reg_kernel");

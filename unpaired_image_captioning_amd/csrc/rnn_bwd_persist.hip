@@ -501,8 +501,6 @@ int uic_rnn_bwd_persist_launch(const UicRnnBwdParams& p0, hipStream_t s) {
     UicRnnBwdParams p = p0;
     p.row0 = r0;
     p.Nrows = p0.N - r0 < cap ? p0.N - r0 : cap;
-    p.force_safe = uic_rnn_persist_mode() == 2;
-    p.status = uic_rnn_persist_status_word();
     p.sync = p0.sync + (size_t)(r0 / cap) * SY_WORDS;
     if (!p0.sync_zeroed) UIC_TRY(uic_check_hip(hipMemsetAsync(p.sync, 0, (size_t)SY_WORDS * 4, s), "hipMemsetAsync(rnn bwd sync)"));
     hipLaunchKernelGGL(rnn_bwd_persist_kernel, dim3(G * PW), dim3(BW_NTH), BW_LDS_BYTES, s, p);

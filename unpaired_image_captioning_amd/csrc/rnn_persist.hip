@@ -544,14 +544,14 @@ __device__ __forceinline__ void ws_cell(const Ctx& c, int tile, const f32x4 (&s)
     if (rr < c.nrow) {
       const unsigned nn = (unsigned)((c.rbegin + rr) * HH);
       const unsigned o = nn + u;
-      if (!(c.exp & 8)) c_out[o] = cn;
+      c_out[o] = cn;
       st_x<SAFE>(h_out + o, h);
-      if (h_drop && !(c.exp & 8)) {
+      if (h_drop) {
         float hd = h;
         if (drop_p > 0.f) hd *= uic_drop_scale(seed, site, o, drop_p, inv_keep);
         h_drop[o] = (bf16_t)hd;
       }
-      if (gates_out && !(c.exp & 4)) {
+      if (gates_out) {
         const unsigned og = 4u * nn + u;
         __builtin_nontemporal_store((bf16_t)gi, gates_out + og);
         __builtin_nontemporal_store((bf16_t)gf, gates_out + og + HH);
@@ -865,21 +865,6 @@ __device__ __forceinline__ void ws_run(const UicRnnFwdParams& p, Ctx& c, char* l
     if (dbg && c.tid == 0) dbg[5] = __builtin_amdgcn_s_memrealtime();
     if (!group_barrier(c)) return;
     if (dbg && c.tid == 0) dbg[6] = __builtin_amdgcn_s_memrealtime();
-    if (dbg && (c.exp & 64) && c.wave == 0) {
-      // latency probe: one sc1 load of fresh exchanged data (ctx of another workgroup's row), then one of a second line,
-      // then a plain load of a third line
-      const unsigned long long t0 = __builtin_amdgcn_s_memtime();
-      u32x4 v = bload<true>(rx, (unsigned)(c.lane * 16), o_ctx + 0u);
-      asm volatile("s_waitcnt vmcnt(0)" : "+v"(v));
-      const unsigned long long t1 = __builtin_amdgcn_s_memtime();
-      u32x4 v2 = bload<true>(rx, (unsigned)(c.lane * 16), o_ctx + 1024u * 7);
-      asm volatile("s_waitcnt vmcnt(0)" : "+v"(v2));
-      const unsigned long long t2 = __builtin_amdgcn_s_memtime();
-      u32x4 v3 = bload<false>(rx, (unsigned)(c.lane * 16), o_ctx + 1024u * 13);
-      asm volatile("s_waitcnt vmcnt(0)" : "+v"(v3));
-      const unsigned long long t3 = __builtin_amdgcn_s_memtime();
-      if (c.tid == 0) { dbg[8] = t1 - t0; dbg[9] = t2 - t1; dbg[10] = t3 - t2 + ((v.x ^ v2.x ^ v3.x) == 0x12345 ? 1 : 0); }
-    }
     asm volatile("" : "+v"(c.lane), "+v"(c.l15), "+v"(c.lq), "+v"(c.tid));   // keep this phase's lane-derived values out of the others' live ranges
     // ---- lang_lstm (:438-441) + output dropout (:443): K split over the waves (stationary fragments in registers), one row
     // tile per pass; pass i writes its partial tiles to LDS half i & 1, ONE barrier, then the tile's owner sums and finishes
@@ -932,8 +917,6 @@ __device__ __forceinline__ void ws_run(const UicRnnFwdParams& p, Ctx& c, char* l
 #if WS_EARLY_PRE
           if (!more && t + 1 < p.t1) load_pre(t + 1, c.wave, pvn, cpn);   // last pass: no later request of this phase waits behind these
 #endif
-          const bool prof = dbg && c.tid == 0 && i == 1 && (c.exp & 32);
-          if (prof) { dbg[8] = __builtin_amdgcn_s_memtime(); dbg[13] = __builtin_amdgcn_s_memrealtime(); }
           f32x4 acc[4];
 #pragma unroll
           for (int j = 0; j < 12; ++j) {
@@ -945,14 +928,11 @@ __device__ __forceinline__ void ws_run(const UicRnnFwdParams& p, Ctx& c, char* l
             if (more) load_frag(j, an);
           }
           asm volatile("s_nop 7\n\ts_nop 7" : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3]));
-          if (prof) dbg[9] = __builtin_amdgcn_s_memtime();
           f32x4* half = scr + (i & 1) * (WS_NW * 4 * 64);
 #pragma unroll
           for (int g = 0; g < 4; ++g) half[(c.wave * 4 + g) * 64 + c.lane] = acc[g];
-          if (prof) dbg[10] = __builtin_amdgcn_s_memtime();
           __syncthreads();
-          if (prof) dbg[11] = __builtin_amdgcn_s_memtime();
-          if (dbg && c.tid == 0 && !(c.exp & 32)) dbg[11 + i] = __builtin_amdgcn_s_memrealtime();
+          if (dbg && c.tid == 0) dbg[11 + i] = __builtin_amdgcn_s_memrealtime();
           {
             // every wave sums component `wave` of the four partial tiles (fixed order: deterministic) and finishes that row
             float sg4[4];
@@ -977,14 +957,14 @@ __device__ __forceinline__ void ws_run(const UicRnnFwdParams& p, Ctx& c, char* l
             if (rr < c.nrow) {
               const unsigned nn = (unsigned)((c.rbegin + rr) * HH);
               const unsigned o = nn + u;
-              if (!(c.exp & 8)) p.c_lang[(size_t)(t + 1) * NH + o] = cn;
+              p.c_lang[(size_t)(t + 1) * NH + o] = cn;
               st_x<SAFE>(h_lang_new + o, h);
-              if (p.hdrop_all && !(c.exp & 8)) {
+              if (p.hdrop_all) {
                 float hd = h;
                 if (p.drop_p > 0.f) hd *= uic_drop_scale(p.seed, UIC_SITE_OUT0 + (unsigned)t, o, p.drop_p, 1.f / (1.f - p.drop_p));
                 ((T*)p.hdrop_all)[(size_t)t * NH + o] = (bf16_t)hd;
               }
-              if (p.gates2 && !(c.exp & 4)) {
+              if (p.gates2) {
                 T* G = (T*)p.gates2 + (size_t)t * N * 4 * HH + 4u * nn + u;
                 __builtin_nontemporal_store((bf16_t)gi, G);
                 __builtin_nontemporal_store((bf16_t)gf, G + HH);
@@ -993,7 +973,6 @@ __device__ __forceinline__ void ws_run(const UicRnnFwdParams& p, Ctx& c, char* l
               }
             }
           }
-          if (prof) { dbg[12] = __builtin_amdgcn_s_memtime(); dbg[14] = __builtin_amdgcn_s_memrealtime(); }
         }
       }
       __syncthreads();                              // the scratch halves are free again (barrier flag, next step)
@@ -1013,45 +992,12 @@ __global__ __launch_bounds__(WS_NTH) void rnn_fwd_persist_ws_kernel(const UicRnn
   else ws_run<false>(p, c, smem);
 }
 
-unsigned* g_status[16] = {};   // caller-allocated sticky status words per device (uic_set_persistent_status)
-int g_persist_mode = -1;     // -1: read UIC_PERSIST (default 3); see uic_set_persistent_rnn in include/uic_hip.h
-
 }  // namespace
-
-unsigned* uic_rnn_persist_status_word() {
-  int dev = 0;
-  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return nullptr;
-  return g_status[dev];
-}
-
-extern "C" int uic_set_persistent_rnn(int32_t mode) {
-  UIC_REQUIRE(mode >= -1 && mode <= 4, "set_persistent_rnn: mode=%d must be -1 (default), 0 (off), 1 (forward calls), 2 (forward calls, SAFE protocol), 3 (also the fused training step) or 4 (also the BPTT loop)", mode);
-  g_persist_mode = mode;
-  return UIC_OK;
-}
-
-extern "C" int uic_set_persistent_status(void* status) {
-  int dev = 0;
-  UIC_TRY(uic_check_hip(hipGetDevice(&dev), "hipGetDevice"));
-  UIC_REQUIRE(dev >= 0 && dev < 16, "device index %d out of range", dev);
-  g_status[dev] = (unsigned*)status;
-  return UIC_OK;
-}
-
-int uic_rnn_persist_mode() {
-  if (g_persist_mode < 0) {
-    const char* e = getenv("UIC_PERSIST");
-    g_persist_mode = e ? atoi(e) : 3;
-    if (g_persist_mode < 0 || g_persist_mode > 4) g_persist_mode = 3;
-  }
-  return g_persist_mode;
-}
 
 constexpr int MAX_SLABS = 8;       // launches of <= 640 caption rows each
 size_t uic_rnn_persist_sync_bytes() { return (size_t)MAX_SLABS * SY_WORDS * 4; }
 
 bool uic_rnn_persist_eligible(int dtype, int N, int H, int A, int R) {
-  if (!uic_rnn_persist_mode()) return false;
   if (dtype != UIC_BF16 && dtype != UIC_F32) return false;
   if (H != HH || A != HH || R < 1 || R > ATT_R || N < 1 || N > MAX_SLABS * 8 * 16 * MT_MAX) return false;
   static int cus = -1;
@@ -1068,7 +1014,6 @@ int uic_rnn_fwd_persist_launch(const UicRnnFwdParams& p0, hipStream_t s) {
   UIC_REQUIRE(p0.sync && p0.t1 > p0.t0 && p0.N > 0, "rnn_fwd_persist: bad arguments");
   static bool configured = false;
   if (!configured) {
-    UIC_TRY(uic_check_hip(hipFuncSetAttribute((const void*)rnn_fwd_persist_kernel<bf16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES), "hipFuncSetAttribute(rnn persist)"));
     UIC_TRY(uic_check_hip(hipFuncSetAttribute((const void*)rnn_fwd_persist_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES), "hipFuncSetAttribute(rnn persist)"));
     UIC_TRY(uic_check_hip(hipFuncSetAttribute((const void*)rnn_fwd_persist_ws_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, WS_LDS_BYTES), "hipFuncSetAttribute(rnn persist ws)"));
     configured = true;
@@ -1078,7 +1023,6 @@ int uic_rnn_fwd_persist_launch(const UicRnnFwdParams& p0, hipStream_t s) {
     UicRnnFwdParams p = p0;
     p.row0 = r0;
     p.Nrows = p0.N - r0 < cap ? p0.N - r0 : cap;
-    p.force_safe = uic_rnn_persist_mode() == 2;
     {
       const char* lo = (const char*)p.h_att;
       if ((const char*)p.h_lang < lo) lo = (const char*)p.h_lang;
@@ -1088,16 +1032,10 @@ int uic_rnn_fwd_persist_launch(const UicRnnFwdParams& p0, hipStream_t s) {
         UIC_REQUIRE((size_t)(ends[k] - lo) + (size_t)(p.t1 + 1) * p.N * HH * 4 < ((size_t)1 << 32), "rnn_fwd_persist: the state slabs must lie within 4 GB of each other");
       p.xbase = lo;
     }
-    {
-      int dev = 0;
-      UIC_TRY(uic_check_hip(hipGetDevice(&dev), "hipGetDevice"));
-      p.status = dev >= 0 && dev < 16 ? g_status[dev] : nullptr;
-    }
     p.sync = p0.sync + (size_t)(r0 / cap) * SY_WORDS;
     UIC_TRY(uic_check_hip(hipMemsetAsync(p.sync, 0, (size_t)SY_WORDS * 4, s), "hipMemsetAsync(rnn sync)"));
-    static const bool ws_on = !(getenv("UIC_PERSIST_WS") && atoi(getenv("UIC_PERSIST_WS")) == 0);
-    if (p.dtype == UIC_BF16 && ws_on) hipLaunchKernelGGL(rnn_fwd_persist_ws_kernel, dim3(G * PW), dim3(WS_NTH), WS_LDS_BYTES, s, p);
-    else if (p.dtype == UIC_BF16) hipLaunchKernelGGL(rnn_fwd_persist_kernel<bf16_t>, dim3(G * PW), dim3(NTH), LDS_BYTES, s, p);
+    // bf16: the weight-stationary kernel; f32 (the parity path): the generic one, weights re-read from L2 every step
+    if (p.dtype == UIC_BF16) hipLaunchKernelGGL(rnn_fwd_persist_ws_kernel, dim3(G * PW), dim3(WS_NTH), WS_LDS_BYTES, s, p);
     else hipLaunchKernelGGL(rnn_fwd_persist_kernel<float>, dim3(G * PW), dim3(NTH), LDS_BYTES, s, p);
     UIC_LAUNCH_CHECK("rnn_fwd_persist_kernel");
   }

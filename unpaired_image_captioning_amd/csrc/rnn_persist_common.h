@@ -48,7 +48,7 @@ struct Ctx {
   int rbegin, nrow, MT;
   unsigned* bar; unsigned* err; unsigned* status; unsigned bar_target;
   char* smem;
-  unsigned long long* dbg; int exp;
+  unsigned long long* dbg;
 };
 
 // Bounded group barrier in two halves, so that loads which do not depend on the exchange can be issued between them
@@ -89,7 +89,7 @@ __device__ __forceinline__ bool group_barrier(Ctx& c) {
   return group_wait(c, (int*)c.smem);
 }
 
-// Registration + grouping.  P: a parameter block with sync / status / force_safe / row0 / Nrows / exp.
+// Registration + grouping.  P: a parameter block with sync / status / force_safe / row0 / Nrows.
 // Returns 0 (leave), 1 (XCD-local protocol) or 2 (SAFE protocol).
 template <typename P>
 __device__ __forceinline__ int setup_ctx(const P& p, char* scratch, Ctx& c) {
@@ -145,7 +145,7 @@ __device__ __forceinline__ int setup_ctx(const P& p, char* scratch, Ctx& c) {
   c.status = p.status;
   c.bar_target = 0;
   c.smem = scratch;
-  c.dbg = nullptr; c.exp = p.exp;
+  c.dbg = nullptr;
   return safe ? 2 : 1;
 }
 

@@ -727,15 +727,14 @@ struct Step {
 
   // decode steps [t0, t1) of the recurrence: one persistent launch (rnn_persist.hip) when the shapes allow, else the
   // per-step chain.  Scheduled sampling needs the logits of step t - 1 on the host-sequenced path.
-  // `fused`: called from the two-stream training step.  There the per-step launches win: the persistent kernel holds
-  // every CU (160 KB of LDS, the whole register file), so the logit layer on the side stream can no longer run beside the
-  // recurrence, and what the recurrence saves (1.02 -> 0.83 ms) is less than the overlap that is lost (measured 4.25 vs
-  // 4.49 ms per step).  Mode 3 forces it there for experiments.
-  bool persist_ok(bool fused) const {
-    return !ss_on() && uic_rnn_persist_eligible(dt, N, H, A, R) && (!fused || uic_rnn_persist_mode() >= 3);
+  // The persistent kernel holds every CU (160 KB of LDS, the whole register file): inside the two-stream training step the
+  // logit layer cannot run beside it; it follows chunk by chunk, last chunk first, beside the BPTT loop (see
+  // uic_topdown_xe_train_step).  d.recurrence & UIC_REC_FWD_CHAIN keeps the per-step launches.
+  bool persist_ok() const {
+    return !ss_on() && !(d.recurrence & UIC_REC_FWD_CHAIN) && uic_rnn_persist_eligible(dt, N, H, A, R);
   }
-  int fwd_steps(int t0, int t1, hipStream_t s, bool fused = false) {
-    if (!persist_ok(fused)) {
+  int fwd_steps(int t0, int t1, hipStream_t s) {
+    if (!persist_ok()) {
       for (int t = t0; t < t1; ++t) UIC_TRY(fwd_step(t, s));
       return UIC_OK;
     }
@@ -755,10 +754,8 @@ struct Step {
     p.att_h_all = L.atth_all; p.alpha_all = L.alpha_all; p.ctx_all = L.ctx_all; p.hdrop_all = L.hdrop_all;
     p.drop_p = drop_p; p.seed = seed;
     p.sync = L.rnn_sync;
-    static const bool dbg_on = getenv("UIC_PERSIST_DBG") != nullptr;
-    p.dbg = dbg_on ? L.rnn_dbg : nullptr; p.dbg_T = d.T;
-    static const int exp_flags = getenv("UIC_PERSIST_EXP") ? atoi(getenv("UIC_PERSIST_EXP")) : 0;
-    p.exp = exp_flags;
+    p.force_safe = (d.recurrence & UIC_REC_SAFE) != 0; p.status = d.rnn_status;
+    p.dbg = (d.recurrence & UIC_REC_STAMPS) ? L.rnn_dbg : nullptr; p.dbg_T = d.T;
     return uic_rnn_fwd_persist_launch(p, s);
   }
 
@@ -849,7 +846,7 @@ struct Step {
 
   // BPTT of decode steps [t_lo, t_hi), latest first: ONE persistent launch (rnn_bwd_persist.hip) when the shapes allow, else
   // the chain of six launches per step.  Either may continue where the other stopped (same carry buffers).
-  bool bwd_persist_ok() const { return uic_rnn_persist_mode() >= 4 && uic_rnn_bwd_persist_eligible(dt, N, H, A, R); }
+  bool bwd_persist_ok() const { return (d.recurrence & UIC_REC_BWD_PERSIST) && uic_rnn_bwd_persist_eligible(dt, N, H, A, R); }
   int bwd_launches = 0;
   int bwd_steps(int t_lo, int t_hi, hipStream_t s) {
     if (!bwd_persist_ok()) {
@@ -870,8 +867,8 @@ struct Step {
     p.sync = L.rnn_bwd_sync + (size_t)bwd_launches * (uic_rnn_persist_sync_bytes() / 4);
     p.sync_zeroed = 1;                 // (bwd_begin zeroed every launch's block of this step)
     ++bwd_launches;
-    static const bool dbg_on = getenv("UIC_PERSIST_DBG") != nullptr;
-    p.dbg = dbg_on ? L.rnn_bwd_dbg : nullptr; p.dbg_T = d.T;
+    p.force_safe = (d.recurrence & UIC_REC_SAFE) != 0; p.status = d.rnn_status;
+    p.dbg = (d.recurrence & UIC_REC_STAMPS) ? L.rnn_bwd_dbg : nullptr; p.dbg_T = d.T;
     return uic_rnn_bwd_persist_launch(p, s);
   }
 
@@ -991,8 +988,7 @@ struct Step {
   // true when EVERY chunk's LSTM weight-gradient GEMM takes the direct transposing-read (TN) path with room for one more
   // 128-column segment: bf16, whole 64-row K rounds per decode step, 128-multiples everywhere
   bool bias_in_chunks() const {
-    static const bool on = !(getenv("UIC_BIAS_IN_CHUNKS") && !atoi(getenv("UIC_BIAS_IN_CHUNKS")));
-    return on && dt == UIC_BF16 && N % 64 == 0 && H % 128 == 0 && E % 128 == 0 && (3 * H + 128) / 128 * (H4 / 128) >= 160 && (2 * H + E + 128) / 128 * (H4 / 128) >= 160;
+    return dt == UIC_BF16 && N % 64 == 0 && H % 128 == 0 && E % 128 == 0 && (3 * H + 128) / 128 * (H4 / 128) >= 160 && (2 * H + E + 128) / 128 * (H4 / 128) >= 160;
   }
 
   // chunked == true: wgrad_chunk already produced the LSTM / h2att weight gradients
@@ -1292,34 +1288,29 @@ int uic_topdown_xe_train_step(const uic_topdown_dims* d, const uic_topdown_weigh
   UIC_HIP(hipStreamWaitEvent(s2, ss->ev_den, 0));
   // the prologue's two independent branches side by side: att_embed + ctx2att here, fc_embed + embedding + the batched
   // input GEMM on the side stream (idle until the recurrence is through; its part of the weight refresh comes first there)
-  static const bool fork_prologue = getenv("UIC_FORK_PROLOGUE") ? atoi(getenv("UIC_FORK_PROLOGUE")) != 0 : true;
   // training bit 2: the workspace already holds this forward pass (uic_topdown_sample_train drew b->labels with these
   // weights, this seed and these dims): the step starts at the criterion
   const bool resume = (training & 4) != 0;
   UIC_REQUIRE(!resume || !st.ss_on(), "xe_train_step: a resumed step cannot use scheduled sampling");
-  if (resume) {
-  } else if (fork_prologue) {
+  if (!resume) {
     UIC_TRY(st.fwd_prologue(s2, 1));
     UIC_HIP(hipEventRecord(ss->ev_pro, s2));
     UIC_TRY(flush_transposes(ss));                    // (behind the branch: only the backward pass reads them)
     UIC_TRY(st.fwd_prologue(s, 2));
     UIC_HIP(hipStreamWaitEvent(s, ss->ev_pro, 0));
     if (ss->cast_recorded) UIC_HIP(hipStreamWaitEvent(s, ss->ev_cast, 0));   // the recurrence reads copies made on the side stream
-  } else {
-    UIC_TRY(st.fwd_prologue(s));
-    UIC_TRY(wait_refresh(s));                         // the recurrence needs the side-stream half of the weight refresh
   }
   UIC_MARK(1, s);
   // persistent mode 3: the whole recurrence as ONE launch (it holds every CU, nothing overlaps it); the logit layer follows
   // chunk by chunk on the side stream beside the BPTT loop
-  const bool one_launch = resume || st.persist_ok(true);
-  if (one_launch) { if (!resume) UIC_TRY(st.fwd_steps(0, t_run, s, true)); UIC_MARK(2, s); }
+  const bool one_launch = resume || st.persist_ok();
+  if (one_launch) { if (!resume) UIC_TRY(st.fwd_steps(0, t_run, s)); UIC_MARK(2, s); }
   for (int i = 0; i < nchunk; ++i) {
     // after a single launch every step is there at once: the logit layer then takes the chunks LAST FIRST, the order the
     // BPTT loop consumes them in, so that loop starts after one chunk instead of after all of them
     const int c = one_launch ? nchunk - 1 - i : i;
     const int t0 = c * CH, t1 = t0 + CH < t_run ? t0 + CH : t_run;
-    if (!one_launch) UIC_TRY(st.fwd_steps(t0, t1, s, true));
+    if (!one_launch) UIC_TRY(st.fwd_steps(t0, t1, s));
     if (!one_launch || i == 0) UIC_HIP(hipEventRecord(ss->ev_main[c], s));
     // side: logit layer of the chunk, forward and backward-to-h (beside the next chunk's recurrence)
     if (!one_launch || i == 0) UIC_HIP(hipStreamWaitEvent(s2, ss->ev_main[c], 0));

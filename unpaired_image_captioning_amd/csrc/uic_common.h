@@ -252,7 +252,8 @@ int uic_attention_bwd_accum_launch(const UicAttnAccumParams& p, hipStream_t s);
 // All state / activation buffers are the time-major workspace slabs of topdown.hip (step stride N*H etc.).
 struct UicRnnFwdParams {
   int dtype, N, R, t0, t1;
-  int row0, Nrows, force_safe;       // filled by the launcher (slabs of <= 640 caption rows)
+  int row0, Nrows;                   // filled by the launcher (slabs of <= 640 caption rows)
+  int force_safe;                    // UIC_REC_SAFE
   const float* gx;                   // [T, N, 4H] xt W_x^T + b_ih + b_hh of att_lstm
   const float* gfc;                  // [N, 4H] fc' W_fc^T, or null
   const void* att_w_ih; int ld_att_ih;   // [4H, ld]: columns [0, H) multiply h_lang_prev
@@ -270,10 +271,9 @@ struct UicRnnFwdParams {
   float drop_p; unsigned seed;
   const void* xbase;                 // filled by the launcher: lowest address of h_att / h_lang / ctx_all (one buffer descriptor)
   unsigned* sync;                    // uic_rnn_persist_sync_bytes() bytes, zeroed by the launcher
-  unsigned long long* dbg; int dbg_T; int exp; // optional [256][dbg_T][16] phase time stamps; exp: timing experiments (wrong results) (100 MHz), indexed by absolute step
-  unsigned* status;                  // filled by the launcher: sticky status words (uic_set_persistent_status) or null
+  unsigned long long* dbg; int dbg_T; // optional [256][dbg_T][16] phase time stamps (100 MHz), indexed by absolute step
+  unsigned* status;                  // sticky status words (uic_topdown_dims.rnn_status) or null
 };
-int uic_rnn_persist_mode();          // 0 off, 1 forward calls, 2 forward calls + SAFE protocol, 3 also the fused training step
 size_t uic_rnn_persist_sync_bytes();
 bool uic_rnn_persist_eligible(int dtype, int N, int H, int A, int R);
 int uic_rnn_fwd_persist_launch(const UicRnnFwdParams& p, hipStream_t s);
@@ -288,7 +288,8 @@ int uic_rnn_fwd_persist_launch(const UicRnnFwdParams& p, hipStream_t s);
 struct UicRnnBwdParams {
   int N, R, t_lo, t_hi;
   int first;                         // 1: step t_hi - 1 is the last executed decode step (nothing carried in)
-  int row0, Nrows, force_safe;       // filled by the launcher (slabs of <= 640 caption rows)
+  int row0, Nrows;                   // filled by the launcher (slabs of <= 640 caption rows)
+  int force_safe;                    // UIC_REC_SAFE
   const void* w2T;                   // [3H, 4H]: rows = inputs [att_res | h_att | h_lang_prev] of lang_lstm, K = its gate columns
   const void* w1recT;                // [2H, 4H]: rows = inputs [h_lang_prev | h_att_prev] of att_lstm
   const void* h2attT;                // [H, A]
@@ -306,12 +307,11 @@ struct UicRnnBwdParams {
   float* de_all; void* datth_all;    // [T, N, R], [T, N, A] out
   unsigned* sync;                    // uic_rnn_persist_sync_bytes() bytes; zeroed by the launcher unless sync_zeroed
   int sync_zeroed;                   // the caller zeroed this launch's sync block itself (one memset for all chunks of a step)
-  unsigned long long* dbg; int dbg_T; int exp;   // optional [256][dbg_T][16] phase time stamps (100 MHz), indexed by absolute step
-  unsigned* status;                  // filled by the launcher
+  unsigned long long* dbg; int dbg_T;   // optional [256][dbg_T][16] phase time stamps (100 MHz), indexed by absolute step
+  unsigned* status;                  // sticky status words (uic_topdown_dims.rnn_status) or null
 };
 bool uic_rnn_bwd_persist_eligible(int dtype, int N, int H, int A, int R);
 int uic_rnn_bwd_persist_launch(const UicRnnBwdParams& p, hipStream_t s);
-unsigned* uic_rnn_persist_status_word();   // the calling thread's device: sticky status words or null (rnn_persist.hip)
 
 // ---------------------------------------------------------------- pointwise (pointwise.hip)
 int uic_cast_f32_launch(int dtype, const float* src, void* dst, size_t n, hipStream_t s);

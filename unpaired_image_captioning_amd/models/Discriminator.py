@@ -26,7 +26,7 @@ class _DiscFn(torch.autograd.Function):
         lib = _lib.load()
         d = module._dims(tokens.shape[0])
         w = module._weights(params)
-        ws = module._workspace(d, tokens.device)
+        ws = module._checkout(d, tokens.device)
         logits = torch.empty(tokens.shape[0], dtype=torch.float32, device=tokens.device)
         check(lib.uic_disc_forward(C.byref(d), C.byref(w), ptr(tokens), tokens.shape[1], int(training), seed, ptr(ws), ptr(logits), None,
                                    stream()), "disc_forward")
@@ -44,6 +44,8 @@ class _DiscFn(torch.autograd.Function):
         dl = dlogits.contiguous().float()
         check(lib.uic_disc_backward(C.byref(ctx.d), C.byref(w), ptr(ctx.tokens), ctx.tokens.shape[1], ctx.training, ctx.seed, ptr(ctx.ws),
                                     ptr(dl), C.byref(g), stream()), "disc_backward")
+        module._release(ctx.d, ctx.ws)
+        ctx.ws = None
         return (None, None, None, None) + tuple(grads)
 
 
@@ -101,14 +103,21 @@ class SentenceDiscriminator(nn.Module):
         w.hw_w, w.hw_b, w.out_w, w.out_b = ptr(next(it)), ptr(next(it)), ptr(next(it)), ptr(next(it))
         return w
 
-    def _workspace(self, d, device):
-        key = (d.N, str(device))
-        if key not in self._ws:
-            nbytes = _lib.load().uic_disc_workspace_bytes(C.byref(d))
-            if nbytes == 0:
-                check(-1, "uic_disc_workspace_bytes")
-            self._ws[key] = torch.empty(nbytes, dtype=torch.uint8, device=device)
-        return self._ws[key]
+    # Workspaces are checked out per forward pass and go back to the pool when its backward has run (or at once for a
+    # no-grad call): two forward passes of the same size before a backward -- D(real) and D(fake) summed into one loss --
+    # must not share the activations they saved.  A pass whose backward never runs simply keeps its buffer out of the pool.
+    def _checkout(self, d, device):
+        free = self._ws.setdefault((d.N, str(device)), [])
+        if free:
+            return free.pop()
+        nbytes = _lib.load().uic_disc_workspace_bytes(C.byref(d))
+        if nbytes == 0:
+            check(-1, "uic_disc_workspace_bytes")
+        return torch.empty(nbytes, dtype=torch.uint8, device=device)
+
+    def _release(self, d, ws):
+        if ws is not None:
+            self._ws.setdefault((d.N, str(ws.device)), []).append(ws)
 
     def _check(self, tokens):
         if not tokens.is_cuda:
@@ -133,10 +142,11 @@ class SentenceDiscriminator(nn.Module):
         with torch.no_grad():
             d = self._dims(tokens.shape[0])
             w = self._weights([p.contiguous() for p in self._param_list()])
-            ws = self._workspace(d, tokens.device)
+            ws = self._checkout(d, tokens.device)
             prob = torch.empty(tokens.shape[0], dtype=torch.float32, device=tokens.device)
             check(lib.uic_disc_forward(C.byref(d), C.byref(w), ptr(tokens), tokens.shape[1], 0, 0, ptr(ws), None, ptr(prob), stream()),
                   "disc_forward")
+            self._release(d, ws)               # (stream order: whoever takes it next runs after this call on the stream)
         return prob
 
     @staticmethod

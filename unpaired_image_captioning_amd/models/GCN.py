@@ -24,7 +24,7 @@ class _GcnFn(torch.autograd.Function):
         lib = _lib.load()
         d = module._dims(x.shape[0], x.shape[1])
         w = module._weights(params)
-        ws = module._workspace(d, x.device)
+        ws = module._checkout(d, x.device)
         out = torch.empty(x.shape[0], x.shape[1], module.H, dtype=torch.float32, device=x.device)
         check(lib.uic_gcn_forward(C.byref(d), C.byref(w), ptr(x), ptr(adj), ptr(ws), ptr(out), stream()), "gcn_forward")
         ctx.module, ctx.d, ctx.ws, ctx.adj, ctx.need_dx = module, d, ws, adj, x.requires_grad
@@ -41,6 +41,8 @@ class _GcnFn(torch.autograd.Function):
         dx = torch.empty(ctx.d.N, ctx.d.R, ctx.d.D, dtype=torch.float32, device=dout.device) if ctx.need_dx else None
         check(lib.uic_gcn_backward(C.byref(ctx.d), C.byref(w), ptr(ctx.adj), ptr(ctx.ws), ptr(dout.contiguous().float()), C.byref(g),
                                    ptr(dx) if dx is not None else None, stream()), "gcn_backward")
+        module._release(ctx.d, ctx.ws)
+        ctx.ws = None
         return (None, dx, None) + tuple(grads)
 
 
@@ -69,14 +71,21 @@ class SceneGraphEncoder(nn.Module):
             w.b[l] = ptr(tensors[2 * l + 1])
         return w
 
-    def _workspace(self, d, device):
-        key = (d.N, d.R, str(device))
-        if key not in self._ws:
-            nbytes = _lib.load().uic_gcn_workspace_bytes(C.byref(d))
-            if nbytes == 0:
-                check(-1, "uic_gcn_workspace_bytes")
-            self._ws[key] = torch.empty(nbytes, dtype=torch.uint8, device=device)
-        return self._ws[key]
+    # Workspaces are checked out per forward pass and go back to the pool when its backward has run (or at once for a
+    # no-grad call): two forward passes of the same size before a backward -- D(real) and D(fake) summed into one loss --
+    # must not share the activations they saved.  A pass whose backward never runs simply keeps its buffer out of the pool.
+    def _checkout(self, d, device):
+        free = self._ws.setdefault((d.N, d.R, str(device)), [])
+        if free:
+            return free.pop()
+        nbytes = _lib.load().uic_gcn_workspace_bytes(C.byref(d))
+        if nbytes == 0:
+            check(-1, "uic_gcn_workspace_bytes")
+        return torch.empty(nbytes, dtype=torch.uint8, device=device)
+
+    def _release(self, d, ws):
+        if ws is not None:
+            self._ws.setdefault((d.N, d.R, str(ws.device)), []).append(ws)
 
     def forward(self, obj_feats, adj):
         if not (obj_feats.is_cuda and adj.is_cuda):

@@ -23,6 +23,17 @@ class GradientExchange(object):
     def rank(self):
         return dist.get_rank(self.group) if dist.is_available() and dist.is_initialized() else 0
 
+    def ranks_share_a_device(self):
+        """True when two ranks of the group drive the same GPU (functional tests on a 1-GPU box).  Such ranks must not both
+        run the persistent recurrence kernel -- each holds every CU while it waits, bounded, for its own workgroups."""
+        if self.world_size == 1 or not torch.cuda.is_available():
+            return False
+        import socket
+        mine = (socket.gethostname(), torch.cuda.current_device())
+        seen = [None] * self.world_size
+        dist.all_gather_object(seen, mine, group=self.group)
+        return len(set(seen)) < len(seen)
+
     def _sum(self, t):
         """In-place sum of `t` over the ranks, on the current stream."""
         dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
@@ -109,7 +120,9 @@ class UicCommExchange(GradientExchange):
         GradientExchange.__init__(self, None)
         self._rank, self._world = int(rank), int(world_size)
         self._lib = _lib.load()
-        assert len(unique_id) == 128
+        if unique_id is None or len(unique_id) != 128:
+            raise ValueError("unique_id must be the 128 bytes of UicCommExchange.new_unique_id() on rank 0")
+        self._comm = None
         buf = (C.c_char * 128).from_buffer_copy(bytes(unique_id))
         comm = C.c_void_p()
         _lib.check(self._lib.uic_comm_init(self._rank, self._world, C.cast(buf, C.c_void_p), C.byref(comm)), "uic_comm_init")
@@ -144,8 +157,23 @@ class UicCommExchange(GradientExchange):
         _lib.check(self._lib.uic_comm_allreduce(self._comm, t.data_ptr(), t.numel(), 0 if t.dtype == torch.float32 else 1,
                                                 torch.cuda.current_stream(t.device).cuda_stream), "uic_comm_allreduce")
 
+    def ranks_share_a_device(self):
+        return False                       # RCCL refuses two ranks of one communicator on one device
+
     def close(self):
         from . import _lib
-        if self._comm is not None:
-            _lib.check(self._lib.uic_comm_destroy(self._comm), "uic_comm_destroy")
-            self._comm = None
+        if getattr(self, "_comm", None) is not None:
+            comm, self._comm = self._comm, None
+            _lib.check(self._lib.uic_comm_destroy(comm), "uic_comm_destroy")
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def __del__(self):                     # the communicator must not outlive its owner (close() is idempotent)
+        try:
+            self.close()
+        except Exception:
+            pass

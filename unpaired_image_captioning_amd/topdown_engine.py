@@ -41,13 +41,17 @@ class TopDownEngine(object):
         self._derived_key = None
         self._pool = {}
         self.seed = 0x5EED
+        # uic_topdown_dims.recurrence (_lib.REC_*): how the decode loop and its BPTT are launched; 0 = the library's default
+        # (persistent forward recurrence where the shapes allow, per-step BPTT launches)
+        self.recurrence = 0
 
     # ------------------------------------------------------------------ arenas
     def dims(self, N, R, T, seq_per_img=1):
         s = self.sizes
         return Dims(N=N, R=R, D=s["D"], Dfc=s["Dfc"], H=s["H"], E=s["E"], A=s["A"], V1=s["V1"], T=T,
                     dtype=self.dtype, drop_p=self.drop_p, use_bn=self.use_bn, seq_per_img=seq_per_img,
-                    logit_layers=self.logit_layers)
+                    logit_layers=self.logit_layers, recurrence=int(self.recurrence),
+                    rnn_status=_lib.status_words().data_ptr() if torch.cuda.is_available() else None)
 
     @staticmethod
     def _key(d):

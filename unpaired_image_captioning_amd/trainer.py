@@ -82,6 +82,9 @@ class Trainer(object):
         self.exchange = exchange if exchange is not None else GradientExchange()
         if self.i2t_model is not None:
             self._mix_rank_into_seed(self.i2t_model, self.exchange)
+            eng = getattr(self.i2t_model, 'engine', None)
+            if eng is not None and hasattr(self.exchange, 'ranks_share_a_device') and self.exchange.ranks_share_a_device():
+                eng.recurrence |= _lib.REC_FWD_CHAIN       # several ranks on ONE GPU: per-step launches (include/uic_hip.h)
         self.lr = getattr(opt, 'i2t_learning_rate', 4e-4)
         self.i2t_current_lr = self.lr
         self.betas = (getattr(opt, 'i2t_optim_alpha', 0.9), getattr(opt, 'i2t_optim_beta', 0.999))
@@ -255,7 +258,16 @@ class Trainer(object):
         if next_data is not None:
             self.prefetch(next_data)
         self.i2t_train_loss = loss.item()          # the reference's per-step host sync (trainer.py:172)
+        self._check_persistent()
         return self.i2t_train_loss
+
+    def _check_persistent(self):
+        """At the step's host sync: did a persistent recurrence launch of this step give up waiting for its workgroups
+        (another process on the GPU, a long kernel on another stream)?  Its results -- and so this step's update -- are then
+        invalid: raise instead of training on them (persistent_status clears the word; set engine.recurrence to
+        _lib.REC_FWD_CHAIN to continue with per-step launches)."""
+        if getattr(self.i2t_model, 'engine', None) is not None:
+            _lib.persistent_status()
 
     def train_self_critical(self, data, reward_fn=None, next_data=None):
         """The self-critical branch of Trainer.train (P/trainer.py:166-171).  reward_fn None: the reference's reward,
@@ -347,6 +359,7 @@ class Trainer(object):
             self.prefetch(next_data)              # the next batch crosses PCIe while this step computes (see train)
         self.i2t_train_loss = loss.item()
         self.i2t_avg_reward = float(avg.item())
+        self._check_persistent()
         return self.i2t_train_loss
 
     # ------------------------------------------------------------------ sentence discriminator (BASELINE configs[3]; parity unpinned)
