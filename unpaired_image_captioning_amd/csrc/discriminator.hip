@@ -200,12 +200,35 @@ inline int grid1(size_t n) {
 }
 #define DISC_DISPATCH(dt, BF, F32) do { if ((dt) == UIC_BF16) { BF; } else { F32; } } while (0)
 
-// operand-dtype copies + the transposes the two dX GEMMs need (the model is small: rebuilt by every call)
+// operand-dtype copies + the transposes the two dX GEMMs need (the model is small: rebuilt by every call) -- ONE cast launch and
+// ONE transpose launch (bf16; up to 5 + 11 jobs), not one launch per tensor and convolution tap: at this model size a training
+// step is made of launches
 int refresh(const uic_disc_dims& d, const uic_disc_weights* w, const DLayout& L, bool with_backward, hipStream_t s) {
   const int dt = d.dtype, E = d.E, F = d.F, Ft = d.nw * d.F;
+  for (int i = 0; i < d.nw; ++i) UIC_REQUIRE(w->conv_w[i] && w->conv_b[i], "disc: null conv weights of width %d", d.widths[i]);
+  int taps = 0;
+  for (int i = 0; i < d.nw; ++i) taps += d.widths[i];
+  const bool multi = dt == UIC_BF16 && d.nw + 1 <= UIC_CAST_MULTI && taps + 1 <= UIC_TRANSPOSE_MULTI;
+  if (multi) {
+    const float* src[UIC_CAST_MULTI];
+    void* dst[UIC_CAST_MULTI];
+    size_t n[UIC_CAST_MULTI];
+    for (int i = 0; i < d.nw; ++i) { src[i] = w->conv_w[i]; dst[i] = L.c_conv[i]; n[i] = (size_t)F * d.widths[i] * E; }
+    src[d.nw] = w->hw_w; dst[d.nw] = L.c_hw; n[d.nw] = (size_t)2 * Ft * Ft;
+    UIC_TRY(uic_cast_f32_multi_launch(dt, d.nw + 1, src, dst, n, s));
+    if (with_backward) {
+      UicTransposeJob jobs[UIC_TRANSPOSE_MULTI];
+      int nj = 0;
+      for (int i = 0; i < d.nw; ++i)
+        for (int j = 0; j < d.widths[i]; ++j)   // W_w[:, j, :] ([F, E], row stride w E) -> [E, F]
+          jobs[nj++] = UicTransposeJob{off(L.c_conv[i], (size_t)j * E, dt), offw(L.convT[i], (size_t)j * E * F, dt), F, E, d.widths[i] * E, F};
+      jobs[nj++] = UicTransposeJob{L.c_hw, L.hwT, 2 * Ft, Ft, Ft, 2 * Ft};
+      UIC_TRY(uic_transpose_multi_launch(dt, nj, jobs, s));
+    }
+    return UIC_OK;
+  }
   for (int i = 0; i < d.nw; ++i) {
     const int wd = d.widths[i];
-    UIC_REQUIRE(w->conv_w[i] && w->conv_b[i], "disc: null conv weights of width %d", wd);
     UIC_TRY(uic_cast_f32_launch(dt, w->conv_w[i], L.c_conv[i], (size_t)F * wd * E, s));
     if (with_backward)
       for (int j = 0; j < wd; ++j)   // W_w[:, j, :] ([F, E], row stride w E) -> [E, F]
