@@ -29,6 +29,11 @@ tail -11 $O/step_marks.txt
 timeout 200 python3 $R/tools/rnn_persist_probe.py --dbg > $O/rnn_persist_probe.txt 2>&1
 grep -E "phase|step  |forward" $O/rnn_persist_probe.txt
 timeout 200 python3 $R/tools/gemm_headroom.py > $O/gemm_headroom.txt 2>&1
+# persistent BPTT kernel (opt-in): parity with the launch chain, phase stamps, backward call and fused step in both modes
+timeout 300 python3 $R/tools/rnn_bwd_probe.py --dbg > $O/rnn_bwd_probe.txt 2>&1
+grep -E "step |fused|backward call" $O/rnn_bwd_probe.txt
+# attention-step kernel variants from a C++ host (shipped structure, loads only, online softmax, wave counts)
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 $R/tools/micro/attn_variants.hip -o /tmp/attn_variants 2>/dev/null && /tmp/attn_variants > $O/attn_variants.txt 2>&1
 # HBM traffic of the persistent recurrence kernel (separate PMC passes, same corrections as for the attention kernel)
 timeout 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d /tmp/pr/fetch -- python3 $R/tools/rnn_kernel_only.py > /tmp/prf.log 2>&1
 timeout 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d /tmp/pr/write -- python3 $R/tools/rnn_kernel_only.py > /tmp/prw.log 2>&1

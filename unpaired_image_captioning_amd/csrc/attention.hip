@@ -144,7 +144,12 @@ __global__ __launch_bounds__(NTHREADS) void attn_bwd_step_kernel(const UicAttnPa
     s_atth[a] = p.att_h[(size_t)n * A + a];
     s_w[a] = p.w_alpha[a];
   }
-  for (int h = tid; h < H; h += NTHREADS) s_dctx[h] = p.dctx[(size_t)n * p.lddctx + h];
+  for (int h = tid; h < H; h += NTHREADS) {
+    float v = p.dctx[(size_t)n * p.lddctx + h];
+    for (int z = 1; z < p.dctx_nslab; ++z) v += p.dctx[(size_t)z * p.dctx_slab_stride + (size_t)n * p.lddctx + h];
+    s_dctx[h] = v;
+    if (p.dctx_sum) p.dctx_sum[(size_t)n * p.ld_dctx_sum + h] = v;
+  }
   for (int r = tid; r < R; r += NTHREADS) s_al[r] = p.alpha[(size_t)n * R + r];
   __syncthreads();
 
@@ -345,6 +350,19 @@ __global__ __launch_bounds__(NTHREADS) void attn_bwd_step_fast_kernel(const UicA
   load_chunk_f32<T>(p.att_h + (size_t)n * A, lane, la, ah);
   load_chunk_f32<T>(p.w_alpha, lane, la, w);
   load_chunk_f32<T>(p.dctx + (size_t)n * p.lddctx, lane, lh, dc);
+  if (p.dctx_nslab > 1) {       // d ctx arrives as split-K partial slabs: summed here (fixed order), the sum left for the accumulation pass
+    for (int z = 1; z < p.dctx_nslab; ++z) {
+      float dz[VEC];
+      load_chunk_f32<T>(p.dctx + (size_t)z * p.dctx_slab_stride + (size_t)n * p.lddctx, lane, lh, dz);
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) dc[j] += dz[j];
+    }
+  }
+  if (p.dctx_sum && lh && wave == 0) {
+#pragma unroll
+    for (int q = 0; q < VEC / 4; ++q)
+      *(float4*)(p.dctx_sum + (size_t)n * p.ld_dctx_sum + lane * VEC + q * 4) = make_float4(dc[q * 4], dc[q * 4 + 1], dc[q * 4 + 2], dc[q * 4 + 3]);
+  }
   for (int r = tid; r < R; r += NTHREADS) s_al[r] = p.alpha[(size_t)n * R + r];
 #pragma unroll
   for (int u = 0; u < UB; ++u) {

@@ -452,6 +452,8 @@ __global__ void lstm_bwd_kernel(const UicLstmBwdParams p) {
     }
     if (p.dh1) dh += p.dh1[(size_t)m * p.lddh1 + u];
     if (p.dh2) dh += p.dh2[(size_t)m * p.lddh2 + u];
+    for (int z = 0; z < p.nA; ++z) dh += p.slabA[(size_t)z * p.strideA + (size_t)m * p.ldA + u];
+    for (int z = 0; z < p.nB; ++z) dh += p.slabB[(size_t)z * p.strideB + (size_t)m * p.ldB + u];
     const T* G = (const T*)p.gates + (size_t)m * 4 * H + u;
     const float gi = uic_to_f(G[0]), gf = uic_to_f(G[H]), gg = uic_to_f(G[2 * H]), go = uic_to_f(G[3 * H]);
     const float c = p.c[idx];
@@ -484,6 +486,17 @@ __global__ __launch_bounds__(NT) void lstm_bwd_vec4_kernel(const UicLstmBwdParam
   if (p.dh0) d0 = *(const float4*)(p.dh0 + (size_t)m * p.lddh0 + u);
   if (p.dh1) d1 = *(const float4*)(p.dh1 + (size_t)m * p.lddh1 + u);
   if (p.dh2) d2 = *(const float4*)(p.dh2 + (size_t)m * p.lddh2 + u);
+  float4 ds = make_float4(0.f, 0.f, 0.f, 0.f);       // split-K partial slabs of two more sources, summed in a fixed order
+  {
+    float4 sv[8];
+    const int nA = p.nA < 4 ? p.nA : 4, nB = p.nB < 4 ? p.nB : 4;
+#pragma unroll
+    for (int z = 0; z < 4; ++z) sv[z] = z < nA ? *(const float4*)(p.slabA + (size_t)z * p.strideA + (size_t)m * p.ldA + u) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int z = 0; z < 4; ++z) sv[4 + z] = z < nB ? *(const float4*)(p.slabB + (size_t)z * p.strideB + (size_t)m * p.ldB + u) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int z = 0; z < 8; ++z) { ds.x += sv[z].x; ds.y += sv[z].y; ds.z += sv[z].z; ds.w += sv[z].w; }
+  }
   const float4 c4 = *(const float4*)(p.c + idx);
   if (p.c_prev) cp = *(const float4*)(p.c_prev + idx);
   const float4 dc4 = *(const float4*)(p.dc + idx);
@@ -500,7 +513,7 @@ __global__ __launch_bounds__(NT) void lstm_bwd_vec4_kernel(const UicLstmBwdParam
       g[q][0] = w.x; g[q][1] = w.y; g[q][2] = w.z; g[q][3] = w.w;
     }
   }
-  const float dh0[4] = {d0.x, d0.y, d0.z, d0.w}, dh1[4] = {d1.x, d1.y, d1.z, d1.w}, dh2[4] = {d2.x, d2.y, d2.z, d2.w};
+  const float dh0[4] = {d0.x, d0.y, d0.z, d0.w}, dh1[4] = {d1.x, d1.y, d1.z, d1.w}, dh2[4] = {d2.x, d2.y, d2.z, d2.w}, dsl[4] = {ds.x, ds.y, ds.z, ds.w};
   const float cc[4] = {c4.x, c4.y, c4.z, c4.w}, cpv[4] = {cp.x, cp.y, cp.z, cp.w}, dcv[4] = {dc4.x, dc4.y, dc4.z, dc4.w};
   float o[4][4], dcn[4];
 #pragma unroll
@@ -513,6 +526,7 @@ __global__ __launch_bounds__(NT) void lstm_bwd_vec4_kernel(const UicLstmBwdParam
     }
     if (p.dh1) dh += dh1[k];
     if (p.dh2) dh += dh2[k];
+    dh += dsl[k];
     const float gi = g[0][k], gf = g[1][k], gg = g[2][k], go = g[3][k];
     const float tc = uic_tanh<T>(cc[k]);
     const float dc = dcv[k] + dh * go * (1.f - tc * tc);
@@ -1508,13 +1522,16 @@ int uic_relu_mask_bwd_fold_launch(int dtype, const float* grad, const void* act,
 }
 int uic_lstm_bwd_launch(const UicLstmBwdParams& p, hipStream_t s) {
   UIC_REQUIRE(p.dc && p.gates && p.c && p.dgates, "lstm_bwd: null pointer");
+  UIC_REQUIRE((!p.nA || p.slabA) && (!p.nB || p.slabB) && p.nA >= 0 && p.nB >= 0, "lstm_bwd: slab sources");
   if (p.M == 0) return UIC_OK;
   auto al16 = [](const void* q) { return ((uintptr_t)q & 15) == 0; };
   // (small problems -- the pivot NMT's 64 rows -- keep one unit per lane: four times the workgroups, measured faster there)
   const bool vec = (size_t)p.M * p.H >= 65536 && p.H % 4 == 0 && al16(p.dc) && al16(p.c) && (!p.c_prev || al16(p.c_prev)) &&
                    ((uintptr_t)p.gates & 7) == 0 && ((uintptr_t)p.dgates & 7) == 0 && (p.dtype == UIC_BF16 || (al16(p.gates) && al16(p.dgates))) &&
                    (!p.dh0 || (al16(p.dh0) && p.lddh0 % 4 == 0)) && (!p.dh1 || (al16(p.dh1) && p.lddh1 % 4 == 0)) &&
-                   (!p.dh2 || (al16(p.dh2) && p.lddh2 % 4 == 0)) && (size_t)p.M * p.H < ((size_t)1 << 32) && p.M <= 65535;
+                   (!p.dh2 || (al16(p.dh2) && p.lddh2 % 4 == 0)) && (size_t)p.M * p.H < ((size_t)1 << 32) && p.M <= 65535 &&
+                   p.nA <= 4 && p.nB <= 4 && (!p.nA || (al16(p.slabA) && p.ldA % 4 == 0 && p.strideA % 4 == 0)) &&
+                   (!p.nB || (al16(p.slabB) && p.ldB % 4 == 0 && p.strideB % 4 == 0));
   if (vec) {
     const int h4 = p.H / 4;
     const int bt = h4 >= NT ? NT : ((h4 + 63) / 64) * 64;

@@ -24,6 +24,10 @@ namespace {
 #define UIC_WG_CHUNK 4
 #endif
 constexpr int WG_CHUNK = UIC_WG_CHUNK;   // decode steps per hand-off between the two streams of the fused training step
+#ifndef UIC_BPTT_SPLIT
+#define UIC_BPTT_SPLIT 4
+#endif
+constexpr int BPTT_SPLIT = UIC_BPTT_SPLIT;   // K slices of the BPTT loop's d x GEMMs (Step::bptt_split)
 
 struct Layout {
   // forward activations
@@ -54,6 +58,7 @@ struct Layout {
   void* fcwT; void* attwT;                     // fc_embed / att_embed weights transposed ([Dfc, H], [D, H]): only for the optional input-feature gradients
   void* ones_blk; size_t ones_rows;           // [max(WG_CHUNK * N, N * R), 128] operand dtype, all ones: the "input" whose weight gradient is the bias gradient
   unsigned* rnn_sync; unsigned long long* rnn_dbg;   // persistent recurrence (rnn_persist.hip): sync block, optional time stamps
+  float* bp_slab2[2]; float* bp_slab1;       // split-K partial slabs of the BPTT loop's d x2 (two generations) and d x1 GEMMs: [BPTT_SPLIT][N, 3H] / [N, 2H]
   unsigned* rnn_bwd_sync; size_t rnn_bwd_sync_bytes; unsigned long long* rnn_bwd_dbg;   // persistent BPTT (rnn_bwd_persist.hip): one sync block per launch of a step
   // sampling
   void* s_h_att[2]; void* s_h_lang[2]; float* s_c_att[2]; float* s_c_lang[2];
@@ -176,6 +181,8 @@ Layout make_layout(const uic_topdown_dims& d, void* ws) {
   L.ones_blk = b.take(L.ones_rows * 128 * S);
   L.rnn_sync = (unsigned*)b.take(uic_rnn_persist_sync_bytes());
   L.rnn_dbg = (unsigned long long*)b.take((size_t)256 * T * 16 * 8);
+  for (int i = 0; i < 2; ++i) L.bp_slab2[i] = (float*)b.take((size_t)BPTT_SPLIT * N * 3 * H * 4);
+  L.bp_slab1 = (float*)b.take((size_t)BPTT_SPLIT * N * 2 * H * 4);
   L.rnn_bwd_sync_bytes = T * uic_rnn_persist_sync_bytes();
   L.rnn_bwd_sync = (unsigned*)b.take(L.rnn_bwd_sync_bytes);
   L.rnn_bwd_dbg = (unsigned long long*)b.take((size_t)256 * T * 16 * 8);
@@ -872,17 +879,34 @@ struct Step {
     return uic_rnn_bwd_persist_launch(p, s);
   }
 
+  // The two d x GEMMs of a BPTT step (640 x 1536 / 1024 outputs, K = 4H) run as BPTT_SPLIT K slices on the LDS-DMA kernel with
+  // 128 x 128 tiles (half the operand traffic of the 64 x 64 skinny tiles, a quarter of the K rounds per workgroup); the slices
+  // land in partial slabs and are summed by whoever reads them next -- the cell backward kernels and the attention backward
+  // kernel (which leaves the summed d att_res where the deferred accumulation pass expects it): no reduction launch.
+  // 15.2 -> 12.7 us and 14.5 -> 11.6 us per launch isolated (profiles/r03_v2_gemm_headroom.txt).  0: small problems, direct GEMMs.
+  int bptt_split() const {
+    const int rounds = H4 / (dt == UIC_BF16 ? 64 : 32);
+    return (BPTT_SPLIT > 1 && N >= 256 && H % 128 == 0 && uic_gemm_glds_eligible(dt, H4) && rounds % BPTT_SPLIT == 0 && rounds / BPTT_SPLIT >= 4) ? BPTT_SPLIT : 0;
+  }
+
   int bwd_step(int t, hipStream_t s) {
     const bool last = t == t_run - 1;
+    const int S = bptt_split();
     float* dx2 = L.dx2_all + (size_t)t * N * 3 * H;
     const float* dx2_next = L.dx2_all + (size_t)(t + 1) * N * 3 * H;
+    float* slab2 = L.bp_slab2[t & 1];
+    const float* slab2_next = L.bp_slab2[(t + 1) & 1];
+    const size_t st2 = (size_t)N * 3 * H, st1 = (size_t)N * 2 * H;
     {
       UicLstmBwdParams p;
       memset(&p, 0, sizeof(p));
       p.dtype = dt; p.M = N; p.H = H;
       p.dh0 = L.dhdrop + t * NH; p.lddh0 = H;
       p.drop_p = drop_p; p.seed = seed; p.site = UIC_SITE_OUT0 + (unsigned)t;
-      if (!last) { p.dh1 = dx2_next + 2 * H; p.lddh1 = 3 * H; p.dh2 = L.dx1; p.lddh2 = 2 * H; }
+      if (!last && S) {
+        p.slabA = slab2_next + 2 * H; p.ldA = 3 * H; p.nA = S; p.strideA = st2;
+        p.slabB = L.bp_slab1; p.ldB = 2 * H; p.nB = S; p.strideB = st1;
+      } else if (!last) { p.dh1 = dx2_next + 2 * H; p.lddh1 = 3 * H; p.dh2 = L.dx1; p.lddh2 = 2 * H; }
       p.dc = L.dc_lang; p.gates = off(L.gates2, (size_t)t * N * H4, dt);
       p.c_prev = L.c_lang + t * NH; p.c = L.c_lang + (t + 1) * NH;
       p.dgates = offw(L.dg2_all, (size_t)t * N * H4, dt);
@@ -891,7 +915,8 @@ struct Step {
     {  // d[att_res | h_att | h_lang_prev] = dG2 [W_ih | W_hh]
       UicGemmParams g = gemm_base(dt, N, 3 * H);
       add_seg(g, off(L.dg2_all, (size_t)t * N * H4, dt), H4, dv.w2T, H4, H4);
-      g.C = dx2; g.ldc = 3 * H; g.flags = UIC_GEMM_OUT_F32;
+      if (S) { g.slab = slab2; g.splitk = S; }
+      else { g.C = dx2; g.ldc = 3 * H; g.flags = UIC_GEMM_OUT_F32; }
       UIC_TRY(uic_gemm_launch(g, s));
     }
     {
@@ -900,7 +925,8 @@ struct Step {
       a.dtype = dt; a.N = N; a.R = R; a.A = A; a.H = H;
       a.att_h = L.atth_all + (size_t)t * N * A; a.p_att = L.patt; a.att = L.attp; a.w_alpha = w->alpha_w;
       a.alpha = L.alpha_all + (size_t)t * N * R;
-      a.dctx = dx2; a.lddctx = 3 * H;
+      a.dctx = S ? slab2 : dx2; a.lddctx = 3 * H;
+      if (S) { a.dctx_nslab = S; a.dctx_slab_stride = st2; a.dctx_sum = dx2; a.ld_dctx_sum = 3 * H; }
       a.de = L.de_all + (size_t)t * N * R;
       a.d_att_h = offw(L.datth_all, (size_t)t * N * A, dt);
       UIC_TRY(uic_attention_bwd_step_launch(a, s));
@@ -908,7 +934,7 @@ struct Step {
     {  // dh_att += d_att_h W_h2att
       UicGemmParams g = gemm_base(dt, N, H);
       add_seg(g, off(L.datth_all, (size_t)t * N * A, dt), A, dv.h2attT, A, A);
-      g.C = dx2 + H; g.ldc = 3 * H; g.flags = UIC_GEMM_OUT_F32 | UIC_GEMM_ACCUM;
+      g.C = dx2 + H; g.ldc = 3 * H; g.flags = UIC_GEMM_OUT_F32 | (S ? 0 : UIC_GEMM_ACCUM);   // (split: the d x2 share is added by the cell backward below)
       UIC_TRY(uic_gemm_launch(g, s));
     }
     {
@@ -916,7 +942,10 @@ struct Step {
       memset(&p, 0, sizeof(p));
       p.dtype = dt; p.M = N; p.H = H;
       p.dh0 = dx2 + H; p.lddh0 = 3 * H;
-      if (!last) { p.dh1 = L.dx1 + H; p.lddh1 = 2 * H; }
+      if (S) {
+        p.slabA = slab2 + H; p.ldA = 3 * H; p.nA = S; p.strideA = st2;
+        if (!last) { p.slabB = L.bp_slab1 + H; p.ldB = 2 * H; p.nB = S; p.strideB = st1; }
+      } else if (!last) { p.dh1 = L.dx1 + H; p.lddh1 = 2 * H; }
       p.dc = L.dc_att; p.gates = off(L.gates1, (size_t)t * N * H4, dt);
       p.c_prev = L.c_att + t * NH; p.c = L.c_att + (t + 1) * NH;
       p.dgates = offw(L.dg1_all, (size_t)t * N * H4, dt);
@@ -925,7 +954,8 @@ struct Step {
     if (t > 0) {  // d[h_lang_prev | h_att_prev] = dG1 [W_ih[:, :H] | W_hh]
       UicGemmParams g = gemm_base(dt, N, 2 * H);
       add_seg(g, off(L.dg1_all, (size_t)t * N * H4, dt), H4, dv.w1recT, H4, H4);
-      g.C = L.dx1; g.ldc = 2 * H; g.flags = UIC_GEMM_OUT_F32;
+      if (S) { g.slab = L.bp_slab1; g.splitk = S; }
+      else { g.C = L.dx1; g.ldc = 2 * H; g.flags = UIC_GEMM_OUT_F32; }
       UIC_TRY(uic_gemm_launch(g, s));
     }
     return UIC_OK;

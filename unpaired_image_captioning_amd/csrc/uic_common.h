@@ -227,6 +227,8 @@ struct UicAttnParams {
   void* ctx; int ldctx;    // [N,H] operand dtype (fwd out)
   // backward step
   const float* dctx; int lddctx;   // [N,H]
+  int dctx_nslab; size_t dctx_slab_stride;   // > 1: d ctx = sum_z dctx[z * stride + n * lddctx + h] (split-K partial slabs) ...
+  float* dctx_sum; int ld_dctx_sum;          // ... and the sum is left here (read by the deferred accumulation pass)
   float* de;               // [N,R]
   void* d_att_h;           // [N,A] operand dtype
 };
@@ -389,6 +391,9 @@ struct UicLstmBwdParams {
   const float* dh1; int lddh1;
   const float* dh2; int lddh2;
   float drop_p; unsigned seed; unsigned site; size_t drop_base;  // dropout applied to dh0 only (out-dropout)
+  // two more dh sources given as split-K partial slabs (uic_linear_partials): dh += sum_z slabX[z * strideX + m * ldX + u]
+  const float* slabA; int ldA, nA; size_t strideA;
+  const float* slabB; int ldB, nB; size_t strideB;
   float* dc;                     // [M,H] in: dc from step t+1 ; out: dc for step t-1  (in place)
   const void* gates;             // [M,4H] activated (i,f,g,o)
   const float* c_prev;           // [M,H] or null
