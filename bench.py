@@ -259,8 +259,10 @@ def main():
                     help="region feature width (secondary measurement): 2053 = 2048 + 5 box features, the reference's default "
                          "use_box=1; the metric is quoted at 2048")
     ap.add_argument("--use-bn", type=int, default=0, help="opt.use_bn of the captioner (secondary measurement; the metric is quoted at 0)")
-    ap.add_argument("--rows-per-gpu-probe", type=int, default=80,
-                    help="also time the step at this many caption rows (the per-rank size of a strong-scaling run; 0 = skip); secondary key only")
+    ap.add_argument("--rows-per-gpu-probe", type=int, default=0,
+                    help="also time the step at this many caption rows, e.g. 80 = the per-rank size of a strong-scaling run of the 640-row "
+                         "batch over 8 GPUs (secondary key `strong_scaling_probe`, never `value`; off by default so that the default "
+                         "command launches the 640-row kernels only and its rocprofv3 summary averages one problem size)")
     ap.add_argument("--cpu-threads", type=int, default=0, help="threads for the CPU oracle leg (0: min(host cores, 16), the fastest setting measured on the GPU box's 256-thread host: 8->293, 16->379, 32->211, 64->110, 128->24 captions/s)")
     args = ap.parse_args()
 

@@ -8,8 +8,11 @@ mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
 timeout 400 python3 $R/bench.py > $O/bench.json 2> $O/bench.err
 tail -c 600 $O/bench.json
+timeout 200 python3 $R/bench.py --no-f32 --no-cpu-baseline --rows-per-gpu-probe 80 2>/dev/null | python3 -c "import sys, json; print(json.dumps(json.loads(sys.stdin.readline())['strong_scaling_probe']))" > $O/strong_scaling_probe.json
+cat $O/strong_scaling_probe.json
 timeout 500 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/p6 -- python3 $R/bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-f32 > /tmp/p6.log 2>&1
 python3 $R/tools/prof_summary.py /tmp/p6 32 45 > $O/bench_summary.txt 2>&1
+python3 $R/tools/step_timeline.py $(find /tmp/p6 -name "*kernel_trace.csv" | head -1) 4 --full > $O/step_timeline.txt 2>&1
 grep '"metric"' /tmp/p6.log | tail -1 > $O/bench_under_rocprof.json   # the same process's own HIP-event figures
 cp $(find /tmp/p6 -name "*kernel_stats.csv" | head -1) $O/bench_kernel_stats.csv
 timeout 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d /tmp/pm/fetch -- python3 $R/tools/attn_kernel_only.py > /tmp/pmf.log 2>&1

@@ -351,11 +351,21 @@ __global__ __launch_bounds__(NTHREADS) void attn_bwd_step_fast_kernel(const UicA
   load_chunk_f32<T>(p.w_alpha, lane, la, w);
   load_chunk_f32<T>(p.dctx + (size_t)n * p.lddctx, lane, lh, dc);
   if (p.dctx_nslab > 1) {       // d ctx arrives as split-K partial slabs: summed here (fixed order), the sum left for the accumulation pass
-    for (int z = 1; z < p.dctx_nslab; ++z) {
-      float dz[VEC];
-      load_chunk_f32<T>(p.dctx + (size_t)z * p.dctx_slab_stride + (size_t)n * p.lddctx, lane, lh, dz);
+    // (all slices requested before the first one is used: a slice per trip would be a memory latency per slice)
+    float dz[3][VEC];
 #pragma unroll
-      for (int j = 0; j < VEC; ++j) dc[j] += dz[j];
+    for (int z = 0; z < 3; ++z) load_chunk_f32<T>(p.dctx + (size_t)min(z + 1, p.dctx_nslab - 1) * p.dctx_slab_stride + (size_t)n * p.lddctx, lane, lh, dz[z]);
+#pragma unroll
+    for (int z = 0; z < 3; ++z)
+      if (z + 1 < p.dctx_nslab) {
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) dc[j] += dz[z][j];
+      }
+    for (int z = 4; z < p.dctx_nslab; ++z) {
+      float dw[VEC];
+      load_chunk_f32<T>(p.dctx + (size_t)z * p.dctx_slab_stride + (size_t)n * p.lddctx, lane, lh, dw);
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) dc[j] += dw[j];
     }
   }
   if (p.dctx_sum && lh && wave == 0) {
