@@ -27,6 +27,9 @@ constexpr int WG_CHUNK = UIC_WG_CHUNK;   // decode steps per hand-off between th
 #ifndef UIC_BPTT_SPLIT
 #define UIC_BPTT_SPLIT 4
 #endif
+#ifndef UIC_BPTT_FUSE_CELL
+#define UIC_BPTT_FUSE_CELL 1
+#endif
 constexpr int BPTT_SPLIT = UIC_BPTT_SPLIT;   // K slices of the BPTT loop's d x GEMMs (Step::bptt_split)
 
 struct Layout {
@@ -931,6 +934,21 @@ struct Step {
       a.d_att_h = offw(L.datth_all, (size_t)t * N * A, dt);
       UIC_TRY(uic_attention_bwd_step_launch(a, s));
     }
+    UicH2attCellParams hc;
+    memset(&hc, 0, sizeof(hc));
+    if (S) {   // d h_att = d_att_h W_h2att + the d x2 / d x1 slices, then the att_lstm cell backward: one launch (bptt_fused.hip)
+      hc.dtype = dt; hc.N = N; hc.H = H; hc.A = A;
+      hc.datth = off(L.datth_all, (size_t)t * N * A, dt); hc.h2attT = dv.h2attT;
+      hc.slabA = slab2 + H; hc.ldA = 3 * H; hc.nA = S; hc.strideA = st2;
+      if (!last) { hc.slabB = L.bp_slab1 + H; hc.ldB = 2 * H; hc.nB = S; hc.strideB = st1; }
+      hc.dc = L.dc_att; hc.gates = off(L.gates1, (size_t)t * N * H4, dt);
+      hc.c_prev = L.c_att + t * NH; hc.c = L.c_att + (t + 1) * NH;
+      hc.dgates = offw(L.dg1_all, (size_t)t * N * H4, dt);
+    }
+    const bool fused_cell = UIC_BPTT_FUSE_CELL && S && uic_h2att_cell_bwd_eligible(hc);
+    if (fused_cell) {
+      UIC_TRY(uic_h2att_cell_bwd_launch(hc, s));
+    } else {
     {  // dh_att += d_att_h W_h2att
       UicGemmParams g = gemm_base(dt, N, H);
       add_seg(g, off(L.datth_all, (size_t)t * N * A, dt), A, dv.h2attT, A, A);
@@ -950,6 +968,7 @@ struct Step {
       p.c_prev = L.c_att + t * NH; p.c = L.c_att + (t + 1) * NH;
       p.dgates = offw(L.dg1_all, (size_t)t * N * H4, dt);
       UIC_TRY(uic_lstm_bwd_launch(p, s));
+    }
     }
     if (t > 0) {  // d[h_lang_prev | h_att_prev] = dG1 [W_ih[:, :H] | W_hh]
       UicGemmParams g = gemm_base(dt, N, 2 * H);

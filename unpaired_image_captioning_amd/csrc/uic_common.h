@@ -401,6 +401,22 @@ struct UicLstmBwdParams {
   void* dgates;                  // [M,4H] operand dtype out
 };
 int uic_lstm_bwd_launch(const UicLstmBwdParams& p, hipStream_t s);
+// d h = d att_h[N, A] h2attT[H, A]^T + the two slab sources, then the nn.LSTMCell backward of UicLstmBwdParams -- the `h2att`
+// input-gradient GEMM and the att_lstm cell backward of a BPTT step in ONE launch (bptt_fused.hip; bf16)
+struct UicH2attCellParams {
+  int dtype, N, H, A;
+  const void* datth;             // [N, A]
+  const void* h2attT;            // [H, A]
+  const float* slabA; int ldA, nA; size_t strideA;
+  const float* slabB; int ldB, nB; size_t strideB;
+  float* dc;                     // [N, H] in / out
+  const void* gates;             // [N, 4H] activated (i, f, g, o)
+  const float* c_prev;           // [N, H] or null
+  const float* c;                // [N, H]
+  void* dgates;                  // [N, 4H] out
+};
+bool uic_h2att_cell_bwd_eligible(const UicH2attCellParams& p);
+int uic_h2att_cell_bwd_launch(const UicH2attCellParams& p, hipStream_t s);
 int uic_maxout_lstm_bwd_launch(const UicLstmBwdParams& p, hipStream_t s);   // gates/dgates are [M,5H]; dh = (dh0 + dh1) * dropout
 int uic_sample_fixup_launch(int N, int L, int ld, const int* n_unfinished, int64_t* seq, float* seq_logp, hipStream_t s);
 
