@@ -43,6 +43,11 @@ int uic_version(void);
  *                        by arrival order) instead of XCD-local groups -- same results bit for bit; tests
  *   UIC_REC_STAMPS       the persistent kernels write per-phase time stamps into the workspace ("rnn_dbg" / "rnn_bwd_dbg" of
  *                        uic_topdown_workspace_ptr: [256 workgroups][T][16] uint64, 100 MHz); tools/
+ *   UIC_REC_EARLY_GRADS  (uic_topdown_xe_train_step; set by a data-parallel caller) the embedding gradient and the fc' columns
+ *                        of core.att_lstm.weight_ih are produced chunk by chunk behind the BPTT loop instead of in one pass
+ *                        after it, so that both tensors are final with gradient group 1 of uic_topdown_grad_ready_wait and
+ *                        only ~10 MB of gradients become final in the step's last 0.1 ms.  A few more, smaller launches:
+ *                        a single GPU, which waits for nothing, leaves it off.  Same gradients up to f32 summation order
  * uic_topdown_dims.rnn_status: NULL, or 4 caller-allocated, caller-zeroed uint32 on the device that the persistent kernels
  * update: [0] != 0 after a bounded spin timed out (the results of that call are invalid), [1] / [2] launches that ran with
  * the XCD-local / the SAFE protocol. */
@@ -50,6 +55,7 @@ int uic_version(void);
 #define UIC_REC_BWD_PERSIST 2
 #define UIC_REC_SAFE 4
 #define UIC_REC_STAMPS 8
+#define UIC_REC_EARLY_GRADS 16
 
 /* ---- shapes of one TopDown step (P/models/AttModel.py:56-92,422-428,530-536) ---- */
 typedef struct uic_topdown_dims {
@@ -198,7 +204,8 @@ int uic_topdown_xe_train_step(const uic_topdown_dims* d, const uic_topdown_weigh
  * FINAL gradients for a group of tensors, while that call is still computing the rest on its own streams:
  *   group 0: logit.* (and the loss)                       -- final when the BPTT loop STARTS (~25 % of the bytes);
  *   group 1: core.lang_lstm.weight_{ih,hh}, core.att_lstm.weight_hh       -- final right after the BPTT loop (~21 %; the fc'
- *            columns of core.att_lstm.weight_ih still come from the sum over steps, so that matrix belongs to group 2);
+ *            columns of core.att_lstm.weight_ih still come from the sum over steps, so that matrix belongs to group 2).
+ *            With UIC_REC_EARLY_GRADS in dims.recurrence also core.att_lstm.weight_ih and embed.0.weight (~60 % with them);
  *   group 2: everything except the late group {att_embed.*, ctx2att.*, core.attention.h2att.*,
  *            core.attention.alpha_net.*}                   -- final when the embedding / fc_embed / bias gradients are done.
  * A caller that lays its flat gradient arena out as [logit | group 1 | rest of the early group | late group] can

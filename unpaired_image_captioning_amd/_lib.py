@@ -25,7 +25,7 @@ class Dims(C.Structure):
 
 
 # uic_topdown_dims.recurrence (include/uic_hip.h)
-REC_FWD_CHAIN, REC_BWD_PERSIST, REC_SAFE, REC_STAMPS = 1, 2, 4, 8
+REC_FWD_CHAIN, REC_BWD_PERSIST, REC_SAFE, REC_STAMPS, REC_EARLY_GRADS = 1, 2, 4, 8, 16
 
 
 MAX_LOGIT_LAYERS = 4

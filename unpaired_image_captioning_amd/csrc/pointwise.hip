@@ -250,7 +250,9 @@ __device__ __forceinline__ int wave_token_add(int* base, int tok, bool active, b
   if (active) slot = atomicAdd(base + tok, 1);
   return slot;
 }
-__global__ void embed_hist_kernel(const int64_t* __restrict__ tokens, int ldtok, int N, int TS, int V1, int* __restrict__ cnt) {
+// chunk > 0: the bucket key is (t / chunk) * V1 + token -- positions ordered by hand-off chunk first, so that the positions of
+// decode steps [c chunk, (c + 1) chunk) are entries [c chunk N, (c + 1) chunk N) of the list and can be gathered on their own
+__global__ void embed_hist_kernel(const int64_t* __restrict__ tokens, int ldtok, int N, int TS, int V1, int chunk, int* __restrict__ cnt) {
   const int total = TS * N;
   const int span = (total + 63) & ~63;                       // whole waves enter the aggregation together
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < span; i += gridDim.x * blockDim.x) {
@@ -260,6 +262,7 @@ __global__ void embed_hist_kernel(const int64_t* __restrict__ tokens, int ldtok,
       const int t = i / N, n = i - t * N;
       tok = tokens[(size_t)n * ldtok + t];
       if (tok < 0 || tok >= V1) tok = 0;
+      if (chunk) tok += (long)(t / chunk) * V1;
     }
     wave_token_add(cnt, (int)tok, ok, false);
   }
@@ -290,7 +293,7 @@ __global__ __launch_bounds__(1024) void embed_scan_kernel(const int* __restrict_
   for (int v = lo; v < hi; ++v) { off[v] = run; cur[v] = run; run += cnt[v]; }
   if (threadIdx.x == 0) off[V1] = tot;
 }
-__global__ void embed_fill_kernel(const int64_t* __restrict__ tokens, int ldtok, int N, int TS, int V1, int* __restrict__ cur, int* __restrict__ perm) {
+__global__ void embed_fill_kernel(const int64_t* __restrict__ tokens, int ldtok, int N, int TS, int V1, int chunk, int* __restrict__ cur, int* __restrict__ perm) {
   const int total = TS * N;
   const int span = (total + 63) & ~63;
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < span; i += gridDim.x * blockDim.x) {
@@ -300,6 +303,7 @@ __global__ void embed_fill_kernel(const int64_t* __restrict__ tokens, int ldtok,
       const int t = i / N, n = i - t * N;
       tok = tokens[(size_t)n * ldtok + t];
       if (tok < 0 || tok >= V1) tok = 0;
+      if (chunk) tok += (long)(t / chunk) * V1;
     }
     const int slot = wave_token_add(cur, (int)tok, ok, true);
     if (ok) perm[slot] = i;
@@ -312,8 +316,10 @@ constexpr int EMB_CH = 16;
 template <typename T>
 __global__ __launch_bounds__(128) void embed_gather_kernel(const float* __restrict__ dxt, const T* __restrict__ xt, const int64_t* __restrict__ tokens,
                                                            int ldtok, int N, int V1, const int* __restrict__ off, const int* __restrict__ perm, int total,
-                                                           int E, float inv_keep, long skip_token, float* __restrict__ dtable) {
-  const int start = blockIdx.x * EMB_CH;
+                                                           int E, float inv_keep, long skip_token, float* __restrict__ dtable, int base, int keybase,
+                                                           int accum) {
+  // entries [base, total) of the list; keybase = this chunk's first bucket key; accum: the table already holds earlier chunks' sums
+  const int start = base + blockIdx.x * EMB_CH;
   const int cnt = min(EMB_CH, total - start);
   __shared__ int s_pos[EMB_CH];
   __shared__ int s_tok[EMB_CH];
@@ -362,9 +368,11 @@ __global__ __launch_bounds__(128) void embed_gather_kernel(const float* __restri
             float* o = dtable + (size_t)s_tok[j] * E + c * 4;
             // a bucket that lies wholly inside this workgroup's entries (most tokens occur once or twice) is stored, not added:
             // the table was zeroed and nobody else touches the row; only hot / straddling buckets pay for atomics
-            const bool whole = off[s_tok[j]] >= start && off[s_tok[j] + 1] <= start + cnt;
+            const bool whole = off[keybase + s_tok[j]] >= start && off[keybase + s_tok[j] + 1] <= start + cnt;
             if (whole) {
-              *(float4*)o = make_float4(acc.x * inv_keep, acc.y * inv_keep, acc.z * inv_keep, acc.w * inv_keep);
+              float4 v = make_float4(acc.x * inv_keep, acc.y * inv_keep, acc.z * inv_keep, acc.w * inv_keep);
+              if (accum) { const float4 q = *(const float4*)o; v.x += q.x; v.y += q.y; v.z += q.z; v.w += q.w; }
+              *(float4*)o = v;
             } else {
               atomicAdd(o, acc.x * inv_keep); atomicAdd(o + 1, acc.y * inv_keep); atomicAdd(o + 2, acc.z * inv_keep); atomicAdd(o + 3, acc.w * inv_keep);
             }
@@ -1400,48 +1408,61 @@ int uic_embed_bwd_launch(int dtype, const float* dxt, const void* xt, const int6
   UIC_LAUNCH_CHECK("embed_bwd");
   return UIC_OK;
 }
-size_t uic_embed_bwd_sorted_scratch_ints(int N, int T, int V1) { return (size_t)3 * (V1 + 1) + (size_t)N * T + 64; }
+size_t uic_embed_bwd_sorted_scratch_ints(int N, int T, int V1, int chunk) {
+  const size_t nkeys = (size_t)(chunk > 0 ? (T + chunk - 1) / chunk : 1) * V1;
+  return 3 * (nkeys + 1) + (size_t)N * T + 64;
+}
 // Two halves, so that a caller can do the token bucketing (which needs only the tokens) long before the gradients exist:
 //   prepare: zero dtable, histogram -> scan -> fill of the position list into `scratch`;   gather: the sums.
-int uic_embed_bwd_sorted_prepare(const int64_t* tokens, int ldtok, int N, int T, int V1, int E, float* dtable, int* scratch, hipStream_t s) {
+// chunk > 0: the list is ordered by hand-off chunk (chunk decode steps each) first; gather then takes steps [t0, t1) of ONE chunk
+// per call (t0 a multiple of chunk) and adds into the table, so every chunk's share can be gathered as soon as its d xt exists.
+int uic_embed_bwd_sorted_prepare(const int64_t* tokens, int ldtok, int N, int T, int V1, int E, float* dtable, int* scratch, hipStream_t s, int chunk) {
   UIC_REQUIRE(E % 4 == 0 && scratch, "embed_bwd_sorted: E=%d must be a multiple of 4", E);
   if (V1 == 0) return UIC_OK;
+  const int nkeys = (chunk > 0 ? (T + chunk - 1) / chunk : 1) * V1;
   int* cnt = scratch;
-  int* off = cnt + (V1 + 1);
-  int* cur = off + (V1 + 1);
-  int* perm = cur + (V1 + 1);
+  int* off = cnt + (nkeys + 1);
+  int* cur = off + (nkeys + 1);
+  int* perm = cur + (nkeys + 1);
   const int total = N * T;
   UIC_TRY(uic_fill_launch(dtable, 0, (size_t)V1 * E * 4, s));
   if (total == 0) return UIC_OK;
-  UIC_TRY(uic_fill_launch(cnt, 0, (size_t)(V1 + 1) * 4, s));
+  UIC_TRY(uic_fill_launch(cnt, 0, (size_t)(nkeys + 1) * 4, s));
   const int g = grid_for((size_t)total, NT);
-  hipLaunchKernelGGL(embed_hist_kernel, dim3(g), dim3(NT), 0, s, tokens, ldtok, N, T, V1, cnt);
+  hipLaunchKernelGGL(embed_hist_kernel, dim3(g), dim3(NT), 0, s, tokens, ldtok, N, T, V1, chunk > 0 ? chunk : 0, cnt);
   UIC_LAUNCH_CHECK("embed_hist");
-  hipLaunchKernelGGL(embed_scan_kernel, dim3(1), dim3(1024), 0, s, (const int*)cnt, V1, off, cur);
+  hipLaunchKernelGGL(embed_scan_kernel, dim3(1), dim3(1024), 0, s, (const int*)cnt, nkeys, off, cur);
   UIC_LAUNCH_CHECK("embed_scan");
-  hipLaunchKernelGGL(embed_fill_kernel, dim3(g), dim3(NT), 0, s, tokens, ldtok, N, T, V1, cur, perm);
+  hipLaunchKernelGGL(embed_fill_kernel, dim3(g), dim3(NT), 0, s, tokens, ldtok, N, T, V1, chunk > 0 ? chunk : 0, cur, perm);
   UIC_LAUNCH_CHECK("embed_fill");
   return UIC_OK;
 }
 int uic_embed_bwd_sorted_gather(int dtype, const float* dxt, const void* xt, const int64_t* tokens, int ldtok, int N, int T,
-                                int V1, int E, float drop_p, long skip_token, float* dtable, const int* scratch, hipStream_t s) {
-  const int total = N * T;
-  if (V1 == 0 || total == 0) return UIC_OK;
-  const int* off = scratch + (V1 + 1);
-  const int* perm = scratch + 3 * (V1 + 1);
+                                int V1, int E, float drop_p, long skip_token, float* dtable, const int* scratch, hipStream_t s,
+                                int chunk, int t0, int t1) {
+  if (V1 == 0 || N * T == 0) return UIC_OK;
+  int base = 0, total = N * T, keybase = 0, nkeys = V1;
+  if (chunk > 0) {
+    UIC_REQUIRE(t0 >= 0 && t0 % chunk == 0 && t1 > t0 && t1 <= T && t1 <= t0 + chunk, "embed_bwd_sorted_gather: steps [%d, %d) are not one chunk of %d", t0, t1, chunk);
+    nkeys = (T + chunk - 1) / chunk * V1;
+    base = t0 * N; total = t1 * N; keybase = t0 / chunk * V1;
+  }
+  const int* off = scratch + (nkeys + 1);
+  const int* perm = scratch + 3 * (nkeys + 1);
   const float inv_keep = drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f;
-  const int gw = (total + EMB_CH - 1) / EMB_CH;
+  const int gw = (total - base + EMB_CH - 1) / EMB_CH;
+  const int accum = chunk > 0;     // (the table was zeroed by prepare; within one launch a whole bucket still has one owner)
   DISPATCH_T(dtype,
-             hipLaunchKernelGGL(embed_gather_kernel<bf16_t>, dim3(gw), dim3(128), 0, s, dxt, (const bf16_t*)xt, tokens, ldtok, N, V1, off, perm, total, E, inv_keep, skip_token, dtable),
-             hipLaunchKernelGGL(embed_gather_kernel<float>, dim3(gw), dim3(128), 0, s, dxt, (const float*)xt, tokens, ldtok, N, V1, off, perm, total, E, inv_keep, skip_token, dtable));
+             hipLaunchKernelGGL(embed_gather_kernel<bf16_t>, dim3(gw), dim3(128), 0, s, dxt, (const bf16_t*)xt, tokens, ldtok, N, V1, off, perm, total, E, inv_keep, skip_token, dtable, base, keybase, accum),
+             hipLaunchKernelGGL(embed_gather_kernel<float>, dim3(gw), dim3(128), 0, s, dxt, (const float*)xt, tokens, ldtok, N, V1, off, perm, total, E, inv_keep, skip_token, dtable, base, keybase, accum));
   UIC_LAUNCH_CHECK("embed_gather");
   return UIC_OK;
 }
 // dtable [V1, E] is overwritten.  scratch: uic_embed_bwd_sorted_scratch_ints ints.
 int uic_embed_bwd_sorted_launch(int dtype, const float* dxt, const void* xt, const int64_t* tokens, int ldtok, int N, int T,
                                 int V1, int E, float drop_p, long skip_token, float* dtable, int* scratch, hipStream_t s) {
-  UIC_TRY(uic_embed_bwd_sorted_prepare(tokens, ldtok, N, T, V1, E, dtable, scratch, s));
-  return uic_embed_bwd_sorted_gather(dtype, dxt, xt, tokens, ldtok, N, T, V1, E, drop_p, skip_token, dtable, scratch, s);
+  UIC_TRY(uic_embed_bwd_sorted_prepare(tokens, ldtok, N, T, V1, E, dtable, scratch, s, 0));
+  return uic_embed_bwd_sorted_gather(dtype, dxt, xt, tokens, ldtok, N, T, V1, E, drop_p, skip_token, dtable, scratch, s, 0, 0, 0);
 }
 // out[c] = sum_n part[n, c] for the ncols <= 1024 columns of a small [rows, ncols] f32 matrix, split over two destinations
 // (columns [0, n0) -> out0, the rest -> out1): d w_alpha / d b_alpha from the attention accumulation's per-row partials in ONE

@@ -625,7 +625,23 @@ __device__ __forceinline__ void ws_run(const UicRnnFwdParams& p, Ctx& c, char* l
   // The recurrence-independent share of att_lstm's gate pre-activations (xt and fc' terms and both biases, one f32 tensor
   // made by the batched input GEMM) and the cell state of step `ts`, for the 4 rows x 1 unit this lane finishes in row tile
   // `tile`.  They come from HBM / the Infinity Cache.
-  auto load_pre = [&](int ts, int tile, float (&pv)[4][4], float (&cp)[4]) {
+  // The caption row's fc' share (Gfc, when the host keeps it out of gx) is the same at every step: read once, kept in registers.
+  float gfo[4][4], gf5[4];
+  {
+    const unsigned u = (unsigned)(c.u0 + c.l15);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int rr = 16 * c.wave + 4 * c.lq + r;
+      const unsigned n1 = (unsigned)((c.rbegin + (rr < c.nrow ? rr : c.nrow - 1)) * HH);
+#pragma unroll
+      for (int g = 0; g < 4; ++g) gfo[r][g] = p.gfc ? p.gfc[4u * n1 + (unsigned)(g * HH) + u] : 0.f;
+    }
+    const int rr = 16 * WS_NW + 4 * c.lq + c.wave;
+    const unsigned n1 = (unsigned)((c.rbegin + (rr < c.nrow ? rr : c.nrow - 1)) * HH);
+#pragma unroll
+    for (int g = 0; g < 4; ++g) gf5[g] = p.gfc ? p.gfc[4u * n1 + (unsigned)(g * HH) + u] : 0.f;
+  }
+  auto load_pre = [&](int ts, int tile, float (&pv)[4][4], float (&cp)[4]) {     // (tile == this wave's own tile)
     const float* gx = p.gx + (size_t)ts * N * 4 * HH;
     const float* c_prev = p.c_att + (size_t)ts * NH;
     const unsigned u = (unsigned)(c.u0 + c.l15);
@@ -635,7 +651,7 @@ __device__ __forceinline__ void ws_run(const UicRnnFwdParams& p, Ctx& c, char* l
       const unsigned n1 = (unsigned)((c.rbegin + (rr < c.nrow ? rr : c.nrow - 1)) * HH);
       cp[r] = c_prev[n1 + u];
 #pragma unroll
-      for (int g = 0; g < 4; ++g) pv[r][g] = gx[4u * n1 + (unsigned)(g * HH) + u] + (p.gfc ? p.gfc[4u * n1 + (unsigned)(g * HH) + u] : 0.f);
+      for (int g = 0; g < 4; ++g) pv[r][g] = gx[4u * n1 + (unsigned)(g * HH) + u];
     }
   };
   // fifth tile: its cell update is shared by the four waves, wave w takes row 4 lq + w of every 4-row group
@@ -646,7 +662,7 @@ __device__ __forceinline__ void ws_run(const UicRnnFwdParams& p, Ctx& c, char* l
     const unsigned n1 = (unsigned)((c.rbegin + (rr < c.nrow ? rr : c.nrow - 1)) * HH);
     cp = p.c_att[(size_t)ts * NH + n1 + u];
 #pragma unroll
-    for (int g = 0; g < 4; ++g) pv[g] = gx[4u * n1 + (unsigned)(g * HH) + u] + (p.gfc ? p.gfc[4u * n1 + (unsigned)(g * HH) + u] : 0.f);
+    for (int g = 0; g < 4; ++g) pv[g] = gx[4u * n1 + (unsigned)(g * HH) + u];
   };
 #if WS_EARLY_PRE
   float pvn[4][4], cpn[4];                          // of the NEXT att_lstm phase, own tile (tile = wave): requested one phase early
@@ -750,6 +766,10 @@ __device__ __forceinline__ void ws_run(const UicRnnFwdParams& p, Ctx& c, char* l
         }
         u32x4 (&f5)[CK] = fa[NCK > 1 ? (NCK & 1) : 0];
         if (dbg && c.tid == 0) dbg[8] = __builtin_amdgcn_s_memrealtime();
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+          for (int g = 0; g < 4; ++g) pvn[r][g] += gfo[r][g];
         ws_cell<SAFE>(c, i, acc, pvn, cpn, p.c_att + (size_t)(t + 1) * NH, h_att_new, (T*)nullptr,
                       p.gates1 ? (T*)p.gates1 + (size_t)t * N * 4 * HH : nullptr, 0.f, 0u, 0u);
         if (dbg && c.tid == 0) dbg[9] = __builtin_amdgcn_s_memrealtime();
@@ -781,10 +801,10 @@ __device__ __forceinline__ void ws_run(const UicRnnFwdParams& p, Ctx& c, char* l
             }
             const int rr = 16 * WS_NW + 4 * c.lq + c.wave;
             const unsigned u = (unsigned)(c.u0 + c.l15);
-            const float gi = uic_sigmoid_t<bf16_t>(sg4[0] + pv5[0]);
-            const float gf = uic_sigmoid_t<bf16_t>(sg4[1] + pv5[1]);
-            const float gg = uic_tanh<bf16_t>(sg4[2] + pv5[2]);
-            const float go = uic_sigmoid_t<bf16_t>(sg4[3] + pv5[3]);
+            const float gi = uic_sigmoid_t<bf16_t>(sg4[0] + (pv5[0] + gf5[0]));
+            const float gf = uic_sigmoid_t<bf16_t>(sg4[1] + (pv5[1] + gf5[1]));
+            const float gg = uic_tanh<bf16_t>(sg4[2] + (pv5[2] + gf5[2]));
+            const float go = uic_sigmoid_t<bf16_t>(sg4[3] + (pv5[3] + gf5[3]));
             const float cn = gf * cp5 + gi * gg;
             const float h = go * uic_tanh<bf16_t>(cn);
             if (rr < c.nrow) {

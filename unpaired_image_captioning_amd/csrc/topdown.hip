@@ -30,6 +30,9 @@ constexpr int WG_CHUNK = UIC_WG_CHUNK;   // decode steps per hand-off between th
 #ifndef UIC_BPTT_FUSE_CELL
 #define UIC_BPTT_FUSE_CELL 1
 #endif
+#ifndef UIC_GFC_SEPARATE
+#define UIC_GFC_SEPARATE 1
+#endif
 constexpr int BPTT_SPLIT = UIC_BPTT_SPLIT;   // K slices of the BPTT loop's d x GEMMs (Step::bptt_split)
 
 struct Layout {
@@ -177,7 +180,7 @@ Layout make_layout(const uic_topdown_dims& d, void* ws) {
     L.slab = (float*)b.take(sl);
     L.slab2 = (float*)b.take(sl);
   }
-  L.embed_scratch = (int*)b.take(uic_embed_bwd_sorted_scratch_ints(N, T, V1) * 4);
+  L.embed_scratch = (int*)b.take(uic_embed_bwd_sorted_scratch_ints(N, T, V1, WG_CHUNK) * 4);
   L.fcwT = b.take(Dfc * H * S);
   L.attwT = b.take(D * H * S);
   L.ones_rows = rup8((size_t)WG_CHUNK * N) > (size_t)N * R ? rup8((size_t)WG_CHUNK * N) : (size_t)N * R;
@@ -643,24 +646,44 @@ struct Step {
   // scheduled sampling (AttModel.py:130-143) is active in train mode only
   bool ss_on() const { return (training & 1) && b->ss_prob > 0.f; }
   bool embed_prepared = false;   // the fused step bucketed the tokens (uic_embed_bwd_sorted_prepare) while the side stream was idle
+  // d.recurrence & UIC_REC_EARLY_GRADS (fused step): the embedding gradient and the fc' columns of att_lstm.weight_ih are
+  // produced chunk by chunk behind the BPTT loop (wgrad_chunk) instead of in the side stream's tail -- a few more, smaller
+  // launches, and in exchange both tensors are final with gradient group 1 (uic_topdown_grad_ready_wait)
+  bool early_grads() const { return (d.recurrence & UIC_REC_EARLY_GRADS) != 0; }
+  const int64_t* embed_tokens() const { return ss_on() ? L.tok_used : b->labels; }
+  int embed_ldtok() const { return ss_on() ? d.T : b->ld_labels; }
 
   // ---------------------------------------------------------------- forward
   // part: 0 = everything on one stream; 1 = the branch that ends in the batched input GEMM (fc_embed, embedding, Gfc, Gx,
   // initial state), 2 = the att_embed / ctx2att branch -- independent of each other (the fused step forks them)
+  // gfc_separate: the persistent recurrence adds the caption row's fc' term (Gfc) itself, so the batched input GEMM (the long
+  // pole of the prologue's side-stream branch) no longer queues behind cast -> fc_embed -> Gfc; the launch chain keeps Gfc
+  // folded into Gx (one operand less per step).  Same f32 additions in the same order either way.
+  bool gfc_separate() const { return UIC_GFC_SEPARATE && persist_ok(); }
+  int fwd_embed(hipStream_t s) {
+    // xt_t = dropout(relu(embed[labels[:, t]])) for all steps (AttModel.py:145,160)
+    return uic_embed_fwd_launch(dt, w->embed_w, V1, E, b->labels, b->ld_labels, N, t_run, drop_p, seed, UIC_SITE_EMBED, 0, 1, L.xt_all, s);
+  }
+  int fwd_gx(hipStream_t s, bool with_gfc) {
+    // Gx = xt W_ih[:, 2H:]^T + b_ih + b_hh [+ Gfc (every step's rows get their caption row's fc' term)], all steps
+    UicGemmParams g = gemm_base(dt, Meff, H4);
+    add_seg(g, L.xt_all, E, off(dv.att_w_ih, 2 * H, dt), ldih, E);
+    g.C = L.gx; g.ldc = H4; g.bias = w->att_lstm_b_ih; g.bias2 = w->att_lstm_b_hh; g.flags = UIC_GEMM_OUT_F32;
+    if (with_gfc) { g.addend = L.gfc; g.add_mod = N; g.ld_add = H4; }
+    return uic_gemm_launch(g, s);
+  }
   int fwd_prologue(hipStream_t s, int part = 0) {
     const void *f, *a;
+    const bool sep = gfc_separate();
+    if (part != 2 && sep) {
+      UIC_TRY(fwd_embed(s));
+      UIC_TRY(fwd_gx(s, false));
+    }
     UIC_TRY(prepare_features(d, w, dv, b, L, training, drop_p, seed, &f, &a, s, part));
     if (part == 2) return UIC_OK;
-    // xt_t = dropout(relu(embed[labels[:, t]])) for all steps (AttModel.py:145,160)
-    UIC_TRY(uic_embed_fwd_launch(dt, w->embed_w, V1, E, b->labels, b->ld_labels, N, t_run, drop_p, seed, UIC_SITE_EMBED, 0, 1, L.xt_all, s));
+    if (!sep) UIC_TRY(fwd_embed(s));
     UIC_TRY(fwd_gfc(s));
-    {  // Gx = xt W_ih[:, 2H:]^T + b_ih + b_hh + Gfc (every step's rows get their caption row's fc' term), all steps
-      UicGemmParams g = gemm_base(dt, Meff, H4);
-      add_seg(g, L.xt_all, E, off(dv.att_w_ih, 2 * H, dt), ldih, E);
-      g.C = L.gx; g.ldc = H4; g.bias = w->att_lstm_b_ih; g.bias2 = w->att_lstm_b_hh; g.flags = UIC_GEMM_OUT_F32;
-      g.addend = L.gfc; g.add_mod = N; g.ld_add = H4;
-      UIC_TRY(uic_gemm_launch(g, s));
-    }
+    if (!sep) UIC_TRY(fwd_gx(s, true));
     if (ss_on()) UIC_TRY(uic_copy_tokens_launch(b->labels, b->ld_labels, N, t_run, L.tok_used, d.T, s));
     // init_hidden (AttModel.py:94-97): slot 0 of the four state buffers, one launch
     return uic_zero4_launch(L.h_att, NH * S, L.h_lang, NH * S, L.c_att, NH * 4, L.c_lang, NH * 4, s);
@@ -751,7 +774,7 @@ struct Step {
     UicRnnFwdParams p;
     memset(&p, 0, sizeof(p));
     p.dtype = dt; p.N = N; p.R = R; p.t0 = t0; p.t1 = t1;
-    p.gx = L.gx; p.gfc = nullptr;     // (Gfc is already folded into Gx)
+    p.gx = L.gx; p.gfc = gfc_separate() ? L.gfc : nullptr;
     p.att_w_ih = dv.att_w_ih; p.ld_att_ih = ldih; p.att_w_hh = dv.att_w_hh;
     p.lang_w_ih = dv.lang_w_ih; p.lang_w_hh = dv.lang_w_hh;
     p.lang_b_ih = w->lang_lstm_b_ih; p.lang_b_hh = w->lang_lstm_b_hh;
@@ -1032,6 +1055,28 @@ struct Step {
       const WDest dd[3] = {{G->att_lstm_w_ih, ldih, 0, H}, {G->att_lstm_w_ih + 2 * H, ldih, H, E}, {G->att_lstm_w_hh, H, H + E, H}};
       UIC_TRY(wgrad_group(L.slab2, off(L.dg1_all, r0 * H4, dt), H4, H4, segs, 3, rows, dd, 3, s, !first, L.tSA, L.tSB));
     }
+    if (!early_grads()) return UIC_OK;
+    {  // d xt of the chunk -> its share of the embedding table (positions bucketed chunk-major by the prepare half)
+      UicGemmParams g = gemm_base(dt, rows, E);
+      add_seg(g, off(L.dg1_all, r0 * H4, dt), H4, dv.wxT, H4, H4);
+      g.C = L.dxt + r0 * E; g.ldc = E; g.flags = UIC_GEMM_OUT_F32;
+      UIC_TRY(uic_gemm_launch(g, s));
+      UIC_TRY(uic_embed_bwd_sorted_gather(dt, L.dxt, L.xt_all, embed_tokens(), embed_ldtok(), N, t_run, V1, E, drop_p, -1, G->embed_w,
+                                          L.embed_scratch, s, WG_CHUNK, t0, t1));
+    }
+    // fc' path: the chunk's share of dGfc = sum_t dG1_t -> the fc' columns of att_lstm.weight_ih and d fc'
+    UIC_TRY(uic_sum_steps_launch(dt, off(L.dg1_all, r0 * H4, dt), t1 - t0, (size_t)N * H4, L.dgfc, s));
+    {
+      const UicGemmTnSeg seg{L.fcp, H, H};
+      const WDest d1{G->att_lstm_w_ih + H, ldih, 0, H};
+      UIC_TRY(wgrad_group(L.slab2, L.dgfc, H4, H4, &seg, 1, N, &d1, 1, s, !first, L.tSA, L.tSB));
+    }
+    {
+      UicGemmParams g = gemm_base(dt, N, H);
+      add_seg(g, L.dgfc, H4, dv.wfcpT, H4, H4);
+      g.C = L.dfcp; g.ldc = H; g.flags = UIC_GEMM_OUT_F32 | (first ? 0 : UIC_GEMM_ACCUM);
+      UIC_TRY(uic_gemm_launch(g, s));
+    }
     return UIC_OK;
   }
   // true when EVERY chunk's LSTM weight-gradient GEMM takes the direct transposing-read (TN) path with room for one more
@@ -1067,28 +1112,30 @@ struct Step {
     if (!(chunked && bias_in_chunks()))
       UIC_TRY(uic_colsum_launch(dt, L.dg1_all, Meff, H4, H4, G->att_lstm_b_ih, colscratch, L.colscratch_floats, s));
     UIC_TRY(uic_copy_launch(G->att_lstm_b_hh, G->att_lstm_b_ih, (size_t)H4 * 4, s));
-    {  // d xt -> embedding table
-      UicGemmParams g = gemm_base(dt, Meff, E);
-      add_seg(g, L.dg1_all, H4, dv.wxT, H4, H4);
-      g.C = L.dxt; g.ldc = E; g.flags = UIC_GEMM_OUT_F32;
-      UIC_TRY(uic_gemm_launch(g, s));
-      if (!embed_prepared)
-        UIC_TRY(uic_embed_bwd_sorted_prepare(ss_on() ? L.tok_used : b->labels, ss_on() ? d.T : b->ld_labels, N, t_run, V1, E, G->embed_w, L.embed_scratch, s));
-      UIC_TRY(uic_embed_bwd_sorted_gather(dt, L.dxt, L.xt_all, ss_on() ? L.tok_used : b->labels, ss_on() ? d.T : b->ld_labels, N, t_run,
-                                          V1, E, drop_p, -1, G->embed_w, L.embed_scratch, s));
-    }
-    // fc' path: dGfc = sum_t dG1_t
-    UIC_TRY(uic_sum_steps_launch(dt, L.dg1_all, t_run, (size_t)N * H4, L.dgfc, s));
-    {
-      const UicGemmTnSeg seg{L.fcp, H, H};
-      const WDest d1{G->att_lstm_w_ih + H, ldih, 0, H};
-      UIC_TRY(wgrad_group(slab, L.dgfc, H4, H4, &seg, 1, N, &d1, 1, s, false, tA, tB));
-    }
-    {
-      UicGemmParams g = gemm_base(dt, N, H);
-      add_seg(g, L.dgfc, H4, dv.wfcpT, H4, H4);
-      g.C = L.dfcp; g.ldc = H; g.flags = UIC_GEMM_OUT_F32;
-      UIC_TRY(uic_gemm_launch(g, s));
+    if (!(chunked && early_grads())) {   // (else wgrad_chunk produced them chunk by chunk)
+      {  // d xt -> embedding table
+        UicGemmParams g = gemm_base(dt, Meff, E);
+        add_seg(g, L.dg1_all, H4, dv.wxT, H4, H4);
+        g.C = L.dxt; g.ldc = E; g.flags = UIC_GEMM_OUT_F32;
+        UIC_TRY(uic_gemm_launch(g, s));
+        if (!embed_prepared)
+          UIC_TRY(uic_embed_bwd_sorted_prepare(embed_tokens(), embed_ldtok(), N, t_run, V1, E, G->embed_w, L.embed_scratch, s));
+        UIC_TRY(uic_embed_bwd_sorted_gather(dt, L.dxt, L.xt_all, embed_tokens(), embed_ldtok(), N, t_run,
+                                            V1, E, drop_p, -1, G->embed_w, L.embed_scratch, s));
+      }
+      // fc' path: dGfc = sum_t dG1_t
+      UIC_TRY(uic_sum_steps_launch(dt, L.dg1_all, t_run, (size_t)N * H4, L.dgfc, s));
+      {
+        const UicGemmTnSeg seg{L.fcp, H, H};
+        const WDest d1{G->att_lstm_w_ih + H, ldih, 0, H};
+        UIC_TRY(wgrad_group(slab, L.dgfc, H4, H4, &seg, 1, N, &d1, 1, s, false, tA, tB));
+      }
+      {
+        UicGemmParams g = gemm_base(dt, N, H);
+        add_seg(g, L.dgfc, H4, dv.wfcpT, H4, H4);
+        g.C = L.dfcp; g.ldc = H; g.flags = UIC_GEMM_OUT_F32;
+        UIC_TRY(uic_gemm_launch(g, s));
+      }
     }
     UIC_TRY(uic_relu_mask_bwd_launch(dt, L.dfcp, L.fcp, inv_keep, L.dfcpre, NH, s));
     {
@@ -1382,8 +1429,11 @@ int uic_topdown_xe_train_step(const uic_topdown_dims* d, const uic_topdown_weigh
   // finished chunk (transposes + accumulating GEMMs), so only the last chunk's share outlives the loop
   UIC_TRY(wait_refresh(s));                           // the BPTT loop reads the transposed weight copies
   UIC_TRY(st.bwd_begin(s));
-  if (!st.ss_on()) {   // the embedding gradient's token bucketing needs only the labels: in the side stream's slack inside the BPTT window
-    UIC_TRY(uic_embed_bwd_sorted_prepare(b->labels, b->ld_labels, d->N, t_run, d->V1, d->E, G->embed_w, st.L.embed_scratch, s2));
+  if (!st.ss_on() || st.early_grads()) {
+    // the embedding gradient's token bucketing needs only the tokens (labels; under scheduled sampling the tokens the forward
+    // pass fed, which the side stream has waited for): in the side stream's slack inside the BPTT window
+    UIC_TRY(uic_embed_bwd_sorted_prepare(st.embed_tokens(), st.embed_ldtok(), d->N, t_run, d->V1, d->E, G->embed_w, st.L.embed_scratch, s2,
+                                         st.early_grads() ? CH : 0));
     st.embed_prepared = true;
   }
   for (int c = nchunk - 1; c >= 0; --c) {

@@ -342,13 +342,16 @@ int uic_embed_bwd_launch(int dtype, const float* dxt, const void* xt, const int6
                          int V1, int E, float drop_p, long skip_token, float* dtable, hipStream_t s);   // skip_token < 0: none (nn.Embedding padding_idx otherwise)
 // the same with the positions bucketed by token first, so that runs of equal tokens are summed in registers and a hot token
 // (padding) costs 1/16 of the contended atomics: dtable is overwritten; scratch = uic_embed_bwd_sorted_scratch_ints(N, T, V1) ints
-size_t uic_embed_bwd_sorted_scratch_ints(int N, int T, int V1);
+size_t uic_embed_bwd_sorted_scratch_ints(int N, int T, int V1, int chunk = 0);
 int uic_embed_bwd_sorted_launch(int dtype, const float* dxt, const void* xt, const int64_t* tokens, int ldtok, int N, int T,
                                 int V1, int E, float drop_p, long skip_token, float* dtable, int* scratch, hipStream_t s);
-// the two halves of it: `prepare` needs only the tokens (zeroes dtable, buckets the positions), `gather` the gradients
-int uic_embed_bwd_sorted_prepare(const int64_t* tokens, int ldtok, int N, int T, int V1, int E, float* dtable, int* scratch, hipStream_t s);
+// the two halves of it: `prepare` needs only the tokens (zeroes dtable, buckets the positions), `gather` the gradients.
+// chunk > 0: positions bucketed by (t / chunk, token); gather then adds the share of decode steps [t0, t1) -- one chunk -- per call
+int uic_embed_bwd_sorted_prepare(const int64_t* tokens, int ldtok, int N, int T, int V1, int E, float* dtable, int* scratch, hipStream_t s,
+                                 int chunk = 0);
 int uic_embed_bwd_sorted_gather(int dtype, const float* dxt, const void* xt, const int64_t* tokens, int ldtok, int N, int T,
-                                int V1, int E, float drop_p, long skip_token, float* dtable, const int* scratch, hipStream_t s);
+                                int V1, int E, float drop_p, long skip_token, float* dtable, const int* scratch, hipStream_t s,
+                                int chunk = 0, int t0 = 0, int t1 = 0);
 // column sums of a small f32 [rows, ncols] matrix into two destinations (columns [0, n0) -> out0, the rest -> out1), one launch
 int uic_colsum_small_launch(const float* part, int rows, int ncols, int n0, float* out0, float* out1, hipStream_t s);
 // dst = (act > 0 ? scale : 0) * grad ; grad f32, act/dst operand dtype
