@@ -127,7 +127,7 @@ def recurrence_roofline(tr, batch, t_run, den_local, dtype_name, extra_steps=6):
     try:
         for _ in range(extra_steps):
             tr.train_device_batch(batch, t_run, den_local)
-            ms = (C.c_float * 10)()
+            ms = (C.c_float * L.STEP_MARKS)()
             L.check(lib.uic_topdown_step_marks(1, ms))
             durs.append((ms[2] - ms[1]) * 1e-3)
     finally:

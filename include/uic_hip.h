@@ -43,11 +43,13 @@ int uic_version(void);
  *                        by arrival order) instead of XCD-local groups -- same results bit for bit; tests
  *   UIC_REC_STAMPS       the persistent kernels write per-phase time stamps into the workspace ("rnn_dbg" / "rnn_bwd_dbg" of
  *                        uic_topdown_workspace_ptr: [256 workgroups][T][16] uint64, 100 MHz); tools/
- *   UIC_REC_EARLY_GRADS  (uic_topdown_xe_train_step; set by a data-parallel caller) the embedding gradient and the fc' columns
- *                        of core.att_lstm.weight_ih are produced chunk by chunk behind the BPTT loop instead of in one pass
- *                        after it, so that both tensors are final with gradient group 1 of uic_topdown_grad_ready_wait and
- *                        only ~10 MB of gradients become final in the step's last 0.1 ms.  A few more, smaller launches:
- *                        a single GPU, which waits for nothing, leaves it off.  Same gradients up to f32 summation order
+ *   UIC_REC_EARLY_GRADS  (uic_topdown_xe_train_step) the order of the gradient work that makes most gradient bytes final EARLY:
+ *                        the recurrent weight gradients of a chunk run on two side streams, the embedding gradient of decode
+ *                        steps >= 4 is gathered during the BPTT loop, the fc' columns of att_lstm.weight_ih and the rest of the
+ *                        embedding table come first after it.  48.8 of 78.8 MB are then final 0.17 ms before the step ends and
+ *                        10.5 MB in its last 0.1 ms (default order: 16.8 MB at -0.24 ms, 42.5 MB in the last 0.1 ms), for a step
+ *                        that is 0.12 ms (4 %) longer on its own -- the chip is busy either way (profiles/LOG.md).  For a
+ *                        data-parallel caller to choose; same gradients up to f32 summation order
  * uic_topdown_dims.rnn_status: NULL, or 4 caller-allocated, caller-zeroed uint32 on the device that the persistent kernels
  * update: [0] != 0 after a bounded spin timed out (the results of that call are invalid), [1] / [2] launches that ran with
  * the XCD-local / the SAFE protocol. */
@@ -205,7 +207,7 @@ int uic_topdown_xe_train_step(const uic_topdown_dims* d, const uic_topdown_weigh
  *   group 0: logit.* (and the loss)                       -- final when the BPTT loop STARTS (~25 % of the bytes);
  *   group 1: core.lang_lstm.weight_{ih,hh}, core.att_lstm.weight_hh       -- final right after the BPTT loop (~21 %; the fc'
  *            columns of core.att_lstm.weight_ih still come from the sum over steps, so that matrix belongs to group 2).
- *            With UIC_REC_EARLY_GRADS in dims.recurrence also core.att_lstm.weight_ih and embed.0.weight (~60 % with them);
+ *            With UIC_REC_EARLY_GRADS in dims.recurrence also core.att_lstm.weight_ih and embed.0.weight (~62 % with them);
  *   group 2: everything except the late group {att_embed.*, ctx2att.*, core.attention.h2att.*,
  *            core.attention.alpha_net.*}                   -- final when the embedding / fc_embed / bias gradients are done.
  * A caller that lays its flat gradient arena out as [logit | group 1 | rest of the early group | late group] can
@@ -217,8 +219,9 @@ int uic_topdown_grad_ready_wait(void* stream, int32_t group);
  * for the last marked step and writes, in ms since its first launch: [1] feature projection + batched input GEMMs done,
  * [2] recurrence done, [3] side stream: logit layer + loss + d hdrop done, [4] BPTT loop starts, [5] BPTT loop done,
  * [6] side stream: recurrent weight gradients done, [7] main tail (attention accumulation, ctx2att, att_embed) done,
- * [8] side tail (biases, embedding, fc_embed) done, [9] joined. */
-#define UIC_STEP_MARKS 10
+ * [8] side tail (biases, embedding, fc_embed) done, [9] joined, [10] side stream: logit-layer gradients and the loss final
+ * (gradient group 0 of uic_topdown_grad_ready_wait; group 1 is [6], group 2 is [8]). */
+#define UIC_STEP_MARKS 11
 int uic_topdown_step_marks(int32_t enable, float* ms_out);
 
 /* AttModel._sample with beam_size = 1 (P/models/AttModel.py:198-253): greedy (sample_max = 1) or

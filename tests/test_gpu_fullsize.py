@@ -42,8 +42,9 @@ def case():
 
 
 # uic_topdown_dims.recurrence: per-step launches everywhere / the default (persistent forward recurrence) / the same with
-# the SAFE exchange protocol / persistent BPTT as well / that with the SAFE protocol
-REC_MODES = {"chain": 1, "default": 0, "safe": 4, "bptt": 2, "bptt_safe": 6}
+# the SAFE exchange protocol / persistent BPTT as well / that with the SAFE protocol / UIC_REC_EARLY_GRADS (three streams, the
+# embedding gradient in two halves)
+REC_MODES = {"chain": 1, "default": 0, "safe": 4, "bptt": 2, "bptt_safe": 6, "early": 16}
 
 
 @pytest.mark.parametrize("mode", list(REC_MODES))
@@ -78,7 +79,7 @@ def test_configs1_full_size_vs_oracle(case, dtype, mode):
     launches = (st[1] - before[1], st[2] - before[2])            # (XCD-local, SAFE) persistent launches of this test
     chunks = (t_run + 3) // 4                                      # BPTT: one launch per hand-off chunk of the fused step
     want = {"chain": (0, 0), "default": (2, 0), "safe": (0, 2), "bptt": (2 + (chunks if dtype == "bf16" else 0), 0),
-            "bptt_safe": (0, 2 + (chunks if dtype == "bf16" else 0))}[mode]
+            "bptt_safe": (0, 2 + (chunks if dtype == "bf16" else 0)), "early": (2, 0)}[mode]
     assert launches == want, (mode, launches, want)
     floor = 1e-3 * max(float(v.norm()) for v in ref_grads.values())
     worst = max(((grads[k].float().cpu().double() - r.double()).norm() / max(r.double().norm().item(), floor)).item() for k, r in ref_grads.items())

@@ -1217,3 +1217,38 @@ def test_self_critical_backward_from_kept_forward_equals_replay(dtype, use_bn, S
         grads_close(g0, g1, 2e-4 if dtype == "f32" else 3e-2)
     for k in s0:
         assert absmax(s0[k], s1[k]) < 1e-6, k
+
+
+# ---------------------------------------------------------------- UIC_REC_EARLY_GRADS (the order that finishes most gradient bytes early)
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+@pytest.mark.parametrize("fixture,ss_prob,drop", [("topdown_tiny", 0.0, 0.0), ("topdown_odd", 0.0, 0.5), ("topdown_tiny_earlybreak", 0.0, 0.0),
+                                                  ("topdown_tiny_ss", 0.25, 0.5)])
+def test_early_grads_order_gives_the_same_step(fixture, ss_prob, drop, dtype):
+    """UIC_REC_EARLY_GRADS: a chunk's weight gradients on two side streams, the embedding gradient gathered in two halves
+    (decode steps >= 4 while the BPTT loop still runs, the rest right after it), att_lstm.weight_ih finished before the bias
+    sums -- against the default order.  Same loss, same gradients up to f32 summation order -- with dropout, scheduled
+    sampling (the bucketed tokens are then the ones the forward pass fed), an early break and decode lengths that are not a
+    multiple of the chunk."""
+    from unpaired_image_captioning_amd import _lib as L
+    cfg, W, I = load_golden(fixture)[:3]
+    model = build_model(cfg, W, dtype, drop)
+    model.train()
+    batch = {k: I[k].cuda() for k in ("fc_feats", "att_feats", "labels", "masks", "att_masks") if k in I}
+    runs = {}
+    try:
+        for name, rec in (("late", 0), ("early", L.REC_EARLY_GRADS), ("early_chain", L.REC_EARLY_GRADS | L.REC_FWD_CHAIN)):
+            model.engine.recurrence = rec
+            runs[name] = _ss_run(model, batch, ss_prob, 4321)
+    finally:
+        model.engine.recurrence = 0
+    loss0, g0, used0 = runs["late"][:3]
+    scale0 = 1e-3 * max(v.abs().max().item() for v in g0.values())
+    for name in ("early", "early_chain"):
+        loss1, g1, used1 = runs[name][:3]
+        assert torch.equal(used0, used1)
+        assert abs(loss0.item() - loss1.item()) < 1e-6
+        for k in g0:
+            a, b = g0[k].double(), g1[k].double()
+            scale = max(a.abs().max().item(), scale0)
+            assert (a - b).abs().max().item() <= {"f32": 2e-5, "bf16": 2e-2}[dtype] * scale, (name, k, (a - b).abs().max().item(), scale)
+    assert any(v.abs().max().item() > 0 for v in g0.values())

@@ -106,7 +106,7 @@ def time_step(mode, steps=30):
         loss.item()
         torch.cuda.synchronize()
         wall += e0.elapsed_time(e1)
-        m = (C.c_float * 10)()
+        m = (C.c_float * L.STEP_MARKS)()
         L.check(lib.uic_topdown_step_marks(1, m))
         for i in range(10):
             tot[i] += m[i]

@@ -26,6 +26,7 @@ class Dims(C.Structure):
 
 # uic_topdown_dims.recurrence (include/uic_hip.h)
 REC_FWD_CHAIN, REC_BWD_PERSIST, REC_SAFE, REC_STAMPS, REC_EARLY_GRADS = 1, 2, 4, 8, 16
+STEP_MARKS = 11          # UIC_STEP_MARKS
 
 
 MAX_LOGIT_LAYERS = 4

@@ -250,9 +250,9 @@ __device__ __forceinline__ int wave_token_add(int* base, int tok, bool active, b
   if (active) slot = atomicAdd(base + tok, 1);
   return slot;
 }
-// chunk > 0: the bucket key is (t / chunk) * V1 + token -- positions ordered by hand-off chunk first, so that the positions of
-// decode steps [c chunk, (c + 1) chunk) are entries [c chunk N, (c + 1) chunk N) of the list and can be gathered on their own
-__global__ void embed_hist_kernel(const int64_t* __restrict__ tokens, int ldtok, int N, int TS, int V1, int chunk, int* __restrict__ cnt) {
+// split > 0: the bucket key is (t >= split) * V1 + token -- the positions of decode steps [0, split) are entries [0, split N) of the
+// list, those of [split, T) the rest, and each half can be gathered on its own (the later steps' half while BPTT still runs)
+__global__ void embed_hist_kernel(const int64_t* __restrict__ tokens, int ldtok, int N, int TS, int V1, int split, int* __restrict__ cnt) {
   const int total = TS * N;
   const int span = (total + 63) & ~63;                       // whole waves enter the aggregation together
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < span; i += gridDim.x * blockDim.x) {
@@ -262,7 +262,7 @@ __global__ void embed_hist_kernel(const int64_t* __restrict__ tokens, int ldtok,
       const int t = i / N, n = i - t * N;
       tok = tokens[(size_t)n * ldtok + t];
       if (tok < 0 || tok >= V1) tok = 0;
-      if (chunk) tok += (long)(t / chunk) * V1;
+      if (split && t >= split) tok += V1;
     }
     wave_token_add(cnt, (int)tok, ok, false);
   }
@@ -293,7 +293,7 @@ __global__ __launch_bounds__(1024) void embed_scan_kernel(const int* __restrict_
   for (int v = lo; v < hi; ++v) { off[v] = run; cur[v] = run; run += cnt[v]; }
   if (threadIdx.x == 0) off[V1] = tot;
 }
-__global__ void embed_fill_kernel(const int64_t* __restrict__ tokens, int ldtok, int N, int TS, int V1, int chunk, int* __restrict__ cur, int* __restrict__ perm) {
+__global__ void embed_fill_kernel(const int64_t* __restrict__ tokens, int ldtok, int N, int TS, int V1, int split, int* __restrict__ cur, int* __restrict__ perm) {
   const int total = TS * N;
   const int span = (total + 63) & ~63;
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < span; i += gridDim.x * blockDim.x) {
@@ -303,7 +303,7 @@ __global__ void embed_fill_kernel(const int64_t* __restrict__ tokens, int ldtok,
       const int t = i / N, n = i - t * N;
       tok = tokens[(size_t)n * ldtok + t];
       if (tok < 0 || tok >= V1) tok = 0;
-      if (chunk) tok += (long)(t / chunk) * V1;
+      if (split && t >= split) tok += V1;
     }
     const int slot = wave_token_add(cur, (int)tok, ok, true);
     if (ok) perm[slot] = i;
@@ -1408,18 +1408,17 @@ int uic_embed_bwd_launch(int dtype, const float* dxt, const void* xt, const int6
   UIC_LAUNCH_CHECK("embed_bwd");
   return UIC_OK;
 }
-size_t uic_embed_bwd_sorted_scratch_ints(int N, int T, int V1, int chunk) {
-  const size_t nkeys = (size_t)(chunk > 0 ? (T + chunk - 1) / chunk : 1) * V1;
-  return 3 * (nkeys + 1) + (size_t)N * T + 64;
-}
+size_t uic_embed_bwd_sorted_scratch_ints(int N, int T, int V1) { return 3 * ((size_t)2 * V1 + 1) + (size_t)N * T + 64; }
 // Two halves, so that a caller can do the token bucketing (which needs only the tokens) long before the gradients exist:
 //   prepare: zero dtable, histogram -> scan -> fill of the position list into `scratch`;   gather: the sums.
-// chunk > 0: the list is ordered by hand-off chunk (chunk decode steps each) first; gather then takes steps [t0, t1) of ONE chunk
-// per call (t0 a multiple of chunk) and adds into the table, so every chunk's share can be gathered as soon as its d xt exists.
-int uic_embed_bwd_sorted_prepare(const int64_t* tokens, int ldtok, int N, int T, int V1, int E, float* dtable, int* scratch, hipStream_t s, int chunk) {
+// split > 0 (< T): the list holds the positions of decode steps [0, split) first, then those of [split, T); gather then takes one
+// of the two halves per call (half = 0 / 1) and adds into the table, so the later steps' share can be gathered before the
+// earlier steps' d xt exists.  Both calls must get the same `split`.
+int uic_embed_bwd_sorted_prepare(const int64_t* tokens, int ldtok, int N, int T, int V1, int E, float* dtable, int* scratch, hipStream_t s, int split) {
   UIC_REQUIRE(E % 4 == 0 && scratch, "embed_bwd_sorted: E=%d must be a multiple of 4", E);
+  UIC_REQUIRE(split >= 0 && split < (T > 0 ? T : 1), "embed_bwd_sorted: split=%d outside [0, %d)", split, T);
   if (V1 == 0) return UIC_OK;
-  const int nkeys = (chunk > 0 ? (T + chunk - 1) / chunk : 1) * V1;
+  const int nkeys = (split > 0 ? 2 : 1) * V1;
   int* cnt = scratch;
   int* off = cnt + (nkeys + 1);
   int* cur = off + (nkeys + 1);
@@ -1429,29 +1428,29 @@ int uic_embed_bwd_sorted_prepare(const int64_t* tokens, int ldtok, int N, int T,
   if (total == 0) return UIC_OK;
   UIC_TRY(uic_fill_launch(cnt, 0, (size_t)(nkeys + 1) * 4, s));
   const int g = grid_for((size_t)total, NT);
-  hipLaunchKernelGGL(embed_hist_kernel, dim3(g), dim3(NT), 0, s, tokens, ldtok, N, T, V1, chunk > 0 ? chunk : 0, cnt);
+  hipLaunchKernelGGL(embed_hist_kernel, dim3(g), dim3(NT), 0, s, tokens, ldtok, N, T, V1, split, cnt);
   UIC_LAUNCH_CHECK("embed_hist");
   hipLaunchKernelGGL(embed_scan_kernel, dim3(1), dim3(1024), 0, s, (const int*)cnt, nkeys, off, cur);
   UIC_LAUNCH_CHECK("embed_scan");
-  hipLaunchKernelGGL(embed_fill_kernel, dim3(g), dim3(NT), 0, s, tokens, ldtok, N, T, V1, chunk > 0 ? chunk : 0, cur, perm);
+  hipLaunchKernelGGL(embed_fill_kernel, dim3(g), dim3(NT), 0, s, tokens, ldtok, N, T, V1, split, cur, perm);
   UIC_LAUNCH_CHECK("embed_fill");
   return UIC_OK;
 }
 int uic_embed_bwd_sorted_gather(int dtype, const float* dxt, const void* xt, const int64_t* tokens, int ldtok, int N, int T,
                                 int V1, int E, float drop_p, long skip_token, float* dtable, const int* scratch, hipStream_t s,
-                                int chunk, int t0, int t1) {
+                                int split, int half) {
   if (V1 == 0 || N * T == 0) return UIC_OK;
   int base = 0, total = N * T, keybase = 0, nkeys = V1;
-  if (chunk > 0) {
-    UIC_REQUIRE(t0 >= 0 && t0 % chunk == 0 && t1 > t0 && t1 <= T && t1 <= t0 + chunk, "embed_bwd_sorted_gather: steps [%d, %d) are not one chunk of %d", t0, t1, chunk);
-    nkeys = (T + chunk - 1) / chunk * V1;
-    base = t0 * N; total = t1 * N; keybase = t0 / chunk * V1;
+  if (split > 0) {
+    UIC_REQUIRE(split < T && (half == 0 || half == 1), "embed_bwd_sorted_gather: split=%d half=%d (T=%d)", split, half, T);
+    nkeys = 2 * V1;
+    base = half ? split * N : 0; total = half ? T * N : split * N; keybase = half ? V1 : 0;
   }
   const int* off = scratch + (nkeys + 1);
   const int* perm = scratch + 3 * (nkeys + 1);
   const float inv_keep = drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f;
   const int gw = (total - base + EMB_CH - 1) / EMB_CH;
-  const int accum = chunk > 0;     // (the table was zeroed by prepare; within one launch a whole bucket still has one owner)
+  const int accum = split > 0;     // (the table was zeroed by prepare; within one launch a whole bucket still has one owner)
   DISPATCH_T(dtype,
              hipLaunchKernelGGL(embed_gather_kernel<bf16_t>, dim3(gw), dim3(128), 0, s, dxt, (const bf16_t*)xt, tokens, ldtok, N, V1, off, perm, total, E, inv_keep, skip_token, dtable, base, keybase, accum),
              hipLaunchKernelGGL(embed_gather_kernel<float>, dim3(gw), dim3(128), 0, s, dxt, (const float*)xt, tokens, ldtok, N, V1, off, perm, total, E, inv_keep, skip_token, dtable, base, keybase, accum));
@@ -1462,7 +1461,7 @@ int uic_embed_bwd_sorted_gather(int dtype, const float* dxt, const void* xt, con
 int uic_embed_bwd_sorted_launch(int dtype, const float* dxt, const void* xt, const int64_t* tokens, int ldtok, int N, int T,
                                 int V1, int E, float drop_p, long skip_token, float* dtable, int* scratch, hipStream_t s) {
   UIC_TRY(uic_embed_bwd_sorted_prepare(tokens, ldtok, N, T, V1, E, dtable, scratch, s, 0));
-  return uic_embed_bwd_sorted_gather(dtype, dxt, xt, tokens, ldtok, N, T, V1, E, drop_p, skip_token, dtable, scratch, s, 0, 0, 0);
+  return uic_embed_bwd_sorted_gather(dtype, dxt, xt, tokens, ldtok, N, T, V1, E, drop_p, skip_token, dtable, scratch, s, 0, 0);
 }
 // out[c] = sum_n part[n, c] for the ncols <= 1024 columns of a small [rows, ncols] f32 matrix, split over two destinations
 // (columns [0, n0) -> out0, the rest -> out1): d w_alpha / d b_alpha from the attention accumulation's per-row partials in ONE

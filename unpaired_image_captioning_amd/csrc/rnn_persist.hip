@@ -26,6 +26,7 @@
 // the wave that owns the 16-row tile.  bf16 operands -> v_mfma_f32_16x16x32_bf16, f32 -> v_mfma_f32_16x16x4_f32.
 #include "rnn_persist_common.h"
 #include <stdlib.h>
+#include <type_traits>
 
 namespace {
 
@@ -562,7 +563,335 @@ __device__ __forceinline__ void ws_cell(const Ctx& c, int tile, const f32x4 (&s)
   }
 }
 
+
+// ---------------------------------------------------------------------------------------------------
+// Decode mode of the weight-stationary kernel (AttModel._sample, P/models/AttModel.py:198-253: greedy or multinomial, the
+// sampling pass and the greedy baseline of the self-critical step, P/trainer.py:167-171): a step's input token exists only
+// once the previous step has picked it, so three more pieces run inside the launch, all per row group:
+//   dec_xt_gemm   the token's share of att_lstm's gates, dropout(relu(embed[token])) W_x^T, for the rows whose cell update
+//                 this wave finishes -- A fragments built straight from the f32 embedding table, the result stays in the
+//                 registers the cell update reads (the teacher-forced kernel gets it from the batched input GEMM);
+//   dec_logits    logits of the group's rows for this workgroup's 1/32 of the vocabulary (W_logit streamed from L2 / the
+//                 Infinity Cache, A = the rows' dropped h_lang), written out, plus per-row (max, sum exp, arg max) partials;
+//   dec_sample    after a group barrier: every workgroup combines the 32 partials of every row (same order everywhere, so
+//                 all agree); greedy: the arg max; multinomial: the workgroup whose vocabulary range holds the inverse-CDF
+//                 target scans its <= 320 logits of that row.  The row's writer stores token, log-prob and finished flag.
+// Three more group barriers per step than the teacher-forced loop.
+constexpr int DEC_NJ = 5;                 // vocabulary tiles (16 columns) per wave: 32 workgroups x 4 waves x 5 x 16 = 10240 >= V1
+
+template <bool SAFE> __device__ __forceinline__ void st_xi(int* p, int v) {
+  if (SAFE) __hip_atomic_store(p, v, RLX_AGENT);
+  else *p = v;
+}
+__device__ __forceinline__ int ld_xi(const int* p) { return __hip_atomic_load(p, RLX_AGENT); }       // (past the vector L1)
+__device__ __forceinline__ float ld_xf(const float* p) { return __hip_atomic_load(p, RLX_AGENT); }
+
+// (m, s, a) <- the combination of two partial (max, sum of exp(x - max), arg max) triples; `o` lies at HIGHER column indices
+__device__ __forceinline__ void dec_merge(float& m, float& s, int& a, float om, float os, int oa) {
+  const float m2 = fmaxf(m, om);
+  const float e1 = m > -INFINITY ? __expf(m - m2) : 0.f, e2 = om > -INFINITY ? __expf(om - m2) : 0.f;
+  s = s * e1 + os * e2;
+  if (om > m || (om == m && oa < a)) a = oa;
+  m = m2;
+}
+
+// xg[r][g] / xg5[g]: the input token's share of att_lstm's gate pre-activations of step `t`, in the layout ws_cell reads
+// (own tile: rows 16 wave + 4 lq + r; fifth tile: row 64 + 4 lq + wave), unit u0 + l15, gate g
+__device__ __forceinline__ void dec_xt_gemm(const UicRnnFwdParams& p, const Ctx& c, int t, float (&xg)[4][4], float (&xg5)[4]) {
+  const bool own = c.wave < c.MT, five = c.MT > WS_NW;
+  int ra = 16 * c.wave + c.l15, r5 = 16 * WS_NW + c.l15;
+  const bool va = own && ra < c.nrow, v5 = five && r5 < c.nrow;
+  ra = ra < c.nrow ? ra : c.nrow - 1;
+  r5 = r5 < c.nrow ? r5 : c.nrow - 1;
+  int tokA = own ? ld_xi(p.dec_tok + c.rbegin + ra) : 0, tok5 = five ? ld_xi(p.dec_tok + c.rbegin + r5) : 0;
+  tokA = tokA < 0 || tokA >= p.dec_V1 ? 0 : tokA;
+  tok5 = tok5 < 0 || tok5 >= p.dec_V1 ? 0 : tok5;
+  const float* eA = p.dec_embed + (size_t)tokA * HH + c.lq * 8;
+  const float* e5 = p.dec_embed + (size_t)tok5 * HH + c.lq * 8;
+  const float dp = p.dec_xt_drop, inv_keep = dp > 0.f ? 1.f / (1.f - dp) : 1.f;
+  // dropout index of element e of row n at step t: (t N + n) E + e, the index uic_embed_fwd_launch uses for the training layout
+  const unsigned iA = (unsigned)(((size_t)t * p.N + c.rbegin + ra) * HH + c.lq * 8);
+  const unsigned i5 = (unsigned)(((size_t)t * p.N + c.rbegin + r5) * HH + c.lq * 8);
+  const __amdgpu_buffer_rsrc_t r_xw = rsrc_of(p.dec_xw);
+  unsigned boff[4];
+#pragma unroll
+  for (int g = 0; g < 4; ++g) boff[g] = (unsigned)(((g * HH + c.u0 + c.l15) * p.dec_ld_xw + c.lq * 8) * 2);
+  bf16_t* xo = (bf16_t*)p.dec_xt_all;
+  f32x4 acc[2][4];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) acc[i][g] = f32x4{0.f, 0.f, 0.f, 0.f};
+  float4 ra0[2], ra1[2], rb0[2], rb1[2];
+  u32x4 fb[2][4];
+  auto load = [&](int buf, int ks) {
+    ra0[buf] = *(const float4*)(eA + ks * 32); ra1[buf] = *(const float4*)(eA + ks * 32 + 4);
+    rb0[buf] = *(const float4*)(e5 + ks * 32); rb1[buf] = *(const float4*)(e5 + ks * 32 + 4);
+#pragma unroll
+    for (int g = 0; g < 4; ++g) fb[buf][g] = bload<false>(r_xw, boff[g], (unsigned)(ks * 64));
+  };
+  auto frag = [&](const float4& lo, const float4& hi, unsigned idx) {
+    float f[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      f[j] = fmaxf(f[j], 0.f);
+      if (dp > 0.f) f[j] *= uic_drop_scale(p.seed, UIC_SITE_EMBED, idx + (unsigned)j, dp, inv_keep);
+    }
+    return u32x4{uic_pack_bf16x2(f[0], f[1]), uic_pack_bf16x2(f[2], f[3]), uic_pack_bf16x2(f[4], f[5]), uic_pack_bf16x2(f[6], f[7])};
+  };
+  auto step = [&](auto bc, int ks) {
+    constexpr int b = decltype(bc)::value;
+    if (ks + 1 < 16) load(b ^ 1, ks + 1);
+    const u32x4 fa = frag(ra0[b], ra1[b], iA + (unsigned)(ks * 32));
+    const u32x4 f5 = frag(rb0[b], rb1[b], i5 + (unsigned)(ks * 32));
+    if (xo && c.rank == ks) {                      // the embedded inputs, for a backward pass: workgroup ks writes k-step ks
+      if (va) *(u32x4*)(xo + ((size_t)t * p.N + c.rbegin + ra) * HH + ks * 32 + c.lq * 8) = fa;
+      if (v5 && c.wave == 0) *(u32x4*)(xo + ((size_t)t * p.N + c.rbegin + r5) * HH + ks * 32 + c.lq * 8) = f5;
+    }
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      acc[0][g] = mma_bf16(fa, fb[b][g], acc[0][g]);
+      acc[1][g] = mma_bf16(f5, fb[b][g], acc[1][g]);
+    }
+  };
+  load(0, 0);
+  for (int ks = 0; ks < 16; ks += 2) {
+    step(std::integral_constant<int, 0>{}, ks);
+    step(std::integral_constant<int, 1>{}, ks + 1);
+  }
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) xg[r][g] = acc[0][g][r];
+    xg5[g] = c.wave == 0 ? acc[1][g][0] : c.wave == 1 ? acc[1][g][1] : c.wave == 2 ? acc[1][g][2] : acc[1][g][3];
+  }
+}
+
+// LDS layout of the decode tail inside the 32 KB scratch (word 0 is the barrier flag)
+constexpr int DEC_OFF_PM = 256, DEC_OFF_PS = DEC_OFF_PM + WS_NW * 80 * 4, DEC_OFF_PA = DEC_OFF_PS + WS_NW * 80 * 4;
+constexpr int DEC_OFF_CNT = DEC_OFF_PA + WS_NW * 80 * 4, DEC_OFF_LIST = DEC_OFF_CNT + 16;   // list: 80 x {row, rt, M, lse}
+
 template <bool SAFE>
+__device__ __forceinline__ void dec_logits(const UicRnnFwdParams& p, const Ctx& c, int t) {
+  const int V1 = p.dec_V1;
+  const int ntile_all = (V1 + 15) >> 4, per = (ntile_all + PW - 1) / PW;
+  const int tile0 = c.rank * per;
+  const int ntile = min(per, max(0, ntile_all - tile0));
+  const bf16_t* hd = (const bf16_t*)p.hdrop_all + ((size_t)t * p.N + c.rbegin) * HH;
+  const __amdgpu_buffer_rsrc_t r_a = rsrc_of(hd), r_w = rsrc_of(p.dec_logit_w);
+  unsigned aoff[MT_MAX], woff[DEC_NJ];
+  int col[DEC_NJ];
+#pragma unroll
+  for (int i = 0; i < MT_MAX; ++i) {
+    int r = 16 * i + c.l15;
+    r = r < c.nrow ? r : c.nrow - 1;
+    aoff[i] = (unsigned)((r * HH + c.lq * 8) * 2);
+  }
+#pragma unroll
+  for (int j = 0; j < DEC_NJ; ++j) {
+    const bool tv = c.wave + WS_NW * j < ntile;
+    col[j] = tv ? 16 * (tile0 + c.wave + WS_NW * j) + c.l15 : V1;          // >= V1: not a column
+    const int wr = col[j] < V1 ? col[j] : V1 - 1;
+    woff[j] = (unsigned)((wr * HH + c.lq * 8) * 2);
+  }
+  f32x4 acc[MT_MAX][DEC_NJ];
+#pragma unroll
+  for (int i = 0; i < MT_MAX; ++i)
+#pragma unroll
+    for (int j = 0; j < DEC_NJ; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  u32x4 fa[2][MT_MAX], fb[2][DEC_NJ];
+  auto load = [&](int buf, int ks) {
+#pragma unroll
+    for (int j = 0; j < DEC_NJ; ++j) fb[buf][j] = bload<false, true>(r_w, woff[j], (unsigned)(ks * 64));
+#pragma unroll
+    for (int i = 0; i < MT_MAX; ++i)
+      if (i < c.MT) fa[buf][i] = bload<true>(r_a, aoff[i], (unsigned)(ks * 64));
+  };
+  const int ks0 = c.rank & 15;                     // de-phased walk over K, as in the recurrence's GEMMs
+  auto step = [&](auto bc, int q) {
+    constexpr int b = decltype(bc)::value;
+    if (q + 1 < 16) load(b ^ 1, (q + 1 + ks0) & 15);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int i = 0; i < MT_MAX; ++i)
+      if (i < c.MT) {
+#pragma unroll
+        for (int j = 0; j < DEC_NJ; ++j) acc[i][j] = mma_bf16(fa[b][i], fb[b][j], acc[i][j]);
+      }
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  load(0, ks0);
+  for (int q = 0; q < 16; q += 2) {
+    step(std::integral_constant<int, 0>{}, q);
+    step(std::integral_constant<int, 1>{}, q + 1);
+  }
+  // bias, store, per-row partials.  D layout: the lane holds rows 4 lq + r, column l15 of every 16 x 16 tile
+  float bias[DEC_NJ];
+#pragma unroll
+  for (int j = 0; j < DEC_NJ; ++j) bias[j] = col[j] < V1 && p.dec_logit_b ? p.dec_logit_b[col[j]] : 0.f;
+  float* lg = p.dec_logits + (size_t)t * p.dec_logits_step;
+  float* pm = (float*)(c.smem + DEC_OFF_PM);
+  float* ps = (float*)(c.smem + DEC_OFF_PS);
+  int* pa = (int*)(c.smem + DEC_OFF_PA);
+#pragma unroll
+  for (int i = 0; i < MT_MAX; ++i)
+    if (i < c.MT) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = 16 * i + 4 * c.lq + r;
+        const bool rv = row < c.nrow;
+        float v[DEC_NJ];
+        float m = -INFINITY;
+        int a = 0x7fffffff;
+#pragma unroll
+        for (int j = 0; j < DEC_NJ; ++j) {
+          v[j] = col[j] < V1 ? acc[i][j][r] + bias[j] : -INFINITY;
+          if (rv && col[j] < V1) st_x<SAFE>(lg + (size_t)(c.rbegin + row) * p.dec_V1p + col[j], v[j]);
+          if (v[j] > m) { m = v[j]; a = col[j]; }
+        }
+        float sum = 0.f;
+#pragma unroll
+        for (int j = 0; j < DEC_NJ; ++j) sum += v[j] > -INFINITY ? __expf(v[j] - m) : 0.f;
+        // across the 16 lanes (columns) of the tile row.  Lane l15 ^ o holds other columns of the same tiles: not ordered by
+        // column, so the arg max is merged by (value, lowest index) explicitly
+#pragma unroll
+        for (int o = 1; o < 16; o <<= 1) {
+          const float om = __shfl_xor(m, o, 64), os = __shfl_xor(sum, o, 64);
+          const int oa = __shfl_xor(a, o, 64);
+          dec_merge(m, sum, a, om, os, oa);
+        }
+        if (c.l15 == 0 && rv) { pm[c.wave * 80 + row] = m; ps[c.wave * 80 + row] = sum; pa[c.wave * 80 + row] = a; }
+      }
+    }
+  __syncthreads();
+  if (c.tid < c.nrow) {
+    const int row = c.tid;
+    float m = pm[row], sum = ps[row];
+    int a = pa[row];
+#pragma unroll
+    for (int w = 1; w < WS_NW; ++w) dec_merge(m, sum, a, pm[w * 80 + row], ps[w * 80 + row], pa[w * 80 + row]);
+    float* o = p.dec_part + ((size_t)(c.rbegin + row) * PW + c.rank) * 4;
+    st_x<SAFE>(o, m); st_x<SAFE>(o + 1, sum); st_x<SAFE>(o + 2, __int_as_float(a));
+  }
+}
+
+template <bool SAFE>
+__device__ __forceinline__ void dec_sample(const UicRnnFwdParams& p, const Ctx& c, int t) {
+  const int V1 = p.dec_V1;
+  const int ntile_all = (V1 + 15) >> 4, per = (ntile_all + PW - 1) / PW;
+  int* s_cnt = (int*)(c.smem + DEC_OFF_CNT);
+  float* s_list = (float*)(c.smem + DEC_OFF_LIST);
+  const float* lg = p.dec_logits + (size_t)t * p.dec_logits_step;
+  if (c.tid == 0) *s_cnt = 0;
+  __syncthreads();
+  auto finish = [&](int n, int choice, float lp) {   // the row's writer (AttModel.py:240-249)
+    int unf = choice > 0;
+    if (t > p.t0) unf = unf && ld_xi(p.dec_unf + n) != 0;
+    const int tok = unf ? choice : 0;
+    st_xi<SAFE>(p.dec_unf + n, unf);
+    st_xi<SAFE>(p.dec_tok + n, tok);
+    p.dec_seq[(size_t)n * p.dec_ld_out + t] = tok;
+    p.dec_seq_logp[(size_t)n * p.dec_ld_out + t] = lp;
+  };
+  if (c.tid < c.nrow) {
+    const int row = c.tid, n = c.rbegin + row;
+    const __amdgpu_buffer_rsrc_t r_p = rsrc_of(p.dec_part + (size_t)n * PW * 4);
+    float M = -INFINITY;
+    int best = 0;
+    u32x4 q[PW];
+#pragma unroll
+    for (int w = 0; w < PW; ++w) q[w] = bload<true>(r_p, 0u, (unsigned)(w * 16));
+#pragma unroll
+    for (int w = 0; w < PW; ++w) {
+      const float mw = __uint_as_float(q[w].x);
+      if (mw > M) { M = mw; best = (int)q[w].z; }       // ranks own increasing column ranges: the first maximum is the lowest index
+    }
+    float Z = 0.f;
+#pragma unroll
+    for (int w = 0; w < PW; ++w) {
+      const float mw = __uint_as_float(q[w].x);
+      Z += mw > -INFINITY ? __uint_as_float(q[w].y) * __expf(mw - M) : 0.f;
+    }
+    const float lse = M + __logf(Z);
+    const bool writer = (row & (PW - 1)) == c.rank;
+    if (p.dec_sample_max) {
+      if (writer) finish(n, best, M - lse);
+    } else if (p.dec_forced) {
+      if (writer) {
+        int ch = (int)p.dec_forced[(size_t)n * p.dec_ld_forced + t];
+        ch = ch < 0 || ch >= V1 ? 0 : ch;
+        finish(n, ch, ld_xf(lg + (size_t)n * p.dec_V1p + ch) - lse);
+      }
+    } else {
+      // inverse-CDF target in units of exp(. - M); the owner is the first workgroup whose cumulative mass exceeds it
+      unsigned x = (unsigned)n * 0x9E3779B1u ^ (p.dec_draw_seed + (unsigned)t * 0x85EBCA77u);
+      x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16;
+      const float target = (float)(x >> 8) * (1.0f / 16777216.0f) * Z;
+      float cum = 0.f, rt = INFINITY;
+      int owner = -1, lastmass = 0;
+#pragma unroll
+      for (int w = 0; w < PW; ++w) {
+        const float mw = __uint_as_float(q[w].x);
+        const float sw = mw > -INFINITY ? __uint_as_float(q[w].y) * __expf(mw - M) : 0.f;
+        if (sw > 0.f) lastmass = w;
+        if (owner < 0) {
+          if (cum + sw > target) { owner = w; rt = target - cum; }
+          else cum += sw;
+        }
+      }
+      if (owner < 0) owner = lastmass;                // rounding left the target at or beyond the total mass: the last token with mass
+      if (owner == c.rank) {
+        const int k = atomicAdd(s_cnt, 1);
+        s_list[4 * k] = __int_as_float(row); s_list[4 * k + 1] = rt; s_list[4 * k + 2] = M; s_list[4 * k + 3] = lse;
+      }
+    }
+  }
+  if (p.dec_sample_max || p.dec_forced) return;
+  __syncthreads();
+  const int cnt = *s_cnt;
+  const int c_lo = 16 * c.rank * per, c_hi = min(V1, c_lo + 16 * per);
+  for (int k = c.wave; k < cnt; k += WS_NW) {          // one wave per owned row: its <= 320 logits, 64 per round
+    const int row = __float_as_int(s_list[4 * k]), n = c.rbegin + row;
+    const float rt = s_list[4 * k + 1], M = s_list[4 * k + 2], lse = s_list[4 * k + 3];
+    const float* lr = lg + (size_t)n * p.dec_V1p;
+    float lv[DEC_NJ];
+#pragma unroll
+    for (int j = 0; j < DEC_NJ; ++j) {
+      const int v = c_lo + 64 * j + c.lane;
+      lv[j] = v < c_hi ? ld_xf(lr + v) : -INFINITY;
+    }
+    float cum = 0.f, lp = 0.f;
+    int pick = -1, last = -1;
+    float lastl = 0.f;
+#pragma unroll
+    for (int j = 0; j < DEC_NJ; ++j) {
+      const float e = lv[j] > -INFINITY ? __expf(lv[j] - M) : 0.f;
+      float incl = e;
+#pragma unroll
+      for (int o = 1; o < 64; o <<= 1) {
+        const float up = __shfl_up(incl, o, 64);
+        if (c.lane >= o) incl += up;
+      }
+      const unsigned long long hit = __ballot(pick < 0 && cum + incl > rt && e > 0.f);
+      const unsigned long long mass = __ballot(e > 0.f);
+      if (mass) {
+        const int hl = 63 - __clzll((long long)mass);
+        last = c_lo + 64 * j + hl;
+        lastl = __shfl(lv[j], hl, 64);
+      }
+      if (hit && pick < 0) {
+        const int fl = __ffsll((long long)hit) - 1;
+        pick = c_lo + 64 * j + fl;
+        lp = __shfl(lv[j], fl, 64) - lse;
+      }
+      cum += __shfl(incl, 63, 64);
+    }
+    if (pick < 0) { pick = last < 0 ? 0 : last; lp = (last < 0 ? ld_xf(lr) : lastl) - lse; }
+    if (c.lane == 0) finish(n, pick, lp);
+  }
+}
+
+template <bool SAFE, bool DEC>
 __device__ __forceinline__ void ws_run(const UicRnnFwdParams& p, Ctx& c, char* lds) {
   typedef bf16_t T;
   const int N = p.N;
@@ -641,6 +970,10 @@ __device__ __forceinline__ void ws_run(const UicRnnFwdParams& p, Ctx& c, char* l
 #pragma unroll
     for (int g = 0; g < 4; ++g) gf5[g] = p.gfc ? p.gfc[4u * n1 + (unsigned)(g * HH) + u] : 0.f;
   }
+  // decode mode: the input token's share of att_lstm's gates of the coming step, made by dec_xt_gemm (the teacher-forced loop
+  // reads it from gx)
+  float xg[4][4], xg5[4];
+  if (DEC) dec_xt_gemm(p, c, p.t0, xg, xg5);
   auto load_pre = [&](int ts, int tile, float (&pv)[4][4], float (&cp)[4]) {     // (tile == this wave's own tile)
     const float* gx = p.gx + (size_t)ts * N * 4 * HH;
     const float* c_prev = p.c_att + (size_t)ts * NH;
@@ -651,7 +984,7 @@ __device__ __forceinline__ void ws_run(const UicRnnFwdParams& p, Ctx& c, char* l
       const unsigned n1 = (unsigned)((c.rbegin + (rr < c.nrow ? rr : c.nrow - 1)) * HH);
       cp[r] = c_prev[n1 + u];
 #pragma unroll
-      for (int g = 0; g < 4; ++g) pv[r][g] = gx[4u * n1 + (unsigned)(g * HH) + u];
+      for (int g = 0; g < 4; ++g) pv[r][g] = DEC ? xg[r][g] : gx[4u * n1 + (unsigned)(g * HH) + u];
     }
   };
   // fifth tile: its cell update is shared by the four waves, wave w takes row 4 lq + w of every 4-row group
@@ -662,7 +995,7 @@ __device__ __forceinline__ void ws_run(const UicRnnFwdParams& p, Ctx& c, char* l
     const unsigned n1 = (unsigned)((c.rbegin + (rr < c.nrow ? rr : c.nrow - 1)) * HH);
     cp = p.c_att[(size_t)ts * NH + n1 + u];
 #pragma unroll
-    for (int g = 0; g < 4; ++g) pv[g] = gx[4u * n1 + (unsigned)(g * HH) + u];
+    for (int g = 0; g < 4; ++g) pv[g] = DEC ? xg5[g] : gx[4u * n1 + (unsigned)(g * HH) + u];
   };
 #if WS_EARLY_PRE
   float pvn[4][4], cpn[4];                          // of the NEXT att_lstm phase, own tile (tile = wave): requested one phase early
@@ -999,6 +1332,19 @@ __device__ __forceinline__ void ws_run(const UicRnnFwdParams& p, Ctx& c, char* l
     }
     if (dbg && c.tid == 0) dbg[7] = __builtin_amdgcn_s_memrealtime();
     if (!group_barrier(c)) return;
+    if (DEC) {
+      asm volatile("" : "+v"(c.lane), "+v"(c.l15), "+v"(c.lq), "+v"(c.tid));
+      dec_logits<SAFE>(p, c, t);
+      if (dbg && c.tid == 0) dbg[8] = __builtin_amdgcn_s_memrealtime();
+      if (!group_barrier(c)) return;
+      asm volatile("" : "+v"(c.lane), "+v"(c.l15), "+v"(c.lq), "+v"(c.tid));
+      dec_sample<SAFE>(p, c, t);
+      if (dbg && c.tid == 0) dbg[9] = __builtin_amdgcn_s_memrealtime();
+      if (!group_barrier(c)) return;
+      asm volatile("" : "+v"(c.lane), "+v"(c.l15), "+v"(c.lq), "+v"(c.tid));
+      if (t + 1 < p.t1) dec_xt_gemm(p, c, t + 1, xg, xg5);
+      if (dbg && c.tid == 0) dbg[10] = __builtin_amdgcn_s_memrealtime();
+    }
     if (dbg) dbg += 16;
   }
 }
@@ -1008,8 +1354,37 @@ __global__ __launch_bounds__(WS_NTH) void rnn_fwd_persist_ws_kernel(const UicRnn
   Ctx c;
   const int mode = setup_ctx(p, smem + WS_W1_BYTES, c);
   if (mode == 0) return;
-  if (mode == 2) ws_run<true>(p, c, smem);
-  else ws_run<false>(p, c, smem);
+  if (mode == 2) ws_run<true, false>(p, c, smem);
+  else ws_run<false, false>(p, c, smem);
+}
+__global__ __launch_bounds__(WS_NTH) void rnn_dec_persist_ws_kernel(const UicRnnFwdParams p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  Ctx c;
+  const int mode = setup_ctx(p, smem + WS_W1_BYTES, c);
+  if (mode == 0) return;
+  if (mode == 2) ws_run<true, true>(p, c, smem);
+  else ws_run<false, true>(p, c, smem);
+}
+
+// the reference stops decoding once every row has finished (AttModel.py:236-238): entries after that step stay zero
+__global__ void dec_finish_kernel(const int64_t* __restrict__ seq, float* __restrict__ seq_logp, int N, int L, int ld) {
+  __shared__ int s_max;
+  if (threadIdx.x == 0) s_max = 0;
+  __syncthreads();
+  int mx = 0;
+  for (int n = threadIdx.x; n < N; n += blockDim.x) {
+    int f = L;                                   // first step at which the row emitted token 0
+    for (int t = 0; t < L; ++t)
+      if (seq[(size_t)n * ld + t] == 0) { f = t; break; }
+    mx = max(mx, f);
+  }
+  atomicMax(&s_max, mx);
+  __syncthreads();
+  const int t_dead = s_max + 1;                  // every row had finished before this step
+  for (int i = threadIdx.x; i < N * L; i += blockDim.x) {
+    const int n = i / L, t = i - n * L;
+    if (t >= t_dead) seq_logp[(size_t)n * ld + t] = 0.f;
+  }
 }
 
 }  // namespace
@@ -1032,10 +1407,15 @@ bool uic_rnn_persist_eligible(int dtype, int N, int H, int A, int R) {
 
 int uic_rnn_fwd_persist_launch(const UicRnnFwdParams& p0, hipStream_t s) {
   UIC_REQUIRE(p0.sync && p0.t1 > p0.t0 && p0.N > 0, "rnn_fwd_persist: bad arguments");
+  UIC_REQUIRE(!p0.dec || (p0.dtype == UIC_BF16 && p0.gfc && p0.dec_embed && p0.dec_xw && p0.dec_logit_w && p0.dec_logits && p0.dec_part &&
+                          p0.dec_tok && p0.dec_unf && p0.dec_seq && p0.dec_seq_logp && p0.hdrop_all && p0.dec_V1 >= 2 &&
+                          p0.dec_V1 <= PW * WS_NW * DEC_NJ * 16),
+              "rnn_fwd_persist: decode mode needs bf16, gfc, the embedding / logit operands and its exchange buffers (V1 <= %d)", PW * WS_NW * DEC_NJ * 16);
   static bool configured = false;
   if (!configured) {
     UIC_TRY(uic_check_hip(hipFuncSetAttribute((const void*)rnn_fwd_persist_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES), "hipFuncSetAttribute(rnn persist)"));
     UIC_TRY(uic_check_hip(hipFuncSetAttribute((const void*)rnn_fwd_persist_ws_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, WS_LDS_BYTES), "hipFuncSetAttribute(rnn persist ws)"));
+    UIC_TRY(uic_check_hip(hipFuncSetAttribute((const void*)rnn_dec_persist_ws_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, WS_LDS_BYTES), "hipFuncSetAttribute(rnn decode persist)"));
     configured = true;
   }
   const int G = 8, cap = G * 16 * MT_MAX;     // caption rows one launch covers
@@ -1055,9 +1435,21 @@ int uic_rnn_fwd_persist_launch(const UicRnnFwdParams& p0, hipStream_t s) {
     p.sync = p0.sync + (size_t)(r0 / cap) * SY_WORDS;
     UIC_TRY(uic_check_hip(hipMemsetAsync(p.sync, 0, (size_t)SY_WORDS * 4, s), "hipMemsetAsync(rnn sync)"));
     // bf16: the weight-stationary kernel; f32 (the parity path): the generic one, weights re-read from L2 every step
-    if (p.dtype == UIC_BF16) hipLaunchKernelGGL(rnn_fwd_persist_ws_kernel, dim3(G * PW), dim3(WS_NTH), WS_LDS_BYTES, s, p);
+    if (p.dec) hipLaunchKernelGGL(rnn_dec_persist_ws_kernel, dim3(G * PW), dim3(WS_NTH), WS_LDS_BYTES, s, p);
+    else if (p.dtype == UIC_BF16) hipLaunchKernelGGL(rnn_fwd_persist_ws_kernel, dim3(G * PW), dim3(WS_NTH), WS_LDS_BYTES, s, p);
     else hipLaunchKernelGGL(rnn_fwd_persist_kernel<float>, dim3(G * PW), dim3(NTH), LDS_BYTES, s, p);
     UIC_LAUNCH_CHECK("rnn_fwd_persist_kernel");
   }
+  return UIC_OK;
+}
+
+bool uic_rnn_decode_persist_eligible(int dtype, int N, int H, int A, int R, int E, int V1) {
+  return dtype == UIC_BF16 && E == HH && V1 >= 2 && V1 <= PW * WS_NW * DEC_NJ * 16 && uic_rnn_persist_eligible(dtype, N, H, A, R);
+}
+size_t uic_rnn_decode_part_floats(int N) { return (size_t)N * PW * 4; }
+int uic_rnn_decode_finish_launch(const int64_t* seq, float* seq_logp, int N, int L, int ld, hipStream_t s) {
+  UIC_REQUIRE(seq && seq_logp && N > 0 && L > 0 && ld >= L, "rnn_decode_finish: bad arguments");
+  hipLaunchKernelGGL(dec_finish_kernel, dim3(1), dim3(1024), 0, s, seq, seq_logp, N, L, ld);
+  UIC_LAUNCH_CHECK("dec_finish_kernel");
   return UIC_OK;
 }

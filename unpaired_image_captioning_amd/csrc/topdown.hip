@@ -60,6 +60,7 @@ struct Layout {
   float* slab; size_t slab_bytes;
   void* tLA; void* tLB; float* colscratchL;   // scratch of the logit-layer weight gradients (side stream)
   void* tSA; void* tSB; float* slab2;         // scratch of the per-chunk recurrent weight gradients (side stream)
+  void* tTA; void* tTB; float* slab3;         // the same for the third stream (att_lstm / h2att share of a chunk)
   int* embed_scratch;                         // uic_embed_bwd_sorted_launch
   void* fcwT; void* attwT;                     // fc_embed / att_embed weights transposed ([Dfc, H], [D, H]): only for the optional input-feature gradients
   void* ones_blk; size_t ones_rows;           // [max(WG_CHUNK * N, N * R), 128] operand dtype, all ones: the "input" whose weight gradient is the bias gradient
@@ -70,6 +71,7 @@ struct Layout {
   void* s_h_att[2]; void* s_h_lang[2]; float* s_c_att[2]; float* s_c_lang[2];
   void* s_xt; float* s_atth; float* s_alpha; void* s_ctx; void* s_hdrop; float* s_logits;
   int64_t* s_it; int* s_unf; int* s_nunf;
+  float* dec_part; int* dec_tok;              // persistent decode (rnn_persist.hip): per-workgroup logit partials, exchanged tokens
   // beam search bookkeeping (rows = (image, beam); sizes depend on N and T only)
   float* bm_cand_val; int* bm_cand_idx; int64_t* bm_seq[2]; float* bm_lp[2]; float* bm_sum; int* bm_parent;
   int* bm_done_count; float* bm_done_p; int64_t* bm_done_seq; float* bm_done_lp;
@@ -171,6 +173,8 @@ Layout make_layout(const uic_topdown_dims& d, void* ws) {
     const size_t la = 4 * H > A ? 4 * H : A;    // left operands: dG [rows, 4H] of the LSTMs, d att_h [rows, A] of h2att
     L.tSA = b.take(la * Kc * S);
     L.tSB = b.take(rb * Kc * S);
+    L.tTA = b.take(la * Kc * S);
+    L.tTB = b.take(rb * Kc * S);
   }
   {  // split-K partial slabs: room for 4 slices of the largest merged weight gradient [4H, 2H + E]
     size_t sl = 4 * (4 * H) * (2 * H + E) * 4;
@@ -179,8 +183,9 @@ Layout make_layout(const uic_topdown_dims& d, void* ws) {
     L.slab_bytes = sl;
     L.slab = (float*)b.take(sl);
     L.slab2 = (float*)b.take(sl);
+    L.slab3 = (float*)b.take(sl);
   }
-  L.embed_scratch = (int*)b.take(uic_embed_bwd_sorted_scratch_ints(N, T, V1, WG_CHUNK) * 4);
+  L.embed_scratch = (int*)b.take(uic_embed_bwd_sorted_scratch_ints(N, T, V1) * 4);
   L.fcwT = b.take(Dfc * H * S);
   L.attwT = b.take(D * H * S);
   L.ones_rows = rup8((size_t)WG_CHUNK * N) > (size_t)N * R ? rup8((size_t)WG_CHUNK * N) : (size_t)N * R;
@@ -207,6 +212,8 @@ Layout make_layout(const uic_topdown_dims& d, void* ws) {
   L.s_it = (int64_t*)b.take(N * 8);
   L.s_unf = (int*)b.take(N * 4);
   L.s_nunf = (int*)b.take((T + 2) * UIC_NUNF_STRIPES * 4);
+  L.dec_part = (float*)b.take(uic_rnn_decode_part_floats((int)N) * 4);
+  L.dec_tok = (int*)b.take(N * 4);
   L.bm_cand_val = (float*)b.take(N * UIC_BEAM_MAX * 4);
   L.bm_cand_idx = (int*)b.take(N * UIC_BEAM_MAX * 4);
   for (int i = 0; i < 2; ++i) {
@@ -422,6 +429,8 @@ int attention_step(const uic_topdown_dims& d, const uic_topdown_weights* w, cons
 constexpr int MAX_CHUNKS = 64;
 struct SideStream {
   hipStream_t stream = nullptr;
+  hipStream_t stream3 = nullptr;    // a chunk's att_lstm / h2att weight gradients beside its lang_lstm ones (independent GEMMs)
+  hipEvent_t ev_s3 = nullptr;       // stream3 -> side: that share of every chunk so far is done
   hipEvent_t ev_den = nullptr, ev_done = nullptr;
   hipEvent_t ev_pro = nullptr;      // side: its branch of the forward prologue (fc_embed, embedding, batched input GEMM) is through
   hipEvent_t ev_logit = nullptr;    // side: the logit layer's gradients and the loss are final (start of the BPTT loop)
@@ -459,6 +468,8 @@ int get_side(SideStream** out) {
     int least = 0, greatest = 0;
     UIC_TRY(uic_check_hip(hipDeviceGetStreamPriorityRange(&least, &greatest), "hipDeviceGetStreamPriorityRange"));
     UIC_TRY(uic_check_hip(hipStreamCreateWithPriority(&ss.stream, hipStreamNonBlocking, least), "hipStreamCreateWithPriority"));
+    UIC_TRY(uic_check_hip(hipStreamCreateWithPriority(&ss.stream3, hipStreamNonBlocking, least), "hipStreamCreateWithPriority"));
+    UIC_TRY(uic_check_hip(hipEventCreateWithFlags(&ss.ev_s3, hipEventDisableTiming), "hipEventCreate"));
     UIC_TRY(uic_check_hip(hipEventCreateWithFlags(&ss.ev_den, hipEventDisableTiming), "hipEventCreate"));
     UIC_TRY(uic_check_hip(hipEventCreateWithFlags(&ss.ev_done, hipEventDisableTiming), "hipEventCreate"));
     UIC_TRY(uic_check_hip(hipEventCreateWithFlags(&ss.ev_pro, hipEventDisableTiming), "hipEventCreate"));
@@ -646,9 +657,9 @@ struct Step {
   // scheduled sampling (AttModel.py:130-143) is active in train mode only
   bool ss_on() const { return (training & 1) && b->ss_prob > 0.f; }
   bool embed_prepared = false;   // the fused step bucketed the tokens (uic_embed_bwd_sorted_prepare) while the side stream was idle
-  // d.recurrence & UIC_REC_EARLY_GRADS (fused step): the embedding gradient and the fc' columns of att_lstm.weight_ih are
-  // produced chunk by chunk behind the BPTT loop (wgrad_chunk) instead of in the side stream's tail -- a few more, smaller
-  // launches, and in exchange both tensors are final with gradient group 1 (uic_topdown_grad_ready_wait)
+  int embed_split = 0;           // > 0: ... into the halves [0, embed_split) / [embed_split, t_run) of the decode steps (embed_grad)
+  // d.recurrence & UIC_REC_EARLY_GRADS (fused step): the order of the gradient work a data-parallel caller may prefer -- see
+  // uic_topdown_xe_train_step
   bool early_grads() const { return (d.recurrence & UIC_REC_EARLY_GRADS) != 0; }
   const int64_t* embed_tokens() const { return ss_on() ? L.tok_used : b->labels; }
   int embed_ldtok() const { return ss_on() ? d.T : b->ld_labels; }
@@ -700,11 +711,56 @@ struct Step {
     return uic_gemm_launch(g, s);
   }
   // Gfc = fc' W_ih[:, H:2H]^T, the caption row's share of every step's att_lstm pre-activations
-  int fwd_gfc(hipStream_t s) {
+  int fwd_gfc(hipStream_t s, bool with_bias = false) {
     UicGemmParams g = gemm_base(dt, N, H4);
     add_seg(g, L.fcp, H, off(dv.att_w_ih, H, dt), ldih, H);
     g.C = L.gfc; g.ldc = H4; g.flags = UIC_GEMM_OUT_F32;
+    if (with_bias) { g.bias = w->att_lstm_b_ih; g.bias2 = w->att_lstm_b_hh; }
     return uic_gemm_launch(g, s);
+  }
+
+  // ---------------------------------------------------------------- decode as one persistent launch
+  // AttModel._sample (P/models/AttModel.py:198-253) with beam_size = 1: all Lsteps decode steps -- embedding of the previous
+  // step's token, att_lstm, attention, lang_lstm, the logit layer and the greedy / multinomial choice -- in ONE launch of
+  // rnn_persist.hip's decode mode instead of six launches per step.  bf16, the default temperature, no decoding constraint,
+  // one logit layer; everything else keeps the per-step chain.  keep: the training layout's activations, the embedded inputs
+  // and every step's logits stay in the workspace for uic_topdown_xe_train_step(training | 4).
+  bool decode_persist_ok(int sample_max, float temperature, int decoding_constraint) const {
+    return !(d.recurrence & UIC_REC_FWD_CHAIN) && !decoding_constraint && (sample_max || temperature == 1.f) && d.logit_layers <= 1 &&
+           uic_rnn_decode_persist_eligible(dt, N, H, A, R, E, V1);
+  }
+  int decode_persist(int Lsteps, int sample_max, const int64_t* forced, bool keep, int64_t* seq, float* seq_logp, hipStream_t s) {
+    UIC_TRY(fwd_gfc(s, true));
+    UIC_TRY(uic_fill_launch(L.dec_tok, 0, (size_t)N * 4, s));          // <bos> = 0 (AttModel.py:214-215)
+    UicRnnFwdParams p;
+    memset(&p, 0, sizeof(p));
+    p.dtype = dt; p.N = N; p.R = R; p.t0 = 0; p.t1 = Lsteps;
+    p.gx = nullptr; p.gfc = L.gfc;
+    p.att_w_ih = dv.att_w_ih; p.ld_att_ih = ldih; p.att_w_hh = dv.att_w_hh;
+    p.lang_w_ih = dv.lang_w_ih; p.lang_w_hh = dv.lang_w_hh;
+    p.lang_b_ih = w->lang_lstm_b_ih; p.lang_b_hh = w->lang_lstm_b_hh;
+    p.h2att_w = dv.h2att_w; p.h2att_b = w->h2att_b;
+    p.w_alpha = w->alpha_w; p.b_alpha = w->alpha_b;
+    p.p_att = L.patt; p.att = L.attp;
+    p.mask = b->att_masks ? (d.seq_per_img > 1 ? L.amask_rep : b->att_masks) : nullptr; p.ldmask = R;
+    p.h_att = L.h_att; p.h_lang = L.h_lang; p.c_att = L.c_att; p.c_lang = L.c_lang;
+    p.gates1 = keep ? L.gates1 : nullptr; p.gates2 = keep ? L.gates2 : nullptr;
+    p.att_h_all = L.atth_all; p.alpha_all = L.alpha_all; p.ctx_all = L.ctx_all; p.hdrop_all = L.hdrop_all;
+    p.drop_p = drop_p; p.seed = seed;
+    p.sync = L.rnn_sync;
+    p.force_safe = (d.recurrence & UIC_REC_SAFE) != 0; p.status = d.rnn_status;
+    p.dbg = (d.recurrence & UIC_REC_STAMPS) ? L.rnn_dbg : nullptr; p.dbg_T = d.T;
+    p.dec = 1;
+    p.dec_embed = w->embed_w; p.dec_xw = off(dv.att_w_ih, 2 * H, dt); p.dec_ld_xw = ldih;
+    p.dec_xt_drop = drop_p; p.dec_xt_all = keep ? L.xt_all : nullptr;
+    p.dec_logit_w = dv.logit_w; p.dec_logit_b = w->logit_b; p.dec_V1 = V1; p.dec_V1p = V1p;
+    p.dec_logits = keep ? L.logits : L.s_logits; p.dec_logits_step = keep ? (size_t)N * V1p : 0;
+    p.dec_part = L.dec_part; p.dec_tok = L.dec_tok; p.dec_unf = L.s_unf;
+    p.dec_seq = seq; p.dec_seq_logp = seq_logp; p.dec_ld_out = Lsteps;
+    p.dec_forced = sample_max ? nullptr : forced; p.dec_ld_forced = Lsteps;
+    p.dec_sample_max = sample_max; p.dec_draw_seed = seed;
+    UIC_TRY(uic_rnn_fwd_persist_launch(p, s));
+    return uic_rnn_decode_finish_launch(seq, seq_logp, N, Lsteps, Lsteps, s);
   }
 
   // inline_inputs: xt_t and fc' enter att_lstm's GEMM as K segments of their own (with both biases) instead of through the
@@ -1018,7 +1074,12 @@ struct Step {
   // recurrent weight gradients (both LSTMs' weights and h2att) restricted to decode steps [t0, t1): one chunk of the
   // stacked-row GEMMs, accumulated into G unless `first`.  Used by the fused step on the side stream, chunk by chunk
   // behind the BPTT loop, so that only the last chunk's share is left when the loop ends.
-  int wgrad_chunk(int t0, int t1, bool first, hipStream_t s) {
+  // sb (optional): a second stream for the att_lstm / h2att share, with scratch of its own (the GEMMs are independent)
+  int wgrad_chunk(int t0, int t1, bool first, hipStream_t s, hipStream_t sb = nullptr) {
+    float* const slabB = sb ? L.slab3 : L.slab2;
+    void* const tBA = sb ? L.tTA : L.tSA;
+    void* const tBB = sb ? L.tTB : L.tSB;
+    if (!sb) sb = s;
     const int rows = (t1 - t0) * N;
     const size_t r0 = (size_t)t0 * N;
     const void* ctx = off(L.ctx_all, r0 * H, dt);
@@ -1039,43 +1100,21 @@ struct Step {
     if (bias_in_chunks() && A % 128 == 0) {  // h2att: d_att_h^T x [h_att | ones]
       const UicGemmTnSeg segs[2] = {{h_att_new, H, H}, {L.ones_blk, 128, 128}};
       const WDest dd[2] = {{G->h2att_w, H, 0, H}, {G->h2att_b, 1, H, 1}};
-      UIC_TRY(wgrad_group(L.slab2, off(L.datth_all, r0 * A, dt), A, A, segs, 2, rows, dd, 2, s, !first, L.tSA, L.tSB));
+      UIC_TRY(wgrad_group(slabB, off(L.datth_all, r0 * A, dt), A, A, segs, 2, rows, dd, 2, sb, !first, tBA, tBB));
     } else {  // h2att: d_att_h^T x h_att
       const UicGemmTnSeg seg{h_att_new, H, H};
       const WDest d1{G->h2att_w, H, 0, H};
-      UIC_TRY(wgrad_group(L.slab2, off(L.datth_all, r0 * A, dt), A, A, &seg, 1, rows, &d1, 1, s, !first, L.tSA, L.tSB));
+      UIC_TRY(wgrad_group(slabB, off(L.datth_all, r0 * A, dt), A, A, &seg, 1, rows, &d1, 1, sb, !first, tBA, tBB));
     }
     if (bias_in_chunks()) {
       const UicGemmTnSeg segs[4] = {{h_lang_prev, H, H}, {off(L.xt_all, r0 * E, dt), E, E}, {h_att_prev, H, H}, {L.ones_blk, 128, 128}};
       const WDest dd[4] = {{G->att_lstm_w_ih, ldih, 0, H}, {G->att_lstm_w_ih + 2 * H, ldih, H, E}, {G->att_lstm_w_hh, H, H + E, H},
                            {G->att_lstm_b_ih, 1, 2 * H + E, 1}};
-      UIC_TRY(wgrad_group(L.slab2, off(L.dg1_all, r0 * H4, dt), H4, H4, segs, 4, rows, dd, 4, s, !first, L.tSA, L.tSB));
+      UIC_TRY(wgrad_group(slabB, off(L.dg1_all, r0 * H4, dt), H4, H4, segs, 4, rows, dd, 4, sb, !first, tBA, tBB));
     } else {  // att_lstm: dG1^T x [h_lang_prev | xt | h_att_prev]
       const UicGemmTnSeg segs[3] = {{h_lang_prev, H, H}, {off(L.xt_all, r0 * E, dt), E, E}, {h_att_prev, H, H}};
       const WDest dd[3] = {{G->att_lstm_w_ih, ldih, 0, H}, {G->att_lstm_w_ih + 2 * H, ldih, H, E}, {G->att_lstm_w_hh, H, H + E, H}};
-      UIC_TRY(wgrad_group(L.slab2, off(L.dg1_all, r0 * H4, dt), H4, H4, segs, 3, rows, dd, 3, s, !first, L.tSA, L.tSB));
-    }
-    if (!early_grads()) return UIC_OK;
-    {  // d xt of the chunk -> its share of the embedding table (positions bucketed chunk-major by the prepare half)
-      UicGemmParams g = gemm_base(dt, rows, E);
-      add_seg(g, off(L.dg1_all, r0 * H4, dt), H4, dv.wxT, H4, H4);
-      g.C = L.dxt + r0 * E; g.ldc = E; g.flags = UIC_GEMM_OUT_F32;
-      UIC_TRY(uic_gemm_launch(g, s));
-      UIC_TRY(uic_embed_bwd_sorted_gather(dt, L.dxt, L.xt_all, embed_tokens(), embed_ldtok(), N, t_run, V1, E, drop_p, -1, G->embed_w,
-                                          L.embed_scratch, s, WG_CHUNK, t0, t1));
-    }
-    // fc' path: the chunk's share of dGfc = sum_t dG1_t -> the fc' columns of att_lstm.weight_ih and d fc'
-    UIC_TRY(uic_sum_steps_launch(dt, off(L.dg1_all, r0 * H4, dt), t1 - t0, (size_t)N * H4, L.dgfc, s));
-    {
-      const UicGemmTnSeg seg{L.fcp, H, H};
-      const WDest d1{G->att_lstm_w_ih + H, ldih, 0, H};
-      UIC_TRY(wgrad_group(L.slab2, L.dgfc, H4, H4, &seg, 1, N, &d1, 1, s, !first, L.tSA, L.tSB));
-    }
-    {
-      UicGemmParams g = gemm_base(dt, N, H);
-      add_seg(g, L.dgfc, H4, dv.wfcpT, H4, H4);
-      g.C = L.dfcp; g.ldc = H; g.flags = UIC_GEMM_OUT_F32 | (first ? 0 : UIC_GEMM_ACCUM);
-      UIC_TRY(uic_gemm_launch(g, s));
+      UIC_TRY(wgrad_group(slabB, off(L.dg1_all, r0 * H4, dt), H4, H4, segs, 3, rows, dd, 3, sb, !first, tBA, tBB));
     }
     return UIC_OK;
   }
@@ -1087,7 +1126,34 @@ struct Step {
 
   // chunked == true: wgrad_chunk already produced the LSTM / h2att weight gradients
   // side == true: runs on the fused step's side stream with that stream's own scratch buffers
-  int bwd_epilogue_early(hipStream_t s, bool chunked = false, bool side = false) {
+  // The two big tensors of the early group, on their own so that the fused step can finish them FIRST after the BPTT loop
+  // (with gradient group 1, uic_topdown_grad_ready_wait):
+  //   fc_cols_grad: dGfc = sum_t dG1_t (left in L.dgfc) -> the fc' columns of att_lstm.weight_ih, which completes that matrix;
+  //   embed_grad(half): d xt = dG1 Wx of the decode steps of one half of the bucketed position list (embed_split; 0: all
+  //                     steps at once) -> their share of the embedding table.
+  int fc_cols_grad(hipStream_t s, float* slab, void* tA, void* tB) {
+    UIC_TRY(uic_sum_steps_launch(dt, L.dg1_all, t_run, (size_t)N * H4, L.dgfc, s));
+    const UicGemmTnSeg seg{L.fcp, H, H};
+    const WDest d1{G->att_lstm_w_ih + H, ldih, 0, H};
+    return wgrad_group(slab, L.dgfc, H4, H4, &seg, 1, N, &d1, 1, s, false, tA, tB);
+  }
+  int embed_grad(int half, hipStream_t s) {
+    const int t0 = embed_split && half ? embed_split : 0, t1 = embed_split && !half ? embed_split : t_run;
+    const size_t r0 = (size_t)t0 * N;
+    UicGemmParams g = gemm_base(dt, (t1 - t0) * N, E);
+    add_seg(g, off(L.dg1_all, r0 * H4, dt), H4, dv.wxT, H4, H4);
+    g.C = L.dxt + r0 * E; g.ldc = E; g.flags = UIC_GEMM_OUT_F32;
+    UIC_TRY(uic_gemm_launch(g, s));
+    if (!embed_prepared) {
+      UIC_REQUIRE(!embed_split, "embed_grad: the position list was not prepared for split=%d", embed_split);
+      UIC_TRY(uic_embed_bwd_sorted_prepare(embed_tokens(), embed_ldtok(), N, t_run, V1, E, G->embed_w, L.embed_scratch, s));
+      embed_prepared = true;
+    }
+    return uic_embed_bwd_sorted_gather(dt, L.dxt, L.xt_all, embed_tokens(), embed_ldtok(), N, t_run, V1, E, drop_p, -1, G->embed_w,
+                                       L.embed_scratch, s, embed_split, half);
+  }
+  // first_done == true: the caller already ran fc_cols_grad and embed_grad (the fused step, right behind the last chunk)
+  int bwd_epilogue_early(hipStream_t s, bool chunked = false, bool side = false, bool first_done = false) {
     void* const tA = side ? L.tSA : L.tA;
     void* const tB = side ? L.tSB : L.tB;
     float* const colscratch = side ? L.colscratchL : L.colscratch;
@@ -1112,30 +1178,15 @@ struct Step {
     if (!(chunked && bias_in_chunks()))
       UIC_TRY(uic_colsum_launch(dt, L.dg1_all, Meff, H4, H4, G->att_lstm_b_ih, colscratch, L.colscratch_floats, s));
     UIC_TRY(uic_copy_launch(G->att_lstm_b_hh, G->att_lstm_b_ih, (size_t)H4 * 4, s));
-    if (!(chunked && early_grads())) {   // (else wgrad_chunk produced them chunk by chunk)
-      {  // d xt -> embedding table
-        UicGemmParams g = gemm_base(dt, Meff, E);
-        add_seg(g, L.dg1_all, H4, dv.wxT, H4, H4);
-        g.C = L.dxt; g.ldc = E; g.flags = UIC_GEMM_OUT_F32;
-        UIC_TRY(uic_gemm_launch(g, s));
-        if (!embed_prepared)
-          UIC_TRY(uic_embed_bwd_sorted_prepare(embed_tokens(), embed_ldtok(), N, t_run, V1, E, G->embed_w, L.embed_scratch, s));
-        UIC_TRY(uic_embed_bwd_sorted_gather(dt, L.dxt, L.xt_all, embed_tokens(), embed_ldtok(), N, t_run,
-                                            V1, E, drop_p, -1, G->embed_w, L.embed_scratch, s));
-      }
-      // fc' path: dGfc = sum_t dG1_t
-      UIC_TRY(uic_sum_steps_launch(dt, L.dg1_all, t_run, (size_t)N * H4, L.dgfc, s));
-      {
-        const UicGemmTnSeg seg{L.fcp, H, H};
-        const WDest d1{G->att_lstm_w_ih + H, ldih, 0, H};
-        UIC_TRY(wgrad_group(slab, L.dgfc, H4, H4, &seg, 1, N, &d1, 1, s, false, tA, tB));
-      }
-      {
-        UicGemmParams g = gemm_base(dt, N, H);
-        add_seg(g, L.dgfc, H4, dv.wfcpT, H4, H4);
-        g.C = L.dfcp; g.ldc = H; g.flags = UIC_GEMM_OUT_F32;
-        UIC_TRY(uic_gemm_launch(g, s));
-      }
+    if (!first_done) {
+      UIC_TRY(fc_cols_grad(s, slab, tA, tB));
+      UIC_TRY(embed_grad(0, s));
+    }
+    {  // d fc' from dGfc (left in L.dgfc by fc_cols_grad)
+      UicGemmParams g = gemm_base(dt, N, H);
+      add_seg(g, L.dgfc, H4, dv.wfcpT, H4, H4);
+      g.C = L.dfcp; g.ldc = H; g.flags = UIC_GEMM_OUT_F32;
+      UIC_TRY(uic_gemm_launch(g, s));
     }
     UIC_TRY(uic_relu_mask_bwd_launch(dt, L.dfcp, L.fcp, inv_keep, L.dfcpre, NH, s));
     {
@@ -1368,8 +1419,10 @@ int uic_topdown_xe_train_step(const uic_topdown_dims* d, const uic_topdown_weigh
   SideStream* ss = nullptr;
   UIC_TRY(get_side(&ss));
   hipStream_t s2 = ss->stream;
+  hipStream_t s3 = ss->stream3;
   Step st;
   st.init(d, w, derived, b, t_run, training, seed, workspace, G);
+  const bool early = st.early_grads();
   const int CH = WG_CHUNK;                            // decode steps per hand-off to the side stream
   const int nchunk = (t_run + CH - 1) / CH;
   UIC_REQUIRE(nchunk <= MAX_CHUNKS, "xe_train_step: too many decode steps (%d)", t_run);
@@ -1425,16 +1478,21 @@ int uic_topdown_xe_train_step(const uic_topdown_dims* d, const uic_topdown_weigh
   UIC_TRY(uic_reduce_sum_launch(st.L.row_loss, (size_t)t_run * d->N, 0.f, inv, loss_out, s2));
   if (den_out) UIC_TRY(uic_copy_launch(den_out, st.L.scalars, 4, s2));
   UIC_HIP(hipEventRecord(ss->ev_logit, s2));          // gradient group 0 (logit layer) final: its exchange can start now
+  UIC_MARK(10, s2);
   // main: BPTT, each step waits for the d hdrop rows of its chunk; side: the recurrent weight gradients of every
   // finished chunk (transposes + accumulating GEMMs), so only the last chunk's share outlives the loop
   UIC_TRY(wait_refresh(s));                           // the BPTT loop reads the transposed weight copies
   UIC_TRY(st.bwd_begin(s));
-  if (!st.ss_on() || st.early_grads()) {
-    // the embedding gradient's token bucketing needs only the tokens (labels; under scheduled sampling the tokens the forward
-    // pass fed, which the side stream has waited for): in the side stream's slack inside the BPTT window
-    UIC_TRY(uic_embed_bwd_sorted_prepare(st.embed_tokens(), st.embed_ldtok(), d->N, t_run, d->V1, d->E, G->embed_w, st.L.embed_scratch, s2,
-                                         st.early_grads() ? CH : 0));
-    st.embed_prepared = true;
+  {
+    // The embedding gradient's token bucketing needs only the tokens (labels; under scheduled sampling the tokens the forward
+    // pass fed, which the side stream has waited for): in the side stream's slack inside the BPTT window.  Two halves: the
+    // share of decode steps [CH, t_run) is gathered while the BPTT loop works on its last chunk, only steps [0, CH) afterwards.
+    st.embed_split = st.early_grads() && nchunk >= 2 ? CH : 0;
+    if (!st.ss_on() || st.early_grads()) {
+      UIC_TRY(uic_embed_bwd_sorted_prepare(st.embed_tokens(), st.embed_ldtok(), d->N, t_run, d->V1, d->E, G->embed_w, st.L.embed_scratch, s2,
+                                           st.embed_split));
+      st.embed_prepared = true;
+    }
   }
   for (int c = nchunk - 1; c >= 0; --c) {
     const int t0 = c * CH, t1 = t0 + CH < t_run ? t0 + CH : t_run;
@@ -1443,17 +1501,27 @@ int uic_topdown_xe_train_step(const uic_topdown_dims* d, const uic_topdown_weigh
     UIC_TRY(st.bwd_steps(t0, t1, s));
     UIC_HIP(hipEventRecord(ss->ev_main[c], s));       // (the forward's use of ev_main[c] was consumed long ago)
     UIC_HIP(hipStreamWaitEvent(s2, ss->ev_main[c], 0));
-    UIC_TRY(st.wgrad_chunk(t0, t1, c == nchunk - 1, s2));
+    if (early) UIC_HIP(hipStreamWaitEvent(s3, ss->ev_main[c], 0));
+    UIC_TRY(st.wgrad_chunk(t0, t1, c == nchunk - 1, s2, early ? s3 : nullptr));
+    if (early && c == 1) UIC_TRY(st.embed_grad(1, s2));   // d xt of steps [CH, t_run) is complete: their share of the embedding table
+  }
+  if (early) {
+    // side: what completes att_lstm.weight_ih and the embedding table comes first, so that the two big tensors of the early
+    // group are final with gradient group 1 (the fc_embed chain and the bias sums -- ~4 MB -- follow)
+    UIC_TRY(st.fc_cols_grad(s2, st.L.slab2, st.L.tSA, st.L.tSB));
+    UIC_TRY(st.embed_grad(0, s2));
+    UIC_HIP(hipEventRecord(ss->ev_s3, s3));
+    UIC_HIP(hipStreamWaitEvent(s2, ss->ev_s3, 0));    // the third stream's share of the weight gradients
   }
   // side: the rest of the early gradient group (LSTM / h2att biases, embedding, fc_embed); main: the late group
   // (attention accumulation, ctx2att, att_embed).  ev_early: the early group, the logit layer and the loss are final.
   g_uic_tn_ring_off = 0;
   UIC_MARK(5, s);                                     // main: BPTT done
-  UIC_HIP(hipEventRecord(ss->ev_lstm, s2));           // gradient group 1 (lang_lstm.weight_*, att_lstm.weight_hh) final
+  UIC_HIP(hipEventRecord(ss->ev_lstm, s2));           // gradient group 1 final (uic_topdown_grad_ready_wait)
   UIC_MARK(6, s2);                                    // side: recurrent weight gradients done
   UIC_TRY(st.bwd_epilogue_late(s, true));             // (enqueued first: it is the longer of the two tails)
   UIC_MARK(7, s);
-  UIC_TRY(st.bwd_epilogue_early(s2, true, true));
+  UIC_TRY(st.bwd_epilogue_early(s2, true, true, early));
   UIC_HIP(hipEventRecord(ss->ev_early, s2));
   ss->early_recorded = true;
   UIC_MARK(8, s2);
@@ -1470,7 +1538,7 @@ int uic_topdown_step_marks(int32_t enable, float* ms_out) {
   UIC_TRY(get_side(&ss));
   if (ms_out) {
     UIC_REQUIRE(ss->marks_valid, "step_marks: no fused step has run with the marks enabled");
-    UIC_TRY(uic_check_hip(hipEventSynchronize(ss->mark[UIC_STEP_MARKS - 1]), "hipEventSynchronize"));
+    UIC_TRY(uic_check_hip(hipEventSynchronize(ss->mark[9]), "hipEventSynchronize"));   // (joined: every other mark precedes it)
     UIC_TRY(uic_check_hip(hipEventSynchronize(ss->mark[8]), "hipEventSynchronize"));
     ms_out[0] = 0.f;
     for (int i = 1; i < UIC_STEP_MARKS; ++i) UIC_TRY(uic_check_hip(hipEventElapsedTime(&ms_out[i], ss->mark[0], ss->mark[i]), "hipEventElapsedTime"));
@@ -1510,6 +1578,14 @@ int uic_topdown_sample(const uic_topdown_dims* d, const uic_topdown_weights* w, 
   const float drop_p = (training & 1) ? d->drop_p : 0.f;
   UIC_TRY(prepare_features(*d, w, dv, b, L, training, drop_p, seed, &fc_in, &att_in, s));
   UIC_TRY(wait_refresh(s));
+  {
+    Step st;
+    st.init(d, w, derived, b, Lsteps, training, seed, workspace, nullptr);
+    if (st.decode_persist_ok(sample_max, temperature, decoding_constraint)) {
+      UIC_TRY(uic_zero4_launch(L.h_att, NH * S, L.h_lang, NH * S, L.c_att, NH * 4, L.c_lang, NH * 4, s));
+      return st.decode_persist(Lsteps, sample_max, forced, false, seq, seq_logp, s);
+    }
+  }
   UIC_TRY(uic_fill_launch(L.s_h_att[0], 0, NH * S, s));
   UIC_TRY(uic_fill_launch(L.s_h_lang[0], 0, NH * S, s));
   UIC_TRY(uic_fill_launch(L.s_c_att[0], 0, NH * 4, s));
@@ -1560,6 +1636,8 @@ int uic_topdown_sample_train(const uic_topdown_dims* d, const uic_topdown_weight
   UIC_TRY(prepare_features(st.d, w, st.dv, b, L, training, st.drop_p, seed, &f, &a, s));
   UIC_TRY(uic_zero4_launch(L.h_att, st.NH * st.S, L.h_lang, st.NH * st.S, L.c_att, st.NH * 4, L.c_lang, st.NH * 4, s));
   UIC_TRY(wait_refresh(s));
+  if (st.decode_persist_ok(sample_max, temperature, decoding_constraint))
+    return st.decode_persist(Lsteps, sample_max, forced, true, seq, seq_logp, s);
   UIC_TRY(uic_fill_launch(L.s_it, 0, (size_t)N * 8, s));       // <bos> = 0 (AttModel.py:214-215)
   UIC_TRY(uic_fill_launch(L.s_unf, 0, (size_t)N * 4, s));
   UIC_TRY(uic_fill_launch(L.s_nunf, 0, (size_t)(d->T + 2) * UIC_NUNF_STRIPES * 4, s));

@@ -275,8 +275,28 @@ struct UicRnnFwdParams {
   unsigned* sync;                    // uic_rnn_persist_sync_bytes() bytes, zeroed by the launcher
   unsigned long long* dbg; int dbg_T; // optional [256][dbg_T][16] phase time stamps (100 MHz), indexed by absolute step
   unsigned* status;                  // sticky status words (uic_topdown_dims.rnn_status) or null
+  // ---- decode mode (AttModel._sample, P/models/AttModel.py:198-253; bf16 only): every step also embeds the row's input
+  // token, runs the logit layer and picks the next token inside the launch.  gx is then unused (gfc holds fc' W^T + b_ih + b_hh)
+  int dec;                           // 0: teacher-forced recurrence; 1: decode
+  const float* dec_embed;            // [V1, E = H] f32 embedding table
+  const void* dec_xw; int dec_ld_xw; // att_lstm.weight_ih columns of xt: [4H, ld], K = E contiguous
+  float dec_xt_drop;                 // dropout on relu(embed) (train-mode sampling pass) with (seed, UIC_SITE_EMBED)
+  void* dec_xt_all;                  // [T, N, E] the embedded inputs, kept for a backward pass, or null
+  const void* dec_logit_w; const float* dec_logit_b; int dec_V1, dec_V1p;   // [V1, H]
+  float* dec_logits; size_t dec_logits_step;   // [N, V1p] f32 of step t at dec_logits + t * dec_logits_step (0: one buffer reused)
+  float* dec_part;                   // [N, 32, 4] per-workgroup (max, sum exp, arg max) of a row's logits
+  int* dec_tok; int* dec_unf;        // [N] next input token / still-unfinished flag (exchanged between the steps)
+  int64_t* dec_seq; float* dec_seq_logp; int dec_ld_out;   // [N, ld_out]
+  const int64_t* dec_forced; int dec_ld_forced;            // optional tokens replacing the draws
+  int dec_sample_max;                // 1: arg max (lowest index on ties), 0: multinomial draw from softmax(logits)
+  unsigned dec_draw_seed;
 };
 size_t uic_rnn_persist_sync_bytes();
+bool uic_rnn_decode_persist_eligible(int dtype, int N, int H, int A, int R, int E, int V1);
+size_t uic_rnn_decode_part_floats(int N);
+// after uic_rnn_fwd_persist_launch in decode mode: the reference's `if unfinished.sum() == 0: break` (AttModel.py:236-238) --
+// log-probs recorded at steps after every row had finished are zeroed (their tokens already are)
+int uic_rnn_decode_finish_launch(const int64_t* seq, float* seq_logp, int N, int L, int ld, hipStream_t s);
 bool uic_rnn_persist_eligible(int dtype, int N, int H, int A, int R);
 int uic_rnn_fwd_persist_launch(const UicRnnFwdParams& p, hipStream_t s);
 
@@ -342,16 +362,17 @@ int uic_embed_bwd_launch(int dtype, const float* dxt, const void* xt, const int6
                          int V1, int E, float drop_p, long skip_token, float* dtable, hipStream_t s);   // skip_token < 0: none (nn.Embedding padding_idx otherwise)
 // the same with the positions bucketed by token first, so that runs of equal tokens are summed in registers and a hot token
 // (padding) costs 1/16 of the contended atomics: dtable is overwritten; scratch = uic_embed_bwd_sorted_scratch_ints(N, T, V1) ints
-size_t uic_embed_bwd_sorted_scratch_ints(int N, int T, int V1, int chunk = 0);
+size_t uic_embed_bwd_sorted_scratch_ints(int N, int T, int V1);
 int uic_embed_bwd_sorted_launch(int dtype, const float* dxt, const void* xt, const int64_t* tokens, int ldtok, int N, int T,
                                 int V1, int E, float drop_p, long skip_token, float* dtable, int* scratch, hipStream_t s);
 // the two halves of it: `prepare` needs only the tokens (zeroes dtable, buckets the positions), `gather` the gradients.
-// chunk > 0: positions bucketed by (t / chunk, token); gather then adds the share of decode steps [t0, t1) -- one chunk -- per call
+// split > 0: positions bucketed by (t >= split, token); gather then adds the share of decode steps [0, split) (half 0) or
+// [split, T) (half 1) per call
 int uic_embed_bwd_sorted_prepare(const int64_t* tokens, int ldtok, int N, int T, int V1, int E, float* dtable, int* scratch, hipStream_t s,
-                                 int chunk = 0);
+                                 int split = 0);
 int uic_embed_bwd_sorted_gather(int dtype, const float* dxt, const void* xt, const int64_t* tokens, int ldtok, int N, int T,
                                 int V1, int E, float drop_p, long skip_token, float* dtable, const int* scratch, hipStream_t s,
-                                int chunk = 0, int t0 = 0, int t1 = 0);
+                                int split = 0, int half = 0);
 // column sums of a small f32 [rows, ncols] matrix into two destinations (columns [0, n0) -> out0, the rest -> out1), one launch
 int uic_colsum_small_launch(const float* part, int rows, int ncols, int n0, float* out0, float* out1, hipStream_t s);
 // dst = (act > 0 ? scale : 0) * grad ; grad f32, act/dst operand dtype

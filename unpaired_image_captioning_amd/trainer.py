@@ -85,10 +85,6 @@ class Trainer(object):
             eng = getattr(self.i2t_model, 'engine', None)
             if eng is not None and hasattr(self.exchange, 'ranks_share_a_device') and self.exchange.ranks_share_a_device():
                 eng.recurrence |= _lib.REC_FWD_CHAIN       # several ranks on ONE GPU: per-step launches (include/uic_hip.h)
-            if eng is not None and self.exchange.world_size > 1:
-                # gradients are exchanged piece by piece while the step still computes: have the embedding gradient and
-                # att_lstm.weight_ih final with group 1 instead of at the very end (include/uic_hip.h, UIC_REC_EARLY_GRADS)
-                eng.recurrence |= _lib.REC_EARLY_GRADS
         self.lr = getattr(opt, 'i2t_learning_rate', 4e-4)
         self.i2t_current_lr = self.lr
         self.betas = (getattr(opt, 'i2t_optim_alpha', 0.9), getattr(opt, 'i2t_optim_beta', 0.999))
@@ -112,16 +108,21 @@ class Trainer(object):
     # flat-arena order [FIRST_GRADS | LSTM_W_GRADS | rest | LATE_GRADS] = gradient groups 0 / 1 / 2 / tail of uic_topdown_grad_ready_wait
     # (include/uic_hip.h): each piece's all-reduce starts while the step is still computing the following ones
     FIRST_GRADS = ("logit.",)
-    # final right after the BPTT loop (the embedding and att_lstm.weight_ih only under REC_EARLY_GRADS, which every
-    # data-parallel trainer sets; a single rank never waits for a group)
-    LSTM_W_GRADS = ("core.lang_lstm.weight_", "core.att_lstm.weight_", "embed.")
+    LSTM_W_GRADS = ("core.lang_lstm.weight_", "core.att_lstm.weight_hh")      # final right after the BPTT loop
+    # opt.early_grads (UIC_REC_EARLY_GRADS, include/uic_hip.h): these two join them, 62 % of the bytes final 0.17 ms before the
+    # step ends for a step that is 4 % longer on its own -- a data-parallel run's choice
+    LSTM_W_GRADS_EARLY = ("core.lang_lstm.weight_", "core.att_lstm.weight_", "embed.")
     LATE_GRADS = ("att_embed.", "ctx2att.", "core.attention.")
 
     def build_optimizer(self):
         self.i2t_model.cuda()
         names = self.i2t_model.param_names
         first = [k for k in names if k.startswith(self.FIRST_GRADS)]
-        lstm_w = [k for k in names if k.startswith(self.LSTM_W_GRADS)]
+        early_order = bool(getattr(self.opt, 'early_grads', False))
+        eng = getattr(self.i2t_model, 'engine', None)
+        if eng is not None:
+            eng.recurrence = (eng.recurrence | _lib.REC_EARLY_GRADS) if early_order else (eng.recurrence & ~_lib.REC_EARLY_GRADS)
+        lstm_w = [k for k in names if k.startswith(self.LSTM_W_GRADS_EARLY if early_order else self.LSTM_W_GRADS)]
         late = [k for k in names if k.startswith(self.LATE_GRADS)]
         early = [k for k in names if k not in first and k not in lstm_w and k not in late]
         self.arena = FlatArena(self.i2t_model, first + lstm_w + early + late)
