@@ -195,3 +195,66 @@ def test_self_critical_step_full_size_vs_oracle(case, dtype):
         assert err < {"f32": 2e-5, "bf16": 5e-2}[dtype], (k, err)
     print("self-critical full size %s: loss %.6f (oracle %.6f), worst per-tensor L2 gradient error %.3e (%s)" %
           (dtype, loss.item(), loss_o.item(), worst, worst_k))
+
+
+@pytest.mark.parametrize("n_rows", [640, 645, 24])
+def test_persistent_decode_launch_against_the_launch_chain(case, n_rows):
+    """bf16: AttModel._sample as ONE persistent launch (rnn_persist.hip's decode mode: embedding, recurrence, logit layer and
+    the greedy / multinomial choice inside the launch) against the per-step chain of six launches -- 640 rows (one slab of 8
+    groups x 80), 645 (a second slab of 5 rows: groups without rows) and 24 (3 rows per group).  The two differ only by
+    summation order in bf16, so: the chain's tokens replayed through the persistent launch give the same ids and log-probs
+    within 1e-2 (eval and train mode / kept forward); greedy decodes mostly identical captions; the placement-independent SAFE
+    protocol gives the persistent launch's results bit for bit; and the sampled captions end at every length (the reference's
+    finished-row bookkeeping, with its early break, included)."""
+    from unpaired_image_captioning_amd import _lib as Lb
+    Wg, Ws, b = case
+    reps = (n_rows + 639) // 640
+    rows = torch.arange(n_rows) % 640
+    fc, att, am = b["fc_feats"][rows].cuda(), b["att_feats"][rows].cuda(), b["att_masks"][rows].cuda()
+    for W, sample_max, training in ((Wg, 1, False), (Ws, 0, False), (Ws, 0, True)):
+        model = build_model(CFG, W, "bf16", drop=0.5)
+        eng = model.engine
+        pd = {k: v.detach() for k, v in model.param_dict().items()}
+        keep = training
+
+        def run(flags, forced=None):
+            eng.recurrence = flags
+            try:
+                out = eng.sample(pd, fc, att, am, L, sample_max=sample_max, seed=4242, forced=forced, training=training, keep_forward=keep)
+            finally:
+                eng.recurrence = 0
+            if keep:
+                eng.release(out[2])
+            return out[0].cpu(), out[1].cpu()
+
+        before = Lb.persistent_status()
+        seq_c, lp_c = run(Lb.REC_FWD_CHAIN)
+        mid = Lb.persistent_status()
+        assert (mid[1], mid[2]) == (before[1], before[2])                   # the chain launched no persistent kernel
+        seq_p, lp_p = run(0)
+        after = Lb.persistent_status()
+        assert after[0] == 0 and after[1] - mid[1] == reps and after[2] == mid[2]
+        seq_s, lp_s = run(Lb.REC_SAFE)
+        assert torch.equal(seq_s, seq_p) and torch.equal(lp_s, lp_p)
+        assert Lb.persistent_status()[2] - after[2] == reps
+        live = alive_mask(seq_c)
+        if sample_max:
+            same_rows = (seq_c == seq_p).all(1).float().mean().item()
+            assert same_rows > 0.9, same_rows
+            both = (seq_c == seq_p).cumprod(1).bool() & live                # positions with an identical history
+            assert (lp_c - lp_p)[both].abs().max().item() < LOGP_TOL["bf16"]
+        else:
+            seq_f, lp_f = run(0, forced=seq_c.cuda())
+            assert torch.equal(seq_f, seq_c)
+            assert (lp_f - lp_c)[live].abs().max().item() < LOGP_TOL["bf16"]
+            same_tok = (seq_c == seq_p).float().mean().item()
+            assert same_tok > 0.5, same_tok                                  # a draw at a rounding boundary changes the rest of its row
+        lens = (seq_p > 0).sum(1)
+        if n_rows >= 640 and W is not Wg:
+            assert len(set(lens.tolist())) > 8
+        # entries behind a finished row are zero, and log-probs behind the step at which EVERY row had finished too
+        fin = ~alive_mask(seq_p)
+        assert (seq_p[fin] == 0).all()
+        t_dead = int(lens.max().item()) + 1 if (lens < L).all() else L
+        if t_dead < L:
+            assert (lp_p[:, t_dead:] == 0).all()

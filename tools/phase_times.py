@@ -103,6 +103,12 @@ rewards.CiderD_scorer = None
 def scst_dev():
     tr.train_self_critical(data)
 print("Trainer.train_self_critical with the device CIDEr-D reward (%d n-grams in the table), incl. H2D: %.3f ms" % (len(df), timeit(scst_dev, iters=5, warm=2)))
+# decode passes of the step: the default (per-step launch chains, the greedy baseline on a second stream beside the sampling
+# pass) against one persistent decode launch per pass (they cannot share the chip, so the two passes run one after the other)
+from unpaired_image_captioning_amd import _lib as _L
+tr.persistent_decode = True
+print("  ... with persistent decode launches (sampling pass, then the greedy baseline): %.3f ms" % timeit(scst_dev, iters=5, warm=2))
+tr.persistent_decode = False
 st3 = {"cur": data, "nxt": dict(data)}
 def scst_dev_prefetch():
     tr.train_self_critical(st3["cur"], next_data=st3["nxt"])

@@ -596,139 +596,213 @@ __device__ __forceinline__ void dec_merge(float& m, float& s, int& a, float om, 
 }
 
 // xg[r][g] / xg5[g]: the input token's share of att_lstm's gate pre-activations of step `t`, in the layout ws_cell reads
-// (own tile: rows 16 wave + 4 lq + r; fifth tile: row 64 + 4 lq + wave), unit u0 + l15, gate g
-__device__ __forceinline__ void dec_xt_gemm(const UicRnnFwdParams& p, const Ctx& c, int t, float (&xg)[4][4], float (&xg5)[4]) {
-  const bool own = c.wave < c.MT, five = c.MT > WS_NW;
-  int ra = 16 * c.wave + c.l15, r5 = 16 * WS_NW + c.l15;
-  const bool va = own && ra < c.nrow, v5 = five && r5 < c.nrow;
-  ra = ra < c.nrow ? ra : c.nrow - 1;
-  r5 = r5 < c.nrow ? r5 : c.nrow - 1;
-  int tokA = own ? ld_xi(p.dec_tok + c.rbegin + ra) : 0, tok5 = five ? ld_xi(p.dec_tok + c.rbegin + r5) : 0;
-  tokA = tokA < 0 || tokA >= p.dec_V1 ? 0 : tokA;
-  tok5 = tok5 < 0 || tok5 >= p.dec_V1 ? 0 : tok5;
-  const float* eA = p.dec_embed + (size_t)tokA * HH + c.lq * 8;
-  const float* e5 = p.dec_embed + (size_t)tok5 * HH + c.lq * 8;
+// (own tile: rows 16 wave + 4 lq + r; fifth tile: row 64 + 4 lq + wave), unit u0 + l15, gate g.
+// K is split over the waves (wave w: k-steps 4w .. 4w+3 of EVERY row tile), so a lane requests its 16 W_x fragments and its
+// <= 20 embedding-row fragments all at once -- the table (relu(embed) in bf16, 10 MB, random rows) comes from the Infinity
+// Cache, W_x from L2,
+// one round trip each -- and the partial tiles are summed through LDS, one row tile per pass (as lang_lstm does).
+__device__ __forceinline__ void dec_xt_gemm(const UicRnnFwdParams& p, const Ctx& c, int t, float (&xg)[4][4], float (&xg5)[4], const int* tok_lds = nullptr) {
   const float dp = p.dec_xt_drop, inv_keep = dp > 0.f ? 1.f / (1.f - dp) : 1.f;
-  // dropout index of element e of row n at step t: (t N + n) E + e, the index uic_embed_fwd_launch uses for the training layout
-  const unsigned iA = (unsigned)(((size_t)t * p.N + c.rbegin + ra) * HH + c.lq * 8);
-  const unsigned i5 = (unsigned)(((size_t)t * p.N + c.rbegin + r5) * HH + c.lq * 8);
   const __amdgpu_buffer_rsrc_t r_xw = rsrc_of(p.dec_xw);
-  unsigned boff[4];
+  u32x4 fb[4][4];                                  // [k-step of this wave][gate]
 #pragma unroll
-  for (int g = 0; g < 4; ++g) boff[g] = (unsigned)(((g * HH + c.u0 + c.l15) * p.dec_ld_xw + c.lq * 8) * 2);
+  for (int k = 0; k < 4; ++k)
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+      fb[k][g] = bload<false>(r_xw, (unsigned)(((g * HH + c.u0 + c.l15) * p.dec_ld_xw + c.lq * 8) * 2), (unsigned)((4 * c.wave + k) * 64));
+  // (tok_lds: the group's tokens as dec_sample left them in LDS -- greedy / forced, where every workgroup knows them all)
+  int tok[MT_MAX], rowi[MT_MAX];
+#pragma unroll
+  for (int i = 0; i < MT_MAX; ++i) {
+    int r = 16 * i + c.l15;
+    r = r < c.nrow ? r : c.nrow - 1;
+    rowi[i] = r;
+    int tk = i < c.MT ? (tok_lds ? tok_lds[r] : ld_xi(p.dec_tok + c.rbegin + r)) : 0;
+    tok[i] = tk < 0 || tk >= p.dec_V1 ? 0 : tk;
+  }
+  if (tok_lds) __syncthreads();                    // (the token list lives in the scratch the partial tiles go to: every wave has read it)
+  const unsigned ko = (unsigned)(c.wave * 128 + c.lq * 8);          // first K element of this lane's fragments
+  // every fragment of the lane (<= 20 x 16 bytes of relu(embed) in bf16, made once per launch by the host side) in flight at once
+  u32x4 fa[MT_MAX][4];
+  const bf16_t* er = (const bf16_t*)p.dec_embed_relu;
+#pragma unroll
+  for (int i = 0; i < MT_MAX; ++i)
+    if (i < c.MT) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) fa[i][k] = *(const u32x4*)(er + (size_t)tok[i] * HH + ko + k * 32);
+    }
   bf16_t* xo = (bf16_t*)p.dec_xt_all;
-  f32x4 acc[2][4];
+  if (dp > 0.f || xo) {
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < MT_MAX; ++i)
+      if (i < c.MT) {
+        // dropout index of element e of row n at step t: (t N + n) E + e, the index uic_embed_fwd_launch uses for the training layout
+        const unsigned idx = (unsigned)(((size_t)t * p.N + c.rbegin + rowi[i]) * HH) + ko;
 #pragma unroll
-    for (int g = 0; g < 4; ++g) acc[i][g] = f32x4{0.f, 0.f, 0.f, 0.f};
-  float4 ra0[2], ra1[2], rb0[2], rb1[2];
-  u32x4 fb[2][4];
-  auto load = [&](int buf, int ks) {
-    ra0[buf] = *(const float4*)(eA + ks * 32); ra1[buf] = *(const float4*)(eA + ks * 32 + 4);
-    rb0[buf] = *(const float4*)(e5 + ks * 32); rb1[buf] = *(const float4*)(e5 + ks * 32 + 4);
+        for (int k = 0; k < 4; ++k) {
+          if (dp > 0.f) {
+            float f[8];
+            uic_unpack<bf16_t>(__builtin_bit_cast(uint4, fa[i][k]), f);
 #pragma unroll
-    for (int g = 0; g < 4; ++g) fb[buf][g] = bload<false>(r_xw, boff[g], (unsigned)(ks * 64));
-  };
-  auto frag = [&](const float4& lo, const float4& hi, unsigned idx) {
-    float f[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      f[j] = fmaxf(f[j], 0.f);
-      if (dp > 0.f) f[j] *= uic_drop_scale(p.seed, UIC_SITE_EMBED, idx + (unsigned)j, dp, inv_keep);
-    }
-    return u32x4{uic_pack_bf16x2(f[0], f[1]), uic_pack_bf16x2(f[2], f[3]), uic_pack_bf16x2(f[4], f[5]), uic_pack_bf16x2(f[6], f[7])};
-  };
-  auto step = [&](auto bc, int ks) {
-    constexpr int b = decltype(bc)::value;
-    if (ks + 1 < 16) load(b ^ 1, ks + 1);
-    const u32x4 fa = frag(ra0[b], ra1[b], iA + (unsigned)(ks * 32));
-    const u32x4 f5 = frag(rb0[b], rb1[b], i5 + (unsigned)(ks * 32));
-    if (xo && c.rank == ks) {                      // the embedded inputs, for a backward pass: workgroup ks writes k-step ks
-      if (va) *(u32x4*)(xo + ((size_t)t * p.N + c.rbegin + ra) * HH + ks * 32 + c.lq * 8) = fa;
-      if (v5 && c.wave == 0) *(u32x4*)(xo + ((size_t)t * p.N + c.rbegin + r5) * HH + ks * 32 + c.lq * 8) = f5;
-    }
-#pragma unroll
-    for (int g = 0; g < 4; ++g) {
-      acc[0][g] = mma_bf16(fa, fb[b][g], acc[0][g]);
-      acc[1][g] = mma_bf16(f5, fb[b][g], acc[1][g]);
-    }
-  };
-  load(0, 0);
-  for (int ks = 0; ks < 16; ks += 2) {
-    step(std::integral_constant<int, 0>{}, ks);
-    step(std::integral_constant<int, 1>{}, ks + 1);
+            for (int j = 0; j < 8; ++j) f[j] *= uic_drop_scale(p.seed, UIC_SITE_EMBED, idx + (unsigned)(k * 32 + j), dp, inv_keep);
+            fa[i][k] = u32x4{uic_pack_bf16x2(f[0], f[1]), uic_pack_bf16x2(f[2], f[3]), uic_pack_bf16x2(f[4], f[5]), uic_pack_bf16x2(f[6], f[7])};
+          }
+          // the embedded inputs, for a backward pass: workgroup `rank` writes k-step `rank` (of the 16) of every row
+          if (xo && c.rank == 4 * c.wave + k && 16 * i + c.l15 < c.nrow)
+            *(u32x4*)(xo + ((size_t)t * p.N + c.rbegin + rowi[i]) * HH + ko + k * 32) = fa[i][k];
+        }
+      }
   }
+  f32x4* scr = (f32x4*)c.smem;                     // two 16 KB halves, as in the lang_lstm phase
 #pragma unroll
-  for (int g = 0; g < 4; ++g) {
+  for (int i = 0; i < MT_MAX; ++i)
+    if (i < c.MT) {
+      f32x4 acc[4];
 #pragma unroll
-    for (int r = 0; r < 4; ++r) xg[r][g] = acc[0][g][r];
-    xg5[g] = c.wave == 0 ? acc[1][g][0] : c.wave == 1 ? acc[1][g][1] : c.wave == 2 ? acc[1][g][2] : acc[1][g][3];
-  }
+      for (int g = 0; g < 4; ++g) acc[g] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int k = 0; k < 4; ++k)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) acc[g] = mma_bf16(fa[i][k], fb[k][g], acc[g]);
+      f32x4* half = scr + (i & 1) * (WS_NW * 4 * 64);
+#pragma unroll
+      for (int g = 0; g < 4; ++g) half[(c.wave * 4 + g) * 64 + c.lane] = acc[g];
+      __syncthreads();
+      if (i < WS_NW) {
+        if (c.wave == i) {                         // the tile's owner: all four accumulator components of its lanes
+#pragma unroll
+          for (int g = 0; g < 4; ++g) {
+            f32x4 v = half[(0 * 4 + g) * 64 + c.lane];
+#pragma unroll
+            for (int w = 1; w < WS_NW; ++w) v += half[(w * 4 + g) * 64 + c.lane];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) xg[r][g] = v[r];
+          }
+        }
+      } else {                                     // the fifth tile: wave w finishes row 4 lq + w
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          float v = 0.f;
+#pragma unroll
+          for (int w = 0; w < WS_NW; ++w) v += ((const float*)(half + (w * 4 + g) * 64 + c.lane))[c.wave];
+          xg5[g] = v;
+        }
+      }
+    }
+  __syncthreads();                                 // (the scratch is the barrier flag's home, and the next pass's)
 }
 
 // LDS layout of the decode tail inside the 32 KB scratch (word 0 is the barrier flag)
 constexpr int DEC_OFF_PM = 256, DEC_OFF_PS = DEC_OFF_PM + WS_NW * 80 * 4, DEC_OFF_PA = DEC_OFF_PS + WS_NW * 80 * 4;
 constexpr int DEC_OFF_CNT = DEC_OFF_PA + WS_NW * 80 * 4, DEC_OFF_LIST = DEC_OFF_CNT + 16;   // list: 80 x {row, rt, M, lse}
 
+// att_lstm's B fragments of k-steps wave + 4 jj, jj in [jj0, jj1), into the LDS image (the launch's one-time load, and the
+// reload of the part dec_logits borrows)
+// (vwave: the wave whose share of the image this wave loads -- normally its own)
+__device__ __forceinline__ void ws_load_w1(const UicRnnFwdParams& p, const Ctx& c, char* lds, int jj0, int jj1, int vwave) {
+  const unsigned bl = (unsigned)(c.lq * 8);
+  const __amdgpu_buffer_rsrc_t r_a_ih = rsrc_of(p.att_w_ih), r_a_hh = rsrc_of(p.att_w_hh);
+#pragma unroll
+  for (int jj = 0; jj < 8; ++jj) {
+    if (jj < jj0 || jj >= jj1) continue;
+    const int s = vwave + 4 * jj;                 // k-step of [h_lang_prev | h_att_prev]
+    const unsigned kk = (unsigned)((s & 15) * 32);
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const unsigned row = (unsigned)(g * HH + c.u0 + c.l15);
+      const u32x4 v = jj < 4 ? bload<false>(r_a_ih, (row * (unsigned)p.ld_att_ih + kk + bl) * 2u, 0)
+                             : bload<false>(r_a_hh, (row * (unsigned)HH + kk + bl) * 2u, 0);
+      ((u32x4*)lds)[(s * 4 + g) * 64 + c.lane] = v;
+    }
+  }
+}
+
+// The group's dropped h_lang rows (80 x 512 bf16 = 80 KB) are every wave's A operand: they are staged ONCE per step into LDS
+// as MFMA fragments, over the first 80 KB of att_lstm's weight image (k-steps 0..19), which is reloaded from L2 afterwards --
+// the weights of W_logit, the operand that comes from the Infinity Cache, can then be requested DEC_LD k-steps ahead.
+constexpr int DEC_LD = 3;
+// arrived: the caller has ARRIVED at the group barrier behind lang_lstm but not waited yet -- W_logit's first fragments are
+// requested before the wait (they do not depend on the exchange).  Returns false after a barrier timeout.
 template <bool SAFE>
-__device__ __forceinline__ void dec_logits(const UicRnnFwdParams& p, const Ctx& c, int t) {
+__device__ __forceinline__ bool dec_logits(const UicRnnFwdParams& p, Ctx& c, int t, char* lds) {
   const int V1 = p.dec_V1;
   const int ntile_all = (V1 + 15) >> 4, per = (ntile_all + PW - 1) / PW;
   const int tile0 = c.rank * per;
   const int ntile = min(per, max(0, ntile_all - tile0));
   const bf16_t* hd = (const bf16_t*)p.hdrop_all + ((size_t)t * p.N + c.rbegin) * HH;
   const __amdgpu_buffer_rsrc_t r_a = rsrc_of(hd), r_w = rsrc_of(p.dec_logit_w);
-  unsigned aoff[MT_MAX], woff[DEC_NJ];
-  int col[DEC_NJ];
-#pragma unroll
-  for (int i = 0; i < MT_MAX; ++i) {
-    int r = 16 * i + c.l15;
-    r = r < c.nrow ? r : c.nrow - 1;
-    aoff[i] = (unsigned)((r * HH + c.lq * 8) * 2);
-  }
+  u32x4* la = (u32x4*)lds;                         // [k-step 16][row tile 5][lane 64]
+  unsigned woff[DEC_NJ];
+  int col0[DEC_NJ];                                // first column of the wave's tile j (>= V1: no tile)
 #pragma unroll
   for (int j = 0; j < DEC_NJ; ++j) {
     const bool tv = c.wave + WS_NW * j < ntile;
-    col[j] = tv ? 16 * (tile0 + c.wave + WS_NW * j) + c.l15 : V1;          // >= V1: not a column
-    const int wr = col[j] < V1 ? col[j] : V1 - 1;
+    col0[j] = tv ? 16 * (tile0 + c.wave + WS_NW * j) : V1;
+    const int wr = col0[j] + c.l15 < V1 ? col0[j] + c.l15 : V1 - 1;
     woff[j] = (unsigned)((wr * HH + c.lq * 8) * 2);
+  }
+  u32x4 fb[DEC_LD][DEC_NJ];
+  auto loadb = [&](int buf, int ks) {
+#pragma unroll
+    for (int j = 0; j < DEC_NJ; ++j) fb[buf][j] = bload<false>(r_w, woff[j], (unsigned)(ks * 64));
+  };
+  const int ks0 = c.rank & 15;                     // de-phased walk over K, as in the recurrence's GEMMs
+#pragma unroll
+  for (int q = 0; q < DEC_LD - 1; ++q) loadb(q, (q + ks0) & 15);
+  if (!group_wait(c, (int*)c.smem)) return false;
+  if (c.dbg && c.tid == 0) c.dbg[15] = __builtin_amdgcn_s_memrealtime();
+  {
+    // fragment f = ks * 5 + i is staged by wave f & 3: 20 loads per lane, all in flight
+    u32x4 st[20];
+#pragma unroll
+    for (int q = 0; q < 20; ++q) {
+      const int f = c.wave + 4 * q, ks = f / MT_MAX, i = f - ks * MT_MAX;
+      int r = 16 * i + c.l15;
+      r = r < c.nrow ? r : c.nrow - 1;
+      st[q] = bload<true>(r_a, (unsigned)((r * HH + c.lq * 8) * 2), (unsigned)(ks * 64));
+    }
+#pragma unroll
+    for (int q = 0; q < 20; ++q) la[(c.wave + 4 * q) * 64 + c.lane] = st[q];
+  }
+  float4 bias[DEC_NJ];
+#pragma unroll
+  for (int j = 0; j < DEC_NJ; ++j) {
+    const int cb = col0[j] + 4 * c.lq;
+    bias[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (p.dec_logit_b && cb < V1) {
+      if (cb + 3 < V1) bias[j] = *(const float4*)(p.dec_logit_b + cb);
+      else { bias[j].x = p.dec_logit_b[cb]; bias[j].y = cb + 1 < V1 ? p.dec_logit_b[cb + 1] : 0.f; bias[j].z = cb + 2 < V1 ? p.dec_logit_b[cb + 2] : 0.f; }
+    }
   }
   f32x4 acc[MT_MAX][DEC_NJ];
 #pragma unroll
   for (int i = 0; i < MT_MAX; ++i)
 #pragma unroll
     for (int j = 0; j < DEC_NJ; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-  u32x4 fa[2][MT_MAX], fb[2][DEC_NJ];
-  auto load = [&](int buf, int ks) {
+  __syncthreads();                                 // the A image is complete
+  if (c.dbg && c.tid == 0) c.dbg[11] = __builtin_amdgcn_s_memrealtime();
+  // W_logit's fragment is the MFMA's FIRST operand: the lane then holds 4 consecutive vocabulary columns (4 lq + r) of ONE
+  // caption row (l15) per tile -- one 16-byte store per tile, and a row's maximum / sum are mostly in-lane
 #pragma unroll
-    for (int j = 0; j < DEC_NJ; ++j) fb[buf][j] = bload<false, true>(r_w, woff[j], (unsigned)(ks * 64));
+  for (int q = 0; q < 16; ++q) {
+    const int ks = (q + ks0) & 15;
+    if (q + DEC_LD - 1 < 16) loadb((q + DEC_LD - 1) % DEC_LD, (q + DEC_LD - 1 + ks0) & 15);
+    u32x4 fa[MT_MAX];
 #pragma unroll
     for (int i = 0; i < MT_MAX; ++i)
-      if (i < c.MT) fa[buf][i] = bload<true>(r_a, aoff[i], (unsigned)(ks * 64));
-  };
-  const int ks0 = c.rank & 15;                     // de-phased walk over K, as in the recurrence's GEMMs
-  auto step = [&](auto bc, int q) {
-    constexpr int b = decltype(bc)::value;
-    if (q + 1 < 16) load(b ^ 1, (q + 1 + ks0) & 15);
+      if (i < c.MT) fa[i] = la[(ks * MT_MAX + i) * 64 + c.lane];
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int i = 0; i < MT_MAX; ++i)
       if (i < c.MT) {
 #pragma unroll
-        for (int j = 0; j < DEC_NJ; ++j) acc[i][j] = mma_bf16(fa[b][i], fb[b][j], acc[i][j]);
+        for (int j = 0; j < DEC_NJ; ++j) acc[i][j] = mma_bf16(fb[q % DEC_LD][j], fa[i], acc[i][j]);
       }
     __builtin_amdgcn_sched_barrier(0);
-  };
-  load(0, ks0);
-  for (int q = 0; q < 16; q += 2) {
-    step(std::integral_constant<int, 0>{}, q);
-    step(std::integral_constant<int, 1>{}, q + 1);
   }
-  // bias, store, per-row partials.  D layout: the lane holds rows 4 lq + r, column l15 of every 16 x 16 tile
-  float bias[DEC_NJ];
-#pragma unroll
-  for (int j = 0; j < DEC_NJ; ++j) bias[j] = col[j] < V1 && p.dec_logit_b ? p.dec_logit_b[col[j]] : 0.f;
+  if (c.dbg && c.tid == 0) c.dbg[12] = __builtin_amdgcn_s_memrealtime();
+  // bias, store, per-row partials
+  const bool store = p.dec_logits_step != 0 || !p.dec_sample_max;     // kept for a backward pass, or read back by the draw
   float* lg = p.dec_logits + (size_t)t * p.dec_logits_step;
   float* pm = (float*)(c.smem + DEC_OFF_PM);
   float* ps = (float*)(c.smem + DEC_OFF_PS);
@@ -736,34 +810,47 @@ __device__ __forceinline__ void dec_logits(const UicRnnFwdParams& p, const Ctx& 
 #pragma unroll
   for (int i = 0; i < MT_MAX; ++i)
     if (i < c.MT) {
+      const int row = 16 * i + c.l15;
+      const bool rv = row < c.nrow;
+      float m = -INFINITY;
+      int a = 0x7fffffff;
+      float v[DEC_NJ][4];
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int row = 16 * i + 4 * c.lq + r;
-        const bool rv = row < c.nrow;
-        float v[DEC_NJ];
-        float m = -INFINITY;
-        int a = 0x7fffffff;
+      for (int j = 0; j < DEC_NJ; ++j) {
+        const int cb = col0[j] + 4 * c.lq;
+        v[j][0] = acc[i][j][0] + bias[j].x; v[j][1] = acc[i][j][1] + bias[j].y;
+        v[j][2] = acc[i][j][2] + bias[j].z; v[j][3] = acc[i][j][3] + bias[j].w;
+        if (store && rv && cb < V1) {
+          float* o = lg + (size_t)(c.rbegin + row) * p.dec_V1p + cb;
+          if (!SAFE && cb + 3 < V1) *(float4*)o = make_float4(v[j][0], v[j][1], v[j][2], v[j][3]);
+          else {
 #pragma unroll
-        for (int j = 0; j < DEC_NJ; ++j) {
-          v[j] = col[j] < V1 ? acc[i][j][r] + bias[j] : -INFINITY;
-          if (rv && col[j] < V1) st_x<SAFE>(lg + (size_t)(c.rbegin + row) * p.dec_V1p + col[j], v[j]);
-          if (v[j] > m) { m = v[j]; a = col[j]; }
+            for (int r = 0; r < 4; ++r)
+              if (cb + r < V1) st_x<SAFE>(o + r, v[j][r]);
+          }
         }
-        float sum = 0.f;
 #pragma unroll
-        for (int j = 0; j < DEC_NJ; ++j) sum += v[j] > -INFINITY ? __expf(v[j] - m) : 0.f;
-        // across the 16 lanes (columns) of the tile row.  Lane l15 ^ o holds other columns of the same tiles: not ordered by
-        // column, so the arg max is merged by (value, lowest index) explicitly
-#pragma unroll
-        for (int o = 1; o < 16; o <<= 1) {
-          const float om = __shfl_xor(m, o, 64), os = __shfl_xor(sum, o, 64);
-          const int oa = __shfl_xor(a, o, 64);
-          dec_merge(m, sum, a, om, os, oa);
+        for (int r = 0; r < 4; ++r) {
+          if (cb + r >= V1) v[j][r] = -INFINITY;
+          if (v[j][r] > m) { m = v[j][r]; a = cb + r; }           // (columns ascend with j and r inside a lane)
         }
-        if (c.l15 == 0 && rv) { pm[c.wave * 80 + row] = m; ps[c.wave * 80 + row] = sum; pa[c.wave * 80 + row] = a; }
       }
+      float sum = 0.f;
+#pragma unroll
+      for (int j = 0; j < DEC_NJ; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) sum += v[j][r] > -INFINITY ? __expf(v[j][r] - m) : 0.f;
+      // the other three column quarters of the same tiles live in lanes l15 + 16, + 32, + 48
+#pragma unroll
+      for (int o = 16; o < 64; o <<= 1) {
+        const float om = __shfl_xor(m, o, 64), os = __shfl_xor(sum, o, 64);
+        const int oa = __shfl_xor(a, o, 64);
+        dec_merge(m, sum, a, om, os, oa);
+      }
+      if (c.lq == 0 && rv) { pm[c.wave * 80 + row] = m; ps[c.wave * 80 + row] = sum; pa[c.wave * 80 + row] = a; }
     }
-  __syncthreads();
+  if (c.dbg && c.tid == 0) c.dbg[14] = __builtin_amdgcn_s_memrealtime();
+  __syncthreads();                                 // partials in LDS; every wave is through with the A image
   if (c.tid < c.nrow) {
     const int row = c.tid;
     float m = pm[row], sum = ps[row];
@@ -773,10 +860,11 @@ __device__ __forceinline__ void dec_logits(const UicRnnFwdParams& p, const Ctx& 
     float* o = p.dec_part + ((size_t)(c.rbegin + row) * PW + c.rank) * 4;
     st_x<SAFE>(o, m); st_x<SAFE>(o + 1, sum); st_x<SAFE>(o + 2, __int_as_float(a));
   }
+  return true;
 }
 
 template <bool SAFE>
-__device__ __forceinline__ void dec_sample(const UicRnnFwdParams& p, const Ctx& c, int t) {
+__device__ __forceinline__ void dec_sample(const UicRnnFwdParams& p, const Ctx& c, int t, char* lds) {
   const int V1 = p.dec_V1;
   const int ntile_all = (V1 + 15) >> 4, per = (ntile_all + PW - 1) / PW;
   int* s_cnt = (int*)(c.smem + DEC_OFF_CNT);
@@ -784,6 +872,33 @@ __device__ __forceinline__ void dec_sample(const UicRnnFwdParams& p, const Ctx& 
   const float* lg = p.dec_logits + (size_t)t * p.dec_logits_step;
   if (c.tid == 0) *s_cnt = 0;
   __syncthreads();
+  // att_lstm's weight fragments of k-steps 0..19 go back into the LDS image dec_logits borrowed (from L2): by the two waves
+  // that have no row to combine below (a group has at most 80 rows = threads 0..79), beside the two that do
+  if (c.wave >= 2) {
+    const unsigned bl = (unsigned)(c.lq * 8);
+    const __amdgpu_buffer_rsrc_t r_a_ih = rsrc_of(p.att_w_ih), r_a_hh = rsrc_of(p.att_w_hh);
+    u32x4 v[40];                                   // all in flight: one L2 round trip
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+      const int vw = c.wave - 2 * half;            // the wave whose share of the image this is
+#pragma unroll
+      for (int jj = 0; jj < 5; ++jj) {
+        const unsigned kk = (unsigned)(((vw + 4 * jj) & 15) * 32);
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const unsigned row = (unsigned)(g * HH + c.u0 + c.l15);
+          v[half * 20 + jj * 4 + g] = jj < 4 ? bload<false>(r_a_ih, (row * (unsigned)p.ld_att_ih + kk + bl) * 2u, 0)
+                                             : bload<false>(r_a_hh, (row * (unsigned)HH + kk + bl) * 2u, 0);
+        }
+      }
+    }
+#pragma unroll
+    for (int half = 0; half < 2; ++half)
+#pragma unroll
+      for (int jj = 0; jj < 5; ++jj)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) ((u32x4*)lds)[((c.wave - 2 * half + 4 * jj) * 4 + g) * 64 + c.lane] = v[half * 20 + jj * 4 + g];
+  }
   auto finish = [&](int n, int choice, float lp) {   // the row's writer (AttModel.py:240-249)
     int unf = choice > 0;
     if (t > p.t0) unf = unf && ld_xi(p.dec_unf + n) != 0;
@@ -795,12 +910,13 @@ __device__ __forceinline__ void dec_sample(const UicRnnFwdParams& p, const Ctx& 
   };
   if (c.tid < c.nrow) {
     const int row = c.tid, n = c.rbegin + row;
-    const __amdgpu_buffer_rsrc_t r_p = rsrc_of(p.dec_part + (size_t)n * PW * 4);
+    const __amdgpu_buffer_rsrc_t r_p = rsrc_of(p.dec_part);       // (one descriptor for the wave: the row is the lane offset)
+    const unsigned poff = (unsigned)n * (unsigned)(PW * 16);
     float M = -INFINITY;
     int best = 0;
     u32x4 q[PW];
 #pragma unroll
-    for (int w = 0; w < PW; ++w) q[w] = bload<true>(r_p, 0u, (unsigned)(w * 16));
+    for (int w = 0; w < PW; ++w) q[w] = bload<true>(r_p, poff, (unsigned)(w * 16));
 #pragma unroll
     for (int w = 0; w < PW; ++w) {
       const float mw = __uint_as_float(q[w].x);
@@ -814,14 +930,17 @@ __device__ __forceinline__ void dec_sample(const UicRnnFwdParams& p, const Ctx& 
     }
     const float lse = M + __logf(Z);
     const bool writer = (row & (PW - 1)) == c.rank;
-    if (p.dec_sample_max) {
-      if (writer) finish(n, best, M - lse);
-    } else if (p.dec_forced) {
-      if (writer) {
-        int ch = (int)p.dec_forced[(size_t)n * p.dec_ld_forced + t];
+    if (p.dec_sample_max || p.dec_forced) {
+      // every workgroup knows the choice of every row of the group: the next step's tokens go to LDS (no exchange, no barrier)
+      int ch = best;
+      if (!p.dec_sample_max) {
+        ch = (int)p.dec_forced[(size_t)n * p.dec_ld_forced + t];
         ch = ch < 0 || ch >= V1 ? 0 : ch;
-        finish(n, ch, ld_xf(lg + (size_t)n * p.dec_V1p + ch) - lse);
       }
+      int unf = ch > 0;
+      if (t > p.t0) unf = unf && ld_xi(p.dec_unf + n) != 0;       // (written by the row's writer one step -- several barriers -- ago)
+      ((int*)s_list)[row] = unf ? ch : 0;
+      if (writer) finish(n, ch, p.dec_sample_max ? M - lse : ld_xf(lg + (size_t)n * p.dec_V1p + ch) - lse);
     } else {
       // inverse-CDF target in units of exp(. - M); the owner is the first workgroup whose cumulative mass exceeds it
       unsigned x = (unsigned)n * 0x9E3779B1u ^ (p.dec_draw_seed + (unsigned)t * 0x85EBCA77u);
@@ -926,19 +1045,7 @@ __device__ __forceinline__ void ws_run(const UicRnnFwdParams& p, Ctx& c, char* l
         w2[j][g] = bload<false>(r_w, (row * ld + bl) * 2u, so);
       }
     }
-    const __amdgpu_buffer_rsrc_t r_a_ih = rsrc_of(p.att_w_ih), r_a_hh = rsrc_of(p.att_w_hh);
-#pragma unroll
-    for (int jj = 0; jj < 8; ++jj) {
-      const int s = c.wave + 4 * jj;                // k-step of [h_lang_prev | h_att_prev]
-      const unsigned kk = (unsigned)((s & 15) * 32);
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const unsigned row = (unsigned)(g * HH + c.u0 + c.l15);
-        const u32x4 v = jj < 4 ? bload<false>(r_a_ih, (row * (unsigned)p.ld_att_ih + kk + bl) * 2u, 0)
-                               : bload<false>(r_a_hh, (row * (unsigned)HH + kk + bl) * 2u, 0);
-        ((u32x4*)lds)[(s * 4 + g) * 64 + c.lane] = v;
-      }
-    }
+    ws_load_w1(p, c, lds, 0, 8, c.wave);
   }
   // lang_lstm's bias for the unit of this lane (tile owners: wave w owns row tile w, wave 0 also tile 4)
   float pb[4][4];
@@ -1331,18 +1438,22 @@ __device__ __forceinline__ void ws_run(const UicRnnFwdParams& p, Ctx& c, char* l
       __syncthreads();                              // the scratch halves are free again (barrier flag, next step)
     }
     if (dbg && c.tid == 0) dbg[7] = __builtin_amdgcn_s_memrealtime();
-    if (!group_barrier(c)) return;
-    if (DEC) {
+    if (!DEC) {
+      if (!group_barrier(c)) return;
+    } else {
+      group_arrive(c);
       asm volatile("" : "+v"(c.lane), "+v"(c.l15), "+v"(c.lq), "+v"(c.tid));
-      dec_logits<SAFE>(p, c, t);
+      if (!dec_logits<SAFE>(p, c, t, lds)) return;
       if (dbg && c.tid == 0) dbg[8] = __builtin_amdgcn_s_memrealtime();
       if (!group_barrier(c)) return;
       asm volatile("" : "+v"(c.lane), "+v"(c.l15), "+v"(c.lq), "+v"(c.tid));
-      dec_sample<SAFE>(p, c, t);
+      dec_sample<SAFE>(p, c, t, lds);
       if (dbg && c.tid == 0) dbg[9] = __builtin_amdgcn_s_memrealtime();
-      if (!group_barrier(c)) return;
+      const bool tok_in_lds = p.dec_sample_max || p.dec_forced;      // greedy / forced: dec_sample left the group's tokens in LDS
+      if (tok_in_lds) __syncthreads();
+      else if (!group_barrier(c)) return;
       asm volatile("" : "+v"(c.lane), "+v"(c.l15), "+v"(c.lq), "+v"(c.tid));
-      if (t + 1 < p.t1) dec_xt_gemm(p, c, t + 1, xg, xg5);
+      if (t + 1 < p.t1) dec_xt_gemm(p, c, t + 1, xg, xg5, tok_in_lds ? (const int*)(c.smem + DEC_OFF_LIST) : nullptr);
       if (dbg && c.tid == 0) dbg[10] = __builtin_amdgcn_s_memrealtime();
     }
     if (dbg) dbg += 16;
@@ -1364,6 +1475,16 @@ __global__ __launch_bounds__(WS_NTH) void rnn_dec_persist_ws_kernel(const UicRnn
   if (mode == 0) return;
   if (mode == 2) ws_run<true, true>(p, c, smem);
   else ws_run<false, true>(p, c, smem);
+}
+
+// relu(embed) in bf16: what every decode step gathers its input rows from (dropout, where the pass has it, is applied to the
+// gathered values; with the reference's p = 0.5 that is exactly dropout(relu(embed)) rounded once, otherwise within one bf16 ulp)
+__global__ void dec_embed_relu_kernel(const float* __restrict__ w, bf16_t* __restrict__ out, size_t n4) {
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+    const float4 v = *(const float4*)(w + 4 * i);
+    *(uint2*)(out + 4 * i) = make_uint2(uic_pack_bf16x2(fmaxf(v.x, 0.f), fmaxf(v.y, 0.f)), uic_pack_bf16x2(fmaxf(v.z, 0.f), fmaxf(v.w, 0.f)));
+  }
 }
 
 // the reference stops decoding once every row has finished (AttModel.py:236-238): entries after that step stay zero
@@ -1407,7 +1528,7 @@ bool uic_rnn_persist_eligible(int dtype, int N, int H, int A, int R) {
 
 int uic_rnn_fwd_persist_launch(const UicRnnFwdParams& p0, hipStream_t s) {
   UIC_REQUIRE(p0.sync && p0.t1 > p0.t0 && p0.N > 0, "rnn_fwd_persist: bad arguments");
-  UIC_REQUIRE(!p0.dec || (p0.dtype == UIC_BF16 && p0.gfc && p0.dec_embed && p0.dec_xw && p0.dec_logit_w && p0.dec_logits && p0.dec_part &&
+  UIC_REQUIRE(!p0.dec || (p0.dtype == UIC_BF16 && p0.gfc && p0.dec_embed_relu && p0.dec_xw && p0.dec_logit_w && p0.dec_logits && p0.dec_part &&
                           p0.dec_tok && p0.dec_unf && p0.dec_seq && p0.dec_seq_logp && p0.hdrop_all && p0.dec_V1 >= 2 &&
                           p0.dec_V1 <= PW * WS_NW * DEC_NJ * 16),
               "rnn_fwd_persist: decode mode needs bf16, gfc, the embedding / logit operands and its exchange buffers (V1 <= %d)", PW * WS_NW * DEC_NJ * 16);
@@ -1451,5 +1572,12 @@ int uic_rnn_decode_finish_launch(const int64_t* seq, float* seq_logp, int N, int
   UIC_REQUIRE(seq && seq_logp && N > 0 && L > 0 && ld >= L, "rnn_decode_finish: bad arguments");
   hipLaunchKernelGGL(dec_finish_kernel, dim3(1), dim3(1024), 0, s, seq, seq_logp, N, L, ld);
   UIC_LAUNCH_CHECK("dec_finish_kernel");
+  return UIC_OK;
+}
+int uic_rnn_decode_embed_relu_launch(const float* embed_w, void* out_bf16, int V1, int E, hipStream_t s) {
+  UIC_REQUIRE(embed_w && out_bf16 && V1 > 0 && E % 4 == 0, "rnn_decode_embed_relu: bad arguments");
+  const size_t n4 = (size_t)V1 * E / 4;
+  hipLaunchKernelGGL(dec_embed_relu_kernel, dim3((unsigned)((n4 + 255) / 256 > 4096 ? 4096 : (n4 + 255) / 256)), dim3(256), 0, s, embed_w, (bf16_t*)out_bf16, n4);
+  UIC_LAUNCH_CHECK("dec_embed_relu_kernel");
   return UIC_OK;
 }

@@ -71,7 +71,7 @@ struct Layout {
   void* s_h_att[2]; void* s_h_lang[2]; float* s_c_att[2]; float* s_c_lang[2];
   void* s_xt; float* s_atth; float* s_alpha; void* s_ctx; void* s_hdrop; float* s_logits;
   int64_t* s_it; int* s_unf; int* s_nunf;
-  float* dec_part; int* dec_tok;              // persistent decode (rnn_persist.hip): per-workgroup logit partials, exchanged tokens
+  float* dec_part; int* dec_tok; void* dec_embed_relu;   // persistent decode (rnn_persist.hip): per-workgroup logit partials, exchanged tokens, relu(embed) in bf16
   // beam search bookkeeping (rows = (image, beam); sizes depend on N and T only)
   float* bm_cand_val; int* bm_cand_idx; int64_t* bm_seq[2]; float* bm_lp[2]; float* bm_sum; int* bm_parent;
   int* bm_done_count; float* bm_done_p; int64_t* bm_done_seq; float* bm_done_lp;
@@ -214,6 +214,7 @@ Layout make_layout(const uic_topdown_dims& d, void* ws) {
   L.s_nunf = (int*)b.take((T + 2) * UIC_NUNF_STRIPES * 4);
   L.dec_part = (float*)b.take(uic_rnn_decode_part_floats((int)N) * 4);
   L.dec_tok = (int*)b.take(N * 4);
+  L.dec_embed_relu = b.take(V1 * E * 2);
   L.bm_cand_val = (float*)b.take(N * UIC_BEAM_MAX * 4);
   L.bm_cand_idx = (int*)b.take(N * UIC_BEAM_MAX * 4);
   for (int i = 0; i < 2; ++i) {
@@ -731,6 +732,7 @@ struct Step {
   }
   int decode_persist(int Lsteps, int sample_max, const int64_t* forced, bool keep, int64_t* seq, float* seq_logp, hipStream_t s) {
     UIC_TRY(fwd_gfc(s, true));
+    UIC_TRY(uic_rnn_decode_embed_relu_launch(w->embed_w, L.dec_embed_relu, V1, E, s));
     UIC_TRY(uic_fill_launch(L.dec_tok, 0, (size_t)N * 4, s));          // <bos> = 0 (AttModel.py:214-215)
     UicRnnFwdParams p;
     memset(&p, 0, sizeof(p));
@@ -751,7 +753,7 @@ struct Step {
     p.force_safe = (d.recurrence & UIC_REC_SAFE) != 0; p.status = d.rnn_status;
     p.dbg = (d.recurrence & UIC_REC_STAMPS) ? L.rnn_dbg : nullptr; p.dbg_T = d.T;
     p.dec = 1;
-    p.dec_embed = w->embed_w; p.dec_xw = off(dv.att_w_ih, 2 * H, dt); p.dec_ld_xw = ldih;
+    p.dec_embed_relu = L.dec_embed_relu; p.dec_xw = off(dv.att_w_ih, 2 * H, dt); p.dec_ld_xw = ldih;
     p.dec_xt_drop = drop_p; p.dec_xt_all = keep ? L.xt_all : nullptr;
     p.dec_logit_w = dv.logit_w; p.dec_logit_b = w->logit_b; p.dec_V1 = V1; p.dec_V1p = V1p;
     p.dec_logits = keep ? L.logits : L.s_logits; p.dec_logits_step = keep ? (size_t)N * V1p : 0;

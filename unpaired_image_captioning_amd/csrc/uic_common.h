@@ -278,7 +278,7 @@ struct UicRnnFwdParams {
   // ---- decode mode (AttModel._sample, P/models/AttModel.py:198-253; bf16 only): every step also embeds the row's input
   // token, runs the logit layer and picks the next token inside the launch.  gx is then unused (gfc holds fc' W^T + b_ih + b_hh)
   int dec;                           // 0: teacher-forced recurrence; 1: decode
-  const float* dec_embed;            // [V1, E = H] f32 embedding table
+  const void* dec_embed_relu;        // [V1, E = H] relu(embedding table) in bf16 (uic_rnn_decode_embed_relu_launch)
   const void* dec_xw; int dec_ld_xw; // att_lstm.weight_ih columns of xt: [4H, ld], K = E contiguous
   float dec_xt_drop;                 // dropout on relu(embed) (train-mode sampling pass) with (seed, UIC_SITE_EMBED)
   void* dec_xt_all;                  // [T, N, E] the embedded inputs, kept for a backward pass, or null
@@ -297,6 +297,7 @@ size_t uic_rnn_decode_part_floats(int N);
 // after uic_rnn_fwd_persist_launch in decode mode: the reference's `if unfinished.sum() == 0: break` (AttModel.py:236-238) --
 // log-probs recorded at steps after every row had finished are zeroed (their tokens already are)
 int uic_rnn_decode_finish_launch(const int64_t* seq, float* seq_logp, int N, int L, int ld, hipStream_t s);
+int uic_rnn_decode_embed_relu_launch(const float* embed_w, void* out_bf16, int V1, int E, hipStream_t s);
 bool uic_rnn_persist_eligible(int dtype, int N, int H, int A, int R);
 int uic_rnn_fwd_persist_launch(const UicRnnFwdParams& p, hipStream_t s);
 

@@ -276,6 +276,32 @@ class Trainer(object):
         if getattr(self.i2t_model, 'engine', None) is not None:
             _lib.persistent_status()
 
+    def _scst_decode(self, model, eng, fc, att, am, S, overlap, cur):
+        """The sampling pass (train mode) and the greedy baseline (eval mode, P/misc/rewards.py:42-47) of the self-critical
+        step; overlap: the baseline on a second stream beside the sampling pass."""
+        if overlap:
+            if getattr(self, '_baseline_stream', None) is None:
+                self._baseline_stream = torch.cuda.Stream()
+            # the derived weight copies are rebuilt once, here, on the current stream (hold_weights: later calls reuse them);
+            # the baseline stream then orders itself behind that and behind the batch's H2D copies
+            eng.refresh({k: v.detach() for k, v in model.param_dict().items()}, eng.dims(att.shape[0], att.shape[1], model.seq_length + 1))
+            self._baseline_stream.wait_stream(cur)
+            model.eval()
+            with torch.cuda.stream(self._baseline_stream), torch.no_grad():
+                greedy_res, _ = model(fc, None, att, am, opt={'sample_max': 1}, mode='sample')
+            model.train()
+            gen_result, sample_logprobs = model(fc, None, att, am, opt={'sample_max': 0, 'captions_per_image': S}, mode='sample')
+            cur.wait_stream(self._baseline_stream)
+            greedy_res.record_stream(cur)
+        else:
+            model.train()
+            gen_result, sample_logprobs = model(fc, None, att, am, opt={'sample_max': 0, 'captions_per_image': S}, mode='sample')
+            model.eval()
+            with torch.no_grad():                                       # rewards.py:42-47: greedy baseline, eval mode
+                greedy_res, _ = model(fc, None, att, am, opt={'sample_max': 1}, mode='sample')
+            model.train()
+        return gen_result, sample_logprobs, greedy_res
+
     def train_self_critical(self, data, reward_fn=None, next_data=None):
         """The self-critical branch of Trainer.train (P/trainer.py:166-171).  reward_fn None: the reference's reward,
         CIDEr-D(sampled) - CIDEr-D(greedy) against data['gts'] with the cached document frequencies of
@@ -300,28 +326,20 @@ class Trainer(object):
             # BatchNorm in att_embed: there the train-mode pass updates the running statistics the eval-mode pass reads (the
             # reference runs them in this order), so the two stay serial.
             cur = torch.cuda.current_stream()
-            overlap = hasattr(eng, 'hold_weights') and int(getattr(model, 'use_bn', 0) or 0) == 0 and not getattr(self, 'serial_baseline', False)
-            if overlap:
-                if getattr(self, '_baseline_stream', None) is None:
-                    self._baseline_stream = torch.cuda.Stream()
-                # the derived weight copies are rebuilt once, here, on the current stream (hold_weights: later calls reuse them);
-                # the baseline stream then orders itself behind that and behind the batch's H2D copies
-                eng.refresh({k: v.detach() for k, v in model.param_dict().items()}, eng.dims(att.shape[0], att.shape[1], model.seq_length + 1))
-                self._baseline_stream.wait_stream(cur)
-                model.eval()
-                with torch.cuda.stream(self._baseline_stream), torch.no_grad():
-                    greedy_res, _ = model(fc, None, att, am, opt={'sample_max': 1}, mode='sample')
-                model.train()
-                gen_result, sample_logprobs = model(fc, None, att, am, opt={'sample_max': 0, 'captions_per_image': S}, mode='sample')
-                cur.wait_stream(self._baseline_stream)
-                greedy_res.record_stream(cur)
-            else:
-                model.train()
-                gen_result, sample_logprobs = model(fc, None, att, am, opt={'sample_max': 0, 'captions_per_image': S}, mode='sample')
-                model.eval()
-                with torch.no_grad():                                       # rewards.py:42-47: greedy baseline, eval mode
-                    greedy_res, _ = model(fc, None, att, am, opt={'sample_max': 1}, mode='sample')
-                model.train()
+            # self.persistent_decode: each pass as ONE persistent launch (rnn_persist.hip's decode mode).  A persistent launch
+            # holds every CU, so the two passes then run one after the other -- measured slower for this step than the two
+            # launch chains side by side (profiles/), hence off by default here; a lone decode pass (eval) takes it by itself.
+            persistent = bool(getattr(self, 'persistent_decode', False))
+            overlap = hasattr(eng, 'hold_weights') and int(getattr(model, 'use_bn', 0) or 0) == 0 and \
+                not getattr(self, 'serial_baseline', False) and not persistent
+            rec0 = getattr(eng, 'recurrence', 0)
+            if eng is not None and not persistent:
+                eng.recurrence = rec0 | _lib.REC_FWD_CHAIN
+            try:
+                gen_result, sample_logprobs, greedy_res = self._scst_decode(model, eng, fc, att, am, S, overlap, cur)
+            finally:
+                if eng is not None:
+                    eng.recurrence = rec0
             if reward_fn is None:
                 scorer = rewards.init_scorer(getattr(self.opt, 'cached_tokens', 'corpus'))
                 reward_t = rewards.self_critical_reward_device(scorer, gen_result, greedy_res, data['gts'],
