@@ -27,7 +27,10 @@ tail -5 $O/bench_summary.txt
 cat $O/attn_fwd_pmc_bf16.json
 # where the fused step's time goes without a profiler attached (timing marks recorded by the step itself) and the host time of its C call
 timeout 200 python3 $R/tools/host_time.py > $O/step_marks.txt 2>&1
-tail -11 $O/step_marks.txt
+tail -18 $O/step_marks.txt
+# the same with UIC_REC_EARLY_GRADS: when each gradient group is final, bytes final in the step's last 0.1 ms
+timeout 200 python3 $R/tools/host_time.py --early > $O/step_marks_early_grads.txt 2>&1
+tail -7 $O/step_marks_early_grads.txt
 # persistent recurrence kernel: phase stamps, parity against the per-step launch chain, forward time in modes 0 / 1 / 2
 timeout 200 python3 $R/tools/rnn_persist_probe.py --dbg > $O/rnn_persist_probe.txt 2>&1
 grep -E "phase|step  |forward" $O/rnn_persist_probe.txt
@@ -35,6 +38,9 @@ timeout 200 python3 $R/tools/gemm_headroom.py > $O/gemm_headroom.txt 2>&1
 # persistent BPTT kernel (opt-in): parity with the launch chain, phase stamps, backward call and fused step in both modes
 timeout 300 python3 $R/tools/rnn_bwd_probe.py --dbg > $O/rnn_bwd_probe.txt 2>&1
 grep -E "step |fused|backward call" $O/rnn_bwd_probe.txt
+# persistent decode launch against the per-step launch chain: agreement, pass times, phase stamps
+timeout 400 python3 $R/tools/decode_probe.py --dbg 2>/dev/null > $O/decode_probe.txt
+cat $O/decode_probe.txt
 # attention-step kernel variants from a C++ host (shipped structure, loads only, online softmax, wave counts)
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 $R/tools/micro/attn_variants.hip -o /tmp/attn_variants 2>/dev/null && /tmp/attn_variants > $O/attn_variants.txt 2>&1
 # HBM traffic of the persistent recurrence kernel (separate PMC passes, same corrections as for the attention kernel)
