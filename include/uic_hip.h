@@ -34,8 +34,11 @@ int uic_version(void);
  * weights stay in LDS and registers for the whole launch; it holds every CU while it runs), in uic_topdown_forward and in
  * uic_topdown_xe_train_step, whose logit layer then follows the recurrence chunk by chunk, last chunk first, beside the BPTT
  * loop.  How a call launches the loop is part of its dims (uic_topdown_dims.recurrence, no library-wide state):
- *   UIC_REC_FWD_CHAIN    the forward recurrence as per-step launches (two processes sharing one GPU must both set it: the
- *                        persistent kernel's workgroups have to be resident together)
+ *   UIC_REC_FWD_CHAIN    the forward recurrence (and the decode loop of uic_topdown_sample / _sample_train) as per-step
+ *                        launches.  Two PROCESSES sharing one GPU must both set it: a persistent kernel's workgroups have to
+ *                        be resident together.  Inside one process the library makes every persistent launch wait for the
+ *                        previous one on its device, whatever streams they are on, so two passes meant to run side by side
+ *                        (the self-critical step's sampling pass and greedy baseline) want the chains
  *   UIC_REC_BWD_PERSIST  the BPTT loop as one persistent launch per chunk of decode steps (bf16) instead of six launches per
  *                        step.  Off by default: alone it runs a step in 57 us instead of 82, but beside the side stream's
  *                        GEMMs of uic_topdown_xe_train_step both slow down (step 3.9 vs 3.6 ms)

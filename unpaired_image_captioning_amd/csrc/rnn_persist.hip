@@ -26,6 +26,7 @@
 // the wave that owns the 16-row tile.  bf16 operands -> v_mfma_f32_16x16x32_bf16, f32 -> v_mfma_f32_16x16x4_f32.
 #include "rnn_persist_common.h"
 #include <stdlib.h>
+#include <mutex>
 #include <type_traits>
 
 namespace {
@@ -1510,6 +1511,34 @@ __global__ void dec_finish_kernel(const int64_t* __restrict__ seq, float* __rest
 
 }  // namespace
 
+// Two persistent launches must not be on the chip at once (each holds every CU while it waits, bounded, for its own
+// workgroups to become resident): inside one process every persistent launch therefore waits for the previous one on its
+// device, whatever stream that ran on.  (Across processes the caller has to choose: UIC_REC_FWD_CHAIN.)
+namespace {
+struct PersistGate { hipEvent_t ev = nullptr; bool recorded = false; };
+PersistGate g_gate[16];
+std::mutex g_gate_mutex;
+}
+int uic_persist_gate_enter(hipStream_t s) {
+  int dev = 0;
+  UIC_TRY(uic_check_hip(hipGetDevice(&dev), "hipGetDevice"));
+  UIC_REQUIRE(dev >= 0 && dev < 16, "device index %d out of range", dev);
+  std::lock_guard<std::mutex> lock(g_gate_mutex);
+  PersistGate& g = g_gate[dev];
+  if (!g.ev) UIC_TRY(uic_check_hip(hipEventCreateWithFlags(&g.ev, hipEventDisableTiming), "hipEventCreate"));
+  if (g.recorded) UIC_TRY(uic_check_hip(hipStreamWaitEvent(s, g.ev, 0), "hipStreamWaitEvent(persistent gate)"));
+  return UIC_OK;
+}
+int uic_persist_gate_leave(hipStream_t s) {
+  int dev = 0;
+  UIC_TRY(uic_check_hip(hipGetDevice(&dev), "hipGetDevice"));
+  std::lock_guard<std::mutex> lock(g_gate_mutex);
+  PersistGate& g = g_gate[dev];
+  UIC_TRY(uic_check_hip(hipEventRecord(g.ev, s), "hipEventRecord(persistent gate)"));
+  g.recorded = true;
+  return UIC_OK;
+}
+
 constexpr int MAX_SLABS = 8;       // launches of <= 640 caption rows each
 size_t uic_rnn_persist_sync_bytes() { return (size_t)MAX_SLABS * SY_WORDS * 4; }
 
@@ -1540,6 +1569,7 @@ int uic_rnn_fwd_persist_launch(const UicRnnFwdParams& p0, hipStream_t s) {
     configured = true;
   }
   const int G = 8, cap = G * 16 * MT_MAX;     // caption rows one launch covers
+  UIC_TRY(uic_persist_gate_enter(s));
   for (int r0 = 0; r0 < p0.N; r0 += cap) {
     UicRnnFwdParams p = p0;
     p.row0 = r0;
@@ -1561,7 +1591,7 @@ int uic_rnn_fwd_persist_launch(const UicRnnFwdParams& p0, hipStream_t s) {
     else hipLaunchKernelGGL(rnn_fwd_persist_kernel<float>, dim3(G * PW), dim3(NTH), LDS_BYTES, s, p);
     UIC_LAUNCH_CHECK("rnn_fwd_persist_kernel");
   }
-  return UIC_OK;
+  return uic_persist_gate_leave(s);
 }
 
 bool uic_rnn_decode_persist_eligible(int dtype, int N, int H, int A, int R, int E, int V1) {

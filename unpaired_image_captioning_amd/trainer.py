@@ -286,11 +286,21 @@ class Trainer(object):
             # the baseline stream then orders itself behind that and behind the batch's H2D copies
             eng.refresh({k: v.detach() for k, v in model.param_dict().items()}, eng.dims(att.shape[0], att.shape[1], model.seq_length + 1))
             self._baseline_stream.wait_stream(cur)
+            # (every pass draws its seed from the model's counter: the sampling pass gets the seed it has in the serial order,
+            # so that the two orders train identically, bit for bit)
+            c0 = getattr(model, '_seed_counter', None)
+            if c0 is not None:
+                model.next_seed()
             model.eval()
             with torch.cuda.stream(self._baseline_stream), torch.no_grad():
                 greedy_res, _ = model(fc, None, att, am, opt={'sample_max': 1}, mode='sample')
             model.train()
+            c2 = getattr(model, '_seed_counter', None)
+            if c0 is not None:
+                model._seed_counter = c0
             gen_result, sample_logprobs = model(fc, None, att, am, opt={'sample_max': 0, 'captions_per_image': S}, mode='sample')
+            if c0 is not None:
+                model._seed_counter = c2
             cur.wait_stream(self._baseline_stream)
             greedy_res.record_stream(cur)
         else:
