@@ -445,19 +445,6 @@ struct UicH2attCellParams {
 };
 bool uic_h2att_cell_bwd_eligible(const UicH2attCellParams& p);
 int uic_h2att_cell_bwd_launch(const UicH2attCellParams& p, hipStream_t s);
-// d[h_lang_prev | h_att_prev] = dG1_t [N, 4H] W1recT[2H, 4H]^T (the `d x1` GEMM of BPTT step t) and, for the h_lang half, the
-// lang_lstm cell backward of step t - 1 in the same launch (bptt_fused.hip; bf16, H = 512): d h = dropout-scaled dh0 + the slabs
-// + the GEMM.  The h_att half is stored to dx1_hatt (f32 [N, H], leading dimension ld_hatt).
-struct UicDx1CellParams {
-  int dtype, N, H;
-  const void* dg1; const void* w1recT;
-  float* dx1_hatt; int ld_hatt;
-  const float* dh0; int lddh0; float drop_p; unsigned seed; unsigned site;
-  const float* slabA; int ldA, nA; size_t strideA;
-  float* dc; const void* gates; const float* c_prev; const float* c; void* dgates;
-};
-bool uic_dx1_cell_bwd_eligible(const UicDx1CellParams& p);
-int uic_dx1_cell_bwd_launch(const UicDx1CellParams& p, hipStream_t s);
 int uic_maxout_lstm_bwd_launch(const UicLstmBwdParams& p, hipStream_t s);   // gates/dgates are [M,5H]; dh = (dh0 + dh1) * dropout
 int uic_sample_fixup_launch(int N, int L, int ld, const int* n_unfinished, int64_t* seq, float* seq_logp, hipStream_t s);
 
