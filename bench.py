@@ -259,6 +259,9 @@ def main():
                     help="region feature width (secondary measurement): 2053 = 2048 + 5 box features, the reference's default "
                          "use_box=1; the metric is quoted at 2048")
     ap.add_argument("--use-bn", type=int, default=0, help="opt.use_bn of the captioner (secondary measurement; the metric is quoted at 0)")
+    ap.add_argument("--early-grads", action="store_true",
+                    help="UIC_REC_EARLY_GRADS (opt.early_grads): the order of the gradient work that has 62 %% of the gradient bytes final "
+                         "0.18 ms before the step ends, for a step that is 4 %% longer on its own -- for N > 1 experiments; off for the headline")
     ap.add_argument("--rows-per-gpu-probe", type=int, default=0,
                     help="also time the step at this many caption rows, e.g. 80 = the per-rank size of a strong-scaling run of the 640-row "
                          "batch over 8 GPUs (secondary key `strong_scaling_probe`, never `value`; off by default so that the default "
@@ -308,12 +311,14 @@ def main():
     c = CFG
     torch.manual_seed(1234)                                    # identical initial weights on every rank
     Datt = args.att_feat_size or c["D"]
-    tr = Trainer(make_opt(args.dtype, 1234 + rank, args.use_bn, Datt))
+    opt_main = make_opt(args.dtype, 1234 + rank, args.use_bn, Datt)
+    opt_main.early_grads = bool(args.early_grads)
+    tr = Trainer(opt_main)
     tr.build_optimizer()
     if share:
         # two processes on ONE GPU must not both run the persistent recurrence kernel (each wants every CU for itself and waits,
         # bounded, for the other: include/uic_hip.h): the functional N > 1 test on a 1-GPU box uses the per-step launch chain
-        tr.i2t_model.engine.recurrence = L.REC_FWD_CHAIN
+        tr.i2t_model.engine.recurrence |= L.REC_FWD_CHAIN
     batch = synthetic_batch(c["n_img"], c["S"], c["R"], Datt, c["V"], c["L"], seed=1234 + rank)
     batch["fc_feats"] = batch["fc_feats"][:, :c["D"]].contiguous()
     N = c["n_img"] * c["S"]
@@ -414,7 +419,7 @@ def main():
             "config": {"workload": "BASELINE configs[1]: TopDown attention LSTM, 128 images x 5 captions = 640 caption "
                                    "rows per GPU, R=36, D=2048, H=E=A=512, V+1=9488, 17 decode steps, dropout 0.5, "
                                    "XE loss + BPTT + Adam", "rows_per_gpu": N, "parallelism": "dp%d" % world, "use_bn": args.use_bn, "att_feat_size": Datt,
-                       "features": args.features},
+                       "features": args.features, "early_grads": bool(args.early_grads)},
             "final_loss": round(loss_val, 4),
             "rccl_ranks": dist.get_world_size() if (world > 1 and dist.get_backend() == "nccl") else (1 if world == 1 else 0),
             "roofline_mfma": gemm_roofline(dtype_id, args.dtype),

@@ -26,16 +26,16 @@ def _free_port():
     return p
 
 
-def _opt(cfg, use_bn=0):
-    return argparse.Namespace(vocab_size=cfg["V"], input_encoding_size=cfg["E"], rnn_size=cfg["H"], num_layers=1,
+def _opt(cfg, use_bn=0, early_grads=False):
+    return argparse.Namespace(early_grads=early_grads, vocab_size=cfg["V"], input_encoding_size=cfg["E"], rnn_size=cfg["H"], num_layers=1,
                               drop_prob_lm=0.0, seq_length=cfg["L"], fc_feat_size=cfg["D"], att_feat_size=cfg["D"],
                               att_hid_size=cfg["A"], use_bn=use_bn, logit_layers=1, caption_model="topdown",
                               compute_dtype="f32", seed=5, i2t_learning_rate=5e-3, i2t_train_flag=1)
 
 
-def _train(cfg, W, data, steps, exchange=None):
+def _train(cfg, W, data, steps, exchange=None, early_grads=False):
     from unpaired_image_captioning_amd.trainer import Trainer
-    tr = Trainer(_opt(cfg), exchange=exchange)
+    tr = Trainer(_opt(cfg, early_grads=early_grads), exchange=exchange)
     tr.i2t_model.load_state_dict(W)
     tr.build_optimizer()
     losses = [tr.train(data) for _ in range(steps)]
@@ -43,7 +43,7 @@ def _train(cfg, W, data, steps, exchange=None):
     return tr, losses
 
 
-def _worker(rank, world, port, out_dir, backend="gloo", uic_comm=False):
+def _worker(rank, world, port, out_dir, backend="gloo", uic_comm=False, early_grads=False):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -59,7 +59,13 @@ def _worker(rank, world, port, out_dir, backend="gloo", uic_comm=False):
     lo, hi = GradientExchange().shard_images(cfg["n_img"])
     rows = slice(lo * cfg["S"], hi * cfg["S"])
     data = {k: I[k][rows].numpy() for k in ("fc_feats", "att_feats", "labels", "masks", "att_masks")}
-    tr, losses = _train(cfg, W, data, STEPS, exchange)
+    tr, losses = _train(cfg, W, data, STEPS, exchange, early_grads)
+    if early_grads:      # group 1 of the overlapped exchange then also holds the embedding and att_lstm.weight_ih
+        from unpaired_image_captioning_amd import _lib
+        assert tr.i2t_model.engine.recurrence & _lib.REC_EARLY_GRADS
+        names = list(tr.arena.offsets)
+        g1 = [k for k in names if tr.arena_splits[0] <= tr.arena.offsets[k] < tr.arena_splits[1]]
+        assert "embed.0.weight" in g1 and "core.att_lstm.weight_ih" in g1, g1
     assert tr.exchange.world_size == world and len(tr.arena_splits) == 3 and 0 < tr.arena_splits[0] < tr.arena_splits[1] < tr.arena_splits[2] < tr.arena.numel
     if rank == 0:
         torch.save({"sd": {k: v.cpu() for k, v in tr.i2t_model.state_dict().items()}, "losses": losses},
@@ -92,6 +98,14 @@ def _check_against_single_process(tmp_path):
 def test_two_ranks_on_one_gpu_match_single_process(tmp_path):
     world = 2
     mp.spawn(_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    _check_against_single_process(tmp_path)
+
+
+def test_two_ranks_with_the_early_gradient_order_match_single_process(tmp_path):
+    """opt.early_grads (UIC_REC_EARLY_GRADS): the embedding gradient and att_lstm.weight_ih travel with gradient group 1 of the
+    overlapped exchange -- their all-reduce starts at ev_lstm, so they must really be final there."""
+    world = 2
+    mp.spawn(_worker, args=(world, _free_port(), str(tmp_path), "gloo", False, True), nprocs=world, join=True)
     _check_against_single_process(tmp_path)
 
 
