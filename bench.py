@@ -92,7 +92,19 @@ def attention_roofline(dtype_id, dtype_name, iters=64, pool=8):
         torch.cuda.synchronize()
         d = sorted(a.elapsed_time(b) for a, b in ev)
         return sum(d[iters // 8: iters - iters // 8]) / (iters - 2 * (iters // 8)) / 1e3      # trimmed mean, seconds
+    def back_to_back(rotate, n=256):
+        """Duration per launch of n launches between ONE event pair (rotating buffers): consecutive launches overlap each other's
+        ramp-up and tail, so this is the kernel's throughput, not its latency -- reported beside `frac`, never as it."""
+        a, b2 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda._sleep(int(5e6))
+        a.record()
+        for i in range(n):
+            launch(i % pool if rotate else 0)
+        b2.record()
+        torch.cuda.synchronize()
+        return a.elapsed_time(b2) / n / 1e3
     cold_s, res_s = timed(True), timed(False)
+    b2b_s = back_to_back(True)
     es = p_atts[0].element_size()
     bytes_per_launch = N * (R * A + R * H + 2 * H + R) * es
     achieved = bytes_per_launch / cold_s / 1e9
@@ -104,7 +116,9 @@ def attention_roofline(dtype_id, dtype_name, iters=64, pool=8):
             "traffic_source": "profiles/attn_fwd_pmc_%s.json (committed rocprofv3 PMC passes of this kernel, NOT measured in this run)" % dtype_name if traffic else None,
             "bytes_per_launch": bytes_per_launch, "us_per_launch": round(cold_s * 1e6, 2),
             "us_per_launch_cache_resident": round(res_s * 1e6, 2),
-            "frac_cache_resident": round(bytes_per_launch / res_s / 1e9 / HBM_PEAK_GBS, 4)}
+            "frac_cache_resident": round(bytes_per_launch / res_s / 1e9 / HBM_PEAK_GBS, 4),
+            "us_per_launch_back_to_back": round(b2b_s * 1e6, 2),
+            "frac_back_to_back": round(bytes_per_launch / b2b_s / 1e9 / HBM_PEAK_GBS, 4)}
 
 
 MFMA_PEAK_TFLOPS = {"bf16": 2500.0, "f32": 157.3}     # dense peaks (MI355X_MICROARCH.md)
