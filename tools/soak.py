@@ -11,6 +11,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 ap = argparse.ArgumentParser()
 ap.add_argument("--minutes", type=float, default=3.0)
+ap.add_argument("--safe", action="store_true", help="the persistent kernels' placement-independent SAFE protocol (UIC_REC_SAFE)")
 args = ap.parse_args()
 
 import numpy as np
@@ -23,6 +24,8 @@ from unpaired_image_captioning_amd.trainer import Trainer
 c = CFG
 tr = Trainer(make_opt("bf16", 1234))
 tr.build_optimizer()
+if args.safe:
+    tr.i2t_model.engine.recurrence |= L.REC_SAFE
 batch = synthetic_batch(c["n_img"], c["S"], c["R"], c["D"], c["V"], c["L"], seed=7)
 dev = {k: v.cuda() for k, v in batch.items()}
 data = {k: v.cpu().numpy() for k, v in batch.items()}

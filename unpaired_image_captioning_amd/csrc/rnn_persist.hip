@@ -1423,7 +1423,9 @@ __device__ __forceinline__ void ws_run(const UicRnnFwdParams& p, Ctx& c, char* l
               if (p.hdrop_all) {
                 float hd = h;
                 if (p.drop_p > 0.f) hd *= uic_drop_scale(p.seed, UIC_SITE_OUT0 + (unsigned)t, o, p.drop_p, 1.f / (1.f - p.drop_p));
-                ((T*)p.hdrop_all)[(size_t)t * NH + o] = (bf16_t)hd;
+                // (decode mode: the logit phase of every workgroup of the group reads these rows -- exchanged data)
+                if (DEC) st_x<SAFE>((T*)p.hdrop_all + (size_t)t * NH + o, hd);
+                else ((T*)p.hdrop_all)[(size_t)t * NH + o] = (bf16_t)hd;
               }
               if (p.gates2) {
                 T* G = (T*)p.gates2 + (size_t)t * N * 4 * HH + 4u * nn + u;
