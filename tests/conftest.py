@@ -40,3 +40,37 @@ def load_golden(name):
 def golden_loader():
     return load_golden
 
+
+def poison_workspaces(eng):
+    """Every workspace the engine hands out from now on is first filled with 0xFF bytes (NaN in f32 and bf16, -1 in the integer
+    buffers), on the stream that is about to use it.  A pooled or re-allocated buffer otherwise still holds the values of the
+    previous, often identical, run -- which would hide a kernel that reads something it (or a neighbour) should have written
+    first, or data that never became visible to the reader (the SAFE exchange protocol's write-through stores)."""
+    orig = eng.checkout
+
+    def checkout(d, device):
+        ws = orig(d, device)
+        ws.buf.fill_(255)
+        return ws
+
+    eng.checkout = checkout
+    return eng
+
+
+@pytest.fixture(autouse=True)
+def _poisoned_engine_workspaces(request, monkeypatch):
+    """GPU tests: every workspace any TopDownEngine hands out is poisoned first (see poison_workspaces) -- results must never
+    depend on what a pooled or recycled buffer still held."""
+    if request.node.get_closest_marker("gpu") is None:
+        yield
+        return
+    from unpaired_image_captioning_amd.topdown_engine import TopDownEngine
+    orig = TopDownEngine.checkout
+
+    def checkout(self, d, device):
+        ws = orig(self, d, device)
+        ws.buf.fill_(255)
+        return ws
+
+    monkeypatch.setattr(TopDownEngine, "checkout", checkout)
+    yield

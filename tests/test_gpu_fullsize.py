@@ -8,6 +8,8 @@ import numpy as np
 import pytest
 import torch
 
+from conftest import poison_workspaces
+
 from oracle import topdown as O
 from test_gpu_topdown import build_model
 
@@ -59,6 +61,7 @@ def test_configs1_full_size_vs_oracle(case, dtype, mode):
     model = build_model(CFG, W, dtype)
     model.train()                                    # drop_prob_lm = 0: deterministic
     model.engine.recurrence = REC_MODES[mode]
+    poison_workspaces(model.engine)                  # no mode may live on what an earlier, identical run left in memory
     before = Lb.persistent_status()
     try:
         logp = model(batch["fc_feats"], None, batch["att_feats"], batch["labels"], batch["att_masks"])

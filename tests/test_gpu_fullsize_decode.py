@@ -11,6 +11,7 @@ import numpy as np
 import pytest
 import torch
 
+from conftest import poison_workspaces
 from oracle import topdown as O
 from test_gpu_topdown import build_model
 
@@ -213,7 +214,7 @@ def test_persistent_decode_launch_against_the_launch_chain(case, n_rows):
     fc, att, am = b["fc_feats"][rows].cuda(), b["att_feats"][rows].cuda(), b["att_masks"][rows].cuda()
     for W, sample_max, training in ((Wg, 1, False), (Ws, 0, False), (Ws, 0, True)):
         model = build_model(CFG, W, "bf16", drop=0.5)
-        eng = model.engine
+        eng = poison_workspaces(model.engine)        # (stale values of the previous, identical pass must not help anybody)
         pd = {k: v.detach() for k, v in model.param_dict().items()}
         keep = training
 
@@ -266,8 +267,8 @@ def test_self_critical_step_overlapped_baseline_equals_serial_when_both_passes_s
     Trainer.train_self_critical have the SAME workspace key and run on two streams -- the pool must not hand the baseline's
     workspace to the sampling pass while the baseline still runs.  Three steps with the baseline beside the sampling pass
     (default), with the two passes one after the other (serial_baseline) and -- bf16 -- with each pass as one persistent decode
-    launch: identical losses, bit for bit, and weights to the last bits in the first two (same kernels, same seeds; f32
-    everywhere the chain)."""
+    launch: the first step's loss bit for bit, later losses and the weights to the last bits in the first two (same kernels, same
+    seeds; the embedding gradient's atomics sum in arrival order; f32 everywhere the chain)."""
     from unpaired_image_captioning_amd.trainer import Trainer
     from test_gpu_topdown import make_opt
     _, Ws, b = case
@@ -295,7 +296,8 @@ def test_self_critical_step_overlapped_baseline_equals_serial_when_both_passes_s
         res[mode] = (losses, {k: v.detach().cpu().clone() for k, v in tr.i2t_model.state_dict().items()})
     l0, w0 = res["serial"]
     l1, w1 = res["overlap"]
-    assert l1 == l0, (l1, l0)                          # three steps, bit for bit
+    assert l1[0] == l0[0], (l1, l0)                    # the first step bit for bit; later ones see weights that differ in the last bits
+    assert np.allclose(l1, l0, rtol=0, atol=2e-4), (l1, l0)
     for k in w0:                                       # (the embedding gradient's atomics sum in arrival order: last-bit differences)
         assert (w1[k].double() - w0[k].double()).abs().max().item() <= 1e-6, k
     if "persistent" in res:      # another summation order in the decode launch: the sampled captions may differ at rounding boundaries

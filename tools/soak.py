@@ -12,6 +12,7 @@ sys.path.insert(0, ROOT)
 ap = argparse.ArgumentParser()
 ap.add_argument("--minutes", type=float, default=3.0)
 ap.add_argument("--safe", action="store_true", help="the persistent kernels' placement-independent SAFE protocol (UIC_REC_SAFE)")
+ap.add_argument("--recurrence", type=int, default=0, help="more UIC_REC_* bits for the engine (2: persistent BPTT, 16: early gradient order)")
 args = ap.parse_args()
 
 import numpy as np
@@ -26,6 +27,7 @@ tr = Trainer(make_opt("bf16", 1234))
 tr.build_optimizer()
 if args.safe:
     tr.i2t_model.engine.recurrence |= L.REC_SAFE
+tr.i2t_model.engine.recurrence |= args.recurrence
 batch = synthetic_batch(c["n_img"], c["S"], c["R"], c["D"], c["V"], c["L"], seed=7)
 dev = {k: v.cuda() for k, v in batch.items()}
 data = {k: v.cpu().numpy() for k, v in batch.items()}
@@ -57,6 +59,6 @@ while time.time() < t_end:
     it += 1
 torch.cuda.synchronize()
 st1 = L.persistent_status()
-print("soak %.1f min: %d XE steps, %d decode passes, %d self-critical steps; persistent launches %d (XCD-local) + %d (SAFE), time-outs %d; last XE loss %.4f"
-      % (args.minutes, n_xe, n_dec, n_sc, st1[1] - st0[1], st1[2] - st0[2], st1[0], tr.last_loss if tr.last_loss is not None else float("nan")))
+print("soak (recurrence flags %d) %.1f min: %d XE steps, %d decode passes, %d self-critical steps; persistent launches %d (XCD-local) + %d (SAFE), time-outs %d; last XE loss %.4f"
+      % (tr.i2t_model.engine.recurrence, args.minutes, n_xe, n_dec, n_sc, st1[1] - st0[1], st1[2] - st0[2], st1[0], tr.last_loss if tr.last_loss is not None else float("nan")))
 assert st1[0] == 0
