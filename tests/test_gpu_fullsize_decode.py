@@ -304,3 +304,43 @@ def test_self_critical_step_overlapped_baseline_equals_serial_when_both_passes_s
     if "persistent" in res:      # another summation order in the decode launch: the sampled captions may differ at rounding boundaries
         lp, wp = res["persistent"]
         assert all(np.isfinite(lp)) and abs(lp[0] - l0[0]) < 0.5
+
+
+@pytest.mark.parametrize("regions,masked", [(7, True), (36, False), (1, True)])
+def test_persistent_decode_launch_other_region_counts(case, regions, masked):
+    """The same comparison with 7 and 1 regions per image (att_masks ragged inside them) and with 36 unmasked ones: the chain's
+    multinomial tokens replayed through the persistent launch, and greedy decoding both ways."""
+    from unpaired_image_captioning_amd import _lib as Lb
+    Wg, Ws, b = case
+    n = 160
+    fc, att = b["fc_feats"][:n].cuda(), b["att_feats"][:n, :regions].contiguous().cuda()
+    am = b["att_masks"][:n, :regions].contiguous().clone()
+    am[:, 0] = 1.0                                    # (every image keeps at least one region)
+    am = am.cuda() if masked else None
+    for W, sample_max in ((Wg, 1), (Ws, 0)):
+        model = build_model(CFG, W, "bf16", drop=0.5)
+        eng = model.engine
+        pd = {k: v.detach() for k, v in model.param_dict().items()}
+
+        def run(flags, forced=None):
+            eng.recurrence = flags
+            try:
+                out = eng.sample(pd, fc, att, am, L, sample_max=sample_max, seed=99, forced=forced, training=not sample_max)
+            finally:
+                eng.recurrence = 0
+            return out[0].cpu(), out[1].cpu()
+
+        before = Lb.persistent_status()
+        seq_c, lp_c = run(Lb.REC_FWD_CHAIN)
+        seq_p, lp_p = run(0)
+        after = Lb.persistent_status()
+        assert after[0] == 0 and after[1] - before[1] == 1
+        live = alive_mask(seq_c)
+        if sample_max:
+            both = (seq_c == seq_p).cumprod(1).bool() & live
+            assert (seq_c == seq_p).all(1).float().mean().item() > 0.85
+            assert (lp_c - lp_p)[both].abs().max().item() < LOGP_TOL["bf16"]
+        else:
+            seq_f, lp_f = run(0, forced=seq_c.cuda())
+            assert torch.equal(seq_f, seq_c)
+            assert (lp_f - lp_c)[live].abs().max().item() < LOGP_TOL["bf16"]
