@@ -344,3 +344,29 @@ def test_persistent_decode_launch_other_region_counts(case, regions, masked):
             seq_f, lp_f = run(0, forced=seq_c.cuda())
             assert torch.equal(seq_f, seq_c)
             assert (lp_f - lp_c)[live].abs().max().item() < LOGP_TOL["bf16"]
+
+
+def test_persistent_launches_on_two_streams_wait_for_each_other(case):
+    """Two persistent decode passes enqueued on two streams at the same time (each launch holds every CU while it waits for
+    its own workgroups): the library orders them (uic_persist_gate), so neither times out and both give what they give alone."""
+    from unpaired_image_captioning_amd import _lib as Lb
+    Wg, Ws, b = case
+    n = 640
+    fc, att, am = b["fc_feats"][:n].cuda(), b["att_feats"][:n].cuda(), b["att_masks"][:n].cuda()
+    models = [build_model(CFG, Wg, "bf16"), build_model(CFG, Ws, "bf16")]
+    pds = [{k: v.detach() for k, v in m.param_dict().items()} for m in models]
+    alone = [m.engine.sample(pd, fc, att, am, L, sample_max=1, seed=5) for m, pd in zip(models, pds)]
+    torch.cuda.synchronize()
+    before = Lb.persistent_status()
+    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+    outs = [None, None]
+    for rep in range(4):
+        for i in (0, 1):
+            streams[i].wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(streams[i]):
+                outs[i] = models[i].engine.sample(pds[i], fc, att, am, L, sample_max=1, seed=5)
+    torch.cuda.synchronize()
+    after = Lb.persistent_status()
+    assert after[0] == 0 and after[1] - before[1] == 8
+    for i in (0, 1):
+        assert torch.equal(outs[i][0], alone[i][0]) and torch.equal(outs[i][1], alone[i][1])
