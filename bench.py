@@ -92,7 +92,7 @@ def attention_roofline(dtype_id, dtype_name, iters=64, pool=8):
         torch.cuda.synchronize()
         d = sorted(a.elapsed_time(b) for a, b in ev)
         return sum(d[iters // 8: iters - iters // 8]) / (iters - 2 * (iters // 8)) / 1e3      # trimmed mean, seconds
-    def back_to_back(rotate, n=256):
+    def back_to_back(rotate, n=96):        # (96 enqueues take the host ~1.4 ms: inside the 2 ms head start the spin kernel gives it)
         """Duration per launch of n launches between ONE event pair (rotating buffers): consecutive launches overlap each other's
         ramp-up and tail, so this is the kernel's throughput, not its latency -- reported beside `frac`, never as it."""
         a, b2 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
