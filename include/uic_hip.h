@@ -454,6 +454,13 @@ int uic_attention_bwd_accum(int32_t dtype, int32_t N, int32_t R, int32_t A, int3
 /* torch.optim.Adam step (P/misc/optimizer.py:70,93) on one flat f32 arena; `step` is 1-based. */
 int uic_adam_step(float* p, const float* g, float* m, float* v, size_t n, float lr, float beta1, float beta2,
                   float eps, int32_t step, float grad_scale, void* stream);
+/* The same step, skipped ON THE DEVICE when skip_if_nonzero[0] has any bit set (NULL: never skipped): the update of a training
+ * step whose persistent recurrence launch timed out (uic_topdown_dims.rnn_status[0] != 0, its gradients are invalid) must not
+ * reach the weights or the Adam moments.  The word may be rnn_status itself or, in a data-parallel run, the all-reduced sum of
+ * the ranks' words as a float (every rank then skips together; replaces nothing in the reference -- P/trainer.py:173 has no
+ * persistent kernels to time out). */
+int uic_adam_step_guarded(float* p, const float* g, float* m, float* v, size_t n, float lr, float beta1, float beta2,
+                          float eps, int32_t step, float grad_scale, const int32_t* skip_if_nonzero, void* stream);
 
 /* torch.nn.utils.clip_grad_norm + Adam as Optim.step applies them to the NMT model (P/misc/optimizer.py:93-100,
  * --nmt_max_grad_norm 5): uic_grad_sqnorm leaves sum(g^2) of the flat gradient arena in out[0] (deterministic

@@ -268,8 +268,9 @@ def test_self_critical_step_overlapped_baseline_equals_serial_when_both_passes_s
     Trainer.train_self_critical have the SAME workspace key and run on two streams -- the pool must not hand the baseline's
     workspace to the sampling pass while the baseline still runs.  Three steps with the baseline beside the sampling pass
     (default), with the two passes one after the other (serial_baseline) and -- bf16 -- with each pass as one persistent decode
-    launch: the first step's loss bit for bit, later losses and the weights to the last bits in the first two (same kernels, same
-    seeds; the embedding gradient's atomics sum in arrival order; f32 everywhere the chain)."""
+    launch: every loss and every weight after three Adam steps BIT FOR BIT in the first two (same kernels, same seeds, and no
+    floating-point atomics anywhere in the step -- the embedding gradient is a stable counting sort with one owner per table
+    row, csrc/pointwise.hip; f32 everywhere the chain).  What the test protects: P/trainer.py:166-171, P/misc/rewards.py:42-47."""
     from unpaired_image_captioning_amd.trainer import Trainer
     from test_gpu_topdown import make_opt
     _, Ws, b = case
@@ -297,10 +298,9 @@ def test_self_critical_step_overlapped_baseline_equals_serial_when_both_passes_s
         res[mode] = (losses, {k: v.detach().cpu().clone() for k, v in tr.i2t_model.state_dict().items()})
     l0, w0 = res["serial"]
     l1, w1 = res["overlap"]
-    assert l1[0] == l0[0], (l1, l0)                    # the first step bit for bit; later ones see weights that differ in the last bits
-    assert np.allclose(l1, l0, rtol=0, atol=2e-4), (l1, l0)
-    for k in w0:                                       # (the embedding gradient's atomics sum in arrival order: last-bit differences)
-        assert (w1[k].double() - w0[k].double()).abs().max().item() <= 1e-6, k
+    assert l1 == l0, (l1, l0)
+    for k in w0:
+        assert torch.equal(w1[k], w0[k]), (k, (w1[k].double() - w0[k].double()).abs().max().item())
     if "persistent" in res:      # another summation order in the decode launch: the sampled captions may differ at rounding boundaries
         lp, wp = res["persistent"]
         assert all(np.isfinite(lp)) and abs(lp[0] - l0[0]) < 0.5
@@ -370,3 +370,74 @@ def test_persistent_launches_on_two_streams_wait_for_each_other(case):
     assert after[0] == 0 and after[1] - before[1] == 8
     for i in (0, 1):
         assert torch.equal(outs[i][0], alone[i][0]) and torch.equal(outs[i][1], alone[i][1])
+
+
+def _force_timeout_word(value):
+    from unpaired_image_captioning_amd import _lib as Lb
+    Lb.status_words()[0] = value
+    torch.cuda.synchronize()
+
+
+def test_timed_out_persistent_launch_poisons_the_captions_and_raises_at_the_call(case):
+    """The status word a persistent launch sets when its bounded spin gives up (forced here by writing it): a lone decode pass
+    (eval mode, one persistent launch) must hand back POISONED captions -- token -1, log-prob NaN -- and raise at the call
+    itself, not at some later training step; the word is cleared by the raise, and the next pass is sound."""
+    from unpaired_image_captioning_amd import _lib as Lb
+    Wg, _, b = case
+    n = 40
+    fc, att, am = b["fc_feats"][:n].cuda(), b["att_feats"][:n].cuda(), b["att_masks"][:n].cuda()
+    model = build_model(CFG, Wg, "bf16")
+    model.eval()
+    good = model(fc, None, att, am, opt={"sample_max": 1}, mode="sample")
+    _force_timeout_word(0x51)
+    try:
+        with pytest.raises(RuntimeError, match="timed out"):
+            model(fc, None, att, am, opt={"sample_max": 1}, mode="sample")
+        assert Lb.persistent_status()[0] == 0                       # cleared by the raise
+        _force_timeout_word(0x51)
+        model.defer_status_check = True                              # the caller's own sync: look at what came back
+        seq, lp = model(fc, None, att, am, opt={"sample_max": 1}, mode="sample")
+        assert (seq == -1).all() and torch.isnan(lp).all()
+    finally:
+        Lb.status_words().zero_()
+        model.defer_status_check = False
+    again = model(fc, None, att, am, opt={"sample_max": 1}, mode="sample")
+    assert torch.equal(again[0], good[0]) and torch.equal(again[1], good[1])
+
+
+def test_training_step_after_a_timeout_is_skipped_on_the_device_and_raises(case):
+    """Trainer.train with the status word set during the step (forced): uic_adam_step_guarded must leave weights, Adam moments
+    and the step counter untouched, the call must raise, and the next call must train exactly as if the bad step had never
+    been issued."""
+    from unpaired_image_captioning_amd import _lib as Lb
+    from unpaired_image_captioning_amd.trainer import Trainer
+    from test_gpu_topdown import make_opt
+    _, Ws, b = case
+    rows = slice(0, 16 * 5)
+    data = {k: b[k][rows].numpy() for k in ("fc_feats", "att_feats", "labels", "masks", "att_masks")}
+
+    def fresh():
+        opt = make_opt(CFG, "bf16", drop=0.5, seed=11)
+        opt.i2t_learning_rate = 1e-3
+        opt.seq_per_img = 1
+        tr = Trainer(opt)
+        tr.i2t_model.load_state_dict(Ws)
+        tr.build_optimizer()
+        return tr
+
+    ref = fresh()
+    ref_losses = [ref.train(data) for _ in range(2)]
+    tr = fresh()
+    assert tr.train(data) == ref_losses[0]
+    snap = (tr.arena.flat.clone(), tr.arena.exp_avg.clone(), tr.arena.exp_avg_sq.clone(), tr._step, tr.i2t_model._seed_counter)
+    _force_timeout_word(0x33)
+    try:
+        with pytest.raises(RuntimeError, match="timed out"):
+            tr.train(data)
+    finally:
+        Lb.status_words().zero_()
+    assert torch.equal(tr.arena.flat, snap[0]) and torch.equal(tr.arena.exp_avg, snap[1]) and torch.equal(tr.arena.exp_avg_sq, snap[2])
+    assert tr._step == snap[3]
+    tr.i2t_model._seed_counter = snap[4]                    # (the skipped step drew a dropout seed)
+    assert tr.train(data) == ref_losses[1]
+    assert torch.equal(tr.arena.flat, ref.arena.flat)

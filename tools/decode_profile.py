@@ -10,6 +10,7 @@ from unpaired_image_captioning_amd.synthetic import synthetic_batch
 c = bench.CFG
 torch.manual_seed(1)
 m = models.setup(bench.make_opt("bf16", 1)).cuda()
+m.defer_status_check = True              # profiling loops: no host sync inside the decode calls
 b = synthetic_batch(c["n_img"], c["S"], c["R"], c["D"], c["V"], c["L"], seed=5)
 which = sys.argv[1] if len(sys.argv) > 1 else "sample"
 for _ in range(6):

@@ -13,6 +13,7 @@ torch.manual_seed(1234)
 tr = Trainer(bench.make_opt("bf16", 1234)); tr.build_optimizer()
 batch = synthetic_batch(c["n_img"], c["S"], c["R"], c["D"], c["V"], c["L"], seed=1234)
 model = tr.i2t_model
+model.defer_status_check = True          # timing loops: no host sync inside the decode calls
 eng = model.engine
 t_run = model._steps_to_run(batch["labels"])
 pd = {k: v.detach() for k, v in model.param_dict().items()}

@@ -16,6 +16,7 @@ torch.manual_seed(1234)
 tr = Trainer(bench.make_opt("bf16", 1234)); tr.build_optimizer()
 batch = synthetic_batch(c["n_img"], c["S"], c["R"], c["D"], c["V"], c["L"], seed=1234)
 model = tr.i2t_model
+model.defer_status_check = True          # timing loops: no host sync inside the decode calls
 eng = model.engine
 data = {k: v.cpu().numpy() for k, v in batch.items()}
 L_ = c["L"]

@@ -284,6 +284,7 @@ _SIGS = {
     "uic_attention_bwd_step": (C.c_int, [C.c_int32] * 5 + [C.c_void_p] * 9),
     "uic_attention_bwd_accum": (C.c_int, [C.c_int32] * 6 + [C.c_void_p] * 10),
     "uic_adam_step": (C.c_int, [C.c_void_p] * 4 + [C.c_size_t] + [C.c_float] * 4 + [C.c_int32, C.c_float, C.c_void_p]),
+    "uic_adam_step_guarded": (C.c_int, [C.c_void_p] * 4 + [C.c_size_t] + [C.c_float] * 4 + [C.c_int32, C.c_float, C.c_void_p, C.c_void_p]),
     "uic_grad_sqnorm": (C.c_int, [C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p]),
     "uic_adam_step_clip": (C.c_int, [C.c_void_p] * 4 + [C.c_size_t] + [C.c_float] * 4 + [C.c_int32, C.c_float, C.c_float,
                                                                                       C.c_void_p, C.c_void_p]),

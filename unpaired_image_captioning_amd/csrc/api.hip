@@ -191,7 +191,20 @@ int uic_adam_step(float* p, const float* g, float* m, float* v, size_t n, float 
   a.bc1 = (float)(1.0 - pow((double)beta1, (double)step));
   a.bc2 = (float)(1.0 - pow((double)beta2, (double)step));
   a.grad_scale = grad_scale;
-  a.max_norm = 0.f; a.sqnorm = nullptr;
+  a.max_norm = 0.f; a.sqnorm = nullptr; a.guard = nullptr;
+  return uic_adam_launch(a, (hipStream_t)stream);
+}
+
+int uic_adam_step_guarded(float* p, const float* g, float* m, float* v, size_t n, float lr, float beta1, float beta2,
+                          float eps, int32_t step, float grad_scale, const int32_t* skip_if_nonzero, void* stream) {
+  UIC_REQUIRE(p && g && m && v, "adam_step_guarded: null pointer");
+  UIC_REQUIRE(step >= 1, "adam_step_guarded: step=%d must be >= 1", step);
+  UicAdamParams a;
+  a.p = p; a.g = g; a.m = m; a.v = v; a.n = n; a.lr = lr; a.beta1 = beta1; a.beta2 = beta2; a.eps = eps;
+  a.bc1 = (float)(1.0 - pow((double)beta1, (double)step));
+  a.bc2 = (float)(1.0 - pow((double)beta2, (double)step));
+  a.grad_scale = grad_scale;
+  a.max_norm = 0.f; a.sqnorm = nullptr; a.guard = skip_if_nonzero;
   return uic_adam_launch(a, (hipStream_t)stream);
 }
 
@@ -208,7 +221,7 @@ int uic_adam_step_clip(float* p, const float* g, float* m, float* v, size_t n, f
   a.bc1 = (float)(1.0 - pow((double)beta1, (double)step));
   a.bc2 = (float)(1.0 - pow((double)beta2, (double)step));
   a.grad_scale = grad_scale;
-  a.max_norm = max_norm; a.sqnorm = sqnorm;
+  a.max_norm = max_norm; a.sqnorm = sqnorm; a.guard = nullptr;
   return uic_adam_launch(a, (hipStream_t)stream);
 }
 

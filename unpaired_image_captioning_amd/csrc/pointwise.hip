@@ -223,15 +223,17 @@ __global__ void relu_mask_bwd_kernel(const float* __restrict__ g, const T* __res
     dst[i] = uic_from_f<T>(uic_to_f(act[i]) > 0.f ? g[i] * scale : 0.f);
 }
 
-// The same gradient with the T*N positions first bucketed by token (histogram -> exclusive scan -> fill): equal tokens become
-// neighbours, so embed_gather_kernel can sum them in registers before it touches the table.
+// The same gradient with the T*N positions first bucketed by token -- a STABLE counting sort (positions of one token stay in
+// position order), so that every run of the repository is bit for bit the same: histogram per block of EMB_BLK positions ->
+// per-token prefix over the blocks -> exclusive scan over the tokens -> fill (slot = bucket start + entries of earlier blocks +
+// rank inside the block, counted in LDS).  Equal tokens become neighbours, so embed_gather_kernel can sum them in registers, and
+// every table row has ONE owner that stores it (no floating-point atomics anywhere).
 // Wave-aggregated counting: a token shared by many lanes of a wave (the padding token at late decode steps, frequent words)
-// costs ONE atomic per wave instead of one per lane -- plain per-lane atomics on cnt[0] serialise ~3000 deep.  Two aggregation
+// costs ONE atomic per wave instead of one per lane -- plain per-lane atomics on cnt[0] serialise ~1000 deep.  Two aggregation
 // rounds (the tokens of the first two still-active lanes) catch the hot tokens; the remaining lanes use plain atomics.
-// Returns the lane's slot (old counter value + rank inside its group); `want` = false skips the (slow) returning form.
-__device__ __forceinline__ int wave_token_add(int* base, int tok, bool active, bool want) {
+// (integer adds whose old value nobody reads: the totals do not depend on arrival order)
+__device__ __forceinline__ void wave_token_add(int* base, int tok, bool active) {
   const int lane = threadIdx.x & 63;
-  int slot = 0;
 #pragma unroll
   for (int round = 0; round < 2; ++round) {
     const unsigned long long todo = __ballot(active);
@@ -239,36 +241,43 @@ __device__ __forceinline__ int wave_token_add(int* base, int tok, bool active, b
     const int leader = __ffsll((long long)todo) - 1;
     const int t0 = __shfl(tok, leader, 64);
     const unsigned long long m = __ballot(active && tok == t0);
-    int old = 0;
-    if (lane == leader) old = atomicAdd(base + t0, __popcll(m));
-    if (want) old = __shfl(old, leader, 64);
-    if (active && tok == t0) {
-      slot = old + __popcll(m & ((1ull << lane) - 1ull));
-      active = false;
-    }
+    if (lane == leader) atomicAdd(base + t0, __popcll(m));
+    if (active && tok == t0) active = false;
   }
-  if (active) slot = atomicAdd(base + tok, 1);
-  return slot;
+  if (active) atomicAdd(base + tok, 1);
 }
+constexpr int EMB_BLK = 1024;                     // positions per histogram block (one workgroup)
 // split > 0: the bucket key is (t >= split) * V1 + token -- the positions of decode steps [0, split) are entries [0, split N) of the
 // list, those of [split, T) the rest, and each half can be gathered on its own (the later steps' half while BPTT still runs)
-__global__ void embed_hist_kernel(const int64_t* __restrict__ tokens, int ldtok, int N, int TS, int V1, int split, int* __restrict__ cnt) {
-  const int total = TS * N;
-  const int span = (total + 63) & ~63;                       // whole waves enter the aggregation together
-  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < span; i += gridDim.x * blockDim.x) {
-    const bool ok = i < total;
-    long tok = 0;
-    if (ok) {
-      const int t = i / N, n = i - t * N;
-      tok = tokens[(size_t)n * ldtok + t];
-      if (tok < 0 || tok >= V1) tok = 0;
-      if (split && t >= split) tok += V1;
-    }
-    wave_token_add(cnt, (int)tok, ok, false);
-  }
+__device__ __forceinline__ int embed_key(const int64_t* __restrict__ tokens, int ldtok, int N, int V1, int split, int i) {
+  const int t = i / N, n = i - t * N;
+  long tok = tokens[(size_t)n * ldtok + t];
+  if (tok < 0 || tok >= V1) tok = 0;
+  if (split && t >= split) tok += V1;
+  return (int)tok;
 }
-// single workgroup: off[v] = exclusive prefix of cnt, cur[v] = off[v] (the fill cursor), off[V1] = total
-__global__ __launch_bounds__(1024) void embed_scan_kernel(const int* __restrict__ cnt, int V1, int* __restrict__ off, int* __restrict__ cur) {
+// cntb[b, key] = how many of block b's positions carry `key`
+__global__ __launch_bounds__(EMB_BLK) void embed_hist_kernel(const int64_t* __restrict__ tokens, int ldtok, int N, int TS, int V1, int split,
+                                                             int nkeys, int* __restrict__ cntb) {
+  const int i = blockIdx.x * EMB_BLK + threadIdx.x;          // whole waves enter the aggregation together
+  const bool ok = i < TS * N;
+  const int key = ok ? embed_key(tokens, ldtok, N, V1, split, i) : 0;
+  wave_token_add(cntb + (size_t)blockIdx.x * nkeys, key, ok);
+}
+// per key: cntb[b, key] <- entries of blocks < b (exclusive prefix over the blocks), cnt[key] <- the key's total
+__global__ void embed_block_prefix_kernel(int* __restrict__ cntb, int nkeys, int nblk, int* __restrict__ cnt) {
+  const int key = blockIdx.x * blockDim.x + threadIdx.x;
+  if (key >= nkeys) return;
+  int run = 0;
+  for (int b = 0; b < nblk; ++b) {
+    const int v = cntb[(size_t)b * nkeys + key];
+    cntb[(size_t)b * nkeys + key] = run;
+    run += v;
+  }
+  cnt[key] = run;
+}
+// single workgroup: off[v] = exclusive prefix of cnt, off[V1] = total
+__global__ __launch_bounds__(1024) void embed_scan_kernel(const int* __restrict__ cnt, int V1, int* __restrict__ off) {
   __shared__ int s_wave[16];
   const int per = (V1 + 1023) / 1024;
   const int lo = threadIdx.x * per, hi = min(V1, lo + per);
@@ -290,34 +299,41 @@ __global__ __launch_bounds__(1024) void embed_scan_kernel(const int* __restrict_
     tot += s_wave[k];
   }
   int run = incl + woff - sum;
-  for (int v = lo; v < hi; ++v) { off[v] = run; cur[v] = run; run += cnt[v]; }
+  for (int v = lo; v < hi; ++v) { off[v] = run; run += cnt[v]; }
   if (threadIdx.x == 0) off[V1] = tot;
 }
-__global__ void embed_fill_kernel(const int64_t* __restrict__ tokens, int ldtok, int N, int TS, int V1, int split, int* __restrict__ cur, int* __restrict__ perm) {
-  const int total = TS * N;
-  const int span = (total + 63) & ~63;
-  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < span; i += gridDim.x * blockDim.x) {
-    const bool ok = i < total;
-    long tok = 0;
-    if (ok) {
-      const int t = i / N, n = i - t * N;
-      tok = tokens[(size_t)n * ldtok + t];
-      if (tok < 0 || tok >= V1) tok = 0;
-      if (split && t >= split) tok += V1;
-    }
-    const int slot = wave_token_add(cur, (int)tok, ok, true);
-    if (ok) perm[slot] = i;
+// perm[off[key] + (entries of earlier blocks) + (earlier entries of this block with the same key)] = position
+__global__ __launch_bounds__(EMB_BLK) void embed_fill_kernel(const int64_t* __restrict__ tokens, int ldtok, int N, int TS, int V1, int split,
+                                                             int nkeys, const int* __restrict__ off, const int* __restrict__ cntb,
+                                                             int* __restrict__ perm) {
+  __shared__ __attribute__((aligned(16))) int s_key[EMB_BLK];
+  const int i = blockIdx.x * EMB_BLK + threadIdx.x;
+  const bool ok = i < TS * N;
+  const int key = ok ? embed_key(tokens, ldtok, N, V1, split, i) : -1;
+  s_key[threadIdx.x] = key;
+  __syncthreads();
+  if (!ok) return;
+  int rank = 0;
+  const int full = threadIdx.x >> 2;
+  for (int q = 0; q < full; ++q) {                 // (LDS broadcast reads: every lane of a wave asks for the same 16 bytes)
+    const int4 v = ((const int4*)s_key)[q];
+    rank += (v.x == key) + (v.y == key) + (v.z == key) + (v.w == key);
   }
+  for (int j = full * 4; j < (int)threadIdx.x; ++j) rank += s_key[j] == key;
+  perm[off[key] + cntb[(size_t)blockIdx.x * nkeys + key] + rank] = i;
 }
-// One workgroup per CH consecutive entries of the token-bucketed position list: it loads its CH rows up front, sums runs of
-// equal tokens in registers and flushes every run with one atomicAdd per column -- a hot token (the padding token 0 owns
-// thousands of positions) costs positions / CH contended atomics per column instead of one per position, rare tokens one.
+// One workgroup per CH consecutive entries of the token-bucketed position list: it loads its CH rows up front and sums runs of
+// equal tokens in registers.  A bucket that lies wholly inside the workgroup's entries (most tokens occur once or twice) is
+// stored straight into the table.  A bucket that straddles workgroups (a hot token -- the padding token 0 owns thousands of
+// positions) leaves one partial row per workgroup in `part` ([2, nchunks, E]: plane 0 = the bucket began in an earlier
+// workgroup, plane 1 = it begins here and goes on), and embed_gather_finish_kernel lets the workgroup in which the bucket begins
+// add them up in list order: one owner per table row, a fixed summation order.
 constexpr int EMB_CH = 16;
 template <typename T>
 __global__ __launch_bounds__(128) void embed_gather_kernel(const float* __restrict__ dxt, const T* __restrict__ xt, const int64_t* __restrict__ tokens,
                                                            int ldtok, int N, int V1, const int* __restrict__ off, const int* __restrict__ perm, int total,
                                                            int E, float inv_keep, long skip_token, float* __restrict__ dtable, int base, int keybase,
-                                                           int accum) {
+                                                           int accum, float* __restrict__ part, int chunk0, size_t plane) {
   // entries [base, total) of the list; keybase = this chunk's first bucket key; accum: the table already holds earlier chunks' sums
   const int start = base + blockIdx.x * EMB_CH;
   const int cnt = min(EMB_CH, total - start);
@@ -365,22 +381,49 @@ __global__ __launch_bounds__(128) void embed_gather_kernel(const float* __restri
         const bool last = j + 1 == cnt || s_tok[j + 1] != s_tok[j];       // uniform over the workgroup
         if (last) {
           if (s_tok[j] != skip_token) {
-            float* o = dtable + (size_t)s_tok[j] * E + c * 4;
-            // a bucket that lies wholly inside this workgroup's entries (most tokens occur once or twice) is stored, not added:
-            // the table was zeroed and nobody else touches the row; only hot / straddling buckets pay for atomics
-            const bool whole = off[keybase + s_tok[j]] >= start && off[keybase + s_tok[j] + 1] <= start + cnt;
-            if (whole) {
+            const int b0 = off[keybase + s_tok[j]], b1 = off[keybase + s_tok[j] + 1];
+            if (b0 >= start && b1 <= start + cnt) {                        // the whole bucket: this workgroup owns the table row
+              float* o = dtable + (size_t)s_tok[j] * E + c * 4;
               float4 v = make_float4(acc.x * inv_keep, acc.y * inv_keep, acc.z * inv_keep, acc.w * inv_keep);
               if (accum) { const float4 q = *(const float4*)o; v.x += q.x; v.y += q.y; v.z += q.z; v.w += q.w; }
               *(float4*)o = v;
             } else {
-              atomicAdd(o, acc.x * inv_keep); atomicAdd(o + 1, acc.y * inv_keep); atomicAdd(o + 2, acc.z * inv_keep); atomicAdd(o + 3, acc.w * inv_keep);
+              *(float4*)(part + (b0 >= start ? plane : 0) + (size_t)(chunk0 + blockIdx.x) * E + c * 4) = acc;
             }
           }
           acc = make_float4(0.f, 0.f, 0.f, 0.f);
         }
       }
     }
+  }
+}
+// the owner of a straddling bucket (the workgroup whose entries hold the bucket's first position) adds the partial rows in list
+// order and stores the table row
+__global__ __launch_bounds__(128) void embed_gather_finish_kernel(const int64_t* __restrict__ tokens, int ldtok, int N, int V1,
+                                                                  const int* __restrict__ off, const int* __restrict__ perm, int total, int E,
+                                                                  float inv_keep, long skip_token, float* __restrict__ dtable, int base, int keybase,
+                                                                  int accum, const float* __restrict__ part, int chunk0, size_t plane) {
+  const int start = base + blockIdx.x * EMB_CH;
+  const int cnt = min(EMB_CH, total - start);
+  const int pos = perm[start + cnt - 1];                      // the workgroup's last entry
+  const int t = pos / N, n = pos - t * N;
+  long tok = tokens[(size_t)n * ldtok + t];
+  if (tok < 0 || tok >= V1) tok = 0;
+  if (tok == skip_token) return;
+  const int b0 = off[keybase + tok], b1 = off[keybase + tok + 1];
+  if (b0 < start || b1 <= start + cnt) return;                // began earlier (somebody else's), or ends here (stored by the gather)
+  const int c_last = (b1 - 1 - base) / EMB_CH;                // the workgroup that holds the bucket's last entry
+  for (int c = threadIdx.x; c < E / 4; c += blockDim.x) {
+    float4 acc = *(const float4*)(part + plane + (size_t)(chunk0 + blockIdx.x) * E + c * 4);
+#pragma unroll 4
+    for (int k = blockIdx.x + 1; k <= c_last; ++k) {
+      const float4 q = *(const float4*)(part + (size_t)(chunk0 + k) * E + c * 4);
+      acc.x += q.x; acc.y += q.y; acc.z += q.z; acc.w += q.w;
+    }
+    float* o = dtable + (size_t)tok * E + c * 4;
+    float4 v = make_float4(acc.x * inv_keep, acc.y * inv_keep, acc.z * inv_keep, acc.w * inv_keep);
+    if (accum) { const float4 q = *(const float4*)o; v.x += q.x; v.y += q.y; v.z += q.z; v.w += q.w; }
+    *(float4*)o = v;
   }
 }
 
@@ -971,6 +1014,7 @@ __global__ void adam_kernel(const UicAdamParams a) {
   const size_t stride = (size_t)gridDim.x * blockDim.x;
   const float step_size = a.lr / a.bc1;
   const float inv_sqrt_bc2 = 1.f / sqrtf(a.bc2);
+  if (a.guard && a.guard[0] != 0) return;          // (uniform over the launch: the step's gradients are invalid, keep the weights)
   float gs = a.grad_scale;
   if (a.sqnorm) {
     const float coef = a.max_norm / (fabsf(a.grad_scale) * sqrtf(a.sqnorm[0]) + 1e-6f);
@@ -1408,12 +1452,22 @@ int uic_embed_bwd_launch(int dtype, const float* dxt, const void* xt, const int6
   UIC_LAUNCH_CHECK("embed_bwd");
   return UIC_OK;
 }
-size_t uic_embed_bwd_sorted_scratch_ints(int N, int T, int V1) { return 3 * ((size_t)2 * V1 + 1) + (size_t)N * T + 64; }
+// scratch layout (ints): cnt [nkeys + 1] | off [nkeys + 1] | (unused) [nkeys + 1] | perm [N T] ... then, at offsets that do not
+// depend on `split`: cntb [nblk, 2 V1] | part [2, nchunks, E] f32
+namespace {
+inline size_t emb_fixed_ints(int N, int T, int V1) { return ((3 * ((size_t)2 * V1 + 1) + (size_t)N * T + 64) + 63) & ~(size_t)63; }
+inline int emb_blocks(int total) { return (total + EMB_BLK - 1) / EMB_BLK; }
+inline size_t emb_cntb_ints(int N, int T, int V1) { return ((size_t)emb_blocks(N * T) * 2 * V1 + 63) & ~(size_t)63; }
+inline size_t emb_chunks(int N, int T) { return (size_t)(N * T) / EMB_CH + 2; }           // two halves, each rounded up
+}  // namespace
+size_t uic_embed_bwd_sorted_scratch_ints(int N, int T, int V1, int E) {
+  return emb_fixed_ints(N, T, V1) + emb_cntb_ints(N, T, V1) + 2 * emb_chunks(N, T) * (size_t)E;
+}
 // Two halves, so that a caller can do the token bucketing (which needs only the tokens) long before the gradients exist:
-//   prepare: zero dtable, histogram -> scan -> fill of the position list into `scratch`;   gather: the sums.
+//   prepare: zero dtable, histogram -> prefixes -> fill of the position list into `scratch`;   gather: the sums.
 // split > 0 (< T): the list holds the positions of decode steps [0, split) first, then those of [split, T); gather then takes one
 // of the two halves per call (half = 0 / 1) and adds into the table, so the later steps' share can be gathered before the
-// earlier steps' d xt exists.  Both calls must get the same `split`.
+// earlier steps' d xt exists.  Both calls must get the same `split` (and the same N, T, V1).
 int uic_embed_bwd_sorted_prepare(const int64_t* tokens, int ldtok, int N, int T, int V1, int E, float* dtable, int* scratch, hipStream_t s, int split) {
   UIC_REQUIRE(E % 4 == 0 && scratch, "embed_bwd_sorted: E=%d must be a multiple of 4", E);
   UIC_REQUIRE(split >= 0 && split < (T > 0 ? T : 1), "embed_bwd_sorted: split=%d outside [0, %d)", split, T);
@@ -1421,40 +1475,47 @@ int uic_embed_bwd_sorted_prepare(const int64_t* tokens, int ldtok, int N, int T,
   const int nkeys = (split > 0 ? 2 : 1) * V1;
   int* cnt = scratch;
   int* off = cnt + (nkeys + 1);
-  int* cur = off + (nkeys + 1);
-  int* perm = cur + (nkeys + 1);
+  int* perm = scratch + 3 * (nkeys + 1);
+  int* cntb = scratch + emb_fixed_ints(N, T, V1);
   const int total = N * T;
   UIC_TRY(uic_fill_launch(dtable, 0, (size_t)V1 * E * 4, s));
   if (total == 0) return UIC_OK;
-  UIC_TRY(uic_fill_launch(cnt, 0, (size_t)(nkeys + 1) * 4, s));
-  const int g = grid_for((size_t)total, NT);
-  hipLaunchKernelGGL(embed_hist_kernel, dim3(g), dim3(NT), 0, s, tokens, ldtok, N, T, V1, split, cnt);
+  const int nblk = emb_blocks(total);
+  UIC_TRY(uic_fill_launch(cntb, 0, (size_t)nblk * nkeys * 4, s));
+  hipLaunchKernelGGL(embed_hist_kernel, dim3(nblk), dim3(EMB_BLK), 0, s, tokens, ldtok, N, T, V1, split, nkeys, cntb);
   UIC_LAUNCH_CHECK("embed_hist");
-  hipLaunchKernelGGL(embed_scan_kernel, dim3(1), dim3(1024), 0, s, (const int*)cnt, nkeys, off, cur);
+  hipLaunchKernelGGL(embed_block_prefix_kernel, dim3((nkeys + NT - 1) / NT), dim3(NT), 0, s, cntb, nkeys, nblk, cnt);
+  UIC_LAUNCH_CHECK("embed_block_prefix");
+  hipLaunchKernelGGL(embed_scan_kernel, dim3(1), dim3(1024), 0, s, (const int*)cnt, nkeys, off);
   UIC_LAUNCH_CHECK("embed_scan");
-  hipLaunchKernelGGL(embed_fill_kernel, dim3(g), dim3(NT), 0, s, tokens, ldtok, N, T, V1, split, cur, perm);
+  hipLaunchKernelGGL(embed_fill_kernel, dim3(nblk), dim3(EMB_BLK), 0, s, tokens, ldtok, N, T, V1, split, nkeys, (const int*)off, (const int*)cntb, perm);
   UIC_LAUNCH_CHECK("embed_fill");
   return UIC_OK;
 }
 int uic_embed_bwd_sorted_gather(int dtype, const float* dxt, const void* xt, const int64_t* tokens, int ldtok, int N, int T,
-                                int V1, int E, float drop_p, long skip_token, float* dtable, const int* scratch, hipStream_t s,
+                                int V1, int E, float drop_p, long skip_token, float* dtable, int* scratch, hipStream_t s,
                                 int split, int half) {
   if (V1 == 0 || N * T == 0) return UIC_OK;
-  int base = 0, total = N * T, keybase = 0, nkeys = V1;
+  int base = 0, total = N * T, keybase = 0, nkeys = V1, chunk0 = 0;
   if (split > 0) {
     UIC_REQUIRE(split < T && (half == 0 || half == 1), "embed_bwd_sorted_gather: split=%d half=%d (T=%d)", split, half, T);
     nkeys = 2 * V1;
     base = half ? split * N : 0; total = half ? T * N : split * N; keybase = half ? V1 : 0;
+    chunk0 = half ? (split * N + EMB_CH - 1) / EMB_CH : 0;
   }
   const int* off = scratch + (nkeys + 1);
   const int* perm = scratch + 3 * (nkeys + 1);
+  float* part = (float*)(scratch + emb_fixed_ints(N, T, V1) + emb_cntb_ints(N, T, V1));
+  const size_t plane = emb_chunks(N, T) * (size_t)E;
   const float inv_keep = drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f;
   const int gw = (total - base + EMB_CH - 1) / EMB_CH;
-  const int accum = split > 0;     // (the table was zeroed by prepare; within one launch a whole bucket still has one owner)
+  const int accum = split > 0;     // (the table was zeroed by prepare; every bucket has one owner per launch)
   DISPATCH_T(dtype,
-             hipLaunchKernelGGL(embed_gather_kernel<bf16_t>, dim3(gw), dim3(128), 0, s, dxt, (const bf16_t*)xt, tokens, ldtok, N, V1, off, perm, total, E, inv_keep, skip_token, dtable, base, keybase, accum),
-             hipLaunchKernelGGL(embed_gather_kernel<float>, dim3(gw), dim3(128), 0, s, dxt, (const float*)xt, tokens, ldtok, N, V1, off, perm, total, E, inv_keep, skip_token, dtable, base, keybase, accum));
+             hipLaunchKernelGGL(embed_gather_kernel<bf16_t>, dim3(gw), dim3(128), 0, s, dxt, (const bf16_t*)xt, tokens, ldtok, N, V1, off, perm, total, E, inv_keep, skip_token, dtable, base, keybase, accum, part, chunk0, plane),
+             hipLaunchKernelGGL(embed_gather_kernel<float>, dim3(gw), dim3(128), 0, s, dxt, (const float*)xt, tokens, ldtok, N, V1, off, perm, total, E, inv_keep, skip_token, dtable, base, keybase, accum, part, chunk0, plane));
   UIC_LAUNCH_CHECK("embed_gather");
+  hipLaunchKernelGGL(embed_gather_finish_kernel, dim3(gw), dim3(128), 0, s, tokens, ldtok, N, V1, off, perm, total, E, inv_keep, skip_token, dtable, base, keybase, accum, (const float*)part, chunk0, plane);
+  UIC_LAUNCH_CHECK("embed_gather_finish");
   return UIC_OK;
 }
 // dtable [V1, E] is overwritten.  scratch: uic_embed_bwd_sorted_scratch_ints ints.

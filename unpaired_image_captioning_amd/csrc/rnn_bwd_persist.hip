@@ -497,7 +497,8 @@ int uic_rnn_bwd_persist_launch(const UicRnnBwdParams& p0, hipStream_t s) {
     configured = true;
   }
   const int G = 8, cap = G * 16 * MT_MAX;     // caption rows one launch covers
-  UIC_TRY(uic_persist_gate_enter(s));         // (its workgroups have to be resident together: never beside another persistent launch)
+  UicPersistGateScope gate;                   // (its workgroups have to be resident together: never beside another persistent launch)
+  UIC_TRY(gate.enter(s));
   for (int r0 = 0; r0 < p0.N; r0 += cap) {
     UicRnnBwdParams p = p0;
     p.row0 = r0;
@@ -507,5 +508,5 @@ int uic_rnn_bwd_persist_launch(const UicRnnBwdParams& p0, hipStream_t s) {
     hipLaunchKernelGGL(rnn_bwd_persist_kernel, dim3(G * PW), dim3(BW_NTH), BW_LDS_BYTES, s, p);
     UIC_LAUNCH_CHECK("rnn_bwd_persist_kernel");
   }
-  return uic_persist_gate_leave(s);
+  return gate.leave();
 }

@@ -1490,9 +1490,19 @@ __global__ void dec_embed_relu_kernel(const float* __restrict__ w, bf16_t* __res
   }
 }
 
-// the reference stops decoding once every row has finished (AttModel.py:236-238): entries after that step stay zero
-__global__ void dec_finish_kernel(const int64_t* __restrict__ seq, float* __restrict__ seq_logp, int N, int L, int ld) {
+// the reference stops decoding once every row has finished (AttModel.py:236-238): entries after that step stay zero.
+// status[0] != 0: a persistent launch gave up waiting for its workgroups (bounded spin) and left its outputs partly unwritten --
+// the captions are then POISONED (token -1, log-prob NaN) so that no caller can score or print them as if they were results.
+__global__ void dec_finish_kernel(int64_t* __restrict__ seq, float* __restrict__ seq_logp, int N, int L, int ld, const int* __restrict__ status) {
   __shared__ int s_max;
+  if (status && status[0] != 0) {
+    for (int i = threadIdx.x; i < N * L; i += blockDim.x) {
+      const int n = i / L, t = i - n * L;
+      seq[(size_t)n * ld + t] = -1;
+      seq_logp[(size_t)n * ld + t] = __int_as_float(0x7fc00000);
+    }
+    return;
+  }
   if (threadIdx.x == 0) s_max = 0;
   __syncthreads();
   int mx = 0;
@@ -1516,30 +1526,38 @@ __global__ void dec_finish_kernel(const int64_t* __restrict__ seq, float* __rest
 // Two persistent launches must not be on the chip at once (each holds every CU while it waits, bounded, for its own
 // workgroups to become resident): inside one process every persistent launch therefore waits for the previous one on its
 // device, whatever stream that ran on.  (Across processes the caller has to choose: UIC_REC_FWD_CHAIN.)
+// enter .. leave is ONE critical section per device (host threads call in through ctypes without the GIL): the lock taken by
+// enter is held until leave has recorded the launch's event -- or until abandon, on an error path (UicPersistGateScope).
 namespace {
-struct PersistGate { hipEvent_t ev = nullptr; bool recorded = false; };
+struct PersistGate { hipEvent_t ev = nullptr; bool recorded = false; std::mutex mu; };
 PersistGate g_gate[16];
-std::mutex g_gate_mutex;
+int gate_device(hipStream_t s, int* dev) {
+  // the STREAM's device, not the calling thread's current one (the default stream belongs to the current device)
+  if (s) return uic_check_hip(hipStreamGetDevice(s, dev), "hipStreamGetDevice");
+  return uic_check_hip(hipGetDevice(dev), "hipGetDevice");
 }
-int uic_persist_gate_enter(hipStream_t s) {
+}
+int uic_persist_gate_enter(hipStream_t s, int* dev_out) {
   int dev = 0;
-  UIC_TRY(uic_check_hip(hipGetDevice(&dev), "hipGetDevice"));
+  UIC_TRY(gate_device(s, &dev));
   UIC_REQUIRE(dev >= 0 && dev < 16, "device index %d out of range", dev);
-  std::lock_guard<std::mutex> lock(g_gate_mutex);
   PersistGate& g = g_gate[dev];
-  if (!g.ev) UIC_TRY(uic_check_hip(hipEventCreateWithFlags(&g.ev, hipEventDisableTiming), "hipEventCreate"));
-  if (g.recorded) UIC_TRY(uic_check_hip(hipStreamWaitEvent(s, g.ev, 0), "hipStreamWaitEvent(persistent gate)"));
+  g.mu.lock();
+  int rc = UIC_OK;
+  if (!g.ev) rc = uic_check_hip(hipEventCreateWithFlags(&g.ev, hipEventDisableTiming), "hipEventCreate");
+  if (rc == UIC_OK && g.recorded) rc = uic_check_hip(hipStreamWaitEvent(s, g.ev, 0), "hipStreamWaitEvent(persistent gate)");
+  if (rc != UIC_OK) { g.mu.unlock(); return rc; }
+  *dev_out = dev;
   return UIC_OK;
 }
-int uic_persist_gate_leave(hipStream_t s) {
-  int dev = 0;
-  UIC_TRY(uic_check_hip(hipGetDevice(&dev), "hipGetDevice"));
-  std::lock_guard<std::mutex> lock(g_gate_mutex);
+int uic_persist_gate_leave(hipStream_t s, int dev) {
   PersistGate& g = g_gate[dev];
-  UIC_TRY(uic_check_hip(hipEventRecord(g.ev, s), "hipEventRecord(persistent gate)"));
-  g.recorded = true;
-  return UIC_OK;
+  const int rc = uic_check_hip(hipEventRecord(g.ev, s), "hipEventRecord(persistent gate)");
+  if (rc == UIC_OK) g.recorded = true;
+  g.mu.unlock();
+  return rc;
 }
+void uic_persist_gate_abandon(int dev) { g_gate[dev].mu.unlock(); }
 
 constexpr int MAX_SLABS = 8;       // launches of <= 640 caption rows each
 size_t uic_rnn_persist_sync_bytes() { return (size_t)MAX_SLABS * SY_WORDS * 4; }
@@ -1571,7 +1589,8 @@ int uic_rnn_fwd_persist_launch(const UicRnnFwdParams& p0, hipStream_t s) {
     configured = true;
   }
   const int G = 8, cap = G * 16 * MT_MAX;     // caption rows one launch covers
-  UIC_TRY(uic_persist_gate_enter(s));
+  UicPersistGateScope gate;
+  UIC_TRY(gate.enter(s));
   for (int r0 = 0; r0 < p0.N; r0 += cap) {
     UicRnnFwdParams p = p0;
     p.row0 = r0;
@@ -1593,16 +1612,16 @@ int uic_rnn_fwd_persist_launch(const UicRnnFwdParams& p0, hipStream_t s) {
     else hipLaunchKernelGGL(rnn_fwd_persist_kernel<float>, dim3(G * PW), dim3(NTH), LDS_BYTES, s, p);
     UIC_LAUNCH_CHECK("rnn_fwd_persist_kernel");
   }
-  return uic_persist_gate_leave(s);
+  return gate.leave();
 }
 
 bool uic_rnn_decode_persist_eligible(int dtype, int N, int H, int A, int R, int E, int V1) {
   return dtype == UIC_BF16 && E == HH && V1 >= 2 && V1 <= PW * WS_NW * DEC_NJ * 16 && uic_rnn_persist_eligible(dtype, N, H, A, R);
 }
 size_t uic_rnn_decode_part_floats(int N) { return (size_t)N * PW * 4; }
-int uic_rnn_decode_finish_launch(const int64_t* seq, float* seq_logp, int N, int L, int ld, hipStream_t s) {
+int uic_rnn_decode_finish_launch(int64_t* seq, float* seq_logp, int N, int L, int ld, const int* status, hipStream_t s) {
   UIC_REQUIRE(seq && seq_logp && N > 0 && L > 0 && ld >= L, "rnn_decode_finish: bad arguments");
-  hipLaunchKernelGGL(dec_finish_kernel, dim3(1), dim3(1024), 0, s, seq, seq_logp, N, L, ld);
+  hipLaunchKernelGGL(dec_finish_kernel, dim3(1), dim3(1024), 0, s, seq, seq_logp, N, L, ld, status);
   UIC_LAUNCH_CHECK("dec_finish_kernel");
   return UIC_OK;
 }

@@ -185,7 +185,7 @@ Layout make_layout(const uic_topdown_dims& d, void* ws) {
     L.slab2 = (float*)b.take(sl);
     L.slab3 = (float*)b.take(sl);
   }
-  L.embed_scratch = (int*)b.take(uic_embed_bwd_sorted_scratch_ints(N, T, V1) * 4);
+  L.embed_scratch = (int*)b.take(uic_embed_bwd_sorted_scratch_ints(N, T, V1, E) * 4);
   L.fcwT = b.take(Dfc * H * S);
   L.attwT = b.take(D * H * S);
   L.ones_rows = rup8((size_t)WG_CHUNK * N) > (size_t)N * R ? rup8((size_t)WG_CHUNK * N) : (size_t)N * R;
@@ -553,6 +553,8 @@ void* uic_topdown_workspace_ptr(const uic_topdown_dims* d, void* workspace, cons
       {"logits", L.logits}, {"dlogits", L.dlogits}, {"row_loss", L.row_loss}, {"scalars", L.scalars},
       {"dhdrop", L.dhdrop}, {"dx2", L.dx2_all}, {"dg1", L.dg1_all}, {"dg2", L.dg2_all}, {"de", L.de_all},
       {"datth", L.datth_all}, {"d_att", L.d_att}, {"d_p_att", L.d_patt}, {"dxt", L.dxt}, {"rnn_dbg", L.rnn_dbg}, {"rnn_bwd_dbg", L.rnn_bwd_dbg},
+      // ("dx1", and columns [H, 3H) of "dx2": written only when the d x GEMMs are not split-K, i.e. by the persistent BPTT kernel
+      // or at shapes where bptt_split() == 0 -- the split chain keeps these sums in its slabs)
       {"dx1", L.dx1}, {"dc_att", L.dc_att}, {"dc_lang", L.dc_lang}};
   for (auto& e : tab)
     if (!strcmp(e.n, name)) return e.p;
@@ -762,7 +764,7 @@ struct Step {
     p.dec_forced = sample_max ? nullptr : forced; p.dec_ld_forced = Lsteps;
     p.dec_sample_max = sample_max; p.dec_draw_seed = seed;
     UIC_TRY(uic_rnn_fwd_persist_launch(p, s));
-    return uic_rnn_decode_finish_launch(seq, seq_logp, N, Lsteps, Lsteps, s);
+    return uic_rnn_decode_finish_launch(seq, seq_logp, N, Lsteps, Lsteps, (const int*)d.rnn_status, s);
   }
 
   // inline_inputs: xt_t and fc' enter att_lstm's GEMM as K segments of their own (with both biases) instead of through the
@@ -936,7 +938,9 @@ struct Step {
   }
 
   // BPTT of decode steps [t_lo, t_hi), latest first: ONE persistent launch (rnn_bwd_persist.hip) when the shapes allow, else
-  // the chain of six launches per step.  Either may continue where the other stopped (same carry buffers).
+  // the chain of five launches per step.  The choice is constant within a step (bwd_persist_ok depends on dims only), and it has
+  // to be: with bptt_split() > 0 the chain carries d h between decode steps in the split-K slabs (bp_slab1 / bp_slab2), not in
+  // L.dx1 / columns [H, 3H) of dx2_all where the persistent kernel keeps it -- a chunk of one cannot hand over to the other.
   bool bwd_persist_ok() const { return (d.recurrence & UIC_REC_BWD_PERSIST) && uic_rnn_bwd_persist_eligible(dt, N, H, A, R); }
   int bwd_launches = 0;
   int bwd_steps(int t_lo, int t_hi, hipStream_t s) {

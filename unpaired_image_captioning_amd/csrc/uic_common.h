@@ -292,14 +292,24 @@ struct UicRnnFwdParams {
   unsigned dec_draw_seed;
 };
 size_t uic_rnn_persist_sync_bytes();
-// every persistent launch of this process on a device waits for the previous one (any stream): enter before, leave after
-int uic_persist_gate_enter(hipStream_t s);
-int uic_persist_gate_leave(hipStream_t s);
+// every persistent launch of this process on a device waits for the previous one (any stream).  enter .. leave is one critical
+// section per device (the device of the STREAM): enter takes the device's lock and makes `s` wait for the previous launch, leave
+// records this launch's event and releases the lock, abandon releases it on an error path.  Use the scope:
+int uic_persist_gate_enter(hipStream_t s, int* dev_out);
+int uic_persist_gate_leave(hipStream_t s, int dev);
+void uic_persist_gate_abandon(int dev);
+struct UicPersistGateScope {
+  hipStream_t s = nullptr; int dev = -1; bool held = false;
+  int enter(hipStream_t st) { s = st; const int rc = uic_persist_gate_enter(s, &dev); held = rc == 0; return rc; }
+  int leave() { held = false; return uic_persist_gate_leave(s, dev); }
+  ~UicPersistGateScope() { if (held) uic_persist_gate_abandon(dev); }
+};
 bool uic_rnn_decode_persist_eligible(int dtype, int N, int H, int A, int R, int E, int V1);
 size_t uic_rnn_decode_part_floats(int N);
 // after uic_rnn_fwd_persist_launch in decode mode: the reference's `if unfinished.sum() == 0: break` (AttModel.py:236-238) --
-// log-probs recorded at steps after every row had finished are zeroed (their tokens already are)
-int uic_rnn_decode_finish_launch(const int64_t* seq, float* seq_logp, int N, int L, int ld, hipStream_t s);
+// log-probs recorded at steps after every row had finished are zeroed (their tokens already are).  status (the caller's
+// rnn_status words or NULL): a timed-out persistent launch poisons the captions instead (token -1, log-prob NaN)
+int uic_rnn_decode_finish_launch(int64_t* seq, float* seq_logp, int N, int L, int ld, const int* status, hipStream_t s);
 int uic_rnn_decode_embed_relu_launch(const float* embed_w, void* out_bf16, int V1, int E, hipStream_t s);
 bool uic_rnn_persist_eligible(int dtype, int N, int H, int A, int R);
 int uic_rnn_fwd_persist_launch(const UicRnnFwdParams& p, hipStream_t s);
@@ -309,8 +319,10 @@ int uic_rnn_fwd_persist_launch(const UicRnnFwdParams& p, hipStream_t s);
 // d att_h), d h_att += d att_h W_h2att, att_lstm cell backward, d[h_lang_prev | h_att_prev] = dG1 W1rec -- the six dependent
 // launches per step of Step::bwd_step (topdown.hip).  Reads what the forward pass saved, writes what the weight-gradient
 // GEMMs and the deferred attention accumulation read afterwards (dg1_all, dg2_all, datth_all, de_all, the d ctx columns of
-// dx2_all); the gradients carried from step to step enter and leave through the buffers the launch chain uses
-// (dc_att, dc_lang, dx1, the h_lang columns of dx2_all[t_hi] / dx2_all[t_lo]), so chunks of steps may be run by either.
+// dx2_all); the gradients carried from step to step enter and leave through dc_att, dc_lang, dx1 and the h_lang columns of
+// dx2_all[t_hi] / dx2_all[t_lo] -- the buffers of the launch chain's UNSPLIT form only: once the chain splits its d x GEMMs
+// (Step::bptt_split() > 0, the default at 640 rows) it carries d h in its split-K slabs instead, so all chunks of one training
+// step have to be run by the same of the two (Step::bwd_persist_ok is constant within a step).
 struct UicRnnBwdParams {
   int N, R, t_lo, t_hi;
   int first;                         // 1: step t_hi - 1 is the last executed decode step (nothing carried in)
@@ -364,9 +376,10 @@ int uic_embed_fwd_launch(int dtype, const float* table, int V1, int E, const int
                          float drop_p, unsigned seed, unsigned site, size_t idx_base, int relu, void* out, hipStream_t s);
 int uic_embed_bwd_launch(int dtype, const float* dxt, const void* xt, const int64_t* tokens, int ldtok, int N, int T,
                          int V1, int E, float drop_p, long skip_token, float* dtable, hipStream_t s);   // skip_token < 0: none (nn.Embedding padding_idx otherwise)
-// the same with the positions bucketed by token first, so that runs of equal tokens are summed in registers and a hot token
-// (padding) costs 1/16 of the contended atomics: dtable is overwritten; scratch = uic_embed_bwd_sorted_scratch_ints(N, T, V1) ints
-size_t uic_embed_bwd_sorted_scratch_ints(int N, int T, int V1);
+// the same with the positions bucketed by token first (a stable counting sort), so that runs of equal tokens are summed in
+// registers and every table row is STORED by one owner in a fixed order -- no floating-point atomics, bit-reproducible:
+// dtable is overwritten; scratch = uic_embed_bwd_sorted_scratch_ints(N, T, V1, E) ints
+size_t uic_embed_bwd_sorted_scratch_ints(int N, int T, int V1, int E);
 int uic_embed_bwd_sorted_launch(int dtype, const float* dxt, const void* xt, const int64_t* tokens, int ldtok, int N, int T,
                                 int V1, int E, float drop_p, long skip_token, float* dtable, int* scratch, hipStream_t s);
 // the two halves of it: `prepare` needs only the tokens (zeroes dtable, buckets the positions), `gather` the gradients.
@@ -375,7 +388,7 @@ int uic_embed_bwd_sorted_launch(int dtype, const float* dxt, const void* xt, con
 int uic_embed_bwd_sorted_prepare(const int64_t* tokens, int ldtok, int N, int T, int V1, int E, float* dtable, int* scratch, hipStream_t s,
                                  int split = 0);
 int uic_embed_bwd_sorted_gather(int dtype, const float* dxt, const void* xt, const int64_t* tokens, int ldtok, int N, int T,
-                                int V1, int E, float drop_p, long skip_token, float* dtable, const int* scratch, hipStream_t s,
+                                int V1, int E, float drop_p, long skip_token, float* dtable, int* scratch, hipStream_t s,
                                 int split = 0, int half = 0);
 // column sums of a small f32 [rows, ncols] matrix into two destinations (columns [0, n0) -> out0, the rest -> out1), one launch
 int uic_colsum_small_launch(const float* part, int rows, int ncols, int n0, float* out0, float* out1, hipStream_t s);
@@ -477,6 +490,9 @@ struct UicAdamParams {
   // clip_grad_norm (P/misc/optimizer.py:99): if sqnorm != null, gradients are additionally scaled by
   // min(1, max_norm / (grad_scale * sqrt(sqnorm[0]) + 1e-6)), read on the device (no host sync)
   float max_norm; const float* sqnorm;
+  // uic_adam_step_guarded: if guard != null and guard[0] != 0 (any bit set: an int32 status word or a float sum of them), the
+  // launch changes nothing -- parameters and moments stay those of before the step
+  const int32_t* guard;
 };
 // out[0] = sum_i g[i]^2, deterministic two-stage reduction; scratch >= 1024 floats
 int uic_sqnorm_launch(const float* g, size_t n, float* scratch, float* out, hipStream_t s);

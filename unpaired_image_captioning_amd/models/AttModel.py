@@ -347,7 +347,15 @@ class AttModel(CaptionModel):
             return _TopDownSample.apply(self, fc, att, am, kw, *params)
         with torch.no_grad():
             pd = {k: v.detach() for k, v in self.param_dict().items()}
-            return self.engine.sample(pd, fc, att, am, self.seq_length, seed=self.next_seed(), training=self.training, **kw)
+            out = self.engine.sample(pd, fc, att, am, self.seq_length, seed=self.next_seed(), training=self.training, **kw)
+        # A lone decode pass is ONE persistent launch (csrc/rnn_persist.hip) whose bounded spin gives up if its workgroups
+        # cannot all become resident (another process on the GPU): the library then poisons the captions (token -1, log-prob
+        # NaN) and sets the status word.  Callers of this path read the captions back at once (eval_utils.eval_split), so the
+        # word is checked HERE -- one 16-byte read-back -- and a time-out raises at the call that suffered it.
+        # `defer_status_check = True`: the caller checks at its own host sync (Trainer's self-critical step, timing loops).
+        if not getattr(self, 'defer_status_check', False):
+            _lib.persistent_status(out[0].device)
+        return out
 
 
 class TopDownModel(AttModel):

@@ -37,6 +37,10 @@ class _DiscFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dlogits):
         lib = _lib.load()
+        if ctx.ws is None:
+            # the activations went back to the workspace pool after the first backward (they may already belong to another forward)
+            raise RuntimeError("the discriminator's activations are released by its first backward: a second backward over the same "
+                               "graph (retain_graph=True) needs a new forward" )
         params = ctx.saved_tensors
         module = ctx.module
         grads = [torch.empty_like(p) for p in params]

@@ -34,6 +34,10 @@ class _GcnFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dout):
         lib = _lib.load()
+        if ctx.ws is None:
+            # the activations went back to the workspace pool after the first backward (they may already belong to another forward)
+            raise RuntimeError("the scene-graph encoder's activations are released by its first backward: a second backward over the same "
+                               "graph (retain_graph=True) needs a new forward" )
         params = ctx.saved_tensors
         module = ctx.module
         grads = [torch.empty_like(p) for p in params]

@@ -212,13 +212,58 @@ class Trainer(object):
             self.exchange.allreduce_sum_overlapped(
                 self.arena.grad, getattr(self, 'arena_splits', []) if hasattr(self.i2t_model, 'use_bn') else [],
                 lambda raw, g: check(lib.uic_topdown_grad_ready_wait(raw, g), "grad_ready_wait"))
-        self._step += 1
-        a = self.arena
-        check(_lib.load().uic_adam_step(ptr(a.flat), ptr(a.grad), ptr(a.exp_avg), ptr(a.exp_avg_sq), a.numel,
-                                        self.i2t_current_lr, self.betas[0], self.betas[1], self.eps, self._step, 1.0,
-                                        stream()), "adam_step")
+        loss = self._guarded_adam(loss, 1.0)
         self.last_loss = loss
         return loss
+
+    def _guarded_adam(self, loss, grad_scale):
+        """Adam on the flat arena, skipped ON THE DEVICE if a persistent recurrence launch of this step timed out
+        (uic_adam_step_guarded reads the status word the kernels set): a bad step never reaches the weights or the moments.
+        Data parallel: [loss, status] travel in ONE 2-float all-reduce issued after the gradient exchange, so the returned loss
+        is the sum over the ranks and every rank skips (and later raises, _finish_step) together.  Returns the loss, a device
+        scalar."""
+        a = self.arena
+        self._step += 1
+        has_eng = getattr(self.i2t_model, 'engine', None) is not None
+        status = _lib.status_words(a.flat.device) if has_eng else None
+        self._guard_pair = None
+        if self.exchange.world_size > 1:
+            flag = status[0:1].float() if status is not None else loss.new_zeros(1)
+            pair = torch.cat([loss.detach().float().reshape(1), flag])
+            self.exchange._sum(pair)
+            self._guard_pair = pair
+            guard, loss = pair[1:], pair[0]
+        else:
+            guard = status
+        check(_lib.load().uic_adam_step_guarded(ptr(a.flat), ptr(a.grad), ptr(a.exp_avg), ptr(a.exp_avg_sq), a.numel,
+                                                self.i2t_current_lr, self.betas[0], self.betas[1], self.eps, self._step,
+                                                grad_scale, ptr(guard), stream()), "adam_step_guarded")
+        return loss
+
+    def _finish_step(self, loss):
+        """The step's ONE host sync (the reference's loss.item(), P/trainer.py:172): returns the loss as a float and raises --
+        on every rank of a data-parallel run -- if a persistent launch of the step timed out (another process on the GPU, a
+        long kernel on another stream).  The update was then already skipped on the device (_guarded_adam): weights, moments
+        and the step counter are those of before the step, and training can go on after the caller has dealt with the cause
+        (engine.recurrence |= _lib.REC_FWD_CHAIN selects per-step launches, which cannot time out)."""
+        pair = getattr(self, '_guard_pair', None)
+        self._guard_pair = None
+        try:
+            if pair is not None:
+                vals = pair.cpu().tolist()
+                if vals[1] != 0:
+                    raise RuntimeError("persistent recurrence kernel timed out on some rank: this step's update was skipped on every rank")
+                _lib.persistent_status()                        # (clears nothing: the local word is zero too)
+                return vals[0]
+            val = loss.item()
+            if getattr(self.i2t_model, 'engine', None) is not None:
+                _lib.persistent_status()                        # raises and clears the word if the launch timed out
+            return val
+        except RuntimeError:
+            if getattr(self.i2t_model, 'engine', None) is not None:
+                _lib.status_words().zero_()
+            self._step -= 1                                     # the skipped step does not count for Adam's bias correction
+            raise
 
     def prefetch(self, data, per_image=True):
         """Ship a batch to the device on a copy stream NOW (pinned staging + asynchronous H2D), to be consumed by the next
@@ -260,21 +305,11 @@ class Trainer(object):
         T = labels_np.shape[1] - 1
         den_local = float(np.asarray(data["masks"])[:, 1:T + 1].sum())
         batch = self._device_batch(data)
-        loss = self.train_device_batch(batch, t_run, den_local)
-        loss = self.exchange.allreduce_sum_scalar(loss)
+        loss = self.train_device_batch(batch, t_run, den_local)       # (already summed over the ranks)
         if next_data is not None:
             self.prefetch(next_data)
-        self.i2t_train_loss = loss.item()          # the reference's per-step host sync (trainer.py:172)
-        self._check_persistent()
+        self.i2t_train_loss = self._finish_step(loss)     # the reference's per-step host sync (trainer.py:172)
         return self.i2t_train_loss
-
-    def _check_persistent(self):
-        """At the step's host sync: did a persistent recurrence launch of this step give up waiting for its workgroups
-        (another process on the GPU, a long kernel on another stream)?  Its results -- and so this step's update -- are then
-        invalid: raise instead of training on them (persistent_status clears the word; set engine.recurrence to
-        _lib.REC_FWD_CHAIN to continue with per-step launches)."""
-        if getattr(self.i2t_model, 'engine', None) is not None:
-            _lib.persistent_status()
 
     def _scst_decode(self, model, eng, fc, att, am, S, overlap, cur):
         """The sampling pass (train mode) and the greedy baseline (eval mode, P/misc/rewards.py:42-47) of the self-critical
@@ -345,9 +380,12 @@ class Trainer(object):
             rec0 = getattr(eng, 'recurrence', 0)
             if eng is not None and not persistent:
                 eng.recurrence = rec0 | _lib.REC_FWD_CHAIN
+            defer0 = getattr(model, 'defer_status_check', False)
+            model.defer_status_check = True               # (no host sync between the passes: _finish_step reads the status word)
             try:
                 gen_result, sample_logprobs, greedy_res = self._scst_decode(model, eng, fc, att, am, S, overlap, cur)
             finally:
+                model.defer_status_check = defer0
                 if eng is not None:
                     eng.recurrence = rec0
             if reward_fn is None:
@@ -383,18 +421,14 @@ class Trainer(object):
             if params[k].grad is not view:
                 view.copy_(params[k].grad)
         self.exchange.allreduce_sum(self.arena.grad)
-        self._step += 1
-        a = self.arena
         scale = 1.0 / self.exchange.world_size                           # per-rank means -> global mean
-        check(_lib.load().uic_adam_step(ptr(a.flat), ptr(a.grad), ptr(a.exp_avg), ptr(a.exp_avg_sq), a.numel,
-                                        self.i2t_current_lr, self.betas[0], self.betas[1], self.eps, self._step, scale,
-                                        stream()), "adam_step")
+        loss_d = self._guarded_adam(loss.detach(), scale)
         avg = reward_t[:, 0].mean()
         if next_data is not None:
             self.prefetch(next_data)              # the next batch crosses PCIe while this step computes (see train)
-        self.i2t_train_loss = loss.item()
+        val = self._finish_step(loss_d)
+        self.i2t_train_loss = val * scale if self.exchange.world_size > 1 else val      # (the mean over the ranks of their per-rank means)
         self.i2t_avg_reward = float(avg.item())
-        self._check_persistent()
         return self.i2t_train_loss
 
     # ------------------------------------------------------------------ sentence discriminator (BASELINE configs[3]; parity unpinned)
