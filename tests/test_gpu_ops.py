@@ -72,6 +72,55 @@ def test_linear(dt, shape, flags):
     assert rel_err(Cd, ref) < TOL[dt]
 
 
+FORCE_128, FORCE_256, FORCE_192, FORCE_PP128 = 0x100, 0x200, 0x400, 0x800
+
+
+@pytest.mark.parametrize("shape", [(256, 256, 128), (300, 260, 256), (2304, 512, 2048), (10880, 512, 512), (1, 4, 384), (777, 1028, 640)])
+@pytest.mark.parametrize("flags", [0, 1, 4, 6, 2])
+@pytest.mark.parametrize("FORCE_PP", [FORCE_256, FORCE_192, FORCE_PP128])
+def test_linear_256_tile_kernel_equals_the_128_tile_kernel_and_torch(shape, flags, FORCE_PP):
+    """The ping-pong GEMM (csrc/gemm_pp.hip; 256 / 192 / 128-row x 256-column tiles), forced per call, against plain torch on the
+    bf16-rounded operands AND against the 128 x 128 LDS-DMA kernel on the same operands: one tile exactly, ragged row / column
+    tiles (clamped source rows, guarded stores), 2 / 4 / 6 / 8 / 10 / 32 K tiles (prologue + last-iteration forms of its
+    pipeline), f32 and bf16 outputs, bias, ReLU, accumulate.  Repeated launches must agree bit for bit (a staged buffer read one
+    phase early would not)."""
+    L = _lib()
+    lib = L.load()
+    M, N, K = shape
+    g = torch.Generator().manual_seed(M * 31 + N * 7 + K + flags)
+    A = torch.randn(M, K, generator=g)
+    B = torch.randn(N, K, generator=g) / K ** 0.5
+    bias = torch.randn(N, generator=g)
+    C0 = torch.randn(M, N, generator=g)
+    out_f32 = bool(flags & 4)
+    Ad, Bd, bd = dev(A, 1), dev(B, 1), dev(bias)
+    outs = []
+    for force in (FORCE_PP, FORCE_PP, FORCE_128):
+        Cd = C0.clone().cuda() if out_f32 else C0.clone().cuda().bfloat16()
+        L.check(lib.uic_linear(1, M, N, K, L.ptr(Ad), K, L.ptr(Bd), K, L.ptr(Cd), N, L.ptr(bd), flags | force, L.stream()))
+        torch.cuda.synchronize()
+        outs.append(Cd)
+    ref = rounded(A, 1).double() @ rounded(B, 1).double().t() + bias.double()
+    if flags & 1:
+        ref = torch.relu(ref)
+    if flags & 2:
+        ref = ref + (C0 if out_f32 else rounded(C0, 1)).double()
+    assert torch.equal(outs[0], outs[1])
+    tol = 2e-5 if out_f32 else 1e-2
+    assert rel_err(outs[0], ref.float()) < tol
+    assert rel_err(outs[0], outs[2].float()) < tol
+
+
+def test_linear_256_tile_kernel_rejects_what_it_cannot_run():
+    L = _lib()
+    lib = L.load()
+    x = torch.zeros(256, 256, device="cuda", dtype=torch.bfloat16)
+    o = torch.zeros(256, 256, device="cuda")
+    assert lib.uic_linear(1, 256, 256, 64, L.ptr(x), 64, L.ptr(x), 64, L.ptr(o), 256, None, 4 | FORCE_256, L.stream()) < 0      # one K tile
+    assert lib.uic_linear(1, 256, 256, 192, L.ptr(x), 192, L.ptr(x), 192, L.ptr(o), 256, None, 4 | FORCE_256, L.stream()) < 0   # odd tile count
+    assert lib.uic_linear(0, 256, 256, 128, L.ptr(o), 128, L.ptr(o), 128, L.ptr(o), 256, None, 4 | FORCE_256, L.stream()) < 0   # f32 operands
+
+
 @pytest.mark.parametrize("dt", [0, 1])
 def test_linear_strided_operands(dt):
     """Column blocks of wider matrices: lda/ldb/ldc larger than the logical widths (weight_ih column blocks)."""

@@ -24,7 +24,7 @@ def timeit(fn, iters=24):
 
 
 g = torch.Generator(device="cuda").manual_seed(3)
-print("%-44s %10s %10s %10s %10s" % ("NT shape  C[M,N] = A[M,K] B[N,K]^T", "lib us", "lib TF/s", "uic us", "uic TF/s"))
+print("%-44s %9s %9s %9s %9s %9s %9s %9s %9s" % ("NT shape  C[M,N] = A[M,K] B[N,K]^T", "lib us", "lib TF/s", "uic us", "uic TF/s", "128x128", "pp 256", "pp 192", "pp 128"))
 for name, M, N, K in [("logit fwd chunk", 2560, 9488, 512), ("att_embed fwd", 23040, 512, 2048), ("ctx2att fwd", 23040, 512, 512),
                       ("Gx batched input GEMM", 10880, 2048, 1024), ("d xt", 10880, 512, 2048), ("logit dX chunk", 2560, 512, 9536),
                       ("BPTT d x2 (one step)", 640, 1536, 2048), ("BPTT d x1 (one step)", 640, 1024, 2048), ("BPTT h2att (one step)", 640, 512, 512)]:
@@ -39,7 +39,14 @@ for name, M, N, K in [("logit fwd chunk", 2560, 9488, 512), ("att_embed fwd", 23
     rows = torch.arange(0, M, max(1, M // 512), device="cuda")
     ref = A[rows].float() @ B.float().t()
     err = float((Cu[rows][:, :N] - ref).abs().max() / ref.abs().max())
-    print("%-44s %10.1f %10.1f %10.1f %10.1f   max rel err %.1e" % ("%s %dx%dx%d" % (name, M, N, K), t_lib, fl / t_lib / 1e6, t_uic, fl / t_uic / 1e6, err))
+    # the two large-GEMM kernels forced per call (UIC_GEMM_FORCE_128 / _256): which one the dispatcher should pick for the shape
+    t128 = timeit(lambda: L.check(lib.uic_linear(1, M, N, K, L.ptr(A), K, L.ptr(B), K, L.ptr(Cu), ldc, L.ptr(bias), 4 | 0x100, L.stream())))
+    tpp = [float("nan")] * 3
+    if K % 128 == 0 and N % 4 == 0:
+        for i, force in enumerate((0x200, 0x400, 0x800)):
+            tpp[i] = timeit(lambda: L.check(lib.uic_linear(1, M, N, K, L.ptr(A), K, L.ptr(B), K, L.ptr(Cu), ldc, L.ptr(bias), 4 | force, L.stream())))
+            err = max(err, float((Cu[rows][:, :N] - ref).abs().max() / ref.abs().max()))
+    print("%-44s %9.1f %9.1f %9.1f %9.1f %9.1f %9.1f %9.1f %9.1f   max rel err %.1e" % ("%s %dx%dx%d" % (name, M, N, K), t_lib, fl / t_lib / 1e6, t_uic, fl / t_uic / 1e6, t128, tpp[0], tpp[1], tpp[2], err))
 print("%-44s %10s %10s" % ("NT split-K partials (uic_linear_partials)", "uic us", "uic TF/s"))
 for name, M, N, K, sk in [("BPTT d x2, 4 slices", 640, 1536, 2048, 4), ("BPTT d x2, 2 slices", 640, 1536, 2048, 2), ("BPTT d x2, 8 slices", 640, 1536, 2048, 8),
                           ("BPTT d x1, 4 slices", 640, 1024, 2048, 4), ("BPTT d x1, 8 slices", 640, 1024, 2048, 8),

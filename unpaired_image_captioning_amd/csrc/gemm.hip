@@ -720,6 +720,18 @@ int launch_cfg(const UicGemmParams& p, hipStream_t s) {
   return UIC_OK;
 }
 
+// Where the ping-pong kernel (gemm_pp.hip) is the faster of the two large-GEMM kernels.  It holds one workgroup per CU, so it needs
+// enough tiles of its best height (uic_gemm_pp_rows) to cover most of the 256 CUs; measured (profiles/r04_*_gemm_headroom.txt,
+// us, 128 x 128 kernel -> ping-pong): att_embed 23040 x 512 x 2048 66 -> 47.5 (192 rows), ctx2att 23040 x 512 x 512 29 -> 23,
+// Gx 10880 x 2048 x 1024 70 -> 57, d xt 10880 x 512 x 2048 42 -> 32 (128 rows), logit chunk 2560 x 9488 x 512 50 -> 49; the
+// BPTT loop's 640-row GEMMs (18-36 tiles) lose 2-3x and stay on the 128 x 128 / skinny kernels.
+inline bool uic_gemm_pp_wins(const UicGemmParams& p) {
+  if (!uic_gemm_pp_eligible(p) || p.seg[0].K < 512) return false;
+  const int rows = uic_gemm_pp_rows(p.M, p.N);
+  const long tiles = (long)((p.M + rows - 1) / rows) * ((p.N + 255) / 256) * (p.splitk > 1 ? p.splitk : 1);
+  return tiles >= 160;
+}
+
 template <typename T>
 int launch_typed(const UicGemmParams& p, hipStream_t s) {
   // skinny problems (the per-decode-step GEMMs, M = rows of one step): 64-row tiles with a 4-way in-block K split
@@ -729,6 +741,10 @@ int launch_typed(const UicGemmParams& p, hipStream_t s) {
   if (p.lstm) return launch_cfg<T, 1, 4, 2, 1, 4, true>(p, s);
   const long blocks128 = (long)((p.M + 127) / 128) * ((p.N + 127) / 128);
   const bool glds_ok = p.nseg == 1 && p.seg[0].K % (128 / (int)sizeof(T)) == 0;
+  if (p.flags & UIC_GEMM_FORCE_256) return uic_gemm_pp_launch(p, 256, s);
+  if (p.flags & UIC_GEMM_FORCE_192) return uic_gemm_pp_launch(p, 192, s);
+  if (p.flags & UIC_GEMM_FORCE_PP128) return uic_gemm_pp_launch(p, 128, s);
+  if (!(p.flags & UIC_GEMM_FORCE_128) && uic_gemm_pp_wins(p)) return uic_gemm_pp_launch(p, 0, s);
   if (p.slab) {
     UIC_REQUIRE(glds_ok && !p.lstm, "gemm: slab output needs one K segment that is a multiple of 128 bytes");
     return launch_glds<T>(p, s);

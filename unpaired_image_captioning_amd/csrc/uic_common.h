@@ -148,6 +148,12 @@ extern thread_local int g_uic_tn_ring_off;
 #define UIC_GEMM_ACCUM 2     // C += v
 #define UIC_GEMM_OUT_F32 4   // C is float regardless of the operand dtype
 #define UIC_GEMM_TANH 8      // v = tanh(v)
+// kernel choice for the large-GEMM path, per call (measurement tools; 0 = the dispatcher's own choice):
+#define UIC_GEMM_FORCE_128 0x100   // the 128 x 128 LDS-DMA kernel (gemm.hip)
+#define UIC_GEMM_FORCE_256 0x200   // the ping-pong kernel (gemm_pp.hip), 256-row tile; an ineligible problem is an error
+#define UIC_GEMM_FORCE_192 0x400   // the same with its 192-row tile
+#define UIC_GEMM_FORCE_PP128 0x800 // the same with its 128-row tile (128 x 256)
+#define UIC_GEMM_FORCE_MASK 0xF00
 #define UIC_GEMM_MAX_SEG 4
 
 // One K-segment: C += A[M,K] * B[Nrows,K]^T.  Segments are summed, which expresses
@@ -193,6 +199,10 @@ int uic_splitk_reduce_launch(const float* slab, int splitk, int M, int N, int co
 bool uic_gemm_glds_eligible(int dtype, int K);
 
 int uic_gemm_launch(const UicGemmParams& p, hipStream_t stream);
+// the 256 x 256 x 64 ping-pong kernel (gemm_pp.hip): bf16, one K segment, K a multiple of 128 per split-K slice
+bool uic_gemm_pp_eligible(const UicGemmParams& p);
+int uic_gemm_pp_rows(int M, int N);
+int uic_gemm_pp_launch(const UicGemmParams& p, int rows, hipStream_t stream);
 
 // ---------------------------------------------------------------- TN GEMM (gemm_tn.hip): C[i,j] = sum_k A[k,i] B[k,j]
 #define UIC_GEMM_TN_MAX_SEG 4
