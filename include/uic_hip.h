@@ -348,6 +348,12 @@ typedef struct uic_nmt_dims {
   int32_t Vs, Vt;   /* source / target dictionary sizes */
   int32_t dtype;
   float drop_p;     /* opt.dropout */
+  /* how the decoder's target-step loop is launched (as uic_topdown_dims.recurrence / .rnn_status): 0 = ONE persistent launch
+   * (csrc/nmt_persist.hip) where the shapes allow -- bf16, rnn_size 512, source length <= 64 --, UIC_REC_FWD_CHAIN = layers + 2
+   * launches per step, UIC_REC_SAFE = the placement-independent exchange protocol; rnn_status: 4 caller-zeroed uint32 status
+   * words on the device (word 0 != 0: a bounded spin gave up, the outputs are invalid) or NULL */
+  int32_t recurrence;
+  uint32_t* rnn_status;
 } uic_nmt_dims;
 
 typedef struct uic_nmt_weights {     /* keys of NMTModel.state_dict() + generator (P/trainer.py:85-89) */

@@ -490,3 +490,44 @@ def test_nmt_configs2_full_size_vs_oracle(dtype):
         worst = max(worst, err)
         assert err < tol, (k, err)
     print("configs[2] full size %s: loss %.4f (oracle %.4f), worst per-tensor L2 gradient error %.3e" % (dtype, loss.item(), ref_loss.item(), worst))
+
+
+@pytest.mark.parametrize("shape", [dict(B=64, S=30, T=31), dict(B=5, S=7, T=9), dict(B=128, S=64, T=6), dict(B=37, S=1, T=4), dict(B=161, S=20, T=5)])
+def test_persistent_decoder_launch_equals_the_launch_chain(shape):
+    """bf16, rnn_size 512: NMT_Models.Decoder.forward's target-step loop (P/models/NMT_Models.py:228-262) as ONE persistent
+    launch (csrc/nmt_persist.hip) against the layers + 2 launches per step it replaces -- decoder outputs, attention, loss and
+    every gradient (the backward pass reads what either form left in the workspace: gates, states, dropped copies, contexts), with
+    training-mode dropout 0.3 (same sites, same masks): configs[2]'s batch (8 rows per XCD group, the weight-stationary kernel), 5
+    rows (groups without rows), 128 rows (full 16-row tiles) with the longest source the kernels take (64), a one-word source, and
+    161 rows (the generic kernel: 21 rows per group, weights re-read every step).  The two forms differ by
+    bf16 summation order only; the placement-independent SAFE protocol must give the persistent launch's results bit for bit."""
+    from unpaired_image_captioning_amd import _lib as Lb
+    cfg = dict(layers=2, H=512, W=512, Vs=300, Vt=260, **shape)
+    W = random_weights(cfg, 11, 0.08)
+    I = synthetic(cfg, 12)
+    res = {}
+    for mode, flags in (("chain", Lb.REC_FWD_CHAIN), ("persistent", 0), ("safe", Lb.REC_SAFE)):
+        model, crit = build(cfg, W, "bf16", dropout=0.3, seed=5)
+        model.train()
+        model.engine.recurrence = flags
+        before = Lb.persistent_status()
+        outputs, attn, loss = run(model, crit, I)
+        after = Lb.persistent_status()
+        launches = (after[1] - before[1], after[2] - before[2])
+        assert launches == {"chain": (0, 0), "persistent": (1, 0), "safe": (0, 1)}[mode], (mode, launches)
+        loss.backward()
+        res[mode] = (outputs.detach().float().cpu(), attn.detach().float().cpu(), loss.item(),
+                     {k: p.grad.detach().float().cpu() for k, p in model.named_parameters()})
+    oc, ac, lc, gc = res["chain"]
+    op, ap, lp, gp = res["persistent"]
+    os_, as_, ls, gs = res["safe"]
+    assert torch.equal(op, os_) and torch.equal(ap, as_) and lp == ls
+    for k in gp:
+        assert torch.equal(gp[k], gs[k]), k
+    nw = int((I["tgt"][1:] != 0).sum())
+    assert (op - oc).abs().max().item() < OUT_TOL["bf16"] and (ap - ac).abs().max().item() < OUT_TOL["bf16"]
+    assert abs(lp - lc) < 2e-3 * nw
+    big = max(float(v.norm()) for v in gc.values())
+    for k in gc:
+        err = ((gp[k].double() - gc[k].double()).norm() / max(gc[k].double().norm().item(), 1e-3 * big)).item()
+        assert err < 5e-2, (k, err)

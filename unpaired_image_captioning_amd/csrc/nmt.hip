@@ -534,6 +534,8 @@ struct NmtLayout {
   // dx_lstm[l]: d[x_l | h_l(t-1)] of decoder layer l > 0, one buffer per layer so that nothing has to be copied
   float* dx_lstm[ML]; float* d_lay; float* dhrec_e; float* dc_e; float* dhrec_e1; float* dc_e1; float* dx_e; void* dpre_e; float* dxe; float* demb_d;
   void* tA; void* tB; float* colscratch; size_t colscratch_floats; float* slab; size_t slab_bytes;
+  unsigned* rnn_sync;          // nmt_persist.hip's registration / barrier counters
+  int* embed_scratch;          // uic_embed_bwd_sorted_launch (both embedding tables, one after the other)
   size_t total;
 };
 
@@ -627,6 +629,11 @@ NmtLayout nmt_layout(const uic_nmt_dims& d, const uic_nmt_weights* w, void* ws) 
   L.colscratch = (float*)b.take(L.colscratch_floats * 4);
   L.slab_bytes = 4 * (4 * H) * (W + 2 * H) * 4;
   L.slab = (float*)b.take(L.slab_bytes);
+  L.rnn_sync = (unsigned*)b.take(uic_rnn_persist_sync_bytes());
+  {
+    const size_t es = uic_embed_bwd_sorted_scratch_ints((int)(S * B), 1, d.Vs, (int)W), ed = uic_embed_bwd_sorted_scratch_ints((int)(Td * B), 1, d.Vt, (int)W);
+    L.embed_scratch = (int*)b.take((es > ed ? es : ed) * 4);
+  }
   L.total = (b.off + 255) & ~(size_t)255;
   return L;
 }
@@ -833,6 +840,24 @@ struct Nmt {
       g.C = L.ctxw; g.ldc = H; g.flags = UIC_GEMM_OUT_F32;
       UIC_TRY(uic_gemm_launch(g, s));
     }
+    if (!(d.recurrence & UIC_REC_FWD_CHAIN) && uic_nmt_dec_persist_eligible(dt, B, S, H, NL)) {
+      // the whole target-step loop as ONE persistent launch (nmt_persist.hip): same buffers, same dropout sites
+      UicNmtDecParams p;
+      memset(&p, 0, sizeof(p));
+      p.B = B; p.S = S; p.Td = Td; p.NL = NL;
+      p.out_all = L.out_all; p.out_pre = L.out_pre; p.gx_d0 = L.gx_d0;
+      for (int l = 0; l < NL; ++l) {
+        p.hd[l] = L.hd[l]; p.cd[l] = L.cd[l]; p.hdrop[l] = L.hdrop[l]; p.gates_d[l] = L.gates_d[l];
+        p.w_ih[l] = l == 0 ? off(L.dec_w_ih[0], W, dt) : L.dec_w_ih[l]; p.ld_ih[l] = l == 0 ? W + H : H;
+        p.w_hh[l] = L.dec_w_hh[l];
+        p.b_ih[l] = w->dec_b_ih[l]; p.b_hh[l] = w->dec_b_hh[l];
+      }
+      p.ctx = off(L.xl[NL], BH, dt); p.ctxw = L.ctxw; p.attn_all = L.attn_all; p.cvec_all = L.cvec_all; p.attn_out_w = L.attn_out_w;
+      p.drop_p = drop_p; p.seed = seed;
+      p.sync = L.rnn_sync; p.status = d.rnn_status; p.force_safe = (d.recurrence & UIC_REC_SAFE) != 0;
+      p.row0 = 0; p.Nrows = B;
+      return uic_nmt_dec_persist_launch(p, s);
+    }
     const size_t lds_att = sizeof(float) * ((size_t)H + S + 4 * (size_t)H);
     for (int t = 0; t < Td; ++t) {
       const void* x = nullptr;
@@ -1014,8 +1039,8 @@ struct Nmt {
       add_seg(g, L.dg_d[0], H4, L.dec_wT[0], H4, H4);
       g.C = L.demb_d; g.ldc = W; g.flags = UIC_GEMM_OUT_F32;
       UIC_TRY(uic_gemm_launch(g, s));
-      UIC_TRY(uic_fill_launch(G->dec_lut, 0, (size_t)Vt * W * 4, s));
-      UIC_TRY(uic_embed_bwd_launch(dt, L.demb_d, nullptr, L.tgt_in, 1, Md, 1, Vt, W, 0.f, 0, G->dec_lut, s));
+      // (bucketed by word, one owner per table row: bit-reproducible, no floating-point atomics -- csrc/pointwise.hip)
+      UIC_TRY(uic_embed_bwd_sorted_launch(dt, L.demb_d, nullptr, L.tgt_in, 1, Md, 1, Vt, W, 0.f, 0, G->dec_lut, L.embed_scratch, s));
     }
     // ---- deferred attention gradients: d context (direct share) and d ctxw, then linear_in through ctxw = context W_in:
     // dW_in = context^T d ctxw,  d context += d ctxw W_in^T
@@ -1118,8 +1143,7 @@ struct Nmt {
       g.C = L.dxe; g.ldc = W; g.flags = UIC_GEMM_OUT_F32;
       UIC_TRY(uic_gemm_launch(g, s));
     }
-    UIC_TRY(uic_fill_launch(G->enc_lut, 0, (size_t)Vs * W * 4, s));
-    return uic_embed_bwd_launch(dt, L.dxe, nullptr, src, 1, Ms, 1, Vs, W, 0.f, 0, G->enc_lut, s);
+    return uic_embed_bwd_sorted_launch(dt, L.dxe, nullptr, src, 1, Ms, 1, Vs, W, 0.f, 0, G->enc_lut, L.embed_scratch, s);
   }
 };
 

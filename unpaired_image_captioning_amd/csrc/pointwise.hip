@@ -276,31 +276,38 @@ __global__ void embed_block_prefix_kernel(int* __restrict__ cntb, int nkeys, int
   }
   cnt[key] = run;
 }
-// single workgroup: off[v] = exclusive prefix of cnt, off[V1] = total
+// single workgroup: off[v] = exclusive prefix of cnt, off[V1] = total.  Rows of 1024 consecutive keys (coalesced loads), each
+// scanned by wave shuffles + one LDS hop, with the running total carried from row to row (a thread that walked its own run of
+// ~50 consecutive keys -- strided loads, one at a time -- took 72 us on the pivot NMT's 100 008 keys).
 __global__ __launch_bounds__(1024) void embed_scan_kernel(const int* __restrict__ cnt, int V1, int* __restrict__ off) {
-  __shared__ int s_wave[16];
-  const int per = (V1 + 1023) / 1024;
-  const int lo = threadIdx.x * per, hi = min(V1, lo + per);
-  int sum = 0;
-  for (int v = lo; v < hi; ++v) sum += cnt[v];
+  __shared__ int s_wave[2][16];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  int incl = sum;                                  // inclusive scan of the per-thread sums: shuffles inside the wave, LDS across
+  int carry = 0;
+  int nxt = (int)threadIdx.x < V1 ? cnt[threadIdx.x] : 0;
+  for (int base = 0, it = 0; base < V1; base += 1024, ++it) {
+    const int v = base + threadIdx.x;
+    const int x = nxt;
+    if (base + 1024 < V1) nxt = v + 1024 < V1 ? cnt[v + 1024] : 0;     // (the next row's load passes behind this row's scan)
+    int incl = x;
 #pragma unroll
-  for (int o = 1; o < 64; o <<= 1) {
-    const int up = __shfl_up(incl, o, 64);
-    if (lane >= o) incl += up;
-  }
-  if (lane == 63) s_wave[wv] = incl;
-  __syncthreads();
-  int woff = 0, tot = 0;
+    for (int o = 1; o < 64; o <<= 1) {
+      const int up = __shfl_up(incl, o, 64);
+      if (lane >= o) incl += up;
+    }
+    int* sw = s_wave[it & 1];
+    if (lane == 63) sw[wv] = incl;
+    __syncthreads();
+    int woff = 0, tot = 0;
 #pragma unroll
-  for (int k = 0; k < 16; ++k) {
-    if (k < wv) woff += s_wave[k];
-    tot += s_wave[k];
+    for (int k = 0; k < 16; ++k) {
+      const int t = sw[k];
+      if (k < wv) woff += t;
+      tot += t;
+    }
+    if (v < V1) off[v] = carry + woff + incl - x;
+    carry += tot;
   }
-  int run = incl + woff - sum;
-  for (int v = lo; v < hi; ++v) { off[v] = run; run += cnt[v]; }
-  if (threadIdx.x == 0) off[V1] = tot;
+  if (threadIdx.x == 0) off[V1] = carry;
 }
 // perm[off[key] + (entries of earlier blocks) + (earlier entries of this block with the same key)] = position
 __global__ __launch_bounds__(EMB_BLK) void embed_fill_kernel(const int64_t* __restrict__ tokens, int ldtok, int N, int TS, int V1, int split,

@@ -149,4 +149,173 @@ __device__ __forceinline__ int setup_ctx(const P& p, char* scratch, Ctx& c) {
   return safe ? 2 : 1;
 }
 
+// ---------------------------------------------------------------------------------------------------
+// GEMM + LSTM-cell phase of the generic (weights re-read every step) persistent kernels: rnn_persist.hip's f32 / generic
+// captioner recurrence and nmt_persist.hip's pivot decoder.
+constexpr int NWAVE = 8;
+constexpr int NTH = NWAVE * 64;
+constexpr int HALF_T = 3;           // row tiles reduced per LDS pass (8 waves x 3 tiles x 4 gates x 1 KB = 96 KB)
+constexpr int LDS_BYTES = NWAVE * HALF_T * 4 * 1024;
+
+template <typename T> struct Mma;
+template <> struct Mma<bf16_t> {
+  static __device__ __forceinline__ f32x4 run(const u32x4& a, const u32x4& b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+  }
+};
+template <> struct Mma<float> {
+  // lane l holds A[row l&15][k0 + 4(l>>4) + j] in component j: four 16x16x4 products, K permuted identically for A and B
+  static __device__ __forceinline__ f32x4 run(const u32x4& a, const u32x4& b, f32x4 c) {
+    c = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.x), __uint_as_float(b.x), c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.y), __uint_as_float(b.y), c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.z), __uint_as_float(b.z), c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.w), __uint_as_float(b.w), c, 0, 0, 0);
+    return c;
+  }
+};
+
+// acc[i][g] += A_seg[rows of tile i, k-steps of this wave] * B_seg[rows brow(g), same k-steps]^T, summed over the segments.
+// A_seg: [nrow, HH] slab of the group's rows (row stride HH), exchanged data (sc1 loads).  B_seg: weight block, row
+// stride ldb elements, K contiguous.  GATES: column tile g = gate g of the workgroup's 16 units (weight row g*HH + u0 + c).
+template <typename T, int NSEG, int NCT, bool GATES>
+__device__ __forceinline__ void gemm_ksplit(const Ctx& c, f32x4 (&acc)[MT_MAX][NCT], const void* const (&Aseg)[NSEG],
+                                            const void* const (&Bseg)[NSEG], const int (&ldb)[NSEG]) {
+  constexpr int VEC = 16 / (int)sizeof(T);
+  constexpr int KE = 4 * VEC;                    // K elements per k-step
+  constexpr int SPS = HH / KE / NWAVE;           // k-steps of one wave per segment
+  constexpr int KPW = NSEG * SPS;
+  unsigned aoff[MT_MAX];
+#pragma unroll
+  for (int i = 0; i < MT_MAX; ++i) {
+    int r = 16 * i + c.l15;
+    r = r < c.nrow ? r : c.nrow - 1;             // rows past the group's share re-read its last row (results unused)
+    aoff[i] = (unsigned)((r * HH + c.lq * VEC) * (int)sizeof(T));
+  }
+  unsigned brow[NCT];
+#pragma unroll
+  for (int g = 0; g < NCT; ++g) brow[g] = (unsigned)((GATES ? g * HH : 0) + c.u0 + c.l15);
+
+  u32x4 fa[2][MT_MAX], fb[2][NCT];
+  auto load = [&](int buf, int s) {
+    const int sg = s / SPS;
+    const unsigned kk = (unsigned)((((s % SPS) * NWAVE + c.wave) * KE) * (int)sizeof(T));
+    const __amdgpu_buffer_rsrc_t ra = rsrc_of(Aseg[sg]);
+    const __amdgpu_buffer_rsrc_t rb = rsrc_of(Bseg[sg]);
+#pragma unroll
+    for (int g = 0; g < NCT; ++g)
+      fb[buf][g] = bload<false>(rb, (brow[g] * (unsigned)ldb[sg] + (unsigned)(c.lq * VEC)) * (unsigned)sizeof(T), kk);
+#pragma unroll
+    for (int i = 0; i < MT_MAX; ++i)
+      if (i < c.MT) fa[buf][i] = bload<true>(ra, aoff[i], kk);
+  };
+  // two k-steps of operands in flight per wave (8 waves x 2 x 9 KB per CU: enough to cover the L2 latency at the
+  // ~70 GB/s a CU takes in); the scheduling barriers keep hipcc from hoisting every k-step's loads to the top
+  load(0, 0);
+#pragma unroll
+  for (int s = 0; s < KPW; ++s) {
+    if (s + 1 < KPW) load((s + 1) & 1, s + 1);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int i = 0; i < MT_MAX; ++i)
+      if (i < c.MT) {
+#pragma unroll
+        for (int g = 0; g < NCT; ++g) acc[i][g] = Mma<T>::run(fa[s & 1][i], fb[s & 1][g], acc[i][g]);
+      }
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}
+
+template <int NCT>
+__device__ __forceinline__ void zero_acc(f32x4 (&acc)[MT_MAX][NCT]) {
+#pragma unroll
+  for (int i = 0; i < MT_MAX; ++i)
+#pragma unroll
+    for (int g = 0; g < NCT; ++g) acc[i][g] = f32x4{0.f, 0.f, 0.f, 0.f};
+}
+
+// One nn.LSTMCell (P/models/AttModel.py:434 / :441) for the group's rows and this workgroup's 16 units.
+// pre: gate pre-activations that do not depend on the recurrence, added per (row, gate, unit).
+template <typename T, bool SAFE, int NSEG, typename PreFn>
+__device__ __forceinline__ void lstm_phase(Ctx& c, const void* const (&Aseg)[NSEG], const void* const (&Bseg)[NSEG],
+                                           const int (&ldb)[NSEG], PreFn pre, const float* c_prev, float* c_out, T* h_out,
+                                           T* h_drop, T* gates_out, int N, float drop_p, unsigned seed, unsigned site) {
+  // the tile-owner threads fetch what the cell update needs before the GEMM: its latency hides behind the operand stream.
+  // (every address below is a uniform base + a 32-bit lane offset: no 64-bit per-lane pointers to keep alive)
+  const bool owner = c.wave < c.MT;
+  const unsigned u = (unsigned)(c.u0 + c.l15);
+  unsigned nn[4];
+  float pv[4][4], cp[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int rr = 16 * c.wave + 4 * c.lq + r;
+    nn[r] = (unsigned)((c.rbegin + (rr < c.nrow ? rr : c.nrow - 1)) * HH);
+  }
+  if (owner) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      cp[r] = c_prev[nn[r] + u];
+#pragma unroll
+      for (int g = 0; g < 4; ++g) pv[r][g] = pre(4u * nn[r] + (unsigned)(g * HH) + u, (unsigned)(g * HH) + u);
+    }
+  }
+  f32x4 acc[MT_MAX][4];
+  zero_acc<4>(acc);
+  gemm_ksplit<T, NSEG, 4, true>(c, acc, Aseg, Bseg, ldb);
+  if (c.dbg && c.tid == 0) c.dbg[8 + (NSEG == 2 ? 0 : 4)] = __builtin_amdgcn_s_memrealtime();
+  f32x4* red = (f32x4*)c.smem;      // [wave][tile in pass][gate][lane]
+  const float inv_keep = drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f;
+#pragma unroll
+  for (int pass = 0; pass < 2; ++pass) {
+    const int tb = pass * HALF_T;
+    if (tb >= c.MT) break;
+#pragma unroll
+    for (int i = 0; i < HALF_T; ++i) {
+      if (tb + i < MT_MAX && tb + i < c.MT) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) red[((c.wave * HALF_T + i) * 4 + g) * 64 + c.lane] = acc[tb + i][g];
+      }
+    }
+    __syncthreads();
+    if (c.dbg && c.tid == 0) c.dbg[9 + pass + (NSEG == 2 ? 0 : 4)] = __builtin_amdgcn_s_memrealtime();
+    if (owner && c.wave >= tb && c.wave < tb + HALF_T) {
+      f32x4 s[4];
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        s[g] = red[((0 * HALF_T + (c.wave - tb)) * 4 + g) * 64 + c.lane];
+#pragma unroll
+        for (int w = 1; w < NWAVE; ++w) s[g] += red[((w * HALF_T + (c.wave - tb)) * 4 + g) * 64 + c.lane];
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int rr = 16 * c.wave + 4 * c.lq + r;
+        if (rr < c.nrow) {
+          const unsigned o = nn[r] + u;                      // element (row n, unit u) of an [N, HH] slab
+          const float gi = uic_sigmoid_t<T>(s[0][r] + pv[r][0]);
+          const float gf = uic_sigmoid_t<T>(s[1][r] + pv[r][1]);
+          const float gg = uic_tanh<T>(s[2][r] + pv[r][2]);
+          const float go = uic_sigmoid_t<T>(s[3][r] + pv[r][3]);
+          const float cn = gf * cp[r] + gi * gg;
+          const float h = go * uic_tanh<T>(cn);
+          c_out[o] = cn;
+          st_x<SAFE>(h_out + o, h);
+          if (h_drop) {
+            float hd = h;
+            if (drop_p > 0.f) hd *= uic_drop_scale(seed, site, o, drop_p, inv_keep);
+            st_x<SAFE>(h_drop + o, hd);                      // (the pivot decoder's next layer reads it in the same launch)
+          }
+          if (gates_out) {
+            const unsigned og = 4u * nn[r] + u;              // read again only in the backward pass
+            __builtin_nontemporal_store(uic_from_f<T>(gi), gates_out + og);
+            __builtin_nontemporal_store(uic_from_f<T>(gf), gates_out + og + HH);
+            __builtin_nontemporal_store(uic_from_f<T>(gg), gates_out + og + 2 * HH);
+            __builtin_nontemporal_store(uic_from_f<T>(go), gates_out + og + 3 * HH);
+          }
+        }
+      }
+    }
+    __syncthreads();
+  }
+  (void)N;
+}
+
 }  // namespace

@@ -358,6 +358,30 @@ struct UicRnnBwdParams {
   unsigned long long* dbg; int dbg_T;   // optional [256][dbg_T][16] phase time stamps (100 MHz), indexed by absolute step
   unsigned* status;                  // sticky status words (uic_topdown_dims.rnn_status) or null
 };
+// nmt_persist.hip: the pivot decoder's target-step loop (NMT_Models.Decoder.forward, P/models/NMT_Models.py:228-262) as ONE launch.
+// All slabs are time-major [step][B][512] in the operand dtype (bf16) unless noted; layer 0's embedding share of the gates
+// (with both biases) comes precomputed in gx_d0, its weight_ih pointer is already offset to the input-feed columns.
+#define UIC_NMT_PERSIST_MAX_LAYERS 4
+struct UicNmtDecParams {
+  int B, S, Td, NL;
+  const void* out_all;               // [(Td + 1)] : slot t = the input feed of step t (slot 0 zeros), slot t + 1 = step t's output
+  void* out_pre;                     // [Td] tanh output before dropout (backward pass)
+  const float* gx_d0;                // [Td][B][4 x 512] f32
+  void* hd[UIC_NMT_PERSIST_MAX_LAYERS]; float* cd[UIC_NMT_PERSIST_MAX_LAYERS];         // [(Td + 1)] h (bf16) / c (f32), slot 0 = initial state
+  void* hdrop[UIC_NMT_PERSIST_MAX_LAYERS]; void* gates_d[UIC_NMT_PERSIST_MAX_LAYERS];  // [Td] dropped h between layers; activated gates [B][4 x 512]
+  const void* w_ih[UIC_NMT_PERSIST_MAX_LAYERS]; int ld_ih[UIC_NMT_PERSIST_MAX_LAYERS]; const void* w_hh[UIC_NMT_PERSIST_MAX_LAYERS];
+  const float* b_ih[UIC_NMT_PERSIST_MAX_LAYERS]; const float* b_hh[UIC_NMT_PERSIST_MAX_LAYERS];   // layers >= 1
+  const void* ctx; const float* ctxw;   // [S][B][512] encoder context (bf16) and context x W_in (f32)
+  float* attn_all;                   // [Td][B][S]
+  void* cvec_all;                    // [Td] attention context
+  const void* attn_out_w;            // [512][1024]
+  float drop_p; unsigned seed;
+  unsigned* sync;                    // uic_rnn_persist_sync_bytes() bytes (zeroed by the launcher)
+  unsigned* status; int force_safe;
+  int row0, Nrows;                   // 0, B
+};
+bool uic_nmt_dec_persist_eligible(int dtype, int B, int S, int H, int NL);
+int uic_nmt_dec_persist_launch(const UicNmtDecParams& p, hipStream_t s);
 bool uic_rnn_bwd_persist_eligible(int dtype, int N, int H, int A, int R);
 int uic_rnn_bwd_persist_launch(const UicRnnBwdParams& p, hipStream_t s);
 

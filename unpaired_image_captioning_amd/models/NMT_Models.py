@@ -133,7 +133,8 @@ class _NmtEngine(object):
         m = self.m
         return NmtDims(B=B, S=S, T=T, H=m.decoder.hidden_size, W=m.encoder.embeddings.word_vec_size, layers=m.encoder.layers,
                        Vs=m.encoder.embeddings.word_lut.num_embeddings, Vt=m.decoder.embeddings.word_lut.num_embeddings,
-                       dtype=self.dtype, drop_p=float(m.opt.dropout))
+                       dtype=self.dtype, drop_p=float(m.opt.dropout), recurrence=int(getattr(self, 'recurrence', 0)),
+                       rnn_status=_lib.status_words().data_ptr() if torch.cuda.is_available() else None)
 
     def workspace(self, d, device):
         key = (d.B, d.S, d.T, d.dtype)
