@@ -536,6 +536,7 @@ struct NmtLayout {
   void* tA; void* tB; float* colscratch; size_t colscratch_floats; float* slab; size_t slab_bytes;
   unsigned* rnn_sync;          // nmt_persist.hip's registration / barrier counters
   int* embed_scratch;          // uic_embed_bwd_sorted_launch (both embedding tables, one after the other)
+  float* dfeed_x; float* dq_att_x;   // [Td, B, H] f32: step-indexed exchange slabs of the persistent BPTT launch
   size_t total;
 };
 
@@ -630,6 +631,8 @@ NmtLayout nmt_layout(const uic_nmt_dims& d, const uic_nmt_weights* w, void* ws) 
   L.slab_bytes = 4 * (4 * H) * (W + 2 * H) * 4;
   L.slab = (float*)b.take(L.slab_bytes);
   L.rnn_sync = (unsigned*)b.take(uic_rnn_persist_sync_bytes());
+  L.dfeed_x = (float*)b.take(Td * B * H * 4);
+  L.dq_att_x = (float*)b.take(Td * B * H * 4);
   {
     const size_t es = uic_embed_bwd_sorted_scratch_ints((int)(S * B), 1, d.Vs, (int)W), ed = uic_embed_bwd_sorted_scratch_ints((int)(Td * B), 1, d.Vt, (int)W);
     L.embed_scratch = (int*)b.take((es > ed ? es : ed) * 4);
@@ -776,9 +779,35 @@ struct Nmt {
       g.C = offw(L.xl[0], (size_t)B * W, dt); g.ldc = W; g.bias = w->enc_lin_b; g.flags = UIC_GEMM_RELU;
       UIC_TRY(uic_gemm_launch(g, s));
     }
+    const bool enc_persist = !(d.recurrence & UIC_REC_FWD_CHAIN) && uic_nmt_enc_persist_eligible(dt, B, S, H);
     for (int l = 0; l < NL; ++l) {
       const int in = l == 0 ? W : H;
       UIC_TRY(uic_fill_launch(L.xl[l + 1], 0, (size_t)(S + 2) * BH * Sz, s));
+      if (enc_persist) {
+        // both directions' S recurrent steps as ONE persistent launch (nmt_persist.hip) behind the two batched input GEMMs
+        UicNmtEncParams p;
+        memset(&p, 0, sizeof(p));
+        p.B = B; p.S = S;
+        for (int st = 0; st < S; ++st) p.nb[st] = nb[st];
+        p.x_out = L.xl[l + 1];
+        for (int dd = 0; dd < 2; ++dd) {
+          UIC_TRY(uic_fill_launch(L.c_e[l][dd], 0, (size_t)(S + 2) * BHd * 4, s));
+          UicGemmParams g = gemm_base(dt, S * B, 4 * Hd);
+          add_seg(g, enc_in(l), in, L.enc_w_ih[l][dd], in, in);
+          g.C = L.gx_e[l][dd]; g.ldc = 4 * Hd; g.bias = w->enc_b_ih[l][dd]; g.bias2 = w->enc_b_hh[l][dd]; g.flags = UIC_GEMM_OUT_F32;
+          UIC_TRY(uic_gemm_launch(g, s));
+          p.w_hh[dd] = L.enc_w_hh[l][dd]; p.gx[dd] = L.gx_e[l][dd]; p.c[dd] = L.c_e[l][dd]; p.gates[dd] = L.gates_e[l][dd];
+        }
+        p.sync = L.rnn_sync; p.status = d.rnn_status; p.force_safe = (d.recurrence & UIC_REC_SAFE) != 0;
+        p.row0 = 0; p.Nrows = B;
+        UIC_TRY(uic_nmt_enc_fwd_persist_launch(p, s));
+        if (l + 1 < NL && drop_p > 0.f) {
+          UIC_TRY(uic_fill_launch(L.xd[l + 1], 0, (size_t)(S + 2) * BH * Sz, s));
+          NMT_T(dropout_apply_kernel, gridn((size_t)S * BH), 0, (const void*)off(L.xl[l + 1], BH, dt), (void*)offw(L.xd[l + 1], BH, dt),
+                (size_t)S * BH, drop_p, seed, SITE_NMT_ENC(l));
+        }
+        continue;
+      }
       // the layer's input and the zeroed output buffer are ready: the backward direction runs on the side stream
       NmtSide* ss = nullptr;
       UIC_TRY(nmt_side(&ss));
@@ -956,12 +985,31 @@ struct Nmt {
     UIC_TRY(uic_colsum_launch(dt, L.dlogits, Md, Vt, Vtp, G->gen_b, L.colscratch, L.colscratch_floats, ssg->stream));
     UIC_TRY(uic_check_hip(hipEventRecord(ssg->ev_done, ssg->stream), "hipEventRecord"));
     // ---- decoder BPTT
-    for (int l = 0; l < NL; ++l) {
+    const bool bptt_persist = !(d.recurrence & UIC_REC_FWD_CHAIN) && uic_nmt_dec_bwd_persist_eligible(dt, B, S, H, NL);
+    if (bptt_persist) {
+      // ONE persistent launch (nmt_persist.hip) instead of 7 launches per step.  It needs every CU (one 160 KB workgroup each), so
+      // the generator's weight gradient cannot run beside it: the main stream waits for the side stream first.
+      UIC_TRY(uic_check_hip(hipStreamWaitEvent(s, ssg->ev_done, 0), "hipStreamWaitEvent"));
+      UicNmtDecBwdParams p;
+      memset(&p, 0, sizeof(p));
+      p.B = B; p.S = S; p.Td = Td;
+      p.d_out_all = L.d_out_all; p.out_pre = L.out_pre; p.d_pre_all = L.d_pre_all; p.d_cq_all = L.d_cq_all;
+      p.attn_all = L.attn_all; p.ctx = off(L.xl[NL], BH, dt); p.ctxw = L.ctxw; p.dscore_all = L.dscore_all;
+      for (int l = 0; l < 2; ++l) { p.gates_d[l] = L.gates_d[l]; p.cd[l] = L.cd[l]; p.dg_d[l] = L.dg_d[l]; p.dc_init[l] = L.dcd[l]; }
+      p.woutT = L.attn_out_wT; p.w1T = L.dec_wT[1]; p.w0T = off(L.dec_wT[0], (size_t)W * H4, dt);
+      p.dfeed_x = L.dfeed_x; p.dq_att_x = L.dq_att_x;
+      p.dh_init[0] = L.dfeed; p.dh_init[1] = L.dx_lstm[1];
+      p.drop_p = drop_p; p.seed = seed;
+      p.sync = L.rnn_sync; p.status = d.rnn_status; p.force_safe = (d.recurrence & UIC_REC_SAFE) != 0;
+      p.row0 = 0; p.Nrows = B;
+      UIC_TRY(uic_nmt_dec_bwd_persist_launch(p, s));
+    }
+    for (int l = 0; l < NL && !bptt_persist; ++l) {
       UIC_TRY(uic_fill_launch(L.dhrec_d[l], 0, BH * 4, s));
       UIC_TRY(uic_fill_launch(L.dcd[l], 0, BH * 4, s));
     }
     const size_t lds_att = sizeof(float) * ((size_t)H + 2 * (size_t)S + 4 * (size_t)H);
-    for (int t = Td - 1; t >= 0; --t) {
+    for (int t = Td - 1; t >= 0 && !bptt_persist; --t) {
       const bool last = t == Td - 1;
       void* d_pre = offw(L.d_pre_all, (size_t)t * BH, dt);
       float* d_cq = L.d_cq_all + (size_t)t * B * 2 * H;
@@ -1063,13 +1111,30 @@ struct Nmt {
       UIC_TRY(wgrad_group(L.slab, L.slab_bytes, dt, L.d_pre_all, H, H, segs, 2, Md, &d2, 1, s, false, L.tA, L.tB));
     }
     // ---- encoder: d context = deferred attention gradient; d h0/c0 of the decoder enter at each row's final steps
+    const bool enc_persist = !(d.recurrence & UIC_REC_FWD_CHAIN) && uic_nmt_enc_persist_eligible(dt, B, S, H);
     for (int l = NL - 1; l >= 0; --l) {
       const int in = l == 0 ? W : H;
       NmtSide* ss = nullptr;
       UIC_TRY(nmt_side(&ss));
+      if (enc_persist) {   // the layer's BPTT, both directions, as ONE persistent launch (nmt_persist.hip)
+        UicNmtEncParams p;
+        memset(&p, 0, sizeof(p));
+        p.B = B; p.S = S;
+        for (int st = 0; st < S; ++st) p.nb[st] = nb[st];
+        for (int dd = 0; dd < 2; ++dd) {
+          UIC_TRY(uic_fill_launch(L.dg_e[l][dd], 0, (size_t)Ms * 4 * Hd * Sz, s));
+          p.w_hh[dd] = L.enc_w_hhT[l][dd]; p.c[dd] = L.c_e[l][dd]; p.gates[dd] = L.gates_e[l][dd]; p.dgates[dd] = L.dg_e[l][dd];
+        }
+        p.d_top = d_top;
+        p.dh_init = (l == 0 ? L.dfeed : L.dx_lstm[l]) + H; p.ld_dh_init = 2 * H;
+        p.dc_init = L.dcd[l]; p.ld_dc_init = H;
+        p.sync = L.rnn_sync; p.status = d.rnn_status; p.force_safe = (d.recurrence & UIC_REC_SAFE) != 0;
+        p.row0 = 0; p.Nrows = B;
+        UIC_TRY(uic_nmt_enc_bwd_persist_launch(p, s));
+      }
       UIC_TRY(uic_check_hip(hipEventRecord(ss->ev_go, s), "hipEventRecord"));          // d_top of this layer is final
       UIC_TRY(uic_check_hip(hipStreamWaitEvent(ss->stream, ss->ev_go, 0), "hipStreamWaitEvent"));
-      for (int dd = 1; dd >= 0; --dd) {                                                  // backward direction on the side stream
+      for (int dd = 1; dd >= 0 && !enc_persist; --dd) {                                  // backward direction on the side stream
         hipStream_t sd = dd == 1 ? ss->stream : s;
         float* dhrec = dd == 1 ? L.dhrec_e1 : L.dhrec_e;
         float* dcc = dd == 1 ? L.dc_e1 : L.dc_e;
@@ -1102,7 +1167,7 @@ struct Nmt {
         }
         if (dd == 1) UIC_TRY(uic_check_hip(hipEventRecord(ss->ev_done, sd), "hipEventRecord"));
       }
-      UIC_TRY(uic_check_hip(hipStreamWaitEvent(s, ss->ev_done, 0), "hipStreamWaitEvent"));
+      if (!enc_persist) UIC_TRY(uic_check_hip(hipStreamWaitEvent(s, ss->ev_done, 0), "hipStreamWaitEvent"));
       for (int dd = 0; dd < 2; ++dd) {
         // weights of this direction: dG^T [4Hd, S*B] x [x_l | h_prev]^T  (padded rows of dG are zero)
         {

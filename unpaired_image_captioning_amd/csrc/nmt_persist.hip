@@ -388,6 +388,477 @@ __global__ __launch_bounds__(NTH) void nmt_dec_persist_kernel(const UicNmtDecPar
   else nmt_dec_steps<false>(p, c);
 }
 
+// ---------------------------------------------------------------------------------------------------
+// BPTT of that loop as ONE launch (weight-stationary, batch <= 128, 2 layers): per target step, latest first,
+//   A  d_pre = (d out_t + d feed) * dropout mask * (1 - out_pre^2)  [computed by every workgroup on the fly as the A operand],
+//      d [c ; q] = d_pre W_out: this workgroup's 16 columns of d c (exchanged) and of d q (kept in registers)
+//   B  attention backward of the row this workgroup takes: d score, d q += sum_s d score[s] ctxw[s] (exchanged)
+//   C  top layer: cell backward of the own 16 units (exchanged: d gates), then d [x_1 ; h_1(t-1)] = d gates W_1 -- own columns of
+//      both halves stay in registers (d x_1 = the gradient of layer 0's dropped h, d h_1(t-1) = the next step's carry)
+//   D  layer 0: cell backward, d gates exchanged, d [feed ; h_0(t-1)] = d gates W_0: d feed exchanged (everybody's next step A)
+// -- tanh_drop_bwd, the d[c;q] GEMM, gattn_bwd_step, 2 x (lstm_bwd + GEMM) of csrc/nmt.hip's chain: 7 launches per step.
+// Five group barriers per step.  Resident: W_0^T's 32 rows x K 2048 (this workgroup's columns of both halves) as an LDS image
+// (128 KB), W_1^T's (128 KB) and W_out^T's (32 KB) in registers.  Exchange slabs are indexed by step (never rewritten inside a
+// launch: a reader's L2 cannot hold a stale line of them).
+// Four waves with the whole 512-entry register file of their SIMD each (as rnn_persist.hip's weight-stationary kernel): 160
+// resident weight registers per lane leave room for the phases' operands -- 8 waves x 256 registers spill.
+constexpr int BW_NW = 4;
+constexpr int BW_NTH = BW_NW * 64;
+constexpr int BW_W0_BYTES = BW_NW * 16 * 2 * 1024;     // [wave][k-step j < 16][half][lane] x 16 B = 128 KB
+
+template <bool SAFE, int MAXR>
+__device__ __forceinline__ void nmt_dec_bwd_steps(const UicNmtDecBwdParams& p, Ctx& c, char* lds) {
+  typedef bf16_t T;
+  const int B = p.B, S = p.S;
+  const size_t BH = (size_t)B * HH;
+  const size_t rb = (size_t)c.rbegin * HH;
+  u32x4* w0t = (u32x4*)lds;
+  // ---- resident weight slices.  Rows n = half * 512 + u0 + l15 of the transposed weights, K contiguous.
+  u32x4 w1t[16][2], wot[4][2];
+#pragma unroll
+  for (int j = 0; j < 16; ++j) {
+    const int kk = (c.wave + BW_NW * j) * 32;                 // K = 4 x 512: 64 k-steps, 16 per wave
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int row = h * HH + c.u0 + c.l15;
+      w0t[((c.wave * 16 + j) * 2 + h) * 64 + c.lane] = ws_wfrag(p.w0T, 4 * HH, row, kk, c.lq);
+      w1t[j][h] = ws_wfrag(p.w1T, 4 * HH, row, kk, c.lq);
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < 4; ++j)                                  // K = 512: 16 k-steps, 4 per wave
+#pragma unroll
+    for (int h = 0; h < 2; ++h) wot[j][h] = ws_wfrag(p.woutT, HH, h * HH + c.u0 + c.l15, (c.wave + BW_NW * j) * 32, c.lq);
+  __syncthreads();
+  const int arow = c.l15 < c.nrow ? c.l15 : c.nrow - 1;
+  const bool owner = c.wave == 0;
+  const unsigned u = (unsigned)(c.u0 + c.l15);
+  f32x4* red = (f32x4*)c.smem;                                 // [wave][half][lane]
+  const float inv_keep = p.drop_p > 0.f ? 1.f / (1.f - p.drop_p) : 1.f;
+  unsigned nn[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int rr = 4 * c.lq + r;
+    nn[r] = (unsigned)((c.rbegin + (rr < c.nrow ? rr : c.nrow - 1)) * HH);
+  }
+  // carried from step to step by the owner lanes (row 4 lq + r, unit u)
+  float dh0_rec[4] = {0.f, 0.f, 0.f, 0.f}, dh1_rec[4] = {0.f, 0.f, 0.f, 0.f}, dc0[4] = {0.f, 0.f, 0.f, 0.f}, dc1[4] = {0.f, 0.f, 0.f, 0.f};
+
+  // sum of the waves' partial [16 x 16] tiles of both halves; result on the owner wave
+  auto reduce2 = [&](const f32x4 (&acc)[2], f32x4 (&out)[2]) {
+    red[(c.wave * 2 + 0) * 64 + c.lane] = acc[0];
+    red[(c.wave * 2 + 1) * 64 + c.lane] = acc[1];
+    __syncthreads();
+    if (owner) {
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        out[h] = red[h * 64 + c.lane];
+#pragma unroll
+        for (int w = 1; w < BW_NW; ++w) out[h] += red[(w * 2 + h) * 64 + c.lane];
+      }
+    }
+    __syncthreads();
+  };
+  // d gates [nrow, 4 x 512] (exchanged) x the resident slice -> this workgroup's columns of both halves
+  auto dgemm = [&](const T* dg, auto wfrag, f32x4 (&out)[2]) {
+    const __amdgpu_buffer_rsrc_t ra = rsrc_of(dg);
+    u32x4 af[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) af[j] = bload<true>(ra, (unsigned)((arow * 4 * HH + (c.wave + BW_NW * j) * 32 + c.lq * 8) * 2), 0);
+    f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+    for (int j = 0; j < 16; ++j)
+#pragma unroll
+      for (int h = 0; h < 2; ++h) acc[h] = Mma<T>::run(af[j], wfrag(j, h), acc[h]);
+    reduce2(acc, out);
+  };
+  // backward of one LSTM cell's gate math for the owner lanes (csrc/pointwise.hip lstm_bwd_kernel): d gates stored (exchanged, and
+  // read again by the weight-gradient GEMMs), dc carried
+  auto cell_bwd = [&](int l, int t, const float (&dh)[4], float (&dc)[4]) {
+    const T* G = (const T*)p.gates_d[l] + (size_t)t * B * 4 * HH;
+    T* D = (T*)p.dg_d[l] + (size_t)t * B * 4 * HH;
+    const float* cn = p.cd[l] + (size_t)(t + 1) * BH;
+    const float* cpv = p.cd[l] + (size_t)t * BH;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      if (4 * c.lq + r < c.nrow) {
+        const unsigned og = 4u * nn[r] + u;
+        const float gi = uic_to_f(G[og]), gf = uic_to_f(G[og + HH]), gg = uic_to_f(G[og + 2 * HH]), go = uic_to_f(G[og + 3 * HH]);
+        const float cc = cn[nn[r] + u], cp = cpv[nn[r] + u];
+        const float tc = uic_tanh<T>(cc);
+        const float d = dc[r] + dh[r] * go * (1.f - tc * tc);
+        const float d_o = dh[r] * tc;
+        st_x<SAFE>(D + og, d * gg * gi * (1.f - gi));
+        st_x<SAFE>(D + og + HH, d * cp * gf * (1.f - gf));
+        st_x<SAFE>(D + og + 2 * HH, d * gi * (1.f - gg * gg));
+        st_x<SAFE>(D + og + 3 * HH, d_o * go * (1.f - go));
+        dc[r] = d * gf;
+      }
+    }
+  };
+
+  for (int t = p.Td - 1; t >= 0; --t) {
+    asm volatile("" : "+v"(c.lane), "+v"(c.l15), "+v"(c.lq), "+v"(c.tid));
+    const bool last = t == p.Td - 1;
+    float dq_lin[4] = {0.f, 0.f, 0.f, 0.f};
+    {  // ---- phase A
+      const float* d_out = p.d_out_all + (size_t)t * BH;
+      const T* out_pre = (const T*)p.out_pre + (size_t)t * BH;
+      T* d_pre = (T*)p.d_pre_all + (size_t)t * BH;
+      const __amdgpu_buffer_rsrc_t rf = rsrc_of(p.dfeed_x + (size_t)(last ? t : t + 1) * BH);
+      u32x4 af[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int k0 = (c.wave + BW_NW * j) * 32 + c.lq * 8;
+        const unsigned e = (unsigned)((c.rbegin + arow) * HH + k0);
+        const float4 o0 = *(const float4*)(d_out + e), o1 = *(const float4*)(d_out + e + 4);
+        float g[8] = {o0.x, o0.y, o0.z, o0.w, o1.x, o1.y, o1.z, o1.w};
+        if (!last) {
+          const u32x4 f0 = bload<true>(rf, e * 4u, 0), f1 = bload<true>(rf, e * 4u + 16u, 0);
+          g[0] += __uint_as_float(f0.x); g[1] += __uint_as_float(f0.y); g[2] += __uint_as_float(f0.z); g[3] += __uint_as_float(f0.w);
+          g[4] += __uint_as_float(f1.x); g[5] += __uint_as_float(f1.y); g[6] += __uint_as_float(f1.z); g[7] += __uint_as_float(f1.w);
+        }
+        float op[8];
+        uic_unpack<T>(*(const uint4*)(out_pre + e), op);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+          if (p.drop_p > 0.f) g[k] *= uic_drop_scale(p.seed, NMT_SITE_OUT(t), e + (unsigned)k, p.drop_p, inv_keep);
+          g[k] *= 1.f - op[k] * op[k];
+        }
+        const uint4 pk = uic_pack<T>(g);
+        af[j] = __builtin_bit_cast(u32x4, pk);
+        // d_pre is also linear_out's weight-gradient operand: the workgroup that owns these 8 columns stores them
+        if ((k0 >> 4) == (c.u0 >> 4) && c.l15 < c.nrow) *(uint4*)(d_pre + e) = pk;
+      }
+      f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int h = 0; h < 2; ++h) acc[h] = Mma<T>::run(af[j], wot[j][h], acc[h]);
+      f32x4 out[2];
+      reduce2(acc, out);
+      if (owner) {
+        float* d_cq = p.d_cq_all + (size_t)t * B * 2 * HH;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          if (4 * c.lq + r < c.nrow) st_x<SAFE>(d_cq + 2u * nn[r] + u, out[0][r]);           // d c (attention backward, deferred accumulation)
+          dq_lin[r] = out[1][r];
+        }
+      }
+    }
+    if (!group_barrier(c)) return;
+    if (c.rank < c.nrow) {  // ---- phase B: attention backward of row `rank` of the group (csrc/nmt.hip gattn_bwd_step_fast_kernel)
+      const int b = c.rbegin + c.rank;
+      float* s_dc = (float*)c.smem + 64;       // [HH]
+      float* s_a = s_dc + HH;                  // [64]
+      float* s_da = s_a + 64;                  // [64]
+      float* s_red = s_da + 64;                // [BW_NW][HH]
+      const T* ctx = (const T*)p.ctx;
+      uint4 cr[MAXR];                          // (S <= BW_NW * MAXR source positions)
+      float4 wr[MAXR][2];
+#pragma unroll
+      for (int uu = 0; uu < MAXR; ++uu) {
+        const int sp = c.wave + BW_NW * uu;
+        const size_t r = ((size_t)(sp < S ? sp : S - 1) * B + b) * HH;
+        cr[uu] = *(const uint4*)(ctx + r + c.lane * 8);
+        wr[uu][0] = *(const float4*)(p.ctxw + r + c.lane * 4);
+        wr[uu][1] = *(const float4*)(p.ctxw + r + (c.lane + 64) * 4);
+      }
+      if (c.wave < 2) {                        // d c of the row: written by the other workgroups in phase A
+        const u32x4 v = bload<true>(rsrc_of(p.d_cq_all + (size_t)t * B * 2 * HH), (unsigned)((b * 2 * HH + c.tid * 4) * 4), 0);
+        *(u32x4*)(s_dc + c.tid * 4) = v;
+      }
+      if (c.tid < S) s_a[c.tid] = p.attn_all[((size_t)t * B + b) * S + c.tid];
+      __syncthreads();
+#pragma unroll
+      for (int uu = 0; uu < MAXR; ++uu) {
+        const int sp = c.wave + BW_NW * uu;
+        if (sp < S) {
+          float f[8];
+          uic_unpack<T>(cr[uu], f);
+          float pr = 0.f;
+#pragma unroll
+          for (int k = 0; k < 8; ++k) pr += f[k] * s_dc[c.lane * 8 + k];
+          pr = uic_wave_sum(pr);
+          if (c.lane == 0) s_da[sp] = pr;
+        }
+      }
+      __syncthreads();
+      float wbar = 0.f;
+      for (int sp = 0; sp < S; ++sp) wbar += s_a[sp] * s_da[sp];
+      __syncthreads();
+      if (c.tid < S) {
+        const float ds = s_a[c.tid] * (s_da[c.tid] - wbar);
+        s_da[c.tid] = ds;
+        p.dscore_all[((size_t)t * B + b) * S + c.tid] = ds;
+      }
+      __syncthreads();
+      float a0[4] = {0.f, 0.f, 0.f, 0.f}, a1[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int uu = 0; uu < MAXR; ++uu) {
+        const int sp = c.wave + BW_NW * uu;
+        if (sp < S) {
+          const float a = s_da[sp];
+          a0[0] += a * wr[uu][0].x; a0[1] += a * wr[uu][0].y; a0[2] += a * wr[uu][0].z; a0[3] += a * wr[uu][0].w;
+          a1[0] += a * wr[uu][1].x; a1[1] += a * wr[uu][1].y; a1[2] += a * wr[uu][1].z; a1[3] += a * wr[uu][1].w;
+        }
+      }
+#pragma unroll
+      for (int k = 0; k < 4; ++k) { s_red[c.wave * HH + c.lane * 4 + k] = a0[k]; s_red[c.wave * HH + (c.lane + 64) * 4 + k] = a1[k]; }
+      __syncthreads();
+#pragma unroll
+      for (int half = 0; half < 2; ++half) {                   // (HH = 2 BW_NTH: two columns per thread)
+        const int col = c.tid + half * BW_NTH;
+        float v = 0.f;
+#pragma unroll
+        for (int w = 0; w < BW_NW; ++w) v += s_red[w * HH + col];
+        st_x<SAFE>(p.dq_att_x + (size_t)t * BH + (size_t)b * HH + col, v);
+      }
+      __syncthreads();
+    }
+    if (!group_barrier(c)) return;
+    float dx1[4] = {0.f, 0.f, 0.f, 0.f};
+    if (owner) {  // ---- phase C1: top layer's cell backward
+      const __amdgpu_buffer_rsrc_t rq = rsrc_of(p.dq_att_x + (size_t)t * BH);
+      float dh[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) dh[r] = dq_lin[r] + __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rq, (nn[r] + u) * 4u, 0, 16)) + dh1_rec[r];
+      cell_bwd(1, t, dh, dc1);
+    }
+    if (!group_barrier(c)) return;
+    {  // ---- phase C2
+      f32x4 out[2];
+      dgemm((const T*)p.dg_d[1] + (size_t)t * B * 4 * HH + 4 * rb, [&](int j, int h) { return w1t[j][h]; }, out);
+      if (owner) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { dx1[r] = out[0][r]; dh1_rec[r] = out[1][r]; }
+      }
+    }
+    if (owner) {  // ---- phase D1: layer 0's cell backward (its h went through the inter-layer dropout)
+      float dh[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float v = dx1[r];
+        if (p.drop_p > 0.f) v *= uic_drop_scale(p.seed, NMT_SITE_DEC(0, t), nn[r] + u, p.drop_p, inv_keep);
+        dh[r] = v + dh0_rec[r];
+      }
+      cell_bwd(0, t, dh, dc0);
+    }
+    if (!group_barrier(c)) return;
+    {  // ---- phase D2
+      f32x4 out[2];
+      dgemm((const T*)p.dg_d[0] + (size_t)t * B * 4 * HH + 4 * rb, [&](int j, int h) { return w0t[((c.wave * 16 + j) * 2 + h) * 64 + c.lane]; }, out);
+      if (owner) {
+        float* df = p.dfeed_x + (size_t)t * BH;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          if (4 * c.lq + r < c.nrow) st_x<SAFE>(df + nn[r] + u, out[0][r]);
+          dh0_rec[r] = out[1][r];
+        }
+      }
+    }
+    if (!group_barrier(c)) return;
+  }
+  // what the encoder's backward pass starts from: d h_l(-1) in the second halves of the [B, 2 x 512] hand-over buffers, d c_l(-1)
+  if (owner) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      if (4 * c.lq + r < c.nrow) {
+        p.dh_init[0][2u * nn[r] + HH + u] = dh0_rec[r];
+        p.dh_init[1][2u * nn[r] + HH + u] = dh1_rec[r];
+        p.dc_init[0][nn[r] + u] = dc0[r];
+        p.dc_init[1][nn[r] + u] = dc1[r];
+      }
+    }
+  }
+}
+
+template <int MAXR>
+__global__ __launch_bounds__(BW_NTH) void nmt_dec_bwd_kernel(const UicNmtDecBwdParams p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  Ctx c;
+  const int mode = setup_ctx(p, smem + BW_W0_BYTES, c);
+  if (mode == 0) return;
+  if (mode == 2) nmt_dec_bwd_steps<true, MAXR>(p, c, smem);
+  else nmt_dec_bwd_steps<false, MAXR>(p, c, smem);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Encoder layer, forward (struct UicNmtEncParams in uic_common.h).  Per iteration ONE group barrier: the recurrent GEMM
+// [<= 16 rows] x [K 256] x [64 gate columns] against a register-resident slice (8 k-steps, one per wave: 16 registers), partial
+// tiles summed through LDS, cell update by wave 0, h exchanged.  30 iterations replace 2 x 30 dependent launches.
+constexpr int ENC_HD = HH / 2;
+
+template <bool SAFE>
+__device__ __forceinline__ void nmt_enc_fwd_steps(const UicNmtEncParams& p, Ctx& c) {
+  typedef bf16_t T;
+  const int B = p.B, S = p.S;
+  const int dir = c.rank >> 4;
+  const int u0 = (c.rank & 15) * 16;                 // first of this workgroup's 16 units inside its direction
+  const unsigned u = (unsigned)(u0 + c.l15);
+  u32x4 wf[4];
+#pragma unroll
+  for (int g = 0; g < 4; ++g) wf[g] = ws_wfrag(p.w_hh[dir], ENC_HD, g * ENC_HD + u0 + c.l15, c.wave * 32, c.lq);
+  const int arow = c.l15 < c.nrow ? c.l15 : c.nrow - 1;
+  const bool owner = c.wave == 0;
+  f32x4* red = (f32x4*)c.smem;
+  const float* gx = p.gx[dir];
+  float* cst = p.c[dir];
+  T* gates = (T*)p.gates[dir];
+  T* xo = (T*)p.x_out;
+  for (int k = 0; k < S; ++k) {
+    asm volatile("" : "+v"(c.lane), "+v"(c.l15), "+v"(c.lq), "+v"(c.tid));
+    const int st = dir == 0 ? k : S - 1 - k;
+    const int prev = dir == 0 ? st : st + 2;         // slot of the previous state in this direction
+    const int alive = p.nb[st];
+    // the owner lanes' operands of the cell update first: their latency passes behind the GEMM
+    float pv[4][4], cp[4];
+    if (owner) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = c.rbegin + min(4 * c.lq + r, c.nrow - 1);
+        cp[r] = cst[((size_t)prev * B + row) * ENC_HD + u];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) pv[r][g] = gx[((size_t)st * B + row) * (4 * ENC_HD) + g * ENC_HD + u];
+      }
+    }
+    const u32x4 af = bload<true>(rsrc_of(xo + (size_t)prev * B * HH), (unsigned)(((c.rbegin + arow) * HH + dir * ENC_HD + c.wave * 32 + c.lq * 8) * 2), 0);
+    f32x4 acc[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) acc[g] = Mma<T>::run(af, wf[g], f32x4{0.f, 0.f, 0.f, 0.f});
+#pragma unroll
+    for (int g = 0; g < 4; ++g) red[(c.wave * 4 + g) * 64 + c.lane] = acc[g];
+    __syncthreads();
+    if (owner) {
+      f32x4 s[4];
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        s[g] = red[g * 64 + c.lane];
+#pragma unroll
+        for (int w = 1; w < NWAVE; ++w) s[g] += red[(w * 4 + g) * 64 + c.lane];
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int rr = 4 * c.lq + r;
+        const int row = c.rbegin + rr;
+        if (rr < c.nrow && row < alive) {
+          const float gi = uic_sigmoid_t<T>(s[0][r] + pv[r][0]);
+          const float gf = uic_sigmoid_t<T>(s[1][r] + pv[r][1]);
+          const float gg = uic_tanh<T>(s[2][r] + pv[r][2]);
+          const float go = uic_sigmoid_t<T>(s[3][r] + pv[r][3]);
+          const float cn = gf * cp[r] + gi * gg;
+          cst[((size_t)(st + 1) * B + row) * ENC_HD + u] = cn;
+          st_x<SAFE>(xo + ((size_t)(st + 1) * B + row) * HH + dir * ENC_HD + u, go * uic_tanh<T>(cn));
+          T* G = gates + ((size_t)st * B + row) * (4 * ENC_HD) + u;
+          __builtin_nontemporal_store(uic_from_f<T>(gi), G);
+          __builtin_nontemporal_store(uic_from_f<T>(gf), G + ENC_HD);
+          __builtin_nontemporal_store(uic_from_f<T>(gg), G + 2 * ENC_HD);
+          __builtin_nontemporal_store(uic_from_f<T>(go), G + 3 * ENC_HD);
+        }
+      }
+    }
+    __syncthreads();
+    if (!group_barrier(c)) return;
+  }
+}
+
+__global__ __launch_bounds__(NTH) void nmt_enc_fwd_kernel(const UicNmtEncParams p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  Ctx c;
+  const int mode = setup_ctx(p, smem, c);
+  if (mode == 0) return;
+  if (mode == 2) nmt_enc_fwd_steps<true>(p, c);
+  else nmt_enc_fwd_steps<false>(p, c);
+}
+
+// Encoder layer, BPTT: per iteration the cell backward of the own units (d h = d_top + the carried d h, d c carried), d gates
+// exchanged, ONE group barrier, then the carried d h of the next iteration = d gates [<= 16 rows, 4 x 256] x the resident W_hh^T slice
+// (16 columns x K 1024: 32 k-steps, 4 per wave).  Replaces (lstm_bwd + GEMM) x S x 2 directions.
+template <bool SAFE>
+__device__ __forceinline__ void nmt_enc_bwd_steps(const UicNmtEncParams& p, Ctx& c) {
+  typedef bf16_t T;
+  const int B = p.B, S = p.S;
+  const int dir = c.rank >> 4;
+  const int u0 = (c.rank & 15) * 16;
+  const unsigned u = (unsigned)(u0 + c.l15);
+  u32x4 wt[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) wt[j] = ws_wfrag(p.w_hh[dir], 4 * ENC_HD, u0 + c.l15, (c.wave + NWAVE * j) * 32, c.lq);
+  const int arow = c.l15 < c.nrow ? c.l15 : c.nrow - 1;
+  const bool owner = c.wave == 0;
+  f32x4* red = (f32x4*)c.smem;
+  const float* cst = p.c[dir];
+  const T* gates = (const T*)p.gates[dir];
+  T* dgs = (T*)p.dgates[dir];
+  float dh[4] = {0.f, 0.f, 0.f, 0.f}, dc[4] = {0.f, 0.f, 0.f, 0.f};
+  if (owner) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int row = c.rbegin + min(4 * c.lq + r, c.nrow - 1);
+      dh[r] = p.dh_init[(size_t)row * p.ld_dh_init + dir * ENC_HD + u];
+      dc[r] = p.dc_init[(size_t)row * p.ld_dc_init + dir * ENC_HD + u];
+    }
+  }
+  for (int k = S - 1; k >= 0; --k) {
+    asm volatile("" : "+v"(c.lane), "+v"(c.l15), "+v"(c.lq), "+v"(c.tid));
+    const int st = dir == 0 ? k : S - 1 - k;
+    const int prev = dir == 0 ? st : st + 2;
+    const int alive = p.nb[st];
+    if (owner) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int rr = 4 * c.lq + r;
+        const int row = c.rbegin + rr;
+        if (rr < c.nrow && row < alive) {
+          const T* G = gates + ((size_t)st * B + row) * (4 * ENC_HD) + u;
+          const float gi = uic_to_f(G[0]), gf = uic_to_f(G[ENC_HD]), gg = uic_to_f(G[2 * ENC_HD]), go = uic_to_f(G[3 * ENC_HD]);
+          const float cc = cst[((size_t)(st + 1) * B + row) * ENC_HD + u], cp = cst[((size_t)prev * B + row) * ENC_HD + u];
+          const float dht = p.d_top[((size_t)st * B + row) * HH + dir * ENC_HD + u] + dh[r];
+          const float tc = uic_tanh<T>(cc);
+          const float d = dc[r] + dht * go * (1.f - tc * tc);
+          const float d_o = dht * tc;
+          T* D = dgs + ((size_t)st * B + row) * (4 * ENC_HD) + u;
+          st_x<SAFE>(D, d * gg * gi * (1.f - gi));
+          st_x<SAFE>(D + ENC_HD, d * cp * gf * (1.f - gf));
+          st_x<SAFE>(D + 2 * ENC_HD, d * gi * (1.f - gg * gg));
+          st_x<SAFE>(D + 3 * ENC_HD, d_o * go * (1.f - go));
+          dc[r] = d * gf;
+        }
+      }
+    }
+    if (!group_barrier(c)) return;
+    {
+      const __amdgpu_buffer_rsrc_t ra = rsrc_of(dgs + (size_t)st * B * 4 * ENC_HD);
+      u32x4 af[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) af[j] = bload<true>(ra, (unsigned)(((c.rbegin + arow) * 4 * ENC_HD + (c.wave + NWAVE * j) * 32 + c.lq * 8) * 2), 0);
+      f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc = Mma<T>::run(af[j], wt[j], acc);
+      red[c.wave * 64 + c.lane] = acc;
+      __syncthreads();
+      if (owner) {
+        f32x4 sres = red[c.lane];
+#pragma unroll
+        for (int w = 1; w < NWAVE; ++w) sres += red[w * 64 + c.lane];
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          if (c.rbegin + 4 * c.lq + r < alive) dh[r] = sres[r];       // (a row that is not alive yet keeps its initial carry)
+      }
+      __syncthreads();
+    }
+  }
+}
+
+__global__ __launch_bounds__(NTH) void nmt_enc_bwd_kernel(const UicNmtEncParams p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  Ctx c;
+  const int mode = setup_ctx(p, smem, c);
+  if (mode == 0) return;
+  if (mode == 2) nmt_enc_bwd_steps<true>(p, c);
+  else nmt_enc_bwd_steps<false>(p, c);
+}
+
 }  // namespace
 
 bool uic_nmt_dec_persist_eligible(int dtype, int B, int S, int H, int NL) {
@@ -418,3 +889,43 @@ int uic_nmt_dec_persist_launch(const UicNmtDecParams& p, hipStream_t s) {
   UIC_LAUNCH_CHECK("nmt_dec_persist_kernel");
   return gate.leave();
 }
+
+bool uic_nmt_dec_bwd_persist_eligible(int dtype, int B, int S, int H, int NL) {
+  return NL == 2 && B <= 8 * 16 && uic_nmt_dec_persist_eligible(dtype, B, S, H, NL);
+}
+
+int uic_nmt_dec_bwd_persist_launch(const UicNmtDecBwdParams& p, hipStream_t s) {
+  UIC_REQUIRE(p.sync && p.Td > 0 && p.B > 0 && p.B <= 8 * 16 && p.Nrows == p.B && p.row0 == 0, "nmt_dec_bwd_persist: bad arguments");
+  static bool configured = false;
+  if (!configured) {
+    UIC_TRY(uic_check_hip(hipFuncSetAttribute((const void*)nmt_dec_bwd_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, BW_W0_BYTES + WS_SCR_BYTES), "hipFuncSetAttribute(nmt dec bwd)"));
+    UIC_TRY(uic_check_hip(hipFuncSetAttribute((const void*)nmt_dec_bwd_kernel<16>, hipFuncAttributeMaxDynamicSharedMemorySize, BW_W0_BYTES + WS_SCR_BYTES), "hipFuncSetAttribute(nmt dec bwd)"));
+    configured = true;
+  }
+  UicPersistGateScope gate;
+  UIC_TRY(gate.enter(s));
+  UIC_TRY(uic_check_hip(hipMemsetAsync(p.sync, 0, (size_t)SY_WORDS * 4, s), "hipMemsetAsync(nmt dec bwd sync)"));
+  if (p.S <= BW_NW * 8) hipLaunchKernelGGL(nmt_dec_bwd_kernel<8>, dim3(8 * PW), dim3(BW_NTH), BW_W0_BYTES + WS_SCR_BYTES, s, p);
+  else hipLaunchKernelGGL(nmt_dec_bwd_kernel<16>, dim3(8 * PW), dim3(BW_NTH), BW_W0_BYTES + WS_SCR_BYTES, s, p);
+  UIC_LAUNCH_CHECK("nmt_dec_bwd_kernel");
+  return gate.leave();
+}
+
+bool uic_nmt_enc_persist_eligible(int dtype, int B, int S, int H) {
+  return S <= UIC_NMT_ENC_MAX_S && B <= 8 * 16 && uic_nmt_dec_persist_eligible(dtype, B, S, H, 1);
+}
+
+namespace {
+template <typename K>
+int enc_launch(K kernel, const char* what, const UicNmtEncParams& p, hipStream_t s) {
+  UIC_REQUIRE(p.sync && p.S > 0 && p.S <= UIC_NMT_ENC_MAX_S && p.B > 0 && p.B <= 8 * 16 && p.Nrows == p.B && p.row0 == 0, "%s: bad arguments", what);
+  UicPersistGateScope gate;
+  UIC_TRY(gate.enter(s));
+  UIC_TRY(uic_check_hip(hipMemsetAsync(p.sync, 0, (size_t)SY_WORDS * 4, s), "hipMemsetAsync(nmt enc sync)"));
+  hipLaunchKernelGGL(kernel, dim3(8 * PW), dim3(NTH), WS_SCR_BYTES, s, p);
+  UIC_LAUNCH_CHECK(what);
+  return gate.leave();
+}
+}  // namespace
+int uic_nmt_enc_fwd_persist_launch(const UicNmtEncParams& p, hipStream_t s) { return enc_launch(nmt_enc_fwd_kernel, "nmt_enc_fwd_kernel", p, s); }
+int uic_nmt_enc_bwd_persist_launch(const UicNmtEncParams& p, hipStream_t s) { return enc_launch(nmt_enc_bwd_kernel, "nmt_enc_bwd_kernel", p, s); }

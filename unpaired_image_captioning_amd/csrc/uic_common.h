@@ -380,6 +380,52 @@ struct UicNmtDecParams {
   unsigned* status; int force_safe;
   int row0, Nrows;                   // 0, B
 };
+// its BPTT (2 layers, batch <= 128): the chain's per-step buffers, plus two step-indexed exchange slabs
+struct UicNmtDecBwdParams {
+  int B, S, Td;
+  const float* d_out_all;            // [Td][B][512] f32: d outputs from the generator
+  const void* out_pre;               // [Td] tanh outputs (bf16)
+  void* d_pre_all;                   // [Td] bf16 (out: linear_out's weight-gradient operand)
+  float* d_cq_all;                   // [Td][B][2 x 512] f32 (out: the d c half; read by the deferred attention accumulation)
+  const float* attn_all; const void* ctx; const float* ctxw;
+  float* dscore_all;                 // [Td][B][S] (out)
+  const void* gates_d[2]; const float* cd[2]; void* dg_d[2];   // activated gates, c states [(Td + 1)], d gates (out)
+  const void* woutT;                 // [2 x 512][512]  = linear_out.weight^T
+  const void* w1T;                   // [2 x 512][4 x 512] = [W_ih_1^T ; W_hh_1^T]
+  const void* w0T;                   // [2 x 512][4 x 512] = [W_ih_0[:, W:]^T ; W_hh_0^T]
+  float* dfeed_x; float* dq_att_x;   // [Td][B][512] f32 exchange slabs (d input feed, the attention's share of d q)
+  float* dh_init[2];                 // [B][2 x 512] f32: second halves receive d h_l(-1)
+  float* dc_init[2];                 // [B][512] f32: d c_l(-1)
+  float drop_p; unsigned seed;
+  unsigned* sync; unsigned* status; int force_safe;
+  int row0, Nrows;
+};
+// One layer of the pivot encoder's packed bidirectional LSTM (NMT_Models.Encoder, P/models/NMT_Models.py:95-135; nn.LSTM over a
+// pack_padded_sequence) as ONE launch, both directions side by side: workgroups 0-15 of a row group own the forward direction's
+// 256 units, 16-31 the backward direction's.  Iteration k runs time step k of the forward and S - 1 - k of the backward direction
+// (the BPTT launch walks k the other way).  Rows are length-sorted: row b is alive at step st iff b < nb[st].
+#define UIC_NMT_ENC_MAX_S 64
+struct UicNmtEncParams {
+  int B, S;
+  int nb[UIC_NMT_ENC_MAX_S];         // rows alive per time step
+  void* x_out;                       // [(S + 2)][B][512] bf16: slot st + 1 = h of step st, [fwd 256 | bwd 256] (slots 0 / S + 1 zero; all zeroed by the caller)
+  const void* w_hh[2];               // forward: [4 x 256][256] recurrent weights;  backward pass: [256][4 x 256] = W_hh^T
+  const float* gx[2];                // [S][B][4 x 256] f32: W_ih x + b_ih + b_hh (forward pass)
+  float* c[2];                       // [(S + 2)][B][256] f32 cell states (zeroed by the caller)
+  void* gates[2];                    // [S][B][4 x 256] bf16 activated gates (written forward, read backward)
+  // backward pass only
+  void* dgates[2];                   // [S][B][4 x 256] bf16 (zeroed by the caller: padded positions stay zero)
+  const float* d_top;                // [S][B][512] f32: gradient w.r.t. this layer's outputs
+  const float* dh_init; int ld_dh_init;   // [B][ld] f32, columns [dir * 256, +256): d h of the final state (the decoder's initial state)
+  const float* dc_init; int ld_dc_init;
+  unsigned* sync; unsigned* status; int force_safe;
+  int row0, Nrows;
+};
+bool uic_nmt_enc_persist_eligible(int dtype, int B, int S, int H);
+int uic_nmt_enc_fwd_persist_launch(const UicNmtEncParams& p, hipStream_t s);
+int uic_nmt_enc_bwd_persist_launch(const UicNmtEncParams& p, hipStream_t s);
+bool uic_nmt_dec_bwd_persist_eligible(int dtype, int B, int S, int H, int NL);
+int uic_nmt_dec_bwd_persist_launch(const UicNmtDecBwdParams& p, hipStream_t s);
 bool uic_nmt_dec_persist_eligible(int dtype, int B, int S, int H, int NL);
 int uic_nmt_dec_persist_launch(const UicNmtDecParams& p, hipStream_t s);
 bool uic_rnn_bwd_persist_eligible(int dtype, int N, int H, int A, int R);
