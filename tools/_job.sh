@@ -1,4 +1,4 @@
 cd $GRAFT_REPO_ROOT
-timeout 600 python -m pytest tests/test_gpu_nmt.py -m gpu -x -q -k "persistent_launches or configs2 or real_width" 2>&1 | tail -25 > gpurun_out/r4_nmt_tests.log
-tail -8 gpurun_out/r4_nmt_tests.log
-timeout 600 python -m pytest tests/test_gpu_nmt.py tests/test_gpu_pivot.py -m gpu -x -q 2>&1 | tail -3
+timeout 1200 python -m pytest tests/test_gpu_fullsize.py tests/test_gpu_topdown.py tests/test_gpu_boundary.py tests/test_gpu_dp2.py tests/test_gpu_fullsize_decode.py -m gpu -x -q > gpurun_out/r4_tests.log 2>&1
+grep -E "passed|failed" gpurun_out/r4_tests.log | tail -3
+for i in 1 2 3; do python bench.py --no-f32 --no-cpu-baseline 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.readline()); print(d['ms_per_step'], d['value'])"; done

@@ -307,6 +307,14 @@ __global__ __launch_bounds__(512) void uic_gemm_pp_kernel(const UicGemmParams p)
           if (col >= p.N) continue;
           f32x4 v = acc[rt][ct] + bj[ct];
           if (ad) v += *(const f32x4*)(ad + col);
+          if (p.acc_src) v += *(const f32x4*)(p.acc_src + (size_t)row * p.ld_acc_src + col);
+          if (p.mask_act) {          // backward of ReLU (+ dropout scale) by the forward activation's sign
+            const uint2 q = *(const uint2*)((const bf16_t*)p.mask_act + (size_t)row * p.ld_mask_act + col);
+            v[0] = __uint_as_float(q.x << 16) > 0.f ? v[0] * p.mask_scale : 0.f;
+            v[1] = __uint_as_float(q.x & 0xffff0000u) > 0.f ? v[1] * p.mask_scale : 0.f;
+            v[2] = __uint_as_float(q.y << 16) > 0.f ? v[2] * p.mask_scale : 0.f;
+            v[3] = __uint_as_float(q.y & 0xffff0000u) > 0.f ? v[3] * p.mask_scale : 0.f;
+          }
 #pragma unroll
           for (int j = 0; j < 4; ++j) {
             if (RELU) v[j] = fmaxf(v[j], 0.f);
@@ -369,6 +377,8 @@ bool uic_gemm_pp_eligible(const UicGemmParams& p) {
   if (p.bias && ((uintptr_t)p.bias & 15)) return false;
   if (p.bias2 && ((uintptr_t)p.bias2 & 15)) return false;
   if (p.addend && (((uintptr_t)p.addend & 15) || p.ld_add % 4 != 0)) return false;
+  if (p.acc_src && (((uintptr_t)p.acc_src & 15) || p.ld_acc_src % 4 != 0)) return false;
+  if (p.mask_act && (((uintptr_t)p.mask_act & 7) || p.ld_mask_act % 4 != 0)) return false;
   return true;
 }
 

@@ -432,6 +432,7 @@ struct SideStream {
   hipStream_t stream = nullptr;
   hipStream_t stream3 = nullptr;    // a chunk's att_lstm / h2att weight gradients beside its lang_lstm ones (independent GEMMs)
   hipEvent_t ev_s3 = nullptr;       // stream3 -> side: that share of every chunk so far is done
+  hipEvent_t ev_prep = nullptr;     // side -> stream3: the embedding gradient's token bucketing is done
   hipEvent_t ev_den = nullptr, ev_done = nullptr;
   hipEvent_t ev_pro = nullptr;      // side: its branch of the forward prologue (fc_embed, embedding, batched input GEMM) is through
   hipEvent_t ev_logit = nullptr;    // side: the logit layer's gradients and the loss are final (start of the BPTT loop)
@@ -471,6 +472,7 @@ int get_side(SideStream** out) {
     UIC_TRY(uic_check_hip(hipStreamCreateWithPriority(&ss.stream, hipStreamNonBlocking, least), "hipStreamCreateWithPriority"));
     UIC_TRY(uic_check_hip(hipStreamCreateWithPriority(&ss.stream3, hipStreamNonBlocking, least), "hipStreamCreateWithPriority"));
     UIC_TRY(uic_check_hip(hipEventCreateWithFlags(&ss.ev_s3, hipEventDisableTiming), "hipEventCreate"));
+    UIC_TRY(uic_check_hip(hipEventCreateWithFlags(&ss.ev_prep, hipEventDisableTiming), "hipEventCreate"));
     UIC_TRY(uic_check_hip(hipEventCreateWithFlags(&ss.ev_den, hipEventDisableTiming), "hipEventCreate"));
     UIC_TRY(uic_check_hip(hipEventCreateWithFlags(&ss.ev_done, hipEventDisableTiming), "hipEventCreate"));
     UIC_TRY(uic_check_hip(hipEventCreateWithFlags(&ss.ev_pro, hipEventDisableTiming), "hipEventCreate"));
@@ -1247,10 +1249,19 @@ struct Step {
       UIC_TRY(wgrad_group(L.slab, L.d_patt, A, A, &seg, 1, NR, &d1, 1, s, false, L.tA, L.tB));
       UIC_TRY(uic_colsum_launch(dt, L.d_patt, NR, A, A, G->ctx2att_b, L.colscratch, L.colscratch_floats, s));
     }
+    // d att' = (the attention's own share, in L.d_att) + d p_att W_ctx2att; without BatchNorm behind it and with one feature row
+    // per caption row, the backward of att_embed's ReLU + dropout rides on this GEMM's epilogue: it writes L.d_pre (the weight
+    // gradient's bf16 operand) directly instead of the f32 sum that a separate pass then masks (53 us of the main stream's tail)
+    bool relu_fused = false;
     {
       UicGemmParams g = gemm_base(dt, NR, H);
       add_seg(g, L.d_patt, A, dv.ctx2attT, A, A);
-      g.C = L.d_att; g.ldc = H; g.flags = UIC_GEMM_OUT_F32 | UIC_GEMM_ACCUM;
+      g.C = L.d_pre; g.ldc = H; g.acc_src = L.d_att; g.ld_acc_src = H; g.mask_act = L.attp; g.ld_mask_act = H; g.mask_scale = inv_keep;
+      relu_fused = d.use_bn != 2 && d.seq_per_img <= 1 && dt == UIC_BF16 && uic_gemm_pp_eligible(g);
+      if (!relu_fused) {
+        g.C = L.d_att; g.flags = UIC_GEMM_OUT_F32 | UIC_GEMM_ACCUM;
+        g.acc_src = nullptr; g.mask_act = nullptr;
+      }
       UIC_TRY(uic_gemm_launch(g, s));
     }
     // att_embed (padded regions have att' = 0 -> zero gradient, as pack_wrapper never touched them)
@@ -1267,7 +1278,7 @@ struct Step {
     const int NRa = fold ? NR / d.seq_per_img : NR;
     if (fold)
       UIC_TRY(uic_relu_mask_bwd_fold_launch(dt, L.d_att, act, inv_keep, L.d_pre, N / d.seq_per_img, d.seq_per_img, (size_t)R * H, s));
-    else
+    else if (!relu_fused)
       UIC_TRY(uic_relu_mask_bwd_launch(dt, L.d_att, act, inv_keep, L.d_pre, (size_t)NR * H, s));
     if (ones_ok && D % 128 == 0 && NRa % 64 == 0) {
       const UicGemmTnSeg segs[2] = {{att_in, D, D}, {L.ones_blk, 128, 128}};
@@ -1498,8 +1509,14 @@ int uic_topdown_xe_train_step(const uic_topdown_dims* d, const uic_topdown_weigh
       UIC_TRY(uic_embed_bwd_sorted_prepare(st.embed_tokens(), st.embed_ldtok(), d->N, t_run, d->V1, d->E, G->embed_w, st.L.embed_scratch, s2,
                                            st.embed_split));
       st.embed_prepared = true;
+      UIC_HIP(hipEventRecord(ss->ev_prep, s2));
     }
   }
+  // The tail after the BPTT loop is three independent pieces of throughput work: the last chunk's recurrent weight gradients
+  // (side stream), the late group (main stream), and what completes att_lstm.weight_ih and the embedding table (sum over steps,
+  // fc' columns, d xt GEMM, gather).  In the default order the third piece goes to the THIRD stream beside the other two
+  // instead of behind the first (measured: the side stream's tail was the end of the step, 0.1 ms after the main stream's).
+  const bool tail3 = !early && st.embed_prepared;
   for (int c = nchunk - 1; c >= 0; --c) {
     const int t0 = c * CH, t1 = t0 + CH < t_run ? t0 + CH : t_run;
     UIC_HIP(hipStreamWaitEvent(s, ss->ev_side[c], 0));
@@ -1518,6 +1535,12 @@ int uic_topdown_xe_train_step(const uic_topdown_dims* d, const uic_topdown_weigh
     UIC_TRY(st.embed_grad(0, s2));
     UIC_HIP(hipEventRecord(ss->ev_s3, s3));
     UIC_HIP(hipStreamWaitEvent(s2, ss->ev_s3, 0));    // the third stream's share of the weight gradients
+  } else if (tail3) {
+    UIC_HIP(hipStreamWaitEvent(s3, ss->ev_main[0], 0));     // the BPTT loop is through: dG1 of every step exists
+    UIC_HIP(hipStreamWaitEvent(s3, ss->ev_prep, 0));
+    UIC_TRY(st.fc_cols_grad(s3, st.L.slab3, st.L.tTA, st.L.tTB));
+    UIC_TRY(st.embed_grad(0, s3));
+    UIC_HIP(hipEventRecord(ss->ev_s3, s3));
   }
   // side: the rest of the early gradient group (LSTM / h2att biases, embedding, fc_embed); main: the late group
   // (attention accumulation, ctx2att, att_embed).  ev_early: the early group, the logit layer and the loss are final.
@@ -1527,7 +1550,8 @@ int uic_topdown_xe_train_step(const uic_topdown_dims* d, const uic_topdown_weigh
   UIC_MARK(6, s2);                                    // side: recurrent weight gradients done
   UIC_TRY(st.bwd_epilogue_late(s, true));             // (enqueued first: it is the longer of the two tails)
   UIC_MARK(7, s);
-  UIC_TRY(st.bwd_epilogue_early(s2, true, true, early));
+  if (tail3) UIC_HIP(hipStreamWaitEvent(s2, ss->ev_s3, 0));      // (d fc' below reads the dGfc that fc_cols_grad left)
+  UIC_TRY(st.bwd_epilogue_early(s2, true, true, early || tail3));
   UIC_HIP(hipEventRecord(ss->ev_early, s2));
   ss->early_recorded = true;
   UIC_MARK(8, s2);

@@ -191,6 +191,12 @@ struct UicGemmParams {
   // ---- split-K over workgroups (large-GEMM path only): slice z of `splitk` writes its raw partial tile to
   // slab[z][M][N] (f32, dense); uic_splitk_reduce_launch sums the slabs in a fixed order (deterministic)
   int splitk; float* slab;
+  // ---- fused backward-of-ReLU epilogue (ping-pong kernel only, gemm_pp.hip): v = (acc + acc_src[row, col]); then, with
+  // mask_act (operand dtype, the forward activation), v = mask_act[row, col] > 0 ? v * mask_scale : 0 -- d att' = d p_att W_ctx2att
+  // + the attention's own share, masked by att' > 0 and scaled by the dropout keep factor, written as the bf16 operand of
+  // att_embed's weight gradient in one pass (was: GEMM into f32, then a 94 MB relu_mask_bwd pass)
+  const float* acc_src; int ld_acc_src;
+  const void* mask_act; int ld_mask_act; float mask_scale;
 };
 // C[row, c - col0] = sum_z slab[z][row, c] for c in [col0, col0 + ncols)
 int uic_splitk_reduce_launch(const float* slab, int splitk, int M, int N, int col0, int ncols, float* C, int ldc, hipStream_t s,
