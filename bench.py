@@ -179,26 +179,28 @@ def recurrence_roofline(tr, batch, t_run, den_local, dtype_name, extra_steps=6):
 
 
 def gemm_roofline(dtype_id, dtype_name, iters=32):
-    """The dominant MFMA-bound GEMM family of the step, the large NT kernel (uic_gemm_glds_kernel), on its largest
-    call: the logit layer of one 4-step chunk, [2560 x 512] x [9488 x 512]^T (P/models/AttModel.py:163) -- achieved
-    TFLOP/s from one HIP event pair per launch against the dense MFMA peak of the operand dtype."""
+    """The dominant MFMA-bound GEMM of the step on its largest call: att_embed, [N R x D] x [H x D]^T = 23040 x 512 x 2048
+    (P/models/AttModel.py:76-80,111) -- since round 4 the ping-pong kernel (csrc/gemm_pp.hip, 192-row tiles at this shape) in
+    bf16, the 128 x 128 LDS-DMA kernel in f32.  Achieved TFLOP/s from one HIP event pair per launch against the dense MFMA
+    peak of the operand dtype; a spin kernel in front of the timed launches lets the host run ahead, so that no pair contains
+    the host's enqueue time (as attention_roofline)."""
     from unpaired_image_captioning_amd import _lib as L
     lib = L.load()
     c = CFG
-    M, Nn, K = 4 * c["n_img"] * c["S"], c["V"] + 1, c["H"]
+    M, Nn, K = c["n_img"] * c["S"] * c["R"], c["H"], c["D"]
     td = L.TORCH_DTYPE[dtype_id]
     g = torch.Generator(device="cuda").manual_seed(2)
     Aop = torch.randn(M, K, device="cuda", generator=g).to(td)
     Bop = torch.randn(Nn, K, device="cuda", generator=g).to(td)
-    ldc = (Nn + 63) // 64 * 64
-    Cout = torch.empty(M, ldc, device="cuda", dtype=torch.float32)
+    Cout = torch.empty(M, Nn, device="cuda", dtype=td)
     bias = torch.zeros(Nn, device="cuda")
 
     def launch():
-        L.check(lib.uic_linear(dtype_id, M, Nn, K, L.ptr(Aop), K, L.ptr(Bop), K, L.ptr(Cout), ldc, L.ptr(bias), 4, L.stream()))
+        L.check(lib.uic_linear(dtype_id, M, Nn, K, L.ptr(Aop), K, L.ptr(Bop), K, L.ptr(Cout), Nn, L.ptr(bias), 1, L.stream()))   # (+ bias, ReLU)
     for _ in range(4):
         launch()
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(iters)]
+    torch.cuda._sleep(int(5e6))
     for a, b in ev:
         a.record()
         launch()
@@ -208,7 +210,8 @@ def gemm_roofline(dtype_id, dtype_name, iters=32):
     dur = sum(d[iters // 8: iters - iters // 8]) / (iters - 2 * (iters // 8)) / 1e3
     flops = 2.0 * M * Nn * K
     tf = flops / dur / 1e12
-    return {"bound": "mfma", "kernel": "uic_gemm_glds_kernel (logit layer of a 4-step chunk: %d x %d x %d)" % (M, Nn, K),
+    kern = "uic_gemm_pp_kernel<3> (192 x 256 ping-pong tiles)" if dtype_name == "bf16" else "uic_gemm_glds_kernel (128 x 128 tiles)"
+    return {"bound": "mfma", "kernel": "%s, att_embed: %d x %d x %d" % (kern, M, Nn, K),
             "achieved": round(tf, 1), "peak": MFMA_PEAK_TFLOPS[dtype_name], "unit": "TFLOP/s", "frac": round(tf / MFMA_PEAK_TFLOPS[dtype_name], 4),
             "flops_per_launch": flops, "us_per_launch": round(dur * 1e6, 2), "traffic": None}
 

@@ -413,6 +413,9 @@ int uic_comm_unique_id(void* id_out);
 int uic_comm_init(int32_t rank, int32_t world, const void* id, void** comm_out);
 int uic_comm_allreduce(void* comm, void* buf, size_t count, int32_t dtype, void* stream);
 int uic_comm_destroy(void* comm);
+/* Measurement aid (tools/comm_proxy.py), NOT a collective: a stand-in for one all-reduce of `bytes` bytes (a multiple of 16) on a
+ * single GPU -- `workgroups` 256-thread workgroups stream buf -> scratch -> buf on `stream`; buf is unchanged afterwards. */
+int uic_comm_proxy(void* buf, void* scratch, size_t bytes, int32_t workgroups, void* stream);
 
 /* ---- single operators (also used by the parity tests) ---- */
 

@@ -213,6 +213,7 @@ _SIGS = {
     "uic_comm_init": (C.c_int, [C.c_int32, C.c_int32, C.c_void_p, C.POINTER(C.c_void_p)]),
     "uic_comm_allreduce": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int32, C.c_void_p]),
     "uic_comm_destroy": (C.c_int, [C.c_void_p]),
+    "uic_comm_proxy": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int32, C.c_void_p]),
     "uic_topdown_step_marks": (C.c_int, [C.c_int32, C.POINTER(C.c_float)]),
     "uic_topdown_workspace_bytes": (C.c_size_t, [C.POINTER(Dims)]),
     "uic_topdown_derived_bytes": (C.c_size_t, [C.POINTER(Dims)]),

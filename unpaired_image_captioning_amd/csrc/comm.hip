@@ -107,3 +107,25 @@ int uic_comm_destroy(void* comm) {
 }
 
 }  // extern "C"
+
+// ---------------------------------------------------------------------------------------------------
+// A stand-in for one all-reduce of `bytes` bytes on a box with ONE GPU (tools/comm_proxy.py): RCCL's all-reduce kernels are a
+// co-resident load of a few workgroups that move every byte out and back over xGMI, so the stand-in is `workgroups` (8-32)
+// 256-thread workgroups that stream buf -> scratch -> buf (two passes over the bytes, nothing changes).  16 workgroups move
+// ~0.38 GB/ms, the order of an 8-GPU ring's bus bandwidth.  A measurement aid, not a collective.
+namespace {
+typedef __attribute__((ext_vector_type(4))) unsigned u32x4c;
+__global__ __launch_bounds__(256) void comm_proxy_kernel(u32x4c* buf, u32x4c* scratch, size_t n16) {
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += stride) scratch[i] = __builtin_nontemporal_load(buf + i);
+  __syncthreads();
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += stride) buf[i] = __builtin_nontemporal_load(scratch + i);
+}
+}  // namespace
+extern "C" int uic_comm_proxy(void* buf, void* scratch, size_t bytes, int32_t workgroups, void* stream) {
+  UIC_REQUIRE(buf && scratch && bytes % 16 == 0 && workgroups >= 1 && workgroups <= 1024, "comm_proxy: bad arguments");
+  if (bytes == 0) return UIC_OK;
+  hipLaunchKernelGGL(comm_proxy_kernel, dim3(workgroups), dim3(256), 0, (hipStream_t)stream, (u32x4c*)buf, (u32x4c*)scratch, bytes / 16);
+  UIC_LAUNCH_CHECK("comm_proxy_kernel");
+  return UIC_OK;
+}
