@@ -39,9 +39,9 @@ int uic_version(void);
  *                        be resident together.  Inside one process the library makes every persistent launch wait for the
  *                        previous one on its device, whatever streams they are on, so two passes meant to run side by side
  *                        (the self-critical step's sampling pass and greedy baseline) want the chains
- *   UIC_REC_BWD_PERSIST  the BPTT loop as one persistent launch per chunk of decode steps (bf16) instead of six launches per
- *                        step.  Off by default: alone it runs a step in 57 us instead of 82, but beside the side stream's
- *                        GEMMs of uic_topdown_xe_train_step both slow down (step 3.9 vs 3.6 ms)
+ *   UIC_REC_BWD_PERSIST  (uic_topdown_backward only) the BPTT loop as one persistent launch (bf16) instead of five launches
+ *                        per step: alone it runs a step in 57 us instead of 82.  uic_topdown_xe_train_step ignores it -- its
+ *                        side stream's GEMMs cannot run beside a kernel that holds every CU (3.81 vs 3.48 ms when tried)
  *   UIC_REC_SAFE         the persistent kernels use their placement-independent exchange protocol (device-scope stores, groups
  *                        by arrival order) instead of XCD-local groups -- same results bit for bit; tests
  *   UIC_REC_STAMPS       the persistent kernels write per-phase time stamps into the workspace ("rnn_dbg" / "rnn_bwd_dbg" of

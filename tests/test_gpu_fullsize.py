@@ -44,16 +44,17 @@ def case():
 
 
 # uic_topdown_dims.recurrence: per-step launches everywhere / the default (persistent forward recurrence) / the same with
-# the SAFE exchange protocol / persistent BPTT as well / that with the SAFE protocol / UIC_REC_EARLY_GRADS (three streams, the
-# embedding gradient in two halves)
-REC_MODES = {"chain": 1, "default": 0, "safe": 4, "bptt": 2, "bptt_safe": 6, "early": 16}
+# the SAFE exchange protocol / UIC_REC_EARLY_GRADS (three streams, the embedding gradient in two halves).  (The persistent BPTT
+# kernel serves the single-stream backward call only -- test_persistent_bptt_equals_the_launch_chain -- the fused step ignores
+# UIC_REC_BWD_PERSIST.)
+REC_MODES = {"chain": 1, "default": 0, "safe": 4, "early": 16}
 
 
 @pytest.mark.parametrize("mode", list(REC_MODES))
 @pytest.mark.parametrize("dtype", ["f32", "bf16"])
 def test_configs1_full_size_vs_oracle(case, dtype, mode):
     """Forward call, fused training step (loss, every gradient) at BASELINE configs[1] size against the oracle, in every
-    way the library can launch the recurrence (REC_MODES; the f32 path has no persistent BPTT kernel and runs the chain)."""
+    way the library can launch the recurrence (REC_MODES)."""
     from unpaired_image_captioning_amd.trainer import xe_step
     Lb = _lib()
     W, b, ref_loss, ref_grads, ref_logp = case
@@ -80,9 +81,7 @@ def test_configs1_full_size_vs_oracle(case, dtype, mode):
         model.engine.recurrence = 0
     assert st[0] == 0
     launches = (st[1] - before[1], st[2] - before[2])            # (XCD-local, SAFE) persistent launches of this test
-    chunks = (t_run + 3) // 4                                      # BPTT: one launch per hand-off chunk of the fused step
-    want = {"chain": (0, 0), "default": (2, 0), "safe": (0, 2), "bptt": (2 + (chunks if dtype == "bf16" else 0), 0),
-            "bptt_safe": (0, 2 + (chunks if dtype == "bf16" else 0)), "early": (2, 0)}[mode]
+    want = {"chain": (0, 0), "default": (2, 0), "safe": (0, 2), "early": (2, 0)}[mode]
     assert launches == want, (mode, launches, want)
     floor = 1e-3 * max(float(v.norm()) for v in ref_grads.values())
     worst = max(((grads[k].float().cpu().double() - r.double()).norm() / max(r.double().norm().item(), floor)).item() for k, r in ref_grads.items())
@@ -238,9 +237,8 @@ def test_persistent_bptt_equals_the_launch_chain(n_img, S):
     assert after[1] - before[1] == 4 * n_launch + 2 * n_launch and after[2] - before[2] == n_launch
     floor = 1e-3 * max(float(v.norm()) for k, v in ref.items() if k.startswith("grad:"))
     for k in ref:
-        if k != "grad:embed.0.weight":                   # (the embedding gradient's atomics are order-dependent in both modes)
-            assert torch.equal(got1[k], got1b[k]), k                     # bit-repeatable
-            assert torch.equal(got1[k], got2[k]), k                      # independent of the protocol / placement
+        assert torch.equal(got1[k], got1b[k]), k                         # bit-repeatable (the embedding gradient included)
+        assert torch.equal(got1[k], got2[k]), k                          # independent of the protocol / placement
         den = max(float(ref[k].norm()), floor if k.startswith("grad:") else 1e-30)
         err = float((got1[k] - ref[k]).norm()) / den
         # measured at 640 rows: per-step buffers 3e-4 .. 9e-4 (bf16 rounding of the gate gradients after a different f32

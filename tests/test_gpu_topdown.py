@@ -198,9 +198,7 @@ def test_two_stream_train_step_equals_separate_calls():
         assert l1.item() == l2.item()
         chunked = ("core.att_lstm.weight", "core.lang_lstm.weight", "core.attention.h2att.weight")
         for k in g1:
-            if k == "embed.0.weight":        # scatter-add by float atomics: summation order may differ
-                assert (g1[k] - g2[k]).abs().max().item() <= 1e-6 * max(1.0, g2[k].abs().max().item())
-            elif k.startswith(chunked):      # fused step: accumulated chunk by chunk (4 decode steps) behind the BPTT loop
+            if k.startswith(chunked):      # fused step: accumulated chunk by chunk (4 decode steps) behind the BPTT loop
                 assert (g1[k] - g2[k]).abs().max().item() <= 2e-5 * max(1e-3, g2[k].abs().max().item()), k
             else:
                 assert torch.equal(g1[k], g2[k]), k

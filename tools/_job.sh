@@ -1,5 +1,5 @@
-cd /tmp && export TMPDIR=/tmp
-timeout 300 rocprofv3 --kernel-trace --output-format csv -d /tmp/pq -- python3 $GRAFT_REPO_ROOT/tools/_probe.py > /tmp/pq.log 2>&1
-tail -2 /tmp/pq.log
-python3 $GRAFT_REPO_ROOT/tools/step_timeline.py $(find /tmp/pq -name "*kernel_trace.csv" | head -1) 8 --full > $GRAFT_REPO_ROOT/gpurun_out/r4_proxy_timeline.txt 2>&1
-grep -n "comm_proxy\|persist\|adam\|step wall\|queue" $GRAFT_REPO_ROOT/gpurun_out/r4_proxy_timeline.txt | head -40
+cd $GRAFT_REPO_ROOT
+timeout 1500 python -m pytest tests -m gpu -x -q > gpurun_out/r4_suite3.log 2>&1
+grep -E "passed|failed" gpurun_out/r4_suite3.log | tail -3
+grep -E "^E |Error" gpurun_out/r4_suite3.log | head -10
+for i in 1 2; do python bench.py --no-f32 --no-cpu-baseline 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.readline()); print(d['ms_per_step'], d['value'])"; done

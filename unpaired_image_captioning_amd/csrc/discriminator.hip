@@ -40,6 +40,7 @@ struct DLayout {
   void* c_hw; void* hwT;                            // [2Ft, Ft], [Ft, 2Ft]
   void* tA; void* tB; float* colscratch; size_t colscratch_floats; float* slab; size_t slab_bytes;
   float* scal;
+  int* embed_scratch;   // uic_embed_bwd_sorted_launch
   size_t total;
 };
 
@@ -92,6 +93,7 @@ DLayout make_layout(const uic_disc_dims& d, void* ws) {
   L.slab_bytes = sl;
   L.slab = (float*)b.take(sl);
   L.scal = (float*)b.take(256);
+  L.embed_scratch = (int*)b.take(uic_embed_bwd_sorted_scratch_ints(d.N, d.L, d.V1, d.E) * 4);
   L.total = (b.off + 255) & ~(size_t)255;
   return L;
 }
@@ -363,8 +365,7 @@ int uic_disc_backward(const uic_disc_dims* d, const uic_disc_weights* w, const i
     }
   }
   UIC_TRY(flush());
-  UIC_TRY(uic_fill_launch(G->embed_w, 0, (size_t)d->V1 * E * 4, s));
-  UIC_TRY(uic_embed_bwd_launch(dt, L.dx, L.x, tokens, ld_tokens, N, T, d->V1, E, 0.f, -1, G->embed_w, s));
+  UIC_TRY(uic_embed_bwd_sorted_launch(dt, L.dx, L.x, tokens, ld_tokens, N, T, d->V1, E, 0.f, -1, G->embed_w, L.embed_scratch, s));
   return UIC_OK;
 }
 

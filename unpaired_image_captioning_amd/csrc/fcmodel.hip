@@ -35,6 +35,7 @@ struct FcLayout {
   // beam search bookkeeping (rows = (image, beam))
   float* bm_cand_val; int* bm_cand_idx; int64_t* bm_seq[2]; float* bm_lp[2]; float* bm_sum; int* bm_parent;
   int* bm_done_count; float* bm_done_p; int64_t* bm_done_seq; float* bm_done_lp;
+  int* embed_scratch;   // uic_embed_bwd_sorted_launch
   size_t total;
 };
 
@@ -106,6 +107,7 @@ FcLayout fc_layout(const uic_fc_dims& d, const uic_fc_weights* w, void* ws) {
   L.bm_done_p = (float*)b.take(N * S * 4);
   L.bm_done_seq = (int64_t*)b.take(N * S * S * 8);
   L.bm_done_lp = (float*)b.take(N * S * S * 4);
+  L.embed_scratch = (int*)b.take(uic_embed_bwd_sorted_scratch_ints((int)N, (int)S, d.V1, d.E) * 4);
   L.total = (b.off + 255) & ~(size_t)255;
   return L;
 }
@@ -295,8 +297,9 @@ int uic_fc_backward(const uic_fc_dims* d, const uic_fc_weights* w, const uic_top
     g.C = L.dx_all; g.ldc = E; g.flags = UIC_GEMM_OUT_F32;
     UIC_TRY(uic_gemm_launch(g, s));
   }
-  UIC_TRY(uic_fill_launch(G->embed_w, 0, (size_t)V1 * E * 4, s));
-  UIC_TRY(uic_embed_bwd_launch(dt, L.dx_all + (size_t)N * E, nullptr, b->labels, b->ld_labels, N, s_run - 1, V1, E, 0.f, -1, G->embed_w, s));
+  // (bucketed by word, one owner per table row: bit-reproducible, no floating-point atomics -- csrc/pointwise.hip)
+  UIC_TRY(uic_embed_bwd_sorted_launch(dt, L.dx_all + (size_t)N * E, nullptr, b->labels, b->ld_labels, N, s_run - 1, V1, E, 0.f, -1, G->embed_w,
+                                      L.embed_scratch, s));
   // img_embed from d x_0
   UIC_TRY(uic_cast_f32_launch(dt, L.dx_all, L.dx0, (size_t)N * E, s));
   {

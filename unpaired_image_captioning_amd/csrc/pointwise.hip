@@ -404,12 +404,16 @@ __global__ __launch_bounds__(128) void embed_gather_kernel(const float* __restri
     }
   }
 }
-// the owner of a straddling bucket (the workgroup whose entries hold the bucket's first position) adds the partial rows in list
-// order and stores the table row
-__global__ __launch_bounds__(128) void embed_gather_finish_kernel(const int64_t* __restrict__ tokens, int ldtok, int N, int V1,
-                                                                  const int* __restrict__ off, const int* __restrict__ perm, int total, int E,
-                                                                  float inv_keep, long skip_token, float* __restrict__ dtable, int base, int keybase,
-                                                                  int accum, const float* __restrict__ part, int chunk0, size_t plane) {
+// the owner of a straddling bucket (the workgroup whose entries hold the bucket's first position) adds the partial rows and
+// stores the table row.  A hot bucket spans hundreds of workgroups (the padding token: ~190 partial rows), so the sum is split
+// over EMB_FG groups of 128 threads -- group g takes the partial rows k = g, g + EMB_FG, ... in that order, the groups' sums are
+// added in group order through LDS: a fixed summation tree, whatever the timing (one thread walking all rows took 33 us).
+constexpr int EMB_FG = 8;
+__global__ __launch_bounds__(128 * EMB_FG) void embed_gather_finish_kernel(const int64_t* __restrict__ tokens, int ldtok, int N, int V1,
+                                                                           const int* __restrict__ off, const int* __restrict__ perm, int total, int E,
+                                                                           float inv_keep, long skip_token, float* __restrict__ dtable, int base, int keybase,
+                                                                           int accum, const float* __restrict__ part, int chunk0, size_t plane) {
+  __shared__ float4 s_sum[EMB_FG][128];
   const int start = base + blockIdx.x * EMB_CH;
   const int cnt = min(EMB_CH, total - start);
   const int pos = perm[start + cnt - 1];                      // the workgroup's last entry
@@ -420,17 +424,29 @@ __global__ __launch_bounds__(128) void embed_gather_finish_kernel(const int64_t*
   const int b0 = off[keybase + tok], b1 = off[keybase + tok + 1];
   if (b0 < start || b1 <= start + cnt) return;                // began earlier (somebody else's), or ends here (stored by the gather)
   const int c_last = (b1 - 1 - base) / EMB_CH;                // the workgroup that holds the bucket's last entry
-  for (int c = threadIdx.x; c < E / 4; c += blockDim.x) {
-    float4 acc = *(const float4*)(part + plane + (size_t)(chunk0 + blockIdx.x) * E + c * 4);
-#pragma unroll 4
-    for (int k = blockIdx.x + 1; k <= c_last; ++k) {
-      const float4 q = *(const float4*)(part + (size_t)(chunk0 + k) * E + c * 4);
-      acc.x += q.x; acc.y += q.y; acc.z += q.z; acc.w += q.w;
+  const int g = threadIdx.x >> 7, lt = threadIdx.x & 127;
+  for (int c0 = 0; c0 < E / 4; c0 += 128) {
+    const int c = c0 + lt;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (c < E / 4) {
+      if (g == 0) acc = *(const float4*)(part + plane + (size_t)(chunk0 + blockIdx.x) * E + c * 4);   // the owner's own tail run
+#pragma unroll 8
+      for (int k = blockIdx.x + 1 + g; k <= c_last; k += EMB_FG) {
+        const float4 q = *(const float4*)(part + (size_t)(chunk0 + k) * E + c * 4);
+        acc.x += q.x; acc.y += q.y; acc.z += q.z; acc.w += q.w;
+      }
     }
-    float* o = dtable + (size_t)tok * E + c * 4;
-    float4 v = make_float4(acc.x * inv_keep, acc.y * inv_keep, acc.z * inv_keep, acc.w * inv_keep);
-    if (accum) { const float4 q = *(const float4*)o; v.x += q.x; v.y += q.y; v.z += q.z; v.w += q.w; }
-    *(float4*)o = v;
+    s_sum[g][lt] = acc;
+    __syncthreads();
+    if (g == 0 && c < E / 4) {
+#pragma unroll
+      for (int j = 1; j < EMB_FG; ++j) { const float4 q = s_sum[j][lt]; acc.x += q.x; acc.y += q.y; acc.z += q.z; acc.w += q.w; }
+      float* o = dtable + (size_t)tok * E + c * 4;
+      float4 v = make_float4(acc.x * inv_keep, acc.y * inv_keep, acc.z * inv_keep, acc.w * inv_keep);
+      if (accum) { const float4 q = *(const float4*)o; v.x += q.x; v.y += q.y; v.z += q.z; v.w += q.w; }
+      *(float4*)o = v;
+    }
+    __syncthreads();
   }
 }
 
@@ -1521,7 +1537,7 @@ int uic_embed_bwd_sorted_gather(int dtype, const float* dxt, const void* xt, con
              hipLaunchKernelGGL(embed_gather_kernel<bf16_t>, dim3(gw), dim3(128), 0, s, dxt, (const bf16_t*)xt, tokens, ldtok, N, V1, off, perm, total, E, inv_keep, skip_token, dtable, base, keybase, accum, part, chunk0, plane),
              hipLaunchKernelGGL(embed_gather_kernel<float>, dim3(gw), dim3(128), 0, s, dxt, (const float*)xt, tokens, ldtok, N, V1, off, perm, total, E, inv_keep, skip_token, dtable, base, keybase, accum, part, chunk0, plane));
   UIC_LAUNCH_CHECK("embed_gather");
-  hipLaunchKernelGGL(embed_gather_finish_kernel, dim3(gw), dim3(128), 0, s, tokens, ldtok, N, V1, off, perm, total, E, inv_keep, skip_token, dtable, base, keybase, accum, (const float*)part, chunk0, plane);
+  hipLaunchKernelGGL(embed_gather_finish_kernel, dim3(gw), dim3(128 * EMB_FG), 0, s, tokens, ldtok, N, V1, off, perm, total, E, inv_keep, skip_token, dtable, base, keybase, accum, (const float*)part, chunk0, plane);
   UIC_LAUNCH_CHECK("embed_gather_finish");
   return UIC_OK;
 }

@@ -1439,6 +1439,10 @@ int uic_topdown_xe_train_step(const uic_topdown_dims* d, const uic_topdown_weigh
   hipStream_t s3 = ss->stream3;
   Step st;
   st.init(d, w, derived, b, t_run, training, seed, workspace, G);
+  // The fused step's BPTT is always the launch chain: the persistent BPTT kernel holds every CU, which serialises the side
+  // stream's GEMMs behind it (measured 3.81 vs 3.48 ms, profiles/r03_v4_rnn_bwd_probe.txt); UIC_REC_BWD_PERSIST selects it for
+  // the single-stream uic_topdown_backward call only, where nothing runs beside it.
+  st.d.recurrence &= ~UIC_REC_BWD_PERSIST;
   const bool early = st.early_grads();
   const int CH = WG_CHUNK;                            // decode steps per hand-off to the side stream
   const int nchunk = (t_run + CH - 1) / CH;
