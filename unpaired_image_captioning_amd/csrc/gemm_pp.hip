@@ -46,7 +46,10 @@ template <int RT, bool SLAB>
 __global__ __launch_bounds__(512) void uic_gemm_pp_kernel(const UicGemmParams p) {
   static_assert(RT == 2 || RT == 3 || RT == 4, "row fragments per sub-half");
   constexpr int BM = 64 * RT;              // rows of the tile; a wave owns 32 RT of them, a sub-half is 16 RT
-  extern __shared__ __attribute__((aligned(16))) char smem[];   // [2][A 32 KB | B 32 KB]
+  constexpr unsigned ABYTES = (unsigned)BM * 128u;       // one K tile of A in LDS; B (256 rows) follows it
+  constexpr unsigned BUFB = ABYTES + 32768u;             // one K-tile buffer: 64 / 56 / 48 KB -- the shorter tiles leave LDS for
+                                                         // a co-resident workgroup of another stream (the BPTT chain's kernels)
+  extern __shared__ __attribute__((aligned(16))) char smem[];   // [2][A 8 RT KB | B 32 KB]
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -100,17 +103,17 @@ __global__ __launch_bounds__(512) void uic_gemm_pp_kernel(const UicGemmParams p)
       srcA[s][j] = (const char*)sg.A + ((size_t)gm * sg.lda + (size_t)kt0 * 64) * 2 + chA * 16;
       srcB[s][j] = (const char*)sg.B + ((size_t)gn * sg.ldb + (size_t)kt0 * 64) * 2 + chB * 16;
       dstA[s][j] = (unsigned)(rowA0 * 128);
-      dstB[s][j] = 32768u + (unsigned)(((qb >> 2) * 64 + s * 32 + (qb & 3) * 8) * 128);
+      dstB[s][j] = ABYTES + (unsigned)(((qb >> 2) * 64 + s * 32 + (qb & 3) * 8) * 128);
     }
 #define PP_GLDS(SRC, DST)                                                                                   \
   __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(SRC),                   \
                                    (__attribute__((address_space(3))) void*)(smem + (DST)), 16, 0, 0)
 #define PP_STAGE_A(S, BUF)                                                                                   \
   do {                                                                                                      \
-    PP_GLDS(srcA[S][0], dstA[S][0] + (BUF) * 65536u); srcA[S][0] += 128;                                    \
-    if (RT == 4 || (RT == 3 && wr == 0)) { PP_GLDS(srcA[S][1], dstA[S][1] + (BUF) * 65536u); srcA[S][1] += 128; } \
+    PP_GLDS(srcA[S][0], dstA[S][0] + (BUF) * BUFB); srcA[S][0] += 128;                                      \
+    if (RT == 4 || (RT == 3 && wr == 0)) { PP_GLDS(srcA[S][1], dstA[S][1] + (BUF) * BUFB); srcA[S][1] += 128; }   \
   } while (0)
-#define PP_STAGE_B(S, BUF) do { PP_GLDS(srcB[S][0], dstB[S][0] + (BUF) * 65536u); PP_GLDS(srcB[S][1], dstB[S][1] + (BUF) * 65536u); \
+#define PP_STAGE_B(S, BUF) do { PP_GLDS(srcB[S][0], dstB[S][0] + (BUF) * BUFB); PP_GLDS(srcB[S][1], dstB[S][1] + (BUF) * BUFB); \
                                 srcB[S][0] += 128; srcB[S][1] += 128; } while (0)
   // all but the three youngest units (always b0, a0, b1 where the schedule waits) have landed
 #define PP_WAIT_UNITS                                                                      \
@@ -128,9 +131,9 @@ __global__ __launch_bounds__(512) void uic_gemm_pp_kernel(const UicGemmParams p)
   for (int ks = 0; ks < 2; ++ks) {
     const unsigned pc = (unsigned)(((ks * 4 + kg) ^ sw) * 16);
     adA0[ks] = lds0 + (unsigned)((wr * 32 * RT + fr) * 128) + pc;
-    adB0[ks] = lds0 + 32768u + (unsigned)((wc * 64 + fr) * 128) + pc;
-    adA1[ks] = adA0[ks] + 65536u;
-    adB1[ks] = adB0[ks] + 65536u;
+    adB0[ks] = lds0 + ABYTES + (unsigned)((wc * 64 + fr) * 128) + pc;
+    adA1[ks] = adA0[ks] + BUFB;
+    adB1[ks] = adB0[ks] + BUFB;
   }
 
   f32x4 acc[2 * RT][4];
@@ -386,7 +389,7 @@ namespace {
 template <int RT>
 int launch_pp(const UicGemmParams& p, hipStream_t s) {
   static bool configured = false;
-  constexpr int lds = 2 * 65536;
+  constexpr int lds = 2 * (64 * RT * 128 + 32768);
   if (!configured) {
     UIC_TRY(uic_check_hip(hipFuncSetAttribute((const void*)uic_gemm_pp_kernel<RT, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds), "hipFuncSetAttribute(gemm pp)"));
     UIC_TRY(uic_check_hip(hipFuncSetAttribute((const void*)uic_gemm_pp_kernel<RT, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds), "hipFuncSetAttribute(gemm pp slab)"));
