@@ -478,6 +478,11 @@ int uic_adam_step_guarded(float* p, const float* g, float* m, float* v, size_t n
 int uic_grad_sqnorm(const float* g, size_t n, float* scratch, float* out, void* stream);
 int uic_adam_step_clip(float* p, const float* g, float* m, float* v, size_t n, float lr, float beta1, float beta2,
                        float eps, int32_t step, float grad_scale, float max_norm, const float* sqnorm, void* stream);
+/* ... skipped on the device when skip_if_nonzero[0] has any bit set (as uic_adam_step_guarded: the pivot NMT step's persistent
+ * launches, uic_nmt_dims.rnn_status) */
+int uic_adam_step_clip_guarded(float* p, const float* g, float* m, float* v, size_t n, float lr, float beta1, float beta2,
+                               float eps, int32_t step, float grad_scale, float max_norm, const float* sqnorm,
+                               const int32_t* skip_if_nonzero, void* stream);
 
 /* LanguageModelCriterion on materialised log-probs [N, T, V1] (API-compatible path): loss_out[0] and,
  * if dlogp != NULL, the dense gradient scaled by grad_out (host scalar). */

@@ -349,6 +349,46 @@ def test_trainer_nmt_half_runs_and_saves(tmp_path):
     assert list(sd.keys()) == tr.nmt_model.param_names
 
 
+def test_trainer_nmt_step_after_a_timeout_is_skipped_on_the_device_and_raises(tmp_path):
+    """The status word the persistent pivot kernels (csrc/nmt_persist.hip) set when a bounded spin gives up, forced here: the
+    clipped Adam update must be skipped on the device (uic_adam_step_clip_guarded), train_nmt must raise with the step counters
+    rolled back, and the next call must train exactly as if the bad step had never been issued."""
+    from unpaired_image_captioning_amd import _lib as Lb
+    from unpaired_image_captioning_amd.trainer import Trainer
+    cfg = dict(layers=2, H=64, W=64, B=8, S=10, T=9, Vs=120, Vt=130)
+    I = synthetic(cfg, 9)
+    batch = argparse.Namespace(src=I["src"].cuda(), tgt=I["tgt"].cuda(), lengths=I["lengths"])
+
+    def fresh():
+        o = make_opt(cfg, "bf16", dropout=0.0, seed=3)
+        o.nmt_train_flag, o.i2t_train_flag, o.checkpoint_path = 1, 0, str(tmp_path)
+        o.nmt_learning_rate, o.nmt_max_grad_norm, o.param_init = 5e-3, 5, 0.1
+        tr = Trainer(o)
+        tr.build_nmt(cfg["Vs"], cfg["Vt"])
+        return tr
+
+    ref = fresh()
+    W0 = {k: v.clone() for k, v in ref.nmt_model.state_dict().items()}
+    ref_losses = [ref.train_nmt(batch) for _ in range(2)]
+    tr = fresh()
+    tr.nmt_model.load_state_dict(W0)
+    assert tr.train_nmt(batch) == ref_losses[0]
+    ar = tr.optim.nmt_arena
+    snap = (ar.flat.clone(), ar.exp_avg.clone(), ar.exp_avg_sq.clone(), tr.optim._nmt_steps, tr.optim._step)
+    Lb.status_words()[0] = 0x7
+    torch.cuda.synchronize()
+    try:
+        with pytest.raises(RuntimeError, match="timed out"):
+            tr.train_nmt(batch)
+        assert int(Lb.status_words()[0]) == 0                       # cleared by the raise
+    finally:
+        Lb.status_words().zero_()
+    assert torch.equal(ar.flat, snap[0]) and torch.equal(ar.exp_avg, snap[1]) and torch.equal(ar.exp_avg_sq, snap[2])
+    assert (tr.optim._nmt_steps, tr.optim._step) == snap[3:]
+    assert tr.train_nmt(batch) == ref_losses[1]
+    assert torch.equal(ar.flat, ref.optim.nmt_arena.flat)
+
+
 @pytest.mark.parametrize("name", ["nmt_translate_tiny", "nmt_translate_odd", "nmt_translate_1layer", "nmt_translate_long"])
 def test_nmt_translate_batch_vs_reference_golden(name):
     """NMTModel.translateBatch + onmt Beam (beam 15, up to 100 steps) on the device, f32: hypotheses token for token, the

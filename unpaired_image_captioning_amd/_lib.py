@@ -290,6 +290,8 @@ _SIGS = {
     "uic_grad_sqnorm": (C.c_int, [C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p]),
     "uic_adam_step_clip": (C.c_int, [C.c_void_p] * 4 + [C.c_size_t] + [C.c_float] * 4 + [C.c_int32, C.c_float, C.c_float,
                                                                                       C.c_void_p, C.c_void_p]),
+    "uic_adam_step_clip_guarded": (C.c_int, [C.c_void_p] * 4 + [C.c_size_t] + [C.c_float] * 4 + [C.c_int32, C.c_float, C.c_float,
+                                              C.c_void_p, C.c_void_p, C.c_void_p]),
     "uic_lm_criterion": (C.c_int, [C.c_int32] * 3 + [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32,
                                    C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_void_p]),
     "uic_reward_criterion": (C.c_int, [C.c_int32, C.c_int32] + [C.c_void_p] * 6),

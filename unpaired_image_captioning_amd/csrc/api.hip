@@ -225,6 +225,20 @@ int uic_adam_step_clip(float* p, const float* g, float* m, float* v, size_t n, f
   return uic_adam_launch(a, (hipStream_t)stream);
 }
 
+int uic_adam_step_clip_guarded(float* p, const float* g, float* m, float* v, size_t n, float lr, float beta1, float beta2,
+                               float eps, int32_t step, float grad_scale, float max_norm, const float* sqnorm,
+                               const int32_t* skip_if_nonzero, void* stream) {
+  UIC_REQUIRE(p && g && m && v && sqnorm, "adam_step_clip_guarded: null pointer");
+  UIC_REQUIRE(step >= 1 && max_norm > 0.f, "adam_step_clip_guarded: step=%d must be >= 1 and max_norm=%f > 0", step, (double)max_norm);
+  UicAdamParams a;
+  a.p = p; a.g = g; a.m = m; a.v = v; a.n = n; a.lr = lr; a.beta1 = beta1; a.beta2 = beta2; a.eps = eps;
+  a.bc1 = (float)(1.0 - pow((double)beta1, (double)step));
+  a.bc2 = (float)(1.0 - pow((double)beta2, (double)step));
+  a.grad_scale = grad_scale;
+  a.max_norm = max_norm; a.sqnorm = sqnorm; a.guard = skip_if_nonzero;
+  return uic_adam_launch(a, (hipStream_t)stream);
+}
+
 int uic_lm_criterion(int32_t N, int32_t T, int32_t V1, const float* logp, const int64_t* target, int32_t ld_target,
                      const float* mask, int32_t ld_mask, float* loss_out, float* scratch, float* dlogp, float grad_out,
                      void* stream) {

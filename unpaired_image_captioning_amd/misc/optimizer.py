@@ -59,17 +59,19 @@ class FlatArena(object):
         self.grad.zero_()
         self.bind_grads()
 
-    def adam(self, lr, betas, eps, step, grad_scale=1.0, max_norm=0.0):
+    def adam(self, lr, betas, eps, step, grad_scale=1.0, max_norm=0.0, guard=None):
+        """guard (optional, a device word): the update is skipped on the device when it is non-zero -- the status word of the
+        persistent kernels, so that a timed-out launch's gradients never reach the weights (include/uic_hip.h)."""
         lib = _lib.load()
         if max_norm and max_norm > 0:
             sq = self.scratch[1024:1025]
             check(lib.uic_grad_sqnorm(ptr(self.grad), self.numel, ptr(self.scratch), ptr(sq), stream()), "grad_sqnorm")
-            check(lib.uic_adam_step_clip(ptr(self.flat), ptr(self.grad), ptr(self.exp_avg), ptr(self.exp_avg_sq), self.numel,
-                                         lr, betas[0], betas[1], eps, step, grad_scale, float(max_norm), ptr(sq), stream()),
-                  "adam_step_clip")
+            check(lib.uic_adam_step_clip_guarded(ptr(self.flat), ptr(self.grad), ptr(self.exp_avg), ptr(self.exp_avg_sq), self.numel,
+                                                 lr, betas[0], betas[1], eps, step, grad_scale, float(max_norm), ptr(sq), ptr(guard),
+                                                 stream()), "adam_step_clip_guarded")
         else:
-            check(lib.uic_adam_step(ptr(self.flat), ptr(self.grad), ptr(self.exp_avg), ptr(self.exp_avg_sq), self.numel,
-                                    lr, betas[0], betas[1], eps, step, grad_scale, stream()), "adam_step")
+            check(lib.uic_adam_step_guarded(ptr(self.flat), ptr(self.grad), ptr(self.exp_avg), ptr(self.exp_avg_sq), self.numel,
+                                            lr, betas[0], betas[1], eps, step, grad_scale, ptr(guard), stream()), "adam_step_guarded")
 
     def grad_norm(self):
         """Host value of the global gradient L2 norm (diagnostics; synchronises)."""
@@ -166,8 +168,17 @@ class Optim(object):
                                                      min(self._step ** (-0.5), self._step * self.nmt_warmup_steps ** (-1.5)))
             self._exchange(self.nmt_arena)
             self._nmt_steps += 1
+            # the pivot step's persistent launches (csrc/nmt_persist.hip) report a time-out in the status words: the update is
+            # then skipped on the device -- on every rank (the flag is summed over them) -- and Trainer.train_nmt raises
+            guard = None
+            if self.nmt_arena.flat.is_cuda:
+                guard = _lib.status_words(self.nmt_arena.flat.device)
+                if self.exchange is not None and self.exchange.world_size > 1:
+                    guard = guard[0:1].float()
+                    self.exchange._sum(guard)
+            self.last_guard = guard
             self.nmt_arena.adam(self.nmt_current_lr, (self.nmt_optim_alpha, self.nmt_optim_beta), self.nmt_optim_epsilon,
-                                self._nmt_steps, nmt_grad_scale, self.nmt_max_grad_norm)
+                                self._nmt_steps, nmt_grad_scale, self.nmt_max_grad_norm, guard=guard)
 
     def zero_grad(self):
         if self.i2t_train_flag and self.i2t_arena is not None:

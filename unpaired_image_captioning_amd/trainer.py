@@ -518,7 +518,16 @@ class Trainer(object):
         self.nmt_crit.report_stats.n_src_words += int(nmt_batch.lengths.sum())
         self.nmt_train_ppl = self.nmt_crit.report_stats.ppl()
         self.nmt_train_acc = self.nmt_crit.report_stats.accuracy()
-        return float(nmt_loss.detach())
+        val = float(nmt_loss.detach())                # (the step's host sync)
+        guard = getattr(self.optim, 'last_guard', None)
+        if guard is not None and float(guard[0].item()) != 0:
+            # a persistent launch of this step timed out (on some rank): Optim.step skipped the update on the device
+            _lib.status_words().zero_()
+            self.optim._step -= 1
+            self.optim._nmt_steps -= 1
+            raise RuntimeError("persistent NMT kernel timed out: this step's update was skipped (weights and moments unchanged); "
+                               "engine.recurrence |= _lib.REC_FWD_CHAIN selects per-step launches")
+        return val
 
     def save_models(self, tag=''):
         """P/trainer.py:98-104: model_i2t[-best].pth = state_dict of the un-wrapped module."""
