@@ -183,7 +183,11 @@ def test_multinomial_sampling_scored_by_oracle():
 
 
 def test_two_stream_train_step_equals_separate_calls():
-    """uic_topdown_xe_train_step (recurrence + side-stream logit layer) == forward, xe_loss, backward in sequence."""
+    """uic_topdown_xe_train_step (recurrence + side-stream logit layer) == forward, xe_loss, backward in sequence.
+    bf16: bit for bit (but for the chunk-accumulated weight gradients).  f32: to rounding -- v_mfma_f32_32x32x2_f32 rounds a
+    row's dot product differently depending on the row's position inside the 32-row tile (measured with uic_linear: the same A
+    row gives a last-bit different result at row offset 6 and at row offset 12), and the fused step hands the logit layer chunks
+    of decode steps whose first row is a multiple of N = 6 here, not of 8 as for every real batch."""
     from unpaired_image_captioning_amd.trainer import xe_step
     cfg, W, I, Out, G, X = load_golden("topdown_odd")
     for dtype in ("f32", "bf16"):
@@ -200,6 +204,8 @@ def test_two_stream_train_step_equals_separate_calls():
         for k in g1:
             if k.startswith(chunked):      # fused step: accumulated chunk by chunk (4 decode steps) behind the BPTT loop
                 assert (g1[k] - g2[k]).abs().max().item() <= 2e-5 * max(1e-3, g2[k].abs().max().item()), k
+            elif dtype == "f32":
+                assert (g1[k] - g2[k]).abs().max().item() <= 2e-6 * max(1e-3, g2[k].abs().max().item()), k
             else:
                 assert torch.equal(g1[k], g2[k]), k
 

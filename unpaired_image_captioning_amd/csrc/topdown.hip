@@ -434,6 +434,7 @@ struct SideStream {
   hipEvent_t ev_s3 = nullptr;       // stream3 -> side: that share of every chunk so far is done
   hipEvent_t ev_prep = nullptr;     // side -> stream3: the embedding gradient's token bucketing is done
   hipEvent_t ev_den = nullptr, ev_done = nullptr;
+  hipEvent_t ev_pro3 = nullptr;     // third stream: its branch of the forward prologue (fc_embed, Gfc, initial state) is through
   hipEvent_t ev_pro = nullptr;      // side: its branch of the forward prologue (fc_embed, embedding, batched input GEMM) is through
   hipEvent_t ev_logit = nullptr;    // side: the logit layer's gradients and the loss are final (start of the BPTT loop)
   hipEvent_t ev_lstm = nullptr;     // side: lang_lstm.weight_{ih,hh} and att_lstm.weight_hh are final (right after the BPTT loop)
@@ -476,6 +477,7 @@ int get_side(SideStream** out) {
     UIC_TRY(uic_check_hip(hipEventCreateWithFlags(&ss.ev_den, hipEventDisableTiming), "hipEventCreate"));
     UIC_TRY(uic_check_hip(hipEventCreateWithFlags(&ss.ev_done, hipEventDisableTiming), "hipEventCreate"));
     UIC_TRY(uic_check_hip(hipEventCreateWithFlags(&ss.ev_pro, hipEventDisableTiming), "hipEventCreate"));
+    UIC_TRY(uic_check_hip(hipEventCreateWithFlags(&ss.ev_pro3, hipEventDisableTiming), "hipEventCreate"));
     UIC_TRY(uic_check_hip(hipEventCreateWithFlags(&ss.ev_early, hipEventDisableTiming), "hipEventCreate"));
     UIC_TRY(uic_check_hip(hipEventCreateWithFlags(&ss.ev_logit, hipEventDisableTiming), "hipEventCreate"));
     UIC_TRY(uic_check_hip(hipEventCreateWithFlags(&ss.ev_lstm, hipEventDisableTiming), "hipEventCreate"));
@@ -688,14 +690,19 @@ struct Step {
     if (with_gfc) { g.addend = L.gfc; g.add_mod = N; g.ld_add = H4; }
     return uic_gemm_launch(g, s);
   }
+  // part: 0 = everything; 1 = the side stream's branch (embedding, batched input GEMM, fc_embed, Gfc, initial state); 2 = the
+  // main stream's (att_embed, ctx2att); with gfc_separate() the side branch splits again into 3 = embedding + batched input
+  // GEMM and 4 = fc_embed + Gfc + initial state (independent of each other: the fused step gives 4 to its third stream)
   int fwd_prologue(hipStream_t s, int part = 0) {
     const void *f, *a;
     const bool sep = gfc_separate();
-    if (part != 2 && sep) {
+    UIC_REQUIRE(part < 3 || sep, "fwd_prologue: parts 3 / 4 need the separate Gfc");
+    if (part != 2 && part != 4 && sep) {
       UIC_TRY(fwd_embed(s));
       UIC_TRY(fwd_gx(s, false));
     }
-    UIC_TRY(prepare_features(d, w, dv, b, L, training, drop_p, seed, &f, &a, s, part));
+    if (part == 3) return UIC_OK;
+    UIC_TRY(prepare_features(d, w, dv, b, L, training, drop_p, seed, &f, &a, s, part == 4 ? 1 : part));
     if (part == 2) return UIC_OK;
     if (!sep) UIC_TRY(fwd_embed(s));
     UIC_TRY(fwd_gfc(s));
@@ -1451,8 +1458,8 @@ int uic_topdown_xe_train_step(const uic_topdown_dims* d, const uic_topdown_weigh
 #define UIC_MARK(i, strm) do { if (ss->marks_on) UIC_HIP(hipEventRecord(ss->mark[i], strm)); } while (0)
 
   UIC_MARK(0, s);
-  // main: loss denominator, features, recurrence; hands each finished chunk of steps to the side stream
-  if (b->masks) UIC_TRY(uic_masked_sum_launch(nullptr, b->masks, b->ld_masks, 1, d->N, d->T, st.L.scalars, st.L.scalars + 1, s));
+  // main: features, recurrence; hands each finished chunk of steps to the side stream.  ev_den: the step has begun (whatever
+  // the caller enqueued on `s` before it is done) -- the side streams start from there.
   const float* inv = inv_den ? inv_den : st.L.scalars + 1;
   UIC_HIP(hipEventRecord(ss->ev_den, s));
   UIC_HIP(hipStreamWaitEvent(s2, ss->ev_den, 0));
@@ -1463,13 +1470,24 @@ int uic_topdown_xe_train_step(const uic_topdown_dims* d, const uic_topdown_weigh
   const bool resume = (training & 4) != 0;
   UIC_REQUIRE(!resume || !st.ss_on(), "xe_train_step: a resumed step cannot use scheduled sampling");
   if (!resume) {
-    UIC_TRY(st.fwd_prologue(s2, 1));
+    // three branches: att_embed + ctx2att (main), embedding + batched input GEMM (side), fc_embed + Gfc + initial state (third
+    // stream: two small latency-bound GEMMs that would otherwise sit behind the batched input GEMM on the side stream)
+    const bool split3 = st.gfc_separate() && !st.ss_on();
+    if (split3) {
+      UIC_HIP(hipStreamWaitEvent(s3, ss->ev_den, 0));
+      UIC_TRY(st.fwd_prologue(s3, 4));
+      UIC_HIP(hipEventRecord(ss->ev_pro3, s3));
+    }
+    UIC_TRY(st.fwd_prologue(s2, split3 ? 3 : 1));
     UIC_HIP(hipEventRecord(ss->ev_pro, s2));
     UIC_TRY(flush_transposes(ss));                    // (behind the branch: only the backward pass reads them)
     UIC_TRY(st.fwd_prologue(s, 2));
     UIC_HIP(hipStreamWaitEvent(s, ss->ev_pro, 0));
+    if (split3) UIC_HIP(hipStreamWaitEvent(s, ss->ev_pro3, 0));
     if (ss->cast_recorded) UIC_HIP(hipStreamWaitEvent(s, ss->ev_cast, 0));   // the recurrence reads copies made on the side stream
   }
+  // side: the loss denominator (the criterion's first use of it is on this stream, after the recurrence)
+  if (b->masks) UIC_TRY(uic_masked_sum_launch(nullptr, b->masks, b->ld_masks, 1, d->N, d->T, st.L.scalars, st.L.scalars + 1, s2));
   UIC_MARK(1, s);
   // persistent mode 3: the whole recurrence as ONE launch (it holds every CU, nothing overlaps it); the logit layer follows
   // chunk by chunk on the side stream beside the BPTT loop
