@@ -423,6 +423,14 @@ int uic_comm_proxy(void* buf, void* scratch, size_t bytes, int32_t workgroups, v
 int uic_linear(int32_t dtype, int32_t M, int32_t N, int32_t K, const void* A, int32_t lda, const void* B, int32_t ldb,
                void* C, int32_t ldc, const float* bias, int32_t flags, void* stream);
 
+/* nn.Linear on an f32 input with bf16 weights (att_embed on the loader's f32 region features, P/models/AttModel.py:76-80 as
+ * prepared by :111-115): A[M,K] f32 is rounded to bf16 inside the GEMM -- bit for bit what uic_cast_from_f32 followed by uic_linear
+ * gives -- and, with a_bf16 != NULL, that bf16 image [M, ld_a_bf16] is stored as well (the weight gradient's operand), so the
+ * separate cast pass over the features disappears.  B[N,K] bf16, C bf16 (or f32 with flag 4), flags as uic_linear.
+ * Needs K % 128 == 0, N % 4 == 0, lda % 4 == 0, ld_a_bf16 % 8 == 0, 16-byte aligned operands, M * lda * 4 < 4 GB. */
+int uic_linear_f32a(int32_t M, int32_t N, int32_t K, const float* A, int32_t lda, const void* B, int32_t ldb,
+                    void* C, int32_t ldc, const float* bias, int32_t flags, void* a_bf16, int32_t ld_a_bf16, void* stream);
+
 /* The same product split over K: slice z of `splitk` (each a whole number of 128-byte K rounds) leaves its raw partial tile in
  * slab[z][M][N] (f32, dense); the caller sums the slices -- what the BPTT loop's d x GEMMs do, whose consumers (cell backward,
  * attention backward) add the slices while they read them.  One K segment, K % 64 == 0 (bf16) / % 32 (f32). */

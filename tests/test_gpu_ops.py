@@ -111,6 +111,54 @@ def test_linear_256_tile_kernel_equals_the_128_tile_kernel_and_torch(shape, flag
     assert rel_err(outs[0], outs[2].float()) < tol
 
 
+@pytest.mark.parametrize("shape", [(192, 256, 128), (300, 260, 256), (4608, 512, 2048), (2880, 512, 384), (1000, 1028, 640), (130, 8, 1024)])
+@pytest.mark.parametrize("flags", [0, 1, 5])
+@pytest.mark.parametrize("copy", [0, 1])
+def test_linear_with_f32_input_equals_cast_then_linear(shape, flags, copy):
+    """uic_linear_f32a (the ping-pong GEMM with an f32 A operand rounded on its way to LDS -- att_embed on the loader's f32 region
+    features): bit for bit what the cast pass followed by the bf16 ping-pong GEMM gives, and the stored bf16 image of A equals
+    torch's round-to-nearest-even cast.  Ragged row / column tiles (clamped source rows), 2 / 4 / 6 / 10 / 16 / 32 K tiles (the
+    register-staged A units' prologue, steady-state and last-iteration waits), with and without the image (the copy stores are
+    counted in the same vmcnt sequence), repeated launches equal."""
+    L = _lib()
+    lib = L.load()
+    M, N, K = shape
+    g = torch.Generator().manual_seed(M * 13 + N * 5 + K + flags)
+    A = torch.randn(M, K, generator=g) * 3
+    B = torch.randn(N, K, generator=g) / K ** 0.5
+    bias = torch.randn(N, generator=g)
+    out_f32 = bool(flags & 4)
+    Af, Ab, Bd, bd = A.cuda(), A.cuda().bfloat16(), dev(B, 1), dev(bias)
+    outs = []
+    for rep in range(2):
+        Cd = torch.full((M, N), 7.0, device="cuda", dtype=torch.float32 if out_f32 else torch.bfloat16)
+        img = torch.full((M, K), 7.0, device="cuda", dtype=torch.bfloat16)
+        L.check(lib.uic_linear_f32a(M, N, K, L.ptr(Af), K, L.ptr(Bd), K, L.ptr(Cd), N, L.ptr(bd), flags, L.ptr(img) if copy else None, K,
+                                    L.stream()))
+        torch.cuda.synchronize()
+        outs.append((Cd, img))
+    Cr = torch.full((M, N), 7.0, device="cuda", dtype=torch.float32 if out_f32 else torch.bfloat16)
+    L.check(lib.uic_linear(1, M, N, K, L.ptr(Ab), K, L.ptr(Bd), K, L.ptr(Cr), N, L.ptr(bd), flags | FORCE_192, L.stream()))
+    torch.cuda.synchronize()
+    assert torch.equal(outs[0][0], outs[1][0])
+    assert torch.equal(outs[0][0], Cr)
+    if copy:
+        assert torch.equal(outs[0][1], Ab) and torch.equal(outs[1][1], Ab)
+    else:
+        assert (outs[0][1] == 7.0).all()
+
+
+def test_linear_with_f32_input_rejects_what_it_cannot_run():
+    L = _lib()
+    lib = L.load()
+    a = torch.zeros(256, 256, device="cuda")
+    w = torch.zeros(256, 256, device="cuda", dtype=torch.bfloat16)
+    o = torch.zeros(256, 256, device="cuda")
+    assert lib.uic_linear_f32a(256, 256, 192, L.ptr(a), 192, L.ptr(w), 192, L.ptr(o), 256, None, 4, None, 192, L.stream()) < 0   # odd K tile count
+    assert lib.uic_linear_f32a(256, 256, 128, L.ptr(a), 130, L.ptr(w), 128, L.ptr(o), 256, None, 4, None, 128, L.stream()) < 0   # lda % 4
+    assert lib.uic_linear_f32a(256, 256, 128, L.ptr(a), 128, L.ptr(w), 128, L.ptr(o), 256, None, 4, L.ptr(w), 100, L.stream()) < 0   # image narrower than K
+
+
 def test_linear_256_tile_kernel_rejects_what_it_cannot_run():
     L = _lib()
     lib = L.load()

@@ -47,6 +47,23 @@ for name, M, N, K in [("logit fwd chunk", 2560, 9488, 512), ("att_embed fwd", 23
             tpp[i] = timeit(lambda: L.check(lib.uic_linear(1, M, N, K, L.ptr(A), K, L.ptr(B), K, L.ptr(Cu), ldc, L.ptr(bias), 4 | force, L.stream())))
             err = max(err, float((Cu[rows][:, :N] - ref).abs().max() / ref.abs().max()))
     print("%-44s %9.1f %9.1f %9.1f %9.1f %9.1f %9.1f %9.1f %9.1f   max rel err %.1e" % ("%s %dx%dx%d" % (name, M, N, K), t_lib, fl / t_lib / 1e6, t_uic, fl / t_uic / 1e6, t128, tpp[0], tpp[1], tpp[2], err))
+# att_embed on the loader's f32 features: cast pass + bf16 GEMM against the GEMM that rounds its f32 A operand itself
+# (uic_linear_f32a, with the bf16 image stored for the weight gradient)
+print("%-44s %10s %10s %10s %10s" % ("f32 input (att_embed 23040x512x2048)", "cast us", "bf16 GEMM", "sum", "f32-A GEMM"))
+for name, M, N, K in [("att_embed fwd", 23040, 512, 2048), ("att_embed fwd, 128 images", 4608, 512, 2048)]:
+    Af = torch.randn(M, K, device="cuda", generator=g)
+    Ab = torch.empty(M, K, device="cuda", dtype=torch.bfloat16)
+    B = torch.randn(N, K, device="cuda", generator=g).bfloat16()
+    Cb = torch.empty(M, N, device="cuda", dtype=torch.bfloat16)
+    bias = torch.zeros(N, device="cuda")
+    t_cast = timeit(lambda: L.check(lib.uic_cast_from_f32(1, L.ptr(Af), L.ptr(Ab), M * K, L.stream())))
+    # (forced onto the ping-pong kernel: the f32-A form shares its accumulation order, so the outputs must be identical)
+    t_gemm = timeit(lambda: L.check(lib.uic_linear(1, M, N, K, L.ptr(Ab), K, L.ptr(B), K, L.ptr(Cb), N, L.ptr(bias), 1 | 0x400, L.stream())))
+    ref = Cb.clone()
+    t_fold = timeit(lambda: L.check(lib.uic_linear_f32a(M, N, K, L.ptr(Af), K, L.ptr(B), K, L.ptr(Cb), N, L.ptr(bias), 1, L.ptr(Ab), K, L.stream())))
+    same = bool(torch.equal(ref, Cb))
+    t_noimg = timeit(lambda: L.check(lib.uic_linear_f32a(M, N, K, L.ptr(Af), K, L.ptr(B), K, L.ptr(Cb), N, L.ptr(bias), 1, None, K, L.stream())))
+    print("%-44s %10.1f %10.1f %10.1f %10.1f   identical %s   (without the bf16 image: %.1f us)" % ("%s %dx%dx%d" % (name, M, N, K), t_cast, t_gemm, t_cast + t_gemm, t_fold, same, t_noimg))
 print("%-44s %10s %10s" % ("NT split-K partials (uic_linear_partials)", "uic us", "uic TF/s"))
 for name, M, N, K, sk in [("BPTT d x2, 4 slices", 640, 1536, 2048, 4), ("BPTT d x2, 2 slices", 640, 1536, 2048, 2), ("BPTT d x2, 8 slices", 640, 1536, 2048, 8),
                           ("BPTT d x1, 4 slices", 640, 1024, 2048, 4), ("BPTT d x1, 8 slices", 640, 1024, 2048, 8),

@@ -265,6 +265,8 @@ _SIGS = {
     "uic_topdown_workspace_ptr": (C.c_void_p, [C.POINTER(Dims), C.c_void_p, C.c_char_p]),
     "uic_linear": (C.c_int, [C.c_int32] * 4 + [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32,
                              C.c_void_p, C.c_int32, C.c_void_p]),
+    "uic_linear_f32a": (C.c_int, [C.c_int32] * 3 + [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p,
+                                   C.c_int32, C.c_void_p, C.c_int32, C.c_void_p]),
     "uic_linear_partials": (C.c_int, [C.c_int32] * 4 + [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p]),
     "uic_ciderd_table_slots": (C.c_int64, [C.c_int64]),
     "uic_ciderd_table_build": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int64]),

@@ -97,6 +97,20 @@ int uic_linear(int32_t dtype, int32_t M, int32_t N, int32_t K, const void* A, in
   return uic_gemm_launch(g, (hipStream_t)stream);
 }
 
+int uic_linear_f32a(int32_t M, int32_t N, int32_t K, const float* A, int32_t lda, const void* B, int32_t ldb,
+                    void* C, int32_t ldc, const float* bias, int32_t flags, void* a_bf16, int32_t ld_a_bf16, void* stream) {
+  UIC_REQUIRE(A && B && C, "linear_f32a: null pointer");
+  UicGemmParams g;
+  memset(&g, 0, sizeof(g));
+  g.dtype = UIC_BF16; g.M = M; g.N = N; g.nseg = 1;
+  g.seg[0].A = A; g.seg[0].B = B; g.seg[0].K = K; g.seg[0].lda = lda; g.seg[0].ldb = ldb;
+  g.C = C; g.ldc = ldc; g.bias = bias; g.flags = flags;
+  g.a_f32 = 1; g.a_copy = a_bf16; g.ld_a_copy = ld_a_bf16;
+  UIC_REQUIRE(uic_gemm_pp_eligible(g), "linear_f32a: needs K %% 128 == 0, N %% 4 == 0, lda %% 4 == 0, 16-byte aligned operands, "
+              "ld_a_bf16 %% 8 == 0 and >= K, A below 4 GB (M=%d N=%d K=%d lda=%d)", M, N, K, lda);
+  return uic_gemm_launch(g, (hipStream_t)stream);
+}
+
 int uic_linear_partials(int32_t dtype, int32_t M, int32_t N, int32_t K, const void* A, int32_t lda, const void* B, int32_t ldb,
                         float* slab, int32_t splitk, void* stream) {
   UIC_REQUIRE(slab && splitk >= 1 && splitk <= 16, "linear_partials: slab / splitk=%d", splitk);

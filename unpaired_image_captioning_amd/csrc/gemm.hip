@@ -741,6 +741,10 @@ int launch_typed(const UicGemmParams& p, hipStream_t s) {
   if (p.lstm) return launch_cfg<T, 1, 4, 2, 1, 4, true>(p, s);
   const long blocks128 = (long)((p.M + 127) / 128) * ((p.N + 127) / 128);
   const bool glds_ok = p.nseg == 1 && p.seg[0].K % (128 / (int)sizeof(T)) == 0;
+  if (p.a_f32) {
+    UIC_REQUIRE(sizeof(T) == 2 && uic_gemm_pp_eligible(p), "gemm: an f32 A operand needs the ping-pong kernel (bf16, one K segment of whole 128-element rounds, < 4 GB)");
+    return uic_gemm_pp_launch(p, 0, s);
+  }
   if (p.acc_src || p.mask_act) {   // the fused backward-of-ReLU epilogue exists in the ping-pong kernel only (callers test uic_gemm_pp_eligible first)
     UIC_REQUIRE(sizeof(T) == 2 && !p.slab && uic_gemm_pp_eligible(p), "gemm: acc_src / mask_act need the ping-pong kernel (bf16, one K segment of whole 128-element rounds)");
     return uic_gemm_pp_launch(p, 0, s);

@@ -33,6 +33,18 @@
 // the CU with the most tiles: RT = 3 (192 rows) and RT = 2 (128 rows) are the same pipeline with 3 / 2 row fragments per
 // sub-half (12 / 8 MFMAs per phase, A units of 12 / 8 KB) for problems whose 256-row tile count falls badly against the 256
 // CUs (att_embed, 23040 x 512: 180 tiles of 256 rows, 240 of 192; d xt, 10880 x 512: 86 tiles of 256 rows, 170 of 128).
+//
+// f32 A operand (AF32; att_embed, whose input -- the loader's region features -- arrives as f32): A cannot take the LDS-DMA path
+// (it needs rounding), so an A unit is loaded into registers where the DMA was issued (two global_load_dwordx4 per eight-row
+// piece), and COMMITTED three phases later: counted vmcnt wait, v_cvt_pk_bf16_f32 x 4, one ds_write_b128 per piece to the
+// address the DMA would have written (lane-linear, source-side swizzle unchanged), lgkmcnt(0) before the phase's barrier.
+// (Loading whole 128-byte lines per instruction -- floats [4c, 4c+4) and [32+4c, ..) per lane, two ds_write_b64 and two 8-byte
+// copy stores per piece -- was built and measured: 87.8 us against 81.0 for this form at 23040 x 512 x 2048.)
+// Loaded at phases 1 / 3 / 5 / 7, committed at 4 / 6 / 8 / 2, read at 7 / 1' / 3' / 5' as before; two register sets (a0 units,
+// a1 units: 32 registers).  The column-0 workgroups also store the bf16 chunks (p.a_copy): the weight gradient's operand,
+// which a separate 283 MB cast pass used to make.  vmcnt counts loads, stores and LDS-DMA together in issue order, so every
+// even phase waits vmcnt(4 + nA + nS): the ops younger than the unit being committed are two B units (2 DMA each), one A unit
+// (nA loads) and the previous commit's nS copy stores.
 #include "uic_common.h"
 #include <type_traits>
 
@@ -42,8 +54,9 @@ typedef __attribute__((ext_vector_type(4))) unsigned u32x4pp;
 
 #define PP_DSR(dst, addr, off) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(off))
 
-template <int RT, bool SLAB>
+template <int RT, bool SLAB, bool AF32 = false>
 __global__ __launch_bounds__(512) void uic_gemm_pp_kernel(const UicGemmParams p) {
+  static_assert(!(AF32 && SLAB), "the f32-A path has no split-K form");
   static_assert(RT == 2 || RT == 3 || RT == 4, "row fragments per sub-half");
   constexpr int BM = 64 * RT;              // rows of the tile; a wave owns 32 RT of them, a sub-half is 16 RT
   constexpr unsigned ABYTES = (unsigned)BM * 128u;       // one K tile of A in LDS; B (256 rows) follows it
@@ -87,6 +100,14 @@ __global__ __launch_bounds__(512) void uic_gemm_pp_kernel(const UicGemmParams p)
   const char* srcA[2][2];
   const char* srcB[2][2];
   unsigned dstA[2][2], dstB[2][2];
+  unsigned offA[2][2], offC[2][2], wrA[2][2];          // (AF32 only)
+  f32x4 ra[2][2][2];                                   // (AF32 only) [unit a0 / a1][piece][16-byte half]: an A unit on its way to LDS
+  const void* const baseA = sg.A;
+  void* const baseC = p.a_copy;
+  const bool two = RT == 4 || (RT == 3 && wr == 0);    // this wave stages two pieces per A unit
+  // the bf16 image's stores are shared by the first two column tiles of a row tile: unit a0's rows by column 0, a1's by column 1
+  const bool cp0 = AF32 && p.a_copy != nullptr && bn == 0;
+  const bool cp1 = AF32 && p.a_copy != nullptr && bn == (gridDim.y > 1 ? 1 : 0);
 #pragma unroll
   for (int s = 0; s < 2; ++s)
 #pragma unroll
@@ -103,6 +124,11 @@ __global__ __launch_bounds__(512) void uic_gemm_pp_kernel(const UicGemmParams p)
       srcA[s][j] = (const char*)sg.A + ((size_t)gm * sg.lda + (size_t)kt0 * 64) * 2 + chA * 16;
       srcB[s][j] = (const char*)sg.B + ((size_t)gn * sg.ldb + (size_t)kt0 * 64) * 2 + chB * 16;
       dstA[s][j] = (unsigned)(rowA0 * 128);
+      if constexpr (AF32) {   // byte offsets from the f32 matrix (loads) and from its bf16 image (copy stores): < 4 GB, launch_pp checks
+        offA[s][j] = (unsigned)(((size_t)gm * sg.lda + (size_t)chA * 8) * 4);
+        offC[s][j] = (unsigned)(((size_t)gm * p.ld_a_copy + (size_t)chA * 8) * 2);
+        wrA[s][j] = (unsigned)(size_t)((__attribute__((address_space(3))) char*)smem) + dstA[s][j] + (unsigned)(lane * 16);
+      }
       dstB[s][j] = ABYTES + (unsigned)(((qb >> 2) * 64 + s * 32 + (qb & 3) * 8) * 128);
     }
 #define PP_GLDS(SRC, DST)                                                                                   \
@@ -112,6 +138,39 @@ __global__ __launch_bounds__(512) void uic_gemm_pp_kernel(const UicGemmParams p)
   do {                                                                                                      \
     PP_GLDS(srcA[S][0], dstA[S][0] + (BUF) * BUFB); srcA[S][0] += 128;                                      \
     if (RT == 4 || (RT == 3 && wr == 0)) { PP_GLDS(srcA[S][1], dstA[S][1] + (BUF) * BUFB); srcA[S][1] += 128; }   \
+  } while (0)
+  // AF32: the A unit's global loads (registers), and its commit three phases later
+#define PP_LOADA1(S, J)                                                                                                         \
+  do {                                                                                                                          \
+    asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(ra[S][J][0]) : "v"(offA[S][J]), "s"(baseA) : "memory");                 \
+    asm volatile("global_load_dwordx4 %0, %1, %2 offset:16" : "=v"(ra[S][J][1]) : "v"(offA[S][J]), "s"(baseA) : "memory");       \
+    offA[S][J] += 256;                                                                                                          \
+  } while (0)
+#define PP_LOADA(S) do { PP_LOADA1(S, 0); if (two) PP_LOADA1(S, 1); } while (0)
+#define PP_VMCNT(N) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory")
+  // all but the EXTRA + nA (+ nS) youngest vector-memory operations are done
+  // (ST: the previous commit stored its share of the image: those stores are among them)
+#define PP_WAIT_A(EXTRA, ST)                                                               \
+  do {                                                                                     \
+    if (two) { if (ST) PP_VMCNT((EXTRA) + 6); else PP_VMCNT((EXTRA) + 4); }                \
+    else     { if (ST) PP_VMCNT((EXTRA) + 3); else PP_VMCNT((EXTRA) + 2); }                \
+  } while (0)
+#define PP_COMMIT1(S, J, BUF, CP)                                                                                               \
+  do {                                                                                                                          \
+    asm volatile("" : "+v"(ra[S][J][0]), "+v"(ra[S][J][1]));                                                                     \
+    u32x4pp pk;                                                                                                                 \
+    pk[0] = uic_pack_bf16x2(ra[S][J][0][0], ra[S][J][0][1]); pk[1] = uic_pack_bf16x2(ra[S][J][0][2], ra[S][J][0][3]);             \
+    pk[2] = uic_pack_bf16x2(ra[S][J][1][0], ra[S][J][1][1]); pk[3] = uic_pack_bf16x2(ra[S][J][1][2], ra[S][J][1][3]);             \
+    asm volatile("ds_write_b128 %0, %1" ::"v"(wrA[S][J] + (unsigned)(BUF) * BUFB), "v"(pk) : "memory");                          \
+    if (CP) { asm volatile("global_store_dwordx4 %0, %1, %2" ::"v"(offC[S][J]), "v"(pk), "s"(baseC) : "memory"); }               \
+    offC[S][J] += 128;                                                                                                          \
+  } while (0)
+  // (the wait is the caller's: PP_WAIT_A / PP_VMCNT)
+#define PP_COMMIT_A(S, BUF)                                          \
+  do {                                                               \
+    PP_COMMIT1(S, 0, BUF, (S) ? cp1 : cp0);                          \
+    if (two) PP_COMMIT1(S, 1, BUF, (S) ? cp1 : cp0);                 \
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");               \
   } while (0)
 #define PP_STAGE_B(S, BUF) do { PP_GLDS(srcB[S][0], dstB[S][0] + (BUF) * BUFB); PP_GLDS(srcB[S][1], dstB[S][1] + (BUF) * BUFB); \
                                 srcB[S][0] += 128; srcB[S][1] += 128; } while (0)
@@ -192,19 +251,37 @@ __global__ __launch_bounds__(512) void uic_gemm_pp_kernel(const UicGemmParams p)
 #define PP_BARRIER do { __builtin_amdgcn_sched_barrier(0); __builtin_amdgcn_s_barrier(); __builtin_amdgcn_sched_barrier(0); } while (0)
 
   // ---- prologue: tile 0 whole, tile 1 less its a1 unit (phase 1 stages that one)
-  PP_STAGE_B(0, 0); PP_STAGE_A(0, 0); PP_STAGE_B(1, 0); PP_STAGE_A(1, 0);
-  PP_STAGE_B(0, 1); PP_STAGE_A(0, 1); PP_STAGE_B(1, 1);
-  PP_WAIT_UNITS;
+  if constexpr (AF32) {
+    // the same units, issued in the order an iteration's phases 5-8 would have issued them; tile 0's a0 is committed here, its
+    // a1 and tile 1's a0 stay in their registers (phases 1 and 3 commit them)
+    PP_LOADA(0);
+    PP_STAGE_B(0, 0); PP_STAGE_B(1, 0);
+    PP_LOADA(1);
+    PP_STAGE_B(0, 1);
+    PP_WAIT_A(6, false);                             // younger than tile 0's a0 loads: three B units + a1's loads
+    PP_COMMIT_A(0, 0);
+    PP_LOADA(0);
+    PP_STAGE_B(1, 1);
+    // tile 0's B units have landed: younger than them are a1's loads, b0 of tile 1, the image stores, a0's loads, b1 of tile 1
+    if (two) { if (cp0) PP_VMCNT(14); else PP_VMCNT(12); } else { if (cp0) PP_VMCNT(9); else PP_VMCNT(8); }
+  } else {
+    PP_STAGE_B(0, 0); PP_STAGE_A(0, 0); PP_STAGE_B(1, 0); PP_STAGE_A(1, 0);
+    PP_STAGE_B(0, 1); PP_STAGE_A(0, 1); PP_STAGE_B(1, 1);
+    PP_WAIT_UNITS;
+  }
   PP_BARRIER;
   if (wr == 1) PP_BARRIER;                 // waves 4-7 run one barrier behind from here on
 
   auto body = [&](auto last_c) {
     constexpr bool LAST = decltype(last_c)::value;
     // ---------------- K tile in buffer 0
+    // (AF32: every odd phase COMMITS the A unit loaded four phases earlier -- wait, round, ds_write, lgkmcnt(0) -- and then loads
+    // the next unit of the same kind into the registers it freed; the commit's counted wait also retires the B units in time)
     // phase 1
     PP_READ_B(b0, 0, adB0); PP_READ_A(0, adA0);
     PP_WAIT_B_READS;
-    PP_STAGE_A(1, 1);
+    if constexpr (AF32) { PP_WAIT_A(4, cp0); PP_COMMIT_A(1, 0); PP_LOADA(1); }      // a1 of this tile (buffer 0), read in phase 3
+    else PP_STAGE_A(1, 1);
     PP_BARRIER;
     PP_WAIT_READS(b0);
     PP_MFMA(0, 0, b0);
@@ -218,14 +295,20 @@ __global__ __launch_bounds__(512) void uic_gemm_pp_kernel(const UicGemmParams p)
     PP_BARRIER;
     // phase 3
     PP_READ_A(1, adA0);
-    if constexpr (!LAST) PP_STAGE_A(0, 0);
+    if constexpr (AF32) {                                                            // a0 of the tile in buffer 1, read in phase 5
+      if constexpr (LAST) PP_WAIT_A(2, cp1); else PP_WAIT_A(4, cp1);
+      PP_COMMIT_A(0, 1);
+      if constexpr (!LAST) PP_LOADA(0);
+    } else if constexpr (!LAST) PP_STAGE_A(0, 0);
     PP_BARRIER;
     PP_WAIT_READS(b1);
     PP_MFMA(RT, 2, b1);
     PP_BARRIER;
     // phase 4
-    if constexpr (!LAST) { PP_STAGE_B(1, 0); PP_WAIT_UNITS; }
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if constexpr (!LAST) {
+      PP_STAGE_B(1, 0);
+      if constexpr (!AF32) PP_WAIT_UNITS;
+    } else if constexpr (!AF32) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     PP_BARRIER;
     PP_MFMA(RT, 0, b0);
     PP_BARRIER;
@@ -233,7 +316,11 @@ __global__ __launch_bounds__(512) void uic_gemm_pp_kernel(const UicGemmParams p)
     // phase 5
     PP_READ_B(b0, 0, adB1); PP_READ_A(0, adA1);
     PP_WAIT_B_READS;
-    if constexpr (!LAST) PP_STAGE_A(1, 0);
+    if constexpr (AF32) {                                                            // a1 of the tile in buffer 1, read in phase 7
+      if constexpr (LAST) asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); else PP_WAIT_A(4, cp0);
+      PP_COMMIT_A(1, 1);
+      if constexpr (!LAST) PP_LOADA(1);
+    } else if constexpr (!LAST) PP_STAGE_A(1, 0);
     PP_BARRIER;
     PP_WAIT_READS(b0);
     PP_MFMA(0, 0, b0);
@@ -247,13 +334,19 @@ __global__ __launch_bounds__(512) void uic_gemm_pp_kernel(const UicGemmParams p)
     PP_BARRIER;
     // phase 7
     PP_READ_A(1, adA1);
-    if constexpr (!LAST) PP_STAGE_A(0, 1);
+    if constexpr (!LAST) {
+      if constexpr (AF32) { PP_WAIT_A(4, cp1); PP_COMMIT_A(0, 0); PP_LOADA(0); }    // a0 of the next tile for buffer 0, read in phase 1
+      else PP_STAGE_A(0, 1);
+    }
     PP_BARRIER;
     PP_WAIT_READS(b1);
     PP_MFMA(RT, 2, b1);
     PP_BARRIER;
     // phase 8
-    if constexpr (!LAST) { PP_STAGE_B(1, 1); PP_WAIT_UNITS; }
+    if constexpr (!LAST) {
+      PP_STAGE_B(1, 1);
+      if constexpr (!AF32) PP_WAIT_UNITS;
+    }
     PP_BARRIER;
     PP_MFMA(RT, 0, b0);
     PP_BARRIER;
@@ -359,6 +452,12 @@ __global__ __launch_bounds__(512) void uic_gemm_pp_kernel(const UicGemmParams p)
 #undef PP_TIE_A
 #undef PP_READ_B
 #undef PP_READ_A
+#undef PP_COMMIT_A
+#undef PP_COMMIT1
+#undef PP_WAIT_A
+#undef PP_VMCNT
+#undef PP_LOADA
+#undef PP_LOADA1
 #undef PP_STAGE_B
 #undef PP_STAGE_A
 #undef PP_GLDS
@@ -373,6 +472,10 @@ bool uic_gemm_pp_eligible(const UicGemmParams& p) {
   const int sk = p.splitk > 1 ? p.splitk : 1;
   if (K % (128 * sk) != 0 || K / sk < 128) return false;
   if (p.N % 4 != 0) return false;
+  if (p.a_f32) {   // f32 A rounded in the kernel: 16-byte loads through 32-bit byte offsets, no split-K form
+    if (sk > 1 || p.slab || p.seg[0].lda % 4 != 0 || ((uintptr_t)p.seg[0].A & 15) || (size_t)p.M * p.seg[0].lda * 4 >= ((size_t)1 << 32)) return false;
+    if (p.a_copy && (p.ld_a_copy % 8 != 0 || ((uintptr_t)p.a_copy & 15) || p.ld_a_copy < K)) return false;
+  } else if (p.a_copy) return false;
   if (p.slab) return ((uintptr_t)p.slab & 15) == 0;
   if (!p.C || p.ldc % 4 != 0) return false;
   const bool f32 = (p.flags & UIC_GEMM_OUT_F32) != 0;
@@ -393,10 +496,17 @@ int launch_pp(const UicGemmParams& p, hipStream_t s) {
   if (!configured) {
     UIC_TRY(uic_check_hip(hipFuncSetAttribute((const void*)uic_gemm_pp_kernel<RT, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds), "hipFuncSetAttribute(gemm pp)"));
     UIC_TRY(uic_check_hip(hipFuncSetAttribute((const void*)uic_gemm_pp_kernel<RT, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds), "hipFuncSetAttribute(gemm pp slab)"));
+    if constexpr (RT < 4)
+      UIC_TRY(uic_check_hip(hipFuncSetAttribute((const void*)uic_gemm_pp_kernel<RT, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds), "hipFuncSetAttribute(gemm pp f32 A)"));
     configured = true;
   }
   dim3 grid((p.M + 64 * RT - 1) / (64 * RT), (p.N + 255) / 256, p.splitk > 1 ? p.splitk : 1);
-  if (p.slab) hipLaunchKernelGGL((uic_gemm_pp_kernel<RT, true>), grid, dim3(512), lds, s, p);
+  if (p.a_f32) {
+    // (the 256-row tile has no registers left for the two A units in flight: 248 + 32 -- it would spill registers whose loads
+    // are still in flight)
+    if constexpr (RT < 4) hipLaunchKernelGGL((uic_gemm_pp_kernel<RT, false, true>), grid, dim3(512), lds, s, p);
+    else UIC_REQUIRE(false, "gemm_pp: the f32-A path has 192- and 128-row tiles only");
+  } else if (p.slab) hipLaunchKernelGGL((uic_gemm_pp_kernel<RT, true>), grid, dim3(512), lds, s, p);
   else hipLaunchKernelGGL((uic_gemm_pp_kernel<RT, false>), grid, dim3(512), lds, s, p);
   UIC_LAUNCH_CHECK("uic_gemm_pp_kernel");
   return UIC_OK;
@@ -406,17 +516,17 @@ int launch_pp(const UicGemmParams& p, hipStream_t s) {
 // rows: the tile height, 256 / 192 / 128 (0 = uic_gemm_pp_rows' choice)
 int uic_gemm_pp_launch(const UicGemmParams& p, int rows, hipStream_t s) {
   UIC_REQUIRE(uic_gemm_pp_eligible(p), "gemm_pp: problem not eligible for the 256-column ping-pong kernel");
-  if (rows == 0) rows = uic_gemm_pp_rows(p.M, p.N);
+  if (rows == 0) rows = uic_gemm_pp_rows(p.M, p.N, p.a_f32 ? 192 : 256);
   UIC_REQUIRE(rows == 256 || rows == 192 || rows == 128, "gemm_pp: tile height %d (256 / 192 / 128)", rows);
   return rows == 256 ? launch_pp<4>(p, s) : rows == 192 ? launch_pp<3>(p, s) : launch_pp<2>(p, s);
 }
 
 // The tile height whose slowest CU has the least work: one workgroup per CU and 256 CUs, so a launch of `tiles` tiles takes
 // ceil(tiles / 256) rounds of one tile's time (~ its height); ties go to the taller tile (fewer operand bytes per flop).
-int uic_gemm_pp_rows(int M, int N) {
+int uic_gemm_pp_rows(int M, int N, int tallest) {
   const long cols = (N + 255) / 256;
-  int best = 256; long best_cost = -1;
-  for (int rows = 256; rows >= 128; rows -= 64) {
+  int best = tallest; long best_cost = -1;
+  for (int rows = tallest; rows >= 128; rows -= 64) {
     const long tiles = (long)((M + rows - 1) / rows) * cols;
     const long cost = ((tiles + 255) / 256) * rows;
     if (best_cost < 0 || cost < best_cost) { best = rows; best_cost = cost; }

@@ -354,6 +354,15 @@ int prepare_features(const uic_topdown_dims& d, const uic_topdown_weights* w, co
     fc_in = L.fcT;
   }
   if (d.use_bn || dt == UIC_BF16) att_in = L.attT;
+  // bf16 without BatchNorm in front: att_embed's GEMM takes the f32 features as they are, rounds them on their way to LDS and
+  // leaves the bf16 image in L.attT for the weight gradient (gemm_pp.hip, f32 A operand) -- no separate 283 MB cast pass
+  bool att_f32a = false;
+  if (do_att && !d.use_bn && dt == UIC_BF16) {
+    UicGemmParams g = gemm_base(dt, Na * R, H);
+    add_seg(g, att_src, d.D, dv.att_w, d.D, d.D);
+    g.C = L.attp; g.ldc = H; g.a_f32 = 1; g.a_copy = L.attT; g.ld_a_copy = d.D;
+    att_f32a = uic_gemm_pp_eligible(g) && (size_t)Na * R >= 2048;
+  }
   if (do_att && d.use_bn) {
     // BatchNorm1d(D) over the packed live regions; xhat goes to the GEMM, the affine part lives in W' / b'.  Features given
     // once per image stand for S identical caption rows each: same mean / biased variance, `rep` fixes the unbiased one.
@@ -363,7 +372,7 @@ int prepare_features(const uic_topdown_dims& d, const uic_topdown_weights* w, co
     else
       UIC_TRY(uic_bn_stats_running_launch(w->att_bn0_rm, w->att_bn0_rv, d.D, BN_EPS, L.bn_stat0, s));
     UIC_TRY(uic_bn_apply_launch(UIC_F32, dt, att_src, Na * R, R, d.D, row_len, L.bn_stat0, nullptr, nullptr, 0, L.attT, s));
-  } else if (do_att && dt == UIC_BF16) {
+  } else if (do_att && dt == UIC_BF16 && !att_f32a) {
     UIC_TRY(uic_cast_f32_launch(dt, att_src, L.attT, (size_t)Na * R * d.D, s));
   }
   *fc_in_out = fc_in;
@@ -382,6 +391,7 @@ int prepare_features(const uic_topdown_dims& d, const uic_topdown_weights* w, co
     // what the S-fold replicated GEMM epilogue writes
     UicGemmParams g = gemm_base(dt, Ni * R, H);
     add_seg(g, att_in, d.D, dv.att_w, d.D, d.D);
+    if (att_f32a) { g.seg[0].A = att_src; g.a_f32 = 1; g.a_copy = L.attT; g.ld_a_copy = d.D; }
     g.C = L.ypre; g.ldc = H; g.bias = d.use_bn ? dv.att_beff : w->att_b; g.flags = UIC_GEMM_RELU | UIC_GEMM_OUT_F32;
     if (b->att_masks) { g.row_len = L.row_len; g.R = R; }
     UIC_TRY(uic_gemm_launch(g, s));
@@ -389,6 +399,7 @@ int prepare_features(const uic_topdown_dims& d, const uic_topdown_weights* w, co
   } else {
     UicGemmParams g = gemm_base(dt, N * R, H);
     add_seg(g, att_in, d.D, dv.att_w, d.D, d.D);
+    if (att_f32a) { g.seg[0].A = att_src; g.a_f32 = 1; g.a_copy = L.attT; g.ld_a_copy = d.D; }
     g.C = att_out; g.ldc = H; g.bias = d.use_bn ? dv.att_beff : w->att_b; g.flags = UIC_GEMM_RELU;
     if (b->att_masks) { g.row_len = L.row_len; g.R = R; }
     g.drop_p = drop_p; g.seed = seed; g.site = UIC_SITE_ATT;
@@ -1472,16 +1483,18 @@ int uic_topdown_xe_train_step(const uic_topdown_dims* d, const uic_topdown_weigh
   if (!resume) {
     // three branches: att_embed + ctx2att (main), embedding + batched input GEMM (side), fc_embed + Gfc + initial state (third
     // stream: two small latency-bound GEMMs that would otherwise sit behind the batched input GEMM on the side stream)
+    // Enqueued longest branch first: the host has just come back from the previous step's loss read, so the GPU starts with an
+    // empty queue and every launch ahead of att_embed's GEMM is ~5 us of its idle time.
     const bool split3 = st.gfc_separate() && !st.ss_on();
+    UIC_TRY(st.fwd_prologue(s, 2));
+    UIC_TRY(st.fwd_prologue(s2, split3 ? 3 : 1));
+    UIC_HIP(hipEventRecord(ss->ev_pro, s2));
     if (split3) {
       UIC_HIP(hipStreamWaitEvent(s3, ss->ev_den, 0));
       UIC_TRY(st.fwd_prologue(s3, 4));
       UIC_HIP(hipEventRecord(ss->ev_pro3, s3));
     }
-    UIC_TRY(st.fwd_prologue(s2, split3 ? 3 : 1));
-    UIC_HIP(hipEventRecord(ss->ev_pro, s2));
     UIC_TRY(flush_transposes(ss));                    // (behind the branch: only the backward pass reads them)
-    UIC_TRY(st.fwd_prologue(s, 2));
     UIC_HIP(hipStreamWaitEvent(s, ss->ev_pro, 0));
     if (split3) UIC_HIP(hipStreamWaitEvent(s, ss->ev_pro3, 0));
     if (ss->cast_recorded) UIC_HIP(hipStreamWaitEvent(s, ss->ev_cast, 0));   // the recurrence reads copies made on the side stream

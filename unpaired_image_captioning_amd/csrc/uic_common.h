@@ -197,6 +197,10 @@ struct UicGemmParams {
   // att_embed's weight gradient in one pass (was: GEMM into f32, then a 94 MB relu_mask_bwd pass)
   const float* acc_src; int ld_acc_src;
   const void* mask_act; int ld_mask_act; float mask_scale;
+  // ---- f32 A operand (ping-pong kernel only, dtype bf16): seg[0].A is f32 [M, K] (lda in floats) and is rounded to bf16 on its
+  // way to LDS, exactly as uic_cast_f32_launch rounds; with a_copy the column-0 workgroups also store that bf16 image
+  // [M, ld_a_copy] (the weight gradient's operand) -- att_embed on the loader's f32 region features without the cast pass
+  int a_f32; void* a_copy; int ld_a_copy;
 };
 // C[row, c - col0] = sum_z slab[z][row, c] for c in [col0, col0 + ncols)
 int uic_splitk_reduce_launch(const float* slab, int splitk, int M, int N, int col0, int ncols, float* C, int ldc, hipStream_t s,
@@ -207,7 +211,7 @@ bool uic_gemm_glds_eligible(int dtype, int K);
 int uic_gemm_launch(const UicGemmParams& p, hipStream_t stream);
 // the 256 x 256 x 64 ping-pong kernel (gemm_pp.hip): bf16, one K segment, K a multiple of 128 per split-K slice
 bool uic_gemm_pp_eligible(const UicGemmParams& p);
-int uic_gemm_pp_rows(int M, int N);
+int uic_gemm_pp_rows(int M, int N, int tallest = 256);
 int uic_gemm_pp_launch(const UicGemmParams& p, int rows, hipStream_t stream);
 
 // ---------------------------------------------------------------- TN GEMM (gemm_tn.hip): C[i,j] = sum_k A[k,i] B[k,j]
