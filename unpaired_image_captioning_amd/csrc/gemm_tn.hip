@@ -54,7 +54,7 @@ __global__ __launch_bounds__(256) void uic_gemm_tn_kernel(const UicGemmTnParams 
     const int r = (wave * 4 + i) * 4 + (lane >> 4);
     const int f = ((r & 3) << 2) | ((r >> 2) & 3);
     const int ch = (lane & 15) ^ f;
-    const int colA = min(m0 + ch * 8, p.M - 8);
+    const int colA = min(m0 + ch * 8, ((p.M + 7) & ~7) - 8);   // (M % 8 != 0: the last chunk runs into the row's padding, lda >= M rounded up)
     const int colB = min(c0 + ch * 8, ncolsB - 8);
     srcA[i] = (const char*)p.A + ((size_t)r * p.lda + colA) * 2;
     srcB[i] = Bbase + ((size_t)r * ldb + colB) * 2;
@@ -350,7 +350,9 @@ int uic_splitk_reduce_multi_launch(const float* slab, int splitk, int M, int N, 
 }
 
 bool uic_gemm_tn_eligible(const UicGemmTnParams& p) {
-  if (p.M < 128 || p.N < 128 || p.K < 64 || p.K % 64 != 0 || p.M % 8 != 0 || p.lda % 8 != 0) return false;
+  // (M need not be a multiple of 8: lda is, so the last 16-byte chunk of a k-row reads padding columns inside the row -- whatever
+  // they hold only reaches output rows >= M, which are never stored.  The pivot NMT's generator: M = 50004 target words.)
+  if (p.M < 128 || p.N < 128 || p.K < 64 || p.K % 64 != 0 || p.lda % 8 != 0 || p.lda < ((p.M + 7) & ~7)) return false;
   if (p.nseg < 1 || p.nseg > UIC_GEMM_TN_MAX_SEG || ((uintptr_t)p.A & 15)) return false;
   int n = 0;
   for (int i = 0; i < p.nseg; ++i) {

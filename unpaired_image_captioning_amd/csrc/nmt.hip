@@ -965,10 +965,11 @@ struct Nmt {
     const int H4 = 4 * H, Md = Td * B, Ms = S * B;
     // ---- generator
     {
-      UicGemmParams g = gemm_base(dt, Md, H);
-      add_seg(g, L.dlogits, Vtp, L.gen_wT, Vtp, Vtp);
-      g.C = L.d_out_all; g.ldc = H; g.flags = UIC_GEMM_OUT_F32;
-      UIC_TRY(uic_gemm_launch(g, s));
+      // d out = d logits W_gen: [T B, H] outputs over K = the target vocabulary -- few tiles and a very long reduction: split-K
+      // over workgroups with the deterministic slab reduction (wgrad_multi; one launch of 64 x 64 tiles walked all 50 048 columns
+      // in 347 us)
+      const WDest d1{L.d_out_all, (int)H, 0, (int)H};
+      UIC_TRY(wgrad_multi(L.slab, L.slab_bytes, dt, L.dlogits, Md, L.gen_wT, H, Vtp, &d1, 1, s));
     }
     // the generator's weight / bias gradients (the largest GEMM of the backward pass, [Vt, H] over all target rows) need nothing
     // from the BPTT loop and the loop -- ~6 dependent launches of 64 rows per step -- leaves the chip idle: they run on the side
