@@ -630,7 +630,7 @@ NmtLayout nmt_layout(const uic_nmt_dims& d, const uic_nmt_weights* w, void* ws) 
   L.colscratch = (float*)b.take(L.colscratch_floats * 4);
   L.slab_bytes = 4 * (4 * H) * (W + 2 * H) * 4;
   L.slab = (float*)b.take(L.slab_bytes);
-  L.rnn_sync = (unsigned*)b.take(uic_rnn_persist_sync_bytes());
+  L.rnn_sync = (unsigned*)b.take((2 * NL + 2) * uic_rnn_persist_sync_bytes());   // one block per persistent launch of a step (sync_block)
   L.dfeed_x = (float*)b.take(Td * B * H * 4);
   L.dq_att_x = (float*)b.take(Td * B * H * 4);
   {
@@ -770,7 +770,36 @@ struct Nmt {
     return off(l > 0 && drop_p > 0.f ? L.xd[l] : L.xl[l], (size_t)B * in, dt);
   }
 
+  // Persistent launch i of a step (encoder layers forward 0..NL-1, decoder forward NL, decoder BPTT NL+1, encoder layers backward
+  // NL+2..) has a sync block of its own, so that one launch clears all of them together with the step's other zero-initialised
+  // buffers (uic_zero_list_launch) instead of one memset per launch and per buffer.
+  unsigned* sync_block(int i) const { return L.rnn_sync + (size_t)i * (uic_rnn_persist_sync_bytes() / 4); }
+  int zero_forward_buffers(hipStream_t s) {
+    void* ptr[4 * UIC_NMT_MAX_LAYERS + 4];
+    size_t nbytes[4 * UIC_NMT_MAX_LAYERS + 4];
+    int n = 0;
+    auto add = [&](void* q, size_t by) { ptr[n] = q; nbytes[n] = (by + 15) & ~(size_t)15; ++n; };
+    for (int l = 0; l < NL; ++l) {
+      add(L.xl[l + 1], (size_t)(S + 2) * BH * Sz);
+      for (int dd = 0; dd < 2; ++dd) add(L.c_e[l][dd], (size_t)(S + 2) * BHd * 4);
+      if (l + 1 < NL && drop_p > 0.f) add(L.xd[l + 1], (size_t)(S + 2) * BH * Sz);
+    }
+    add(L.out_all, BH * Sz);                                         // init_input_feed: zeros (:454-458)
+    add(sync_block(0), (size_t)(NL + 1) * uic_rnn_persist_sync_bytes());
+    return uic_zero_list_launch(ptr, nbytes, n, s);
+  }
+  int zero_backward_buffers(hipStream_t s) {
+    void* ptr[2 * UIC_NMT_MAX_LAYERS + 2];
+    size_t nbytes[2 * UIC_NMT_MAX_LAYERS + 2];
+    int n = 0;
+    for (int l = 0; l < NL; ++l)
+      for (int dd = 0; dd < 2; ++dd) { ptr[n] = L.dg_e[l][dd]; nbytes[n] = ((size_t)S * B * 4 * Hd * Sz + 15) & ~(size_t)15; ++n; }
+    ptr[n] = sync_block(NL + 1); nbytes[n] = (size_t)(NL + 1) * uic_rnn_persist_sync_bytes(); ++n;
+    return uic_zero_list_launch(ptr, nbytes, n, s);
+  }
+
   int encoder_fwd(const int32_t* lengths_dev, hipStream_t s) {
+    UIC_TRY(zero_forward_buffers(s));
     // relu(linear(word_lut[src]))  (NMT_Models.py:63-67)
     UIC_TRY(uic_embed_fwd_launch(dt, w->enc_lut, Vs, W, src, 1, S * B, 1, 0.f, 0, 0, 0, 0, L.xe, s));
     {
@@ -782,7 +811,6 @@ struct Nmt {
     const bool enc_persist = !(d.recurrence & UIC_REC_FWD_CHAIN) && uic_nmt_enc_persist_eligible(dt, B, S, H);
     for (int l = 0; l < NL; ++l) {
       const int in = l == 0 ? W : H;
-      UIC_TRY(uic_fill_launch(L.xl[l + 1], 0, (size_t)(S + 2) * BH * Sz, s));
       if (enc_persist) {
         // both directions' S recurrent steps as ONE persistent launch (nmt_persist.hip) behind the two batched input GEMMs
         UicNmtEncParams p;
@@ -791,18 +819,16 @@ struct Nmt {
         for (int st = 0; st < S; ++st) p.nb[st] = nb[st];
         p.x_out = L.xl[l + 1];
         for (int dd = 0; dd < 2; ++dd) {
-          UIC_TRY(uic_fill_launch(L.c_e[l][dd], 0, (size_t)(S + 2) * BHd * 4, s));
           UicGemmParams g = gemm_base(dt, S * B, 4 * Hd);
           add_seg(g, enc_in(l), in, L.enc_w_ih[l][dd], in, in);
           g.C = L.gx_e[l][dd]; g.ldc = 4 * Hd; g.bias = w->enc_b_ih[l][dd]; g.bias2 = w->enc_b_hh[l][dd]; g.flags = UIC_GEMM_OUT_F32;
           UIC_TRY(uic_gemm_launch(g, s));
           p.w_hh[dd] = L.enc_w_hh[l][dd]; p.gx[dd] = L.gx_e[l][dd]; p.c[dd] = L.c_e[l][dd]; p.gates[dd] = L.gates_e[l][dd];
         }
-        p.sync = L.rnn_sync; p.status = d.rnn_status; p.force_safe = (d.recurrence & UIC_REC_SAFE) != 0;
+        p.sync = sync_block(l); p.sync_zeroed = 1; p.status = d.rnn_status; p.force_safe = (d.recurrence & UIC_REC_SAFE) != 0;
         p.row0 = 0; p.Nrows = B;
         UIC_TRY(uic_nmt_enc_fwd_persist_launch(p, s));
         if (l + 1 < NL && drop_p > 0.f) {
-          UIC_TRY(uic_fill_launch(L.xd[l + 1], 0, (size_t)(S + 2) * BH * Sz, s));
           NMT_T(dropout_apply_kernel, gridn((size_t)S * BH), 0, (const void*)off(L.xl[l + 1], BH, dt), (void*)offw(L.xd[l + 1], BH, dt),
                 (size_t)S * BH, drop_p, seed, SITE_NMT_ENC(l));
         }
@@ -815,7 +841,6 @@ struct Nmt {
       UIC_TRY(uic_check_hip(hipStreamWaitEvent(ss->stream, ss->ev_go, 0), "hipStreamWaitEvent"));
       for (int dd = 1; dd >= 0; --dd) {
         hipStream_t sd = dd == 1 ? ss->stream : s;
-        UIC_TRY(uic_fill_launch(L.c_e[l][dd], 0, (size_t)(S + 2) * BHd * 4, sd));
         {  // W_ih x + b_ih + b_hh for every (s, b)
           UicGemmParams g = gemm_base(dt, S * B, 4 * Hd);
           add_seg(g, enc_in(l), in, L.enc_w_ih[l][dd], in, in);
@@ -839,7 +864,6 @@ struct Nmt {
       }
       UIC_TRY(uic_check_hip(hipStreamWaitEvent(s, ss->ev_done, 0), "hipStreamWaitEvent"));
       if (l + 1 < NL && drop_p > 0.f) {  // nn.LSTM's inter-layer dropout (element index over the [S*B, H] slots 1..S)
-        UIC_TRY(uic_fill_launch(L.xd[l + 1], 0, (size_t)(S + 2) * BH * Sz, s));
         NMT_T(dropout_apply_kernel, gridn((size_t)S * BH), 0, (const void*)off(L.xl[l + 1], BH, dt), (void*)offw(L.xd[l + 1], BH, dt),
               (size_t)S * BH, drop_p, seed, SITE_NMT_ENC(l));
       }
@@ -862,7 +886,6 @@ struct Nmt {
       g.C = L.gx_d0; g.ldc = H4; g.bias = w->dec_b_ih[0]; g.bias2 = w->dec_b_hh[0]; g.flags = UIC_GEMM_OUT_F32;
       UIC_TRY(uic_gemm_launch(g, s));
     }
-    UIC_TRY(uic_fill_launch(L.out_all, 0, BH * Sz, s));        // init_input_feed: zeros (:454-458)
     {  // ctxw[s, b, :] = context[s, b, :] W_in, all source positions at once (see gattn_fwd_kernel)
       UicGemmParams g = gemm_base(dt, S * B, H);
       add_seg(g, off(L.xl[NL], BH, dt), H, L.attn_in_wT, H, H);
@@ -883,7 +906,7 @@ struct Nmt {
       }
       p.ctx = off(L.xl[NL], BH, dt); p.ctxw = L.ctxw; p.attn_all = L.attn_all; p.cvec_all = L.cvec_all; p.attn_out_w = L.attn_out_w;
       p.drop_p = drop_p; p.seed = seed;
-      p.sync = L.rnn_sync; p.status = d.rnn_status; p.force_safe = (d.recurrence & UIC_REC_SAFE) != 0;
+      p.sync = sync_block(NL); p.sync_zeroed = 1; p.status = d.rnn_status; p.force_safe = (d.recurrence & UIC_REC_SAFE) != 0;
       p.row0 = 0; p.Nrows = B;
       return uic_nmt_dec_persist_launch(p, s);
     }
@@ -963,6 +986,7 @@ struct Nmt {
 
   int backward(hipStream_t s) {
     const int H4 = 4 * H, Md = Td * B, Ms = S * B;
+    UIC_TRY(zero_backward_buffers(s));
     // ---- generator
     {
       // d out = d logits W_gen: [T B, H] outputs over K = the target vocabulary -- few tiles and a very long reduction: split-K
@@ -1001,7 +1025,7 @@ struct Nmt {
       p.dfeed_x = L.dfeed_x; p.dq_att_x = L.dq_att_x;
       p.dh_init[0] = L.dfeed; p.dh_init[1] = L.dx_lstm[1];
       p.drop_p = drop_p; p.seed = seed;
-      p.sync = L.rnn_sync; p.status = d.rnn_status; p.force_safe = (d.recurrence & UIC_REC_SAFE) != 0;
+      p.sync = sync_block(NL + 1); p.sync_zeroed = 1; p.status = d.rnn_status; p.force_safe = (d.recurrence & UIC_REC_SAFE) != 0;
       p.row0 = 0; p.Nrows = B;
       UIC_TRY(uic_nmt_dec_bwd_persist_launch(p, s));
     }
@@ -1123,13 +1147,12 @@ struct Nmt {
         p.B = B; p.S = S;
         for (int st = 0; st < S; ++st) p.nb[st] = nb[st];
         for (int dd = 0; dd < 2; ++dd) {
-          UIC_TRY(uic_fill_launch(L.dg_e[l][dd], 0, (size_t)Ms * 4 * Hd * Sz, s));
           p.w_hh[dd] = L.enc_w_hhT[l][dd]; p.c[dd] = L.c_e[l][dd]; p.gates[dd] = L.gates_e[l][dd]; p.dgates[dd] = L.dg_e[l][dd];
         }
         p.d_top = d_top;
         p.dh_init = (l == 0 ? L.dfeed : L.dx_lstm[l]) + H; p.ld_dh_init = 2 * H;
         p.dc_init = L.dcd[l]; p.ld_dc_init = H;
-        p.sync = L.rnn_sync; p.status = d.rnn_status; p.force_safe = (d.recurrence & UIC_REC_SAFE) != 0;
+        p.sync = sync_block(NL + 2 + l); p.sync_zeroed = 1; p.status = d.rnn_status; p.force_safe = (d.recurrence & UIC_REC_SAFE) != 0;
         p.row0 = 0; p.Nrows = B;
         UIC_TRY(uic_nmt_enc_bwd_persist_launch(p, s));
       }
@@ -1139,7 +1162,6 @@ struct Nmt {
         hipStream_t sd = dd == 1 ? ss->stream : s;
         float* dhrec = dd == 1 ? L.dhrec_e1 : L.dhrec_e;
         float* dcc = dd == 1 ? L.dc_e1 : L.dc_e;
-        UIC_TRY(uic_fill_launch(L.dg_e[l][dd], 0, (size_t)Ms * 4 * Hd * Sz, sd));
         // carried dh / dc start from the decoder-initial-state gradient halves (rows join the BPTT when they become active)
         // (d h_l(-1) of decoder layers > 0 sits in the second half of that layer's last dX)
         const float* dh_init = (l == 0 ? L.dfeed : L.dx_lstm[l]) + H;

@@ -883,7 +883,7 @@ int uic_nmt_dec_persist_launch(const UicNmtDecParams& p, hipStream_t s) {
   }
   UicPersistGateScope gate;       // (its workgroups have to be resident together: never beside another persistent launch)
   UIC_TRY(gate.enter(s));
-  UIC_TRY(uic_check_hip(hipMemsetAsync(p.sync, 0, (size_t)SY_WORDS * 4, s), "hipMemsetAsync(nmt dec sync)"));
+  if (!p.sync_zeroed) UIC_TRY(uic_check_hip(hipMemsetAsync(p.sync, 0, (size_t)SY_WORDS * 4, s), "hipMemsetAsync(nmt dec sync)"));
   if (p.B <= 8 * 16 && p.NL <= 2) hipLaunchKernelGGL(nmt_dec_ws_kernel, dim3(8 * PW), dim3(NTH), WS_LDS_BYTES, s, p);     // one 16-row tile per group
   else hipLaunchKernelGGL(nmt_dec_persist_kernel, dim3(8 * PW), dim3(NTH), LDS_BYTES, s, p);
   UIC_LAUNCH_CHECK("nmt_dec_persist_kernel");
@@ -904,7 +904,7 @@ int uic_nmt_dec_bwd_persist_launch(const UicNmtDecBwdParams& p, hipStream_t s) {
   }
   UicPersistGateScope gate;
   UIC_TRY(gate.enter(s));
-  UIC_TRY(uic_check_hip(hipMemsetAsync(p.sync, 0, (size_t)SY_WORDS * 4, s), "hipMemsetAsync(nmt dec bwd sync)"));
+  if (!p.sync_zeroed) UIC_TRY(uic_check_hip(hipMemsetAsync(p.sync, 0, (size_t)SY_WORDS * 4, s), "hipMemsetAsync(nmt dec bwd sync)"));
   if (p.S <= BW_NW * 8) hipLaunchKernelGGL(nmt_dec_bwd_kernel<8>, dim3(8 * PW), dim3(BW_NTH), BW_W0_BYTES + WS_SCR_BYTES, s, p);
   else hipLaunchKernelGGL(nmt_dec_bwd_kernel<16>, dim3(8 * PW), dim3(BW_NTH), BW_W0_BYTES + WS_SCR_BYTES, s, p);
   UIC_LAUNCH_CHECK("nmt_dec_bwd_kernel");
@@ -921,7 +921,7 @@ int enc_launch(K kernel, const char* what, const UicNmtEncParams& p, hipStream_t
   UIC_REQUIRE(p.sync && p.S > 0 && p.S <= UIC_NMT_ENC_MAX_S && p.B > 0 && p.B <= 8 * 16 && p.Nrows == p.B && p.row0 == 0, "%s: bad arguments", what);
   UicPersistGateScope gate;
   UIC_TRY(gate.enter(s));
-  UIC_TRY(uic_check_hip(hipMemsetAsync(p.sync, 0, (size_t)SY_WORDS * 4, s), "hipMemsetAsync(nmt enc sync)"));
+  if (!p.sync_zeroed) UIC_TRY(uic_check_hip(hipMemsetAsync(p.sync, 0, (size_t)SY_WORDS * 4, s), "hipMemsetAsync(nmt enc sync)"));
   hipLaunchKernelGGL(kernel, dim3(8 * PW), dim3(NTH), WS_SCR_BYTES, s, p);
   UIC_LAUNCH_CHECK(what);
   return gate.leave();

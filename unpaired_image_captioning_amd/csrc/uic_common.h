@@ -387,6 +387,7 @@ struct UicNmtDecParams {
   const void* attn_out_w;            // [512][1024]
   float drop_p; unsigned seed;
   unsigned* sync;                    // uic_rnn_persist_sync_bytes() bytes (zeroed by the launcher)
+  int sync_zeroed;                  // the caller has already cleared `sync` for this launch (uic_zero_list_launch with its other buffers)
   unsigned* status; int force_safe;
   int row0, Nrows;                   // 0, B
 };
@@ -408,6 +409,7 @@ struct UicNmtDecBwdParams {
   float* dc_init[2];                 // [B][512] f32: d c_l(-1)
   float drop_p; unsigned seed;
   unsigned* sync; unsigned* status; int force_safe;
+  int sync_zeroed;                  // the caller has already cleared `sync` for this launch (uic_zero_list_launch with its other buffers)
   int row0, Nrows;
 };
 // One layer of the pivot encoder's packed bidirectional LSTM (NMT_Models.Encoder, P/models/NMT_Models.py:95-135; nn.LSTM over a
@@ -429,6 +431,7 @@ struct UicNmtEncParams {
   const float* dh_init; int ld_dh_init;   // [B][ld] f32, columns [dir * 256, +256): d h of the final state (the decoder's initial state)
   const float* dc_init; int ld_dc_init;
   unsigned* sync; unsigned* status; int force_safe;
+  int sync_zeroed;                  // the caller has already cleared `sync` for this launch (uic_zero_list_launch with its other buffers)
   int row0, Nrows;
 };
 bool uic_nmt_enc_persist_eligible(int dtype, int B, int S, int H);
@@ -451,6 +454,9 @@ int uic_copy_launch(void* dst, const void* src, size_t bytes, hipStream_t s);
 int uic_fill_value_launch(int dtype, void* dst, size_t n, float value, hipStream_t s);   // n elements of the operand dtype = value   // device -> device, 4-byte granules
 // zero up to four buffers (16-byte aligned, sizes multiples of 16) in ONE launch instead of one memset node each
 int uic_zero4_launch(void* p0, size_t b0, void* p1, size_t b1, void* p2, size_t b2, void* p3, size_t b3, hipStream_t s);
+#define UIC_ZERO_LIST 16
+// the same for a list of buffers (16-byte aligned / sized each), one launch per UIC_ZERO_LIST of them
+int uic_zero_list_launch(void* const* ptrs, const size_t* bytes, int n, hipStream_t s);
 // dst[cols, ldd] = src[rows, lds]^T, zero-filling dst columns rows..ldd-1
 int uic_transpose_launch(int dtype, const void* src, int rows, int cols, int lds, void* dst, int ldd, hipStream_t s);
 // up to UIC_TRANSPOSE_MULTI transposes (same argument meaning, one entry each) in ONE launch
