@@ -1474,6 +1474,9 @@ int uic_topdown_xe_train_step(const uic_topdown_dims* d, const uic_topdown_weigh
   const float* inv = inv_den ? inv_den : st.L.scalars + 1;
   UIC_HIP(hipEventRecord(ss->ev_den, s));
   UIC_HIP(hipStreamWaitEvent(s2, ss->ev_den, 0));
+  // side: the loss denominator (the criterion's first use of it is on this stream, after the recurrence).  First on its stream:
+  // behind the branch below it would be dispatched beside the persistent recurrence and wait for a CU until that ends.
+  if (b->masks) UIC_TRY(uic_masked_sum_launch(nullptr, b->masks, b->ld_masks, 1, d->N, d->T, st.L.scalars, st.L.scalars + 1, s2));
   // the prologue's two independent branches side by side: att_embed + ctx2att here, fc_embed + embedding + the batched
   // input GEMM on the side stream (idle until the recurrence is through; its part of the weight refresh comes first there)
   // training bit 2: the workspace already holds this forward pass (uic_topdown_sample_train drew b->labels with these
@@ -1499,8 +1502,7 @@ int uic_topdown_xe_train_step(const uic_topdown_dims* d, const uic_topdown_weigh
     if (split3) UIC_HIP(hipStreamWaitEvent(s, ss->ev_pro3, 0));
     if (ss->cast_recorded) UIC_HIP(hipStreamWaitEvent(s, ss->ev_cast, 0));   // the recurrence reads copies made on the side stream
   }
-  // side: the loss denominator (the criterion's first use of it is on this stream, after the recurrence)
-  if (b->masks) UIC_TRY(uic_masked_sum_launch(nullptr, b->masks, b->ld_masks, 1, d->N, d->T, st.L.scalars, st.L.scalars + 1, s2));
+
   UIC_MARK(1, s);
   // persistent mode 3: the whole recurrence as ONE launch (it holds every CU, nothing overlaps it); the logit layer follows
   // chunk by chunk on the side stream beside the BPTT loop
