@@ -1,28 +1,38 @@
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
 import torch
-from unpaired_image_captioning_amd import _lib as L
-lib = L.load()
-def timeit(fn, iters=60):
-    for _ in range(5): fn()
+import test_gpu_fullsize as TF
+from test_gpu_fullsize import *
+Lb = TF._lib()
+W = O.init_weights(V + 1, E, H, A, D, D, seed=11)
+n_img, S = 128, 5
+b = O.synthetic_batch(n_img, S, R, D, V, L, seed=77, ragged_regions=True)
+batch = {k: v.cuda() for k, v in b.items()}
+model = build_model(CFG, W, "bf16", drop=0.5)
+model.train()
+eng = model.engine
+N, T = n_img * S, L + 1
+t_run = model._steps_to_run(batch["labels"])
+pd = {k: v.detach() for k, v in model.param_dict().items()}
+td = torch.bfloat16
+def run(rec):
+    eng.recurrence = rec
+    logp, ws, _ = eng.forward(pd, batch["fc_feats"], batch["att_feats"], batch["att_masks"], batch["labels"], t_run, True, 99)
+    out = {n: eng.workspace_tensor(ws, n, shp, dt)[: (t_run + 1 if shp[0] == T + 1 else t_run)].float().clone() for n, shp, dt in NAMES(T, N, td)}
     torch.cuda.synchronize()
-    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(iters)]
-    for a, b in ev:
-        a.record(); fn(); b.record()
-    torch.cuda.synchronize()
-    d = sorted(a.elapsed_time(b) for a, b in ev)
-    return sum(d[iters // 8: iters - iters // 8]) / (iters - 2 * (iters // 8)) * 1e3
-g = torch.Generator(device="cuda").manual_seed(3)
-print("%-28s %9s %9s %9s %9s %9s" % ("shape M x N x K", "default", "128x128", "pp 256", "pp 192", "pp 128"))
-for M, N, K in [(1920, 2048, 512), (2048, 2048, 512), (2048, 2048, 1024), (1920, 512, 2048), (2048, 512, 2048), (1920, 512, 512), (2048, 512, 512), (2048, 1024, 2048),
-                (640, 512, 2048), (640, 2048, 512), (1920, 1024, 512), (1280, 2048, 512), (960, 2048, 512)]:
-    A = torch.randn(M, K, device="cuda", generator=g).bfloat16()
-    B = torch.randn(N, K, device="cuda", generator=g).bfloat16()
-    C = torch.empty(M, N, device="cuda", dtype=torch.float32)
-    ts = []
-    for force in (0, 0x100, 0x200, 0x400, 0x800):
-        try:
-            ts.append(timeit(lambda: L.check(lib.uic_linear(1, M, N, K, L.ptr(A), K, L.ptr(B), K, L.ptr(C), N, None, 4 | force, L.stream()))))
-        except Exception as e:
-            ts.append(float("nan"))
-    print("%-28s %9.1f %9.1f %9.1f %9.1f %9.1f" % ("%d x %d x %d" % (M, N, K), *ts))
+    eng.release(ws)
+    return out
+ref = run(Lb.REC_FWD_CHAIN)
+g1, g1b, g2 = run(0), run(0), run(Lb.REC_SAFE)
+for k in ("alpha", "ctx", "att_h", "h_att"):
+    d12 = (g1[k] - g2[k]).abs()
+    d1r = (g1[k] - ref[k]).abs()
+    d2r = (g2[k] - ref[k]).abs()
+    print(k, "fast-vs-safe max %.3e; fast-vs-chain %.3e; safe-vs-chain %.3e" % (d12.max().item(), d1r.max().item(), d2r.max().item()))
+    if d12.max() > 0:
+        tt, nn = torch.nonzero(d12.amax(2) > 0, as_tuple=True)
+        print("   first differing (t, row, row%80, group):", [(int(a), int(b), int(b) % 80, int(b) // 80) for a, b in list(zip(tt, nn))[:12]], "count", len(tt))
+# NaN check on alpha rows of shared rows
+a = g1["alpha"]
+print("alpha row sums fast: min %.6f max %.6f; safe: min %.6f max %.6f" % (a.sum(2).min().item(), a.sum(2).max().item(), g2["alpha"].sum(2).min().item(), g2["alpha"].sum(2).max().item()))
