@@ -148,6 +148,40 @@ def test_linear_with_f32_input_equals_cast_then_linear(shape, flags, copy):
         assert (outs[0][1] == 7.0).all()
 
 
+def test_linear_with_f32_input_beside_busy_neighbours():
+    """The same equality, 300 launches with an HBM-bound copy and an MFMA-bound GEMM running on another stream (timing inside
+    the kernel changes: its counted waits and the image stores must not care).  The first form of the image store -- inline asm
+    the compiler could not see as a VMEM store -- failed exactly here, 1 launch in 100 (tools/gemm_f32a_soak.py)."""
+    L = _lib()
+    lib = L.load()
+    M, N, K = 4608, 512, 2048
+    g = torch.Generator().manual_seed(9)
+    A = (torch.randn(M, K, generator=g) * 3).cuda()
+    Ab = A.bfloat16()
+    Bd = dev(torch.randn(N, K, generator=g) / K ** 0.5, 1)
+    bd = dev(torch.randn(N, generator=g))
+    ref = torch.empty(M, N, device="cuda", dtype=torch.bfloat16)
+    L.check(lib.uic_linear(1, M, N, K, L.ptr(Ab), K, L.ptr(Bd), K, L.ptr(ref), N, L.ptr(bd), 1 | FORCE_192, L.stream()))
+    torch.cuda.synchronize()
+    side = torch.cuda.Stream()
+    hog_a = torch.randn(32 << 20, device="cuda")
+    hog_b = torch.empty_like(hog_a)
+    X = torch.randn(4096, 4096, device="cuda").bfloat16()
+    bad = 0
+    for it in range(300):
+        with torch.cuda.stream(side):
+            if it % 2 == 0:
+                hog_b.copy_(hog_a)
+            if it % 3 != 0:
+                torch.matmul(X, X)
+        C = torch.full((M, N), 7.0, device="cuda", dtype=torch.bfloat16)
+        img = torch.full((M, K), 7.0, device="cuda", dtype=torch.bfloat16)
+        L.check(lib.uic_linear_f32a(M, N, K, L.ptr(A), K, L.ptr(Bd), K, L.ptr(C), N, L.ptr(bd), 1, L.ptr(img), K, L.stream()))
+        torch.cuda.synchronize()
+        bad += int(not (torch.equal(C, ref) and torch.equal(img, Ab)))
+    assert bad == 0, bad
+
+
 def test_linear_with_f32_input_rejects_what_it_cannot_run():
     L = _lib()
     lib = L.load()

@@ -161,8 +161,12 @@ __global__ __launch_bounds__(512) void uic_gemm_pp_kernel(const UicGemmParams p)
     u32x4pp pk;                                                                                                                 \
     pk[0] = uic_pack_bf16x2(ra[S][J][0][0], ra[S][J][0][1]); pk[1] = uic_pack_bf16x2(ra[S][J][0][2], ra[S][J][0][3]);             \
     pk[2] = uic_pack_bf16x2(ra[S][J][1][0], ra[S][J][1][1]); pk[3] = uic_pack_bf16x2(ra[S][J][1][2], ra[S][J][1][3]);             \
-    asm volatile("ds_write_b128 %0, %1" ::"v"(wrA[S][J] + (unsigned)(BUF) * BUFB), "v"(pk) : "memory");                          \
-    if (CP) { asm volatile("global_store_dwordx4 %0, %1, %2" ::"v"(offC[S][J]), "v"(pk), "s"(baseC) : "memory"); }               \
+    *(__attribute__((address_space(3))) u32x4pp*)(size_t)(wrA[S][J] + (unsigned)(BUF) * BUFB) = pk;   /* (compiler-visible too) */  \
+    /* (a compiler-visible store: as inline asm the machine does not know that pk is VMEM store data and lets the next piece's */ \
+    /* conversions overwrite the registers while the store still reads them -- 32-64 wrong elements in 1 % of the launches     */ \
+    /* beside a busy neighbour, found by a soak; the asm statements around it carry memory clobbers, so it stays in place and  */ \
+    /* counts in vmcnt exactly where the waits expect it)                                                                      */ \
+    if (CP) *(u32x4pp*)((char*)baseC + offC[S][J]) = pk;                                                                        \
     offC[S][J] += 128;                                                                                                          \
   } while (0)
   // (the wait is the caller's: PP_WAIT_A / PP_VMCNT)
