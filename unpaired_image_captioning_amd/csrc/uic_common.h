@@ -66,10 +66,12 @@ template <> __device__ __forceinline__ void uic_unpack<bf16_t>(const uint4& v, f
   f[4] = __uint_as_float(v.z << 16); f[5] = __uint_as_float(v.z & 0xffff0000u);
   f[6] = __uint_as_float(v.w << 16); f[7] = __uint_as_float(v.w & 0xffff0000u);
 }
+// (as a vector conversion: ONE v_cvt_pk_bf16_f32 for the pair; two scalar conversions compile to two of them plus the packing)
 __device__ __forceinline__ unsigned uic_pack_bf16x2(float lo, float hi) {
-  bf16_t a = (bf16_t)lo, b = (bf16_t)hi;
-  unsigned short ua = __builtin_bit_cast(unsigned short, a), ub = __builtin_bit_cast(unsigned short, b);
-  return (unsigned)ua | ((unsigned)ub << 16);
+  typedef __attribute__((ext_vector_type(2))) float f32x2;
+  typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+  const f32x2 v = {lo, hi};
+  return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2));
 }
 template <typename T> __device__ __forceinline__ uint4 uic_pack(const float* f);
 template <> __device__ __forceinline__ uint4 uic_pack<float>(const float* f) {
