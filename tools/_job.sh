@@ -1,7 +1,8 @@
 #!/bin/bash
 mkdir -p gpurun_out
-python -m pytest tests -m gpu -x -q > gpurun_out/gpu_suite.txt 2>&1
-tail -3 gpurun_out/gpu_suite.txt
-for i in 1 2; do python bench.py --no-cpu-baseline --no-f32 2>/dev/null | python -c "import sys,json; print(json.loads(sys.stdin.readline())['ms_per_step'])"; done
-python tools/nmt_bench.py --steps 20 2>/dev/null | tail -1
-python tools/gemm_headroom.py 2>&1 | grep -A3 "f32 input"
+timeout 1500 python -m pytest tests/test_gpu_topdown.py tests/test_gpu_fullsize.py tests/test_gpu_fullsize_decode.py tests/test_gpu_boundary.py tests/test_gpu_dp2.py -x -q > gpurun_out/td.log 2>&1
+grep -E "passed|failed" gpurun_out/td.log | tail -2
+for i in 1 2 3; do
+python tools/host_time.py 2>&1 | grep -E "prologue|recurrence done|joined" | tr -s ' ' | tr '\n' ' '
+python bench.py --no-cpu-baseline --no-f32 2>/dev/null | python -c "import sys,json; print(json.loads(sys.stdin.readline())['ms_per_step'])"
+done
