@@ -1,8 +1,10 @@
 #!/bin/bash
 mkdir -p gpurun_out
-timeout 1500 python -m pytest tests/test_gpu_topdown.py tests/test_gpu_fullsize.py tests/test_gpu_fullsize_decode.py tests/test_gpu_boundary.py tests/test_gpu_dp2.py -x -q > gpurun_out/td.log 2>&1
-grep -E "passed|failed" gpurun_out/td.log | tail -2
-for i in 1 2 3; do
-python tools/host_time.py 2>&1 | grep -E "prologue|recurrence done|joined" | tr -s ' ' | tr '\n' ' '
-python bench.py --no-cpu-baseline --no-f32 2>/dev/null | python -c "import sys,json; print(json.loads(sys.stdin.readline())['ms_per_step'])"
-done
+timeout 900 python -m pytest tests/test_gpu_nmt.py tests/test_gpu_pivot.py -x -q > gpurun_out/nmt.log 2>&1
+grep -E "passed|failed" gpurun_out/nmt.log | tail -2
+grep -E "^E|Error" gpurun_out/nmt.log | head -5
+python tools/nmt_bench.py --steps 20 2>/dev/null | tail -1
+python tools/nmt_bench.py --steps 20 2>/dev/null | tail -1
+R=$GRAFT_REPO_ROOT
+cd /tmp && export TMPDIR=/tmp
+bash $R/tools/nmt_profile.sh 2>&1 | tail -19 | cut -c1-150 | grep -E "total|xe_"

@@ -957,6 +957,94 @@ __global__ __launch_bounds__(NT) void xe_reg_kernel(const UicXeParams p, const f
   }
 }
 
+// The same for rows too long for 256 threads' registers -- the pivot NMT's generator, 50 004 words = 200 KB per row: a workgroup
+// of 1024 threads holds the row (13 float4 per thread), so the criterion reads the 397 MB of logits ONCE (xe_big_kernel: twice)
+// and keeps the arg-max for the accuracy counters of NMT_loss.score (criterion.py:175-184) on the way.
+constexpr int XE_WTH = 1024, XE_WCH = 13;     // rows up to 13 * 1024 * 4 = 53 248 columns
+template <typename T>
+__global__ __launch_bounds__(XE_WTH) void xe_reg_wide_kernel(const UicXeParams p, const float* __restrict__ logits, T* __restrict__ dlogits) {
+  __shared__ float s_f[XE_WTH / 64], s_bv[XE_WTH / 64];
+  __shared__ int s_bi[XE_WTH / 64];
+  __shared__ float s_y;
+  const int m = blockIdx.x;
+  const int t = m / p.N, n = m - t * p.N;
+  const float* row = logits + (size_t)m * p.ldv;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const long y0 = p.target[(size_t)n * p.ldtarget + p.target_col0 + t];
+  const float mk = p.mask ? p.mask[(size_t)n * p.ldmask + p.mask_col0 + t] : 0.f;
+  const long y = y0 < 0 || y0 >= p.V1 ? 0 : y0;
+  float4 x[XE_WCH];
+  float mx = -INFINITY, bv = -INFINITY;
+  int bi = 0x7fffffff;
+#pragma unroll
+  for (int i = 0; i < XE_WCH; ++i) {
+    const int v = (threadIdx.x + i * XE_WTH) * 4;
+    x[i] = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+    if (v < p.ldv) {
+      const float4 r = *(const float4*)(row + v);
+      x[i].x = v < p.V1 ? r.x : -INFINITY; x[i].y = v + 1 < p.V1 ? r.y : -INFINITY;
+      x[i].z = v + 2 < p.V1 ? r.z : -INFINITY; x[i].w = v + 3 < p.V1 ? r.w : -INFINITY;
+      if ((long)v <= y && y < (long)v + 4) s_y = y == v ? r.x : y == v + 1 ? r.y : y == v + 2 ? r.z : r.w;
+    }
+    // (ascending index inside the thread: a later equal value does not replace the arg-max)
+    if (x[i].x > bv) { bv = x[i].x; bi = v; }
+    if (x[i].y > bv) { bv = x[i].y; bi = v + 1; }
+    if (x[i].z > bv) { bv = x[i].z; bi = v + 2; }
+    if (x[i].w > bv) { bv = x[i].w; bi = v + 3; }
+  }
+  mx = bv;
+  // workgroup maximum and its lowest index
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const float ov = __shfl_xor(bv, o, 64);
+    const int oi = __shfl_xor(bi, o, 64);
+    if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+  }
+  if (lane == 0) { s_bv[wave] = bv; s_bi[wave] = bi; }
+  __syncthreads();
+  bv = s_bv[0]; bi = s_bi[0];
+#pragma unroll
+  for (int w2 = 1; w2 < XE_WTH / 64; ++w2)
+    if (s_bv[w2] > bv || (s_bv[w2] == bv && s_bi[w2] < bi)) { bv = s_bv[w2]; bi = s_bi[w2]; }
+  mx = bv;
+  float sum = 0.f;
+#pragma unroll
+  for (int i = 0; i < XE_WCH; ++i) {        // padded / out-of-row entries hold -inf -> e = 0
+    x[i].x = __expf(x[i].x - mx); x[i].y = __expf(x[i].y - mx); x[i].z = __expf(x[i].z - mx); x[i].w = __expf(x[i].w - mx);
+    sum += (x[i].x + x[i].y) + (x[i].z + x[i].w);
+  }
+  sum = uic_wave_sum(sum);
+  if (lane == 0) s_f[wave] = sum;
+  __syncthreads();                          // (also publishes s_y)
+  sum = 0.f;
+#pragma unroll
+  for (int w2 = 0; w2 < XE_WTH / 64; ++w2) sum += s_f[w2];
+  const float lse = mx + logf(sum);
+  if (threadIdx.x == 0) {
+    p.row_loss[m] = -(s_y - lse) * mk;
+    if (p.score_stats && y0 != 0) {
+      atomicAdd(&p.score_stats[1], 1);
+      if (bi == (int)y0) atomicAdd(&p.score_stats[0], 1);
+    }
+  }
+  const float sc = p.grad_scale ? p.grad_scale[(size_t)n * p.ldscale + p.scale_col0 + t] : mk * p.inv_den[0];
+  const float k = sc / sum;
+  T* d = dlogits + (size_t)m * p.ldv;
+#pragma unroll
+  for (int i = 0; i < XE_WCH; ++i) {
+    const int v = (threadIdx.x + i * XE_WTH) * 4;
+    if (v >= p.ldv) continue;
+    float g[4] = {x[i].x * k, x[i].y * k, x[i].z * k, x[i].w * k};
+    const long j = y - (long)v;
+    g[0] -= j == 0 ? sc : 0.f; g[1] -= j == 1 ? sc : 0.f; g[2] -= j == 2 ? sc : 0.f; g[3] -= j == 3 ? sc : 0.f;
+    if constexpr (sizeof(T) == 2) {
+      *(uint2*)(d + v) = make_uint2(uic_pack_bf16x2(g[0], g[1]), uic_pack_bf16x2(g[2], g[3]));
+    } else {
+      *(float4*)(d + v) = make_float4(g[0], g[1], g[2], g[3]);
+    }
+  }
+}
+
 // API-compat backward: upstream grad g wrt log-probs [n][t][v]; d logits = g - softmax * sum_v g
 template <typename T>
 __global__ __launch_bounds__(NT) void logsoftmax_bwd_kernel(T* __restrict__ dlogits, int V1, int ldv, int N, const float* __restrict__ g,
@@ -1693,6 +1781,12 @@ int uic_xe_launch(const UicXeParams& p, hipStream_t s) {
       !p.logprobs && !p.score_stats && ((uintptr_t)p.dlogits & 7) == 0) {
     hipLaunchKernelGGL(xe_reg_kernel<bf16_t>, dim3(p.M), dim3(NT), 0, s, p, p.logits, (bf16_t*)p.dlogits);
     UIC_LAUNCH_CHECK("xe_reg_kernel");
+    return UIC_OK;
+  }
+  if (p.dtype == UIC_BF16 && p.ldv % 4 == 0 && p.ldv > XE_RCH * NT * 4 && p.ldv <= XE_WCH * XE_WTH * 4 && ((uintptr_t)p.logits & 15) == 0 &&
+      p.write_grad && p.target && !p.logprobs && ((uintptr_t)p.dlogits & 7) == 0) {
+    hipLaunchKernelGGL(xe_reg_wide_kernel<bf16_t>, dim3(p.M), dim3(XE_WTH), 0, s, p, p.logits, (bf16_t*)p.dlogits);
+    UIC_LAUNCH_CHECK("xe_reg_wide_kernel");
     return UIC_OK;
   }
   if (p.dtype == UIC_BF16 && p.ldv % 4 == 0 && row_bytes <= 64 * 1024 && ((uintptr_t)p.logits & 15) == 0) {
