@@ -280,15 +280,28 @@ __global__ void embed_block_prefix_kernel(int* __restrict__ cntb, int nkeys, int
 // scanned by wave shuffles + one LDS hop, with the running total carried from row to row (a thread that walked its own run of
 // ~50 consecutive keys -- strided loads, one at a time -- took 72 us on the pivot NMT's 100 008 keys).
 __global__ __launch_bounds__(1024) void embed_scan_kernel(const int* __restrict__ cnt, int V1, int* __restrict__ off) {
+  // four consecutive keys per thread and trip (one 16-byte load): 4096 keys per trip, 13 trips for the pivot NMT's 50 005 keys
+  // (one key per thread: 49 trips of shuffle scan + LDS hop + barrier = 40 us)
   __shared__ int s_wave[2][16];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   int carry = 0;
-  int nxt = (int)threadIdx.x < V1 ? cnt[threadIdx.x] : 0;
-  for (int base = 0, it = 0; base < V1; base += 1024, ++it) {
-    const int v = base + threadIdx.x;
-    const int x = nxt;
-    if (base + 1024 < V1) nxt = v + 1024 < V1 ? cnt[v + 1024] : 0;     // (the next row's load passes behind this row's scan)
-    int incl = x;
+  auto load4 = [&](int v0, int (&x)[4]) {
+    if (v0 + 3 < V1) {
+      const int4 q = *(const int4*)(cnt + v0);          // (cnt is 16-byte aligned and v0 a multiple of 4)
+      x[0] = q.x; x[1] = q.y; x[2] = q.z; x[3] = q.w;
+    } else {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) x[k] = v0 + k < V1 ? cnt[v0 + k] : 0;
+    }
+  };
+  int nxt[4];
+  load4((int)threadIdx.x * 4, nxt);
+  for (int base = 0, it = 0; base < V1; base += 4096, ++it) {
+    const int v0 = base + (int)threadIdx.x * 4;
+    const int x[4] = {nxt[0], nxt[1], nxt[2], nxt[3]};
+    if (base + 4096 < V1) load4(v0 + 4096, nxt);          // (the next trip's load passes behind this trip's scan)
+    const int t4 = (x[0] + x[1]) + (x[2] + x[3]);
+    int incl = t4;
 #pragma unroll
     for (int o = 1; o < 64; o <<= 1) {
       const int up = __shfl_up(incl, o, 64);
@@ -304,7 +317,12 @@ __global__ __launch_bounds__(1024) void embed_scan_kernel(const int* __restrict_
       if (k < wv) woff += t;
       tot += t;
     }
-    if (v < V1) off[v] = carry + woff + incl - x;
+    int run = carry + woff + incl - t4;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      if (v0 + k < V1) off[v0 + k] = run;
+      run += x[k];
+    }
     carry += tot;
   }
   if (threadIdx.x == 0) off[V1] = carry;
