@@ -349,6 +349,56 @@ def test_trainer_nmt_half_runs_and_saves(tmp_path):
     assert list(sd.keys()) == tr.nmt_model.param_names
 
 
+def test_trainer_nmt_without_the_arena_fill_equals_the_eager_zero_grad(tmp_path):
+    """Trainer.train_nmt skips the fill of the gradient arena (Optim.zero_grad(nmt_direct=True)): the in-place backward pass
+    overwrites every gradient, embedding tables included.  Three steps with the arena POISONED before each backward pass must
+    give the losses and weights of three steps with the eager fill, bit for bit; a backward pass that takes the accumulating
+    path after a lazy zero_grad must clear the arena itself."""
+    from unpaired_image_captioning_amd.trainer import Trainer
+    cfg = dict(layers=2, H=64, W=64, B=8, S=10, T=9, Vs=120, Vt=130)
+    I = synthetic(cfg, 9)
+    batch = argparse.Namespace(src=I["src"].cuda(), tgt=I["tgt"].cuda(), lengths=I["lengths"])
+
+    def fresh():
+        o = make_opt(cfg, "bf16", dropout=0.1, seed=3)
+        o.nmt_train_flag, o.i2t_train_flag, o.checkpoint_path = 1, 0, str(tmp_path)
+        o.nmt_learning_rate, o.nmt_max_grad_norm, o.param_init = 5e-3, 5, 0.1
+        tr = Trainer(o)
+        tr.build_nmt(cfg["Vs"], cfg["Vt"])
+        return tr
+
+    eager = fresh()
+    W0 = {k: v.clone() for k, v in eager.nmt_model.state_dict().items()}
+    z = eager.optim.zero_grad
+    eager.optim.zero_grad = lambda nmt_direct=False: z()                 # always the fill
+    ref = [eager.train_nmt(batch) for _ in range(3)]
+    lazy = fresh()
+    lazy.nmt_model.load_state_dict(W0)
+    zl = lazy.optim.zero_grad
+
+    def poisoned(nmt_direct=False):
+        zl(nmt_direct=nmt_direct)
+        if nmt_direct:
+            g = lazy.optim.nmt_arena.grad
+            base = g.data_ptr()
+            for v in lazy.optim.nmt_arena.grad_views.values():          # (the padding between tensors stays zero, as in real use)
+                v.fill_(float("nan"))
+    lazy.optim.zero_grad = poisoned
+    got = [lazy.train_nmt(batch) for _ in range(3)]
+    assert got == ref
+    assert torch.equal(lazy.optim.nmt_arena.flat, eager.optim.nmt_arena.flat)
+    # the accumulating path after a lazy zero_grad: the arena is cleared before autograd adds into it
+    lazy.optim.zero_grad = zl
+    lazy.optim.zero_grad(nmt_direct=True)
+    for v in lazy.optim.nmt_arena.grad_views.values():
+        v.fill_(1e6)
+    lazy.nmt_model.unit_loss_gradient = False
+    outputs, attn, _, _ = lazy.dp_nmt_model(batch.src, batch.tgt, batch.lengths, None)
+    lazy.nmt_crit(None, batch, outputs, attn).backward()
+    torch.cuda.synchronize()
+    assert float(lazy.optim.nmt_arena.grad.abs().max()) < 1e5
+
+
 def test_trainer_nmt_step_after_a_timeout_is_skipped_on_the_device_and_raises(tmp_path):
     """The status word the persistent pivot kernels (csrc/nmt_persist.hip) set when a bounded spin gives up, forced here: the
     clipped Adam update must be skipped on the device (uic_adam_step_clip_guarded), train_nmt must raise with the step counters

@@ -180,13 +180,24 @@ class Optim(object):
             self.nmt_arena.adam(self.nmt_current_lr, (self.nmt_optim_alpha, self.nmt_optim_beta), self.nmt_optim_epsilon,
                                 self._nmt_steps, nmt_grad_scale, self.nmt_max_grad_norm, guard=guard)
 
-    def zero_grad(self):
+    def zero_grad(self, nmt_direct=False):
+        """nmt_direct (Trainer.train_nmt): the coming backward pass is the in-place one (models/NMT_Models.py, _NmtStep.backward:
+        the kernels OVERWRITE every gradient in the arena, the embedding tables included), so the 360 MB fill of the pivot
+        model's arena is skipped; the padding between tensors was zeroed when the arena was made and nothing writes it.  Should
+        that backward pass take the accumulating path after all, it clears the arena itself first (model._lazy_zero)."""
         if self.i2t_train_flag and self.i2t_arena is not None:
             self.i2t_arena.zero_grad()
         if self.nmt_train_flag and self.nmt_arena is not None:
-            self.nmt_arena.zero_grad()
-            if getattr(self, '_nmt_model', None) is not None:
-                self._nmt_model._sink_written = False
+            m = getattr(self, '_nmt_model', None)
+            if nmt_direct and m is not None and m.grad_sink is not None and self.nmt_arena.flat.is_cuda:
+                self.nmt_arena.bind_grads()
+                m._lazy_zero = self.nmt_arena.grad.zero_
+            else:
+                self.nmt_arena.zero_grad()
+                if m is not None:
+                    m._lazy_zero = None
+            if m is not None:
+                m._sink_written = False
 
     def update_ScheduledSampling_prob(self, opt, epoch, dp_i2t_model):
         if epoch > opt.scheduled_sampling_start and opt.scheduled_sampling_start >= 0:

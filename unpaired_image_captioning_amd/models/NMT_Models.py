@@ -199,6 +199,10 @@ class _NmtStep(torch.autograd.Function):
         # weight 1 (a plain loss.backward()), so the kernels write the arena in place -- no temporaries, no scale, no
         # accumulate pass over the 86 M parameters.  Any other caller (scaled losses, loss.backward(gradient=...)) takes
         # the general path below, which honours g_loss and lets autograd accumulate.
+        lazy = getattr(model, '_lazy_zero', None)
+        if not direct and lazy is not None:
+            lazy()                       # (Optim.zero_grad(nmt_direct=True) left the arena as it was: clear it before autograd accumulates)
+        model._lazy_zero = None
         if direct:
             if model._sink_written:
                 raise RuntimeError("NMT backward ran twice into the optimizer's gradient arena without Optim.zero_grad() in between: "
