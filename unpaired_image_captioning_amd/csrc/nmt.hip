@@ -657,6 +657,7 @@ int nmt_check(const uic_nmt_dims* d) {
 struct NmtSide {
   hipStream_t stream = nullptr;
   hipEvent_t ev_go = nullptr, ev_done = nullptr;
+  hipEvent_t ev_r0 = nullptr, ev_gen = nullptr;   // refresh: the caller's stream has reached it; the generator's copies are made
   bool ready = false;
 };
 NmtSide g_nmt_side[16];
@@ -671,6 +672,8 @@ int nmt_side(NmtSide** out) {
     UIC_TRY(uic_check_hip(hipStreamCreateWithFlags(&ss.stream, hipStreamNonBlocking), "hipStreamCreateWithFlags"));
     UIC_TRY(uic_check_hip(hipEventCreateWithFlags(&ss.ev_go, hipEventDisableTiming), "hipEventCreate"));
     UIC_TRY(uic_check_hip(hipEventCreateWithFlags(&ss.ev_done, hipEventDisableTiming), "hipEventCreate"));
+    UIC_TRY(uic_check_hip(hipEventCreateWithFlags(&ss.ev_r0, hipEventDisableTiming), "hipEventCreate"));
+    UIC_TRY(uic_check_hip(hipEventCreateWithFlags(&ss.ev_gen, hipEventDisableTiming), "hipEventCreate"));
     ss.ready = true;
   }
   *out = &ss;
@@ -711,9 +714,29 @@ struct Nmt {
     return UIC_OK;
   }
 
+  // the generator's 25.6 M-element operand copy and its transpose (28 + 28 us) are not needed before the decoder is through: they
+  // run on the side stream, and whoever reads them first waits for ev_gen (wait_gen)
+  bool gen_pending = false;
+  int wait_gen(hipStream_t s) {
+    if (!gen_pending) return UIC_OK;
+    gen_pending = false;
+    NmtSide* ss = nullptr;
+    UIC_TRY(nmt_side(&ss));
+    return uic_check_hip(hipStreamWaitEvent(s, ss->ev_gen, 0), "hipStreamWaitEvent(generator copies)");
+  }
   int refresh(hipStream_t s) {
     // operand-dtype copies and transposes of the weights, a handful of multi-tensor launches instead of one per tensor
     // (the step is a chain of small launches: 34 of them were this)
+    {
+      NmtSide* ss = nullptr;
+      UIC_TRY(nmt_side(&ss));
+      UIC_TRY(uic_check_hip(hipEventRecord(ss->ev_r0, s), "hipEventRecord"));            // the master weights are final
+      UIC_TRY(uic_check_hip(hipStreamWaitEvent(ss->stream, ss->ev_r0, 0), "hipStreamWaitEvent"));
+      if (dt == UIC_BF16) UIC_TRY(uic_cast_f32_launch(dt, w->gen_w, L.c_gen_w, (size_t)Vt * H, ss->stream));   // (25.6 M elements: a launch of its own)
+      UIC_TRY(uic_transpose_launch(dt, L.gen_w, Vt, H, H, L.gen_wT, Vtp, ss->stream));
+      UIC_TRY(uic_check_hip(hipEventRecord(ss->ev_gen, ss->stream), "hipEventRecord"));
+      gen_pending = true;
+    }
     if (dt == UIC_BF16) {
       const float* src[UIC_CAST_MULTI]; void* dst[UIC_CAST_MULTI]; size_t n[UIC_CAST_MULTI];
       int k = 0;
@@ -736,7 +759,6 @@ struct Nmt {
       UIC_TRY(add(w->attn_in_w, L.c_attn_in_w, (size_t)H * H));
       UIC_TRY(add(w->attn_out_w, L.c_attn_out_w, (size_t)H * 2 * H));
       UIC_TRY(flush());
-      UIC_TRY(uic_cast_f32_launch(dt, w->gen_w, L.c_gen_w, (size_t)Vt * H, s));   // (25.6 M elements: a launch of its own)
     }
     {
       UicTransposeJob jobs[UIC_TRANSPOSE_MULTI];
@@ -761,7 +783,7 @@ struct Nmt {
       UIC_TRY(add(L.attn_out_w, H, 2 * H, 2 * H, L.attn_out_wT, H));
       UIC_TRY(flush());
     }
-    return uic_transpose_launch(dt, L.gen_w, Vt, H, H, L.gen_wT, Vtp, s);
+    return UIC_OK;
   }
 
   // input of encoder layer l as seen by its W_ih GEMM (slots 1..S): the dropped copy between layers in training
@@ -957,6 +979,7 @@ struct Nmt {
 
   // generator + NMTCriterion + NMT_loss.score (criterion.py:126-136,175-184)
   int loss_fwd(float* loss_out, int32_t* stats_out, hipStream_t s) {
+    UIC_TRY(wait_gen(s));
     {
       UicGemmParams g = gemm_base(dt, Td * B, Vt);
       add_seg(g, off(L.out_all, BH, dt), H, L.gen_w, H, H);
@@ -1362,6 +1385,7 @@ int uic_nmt_translate(const uic_nmt_dims* d, const uic_nmt_weights* w, const int
   }
   UIC_TRY(st.refresh(s));
   UIC_TRY(st.encoder_fwd(T.lens_dev, s));
+  UIC_TRY(st.wait_gen(s));                  // the generator's copies (side stream) are read from the first decode step on
   const NmtLayout& L = st.L;
   // (2) decoder state = encoder final states (slot 0 of the training path's state buffers), zero input feed
   for (int l = 0; l < NL; ++l) {
