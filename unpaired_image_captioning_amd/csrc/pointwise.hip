@@ -978,7 +978,8 @@ __global__ __launch_bounds__(NT) void xe_reg_kernel(const UicXeParams p, const f
 // The same for rows too long for 256 threads' registers -- the pivot NMT's generator, 50 004 words = 200 KB per row: a workgroup
 // of 1024 threads holds the row (13 float4 per thread), so the criterion reads the 397 MB of logits ONCE (xe_big_kernel: twice)
 // and keeps the arg-max for the accuracy counters of NMT_loss.score (criterion.py:175-184) on the way.
-constexpr int XE_WTH = 1024, XE_WCH = 13;     // rows up to 13 * 1024 * 4 = 53 248 columns
+constexpr int XE_WTH = 1024, XE_WCH = 13;     // rows up to 13 * 1024 * 4 = 53 248 columns (512 threads x 26 float4 at two
+                                              // workgroups per CU: 128 registers per lane, 307 spilled -- 427 us)
 template <typename T>
 __global__ __launch_bounds__(XE_WTH) void xe_reg_wide_kernel(const UicXeParams p, const float* __restrict__ logits, T* __restrict__ dlogits) {
   __shared__ float s_f[XE_WTH / 64], s_bv[XE_WTH / 64];
