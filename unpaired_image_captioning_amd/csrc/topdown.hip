@@ -1482,6 +1482,7 @@ int uic_topdown_xe_train_step(const uic_topdown_dims* d, const uic_topdown_weigh
   // training bit 2: the workspace already holds this forward pass (uic_topdown_sample_train drew b->labels with these
   // weights, this seed and these dims): the step starts at the criterion
   const bool resume = (training & 4) != 0;
+  bool bwd_begun = false;
   UIC_REQUIRE(!resume || !st.ss_on(), "xe_train_step: a resumed step cannot use scheduled sampling");
   if (!resume) {
     // three branches: att_embed + ctx2att (main), embedding + batched input GEMM (side), fc_embed + Gfc + initial state (third
@@ -1495,6 +1496,8 @@ int uic_topdown_xe_train_step(const uic_topdown_dims* d, const uic_topdown_weigh
     if (split3) {
       UIC_HIP(hipStreamWaitEvent(s3, ss->ev_den, 0));
       UIC_TRY(st.fwd_prologue(s3, 4));
+      UIC_TRY(st.bwd_begin(s3));                      // (the BPTT loop's zeroed carries and ones block: nothing in the forward pass touches them)
+      bwd_begun = true;
       UIC_HIP(hipEventRecord(ss->ev_pro3, s3));
     }
     UIC_TRY(flush_transposes(ss));                    // (behind the branch: only the backward pass reads them)
@@ -1507,6 +1510,7 @@ int uic_topdown_xe_train_step(const uic_topdown_dims* d, const uic_topdown_weigh
   // persistent mode 3: the whole recurrence as ONE launch (it holds every CU, nothing overlaps it); the logit layer follows
   // chunk by chunk on the side stream beside the BPTT loop
   const bool one_launch = resume || st.persist_ok();
+  const bool first_on_main = one_launch && nchunk >= 2 && !st.ss_on();
   if (one_launch) { if (!resume) UIC_TRY(st.fwd_steps(0, t_run, s)); UIC_MARK(2, s); }
   for (int i = 0; i < nchunk; ++i) {
     // after a single launch every step is there at once: the logit layer then takes the chunks LAST FIRST, the order the
@@ -1514,6 +1518,16 @@ int uic_topdown_xe_train_step(const uic_topdown_dims* d, const uic_topdown_weigh
     const int c = one_launch ? nchunk - 1 - i : i;
     const int t0 = c * CH, t1 = t0 + CH < t_run ? t0 + CH : t_run;
     if (!one_launch) UIC_TRY(st.fwd_steps(t0, t1, s));
+    if (first_on_main && i == 0) {
+      // the chunk the BPTT loop starts from, on the MAIN stream itself (idle until that chunk is through anyway): no event hop to
+      // the side stream and back in front of the loop; the side stream starts with the next chunk once this one is done
+      if (!resume) UIC_TRY(st.logits_rows(t0, t1, s));
+      UIC_TRY(st.xe_rows(t0, t1, inv, nullptr, 1, s));
+      UIC_TRY(st.dh_rows(t0, t1, s, false));
+      UIC_HIP(hipEventRecord(ss->ev_main[c], s));
+      UIC_HIP(hipStreamWaitEvent(s2, ss->ev_main[c], 0));
+      continue;
+    }
     if (!one_launch || i == 0) UIC_HIP(hipEventRecord(ss->ev_main[c], s));
     // side: logit layer of the chunk, forward and backward-to-h (beside the next chunk's recurrence)
     if (!one_launch || i == 0) UIC_HIP(hipStreamWaitEvent(s2, ss->ev_main[c], 0));
@@ -1536,7 +1550,7 @@ int uic_topdown_xe_train_step(const uic_topdown_dims* d, const uic_topdown_weigh
   // main: BPTT, each step waits for the d hdrop rows of its chunk; side: the recurrent weight gradients of every
   // finished chunk (transposes + accumulating GEMMs), so only the last chunk's share outlives the loop
   UIC_TRY(wait_refresh(s));                           // the BPTT loop reads the transposed weight copies
-  UIC_TRY(st.bwd_begin(s));
+  if (!bwd_begun) UIC_TRY(st.bwd_begin(s));
   {
     // The embedding gradient's token bucketing needs only the tokens (labels; under scheduled sampling the tokens the forward
     // pass fed, which the side stream has waited for): in the side stream's slack inside the BPTT window.  Two halves: the
@@ -1556,7 +1570,7 @@ int uic_topdown_xe_train_step(const uic_topdown_dims* d, const uic_topdown_weigh
   const bool tail3 = !early && st.embed_prepared;
   for (int c = nchunk - 1; c >= 0; --c) {
     const int t0 = c * CH, t1 = t0 + CH < t_run ? t0 + CH : t_run;
-    UIC_HIP(hipStreamWaitEvent(s, ss->ev_side[c], 0));
+    if (!(first_on_main && c == nchunk - 1)) UIC_HIP(hipStreamWaitEvent(s, ss->ev_side[c], 0));
     if (c == nchunk - 1) UIC_MARK(4, s);              // main: BPTT starts
     UIC_TRY(st.bwd_steps(t0, t1, s));
     UIC_HIP(hipEventRecord(ss->ev_main[c], s));       // (the forward's use of ev_main[c] was consumed long ago)
