@@ -727,7 +727,7 @@ int launch_cfg(const UicGemmParams& p, hipStream_t s) {
 // BPTT loop's 640-row GEMMs (18-36 tiles) lose 2-3x and stay on the 128 x 128 / skinny kernels.
 inline bool uic_gemm_pp_wins(const UicGemmParams& p) {
   if (!uic_gemm_pp_eligible(p) || p.seg[0].K < 512) return false;
-  const int rows = uic_gemm_pp_rows(p.M, p.N);
+  const int rows = uic_gemm_pp_rows(p.M, p.N, 256, p.seg[0].K / (p.splitk > 1 ? p.splitk : 1));
   const long tiles = (long)((p.M + rows - 1) / rows) * ((p.N + 255) / 256) * (p.splitk > 1 ? p.splitk : 1);
   return tiles >= 160;
 }

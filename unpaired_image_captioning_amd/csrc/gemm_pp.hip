@@ -520,19 +520,23 @@ int launch_pp(const UicGemmParams& p, hipStream_t s) {
 // rows: the tile height, 256 / 192 / 128 (0 = uic_gemm_pp_rows' choice)
 int uic_gemm_pp_launch(const UicGemmParams& p, int rows, hipStream_t s) {
   UIC_REQUIRE(uic_gemm_pp_eligible(p), "gemm_pp: problem not eligible for the 256-column ping-pong kernel");
-  if (rows == 0) rows = uic_gemm_pp_rows(p.M, p.N, p.a_f32 ? 192 : 256);
+  if (rows == 0) rows = uic_gemm_pp_rows(p.M, p.N, p.a_f32 ? 192 : 256, p.seg[0].K / (p.splitk > 1 ? p.splitk : 1));
   UIC_REQUIRE(rows == 256 || rows == 192 || rows == 128, "gemm_pp: tile height %d (256 / 192 / 128)", rows);
   return rows == 256 ? launch_pp<4>(p, s) : rows == 192 ? launch_pp<3>(p, s) : launch_pp<2>(p, s);
 }
 
 // The tile height whose slowest CU has the least work: one workgroup per CU and 256 CUs, so a launch of `tiles` tiles takes
-// ceil(tiles / 256) rounds of one tile's time (~ its height); ties go to the taller tile (fewer operand bytes per flop).
-int uic_gemm_pp_rows(int M, int N, int tallest) {
+// ceil(tiles / 256) rounds of one tile's time -- its K loop (~ rows x K tiles) plus what every tile pays regardless of its height
+// (the 256-column B operand, prologue, epilogue: ~ 96 rows' worth of an 8-K-tile loop, fitted to the vocabulary GEMMs with K =
+// 512: 1984 x 50004 takes 185 us with 256-row tiles, 187 with 192, 225 with 128 -- the count of rounds alone picked 128).
+// Ties go to the taller tile (fewer operand bytes per flop).
+int uic_gemm_pp_rows(int M, int N, int tallest, int K) {
   const long cols = (N + 255) / 256;
+  const long ktiles = K > 64 ? K / 64 : 1;
   int best = tallest; long best_cost = -1;
   for (int rows = tallest; rows >= 128; rows -= 64) {
     const long tiles = (long)((M + rows - 1) / rows) * cols;
-    const long cost = ((tiles + 255) / 256) * rows;
+    const long cost = ((tiles + 255) / 256) * ((long)rows * ktiles + 768);
     if (best_cost < 0 || cost < best_cost) { best = rows; best_cost = cost; }
   }
   return best;

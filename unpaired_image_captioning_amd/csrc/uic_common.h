@@ -213,7 +213,7 @@ bool uic_gemm_glds_eligible(int dtype, int K);
 int uic_gemm_launch(const UicGemmParams& p, hipStream_t stream);
 // the 256 x 256 x 64 ping-pong kernel (gemm_pp.hip): bf16, one K segment, K a multiple of 128 per split-K slice
 bool uic_gemm_pp_eligible(const UicGemmParams& p);
-int uic_gemm_pp_rows(int M, int N, int tallest = 256);
+int uic_gemm_pp_rows(int M, int N, int tallest = 256, int K = 512);
 int uic_gemm_pp_launch(const UicGemmParams& p, int rows, hipStream_t stream);
 
 // ---------------------------------------------------------------- TN GEMM (gemm_tn.hip): C[i,j] = sum_k A[k,i] B[k,j]
