@@ -9,6 +9,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 ap = argparse.ArgumentParser()
 ap.add_argument("--iters", type=int, default=300)
+ap.add_argument("--safe", action="store_true", help="the persistent kernels' placement-independent SAFE protocol (UIC_REC_SAFE)")
 a = ap.parse_args()
 import torch
 from bench import CFG, make_opt
@@ -36,6 +37,8 @@ tr = Trainer(make_opt("bf16", 1234))
 tr.build_optimizer()
 model = tr.i2t_model
 model.train()
+if a.safe:
+    model.engine.recurrence |= L.REC_SAFE
 batch = {k: v.cuda() for k, v in synthetic_batch(c["n_img"], c["S"], c["R"], c["D"], c["V"], c["L"], seed=7).items()}
 ref = None
 bad = {}
@@ -79,6 +82,8 @@ nb = argparse.Namespace(src=src.unsqueeze(2).cuda(), tgt=tgt.cuda(), lengths=len
 ref = None
 bad = {}
 m = tn.nmt_model
+if a.safe:
+    m.engine.recurrence = int(getattr(m.engine, "recurrence", 0)) | L.REC_SAFE
 for it in range(a.iters):
     neighbours(it)
     m._seed_counter = 777
