@@ -1476,7 +1476,10 @@ int uic_topdown_xe_train_step(const uic_topdown_dims* d, const uic_topdown_weigh
   UIC_HIP(hipStreamWaitEvent(s2, ss->ev_den, 0));
   // side: the loss denominator (the criterion's first use of it is on this stream, after the recurrence).  First on its stream:
   // behind the branch below it would be dispatched beside the persistent recurrence and wait for a CU until that ends.
-  if (b->masks) UIC_TRY(uic_masked_sum_launch(nullptr, b->masks, b->ld_masks, 1, d->N, d->T, st.L.scalars, st.L.scalars + 1, s2));
+  // (A resumed step has no prologue after which the main stream waits for the side stream, and the loop's first logit chunk --
+  // its criterion reads the denominator -- runs on the main stream: there the denominator is made on the main stream.)
+  if (b->masks) UIC_TRY(uic_masked_sum_launch(nullptr, b->masks, b->ld_masks, 1, d->N, d->T, st.L.scalars, st.L.scalars + 1,
+                                              (training & 4) ? s : s2));
   // the prologue's two independent branches side by side: att_embed + ctx2att here, fc_embed + embedding + the batched
   // input GEMM on the side stream (idle until the recurrence is through; its part of the weight refresh comes first there)
   // training bit 2: the workspace already holds this forward pass (uic_topdown_sample_train drew b->labels with these
