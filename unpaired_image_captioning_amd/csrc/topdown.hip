@@ -1524,6 +1524,7 @@ int uic_topdown_xe_train_step(const uic_topdown_dims* d, const uic_topdown_weigh
     if (first_on_main && i == 0) {
       // the chunk the BPTT loop starts from, on the MAIN stream itself (idle until that chunk is through anyway): no event hop to
       // the side stream and back in front of the loop; the side stream starts with the next chunk once this one is done
+      UIC_TRY(wait_refresh(s));                       // (d hdrop = d logits W_logit reads the transposed copy the side stream made)
       if (!resume) UIC_TRY(st.logits_rows(t0, t1, s));
       UIC_TRY(st.xe_rows(t0, t1, inv, nullptr, 1, s));
       UIC_TRY(st.dh_rows(t0, t1, s, false));
