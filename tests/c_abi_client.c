@@ -2,7 +2,7 @@
  * device memory.  Compiled and run by tests/test_gpu_c_abi.py on the GPU box:
  *     gcc -std=c11 tests/c_abi_client.c -Iinclude -I/opt/rocm/include -D__HIP_PLATFORM_AMD__ -Lunpaired_image_captioning_amd -luic_hip \
  *         -L/opt/rocm/lib -lamdhip64 -lm -o c_abi_client
- * Exercises: the workspace-size queries, an argument error with its message, uic_linear (f32), uic_attention_fwd (f32),
+ * Exercises: the workspace-size queries, an argument error with its message, uic_linear (f32), uic_linear_f32a, uic_attention_fwd (f32),
  * uic_adam_step and the fused captioner training step (uic_topdown_refresh_weights + uic_topdown_xe_train_step) against
  * loops / closed forms written here, on the caller's own stream.  Prints "C ABI OK" and exits 0. */
 #include <math.h>
@@ -64,6 +64,47 @@ int main(void) {
       }
     if (worst > 1e-4) { fprintf(stderr, "uic_linear off by %g\n", worst); return 1; }
     hipFree(dA); hipFree(dB); hipFree(db); hipFree(dC); free(A); free(B); free(bias); free(C);
+  }
+
+  /* uic_linear_f32a: f32 input rounded inside the GEMM, bf16 weights, f32 output + the bf16 image of the input.
+   * bf16 <-> f32 by hand (round to nearest even), the product against a double loop over the ROUNDED operands. */
+  {
+    const int M = 384, N = 256, K = 256;
+    float *A = malloc(sizeof(float) * M * K), *C = malloc(sizeof(float) * M * N);
+    unsigned short *Bh = malloc(2 * N * K), *img = malloc(2 * M * K);
+    float *Br = malloc(sizeof(float) * N * K), *Ar = malloc(sizeof(float) * M * K);
+    for (int i = 0; i < M * K; ++i) A[i] = frand(&seed) * 3.0f;
+    for (int i = 0; i < N * K; ++i) {
+      float f = frand(&seed) * 0.25f; unsigned u; memcpy(&u, &f, 4);
+      u = (u + 0x7fffu + ((u >> 16) & 1u)) >> 16; Bh[i] = (unsigned short)u; u <<= 16; memcpy(&Br[i], &u, 4);
+    }
+    for (int i = 0; i < M * K; ++i) {
+      unsigned u; memcpy(&u, &A[i], 4);
+      u = ((u + 0x7fffu + ((u >> 16) & 1u)) >> 16) << 16; memcpy(&Ar[i], &u, 4);
+    }
+    float* dA = to_dev(A, sizeof(float) * M * K);
+    void *dB = to_dev(Bh, 2 * N * K), *dI = to_dev(NULL, 2 * M * K);
+    float* dC = to_dev(NULL, sizeof(float) * M * N);
+    if (!dA || !dB || !dI || !dC) return 2;
+    CHECK_UIC(uic_linear_f32a(M, N, K, dA, K, dB, K, dC, N, NULL, 4, dI, K, stream));
+    CHECK_HIP(hipStreamSynchronize(stream));
+    CHECK_HIP(hipMemcpy(C, dC, sizeof(float) * M * N, hipMemcpyDeviceToHost));
+    CHECK_HIP(hipMemcpy(img, dI, 2 * M * K, hipMemcpyDeviceToHost));
+    for (int i = 0; i < M * K; ++i) {
+      unsigned u; memcpy(&u, &Ar[i], 4);
+      if (img[i] != (unsigned short)(u >> 16)) { fprintf(stderr, "uic_linear_f32a: bf16 image differs at %d\n", i); return 1; }
+    }
+    double worst = 0;
+    for (int m = 0; m < M; m += 7)
+      for (int n = 0; n < N; ++n) {
+        double acc = 0;
+        for (int k = 0; k < K; ++k) acc += (double)Ar[m * K + k] * Br[n * K + k];
+        double e = fabs(acc - C[m * N + n]);
+        if (e > worst) worst = e;
+      }
+    if (worst > 2e-3) { fprintf(stderr, "uic_linear_f32a off by %g\n", worst); return 1; }
+    if (uic_linear_f32a(M, N, 192, dA, K, dB, K, dC, N, NULL, 4, NULL, K, stream) >= 0) { fprintf(stderr, "uic_linear_f32a accepted K = 192\n"); return 1; }
+    hipFree(dA); hipFree(dB); hipFree(dI); hipFree(dC); free(A); free(C); free(Bh); free(img); free(Br); free(Ar);
   }
 
   /* uic_attention_fwd, f32: alpha = softmax_r(w . tanh(p_att[r] + att_h) + b), masked + renormalised; ctx = sum_r alpha_r att[r] */
