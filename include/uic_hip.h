@@ -389,6 +389,14 @@ int uic_nmt_backward(const uic_nmt_dims* d, const uic_nmt_weights* w, const int6
                      const int64_t* tgt, int32_t training, uint32_t seed, void* workspace, const uic_nmt_weights* grads,
                      void* stream);
 
+/* Data-parallel callers (replaces DataParallel(nmt_model, dim=1)'s reduce-add, P/trainer.py:88-89): lets `stream` wait until a
+ * gradient group of the last uic_nmt_backward on this device is final, so that its exchange runs beside the rest of the
+ * backward pass.  group 0: generator.{weight,bias} (30 % of the bytes at the reference's sizes; final before the decoder BPTT
+ * starts); group 1: the decoder side (decoder.rnn.*, decoder.embeddings.*, decoder.attn.*; final before the encoder's backward
+ * pass).  The encoder's gradients are final when uic_nmt_backward's own stream is through.  The clipped Adam step needs the
+ * norm of the SUMMED gradient: uic_grad_sqnorm after all three pieces. */
+int uic_nmt_grad_ready_wait(void* stream, int32_t group);
+
 /* NMTModel.translateBatch (P/models/NMT_Models.py:322-395) with the fork's Beam (O/Beam.py): beam search translation of a
  * batch, n_best = 1.  src [S, B] int64 (PAD = 0; the encoder runs without lengths, as the reference's does here).  Outputs:
  * hyp_out [B, max_steps] int64 (first *n_iter_out columns valid: the number of decoder steps taken, identical for all
@@ -440,7 +448,10 @@ int uic_linear_partials(int32_t dtype, int32_t M, int32_t N, int32_t K, const vo
 /* Weight gradient of nn.Linear without transposed copies: dW[M,N] (f32) = dY[K,M]^T X[K,N] (+= if accumulate), dY / X bf16
  * row-major with the reduction index (caption rows / decode steps) as the ROW index, exactly as the backward pass holds
  * them.  gfx950 transposing LDS reads (csrc/gemm_tn.hip).  Needs M >= 128, M % 8 == 0, N % 128 == 0, K % 64 == 0;
- * workspace: at least 4*M*N bytes (more lets it split K over workgroups, up to 8 slices). */
+ * workspace: at least 4*M*N bytes (more lets it split K over workgroups: deterministic f32 partial slabs, summed in slice order).
+ * accumulate: bit 0 = add to dW; for measurements and tests bits 8-9 pick the kernel (0x100: 128 x 128 tiles, csrc/gemm_tn.hip;
+ * 0x200: 256 x 256 ping-pong tiles, csrc/gemm_tn_pp.hip, needs K % 128 == 0) and bits 16-23 the number of K slices (0: the
+ * library's choice). */
 int uic_linear_wgrad(int32_t dtype, int32_t M, int32_t N, int32_t K, const void* dY, int32_t ldy, const void* X, int32_t ldx,
                      float* dW, int32_t ldw, void* workspace, size_t workspace_bytes, int32_t accumulate, void* stream);
 

@@ -76,3 +76,60 @@ def test_single_rank_exchange_is_identity():
     x = torch.arange(4.0)
     assert ex.allreduce_sum(x) is x and torch.equal(ex.allreduce_sum_scalar(x), x)
     assert ex.shard_images(128) == (0, 128)
+
+
+def _sc_worker(rank, world, port, out_dir):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.set_num_threads(2)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from oracle import topdown as O
+    from unpaired_image_captioning_amd.parallel_exchange import GradientExchange
+    from unpaired_image_captioning_amd.trainer import Trainer
+    ex = GradientExchange()
+    logp, seq, reward = _sc_case()
+    n = seq.shape[0] // world
+    rows = slice(rank * n, (rank + 1) * n)
+    lp = logp[rows].clone().requires_grad_(True)
+    # the rank's RewardCriterion mean, rescaled to its share of the whole batch's mask sum (Trainer.train_self_critical)
+    loss = O.reward_criterion(lp, seq[rows], reward[rows]) * ex.global_share(Trainer._reward_mask_sum(seq[rows]))
+    loss.backward()
+    total = ex.allreduce_sum_scalar(loss.detach().reshape(1))
+    gathered = [torch.zeros_like(lp.grad) for _ in range(world)]
+    dist.all_gather(gathered, lp.grad)
+    if rank == 0:
+        torch.save({"loss": total, "grad": torch.cat(gathered)}, os.path.join(out_dir, "sc.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def _sc_case():
+    g = torch.Generator().manual_seed(21)
+    N, L = 12, 7
+    logp = -torch.rand(N, L, generator=g) * 3
+    seq = torch.randint(1, 50, (N, L), generator=g)
+    for n in range(N):
+        seq[n, (1 + n % 2 if n < N // 2 else 4 + n % 3):] = 0      # unequal lengths: the first half's captions are much shorter
+    reward = torch.randn(N, 1, generator=g).repeat(1, L)
+    return logp, seq, reward
+
+
+def test_two_rank_self_critical_loss_uses_the_whole_batch_mask_sum(tmp_path):
+    """RewardCriterion across ranks (P/misc/criterion.py:117-122 on the gathered batch, P/trainer.py:168-170): per-rank means
+    rescaled by mask_sum_rank / mask_sum_all and then SUMMED equal the single-process loss and gradient -- and the plain average
+    of the per-rank means (what round 4 did) does not."""
+    from oracle import topdown as O
+    world = 2
+    mp.spawn(_sc_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    res = torch.load(os.path.join(str(tmp_path), "sc.pt"))
+    logp, seq, reward = _sc_case()
+    lp = logp.clone().requires_grad_(True)
+    ref = O.reward_criterion(lp, seq, reward)
+    ref.backward()
+    assert abs(float(res["loss"]) - float(ref)) < 1e-6
+    assert (res["grad"] - lp.grad).abs().max().item() < 1e-7
+    n = seq.shape[0] // 2
+    naive = 0.5 * (O.reward_criterion(logp[:n], seq[:n], reward[:n]) + O.reward_criterion(logp[n:], seq[n:], reward[n:]))
+    assert abs(float(naive) - float(ref)) > 1e-3      # the shards really weigh differently

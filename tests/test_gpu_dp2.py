@@ -152,3 +152,155 @@ def test_uic_comm_single_rank_rccl():
         assert torch.equal(a, a0) and torch.equal(b, b0)
         assert ex.world_size == 1 and ex.rank == 0 and ex.allreduce_sum(a) is a
     assert ex._comm is None                                     # closed by the context manager
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# The self-critical step and the pivot NMT step across two ranks.  Same harness: two processes on
+# cuda:0, gloo carrying the device tensors.
+
+SC_STEPS = 3
+
+
+def _sc_tokens(cfg, n_rows, seed=11):
+    """A fixed `sampled` caption matrix [n_rows, L] with UNEQUAL lengths (rows end at a 0 after 1 .. L tokens): the two ranks' mask
+    sums differ, so averaging their per-rank means would weight their rows differently from the whole batch's mean."""
+    g = torch.Generator().manual_seed(seed)
+    L = cfg["L"]
+    tok = torch.randint(1, cfg["V"] + 1, (n_rows, L), generator=g)
+    lens = torch.where(torch.arange(n_rows) < n_rows // 2, 1 + torch.arange(n_rows) % 2, L - torch.arange(n_rows) % 2)   # short first half
+    for n in range(n_rows):
+        tok[n, int(lens[n]):] = 0
+    return tok
+
+
+def _sc_reward(data, sampled, greedy):
+    """A deterministic stand-in for CIDEr-D(sampled) - CIDEr-D(greedy): any function of the two token matrices, per row."""
+    import numpy as np
+    r = (sampled.sum(1) % 7).astype(np.float32) / 7.0 - (greedy.sum(1) % 5).astype(np.float32) / 5.0 + 0.3
+    return np.repeat(r[:, None], sampled.shape[1], 1)
+
+
+def _train_sc(cfg, W, data, forced, steps, exchange=None):
+    from unpaired_image_captioning_amd.trainer import Trainer
+    tr = Trainer(_opt(cfg), exchange=exchange)
+    tr.i2t_model.load_state_dict(W)
+    tr.build_optimizer()
+    tr.forced_samples = forced.cuda()
+    losses = [tr.train_self_critical(data, reward_fn=_sc_reward) for _ in range(steps)]
+    torch.cuda.synchronize()
+    return tr, losses
+
+
+def _sc_worker(rank, world, port, out_dir):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from unpaired_image_captioning_amd.parallel_exchange import GradientExchange
+    cfg, W, I, Out, G, X = load_golden("topdown_tiny_ragged")
+    lo, hi = GradientExchange().shard_images(cfg["n_img"])
+    rows = slice(lo * cfg["S"], hi * cfg["S"])
+    data = {k: I[k][rows].numpy() for k in ("fc_feats", "att_feats", "labels", "masks", "att_masks")}
+    forced = _sc_tokens(cfg, cfg["n_img"] * cfg["S"])[rows]
+    tr, losses = _train_sc(cfg, W, data, forced, SC_STEPS)
+    assert tr.exchange.world_size == world
+    if rank == 0:
+        torch.save({"sd": {k: v.cpu() for k, v in tr.i2t_model.state_dict().items()}, "losses": losses}, os.path.join(out_dir, "sc2.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_ranks_self_critical_step_matches_single_process(tmp_path):
+    """Trainer.train_self_critical on two ranks whose captions differ in length: RewardCriterion's denominator is the mask sum of
+    the WHOLE batch (P/misc/criterion.py:117-122 on the gathered outputs, P/trainer.py:168-170), so the summed gradients -- and
+    the reported loss -- must be those of one process on the whole batch.  (The sampled captions are pinned through
+    Trainer.forced_samples and the reward is a fixed function of the tokens: nothing random is left.)"""
+    world = 2
+    mp.spawn(_sc_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    res = torch.load(os.path.join(str(tmp_path), "sc2.pt"))
+    cfg, W, I, Out, G, X = load_golden("topdown_tiny_ragged")
+    data = {k: I[k].numpy() for k in ("fc_feats", "att_feats", "labels", "masks", "att_masks")}
+    forced = _sc_tokens(cfg, cfg["n_img"] * cfg["S"])
+    half = forced.shape[0] // 2
+    m = lambda t: int((t[:, :-1] > 0).sum()) + t.shape[0]
+    assert m(forced[:half]) != m(forced[half:])          # the case the per-rank-mean average gets wrong
+    tr, losses = _train_sc(cfg, W, data, forced, SC_STEPS)
+    for a, b in zip(res["losses"], losses):
+        assert abs(a - b) < 1e-4 * max(1.0, abs(b)), (res["losses"], losses)
+    sd = tr.i2t_model.state_dict()
+    for k, v in res["sd"].items():
+        ref = sd[k].cpu()
+        moved = (ref - W[k]).abs().max().item()
+        floor = 3 * 5e-3 * 1e-2 if k == "core.attention.alpha_net.bias" else 1e-7
+        assert (v - ref).abs().max().item() <= 2e-2 * moved + floor, (k, (v - ref).abs().max().item(), moved)
+
+
+NMT_CFG = dict(layers=2, H=64, W=64, B=8, S=10, T=9, Vs=120, Vt=130)
+
+
+def _nmt_trainer(tmp, exchange=None):
+    from test_gpu_nmt import make_opt
+    from unpaired_image_captioning_amd.trainer import Trainer
+    o = make_opt(NMT_CFG, "f32", dropout=0.0, seed=3)
+    o.nmt_train_flag, o.i2t_train_flag, o.checkpoint_path = 1, 0, str(tmp)
+    o.nmt_learning_rate, o.nmt_max_grad_norm, o.param_init = 5e-3, 0.5, 0.1      # (a clip that really bites: the norm is ~2)
+    o.caption_model = None
+    tr = Trainer(o, exchange=exchange)
+    torch.manual_seed(17)                                 # (param_init draws from torch's global generator: same weights everywhere)
+    tr.build_nmt(NMT_CFG["Vs"], NMT_CFG["Vt"])
+    return tr
+
+
+def _nmt_worker(rank, world, port, out_dir):
+    import argparse as ap
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from test_gpu_nmt import synthetic
+    from unpaired_image_captioning_amd import _lib
+    I = synthetic(NMT_CFG, 9)
+    cols = slice(rank, None, world)                       # DataParallel(dim=1) scatters columns; every shard stays length-sorted
+    batch = ap.Namespace(src=I["src"][:, cols].contiguous().cuda(), tgt=I["tgt"][:, cols].contiguous().cuda(), lengths=I["lengths"][:, cols].contiguous())
+    tr = _nmt_trainer(out_dir)
+    tr.nmt_model.engine.recurrence = _lib.REC_FWD_CHAIN   # (two ranks on one GPU: per-step launches)
+    assert tr.exchange.world_size == world and len(tr.optim.nmt_splits) == 2
+    names = list(tr.optim.nmt_arena.offsets)
+    assert names[0].startswith("generator.") and names[-1].startswith("encoder.")
+    losses = [tr.train_nmt(batch) for _ in range(3)]
+    torch.cuda.synchronize()
+    if rank == 0:
+        torch.save({"sd": {k: v.cpu() for k, v in tr.nmt_model.state_dict().items()}, "losses": losses}, os.path.join(out_dir, "nmt2.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_ranks_nmt_step_matches_single_process(tmp_path):
+    """Trainer.train_nmt on two ranks (column shards of the batch, as DataParallel(nmt_model, dim=1) scatters them,
+    P/trainer.py:88): the pieces of the gradient arena travel as they become final (generator, decoder side on the
+    communication stream behind uic_nmt_grad_ready_wait, the encoder's share last), the clip takes the norm of the SUMMED
+    gradient, and loss and weights after three steps are those of one process on the whole batch."""
+    import argparse as ap
+    world = 2
+    mp.spawn(_nmt_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    res = torch.load(os.path.join(str(tmp_path), "nmt2.pt"))
+    from test_gpu_nmt import synthetic
+    I = synthetic(NMT_CFG, 9)
+    batch = ap.Namespace(src=I["src"].cuda(), tgt=I["tgt"].cuda(), lengths=I["lengths"])
+    tr = _nmt_trainer(tmp_path)
+    W0 = {k: v.detach().cpu().clone() for k, v in tr.nmt_model.state_dict().items()}
+    losses = [tr.train_nmt(batch) for _ in range(3)]
+    for a, b in zip(res["losses"], losses):
+        assert abs(a - b) < 2e-4 * abs(b), (res["losses"], losses)
+    sd = tr.nmt_model.state_dict()
+    for k, v in res["sd"].items():
+        ref = sd[k].cpu()
+        moved = (ref - W0[k]).abs().max().item()
+        assert moved > 0, k
+        assert (v - ref).abs().max().item() <= 2e-2 * moved + 1e-7, (k, (v - ref).abs().max().item(), moved)

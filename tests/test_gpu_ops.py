@@ -462,13 +462,23 @@ def test_library_exports_every_declared_symbol():
     assert lib.uic_version() >= 100
 
 
+TN_128, TN_256 = 0x100, 0x200          # uic_linear_wgrad's kernel bits (include/uic_hip.h)
+
+
+def TN_SK(n):
+    return (n & 0xff) << 16
+
+
 @pytest.mark.parametrize("M,N,K,ldy,ldx", [(128, 128, 64, 128, 128), (256, 384, 640, 256, 384), (2048, 512, 2560, 2048, 512),
-                                            (1192, 256, 1280, 1216, 320), (512, 2048, 4608, 512, 2048)])
+                                            (1192, 256, 1280, 1216, 320), (512, 2048, 4608, 512, 2048), (2048, 1664, 2560, 2048, 1664),
+                                            (520, 640, 3840, 520, 768)])
 @pytest.mark.parametrize("accumulate", [0, 1])
 def test_linear_wgrad_tn_matches_matmul(M, N, K, ldy, ldx, accumulate):
     """dW = dY^T X straight from row-major [K, M] / [K, N] bf16 operands (transposing LDS reads, no transposed copies):
-    exact products, f32 accumulation -> compare with a float64 matmul of the same bf16 values; ragged M (1192), leading
-    dimensions larger than the width, one K round (64) up to 72, split-K chosen from the workspace size."""
+    exact products, f32 accumulation -> compare with a float64 matmul of the same bf16 values; ragged M (1192, 520), leading
+    dimensions larger than the width, one K round (64) up to 72, split-K chosen from the workspace size.  Both kernels: the
+    128 x 128 tile (csrc/gemm_tn.hip) and the 256 x 256 ping-pong tile (csrc/gemm_tn_pp.hip: whole tiles, half-empty column tiles
+    (N = 384, 640, 1664), a ragged last row tile, direct stores and every split-K that leaves whole pairs of K tiles)."""
     from unpaired_image_captioning_amd import _lib as L
     lib = L.load()
     g = torch.Generator().manual_seed(M + N + K)
@@ -476,19 +486,37 @@ def test_linear_wgrad_tn_matches_matmul(M, N, K, ldy, ldx, accumulate):
     X = torch.randn(K, ldx, generator=g).bfloat16()
     ref = dY[:, :M].double().t() @ X[:, :N].double()
     dW0 = torch.randn(M, N, generator=g)
-    dW = dW0.clone().cuda()
     ws = torch.empty(8 * M * N * 4, dtype=torch.uint8, device="cuda")
     dYd, Xd = dY.cuda(), X.cuda()
-    L.check(lib.uic_linear_wgrad(L.BF16, M, N, K, L.ptr(dYd), ldy, L.ptr(Xd), ldx, L.ptr(dW), N, L.ptr(ws), ws.numel(), accumulate,
-                                 L.stream()), "linear_wgrad")
     want = ref + (dW0.double() if accumulate else 0)
-    err = (dW.cpu().double() - want).abs().max().item()
-    assert err <= 2e-5 * max(1.0, want.abs().max().item()) * (K ** 0.5), err
+    tol = 2e-5 * max(1.0, want.abs().max().item()) * (K ** 0.5)
+    hows = [0, TN_128]
+    if K % 128 == 0:
+        hows += [TN_256 | TN_SK(sk) for sk in (1, 2, 3, 5, 6) if K % (128 * sk) == 0]
+    outs = {}
+    for how in hows:
+        dW = dW0.clone().cuda()
+        L.check(lib.uic_linear_wgrad(L.BF16, M, N, K, L.ptr(dYd), ldy, L.ptr(Xd), ldx, L.ptr(dW), N, L.ptr(ws), ws.numel(), accumulate | how,
+                                     L.stream()), "linear_wgrad")
+        err = (dW.cpu().double() - want).abs().max().item()
+        assert err <= tol, (hex(how), err)
+        outs[how] = dW
+        # deterministic: the same call again gives the same bits (fixed slice order, no atomics)
+        dW2 = dW0.clone().cuda()
+        L.check(lib.uic_linear_wgrad(L.BF16, M, N, K, L.ptr(dYd), ldy, L.ptr(Xd), ldx, L.ptr(dW2), N, L.ptr(ws), ws.numel(), accumulate | how,
+                                     L.stream()), "linear_wgrad")
+        assert torch.equal(dW, dW2), hex(how)
+    dW = outs[0]
     # a workspace with room for a single slice only (no split-K) gives the same result up to summation order
     dW2 = dW0.clone().cuda()
     ws1 = torch.empty(M * N * 4, dtype=torch.uint8, device="cuda")
     L.check(lib.uic_linear_wgrad(L.BF16, M, N, K, L.ptr(dYd), ldy, L.ptr(Xd), ldx, L.ptr(dW2), N, L.ptr(ws1), ws1.numel(), accumulate,
                                  L.stream()), "linear_wgrad")
     assert (dW2 - dW).abs().max().item() <= 1e-4 * max(1.0, want.abs().max().item())
+    # a forced kernel that cannot take the problem is an argument error (odd number of K tiles / slices that split a tile pair)
+    if K % 128 != 0:
+        assert lib.uic_linear_wgrad(L.BF16, M, N, K, L.ptr(dYd), ldy, L.ptr(Xd), ldx, L.ptr(dW), N, L.ptr(ws), ws.numel(), TN_256, L.stream()) != 0
+    else:
+        assert lib.uic_linear_wgrad(L.BF16, M, N, K, L.ptr(dYd), ldy, L.ptr(Xd), ldx, L.ptr(dW), N, L.ptr(ws), ws.numel(), TN_256 | TN_SK(7), L.stream()) != 0
     # ineligible shapes are argument errors, not silent fallbacks
     assert lib.uic_linear_wgrad(L.BF16, M, N, K - 8, L.ptr(dYd), ldy, L.ptr(Xd), ldx, L.ptr(dW), N, L.ptr(ws), ws.numel(), 0, L.stream()) != 0

@@ -100,6 +100,28 @@ def test_forward_loss_backward_vs_reference_golden(name, dtype):
     grads_close({k: p.grad for k, p in model.named_parameters()}, G, GRAD_TOL[dtype])
 
 
+def test_second_backward_over_one_forward_raises_clearly():
+    """The reference's step is loss.backward(retain_graph=True) (P/trainer.py:173) -- one walk of the graph.  A SECOND walk over
+    the same forward cannot be served (the first one returned the forward's workspace to the pool): it must say so, not die on
+    a None workspace."""
+    from unpaired_image_captioning_amd.misc.criterion import LanguageModelCriterion
+    cfg, W, I, Out, G, X = load_golden("topdown_tiny")
+    model = build_model(cfg, W, "f32").train()
+    fc, att, labels, masks = (I[k].cuda() for k in ("fc_feats", "att_feats", "labels", "masks"))
+    am = I["att_masks"].cuda() if "att_masks" in I else None
+    logp = model(fc, torch.zeros(fc.shape[0], 1, device="cuda"), att, labels, am)
+    loss = LanguageModelCriterion(make_opt(cfg, "f32"))(logp, labels[:, 1:], masks[:, 1:])
+    loss.backward(retain_graph=True)                      # the reference's call: fine
+    grads_close({k: p.grad for k, p in model.named_parameters()}, G, GRAD_TOL["f32"])
+    with pytest.raises(RuntimeError, match="second time"):
+        loss.backward()
+    # and the model is still usable afterwards
+    model.zero_grad()
+    logp = model(fc, torch.zeros(fc.shape[0], 1, device="cuda"), att, labels, am)
+    LanguageModelCriterion(make_opt(cfg, "f32"))(logp, labels[:, 1:], masks[:, 1:]).backward()
+    grads_close({k: p.grad for k, p in model.named_parameters()}, G, GRAD_TOL["f32"])
+
+
 @pytest.mark.parametrize("dtype", ["f32", "bf16"])
 @pytest.mark.parametrize("name", FIXTURES)
 def test_intermediates_vs_reference_golden(name, dtype):

@@ -232,6 +232,7 @@ _SIGS = {
     "uic_topdown_sample_beam": (C.c_int, [C.POINTER(Dims), C.POINTER(Weights), C.c_void_p, C.POINTER(Batch), C.c_int32, C.c_int32,
                                           C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "uic_topdown_grad_ready_wait": (C.c_int, [C.c_void_p, C.c_int32]),
+    "uic_nmt_grad_ready_wait": (C.c_int, [C.c_void_p, C.c_int32]),
     "uic_topdown_beam_done_lists": (C.c_int, [C.POINTER(Dims), C.c_void_p, C.c_int32, C.c_int32] + [C.c_void_p] * 5),
     "uic_topdown_prepare_feature": (C.c_int, [C.POINTER(Dims), C.POINTER(Weights), C.c_void_p, C.POINTER(Batch), C.c_int32, C.c_uint32,
                                               C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),

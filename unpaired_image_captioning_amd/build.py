@@ -10,7 +10,7 @@ import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
-SOURCES = ["api.hip", "gemm.hip", "gemm_pp.hip", "gemm_tn.hip", "attention.hip", "rnn_persist.hip", "rnn_bwd_persist.hip", "bptt_fused.hip", "pointwise.hip", "batchnorm.hip", "beam.hip", "topdown.hip", "fcmodel.hip", "nmt.hip", "nmt_persist.hip", "cider.hip", "loader.hip", "loader_io.hip", "comm.hip", "discriminator.hip", "gcn.hip"]
+SOURCES = ["api.hip", "gemm.hip", "gemm_pp.hip", "gemm_tn.hip", "gemm_tn_pp.hip", "attention.hip", "rnn_persist.hip", "rnn_bwd_persist.hip", "bptt_fused.hip", "pointwise.hip", "batchnorm.hip", "beam.hip", "topdown.hip", "fcmodel.hip", "nmt.hip", "nmt_persist.hip", "cider.hip", "loader.hip", "loader_io.hip", "comm.hip", "discriminator.hip", "gcn.hip"]
 LIB = os.path.join(HERE, "libuic_hip.so")
 
 

@@ -130,7 +130,8 @@ int uic_linear_wgrad(int32_t dtype, int32_t M, int32_t N, int32_t K, const void*
   const WDest d1{dW, ldw, 0, N};
   const UicGemmTnSeg seg{X, ldx, N};
   bool done = false;
-  UIC_TRY(wgrad_tn((float*)workspace, workspace_bytes, dtype, dY, ldy, M, &seg, 1, K, &d1, 1, (hipStream_t)stream, accumulate != 0, &done));
+  UIC_TRY(wgrad_tn((float*)workspace, workspace_bytes, dtype, dY, ldy, M, &seg, 1, K, &d1, 1, (hipStream_t)stream, (accumulate & 1) != 0, &done,
+                   accumulate & (UIC_TN_FORCE_128 | UIC_TN_FORCE_256 | UIC_TN_SPLITK(0xff))));
   UIC_REQUIRE(done, "linear_wgrad: shape M=%d N=%d K=%d not eligible (needs M >= 128, M %% 8 == 0, N %% 128 == 0, K %% 64 == 0, "
                     "16-byte aligned rows) or workspace of %zu bytes too small", M, N, K, workspace_bytes);
   return UIC_OK;

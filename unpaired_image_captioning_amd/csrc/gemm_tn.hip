@@ -21,6 +21,7 @@
 #include <stdlib.h>
 
 thread_local int g_uic_tn_ring_off = 0;
+thread_local int g_uic_knobs = 0;
 
 namespace {
 

@@ -658,6 +658,10 @@ struct NmtSide {
   hipStream_t stream = nullptr;
   hipEvent_t ev_go = nullptr, ev_done = nullptr;
   hipEvent_t ev_r0 = nullptr, ev_gen = nullptr;   // refresh: the caller's stream has reached it; the generator's copies are made
+  // uic_nmt_grad_ready_wait: the generator's gradients (side stream) / the decoder-side gradients (caller's stream) of the last
+  // uic_nmt_backward are final
+  hipEvent_t ev_grad_gen = nullptr, ev_grad_dec = nullptr;
+  bool grads_recorded = false;
   bool ready = false;
 };
 NmtSide g_nmt_side[16];
@@ -674,6 +678,8 @@ int nmt_side(NmtSide** out) {
     UIC_TRY(uic_check_hip(hipEventCreateWithFlags(&ss.ev_done, hipEventDisableTiming), "hipEventCreate"));
     UIC_TRY(uic_check_hip(hipEventCreateWithFlags(&ss.ev_r0, hipEventDisableTiming), "hipEventCreate"));
     UIC_TRY(uic_check_hip(hipEventCreateWithFlags(&ss.ev_gen, hipEventDisableTiming), "hipEventCreate"));
+    UIC_TRY(uic_check_hip(hipEventCreateWithFlags(&ss.ev_grad_gen, hipEventDisableTiming), "hipEventCreate"));
+    UIC_TRY(uic_check_hip(hipEventCreateWithFlags(&ss.ev_grad_dec, hipEventDisableTiming), "hipEventCreate"));
     ss.ready = true;
   }
   *out = &ss;
@@ -1032,6 +1038,7 @@ struct Nmt {
     }
     UIC_TRY(uic_colsum_launch(dt, L.dlogits, Md, Vt, Vtp, G->gen_b, L.colscratch, L.colscratch_floats, ssg->stream));
     UIC_TRY(uic_check_hip(hipEventRecord(ssg->ev_done, ssg->stream), "hipEventRecord"));
+    UIC_TRY(uic_check_hip(hipEventRecord(ssg->ev_grad_gen, ssg->stream), "hipEventRecord"));   // gradient group 0: generator.*
     // ---- decoder BPTT
     const bool bptt_persist = !(d.recurrence & UIC_REC_FWD_CHAIN) && uic_nmt_dec_bwd_persist_eligible(dt, B, S, H, NL);
     if (bptt_persist) {
@@ -1158,6 +1165,9 @@ struct Nmt {
       const WDest d2{G->attn_out_w, 2 * H, 0, 2 * H};
       UIC_TRY(wgrad_group(L.slab, L.slab_bytes, dt, L.d_pre_all, H, H, segs, 2, Md, &d2, 1, s, false, L.tA, L.tB));
     }
+    // gradient group 1 (uic_nmt_grad_ready_wait): decoder LSTMs, decoder embeddings, linear_in, linear_out are final
+    UIC_TRY(uic_check_hip(hipEventRecord(ssg->ev_grad_dec, s), "hipEventRecord"));
+    ssg->grads_recorded = true;
     // ---- encoder: d context = deferred attention gradient; d h0/c0 of the decoder enter at each row's final steps
     const bool enc_persist = !(d.recurrence & UIC_REC_FWD_CHAIN) && uic_nmt_enc_persist_eligible(dt, B, S, H);
     for (int l = NL - 1; l >= 0; --l) {
@@ -1295,6 +1305,14 @@ int uic_nmt_backward(const uic_nmt_dims* d, const uic_nmt_weights* w, const int6
   static thread_local Nmt st;
   UIC_TRY(st.init(d, w, src, lengths_host, tgt, training, seed, workspace, grads));
   return st.backward((hipStream_t)stream);
+}
+
+int uic_nmt_grad_ready_wait(void* stream, int32_t group) {
+  NmtSide* ss = nullptr;
+  UIC_TRY(nmt_side(&ss));
+  UIC_REQUIRE(group == 0 || group == 1, "nmt_grad_ready_wait: group=%d must be 0 (generator) or 1 (decoder side)", group);
+  UIC_REQUIRE(ss->grads_recorded, "nmt_grad_ready_wait: no uic_nmt_backward has run on this device yet");
+  return uic_check_hip(hipStreamWaitEvent((hipStream_t)stream, group == 0 ? ss->ev_grad_gen : ss->ev_grad_dec, 0), "hipStreamWaitEvent");
 }
 
 

@@ -197,24 +197,6 @@ __global__ void embed_fwd_kernel(const float* __restrict__ table, int V1, int E,
     for (int j = 0; j < 4; ++j) o[j] = uic_from_f<T>(f[j]);
   }
 }
-// d table[tok] += dxt * (xt > 0 ? 1/(1-p) : 0): xt > 0 iff the ReLU was open and the unit was kept
-template <typename T>
-__global__ void embed_bwd_kernel(const float* __restrict__ dxt, const T* __restrict__ xt, const int64_t* __restrict__ tokens,
-                                 int ldtok, int N, int TS, int V1, int E, float inv_keep, long skip_token, float* __restrict__ dtable) {
-  const size_t total = (size_t)TS * N * E;
-  const size_t stride = (size_t)gridDim.x * blockDim.x;
-  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
-    const size_t row = i / E;
-    const int e = (int)(i - row * E);
-    if (!xt || uic_to_f(xt[i]) > 0.f) {
-      const int t = (int)(row / N), n = (int)(row - (size_t)t * N);
-      long tok = tokens[(size_t)n * ldtok + t];
-      if (tok < 0 || tok >= V1) tok = 0;
-      if (tok != skip_token) atomicAdd(dtable + (size_t)tok * E + e, dxt[i] * inv_keep);
-    }
-  }
-}
-
 template <typename T>
 __global__ void relu_mask_bwd_kernel(const float* __restrict__ g, const T* __restrict__ act, float scale,
                                      T* __restrict__ dst, size_t n) {
@@ -1600,17 +1582,6 @@ int uic_embed_fwd_launch(int dtype, const float* table, int V1, int E, const int
              hipLaunchKernelGGL(embed_fwd_kernel<bf16_t>, dim3(g), dim3(NT), 0, s, table, V1, E, tokens, ldtok, N, T, drop_p, seed, site, idx_base, relu, (bf16_t*)out),
              hipLaunchKernelGGL(embed_fwd_kernel<float>, dim3(g), dim3(NT), 0, s, table, V1, E, tokens, ldtok, N, T, drop_p, seed, site, idx_base, relu, (float*)out));
   UIC_LAUNCH_CHECK("embed_fwd");
-  return UIC_OK;
-}
-int uic_embed_bwd_launch(int dtype, const float* dxt, const void* xt, const int64_t* tokens, int ldtok, int N, int T,
-                         int V1, int E, float drop_p, long skip_token, float* dtable, hipStream_t s) {
-  if (N == 0 || T == 0) return UIC_OK;
-  const float inv_keep = drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f;
-  const int g = grid_for((size_t)T * N * E, NT);
-  DISPATCH_T(dtype,
-             hipLaunchKernelGGL(embed_bwd_kernel<bf16_t>, dim3(g), dim3(NT), 0, s, dxt, (const bf16_t*)xt, tokens, ldtok, N, T, V1, E, inv_keep, skip_token, dtable),
-             hipLaunchKernelGGL(embed_bwd_kernel<float>, dim3(g), dim3(NT), 0, s, dxt, (const float*)xt, tokens, ldtok, N, T, V1, E, inv_keep, skip_token, dtable));
-  UIC_LAUNCH_CHECK("embed_bwd");
   return UIC_OK;
 }
 // scratch layout (ints): cnt [nkeys + 1] | off [nkeys + 1] | (unused) [nkeys + 1] | perm [N T] ... then, at offsets that do not

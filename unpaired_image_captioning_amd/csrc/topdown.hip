@@ -61,6 +61,7 @@ struct Layout {
   void* tLA; void* tLB; float* colscratchL;   // scratch of the logit-layer weight gradients (side stream)
   void* tSA; void* tSB; float* slab2;         // scratch of the per-chunk recurrent weight gradients (side stream)
   void* tTA; void* tTB; float* slab3;         // the same for the third stream (att_lstm / h2att share of a chunk)
+  void* tUA; void* tUB; float* slab4;         // ... and the fourth (default order: the chunks' shares run on streams 3 and 4)
   int* embed_scratch;                         // uic_embed_bwd_sorted_launch
   void* fcwT; void* attwT;                     // fc_embed / att_embed weights transposed ([Dfc, H], [D, H]): only for the optional input-feature gradients
   void* ones_blk; size_t ones_rows;           // [max(WG_CHUNK * N, N * R), 128] operand dtype, all ones: the "input" whose weight gradient is the bias gradient
@@ -175,6 +176,8 @@ Layout make_layout(const uic_topdown_dims& d, void* ws) {
     L.tSB = b.take(rb * Kc * S);
     L.tTA = b.take(la * Kc * S);
     L.tTB = b.take(rb * Kc * S);
+    L.tUA = b.take(la * Kc * S);
+    L.tUB = b.take(rb * Kc * S);
   }
   {  // split-K partial slabs: room for 4 slices of the largest merged weight gradient [4H, 2H + E]
     size_t sl = 4 * (4 * H) * (2 * H + E) * 4;
@@ -184,6 +187,7 @@ Layout make_layout(const uic_topdown_dims& d, void* ws) {
     L.slab = (float*)b.take(sl);
     L.slab2 = (float*)b.take(sl);
     L.slab3 = (float*)b.take(sl);
+    L.slab4 = (float*)b.take(sl);
   }
   L.embed_scratch = (int*)b.take(uic_embed_bwd_sorted_scratch_ints(N, T, V1, E) * 4);
   L.fcwT = b.take(Dfc * H * S);
@@ -443,6 +447,8 @@ struct SideStream {
   hipStream_t stream = nullptr;
   hipStream_t stream3 = nullptr;    // a chunk's att_lstm / h2att weight gradients beside its lang_lstm ones (independent GEMMs)
   hipEvent_t ev_s3 = nullptr;       // stream3 -> side: that share of every chunk so far is done
+  hipStream_t stream4 = nullptr;    // default order: lang_lstm share of a chunk on stream3, att_lstm / h2att share on stream4
+  hipEvent_t ev_s4 = nullptr;       // stream4 -> stream3: its share of every chunk is done
   hipEvent_t ev_prep = nullptr;     // side -> stream3: the embedding gradient's token bucketing is done
   hipEvent_t ev_den = nullptr, ev_done = nullptr;
   hipEvent_t ev_pro3 = nullptr;     // third stream: its branch of the forward prologue (fc_embed, Gfc, initial state) is through
@@ -483,7 +489,9 @@ int get_side(SideStream** out) {
     UIC_TRY(uic_check_hip(hipDeviceGetStreamPriorityRange(&least, &greatest), "hipDeviceGetStreamPriorityRange"));
     UIC_TRY(uic_check_hip(hipStreamCreateWithPriority(&ss.stream, hipStreamNonBlocking, least), "hipStreamCreateWithPriority"));
     UIC_TRY(uic_check_hip(hipStreamCreateWithPriority(&ss.stream3, hipStreamNonBlocking, least), "hipStreamCreateWithPriority"));
+    UIC_TRY(uic_check_hip(hipStreamCreateWithPriority(&ss.stream4, hipStreamNonBlocking, least), "hipStreamCreateWithPriority"));
     UIC_TRY(uic_check_hip(hipEventCreateWithFlags(&ss.ev_s3, hipEventDisableTiming), "hipEventCreate"));
+    UIC_TRY(uic_check_hip(hipEventCreateWithFlags(&ss.ev_s4, hipEventDisableTiming), "hipEventCreate"));
     UIC_TRY(uic_check_hip(hipEventCreateWithFlags(&ss.ev_prep, hipEventDisableTiming), "hipEventCreate"));
     UIC_TRY(uic_check_hip(hipEventCreateWithFlags(&ss.ev_den, hipEventDisableTiming), "hipEventCreate"));
     UIC_TRY(uic_check_hip(hipEventCreateWithFlags(&ss.ev_done, hipEventDisableTiming), "hipEventCreate"));
@@ -1101,10 +1109,15 @@ struct Step {
   // stacked-row GEMMs, accumulated into G unless `first`.  Used by the fused step on the side stream, chunk by chunk
   // behind the BPTT loop, so that only the last chunk's share is left when the loop ends.
   // sb (optional): a second stream for the att_lstm / h2att share, with scratch of its own (the GEMMs are independent)
-  int wgrad_chunk(int t0, int t1, bool first, hipStream_t s, hipStream_t sb = nullptr) {
-    float* const slabB = sb ? L.slab3 : L.slab2;
-    void* const tBA = sb ? L.tTA : L.tSA;
-    void* const tBB = sb ? L.tTB : L.tSB;
+  // own34: both shares away from the side stream -- lang_lstm on `s` with the third stream's scratch, att_lstm / h2att on `sb`
+  // with the fourth's (the default order of the fused step: the side stream keeps the logit layer)
+  int wgrad_chunk(int t0, int t1, bool first, hipStream_t s, hipStream_t sb = nullptr, bool own34 = false) {
+    float* const slabA = own34 ? L.slab3 : L.slab2;
+    void* const tAA = own34 ? L.tTA : L.tSA;
+    void* const tAB = own34 ? L.tTB : L.tSB;
+    float* const slabB = own34 ? L.slab4 : sb ? L.slab3 : L.slab2;
+    void* const tBA = own34 ? L.tUA : sb ? L.tTA : L.tSA;
+    void* const tBB = own34 ? L.tUB : sb ? L.tTB : L.tSB;
     if (!sb) sb = s;
     const int rows = (t1 - t0) * N;
     const size_t r0 = (size_t)t0 * N;
@@ -1117,11 +1130,11 @@ struct Step {
       // weight gradient IS the column sum -- one more column tile per row tile instead of two column-sum passes in the tail
       const UicGemmTnSeg segs[4] = {{ctx, H, H}, {h_att_new, H, H}, {h_lang_prev, H, H}, {L.ones_blk, 128, 128}};
       const WDest dd[3] = {{G->lang_lstm_w_ih, 2 * H, 0, 2 * H}, {G->lang_lstm_w_hh, H, 2 * H, H}, {G->lang_lstm_b_ih, 1, 3 * H, 1}};
-      UIC_TRY(wgrad_group(L.slab2, off(L.dg2_all, r0 * H4, dt), H4, H4, segs, 4, rows, dd, 3, s, !first, L.tSA, L.tSB));
+      UIC_TRY(wgrad_group(slabA, off(L.dg2_all, r0 * H4, dt), H4, H4, segs, 4, rows, dd, 3, s, !first, tAA, tAB));
     } else {  // lang_lstm: dG2^T x [att_res | h_att | h_lang_prev]
       const UicGemmTnSeg segs[3] = {{ctx, H, H}, {h_att_new, H, H}, {h_lang_prev, H, H}};
       const WDest dd[2] = {{G->lang_lstm_w_ih, 2 * H, 0, 2 * H}, {G->lang_lstm_w_hh, H, 2 * H, H}};
-      UIC_TRY(wgrad_group(L.slab2, off(L.dg2_all, r0 * H4, dt), H4, H4, segs, 3, rows, dd, 2, s, !first, L.tSA, L.tSB));
+      UIC_TRY(wgrad_group(slabA, off(L.dg2_all, r0 * H4, dt), H4, H4, segs, 3, rows, dd, 2, s, !first, tAA, tAB));
     }
     if (bias_in_chunks() && A % 128 == 0) {  // h2att: d_att_h^T x [h_att | ones]
       const UicGemmTnSeg segs[2] = {{h_att_new, H, H}, {L.ones_blk, 128, 128}};
@@ -1455,6 +1468,7 @@ int uic_topdown_xe_train_step(const uic_topdown_dims* d, const uic_topdown_weigh
   UIC_TRY(get_side(&ss));
   hipStream_t s2 = ss->stream;
   hipStream_t s3 = ss->stream3;
+  hipStream_t s4 = ss->stream4;
   Step st;
   st.init(d, w, derived, b, t_run, training, seed, workspace, G);
   // The fused step's BPTT is always the launch chain: the persistent BPTT kernel holds every CU, which serialises the side
@@ -1546,6 +1560,7 @@ int uic_topdown_xe_train_step(const uic_topdown_dims* d, const uic_topdown_weigh
   // (weight-gradient GEMMs that run beside the BPTT loop keep the 2-stage kernel: the 4-stage ring's 128 KB of LDS would
   // keep the loop's 74-KB workgroups off its CUs -- measured 3.89 -> 3.99 ms)
   g_uic_tn_ring_off = 1;
+  g_uic_knobs = d->recurrence & UIC_KNOB_MASK;
   UIC_TRY(st.logit_weight_grads(s2, true));
   UIC_TRY(uic_reduce_sum_launch(st.L.row_loss, (size_t)t_run * d->N, 0.f, inv, loss_out, s2));
   if (den_out) UIC_TRY(uic_copy_launch(den_out, st.L.scalars, 4, s2));
@@ -1578,10 +1593,28 @@ int uic_topdown_xe_train_step(const uic_topdown_dims* d, const uic_topdown_weigh
     if (c == nchunk - 1) UIC_MARK(4, s);              // main: BPTT starts
     UIC_TRY(st.bwd_steps(t0, t1, s));
     UIC_HIP(hipEventRecord(ss->ev_main[c], s));       // (the forward's use of ev_main[c] was consumed long ago)
-    UIC_HIP(hipStreamWaitEvent(s2, ss->ev_main[c], 0));
-    if (early) UIC_HIP(hipStreamWaitEvent(s3, ss->ev_main[c], 0));
-    UIC_TRY(st.wgrad_chunk(t0, t1, c == nchunk - 1, s2, early ? s3 : nullptr));
-    if (early && c == 1) UIC_TRY(st.embed_grad(1, s2));   // d xt of steps [CH, t_run) is complete: their share of the embedding table
+    if (early) {
+      UIC_HIP(hipStreamWaitEvent(s2, ss->ev_main[c], 0));
+      UIC_HIP(hipStreamWaitEvent(s3, ss->ev_main[c], 0));
+      UIC_TRY(st.wgrad_chunk(t0, t1, c == nchunk - 1, s2, s3));
+      if (c == 1) UIC_TRY(st.embed_grad(1, s2));      // d xt of steps [CH, t_run) is complete: their share of the embedding table
+    } else {
+      // default order: the chunk's two independent shares on streams 3 and 4 (the 256 x 256 weight-gradient kernel runs a share on
+      // ~60 CUs: side by side, and beside the side stream's logit layer, they leave the BPTT chain most of the chip), the side
+      // stream stays with the logit layer
+      // ... one chunk after the other on stream 3 while the loop runs (two streams of them slow the chain down again: 3.15 vs
+      // 3.08 ms, profiles/r05_v1_ab_knobs.txt); the LAST chunk's shares, which start when the loop is over, side by side
+      const bool two = (g_uic_knobs & UIC_KNOB_TWO_WG_STREAMS) != 0 || (c == 0 && !(g_uic_knobs & UIC_KNOB_LAST_ONE_STREAM));
+      if (two && !(g_uic_knobs & UIC_KNOB_TWO_WG_STREAMS) && nchunk > 1) {
+        // (the att_lstm / h2att share moves to stream 4 for this chunk: it accumulates into what stream 3's chunks wrote)
+        UIC_HIP(hipEventRecord(ss->ev_s3, s3));
+        UIC_HIP(hipStreamWaitEvent(s4, ss->ev_s3, 0));
+      }
+      UIC_HIP(hipStreamWaitEvent(s3, ss->ev_main[c], 0));
+      if (two) UIC_HIP(hipStreamWaitEvent(s4, ss->ev_main[c], 0));
+      if (c == 0 && !(g_uic_knobs & UIC_KNOB_LAST_BESIDE)) g_uic_tn_ring_off = 0;
+      UIC_TRY(st.wgrad_chunk(t0, t1, c == nchunk - 1, s3, two ? s4 : s3, true));
+    }
   }
   if (early) {
     // side: what completes att_lstm.weight_ih and the embedding table comes first, so that the two big tensors of the early
@@ -1590,23 +1623,27 @@ int uic_topdown_xe_train_step(const uic_topdown_dims* d, const uic_topdown_weigh
     UIC_TRY(st.embed_grad(0, s2));
     UIC_HIP(hipEventRecord(ss->ev_s3, s3));
     UIC_HIP(hipStreamWaitEvent(s2, ss->ev_s3, 0));    // the third stream's share of the weight gradients
-  } else if (tail3) {
-    UIC_HIP(hipStreamWaitEvent(s3, ss->ev_main[0], 0));     // the BPTT loop is through: dG1 of every step exists
-    UIC_HIP(hipStreamWaitEvent(s3, ss->ev_prep, 0));
-    UIC_TRY(st.fc_cols_grad(s3, st.L.slab3, st.L.tTA, st.L.tTB));
-    UIC_TRY(st.embed_grad(0, s3));
-    UIC_HIP(hipEventRecord(ss->ev_s3, s3));
+  } else {
+    // the recurrent weight gradients are complete when both shares of the last chunk are (joined on stream 3)
+    UIC_HIP(hipEventRecord(ss->ev_s4, s4));
+    UIC_HIP(hipStreamWaitEvent(s3, ss->ev_s4, 0));
+    if (tail3) {
+      UIC_HIP(hipStreamWaitEvent(s2, ss->ev_main[0], 0));   // the BPTT loop is through: dG1 of every step exists
+      UIC_TRY(st.fc_cols_grad(s2, st.L.slab2, st.L.tSA, st.L.tSB));
+      UIC_TRY(st.embed_grad(0, s2));
+    }
   }
   // side: the rest of the early gradient group (LSTM / h2att biases, embedding, fc_embed); main: the late group
   // (attention accumulation, ctx2att, att_embed).  ev_early: the early group, the logit layer and the loss are final.
   g_uic_tn_ring_off = 0;
   UIC_MARK(5, s);                                     // main: BPTT done
-  UIC_HIP(hipEventRecord(ss->ev_lstm, s2));           // gradient group 1 final (uic_topdown_grad_ready_wait)
-  UIC_MARK(6, s2);                                    // side: recurrent weight gradients done
+  UIC_HIP(hipEventRecord(ss->ev_lstm, early ? s2 : s3));     // gradient group 1 final (uic_topdown_grad_ready_wait)
+  UIC_MARK(6, early ? s2 : s3);                       // side: recurrent weight gradients done
   UIC_TRY(st.bwd_epilogue_late(s, true));             // (enqueued first: it is the longer of the two tails)
   UIC_MARK(7, s);
-  if (tail3) UIC_HIP(hipStreamWaitEvent(s2, ss->ev_s3, 0));      // (d fc' below reads the dGfc that fc_cols_grad left)
+  if (!early && !tail3) UIC_HIP(hipStreamWaitEvent(s2, ss->ev_main[0], 0));
   UIC_TRY(st.bwd_epilogue_early(s2, true, true, early || tail3));
+  if (!early) UIC_HIP(hipStreamWaitEvent(s2, ss->ev_lstm, 0));   // the early group includes the chunks' shares of streams 3 and 4
   UIC_HIP(hipEventRecord(ss->ev_early, s2));
   ss->early_recorded = true;
   UIC_MARK(8, s2);

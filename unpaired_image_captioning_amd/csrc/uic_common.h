@@ -144,6 +144,16 @@ __device__ __forceinline__ float uic_wave_max(float v) {
 // gemm_tn.hip: set (by the calling host thread, around its launches) to keep uic_gemm_tn_launch on the 2-stage kernel even
 // for grids of at most one workgroup per CU -- for launches that must share CUs with another stream's LDS-heavy workgroups
 extern thread_local int g_uic_tn_ring_off;
+// measurement knobs of the fused training step (bits 8-15 of uic_topdown_dims.recurrence; tools/ab_knobs.py): NOT part of the
+// interface, every bit off = the shipped behaviour
+extern thread_local int g_uic_knobs;
+#define UIC_KNOB_TWO_WG_STREAMS 0x100  // every chunk's two weight-gradient shares on TWO extra streams (default: one; two for the last chunk only)
+#define UIC_KNOB_CHUNK_TN128 0x200     // beside the BPTT chain: the LSTM / h2att chunk gradients on the 128 x 128 kernel
+#define UIC_KNOB_LOGIT_TN128 0x400     // beside the BPTT chain: the logit weight gradient on the 128 x 128 kernel
+#define UIC_KNOB_CHUNK_SK2 0x800       // beside the BPTT chain: two K slices for the chunk gradients
+#define UIC_KNOB_LAST_BESIDE 0x1000    // the last chunk's gradients (after the loop) dispatched like the others (default: as if alone on the chip)
+#define UIC_KNOB_LAST_ONE_STREAM 0x2000 // the last chunk's two shares on one stream
+#define UIC_KNOB_MASK 0xff00
 
 // ---------------------------------------------------------------- GEMM (gemm.hip)
 #define UIC_GEMM_RELU 1      // v = max(v, 0)
@@ -235,6 +245,13 @@ struct UicSlabDest { float* C; int ldc, col0, ncols; };
 int uic_splitk_reduce_multi_launch(const float* slab, int splitk, int M, int N, const UicSlabDest* dst, int nd, int accumulate, hipStream_t s);
 bool uic_gemm_tn_eligible(const UicGemmTnParams& p);
 int uic_gemm_tn_launch(const UicGemmTnParams& p, hipStream_t s);
+// the 256 x 256 ping-pong form (gemm_tn_pp.hip): whole pairs of 64-row K tiles per split-K slice
+bool uic_gemm_tnpp_eligible(const UicGemmTnParams& p);
+int uic_gemm_tnpp_launch(const UicGemmTnParams& p, hipStream_t s);
+// kernel choice of a weight-gradient call (wgrad_tn's `how`; uic_linear_wgrad passes bits 8-9 and 16-23 of its last argument):
+#define UIC_TN_FORCE_128 0x100     // the 128 x 128 kernel (gemm_tn.hip)
+#define UIC_TN_FORCE_256 0x200     // the 256 x 256 ping-pong kernel (gemm_tn_pp.hip); an ineligible problem is an error
+#define UIC_TN_SPLITK(n) (((n) & 0xff) << 16)   // K slices (0: the dispatcher's choice)
 
 // ---------------------------------------------------------------- attention (attention.hip)
 struct UicAttnParams {
@@ -472,9 +489,7 @@ int uic_colsum_launch(int src_dtype, const void* src, int rows, int cols, int ld
 int uic_sum_steps_launch(int dtype, const void* src, int T, size_t step_elems, void* dst, hipStream_t s);
 int uic_embed_fwd_launch(int dtype, const float* table, int V1, int E, const int64_t* tokens, int ldtok, int N, int T,
                          float drop_p, unsigned seed, unsigned site, size_t idx_base, int relu, void* out, hipStream_t s);
-int uic_embed_bwd_launch(int dtype, const float* dxt, const void* xt, const int64_t* tokens, int ldtok, int N, int T,
-                         int V1, int E, float drop_p, long skip_token, float* dtable, hipStream_t s);   // skip_token < 0: none (nn.Embedding padding_idx otherwise)
-// the same with the positions bucketed by token first (a stable counting sort), so that runs of equal tokens are summed in
+// the embedding gradient (nn.Embedding backward; skip_token < 0: none, nn.Embedding padding_idx otherwise) with the positions bucketed by token first (a stable counting sort), so that runs of equal tokens are summed in
 // registers and every table row is STORED by one owner in a fixed order -- no floating-point atomics, bit-reproducible:
 // dtable is overwritten; scratch = uic_embed_bwd_sorted_scratch_ints(N, T, V1, E) ints
 size_t uic_embed_bwd_sorted_scratch_ints(int N, int T, int V1, int E);

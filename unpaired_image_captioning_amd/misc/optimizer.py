@@ -145,15 +145,33 @@ class Optim(object):
             self.i2t_arena.bind_grads()
         if nmt_model is not None:
             self._check_method('nmt', self.nmt_method, self.nmt_weight_decay)
-            self.nmt_arena = FlatArena(nmt_model, getattr(nmt_model, 'param_names', None))
+            # arena order = the order in which uic_nmt_backward makes the gradients final (include/uic_hip.h,
+            # uic_nmt_grad_ready_wait): generator first (before the decoder BPTT starts), the decoder side, the encoder last -- a
+            # data-parallel run exchanges each piece while the backward pass computes the following ones
+            names = getattr(nmt_model, 'param_names', None)
+            self.nmt_splits = []
+            if names is not None:
+                gen = [k for k in names if k.startswith("generator.")]
+                dec = [k for k in names if k.startswith("decoder.")]
+                enc = [k for k in names if not k.startswith(("generator.", "decoder."))]
+                names = gen + dec + enc
+            self.nmt_arena = FlatArena(nmt_model, names)
+            if names is not None and gen and dec and enc:
+                self.nmt_splits = [self.nmt_arena.offsets[dec[0]], self.nmt_arena.offsets[enc[0]]]
             self.nmt_arena.bind_grads()
             if hasattr(nmt_model, 'grad_sink'):
                 nmt_model.grad_sink = self.nmt_arena.grad_views      # backward may write the arena in place (see _NmtStep.backward)
                 self._nmt_model = nmt_model
 
-    def _exchange(self, arena):
+    def _exchange(self, arena, splits=None, wait_group=None):
+        """Sum the gradient arena over the ranks.  splits / wait_group: the arena's pieces in the order they become final and the
+        call that lets a stream wait for piece g (GradientExchange.allreduce_sum_overlapped): all but the last piece travel on
+        the communication stream beside the rest of the backward pass."""
         if self.exchange is not None and self.exchange.world_size > 1:
-            self.exchange.allreduce_sum(arena.grad)
+            if splits and wait_group is not None and arena.grad.is_cuda:
+                self.exchange.allreduce_sum_overlapped(arena.grad, splits, wait_group)
+            else:
+                self.exchange.allreduce_sum(arena.grad)
 
     def step(self, i2t_grad_scale=1.0, nmt_grad_scale=1.0):
         self._step += 1
@@ -166,7 +184,13 @@ class Optim(object):
             if self.nmt_decay_method == "noam":
                 self.nmt_current_lr = self.nmt_lr * (self.opt.rnn_size ** (-0.5) *
                                                      min(self._step ** (-0.5), self._step * self.nmt_warmup_steps ** (-1.5)))
-            self._exchange(self.nmt_arena)
+            # the pivot model's 344 MB: generator (102 MB, final before the decoder BPTT starts) and the decoder side on the
+            # communication stream as they become final, the encoder's share on this stream; the clipped Adam below takes the
+            # norm of the summed gradient (one pass over the arena after all three pieces)
+            m = getattr(self, '_nmt_model', None)
+            direct = m is not None and getattr(m, '_sink_written', False)      # the in-place backward ran: its events are recorded
+            self._exchange(self.nmt_arena, getattr(self, 'nmt_splits', None) if direct else None,
+                           lambda raw, g: check(_lib.load().uic_nmt_grad_ready_wait(raw, g), "nmt_grad_ready_wait"))
             self._nmt_steps += 1
             # the pivot step's persistent launches (csrc/nmt_persist.hip) report a time-out in the status words: the update is
             # then skipped on the device -- on every rank (the flag is summed over them) -- and Trainer.train_nmt raises

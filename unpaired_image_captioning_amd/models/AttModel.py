@@ -57,6 +57,12 @@ class _TopDownForward(torch.autograd.Function):
     def backward(ctx, g):
         model = ctx.model
         eng = model.engine
+        if ctx.ws is None:
+            # the reference calls loss.backward(retain_graph=True) (P/trainer.py:173) but never walks the graph twice; here the
+            # first backward hands the forward's workspace (activations of every decode step) back to the engine's pool
+            raise RuntimeError("TopDownModel: backward ran a second time over the same forward pass; its workspace was released "
+                               "after the first one (retain_graph=True keeps the autograd graph, not the HIP workspace) -- run the "
+                               "forward again")
         (logp,) = ctx.saved_tensors
         d, t_run, training, seed, ss_prob = ctx.call
         fc, att, att_masks, seq = ctx.inputs

@@ -61,6 +61,16 @@ class GradientExchange(object):
         self._sum(t)
         return t.reciprocal_()
 
+    def global_share(self, local):
+        """local / sum_over_ranks(local) as a 1-element tensor on local's device (1 on a single rank): the weight of this rank's
+        per-rank MEAN in the whole batch's mean, when `local` is the rank's denominator (RewardCriterion's mask sum)."""
+        local = local.detach().to(torch.float32).reshape(1)
+        if self.world_size == 1:
+            return torch.ones_like(local)
+        total = local.clone()
+        self._sum(total)
+        return local / total
+
     def allreduce_sum(self, flat):
         """Sum the flat gradient arena over ranks, in place (one collective per step)."""
         if self.world_size > 1:

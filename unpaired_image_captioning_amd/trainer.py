@@ -311,6 +311,15 @@ class Trainer(object):
         self.i2t_train_loss = self._finish_step(loss)     # the reference's per-step host sync (trainer.py:172)
         return self.i2t_train_loss
 
+    def _sample_opt(self, S):
+        """Options of the self-critical step's sampling pass (P/trainer.py:167: sample_max = 0).  self.forced_samples (tests):
+        an int64 [rows, L] tensor the pass replays instead of drawing -- its log-probs and gradients are those of these tokens."""
+        o = {'sample_max': 0, 'captions_per_image': S}
+        forced = getattr(self, 'forced_samples', None)
+        if forced is not None:
+            o['forced_tokens'] = forced
+        return o
+
     def _scst_decode(self, model, eng, fc, att, am, S, overlap, cur):
         """The sampling pass (train mode) and the greedy baseline (eval mode, P/misc/rewards.py:42-47) of the self-critical
         step; overlap: the baseline on a second stream beside the sampling pass."""
@@ -333,19 +342,26 @@ class Trainer(object):
             c2 = getattr(model, '_seed_counter', None)
             if c0 is not None:
                 model._seed_counter = c0
-            gen_result, sample_logprobs = model(fc, None, att, am, opt={'sample_max': 0, 'captions_per_image': S}, mode='sample')
+            gen_result, sample_logprobs = model(fc, None, att, am, opt=self._sample_opt(S), mode='sample')
             if c0 is not None:
                 model._seed_counter = c2
             cur.wait_stream(self._baseline_stream)
             greedy_res.record_stream(cur)
         else:
             model.train()
-            gen_result, sample_logprobs = model(fc, None, att, am, opt={'sample_max': 0, 'captions_per_image': S}, mode='sample')
+            gen_result, sample_logprobs = model(fc, None, att, am, opt=self._sample_opt(S), mode='sample')
             model.eval()
             with torch.no_grad():                                       # rewards.py:42-47: greedy baseline, eval mode
                 greedy_res, _ = model(fc, None, att, am, opt={'sample_max': 1}, mode='sample')
             model.train()
         return gen_result, sample_logprobs, greedy_res
+
+    @staticmethod
+    def _reward_mask_sum(seq):
+        """Sum of RewardCriterion's mask (P/misc/criterion.py:118-120): (seq > 0) shifted right by one with a leading 1 -- every
+        row counts its tokens up to and including the first 0.  A device scalar, no host sync."""
+        m = (seq[:, :-1] > 0).sum() + seq.shape[0]
+        return m.to(torch.float32).reshape(1)
 
     def train_self_critical(self, data, reward_fn=None, next_data=None):
         """The self-critical branch of Trainer.train (P/trainer.py:166-171).  reward_fn None: the reference's reward,
@@ -405,6 +421,12 @@ class Trainer(object):
                 adv = self.discriminator_scores(gen_result) - self.discriminator_scores(g_rows)
                 reward_t = reward_t + dw * adv[:, None]
             loss = RewardCriterion()(sample_logprobs, gen_result, reward_t)
+            # Data parallel: the reference gathers every replica's output to GPU0 and divides by the mask sum of the WHOLE batch
+            # (P/misc/criterion.py:117-122 on the gathered tensors, P/trainer.py:168-170); ranks whose captions differ in length must
+            # therefore not average their per-rank means.  Each rank rescales its mean by (its mask sum) / (sum over ranks) -- a
+            # 1-float all-reduce before the backward pass -- and the gradients (and losses) are then SUMMED, as in the XE step.
+            if self.exchange.world_size > 1:
+                loss = loss * self.exchange.global_share(self._reward_mask_sum(gen_result))
             # every p.grad is its view of the flat gradient arena: the backward kernels write there directly (models/AttModel.py
             # _TopDownSample.backward); a model without that path hands tensors back to autograd, copied below
             params = dict(model.named_parameters())
@@ -421,13 +443,12 @@ class Trainer(object):
             if params[k].grad is not view:
                 view.copy_(params[k].grad)
         self.exchange.allreduce_sum(self.arena.grad)
-        scale = 1.0 / self.exchange.world_size                           # per-rank means -> global mean
-        loss_d = self._guarded_adam(loss.detach(), scale)
+        loss_d = self._guarded_adam(loss.detach(), 1.0)                   # (already the whole batch's loss: summed over the ranks)
         avg = reward_t[:, 0].mean()
         if next_data is not None:
             self.prefetch(next_data)              # the next batch crosses PCIe while this step computes (see train)
         val = self._finish_step(loss_d)
-        self.i2t_train_loss = val * scale if self.exchange.world_size > 1 else val      # (the mean over the ranks of their per-rank means)
+        self.i2t_train_loss = val
         self.i2t_avg_reward = float(avg.item())
         return self.i2t_train_loss
 
@@ -518,7 +539,13 @@ class Trainer(object):
         self.nmt_crit.report_stats.n_src_words += int(nmt_batch.lengths.sum())
         self.nmt_train_ppl = self.nmt_crit.report_stats.ppl()
         self.nmt_train_acc = self.nmt_crit.report_stats.accuracy()
-        val = float(nmt_loss.detach())                # (the step's host sync)
+        loss_d = nmt_loss.detach()
+        if self.exchange is not None and self.exchange.world_size > 1:
+            # the criterion is a SUM over target words (size_average=False, P/misc/criterion.py:126-136): the whole batch's loss
+            # is the sum over the ranks' column shards, as DataParallel(dim=1) + gather gives the reference (P/trainer.py:88,178)
+            loss_d = loss_d.float().reshape(1).clone()
+            self.exchange._sum(loss_d)
+        val = float(loss_d)                           # (the step's host sync)
         guard = getattr(self.optim, 'last_guard', None)
         if guard is not None and float(guard[0].item()) != 0:
             # a persistent launch of this step timed out (on some rank): Optim.step skipped the update on the device
