@@ -53,6 +53,10 @@ int uic_version(void);
  *                        10.5 MB in its last 0.1 ms (default order: 16.8 MB at -0.24 ms, 42.5 MB in the last 0.1 ms), for a step
  *                        that is 0.12 ms (4 %) longer on its own -- the chip is busy either way (profiles/LOG.md).  For a
  *                        data-parallel caller to choose; same gradients up to f32 summation order
+ *   UIC_REC_NO_F32A      att_embed (P/models/AttModel.py:76-80,111-115) as a cast pass over the f32 region features + the bf16
+ *                        GEMM instead of the GEMM that rounds its f32 A operand itself (csrc/gemm_pp.hip): bit-identical
+ *                        results, ~45 us more per step.  The fallback for that kernel's hand-counted register loads (its build
+ *                        is audited by tools/audit_f32a_asm.py and soaked in the GPU suite)
  * uic_topdown_dims.rnn_status: NULL, or 4 caller-allocated, caller-zeroed uint32 on the device that the persistent kernels
  * update: [0] != 0 after a bounded spin timed out (the results of that call are invalid), [1] / [2] launches that ran with
  * the XCD-local / the SAFE protocol. */
@@ -61,6 +65,7 @@ int uic_version(void);
 #define UIC_REC_SAFE 4
 #define UIC_REC_STAMPS 8
 #define UIC_REC_EARLY_GRADS 16
+#define UIC_REC_NO_F32A 32
 
 /* ---- shapes of one TopDown step (P/models/AttModel.py:56-92,422-428,530-536) ---- */
 typedef struct uic_topdown_dims {

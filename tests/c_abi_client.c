@@ -104,6 +104,24 @@ int main(void) {
       }
     if (worst > 2e-3) { fprintf(stderr, "uic_linear_f32a off by %g\n", worst); return 1; }
     if (uic_linear_f32a(M, N, 192, dA, K, dB, K, dC, N, NULL, 4, NULL, K, stream) >= 0) { fprintf(stderr, "uic_linear_f32a accepted K = 192\n"); return 1; }
+    /* a row stride of the f32 input that is a multiple of 4 floats but not of 8 (the header's contract: lda % 4 == 0): same bits */
+    {
+      const int lda = K + 4;
+      float* A2 = malloc(sizeof(float) * M * lda);
+      float* C2 = malloc(sizeof(float) * M * N);
+      for (int m = 0; m < M; ++m) {
+        for (int k = 0; k < K; ++k) A2[m * lda + k] = A[m * K + k];
+        for (int k = K; k < lda; ++k) A2[m * lda + k] = 1e30f;
+      }
+      float* dA2 = to_dev(A2, sizeof(float) * M * lda);
+      if (!dA2) return 2;
+      CHECK_UIC(uic_linear_f32a(M, N, K, dA2, lda, dB, K, dC, N, NULL, 4, NULL, K, stream));
+      CHECK_HIP(hipStreamSynchronize(stream));
+      CHECK_HIP(hipMemcpy(C2, dC, sizeof(float) * M * N, hipMemcpyDeviceToHost));
+      if (memcmp(C, C2, sizeof(float) * M * N) != 0) { fprintf(stderr, "uic_linear_f32a: lda = K + 4 changes the result\n"); return 1; }
+      if (uic_linear_f32a(M, N, K, dA2, K + 2, dB, K, dC, N, NULL, 4, NULL, K, stream) >= 0) { fprintf(stderr, "uic_linear_f32a accepted lda %% 4 != 0\n"); return 1; }
+      hipFree(dA2); free(A2); free(C2);
+    }
     hipFree(dA); hipFree(dB); hipFree(dI); hipFree(dC); free(A); free(C); free(Bh); free(img); free(Br); free(Ar);
   }
 

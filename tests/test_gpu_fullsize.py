@@ -168,6 +168,64 @@ def test_training_step_reproduces_beside_busy_neighbours(case):
             assert torch.equal(g, ref[1][k]), (it, k)
 
 
+def test_step_without_the_f32a_gemm_is_bit_identical(case):
+    """UIC_REC_NO_F32A (include/uic_hip.h): att_embed as cast + bf16 GEMM instead of the GEMM that rounds its f32 A operand in
+    flight -- the fallback for that kernel's hand-counted register loads.  Both forms round the same values
+    the same way and accumulate in the same order: every gradient must be the same bits."""
+    from unpaired_image_captioning_amd import _lib as Lb
+    from unpaired_image_captioning_amd.trainer import xe_step
+    W, b, *_ = case
+    batch = {k: v.cuda() for k, v in b.items()}
+    model = build_model(CFG, W, "bf16", drop=0.5)
+    model.train()
+    out = []
+    for rec in (0, Lb.REC_NO_F32A):
+        model.engine.recurrence = rec
+        model._seed_counter = 77
+        loss, grads = xe_step(model, batch)
+        torch.cuda.synchronize()
+        out.append((loss.clone(), {k: g.clone() for k, g in grads.items()}))
+    model.engine.recurrence = 0
+    assert torch.equal(out[0][0], out[1][0])
+    for k in out[0][1]:
+        assert torch.equal(out[0][1][k], out[1][1][k]), k
+
+
+@pytest.mark.parametrize("M,N,K", [(23040, 512, 2048), (4608, 512, 2048), (1000, 1028, 640), (2880, 512, 384)])
+def test_linear_f32a_beside_busy_neighbours_is_bit_exact(M, N, K):
+    """The short form of tools/gemm_f32a_soak.py in the suite: uic_linear_f32a (csrc/gemm_pp.hip: A loaded by inline-asm register
+    loads, committed four phases later behind a hand-counted vmcnt) beside an HBM-bound and an MFMA-bound neighbour, output and
+    bf16 image compared bit for bit with cast + GEMM at every launch.  Its first form failed exactly this way: 32-64 wrong
+    elements in 1 % of the launches, only with a busy neighbour."""
+    from unpaired_image_captioning_amd import _lib as L
+    lib = L.load()
+    torch.manual_seed(1)
+    A = torch.randn(M, K, device="cuda") * 3
+    Ab = A.bfloat16()
+    B = (torch.randn(N, K, device="cuda") / K ** 0.5).bfloat16()
+    bias = torch.randn(N, device="cuda")
+    ref = torch.empty(M, N, device="cuda", dtype=torch.bfloat16)
+    L.check(lib.uic_linear(1, M, N, K, L.ptr(Ab), K, L.ptr(B), K, L.ptr(ref), N, L.ptr(bias), 1 | 0x400, L.stream()))
+    torch.cuda.synchronize()
+    side = torch.cuda.Stream()
+    hog_a = torch.randn(32 << 20, device="cuda")
+    hog_b = torch.empty_like(hog_a)
+    X = torch.randn(4096, 4096, device="cuda").bfloat16()
+    for it in range(60 if M > 10000 else 120):
+        mode = it % 4
+        with torch.cuda.stream(side):
+            if mode in (1, 3):
+                hog_b.copy_(hog_a)
+            if mode in (2, 3):
+                torch.matmul(X, X)
+        C = torch.full((M, N), 7.0, device="cuda", dtype=torch.bfloat16)
+        img = torch.full((M, K), 7.0, device="cuda", dtype=torch.bfloat16)
+        L.check(lib.uic_linear_f32a(M, N, K, L.ptr(A), K, L.ptr(B), K, L.ptr(C), N, L.ptr(bias), 1, L.ptr(img), K, L.stream()))
+        torch.cuda.synchronize()
+        assert torch.equal(C, ref), (it, mode, int((C != ref).sum()))
+        assert torch.equal(img, Ab), (it, mode, int((img != Ab).sum()))
+
+
 NAMES = lambda T, N, td: [("h_att", (T + 1, N, H), td), ("h_lang", (T + 1, N, H), td), ("c_att", (T + 1, N, H), torch.float32),
                           ("c_lang", (T + 1, N, H), torch.float32), ("att_h", (T, N, H), torch.float32), ("alpha", (T, N, R), torch.float32),
                           ("ctx", (T, N, H), td), ("hdrop", (T, N, H), td), ("gates1", (T, N, 4 * H), td), ("gates2", (T, N, 4 * H), td)]

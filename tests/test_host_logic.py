@@ -252,3 +252,16 @@ def test_data_parallel_ranks_start_from_different_dropout_seeds():
         Trainer._mix_rank_into_seed(m, FakeExchange(r))
         seeds.append(m._seed_counter)
     assert seeds[0] == 1234 and len(set(seeds)) == 4 and all(0 <= s_ <= 0x7FFFFFFF for s_ in seeds)
+
+
+def test_f32a_gemm_build_has_no_compiler_touch_of_in_flight_registers():
+    """tools/audit_f32a_asm.py: the f32-A ping-pong GEMM loads its A units with inline-asm
+    global_load_dwordx4 into C++ variables and waits for them by a hand-counted vmcnt four phases later; hipcc counts an asm
+    statement's VGPR destination as written when the statement ends.  The audit compiles csrc/gemm_pp.hip for gfx950 (no GPU
+    needed), walks the control-flow graph of every f32-A instantiation and fails on any spill, or any instruction outside an asm
+    block that reads or writes a destination between its load and the conversion that consumes it."""
+    import subprocess
+    import sys
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "audit_f32a_asm.py")], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "0 problems" in r.stdout and r.stdout.count("asm loads") >= 2, r.stdout

@@ -1,0 +1,91 @@
+#!/usr/bin/env python3
+"""Can the fused training step be captured into a hipGraph and replayed?  (the C ABI is enqueue-only "so hipGraph
+capture works"; VERDICT round 4: untested.)  Captures uic_topdown_refresh_weights + uic_topdown_xe_train_step -- the caller's stream
+plus the library's four side streams, forked and joined by events -- in relaxed mode, replays the graph and compares every
+gradient bit for bit with the eager step.    gpurun -- python tools/graph_capture_probe.py [--full]"""
+import ctypes as C
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch
+
+
+def capture_and_replay(model, batch, replays=3, verbose=True):
+    """Returns (eager grads, [replayed grads, ...], eager ms, replay ms)."""
+    from unpaired_image_captioning_amd import _lib as L
+    hip = C.CDLL("libamdhip64.so")
+    eng = model.engine
+    pd = {k: v.detach() for k, v in model.param_dict().items()}
+    fc, att, am, labels, masks = batch["fc_feats"], batch["att_feats"], batch.get("att_masks"), batch["labels"], batch["masks"]
+    t_run = model._steps_to_run(labels)
+    seed = 4242
+
+    def step(grads):
+        return eng.xe_train_step(pd, fc, att, am, labels, masks, t_run, True, seed, grads, keep_workspace=True)
+
+    ref = {k: torch.zeros_like(v) for k, v in pd.items()}
+    for _ in range(2):                                       # warm-up: one-time attribute calls, the allocator's cache
+        out, ws = step(ref)
+        torch.cuda.synchronize()
+        eng.release(ws)
+    t0 = time.perf_counter()
+    out_ref, ws = step(ref)
+    torch.cuda.synchronize()
+    eager_ms = (time.perf_counter() - t0) * 1e3
+    eng.release(ws)
+    loss_ref = out_ref.clone()
+
+    got = {k: torch.zeros_like(v) for k, v in pd.items()}
+    cs = torch.cuda.Stream()
+    graph, gexec = C.c_void_p(), C.c_void_p()
+    torch.cuda.synchronize()
+    with torch.cuda.stream(cs):
+        rc = hip.hipStreamBeginCapture(C.c_void_p(cs.cuda_stream), 2)              # hipStreamCaptureModeRelaxed
+        assert rc == 0, "hipStreamBeginCapture: %d" % rc
+        try:
+            out, ws = step(got)
+        finally:
+            rc = hip.hipStreamEndCapture(C.c_void_p(cs.cuda_stream), C.byref(graph))
+        assert rc == 0 and graph.value, "hipStreamEndCapture: %d" % rc
+    rc = hip.hipGraphInstantiate(C.byref(gexec), graph, None, None, C.c_size_t(0))
+    assert rc == 0, "hipGraphInstantiate: %d" % rc
+    nnodes = C.c_size_t(0)
+    hip.hipGraphGetNodes(graph, None, C.byref(nnodes))
+    if verbose:
+        print("captured %d graph nodes" % nnodes.value)
+    results = []
+    replay_ms = 0.0
+    for _ in range(replays):
+        for g in got.values():
+            g.fill_(float("nan"))
+        out.fill_(float("nan"))
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        rc = hip.hipGraphLaunch(gexec, C.c_void_p(cs.cuda_stream))
+        assert rc == 0, "hipGraphLaunch: %d" % rc
+        cs.synchronize()
+        replay_ms = (time.perf_counter() - t0) * 1e3
+        results.append(({k: v.clone() for k, v in got.items()}, out.clone()))
+    hip.hipGraphExecDestroy(gexec)
+    hip.hipGraphDestroy(graph)
+    torch.cuda.synchronize()
+    eng.release(ws)
+    return (ref, loss_ref), results, eager_ms, replay_ms, nnodes.value
+
+
+if __name__ == "__main__":
+    from bench import CFG, make_opt
+    from unpaired_image_captioning_amd import models
+    from unpaired_image_captioning_amd.synthetic import synthetic_batch
+    c = CFG
+    model = models.setup(make_opt("bf16", 1234)).cuda()
+    model.train()
+    batch = {k: v.cuda() for k, v in synthetic_batch(c["n_img"], c["S"], c["R"], c["D"], c["V"], c["L"], seed=1).items()}
+    (ref, loss_ref), results, eager_ms, replay_ms, nn = capture_and_replay(model, batch)
+    for i, (g, out) in enumerate(results):
+        bad = [k for k in ref if not torch.equal(ref[k], g[k])]
+        print("replay %d: loss %s (eager %s), tensors that differ from the eager step: %s" % (i, out.tolist(), loss_ref.tolist(), bad or "none"))
+    print("eager step (enqueue + run) %.3f ms, graph replay %.3f ms, %d nodes" % (eager_ms, replay_ms, nn))

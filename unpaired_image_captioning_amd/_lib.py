@@ -25,7 +25,7 @@ class Dims(C.Structure):
 
 
 # uic_topdown_dims.recurrence (include/uic_hip.h)
-REC_FWD_CHAIN, REC_BWD_PERSIST, REC_SAFE, REC_STAMPS, REC_EARLY_GRADS = 1, 2, 4, 8, 16
+REC_FWD_CHAIN, REC_BWD_PERSIST, REC_SAFE, REC_STAMPS, REC_EARLY_GRADS, REC_NO_F32A = 1, 2, 4, 8, 16, 32
 STEP_MARKS = 11          # UIC_STEP_MARKS
 
 
@@ -328,6 +328,11 @@ def load():
 _status = {}
 
 
+class PersistentTimeout(RuntimeError):
+    """A bounded spin of a persistent recurrence kernel gave up (another process on the GPU, a long kernel on another stream):
+    the results of that call are invalid and the optimizer step that followed was skipped on the device."""
+
+
 def status_words(device=None):
     """The 4 status words of the persistent recurrence kernels on `device` (a device tensor, allocated on first use): what
     TopDownEngine.dims() hands the library as uic_topdown_dims.rnn_status."""
@@ -348,7 +353,7 @@ def persistent_status(device=None):
     vals = [int(v) for v in _status[idx].cpu().tolist()]
     if vals[0] != 0:
         _status[idx].zero_()
-        raise RuntimeError("persistent recurrence kernel timed out (code 0x%x): results of the last calls are invalid" % vals[0])
+        raise PersistentTimeout("persistent recurrence kernel timed out (code 0x%x): results of the last calls are invalid" % vals[0])
     return vals[:3]
 
 

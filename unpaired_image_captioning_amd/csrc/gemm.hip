@@ -832,8 +832,10 @@ int uic_gemm_launch(const UicGemmParams& p, hipStream_t s) {
   for (int i = 0; i < p.nseg; ++i) {
     const UicGemmSeg& g = p.seg[i];
     UIC_REQUIRE(g.A && g.B, "gemm: null operand in segment %d", i);
-    UIC_REQUIRE(g.K > 0 && g.K % vec == 0 && g.lda % vec == 0 && g.ldb % vec == 0,
-                "gemm: segment %d K=%d lda=%d ldb=%d must be multiples of %d elements", i, g.K, g.lda, g.ldb, vec);
+    // (an f32 A operand of the bf16 ping-pong kernel -- uic_linear_f32a -- is read in 16-byte pieces of FOUR floats: lda % 4)
+    const int veca = p.a_f32 ? 4 : vec;
+    UIC_REQUIRE(g.K > 0 && g.K % vec == 0 && g.lda % veca == 0 && g.ldb % vec == 0,
+                "gemm: segment %d K=%d lda=%d ldb=%d must be multiples of %d elements (lda: %d)", i, g.K, g.lda, g.ldb, vec, veca);
     UIC_REQUIRE(((uintptr_t)g.A & 15) == 0 && ((uintptr_t)g.B & 15) == 0, "gemm: segment %d operands must be 16-byte aligned", i);
   }
   if (p.lstm) {

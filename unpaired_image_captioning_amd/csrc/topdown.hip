@@ -365,7 +365,7 @@ int prepare_features(const uic_topdown_dims& d, const uic_topdown_weights* w, co
     UicGemmParams g = gemm_base(dt, Na * R, H);
     add_seg(g, att_src, d.D, dv.att_w, d.D, d.D);
     g.C = L.attp; g.ldc = H; g.a_f32 = 1; g.a_copy = L.attT; g.ld_a_copy = d.D;
-    att_f32a = uic_gemm_pp_eligible(g) && (size_t)Na * R >= 2048;
+    att_f32a = uic_gemm_pp_eligible(g) && (size_t)Na * R >= 2048 && !(d.recurrence & UIC_REC_NO_F32A);
   }
   if (do_att && d.use_bn) {
     // BatchNorm1d(D) over the packed live regions; xhat goes to the GEMM, the affine part lives in W' / b'.  Features given

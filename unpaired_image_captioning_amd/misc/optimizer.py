@@ -178,8 +178,17 @@ class Optim(object):
         if self.i2t_train_flag and self.i2t_arena is not None:
             self._exchange(self.i2t_arena)
             self._i2t_steps += 1
+            # (guarded like the pivot model's step below: a captioner trained through Optim.step must not apply a step whose
+            # persistent launch timed out)
+            ig = None
+            if self.i2t_arena.flat.is_cuda:
+                ig = _lib.status_words(self.i2t_arena.flat.device)
+                if self.exchange is not None and self.exchange.world_size > 1:
+                    ig = ig[0:1].float()
+                    self.exchange._sum(ig)
+            self.last_i2t_guard = ig
             self.i2t_arena.adam(self.i2t_current_lr, (self.i2t_optim_alpha, self.i2t_optim_beta), self.i2t_optim_epsilon,
-                                self._i2t_steps, i2t_grad_scale, 0.0)
+                                self._i2t_steps, i2t_grad_scale, 0.0, guard=ig)
         if _get(self.opt, 'nmt_train_flag', 0) and self.nmt_arena is not None:
             if self.nmt_decay_method == "noam":
                 self.nmt_current_lr = self.nmt_lr * (self.opt.rnn_size ** (-0.5) *

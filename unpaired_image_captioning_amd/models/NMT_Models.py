@@ -134,7 +134,13 @@ class _NmtEngine(object):
         return NmtDims(B=B, S=S, T=T, H=m.decoder.hidden_size, W=m.encoder.embeddings.word_vec_size, layers=m.encoder.layers,
                        Vs=m.encoder.embeddings.word_lut.num_embeddings, Vt=m.decoder.embeddings.word_lut.num_embeddings,
                        dtype=self.dtype, drop_p=float(m.opt.dropout), recurrence=int(getattr(self, 'recurrence', 0)),
-                       rnn_status=_lib.status_words().data_ptr() if torch.cuda.is_available() else None)
+                       rnn_status=_lib.status_words(self.device()).data_ptr() if torch.cuda.is_available() else None)
+
+    def device(self):
+        """The device the model lives on (its status words -- written by the persistent kernels, read by Optim.step's guarded
+        Adam and cleared by Trainer.train_nmt -- are that device's, whatever torch.cuda.current_device() is)."""
+        w = self.m.decoder.embeddings.word_lut.weight
+        return w.device if w.is_cuda else None
 
     def workspace(self, d, device):
         key = (d.B, d.S, d.T, d.dtype)

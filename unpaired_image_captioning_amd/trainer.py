@@ -240,6 +240,20 @@ class Trainer(object):
                                                 grad_scale, ptr(guard), stream()), "adam_step_guarded")
         return loss
 
+    def _raise_if_timed_out(self, cause):
+        """After a failure inside a step: if a persistent launch of the step timed out, clear the status word and raise
+        PersistentTimeout (chained to `cause`) -- the step's update never ran or was skipped on the device."""
+        if isinstance(cause, _lib.PersistentTimeout) or getattr(self.i2t_model, 'engine', None) is None or self.arena is None:
+            return
+        word = _lib.status_words(self.arena.flat.device)
+        try:
+            code = int(word[0].item())
+        except Exception:
+            return
+        if code != 0:
+            word[0:1].zero_()
+            raise _lib.PersistentTimeout("persistent recurrence kernel timed out (code 0x%x): the step failed before its update" % code) from cause
+
     def _finish_step(self, loss):
         """The step's ONE host sync (the reference's loss.item(), P/trainer.py:172): returns the loss as a float and raises --
         on every rank of a data-parallel run -- if a persistent launch of the step timed out (another process on the GPU, a
@@ -252,16 +266,18 @@ class Trainer(object):
             if pair is not None:
                 vals = pair.cpu().tolist()
                 if vals[1] != 0:
-                    raise RuntimeError("persistent recurrence kernel timed out on some rank: this step's update was skipped on every rank")
-                _lib.persistent_status()                        # (clears nothing: the local word is zero too)
+                    raise _lib.PersistentTimeout("persistent recurrence kernel timed out on some rank: this step's update was skipped on every rank")
+                _lib.persistent_status(self.arena.flat.device)  # (clears nothing: the local word is zero too)
                 return vals[0]
             val = loss.item()
             if getattr(self.i2t_model, 'engine', None) is not None:
-                _lib.persistent_status()                        # raises and clears the word if the launch timed out
+                _lib.persistent_status(self.arena.flat.device)  # raises and clears the word if the launch timed out
             return val
-        except RuntimeError:
+        except _lib.PersistentTimeout:
+            # ONLY the time-out rolls the step back (the update was skipped on the device): any other failure -- a HIP error out
+            # of loss.item(), a collective's -- leaves the counters and the launch statistics alone
             if getattr(self.i2t_model, 'engine', None) is not None:
-                _lib.status_words().zero_()
+                _lib.status_words(self.arena.flat.device)[0:1].zero_()
             self._step -= 1                                     # the skipped step does not count for Adam's bias correction
             raise
 
@@ -380,70 +396,76 @@ class Trainer(object):
         S = n_rows // att.shape[0]                        # > 1 when to_device shipped every image once
         import contextlib
         eng = getattr(model, 'engine', None)
-        # the weights stay put until Adam below: ONE weight refresh serves the sampling pass, the greedy baseline and the replay
-        with (eng.hold_weights() if hasattr(eng, 'hold_weights') else contextlib.nullcontext()):
-            # The sampling pass (train mode) and the greedy baseline (eval mode, rewards.py:42-47) are independent latency chains
-            # of ~7 small launches per decode step: the baseline runs on a second stream beside the sampling pass.  Not with
-            # BatchNorm in att_embed: there the train-mode pass updates the running statistics the eval-mode pass reads (the
-            # reference runs them in this order), so the two stay serial.
-            cur = torch.cuda.current_stream()
-            # self.persistent_decode: each pass as ONE persistent launch (rnn_persist.hip's decode mode).  A persistent launch
-            # holds every CU, so the two passes then run one after the other -- measured slower for this step than the two
-            # launch chains side by side (profiles/), hence off by default here; a lone decode pass (eval) takes it by itself.
-            persistent = bool(getattr(self, 'persistent_decode', False))
-            overlap = hasattr(eng, 'hold_weights') and int(getattr(model, 'use_bn', 0) or 0) == 0 and \
-                not getattr(self, 'serial_baseline', False) and not persistent
-            rec0 = getattr(eng, 'recurrence', 0)
-            if eng is not None and not persistent:
-                eng.recurrence = rec0 | _lib.REC_FWD_CHAIN
-            defer0 = getattr(model, 'defer_status_check', False)
-            model.defer_status_check = True               # (no host sync between the passes: _finish_step reads the status word)
-            try:
-                gen_result, sample_logprobs, greedy_res = self._scst_decode(model, eng, fc, att, am, S, overlap, cur)
-            finally:
-                model.defer_status_check = defer0
-                if eng is not None:
-                    eng.recurrence = rec0
-            if reward_fn is None:
-                scorer = rewards.init_scorer(getattr(self.opt, 'cached_tokens', 'corpus'))
-                reward_t = rewards.self_critical_reward_device(scorer, gen_result, greedy_res, data['gts'],
-                                                               float(getattr(self.opt, 'cider_reward_weight', 1)),
-                                                               float(getattr(self.opt, 'bleu_reward_weight', 0)))
-            else:
-                if S > 1:                                     # eval mode is deterministic: the S replicas decode identically
-                    greedy_res = greedy_res.repeat_interleave(S, 0)
-                reward = np.asarray(reward_fn(data, gen_result.cpu().numpy(), greedy_res.cpu().numpy()), dtype=np.float32)
-                reward_t = torch.from_numpy(reward).cuda()
-            dw = float(getattr(self.opt, 'disc_reward_weight', 0) or 0)
-            if dw > 0 and getattr(self, 'discriminator', None) is not None:
-                # adversarial reward of BASELINE configs[3]: + w (D(sampled) - D(greedy)), the same self-critical form, per row
-                g_rows = greedy_res.repeat_interleave(S, 0) if greedy_res.shape[0] != gen_result.shape[0] else greedy_res
-                adv = self.discriminator_scores(gen_result) - self.discriminator_scores(g_rows)
-                reward_t = reward_t + dw * adv[:, None]
-            loss = RewardCriterion()(sample_logprobs, gen_result, reward_t)
-            # Data parallel: the reference gathers every replica's output to GPU0 and divides by the mask sum of the WHOLE batch
-            # (P/misc/criterion.py:117-122 on the gathered tensors, P/trainer.py:168-170); ranks whose captions differ in length must
-            # therefore not average their per-rank means.  Each rank rescales its mean by (its mask sum) / (sum over ranks) -- a
-            # 1-float all-reduce before the backward pass -- and the gradients (and losses) are then SUMMED, as in the XE step.
-            if self.exchange.world_size > 1:
-                loss = loss * self.exchange.global_share(self._reward_mask_sum(gen_result))
-            # every p.grad is its view of the flat gradient arena: the backward kernels write there directly (models/AttModel.py
-            # _TopDownSample.backward); a model without that path hands tensors back to autograd, copied below
-            params = dict(model.named_parameters())
-            views = self.arena.grad_views
-            sink_ok = getattr(model, 'supports_grad_sink', False)
-            for k, p in params.items():
-                p.grad = views[k] if (sink_ok and k in views) else None
-            model._grad_sink = views if sink_ok else None
-            try:
-                loss.backward()
-            finally:
-                model._grad_sink = None
-        for k, view in views.items():
-            if params[k].grad is not view:
-                view.copy_(params[k].grad)
-        self.exchange.allreduce_sum(self.arena.grad)
-        loss_d = self._guarded_adam(loss.detach(), 1.0)                   # (already the whole batch's loss: summed over the ranks)
+        try:
+            # the weights stay put until Adam below: ONE weight refresh serves the sampling pass, the greedy baseline and the replay
+            with (eng.hold_weights() if hasattr(eng, 'hold_weights') else contextlib.nullcontext()):
+                # The sampling pass (train mode) and the greedy baseline (eval mode, rewards.py:42-47) are independent latency chains
+                # of ~7 small launches per decode step: the baseline runs on a second stream beside the sampling pass.  Not with
+                # BatchNorm in att_embed: there the train-mode pass updates the running statistics the eval-mode pass reads (the
+                # reference runs them in this order), so the two stay serial.
+                cur = torch.cuda.current_stream()
+                # self.persistent_decode: each pass as ONE persistent launch (rnn_persist.hip's decode mode).  A persistent launch
+                # holds every CU, so the two passes then run one after the other -- measured slower for this step than the two
+                # launch chains side by side (profiles/), hence off by default here; a lone decode pass (eval) takes it by itself.
+                persistent = bool(getattr(self, 'persistent_decode', False))
+                overlap = hasattr(eng, 'hold_weights') and int(getattr(model, 'use_bn', 0) or 0) == 0 and \
+                    not getattr(self, 'serial_baseline', False) and not persistent
+                rec0 = getattr(eng, 'recurrence', 0)
+                if eng is not None and not persistent:
+                    eng.recurrence = rec0 | _lib.REC_FWD_CHAIN
+                defer0 = getattr(model, 'defer_status_check', False)
+                model.defer_status_check = True               # (no host sync between the passes: _finish_step reads the status word)
+                try:
+                    gen_result, sample_logprobs, greedy_res = self._scst_decode(model, eng, fc, att, am, S, overlap, cur)
+                finally:
+                    model.defer_status_check = defer0
+                    if eng is not None:
+                        eng.recurrence = rec0
+                if reward_fn is None:
+                    scorer = rewards.init_scorer(getattr(self.opt, 'cached_tokens', 'corpus'))
+                    reward_t = rewards.self_critical_reward_device(scorer, gen_result, greedy_res, data['gts'],
+                                                                   float(getattr(self.opt, 'cider_reward_weight', 1)),
+                                                                   float(getattr(self.opt, 'bleu_reward_weight', 0)))
+                else:
+                    if S > 1:                                     # eval mode is deterministic: the S replicas decode identically
+                        greedy_res = greedy_res.repeat_interleave(S, 0)
+                    reward = np.asarray(reward_fn(data, gen_result.cpu().numpy(), greedy_res.cpu().numpy()), dtype=np.float32)
+                    reward_t = torch.from_numpy(reward).cuda()
+                dw = float(getattr(self.opt, 'disc_reward_weight', 0) or 0)
+                if dw > 0 and getattr(self, 'discriminator', None) is not None:
+                    # adversarial reward of BASELINE configs[3]: + w (D(sampled) - D(greedy)), the same self-critical form, per row
+                    g_rows = greedy_res.repeat_interleave(S, 0) if greedy_res.shape[0] != gen_result.shape[0] else greedy_res
+                    adv = self.discriminator_scores(gen_result) - self.discriminator_scores(g_rows)
+                    reward_t = reward_t + dw * adv[:, None]
+                loss = RewardCriterion()(sample_logprobs, gen_result, reward_t)
+                # Data parallel: the reference gathers every replica's output to GPU0 and divides by the mask sum of the WHOLE batch
+                # (P/misc/criterion.py:117-122 on the gathered tensors, P/trainer.py:168-170); ranks whose captions differ in length must
+                # therefore not average their per-rank means.  Each rank rescales its mean by (its mask sum) / (sum over ranks) -- a
+                # 1-float all-reduce before the backward pass -- and the gradients (and losses) are then SUMMED, as in the XE step.
+                if self.exchange.world_size > 1:
+                    loss = loss * self.exchange.global_share(self._reward_mask_sum(gen_result))
+                # every p.grad is its view of the flat gradient arena: the backward kernels write there directly (models/AttModel.py
+                # _TopDownSample.backward); a model without that path hands tensors back to autograd, copied below
+                params = dict(model.named_parameters())
+                views = self.arena.grad_views
+                sink_ok = getattr(model, 'supports_grad_sink', False)
+                for k, p in params.items():
+                    p.grad = views[k] if (sink_ok and k in views) else None
+                model._grad_sink = views if sink_ok else None
+                try:
+                    loss.backward()
+                finally:
+                    model._grad_sink = None
+            for k, view in views.items():
+                if params[k].grad is not view:
+                    view.copy_(params[k].grad)
+            self.exchange.allreduce_sum(self.arena.grad)
+            loss_d = self._guarded_adam(loss.detach(), 1.0)                   # (already the whole batch's loss: summed over the ranks)
+        except BaseException as e:
+            # whatever went wrong between the decode passes and the guarded Adam (a reward function fed the -1 tokens of a
+            # timed-out pass, for one): a time-out word left behind would make the NEXT, good step skip its update and raise
+            self._raise_if_timed_out(e)
+            raise
         avg = reward_t[:, 0].mean()
         if next_data is not None:
             self.prefetch(next_data)              # the next batch crosses PCIe while this step computes (see train)
@@ -549,11 +571,11 @@ class Trainer(object):
         guard = getattr(self.optim, 'last_guard', None)
         if guard is not None and float(guard[0].item()) != 0:
             # a persistent launch of this step timed out (on some rank): Optim.step skipped the update on the device
-            _lib.status_words().zero_()
+            _lib.status_words(self.optim.nmt_arena.flat.device)[0:1].zero_()
             self.optim._step -= 1
             self.optim._nmt_steps -= 1
-            raise RuntimeError("persistent NMT kernel timed out: this step's update was skipped (weights and moments unchanged); "
-                               "engine.recurrence |= _lib.REC_FWD_CHAIN selects per-step launches")
+            raise _lib.PersistentTimeout("persistent NMT kernel timed out: this step's update was skipped (weights and moments unchanged); "
+                                         "engine.recurrence |= _lib.REC_FWD_CHAIN selects per-step launches")
         return val
 
     def save_models(self, tag=''):
