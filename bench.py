@@ -24,6 +24,14 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
+# Data-parallel runs: the step's streams, the communication stream and torch.distributed's own RCCL stream are more HIP streams
+# than the four hardware queues ROCclr opens per priority by default, and on MI355X a process with MORE THAN FOUR busy
+# hardware queues dispatches every dependent launch 1.5-2.5x slower (profiles/r05_*_queue_probe.txt: the step beside two
+# one-wave kernels on two more streams, 3.08 -> 3.82 ms with the default, 3.20 with GPU_MAX_HW_QUEUES=2).  Read by the HIP
+# runtime when it loads: set before torch is imported.  Single-GPU runs are left alone (no effect there: 3.076 vs 3.070 ms).
+if int(os.environ.get("WORLD_SIZE", "1")) > 1:
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "2")
+
 import torch
 import torch.distributed as dist
 

@@ -57,6 +57,13 @@ int uic_version(void);
  *                        GEMM instead of the GEMM that rounds its f32 A operand itself (csrc/gemm_pp.hip): bit-identical
  *                        results, ~45 us more per step.  The fallback for that kernel's hand-counted register loads (its build
  *                        is audited by tools/audit_f32a_asm.py and soaked in the GPU suite)
+ *   UIC_REC_COMM_STREAM  (uic_topdown_xe_train_step) the caller keeps a communication stream busy beside the step -- the
+ *                        overlapped gradient exchange of a data-parallel run (uic_topdown_grad_ready_wait).  MI355X dispatches
+ *                        from three busy hardware queues at full speed; with a fourth non-empty one -- even a single wave that
+ *                        only waits for an event -- the BPTT loop's dependent launches take 1.5-2.5x as long (measured:
+ *                        profiles/r05_*_queue_probe.txt, r05_*_comm_proxy.txt).  With this flag the step uses two queues of its
+ *                        own while the loop runs (the chunks' weight gradients behind the logit layer on the side stream)
+ *                        instead of three; without a communication stream the three-queue order is 0.07 ms faster
  * uic_topdown_dims.rnn_status: NULL, or 4 caller-allocated, caller-zeroed uint32 on the device that the persistent kernels
  * update: [0] != 0 after a bounded spin timed out (the results of that call are invalid), [1] / [2] launches that ran with
  * the XCD-local / the SAFE protocol. */
@@ -66,6 +73,7 @@ int uic_version(void);
 #define UIC_REC_STAMPS 8
 #define UIC_REC_EARLY_GRADS 16
 #define UIC_REC_NO_F32A 32
+#define UIC_REC_COMM_STREAM 64
 
 /* ---- shapes of one TopDown step (P/models/AttModel.py:56-92,422-428,530-536) ---- */
 typedef struct uic_topdown_dims {
@@ -220,7 +228,16 @@ int uic_topdown_xe_train_step(const uic_topdown_dims* d, const uic_topdown_weigh
  *            core.attention.alpha_net.*}                   -- final when the embedding / fc_embed / bias gradients are done.
  * A caller that lays its flat gradient arena out as [logit | group 1 | rest of the early group | late group] can
  * start the RCCL all-reduce of the first three pieces on a communication stream as each becomes final; the tail follows on
- * the step's stream.  Enqueue-only (hipStreamWaitEvent), no host sync. */
+ * the step's stream.  Enqueue-only, no host sync.  Two forms of the wait:
+ *   group                         hipStreamWaitEvent: a barrier packet parked at the head of `stream`'s hardware queue until the
+ *                                 group's event fires;
+ *   group | UIC_GRAD_WAIT_POLL    a one-wave kernel on `stream` that polls a device word the step sets where it records that
+ *                                 event.  Measured with a one-GPU stand-in for the collectives (tools/comm_proxy.py,
+ *                                 profiles/r05_*_comm_proxy.txt): while a barrier packet waits in ANOTHER hardware queue the step's
+ *                                 launch chain (85 dependent launches) is dispatched 2.5x slower -- 6.8 ms per step instead of
+ *                                 3.2 -- and a polling kernel does not have that effect.  The form to use for an exchange that
+ *                                 is enqueued while the step still runs; bounded spin (0.2 s), bit 6 of rnn_status[0] on time-out. */
+#define UIC_GRAD_WAIT_POLL 0x100
 int uic_topdown_grad_ready_wait(void* stream, int32_t group);
 /* Timing marks of the last uic_topdown_xe_train_step on this device (diagnostics; off by default, the step records no timing
  * events then).  enable != 0 switches the marks on for the following steps.  ms_out (optional, UIC_STEP_MARKS floats): waits

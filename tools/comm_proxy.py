@@ -23,6 +23,12 @@ from unpaired_image_captioning_amd.trainer import Trainer
 ap = argparse.ArgumentParser()
 ap.add_argument("--workgroups", type=int, default=16)
 ap.add_argument("--steps", type=int, default=30)
+ap.add_argument("--rec", default="0", help="extra uic_topdown_dims.recurrence bits (measurement knobs, csrc/uic_common.h)")
+ap.add_argument("--overlap", type=int, default=3, help="how many leading pieces go to the communication stream (rest: after the step)")
+ap.add_argument("--poll", action="store_true", help="uic_topdown_grad_ready_wait(group | UIC_GRAD_WAIT_POLL): polling kernels instead of barrier packets")
+ap.add_argument("--skip", type=int, default=0, help="create (and use once) this many throw-away streams before the communication stream exists")
+ap.add_argument("--no-comm-flag", action="store_true", help="clear UIC_REC_COMM_STREAM: the single-GPU stream layout beside the exchange")
+ap.add_argument("--only", default="", help="default4: only the default order with the four overlapped pieces (for traces)")
 args = ap.parse_args()
 lib = L.load()
 
@@ -32,6 +38,7 @@ class ProxyExchange(GradientExchange):
     def __init__(self, workgroups, pieces=True):
         GradientExchange.__init__(self, None)
         self.wg, self.pieces, self.scratch, self.moved = workgroups, pieces, None, 0
+        self.stamps = None          # [(start event, end event, bytes)] of the current step's pieces when not None
 
     world_size = property(lambda self: 2)
     rank = property(lambda self: 0)
@@ -45,13 +52,21 @@ class ProxyExchange(GradientExchange):
             return                                     # the 1-float / 2-float sums: latency, not bandwidth
         if self.scratch is None or self.scratch.numel() < nbytes:
             self.scratch = torch.empty(nbytes + 256, dtype=torch.uint8, device=t.device)
+        if self.stamps is not None:
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
         L.check(lib.uic_comm_proxy(t.data_ptr(), L.ptr(self.scratch), nbytes - nbytes % 16, self.wg, torch.cuda.current_stream().cuda_stream))
+        if self.stamps is not None:
+            b.record()
+            self.stamps.append((a, b, nbytes))
         self.moved += nbytes
 
     def allreduce_sum_overlapped(self, flat, splits, wait_group):
         if not self.pieces:
             return self.allreduce_sum(flat)
-        return GradientExchange.allreduce_sum_overlapped(self, flat, splits, wait_group)
+        if args.poll:
+            wait_group = lambda raw, g: L.check(lib.uic_topdown_grad_ready_wait(raw, g | 0x100), "grad_ready_wait")
+        return GradientExchange.allreduce_sum_overlapped(self, flat, list(splits)[:args.overlap], wait_group)
 
 
 c = bench.CFG
@@ -66,6 +81,9 @@ def run(early, exchange):
     opt.early_grads = int(early)
     tr = Trainer(opt, exchange=exchange) if exchange is not None else Trainer(opt)
     tr.build_optimizer()
+    tr.i2t_model.engine.recurrence |= int(args.rec, 0)
+    if args.no_comm_flag:
+        tr.i2t_model.engine.recurrence &= ~L.REC_COMM_STREAM
     t_run = tr.i2t_model._steps_to_run(batch["labels"])
     for _ in range(5):
         tr.train_device_batch(batch, t_run, den)
@@ -74,11 +92,42 @@ def run(early, exchange):
     for _ in range(args.steps):
         tr.train_device_batch(batch, t_run, den)
     torch.cuda.synchronize()
-    return (time.perf_counter() - t0) / args.steps * 1e3
+    ms = (time.perf_counter() - t0) / args.steps * 1e3
+    if exchange is not None and getattr(exchange, "pieces", False):
+        # when the pieces run, un-traced: events around every piece of three more steps, relative to the step's start
+        import ctypes as C
+        names = ["start", "prologue", "recurrence", "logit layer", "BPTT starts", "BPTT done", "rec wgrads", "main tail", "side tail", "joined", "logit grads"]
+        L.check(lib.uic_topdown_step_marks(1, None))
+        for _ in range(3):
+            exchange.stamps = []
+            e0 = torch.cuda.Event(enable_timing=True)
+            e1 = torch.cuda.Event(enable_timing=True)
+            e0.record()
+            tr.train_device_batch(batch, t_run, den)
+            e1.record()
+            torch.cuda.synchronize()
+            ms_ = (C.c_float * L.STEP_MARKS)()
+            L.check(lib.uic_topdown_step_marks(1, ms_))
+            print("      marks: " + "  ".join("%s %.3f" % (n, v) for n, v in zip(names[1:], list(ms_)[1:])))
+            print("      step %.3f ms; pieces (MB: start -> end ms): " % e0.elapsed_time(e1) +
+                  "  ".join("%.1f: %.3f -> %.3f" % (n / 1e6, e0.elapsed_time(a), e0.elapsed_time(b)) for a, b, n in exchange.stamps))
+        exchange.stamps = None
+        L.check(lib.uic_topdown_step_marks(0, None))
+    return ms
 
 
+_dummies = []
+for _ in range(args.skip):
+    st_ = torch.cuda.Stream()
+    with torch.cuda.stream(st_):
+        torch.zeros(16, device="cuda").add_(1)
+    _dummies.append(st_)
+torch.cuda.synchronize()
 print("comm stand-in: %d workgroups per collective; %d timed steps; 640 caption rows, bf16" % (args.workgroups, args.steps))
 print("%-22s %12s %22s %22s" % ("gradient order", "no exchange", "4 overlapped pieces", "1 piece after the step"))
+if args.only == "default4":
+    print("default order, 4 overlapped pieces: %.3f ms" % run(False, ProxyExchange(args.workgroups, True)))
+    sys.exit(0)
 for name, early in (("default", False), ("early_grads", True)):
     base = run(early, None)
     ex4 = ProxyExchange(args.workgroups, True)

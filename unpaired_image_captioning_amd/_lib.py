@@ -25,7 +25,7 @@ class Dims(C.Structure):
 
 
 # uic_topdown_dims.recurrence (include/uic_hip.h)
-REC_FWD_CHAIN, REC_BWD_PERSIST, REC_SAFE, REC_STAMPS, REC_EARLY_GRADS, REC_NO_F32A = 1, 2, 4, 8, 16, 32
+REC_FWD_CHAIN, REC_BWD_PERSIST, REC_SAFE, REC_STAMPS, REC_EARLY_GRADS, REC_NO_F32A, REC_COMM_STREAM = 1, 2, 4, 8, 16, 32, 64
 STEP_MARKS = 11          # UIC_STEP_MARKS
 
 
@@ -318,6 +318,8 @@ def load():
                 "there is no CPU fallback for the captioner hot path." % LIB_PATH)
         lib = C.CDLL(os.environ.get("UIC_LIB", LIB_PATH))      # UIC_LIB: a variant build to A/B (tools/build_variant.sh)
         for name, (res, args) in _SIGS.items():
+            if "UIC_LIB" in os.environ and not hasattr(lib, name):
+                continue                                        # (an A/B variant of an older source tree)
             fn = getattr(lib, name)
             fn.restype = res
             fn.argtypes = args

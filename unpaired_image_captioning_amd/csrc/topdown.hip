@@ -1,7 +1,10 @@
 // Host-side sequencing of the TopDown captioner step on one MI355X: every launch of
 // AttModel._forward / _sample, LanguageModelCriterion and their backward, enqueued on the
-// caller's HIP stream with no host synchronisation.  (The fused training step also forks onto a library-owned side stream
-// and joins it before returning; capturing it into a hipGraph is untested.)
+// caller's HIP stream with no host synchronisation.  (The fused training step also forks onto two library-owned side streams
+// and joins them before returning.  Capturing it into a hipGraph is NOT supported: with every stream joined the capture itself
+// goes through, but hipStreamEndCapture crashes inside the ROCm 7.2 runtime -- tools/graph_capture_probe.py; an un-joined stream
+// is reported properly as hipErrorStreamCaptureUnjoined.  The step is GPU-bound with the host 2.5 ms ahead, so a graph would not
+// shorten it.)
 //
 // Restructuring relative to the reference's per-step Python loop (P/models/AttModel.py:119-165):
 //   * teacher forcing makes xt_t and fc' known up front, so their share of the att_lstm gate
@@ -442,6 +445,20 @@ int attention_step(const uic_topdown_dims& d, const uic_topdown_weights* w, cons
 
 // Side stream + events for the fused training step: the logit layer of finished decode steps (logit GEMM,
 // log-softmax/criterion, dH GEMM, later dW_logit) runs beside the latency-bound recurrence on a second HIP stream.
+__global__ void grad_flag_set_kernel(unsigned* flag, unsigned epoch) {
+  __hip_atomic_store(flag, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// one wave polls (L1-bypassing agent-scope loads, s_sleep between polls) until the word has reached `epoch`; bounded (~0.2 s)
+__global__ void grad_flag_wait_kernel(const unsigned* flag, unsigned epoch, unsigned* status) {
+  if (threadIdx.x != 0) return;
+  for (int i = 0; i < 4000000; ++i) {
+    const unsigned v = __hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if ((int)(v - epoch) >= 0) return;
+    __builtin_amdgcn_s_sleep(32);
+  }
+  if (status) atomicOr(status, 0x40u);      // (never reached in a healthy run: the step's status word reports it)
+}
+
 constexpr int MAX_CHUNKS = 64;
 struct SideStream {
   hipStream_t stream = nullptr;
@@ -449,6 +466,12 @@ struct SideStream {
   hipEvent_t ev_s3 = nullptr;       // stream3 -> side: that share of every chunk so far is done
   hipStream_t stream4 = nullptr;    // default order: lang_lstm share of a chunk on stream3, att_lstm / h2att share on stream4
   hipEvent_t ev_s4 = nullptr;       // stream4 -> stream3: its share of every chunk is done
+  // uic_topdown_grad_ready_wait's second form: one device word per gradient group, set to the step's epoch by a one-lane kernel
+  // where the group's event is recorded; the waiting stream runs a one-wave kernel that polls the word (no barrier packet parked
+  // in a hardware queue while the step's launch chain is being dispatched -- see the entry point)
+  unsigned* grad_flags = nullptr;   // [3] words, 64 bytes apart
+  unsigned epoch = 0;
+  unsigned* status_word = nullptr;  // the last step's uic_topdown_dims.rnn_status
   hipEvent_t ev_prep = nullptr;     // side -> stream3: the embedding gradient's token bucketing is done
   hipEvent_t ev_den = nullptr, ev_done = nullptr;
   hipEvent_t ev_pro3 = nullptr;     // third stream: its branch of the forward prologue (fc_embed, Gfc, initial state) is through
@@ -489,9 +512,15 @@ int get_side(SideStream** out) {
     UIC_TRY(uic_check_hip(hipDeviceGetStreamPriorityRange(&least, &greatest), "hipDeviceGetStreamPriorityRange"));
     UIC_TRY(uic_check_hip(hipStreamCreateWithPriority(&ss.stream, hipStreamNonBlocking, least), "hipStreamCreateWithPriority"));
     UIC_TRY(uic_check_hip(hipStreamCreateWithPriority(&ss.stream3, hipStreamNonBlocking, least), "hipStreamCreateWithPriority"));
-    UIC_TRY(uic_check_hip(hipStreamCreateWithPriority(&ss.stream4, hipStreamNonBlocking, least), "hipStreamCreateWithPriority"));
+    // NO fourth stream: a process gets full-speed dispatch from four HIP streams in all (tools/queue_probe.py: with the caller's
+    // stream, these two and ONE more stream of the caller -- its communication stream -- a busy extra stream costs nothing; with a
+    // fifth stream in existence, used or not, the same extra stream makes the step 0.7 ms longer).  The last chunk's second share
+    // therefore runs behind the first on stream 3.
+    ss.stream4 = ss.stream3;
     UIC_TRY(uic_check_hip(hipEventCreateWithFlags(&ss.ev_s3, hipEventDisableTiming), "hipEventCreate"));
     UIC_TRY(uic_check_hip(hipEventCreateWithFlags(&ss.ev_s4, hipEventDisableTiming), "hipEventCreate"));
+    UIC_TRY(uic_check_hip(hipMalloc((void**)&ss.grad_flags, 64), "hipMalloc(grad flags)"));
+    UIC_TRY(uic_check_hip(hipMemset(ss.grad_flags, 0, 64), "hipMemset(grad flags)"));
     UIC_TRY(uic_check_hip(hipEventCreateWithFlags(&ss.ev_prep, hipEventDisableTiming), "hipEventCreate"));
     UIC_TRY(uic_check_hip(hipEventCreateWithFlags(&ss.ev_den, hipEventDisableTiming), "hipEventCreate"));
     UIC_TRY(uic_check_hip(hipEventCreateWithFlags(&ss.ev_done, hipEventDisableTiming), "hipEventCreate"));
@@ -1192,7 +1221,13 @@ struct Step {
                                        L.embed_scratch, s, embed_split, half);
   }
   // first_done == true: the caller already ran fc_cols_grad and embed_grad (the fused step, right behind the last chunk)
-  int bwd_epilogue_early(hipStream_t s, bool chunked = false, bool side = false, bool first_done = false) {
+  // bias_copies == false: the caller copies bias_ih -> bias_hh of the two cells itself (the fused step's default order: the
+  // chunks' gradients -- the bias columns among them -- come from ANOTHER stream and are joined after this call)
+  int bias_hh_copies(hipStream_t s) {
+    UIC_TRY(uic_copy_launch(G->lang_lstm_b_hh, G->lang_lstm_b_ih, (size_t)H4 * 4, s));
+    return uic_copy_launch(G->att_lstm_b_hh, G->att_lstm_b_ih, (size_t)H4 * 4, s);
+  }
+  int bwd_epilogue_early(hipStream_t s, bool chunked = false, bool side = false, bool first_done = false, bool bias_copies = true) {
     void* const tA = side ? L.tSA : L.tA;
     void* const tB = side ? L.tSB : L.tB;
     float* const colscratch = side ? L.colscratchL : L.colscratch;
@@ -1207,7 +1242,7 @@ struct Step {
     }
     if (!(chunked && bias_in_chunks()))
       UIC_TRY(uic_colsum_launch(dt, L.dg2_all, Meff, H4, H4, G->lang_lstm_b_ih, colscratch, L.colscratch_floats, s));
-    UIC_TRY(uic_copy_launch(G->lang_lstm_b_hh, G->lang_lstm_b_ih, (size_t)H4 * 4, s));
+    if (bias_copies) UIC_TRY(uic_copy_launch(G->lang_lstm_b_hh, G->lang_lstm_b_ih, (size_t)H4 * 4, s));
     // att_lstm inputs [h_lang_prev | xt | h_att_prev]  (the fc' columns are handled below from dGfc)
     if (!chunked) {
       const UicGemmTnSeg segs[3] = {{L.h_lang, H, H}, {L.xt_all, E, E}, {L.h_att, H, H}};
@@ -1216,7 +1251,7 @@ struct Step {
     }
     if (!(chunked && bias_in_chunks()))
       UIC_TRY(uic_colsum_launch(dt, L.dg1_all, Meff, H4, H4, G->att_lstm_b_ih, colscratch, L.colscratch_floats, s));
-    UIC_TRY(uic_copy_launch(G->att_lstm_b_hh, G->att_lstm_b_ih, (size_t)H4 * 4, s));
+    if (bias_copies) UIC_TRY(uic_copy_launch(G->att_lstm_b_hh, G->att_lstm_b_ih, (size_t)H4 * 4, s));
     if (!first_done) {
       UIC_TRY(fc_cols_grad(s, slab, tA, tB));
       UIC_TRY(embed_grad(0, s));
@@ -1476,12 +1511,20 @@ int uic_topdown_xe_train_step(const uic_topdown_dims* d, const uic_topdown_weigh
   // the single-stream uic_topdown_backward call only, where nothing runs beside it.
   st.d.recurrence &= ~UIC_REC_BWD_PERSIST;
   const bool early = st.early_grads();
+  // UIC_REC_COMM_STREAM: a communication stream of the caller is busy beside this step (data parallel).  The chip dispatches
+  // from THREE busy hardware queues at full speed; a fourth non-empty queue -- even one wave that only waits -- makes the BPTT
+  // loop's 85 dependent launches 1.5-2.5x slower (tools/queue_probe.py, profiles/r05_*_queue_probe.txt).  So with the caller's
+  // queue counted the step keeps to two of its own while the loop runs: the chunks' weight gradients go back to the side stream,
+  // behind the logit layer (round 4's order), instead of stream 3.
+  const bool comm = (d->recurrence & UIC_REC_COMM_STREAM) != 0;
   const int CH = WG_CHUNK;                            // decode steps per hand-off to the side stream
   const int nchunk = (t_run + CH - 1) / CH;
   UIC_REQUIRE(nchunk <= MAX_CHUNKS, "xe_train_step: too many decode steps (%d)", t_run);
 #define UIC_HIP(expr) UIC_TRY(uic_check_hip((expr), #expr))
 #define UIC_MARK(i, strm) do { if (ss->marks_on) UIC_HIP(hipEventRecord(ss->mark[i], strm)); } while (0)
 
+  ++ss->epoch;
+  ss->status_word = (unsigned*)d->rnn_status;
   UIC_MARK(0, s);
   // main: features, recurrence; hands each finished chunk of steps to the side stream.  ev_den: the step has begun (whatever
   // the caller enqueued on `s` before it is done) -- the side streams start from there.
@@ -1561,9 +1604,15 @@ int uic_topdown_xe_train_step(const uic_topdown_dims* d, const uic_topdown_weigh
   // keep the loop's 74-KB workgroups off its CUs -- measured 3.89 -> 3.99 ms)
   g_uic_tn_ring_off = 1;
   g_uic_knobs = d->recurrence & UIC_KNOB_MASK;
+  // (data-parallel order: the chunks' gradients share the side stream with the logit layer, where the 128 x 128 kernel's short
+  // launches serve the stream's latency better than 56-workgroup ones -- 3.84 vs 3.99 ms per step beside the stand-in exchange)
+  if (comm) g_uic_knobs |= UIC_KNOB_CHUNK_TN128;
   UIC_TRY(st.logit_weight_grads(s2, true));
   UIC_TRY(uic_reduce_sum_launch(st.L.row_loss, (size_t)t_run * d->N, 0.f, inv, loss_out, s2));
   if (den_out) UIC_TRY(uic_copy_launch(den_out, st.L.scalars, 4, s2));
+  // (the flag kernels come BEFORE their events: a stream's last launch has to be one the caller's stream joins, or the step
+  // cannot be captured into a hipGraph -- hipErrorStreamCaptureUnjoined)
+  hipLaunchKernelGGL(grad_flag_set_kernel, dim3(1), dim3(1), 0, s2, ss->grad_flags + 0, ss->epoch);
   UIC_HIP(hipEventRecord(ss->ev_logit, s2));          // gradient group 0 (logit layer) final: its exchange can start now
   UIC_MARK(10, s2);
   // main: BPTT, each step waits for the d hdrop rows of its chunk; side: the recurrent weight gradients of every
@@ -1598,13 +1647,16 @@ int uic_topdown_xe_train_step(const uic_topdown_dims* d, const uic_topdown_weigh
       UIC_HIP(hipStreamWaitEvent(s3, ss->ev_main[c], 0));
       UIC_TRY(st.wgrad_chunk(t0, t1, c == nchunk - 1, s2, s3));
       if (c == 1) UIC_TRY(st.embed_grad(1, s2));      // d xt of steps [CH, t_run) is complete: their share of the embedding table
+    } else if (comm) {
+      UIC_HIP(hipStreamWaitEvent(s2, ss->ev_main[c], 0));
+      UIC_TRY(st.wgrad_chunk(t0, t1, c == nchunk - 1, s2));
     } else {
       // default order: the chunk's two independent shares on streams 3 and 4 (the 256 x 256 weight-gradient kernel runs a share on
       // ~60 CUs: side by side, and beside the side stream's logit layer, they leave the BPTT chain most of the chip), the side
       // stream stays with the logit layer
       // ... one chunk after the other on stream 3 while the loop runs (two streams of them slow the chain down again: 3.15 vs
       // 3.08 ms, profiles/r05_v1_ab_knobs.txt); the LAST chunk's shares, which start when the loop is over, side by side
-      const bool two = (g_uic_knobs & UIC_KNOB_TWO_WG_STREAMS) != 0 || (c == 0 && !(g_uic_knobs & UIC_KNOB_LAST_ONE_STREAM));
+      const bool two = false;      // (a fourth stream is not worth having: see get_side)
       if (two && !(g_uic_knobs & UIC_KNOB_TWO_WG_STREAMS) && nchunk > 1) {
         // (the att_lstm / h2att share moves to stream 4 for this chunk: it accumulates into what stream 3's chunks wrote)
         UIC_HIP(hipEventRecord(ss->ev_s3, s3));
@@ -1623,6 +1675,14 @@ int uic_topdown_xe_train_step(const uic_topdown_dims* d, const uic_topdown_weigh
     UIC_TRY(st.embed_grad(0, s2));
     UIC_HIP(hipEventRecord(ss->ev_s3, s3));
     UIC_HIP(hipStreamWaitEvent(s2, ss->ev_s3, 0));    // the third stream's share of the weight gradients
+  } else if (comm) {
+    if (tail3) {   // (round 4's tail: what completes att_lstm.weight_ih and the embedding table on stream 3 beside the last chunk's gradients)
+      UIC_HIP(hipStreamWaitEvent(s3, ss->ev_main[0], 0));
+      UIC_HIP(hipStreamWaitEvent(s3, ss->ev_prep, 0));
+      UIC_TRY(st.fc_cols_grad(s3, st.L.slab3, st.L.tTA, st.L.tTB));
+      UIC_TRY(st.embed_grad(0, s3));
+      UIC_HIP(hipEventRecord(ss->ev_s3, s3));
+    }
   } else {
     // the recurrent weight gradients are complete when both shares of the last chunk are (joined on stream 3)
     UIC_HIP(hipEventRecord(ss->ev_s4, s4));
@@ -1637,13 +1697,21 @@ int uic_topdown_xe_train_step(const uic_topdown_dims* d, const uic_topdown_weigh
   // (attention accumulation, ctx2att, att_embed).  ev_early: the early group, the logit layer and the loss are final.
   g_uic_tn_ring_off = 0;
   UIC_MARK(5, s);                                     // main: BPTT done
-  UIC_HIP(hipEventRecord(ss->ev_lstm, early ? s2 : s3));     // gradient group 1 final (uic_topdown_grad_ready_wait)
-  UIC_MARK(6, early ? s2 : s3);                       // side: recurrent weight gradients done
+  hipStream_t s_lstm = (early || comm) ? s2 : s3;
+  hipLaunchKernelGGL(grad_flag_set_kernel, dim3(1), dim3(1), 0, s_lstm, ss->grad_flags + 16, ss->epoch);
+  UIC_HIP(hipEventRecord(ss->ev_lstm, s_lstm));       // gradient group 1 final (uic_topdown_grad_ready_wait)
+  UIC_MARK(6, s_lstm);                                // side: recurrent weight gradients done
   UIC_TRY(st.bwd_epilogue_late(s, true));             // (enqueued first: it is the longer of the two tails)
   UIC_MARK(7, s);
   if (!early && !tail3) UIC_HIP(hipStreamWaitEvent(s2, ss->ev_main[0], 0));
-  UIC_TRY(st.bwd_epilogue_early(s2, true, true, early || tail3));
-  if (!early) UIC_HIP(hipStreamWaitEvent(s2, ss->ev_lstm, 0));   // the early group includes the chunks' shares of streams 3 and 4
+  if (comm && tail3) UIC_HIP(hipStreamWaitEvent(s2, ss->ev_s3, 0));      // (d fc' below reads the dGfc that fc_cols_grad left)
+  const bool chunks_elsewhere = !early && !comm;      // the chunks' weight (and bias) gradients were made on stream 3
+  UIC_TRY(st.bwd_epilogue_early(s2, true, true, early || tail3, !chunks_elsewhere));
+  if (chunks_elsewhere) {
+    UIC_HIP(hipStreamWaitEvent(s2, ss->ev_lstm, 0));  // the early group includes them; bias_hh = bias_ih needs the bias columns
+    UIC_TRY(st.bias_hh_copies(s2));
+  }
+  hipLaunchKernelGGL(grad_flag_set_kernel, dim3(1), dim3(1), 0, s2, ss->grad_flags + 32, ss->epoch);
   UIC_HIP(hipEventRecord(ss->ev_early, s2));
   ss->early_recorded = true;
   UIC_MARK(8, s2);
@@ -1673,8 +1741,15 @@ int uic_topdown_step_marks(int32_t enable, float* ms_out) {
 int uic_topdown_grad_ready_wait(void* stream, int32_t group) {
   SideStream* ss = nullptr;
   UIC_TRY(get_side(&ss));
+  const bool poll = (group & UIC_GRAD_WAIT_POLL) != 0;
+  group &= ~UIC_GRAD_WAIT_POLL;
   UIC_REQUIRE(group >= 0 && group <= 2, "grad_ready_wait: group=%d must be 0 (logit layer), 1 (LSTM weights) or 2 (early group)", group);
   UIC_REQUIRE(ss->early_recorded, "grad_ready_wait: no uic_topdown_xe_train_step has run on this device yet");
+  if (poll) {
+    hipLaunchKernelGGL(grad_flag_wait_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, ss->grad_flags + 16 * group, ss->epoch, ss->status_word);
+    UIC_LAUNCH_CHECK("grad_flag_wait_kernel");
+    return UIC_OK;
+  }
   hipEvent_t ev = group == 0 ? ss->ev_logit : group == 1 ? ss->ev_lstm : ss->ev_early;
   return uic_check_hip(hipStreamWaitEvent((hipStream_t)stream, ev, 0), "hipStreamWaitEvent");
 }

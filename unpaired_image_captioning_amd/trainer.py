@@ -85,6 +85,10 @@ class Trainer(object):
             eng = getattr(self.i2t_model, 'engine', None)
             if eng is not None and hasattr(self.exchange, 'ranks_share_a_device') and self.exchange.ranks_share_a_device():
                 eng.recurrence |= _lib.REC_FWD_CHAIN       # several ranks on ONE GPU: per-step launches (include/uic_hip.h)
+            if eng is not None and self.exchange.world_size > 1:
+                # the overlapped exchange keeps a communication queue busy beside the step: the step then stays on two hardware
+                # queues of its own (a fourth busy queue slows every dependent launch of the BPTT loop, include/uic_hip.h)
+                eng.recurrence |= _lib.REC_COMM_STREAM
         self.lr = getattr(opt, 'i2t_learning_rate', 4e-4)
         self.i2t_current_lr = self.lr
         self.betas = (getattr(opt, 'i2t_optim_alpha', 0.9), getattr(opt, 'i2t_optim_beta', 0.999))
