@@ -287,6 +287,8 @@ def main():
     ap.add_argument("--early-grads", action="store_true",
                     help="UIC_REC_EARLY_GRADS (opt.early_grads): the order of the gradient work that has 62 %% of the gradient bytes final "
                          "0.18 ms before the step ends, for a step that is 4 %% longer on its own -- for N > 1 experiments; off for the headline")
+    ap.add_argument("--long-run", type=int, default=200, help="steps of the secondary `long_run` figure (0: skip); the timed region "
+                    "of the default command is 65 ms -- the boxes of the pool differ by more than a round's progress")
     ap.add_argument("--rows-per-gpu-probe", type=int, default=0,
                     help="also time the step at this many caption rows, e.g. 80 = the per-rank size of a strong-scaling run of the 640-row "
                          "batch over 8 GPUs (secondary key `strong_scaling_probe`, never `value`; off by default so that the default "
@@ -385,6 +387,15 @@ def main():
         elapsed_img, _ = timed(per_image)
     loss_val = float(loss.item())
     L.persistent_status()                                      # raises if a persistent-kernel spin timed out
+    long_run = None
+    if args.long_run > 0:
+        # the same step over a window long enough to tell a 1 % change from noise (a secondary key; `value` is the contract's K steps)
+        keep_steps = args.steps
+        args.steps = args.long_run
+        el_long, _ = timed(batch)
+        args.steps = keep_steps
+        long_run = {"steps": args.long_run, "ms_per_step": round(el_long / args.long_run * 1e3, 4),
+                    "value": round(world * N * args.long_run / el_long, 1), "unit": "captions/s"}
     strong = None
     if world == 1 and args.rows_per_gpu_probe:
         # What one rank of a STRONG-scaling run (640 rows over 8 GPUs) would do per step: the same step on rows_per_gpu_probe
@@ -459,6 +470,8 @@ def main():
             out["roofline"] = att_roof
         if f32_line is not None:
             out["f32"] = f32_line
+        if long_run is not None:
+            out["long_run"] = long_run
         if strong is not None:
             out["strong_scaling_probe"] = strong
         if elapsed_img is not None:
