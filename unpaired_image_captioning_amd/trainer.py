@@ -216,11 +216,11 @@ class Trainer(object):
             self.exchange.allreduce_sum_overlapped(
                 self.arena.grad, getattr(self, 'arena_splits', []) if hasattr(self.i2t_model, 'use_bn') else [],
                 lambda raw, g: check(lib.uic_topdown_grad_ready_wait(raw, g), "grad_ready_wait"))
-        loss = self._guarded_adam(loss, 1.0, early_groups=self.exchange.world_size == 1 and hasattr(self.i2t_model, 'use_bn'))
+        loss = self._guarded_adam(loss, 1.0)
         self.last_loss = loss
         return loss
 
-    def _guarded_adam(self, loss, grad_scale, early_groups=False):
+    def _guarded_adam(self, loss, grad_scale):
         """Adam on the flat arena, skipped ON THE DEVICE if a persistent recurrence launch of this step timed out
         (uic_adam_step_guarded reads the status word the kernels set): a bad step never reaches the weights or the moments.
         Data parallel: [loss, status] travel in ONE 2-float all-reduce issued after the gradient exchange, so the returned loss
@@ -239,32 +239,9 @@ class Trainer(object):
             guard, loss = pair[1:], pair[0]
         else:
             guard = status
-        lib = _lib.load()
-
-        def adam(lo, hi, raw_stream):
-            check(lib.uic_adam_step_guarded(a.flat.data_ptr() + 4 * lo, a.grad.data_ptr() + 4 * lo, a.exp_avg.data_ptr() + 4 * lo,
-                                            a.exp_avg_sq.data_ptr() + 4 * lo, hi - lo, self.i2t_current_lr, self.betas[0], self.betas[1],
-                                            self.eps, self._step, grad_scale, ptr(guard), raw_stream), "adam_step_guarded")
-
-        splits = getattr(self, 'arena_splits', [])
-        lo = 0
-        if early_groups and len(splits) == 3 and not getattr(self, 'serial_adam', False):
-            # Single GPU: Adam is element-wise, so the slices of the arena whose gradients are final early -- the logit layer when
-            # the BPTT loop starts, the LSTM matrices right after it (uic_topdown_grad_ready_wait) -- are updated on a fourth
-            # stream while the step still computes the rest; only the late 54 % of the arena is left for the end of the step.
-            # (Nothing in the step reads the f32 master weights of those tensors after their gradients are final: the kernels
-            # work on the bf16 copies refreshed at the start of the step.)  Same update, bit for bit.
-            if getattr(self, '_adam_stream', None) is None:
-                self._adam_stream = torch.cuda.Stream()
-            side = self._adam_stream
-            for g in (0, 1):
-                check(lib.uic_topdown_grad_ready_wait(side.cuda_stream, g), "grad_ready_wait")
-                adam(lo, splits[g], side.cuda_stream)
-                lo = splits[g]
-            adam(lo, a.numel, stream())
-            torch.cuda.current_stream().wait_stream(side)
-        else:
-            adam(0, a.numel, stream())
+        check(_lib.load().uic_adam_step_guarded(ptr(a.flat), ptr(a.grad), ptr(a.exp_avg), ptr(a.exp_avg_sq), a.numel,
+                                                self.i2t_current_lr, self.betas[0], self.betas[1], self.eps, self._step,
+                                                grad_scale, ptr(guard), stream()), "adam_step_guarded")
         return loss
 
     def _raise_if_timed_out(self, cause):
