@@ -417,6 +417,38 @@ def main():
         strong = {"rows_per_gpu": n_img_s * c["S"], "ms_per_step": round(el_s / 20 * 1e3, 3), "host_enqueue_ms_per_step": round(host / 20 * 1e3, 3),
                   "captions_per_s_per_gpu": round(n_img_s * c["S"] * 20 / el_s, 1),
                   "note": "1-GPU step at the per-rank size of a strong-scaling run (640 rows / 8 GPUs); no collective in it"}
+    comm = None
+    if world > 1:
+        # exposed communication: the same step on every rank WITHOUT the exchange (same stream layout: UIC_REC_COMM_STREAM stays set),
+        # timed rank-locally right after the measurement; what the collectives add to a step is ms_per_step minus this
+        if not share and dist.get_backend() != "nccl":
+            raise SystemExit("bench.py: %d ranks but the backend is %s, not RCCL: refusing to report a scaling number" % (world, dist.get_backend()))
+        from unpaired_image_captioning_amd.parallel_exchange import GradientExchange
+
+        class _Alone(GradientExchange):
+            world_size = property(lambda self: 1)
+            rank = property(lambda self: 0)
+
+        real = tr.exchange
+        tr.exchange = _Alone()
+        for _ in range(args.warmup):
+            tr.train_device_batch(batch, t_run, den_local)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            tr.train_device_batch(batch, t_run, den_local)
+        torch.cuda.synchronize()
+        alone_ms = (time.perf_counter() - t0) / args.steps * 1e3
+        tr.exchange = real
+        per_rank = [None] * world
+        dist.all_gather_object(per_rank, round(alone_ms, 4))
+        step_ms = elapsed / args.steps * 1e3
+        comm = {"ms_per_step_without_exchange_per_rank": per_rank,
+                "exposed_communication_ms_per_rank": [round(step_ms - a, 4) for a in per_rank],
+                "gradient_bytes_per_step": int(tr.arena.grad.numel() * 4), "pieces": len(getattr(tr, "arena_splits", [])) + 1,
+                "GPU_MAX_HW_QUEUES": os.environ.get("GPU_MAX_HW_QUEUES"),
+                "note": "step time of each rank with the collectives removed (same stream layout), measured after the timed region; "
+                        "exposed = ms_per_step - that"}
     rec_roof = recurrence_roofline(tr, batch, t_run, den_local, args.dtype)   # untimed extra steps, every rank (collectives stay matched)
     f32_line = None
     if world == 1 and args.dtype != "f32" and not args.no_f32:
@@ -472,6 +504,10 @@ def main():
             out["f32"] = f32_line
         if long_run is not None:
             out["long_run"] = long_run
+        if comm is not None:
+            out["communication"] = comm
+            if not share and out["rccl_ranks"] != world:
+                raise SystemExit("bench.py: rccl_ranks %s != --gpus %d" % (out["rccl_ranks"], world))
         if strong is not None:
             out["strong_scaling_probe"] = strong
         if elapsed_img is not None:

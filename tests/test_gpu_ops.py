@@ -437,6 +437,43 @@ def test_adam_step_matches_oracle():
     assert (pd.cpu() - P["w"]).abs().max().item() < 1e-6
 
 
+@pytest.mark.parametrize("M,N,K,sk", [(2048, 1664, 2560, 1), (2048, 1664, 2560, 2), (512, 640, 2560, 5), (9488, 512, 10880, 5), (520, 384, 1280, 1)])
+def test_linear_wgrad_256_tile_repeats_bit_for_bit_beside_busy_neighbours(M, N, K, sk):
+    """csrc/gemm_tn_pp.hip keeps three LDS-DMA units in flight across raw barriers behind counted vmcnt / lgkmcnt waits: a wait that
+    is one short, or a region restaged a phase early, shows up as a result that depends on timing.  The step's shapes (LSTM chunk
+    direct and split, h2att chunk, logit dW) and a ragged one, 60 launches each beside an HBM-bound and an MFMA-bound neighbour on
+    another stream: every launch must give the first launch's bits, and those must be the product."""
+    from unpaired_image_captioning_amd import _lib as L
+    lib = L.load()
+    g = torch.Generator(device="cuda").manual_seed(M + K)
+    lda = (M + 7) // 8 * 8
+    A = torch.randn(K, lda, device="cuda", generator=g).bfloat16()
+    B = torch.randn(K, N, device="cuda", generator=g).bfloat16()
+    ref = A[:, :M].float().t() @ B.float()
+    ws = torch.empty(max(sk, 1) * M * N * 4, dtype=torch.uint8, device="cuda")
+    side = torch.cuda.Stream()
+    hog_a = torch.randn(32 << 20, device="cuda")
+    hog_b = torch.empty_like(hog_a)
+    X = torch.randn(4096, 4096, device="cuda").bfloat16()
+    first = None
+    for it in range(60):
+        mode = it % 4
+        with torch.cuda.stream(side):
+            if mode in (1, 3):
+                hog_b.copy_(hog_a)
+            if mode in (2, 3):
+                torch.matmul(X, X)
+        dW = torch.full((M, N), float("nan"), device="cuda")
+        L.check(lib.uic_linear_wgrad(L.BF16, M, N, K, L.ptr(A), lda, L.ptr(B), N, L.ptr(dW), N, L.ptr(ws), ws.numel(), TN_256 | TN_SK(sk),
+                                     L.stream()), "linear_wgrad")
+        torch.cuda.synchronize()
+        if first is None:
+            first = dW
+            assert (dW - ref).abs().max().item() <= 2e-3 * ref.abs().max().item()
+        else:
+            assert torch.equal(dW, first), (it, mode, int((dW != first).sum()))
+
+
 def test_lm_criterion_matches_oracle():
     from unpaired_image_captioning_amd.misc.criterion import LanguageModelCriterion
     g = torch.Generator().manual_seed(4)

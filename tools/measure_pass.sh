@@ -8,9 +8,9 @@ mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
 timeout 400 python3 $R/bench.py > $O/bench.json 2> $O/bench.err
 tail -c 600 $O/bench.json
-timeout 200 python3 $R/bench.py --no-f32 --no-cpu-baseline --rows-per-gpu-probe 80 2>/dev/null | python3 -c "import sys, json; print(json.dumps(json.loads(sys.stdin.readline())['strong_scaling_probe']))" > $O/strong_scaling_probe.json
+timeout 200 python3 $R/bench.py --no-f32 --no-cpu-baseline --long-run 0 --rows-per-gpu-probe 80 2>/dev/null | python3 -c "import sys, json; print(json.dumps(json.loads(sys.stdin.readline())['strong_scaling_probe']))" > $O/strong_scaling_probe.json
 cat $O/strong_scaling_probe.json
-timeout 500 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/p6 -- python3 $R/bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-f32 > /tmp/p6.log 2>&1
+timeout 500 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/p6 -- python3 $R/bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-f32 --long-run 0 > /tmp/p6.log 2>&1
 python3 $R/tools/prof_summary.py /tmp/p6 32 45 > $O/bench_summary.txt 2>&1
 python3 $R/tools/step_timeline.py $(find /tmp/p6 -name "*kernel_trace.csv" | head -1) 4 --full > $O/step_timeline.txt 2>&1
 grep '"metric"' /tmp/p6.log | tail -1 > $O/bench_under_rocprof.json   # the same process's own HIP-event figures
@@ -20,7 +20,7 @@ timeout 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d /tm
 python3 $R/tools/pmc_traffic.py /tmp/pm attn_fwd_fast_kernel $O/attn_fwd_pmc_bf16.json
 cp $(find /tmp/pm/fetch -name "*counter_collection.csv" | head -1) $O/attn_fwd_pmc_fetch.csv
 cp $(find /tmp/pm/write -name "*counter_collection.csv" | head -1) $O/attn_fwd_pmc_write.csv
-timeout 400 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d /tmp/mf -- python3 $R/bench.py --steps 4 --warmup 2 --no-cpu-baseline --no-f32 > /tmp/mf.log 2>&1
+timeout 400 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d /tmp/mf -- python3 $R/bench.py --steps 4 --warmup 2 --no-cpu-baseline --no-f32 --long-run 0 > /tmp/mf.log 2>&1
 python3 $R/tools/pmc_mfma.py /tmp/mf 12 > $O/mfma_busy.txt 2>&1
 head -12 $O/mfma_busy.txt
 tail -5 $O/bench_summary.txt
@@ -56,3 +56,12 @@ timeout 200 python3 $R/tools/pivot_decode_bench.py --iters 20 2>/dev/null | tail
 timeout 300 bash $R/tools/nmt_profile.sh > $O/nmt_profile.txt 2>&1
 timeout 300 bash $R/tools/pivot_profile.sh > $O/pivot_profile.txt 2>&1
 cat $O/nmt_bench.txt $O/pivot_decode.txt
+# round 5: the weight-gradient kernels per split-K, the stream-count probe, the overlapped exchange with the one-GPU stand-in
+timeout 300 python3 $R/tools/tn_bench.py > $O/tn_bench.txt 2>&1
+timeout 200 python3 $R/tools/queue_probe.py 0 > $O/queue_probe.txt 2>&1
+echo "--- GPU_MAX_HW_QUEUES=2" >> $O/queue_probe.txt
+GPU_MAX_HW_QUEUES=2 timeout 200 python3 $R/tools/queue_probe.py 0 >> $O/queue_probe.txt 2>&1
+timeout 300 python3 $R/tools/comm_proxy.py --steps 20 > $O/comm_proxy.txt 2>&1
+tail -4 $O/comm_proxy.txt
+timeout 200 python3 $R/tools/ab_knobs.py 0 0x200 0x600 > $O/ab_knobs.txt 2>&1
+cat $O/ab_knobs.txt

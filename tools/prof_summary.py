@@ -27,6 +27,24 @@ for r in rows[:nrows]:
 
 traces = glob.glob(os.path.dirname(f) + '/*kernel_trace.csv')
 if traces:
+    # CU-time: a launch of W workgroups holds at most min(W, 256) of the 256 CUs, so its claim on the chip is duration x min(W, 256) /
+    # 256 "chip-microseconds".  The step's BPTT window is bound by CU time: this, not the kernel's own duration, is
+    # what a kernel that deliberately runs on few CUs (gemm_tn_pp.hip: 56 workgroups per LSTM chunk) costs the step.
+    cu = collections.defaultdict(lambda: [0.0, 0.0, 0])
+    for r in csv.DictReader(open(traces[0])):
+        try:
+            wgs = (int(r['Grid_Size_X']) // max(1, int(r['Workgroup_Size_X']))) * (int(r['Grid_Size_Y']) // max(1, int(r['Workgroup_Size_Y']))) * \
+                  (int(r['Grid_Size_Z']) // max(1, int(r['Workgroup_Size_Z'])))
+        except (KeyError, ValueError):
+            continue
+        dur = (int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e3
+        a = cu[r['Kernel_Name']]
+        a[0] += dur * min(wgs, 256) / 256.0
+        a[1] += dur
+        a[2] += 1
+    print("\nchip-time per step (duration x min(workgroups, 256) / 256), the kernels that claim most of the chip:")
+    for k, a in sorted(cu.items(), key=lambda kv: -kv[1][0])[:14]:
+        print("%-78s chip-ms/step %7.3f   (kernel ms/step %7.3f, mean CUs %5.0f)" % (k[:78], a[0] / 1e3 / steps, a[1] / 1e3 / steps, 256.0 * a[0] / a[1] if a[1] else 0))
     ev = []
     for r in csv.DictReader(open(traces[0])):
         ev.append((int(r['Start_Timestamp']), int(r['End_Timestamp']), roof in r['Kernel_Name']))
