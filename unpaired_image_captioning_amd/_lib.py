@@ -253,6 +253,7 @@ _SIGS = {
     "uic_fc_sample": (C.c_int, [C.POINTER(FcDims), C.POINTER(FcWeights), C.POINTER(Batch), C.c_int32, C.c_int32, C.c_float,
                                 C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "uic_nmt_workspace_bytes": (C.c_size_t, [C.POINTER(NmtDims)]),
+    "uic_nmt_workspace_ptr": (C.c_void_p, [C.POINTER(NmtDims), C.c_void_p, C.c_char_p]),
     "uic_nmt_forward_loss": (C.c_int, [C.POINTER(NmtDims), C.POINTER(NmtWeights), C.c_void_p, C.POINTER(C.c_int32), C.c_void_p,
                                        C.c_void_p, C.c_int32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                        C.c_void_p, C.c_void_p, C.c_void_p]),

@@ -537,6 +537,7 @@ struct NmtLayout {
   unsigned* rnn_sync;          // nmt_persist.hip's registration / barrier counters
   int* embed_scratch;          // uic_embed_bwd_sorted_launch (both embedding tables, one after the other)
   float* dfeed_x; float* dq_att_x;   // [Td, B, H] f32: step-indexed exchange slabs of the persistent BPTT launch
+  unsigned long long* dec_bwd_dbg;   // [256][Td][16] time stamps of the persistent BPTT launch (UIC_REC_STAMPS)
   size_t total;
 };
 
@@ -633,6 +634,7 @@ NmtLayout nmt_layout(const uic_nmt_dims& d, const uic_nmt_weights* w, void* ws) 
   L.rnn_sync = (unsigned*)b.take((2 * NL + 2) * uic_rnn_persist_sync_bytes());   // one block per persistent launch of a step (sync_block)
   L.dfeed_x = (float*)b.take(Td * B * H * 4);
   L.dq_att_x = (float*)b.take(Td * B * H * 4);
+  L.dec_bwd_dbg = (unsigned long long*)b.take((size_t)256 * Td * 16 * 8);
   {
     const size_t es = uic_embed_bwd_sorted_scratch_ints((int)(S * B), 1, d.Vs, (int)W), ed = uic_embed_bwd_sorted_scratch_ints((int)(Td * B), 1, d.Vt, (int)W);
     L.embed_scratch = (int*)b.take((es > ed ? es : ed) * 4);
@@ -1057,6 +1059,7 @@ struct Nmt {
       p.drop_p = drop_p; p.seed = seed;
       p.sync = sync_block(NL + 1); p.sync_zeroed = 1; p.status = d.rnn_status; p.force_safe = (d.recurrence & UIC_REC_SAFE) != 0;
       p.row0 = 0; p.Nrows = B;
+      p.dbg = (d.recurrence & UIC_REC_STAMPS) ? L.dec_bwd_dbg : nullptr;
       UIC_TRY(uic_nmt_dec_bwd_persist_launch(p, s));
     }
     for (int l = 0; l < NL && !bptt_persist; ++l) {
@@ -1275,6 +1278,15 @@ extern "C" {
 size_t uic_nmt_workspace_bytes(const uic_nmt_dims* d) {
   if (nmt_check(d)) return 0;
   return nmt_layout(*d, nullptr, nullptr).total;
+}
+
+void* uic_nmt_workspace_ptr(const uic_nmt_dims* d, void* workspace, const char* name) {
+  if (nmt_check(d) || !workspace || !name) return nullptr;
+  const NmtLayout L = nmt_layout(*d, nullptr, workspace);
+  struct { const char* n; void* p; } tab[] = {{"dec_bwd_dbg", L.dec_bwd_dbg}, {"d_cq", L.d_cq_all}, {"dscore", L.dscore_all}, {"d_pre", L.d_pre_all}};
+  for (auto& e : tab)
+    if (!strcmp(e.n, name)) return e.p;
+  return nullptr;
 }
 
 int uic_nmt_forward_loss(const uic_nmt_dims* d, const uic_nmt_weights* w, const int64_t* src, const int32_t* lengths_host,

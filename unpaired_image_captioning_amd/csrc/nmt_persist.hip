@@ -431,36 +431,32 @@ __device__ __forceinline__ void nmt_dec_bwd_steps(const UicNmtDecBwdParams& p, C
     for (int h = 0; h < 2; ++h) wot[j][h] = ws_wfrag(p.woutT, HH, h * HH + c.u0 + c.l15, (c.wave + BW_NW * j) * 32, c.lq);
   __syncthreads();
   const int arow = c.l15 < c.nrow ? c.l15 : c.nrow - 1;
-  const bool owner = c.wave == 0;
   const unsigned u = (unsigned)(c.u0 + c.l15);
   f32x4* red = (f32x4*)c.smem;                                 // [wave][half][lane]
   const float inv_keep = p.drop_p > 0.f ? 1.f / (1.f - p.drop_p) : 1.f;
-  unsigned nn[4];
-#pragma unroll
-  for (int r = 0; r < 4; ++r) {
-    const int rr = 4 * c.lq + r;
-    nn[r] = (unsigned)((c.rbegin + (rr < c.nrow ? rr : c.nrow - 1)) * HH);
-  }
-  // carried from step to step by the owner lanes (row 4 lq + r, unit u)
-  float dh0_rec[4] = {0.f, 0.f, 0.f, 0.f}, dh1_rec[4] = {0.f, 0.f, 0.f, 0.f}, dc0[4] = {0.f, 0.f, 0.f, 0.f}, dc1[4] = {0.f, 0.f, 0.f, 0.f};
+  // Everything element-wise is spread over the four waves: of the [16 rows x 16 units] tile a lane holds rows 4 lq + r in an
+  // accumulator, wave w finishes r = w -- row 4 lq + w, unit u -- and carries that element's state from step to step.
+  const int rw = 4 * c.lq + c.wave;
+  const bool valid = rw < c.nrow;
+  const unsigned nnw = (unsigned)((c.rbegin + (valid ? rw : c.nrow - 1)) * HH);
+  float dh0_rec = 0.f, dh1_rec = 0.f, dc0 = 0.f, dc1 = 0.f;
 
-  // sum of the waves' partial [16 x 16] tiles of both halves; result on the owner wave
-  auto reduce2 = [&](const f32x4 (&acc)[2], f32x4 (&out)[2]) {
+  // sum of the waves' partial [16 x 16] tiles of both halves (fixed order); wave w receives component w
+  auto reduce2 = [&](const f32x4 (&acc)[2], float (&out)[2]) {
     red[(c.wave * 2 + 0) * 64 + c.lane] = acc[0];
     red[(c.wave * 2 + 1) * 64 + c.lane] = acc[1];
     __syncthreads();
-    if (owner) {
 #pragma unroll
-      for (int h = 0; h < 2; ++h) {
-        out[h] = red[h * 64 + c.lane];
+    for (int h = 0; h < 2; ++h) {
+      float v = ((const float*)(red + h * 64 + c.lane))[c.wave];
 #pragma unroll
-        for (int w = 1; w < BW_NW; ++w) out[h] += red[(w * 2 + h) * 64 + c.lane];
-      }
+      for (int w = 1; w < BW_NW; ++w) v += ((const float*)(red + (w * 2 + h) * 64 + c.lane))[c.wave];
+      out[h] = v;
     }
     __syncthreads();
   };
   // d gates [nrow, 4 x 512] (exchanged) x the resident slice -> this workgroup's columns of both halves
-  auto dgemm = [&](const T* dg, auto wfrag, f32x4 (&out)[2]) {
+  auto dgemm = [&](const T* dg, auto wfrag, float (&out)[2]) {
     const __amdgpu_buffer_rsrc_t ra = rsrc_of(dg);
     u32x4 af[16];
 #pragma unroll
@@ -472,35 +468,62 @@ __device__ __forceinline__ void nmt_dec_bwd_steps(const UicNmtDecBwdParams& p, C
       for (int h = 0; h < 2; ++h) acc[h] = Mma<T>::run(af[j], wfrag(j, h), acc[h]);
     reduce2(acc, out);
   };
-  // backward of one LSTM cell's gate math for the owner lanes (csrc/pointwise.hip lstm_bwd_kernel): d gates stored (exchanged, and
-  // read again by the weight-gradient GEMMs), dc carried
-  auto cell_bwd = [&](int l, int t, const float (&dh)[4], float (&dc)[4]) {
+  // Backward of one LSTM cell's gate math for this wave's element (csrc/pointwise.hip lstm_bwd_kernel): d gates stored (exchanged,
+  // and read again by the weight-gradient GEMMs), dc carried.  Its operands -- the forward pass's activated gates and cell states --
+  // do not depend on anything this launch computes: cell_load requests them at the top of the step, two group barriers before
+  // they are used (requested where they are used, each of them is a memory latency on the step's critical path).
+  struct CellIn { float gi, gf, gg, go, cc, cp; };
+  auto cell_load = [&](int l, int t, CellIn& q) {
     const T* G = (const T*)p.gates_d[l] + (size_t)t * B * 4 * HH;
+    const unsigned og = 4u * nnw + u;
+    q.gi = uic_to_f(G[og]); q.gf = uic_to_f(G[og + HH]); q.gg = uic_to_f(G[og + 2 * HH]); q.go = uic_to_f(G[og + 3 * HH]);
+    q.cc = p.cd[l][(size_t)(t + 1) * BH + nnw + u];
+    q.cp = p.cd[l][(size_t)t * BH + nnw + u];
+  };
+  auto cell_bwd = [&](int l, int t, const CellIn& q, float dh, float& dc) {
     T* D = (T*)p.dg_d[l] + (size_t)t * B * 4 * HH;
-    const float* cn = p.cd[l] + (size_t)(t + 1) * BH;
-    const float* cpv = p.cd[l] + (size_t)t * BH;
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      if (4 * c.lq + r < c.nrow) {
-        const unsigned og = 4u * nn[r] + u;
-        const float gi = uic_to_f(G[og]), gf = uic_to_f(G[og + HH]), gg = uic_to_f(G[og + 2 * HH]), go = uic_to_f(G[og + 3 * HH]);
-        const float cc = cn[nn[r] + u], cp = cpv[nn[r] + u];
-        const float tc = uic_tanh<T>(cc);
-        const float d = dc[r] + dh[r] * go * (1.f - tc * tc);
-        const float d_o = dh[r] * tc;
-        st_x<SAFE>(D + og, d * gg * gi * (1.f - gi));
-        st_x<SAFE>(D + og + HH, d * cp * gf * (1.f - gf));
-        st_x<SAFE>(D + og + 2 * HH, d * gi * (1.f - gg * gg));
-        st_x<SAFE>(D + og + 3 * HH, d_o * go * (1.f - go));
-        dc[r] = d * gf;
-      }
+    if (valid) {
+      const unsigned og = 4u * nnw + u;
+      const float tc = uic_tanh<T>(q.cc);
+      const float d = dc + dh * q.go * (1.f - tc * tc);
+      const float d_o = dh * tc;
+      st_x<SAFE>(D + og, d * q.gg * q.gi * (1.f - q.gi));
+      st_x<SAFE>(D + og + HH, d * q.cp * q.gf * (1.f - q.gf));
+      st_x<SAFE>(D + og + 2 * HH, d * q.gi * (1.f - q.gg * q.gg));
+      st_x<SAFE>(D + og + 3 * HH, d_o * q.go * (1.f - q.go));
+      dc = d * q.gf;
     }
   };
+  // The attention backward's operands of the row this workgroup takes (phase B) are the same at every step: the encoder's
+  // contexts and their linear_in image.  With <= 32 source positions they stay in registers for the whole launch.
+  constexpr bool HOIST = MAXR <= 8;
+  const bool att_wg = c.rank < c.nrow;
+  uint4 cr[MAXR];                          // (S <= BW_NW * MAXR source positions)
+  float4 wr[MAXR][2];
+  auto att_load = [&]() {
+    const int b = c.rbegin + c.rank;
+    const T* ctx = (const T*)p.ctx;
+#pragma unroll
+    for (int uu = 0; uu < MAXR; ++uu) {
+      const int sp = c.wave + BW_NW * uu;
+      const size_t r = ((size_t)(sp < S ? sp : S - 1) * B + b) * HH;
+      cr[uu] = *(const uint4*)(ctx + r + c.lane * 8);
+      wr[uu][0] = *(const float4*)(p.ctxw + r + c.lane * 4);
+      wr[uu][1] = *(const float4*)(p.ctxw + r + (c.lane + 64) * 4);
+    }
+  };
+  if (HOIST && att_wg) att_load();
 
+#define BW_STAMP(i) do { if (dbg && c.tid == 0) dbg[i] = __builtin_amdgcn_s_memrealtime(); } while (0)
   for (int t = p.Td - 1; t >= 0; --t) {
     asm volatile("" : "+v"(c.lane), "+v"(c.l15), "+v"(c.lq), "+v"(c.tid));
+    unsigned long long* dbg = p.dbg ? p.dbg + ((size_t)blockIdx.x * p.Td + t) * 16 : nullptr;
+    BW_STAMP(0);
     const bool last = t == p.Td - 1;
-    float dq_lin[4] = {0.f, 0.f, 0.f, 0.f};
+    CellIn q1, q0;
+    cell_load(1, t, q1);
+    cell_load(0, t, q0);
+    float dq_lin = 0.f;
     {  // ---- phase A
       const float* d_out = p.d_out_all + (size_t)t * BH;
       const T* out_pre = (const T*)p.out_pre + (size_t)t * BH;
@@ -535,35 +558,22 @@ __device__ __forceinline__ void nmt_dec_bwd_steps(const UicNmtDecBwdParams& p, C
       for (int j = 0; j < 4; ++j)
 #pragma unroll
         for (int h = 0; h < 2; ++h) acc[h] = Mma<T>::run(af[j], wot[j][h], acc[h]);
-      f32x4 out[2];
+      float out[2];
       reduce2(acc, out);
-      if (owner) {
-        float* d_cq = p.d_cq_all + (size_t)t * B * 2 * HH;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          if (4 * c.lq + r < c.nrow) st_x<SAFE>(d_cq + 2u * nn[r] + u, out[0][r]);           // d c (attention backward, deferred accumulation)
-          dq_lin[r] = out[1][r];
-        }
-      }
+      float* d_cq = p.d_cq_all + (size_t)t * B * 2 * HH;
+      if (valid) st_x<SAFE>(d_cq + 2u * nnw + u, out[0]);                 // d c (attention backward, deferred accumulation)
+      dq_lin = out[1];
     }
+    BW_STAMP(1);
     if (!group_barrier(c)) return;
-    if (c.rank < c.nrow) {  // ---- phase B: attention backward of row `rank` of the group (csrc/nmt.hip gattn_bwd_step_fast_kernel)
+    BW_STAMP(2);
+    if (att_wg) {  // ---- phase B: attention backward of row `rank` of the group (csrc/nmt.hip gattn_bwd_step_fast_kernel)
       const int b = c.rbegin + c.rank;
       float* s_dc = (float*)c.smem + 64;       // [HH]
       float* s_a = s_dc + HH;                  // [64]
       float* s_da = s_a + 64;                  // [64]
       float* s_red = s_da + 64;                // [BW_NW][HH]
-      const T* ctx = (const T*)p.ctx;
-      uint4 cr[MAXR];                          // (S <= BW_NW * MAXR source positions)
-      float4 wr[MAXR][2];
-#pragma unroll
-      for (int uu = 0; uu < MAXR; ++uu) {
-        const int sp = c.wave + BW_NW * uu;
-        const size_t r = ((size_t)(sp < S ? sp : S - 1) * B + b) * HH;
-        cr[uu] = *(const uint4*)(ctx + r + c.lane * 8);
-        wr[uu][0] = *(const float4*)(p.ctxw + r + c.lane * 4);
-        wr[uu][1] = *(const float4*)(p.ctxw + r + (c.lane + 64) * 4);
-      }
+      if (!HOIST) att_load();
       if (c.wave < 2) {                        // d c of the row: written by the other workgroups in phase A
         const u32x4 v = bload<true>(rsrc_of(p.d_cq_all + (size_t)t * B * 2 * HH), (unsigned)((b * 2 * HH + c.tid * 4) * 4), 0);
         *(u32x4*)(s_dc + c.tid * 4) = v;
@@ -616,60 +626,48 @@ __device__ __forceinline__ void nmt_dec_bwd_steps(const UicNmtDecBwdParams& p, C
       }
       __syncthreads();
     }
+    BW_STAMP(3);
     if (!group_barrier(c)) return;
-    float dx1[4] = {0.f, 0.f, 0.f, 0.f};
-    if (owner) {  // ---- phase C1: top layer's cell backward
+    BW_STAMP(4);
+    float dx1 = 0.f;
+    {  // ---- phase C1: top layer's cell backward
       const __amdgpu_buffer_rsrc_t rq = rsrc_of(p.dq_att_x + (size_t)t * BH);
-      float dh[4];
-#pragma unroll
-      for (int r = 0; r < 4; ++r) dh[r] = dq_lin[r] + __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rq, (nn[r] + u) * 4u, 0, 16)) + dh1_rec[r];
-      cell_bwd(1, t, dh, dc1);
+      const float dh = dq_lin + __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rq, (nnw + u) * 4u, 0, 16)) + dh1_rec;
+      cell_bwd(1, t, q1, dh, dc1);
     }
+    BW_STAMP(5);
     if (!group_barrier(c)) return;
+    BW_STAMP(6);
     {  // ---- phase C2
-      f32x4 out[2];
+      float out[2];
       dgemm((const T*)p.dg_d[1] + (size_t)t * B * 4 * HH + 4 * rb, [&](int j, int h) { return w1t[j][h]; }, out);
-      if (owner) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) { dx1[r] = out[0][r]; dh1_rec[r] = out[1][r]; }
-      }
+      dx1 = out[0]; dh1_rec = out[1];
     }
-    if (owner) {  // ---- phase D1: layer 0's cell backward (its h went through the inter-layer dropout)
-      float dh[4];
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        float v = dx1[r];
-        if (p.drop_p > 0.f) v *= uic_drop_scale(p.seed, NMT_SITE_DEC(0, t), nn[r] + u, p.drop_p, inv_keep);
-        dh[r] = v + dh0_rec[r];
-      }
-      cell_bwd(0, t, dh, dc0);
+    {  // ---- phase D1: layer 0's cell backward (its h went through the inter-layer dropout)
+      float v = dx1;
+      if (p.drop_p > 0.f) v *= uic_drop_scale(p.seed, NMT_SITE_DEC(0, t), nnw + u, p.drop_p, inv_keep);
+      cell_bwd(0, t, q0, v + dh0_rec, dc0);
     }
+    BW_STAMP(7);
     if (!group_barrier(c)) return;
+    BW_STAMP(8);
     {  // ---- phase D2
-      f32x4 out[2];
+      float out[2];
       dgemm((const T*)p.dg_d[0] + (size_t)t * B * 4 * HH + 4 * rb, [&](int j, int h) { return w0t[((c.wave * 16 + j) * 2 + h) * 64 + c.lane]; }, out);
-      if (owner) {
-        float* df = p.dfeed_x + (size_t)t * BH;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          if (4 * c.lq + r < c.nrow) st_x<SAFE>(df + nn[r] + u, out[0][r]);
-          dh0_rec[r] = out[1][r];
-        }
-      }
+      if (valid) st_x<SAFE>(p.dfeed_x + (size_t)t * BH + nnw + u, out[0]);
+      dh0_rec = out[1];
     }
+    BW_STAMP(9);
     if (!group_barrier(c)) return;
+    BW_STAMP(10);
   }
+#undef BW_STAMP
   // what the encoder's backward pass starts from: d h_l(-1) in the second halves of the [B, 2 x 512] hand-over buffers, d c_l(-1)
-  if (owner) {
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      if (4 * c.lq + r < c.nrow) {
-        p.dh_init[0][2u * nn[r] + HH + u] = dh0_rec[r];
-        p.dh_init[1][2u * nn[r] + HH + u] = dh1_rec[r];
-        p.dc_init[0][nn[r] + u] = dc0[r];
-        p.dc_init[1][nn[r] + u] = dc1[r];
-      }
-    }
+  if (valid) {
+    p.dh_init[0][2u * nnw + HH + u] = dh0_rec;
+    p.dh_init[1][2u * nnw + HH + u] = dh1_rec;
+    p.dc_init[0][nnw + u] = dc0;
+    p.dc_init[1][nnw + u] = dc1;
   }
 }
 

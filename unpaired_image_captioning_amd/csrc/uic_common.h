@@ -430,6 +430,7 @@ struct UicNmtDecBwdParams {
   unsigned* sync; unsigned* status; int force_safe;
   int sync_zeroed;                  // the caller has already cleared `sync` for this launch (uic_zero_list_launch with its other buffers)
   int row0, Nrows;
+  unsigned long long* dbg;           // optional (UIC_REC_STAMPS): [256 workgroups][Td][16] s_memrealtime stamps (100 MHz)
 };
 // One layer of the pivot encoder's packed bidirectional LSTM (NMT_Models.Encoder, P/models/NMT_Models.py:95-135; nn.LSTM over a
 // pack_padded_sequence) as ONE launch, both directions side by side: workgroups 0-15 of a row group own the forward direction's
