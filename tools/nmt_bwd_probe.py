@@ -39,25 +39,37 @@ torch.cuda.synchronize()
 d = eng.dims(B, S, T)
 (ws,) = eng._pool[(d.B, d.S, d.T, d.dtype)]
 lib = L.load()
-p = lib.uic_nmt_workspace_ptr(C.byref(d), C.c_void_p(ws.data_ptr()), b"dec_bwd_dbg")
-assert p, "no dec_bwd_dbg in the workspace"
 Td = T - 1
 n = 256 * Td * 16
-buf = (C.c_uint64 * n).from_address(0) if False else None
-host = torch.empty(n, dtype=torch.int64)
 hip = C.CDLL("libamdhip64.so")
 hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
-assert hip.hipMemcpy(C.c_void_p(host.data_ptr()), C.c_void_p(p), n * 8, 2) == 0
-st = host.view(256, Td, 16).double() * 10e-3          # 100 MHz ticks -> us
-names = ["A: d_pre, d[c;q] GEMM", "barrier 1", "B: attention backward", "barrier 2", "C1: top cell backward", "barrier 3",
-         "C2 + D1: d x GEMM, cell 0", "barrier 4", "D2: d feed GEMM", "barrier 5"]
-mid = st[:, 1:Td - 1]                                 # (first / last steps: cold loads, no carry)
-tot = 0.0
-for i, nm in enumerate(names):
-    ph = mid[:, :, i + 1] - mid[:, :, i]
-    tot += ph.mean().item()
-    print("   %-28s mean %6.2f us   median %6.2f   max over WGs (mean over t) %6.2f   min over WGs %6.2f" % (
-        nm, ph.mean().item(), ph.median().item(), ph.mean(1).max().item(), ph.mean(1).min().item()))
-step = (mid[:, :, 10] - mid[:, :, 0]).mean().item()
-print("   step   mean %6.2f us (sum of phases %.2f); launch: first stamp -> last stamp %.1f us for %d steps" % (
-    step, tot, (st[:, 0, 10].max() - st[:, Td - 1, 0].min()).item(), Td))
+
+
+def stamps(name):
+    p = lib.uic_nmt_workspace_ptr(C.byref(d), C.c_void_p(ws.data_ptr()), name)
+    assert p, "no %s in the workspace" % name
+    host = torch.empty(n, dtype=torch.int64)
+    assert hip.hipMemcpy(C.c_void_p(host.data_ptr()), C.c_void_p(p), n * 8, 2) == 0
+    return host.view(256, Td, 16).double() * 10e-3          # 100 MHz ticks -> us
+
+
+def report(title, st, names, first, lastt):
+    print(title)
+    mid = st[:, 1:Td - 1]                                 # (first / last steps: cold loads, no carry)
+    tot = 0.0
+    for i, nm in enumerate(names):
+        ph = mid[:, :, i + 1] - mid[:, :, i]
+        tot += ph.mean().item()
+        print("   %-28s mean %6.2f us   median %6.2f   max over WGs (mean over t) %6.2f   min over WGs %6.2f" % (
+            nm, ph.mean().item(), ph.median().item(), ph.mean(1).max().item(), ph.mean(1).min().item()))
+    k = len(names)
+    step = (mid[:, :, k] - mid[:, :, 0]).mean().item()
+    print("   step   mean %6.2f us (sum of phases %.2f); launch: first stamp -> last stamp %.1f us for %d steps" % (
+        step, tot, (st[:, lastt, k].max() - st[:, first, 0].min()).item(), Td))
+
+
+report("decoder forward (nmt_dec_ws_kernel)", stamps(b"dec_fwd_dbg"),
+       ["layer 0 cell", "barrier 1", "layer 1 cell", "barrier 2", "attention", "barrier 3", "linear_out + tanh", "barrier 4"], 0, Td - 1)
+report("decoder BPTT (nmt_dec_bwd_kernel)", stamps(b"dec_bwd_dbg"),
+       ["A: d_pre, d[c;q] GEMM", "barrier 1", "B: attention backward", "barrier 2", "C1: top cell backward", "barrier 3",
+        "C2 + D1: d x GEMM, cell 0", "barrier 4", "D2: d feed GEMM", "barrier 5"], Td - 1, 0)

@@ -538,6 +538,7 @@ struct NmtLayout {
   int* embed_scratch;          // uic_embed_bwd_sorted_launch (both embedding tables, one after the other)
   float* dfeed_x; float* dq_att_x;   // [Td, B, H] f32: step-indexed exchange slabs of the persistent BPTT launch
   unsigned long long* dec_bwd_dbg;   // [256][Td][16] time stamps of the persistent BPTT launch (UIC_REC_STAMPS)
+  unsigned long long* dec_fwd_dbg;   // the same of the persistent forward launch
   size_t total;
 };
 
@@ -635,6 +636,7 @@ NmtLayout nmt_layout(const uic_nmt_dims& d, const uic_nmt_weights* w, void* ws) 
   L.dfeed_x = (float*)b.take(Td * B * H * 4);
   L.dq_att_x = (float*)b.take(Td * B * H * 4);
   L.dec_bwd_dbg = (unsigned long long*)b.take((size_t)256 * Td * 16 * 8);
+  L.dec_fwd_dbg = (unsigned long long*)b.take((size_t)256 * Td * 16 * 8);
   {
     const size_t es = uic_embed_bwd_sorted_scratch_ints((int)(S * B), 1, d.Vs, (int)W), ed = uic_embed_bwd_sorted_scratch_ints((int)(Td * B), 1, d.Vt, (int)W);
     L.embed_scratch = (int*)b.take((es > ed ? es : ed) * 4);
@@ -938,6 +940,7 @@ struct Nmt {
       p.drop_p = drop_p; p.seed = seed;
       p.sync = sync_block(NL); p.sync_zeroed = 1; p.status = d.rnn_status; p.force_safe = (d.recurrence & UIC_REC_SAFE) != 0;
       p.row0 = 0; p.Nrows = B;
+      p.dbg = (d.recurrence & UIC_REC_STAMPS) ? L.dec_fwd_dbg : nullptr;
       return uic_nmt_dec_persist_launch(p, s);
     }
     const size_t lds_att = sizeof(float) * ((size_t)H + S + 4 * (size_t)H);
@@ -1283,7 +1286,7 @@ size_t uic_nmt_workspace_bytes(const uic_nmt_dims* d) {
 void* uic_nmt_workspace_ptr(const uic_nmt_dims* d, void* workspace, const char* name) {
   if (nmt_check(d) || !workspace || !name) return nullptr;
   const NmtLayout L = nmt_layout(*d, nullptr, workspace);
-  struct { const char* n; void* p; } tab[] = {{"dec_bwd_dbg", L.dec_bwd_dbg}, {"d_cq", L.d_cq_all}, {"dscore", L.dscore_all}, {"d_pre", L.d_pre_all}};
+  struct { const char* n; void* p; } tab[] = {{"dec_bwd_dbg", L.dec_bwd_dbg}, {"dec_fwd_dbg", L.dec_fwd_dbg}, {"d_cq", L.d_cq_all}, {"dscore", L.dscore_all}, {"d_pre", L.d_pre_all}};
   for (auto& e : tab)
     if (!strcmp(e.n, name)) return e.p;
   return nullptr;

@@ -215,7 +215,7 @@ __device__ __forceinline__ void nmt_dec_ws_steps(const UicNmtDecParams& p, Ctx& 
   const size_t rb = (size_t)c.rbegin * HH;
   u32x4* w0 = (u32x4*)lds;                       // layer 0's image; c.smem (the scratch) lies behind it
   // ---- the weight slices, once per launch.  k-step ks = wave + 8 j of the 32 (K = 1024 = two 512-wide segments)
-  u32x4 w1[4][4], wo[4];
+  u32x4 w1[4][4];
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
     const int ks = c.wave + NWAVE * j;
@@ -227,13 +227,28 @@ __device__ __forceinline__ void nmt_dec_ws_steps(const UicNmtDecParams& p, Ctx& 
       if (p.NL > 1) w1[j][g] = seg == 0 ? ws_wfrag(p.w_ih[1], p.ld_ih[1], row, kk, c.lq) : ws_wfrag(p.w_hh[1], HH, row, kk, c.lq);
       else w1[j][g] = u32x4{0u, 0u, 0u, 0u};
     }
-    wo[j] = ws_wfrag(p.attn_out_w, 2 * HH, c.u0 + c.l15, seg * HH + kk, c.lq);
   }
   __syncthreads();
   const int arow = c.l15 < c.nrow ? c.l15 : c.nrow - 1;      // rows past the group's share re-read its last row (results unused)
-  const bool owner = c.wave == 0;
   const unsigned u = (unsigned)(c.u0 + c.l15);
   f32x4* red = (f32x4*)c.smem;                   // [wave][gate][lane]
+  // Element-wise work is spread over waves 0-3: of the [16 rows x 16 units] tile a lane holds rows 4 lq + r in an accumulator,
+  // wave w < 4 finishes r = w -- row 4 lq + w, unit u -- and keeps that element's cell states in registers from step to step.
+  const bool fin = c.wave < 4;
+  const int rw = 4 * c.lq + (c.wave & 3);
+  const bool valid = fin && rw < c.nrow;
+  const unsigned nnw = (unsigned)((c.rbegin + (rw < c.nrow ? rw : c.nrow - 1)) * HH);
+  const float inv_keep = p.drop_p > 0.f ? 1.f / (1.f - p.drop_p) : 1.f;
+  float cs0 = p.cd[0][nnw + u], cs1 = p.NL > 1 ? p.cd[1][nnw + u] : 0.f;
+  // layer 0's share of the gate pre-activations that does not depend on the recurrence (embedding + both biases, made by a batched
+  // GEMM): requested one step ahead -- it comes from HBM, and requested where it is used its latency is on the step's critical path
+  float gxn[4];
+  auto load_gx = [&](int t) {
+    const float* gx = p.gx_d0 + (size_t)t * B * 4 * HH;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) gxn[g] = gx[4u * nnw + (unsigned)(g * HH) + u];
+  };
+  load_gx(0);
 
   // A fragments of this wave's four k-steps from two [nrow, 512] slabs of exchanged rows (sc1 loads), all issued at once
   auto load_a = [&](const T* a0, const T* a1, u32x4 (&af)[4]) {
@@ -245,24 +260,10 @@ __device__ __forceinline__ void nmt_dec_ws_steps(const UicNmtDecParams& p, Ctx& 
       af[j] = (ks >> 4) == 0 ? bload<true>(r0, voff, 0) : bload<true>(r1, voff, 0);
     }
   };
-  // one LSTM cell of the group's rows and this workgroup's 16 units; wfrag(j, g): the resident B fragment
-  auto lstm = [&](const T* a0, const T* a1, auto wfrag, auto pre, const float* c_prev, float* c_out, T* h_out, T* h_drop, T* gates_out,
+  // one LSTM cell of the group's rows and this workgroup's 16 units; wfrag(j, g): the resident B fragment; pv: this element's
+  // recurrence-independent share; cst: its cell state (in / out)
+  auto lstm = [&](const T* a0, const T* a1, auto wfrag, const float (&pv)[4], float& cst, float* c_out, T* h_out, T* h_drop, T* gates_out,
                   float drop_p, unsigned site) {
-    unsigned nn[4];
-    float pv[4][4], cp[4];
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int rr = 4 * c.lq + r;
-      nn[r] = (unsigned)((c.rbegin + (rr < c.nrow ? rr : c.nrow - 1)) * HH);
-    }
-    if (owner) {
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        cp[r] = c_prev[nn[r] + u];
-#pragma unroll
-        for (int g = 0; g < 4; ++g) pv[r][g] = pre(4u * nn[r] + (unsigned)(g * HH) + u, (unsigned)(g * HH) + u);
-      }
-    }
     u32x4 af[4];
     load_a(a0, a1, af);
     f32x4 acc[4];
@@ -275,69 +276,161 @@ __device__ __forceinline__ void nmt_dec_ws_steps(const UicNmtDecParams& p, Ctx& 
 #pragma unroll
     for (int g = 0; g < 4; ++g) red[(c.wave * 4 + g) * 64 + c.lane] = acc[g];
     __syncthreads();
-    if (owner) {
-      f32x4 s[4];
+    if (fin) {
+      float sg[4];
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
-        s[g] = red[(0 * 4 + g) * 64 + c.lane];
+        float v = ((const float*)(red + (0 * 4 + g) * 64 + c.lane))[c.wave];
 #pragma unroll
-        for (int w = 1; w < NWAVE; ++w) s[g] += red[(w * 4 + g) * 64 + c.lane];
+        for (int w = 1; w < NWAVE; ++w) v += ((const float*)(red + (w * 4 + g) * 64 + c.lane))[c.wave];
+        sg[g] = v;
       }
-      const float inv_keep = drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f;
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int rr = 4 * c.lq + r;
-        if (rr < c.nrow) {
-          const unsigned o = nn[r] + u;
-          const float gi = uic_sigmoid_t<T>(s[0][r] + pv[r][0]);
-          const float gf = uic_sigmoid_t<T>(s[1][r] + pv[r][1]);
-          const float gg = uic_tanh<T>(s[2][r] + pv[r][2]);
-          const float go = uic_sigmoid_t<T>(s[3][r] + pv[r][3]);
-          const float cn = gf * cp[r] + gi * gg;
-          const float h = go * uic_tanh<T>(cn);
-          c_out[o] = cn;
-          st_x<SAFE>(h_out + o, h);
-          if (h_drop) st_x<SAFE>(h_drop + o, drop_p > 0.f ? h * uic_drop_scale(p.seed, site, o, drop_p, inv_keep) : h);
-          const unsigned og = 4u * nn[r] + u;                  // read again only in the backward pass
-          __builtin_nontemporal_store(uic_from_f<T>(gi), gates_out + og);
-          __builtin_nontemporal_store(uic_from_f<T>(gf), gates_out + og + HH);
-          __builtin_nontemporal_store(uic_from_f<T>(gg), gates_out + og + 2 * HH);
-          __builtin_nontemporal_store(uic_from_f<T>(go), gates_out + og + 3 * HH);
-        }
+      if (valid) {
+        const unsigned o = nnw + u;
+        const float gi = uic_sigmoid_t<T>(sg[0] + pv[0]);
+        const float gf = uic_sigmoid_t<T>(sg[1] + pv[1]);
+        const float gg = uic_tanh<T>(sg[2] + pv[2]);
+        const float go = uic_sigmoid_t<T>(sg[3] + pv[3]);
+        const float cn = gf * cst + gi * gg;
+        const float h = go * uic_tanh<T>(cn);
+        cst = cn;
+        c_out[o] = cn;
+        st_x<SAFE>(h_out + o, h);
+        if (h_drop) st_x<SAFE>(h_drop + o, drop_p > 0.f ? h * uic_drop_scale(p.seed, site, o, drop_p, inv_keep) : h);
+        const unsigned og = 4u * nnw + u;                  // read again only in the backward pass
+        __builtin_nontemporal_store(uic_from_f<T>(gi), gates_out + og);
+        __builtin_nontemporal_store(uic_from_f<T>(gf), gates_out + og + HH);
+        __builtin_nontemporal_store(uic_from_f<T>(gg), gates_out + og + 2 * HH);
+        __builtin_nontemporal_store(uic_from_f<T>(go), gates_out + og + 3 * HH);
       }
     }
     __syncthreads();
   };
+  // The attention phase's operands of the row this workgroup takes (at most one: <= 16 rows per group, 32 workgroups): the
+  // encoder's contexts and their linear_in image.  Requested between the two halves of the group barrier in front of the phase
+  // -- they do not depend on the exchange, so their latency passes while the workgroup waits for the others.  (Kept in registers
+  // for the whole launch they are 96 registers: with 8 waves x 256 the LSTM phases spill.)
+  const bool att_wg = c.rank < c.nrow;
+  uint4 cr[NMT_MAXR];
+  float4 wr[NMT_MAXR][2];
+  auto att_load = [&]() {
+    const int b = c.rbegin + c.rank;
+#pragma unroll
+    for (int uu = 0; uu < NMT_MAXR; ++uu) {
+      const int sp = c.wave + NWAVE * uu;
+      const size_t r = ((size_t)(sp < p.S ? sp : p.S - 1) * B + b) * HH;
+      cr[uu] = *(const uint4*)((const T*)p.ctx + r + c.lane * 8);
+      wr[uu][0] = *(const float4*)(p.ctxw + r + c.lane * 4);
+      wr[uu][1] = *(const float4*)(p.ctxw + r + (c.lane + 64) * 4);
+    }
+  };
+  // dot attention of that row (GlobalAttention.py:120-160; csrc/nmt.hip gattn_fwd_fast_kernel): every wave reads the query in the
+  // layout of its own products, takes source positions wave + 8 u, and redoes the <= 64-way softmax in its lanes (no LDS loops)
+  auto attention = [&](const T* q_all, float* attn_t, T* cvec_t) {
+    const int S = p.S;
+    const int b = c.rbegin + c.rank;
+    float* s_a = (float*)c.smem + 64;        // [64]   (the first words stay free: the barrier's flag lives there)
+    float* s_red = s_a + 64;                 // [NWAVE][HH]
+    const __amdgpu_buffer_rsrc_t rq = rsrc_of(q_all);
+    typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
+    const u32x2 qa = __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(rq, (unsigned)((b * HH + c.lane * 4) * 2), 0, 16));
+    const u32x2 qb = __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(rq, (unsigned)((b * HH + (c.lane + 64) * 4) * 2), 0, 16));
+    const float v0[4] = {__uint_as_float(qa.x << 16), __uint_as_float(qa.x & 0xffff0000u), __uint_as_float(qa.y << 16), __uint_as_float(qa.y & 0xffff0000u)};
+    const float v1[4] = {__uint_as_float(qb.x << 16), __uint_as_float(qb.x & 0xffff0000u), __uint_as_float(qb.y << 16), __uint_as_float(qb.y & 0xffff0000u)};
+#pragma unroll
+    for (int uu = 0; uu < NMT_MAXR; ++uu) {
+      const int sp = c.wave + NWAVE * uu;
+      if (sp < S) {
+        float pr = 0.f;
+        pr += wr[uu][0].x * v0[0]; pr += wr[uu][0].y * v0[1]; pr += wr[uu][0].z * v0[2]; pr += wr[uu][0].w * v0[3];
+        pr += wr[uu][1].x * v1[0]; pr += wr[uu][1].y * v1[1]; pr += wr[uu][1].z * v1[2]; pr += wr[uu][1].w * v1[3];
+        pr = uic_wave_sum(pr);
+        if (c.lane == 0) s_a[sp] = pr;
+      }
+    }
+    __syncthreads();
+    const float x = c.lane < S ? s_a[c.lane] : -INFINITY;
+    const float mx = uic_wave_max(x);
+    const float e = c.lane < S ? expf(x - mx) : 0.f;
+    const float a_l = e * (1.f / uic_wave_sum(e));
+    if (c.wave == 0 && c.lane < S) attn_t[(size_t)b * S + c.lane] = a_l;
+    float acc[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) acc[k] = 0.f;
+#pragma unroll
+    for (int uu = 0; uu < NMT_MAXR; ++uu) {
+      const int sp = c.wave + NWAVE * uu;
+      const float a = __shfl(a_l, sp & 63, 64);
+      if (sp < S) {
+        float f[8];
+        uic_unpack<bf16_t>(cr[uu], f);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) acc[k] += a * f[k];
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) s_red[c.wave * HH + c.lane * 8 + k] = acc[k];
+    __syncthreads();
+    {
+      float v = 0.f;
+#pragma unroll
+      for (int w = 0; w < NWAVE; ++w) v += s_red[w * HH + c.tid];      // (NTH == HH: one column per thread)
+      st_x<SAFE>(cvec_t + (size_t)b * HH + c.tid, v);
+    }
+    __syncthreads();
+  };
 
+#define FW_STAMP(i) do { if (dbg && c.tid == 0) dbg[i] = __builtin_amdgcn_s_memrealtime(); } while (0)
   for (int t = 0; t < p.Td; ++t) {
     asm volatile("" : "+v"(c.lane), "+v"(c.l15), "+v"(c.lq), "+v"(c.tid));
+    unsigned long long* dbg = p.dbg ? p.dbg + ((size_t)blockIdx.x * p.Td + t) * 16 : nullptr;
+    FW_STAMP(0);
     const bool two = p.NL > 1;
     T* h0_prev = (T*)p.hd[0] + (size_t)t * BH;
     T* h0_new = h0_prev + BH;
     T* hdrop0 = two ? (T*)p.hdrop[0] + (size_t)t * BH : nullptr;
     {  // layer 0: [input feed ; h_0] against the LDS image; the embedding share (+ both biases) is p.gx_d0
-      const float* gx = p.gx_d0 + (size_t)t * B * 4 * HH;
+      const float pv[4] = {gxn[0], gxn[1], gxn[2], gxn[3]};
       lstm((const T*)p.out_all + (size_t)t * BH + rb, h0_prev + rb,
-           [&](int j, int g) { return w0[((c.wave * 4 + j) * 4 + g) * 64 + c.lane]; },
-           [&](unsigned idx4, unsigned) { return gx[idx4]; },
-           p.cd[0] + (size_t)t * BH, p.cd[0] + (size_t)(t + 1) * BH, h0_new, hdrop0, (T*)p.gates_d[0] + (size_t)t * B * 4 * HH,
+           [&](int j, int g) { return w0[((c.wave * 4 + j) * 4 + g) * 64 + c.lane]; }, pv, cs0,
+           p.cd[0] + (size_t)(t + 1) * BH, h0_new, hdrop0, (T*)p.gates_d[0] + (size_t)t * B * 4 * HH,
            two ? p.drop_p : 0.f, NMT_SITE_DEC(0, t));
+      if (t + 1 < p.Td) load_gx(t + 1);
     }
-    if (!group_barrier(c)) return;
+    FW_STAMP(1);
+    group_arrive(c);
+    if (!two && att_wg) att_load();
+    if (!group_wait(c, (int*)c.smem)) return;
+    FW_STAMP(2);
     const T* q = h0_new;
     if (two) {  // layer 1: [dropped h_0 ; h_1] against the register-resident slice
       T* h1_prev = (T*)p.hd[1] + (size_t)t * BH;
-      const float* b1 = p.b_ih[1];
-      const float* b2 = p.b_hh[1];
-      lstm(hdrop0 + rb, h1_prev + rb, [&](int j, int g) { return w1[j][g]; }, [&](unsigned, unsigned col) { return b1[col] + b2[col]; },
-           p.cd[1] + (size_t)t * BH, p.cd[1] + (size_t)(t + 1) * BH, h1_prev + BH, (T*)nullptr, (T*)p.gates_d[1] + (size_t)t * B * 4 * HH,
-           0.f, 0u);
+      float pb1[4];                                // both biases of this element's gate columns (L2 hits, requested before the A fragments)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) pb1[g] = p.b_ih[1][g * HH + u] + p.b_hh[1][g * HH + u];
+      lstm(hdrop0 + rb, h1_prev + rb, [&](int j, int g) { return w1[j][g]; }, pb1, cs1,
+           p.cd[1] + (size_t)(t + 1) * BH, h1_prev + BH, (T*)nullptr, (T*)p.gates_d[1] + (size_t)t * B * 4 * HH, 0.f, 0u);
       q = h1_prev + BH;
-      if (!group_barrier(c)) return;
+      FW_STAMP(3);
+      group_arrive(c);
+      if (att_wg) att_load();
+      if (!group_wait(c, (int*)c.smem)) return;
+      FW_STAMP(4);
     }
     T* cvec = (T*)p.cvec_all + (size_t)t * BH;
-    nmt_attn_phase<SAFE>(c, p, q, p.attn_all + (size_t)t * B * p.S, cvec);
-    if (!group_barrier(c)) return;
+    if (att_wg) attention(q, p.attn_all + (size_t)t * B * p.S, cvec);
+    FW_STAMP(5);
+    group_arrive(c);
+    // linear_out's slice (4 KB per workgroup, L2-resident) is re-read every step while the workgroup waits for the others: as
+    // 16 resident registers it made the LSTM phases spill
+    u32x4 wo[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int ks = c.wave + NWAVE * j;
+      wo[j] = ws_wfrag(p.attn_out_w, 2 * HH, c.u0 + c.l15, (ks >> 4) * HH + (ks & 15) * 32, c.lq);
+    }
+    if (!group_wait(c, (int*)c.smem)) return;
+    FW_STAMP(6);
     {  // out = dropout(tanh(linear_out([c ; q])))
       u32x4 af[4];
       load_a(cvec + rb, q + rb, af);
@@ -346,28 +439,24 @@ __device__ __forceinline__ void nmt_dec_ws_steps(const UicNmtDecParams& p, Ctx& 
       for (int j = 0; j < 4; ++j) acc = Mma<T>::run(af[j], wo[j], acc);
       red[c.wave * 64 + c.lane] = acc;
       __syncthreads();
-      if (owner) {
-        f32x4 sres = red[c.lane];
+      if (fin) {
+        float sres = ((const float*)(red + c.lane))[c.wave];
 #pragma unroll
-        for (int w = 1; w < NWAVE; ++w) sres += red[w * 64 + c.lane];
-        const float inv_keep = p.drop_p > 0.f ? 1.f / (1.f - p.drop_p) : 1.f;
-        T* out_pre = (T*)p.out_pre + (size_t)t * BH;
-        T* out = (T*)p.out_all + (size_t)(t + 1) * BH;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int rr = 4 * c.lq + r;
-          if (rr < c.nrow) {
-            const unsigned o = (unsigned)((c.rbegin + rr) * HH) + u;
-            const float v = uic_tanh<T>(sres[r]);
-            out_pre[o] = uic_from_f<T>(v);
-            st_x<SAFE>(out + o, p.drop_p > 0.f ? v * uic_drop_scale(p.seed, NMT_SITE_OUT(t), o, p.drop_p, inv_keep) : v);
-          }
+        for (int w = 1; w < NWAVE; ++w) sres += ((const float*)(red + w * 64 + c.lane))[c.wave];
+        if (valid) {
+          const unsigned o = nnw + u;
+          const float v = uic_tanh<T>(sres);
+          ((T*)p.out_pre)[(size_t)t * BH + o] = uic_from_f<T>(v);
+          st_x<SAFE>((T*)p.out_all + (size_t)(t + 1) * BH + o, p.drop_p > 0.f ? v * uic_drop_scale(p.seed, NMT_SITE_OUT(t), o, p.drop_p, inv_keep) : v);
         }
       }
       __syncthreads();
     }
+    FW_STAMP(7);
     if (!group_barrier(c)) return;
+    FW_STAMP(8);
   }
+#undef FW_STAMP
 }
 
 __global__ __launch_bounds__(NTH) void nmt_dec_ws_kernel(const UicNmtDecParams p) {

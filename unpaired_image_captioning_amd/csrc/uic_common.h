@@ -409,6 +409,7 @@ struct UicNmtDecParams {
   int sync_zeroed;                  // the caller has already cleared `sync` for this launch (uic_zero_list_launch with its other buffers)
   unsigned* status; int force_safe;
   int row0, Nrows;                   // 0, B
+  unsigned long long* dbg;           // optional (UIC_REC_STAMPS): [256 workgroups][Td][16] s_memrealtime stamps (100 MHz)
 };
 // its BPTT (2 layers, batch <= 128): the chain's per-step buffers, plus two step-indexed exchange slabs
 struct UicNmtDecBwdParams {
