@@ -545,11 +545,12 @@ __device__ __forceinline__ void nmt_dec_bwd_steps(const UicNmtDecBwdParams& p, C
     __syncthreads();
   };
   // d gates [nrow, 4 x 512] (exchanged) x the resident slice -> this workgroup's columns of both halves
-  auto dgemm = [&](const T* dg, auto wfrag, float (&out)[2]) {
+  auto dgemm = [&](const T* dg, auto wfrag, float (&out)[2], auto after_loads) {
     const __amdgpu_buffer_rsrc_t ra = rsrc_of(dg);
     u32x4 af[16];
 #pragma unroll
     for (int j = 0; j < 16; ++j) af[j] = bload<true>(ra, (unsigned)((arow * 4 * HH + (c.wave + BW_NW * j) * 32 + c.lq * 8) * 2), 0);
+    after_loads();                                  // (requests that may return after the fragments: loads come back in issue order)
     f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
 #pragma unroll
     for (int j = 0; j < 16; ++j)
@@ -602,6 +603,24 @@ __device__ __forceinline__ void nmt_dec_bwd_steps(const UicNmtDecBwdParams& p, C
     }
   };
   if (HOIST && att_wg) att_load();
+  // Phase A's operands that do not depend on the exchange -- the generator's d out (f32, HBM) and the forward pass's tanh outputs
+  // -- are requested a step ahead, behind phase D2's fragment loads.
+  float4 ao0[4], ao1[4];
+  uint4 aop[4];
+  auto a_prefetch = [&](int t) {
+    const float* d_out = p.d_out_all + (size_t)t * BH;
+    const T* out_pre = (const T*)p.out_pre + (size_t)t * BH;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const unsigned e = (unsigned)((c.rbegin + arow) * HH + (c.wave + BW_NW * j) * 32 + c.lq * 8);
+      ao0[j] = *(const float4*)(d_out + e);
+      ao1[j] = *(const float4*)(d_out + e + 4);
+      aop[j] = *(const uint4*)(out_pre + e);
+    }
+  };
+  constexpr bool PREA = MAXR <= 8;          // (with 64 source positions' operands in flight in phase B there are no registers for it)
+  if (PREA) a_prefetch(p.Td - 1);
+  float att_al = 0.f;                      // phase B: the forward pass's attention weight of source position `lane` of this workgroup's row
 
 #define BW_STAMP(i) do { if (dbg && c.tid == 0) dbg[i] = __builtin_amdgcn_s_memrealtime(); } while (0)
   for (int t = p.Td - 1; t >= 0; --t) {
@@ -614,16 +633,15 @@ __device__ __forceinline__ void nmt_dec_bwd_steps(const UicNmtDecBwdParams& p, C
     cell_load(0, t, q0);
     float dq_lin = 0.f;
     {  // ---- phase A
-      const float* d_out = p.d_out_all + (size_t)t * BH;
-      const T* out_pre = (const T*)p.out_pre + (size_t)t * BH;
       T* d_pre = (T*)p.d_pre_all + (size_t)t * BH;
+      if (!PREA) a_prefetch(t);
       const __amdgpu_buffer_rsrc_t rf = rsrc_of(p.dfeed_x + (size_t)(last ? t : t + 1) * BH);
       u32x4 af[4];
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         const int k0 = (c.wave + BW_NW * j) * 32 + c.lq * 8;
         const unsigned e = (unsigned)((c.rbegin + arow) * HH + k0);
-        const float4 o0 = *(const float4*)(d_out + e), o1 = *(const float4*)(d_out + e + 4);
+        const float4 o0 = ao0[j], o1 = ao1[j];
         float g[8] = {o0.x, o0.y, o0.z, o0.w, o1.x, o1.y, o1.z, o1.w};
         if (!last) {
           const u32x4 f0 = bload<true>(rf, e * 4u, 0), f1 = bload<true>(rf, e * 4u + 16u, 0);
@@ -631,7 +649,7 @@ __device__ __forceinline__ void nmt_dec_bwd_steps(const UicNmtDecBwdParams& p, C
           g[4] += __uint_as_float(f1.x); g[5] += __uint_as_float(f1.y); g[6] += __uint_as_float(f1.z); g[7] += __uint_as_float(f1.w);
         }
         float op[8];
-        uic_unpack<T>(*(const uint4*)(out_pre + e), op);
+        uic_unpack<T>(aop[j], op);
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
           if (p.drop_p > 0.f) g[k] *= uic_drop_scale(p.seed, NMT_SITE_OUT(t), e + (unsigned)k, p.drop_p, inv_keep);
@@ -654,21 +672,26 @@ __device__ __forceinline__ void nmt_dec_bwd_steps(const UicNmtDecBwdParams& p, C
       dq_lin = out[1];
     }
     BW_STAMP(1);
-    if (!group_barrier(c)) return;
+    group_arrive(c);
+    if (att_wg) {                          // (not exchanged: requested while the workgroup waits for the others)
+      if (!HOIST) att_load();
+      att_al = c.lane < S ? p.attn_all[((size_t)t * B + (c.rbegin + c.rank)) * S + c.lane] : 0.f;
+    }
+    if (!group_wait(c, (int*)c.smem)) return;
     BW_STAMP(2);
     if (att_wg) {  // ---- phase B: attention backward of row `rank` of the group (csrc/nmt.hip gattn_bwd_step_fast_kernel)
       const int b = c.rbegin + c.rank;
-      float* s_dc = (float*)c.smem + 64;       // [HH]
-      float* s_a = s_dc + HH;                  // [64]
-      float* s_da = s_a + 64;                  // [64]
+      float* s_da = (float*)c.smem + 64;       // [64]
       float* s_red = s_da + 64;                // [BW_NW][HH]
-      if (!HOIST) att_load();
-      if (c.wave < 2) {                        // d c of the row: written by the other workgroups in phase A
-        const u32x4 v = bload<true>(rsrc_of(p.d_cq_all + (size_t)t * B * 2 * HH), (unsigned)((b * 2 * HH + c.tid * 4) * 4), 0);
-        *(u32x4*)(s_dc + c.tid * 4) = v;
+      // d c of the row (written by the other workgroups in phase A): every wave reads its own copy in the layout of its products
+      float dcv[8];
+      {
+        const __amdgpu_buffer_rsrc_t rd = rsrc_of(p.d_cq_all + (size_t)t * B * 2 * HH);
+        const unsigned o = (unsigned)((b * 2 * HH + c.lane * 8) * 4);
+        const u32x4 d0 = bload<true>(rd, o, 0), d1 = bload<true>(rd, o + 16u, 0);
+        dcv[0] = __uint_as_float(d0.x); dcv[1] = __uint_as_float(d0.y); dcv[2] = __uint_as_float(d0.z); dcv[3] = __uint_as_float(d0.w);
+        dcv[4] = __uint_as_float(d1.x); dcv[5] = __uint_as_float(d1.y); dcv[6] = __uint_as_float(d1.z); dcv[7] = __uint_as_float(d1.w);
       }
-      if (c.tid < S) s_a[c.tid] = p.attn_all[((size_t)t * B + b) * S + c.tid];
-      __syncthreads();
 #pragma unroll
       for (int uu = 0; uu < MAXR; ++uu) {
         const int sp = c.wave + BW_NW * uu;
@@ -677,33 +700,29 @@ __device__ __forceinline__ void nmt_dec_bwd_steps(const UicNmtDecBwdParams& p, C
           uic_unpack<T>(cr[uu], f);
           float pr = 0.f;
 #pragma unroll
-          for (int k = 0; k < 8; ++k) pr += f[k] * s_dc[c.lane * 8 + k];
+          for (int kk = 0; kk < 8; ++kk) pr += f[kk] * dcv[kk];
           pr = uic_wave_sum(pr);
           if (c.lane == 0) s_da[sp] = pr;
         }
       }
       __syncthreads();
-      float wbar = 0.f;
-      for (int sp = 0; sp < S; ++sp) wbar += s_a[sp] * s_da[sp];
-      __syncthreads();
-      if (c.tid < S) {
-        const float ds = s_a[c.tid] * (s_da[c.tid] - wbar);
-        s_da[c.tid] = ds;
-        p.dscore_all[((size_t)t * B + b) * S + c.tid] = ds;
-      }
-      __syncthreads();
+      // softmax backward in the lanes (S <= 64): d score[s] = a[s] (d a[s] - sum_s' a[s'] d a[s'])
+      const float da_l = c.lane < S ? s_da[c.lane] : 0.f;
+      const float wbar = uic_wave_sum(att_al * da_l);
+      const float ds_l = att_al * (da_l - wbar);
+      if (c.wave == 0 && c.lane < S) p.dscore_all[((size_t)t * B + b) * S + c.lane] = ds_l;
       float a0[4] = {0.f, 0.f, 0.f, 0.f}, a1[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int uu = 0; uu < MAXR; ++uu) {
         const int sp = c.wave + BW_NW * uu;
+        const float a = __shfl(ds_l, sp & 63, 64);
         if (sp < S) {
-          const float a = s_da[sp];
           a0[0] += a * wr[uu][0].x; a0[1] += a * wr[uu][0].y; a0[2] += a * wr[uu][0].z; a0[3] += a * wr[uu][0].w;
           a1[0] += a * wr[uu][1].x; a1[1] += a * wr[uu][1].y; a1[2] += a * wr[uu][1].z; a1[3] += a * wr[uu][1].w;
         }
       }
 #pragma unroll
-      for (int k = 0; k < 4; ++k) { s_red[c.wave * HH + c.lane * 4 + k] = a0[k]; s_red[c.wave * HH + (c.lane + 64) * 4 + k] = a1[k]; }
+      for (int kk = 0; kk < 4; ++kk) { s_red[c.wave * HH + c.lane * 4 + kk] = a0[kk]; s_red[c.wave * HH + (c.lane + 64) * 4 + kk] = a1[kk]; }
       __syncthreads();
 #pragma unroll
       for (int half = 0; half < 2; ++half) {                   // (HH = 2 BW_NTH: two columns per thread)
@@ -729,7 +748,7 @@ __device__ __forceinline__ void nmt_dec_bwd_steps(const UicNmtDecBwdParams& p, C
     BW_STAMP(6);
     {  // ---- phase C2
       float out[2];
-      dgemm((const T*)p.dg_d[1] + (size_t)t * B * 4 * HH + 4 * rb, [&](int j, int h) { return w1t[j][h]; }, out);
+      dgemm((const T*)p.dg_d[1] + (size_t)t * B * 4 * HH + 4 * rb, [&](int j, int h) { return w1t[j][h]; }, out, [] {});
       dx1 = out[0]; dh1_rec = out[1];
     }
     {  // ---- phase D1: layer 0's cell backward (its h went through the inter-layer dropout)
@@ -742,7 +761,8 @@ __device__ __forceinline__ void nmt_dec_bwd_steps(const UicNmtDecBwdParams& p, C
     BW_STAMP(8);
     {  // ---- phase D2
       float out[2];
-      dgemm((const T*)p.dg_d[0] + (size_t)t * B * 4 * HH + 4 * rb, [&](int j, int h) { return w0t[((c.wave * 16 + j) * 2 + h) * 64 + c.lane]; }, out);
+      dgemm((const T*)p.dg_d[0] + (size_t)t * B * 4 * HH + 4 * rb, [&](int j, int h) { return w0t[((c.wave * 16 + j) * 2 + h) * 64 + c.lane]; }, out,
+            [&] { if (PREA && t > 0) a_prefetch(t - 1); });
       if (valid) st_x<SAFE>(p.dfeed_x + (size_t)t * BH + nnw + u, out[0]);
       dh0_rec = out[1];
     }
