@@ -32,7 +32,7 @@ for b in range(B):
     tgt[tl[b] - 1, b] = 3; tgt[tl[b]:, b] = 0
 batch = argparse.Namespace(src=src.unsqueeze(2).cuda(), tgt=tgt.cuda(), lengths=lengths.view(1, -1))
 ntok = int((tgt[1:] != 0).sum())
-for _ in range(3):
+for _ in range(15):                      # (the first process on a fresh box needs more than a few steps to reach its pace)
     tr.train_nmt(batch)
 torch.cuda.synchronize(); t0 = time.perf_counter()
 for _ in range(a.steps):

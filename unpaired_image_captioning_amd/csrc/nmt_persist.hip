@@ -793,7 +793,7 @@ __global__ __launch_bounds__(BW_NTH) void nmt_dec_bwd_kernel(const UicNmtDecBwdP
 // ---------------------------------------------------------------------------------------------------
 // Encoder layer, forward (struct UicNmtEncParams in uic_common.h).  Per iteration ONE group barrier: the recurrent GEMM
 // [<= 16 rows] x [K 256] x [64 gate columns] against a register-resident slice (8 k-steps, one per wave: 16 registers), partial
-// tiles summed through LDS, cell update by wave 0, h exchanged.  30 iterations replace 2 x 30 dependent launches.
+// tiles summed through LDS, cell update by waves 0-3 (a row of every 4-row group each), h exchanged.  30 iterations replace 2 x 30 dependent launches.
 constexpr int ENC_HD = HH / 2;
 
 template <bool SAFE>
@@ -807,61 +807,62 @@ __device__ __forceinline__ void nmt_enc_fwd_steps(const UicNmtEncParams& p, Ctx&
 #pragma unroll
   for (int g = 0; g < 4; ++g) wf[g] = ws_wfrag(p.w_hh[dir], ENC_HD, g * ENC_HD + u0 + c.l15, c.wave * 32, c.lq);
   const int arow = c.l15 < c.nrow ? c.l15 : c.nrow - 1;
-  const bool owner = c.wave == 0;
+  // the cell update is spread over waves 0-3: wave w finishes accumulator component w, i.e. row 4 lq + w, unit u, and keeps that
+  // element's cell state in a register
+  const bool fin = c.wave < 4;
+  const int rw = 4 * c.lq + (c.wave & 3);
+  const int row = c.rbegin + (rw < c.nrow ? rw : c.nrow - 1);
   f32x4* red = (f32x4*)c.smem;
   const float* gx = p.gx[dir];
   float* cst = p.c[dir];
   T* gates = (T*)p.gates[dir];
   T* xo = (T*)p.x_out;
+  // this element's share of W_ih x + b (f32, HBM): requested one iteration ahead, behind the iteration's A fragment
+  float pvn[4];
+  auto load_pv = [&](int k) {
+    const int st = dir == 0 ? k : S - 1 - k;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) pvn[g] = gx[((size_t)st * B + row) * (4 * ENC_HD) + g * ENC_HD + u];
+  };
+  load_pv(0);
+  float cs = cst[((size_t)(dir == 0 ? 0 : S + 1) * B + row) * ENC_HD + u];      // (the zeroed slot in front of the first step)
   for (int k = 0; k < S; ++k) {
     asm volatile("" : "+v"(c.lane), "+v"(c.l15), "+v"(c.lq), "+v"(c.tid));
     const int st = dir == 0 ? k : S - 1 - k;
     const int prev = dir == 0 ? st : st + 2;         // slot of the previous state in this direction
     const int alive = p.nb[st];
-    // the owner lanes' operands of the cell update first: their latency passes behind the GEMM
-    float pv[4][4], cp[4];
-    if (owner) {
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int row = c.rbegin + min(4 * c.lq + r, c.nrow - 1);
-        cp[r] = cst[((size_t)prev * B + row) * ENC_HD + u];
-#pragma unroll
-        for (int g = 0; g < 4; ++g) pv[r][g] = gx[((size_t)st * B + row) * (4 * ENC_HD) + g * ENC_HD + u];
-      }
-    }
     const u32x4 af = bload<true>(rsrc_of(xo + (size_t)prev * B * HH), (unsigned)(((c.rbegin + arow) * HH + dir * ENC_HD + c.wave * 32 + c.lq * 8) * 2), 0);
+    const float pv[4] = {pvn[0], pvn[1], pvn[2], pvn[3]};
+    if (k + 1 < S) load_pv(k + 1);
     f32x4 acc[4];
 #pragma unroll
     for (int g = 0; g < 4; ++g) acc[g] = Mma<T>::run(af, wf[g], f32x4{0.f, 0.f, 0.f, 0.f});
 #pragma unroll
     for (int g = 0; g < 4; ++g) red[(c.wave * 4 + g) * 64 + c.lane] = acc[g];
     __syncthreads();
-    if (owner) {
-      f32x4 s[4];
+    if (fin) {
+      float sg[4];
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
-        s[g] = red[g * 64 + c.lane];
+        float v = ((const float*)(red + g * 64 + c.lane))[c.wave];
 #pragma unroll
-        for (int w = 1; w < NWAVE; ++w) s[g] += red[(w * 4 + g) * 64 + c.lane];
+        for (int w = 1; w < NWAVE; ++w) v += ((const float*)(red + (w * 4 + g) * 64 + c.lane))[c.wave];
+        sg[g] = v;
       }
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int rr = 4 * c.lq + r;
-        const int row = c.rbegin + rr;
-        if (rr < c.nrow && row < alive) {
-          const float gi = uic_sigmoid_t<T>(s[0][r] + pv[r][0]);
-          const float gf = uic_sigmoid_t<T>(s[1][r] + pv[r][1]);
-          const float gg = uic_tanh<T>(s[2][r] + pv[r][2]);
-          const float go = uic_sigmoid_t<T>(s[3][r] + pv[r][3]);
-          const float cn = gf * cp[r] + gi * gg;
-          cst[((size_t)(st + 1) * B + row) * ENC_HD + u] = cn;
-          st_x<SAFE>(xo + ((size_t)(st + 1) * B + row) * HH + dir * ENC_HD + u, go * uic_tanh<T>(cn));
-          T* G = gates + ((size_t)st * B + row) * (4 * ENC_HD) + u;
-          __builtin_nontemporal_store(uic_from_f<T>(gi), G);
-          __builtin_nontemporal_store(uic_from_f<T>(gf), G + ENC_HD);
-          __builtin_nontemporal_store(uic_from_f<T>(gg), G + 2 * ENC_HD);
-          __builtin_nontemporal_store(uic_from_f<T>(go), G + 3 * ENC_HD);
-        }
+      if (rw < c.nrow && row < alive) {
+        const float gi = uic_sigmoid_t<T>(sg[0] + pv[0]);
+        const float gf = uic_sigmoid_t<T>(sg[1] + pv[1]);
+        const float gg = uic_tanh<T>(sg[2] + pv[2]);
+        const float go = uic_sigmoid_t<T>(sg[3] + pv[3]);
+        const float cn = gf * cs + gi * gg;
+        cs = cn;
+        cst[((size_t)(st + 1) * B + row) * ENC_HD + u] = cn;
+        st_x<SAFE>(xo + ((size_t)(st + 1) * B + row) * HH + dir * ENC_HD + u, go * uic_tanh<T>(cn));
+        T* G = gates + ((size_t)st * B + row) * (4 * ENC_HD) + u;
+        __builtin_nontemporal_store(uic_from_f<T>(gi), G);
+        __builtin_nontemporal_store(uic_from_f<T>(gf), G + ENC_HD);
+        __builtin_nontemporal_store(uic_from_f<T>(gg), G + 2 * ENC_HD);
+        __builtin_nontemporal_store(uic_from_f<T>(go), G + 3 * ENC_HD);
       }
     }
     __syncthreads();
@@ -892,46 +893,50 @@ __device__ __forceinline__ void nmt_enc_bwd_steps(const UicNmtEncParams& p, Ctx&
 #pragma unroll
   for (int j = 0; j < 4; ++j) wt[j] = ws_wfrag(p.w_hh[dir], 4 * ENC_HD, u0 + c.l15, (c.wave + NWAVE * j) * 32, c.lq);
   const int arow = c.l15 < c.nrow ? c.l15 : c.nrow - 1;
-  const bool owner = c.wave == 0;
+  // element-wise work spread over waves 0-3 (wave w: accumulator component w = row 4 lq + w, unit u); d h and d c of that
+  // element are carried in registers
+  const bool fin = c.wave < 4;
+  const int rw = 4 * c.lq + (c.wave & 3);
+  const int row = c.rbegin + (rw < c.nrow ? rw : c.nrow - 1);
   f32x4* red = (f32x4*)c.smem;
   const float* cst = p.c[dir];
   const T* gates = (const T*)p.gates[dir];
   T* dgs = (T*)p.dgates[dir];
-  float dh[4] = {0.f, 0.f, 0.f, 0.f}, dc[4] = {0.f, 0.f, 0.f, 0.f};
-  if (owner) {
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int row = c.rbegin + min(4 * c.lq + r, c.nrow - 1);
-      dh[r] = p.dh_init[(size_t)row * p.ld_dh_init + dir * ENC_HD + u];
-      dc[r] = p.dc_init[(size_t)row * p.ld_dc_init + dir * ENC_HD + u];
-    }
+  float dh = 0.f, dc = 0.f;
+  if (fin) {
+    dh = p.dh_init[(size_t)row * p.ld_dh_init + dir * ENC_HD + u];
+    dc = p.dc_init[(size_t)row * p.ld_dc_init + dir * ENC_HD + u];
   }
+  // The cell backward's operands (the forward pass's gates and cell states, the gradient from the layer above) do not depend on
+  // this launch: requested one iteration ahead, behind the iteration's A fragments -- requested where they are used they are a
+  // memory latency per iteration on the critical path.
+  struct Ops { float gi, gf, gg, go, cc, cp, dtop; };
+  auto load_ops = [&](int k, Ops& q) {
+    const int st = dir == 0 ? k : S - 1 - k;
+    const int prev = dir == 0 ? st : st + 2;
+    const T* G = gates + ((size_t)st * B + row) * (4 * ENC_HD) + u;
+    q.gi = uic_to_f(G[0]); q.gf = uic_to_f(G[ENC_HD]); q.gg = uic_to_f(G[2 * ENC_HD]); q.go = uic_to_f(G[3 * ENC_HD]);
+    q.cc = cst[((size_t)(st + 1) * B + row) * ENC_HD + u];
+    q.cp = cst[((size_t)prev * B + row) * ENC_HD + u];
+    q.dtop = p.d_top[((size_t)st * B + row) * HH + dir * ENC_HD + u];
+  };
+  Ops q, qn;
+  if (fin) load_ops(S - 1, q);
   for (int k = S - 1; k >= 0; --k) {
     asm volatile("" : "+v"(c.lane), "+v"(c.l15), "+v"(c.lq), "+v"(c.tid));
     const int st = dir == 0 ? k : S - 1 - k;
-    const int prev = dir == 0 ? st : st + 2;
     const int alive = p.nb[st];
-    if (owner) {
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int rr = 4 * c.lq + r;
-        const int row = c.rbegin + rr;
-        if (rr < c.nrow && row < alive) {
-          const T* G = gates + ((size_t)st * B + row) * (4 * ENC_HD) + u;
-          const float gi = uic_to_f(G[0]), gf = uic_to_f(G[ENC_HD]), gg = uic_to_f(G[2 * ENC_HD]), go = uic_to_f(G[3 * ENC_HD]);
-          const float cc = cst[((size_t)(st + 1) * B + row) * ENC_HD + u], cp = cst[((size_t)prev * B + row) * ENC_HD + u];
-          const float dht = p.d_top[((size_t)st * B + row) * HH + dir * ENC_HD + u] + dh[r];
-          const float tc = uic_tanh<T>(cc);
-          const float d = dc[r] + dht * go * (1.f - tc * tc);
-          const float d_o = dht * tc;
-          T* D = dgs + ((size_t)st * B + row) * (4 * ENC_HD) + u;
-          st_x<SAFE>(D, d * gg * gi * (1.f - gi));
-          st_x<SAFE>(D + ENC_HD, d * cp * gf * (1.f - gf));
-          st_x<SAFE>(D + 2 * ENC_HD, d * gi * (1.f - gg * gg));
-          st_x<SAFE>(D + 3 * ENC_HD, d_o * go * (1.f - go));
-          dc[r] = d * gf;
-        }
-      }
+    if (fin && rw < c.nrow && row < alive) {
+      const float dht = q.dtop + dh;
+      const float tc = uic_tanh<T>(q.cc);
+      const float d = dc + dht * q.go * (1.f - tc * tc);
+      const float d_o = dht * tc;
+      T* D = dgs + ((size_t)st * B + row) * (4 * ENC_HD) + u;
+      st_x<SAFE>(D, d * q.gg * q.gi * (1.f - q.gi));
+      st_x<SAFE>(D + ENC_HD, d * q.cp * q.gf * (1.f - q.gf));
+      st_x<SAFE>(D + 2 * ENC_HD, d * q.gi * (1.f - q.gg * q.gg));
+      st_x<SAFE>(D + 3 * ENC_HD, d_o * q.go * (1.f - q.go));
+      dc = d * q.gf;
     }
     if (!group_barrier(c)) return;
     {
@@ -939,20 +944,20 @@ __device__ __forceinline__ void nmt_enc_bwd_steps(const UicNmtEncParams& p, Ctx&
       u32x4 af[4];
 #pragma unroll
       for (int j = 0; j < 4; ++j) af[j] = bload<true>(ra, (unsigned)(((c.rbegin + arow) * 4 * ENC_HD + (c.wave + NWAVE * j) * 32 + c.lq * 8) * 2), 0);
+      if (fin && k > 0) load_ops(k - 1, qn);
       f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int j = 0; j < 4; ++j) acc = Mma<T>::run(af[j], wt[j], acc);
       red[c.wave * 64 + c.lane] = acc;
       __syncthreads();
-      if (owner) {
-        f32x4 sres = red[c.lane];
+      if (fin) {
+        float sres = ((const float*)(red + c.lane))[c.wave];
 #pragma unroll
-        for (int w = 1; w < NWAVE; ++w) sres += red[w * 64 + c.lane];
-#pragma unroll
-        for (int r = 0; r < 4; ++r)
-          if (c.rbegin + 4 * c.lq + r < alive) dh[r] = sres[r];       // (a row that is not alive yet keeps its initial carry)
+        for (int w = 1; w < NWAVE; ++w) sres += ((const float*)(red + w * 64 + c.lane))[c.wave];
+        if (c.rbegin + rw < alive) dh = sres;       // (a row that is not alive yet keeps its initial carry)
       }
       __syncthreads();
+      q = qn;
     }
   }
 }
