@@ -944,6 +944,38 @@ __device__ __forceinline__ void ws_run(const UicRnnFwdParams& p, Ctx& c, char* l
   load_pre(p.t0, c.wave, pvn, cpn);
 #endif
   __syncthreads();                                  // the W1 image is complete
+  // att_lstm's gate accumulators of this wave's own row tile, and the half of its K that needs no exchange at the step boundary:
+  // h_att_prev of step t + 1 is step t's h_att_new, which every workgroup has had since the barrier behind att_lstm -- so its 16
+  // k-steps are multiplied between the two halves of the step's LAST group barrier (after this workgroup's arrival, before it
+  // looks for the others'), i.e. in time that was idle; what is left behind the barrier is the h_lang_prev half.
+  f32x4 acc1[4];
+  const __amdgpu_buffer_rsrc_t rx0 = __builtin_amdgcn_make_buffer_rsrc((void*)p.xbase, 0, -1, 0x00020000);
+  auto lstm1_early = [&](unsigned o_hap_t) {
+#pragma unroll
+    for (int g = 0; g < 4; ++g) acc1[g] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (c.wave < c.MT) {
+      int ar = 16 * c.wave + c.l15;
+      ar = ar < c.nrow ? ar : c.nrow - 1;
+      const unsigned aoff = (unsigned)((ar * HH + c.lq * 8) * 2);
+      const int h0 = c.rank & 15;                   // each workgroup starts its walk over the half at an offset of its own
+      u32x4 fa[16];
+#pragma unroll
+      for (int q = 0; q < 16; ++q) fa[q] = bload<true>(rx0, aoff, o_hap_t + (unsigned)(((q + h0) & 15) * 64));
+      u32x4 fb[2][4];
+#pragma unroll
+      for (int g = 0; g < 4; ++g) fb[0][g] = w1[((16 + h0) * 4 + g) * 64 + c.lane];
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int q = 0; q < 16; ++q) {
+        const int sn = 16 + ((q + 1 + h0) & 15);    // (the last prefetch wraps and is unused)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) fb[(q + 1) & 1][g] = w1[(sn * 4 + g) * 64 + c.lane];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) acc1[g] = mma_bf16(fa[q], fb[q & 1][g], acc1[g]);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  };
   unsigned long long* dbg = p.dbg ? p.dbg + ((size_t)blockIdx.x * p.dbg_T + p.t0) * 16 : nullptr;
   for (int t = p.t0; t < p.t1; ++t) {
     asm volatile("" : "+v"(c.lane), "+v"(c.l15), "+v"(c.lq), "+v"(c.tid));
@@ -964,10 +996,13 @@ __device__ __forceinline__ void ws_run(const UicRnnFwdParams& p, Ctx& c, char* l
     const unsigned o_ctx = (unsigned)((const char*)(ctx + rb) - (const char*)p.xbase);
     if (dbg && c.tid == 0) dbg[0] = __builtin_amdgcn_s_memrealtime();
     // ---- att_lstm (:431-434): wave w = row tile w (all 32 k-steps, B fragments from LDS); tile 4: k-steps w, w+4, ...
+    // The h_att_prev half of K (k-steps 16..31) has been multiplied already (lstm1_early: at the top of the first step, else
+    // inside the previous step's last group barrier); here the h_lang_prev half, which that barrier exchanged.
+    if (DEC || t == p.t0) lstm1_early(o_hap);
     {
       // k-step s of [h_lang_prev | h_att_prev]: its slab and its byte offset inside a row
       auto a_soff = [&](int s) { return ((s >> 4) ? o_hap : o_hlp) + (unsigned)((s & 15) * 64); };
-      const int s0 = c.rank;                        // this workgroup walks the 32 k-steps starting at s0
+      const int s0 = c.rank;                        // (fifth tile: this workgroup walks its k-steps starting at s0)
       float pv5[4], cp5 = 0.f;
       const bool split5 = c.MT > WS_NW;             // an 80-row group: a fifth tile, shared by the waves (then every wave has a tile of its own too)
       if (c.wave < c.MT) {
@@ -978,77 +1013,52 @@ __device__ __forceinline__ void ws_run(const UicRnnFwdParams& p, Ctx& c, char* l
         int ar5 = 16 * WS_NW + c.l15;
         ar5 = ar5 < c.nrow ? ar5 : c.nrow - 1;
         const unsigned aoff5 = (unsigned)((ar5 * HH + c.lq * 8) * 2);
-        // WS_P1_CHUNK k-steps per chunk, two chunks of the tile's activations in flight (32: the whole tile at once); the L2
-        // latency is paid once per chunk pair and the MFMAs run as the fragments arrive (loads return in order)
-        constexpr int CK = WS_P1_CHUNK, NCK = 32 / CK, NB = NCK > 1 ? 2 : 1;
-        u32x4 fa[NB][CK];
+        const int h0 = c.rank & 15;                 // de-phased walk over the half, as lstm1_early's
+        // the whole half of the tile's activations in flight: the L2 latency is paid once and the MFMAs run as the fragments
+        // arrive (loads return in order); then the cell update's own operands
+        u32x4 fa[16];
 #pragma unroll
-        for (int q = 0; q < CK; ++q) {
-          const int sr = (q + s0) & 31;
-          fa[0][q] = bload<true>(rx, aoff, a_soff(sr));
-        }
+        for (int q = 0; q < 16; ++q) fa[q] = bload<true>(rx, aoff, o_hlp + (unsigned)(((q + h0) & 15) * 64));
 #if !WS_EARLY_PRE
         float pvn[4][4], cpn[4];
-        if (NCK == 1) load_pre(t, i, pvn, cpn);
+        load_pre(t, i, pvn, cpn);
 #endif
-        f32x4 acc[4];
-#pragma unroll
-        for (int g = 0; g < 4; ++g) acc[g] = f32x4{0.f, 0.f, 0.f, 0.f};
         // B fragments of k-step q + 1 are read from LDS while the MFMAs of k-step q run (left alone hipcc emits
         // read - wait - MFMA per fragment: an LDS round trip per MFMA, 7 us for the 128 of a tile)
         u32x4 fb[2][4];
 #pragma unroll
-        for (int g = 0; g < 4; ++g) fb[0][g] = w1[((s0 & 31) * 4 + g) * 64 + c.lane];
+        for (int g = 0; g < 4; ++g) fb[0][g] = w1[(h0 * 4 + g) * 64 + c.lane];
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int cc = 0; cc < NCK; ++cc) {
-          if (cc + 1 < NCK) {
+        for (int q = 0; q < 16; ++q) {
+          const int sn = (q + 1 + h0) & 15;         // (the last prefetch wraps to k-step h0 and is unused)
 #pragma unroll
-            for (int q = 0; q < CK; ++q) {
-              const int sr = ((cc + 1) * CK + q + s0) & 31;
-              fa[(cc + 1) & 1][q] = bload<true>(rx, aoff, a_soff(sr));
-            }
-#if !WS_EARLY_PRE
-            if (cc == 0) load_pre(t, i, pvn, cpn);
-#endif
-          } else if (split5 && NCK > 1) {
-            // the buffer that has just been consumed takes this wave's share of tile 4: k-steps wave, wave + 4, ...
+          for (int g = 0; g < 4; ++g) fb[(q + 1) & 1][g] = w1[(sn * 4 + g) * 64 + c.lane];
+#pragma unroll
+          for (int g = 0; g < 4; ++g) acc1[g] = mma_bf16(fa[q], fb[q & 1][g], acc1[g]);
+          if (q == 7 && split5) {
+            // the registers that have just been consumed take this wave's share of tile 4: k-steps wave, wave + 4, ...
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int k = 0; k < 8; ++k) {
               const int sr = c.wave + 4 * ((k + s0) & 7);
-              fa[(cc + 1) & 1][k] = bload<true>(rx, aoff5, a_soff(sr));
+              fa[k] = bload<true>(rx, aoff5, a_soff(sr));
             }
+            __builtin_amdgcn_sched_barrier(0);
           }
-          __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-          for (int q = 0; q < CK; ++q) {
-            const int qq = cc * CK + q;
-            const int sn = (qq + 1 + s0) & 31;      // (the last prefetch wraps to k-step s0 and is unused)
-#pragma unroll
-            for (int g = 0; g < 4; ++g) fb[(qq + 1) & 1][g] = w1[(sn * 4 + g) * 64 + c.lane];
-#pragma unroll
-            for (int g = 0; g < 4; ++g) acc[g] = mma_bf16(fa[cc & 1][q], fb[qq & 1][g], acc[g]);
-            if (NCK == 1 && q == 15 && split5) {
-              __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-              for (int k = 0; k < 8; ++k) {
-                const int sr = c.wave + 4 * ((k + s0) & 7);
-                fa[0][k] = bload<true>(rx, aoff5, a_soff(sr));
-              }
-              __builtin_amdgcn_sched_barrier(0);
-            }
-          }
-          __builtin_amdgcn_sched_barrier(0);
         }
-        u32x4 (&f5)[CK] = fa[NCK > 1 ? (NCK & 1) : 0];
+        __builtin_amdgcn_sched_barrier(0);
+        u32x4 (&f5)[16] = fa;
         if (dbg && c.tid == 0) dbg[8] = __builtin_amdgcn_s_memrealtime();
 #pragma unroll
         for (int r = 0; r < 4; ++r)
 #pragma unroll
           for (int g = 0; g < 4; ++g) pvn[r][g] += gfo[r][g];
-        ws_cell<SAFE>(c, i, acc, pvn, cpn, p.c_att + (size_t)(t + 1) * NH, h_att_new, (T*)nullptr,
+        ws_cell<SAFE>(c, i, acc1, pvn, cpn, p.c_att + (size_t)(t + 1) * NH, h_att_new, (T*)nullptr,
                       p.gates1 ? (T*)p.gates1 + (size_t)t * N * 4 * HH : nullptr, 0.f, 0u, 0u);
         if (dbg && c.tid == 0) dbg[9] = __builtin_amdgcn_s_memrealtime();
         if (split5) {
+          f32x4 acc[4];
 #pragma unroll
           for (int g = 0; g < 4; ++g) acc[g] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -1276,7 +1286,9 @@ __device__ __forceinline__ void ws_run(const UicRnnFwdParams& p, Ctx& c, char* l
     }
     if (dbg && c.tid == 0) dbg[7] = __builtin_amdgcn_s_memrealtime();
     if (!DEC) {
-      if (!group_barrier(c)) return;
+      group_arrive(c);
+      if (t + 1 < p.t1) lstm1_early(o_han);         // (step t + 1's h_att_prev = this step's h_att_new)
+      if (!group_wait(c, (int*)c.smem)) return;
     } else {
       group_arrive(c);
       asm volatile("" : "+v"(c.lane), "+v"(c.l15), "+v"(c.lq), "+v"(c.tid));
