@@ -51,6 +51,19 @@ def test_workspace_size_queries_and_argument_errors():
     assert lib.uic_topdown_workspace_bytes(C.byref(d)) == 0
     # null pointers are argument errors (negative), never a crash
     assert lib.uic_adam_step(None, None, None, None, 10, 1e-3, 0.9, 0.999, 1e-8, 1, 1.0, None) < 0
+    # named workspace pieces (tools read time stamps through these): inside the workspace, NULL for unknown names / bad dims
+    nd = _lib.NmtDims(B=64, S=30, T=32, H=512, W=512, layers=2, Vs=50004, Vt=50004, dtype=1, drop_p=0.3)
+    total = lib.uic_nmt_workspace_bytes(C.byref(nd))
+    base = 1 << 40                                    # (an address, never dereferenced: the call only lays the workspace out)
+    for name in (b"dec_bwd_dbg", b"dec_fwd_dbg", b"d_cq", b"dscore", b"d_pre"):
+        ptr = lib.uic_nmt_workspace_ptr(C.byref(nd), C.c_void_p(base), name)
+        assert ptr is not None and base <= ptr < base + total and ptr % 256 == 0, name
+    assert lib.uic_nmt_workspace_ptr(C.byref(nd), C.c_void_p(base), b"no such piece") is None
+    assert lib.uic_nmt_workspace_ptr(C.byref(nd), None, b"d_cq") is None
+    td = _lib.Dims(N=640, R=36, D=2048, Dfc=2048, H=512, E=512, A=512, V1=9488, T=17, dtype=1, drop_p=0.5)
+    ptr = lib.uic_topdown_workspace_ptr(C.byref(td), C.c_void_p(base), b"rnn_dbg")
+    assert ptr is not None and base <= ptr < base + ws_bf16
+    assert lib.uic_topdown_workspace_ptr(C.byref(td), C.c_void_p(base), b"no such piece") is None
 
 
 def test_weight_struct_matches_reference_state_dict_order():
