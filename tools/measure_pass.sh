@@ -65,3 +65,7 @@ timeout 300 python3 $R/tools/comm_proxy.py --steps 20 > $O/comm_proxy.txt 2>&1
 tail -4 $O/comm_proxy.txt
 timeout 200 python3 $R/tools/ab_knobs.py 0 0x200 0x600 > $O/ab_knobs.txt 2>&1
 cat $O/ab_knobs.txt
+# round 5 (second half): per-phase stamps of the pivot decoder's persistent launches; what a dependent launch costs
+timeout 300 python3 $R/tools/nmt_bwd_probe.py > $O/nmt_bwd_probe.txt 2>&1
+tail -24 $O/nmt_bwd_probe.txt
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 $R/tools/micro/chain_probe.hip -o /tmp/chain_probe 2>/dev/null && timeout 200 /tmp/chain_probe > $O/chain_probe.txt 2>&1
