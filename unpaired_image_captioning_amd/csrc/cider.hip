@@ -4,7 +4,7 @@
 // captions never leave the GPU (the reference round-trips them through the host and scores them in python loops,
 // which serialises the step).
 //
-// One wavefront per hypothesis.  A caption's words are its tokens up to and including the first 0 (array_to_str,
+// One workgroup of six waves per hypothesis (below).  A caption's words are its tokens up to and including the first 0 (array_to_str,
 // rewards.py:29-35).  For the hypothesis and then for each reference of its image:
 //   cook    lanes over the (order k, position i) n-grams: term frequency = number of equal n-grams of the caption, kept at
 //           the FIRST occurrence only (precook's dict, :13-28); tf-idf weight tf * (ref_len - log(max(1, df))) with
@@ -56,16 +56,22 @@ __device__ __forceinline__ double table_lookup(const CiderParams& p, int t0, int
   return 0.0;
 }
 
-// words of a caption row into LDS; returns the word count (tokens up to and including the first 0)
+// words of a caption row into LDS by one wave; returns the word count (tokens up to and including the first 0).  One load per
+// lane and a ballot (every lane walking the row by itself was 16 dependent loads per caption).  No barrier inside.
+__device__ __forceinline__ int load_words_wave(const int64_t* row, int L, int* tok, int lane) {
+  const int64_t v = lane < L ? row[lane] : 1;
+  const unsigned long long z = __ballot(lane < L && v == 0);
+  const int w = z ? (int)__ffsll((long long)z) : L;
+  if (lane < w) tok[lane] = (int)v;
+  return w;
+}
 __device__ __forceinline__ int load_words(const int64_t* row, int L, int* tok, int lane) {
-  int w = L;
-  for (int i = 0; i < L; ++i)
-    if (row[i] == 0) { w = i + 1; break; }
-  for (int i = lane; i < w; i += 64) tok[i] = (int)row[i];
+  const int w = load_words_wave(row, L, tok, lane);
   __syncthreads();
   return w;
 }
 
+// one wave: tf-idf weights of a caption's n-grams, kept at the first occurrence (no barrier inside)
 __device__ __forceinline__ void cook(const CiderParams& p, const int* tok, int W, double* w, unsigned char* first, int lane) {
   for (int g = lane; g < NG * MAXW; g += 64) {
     const int k = g / MAXW, i = g - k * MAXW;      // order k + 1
@@ -88,7 +94,6 @@ __device__ __forceinline__ void cook(const CiderParams& p, const int* tok, int W
     w[g] = wt;
     first[g] = f;
   }
-  __syncthreads();
 }
 
 __device__ __forceinline__ void norms(const double* w, const unsigned char* first, int W, double* norm, int lane) {
@@ -99,56 +104,74 @@ __device__ __forceinline__ void norms(const double* w, const unsigned char* firs
       if (first[k * MAXW + i]) s += w[k * MAXW + i] * w[k * MAXW + i];
     norm[k] = sqrt(s);
   }
-  __syncthreads();
 }
 
-__global__ __launch_bounds__(64) void ciderd_kernel(const CiderParams p) {
-  __shared__ int tok_h[MAXW], tok_r[MAXW];
-  __shared__ double w_h[NG * MAXW], w_r[NG * MAXW], contrib[NG * MAXW];
-  __shared__ unsigned char first_h[NG * MAXW], first_r[NG * MAXW];
-  __shared__ double norm_h[NG], norm_r[NG], score[NG];
-  const int h = blockIdx.x, lane = threadIdx.x;
+// Six waves per hypothesis: wave 0 cooks the hypothesis while waves 1..5 cook one reference each (images with more than five
+// references: rounds of five); then waves 1..5 match their reference against the hypothesis, and one lane per order adds the
+// references' values in reference order -- the same f64 operations in the same order as with one wave walking hypothesis and
+// references one after the other (263 us per launch then: a latency chain of 6 cooks + 5 matches), so scores are unchanged to the bit.
+constexpr int CW = 6, RPR = CW - 1;
+
+__global__ __launch_bounds__(64 * CW) void ciderd_kernel(const CiderParams p) {
+  __shared__ int tok[CW][MAXW];
+  __shared__ double w[CW][NG * MAXW], contrib[CW][NG * MAXW];
+  __shared__ unsigned char first[CW][NG * MAXW];
+  __shared__ double norm[CW][NG], vals[RPR][NG], score[NG];
+  __shared__ int Wd[CW];
+  const int h = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int img = (h % p.batch_size) / p.seq_per_img;
-  const int Wh = load_words(p.hyp + (size_t)h * p.L, p.L, tok_h, lane);
-  cook(p, tok_h, Wh, w_h, first_h, lane);
-  norms(w_h, first_h, Wh, norm_h, lane);
-  if (lane < NG) score[lane] = 0.0;
-  const int len_h = Wh >= 2 ? Wh - 1 : 0;
   const int r0 = p.ref_start[img], r1 = p.ref_start[img + 1];
-  for (int r = r0; r < r1; ++r) {
+  if (wave == 0 && lane < NG) score[lane] = 0.0;
+  for (int base = r0, round = 0;; base += RPR, ++round) {
+    const int r = base + wave - 1;
+    const bool hyp_turn = wave == 0 && round == 0, ref_turn = wave >= 1 && r < r1;
+    int W = 0;
+    if (hyp_turn) W = load_words_wave(p.hyp + (size_t)h * p.L, p.L, tok[0], lane);
+    if (ref_turn) W = load_words_wave(p.ref_tok + (size_t)r * p.Lr, p.Lr, tok[wave], lane);
+    if ((hyp_turn || ref_turn) && lane == 0) Wd[wave] = W;
     __syncthreads();
-    const int Wr = load_words(p.ref_tok + (size_t)r * p.Lr, p.Lr, tok_r, lane);
-    cook(p, tok_r, Wr, w_r, first_r, lane);
-    norms(w_r, first_r, Wr, norm_r, lane);
-    for (int g = lane; g < NG * MAXW; g += 64) {
-      const int k = g / MAXW, i = g - k * MAXW;
-      double c = 0.0;
-      if (first_h[g]) {
-        double wr = 0.0;
-        for (int j = 0; j + k < Wr; ++j) {
-          if (!first_r[k * MAXW + j]) continue;
-          bool m = true;
-          for (int q = 0; q <= k; ++q) m = m && tok_h[i + q] == tok_r[j + q];
-          if (m) { wr = w_r[k * MAXW + j]; break; }
+    if (hyp_turn || ref_turn) cook(p, tok[wave], W, w[wave], first[wave], lane);
+    __syncthreads();
+    if (hyp_turn || ref_turn) norms(w[wave], first[wave], W, norm[wave], lane);
+    __syncthreads();
+    const int Wh = Wd[0];
+    if (ref_turn) {
+      for (int g = lane; g < NG * MAXW; g += 64) {
+        const int k = g / MAXW, i = g - k * MAXW;
+        double c = 0.0;
+        if (first[0][g]) {
+          double wr = 0.0;
+          for (int j = 0; j + k < W; ++j) {
+            if (!first[wave][k * MAXW + j]) continue;
+            bool m = true;
+            for (int q = 0; q <= k; ++q) m = m && tok[0][i + q] == tok[wave][j + q];
+            if (m) { wr = w[wave][k * MAXW + j]; break; }
+          }
+          c = fmin(w[0][g], wr) * wr;
         }
-        c = fmin(w_h[g], wr) * wr;
+        contrib[wave][g] = c;
       }
-      contrib[g] = c;
     }
     __syncthreads();
-    if (lane < NG) {
+    if (ref_turn && lane < NG) {
       const int k = lane;
       double val = 0.0;
       for (int i = 0; i + k < Wh; ++i)
-        if (first_h[k * MAXW + i]) val += contrib[k * MAXW + i];
-      if (norm_h[k] != 0.0 && norm_r[k] != 0.0) val /= (norm_h[k] * norm_r[k]);
-      const int len_r = Wr >= 2 ? Wr - 1 : 0;
+        if (first[0][k * MAXW + i]) val += contrib[wave][k * MAXW + i];
+      if (norm[0][k] != 0.0 && norm[wave][k] != 0.0) val /= (norm[0][k] * norm[wave][k]);
+      const int len_h = Wh >= 2 ? Wh - 1 : 0, len_r = W >= 2 ? W - 1 : 0;
       val *= p.penalty[len_h - len_r + p.pen_half];
-      score[k] += val;
+      vals[wave - 1][k] = val;
     }
+    __syncthreads();
+    if (wave == 0 && lane < NG) {
+      const int n = r1 - base < RPR ? r1 - base : RPR;
+      for (int j = 0; j < n; ++j) score[lane] += vals[j][lane];
+    }
+    if (base + RPR >= r1) break;
   }
   __syncthreads();
-  if (lane == 0) {
+  if (threadIdx.x == 0) {
     double avg = ((score[0] + score[1]) + score[2]) + score[3];
     avg /= 4.0;
     avg /= (double)(r1 - r0);
@@ -286,7 +309,7 @@ int uic_ciderd_scores(const int64_t* hyp, int32_t n_hyp, int32_t L, int32_t batc
   p.ref_tok = ref_tok; p.Lr = Lr; p.ref_start = ref_start;
   p.slot_keys = slot_keys; p.slot_vals = slot_vals; p.slots = slots; p.ref_len = ref_len;
   p.penalty = penalty; p.pen_half = pen_half; p.scores = scores;
-  hipLaunchKernelGGL(ciderd_kernel, dim3(n_hyp), dim3(64), 0, (hipStream_t)stream, p);
+  hipLaunchKernelGGL(ciderd_kernel, dim3(n_hyp), dim3(64 * CW), 0, (hipStream_t)stream, p);
   UIC_LAUNCH_CHECK("ciderd_kernel");
   return UIC_OK;
 }

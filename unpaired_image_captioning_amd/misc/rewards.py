@@ -162,12 +162,20 @@ def self_critical_reward_device(scorer, gen_result, greedy_res, gts, cider_rewar
     the N caption rows."""
     N, L = gen_result.shape
     seq_per_img = N // len(gts)
-    if greedy_res.shape[0] != N:
-        greedy_res = greedy_res.repeat_interleave(N // greedy_res.shape[0], 0)
-    hyp = torch.cat([gen_result, greedy_res], 0)
     refs = upload_references(gts, gen_result.device)
     lib = _lib.load()
     reward = torch.empty(N, L, dtype=torch.float32, device=gen_result.device)
+    n_g = greedy_res.shape[0]
+    if n_g != N and bleu_reward_weight <= 0 and not getattr(scorer, 'corpus', False) and n_g % len(gts) == 0:
+        # one greedy row per image and a document-frequency table that does not depend on the hypothesis count: every distinct
+        # greedy caption is scored ONCE and its score repeated (the same f64 operations per hypothesis: identical scores)
+        s = torch.cat([scorer.scores(gen_result, gts, N, seq_per_img, refs),
+                       scorer.scores(greedy_res, gts, n_g, n_g // len(gts), refs).repeat_interleave(N // n_g)])
+        check(lib.uic_ciderd_reward(ptr(s), N, L, float(cider_reward_weight), ptr(reward), stream()), "ciderd_reward")
+        return reward
+    if n_g != N:
+        greedy_res = greedy_res.repeat_interleave(N // n_g, 0)
+    hyp = torch.cat([gen_result, greedy_res], 0)
     if bleu_reward_weight > 0:
         s = float(bleu_reward_weight) * bleu4_scores_device(hyp, gts, N, seq_per_img, refs)
         if cider_reward_weight > 0:                   # :76, in that order, f64
