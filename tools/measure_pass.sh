@@ -69,3 +69,5 @@ cat $O/ab_knobs.txt
 timeout 300 python3 $R/tools/nmt_bwd_probe.py > $O/nmt_bwd_probe.txt 2>&1
 tail -24 $O/nmt_bwd_probe.txt
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 $R/tools/micro/chain_probe.hip -o /tmp/chain_probe 2>/dev/null && timeout 200 /tmp/chain_probe > $O/chain_probe.txt 2>&1
+timeout 400 python3 $R/tools/scst_bench.py > $O/scst_bench.txt 2>&1
+tail -5 $O/scst_bench.txt
