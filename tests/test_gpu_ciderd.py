@@ -83,7 +83,7 @@ def _cider_sweep(n, seed):
 @pytest.mark.parametrize("cfg", _cider_sweep(20, 9), ids=lambda c: "cider%d" % c["idx"])
 def test_device_scores_random_sweep_vs_oracle(cfg):
     """20 seeded random configurations: captions of 1..64 tokens (hypotheses and references of different widths), tiny
-    vocabularies (many repeated n-grams and hash-table hits), 1..5 references, cached and 'corpus' document frequencies."""
+    vocabularies (many repeated n-grams and hash-table hits), 1..5 or 1..13 references, cached and 'corpus' document frequencies."""
     from unpaired_image_captioning_amd.misc import rewards
     g = np.random.default_rng(1000 + cfg["idx"])
     V, L, Lr, S = cfg["V"], cfg["L"], cfg["Lr"], cfg["S"]
@@ -94,7 +94,10 @@ def test_device_scores_random_sweep_vs_oracle(cfg):
             ln = width if g.random() > 0.6 else int(g.integers(0, width + 1))
             r[i, :ln] = g.integers(1, V + 1, ln)
         return r
-    gts = [caps(int(g.integers(1, 6)), Lr) for _ in range(cfg["n_img"])]
+    # (odd configurations: up to 13 references per image -- the kernel cooks references five at a time, one wave each, so images
+    # with 6..13 of them take two or three rounds; the greedy rows given once per image take the scored-once path)
+    max_refs = 14 if cfg["idx"] % 2 else 6
+    gts = [caps(int(g.integers(1, max_refs)), Lr) for _ in range(cfg["n_img"])]
     N = cfg["n_img"] * S
     gen, greedy = caps(N, L), caps(N, L)
     df = ref_len = None
@@ -116,6 +119,14 @@ def test_device_scores_random_sweep_vs_oracle(cfg):
     refs = [[OC.caption_words(x) for x in im] for im in gts]
     _, want_s = OC.ciderd_scores(hyps, [refs[i % N // S] for i in range(2 * N)], df, ref_len)
     assert np.abs(s - want_s).max() <= 1e-11 * max(1.0, np.abs(want_s).max()), (cfg, np.abs(s - want_s).max())
+    if df is not None and S > 1:
+        # one greedy row per image (what the eval-mode decode of identical replicas hands over): scored once, repeated -- the same
+        # reward, bit for bit, as with the S copies written out
+        g1 = greedy[::S].copy()
+        rep = np.repeat(g1, S, 0)
+        r_rep = rewards.self_critical_reward_device(sc, torch.from_numpy(gen).cuda(), torch.from_numpy(rep).cuda(), gts, 1.0)
+        r_one = rewards.self_critical_reward_device(sc, torch.from_numpy(gen).cuda(), torch.from_numpy(g1).cuda(), gts, 1.0)
+        assert torch.equal(r_rep, r_one)
 
 
 def test_get_self_critical_reward_mirror_and_errors():
