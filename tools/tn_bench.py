@@ -43,7 +43,7 @@ wsb = 256 << 20
 wsp = torch.empty(wsb, dtype=torch.uint8, device="cuda")
 shapes = [("lang / att LSTM dW, 4-step chunk", 2048, 1664, 2560), ("h2att dW, 4-step chunk", 512, 640, 2560), ("LSTM dW, 1-step chunk", 2048, 1664, 640),
           ("logit dW", 9488, 512, 10880), ("att_embed dW", 512, 2176, 23040), ("ctx2att dW", 512, 640, 23040),
-          ("fc_embed dW", 512, 2048, 640), ("att_lstm fc' columns", 2048, 512, 640), ("NMT generator dW", 50004, 512, 1984)]
+          ("fc_embed dW", 512, 2048, 640), ("att_lstm fc' columns", 2048, 512, 640), ("NMT generator dW", 50004, 512, 1984), ("NMT generator dW, rows padded to 2048", 50004, 512, 2048), ("NMT LSTM dW, rows padded", 2048, 1024, 2048)]
 if len(sys.argv) > 1:
     shapes = [s for s in shapes if any(a in s[0] for a in sys.argv[1:])]
 for name, M, N, K in shapes:

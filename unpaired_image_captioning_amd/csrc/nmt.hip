@@ -602,9 +602,12 @@ NmtLayout nmt_layout(const uic_nmt_dims& d, const uic_nmt_weights* w, void* ws) 
   L.attn_all = (float*)b.take(Td * B * S * 4);
   L.cvec_all = b.take(Td * B * H * Sz);
   L.out_pre = b.take(Td * B * H * Sz);
-  L.out_all = b.take((Td + 1) * B * H * Sz);
+  // (the generator's weight gradient is one TN GEMM over the T B target rows: they are padded with zero rows to a multiple of 128, the
+  // K granularity of the 256 x 256 ping-pong kernel -- 190 -> 135 us at configs[2]'s 1984 rows; backward() clears the padding)
+  const size_t Mdp = (Td * B + 127) & ~(size_t)127;
+  L.out_all = b.take(((Td + 1) * B + (Mdp - Td * B)) * H * Sz);
   L.logits = (float*)b.take(Td * B * Vtp * 4);
-  L.dlogits = b.take(Td * B * Vtp * Sz);
+  L.dlogits = b.take(Mdp * Vtp * Sz);
   L.row_loss = (float*)b.take(Td * B * 4);
   L.scalars = (float*)b.take(64);
   L.stats = (int*)b.take(64);
@@ -624,7 +627,7 @@ NmtLayout nmt_layout(const uic_nmt_dims& d, const uic_nmt_weights* w, void* ws) 
   L.dpre_e = b.take(S * B * W * Sz);
   L.dxe = (float*)b.take(S * B * W * 4);
   L.demb_d = (float*)b.take(Td * B * W * 4);
-  const size_t rows = rup8((S > Td ? S : Td) * B);
+  const size_t rows = rup8((S > Td ? S : Td) * B) > Mdp ? rup8((S > Td ? S : Td) * B) : Mdp;   // (the generator's padded rows: the transposing fallback of wgrad_group)
   L.tA = b.take((Vt > 4 * H ? Vt : 4 * H) * rows * Sz);
   L.tB = b.take((W + 2 * H) * rows * Sz);
   const size_t maxcols = Vtp > 4 * H ? Vtp : 4 * H;
@@ -820,13 +823,19 @@ struct Nmt {
     add(sync_block(0), (size_t)(NL + 1) * uic_rnn_persist_sync_bytes());
     return uic_zero_list_launch(ptr, nbytes, n, s);
   }
+  size_t gen_rows() const { return ((size_t)Td * B + 127) & ~(size_t)127; }
   int zero_backward_buffers(hipStream_t s) {
-    void* ptr[2 * UIC_NMT_MAX_LAYERS + 2];
-    size_t nbytes[2 * UIC_NMT_MAX_LAYERS + 2];
+    void* ptr[2 * UIC_NMT_MAX_LAYERS + 4];
+    size_t nbytes[2 * UIC_NMT_MAX_LAYERS + 4];
     int n = 0;
     for (int l = 0; l < NL; ++l)
       for (int dd = 0; dd < 2; ++dd) { ptr[n] = L.dg_e[l][dd]; nbytes[n] = ((size_t)S * B * 4 * Hd * Sz + 15) & ~(size_t)15; ++n; }
     ptr[n] = sync_block(NL + 1); nbytes[n] = (size_t)(NL + 1) * uic_rnn_persist_sync_bytes(); ++n;
+    const size_t pad = gen_rows() - (size_t)Td * B;      // zero rows behind the generator weight gradient's operands (nmt_layout)
+    if (pad) {
+      ptr[n] = offw(L.dlogits, (size_t)Td * B * Vtp, dt); nbytes[n] = pad * Vtp * Sz; ++n;
+      ptr[n] = offw(L.out_all, (size_t)(Td + 1) * B * H, dt); nbytes[n] = pad * H * Sz; ++n;
+    }
     return uic_zero_list_launch(ptr, nbytes, n, s);
   }
 
@@ -1039,7 +1048,7 @@ struct Nmt {
     {
       const UicGemmTnSeg seg{off(L.out_all, BH, dt), H, H};
       const WDest d1{G->gen_w, H, 0, H};
-      UIC_TRY(wgrad_group(L.slab, L.slab_bytes, dt, L.dlogits, Vtp, Vt, &seg, 1, Md, &d1, 1, ssg->stream, false, L.tA, L.tB));
+      UIC_TRY(wgrad_group(L.slab, L.slab_bytes, dt, L.dlogits, Vtp, Vt, &seg, 1, (int)gen_rows(), &d1, 1, ssg->stream, false, L.tA, L.tB));
     }
     UIC_TRY(uic_colsum_launch(dt, L.dlogits, Md, Vt, Vtp, G->gen_b, L.colscratch, L.colscratch_floats, ssg->stream));
     UIC_TRY(uic_check_hip(hipEventRecord(ssg->ev_done, ssg->stream), "hipEventRecord"));
