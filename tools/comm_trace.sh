@@ -5,6 +5,7 @@ R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/${1:-commtrace}
 mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
+rm -rf /tmp/ct     # (a box can be handed out again with its /tmp: never read an earlier run's trace)
 timeout 500 rocprofv3 --kernel-trace --output-format csv -d /tmp/ct -- python3 $R/tools/comm_proxy.py --steps 6 --only default4 > /tmp/ct.log 2>&1
 tail -3 /tmp/ct.log
 python3 - <<PY > $O/comm_timeline.txt

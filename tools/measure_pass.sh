@@ -6,6 +6,7 @@ R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/pass
 mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
+rm -rf /tmp/p6 /tmp/pm /tmp/mf /tmp/pr     # (a box can be handed out again with its /tmp: never read an earlier run's trace)
 timeout 400 python3 $R/bench.py > $O/bench.json 2> $O/bench.err
 tail -c 600 $O/bench.json
 timeout 200 python3 $R/bench.py --no-f32 --no-cpu-baseline --long-run 0 --rows-per-gpu-probe 80 2>/dev/null | python3 -c "import sys, json; print(json.dumps(json.loads(sys.stdin.readline())['strong_scaling_probe']))" > $O/strong_scaling_probe.json
