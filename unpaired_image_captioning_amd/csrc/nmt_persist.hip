@@ -920,7 +920,7 @@ __device__ __forceinline__ void nmt_enc_bwd_steps(const UicNmtEncParams& p, Ctx&
     q.cp = cst[((size_t)prev * B + row) * ENC_HD + u];
     q.dtop = p.d_top[((size_t)st * B + row) * HH + dir * ENC_HD + u];
   };
-  Ops q, qn;
+  Ops q = {}, qn = {};
   if (fin) load_ops(S - 1, q);
   for (int k = S - 1; k >= 0; --k) {
     asm volatile("" : "+v"(c.lane), "+v"(c.l15), "+v"(c.lq), "+v"(c.tid));
