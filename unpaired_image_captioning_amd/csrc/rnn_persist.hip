@@ -251,6 +251,106 @@ __device__ __forceinline__ void attn_phase(const Ctx& c, const UicRnnFwdParams& 
   }
 }
 
+// Round 5: the attention phase of the weight-stationary TRAINING kernel with ONE WAVE PER CAPTION ROW.  The four-waves-per-row form
+// above is a chain of dependent stages per row (head load, two workgroup barriers, an LDS reduction between the waves, the
+// softmax, another barrier, the context reduction): ~4 us of latency per row beside 2 us of arithmetic, three rows in a row for
+// half of the workgroups (17.4 us) and two for the others, who then wait in the group barrier.  Here wave w of workgroup `rank`
+// takes row rank + 32 w of the group by itself (waves 0..2; 80 rows on 96 of the group's 128 waves): no workgroup barrier, no
+// cross-wave reduction, every wave one row -- the phase is one row's arithmetic on one SIMD (~8 us, 4.8 of it v_exp / v_rcp) and
+// the same length for every workgroup.  Region rows arrive in chunks of 10 through two register buffers; att's first chunk is
+// requested before the scores so that the context starts without a load latency.  Per-region score arithmetic is that of
+// attn_scores (same order); the context is one running sum over the regions instead of four partial sums.
+template <bool SAFE>
+__device__ __forceinline__ void attn_phase_wave(const Ctx& c, const UicRnnFwdParams& p, const float* att_h, float* alpha, bf16_t* ctx) {
+  typedef bf16_t T;
+  const int R = p.R;
+  const int r = c.rank + PW * c.wave;                 // this wave's row of the group (uniform per wave)
+  if (r >= c.nrow) return;
+  const int n = c.rbegin + r;
+  constexpr int CR = 10, NCH = ATT_R / CR;
+  static_assert(NCH * CR == ATT_R, "chunks cover the region slots");
+  const T* P = (const T*)p.p_att + (size_t)n * R * HH + c.lane * 8;
+  const T* V = (const T*)p.att + (size_t)n * R * HH + c.lane * 8;
+  float* s_e = (float*)c.smem + 64 + c.wave * (4 * ATT_R);      // [R][4] row-of-16 partial scores of this wave's row (word 0: barrier flag)
+  auto load_chunk = [&](const T* base, int ch, uint4 (&q)[CR]) {
+#pragma unroll
+    for (int u = 0; u < CR; ++u) {
+      const int rr = min(ch * CR + u, R - 1);
+      const u32x4 v = *(const u32x4*)(base + (unsigned)(rr * HH));
+      q[u] = make_uint4(v.x, v.y, v.z, v.w);
+    }
+  };
+  const __amdgpu_buffer_rsrc_t rh = rsrc_of(att_h + (size_t)n * HH);
+  const u32x4 h0 = bload<true>(rh, (unsigned)(c.lane * 32), 0), h1 = bload<true>(rh, (unsigned)(c.lane * 32 + 16), 0);
+  uint4 pa[2][CR], va[2][CR];
+  load_chunk(P, 0, pa[0]);
+  load_chunk(P, 1, pa[1]);
+  load_chunk(V, 0, va[0]);
+  float ah[8], w[8];
+  ah[0] = __uint_as_float(h0.x); ah[1] = __uint_as_float(h0.y); ah[2] = __uint_as_float(h0.z); ah[3] = __uint_as_float(h0.w);
+  ah[4] = __uint_as_float(h1.x); ah[5] = __uint_as_float(h1.y); ah[6] = __uint_as_float(h1.z); ah[7] = __uint_as_float(h1.w);
+  {
+    const float4 w0 = *(const float4*)(p.w_alpha + c.lane * 8), w1 = *(const float4*)(p.w_alpha + c.lane * 8 + 4);
+    w[0] = w0.x; w[1] = w0.y; w[2] = w0.z; w[3] = w0.w; w[4] = w1.x; w[5] = w1.y; w[6] = w1.z; w[7] = w1.w;
+  }
+  const float b_alpha = p.b_alpha ? p.b_alpha[0] : 0.f;
+#pragma unroll
+  for (int ch = 0; ch < NCH; ++ch) {
+#pragma unroll
+    for (int u = 0; u < CR; ++u) {
+      const int rr = ch * CR + u;
+      float f[8];
+      uic_unpack<T>(pa[ch & 1][u], f);
+      float part = 0.f;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) part += w[j] * uic_tanh<T>(f[j] + ah[j]);
+      part = uic_row16_sum(part);
+      if (c.l15 == 0 && rr < R) s_e[rr * 4 + c.lq] = part;
+    }
+    if (ch + 2 < NCH) load_chunk(P, ch + 2, pa[ch & 1]);
+  }
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // this wave's LDS writes are done (LDS serves a wave's requests in order)
+  const float* mk = p.mask ? p.mask + (size_t)n * p.ldmask : nullptr;
+  float e = -INFINITY;
+  if (c.lane < R) {
+    const float4 qq = *(const float4*)(s_e + c.lane * 4);
+    e = (qq.x + qq.y) + (qq.z + qq.w) + b_alpha;
+  }
+  const float mx = uic_wave_max(e);
+  const float ex = c.lane < R ? __builtin_amdgcn_exp2f((e - mx) * 1.4426950408889634f) : 0.f;
+  float wgt = ex * __builtin_amdgcn_rcpf(uic_wave_sum(ex));
+  if (mk) {
+    wgt *= c.lane < R ? mk[c.lane] : 0.f;
+    wgt = wgt / uic_wave_sum(wgt);
+  }
+  if (c.lane < R) alpha[(unsigned)(n * R + c.lane)] = wgt;
+  load_chunk(V, 1, va[1]);
+  float acc[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) acc[j] = 0.f;
+#pragma unroll
+  for (int ch = 0; ch < NCH; ++ch) {
+#pragma unroll
+    for (int u = 0; u < CR; ++u) {
+      const int rr = ch * CR + u;
+      float al = __shfl(wgt, rr < ATT_R ? (rr < 64 ? rr : 0) : 0, 64);
+      if (rr >= R) al = 0.f;
+      float f[8];
+      uic_unpack<T>(va[ch & 1][u], f);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) acc[j] += al * f[j];
+    }
+    if (ch + 2 < NCH) load_chunk(V, ch + 2, va[ch & 1]);
+  }
+  T* o = ctx + (unsigned)(n * HH + c.lane * 8);
+  if (!SAFE) {
+    *(uint4*)o = uic_pack<T>(acc);
+  } else {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) st_x<SAFE>(o + j, acc[j]);
+  }
+}
+
 template <typename T, bool SAFE>
 __device__ __forceinline__ void run_steps(const UicRnnFwdParams& p, Ctx& c) {
   const int N = p.N;
@@ -1166,7 +1266,8 @@ __device__ __forceinline__ void ws_run(const UicRnnFwdParams& p, Ctx& c, char* l
     if (dbg && c.tid == 0) dbg[4] = __builtin_amdgcn_s_memrealtime();
     asm volatile("" : "+v"(c.lane), "+v"(c.l15), "+v"(c.lq), "+v"(c.tid));   // keep this phase's lane-derived values out of the others' live ranges
     // ---- attention (:544-556)
-    attn_phase<T, SAFE, WS_NW, WS_ATT_SLOTS>(c, p, att_h, p.alpha_all + (size_t)t * N * p.R, ctx);
+    if constexpr (!DEC) attn_phase_wave<SAFE>(c, p, att_h, p.alpha_all + (size_t)t * N * p.R, ctx);
+    else attn_phase<T, SAFE, WS_NW, WS_ATT_SLOTS>(c, p, att_h, p.alpha_all + (size_t)t * N * p.R, ctx);   // (the decode kernel has no registers to spare)
     if (dbg && c.tid == 0) dbg[5] = __builtin_amdgcn_s_memrealtime();
     if (!group_barrier(c)) return;
     if (dbg && c.tid == 0) dbg[6] = __builtin_amdgcn_s_memrealtime();
