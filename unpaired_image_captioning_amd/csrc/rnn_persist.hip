@@ -258,8 +258,8 @@ __device__ __forceinline__ void attn_phase(const Ctx& c, const UicRnnFwdParams& 
 // takes row rank + 32 w of the group by itself (waves 0..2; 80 rows on 96 of the group's 128 waves): no workgroup barrier, no
 // cross-wave reduction, every wave one row -- the phase is one row's arithmetic on one SIMD (~8 us, 4.8 of it v_exp / v_rcp) and
 // the same length for every workgroup.  Region rows arrive in chunks of 10 through two register buffers; att's first chunk is
-// requested before the scores so that the context starts without a load latency.  Per-region score arithmetic is that of
-// attn_scores (same order); the context is one running sum over the regions instead of four partial sums.
+// requested before the scores so that the context starts without a load latency.  The context is one running sum over the
+// regions instead of four partial sums.
 template <bool SAFE>
 __device__ __forceinline__ void attn_phase_wave(const Ctx& c, const UicRnnFwdParams& p, const float* att_h, float* alpha, bf16_t* ctx) {
   typedef bf16_t T;
@@ -294,6 +294,9 @@ __device__ __forceinline__ void attn_phase_wave(const Ctx& c, const UicRnnFwdPar
     w[0] = w0.x; w[1] = w0.y; w[2] = w0.z; w[3] = w0.w; w[4] = w1.x; w[5] = w1.y; w[6] = w1.z; w[7] = w1.w;
   }
   const float b_alpha = p.b_alpha ? p.b_alpha[0] : 0.f;
+  float ah2[8], wm2[8], wsum = 0.f;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) { ah2[j] = ah[j] * 2.8853900817779268f; wm2[j] = -2.f * w[j]; wsum += w[j]; }
 #pragma unroll
   for (int ch = 0; ch < NCH; ++ch) {
 #pragma unroll
@@ -301,9 +304,11 @@ __device__ __forceinline__ void attn_phase_wave(const Ctx& c, const UicRnnFwdPar
       const int rr = ch * CR + u;
       float f[8];
       uic_unpack<T>(pa[ch & 1][u], f);
-      float part = 0.f;
+      // w tanh(x) = w - 2 w / (e^{2x} + 1) with the constants folded in: per element one fma, v_exp, one add, v_rcp, one fma
+      float part = wsum;
 #pragma unroll
-      for (int j = 0; j < 8; ++j) part += w[j] * uic_tanh<T>(f[j] + ah[j]);
+      for (int j = 0; j < 8; ++j)
+        part = __builtin_fmaf(wm2[j], __builtin_amdgcn_rcpf(__builtin_amdgcn_exp2f(__builtin_fmaf(f[j], 2.8853900817779268f, ah2[j])) + 1.f), part);
       part = uic_row16_sum(part);
       if (c.l15 == 0 && rr < R) s_e[rr * 4 + c.lq] = part;
     }
