@@ -260,14 +260,27 @@ __device__ __forceinline__ void attn_phase(const Ctx& c, const UicRnnFwdParams& 
 // the same length for every workgroup.  Region rows arrive in chunks of 10 through two register buffers; att's first chunk is
 // requested before the scores so that the context starts without a load latency.  The context is one running sum over the
 // regions instead of four partial sums.
+constexpr int AW_CR = 10;                             // regions per chunk of attn_phase_wave
+// the first chunk of the wave's p_att rows: requested between the two halves of the group barrier in front of the phase
+__device__ __forceinline__ void attn_wave_preload(const Ctx& c, const UicRnnFwdParams& p, uint4 (&q)[AW_CR]) {
+  const int r = c.rank + PW * c.wave;
+  if (r >= c.nrow) return;
+  const bf16_t* P = (const bf16_t*)p.p_att + (size_t)(c.rbegin + r) * p.R * HH + c.lane * 8;
+#pragma unroll
+  for (int u = 0; u < AW_CR; ++u) {
+    const u32x4 v = *(const u32x4*)(P + (unsigned)(min(u, p.R - 1) * HH));
+    q[u] = make_uint4(v.x, v.y, v.z, v.w);
+  }
+}
 template <bool SAFE>
-__device__ __forceinline__ void attn_phase_wave(const Ctx& c, const UicRnnFwdParams& p, const float* att_h, float* alpha, bf16_t* ctx) {
+__device__ __forceinline__ void attn_phase_wave(const Ctx& c, const UicRnnFwdParams& p, const float* att_h, float* alpha, bf16_t* ctx,
+                                                const uint4 (&pre)[AW_CR]) {
   typedef bf16_t T;
   const int R = p.R;
   const int r = c.rank + PW * c.wave;                 // this wave's row of the group (uniform per wave)
   if (r >= c.nrow) return;
   const int n = c.rbegin + r;
-  constexpr int CR = 10, NCH = ATT_R / CR;
+  constexpr int CR = AW_CR, NCH = ATT_R / CR;
   static_assert(NCH * CR == ATT_R, "chunks cover the region slots");
   const T* P = (const T*)p.p_att + (size_t)n * R * HH + c.lane * 8;
   const T* V = (const T*)p.att + (size_t)n * R * HH + c.lane * 8;
@@ -283,7 +296,8 @@ __device__ __forceinline__ void attn_phase_wave(const Ctx& c, const UicRnnFwdPar
   const __amdgpu_buffer_rsrc_t rh = rsrc_of(att_h + (size_t)n * HH);
   const u32x4 h0 = bload<true>(rh, (unsigned)(c.lane * 32), 0), h1 = bload<true>(rh, (unsigned)(c.lane * 32 + 16), 0);
   uint4 pa[2][CR], va[2][CR];
-  load_chunk(P, 0, pa[0]);
+#pragma unroll
+  for (int u = 0; u < CR; ++u) pa[0][u] = pre[u];
   load_chunk(P, 1, pa[1]);
   load_chunk(V, 0, va[0]);
   float ah[8], w[8];
@@ -343,7 +357,7 @@ __device__ __forceinline__ void attn_phase_wave(const Ctx& c, const UicRnnFwdPar
       float f[8];
       uic_unpack<T>(va[ch & 1][u], f);
 #pragma unroll
-      for (int j = 0; j < 8; ++j) acc[j] += al * f[j];
+      for (int j = 0; j < 8; ++j) acc[j] = __builtin_fmaf(al, f[j], acc[j]);   // (explicit: the SAFE and the XCD-local instantiation must round alike)
     }
     if (ch + 2 < NCH) load_chunk(V, ch + 2, va[ch & 1]);
   }
@@ -1267,12 +1281,21 @@ __device__ __forceinline__ void ws_run(const UicRnnFwdParams& p, Ctx& c, char* l
       }
     }
     if (dbg && c.tid == 0) dbg[3] = __builtin_amdgcn_s_memrealtime();
-    if (!group_barrier(c)) return;
-    if (dbg && c.tid == 0) dbg[4] = __builtin_amdgcn_s_memrealtime();
-    asm volatile("" : "+v"(c.lane), "+v"(c.l15), "+v"(c.lq), "+v"(c.tid));   // keep this phase's lane-derived values out of the others' live ranges
     // ---- attention (:544-556)
-    if constexpr (!DEC) attn_phase_wave<SAFE>(c, p, att_h, p.alpha_all + (size_t)t * N * p.R, ctx);
-    else attn_phase<T, SAFE, WS_NW, WS_ATT_SLOTS>(c, p, att_h, p.alpha_all + (size_t)t * N * p.R, ctx);   // (the decode kernel has no registers to spare)
+    if constexpr (!DEC) {
+      group_arrive(c);
+      asm volatile("" : "+v"(c.lane), "+v"(c.l15), "+v"(c.lq), "+v"(c.tid));
+      uint4 apre[AW_CR];
+      attn_wave_preload(c, p, apre);                  // (not exchanged data: its latency passes while the workgroup waits for the others)
+      if (!group_wait(c, (int*)c.smem)) return;
+      if (dbg && c.tid == 0) dbg[4] = __builtin_amdgcn_s_memrealtime();
+      attn_phase_wave<SAFE>(c, p, att_h, p.alpha_all + (size_t)t * N * p.R, ctx, apre);
+    } else {                                          // (the decode kernel has no registers to spare)
+      if (!group_barrier(c)) return;
+      if (dbg && c.tid == 0) dbg[4] = __builtin_amdgcn_s_memrealtime();
+      asm volatile("" : "+v"(c.lane), "+v"(c.l15), "+v"(c.lq), "+v"(c.tid));   // keep this phase's lane-derived values out of the others' live ranges
+      attn_phase<T, SAFE, WS_NW, WS_ATT_SLOTS>(c, p, att_h, p.alpha_all + (size_t)t * N * p.R, ctx);
+    }
     if (dbg && c.tid == 0) dbg[5] = __builtin_amdgcn_s_memrealtime();
     if (!group_barrier(c)) return;
     if (dbg && c.tid == 0) dbg[6] = __builtin_amdgcn_s_memrealtime();
