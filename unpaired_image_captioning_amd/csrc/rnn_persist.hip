@@ -978,7 +978,7 @@ __device__ __forceinline__ void ws_run(const UicRnnFwdParams& p, Ctx& c, char* l
   // over K (and over the row tiles) at an offset of its own, `rank`; the stationary fragments are laid out to match.
   const int j0 = __builtin_amdgcn_readfirstlane(c.rank % 12);
   const int tr = __builtin_amdgcn_readfirstlane(c.rank % c.MT);   // the row tiles are walked starting at tile tr
-  u32x4 w2[12][4];                                 // slot j: k-step wave + 4 m, m = (j + j0) % 12, of [att_res | h_att | h_lang_prev]
+  u32x4 w2[12][4];                                 // slot j: k-step wave + 4 m of [att_res | h_att | h_lang_prev], m as below
   {
     const unsigned bl = (unsigned)(c.lq * 8);
     // (one descriptor for weight_ih and weight_hh of lang_lstm: which of them slot j reads is a select of a 32-bit offset)
@@ -987,9 +987,11 @@ __device__ __forceinline__ void ws_run(const UicRnnFwdParams& p, Ctx& c, char* l
     const unsigned o_ih = (unsigned)((const char*)p.lang_w_ih - wlo), o_hh = (unsigned)((const char*)p.lang_w_hh - wlo);
 #pragma unroll
     for (int j = 0; j < 12; ++j) {
-      int m = j + j0;
-      m = m >= 12 ? m - 12 : m;
-      const int sg = m >> 2;                        // 0: att_res, 1: h_att, 2: h_lang_prev   (16 k-steps each)
+      // slots 0-3: h_att, 4-7: h_lang_prev, 8-11: att_res -- the segment that the attention phase produces comes LAST, so that a
+      // row tile's first eight fragments can be requested (and multiplied) before the group barrier behind the attention is through;
+      // inside a segment the four k-steps are walked from an offset of the workgroup's own (j0)
+      const int sg = (j >> 2) == 2 ? 0 : (j >> 2) + 1;   // 0: att_res, 1: h_att, 2: h_lang_prev   (16 k-steps each)
+      const int m = sg * 4 + ((j + j0) & 3);
       const unsigned kk = (unsigned)(((m & 3) * 4 + c.wave) * 32);
       const unsigned ld = sg < 2 ? 2u * HH : (unsigned)HH;
       const unsigned so = (sg < 2 ? o_ih + (unsigned)(sg * HH) * 2u : o_hh) + kk * 2u;
@@ -1297,8 +1299,7 @@ __device__ __forceinline__ void ws_run(const UicRnnFwdParams& p, Ctx& c, char* l
       attn_phase<T, SAFE, WS_NW, WS_ATT_SLOTS>(c, p, att_h, p.alpha_all + (size_t)t * N * p.R, ctx);
     }
     if (dbg && c.tid == 0) dbg[5] = __builtin_amdgcn_s_memrealtime();
-    if (!group_barrier(c)) return;
-    if (dbg && c.tid == 0) dbg[6] = __builtin_amdgcn_s_memrealtime();
+    group_arrive(c);                                // (the wait is inside the block below, behind the requests that need no exchange)
     asm volatile("" : "+v"(c.lane), "+v"(c.l15), "+v"(c.lq), "+v"(c.tid));   // keep this phase's lane-derived values out of the others' live ranges
     // ---- lang_lstm (:438-441) + output dropout (:443): K split over the waves (stationary fragments in registers), one row
     // tile per pass; pass i writes its partial tiles to LDS half i & 1, ONE barrier, then the tile's owner sums and finishes
@@ -1326,17 +1327,22 @@ __device__ __forceinline__ void ws_run(const UicRnnFwdParams& p, Ctx& c, char* l
         return (unsigned)((ar * HH + c.lq * 8) * 2);
       };
       auto load_frag = [&](int j, unsigned aoff) {
-        int m = j + j0;
-        m = m >= 12 ? m - 12 : m;
+        const int m = ((j >> 2) == 2 ? 0 : (j >> 2) + 1) * 4 + ((j + j0) & 3);     // (as the stationary fragments' slots)
         // (two independent selects: a three-way select chain becomes a table in private memory, and with it everything
         // this lambda captures)
         const unsigned so = o_ctx + (m >= 4 ? o_han - o_ctx : 0u) + (m >= 8 ? o_hlp - o_han : 0u);
         fa[j] = bload<true>(rx, aoff, so + (unsigned)(((m & 3) * 4 + c.wave) * 64));
       };
       {
+        // the first row tile's h_att / h_lang_prev fragments (exchanged one and three barriers ago) are requested before this
+        // workgroup looks for the others' arrival at the barrier behind the attention; att_res's four behind it
         const unsigned a0 = aoff_of(tile_of(0));
 #pragma unroll
-        for (int j = 0; j < 12; ++j) load_frag(j, a0);
+        for (int j = 0; j < 8; ++j) load_frag(j, a0);
+        if (!group_wait(c, (int*)c.smem)) return;
+        if (dbg && c.tid == 0) dbg[6] = __builtin_amdgcn_s_memrealtime();
+#pragma unroll
+        for (int j = 8; j < 12; ++j) load_frag(j, a0);
       }
 #pragma unroll
       for (int i = 0; i < MT_MAX; ++i) {
