@@ -1339,8 +1339,28 @@ __device__ __forceinline__ void ws_run(const UicRnnFwdParams& p, Ctx& c, char* l
         const unsigned a0 = aoff_of(tile_of(0));
 #pragma unroll
         for (int j = 0; j < 8; ++j) load_frag(j, a0);
+      }
+      // ... and multiplied too (the first tile's eight k-fragments that need no exchange): in the time between this workgroup's
+      // arrival and its first look at the barrier.  mfma_range: slots [jlo, jhi) of a pass (see the note on the inline asm below).
+      f32x4 acc0[4];
+      auto mfma_range = [&](f32x4 (&acc)[4], int jlo, int jhi, bool more, unsigned an) {
+#pragma unroll
+        for (int j = 0; j < 12; ++j) {
+          if (j < jlo || j >= jhi) continue;
+#pragma unroll
+          for (int g = 0; g < 4; ++g) {
+            if (j == 0) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, 0" : "=&v"(acc[g]) : "v"(fa[0]), "a"(w2[0][g]));
+            else asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(acc[g]) : "v"(fa[j]), "a"(w2[j][g]));
+          }
+          if (more) load_frag(j, an);
+        }
+      };
+      {
+        const bool more0 = 1 < MT_MAX && 1 < c.MT;
+        if constexpr (!DEC) mfma_range(acc0, 0, 8, more0, aoff_of(tile_of(more0 ? 1 : 0)));   // (not the decode kernel: it spills as it is)
         if (!group_wait(c, (int*)c.smem)) return;
         if (dbg && c.tid == 0) dbg[6] = __builtin_amdgcn_s_memrealtime();
+        const unsigned a0 = aoff_of(tile_of(0));
 #pragma unroll
         for (int j = 8; j < 12; ++j) load_frag(j, a0);
       }
@@ -1358,14 +1378,24 @@ __device__ __forceinline__ void ws_run(const UicRnnFwdParams& p, Ctx& c, char* l
           if (!more && t + 1 < p.t1) load_pre(t + 1, c.wave, pvn, cpn);   // last pass: no later request of this phase waits behind these
 #endif
           f32x4 acc[4];
+          if constexpr (!DEC) {
+            if (i == 0) {
 #pragma unroll
-          for (int j = 0; j < 12; ++j) {
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-              if (j == 0) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, 0" : "=&v"(acc[g]) : "v"(fa[0]), "a"(w2[0][g]));
-              else asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(acc[g]) : "v"(fa[j]), "a"(w2[j][g]));
+              for (int g = 0; g < 4; ++g) acc[g] = acc0[g];
+              mfma_range(acc, 8, 12, more, an);
+            } else {
+              mfma_range(acc, 0, 12, more, an);
             }
-            if (more) load_frag(j, an);
+          } else {
+#pragma unroll
+            for (int j = 0; j < 12; ++j) {
+#pragma unroll
+              for (int g = 0; g < 4; ++g) {
+                if (j == 0) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, 0" : "=&v"(acc[g]) : "v"(fa[0]), "a"(w2[0][g]));
+                else asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(acc[g]) : "v"(fa[j]), "a"(w2[j][g]));
+              }
+              if (more) load_frag(j, an);
+            }
           }
           asm volatile("s_nop 7\n\ts_nop 7" : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3]));
           f32x4* half = scr + (i & 1) * (WS_NW * 4 * 64);
