@@ -398,9 +398,9 @@ typedef struct uic_nmt_weights {     /* keys of NMTModel.state_dict() + generato
 } uic_nmt_weights;
 
 size_t uic_nmt_workspace_bytes(const uic_nmt_dims* d);
-/* Named pieces of a workspace, for tools (as uic_topdown_workspace_ptr): "dec_bwd_dbg" = the persistent decoder-BPTT launch's
- * per-phase time stamps when dims.recurrence has UIC_REC_STAMPS ([256 workgroups][T-1][16] uint64, 100 MHz), "d_cq", "dscore",
- * "d_pre".  NULL for an unknown name. */
+/* Named pieces of a workspace, for tools (as uic_topdown_workspace_ptr): "dec_fwd_dbg" / "dec_bwd_dbg" = the persistent decoder
+ * forward / BPTT launches' per-phase time stamps when dims.recurrence has UIC_REC_STAMPS ([256 workgroups][T-1][16] uint64,
+ * 100 MHz; tools/nmt_bwd_probe.py prints them), "d_cq", "dscore", "d_pre".  NULL for an unknown name. */
 void* uic_nmt_workspace_ptr(const uic_nmt_dims* d, void* workspace, const char* name);
 /* Forward + loss: src [S,B] int64 (PAD = 0), lengths sorted descending (host AND device copies: the reference moves
  * them to the host for pack_padded_sequence too), tgt [T,B] int64.  Outputs (all optional except loss): loss_out[0] =
