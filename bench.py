@@ -5,7 +5,8 @@ caption rows per GPU, bf16 operands), synthetic data generated on the device.
 
 One "step" = Trainer.train's work with inputs already resident in HBM: operand casts, feature
 projection, 17-step teacher-forced unroll, logit GEMM + log-softmax + LanguageModelCriterion,
-full BPTT, [RCCL all-reduce of the flat gradient arena], Adam, weight-copy refresh.
+full BPTT, [N > 1: the sharded RCCL exchange -- reduce-scatter of the gradient pieces, Adam on the
+rank's slice, all-gather of the bf16 weights], Adam, weight-copy refresh.
 
     python bench.py --gpus 1 --steps 20 --warmup 5
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
@@ -284,6 +285,8 @@ def main():
                     help="region feature width (secondary measurement): 2053 = 2048 + 5 box features, the reference's default "
                          "use_box=1; the metric is quoted at 2048")
     ap.add_argument("--use-bn", type=int, default=0, help="opt.use_bn of the captioner (secondary measurement; the metric is quoted at 0)")
+    ap.add_argument("--allreduce-exchange", action="store_true", help="N > 1: round 5's exchange (all-reduce of the arena in four pieces, Adam on "
+                    "everything on every rank) instead of the sharded one")
     ap.add_argument("--early-grads", action="store_true",
                     help="UIC_REC_EARLY_GRADS (opt.early_grads): the order of the gradient work that has 62 %% of the gradient bytes final "
                          "0.18 ms before the step ends, for a step that is 4 %% longer on its own -- for N > 1 experiments; off for the headline")
@@ -340,6 +343,7 @@ def main():
     Datt = args.att_feat_size or c["D"]
     opt_main = make_opt(args.dtype, 1234 + rank, args.use_bn, Datt)
     opt_main.early_grads = bool(args.early_grads)
+    opt_main.allreduce_exchange = int(args.allreduce_exchange)
     tr = Trainer(opt_main)
     tr.build_optimizer()
     if share:
@@ -360,12 +364,15 @@ def main():
             torch.cuda.synchronize()
 
     def timed(bt):
+        # (the synthetic batch is resident and the same every step: its mask sum is "the next batch's" too -- a data-parallel run
+        # carries it in the step's small all-reduce instead of a collective in front of the next forward pass, as Trainer.train
+        # does with next_data=)
         for _ in range(args.warmup):
-            tr.train_device_batch(bt, t_run, den_local)
+            tr.train_device_batch(bt, t_run, den_local, den_local)
         barrier()
         t0 = time.perf_counter()
         for _ in range(args.steps):
-            ls = tr.train_device_batch(bt, t_run, den_local)
+            ls = tr.train_device_batch(bt, t_run, den_local, den_local)
         barrier()
         el = time.perf_counter() - t0
         if world > 1:
@@ -429,23 +436,32 @@ def main():
             world_size = property(lambda self: 1)
             rank = property(lambda self: 0)
 
+            def _sum(self, t):
+                pass
+
         real = tr.exchange
         tr.exchange = _Alone()
         for _ in range(args.warmup):
-            tr.train_device_batch(batch, t_run, den_local)
+            tr.train_device_batch(batch, t_run, den_local, den_local)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for _ in range(args.steps):
-            tr.train_device_batch(batch, t_run, den_local)
+            tr.train_device_batch(batch, t_run, den_local, den_local)
         torch.cuda.synchronize()
         alone_ms = (time.perf_counter() - t0) / args.steps * 1e3
         tr.exchange = real
+        tr._next_den = None
         per_rank = [None] * world
         dist.all_gather_object(per_rank, round(alone_ms, 4))
         step_ms = elapsed / args.steps * 1e3
         comm = {"ms_per_step_without_exchange_per_rank": per_rank,
                 "exposed_communication_ms_per_rank": [round(step_ms - a, 4) for a in per_rank],
-                "gradient_bytes_per_step": int(tr.arena.grad.numel() * 4), "pieces": len(getattr(tr, "arena_splits", [])) + 1,
+                "gradient_bytes_per_step": int(tr.arena.grad.numel() * 4),
+                "exchange": "sharded: reduce-scatter of %d gradient pieces + all-reduce of the replicated tail (%d bytes) + Adam on 1/%d of the arena + "
+                            "all-gather of the %s weights (%d bytes) beside the next forward pass" % (
+                                len(tr.arena.pieces), (tr.arena.scalars_off + 4 - tr.arena.repl_off) * 4, world,
+                                "bf16" if tr.arena.w16 is not None else "f32", tr.arena.repl_off * (2 if tr.arena.w16 is not None else 4))
+                if getattr(tr, "sharded", False) else "all-reduce in %d pieces" % (len(getattr(tr, "arena_splits", [])) + 1),
                 "GPU_MAX_HW_QUEUES": os.environ.get("GPU_MAX_HW_QUEUES"),
                 "note": "step time of each rank with the collectives removed (same stream layout), measured after the timed region; "
                         "exposed = ms_per_step - that"}

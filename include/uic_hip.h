@@ -186,6 +186,31 @@ int uic_topdown_refresh_weights(const uic_topdown_dims* d, const uic_topdown_wei
  * tensors and `derived` must stay alive and unchanged until then (as they must for that call anyway). */
 int uic_topdown_refresh_weights_deferred(const uic_topdown_dims* d, const uic_topdown_weights* w, void* derived, void* stream);
 
+/* Sharded data parallelism (replaces DataParallel's per-step parameter broadcast, P/trainer.py:74): each
+ * rank owns 1/world of every gradient piece (reduce-scatter), runs Adam on that shard only (uic_adam_step_ranges, which also
+ * leaves the shard's updated weights in the operand dtype) and the ranks all-gather the OPERAND-DTYPE weights -- half the bytes of
+ * the f32 masters in bf16 runs -- while the next step's feature projection already runs.  This struct names the gathered tensors
+ * (operand dtype, same shapes as the masters; with f32 operands they must BE the masters) and, per gather group, the hipEvent_t the
+ * caller recorded behind that group's all-gather (NULL: already ordered on `stream`):
+ *   ready[3]: att_embed weight (ignored / NULL with use_bn: the folded weight needs the f32 master, which the caller keeps
+ *             replicated), ctx2att.weight, core.attention.h2att.weight   -- consumed first (main branch of the prologue)
+ *   ready[2]: embed.0.weight, fc_embed.0.weight, core.att_lstm.weight_ih
+ *   ready[1]: core.lang_lstm.weight_{ih,hh}, core.att_lstm.weight_hh     -- the recurrence
+ *   ready[0]: logit weight(s)                                            -- the logit layer
+ * (the groups are the gradient groups of uic_topdown_grad_ready_wait, in reverse).  Biases and the other small f32 tensors are read
+ * from the masters in `w`: the caller keeps those replicated (all-reduce + the same Adam on every rank). */
+typedef struct uic_topdown_gathered {
+  const void* embed_w; const void* fc_w; const void* att_w; const void* logit_w; const void* ctx2att_w;
+  const void* att_lstm_w_ih; const void* att_lstm_w_hh; const void* lang_lstm_w_ih; const void* lang_lstm_w_hh; const void* h2att_w;
+  const void* logit_h_w[UIC_MAX_LOGIT_LAYERS - 1];
+  void* ready[4];
+} uic_topdown_gathered;
+/* uic_topdown_refresh_weights from the gathered tensors.  deferred != 0: as uic_topdown_refresh_weights_deferred (the caller's next
+ * call on this device is uic_topdown_xe_train_step, which orders its own streams behind the groups they read, so that e.g. the
+ * att_embed GEMM starts as soon as group 3 has arrived); deferred == 0: everything is ordered in front of `stream`. */
+int uic_topdown_refresh_weights_gathered(const uic_topdown_dims* d, const uic_topdown_weights* w, const uic_topdown_gathered* g,
+                                         void* derived, int32_t deferred, void* stream);
+
 /* AttModel._forward (P/models/AttModel.py:119-156) with ss_prob = 0: feature projection, the
  * teacher-forced unroll over `t_run` <= d->T steps (t_run < T reproduces the early break at :151)
  * and the logit GEMM.  If `logprobs_out` != NULL it receives log-probs as [N, T, V1] f32 (rows of
@@ -228,16 +253,10 @@ int uic_topdown_xe_train_step(const uic_topdown_dims* d, const uic_topdown_weigh
  *            core.attention.alpha_net.*}                   -- final when the embedding / fc_embed / bias gradients are done.
  * A caller that lays its flat gradient arena out as [logit | group 1 | rest of the early group | late group] can
  * start the RCCL all-reduce of the first three pieces on a communication stream as each becomes final; the tail follows on
- * the step's stream.  Enqueue-only, no host sync.  Two forms of the wait:
- *   group                         hipStreamWaitEvent: a barrier packet parked at the head of `stream`'s hardware queue until the
- *                                 group's event fires;
- *   group | UIC_GRAD_WAIT_POLL    a one-wave kernel on `stream` that polls a device word the step sets where it records that
- *                                 event.  Measured with a one-GPU stand-in for the collectives (tools/comm_proxy.py,
- *                                 profiles/r05_*_comm_proxy.txt): while a barrier packet waits in ANOTHER hardware queue the step's
- *                                 launch chain (85 dependent launches) is dispatched 2.5x slower -- 6.8 ms per step instead of
- *                                 3.2 -- and a polling kernel does not have that effect.  The form to use for an exchange that
- *                                 is enqueued while the step still runs; bounded spin (0.2 s), bit 6 of rnn_status[0] on time-out. */
-#define UIC_GRAD_WAIT_POLL 0x100
+ * the step's stream.  Enqueue-only, no host sync: a hipStreamWaitEvent on the group's event.  (Round 5 also had a polling-kernel
+ * form of the wait; measured no different -- what slows the step's launch chain beside a communication stream is the NUMBER of
+ * busy hardware queues of the process (> 4; profiles/r05_v4_queue_probe.txt), not the packet type -- and removed in round 6.
+ * A data-parallel process should run with GPU_MAX_HW_QUEUES=2 in its environment: Trainer sets / checks it.) */
 int uic_topdown_grad_ready_wait(void* stream, int32_t group);
 /* Timing marks of the last uic_topdown_xe_train_step on this device (diagnostics; off by default, the step records no timing
  * events then).  enable != 0 switches the marks on for the following steps.  ms_out (optional, UIC_STEP_MARKS floats): waits
@@ -447,9 +466,20 @@ int uic_comm_unique_id(void* id_out);
 int uic_comm_init(int32_t rank, int32_t world, const void* id, void** comm_out);
 int uic_comm_allreduce(void* comm, void* buf, size_t count, int32_t dtype, void* stream);
 int uic_comm_destroy(void* comm);
-/* Measurement aid (tools/comm_proxy.py), NOT a collective: a stand-in for one all-reduce of `bytes` bytes (a multiple of 16) on a
- * single GPU -- `workgroups` 256-thread workgroups stream buf -> scratch -> buf on `stream`; buf is unchanged afterwards. */
+/* The two halves of the sharded exchange: uic_comm_reduce_scatter sums `world * recvcount` elements at
+ * sendbuf over the ranks and leaves elements [rank * recvcount, (rank + 1) * recvcount) of the sum at recvbuf (in place when
+ * recvbuf == sendbuf + rank * recvcount); uic_comm_allgather sends `sendcount` elements from every rank and leaves the ranks'
+ * blocks in rank order at recvbuf (in place when sendbuf == recvbuf + rank * sendcount).  uic_comm_group_start / _end bracket
+ * several of them so that RCCL launches them as one kernel (ncclGroupStart / ncclGroupEnd). */
+int uic_comm_reduce_scatter(void* comm, const void* sendbuf, void* recvbuf, size_t recvcount, int32_t dtype, void* stream);
+int uic_comm_allgather(void* comm, const void* sendbuf, void* recvbuf, size_t sendcount, int32_t dtype, void* stream);
+int uic_comm_group_start(void);
+int uic_comm_group_end(void);
+/* Measurement aids (tools/comm_proxy.py), NOT collectives: stand-ins on a single GPU.  uic_comm_proxy: one all-reduce of `bytes`
+ * bytes (a multiple of 16) -- `workgroups` 256-thread workgroups stream buf -> scratch -> buf on `stream`; buf is unchanged
+ * afterwards.  uic_comm_proxy_oneway: a reduce-scatter or an all-gather of `bytes` bytes -- one pass, src -> dst. */
 int uic_comm_proxy(void* buf, void* scratch, size_t bytes, int32_t workgroups, void* stream);
+int uic_comm_proxy_oneway(const void* src, void* dst, size_t bytes, int32_t workgroups, void* stream);
 
 /* ---- single operators (also used by the parity tests) ---- */
 
@@ -515,6 +545,15 @@ int uic_adam_step(float* p, const float* g, float* m, float* v, size_t n, float 
  * persistent kernels to time out). */
 int uic_adam_step_guarded(float* p, const float* g, float* m, float* v, size_t n, float lr, float beta1, float beta2,
                           float eps, int32_t step, float grad_scale, const int32_t* skip_if_nonzero, void* stream);
+
+/* The same step (optionally clipped, optionally guarded -- max_norm = 0 / sqnorm = NULL / skip_if_nonzero = NULL switch those off)
+ * on `n_ranges` (at most 24) index ranges [lo[i], hi[i]) of the arena in ONE launch: the ranges a data-parallel rank owns after the
+ * reduce-scatter of the gradient pieces, plus the replicated tail.  lo / hi are HOST arrays.  w_out (optional): the updated
+ * parameters of those ranges are also written there in w_dtype (UIC_DTYPE_BF16; element index = arena index) -- the rank's
+ * contribution to the all-gather of the operand-dtype weights.  Element for element the arithmetic of uic_adam_step. */
+int uic_adam_step_ranges(float* p, const float* g, float* m, float* v, int32_t n_ranges, const uint64_t* lo, const uint64_t* hi,
+                         float lr, float beta1, float beta2, float eps, int32_t step, float grad_scale, float max_norm,
+                         const float* sqnorm, const int32_t* skip_if_nonzero, void* w_out, int32_t w_dtype, void* stream);
 
 /* torch.nn.utils.clip_grad_norm + Adam as Optim.step applies them to the NMT model (P/misc/optimizer.py:93-100,
  * --nmt_max_grad_norm 5): uic_grad_sqnorm leaves sum(g^2) of the flat gradient arena in out[0] (deterministic

@@ -1,7 +1,10 @@
 """Two data-parallel ranks on ONE MI355X (both processes on cuda:0, `gloo` carrying the device tensors): the whole
-Trainer step -- global mask-sum denominator, fused HIP step on each rank's image shard, overlapped two-bucket
-all-reduce of the flat gradient arena (uic_topdown_grad_ready_wait), Adam -- must leave the same weights as one process
-training on the whole batch.  (RCCL itself needs one GPU per rank; the collective's call pattern is what is tested.)"""
+Trainer step -- global mask-sum denominator, fused HIP step on each rank's image shard, the gradient exchange behind
+uic_topdown_grad_ready_wait, Adam -- must leave the same weights as one process training on the whole batch.  Both
+exchanges are run: the SHARDED one (round 6 default: reduce-scatter of the gradient pieces, Adam on the rank's slices,
+all-gather of the operand-dtype weights consumed by uic_topdown_refresh_weights_gathered) and round 5's all-reduce in four
+pieces (opt.allreduce_exchange) -- and they must leave BIT-IDENTICAL weights, in f32 and in bf16.
+(RCCL itself needs one GPU per rank; the collectives' call pattern is what is tested.)"""
 import argparse
 import os
 import socket
@@ -26,24 +29,36 @@ def _free_port():
     return p
 
 
-def _opt(cfg, use_bn=0, early_grads=False):
-    return argparse.Namespace(early_grads=early_grads, vocab_size=cfg["V"], input_encoding_size=cfg["E"], rnn_size=cfg["H"], num_layers=1,
+def _opt(cfg, use_bn=0, early_grads=False, allreduce=False, dtype="f32"):
+    return argparse.Namespace(early_grads=early_grads, allreduce_exchange=int(allreduce), allow_many_hw_queues=1, vocab_size=cfg["V"], input_encoding_size=cfg["E"], rnn_size=cfg["H"], num_layers=1,
                               drop_prob_lm=0.0, seq_length=cfg["L"], fc_feat_size=cfg["D"], att_feat_size=cfg["D"],
                               att_hid_size=cfg["A"], use_bn=use_bn, logit_layers=1, caption_model="topdown",
-                              compute_dtype="f32", seed=5, i2t_learning_rate=5e-3, i2t_train_flag=1)
+                              compute_dtype=dtype, seed=5, i2t_learning_rate=5e-3, i2t_train_flag=1)
 
 
-def _train(cfg, W, data, steps, exchange=None, early_grads=False):
+def _train(cfg, W, data, steps, exchange=None, early_grads=False, allreduce=False, dtype="f32", use_bn=0, next_data=False):
     from unpaired_image_captioning_amd.trainer import Trainer
-    tr = Trainer(_opt(cfg, early_grads=early_grads), exchange=exchange)
-    tr.i2t_model.load_state_dict(W)
+    tr = Trainer(_opt(cfg, use_bn=use_bn, early_grads=early_grads, allreduce=allreduce, dtype=dtype), exchange=exchange)
+    if use_bn:      # att_embed = [BatchNorm1d, Linear, ...]: the golden Linear moves to index 1, the BatchNorm keeps its initial values
+        W = {k.replace("att_embed.0.", "att_embed.1."): v for k, v in W.items()}
+    tr.i2t_model.load_state_dict(W, strict=not use_bn)
     tr.build_optimizer()
-    losses = [tr.train(data) for _ in range(steps)]
+    grads1 = None
+    losses = []
+    for i in range(steps):
+        # next_data: the NEXT batch's mask sum rides in this step's small all-reduce (a dict on even steps, a callable on odd ones)
+        nd = None if not next_data else (data if i % 2 == 0 else (lambda: data))
+        losses.append(tr.train(data, next_data=nd))
+        if i == 0 and not getattr(tr, "sharded", False):
+            torch.cuda.synchronize()
+            grads1 = {k: v.detach().cpu().clone() for k, v in tr.arena.grad_views.items()}     # (summed over the ranks by the all-reduce)
     torch.cuda.synchronize()
+    tr.grads_after_first_step = grads1
     return tr, losses
 
 
-def _worker(rank, world, port, out_dir, backend="gloo", uic_comm=False, early_grads=False):
+def _worker(rank, world, port, out_dir, backend="gloo", uic_comm=False, early_grads=False, allreduce=False, dtype="f32", tag="dp2",
+            use_bn=0, next_data=False):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -59,29 +74,54 @@ def _worker(rank, world, port, out_dir, backend="gloo", uic_comm=False, early_gr
     lo, hi = GradientExchange().shard_images(cfg["n_img"])
     rows = slice(lo * cfg["S"], hi * cfg["S"])
     data = {k: I[k][rows].numpy() for k in ("fc_feats", "att_feats", "labels", "masks", "att_masks")}
-    tr, losses = _train(cfg, W, data, STEPS, exchange, early_grads)
+    tr, losses = _train(cfg, W, data, STEPS, exchange, early_grads, allreduce, dtype, use_bn, next_data)
+    from unpaired_image_captioning_amd import _lib
     if early_grads:      # group 1 of the overlapped exchange then also holds the embedding and att_lstm.weight_ih
-        from unpaired_image_captioning_amd import _lib
         assert tr.i2t_model.engine.recurrence & _lib.REC_EARLY_GRADS
-        names = list(tr.arena.offsets)
-        g1 = [k for k in names if tr.arena_splits[0] <= tr.arena.offsets[k] < tr.arena_splits[1]]
-        assert "embed.0.weight" in g1 and "core.att_lstm.weight_ih" in g1, g1
-    assert tr.exchange.world_size == world and len(tr.arena_splits) == 3 and 0 < tr.arena_splits[0] < tr.arena_splits[1] < tr.arena_splits[2] < tr.arena.numel
+    assert tr.exchange.world_size == world
+    if allreduce:
+        assert not tr.sharded and len(tr.arena_splits) == 3 and 0 < tr.arena_splits[0] < tr.arena_splits[1] < tr.arena_splits[2] < tr.arena.numel
+        if early_grads:
+            names = list(tr.arena.offsets)
+            g1 = [k for k in names if tr.arena_splits[0] <= tr.arena.offsets[k] < tr.arena_splits[1]]
+            assert "embed.0.weight" in g1 and "core.att_lstm.weight_ih" in g1, g1
+    else:
+        a = tr.arena
+        assert tr.sharded and a.world == world and a.rank == rank
+        assert len(a.pieces) == (4 if not use_bn else 4) and all(n % (64 * world) == 0 for _, n in a.pieces)
+        assert (a.w16 is not None) == (dtype == "bf16")
+        if early_grads:
+            assert "embed.0.weight" in a.piece_names[1] and "core.att_lstm.weight_ih" in a.piece_names[1], a.piece_names
+        # the small f32 tensors stay replicated; with a BatchNorm in att_embed its Linear too (the fold needs the f32 master)
+        assert "logit.bias" in a.replicated and "core.attention.alpha_net.weight" in a.replicated
+        assert ("att_embed.1.weight" in a.replicated) == bool(use_bn)
+        if dtype == "bf16":
+            # between steps a rank's f32 masters are current only inside its own shard: state_dict refuses until the collective ran
+            with pytest.raises(RuntimeError, match="gather_masters"):
+                tr.i2t_model.state_dict()
+        tr.gather_masters()
     if rank == 0:
-        torch.save({"sd": {k: v.cpu() for k, v in tr.i2t_model.state_dict().items()}, "losses": losses},
-                   os.path.join(out_dir, "dp2.pt"))
+        torch.save({"sd": {k: v.cpu() for k, v in tr.i2t_model.state_dict().items()}, "losses": losses, "grads1": tr.grads_after_first_step},
+                   os.path.join(out_dir, tag + ".pt"))
     if exchange is not None:
         exchange.close()
     dist.barrier()
     dist.destroy_process_group()
 
 
-def _check_against_single_process(tmp_path):
-    res = torch.load(os.path.join(str(tmp_path), "dp2.pt"))
+def _check_against_single_process(tmp_path, tag="dp2", early_grads=False):
+    res = torch.load(os.path.join(str(tmp_path), tag + ".pt"))
     cfg, W, I, Out, G, X = load_golden("topdown_tiny_ragged")
     data = {k: I[k].numpy() for k in ("fc_feats", "att_feats", "labels", "masks", "att_masks")}
-    tr, losses = _train(cfg, W, data, STEPS)
+    tr, losses = _train(cfg, W, data, STEPS, early_grads=early_grads)
     assert abs(losses[0] - float(Out["loss"])) < 1e-4
+    if res.get("grads1") is not None:
+        # the all-reduced gradient arena of the FIRST step against the reference's own gradients (golden) -- before Adam blurs it
+        # (hygiene): f32, no dropout, so the two ranks' partial sums differ from one process by summation order only
+        floor = 1e-3 * max(float(g.abs().max()) for g in G.values())
+        for k, g in G.items():
+            err = (res["grads1"][k] - g).abs().max().item() / max(g.abs().max().item(), floor)
+            assert err < 2e-5, (k, err)
     for a, b in zip(res["losses"], losses):
         assert abs(a - b) < 1e-4, (res["losses"], losses)
     sd = tr.i2t_model.state_dict()
@@ -95,26 +135,58 @@ def _check_against_single_process(tmp_path):
         assert (v - ref).abs().max().item() <= 2e-2 * moved + floor, (k, (v - ref).abs().max().item(), moved)
 
 
-def test_two_ranks_on_one_gpu_match_single_process(tmp_path):
+def _spawn(tmp_path, **kw):
     world = 2
-    mp.spawn(_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    args = dict(backend="gloo", uic_comm=False, early_grads=False, allreduce=False, dtype="f32", tag="dp2", use_bn=0, next_data=False)
+    args.update(kw)
+    mp.spawn(_worker, args=(world, _free_port(), str(tmp_path), args["backend"], args["uic_comm"], args["early_grads"], args["allreduce"],
+                            args["dtype"], args["tag"], args["use_bn"], args["next_data"]), nprocs=world, join=True)
+    return torch.load(os.path.join(str(tmp_path), args["tag"] + ".pt"))
+
+
+@pytest.mark.parametrize("allreduce", [False, True], ids=["sharded", "allreduce"])
+def test_two_ranks_on_one_gpu_match_single_process(tmp_path, allreduce):
+    _spawn(tmp_path, allreduce=allreduce)
     _check_against_single_process(tmp_path)
 
 
-def test_two_ranks_with_the_early_gradient_order_match_single_process(tmp_path):
+@pytest.mark.parametrize("allreduce", [False, True], ids=["sharded", "allreduce"])
+def test_two_ranks_with_the_early_gradient_order_match_single_process(tmp_path, allreduce):
     """opt.early_grads (UIC_REC_EARLY_GRADS): the embedding gradient and att_lstm.weight_ih travel with gradient group 1 of the
-    overlapped exchange -- their all-reduce starts at ev_lstm, so they must really be final there."""
-    world = 2
-    mp.spawn(_worker, args=(world, _free_port(), str(tmp_path), "gloo", False, True), nprocs=world, join=True)
-    _check_against_single_process(tmp_path)
+    overlapped exchange -- their collective starts at ev_lstm, so they must really be final there."""
+    _spawn(tmp_path, early_grads=True, allreduce=allreduce)
+    _check_against_single_process(tmp_path, early_grads=True)
+
+
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+def test_sharded_exchange_leaves_the_same_bits_as_the_all_reduce(tmp_path, dtype):
+    """reduce-scatter + Adam on the rank's slices + all-gather of the operand-dtype weights against
+    all-reduce + Adam on everything, two ranks, three steps: every weight BIT-IDENTICAL (two ranks: a + b in both collectives;
+    Adam is element-wise; bf16(master) is the same number whichever rank rounds it), and so are the losses.  The sharded run also
+    carries the next batch's mask sum in the step's small all-reduce (Trainer.train(next_data=...), dict and callable)."""
+    sh = _spawn(tmp_path, dtype=dtype, tag="sh", next_data=True)
+    ar = _spawn(tmp_path, dtype=dtype, tag="ar", allreduce=True)
+    assert sh["losses"] == ar["losses"], (sh["losses"], ar["losses"])
+    for k, v in ar["sd"].items():
+        assert torch.equal(sh["sd"][k], v), (k, (sh["sd"][k] - v).abs().max().item())
+
+
+def test_sharded_exchange_with_batchnorm_in_att_embed(tmp_path):
+    """use_bn = 1: att_embed's Linear is folded with the BatchNorm from its f32 master at every refresh, so the sharded exchange
+    keeps that tensor replicated (all-reduced with the small tensors) -- same bits as the all-reduce path (bf16 operands).  The
+    running statistics are per rank in both (DataParallel replica semantics)."""
+    sh = _spawn(tmp_path, dtype="bf16", tag="sh", use_bn=1)
+    ar = _spawn(tmp_path, dtype="bf16", tag="ar", allreduce=True, use_bn=1)
+    assert sh["losses"] == ar["losses"], (sh["losses"], ar["losses"])
+    for k, v in ar["sd"].items():
+        assert torch.equal(sh["sd"][k], v), (k, (sh["sd"][k].float() - v.float()).abs().max().item())
 
 
 @pytest.mark.skipif(torch.cuda.device_count() < 2, reason="RCCL needs one GPU per rank: this box has %d" % torch.cuda.device_count())
 def test_two_ranks_over_rccl_match_single_process(tmp_path):
     """The same step with the collectives on RCCL (backend "nccl"), one GPU per rank over xGMI: runs wherever two GPUs are
     visible (the 1-GPU boxes skip it)."""
-    world = 2
-    mp.spawn(_worker, args=(world, _free_port(), str(tmp_path), "nccl"), nprocs=world, join=True)
+    _spawn(tmp_path, backend="nccl")
     _check_against_single_process(tmp_path)
 
 
@@ -122,8 +194,7 @@ def test_two_ranks_over_rccl_match_single_process(tmp_path):
 def test_two_ranks_over_uic_comm_match_single_process(tmp_path):
     """The same step with the collectives on libuic_hip's OWN RCCL communicator (uic_comm_init / uic_comm_allreduce with the
     by-value ncclUniqueId hand-over, UicCommExchange.from_torch_distributed): exercises the C-ABI communicator across ranks."""
-    world = 2
-    mp.spawn(_worker, args=(world, _free_port(), str(tmp_path), "gloo", True), nprocs=world, join=True)
+    _spawn(tmp_path, uic_comm=True)
     _check_against_single_process(tmp_path)
 
 
@@ -180,9 +251,9 @@ def _sc_reward(data, sampled, greedy):
     return np.repeat(r[:, None], sampled.shape[1], 1)
 
 
-def _train_sc(cfg, W, data, forced, steps, exchange=None):
+def _train_sc(cfg, W, data, forced, steps, exchange=None, allreduce=False):
     from unpaired_image_captioning_amd.trainer import Trainer
-    tr = Trainer(_opt(cfg), exchange=exchange)
+    tr = Trainer(_opt(cfg, allreduce=allreduce), exchange=exchange)
     tr.i2t_model.load_state_dict(W)
     tr.build_optimizer()
     tr.forced_samples = forced.cuda()
@@ -191,7 +262,7 @@ def _train_sc(cfg, W, data, forced, steps, exchange=None):
     return tr, losses
 
 
-def _sc_worker(rank, world, port, out_dir):
+def _sc_worker(rank, world, port, out_dir, allreduce=False):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -205,21 +276,22 @@ def _sc_worker(rank, world, port, out_dir):
     rows = slice(lo * cfg["S"], hi * cfg["S"])
     data = {k: I[k][rows].numpy() for k in ("fc_feats", "att_feats", "labels", "masks", "att_masks")}
     forced = _sc_tokens(cfg, cfg["n_img"] * cfg["S"])[rows]
-    tr, losses = _train_sc(cfg, W, data, forced, SC_STEPS)
-    assert tr.exchange.world_size == world
+    tr, losses = _train_sc(cfg, W, data, forced, SC_STEPS, allreduce=allreduce)
+    assert tr.exchange.world_size == world and tr.sharded == (not allreduce)
     if rank == 0:
         torch.save({"sd": {k: v.cpu() for k, v in tr.i2t_model.state_dict().items()}, "losses": losses}, os.path.join(out_dir, "sc2.pt"))
     dist.barrier()
     dist.destroy_process_group()
 
 
-def test_two_ranks_self_critical_step_matches_single_process(tmp_path):
+@pytest.mark.parametrize("allreduce", [False, True], ids=["sharded", "allreduce"])
+def test_two_ranks_self_critical_step_matches_single_process(tmp_path, allreduce):
     """Trainer.train_self_critical on two ranks whose captions differ in length: RewardCriterion's denominator is the mask sum of
     the WHOLE batch (P/misc/criterion.py:117-122 on the gathered outputs, P/trainer.py:168-170), so the summed gradients -- and
     the reported loss -- must be those of one process on the whole batch.  (The sampled captions are pinned through
     Trainer.forced_samples and the reward is a fixed function of the tokens: nothing random is left.)"""
     world = 2
-    mp.spawn(_sc_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    mp.spawn(_sc_worker, args=(world, _free_port(), str(tmp_path), allreduce), nprocs=world, join=True)
     res = torch.load(os.path.join(str(tmp_path), "sc2.pt"))
     cfg, W, I, Out, G, X = load_golden("topdown_tiny_ragged")
     data = {k: I[k].numpy() for k in ("fc_feats", "att_feats", "labels", "masks", "att_masks")}
@@ -241,20 +313,21 @@ def test_two_ranks_self_critical_step_matches_single_process(tmp_path):
 NMT_CFG = dict(layers=2, H=64, W=64, B=8, S=10, T=9, Vs=120, Vt=130)
 
 
-def _nmt_trainer(tmp, exchange=None):
+def _nmt_trainer(tmp, exchange=None, allreduce=False):
     from test_gpu_nmt import make_opt
     from unpaired_image_captioning_amd.trainer import Trainer
     o = make_opt(NMT_CFG, "f32", dropout=0.0, seed=3)
     o.nmt_train_flag, o.i2t_train_flag, o.checkpoint_path = 1, 0, str(tmp)
     o.nmt_learning_rate, o.nmt_max_grad_norm, o.param_init = 5e-3, 0.5, 0.1      # (a clip that really bites: the norm is ~2)
     o.caption_model = None
+    o.allreduce_exchange, o.allow_many_hw_queues = int(allreduce), 1
     tr = Trainer(o, exchange=exchange)
     torch.manual_seed(17)                                 # (param_init draws from torch's global generator: same weights everywhere)
     tr.build_nmt(NMT_CFG["Vs"], NMT_CFG["Vt"])
     return tr
 
 
-def _nmt_worker(rank, world, port, out_dir):
+def _nmt_worker(rank, world, port, out_dir, allreduce=False):
     import argparse as ap
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -268,9 +341,12 @@ def _nmt_worker(rank, world, port, out_dir):
     I = synthetic(NMT_CFG, 9)
     cols = slice(rank, None, world)                       # DataParallel(dim=1) scatters columns; every shard stays length-sorted
     batch = ap.Namespace(src=I["src"][:, cols].contiguous().cuda(), tgt=I["tgt"][:, cols].contiguous().cuda(), lengths=I["lengths"][:, cols].contiguous())
-    tr = _nmt_trainer(out_dir)
+    tr = _nmt_trainer(out_dir, allreduce=allreduce)
     tr.nmt_model.engine.recurrence = _lib.REC_FWD_CHAIN   # (two ranks on one GPU: per-step launches)
-    assert tr.exchange.world_size == world and len(tr.optim.nmt_splits) == 2
+    assert tr.exchange.world_size == world and len(tr.optim.nmt_splits) == 2 and tr.optim.nmt_sharded == (not allreduce)
+    if not allreduce:
+        a = tr.optim.nmt_arena
+        assert len(a.pieces) == 3 and a.w16 is None and not a.replicated and all(n % (64 * world) == 0 for _, n in a.pieces)
     names = list(tr.optim.nmt_arena.offsets)
     assert names[0].startswith("generator.") and names[-1].startswith("encoder.")
     losses = [tr.train_nmt(batch) for _ in range(3)]
@@ -281,14 +357,15 @@ def _nmt_worker(rank, world, port, out_dir):
     dist.destroy_process_group()
 
 
-def test_two_ranks_nmt_step_matches_single_process(tmp_path):
+@pytest.mark.parametrize("allreduce", [False, True], ids=["sharded", "allreduce"])
+def test_two_ranks_nmt_step_matches_single_process(tmp_path, allreduce):
     """Trainer.train_nmt on two ranks (column shards of the batch, as DataParallel(nmt_model, dim=1) scatters them,
     P/trainer.py:88): the pieces of the gradient arena travel as they become final (generator, decoder side on the
     communication stream behind uic_nmt_grad_ready_wait, the encoder's share last), the clip takes the norm of the SUMMED
     gradient, and loss and weights after three steps are those of one process on the whole batch."""
     import argparse as ap
     world = 2
-    mp.spawn(_nmt_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    mp.spawn(_nmt_worker, args=(world, _free_port(), str(tmp_path), allreduce), nprocs=world, join=True)
     res = torch.load(os.path.join(str(tmp_path), "nmt2.pt"))
     from test_gpu_nmt import synthetic
     I = synthetic(NMT_CFG, 9)

@@ -267,6 +267,7 @@ def test_data_parallel_ranks_start_from_different_dropout_seeds():
     assert seeds[0] == 1234 and len(set(seeds)) == 4 and all(0 <= s_ <= 0x7FFFFFFF for s_ in seeds)
 
 
+@pytest.mark.skipif(not os.path.exists("/opt/rocm/bin/hipcc"), reason="needs hipcc (cross-compiles gfx950 without a GPU)")
 def test_f32a_gemm_build_has_no_compiler_touch_of_in_flight_registers():
     """tools/audit_f32a_asm.py: the f32-A ping-pong GEMM loads its A units with inline-asm
     global_load_dwordx4 into C++ variables and waits for them by a hand-counted vmcnt four phases later; hipcc counts an asm

@@ -11,6 +11,7 @@ and checks, for every f32-A instantiation:
 Exit status 0 = clean.  tests/test_host_logic.py runs it (no GPU needed: hipcc cross-compiles)."""
 import os
 import re
+import shutil
 import subprocess
 import sys
 import tempfile
@@ -132,15 +133,21 @@ def audit_kernel(name, lines):
 
 
 def main():
+    tmp = None
     if len(sys.argv) > 1:
         spath = sys.argv[1]
     else:
         tmp = tempfile.mkdtemp(prefix="uic_audit_")
         hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-        subprocess.check_call([hipcc, "--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-save-temps", "-c", SRC, "-o", os.path.join(tmp, "pp.o")],
-                              cwd=tmp, stderr=subprocess.DEVNULL)
+        r = subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-save-temps", "-c", SRC, "-o", os.path.join(tmp, "pp.o")],
+                           cwd=tmp, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+        if r.returncode != 0:
+            shutil.rmtree(tmp, ignore_errors=True)
+            sys.exit("audit_f32a_asm: %s failed (%d):\n%s" % (hipcc, r.returncode, r.stdout[-4000:]))
         spath = [os.path.join(tmp, f) for f in os.listdir(tmp) if f.endswith("gfx950.s")][0]
     text = open(spath).read().split("\n")
+    if tmp is not None:
+        shutil.rmtree(tmp, ignore_errors=True)
     start = re.compile(r"^(_ZN12_GLOBAL__N_118uic_gemm_pp_kernelILi(\d)ELb0ELb1EEEv13UicGemmParams):")
     kernels = []
     cur = None

@@ -188,6 +188,19 @@ def nmt_weights(tensors, layers):
     return w
 
 
+GATHERED_FIELDS = [
+    # (struct field of uic_topdown_gathered, struct field of uic_topdown_weights it shadows, gather group)
+    ("embed_w", "embed_w", 2), ("fc_w", "fc_w", 2), ("att_w", "att_w", 3), ("logit_w", "logit_w", 0), ("ctx2att_w", "ctx2att_w", 3),
+    ("att_lstm_w_ih", "att_lstm_w_ih", 2), ("att_lstm_w_hh", "att_lstm_w_hh", 1), ("lang_lstm_w_ih", "lang_lstm_w_ih", 1),
+    ("lang_lstm_w_hh", "lang_lstm_w_hh", 1), ("h2att_w", "h2att_w", 3),
+]
+
+
+class Gathered(C.Structure):
+    """uic_topdown_gathered: the all-gathered operand-dtype weights of a sharded data-parallel rank + one event per gather group."""
+    _fields_ = [(f, C.c_void_p) for f, _, _ in GATHERED_FIELDS] + [("logit_h_w", C.c_void_p * (MAX_LOGIT_LAYERS - 1)), ("ready", C.c_void_p * 4)]
+
+
 class Batch(C.Structure):
     _fields_ = [("fc_feats", C.c_void_p), ("att_feats", C.c_void_p), ("att_masks", C.c_void_p),
                 ("labels", C.c_void_p), ("ld_labels", C.c_int32),
@@ -214,6 +227,14 @@ _SIGS = {
     "uic_comm_allreduce": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int32, C.c_void_p]),
     "uic_comm_destroy": (C.c_int, [C.c_void_p]),
     "uic_comm_proxy": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int32, C.c_void_p]),
+    "uic_comm_proxy_oneway": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int32, C.c_void_p]),
+    "uic_comm_reduce_scatter": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int32, C.c_void_p]),
+    "uic_comm_allgather": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int32, C.c_void_p]),
+    "uic_comm_group_start": (C.c_int, []),
+    "uic_comm_group_end": (C.c_int, []),
+    "uic_topdown_refresh_weights_gathered": (C.c_int, [C.POINTER(Dims), C.POINTER(Weights), C.POINTER(Gathered), C.c_void_p, C.c_int32, C.c_void_p]),
+    "uic_adam_step_ranges": (C.c_int, [C.c_void_p] * 4 + [C.c_int32, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)] + [C.c_float] * 4 +
+                             [C.c_int32, C.c_float, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]),
     "uic_topdown_step_marks": (C.c_int, [C.c_int32, C.POINTER(C.c_float)]),
     "uic_topdown_workspace_bytes": (C.c_size_t, [C.POINTER(Dims)]),
     "uic_topdown_derived_bytes": (C.c_size_t, [C.POINTER(Dims)]),

@@ -276,6 +276,30 @@ int uic_adam_step_clip_guarded(float* p, const float* g, float* m, float* v, siz
   return uic_adam_launch(a, (hipStream_t)stream);
 }
 
+int uic_adam_step_ranges(float* p, const float* g, float* m, float* v, int32_t n_ranges, const uint64_t* lo, const uint64_t* hi,
+                         float lr, float beta1, float beta2, float eps, int32_t step, float grad_scale, float max_norm,
+                         const float* sqnorm, const int32_t* skip_if_nonzero, void* w_out, int32_t w_dtype, void* stream) {
+  UIC_REQUIRE(p && g && m && v && (n_ranges == 0 || (lo && hi)), "adam_step_ranges: null pointer");
+  UIC_REQUIRE(step >= 1, "adam_step_ranges: step=%d must be >= 1", step);
+  UIC_REQUIRE(n_ranges >= 0 && n_ranges <= UIC_ADAM_RANGES, "adam_step_ranges: %d ranges (max %d)", n_ranges, UIC_ADAM_RANGES);
+  UIC_REQUIRE(!w_out || w_dtype == UIC_F32 || w_dtype == UIC_BF16, "adam_step_ranges: bad w_dtype %d", w_dtype);
+  UIC_REQUIRE((max_norm > 0.f) == (sqnorm != nullptr), "adam_step_ranges: max_norm and sqnorm go together");
+  UicAdamParams a;
+  a.p = p; a.g = g; a.m = m; a.v = v; a.n = 0; a.lr = lr; a.beta1 = beta1; a.beta2 = beta2; a.eps = eps;
+  a.bc1 = (float)(1.0 - pow((double)beta1, (double)step));
+  a.bc2 = (float)(1.0 - pow((double)beta2, (double)step));
+  a.grad_scale = grad_scale;
+  a.max_norm = max_norm; a.sqnorm = sqnorm; a.guard = skip_if_nonzero;
+  UicAdamRanges r;
+  memset(&r, 0, sizeof(r));
+  for (int i = 0; i < n_ranges; ++i) {
+    UIC_REQUIRE(hi[i] >= lo[i], "adam_step_ranges: range %d is [%llu, %llu)", i, (unsigned long long)lo[i], (unsigned long long)hi[i]);
+    if (hi[i] == lo[i]) continue;
+    r.lo[r.count] = (size_t)lo[i]; r.start[r.count] = r.total; r.total += (size_t)(hi[i] - lo[i]); ++r.count;
+  }
+  return uic_adam_ranges_launch(a, r, w_out, w_dtype, (hipStream_t)stream);
+}
+
 int uic_lm_criterion(int32_t N, int32_t T, int32_t V1, const float* logp, const int64_t* target, int32_t ld_target,
                      const float* mask, int32_t ld_mask, float* loss_out, float* scratch, float* dlogp, float grad_out,
                      void* stream) {

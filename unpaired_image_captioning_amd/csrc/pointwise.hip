@@ -169,8 +169,22 @@ __global__ void sum_steps_vec_kernel(const T* __restrict__ src, int TS, size_t s
 // ------------------------------------------------------------------ word embedding
 // self.embed = Embedding + ReLU + Dropout (P/models/AttModel.py:73-75,160), all T steps at once:
 // out[(t*N+n), :] = dropout(relu(table[tokens[n, t]]))
-template <typename T>
-__global__ void embed_fwd_kernel(const float* __restrict__ table, int V1, int E, const int64_t* __restrict__ tokens,
+// (the table comes as f32 masters or in the operand dtype: bf16 runs of the captioner gather from the bf16 copy of the table that
+// the weight refresh keeps beside the other operand copies -- the copy a data-parallel rank receives from the all-gather)
+__device__ __forceinline__ void uic_table_load4(const float* p, float* f) { const float4 v = *(const float4*)p; f[0] = v.x; f[1] = v.y; f[2] = v.z; f[3] = v.w; }
+__device__ __forceinline__ void uic_table_load4(const bf16_t* p, float* f) {
+  const uint2 v = *(const uint2*)p;
+  f[0] = __uint_as_float(v.x << 16); f[1] = __uint_as_float(v.x & 0xFFFF0000u); f[2] = __uint_as_float(v.y << 16); f[3] = __uint_as_float(v.y & 0xFFFF0000u);
+}
+__device__ __forceinline__ void uic_table_load8(const float* p, float* f) { uic_table_load4(p, f); uic_table_load4(p + 4, f + 4); }
+__device__ __forceinline__ void uic_table_load8(const bf16_t* p, float* f) {
+  const uint4 v = *(const uint4*)p;
+  const unsigned w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+  for (int j = 0; j < 4; ++j) { f[2 * j] = __uint_as_float(w[j] << 16); f[2 * j + 1] = __uint_as_float(w[j] & 0xFFFF0000u); }
+}
+template <typename T, typename TT>
+__global__ void embed_fwd_kernel(const TT* __restrict__ table, int V1, int E, const int64_t* __restrict__ tokens,
                                  int ldtok, int N, int TS, float drop_p, unsigned seed, unsigned site, size_t idx_base, int relu, T* __restrict__ out) {
   const int e4 = E / 4;
   const size_t total = (size_t)TS * N * e4;
@@ -182,8 +196,8 @@ __global__ void embed_fwd_kernel(const float* __restrict__ table, int V1, int E,
     const int t = (int)(row / N), n = (int)(row - (size_t)t * N);
     long tok = tokens[(size_t)n * ldtok + t];
     if (tok < 0 || tok >= V1) tok = 0;
-    const float4 v = *(const float4*)(table + (size_t)tok * E + c);
-    float f[4] = {v.x, v.y, v.z, v.w};
+    float f[4];
+    uic_table_load4(table + (size_t)tok * E + c, f);
     if (relu) {
 #pragma unroll
       for (int j = 0; j < 4; ++j) f[j] = fmaxf(f[j], 0.f);
@@ -201,7 +215,8 @@ __global__ void embed_fwd_kernel(const float* __restrict__ table, int V1, int E,
 // no 64-bit divisions), a lane takes 8 consecutive elements -- two 16-byte loads, ONE 16-byte store (the element-wise form
 // above stores four 2-byte values per lane and ran at 0.7 TB/s: 48 us for the step's 10880 rows).  Same values, same dropout
 // decisions (the hash is per element index).
-__global__ __launch_bounds__(256) void embed_fwd_rows_bf16_kernel(const float* __restrict__ table, int V1, int E, const int64_t* __restrict__ tokens,
+template <typename TT>
+__global__ __launch_bounds__(256) void embed_fwd_rows_bf16_kernel(const TT* __restrict__ table, int V1, int E, const int64_t* __restrict__ tokens,
                                                                   int ldtok, int N, int rows, float drop_p, unsigned seed, unsigned site, size_t idx_base,
                                                                   int relu, bf16_t* __restrict__ out) {
   const int lane = threadIdx.x & 63;
@@ -212,11 +227,11 @@ __global__ __launch_bounds__(256) void embed_fwd_rows_bf16_kernel(const float* _
     const int t = row / N, n = row - t * N;
     long tok = tokens[(size_t)n * ldtok + t];
     if (tok < 0 || tok >= V1) tok = 0;
-    const float* src = table + (size_t)tok * E;
+    const TT* src = table + (size_t)tok * E;
     bf16_t* dst = out + (size_t)row * E;
     for (int c = lane; c < e8; c += 64) {
-      const float4 a = *(const float4*)(src + c * 8), b = *(const float4*)(src + c * 8 + 4);
-      float f[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+      float f[8];
+      uic_table_load8(src + c * 8, f);
       if (relu) {
 #pragma unroll
         for (int j = 0; j < 8; ++j) f[j] = fmaxf(f[j], 0.f);
@@ -1209,6 +1224,36 @@ __global__ void adam_kernel(const UicAdamParams a) {
   }
 }
 
+// The same update on up to UIC_ADAM_RANGES index ranges of the arena in ONE launch -- the ranges a data-parallel rank owns after
+// the reduce-scatter (one per gradient piece) plus the replicated tail -- optionally leaving the updated parameters of those
+// ranges in the operand dtype in `w_out` (same element index), which is what the all-gather then distributes.
+template <typename WT>
+__global__ void adam_ranges_kernel(const UicAdamParams a, const UicAdamRanges r, WT* __restrict__ w_out) {
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  const float step_size = a.lr / a.bc1;
+  const float inv_sqrt_bc2 = 1.f / sqrtf(a.bc2);
+  if (a.guard && a.guard[0] != 0) return;
+  float gs = a.grad_scale;
+  if (a.sqnorm) {
+    const float coef = a.max_norm / (fabsf(a.grad_scale) * sqrtf(a.sqnorm[0]) + 1e-6f);
+    if (coef < 1.f) gs *= coef;
+  }
+  for (size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x; j < r.total; j += stride) {
+    int k = 0;
+    while (k + 1 < r.count && j >= r.start[k + 1]) ++k;       // start[k]: position of range k in the concatenation
+    const size_t i = r.lo[k] + (j - r.start[k]);
+    const float g = __builtin_nontemporal_load(a.g + i) * gs;
+    const float m = a.beta1 * __builtin_nontemporal_load(a.m + i) + (1.f - a.beta1) * g;
+    const float v = a.beta2 * __builtin_nontemporal_load(a.v + i) + (1.f - a.beta2) * g * g;
+    __builtin_nontemporal_store(m, a.m + i);
+    __builtin_nontemporal_store(v, a.v + i);
+    const float denom = sqrtf(v) * inv_sqrt_bc2 + a.eps;
+    const float pn = a.p[i] - step_size * (m / denom);
+    a.p[i] = pn;
+    if (w_out) w_out[i] = uic_from_f<WT>(pn);
+  }
+}
+
 // ------------------------------------------------------------------ scheduled sampling (AttModel.py:130-143)
 // One block per caption row: rows whose uniform falls under ss_prob take an inverse-CDF draw from
 // softmax(previous step's logits) (= exp(outputs[:, i-1]), torch.multinomial's distribution); the others keep seq[:, i].
@@ -1417,8 +1462,11 @@ __global__ __launch_bounds__(NT) void sample_step_kernel(const UicSampleParams p
     const int E = p.embed_E;
     const float inv_keep = p.embed_drop_p > 0.f ? 1.f / (1.f - p.embed_drop_p) : 1.f;
     for (int c = threadIdx.x * 4; c < E; c += NT * 4) {
-      const float4 v = *(const float4*)(p.embed_table + (size_t)tok * E + c);
-      float f[4] = {fmaxf(v.x, 0.f), fmaxf(v.y, 0.f), fmaxf(v.z, 0.f), fmaxf(v.w, 0.f)};
+      float f[4];
+      if (p.embed_table_dtype == UIC_BF16) uic_table_load4((const bf16_t*)p.embed_table + (size_t)tok * E + c, f);
+      else uic_table_load4((const float*)p.embed_table + (size_t)tok * E + c, f);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) f[j] = fmaxf(f[j], 0.f);
       if (p.embed_drop_p > 0.f) {
 #pragma unroll
         for (int j = 0; j < 4; ++j)
@@ -1480,6 +1528,36 @@ __global__ void cast_multi_kernel(const CastMulti c) {
   }
 }
 }  // namespace
+namespace {
+typedef __attribute__((ext_vector_type(4))) unsigned u32x4m;
+struct CopyMulti { const u32x4m* src[UIC_CAST_MULTI]; u32x4m* dst[UIC_CAST_MULTI]; size_t n16[UIC_CAST_MULTI]; };
+__global__ __launch_bounds__(NT) void copy_multi_kernel(const CopyMulti c) {
+  const int k = blockIdx.y;
+  const u32x4m* src = c.src[k];
+  u32x4m* dst = c.dst[k];
+  const size_t n = c.n16[k], stride = (size_t)gridDim.x * blockDim.x;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) dst[i] = __builtin_nontemporal_load(src + i);
+}
+}  // namespace
+// up to UIC_CAST_MULTI device-to-device copies in ONE launch (sizes in bytes, multiples of 16; 16-byte aligned pointers)
+int uic_copy_multi_launch(int count, const void* const* src, void* const* dst, const size_t* bytes, hipStream_t s) {
+  UIC_REQUIRE(count >= 0 && count <= UIC_CAST_MULTI, "copy_multi: %d tensors (max %d)", count, UIC_CAST_MULTI);
+  CopyMulti c;
+  memset(&c, 0, sizeof(c));
+  size_t most = 0;
+  int m = 0;
+  for (int i = 0; i < count; ++i) {
+    if (bytes[i] == 0) continue;
+    UIC_REQUIRE(src[i] && dst[i] && (((uintptr_t)src[i] | (uintptr_t)dst[i] | bytes[i]) & 15) == 0, "copy_multi: tensor %d must be 16-byte aligned", i);
+    c.src[m] = (const u32x4m*)src[i]; c.dst[m] = (u32x4m*)dst[i]; c.n16[m] = bytes[i] / 16;
+    if (c.n16[m] > most) most = c.n16[m];
+    ++m;
+  }
+  if (m == 0) return UIC_OK;
+  hipLaunchKernelGGL(copy_multi_kernel, dim3(grid_for(most, NT * 2), m), dim3(NT), 0, s, c);
+  UIC_LAUNCH_CHECK("copy_multi");
+  return UIC_OK;
+}
 int uic_cast_f32_multi_launch(int dtype, int count, const float* const* src, void* const* dst, const size_t* n, hipStream_t s) {
   UIC_REQUIRE(count >= 0 && count <= UIC_CAST_MULTI, "cast_multi: %d tensors (max %d)", count, UIC_CAST_MULTI);
   CastMulti c;
@@ -1606,24 +1684,35 @@ int uic_sum_steps_launch(int dtype, const void* src, int T, size_t step_elems, v
   UIC_LAUNCH_CHECK("sum_steps");
   return UIC_OK;
 }
-int uic_embed_fwd_launch(int dtype, const float* table, int V1, int E, const int64_t* tokens, int ldtok, int N, int T,
-                         float drop_p, unsigned seed, unsigned site, size_t idx_base, int relu, void* out, hipStream_t s) {
+int uic_embed_fwd_t_launch(int dtype, const void* table, int table_dtype, int V1, int E, const int64_t* tokens, int ldtok, int N, int T,
+                           float drop_p, unsigned seed, unsigned site, size_t idx_base, int relu, void* out, hipStream_t s) {
   UIC_REQUIRE(E % 4 == 0, "embed: E=%d must be a multiple of 4", E);
+  UIC_REQUIRE(table_dtype == UIC_F32 || (table_dtype == UIC_BF16 && dtype == UIC_BF16), "embed: a bf16 table needs bf16 outputs");
   if (N == 0 || T == 0) return UIC_OK;
+  const bool t16 = table_dtype == UIC_BF16;
   if (dtype == UIC_BF16 && E % 8 == 0 && ((uintptr_t)out & 15) == 0 && ((uintptr_t)table & 15) == 0 && (size_t)T * N < ((size_t)1 << 30)) {
     const int rows = T * N;
     int gw = (rows + 3) / 4;
     if (gw > 8192) gw = 8192;
-    hipLaunchKernelGGL(embed_fwd_rows_bf16_kernel, dim3(gw), dim3(256), 0, s, table, V1, E, tokens, ldtok, N, rows, drop_p, seed, site, idx_base, relu, (bf16_t*)out);
+    if (t16) hipLaunchKernelGGL(embed_fwd_rows_bf16_kernel<bf16_t>, dim3(gw), dim3(256), 0, s, (const bf16_t*)table, V1, E, tokens, ldtok, N, rows, drop_p, seed, site, idx_base, relu, (bf16_t*)out);
+    else hipLaunchKernelGGL(embed_fwd_rows_bf16_kernel<float>, dim3(gw), dim3(256), 0, s, (const float*)table, V1, E, tokens, ldtok, N, rows, drop_p, seed, site, idx_base, relu, (bf16_t*)out);
     UIC_LAUNCH_CHECK("embed_fwd_rows");
     return UIC_OK;
   }
   const int g = grid_for((size_t)T * N * (E / 4), NT);
-  DISPATCH_T(dtype,
-             hipLaunchKernelGGL(embed_fwd_kernel<bf16_t>, dim3(g), dim3(NT), 0, s, table, V1, E, tokens, ldtok, N, T, drop_p, seed, site, idx_base, relu, (bf16_t*)out),
-             hipLaunchKernelGGL(embed_fwd_kernel<float>, dim3(g), dim3(NT), 0, s, table, V1, E, tokens, ldtok, N, T, drop_p, seed, site, idx_base, relu, (float*)out));
+  if (t16) {
+    hipLaunchKernelGGL((embed_fwd_kernel<bf16_t, bf16_t>), dim3(g), dim3(NT), 0, s, (const bf16_t*)table, V1, E, tokens, ldtok, N, T, drop_p, seed, site, idx_base, relu, (bf16_t*)out);
+  } else {
+    DISPATCH_T(dtype,
+               hipLaunchKernelGGL((embed_fwd_kernel<bf16_t, float>), dim3(g), dim3(NT), 0, s, (const float*)table, V1, E, tokens, ldtok, N, T, drop_p, seed, site, idx_base, relu, (bf16_t*)out),
+               hipLaunchKernelGGL((embed_fwd_kernel<float, float>), dim3(g), dim3(NT), 0, s, (const float*)table, V1, E, tokens, ldtok, N, T, drop_p, seed, site, idx_base, relu, (float*)out));
+  }
   UIC_LAUNCH_CHECK("embed_fwd");
   return UIC_OK;
+}
+int uic_embed_fwd_launch(int dtype, const float* table, int V1, int E, const int64_t* tokens, int ldtok, int N, int T,
+                         float drop_p, unsigned seed, unsigned site, size_t idx_base, int relu, void* out, hipStream_t s) {
+  return uic_embed_fwd_t_launch(dtype, table, UIC_F32, V1, E, tokens, ldtok, N, T, drop_p, seed, site, idx_base, relu, out, s);
 }
 // scratch layout (ints): cnt [nkeys + 1] | off [nkeys + 1] | (unused) [nkeys + 1] | perm [N T] ... then, at offsets that do not
 // depend on `split`: cntb [nblk, 2 V1] | part [2, nchunks, E] f32
@@ -1918,6 +2007,14 @@ int uic_sqnorm_launch(const float* g, size_t n, float* scratch, float* out, hipS
   UIC_LAUNCH_CHECK("sqnorm_part");
   hipLaunchKernelGGL(reduce_sum_kernel, dim3(1), dim3(NT), 0, s, scratch, (size_t)blocks, (const float*)nullptr, out);
   UIC_LAUNCH_CHECK("sqnorm_final");
+  return UIC_OK;
+}
+int uic_adam_ranges_launch(const UicAdamParams& a, const UicAdamRanges& r, void* w_out, int w_dtype, hipStream_t s) {
+  if (r.total == 0) return UIC_OK;
+  const int g = grid_for(r.total, NT);
+  if (w_out && w_dtype == UIC_BF16) hipLaunchKernelGGL(adam_ranges_kernel<bf16_t>, dim3(g), dim3(NT), 0, s, a, r, (bf16_t*)w_out);
+  else hipLaunchKernelGGL(adam_ranges_kernel<float>, dim3(g), dim3(NT), 0, s, a, r, (float*)nullptr);   // (f32 operands ARE the masters)
+  UIC_LAUNCH_CHECK("adam_ranges");
   return UIC_OK;
 }
 int uic_adam_launch(const UicAdamParams& a, hipStream_t s) {

@@ -1500,6 +1500,18 @@ __global__ void dec_embed_relu_kernel(const float* __restrict__ w, bf16_t* __res
     *(uint2*)(out + 4 * i) = make_uint2(uic_pack_bf16x2(fmaxf(v.x, 0.f), fmaxf(v.y, 0.f)), uic_pack_bf16x2(fmaxf(v.z, 0.f), fmaxf(v.w, 0.f)));
   }
 }
+// the same from the bf16 copy of the table (relu of a bf16 value: clear the halves whose sign bit is set)
+__global__ void dec_embed_relu16_kernel(const uint2* __restrict__ w, uint2* __restrict__ out, size_t n4) {
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+    uint2 v = w[i];
+    if (v.x & 0x8000u) v.x &= 0xFFFF0000u;
+    if (v.x & 0x80000000u) v.x &= 0x0000FFFFu;
+    if (v.y & 0x8000u) v.y &= 0xFFFF0000u;
+    if (v.y & 0x80000000u) v.y &= 0x0000FFFFu;
+    out[i] = v;
+  }
+}
 
 // the reference stops decoding once every row has finished (AttModel.py:236-238): entries after that step stay zero.
 // status[0] != 0: a persistent launch gave up waiting for its workgroups (bounded spin) and left its outputs partly unwritten --
@@ -1636,10 +1648,12 @@ int uic_rnn_decode_finish_launch(int64_t* seq, float* seq_logp, int N, int L, in
   UIC_LAUNCH_CHECK("dec_finish_kernel");
   return UIC_OK;
 }
-int uic_rnn_decode_embed_relu_launch(const float* embed_w, void* out_bf16, int V1, int E, hipStream_t s) {
+int uic_rnn_decode_embed_relu_launch(const void* embed_w, int table_dtype, void* out_bf16, int V1, int E, hipStream_t s) {
   UIC_REQUIRE(embed_w && out_bf16 && V1 > 0 && E % 4 == 0, "rnn_decode_embed_relu: bad arguments");
   const size_t n4 = (size_t)V1 * E / 4;
-  hipLaunchKernelGGL(dec_embed_relu_kernel, dim3((unsigned)((n4 + 255) / 256 > 4096 ? 4096 : (n4 + 255) / 256)), dim3(256), 0, s, embed_w, (bf16_t*)out_bf16, n4);
+  const dim3 grid((unsigned)((n4 + 255) / 256 > 4096 ? 4096 : (n4 + 255) / 256));
+  if (table_dtype == UIC_BF16) hipLaunchKernelGGL(dec_embed_relu16_kernel, grid, dim3(256), 0, s, (const uint2*)embed_w, (uint2*)out_bf16, n4);
+  else hipLaunchKernelGGL(dec_embed_relu_kernel, grid, dim3(256), 0, s, (const float*)embed_w, (bf16_t*)out_bf16, n4);
   UIC_LAUNCH_CHECK("dec_embed_relu_kernel");
   return UIC_OK;
 }

@@ -240,6 +240,7 @@ Layout make_layout(const uic_topdown_dims& d, void* ws) {
 
 // operand-dtype and transposed weight copies
 struct Derived {
+  const void* embed_w;   // [V1, E] the embedding table in the operand dtype (the f32 master itself in f32 runs)
   const void* fc_w; const void* att_w; const void* ctx2att_w; const void* logit_w;
   const void* att_w_ih; const void* att_w_hh; const void* lang_w_ih; const void* lang_w_hh; const void* h2att_w;
   void* logit_wT;    // [H, V1p]
@@ -280,6 +281,7 @@ Derived make_derived(const uic_topdown_dims& d, const uic_topdown_weights* w, vo
   v.lang_w_ih = copy(w ? w->lang_lstm_w_ih : nullptr, 4 * H * 2 * H);
   v.lang_w_hh = copy(w ? w->lang_lstm_w_hh : nullptr, 4 * H * H);
   v.h2att_w = copy(w ? w->h2att_w : nullptr, A * H);
+  v.embed_w = copy(w ? w->embed_w : nullptr, V1 * E);
   v.logit_wT = b.take(H * V1p * S);
   v.w2T = b.take(3 * H * 4 * H * S);
   v.w1recT = b.take(2 * H * 4 * H * S);
@@ -445,20 +447,6 @@ int attention_step(const uic_topdown_dims& d, const uic_topdown_weights* w, cons
 
 // Side stream + events for the fused training step: the logit layer of finished decode steps (logit GEMM,
 // log-softmax/criterion, dH GEMM, later dW_logit) runs beside the latency-bound recurrence on a second HIP stream.
-__global__ void grad_flag_set_kernel(unsigned* flag, unsigned epoch) {
-  __hip_atomic_store(flag, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-// one wave polls (L1-bypassing agent-scope loads, s_sleep between polls) until the word has reached `epoch`; bounded (~0.2 s)
-__global__ void grad_flag_wait_kernel(const unsigned* flag, unsigned epoch, unsigned* status) {
-  if (threadIdx.x != 0) return;
-  for (int i = 0; i < 4000000; ++i) {
-    const unsigned v = __hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if ((int)(v - epoch) >= 0) return;
-    __builtin_amdgcn_s_sleep(32);
-  }
-  if (status) atomicOr(status, 0x40u);      // (never reached in a healthy run: the step's status word reports it)
-}
-
 constexpr int MAX_CHUNKS = 64;
 struct SideStream {
   hipStream_t stream = nullptr;
@@ -466,12 +454,6 @@ struct SideStream {
   hipEvent_t ev_s3 = nullptr;       // stream3 -> side: that share of every chunk so far is done
   hipStream_t stream4 = nullptr;    // default order: lang_lstm share of a chunk on stream3, att_lstm / h2att share on stream4
   hipEvent_t ev_s4 = nullptr;       // stream4 -> stream3: its share of every chunk is done
-  // uic_topdown_grad_ready_wait's second form: one device word per gradient group, set to the step's epoch by a one-lane kernel
-  // where the group's event is recorded; the waiting stream runs a one-wave kernel that polls the word (no barrier packet parked
-  // in a hardware queue while the step's launch chain is being dispatched -- see the entry point)
-  unsigned* grad_flags = nullptr;   // [3] words, 64 bytes apart
-  unsigned epoch = 0;
-  unsigned* status_word = nullptr;  // the last step's uic_topdown_dims.rnn_status
   hipEvent_t ev_prep = nullptr;     // side -> stream3: the embedding gradient's token bucketing is done
   hipEvent_t ev_den = nullptr, ev_done = nullptr;
   hipEvent_t ev_pro3 = nullptr;     // third stream: its branch of the forward prologue (fc_embed, Gfc, initial state) is through
@@ -487,6 +469,17 @@ struct SideStream {
   // in front of them, everything else gets them through wait_refresh.
   hipEvent_t ev_cast = nullptr;
   bool cast_recorded = false, transposes_pending = false;
+  // uic_topdown_refresh_weights_gathered (deferred form): the side stream's copies of gather group 2 (embedding table, fc_embed,
+  // att_lstm.weight_ih) are done -- the fused step's third stream (fc_embed, Gfc) waits for it; cleared by every other refresh
+  hipEvent_t ev_g2 = nullptr;
+  bool g2_recorded = false;
+  // ... and its late half: the copies of gather groups 1 and 0 (recurrent LSTM matrices, logit layer), the last bytes to arrive.
+  // Deferred to the fused step, which enqueues them BEHIND its third stream's prologue branch -- in front of it they would hold
+  // that branch back until the last all-gather is through; nothing before the recurrence reads them (ev_gl: they are done)
+  bool gl_pending = false, gl_recorded = false;
+  hipEvent_t ev_gl = nullptr;
+  const void* gl_src[UIC_CAST_MULTI]; void* gl_dst[UIC_CAST_MULTI]; size_t gl_bytes[UIC_CAST_MULTI]; int gl_count = 0;
+  void* gl_ready[2] = {nullptr, nullptr};
   uic_topdown_dims tp_d; uic_topdown_weights tp_w; void* tp_derived = nullptr;
   hipEvent_t ev_main[MAX_CHUNKS];   // main  -> side: decode steps of chunk c are finished
   hipEvent_t ev_side[MAX_CHUNKS];   // side  -> main: d hdrop of chunk c is ready
@@ -519,8 +512,6 @@ int get_side(SideStream** out) {
     ss.stream4 = ss.stream3;
     UIC_TRY(uic_check_hip(hipEventCreateWithFlags(&ss.ev_s3, hipEventDisableTiming), "hipEventCreate"));
     UIC_TRY(uic_check_hip(hipEventCreateWithFlags(&ss.ev_s4, hipEventDisableTiming), "hipEventCreate"));
-    UIC_TRY(uic_check_hip(hipMalloc((void**)&ss.grad_flags, 64), "hipMalloc(grad flags)"));
-    UIC_TRY(uic_check_hip(hipMemset(ss.grad_flags, 0, 64), "hipMemset(grad flags)"));
     UIC_TRY(uic_check_hip(hipEventCreateWithFlags(&ss.ev_prep, hipEventDisableTiming), "hipEventCreate"));
     UIC_TRY(uic_check_hip(hipEventCreateWithFlags(&ss.ev_den, hipEventDisableTiming), "hipEventCreate"));
     UIC_TRY(uic_check_hip(hipEventCreateWithFlags(&ss.ev_done, hipEventDisableTiming), "hipEventCreate"));
@@ -532,6 +523,8 @@ int get_side(SideStream** out) {
     UIC_TRY(uic_check_hip(hipEventCreateWithFlags(&ss.ev_r0, hipEventDisableTiming), "hipEventCreate"));
     UIC_TRY(uic_check_hip(hipEventCreateWithFlags(&ss.ev_refresh, hipEventDisableTiming), "hipEventCreate"));
     UIC_TRY(uic_check_hip(hipEventCreateWithFlags(&ss.ev_cast, hipEventDisableTiming), "hipEventCreate"));
+    UIC_TRY(uic_check_hip(hipEventCreateWithFlags(&ss.ev_g2, hipEventDisableTiming), "hipEventCreate"));
+    UIC_TRY(uic_check_hip(hipEventCreateWithFlags(&ss.ev_gl, hipEventDisableTiming), "hipEventCreate"));
     for (int i = 0; i < UIC_STEP_MARKS; ++i) UIC_TRY(uic_check_hip(hipEventCreate(&ss.mark[i]), "hipEventCreate"));
     for (int i = 0; i < MAX_CHUNKS; ++i) {
       UIC_TRY(uic_check_hip(hipEventCreateWithFlags(&ss.ev_main[i], hipEventDisableTiming), "hipEventCreate"));
@@ -543,10 +536,24 @@ int get_side(SideStream** out) {
   return UIC_OK;
 }
 
+// the late half of uic_topdown_refresh_weights_gathered (see SideStream::gl_pending), on `st`
+int flush_gathered_late(SideStream* ss, hipStream_t st) {
+  if (!ss->gl_pending) return UIC_OK;
+  ss->gl_pending = false;
+  for (int i = 0; i < 2; ++i)
+    if (ss->gl_ready[i]) UIC_TRY(uic_check_hip(hipStreamWaitEvent(st, (hipEvent_t)ss->gl_ready[i], 0), "hipStreamWaitEvent(gathered)"));
+  UIC_TRY(uic_copy_multi_launch(ss->gl_count, ss->gl_src, ss->gl_dst, ss->gl_bytes, st));
+  UIC_TRY(uic_check_hip(hipEventRecord(ss->ev_gl, st), "hipEventRecord"));
+  ss->gl_recorded = true;
+  return UIC_OK;
+}
+
 // the deferred half of uic_topdown_refresh_weights: the transposed copies the backward pass reads, on the side stream
 int flush_transposes(SideStream* ss) {
+  if (ss->gl_pending) UIC_TRY(flush_gathered_late(ss, ss->stream));
   if (!ss->transposes_pending) return UIC_OK;
   ss->transposes_pending = false;
+  if (ss->gl_recorded) UIC_TRY(uic_check_hip(hipStreamWaitEvent(ss->stream, ss->ev_gl, 0), "hipStreamWaitEvent(gathered late)"));
   const uic_topdown_dims* d = &ss->tp_d;
   const Derived v = make_derived(*d, &ss->tp_w, ss->tp_derived);
   hipStream_t s2 = ss->stream;
@@ -635,6 +642,9 @@ int uic_topdown_refresh_weights_deferred(const uic_topdown_dims* d, const uic_to
   UIC_TRY(get_side(&ss));
   hipStream_t s2 = ss->stream;
   if (ss->transposes_pending && ss->tp_derived != derived) UIC_TRY(flush_transposes(ss));   // another model's deferred half
+  ss->g2_recorded = false;
+  ss->gl_pending = false;                             // (a gathered refresh nobody consumed: this refresh rewrites every copy)
+  ss->gl_recorded = false;
   UIC_TRY(uic_check_hip(hipEventRecord(ss->ev_r0, s), "hipEventRecord"));          // the master weights are final
   UIC_TRY(uic_check_hip(hipStreamWaitEvent(s2, ss->ev_r0, 0), "hipStreamWaitEvent"));
   if (dt == UIC_BF16) {   // one launch per stream (the step waits for launches here, not for bytes)
@@ -645,10 +655,11 @@ int uic_topdown_refresh_weights_deferred(const uic_topdown_dims* d, const uic_to
       UIC_TRY(uic_cast_f32_multi_launch(dt, 4, src, dst, n, s));
     }
     {
-      const float* src[5] = {w->logit_w, w->att_lstm_w_hh, w->lang_lstm_w_ih, w->lang_lstm_w_hh, w->h2att_w};
-      void* dst[5] = {(void*)v.logit_w, (void*)v.att_w_hh, (void*)v.lang_w_ih, (void*)v.lang_w_hh, (void*)v.h2att_w};
-      const size_t n[5] = {(size_t)V1 * H, (size_t)4 * H * H, (size_t)4 * H * 2 * H, (size_t)4 * H * H, (size_t)A * H};
-      UIC_TRY(uic_cast_f32_multi_launch(dt, 5, src, dst, n, s2));
+      // (the embedding table first: the side stream's branch of the fused step's prologue starts with the lookup)
+      const float* src[6] = {w->embed_w, w->logit_w, w->att_lstm_w_hh, w->lang_lstm_w_ih, w->lang_lstm_w_hh, w->h2att_w};
+      void* dst[6] = {(void*)v.embed_w, (void*)v.logit_w, (void*)v.att_w_hh, (void*)v.lang_w_ih, (void*)v.lang_w_hh, (void*)v.h2att_w};
+      const size_t n[6] = {(size_t)V1 * E, (size_t)V1 * H, (size_t)4 * H * H, (size_t)4 * H * 2 * H, (size_t)4 * H * H, (size_t)A * H};
+      UIC_TRY(uic_cast_f32_multi_launch(dt, 6, src, dst, n, s2));
     }
   }
   if (d->use_bn) {
@@ -668,6 +679,96 @@ int uic_topdown_refresh_weights_deferred(const uic_topdown_dims* d, const uic_to
   // the transposes (backward pass only) follow when the first consumer asks for them: flush_transposes
   ss->tp_d = *d; ss->tp_w = *w; ss->tp_derived = derived;
   ss->transposes_pending = true;
+  return UIC_OK;
+}
+
+
+// The refresh of a data-parallel rank whose optimizer is sharded (reduce-scatter -> Adam on the rank's shard -> all-gather of the
+// updated weights in the operand dtype): the operand copies are not cast from the f32 masters -- a rank's masters are current only
+// inside its own shard -- but copied from the all-gathered operand-dtype arena (`g`), each gather group behind the event the
+// caller recorded after that group's all-gather.  f32 operands: the gathered tensors ARE the masters (make_derived points at
+// them); the call only orders the streams behind the events.
+int uic_topdown_refresh_weights_gathered(const uic_topdown_dims* d, const uic_topdown_weights* w, const uic_topdown_gathered* g,
+                                         void* derived, int32_t deferred, void* stream) {
+  UIC_TRY(check_dims(d));
+  UIC_REQUIRE(w && g && derived, "refresh_weights_gathered: null pointer");
+  hipStream_t s = (hipStream_t)stream;
+  const Derived v = make_derived(*d, w, derived);
+  const int dt = d->dtype;
+  const size_t D = d->D, Dfc = d->Dfc, H = d->H, E = d->E, A = d->A, V1 = d->V1, S = uic_dtype_size(dt);
+  SideStream* ss = nullptr;
+  UIC_TRY(get_side(&ss));
+  hipStream_t s2 = ss->stream;
+  if (ss->transposes_pending && ss->tp_derived != derived) UIC_TRY(flush_transposes(ss));
+  ss->gl_pending = false;                             // (a gathered refresh nobody consumed: this one rewrites every copy)
+  ss->g2_recorded = false;
+  ss->gl_recorded = false;
+  auto wait_group = [&](hipStream_t st, int grp) -> int {
+    if (g->ready[grp]) UIC_TRY(uic_check_hip(hipStreamWaitEvent(st, (hipEvent_t)g->ready[grp], 0), "hipStreamWaitEvent(gathered)"));
+    return UIC_OK;
+  };
+  if (dt != UIC_BF16) {
+    // f32 operands: nothing to copy; every consumer stream is ordered behind `s`, which waits for all four groups
+    UIC_REQUIRE((!g->logit_w || g->logit_w == w->logit_w) && (!g->embed_w || g->embed_w == w->embed_w) && (!g->att_w || g->att_w == w->att_w),
+                "refresh_weights_gathered: with f32 operands the gathered tensors must be the masters themselves");
+    for (int grp = 3; grp >= 0; --grp) UIC_TRY(wait_group(s, grp));
+    return deferred ? uic_topdown_refresh_weights_deferred(d, w, derived, stream) : uic_topdown_refresh_weights(d, w, derived, stream);
+  }
+  UIC_REQUIRE(g->embed_w && g->fc_w && g->logit_w && g->ctx2att_w && g->att_lstm_w_ih && g->att_lstm_w_hh && g->lang_lstm_w_ih &&
+                  g->lang_lstm_w_hh && g->h2att_w && (g->att_w || d->use_bn),
+              "refresh_weights_gathered: a gathered tensor is missing");
+  UIC_TRY(uic_check_hip(hipEventRecord(ss->ev_r0, s), "hipEventRecord"));          // whatever the caller enqueued before (the replicated f32 tensors' update)
+  UIC_TRY(uic_check_hip(hipStreamWaitEvent(s2, ss->ev_r0, 0), "hipStreamWaitEvent"));
+  {   // gather group 3 on the caller's stream: all the main branch of the fused step's prologue reads (att_embed, ctx2att) + h2att
+    UIC_TRY(wait_group(s, 3));
+    const void* src[3] = {d->use_bn ? nullptr : g->att_w, g->ctx2att_w, g->h2att_w};
+    void* dst[3] = {(void*)v.att_w, (void*)v.ctx2att_w, (void*)v.h2att_w};
+    const size_t n[3] = {d->use_bn ? 0 : H * D * S, A * H * S, A * H * S};
+    UIC_TRY(uic_copy_multi_launch(3, src, dst, n, s));
+  }
+  {   // group 2 on the side stream (its prologue branch -- embedding lookup, batched input GEMM -- follows there; the third stream's
+      // fc_embed / Gfc wait for ev_g2), then the recurrence's and the logit layer's groups
+    UIC_TRY(wait_group(s2, 2));
+    const void* src[3] = {g->embed_w, g->fc_w, g->att_lstm_w_ih};
+    void* dst[3] = {(void*)v.embed_w, (void*)v.fc_w, (void*)v.att_w_ih};
+    const size_t n[3] = {V1 * E * S, H * Dfc * S, 4 * H * (E + 2 * H) * S};
+    UIC_TRY(uic_copy_multi_launch(3, src, dst, n, s2));
+    UIC_TRY(uic_check_hip(hipEventRecord(ss->ev_g2, s2), "hipEventRecord"));
+    ss->g2_recorded = true;
+  }
+  {
+    UIC_REQUIRE(d->logit_layers - 1 + 4 <= UIC_CAST_MULTI, "refresh_weights_gathered: too many logit layers (%d)", d->logit_layers);
+    int k = 0;
+    auto add = [&](const void* src, const void* dst, size_t bytes) { ss->gl_src[k] = src; ss->gl_dst[k] = (void*)dst; ss->gl_bytes[k] = bytes; ++k; };
+    add(g->att_lstm_w_hh, v.att_w_hh, 4 * H * H * S);
+    add(g->lang_lstm_w_ih, v.lang_w_ih, 4 * H * 2 * H * S);
+    add(g->lang_lstm_w_hh, v.lang_w_hh, 4 * H * H * S);
+    add(g->logit_w, v.logit_w, V1 * H * S);
+    for (int l = 0; l + 1 < d->logit_layers; ++l) {
+      UIC_REQUIRE(g->logit_h_w[l] && w->logit_h_b[l], "logit_layers=%d needs the hidden logit block %d", d->logit_layers, l);
+      add(g->logit_h_w[l], v.logit_h_w[l], H * H * S);
+    }
+    ss->gl_count = k;
+    ss->gl_ready[0] = g->ready[1]; ss->gl_ready[1] = g->ready[0];
+    ss->gl_pending = true;
+    ss->gl_recorded = false;
+    if (!deferred) UIC_TRY(flush_gathered_late(ss, s2));
+  }
+  if (d->use_bn) {   // att_embed's Linear with the BatchNorm folded in needs the f32 master: the caller keeps that tensor replicated
+    UIC_REQUIRE(w->att_bn0_w && w->att_bn0_b && w->att_bn0_rm && w->att_bn0_rv, "use_bn=%d needs the att_embed.0 BatchNorm tensors", d->use_bn);
+    UIC_TRY(uic_bn_fold_weight_launch(dt, w->att_w, w->att_bn0_w, w->att_bn0_b, w->att_b, (int)H, (int)D, (void*)v.att_w, v.att_beff, s));
+  }
+  UIC_TRY(uic_check_hip(hipEventRecord(ss->ev_r0, s), "hipEventRecord"));          // the side stream's transposes read ctx2att / h2att copied on `s`
+  UIC_TRY(uic_check_hip(hipStreamWaitEvent(s2, ss->ev_r0, 0), "hipStreamWaitEvent"));
+  UIC_TRY(uic_check_hip(hipEventRecord(ss->ev_cast, s2), "hipEventRecord"));
+  ss->cast_recorded = true;
+  ss->tp_d = *d; ss->tp_w = *w; ss->tp_derived = derived;
+  ss->transposes_pending = true;
+  if (!deferred) {
+    // any consumer may follow on `s` (decode passes, single calls): everything the side stream copied is ordered in front of it
+    UIC_TRY(flush_transposes(ss));
+    UIC_TRY(uic_check_hip(hipStreamWaitEvent(s, ss->ev_refresh, 0), "hipStreamWaitEvent(refresh)"));
+  }
   return UIC_OK;
 }
 
@@ -728,7 +829,7 @@ struct Step {
   bool gfc_separate() const { return UIC_GFC_SEPARATE && persist_ok(); }
   int fwd_embed(hipStream_t s) {
     // xt_t = dropout(relu(embed[labels[:, t]])) for all steps (AttModel.py:145,160)
-    return uic_embed_fwd_launch(dt, w->embed_w, V1, E, b->labels, b->ld_labels, N, t_run, drop_p, seed, UIC_SITE_EMBED, 0, 1, L.xt_all, s);
+    return uic_embed_fwd_t_launch(dt, dv.embed_w, dt, V1, E, b->labels, b->ld_labels, N, t_run, drop_p, seed, UIC_SITE_EMBED, 0, 1, L.xt_all, s);
   }
   int fwd_gx(hipStream_t s, bool with_gfc) {
     // Gx = xt W_ih[:, 2H:]^T + b_ih + b_hh [+ Gfc (every step's rows get their caption row's fc' term)], all steps
@@ -762,7 +863,7 @@ struct Step {
 
   // step t's embedding row block and its slice of Gx from the tokens tok[n * ld] (the prologue made them from the labels)
   int fwd_step_inputs(int t, const int64_t* tok, int ld, hipStream_t s) {
-    UIC_TRY(uic_embed_fwd_launch(dt, w->embed_w, V1, E, tok, ld, N, 1, drop_p, seed, UIC_SITE_EMBED,
+    UIC_TRY(uic_embed_fwd_t_launch(dt, dv.embed_w, dt, V1, E, tok, ld, N, 1, drop_p, seed, UIC_SITE_EMBED,
                                  (size_t)t * N * E, 1, offw(L.xt_all, (size_t)t * N * E, dt), s));
     UicGemmParams g = gemm_base(dt, N, H4);
     add_seg(g, off(L.xt_all, (size_t)t * N * E, dt), E, off(dv.att_w_ih, 2 * H, dt), ldih, E);
@@ -791,7 +892,7 @@ struct Step {
   }
   int decode_persist(int Lsteps, int sample_max, const int64_t* forced, bool keep, int64_t* seq, float* seq_logp, hipStream_t s) {
     UIC_TRY(fwd_gfc(s, true));
-    UIC_TRY(uic_rnn_decode_embed_relu_launch(w->embed_w, L.dec_embed_relu, V1, E, s));
+    UIC_TRY(uic_rnn_decode_embed_relu_launch(dv.embed_w, dt, L.dec_embed_relu, V1, E, s));
     UIC_TRY(uic_fill_launch(L.dec_tok, 0, (size_t)N * 4, s));          // <bos> = 0 (AttModel.py:214-215)
     UicRnnFwdParams p;
     memset(&p, 0, sizeof(p));
@@ -1379,7 +1480,7 @@ int decode_step(const uic_topdown_dims& d, const uic_topdown_weights* w, const D
   const int N = d.N, H = d.H, E = d.E, V1 = d.V1;
   const int V1p = (int)vpad(V1), H4 = 4 * H, ldih = E + 2 * H;
   // (xt_ready: the sampling kernel of the previous step already wrote this step's embedding rows into L.s_xt)
-  if (!xt_ready) UIC_TRY(uic_embed_fwd_launch(dt, w->embed_w, V1, E, L.s_it, 1, N, 1, drop_p, seed, UIC_SITE_EMBED, (size_t)t * N * E, 1, L.s_xt, s));
+  if (!xt_ready) UIC_TRY(uic_embed_fwd_t_launch(dt, dv.embed_w, dt, V1, E, L.s_it, 1, N, 1, drop_p, seed, UIC_SITE_EMBED, (size_t)t * N * E, 1, L.s_xt, s));
   {
     UicGemmParams g = gemm_base(dt, N, H4);
     g.lstm = 1; g.H = H;
@@ -1436,8 +1537,8 @@ int uic_topdown_forward(const uic_topdown_dims* d, const uic_topdown_weights* w,
   hipStream_t s = (hipStream_t)stream;
   Step st;
   st.init(d, w, derived, b, t_run, training, seed, workspace, nullptr);
+  UIC_TRY(wait_refresh(s));                           // (the embedding table's operand copy is made on the side stream)
   UIC_TRY(st.fwd_prologue(s));
-  UIC_TRY(wait_refresh(s));
   UIC_TRY(st.fwd_steps(0, t_run, s));
   UIC_TRY(st.logits_rows(0, t_run, s));
   if (logprobs_out) UIC_TRY(st.xe_rows(0, t_run, nullptr, logprobs_out, 0, s));
@@ -1523,8 +1624,6 @@ int uic_topdown_xe_train_step(const uic_topdown_dims* d, const uic_topdown_weigh
 #define UIC_HIP(expr) UIC_TRY(uic_check_hip((expr), #expr))
 #define UIC_MARK(i, strm) do { if (ss->marks_on) UIC_HIP(hipEventRecord(ss->mark[i], strm)); } while (0)
 
-  ++ss->epoch;
-  ss->status_word = (unsigned*)d->rnn_status;
   UIC_MARK(0, s);
   // main: features, recurrence; hands each finished chunk of steps to the side stream.  ev_den: the step has begun (whatever
   // the caller enqueued on `s` before it is done) -- the side streams start from there.
@@ -1552,12 +1651,15 @@ int uic_topdown_xe_train_step(const uic_topdown_dims* d, const uic_topdown_weigh
     const bool split3 = st.gfc_separate() && !st.ss_on();
     UIC_TRY(st.fwd_prologue(s, 2));
     UIC_TRY(st.fwd_prologue(s2, split3 ? 3 : 1));
+    if (!split3) UIC_TRY(flush_gathered_late(ss, s2));
     UIC_HIP(hipEventRecord(ss->ev_pro, s2));
     if (split3) {
       UIC_HIP(hipStreamWaitEvent(s3, ss->ev_den, 0));
+      if (ss->g2_recorded) UIC_HIP(hipStreamWaitEvent(s3, ss->ev_g2, 0));   // (gathered refresh: fc_embed's operand copy was made on the side stream)
       UIC_TRY(st.fwd_prologue(s3, 4));
       UIC_TRY(st.bwd_begin(s3));                      // (the BPTT loop's zeroed carries and ones block: nothing in the forward pass touches them)
       bwd_begun = true;
+      UIC_TRY(flush_gathered_late(ss, s3));           // (gathered refresh: the recurrence's and the logit layer's operand copies, last to arrive)
       UIC_HIP(hipEventRecord(ss->ev_pro3, s3));
     }
     UIC_TRY(flush_transposes(ss));                    // (behind the branch: only the backward pass reads them)
@@ -1610,9 +1712,6 @@ int uic_topdown_xe_train_step(const uic_topdown_dims* d, const uic_topdown_weigh
   UIC_TRY(st.logit_weight_grads(s2, true));
   UIC_TRY(uic_reduce_sum_launch(st.L.row_loss, (size_t)t_run * d->N, 0.f, inv, loss_out, s2));
   if (den_out) UIC_TRY(uic_copy_launch(den_out, st.L.scalars, 4, s2));
-  // (the flag kernels come BEFORE their events: a stream's last launch has to be one the caller's stream joins, or the step
-  // cannot be captured into a hipGraph -- hipErrorStreamCaptureUnjoined)
-  hipLaunchKernelGGL(grad_flag_set_kernel, dim3(1), dim3(1), 0, s2, ss->grad_flags + 0, ss->epoch);
   UIC_HIP(hipEventRecord(ss->ev_logit, s2));          // gradient group 0 (logit layer) final: its exchange can start now
   UIC_MARK(10, s2);
   // main: BPTT, each step waits for the d hdrop rows of its chunk; side: the recurrent weight gradients of every
@@ -1698,7 +1797,6 @@ int uic_topdown_xe_train_step(const uic_topdown_dims* d, const uic_topdown_weigh
   g_uic_tn_ring_off = 0;
   UIC_MARK(5, s);                                     // main: BPTT done
   hipStream_t s_lstm = (early || comm) ? s2 : s3;
-  hipLaunchKernelGGL(grad_flag_set_kernel, dim3(1), dim3(1), 0, s_lstm, ss->grad_flags + 16, ss->epoch);
   UIC_HIP(hipEventRecord(ss->ev_lstm, s_lstm));       // gradient group 1 final (uic_topdown_grad_ready_wait)
   UIC_MARK(6, s_lstm);                                // side: recurrent weight gradients done
   UIC_TRY(st.bwd_epilogue_late(s, true));             // (enqueued first: it is the longer of the two tails)
@@ -1711,7 +1809,6 @@ int uic_topdown_xe_train_step(const uic_topdown_dims* d, const uic_topdown_weigh
     UIC_HIP(hipStreamWaitEvent(s2, ss->ev_lstm, 0));  // the early group includes them; bias_hh = bias_ih needs the bias columns
     UIC_TRY(st.bias_hh_copies(s2));
   }
-  hipLaunchKernelGGL(grad_flag_set_kernel, dim3(1), dim3(1), 0, s2, ss->grad_flags + 32, ss->epoch);
   UIC_HIP(hipEventRecord(ss->ev_early, s2));
   ss->early_recorded = true;
   UIC_MARK(8, s2);
@@ -1741,15 +1838,8 @@ int uic_topdown_step_marks(int32_t enable, float* ms_out) {
 int uic_topdown_grad_ready_wait(void* stream, int32_t group) {
   SideStream* ss = nullptr;
   UIC_TRY(get_side(&ss));
-  const bool poll = (group & UIC_GRAD_WAIT_POLL) != 0;
-  group &= ~UIC_GRAD_WAIT_POLL;
   UIC_REQUIRE(group >= 0 && group <= 2, "grad_ready_wait: group=%d must be 0 (logit layer), 1 (LSTM weights) or 2 (early group)", group);
   UIC_REQUIRE(ss->early_recorded, "grad_ready_wait: no uic_topdown_xe_train_step has run on this device yet");
-  if (poll) {
-    hipLaunchKernelGGL(grad_flag_wait_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, ss->grad_flags + 16 * group, ss->epoch, ss->status_word);
-    UIC_LAUNCH_CHECK("grad_flag_wait_kernel");
-    return UIC_OK;
-  }
   hipEvent_t ev = group == 0 ? ss->ev_logit : group == 1 ? ss->ev_lstm : ss->ev_early;
   return uic_check_hip(hipStreamWaitEvent((hipStream_t)stream, ev, 0), "hipStreamWaitEvent");
 }
@@ -1801,7 +1891,7 @@ int uic_topdown_sample(const uic_topdown_dims* d, const uic_topdown_weights* w, 
     p.seq = seq; p.seq_logp = seq_logp; p.it = L.s_it; p.unfinished = L.s_unf; p.n_unfinished = L.s_nunf;
     p.forced = forced;
     if (t + 1 < Lsteps) {      // the next step's embedding rows ride in the sampling kernel (one launch less per step)
-      p.embed_table = w->embed_w; p.embed_V1 = V1; p.embed_E = d->E; p.embed_drop_p = drop_p; p.embed_site = UIC_SITE_EMBED;
+      p.embed_table = dv.embed_w; p.embed_table_dtype = dt; p.embed_V1 = V1; p.embed_E = d->E; p.embed_drop_p = drop_p; p.embed_site = UIC_SITE_EMBED;
       p.embed_idx_base = (size_t)(t + 1) * N * d->E; p.xt_out = L.s_xt;
     }
     UIC_TRY(uic_sample_step_launch(p, s));
@@ -1840,7 +1930,7 @@ int uic_topdown_sample_train(const uic_topdown_dims* d, const uic_topdown_weight
   UIC_TRY(uic_fill_launch(L.s_nunf, 0, (size_t)(d->T + 2) * UIC_NUNF_STRIPES * 4, s));
   for (int t = 0; t < Lsteps; ++t) {
     if (t == 0)   // (later steps: written by the previous step's sampling kernel)
-      UIC_TRY(uic_embed_fwd_launch(st.dt, w->embed_w, st.V1, st.E, L.s_it, 1, N, 1, st.drop_p, seed, UIC_SITE_EMBED,
+      UIC_TRY(uic_embed_fwd_t_launch(st.dt, st.dv.embed_w, st.dt, st.V1, st.E, L.s_it, 1, N, 1, st.drop_p, seed, UIC_SITE_EMBED,
                                    (size_t)t * N * st.E, 1, offw(L.xt_all, (size_t)t * N * st.E, st.dt), s));
     UIC_TRY(st.fwd_step(t, s, true));
     UIC_TRY(st.logits_rows_now(t, t + 1, s));
@@ -1852,7 +1942,7 @@ int uic_topdown_sample_train(const uic_topdown_dims* d, const uic_topdown_weight
     p.seq = seq; p.seq_logp = seq_logp; p.it = L.s_it; p.unfinished = L.s_unf; p.n_unfinished = L.s_nunf;
     p.forced = forced;
     if (t + 1 < Lsteps) {
-      p.embed_table = w->embed_w; p.embed_V1 = st.V1; p.embed_E = st.E; p.embed_drop_p = st.drop_p; p.embed_site = UIC_SITE_EMBED;
+      p.embed_table = st.dv.embed_w; p.embed_table_dtype = st.dt; p.embed_V1 = st.V1; p.embed_E = st.E; p.embed_drop_p = st.drop_p; p.embed_site = UIC_SITE_EMBED;
       p.embed_idx_base = (size_t)(t + 1) * N * st.E; p.xt_out = offw(L.xt_all, (size_t)(t + 1) * N * st.E, st.dt);
     }
     UIC_TRY(uic_sample_step_launch(p, s));

@@ -349,7 +349,7 @@ size_t uic_rnn_decode_part_floats(int N);
 // log-probs recorded at steps after every row had finished are zeroed (their tokens already are).  status (the caller's
 // rnn_status words or NULL): a timed-out persistent launch poisons the captions instead (token -1, log-prob NaN)
 int uic_rnn_decode_finish_launch(int64_t* seq, float* seq_logp, int N, int L, int ld, const int* status, hipStream_t s);
-int uic_rnn_decode_embed_relu_launch(const float* embed_w, void* out_bf16, int V1, int E, hipStream_t s);
+int uic_rnn_decode_embed_relu_launch(const void* embed_w, int table_dtype, void* out_bf16, int V1, int E, hipStream_t s);
 bool uic_rnn_persist_eligible(int dtype, int N, int H, int A, int R);
 int uic_rnn_fwd_persist_launch(const UicRnnFwdParams& p, hipStream_t s);
 
@@ -469,6 +469,7 @@ int uic_rnn_bwd_persist_launch(const UicRnnBwdParams& p, hipStream_t s);
 int uic_cast_f32_launch(int dtype, const float* src, void* dst, size_t n, hipStream_t s);
 int uic_to_f32_launch(int dtype, const void* src, float* dst, size_t n, hipStream_t s);
 #define UIC_CAST_MULTI 6
+int uic_copy_multi_launch(int count, const void* const* src, void* const* dst, const size_t* bytes, hipStream_t s);
 int uic_cast_f32_multi_launch(int dtype, int count, const float* const* src, void* const* dst, const size_t* n, hipStream_t s);   // several casts, one launch
 int uic_fill_launch(void* dst, int value_byte, size_t bytes, hipStream_t s);
 int uic_copy_launch(void* dst, const void* src, size_t bytes, hipStream_t s);
@@ -489,6 +490,9 @@ int uic_colsum_launch(int src_dtype, const void* src, int rows, int cols, int ld
                       size_t scratch_floats, hipStream_t s);
 // dst[n, c] = sum_t src[t, n, c]
 int uic_sum_steps_launch(int dtype, const void* src, int T, size_t step_elems, void* dst, hipStream_t s);
+// table in f32 (table_dtype = UIC_F32) or, for bf16 outputs only, in bf16
+int uic_embed_fwd_t_launch(int dtype, const void* table, int table_dtype, int V1, int E, const int64_t* tokens, int ldtok, int N, int T,
+                           float drop_p, unsigned seed, unsigned site, size_t idx_base, int relu, void* out, hipStream_t s);
 int uic_embed_fwd_launch(int dtype, const float* table, int V1, int E, const int64_t* tokens, int ldtok, int N, int T,
                          float drop_p, unsigned seed, unsigned site, size_t idx_base, int relu, void* out, hipStream_t s);
 // the embedding gradient (nn.Embedding backward; skip_token < 0: none, nn.Embedding padding_idx otherwise) with the positions bucketed by token first (a stable counting sort), so that runs of equal tokens are summed in
@@ -612,6 +616,9 @@ struct UicAdamParams {
 // out[0] = sum_i g[i]^2, deterministic two-stage reduction; scratch >= 1024 floats
 int uic_sqnorm_launch(const float* g, size_t n, float* scratch, float* out, hipStream_t s);
 int uic_adam_launch(const UicAdamParams& a, hipStream_t s);
+constexpr int UIC_ADAM_RANGES = 24;
+struct UicAdamRanges { int count; size_t total; size_t lo[UIC_ADAM_RANGES]; size_t start[UIC_ADAM_RANGES]; };
+int uic_adam_ranges_launch(const UicAdamParams& a, const UicAdamRanges& r, void* w_out, int w_dtype, hipStream_t s);
 
 constexpr int UIC_NUNF_STRIPES = 64;
 struct UicSampleParams {
@@ -632,7 +639,7 @@ struct UicSampleParams {
   // optional: the NEXT step's embedding row of every caption row, written by the workgroup that just chose its token
   // (xt_out[n, :] = dropout(relu(embed_table[it[n]])), element index embed_idx_base + n * E + e at site embed_site, seed `seed`):
   // one launch less per decode step
-  const float* embed_table; int embed_V1, embed_E; float embed_drop_p; unsigned embed_site; size_t embed_idx_base; void* xt_out;
+  const void* embed_table; int embed_table_dtype; int embed_V1, embed_E; float embed_drop_p; unsigned embed_site; size_t embed_idx_base; void* xt_out;
 };
 int uic_sample_step_launch(const UicSampleParams& p, hipStream_t s);
 // ---- beam search bookkeeping (beam.hip): rows = (image, beam)

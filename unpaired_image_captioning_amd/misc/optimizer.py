@@ -22,16 +22,59 @@ from .._lib import check, ptr, stream
 
 
 class FlatArena(object):
-    """All parameters of a module re-homed into one flat f32 tensor (plus same-layout grad / Adam arenas)."""
+    """All parameters of a module re-homed into one flat f32 tensor (plus same-layout grad / Adam arenas).
 
-    def __init__(self, module, names=None):
+    pieces (data parallel, world > 1): lists of parameter names -- the SHARDED gradient pieces, in the order in which the backward
+    pass makes them final.  Each piece is padded to a multiple of 64 * world elements and split evenly over the ranks: rank r owns
+    elements [off + r * len / world, off + (r + 1) * len / world) of every piece -- it receives that slice of the summed gradient
+    from the reduce-scatter, runs Adam on it and contributes it to the all-gather of the updated weights.  Parameters of `names` in
+    no piece are REPLICATED: they sit in a tail region that is all-reduced and updated identically on every rank (biases and the other
+    small tensors the kernels read as f32), followed by 64 scalar slots that ride in the same all-reduce (loss, status word, the
+    next batch's mask sum, squared gradient norm).  operand_dtype (torch.bfloat16): the all-gather distributes the weights in the
+    operand dtype from `w16` (half the bytes; a rank's f32 masters are then current only inside its own shard until
+    gather_masters()); None / float32: the all-gather runs on the f32 masters in place."""
+
+    SCALAR_SLOTS = 64
+
+    def __init__(self, module, names=None, world=1, rank=0, pieces=None, operand_dtype=None):
         params = dict(module.named_parameters())
-        self.names = list(names) if names is not None else list(params.keys())
+        self.world, self.rank = int(world), int(rank)
+        self.pieces, self.piece_names = [], []
         self.offsets = {}
         off = 0
-        for k in self.names:
-            self.offsets[k] = off
-            off += (params[k].numel() + 63) // 64 * 64          # 256-byte aligned blocks
+        if pieces:
+            all_names = list(names) if names is not None else list(params.keys())
+            unit = 64 * self.world
+            sharded = []
+            for piece in pieces:
+                piece = [k for k in piece if k in params]
+                if not piece:
+                    continue
+                start = off
+                for k in piece:
+                    self.offsets[k] = off
+                    off += (params[k].numel() + 63) // 64 * 64
+                off = start + (off - start + unit - 1) // unit * unit
+                self.pieces.append((start, off - start))
+                self.piece_names.append(piece)
+                sharded += piece
+            self.replicated = [k for k in all_names if k not in self.offsets]
+            self.names = sharded + self.replicated
+            self.repl_off = off
+            for k in self.replicated:
+                self.offsets[k] = off
+                off += (params[k].numel() + 63) // 64 * 64
+            self.repl_end = off
+        else:
+            self.names = list(names) if names is not None else list(params.keys())
+            self.replicated = []
+            for k in self.names:
+                self.offsets[k] = off
+                off += (params[k].numel() + 63) // 64 * 64          # 256-byte aligned blocks
+            self.repl_off = self.repl_end = off
+        self.scalars_off = off
+        if pieces:
+            off += self.SCALAR_SLOTS
         dev = params[self.names[0]].device
         self.numel = off
         self.flat = torch.zeros(off, dtype=torch.float32, device=dev)
@@ -39,6 +82,7 @@ class FlatArena(object):
         self.exp_avg = torch.zeros(off, dtype=torch.float32, device=dev)
         self.exp_avg_sq = torch.zeros(off, dtype=torch.float32, device=dev)
         self.scratch = torch.zeros(1024 + 8, dtype=torch.float32, device=dev)    # sqnorm partials + result
+        self.scalars = self.grad[self.scalars_off:self.scalars_off + self.SCALAR_SLOTS] if pieces else None
         self.grad_views = {}
         self.params = {}
         for k in self.names:
@@ -49,6 +93,136 @@ class FlatArena(object):
             p.data = view
             self.grad_views[k] = self.grad[o:o + n].view(p.shape)
             self.params[k] = p
+        # the all-gathered weights: operand-dtype copies of the sharded region (bf16 runs) or the masters themselves
+        self.operand_dtype = operand_dtype if (pieces and operand_dtype not in (None, torch.float32)) else None
+        self.w16 = None
+        self.masters_stale = False
+        if self.operand_dtype is not None:
+            self.w16 = torch.zeros(self.repl_off, dtype=self.operand_dtype, device=dev)
+            self.sync_operand_copy()
+        self.gathered_views = {}
+        for piece in self.piece_names:
+            for k in piece:
+                o, n = self.offsets[k], self.params[k].numel()
+                src = self.w16 if self.w16 is not None else self.flat
+                self.gathered_views[k] = src[o:o + n].view(self.params[k].shape)
+
+    # ------------------------------------------------------------------ sharded data parallelism
+    def sync_operand_copy(self):
+        """w16 <- cast(masters) over the whole sharded region: after the arena is built and after the masters were written from
+        outside (load_state_dict)."""
+        if self.w16 is not None and self.w16.is_cuda:
+            check(_lib.load().uic_cast_from_f32(_lib.dtype_id("bf16"), ptr(self.flat), ptr(self.w16), self.repl_off, stream()), "cast_from_f32")
+        elif self.w16 is not None:
+            self.w16.copy_(self.flat[:self.repl_off])
+
+    def shard(self, piece, rank=None):
+        """(lo, hi) of rank's slice of gradient piece `piece`."""
+        r = self.rank if rank is None else rank
+        off, n = self.pieces[piece]
+        per = n // self.world
+        return off + r * per, off + (r + 1) * per
+
+    def owned_ranges(self):
+        """The index ranges this rank's Adam updates: its slice of every piece + the replicated tensors (not the scalar slots)."""
+        out = [self.shard(g) for g in range(len(self.pieces))]
+        if self.repl_end > self.repl_off:
+            out.append((self.repl_off, self.repl_end))
+        return out
+
+    def adam_owned(self, lr, betas, eps, step, grad_scale=1.0, max_norm=0.0, sqnorm=None, guard=None):
+        """uic_adam_step_ranges on owned_ranges(); in operand-dtype mode the updated shard is also written to w16 (the rank's
+        contribution to the all-gather)."""
+        import ctypes as C
+        rg = self.owned_ranges()
+        lo = (C.c_uint64 * len(rg))(*[a for a, _ in rg])
+        hi = (C.c_uint64 * len(rg))(*[b for _, b in rg])
+        clip = bool(max_norm and max_norm > 0)
+        check(_lib.load().uic_adam_step_ranges(ptr(self.flat), ptr(self.grad), ptr(self.exp_avg), ptr(self.exp_avg_sq), len(rg), lo, hi,
+                                               lr, betas[0], betas[1], eps, step, grad_scale, float(max_norm) if clip else 0.0,
+                                               ptr(sqnorm) if clip else None, ptr(guard), ptr(self.w16),
+                                               _lib.dtype_id("bf16") if self.w16 is not None else 0, stream()), "adam_step_ranges")
+        if self.w16 is not None and self.world > 1:
+            self.masters_stale = True
+
+    def shard_sqnorm(self):
+        """Sum of g^2 over this rank's slices of the pieces (after the reduce-scatter: of the SUMMED gradient), as a 1-element
+        device tensor; the ranks' values add up to the squared norm of the sharded region."""
+        lib = _lib.load()
+        outs = self.scratch[1025:1025 + len(self.pieces)]
+        for g in range(len(self.pieces)):
+            lo, hi = self.shard(g)
+            check(lib.uic_grad_sqnorm(ptr(self.grad[lo:hi]), hi - lo, ptr(self.scratch), ptr(outs[g:g + 1]), stream()), "grad_sqnorm")
+        return outs.sum().reshape(1)
+
+    def sharded_step(self, ex, lr, betas, eps, step, grad_scale=1.0, max_norm=0.0, wait_piece=None, comm=None, gather_async=False):
+        """One optimizer step of the sharded exchange on this arena (gradients final or becoming final on the current stream):
+
+          1. reduce-scatter every piece -- piece i on the communication stream `comm` behind wait_piece(comm raw stream, i) when
+             that returns True (the piece becomes final while the backward pass still runs), else on the current stream;
+          2. one small all-reduce of the replicated tail + the scalar slots the caller filled beforehand ([0] loss, [1] status
+             flag, [3] the next batch's mask sum; [2] is used here for the clip norm);
+          3. Adam on owned_ranges(), clipped by the GLOBAL gradient norm when max_norm > 0, skipped on the device on every rank when
+             the summed status flag is non-zero;
+          4. all-gather of the updated weights (operand-dtype copy or the f32 masters in place), last piece first -- the order a
+             forward pass consumes them in.  gather_async: on `comm`, one event per piece, the current stream does NOT wait
+             (the next refresh does, group by group); otherwise on the current stream.
+
+        Returns (pair, events): pair = [summed loss, summed status flag] (a fresh 2-float tensor), events = {piece: event} or None."""
+        cur = torch.cuda.current_stream(self.flat.device)
+        used_comm = False
+        for i in range(len(self.pieces)):
+            if comm is not None and wait_piece is not None and wait_piece(comm.cuda_stream, i):
+                with torch.cuda.stream(comm):
+                    ex.reduce_scatter(self.grad, *self.pieces[i])
+                used_comm = True
+            else:
+                ex.reduce_scatter(self.grad, *self.pieces[i])
+        clip = bool(max_norm and max_norm > 0)
+        sc = self.scalars
+        if clip:
+            if used_comm:
+                cur.wait_stream(comm)
+                used_comm = False
+            sc[2:3].copy_(self.shard_sqnorm())
+        ex._sum(self.grad[self.repl_off:self.scalars_off + 4])
+        if used_comm:
+            cur.wait_stream(comm)
+        sq = None
+        if clip:
+            sq = sc[2:3].clone()
+            if self.repl_end > self.repl_off:
+                rs = self.scratch[1024:1025]
+                check(_lib.load().uic_grad_sqnorm(ptr(self.grad[self.repl_off:self.repl_end]), self.repl_end - self.repl_off,
+                                                  ptr(self.scratch), ptr(rs), stream()), "grad_sqnorm")
+                sq += rs
+        pair = sc[0:2].clone()
+        self.adam_owned(lr, betas, eps, step, grad_scale, max_norm if clip else 0.0, sq, guard=pair[1:2])
+        buf = self.w16 if self.w16 is not None else self.flat
+        events = None
+        if gather_async and comm is not None:
+            ev = torch.cuda.Event()
+            ev.record(cur)
+            comm.wait_event(ev)
+            events = {}
+            with torch.cuda.stream(comm):
+                for i in reversed(range(len(self.pieces))):
+                    ex.all_gather(buf, *self.pieces[i])
+                    e = torch.cuda.Event()
+                    e.record(comm)
+                    events[i] = e
+        else:
+            for i in reversed(range(len(self.pieces))):
+                ex.all_gather(buf, *self.pieces[i])
+        return pair, events
+
+    def gather_masters(self, exchange):
+        """All-gather the f32 masters of every piece in place (a collective: every rank calls it), so that each rank's parameters
+        -- state_dict(), a checkpoint -- are the full f32 weights again.  Needed only in operand-dtype mode."""
+        if self.masters_stale and exchange is not None and exchange.world_size > 1:
+            for g in range(len(self.pieces)):
+                exchange.all_gather(self.flat, *self.pieces[g])
+        self.masters_stale = False
 
     def bind_grads(self):
         """Make every p.grad the arena view, so autograd accumulates in place."""
@@ -155,7 +329,16 @@ class Optim(object):
                 dec = [k for k in names if k.startswith("decoder.")]
                 enc = [k for k in names if not k.startswith(("generator.", "decoder."))]
                 names = gen + dec + enc
-            self.nmt_arena = FlatArena(nmt_model, names)
+            ex = self.exchange
+            self.nmt_sharded = bool(ex is not None and ex.world_size > 1 and names is not None and gen and dec and enc and
+                                    not _get(self.opt, 'allreduce_exchange', 0))
+            if self.nmt_sharded:
+                # sharded exchange with the f32 masters as the gathered weights (the pivot model's operand copies are cast from them
+                # by uic_nmt_forward_loss itself): reduce-scatter [generator | decoder | encoder], clipped Adam on this rank's third
+                # of a third, all-gather in place -- the bytes of one all-reduce, an eighth of the optimizer's work
+                self.nmt_arena = FlatArena(nmt_model, names, world=ex.world_size, rank=ex.rank, pieces=[gen, dec, enc])
+            else:
+                self.nmt_arena = FlatArena(nmt_model, names)
             if names is not None and gen and dec and enc:
                 self.nmt_splits = [self.nmt_arena.offsets[dec[0]], self.nmt_arena.offsets[enc[0]]]
             self.nmt_arena.bind_grads()
@@ -198,17 +381,41 @@ class Optim(object):
             # norm of the summed gradient (one pass over the arena after all three pieces)
             m = getattr(self, '_nmt_model', None)
             direct = m is not None and getattr(m, '_sink_written', False)      # the in-place backward ran: its events are recorded
-            self._exchange(self.nmt_arena, getattr(self, 'nmt_splits', None) if direct else None,
-                           lambda raw, g: check(_lib.load().uic_nmt_grad_ready_wait(raw, g), "nmt_grad_ready_wait"))
+            # The first two pieces may travel beside the rest of the backward pass ONLY when that pass is a launch chain: its
+            # persistent launches (csrc/nmt_persist.hip) want one workgroup on EVERY CU and register with a bounded spin, and a CU
+            # that holds an RCCL workgroup waiting for a late peer cannot take one -- every rank would then skip the step with a
+            # PersistentTimeout.  With persistent launches the exchange starts after the backward pass.
+            chain = m is not None and bool(int(getattr(m.engine, 'recurrence', 0)) & _lib.REC_FWD_CHAIN)
+            overlap = direct and chain and self.nmt_arena.grad.is_cuda
+            wait_g = lambda raw, g: check(_lib.load().uic_nmt_grad_ready_wait(raw, g), "nmt_grad_ready_wait")
             self._nmt_steps += 1
-            # the pivot step's persistent launches (csrc/nmt_persist.hip) report a time-out in the status words: the update is
-            # then skipped on the device -- on every rank (the flag is summed over them) -- and Trainer.train_nmt raises
-            guard = None
-            if self.nmt_arena.flat.is_cuda:
-                guard = _lib.status_words(self.nmt_arena.flat.device)
-                if self.exchange is not None and self.exchange.world_size > 1:
-                    guard = guard[0:1].float()
-                    self.exchange._sum(guard)
+            # the pivot step's persistent launches report a time-out in the status words: the update is then skipped on the
+            # device -- on every rank (the flag is summed over them) -- and Trainer.train_nmt raises
+            guard = _lib.status_words(self.nmt_arena.flat.device) if self.nmt_arena.flat.is_cuda else None
+            if getattr(self, 'nmt_sharded', False):
+                a = self.nmt_arena
+                if guard is not None:
+                    a.scalars[1:2].copy_(guard[0:1])
+                else:
+                    a.scalars[1:2].zero_()
+                if getattr(self, '_comm_stream', None) is None and overlap:
+                    self._comm_stream = torch.cuda.Stream(device=a.flat.device)
+
+                def wait_piece(raw, i):
+                    if not overlap or i > 1:
+                        return False
+                    wait_g(raw, i)
+                    return True
+                pair, _ = a.sharded_step(self.exchange, self.nmt_current_lr, (self.nmt_optim_alpha, self.nmt_optim_beta), self.nmt_optim_epsilon,
+                                         self._nmt_steps, nmt_grad_scale, self.nmt_max_grad_norm, wait_piece=wait_piece,
+                                         comm=getattr(self, '_comm_stream', None) if overlap else None)
+                self.last_pair = pair                   # [summed loss (slot 0, filled by the caller), summed status flag]
+                self.last_guard = pair[1:2]
+                return
+            self._exchange(self.nmt_arena, getattr(self, 'nmt_splits', None) if overlap else None, wait_g)
+            if guard is not None and self.exchange is not None and self.exchange.world_size > 1:
+                guard = guard[0:1].float()
+                self.exchange._sum(guard)
             self.last_guard = guard
             self.nmt_arena.adam(self.nmt_current_lr, (self.nmt_optim_alpha, self.nmt_optim_beta), self.nmt_optim_epsilon,
                                 self._nmt_steps, nmt_grad_scale, self.nmt_max_grad_norm, guard=guard)

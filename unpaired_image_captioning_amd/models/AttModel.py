@@ -228,6 +228,16 @@ class AttModel(CaptionModel):
                 if isinstance(m, nn.BatchNorm1d):
                     m.num_batches_tracked += 1
 
+    def state_dict(self, *args, **kwargs):
+        """The reference's checkpoint contract.  Under the sharded data-parallel exchange with bf16 operands a rank's f32 masters
+        are current only inside its own shard between steps: Trainer.gather_masters() (a collective) makes them whole again, and
+        this call refuses to hand out a stale mixture."""
+        stale = getattr(self, '_stale_masters', None)
+        if stale is not None and stale():
+            raise RuntimeError("state_dict(): this rank's f32 master weights are current only inside its own shard (sharded bf16 exchange); "
+                               "call Trainer.gather_masters() -- or save_models() -- on EVERY rank first")
+        return super(AttModel, self).state_dict(*args, **kwargs)
+
     def param_dict(self):
         sd = dict(self.named_parameters())
         return {k: sd[k] for k in self.param_names}

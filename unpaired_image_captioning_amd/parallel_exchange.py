@@ -1,7 +1,15 @@
-"""Data-parallel exchange of the captioner step: one process per GPU, one RCCL all-reduce
-of the flat gradient arena per step over xGMI (backend "nccl" is RCCL on ROCm; "gloo" in the
-CPU tests).  Replaces torch.nn.DataParallel's per-step parameter broadcast, output gather to
-GPU0 and reduce-add (P/trainer.py:74, SURVEY.md section 2a "Collectives").
+"""Data-parallel exchange of the training steps: one process per GPU over RCCL / xGMI (backend "nccl"
+is RCCL on ROCm; "gloo" in the CPU tests).  Replaces torch.nn.DataParallel's per-step parameter
+broadcast, output gather to GPU0 and reduce-add (P/trainer.py:74,88-89).
+
+Default since round 6 -- the SHARDED exchange: the flat gradient arena is cut into
+the pieces the backward pass finishes one after the other; each piece is REDUCE-SCATTERED as soon as it is
+final (beside the rest of the backward pass), every rank runs Adam on its 1/world slice only, and the
+updated weights are ALL-GATHERED in the operand dtype (bf16: half the bytes) in the order the next step's
+forward pass consumes them, beside its feature projection.  The small f32 tensors (biases, ...) and the
+step's scalars (loss, status word, the NEXT batch's mask sum) travel in one small all-reduce.  The
+round-5 path -- all-reduce of the whole arena in four pieces, Adam on everything on every rank -- stays
+available (opt.allreduce_exchange = 1).
 
 Loss normalisation: the reference divides by the mask sum of the WHOLE batch
 (P/misc/criterion.py:149).  Each rank therefore scales its rows by 1 / sum_over_ranks(mask sum)
@@ -105,6 +113,33 @@ class GradientExchange(object):
         torch.cuda.current_stream(flat.device).wait_stream(comm)
         return flat
 
+    # ------------------------------------------------------------------ the sharded exchange (misc/optimizer.py FlatArena pieces)
+    def reduce_scatter(self, flat, off, n):
+        """Sum flat[off:off + n] over the ranks; this rank's slice [off + r n / W, off + (r + 1) n / W) of the sum is left IN PLACE
+        (the rest of the piece is scratch afterwards).  On the current stream."""
+        w, r = self.world_size, self.rank
+        if w == 1:
+            return
+        per = n // w
+        assert per * w == n, "piece length %d is not a multiple of the world size %d" % (n, w)
+        self._reduce_scatter(flat[off:off + n], flat[off + r * per:off + (r + 1) * per])
+
+    def all_gather(self, flat, off, n):
+        """Every rank contributes its slice of flat[off:off + n] (same split as reduce_scatter); afterwards the whole piece is
+        current on every rank.  In place, on the current stream."""
+        w, r = self.world_size, self.rank
+        if w == 1:
+            return
+        per = n // w
+        assert per * w == n, "piece length %d is not a multiple of the world size %d" % (n, w)
+        self._all_gather(flat[off:off + n], flat[off + r * per:off + (r + 1) * per])
+
+    def _reduce_scatter(self, whole, mine):
+        dist.reduce_scatter_tensor(mine, whole, op=dist.ReduceOp.SUM, group=self.group)
+
+    def _all_gather(self, whole, mine):
+        dist.all_gather_into_tensor(whole, mine, group=self.group)
+
     def allreduce_sum_scalar(self, x):
         if self.world_size > 1:
             x = x.clone()
@@ -166,6 +201,20 @@ class UicCommExchange(GradientExchange):
         assert t.is_cuda and t.is_contiguous() and t.dtype in (torch.float32, torch.bfloat16)
         _lib.check(self._lib.uic_comm_allreduce(self._comm, t.data_ptr(), t.numel(), 0 if t.dtype == torch.float32 else 1,
                                                 torch.cuda.current_stream(t.device).cuda_stream), "uic_comm_allreduce")
+
+    def _reduce_scatter(self, whole, mine):
+        from . import _lib
+        assert whole.is_cuda and whole.is_contiguous() and whole.dtype in (torch.float32, torch.bfloat16)
+        _lib.check(self._lib.uic_comm_reduce_scatter(self._comm, whole.data_ptr(), mine.data_ptr(), mine.numel(),
+                                                     0 if whole.dtype == torch.float32 else 1,
+                                                     torch.cuda.current_stream(whole.device).cuda_stream), "uic_comm_reduce_scatter")
+
+    def _all_gather(self, whole, mine):
+        from . import _lib
+        assert whole.is_cuda and whole.is_contiguous() and whole.dtype in (torch.float32, torch.bfloat16)
+        _lib.check(self._lib.uic_comm_allgather(self._comm, mine.data_ptr(), whole.data_ptr(), mine.numel(),
+                                                0 if whole.dtype == torch.float32 else 1,
+                                                torch.cuda.current_stream(whole.device).cuda_stream), "uic_comm_allgather")
 
     def ranks_share_a_device(self):
         return False                       # RCCL refuses two ranks of one communicator on one device

@@ -8,7 +8,7 @@ import ctypes as C
 import torch
 
 from . import _lib
-from ._lib import Batch, Dims, Weights, check, ptr, stream, weight_fields
+from ._lib import Batch, Dims, Gathered, Weights, check, ptr, stream, weight_fields
 
 
 class Workspace(object):
@@ -44,6 +44,9 @@ class TopDownEngine(object):
         # uic_topdown_dims.recurrence (_lib.REC_*): how the decode loop and its BPTT are launched; 0 = the library's default
         # (persistent forward recurrence where the shapes allow, per-step BPTT launches)
         self.recurrence = 0
+        # sharded data parallelism (trainer._GatheredWeights): the operand-dtype weights come from the all-gathered arena, each
+        # gather group behind its event (uic_topdown_refresh_weights_gathered); None = cast from the f32 masters
+        self.gathered = None
 
     # ------------------------------------------------------------------ arenas
     def dims(self, N, R, T, seq_per_img=1):
@@ -183,6 +186,24 @@ class TopDownEngine(object):
         if self._derived is None or self._derived.numel() < nbytes or self._derived.device != dev:
             self._derived = torch.empty(nbytes, dtype=torch.uint8, device=dev)
         w = self.weights_struct(params)
+        gw = self.gathered
+        if gw is not None:
+            g = Gathered()
+            g._keep = []
+            for key, (field, _grp) in gw.keys.items():
+                t = gw.views[key]
+                if ":" in field:
+                    name, idx = field.split(":")
+                    getattr(g, name)[int(idx)] = ptr(t)
+                else:
+                    setattr(g, field, ptr(t))
+            for grp, ev in enumerate(gw.events):
+                g.ready[grp] = ev.cuda_event if ev is not None else None
+            g._keep = list(gw.events)
+            check(self.lib.uic_topdown_refresh_weights_gathered(C.byref(d), C.byref(w), C.byref(g), ptr(self._derived), int(bool(defer)),
+                                                                stream()), "refresh_weights_gathered")
+            w._gathered = g                # (the library keeps the late groups' events until the consumer runs: keep them alive)
+            return w
         fn = self.lib.uic_topdown_refresh_weights_deferred if defer else self.lib.uic_topdown_refresh_weights
         check(fn(C.byref(d), C.byref(w), ptr(self._derived), stream()), "refresh_weights")
         return w
@@ -239,7 +260,7 @@ class TopDownEngine(object):
         self._write_back(g)
 
     def xe_train_step(self, params, fc, att, att_masks, labels, masks, t_run, training, seed, grads, inv_den=None,
-                      grad_scale=None, ss_prob=0.0, keep_workspace=False, d_fc=None, d_att=None, resume_ws=None):
+                      grad_scale=None, ss_prob=0.0, keep_workspace=False, d_fc=None, d_att=None, resume_ws=None, out=None):
         """Fused forward + criterion + backward on two HIP streams; returns a device tensor [loss, sum(mask)].
         resume_ws: the workspace sample(..., keep_forward=True) left behind for these labels (same weights, seed, L): the
         step starts at the criterion (training bit 2) and the workspace is released afterwards."""
@@ -254,7 +275,8 @@ class TopDownEngine(object):
             ws = self.checkout(d, fc.device)
         b = self.batch_struct(fc, att, att_masks, labels, masks, grad_scale, ss_prob, d_fc=d_fc, d_att=d_att)
         g = self.weights_struct(grads, outputs=True)
-        out = torch.empty(2, dtype=torch.float32, device=fc.device)
+        if out is None:
+            out = torch.empty(2, dtype=torch.float32, device=fc.device)
         try:
             check(self.lib.uic_topdown_xe_train_step(C.byref(d), C.byref(w), ptr(self._derived), C.byref(b), t_run,
                                                      int(training), seed & 0xFFFFFFFF, ptr(ws.buf), ptr(inv_den),

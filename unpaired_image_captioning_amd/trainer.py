@@ -27,11 +27,12 @@ def _steps_from_host_labels(labels_np):
     return int(z[0]) + 1 if z.size else T
 
 
-def xe_step(model, batch, t_run=None, inv_den=None, grads=None, return_seed=False, fused=True, d_fc=None, d_att=None):
+def xe_step(model, batch, t_run=None, inv_den=None, grads=None, return_seed=False, fused=True, d_fc=None, d_att=None, out=None):
     """forward + fused criterion + backward on device tensors.  Returns (loss[device scalar], grads dict).
     fused=True: one library call scheduled on two HIP streams; False: the three separate calls.
     d_fc / d_att (eng.input_grad_buffers): optional outputs for the gradients w.r.t. the input features (an encoder in
-    front of the captioner; the reference's features are data)."""
+    front of the captioner; the reference's features are data).  out (fused only): a 2-float device tensor that receives
+    [loss, sum(mask)] instead of a fresh one (the sharded exchange hands over scalar slots of its gradient arena)."""
     eng = model.engine
     labels = batch["labels"]
     if t_run is None:
@@ -46,7 +47,7 @@ def xe_step(model, batch, t_run=None, inv_den=None, grads=None, return_seed=Fals
         if grads is None:
             grads = {k: torch.empty_like(v) for k, v in pd.items()}
         out = eng.xe_train_step(pd, batch["fc_feats"], batch["att_feats"], batch.get("att_masks"), labels, batch["masks"],
-                                t_run, training, seed, grads, inv_den, ss_prob=ss_prob, d_fc=d_fc, d_att=d_att)
+                                t_run, training, seed, grads, inv_den, ss_prob=ss_prob, d_fc=d_fc, d_att=d_att, out=out)
         if return_seed:
             return out[0], grads, seed
         return out[0], grads
@@ -63,6 +64,32 @@ def xe_step(model, batch, t_run=None, inv_den=None, grads=None, return_seed=Fals
     if return_seed:
         return out[0], grads, seed
     return out[0], grads
+
+
+class _GatheredWeights(object):
+    """What TopDownEngine.refresh hands uic_topdown_refresh_weights_gathered: the arena's all-gathered operand-dtype views by
+    reference key, and per gather group of the C struct the event behind the all-gather that completed it."""
+
+    def __init__(self, arena, keys):
+        self.arena = arena
+        self.keys = keys                                  # {reference key: (struct field, C gather group)}
+        self.views = {k: arena.gathered_views[k] for k in keys}
+        self.piece_of = {}
+        for i, names in enumerate(arena.piece_names):
+            for k in names:
+                self.piece_of[k] = i
+        self.events = [None] * 4
+
+    def set_events(self, piece_events):
+        """piece_events: {arena piece index: event recorded behind its all-gather}; the gathers ran in DESCENDING piece order on
+        one stream, so the event of the lowest piece a group needs covers the others."""
+        ev = [None] * 4
+        for k, (_, grp) in self.keys.items():
+            i = self.piece_of[k]
+            cur = ev[grp]
+            if cur is None or i < cur[0]:
+                ev[grp] = (i, piece_events[i])
+        self.events = [e[1] if e is not None else None for e in ev]
 
 
 class Trainer(object):
@@ -89,6 +116,8 @@ class Trainer(object):
                 # the overlapped exchange keeps a communication queue busy beside the step: the step then stays on two hardware
                 # queues of its own (a fourth busy queue slows every dependent launch of the BPTT loop, include/uic_hip.h)
                 eng.recurrence |= _lib.REC_COMM_STREAM
+        if self.exchange.world_size > 1:
+            self._require_two_hw_queues(opt)
         self.lr = getattr(opt, 'i2t_learning_rate', 4e-4)
         self.i2t_current_lr = self.lr
         self.betas = (getattr(opt, 'i2t_optim_alpha', 0.9), getattr(opt, 'i2t_optim_beta', 0.999))
@@ -100,6 +129,29 @@ class Trainer(object):
         self._step = 0
         self.arena = None
         self.last_loss = None
+
+    @staticmethod
+    def _require_two_hw_queues(opt):
+        """A data-parallel process has more HIP streams than the four hardware queues ROCclr opens by default (the step's three,
+        the communication stream, torch.distributed's own), and on MI355X a process with more than four BUSY hardware queues
+        dispatches every dependent launch 1.5-2.5x slower (profiles/r05_v4_queue_probe.txt).  GPU_MAX_HW_QUEUES=2 multiplexes the
+        streams onto two queues and removes the effect at no cost.  The HIP runtime reads it when it initialises: it is set here
+        when that has not happened yet, and a process that comes too late is told so LOUDLY instead of silently running at half
+        speed (opt.allow_many_hw_queues = 1 turns the error into a warning)."""
+        val = os.environ.get("GPU_MAX_HW_QUEUES")
+        if val is not None and val.strip().isdigit() and int(val) <= 2:
+            return
+        if val is None and not torch.cuda.is_initialized():
+            os.environ["GPU_MAX_HW_QUEUES"] = "2"
+            return
+        msg = ("data-parallel Trainer: GPU_MAX_HW_QUEUES is %s but the HIP runtime is already initialised -- export GPU_MAX_HW_QUEUES=2 "
+               "before the first HIP call (before `import torch` is safest), or the BPTT loop's launches dispatch 1.5-2.5x slower "
+               "beside the communication stream (DESIGN.md section 6)" % ("unset" if val is None else "'%s'" % val))
+        if getattr(opt, 'allow_many_hw_queues', 0) or (val is not None and not (val.strip().isdigit() and int(val) > 2)):
+            import warnings
+            warnings.warn(msg)
+        else:
+            raise RuntimeError(msg + "; opt.allow_many_hw_queues = 1 overrides")
 
     @staticmethod
     def _mix_rank_into_seed(model, exchange):
@@ -129,10 +181,47 @@ class Trainer(object):
         lstm_w = [k for k in names if k.startswith(self.LSTM_W_GRADS_EARLY if early_order else self.LSTM_W_GRADS)]
         late = [k for k in names if k.startswith(self.LATE_GRADS)]
         early = [k for k in names if k not in first and k not in lstm_w and k not in late]
-        self.arena = FlatArena(self.i2t_model, first + lstm_w + early + late)
-        groups = (lstm_w, early, late)
-        self.arena_splits = [self.arena.offsets[g[0]] for g in groups] if first and all(groups) else []
+        groups = (first, lstm_w, early, late)
+        ex = self.exchange
+        self.sharded = bool(ex.world_size > 1 and eng is not None and hasattr(self.i2t_model, 'use_bn') and
+                            not getattr(self.opt, 'allreduce_exchange', 0))
+        if self.sharded:
+            # the SHARDED exchange (parallel_exchange.py): only the matrices the kernels consume in the operand dtype are sharded;
+            # everything the kernels read as f32 (biases, alpha_net, BatchNorm tensors -- and att_embed's Linear when it has to be
+            # folded with the BatchNorm or zero-padded from its f32 master) stays replicated in the arena's tail
+            mats = self._gathered_keys()
+            pieces = [[k for k in g if k in mats] for g in groups]
+            self.piece_groups = [gid for gid, p in enumerate(pieces) if p]
+            op_dtype = _lib.TORCH_DTYPE[eng.dtype]
+            self.arena = FlatArena(self.i2t_model, first + lstm_w + early + late, world=ex.world_size, rank=ex.rank,
+                                   pieces=[p for p in pieces if p], operand_dtype=op_dtype)
+            self.arena_splits = []
+            eng.gathered = _GatheredWeights(self.arena, mats)
+            self._next_den = None
+            arena = self.arena
+            self.i2t_model._stale_masters = lambda: arena.masters_stale
+        else:
+            self.arena = FlatArena(self.i2t_model, first + lstm_w + early + late)
+            self.arena_splits = [self.arena.offsets[g[0]] for g in groups[1:]] if first and all(groups[1:]) else []
+            if eng is not None:
+                eng.gathered = None
+            self.i2t_model._stale_masters = None
         self._step = 0
+
+    def _gathered_keys(self):
+        """{reference key: (uic_topdown_gathered field, gather group)} of the parameters the sharded exchange all-gathers in the
+        operand dtype."""
+        m = self.i2t_model
+        eng = m.engine
+        by_field = {f: k for f, k, is_param in _lib.weight_fields(m.use_bn, m.logit_layers) if is_param}
+        out = {}
+        for gf, wf, grp in _lib.GATHERED_FIELDS:
+            if gf == "att_w" and (m.use_bn or eng.Dp != eng.D):
+                continue
+            out[by_field[wf]] = (gf, grp)
+        for l in range(m.logit_layers - 1):
+            out[by_field["logit_h_w:%d" % l]] = ("logit_h_w:%d" % l, 0)
+        return out
 
     def update_LearningRate(self, epoch):
         """Optim.update_LearningRate('i2t', epoch), P/misc/optimizer.py:114-122."""
@@ -205,20 +294,114 @@ class Trainer(object):
         ring[i][1] = ev
         return dev
 
-    def train_device_batch(self, batch, t_run, den_local):
-        """The timed hot path: everything from device-resident inputs to updated weights."""
+    def train_device_batch(self, batch, t_run, den_local, next_den_local=None):
+        """The timed hot path: everything from device-resident inputs to updated weights.  next_den_local (data parallel): the
+        NEXT batch's local mask sum, when the caller knows it (Trainer.train(next_data=...), a benchmark's resident batch): it
+        rides in this step's small all-reduce, so that no collective sits in front of the next step's forward pass."""
         if self.arena is None:
             self.build_optimizer()
-        inv_den = self.exchange.global_inv_den(den_local, batch["fc_feats"].device)
+        dev = batch["fc_feats"].device
+        if getattr(self, 'sharded', False):
+            a = self.arena
+            inv_den = self._take_next_inv_den(den_local)
+            if inv_den is None:
+                inv_den = self.exchange.global_inv_den(den_local, dev)
+            loss_slot = a.scalars[0:2]                              # the fused step writes [loss, sum(mask)]; slot 1 is rewritten below
+            loss, _ = xe_step(self.i2t_model, batch, t_run=t_run, inv_den=inv_den, grads=a.grad_views, out=loss_slot)
+            loss = self._sharded_update(loss, 1.0, next_den_local)
+            self.last_loss = loss
+            return loss
+        inv_den = self.exchange.global_inv_den(den_local, dev)
         loss, _ = xe_step(self.i2t_model, batch, t_run=t_run, inv_den=inv_den, grads=self.arena.grad_views)
+        loss = self._exchange_and_adam(loss, 1.0)
+        self.last_loss = loss
+        return loss
+
+    def _exchange_and_adam(self, loss, grad_scale, next_den_local=None):
+        """Gradient exchange + optimizer step behind a backward pass of the captioner (the XE step and the self-critical step's
+        resumed backward both end in uic_topdown_xe_train_step, whose gradient-group events the overlapped forms wait on)."""
+        if getattr(self, 'sharded', False):
+            return self._sharded_update(loss, grad_scale, next_den_local)
         if self.exchange.world_size > 1:
+            # opt.allreduce_exchange: round 5's exchange -- the arena all-reduced in four pieces, the first three on the communication
+            # stream as they become final; Adam on the whole arena on every rank
             lib = _lib.load()
             self.exchange.allreduce_sum_overlapped(
                 self.arena.grad, getattr(self, 'arena_splits', []) if hasattr(self.i2t_model, 'use_bn') else [],
                 lambda raw, g: check(lib.uic_topdown_grad_ready_wait(raw, g), "grad_ready_wait"))
-        loss = self._guarded_adam(loss, 1.0)
-        self.last_loss = loss
-        return loss
+        return self._guarded_adam(loss, grad_scale)
+
+    # ------------------------------------------------------------------ the sharded exchange (DESIGN.md section 6)
+    def _take_next_inv_den(self, den_local):
+        """1 / (global mask sum) of THIS batch if the previous step's all-reduce carried it (its local share must be the value
+        announced then), else None."""
+        nd = getattr(self, '_next_den', None)
+        self._next_den = None
+        if nd is not None and den_local is not None and abs(float(nd[0]) - float(den_local)) <= 1e-6 * max(1.0, abs(float(den_local))):
+            return nd[1]
+        return None
+
+    def _comm(self, dev):
+        if getattr(self, '_comm_stream', None) is None or self._comm_stream.device != dev:
+            self._comm_stream = torch.cuda.Stream(device=dev)
+        return self._comm_stream
+
+    def _sharded_update(self, loss, grad_scale, next_den_local=None, overlap=True):
+        """The sharded exchange of the captioner step (FlatArena.sharded_step): reduce-scatter of the gradient pieces -- the first
+        three beside the rest of the backward pass, behind uic_topdown_grad_ready_wait --, one small all-reduce of the replicated
+        tail with the step's scalars, Adam on this rank's slices (skipped on the device on every rank if a persistent launch timed
+        out anywhere), all-gather of the updated operand-dtype weights on the communication stream in the order the next forward
+        pass consumes them: the next refresh waits per group (uic_topdown_refresh_weights_gathered), nothing here does.
+        Returns the whole batch's loss (device scalar)."""
+        a = self.arena
+        dev = a.flat.device
+        lib = _lib.load()
+        sc = a.scalars
+        # scalar slots: [0] loss, [1] status flag, [2] (clip norm, unused here), [3] the next batch's mask sum
+        if loss.data_ptr() != sc.data_ptr():
+            sc[0:1].copy_(loss.detach().reshape(1))
+        if getattr(self.i2t_model, 'engine', None) is not None:
+            sc[1:2].copy_(_lib.status_words(dev)[0:1])             # (int32 -> float: non-zero stays non-zero)
+        else:
+            sc[1:2].zero_()
+        if next_den_local is not None:
+            sc[3:4].copy_(self._host_float(float(next_den_local), dev), non_blocking=True)
+        groups = self.piece_groups
+
+        def wait_piece(raw, i):
+            if not overlap or groups[i] > 2:
+                return False                                        # the late piece: the step's own stream has joined
+            check(lib.uic_topdown_grad_ready_wait(raw, groups[i]), "grad_ready_wait")
+            return True
+        self._step += 1
+        pair, events = a.sharded_step(self.exchange, self.i2t_current_lr, self.betas, self.eps, self._step, grad_scale,
+                                      wait_piece=wait_piece, comm=self._comm(dev), gather_async=True)
+        self._guard_pair = pair
+        if next_den_local is not None:
+            self._next_den = (float(next_den_local), sc[3:4].reciprocal())
+        eng = getattr(self.i2t_model, 'engine', None)
+        if eng is not None and getattr(eng, 'gathered', None) is not None:
+            eng.gathered.set_events(events)
+        return pair[0]
+
+    def _host_float(self, x, dev):
+        """A host float as a 1-element device tensor without a synchronous pageable copy (ring of pinned floats)."""
+        if getattr(self, '_pinf', None) is None:
+            self._pinf = torch.zeros(64, dtype=torch.float32).pin_memory()
+            self._pinf_i = 0
+        i = self._pinf_i
+        self._pinf_i = (i + 1) % 64
+        self._pinf[i] = x
+        return self._pinf[i:i + 1].to(dev, non_blocking=True)
+
+    def gather_masters(self):
+        """Collective (every rank calls it): after a sharded bf16 step a rank's f32 master weights are current only inside its own
+        shard -- this all-gathers them, so that state_dict() / save_models() see the full f32 weights everywhere."""
+        a = self.arena
+        if a is not None and getattr(a, 'masters_stale', False):
+            dev = a.flat.device
+            torch.cuda.current_stream(dev).wait_stream(self._comm(dev))
+            a.gather_masters(self.exchange)
 
     def _guarded_adam(self, loss, grad_scale):
         """Adam on the flat arena, skipped ON THE DEVICE if a persistent recurrence launch of this step timed out
@@ -323,13 +506,40 @@ class Trainer(object):
         labels_np = np.asarray(data["labels"])
         t_run = _steps_from_host_labels(labels_np)
         T = labels_np.shape[1] - 1
-        den_local = float(np.asarray(data["masks"])[:, 1:T + 1].sum())
+        den_local = self._mask_sum(data)
         batch = self._device_batch(data)
-        loss = self.train_device_batch(batch, t_run, den_local)       # (already summed over the ranks)
-        if next_data is not None:
-            self.prefetch(next_data)
+        if getattr(self, 'sharded', False) or (self.arena is None and self.exchange.world_size > 1):
+            # sharded exchange: the NEXT batch's mask sum rides in this step's small all-reduce, so that no collective sits in
+            # front of the next forward pass.  A dict is known now; a callable is fetched after the step's compute is enqueued (its
+            # host work then overlaps the GPU's), and the exchange -- which needs the number -- is enqueued behind it
+            if self.arena is None:
+                self.build_optimizer()
+        if getattr(self, 'sharded', False) and next_data is not None:
+            if callable(next_data):
+                a = self.arena
+                inv_den = self._take_next_inv_den(den_local)
+                if inv_den is None:
+                    inv_den = self.exchange.global_inv_den(den_local, batch["fc_feats"].device)
+                loss, _ = xe_step(self.i2t_model, batch, t_run=t_run, inv_den=inv_den, grads=a.grad_views, out=a.scalars[0:2])
+                self.prefetch(next_data)
+                nd = self._mask_sum(self.next_data) if self.next_data is not None else None
+                loss = self._sharded_update(loss, 1.0, nd)
+                self.last_loss = loss
+            else:
+                loss = self.train_device_batch(batch, t_run, den_local, self._mask_sum(next_data))
+                self.prefetch(next_data)
+        else:
+            loss = self.train_device_batch(batch, t_run, den_local)       # (already summed over the ranks)
+            if next_data is not None:
+                self.prefetch(next_data)
         self.i2t_train_loss = self._finish_step(loss)     # the reference's per-step host sync (trainer.py:172)
         return self.i2t_train_loss
+
+    @staticmethod
+    def _mask_sum(data):
+        """LanguageModelCriterion's denominator of a host batch: sum of masks[:, 1:] (P/misc/criterion.py:147-149)."""
+        m = np.asarray(data["masks"])
+        return float(m[:, 1:].sum())
 
     def _sample_opt(self, S):
         """Options of the self-critical step's sampling pass (P/trainer.py:167: sample_max = 0).  self.forced_samples (tests):
@@ -463,8 +673,13 @@ class Trainer(object):
             for k, view in views.items():
                 if params[k].grad is not view:
                     view.copy_(params[k].grad)
-            self.exchange.allreduce_sum(self.arena.grad)
-            loss_d = self._guarded_adam(loss.detach(), 1.0)                   # (already the whole batch's loss: summed over the ranks)
+            # (the backward pass above ended in the fused step: its gradient-group events release the exchange's first pieces
+            # while the tail still runs, exactly as in the XE step; a model without that path exchanges after the pass)
+            if sink_ok:
+                loss_d = self._exchange_and_adam(loss.detach(), 1.0)          # (already the whole batch's loss: summed over the ranks)
+            else:
+                self.exchange.allreduce_sum(self.arena.grad)
+                loss_d = self._guarded_adam(loss.detach(), 1.0)
         except BaseException as e:
             # whatever went wrong between the decode passes and the guarded Adam (a reward function fed the -1 tokens of a
             # timed-out pass, for one): a time-out word left behind would make the NEXT, good step skip its update and raise
@@ -487,7 +702,13 @@ class Trainer(object):
         self.discriminator = SentenceDiscriminator(self.opt).cuda()
         rank = self.exchange.rank if self.exchange is not None else 0
         self.discriminator.seed = (self.discriminator.seed + 0x9E3779B1 * rank) & 0x7FFFFFFF    # per-rank dropout noise
-        self.disc_arena = FlatArena(self.discriminator)
+        ex = self.exchange
+        self.disc_sharded = bool(ex is not None and ex.world_size > 1 and not getattr(self.opt, 'allreduce_exchange', 0))
+        if self.disc_sharded:        # one piece, f32 masters gathered in place (the discriminator's kernels read the masters)
+            names = [k for k, _ in self.discriminator.named_parameters()]
+            self.disc_arena = FlatArena(self.discriminator, names, world=ex.world_size, rank=ex.rank, pieces=[names])
+        else:
+            self.disc_arena = FlatArena(self.discriminator)
         self.disc_lr = float(getattr(self.opt, 'disc_learning_rate', 1e-4) or 1e-4)
         self._disc_step = 0
         return self.discriminator
@@ -515,8 +736,14 @@ class Trainer(object):
         a.zero_grad()
         loss = D.bce(D(tok), lab)
         loss.backward()
-        self.exchange.allreduce_sum(a.grad)
         self._disc_step += 1
+        if getattr(self, 'disc_sharded', False):
+            a.scalars[0:2].zero_()
+            a.scalars[0:1].copy_(loss.detach().reshape(1))
+            pair, _ = a.sharded_step(self.exchange, self.disc_lr, self.betas, self.eps, self._disc_step, 1.0 / self.exchange.world_size)
+            self.disc_train_loss = float(pair[0].item()) / self.exchange.world_size      # (mean of the ranks' batch means)
+            return self.disc_train_loss
+        self.exchange.allreduce_sum(a.grad)
         a.adam(self.disc_lr, self.betas, self.eps, self._disc_step, grad_scale=1.0 / self.exchange.world_size)
         self.disc_train_loss = loss.item()
         return self.disc_train_loss
@@ -560,13 +787,19 @@ class Trainer(object):
         outputs, attn, dec_state, upper_bounds = self.dp_nmt_model(nmt_batch.src, nmt_batch.tgt, nmt_batch.lengths, None)
         nmt_loss = self.nmt_crit(loader, nmt_batch, outputs, attn)
         nmt_loss.backward()
+        sharded = getattr(self.optim, 'nmt_sharded', False)
+        if sharded:
+            # the step's loss rides in the sharded exchange's small all-reduce (slot 0 of the arena's scalar slots)
+            self.optim.nmt_arena.scalars[0:1].copy_(nmt_loss.detach().reshape(1))
         self.optim.step()
         # the statistics are read AFTER the whole step is enqueued (one host sync per step, at its end)
         self.nmt_crit.report_stats.n_src_words += int(nmt_batch.lengths.sum())
         self.nmt_train_ppl = self.nmt_crit.report_stats.ppl()
         self.nmt_train_acc = self.nmt_crit.report_stats.accuracy()
         loss_d = nmt_loss.detach()
-        if self.exchange is not None and self.exchange.world_size > 1:
+        if sharded:
+            loss_d = self.optim.last_pair[0]
+        elif self.exchange is not None and self.exchange.world_size > 1:
             # the criterion is a SUM over target words (size_average=False, P/misc/criterion.py:126-136): the whole batch's loss
             # is the sum over the ranks' column shards, as DataParallel(dim=1) + gather gives the reference (P/trainer.py:88,178)
             loss_d = loss_d.float().reshape(1).clone()
@@ -586,6 +819,9 @@ class Trainer(object):
         """P/trainer.py:98-104: model_i2t[-best].pth = state_dict of the un-wrapped module."""
         path = self.opt.checkpoint_path
         os.makedirs(path, exist_ok=True)
+        self.gather_masters()        # (sharded bf16 exchange: a collective -- every rank calls save_models, as every rank runs the loop)
+        if self.exchange is not None and self.exchange.rank != 0:
+            return                   # one writer: the ranks hold identical weights
         if self.i2t_model is not None:
             torch.save({k: v.detach().cpu().clone() for k, v in self.i2t_model.state_dict().items()},
                        os.path.join(path, 'model_i2t' + tag + '.pth'))
