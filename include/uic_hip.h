@@ -250,7 +250,11 @@ int uic_topdown_xe_train_step(const uic_topdown_dims* d, const uic_topdown_weigh
  *            columns of core.att_lstm.weight_ih still come from the sum over steps, so that matrix belongs to group 2).
  *            With UIC_REC_EARLY_GRADS in dims.recurrence also core.att_lstm.weight_ih and embed.0.weight (~62 % with them);
  *   group 2: everything except the late group {att_embed.*, ctx2att.*, core.attention.h2att.*,
- *            core.attention.alpha_net.*}                   -- final when the embedding / fc_embed / bias gradients are done.
+ *            core.attention.alpha_net.*}                   -- final when the embedding / fc_embed / bias gradients are done;
+ *   group 3: embed.0.weight and core.att_lstm.weight_ih (a subset of group 2, 32 of its 36 MB at the reference's sizes), final
+ *            ~0.1 ms before the rest of it: the table's gather and the fc' columns run beside the last chunk's weight gradients;
+ *   group 4: embed.0.weight alone (19 MB) -- does not wait for the recurrent weight gradients, so it is the first of the tail's
+ *            pieces to be final.
  * A caller that lays its flat gradient arena out as [logit | group 1 | rest of the early group | late group] can
  * start the RCCL all-reduce of the first three pieces on a communication stream as each becomes final; the tail follows on
  * the step's stream.  Enqueue-only, no host sync: a hipStreamWaitEvent on the group's event.  (Round 5 also had a polling-kernel
@@ -549,8 +553,8 @@ int uic_adam_step_guarded(float* p, const float* g, float* m, float* v, size_t n
 /* The same step (optionally clipped, optionally guarded -- max_norm = 0 / sqnorm = NULL / skip_if_nonzero = NULL switch those off)
  * on `n_ranges` (at most 24) index ranges [lo[i], hi[i]) of the arena in ONE launch: the ranges a data-parallel rank owns after the
  * reduce-scatter of the gradient pieces, plus the replicated tail.  lo / hi are HOST arrays.  w_out (optional): the updated
- * parameters of those ranges are also written there in w_dtype (UIC_DTYPE_BF16; element index = arena index) -- the rank's
- * contribution to the all-gather of the operand-dtype weights.  Element for element the arithmetic of uic_adam_step. */
+ * parameters of those ranges are also written there in w_dtype (UIC_DTYPE_BF16; element index = arena index, so w_out must span
+ * every listed range -- in practice the whole arena's length) -- the rank's contribution to the all-gather of the operand-dtype weights.  Element for element the arithmetic of uic_adam_step. */
 int uic_adam_step_ranges(float* p, const float* g, float* m, float* v, int32_t n_ranges, const uint64_t* lo, const uint64_t* hi,
                          float lr, float beta1, float beta2, float eps, int32_t step, float grad_scale, float max_norm,
                          const float* sqnorm, const int32_t* skip_if_nonzero, void* w_out, int32_t w_dtype, void* stream);

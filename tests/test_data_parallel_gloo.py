@@ -184,9 +184,9 @@ def _sharded_worker(rank, world, port, out_dir):
               [key(k) for k in mats if k.startswith(("embed.", "fc_embed."))], [key(k) for k in mats if k.startswith(("att_embed.", "ctx2att.", "core.attention."))]]
     module = _tiny_module(W)
     a = FlatArena(module, [key(k) for k in W], world=world, rank=rank, pieces=pieces, operand_dtype=torch.bfloat16)
-    assert len(a.pieces) == 4 and all(n % (64 * world) == 0 for _, n in a.pieces) and a.w16 is not None and a.w16.numel() == a.repl_off
+    assert len(a.pieces) == 4 and all(n % (64 * world) == 0 for _, n in a.pieces) and a.w16 is not None and a.w16.numel() == a.numel
     assert set(a.replicated) == {key(k) for k in W if k not in mats} and a.numel == a.scalars_off + FlatArena.SCALAR_SLOTS
-    assert torch.equal(a.w16.float(), a.flat[:a.repl_off].bfloat16().float())            # built from the masters
+    assert torch.equal(a.w16[:a.repl_off].float(), a.flat[:a.repl_off].bfloat16().float())            # built from the masters
     for k, g in grads_l.items():
         a.grad_views[key(k)].copy_(g * scale)
     a.scalars[0] = float(loss_l) * scale
@@ -248,4 +248,4 @@ def test_two_rank_sharded_exchange_equals_all_reduce_and_full_adam(tmp_path):
     # Adam's first step is lr * sign(g) wherever |g| >> eps: compare where the gradient is not rounding noise
     sig = g.abs() > 1e-4 * gmax
     assert (r[0]["flat"][:n][sig] - p[sig]).abs().max().item() < 1e-5
-    assert torch.equal(r[0]["w16"].float(), r[0]["flat"][:r[0]["repl"][0]].bfloat16().float())
+    assert torch.equal(r[0]["w16"][:r[0]["repl"][0]].float(), r[0]["flat"][:r[0]["repl"][0]].bfloat16().float())

@@ -88,10 +88,12 @@ def _worker(rank, world, port, out_dir, backend="gloo", uic_comm=False, early_gr
     else:
         a = tr.arena
         assert tr.sharded and a.world == world and a.rank == rank
-        assert len(a.pieces) == (4 if not use_bn else 4) and all(n % (64 * world) == 0 for _, n in a.pieces)
+        assert len(a.pieces) == (3 if early_grads else 4) and all(n % (64 * world) == 0 for _, n in a.pieces)
         assert (a.w16 is not None) == (dtype == "bf16")
         if early_grads:
             assert "embed.0.weight" in a.piece_names[1] and "core.att_lstm.weight_ih" in a.piece_names[1], a.piece_names
+        else:
+            assert a.piece_names[1] == ["embed.0.weight"] and "core.att_lstm.weight_ih" in a.piece_names[2] and tr.piece_groups == [0, 4, 3, None]
         # the small f32 tensors stay replicated; with a BatchNorm in att_embed its Linear too (the fold needs the f32 master)
         assert "logit.bias" in a.replicated and "core.attention.alpha_net.weight" in a.replicated
         assert ("att_embed.1.weight" in a.replicated) == bool(use_bn)

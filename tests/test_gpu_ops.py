@@ -437,6 +437,61 @@ def test_adam_step_matches_oracle():
     assert (pd.cpu() - P["w"]).abs().max().item() < 1e-6
 
 
+@pytest.mark.parametrize("w16", [False, True], ids=["f32", "bf16-copy"])
+@pytest.mark.parametrize("clip,guard", [(False, None), (True, None), (False, 0), (False, 7)])
+def test_adam_step_ranges_is_adam_step_on_the_ranges_and_nowhere_else(w16, clip, guard):
+    """uic_adam_step_ranges (the sharded exchange's optimizer launch): on every listed range bit for bit what uic_adam_step[_clip]
+    leaves there, nothing written outside the ranges or past the arenas (canaries around all four arrays and the operand copy),
+    the bf16 copy of exactly the updated elements, and no update at all behind a non-zero guard word."""
+    L = _lib()
+    lib = L.load()
+    g = torch.Generator().manual_seed(21)
+    n, pad = 70016, 256
+    ranges = [(0, 64), (128, 128), (4096, 4096 + 9984), (20032, 20032 + 1), (50048, 70016)]      # (one empty, one single element, the tail)
+    big = torch.full((5, n + 2 * pad), 7.25)
+    p0, gr, m0, v0 = torch.randn(n, generator=g), torch.randn(n, generator=g), torch.randn(n, generator=g) * 0.1, torch.rand(n, generator=g) * 0.01
+    for row, t in enumerate((p0, gr, m0, v0)):
+        big[row, pad:pad + n] = t
+    dev_big = big.cuda()
+    P, G, M, V = (dev_big[r, pad:pad + n] for r in range(4))
+    w_out = torch.full((n + 2 * pad,), 3.0, device="cuda").bfloat16()
+    W = w_out[pad:pad + n]
+    sq = torch.tensor([float((gr * gr).sum())], device="cuda") if clip else None
+    gw = torch.tensor([0, guard if guard is not None else 0], dtype=torch.int32, device="cuda") if guard is not None else None
+    lo = (C.c_uint64 * len(ranges))(*[a for a, _ in ranges])
+    hi = (C.c_uint64 * len(ranges))(*[b for _, b in ranges])
+    L.check(lib.uic_adam_step_ranges(P.data_ptr(), G.data_ptr(), M.data_ptr(), V.data_ptr(), len(ranges), lo, hi, 5e-3, 0.9, 0.999, 1e-8, 3, 0.5,
+                                     0.25 if clip else 0.0, L.ptr(sq), gw[1:2].data_ptr() if gw is not None else None,
+                                     W.data_ptr() if w16 else None, 1 if w16 else 0, L.stream()))
+    # the reference: the whole-arena kernel on copies
+    rp, rm, rv = dev(p0).clone(), dev(m0).clone(), dev(v0).clone()
+    if clip:
+        L.check(lib.uic_adam_step_clip(L.ptr(rp), L.ptr(dev(gr)), L.ptr(rm), L.ptr(rv), n, 5e-3, 0.9, 0.999, 1e-8, 3, 0.5, 0.25, L.ptr(sq), L.stream()))
+    else:
+        L.check(lib.uic_adam_step(L.ptr(rp), L.ptr(dev(gr)), L.ptr(rm), L.ptr(rv), n, 5e-3, 0.9, 0.999, 1e-8, 3, 0.5, L.stream()))
+    torch.cuda.synchronize()
+    inside = torch.zeros(n, dtype=torch.bool)
+    for a, b in ranges:
+        inside[a:b] = True
+    skipped = guard is not None and guard != 0
+    out = dev_big.cpu()
+    for row, (new, old) in enumerate(((rp.cpu(), p0), (None, gr), (rm.cpu(), m0), (rv.cpu(), v0))):
+        got = out[row, pad:pad + n]
+        want = old.clone()
+        if new is not None and not skipped:
+            want[inside] = new[inside]
+        assert torch.equal(got, want), (row, (got - want).abs().max().item(), (got != want).nonzero()[:4].tolist())
+        assert (out[row, :pad] == 7.25).all() and (out[row, pad + n:] == 7.25).all(), row        # canaries
+    assert (out[4] == 7.25).all()
+    wo = w_out.float().cpu()
+    assert (wo[:pad] == 3.0).all() and (wo[pad + n:] == 3.0).all()
+    wmid = wo[pad:pad + n]
+    if w16 and not skipped:
+        assert torch.equal(wmid[inside], rp.cpu()[inside].bfloat16().float()) and (wmid[~inside] == 3.0).all()
+    else:
+        assert (wmid == 3.0).all()
+
+
 @pytest.mark.parametrize("M,N,K,sk", [(2048, 1664, 2560, 1), (2048, 1664, 2560, 2), (512, 640, 2560, 5), (9488, 512, 10880, 5), (520, 384, 1280, 1)])
 def test_linear_wgrad_256_tile_repeats_bit_for_bit_beside_busy_neighbours(M, N, K, sk):
     """csrc/gemm_tn_pp.hip keeps three LDS-DMA units in flight across raw barriers behind counted vmcnt / lgkmcnt waits: a wait that

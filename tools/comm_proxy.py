@@ -34,6 +34,14 @@ ap.add_argument("--no-next-den", action="store_true", help="do not carry the nex
                 "collective then sits in front of every forward pass)")
 ap.add_argument("--only", default="", help="sharded | allreduce: only that exchange (for traces)")
 ap.add_argument("--f32", action="store_true")
+ap.add_argument("--no-comm-flag", action="store_true", help="clear UIC_REC_COMM_STREAM: the single-GPU stream layout (chunk weight gradients on the "
+                "third stream, 256 x 256 kernel) beside the exchange")
+ap.add_argument("--early", action="store_true", help="opt.early_grads (UIC_REC_EARLY_GRADS): the embedding table and att_lstm.weight_ih final with the LSTM matrices")
+ap.add_argument("--no-pipeline", action="store_true", help="opt.no_pipelined_logit_piece: the logit piece's Adam + all-gather with the others, after the step")
+ap.add_argument("--comm-stream", default="torch", choices=["torch", "high", "raw", "raw-early", "raw-low"],
+                help="how the communication stream is made: torch = torch.cuda.Stream() (the Trainer's default); high = priority -1; raw = "
+                     "hipStreamCreateWithFlags(non-blocking) wrapped as an ExternalStream, created after the library's side streams; "
+                     "raw-early = the same, created before anything else touches the GPU; raw-low = lowest priority")
 args = ap.parse_args()
 lib = L.load()
 
@@ -89,13 +97,47 @@ den = float(batch["masks"][:, 1:T + 1].sum().item())
 NAMES = ["start", "prologue", "recurrence", "logit layer", "BPTT starts", "BPTT done", "rec wgrads", "main tail", "side tail", "joined", "logit grads"]
 
 
+_raw_streams = []
+
+
+def make_comm_stream(kind):
+    if kind == "torch":
+        return None
+    if kind == "high":
+        return torch.cuda.Stream(priority=-1)
+    import ctypes as C
+    hip = C.CDLL("libamdhip64.so")
+    h = C.c_void_p()
+    if kind == "raw-low":
+        lo, hi = C.c_int(), C.c_int()
+        hip.hipDeviceGetStreamPriorityRange(C.byref(lo), C.byref(hi))
+        rc = hip.hipStreamCreateWithPriority(C.byref(h), 1, lo.value)
+    else:
+        rc = hip.hipStreamCreateWithFlags(C.byref(h), 1)
+    assert rc == 0, rc
+    _raw_streams.append(h)
+    return torch.cuda.ExternalStream(h.value)
+
+
+_early = make_comm_stream("raw") if args.comm_stream == "raw-early" else None
+
+
 def run(exchange, allreduce):
     opt = bench.make_opt("f32" if args.f32 else "bf16", 1234)
     opt.allreduce_exchange = int(allreduce)
     opt.allow_many_hw_queues = 1
+    opt.early_grads = int(args.early)
+    opt.no_pipelined_logit_piece = int(args.no_pipeline)
     tr = Trainer(opt, exchange=exchange) if exchange is not None else Trainer(opt)
     tr.build_optimizer()
     tr.i2t_model.engine.recurrence |= int(args.rec, 0)
+    if args.no_comm_flag:
+        tr.i2t_model.engine.recurrence &= ~L.REC_COMM_STREAM
+    if exchange is not None and args.comm_stream != "torch":
+        if args.comm_stream != "raw-early":
+            tr.train_device_batch(batch, tr.i2t_model._steps_to_run(batch["labels"]), den, None) if False else None
+        tr._comm_stream = _early if args.comm_stream == "raw-early" else make_comm_stream(args.comm_stream)
+        exchange._comm_stream = tr._comm_stream
     t_run = tr.i2t_model._steps_to_run(batch["labels"])
     nd = None if (args.no_next_den or exchange is None) else den
     for _ in range(5):

@@ -6,14 +6,14 @@ O=$R/gpurun_out/${1:-commtrace}
 mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
 rm -rf /tmp/ct     # (a box can be handed out again with its /tmp: never read an earlier run's trace)
-timeout 500 rocprofv3 --kernel-trace --output-format csv -d /tmp/ct -- python3 $R/tools/comm_proxy.py --steps 6 --only default4 > /tmp/ct.log 2>&1
+timeout 500 rocprofv3 --kernel-trace --output-format csv -d /tmp/ct -- python3 $R/tools/comm_proxy.py --steps 6 --only sharded > /tmp/ct.log 2>&1
 tail -3 /tmp/ct.log
 python3 - <<PY > $O/comm_timeline.txt
 import csv, glob
 f = glob.glob('/tmp/ct/**/*kernel_trace.csv', recursive=True)[0]
 rows = sorted(csv.DictReader(open(f)), key=lambda r: int(r['Start_Timestamp']))
-adam = [i for i, r in enumerate(rows) if 'adam_kernel' in r['Kernel_Name']]
-a, b = adam[-3], adam[-2]
+adam = [i for i, r in enumerate(rows) if 'adam_ranges_kernel' in r['Kernel_Name'] or 'adam_kernel' in r['Kernel_Name']]
+a, b = adam[-6], adam[-5]      # (a timed step: the last three are the stamped ones, each behind a host sync)
 t0 = int(rows[a]['End_Timestamp'])
 for r in rows[a:b + 1]:
     n = r['Kernel_Name'].replace('(anonymous namespace)::', '').replace('void ', '')[:44]

@@ -1201,26 +1201,41 @@ __global__ __launch_bounds__(NT) void sqnorm_part_kernel(const float* __restrict
   float s = block_reduce_sum((s0 + s1) + (s2 + s3), s_buf);
   if (threadIdx.x == 0) part[blockIdx.x] = s;
 }
-__global__ void adam_kernel(const UicAdamParams a) {
-  const size_t stride = (size_t)gridDim.x * blockDim.x;
-  const float step_size = a.lr / a.bc1;
-  const float inv_sqrt_bc2 = 1.f / sqrtf(a.bc2);
-  if (a.guard && a.guard[0] != 0) return;          // (uniform over the launch: the step's gradients are invalid, keep the weights)
+// ONE definition of the element update for both Adam kernels, with floating-point contraction off: the whole-arena kernel and the
+// ranges kernel of the sharded exchange must produce the same bits from the same inputs (tests/test_gpu_dp2.py compares the two
+// exchanges bit for bit), whatever fused multiply-adds the optimizer would pick for each loop shape.
+__device__ __forceinline__ float uic_adam_update(float p, float& m, float& v, float g, float beta1, float beta2, float step_size,
+                                                 float inv_sqrt_bc2, float eps) {
+#pragma clang fp contract(off)
+  m = beta1 * m + (1.f - beta1) * g;
+  v = beta2 * v + (1.f - beta2) * g * g;
+  const float denom = sqrtf(v) * inv_sqrt_bc2 + eps;
+  return p - step_size * (m / denom);
+}
+__device__ __forceinline__ float uic_adam_grad_scale(const UicAdamParams& a) {
+#pragma clang fp contract(off)
   float gs = a.grad_scale;
   if (a.sqnorm) {
     const float coef = a.max_norm / (fabsf(a.grad_scale) * sqrtf(a.sqnorm[0]) + 1e-6f);
     if (coef < 1.f) gs *= coef;
   }
+  return gs;
+}
+__global__ void adam_kernel(const UicAdamParams a) {
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  const float step_size = a.lr / a.bc1;
+  const float inv_sqrt_bc2 = 1.f / sqrtf(a.bc2);
+  if (a.guard && a.guard[0] != 0) return;          // (uniform over the launch: the step's gradients are invalid, keep the weights)
+  const float gs = uic_adam_grad_scale(a);
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < a.n; i += stride) {
     // gradient and moments are touched once per step, by this kernel only: streamed past the caches (the parameters are
     // re-read right after by the operand-copy refresh and stay cacheable)
     const float g = __builtin_nontemporal_load(a.g + i) * gs;
-    const float m = a.beta1 * __builtin_nontemporal_load(a.m + i) + (1.f - a.beta1) * g;
-    const float v = a.beta2 * __builtin_nontemporal_load(a.v + i) + (1.f - a.beta2) * g * g;
+    float m = __builtin_nontemporal_load(a.m + i), v = __builtin_nontemporal_load(a.v + i);
+    const float pn = uic_adam_update(a.p[i], m, v, g, a.beta1, a.beta2, step_size, inv_sqrt_bc2, a.eps);
     __builtin_nontemporal_store(m, a.m + i);
     __builtin_nontemporal_store(v, a.v + i);
-    const float denom = sqrtf(v) * inv_sqrt_bc2 + a.eps;
-    a.p[i] -= step_size * (m / denom);
+    a.p[i] = pn;
   }
 }
 
@@ -1233,22 +1248,16 @@ __global__ void adam_ranges_kernel(const UicAdamParams a, const UicAdamRanges r,
   const float step_size = a.lr / a.bc1;
   const float inv_sqrt_bc2 = 1.f / sqrtf(a.bc2);
   if (a.guard && a.guard[0] != 0) return;
-  float gs = a.grad_scale;
-  if (a.sqnorm) {
-    const float coef = a.max_norm / (fabsf(a.grad_scale) * sqrtf(a.sqnorm[0]) + 1e-6f);
-    if (coef < 1.f) gs *= coef;
-  }
+  const float gs = uic_adam_grad_scale(a);
   for (size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x; j < r.total; j += stride) {
     int k = 0;
     while (k + 1 < r.count && j >= r.start[k + 1]) ++k;       // start[k]: position of range k in the concatenation
     const size_t i = r.lo[k] + (j - r.start[k]);
     const float g = __builtin_nontemporal_load(a.g + i) * gs;
-    const float m = a.beta1 * __builtin_nontemporal_load(a.m + i) + (1.f - a.beta1) * g;
-    const float v = a.beta2 * __builtin_nontemporal_load(a.v + i) + (1.f - a.beta2) * g * g;
+    float m = __builtin_nontemporal_load(a.m + i), v = __builtin_nontemporal_load(a.v + i);
+    const float pn = uic_adam_update(a.p[i], m, v, g, a.beta1, a.beta2, step_size, inv_sqrt_bc2, a.eps);
     __builtin_nontemporal_store(m, a.m + i);
     __builtin_nontemporal_store(v, a.v + i);
-    const float denom = sqrtf(v) * inv_sqrt_bc2 + a.eps;
-    const float pn = a.p[i] - step_size * (m / denom);
     a.p[i] = pn;
     if (w_out) w_out[i] = uic_from_f<WT>(pn);
   }

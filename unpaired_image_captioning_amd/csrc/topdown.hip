@@ -462,6 +462,8 @@ struct SideStream {
   hipEvent_t ev_lstm = nullptr;     // side: lang_lstm.weight_{ih,hh} and att_lstm.weight_hh are final (right after the BPTT loop)
   hipEvent_t ev_early = nullptr;    // main: every gradient except the late group (see uic_topdown_grad_ready_wait) is final
   bool early_recorded = false;
+  hipEvent_t ev_embed = nullptr;    // the embedding table's gradient and the fc' columns of att_lstm.weight_ih are final (gradient group 3)
+  bool embed_recorded = false;
   hipEvent_t ev_r0 = nullptr, ev_refresh = nullptr;   // uic_topdown_refresh_weights: main -> side, side -> consumers
   bool refresh_pending = false;
   // The refresh in two halves: the operand-dtype copies (all the forward pass needs; ev_cast) are enqueued by the call
@@ -518,6 +520,7 @@ int get_side(SideStream** out) {
     UIC_TRY(uic_check_hip(hipEventCreateWithFlags(&ss.ev_pro, hipEventDisableTiming), "hipEventCreate"));
     UIC_TRY(uic_check_hip(hipEventCreateWithFlags(&ss.ev_pro3, hipEventDisableTiming), "hipEventCreate"));
     UIC_TRY(uic_check_hip(hipEventCreateWithFlags(&ss.ev_early, hipEventDisableTiming), "hipEventCreate"));
+    UIC_TRY(uic_check_hip(hipEventCreateWithFlags(&ss.ev_embed, hipEventDisableTiming), "hipEventCreate"));
     UIC_TRY(uic_check_hip(hipEventCreateWithFlags(&ss.ev_logit, hipEventDisableTiming), "hipEventCreate"));
     UIC_TRY(uic_check_hip(hipEventCreateWithFlags(&ss.ev_lstm, hipEventDisableTiming), "hipEventCreate"));
     UIC_TRY(uic_check_hip(hipEventCreateWithFlags(&ss.ev_r0, hipEventDisableTiming), "hipEventCreate"));
@@ -1612,6 +1615,7 @@ int uic_topdown_xe_train_step(const uic_topdown_dims* d, const uic_topdown_weigh
   // the single-stream uic_topdown_backward call only, where nothing runs beside it.
   st.d.recurrence &= ~UIC_REC_BWD_PERSIST;
   const bool early = st.early_grads();
+  ss->embed_recorded = false;
   // UIC_REC_COMM_STREAM: a communication stream of the caller is busy beside this step (data parallel).  The chip dispatches
   // from THREE busy hardware queues at full speed; a fourth non-empty queue -- even one wave that only waits -- makes the BPTT
   // loop's 85 dependent launches 1.5-2.5x slower (tools/queue_probe.py, profiles/r05_*_queue_probe.txt).  So with the caller's
@@ -1619,8 +1623,24 @@ int uic_topdown_xe_train_step(const uic_topdown_dims* d, const uic_topdown_weigh
   // behind the logit layer (round 4's order), instead of stream 3.
   const bool comm = (d->recurrence & UIC_REC_COMM_STREAM) != 0;
   const int CH = WG_CHUNK;                            // decode steps per hand-off to the side stream
-  const int nchunk = (t_run + CH - 1) / CH;
-  UIC_REQUIRE(nchunk <= MAX_CHUNKS, "xe_train_step: too many decode steps (%d)", t_run);
+  // chunk c = decode steps [cb[c], cb[c + 1]).  Default: chunks of CH from step 0 (the last one -- the one the BPTT loop starts
+  // from -- is t_run % CH steps long: ONE at the reference's 17 steps).  UIC_KNOB_SHORT_FIRST (measurement knob): the FIRST chunk is
+  // one step too -- the BPTT loop ends on it, so that all but 1/t_run of the recurrent weight gradients is done when the loop ends.
+  int cb[MAX_CHUNKS + 1];
+  int nchunk = 0;
+  {
+    UIC_REQUIRE((t_run + CH - 1) / CH + 2 <= MAX_CHUNKS, "xe_train_step: too many decode steps (%d)", t_run);
+    int t = 0;
+    cb[0] = 0;
+    const bool short_first = (d->recurrence & UIC_KNOB_SHORT_FIRST) && !early && t_run > CH + 1;
+    if (short_first) { cb[++nchunk] = 1; t = 1; }
+    while (t < t_run) {
+      int len = CH < t_run - t ? CH : t_run - t;
+      if (short_first && t_run - t > 1 && t + len == t_run) len = t_run - t - 1;   // keep the loop's first chunk short too
+      t += len;
+      cb[++nchunk] = t;
+    }
+  }
 #define UIC_HIP(expr) UIC_TRY(uic_check_hip((expr), #expr))
 #define UIC_MARK(i, strm) do { if (ss->marks_on) UIC_HIP(hipEventRecord(ss->mark[i], strm)); } while (0)
 
@@ -1678,7 +1698,7 @@ int uic_topdown_xe_train_step(const uic_topdown_dims* d, const uic_topdown_weigh
     // after a single launch every step is there at once: the logit layer then takes the chunks LAST FIRST, the order the
     // BPTT loop consumes them in, so that loop starts after one chunk instead of after all of them
     const int c = one_launch ? nchunk - 1 - i : i;
-    const int t0 = c * CH, t1 = t0 + CH < t_run ? t0 + CH : t_run;
+    const int t0 = cb[c], t1 = cb[c + 1];
     if (!one_launch) UIC_TRY(st.fwd_steps(t0, t1, s));
     if (first_on_main && i == 0) {
       // the chunk the BPTT loop starts from, on the MAIN stream itself (idle until that chunk is through anyway): no event hop to
@@ -1722,7 +1742,7 @@ int uic_topdown_xe_train_step(const uic_topdown_dims* d, const uic_topdown_weigh
     // The embedding gradient's token bucketing needs only the tokens (labels; under scheduled sampling the tokens the forward
     // pass fed, which the side stream has waited for): in the side stream's slack inside the BPTT window.  Two halves: the
     // share of decode steps [CH, t_run) is gathered while the BPTT loop works on its last chunk, only steps [0, CH) afterwards.
-    st.embed_split = st.early_grads() && nchunk >= 2 ? CH : 0;
+    st.embed_split = st.early_grads() && nchunk >= 2 ? cb[1] : 0;
     if (!st.ss_on() || st.early_grads()) {
       UIC_TRY(uic_embed_bwd_sorted_prepare(st.embed_tokens(), st.embed_ldtok(), d->N, t_run, d->V1, d->E, G->embed_w, st.L.embed_scratch, s2,
                                            st.embed_split));
@@ -1736,7 +1756,7 @@ int uic_topdown_xe_train_step(const uic_topdown_dims* d, const uic_topdown_weigh
   // instead of behind the first (measured: the side stream's tail was the end of the step, 0.1 ms after the main stream's).
   const bool tail3 = !early && st.embed_prepared;
   for (int c = nchunk - 1; c >= 0; --c) {
-    const int t0 = c * CH, t1 = t0 + CH < t_run ? t0 + CH : t_run;
+    const int t0 = cb[c], t1 = cb[c + 1];
     if (!(first_on_main && c == nchunk - 1)) UIC_HIP(hipStreamWaitEvent(s, ss->ev_side[c], 0));
     if (c == nchunk - 1) UIC_MARK(4, s);              // main: BPTT starts
     UIC_TRY(st.bwd_steps(t0, t1, s));
@@ -1772,6 +1792,8 @@ int uic_topdown_xe_train_step(const uic_topdown_dims* d, const uic_topdown_weigh
     // group are final with gradient group 1 (the fc_embed chain and the bias sums -- ~4 MB -- follow)
     UIC_TRY(st.fc_cols_grad(s2, st.L.slab2, st.L.tSA, st.L.tSB));
     UIC_TRY(st.embed_grad(0, s2));
+    UIC_HIP(hipEventRecord(ss->ev_embed, s2));
+    ss->embed_recorded = true;
     UIC_HIP(hipEventRecord(ss->ev_s3, s3));
     UIC_HIP(hipStreamWaitEvent(s2, ss->ev_s3, 0));    // the third stream's share of the weight gradients
   } else if (comm) {
@@ -1781,6 +1803,8 @@ int uic_topdown_xe_train_step(const uic_topdown_dims* d, const uic_topdown_weigh
       UIC_TRY(st.fc_cols_grad(s3, st.L.slab3, st.L.tTA, st.L.tTB));
       UIC_TRY(st.embed_grad(0, s3));
       UIC_HIP(hipEventRecord(ss->ev_s3, s3));
+      UIC_HIP(hipEventRecord(ss->ev_embed, s3));
+      ss->embed_recorded = true;
     }
   } else {
     // the recurrent weight gradients are complete when both shares of the last chunk are (joined on stream 3)
@@ -1790,6 +1814,8 @@ int uic_topdown_xe_train_step(const uic_topdown_dims* d, const uic_topdown_weigh
       UIC_HIP(hipStreamWaitEvent(s2, ss->ev_main[0], 0));   // the BPTT loop is through: dG1 of every step exists
       UIC_TRY(st.fc_cols_grad(s2, st.L.slab2, st.L.tSA, st.L.tSB));
       UIC_TRY(st.embed_grad(0, s2));
+      UIC_HIP(hipEventRecord(ss->ev_embed, s2));
+      ss->embed_recorded = true;
     }
   }
   // side: the rest of the early gradient group (LSTM / h2att biases, embedding, fc_embed); main: the late group
@@ -1838,8 +1864,18 @@ int uic_topdown_step_marks(int32_t enable, float* ms_out) {
 int uic_topdown_grad_ready_wait(void* stream, int32_t group) {
   SideStream* ss = nullptr;
   UIC_TRY(get_side(&ss));
-  UIC_REQUIRE(group >= 0 && group <= 2, "grad_ready_wait: group=%d must be 0 (logit layer), 1 (LSTM weights) or 2 (early group)", group);
+  UIC_REQUIRE(group >= 0 && group <= 4, "grad_ready_wait: group=%d must be 0 (logit layer), 1 (LSTM weights), 2 (early group), 3 (embedding table + att_lstm.weight_ih) or 4 (embedding table)", group);
   UIC_REQUIRE(ss->early_recorded, "grad_ready_wait: no uic_topdown_xe_train_step has run on this device yet");
+  if (group == 4)   // embed.0.weight alone: its gather runs beside the last chunk's weight gradients and is through first
+    return uic_check_hip(hipStreamWaitEvent((hipStream_t)stream, ss->embed_recorded ? ss->ev_embed : ss->ev_early, 0), "hipStreamWaitEvent");
+  if (group == 3) {
+    // embed.0.weight and core.att_lstm.weight_ih: the table's gather and the fc' columns (ev_embed) + the matrix's other columns,
+    // which come with the recurrent weight gradients (ev_lstm).  A step that made them inside its early epilogue (scheduled
+    // sampling without the early order) has no separate event: they are final with the early group
+    if (!ss->embed_recorded) return uic_check_hip(hipStreamWaitEvent((hipStream_t)stream, ss->ev_early, 0), "hipStreamWaitEvent");
+    UIC_TRY(uic_check_hip(hipStreamWaitEvent((hipStream_t)stream, ss->ev_embed, 0), "hipStreamWaitEvent"));
+    return uic_check_hip(hipStreamWaitEvent((hipStream_t)stream, ss->ev_lstm, 0), "hipStreamWaitEvent");
+  }
   hipEvent_t ev = group == 0 ? ss->ev_logit : group == 1 ? ss->ev_lstm : ss->ev_early;
   return uic_check_hip(hipStreamWaitEvent((hipStream_t)stream, ev, 0), "hipStreamWaitEvent");
 }

@@ -153,6 +153,7 @@ extern thread_local int g_uic_knobs;
 #define UIC_KNOB_CHUNK_SK2 0x800       // beside the BPTT chain: two K slices for the chunk gradients
 #define UIC_KNOB_LAST_BESIDE 0x1000    // the last chunk's gradients (after the loop) dispatched like the others (default: as if alone on the chip)
 #define UIC_KNOB_LAST_ONE_STREAM 0x2000 // the last chunk's two shares on one stream
+#define UIC_KNOB_SHORT_FIRST 0x4000     // the first decode step is a chunk of its own (the BPTT loop ends on it): see uic_topdown_xe_train_step
 #define UIC_KNOB_MASK 0xff00
 
 // ---------------------------------------------------------------- GEMM (gemm.hip)

@@ -98,7 +98,9 @@ class FlatArena(object):
         self.w16 = None
         self.masters_stale = False
         if self.operand_dtype is not None:
-            self.w16 = torch.zeros(self.repl_off, dtype=self.operand_dtype, device=dev)
+            # (the whole arena's length: uic_adam_step_ranges leaves the operand copy of EVERY element it updates, the replicated
+            # tail's too -- only the sharded region [0, repl_off) is ever gathered or read)
+            self.w16 = torch.zeros(self.numel, dtype=self.operand_dtype, device=dev)
             self.sync_operand_copy()
         self.gathered_views = {}
         for piece in self.piece_names:
@@ -114,7 +116,7 @@ class FlatArena(object):
         if self.w16 is not None and self.w16.is_cuda:
             check(_lib.load().uic_cast_from_f32(_lib.dtype_id("bf16"), ptr(self.flat), ptr(self.w16), self.repl_off, stream()), "cast_from_f32")
         elif self.w16 is not None:
-            self.w16.copy_(self.flat[:self.repl_off])
+            self.w16[:self.repl_off].copy_(self.flat[:self.repl_off])
 
     def shard(self, piece, rank=None):
         """(lo, hi) of rank's slice of gradient piece `piece`."""
@@ -130,11 +132,13 @@ class FlatArena(object):
             out.append((self.repl_off, self.repl_end))
         return out
 
-    def adam_owned(self, lr, betas, eps, step, grad_scale=1.0, max_norm=0.0, sqnorm=None, guard=None):
-        """uic_adam_step_ranges on owned_ranges(); in operand-dtype mode the updated shard is also written to w16 (the rank's
-        contribution to the all-gather)."""
+    def adam_owned(self, lr, betas, eps, step, grad_scale=1.0, max_norm=0.0, sqnorm=None, guard=None, ranges=None):
+        """uic_adam_step_ranges on owned_ranges() (or the given subset of them); in operand-dtype mode the updated shard is also
+        written to w16 (the rank's contribution to the all-gather)."""
         import ctypes as C
-        rg = self.owned_ranges()
+        rg = self.owned_ranges() if ranges is None else list(ranges)
+        if not rg:
+            return
         lo = (C.c_uint64 * len(rg))(*[a for a, _ in rg])
         hi = (C.c_uint64 * len(rg))(*[b for _, b in rg])
         clip = bool(max_norm and max_norm > 0)
@@ -155,7 +159,8 @@ class FlatArena(object):
             check(lib.uic_grad_sqnorm(ptr(self.grad[lo:hi]), hi - lo, ptr(self.scratch), ptr(outs[g:g + 1]), stream()), "grad_sqnorm")
         return outs.sum().reshape(1)
 
-    def sharded_step(self, ex, lr, betas, eps, step, grad_scale=1.0, max_norm=0.0, wait_piece=None, comm=None, gather_async=False):
+    def sharded_step(self, ex, lr, betas, eps, step, grad_scale=1.0, max_norm=0.0, wait_piece=None, comm=None, gather_async=False,
+                     early_guard=None, pipeline=()):
         """One optimizer step of the sharded exchange on this arena (gradients final or becoming final on the current stream):
 
           1. reduce-scatter every piece -- piece i on the communication stream `comm` behind wait_piece(comm raw stream, i) when
@@ -168,25 +173,51 @@ class FlatArena(object):
              forward pass consumes them in.  gather_async: on `comm`, one event per piece, the current stream does NOT wait
              (the next refresh does, group by group); otherwise on the current stream.
 
+        pipeline (with early_guard; needs `comm`, no clipping): pieces whose Adam and all-gather run on the communication stream
+        RIGHT BEHIND their reduce-scatter, while the backward pass still computes the later pieces -- the logit layer's quarter of
+        the bytes is then back on every rank long before the step ends, instead of in the next step's prologue.  early_guard: the
+        status word (device int32), already final when the first overlapped piece is released; it is summed over the ranks there
+        (one tiny all-reduce) and guards EVERY Adam launch of the step, so that the ranks skip together or not at all.
+
         Returns (pair, events): pair = [summed loss, summed status flag] (a fresh 2-float tensor), events = {piece: event} or None."""
         cur = torch.cuda.current_stream(self.flat.device)
-        used_comm = False
-        for i in range(len(self.pieces)):
-            if comm is not None and wait_piece is not None and wait_piece(comm.cuda_stream, i):
-                with torch.cuda.stream(comm):
-                    ex.reduce_scatter(self.grad, *self.pieces[i])
-                used_comm = True
-            else:
-                ex.reduce_scatter(self.grad, *self.pieces[i])
         clip = bool(max_norm and max_norm > 0)
+        pipeline = tuple(pipeline) if (comm is not None and early_guard is not None and not clip) else ()
+        buf = self.w16 if self.w16 is not None else self.flat
+        guard = None
+        events = {}
         sc = self.scalars
-        if clip:
-            if used_comm:
-                cur.wait_stream(comm)
-                used_comm = False
-            sc[2:3].copy_(self.shard_sqnorm())
-        ex._sum(self.grad[self.repl_off:self.scalars_off + 4])
-        if used_comm:
+        # With a communication stream EVERY collective of the step runs there, in one order (RCCL serialises the collectives of a
+        # communicator anyway; so does the one-GPU stand-in this way): the pieces that become final during the backward pass behind
+        # their events, the rest behind the point the current stream has reached (the step has joined there).
+        joined = False
+        on = comm if comm is not None else cur
+        with torch.cuda.stream(on):
+            for i in range(len(self.pieces)):
+                early = comm is not None and wait_piece is not None and not joined and wait_piece(comm.cuda_stream, i)
+                if not early and comm is not None and not joined:
+                    ev = torch.cuda.Event()
+                    ev.record(cur)
+                    comm.wait_event(ev)
+                    joined = True
+                if early and guard is None and early_guard is not None:
+                    guard = early_guard[0:1].to(torch.float32)
+                    ex._sum(guard)
+                ex.reduce_scatter(self.grad, *self.pieces[i])
+                if early and i in pipeline and guard is not None:
+                    self.adam_owned(lr, betas, eps, step, grad_scale, guard=guard, ranges=[self.shard(i)])
+                    ex.all_gather(buf, *self.pieces[i])
+                    e = torch.cuda.Event()
+                    e.record(comm)
+                    events[i] = e
+            if comm is not None and not joined:
+                ev = torch.cuda.Event()
+                ev.record(cur)
+                comm.wait_event(ev)
+            if clip:
+                sc[2:3].copy_(self.shard_sqnorm())
+            ex._sum(self.grad[self.repl_off:self.scalars_off + 4])
+        if comm is not None:
             cur.wait_stream(comm)
         sq = None
         if clip:
@@ -196,24 +227,28 @@ class FlatArena(object):
                 check(_lib.load().uic_grad_sqnorm(ptr(self.grad[self.repl_off:self.repl_end]), self.repl_end - self.repl_off,
                                                   ptr(self.scratch), ptr(rs), stream()), "grad_sqnorm")
                 sq += rs
-        pair = sc[0:2].clone()
-        self.adam_owned(lr, betas, eps, step, grad_scale, max_norm if clip else 0.0, sq, guard=pair[1:2])
-        buf = self.w16 if self.w16 is not None else self.flat
-        events = None
+        pair = torch.cat([sc[0:1], guard]) if guard is not None else sc[0:2].clone()
+        rest = [i for i in range(len(self.pieces)) if i not in events]
+        rg = [self.shard(i) for i in rest]
+        if self.repl_end > self.repl_off:
+            rg.append((self.repl_off, self.repl_end))
+        self.adam_owned(lr, betas, eps, step, grad_scale, max_norm if clip else 0.0, sq, guard=pair[1:2], ranges=rg)
         if gather_async and comm is not None:
             ev = torch.cuda.Event()
             ev.record(cur)
             comm.wait_event(ev)
-            events = {}
             with torch.cuda.stream(comm):
-                for i in reversed(range(len(self.pieces))):
+                for i in reversed(rest):
                     ex.all_gather(buf, *self.pieces[i])
                     e = torch.cuda.Event()
                     e.record(comm)
                     events[i] = e
         else:
-            for i in reversed(range(len(self.pieces))):
+            for i in reversed(rest):
                 ex.all_gather(buf, *self.pieces[i])
+            if events:                                    # (the pipelined pieces' gathers ran on comm)
+                cur.wait_stream(comm)
+            events = None
         return pair, events
 
     def gather_masters(self, exchange):

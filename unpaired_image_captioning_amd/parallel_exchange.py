@@ -134,11 +134,29 @@ class GradientExchange(object):
         assert per * w == n, "piece length %d is not a multiple of the world size %d" % (n, w)
         self._all_gather(flat[off:off + n], flat[off + r * per:off + (r + 1) * per])
 
+    def _native_halves(self, t):
+        """RCCL ("nccl") runs reduce-scatter / all-gather in place on device tensors, and gloo does on HOST tensors.  gloo carrying
+        DEVICE tensors (the functional tests with two ranks on one GPU) is kept on all_reduce -- the one gloo collective whose
+        stream semantics with device tensors this suite has relied on since round 3 (its reduce_scatter_tensor on device tensors
+        gave a wrong scalar once in a while on some boxes); the two halves are expressed through it, bit-exactly."""
+        return (not t.is_cuda) or dist.get_backend(self.group) == "nccl"
+
     def _reduce_scatter(self, whole, mine):
-        dist.reduce_scatter_tensor(mine, whole, op=dist.ReduceOp.SUM, group=self.group)
+        if self._native_halves(whole):
+            dist.reduce_scatter_tensor(mine, whole, op=dist.ReduceOp.SUM, group=self.group)
+        else:
+            dist.all_reduce(whole, op=dist.ReduceOp.SUM, group=self.group)      # (this rank's slice of it is what the caller reads)
 
     def _all_gather(self, whole, mine):
-        dist.all_gather_into_tensor(whole, mine, group=self.group)
+        if self._native_halves(whole):
+            dist.all_gather_into_tensor(whole, mine, group=self.group)
+        else:
+            # every other rank's slice zeroed, then an INTEGER sum of the bit patterns: x + 0 + ... + 0 = x, exactly
+            keep = mine.clone()
+            whole.zero_()
+            mine.copy_(keep)
+            # (as int32 words -- gloo has no 16-bit integer sum; a piece is a multiple of 64 elements)
+            dist.all_reduce(whole.view(torch.int32), op=dist.ReduceOp.SUM, group=self.group)
 
     def allreduce_sum_scalar(self, x):
         if self.world_size > 1:

@@ -81,15 +81,15 @@ class _GatheredWeights(object):
         self.events = [None] * 4
 
     def set_events(self, piece_events):
-        """piece_events: {arena piece index: event recorded behind its all-gather}; the gathers ran in DESCENDING piece order on
-        one stream, so the event of the lowest piece a group needs covers the others."""
+        """piece_events: {arena piece index: event recorded behind its all-gather}, in the order the gathers were enqueued on the
+        communication stream: the event of the LAST-gathered piece a group needs covers its others."""
+        order = {i: n for n, i in enumerate(piece_events)}
         ev = [None] * 4
         for k, (_, grp) in self.keys.items():
             i = self.piece_of[k]
-            cur = ev[grp]
-            if cur is None or i < cur[0]:
-                ev[grp] = (i, piece_events[i])
-        self.events = [e[1] if e is not None else None for e in ev]
+            if ev[grp] is None or order[i] > order[ev[grp]]:
+                ev[grp] = i
+        self.events = [piece_events[i] if i is not None else None for i in ev]
 
 
 class Trainer(object):
@@ -182,6 +182,10 @@ class Trainer(object):
         late = [k for k in names if k.startswith(self.LATE_GRADS)]
         early = [k for k in names if k not in first and k not in lstm_w and k not in late]
         groups = (first, lstm_w, early, late)
+        # gradient groups 4 / 3 of uic_topdown_grad_ready_wait: the embedding table is the first piece of the tail to be final, and
+        # att_lstm.weight_ih is complete with the recurrent matrices (both empty lists under opt.early_grads: group 1 has them then)
+        emb = [k for k in early if k == "embed.0.weight"]
+        wih = [k for k in early if k == "core.att_lstm.weight_ih"]
         ex = self.exchange
         self.sharded = bool(ex.world_size > 1 and eng is not None and hasattr(self.i2t_model, 'use_bn') and
                             not getattr(self.opt, 'allreduce_exchange', 0))
@@ -189,11 +193,15 @@ class Trainer(object):
             # the SHARDED exchange (parallel_exchange.py): only the matrices the kernels consume in the operand dtype are sharded;
             # everything the kernels read as f32 (biases, alpha_net, BatchNorm tensors -- and att_embed's Linear when it has to be
             # folded with the BatchNorm or zero-padded from its f32 master) stays replicated in the arena's tail
+            # pieces in the order the backward pass finishes them, each with the gradient group whose event releases its
+            # reduce-scatter (None: after the step has joined): logit | embedding table | recurrent LSTM matrices + att_lstm.weight_ih |
+            # fc_embed + the late group's matrices
             mats = self._gathered_keys()
-            pieces = [[k for k in g if k in mats] for g in groups]
-            self.piece_groups = [gid for gid, p in enumerate(pieces) if p]
+            cand = [(first, 0), (emb, 4), (lstm_w + wih, 3 if wih else 1), ([k for k in early if k not in emb + wih] + late, None)]
+            pieces = [[k for k in g if k in mats] for g, _ in cand]
+            self.piece_groups = [gid for (g, gid), p in zip(cand, pieces) if p]
             op_dtype = _lib.TORCH_DTYPE[eng.dtype]
-            self.arena = FlatArena(self.i2t_model, first + lstm_w + early + late, world=ex.world_size, rank=ex.rank,
+            self.arena = FlatArena(self.i2t_model, first + emb + lstm_w + wih + [k for k in early if k not in emb + wih] + late, world=ex.world_size, rank=ex.rank,
                                    pieces=[p for p in pieces if p], operand_dtype=op_dtype)
             self.arena_splits = []
             eng.gathered = _GatheredWeights(self.arena, mats)
@@ -369,13 +377,19 @@ class Trainer(object):
         groups = self.piece_groups
 
         def wait_piece(raw, i):
-            if not overlap or groups[i] > 2:
-                return False                                        # the late piece: the step's own stream has joined
+            if not overlap or groups[i] is None:
+                return False                                        # the last piece: the step's own stream has joined
             check(lib.uic_topdown_grad_ready_wait(raw, groups[i]), "grad_ready_wait")
             return True
         self._step += 1
+        # the logit layer's piece -- a quarter of the bytes, final when the BPTT loop STARTS -- is reduce-scattered, updated and
+        # all-gathered on the communication stream while the loop runs (no kernel of the step reads logit.weight after that point);
+        # the status word it is guarded by is final then too (the step's only persistent launch is the forward recurrence)
+        has_eng = getattr(self.i2t_model, 'engine', None) is not None
+        pipe = (0,) if (has_eng and overlap and groups and groups[0] == 0 and not getattr(self.opt, 'no_pipelined_logit_piece', 0)) else ()
         pair, events = a.sharded_step(self.exchange, self.i2t_current_lr, self.betas, self.eps, self._step, grad_scale,
-                                      wait_piece=wait_piece, comm=self._comm(dev), gather_async=True)
+                                      wait_piece=wait_piece, comm=self._comm(dev), gather_async=True,
+                                      early_guard=_lib.status_words(dev) if pipe else None, pipeline=pipe)
         self._guard_pair = pair
         if next_den_local is not None:
             self._next_den = (float(next_den_local), sc[3:4].reciprocal())
@@ -453,7 +467,8 @@ class Trainer(object):
             if pair is not None:
                 vals = pair.cpu().tolist()
                 if vals[1] != 0:
-                    raise _lib.PersistentTimeout("persistent recurrence kernel timed out on some rank: this step's update was skipped on every rank")
+                    raise _lib.PersistentTimeout("persistent recurrence kernel timed out on some rank (summed status flag %r): this step's "
+                                                 "update was skipped on every rank" % (vals[1],))
                 _lib.persistent_status(self.arena.flat.device)  # (clears nothing: the local word is zero too)
                 return vals[0]
             val = loss.item()
