@@ -14,14 +14,17 @@
 #include <zlib.h>
 
 #include <atomic>
+#include <condition_variable>
 #include <cstring>
+#include <functional>
+#include <mutex>
 #include <string>
 #include <thread>
 #include <vector>
 
 namespace {
 
-constexpr int IO_MAX_THREADS = 64;
+constexpr int IO_MAX_THREADS = 128;
 constexpr int IO_INFO = 6;            // per file: ndim, d0, d1, data offset in the (uncompressed) member, zip method, member offset in the file
 
 struct FileBytes {
@@ -104,9 +107,21 @@ bool parse_npy(const unsigned char* p, size_t n, int64_t* ndim, int64_t* d0, int
 // want == 0 and only `head` -- the first head_cap bytes -- is wanted).
 bool inflate_member(const unsigned char* src, size_t n, size_t skip, unsigned char* dst, size_t want, unsigned char* head,
                     size_t head_cap, size_t* head_got) {
-  z_stream z;
-  memset(&z, 0, sizeof(z));
-  if (inflateInit2(&z, -15) != Z_OK) return false;
+  // one inflate state per reader thread for the life of the pool (inflateInit2 allocates ~40 KB: per file and from 128 threads it
+  // was mmap / page-fault traffic on the process's address-space lock, which is what kept more threads from helping)
+  struct ZState {
+    z_stream z; bool ready = false;
+    ~ZState() { if (ready) inflateEnd(&z); }
+  };
+  static thread_local ZState zs;
+  z_stream& z = zs.z;
+  if (!zs.ready) {
+    memset(&z, 0, sizeof(z));
+    if (inflateInit2(&z, -15) != Z_OK) return false;
+    zs.ready = true;
+  } else if (inflateReset2(&z, -15) != Z_OK) {
+    return false;
+  }
   z.next_in = const_cast<unsigned char*>(src);
   z.avail_in = (uInt)n;
   bool ok = true;
@@ -116,7 +131,8 @@ bool inflate_member(const unsigned char* src, size_t n, size_t skip, unsigned ch
     ok = r == Z_OK || r == Z_STREAM_END || r == Z_BUF_ERROR;
     *head_got = head_cap - z.avail_out;
   } else {
-    std::vector<unsigned char> scratch(skip ? skip : 1);
+    static thread_local std::vector<unsigned char> scratch;
+    if (scratch.size() < (skip ? skip : 1)) scratch.resize(skip ? skip : 1);
     z.next_out = scratch.data(); z.avail_out = (uInt)skip;
     while (ok && z.avail_out > 0) {
       const int r = inflate(&z, Z_NO_FLUSH);
@@ -132,16 +148,73 @@ bool inflate_member(const unsigned char* src, size_t n, size_t skip, unsigned ch
     }
     ok = ok && z.avail_out == 0;
   }
-  inflateEnd(&z);
   return ok;
+}
+
+// The reader team is a process-wide pool of worker threads that lives as long as the process (round 6): a std::thread team per
+// call cost ~1 ms per batch at 32 threads and made more threads a loss for stored files; with the pool a batch of DEFLATED files
+// (what np.savez_compressed / make_bu_data.py writes: ~1.4 ms of inflate per 36 x 2048 file) spreads over up to 128 workers.
+// One job at a time (the loader's read-ahead thread and the caller's thread serialise on job_mu); the caller works too.
+class Pool {
+ public:
+  void run(int nt, const std::function<void(int)>& body) {
+    std::lock_guard<std::mutex> job(job_mu_);
+    {
+      std::unique_lock<std::mutex> lk(mu_);
+      while ((int)workers_.size() < nt - 1) {
+        const int idx = (int)workers_.size();
+        workers_.emplace_back([this, idx] { loop(idx); });
+        workers_.back().detach();                      // (they sleep on the condition variable until the process ends)
+      }
+      body_ = &body;
+      want_ = nt - 1;
+      active_ = nt - 1;
+      ++gen_;
+    }
+    cv_.notify_all();
+    body(0);
+    std::unique_lock<std::mutex> lk(mu_);
+    done_.wait(lk, [this] { return active_ == 0; });
+    body_ = nullptr;
+  }
+
+ private:
+  void loop(int idx) {
+    unsigned long seen = 0;
+    for (;;) {
+      const std::function<void(int)>* body = nullptr;
+      {
+        std::unique_lock<std::mutex> lk(mu_);
+        cv_.wait(lk, [&] { return gen_ != seen; });
+        seen = gen_;
+        if (idx < want_) body = body_;
+      }
+      if (body) {
+        (*body)(idx + 1);
+        std::lock_guard<std::mutex> lk(mu_);
+        if (--active_ == 0) done_.notify_all();
+      }
+    }
+  }
+  std::mutex job_mu_, mu_;
+  std::condition_variable cv_, done_;
+  std::vector<std::thread> workers_;
+  const std::function<void(int)>* body_ = nullptr;
+  int want_ = 0, active_ = 0;
+  unsigned long gen_ = 0;
+};
+Pool& pool() {
+  static Pool* p = new Pool();                          // never destroyed: its detached workers may outlive static destructors
+  return *p;
 }
 
 template <typename F>
 int run_team(int n, int n_threads, F&& work, std::string* first_error) {
   std::atomic<int> next(0), failed(0);
   std::string errors[IO_MAX_THREADS];
-  const int nt = n_threads < 1 ? 1 : (n_threads > IO_MAX_THREADS ? IO_MAX_THREADS : n_threads);
-  auto body = [&](int t) {
+  int nt = n_threads < 1 ? 1 : (n_threads > IO_MAX_THREADS ? IO_MAX_THREADS : n_threads);
+  if (nt > n) nt = n;
+  const std::function<void(int)> body = [&](int t) {
     for (;;) {
       const int i = next.fetch_add(1);
       if (i >= n || failed.load()) return;
@@ -149,10 +222,8 @@ int run_team(int n, int n_threads, F&& work, std::string* first_error) {
       if (!work(i, &why)) { errors[t] = why; failed.store(1); return; }
     }
   };
-  std::vector<std::thread> team;
-  for (int t = 1; t < nt && t < n; ++t) team.emplace_back(body, t);
-  body(0);
-  for (auto& th : team) th.join();
+  if (nt <= 1) body(0);
+  else pool().run(nt, body);
   if (failed.load())
     for (int t = 0; t < nt; ++t)
       if (!errors[t].empty()) { *first_error = errors[t]; return 1; }
@@ -196,7 +267,7 @@ int uic_loader_read(const char* const* paths, int32_t n, const int64_t* info, vo
     const int64_t* o = info + (size_t)i * IO_INFO;
     const size_t want = (size_t)(o[1] * o[2]) * sizeof(float), data_off = (size_t)o[3], off = (size_t)o[5];
     if (o[4] == 8) {                                   // deflate: the whole file, inflate past the header into place
-      FileBytes f;
+      static thread_local FileBytes f;                 // (kept across files: a fresh 270-KB vector per file is an mmap + page faults)
       if (!f.read_all(paths[i], 0) || f.buf.size() <= off) { *why = std::string("cannot read ") + paths[i]; return false; }
       if (!inflate_member(f.buf.data() + off, f.buf.size() - off, data_off, (unsigned char*)dst[i], want, nullptr, 0, nullptr)) {
         *why = std::string(paths[i]) + ": inflate failed or the member is shorter than its header says";

@@ -118,7 +118,10 @@ class DataLoader(object):
         # .npy line is commented out at :330): take whichever the data set has
         first = str(self.info['images'][0]['id'])
         self._fc_ext = '.npz' if os.path.exists(os.path.join(self.input_fc_dir, first + '.npz')) else '.npy'
-        self.read_threads = int(read_threads or min(32, os.cpu_count() or 8))     # 64: deflated files 10 % faster, stored ones 3x slower (measured)
+        # the library's reader team (a persistent pool since round 6): 32 workers move stored members at the page cache's rate;
+        # DEFLATED members (np.savez_compressed, what make_bu_data.py writes) cost ~1.4 ms of inflate each and get up to 128
+        self.read_threads = int(read_threads or min(32, os.cpu_count() or 8))
+        self.read_threads_deflate = int(read_threads or min(128, max(8, (os.cpu_count() or 8) // 2)))
         self.read_ahead = read_ahead
         self._pool = ThreadPoolExecutor(max_workers=1)                 # the read-ahead thread (the team is inside the library)
         self._ahead_job = None
@@ -232,7 +235,9 @@ class DataLoader(object):
         arr = (C.c_char_p * len(paths))(*paths)
         info = np.ascontiguousarray(np.concatenate(infos, 0))
         dst = (C.c_void_p * len(dsts))(*dsts)
-        check(self.lib.uic_loader_read(arr, len(paths), info.ctypes.data, dst, self.read_threads), "loader_read")
+        deflated = bool((info[:, 4] == 8).any())
+        check(self.lib.uic_loader_read(arr, len(paths), info.ctypes.data, dst, self.read_threads_deflate if deflated else self.read_threads),
+              "loader_read")
         return st
 
     def _staging(self, key, shape, dtype, turn):
