@@ -295,6 +295,11 @@ __device__ __forceinline__ void attn_phase_wave(const Ctx& c, const UicRnnFwdPar
   };
   const __amdgpu_buffer_rsrc_t rh = rsrc_of(att_h + (size_t)n * HH);
   const u32x4 h0 = bload<true>(rh, (unsigned)(c.lane * 32), 0), h1 = bload<true>(rh, (unsigned)(c.lane * 32 + 16), 0);
+  // the region mask of this lane's region, requested HERE and without a branch (no mask: any readable word, ignored below): read
+  // where it is used, under `if (mask)`, it was a load behind a run-time branch followed by s_waitcnt vmcnt(0) -- an exposed L2
+  // round trip between the softmax and the context, with the context's first chunks held up behind it
+  const float* mkp = p.mask ? p.mask + (size_t)n * p.ldmask : p.w_alpha;
+  const float mkv = mkp[c.lane < R ? c.lane : 0];
   uint4 pa[2][CR], va[2][CR];
 #pragma unroll
   for (int u = 0; u < CR; ++u) pa[0][u] = pre[u];
@@ -329,7 +334,6 @@ __device__ __forceinline__ void attn_phase_wave(const Ctx& c, const UicRnnFwdPar
     if (ch + 2 < NCH) load_chunk(P, ch + 2, pa[ch & 1]);
   }
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // this wave's LDS writes are done (LDS serves a wave's requests in order)
-  const float* mk = p.mask ? p.mask + (size_t)n * p.ldmask : nullptr;
   float e = -INFINITY;
   if (c.lane < R) {
     const float4 qq = *(const float4*)(s_e + c.lane * 4);
@@ -338,8 +342,8 @@ __device__ __forceinline__ void attn_phase_wave(const Ctx& c, const UicRnnFwdPar
   const float mx = uic_wave_max(e);
   const float ex = c.lane < R ? __builtin_amdgcn_exp2f((e - mx) * 1.4426950408889634f) : 0.f;
   float wgt = ex * __builtin_amdgcn_rcpf(uic_wave_sum(ex));
-  if (mk) {
-    wgt *= c.lane < R ? mk[c.lane] : 0.f;
+  if (p.mask) {                                       // (wave-uniform; the value has been here since the top of the phase)
+    wgt *= c.lane < R ? mkv : 0.f;
     wgt = wgt / uic_wave_sum(wgt);
   }
   if (c.lane < R) alpha[(unsigned)(n * R + c.lane)] = wgt;
@@ -1157,8 +1161,10 @@ __device__ __forceinline__ void ws_run(const UicRnnFwdParams& p, Ctx& c, char* l
           for (int g = 0; g < 4; ++g) fb[(q + 1) & 1][g] = w1[(sn * 4 + g) * 64 + c.lane];
 #pragma unroll
           for (int g = 0; g < 4; ++g) acc1[g] = mma_bf16(fa[q], fb[q & 1][g], acc1[g]);
-          if (q == 7 && split5) {
+          if (q == 7 && (DEC ? split5 : true)) {
             // the registers that have just been consumed take this wave's share of tile 4: k-steps wave, wave + 4, ...
+            // (training kernel: requested whether or not the group has a fifth tile -- the row index is clamped --, so that the
+            // waits of the remaining k-steps are counted exactly; see the note at mfma_range)
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int k = 0; k < 8; ++k) {
@@ -1250,13 +1256,16 @@ __device__ __forceinline__ void ws_run(const UicRnnFwdParams& p, Ctx& c, char* l
 #pragma unroll
       for (int j = 0; j < 4; ++j)
         wh[j] = bload<false>(r_h2, (unsigned)(((c.u0 + c.l15) * HH + c.lq * 8) * 2), (unsigned)((c.wave + 4 * ((j + c.rank) & 3)) * 64));
+      // (requests without run-time conditions -- a tile the group does not have is its last real tile again -- and an early exit
+      // instead of skipped blocks: the waits in front of every tile's MFMAs are then counted exactly; see the note at mfma_range)
+      auto clamp_tile = [&](int i) { return i < c.MT ? i : c.MT - 1; };
 #pragma unroll
-      for (int i = 0; i < P2D - 1; ++i)
-        if (i < c.MT) load_tile(i, i);
+      for (int i = 0; i < P2D - 1; ++i) load_tile(i, clamp_tile(i));
 #pragma unroll
-      for (int i = 0; i < MT_MAX; ++i)
-        if (i < c.MT) {
-          if (i + P2D - 1 < MT_MAX && i + P2D - 1 < c.MT) load_tile((i + P2D - 1) % P2D, i + P2D - 1);
+      for (int i = 0; i < MT_MAX; ++i) {
+        if (i >= c.MT) break;
+        {
+          if (i + P2D - 1 < MT_MAX) load_tile((i + P2D - 1) % P2D, DEC ? (i + P2D - 1 < c.MT ? i + P2D - 1 : i) : clamp_tile(i + P2D - 1));
           __builtin_amdgcn_sched_barrier(0);
           f32x4 a = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -1264,6 +1273,7 @@ __device__ __forceinline__ void ws_run(const UicRnnFwdParams& p, Ctx& c, char* l
           scr[(c.wave * MT_MAX + tile_of(i)) * 64 + c.lane] = a;
           __builtin_amdgcn_sched_barrier(0);
         }
+      }
       __syncthreads();
       const int a = c.u0 + c.l15;
       const float bias = p.h2att_b ? p.h2att_b[a] : 0.f;
@@ -1343,6 +1353,10 @@ __device__ __forceinline__ void ws_run(const UicRnnFwdParams& p, Ctx& c, char* l
       // ... and multiplied too (the first tile's eight k-fragments that need no exchange): in the time between this workgroup's
       // arrival and its first look at the barrier.  mfma_range: slots [jlo, jhi) of a pass (see the note on the inline asm below).
       f32x4 acc0[4];
+      // `more` is a COMPILE-TIME fact (is there a later pass in the unrolled loop at all); whether the group really has that tile
+      // only picks the address (the last real tile's again).  A load under a run-time branch here makes hipcc's s_waitcnt
+      // insertion assume it may NOT have been issued, and every later slot of the pass then waits with vmcnt(4) .. vmcnt(0) --
+      // i.e. for the loads this very pass has just issued, an L2 round trip per pass (round 6: 1.46 us of a pass's 2.26 were this).
       auto mfma_range = [&](f32x4 (&acc)[4], int jlo, int jhi, bool more, unsigned an) {
 #pragma unroll
         for (int j = 0; j < 12; ++j) {
@@ -1356,8 +1370,8 @@ __device__ __forceinline__ void ws_run(const UicRnnFwdParams& p, Ctx& c, char* l
         }
       };
       {
-        const bool more0 = 1 < MT_MAX && 1 < c.MT;
-        if constexpr (!DEC) mfma_range(acc0, 0, 8, more0, aoff_of(tile_of(more0 ? 1 : 0)));   // (not the decode kernel: it spills as it is)
+        constexpr bool more0 = 1 < MT_MAX;
+        if constexpr (!DEC) mfma_range(acc0, 0, 8, more0, aoff_of(tile_of(1 < c.MT ? 1 : 0)));   // (not the decode kernel: it spills as it is)
         if (!group_wait(c, (int*)c.smem)) return;
         if (dbg && c.tid == 0) dbg[6] = __builtin_amdgcn_s_memrealtime();
         const unsigned a0 = aoff_of(tile_of(0));
@@ -1366,10 +1380,11 @@ __device__ __forceinline__ void ws_run(const UicRnnFwdParams& p, Ctx& c, char* l
       }
 #pragma unroll
       for (int i = 0; i < MT_MAX; ++i) {
-        if (i < c.MT) {
-          const bool more = i + 1 < MT_MAX && i + 1 < c.MT;
+        if (i >= c.MT) break;                       // (an early exit, not a skipped block: pass i + 1 is reachable through pass i only)
+        {
+          const bool more = DEC ? (i + 1 < MT_MAX && i + 1 < c.MT) : i + 1 < MT_MAX;      // training kernel: compile-time (see mfma_range)
           const int tile = tile_of(i);
-          const unsigned an = aoff_of(tile_of(more ? i + 1 : i));
+          const unsigned an = aoff_of(tile_of(i + 1 < MT_MAX && i + 1 < c.MT ? i + 1 : i));
           // The stationary B fragments are named as ACCUMULATOR-file operands ("a"), which is what keeps them there for the
           // whole launch: left to itself hipcc parks them in AGPRs but copies each one back (4 x v_accvgpr_read) in front of
           // every MFMA.  Inline-asm MFMAs get no hazard padding from the compiler: gate g's chain is re-entered only after
