@@ -247,7 +247,11 @@ __device__ __forceinline__ void load_chunk_f32(const float* src, int c, bool ok,
 
 // NW waves per caption row, each keeping UBX = ceil(36 / NW) regions in flight (NW = 8: more waves to hide the HBM latency of
 // the one-shot load burst and half the per-wave tanh / reduction work; measured against NW = 4 on MI355X)
-template <typename T, int NW>
+// FULL (att_hid_size = rnn_size = 64 lanes x VEC): no lane predicates -- see attn_bwd_step_fast_kernel.  Requests in the order of
+// use: att_h and w_alpha (the scores' other operands) FIRST, then the p_att rows, then the att' rows, which keep arriving while the
+// scores are computed.  (Before round 6 the two small vectors were requested last, behind a lane predicate: the first score then
+// waited for all 2 x UB row loads of the wave.)
+template <typename T, int NW, bool FULL>
 __global__ __launch_bounds__(NW * 64) void attn_fwd_fast_kernel(const UicAttnParams p) {
   constexpr int NWAVES = NW, NTHREADS = NW * 64, UB = (UIC_ATT_FAST_R + NW - 1) / NW;
   constexpr int VEC = uic_vec<T>::N;
@@ -257,19 +261,25 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_fast_kernel(const UicAttnPar
   float* s_red = s_e + 4 * R;
   const int n = blockIdx.x;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const bool la = lane < A / VEC, lh = lane < H / VEC;
+  const bool la = FULL ? true : lane < A / VEC, lh = FULL ? true : lane < H / VEC;
   // indices are clamped instead of predicated (no exec-mask branches around the 18 loads); out-of-range
   // regions / lanes read valid memory and are neutralised by zero weights below
   const T* pa = (const T*)p.p_att + (size_t)n * R * A + (la ? lane : 0) * VEC;
   const T* pt = (const T*)p.att + (size_t)n * R * H + (lh ? lane : 0) * VEC;
-  uint4 vp[UB], va[UB];
-#pragma unroll
-  for (int u = 0; u < UB; ++u) vp[u] = *(const uint4*)(pa + (size_t)min(wave + u * NWAVES, R - 1) * A);
-#pragma unroll
-  for (int u = 0; u < UB; ++u) va[u] = *(const uint4*)(pt + (size_t)min(wave + u * NWAVES, R - 1) * H);
   float ah[VEC], w[VEC];
   load_chunk_f32<T>(p.att_h + (size_t)n * A, lane, la, ah);
   load_chunk_f32<T>(p.w_alpha, lane, la, w);
+  // (the region mask value of this lane's region: requested here, without a branch -- no mask: any readable word, ignored below)
+  const float* mkp = p.mask ? p.mask + (size_t)n * p.ldmask : p.w_alpha;
+  const float mkv = mkp[lane < R ? lane : 0];
+  __builtin_amdgcn_sched_barrier(0);                  // (or hipcc issues the row loads first and these arrive behind them)
+  uint4 vp[UB], va[UB];
+#pragma unroll
+  for (int u = 0; u < UB; ++u) vp[u] = *(const uint4*)(pa + (size_t)min(wave + u * NWAVES, R - 1) * A);
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int u = 0; u < UB; ++u) va[u] = *(const uint4*)(pt + (size_t)min(wave + u * NWAVES, R - 1) * H);
+  __builtin_amdgcn_sched_barrier(0);
   const float b_alpha = p.b_alpha ? p.b_alpha[0] : 0.f;
 #pragma unroll
   for (int u = 0; u < UB; ++u) {
@@ -284,7 +294,6 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_fast_kernel(const UicAttnPar
   }
   __syncthreads();
   // every wave normalises the R <= 64 scores with one lane per region (softmax, then mask-renormalise)
-  const float* mk = p.mask ? p.mask + (size_t)n * p.ldmask : nullptr;
   float e = -INFINITY;
   if (lane < R) {
     const float4 q = *(const float4*)(s_e + lane * 4);
@@ -294,8 +303,8 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_fast_kernel(const UicAttnPar
   // (bf16 path: one v_exp_f32 / v_rcp_f32 instead of libm's exp and an IEEE division -- this kernel is made of instruction issue)
   const float ex = lane < R ? (sizeof(T) == 2 ? __builtin_amdgcn_exp2f((e - mx) * 1.4426950408889634f) : expf(e - mx)) : 0.f;
   float wgt = ex * (sizeof(T) == 2 ? __builtin_amdgcn_rcpf(uic_wave_sum(ex)) : 1.f / uic_wave_sum(ex));
-  if (mk) {
-    wgt *= lane < R ? mk[lane] : 0.f;
+  if (p.mask) {
+    wgt *= lane < R ? mkv : 0.f;
     wgt = wgt / uic_wave_sum(wgt);
   }
   if (wave == 0 && lane < R) p.alpha[(size_t)n * R + lane] = wgt;
@@ -327,7 +336,14 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_fast_kernel(const UicAttnPar
   }
 }
 
-template <typename T>
+// FULL: att_hid_size = rnn_size = 64 lanes x VEC (512 in bf16, the reference's sizes): every lane holds a chunk of every vector, so
+// no load sits behind a lane predicate.  That matters beyond the branch itself: hipcc waits for a predicated load at the JOIN of
+// its branch (s_waitcnt vmcnt(1) one instruction behind the request), and with loads returning in order that wait is for every
+// load issued before it -- the kernel then ran "request 36 region rows, wait for all of them, request the small vectors, wait,
+// request d ctx, wait, request its slabs, wait": three to four serial memory round trips behind the burst (round 6).  Order of
+// the requests now = order of use: d ctx (+ slabs) and the att' rows (first pass), att_h, w_alpha and the p_att rows (second pass,
+// still arriving while the first pass computes).
+template <typename T, bool FULL>
 __global__ __launch_bounds__(NTHREADS) void attn_bwd_step_fast_kernel(const UicAttnParams p) {
   constexpr int VEC = uic_vec<T>::N;
   extern __shared__ __attribute__((aligned(16))) float sm[];
@@ -338,42 +354,48 @@ __global__ __launch_bounds__(NTHREADS) void attn_bwd_step_fast_kernel(const UicA
   float* s_red = s_da4 + 4 * Rp;
   const int n = blockIdx.x;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const bool la = lane < A / VEC, lh = lane < H / VEC;
+  const bool la = FULL ? true : lane < A / VEC, lh = FULL ? true : lane < H / VEC;
   const T* pa = (const T*)p.p_att + (size_t)n * R * A + (la ? lane : 0) * VEC;
   const T* pt = (const T*)p.att + (size_t)n * R * H + (lh ? lane : 0) * VEC;
+  float ah[VEC], w[VEC], dc[VEC];
+  float dz[3][VEC];
+  load_chunk_f32<T>(p.dctx + (size_t)n * p.lddctx, lane, lh, dc);
+  // d ctx may arrive as split-K partial slabs, summed here in a fixed order (the sum is left for the accumulation pass).  The
+  // first three extra slabs are requested whether or not they exist (a slab that does not is the last one again, and dropped).
+  const int ns = p.dctx_nslab > 1 ? p.dctx_nslab : 1;
+#pragma unroll
+  for (int z = 0; z < 3; ++z) load_chunk_f32<T>(p.dctx + (size_t)min(z + 1, ns - 1) * p.dctx_slab_stride + (size_t)n * p.lddctx, lane, lh, dz[z]);
+  const float al_mine = p.alpha[(size_t)n * R + (tid < R ? tid : 0)];       // (R <= 64 < NTHREADS in the fast path)
+  // (scheduling barriers: left alone hipcc issues the 2 x UB row loads first -- their addresses are ready first -- and everything
+  // above would again arrive behind them)
+  __builtin_amdgcn_sched_barrier(0);
   uint4 vp[UB], va[UB];
 #pragma unroll
   for (int u = 0; u < UB; ++u) va[u] = *(const uint4*)(pt + (size_t)min(wave + u * NWAVES, R - 1) * H);
-#pragma unroll
-  for (int u = 0; u < UB; ++u) vp[u] = *(const uint4*)(pa + (size_t)min(wave + u * NWAVES, R - 1) * A);
-  float ah[VEC], w[VEC], dc[VEC];
+  __builtin_amdgcn_sched_barrier(0);
   load_chunk_f32<T>(p.att_h + (size_t)n * A, lane, la, ah);
   load_chunk_f32<T>(p.w_alpha, lane, la, w);
-  load_chunk_f32<T>(p.dctx + (size_t)n * p.lddctx, lane, lh, dc);
-  if (p.dctx_nslab > 1) {       // d ctx arrives as split-K partial slabs: summed here (fixed order), the sum left for the accumulation pass
-    // (all slices requested before the first one is used: a slice per trip would be a memory latency per slice)
-    float dz[3][VEC];
 #pragma unroll
-    for (int z = 0; z < 3; ++z) load_chunk_f32<T>(p.dctx + (size_t)min(z + 1, p.dctx_nslab - 1) * p.dctx_slab_stride + (size_t)n * p.lddctx, lane, lh, dz[z]);
+  for (int u = 0; u < UB; ++u) vp[u] = *(const uint4*)(pa + (size_t)min(wave + u * NWAVES, R - 1) * A);
+  __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-    for (int z = 0; z < 3; ++z)
-      if (z + 1 < p.dctx_nslab) {
+  for (int z = 0; z < 3; ++z) {
+    const bool use = z + 1 < ns;
 #pragma unroll
-        for (int j = 0; j < VEC; ++j) dc[j] += dz[z][j];
-      }
-    for (int z = 4; z < p.dctx_nslab; ++z) {
-      float dw[VEC];
-      load_chunk_f32<T>(p.dctx + (size_t)z * p.dctx_slab_stride + (size_t)n * p.lddctx, lane, lh, dw);
+    for (int j = 0; j < VEC; ++j) dc[j] += use ? dz[z][j] : 0.f;
+  }
+  for (int z = 4; z < ns; ++z) {
+    float dw[VEC];
+    load_chunk_f32<T>(p.dctx + (size_t)z * p.dctx_slab_stride + (size_t)n * p.lddctx, lane, lh, dw);
 #pragma unroll
-      for (int j = 0; j < VEC; ++j) dc[j] += dw[j];
-    }
+    for (int j = 0; j < VEC; ++j) dc[j] += dw[j];
   }
   if (p.dctx_sum && lh && wave == 0) {
 #pragma unroll
     for (int q = 0; q < VEC / 4; ++q)
       *(float4*)(p.dctx_sum + (size_t)n * p.ld_dctx_sum + lane * VEC + q * 4) = make_float4(dc[q * 4], dc[q * 4 + 1], dc[q * 4 + 2], dc[q * 4 + 3]);
   }
-  for (int r = tid; r < R; r += NTHREADS) s_al[r] = p.alpha[(size_t)n * R + r];
+  if (tid < R) s_al[tid] = al_mine;
 #pragma unroll
   for (int u = 0; u < UB; ++u) {
     const int r = wave + u * NWAVES;
@@ -595,10 +617,15 @@ int uic_attention_fwd_launch(const UicAttnParams& p, hipStream_t s) {
     // taken for the steadier, faster kernel.
     const size_t lds8 = sizeof(float) * (4 * (size_t)p.R + 4 + 8 * (size_t)p.H);
     const size_t lds12 = sizeof(float) * (4 * (size_t)p.R + 4 + 12 * (size_t)p.H);
-    if (p.dtype == UIC_BF16)
-      hipLaunchKernelGGL((attn_fwd_fast_kernel<bf16_t, 12>), dim3(p.N), dim3(768), lds12, s, p);
-    else
-      hipLaunchKernelGGL((attn_fwd_fast_kernel<float, 8>), dim3(p.N), dim3(512), lds8, s, p);
+    const int vec = p.dtype == UIC_BF16 ? 8 : 4;
+    const bool full = p.A == 64 * vec && p.H == 64 * vec;
+    if (p.dtype == UIC_BF16) {
+      if (full) hipLaunchKernelGGL((attn_fwd_fast_kernel<bf16_t, 12, true>), dim3(p.N), dim3(768), lds12, s, p);
+      else hipLaunchKernelGGL((attn_fwd_fast_kernel<bf16_t, 12, false>), dim3(p.N), dim3(768), lds12, s, p);
+    } else {
+      if (full) hipLaunchKernelGGL((attn_fwd_fast_kernel<float, 8, true>), dim3(p.N), dim3(512), lds8, s, p);
+      else hipLaunchKernelGGL((attn_fwd_fast_kernel<float, 8, false>), dim3(p.N), dim3(512), lds8, s, p);
+    }
   } else if (p.dtype == UIC_BF16)
     hipLaunchKernelGGL(attn_fwd_kernel<bf16_t>, dim3(p.N), dim3(NTHREADS), lds, s, p);
   else
@@ -615,10 +642,15 @@ int uic_attention_bwd_step_launch(const UicAttnParams& p, hipStream_t s) {
   const size_t lds = sizeof(float) * (2 * (size_t)p.A + p.H + 5 * ((p.R + 3) & ~3) + NWAVES * (size_t)p.A);
   UIC_REQUIRE(lds <= 160 * 1024, "attention_bwd_step: needs %zu B of LDS", lds);
   if (fast_ok(p)) {
-    if (p.dtype == UIC_BF16)
-      hipLaunchKernelGGL(attn_bwd_step_fast_kernel<bf16_t>, dim3(p.N), dim3(NTHREADS), lds, s, p);
-    else
-      hipLaunchKernelGGL(attn_bwd_step_fast_kernel<float>, dim3(p.N), dim3(NTHREADS), lds, s, p);
+    const int vec = p.dtype == UIC_BF16 ? 8 : 4;
+    const bool full = p.A == 64 * vec && p.H == 64 * vec;
+    if (p.dtype == UIC_BF16) {
+      if (full) hipLaunchKernelGGL((attn_bwd_step_fast_kernel<bf16_t, true>), dim3(p.N), dim3(NTHREADS), lds, s, p);
+      else hipLaunchKernelGGL((attn_bwd_step_fast_kernel<bf16_t, false>), dim3(p.N), dim3(NTHREADS), lds, s, p);
+    } else {
+      if (full) hipLaunchKernelGGL((attn_bwd_step_fast_kernel<float, true>), dim3(p.N), dim3(NTHREADS), lds, s, p);
+      else hipLaunchKernelGGL((attn_bwd_step_fast_kernel<float, false>), dim3(p.N), dim3(NTHREADS), lds, s, p);
+    }
   } else if (p.dtype == UIC_BF16)
     hipLaunchKernelGGL(attn_bwd_step_kernel<bf16_t>, dim3(p.N), dim3(NTHREADS), lds, s, p);
   else
