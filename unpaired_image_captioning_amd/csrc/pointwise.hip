@@ -595,7 +595,9 @@ __global__ void lstm_bwd_kernel(const UicLstmBwdParams p) {
 // The same for H % 4 == 0 and 16-byte aligned rows: FOUR hidden units per lane, one 16-byte (f32) / 8-byte (bf16) access per
 // tensor and gate instead of four scalar ones -- the kernel sits in the BPTT chain 34 times per step and is made of memory
 // latency and instruction issue, not of bytes (captioner step 3.775 -> 3.757 ms over six alternations).  Same formulas per element.
-template <typename T>
+// SIMPLE: dh0 and c_prev present, dh1 / dh2 absent -- the two calls of the split BPTT chain (topdown.hip); then no load has an
+// optional address at all, only the slab stand-ins below.
+template <typename T, bool SIMPLE>
 __global__ __launch_bounds__(NT) void lstm_bwd_vec4_kernel(const UicLstmBwdParams p) {
   const int H = p.H, H4 = H >> 2;
   const int m = blockIdx.y, u4 = blockIdx.x * blockDim.x + threadIdx.x;      // (row from the grid: no division per lane)
@@ -603,25 +605,40 @@ __global__ __launch_bounds__(NT) void lstm_bwd_vec4_kernel(const UicLstmBwdParam
   const int u = u4 * 4;
   const size_t idx = (size_t)m * H + u;
   const float inv_keep = p.drop_p > 0.f ? 1.f / (1.f - p.drop_p) : 1.f;
-  // every load first
-  float4 d0 = make_float4(0.f, 0.f, 0.f, 0.f), d1 = d0, d2 = d0, cp = d0;
-  if (p.dh0) d0 = *(const float4*)(p.dh0 + (size_t)m * p.lddh0 + u);
-  if (p.dh1) d1 = *(const float4*)(p.dh1 + (size_t)m * p.lddh1 + u);
-  if (p.dh2) d2 = *(const float4*)(p.dh2 + (size_t)m * p.lddh2 + u);
-  float4 ds = make_float4(0.f, 0.f, 0.f, 0.f);       // split-K partial slabs of two more sources, summed in a fixed order
-  {
-    float4 sv[8];
-    const int nA = p.nA < 4 ? p.nA : 4, nB = p.nB < 4 ? p.nB : 4;
-#pragma unroll
-    for (int z = 0; z < 4; ++z) sv[z] = z < nA ? *(const float4*)(p.slabA + (size_t)z * p.strideA + (size_t)m * p.ldA + u) : make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll
-    for (int z = 0; z < 4; ++z) sv[4 + z] = z < nB ? *(const float4*)(p.slabB + (size_t)z * p.strideB + (size_t)m * p.ldB + u) : make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll
-    for (int z = 0; z < 8; ++z) { ds.x += sv[z].x; ds.y += sv[z].y; ds.z += sv[z].z; ds.w += sv[z].w; }
+  // Every load first, and NONE behind a run-time condition (round 6): an optional source that is absent is read from a valid
+  // stand-in address (the d c row) and dropped by a select below.  hipcc waits for a predicated load at the join of its branch --
+  // s_waitcnt vmcnt(0) right behind the first optional slab --, which made this link of the BPTT chain two to three serial memory
+  // round trips instead of one.  The loads are raw buffer loads: a plain float4 load hipcc is free to split (it made one of them
+  // a dwordx3 plus a dword under the dropout branch, with a full drain behind it) or to fold into another one of the same address.
+  auto ld4 = [](const float* base, size_t elem) -> float4 {
+    const f32x4 v = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
+        __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, 0x7fffffff, 0x00020000), (unsigned)(elem * 4), 0, 0));
+    return make_float4(v[0], v[1], v[2], v[3]);
+  };
+  const bool has0 = SIMPLE || p.dh0 != nullptr, has1 = !SIMPLE && p.dh1 != nullptr, has2 = !SIMPLE && p.dh2 != nullptr;
+  const bool hascp = SIMPLE || p.c_prev != nullptr;
+  const float4 c4 = ld4(p.c, idx);
+  const float4 dc4 = ld4(p.dc, idx);
+  const float4 d0r = has0 ? ld4(p.dh0, (size_t)m * p.lddh0 + u) : dc4;
+  float4 d1r = make_float4(0.f, 0.f, 0.f, 0.f), d2r = d1r;
+  if constexpr (!SIMPLE) {
+    d1r = ld4(p.dh1 ? p.dh1 : p.dc, p.dh1 ? (size_t)m * p.lddh1 + u : idx);
+    d2r = ld4(p.dh2 ? p.dh2 : p.dc, p.dh2 ? (size_t)m * p.lddh2 + u : idx);
   }
-  const float4 c4 = *(const float4*)(p.c + idx);
-  if (p.c_prev) cp = *(const float4*)(p.c_prev + idx);
-  const float4 dc4 = *(const float4*)(p.dc + idx);
+  const float4 cpr = ld4(hascp ? p.c_prev : p.c, idx);
+  float4 sv[8];
+  const int nA = p.nA < 4 ? p.nA : 4, nB = p.nB < 4 ? p.nB : 4;
+  {
+    const float* bA = nA > 0 ? p.slabA : p.dc;
+    const float* bB = nB > 0 ? p.slabB : p.dc;
+    const size_t oA = nA > 0 ? (size_t)m * p.ldA + u : idx, oB = nB > 0 ? (size_t)m * p.ldB + u : idx;
+    const size_t sA = nA > 0 ? p.strideA : 0, sB = nB > 0 ? p.strideB : 0;
+    const int mA = nA > 0 ? nA - 1 : 0, mB = nB > 0 ? nB - 1 : 0;
+#pragma unroll
+    for (int z = 0; z < 4; ++z) sv[z] = ld4(bA, (size_t)min(z, mA) * sA + oA);
+#pragma unroll
+    for (int z = 0; z < 4; ++z) sv[4 + z] = ld4(bB, (size_t)min(z, mB) * sB + oB);
+  }
   float g[4][4];
   const T* G = (const T*)p.gates + (size_t)m * 4 * H + u;
 #pragma unroll
@@ -635,19 +652,26 @@ __global__ __launch_bounds__(NT) void lstm_bwd_vec4_kernel(const UicLstmBwdParam
       g[q][0] = w.x; g[q][1] = w.y; g[q][2] = w.z; g[q][3] = w.w;
     }
   }
-  const float dh0[4] = {d0.x, d0.y, d0.z, d0.w}, dh1[4] = {d1.x, d1.y, d1.z, d1.w}, dh2[4] = {d2.x, d2.y, d2.z, d2.w}, dsl[4] = {ds.x, ds.y, ds.z, ds.w};
+  float4 ds = make_float4(0.f, 0.f, 0.f, 0.f);       // split-K partial slabs of two more sources, summed in a fixed order
+#pragma unroll
+  for (int z = 0; z < 8; ++z) {
+    const bool use = z < 4 ? z < nA : z - 4 < nB;
+    ds.x += use ? sv[z].x : 0.f; ds.y += use ? sv[z].y : 0.f; ds.z += use ? sv[z].z : 0.f; ds.w += use ? sv[z].w : 0.f;
+  }
+  const float4 cp = hascp ? cpr : make_float4(0.f, 0.f, 0.f, 0.f);
+  const float dh0[4] = {d0r.x, d0r.y, d0r.z, d0r.w}, dh1[4] = {d1r.x, d1r.y, d1r.z, d1r.w}, dh2[4] = {d2r.x, d2r.y, d2r.z, d2r.w}, dsl[4] = {ds.x, ds.y, ds.z, ds.w};
   const float cc[4] = {c4.x, c4.y, c4.z, c4.w}, cpv[4] = {cp.x, cp.y, cp.z, cp.w}, dcv[4] = {dc4.x, dc4.y, dc4.z, dc4.w};
   float o[4][4], dcn[4];
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
     float dh = 0.f;
-    if (p.dh0) {
+    if (has0) {
       float v = dh0[k];
       if (p.drop_p > 0.f) v *= uic_drop_scale(p.seed, p.site, (unsigned)(idx + k), p.drop_p, inv_keep);
       dh += v;
     }
-    if (p.dh1) dh += dh1[k];
-    if (p.dh2) dh += dh2[k];
+    if (has1) dh += dh1[k];
+    if (has2) dh += dh2[k];
     dh += dsl[k];
     const float gi = g[0][k], gf = g[1][k], gg = g[2][k], go = g[3][k];
     const float tc = uic_tanh<T>(cc[k]);
@@ -1888,8 +1912,14 @@ int uic_lstm_bwd_launch(const UicLstmBwdParams& p, hipStream_t s) {
     const int h4 = p.H / 4;
     const int bt = h4 >= NT ? NT : ((h4 + 63) / 64) * 64;
     const dim3 g4((unsigned)((h4 + bt - 1) / bt), (unsigned)p.M);
-    DISPATCH_T(p.dtype, hipLaunchKernelGGL(lstm_bwd_vec4_kernel<bf16_t>, g4, dim3(bt), 0, s, p),
-               hipLaunchKernelGGL(lstm_bwd_vec4_kernel<float>, g4, dim3(bt), 0, s, p));
+    const bool simple = p.dh0 && !p.dh1 && !p.dh2 && p.c_prev;
+    if (simple) {
+      DISPATCH_T(p.dtype, hipLaunchKernelGGL((lstm_bwd_vec4_kernel<bf16_t, true>), g4, dim3(bt), 0, s, p),
+                 hipLaunchKernelGGL((lstm_bwd_vec4_kernel<float, true>), g4, dim3(bt), 0, s, p));
+    } else {
+      DISPATCH_T(p.dtype, hipLaunchKernelGGL((lstm_bwd_vec4_kernel<bf16_t, false>), g4, dim3(bt), 0, s, p),
+                 hipLaunchKernelGGL((lstm_bwd_vec4_kernel<float, false>), g4, dim3(bt), 0, s, p));
+    }
     UIC_LAUNCH_CHECK("lstm_bwd_vec4");
     return UIC_OK;
   }
