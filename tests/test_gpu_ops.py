@@ -437,6 +437,40 @@ def test_adam_step_matches_oracle():
     assert (pd.cpu() - P["w"]).abs().max().item() < 1e-6
 
 
+@pytest.mark.parametrize("dtype", ["bf16", "f32"])
+@pytest.mark.parametrize("M,N,K,S", [(640, 1536, 2048, 4), (640, 1024, 2048, 4), (640, 512, 2048, 8), (600, 1000, 1024, 2), (128, 128, 512, 1)])
+def test_linear_partials_slices_add_up_to_the_product_and_repeat_bit_for_bit(dtype, M, N, K, S):
+    """uic_linear_partials (the BPTT loop's split-K d x GEMMs, csrc/gemm.hip: LDS-DMA staging ordered by hand-placed vmcnt waits
+    and raw barriers): the slices add up to the product, and 30 launches beside an HBM-bound neighbour on another stream all give
+    the first launch's bits (a wait that is one round short shows up as a result that depends on timing).  Round 6 also tried a
+    ring of four staging buffers for these launches: same bits, same 13.4 us -- their time is MFMA issue (3.9 us per wave),
+    the slab stores and launch ramps, not exposed load latency -- and it was removed again."""
+    L = _lib()
+    lib = L.load()
+    dt = L.dtype_id(dtype)
+    td = torch.bfloat16 if dtype == "bf16" else torch.float32
+    g = torch.Generator(device="cuda").manual_seed(M + N + K)
+    A = (torch.randn(M, K, device="cuda", generator=g) * 0.5).to(td)
+    B = (torch.randn(N, K, device="cuda", generator=g) * 0.5).to(td)
+    ref = A.double() @ B.double().t()
+
+    def run():
+        slab = torch.full((S, M, N), float("nan"), device="cuda")
+        L.check(lib.uic_linear_partials(dt, M, N, K, L.ptr(A), K, L.ptr(B), K, L.ptr(slab), S, L.stream()))
+        return slab
+    first = run()
+    torch.cuda.synchronize()
+    err = (first.double().sum(0) - ref).abs().max().item()
+    assert err <= 2e-3 * max(1.0, ref.abs().max().item()), err
+    side = torch.cuda.Stream()
+    big = torch.empty(64 << 20, device="cuda")
+    for _ in range(30):
+        with torch.cuda.stream(side):
+            big.add_(1.0)
+        assert torch.equal(run(), first)
+    torch.cuda.synchronize()
+
+
 @pytest.mark.parametrize("w16", [False, True], ids=["f32", "bf16-copy"])
 @pytest.mark.parametrize("clip,guard", [(False, None), (True, None), (False, 0), (False, 7)])
 def test_adam_step_ranges_is_adam_step_on_the_ranges_and_nowhere_else(w16, clip, guard):

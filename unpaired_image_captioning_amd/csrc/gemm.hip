@@ -142,26 +142,52 @@ __global__ __launch_bounds__(64 * WM * WN * KS) void uic_gemm_kernel(const UicGe
   // (these launches are a few microseconds of dependent latencies each; the NMT step is 256 of them)
   constexpr int RPG0 = 16 / KS;
   float pf_pre[LSTM ? TM : 1][LSTM ? RPG0 : 1][LSTM ? TN : 1], pf_c[LSTM ? TM : 1][LSTM ? RPG0 : 1], pf_b[LSTM ? TN : 1];
+  float pf_pre2[LSTM ? TM : 1][LSTM ? RPG0 : 1][LSTM ? TN : 1], pf_b2[LSTM ? TN : 1];
   if constexpr (LSTM) {
+    // Round 6: none of these requests sits behind a condition any more.  An optional operand that is absent is read from a valid
+    // stand-in word (c_out[0]) and dropped by a select; lanes / rows beyond the problem read a clamped index.  hipcc waits for a
+    // load under a branch at the join of that branch: the two biases were eight serial memory round trips at the top of every
+    // launch, and `pre2`, read in the epilogue under `if (p.pre2)`, four more per output row -- in launches that are a few
+    // microseconds of dependent latencies in the first place.
     const int u = n0 + wn * 32 + r32;
+    const int uc = u < p.H ? u : p.H - 1;
+    const float* b1 = p.bias ? p.bias : p.c_out;
+    const float* b2 = p.bias2 ? p.bias2 : p.c_out;
+    float l1[TN], l2[TN];
 #pragma unroll
     for (int g = 0; g < TN; ++g) {
-      pf_b[g] = 0.f;
-      if (u < p.H) {
-        if (p.bias) pf_b[g] += p.bias[g * p.H + u];
-        if (p.bias2) pf_b[g] += p.bias2[g * p.H + u];
-      }
+      l1[g] = b1[p.bias ? g * p.H + uc : 0];
+      l2[g] = b2[p.bias2 ? g * p.H + uc : 0];
     }
+    const float* cpp = p.c_prev ? p.c_prev : p.c_out;
+    const float* p1 = p.pre1 ? p.pre1 : p.c_out;
+    const float* p2 = p.pre2 ? p.pre2 : p.c_out;
+    float lc[TM][RPG0], lp1[TM][RPG0][TN], lp2[TM][RPG0][TN];
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
       for (int q = 0; q < RPG0; ++q) {
         const int reg = ks_id * RPG0 + q;
         const int row = m0 + (wm * TM + i) * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * half;
-        const bool ok = row < p.M && u < p.H;
-        pf_c[i][q] = (ok && p.c_prev) ? p.c_prev[(size_t)row * p.H + u] : 0.f;
+        const int rc = row < p.M ? row : p.M - 1;
+        lc[i][q] = cpp[p.c_prev ? (size_t)rc * p.H + uc : 0];
 #pragma unroll
-        for (int g = 0; g < TN; ++g) pf_pre[i][q][g] = (ok && p.pre1) ? p.pre1[(size_t)row * p.ldpre1 + g * p.H + u] : 0.f;
+        for (int g = 0; g < TN; ++g) {
+          lp1[i][q][g] = p1[p.pre1 ? (size_t)rc * p.ldpre1 + g * p.H + uc : 0];
+          lp2[i][q][g] = p2[p.pre2 ? (size_t)rc * p.ldpre2 + g * p.H + uc : 0];
+        }
+      }
+    // (the raw values stay in registers through the K rounds; the selects that drop the stand-ins are applied in the epilogue --
+    // here they would be the first use of the loads and bring their wait to the top of the launch)
+#pragma unroll
+    for (int g = 0; g < TN; ++g) { pf_b[g] = l1[g]; pf_b2[g] = l2[g]; }
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int q = 0; q < RPG0; ++q) {
+        pf_c[i][q] = lc[i][q];
+#pragma unroll
+        for (int g = 0; g < TN; ++g) { pf_pre[i][q][g] = lp1[i][q][g]; pf_pre2[i][q][g] = lp2[i][q][g]; }
       }
   }
   // likewise the values an accumulating skinny GEMM adds to (f32 C += A B^T: the per-step `h2att` term of the BPTT loop)
@@ -329,12 +355,12 @@ __global__ __launch_bounds__(64 * WM * WN * KS) void uic_gemm_kernel(const UicGe
             float g4[TN];
 #pragma unroll
             for (int g = 0; g < TN; ++g) {
-              float v = acc[i][g][reg] + pf_b[g];
+              float v = acc[i][g][reg] + ((p.bias ? pf_b[g] : 0.f) + (p.bias2 ? pf_b2[g] : 0.f));
               if (p.pre1) v += pf_pre[i][reg - R0][g];             // (requested before the K rounds)
-              if (p.pre2) v += p.pre2[(size_t)row * p.ldpre2 + g * H + u];
+              if (p.pre2) v += pf_pre2[i][reg - R0][g];
               g4[g] = v;
             }
-            const float cp = pf_c[i][reg - R0];
+            const float cp = p.c_prev ? pf_c[i][reg - R0] : 0.f;
             if constexpr (TN == 4) {
               // nn.LSTMCell: chunks (i, f, g, o)
               const float gi = uic_sigmoid_t<T>(g4[0]);
