@@ -401,6 +401,48 @@ def test_attention_bwd_accum_multi_step(dt, large):
 
 
 @pytest.mark.parametrize("dt", [0, 1])
+@pytest.mark.parametrize("shape", [(3, 40, 128, 64, 5), (2, 36, 512, 512, 17), (4, 37, 72, 40, 6), (1, 1, 8, 8, 1), (2, 75, 256, 128, 7)])
+def test_attention_bwd_accum_shapes(dt, shape):
+    """The accumulation passes at shapes that exercise every loop bound of the round-6 kernels: more than 36 regions (a second
+    block of nine accumulators per wave), odd and even step counts (the shared-reciprocal pairs + the odd step), column counts that
+    are not a multiple of the 64-lane pass, the reference's own 36 x 512 x 512 x 17."""
+    L = _lib()
+    lib = L.load()
+    N, R, A, H, T = shape
+    g = torch.Generator().manual_seed(N * 1000 + R)
+    p_att = torch.randn(N, R, A, generator=g) * 1.5
+    w = torch.randn(A, generator=g) / A ** 0.5
+    att_h = torch.randn(T, N, A, generator=g) * 1.5
+    alpha = torch.softmax(torch.randn(T, N, R, generator=g), 2)
+    de = torch.randn(T, N, R, generator=g) * 0.1
+    dctx = torch.randn(T, N, H, generator=g)
+    pr = rounded(p_att, dt)
+    d_att_ref = torch.einsum("tnr,tnh->nrh", alpha, dctx)
+    th = torch.tanh(pr.unsqueeze(0).double() + att_h.unsqueeze(2).double())    # [T,N,R,A]
+    d_p_ref = ((de.unsqueeze(3).double() * (1 - th * th)).sum(0) * w.double()).float()
+    d_w_ref = (de.unsqueeze(3).double() * th).sum((0, 1, 2)).float()
+    d_att = torch.full((N, R, H), 7.0, device="cuda")
+    d_p = torch.full((N, R, A), 7.0, device="cuda", dtype=TD[dt])
+    part = torch.full((N, A + 1), 7.0, device="cuda")
+    L.check(lib.uic_attention_bwd_accum(dt, N, R, A, H, T, L.ptr(dev(att_h)), L.ptr(dev(alpha)), L.ptr(dev(de)), L.ptr(dev(dctx)),
+                                        L.ptr(dev(p_att, dt)), L.ptr(dev(w)), L.ptr(d_att), L.ptr(d_p), L.ptr(part), L.stream()))
+    torch.cuda.synchronize()
+    tol = 1e-4 if dt == 0 else 1e-2
+    assert rel_err(d_att, d_att_ref) < 1e-5
+    assert rel_err(d_p, d_p_ref) < tol
+    assert rel_err(part[:, :A].sum(0), d_w_ref) < (1e-4 if dt == 0 else 2e-3)
+    assert rel_err(part[:, A].sum().view(1), de.sum().view(1)) < 1e-3
+    # a second launch reproduces the first bit for bit
+    d_p2 = torch.empty_like(d_p)
+    part2 = torch.empty_like(part)
+    d_att2 = torch.empty_like(d_att)
+    L.check(lib.uic_attention_bwd_accum(dt, N, R, A, H, T, L.ptr(dev(att_h)), L.ptr(dev(alpha)), L.ptr(dev(de)), L.ptr(dev(dctx)),
+                                        L.ptr(dev(p_att, dt)), L.ptr(dev(w)), L.ptr(d_att2), L.ptr(d_p2), L.ptr(part2), L.stream()))
+    torch.cuda.synchronize()
+    assert torch.equal(d_p, d_p2) and torch.equal(part, part2) and torch.equal(d_att, d_att2)
+
+
+@pytest.mark.parametrize("dt", [0, 1])
 @pytest.mark.parametrize("shape", [(42, 78, 80), (130, 64, 64), (7, 5, 8)])
 def test_transpose_and_casts(dt, shape):
     L = _lib()

@@ -62,8 +62,18 @@ timeout 300 python3 $R/tools/tn_bench.py > $O/tn_bench.txt 2>&1
 timeout 200 python3 $R/tools/queue_probe.py 0 > $O/queue_probe.txt 2>&1
 echo "--- GPU_MAX_HW_QUEUES=2" >> $O/queue_probe.txt
 GPU_MAX_HW_QUEUES=2 timeout 200 python3 $R/tools/queue_probe.py 0 >> $O/queue_probe.txt 2>&1
-timeout 300 python3 $R/tools/comm_proxy.py --steps 20 > $O/comm_proxy.txt 2>&1
-tail -4 $O/comm_proxy.txt
+# round 6: the sharded exchange (reduce-scatter / Adam on the shard / all-gather) and round 5's all-reduce beside the step, stand-ins
+# for RCCL on one GPU; with the two hardware queues a data-parallel Trainer insists on, and without
+GPU_MAX_HW_QUEUES=2 timeout 300 python3 $R/tools/comm_proxy.py --steps 20 > $O/comm_proxy.txt 2>&1
+echo "--- without GPU_MAX_HW_QUEUES" >> $O/comm_proxy.txt
+timeout 300 python3 $R/tools/comm_proxy.py --steps 20 >> $O/comm_proxy.txt 2>&1
+grep -E "^no exchange|^SHARDED|^round 5|^---" $O/comm_proxy.txt
+# round 6: the file-backed loader (stored and deflated members) against resident batches, and training from files
+timeout 300 python3 $R/tools/loader_bench.py > $O/loader_bench.txt 2>&1
+echo "--- --compressed" >> $O/loader_bench.txt
+timeout 300 python3 $R/tools/loader_bench.py --compressed >> $O/loader_bench.txt 2>&1
+tail -12 $O/loader_bench.txt
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 $R/tools/micro/mfma_agpr.hip -o /tmp/mfma_agpr 2>/dev/null && timeout 100 /tmp/mfma_agpr > $O/mfma_agpr.txt 2>&1
 timeout 200 python3 $R/tools/ab_knobs.py 0 0x200 0x600 > $O/ab_knobs.txt 2>&1
 cat $O/ab_knobs.txt
 # round 5 (second half): per-phase stamps of the pivot decoder's persistent launches; what a dependent launch costs

@@ -594,6 +594,228 @@ __global__ __launch_bounds__(512) void attn_bwd_accum_kernel(const UicAttnAccumP
   }
 }
 
+// ---- round 6: the two accumulation passes rewritten for instruction count (they head the step's tail, where three streams
+// compete for CU time: every VALU / LDS instruction saved here is step time).
+//
+// PART 1, any dtype (its operands are f32): a lane keeps the d ctx values of its four columns for SIX decode steps in registers
+// and nine region accumulators, so the inner loop is FMAs fed by one wave-uniform LDS word each -- the first form re-read every
+// d ctx value from LDS for every region (R x T 16-byte LDS reads per lane).  8 waves: two column halves x four region groups.
+constexpr int P1_TCH = 6, P1_RU = 9;
+__global__ __launch_bounds__(512) void attn_bwd_accum_p1_kernel(const UicAttnAccumParams p) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  const int H = p.H, R = p.R, TS = p.T, N = p.N;
+  const int TSp = (TS + P1_TCH - 1) / P1_TCH * P1_TCH;
+  const int n = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  float* s_al = sm;                     // [R][TSp]: a region's weights over the steps, zero behind step TS
+  for (int i = tid; i < R * TSp; i += 512) {
+    const int r = i / TSp, t = i - r * TSp;
+    s_al[i] = t < TS ? p.alpha_all[((size_t)t * N + n) * R + r] : 0.f;
+  }
+  __syncthreads();
+  const int nc4 = H >> 2;
+  const int rg = wave >> 1;
+  float* dat = p.d_att + (size_t)n * R * H;
+  const float* dc = p.dctx_all + (size_t)n * p.lddctx;
+  for (int c = (wave & 1) * 64 + lane; c < nc4; c += 128) {
+    for (int rb = 0; rb < R; rb += 4 * P1_RU) {
+      float4 acc[P1_RU];
+#pragma unroll
+      for (int k = 0; k < P1_RU; ++k) acc[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+      for (int t0 = 0; t0 < TS; t0 += P1_TCH) {
+        float4 d[P1_TCH];
+#pragma unroll
+        for (int u = 0; u < P1_TCH; ++u) {       // (steps behind TS: a valid address, weight zero)
+          const int t = t0 + u < TS ? t0 + u : TS - 1;
+          d[u] = *(const float4*)(dc + (size_t)t * p.dctx_step_stride + c * 4);
+        }
+#pragma unroll
+        for (int k = 0; k < P1_RU; ++k) {
+          int r = rb + rg + 4 * k;
+          r = r < R ? r : R - 1;
+          const float* al = s_al + r * TSp + t0;
+#pragma unroll
+          for (int u = 0; u < P1_TCH; ++u) {
+            const float a = al[u];
+            acc[k].x = fmaf(a, d[u].x, acc[k].x); acc[k].y = fmaf(a, d[u].y, acc[k].y);
+            acc[k].z = fmaf(a, d[u].z, acc[k].z); acc[k].w = fmaf(a, d[u].w, acc[k].w);
+          }
+        }
+      }
+#pragma unroll
+      for (int k = 0; k < P1_RU; ++k) {
+        const int r = rb + rg + 4 * k;
+        if (r < R) *(float4*)(dat + (size_t)r * H + c * 4) = acc[k];
+      }
+    }
+  }
+}
+
+// PART 2, bf16: one workgroup per (caption row, HALF of A) -- 2 N workgroups of four waves spread evenly over the 256 CUs where N
+// of them left every other CU a third workgroup -- and per (region, column, step) three packed FMA-class instructions and HALF a
+// reciprocal:
+//   rc_t = 1 / (1 + e^{2p} e^{2h_t});   1 - tanh^2 = 4 (rc - rc^2);   tanh = 1 - 2 rc
+//   d p_att = 4 w (S1 - S2),  d w_alpha = sum de - 2 sum S1   with S1 = sum_t de_t rc_t, S2 = sum_t de_t rc_t^2
+//   two steps share one reciprocal: 1 / (x0 x1), rc_0 = x1 / (x0 x1), rc_1 = x0 / (x0 x1)
+// Products stay finite for |2p|, |2h| <= P2_LIM (x <= 1 + e^{43}); larger values -- never seen with initial or trained weights --
+// take the direct tanh form for the whole workgroup.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+constexpr float P2_LIM = 21.5f;
+__global__ __launch_bounds__(256) void attn_bwd_accum_p2_bf16_kernel(const UicAttnAccumParams p) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  constexpr float LOG2E2 = 2.8853900817779268f;
+  const int A = p.A, R = p.R, TS = p.T, N = p.N;
+  const int Ah = A >> 1, nc = Ah >> 2;
+  const int Rp = (R + 3) & ~3;
+  const int n = blockIdx.x, a0 = blockIdx.y * Ah;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  float* s_eh = sm;                     // [TS][Ah]  e^{2 h_t[a]} (the direct form: h_t[a])
+  float* s_de = s_eh + TS * Ah;         // [TS][Rp]
+  float* s_red = s_de + TS * Rp;        // [4][Ah]
+  float* s_tot = s_red + 4 * Ah;        // [4]
+  // ---- staging: every load of a thread requested before the first use
+  int bad = 0;
+  {
+    const int total = TS * nc;
+    for (int i0 = tid; i0 < total; i0 += 256 * 8) {
+      float4 v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        int i = i0 + u * 256;
+        i = i < total ? i : total - 1;
+        const int t = i / nc, c = i - t * nc;
+        v[u] = *(const float4*)(p.att_h_all + ((size_t)t * N + n) * A + a0 + c * 4);
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int i = i0 + u * 256;
+        if (i < total) {
+          bad |= !(fabsf(v[u].x) * 2.f <= P2_LIM) | !(fabsf(v[u].y) * 2.f <= P2_LIM) | !(fabsf(v[u].z) * 2.f <= P2_LIM) | !(fabsf(v[u].w) * 2.f <= P2_LIM);
+          *(float4*)(s_eh + (size_t)i * 4) = v[u];          // (t * Ah + c * 4 == i * 4)
+        }
+      }
+    }
+    const int nde = TS * R;
+    float dsum = 0.f;
+    for (int i0 = tid; i0 < nde; i0 += 256 * 4) {
+      float v[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        int i = i0 + u * 256;
+        i = i < nde ? i : nde - 1;
+        const int t = i / R, r = i - t * R;
+        v[u] = p.de_all[((size_t)t * N + n) * R + r];
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int i = i0 + u * 256;
+        if (i < nde) { const int t = i / R, r = i - t * R; s_de[t * Rp + r] = v[u]; dsum += v[u]; }
+      }
+    }
+    dsum = uic_wave_sum(dsum);
+    if (lane == 0) s_tot[wave] = dsum;
+  }
+  const bf16_t* pa = (const bf16_t*)p.p_att + (size_t)n * R * A + a0;
+  bf16_t* dpa = (bf16_t*)p.d_p_att + (size_t)n * R * A + a0;
+  const bool direct = __syncthreads_or(bad) != 0;
+  if (!direct) {         // e^{2h} in place (each thread the entries it staged itself would do, but the barrier is behind us anyway)
+    for (int i = tid; i < TS * Ah; i += 256) s_eh[i] = __builtin_amdgcn_exp2f(s_eh[i] * LOG2E2);
+    __syncthreads();
+  }
+  for (int c = lane; c < nc; c += 64) {
+    const float4 w4 = *(const float4*)(p.w_alpha + a0 + c * 4);
+    f32x2 dw0 = {0.f, 0.f}, dw1 = {0.f, 0.f};            // sum over this wave's regions of S1 (direct form: of de tanh)
+    {
+      // (the next region's chunk is requested before this region's arithmetic -- ~1.5 us of it: the latency is covered)
+      uint2 vnext = *(const uint2*)(pa + (size_t)(wave < R ? wave : R - 1) * A + c * 4);
+#pragma clang loop unroll(disable)
+      for (int r = wave; r < R; r += 4) {
+        const uint2 pvk = vnext;
+        vnext = *(const uint2*)(pa + (size_t)(r + 4 < R ? r + 4 : R - 1) * A + c * 4);
+        const float f0 = __uint_as_float(pvk.x << 16), f1 = __uint_as_float(pvk.x & 0xffff0000u);
+        const float f2 = __uint_as_float(pvk.y << 16), f3 = __uint_as_float(pvk.y & 0xffff0000u);
+        float o[4];
+        const bool big = !(fabsf(f0) * 2.f <= P2_LIM) | !(fabsf(f1) * 2.f <= P2_LIM) | !(fabsf(f2) * 2.f <= P2_LIM) | !(fabsf(f3) * 2.f <= P2_LIM);
+        if (!direct && !__any(big)) {
+          const f32x2 ep0 = {__builtin_amdgcn_exp2f(f0 * LOG2E2), __builtin_amdgcn_exp2f(f1 * LOG2E2)};
+          const f32x2 ep1 = {__builtin_amdgcn_exp2f(f2 * LOG2E2), __builtin_amdgcn_exp2f(f3 * LOG2E2)};
+          const f32x2 one = {1.f, 1.f};
+          f32x2 s1a = {0.f, 0.f}, s1b = {0.f, 0.f}, s2a = {0.f, 0.f}, s2b = {0.f, 0.f};
+          const float* eh = s_eh + c * 4;
+          const float* de = s_de + r;
+          int t = 0;
+#pragma unroll 2
+          for (; t + 1 < TS; t += 2) {
+            const float4 e0 = *(const float4*)(eh + t * Ah), e1 = *(const float4*)(eh + (t + 1) * Ah);
+            const float d0 = de[t * Rp], d1 = de[(t + 1) * Rp];
+            const f32x2 d0v = {d0, d0}, d1v = {d1, d1};
+            {
+              const f32x2 x0 = __builtin_elementwise_fma(ep0, (f32x2){e0.x, e0.y}, one), x1 = __builtin_elementwise_fma(ep0, (f32x2){e1.x, e1.y}, one);
+              const f32x2 pr = x0 * x1;
+              const f32x2 inv = {__builtin_amdgcn_rcpf(pr.x), __builtin_amdgcn_rcpf(pr.y)};
+              const f32x2 rc0 = inv * x1, rc1 = inv * x0;
+              s1a = __builtin_elementwise_fma(d0v, rc0, s1a); s2a = __builtin_elementwise_fma(d0v * rc0, rc0, s2a);
+              s1a = __builtin_elementwise_fma(d1v, rc1, s1a); s2a = __builtin_elementwise_fma(d1v * rc1, rc1, s2a);
+            }
+            {
+              const f32x2 x0 = __builtin_elementwise_fma(ep1, (f32x2){e0.z, e0.w}, one), x1 = __builtin_elementwise_fma(ep1, (f32x2){e1.z, e1.w}, one);
+              const f32x2 pr = x0 * x1;
+              const f32x2 inv = {__builtin_amdgcn_rcpf(pr.x), __builtin_amdgcn_rcpf(pr.y)};
+              const f32x2 rc0 = inv * x1, rc1 = inv * x0;
+              s1b = __builtin_elementwise_fma(d0v, rc0, s1b); s2b = __builtin_elementwise_fma(d0v * rc0, rc0, s2b);
+              s1b = __builtin_elementwise_fma(d1v, rc1, s1b); s2b = __builtin_elementwise_fma(d1v * rc1, rc1, s2b);
+            }
+          }
+          if (t < TS) {
+            const float4 e0 = *(const float4*)(eh + t * Ah);
+            const float d0 = de[t * Rp];
+            const f32x2 d0v = {d0, d0};
+            const f32x2 x0 = __builtin_elementwise_fma(ep0, (f32x2){e0.x, e0.y}, one), x1 = __builtin_elementwise_fma(ep1, (f32x2){e0.z, e0.w}, one);
+            const f32x2 rc0 = {__builtin_amdgcn_rcpf(x0.x), __builtin_amdgcn_rcpf(x0.y)}, rc1 = {__builtin_amdgcn_rcpf(x1.x), __builtin_amdgcn_rcpf(x1.y)};
+            s1a = __builtin_elementwise_fma(d0v, rc0, s1a); s2a = __builtin_elementwise_fma(d0v * rc0, rc0, s2a);
+            s1b = __builtin_elementwise_fma(d0v, rc1, s1b); s2b = __builtin_elementwise_fma(d0v * rc1, rc1, s2b);
+          }
+          dw0 += s1a; dw1 += s1b;
+          o[0] = 4.f * (s1a.x - s2a.x) * w4.x; o[1] = 4.f * (s1a.y - s2a.y) * w4.y;
+          o[2] = 4.f * (s1b.x - s2b.x) * w4.z; o[3] = 4.f * (s1b.y - s2b.y) * w4.w;
+        } else {
+          // direct form (s_eh holds h when the whole workgroup is direct, e^{2h} otherwise: h is re-read from memory then)
+          const float f[4] = {f0, f1, f2, f3};
+          const float w[4] = {w4.x, w4.y, w4.z, w4.w};
+          float accd[4] = {0.f, 0.f, 0.f, 0.f}, dwd[4] = {0.f, 0.f, 0.f, 0.f};
+          for (int t = 0; t < TS; ++t) {
+            const float d0 = s_de[t * Rp + r];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              const float h = direct ? s_eh[t * Ah + c * 4 + j] : p.att_h_all[((size_t)t * N + n) * A + a0 + c * 4 + j];
+              const float th = uic_tanh<bf16_t>(f[j] + h);
+              accd[j] += d0 * (1.f - th * th);
+              dwd[j] += d0 * th;
+            }
+          }
+          // (the epilogue below computes sum de - 2 sum S1: hand it S1-equivalents, (sum_t de - sum_t de tanh) / 2)
+          float dsr = 0.f;
+          for (int t = 0; t < TS; ++t) dsr += s_de[t * Rp + r];
+          dw0.x += 0.5f * (dsr - dwd[0]); dw0.y += 0.5f * (dsr - dwd[1]); dw1.x += 0.5f * (dsr - dwd[2]); dw1.y += 0.5f * (dsr - dwd[3]);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) o[j] = accd[j] * w[j];
+        }
+        uint2 st;
+        st.x = uic_pack_bf16x2(o[0], o[1]); st.y = uic_pack_bf16x2(o[2], o[3]);
+        *(uint2*)(dpa + (size_t)r * A + c * 4) = st;
+      }
+    }
+    *(float4*)(s_red + wave * Ah + c * 4) = make_float4(dw0.x, dw0.y, dw1.x, dw1.y);
+  }
+  __syncthreads();
+  const float tot = (s_tot[0] + s_tot[1]) + (s_tot[2] + s_tot[3]);
+  float* part = p.d_walpha_part + (size_t)n * (A + 1);
+  for (int a = tid; a < Ah; a += 256)
+    part[a0 + a] = tot - 2.f * ((s_red[a] + s_red[Ah + a]) + (s_red[2 * Ah + a] + s_red[3 * Ah + a]));
+  if (tid == 0 && blockIdx.y == 0) part[A] = tot;
+}
+
 int check_common(int dtype, int N, int R, int A, int H) {
   const int vec = dtype == UIC_BF16 ? 8 : 4;
   UIC_REQUIRE(dtype == UIC_F32 || dtype == UIC_BF16, "attention: bad dtype %d", dtype);
@@ -668,6 +890,22 @@ int uic_attention_bwd_accum_launch(const UicAttnAccumParams& p, hipStream_t s) {
   const int Rp = (p.R + 3) & ~3;
   // measured at the benchmark shapes: PART 1 (f32 FMAs over LDS-staged rows) 42 -> 32 us with 8 waves per workgroup, PART 2
   // (one reciprocal per element) 110 us with 4 waves, 118 with 8
+  // round 6 forms (above): PART 2 for bf16 with an even split of A into 4-column chunks, PART 1 wherever a lane's 16-byte loads
+  // and stores are aligned
+  const bool p1_new = p.H % 4 == 0 && p.lddctx % 4 == 0 && p.dctx_step_stride % 4 == 0 && ((uintptr_t)p.dctx_all & 15) == 0 && ((uintptr_t)p.d_att & 15) == 0;
+  const bool p2_new = p.dtype == UIC_BF16 && p.A % 8 == 0 && ((uintptr_t)p.att_h_all & 15) == 0 && ((uintptr_t)p.w_alpha & 15) == 0 &&
+                      ((uintptr_t)p.p_att & 7) == 0 && ((uintptr_t)p.d_p_att & 7) == 0;
+  const size_t lds1n = sizeof(float) * (size_t)p.R * ((p.T + P1_TCH - 1) / P1_TCH * P1_TCH);
+  const size_t lds2n = sizeof(float) * ((size_t)p.T * (p.A / 2 + Rp) + 4 * (size_t)(p.A / 2) + 4);
+  UIC_REQUIRE(lds1n <= 160 * 1024 && lds2n <= 160 * 1024, "attention_bwd_accum: needs %zu B of LDS (T=%d)", lds1n > lds2n ? lds1n : lds2n, p.T);
+  if (p2_new) {
+    if (lds2n > 64 * 1024) UIC_TRY(uic_check_hip(hipFuncSetAttribute((const void*)attn_bwd_accum_p2_bf16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2n), "hipFuncSetAttribute"));
+    hipLaunchKernelGGL(attn_bwd_accum_p2_bf16_kernel, dim3(p.N, 2), dim3(256), lds2n, s, p);
+  }
+  if (p1_new) {
+    if (lds1n > 64 * 1024) UIC_TRY(uic_check_hip(hipFuncSetAttribute((const void*)attn_bwd_accum_p1_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1n), "hipFuncSetAttribute"));
+    hipLaunchKernelGGL(attn_bwd_accum_p1_kernel, dim3(p.N), dim3(512), lds1n, s, p);
+  }
   const int nthreads1 = 512, nthreads2 = 256;
   const size_t lds1 = sizeof(float) * ((size_t)p.T * (p.H + Rp));
   const size_t lds2 = sizeof(float) * ((size_t)p.T * (p.A + Rp) + p.A + (nthreads2 / 64) * (size_t)p.A);
@@ -676,8 +914,8 @@ int uic_attention_bwd_accum_launch(const UicAttnAccumParams& p, hipStream_t s) {
   do {                                                                                                                            \
     if (lds1 > 64 * 1024) UIC_TRY(uic_check_hip(hipFuncSetAttribute((const void*)attn_bwd_accum_kernel<TT, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1), "hipFuncSetAttribute")); \
     if (lds2 > 64 * 1024) UIC_TRY(uic_check_hip(hipFuncSetAttribute((const void*)attn_bwd_accum_kernel<TT, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2), "hipFuncSetAttribute")); \
-    hipLaunchKernelGGL((attn_bwd_accum_kernel<TT, 2>), dim3(p.N), dim3(nthreads2), lds2, s, p);                                     \
-    hipLaunchKernelGGL((attn_bwd_accum_kernel<TT, 1>), dim3(p.N), dim3(nthreads1), lds1, s, p);                                     \
+    if (!p2_new) hipLaunchKernelGGL((attn_bwd_accum_kernel<TT, 2>), dim3(p.N), dim3(nthreads2), lds2, s, p);                        \
+    if (!p1_new) hipLaunchKernelGGL((attn_bwd_accum_kernel<TT, 1>), dim3(p.N), dim3(nthreads1), lds1, s, p);                        \
   } while (0)
   if (p.dtype == UIC_BF16) ACCUM_LAUNCH(bf16_t); else ACCUM_LAUNCH(float);
 #undef ACCUM_LAUNCH
