@@ -277,6 +277,38 @@ def test_persistent_recurrence_equals_the_launch_chain(dtype, n_img, S):
     assert (got1["logp"] - ref["logp"]).abs().max().item() < (2e-4 if dtype == "f32" else 1e-2)
 
 
+@pytest.mark.parametrize("n_img,S", [(1, 4), (17, 5), (128, 5)])
+def test_e_att_is_exp_of_twice_the_stored_p_att(n_img, S):
+    """The persistent training recurrence's attention reads e_att = e^{2 p_att} (tanh(p + h) = 1 - 2 / (1 + e^{2p} e^{2h}),
+    csrc/rnn_persist.hip).  It is made from the ROUNDED bf16 p_att -- by the ctx2att GEMM's epilogue at the large shapes, by an
+    element-wise pass behind the small ones -- so both forms must give bf16(2^(2 log2(e) p)) of the stored p_att: within one bf16
+    step of torch's exp (v_exp_f32 is not correctly rounded), and identical between two runs."""
+    Lb = _lib()
+    W = O.init_weights(V + 1, E, H, A, D, D, seed=11)
+    b = O.synthetic_batch(n_img, S, R, D, V, L, seed=78, ragged_regions=True)
+    batch = {k: v.cuda() for k, v in b.items()}
+    model = build_model(CFG, W, "bf16", drop=0.5)
+    model.train()
+    eng = model.engine
+    N = n_img * S
+    t_run = model._steps_to_run(batch["labels"])
+    pd = {k: v.detach() for k, v in model.param_dict().items()}
+    outs = []
+    for _ in range(2):
+        logp, ws, _ = eng.forward(pd, batch["fc_feats"], batch["att_feats"], batch["att_masks"], batch["labels"], t_run, True, 99)
+        p_att = eng.workspace_tensor(ws, "p_att", (N, R, A), torch.bfloat16).float().clone()
+        e_att = eng.workspace_tensor(ws, "e_att", (N, R, A), torch.bfloat16).float().clone()
+        torch.cuda.synchronize()
+        eng.release(ws)
+        outs.append((p_att, e_att))
+    p_att, e_att = outs[0]
+    assert torch.equal(e_att, outs[1][1]) and torch.equal(p_att, outs[1][0])
+    ref = torch.exp(2.0 * p_att.double()).float()
+    assert p_att.abs().max().item() < 20.0                      # (far inside the clamp at 2^+-60)
+    assert ((e_att - ref).abs() / ref).max().item() <= 2.0 ** -7 * 1.01
+    assert ((e_att - ref).abs() / ref).mean().item() < 2.0 ** -9
+
+
 BNAMES = lambda T, N: [("dg1", (T, N, 4 * H), torch.bfloat16), ("dg2", (T, N, 4 * H), torch.bfloat16), ("datth", (T, N, H), torch.bfloat16),
                        ("de", (T, N, R), torch.float32), ("dx2", (T, N, 3 * H), torch.float32)]
 

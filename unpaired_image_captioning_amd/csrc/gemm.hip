@@ -449,12 +449,18 @@ __global__ __launch_bounds__(256, 2) void uic_gemm_glds_kernel(const UicGemmPara
   // XCD-aware + grouped tile order: each XCD takes a contiguous run of tiles; inside it tiles advance over
   // GM = 8 row-tiles before moving to the next column tile, so one XCD's L2 holds an 8-tile A band while
   // B tiles stream through once per band.
-  int bm, bn;
+  // Split-K launches (round 6): the run is taken over the whole 3-D grid in dispatch order (x fastest, z slowest), K slice
+  // slowest in the tile order -- an XCD then works on ONE K slice (two at most) of a few column tiles: at the BPTT loop's
+  // 5 x 12 x 4 grid it reads 0.66 MB of A and 0.79 MB of B instead of all 2.6 MB of A and B tiles of every K slice, and its B
+  // tiles are the same ones every decode step.  (gz = 1: the order above, unchanged)
+  int bm, bn, bz;
   {
-    const int gx = gridDim.x, gy = gridDim.y, nblk = gx * gy;
-    const int lin = blockIdx.x + gx * blockIdx.y;
+    const int gx = gridDim.x, gy = gridDim.y, nxy = gx * gy, nblk = nxy * gridDim.z;
+    const int lin = blockIdx.x + gx * (blockIdx.y + gy * blockIdx.z);
     const int q = nblk >> 3, r = nblk & 7, xcd = lin & 7, idx = lin >> 3;
-    const int lp = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    const int lp3 = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    bz = lp3 / nxy;
+    const int lp = lp3 - bz * nxy;
     constexpr int GM = 8;
     const int width = GM * gy;
     const int first = (lp / width) * GM;
@@ -504,7 +510,7 @@ __global__ __launch_bounds__(256, 2) void uic_gemm_glds_kernel(const UicGemmPara
   int kt0 = 0, nt = sg.K / BK;
   if (p.splitk > 1) {
     const int tps = (nt + p.splitk - 1) / p.splitk;
-    kt0 = blockIdx.z * tps;
+    kt0 = bz * tps;
     nt = max(0, min(nt - kt0, tps));
   }
   // LDS byte addresses of this lane's fragment chunks (buffer 0, first 32-row sub-tile), one per K step
@@ -579,7 +585,7 @@ __global__ __launch_bounds__(256, 2) void uic_gemm_glds_kernel(const UicGemmPara
   }
 
   if (p.slab) {   // raw partial tile -> slab[z]
-    float* slab = p.slab + (size_t)blockIdx.z * p.M * p.N;
+    float* slab = p.slab + (size_t)bz * p.M * p.N;
     if (m0 + BM <= p.M && n0 + BN <= p.N && (size_t)p.M * (size_t)p.N < ((size_t)1 << 31)) {   // whole tile: no tests, 32-bit offsets
 #pragma unroll
       for (int i = 0; i < 2; ++i)
@@ -767,6 +773,17 @@ int launch_typed(const UicGemmParams& p, hipStream_t s) {
   if (p.lstm) return launch_cfg<T, 1, 4, 2, 1, 4, true>(p, s);
   const long blocks128 = (long)((p.M + 127) / 128) * ((p.N + 127) / 128);
   const bool glds_ok = p.nseg == 1 && p.seg[0].K % (128 / (int)sizeof(T)) == 0;
+  if (p.C_exp2) {        // second output e^{2 C}: the ping-pong kernel's epilogue, or one element-wise pass behind any other kernel
+    UIC_REQUIRE(sizeof(T) == 2 && !(p.flags & UIC_GEMM_OUT_F32) && p.C && p.ldc == p.N && ((size_t)p.M * p.N) % 8 == 0 && !p.slab,
+                "gemm: C_exp2 needs a contiguous bf16 output");
+    if (!(uic_gemm_pp_eligible(p) && ((p.flags & (UIC_GEMM_FORCE_256 | UIC_GEMM_FORCE_192 | UIC_GEMM_FORCE_PP128)) || p.a_f32 || p.acc_src || p.mask_act ||
+                                      (!(p.flags & UIC_GEMM_FORCE_128) && uic_gemm_pp_wins(p))))) {
+      UicGemmParams q = p;
+      q.C_exp2 = nullptr;
+      UIC_TRY(launch_typed<T>(q, s));
+      return uic_exp2x2_launch(p.C, p.C_exp2, (size_t)p.M * p.N, s);
+    }
+  }
   if (p.a_f32) {
     UIC_REQUIRE(sizeof(T) == 2 && uic_gemm_pp_eligible(p), "gemm: an f32 A operand needs the ping-pong kernel (bf16, one K segment of whole 128-element rounds, < 4 GB)");
     return uic_gemm_pp_launch(p, 0, s);

@@ -432,7 +432,15 @@ __global__ __launch_bounds__(512) void uic_gemm_pp_kernel(const UicGemmParams p)
               v[0] += __uint_as_float(q.x << 16); v[1] += __uint_as_float(q.x & 0xffff0000u);
               v[2] += __uint_as_float(q.y << 16); v[3] += __uint_as_float(q.y & 0xffff0000u);
             }
-            *o = make_uint2(uic_pack_bf16x2(v[0], v[1]), uic_pack_bf16x2(v[2], v[3]));
+            const uint2 q2 = make_uint2(uic_pack_bf16x2(v[0], v[1]), uic_pack_bf16x2(v[2], v[3]));
+            *o = q2;
+            if (p.C_exp2) {
+              const float e0 = __uint_as_float(q2.x << 16), e1 = __uint_as_float(q2.x & 0xffff0000u);
+              const float e2 = __uint_as_float(q2.y << 16), e3 = __uint_as_float(q2.y & 0xffff0000u);
+#define PP_E2(x) __builtin_amdgcn_exp2f(fminf(fmaxf((x) * 2.8853900817779268f, -UIC_E2_CLAMP), UIC_E2_CLAMP))
+              *(uint2*)((bf16_t*)p.C_exp2 + ro + col) = make_uint2(uic_pack_bf16x2(PP_E2(e0), PP_E2(e1)), uic_pack_bf16x2(PP_E2(e2), PP_E2(e3)));
+#undef PP_E2
+            }
           }
         }
       }
@@ -484,6 +492,7 @@ bool uic_gemm_pp_eligible(const UicGemmParams& p) {
   if (!p.C || p.ldc % 4 != 0) return false;
   const bool f32 = (p.flags & UIC_GEMM_OUT_F32) != 0;
   if (((uintptr_t)p.C & (f32 ? 15 : 7)) != 0) return false;
+  if (p.C_exp2 && (f32 || ((uintptr_t)p.C_exp2 & 7) != 0)) return false;
   if (p.bias && ((uintptr_t)p.bias & 15)) return false;
   if (p.bias2 && ((uintptr_t)p.bias2 & 15)) return false;
   if (p.addend && (((uintptr_t)p.addend & 15) || p.ld_add % 4 != 0)) return false;

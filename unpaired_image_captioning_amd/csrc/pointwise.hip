@@ -1138,27 +1138,36 @@ __global__ __launch_bounds__(NT) void logsoftmax_bwd_kernel(T* __restrict__ dlog
   }
 }
 
-__global__ __launch_bounds__(NT) void masked_sum_kernel(const float* __restrict__ mask, int ldmask, int col0, int N, int TS,
-                                                        float* out_sum, float* out_inv) {
-  __shared__ float s_buf[NT / 64];
-  // eight independent loads in flight per thread: a single 256-thread block chasing one load at a time took 21 us here
+constexpr int MS_NT = 1024, MS_U = 16;
+__global__ __launch_bounds__(MS_NT) void masked_sum_kernel(const float* __restrict__ mask, int ldmask, int col0, int N, int TS,
+                                                           float* out_sum, float* out_inv) {
+  __shared__ float s_buf[MS_NT / 64];
+  // One workgroup (the sum is one number and must not depend on a grid), but ONE round trip: 1024 threads x 16 unconditional
+  // loads from clamped addresses cover the reference's 640 x 17 mask in a single pass (round 6; 256 threads x 8 loads at a time
+  // took six dependent passes -- 12-19 us at the head of the step's side stream)
   float s = 0.f;
   const int total = N * TS;
-  for (int i0 = threadIdx.x; i0 < total; i0 += NT * 8) {
-    float v[8];
+  for (int i0 = threadIdx.x; i0 < total; i0 += MS_NT * MS_U) {
+    float v[MS_U];
 #pragma unroll
-    for (int u = 0; u < 8; ++u) {
-      const int i = i0 + u * NT;
+    for (int u = 0; u < MS_U; ++u) {
+      int i = i0 + u * MS_NT;
+      i = i < total ? i : total - 1;
       const int n = i / TS, t = i - n * TS;
-      v[u] = i < total ? mask[(size_t)n * ldmask + col0 + t] : 0.f;
+      v[u] = mask[(size_t)n * ldmask + col0 + t];
     }
 #pragma unroll
-    for (int u = 0; u < 8; ++u) s += v[u];
+    for (int u = 0; u < MS_U; ++u) s += i0 + u * MS_NT < total ? v[u] : 0.f;
   }
-  s = block_reduce_sum(s, s_buf);
+  s = uic_wave_sum(s);
+  if ((threadIdx.x & 63) == 0) s_buf[threadIdx.x >> 6] = s;
+  __syncthreads();
   if (threadIdx.x == 0) {
-    if (out_sum) out_sum[0] = s;
-    if (out_inv) out_inv[0] = 1.f / s;
+    float tot = 0.f;
+#pragma unroll
+    for (int k = 0; k < MS_NT / 64; ++k) tot += s_buf[k];
+    if (out_sum) out_sum[0] = tot;
+    if (out_inv) out_inv[0] = 1.f / tot;
   }
 }
 
@@ -1636,6 +1645,26 @@ int uic_copy_launch(void* dst, const void* src, size_t bytes, hipStream_t s) {
   UIC_LAUNCH_CHECK("copy_words");
   return UIC_OK;
 }
+namespace {
+__global__ __launch_bounds__(256) void exp2x2_bf16_kernel(const uint4* __restrict__ src, uint4* __restrict__ dst, size_t n8) {
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += stride) {
+    float f[8];
+    uic_unpack<bf16_t>(src[i], f);
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+      f[j] = __builtin_amdgcn_exp2f(fminf(fmaxf(f[j] * 2.8853900817779268f, -UIC_E2_CLAMP), UIC_E2_CLAMP));
+    dst[i] = uic_pack<bf16_t>(f);
+  }
+}
+}  // namespace
+int uic_exp2x2_launch(const void* src, void* dst, size_t n, hipStream_t s) {
+  UIC_REQUIRE(n % 8 == 0 && ((uintptr_t)src & 15) == 0 && ((uintptr_t)dst & 15) == 0, "exp2x2: n %% 8 and 16-byte alignment");
+  if (n == 0) return UIC_OK;
+  hipLaunchKernelGGL(exp2x2_bf16_kernel, dim3(grid_for(n / 8, 256)), dim3(256), 0, s, (const uint4*)src, (uint4*)dst, n / 8);
+  UIC_LAUNCH_CHECK("exp2x2");
+  return UIC_OK;
+}
 int uic_fill_launch(void* dst, int value_byte, size_t bytes, hipStream_t s) {
   if (bytes == 0) return UIC_OK;
   return uic_check_hip(hipMemsetAsync(dst, value_byte, bytes, s), "hipMemsetAsync");
@@ -1977,7 +2006,7 @@ int uic_logsoftmax_bwd_launch(int dtype, void* dlogits, int M, int V1, int ldv, 
 int uic_masked_sum_launch(const float* x, const float* mask, int ldmask, int col0, int N, int T, float* out_sum,
                           float* out_inv, hipStream_t s) {
   (void)x;
-  hipLaunchKernelGGL(masked_sum_kernel, dim3(1), dim3(NT), 0, s, mask, ldmask, col0, N, T, out_sum, out_inv);
+  hipLaunchKernelGGL(masked_sum_kernel, dim3(1), dim3(MS_NT), 0, s, mask, ldmask, col0, N, T, out_sum, out_inv);
   UIC_LAUNCH_CHECK("masked_sum");
   return UIC_OK;
 }

@@ -265,7 +265,7 @@ constexpr int AW_CR = 10;                             // regions per chunk of at
 __device__ __forceinline__ void attn_wave_preload(const Ctx& c, const UicRnnFwdParams& p, uint4 (&q)[AW_CR]) {
   const int r = c.rank + PW * c.wave;
   if (r >= c.nrow) return;
-  const bf16_t* P = (const bf16_t*)p.p_att + (size_t)(c.rbegin + r) * p.R * HH + c.lane * 8;
+  const bf16_t* P = (const bf16_t*)p.e_att + (size_t)(c.rbegin + r) * p.R * HH + c.lane * 8;
 #pragma unroll
   for (int u = 0; u < AW_CR; ++u) {
     const u32x4 v = *(const u32x4*)(P + (unsigned)(min(u, p.R - 1) * HH));
@@ -282,7 +282,7 @@ __device__ __forceinline__ void attn_phase_wave(const Ctx& c, const UicRnnFwdPar
   const int n = c.rbegin + r;
   constexpr int CR = AW_CR, NCH = ATT_R / CR;
   static_assert(NCH * CR == ATT_R, "chunks cover the region slots");
-  const T* P = (const T*)p.p_att + (size_t)n * R * HH + c.lane * 8;
+  const T* P = (const T*)p.e_att + (size_t)n * R * HH + c.lane * 8;      // e^{2 p_att} (round 6, below)
   const T* V = (const T*)p.att + (size_t)n * R * HH + c.lane * 8;
   float* s_e = (float*)c.smem + 64 + c.wave * (4 * ATT_R);      // [R][4] row-of-16 partial scores of this wave's row (word 0: barrier flag)
   auto load_chunk = [&](const T* base, int ch, uint4 (&q)[CR]) {
@@ -313,25 +313,46 @@ __device__ __forceinline__ void attn_phase_wave(const Ctx& c, const UicRnnFwdPar
     w[0] = w0.x; w[1] = w0.y; w[2] = w0.z; w[3] = w0.w; w[4] = w1.x; w[5] = w1.y; w[6] = w1.z; w[7] = w1.w;
   }
   const float b_alpha = p.b_alpha ? p.b_alpha[0] : 0.f;
-  float ah2[8], wm2[8], wsum = 0.f;
+  // Round 6: w tanh(p + h) = w - 2 w rc,  rc = 1 / (1 + e^{2p} e^{2h}).  e^{2p} comes from memory (uic_exp2x2_launch, once per
+  // training step), e^{2h} is eight v_exp per lane and step, and TWO regions share one reciprocal: rc_0 = x_1 / (x_0 x_1),
+  // rc_1 = x_0 / (x_0 x_1) -- per element 0.5 v_rcp and three packed / plain VALU instructions where the direct form spent
+  // v_exp + v_rcp + four (the phase is one row's arithmetic on one SIMD: 288 elements per lane).  Both factors are clamped to
+  // 2^+-60 where they are made, so x <= 2^120 + 1 is finite; a product beyond f32 gives rc = 0 for both, which is what
+  // tanh = 1 means (the partner's own x would have to be < 2^8 against 2^120 for that to matter).
+  typedef float f32x2 __attribute__((ext_vector_type(2)));
+  f32x2 eh[8], wm2[8];
+  float wsum = 0.f;
 #pragma unroll
-  for (int j = 0; j < 8; ++j) { ah2[j] = ah[j] * 2.8853900817779268f; wm2[j] = -2.f * w[j]; wsum += w[j]; }
+  for (int j = 0; j < 8; ++j) {
+    const float e = __builtin_amdgcn_exp2f(fminf(fmaxf(ah[j] * 2.8853900817779268f, -UIC_E2_CLAMP), UIC_E2_CLAMP));
+    eh[j] = (f32x2){e, e};
+    wm2[j] = (f32x2){-2.f * w[j], -2.f * w[j]};
+    wsum += w[j];
+  }
+  const f32x2 one2 = {1.f, 1.f};
+  static_assert(CR % 2 == 0 && NCH == 4, "regions are taken in pairs; four chunks (the att' schedule below)");
 #pragma unroll
   for (int ch = 0; ch < NCH; ++ch) {
 #pragma unroll
-    for (int u = 0; u < CR; ++u) {
+    for (int u = 0; u < CR; u += 2) {
       const int rr = ch * CR + u;
-      float f[8];
-      uic_unpack<T>(pa[ch & 1][u], f);
-      // w tanh(x) = w - 2 w / (e^{2x} + 1) with the constants folded in: per element one fma, v_exp, one add, v_rcp, one fma
-      float part = wsum;
+      float f0[8], f1[8];
+      uic_unpack<T>(pa[ch & 1][u], f0);
+      uic_unpack<T>(pa[ch & 1][u + 1], f1);
+      f32x2 part = {wsum, wsum};
 #pragma unroll
-      for (int j = 0; j < 8; ++j)
-        part = __builtin_fmaf(wm2[j], __builtin_amdgcn_rcpf(__builtin_amdgcn_exp2f(__builtin_fmaf(f[j], 2.8853900817779268f, ah2[j])) + 1.f), part);
-      part = uic_row16_sum(part);
-      if (c.l15 == 0 && rr < R) s_e[rr * 4 + c.lq] = part;
+      for (int j = 0; j < 8; ++j) {
+        const f32x2 x = __builtin_elementwise_fma((f32x2){f0[j], f1[j]}, eh[j], one2);
+        const float inv = __builtin_amdgcn_rcpf(x.x * x.y);
+        part = __builtin_elementwise_fma(wm2[j], (f32x2){inv, inv} * x.yx, part);
+      }
+      const float p0 = uic_row16_sum(part.x), p1 = uic_row16_sum(part.y);
+      if (c.l15 == 0 && rr < R) s_e[rr * 4 + c.lq] = p0;
+      if (c.l15 == 0 && rr + 1 < R) s_e[(rr + 1) * 4 + c.lq] = p1;
     }
     if (ch + 2 < NCH) load_chunk(P, ch + 2, pa[ch & 1]);
+    else load_chunk(V, ch, pa[ch & 1]);               // (round 6, NCH == 4: att' chunks 2 / 3 go into the score buffers as those fall free -- requested a
+                                                      //  microsecond before the context needs them; behind chunks 0 / 1 they were exposed Infinity Cache round trips)
   }
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // this wave's LDS writes are done (LDS serves a wave's requests in order)
   float e = -INFINITY;
@@ -359,11 +380,10 @@ __device__ __forceinline__ void attn_phase_wave(const Ctx& c, const UicRnnFwdPar
       float al = __shfl(wgt, rr < ATT_R ? (rr < 64 ? rr : 0) : 0, 64);
       if (rr >= R) al = 0.f;
       float f[8];
-      uic_unpack<T>(va[ch & 1][u], f);
+      uic_unpack<T>(ch < 2 ? va[ch][u] : pa[ch & 1][u], f);
 #pragma unroll
       for (int j = 0; j < 8; ++j) acc[j] = __builtin_fmaf(al, f[j], acc[j]);   // (explicit: the SAFE and the XCD-local instantiation must round alike)
     }
-    if (ch + 2 < NCH) load_chunk(V, ch + 2, va[ch & 1]);
   }
   T* o = ctx + (unsigned)(n * HH + c.lane * 8);
   if (!SAFE) {
@@ -1643,10 +1663,13 @@ int uic_rnn_fwd_persist_launch(const UicRnnFwdParams& p0, hipStream_t s) {
       p.xbase = lo;
     }
     p.sync = p0.sync + (size_t)(r0 / cap) * SY_WORDS;
-    UIC_TRY(uic_check_hip(hipMemsetAsync(p.sync, 0, (size_t)SY_WORDS * 4, s), "hipMemsetAsync(rnn sync)"));
+    if (!(p0.sync_zeroed && r0 == 0)) UIC_TRY(uic_check_hip(hipMemsetAsync(p.sync, 0, (size_t)SY_WORDS * 4, s), "hipMemsetAsync(rnn sync)"));
     // bf16: the weight-stationary kernel; f32 (the parity path): the generic one, weights re-read from L2 every step
     if (p.dec) hipLaunchKernelGGL(rnn_dec_persist_ws_kernel, dim3(G * PW), dim3(WS_NTH), WS_LDS_BYTES, s, p);
-    else if (p.dtype == UIC_BF16) hipLaunchKernelGGL(rnn_fwd_persist_ws_kernel, dim3(G * PW), dim3(WS_NTH), WS_LDS_BYTES, s, p);
+    else if (p.dtype == UIC_BF16) {
+      UIC_REQUIRE(p.e_att, "rnn_fwd_persist: the weight-stationary training kernel reads e_att = e^{2 p_att} (uic_exp2x2_launch)");
+      hipLaunchKernelGGL(rnn_fwd_persist_ws_kernel, dim3(G * PW), dim3(WS_NTH), WS_LDS_BYTES, s, p);
+    }
     else hipLaunchKernelGGL(rnn_fwd_persist_kernel<float>, dim3(G * PW), dim3(NTH), LDS_BYTES, s, p);
     UIC_LAUNCH_CHECK("rnn_fwd_persist_kernel");
   }

@@ -43,6 +43,7 @@ struct Layout {
   void* fcT; void* attT; int* row_len;
   float* ypre; float* amask_rep; int* row_len_rep;   // seq_per_img > 1: per-image relu(att_embed) (f32), att_masks / region counts per caption row
   void* fcp; void* attp; void* patt;
+  void* eatt;                                  // bf16: e^{2 p_att}, what the persistent training recurrence's attention reads (rnn_persist.hip)
   void* ybn; float* bn_stat0; float* bn_stat4; float* bn_part; float* bn_red;   // use_bn: pre-BN4 activations, {mean, rstd}, scratch
   void* xt_all; float* gx; float* gfc;
   int64_t* tok_used;   // [N, T] inputs actually fed to the embedding (differs from labels under scheduled sampling)
@@ -100,6 +101,7 @@ Layout make_layout(const uic_topdown_dims& d, void* ws) {
   L.fcp = b.take(N * H * S);
   L.attp = b.take(NR * H * S);
   L.patt = b.take(NR * A * S);
+  L.eatt = d.dtype == UIC_BF16 ? b.take(NR * A * S) : nullptr;
   if (d.use_bn) {
     L.bn_stat0 = (float*)b.take(2 * D * 4);
     L.bn_stat4 = (float*)b.take(2 * H * 4);
@@ -426,6 +428,9 @@ int prepare_features(const uic_topdown_dims& d, const uic_topdown_weights* w, co
     UicGemmParams g = gemm_base(dt, N * R, A);
     add_seg(g, L.attp, H, dv.ctx2att_w, H, H);
     g.C = L.patt; g.ldc = A; g.bias = w->ctx2att_b;
+    // e^{2 p_att} for the persistent recurrence's attention (rnn_persist.hip): from the ping-pong kernel's epilogue where that
+    // kernel takes the problem, else one element-wise pass -- the same values either way
+    g.C_exp2 = L.eatt;
     UIC_TRY(uic_gemm_launch(g, s));
   }
   return UIC_OK;
@@ -609,7 +614,7 @@ void* uic_topdown_workspace_ptr(const uic_topdown_dims* d, void* workspace, cons
   if (check_dims(d) || !workspace || !name) return nullptr;
   const Layout L = make_layout(*d, workspace);
   struct { const char* n; void* p; } tab[] = {
-      {"tok_used", L.tok_used}, {"d_pre", L.d_pre}, {"fc_embed", L.fcp}, {"att_embed", L.attp}, {"p_att", L.patt}, {"xt", L.xt_all}, {"gx", L.gx}, {"gfc", L.gfc},
+      {"tok_used", L.tok_used}, {"d_pre", L.d_pre}, {"fc_embed", L.fcp}, {"att_embed", L.attp}, {"p_att", L.patt}, {"e_att", L.eatt}, {"xt", L.xt_all}, {"gx", L.gx}, {"gfc", L.gfc},
       {"h_att", L.h_att}, {"h_lang", L.h_lang}, {"c_att", L.c_att}, {"c_lang", L.c_lang}, {"gates1", L.gates1},
       {"gates2", L.gates2}, {"att_h", L.atth_all}, {"alpha", L.alpha_all}, {"ctx", L.ctx_all}, {"hdrop", L.hdrop_all},
       {"logits", L.logits}, {"dlogits", L.dlogits}, {"row_loss", L.row_loss}, {"scalars", L.scalars},
@@ -1001,13 +1006,14 @@ struct Step {
     p.lang_b_ih = w->lang_lstm_b_ih; p.lang_b_hh = w->lang_lstm_b_hh;
     p.h2att_w = dv.h2att_w; p.h2att_b = w->h2att_b;
     p.w_alpha = w->alpha_w; p.b_alpha = w->alpha_b;
-    p.p_att = L.patt; p.att = L.attp;
+    p.p_att = L.patt; p.att = L.attp; p.e_att = L.eatt;
     p.mask = b->att_masks ? (d.seq_per_img > 1 ? L.amask_rep : b->att_masks) : nullptr; p.ldmask = R;
     p.h_att = L.h_att; p.h_lang = L.h_lang; p.c_att = L.c_att; p.c_lang = L.c_lang;
     p.gates1 = L.gates1; p.gates2 = L.gates2;
     p.att_h_all = L.atth_all; p.alpha_all = L.alpha_all; p.ctx_all = L.ctx_all; p.hdrop_all = L.hdrop_all;
     p.drop_p = drop_p; p.seed = seed;
-    p.sync = L.rnn_sync;
+    p.sync = L.rnn_sync; p.sync_zeroed = fwd_sync_clean ? 1 : 0;
+    fwd_sync_clean = false;            // (one launch's worth)
     p.force_safe = (d.recurrence & UIC_REC_SAFE) != 0; p.status = d.rnn_status;
     p.dbg = (d.recurrence & UIC_REC_STAMPS) ? L.rnn_dbg : nullptr; p.dbg_T = d.T;
     return uic_rnn_fwd_persist_launch(p, s);
@@ -1091,11 +1097,15 @@ struct Step {
   }
 
   // ---------------------------------------------------------------- backward
-  int bwd_begin(hipStream_t s) {
+  // with_fwd_sync (the fused step, whose third stream runs this beside the prologue): the forward recurrence's sync block is
+  // cleared here too, so that no memset node sits between the prologue's join and the persistent launch on the main stream
+  bool fwd_sync_clean = false;
+  int bwd_begin(hipStream_t s, bool with_fwd_sync = false) {
     if (bias_in_chunks()) UIC_TRY(uic_fill_value_launch(dt, L.ones_blk, L.ones_rows * 128, 1.f, s));
     bwd_launches = 0;
+    fwd_sync_clean = with_fwd_sync;
     return uic_zero4_launch(L.dc_att, NH * 4, L.dc_lang, NH * 4, bwd_persist_ok() ? L.rnn_bwd_sync : nullptr, bwd_persist_ok() ? L.rnn_bwd_sync_bytes : 0,
-                            nullptr, 0, s);
+                            with_fwd_sync ? L.rnn_sync : nullptr, with_fwd_sync ? uic_rnn_persist_sync_bytes() : 0, s);
   }
 
   // BPTT of decode steps [t_lo, t_hi), latest first: ONE persistent launch (rnn_bwd_persist.hip) when the shapes allow, else
@@ -1677,7 +1687,7 @@ int uic_topdown_xe_train_step(const uic_topdown_dims* d, const uic_topdown_weigh
       UIC_HIP(hipStreamWaitEvent(s3, ss->ev_den, 0));
       if (ss->g2_recorded) UIC_HIP(hipStreamWaitEvent(s3, ss->ev_g2, 0));   // (gathered refresh: fc_embed's operand copy was made on the side stream)
       UIC_TRY(st.fwd_prologue(s3, 4));
-      UIC_TRY(st.bwd_begin(s3));                      // (the BPTT loop's zeroed carries and ones block: nothing in the forward pass touches them)
+      UIC_TRY(st.bwd_begin(s3, st.persist_ok()));     // (the BPTT loop's zeroed carries and ones block: nothing in the forward pass touches them)
       bwd_begun = true;
       UIC_TRY(flush_gathered_late(ss, s3));           // (gathered refresh: the recurrence's and the logit layer's operand copies, last to arrive)
       UIC_HIP(hipEventRecord(ss->ev_pro3, s3));

@@ -214,6 +214,9 @@ struct UicGemmParams {
   // way to LDS, exactly as uic_cast_f32_launch rounds; with a_copy the column-0 workgroups also store that bf16 image
   // [M, ld_a_copy] (the weight gradient's operand) -- att_embed on the loader's f32 region features without the cast pass
   int a_f32; void* a_copy; int ld_a_copy;
+  // ping-pong kernel, bf16 output: a second output [M, ldc] = bf16(2^clamp(2 log2(e) c, +-UIC_E2_CLAMP)) of the ROUNDED bf16 value c that
+  // goes to C -- e^{2 p_att} for the persistent recurrence's attention, made where p_att is made (uic_exp2x2_launch's values)
+  void* C_exp2;
 };
 // C[row, c - col0] = sum_z slab[z][row, c] for c in [col0, col0 + ncols)
 int uic_splitk_reduce_launch(const float* slab, int splitk, int M, int N, int col0, int ncols, float* C, int ldc, hipStream_t s,
@@ -306,13 +309,16 @@ struct UicRnnFwdParams {
   const void* h2att_w; const float* h2att_b;     // [A, H]
   const float* w_alpha; const float* b_alpha;
   const void* p_att; const void* att;            // [N, R, A], [N, R, H]
+  const void* e_att;                 // [N, R, A] bf16 e^{2 p_att} (uic_exp2x2_launch): what the weight-stationary TRAINING kernel's attention reads in
+                                     // place of p_att (required there); ignored by the decode and the generic kernels
   const float* mask; int ldmask;                 // [N, R] or null
   void* h_att; void* h_lang; float* c_att; float* c_lang;     // [(T+1), N, H]: slot t is the state before step t
   void* gates1; void* gates2;                    // [T, N, 4H] activated gates for the backward pass, or null
   float* att_h_all; float* alpha_all; void* ctx_all; void* hdrop_all;   // [T, N, .]
   float drop_p; unsigned seed;
   const void* xbase;                 // filled by the launcher: lowest address of h_att / h_lang / ctx_all (one buffer descriptor)
-  unsigned* sync;                    // uic_rnn_persist_sync_bytes() bytes, zeroed by the launcher
+  unsigned* sync;                    // uic_rnn_persist_sync_bytes() bytes, zeroed by the launcher unless sync_zeroed
+  int sync_zeroed;                   // the caller cleared the FIRST launch's sync block itself (with other buffers, off the critical path)
   unsigned long long* dbg; int dbg_T; // optional [256][dbg_T][16] phase time stamps (100 MHz), indexed by absolute step
   unsigned* status;                  // sticky status words (uic_topdown_dims.rnn_status) or null
   // ---- decode mode (AttModel._sample, P/models/AttModel.py:198-253; bf16 only): every step also embeds the row's input
@@ -473,6 +479,10 @@ int uic_to_f32_launch(int dtype, const void* src, float* dst, size_t n, hipStrea
 int uic_copy_multi_launch(int count, const void* const* src, void* const* dst, const size_t* bytes, hipStream_t s);
 int uic_cast_f32_multi_launch(int dtype, int count, const float* const* src, void* const* dst, const size_t* n, hipStream_t s);   // several casts, one launch
 int uic_fill_launch(void* dst, int value_byte, size_t bytes, hipStream_t s);
+// dst[i] = bf16(2^clamp(2 log2(e) src[i], -UIC_E2_CLAMP, UIC_E2_CLAMP)) = e^{2 src[i]} for |src| < 20.8: the factored tanh of the
+// persistent recurrence's attention phase, tanh(p + h) = 1 - 2 / (1 + e^{2p} e^{2h}).  n % 8 == 0, 16-byte aligned.
+#define UIC_E2_CLAMP 60.f
+int uic_exp2x2_launch(const void* src_bf16, void* dst_bf16, size_t n, hipStream_t s);
 int uic_copy_launch(void* dst, const void* src, size_t bytes, hipStream_t s);
 int uic_fill_value_launch(int dtype, void* dst, size_t n, float value, hipStream_t s);   // n elements of the operand dtype = value   // device -> device, 4-byte granules
 // zero up to four buffers (16-byte aligned, sizes multiples of 16) in ONE launch instead of one memset node each
