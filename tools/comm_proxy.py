@@ -38,6 +38,7 @@ ap.add_argument("--no-comm-flag", action="store_true", help="clear UIC_REC_COMM_
                 "third stream, 256 x 256 kernel) beside the exchange")
 ap.add_argument("--early", action="store_true", help="opt.early_grads (UIC_REC_EARLY_GRADS): the embedding table and att_lstm.weight_ih final with the LSTM matrices")
 ap.add_argument("--no-pipeline", action="store_true", help="opt.no_pipelined_logit_piece: the logit piece's Adam + all-gather with the others, after the step")
+ap.add_argument("--half", action="store_true", help="opt.bf16_gradient_exchange: the pieces that are still on the wire when the step has joined travel as bf16")
 ap.add_argument("--comm-stream", default="torch", choices=["torch", "high", "raw", "raw-early", "raw-low"],
                 help="how the communication stream is made: torch = torch.cuda.Stream() (the Trainer's default); high = priority -1; raw = "
                      "hipStreamCreateWithFlags(non-blocking) wrapped as an ExternalStream, created after the library's side streams; "
@@ -128,6 +129,7 @@ def run(exchange, allreduce):
     opt.allow_many_hw_queues = 1
     opt.early_grads = int(args.early)
     opt.no_pipelined_logit_piece = int(args.no_pipeline)
+    opt.bf16_gradient_exchange = int(args.half)
     tr = Trainer(opt, exchange=exchange) if exchange is not None else Trainer(opt)
     tr.build_optimizer()
     tr.i2t_model.engine.recurrence |= int(args.rec, 0)

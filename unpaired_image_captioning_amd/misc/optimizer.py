@@ -96,6 +96,7 @@ class FlatArena(object):
         # the all-gathered weights: operand-dtype copies of the sharded region (bf16 runs) or the masters themselves
         self.operand_dtype = operand_dtype if (pieces and operand_dtype not in (None, torch.float32)) else None
         self.w16 = None
+        self.g16 = None                 # bf16 staging of the gradient pieces that sharded_step(half=...) exchanges in bf16 (made on first use)
         self.masters_stale = False
         if self.operand_dtype is not None:
             # (the whole arena's length: uic_adam_step_ranges leaves the operand copy of EVERY element it updates, the replicated
@@ -160,7 +161,7 @@ class FlatArena(object):
         return outs.sum().reshape(1)
 
     def sharded_step(self, ex, lr, betas, eps, step, grad_scale=1.0, max_norm=0.0, wait_piece=None, comm=None, gather_async=False,
-                     early_guard=None, pipeline=()):
+                     early_guard=None, pipeline=(), half=()):
         """One optimizer step of the sharded exchange on this arena (gradients final or becoming final on the current stream):
 
           1. reduce-scatter every piece -- piece i on the communication stream `comm` behind wait_piece(comm raw stream, i) when
@@ -178,6 +179,10 @@ class FlatArena(object):
         the bytes is then back on every rank long before the step ends, instead of in the next step's prologue.  early_guard: the
         status word (device int32), already final when the first overlapped piece is released; it is summed over the ranks there
         (one tiny all-reduce) and guards EVERY Adam launch of the step, so that the ranks skip together or not at all.
+
+        half: pieces whose reduce-scatter travels as bf16 (each rank's gradient rounded once, the sum in the collective's bf16
+        arithmetic, this rank's slice widened back to f32 for Adam) -- half the bytes on the wire for pieces that cannot hide behind
+        the backward pass; NOT bit-reproducible against the f32 exchange (opt.bf16_gradient_exchange, off by default).
 
         Returns (pair, events): pair = [summed loss, summed status flag] (a fresh 2-float tensor), events = {piece: event} or None."""
         cur = torch.cuda.current_stream(self.flat.device)
@@ -203,7 +208,16 @@ class FlatArena(object):
                 if early and guard is None and early_guard is not None:
                     guard = early_guard[0:1].to(torch.float32)
                     ex._sum(guard)
-                ex.reduce_scatter(self.grad, *self.pieces[i])
+                if i in half:
+                    if self.g16 is None:
+                        self.g16 = torch.empty(self.repl_off, dtype=torch.bfloat16, device=self.grad.device)
+                    off, n = self.pieces[i]
+                    self.g16[off:off + n].copy_(self.grad[off:off + n])
+                    ex.reduce_scatter(self.g16, off, n)
+                    lo, hi = self.shard(i)
+                    self.grad[lo:hi].copy_(self.g16[lo:hi])
+                else:
+                    ex.reduce_scatter(self.grad, *self.pieces[i])
                 if early and i in pipeline and guard is not None:
                     self.adam_owned(lr, betas, eps, step, grad_scale, guard=guard, ranges=[self.shard(i)])
                     ex.all_gather(buf, *self.pieces[i])

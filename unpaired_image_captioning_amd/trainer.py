@@ -201,7 +201,7 @@ class Trainer(object):
             pieces = [[k for k in g if k in mats] for g, _ in cand]
             self.piece_groups = [gid for (g, gid), p in zip(cand, pieces) if p]
             op_dtype = _lib.TORCH_DTYPE[eng.dtype]
-            self.arena = FlatArena(self.i2t_model, first + emb + lstm_w + wih + [k for k in early if k not in emb + wih] + late, world=ex.world_size, rank=ex.rank,
+            self.arena = FlatArena(self.i2t_model, [k for g, _ in cand for k in g], world=ex.world_size, rank=ex.rank,
                                    pieces=[p for p in pieces if p], operand_dtype=op_dtype)
             self.arena_splits = []
             eng.gathered = _GatheredWeights(self.arena, mats)
@@ -387,9 +387,12 @@ class Trainer(object):
         # the status word it is guarded by is final then too (the step's only persistent launch is the forward recurrence)
         has_eng = getattr(self.i2t_model, 'engine', None) is not None
         pipe = (0,) if (has_eng and overlap and groups and groups[0] == 0 and not getattr(self.opt, 'no_pipelined_logit_piece', 0)) else ()
+        # opt.bf16_gradient_exchange: every piece that is NOT pipelined behind the BPTT loop -- i.e. the bytes that are still on the
+        # wire when the step has joined -- is reduce-scattered as bf16
+        half = tuple(i for i in range(len(a.pieces)) if i not in pipe) if getattr(self.opt, 'bf16_gradient_exchange', 0) else ()
         pair, events = a.sharded_step(self.exchange, self.i2t_current_lr, self.betas, self.eps, self._step, grad_scale,
                                       wait_piece=wait_piece, comm=self._comm(dev), gather_async=True,
-                                      early_guard=_lib.status_words(dev) if pipe else None, pipeline=pipe)
+                                      early_guard=_lib.status_words(dev) if pipe else None, pipeline=pipe, half=half)
         self._guard_pair = pair
         if next_den_local is not None:
             self._next_den = (float(next_den_local), sc[3:4].reciprocal())
