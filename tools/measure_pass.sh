@@ -65,6 +65,8 @@ GPU_MAX_HW_QUEUES=2 timeout 200 python3 $R/tools/queue_probe.py 0 >> $O/queue_pr
 # round 6: the sharded exchange (reduce-scatter / Adam on the shard / all-gather) and round 5's all-reduce beside the step, stand-ins
 # for RCCL on one GPU; with the two hardware queues a data-parallel Trainer insists on, and without
 GPU_MAX_HW_QUEUES=2 timeout 300 python3 $R/tools/comm_proxy.py --steps 20 > $O/comm_proxy.txt 2>&1
+echo "--- opt.bf16_gradient_exchange (the pieces behind the join reduce-scattered as bf16)" >> $O/comm_proxy.txt
+GPU_MAX_HW_QUEUES=2 timeout 300 python3 $R/tools/comm_proxy.py --steps 20 --only sharded --half >> $O/comm_proxy.txt 2>&1
 echo "--- without GPU_MAX_HW_QUEUES" >> $O/comm_proxy.txt
 timeout 300 python3 $R/tools/comm_proxy.py --steps 20 >> $O/comm_proxy.txt 2>&1
 grep -E "^no exchange|^SHARDED|^round 5|^---" $O/comm_proxy.txt
