@@ -28,6 +28,7 @@ def main():
     ap.add_argument("--feat", type=int, default=2048)
     ap.add_argument("--batches", type=int, default=20)
     ap.add_argument("--dataset-images", type=int, default=512)
+    ap.add_argument("--read-threads", type=int, default=0, help="reader team size (0: the loader's default)")
     ap.add_argument("--compressed", action="store_true", help="att files as np.savez_compressed writes them (make_bu_data.py:55)")
     a = ap.parse_args()
     from unpaired_image_captioning_amd import _lib
@@ -90,16 +91,20 @@ def main():
             for i in range(N):
                 np.savez_compressed(os.path.join(tmp, "att", "%d.npz" % i), feat=att[i])
         opt = loader_opt(tmp, label_path, n, 5, D, Dout, 1, 1, 1)
-        loader = DataLoader(opt)
+        loader = DataLoader(opt, read_threads=a.read_threads or None)
         random.seed(0)
         for _ in range(3):
             loader.get_batch("train")
         torch.cuda.synchronize()
         t0 = time.perf_counter()
+        per_batch = []
         for _ in range(a.batches):
+            t1 = time.perf_counter()
             d = loader.get_batch("train")
+            per_batch.append(round((time.perf_counter() - t1) * 1e3, 2))
         torch.cuda.synchronize()
         dt_loader = (time.perf_counter() - t0) / a.batches
+        print("get_batch, ms per call: " + " ".join("%.2f" % x for x in per_batch), file=sys.stderr)
 
         # ---- 3. training from files: loader -> Trainer.train, the reference's defaults (use_box: 2053 features, use_bn 1) ----
         import argparse as _ap
@@ -171,7 +176,7 @@ def main():
                    "GBps_resident": round(algo / us_resident / 1e3, 1), "GBps_hbm_cold": round(algo / us_cold / 1e3, 1),
                    "frac_of_8TBps_hbm_cold": round(algo / us_cold / 1e3 / 8000, 3), "rotating_sets": n_sets},
         "loader_end_to_end": {"ms_per_batch": round(dt_loader * 1e3, 2), "images_per_s": round(n / dt_loader, 1),
-                              "reader_threads": loader.read_threads, "att_files": "deflated" if a.compressed else "stored",
+                              "reader_threads": loader.read_threads_deflate if a.compressed else loader.read_threads, "att_files": "deflated" if a.compressed else "stored",
                               "note": "files in the page cache, library reader team straight into pinned staging, read-ahead of the next batch, un-replicated H2D"},
         "train_from_files": {"ms_per_step": round(dt_train * 1e3, 2), "captions_per_s": round(n * 5 / dt_train, 0),
                              "ms_per_step_same_batch_resident": round(dt_resident * 1e3, 2),

@@ -47,6 +47,32 @@ def padded_width(D):
     return D if D % 8 == 0 else (D + 127) // 128 * 128
 
 
+def cpu_budget():
+    """CPUs this process can keep busy: the affinity mask, cut down to the cgroup's CPU quota when it has one (cgroup v2
+    cpu.max "quota period", v1 cpu.cfs_quota_us / cpu.cfs_period_us)."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except (AttributeError, OSError):
+        n = os.cpu_count() or 8
+    quota = None
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:
+            q, per = f.read().split()[:2]
+            if q != "max":
+                quota = float(q) / float(per)
+    except (OSError, ValueError):
+        try:
+            with open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us") as f, open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as g:
+                q, per = float(f.read()), float(g.read())
+                if q > 0 and per > 0:
+                    quota = q / per
+        except (OSError, ValueError):
+            pass
+    if quota is not None:
+        n = min(n, max(1, int(quota + 0.5)))
+    return max(1, n)
+
+
 class DataLoader(object):
 
     def reset_iterator(self, split):                                   # :26-30
@@ -120,8 +146,13 @@ class DataLoader(object):
         self._fc_ext = '.npz' if os.path.exists(os.path.join(self.input_fc_dir, first + '.npz')) else '.npy'
         # the library's reader team (a persistent pool since round 6): 32 workers move stored members at the page cache's rate;
         # DEFLATED members (np.savez_compressed, what make_bu_data.py writes) cost ~1.4 ms of inflate each and get up to 128
-        self.read_threads = int(read_threads or min(32, os.cpu_count() or 8))
-        self.read_threads_deflate = int(read_threads or min(128, max(8, (os.cpu_count() or 8) // 2)))
+        # -- both capped by the CPUs this process may actually USE (affinity mask and cgroup quota): a team larger than a container's
+        # CPU quota gets the whole process frozen until the next scheduling period once the quota is spent (measured on a 16-CPU
+        # pod of a 256-thread host: 64-128 inflating threads = 3 ms batches with 20-170 ms stalls every few batches, 16 threads =
+        # a steady 7.5 ms -- the same average, tools/loader_bench.py --compressed --read-threads N)
+        cpus = cpu_budget()
+        self.read_threads = int(read_threads or max(1, min(32, cpus)))
+        self.read_threads_deflate = int(read_threads or max(1, min(128, cpus)))
         self.read_ahead = read_ahead
         self._pool = ThreadPoolExecutor(max_workers=1)                 # the read-ahead thread (the team is inside the library)
         self._ahead_job = None
