@@ -709,9 +709,21 @@ int uic_att_batch_assemble(const float* feat_pack, const float* box_pack, const 
  * uic_loader_scan: info [n, 6] i64 per file = (ndim, d0, d1, offset of the data inside the member, zip method or -1,
  * offset of the member in the file).  uic_loader_read: the d0 * d1 floats of file i are written at dst[i]; `info` as
  * returned by the scan.  `member` may be NULL for plain .npy files.  A file that cannot be read, or is not float32, fails the
- * whole call (UIC_EARG, uic_last_error_string() names the file).  Thread-safe; n_threads <= 64. */
+ * whole call (UIC_EARG, uic_last_error_string() names the file).  Thread-safe; n_threads <= 128. */
 int uic_loader_scan(const char* const* paths, int32_t n, const char* member, int64_t* info, int32_t n_threads);
 int uic_loader_read(const char* const* paths, int32_t n, const int64_t* info, void* const* dst, int32_t n_threads);
+/* The decoder uic_loader_read uses for deflated members, on one raw deflate stream (RFC 1951; what a zip member of
+ * np.savez_compressed holds): src[0..n) -> exactly m bytes at dst.  fast != 0: the library's own table-driven decoder
+ * (csrc/inflate_fast.h: 64-bit bit buffer, one 11-bit lookup per symbol, up to three literals per refill), returns 1 when it
+ * declines the stream (malformed, or not exactly m bytes long) -- uic_loader_read then retries with zlib; fast == 0: zlib.  Host
+ * only; a test hook (tests/test_dataloader_host.py compares the two decoders on stored, fixed and dynamic blocks).
+ * The worker threads of the reader team are pinned to CPUs of their own unless UIC_LOADER_NO_PIN=1 is in the environment;
+ * UIC_LOADER_ZLIB=1 keeps uic_loader_read on zlib (both read once, at first use: the library's only environment reads, host side). */
+int uic_loader_inflate(const void* src, size_t n, void* dst, size_t m, int32_t fast);
+/* The same decoder on TWO streams in lock-step on the calling thread -- how uic_loader_read takes deflated members (a deflate
+ * stream is one chain of dependent table lookups; two chains share a core's issue slots).  Returns a bit mask: bit k set = stream k
+ * declined. */
+int uic_loader_inflate_pair(const void* src0, size_t n0, void* dst0, size_t m0, const void* src1, size_t n1, void* dst1, size_t m1);
 
 #ifdef __cplusplus
 }

@@ -195,6 +195,130 @@ def test_library_reader_takes_npy_stored_npz_and_deflated_npz(tmp_path):
         _lib.check(lib.uic_loader_scan(arr, 1, b"feat", info.ctypes.data, 1), "scan")
 
 
+def _raw_deflate(data, level=6, strategy=None):
+    import zlib
+    c = zlib.compressobj(level, zlib.DEFLATED, -15, 9, zlib.Z_DEFAULT_STRATEGY if strategy is None else strategy)
+    return c.compress(data) + c.flush()
+
+
+def _inflate_cases():
+    rng = np.random.default_rng(1)
+    return {
+        "bottom-up-like (|N|, f32)": np.abs(rng.standard_normal((36, 2048))).astype(np.float32).tobytes(),
+        "half zeros (relu, f32)": np.maximum(rng.standard_normal((20, 2048)), 0).astype(np.float32).tobytes(),
+        "zeros": bytes(100000), "one byte": b"x", "empty": b"", "text": b"the quick brown fox " * 3000,
+        "random bytes": rng.integers(0, 256, 150000, dtype=np.uint8).tobytes(),
+        "small alphabet": rng.integers(0, 4, 100000, dtype=np.uint8).tobytes(),
+    }
+
+
+def test_the_loaders_own_inflate_agrees_with_zlib_on_every_block_type():
+    """csrc/inflate_fast.h (what uic_loader_read decodes np.savez_compressed members with) against zlib, on stored, fixed-Huffman
+    and dynamic-Huffman blocks, literal-only and match-heavy data, empty and one-byte streams; a stream of the wrong length or a
+    truncated one must be DECLINED without a byte written outside the destination; a corrupted stream is either declined or
+    decoded to exactly what zlib makes of it."""
+    import ctypes as C
+    import zlib
+    from unpaired_image_captioning_amd import _lib
+    lib = _lib.load()
+
+    def run(src, m, fast):
+        out = np.full(m + 8, 0xAB, dtype=np.uint8)
+        rc = lib.uic_loader_inflate(src, len(src), out.ctypes.data, m, fast)
+        return rc, out[:m].tobytes(), out[m:].tobytes()
+    guard = bytes([0xAB]) * 8
+    cases = _inflate_cases()
+    settings = ((6, None), (1, None), (9, None), (0, None), (6, zlib.Z_FIXED), (6, zlib.Z_HUFFMAN_ONLY), (6, zlib.Z_RLE))
+    for name, data in cases.items():
+        for level, strat in settings:
+            src = _raw_deflate(data, level, strat)
+            rc0, o0, _ = run(src, len(data), 0)
+            rc1, o1, g1 = run(src, len(data), 1)
+            assert rc0 == 0 and o0 == data, (name, level, strat)
+            assert rc1 == 0 and o1 == data and g1 == guard, (name, level, strat, rc1)
+            if data:
+                rc, _, g = run(src, len(data) - 1, 1)
+                assert rc == 1 and g == guard, (name, "one byte short")
+            rc, _, g = run(src, len(data) + 1, 1)
+            assert rc == 1 and g == guard, (name, "one byte long")
+            if len(src) > 4:
+                rc, _, g = run(src[:len(src) // 2], len(data), 1)
+                assert rc == 1 and g == guard, (name, "truncated")
+    data = cases["bottom-up-like (|N|, f32)"]
+    src = bytearray(_raw_deflate(data))
+    rng = np.random.default_rng(2)
+    declined = 0
+    for _ in range(200):
+        bad = bytearray(src)
+        bad[int(rng.integers(0, len(bad)))] ^= 1 << int(rng.integers(0, 8))
+        rc, o, g = run(bytes(bad), len(data), 1)
+        assert g == guard
+        if rc == 0:
+            assert o == zlib.decompress(bytes(bad), -15)
+        declined += rc
+    assert declined > 0
+
+
+def test_two_streams_in_lock_step_decode_like_one_at_a_time():
+    """uic_loader_inflate_pair: one thread, two deflate streams decoded side by side (how uic_loader_read takes deflated members:
+    the two dependency chains share a core).  Every pairing of data kinds x block types; a broken stream must not disturb its
+    partner."""
+    import itertools
+    import zlib
+    from unpaired_image_captioning_amd import _lib
+    lib = _lib.load()
+    cases = _inflate_cases()
+
+    def run_pair(s0, m0, s1, m1):
+        o0, o1 = np.full(m0 + 8, 0xAB, dtype=np.uint8), np.full(m1 + 8, 0xAB, dtype=np.uint8)
+        rc = lib.uic_loader_inflate_pair(s0, len(s0), o0.ctypes.data, m0, s1, len(s1), o1.ctypes.data, m1)
+        return rc, o0[:m0].tobytes(), o1[:m1].tobytes(), o0[m0:].tobytes() + o1[m1:].tobytes()
+    guard = bytes([0xAB]) * 16
+    settings = ((6, None), (0, None), (6, zlib.Z_FIXED), (1, zlib.Z_RLE))
+    streams = {(k, s): _raw_deflate(v, *s) for k, v in cases.items() for s in settings}
+    for (a, sa), (b, sb) in itertools.product(streams, streams):
+        rc, o0, o1, g = run_pair(streams[(a, sa)], len(cases[a]), streams[(b, sb)], len(cases[b]))
+        assert rc == 0 and o0 == cases[a] and o1 == cases[b] and g == guard, (a, sa, b, sb, rc)
+    a, b = "bottom-up-like (|N|, f32)", "half zeros (relu, f32)"
+    good = streams[(a, (6, None))]
+    broken = bytearray(streams[(b, (6, None))])
+    broken[len(broken) // 3] ^= 0x55
+    rc, o0, _, g = run_pair(good, len(cases[a]), bytes(broken), len(cases[b]))
+    assert (rc & 1) == 0 and o0 == cases[a] and g == guard
+    rc, _, o1, g = run_pair(bytes(broken), len(cases[b]), good, len(cases[a]))
+    assert (rc & 2) == 0 and o1 == cases[a] and g == guard
+
+
+def test_reader_pairs_deflated_members_and_falls_back_to_zlib(tmp_path, monkeypatch):
+    """uic_loader_read over an odd number of deflated members mixed with stored ones and plain .npy files (pairs + one single +
+    the rest), on one thread and on several: every array arrives, whichever decoder took it."""
+    import ctypes as C
+    from unpaired_image_captioning_amd import _lib
+    lib = _lib.load()
+    rng = np.random.default_rng(5)
+    arrays, paths = [], []
+    for i in range(11):
+        a = np.abs(rng.standard_normal((int(rng.integers(1, 40)), 256))).astype(np.float32)
+        p = str(tmp_path / ("f%d" % i))
+        if i % 3 == 2:
+            np.savez(p, feat=a); p += ".npz"
+        elif i == 4:
+            np.save(p, a); p += ".npy"
+        else:
+            np.savez_compressed(p, feat=a); p += ".npz"
+        arrays.append(a)
+        paths.append(p.encode())
+    arr = (C.c_char_p * len(paths))(*paths)
+    info = np.zeros((len(paths), 6), dtype=np.int64)
+    _lib.check(lib.uic_loader_scan(arr, len(paths), b"feat", info.ctypes.data, 2), "scan")
+    assert (info[:, 4] == 8).sum() == 7
+    for nt in (1, 3):
+        out = [np.full(a.shape, np.nan, dtype=np.float32) for a in arrays]
+        dst = (C.c_void_p * len(out))(*[o.ctypes.data for o in out])
+        _lib.check(lib.uic_loader_read(arr, len(paths), info.ctypes.data, dst, nt), "read")
+        assert all(np.array_equal(o, a) for o, a in zip(out, arrays))
+
+
 def test_fc_vectors_as_npy_files(tmp_path, monkeypatch):
     """make_bu_data.py writes the fc vectors as <id>.npy; the loader takes either extension."""
     import os

@@ -301,6 +301,8 @@ _SIGS = {
     "uic_ciderd_reward": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_float, C.c_void_p, C.c_void_p]),
     "uic_loader_scan": (C.c_int, [C.c_void_p, C.c_int32, C.c_char_p, C.c_void_p, C.c_int32]),
     "uic_loader_read": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32]),
+    "uic_loader_inflate": (C.c_int, [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_int32]),
+    "uic_loader_inflate_pair": (C.c_int, [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t]),
     "uic_att_batch_assemble": (C.c_int, [C.c_void_p] * 5 + [C.c_int32] * 6 + [C.c_void_p] * 3),
     "uic_linear_wgrad": (C.c_int, [C.c_int32] * 4 + [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32,
                                    C.c_void_p, C.c_size_t, C.c_int32, C.c_void_p]),
