@@ -145,14 +145,17 @@ class DataLoader(object):
         first = str(self.info['images'][0]['id'])
         self._fc_ext = '.npz' if os.path.exists(os.path.join(self.input_fc_dir, first + '.npz')) else '.npy'
         # the library's reader team (a persistent pool since round 6): 32 workers move stored members at the page cache's rate;
-        # DEFLATED members (np.savez_compressed, what make_bu_data.py writes) cost ~1.4 ms of inflate each and get up to 128
+        # DEFLATED members (np.savez_compressed, what make_bu_data.py writes) cost ~0.55 ms of CPU each with the library's own decoder
+        # (csrc/inflate_fast.h, two streams per thread; zlib: ~0.95 ms) and get up to 128
         # -- both capped by the CPUs this process may actually USE (affinity mask and cgroup quota): a team larger than a container's
         # CPU quota gets the whole process frozen until the next scheduling period once the quota is spent (measured on a 16-CPU
         # pod of a 256-thread host: 64-128 inflating threads = 3 ms batches with 20-170 ms stalls every few batches, 16 threads =
         # a steady 7.5 ms -- the same average, tools/loader_bench.py --compressed --read-threads N)
         cpus = cpu_budget()
         self.read_threads = int(read_threads or max(1, min(32, cpus)))
-        self.read_threads_deflate = int(read_threads or max(1, min(128, cpus)))
+        # (two CPUs are left to the training loop's own host threads: with all 16 of a 16-CPU quota inflating, batches took 4.6 ms
+        # but every few of them 10-15 ms; 14 threads: a steady 5.5 ms)
+        self.read_threads_deflate = int(read_threads or max(1, min(128, cpus - 2)))
         self.read_ahead = read_ahead
         self._pool = ThreadPoolExecutor(max_workers=1)                 # the read-ahead thread (the team is inside the library)
         self._ahead_job = None
