@@ -330,7 +330,7 @@ __device__ __forceinline__ void attn_phase_wave(const Ctx& c, const UicRnnFwdPar
     wsum += w[j];
   }
   const f32x2 one2 = {1.f, 1.f};
-  static_assert(CR % 2 == 0 && NCH == 4, "regions are taken in pairs; four chunks (the att' schedule below)");
+  static_assert(CR % 2 == 0, "regions are taken in pairs");
 #pragma unroll
   for (int ch = 0; ch < NCH; ++ch) {
 #pragma unroll
@@ -351,8 +351,12 @@ __device__ __forceinline__ void attn_phase_wave(const Ctx& c, const UicRnnFwdPar
       if (c.l15 == 0 && rr + 1 < R) s_e[(rr + 1) * 4 + c.lq] = p1;
     }
     if (ch + 2 < NCH) load_chunk(P, ch + 2, pa[ch & 1]);
-    else load_chunk(V, ch, pa[ch & 1]);               // (round 6, NCH == 4: att' chunks 2 / 3 go into the score buffers as those fall free -- requested a
-                                                      //  microsecond before the context needs them; behind chunks 0 / 1 they were exposed Infinity Cache round trips)
+#ifdef UIC_AW_RESCHED   // (A/B build, tools/build_variant.sh: att' chunks 2 / 3 requested into the score buffers as those fall free -- the
+                        //  context then never waits for them, but four buffers live at once cost the kernel its last 29 free registers:
+                        //  256 + 256, i.e. a whole SIMD's register file per wave, and ANY foreign wave on a CU then keeps the launch from
+                        //  becoming resident -- tools/queue_probe.py: one waiting wave on another stream, step 2.9 -> 5.9 ms.  Off.)
+    else load_chunk(V, ch, pa[ch & 1]);
+#endif
   }
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // this wave's LDS writes are done (LDS serves a wave's requests in order)
   float e = -INFINITY;
@@ -380,10 +384,17 @@ __device__ __forceinline__ void attn_phase_wave(const Ctx& c, const UicRnnFwdPar
       float al = __shfl(wgt, rr < ATT_R ? (rr < 64 ? rr : 0) : 0, 64);
       if (rr >= R) al = 0.f;
       float f[8];
+#ifdef UIC_AW_RESCHED
       uic_unpack<T>(ch < 2 ? va[ch][u] : pa[ch & 1][u], f);
+#else
+      uic_unpack<T>(va[ch & 1][u], f);
+#endif
 #pragma unroll
       for (int j = 0; j < 8; ++j) acc[j] = __builtin_fmaf(al, f[j], acc[j]);   // (explicit: the SAFE and the XCD-local instantiation must round alike)
     }
+#ifndef UIC_AW_RESCHED
+    if (ch + 2 < NCH) load_chunk(V, ch + 2, va[ch & 1]);
+#endif
   }
   T* o = ctx + (unsigned)(n * HH + c.lane * 8);
   if (!SAFE) {
