@@ -434,7 +434,11 @@ __global__ __launch_bounds__(64 * WM * WN * KS) void uic_gemm_kernel(const UicGe
 // fragment read: 16-byte chunk c of tile row r lives at chunk c ^ ((r >> 1) & 7), which makes the 16-lane
 // groups of ds_read_b128 hit 16 distinct 16-byte slots of the 256-byte bank row.
 // Requires one K segment with K a multiple of the round (64 bf16 / 32 f32 elements).
-template <typename T>
+// STAGES (round 6): 2 = two LDS buffers, the next round's DMA issued at the top of a round and waited for at the top of the next
+// -- one L2 / Infinity Cache latency (~0.8 us) per 64-deep K round whatever the MFMA time (0.2 us), hidden only by the CU's second
+// workgroup; 3 = a ring of three buffers (96 KB: one workgroup per CU), two rounds in flight.  For launches that put at most one
+// workgroup on a CU anyway -- the BPTT loop's split-K d x GEMMs: 160 / 240 workgroups of 8 rounds -- the ring is what hides the latency.
+template <typename T, int STAGES = 2>
 __global__ __launch_bounds__(256, 2) void uic_gemm_glds_kernel(const UicGemmParams p) {   // (2 waves per SIMD = two workgroups per CU: <= 256 registers)
   constexpr int BM = 128, BN = 128;
   constexpr int BK = 128 / (int)sizeof(T);
@@ -545,22 +549,24 @@ __global__ __launch_bounds__(256, 2) void uic_gemm_glds_kernel(const UicGemmPara
       }                                                                                                  \
     }                                                                                                    \
   } while (0)
-#define UIC_ISSUE(A0, A1, B0, B1, KS, BO) \
-  UIC_DSR(A0, adA[KS], BO); UIC_DSR(A1, adA[KS], BO + 4096); UIC_DSR(B0, adB[KS], BO); UIC_DSR(B1, adB[KS], BO + 4096)
+#define UIC_ISSUE(A0, A1, B0, B1, KS) \
+  UIC_DSR(A0, aA[KS], 0); UIC_DSR(A1, aA[KS], 4096); UIC_DSR(B0, aB[KS], 0); UIC_DSR(B1, aB[KS], 4096)
 #define UIC_WAIT(N, A0, A1, B0, B1)                                                           \
   asm volatile("s_waitcnt lgkmcnt(" #N ")" : "+v"(A0), "+v"(A1), "+v"(B0), "+v"(B1));         \
   __builtin_amdgcn_sched_barrier(0)
-  auto compute = [&](auto bufc) {
-    constexpr int BO = decltype(bufc)::value * 32768;
+  auto compute = [&](unsigned bo) {                    // bo = byte offset of the round's buffer (uniform)
+    unsigned aA[4], aB[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) { aA[ks] = adA[ks] + bo; aB[ks] = adB[ks] + bo; }
     u32x4 a00, a01, b00, b01, a10, a11, b10, b11;     // two register sets: K step ks uses set ks & 1
-    UIC_ISSUE(a00, a01, b00, b01, 0, BO);
-    UIC_ISSUE(a10, a11, b10, b11, 1, BO);
+    UIC_ISSUE(a00, a01, b00, b01, 0);
+    UIC_ISSUE(a10, a11, b10, b11, 1);
     UIC_WAIT(4, a00, a01, b00, b01);
     UIC_MFMA4(a00, a01, b00, b01);
-    UIC_ISSUE(a00, a01, b00, b01, 2, BO);
+    UIC_ISSUE(a00, a01, b00, b01, 2);
     UIC_WAIT(4, a10, a11, b10, b11);
     UIC_MFMA4(a10, a11, b10, b11);
-    UIC_ISSUE(a10, a11, b10, b11, 3, BO);
+    UIC_ISSUE(a10, a11, b10, b11, 3);
     UIC_WAIT(4, a00, a01, b00, b01);
     UIC_MFMA4(a00, a01, b00, b01);
     UIC_WAIT(0, a10, a11, b10, b11);
@@ -570,17 +576,35 @@ __global__ __launch_bounds__(256, 2) void uic_gemm_glds_kernel(const UicGemmPara
 #undef UIC_ISSUE
 #undef UIC_MFMA4
 #undef UIC_DSR
-  if (nt > 0) stage(kt0, 0);
-  for (int t = 0; t < nt; t += 2) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    if (t + 1 < nt) stage(kt0 + t + 1, 1);
-    compute(std::integral_constant<int, 0>{});
-    if (t + 1 < nt) {
+  if constexpr (STAGES == 2) {
+    if (nt > 0) stage(kt0, 0);
+    for (int t = 0; t < nt; t += 2) {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();
-      if (t + 2 < nt) stage(kt0 + t + 2, 0);
-      compute(std::integral_constant<int, 1>{});
+      if (t + 1 < nt) stage(kt0 + t + 1, 1);
+      compute(0u);
+      if (t + 1 < nt) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (t + 2 < nt) stage(kt0 + t + 2, 0);
+        compute(32768u);
+      }
+    }
+  } else {
+    // ring: rounds t .. t + STAGES - 2 are in flight at the top of round t.  A wave's DMA instructions complete in order, 8 per round:
+    // round t's have landed once at most 8 x (newer rounds) are outstanding; the barrier behind the wait makes every wave's share
+    // of round t visible and says that buffer (t - 1) % STAGES -- which the next DMA overwrites -- has been read by all.
+    for (int i = 0; i < STAGES - 1 && i < nt; ++i) stage(kt0 + i, i);
+    int buf = 0;
+    for (int t = 0; t < nt; ++t) {
+      const int newer = min(STAGES - 2, nt - 1 - t);
+      if (newer >= 2) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+      else if (newer == 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      if (t + STAGES - 1 < nt) stage(kt0 + t + STAGES - 1, buf == 0 ? STAGES - 1 : buf - 1);
+      compute((unsigned)buf * 32768u);
+      buf = buf + 1 == STAGES ? 0 : buf + 1;
     }
   }
 
@@ -723,12 +747,27 @@ template <typename T>
 int launch_glds(const UicGemmParams& p, hipStream_t s) {
   static bool configured = false;
   if (!configured) {
-    UIC_TRY(uic_check_hip(hipFuncSetAttribute((const void*)uic_gemm_glds_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536),
+    UIC_TRY(uic_check_hip(hipFuncSetAttribute((const void*)uic_gemm_glds_kernel<T, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536),
                           "hipFuncSetAttribute(gemm glds)"));
+    UIC_TRY(uic_check_hip(hipFuncSetAttribute((const void*)uic_gemm_glds_kernel<T, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, 98304),
+                          "hipFuncSetAttribute(gemm glds ring)"));
     configured = true;
   }
   dim3 grid((p.M + 127) / 128, (p.N + 127) / 128, p.splitk > 1 ? p.splitk : 1);
-  hipLaunchKernelGGL((uic_gemm_glds_kernel<T>), grid, dim3(256), 65536, s, p);
+  // the three-buffer ring where the launch is well under one workgroup per CU and the K loop has rounds to overlap.  Measured in the
+  // training step (rocprofv3, median): the first logit chunk's d h (5 x 4 x 8 workgroups, 18 rounds) 22.7 -> 17.6 us, the BPTT loop's
+  // d x1 (5 x 8 x 4, 8 rounds) 10.1 -> 9.8; its d x2 (5 x 12 x 4 = 240 workgroups) 13.2 -> 15.6: at 96 KB a CU takes ONE of them where
+  // it took two 64-KB ones, and beside the side streams' 128-KB workgroups the launch then waits for 240 free CUs instead of 120 --
+  // so the ring stops at 192 workgroups.  Alone on the chip it makes a K round cost 0.3 us instead of 0.8 (tools/gemm_headroom.py).
+  const int rounds = p.seg[0].K / (128 / (int)sizeof(T)) / (p.splitk > 1 ? p.splitk : 1);
+#ifdef UIC_GLDS_NO_RING           // (A/B builds: tools/build_variant.sh)
+  const bool ring = false;
+  (void)rounds;
+#else
+  const bool ring = (long)grid.x * grid.y * grid.z <= 192 && rounds >= 3 && !(p.flags & UIC_GEMM_NO_RING);
+#endif
+  if (ring) hipLaunchKernelGGL((uic_gemm_glds_kernel<T, 3>), grid, dim3(256), 98304, s, p);
+  else hipLaunchKernelGGL((uic_gemm_glds_kernel<T, 2>), grid, dim3(256), 65536, s, p);
   UIC_LAUNCH_CHECK("uic_gemm_glds_kernel");
   return UIC_OK;
 }

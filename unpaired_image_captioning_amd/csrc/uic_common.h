@@ -167,6 +167,7 @@ extern thread_local int g_uic_knobs;
 #define UIC_GEMM_FORCE_192 0x400   // the same with its 192-row tile
 #define UIC_GEMM_FORCE_PP128 0x800 // the same with its 128-row tile (128 x 256)
 #define UIC_GEMM_FORCE_MASK 0xF00
+#define UIC_GEMM_NO_RING 0x1000     // the 128 x 128 kernel with two LDS buffers even where the dispatcher would take its three-buffer ring (A/B)
 #define UIC_GEMM_MAX_SEG 4
 
 // One K-segment: C += A[M,K] * B[Nrows,K]^T.  Segments are summed, which expresses
