@@ -416,3 +416,25 @@ def test_two_ranks_nmt_step_matches_single_process(tmp_path, allreduce):
         moved = (ref - W0[k]).abs().max().item()
         assert moved > 0, k
         assert (v - ref).abs().max().item() <= 2e-2 * moved + 1e-7, (k, (v - ref).abs().max().item(), moved)
+
+
+def test_bench_two_rank_path_runs_end_to_end_on_one_gpu():
+    """bench.py --gpus 2 in its functional mode (UIC_BENCH_SHARE_GPU=1: both ranks on this GPU, gloo, launch-chain recurrence --
+    RCCL needs a GPU per rank): the N > 1 code of the benchmark -- rank-local seeds, the sharded exchange with the next batch's mask
+    sum riding in the step's all-reduce, the "without exchange" leg, the per-rank gather, the untimed roofline steps with matched
+    collectives -- must run and print its one line with the communication object.  (The line says it is not a measurement.)"""
+    import json
+    import subprocess
+    env = dict(os.environ, UIC_BENCH_SHARE_GPU="1")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT"):
+        env.pop(k, None)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--no-f32",
+                          "--no-cpu-baseline", "--long-run", "0"], env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and "NOT a measurement" in d["data"]
+    c = d["communication"]
+    assert c["exchange"].startswith("sharded: reduce-scatter of 4 gradient pieces") and len(c["ms_per_step_without_exchange_per_rank"]) == 2
+    assert d["final_loss"] == d["final_loss"] and 5.0 < d["final_loss"] < 12.0
