@@ -143,13 +143,17 @@ class GradientExchange(object):
 
     def _reduce_scatter(self, whole, mine):
         if self._native_halves(whole):
-            dist.reduce_scatter_tensor(mine, whole, op=dist.ReduceOp.SUM, group=self.group)
+            # (through a staging slice rather than in place: NCCL defines the in-place form -- recvbuff = sendbuff + rank * count --, but
+            # nothing in torch.distributed promises to accept an output that aliases its input; one copy of 1 / world of the piece)
+            out = torch.empty_like(mine)
+            dist.reduce_scatter_tensor(out, whole, op=dist.ReduceOp.SUM, group=self.group)
+            mine.copy_(out)
         else:
             dist.all_reduce(whole, op=dist.ReduceOp.SUM, group=self.group)      # (this rank's slice of it is what the caller reads)
 
     def _all_gather(self, whole, mine):
         if self._native_halves(whole):
-            dist.all_gather_into_tensor(whole, mine, group=self.group)
+            dist.all_gather_into_tensor(whole, mine.clone(), group=self.group)      # (the same: no aliasing of input and output)
         else:
             # every other rank's slice zeroed, then an INTEGER sum of the bit patterns: x + 0 + ... + 0 = x, exactly
             keep = mine.clone()
