@@ -175,8 +175,8 @@ def capture_single_stream(model, batch, replays=5, rows=80):
     replay_ms = (time.perf_counter() - t0) / (replays * 10) * 1e3
     eng.release(ws)
     eng.recurrence = 0
-    print("single-stream step at %d caption rows (forward + loss + backward, launch-chain recurrence): eager %.3f ms per step "
-          "(enqueue-bound), graph replay %.3f ms, %d nodes; tensors that differ from the eager step in two replays: %s" % (
+    print("single-stream step at %d caption rows (forward + loss + backward, launch-chain recurrence): eager %.3f ms per step, "
+          "graph replay %.3f ms, %d nodes; tensors that differ from the eager step in two replays: %s" % (
               n, eager_ms, replay_ms, nnodes.value, [b or "none" for b in bad_all]))
 
 
