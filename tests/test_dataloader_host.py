@@ -395,3 +395,61 @@ def test_read_ahead_survives_interleaved_splits_and_batch_sizes(tmp_path, monkey
         assert all(splits[ix] == split for ix in fetch)
         assert np.array_equal(seen["feat"][0].numpy(), np.concatenate([z["in::att_%d" % ix] for ix in fetch], 0)), (split, bs)
         assert np.array_equal(seen["fc"][0].numpy(), np.stack([z["in::fc_%d" % d["ix"]] for d in data["infos"]]))
+
+
+def test_cpu_budget_follows_affinity_and_cgroup_quota(monkeypatch, tmp_path):
+    """The reader teams are sized by what the process may USE: the affinity mask, cut down to a cgroup CPU quota (v2 `cpu.max`) --
+    a team larger than the quota gets the whole process frozen once the period's quota is spent (profiles/LOG.md, round 6)."""
+    import builtins
+    import os
+    from unpaired_image_captioning_amd.misc.dataloader import dataloader as dl
+    real_open = builtins.open
+
+    def fake(quota_text):
+        def _open(path, *a, **k):
+            if path == "/sys/fs/cgroup/cpu.max":
+                if quota_text is None:
+                    raise OSError("no cgroup v2")
+                p = tmp_path / "cpu.max"
+                p.write_text(quota_text)
+                return real_open(str(p), *a, **k)
+            if str(path).startswith("/sys/fs/cgroup/cpu/"):
+                raise OSError("no cgroup v1")
+            return real_open(path, *a, **k)
+        return _open
+    monkeypatch.setattr(os, "sched_getaffinity", lambda pid: set(range(64)))
+    monkeypatch.setattr(builtins, "open", fake("1600000 100000\n"))
+    assert dl.cpu_budget() == 16
+    monkeypatch.setattr(builtins, "open", fake("max 100000\n"))
+    assert dl.cpu_budget() == 64
+    monkeypatch.setattr(builtins, "open", fake("50000 100000\n"))
+    assert dl.cpu_budget() == 1
+    monkeypatch.setattr(builtins, "open", fake(None))
+    assert dl.cpu_budget() == 64
+    monkeypatch.setattr(os, "sched_getaffinity", lambda pid: set(range(4)))
+    monkeypatch.setattr(builtins, "open", fake("1600000 100000\n"))
+    assert dl.cpu_budget() == 4
+
+
+def test_store_att_uncompressed_tool_keeps_the_arrays_and_drops_the_deflate(tmp_path):
+    """tools/store_att_uncompressed.py: np.savez_compressed members -> stored ones, same arrays, readable by np.load (the
+    reference's loader) and by the library's reader; a second run finds nothing to do."""
+    import os
+    import subprocess
+    import sys
+    import zipfile
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    rng = np.random.default_rng(9)
+    arrays = {}
+    for i in range(5):
+        arrays[i] = np.abs(rng.standard_normal((int(rng.integers(5, 30)), 64))).astype(np.float32)
+        np.savez_compressed(str(tmp_path / ("%d" % i)), feat=arrays[i])
+    tool = os.path.join(root, "tools", "store_att_uncompressed.py")
+    out = subprocess.run([sys.executable, tool, str(tmp_path), "--workers", "2"], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0 and "5 of 5 files rewritten" in out.stdout, out.stdout + out.stderr
+    for i, a in arrays.items():
+        p = str(tmp_path / ("%d.npz" % i))
+        assert all(m.compress_type == zipfile.ZIP_STORED for m in zipfile.ZipFile(p).infolist())
+        assert np.array_equal(np.load(p)["feat"], a)
+    out = subprocess.run([sys.executable, tool, str(tmp_path)], capture_output=True, text=True, timeout=120)
+    assert "0 of 5 files rewritten" in out.stdout
