@@ -395,10 +395,12 @@ __device__ __forceinline__ void nmt_dec_ws_steps(const UicNmtDecParams& p, Ctx& 
            [&](int j, int g) { return w0[((c.wave * 4 + j) * 4 + g) * 64 + c.lane]; }, pv, cs0,
            p.cd[0] + (size_t)(t + 1) * BH, h0_new, hdrop0, (T*)p.gates_d[0] + (size_t)t * B * 4 * HH,
            two ? p.drop_p : 0.f, NMT_SITE_DEC(0, t));
-      if (t + 1 < p.Td) load_gx(t + 1);
     }
     FW_STAMP(1);
     group_arrive(c);
+    // (the next step's input-GEMM rows -- f32 from HBM -- are requested BEHIND the arrival: in front of it the arrival's
+    // s_waitcnt vmcnt(0), which is there for this phase's stores, waited for them too, every step)
+    load_gx(t + 1 < p.Td ? t + 1 : t);           // (unconditional: a load behind a run-time branch makes hipcc wait for it at the branch's join)
     if (!two && att_wg) att_load();
     if (!group_wait(c, (int*)c.smem)) return;
     FW_STAMP(2);
@@ -643,10 +645,14 @@ __device__ __forceinline__ void nmt_dec_bwd_steps(const UicNmtDecBwdParams& p, C
         const unsigned e = (unsigned)((c.rbegin + arow) * HH + k0);
         const float4 o0 = ao0[j], o1 = ao1[j];
         float g[8] = {o0.x, o0.y, o0.z, o0.w, o1.x, o1.y, o1.z, o1.w};
-        if (!last) {
+        {
+          // (loaded at the last step too -- from that step's own slab, a valid address -- and dropped by a select: behind `if (!last)` hipcc
+          // waited for each pair of loads at the branch's join, four L2 round trips in a row)
           const u32x4 f0 = bload<true>(rf, e * 4u, 0), f1 = bload<true>(rf, e * 4u + 16u, 0);
-          g[0] += __uint_as_float(f0.x); g[1] += __uint_as_float(f0.y); g[2] += __uint_as_float(f0.z); g[3] += __uint_as_float(f0.w);
-          g[4] += __uint_as_float(f1.x); g[5] += __uint_as_float(f1.y); g[6] += __uint_as_float(f1.z); g[7] += __uint_as_float(f1.w);
+          g[0] += last ? 0.f : __uint_as_float(f0.x); g[1] += last ? 0.f : __uint_as_float(f0.y);
+          g[2] += last ? 0.f : __uint_as_float(f0.z); g[3] += last ? 0.f : __uint_as_float(f0.w);
+          g[4] += last ? 0.f : __uint_as_float(f1.x); g[5] += last ? 0.f : __uint_as_float(f1.y);
+          g[6] += last ? 0.f : __uint_as_float(f1.z); g[7] += last ? 0.f : __uint_as_float(f1.w);
         }
         float op[8];
         uic_unpack<T>(aop[j], op);
@@ -762,7 +768,7 @@ __device__ __forceinline__ void nmt_dec_bwd_steps(const UicNmtDecBwdParams& p, C
     {  // ---- phase D2
       float out[2];
       dgemm((const T*)p.dg_d[0] + (size_t)t * B * 4 * HH + 4 * rb, [&](int j, int h) { return w0t[((c.wave * 16 + j) * 2 + h) * 64 + c.lane]; }, out,
-            [&] { if (PREA && t > 0) a_prefetch(t - 1); });
+            [&] { if (PREA) a_prefetch(t > 0 ? t - 1 : 0); });      // (PREA is a compile-time constant; no run-time branch around the loads)
       if (valid) st_x<SAFE>(p.dfeed_x + (size_t)t * BH + nnw + u, out[0]);
       dh0_rec = out[1];
     }
@@ -833,7 +839,9 @@ __device__ __forceinline__ void nmt_enc_fwd_steps(const UicNmtEncParams& p, Ctx&
     const int alive = p.nb[st];
     const u32x4 af = bload<true>(rsrc_of(xo + (size_t)prev * B * HH), (unsigned)(((c.rbegin + arow) * HH + dir * ENC_HD + c.wave * 32 + c.lq * 8) * 2), 0);
     const float pv[4] = {pvn[0], pvn[1], pvn[2], pvn[3]};
-    if (k + 1 < S) load_pv(k + 1);
+    // (unconditional, the last iteration re-reads its own row: behind `if (k + 1 < S)` hipcc waited for these HBM loads at the branch's
+    // join -- vmcnt(0) in front of the MFMAs below -- and the prefetch hid nothing)
+    load_pv(k + 1 < S ? k + 1 : k);
     f32x4 acc[4];
 #pragma unroll
     for (int g = 0; g < 4; ++g) acc[g] = Mma<T>::run(af, wf[g], f32x4{0.f, 0.f, 0.f, 0.f});
@@ -944,7 +952,9 @@ __device__ __forceinline__ void nmt_enc_bwd_steps(const UicNmtEncParams& p, Ctx&
       u32x4 af[4];
 #pragma unroll
       for (int j = 0; j < 4; ++j) af[j] = bload<true>(ra, (unsigned)(((c.rbegin + arow) * 4 * ENC_HD + (c.wave + NWAVE * j) * 32 + c.lq * 8) * 2), 0);
-      if (fin && k > 0) load_ops(k - 1, qn);
+      // (every wave, every iteration -- waves 4-7 and the last iteration load operands nobody uses: behind `if (fin && k > 0)` hipcc
+      // waited for these HBM loads at the branch's join, in front of the MFMAs)
+      load_ops(k > 0 ? k - 1 : 0, qn);
       f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int j = 0; j < 4; ++j) acc = Mma<T>::run(af[j], wt[j], acc);
