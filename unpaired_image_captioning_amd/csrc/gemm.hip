@@ -764,7 +764,8 @@ int launch_glds(const UicGemmParams& p, hipStream_t s) {
   const bool ring = false;
   (void)rounds;
 #else
-  const bool ring = (long)grid.x * grid.y * grid.z <= 192 && rounds >= 3 && !(p.flags & UIC_GEMM_NO_RING);
+  const long wgs = (long)grid.x * grid.y * grid.z;
+  const bool ring = ((wgs <= 192 && rounds >= 3) || (wgs <= 256 && rounds >= 32)) && !(p.flags & UIC_GEMM_NO_RING);   // (long K loops: also at one workgroup per CU)
 #endif
   if (ring) hipLaunchKernelGGL((uic_gemm_glds_kernel<T, 3>), grid, dim3(256), 98304, s, p);
   else hipLaunchKernelGGL((uic_gemm_glds_kernel<T, 2>), grid, dim3(256), 65536, s, p);
