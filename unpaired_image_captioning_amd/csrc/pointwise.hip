@@ -989,16 +989,21 @@ __global__ __launch_bounds__(NT) void xe_reg_kernel(const UicXeParams p, const f
   if (y < 0 || y >= p.V1) y = 0;
   float4 x[XE_RCH];
   float mx = -INFINITY;
+  // Every chunk of the row requested before the first is used, from a clamped address (round 6): behind `if (v < p.ldv)` hipcc
+  // waited for each load at its branch's join -- a thread's ten loads were ten HBM round trips in a row.
 #pragma unroll
   for (int i = 0; i < XE_RCH; ++i) {
     const int v = (threadIdx.x + i * NT) * 4;
-    x[i] = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
-    if (v < p.ldv) {
-      const float4 r = *(const float4*)(row + v);
-      x[i].x = v < p.V1 ? r.x : -INFINITY; x[i].y = v + 1 < p.V1 ? r.y : -INFINITY;
-      x[i].z = v + 2 < p.V1 ? r.z : -INFINITY; x[i].w = v + 3 < p.V1 ? r.w : -INFINITY;
-      if ((long)v <= y && y < (long)v + 4) s_y = y == v ? r.x : y == v + 1 ? r.y : y == v + 2 ? r.z : r.w;
-    }
+    x[i] = *(const float4*)(row + (v < p.ldv ? v : p.ldv - 4));
+  }
+#pragma unroll
+  for (int i = 0; i < XE_RCH; ++i) {
+    const int v = (threadIdx.x + i * NT) * 4;
+    const float4 r = x[i];
+    const bool in = v < p.ldv;
+    x[i].x = in && v < p.V1 ? r.x : -INFINITY; x[i].y = in && v + 1 < p.V1 ? r.y : -INFINITY;
+    x[i].z = in && v + 2 < p.V1 ? r.z : -INFINITY; x[i].w = in && v + 3 < p.V1 ? r.w : -INFINITY;
+    if (in && (long)v <= y && y < (long)v + 4) s_y = y == v ? r.x : y == v + 1 ? r.y : y == v + 2 ? r.z : r.w;
     mx = fmaxf(mx, fmaxf(fmaxf(x[i].x, x[i].y), fmaxf(x[i].z, x[i].w)));
   }
   mx = block_reduce_max(mx, s_buf);
@@ -1049,15 +1054,21 @@ __global__ __launch_bounds__(XE_WTH) void xe_reg_wide_kernel(const UicXeParams p
   float4 x[XE_WCH];
   float mx = -INFINITY, bv = -INFINITY;
   int bi = 0x7fffffff;
+  // (all thirteen chunks requested before the first is used, from clamped addresses: see xe_reg_kernel)
 #pragma unroll
   for (int i = 0; i < XE_WCH; ++i) {
     const int v = (threadIdx.x + i * XE_WTH) * 4;
-    x[i] = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
-    if (v < p.ldv) {
-      const float4 r = *(const float4*)(row + v);
-      x[i].x = v < p.V1 ? r.x : -INFINITY; x[i].y = v + 1 < p.V1 ? r.y : -INFINITY;
-      x[i].z = v + 2 < p.V1 ? r.z : -INFINITY; x[i].w = v + 3 < p.V1 ? r.w : -INFINITY;
-      if ((long)v <= y && y < (long)v + 4) s_y = y == v ? r.x : y == v + 1 ? r.y : y == v + 2 ? r.z : r.w;
+    x[i] = *(const float4*)(row + (v < p.ldv ? v : p.ldv - 4));
+  }
+#pragma unroll
+  for (int i = 0; i < XE_WCH; ++i) {
+    const int v = (threadIdx.x + i * XE_WTH) * 4;
+    {
+      const float4 r = x[i];
+      const bool in = v < p.ldv;
+      x[i].x = in && v < p.V1 ? r.x : -INFINITY; x[i].y = in && v + 1 < p.V1 ? r.y : -INFINITY;
+      x[i].z = in && v + 2 < p.V1 ? r.z : -INFINITY; x[i].w = in && v + 3 < p.V1 ? r.w : -INFINITY;
+      if (in && (long)v <= y && y < (long)v + 4) s_y = y == v ? r.x : y == v + 1 ? r.y : y == v + 2 ? r.z : r.w;
     }
     // (ascending index inside the thread: a later equal value does not replace the arg-max)
     if (x[i].x > bv) { bv = x[i].x; bi = v; }
