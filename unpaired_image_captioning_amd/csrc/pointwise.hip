@@ -1,6 +1,7 @@
 // HBM-bound helper kernels of the TopDown training / decoding path (gfx950).
 // Every kernel cites the reference lines whose arithmetic it carries.
 #include "uic_common.h"
+#include <type_traits>
 #include <string.h>
 #include <stdlib.h>
 #include "../../include/uic_hip.h"
@@ -394,6 +395,8 @@ __global__ __launch_bounds__(128) void embed_gather_kernel(const float* __restri
   const int cnt = min(EMB_CH, total - start);
   __shared__ int s_pos[EMB_CH];
   __shared__ int s_tok[EMB_CH];
+  __shared__ int s_b0[EMB_CH], s_b1[EMB_CH];          // the bucket bounds of entry j's token (round 6: fetched here, by the thread that
+                                                      // has the token, instead of one dependent load pair per run in the loop below)
   if (threadIdx.x < cnt) {
     const int pos = perm[start + threadIdx.x];
     const int t = pos / N, n = pos - t * N;
@@ -401,32 +404,39 @@ __global__ __launch_bounds__(128) void embed_gather_kernel(const float* __restri
     if (tok < 0 || tok >= V1) tok = 0;
     s_pos[threadIdx.x] = pos;
     s_tok[threadIdx.x] = (int)tok;
+    s_b0[threadIdx.x] = off[keybase + (int)tok];
+    s_b1[threadIdx.x] = off[keybase + (int)tok + 1];
   }
   __syncthreads();
   for (int c = threadIdx.x; c < E / 4; c += blockDim.x) {
+    // All 2 x EMB_CH loads of the lane requested before the first is used (round 6): entries behind `cnt` re-read the last valid
+    // row and are dropped by a select, the ReLU mask comes from a stand-in (the gradient itself) when there is no xt -- behind
+    // `if (j < cnt)` / `if (xt)` hipcc waited for every load at its branch's join: 32 dependent HBM round trips per workgroup.
     float4 g[EMB_CH];
+    typename std::conditional<sizeof(T) == 2, uint2, float4>::type a[EMB_CH];
+    const char* const xsrc = xt ? (const char*)xt : (const char*)dxt;
+    const size_t xscale = xt ? sizeof(T) : sizeof(float);
 #pragma unroll
     for (int j = 0; j < EMB_CH; ++j) {
-      g[j] = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (j < cnt) {
-        const size_t o = (size_t)s_pos[j] * E + c * 4;
-        g[j] = *(const float4*)(dxt + o);
-        if (xt) {
-          float a4[4];
-          if constexpr (sizeof(T) == 2) {
-            const uint2 q = *(const uint2*)(xt + o);            // 4 bf16 in one 8-byte load
-            a4[0] = __uint_as_float(q.x << 16); a4[1] = __uint_as_float(q.x & 0xffff0000u);
-            a4[2] = __uint_as_float(q.y << 16); a4[3] = __uint_as_float(q.y & 0xffff0000u);
-          } else {
-            const float4 q = *(const float4*)(xt + o);
-            a4[0] = q.x; a4[1] = q.y; a4[2] = q.z; a4[3] = q.w;
-          }
-          if (!(a4[0] > 0.f)) g[j].x = 0.f;
-          if (!(a4[1] > 0.f)) g[j].y = 0.f;
-          if (!(a4[2] > 0.f)) g[j].z = 0.f;
-          if (!(a4[3] > 0.f)) g[j].w = 0.f;
-        }
+      const size_t o = (size_t)s_pos[j < cnt ? j : cnt - 1] * E + c * 4;
+      g[j] = *(const float4*)(dxt + o);
+      if constexpr (sizeof(T) == 2) a[j] = *(const uint2*)(xsrc + o * xscale);        // 4 bf16 in one 8-byte load
+      else a[j] = *(const float4*)(xsrc + o * xscale);
+    }
+#pragma unroll
+    for (int j = 0; j < EMB_CH; ++j) {
+      float a4[4];
+      if constexpr (sizeof(T) == 2) {
+        a4[0] = __uint_as_float(a[j].x << 16); a4[1] = __uint_as_float(a[j].x & 0xffff0000u);
+        a4[2] = __uint_as_float(a[j].y << 16); a4[3] = __uint_as_float(a[j].y & 0xffff0000u);
+      } else {
+        a4[0] = a[j].x; a4[1] = a[j].y; a4[2] = a[j].z; a4[3] = a[j].w;
       }
+      const bool live = j < cnt, relu = xt != nullptr;
+      g[j].x = live && !(relu && !(a4[0] > 0.f)) ? g[j].x : 0.f;
+      g[j].y = live && !(relu && !(a4[1] > 0.f)) ? g[j].y : 0.f;
+      g[j].z = live && !(relu && !(a4[2] > 0.f)) ? g[j].z : 0.f;
+      g[j].w = live && !(relu && !(a4[3] > 0.f)) ? g[j].w : 0.f;
     }
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
@@ -436,7 +446,7 @@ __global__ __launch_bounds__(128) void embed_gather_kernel(const float* __restri
         const bool last = j + 1 == cnt || s_tok[j + 1] != s_tok[j];       // uniform over the workgroup
         if (last) {
           if (s_tok[j] != skip_token) {
-            const int b0 = off[keybase + s_tok[j]], b1 = off[keybase + s_tok[j] + 1];
+            const int b0 = s_b0[j], b1 = s_b1[j];
             if (b0 >= start && b1 <= start + cnt) {                        // the whole bucket: this workgroup owns the table row
               float* o = dtable + (size_t)s_tok[j] * E + c * 4;
               float4 v = make_float4(acc.x * inv_keep, acc.y * inv_keep, acc.z * inv_keep, acc.w * inv_keep);
