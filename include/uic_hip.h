@@ -329,7 +329,8 @@ int uic_topdown_logprobs_state(const uic_topdown_dims* d, const uic_topdown_weig
                                float* logprobs, float* h_out, float* c_out, void* stream);
 
 /* Address of a named activation inside the workspace (tests / debugging); NULL if unknown.
- * Names: fc_embed att_embed p_att xt gx h_att h_lang c_att c_lang att_h alpha ctx logits dlogits ... */
+ * Names: fc_embed att_embed p_att e_att xt gx h_att h_lang c_att c_lang att_h alpha ctx logits dlogits ...  (e_att, bf16 workspaces
+ * only: e^{2 p_att} of the rounded p_att, what the persistent training recurrence's attention reads -- tanh(p + h) = 1 - 2 / (1 + e^{2p} e^{2h})) */
 void* uic_topdown_workspace_ptr(const uic_topdown_dims* d, void* workspace, const char* name);
 
 /* ---- FC captioner: the `fc` caption model = FCModel_NMT + maxout LSTMCore (P/models/FCModel_NMT.py:21-217,
