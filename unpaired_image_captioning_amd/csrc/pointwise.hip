@@ -997,6 +997,17 @@ __global__ __launch_bounds__(NT) void xe_reg_kernel(const UicXeParams p, const f
   long y = p.target[(size_t)n * p.ldtarget + p.target_col0 + t];
   const float mk = p.mask ? p.mask[(size_t)n * p.ldmask + p.mask_col0 + t] : 0.f;
   if (y < 0 || y >= p.V1) y = 0;
+  if (mk == 0.f && !p.grad_scale) {
+    // a position behind its caption's end (a quarter of the benchmark's, a third of COCO's): loss 0 x (.), d logits = 0 x softmax - 0 --
+    // exact zeros whatever the logits are, so the row is not read (round 6; uniform over the workgroup)
+    if (threadIdx.x == 0) p.row_loss[m] = 0.f;
+    T* d = dlogits + (size_t)m * p.ldv;
+    for (int v = threadIdx.x * 4; v < p.ldv; v += NT * 4) {
+      if constexpr (sizeof(T) == 2) *(uint2*)(d + v) = make_uint2(0u, 0u);
+      else *(float4*)(d + v) = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    return;
+  }
   float4 x[XE_RCH];
   float mx = -INFINITY;
   // Every chunk of the row requested before the first is used, from a clamped address (round 6): behind `if (v < p.ldv)` hipcc
@@ -1061,6 +1072,15 @@ __global__ __launch_bounds__(XE_WTH) void xe_reg_wide_kernel(const UicXeParams p
   const long y0 = p.target[(size_t)n * p.ldtarget + p.target_col0 + t];
   const float mk = p.mask ? p.mask[(size_t)n * p.ldmask + p.mask_col0 + t] : 0.f;
   const long y = y0 < 0 || y0 >= p.V1 ? 0 : y0;
+  if (mk == 0.f && !p.grad_scale && !(p.score_stats && y0 != 0)) {      // (a padded target position: see xe_reg_kernel)
+    if (threadIdx.x == 0) p.row_loss[m] = 0.f;
+    T* d = dlogits + (size_t)m * p.ldv;
+    for (int v = threadIdx.x * 4; v < p.ldv; v += XE_WTH * 4) {
+      if constexpr (sizeof(T) == 2) *(uint2*)(d + v) = make_uint2(0u, 0u);
+      else *(float4*)(d + v) = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    return;
+  }
   float4 x[XE_WCH];
   float mx = -INFINITY, bv = -INFINITY;
   int bi = 0x7fffffff;
