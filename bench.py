@@ -16,6 +16,7 @@ recurrence kernel; `roofline_attention_step` = the stand-alone attention kernel,
 GEMM) and, at N=1, `cpu_baseline` (the CPU oracle timed on this host's cores).
 """
 import argparse
+import gc
 import json
 import os
 import sys
@@ -290,6 +291,8 @@ def main():
     ap.add_argument("--early-grads", action="store_true",
                     help="UIC_REC_EARLY_GRADS (opt.early_grads): the order of the gradient work that has 62 %% of the gradient bytes final "
                          "0.18 ms before the step ends, for a step that is 4 %% longer on its own -- for N > 1 experiments; off for the headline")
+    ap.add_argument("--all-positions", action="store_true", help="do not hand the step the list of unmasked positions (uic_topdown_batch.live_rows): "
+                    "the logit layer and the criterion then compute the positions behind the captions' ends too (exact zeros; round 5's behaviour)")
     ap.add_argument("--long-run", type=int, default=200, help="steps of the secondary `long_run` figure (0: skip); the timed region "
                     "of the default command is 65 ms -- the boxes of the pool differ by more than a round's progress")
     ap.add_argument("--rows-per-gpu-probe", type=int, default=0,
@@ -356,6 +359,11 @@ def main():
     T = c["L"] + 1
     t_run = tr.i2t_model._steps_to_run(batch["labels"])
     den_local = float(batch["masks"][:, 1:T + 1].sum().item())
+    # The list of unmasked (step, row) positions, made from the masks on the host like the step count and the mask sum above (the
+    # loader builds the masks there; Trainer.to_device attaches the list to every real batch): the logit layer and the criterion
+    # skip the positions behind the captions' ends.  --all-positions computes them all (their loss and gradient are exact zeros).
+    if not args.all_positions:
+        tr.attach_live(batch)
 
     def barrier():
         torch.cuda.synchronize()
@@ -369,6 +377,11 @@ def main():
         # does with next_data=)
         for _ in range(args.warmup):
             tr.train_device_batch(bt, t_run, den_local, den_local)
+        # (a full pass of Python's cyclic garbage collector over the interpreter's ~1e6 objects takes ~40 ms on these hosts -- 15 steps --
+        # and falls wherever the allocation count happens to trip it: collect now and move what is alive out of the collector's
+        # way, as a training loop that cares does once after start-up, instead of timing the collector)
+        gc.collect()
+        gc.freeze()
         barrier()
         t0 = time.perf_counter()
         for _ in range(args.steps):
@@ -408,7 +421,9 @@ def main():
         # What one rank of a STRONG-scaling run (640 rows over 8 GPUs) would do per step: the same step on rows_per_gpu_probe
         # caption rows -- a latency chain at that size -- next to the host time of enqueueing it (a secondary key, never `value`).
         n_img_s = max(1, args.rows_per_gpu_probe // c["S"])
-        small = {k: v[:n_img_s * c["S"]].contiguous() for k, v in batch.items()}
+        small = {k: v[:n_img_s * c["S"]].contiguous() for k, v in batch.items() if not k.startswith("live_")}
+        if not args.all_positions:
+            tr.attach_live(small)
         den_s = float(small["masks"][:, 1:T + 1].sum().item())
         for _ in range(5):
             tr.train_device_batch(small, t_run, den_s)
@@ -503,7 +518,9 @@ def main():
             "config": {"workload": "BASELINE configs[1]: TopDown attention LSTM, 128 images x 5 captions = 640 caption "
                                    "rows per GPU, R=36, D=2048, H=E=A=512, V+1=9488, 17 decode steps, dropout 0.5, "
                                    "XE loss + BPTT + Adam", "rows_per_gpu": N, "parallelism": "dp%d" % world, "use_bn": args.use_bn, "att_feat_size": Datt,
-                       "features": args.features, "early_grads": bool(args.early_grads)},
+                       "features": args.features, "early_grads": bool(args.early_grads),
+                       "positions": "all" if args.all_positions else "unmasked (%d of %d; the list is made on the host from the masks, outside the timed region)"
+                       % (int(batch["live_count"][:t_run].sum()), t_run * N)},
             "final_loss": round(loss_val, 4),
             "rccl_ranks": dist.get_world_size() if (world > 1 and dist.get_backend() == "nccl") else (1 if world == 1 else 0),
             "roofline_mfma": gemm_roofline(dtype_id, args.dtype),

@@ -171,7 +171,23 @@ typedef struct uic_topdown_batch {
      encoder in front of the captioner (BASELINE configs[4]'s scene-graph GCN, uic_gcn_backward's `dout`): */
   float* d_att_feats;       /* [N, R, D]  ([N / seq_per_img, R, D]); padded regions get zeros.  Needs dims.use_bn == 0 */
   float* d_fc_feats;        /* [N, Dfc]   ([N / seq_per_img, Dfc]) */
+  /* Optional list of the LIVE positions of the batch, for uic_topdown_xe_train_step (NULL = every position is computed, and
+     positions with mask 0 contribute exact zeros -- the same result).  A position (t, n) -- decode step t, row n -- is live
+     when masks[n, 1 + t] != 0; positions behind a caption's end (LanguageModelCriterion multiplies them by 0,
+     P/misc/utils.py:62-73) are a quarter of the benchmark's batch and a third of COCO's.  With the list the logit layer, the
+     criterion and their gradients run over the listed rows only.
+       live_rows   DEVICE int32 [roundup(sum(live_count), 128)]: t * N + n of every live position, step-major (all of step 0,
+                   then step 1, ...; any order within a step); the tail up to the multiple of 128 holds -1
+       live_count  HOST int32 [t_run]: the number of entries of each step
+     The caller builds both from the masks it already holds on the host (DataLoader.get_batch makes the masks there).  A list that
+     omits a position whose mask is not zero drops that position's loss and gradient; listing a masked position is harmless.
+     Ignored (every position computed) under scheduled sampling, with grad_scale, with logit_layers > 1, without masks, when a row
+     of hidden units is not a multiple of 16 bytes, when t_run >
+     UIC_MAX_LIVE_STEPS, or when a count is outside [0, N]. */
+  const int32_t* live_rows;
+  const int32_t* live_count;
 } uic_topdown_batch;
+#define UIC_MAX_LIVE_STEPS 64
 
 /* Sizes (bytes) of the two caller-allocated arenas. */
 size_t uic_topdown_workspace_bytes(const uic_topdown_dims* d);

@@ -13,6 +13,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--steps", type=int, default=30)
 ap.add_argument("--dtype", default="bf16")
 ap.add_argument("--early", action="store_true", help="UIC_REC_EARLY_GRADS: the order of the gradient work that finishes most bytes early")
+ap.add_argument("--live", action="store_true", help="hand the step the list of unmasked positions (uic_topdown_batch.live_rows)")
 args = ap.parse_args()
 
 import torch
@@ -28,6 +29,8 @@ model.train()
 if args.early:
     model.engine.recurrence |= L.REC_EARLY_GRADS
 batch = {k: v.cuda() for k, v in synthetic_batch(c["n_img"], c["S"], c["R"], c["D"], c["V"], c["L"], seed=1).items()}
+if args.live:
+    trainer.Trainer.attach_live(batch)
 real = lib.uic_topdown_xe_train_step
 acc = {"n": 0, "t": 0.0}
 

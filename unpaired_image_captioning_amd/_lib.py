@@ -206,7 +206,8 @@ class Batch(C.Structure):
                 ("labels", C.c_void_p), ("ld_labels", C.c_int32),
                 ("masks", C.c_void_p), ("ld_masks", C.c_int32),
                 ("grad_scale", C.c_void_p), ("ld_grad_scale", C.c_int32), ("ss_prob", C.c_float),
-                ("d_att_feats", C.c_void_p), ("d_fc_feats", C.c_void_p)]
+                ("d_att_feats", C.c_void_p), ("d_fc_feats", C.c_void_p),
+                ("live_rows", C.c_void_p), ("live_count", C.POINTER(C.c_int32))]
 
 
 _SIGS = {

@@ -801,7 +801,10 @@ template <typename T>
 __global__ __launch_bounds__(NT) void xe_kernel(const UicXeParams p, const float* __restrict__ logits, T* __restrict__ dlogits) {
   __shared__ float s_buf[NT / 64];
   const int m = blockIdx.x;
-  const int t = m / p.N, n = m - t * p.N;
+  const int mr = p.row_map ? p.row_map[m] : m;       // (row_map: the rows are a compacted list of (step, row) positions;
+  const bool pad = p.row_map && (unsigned)mr >= (unsigned)p.row_map_limit;   //  -1 (or out of range) = a padding row: zero gradient, no loss entry)
+  const int mo = pad ? 0 : mr;
+  const int t = mo / p.N, n = mo - t * p.N;
   const float* row = logits + (size_t)m * p.ldv;
   float mx = -INFINITY;
   for (int v = threadIdx.x; v < p.V1; v += NT) mx = fmaxf(mx, row[v]);
@@ -814,7 +817,7 @@ __global__ __launch_bounds__(NT) void xe_kernel(const UicXeParams p, const float
   float mk = 0.f;
   if (p.target) {
     y = p.target[(size_t)n * p.ldtarget + p.target_col0 + t];
-    mk = p.mask ? p.mask[(size_t)n * p.ldmask + p.mask_col0 + t] : 0.f;
+    mk = p.mask && !pad ? p.mask[(size_t)n * p.ldmask + p.mask_col0 + t] : 0.f;
     if (p.score_stats) {
       __shared__ float s_bv[NT / 64];
       __shared__ int s_bi[NT / 64];
@@ -825,7 +828,7 @@ __global__ __launch_bounds__(NT) void xe_kernel(const UicXeParams p, const float
       }
     }
     if (y < 0 || y >= p.V1) y = 0;
-    if (threadIdx.x == 0) p.row_loss[m] = -(row[y] - lse) * mk;
+    if (threadIdx.x == 0 && !pad) p.row_loss[m] = -(row[y] - lse) * mk;
   }
   if (p.logprobs) {
     float* lp = p.logprobs + (size_t)n * p.lp_row_stride + (size_t)t * p.lp_step_stride;
@@ -851,7 +854,10 @@ __global__ __launch_bounds__(NT) void xe_big_kernel(const UicXeParams p, const f
   __shared__ float s_m[NT / 64], s_s[NT / 64], s_bv[NT / 64];
   __shared__ int s_bi[NT / 64];
   const int m = blockIdx.x;
-  const int t = m / p.N, n = m - t * p.N;
+  const int mr = p.row_map ? p.row_map[m] : m;       // (row_map: the rows are a compacted list of (step, row) positions;
+  const bool pad = p.row_map && (unsigned)mr >= (unsigned)p.row_map_limit;   //  -1 (or out of range) = a padding row: zero gradient, no loss entry)
+  const int mo = pad ? 0 : mr;
+  const int t = mo / p.N, n = mo - t * p.N;
   const float* row = logits + (size_t)m * p.ldv;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   float mx = -INFINITY, sum = 0.f, bv = -INFINITY;
@@ -887,13 +893,13 @@ __global__ __launch_bounds__(NT) void xe_big_kernel(const UicXeParams p, const f
   float mk = 0.f;
   if (p.target) {
     y = p.target[(size_t)n * p.ldtarget + p.target_col0 + t];
-    mk = p.mask ? p.mask[(size_t)n * p.ldmask + p.mask_col0 + t] : 0.f;
+    mk = p.mask && !pad ? p.mask[(size_t)n * p.ldmask + p.mask_col0 + t] : 0.f;
     if (threadIdx.x == 0 && p.score_stats && y != 0) {
       atomicAdd(&p.score_stats[1], 1);
       if (bi == (int)y) atomicAdd(&p.score_stats[0], 1);
     }
     if (y < 0 || y >= p.V1) y = 0;
-    if (threadIdx.x == 0) p.row_loss[m] = -(row[y] - lse) * mk;
+    if (threadIdx.x == 0 && !pad) p.row_loss[m] = -(row[y] - lse) * mk;
   }
   if (p.logprobs) {
     float* lp = p.logprobs + (size_t)n * p.lp_row_stride + (size_t)t * p.lp_step_stride;
@@ -927,7 +933,10 @@ __global__ __launch_bounds__(NT) void xe_lds_kernel(const UicXeParams p, const f
   extern __shared__ __attribute__((aligned(16))) float s_row[];
   __shared__ float s_buf[NT / 64];
   const int m = blockIdx.x;
-  const int t = m / p.N, n = m - t * p.N;
+  const int mr = p.row_map ? p.row_map[m] : m;       // (row_map: the rows are a compacted list of (step, row) positions;
+  const bool pad = p.row_map && (unsigned)mr >= (unsigned)p.row_map_limit;   //  -1 (or out of range) = a padding row: zero gradient, no loss entry)
+  const int mo = pad ? 0 : mr;
+  const int t = mo / p.N, n = mo - t * p.N;
   const float* row = logits + (size_t)m * p.ldv;
   float mx = -INFINITY;
   for (int v = threadIdx.x * 4; v < p.ldv; v += NT * 4) {
@@ -947,7 +956,7 @@ __global__ __launch_bounds__(NT) void xe_lds_kernel(const UicXeParams p, const f
   float mk = 0.f;
   if (p.target) {
     y = p.target[(size_t)n * p.ldtarget + p.target_col0 + t];
-    mk = p.mask ? p.mask[(size_t)n * p.ldmask + p.mask_col0 + t] : 0.f;
+    mk = p.mask && !pad ? p.mask[(size_t)n * p.ldmask + p.mask_col0 + t] : 0.f;
     if (p.score_stats) {
       __shared__ float s_bv[NT / 64];
       __shared__ int s_bi[NT / 64];
@@ -958,7 +967,7 @@ __global__ __launch_bounds__(NT) void xe_lds_kernel(const UicXeParams p, const f
       }
     }
     if (y < 0 || y >= p.V1) y = 0;
-    if (threadIdx.x == 0) p.row_loss[m] = -(s_row[y] - lse) * mk;
+    if (threadIdx.x == 0 && !pad) p.row_loss[m] = -(s_row[y] - lse) * mk;
   }
   if (p.logprobs) {
     float* lp = p.logprobs + (size_t)n * p.lp_row_stride + (size_t)t * p.lp_step_stride;
@@ -992,15 +1001,18 @@ __global__ __launch_bounds__(NT) void xe_reg_kernel(const UicXeParams p, const f
   __shared__ float s_buf[NT / 64];
   __shared__ float s_y;
   const int m = blockIdx.x;
-  const int t = m / p.N, n = m - t * p.N;
+  const int mr = p.row_map ? p.row_map[m] : m;       // (row_map: the rows are a compacted list of (step, row) positions;
+  const bool pad = p.row_map && (unsigned)mr >= (unsigned)p.row_map_limit;   //  -1 (or out of range) = a padding row: zero gradient, no loss entry)
+  const int mo = pad ? 0 : mr;
+  const int t = mo / p.N, n = mo - t * p.N;
   const float* row = logits + (size_t)m * p.ldv;
   long y = p.target[(size_t)n * p.ldtarget + p.target_col0 + t];
-  const float mk = p.mask ? p.mask[(size_t)n * p.ldmask + p.mask_col0 + t] : 0.f;
+  const float mk = p.mask && !pad ? p.mask[(size_t)n * p.ldmask + p.mask_col0 + t] : 0.f;
   if (y < 0 || y >= p.V1) y = 0;
   if (mk == 0.f && !p.grad_scale) {
     // a position behind its caption's end (a quarter of the benchmark's, a third of COCO's): loss 0 x (.), d logits = 0 x softmax - 0 --
     // exact zeros whatever the logits are, so the row is not read (round 6; uniform over the workgroup)
-    if (threadIdx.x == 0) p.row_loss[m] = 0.f;
+    if (threadIdx.x == 0 && !pad) p.row_loss[m] = 0.f;
     T* d = dlogits + (size_t)m * p.ldv;
     for (int v = threadIdx.x * 4; v < p.ldv; v += NT * 4) {
       if constexpr (sizeof(T) == 2) *(uint2*)(d + v) = make_uint2(0u, 0u);
@@ -1036,7 +1048,7 @@ __global__ __launch_bounds__(NT) void xe_reg_kernel(const UicXeParams p, const f
   }
   sum = block_reduce_sum(sum, s_buf);       // (its barriers also publish s_y)
   const float lse = mx + logf(sum);
-  if (threadIdx.x == 0) p.row_loss[m] = -(s_y - lse) * mk;
+  if (threadIdx.x == 0 && !pad) p.row_loss[m] = -(s_y - lse) * mk;
   const float sc = p.grad_scale ? p.grad_scale[(size_t)n * p.ldscale + p.scale_col0 + t] : mk * p.inv_den[0];
   const float k = sc / sum;
   T* d = dlogits + (size_t)m * p.ldv;
@@ -1066,14 +1078,17 @@ __global__ __launch_bounds__(XE_WTH) void xe_reg_wide_kernel(const UicXeParams p
   __shared__ int s_bi[XE_WTH / 64];
   __shared__ float s_y;
   const int m = blockIdx.x;
-  const int t = m / p.N, n = m - t * p.N;
+  const int mr = p.row_map ? p.row_map[m] : m;       // (row_map: the rows are a compacted list of (step, row) positions;
+  const bool pad = p.row_map && (unsigned)mr >= (unsigned)p.row_map_limit;   //  -1 (or out of range) = a padding row: zero gradient, no loss entry)
+  const int mo = pad ? 0 : mr;
+  const int t = mo / p.N, n = mo - t * p.N;
   const float* row = logits + (size_t)m * p.ldv;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const long y0 = p.target[(size_t)n * p.ldtarget + p.target_col0 + t];
-  const float mk = p.mask ? p.mask[(size_t)n * p.ldmask + p.mask_col0 + t] : 0.f;
+  const float mk = p.mask && !pad ? p.mask[(size_t)n * p.ldmask + p.mask_col0 + t] : 0.f;
   const long y = y0 < 0 || y0 >= p.V1 ? 0 : y0;
   if (mk == 0.f && !p.grad_scale && !(p.score_stats && y0 != 0)) {      // (a padded target position: see xe_reg_kernel)
-    if (threadIdx.x == 0) p.row_loss[m] = 0.f;
+    if (threadIdx.x == 0 && !pad) p.row_loss[m] = 0.f;
     T* d = dlogits + (size_t)m * p.ldv;
     for (int v = threadIdx.x * 4; v < p.ldv; v += XE_WTH * 4) {
       if constexpr (sizeof(T) == 2) *(uint2*)(d + v) = make_uint2(0u, 0u);
@@ -1999,11 +2014,51 @@ int uic_lstm_bwd_launch(const UicLstmBwdParams& p, hipStream_t s) {
   UIC_LAUNCH_CHECK("lstm_bwd");
   return UIC_OK;
 }
+namespace {
+// out[m, :] = src[map[m], :] (rows of `chunks` 16-byte pieces) for m < M; rows [M, Mpad) of out are cleared
+__global__ __launch_bounds__(256) void gather_rows_kernel(const uint4* __restrict__ src, const int* __restrict__ map, uint4* __restrict__ out, int M, int Mpad,
+                                                          int chunks, int limit) {
+  const size_t total = (size_t)Mpad * chunks, stride = (size_t)gridDim.x * blockDim.x;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+    const int m = (int)(i / chunks), c = (int)(i - (size_t)m * chunks);
+    const int r = m < M ? map[m] : -1;
+    out[i] = (unsigned)r < (unsigned)limit ? src[(size_t)r * chunks + c] : make_uint4(0u, 0u, 0u, 0u);
+  }
+}
+// dst[map[m], :] = src[m, :] for m < M
+__global__ __launch_bounds__(256) void scatter_rows_kernel(const uint4* __restrict__ src, const int* __restrict__ map, uint4* __restrict__ dst, int M, int chunks, int limit) {
+  const size_t total = (size_t)M * chunks, stride = (size_t)gridDim.x * blockDim.x;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+    const int m = (int)(i / chunks), c = (int)(i - (size_t)m * chunks);
+    const int r = map[m];
+    if ((unsigned)r < (unsigned)limit) dst[(size_t)r * chunks + c] = src[i];
+  }
+}
+}  // namespace
+int uic_gather_rows_launch(const void* src, const int* map, int src_rows, void* out, int M, int Mpad, size_t row_bytes, hipStream_t s) {
+  UIC_REQUIRE(row_bytes % 16 == 0 && ((uintptr_t)src & 15) == 0 && ((uintptr_t)out & 15) == 0 && Mpad >= M && M >= 0, "gather_rows: bad arguments");
+  if (Mpad == 0) return UIC_OK;
+  const int chunks = (int)(row_bytes / 16);
+  hipLaunchKernelGGL(gather_rows_kernel, dim3(grid_for((size_t)Mpad * chunks, 256)), dim3(256), 0, s, (const uint4*)src, map, (uint4*)out, M, Mpad, chunks, src_rows);
+  UIC_LAUNCH_CHECK("gather_rows");
+  return UIC_OK;
+}
+int uic_scatter_rows_launch(const void* src, const int* map, void* dst, int dst_rows, int M, size_t row_bytes, hipStream_t s) {
+  UIC_REQUIRE(row_bytes % 16 == 0 && ((uintptr_t)src & 15) == 0 && ((uintptr_t)dst & 15) == 0 && M >= 0, "scatter_rows: bad arguments");
+  if (M == 0) return UIC_OK;
+  const int chunks = (int)(row_bytes / 16);
+  hipLaunchKernelGGL(scatter_rows_kernel, dim3(grid_for((size_t)M * chunks, 256)), dim3(256), 0, s, (const uint4*)src, map, (uint4*)dst, M, chunks, dst_rows);
+  UIC_LAUNCH_CHECK("scatter_rows");
+  return UIC_OK;
+}
+
 int uic_xe_launch(const UicXeParams& p, hipStream_t s) {
   UIC_REQUIRE(p.logits && p.N > 0, "xe: null logits or N=0");
   UIC_REQUIRE(!p.write_grad || (p.target && ((p.mask && p.inv_den) || p.grad_scale)), "xe: gradient needs target and mask+inv_den or grad_scale");
   UIC_REQUIRE(!p.write_grad || p.dlogits, "xe: null dlogits");
   UIC_REQUIRE(!p.target || p.row_loss, "xe: null row_loss");
+  UIC_REQUIRE(!p.row_map || (p.write_grad && p.mask && !p.grad_scale && !p.score_stats && !p.logprobs),
+              "xe: a row list goes with the masked criterion only (target, mask, gradient; no per-position scale, statistics or log-probabilities)");
   if (p.M == 0) return UIC_OK;
   const size_t row_bytes = (size_t)p.ldv * 4;
   if (p.dtype == UIC_BF16 && p.ldv % 4 == 0 && p.ldv <= XE_RCH * NT * 4 && ((uintptr_t)p.logits & 15) == 0 && p.write_grad && p.target &&

@@ -51,6 +51,8 @@ struct Layout {
   void* gates1; void* gates2;
   float* atth_all; float* alpha_all; void* ctx_all; void* hdrop_all;
   float* logits; void* dlogits; float* row_loss; float* scalars;
+  void* hc; float* dhc;                         // live-position logit layer (uic_topdown_batch.live_rows): the live rows of hdrop, operand dtype
+                                                // [T N + 128, H]; their d hdrop, f32 [T N, H]
   void* lh[UIC_MAX_LOGIT_LAYERS - 1];       // logit_layers > 1: dropout(relu(hidden logit block l)) [T*N, H]
   void* dlh_pre[UIC_MAX_LOGIT_LAYERS - 1];  // its pre-activation gradient [T*N, H] (operand dtype), kept for the weight gradient
   float* dlh;                               // gradient flowing between the logit blocks [T*N, H] f32
@@ -124,8 +126,9 @@ Layout make_layout(const uic_topdown_dims& d, void* ws) {
   L.alpha_all = (float*)b.take(M * R * 4);
   L.ctx_all = b.take(M * H * S);
   L.hdrop_all = b.take(M * H * S);
-  L.logits = (float*)b.take(M * V1p * 4);
-  L.dlogits = b.take(M * V1p * S);
+  // (+128 rows: the live-position list is padded to whole 128-row tiles, uic_topdown_batch.live_rows)
+  L.logits = (float*)b.take((M + 128) * V1p * 4);
+  L.dlogits = b.take((M + 128) * V1p * S);
   L.row_loss = (float*)b.take(M * 4);
   for (int l = 0; l + 1 < d.logit_layers; ++l) {
     L.lh[l] = b.take(M * H * S);
@@ -135,6 +138,8 @@ Layout make_layout(const uic_topdown_dims& d, void* ws) {
   if (d.logit_layers > 1) L.dlh = (float*)b.take(M * H * 4);
   L.scalars = (float*)b.take(64);
   L.dhdrop = (float*)b.take(M * H * 4);
+  L.hc = b.take((M + 128) * H * S);
+  L.dhc = (float*)b.take((M + 128) * H * 4);
   L.dx2_all = (float*)b.take(M * 3 * H * 4);
   L.dx1 = (float*)b.take(N * 2 * H * 4);
   L.dc_att = (float*)b.take(N * H * 4);
@@ -168,8 +173,8 @@ Layout make_layout(const uic_topdown_dims& d, void* ws) {
   L.colscratch_floats = 128 * maxcols;
   L.colscratch = (float*)b.take(L.colscratch_floats * 4);
   L.small = (float*)b.take((A + 8) * 4);
-  L.tLA = b.take((d.logit_layers > 1 && H > V1 ? H : V1) * Mp * S);   // dlogits^T [V1, M]; hidden logit blocks: d pre^T [H, M]
-  L.tLB = b.take(H * Mp * S);
+  L.tLA = b.take((d.logit_layers > 1 && H > V1 ? H : V1) * (Mp + 128) * S);   // dlogits^T [V1, M]; hidden logit blocks: d pre^T [H, M]
+  L.tLB = b.take(H * (Mp + 128) * S);
   L.colscratchL = (float*)b.take(L.colscratch_floats * 4);
   {
     const size_t Kc = rup8((size_t)WG_CHUNK * N);
@@ -821,6 +826,28 @@ struct Step {
   // scheduled sampling (AttModel.py:130-143) is active in train mode only
   bool ss_on() const { return (training & 1) && b->ss_prob > 0.f; }
   bool embed_prepared = false;   // the fused step bucketed the tokens (uic_embed_bwd_sorted_prepare) while the side stream was idle
+  // Live-position logit layer (round 6).  uic_topdown_batch.live_rows / live_count list the (step, row) positions whose mask is not
+  // zero; positions behind a caption's end -- a quarter of the benchmark's, a third of COCO's -- have loss 0 and gradient 0, so the
+  // logit layer (GEMM, criterion, d hdrop, its weight gradient) runs over the listed rows only: gathered into L.hc, logits / d
+  // logits / d hdrop compact, d hdrop scattered back into the (zeroed) step-major buffer the BPTT loop reads.
+  bool compact = false;
+  const int32_t* live_rows = nullptr;
+  int live_off[UIC_MAX_LIVE_STEPS + 1];
+  int live_total() const { return live_off[t_run]; }
+  int live_pad() const { return (live_total() + 127) & ~127; }
+  void init_live() {
+    compact = false;
+    if (!b->live_rows || !b->live_count || !b->masks || t_run > UIC_MAX_LIVE_STEPS || ss_on() || b->grad_scale || nlh() != 0) return;
+    if (((size_t)H * uic_dtype_size(dt)) % 16 != 0) return;     // (rows move as 16-byte pieces)
+    live_off[0] = 0;
+    for (int t = 0; t < t_run; ++t) {
+      const int c = b->live_count[t];
+      if (c < 0 || c > N) return;                       // (not a list of this batch: the plain path)
+      live_off[t + 1] = live_off[t] + c;
+    }
+    live_rows = b->live_rows;
+    compact = true;
+  }
   int embed_split = 0;           // > 0: ... into the halves [0, embed_split) / [embed_split, t_run) of the decode steps (embed_grad)
   // d.recurrence & UIC_REC_EARLY_GRADS (fused step): the order of the gradient work a data-parallel caller may prefer -- see
   // uic_topdown_xe_train_step
@@ -1027,7 +1054,23 @@ struct Step {
   // logit_layers = n > 1 (AttModel.py:90-91): n - 1 blocks Linear(H, H) + ReLU + Dropout(0.5) in front of the vocabulary layer
   int nlh() const { return d.logit_layers > 1 ? d.logit_layers - 1 : 0; }
   const void* logit_in_all() const { return nlh() ? L.lh[nlh() - 1] : L.hdrop_all; }
+  // rows [c0, c0 + rows) of the live list = the live positions of decode steps [t0, t1); the list's last chunk carries the padding
+  // rows up to a multiple of 128 (zero operand rows, zero gradient rows: the weight-gradient GEMM's K runs over whole tiles)
+  // d hdrop of the positions the list leaves out is zero: the whole buffer is cleared before the chunks scatter into it
+  int live_begin(hipStream_t s) { return uic_zero4_launch(L.dhdrop, (size_t)Meff * H * 4, nullptr, 0, nullptr, 0, nullptr, 0, s); }
+  int live_c0(int t0) const { return live_off[t0]; }
+  int live_rows_of(int t0, int t1) const { return (t1 == t_run ? live_pad() : live_off[t1]) - live_off[t0]; }
+  int logits_rows_live(int t0, int t1, hipStream_t s) {
+    const int c0 = live_c0(t0), real = live_off[t1] - c0, rows = live_rows_of(t0, t1);
+    UIC_TRY(uic_gather_rows_launch(L.hdrop_all, live_rows + c0, Meff, offw(L.hc, (size_t)c0 * H, dt), real, rows, (size_t)H * uic_dtype_size(dt), s));
+    if (rows == 0) return UIC_OK;
+    UicGemmParams g = gemm_base(dt, rows, V1);
+    add_seg(g, off(L.hc, (size_t)c0 * H, dt), H, dv.logit_w, H, H);
+    g.C = L.logits + (size_t)c0 * V1p; g.ldc = V1p; g.bias = w->logit_b; g.flags = UIC_GEMM_OUT_F32;
+    return uic_gemm_launch(g, s);
+  }
   int logits_rows_now(int t0, int t1, hipStream_t s) {
+    if (compact) return logits_rows_live(t0, t1, s);
     const int rows = (t1 - t0) * N;
     for (int l = 0; l < nlh(); ++l) {
       UicGemmParams g = gemm_base(dt, rows, H);
@@ -1048,6 +1091,20 @@ struct Step {
     const size_t r0 = (size_t)t0 * N;
     x.dtype = dt; x.M = (t1 - t0) * N; x.V1 = V1; x.ldv = V1p; x.N = N;
     x.logits = L.logits + r0 * V1p;
+    if (compact && with_loss) {
+      // the live list's rows of these steps: logits / d logits / row losses are indexed by list position, labels and masks by the
+      // (step, row) the list names (steps counted from 0: the column offsets below are those of step 0)
+      const int c0 = live_c0(t0);
+      x.M = live_rows_of(t0, t1);
+      if (x.M == 0) return UIC_OK;
+      x.row_map = live_rows + c0; x.row_map_limit = Meff;
+      x.logits = L.logits + (size_t)c0 * V1p;
+      x.dlogits = offw(L.dlogits, (size_t)c0 * V1p, dt);
+      x.target = b->labels; x.ldtarget = b->ld_labels; x.target_col0 = 1;
+      x.mask = b->masks; x.ldmask = b->ld_masks; x.mask_col0 = 1;
+      x.inv_den = inv; x.row_loss = L.row_loss + c0; x.write_grad = 1;
+      return uic_xe_launch(x, s);
+    }
     if (with_loss) {
       x.dlogits = offw(L.dlogits, r0 * V1p, dt);
       x.target = b->labels; x.ldtarget = b->ld_labels; x.target_col0 = 1 + t0;
@@ -1064,6 +1121,17 @@ struct Step {
   // (long K = V1, few output tiles: split-K over workgroups on the LDS-DMA GEMM when the shape allows; `side` picks
   // the side stream's slab)
   int dh_rows(int t0, int t1, hipStream_t s, bool side = false) {
+    if (compact) {
+      const int c0 = live_c0(t0), real = live_off[t1] - c0;
+      if (real == 0) return UIC_OK;
+      const WDest dc{L.dhc + (size_t)c0 * H, H, 0, H};
+      // (a chunk of a few rows -- the captions' last steps -- runs as one whole 128-row tile of the split-K kernel instead of the
+      // generic one, 50 -> 17 us on the main stream in front of the BPTT loop: the rows behind the chunk's are the next chunk's or
+      // padding, inside both buffers, and what they produce is not scattered)
+      const int rows = real < 128 ? 128 : real;
+      UIC_TRY(wgrad_multi(side ? L.slab2 : L.slab, L.slab_bytes, dt, off(L.dlogits, (size_t)c0 * V1p, dt), rows, dv.logit_wT, H, V1p, &dc, 1, s));
+      return uic_scatter_rows_launch(L.dhc + (size_t)c0 * H, live_rows + c0, L.dhdrop, Meff, real, (size_t)H * 4, s);
+    }
     const size_t r0 = (size_t)t0 * N;
     const int rows = (t1 - t0) * N;
     const WDest d1{(nlh() ? L.dlh : L.dhdrop) + r0 * H, H, 0, H};
@@ -1081,6 +1149,16 @@ struct Step {
   }
   // d W_logit, d b_logit over all executed steps (own scratch buffers: may run beside the BPTT loop)
   int logit_weight_grads(hipStream_t s, bool side = false) {
+    if (compact) {
+      const int K = live_pad();
+      if (K == 0) {
+        return uic_zero4_launch(G->logit_w, (size_t)V1 * H * 4, G->logit_b, (size_t)V1 * 4, nullptr, 0, nullptr, 0, s);
+      }
+      const UicGemmTnSeg seg{L.hc, H, H};
+      const WDest d1{G->logit_w, H, 0, H};
+      UIC_TRY(wgrad_group(side ? L.slab2 : L.slab, L.dlogits, V1p, V1, &seg, 1, K, &d1, 1, s, false, L.tLA, L.tLB));
+      return uic_colsum_launch(dt, L.dlogits, K, V1, V1p, G->logit_b, L.colscratchL, L.colscratch_floats, s);
+    }
     {
       const UicGemmTnSeg seg{logit_in_all(), H, H};
       const WDest d1{G->logit_w, H, 0, H};
@@ -1624,6 +1702,7 @@ int uic_topdown_xe_train_step(const uic_topdown_dims* d, const uic_topdown_weigh
   // stream's GEMMs behind it (measured 3.81 vs 3.48 ms, profiles/r03_v4_rnn_bwd_probe.txt); UIC_REC_BWD_PERSIST selects it for
   // the single-stream uic_topdown_backward call only, where nothing runs beside it.
   st.d.recurrence &= ~UIC_REC_BWD_PERSIST;
+  st.init_live();
   const bool early = st.early_grads();
   ss->embed_recorded = false;
   // UIC_REC_COMM_STREAM: a communication stream of the caller is busy beside this step (data parallel).  The chip dispatches
@@ -1671,7 +1750,7 @@ int uic_topdown_xe_train_step(const uic_topdown_dims* d, const uic_topdown_weigh
   // training bit 2: the workspace already holds this forward pass (uic_topdown_sample_train drew b->labels with these
   // weights, this seed and these dims): the step starts at the criterion
   const bool resume = (training & 4) != 0;
-  bool bwd_begun = false;
+  bool bwd_begun = false, live_begun = false;
   UIC_REQUIRE(!resume || !st.ss_on(), "xe_train_step: a resumed step cannot use scheduled sampling");
   if (!resume) {
     // three branches: att_embed + ctx2att (main), embedding + batched input GEMM (side), fc_embed + Gfc + initial state (third
@@ -1689,6 +1768,7 @@ int uic_topdown_xe_train_step(const uic_topdown_dims* d, const uic_topdown_weigh
       UIC_TRY(st.fwd_prologue(s3, 4));
       UIC_TRY(st.bwd_begin(s3, st.persist_ok()));     // (the BPTT loop's zeroed carries and ones block: nothing in the forward pass touches them)
       bwd_begun = true;
+      if (st.compact) { UIC_TRY(st.live_begin(s3)); live_begun = true; }
       UIC_TRY(flush_gathered_late(ss, s3));           // (gathered refresh: the recurrence's and the logit layer's operand copies, last to arrive)
       UIC_HIP(hipEventRecord(ss->ev_pro3, s3));
     }
@@ -1698,6 +1778,7 @@ int uic_topdown_xe_train_step(const uic_topdown_dims* d, const uic_topdown_weigh
     if (ss->cast_recorded) UIC_HIP(hipStreamWaitEvent(s, ss->ev_cast, 0));   // the recurrence reads copies made on the side stream
   }
 
+  if (st.compact && !live_begun) UIC_TRY(st.live_begin(s));   // (every logit chunk, on either stream, is ordered behind this point of the main stream)
   UIC_MARK(1, s);
   // persistent mode 3: the whole recurrence as ONE launch (it holds every CU, nothing overlaps it); the logit layer follows
   // chunk by chunk on the side stream beside the BPTT loop
@@ -1740,7 +1821,7 @@ int uic_topdown_xe_train_step(const uic_topdown_dims* d, const uic_topdown_weigh
   // launches serve the stream's latency better than 56-workgroup ones -- 3.84 vs 3.99 ms per step beside the stand-in exchange)
   if (comm) g_uic_knobs |= UIC_KNOB_CHUNK_TN128;
   UIC_TRY(st.logit_weight_grads(s2, true));
-  UIC_TRY(uic_reduce_sum_launch(st.L.row_loss, (size_t)t_run * d->N, 0.f, inv, loss_out, s2));
+  UIC_TRY(uic_reduce_sum_launch(st.L.row_loss, st.compact ? (size_t)st.live_total() : (size_t)t_run * d->N, 0.f, inv, loss_out, s2));
   if (den_out) UIC_TRY(uic_copy_launch(den_out, st.L.scalars, 4, s2));
   UIC_HIP(hipEventRecord(ss->ev_logit, s2));          // gradient group 0 (logit layer) final: its exchange can start now
   UIC_MARK(10, s2);

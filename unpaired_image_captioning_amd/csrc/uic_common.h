@@ -605,8 +605,16 @@ struct UicXeParams {
   float* logprobs; size_t lp_step_stride, lp_row_stride;  // optional full log-probs out [n][t][v]
   int write_grad;
   int* score_stats;              // optional: [0] += rows whose arg-max (lowest index on ties) is the target, [1] += rows with target != 0
+  const int* row_map;            // optional [M]: row m of logits / dlogits is position row_map[m] = t * N + n (target, mask, grad_scale and
+                                 // are indexed by THAT, with the column offsets of step 0; row_loss by m).  Entries outside
+                                 // [0, row_map_limit) -- the list's -1 padding -- are rows with zero gradient and no loss entry
+  int row_map_limit;
 };
 int uic_xe_launch(const UicXeParams& p, hipStream_t s);
+// rows by index: out[m] = src[map[m]] (rows [M, Mpad) of out, and rows whose index is outside [0, src_rows), cleared) /
+// dst[map[m]] = src[m] (indices outside [0, dst_rows) skipped); row_bytes % 16 == 0
+int uic_gather_rows_launch(const void* src, const int* map, int src_rows, void* out, int M, int Mpad, size_t row_bytes, hipStream_t s);
+int uic_scatter_rows_launch(const void* src, const int* map, void* dst, int dst_rows, int M, size_t row_bytes, hipStream_t s);
 // general log-softmax backward given dense upstream grad g [N,T,V1] (API-compat path):
 // dlogits = g - softmax * sum(g)
 int uic_logsoftmax_bwd_launch(int dtype, void* dlogits, int M, int V1, int ldv, int N, const float* g,

@@ -5,6 +5,7 @@ streams); all arithmetic happens in libuic_hip.so.
 """
 import ctypes as C
 
+import numpy as np
 import torch
 
 from . import _lib
@@ -214,8 +215,20 @@ class TopDownEngine(object):
         d_att = torch.empty(att.shape[:-1] + (self.Dp,), dtype=torch.float32, device=att.device) if want_att else None
         return d_fc, d_att
 
-    def batch_struct(self, fc, att, att_masks, labels=None, masks=None, grad_scale=None, ss_prob=0.0, d_fc=None, d_att=None):
+    def batch_struct(self, fc, att, att_masks, labels=None, masks=None, grad_scale=None, ss_prob=0.0, d_fc=None, d_att=None, live=None):
+        """live: (live_rows [device int32], live_count [host int32 numpy]) of live_positions(masks) -- uic_topdown_batch.live_rows."""
         b = Batch()
+        if live is not None and live[0] is not None:
+            rows, count = live
+            if rows.dtype != torch.int32 or not rows.is_contiguous() or rows.device != fc.device:
+                raise ValueError("live_rows must be a contiguous int32 tensor on the batch's device")
+            count = np.ascontiguousarray(count, dtype=np.int32)
+            T = (labels.shape[1] - 1) if labels is not None else 0
+            if count.shape != (T,) or rows.numel() != ((int(count.sum()) + 127) // 128) * 128:
+                raise ValueError("live_count must hold one entry per decode step (%d) and live_rows roundup(sum, 128) entries" % T)
+            b._keep_live = (rows, count)
+            b.live_rows = rows.data_ptr()
+            b.live_count = count.ctypes.data_as(C.POINTER(C.c_int32))
         att = self._pad_att(att)
         b._keep = att                          # (a padded copy must outlive the call)
         b.d_fc_feats = ptr(d_fc)
@@ -260,8 +273,9 @@ class TopDownEngine(object):
         self._write_back(g)
 
     def xe_train_step(self, params, fc, att, att_masks, labels, masks, t_run, training, seed, grads, inv_den=None,
-                      grad_scale=None, ss_prob=0.0, keep_workspace=False, d_fc=None, d_att=None, resume_ws=None, out=None):
+                      grad_scale=None, ss_prob=0.0, keep_workspace=False, d_fc=None, d_att=None, resume_ws=None, out=None, live=None):
         """Fused forward + criterion + backward on two HIP streams; returns a device tensor [loss, sum(mask)].
+        live: live_positions(masks) -- the logit layer and the criterion then run over the unmasked positions only.
         resume_ws: the workspace sample(..., keep_forward=True) left behind for these labels (same weights, seed, L): the
         step starts at the criterion (training bit 2) and the workspace is released afterwards."""
         (N, S), R = self._rows(att, labels), att.shape[1]
@@ -273,7 +287,7 @@ class TopDownEngine(object):
             training = int(training) | 4
         else:
             ws = self.checkout(d, fc.device)
-        b = self.batch_struct(fc, att, att_masks, labels, masks, grad_scale, ss_prob, d_fc=d_fc, d_att=d_att)
+        b = self.batch_struct(fc, att, att_masks, labels, masks, grad_scale, ss_prob, d_fc=d_fc, d_att=d_att, live=live)
         g = self.weights_struct(grads, outputs=True)
         if out is None:
             out = torch.empty(2, dtype=torch.float32, device=fc.device)
@@ -397,3 +411,24 @@ class TopDownEngine(object):
             n *= s
         esz = torch.empty(0, dtype=dtype).element_size()
         return ws.buf[offset:offset + n * esz].view(dtype).view(*shape)
+
+
+def live_positions(masks, device=None):
+    """The list of live positions of a batch (uic_topdown_batch.live_rows / live_count, include/uic_hip.h): position (t, n) is
+    live when masks[n, 1 + t] != 0 -- LanguageModelCriterion multiplies every other one by zero (P/misc/utils.py:62-73).
+    masks: [N, T + 1] host array or tensor (the loader makes it on the host, P/misc/dataloader/dataloader.py:200-203).
+    Returns (live_rows: int32 tensor on `device`, live_count: int32 numpy [T])."""
+    if torch.is_tensor(masks):
+        device = device if device is not None else masks.device
+        m = masks.detach().cpu().numpy()
+    else:
+        m = np.asarray(masks)
+    live = np.ascontiguousarray(m[:, 1:].T != 0)                     # [T, N], step-major
+    count = live.sum(1).astype(np.int32)
+    flat = np.flatnonzero(live).astype(np.int32)                     # t * N + n, ascending = step-major
+    rows = np.full(((flat.size + 127) // 128) * 128, -1, dtype=np.int32)
+    rows[:flat.size] = flat
+    t = torch.from_numpy(rows)
+    if device is not None and torch.device(device).type != "cpu":
+        t = t.to(device, non_blocking=False)
+    return t, count

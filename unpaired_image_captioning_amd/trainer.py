@@ -15,6 +15,7 @@ import torch
 
 from . import _lib, models
 from ._lib import check, ptr, stream
+from .topdown_engine import live_positions
 from .misc.optimizer import FlatArena, Optim  # noqa: F401
 from .parallel_exchange import GradientExchange
 
@@ -46,8 +47,9 @@ def xe_step(model, batch, t_run=None, inv_den=None, grads=None, return_seed=Fals
     if fused:
         if grads is None:
             grads = {k: torch.empty_like(v) for k, v in pd.items()}
+        live = (batch["live_rows"], batch["live_count"]) if batch.get("live_rows") is not None else None
         out = eng.xe_train_step(pd, batch["fc_feats"], batch["att_feats"], batch.get("att_masks"), labels, batch["masks"],
-                                t_run, training, seed, grads, inv_den, ss_prob=ss_prob, d_fc=d_fc, d_att=d_att, out=out)
+                                t_run, training, seed, grads, inv_den, ss_prob=ss_prob, d_fc=d_fc, d_att=d_att, out=out, live=live)
         if return_seed:
             return out[0], grads, seed
         return out[0], grads
@@ -267,7 +269,21 @@ class Trainer(object):
                 v = torch.from_numpy(v if v.flags.writeable else v.copy())
             out[k] = self._ship(k, v, torch.int64 if k == "labels" else torch.float32)
         self._replication_checked = True
+        if getattr(self.opt, 'live_positions', 1) and data.get("masks") is not None and not torch.is_tensor(data["masks"]):
+            # the positions behind the captions' ends are known here, on the host, where the loader made the masks: the step's
+            # logit layer and criterion skip them (uic_topdown_batch.live_rows; opt.live_positions = 0 computes every position)
+            rows, count = live_positions(data["masks"])
+            out["live_rows"] = self._ship("live_rows", rows, torch.int32)
+            out["live_count"] = count
         return out
+
+    @staticmethod
+    def attach_live(batch):
+        """Adds the live-position list to a DEVICE batch (a resident benchmark batch; Trainer.to_device does it for host batches).
+        One device-to-host read of the masks: call it once per batch, outside a timed region."""
+        rows, count = live_positions(batch["masks"])
+        batch["live_rows"], batch["live_count"] = rows, count
+        return batch
 
     def _ship(self, key, t, dtype):
         """Host tensor (any strides / dtype) -> device: ONE threaded gather-and-convert pass into a pinned staging buffer
@@ -513,7 +529,8 @@ class Trainer(object):
             cur = torch.cuda.current_stream()
             cur.wait_event(pf[3])
             for t in pf[2].values():
-                t.record_stream(cur)               # allocated on the copy stream, consumed on this one
+                if torch.is_tensor(t):
+                    t.record_stream(cur)               # allocated on the copy stream, consumed on this one
             return pf[2]
         return self.to_device(data, per_image)
 
