@@ -27,7 +27,7 @@ lib = L.load()
 c = CFG
 model = models.setup(make_opt("bf16", 1234)).cuda()
 model.train()
-batch = {k: v.cuda() for k, v in synthetic_batch(c["n_img"], c["S"], c["R"], c["D"], c["V"], c["L"], seed=1).items()}
+batch = trainer.Trainer.attach_live({k: v.cuda() for k, v in synthetic_batch(c["n_img"], c["S"], c["R"], c["D"], c["V"], c["L"], seed=1).items()})
 settings = [int(s, 0) for s in args.settings]
 names = ["start", "prologue", "recurrence", "logit layer", "BPTT starts", "BPTT done", "rec wgrads", "main tail", "side tail", "joined", "logit grads"]
 

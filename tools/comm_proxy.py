@@ -92,7 +92,7 @@ class ProxyExchange(GradientExchange):
 
 c = bench.CFG
 batch_cpu = synthetic_batch(c["n_img"], c["S"], c["R"], c["D"], c["V"], c["L"], seed=1234)
-batch = {k: v.cuda() for k, v in batch_cpu.items()}
+batch = Trainer.attach_live({k: v.cuda() for k, v in batch_cpu.items()})   # (as Trainer.to_device does for every real batch)
 T = batch["labels"].shape[1] - 1
 den = float(batch["masks"][:, 1:T + 1].sum().item())
 NAMES = ["start", "prologue", "recurrence", "logit layer", "BPTT starts", "BPTT done", "rec wgrads", "main tail", "side tail", "joined", "logit grads"]

@@ -13,7 +13,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--steps", type=int, default=30)
 ap.add_argument("--dtype", default="bf16")
 ap.add_argument("--early", action="store_true", help="UIC_REC_EARLY_GRADS: the order of the gradient work that finishes most bytes early")
-ap.add_argument("--live", action="store_true", help="hand the step the list of unmasked positions (uic_topdown_batch.live_rows)")
+ap.add_argument("--all-positions", action="store_true", help="without the list of unmasked positions (uic_topdown_batch.live_rows)")
 args = ap.parse_args()
 
 import torch
@@ -28,9 +28,9 @@ model = models.setup(make_opt(args.dtype, 1234)).cuda()
 model.train()
 if args.early:
     model.engine.recurrence |= L.REC_EARLY_GRADS
-batch = {k: v.cuda() for k, v in synthetic_batch(c["n_img"], c["S"], c["R"], c["D"], c["V"], c["L"], seed=1).items()}
-if args.live:
-    trainer.Trainer.attach_live(batch)
+batch = trainer.Trainer.attach_live({k: v.cuda() for k, v in synthetic_batch(c["n_img"], c["S"], c["R"], c["D"], c["V"], c["L"], seed=1).items()})
+if args.all_positions:
+    batch = {k: v for k, v in batch.items() if not k.startswith("live_")}
 real = lib.uic_topdown_xe_train_step
 acc = {"n": 0, "t": 0.0}
 

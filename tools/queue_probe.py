@@ -16,7 +16,7 @@ c = CFG
 model = models.setup(make_opt("bf16", 1234)).cuda()
 model.train()
 model.engine.recurrence = int(sys.argv[1], 0) if len(sys.argv) > 1 else 0
-batch = {k: v.cuda() for k, v in synthetic_batch(c["n_img"], c["S"], c["R"], c["D"], c["V"], c["L"], seed=1).items()}
+batch = trainer.Trainer.attach_live({k: v.cuda() for k, v in synthetic_batch(c["n_img"], c["S"], c["R"], c["D"], c["V"], c["L"], seed=1).items()})
 extra = [torch.cuda.Stream() for _ in range(2)]
 names = ["start", "prologue", "recurrence", "logit layer", "BPTT starts", "BPTT done", "rec wgrads", "main tail", "side tail", "joined", "logit grads"]
 for n_busy in (0, 1, 2, 0):
