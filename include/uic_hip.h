@@ -416,6 +416,16 @@ typedef struct uic_nmt_dims {
    * words on the device (word 0 != 0: a bounded spin gave up, the outputs are invalid) or NULL */
   int32_t recurrence;
   uint32_t* rnn_status;
+  /* Optional list of the target positions that are not PAD, for uic_nmt_forward_loss / uic_nmt_backward (NULL: every position is
+   * computed; NMTCriterion's weight[PAD] = 0 makes the padded ones exact zeros, P/misc/criterion.py:126-136 -- the same result).
+   * Position t * B + b (decoder step t, sentence b) is live when tgt[t + 1, b] != PAD (0).  With the list the generator, the
+   * criterion, d outputs and the generator's weight gradient run over the listed rows only (40 % of the positions are padding
+   * in a batch of target lengths ~U{7..30}).  tgt_live_rows: DEVICE int32 [roundup(tgt_live_count, 128)], ascending or not, the
+   * tail up to the multiple of 128 holds -1; tgt_live_count: the number of listed positions.  The caller makes it from the target
+   * batch where it assembles it (on the host, as the reference's onmt.Dataset does); the SAME list must be passed to the
+   * forward and the backward call of a step.  A list that leaves out a non-PAD position drops its loss and gradient. */
+  const int32_t* tgt_live_rows;
+  int32_t tgt_live_count;
 } uic_nmt_dims;
 
 typedef struct uic_nmt_weights {     /* keys of NMTModel.state_dict() + generator (P/trainer.py:85-89) */

@@ -11,6 +11,8 @@ from unpaired_image_captioning_amd.trainer import Trainer
 ap = argparse.ArgumentParser()
 ap.add_argument("--dtype", default="bf16"); ap.add_argument("--steps", type=int, default=20); ap.add_argument("--batch", type=int, default=64)
 ap.add_argument("--vocab", type=int, default=50004); ap.add_argument("--maxlen", type=int, default=30)
+ap.add_argument("--all-positions", action="store_true", help="without the list of non-PAD target positions (uic_nmt_dims.tgt_live_rows)")
+ap.add_argument("--ab", type=int, default=0, help="alternate blocks with / without the list this many times and print both medians")
 a = ap.parse_args()
 opt = argparse.Namespace(layers=2, rnn_size=512, word_vec_size=512, brnn=True, rnn_type="LSTM", dropout=0.3, input_feed=1,
                          position_encoding=False, coverage_attn=False, copy_attn=False, context_gate=None, attention_type="dot",
@@ -31,6 +33,9 @@ tgt = torch.randint(4, a.vocab, (T, B), generator=g); tgt[0] = 2
 for b in range(B):
     tgt[tl[b] - 1, b] = 3; tgt[tl[b]:, b] = 0
 batch = argparse.Namespace(src=src.unsqueeze(2).cuda(), tgt=tgt.cuda(), lengths=lengths.view(1, -1))
+if not a.all_positions:                  # (what the Dataset attaches where it assembles the batch, onmt_dataset_h5.py)
+    from unpaired_image_captioning_amd.models.NMT_Models import tgt_live_positions
+    batch.tgt.uic_live = tgt_live_positions(tgt, batch.tgt.device)
 ntok = int((tgt[1:] != 0).sum())
 for _ in range(15):                      # (the first process on a fresh box needs more than a few steps to reach its pace)
     tr.train_nmt(batch)
@@ -40,3 +45,20 @@ for _ in range(a.steps):
 torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / a.steps
 print("nmt %s: %.3f ms/step, %.0f sentences/s, %.0f target tokens/s (B=%d, S=%d, T=%d, V=%d, %d target tokens), loss %.1f" % (
     a.dtype, dt * 1e3, B / dt, ntok / dt, B, S, T, a.vocab, ntok, loss))
+if a.ab:
+    import copy
+    plain = argparse.Namespace(src=batch.src, tgt=batch.tgt.clone(), lengths=batch.lengths)      # (a tensor without the attribute)
+    res = {"all": [], "live": []}
+    for r in range(a.ab + 1):
+        for name, bt in (("all", plain), ("live", batch)):
+            for _ in range(3):
+                tr.train_nmt(bt)
+            torch.cuda.synchronize(); t0 = time.perf_counter()
+            for _ in range(a.steps):
+                tr.train_nmt(bt)
+            torch.cuda.synchronize()
+            if r:
+                res[name].append((time.perf_counter() - t0) / a.steps * 1e3)
+    for name, v in res.items():
+        v = sorted(v)
+        print("%-5s median %.3f ms  min %.3f  max %.3f" % (name, v[len(v) // 2], v[0], v[-1]))

@@ -143,7 +143,7 @@ SITE_NMT_ENC0, SITE_NMT_DEC0, SITE_NMT_OUT0 = 1000, 2000, 4000   # + layer ; + l
 
 class NmtDims(C.Structure):
     _fields_ = [(n, C.c_int32) for n in ("B", "S", "T", "H", "W", "layers", "Vs", "Vt", "dtype")] + [("drop_p", C.c_float),
-                ("recurrence", C.c_int32), ("rnn_status", C.c_void_p)]
+                ("recurrence", C.c_int32), ("rnn_status", C.c_void_p), ("tgt_live_rows", C.c_void_p), ("tgt_live_count", C.c_int32)]
 
 
 class NmtWeights(C.Structure):

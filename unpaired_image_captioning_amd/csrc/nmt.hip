@@ -529,6 +529,7 @@ struct NmtLayout {
   void* hd[ML]; float* cd[ML]; void* hdrop[ML]; void* gates_d[ML]; void* dg_d[ML]; float* dhrec_d[ML]; float* dcd[ML];
   float* ctxw; void* dctxw; float* attn_all; void* cvec_all; void* out_pre; void* out_all;   // ctxw = context x W_in [S*B, H] f32
   float* logits; void* dlogits; float* row_loss; float* scalars; int* stats;
+  void* out_live; float* d_out_live;
   // backward
   float* d_out_all; float* dfeed; void* d_pre_all; float* d_cq_all; float* dscore_all; float* dq;
   // dx_lstm[l]: d[x_l | h_l(t-1)] of decoder layer l > 0, one buffer per layer so that nothing has to be copied
@@ -606,8 +607,10 @@ NmtLayout nmt_layout(const uic_nmt_dims& d, const uic_nmt_weights* w, void* ws) 
   // K granularity of the 256 x 256 ping-pong kernel -- 190 -> 135 us at configs[2]'s 1984 rows; backward() clears the padding)
   const size_t Mdp = (Td * B + 127) & ~(size_t)127;
   L.out_all = b.take(((Td + 1) * B + (Mdp - Td * B)) * H * Sz);
-  L.logits = (float*)b.take(Td * B * Vtp * 4);
+  L.logits = (float*)b.take(Mdp * Vtp * 4);            // (Mdp rows: the live-position list is padded to whole 128-row tiles)
   L.dlogits = b.take(Mdp * Vtp * Sz);
+  L.out_live = b.take(Mdp * H * Sz);                   // uic_nmt_dims.tgt_live_rows: the listed rows of `out_all`, their d out
+  L.d_out_live = (float*)b.take(Mdp * H * 4);
   L.row_loss = (float*)b.take(Td * B * 4);
   L.scalars = (float*)b.take(64);
   L.stats = (int*)b.take(64);
@@ -705,6 +708,9 @@ struct Nmt {
   const int64_t* src;
   const int64_t* tgt;
   int nb[4096];
+  // uic_nmt_dims.tgt_live_rows: generator, criterion and their gradients over the non-PAD target positions only
+  bool live = false;
+  int live_n = 0, live_pad = 0;
 
   int init(const uic_nmt_dims* d_, const uic_nmt_weights* w_, const int64_t* src_, const int32_t* lengths_host,
            const int64_t* tgt_, int training, unsigned seed_, void* ws, const uic_nmt_weights* G_) {
@@ -715,6 +721,9 @@ struct Nmt {
     Sz = uic_dtype_size(dt); BH = (size_t)B * H; BHd = (size_t)B * Hd;
     drop_p = training ? d.drop_p : 0.f;
     seed = seed_;
+    live = d.tgt_live_rows != nullptr && d.tgt_live_count >= 0 && d.tgt_live_count <= Td * B && ((size_t)H * Sz) % 16 == 0;
+    live_n = live ? d.tgt_live_count : 0;
+    live_pad = (live_n + 127) & ~127;
     for (int b = 0; b < B; ++b) {
       UIC_REQUIRE(lengths_host[b] >= 1 && lengths_host[b] <= S, "lengths[%d]=%d outside [1,%d]", b, lengths_host[b], S);
       UIC_REQUIRE(b == 0 || lengths_host[b] <= lengths_host[b - 1], "lengths must be sorted in decreasing order (pack_padded_sequence)");
@@ -825,9 +834,10 @@ struct Nmt {
   }
   size_t gen_rows() const { return ((size_t)Td * B + 127) & ~(size_t)127; }
   int zero_backward_buffers(hipStream_t s) {
-    void* ptr[2 * UIC_NMT_MAX_LAYERS + 4];
-    size_t nbytes[2 * UIC_NMT_MAX_LAYERS + 4];
+    void* ptr[2 * UIC_NMT_MAX_LAYERS + 5];
+    size_t nbytes[2 * UIC_NMT_MAX_LAYERS + 5];
     int n = 0;
+    if (live) { ptr[n] = L.d_out_all; nbytes[n] = (size_t)Td * B * H * 4; ++n; }
     for (int l = 0; l < NL; ++l)
       for (int dd = 0; dd < 2; ++dd) { ptr[n] = L.dg_e[l][dd]; nbytes[n] = ((size_t)S * B * 4 * Hd * Sz + 15) & ~(size_t)15; ++n; }
     ptr[n] = sync_block(NL + 1); nbytes[n] = (size_t)(NL + 1) * uic_rnn_persist_sync_bytes(); ++n;
@@ -1000,9 +1010,10 @@ struct Nmt {
   // generator + NMTCriterion + NMT_loss.score (criterion.py:126-136,175-184)
   int loss_fwd(float* loss_out, int32_t* stats_out, hipStream_t s) {
     UIC_TRY(wait_gen(s));
-    {
-      UicGemmParams g = gemm_base(dt, Td * B, Vt);
-      add_seg(g, off(L.out_all, BH, dt), H, L.gen_w, H, H);
+    if (live) UIC_TRY(uic_gather_rows_launch(off(L.out_all, BH, dt), d.tgt_live_rows, Td * B, L.out_live, live_n, live_pad, (size_t)H * Sz, s));
+    if (!live || live_pad > 0) {
+      UicGemmParams g = gemm_base(dt, live ? live_pad : Td * B, Vt);
+      add_seg(g, live ? L.out_live : off(L.out_all, BH, dt), H, L.gen_w, H, H);
       g.C = L.logits; g.ldc = Vtp; g.bias = w->gen_b; g.flags = UIC_GEMM_OUT_F32;
       UIC_TRY(uic_gemm_launch(g, s));
     }
@@ -1018,8 +1029,9 @@ struct Nmt {
       UIC_TRY(uic_fill_launch(L.stats, 0, 8, s));
       x.score_stats = L.stats;
     }
+    if (live) { x.M = live_pad; x.row_map = d.tgt_live_rows; x.row_map_limit = Td * B; }   // (rows of logits / d logits / row_loss by list position)
     UIC_TRY(uic_xe_launch(x, s));
-    UIC_TRY(uic_reduce_sum_launch(L.row_loss, (size_t)Td * B, 0.f, nullptr, loss_out, s));
+    UIC_TRY(uic_reduce_sum_launch(L.row_loss, live ? (size_t)live_n : (size_t)Td * B, 0.f, nullptr, loss_out, s));
     if (stats_out) {
       UIC_TRY(uic_copy_launch(stats_out, L.stats, 8, s));
     }
@@ -1035,8 +1047,10 @@ struct Nmt {
       // d out = d logits W_gen: [T B, H] outputs over K = the target vocabulary -- few tiles and a very long reduction: split-K
       // over workgroups with the deterministic slab reduction (wgrad_multi; one launch of 64 x 64 tiles walked all 50 048 columns
       // in 347 us)
-      const WDest d1{L.d_out_all, (int)H, 0, (int)H};
-      UIC_TRY(wgrad_multi(L.slab, L.slab_bytes, dt, L.dlogits, Md, L.gen_wT, H, Vtp, &d1, 1, s));
+      const WDest d1{live ? L.d_out_live : L.d_out_all, (int)H, 0, (int)H};
+      if (!live || live_pad > 0) UIC_TRY(wgrad_multi(L.slab, L.slab_bytes, dt, L.dlogits, live ? live_pad : Md, L.gen_wT, H, Vtp, &d1, 1, s));
+      // (d out of the positions the list leaves out is zero: zero_backward_buffers cleared the buffer)
+      if (live) UIC_TRY(uic_scatter_rows_launch(L.d_out_live, d.tgt_live_rows, L.d_out_all, Md, live_n, (size_t)H * 4, s));
     }
     // the generator's weight / bias gradients (the largest GEMM of the backward pass, [Vt, H] over all target rows) need nothing
     // from the BPTT loop and the loop -- ~6 dependent launches of 64 rows per step -- leaves the chip idle: they run on the side
@@ -1045,12 +1059,16 @@ struct Nmt {
     UIC_TRY(nmt_side(&ssg));
     UIC_TRY(uic_check_hip(hipEventRecord(ssg->ev_go, s), "hipEventRecord"));
     UIC_TRY(uic_check_hip(hipStreamWaitEvent(ssg->stream, ssg->ev_go, 0), "hipStreamWaitEvent"));
-    {
-      const UicGemmTnSeg seg{off(L.out_all, BH, dt), H, H};
+    if (live && live_pad == 0) {
+      // (a batch without a single target word: no gradient)
+      UIC_TRY(uic_check_hip(hipMemsetAsync(G->gen_w, 0, (size_t)Vt * H * 4, ssg->stream), "hipMemsetAsync(d generator.weight)"));
+      UIC_TRY(uic_check_hip(hipMemsetAsync(G->gen_b, 0, (size_t)Vt * 4, ssg->stream), "hipMemsetAsync(d generator.bias)"));
+    } else {
+      const UicGemmTnSeg seg{live ? L.out_live : off(L.out_all, BH, dt), H, H};
       const WDest d1{G->gen_w, H, 0, H};
-      UIC_TRY(wgrad_group(L.slab, L.slab_bytes, dt, L.dlogits, Vtp, Vt, &seg, 1, (int)gen_rows(), &d1, 1, ssg->stream, false, L.tA, L.tB));
+      UIC_TRY(wgrad_group(L.slab, L.slab_bytes, dt, L.dlogits, Vtp, Vt, &seg, 1, live ? live_pad : (int)gen_rows(), &d1, 1, ssg->stream, false, L.tA, L.tB));
+      UIC_TRY(uic_colsum_launch(dt, L.dlogits, live ? live_pad : Md, Vt, Vtp, G->gen_b, L.colscratch, L.colscratch_floats, ssg->stream));
     }
-    UIC_TRY(uic_colsum_launch(dt, L.dlogits, Md, Vt, Vtp, G->gen_b, L.colscratch, L.colscratch_floats, ssg->stream));
     UIC_TRY(uic_check_hip(hipEventRecord(ssg->ev_done, ssg->stream), "hipEventRecord"));
     UIC_TRY(uic_check_hip(hipEventRecord(ssg->ev_grad_gen, ssg->stream), "hipEventRecord"));   // gradient group 0: generator.*
     // ---- decoder BPTT

@@ -816,7 +816,7 @@ __global__ __launch_bounds__(NT) void xe_kernel(const UicXeParams p, const float
   long y = 0;
   float mk = 0.f;
   if (p.target) {
-    y = p.target[(size_t)n * p.ldtarget + p.target_col0 + t];
+    y = pad ? 0 : p.target[(size_t)n * p.ldtarget + p.target_col0 + t];
     mk = p.mask && !pad ? p.mask[(size_t)n * p.ldmask + p.mask_col0 + t] : 0.f;
     if (p.score_stats) {
       __shared__ float s_bv[NT / 64];
@@ -892,7 +892,7 @@ __global__ __launch_bounds__(NT) void xe_big_kernel(const UicXeParams p, const f
   long y = 0;
   float mk = 0.f;
   if (p.target) {
-    y = p.target[(size_t)n * p.ldtarget + p.target_col0 + t];
+    y = pad ? 0 : p.target[(size_t)n * p.ldtarget + p.target_col0 + t];
     mk = p.mask && !pad ? p.mask[(size_t)n * p.ldmask + p.mask_col0 + t] : 0.f;
     if (threadIdx.x == 0 && p.score_stats && y != 0) {
       atomicAdd(&p.score_stats[1], 1);
@@ -955,7 +955,7 @@ __global__ __launch_bounds__(NT) void xe_lds_kernel(const UicXeParams p, const f
   long y = 0;
   float mk = 0.f;
   if (p.target) {
-    y = p.target[(size_t)n * p.ldtarget + p.target_col0 + t];
+    y = pad ? 0 : p.target[(size_t)n * p.ldtarget + p.target_col0 + t];
     mk = p.mask && !pad ? p.mask[(size_t)n * p.ldmask + p.mask_col0 + t] : 0.f;
     if (p.score_stats) {
       __shared__ float s_bv[NT / 64];
@@ -1006,7 +1006,7 @@ __global__ __launch_bounds__(NT) void xe_reg_kernel(const UicXeParams p, const f
   const int mo = pad ? 0 : mr;
   const int t = mo / p.N, n = mo - t * p.N;
   const float* row = logits + (size_t)m * p.ldv;
-  long y = p.target[(size_t)n * p.ldtarget + p.target_col0 + t];
+  long y = pad ? 0 : p.target[(size_t)n * p.ldtarget + p.target_col0 + t];
   const float mk = p.mask && !pad ? p.mask[(size_t)n * p.ldmask + p.mask_col0 + t] : 0.f;
   if (y < 0 || y >= p.V1) y = 0;
   if (mk == 0.f && !p.grad_scale) {
@@ -1084,7 +1084,7 @@ __global__ __launch_bounds__(XE_WTH) void xe_reg_wide_kernel(const UicXeParams p
   const int t = mo / p.N, n = mo - t * p.N;
   const float* row = logits + (size_t)m * p.ldv;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const long y0 = p.target[(size_t)n * p.ldtarget + p.target_col0 + t];
+  const long y0 = pad ? 0 : p.target[(size_t)n * p.ldtarget + p.target_col0 + t];
   const float mk = p.mask && !pad ? p.mask[(size_t)n * p.ldmask + p.mask_col0 + t] : 0.f;
   const long y = y0 < 0 || y0 >= p.V1 ? 0 : y0;
   if (mk == 0.f && !p.grad_scale && !(p.score_stats && y0 != 0)) {      // (a padded target position: see xe_reg_kernel)
@@ -2057,8 +2057,8 @@ int uic_xe_launch(const UicXeParams& p, hipStream_t s) {
   UIC_REQUIRE(!p.write_grad || (p.target && ((p.mask && p.inv_den) || p.grad_scale)), "xe: gradient needs target and mask+inv_den or grad_scale");
   UIC_REQUIRE(!p.write_grad || p.dlogits, "xe: null dlogits");
   UIC_REQUIRE(!p.target || p.row_loss, "xe: null row_loss");
-  UIC_REQUIRE(!p.row_map || (p.write_grad && p.mask && !p.grad_scale && !p.score_stats && !p.logprobs),
-              "xe: a row list goes with the masked criterion only (target, mask, gradient; no per-position scale, statistics or log-probabilities)");
+  UIC_REQUIRE(!p.row_map || (p.write_grad && p.mask && !p.grad_scale && !p.logprobs),
+              "xe: a row list goes with the masked criterion only (target, mask, gradient; no per-position scale or log-probabilities)");
   if (p.M == 0) return UIC_OK;
   const size_t row_bytes = (size_t)p.ldv * 4;
   if (p.dtype == UIC_BF16 && p.ldv % 4 == 0 && p.ldv <= XE_RCH * NT * 4 && ((uintptr_t)p.logits & 15) == 0 && p.write_grad && p.target &&

@@ -73,7 +73,13 @@ class onmt_dataset_h5(object):
         order = perm.numpy()
         src_t = np.ascontiguousarray(src[order].T)[:, :, None]          # [S, n, 1]
         tgt_t = np.ascontiguousarray(tgt[order].T)                      # [T, n]
-        return Batch(self._ship(src_t), self._ship(tgt_t), lengths.view(1, -1), [int(p) for p in perm], n)
+        tgt_dev = self._ship(tgt_t)
+        if self.cuda:
+            # the target positions that are not PAD, known here where the batch is assembled: the NMT step's generator and
+            # criterion skip the others (uic_nmt_dims.tgt_live_rows; NMTModel.forward reads the attribute)
+            from ...models.NMT_Models import tgt_live_positions
+            tgt_dev.uic_live = tgt_live_positions(tgt_t, tgt_dev.device)
+        return Batch(self._ship(src_t), tgt_dev, lengths.view(1, -1), [int(p) for p in perm], n)
 
     def _ship(self, a):
         t = torch.from_numpy(a)

@@ -21,6 +21,7 @@ reference's state_dict keys and initialisation; they are never called.
 """
 import ctypes as C
 
+import numpy as np
 import torch
 import torch.nn as nn
 
@@ -161,16 +162,38 @@ class _NmtEngine(object):
         return _lib.nmt_weights(tensors, self.m.encoder.layers)
 
 
+def tgt_live_positions(tgt, device=None):
+    """The list of the target positions that are not PAD (uic_nmt_dims.tgt_live_rows, include/uic_hip.h): position t * B + b is
+    live when tgt[t + 1, b] != PAD -- NMTCriterion weighs every other one with zero (P/misc/criterion.py:126-136).
+    tgt: [T, B] host array / tensor, as the Dataset assembles it.  Returns (int32 tensor of roundup(count, 128) positions, the tail
+    -1, on `device`; count).  Attach it to the device batch as `batch.tgt.uic_live`: NMTModel.forward picks it up there."""
+    t = tgt.detach().cpu().numpy() if torch.is_tensor(tgt) else np.asarray(tgt)
+    flat = np.flatnonzero(np.ascontiguousarray(t[1:]) != 0).astype(np.int32)
+    rows = np.full(((flat.size + 127) // 128) * 128, -1, dtype=np.int32)
+    rows[:flat.size] = flat
+    out = torch.from_numpy(rows)
+    if device is not None and torch.device(device).type != "cpu":
+        out = out.pin_memory().to(device, non_blocking=True)
+    return out, int(flat.size)
+
+
 class _NmtStep(torch.autograd.Function):
     """(loss, outputs, attn, stats) = fused NMTModel.forward + NMT_loss; only `loss` is differentiable."""
 
     @staticmethod
-    def forward(ctx, model, src, tgt, lengths_host, lengths_dev, *params):
+    def forward(ctx, model, src, tgt, lengths_host, lengths_dev, live, *params):
         eng = model.engine
         pd = dict(zip(model.param_names, params))
         S, B = src.shape
         T = tgt.shape[0]
         d = eng.dims(B, S, T)
+        if live is not None:                       # tgt_live_positions(tgt): the generator runs over the non-PAD positions only
+            rows, count = live
+            if rows.dtype != torch.int32 or not rows.is_contiguous() or rows.device != src.device or rows.numel() != ((int(count) + 127) // 128) * 128:
+                raise ValueError("tgt.uic_live must be (contiguous int32 device tensor of roundup(count, 128) positions, count)")
+            d.tgt_live_rows = rows.data_ptr()
+            d.tgt_live_count = int(count)
+            ctx.live = live                        # (the backward call reads the same list through ctx.d)
         ws = eng.workspace(d, src.device)
         seed = model.next_seed()
         dev = src.device
@@ -221,11 +244,11 @@ class _NmtStep(torch.autograd.Function):
         eng.release(ctx.d, ctx.ws)
         ctx.ws = None
         if direct:
-            return (None,) * (5 + len(model.param_names))
+            return (None,) * (6 + len(model.param_names))
         out = []
         for k in model.param_names:
             out.append(grads[k] * g_loss if model.scale_grads else grads[k])
-        return (None, None, None, None, None) + tuple(out)
+        return (None, None, None, None, None, None) + tuple(out)
 
 
 class NMTModel(nn.Module):
@@ -317,12 +340,13 @@ class NMTModel(nn.Module):
             if src.shape[2] != 1:
                 raise NotImplementedError("source word features (nfeat > 1) are outside the hot path")
             src = src[:, :, 0]
+        live = getattr(tgt, 'uic_live', None) if getattr(self.opt, 'live_positions', 1) else None
         src = src.contiguous()
         tgt = tgt.contiguous()
         lengths_host = [int(x) for x in lengths.reshape(-1).tolist()]
         lengths_dev = lengths.reshape(-1).to(device=src.device, dtype=torch.int32).contiguous()
         pd = self._param_dict()
-        loss, outputs, attn, stats = _NmtStep.apply(self, src, tgt, lengths_host, lengths_dev, *[pd[k] for k in self.param_names])
+        loss, outputs, attn, stats = _NmtStep.apply(self, src, tgt, lengths_host, lengths_dev, live, *[pd[k] for k in self.param_names])
         outputs.uic_loss = loss
         outputs.uic_stats = stats
         return outputs, {'std': attn}, None, None
