@@ -519,7 +519,7 @@ def main():
                                    "rows per GPU, R=36, D=2048, H=E=A=512, V+1=9488, 17 decode steps, dropout 0.5, "
                                    "XE loss + BPTT + Adam", "rows_per_gpu": N, "parallelism": "dp%d" % world, "use_bn": args.use_bn, "att_feat_size": Datt,
                        "features": args.features, "early_grads": bool(args.early_grads),
-                       "positions": "all" if args.all_positions else "unmasked (%d of %d; the list is made on the host from the masks, outside the timed region)"
+                       "positions": "all" if args.all_positions else "unmasked (%d of %d; counted per step on the host from the masks, outside the timed region)"
                        % (int(batch["live_count"][:t_run].sum()), t_run * N)},
             "final_loss": round(loss_val, 4),
             "rccl_ranks": dist.get_world_size() if (world > 1 and dist.get_backend() == "nccl") else (1 if world == 1 else 0),

@@ -171,16 +171,19 @@ typedef struct uic_topdown_batch {
      encoder in front of the captioner (BASELINE configs[4]'s scene-graph GCN, uic_gcn_backward's `dout`): */
   float* d_att_feats;       /* [N, R, D]  ([N / seq_per_img, R, D]); padded regions get zeros.  Needs dims.use_bn == 0 */
   float* d_fc_feats;        /* [N, Dfc]   ([N / seq_per_img, Dfc]) */
-  /* Optional list of the LIVE positions of the batch, for uic_topdown_xe_train_step (NULL = every position is computed, and
+  /* Optional list of the LIVE positions of the batch, for uic_topdown_xe_train_step (live_count NULL = every position is computed, and
      positions with mask 0 contribute exact zeros -- the same result).  A position (t, n) -- decode step t, row n -- is live
      when masks[n, 1 + t] != 0; positions behind a caption's end (LanguageModelCriterion multiplies them by 0,
      P/misc/utils.py:62-73) are a quarter of the benchmark's batch and a third of COCO's.  With the list the logit layer, the
      criterion and their gradients run over the listed rows only.
-       live_rows   DEVICE int32 [roundup(sum(live_count), 128)]: t * N + n of every live position, step-major (all of step 0,
-                   then step 1, ...; any order within a step); the tail up to the multiple of 128 holds -1
-       live_count  HOST int32 [t_run]: the number of entries of each step
-     The caller builds both from the masks it already holds on the host (DataLoader.get_batch makes the masks there).  A list that
-     omits a position whose mask is not zero drops that position's loss and gradient; listing a masked position is harmless.
+       live_count  HOST int32 [t_run]: the number of live positions of each step -- the step sizes its launches with them
+       live_rows   DEVICE int32 [roundup(sum(live_count), 128)] or NULL: t * N + n of every live position, step-major (all of
+                   step 0, then step 1, ...; any order within a step); the tail up to the multiple of 128 holds -1.
+                   NULL (what Trainer passes): the step compacts `masks` itself with one small launch beside its prologue, so
+                   nothing but the counts has to be made on the host
+     The caller counts from the masks it already holds on the host (DataLoader.get_batch makes the masks there).  The counts must
+     be those of `masks`; a list that omits a position whose mask is not zero drops that position's loss and gradient; listing a
+     masked position is harmless.
      Ignored (every position computed) under scheduled sampling, with grad_scale, with logit_layers > 1, without masks, when a row
      of hidden units is not a multiple of 16 bytes, when t_run >
      UIC_MAX_LIVE_STEPS, or when a count is outside [0, N]. */
@@ -420,10 +423,12 @@ typedef struct uic_nmt_dims {
    * computed; NMTCriterion's weight[PAD] = 0 makes the padded ones exact zeros, P/misc/criterion.py:126-136 -- the same result).
    * Position t * B + b (decoder step t, sentence b) is live when tgt[t + 1, b] != PAD (0).  With the list the generator, the
    * criterion, d outputs and the generator's weight gradient run over the listed rows only (40 % of the positions are padding
-   * in a batch of target lengths ~U{7..30}).  tgt_live_rows: DEVICE int32 [roundup(tgt_live_count, 128)], ascending or not, the
-   * tail up to the multiple of 128 holds -1; tgt_live_count: the number of listed positions.  The caller makes it from the target
-   * batch where it assembles it (on the host, as the reference's onmt.Dataset does); the SAME list must be passed to the
-   * forward and the backward call of a step.  A list that leaves out a non-PAD position drops its loss and gradient. */
+   * in a batch of target lengths ~U{7..30}).  tgt_live_count > 0: the number of non-PAD positions of tgt[1:] (the caller counts
+   * them where it assembles the batch -- on the host, as the reference's onmt.Dataset does); tgt_live_rows: DEVICE int32
+   * [roundup(tgt_live_count, 128)], any order, the tail up to the multiple of 128 holds -1, or NULL: the forward call compacts
+   * the targets itself (one small launch) and the backward call reads that list from the workspace.  The same values must be
+   * passed to the forward and the backward call of a step.  A list that leaves out a non-PAD position drops its loss and
+   * gradient.  tgt_live_count == 0: every position is computed. */
   const int32_t* tgt_live_rows;
   int32_t tgt_live_count;
 } uic_nmt_dims;

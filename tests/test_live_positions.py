@@ -63,6 +63,8 @@ def test_batch_struct_refuses_a_list_of_the_wrong_shape():
     assert rows.is_cuda
     b = eng.batch_struct(fc, att, None, labels, masks, live=(rows, count))
     assert b.live_rows == rows.data_ptr() and b.live_count[0] == 4
+    b = eng.batch_struct(fc, att, None, labels, masks, live=(None, count))      # counts only: the step makes the list
+    assert not b.live_rows and b.live_count[5] == 4
     with pytest.raises(ValueError):
         eng.batch_struct(fc, att, None, labels, masks, live=(rows, count[:-1]))
     with pytest.raises(ValueError):
@@ -77,8 +79,12 @@ def test_batch_struct_refuses_a_list_of_the_wrong_shape():
 def _step(model, batch, live, seed=11):
     from unpaired_image_captioning_amd.trainer import Trainer, xe_step
     b = {k: v for k, v in batch.items() if not k.startswith("live_")}
-    if live:
+    if live == "rows":                                   # the caller's own list
+        from unpaired_image_captioning_amd.topdown_engine import live_positions
+        b["live_rows"], b["live_count"] = live_positions(b["masks"])
+    elif live:                                           # counts only (what Trainer does): the step compacts the masks itself
         Trainer.attach_live(b)
+        assert "live_rows" not in b
     model._seed_counter = seed                           # (the same dropout masks in every call)
     loss, grads = xe_step(model, b)
     torch.cuda.synchronize()
@@ -94,14 +100,15 @@ def _same(g1, g0, tol):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("dtype", ["f32", "bf16"])
+@pytest.mark.parametrize("form", ["rows", "device"])
 @pytest.mark.parametrize("name", ["topdown_tiny", "topdown_tiny_ragged", "topdown_tiny_earlybreak", "topdown_odd", "topdown_tiny_box"])
-def test_step_over_live_positions_vs_reference_golden(name, dtype):
+def test_step_over_live_positions_vs_reference_golden(name, dtype, form):
     from test_gpu_topdown import GRAD_TOL, LOGP_TOL, build_model, grads_close
     cfg, W, I, Out, G, X = load_golden(name)
     model = build_model(cfg, W, dtype)
     model.train()
     batch = {k: I[k].cuda() for k in ("fc_feats", "att_feats", "labels", "masks", "att_masks") if I.get(k) is not None}
-    loss, grads = _step(model, batch, live=True)
+    loss, grads = _step(model, batch, live=form)
     assert abs(loss - float(Out["loss"])) < (1e-4 if dtype == "f32" else LOGP_TOL[dtype])
     grads_close(grads, G, GRAD_TOL[dtype])
 
@@ -123,9 +130,13 @@ def test_step_over_live_positions_equals_the_step_over_all(shape, dtype):
     batch = {k: v.cuda() for k, v in b.items()}
     assert (b["masks"][:, 1:] == 0).any()
     l0, g0 = _step(model, batch, live=False)
-    l1, g1 = _step(model, batch, live=True)
+    l1, g1 = _step(model, batch, live="rows")
+    l2, g2 = _step(model, batch, live="device")
     assert abs(l1 - l0) < (2e-6 if dtype == "f32" else 2e-5) * max(1.0, abs(l0))
     _same(g1, g0, 2e-5 if dtype == "f32" else 2e-3)
+    assert l2 == l1                                      # (the device's list is the host's: ascending positions)
+    for k in g1:
+        assert torch.equal(g1[k], g2[k]), k
 
 
 @pytest.mark.gpu
@@ -179,7 +190,7 @@ def test_trainer_attaches_the_list_to_host_batches_and_trains_the_same():
             b = O.synthetic_batch(6, 5, 9, cfg["D"], cfg["V"], cfg["L"], seed=20 + i)
             data = {k: v.numpy() for k, v in b.items()}
             dev = tr.to_device(data, per_image=False)
-            assert ("live_rows" in dev) == bool(live)
+            assert ("live_count" in dev) == bool(live) and "live_rows" not in dev
             losses.append(tr.train(data))
         return losses, {k: v.detach().clone() for k, v in tr.i2t_model.state_dict().items()}
 

@@ -49,8 +49,11 @@ def _run(model, crit, I, live):
     model.zero_grad()
     model._seed_counter = 5
     tgt = I["tgt"].cuda()
-    if live:
+    if live == "rows":                                       # the caller's own list
         tgt.uic_live = tgt_live_positions(I["tgt"], tgt.device)
+    elif live:                                               # the count only (what the Dataset attaches): the step compacts the targets
+        from unpaired_image_captioning_amd.models.NMT_Models import tgt_live_count
+        tgt.uic_live = (None, tgt_live_count(I["tgt"]))
     batch = argparse.Namespace(src=I["src"].cuda(), tgt=tgt, lengths=I["lengths"])
     outputs, attns, _, _ = model(batch.src, batch.tgt, batch.lengths, None)
     crit.report_stats = type(crit.report_stats)()             # (fresh counters for this call)
@@ -62,13 +65,14 @@ def _run(model, crit, I, live):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("dtype", ["f32", "bf16"])
+@pytest.mark.parametrize("form", ["rows", "device"])
 @pytest.mark.parametrize("name", ["nmt_tiny", "nmt_tiny_1layer", "nmt_odd"])
-def test_nmt_step_over_live_positions_vs_reference_golden(name, dtype):
+def test_nmt_step_over_live_positions_vs_reference_golden(name, dtype, form):
     from test_gpu_nmt import GRAD_TOL, OUT_TOL, absmax, build, grads_close, load
     cfg, W, I, Out, G = load(name)
     model, crit = build(cfg, W, dtype)
     model.train()
-    loss, outputs, grads, (n_words, n_correct) = _run(model, crit, I, live=True)
+    loss, outputs, grads, (n_words, n_correct) = _run(model, crit, I, live=form)
     assert absmax(outputs, Out["outputs"]) < OUT_TOL[dtype]
     assert abs(loss - float(Out["loss"])) < OUT_TOL[dtype] * int(Out["num_words"])
     assert n_words == int(Out["num_words"])
@@ -91,7 +95,9 @@ def test_nmt_step_over_live_positions_equals_the_step_over_all(cfg, dtype):
     model, crit = build(cfg, W, dtype, dropout=0.3)
     model.train()
     l0, o0, g0, s0 = _run(model, crit, I, live=False)
-    l1, o1, g1, s1 = _run(model, crit, I, live=True)
+    l1, o1, g1, s1 = _run(model, crit, I, live="rows")
+    l2, o2, g2, s2 = _run(model, crit, I, live="device")
+    assert l2 == l1 and s2 == s1 and all(torch.equal(g1[k], g2[k]) for k in g1)      # (the device's list is the host's)
     assert torch.equal(o0, o1)                                    # (the forward pass up to the generator is the same launches)
     assert abs(l1 - l0) <= (2e-6 if dtype == "f32" else 2e-5) * max(1.0, abs(l0))
     assert s0 == s1

@@ -34,8 +34,8 @@ for b in range(B):
     tgt[tl[b] - 1, b] = 3; tgt[tl[b]:, b] = 0
 batch = argparse.Namespace(src=src.unsqueeze(2).cuda(), tgt=tgt.cuda(), lengths=lengths.view(1, -1))
 if not a.all_positions:                  # (what the Dataset attaches where it assembles the batch, onmt_dataset_h5.py)
-    from unpaired_image_captioning_amd.models.NMT_Models import tgt_live_positions
-    batch.tgt.uic_live = tgt_live_positions(tgt, batch.tgt.device)
+    from unpaired_image_captioning_amd.models.NMT_Models import tgt_live_count
+    batch.tgt.uic_live = (None, tgt_live_count(tgt))
 ntok = int((tgt[1:] != 0).sum())
 for _ in range(15):                      # (the first process on a fresh box needs more than a few steps to reach its pace)
     tr.train_nmt(batch)

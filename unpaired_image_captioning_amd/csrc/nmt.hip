@@ -529,7 +529,7 @@ struct NmtLayout {
   void* hd[ML]; float* cd[ML]; void* hdrop[ML]; void* gates_d[ML]; void* dg_d[ML]; float* dhrec_d[ML]; float* dcd[ML];
   float* ctxw; void* dctxw; float* attn_all; void* cvec_all; void* out_pre; void* out_all;   // ctxw = context x W_in [S*B, H] f32
   float* logits; void* dlogits; float* row_loss; float* scalars; int* stats;
-  void* out_live; float* d_out_live;
+  void* out_live; float* d_out_live; int* live_map;
   // backward
   float* d_out_all; float* dfeed; void* d_pre_all; float* d_cq_all; float* dscore_all; float* dq;
   // dx_lstm[l]: d[x_l | h_l(t-1)] of decoder layer l > 0, one buffer per layer so that nothing has to be copied
@@ -611,6 +611,7 @@ NmtLayout nmt_layout(const uic_nmt_dims& d, const uic_nmt_weights* w, void* ws) 
   L.dlogits = b.take(Mdp * Vtp * Sz);
   L.out_live = b.take(Mdp * H * Sz);                   // uic_nmt_dims.tgt_live_rows: the listed rows of `out_all`, their d out
   L.d_out_live = (float*)b.take(Mdp * H * 4);
+  L.live_map = (int*)b.take(Mdp * 4);                  // the list made on the device (tgt_live_rows == NULL)
   L.row_loss = (float*)b.take(Td * B * 4);
   L.scalars = (float*)b.take(64);
   L.stats = (int*)b.take(64);
@@ -711,6 +712,7 @@ struct Nmt {
   // uic_nmt_dims.tgt_live_rows: generator, criterion and their gradients over the non-PAD target positions only
   bool live = false;
   int live_n = 0, live_pad = 0;
+  const int32_t* live_rows = nullptr;
 
   int init(const uic_nmt_dims* d_, const uic_nmt_weights* w_, const int64_t* src_, const int32_t* lengths_host,
            const int64_t* tgt_, int training, unsigned seed_, void* ws, const uic_nmt_weights* G_) {
@@ -721,9 +723,10 @@ struct Nmt {
     Sz = uic_dtype_size(dt); BH = (size_t)B * H; BHd = (size_t)B * Hd;
     drop_p = training ? d.drop_p : 0.f;
     seed = seed_;
-    live = d.tgt_live_rows != nullptr && d.tgt_live_count >= 0 && d.tgt_live_count <= Td * B && ((size_t)H * Sz) % 16 == 0;
+    live = d.tgt_live_count > 0 && d.tgt_live_count <= Td * B && ((size_t)H * Sz) % 16 == 0;
     live_n = live ? d.tgt_live_count : 0;
     live_pad = (live_n + 127) & ~127;
+    live_rows = !live ? nullptr : d.tgt_live_rows ? d.tgt_live_rows : L.live_map;
     for (int b = 0; b < B; ++b) {
       UIC_REQUIRE(lengths_host[b] >= 1 && lengths_host[b] <= S, "lengths[%d]=%d outside [1,%d]", b, lengths_host[b], S);
       UIC_REQUIRE(b == 0 || lengths_host[b] <= lengths_host[b - 1], "lengths must be sorted in decreasing order (pack_padded_sequence)");
@@ -1010,7 +1013,8 @@ struct Nmt {
   // generator + NMTCriterion + NMT_loss.score (criterion.py:126-136,175-184)
   int loss_fwd(float* loss_out, int32_t* stats_out, hipStream_t s) {
     UIC_TRY(wait_gen(s));
-    if (live) UIC_TRY(uic_gather_rows_launch(off(L.out_all, BH, dt), d.tgt_live_rows, Td * B, L.out_live, live_n, live_pad, (size_t)H * Sz, s));
+    if (live && !d.tgt_live_rows) UIC_TRY(uic_live_list_launch(L.mask_bt, Td, 0, B, Td * B, L.live_map, live_pad, s));   // (mask_bt: nmt_prep_kernel, this stream)
+    if (live) UIC_TRY(uic_gather_rows_launch(off(L.out_all, BH, dt), live_rows, Td * B, L.out_live, live_n, live_pad, (size_t)H * Sz, s));
     if (!live || live_pad > 0) {
       UicGemmParams g = gemm_base(dt, live ? live_pad : Td * B, Vt);
       add_seg(g, live ? L.out_live : off(L.out_all, BH, dt), H, L.gen_w, H, H);
@@ -1029,7 +1033,7 @@ struct Nmt {
       UIC_TRY(uic_fill_launch(L.stats, 0, 8, s));
       x.score_stats = L.stats;
     }
-    if (live) { x.M = live_pad; x.row_map = d.tgt_live_rows; x.row_map_limit = Td * B; }   // (rows of logits / d logits / row_loss by list position)
+    if (live) { x.M = live_pad; x.row_map = live_rows; x.row_map_limit = Td * B; }   // (rows of logits / d logits / row_loss by list position)
     UIC_TRY(uic_xe_launch(x, s));
     UIC_TRY(uic_reduce_sum_launch(L.row_loss, live ? (size_t)live_n : (size_t)Td * B, 0.f, nullptr, loss_out, s));
     if (stats_out) {
@@ -1050,7 +1054,7 @@ struct Nmt {
       const WDest d1{live ? L.d_out_live : L.d_out_all, (int)H, 0, (int)H};
       if (!live || live_pad > 0) UIC_TRY(wgrad_multi(L.slab, L.slab_bytes, dt, L.dlogits, live ? live_pad : Md, L.gen_wT, H, Vtp, &d1, 1, s));
       // (d out of the positions the list leaves out is zero: zero_backward_buffers cleared the buffer)
-      if (live) UIC_TRY(uic_scatter_rows_launch(L.d_out_live, d.tgt_live_rows, L.d_out_all, Md, live_n, (size_t)H * 4, s));
+      if (live) UIC_TRY(uic_scatter_rows_launch(L.d_out_live, live_rows, L.d_out_all, Md, live_n, (size_t)H * 4, s));
     }
     // the generator's weight / bias gradients (the largest GEMM of the backward pass, [Vt, H] over all target rows) need nothing
     // from the BPTT loop and the loop -- ~6 dependent launches of 64 rows per step -- leaves the chip idle: they run on the side

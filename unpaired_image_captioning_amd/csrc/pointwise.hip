@@ -2034,7 +2034,40 @@ __global__ __launch_bounds__(256) void scatter_rows_kernel(const uint4* __restri
     if ((unsigned)r < (unsigned)limit) dst[(size_t)r * chunks + c] = src[i];
   }
 }
+// out = the positions p = t * N + n, ascending, whose mask[n * ld + col0 + t] is not zero; entries behind them up to out_len: -1.
+// ONE workgroup: an ordered compaction of ~1e4 positions in chunks of 1024 (ballot + wave prefix + one running offset), a few
+// microseconds beside the prologue -- the list never crosses PCIe.
+__global__ __launch_bounds__(1024) void live_list_kernel(const float* __restrict__ mask, int ld, int col0, int N, int M, int* __restrict__ out, int out_len) {
+  __shared__ int s_wave[16];
+  __shared__ int s_base;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  if (tid == 0) s_base = 0;
+  __syncthreads();
+  for (int p0 = 0; p0 < M; p0 += 1024) {
+    const int p = p0 + tid;
+    bool on = false;
+    if (p < M) { const int t = p / N, n = p - t * N; on = mask[(size_t)n * ld + col0 + t] != 0.f; }
+    const unsigned long long b = __ballot(on);
+    const int before = __popcll(b & ((1ull << lane) - 1ull));
+    if (lane == 0) s_wave[wave] = __popcll(b);
+    __syncthreads();
+    int off = s_base;
+    for (int w2 = 0; w2 < wave; ++w2) off += s_wave[w2];
+    if (on && off + before < out_len) out[off + before] = p;
+    __syncthreads();
+    if (tid == 0) { int tot = 0; for (int w2 = 0; w2 < 16; ++w2) tot += s_wave[w2]; s_base += tot; }
+    __syncthreads();
+  }
+  for (int i = s_base + tid; i < out_len; i += 1024) out[i] = -1;
+}
 }  // namespace
+int uic_live_list_launch(const float* mask, int ld, int col0, int N, int M, int* out, int out_len, hipStream_t s) {
+  UIC_REQUIRE(mask && out && N > 0 && M >= 0 && out_len >= 0, "live_list: bad arguments");
+  if (out_len == 0) return UIC_OK;
+  hipLaunchKernelGGL(live_list_kernel, dim3(1), dim3(1024), 0, s, mask, ld, col0, N, M, out, out_len);
+  UIC_LAUNCH_CHECK("live_list");
+  return UIC_OK;
+}
 int uic_gather_rows_launch(const void* src, const int* map, int src_rows, void* out, int M, int Mpad, size_t row_bytes, hipStream_t s) {
   UIC_REQUIRE(row_bytes % 16 == 0 && ((uintptr_t)src & 15) == 0 && ((uintptr_t)out & 15) == 0 && Mpad >= M && M >= 0, "gather_rows: bad arguments");
   if (Mpad == 0) return UIC_OK;

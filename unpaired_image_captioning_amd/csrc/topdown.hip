@@ -51,6 +51,7 @@ struct Layout {
   void* gates1; void* gates2;
   float* atth_all; float* alpha_all; void* ctx_all; void* hdrop_all;
   float* logits; void* dlogits; float* row_loss; float* scalars;
+  int* live_map;                                // the live list made on the device (uic_topdown_batch.live_rows == NULL): [T N + 128]
   void* hc; float* dhc;                         // live-position logit layer (uic_topdown_batch.live_rows): the live rows of hdrop, operand dtype
                                                 // [T N + 128, H]; their d hdrop, f32 [T N, H]
   void* lh[UIC_MAX_LOGIT_LAYERS - 1];       // logit_layers > 1: dropout(relu(hidden logit block l)) [T*N, H]
@@ -138,6 +139,7 @@ Layout make_layout(const uic_topdown_dims& d, void* ws) {
   if (d.logit_layers > 1) L.dlh = (float*)b.take(M * H * 4);
   L.scalars = (float*)b.take(64);
   L.dhdrop = (float*)b.take(M * H * 4);
+  L.live_map = (int*)b.take((M + 128) * 4);
   L.hc = b.take((M + 128) * H * S);
   L.dhc = (float*)b.take((M + 128) * H * 4);
   L.dx2_all = (float*)b.take(M * 3 * H * 4);
@@ -830,14 +832,15 @@ struct Step {
   // zero; positions behind a caption's end -- a quarter of the benchmark's, a third of COCO's -- have loss 0 and gradient 0, so the
   // logit layer (GEMM, criterion, d hdrop, its weight gradient) runs over the listed rows only: gathered into L.hc, logits / d
   // logits / d hdrop compact, d hdrop scattered back into the (zeroed) step-major buffer the BPTT loop reads.
-  bool compact = false;
+  bool compact = false, build_live = false;
   const int32_t* live_rows = nullptr;
   int live_off[UIC_MAX_LIVE_STEPS + 1];
   int live_total() const { return live_off[t_run]; }
   int live_pad() const { return (live_total() + 127) & ~127; }
   void init_live() {
     compact = false;
-    if (!b->live_rows || !b->live_count || !b->masks || t_run > UIC_MAX_LIVE_STEPS || ss_on() || b->grad_scale || nlh() != 0) return;
+    build_live = false;
+    if (!b->live_count || !b->masks || t_run > UIC_MAX_LIVE_STEPS || ss_on() || b->grad_scale || nlh() != 0) return;
     if (((size_t)H * uic_dtype_size(dt)) % 16 != 0) return;     // (rows move as 16-byte pieces)
     live_off[0] = 0;
     for (int t = 0; t < t_run; ++t) {
@@ -845,9 +848,13 @@ struct Step {
       if (c < 0 || c > N) return;                       // (not a list of this batch: the plain path)
       live_off[t + 1] = live_off[t] + c;
     }
-    live_rows = b->live_rows;
+    // (no list from the caller: one small launch compacts the masks on the device, uic_live_list_launch -- the caller then
+    // ships nothing but the counts it sizes the launches with)
+    build_live = b->live_rows == nullptr;
+    live_rows = build_live ? L.live_map : b->live_rows;
     compact = true;
   }
+  int live_build(hipStream_t s) { return uic_live_list_launch(b->masks, b->ld_masks, 1, N, t_run * N, L.live_map, live_pad(), s); }
   int embed_split = 0;           // > 0: ... into the halves [0, embed_split) / [embed_split, t_run) of the decode steps (embed_grad)
   // d.recurrence & UIC_REC_EARLY_GRADS (fused step): the order of the gradient work a data-parallel caller may prefer -- see
   // uic_topdown_xe_train_step
@@ -1750,6 +1757,9 @@ int uic_topdown_xe_train_step(const uic_topdown_dims* d, const uic_topdown_weigh
   // its criterion reads the denominator -- runs on the main stream: there the denominator is made on the main stream.)
   if (b->masks) UIC_TRY(uic_masked_sum_launch(nullptr, b->masks, b->ld_masks, 1, d->N, d->T, st.L.scalars, st.L.scalars + 1,
                                               (training & 4) ? s : s2));
+  // (the live list, when the caller left it to the library: on the side stream ahead of its prologue branch, whose event the main
+  // stream waits for before the recurrence -- every logit chunk on either stream is ordered behind it)
+  if (st.compact && st.build_live) UIC_TRY(st.live_build((training & 4) ? s : s2));
   // the prologue's two independent branches side by side: att_embed + ctx2att here, fc_embed + embedding + the batched
   // input GEMM on the side stream (idle until the recurrence is through; its part of the weight refresh comes first there)
   // training bit 2: the workspace already holds this forward pass (uic_topdown_sample_train drew b->labels with these

@@ -613,6 +613,8 @@ struct UicXeParams {
 int uic_xe_launch(const UicXeParams& p, hipStream_t s);
 // rows by index: out[m] = src[map[m]] (rows [M, Mpad) of out, and rows whose index is outside [0, src_rows), cleared) /
 // dst[map[m]] = src[m] (indices outside [0, dst_rows) skipped); row_bytes % 16 == 0
+// the ascending list of the positions t * N + n (p < M) with mask[n * ld + col0 + t] != 0, padded with -1 up to out_len entries
+int uic_live_list_launch(const float* mask, int ld, int col0, int N, int M, int* out, int out_len, hipStream_t s);
 int uic_gather_rows_launch(const void* src, const int* map, int src_rows, void* out, int M, int Mpad, size_t row_bytes, hipStream_t s);
 int uic_scatter_rows_launch(const void* src, const int* map, void* dst, int dst_rows, int M, size_t row_bytes, hipStream_t s);
 // general log-softmax backward given dense upstream grad g [N,T,V1] (API-compat path):

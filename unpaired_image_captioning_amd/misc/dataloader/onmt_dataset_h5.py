@@ -75,10 +75,9 @@ class onmt_dataset_h5(object):
         tgt_t = np.ascontiguousarray(tgt[order].T)                      # [T, n]
         tgt_dev = self._ship(tgt_t)
         if self.cuda:
-            # the target positions that are not PAD, known here where the batch is assembled: the NMT step's generator and
-            # criterion skip the others (uic_nmt_dims.tgt_live_rows; NMTModel.forward reads the attribute)
-            from ...models.NMT_Models import tgt_live_positions
-            tgt_dev.uic_live = tgt_live_positions(tgt_t, tgt_dev.device)
+            # how many target positions are words is known here where the batch is assembled: the NMT step's generator and
+            # criterion skip the padding (uic_nmt_dims.tgt_live_count; NMTModel.forward reads the attribute)
+            tgt_dev.uic_live = (None, int(np.count_nonzero(tgt_t[1:])))
         return Batch(self._ship(src_t), tgt_dev, lengths.view(1, -1), [int(p) for p in perm], n)
 
     def _ship(self, a):

@@ -162,6 +162,13 @@ class _NmtEngine(object):
         return _lib.nmt_weights(tensors, self.m.encoder.layers)
 
 
+def tgt_live_count(tgt):
+    """The number of target positions that are not PAD (uic_nmt_dims.tgt_live_count): tgt [T, B] host array / tensor.  Attach
+    `(None, count)` to the device batch as `batch.tgt.uic_live`: the step then compacts the targets on the device."""
+    t = tgt.detach().cpu().numpy() if torch.is_tensor(tgt) else np.asarray(tgt)
+    return int(np.count_nonzero(t[1:]))
+
+
 def tgt_live_positions(tgt, device=None):
     """The list of the target positions that are not PAD (uic_nmt_dims.tgt_live_rows, include/uic_hip.h): position t * B + b is
     live when tgt[t + 1, b] != PAD -- NMTCriterion weighs every other one with zero (P/misc/criterion.py:126-136).
@@ -189,9 +196,10 @@ class _NmtStep(torch.autograd.Function):
         d = eng.dims(B, S, T)
         if live is not None:                       # tgt_live_positions(tgt): the generator runs over the non-PAD positions only
             rows, count = live
-            if rows.dtype != torch.int32 or not rows.is_contiguous() or rows.device != src.device or rows.numel() != ((int(count) + 127) // 128) * 128:
-                raise ValueError("tgt.uic_live must be (contiguous int32 device tensor of roundup(count, 128) positions, count)")
-            d.tgt_live_rows = rows.data_ptr()
+            if rows is not None:
+                if rows.dtype != torch.int32 or not rows.is_contiguous() or rows.device != src.device or rows.numel() != ((int(count) + 127) // 128) * 128:
+                    raise ValueError("tgt.uic_live must be (contiguous int32 device tensor of roundup(count, 128) positions or None, count)")
+                d.tgt_live_rows = rows.data_ptr()
             d.tgt_live_count = int(count)
             ctx.live = live                        # (the backward call reads the same list through ctx.d)
         ws = eng.workspace(d, src.device)

@@ -216,18 +216,23 @@ class TopDownEngine(object):
         return d_fc, d_att
 
     def batch_struct(self, fc, att, att_masks, labels=None, masks=None, grad_scale=None, ss_prob=0.0, d_fc=None, d_att=None, live=None):
-        """live: (live_rows [device int32], live_count [host int32 numpy]) of live_positions(masks) -- uic_topdown_batch.live_rows."""
+        """live: (live_rows, live_count) -- uic_topdown_batch.live_rows / live_count: the per-step counts of unmasked positions (host
+        int32 numpy, live_counts(masks)) and, optionally, the list itself (device int32, live_positions(masks)); with live_rows
+        None the step compacts the masks on the device."""
         b = Batch()
-        if live is not None and live[0] is not None:
+        if live is not None and live[1] is not None:
             rows, count = live
-            if rows.dtype != torch.int32 or not rows.is_contiguous() or rows.device != fc.device:
-                raise ValueError("live_rows must be a contiguous int32 tensor on the batch's device")
             count = np.ascontiguousarray(count, dtype=np.int32)
             T = (labels.shape[1] - 1) if labels is not None else 0
-            if count.shape != (T,) or rows.numel() != ((int(count.sum()) + 127) // 128) * 128:
-                raise ValueError("live_count must hold one entry per decode step (%d) and live_rows roundup(sum, 128) entries" % T)
+            if count.shape != (T,):
+                raise ValueError("live_count must hold one entry per decode step (%d)" % T)
+            if rows is not None:
+                if rows.dtype != torch.int32 or not rows.is_contiguous() or rows.device != fc.device:
+                    raise ValueError("live_rows must be a contiguous int32 tensor on the batch's device")
+                if rows.numel() != ((int(count.sum()) + 127) // 128) * 128:
+                    raise ValueError("live_rows must hold roundup(sum(live_count), 128) entries")
+                b.live_rows = rows.data_ptr()
             b._keep_live = (rows, count)
-            b.live_rows = rows.data_ptr()
             b.live_count = count.ctypes.data_as(C.POINTER(C.c_int32))
         att = self._pad_att(att)
         b._keep = att                          # (a padded copy must outlive the call)
@@ -411,6 +416,13 @@ class TopDownEngine(object):
             n *= s
         esz = torch.empty(0, dtype=dtype).element_size()
         return ws.buf[offset:offset + n * esz].view(dtype).view(*shape)
+
+
+def live_counts(masks):
+    """Per decode step, the number of positions whose mask is not zero (uic_topdown_batch.live_count): masks [N, T + 1] host
+    array (the loader makes it on the host, P/misc/dataloader/dataloader.py:200-203) -> int32 numpy [T]."""
+    m = masks.detach().cpu().numpy() if torch.is_tensor(masks) else np.asarray(masks)
+    return np.count_nonzero(m[:, 1:], axis=0).astype(np.int32)
 
 
 def live_positions(masks, device=None):

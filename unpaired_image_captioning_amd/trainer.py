@@ -15,7 +15,7 @@ import torch
 
 from . import _lib, models
 from ._lib import check, ptr, stream
-from .topdown_engine import live_positions
+from .topdown_engine import live_counts
 from .misc.optimizer import FlatArena, Optim  # noqa: F401
 from .parallel_exchange import GradientExchange
 
@@ -47,7 +47,7 @@ def xe_step(model, batch, t_run=None, inv_den=None, grads=None, return_seed=Fals
     if fused:
         if grads is None:
             grads = {k: torch.empty_like(v) for k, v in pd.items()}
-        live = (batch["live_rows"], batch["live_count"]) if batch.get("live_rows") is not None else None
+        live = (batch.get("live_rows"), batch["live_count"]) if batch.get("live_count") is not None else None
         out = eng.xe_train_step(pd, batch["fc_feats"], batch["att_feats"], batch.get("att_masks"), labels, batch["masks"],
                                 t_run, training, seed, grads, inv_den, ss_prob=ss_prob, d_fc=d_fc, d_att=d_att, out=out, live=live)
         if return_seed:
@@ -270,19 +270,17 @@ class Trainer(object):
             out[k] = self._ship(k, v, torch.int64 if k == "labels" else torch.float32)
         self._replication_checked = True
         if getattr(self.opt, 'live_positions', 1) and data.get("masks") is not None and not torch.is_tensor(data["masks"]):
-            # the positions behind the captions' ends are known here, on the host, where the loader made the masks: the step's
-            # logit layer and criterion skip them (uic_topdown_batch.live_rows; opt.live_positions = 0 computes every position)
-            rows, count = live_positions(data["masks"])
-            out["live_rows"] = self._ship("live_rows", rows, torch.int32)
-            out["live_count"] = count
+            # how many positions of each decode step lie in front of their caption's end is known here, on the host, where the
+            # loader made the masks: the step's logit layer and criterion skip the others (uic_topdown_batch.live_count: the step
+            # compacts the device masks itself, nothing more is shipped; opt.live_positions = 0 computes every position)
+            out["live_count"] = live_counts(data["masks"])
         return out
 
     @staticmethod
     def attach_live(batch):
-        """Adds the live-position list to a DEVICE batch (a resident benchmark batch; Trainer.to_device does it for host batches).
-        One device-to-host read of the masks: call it once per batch, outside a timed region."""
-        rows, count = live_positions(batch["masks"])
-        batch["live_rows"], batch["live_count"] = rows, count
+        """Adds the per-step counts of unmasked positions to a DEVICE batch (a resident benchmark batch; Trainer.to_device does it
+        for host batches).  One device-to-host read of the masks: call it once per batch, outside a timed region."""
+        batch["live_count"] = live_counts(batch["masks"])
         return batch
 
     def _ship(self, key, t, dtype):
