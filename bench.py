@@ -375,13 +375,14 @@ def main():
         # (the synthetic batch is resident and the same every step: its mask sum is "the next batch's" too -- a data-parallel run
         # carries it in the step's small all-reduce instead of a collective in front of the next forward pass, as Trainer.train
         # does with next_data=)
-        for _ in range(args.warmup):
-            tr.train_device_batch(bt, t_run, den_local, den_local)
         # (a full pass of Python's cyclic garbage collector over the interpreter's ~1e6 objects takes ~40 ms on these hosts -- 15 steps --
         # and falls wherever the allocation count happens to trip it: collect now and move what is alive out of the collector's
-        # way, as a training loop that cares does once after start-up, instead of timing the collector)
+        # way, as a training loop that cares does once after start-up, instead of timing the collector.  In FRONT of the warm-up
+        # steps: the GPU goes from them straight into the timed region)
         gc.collect()
         gc.freeze()
+        for _ in range(args.warmup):
+            tr.train_device_batch(bt, t_run, den_local, den_local)
         barrier()
         t0 = time.perf_counter()
         for _ in range(args.steps):
