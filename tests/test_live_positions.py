@@ -117,7 +117,9 @@ def test_step_over_live_positions_vs_reference_golden(name, dtype, form):
 @pytest.mark.parametrize("dtype", ["f32", "bf16"])
 @pytest.mark.parametrize("shape", [dict(V=1000, E=96, H=160, A=128, D=200, L=9, n_img=14, S=5, R=50),
                                    dict(V=2047, E=128, H=128, A=128, D=256, L=12, n_img=40, S=5, R=36),
-                                   dict(V=300, E=64, H=64, A=64, D=64, L=6, n_img=3, S=1, R=7)])
+                                   dict(V=300, E=64, H=64, A=64, D=64, L=6, n_img=3, S=1, R=7),
+                                   # 1050 rows x 17 steps = 17 850 positions: past the one-round-trip list kernel's 16 384
+                                   dict(V=300, E=64, H=64, A=64, D=64, L=16, n_img=210, S=5, R=7)])
 def test_step_over_live_positions_equals_the_step_over_all(shape, dtype):
     """Same weights, same batch, same dropout seed: the step with the list and the step without it agree to summation order (the
     weight gradient sums the same products over fewer, reordered rows; d hdrop rows are the same dot products)."""
