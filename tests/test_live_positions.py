@@ -142,6 +142,38 @@ def test_step_over_live_positions_equals_the_step_over_all(shape, dtype):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+def test_arbitrary_masks_holes_empty_steps_and_fractional_weights(dtype):
+    """The list is defined by mask != 0, not by caption lengths: masks with holes, a decode step without a single live row (an
+    empty chunk of the logit layer), fractional mask weights and a row without any live position give the step over all positions."""
+    from oracle import topdown as O
+    from test_gpu_topdown import make_opt
+    from unpaired_image_captioning_amd import models
+    shape = dict(V=500, E=64, H=64, A=64, D=96, L=11, n_img=9, S=5, R=12)
+    torch.manual_seed(8)
+    model = models.setup(make_opt(shape, dtype, drop=0.5, seed=2)).cuda().train()
+    b = O.synthetic_batch(shape["n_img"], shape["S"], shape["R"], shape["D"], shape["V"], shape["L"], seed=3)
+    g = torch.Generator().manual_seed(4)
+    T = b["masks"].shape[1] - 1
+    m = (torch.rand(b["masks"].shape, generator=g) < 0.6).float() * (0.25 + torch.rand(b["masks"].shape, generator=g))
+    m[:, 1 + 4] = 0.0                                     # decode step 4: nothing live
+    m[:, 1 + 5] = 0.0                                     # ... nor step 5 (steps 4-7 are one chunk: partly empty)
+    m[7, :] = 0.0                                         # a row that contributes nothing
+    m[:, 1 + T - 1] = 0.0
+    m[3, 1 + T - 1] = 1.0                                 # the last step: one live row (the chunk in front of the BPTT loop)
+    b["labels"][3, 1:] = torch.randint(1, shape["V"], (T,), generator=g)     # (so that every step is run: no early break)
+    b["masks"] = m
+    batch = {k: v.cuda() for k, v in b.items()}
+    assert model._steps_to_run(batch["labels"]) == T
+    l0, g0 = _step(model, batch, live=False)
+    l1, g1 = _step(model, batch, live="rows")
+    l2, g2 = _step(model, batch, live="device")
+    assert abs(l1 - l0) < (2e-6 if dtype == "f32" else 2e-5) * max(1.0, abs(l0))
+    _same(g1, g0, 2e-5 if dtype == "f32" else 2e-3)
+    assert l2 == l1 and all(torch.equal(g1[k], g2[k]) for k in g1)
+
+
+@pytest.mark.gpu
 def test_full_size_step_over_live_positions_bf16():
     """BASELINE config 2 (640 caption rows, 9488 words): with and without the list."""
     from oracle import topdown as O
