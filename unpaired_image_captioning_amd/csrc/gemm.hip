@@ -886,7 +886,39 @@ __global__ void splitk_reduce_vec_kernel(const float* __restrict__ slab, int spl
     *o = v;
   }
 }
+// the same sum with the output rows placed by a list: row r < map_rows of the slab goes to row map[r] of C (entries outside
+// [0, map_limit) -- a list's -1 padding -- and rows >= map_rows are dropped).  The live-position logit layer's d hdrop (topdown.hip).
+__global__ void splitk_reduce_rows_kernel(const float* __restrict__ slab, int splitk, int M, int N, const int* __restrict__ map, int map_rows,
+                                          int map_limit, float* __restrict__ C, int ldc) {
+  const int c = (blockIdx.x * blockDim.x + threadIdx.x) * 4;
+  if (c >= N) return;
+  const size_t MN = (size_t)M * N;
+  for (int row = blockIdx.y; row < map_rows; row += gridDim.y) {
+    const int orow = map[row];
+    const float* src = slab + (size_t)row * N + c;
+    float4 v = *(const float4*)src;
+    for (int z = 1; z < splitk; ++z) {
+      const float4 w = *(const float4*)(src + (size_t)z * MN);
+      v.x += w.x; v.y += w.y; v.z += w.z; v.w += w.w;
+    }
+    if ((unsigned)orow < (unsigned)map_limit) *(float4*)(C + (size_t)orow * ldc + c) = v;
+  }
+}
 }  // namespace
+
+bool uic_splitk_reduce_rows_ok(const float* slab, int M, int N, const float* C, int ldc) {
+  return N % 4 == 0 && ldc % 4 == 0 && ((uintptr_t)slab & 15) == 0 && ((uintptr_t)C & 15) == 0 && ((size_t)M * N) % 4 == 0;
+}
+int uic_splitk_reduce_rows_launch(const float* slab, int splitk, int M, int N, const int* map, int map_rows, int map_limit, float* C, int ldc,
+                                  hipStream_t s) {
+  UIC_REQUIRE(map && map_rows <= M && uic_splitk_reduce_rows_ok(slab, M, N, C, ldc), "splitk_reduce_rows: bad arguments");
+  if (map_rows <= 0) return UIC_OK;
+  const int bt = N / 4 >= 256 ? 256 : ((N / 4 + 63) / 64) * 64;
+  hipLaunchKernelGGL(splitk_reduce_rows_kernel, dim3((unsigned)((N / 4 + bt - 1) / bt), (unsigned)(map_rows > 65535 ? 65535 : map_rows)), dim3(bt), 0, s,
+                     slab, splitk, M, N, map, map_rows, map_limit, C, ldc);
+  UIC_LAUNCH_CHECK("splitk_reduce_rows");
+  return UIC_OK;
+}
 
 int uic_splitk_reduce_launch(const float* slab, int splitk, int M, int N, int col0, int ncols, float* C, int ldc, hipStream_t s,
                              int accumulate) {

@@ -1052,9 +1052,11 @@ struct Nmt {
       // over workgroups with the deterministic slab reduction (wgrad_multi; one launch of 64 x 64 tiles walked all 50 048 columns
       // in 347 us)
       const WDest d1{live ? L.d_out_live : L.d_out_all, (int)H, 0, (int)H};
-      if (!live || live_pad > 0) UIC_TRY(wgrad_multi(L.slab, L.slab_bytes, dt, L.dlogits, live ? live_pad : Md, L.gen_wT, H, Vtp, &d1, 1, s));
-      // (d out of the positions the list leaves out is zero: zero_backward_buffers cleared the buffer)
-      if (live) UIC_TRY(uic_scatter_rows_launch(L.d_out_live, live_rows, L.d_out_all, Md, live_n, (size_t)H * 4, s));
+      // (d out of the positions the list leaves out is zero: zero_backward_buffers cleared the buffer; the split-K reduce places
+      // the listed rows itself, a direct GEMM leaves compact rows to scatter)
+      WRows wr{live_rows, live_n, Md, L.d_out_all, (int)H, false};
+      if (!live || live_pad > 0) UIC_TRY(wgrad_multi(L.slab, L.slab_bytes, dt, L.dlogits, live ? live_pad : Md, L.gen_wT, H, Vtp, &d1, 1, s, false, live ? &wr : nullptr));
+      if (live && !wr.used) UIC_TRY(uic_scatter_rows_launch(L.d_out_live, live_rows, L.d_out_all, Md, live_n, (size_t)H * 4, s));
     }
     // the generator's weight / bias gradients (the largest GEMM of the backward pass, [Vt, H] over all target rows) need nothing
     // from the BPTT loop and the loop -- ~6 dependent launches of 64 rows per step -- leaves the chip idle: they run on the side

@@ -1136,7 +1136,10 @@ struct Step {
       // generic one, 50 -> 17 us on the main stream in front of the BPTT loop: the rows behind the chunk's are the next chunk's or
       // padding, inside both buffers, and what they produce is not scattered)
       const int rows = real < 128 ? 128 : real;
-      UIC_TRY(wgrad_multi(side ? L.slab2 : L.slab, L.slab_bytes, dt, off(L.dlogits, (size_t)c0 * V1p, dt), rows, dv.logit_wT, H, V1p, &dc, 1, s));
+      // (the split-K reduce places the rows itself; the direct GEMM -- shapes off the split-K path -- leaves compact rows to scatter)
+      WRows wr{live_rows + c0, real, Meff, L.dhdrop, H, false};
+      UIC_TRY(wgrad_multi(side ? L.slab2 : L.slab, L.slab_bytes, dt, off(L.dlogits, (size_t)c0 * V1p, dt), rows, dv.logit_wT, H, V1p, &dc, 1, s, false, &wr));
+      if (wr.used) return UIC_OK;
       return uic_scatter_rows_launch(L.dhc + (size_t)c0 * H, live_rows + c0, L.dhdrop, Meff, real, (size_t)H * 4, s);
     }
     const size_t r0 = (size_t)t0 * N;

@@ -220,6 +220,10 @@ struct UicGemmParams {
   void* C_exp2;
 };
 // C[row, c - col0] = sum_z slab[z][row, c] for c in [col0, col0 + ncols)
+// ... with the output rows placed by a list (rows r < map_rows -> row map[r] of C; entries outside [0, map_limit) dropped)
+bool uic_splitk_reduce_rows_ok(const float* slab, int M, int N, const float* C, int ldc);
+int uic_splitk_reduce_rows_launch(const float* slab, int splitk, int M, int N, const int* map, int map_rows, int map_limit, float* C, int ldc,
+                                  hipStream_t s);
 int uic_splitk_reduce_launch(const float* slab, int splitk, int M, int N, int col0, int ncols, float* C, int ldc, hipStream_t s,
                              int accumulate = 0);   // accumulate: C += sum_z slab[z]
 // true if the large-GEMM (LDS-DMA) path accepts this single-segment problem

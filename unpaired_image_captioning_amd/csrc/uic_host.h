@@ -40,8 +40,12 @@ inline void add_seg(UicGemmParams& g, const void* A, int lda, const void* B, int
 // (right operands stacked row-wise in `right`).  Long-K, few-tile problems run split-K over workgroups on the
 // LDS-DMA GEMM with deterministic slab reduction; anything else falls back to one direct GEMM per destination.
 struct WDest { float* C; int ldc; int col0; int ncols; };
+// rows: optional (one destination, no accumulate): the split-K path stores output row r < rows->n at row rows->map[r] of rows->C
+// instead of dst (entries outside [0, rows->limit) dropped) and sets rows->used; the direct path ignores it and writes dst
+struct WRows { const int* map; int n; int limit; float* C; int ldc; bool used; };
 inline int wgrad_multi(float* slab, size_t slab_bytes, int dt, const void* left, int lrows, const void* right, int rrows, int K,
-                const WDest* dst, int nd, hipStream_t s, bool accumulate = false) {
+                const WDest* dst, int nd, hipStream_t s, bool accumulate = false, WRows* rows = nullptr) {
+  if (rows) rows->used = false;
   const long blocks = (long)((lrows + 127) / 128) * ((rrows + 127) / 128);
   if (uic_gemm_glds_eligible(dt, K) && lrows >= 128 && rrows >= 128) {
     const int nt = K / (dt == UIC_BF16 ? 64 : 32);
@@ -61,6 +65,13 @@ inline int wgrad_multi(float* slab, size_t slab_bytes, int dt, const void* left,
       add_seg(g, left, K, right, K, K);
       g.splitk = sk; g.slab = slab;
       UIC_TRY(uic_gemm_launch(g, s));
+#ifndef UIC_NO_REDUCE_ROWS        // (A/B builds: the separate scatter launch)
+      if (rows && nd == 1 && !accumulate && dst[0].col0 == 0 && dst[0].ncols == rrows && rows->n <= lrows &&
+          uic_splitk_reduce_rows_ok(slab, lrows, rrows, rows->C, rows->ldc)) {
+        rows->used = true;
+        return uic_splitk_reduce_rows_launch(slab, sk, lrows, rrows, rows->map, rows->n, rows->limit, rows->C, rows->ldc, s);
+      }
+#endif
       for (int i = 0; i < nd; ++i)
         UIC_TRY(uic_splitk_reduce_launch(slab, sk, lrows, rrows, dst[i].col0, dst[i].ncols, dst[i].C, dst[i].ldc, s, accumulate ? 1 : 0));
       return UIC_OK;
