@@ -2037,7 +2037,10 @@ __global__ __launch_bounds__(256) void scatter_rows_kernel(const uint4* __restri
 // out = the positions p = t * N + n, ascending, whose mask[n * ld + col0 + t] is not zero; entries behind them up to out_len: -1.
 // ONE workgroup: an ordered compaction of ~1e4 positions in chunks of 1024 (ballot + wave prefix + one running offset), a few
 // microseconds beside the prologue -- the list never crosses PCIe.
-__global__ __launch_bounds__(1024) void live_list_kernel(const float* __restrict__ mask, int ld, int col0, int N, int M, int* __restrict__ out, int out_len) {
+// inv (optional, [M]): the inverse -- inv[p] = the list index of position p, or -1; zero16 (optional): n16 16-byte words cleared on
+// the way (the padding rows of the compact operand the list's consumer fills by itself, rnn_persist.hip)
+__global__ __launch_bounds__(1024) void live_list_kernel(const float* __restrict__ mask, int ld, int col0, int N, int M, int* __restrict__ out, int out_len,
+                                                         int* __restrict__ inv, uint4* __restrict__ zero16, int n16) {
   __shared__ int s_wave[16];
   __shared__ int s_base;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -2054,17 +2057,20 @@ __global__ __launch_bounds__(1024) void live_list_kernel(const float* __restrict
     int off = s_base;
     for (int w2 = 0; w2 < wave; ++w2) off += s_wave[w2];
     if (on && off + before < out_len) out[off + before] = p;
+    if (inv && p < M) inv[p] = on && off + before < out_len ? off + before : -1;
     __syncthreads();
     if (tid == 0) { int tot = 0; for (int w2 = 0; w2 < 16; ++w2) tot += s_wave[w2]; s_base += tot; }
     __syncthreads();
   }
   for (int i = s_base + tid; i < out_len; i += 1024) out[i] = -1;
+  for (int i = tid; i < n16; i += 1024) zero16[i] = make_uint4(0u, 0u, 0u, 0u);
 }
 // the same for M <= 16 x 1024 positions (the captioner's 10 880, the NMT step's ~2 000) with ONE round trip to memory: every
 // thread requests its <= 16 mask words at once, the per-(round, wave) counts meet in LDS, one wave scans the 256 of them
 // (19 -> 4 us: the first form paid a memory latency and three barriers per 1024 positions)
 constexpr int LL_R = 16;
-__global__ __launch_bounds__(1024) void live_list_burst_kernel(const float* __restrict__ mask, int ld, int col0, int N, int M, int* __restrict__ out, int out_len) {
+__global__ __launch_bounds__(1024) void live_list_burst_kernel(const float* __restrict__ mask, int ld, int col0, int N, int M, int* __restrict__ out, int out_len,
+                                                               int* __restrict__ inv, uint4* __restrict__ zero16, int n16) {
   __shared__ int s_cnt[LL_R * 16];
   __shared__ int s_off[LL_R * 16 + 1];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -2104,15 +2110,19 @@ __global__ __launch_bounds__(1024) void live_list_burst_kernel(const float* __re
     const unsigned long long b = __ballot(on);
     const int at = s_off[i * 16 + wave] + __popcll(b & ((1ull << lane) - 1ull));
     if (on && at < out_len) out[at] = i * 1024 + tid;
+    if (inv && i * 1024 + tid < M) inv[i * 1024 + tid] = on && at < out_len ? at : -1;
   }
   for (int i = s_off[LL_R * 16] + tid; i < out_len; i += 1024) out[i] = -1;
+  for (int i = tid; i < n16; i += 1024) zero16[i] = make_uint4(0u, 0u, 0u, 0u);
 }
 }  // namespace
-int uic_live_list_launch(const float* mask, int ld, int col0, int N, int M, int* out, int out_len, hipStream_t s) {
+int uic_live_list_launch(const float* mask, int ld, int col0, int N, int M, int* out, int out_len, hipStream_t s, int* inv, void* zero, size_t zero_bytes) {
   UIC_REQUIRE(mask && out && N > 0 && M >= 0 && out_len >= 0, "live_list: bad arguments");
-  if (out_len == 0) return UIC_OK;
-  if (M <= LL_R * 1024 && M > 0) hipLaunchKernelGGL(live_list_burst_kernel, dim3(1), dim3(1024), 0, s, mask, ld, col0, N, M, out, out_len);
-  else hipLaunchKernelGGL(live_list_kernel, dim3(1), dim3(1024), 0, s, mask, ld, col0, N, M, out, out_len);
+  UIC_REQUIRE(zero_bytes == 0 || (zero && ((uintptr_t)zero & 15) == 0 && zero_bytes % 16 == 0 && zero_bytes < ((size_t)1 << 30)), "live_list: the cleared region must be 16-byte aligned / sized");
+  if (out_len == 0 && !inv) return UIC_OK;
+  const int n16 = (int)(zero_bytes / 16);
+  if (M <= LL_R * 1024 && M > 0) hipLaunchKernelGGL(live_list_burst_kernel, dim3(1), dim3(1024), 0, s, mask, ld, col0, N, M, out, out_len, inv, (uint4*)zero, n16);
+  else hipLaunchKernelGGL(live_list_kernel, dim3(1), dim3(1024), 0, s, mask, ld, col0, N, M, out, out_len, inv, (uint4*)zero, n16);
   UIC_LAUNCH_CHECK("live_list");
   return UIC_OK;
 }

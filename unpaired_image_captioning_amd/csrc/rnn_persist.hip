@@ -1416,6 +1416,15 @@ __device__ __forceinline__ void ws_run(const UicRnnFwdParams& p, Ctx& c, char* l
           const bool more = DEC ? (i + 1 < MT_MAX && i + 1 < c.MT) : i + 1 < MT_MAX;      // training kernel: compile-time (see mfma_range)
           const int tile = tile_of(i);
           const unsigned an = aoff_of(tile_of(i + 1 < MT_MAX && i + 1 < c.MT ? i + 1 : i));
+          // (live-position logit layer: where this lane's row of the tile goes in the compact operand -- requested now, used in the
+          // epilogue behind the MFMAs; a valid address whatever the row)
+          int live_ci = -1;
+          if constexpr (!DEC) {
+            if (p.live_inv) {
+              const int rq = 16 * tile + 4 * c.lq + c.wave;
+              live_ci = p.live_inv[t * N + c.rbegin + (rq < c.nrow ? rq : 0)];
+            }
+          }
           // The stationary B fragments are named as ACCUMULATOR-file operands ("a"), which is what keeps them there for the
           // whole launch: left to itself hipcc parks them in AGPRs but copies each one back (4 x v_accvgpr_read) in front of
           // every MFMA.  Inline-asm MFMAs get no hazard padding from the compiler: gate g's chain is re-entered only after
@@ -1480,7 +1489,11 @@ __device__ __forceinline__ void ws_run(const UicRnnFwdParams& p, Ctx& c, char* l
                 if (p.drop_p > 0.f) hd *= uic_drop_scale(p.seed, UIC_SITE_OUT0 + (unsigned)t, o, p.drop_p, 1.f / (1.f - p.drop_p));
                 // (decode mode: the logit phase of every workgroup of the group reads these rows -- exchanged data)
                 if (DEC) st_x<SAFE>((T*)p.hdrop_all + (size_t)t * NH + o, hd);
-                else ((T*)p.hdrop_all)[(size_t)t * NH + o] = (bf16_t)hd;
+                else {
+                  ((T*)p.hdrop_all)[(size_t)t * NH + o] = (bf16_t)hd;
+                  // (live-position logit layer: the row also goes to its place in the compact operand -- no gather launches)
+                  if (live_ci >= 0) ((T*)p.hdrop_live)[(size_t)live_ci * HH + u] = (bf16_t)hd;
+                }
               }
               if (p.gates2) {
                 T* G = (T*)p.gates2 + (size_t)t * N * 4 * HH + 4u * nn + u;

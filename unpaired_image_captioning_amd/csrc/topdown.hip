@@ -51,6 +51,7 @@ struct Layout {
   void* gates1; void* gates2;
   float* atth_all; float* alpha_all; void* ctx_all; void* hdrop_all;
   float* logits; void* dlogits; float* row_loss; float* scalars;
+  int* live_inv;                                // ... and its inverse [T N]: position -> list index or -1 (the recurrence stores hdrop rows by it)
   int* live_map;                                // the live list made on the device (uic_topdown_batch.live_rows == NULL): [T N + 128]
   void* hc; float* dhc;                         // live-position logit layer (uic_topdown_batch.live_rows): the live rows of hdrop, operand dtype
                                                 // [T N + 128, H]; their d hdrop, f32 [T N, H]
@@ -140,6 +141,7 @@ Layout make_layout(const uic_topdown_dims& d, void* ws) {
   L.scalars = (float*)b.take(64);
   L.dhdrop = (float*)b.take(M * H * 4);
   L.live_map = (int*)b.take((M + 128) * 4);
+  L.live_inv = (int*)b.take(M * 4);
   L.hc = b.take((M + 128) * H * S);
   L.dhc = (float*)b.take((M + 128) * H * 4);
   L.dx2_all = (float*)b.take(M * 3 * H * 4);
@@ -854,7 +856,16 @@ struct Step {
     live_rows = build_live ? L.live_map : b->live_rows;
     compact = true;
   }
-  int live_build(hipStream_t s) { return uic_live_list_launch(b->masks, b->ld_masks, 1, N, t_run * N, L.live_map, live_pad(), s); }
+  // fused_gather: the persistent recurrence stores every live row of hdrop into the compact operand itself (rnn_persist.hip, by the
+  // list's inverse): no gather launches -- one of them sat on the main stream in front of the BPTT loop.  The list kernel clears the
+  // operand's padding rows then.
+  bool fused_gather = false;
+  int live_build(hipStream_t s) {
+    const size_t S = uic_dtype_size(dt);
+    return uic_live_list_launch(b->masks, b->ld_masks, 1, N, t_run * N, L.live_map, live_pad(), s, fused_gather ? L.live_inv : nullptr,
+                                fused_gather ? offw(L.hc, (size_t)live_total() * H, dt) : nullptr,
+                                fused_gather ? (size_t)(live_pad() - live_total()) * H * S : 0);
+  }
   int embed_split = 0;           // > 0: ... into the halves [0, embed_split) / [embed_split, t_run) of the decode steps (embed_grad)
   // d.recurrence & UIC_REC_EARLY_GRADS (fused step): the order of the gradient work a data-parallel caller may prefer -- see
   // uic_topdown_xe_train_step
@@ -1046,6 +1057,7 @@ struct Step {
     p.gates1 = L.gates1; p.gates2 = L.gates2;
     p.att_h_all = L.atth_all; p.alpha_all = L.alpha_all; p.ctx_all = L.ctx_all; p.hdrop_all = L.hdrop_all;
     p.drop_p = drop_p; p.seed = seed;
+    if (fused_gather) { p.live_inv = L.live_inv; p.hdrop_live = L.hc; }
     p.sync = L.rnn_sync; p.sync_zeroed = fwd_sync_clean ? 1 : 0;
     fwd_sync_clean = false;            // (one launch's worth)
     p.force_safe = (d.recurrence & UIC_REC_SAFE) != 0; p.status = d.rnn_status;
@@ -1069,7 +1081,7 @@ struct Step {
   int live_rows_of(int t0, int t1) const { return (t1 == t_run ? live_pad() : live_off[t1]) - live_off[t0]; }
   int logits_rows_live(int t0, int t1, hipStream_t s) {
     const int c0 = live_c0(t0), real = live_off[t1] - c0, rows = live_rows_of(t0, t1);
-    UIC_TRY(uic_gather_rows_launch(L.hdrop_all, live_rows + c0, Meff, offw(L.hc, (size_t)c0 * H, dt), real, rows, (size_t)H * uic_dtype_size(dt), s));
+    if (!fused_gather) UIC_TRY(uic_gather_rows_launch(L.hdrop_all, live_rows + c0, Meff, offw(L.hc, (size_t)c0 * H, dt), real, rows, (size_t)H * uic_dtype_size(dt), s));
     if (rows == 0) return UIC_OK;
     UicGemmParams g = gemm_base(dt, rows, V1);
     add_seg(g, off(L.hc, (size_t)c0 * H, dt), H, dv.logit_w, H, H);
@@ -1762,6 +1774,10 @@ int uic_topdown_xe_train_step(const uic_topdown_dims* d, const uic_topdown_weigh
                                               (training & 4) ? s : s2));
   // (the live list, when the caller left it to the library: on the side stream ahead of its prologue branch, whose event the main
   // stream waits for before the recurrence -- every logit chunk on either stream is ordered behind it)
+  // (the whole recurrence as one launch of the weight-stationary kernel: it fills the compact operand itself)
+#ifndef UIC_NO_FUSED_GATHER          // (A/B builds: the gather launches)
+  st.fused_gather = st.compact && st.build_live && !(training & 4) && st.persist_ok() && st.dt == UIC_BF16;
+#endif
   if (st.compact && st.build_live) UIC_TRY(st.live_build((training & 4) ? s : s2));
   // the prologue's two independent branches side by side: att_embed + ctx2att here, fc_embed + embedding + the batched
   // input GEMM on the side stream (idle until the recurrence is through; its part of the weight refresh comes first there)

@@ -314,6 +314,8 @@ struct UicRnnFwdParams {
   const void* h2att_w; const float* h2att_b;     // [A, H]
   const float* w_alpha; const float* b_alpha;
   const void* p_att; const void* att;            // [N, R, A], [N, R, H]
+  const int* live_inv; void* hdrop_live;   // optional (weight-stationary training kernel): live_inv[t * N + n] = the row of hdrop_live [., H] that
+                                     // position (t, n)'s dropped h_lang is ALSO stored to, or -1 (the live-position logit layer's compact operand)
   const void* e_att;                 // [N, R, A] bf16 e^{2 p_att} (uic_exp2x2_launch): what the weight-stationary TRAINING kernel's attention reads in
                                      // place of p_att (required there); ignored by the decode and the generic kernels
   const float* mask; int ldmask;                 // [N, R] or null
@@ -618,7 +620,9 @@ int uic_xe_launch(const UicXeParams& p, hipStream_t s);
 // rows by index: out[m] = src[map[m]] (rows [M, Mpad) of out, and rows whose index is outside [0, src_rows), cleared) /
 // dst[map[m]] = src[m] (indices outside [0, dst_rows) skipped); row_bytes % 16 == 0
 // the ascending list of the positions t * N + n (p < M) with mask[n * ld + col0 + t] != 0, padded with -1 up to out_len entries
-int uic_live_list_launch(const float* mask, int ld, int col0, int N, int M, int* out, int out_len, hipStream_t s);
+// inv (optional, [M]): inv[p] = the list index of position p or -1; zero / zero_bytes (optional): a region cleared by the same launch
+int uic_live_list_launch(const float* mask, int ld, int col0, int N, int M, int* out, int out_len, hipStream_t s, int* inv = nullptr,
+                         void* zero = nullptr, size_t zero_bytes = 0);
 int uic_gather_rows_launch(const void* src, const int* map, int src_rows, void* out, int M, int Mpad, size_t row_bytes, hipStream_t s);
 int uic_scatter_rows_launch(const void* src, const int* map, void* dst, int dst_rows, int M, size_t row_bytes, hipStream_t s);
 // general log-softmax backward given dense upstream grad g [N,T,V1] (API-compat path):
