@@ -354,6 +354,15 @@ __global__ __launch_bounds__(NTHREADS) void attn_bwd_step_fast_kernel(const UicA
   float* s_red = s_da4 + 4 * Rp;
   const int n = blockIdx.x;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  if (p.row_len && p.step >= p.row_len[n]) {
+    // a caption that ended before this decode step: d ctx is all zero, so is everything this workgroup would compute -- written
+    // without a single operand read (one scalar load decides; a third of a real batch's (step, row) pairs)
+    if (p.dctx_sum) for (int h = tid; h < H; h += NTHREADS) p.dctx_sum[(size_t)n * p.ld_dctx_sum + h] = 0.f;
+    for (int r = tid; r < R; r += NTHREADS) p.de[(size_t)n * R + r] = 0.f;
+    T* out0 = (T*)p.d_att_h + (size_t)n * A;
+    for (int a = tid; a < A; a += NTHREADS) out0[a] = uic_from_f<T>(0.f);
+    return;
+  }
   const bool la = FULL ? true : lane < A / VEC, lh = FULL ? true : lane < H / VEC;
   const T* pa = (const T*)p.p_att + (size_t)n * R * A + (la ? lane : 0) * VEC;
   const T* pt = (const T*)p.att + (size_t)n * R * H + (lh ? lane : 0) * VEC;

@@ -2040,16 +2040,21 @@ __global__ __launch_bounds__(256) void scatter_rows_kernel(const uint4* __restri
 // inv (optional, [M]): the inverse -- inv[p] = the list index of position p, or -1; zero16 (optional): n16 16-byte words cleared on
 // the way (the padding rows of the compact operand the list's consumer fills by itself, rnn_persist.hip)
 __global__ __launch_bounds__(1024) void live_list_kernel(const float* __restrict__ mask, int ld, int col0, int N, int M, int* __restrict__ out, int out_len,
-                                                         int* __restrict__ inv, uint4* __restrict__ zero16, int n16) {
+                                                         int* __restrict__ inv, uint4* __restrict__ zero16, int n16, int* __restrict__ row_len) {
   __shared__ int s_wave[16];
   __shared__ int s_base;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   if (tid == 0) s_base = 0;
+  if (row_len) for (int i = tid; i < N; i += 1024) row_len[i] = 0;
   __syncthreads();
   for (int p0 = 0; p0 < M; p0 += 1024) {
     const int p = p0 + tid;
     bool on = false;
-    if (p < M) { const int t = p / N, n = p - t * N; on = mask[(size_t)n * ld + col0 + t] != 0.f; }
+    if (p < M) {
+      const int t = p / N, n = p - t * N;
+      on = mask[(size_t)n * ld + col0 + t] != 0.f;
+      if (on && row_len) atomicMax(row_len + n, t + 1);
+    }
     const unsigned long long b = __ballot(on);
     const int before = __popcll(b & ((1ull << lane) - 1ull));
     if (lane == 0) s_wave[wave] = __popcll(b);
@@ -2070,7 +2075,7 @@ __global__ __launch_bounds__(1024) void live_list_kernel(const float* __restrict
 // (19 -> 4 us: the first form paid a memory latency and three barriers per 1024 positions)
 constexpr int LL_R = 16;
 __global__ __launch_bounds__(1024) void live_list_burst_kernel(const float* __restrict__ mask, int ld, int col0, int N, int M, int* __restrict__ out, int out_len,
-                                                               int* __restrict__ inv, uint4* __restrict__ zero16, int n16) {
+                                                               int* __restrict__ inv, uint4* __restrict__ zero16, int n16, int* __restrict__ row_len) {
   __shared__ int s_cnt[LL_R * 16];
   __shared__ int s_off[LL_R * 16 + 1];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -2090,7 +2095,13 @@ __global__ __launch_bounds__(1024) void live_list_burst_kernel(const float* __re
     const unsigned long long b = __ballot(on);
     if (lane == 0) s_cnt[i * 16 + wave] = __popcll(b);
   }
+  if (row_len) for (int i = tid; i < N; i += 1024) row_len[i] = 0;
   __syncthreads();
+  if (row_len) {
+#pragma unroll
+    for (int i = 0; i < LL_R; ++i)
+      if ((bits >> i) & 1u) { const int p = i * 1024 + tid, t = p / N; atomicMax(row_len + (p - t * N), t + 1); }
+  }
   if (wave == 0) {                                      // exclusive prefix of the 256 counts: 4 per lane + a wave scan
     int c[4], sum = 0;
 #pragma unroll
@@ -2116,13 +2127,14 @@ __global__ __launch_bounds__(1024) void live_list_burst_kernel(const float* __re
   for (int i = tid; i < n16; i += 1024) zero16[i] = make_uint4(0u, 0u, 0u, 0u);
 }
 }  // namespace
-int uic_live_list_launch(const float* mask, int ld, int col0, int N, int M, int* out, int out_len, hipStream_t s, int* inv, void* zero, size_t zero_bytes) {
+int uic_live_list_launch(const float* mask, int ld, int col0, int N, int M, int* out, int out_len, hipStream_t s, int* inv, void* zero, size_t zero_bytes,
+                         int* row_len) {
   UIC_REQUIRE(mask && out && N > 0 && M >= 0 && out_len >= 0, "live_list: bad arguments");
   UIC_REQUIRE(zero_bytes == 0 || (zero && ((uintptr_t)zero & 15) == 0 && zero_bytes % 16 == 0 && zero_bytes < ((size_t)1 << 30)), "live_list: the cleared region must be 16-byte aligned / sized");
-  if (out_len == 0 && !inv) return UIC_OK;
+  if (out_len == 0 && !inv && !row_len) return UIC_OK;
   const int n16 = (int)(zero_bytes / 16);
-  if (M <= LL_R * 1024 && M > 0) hipLaunchKernelGGL(live_list_burst_kernel, dim3(1), dim3(1024), 0, s, mask, ld, col0, N, M, out, out_len, inv, (uint4*)zero, n16);
-  else hipLaunchKernelGGL(live_list_kernel, dim3(1), dim3(1024), 0, s, mask, ld, col0, N, M, out, out_len, inv, (uint4*)zero, n16);
+  if (M <= LL_R * 1024 && M > 0) hipLaunchKernelGGL(live_list_burst_kernel, dim3(1), dim3(1024), 0, s, mask, ld, col0, N, M, out, out_len, inv, (uint4*)zero, n16, row_len);
+  else hipLaunchKernelGGL(live_list_kernel, dim3(1), dim3(1024), 0, s, mask, ld, col0, N, M, out, out_len, inv, (uint4*)zero, n16, row_len);
   UIC_LAUNCH_CHECK("live_list");
   return UIC_OK;
 }

@@ -51,6 +51,7 @@ struct Layout {
   void* gates1; void* gates2;
   float* atth_all; float* alpha_all; void* ctx_all; void* hdrop_all;
   float* logits; void* dlogits; float* row_loss; float* scalars;
+  int* cap_len;                                 // ... [N]: 1 + the last decode step at which the row has a live position (the BPTT steps behind it are zeros)
   int* live_inv;                                // ... and its inverse [T N]: position -> list index or -1 (the recurrence stores hdrop rows by it)
   int* live_map;                                // the live list made on the device (uic_topdown_batch.live_rows == NULL): [T N + 128]
   void* hc; float* dhc;                         // live-position logit layer (uic_topdown_batch.live_rows): the live rows of hdrop, operand dtype
@@ -142,6 +143,7 @@ Layout make_layout(const uic_topdown_dims& d, void* ws) {
   L.dhdrop = (float*)b.take(M * H * 4);
   L.live_map = (int*)b.take((M + 128) * 4);
   L.live_inv = (int*)b.take(M * 4);
+  L.cap_len = (int*)b.take(N * 4);
   L.hc = b.take((M + 128) * H * S);
   L.dhc = (float*)b.take((M + 128) * H * 4);
   L.dx2_all = (float*)b.take(M * 3 * H * 4);
@@ -864,7 +866,7 @@ struct Step {
     const size_t S = uic_dtype_size(dt);
     return uic_live_list_launch(b->masks, b->ld_masks, 1, N, t_run * N, L.live_map, live_pad(), s, fused_gather ? L.live_inv : nullptr,
                                 fused_gather ? offw(L.hc, (size_t)live_total() * H, dt) : nullptr,
-                                fused_gather ? (size_t)(live_pad() - live_total()) * H * S : 0);
+                                fused_gather ? (size_t)(live_pad() - live_total()) * H * S : 0, L.cap_len);
   }
   int embed_split = 0;           // > 0: ... into the halves [0, embed_split) / [embed_split, t_run) of the decode steps (embed_grad)
   // d.recurrence & UIC_REC_EARLY_GRADS (fused step): the order of the gradient work a data-parallel caller may prefer -- see
@@ -1293,6 +1295,9 @@ struct Step {
       if (S) { a.dctx_nslab = S; a.dctx_slab_stride = st2; a.dctx_sum = dx2; a.ld_dctx_sum = 3 * H; }
       a.de = L.de_all + (size_t)t * N * R;
       a.d_att_h = offw(L.datth_all, (size_t)t * N * A, dt);
+#ifndef UIC_NO_DEAD_ROWS              // (A/B builds)
+      if (compact && build_live) { a.row_len = L.cap_len; a.step = t; }      // (live_build made the row lengths with the list)
+#endif
       UIC_TRY(uic_attention_bwd_step_launch(a, s));
     }
     UicH2attCellParams hc;

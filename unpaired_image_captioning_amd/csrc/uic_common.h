@@ -279,6 +279,9 @@ struct UicAttnParams {
   float* dctx_sum; int ld_dctx_sum;          // ... and the sum is left here (read by the deferred accumulation pass)
   float* de;               // [N,R]
   void* d_att_h;           // [N,A] operand dtype
+  // backward step, optional: rows whose caption has no live position at or behind this decode step (step >= row_len[n]) carry an
+  // all-zero gradient -- the fast kernel writes their zeros without reading their 74 KB of operands
+  const int* row_len; int step;
 };
 int uic_attention_fwd_launch(const UicAttnParams& p, hipStream_t s);
 int uic_attention_bwd_step_launch(const UicAttnParams& p, hipStream_t s);
@@ -621,8 +624,9 @@ int uic_xe_launch(const UicXeParams& p, hipStream_t s);
 // dst[map[m]] = src[m] (indices outside [0, dst_rows) skipped); row_bytes % 16 == 0
 // the ascending list of the positions t * N + n (p < M) with mask[n * ld + col0 + t] != 0, padded with -1 up to out_len entries
 // inv (optional, [M]): inv[p] = the list index of position p or -1; zero / zero_bytes (optional): a region cleared by the same launch
+// row_len (optional, [N]): row_len[n] = 1 + the last t with mask[n, col0 + t] != 0 (0: none)
 int uic_live_list_launch(const float* mask, int ld, int col0, int N, int M, int* out, int out_len, hipStream_t s, int* inv = nullptr,
-                         void* zero = nullptr, size_t zero_bytes = 0);
+                         void* zero = nullptr, size_t zero_bytes = 0, int* row_len = nullptr);
 int uic_gather_rows_launch(const void* src, const int* map, int src_rows, void* out, int M, int Mpad, size_t row_bytes, hipStream_t s);
 int uic_scatter_rows_launch(const void* src, const int* map, void* dst, int dst_rows, int M, size_t row_bytes, hipStream_t s);
 // general log-softmax backward given dense upstream grad g [N,T,V1] (API-compat path):
