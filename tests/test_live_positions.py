@@ -136,9 +136,10 @@ def test_step_over_live_positions_equals_the_step_over_all(shape, dtype):
     l2, g2 = _step(model, batch, live="device")
     assert abs(l1 - l0) < (2e-6 if dtype == "f32" else 2e-5) * max(1.0, abs(l0))
     _same(g1, g0, 2e-5 if dtype == "f32" else 2e-3)
-    assert l2 == l1                                      # (the device's list is the host's: ascending positions)
-    for k in g1:
-        assert torch.equal(g1[k], g2[k]), k
+    # (the device's list is the host's -- ascending positions -- but with it the step also knows the captions' lengths and its
+    # attention accumulation sums over each row's own steps only: the same sums, paired differently in the last bits)
+    assert abs(l2 - l1) <= 1e-6 * max(1.0, abs(l1))
+    _same(g2, g1, 2e-5 if dtype == "f32" else 2e-3)
 
 
 @pytest.mark.gpu
@@ -170,7 +171,8 @@ def test_arbitrary_masks_holes_empty_steps_and_fractional_weights(dtype):
     l2, g2 = _step(model, batch, live="device")
     assert abs(l1 - l0) < (2e-6 if dtype == "f32" else 2e-5) * max(1.0, abs(l0))
     _same(g1, g0, 2e-5 if dtype == "f32" else 2e-3)
-    assert l2 == l1 and all(torch.equal(g1[k], g2[k]) for k in g1)
+    assert abs(l2 - l1) <= 1e-6 * max(1.0, abs(l1))
+    _same(g2, g1, 2e-5 if dtype == "f32" else 2e-3)
 
 
 @pytest.mark.gpu

@@ -612,9 +612,16 @@ __global__ __launch_bounds__(512) void attn_bwd_accum_kernel(const UicAttnAccumP
 constexpr int P1_TCH = 6, P1_RU = 9;
 __global__ __launch_bounds__(512) void attn_bwd_accum_p1_kernel(const UicAttnAccumParams p) {
   extern __shared__ __attribute__((aligned(16))) float sm[];
-  const int H = p.H, R = p.R, TS = p.T, N = p.N;
-  const int TSp = (TS + P1_TCH - 1) / P1_TCH * P1_TCH;
+  const int H = p.H, R = p.R, N = p.N;
   const int n = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
+  // (the steps behind the caption's end add exact zeros: d ctx = 0 there)
+  const int TS = p.row_len ? min(p.T, p.row_len[n]) : p.T;
+  if (TS <= 0) {                        // a row without a live position: d att' = 0
+    float4* o = (float4*)(p.d_att + (size_t)n * R * H);
+    for (int i = tid; i < R * H / 4; i += 512) o[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    return;
+  }
+  const int TSp = (TS + P1_TCH - 1) / P1_TCH * P1_TCH;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   float* s_al = sm;                     // [R][TSp]: a region's weights over the steps, zero behind step TS
   for (int i = tid; i < R * TSp; i += 512) {
@@ -673,12 +680,22 @@ constexpr float P2_LIM = 21.5f;
 __global__ __launch_bounds__(256) void attn_bwd_accum_p2_bf16_kernel(const UicAttnAccumParams p) {
   extern __shared__ __attribute__((aligned(16))) float sm[];
   constexpr float LOG2E2 = 2.8853900817779268f;
-  const int A = p.A, R = p.R, TS = p.T, N = p.N;
+  const int A = p.A, R = p.R, N = p.N;
   const int Ah = A >> 1, nc = Ah >> 2;
   const int Rp = (R + 3) & ~3;
   const int n = blockIdx.x, a0 = blockIdx.y * Ah;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  // (the steps behind the caption's end add exact zeros: d e = 0 there)
+  const int TS = p.row_len ? min(p.T, p.row_len[n]) : p.T;
+  if (TS <= 0) {                        // a row without a live position: d p_att = 0, no share of d w_alpha
+    uint2* o = (uint2*)((bf16_t*)p.d_p_att + (size_t)n * R * A + a0);
+    for (int i = tid; i < R * nc; i += 256) { const int r = i / nc, c = i - r * nc; o[(size_t)r * (A / 4) + c] = make_uint2(0u, 0u); }
+    float* part0 = p.d_walpha_part + (size_t)n * (A + 1);
+    for (int a = tid; a < Ah; a += 256) part0[a0 + a] = 0.f;
+    if (tid == 0 && blockIdx.y == 0) part0[A] = 0.f;
+    return;
+  }
   float* s_eh = sm;                     // [TS][Ah]  e^{2 h_t[a]} (the direct form: h_t[a])
   float* s_de = s_eh + TS * Ah;         // [TS][Rp]
   float* s_red = s_de + TS * Rp;        // [4][Ah]

@@ -1523,6 +1523,9 @@ struct Step {
       a.dctx_all = L.dx2_all; a.lddctx = 3 * H; a.dctx_step_stride = (size_t)N * 3 * H;
       a.p_att = L.patt; a.w_alpha = w->alpha_w;
       a.d_att = L.d_att; a.d_p_att = L.d_patt; a.d_walpha_part = L.dwalpha_part;
+#ifndef UIC_NO_DEAD_ACCUM             // (A/B builds)
+      if (compact && build_live) a.row_len = L.cap_len;     // (the fused step over the live list: steps behind a caption's end add zeros)
+#endif
       UIC_TRY(uic_attention_bwd_accum_launch(a, s));
       UIC_TRY(uic_colsum_small_launch(L.dwalpha_part, N, A + 1, A, G->alpha_w, G->alpha_b, s));
     }

@@ -297,6 +297,8 @@ struct UicAttnAccumParams {
   float* d_att;            // [N,R,H] fp32 out (overwritten)
   void* d_p_att;           // [N,R,A] operand dtype out
   float* d_walpha_part;    // [N,A+1] per-row partial of (d w_alpha, d b_alpha)
+  const int* row_len;      // optional [N]: decode steps >= row_len[n] of row n carry zero gradients (d e = d ctx = 0: the caption
+                           // ended): the round-6 kernels sum over the row's first min(T, row_len[n]) steps only -- the same sums
 };
 int uic_attention_bwd_accum_launch(const UicAttnAccumParams& p, hipStream_t s);
 
