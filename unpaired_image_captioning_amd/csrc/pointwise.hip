@@ -2034,6 +2034,16 @@ __global__ __launch_bounds__(256) void scatter_rows_kernel(const uint4* __restri
     if ((unsigned)r < (unsigned)limit) dst[(size_t)r * chunks + c] = src[i];
   }
 }
+// row_len[n] = 1 + the last t < T with mask[n * ld + col0 + t] != 0 (0: none): a thread per row walks its T consecutive words (the
+// list kernels have just read them: cache hits) -- no atomics
+__device__ inline void live_row_len(const float* __restrict__ mask, int ld, int col0, int N, int T, int* __restrict__ row_len, int tid) {
+  for (int n = tid; n < N; n += 1024) {
+    const float* m = mask + (size_t)n * ld + col0;
+    int len = 0;
+    for (int t = 0; t < T; ++t) len = m[t] != 0.f ? t + 1 : len;
+    row_len[n] = len;
+  }
+}
 // out = the positions p = t * N + n, ascending, whose mask[n * ld + col0 + t] is not zero; entries behind them up to out_len: -1.
 // ONE workgroup: an ordered compaction of ~1e4 positions in chunks of 1024 (ballot + wave prefix + one running offset), a few
 // microseconds beside the prologue -- the list never crosses PCIe.
@@ -2045,7 +2055,6 @@ __global__ __launch_bounds__(1024) void live_list_kernel(const float* __restrict
   __shared__ int s_base;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   if (tid == 0) s_base = 0;
-  if (row_len) for (int i = tid; i < N; i += 1024) row_len[i] = 0;
   __syncthreads();
   for (int p0 = 0; p0 < M; p0 += 1024) {
     const int p = p0 + tid;
@@ -2053,7 +2062,6 @@ __global__ __launch_bounds__(1024) void live_list_kernel(const float* __restrict
     if (p < M) {
       const int t = p / N, n = p - t * N;
       on = mask[(size_t)n * ld + col0 + t] != 0.f;
-      if (on && row_len) atomicMax(row_len + n, t + 1);
     }
     const unsigned long long b = __ballot(on);
     const int before = __popcll(b & ((1ull << lane) - 1ull));
@@ -2069,6 +2077,7 @@ __global__ __launch_bounds__(1024) void live_list_kernel(const float* __restrict
   }
   for (int i = s_base + tid; i < out_len; i += 1024) out[i] = -1;
   for (int i = tid; i < n16; i += 1024) zero16[i] = make_uint4(0u, 0u, 0u, 0u);
+  if (row_len) live_row_len(mask, ld, col0, N, M / N, row_len, tid);
 }
 // the same for M <= 16 x 1024 positions (the captioner's 10 880, the NMT step's ~2 000) with ONE round trip to memory: every
 // thread requests its <= 16 mask words at once, the per-(round, wave) counts meet in LDS, one wave scans the 256 of them
@@ -2095,13 +2104,7 @@ __global__ __launch_bounds__(1024) void live_list_burst_kernel(const float* __re
     const unsigned long long b = __ballot(on);
     if (lane == 0) s_cnt[i * 16 + wave] = __popcll(b);
   }
-  if (row_len) for (int i = tid; i < N; i += 1024) row_len[i] = 0;
   __syncthreads();
-  if (row_len) {
-#pragma unroll
-    for (int i = 0; i < LL_R; ++i)
-      if ((bits >> i) & 1u) { const int p = i * 1024 + tid, t = p / N; atomicMax(row_len + (p - t * N), t + 1); }
-  }
   if (wave == 0) {                                      // exclusive prefix of the 256 counts: 4 per lane + a wave scan
     int c[4], sum = 0;
 #pragma unroll
@@ -2125,6 +2128,7 @@ __global__ __launch_bounds__(1024) void live_list_burst_kernel(const float* __re
   }
   for (int i = s_off[LL_R * 16] + tid; i < out_len; i += 1024) out[i] = -1;
   for (int i = tid; i < n16; i += 1024) zero16[i] = make_uint4(0u, 0u, 0u, 0u);
+  if (row_len) live_row_len(mask, ld, col0, N, M / N, row_len, tid);
 }
 }  // namespace
 int uic_live_list_launch(const float* mask, int ld, int col0, int N, int M, int* out, int out_len, hipStream_t s, int* inv, void* zero, size_t zero_bytes,
