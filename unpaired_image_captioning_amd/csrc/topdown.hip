@@ -862,6 +862,14 @@ struct Step {
   // list's inverse): no gather launches -- one of them sat on the main stream in front of the BPTT loop.  The list kernel clears the
   // operand's padding rows then.
   bool fused_gather = false;
+  // have_len: L.cap_len holds every row's caption length (1 + the last decode step with a non-zero mask / gradient weight): the BPTT
+  // loop's attention backward and the attention accumulation skip the steps behind it.  Made with the list, or -- a step that
+  // computes every position with per-position weights (the self-critical step: a sampled caption's positions behind its end weigh
+  // zero) -- by the list kernel alone.
+  bool have_len = false;
+  int len_build(hipStream_t s) {
+    return uic_live_list_launch(b->grad_scale, b->ld_grad_scale, 0, N, t_run * N, L.live_map, 0, s, nullptr, nullptr, 0, L.cap_len);
+  }
   int live_build(hipStream_t s) {
     const size_t S = uic_dtype_size(dt);
     return uic_live_list_launch(b->masks, b->ld_masks, 1, N, t_run * N, L.live_map, live_pad(), s, fused_gather ? L.live_inv : nullptr,
@@ -1296,7 +1304,7 @@ struct Step {
       a.de = L.de_all + (size_t)t * N * R;
       a.d_att_h = offw(L.datth_all, (size_t)t * N * A, dt);
 #ifndef UIC_NO_DEAD_ROWS              // (A/B builds)
-      if (compact && build_live) { a.row_len = L.cap_len; a.step = t; }      // (live_build made the row lengths with the list)
+      if (have_len) { a.row_len = L.cap_len; a.step = t; }
 #endif
       UIC_TRY(uic_attention_bwd_step_launch(a, s));
     }
@@ -1524,7 +1532,7 @@ struct Step {
       a.p_att = L.patt; a.w_alpha = w->alpha_w;
       a.d_att = L.d_att; a.d_p_att = L.d_patt; a.d_walpha_part = L.dwalpha_part;
 #ifndef UIC_NO_DEAD_ACCUM             // (A/B builds)
-      if (compact && build_live) a.row_len = L.cap_len;     // (the fused step over the live list: steps behind a caption's end add zeros)
+      if (have_len) a.row_len = L.cap_len;     // (steps behind a caption's end add zeros)
 #endif
       UIC_TRY(uic_attention_bwd_accum_launch(a, s));
       UIC_TRY(uic_colsum_small_launch(L.dwalpha_part, N, A + 1, A, G->alpha_w, G->alpha_b, s));
@@ -1787,6 +1795,10 @@ int uic_topdown_xe_train_step(const uic_topdown_dims* d, const uic_topdown_weigh
   st.fused_gather = st.compact && st.build_live && !(training & 4) && st.persist_ok() && st.dt == UIC_BF16;
 #endif
   if (st.compact && st.build_live) UIC_TRY(st.live_build((training & 4) ? s : s2));
+  else if (b->grad_scale) UIC_TRY(st.len_build((training & 4) ? s : s2));
+  // (not for a plain masked step without counts: it stays bit-equal to the three separate API calls, whose backward pass sums over
+  // every step -- tests/test_gpu_topdown.py)
+  st.have_len = (st.compact && st.build_live) || b->grad_scale;
   // the prologue's two independent branches side by side: att_embed + ctx2att here, fc_embed + embedding + the batched
   // input GEMM on the side stream (idle until the recurrence is through; its part of the weight refresh comes first there)
   // training bit 2: the workspace already holds this forward pass (uic_topdown_sample_train drew b->labels with these
