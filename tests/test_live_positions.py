@@ -176,6 +176,27 @@ def test_arbitrary_masks_holes_empty_steps_and_fractional_weights(dtype):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+def test_batch_without_a_live_position(dtype):
+    """Every mask zero: the list is empty, nothing of the logit layer runs; every gradient is zero and the loss is 0 / 0 as the
+    reference's criterion gives it (a vocabulary of 501 words: the cleared gradient tensors are not multiples of 16 bytes)."""
+    from oracle import topdown as O
+    from test_gpu_topdown import make_opt
+    from unpaired_image_captioning_amd import models
+    shape = dict(V=500, E=64, H=64, A=64, D=96, L=7, n_img=4, S=5, R=9)
+    torch.manual_seed(8)
+    model = models.setup(make_opt(shape, dtype, drop=0.0, seed=2)).cuda().train()
+    b = O.synthetic_batch(shape["n_img"], shape["S"], shape["R"], shape["D"], shape["V"], shape["L"], seed=3)
+    b["masks"] = torch.zeros_like(b["masks"])
+    batch = {k: v.cuda() for k, v in b.items()}
+    for form in ("rows", "device"):
+        loss, grads = _step(model, batch, live=form)
+        assert loss != loss                               # NaN
+        for k, g in grads.items():
+            assert float(g.abs().max()) == 0.0, (form, k)
+
+
+@pytest.mark.gpu
 def test_full_size_step_over_live_positions_bf16():
     """BASELINE config 2 (640 caption rows, 9488 words): with and without the list."""
     from oracle import topdown as O

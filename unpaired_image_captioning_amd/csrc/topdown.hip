@@ -1184,7 +1184,9 @@ struct Step {
     if (compact) {
       const int K = live_pad();
       if (K == 0) {
-        return uic_zero4_launch(G->logit_w, (size_t)V1 * H * 4, G->logit_b, (size_t)V1 * 4, nullptr, 0, nullptr, 0, s);
+        // (a batch without a single live position: no gradient; plain memsets -- V1 need not be a multiple of four)
+        UIC_TRY(uic_check_hip(hipMemsetAsync(G->logit_w, 0, (size_t)V1 * H * 4, s), "hipMemsetAsync(d logit.weight)"));
+        return uic_check_hip(hipMemsetAsync(G->logit_b, 0, (size_t)V1 * 4, s), "hipMemsetAsync(d logit.bias)");
       }
       const UicGemmTnSeg seg{L.hc, H, H};
       const WDest d1{G->logit_w, H, 0, H};
