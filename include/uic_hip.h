@@ -175,7 +175,10 @@ typedef struct uic_topdown_batch {
      positions with mask 0 contribute exact zeros -- the same result).  A position (t, n) -- decode step t, row n -- is live
      when masks[n, 1 + t] != 0; positions behind a caption's end (LanguageModelCriterion multiplies them by 0,
      P/misc/utils.py:62-73) are a quarter of the benchmark's batch and a third of COCO's.  With the list the logit layer, the
-     criterion and their gradients run over the listed rows only.
+     criterion and their gradients run over the listed rows only; with the list made by the step itself (live_rows NULL) the
+     recurrence also stores the listed rows compactly, and the BPTT loop's attention backward and the deferred attention
+     accumulation skip, per row, the decode steps behind the row's last live position.  The loss and the gradients are those of
+     the full computation up to floating-point summation order (sums run over fewer, differently grouped terms).
        live_count  HOST int32 [t_run]: the number of live positions of each step -- the step sizes its launches with them
        live_rows   DEVICE int32 [roundup(sum(live_count), 128)] or NULL: t * N + n of every live position, step-major (all of
                    step 0, then step 1, ...; any order within a step); the tail up to the multiple of 128 holds -1.
